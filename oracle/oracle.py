@@ -1,0 +1,321 @@
+"""ctypes binding of the CPU oracle (oracle/fs_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by the
+``cpu_baseline`` leg of bench.py -- never by frankensearch_amd/ (the product fails loudly
+when libfsgpu.so is missing instead of falling back to this).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libfsoracle.so")
+
+HREDUCE_SSE2 = 0
+HREDUCE_AVX = 1
+
+OK = 0
+ERR_DIMENSION_MISMATCH = 1
+ERR_INVALID_CONFIG = 2
+ERR_INDEX_CORRUPTED = 3
+ERR_INDEX_VERSION_MISMATCH = 4
+ERR_IO = 5
+
+PARALLEL_THRESHOLD = 10_000  # search.rs:23
+PARALLEL_CHUNK_SIZE = 1_024  # search.rs:25
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (idempotent)."""
+    srcs = [os.path.join(_HERE, f) for f in ("fs_oracle.c", "fs_oracle_avx2.c", "fs_oracle.h", "Makefile")]
+    stale = force or not os.path.exists(_SO) or any(
+        os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs
+    )
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        u8p, f32p, u16p, u32p, u64p = (C.POINTER(t) for t in (C.c_uint8, C.c_float, C.c_uint16, C.c_uint32, C.c_uint64))
+        L.fso_f16_to_f32.restype = C.c_float
+        L.fso_f16_to_f32.argtypes = [C.c_uint16]
+        L.fso_f32_to_f16.restype = C.c_uint16
+        L.fso_f32_to_f16.argtypes = [C.c_float]
+        L.fso_encode_f32_to_f16.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        for name in ("fso_dot_f16_f32", "fso_dot_f16_f32_fast"):
+            fn = getattr(L, name)
+            fn.restype = C.c_float
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        L.fso_has_avx2_f16c.restype = C.c_int
+        L.fso_ranks_before.restype = C.c_int
+        L.fso_ranks_before.argtypes = [C.c_uint64, C.c_float, C.c_uint64, C.c_float]
+        L.fso_search_top_k.restype = C.c_size_t
+        L.fso_search_top_k.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t,
+                                       C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.fso_classify_query.restype = C.c_int
+        L.fso_classify_query.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_size_t, C.POINTER(C.c_int)]
+        L.fso_gather_dot.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        L.fso_fnv1a64.restype = C.c_uint64
+        L.fso_fnv1a64.argtypes = [C.c_char_p, C.c_size_t]
+        L.fso_crc32.restype = C.c_uint32
+        L.fso_crc32.argtypes = [C.c_char_p, C.c_size_t]
+        L.fso_align_up.restype = C.c_uint64
+        L.fso_align_up.argtypes = [C.c_uint64, C.c_uint64]
+        L.fso_vector_signal_usable.restype = C.c_int
+        L.fso_vector_signal_usable.argtypes = [C.c_void_p, C.c_size_t]
+        L.fso_l2_normalize.argtypes = [C.c_void_p, C.c_size_t]
+        L.fso_fsvi_write.restype = C.c_int
+        L.fso_fsvi_write.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint64,
+                                     C.POINTER(C.c_char_p), C.c_void_p, C.c_uint8]
+        L.fso_fsvi_open.restype = C.c_int
+        L.fso_fsvi_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.fso_fsvi_close.argtypes = [C.c_void_p]
+        L.fso_fsvi_record_count.restype = C.c_uint64
+        L.fso_fsvi_record_count.argtypes = [C.c_void_p]
+        L.fso_fsvi_dimension.restype = C.c_uint32
+        L.fso_fsvi_dimension.argtypes = [C.c_void_p]
+        L.fso_fsvi_vectors_offset.restype = C.c_uint64
+        L.fso_fsvi_vectors_offset.argtypes = [C.c_void_p]
+        L.fso_fsvi_slab.restype = C.c_void_p
+        L.fso_fsvi_slab.argtypes = [C.c_void_p]
+        L.fso_fsvi_doc_id.restype = C.c_uint32
+        L.fso_fsvi_doc_id.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+        L.fso_fsvi_flags.restype = C.c_uint16
+        L.fso_fsvi_flags.argtypes = [C.c_void_p, C.c_uint64]
+        L.fso_fsvi_set_flags.argtypes = [C.c_void_p, C.c_uint64, C.c_uint16]
+        L.fso_fsvi_search.restype = C.c_size_t
+        L.fso_fsvi_search.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        L.fso_fixture_hashmix.restype = C.c_float
+        L.fso_fixture_hashmix.argtypes = [C.c_uint64, C.c_uint64]
+        L.fso_raw_vector.argtypes = [C.c_uint64, C.c_uint32, C.c_void_p]
+        L.fso_normalize_bench.argtypes = [C.c_void_p, C.c_uint32]
+        L.fso_clustered_corpus_f16.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
+        L.fso_clustered_query.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
+        L.fso_m2v_embed.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a: np.ndarray) -> int:
+    return a.ctypes.data
+
+
+# ---- f16 ----
+def f16_to_f32(h: int) -> float:
+    return lib().fso_f16_to_f32(h)
+
+
+def f32_to_f16(f: float) -> int:
+    return lib().fso_f32_to_f16(f)
+
+
+def encode_f32_to_f16(src: np.ndarray) -> np.ndarray:
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    dst = np.empty(src.shape, dtype=np.uint16)
+    lib().fso_encode_f32_to_f16(_p(src), src.size, _p(dst))
+    return dst
+
+
+# ---- dot / search ----
+def dot_f16_f32(row_u16: np.ndarray, q: np.ndarray, hreduce: int = HREDUCE_SSE2, fast: bool = False) -> float:
+    row = np.ascontiguousarray(row_u16, dtype=np.uint16)
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    assert row.size == q.size
+    fn = lib().fso_dot_f16_f32_fast if fast else lib().fso_dot_f16_f32
+    return fn(_p(row), _p(q), q.size, hreduce)
+
+
+def live_bitmap(live_bool: np.ndarray) -> np.ndarray:
+    """bool[N] -> uint64 bitmap (bit r set = row r live)."""
+    n = live_bool.size
+    words = (n + 63) // 64
+    padded = np.zeros(words * 64, dtype=np.uint8)
+    padded[:n] = live_bool.astype(np.uint8)
+    return np.packbits(padded, bitorder="little").view(np.uint64).copy()
+
+
+def search_top_k(slab_u16: np.ndarray, q: np.ndarray, k: int, live: np.ndarray | None = None,
+                 parallel_threshold: int = PARALLEL_THRESHOLD, chunk_size: int = PARALLEL_CHUNK_SIZE,
+                 parallel_enabled: bool = True, nthreads: int = 1, hreduce: int = HREDUCE_SSE2):
+    """Returns (rows uint32[count], scores float32[count]) best-first; slab_u16 is [N, dim] uint16."""
+    slab = np.ascontiguousarray(slab_u16, dtype=np.uint16)
+    n, dim = slab.shape
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    if q.size != dim:
+        raise ValueError(f"DimensionMismatch expected={dim} found={q.size}")
+    cap = max(1, min(k, n))
+    rows = np.empty(cap, dtype=np.uint32)
+    scores = np.empty(cap, dtype=np.float32)
+    bm = None
+    if live is not None:
+        bm = live_bitmap(np.asarray(live, dtype=bool)) if live.dtype != np.uint64 else live
+    cnt = lib().fso_search_top_k(_p(slab), n, dim, _p(bm) if bm is not None else None, _p(q), k,
+                                 parallel_threshold, chunk_size, int(parallel_enabled), nthreads, hreduce,
+                                 _p(rows), _p(scores))
+    return rows[:cnt].copy(), scores[:cnt].copy()
+
+
+def classify_query(q: np.ndarray, dim: int, k: int):
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    z = C.c_int(0)
+    st = lib().fso_classify_query(_p(q), q.size, dim, k, C.byref(z))
+    return st, z.value
+
+
+def gather_dot(slab_u16: np.ndarray, q: np.ndarray, rows: np.ndarray, hreduce: int = HREDUCE_SSE2) -> np.ndarray:
+    slab = np.ascontiguousarray(slab_u16, dtype=np.uint16)
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    rows = np.ascontiguousarray(rows, dtype=np.uint32)
+    out = np.empty(rows.size, dtype=np.float32)
+    lib().fso_gather_dot(_p(slab), slab.shape[1], _p(q), _p(rows), rows.size, hreduce, _p(out))
+    return out
+
+
+# ---- hashes ----
+def fnv1a64(b: bytes) -> int:
+    return lib().fso_fnv1a64(b, len(b))
+
+
+def crc32(b: bytes) -> int:
+    return lib().fso_crc32(b, len(b))
+
+
+def align_up(v: int, a: int) -> int:
+    return lib().fso_align_up(v, a)
+
+
+def vector_signal_usable(v: np.ndarray) -> bool:
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    return bool(lib().fso_vector_signal_usable(_p(v), v.size))
+
+
+def l2_normalize(v: np.ndarray) -> np.ndarray:
+    v = np.array(v, dtype=np.float32, copy=True)
+    lib().fso_l2_normalize(_p(v), v.size)
+    return v
+
+
+# ---- FSVI ----
+def fsvi_write(path: str, rows, embedder_id: str = "hash", revision: str = "test", compaction_gen: int = 1) -> int:
+    """rows: list of (doc_id, vector) like the reference test helper write_index (search.rs:1784-1799)."""
+    n = len(rows)
+    dim = len(rows[0][1]) if n else 0
+    if n == 0:
+        return ERR_INVALID_CONFIG
+    ids = (C.c_char_p * n)(*[r[0].encode() for r in rows])
+    vecs = np.ascontiguousarray(np.array([r[1] for r in rows], dtype=np.float32))
+    return lib().fso_fsvi_write(path.encode(), embedder_id.encode(), revision.encode(), dim, n, ids, _p(vecs),
+                                compaction_gen)
+
+
+class Fsvi:
+    def __init__(self, path: str):
+        self.h = None
+        h = C.c_void_p()
+        st = lib().fso_fsvi_open(path.encode(), C.byref(h))
+        if st != OK:
+            raise IOError(f"fso_fsvi_open failed: status {st}")
+        self.h = h
+        self.status = st
+
+    def close(self):
+        if self.h:
+            lib().fso_fsvi_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def record_count(self) -> int:
+        return lib().fso_fsvi_record_count(self.h)
+
+    @property
+    def dimension(self) -> int:
+        return lib().fso_fsvi_dimension(self.h)
+
+    @property
+    def vectors_offset(self) -> int:
+        return lib().fso_fsvi_vectors_offset(self.h)
+
+    def slab(self) -> np.ndarray:
+        n, d = self.record_count, self.dimension
+        ptr = lib().fso_fsvi_slab(self.h)
+        buf = (C.c_uint16 * (n * d)).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.uint16).reshape(n, d).copy()
+
+    def doc_id(self, row: int) -> str:
+        p = C.c_void_p()
+        ln = lib().fso_fsvi_doc_id(self.h, row, C.byref(p))
+        return C.string_at(p.value, ln).decode()
+
+    def flags(self, row: int) -> int:
+        return lib().fso_fsvi_flags(self.h, row)
+
+    def soft_delete(self, doc_id: str) -> bool:
+        hit = False
+        for r in range(self.record_count):
+            if self.doc_id(r) == doc_id and (self.flags(r) & 1) == 0:
+                lib().fso_fsvi_set_flags(self.h, r, self.flags(r) | 1)
+                hit = True
+        return hit
+
+    def search_top_k(self, q, k: int, hreduce: int = HREDUCE_SSE2):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        if q.size != self.dimension:
+            raise ValueError(f"DimensionMismatch expected={self.dimension} found={q.size}")
+        cap = max(1, min(k, self.record_count))
+        rows = np.empty(cap, dtype=np.uint32)
+        scores = np.empty(cap, dtype=np.float32)
+        cnt = lib().fso_fsvi_search(self.h, _p(q), k, hreduce, _p(rows), _p(scores))
+        return [(int(rows[i]), float(scores[i]), self.doc_id(int(rows[i]))) for i in range(cnt)], scores[:cnt].copy()
+
+
+# ---- fixtures ----
+def fixture_hashmix(count: int, dim: int) -> np.ndarray:
+    out = np.empty((count, dim), dtype=np.float32)
+    L = lib()
+    for i in range(count):
+        for j in range(dim):
+            out[i, j] = L.fso_fixture_hashmix(i, j)
+    return out
+
+
+def raw_vector(seed: int, dim: int) -> np.ndarray:
+    out = np.empty(dim, dtype=np.float32)
+    lib().fso_raw_vector(seed, dim, _p(out))
+    return out
+
+
+def clustered_corpus_f16(row0: int, n: int, dim: int, clusters: int = 64, noise: float = 0.30) -> np.ndarray:
+    out = np.empty((n, dim), dtype=np.uint16)
+    lib().fso_clustered_corpus_f16(row0, n, dim, clusters, noise, _p(out))
+    return out
+
+
+def clustered_query(q: int, dim: int, clusters: int = 64, noise: float = 0.30) -> np.ndarray:
+    out = np.empty(dim, dtype=np.float32)
+    lib().fso_clustered_query(q, dim, clusters, noise, _p(out))
+    return out
+
+
+# ---- Model2Vec ----
+def m2v_embed(table: np.ndarray, ids) -> np.ndarray:
+    table = np.ascontiguousarray(table, dtype=np.float32)
+    ids = np.ascontiguousarray(ids, dtype=np.uint32)
+    out = np.empty(table.shape[1], dtype=np.float32)
+    lib().fso_m2v_embed(_p(table), table.shape[0], table.shape[1], _p(ids), ids.size, _p(out))
+    return out

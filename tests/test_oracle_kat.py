@@ -1,0 +1,382 @@
+"""Pins the CPU oracle on the reference's own known-answer / invariant tests.
+
+Each test names the reference test it restates (paths relative to the reference repo).
+No GPU needed.
+"""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+
+def f32(x):
+    return np.float32(x)
+
+
+# ---------------------------------------------------------------- hashes / helpers
+def test_fnv1a_known_answers(oracle):
+    # crates/frankensearch-index/src/lib.rs:10223-10227 fnv1a_hash_empty_input
+    assert oracle.fnv1a64(b"") == 0xCBF29CE484222325
+    # :10236-10240 different inputs differ; values cross-checked with an independent python FNV-1a
+    def py(b):
+        h = 0xCBF29CE484222325
+        for c in b:
+            h = ((h ^ c) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+        return h
+    for s in (b"doc-a", b"doc-b", b"doc-c", b"hello", bytes(range(256))):
+        assert oracle.fnv1a64(s) == py(s)
+    assert oracle.fnv1a64(b"doc-a") == 0x42D495AB72FC02AB
+
+
+def test_align_up_edge_cases(oracle):
+    # lib.rs:10201-10216
+    assert oracle.align_up(42, 0) == 42
+    assert oracle.align_up(128, 64) == 128
+    assert oracle.align_up(0, 64) == 0
+    assert oracle.align_up(65, 64) == 128
+
+
+def test_crc32_matches_zlib(oracle):
+    import zlib
+
+    rng = np.random.default_rng(1)
+    for n in (0, 1, 42, 1000):
+        b = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert oracle.crc32(b) == zlib.crc32(b)
+
+
+# ---------------------------------------------------------------- f16
+def test_f16_widen_is_bit_exact_all_patterns(oracle):
+    # simd.rs:2711-2744 simd_f16_widen_is_bit_exact: every one of 65,536 patterns
+    bits = np.arange(65536, dtype=np.uint16)
+    ref = bits.view(np.float16).astype(np.float32)
+    got = np.array([oracle.f16_to_f32(int(b)) for b in bits], dtype=np.float32)
+    nan = np.isnan(ref)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.array_equal(np.signbit(got[nan]), np.signbit(ref[nan]))
+    assert np.array_equal(got[~nan].view(np.uint32), ref[~nan].view(np.uint32))
+
+
+def test_f16_sample_patterns(oracle):
+    # simd.rs:2750-2774 simd_f16_bytes_load_matches_scalar
+    assert oracle.f16_to_f32(0x0000) == 0.0
+    assert np.signbit(np.float32(oracle.f16_to_f32(0x8000)))
+    assert oracle.f16_to_f32(0x3E00) == 1.5
+    assert oracle.f16_to_f32(0xC080) == -2.25
+    assert oracle.f16_to_f32(0x0001) == 2.0 ** -24
+    assert oracle.f16_to_f32(0x7BFF) == 65504.0
+    assert oracle.f16_to_f32(0x7C00) == float("inf")
+    assert np.isnan(oracle.f16_to_f32(0x7E00))
+
+
+def test_f32_to_f16_rne_matches_ieee(oracle):
+    # simd.rs:2669 avx2_f16encode_matches_generic; half::f16::from_f32 is IEEE RNE == numpy astype(float16)
+    rng = np.random.default_rng(7)
+    vals = np.concatenate([
+        rng.standard_normal(20000).astype(np.float32),
+        (rng.standard_normal(5000) * 1e-5).astype(np.float32),   # f16 subnormal range
+        (rng.standard_normal(2000) * 1e-8).astype(np.float32),   # underflow
+        (rng.standard_normal(2000) * 7e4).astype(np.float32),    # overflow edge
+        np.array([0.0, -0.0, 1.0, 0.8, 0.2, 65504.0, 65520.0, 65519.99, 2.0 ** -24, 2.0 ** -25,
+                  1.5 * 2.0 ** -25, np.inf, -np.inf, 6.1e-5, 5.96e-8, 2.98e-8, 2.9802322e-8],
+                 dtype=np.float32),
+        rng.integers(0, 2 ** 32, 20000, dtype=np.uint64).astype(np.uint32).view(np.float32),
+    ])
+    with np.errstate(over="ignore"):
+        ref = vals.astype(np.float16).view(np.uint16)
+    got = oracle.encode_f32_to_f16(vals)
+    nan = np.isnan(vals)
+    assert np.array_equal(got[~nan], ref[~nan])
+    assert np.all((got[nan] & 0x7C00) == 0x7C00) and np.all((got[nan] & 0x03FF) != 0)
+    assert oracle.f32_to_f16(1.0) == 0x3C00 and oracle.f32_to_f16(0.8) == 0x3A66 and oracle.f32_to_f16(0.2) == 0x3266
+
+
+# ---------------------------------------------------------------- dot
+def numpy_dot_reference_order(row_u16, q, hreduce=0):
+    """Independent numpy statement of simd.rs:532-571 (each numpy f32 op is one IEEE op)."""
+    dim = q.size
+    w = row_u16.view(np.float16).astype(np.float32)
+    chunks = dim // 8
+    s = np.zeros((4, 8), dtype=np.float32)
+    c = 0
+    while c + 4 <= chunks:
+        for a in range(4):
+            sl = slice((c + a) * 8, (c + a) * 8 + 8)
+            s[a] = s[a] + w[sl] * q[sl]
+        c += 4
+    while c < chunks:
+        sl = slice(c * 8, c * 8 + 8)
+        s[0] = s[0] + w[sl] * q[sl]
+        c += 1
+    v = (s[0] + s[1]) + (s[2] + s[3])
+    if hreduce == 0:
+        r = ((v[0] + v[2]) + (v[1] + v[3])) + ((v[4] + v[6]) + (v[5] + v[7]))
+    else:
+        r = ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]))
+    r = np.float32(r)
+    for i in range(chunks * 8, dim):
+        r = np.float32(np.float64(w[i]) * np.float64(q[i]) + np.float64(r))  # fma: exact product, one rounding
+    return r
+
+
+@pytest.mark.parametrize("dim", [0, 1, 4, 7, 8, 9, 16, 31, 32, 33, 40, 56, 64, 100, 128, 256, 384, 385, 391, 768])
+def test_dot_matches_numpy_restatement_and_fast_path_bitwise(oracle, dim):
+    # simd.rs:2423 avx2_f16dot_matches_generic (bit-identical across many shapes)
+    rng = np.random.default_rng(dim + 3)
+    for hreduce in (0, 1):
+        for _ in range(4):
+            row = rng.standard_normal(dim).astype(np.float16).view(np.uint16)
+            q = rng.standard_normal(dim).astype(np.float32)
+            a = np.float32(oracle.dot_f16_f32(row, q, hreduce))
+            b = np.float32(oracle.dot_f16_f32(row, q, hreduce, fast=True))
+            c = numpy_dot_reference_order(row, q, hreduce)
+            assert a.view(np.uint32) == b.view(np.uint32)
+            if dim % 8 == 0:  # numpy's emulated fma is exact only when no tail rounding subtlety
+                assert a.view(np.uint32) == c.view(np.uint32)
+            else:
+                assert abs(float(a) - float(c)) <= 1e-6 * max(1.0, abs(float(c)))
+
+
+def test_simd_matches_scalar_f16(oracle):
+    # simd.rs:3044-3070
+    query = np.array([0.4, -0.1, 0.6, 0.2, -0.3, 0.8, 0.7, -0.5, 0.9, -0.6, 0.11, 0.25, 0.41, -0.72, 0.55, 0.31],
+                     dtype=np.float32)
+    stored = np.array([-0.8, 0.7, 0.6, -0.2, 0.3, 0.9, -0.4, 0.1, 0.12, 0.21, -0.14, 0.75, -0.22, 0.35, 0.66, -0.19],
+                      dtype=np.float32).astype(np.float16)
+    simd = oracle.dot_f16_f32(stored.view(np.uint16), query)
+    scalar = np.float32(0)
+    for a, b in zip(stored.astype(np.float32), query):
+        scalar = np.float32(scalar + a * b)
+    assert abs(simd - float(scalar)) < 1e-6
+
+
+def test_dot_empty_and_nan(oracle):
+    # simd.rs:3183-3211 (empty), :3222-3232 (f16_nan_propagates)
+    assert oracle.dot_f16_f32(np.zeros(0, np.uint16), np.zeros(0, np.float32)) == 0.0
+    stored = np.array([1.0, np.nan, 1.0, 1.0], dtype=np.float16).view(np.uint16)
+    assert np.isnan(oracle.dot_f16_f32(stored, np.ones(4, np.float32)))
+
+
+def test_f16_unit_vector_error_bound(oracle):
+    # simd.rs:3113-3135: f16 storage error of a unit-vector self-dot stays < 0.01
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal(384).astype(np.float32)
+    v /= np.linalg.norm(v)
+    got = oracle.dot_f16_f32(v.astype(np.float16).view(np.uint16), v)
+    assert abs(got - 1.0) < 0.01
+
+
+# ---------------------------------------------------------------- ordering + search
+def test_compare_functions(oracle):
+    # search.rs:3439-3470 compare_best_first / candidate_is_better semantics; :1655-1661 score_key
+    rb = oracle.lib().fso_ranks_before
+    assert rb(5, 0.9, 1, 0.8) == 1          # higher score first
+    assert rb(1, 0.5, 2, 0.5) == 1          # tie -> lower index
+    assert rb(2, 0.5, 1, 0.5) == 0
+    assert rb(9, -1e30, 0, float("nan")) == 1     # NaN ranks as -inf
+    assert rb(0, float("-inf"), 1, float("nan")) == 1   # equal key -> index
+    assert rb(1, float("nan"), 0, float("-inf")) == 0
+    assert rb(7, 0.0, 3, -0.0) == 1         # total_cmp: -0.0 < +0.0
+
+
+def rows4(vals):
+    return np.array([[v, 0, 0, 0] for v in vals], dtype=np.float32)
+
+
+def test_top_k_orders_by_score_descending(oracle, tmp_path):
+    # search.rs:2116-2137 (+ SURVEY Appendix C byte-level known answer)
+    p = str(tmp_path / "a.fsvi")
+    assert oracle.fsvi_write(p, [("doc-a", [1.0, 0, 0, 0]), ("doc-b", [0.8, 0, 0, 0]), ("doc-c", [0.2, 0, 0, 0])]) == 0
+    raw = open(p, "rb").read()
+    assert len(raw) == 152
+    assert raw[:46].hex() == ("4653564901000400686173680400746573740400000001010000"
+                              "030000000000000080000000000000001df0d5cc")
+    assert raw[46:94].hex() == ("ab02fc72ab95d4420000000005000000" "5e04fc72ab96d4420500000005000000"
+                                "1106fc72ab97d4420a00000005000000")
+    assert raw[94:109] == b"doc-adoc-bdoc-c" and raw[109:128] == bytes(19)
+    assert raw[128:].hex() == "003c000000000000663a0000000000006632000000000000"
+    idx = oracle.Fsvi(p)
+    hits, scores = idx.search_top_k([1.0, 0, 0, 0], 2)
+    assert [h[2] for h in hits] == ["doc-a", "doc-b"]
+    assert [h[0] for h in hits] == [0, 1]
+    assert scores.view(np.uint32).tolist() == [0x3F800000, 0x3F4CC000]
+
+
+def test_tombstoned_records_are_excluded(oracle, tmp_path):
+    # search.rs:2163-2187
+    p = str(tmp_path / "t.fsvi")
+    oracle.fsvi_write(p, [("doc-a", [1.0, 0, 0, 0]), ("doc-b", [0.8, 0, 0, 0]), ("doc-c", [0.2, 0, 0, 0])])
+    idx = oracle.Fsvi(p)
+    assert idx.soft_delete("doc-a")
+    hits, _ = idx.search_top_k([1.0, 0, 0, 0], 10)
+    assert len(hits) == 2 and all(h[2] != "doc-a" for h in hits)
+
+
+def test_k_above_record_count_returns_all_hits(oracle, tmp_path):
+    # search.rs:2627-2643
+    p = str(tmp_path / "k.fsvi")
+    oracle.fsvi_write(p, [("doc-a", [0.1, 0, 0, 0]), ("doc-b", [0.2, 0, 0, 0])])
+    hits, _ = oracle.Fsvi(p).search_top_k([1.0, 0, 0, 0], 20)
+    assert len(hits) == 2
+
+
+def test_collect_all_matches_heap_prefix(oracle):
+    # search.rs:2646-2685: collect-all (k == N, parallel threshold 1, chunk 8) == heap top (N-7) prefix
+    slab = oracle.encode_f32_to_f16(rows4([80 - i for i in range(80)]))
+    q = np.array([1, 0, 0, 0], dtype=np.float32)
+    ra, sa = oracle.search_top_k(slab, q, 80, parallel_threshold=1, chunk_size=8)
+    rh, sh = oracle.search_top_k(slab, q, 73, parallel_threshold=2 ** 62, chunk_size=1024)
+    assert len(ra) == 80 and len(rh) == 73
+    assert np.array_equal(ra[:73], rh) and np.array_equal(sa[:73].view(np.uint32), sh.view(np.uint32))
+
+
+def test_ties_are_broken_by_index(oracle):
+    # search.rs:2741-2764
+    slab = oracle.encode_f32_to_f16(rows4([1.0, 1.0, 1.0]))
+    r, _ = oracle.search_top_k(slab, np.array([1, 0, 0, 0], np.float32), 3)
+    assert r.tolist() == [0, 1, 2]
+    r, _ = oracle.search_top_k(slab, np.array([1, 0, 0, 0], np.float32), 2)
+    assert r.tolist() == [0, 1]
+
+
+def test_nan_scores_do_not_panic_and_sort_last(oracle):
+    # search.rs:2767-2787
+    slab = oracle.encode_f32_to_f16(rows4([1.0, 0.5, 0.2]))
+    r, s = oracle.search_top_k(slab, np.array([np.nan, 0, 0, 0], np.float32), 3)
+    assert len(r) == 3 and np.all(np.isnan(s)) and r.tolist() == sorted(r.tolist())
+
+
+def test_parallel_equals_sequential_property(oracle):
+    # search.rs:2054-2113 proptest: parallel == sequential (here bit-exact), plus tombstones (:2190-2233)
+    rng = np.random.default_rng(11)
+    for trial in range(12):
+        n = int(rng.integers(1, 400))
+        dim = int(rng.choice([4, 8, 16, 24, 40]))
+        k = int(rng.integers(1, 50))
+        slab = rng.standard_normal((n, dim)).astype(np.float16).view(np.uint16)
+        if trial % 3 == 0:
+            slab[rng.integers(0, n, 5)] = slab[0]  # duplicates -> score ties
+        live = rng.random(n) > 0.2 if trial % 2 else None
+        q = rng.standard_normal(dim).astype(np.float32)
+        r1, s1 = oracle.search_top_k(slab, q, k, live=live, parallel_threshold=2 ** 62)
+        r2, s2 = oracle.search_top_k(slab, q, k, live=live, parallel_threshold=1, chunk_size=7, nthreads=3)
+        assert np.array_equal(r1, r2) and np.array_equal(s1.view(np.uint32), s2.view(np.uint32))
+        # brute-force cross-check with python sort under the reference order
+        scores = np.array([oracle.dot_f16_f32(slab[i], q) for i in range(n)], dtype=np.float32)
+        cand = [i for i in range(n) if live is None or live[i]]
+        key = lambda i: (-(scores[i] if not np.isnan(scores[i]) else -np.inf), i)
+        want = sorted(cand, key=key)[:k]
+        assert r1.tolist() == want
+
+
+def test_hashmix_fixture_two_pass_shape(oracle):
+    # search.rs:1815-1859 fixture: 300 x 8 hash-mixed rows, 8 queries, top-10 — exact search is deterministic
+    vec = oracle.fixture_hashmix(300, 8)
+    s = (np.uint64(3) * np.uint64(2654435761)) ^ (np.uint64(5) * np.uint64(40503))
+    s ^= s >> np.uint64(13)
+    assert vec[3, 5] == np.float32(np.float32(int(s) & 0xFFFF) / np.float32(65535.0)) - np.float32(0.5)
+    slab = oracle.encode_f32_to_f16(vec)
+    for qi in range(8):
+        q = np.array([(((qi * 7 + j * 3) % 11) / 11.0) - 0.5 for j in range(8)], dtype=np.float32)
+        r, sc = oracle.search_top_k(slab, q, 10)
+        assert len(r) == 10 and np.all(np.diff(sc) <= 0)
+
+
+def test_classify_query(oracle):
+    # search.rs:227-261
+    assert oracle.classify_query(np.ones(3, np.float32), 4, 5) == (oracle.ERR_DIMENSION_MISMATCH, 0)
+    assert oracle.classify_query(np.ones(4, np.float32), 4, 0) == (0, 1)
+    assert oracle.classify_query(np.array([1, np.inf, 0, 0], np.float32), 4, 5)[0] == oracle.ERR_INVALID_CONFIG
+    assert oracle.classify_query(np.zeros(4, np.float32), 4, 5) == (0, 2)
+    assert oracle.classify_query(np.ones(4, np.float32), 4, 5) == (0, 0)
+
+
+# ---------------------------------------------------------------- FSVI
+def test_fsvi_roundtrip_sorted_by_hash_and_crc(oracle, tmp_path):
+    # crates/frankensearch-index/tests/fsvi_roundtrip.rs:34-120; lib.rs:3758-3762 (row order)
+    rng = np.random.default_rng(2)
+    rows = [(f"doc-{i:03}", rng.standard_normal(16).astype(np.float32).tolist()) for i in range(50)]
+    p = str(tmp_path / "r.fsvi")
+    assert oracle.fsvi_write(p, rows, "emb", "rev1") == 0
+    idx = oracle.Fsvi(p)
+    assert idx.record_count == 50 and idx.dimension == 16 and idx.vectors_offset % 64 == 0
+    ids = [idx.doc_id(r) for r in range(50)]
+    want = sorted((d for d, _ in rows), key=lambda d: (oracle.fnv1a64(d.encode()), d.encode()))
+    assert ids == want
+    slab = idx.slab()
+    by_id = dict(rows)
+    for r in range(50):
+        assert np.array_equal(slab[r], np.array(by_id[ids[r]], np.float32).astype(np.float16).view(np.uint16))
+    # corruption: flip a header byte -> CRC mismatch (IndexCorrupted); bad magic; bad version
+    raw = bytearray(open(p, "rb").read())
+    bad = bytearray(raw); bad[20] ^= 1
+    open(p + ".crc", "wb").write(bad)
+    with pytest.raises(IOError, match="status 3"):
+        oracle.Fsvi(p + ".crc")
+    bad = bytearray(raw); bad[0] = ord("X")
+    open(p + ".magic", "wb").write(bad)
+    with pytest.raises(IOError, match="status 3"):
+        oracle.Fsvi(p + ".magic")
+    bad = bytearray(raw); bad[4] = 9
+    open(p + ".ver", "wb").write(bad)
+    with pytest.raises(IOError, match="status 4"):
+        oracle.Fsvi(p + ".ver")
+
+
+def test_fsvi_writer_rejects_bad_vectors(oracle, tmp_path):
+    # lib.rs:3647-3660: non-finite and zero-norm embeddings rejected with InvalidConfig
+    p = str(tmp_path / "bad.fsvi")
+    assert oracle.fsvi_write(p, [("a", [np.nan, 0, 0, 0])]) == oracle.ERR_INVALID_CONFIG
+    assert oracle.fsvi_write(p, [("a", [0.0, 0, 0, 0])]) == oracle.ERR_INVALID_CONFIG
+
+
+def test_fsvi_doc_id_dedup_keeps_best(oracle, tmp_path):
+    # search.rs:1540-1543: main-vs-main duplicates -> first (best) wins
+    p = str(tmp_path / "d.fsvi")
+    oracle.fsvi_write(p, [("dup", [0.9, 0, 0, 0]), ("dup", [0.5, 0, 0, 0]), ("other", [0.7, 0, 0, 0])])
+    hits, _ = oracle.Fsvi(p).search_top_k([1.0, 0, 0, 0], 3)
+    assert [h[2] for h in hits] == ["dup", "other"]
+    assert abs(hits[0][1] - 0.9) < 1e-3
+
+
+# ---------------------------------------------------------------- Model2Vec / normalize
+def test_m2v_formula_model(oracle):
+    # embed/src/model2vec_embedder.rs:691-849 synthetic model val=row*0.1+col*0.01; :962-1010 invariants
+    vocab, dim = 10, 8
+    table = (np.arange(vocab, dtype=np.float32)[:, None] * np.float32(0.1)
+             + np.arange(dim, dtype=np.float32)[None, :] * np.float32(0.01)).astype(np.float32)
+    e = oracle.m2v_embed(table, [1, 2, 3])
+    assert abs(float(np.linalg.norm(e)) - 1.0) < 1e-5
+    assert np.all(oracle.m2v_embed(table, []) == 0)
+    assert np.all(oracle.m2v_embed(table, [99, 100]) == 0)           # all OOV -> zeros
+    assert np.array_equal(oracle.m2v_embed(table, [1, 99, 2]), oracle.m2v_embed(table, [1, 2]))  # OOV skipped
+    assert np.array_equal(oracle.m2v_embed(table, [3, 4]), oracle.m2v_embed(table, [3, 4]))       # deterministic
+
+
+def test_l2_normalize(oracle):
+    # core/src/traits.rs:590-618
+    assert np.all(oracle.l2_normalize(np.zeros(4)) == 0)
+    v = oracle.l2_normalize(np.array([3.0, 4.0]))
+    assert np.allclose(v, [0.6, 0.8], atol=1e-7)
+    assert np.all(oracle.l2_normalize(np.array([np.inf, 1.0])) == 0)
+
+
+def test_bench_generator(oracle):
+    # frankensearch/benches/fsvi_4bit_vs_incumbent.rs:66-101
+    state = 5 | 1
+    vals = []
+    for _ in range(4):
+        state ^= (state << 13) & 0xFFFFFFFFFFFFFFFF
+        state ^= state >> 7
+        state ^= (state << 17) & 0xFFFFFFFFFFFFFFFF
+        vals.append(np.float32(np.float32(state >> 40) / np.float32(1 << 23)) - np.float32(1.0))
+    assert np.array_equal(oracle.raw_vector(5, 4), np.array(vals, np.float32))
+    c = oracle.clustered_corpus_f16(0, 130, 384)
+    w = c.view(np.float16).astype(np.float32)
+    assert np.allclose(np.linalg.norm(w, axis=1), 1.0, atol=2e-3)
+    assert np.array_equal(oracle.clustered_corpus_f16(64, 66, 384), c[64:])
+    q = oracle.clustered_query(3, 384)
+    assert abs(float(np.linalg.norm(q)) - 1.0) < 1e-5
+    # (noise 0.30 * uniform[-1,1) dominates the unit centroid, so clusters barely separate: low-margin scores)
+    assert np.all(np.abs(w @ q) < 0.5)
