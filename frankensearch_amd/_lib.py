@@ -1,0 +1,85 @@
+"""ctypes binding of libfsgpu.so (the C ABI declared in include/fsgpu.h).
+
+There is NO fallback: if the HIP library is missing this module raises at import of the symbol
+table, and every compute entry point fails with FSGPU_ERR_NO_DEVICE when no GPU is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfsgpu.so")
+
+OK = 0
+ERR_DIMENSION_MISMATCH = 1
+ERR_INVALID_CONFIG = 2
+ERR_INDEX_CORRUPTED = 3
+ERR_INDEX_VERSION_MISMATCH = 4
+ERR_IO = 5
+ERR_DEVICE = 6
+ERR_NO_DEVICE = 7
+ERR_NULL_ARGUMENT = 8
+ERR_EMBEDDING_FAILED = 9
+
+ZERO_SIGNAL_NONE = 0
+ZERO_SIGNAL_CALLER_REQUESTED_ZERO_K = 1
+ZERO_SIGNAL_ZERO_NORM_QUERY = 2
+ZERO_SIGNAL_NO_MATCH = 3
+
+HREDUCE_SSE2 = 0
+HREDUCE_AVX = 1
+
+_vp, _u32, _u64, _i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
+
+# name -> (restype, argtypes); must list every symbol include/fsgpu.h declares
+SIGNATURES = {
+    "fsgpu_version": (C.c_char_p, []),
+    "fsgpu_device_count": (_i32, []),
+    "fsgpu_last_error": (C.c_char_p, []),
+    "fsgpu_index_create": (_i32, [_i32, _u32, _u64, _vp, _vp, _u64, C.POINTER(_vp)]),
+    "fsgpu_index_create_device": (_i32, [_i32, _u32, _u64, _vp, _vp, _u64, C.POINTER(_vp)]),
+    "fsgpu_index_open_fsvi": (_i32, [C.c_char_p, _i32, C.POINTER(_vp)]),
+    "fsgpu_index_destroy": (None, [_vp]),
+    "fsgpu_index_record_count": (_u64, [_vp]),
+    "fsgpu_index_dimension": (_u32, [_vp]),
+    "fsgpu_index_set_hreduce": (_i32, [_vp, _i32]),
+    "fsgpu_index_doc_id": (_i32, [_vp, _u32, C.POINTER(_vp), C.POINTER(_u32)]),
+    "fsgpu_index_soft_delete": (_i32, [_vp, C.c_char_p, _u32, C.POINTER(_i32)]),
+    "fsgpu_index_set_live_bitmap": (_i32, [_vp, _vp]),
+    "fsgpu_search_topk": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "fsgpu_search_topk_device": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp]),
+    "fsgpu_search_topk_classified": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, C.POINTER(_u32), C.POINTER(_i32)]),
+    "fsgpu_search_hits": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),
+    "fsgpu_gather_dot": (_i32, [_vp, _vp, _u32, _vp, _u32, _vp]),
+    "fsgpu_encode_f32_to_f16": (_i32, [_i32, _vp, _u64, _vp]),
+    "fsgpu_widen_f16_to_f32": (_i32, [_i32, _vp, _u64, _vp]),
+    "fsgpu_m2v_create": (_i32, [_i32, _vp, _u32, _u32, C.POINTER(_vp)]),
+    "fsgpu_m2v_destroy": (None, [_vp]),
+    "fsgpu_m2v_embed": (_i32, [_vp, _vp, _vp, _u32, _vp]),
+    "fsgpu_index_set_profiling": (_i32, [_vp, _i32]),
+    "fsgpu_index_scan_time": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(_u64), _i32]),
+    "fsgpu_index_set_variant": (_i32, [_vp, _i32]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -m frankensearch_amd.build` "
+                "(the HIP library is the product; there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the ABI and the header drift apart
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return (lib().fsgpu_last_error() or b"").decode("utf-8", "replace")

@@ -1,0 +1,68 @@
+"""Builds frankensearch_amd/libfsgpu.so for gfx950 with hipcc (in-tree, no JIT cache).
+
+`python -m frankensearch_amd.build` or `frankensearch_amd.build.build()`.  hipcc cross-compiles
+without a GPU, so this also runs in the CPU-only authoring container.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_build")
+LIB = os.path.join(HERE, "libfsgpu.so")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+
+SOURCES = ["scan_kernels.hip", "sort_general.hip", "m2v_kernels.hip", "bert_kernels.hip", "vector_index.cpp",
+           "bert_embedder.cpp", "fsgpu_api.cpp"]
+HEADERS = ["device_util.hpp", "kernels.hpp", "vector_index.hpp", "bert_embedder.hpp"]
+# -ffp-contract=off: the scan must issue a separate multiply and add (reference order, simd.rs:398-446).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-result", "-x", "hip"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def _stale(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    sources = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    common = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "fsgpu.h"), __file__]
+    hipcc = _hipcc()
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+        path = os.path.join(CSRC, src)
+        if force or _stale(obj, [path] + common):
+            cmd = [hipcc] + FLAGS + ["-I", INCLUDE, "-c", path, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(4, len(sources))) as pool:
+        objs = list(pool.map(compile_one, sources))
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

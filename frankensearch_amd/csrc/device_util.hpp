@@ -1,0 +1,117 @@
+// device_util.hpp — gfx950 device helpers shared by the fsgpu kernels.
+//
+// Ordering contract (crates/frankensearch-index/src/search.rs:91-126,1655-1686 in the reference):
+// best-first = higher score_key first where score_key maps NaN to -inf and compares with f32
+// total_cmp (-0.0 < +0.0); ties go to the LOWER row.  A candidate is carried as one 64-bit word
+//   packed  = raw f32 score bits << 32 | global row id
+// and compared through
+//   sortkey = ord(score bits) << 32 | ~row
+// where ord() is the monotone u32 image of that total order.  Larger sortkey == better, all
+// sortkeys of real rows are distinct and > 0, so top-k selection is an order-independent integer
+// problem: any parallel schedule yields the reference's exact ranking.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fsgpu {
+
+typedef unsigned long long u64;
+
+// Padding value: sorts below every real entry (row 0xFFFFFFFF never exists: row < 2^32-1).
+static constexpr u64 kEmpty = ~0ull;
+
+__device__ __forceinline__ uint32_t score_ord(uint32_t bits) {
+    if ((bits & 0x7fffffffu) > 0x7f800000u) bits = 0xff800000u;  // NaN ranks as -inf (score_key)
+    return (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);  // f32::total_cmp order
+}
+
+__device__ __forceinline__ u64 sortkey(u64 packed) {
+    return ((u64)score_ord((uint32_t)(packed >> 32)) << 32) | (uint32_t)(~(uint32_t)packed);
+}
+
+__device__ __forceinline__ u64 pack(float score, uint32_t row) {
+    return ((u64)__float_as_uint(score) << 32) | row;
+}
+
+// Compiler-level ordering of LDS traffic inside ONE wave (DS ops of a wave execute in order in
+// hardware; this only stops hipcc from moving/caching accesses across the point).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Quad (4-lane) butterfly through DPP quad_perm — no LDS, no bpermute.
+__device__ __forceinline__ float quad_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));  // [1,0,3,2]
+}
+__device__ __forceinline__ float quad_xor2(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));  // [2,3,0,1]
+}
+
+// wide::f32x8::reduce_add (third-party; simd.rs:439,563).  mode 0 = SSE2 build order, 1 = AVX order.
+__device__ __forceinline__ float hreduce8(const float (&v)[8], int mode) {
+    if (mode == 1) {
+        float a = v[0] + v[4], b = v[1] + v[5], c = v[2] + v[6], d = v[3] + v[7];
+        float lo = a + c, hi = b + d;
+        return lo + hi;
+    }
+    float a = (v[0] + v[2]) + (v[1] + v[3]);
+    float b = (v[4] + v[6]) + (v[5] + v[7]);
+    return a + b;
+}
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// One wave sorts CAP (power of two, >= 128) packed entries in LDS, best first.
+template <int CAP>
+__device__ __forceinline__ void wave_sort_desc(u64* buf, int lane) {
+#pragma unroll 1
+    for (int size = 2; size <= CAP; size <<= 1) {
+#pragma unroll 1
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            wave_lds_fence();
+#pragma unroll
+            for (int t = lane; t < CAP / 2; t += 64) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const u64 x = buf[lo], y = buf[hi];
+                const bool lt = sortkey(x) < sortkey(y);
+                if (lt == desc) {
+                    buf[lo] = y;
+                    buf[hi] = x;
+                }
+            }
+        }
+    }
+    wave_lds_fence();
+}
+
+// Whole block (NT threads) sorts CAP packed entries in LDS, best first.
+template <int CAP, int NT>
+__device__ __forceinline__ void block_sort_desc(u64* buf, int tid) {
+#pragma unroll 1
+    for (int size = 2; size <= CAP; size <<= 1) {
+#pragma unroll 1
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+#pragma unroll
+            for (int t = tid; t < CAP / 2; t += NT) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const u64 x = buf[lo], y = buf[hi];
+                const bool lt = sortkey(x) < sortkey(y);
+                if (lt == desc) {
+                    buf[lo] = y;
+                    buf[hi] = x;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+}  // namespace fsgpu

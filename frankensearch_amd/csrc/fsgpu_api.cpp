@@ -1,0 +1,332 @@
+// fsgpu_api.cpp — the extern "C" boundary of libfsgpu.so (declared in include/fsgpu.h).
+// Plain pointers and sizes only; every entry point catches C++ exceptions and reports a status.
+#include "../../include/fsgpu.h"
+
+#include <cmath>
+#include <cstring>
+#include <exception>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "vector_index.hpp"
+
+struct fsgpu_index {
+    fsgpu::VectorIndex impl;
+};
+struct fsgpu_m2v {
+    fsgpu::Model2VecEmbedder impl;
+};
+
+namespace {
+
+thread_local std::string g_last_error;
+
+fsgpu_status finish(const fsgpu::SearchError& e) {
+    if (!e.ok()) g_last_error = e.detail;
+    return e.code;
+}
+
+fsgpu_status fail(fsgpu_status code, const char* detail) {
+    g_last_error = detail;
+    return code;
+}
+
+template <typename F>
+fsgpu_status guarded(F&& body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(FSGPU_ERR_DEVICE, "host allocation failed");
+    } catch (const std::exception& ex) {
+        g_last_error = ex.what();
+        return FSGPU_ERR_DEVICE;
+    } catch (...) {
+        return fail(FSGPU_ERR_DEVICE, "unknown exception");
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fsgpu_version(void) { return "fsgpu 0.1.0 (gfx950)"; }
+
+int32_t fsgpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* fsgpu_last_error(void) { return g_last_error.c_str(); }
+
+fsgpu_status fsgpu_index_create(int32_t device, uint32_t dim, uint64_t nrows, const void* slab_f16_le,
+                                const uint64_t* live_bitmap, uint64_t row_base, fsgpu_index** out) {
+    if (!out) return fail(FSGPU_ERR_NULL_ARGUMENT, "out is null");
+    *out = nullptr;
+    return guarded([&]() -> fsgpu_status {
+        auto* h = new fsgpu_index();
+        fsgpu::SearchError e = h->impl.init_host(device, dim, nrows, slab_f16_le, live_bitmap, row_base);
+        if (!e.ok()) {
+            delete h;
+            return finish(e);
+        }
+        *out = h;
+        return FSGPU_OK;
+    });
+}
+
+fsgpu_status fsgpu_index_create_device(int32_t device, uint32_t dim, uint64_t nrows, const void* slab_f16_dev,
+                                       const uint64_t* live_bitmap_dev, uint64_t row_base, fsgpu_index** out) {
+    if (!out) return fail(FSGPU_ERR_NULL_ARGUMENT, "out is null");
+    *out = nullptr;
+    return guarded([&]() -> fsgpu_status {
+        auto* h = new fsgpu_index();
+        fsgpu::SearchError e = h->impl.init_device(device, dim, nrows, slab_f16_dev, live_bitmap_dev, row_base);
+        if (!e.ok()) {
+            delete h;
+            return finish(e);
+        }
+        *out = h;
+        return FSGPU_OK;
+    });
+}
+
+fsgpu_status fsgpu_index_open_fsvi(const char* path, int32_t device, fsgpu_index** out) {
+    if (!out) return fail(FSGPU_ERR_NULL_ARGUMENT, "out is null");
+    *out = nullptr;
+    return guarded([&]() -> fsgpu_status {
+        auto* h = new fsgpu_index();
+        fsgpu::SearchError e = h->impl.open_fsvi(path, device);
+        if (!e.ok()) {
+            delete h;
+            return finish(e);
+        }
+        *out = h;
+        return FSGPU_OK;
+    });
+}
+
+void fsgpu_index_destroy(fsgpu_index* idx) { delete idx; }
+
+uint64_t fsgpu_index_record_count(const fsgpu_index* idx) { return idx ? idx->impl.record_count() : 0; }
+uint32_t fsgpu_index_dimension(const fsgpu_index* idx) { return idx ? idx->impl.dimension() : 0; }
+
+fsgpu_status fsgpu_index_set_hreduce(fsgpu_index* idx, int32_t mode) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    if (mode != FSGPU_HREDUCE_SSE2 && mode != FSGPU_HREDUCE_AVX)
+        return fail(FSGPU_ERR_INVALID_CONFIG, "unknown hreduce mode");
+    std::lock_guard<std::mutex> lock(idx->impl.mutex());
+    idx->impl.hreduce = mode;
+    return FSGPU_OK;
+}
+
+fsgpu_status fsgpu_index_doc_id(const fsgpu_index* idx, uint32_t row, const char** ptr, uint32_t* len) {
+    if (!idx || !ptr || !len) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return finish(idx->impl.doc_id_at(row, ptr, len));
+}
+
+fsgpu_status fsgpu_index_soft_delete(fsgpu_index* idx, const char* doc_id, uint32_t doc_id_len, int32_t* deleted) {
+    if (!idx || !doc_id || !deleted) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.soft_delete(doc_id, doc_id_len, deleted));
+    });
+}
+
+fsgpu_status fsgpu_index_set_live_bitmap(fsgpu_index* idx, const uint64_t* live_bitmap) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.set_live_bitmap(live_bitmap));
+    });
+}
+
+fsgpu_status fsgpu_search_topk(fsgpu_index* idx, const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
+                               const uint64_t* allow_bitmap, uint32_t* out_rows, float* out_scores,
+                               uint32_t* out_counts) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    if (nq && (!queries || !out_counts || (k && (!out_rows || !out_scores))))
+        return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.search_top_k(queries, nq, query_len, k, allow_bitmap, out_rows, out_scores, out_counts));
+    });
+}
+
+fsgpu_status fsgpu_search_topk_device(fsgpu_index* idx, const float* queries_dev, uint32_t nq, uint32_t query_len,
+                                      uint32_t k, const uint64_t* allow_bitmap_dev, uint32_t* out_rows_dev,
+                                      float* out_scores_dev, uint32_t* out_counts_dev, void* hip_stream) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    if (nq && (!queries_dev || !out_counts_dev || (k && (!out_rows_dev || !out_scores_dev))))
+        return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.search_top_k_device(queries_dev, nq, query_len, k, allow_bitmap_dev, out_rows_dev,
+                                                    out_scores_dev, out_counts_dev,
+                                                    static_cast<hipStream_t>(hip_stream)));
+    });
+}
+
+// search_top_k_classified (crates/frankensearch-index/src/search.rs:227-261)
+fsgpu_status fsgpu_search_topk_classified(fsgpu_index* idx, const float* query, uint32_t query_len, uint32_t k,
+                                          uint32_t* out_rows, float* out_scores, uint32_t* out_count,
+                                          int32_t* zero_signal) {
+    if (!idx || !query || !out_count || !zero_signal) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    *zero_signal = FSGPU_ZERO_SIGNAL_NONE;
+    *out_count = 0;
+    if (query_len != idx->impl.dimension()) {
+        g_last_error = "expected " + std::to_string(idx->impl.dimension()) + ", found " + std::to_string(query_len);
+        return FSGPU_ERR_DIMENSION_MISMATCH;
+    }
+    if (k == 0) {
+        *zero_signal = FSGPU_ZERO_SIGNAL_CALLER_REQUESTED_ZERO_K;
+        return FSGPU_OK;
+    }
+    bool all_zero = true;
+    for (uint32_t i = 0; i < query_len; ++i) {
+        if (!std::isfinite(query[i])) return fail(FSGPU_ERR_INVALID_CONFIG, "query vector must be finite");
+        if (query[i] != 0.0f) all_zero = false;
+    }
+    if (all_zero) {
+        *zero_signal = FSGPU_ZERO_SIGNAL_ZERO_NORM_QUERY;
+        return FSGPU_OK;
+    }
+    fsgpu_status st = fsgpu_search_topk(idx, query, 1, query_len, k, nullptr, out_rows, out_scores, out_count);
+    if (st == FSGPU_OK && *out_count == 0) *zero_signal = FSGPU_ZERO_SIGNAL_NO_MATCH;
+    return st;
+}
+
+// search_top_k -> resolve_sorted_entries (search.rs:1503-1558): post-top-k doc-id dedup, first wins.
+fsgpu_status fsgpu_search_hits(fsgpu_index* idx, const float* query, uint32_t query_len, uint32_t k,
+                               uint32_t* out_rows, float* out_scores, uint32_t* out_count) {
+    if (!idx || !query || !out_count) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    *out_count = 0;
+    if (!idx->impl.has_doc_ids()) return fail(FSGPU_ERR_INVALID_CONFIG, "index has no doc-id table");
+    return guarded([&]() -> fsgpu_status {
+        std::vector<uint32_t> rows(k ? k : 1);
+        std::vector<float> scores(k ? k : 1);
+        uint32_t count = 0;
+        fsgpu_status st = fsgpu_search_topk(idx, query, 1, query_len, k, nullptr, rows.data(), scores.data(), &count);
+        if (st != FSGPU_OK) return st;
+        uint32_t n = 0;
+        for (uint32_t i = 0; i < count; ++i) {
+            const char* di = nullptr;
+            uint32_t li = 0;
+            fsgpu::SearchError e = idx->impl.doc_id_at(rows[i], &di, &li);
+            if (!e.ok()) return finish(e);
+            bool dup = false;
+            for (uint32_t j = 0; j < n && !dup; ++j) {
+                const char* dj = nullptr;
+                uint32_t lj = 0;
+                (void)idx->impl.doc_id_at(out_rows[j], &dj, &lj);
+                dup = (lj == li) && std::memcmp(di, dj, li) == 0;
+            }
+            if (dup) continue;
+            out_rows[n] = rows[i];
+            out_scores[n] = scores[i];
+            ++n;
+        }
+        *out_count = n;
+        return FSGPU_OK;
+    });
+}
+
+fsgpu_status fsgpu_gather_dot(fsgpu_index* idx, const float* query, uint32_t query_len, const uint32_t* rows,
+                              uint32_t n, float* out_scores) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    if (n && (!query || !rows || !out_scores)) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.gather_dot(query, query_len, rows, n, out_scores));
+    });
+}
+
+static fsgpu_status convert_on_device(int32_t device, const void* src, size_t src_elem, uint64_t n, void* dst,
+                                      size_t dst_elem, bool encode) {
+    if (n == 0) return FSGPU_OK;
+    if (!src || !dst) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(FSGPU_ERR_NO_DEVICE, "no HIP device visible (libfsgpu has no CPU fallback)");
+    if (device < 0 || device >= count) return fail(FSGPU_ERR_INVALID_CONFIG, "device ordinal out of range");
+    return guarded([&]() -> fsgpu_status {
+        if (hipSetDevice(device) != hipSuccess) return fail(FSGPU_ERR_DEVICE, "hipSetDevice failed");
+        fsgpu::DeviceBuffer a, b;
+        fsgpu::SearchError e = a.reserve((size_t)n * src_elem);
+        if (e.ok()) e = b.reserve((size_t)n * dst_elem);
+        if (!e.ok()) {
+            a.release();
+            b.release();
+            return finish(e);
+        }
+        hipError_t he = hipMemcpy(a.ptr, src, (size_t)n * src_elem, hipMemcpyHostToDevice);
+        if (he == hipSuccess)
+            he = encode ? fsgpu::launch_encode_f16(static_cast<const float*>(a.ptr), (size_t)n,
+                                                   static_cast<unsigned short*>(b.ptr), nullptr)
+                        : fsgpu::launch_widen_f16(static_cast<const unsigned short*>(a.ptr), (size_t)n,
+                                                  static_cast<float*>(b.ptr), nullptr);
+        if (he == hipSuccess) he = hipMemcpy(dst, b.ptr, (size_t)n * dst_elem, hipMemcpyDeviceToHost);
+        a.release();
+        b.release();
+        if (he != hipSuccess) {
+            g_last_error = hipGetErrorString(he);
+            return FSGPU_ERR_DEVICE;
+        }
+        return FSGPU_OK;
+    });
+}
+
+fsgpu_status fsgpu_encode_f32_to_f16(int32_t device, const float* src, uint64_t n, uint16_t* dst) {
+    return convert_on_device(device, src, 4, n, dst, 2, true);
+}
+
+fsgpu_status fsgpu_widen_f16_to_f32(int32_t device, const uint16_t* src, uint64_t n, float* dst) {
+    return convert_on_device(device, src, 2, n, dst, 4, false);
+}
+
+fsgpu_status fsgpu_m2v_create(int32_t device, const float* table, uint32_t vocab, uint32_t dim, fsgpu_m2v** out) {
+    if (!out) return fail(FSGPU_ERR_NULL_ARGUMENT, "out is null");
+    *out = nullptr;
+    return guarded([&]() -> fsgpu_status {
+        auto* h = new fsgpu_m2v();
+        fsgpu::SearchError e = h->impl.init(device, table, vocab, dim);
+        if (!e.ok()) {
+            delete h;
+            return finish(e);
+        }
+        *out = h;
+        return FSGPU_OK;
+    });
+}
+
+void fsgpu_m2v_destroy(fsgpu_m2v* m) { delete m; }
+
+fsgpu_status fsgpu_m2v_embed(fsgpu_m2v* m, const uint32_t* ids, const uint32_t* offsets, uint32_t n, float* out) {
+    if (!m) return fail(FSGPU_ERR_NULL_ARGUMENT, "embedder is null");
+    return guarded([&]() -> fsgpu_status { return finish(m->impl.embed_batch(ids, offsets, n, out)); });
+}
+
+fsgpu_status fsgpu_index_set_profiling(fsgpu_index* idx, int32_t enabled) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    std::lock_guard<std::mutex> lock(idx->impl.mutex());
+    idx->impl.profiling = enabled != 0;
+    return FSGPU_OK;
+}
+
+fsgpu_status fsgpu_index_scan_time(fsgpu_index* idx, double* total_ms, uint64_t* launches, int32_t reset) {
+    if (!idx || !total_ms || !launches) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.scan_time(total_ms, launches, reset != 0));
+    });
+}
+
+fsgpu_status fsgpu_index_set_variant(fsgpu_index* idx, int32_t variant) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    std::lock_guard<std::mutex> lock(idx->impl.mutex());
+    idx->impl.variant = variant;
+    return FSGPU_OK;
+}
+
+}  // extern "C"

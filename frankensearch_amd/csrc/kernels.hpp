@@ -1,0 +1,58 @@
+// kernels.hpp — argument blocks and host launchers of the fsgpu HIP kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace fsgpu {
+
+typedef unsigned long long u64;
+
+struct ScanArgs {
+    const void* slab;       // [nrows, dim] little-endian f16, row-major (FSVI slab, lib.rs:36-41)
+    const u64* live;        // bit r set = row r live (tombstone flag clear); nullptr = all live
+    const u64* allow;       // per-call filter bitmap; nullptr = no filter
+    const float* queries;   // [nq, dim] f32 (device)
+    u64* partial;           // [nq, grid, kcap] packed best-first lists (device)
+    uint32_t nrows;
+    uint32_t dim;
+    uint32_t k;
+    uint32_t row_base;      // added to local rows (shard offset)
+    int32_t hreduce;        // FSGPU_HREDUCE_*
+};
+
+struct MergeArgs {
+    const u64* lists;       // [nq, nlists, list_len] packed
+    uint32_t nlists;
+    uint32_t list_len;
+    uint32_t k;             // entries to select per query
+    uint32_t out_stride;    // row stride of the outputs (>= k); slots beyond the count are padded
+    uint32_t* out_rows;     // [nq, out_stride]
+    float* out_scores;      // [nq, out_stride]
+    uint32_t* out_counts;   // [nq]
+};
+
+size_t scan_lds_bytes(int dim, int nq, int kcap);
+int scan_occupancy_blocks_per_cu(int dim, int nq, int kcap);
+hipError_t launch_scan_topk(const ScanArgs& args, int nq, int kcap, int grid, hipStream_t stream,
+                            bool force_runtime_dim);
+hipError_t launch_merge_topk(const MergeArgs& args, int nq, hipStream_t stream);
+hipError_t launch_score_rows(const ScanArgs& args, u64* out_packed, int q_index, int grid, hipStream_t stream);
+hipError_t launch_packed_to_sortkey(u64* data, size_t n, hipStream_t stream);
+hipError_t launch_sorted_keys_to_rows(const u64* keys, uint32_t k, uint32_t* out_rows, uint32_t* out_count,
+                                      hipStream_t stream);
+hipError_t launch_gather_dot(const ScanArgs& args, const uint32_t* rows, uint32_t n, float* out, hipStream_t stream);
+hipError_t launch_encode_f16(const float* src, size_t n, unsigned short* dst, hipStream_t stream);
+hipError_t launch_widen_f16(const unsigned short* src, size_t n, float* dst, hipStream_t stream);
+
+// sort_general.hip (rocPRIM radix sort, descending u64 keys) — the large-k / collect-all path.
+hipError_t sort_keys_desc_temp_bytes(size_t n, size_t* temp_bytes);
+hipError_t sort_keys_desc(void* temp, size_t temp_bytes, const u64* keys_in, u64* keys_out, size_t n,
+                          hipStream_t stream);
+
+// m2v_kernels.hip
+hipError_t launch_m2v_embed(const float* table, uint32_t vocab, uint32_t dim, const uint32_t* ids,
+                            const uint32_t* offsets, uint32_t n, float* out, hipStream_t stream);
+
+}  // namespace fsgpu

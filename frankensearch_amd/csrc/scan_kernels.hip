@@ -1,0 +1,628 @@
+// scan_kernels.hip — the f16 cosine brute-force scan fused with a wave-parallel top-k (gfx950).
+//
+// Replaces, for a device-resident slab, the reference's hot loop
+//   scan_parallel -> scan_range_chunk -> dot_product_f16_bytes_f32 -> bounded BinaryHeap ->
+//   merge_partial_heaps -> resolve_hits sort
+// (crates/frankensearch-index/src/search.rs:1013-1036,1257-1327,1704-1720,1493-1501;
+//  crates/frankensearch-index/src/simd.rs:398-446).
+//
+// Arithmetic contract: the score of a row is computed in the reference's exact operation order —
+// 8-lane chunks, chunk c of every group of four accumulated into accumulator (c mod 4) with a
+// separate IEEE multiply and add (never an FMA), leftover chunks into accumulator 0, the lane-wise
+// (s0+s1)+(s2+s3), the 8-lane horizontal add, and a fused scalar tail for dim % 8 — so GPU scores
+// are bit-identical to the CPU path and the ranking needs no re-scoring.
+//
+// Mapping to CDNA4: FOUR LANES PER ROW.  Lane a (0..3) of a quad owns accumulator s_a, i.e. the
+// 16-byte chunks c = 4g+a of its row, so every load is a dwordx4 and the four lanes of a quad
+// fetch 64 contiguous bytes; a wave covers a 16-row tile (16 x dim x 2 bytes, contiguous in HBM).
+// The (s0+s1)+(s2+s3) step is two DPP quad_perm butterflies (IEEE add is commutative, so every
+// lane of the quad ends with the same bits).  Queries sit in LDS (broadcast ds_read_b128).
+// Top-k: each wave keeps a threshold-gated candidate buffer in LDS (ballot + mbcnt compaction, no
+// atomics), re-sorted by a wave-local bitonic network only when it fills; waves of a block merge
+// at the end and one sorted list per block goes to HBM for the final merge kernel.
+#pragma clang fp contract(off)
+
+#include "device_util.hpp"
+#include "kernels.hpp"
+
+namespace fsgpu {
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kRowsPerTile = 16;
+
+__device__ __forceinline__ u32x4 load_nt16(const u32x4* p) { return __builtin_nontemporal_load(p); }
+
+// ---- per-wave top-k state over an LDS buffer of CAP packed entries ---------------------------------
+template <int CAP>
+struct WaveTopK {
+    u64* buf;   // CAP entries (LDS)
+    int count;  // wave-uniform
+    __device__ __forceinline__ void init(u64* b) {
+        buf = b;
+        count = 0;
+    }
+    // Sort, trim to k, return the new threshold sortkey (0 while fewer than k entries are held).
+    __device__ __forceinline__ u64 compact(int k, int lane) {
+        for (int i = count + lane; i < CAP; i += 64) buf[i] = kEmpty;
+        wave_sort_desc<CAP>(buf, lane);
+        if (count > k) count = k;
+        u64 thr = 0;
+        if (count == k) thr = sortkey(buf[k - 1]);
+        return thr;
+    }
+};
+
+// One chunk (8 f16 x 8 f32) into the lane's 8 accumulators: separate multiply and add.
+__device__ __forceinline__ void chunk_mac(float (&acc)[8], const u32x4& w, const float4& q0, const float4& q1) {
+    const half8 h = __builtin_bit_cast(half8, w);
+    float p;
+    p = (float)h[0] * q0.x; acc[0] = acc[0] + p;
+    p = (float)h[1] * q0.y; acc[1] = acc[1] + p;
+    p = (float)h[2] * q0.z; acc[2] = acc[2] + p;
+    p = (float)h[3] * q0.w; acc[3] = acc[3] + p;
+    p = (float)h[4] * q1.x; acc[4] = acc[4] + p;
+    p = (float)h[5] * q1.y; acc[5] = acc[5] + p;
+    p = (float)h[6] * q1.z; acc[6] = acc[6] + p;
+    p = (float)h[7] * q1.w; acc[7] = acc[7] + p;
+}
+
+// (s0+s1)+(s2+s3) across the quad, then the horizontal add; every lane of the quad gets the result.
+__device__ __forceinline__ float quad_finish(const float (&acc)[8], int hreduce) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float u = acc[j] + quad_xor1(acc[j]);  // lanes 0,1: s0+s1   lanes 2,3: s2+s3
+        v[j] = u + quad_xor2(u);                     // (s0+s1)+(s2+s3)
+    }
+    return hreduce8(v, hreduce);
+}
+
+}  // namespace
+
+// DIM_CT: compile-time dimension (multiple of 32, <= 512: register double-buffered tiles) or 0 for the
+//         runtime-dimension body (any dim % 8 == 0, incl. leftover chunks).
+// NQ:     queries scored per pass (1, 2 or 4): lane a of a quad owns query a's candidate.
+// KCAP:   capacity tier of the per-wave / per-block lists (k <= KCAP); CAP = 2*KCAP.
+template <int DIM_CT, int NQ, int KCAP>
+__global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs args) {
+    constexpr int CAP = 2 * KCAP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int dim = DIM_CT ? DIM_CT : (int)args.dim;
+    float* qs = reinterpret_cast<float*>(smem);                                   // [NQ][dim]
+    u64* bufs = reinterpret_cast<u64*>(smem + (((size_t)NQ * dim * 4 + 15) & ~(size_t)15));  // [wave][NQ][CAP]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int a = lane & 3;
+    const int r = lane >> 2;
+
+    for (int i = tid; i < NQ * dim; i += 256) qs[i] = args.queries[i];
+    __syncthreads();
+
+    WaveTopK<CAP> tk[NQ];
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) tk[b].init(bufs + ((size_t)wave * NQ + b) * CAP);
+    u64 thr = 0;  // lane a holds the threshold of query a
+
+    const uint32_t nrows = args.nrows;
+    const uint32_t ntiles = (nrows + kRowsPerTile - 1) / kRowsPerTile;
+    const uint32_t nwaves = gridDim.x * kWavesPerBlock;
+    const uint32_t wave_gid = blockIdx.x * kWavesPerBlock + wave;
+    const unsigned char* slab = reinterpret_cast<const unsigned char*>(args.slab);
+    const size_t row_bytes = (size_t)dim * 2;
+    const int k = (int)args.k;
+    const int hreduce = args.hreduce;
+    const u64 qmask = 0x1111111111111111ull;
+
+    // Scores one tile and pushes candidates.  `w(g)` yields chunk 4g+a of this lane's row.
+    auto finish_tile = [&](uint32_t tile, float (&acc)[NQ][8], u64 live_word, u64 allow_word) {
+        const uint32_t row = tile * kRowsPerTile + r;
+        bool valid = row < nrows;
+        valid = valid && ((live_word >> (row & 63)) & 1ull) && ((allow_word >> (row & 63)) & 1ull);
+        float score = 0.f;
+#pragma unroll
+        for (int b = 0; b < NQ; ++b) {
+            float s = quad_finish(acc[b], hreduce);
+            if (DIM_CT == 0 && (dim & 7)) {  // scalar tail: fused mul_add, in index order
+                const uint32_t rowc = row < nrows ? row : nrows - 1;
+                const _Float16* hp = reinterpret_cast<const _Float16*>(slab + (size_t)rowc * row_bytes);
+                for (int i = dim & ~7; i < dim; ++i) s = __builtin_fmaf((float)hp[i], qs[b * dim + i], s);
+            }
+            if (a == b) score = s;
+        }
+        const u64 packed = pack(score, args.row_base + row);
+        bool cand = valid && (a < NQ) && sortkey(packed) > thr;
+        u64 m = __ballot(cand);
+        if (m == 0) return;
+#pragma unroll
+        for (int b = 0; b < NQ; ++b) {
+            u64 mb = m & (qmask << b);
+            if (mb == 0) continue;
+            if (tk[b].count + (int)__popcll(mb) > CAP) {
+                const u64 t = tk[b].compact(k, lane);
+                if (a == b) thr = t;
+                cand = cand && sortkey(packed) > thr;
+                mb = __ballot(cand) & (qmask << b);
+            }
+            if (cand && a == b) {
+                const int pos = tk[b].count + (int)__popcll(mb & ((1ull << lane) - 1ull));
+                tk[b].buf[pos] = packed;
+            }
+            tk[b].count += (int)__popcll(mb);
+        }
+    };
+
+    auto tile_words = [&](uint32_t tile, u64& live_word, u64& allow_word) {
+        const uint32_t w64 = (tile * kRowsPerTile) >> 6;
+        live_word = args.live ? args.live[w64] : ~0ull;
+        allow_word = args.allow ? args.allow[w64] : ~0ull;
+    };
+
+    if constexpr (DIM_CT != 0) {
+        constexpr int G = DIM_CT / 32;
+        auto load_tile = [&](uint32_t tile, u32x4 (&w)[G]) {
+            uint32_t row = tile * kRowsPerTile + r;
+            row = row < nrows ? row : nrows - 1;
+            const u32x4* p = reinterpret_cast<const u32x4*>(slab + (size_t)row * row_bytes) + a;
+#pragma unroll
+            for (int g = 0; g < G; ++g) w[g] = load_nt16(p + 4 * g);
+        };
+        // NQ == 1 keeps the whole query in registers (G*8 VGPRs, loaded once): the hot loop then has no
+        // LDS traffic at all.  (Compile-time dims are only instantiated for NQ == 1.)
+        static_assert(NQ == 1, "compile-time dimension bodies are single-query");
+        float4 q0[G], q1[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float4* qp = reinterpret_cast<const float4*>(qs + 32 * g + 8 * a);
+            q0[g] = qp[0];
+            q1[g] = qp[1];
+        }
+        auto compute_tile = [&](uint32_t tile, const u32x4 (&w)[G], u64 live_word, u64 allow_word) {
+            float acc[NQ][8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[0][j] = 0.f;
+#pragma unroll
+            for (int g = 0; g < G; ++g) chunk_mac(acc[0], w[g], q0[g], q1[g]);
+            finish_tile(tile, acc, live_word, allow_word);
+        };
+        constexpr bool kDoubleBuffer = G <= 12;
+        if constexpr (kDoubleBuffer) {
+            u32x4 wa[G], wb[G];
+            u64 la = ~0ull, aa = ~0ull, lb = ~0ull, ab = ~0ull;
+            uint32_t tile = wave_gid;
+            if (tile < ntiles) {
+                load_tile(tile, wa);
+                tile_words(tile, la, aa);
+            }
+            while (tile < ntiles) {
+                uint32_t next = tile + nwaves;
+                if (next < ntiles) {
+                    load_tile(next, wb);
+                    tile_words(next, lb, ab);
+                }
+                compute_tile(tile, wa, la, aa);
+                tile = next;
+                if (tile >= ntiles) break;
+                next = tile + nwaves;
+                if (next < ntiles) {
+                    load_tile(next, wa);
+                    tile_words(next, la, aa);
+                }
+                compute_tile(tile, wb, lb, ab);
+                tile = next;
+            }
+        } else {
+            for (uint32_t tile = wave_gid; tile < ntiles; tile += nwaves) {
+                u32x4 w[G];
+                u64 lw, aw;
+                load_tile(tile, w);
+                tile_words(tile, lw, aw);
+                compute_tile(tile, w, lw, aw);
+            }
+        }
+    } else {
+        // Runtime dimension (dim % 8 == 0 for the 16-byte loads; tail handled in finish_tile when the
+        // host routes an unaligned dim here it uses the thread-per-row kernel instead).
+        const int chunks = dim >> 3;
+        const int groups = chunks >> 2;
+        const int leftover = chunks & 3;
+        for (uint32_t tile = wave_gid; tile < ntiles; tile += nwaves) {
+            uint32_t row = tile * kRowsPerTile + r;
+            row = row < nrows ? row : nrows - 1;
+            const u32x4* p = reinterpret_cast<const u32x4*>(slab + (size_t)row * row_bytes);
+            u64 lw, aw;
+            tile_words(tile, lw, aw);
+            float acc[NQ][8];
+#pragma unroll
+            for (int b = 0; b < NQ; ++b)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[b][j] = 0.f;
+#pragma unroll 4
+            for (int g = 0; g < groups; ++g) {
+                const u32x4 w = load_nt16(p + 4 * g + a);
+#pragma unroll
+                for (int b = 0; b < NQ; ++b) {
+                    const float4* qp = reinterpret_cast<const float4*>(qs + b * dim + 32 * g + 8 * a);
+                    chunk_mac(acc[b], w, qp[0], qp[1]);
+                }
+            }
+            if (a == 0) {  // leftover chunks all accumulate into s0, in order
+                for (int c = 4 * groups; c < 4 * groups + leftover; ++c) {
+                    const u32x4 w = load_nt16(p + c);
+#pragma unroll
+                    for (int b = 0; b < NQ; ++b) {
+                        const float4* qp = reinterpret_cast<const float4*>(qs + b * dim + 8 * c);
+                        chunk_mac(acc[b], w, qp[0], qp[1]);
+                    }
+                }
+            }
+            finish_tile(tile, acc, lw, aw);
+        }
+    }
+
+    // ---- block merge: every wave sorts its lists, then wave b folds the four lists of query b ----
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) (void)tk[b].compact(k, lane);
+    __syncthreads();
+    for (int b = wave; b < NQ; b += kWavesPerBlock) {
+        u64* dst = bufs + ((size_t)0 * NQ + b) * CAP;
+        for (int w = 1; w < kWavesPerBlock; ++w) {
+            const u64* src = bufs + ((size_t)w * NQ + b) * CAP;
+            // top-KCAP of two best-first lists: elementwise max of A[i] and B[KCAP-1-i], then re-sort
+            for (int i = lane; i < KCAP; i += 64) {
+                const u64 x = dst[i], y = src[KCAP - 1 - i];
+                dst[i] = sortkey(x) >= sortkey(y) ? x : y;
+            }
+            for (int i = KCAP + lane; i < CAP; i += 64) dst[i] = kEmpty;
+            wave_sort_desc<CAP>(dst, lane);
+        }
+        u64* out = args.partial + ((size_t)b * gridDim.x + blockIdx.x) * KCAP;
+        for (int i = lane; i < KCAP; i += 64) out[i] = i < k ? dst[i] : kEmpty;
+    }
+}
+
+// Thread-per-row fallback for dimensions that are not a multiple of 8 (rows are not 16-byte aligned).
+// Same arithmetic order; writes one packed entry per row (kEmpty for dead rows) for the general path.
+__global__ __launch_bounds__(256) void score_rows_generic_kernel(ScanArgs args, u64* out_packed, int q_index) {
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= args.nrows) return;
+    const int dim = (int)args.dim;
+    bool valid = true;
+    if (args.live) valid = valid && ((args.live[row >> 6] >> (row & 63)) & 1ull);
+    if (args.allow) valid = valid && ((args.allow[row >> 6] >> (row & 63)) & 1ull);
+    if (!valid) {
+        out_packed[row] = kEmpty;
+        return;
+    }
+    const _Float16* hp = reinterpret_cast<const _Float16*>(args.slab) + (size_t)row * dim;
+    const float* q = args.queries + (size_t)q_index * dim;
+    float s[4][8];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[x][j] = 0.f;
+    const int chunks = dim >> 3;
+    int c = 0;
+    for (; c + 4 <= chunks; c += 4) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float p = (float)hp[(c + x) * 8 + j] * q[(c + x) * 8 + j];
+                s[x][j] = s[x][j] + p;
+            }
+    }
+    for (; c < chunks; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float p = (float)hp[c * 8 + j] * q[c * 8 + j];
+            s[0][j] = s[0][j] + p;
+        }
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (s[0][j] + s[1][j]) + (s[2][j] + s[3][j]);
+    float result = hreduce8(v, args.hreduce);
+    for (int i = chunks * 8; i < dim; ++i) result = __builtin_fmaf((float)hp[i], q[i], result);
+    out_packed[row] = pack(result, args.row_base + row);
+}
+
+// Four-lanes-per-row scorer that writes every row's packed entry (general path: k beyond the fused
+// tiers, collect-all).  dim % 8 == 0.
+__global__ __launch_bounds__(256) void score_rows_kernel(ScanArgs args, u64* out_packed, int q_index) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* qs = reinterpret_cast<float*>(smem);
+    const int dim = (int)args.dim;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, a = lane & 3, r = lane >> 2;
+    for (int i = tid; i < dim; i += 256) qs[i] = args.queries[(size_t)q_index * dim + i];
+    __syncthreads();
+    const uint32_t nrows = args.nrows;
+    const uint32_t ntiles = (nrows + kRowsPerTile - 1) / kRowsPerTile;
+    const uint32_t nwaves = gridDim.x * kWavesPerBlock;
+    const unsigned char* slab = reinterpret_cast<const unsigned char*>(args.slab);
+    const size_t row_bytes = (size_t)dim * 2;
+    const int chunks = dim >> 3, groups = chunks >> 2, leftover = chunks & 3;
+    for (uint32_t tile = blockIdx.x * kWavesPerBlock + wave; tile < ntiles; tile += nwaves) {
+        const uint32_t row = tile * kRowsPerTile + r;
+        const uint32_t rowc = row < nrows ? row : nrows - 1;
+        const u32x4* p = reinterpret_cast<const u32x4*>(slab + (size_t)rowc * row_bytes);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll 4
+        for (int g = 0; g < groups; ++g) {
+            const u32x4 w = load_nt16(p + 4 * g + a);
+            const float4* qp = reinterpret_cast<const float4*>(qs + 32 * g + 8 * a);
+            chunk_mac(acc, w, qp[0], qp[1]);
+        }
+        if (a == 0) {
+            for (int c = 4 * groups; c < 4 * groups + leftover; ++c) {
+                const u32x4 w = load_nt16(p + c);
+                const float4* qp = reinterpret_cast<const float4*>(qs + 8 * c);
+                chunk_mac(acc, w, qp[0], qp[1]);
+            }
+        }
+        const float s = quad_finish(acc, args.hreduce);
+        if (a == 0 && row < nrows) {
+            bool valid = true;
+            if (args.live) valid = valid && ((args.live[row >> 6] >> (row & 63)) & 1ull);
+            if (args.allow) valid = valid && ((args.allow[row >> 6] >> (row & 63)) & 1ull);
+            out_packed[row] = valid ? pack(s, args.row_base + row) : kEmpty;
+        }
+    }
+}
+
+// Final merge: one block per query folds P best-first lists of LIST entries into the top-k and emits
+// (row, score) arrays, best first.  Selection is by unique integer sortkeys, so the LDS-atomic append
+// order does not affect the result.
+template <int MCAP>
+__global__ __launch_bounds__(256) void merge_topk_kernel(MergeArgs args) {
+    __shared__ u64 buf[MCAP];
+    __shared__ int s_count;
+    __shared__ u64 s_thr;
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x;
+    const u64* in = args.lists + (size_t)q * args.nlists * args.list_len;
+    const size_t total = (size_t)args.nlists * args.list_len;
+    const int k = (int)args.k;
+    if (tid == 0) {
+        s_count = 0;
+        s_thr = 0;
+    }
+    __syncthreads();
+    for (size_t base = 0; base < total; base += 256) {
+        const size_t i = base + tid;
+        u64 c = kEmpty;
+        if (i < total) c = in[i];
+        const bool ok = c != kEmpty && sortkey(c) > s_thr;
+        if (ok) {
+            const int pos = atomicAdd(&s_count, 1);
+            buf[pos] = c;
+        }
+        __syncthreads();
+        if (s_count > MCAP - 256) {  // block-uniform
+            const int cnt = s_count;
+            for (int j = cnt + tid; j < MCAP; j += 256) buf[j] = kEmpty;
+            block_sort_desc<MCAP, 256>(buf, tid);
+            if (tid == 0) {
+                s_count = cnt < k ? cnt : k;
+                s_thr = cnt >= k ? sortkey(buf[k - 1]) : 0;
+            }
+            __syncthreads();
+        }
+    }
+    const int cnt = s_count;
+    for (int j = cnt + tid; j < MCAP; j += 256) buf[j] = kEmpty;
+    block_sort_desc<MCAP, 256>(buf, tid);
+    const int n = cnt < k ? cnt : k;
+    for (int j = tid; j < (int)args.out_stride; j += 256) {
+        const u64 c = j < n ? buf[j] : kEmpty;
+        args.out_rows[(size_t)q * args.out_stride + j] = (uint32_t)c;
+        args.out_scores[(size_t)q * args.out_stride + j] = __uint_as_float((uint32_t)(c >> 32));
+    }
+    if (tid == 0) args.out_counts[q] = (uint32_t)n;
+}
+
+// packed -> sortkey (in place), for the general path's radix sort; and the inverse for rows.
+__global__ void packed_to_sortkey_kernel(u64* data, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const u64 c = data[i];
+        data[i] = c == kEmpty ? 0ull : sortkey(c);
+    }
+}
+
+// General-path epilogue: first k sorted sortkeys -> rows (+count of real entries).
+__global__ void sorted_keys_to_rows_kernel(const u64* keys, uint32_t k, uint32_t* out_rows, uint32_t* out_count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) {
+        const u64 key = keys[i];
+        out_rows[i] = key ? ~(uint32_t)key : 0xffffffffu;
+        // count = number of non-zero keys among the first k (zeros sort last)
+        if (key != 0 && (i + 1 == k || keys[i + 1] == 0)) *out_count = i + 1;
+        if (i == 0 && key == 0) *out_count = 0;
+    }
+}
+
+// gather-dot: VectorIndex::dot_query_at (lib.rs:3229-3239) over a row list; one quad per row.
+// rows are global ids; out-of-shard rows are skipped (left untouched).
+__global__ __launch_bounds__(256) void gather_dot_kernel(ScanArgs args, const uint32_t* rows, uint32_t n, float* out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* qs = reinterpret_cast<float*>(smem);
+    const int dim = (int)args.dim;
+    const int tid = threadIdx.x, lane = tid & 63, a = lane & 3;
+    for (int i = tid; i < dim; i += 256) qs[i] = args.queries[i];
+    __syncthreads();
+    const uint32_t item = (blockIdx.x * 256 + tid) >> 2;
+    const bool in_range = item < n;
+    uint32_t row = in_range ? rows[item] - args.row_base : 0;  // wraps for rows below the shard base
+    const bool mine = in_range && row < args.nrows;
+    if (!mine) row = 0;
+    const unsigned char* slab = reinterpret_cast<const unsigned char*>(args.slab);
+    const int chunks = dim >> 3, groups = chunks >> 2, leftover = chunks & 3;
+    float s;
+    if ((dim & 7) == 0) {
+        const u32x4* p = reinterpret_cast<const u32x4*>(slab + (size_t)row * dim * 2);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int g = 0; g < groups; ++g) {
+            const u32x4 w = p[4 * g + a];
+            const float4* qp = reinterpret_cast<const float4*>(qs + 32 * g + 8 * a);
+            chunk_mac(acc, w, qp[0], qp[1]);
+        }
+        if (a == 0) {
+            for (int c = 4 * groups; c < 4 * groups + leftover; ++c) {
+                const u32x4 w = p[c];
+                const float4* qp = reinterpret_cast<const float4*>(qs + 8 * c);
+                chunk_mac(acc, w, qp[0], qp[1]);
+            }
+        }
+        s = quad_finish(acc, args.hreduce);
+    } else {
+        // unaligned rows: lane a still owns accumulator a, element loads
+        const _Float16* hp = reinterpret_cast<const _Float16*>(slab) + (size_t)row * dim;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int g = 0; g < groups; ++g)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = 32 * g + 8 * a + j;
+                const float p = (float)hp[e] * qs[e];
+                acc[j] = acc[j] + p;
+            }
+        if (a == 0)
+            for (int c = 4 * groups; c < 4 * groups + leftover; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float p = (float)hp[8 * c + j] * qs[8 * c + j];
+                    acc[j] = acc[j] + p;
+                }
+        s = quad_finish(acc, args.hreduce);
+        for (int i = chunks * 8; i < dim; ++i) s = __builtin_fmaf((float)hp[i], qs[i], s);
+    }
+    if (mine && a == 0) out[item] = s;
+}
+
+// f32 -> f16 round-to-nearest-even (encode_f32_to_f16_extend, simd.rs:2245-2305): v_cvt_f16_f32 is RNE.
+__global__ void encode_f16_kernel(const float* src, size_t n, unsigned short* dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const _Float16 h = (_Float16)src[i];
+        dst[i] = __builtin_bit_cast(unsigned short, h);
+    }
+}
+
+// f16 -> f32 widen (widen8_f16_lanes, simd.rs:63-82): exact.
+__global__ void widen_f16_kernel(const unsigned short* src, size_t n, float* dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)__builtin_bit_cast(_Float16, src[i]);
+}
+
+// ---- host-side launchers ---------------------------------------------------------------------------
+
+size_t scan_lds_bytes(int dim, int nq, int kcap) {
+    return (((size_t)nq * dim * 4 + 15) & ~(size_t)15) + (size_t)kWavesPerBlock * nq * (2 * kcap) * 8;
+}
+
+template <int DIM_CT, int NQ, int KCAP>
+static hipError_t launch_scan_t(const ScanArgs& args, int grid, hipStream_t stream) {
+    const size_t lds = scan_lds_bytes(DIM_CT ? DIM_CT : (int)args.dim, NQ, KCAP);
+    auto kern = scan_topk_kernel<DIM_CT, NQ, KCAP>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, args);
+    return hipGetLastError();
+}
+
+template <int NQ, int KCAP>
+static hipError_t launch_scan_dim(const ScanArgs& args, int grid, hipStream_t stream, bool force_runtime_dim) {
+    if constexpr (NQ == 1) {
+        if (!force_runtime_dim) {
+            switch (args.dim) {
+                case 128: return launch_scan_t<128, NQ, KCAP>(args, grid, stream);
+                case 256: return launch_scan_t<256, NQ, KCAP>(args, grid, stream);
+                case 384: return launch_scan_t<384, NQ, KCAP>(args, grid, stream);
+                case 512: return launch_scan_t<512, NQ, KCAP>(args, grid, stream);
+                default: break;
+            }
+        }
+    }
+    return launch_scan_t<0, NQ, KCAP>(args, grid, stream);
+}
+
+hipError_t launch_scan_topk(const ScanArgs& args, int nq, int kcap, int grid, hipStream_t stream,
+                            bool force_runtime_dim) {
+#define FSGPU_DISPATCH(NQ_, KCAP_) \
+    if (nq == NQ_ && kcap == KCAP_) return launch_scan_dim<NQ_, KCAP_>(args, grid, stream, force_runtime_dim);
+    FSGPU_DISPATCH(1, 64)
+    FSGPU_DISPATCH(2, 64)
+    FSGPU_DISPATCH(4, 64)
+    FSGPU_DISPATCH(1, 256)
+    FSGPU_DISPATCH(2, 256)
+    FSGPU_DISPATCH(4, 256)
+#undef FSGPU_DISPATCH
+    return hipErrorInvalidValue;
+}
+
+int scan_occupancy_blocks_per_cu(int dim, int nq, int kcap) {
+    // Conservative: the kernel is declared for 256-thread blocks; registers allow >= 2 blocks/CU for
+    // every instantiation, LDS decides the rest.
+    const size_t lds = scan_lds_bytes(dim, nq, kcap);
+    int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
+    if (by_lds < 1) by_lds = 1;
+    return by_lds > 3 ? 3 : by_lds;
+}
+
+hipError_t launch_merge_topk(const MergeArgs& args, int nq, hipStream_t stream) {
+    hipLaunchKernelGGL(merge_topk_kernel<2048>, dim3(nq), dim3(256), 0, stream, args);
+    return hipGetLastError();
+}
+
+hipError_t launch_score_rows(const ScanArgs& args, u64* out_packed, int q_index, int grid, hipStream_t stream) {
+    if (args.dim % 8 != 0) {
+        const int blocks = (int)((args.nrows + 255) / 256);
+        hipLaunchKernelGGL(score_rows_generic_kernel, dim3(blocks), dim3(256), 0, stream, args, out_packed, q_index);
+    } else {
+        hipLaunchKernelGGL(score_rows_kernel, dim3(grid), dim3(256), (size_t)args.dim * 4, stream, args, out_packed,
+                           q_index);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_packed_to_sortkey(u64* data, size_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(packed_to_sortkey_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, data, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_sorted_keys_to_rows(const u64* keys, uint32_t k, uint32_t* out_rows, uint32_t* out_count,
+                                      hipStream_t stream) {
+    hipLaunchKernelGGL(sorted_keys_to_rows_kernel, dim3((k + 255) / 256), dim3(256), 0, stream, keys, k, out_rows,
+                       out_count);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_dot(const ScanArgs& args, const uint32_t* rows, uint32_t n, float* out, hipStream_t stream) {
+    const unsigned blocks = (unsigned)(((size_t)n * 4 + 255) / 256);
+    hipLaunchKernelGGL(gather_dot_kernel, dim3(blocks ? blocks : 1), dim3(256), (size_t)args.dim * 4, stream, args,
+                       rows, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_encode_f16(const float* src, size_t n, unsigned short* dst, hipStream_t stream) {
+    hipLaunchKernelGGL(encode_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, n, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_widen_f16(const unsigned short* src, size_t n, float* dst, hipStream_t stream) {
+    hipLaunchKernelGGL(widen_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, n, dst);
+    return hipGetLastError();
+}
+
+}  // namespace fsgpu

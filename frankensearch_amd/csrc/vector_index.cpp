@@ -1,0 +1,527 @@
+// vector_index.cpp — host side of the device-resident VectorIndex and Model2VecEmbedder.
+//
+// Follows the reference's orchestration and error behaviour:
+//   search_top_k_internal  crates/frankensearch-index/src/search.rs:426-494
+//   ensure_query_dimension src/search.rs:1602-1610
+//   parse_header / record table / slab offsets  src/lib.rs:4049-4144, 3510-3537, 1780-1816
+//   soft_delete (tombstone flag)  src/lib.rs:171-173
+// The data path itself runs in the HIP kernels of scan_kernels.hip; there is no CPU fallback.
+#include "vector_index.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/fsgpu.h"
+
+namespace fsgpu {
+
+namespace {
+
+SearchError ok() { return SearchError{}; }
+
+SearchError hip_fail(hipError_t e, const char* what) {
+    SearchError err;
+    err.code = FSGPU_ERR_DEVICE;
+    err.detail = std::string(what) + ": " + hipGetErrorString(e);
+    return err;
+}
+
+#define FSGPU_HIP(expr)                                   \
+    do {                                                  \
+        hipError_t _e = (expr);                           \
+        if (_e != hipSuccess) return hip_fail(_e, #expr); \
+    } while (0)
+
+#define FSGPU_TRY(expr)            \
+    do {                           \
+        SearchError _s = (expr);   \
+        if (!_s.ok()) return _s;   \
+    } while (0)
+
+SearchError make_error(int32_t code, std::string detail) {
+    SearchError e;
+    e.code = code;
+    e.detail = std::move(detail);
+    return e;
+}
+
+uint32_t crc32_ieee(const uint8_t* p, size_t n) {
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int b = 0; b < 8; ++b) c = (c & 1u) ? (0xedb88320u ^ (c >> 1)) : (c >> 1);
+            table[i] = c;
+        }
+        init = true;
+    }
+    uint32_t c = 0xffffffffu;
+    for (size_t i = 0; i < n; ++i) c = table[(c ^ p[i]) & 0xffu] ^ (c >> 8);
+    return ~c;
+}
+
+uint64_t fnv1a(const char* p, size_t n) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (size_t i = 0; i < n; ++i) {
+        h ^= (uint8_t)p[i];
+        h *= 0x100000001b3ull;
+    }
+    return h;
+}
+
+template <typename T>
+T read_le(const uint8_t* p) {
+    T v = 0;
+    for (size_t i = 0; i < sizeof(T); ++i) v |= (T)p[i] << (8 * i);
+    return v;
+}
+
+}  // namespace
+
+SearchError DeviceBuffer::reserve(size_t want) {
+    if (want <= bytes && ptr) return ok();
+    release();
+    size_t alloc = want < 256 ? 256 : want;
+    FSGPU_HIP(hipMalloc(&ptr, alloc));
+    bytes = alloc;
+    return ok();
+}
+
+void DeviceBuffer::release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// VectorIndex
+// ------------------------------------------------------------------------------------------------
+
+VectorIndex::~VectorIndex() {
+    if (device_ >= 0) (void)hipSetDevice(device_);
+    for (auto& ev : events_) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    if (stream_) (void)hipStreamDestroy(stream_);
+    for (DeviceBuffer* b : {&slab_own_, &live_own_, &ws_partial_, &ws_queries_, &ws_allow_, &ws_rows_, &ws_scores_,
+                            &ws_counts_, &ws_keys_a_, &ws_keys_b_, &ws_sort_tmp_, &ws_gather_rows_, &ws_gather_out_})
+        b->release();
+}
+
+SearchError VectorIndex::common_init(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return make_error(FSGPU_ERR_NO_DEVICE, "no HIP device visible (libfsgpu has no CPU fallback)");
+    if (device < 0 || device >= count) return make_error(FSGPU_ERR_INVALID_CONFIG, "device ordinal out of range");
+    FSGPU_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    FSGPU_HIP(hipGetDeviceProperties(&prop, device));
+    num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    device_ = device;
+    FSGPU_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    return ok();
+}
+
+SearchError VectorIndex::init_host(int device, uint32_t dim, uint64_t nrows, const void* slab, const uint64_t* live,
+                                   uint64_t row_base) {
+    if (dim == 0) return make_error(FSGPU_ERR_INVALID_CONFIG, "dimension must be greater than zero");
+    if (nrows + row_base >= 0xffffffffull)
+        return make_error(FSGPU_ERR_INVALID_CONFIG, "row ids must fit in u32 (VectorHit.index)");
+    if (nrows > 0 && !slab) return make_error(FSGPU_ERR_NULL_ARGUMENT, "slab is null");
+    FSGPU_TRY(common_init(device));
+    dim_ = dim;
+    nrows_ = nrows;
+    row_base_ = row_base;
+    const size_t bytes = (size_t)nrows * dim * 2;
+    FSGPU_TRY(slab_own_.reserve(bytes));
+    if (bytes) FSGPU_HIP(hipMemcpy(slab_own_.ptr, slab, bytes, hipMemcpyHostToDevice));
+    slab_dev_ = slab_own_.ptr;
+    owns_slab_ = true;
+    return set_live_bitmap(live);
+}
+
+SearchError VectorIndex::init_device(int device, uint32_t dim, uint64_t nrows, const void* slab_dev,
+                                     const uint64_t* live_dev, uint64_t row_base) {
+    if (dim == 0) return make_error(FSGPU_ERR_INVALID_CONFIG, "dimension must be greater than zero");
+    if (nrows + row_base >= 0xffffffffull)
+        return make_error(FSGPU_ERR_INVALID_CONFIG, "row ids must fit in u32 (VectorHit.index)");
+    if (nrows > 0 && !slab_dev) return make_error(FSGPU_ERR_NULL_ARGUMENT, "slab is null");
+    FSGPU_TRY(common_init(device));
+    dim_ = dim;
+    nrows_ = nrows;
+    row_base_ = row_base;
+    slab_dev_ = slab_dev;
+    live_dev_ = live_dev;
+    owns_slab_ = false;
+    return ok();
+}
+
+SearchError VectorIndex::set_live_bitmap(const uint64_t* live) {
+    if (!live) {
+        live_dev_ = nullptr;
+        live_host_.clear();
+        return ok();
+    }
+    FSGPU_HIP(hipSetDevice(device_));
+    const size_t words = (size_t)((nrows_ + 63) / 64);
+    live_host_.assign(live, live + words);
+    FSGPU_TRY(live_own_.reserve(words * 8));
+    if (words) FSGPU_HIP(hipMemcpy(live_own_.ptr, live_host_.data(), words * 8, hipMemcpyHostToDevice));
+    live_dev_ = static_cast<const uint64_t*>(live_own_.ptr);
+    return ok();
+}
+
+// VectorIndex::open for FSVI v1 (lib.rs:1747-1816, parse_header :4049-4144).
+SearchError VectorIndex::open_fsvi(const char* path, int device) {
+    if (!path) return make_error(FSGPU_ERR_NULL_ARGUMENT, "path is null");
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return make_error(FSGPU_ERR_IO, std::string("cannot open ") + path);
+    std::fseek(f, 0, SEEK_END);
+    const long sz = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> data((size_t)(sz > 0 ? sz : 0));
+    const size_t rd = data.empty() ? 0 : std::fread(data.data(), 1, data.size(), f);
+    std::fclose(f);
+    if (rd != data.size()) return make_error(FSGPU_ERR_IO, std::string("short read on ") + path);
+
+    auto corrupt = [&](const std::string& detail) {
+        return make_error(FSGPU_ERR_INDEX_CORRUPTED, std::string(path) + ": " + detail);
+    };
+    size_t c = 0;
+    auto need = [&](size_t n) { return c + n <= data.size(); };
+    if (!need(4) || std::memcmp(data.data(), "FSVI", 4) != 0) return corrupt("bad magic bytes");
+    c = 4;
+    if (!need(2)) return corrupt("truncated header (version)");
+    const uint16_t version = read_le<uint16_t>(&data[c]);
+    c += 2;
+    if (version != 1)
+        return make_error(FSGPU_ERR_INDEX_VERSION_MISMATCH,
+                          "FSVI version expected 1, found " + std::to_string(version));
+    for (const char* field : {"embedder_id", "embedder_revision"}) {
+        if (!need(2)) return corrupt(std::string("truncated header (") + field + "_len)");
+        const size_t len = read_le<uint16_t>(&data[c]);
+        c += 2;
+        if (!need(len)) return corrupt(std::string("truncated header (") + field + ")");
+        c += len;
+    }
+    if (!need(4)) return corrupt("truncated header (dimension)");
+    const uint32_t dim = read_le<uint32_t>(&data[c]);
+    c += 4;
+    if (dim == 0) return corrupt("dimension must be greater than zero");
+    if (!need(1)) return corrupt("truncated header (quantization)");
+    const uint8_t quant = data[c++];
+    if (quant > 1) return corrupt("unknown quantization byte");
+    if (!need(3)) return corrupt("truncated header (reserved)");
+    c += 3;
+    if (!need(16)) return corrupt("truncated header (record_count / vectors_offset)");
+    const uint64_t record_count = read_le<uint64_t>(&data[c]);
+    c += 8;
+    const uint64_t vectors_offset = read_le<uint64_t>(&data[c]);
+    c += 8;
+    if (!need(4)) return corrupt("truncated header (crc)");
+    const uint32_t want_crc = read_le<uint32_t>(&data[c]);
+    if (crc32_ieee(data.data(), c) != want_crc) return corrupt("header CRC mismatch");
+    c += 4;
+    if (quant != 1)
+        return make_error(FSGPU_ERR_INVALID_CONFIG, "only Quantization::F16 slabs are accelerated (found F32)");
+    const size_t records_offset = c;
+    const uint64_t strings_offset = records_offset + record_count * 16;
+    if (strings_offset > vectors_offset || vectors_offset % 64 != 0 ||
+        vectors_offset + record_count * dim * 2 > data.size())
+        return corrupt("record table / vector slab out of bounds");
+
+    std::vector<uint64_t> live((size_t)((record_count + 63) / 64), 0);
+    doc_hashes_.resize((size_t)record_count);
+    doc_offsets_.assign((size_t)record_count + 1, 0);
+    doc_blob_.clear();
+    for (uint64_t r = 0; r < record_count; ++r) {
+        const uint8_t* rec = &data[records_offset + r * 16];
+        const uint64_t off = read_le<uint32_t>(rec + 8), len = read_le<uint16_t>(rec + 12);
+        const uint16_t flags = read_le<uint16_t>(rec + 14);
+        if (strings_offset + off + len > vectors_offset) return corrupt("doc_id string out of bounds");
+        doc_hashes_[(size_t)r] = read_le<uint64_t>(rec);
+        doc_offsets_[(size_t)r] = doc_blob_.size();
+        doc_blob_.append(reinterpret_cast<const char*>(&data[strings_offset + off]), (size_t)len);
+        if ((flags & 0x0001u) == 0) live[(size_t)(r >> 6)] |= 1ull << (r & 63);
+    }
+    doc_offsets_[(size_t)record_count] = doc_blob_.size();
+    return init_host(device, dim, record_count, data.data() + vectors_offset, live.data(), 0);
+}
+
+SearchError VectorIndex::doc_id_at(uint32_t row, const char** ptr, uint32_t* len) const {
+    if (doc_offsets_.empty()) return make_error(FSGPU_ERR_INVALID_CONFIG, "index has no doc-id table");
+    if (row >= nrows_) return make_error(FSGPU_ERR_INVALID_CONFIG, "row out of range");
+    *ptr = doc_blob_.data() + doc_offsets_[row];
+    *len = (uint32_t)(doc_offsets_[row + 1] - doc_offsets_[row]);
+    return ok();
+}
+
+SearchError VectorIndex::soft_delete(const char* doc_id, uint32_t len, int32_t* deleted) {
+    *deleted = 0;
+    if (doc_offsets_.empty()) return make_error(FSGPU_ERR_INVALID_CONFIG, "index has no doc-id table");
+    const uint64_t h = fnv1a(doc_id, len);
+    // rows are sorted by (hash, doc_id) (lib.rs:3758-3762): binary-search the hash run
+    auto lo = std::lower_bound(doc_hashes_.begin(), doc_hashes_.end(), h);
+    bool changed = false;
+    for (auto it = lo; it != doc_hashes_.end() && *it == h; ++it) {
+        const size_t r = (size_t)(it - doc_hashes_.begin());
+        const size_t dl = (size_t)(doc_offsets_[r + 1] - doc_offsets_[r]);
+        if (dl == len && std::memcmp(doc_blob_.data() + doc_offsets_[r], doc_id, len) == 0) {
+            if (live_host_.empty()) live_host_.assign((size_t)((nrows_ + 63) / 64), ~0ull);
+            if ((live_host_[r >> 6] >> (r & 63)) & 1ull) {
+                live_host_[r >> 6] &= ~(1ull << (r & 63));
+                changed = true;
+            }
+        }
+    }
+    if (changed) {
+        std::vector<uint64_t> copy = live_host_;
+        FSGPU_TRY(set_live_bitmap(copy.data()));
+        *deleted = 1;
+    }
+    return ok();
+}
+
+SearchError VectorIndex::ensure_query_dimension(uint32_t query_len) const {
+    if (query_len != dim_)
+        return make_error(FSGPU_ERR_DIMENSION_MISMATCH,
+                          "expected " + std::to_string(dim_) + ", found " + std::to_string(query_len));
+    return ok();
+}
+
+ScanArgs VectorIndex::base_args(const float* queries_dev, const uint64_t* allow_dev) const {
+    ScanArgs a;
+    a.slab = slab_dev_;
+    a.live = reinterpret_cast<const u64*>(live_dev_);
+    a.allow = reinterpret_cast<const u64*>(allow_dev);
+    a.queries = queries_dev;
+    a.partial = nullptr;
+    a.nrows = (uint32_t)nrows_;
+    a.dim = dim_;
+    a.k = 0;
+    a.row_base = (uint32_t)row_base_;
+    a.hreduce = hreduce;
+    return a;
+}
+
+SearchError VectorIndex::fused_search(const float* queries_dev, uint32_t nq, uint32_t k_out, uint32_t k_eff,
+                                      const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
+                                      uint32_t* out_counts_dev, hipStream_t stream) {
+    const int kcap = k_eff <= 64 ? 64 : 256;
+    const uint32_t ntiles = (uint32_t)((nrows_ + 15) / 16);
+    uint32_t done = 0;
+    while (done < nq) {
+        const uint32_t left = nq - done;
+        int pass = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
+        if (scan_lds_bytes((int)dim_, pass, kcap) > 150 * 1024) pass = 1;
+        const int per_cu = scan_occupancy_blocks_per_cu((int)dim_, pass, kcap);
+        int grid = num_cus_ * per_cu;
+        const int max_useful = (int)((ntiles + 3) / 4);
+        if (grid > max_useful) grid = max_useful;
+        if (grid < 1) grid = 1;
+        FSGPU_TRY(ws_partial_.reserve((size_t)pass * grid * kcap * 8));
+        ScanArgs a = base_args(queries_dev + (size_t)done * dim_, allow_dev);
+        a.partial = static_cast<u64*>(ws_partial_.ptr);
+        a.k = k_eff;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (profiling) {
+            FSGPU_HIP(hipEventCreate(&e0));
+            FSGPU_HIP(hipEventCreate(&e1));
+            FSGPU_HIP(hipEventRecord(e0, stream));
+        }
+        FSGPU_HIP(launch_scan_topk(a, pass, kcap, grid, stream, variant == 1));
+        if (profiling) {
+            FSGPU_HIP(hipEventRecord(e1, stream));
+            events_.emplace_back(e0, e1);
+        }
+        MergeArgs m;
+        m.lists = a.partial;
+        m.nlists = (uint32_t)grid;
+        m.list_len = (uint32_t)kcap;
+        m.k = k_eff;
+        m.out_stride = k_out;
+        m.out_rows = out_rows_dev + (size_t)done * k_out;
+        m.out_scores = out_scores_dev + (size_t)done * k_out;
+        m.out_counts = out_counts_dev + done;
+        FSGPU_HIP(launch_merge_topk(m, pass, stream));
+        done += (uint32_t)pass;
+    }
+    return ok();
+}
+
+// Large-k / collect-all (search.rs:449-473) and dims that are not a multiple of 8: score every row,
+// radix-sort the integer sortkeys, re-score the winners for their exact f32 bits (keeps NaN scores).
+SearchError VectorIndex::general_search(const float* queries_dev, uint32_t nq, uint32_t k_out, uint32_t k_eff,
+                                        const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
+                                        uint32_t* out_counts_dev, hipStream_t stream) {
+    const size_t n = (size_t)nrows_;
+    FSGPU_TRY(ws_keys_a_.reserve(n * 8));
+    FSGPU_TRY(ws_keys_b_.reserve(n * 8));
+    size_t tmp_bytes = 0;
+    FSGPU_HIP(sort_keys_desc_temp_bytes(n, &tmp_bytes));
+    FSGPU_TRY(ws_sort_tmp_.reserve(tmp_bytes));
+    const uint32_t ntiles = (uint32_t)((nrows_ + 15) / 16);
+    int grid = num_cus_ * 4;
+    if (grid > (int)((ntiles + 3) / 4)) grid = (int)((ntiles + 3) / 4);
+    if (grid < 1) grid = 1;
+    FSGPU_HIP(hipMemsetAsync(out_rows_dev, 0xff, (size_t)nq * k_out * 4, stream));
+    FSGPU_HIP(hipMemsetAsync(out_scores_dev, 0xff, (size_t)nq * k_out * 4, stream));
+    for (uint32_t q = 0; q < nq; ++q) {
+        ScanArgs a = base_args(queries_dev, allow_dev);
+        u64* keys_a = static_cast<u64*>(ws_keys_a_.ptr);
+        u64* keys_b = static_cast<u64*>(ws_keys_b_.ptr);
+        FSGPU_HIP(launch_score_rows(a, keys_a, (int)q, grid, stream));
+        FSGPU_HIP(launch_packed_to_sortkey(keys_a, n, stream));
+        FSGPU_HIP(sort_keys_desc(ws_sort_tmp_.ptr, ws_sort_tmp_.bytes, keys_a, keys_b, n, stream));
+        uint32_t* rows_q = out_rows_dev + (size_t)q * k_out;
+        FSGPU_HIP(launch_sorted_keys_to_rows(keys_b, k_eff, rows_q, out_counts_dev + q, stream));
+        ScanArgs g = base_args(queries_dev + (size_t)q * dim_, nullptr);
+        // rows beyond the count are 0xffffffff -> outside the shard -> left as padding
+        FSGPU_HIP(launch_gather_dot(g, rows_q, k_eff, out_scores_dev + (size_t)q * k_out, stream));
+    }
+    return ok();
+}
+
+SearchError VectorIndex::search_top_k_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
+                                             const uint64_t* allow_dev, uint32_t* out_rows_dev,
+                                             float* out_scores_dev, uint32_t* out_counts_dev, hipStream_t stream) {
+    FSGPU_TRY(ensure_query_dimension(query_len));
+    if (nq == 0) return ok();
+    FSGPU_HIP(hipSetDevice(device_));
+    if (k == 0 || nrows_ == 0) {  // search.rs:437-439
+        FSGPU_HIP(hipMemsetAsync(out_counts_dev, 0, (size_t)nq * 4, stream));
+        return ok();
+    }
+    const uint32_t k_eff = (uint64_t)k < nrows_ ? k : (uint32_t)nrows_;
+    if (dim_ % 8 == 0 && k_eff <= 256)
+        return fused_search(queries_dev, nq, k, k_eff, allow_dev, out_rows_dev, out_scores_dev, out_counts_dev, stream);
+    return general_search(queries_dev, nq, k, k_eff, allow_dev, out_rows_dev, out_scores_dev, out_counts_dev, stream);
+}
+
+SearchError VectorIndex::search_top_k(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
+                                      const uint64_t* allow, uint32_t* out_rows, float* out_scores,
+                                      uint32_t* out_counts) {
+    FSGPU_TRY(ensure_query_dimension(query_len));
+    if (nq == 0) return ok();
+    if (k == 0 || nrows_ == 0) {
+        for (uint32_t q = 0; q < nq; ++q) out_counts[q] = 0;
+        return ok();
+    }
+    FSGPU_HIP(hipSetDevice(device_));
+    const size_t qbytes = (size_t)nq * dim_ * 4;
+    FSGPU_TRY(ws_queries_.reserve(qbytes));
+    FSGPU_TRY(ws_rows_.reserve((size_t)nq * k * 4));
+    FSGPU_TRY(ws_scores_.reserve((size_t)nq * k * 4));
+    FSGPU_TRY(ws_counts_.reserve((size_t)nq * 4));
+    FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, queries, qbytes, hipMemcpyHostToDevice, stream_));
+    const uint64_t* allow_dev = nullptr;
+    if (allow) {
+        const size_t words = (size_t)((nrows_ + 63) / 64);
+        FSGPU_TRY(ws_allow_.reserve(words * 8));
+        FSGPU_HIP(hipMemcpyAsync(ws_allow_.ptr, allow, words * 8, hipMemcpyHostToDevice, stream_));
+        allow_dev = static_cast<const uint64_t*>(ws_allow_.ptr);
+    }
+    FSGPU_TRY(search_top_k_device(static_cast<const float*>(ws_queries_.ptr), nq, query_len, k, allow_dev,
+                                  static_cast<uint32_t*>(ws_rows_.ptr), static_cast<float*>(ws_scores_.ptr),
+                                  static_cast<uint32_t*>(ws_counts_.ptr), stream_));
+    FSGPU_HIP(hipMemcpyAsync(out_rows, ws_rows_.ptr, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream_));
+    FSGPU_HIP(hipMemcpyAsync(out_scores, ws_scores_.ptr, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream_));
+    FSGPU_HIP(hipMemcpyAsync(out_counts, ws_counts_.ptr, (size_t)nq * 4, hipMemcpyDeviceToHost, stream_));
+    FSGPU_HIP(hipStreamSynchronize(stream_));
+    return ok();
+}
+
+SearchError VectorIndex::gather_dot(const float* query, uint32_t query_len, const uint32_t* rows, uint32_t n,
+                                    float* out) {
+    FSGPU_TRY(ensure_query_dimension(query_len));
+    if (n == 0) return ok();
+    for (uint32_t i = 0; i < n; ++i)
+        if (rows[i] < row_base_ || rows[i] - row_base_ >= nrows_)
+            return make_error(FSGPU_ERR_INVALID_CONFIG, "row index out of range for dot_query_at");
+    FSGPU_HIP(hipSetDevice(device_));
+    FSGPU_TRY(ws_queries_.reserve((size_t)dim_ * 4));
+    FSGPU_TRY(ws_gather_rows_.reserve((size_t)n * 4));
+    FSGPU_TRY(ws_gather_out_.reserve((size_t)n * 4));
+    FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, query, (size_t)dim_ * 4, hipMemcpyHostToDevice, stream_));
+    FSGPU_HIP(hipMemcpyAsync(ws_gather_rows_.ptr, rows, (size_t)n * 4, hipMemcpyHostToDevice, stream_));
+    ScanArgs a = base_args(static_cast<const float*>(ws_queries_.ptr), nullptr);
+    FSGPU_HIP(launch_gather_dot(a, static_cast<const uint32_t*>(ws_gather_rows_.ptr), n,
+                                static_cast<float*>(ws_gather_out_.ptr), stream_));
+    FSGPU_HIP(hipMemcpyAsync(out, ws_gather_out_.ptr, (size_t)n * 4, hipMemcpyDeviceToHost, stream_));
+    FSGPU_HIP(hipStreamSynchronize(stream_));
+    return ok();
+}
+
+SearchError VectorIndex::scan_time(double* total_ms, uint64_t* launches, bool reset) {
+    FSGPU_HIP(hipSetDevice(device_));
+    double sum = 0.0;
+    for (auto& ev : events_) {
+        FSGPU_HIP(hipEventSynchronize(ev.second));
+        float ms = 0.f;
+        FSGPU_HIP(hipEventElapsedTime(&ms, ev.first, ev.second));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = events_.size();
+    if (reset) {
+        for (auto& ev : events_) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+        events_.clear();
+    }
+    return ok();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Model2VecEmbedder
+// ------------------------------------------------------------------------------------------------
+
+Model2VecEmbedder::~Model2VecEmbedder() {
+    if (device_ >= 0) (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+    for (DeviceBuffer* b : {&table_, &ids_, &offsets_, &out_}) b->release();
+}
+
+SearchError Model2VecEmbedder::init(int device, const float* table, uint32_t vocab, uint32_t dim) {
+    if (!table) return make_error(FSGPU_ERR_NULL_ARGUMENT, "table is null");
+    if (dim == 0 || vocab == 0) return make_error(FSGPU_ERR_INVALID_CONFIG, "vocab and dim must be non-zero");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return make_error(FSGPU_ERR_NO_DEVICE, "no HIP device visible (libfsgpu has no CPU fallback)");
+    if (device < 0 || device >= count) return make_error(FSGPU_ERR_INVALID_CONFIG, "device ordinal out of range");
+    FSGPU_HIP(hipSetDevice(device));
+    device_ = device;
+    vocab_ = vocab;
+    dim_ = dim;
+    FSGPU_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    FSGPU_TRY(table_.reserve((size_t)vocab * dim * 4));
+    FSGPU_HIP(hipMemcpy(table_.ptr, table, (size_t)vocab * dim * 4, hipMemcpyHostToDevice));
+    return ok();
+}
+
+SearchError Model2VecEmbedder::embed_batch(const uint32_t* ids, const uint32_t* offsets, uint32_t n, float* out) {
+    if (n == 0) return ok();
+    if (!offsets || !out) return make_error(FSGPU_ERR_NULL_ARGUMENT, "offsets/out is null");
+    for (uint32_t i = 0; i < n; ++i)
+        if (offsets[i + 1] < offsets[i]) return make_error(FSGPU_ERR_INVALID_CONFIG, "offsets must be non-decreasing");
+    const uint32_t total = offsets[n];
+    FSGPU_HIP(hipSetDevice(device_));
+    FSGPU_TRY(ids_.reserve((size_t)(total ? total : 1) * 4));
+    FSGPU_TRY(offsets_.reserve((size_t)(n + 1) * 4));
+    FSGPU_TRY(out_.reserve((size_t)n * dim_ * 4));
+    if (total) FSGPU_HIP(hipMemcpyAsync(ids_.ptr, ids, (size_t)total * 4, hipMemcpyHostToDevice, stream_));
+    FSGPU_HIP(hipMemcpyAsync(offsets_.ptr, offsets, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, stream_));
+    FSGPU_HIP(launch_m2v_embed(static_cast<const float*>(table_.ptr), vocab_, dim_,
+                               static_cast<const uint32_t*>(ids_.ptr), static_cast<const uint32_t*>(offsets_.ptr), n,
+                               static_cast<float*>(out_.ptr), stream_));
+    FSGPU_HIP(hipMemcpyAsync(out, out_.ptr, (size_t)n * dim_ * 4, hipMemcpyDeviceToHost, stream_));
+    FSGPU_HIP(hipStreamSynchronize(stream_));
+    return ok();
+}
+
+}  // namespace fsgpu

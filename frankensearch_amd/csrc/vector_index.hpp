@@ -1,0 +1,121 @@
+// vector_index.hpp — host-side mirror of the reference's VectorIndex / Model2VecEmbedder for the
+// device-resident path (names and error behaviour follow crates/frankensearch-index/src/lib.rs:819,
+// src/search.rs:192-494 and crates/frankensearch-embed/src/model2vec_embedder.rs:55-58).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace fsgpu {
+
+// SearchError (crates/frankensearch-core/src/error.rs:57-176) carried as code + detail.
+struct SearchError {
+    int32_t code = 0;
+    std::string detail;
+    bool ok() const { return code == 0; }
+};
+
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    SearchError reserve(size_t want);
+    void release();
+};
+
+class VectorIndex {
+  public:
+    VectorIndex() = default;
+    ~VectorIndex();
+    VectorIndex(const VectorIndex&) = delete;
+    VectorIndex& operator=(const VectorIndex&) = delete;
+
+    // VectorIndex::open for a raw slab (host copy) / an adopted device slab / an FSVI v1 file.
+    SearchError init_host(int device, uint32_t dim, uint64_t nrows, const void* slab, const uint64_t* live,
+                          uint64_t row_base);
+    SearchError init_device(int device, uint32_t dim, uint64_t nrows, const void* slab_dev, const uint64_t* live_dev,
+                            uint64_t row_base);
+    SearchError open_fsvi(const char* path, int device);
+
+    uint64_t record_count() const { return nrows_; }
+    uint32_t dimension() const { return dim_; }
+
+    // search_top_k over nq queries (host pointers; synchronous).
+    SearchError search_top_k(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
+                             const uint64_t* allow, uint32_t* out_rows, float* out_scores, uint32_t* out_counts);
+    // same with device pointers, enqueued on `stream`.
+    SearchError search_top_k_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
+                                    const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
+                                    uint32_t* out_counts_dev, hipStream_t stream);
+    SearchError gather_dot(const float* query, uint32_t query_len, const uint32_t* rows, uint32_t n, float* out);
+
+    SearchError doc_id_at(uint32_t row, const char** ptr, uint32_t* len) const;
+    SearchError soft_delete(const char* doc_id, uint32_t len, int32_t* deleted);
+    SearchError set_live_bitmap(const uint64_t* live);
+    bool has_doc_ids() const { return !doc_offsets_.empty(); }
+
+    std::mutex& mutex() { return mu_; }
+    int device() const { return device_; }
+    int32_t hreduce = 0;
+    int32_t variant = 0;
+    bool profiling = false;
+    SearchError scan_time(double* total_ms, uint64_t* launches, bool reset);
+
+  private:
+    SearchError ensure_query_dimension(uint32_t query_len) const;
+    SearchError common_init(int device);
+    SearchError fused_search(const float* queries_dev, uint32_t nq, uint32_t k_out, uint32_t k_eff,
+                             const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
+                             uint32_t* out_counts_dev, hipStream_t stream);
+    SearchError general_search(const float* queries_dev, uint32_t nq, uint32_t k_out, uint32_t k_eff,
+                               const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
+                               uint32_t* out_counts_dev, hipStream_t stream);
+    ScanArgs base_args(const float* queries_dev, const uint64_t* allow_dev) const;
+
+    std::mutex mu_;
+    int device_ = -1;
+    int num_cus_ = 256;
+    uint32_t dim_ = 0;
+    uint64_t nrows_ = 0;
+    uint64_t row_base_ = 0;
+    const void* slab_dev_ = nullptr;
+    const uint64_t* live_dev_ = nullptr;
+    bool owns_slab_ = false;
+    DeviceBuffer slab_own_, live_own_;
+    hipStream_t stream_ = nullptr;
+    // workspaces (grown on demand, reused)
+    DeviceBuffer ws_partial_, ws_queries_, ws_allow_, ws_rows_, ws_scores_, ws_counts_, ws_keys_a_, ws_keys_b_,
+        ws_sort_tmp_, ws_gather_rows_, ws_gather_out_;
+    // profiling events
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events_;
+    // FSVI host-side tables
+    std::vector<uint64_t> live_host_;
+    std::vector<uint64_t> doc_hashes_;
+    std::vector<uint64_t> doc_offsets_;  // nrows+1 offsets into doc_blob_
+    std::string doc_blob_;
+};
+
+class Model2VecEmbedder {
+  public:
+    ~Model2VecEmbedder();
+    SearchError init(int device, const float* table, uint32_t vocab, uint32_t dim);
+    SearchError embed_batch(const uint32_t* ids, const uint32_t* offsets, uint32_t n, float* out);
+    uint32_t dimension() const { return dim_; }
+
+  private:
+    std::mutex mu_;
+    int device_ = -1;
+    uint32_t vocab_ = 0, dim_ = 0;
+    DeviceBuffer table_, ids_, offsets_, out_;
+    hipStream_t stream_ = nullptr;
+};
+
+void set_last_error(const SearchError& e);
+
+}  // namespace fsgpu

@@ -1,0 +1,209 @@
+"""VectorIndex — host-side mirror of the reference's `frankensearch_index::VectorIndex` method set
+(crates/frankensearch-index/src/lib.rs:819, src/search.rs:192-494) over the C ABI of libfsgpu.so.
+
+Same names, argument meaning and error behaviour as the reference so the parity tests read like the
+reference's own tests; all compute happens in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .errors import check
+
+
+@dataclass(frozen=True)
+class VectorHit:
+    """crates/frankensearch-core/src/types.rs:88-95"""
+    index: int
+    score: float
+    doc_id: Optional[str] = None
+
+
+@dataclass(frozen=True)
+class ClassifiedHits:
+    """search.rs:66-89: zero_signal is set iff hits is empty."""
+    hits: List[VectorHit]
+    zero_signal: Optional[str]
+
+
+_ZERO_SIGNAL = {1: "CallerRequestedZeroK", 2: "ZeroNormQuery", 3: "NoMatch"}
+
+
+def _ptr(a) -> Optional[int]:
+    return None if a is None else a.ctypes.data
+
+
+def pack_bitmap(mask: np.ndarray) -> np.ndarray:
+    """bool[N] -> uint64 words (bit r of word r//64 = mask[r])."""
+    mask = np.asarray(mask, dtype=bool)
+    words = (mask.size + 63) // 64
+    padded = np.zeros(words * 64, dtype=np.uint8)
+    padded[: mask.size] = mask
+    return np.packbits(padded, bitorder="little").view(np.uint64).copy()
+
+
+class VectorIndex:
+    def __init__(self, handle: int, keepalive=None):
+        self._h = C.c_void_p(handle)
+        self._keepalive = keepalive
+
+    # ---- constructors -------------------------------------------------------------------------
+    @classmethod
+    def from_slab(cls, slab_f16: np.ndarray, live: Optional[np.ndarray] = None, device: int = 0,
+                  row_base: int = 0) -> "VectorIndex":
+        """slab_f16: [N, dim] uint16/float16 (little-endian f16 rows, the FSVI slab)."""
+        slab = np.ascontiguousarray(slab_f16)
+        if slab.dtype == np.float16:
+            slab = slab.view(np.uint16)
+        if slab.dtype != np.uint16 or slab.ndim != 2:
+            raise TypeError("slab must be a 2-D uint16/float16 array")
+        bm = pack_bitmap(live) if live is not None else None
+        h = C.c_void_p()
+        check(_lib.lib().fsgpu_index_create(device, slab.shape[1], slab.shape[0], _ptr(slab), _ptr(bm), row_base,
+                                            C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_device_slab(cls, data_ptr: int, nrows: int, dim: int, live_ptr: Optional[int] = None, device: int = 0,
+                         row_base: int = 0, keepalive=None) -> "VectorIndex":
+        """Adopts a device-resident slab (e.g. a torch tensor's data_ptr()); `keepalive` pins its owner."""
+        h = C.c_void_p()
+        check(_lib.lib().fsgpu_index_create_device(device, dim, nrows, data_ptr, live_ptr, row_base, C.byref(h)))
+        return cls(h.value, keepalive)
+
+    @classmethod
+    def open(cls, path: str, device: int = 0) -> "VectorIndex":
+        """VectorIndex::open for an FSVI v1 / F16 file."""
+        h = C.c_void_p()
+        check(_lib.lib().fsgpu_index_open_fsvi(str(path).encode(), device, C.byref(h)))
+        return cls(h.value)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.lib().fsgpu_index_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- metadata -----------------------------------------------------------------------------
+    def record_count(self) -> int:
+        return _lib.lib().fsgpu_index_record_count(self._h)
+
+    def dimension(self) -> int:
+        return _lib.lib().fsgpu_index_dimension(self._h)
+
+    def set_hreduce(self, mode: int) -> None:
+        check(_lib.lib().fsgpu_index_set_hreduce(self._h, mode))
+
+    def doc_id_at(self, row: int) -> str:
+        p, n = C.c_void_p(), C.c_uint32()
+        check(_lib.lib().fsgpu_index_doc_id(self._h, row, C.byref(p), C.byref(n)))
+        return C.string_at(p.value, n.value).decode()
+
+    def soft_delete(self, doc_id: str) -> bool:
+        b = doc_id.encode()
+        d = C.c_int32()
+        check(_lib.lib().fsgpu_index_soft_delete(self._h, b, len(b), C.byref(d)))
+        return bool(d.value)
+
+    def set_live(self, live: Optional[np.ndarray]) -> None:
+        bm = pack_bitmap(live) if live is not None else None
+        check(_lib.lib().fsgpu_index_set_live_bitmap(self._h, _ptr(bm)))
+
+    # ---- search -------------------------------------------------------------------------------
+    def search_batch(self, queries: np.ndarray, limit: int, allow: Optional[np.ndarray] = None
+                     ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """nq queries at once -> (rows [nq,limit] u32, scores [nq,limit] f32, counts [nq] u32)."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        nq, qlen = q.shape
+        rows = np.full((nq, max(limit, 1)), 0xFFFFFFFF, dtype=np.uint32)
+        scores = np.full((nq, max(limit, 1)), np.nan, dtype=np.float32)
+        counts = np.zeros(nq, dtype=np.uint32)
+        bm = pack_bitmap(allow) if allow is not None else None
+        check(_lib.lib().fsgpu_search_topk(self._h, _ptr(q), nq, qlen, limit, _ptr(bm), _ptr(rows), _ptr(scores),
+                                           _ptr(counts)))
+        return rows[:, :limit], scores[:, :limit], counts
+
+    def search_top_k(self, query: Sequence[float], limit: int, filter: Optional[np.ndarray] = None
+                     ) -> List[VectorHit]:
+        """VectorIndex::search_top_k(query, limit, filter) (search.rs:192-206).  `filter` is a precomputed
+        allow mask over rows (bool[N]); doc-id dedup applies when the index has a doc-id table."""
+        q = np.ascontiguousarray(query, dtype=np.float32).reshape(-1)
+        if filter is None and self._has_doc_ids():
+            rows = np.empty(max(limit, 1), dtype=np.uint32)
+            scores = np.empty(max(limit, 1), dtype=np.float32)
+            n = C.c_uint32()
+            check(_lib.lib().fsgpu_search_hits(self._h, _ptr(q), q.size, limit, _ptr(rows), _ptr(scores), C.byref(n)))
+            return [VectorHit(int(rows[i]), float(scores[i]), self.doc_id_at(int(rows[i]))) for i in range(n.value)]
+        rows, scores, counts = self.search_batch(q, limit, filter)
+        return [VectorHit(int(rows[0, i]), float(scores[0, i])) for i in range(int(counts[0]))]
+
+    def search_top_k_classified(self, query: Sequence[float], limit: int) -> ClassifiedHits:
+        """search.rs:227-261"""
+        q = np.ascontiguousarray(query, dtype=np.float32).reshape(-1)
+        rows = np.empty(max(limit, 1), dtype=np.uint32)
+        scores = np.empty(max(limit, 1), dtype=np.float32)
+        n, z = C.c_uint32(), C.c_int32()
+        check(_lib.lib().fsgpu_search_topk_classified(self._h, _ptr(q), q.size, limit, _ptr(rows), _ptr(scores),
+                                                      C.byref(n), C.byref(z)))
+        hits = [VectorHit(int(rows[i]), float(scores[i])) for i in range(n.value)]
+        return ClassifiedHits(hits, _ZERO_SIGNAL.get(z.value))
+
+    def dot_query_at(self, index: int, query: Sequence[float]) -> float:
+        """lib.rs:3229-3239"""
+        return float(self.gather_dot(query, [index])[0])
+
+    def gather_dot(self, query: Sequence[float], rows: Sequence[int]) -> np.ndarray:
+        q = np.ascontiguousarray(query, dtype=np.float32).reshape(-1)
+        r = np.ascontiguousarray(rows, dtype=np.uint32)
+        out = np.empty(r.size, dtype=np.float32)
+        check(_lib.lib().fsgpu_gather_dot(self._h, _ptr(q), q.size, _ptr(r), r.size, _ptr(out)))
+        return out
+
+    # device-pointer path (torch tensors): everything stays in HBM, enqueued on `stream`
+    def search_device(self, queries_ptr: int, nq: int, limit: int, out_rows_ptr: int, out_scores_ptr: int,
+                      out_counts_ptr: int, stream: int = 0, allow_ptr: Optional[int] = None) -> None:
+        check(_lib.lib().fsgpu_search_topk_device(self._h, queries_ptr, nq, self.dimension(), limit, allow_ptr,
+                                                  out_rows_ptr, out_scores_ptr, out_counts_ptr, stream))
+
+    # ---- instrumentation ----------------------------------------------------------------------
+    def set_profiling(self, enabled: bool) -> None:
+        check(_lib.lib().fsgpu_index_set_profiling(self._h, int(enabled)))
+
+    def scan_time(self, reset: bool = True) -> Tuple[float, int]:
+        ms, n = C.c_double(), C.c_uint64()
+        check(_lib.lib().fsgpu_index_scan_time(self._h, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
+    def set_variant(self, variant: int) -> None:
+        check(_lib.lib().fsgpu_index_set_variant(self._h, variant))
+
+    def _has_doc_ids(self) -> bool:
+        p, n = C.c_void_p(), C.c_uint32()
+        return self.record_count() > 0 and _lib.lib().fsgpu_index_doc_id(self._h, 0, C.byref(p), C.byref(n)) == 0
+
+
+def encode_f32_to_f16(src: np.ndarray, device: int = 0) -> np.ndarray:
+    """encode_f32_to_f16_extend (simd.rs:2245-2305) on the GPU."""
+    s = np.ascontiguousarray(src, dtype=np.float32)
+    out = np.empty(s.shape, dtype=np.uint16)
+    check(_lib.lib().fsgpu_encode_f32_to_f16(device, _ptr(s), s.size, _ptr(out)))
+    return out
+
+
+def widen_f16_to_f32(src: np.ndarray, device: int = 0) -> np.ndarray:
+    s = np.ascontiguousarray(src, dtype=np.uint16)
+    out = np.empty(s.shape, dtype=np.float32)
+    check(_lib.lib().fsgpu_widen_f16_to_f32(device, _ptr(s), s.size, _ptr(out)))
+    return out

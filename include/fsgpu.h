@@ -1,0 +1,142 @@
+/*
+ * fsgpu.h — C ABI of libfsgpu.so, the MI355X (gfx950) semantic tier for frankensearch.
+ *
+ * The reference has no FFI for this path: its seams are Rust traits and one concrete method
+ * set.  Each entry point below names the reference interface it replaces
+ * (file:line relative to the reference repo) so a ~100-line Rust shim can bind it
+ * (see INTEGRATION.md for that shim).
+ *
+ * Conventions
+ *   - every function returns an fsgpu_status (0 = OK); no exception crosses the boundary;
+ *   - fsgpu_last_error() returns the calling thread's last failure detail (UTF-8);
+ *   - all pointers are caller-owned unless stated; "_dev" pointers are HIP device pointers;
+ *   - handles may be used from many host threads; calls on one handle serialise internally;
+ *   - row ids are GLOBAL physical row ids (row_base + local row), u32 like VectorHit.index
+ *     (crates/frankensearch-core/src/types.rs:88-95);
+ *   - result order is the reference's: score descending with NaN ranked as -inf, f32 total
+ *     order (-0.0 < +0.0), ties by ascending row (crates/frankensearch-index/src/search.rs:1655-1686);
+ *   - scores are computed in the reference's exact accumulation order (simd.rs:398-446), so they
+ *     are bit-identical to the CPU path's scores for a given FSGPU_HREDUCE_* mode.
+ */
+#ifndef FSGPU_H
+#define FSGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t fsgpu_status;
+
+/* Status codes <-> SearchError variants (crates/frankensearch-core/src/error.rs:57-176). */
+#define FSGPU_OK 0
+#define FSGPU_ERR_DIMENSION_MISMATCH 1     /* SearchError::DimensionMismatch{expected,found} */
+#define FSGPU_ERR_INVALID_CONFIG 2         /* SearchError::InvalidConfig{field,value,reason} */
+#define FSGPU_ERR_INDEX_CORRUPTED 3        /* SearchError::IndexCorrupted{path,detail} */
+#define FSGPU_ERR_INDEX_VERSION_MISMATCH 4 /* SearchError::IndexVersionMismatch{expected,found} */
+#define FSGPU_ERR_IO 5                     /* SearchError::Io */
+#define FSGPU_ERR_DEVICE 6                 /* HIP runtime failure (no reference analogue) */
+#define FSGPU_ERR_NO_DEVICE 7              /* no gfx950 device visible */
+#define FSGPU_ERR_NULL_ARGUMENT 8
+#define FSGPU_ERR_EMBEDDING_FAILED 9       /* SearchError::EmbeddingFailed */
+
+/* ZeroSignalReason of search_top_k_classified (search.rs:227-261). */
+#define FSGPU_ZERO_SIGNAL_NONE 0
+#define FSGPU_ZERO_SIGNAL_CALLER_REQUESTED_ZERO_K 1
+#define FSGPU_ZERO_SIGNAL_ZERO_NORM_QUERY 2
+#define FSGPU_ZERO_SIGNAL_NO_MATCH 3
+
+/* Order of the final 8-lane horizontal add (`wide::f32x8::reduce_add`, simd.rs:439,563).
+ * SSE2 is the reference's default build (no +avx2 in .cargo/config.toml). */
+#define FSGPU_HREDUCE_SSE2 0 /* ((v0+v2)+(v1+v3)) + ((v4+v6)+(v5+v7)) */
+#define FSGPU_HREDUCE_AVX 1  /* ((v0+v4)+(v2+v6)) + ((v1+v5)+(v3+v7)) */
+
+typedef struct fsgpu_index fsgpu_index;     /* device-resident VectorIndex (lib.rs:819) */
+typedef struct fsgpu_m2v fsgpu_m2v;         /* Model2VecEmbedder (embed/src/model2vec_embedder.rs:55) */
+
+/* ---- library ---- */
+const char *fsgpu_version(void);
+int32_t fsgpu_device_count(void);
+const char *fsgpu_last_error(void);
+
+/* ---- index lifecycle ---- */
+/* Replaces VectorIndex::open + the mmap of the slab (lib.rs:1747-1816): copies `nrows` x `dim`
+ * little-endian f16 rows from host memory to device `device`.  live_bitmap (bit r = row r is live,
+ * i.e. RECORD_FLAG_TOMBSTONE clear, lib.rs:171-173) may be NULL = all live.  row_base is added to
+ * every reported row id (shard offset). */
+fsgpu_status fsgpu_index_create(int32_t device, uint32_t dim, uint64_t nrows, const void *slab_f16_le,
+                                const uint64_t *live_bitmap, uint64_t row_base, fsgpu_index **out);
+/* Zero-copy variant: adopts (does not free) a device-resident slab / bitmap. */
+fsgpu_status fsgpu_index_create_device(int32_t device, uint32_t dim, uint64_t nrows, const void *slab_f16_dev,
+                                       const uint64_t *live_bitmap_dev, uint64_t row_base, fsgpu_index **out);
+/* VectorIndex::open for an FSVI v1 / F16 file (lib.rs:4049-4144 header+CRC, :3510-3537 record table):
+ * uploads the slab, builds the live bitmap from record flags, keeps the doc-id table on the host. */
+fsgpu_status fsgpu_index_open_fsvi(const char *path, int32_t device, fsgpu_index **out);
+void fsgpu_index_destroy(fsgpu_index *idx);
+
+uint64_t fsgpu_index_record_count(const fsgpu_index *idx); /* VectorIndex::record_count */
+uint32_t fsgpu_index_dimension(const fsgpu_index *idx);    /* VectorIndex::dimension */
+fsgpu_status fsgpu_index_set_hreduce(fsgpu_index *idx, int32_t mode);
+/* doc id of a global row (FSVI-opened indexes only; pointer valid until destroy; not NUL-terminated). */
+fsgpu_status fsgpu_index_doc_id(const fsgpu_index *idx, uint32_t row, const char **ptr, uint32_t *len);
+/* VectorIndex::soft_delete (lib.rs, tombstone flag): clears the live bit(s) of doc_id; *deleted = 1 if any. */
+fsgpu_status fsgpu_index_soft_delete(fsgpu_index *idx, const char *doc_id, uint32_t doc_id_len, int32_t *deleted);
+/* Replace the live bitmap (host words, ceil(nrows/64)); NULL = all live. */
+fsgpu_status fsgpu_index_set_live_bitmap(fsgpu_index *idx, const uint64_t *live_bitmap);
+
+/* ---- search ---- */
+/* Replaces VectorIndex::search_top_k(query, limit, None) (search.rs:192-206 -> :426-494) for nq queries
+ * at once: tombstones via the live bitmap, optional per-call allow bitmap (a precomputed SearchFilter,
+ * filter.rs:19-56), collect-all when k >= nrows.  query_len must equal the index dimension
+ * (else FSGPU_ERR_DIMENSION_MISMATCH, search.rs:1602-1610).  Outputs are [nq,k] row-major, best first;
+ * out_counts[q] <= k entries are valid.  No doc-id dedup (see fsgpu_search_hits). */
+fsgpu_status fsgpu_search_topk(fsgpu_index *idx, const float *queries, uint32_t nq, uint32_t query_len,
+                               uint32_t k, const uint64_t *allow_bitmap, uint32_t *out_rows,
+                               float *out_scores, uint32_t *out_counts);
+/* Same, all pointers device-resident, enqueued on `hip_stream` (a hipStream_t), no host sync. */
+fsgpu_status fsgpu_search_topk_device(fsgpu_index *idx, const float *queries_dev, uint32_t nq,
+                                      uint32_t query_len, uint32_t k, const uint64_t *allow_bitmap_dev,
+                                      uint32_t *out_rows_dev, float *out_scores_dev, uint32_t *out_counts_dev,
+                                      void *hip_stream);
+/* search_top_k_classified (search.rs:227-261): validates the query (non-finite -> INVALID_CONFIG),
+ * reports the ZeroSignalReason, then searches one query. */
+fsgpu_status fsgpu_search_topk_classified(fsgpu_index *idx, const float *query, uint32_t query_len, uint32_t k,
+                                          uint32_t *out_rows, float *out_scores, uint32_t *out_count,
+                                          int32_t *zero_signal);
+/* search_top_k + resolve_hits (search.rs:1493-1558) for FSVI-opened indexes: post-top-k doc-id dedup
+ * (first = best wins).  out_* hold up to k entries. */
+fsgpu_status fsgpu_search_hits(fsgpu_index *idx, const float *query, uint32_t query_len, uint32_t k,
+                               uint32_t *out_rows, float *out_scores, uint32_t *out_count);
+/* VectorIndex::dot_query_at (lib.rs:3229-3239) over a row list, as used by
+ * TwoTierIndex::quality_scores_for_hits (two_tier.rs:1566-1631).  rows are global ids. */
+fsgpu_status fsgpu_gather_dot(fsgpu_index *idx, const float *query, uint32_t query_len, const uint32_t *rows,
+                              uint32_t n, float *out_scores);
+
+/* ---- index build helpers ---- */
+/* encode_f32_to_f16_extend (simd.rs:2245-2305): f32 -> f16 round-to-nearest-even on the GPU. */
+fsgpu_status fsgpu_encode_f32_to_f16(int32_t device, const float *src, uint64_t n, uint16_t *dst);
+/* f16 -> f32 widen (simd.rs:63-94), exposed for the exhaustive 65,536-pattern parity test. */
+fsgpu_status fsgpu_widen_f16_to_f32(int32_t device, const uint16_t *src, uint64_t n, float *dst);
+
+/* ---- Model2Vec (potion) ---- */
+/* Model2VecEmbedder (embed/src/model2vec_embedder.rs:55-58): table is [vocab,dim] f32 row-major (host). */
+fsgpu_status fsgpu_m2v_create(int32_t device, const float *table, uint32_t vocab, uint32_t dim, fsgpu_m2v **out);
+void fsgpu_m2v_destroy(fsgpu_m2v *m);
+/* embed_batch_sync over token ids (model2vec_embedder.rs:310-335,409-419,435-451): text i owns
+ * ids[offsets[i]..offsets[i+1]); out is [n,dim].  Empty / all-OOV texts give zeros. */
+fsgpu_status fsgpu_m2v_embed(fsgpu_m2v *m, const uint32_t *ids, const uint32_t *offsets, uint32_t n, float *out);
+
+/* ---- instrumentation ---- */
+/* When enabled, HIP events bracket the scan kernel of every fsgpu_search_topk* call. */
+fsgpu_status fsgpu_index_set_profiling(fsgpu_index *idx, int32_t enabled);
+/* Sum of scan-kernel time (ms) and number of scan launches since the last reset; synchronises. */
+fsgpu_status fsgpu_index_scan_time(fsgpu_index *idx, double *total_ms, uint64_t *launches, int32_t reset);
+/* Selects the scan kernel variant (0 = default) — used by bench A/B runs only. */
+fsgpu_status fsgpu_index_set_variant(fsgpu_index *idx, int32_t variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSGPU_H */

@@ -1,0 +1,322 @@
+"""GPU parity tests: libfsgpu.so (through the C ABI) vs the CPU oracle on the same inputs.
+
+Bar: BIT-EXACT row ids and BIT-EXACT f32 score bits (the HIP scan reproduces the reference's
+accumulation order), far inside the north-star's 1e-3 score tolerance.
+Run on the GPU box with `pytest -m gpu`.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import frankensearch_amd as fa_mod
+    from frankensearch_amd.build import build
+
+    build()
+    assert fa_mod._lib.lib().fsgpu_device_count() >= 1, "no GPU visible"
+    return fa_mod
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def rand_slab(rng, n, dim, scale=1.0):
+    return (rng.standard_normal((n, dim)) * scale).astype(np.float16).view(np.uint16)
+
+
+def assert_same(fa, oracle, slab, queries, k, live=None, allow=None, hreduce=0, variant=0):
+    idx = fa.VectorIndex.from_slab(slab, live=live)
+    idx.set_hreduce(hreduce)
+    idx.set_variant(variant)
+    rows, scores, counts = idx.search_batch(queries, k, allow=allow)
+    eff_live = None
+    if live is not None or allow is not None:
+        eff_live = np.ones(slab.shape[0], bool)
+        if live is not None:
+            eff_live &= live
+        if allow is not None:
+            eff_live &= allow
+    for qi in range(queries.shape[0]):
+        er, es = oracle.search_top_k(slab, queries[qi], k, live=eff_live, hreduce=hreduce)
+        n = int(counts[qi])
+        assert n == len(er), (n, len(er))
+        assert np.array_equal(rows[qi, :n], er), f"rows differ q={qi} k={k} shape={slab.shape}"
+        assert np.array_equal(bits(scores[qi, :n]), bits(es)), f"score bits differ q={qi}"
+    idx.close()
+
+
+# ------------------------------------------------------------------------------------------------
+def test_widen_f16_all_patterns_bit_exact(fa, oracle):
+    # simd.rs:2711-2744
+    src = np.arange(65536, dtype=np.uint16)
+    got = fa.widen_f16_to_f32(src)
+    ref = src.view(np.float16).astype(np.float32)
+    nan = np.isnan(ref)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.array_equal(np.signbit(got[nan]), np.signbit(ref[nan]))
+    assert np.array_equal(got[~nan].view(np.uint32), ref[~nan].view(np.uint32))
+
+
+def test_encode_f32_to_f16_matches_oracle(fa, oracle):
+    # simd.rs:2245-2305 / :2669
+    rng = np.random.default_rng(3)
+    vals = np.concatenate([
+        rng.standard_normal(100000).astype(np.float32),
+        (rng.standard_normal(20000) * 1e-5).astype(np.float32),
+        (rng.standard_normal(5000) * 7e4).astype(np.float32),
+        np.array([0.0, -0.0, 1.0, 0.8, 0.2, 65504.0, 65520.0, 2.0 ** -24, 2.0 ** -25, 1.5 * 2.0 ** -25, np.inf,
+                  -np.inf], dtype=np.float32),
+        rng.integers(0, 2 ** 32, 100000, dtype=np.uint64).astype(np.uint32).view(np.float32),
+    ])
+    got = fa.encode_f32_to_f16(vals)
+    want = oracle.encode_f32_to_f16(vals)
+    nan = np.isnan(vals)
+    assert np.array_equal(got[~nan], want[~nan])
+    assert np.all((got[nan] & 0x7C00) == 0x7C00) and np.all((got[nan] & 0x03FF) != 0)
+
+
+@pytest.mark.parametrize("dim", [8, 16, 24, 40, 72, 128, 256, 384, 512, 768])
+def test_scan_parity_dims(fa, oracle, dim):
+    rng = np.random.default_rng(dim)
+    for n in (1, 15, 16, 17, 1000, 4099):
+        slab = rand_slab(rng, n, dim)
+        q = rng.standard_normal((3, dim)).astype(np.float32)
+        for k in (1, 10):
+            assert_same(fa, oracle, slab, q, k)
+
+
+@pytest.mark.parametrize("dim", [4, 7, 12, 100, 390])
+def test_scan_parity_unaligned_dims_general_path(fa, oracle, dim):
+    # dim % 8 != 0: scalar fused tail (simd.rs:441-445), rows not 16-byte aligned
+    rng = np.random.default_rng(dim)
+    for n in (3, 257, 3000):
+        slab = rand_slab(rng, n, dim)
+        q = rng.standard_normal((2, dim)).astype(np.float32)
+        assert_same(fa, oracle, slab, q, 7)
+
+
+@pytest.mark.parametrize("k", [1, 2, 10, 30, 60, 64, 65, 100, 256, 257, 300, 1000])
+def test_scan_parity_k_tiers(fa, oracle, k):
+    rng = np.random.default_rng(k)
+    slab = rand_slab(rng, 20011, 128)
+    q = rng.standard_normal((2, 128)).astype(np.float32)
+    assert_same(fa, oracle, slab, q, k)
+
+
+@pytest.mark.parametrize("nq", [1, 2, 3, 4, 5, 8, 9])
+def test_scan_parity_query_batches(fa, oracle, nq):
+    rng = np.random.default_rng(nq)
+    for dim in (384, 256):
+        slab = rand_slab(rng, 30000, dim)
+        q = rng.standard_normal((nq, dim)).astype(np.float32)
+        assert_same(fa, oracle, slab, q, 10)
+        assert_same(fa, oracle, slab, q, 100)
+
+
+def test_scan_parity_tombstones_and_allow_bitmap(fa, oracle):
+    # search.rs:2163-2233 tombstones; filter.rs:19-56 as an allow bitmap
+    rng = np.random.default_rng(17)
+    slab = rand_slab(rng, 10007, 384)
+    q = rng.standard_normal((4, 384)).astype(np.float32)
+    live = rng.random(10007) > 0.3
+    allow = rng.random(10007) > 0.5
+    assert_same(fa, oracle, slab, q, 10, live=live)
+    assert_same(fa, oracle, slab, q, 10, allow=allow)
+    assert_same(fa, oracle, slab, q, 50, live=live, allow=allow)
+    none_live = np.zeros(10007, bool)
+    assert_same(fa, oracle, slab, q, 10, live=none_live)
+    few = np.zeros(10007, bool)
+    few[[5, 77, 9000]] = True
+    assert_same(fa, oracle, slab, q, 10, live=few)
+    assert_same(fa, oracle, slab, q, 400, live=live)  # general path with tombstones
+
+
+def test_collect_all_and_k_above_n(fa, oracle):
+    # search.rs:449-473 (k >= N), :2627-2643
+    rng = np.random.default_rng(23)
+    for n, dim in ((2, 8), (80, 8), (700, 128), (5000, 384)):
+        slab = rand_slab(rng, n, dim)
+        q = rng.standard_normal((2, dim)).astype(np.float32)
+        assert_same(fa, oracle, slab, q, n)
+        assert_same(fa, oracle, slab, q, n + 20)
+
+
+def test_ties_nan_and_signed_zero_ordering(fa, oracle):
+    # search.rs:2741-2764 ties by index; :2767-2787 NaN sorts last; total_cmp -0.0 < +0.0
+    rng = np.random.default_rng(29)
+    base = rand_slab(rng, 64, 128)
+    slab = np.concatenate([base] * 40)  # every score appears 40 times -> pure index tie-breaks
+    q = rng.standard_normal((2, 128)).astype(np.float32)
+    for k in (1, 10, 64, 100, 300, slab.shape[0]):
+        assert_same(fa, oracle, slab, q, k)
+    qn = q.copy()
+    qn[0, 3] = np.nan
+    assert_same(fa, oracle, slab[:333], qn, 10)
+    assert_same(fa, oracle, slab[:333], qn, 333)
+    # rows of +inf / -inf / nan / zeros, and a query producing -0.0 and +0.0 scores
+    special = np.zeros((48, 16), np.float16)
+    special[1, 0] = np.inf
+    special[2, 0] = -np.inf
+    special[3, 0] = np.nan
+    special[4, 0] = 1.0
+    special[5, 0] = -1.0
+    special[6, 0] = np.inf
+    special[6, 1] = -np.inf
+    slab2 = special.view(np.uint16)
+    for qv in ([1.0] + [0.0] * 15, [-0.0] + [0.0] * 15, [0.0] * 16, [1.0, 1.0] + [0.0] * 14):
+        q2 = np.array([qv], np.float32)
+        for k in (5, 48):
+            idx = fa.VectorIndex.from_slab(slab2)
+            rows, scores, counts = idx.search_batch(q2, k)
+            er, es = oracle.search_top_k(slab2, q2[0], k)
+            n = int(counts[0])
+            assert n == len(er) and np.array_equal(rows[0, :n], er)
+            # NaN payload/sign is platform-defined (x86 default NaN is negative); compare NaN-ness + other bits
+            gn, en = np.isnan(scores[0, :n]), np.isnan(es)
+            assert np.array_equal(gn, en)
+            assert np.array_equal(bits(scores[0, :n])[~gn], bits(es)[~en])
+
+
+def test_hreduce_avx_order(fa, oracle):
+    rng = np.random.default_rng(31)
+    slab = rand_slab(rng, 5000, 384)
+    q = rng.standard_normal((2, 384)).astype(np.float32)
+    assert_same(fa, oracle, slab, q, 10, hreduce=1)
+    assert_same(fa, oracle, slab, q, 300, hreduce=1)
+
+
+def test_runtime_dim_kernel_variant(fa, oracle):
+    rng = np.random.default_rng(37)
+    slab = rand_slab(rng, 9001, 384)
+    q = rng.standard_normal((3, 384)).astype(np.float32)
+    assert_same(fa, oracle, slab, q, 10, variant=1)
+
+
+def test_reference_known_answers_through_fsvi(fa, oracle, tmp_path):
+    # search.rs:2116-2137, 2163-2187, 2627-2643, 2741-2764 through the FSVI file + doc ids
+    p = str(tmp_path / "kat.fsvi")
+    assert oracle.fsvi_write(p, [("doc-a", [1.0, 0, 0, 0]), ("doc-b", [0.8, 0, 0, 0]), ("doc-c", [0.2, 0, 0, 0])]) == 0
+    idx = fa.VectorIndex.open(p)
+    assert idx.record_count() == 3 and idx.dimension() == 4
+    hits = idx.search_top_k([1.0, 0, 0, 0], 2)
+    assert [h.doc_id for h in hits] == ["doc-a", "doc-b"]
+    assert [h.index for h in hits] == [0, 1]
+    assert bits([h.score for h in hits]).tolist() == [0x3F800000, 0x3F4CC000]
+    assert len(idx.search_top_k([1.0, 0, 0, 0], 20)) == 3
+    assert idx.soft_delete("doc-a") and not idx.soft_delete("doc-a") and not idx.soft_delete("nope")
+    hits = idx.search_top_k([1.0, 0, 0, 0], 10)
+    assert [h.doc_id for h in hits] == ["doc-b", "doc-c"]
+    with pytest.raises(fa.DimensionMismatch):
+        idx.search_top_k([1.0, 0, 0], 2)
+    # classified (search.rs:227-261)
+    assert idx.search_top_k_classified([1.0, 0, 0, 0], 0).zero_signal == "CallerRequestedZeroK"
+    assert idx.search_top_k_classified([0.0, 0, 0, 0], 3).zero_signal == "ZeroNormQuery"
+    with pytest.raises(fa.InvalidConfig):
+        idx.search_top_k_classified([np.inf, 0, 0, 0], 3)
+    assert idx.search_top_k_classified([1.0, 0, 0, 0], 3).zero_signal is None
+    # NaN query through the unclassified path: all NaN, index ascending
+    hits = idx.search_top_k([np.nan, 0, 0, 0], 3)
+    assert all(np.isnan(h.score) for h in hits) and [h.index for h in hits] == sorted(h.index for h in hits)
+
+
+def test_fsvi_file_parity_with_dedup_and_corruption(fa, oracle, tmp_path):
+    rng = np.random.default_rng(41)
+    rows = [(f"doc-{i % 180:03}", rng.standard_normal(64).astype(np.float32).tolist()) for i in range(200)]  # 20 dup ids
+    p = str(tmp_path / "d.fsvi")
+    assert oracle.fsvi_write(p, rows, "emb", "r1") == 0
+    o = oracle.Fsvi(p)
+    g = fa.VectorIndex.open(p)
+    assert [g.doc_id_at(r) for r in range(200)] == [o.doc_id(r) for r in range(200)]
+    for qi in range(5):
+        q = rng.standard_normal(64).astype(np.float32)
+        for k in (5, 40, 200):
+            oh, os_ = o.search_top_k(q, k)
+            gh = g.search_top_k(q, k)
+            assert [(h.index, h.doc_id) for h in gh] == [(h[0], h[2]) for h in oh]
+            assert np.array_equal(bits([h.score for h in gh]), bits(os_))
+    raw = bytearray(open(p, "rb").read())
+    for off, exc in ((20, fa.IndexCorrupted), (0, fa.IndexCorrupted), (4, fa.IndexVersionMismatch)):
+        bad = bytearray(raw)
+        bad[off] ^= 0x5A
+        q = str(tmp_path / f"bad{off}.fsvi")
+        open(q, "wb").write(bad)
+        with pytest.raises(exc):
+            fa.VectorIndex.open(q)
+    with pytest.raises(fa.IoError):
+        fa.VectorIndex.open(str(tmp_path / "missing.fsvi"))
+
+
+def test_gather_dot_matches_oracle(fa, oracle):
+    # lib.rs:3229-3239 / two_tier.rs:1566-1631
+    rng = np.random.default_rng(43)
+    for dim in (384, 40, 100, 7):
+        slab = rand_slab(rng, 5000, dim)
+        q = rng.standard_normal(dim).astype(np.float32)
+        rows = rng.integers(0, 5000, 77).astype(np.uint32)
+        idx = fa.VectorIndex.from_slab(slab)
+        got = idx.gather_dot(q, rows)
+        want = oracle.gather_dot(slab, q, rows)
+        assert np.array_equal(bits(got), bits(want))
+        assert bits([idx.dot_query_at(int(rows[0]), q)])[0] == bits(want[:1])[0]
+        with pytest.raises(fa.InvalidConfig):
+            idx.gather_dot(q, [5000])
+
+
+def test_row_base_shards_merge_to_whole(fa, oracle):
+    # contiguous row shards + global row ids => merged shard top-k == whole-index top-k
+    rng = np.random.default_rng(47)
+    n, dim, k = 30000, 384, 25
+    slab = rand_slab(rng, n, dim)
+    slab[100:110] = slab[20000:20010]  # cross-shard ties
+    q = rng.standard_normal((3, dim)).astype(np.float32)
+    whole = fa.VectorIndex.from_slab(slab)
+    wr, ws, wc = whole.search_batch(q, k)
+    cuts = [0, 7000, 15001, 15002, n]
+    parts = [fa.VectorIndex.from_slab(slab[a:b], row_base=a) for a, b in zip(cuts[:-1], cuts[1:])]
+    for qi in range(3):
+        cand = []
+        for p in parts:
+            r, s, c = p.search_batch(q[qi:qi + 1], k)
+            cand += [(int(r[0, i]), s[0, i]) for i in range(int(c[0]))]
+        cand.sort(key=lambda t: (-(t[1] if not np.isnan(t[1]) else -np.inf), t[0]))
+        assert [c[0] for c in cand[:k]] == wr[qi].tolist()
+        assert np.array_equal(bits([c[1] for c in cand[:k]]), bits(ws[qi]))
+
+
+def test_model2vec_bit_exact(fa, oracle):
+    # model2vec_embedder.rs:691-849 formula model + random tables; :962-1010 invariants
+    rng = np.random.default_rng(53)
+    vocab, dim = 10, 8
+    table = (np.arange(vocab, dtype=np.float32)[:, None] * np.float32(0.1)
+             + np.arange(dim, dtype=np.float32)[None, :] * np.float32(0.01)).astype(np.float32)
+    m = fa.Model2VecEmbedder(table)
+    batch = [[1, 2, 3], [], [99, 100], [1, 99, 2], [0], [9, 9, 9, 9]]
+    got = m.embed_batch_token_ids(batch)
+    for i, ids in enumerate(batch):
+        assert np.array_equal(bits(got[i]), bits(oracle.m2v_embed(table, ids))), i
+    for vocab, dim in ((5000, 256), (3000, 128), (1000, 384)):
+        table = rng.standard_normal((vocab, dim)).astype(np.float32)
+        m = fa.Model2VecEmbedder(table)
+        batch = [rng.integers(0, vocab + 50, int(rng.integers(0, 600))).tolist() for _ in range(40)]
+        got = m.embed_batch_token_ids(batch)
+        for i, ids in enumerate(batch):
+            assert np.array_equal(bits(got[i]), bits(oracle.m2v_embed(table, ids))), (vocab, dim, i)
+
+
+def test_config2_1m_x_384_clustered_corpus(fa, oracle):
+    # BASELINE config 2: 1M x 384 f16, top-10, the reference's bench generator (fsvi_4bit_vs_incumbent.rs:56-101)
+    n, dim = 1_000_000, 384
+    slab = oracle.clustered_corpus_f16(0, n, dim)
+    idx = fa.VectorIndex.from_slab(slab)
+    queries = np.stack([oracle.clustered_query(q, dim) for q in range(6)])
+    for k in (10, 30):
+        rows, scores, counts = idx.search_batch(queries, k)
+        for qi in range(queries.shape[0]):
+            er, es = oracle.search_top_k(slab, queries[qi], k, nthreads=8)
+            assert np.array_equal(rows[qi], er) and np.array_equal(bits(scores[qi]), bits(es))
