@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py — queries/sec of the f16 cosine scan + top-k on a 10M x 384 f16 corpus (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one batch of B queries searched against the WHOLE corpus: fused scan + wave top-k on each
+rank's contiguous row shard, one all-gather of the packed per-shard top-k (RCCL when N > 1), merge.
+The corpus is fixed (strong scaling: 10M rows total, sharded N ways) and already resident in HBM when the
+timed region starts; queries are device-resident f32.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line (task contract):
+  roofline     — the scan kernel against the HBM roof: algorithmic bytes (rows x dim x 2 per launch)
+                 / mean launch duration measured live with HIP events on the launch stream.
+  cpu_baseline — the oracle's AVX2+F16C restatement of the reference CPU path (kind "port"), timed on the
+                 host cores of this box on a bounded sample of the same corpus, in the same run, and used as
+                 the bit-exact parity checker for the GPU result on that sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+CHUNK_ROWS = 250_000    # corpus generation granule (seeded per chunk -> identical corpus for any N)
+CLUSTERS = 64
+NOISE = 0.30
+
+
+def gen_chunk(chunk: int, dim: int, device) -> torch.Tensor:
+    """Synthetic clustered unit vectors, same recipe as the reference bench generator
+    (frankensearch/benches/fsvi_4bit_vs_incumbent.rs:56-101: 64 centroids + 0.30 * uniform noise, L2
+    normalised, then f32 -> f16 RNE), generated on the GPU with a per-chunk seed."""
+    g = torch.Generator(device=device)
+    g.manual_seed(0xC0000000)
+    cent = torch.rand((CLUSTERS, dim), generator=g, device=device) * 2 - 1
+    cent = cent / cent.norm(dim=1, keepdim=True)
+    g.manual_seed(1 + chunk)
+    noise = torch.rand((CHUNK_ROWS, dim), generator=g, device=device) * 2 - 1
+    rows = torch.arange(chunk * CHUNK_ROWS, (chunk + 1) * CHUNK_ROWS, device=device) % CLUSTERS
+    v = cent[rows] + NOISE * noise
+    v = v / v.norm(dim=1, keepdim=True)
+    return v.to(torch.float16)
+
+
+def gen_corpus(lo: int, hi: int, dim: int, device) -> torch.Tensor:
+    out = torch.empty((hi - lo, dim), dtype=torch.float16, device=device)
+    c0, c1 = lo // CHUNK_ROWS, (hi + CHUNK_ROWS - 1) // CHUNK_ROWS
+    for c in range(c0, c1):
+        ch = gen_chunk(c, dim, device)
+        a, b = max(lo, c * CHUNK_ROWS), min(hi, (c + 1) * CHUNK_ROWS)
+        out[a - lo:b - lo] = ch[a - c * CHUNK_ROWS:b - c * CHUNK_ROWS]
+        del ch
+    return out
+
+
+def gen_queries(n: int, dim: int, device) -> torch.Tensor:
+    g = torch.Generator(device=device)
+    g.manual_seed(0xDEAD0000)
+    cent = torch.rand((CLUSTERS, dim), generator=torch.Generator(device=device).manual_seed(0xC0000000),
+                      device=device) * 2 - 1
+    cent = cent / cent.norm(dim=1, keepdim=True)
+    noise = torch.rand((n, dim), generator=g, device=device) * 2 - 1
+    v = cent[torch.arange(n, device=device) % CLUSTERS] + NOISE * noise
+    v = v / v.norm(dim=1, keepdim=True)
+    return v.to(torch.float32).contiguous()
+
+
+def cpu_baseline_and_parity(slab_dev: torch.Tensor, queries: torch.Tensor, k: int, rows_total: int, index_cls):
+    """Oracle (AVX2+F16C restatement, all host cores) on the first `sample` rows; also the parity checker."""
+    from oracle import oracle
+
+    oracle.build()
+    sample = int(min(slab_dev.shape[0], 2_500_000))
+    host = slab_dev[:sample].contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
+    cores = os.cpu_count() or 1
+    nthreads = min(cores, 64)
+    nq = 4
+    q_host = queries[:nq].cpu().numpy()
+    sub = index_cls.from_device_slab(slab_dev.data_ptr(), sample, slab_dev.shape[1], device=slab_dev.device.index or 0,
+                                     keepalive=slab_dev)
+    g_rows, g_scores, g_counts = sub.search_batch(q_host, k)
+    oracle.search_top_k(host[:200_000], q_host[0], k, nthreads=nthreads)  # warm the thread pool / pages
+    t0 = time.perf_counter()
+    ok = True
+    for qi in range(nq):
+        er, es = oracle.search_top_k(host, q_host[qi], k, nthreads=nthreads)
+        ok &= bool(np.array_equal(g_rows[qi, :len(er)], er) and
+                   np.array_equal(g_scores[qi, :len(es)].view(np.uint32), es.view(np.uint32)))
+    dt = time.perf_counter() - t0
+    sub.close()
+    qps_sample = nq / dt
+    gbps = sample * slab_dev.shape[1] * 2 * nq / dt / 1e9
+    return {
+        "value": qps_sample * sample / rows_total,
+        "unit": "queries/sec",
+        "cores": nthreads,
+        "kind": "port",
+        "sample": f"{nq} queries x first {sample} rows of the same corpus, one at a time; value scaled by "
+                  f"{sample}/{rows_total} to the full corpus; {gbps:.1f} GB/s of f16 on {nthreads} threads "
+                  f"({cores} host cpus)",
+        "parity_bit_exact": ok,
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=384)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=4, help="queries per step (one scan pass serves up to 4)")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from __graft_entry__ import build
+    if rank == 0:
+        build()
+    if world > 1:
+        dist.barrier()
+    import frankensearch_amd as fa
+    from frankensearch_amd.sharded import GpuShardBackend, ShardedVectorIndex, shard_range
+
+    lo, hi = shard_range(args.rows, rank, world)
+    slab = gen_corpus(lo, hi, args.dim, device)
+    pool = 64
+    queries = gen_queries(max(pool, args.batch), args.dim, device)
+    index = fa.VectorIndex.from_device_slab(slab.data_ptr(), hi - lo, args.dim, device=local_rank, row_base=lo,
+                                            keepalive=slab)
+    index.set_variant(args.variant)
+    sharded = ShardedVectorIndex(GpuShardBackend(index, device))
+    B, k = args.batch, args.k
+
+    def step(i: int):
+        s = (i * B) % (queries.shape[0] - B + 1)
+        return sharded.search(queries[s:s + B], k)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    index.set_profiling(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    index.set_profiling(False)
+    scan_ms, launches = index.scan_time(reset=True)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # single-query latency through the host-pointer boundary (H2D query, scan, merge, D2H hits, sync)
+    lat = []
+    if world == 1:
+        q1 = queries[:32].cpu().numpy()
+        for i in range(40):
+            t1 = time.perf_counter()
+            index.search_batch(q1[i % 32], k)
+            lat.append((time.perf_counter() - t1) * 1e3)
+        lat = sorted(lat[8:])
+
+    if rank == 0:
+        rows, scores, counts = out
+        assert int(counts.min().item()) == min(k, args.rows)
+        sc = scores.cpu().numpy()
+        assert np.all(np.diff(sc, axis=1) <= 0), "results must be best-first"
+        per_launch_ms = scan_ms / max(launches, 1)
+        alg_bytes = (hi - lo) * args.dim * 2
+        achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        line = {
+            "metric": "queries/sec, f16 cosine scan + top-k, 10Mx384 f16 corpus",
+            "value": args.steps * B / elapsed,
+            "unit": "queries/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f16 x f32 -> f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.rows}x{args.dim} f16 corpus (clustered unit vectors), exact brute-force cosine "
+                            f"top-{k}, {B} queries per step, rows sharded {world} way(s)",
+                "rows": args.rows, "dim": args.dim, "k": k, "queries_per_step": B,
+                "parallelism": f"row-shard x{world}" + (" + all-gather(top-k) over RCCL" if world > 1 else ""),
+                "kernel_variant": args.variant,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None,
+                "kernel": "scan_topk_kernel",
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_ms": per_launch_ms,
+                "launches": launches,
+            },
+        }
+        if lat:
+            line["p50_latency_ms_single_query"] = lat[len(lat) // 2]
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_and_parity(slab, queries, k, args.rows, fa.VectorIndex)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -168,6 +168,32 @@ fsgpu_status fsgpu_search_topk_device(fsgpu_index* idx, const float* queries_dev
     });
 }
 
+fsgpu_status fsgpu_search_topk_packed_device(fsgpu_index* idx, const float* queries_dev, uint32_t nq,
+                                             uint32_t query_len, uint32_t k, const uint64_t* allow_bitmap_dev,
+                                             uint64_t* out_packed_dev, void* hip_stream) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    if (nq && k && (!queries_dev || !out_packed_dev)) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.search_top_k_packed_device(queries_dev, nq, query_len, k, allow_bitmap_dev,
+                                                           out_packed_dev, static_cast<hipStream_t>(hip_stream)));
+    });
+}
+
+fsgpu_status fsgpu_merge_topk_device(int32_t device, const uint64_t* lists_dev, uint32_t nq, uint32_t nlists,
+                                     uint32_t list_len, uint64_t q_stride, uint64_t l_stride, uint32_t k,
+                                     uint32_t* out_rows_dev, float* out_scores_dev, uint32_t* out_counts_dev,
+                                     void* hip_stream) {
+    if (nq && (!lists_dev || !out_rows_dev || !out_scores_dev || !out_counts_dev))
+        return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    if (k == 0 || k > 1024) return fail(FSGPU_ERR_INVALID_CONFIG, "merge supports 1 <= k <= 1024");
+    return guarded([&]() -> fsgpu_status {
+        return finish(fsgpu::merge_packed_lists_device(device, lists_dev, nq, nlists, list_len, q_stride, l_stride, k,
+                                                       out_rows_dev, out_scores_dev, out_counts_dev,
+                                                       static_cast<hipStream_t>(hip_stream)));
+    });
+}
+
 // search_top_k_classified (crates/frankensearch-index/src/search.rs:227-261)
 fsgpu_status fsgpu_search_topk_classified(fsgpu_index* idx, const float* query, uint32_t query_len, uint32_t k,
                                           uint32_t* out_rows, float* out_scores, uint32_t* out_count,

@@ -23,7 +23,9 @@ struct ScanArgs {
 };
 
 struct MergeArgs {
-    const u64* lists;       // [nq, nlists, list_len] packed
+    const u64* lists;       // packed entries; element (q, l, i) at lists[q*q_stride + l*l_stride + i]
+    uint64_t q_stride;
+    uint64_t l_stride;
     uint32_t nlists;
     uint32_t list_len;
     uint32_t k;             // entries to select per query
@@ -31,6 +33,7 @@ struct MergeArgs {
     uint32_t* out_rows;     // [nq, out_stride]
     float* out_scores;      // [nq, out_stride]
     uint32_t* out_counts;   // [nq]
+    u64* out_packed;        // optional [nq, out_stride] packed copy of the result (kEmpty padded)
 };
 
 size_t scan_lds_bytes(int dim, int nq, int kcap);

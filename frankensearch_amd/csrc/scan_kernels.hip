@@ -384,8 +384,9 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(MergeArgs args) {
     __shared__ u64 s_thr;
     const int tid = threadIdx.x;
     const int q = blockIdx.x;
-    const u64* in = args.lists + (size_t)q * args.nlists * args.list_len;
-    const size_t total = (size_t)args.nlists * args.list_len;
+    const u64* in = args.lists + (size_t)q * args.q_stride;
+    const uint32_t list_len = args.list_len;
+    const size_t total = (size_t)args.nlists * list_len;
     const int k = (int)args.k;
     if (tid == 0) {
         s_count = 0;
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(MergeArgs args) {
     for (size_t base = 0; base < total; base += 256) {
         const size_t i = base + tid;
         u64 c = kEmpty;
-        if (i < total) c = in[i];
+        if (i < total) c = in[(i / list_len) * args.l_stride + (i % list_len)];
         const bool ok = c != kEmpty && sortkey(c) > s_thr;
         if (ok) {
             const int pos = atomicAdd(&s_count, 1);
@@ -419,10 +420,11 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(MergeArgs args) {
     const int n = cnt < k ? cnt : k;
     for (int j = tid; j < (int)args.out_stride; j += 256) {
         const u64 c = j < n ? buf[j] : kEmpty;
-        args.out_rows[(size_t)q * args.out_stride + j] = (uint32_t)c;
-        args.out_scores[(size_t)q * args.out_stride + j] = __uint_as_float((uint32_t)(c >> 32));
+        if (args.out_rows) args.out_rows[(size_t)q * args.out_stride + j] = (uint32_t)c;
+        if (args.out_scores) args.out_scores[(size_t)q * args.out_stride + j] = __uint_as_float((uint32_t)(c >> 32));
+        if (args.out_packed) args.out_packed[(size_t)q * args.out_stride + j] = c;
     }
-    if (tid == 0) args.out_counts[q] = (uint32_t)n;
+    if (tid == 0 && args.out_counts) args.out_counts[q] = (uint32_t)n;
 }
 
 // packed -> sortkey (in place), for the general path's radix sort; and the inverse for rows.

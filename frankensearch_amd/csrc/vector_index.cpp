@@ -310,7 +310,7 @@ ScanArgs VectorIndex::base_args(const float* queries_dev, const uint64_t* allow_
 
 SearchError VectorIndex::fused_search(const float* queries_dev, uint32_t nq, uint32_t k_out, uint32_t k_eff,
                                       const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
-                                      uint32_t* out_counts_dev, hipStream_t stream) {
+                                      uint32_t* out_counts_dev, u64* out_packed_dev, hipStream_t stream) {
     const int kcap = k_eff <= 64 ? 64 : 256;
     const uint32_t ntiles = (uint32_t)((nrows_ + 15) / 16);
     uint32_t done = 0;
@@ -340,13 +340,16 @@ SearchError VectorIndex::fused_search(const float* queries_dev, uint32_t nq, uin
         }
         MergeArgs m;
         m.lists = a.partial;
+        m.q_stride = (uint64_t)grid * kcap;
+        m.l_stride = (uint64_t)kcap;
+        m.out_packed = out_packed_dev ? out_packed_dev + (size_t)done * k_out : nullptr;
         m.nlists = (uint32_t)grid;
         m.list_len = (uint32_t)kcap;
         m.k = k_eff;
         m.out_stride = k_out;
-        m.out_rows = out_rows_dev + (size_t)done * k_out;
-        m.out_scores = out_scores_dev + (size_t)done * k_out;
-        m.out_counts = out_counts_dev + done;
+        m.out_rows = out_rows_dev ? out_rows_dev + (size_t)done * k_out : nullptr;
+        m.out_scores = out_scores_dev ? out_scores_dev + (size_t)done * k_out : nullptr;
+        m.out_counts = out_counts_dev ? out_counts_dev + done : nullptr;
         FSGPU_HIP(launch_merge_topk(m, pass, stream));
         done += (uint32_t)pass;
     }
@@ -398,7 +401,8 @@ SearchError VectorIndex::search_top_k_device(const float* queries_dev, uint32_t 
     }
     const uint32_t k_eff = (uint64_t)k < nrows_ ? k : (uint32_t)nrows_;
     if (dim_ % 8 == 0 && k_eff <= 256)
-        return fused_search(queries_dev, nq, k, k_eff, allow_dev, out_rows_dev, out_scores_dev, out_counts_dev, stream);
+        return fused_search(queries_dev, nq, k, k_eff, allow_dev, out_rows_dev, out_scores_dev, out_counts_dev, nullptr,
+                            stream);
     return general_search(queries_dev, nq, k, k_eff, allow_dev, out_rows_dev, out_scores_dev, out_counts_dev, stream);
 }
 
@@ -522,6 +526,79 @@ SearchError Model2VecEmbedder::embed_batch(const uint32_t* ids, const uint32_t* 
     FSGPU_HIP(hipMemcpyAsync(out, out_.ptr, (size_t)n * dim_ * 4, hipMemcpyDeviceToHost, stream_));
     FSGPU_HIP(hipStreamSynchronize(stream_));
     return ok();
+}
+
+}  // namespace fsgpu
+
+namespace fsgpu {
+
+SearchError VectorIndex::search_top_k_packed_device(const float* queries_dev, uint32_t nq, uint32_t query_len,
+                                                    uint32_t k, const uint64_t* allow_dev, uint64_t* out_packed_dev,
+                                                    hipStream_t stream) {
+    if (query_len != dim_) {
+        SearchError e;
+        e.code = FSGPU_ERR_DIMENSION_MISMATCH;
+        e.detail = "expected " + std::to_string(dim_) + ", found " + std::to_string(query_len);
+        return e;
+    }
+    if (nq == 0 || k == 0) return SearchError{};
+    if (dim_ % 8 != 0 || k > 256) {
+        SearchError e;
+        e.code = FSGPU_ERR_INVALID_CONFIG;
+        e.detail = "packed shard search supports k <= 256 and dim % 8 == 0";
+        return e;
+    }
+    if (hipSetDevice(device_) != hipSuccess) {
+        SearchError e;
+        e.code = FSGPU_ERR_DEVICE;
+        e.detail = "hipSetDevice failed";
+        return e;
+    }
+    if (nrows_ == 0) {
+        if (hipMemsetAsync(out_packed_dev, 0xff, (size_t)nq * k * 8, stream) != hipSuccess) {
+            SearchError e;
+            e.code = FSGPU_ERR_DEVICE;
+            e.detail = "hipMemsetAsync failed";
+            return e;
+        }
+        return SearchError{};
+    }
+    const uint32_t k_eff = (uint64_t)k < nrows_ ? k : (uint32_t)nrows_;
+    return fused_search(queries_dev, nq, k, k_eff, allow_dev, nullptr, nullptr, nullptr,
+                        reinterpret_cast<u64*>(out_packed_dev), stream);
+}
+
+// Cross-shard merge of packed best-first lists (the step after the RCCL all-gather, SURVEY §8e;
+// same selection rule as merge_partial_heaps, search.rs:1704-1720).
+SearchError merge_packed_lists_device(int device, const uint64_t* lists_dev, uint32_t nq, uint32_t nlists,
+                                      uint32_t list_len, uint64_t q_stride, uint64_t l_stride, uint32_t k,
+                                      uint32_t* out_rows_dev, float* out_scores_dev, uint32_t* out_counts_dev,
+                                      hipStream_t stream) {
+    SearchError e;
+    if (nq == 0) return e;
+    if (hipSetDevice(device) != hipSuccess) {
+        e.code = FSGPU_ERR_DEVICE;
+        e.detail = "hipSetDevice failed";
+        return e;
+    }
+    MergeArgs m;
+    m.lists = reinterpret_cast<const u64*>(lists_dev);
+    m.q_stride = q_stride;
+    m.l_stride = l_stride;
+    m.nlists = nlists;
+    m.list_len = list_len;
+    m.k = k;
+    m.out_stride = k;
+    m.out_rows = out_rows_dev;
+    m.out_scores = out_scores_dev;
+    m.out_counts = out_counts_dev;
+    m.out_packed = nullptr;
+    hipError_t he = launch_merge_topk(m, (int)nq, stream);
+    if (he != hipSuccess) {
+        e.code = FSGPU_ERR_DEVICE;
+        e.detail = hipGetErrorString(he);
+    }
+    return e;
 }
 
 }  // namespace fsgpu

@@ -53,6 +53,10 @@ class VectorIndex {
     SearchError search_top_k_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
                                     const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
                                     uint32_t* out_counts_dev, hipStream_t stream);
+    // Shard-local search whose result stays packed (score bits << 32 | global row; ~0 padding) for the
+    // cross-GPU exchange: out_packed_dev is [nq, k].  Fused tiers only (k <= 256, dim % 8 == 0).
+    SearchError search_top_k_packed_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
+                                           const uint64_t* allow_dev, uint64_t* out_packed_dev, hipStream_t stream);
     SearchError gather_dot(const float* query, uint32_t query_len, const uint32_t* rows, uint32_t n, float* out);
 
     SearchError doc_id_at(uint32_t row, const char** ptr, uint32_t* len) const;
@@ -72,7 +76,7 @@ class VectorIndex {
     SearchError common_init(int device);
     SearchError fused_search(const float* queries_dev, uint32_t nq, uint32_t k_out, uint32_t k_eff,
                              const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
-                             uint32_t* out_counts_dev, hipStream_t stream);
+                             uint32_t* out_counts_dev, u64* out_packed_dev, hipStream_t stream);
     SearchError general_search(const float* queries_dev, uint32_t nq, uint32_t k_out, uint32_t k_eff,
                                const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
                                uint32_t* out_counts_dev, hipStream_t stream);
@@ -116,6 +120,9 @@ class Model2VecEmbedder {
     hipStream_t stream_ = nullptr;
 };
 
-void set_last_error(const SearchError& e);
+SearchError merge_packed_lists_device(int device, const uint64_t* lists_dev, uint32_t nq, uint32_t nlists,
+                                      uint32_t list_len, uint64_t q_stride, uint64_t l_stride, uint32_t k,
+                                      uint32_t* out_rows_dev, float* out_scores_dev, uint32_t* out_counts_dev,
+                                      hipStream_t stream);
 
 }  // namespace fsgpu

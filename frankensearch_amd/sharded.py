@@ -1,0 +1,88 @@
+"""Row-sharded search across the GPUs of one node.
+
+The reference is single-process; its only partitioning is `scan_parallel`'s contiguous row chunks
+merged by `merge_partial_heaps` (crates/frankensearch-index/src/search.rs:1013-1036,1704-1720).
+The same shape across GPUs: rank r owns the contiguous rows [r*ceil(N/W), ...), reports GLOBAL row
+ids, so the (score, row) tie-break is shard-invariant; queries are replicated; each rank produces
+[B, k] packed hits (8 bytes each); ONE all-gather (RCCL over xGMI when the backend is nccl) of
+B*k*8 bytes per rank; every rank merges the W lists with the reference order.  No all-reduce, no row
+exchange.
+
+The compute backend is injected: `GpuShardBackend` (libfsgpu.so) in production; the CPU test suite
+injects an oracle-based stand-in to exercise the partitioning / collective / layout logic under gloo.
+"""
+from __future__ import annotations
+
+from typing import Optional, Protocol, Tuple
+
+import torch
+import torch.distributed as dist
+
+EMPTY = -1  # 0xFFFFFFFFFFFFFFFF as int64: padding entry of a packed list
+
+
+def shard_range(nrows: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous ceil-split: rank r owns [r*ceil(N/W), min(N, (r+1)*ceil(N/W)))."""
+    per = (nrows + world - 1) // world
+    lo = min(nrows, rank * per)
+    hi = min(nrows, lo + per)
+    return lo, hi
+
+
+class ShardBackend(Protocol):
+    def search_packed(self, queries: torch.Tensor, k: int) -> torch.Tensor:
+        """[B, dim] f32 queries -> [B, k] int64 packed hits of THIS shard (global rows), best first."""
+
+    def merge(self, gathered: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """[W, B, k] int64 packed -> (rows [B,k] int32-as-u32, scores [B,k] f32, counts [B] int32)."""
+
+
+class GpuShardBackend:
+    """libfsgpu.so on the current torch device / current stream."""
+
+    def __init__(self, index, device: torch.device):
+        self.index = index
+        self.device = device
+
+    def search_packed(self, queries: torch.Tensor, k: int) -> torch.Tensor:
+        from . import _lib
+        from .errors import check
+
+        assert queries.is_cuda and queries.dtype == torch.float32 and queries.is_contiguous()
+        b, dim = queries.shape
+        out = torch.empty((b, k), dtype=torch.int64, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(_lib.lib().fsgpu_search_topk_packed_device(self.index._h, queries.data_ptr(), b, dim, k, None,
+                                                         out.data_ptr(), stream))
+        return out
+
+    def merge(self, gathered: torch.Tensor, k: int):
+        from . import _lib
+        from .errors import check
+
+        w, b, kk = gathered.shape
+        rows = torch.empty((b, k), dtype=torch.int32, device=self.device)
+        scores = torch.empty((b, k), dtype=torch.float32, device=self.device)
+        counts = torch.empty((b,), dtype=torch.int32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(_lib.lib().fsgpu_merge_topk_device(self.device.index or 0, gathered.data_ptr(), b, w, kk, kk, b * kk, k,
+                                                 rows.data_ptr(), scores.data_ptr(), counts.data_ptr(), stream))
+        return rows, scores, counts
+
+
+class ShardedVectorIndex:
+    """One process per GPU; `search` is collective: every rank calls it with the same queries."""
+
+    def __init__(self, backend: ShardBackend, group: Optional[dist.ProcessGroup] = None):
+        self.backend = backend
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def search(self, queries: torch.Tensor, k: int):
+        local = self.backend.search_packed(queries, k)  # [B, k]
+        if self.world == 1:
+            gathered = local.unsqueeze(0)
+        else:
+            gathered = torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(gathered, local, group=self.group)
+        return self.backend.merge(gathered, k)

@@ -100,6 +100,21 @@ fsgpu_status fsgpu_search_topk_device(fsgpu_index *idx, const float *queries_dev
                                       uint32_t query_len, uint32_t k, const uint64_t *allow_bitmap_dev,
                                       uint32_t *out_rows_dev, float *out_scores_dev, uint32_t *out_counts_dev,
                                       void *hip_stream);
+/* Shard-local search for the multi-GPU path (the reference partitions the same way per
+ * rayon chunk, search.rs:1020-1035): like fsgpu_search_topk_device but the result stays PACKED,
+ * out_packed_dev[q*k+i] = (f32 score bits << 32) | global row, best first, ~0ull padding — one
+ * 8-byte word per hit, ready for an RCCL all-gather.  k <= 256, dim % 8 == 0. */
+fsgpu_status fsgpu_search_topk_packed_device(fsgpu_index *idx, const float *queries_dev, uint32_t nq,
+                                             uint32_t query_len, uint32_t k, const uint64_t *allow_bitmap_dev,
+                                             uint64_t *out_packed_dev, void *hip_stream);
+/* Merge of gathered packed lists = merge_partial_heaps + resolve_hits sort (search.rs:1704-1720,1493-1501)
+ * across shards: entry (q, l, i) is lists_dev[q*q_stride + l*l_stride + i]; selects the k best per query
+ * under the reference order.  For an all-gather result laid out [nlists][nq][list_len]:
+ * q_stride = list_len, l_stride = nq*list_len. */
+fsgpu_status fsgpu_merge_topk_device(int32_t device, const uint64_t *lists_dev, uint32_t nq, uint32_t nlists,
+                                     uint32_t list_len, uint64_t q_stride, uint64_t l_stride, uint32_t k,
+                                     uint32_t *out_rows_dev, float *out_scores_dev, uint32_t *out_counts_dev,
+                                     void *hip_stream);
 /* search_top_k_classified (search.rs:227-261): validates the query (non-finite -> INVALID_CONFIG),
  * reports the ZeroSignalReason, then searches one query. */
 fsgpu_status fsgpu_search_topk_classified(fsgpu_index *idx, const float *query, uint32_t query_len, uint32_t k,
