@@ -121,7 +121,7 @@ def main() -> None:
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=4, help="queries per step (one scan pass serves up to 4)")
+    ap.add_argument("--batch", type=int, default=2, help="queries per step (one scan pass serves up to 4)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

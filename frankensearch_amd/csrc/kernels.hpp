@@ -14,7 +14,7 @@ struct ScanArgs {
     const u64* live;        // bit r set = row r live (tombstone flag clear); nullptr = all live
     const u64* allow;       // per-call filter bitmap; nullptr = no filter
     const float* queries;   // [nq, dim] f32 (device)
-    u64* partial;           // [nq, grid, kcap] packed best-first lists (device)
+    u64* partial;           // [nq, grid, k] packed best-first lists (device)
     uint32_t nrows;
     uint32_t dim;
     uint32_t k;
@@ -37,7 +37,7 @@ struct MergeArgs {
 };
 
 size_t scan_lds_bytes(int dim, int nq, int kcap);
-int scan_occupancy_blocks_per_cu(int dim, int nq, int kcap);
+int scan_occupancy_blocks_per_cu(int dim, int nq, int kcap, bool force_runtime_dim);
 hipError_t launch_scan_topk(const ScanArgs& args, int nq, int kcap, int grid, hipStream_t stream,
                             bool force_runtime_dim);
 hipError_t launch_merge_topk(const MergeArgs& args, int nq, hipStream_t stream);

@@ -81,13 +81,18 @@ __device__ __forceinline__ float quad_finish(const float (&acc)[8], int hreduce)
 
 }  // namespace
 
-// DIM_CT: compile-time dimension (multiple of 32, <= 512: register double-buffered tiles) or 0 for the
-//         runtime-dimension body (any dim % 8 == 0, incl. leftover chunks).
-// NQ:     queries scored per pass (1, 2 or 4): lane a of a quad owns query a's candidate.
+// DIM_CT: compile-time dimension (multiple of 32, <= 512: query and double-buffered tiles live in
+//         registers, no LDS traffic in the hot loop) or 0 for the runtime-dimension body (any
+//         dim % 8 == 0, incl. leftover chunks; query read from LDS).
+// NQ:     queries scored per pass (1, 2 or 4).  A lane is (row r, accumulator a, query b):
+//         lane = r*4*NQ + b*4 + a, so a wave covers 16/NQ rows and the NQ lanes that share (r, a)
+//         load the same 16 bytes (coalesced by the TA into one fetch) but multiply by different
+//         queries.  Per-lane arithmetic is identical for every NQ.
 // KCAP:   capacity tier of the per-wave / per-block lists (k <= KCAP); CAP = 2*KCAP.
 template <int DIM_CT, int NQ, int KCAP>
 __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs args) {
     constexpr int CAP = 2 * KCAP;
+    constexpr int kRows = kRowsPerTile / NQ;  // rows per wave tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int dim = DIM_CT ? DIM_CT : (int)args.dim;
     float* qs = reinterpret_cast<float*>(smem);                                   // [NQ][dim]
@@ -97,95 +102,93 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs args) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int a = lane & 3;
-    const int r = lane >> 2;
+    const int b = (lane >> 2) & (NQ - 1);
+    const int r = lane / (4 * NQ);
 
     for (int i = tid; i < NQ * dim; i += 256) qs[i] = args.queries[i];
     __syncthreads();
 
     WaveTopK<CAP> tk[NQ];
 #pragma unroll
-    for (int b = 0; b < NQ; ++b) tk[b].init(bufs + ((size_t)wave * NQ + b) * CAP);
-    u64 thr = 0;  // lane a holds the threshold of query a
+    for (int x = 0; x < NQ; ++x) tk[x].init(bufs + ((size_t)wave * NQ + x) * CAP);
+    u64 thr = 0;  // this lane's query's threshold
 
     const uint32_t nrows = args.nrows;
-    const uint32_t ntiles = (nrows + kRowsPerTile - 1) / kRowsPerTile;
+    const uint32_t ntiles = (nrows + kRows - 1) / kRows;
     const uint32_t nwaves = gridDim.x * kWavesPerBlock;
     const uint32_t wave_gid = blockIdx.x * kWavesPerBlock + wave;
     const unsigned char* slab = reinterpret_cast<const unsigned char*>(args.slab);
     const size_t row_bytes = (size_t)dim * 2;
     const int k = (int)args.k;
     const int hreduce = args.hreduce;
-    const u64 qmask = 0x1111111111111111ull;
+    // lanes with a == 0 carry the candidates; those of query x sit at bit positions 4*NQ*r + 4*x
+    constexpr u64 kOwnerMask = NQ == 1 ? 0x1111111111111111ull : (NQ == 2 ? 0x0101010101010101ull : 0x0001000100010001ull);
+    const float* qlane = qs + b * dim;
 
-    // Scores one tile and pushes candidates.  `w(g)` yields chunk 4g+a of this lane's row.
-    auto finish_tile = [&](uint32_t tile, float (&acc)[NQ][8], u64 live_word, u64 allow_word) {
-        const uint32_t row = tile * kRowsPerTile + r;
+    // Turns the lane's 8 partial sums into the row score and pushes candidates.
+    auto finish_tile = [&](uint32_t tile, float (&acc)[8], u64 live_word, u64 allow_word) {
+        const uint32_t row = tile * kRows + r;
         bool valid = row < nrows;
         valid = valid && ((live_word >> (row & 63)) & 1ull) && ((allow_word >> (row & 63)) & 1ull);
-        float score = 0.f;
-#pragma unroll
-        for (int b = 0; b < NQ; ++b) {
-            float s = quad_finish(acc[b], hreduce);
-            if (DIM_CT == 0 && (dim & 7)) {  // scalar tail: fused mul_add, in index order
-                const uint32_t rowc = row < nrows ? row : nrows - 1;
-                const _Float16* hp = reinterpret_cast<const _Float16*>(slab + (size_t)rowc * row_bytes);
-                for (int i = dim & ~7; i < dim; ++i) s = __builtin_fmaf((float)hp[i], qs[b * dim + i], s);
-            }
-            if (a == b) score = s;
+        float score = quad_finish(acc, hreduce);
+        if (DIM_CT == 0 && (dim & 7)) {  // scalar tail: fused mul_add, in index order (unused: host routes
+                                         // unaligned dims to the general path)
+            const uint32_t rowc = row < nrows ? row : nrows - 1;
+            const _Float16* hp = reinterpret_cast<const _Float16*>(slab + (size_t)rowc * row_bytes);
+            for (int i = dim & ~7; i < dim; ++i) score = __builtin_fmaf((float)hp[i], qlane[i], score);
         }
         const u64 packed = pack(score, args.row_base + row);
-        bool cand = valid && (a < NQ) && sortkey(packed) > thr;
+        bool cand = valid && (a == 0) && sortkey(packed) > thr;
         u64 m = __ballot(cand);
         if (m == 0) return;
 #pragma unroll
-        for (int b = 0; b < NQ; ++b) {
-            u64 mb = m & (qmask << b);
-            if (mb == 0) continue;
-            if (tk[b].count + (int)__popcll(mb) > CAP) {
-                const u64 t = tk[b].compact(k, lane);
-                if (a == b) thr = t;
+        for (int x = 0; x < NQ; ++x) {
+            const u64 xmask = kOwnerMask << (4 * x);
+            u64 mx = m & xmask;
+            if (mx == 0) continue;
+            if (tk[x].count + (int)__popcll(mx) > CAP) {
+                const u64 t = tk[x].compact(k, lane);
+                if (b == x) thr = t;
                 cand = cand && sortkey(packed) > thr;
-                mb = __ballot(cand) & (qmask << b);
+                mx = __ballot(cand) & xmask;
             }
-            if (cand && a == b) {
-                const int pos = tk[b].count + (int)__popcll(mb & ((1ull << lane) - 1ull));
-                tk[b].buf[pos] = packed;
+            if (cand && b == x) {
+                const int pos = tk[x].count + (int)__popcll(mx & ((1ull << lane) - 1ull));
+                tk[x].buf[pos] = packed;
             }
-            tk[b].count += (int)__popcll(mb);
+            tk[x].count += (int)__popcll(mx);
         }
     };
 
     auto tile_words = [&](uint32_t tile, u64& live_word, u64& allow_word) {
-        const uint32_t w64 = (tile * kRowsPerTile) >> 6;
+        const uint32_t w64 = (tile * kRows) >> 6;
         live_word = args.live ? args.live[w64] : ~0ull;
         allow_word = args.allow ? args.allow[w64] : ~0ull;
     };
 
     if constexpr (DIM_CT != 0) {
         constexpr int G = DIM_CT / 32;
+        // The lane's slice of its query lives in registers for the whole kernel (G*8 VGPRs).
+        float4 q0[G], q1[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float4* qp = reinterpret_cast<const float4*>(qlane + 32 * g + 8 * a);
+            q0[g] = qp[0];
+            q1[g] = qp[1];
+        }
         auto load_tile = [&](uint32_t tile, u32x4 (&w)[G]) {
-            uint32_t row = tile * kRowsPerTile + r;
+            uint32_t row = tile * kRows + r;
             row = row < nrows ? row : nrows - 1;
             const u32x4* p = reinterpret_cast<const u32x4*>(slab + (size_t)row * row_bytes) + a;
 #pragma unroll
             for (int g = 0; g < G; ++g) w[g] = load_nt16(p + 4 * g);
         };
-        // NQ == 1 keeps the whole query in registers (G*8 VGPRs, loaded once): the hot loop then has no
-        // LDS traffic at all.  (Compile-time dims are only instantiated for NQ == 1.)
-        static_assert(NQ == 1, "compile-time dimension bodies are single-query");
-        float4 q0[G], q1[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const float4* qp = reinterpret_cast<const float4*>(qs + 32 * g + 8 * a);
-            q0[g] = qp[0];
-            q1[g] = qp[1];
-        }
         auto compute_tile = [&](uint32_t tile, const u32x4 (&w)[G], u64 live_word, u64 allow_word) {
-            float acc[NQ][8];
+            float acc[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[0][j] = 0.f;
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
-            for (int g = 0; g < G; ++g) chunk_mac(acc[0], w[g], q0[g], q1[g]);
+            for (int g = 0; g < G; ++g) chunk_mac(acc, w[g], q0[g], q1[g]);
             finish_tile(tile, acc, live_word, allow_word);
         };
         constexpr bool kDoubleBuffer = G <= 12;
@@ -224,63 +227,55 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs args) {
             }
         }
     } else {
-        // Runtime dimension (dim % 8 == 0 for the 16-byte loads; tail handled in finish_tile when the
-        // host routes an unaligned dim here it uses the thread-per-row kernel instead).
+        // Runtime dimension (dim % 8 == 0 for the 16-byte loads).
         const int chunks = dim >> 3;
         const int groups = chunks >> 2;
         const int leftover = chunks & 3;
         for (uint32_t tile = wave_gid; tile < ntiles; tile += nwaves) {
-            uint32_t row = tile * kRowsPerTile + r;
+            uint32_t row = tile * kRows + r;
             row = row < nrows ? row : nrows - 1;
             const u32x4* p = reinterpret_cast<const u32x4*>(slab + (size_t)row * row_bytes);
             u64 lw, aw;
             tile_words(tile, lw, aw);
-            float acc[NQ][8];
+            float acc[8];
 #pragma unroll
-            for (int b = 0; b < NQ; ++b)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[b][j] = 0.f;
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll 4
             for (int g = 0; g < groups; ++g) {
                 const u32x4 w = load_nt16(p + 4 * g + a);
-#pragma unroll
-                for (int b = 0; b < NQ; ++b) {
-                    const float4* qp = reinterpret_cast<const float4*>(qs + b * dim + 32 * g + 8 * a);
-                    chunk_mac(acc[b], w, qp[0], qp[1]);
-                }
+                const float4* qp = reinterpret_cast<const float4*>(qlane + 32 * g + 8 * a);
+                chunk_mac(acc, w, qp[0], qp[1]);
             }
             if (a == 0) {  // leftover chunks all accumulate into s0, in order
                 for (int c = 4 * groups; c < 4 * groups + leftover; ++c) {
                     const u32x4 w = load_nt16(p + c);
-#pragma unroll
-                    for (int b = 0; b < NQ; ++b) {
-                        const float4* qp = reinterpret_cast<const float4*>(qs + b * dim + 8 * c);
-                        chunk_mac(acc[b], w, qp[0], qp[1]);
-                    }
+                    const float4* qp = reinterpret_cast<const float4*>(qlane + 8 * c);
+                    chunk_mac(acc, w, qp[0], qp[1]);
                 }
             }
             finish_tile(tile, acc, lw, aw);
         }
     }
 
-    // ---- block merge: every wave sorts its lists, then wave b folds the four lists of query b ----
+    // ---- block merge: every wave sorts its lists, then wave x folds the four lists of query x ----
 #pragma unroll
-    for (int b = 0; b < NQ; ++b) (void)tk[b].compact(k, lane);
+    for (int x = 0; x < NQ; ++x) (void)tk[x].compact(k, lane);
     __syncthreads();
-    for (int b = wave; b < NQ; b += kWavesPerBlock) {
-        u64* dst = bufs + ((size_t)0 * NQ + b) * CAP;
+    for (int x = wave; x < NQ; x += kWavesPerBlock) {
+        u64* dst = bufs + ((size_t)0 * NQ + x) * CAP;
         for (int w = 1; w < kWavesPerBlock; ++w) {
-            const u64* src = bufs + ((size_t)w * NQ + b) * CAP;
+            const u64* src = bufs + ((size_t)w * NQ + x) * CAP;
             // top-KCAP of two best-first lists: elementwise max of A[i] and B[KCAP-1-i], then re-sort
             for (int i = lane; i < KCAP; i += 64) {
-                const u64 x = dst[i], y = src[KCAP - 1 - i];
-                dst[i] = sortkey(x) >= sortkey(y) ? x : y;
+                const u64 xx = dst[i], yy = src[KCAP - 1 - i];
+                dst[i] = sortkey(xx) >= sortkey(yy) ? xx : yy;
             }
             for (int i = KCAP + lane; i < CAP; i += 64) dst[i] = kEmpty;
             wave_sort_desc<CAP>(dst, lane);
         }
-        u64* out = args.partial + ((size_t)b * gridDim.x + blockIdx.x) * KCAP;
-        for (int i = lane; i < KCAP; i += 64) out[i] = i < k ? dst[i] : kEmpty;
+        // one best-first list of k entries per (query, block)
+        u64* out = args.partial + ((size_t)x * gridDim.x + blockIdx.x) * k;
+        for (int i = lane; i < k; i += 64) out[i] = dst[i];
     }
 }
 
@@ -374,12 +369,14 @@ __global__ __launch_bounds__(256) void score_rows_kernel(ScanArgs args, u64* out
     }
 }
 
-// Final merge: one block per query folds P best-first lists of LIST entries into the top-k and emits
-// (row, score) arrays, best first.  Selection is by unique integer sortkeys, so the LDS-atomic append
-// order does not affect the result.
-template <int MCAP>
-__global__ __launch_bounds__(256) void merge_topk_kernel(MergeArgs args) {
-    __shared__ u64 buf[MCAP];
+// Final merge: one block per query folds nlists best-first lists of list_len entries into the top-k and
+// emits (row, score) arrays, best first.  Selection is by unique integer sortkeys, so the LDS-atomic
+// append order does not affect the result.  When everything fits (the usual case: grid*k entries) it is
+// a single load + one bitonic sort; otherwise a threshold-gated streaming pass.
+template <int MCAP, int NT>
+__global__ __launch_bounds__(NT) void merge_topk_kernel(MergeArgs args) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char merge_smem[];
+    u64* buf = reinterpret_cast<u64*>(merge_smem);
     __shared__ int s_count;
     __shared__ u64 s_thr;
     const int tid = threadIdx.x;
@@ -388,37 +385,54 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(MergeArgs args) {
     const uint32_t list_len = args.list_len;
     const size_t total = (size_t)args.nlists * list_len;
     const int k = (int)args.k;
-    if (tid == 0) {
-        s_count = 0;
-        s_thr = 0;
-    }
-    __syncthreads();
-    for (size_t base = 0; base < total; base += 256) {
-        const size_t i = base + tid;
-        u64 c = kEmpty;
-        if (i < total) c = in[(i / list_len) * args.l_stride + (i % list_len)];
-        const bool ok = c != kEmpty && sortkey(c) > s_thr;
-        if (ok) {
-            const int pos = atomicAdd(&s_count, 1);
-            buf[pos] = c;
+    int cnt;
+    if (total <= (size_t)MCAP) {
+        for (int i = tid; i < MCAP; i += NT) {
+            u64 c = kEmpty;
+            if ((size_t)i < total) c = in[(size_t)(i / list_len) * args.l_stride + (i % list_len)];
+            buf[i] = c;
+        }
+        cnt = (int)total;  // upper bound; kEmpty entries sort last
+    } else {
+        if (tid == 0) {
+            s_count = 0;
+            s_thr = 0;
         }
         __syncthreads();
-        if (s_count > MCAP - 256) {  // block-uniform
-            const int cnt = s_count;
-            for (int j = cnt + tid; j < MCAP; j += 256) buf[j] = kEmpty;
-            block_sort_desc<MCAP, 256>(buf, tid);
-            if (tid == 0) {
-                s_count = cnt < k ? cnt : k;
-                s_thr = cnt >= k ? sortkey(buf[k - 1]) : 0;
+        for (size_t base = 0; base < total; base += NT) {
+            const size_t i = base + tid;
+            u64 c = kEmpty;
+            if (i < total) c = in[(i / list_len) * args.l_stride + (i % list_len)];
+            const bool ok = c != kEmpty && sortkey(c) > s_thr;
+            if (ok) {
+                const int pos = atomicAdd(&s_count, 1);
+                buf[pos] = c;
             }
             __syncthreads();
+            if (s_count > MCAP - NT) {  // block-uniform
+                const int have = s_count;
+                for (int j = have + tid; j < MCAP; j += NT) buf[j] = kEmpty;
+                block_sort_desc<MCAP, NT>(buf, tid);
+                if (tid == 0) {
+                    s_count = have < k ? have : k;
+                    s_thr = have >= k ? sortkey(buf[k - 1]) : 0;
+                }
+                __syncthreads();
+            }
         }
+        cnt = s_count;
+        for (int j = cnt + tid; j < MCAP; j += NT) buf[j] = kEmpty;
     }
-    const int cnt = s_count;
-    for (int j = cnt + tid; j < MCAP; j += 256) buf[j] = kEmpty;
-    block_sort_desc<MCAP, 256>(buf, tid);
-    const int n = cnt < k ? cnt : k;
-    for (int j = tid; j < (int)args.out_stride; j += 256) {
+    block_sort_desc<MCAP, NT>(buf, tid);
+    // count real entries among the first k (kEmpty sorts last)
+    int n = cnt < k ? cnt : k;
+    __shared__ int s_n;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    if (tid < n && buf[tid] != kEmpty && (tid + 1 == n || buf[tid + 1] == kEmpty)) s_n = tid + 1;
+    __syncthreads();
+    n = s_n;
+    for (int j = tid; j < (int)args.out_stride; j += NT) {
         const u64 c = j < n ? buf[j] : kEmpty;
         if (args.out_rows) args.out_rows[(size_t)q * args.out_stride + j] = (uint32_t)c;
         if (args.out_scores) args.out_scores[(size_t)q * args.out_stride + j] = __uint_as_float((uint32_t)(c >> 32));
@@ -545,15 +559,13 @@ static hipError_t launch_scan_t(const ScanArgs& args, int grid, hipStream_t stre
 
 template <int NQ, int KCAP>
 static hipError_t launch_scan_dim(const ScanArgs& args, int grid, hipStream_t stream, bool force_runtime_dim) {
-    if constexpr (NQ == 1) {
-        if (!force_runtime_dim) {
-            switch (args.dim) {
-                case 128: return launch_scan_t<128, NQ, KCAP>(args, grid, stream);
-                case 256: return launch_scan_t<256, NQ, KCAP>(args, grid, stream);
-                case 384: return launch_scan_t<384, NQ, KCAP>(args, grid, stream);
-                case 512: return launch_scan_t<512, NQ, KCAP>(args, grid, stream);
-                default: break;
-            }
+    if (!force_runtime_dim) {
+        switch (args.dim) {
+            case 128: return launch_scan_t<128, NQ, KCAP>(args, grid, stream);
+            case 256: return launch_scan_t<256, NQ, KCAP>(args, grid, stream);
+            case 384: return launch_scan_t<384, NQ, KCAP>(args, grid, stream);
+            case 512: return launch_scan_t<512, NQ, KCAP>(args, grid, stream);
+            default: break;
         }
     }
     return launch_scan_t<0, NQ, KCAP>(args, grid, stream);
@@ -573,17 +585,58 @@ hipError_t launch_scan_topk(const ScanArgs& args, int nq, int kcap, int grid, hi
     return hipErrorInvalidValue;
 }
 
-int scan_occupancy_blocks_per_cu(int dim, int nq, int kcap) {
-    // Conservative: the kernel is declared for 256-thread blocks; registers allow >= 2 blocks/CU for
-    // every instantiation, LDS decides the rest.
-    const size_t lds = scan_lds_bytes(dim, nq, kcap);
-    int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
-    if (by_lds < 1) by_lds = 1;
-    return by_lds > 3 ? 3 : by_lds;
+template <int DIM_CT, int NQ, int KCAP>
+static int occupancy_t(int dim) {
+    int blocks = 0;
+    const size_t lds = scan_lds_bytes(DIM_CT ? DIM_CT : dim, NQ, KCAP);
+    auto kern = scan_topk_kernel<DIM_CT, NQ, KCAP>;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, 256, lds) != hipSuccess || blocks < 1) blocks = 1;
+    return blocks;
+}
+
+template <int NQ, int KCAP>
+static int occupancy_dim(int dim, bool force_runtime_dim) {
+    if (!force_runtime_dim) {
+        switch (dim) {
+            case 128: return occupancy_t<128, NQ, KCAP>(dim);
+            case 256: return occupancy_t<256, NQ, KCAP>(dim);
+            case 384: return occupancy_t<384, NQ, KCAP>(dim);
+            case 512: return occupancy_t<512, NQ, KCAP>(dim);
+            default: break;
+        }
+    }
+    return occupancy_t<0, NQ, KCAP>(dim);
+}
+
+// Resident 256-thread blocks per CU for the instantiation launch_scan_topk would pick: the grid is
+// sized to exactly one resident wave of blocks so the strided tile walk has no tail.
+int scan_occupancy_blocks_per_cu(int dim, int nq, int kcap, bool force_runtime_dim) {
+#define FSGPU_OCC(NQ_, KCAP_) \
+    if (nq == NQ_ && kcap == KCAP_) return occupancy_dim<NQ_, KCAP_>(dim, force_runtime_dim);
+    FSGPU_OCC(1, 64)
+    FSGPU_OCC(2, 64)
+    FSGPU_OCC(4, 64)
+    FSGPU_OCC(1, 256)
+    FSGPU_OCC(2, 256)
+    FSGPU_OCC(4, 256)
+#undef FSGPU_OCC
+    return 1;
 }
 
 hipError_t launch_merge_topk(const MergeArgs& args, int nq, hipStream_t stream) {
-    hipLaunchKernelGGL(merge_topk_kernel<2048>, dim3(nq), dim3(256), 0, stream, args);
+    constexpr int MCAP = 8192, NT = 1024;
+    auto kern = merge_topk_kernel<MCAP, NT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, MCAP * 8);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nq), dim3(NT), MCAP * 8, stream, args);
     return hipGetLastError();
 }
 

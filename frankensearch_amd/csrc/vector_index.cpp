@@ -312,18 +312,18 @@ SearchError VectorIndex::fused_search(const float* queries_dev, uint32_t nq, uin
                                       const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
                                       uint32_t* out_counts_dev, u64* out_packed_dev, hipStream_t stream) {
     const int kcap = k_eff <= 64 ? 64 : 256;
-    const uint32_t ntiles = (uint32_t)((nrows_ + 15) / 16);
     uint32_t done = 0;
     while (done < nq) {
         const uint32_t left = nq - done;
         int pass = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
         if (scan_lds_bytes((int)dim_, pass, kcap) > 150 * 1024) pass = 1;
-        const int per_cu = scan_occupancy_blocks_per_cu((int)dim_, pass, kcap);
+        const int per_cu = scan_occupancy_blocks_per_cu((int)dim_, pass, kcap, variant == 1);
         int grid = num_cus_ * per_cu;
-        const int max_useful = (int)((ntiles + 3) / 4);
+        const uint32_t ntiles_pass = (uint32_t)((nrows_ + (16 / pass) - 1) / (16 / pass));
+        const int max_useful = (int)((ntiles_pass + 3) / 4);
         if (grid > max_useful) grid = max_useful;
         if (grid < 1) grid = 1;
-        FSGPU_TRY(ws_partial_.reserve((size_t)pass * grid * kcap * 8));
+        FSGPU_TRY(ws_partial_.reserve((size_t)pass * grid * k_eff * 8));
         ScanArgs a = base_args(queries_dev + (size_t)done * dim_, allow_dev);
         a.partial = static_cast<u64*>(ws_partial_.ptr);
         a.k = k_eff;
@@ -340,11 +340,11 @@ SearchError VectorIndex::fused_search(const float* queries_dev, uint32_t nq, uin
         }
         MergeArgs m;
         m.lists = a.partial;
-        m.q_stride = (uint64_t)grid * kcap;
-        m.l_stride = (uint64_t)kcap;
+        m.q_stride = (uint64_t)grid * k_eff;
+        m.l_stride = (uint64_t)k_eff;
         m.out_packed = out_packed_dev ? out_packed_dev + (size_t)done * k_out : nullptr;
         m.nlists = (uint32_t)grid;
-        m.list_len = (uint32_t)kcap;
+        m.list_len = k_eff;
         m.k = k_eff;
         m.out_stride = k_out;
         m.out_rows = out_rows_dev ? out_rows_dev + (size_t)done * k_out : nullptr;

@@ -56,6 +56,20 @@ class GpuShardBackend:
                                                          out.data_ptr(), stream))
         return out
 
+    def search_unsharded(self, queries: torch.Tensor, k: int):
+        """world == 1: the shard-local merge already is the final answer (no exchange, no second merge)."""
+        from . import _lib
+        from .errors import check
+
+        b, dim = queries.shape
+        rows = torch.empty((b, k), dtype=torch.int32, device=self.device)
+        scores = torch.empty((b, k), dtype=torch.float32, device=self.device)
+        counts = torch.empty((b,), dtype=torch.int32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(_lib.lib().fsgpu_search_topk_device(self.index._h, queries.data_ptr(), b, dim, k, None, rows.data_ptr(),
+                                                  scores.data_ptr(), counts.data_ptr(), stream))
+        return rows, scores, counts
+
     def merge(self, gathered: torch.Tensor, k: int):
         from . import _lib
         from .errors import check
@@ -79,10 +93,14 @@ class ShardedVectorIndex:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
     def search(self, queries: torch.Tensor, k: int):
+        if self.world == 1 and hasattr(self.backend, "search_unsharded"):
+            return self.backend.search_unsharded(queries, k)
         local = self.backend.search_packed(queries, k)  # [B, k]
         if self.world == 1:
             gathered = local.unsqueeze(0)
         else:
-            gathered = torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-            dist.all_gather_into_tensor(gathered, local, group=self.group)
+            # dim-0 concatenation form (accepted by both RCCL and gloo), viewed as [W, B, k]
+            flat = torch.empty((self.world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(flat, local, group=self.group)
+            gathered = flat.view(self.world, local.shape[0], local.shape[1])
         return self.backend.merge(gathered, k)
