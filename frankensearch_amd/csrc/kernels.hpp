@@ -39,7 +39,7 @@ struct MergeArgs {
 size_t scan_lds_bytes(int dim, int nq, int kcap);
 int scan_occupancy_blocks_per_cu(int dim, int nq, int kcap, bool force_runtime_dim);
 hipError_t launch_scan_topk(const ScanArgs& args, int nq, int kcap, int grid, hipStream_t stream,
-                            bool force_runtime_dim);
+                            bool force_runtime_dim, bool plain_loads);
 hipError_t launch_merge_topk(const MergeArgs& args, int nq, hipStream_t stream);
 hipError_t launch_score_rows(const ScanArgs& args, u64* out_packed, int q_index, int grid, hipStream_t stream);
 hipError_t launch_packed_to_sortkey(u64* data, size_t n, hipStream_t stream);

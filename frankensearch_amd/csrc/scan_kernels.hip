@@ -89,7 +89,7 @@ __device__ __forceinline__ float quad_finish(const float (&acc)[8], int hreduce)
 //         load the same 16 bytes (coalesced by the TA into one fetch) but multiply by different
 //         queries.  Per-lane arithmetic is identical for every NQ.
 // KCAP:   capacity tier of the per-wave / per-block lists (k <= KCAP); CAP = 2*KCAP.
-template <int DIM_CT, int NQ, int KCAP>
+template <int DIM_CT, int NQ, int KCAP, bool NT_LOADS = false>
 __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs args) {
     constexpr int CAP = 2 * KCAP;
     constexpr int kRows = kRowsPerTile / NQ;  // rows per wave tile
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs args) {
             row = row < nrows ? row : nrows - 1;
             const u32x4* p = reinterpret_cast<const u32x4*>(slab + (size_t)row * row_bytes) + a;
 #pragma unroll
-            for (int g = 0; g < G; ++g) w[g] = load_nt16(p + 4 * g);
+            for (int g = 0; g < G; ++g) w[g] = NT_LOADS ? load_nt16(p + 4 * g) : p[4 * g];
         };
         auto compute_tile = [&](uint32_t tile, const u32x4 (&w)[G], u64 live_word, u64 allow_word) {
             float acc[8];
@@ -370,43 +370,120 @@ __global__ __launch_bounds__(256) void score_rows_kernel(ScanArgs args, u64* out
 }
 
 // Final merge: one block per query folds nlists best-first lists of list_len entries into the top-k and
-// emits (row, score) arrays, best first.  Selection is by unique integer sortkeys, so the LDS-atomic
-// append order does not affect the result.  When everything fits (the usual case: grid*k entries) it is
-// a single load + one bitonic sort; otherwise a threshold-gated streaming pass.
+// emits (row, score) arrays, best first (merge_partial_heaps + the resolve_hits sort, search.rs:1704-1720,
+// 1493-1501).  Selection is by unique integer sortkeys, so the LDS append order cannot change the result.
+// Latency-shaped for the usual case (nlists*list_len <= 8192 entries, e.g. 512 block lists x k=10):
+//   1. every thread fetches its <= 8 entries with independent loads (ONE memory round trip);
+//   2. two lower bounds on the global k-th best prune them: the best k-th entry of any list ("tails") and
+//      the k-th largest list head ("heads": the k largest heads are k distinct entries);
+//   3. survivors (typically a few multiples of k) are appended wave-aggregated and sorted by one wave.
+// Larger inputs take a threshold-tightening streaming pass with whole-block sorts.
 template <int MCAP, int NT>
 __global__ __launch_bounds__(NT) void merge_topk_kernel(MergeArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char merge_smem[];
     u64* buf = reinterpret_cast<u64*>(merge_smem);
     __shared__ int s_count;
     __shared__ u64 s_thr;
+    __shared__ int s_rank[2048];
+    constexpr int HCAP = 2048;
+    constexpr int PER = MCAP / NT;
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
     const int q = blockIdx.x;
     const u64* in = args.lists + (size_t)q * args.q_stride;
     const uint32_t list_len = args.list_len;
-    const size_t total = (size_t)args.nlists * list_len;
+    const uint32_t nlists = args.nlists;
+    const size_t total = (size_t)nlists * list_len;
+    const uint32_t total32 = (uint32_t)total;
     const int k = (int)args.k;
+    if (tid == 0) {
+        s_count = 0;
+        s_thr = 0;
+    }
     int cnt;
     if (total <= (size_t)MCAP) {
-        for (int i = tid; i < MCAP; i += NT) {
-            u64 c = kEmpty;
-            if ((size_t)i < total) c = in[(size_t)(i / list_len) * args.l_stride + (i % list_len)];
-            buf[i] = c;
-        }
-        cnt = (int)total;  // upper bound; kEmpty entries sort last
-    } else {
-        if (tid == 0) {
-            s_count = 0;
-            s_thr = 0;
+        u64* hkeys = buf + (MCAP - HCAP);  // aliased: dead before survivors are appended
+        const bool use_heads = nlists >= (uint32_t)k && nlists <= (uint32_t)HCAP;
+        for (int j = tid; j < HCAP; j += NT) s_rank[j] = 0;
+        u64 e[PER];
+        uint32_t pos[PER], lst[PER];
+#pragma unroll
+        for (int x = 0; x < PER; ++x) {
+            const uint32_t i = tid + x * NT;
+            e[x] = kEmpty;
+            lst[x] = i / list_len;
+            pos[x] = i - lst[x] * list_len;
+            if (i < total32) e[x] = in[(size_t)lst[x] * args.l_stride + pos[x]];
         }
         __syncthreads();
-        for (size_t base = 0; base < total; base += NT) {
-            const size_t i = base + tid;
+        u64 best_tail = 0;
+#pragma unroll
+        for (int x = 0; x < PER; ++x) {
+            const bool real = e[x] != kEmpty;
+            const u64 key = real ? sortkey(e[x]) : 0ull;
+            if (real && pos[x] == (uint32_t)(k - 1)) best_tail = key > best_tail ? key : best_tail;
+            if (use_heads && pos[x] == 0 && tid + x * NT < total32) hkeys[lst[x]] = key;
+        }
+        // wave max of best_tail, then one LDS atomic per wave
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const u64 other = __shfl_xor(best_tail, off);
+            best_tail = other > best_tail ? other : best_tail;
+        }
+        if (lane == 0 && best_tail) atomicMax(&s_thr, best_tail);
+        __syncthreads();
+        if (use_heads) {
+            // rank heads: P threads share one head, each scanning a slice of the head array (broadcast reads)
+            uint32_t np2 = 1;
+            while (np2 < nlists) np2 <<= 1;
+            const uint32_t P = NT / np2 > 0 ? NT / np2 : 1;           // threads per head (NT, np2 powers of two)
+            const uint32_t heads_per_round = NT / P;
+            for (uint32_t h0 = 0; h0 < nlists; h0 += heads_per_round) {
+                const uint32_t h = h0 + tid / P;
+                const uint32_t part = tid % P;
+                if (h < nlists) {
+                    const u64 mine = hkeys[h];
+                    const uint32_t span = (nlists + P - 1) / P;
+                    const uint32_t j0 = part * span, j1 = j0 + span < nlists ? j0 + span : nlists;
+                    int greater = 0;
+#pragma unroll 4
+                    for (uint32_t j = j0; j < j1; ++j) greater += hkeys[j] > mine ? 1 : 0;
+                    if (greater) atomicAdd(&s_rank[h], greater);
+                }
+            }
+            __syncthreads();
+            for (uint32_t h = tid; h < nlists; h += NT)
+                if (hkeys[h] != 0 && s_rank[h] == k - 1) atomicMax(&s_thr, hkeys[h]);  // k-th largest head
+            __syncthreads();
+        }
+        const u64 thr0 = s_thr;
+#pragma unroll
+        for (int x = 0; x < PER; ++x) {
+            const bool ok = e[x] != kEmpty && sortkey(e[x]) >= thr0;
+            const u64 m = __ballot(ok);
+            if (m) {
+                int wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&s_count, (int)__popcll(m));
+                wbase = __shfl(wbase, 0);
+                if (ok) buf[wbase + (int)__popcll(m & ((1ull << lane) - 1ull))] = e[x];
+            }
+        }
+        __syncthreads();
+        cnt = s_count;
+    } else {
+        // threshold-tightening stream (compacts whenever the buffer nearly fills)
+        __syncthreads();
+        for (uint32_t base = 0; base < total32; base += NT) {
+            const uint32_t i = base + tid;
             u64 c = kEmpty;
-            if (i < total) c = in[(i / list_len) * args.l_stride + (i % list_len)];
+            if (i < total32) {
+                const uint32_t l = i / list_len;
+                c = in[(size_t)l * args.l_stride + (i - l * list_len)];
+            }
             const bool ok = c != kEmpty && sortkey(c) > s_thr;
             if (ok) {
-                const int pos = atomicAdd(&s_count, 1);
-                buf[pos] = c;
+                const int pos1 = atomicAdd(&s_count, 1);
+                buf[pos1] = c;
             }
             __syncthreads();
             if (s_count > MCAP - NT) {  // block-uniform
@@ -415,23 +492,25 @@ __global__ __launch_bounds__(NT) void merge_topk_kernel(MergeArgs args) {
                 block_sort_desc<MCAP, NT>(buf, tid);
                 if (tid == 0) {
                     s_count = have < k ? have : k;
-                    s_thr = have >= k ? sortkey(buf[k - 1]) : 0;
+                    if (have >= k) s_thr = sortkey(buf[k - 1]);
                 }
                 __syncthreads();
             }
         }
         cnt = s_count;
-        for (int j = cnt + tid; j < MCAP; j += NT) buf[j] = kEmpty;
     }
-    block_sort_desc<MCAP, NT>(buf, tid);
-    // count real entries among the first k (kEmpty sorts last)
-    int n = cnt < k ? cnt : k;
-    __shared__ int s_n;
-    if (tid == 0) s_n = 0;
+    // sort the survivors
+    int np2s = 64;
+    while (np2s < cnt) np2s <<= 1;
+    for (int j = cnt + tid; j < np2s; j += NT) buf[j] = kEmpty;
     __syncthreads();
-    if (tid < n && buf[tid] != kEmpty && (tid + 1 == n || buf[tid + 1] == kEmpty)) s_n = tid + 1;
-    __syncthreads();
-    n = s_n;
+    if (np2s <= 512) {
+        if (tid < 64) wave_sort_desc_rt(buf, np2s, lane);
+        __syncthreads();
+    } else {
+        block_sort_desc_rt<NT>(buf, np2s, tid);
+    }
+    const int n = cnt < k ? cnt : k;  // every survivor is a real entry
     for (int j = tid; j < (int)args.out_stride; j += NT) {
         const u64 c = j < n ? buf[j] : kEmpty;
         if (args.out_rows) args.out_rows[(size_t)q * args.out_stride + j] = (uint32_t)c;
@@ -544,10 +623,10 @@ size_t scan_lds_bytes(int dim, int nq, int kcap) {
     return (((size_t)nq * dim * 4 + 15) & ~(size_t)15) + (size_t)kWavesPerBlock * nq * (2 * kcap) * 8;
 }
 
-template <int DIM_CT, int NQ, int KCAP>
+template <int DIM_CT, int NQ, int KCAP, bool NT_LOADS = false>
 static hipError_t launch_scan_t(const ScanArgs& args, int grid, hipStream_t stream) {
     const size_t lds = scan_lds_bytes(DIM_CT ? DIM_CT : (int)args.dim, NQ, KCAP);
-    auto kern = scan_topk_kernel<DIM_CT, NQ, KCAP>;
+    auto kern = scan_topk_kernel<DIM_CT, NQ, KCAP, NT_LOADS>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -558,7 +637,9 @@ static hipError_t launch_scan_t(const ScanArgs& args, int grid, hipStream_t stre
 }
 
 template <int NQ, int KCAP>
-static hipError_t launch_scan_dim(const ScanArgs& args, int grid, hipStream_t stream, bool force_runtime_dim) {
+static hipError_t launch_scan_dim(const ScanArgs& args, int grid, hipStream_t stream, bool force_runtime_dim,
+                                  bool plain_loads /* variant 2: nontemporal loads (A/B only) */) {
+    if (plain_loads && args.dim == 384) return launch_scan_t<384, NQ, KCAP, true>(args, grid, stream);  // A/B: nt loads
     if (!force_runtime_dim) {
         switch (args.dim) {
             case 128: return launch_scan_t<128, NQ, KCAP>(args, grid, stream);
@@ -572,9 +653,10 @@ static hipError_t launch_scan_dim(const ScanArgs& args, int grid, hipStream_t st
 }
 
 hipError_t launch_scan_topk(const ScanArgs& args, int nq, int kcap, int grid, hipStream_t stream,
-                            bool force_runtime_dim) {
+                            bool force_runtime_dim, bool plain_loads) {
 #define FSGPU_DISPATCH(NQ_, KCAP_) \
-    if (nq == NQ_ && kcap == KCAP_) return launch_scan_dim<NQ_, KCAP_>(args, grid, stream, force_runtime_dim);
+    if (nq == NQ_ && kcap == KCAP_)  \
+        return launch_scan_dim<NQ_, KCAP_>(args, grid, stream, force_runtime_dim, plain_loads);
     FSGPU_DISPATCH(1, 64)
     FSGPU_DISPATCH(2, 64)
     FSGPU_DISPATCH(4, 64)

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/fsgpu.h"
@@ -319,6 +320,10 @@ SearchError VectorIndex::fused_search(const float* queries_dev, uint32_t nq, uin
         if (scan_lds_bytes((int)dim_, pass, kcap) > 150 * 1024) pass = 1;
         const int per_cu = scan_occupancy_blocks_per_cu((int)dim_, pass, kcap, variant == 1);
         int grid = num_cus_ * per_cu;
+        if (const char* env = std::getenv("FSGPU_GRID_BLOCKS")) {  // tuning experiments only
+            const int forced = std::atoi(env);
+            if (forced > 0) grid = forced;
+        }
         const uint32_t ntiles_pass = (uint32_t)((nrows_ + (16 / pass) - 1) / (16 / pass));
         const int max_useful = (int)((ntiles_pass + 3) / 4);
         if (grid > max_useful) grid = max_useful;
@@ -333,7 +338,7 @@ SearchError VectorIndex::fused_search(const float* queries_dev, uint32_t nq, uin
             FSGPU_HIP(hipEventCreate(&e1));
             FSGPU_HIP(hipEventRecord(e0, stream));
         }
-        FSGPU_HIP(launch_scan_topk(a, pass, kcap, grid, stream, variant == 1));
+        FSGPU_HIP(launch_scan_topk(a, pass, kcap, grid, stream, variant == 1, variant == 2));
         if (profiling) {
             FSGPU_HIP(hipEventRecord(e1, stream));
             events_.emplace_back(e0, e1);
