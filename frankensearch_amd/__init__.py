@@ -4,11 +4,11 @@ The product is the HIP library `libfsgpu.so` (C ABI in include/fsgpu.h); this pa
 host-side mirror of the reference's VectorIndex / embedder interfaces used by tests and bench.py.
 """
 from . import _lib
-from .embed import Model2VecEmbedder
+from .embed import Model2VecEmbedder, NativeEmbedder
 from .errors import (DeviceError, DimensionMismatch, IndexCorrupted, IndexVersionMismatch, InvalidConfig, IoError,
                      NoDevice, SearchError)
 from .index import ClassifiedHits, VectorHit, VectorIndex, encode_f32_to_f16, pack_bitmap, widen_f16_to_f32
 
-__all__ = ["VectorIndex", "VectorHit", "ClassifiedHits", "Model2VecEmbedder", "SearchError", "DimensionMismatch",
+__all__ = ["VectorIndex", "VectorHit", "ClassifiedHits", "Model2VecEmbedder", "NativeEmbedder", "SearchError", "DimensionMismatch",
            "InvalidConfig", "IndexCorrupted", "IndexVersionMismatch", "IoError", "DeviceError", "NoDevice",
            "encode_f32_to_f16", "widen_f16_to_f32", "pack_bitmap", "_lib"]

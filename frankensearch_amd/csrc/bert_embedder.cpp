@@ -1,0 +1,201 @@
+// bert_embedder.cpp — orchestration of the BERT forward on one GPU (see bert_kernels.hip for the arithmetic).
+// Layer order follows encoder_layer_raw (crates/frankensearch-rerank/src/native.rs:587-626).
+#include "bert_embedder.hpp"
+
+#include <string>
+
+namespace fsgpu {
+
+namespace {
+SearchError err(int32_t code, std::string detail) {
+    SearchError e;
+    e.code = code;
+    e.detail = std::move(detail);
+    return e;
+}
+SearchError hip_err(hipError_t e, const char* what) {
+    return err(FSGPU_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define BERT_HIP(expr)                                   \
+    do {                                                 \
+        hipError_t _e = (expr);                          \
+        if (_e != hipSuccess) return hip_err(_e, #expr); \
+    } while (0)
+#define BERT_TRY(expr)           \
+    do {                         \
+        SearchError _s = (expr); \
+        if (!_s.ok()) return _s; \
+    } while (0)
+}  // namespace
+
+NativeEmbedder::~NativeEmbedder() {
+    if (device_ >= 0) (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+    for (DeviceBuffer* b : {&word_, &pos_, &type_, &emb_ln_w_, &emb_ln_b_, &ids_, &positions_, &offsets_, &x_f32_, &x_h_,
+                            &qkv_f32_, &ctx_h_, &tmp_f32_, &inter_h_, &out_})
+        b->release();
+    for (Layer& l : layers_)
+        for (DeviceBuffer* b : {&l.qkv_w, &l.ao_w, &l.i_w, &l.o_w, &l.qkv_b, &l.ao_b, &l.ln1_w, &l.ln1_b, &l.i_b, &l.o_b,
+                                &l.ln2_w, &l.ln2_b})
+            b->release();
+}
+
+SearchError NativeEmbedder::upload_f32(DeviceBuffer& dst, const float* src, size_t n) {
+    if (!src) return err(FSGPU_ERR_NULL_ARGUMENT, "missing weight tensor");
+    BERT_TRY(dst.reserve(n * 4));
+    BERT_HIP(hipMemcpy(dst.ptr, src, n * 4, hipMemcpyHostToDevice));
+    return SearchError{};
+}
+
+SearchError NativeEmbedder::upload_f16(DeviceBuffer& dst, const float* src, size_t n, DeviceBuffer& staging) {
+    if (!src) return err(FSGPU_ERR_NULL_ARGUMENT, "missing weight tensor");
+    BERT_TRY(staging.reserve(n * 4));
+    BERT_TRY(dst.reserve(n * 2));
+    BERT_HIP(hipMemcpy(staging.ptr, src, n * 4, hipMemcpyHostToDevice));
+    BERT_HIP(launch_bert_to_half(static_cast<const float*>(staging.ptr), dst.ptr, n, nullptr));
+    BERT_HIP(hipDeviceSynchronize());
+    return SearchError{};
+}
+
+SearchError NativeEmbedder::init(int device, const fsgpu_bert_config& cfg, const fsgpu_bert_weights& w) {
+    if (cfg.hidden == 0 || cfg.hidden % 128 != 0 || cfg.hidden > 1024)
+        return err(FSGPU_ERR_INVALID_CONFIG, "hidden must be a multiple of 128 and <= 1024");
+    if (cfg.heads * 32 != cfg.hidden) return err(FSGPU_ERR_INVALID_CONFIG, "head dimension must be 32");
+    if (cfg.inter == 0 || cfg.inter % 128 != 0) return err(FSGPU_ERR_INVALID_CONFIG, "inter must be a multiple of 128");
+    if (cfg.layers == 0 || cfg.vocab == 0 || cfg.max_pos == 0 || cfg.max_pos > 512)
+        return err(FSGPU_ERR_INVALID_CONFIG, "layers/vocab must be non-zero and max_pos in 1..=512");
+    if (!w.layers) return err(FSGPU_ERR_NULL_ARGUMENT, "layer weights are null");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return err(FSGPU_ERR_NO_DEVICE, "no HIP device visible (libfsgpu has no CPU fallback)");
+    if (device < 0 || device >= count) return err(FSGPU_ERR_INVALID_CONFIG, "device ordinal out of range");
+    BERT_HIP(hipSetDevice(device));
+    device_ = device;
+    cfg_ = cfg;
+    BERT_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    const size_t H = cfg.hidden, I = cfg.inter;
+    BERT_TRY(upload_f32(word_, w.word_emb, (size_t)cfg.vocab * H));
+    BERT_TRY(upload_f32(pos_, w.pos_emb, (size_t)cfg.max_pos * H));
+    BERT_TRY(upload_f32(type_, w.type_emb, H));  // token type 0 only (single text, native.rs:1166)
+    BERT_TRY(upload_f32(emb_ln_w_, w.emb_ln_w, H));
+    BERT_TRY(upload_f32(emb_ln_b_, w.emb_ln_b, H));
+    DeviceBuffer staging;
+    layers_.resize(cfg.layers);
+    for (uint32_t i = 0; i < cfg.layers; ++i) {
+        const fsgpu_bert_layer_weights& lw = w.layers[i];
+        Layer& l = layers_[i];
+        // Q/K/V stacked to [3H, H] (parse_weights, native.rs:1500-1540)
+        if (!lw.q_w || !lw.k_w || !lw.v_w || !lw.q_b || !lw.k_b || !lw.v_b) {
+            staging.release();
+            return err(FSGPU_ERR_NULL_ARGUMENT, "missing q/k/v weights");
+        }
+        std::vector<float> stacked(3 * H * H), sb(3 * H);
+        std::copy(lw.q_w, lw.q_w + H * H, stacked.begin());
+        std::copy(lw.k_w, lw.k_w + H * H, stacked.begin() + H * H);
+        std::copy(lw.v_w, lw.v_w + H * H, stacked.begin() + 2 * H * H);
+        std::copy(lw.q_b, lw.q_b + H, sb.begin());
+        std::copy(lw.k_b, lw.k_b + H, sb.begin() + H);
+        std::copy(lw.v_b, lw.v_b + H, sb.begin() + 2 * H);
+        SearchError e = upload_f16(l.qkv_w, stacked.data(), stacked.size(), staging);
+        if (e.ok()) e = upload_f32(l.qkv_b, sb.data(), sb.size());
+        if (e.ok()) e = upload_f16(l.ao_w, lw.ao_w, H * H, staging);
+        if (e.ok()) e = upload_f32(l.ao_b, lw.ao_b, H);
+        if (e.ok()) e = upload_f32(l.ln1_w, lw.ln1_w, H);
+        if (e.ok()) e = upload_f32(l.ln1_b, lw.ln1_b, H);
+        if (e.ok()) e = upload_f16(l.i_w, lw.i_w, I * H, staging);
+        if (e.ok()) e = upload_f32(l.i_b, lw.i_b, I);
+        if (e.ok()) e = upload_f16(l.o_w, lw.o_w, H * I, staging);
+        if (e.ok()) e = upload_f32(l.o_b, lw.o_b, H);
+        if (e.ok()) e = upload_f32(l.ln2_w, lw.ln2_w, H);
+        if (e.ok()) e = upload_f32(l.ln2_b, lw.ln2_b, H);
+        if (!e.ok()) {
+            staging.release();
+            return e;
+        }
+    }
+    staging.release();
+    return SearchError{};
+}
+
+SearchError NativeEmbedder::forward(uint32_t n_docs, uint32_t tokens, uint32_t max_seq) {
+    const int H = (int)cfg_.hidden, I = (int)cfg_.inter, T = (int)tokens;
+    const float eps = cfg_.ln_eps;
+    BERT_TRY(x_f32_.reserve((size_t)T * H * 4));
+    BERT_TRY(x_h_.reserve((size_t)T * H * 2));
+    BERT_TRY(qkv_f32_.reserve((size_t)T * 3 * H * 4));
+    BERT_TRY(ctx_h_.reserve((size_t)T * H * 2));
+    BERT_TRY(tmp_f32_.reserve((size_t)T * H * 4));
+    BERT_TRY(inter_h_.reserve((size_t)T * I * 2));
+    float* x = static_cast<float*>(x_f32_.ptr);
+    float* tmp = static_cast<float*>(tmp_f32_.ptr);
+    float* qkv = static_cast<float*>(qkv_f32_.ptr);
+    const uint32_t* offs = static_cast<const uint32_t*>(offsets_.ptr);
+    BERT_HIP(launch_bert_embed_ln(static_cast<const int32_t*>(ids_.ptr), static_cast<const int32_t*>(positions_.ptr),
+                                  static_cast<const float*>(word_.ptr), static_cast<const float*>(pos_.ptr),
+                                  static_cast<const float*>(type_.ptr), static_cast<const float*>(emb_ln_w_.ptr),
+                                  static_cast<const float*>(emb_ln_b_.ptr), x, x_h_.ptr, T, H, eps, stream_));
+    const float scale = 0.17677669f;  // ATTN_SCALE_F32 = 1/sqrt(32) (native.rs:44)
+    for (Layer& l : layers_) {
+        BERT_HIP(launch_bert_gemm(x_h_.ptr, l.qkv_w.ptr, static_cast<const float*>(l.qkv_b.ptr), qkv, nullptr, T, 3 * H, H,
+                                  false, stream_));
+        BERT_HIP(launch_bert_attention(qkv, offs, ctx_h_.ptr, (int)n_docs, (int)cfg_.heads, H, (int)max_seq, scale,
+                                       stream_));
+        BERT_HIP(launch_bert_gemm(ctx_h_.ptr, l.ao_w.ptr, static_cast<const float*>(l.ao_b.ptr), tmp, nullptr, T, H, H,
+                                  false, stream_));
+        BERT_HIP(launch_bert_add_ln(x, tmp, static_cast<const float*>(l.ln1_w.ptr), static_cast<const float*>(l.ln1_b.ptr),
+                                    x_h_.ptr, T, H, eps, stream_));
+        BERT_HIP(launch_bert_gemm(x_h_.ptr, l.i_w.ptr, static_cast<const float*>(l.i_b.ptr), nullptr, inter_h_.ptr, T, I, H,
+                                  true, stream_));
+        BERT_HIP(launch_bert_gemm(inter_h_.ptr, l.o_w.ptr, static_cast<const float*>(l.o_b.ptr), tmp, nullptr, T, H, I,
+                                  false, stream_));
+        BERT_HIP(launch_bert_add_ln(x, tmp, static_cast<const float*>(l.ln2_w.ptr), static_cast<const float*>(l.ln2_b.ptr),
+                                    x_h_.ptr, T, H, eps, stream_));
+    }
+    BERT_HIP(launch_bert_pool(x, offs, static_cast<float*>(out_.ptr), (int)n_docs, H, stream_));
+    return SearchError{};
+}
+
+SearchError NativeEmbedder::embed_batch(const int32_t* ids, const uint32_t* offsets, uint32_t n, float* out) {
+    if (n == 0) return SearchError{};
+    if (!offsets || !out) return err(FSGPU_ERR_NULL_ARGUMENT, "offsets/out is null");
+    std::lock_guard<std::mutex> lock(mu_);
+    uint32_t max_seq = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (offsets[i + 1] < offsets[i]) return err(FSGPU_ERR_INVALID_CONFIG, "offsets must be non-decreasing");
+        const uint32_t len = offsets[i + 1] - offsets[i];
+        if (len > cfg_.max_pos)
+            return err(FSGPU_ERR_INVALID_CONFIG, "sequence longer than max_position_embeddings (truncate to 512 first)");
+        if (len > max_seq) max_seq = len;
+    }
+    const uint32_t base = offsets[0];
+    const uint32_t total = offsets[n] - base;
+    const size_t H = cfg_.hidden;
+    if (total == 0) {  // every text empty -> zeros (native.rs:1146-1148)
+        std::fill(out, out + (size_t)n * H, 0.0f);
+        return SearchError{};
+    }
+    if (!ids) return err(FSGPU_ERR_NULL_ARGUMENT, "ids is null");
+    std::vector<int32_t> positions(total);
+    std::vector<uint32_t> offs(n + 1);
+    for (uint32_t i = 0; i <= n; ++i) offs[i] = offsets[i] - base;
+    for (uint32_t i = 0; i < n; ++i)
+        for (uint32_t t = offs[i]; t < offs[i + 1]; ++t) {
+            const int32_t id = ids[base + t];
+            if (id < 0 || (uint32_t)id >= cfg_.vocab) return err(FSGPU_ERR_INVALID_CONFIG, "token id out of vocabulary");
+            positions[t] = (int32_t)(t - offs[i]);  // positions restart at 0 per input (native.rs:1159-1167)
+        }
+    BERT_HIP(hipSetDevice(device_));
+    BERT_TRY(ids_.reserve((size_t)total * 4));
+    BERT_TRY(positions_.reserve((size_t)total * 4));
+    BERT_TRY(offsets_.reserve((size_t)(n + 1) * 4));
+    BERT_TRY(out_.reserve((size_t)n * H * 4));
+    BERT_HIP(hipMemcpyAsync(ids_.ptr, ids + base, (size_t)total * 4, hipMemcpyHostToDevice, stream_));
+    BERT_HIP(hipMemcpyAsync(positions_.ptr, positions.data(), (size_t)total * 4, hipMemcpyHostToDevice, stream_));
+    BERT_HIP(hipMemcpyAsync(offsets_.ptr, offs.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, stream_));
+    BERT_TRY(forward(n, total, max_seq));
+    BERT_HIP(hipMemcpyAsync(out, out_.ptr, (size_t)n * H * 4, hipMemcpyDeviceToHost, stream_));
+    BERT_HIP(hipStreamSynchronize(stream_));
+    return SearchError{};
+}
+
+}  // namespace fsgpu

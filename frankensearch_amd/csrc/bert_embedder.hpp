@@ -1,0 +1,42 @@
+// bert_embedder.hpp — host side of the GPU MiniLM-class embedder; mirrors the reference's NativeEmbedder
+// (crates/frankensearch-rerank/src/native_embedder.rs:40-50,173-255: embed_sync / embed_batch_sync over token
+// ids) and the weight contract of parse_weights (crates/frankensearch-rerank/src/native.rs:1359-1602).
+#pragma once
+
+#include <cstdint>
+#include <mutex>
+#include <vector>
+
+#include "../../include/fsgpu.h"
+#include "vector_index.hpp"
+
+namespace fsgpu {
+
+class NativeEmbedder {
+  public:
+    ~NativeEmbedder();
+    SearchError init(int device, const fsgpu_bert_config& cfg, const fsgpu_bert_weights& w);
+    // ids: concatenated token ids; text i owns ids[offsets[i]..offsets[i+1]).  out: [n, hidden] f32.
+    SearchError embed_batch(const int32_t* ids, const uint32_t* offsets, uint32_t n, float* out);
+    uint32_t dimension() const { return cfg_.hidden; }
+
+  private:
+    struct Layer {
+        DeviceBuffer qkv_w, ao_w, i_w, o_w;              // f16 [N,K]
+        DeviceBuffer qkv_b, ao_b, ln1_w, ln1_b, i_b, o_b, ln2_w, ln2_b;  // f32
+    };
+    SearchError upload_f32(DeviceBuffer& dst, const float* src, size_t n);
+    SearchError upload_f16(DeviceBuffer& dst, const float* src, size_t n, DeviceBuffer& staging);
+    SearchError forward(uint32_t n_docs, uint32_t tokens, uint32_t max_seq);
+
+    std::mutex mu_;
+    int device_ = -1;
+    fsgpu_bert_config cfg_{};
+    hipStream_t stream_ = nullptr;
+    DeviceBuffer word_, pos_, type_, emb_ln_w_, emb_ln_b_;
+    std::vector<Layer> layers_;
+    // workspaces
+    DeviceBuffer ids_, positions_, offsets_, x_f32_, x_h_, qkv_f32_, ctx_h_, tmp_f32_, inter_h_, out_;
+};
+
+}  // namespace fsgpu

@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 
+#include "bert_embedder.hpp"
 #include "vector_index.hpp"
 
 struct fsgpu_index {
@@ -16,6 +17,9 @@ struct fsgpu_index {
 };
 struct fsgpu_m2v {
     fsgpu::Model2VecEmbedder impl;
+};
+struct fsgpu_bert {
+    fsgpu::NativeEmbedder impl;
 };
 
 namespace {
@@ -329,6 +333,29 @@ fsgpu_status fsgpu_m2v_create(int32_t device, const float* table, uint32_t vocab
 void fsgpu_m2v_destroy(fsgpu_m2v* m) { delete m; }
 
 fsgpu_status fsgpu_m2v_embed(fsgpu_m2v* m, const uint32_t* ids, const uint32_t* offsets, uint32_t n, float* out) {
+    if (!m) return fail(FSGPU_ERR_NULL_ARGUMENT, "embedder is null");
+    return guarded([&]() -> fsgpu_status { return finish(m->impl.embed_batch(ids, offsets, n, out)); });
+}
+
+fsgpu_status fsgpu_bert_create(int32_t device, const fsgpu_bert_config* config, const fsgpu_bert_weights* weights,
+                               fsgpu_bert** out) {
+    if (!out || !config || !weights) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    *out = nullptr;
+    return guarded([&]() -> fsgpu_status {
+        auto* h = new fsgpu_bert();
+        fsgpu::SearchError e = h->impl.init(device, *config, *weights);
+        if (!e.ok()) {
+            delete h;
+            return finish(e);
+        }
+        *out = h;
+        return FSGPU_OK;
+    });
+}
+
+void fsgpu_bert_destroy(fsgpu_bert* m) { delete m; }
+
+fsgpu_status fsgpu_bert_embed(fsgpu_bert* m, const int32_t* ids, const uint32_t* offsets, uint32_t n, float* out) {
     if (!m) return fail(FSGPU_ERR_NULL_ARGUMENT, "embedder is null");
     return guarded([&]() -> fsgpu_status { return finish(m->impl.embed_batch(ids, offsets, n, out)); });
 }

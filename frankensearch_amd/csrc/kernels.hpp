@@ -58,4 +58,18 @@ hipError_t sort_keys_desc(void* temp, size_t temp_bytes, const u64* keys_in, u64
 hipError_t launch_m2v_embed(const float* table, uint32_t vocab, uint32_t dim, const uint32_t* ids,
                             const uint32_t* offsets, uint32_t n, float* out, hipStream_t stream);
 
+// bert_kernels.hip
+hipError_t launch_bert_embed_ln(const int32_t* ids, const int32_t* positions, const float* word, const float* pos,
+                                const float* type0, const float* lnw, const float* lnb, float* x_f32, void* x_h,
+                                int tokens, int hidden, float eps, hipStream_t stream);
+hipError_t launch_bert_add_ln(float* x_f32, const float* delta, const float* lnw, const float* lnb, void* x_h, int tokens,
+                              int hidden, float eps, hipStream_t stream);
+hipError_t launch_bert_gemm(const void* a_h, const void* w_h, const float* bias, float* out_f32, void* out_h, int M,
+                            int N, int K, bool gelu_half_out, hipStream_t stream);
+hipError_t launch_bert_attention(const float* qkv, const uint32_t* offsets, void* ctx_h, int n_docs, int heads,
+                                 int hidden, int max_seq, float scale, hipStream_t stream);
+hipError_t launch_bert_pool(const float* x, const uint32_t* offsets, float* out, int n_docs, int hidden,
+                            hipStream_t stream);
+hipError_t launch_bert_to_half(const float* src, void* dst, size_t n, hipStream_t stream);
+
 }  // namespace fsgpu

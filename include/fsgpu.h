@@ -55,6 +55,26 @@ typedef int32_t fsgpu_status;
 
 typedef struct fsgpu_index fsgpu_index;     /* device-resident VectorIndex (lib.rs:819) */
 typedef struct fsgpu_m2v fsgpu_m2v;         /* Model2VecEmbedder (embed/src/model2vec_embedder.rs:55) */
+typedef struct fsgpu_bert fsgpu_bert;       /* NativeEmbedder (rerank/src/native_embedder.rs:40-50) */
+
+/* BERT shape (all-MiniLM-L6-v2: vocab 30522, hidden 384, layers 6, heads 12, inter 1536, max_pos 512,
+ * ln_eps 1e-12; crates/frankensearch-rerank/src/native.rs:36-45).  heads*32 must equal hidden. */
+typedef struct fsgpu_bert_config {
+    uint32_t vocab, hidden, layers, heads, inter, max_pos;
+    float ln_eps;
+} fsgpu_bert_config;
+/* One encoder layer in HuggingFace tensor layout ([out, in] row-major f32), the keys parse_weights reads
+ * (native.rs:1359-1602): attention.self.{query,key,value}, attention.output.{dense,LayerNorm},
+ * intermediate.dense, output.{dense,LayerNorm}. */
+typedef struct fsgpu_bert_layer_weights {
+    const float *q_w, *q_b, *k_w, *k_b, *v_w, *v_b;
+    const float *ao_w, *ao_b, *ln1_w, *ln1_b;
+    const float *i_w, *i_b, *o_w, *o_b, *ln2_w, *ln2_b;
+} fsgpu_bert_layer_weights;
+typedef struct fsgpu_bert_weights {
+    const float *word_emb, *pos_emb, *type_emb, *emb_ln_w, *emb_ln_b;
+    const fsgpu_bert_layer_weights *layers; /* [config.layers] */
+} fsgpu_bert_weights;
 
 /* ---- library ---- */
 const char *fsgpu_version(void);
@@ -142,6 +162,17 @@ void fsgpu_m2v_destroy(fsgpu_m2v *m);
 /* embed_batch_sync over token ids (model2vec_embedder.rs:310-335,409-419,435-451): text i owns
  * ids[offsets[i]..offsets[i+1]); out is [n,dim].  Empty / all-OOV texts give zeros. */
 fsgpu_status fsgpu_m2v_embed(fsgpu_m2v *m, const uint32_t *ids, const uint32_t *offsets, uint32_t n, float *out);
+
+/* ---- MiniLM-class BERT embedder ---- */
+/* NativeEmbedder::load (native_embedder.rs:60-116): copies the weights to the GPU (linears as f16). */
+fsgpu_status fsgpu_bert_create(int32_t device, const fsgpu_bert_config *config, const fsgpu_bert_weights *weights,
+                               fsgpu_bert **out);
+void fsgpu_bert_destroy(fsgpu_bert *m);
+/* embed_batch_sync over token ids (native_embedder.rs:218-255 -> Model::embed_forward native.rs:1142-1236):
+ * text i owns ids[offsets[i]..offsets[i+1]) (already tokenised WITH special tokens and truncated to <= 512,
+ * no padding); every returned token is mean-pooled, then L2-normalised (zeros for empty / zero-norm,
+ * fastembed_embedder.rs:416-426).  out is [n, hidden]. */
+fsgpu_status fsgpu_bert_embed(fsgpu_bert *m, const int32_t *ids, const uint32_t *offsets, uint32_t n, float *out);
 
 /* ---- instrumentation ---- */
 /* When enabled, HIP events bracket the scan kernel of every fsgpu_search_topk* call. */

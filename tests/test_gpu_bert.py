@@ -1,0 +1,89 @@
+"""GPU MiniLM-class encoder vs the f32 oracle and the transformers golden vectors.
+Tolerance: cosine >= 0.999 and max-abs <= 2e-3 on unit vectors (f16 MFMA linears, f32 elsewhere)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bert_golden.npz")
+COS_MIN, ABS_MAX = 0.999, 2e-3
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import frankensearch_amd as fa_mod
+    from frankensearch_amd.build import build
+    build()
+    return fa_mod
+
+
+def check(got, want):
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) <= ABS_MAX, np.max(np.abs(got - want))
+    nz = np.linalg.norm(want, axis=1) > 0
+    assert np.all(np.sum(got[nz] * want[nz], axis=1) >= COS_MIN)
+    assert np.all(got[~nz] == 0)
+
+
+def golden_batch(g):
+    out, o = [], 0
+    for n in g["batch_lens"]:
+        out.append(g["batch_ids"][o:o + n].tolist())
+        o += n
+    return out
+
+
+@pytest.mark.parametrize("name", ["tiny", "minilm_shape"])
+def test_matches_transformers_golden(fa, name):
+    from oracle import bert_oracle
+    g = np.load(GOLD)
+    seed, vocab, hidden, layers, inter = (int(x) for x in g[f"{name}_config"])
+    w = bert_oracle.random_weights(seed, vocab, hidden, layers, inter)
+    m = fa.NativeEmbedder(w)
+    check(m.embed_batch_token_ids(golden_batch(g)), g[f"{name}_expected"])
+
+
+def test_matches_oracle_on_ragged_batches(fa):
+    from oracle import bert_oracle
+    rng = np.random.default_rng(7)
+    w = bert_oracle.random_weights(21, 2000, 384, 6, 1536)
+    m = fa.NativeEmbedder(w)
+    lens = [1, 2, 3, 8, 16, 17, 31, 32, 33, 63, 64, 65, 100, 128, 200, 0, 5]
+    batch = [[101] + rng.integers(1000, 2000, max(n - 2, 0)).tolist() + ([102] if n > 1 else []) if n else [] for n in lens]
+    batch = [b[:n] for b, n in zip(batch, lens)]
+    got = m.embed_batch_token_ids(batch)
+    want = bert_oracle.embed_forward(w, batch, 6)
+    check(got, want)
+    assert np.allclose(np.linalg.norm(got[[i for i, n in enumerate(lens) if n]], axis=1), 1.0, atol=1e-4)
+    # single == batch (native_embedder.rs:308-333)
+    single = m.embed_token_ids(batch[9])
+    assert np.sum(single * got[9]) > 0.99999
+    # all-empty batch -> zeros
+    assert np.all(m.embed_batch_token_ids([[], []]) == 0)
+
+
+def test_max_length_512_and_errors(fa):
+    from oracle import bert_oracle
+    rng = np.random.default_rng(9)
+    w = bert_oracle.random_weights(22, 500, 128, 2, 512)
+    m = fa.NativeEmbedder(w)
+    long = [101] + rng.integers(1, 500, 510).tolist() + [102]
+    got = m.embed_batch_token_ids([long, long[:300]])
+    check(got, bert_oracle.embed_forward(w, [long, long[:300]], 2))
+    with pytest.raises(fa.InvalidConfig):
+        m.embed_token_ids(long + [5])          # > 512 tokens: caller must truncate (native.rs:45)
+    with pytest.raises(fa.InvalidConfig):
+        m.embed_token_ids([101, 9999, 102])    # id outside the vocabulary
+
+
+def test_batch_256_queries_config5_shape(fa):
+    """BASELINE config 5 shape: 256 queries, lengths uniform 8..32 incl. [CLS]=101/[SEP]=102."""
+    from oracle import bert_oracle
+    rng = np.random.default_rng(11)
+    w = bert_oracle.random_weights(23, 30522, 384, 6, 1536)
+    m = fa.NativeEmbedder(w)
+    batch = [[101] + rng.integers(1000, 30000, int(rng.integers(6, 31))).tolist() + [102] for _ in range(256)]
+    got = m.embed_batch_token_ids(batch)
+    want = bert_oracle.embed_forward(w, batch[:24], 6)
+    check(got[:24], want)
