@@ -227,40 +227,29 @@ fsgpu_status fsgpu_search_topk_classified(fsgpu_index* idx, const float* query, 
     return st;
 }
 
-// search_top_k -> resolve_sorted_entries (search.rs:1503-1558): post-top-k doc-id dedup, first wins.
+// search_top_k -> scan_wal -> resolve_sorted_entries (search.rs:426-494, 1449-1475, 1503-1558).
 fsgpu_status fsgpu_search_hits(fsgpu_index* idx, const float* query, uint32_t query_len, uint32_t k,
                                uint32_t* out_rows, float* out_scores, uint32_t* out_count) {
     if (!idx || !query || !out_count) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
     *out_count = 0;
-    if (!idx->impl.has_doc_ids()) return fail(FSGPU_ERR_INVALID_CONFIG, "index has no doc-id table");
+    if (k && (!out_rows || !out_scores)) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
     return guarded([&]() -> fsgpu_status {
-        std::vector<uint32_t> rows(k ? k : 1);
-        std::vector<float> scores(k ? k : 1);
-        uint32_t count = 0;
-        fsgpu_status st = fsgpu_search_topk(idx, query, 1, query_len, k, nullptr, rows.data(), scores.data(), &count);
-        if (st != FSGPU_OK) return st;
-        uint32_t n = 0;
-        for (uint32_t i = 0; i < count; ++i) {
-            const char* di = nullptr;
-            uint32_t li = 0;
-            fsgpu::SearchError e = idx->impl.doc_id_at(rows[i], &di, &li);
-            if (!e.ok()) return finish(e);
-            bool dup = false;
-            for (uint32_t j = 0; j < n && !dup; ++j) {
-                const char* dj = nullptr;
-                uint32_t lj = 0;
-                (void)idx->impl.doc_id_at(out_rows[j], &dj, &lj);
-                dup = (lj == li) && std::memcmp(di, dj, li) == 0;
-            }
-            if (dup) continue;
-            out_rows[n] = rows[i];
-            out_scores[n] = scores[i];
-            ++n;
-        }
-        *out_count = n;
-        return FSGPU_OK;
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.search_hits(query, query_len, k, out_rows, out_scores, out_count));
     });
 }
+
+// VectorIndex::append (lib.rs:2532-2720)
+fsgpu_status fsgpu_index_wal_append(fsgpu_index* idx, const char* doc_id, uint32_t doc_id_len, const float* vector,
+                                    uint32_t vector_len) {
+    if (!idx || !doc_id || !vector) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.wal_append(doc_id, doc_id_len, vector, vector_len));
+    });
+}
+
+uint64_t fsgpu_index_wal_record_count(const fsgpu_index* idx) { return idx ? idx->impl.wal_record_count() : 0; }
 
 fsgpu_status fsgpu_gather_dot(fsgpu_index* idx, const float* query, uint32_t query_len, const uint32_t* rows,
                               uint32_t n, float* out_scores) {

@@ -9,6 +9,7 @@
 #include "vector_index.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -255,9 +256,167 @@ SearchError VectorIndex::open_fsvi(const char* path, int device) {
 
 SearchError VectorIndex::doc_id_at(uint32_t row, const char** ptr, uint32_t* len) const {
     if (doc_offsets_.empty()) return make_error(FSGPU_ERR_INVALID_CONFIG, "index has no doc-id table");
-    if (row >= nrows_) return make_error(FSGPU_ERR_INVALID_CONFIG, "row out of range");
+    if (row >= nrows_) {  // WAL virtual row = record_count + wal index (search.rs:1579-1596)
+        const uint64_t wi = row - nrows_;
+        if (wi >= wal_.size()) return make_error(FSGPU_ERR_INDEX_CORRUPTED, "WAL index out of bounds");
+        *ptr = wal_[wi].doc_id.data();
+        *len = (uint32_t)wal_[wi].doc_id.size();
+        return ok();
+    }
     *ptr = doc_blob_.data() + doc_offsets_[row];
     *len = (uint32_t)(doc_offsets_[row + 1] - doc_offsets_[row]);
+    return ok();
+}
+
+namespace {
+
+// dot_product_f32_f32 (crates/frankensearch-index/src/simd.rs:134-222), host side (WAL rows stay on the CPU
+// in the reference too): groups of 32 into four 8-lane accumulators, (a0+a1)+(a2+a3), leftover chunks into
+// the sum, horizontal add, scalar tail with separate multiply and add.  Built with -ffp-contract=off.
+float dot_f32_f32(const float* a, const float* b, size_t n, int hreduce) {
+    const size_t groups = n / 32, chunks = n / 8;
+    float acc[4][8] = {};
+    for (size_t g = 0; g < groups; ++g)
+        for (int x = 0; x < 4; ++x)
+            for (int j = 0; j < 8; ++j) {
+                const size_t o = g * 32 + (size_t)x * 8 + (size_t)j;
+                const float p = a[o] * b[o];
+                acc[x][j] = acc[x][j] + p;
+            }
+    float v[8];
+    for (int j = 0; j < 8; ++j) v[j] = (acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j]);
+    for (size_t c = groups * 4; c < chunks; ++c)
+        for (int j = 0; j < 8; ++j) {
+            const float p = a[c * 8 + (size_t)j] * b[c * 8 + (size_t)j];
+            v[j] = v[j] + p;
+        }
+    float result;
+    if (hreduce == FSGPU_HREDUCE_AVX) {
+        const float s0 = v[0] + v[4], s1 = v[1] + v[5], s2 = v[2] + v[6], s3 = v[3] + v[7];
+        const float lo = s0 + s2, hi = s1 + s3;
+        result = lo + hi;
+    } else {
+        const float lo = (v[0] + v[2]) + (v[1] + v[3]);
+        const float hi = (v[4] + v[6]) + (v[5] + v[7]);
+        result = lo + hi;
+    }
+    for (size_t i = chunks * 8; i < n; ++i) {
+        const float p = a[i] * b[i];
+        result = result + p;
+    }
+    return result;
+}
+
+// monotone image of score_key + f32::total_cmp (search.rs:1655-1686); larger = ranks earlier
+uint32_t host_score_ord(float score) {
+    uint32_t bits;
+    std::memcpy(&bits, &score, 4);
+    if ((bits & 0x7fffffffu) > 0x7f800000u) bits = 0xff800000u;
+    return (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+}
+
+}  // namespace
+
+SearchError VectorIndex::wal_append(const char* doc_id, uint32_t len, const float* vector, uint32_t vector_len) {
+    if (doc_offsets_.empty()) return make_error(FSGPU_ERR_INVALID_CONFIG, "index has no doc-id table");
+    if (vector_len != dim_)
+        return make_error(FSGPU_ERR_DIMENSION_MISMATCH,
+                          "expected " + std::to_string(dim_) + ", found " + std::to_string(vector_len));
+    float norm_sq = 0.f;
+    for (uint32_t i = 0; i < vector_len; ++i) {
+        if (!std::isfinite(vector[i]))
+            return make_error(FSGPU_ERR_INVALID_CONFIG, "all embedding values must be finite");
+        const float p = vector[i] * vector[i];
+        norm_sq = norm_sq + p;
+    }
+    if (!(norm_sq > 0.0f) || !std::isfinite(norm_sq))
+        return make_error(FSGPU_ERR_INVALID_CONFIG, "embedding norm must be non-zero and finite");
+    if (len > 0xffffu) return make_error(FSGPU_ERR_INVALID_CONFIG, "doc_id byte length must fit in u16");
+    const std::string id(doc_id, len);
+    // supersede older resident copies (lib.rs:2641-2647), then admit the new entry
+    wal_.erase(std::remove_if(wal_.begin(), wal_.end(), [&](const WalEntry& e) { return e.doc_id == id; }),
+               wal_.end());
+    wal_.push_back(WalEntry{id, std::vector<float>(vector, vector + vector_len)});
+    // tombstone the first live main row with this doc id so it cannot take a top-k slot (lib.rs:2665-2710)
+    const uint64_t h = fnv1a(doc_id, len);
+    auto lo = std::lower_bound(doc_hashes_.begin(), doc_hashes_.end(), h);
+    for (auto it = lo; it != doc_hashes_.end() && *it == h; ++it) {
+        const size_t r = (size_t)(it - doc_hashes_.begin());
+        const size_t dl = (size_t)(doc_offsets_[r + 1] - doc_offsets_[r]);
+        if (dl != len || std::memcmp(doc_blob_.data() + doc_offsets_[r], doc_id, len) != 0) continue;
+        if (live_host_.empty()) live_host_.assign((size_t)((nrows_ + 63) / 64), ~0ull);
+        if ((live_host_[r >> 6] >> (r & 63)) & 1ull) {
+            live_host_[r >> 6] &= ~(1ull << (r & 63));
+            std::vector<uint64_t> copy = live_host_;
+            FSGPU_TRY(set_live_bitmap(copy.data()));
+            break;
+        }
+    }
+    return ok();
+}
+
+SearchError VectorIndex::search_hits(const float* query, uint32_t query_len, uint32_t k, uint32_t* out_rows,
+                                     float* out_scores, uint32_t* out_count) {
+    *out_count = 0;
+    if (doc_offsets_.empty()) return make_error(FSGPU_ERR_INVALID_CONFIG, "index has no doc-id table");
+    FSGPU_TRY(ensure_query_dimension(query_len));
+    if (k == 0 || (nrows_ == 0 && wal_.empty())) return ok();
+    struct Cand {
+        uint64_t index;  // main row, or WAL-tagged (top bit) like wal.rs:557-569
+        float score;
+    };
+    const uint64_t wal_tag = 1ull << 63;
+    std::vector<Cand> cand;
+    if (nrows_ > 0) {
+        std::vector<uint32_t> rows(k);
+        std::vector<float> scores(k);
+        uint32_t count = 0;
+        FSGPU_TRY(search_top_k(query, 1, query_len, k, nullptr, rows.data(), scores.data(), &count));
+        for (uint32_t i = 0; i < count; ++i) cand.push_back(Cand{rows[i], scores[i]});
+    }
+    for (size_t w = 0; w < wal_.size(); ++w) {
+        const float s = dot_f32_f32(wal_[w].embedding.data(), query, dim_, hreduce);
+        if (!std::isfinite(s)) continue;  // search.rs:1466-1470
+        cand.push_back(Cand{wal_tag | w, s});
+    }
+    std::sort(cand.begin(), cand.end(), [](const Cand& a, const Cand& b) {
+        const uint32_t ka = host_score_ord(a.score), kb = host_score_ord(b.score);
+        if (ka != kb) return ka > kb;
+        return a.index < b.index;
+    });
+    if (cand.size() > k) cand.resize(k);  // the size-k heap holds exactly the k best of main U wal
+    uint32_t n = 0;
+    std::vector<std::pair<const char*, uint32_t>> seen;
+    for (const Cand& c : cand) {
+        const char* di = nullptr;
+        uint32_t dl = 0;
+        uint32_t index;
+        if (c.index & wal_tag) {
+            const size_t w = (size_t)(c.index & ~wal_tag);
+            di = wal_[w].doc_id.data();
+            dl = (uint32_t)wal_[w].doc_id.size();
+            index = (uint32_t)(nrows_ + w);
+        } else {
+            const size_t r = (size_t)(c.index - row_base_);
+            if (!live_host_.empty() && !((live_host_[r >> 6] >> (r & 63)) & 1ull)) continue;
+            di = doc_blob_.data() + doc_offsets_[r];
+            dl = (uint32_t)(doc_offsets_[r + 1] - doc_offsets_[r]);
+            bool shadowed = false;
+            for (const WalEntry& e : wal_)
+                if (e.doc_id.size() == dl && std::memcmp(e.doc_id.data(), di, dl) == 0) shadowed = true;
+            if (shadowed) continue;
+            index = (uint32_t)c.index;
+        }
+        bool dup = false;
+        for (auto& sd : seen)
+            if (sd.second == dl && std::memcmp(sd.first, di, dl) == 0) dup = true;
+        if (dup) continue;
+        seen.emplace_back(di, dl);
+        out_rows[n] = index;
+        out_scores[n] = c.score;
+        ++n;
+    }
+    *out_count = n;
     return ok();
 }
 

@@ -59,6 +59,13 @@ class VectorIndex {
                                            const uint64_t* allow_dev, uint64_t* out_packed_dev, hipStream_t stream);
     SearchError gather_dot(const float* query, uint32_t query_len, const uint32_t* rows, uint32_t n, float* out);
 
+    // search_top_k + scan_wal + resolve_hits (search.rs:426-494, 1449-1475, 1493-1558): GPU top-k of the main
+    // rows, host merge of the resident WAL entries, WAL shadowing and doc-id dedup.  Needs a doc-id table.
+    SearchError search_hits(const float* query, uint32_t query_len, uint32_t k, uint32_t* out_rows, float* out_scores,
+                            uint32_t* out_count);
+    // VectorIndex::append (lib.rs:2532-2720): resident WAL entry, immediately searchable.
+    SearchError wal_append(const char* doc_id, uint32_t len, const float* vector, uint32_t vector_len);
+    uint64_t wal_record_count() const { return wal_.size(); }
     SearchError doc_id_at(uint32_t row, const char** ptr, uint32_t* len) const;
     SearchError soft_delete(const char* doc_id, uint32_t len, int32_t* deleted);
     SearchError set_live_bitmap(const uint64_t* live);
@@ -103,6 +110,12 @@ class VectorIndex {
     std::vector<uint64_t> doc_hashes_;
     std::vector<uint64_t> doc_offsets_;  // nrows+1 offsets into doc_blob_
     std::string doc_blob_;
+    // resident WAL entries (crates/frankensearch-index/src/wal.rs WalEntry)
+    struct WalEntry {
+        std::string doc_id;
+        std::vector<float> embedding;
+    };
+    std::vector<WalEntry> wal_;
 };
 
 class Model2VecEmbedder {

@@ -115,6 +115,15 @@ class VectorIndex:
         check(_lib.lib().fsgpu_index_soft_delete(self._h, b, len(b), C.byref(d)))
         return bool(d.value)
 
+    def append(self, doc_id: str, vector: Sequence[float]) -> None:
+        """VectorIndex::append (lib.rs:2532): resident WAL entry, immediately searchable."""
+        b = doc_id.encode()
+        v = np.ascontiguousarray(vector, dtype=np.float32).reshape(-1)
+        check(_lib.lib().fsgpu_index_wal_append(self._h, b, len(b), _ptr(v), v.size))
+
+    def wal_record_count(self) -> int:
+        return _lib.lib().fsgpu_index_wal_record_count(self._h)
+
     def set_live(self, live: Optional[np.ndarray]) -> None:
         bm = pack_bitmap(live) if live is not None else None
         check(_lib.lib().fsgpu_index_set_live_bitmap(self._h, _ptr(bm)))
@@ -141,8 +150,9 @@ class VectorIndex:
         allow mask over rows (bool[N]); doc-id dedup applies when the index has a doc-id table."""
         q = np.ascontiguousarray(query, dtype=np.float32).reshape(-1)
         if filter is None and self._has_doc_ids():
-            rows = np.empty(max(limit, 1), dtype=np.uint32)
-            scores = np.empty(max(limit, 1), dtype=np.float32)
+            cap = max(limit, 1)
+            rows = np.empty(cap, dtype=np.uint32)
+            scores = np.empty(cap, dtype=np.float32)
             n = C.c_uint32()
             check(_lib.lib().fsgpu_search_hits(self._h, _ptr(q), q.size, limit, _ptr(rows), _ptr(scores), C.byref(n)))
             return [VectorHit(int(rows[i]), float(scores[i]), self.doc_id_at(int(rows[i]))) for i in range(n.value)]
@@ -191,7 +201,9 @@ class VectorIndex:
 
     def _has_doc_ids(self) -> bool:
         p, n = C.c_void_p(), C.c_uint32()
-        return self.record_count() > 0 and _lib.lib().fsgpu_index_doc_id(self._h, 0, C.byref(p), C.byref(n)) == 0
+        if self.record_count() + self.wal_record_count() == 0:
+            return False
+        return _lib.lib().fsgpu_index_doc_id(self._h, 0, C.byref(p), C.byref(n)) == 0
 
 
 def encode_f32_to_f16(src: np.ndarray, device: int = 0) -> np.ndarray:

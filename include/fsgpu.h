@@ -103,6 +103,13 @@ fsgpu_status fsgpu_index_set_hreduce(fsgpu_index *idx, int32_t mode);
 fsgpu_status fsgpu_index_doc_id(const fsgpu_index *idx, uint32_t row, const char **ptr, uint32_t *len);
 /* VectorIndex::soft_delete (lib.rs, tombstone flag): clears the live bit(s) of doc_id; *deleted = 1 if any. */
 fsgpu_status fsgpu_index_soft_delete(fsgpu_index *idx, const char *doc_id, uint32_t doc_id_len, int32_t *deleted);
+/* VectorIndex::append (lib.rs:2532-2720): a resident WAL entry (f32 vector, immediately searchable through
+ * fsgpu_search_hits with the reference's scan_wal / shadowing rules, search.rs:1449-1475,1503-1558); supersedes a
+ * resident entry with the same doc id and tombstones the first live main row with that doc id.  The WAL *file*
+ * (durability) stays with the caller.  FSVI-opened indexes only. */
+fsgpu_status fsgpu_index_wal_append(fsgpu_index *idx, const char *doc_id, uint32_t doc_id_len, const float *vector,
+                                    uint32_t vector_len);
+uint64_t fsgpu_index_wal_record_count(const fsgpu_index *idx); /* VectorIndex::wal_record_count */
 /* Replace the live bitmap (host words, ceil(nrows/64)); NULL = all live. */
 fsgpu_status fsgpu_index_set_live_bitmap(fsgpu_index *idx, const uint64_t *live_bitmap);
 
@@ -140,8 +147,10 @@ fsgpu_status fsgpu_merge_topk_device(int32_t device, const uint64_t *lists_dev, 
 fsgpu_status fsgpu_search_topk_classified(fsgpu_index *idx, const float *query, uint32_t query_len, uint32_t k,
                                           uint32_t *out_rows, float *out_scores, uint32_t *out_count,
                                           int32_t *zero_signal);
-/* search_top_k + resolve_hits (search.rs:1493-1558) for FSVI-opened indexes: post-top-k doc-id dedup
- * (first = best wins).  out_* hold up to k entries. */
+/* search_top_k + scan_wal + resolve_hits (search.rs:426-494, 1449-1475, 1493-1558) for FSVI-opened indexes:
+ * GPU top-k of the main rows, merge of the resident WAL entries (dot_product_f32_f32 on the host, as in the
+ * reference), WAL shadowing, post-top-k doc-id dedup (first = best wins).  WAL hits report the virtual row
+ * record_count + wal index.  out_* hold up to k entries. */
 fsgpu_status fsgpu_search_hits(fsgpu_index *idx, const float *query, uint32_t query_len, uint32_t k,
                                uint32_t *out_rows, float *out_scores, uint32_t *out_count);
 /* VectorIndex::dot_query_at (lib.rs:3229-3239) over a row list, as used by

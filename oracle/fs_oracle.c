@@ -162,6 +162,33 @@ float fso_dot_f16_f32(const uint8_t *row, const float *q, size_t dim, int hreduc
     return result;
 }
 
+/* dot_product_f32_f32 (crates/frankensearch-index/src/simd.rs:134-222). */
+float fso_dot_f32_f32(const float *a, const float *b, size_t n, int hreduce) {
+    size_t groups = n / 32, chunks = n / 8;
+    float acc[4][8];
+    memset(acc, 0, sizeof acc);
+    for (size_t g = 0; g < groups; ++g)
+        for (int x = 0; x < 4; ++x)
+            for (int j = 0; j < 8; ++j) {
+                size_t o = g * 32 + (size_t)x * 8 + (size_t)j;
+                float p = a[o] * b[o];
+                acc[x][j] = acc[x][j] + p;
+            }
+    float sum[8];
+    for (int j = 0; j < 8; ++j) sum[j] = (acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j]);
+    for (size_t c = groups * 4; c < chunks; ++c)
+        for (int j = 0; j < 8; ++j) {
+            float p = a[c * 8 + (size_t)j] * b[c * 8 + (size_t)j];
+            sum[j] = sum[j] + p;
+        }
+    float result = hreduce8(sum, hreduce);
+    for (size_t i = chunks * 8; i < n; ++i) {
+        float p = a[i] * b[i];
+        result = result + p;
+    }
+    return result;
+}
+
 /* provided by fs_oracle_avx2.c */
 float fso_dot_f16_f32_avx2_impl(const uint8_t *row, const float *q, size_t dim, int hreduce);
 
@@ -529,6 +556,10 @@ struct fso_fsvi {
     uint64_t vectors_offset;
     size_t records_offset;
     size_t strings_offset;
+    /* resident WAL entries (wal.rs WalEntry: doc_id, doc_id_hash, f32 embedding) */
+    char **wal_ids;
+    float **wal_vecs;
+    size_t wal_len, wal_cap;
 };
 
 typedef struct {
@@ -764,8 +795,62 @@ int fso_fsvi_open(const char *path, fso_fsvi **out) {
 
 void fso_fsvi_close(fso_fsvi *idx) {
     if (!idx) return;
+    for (size_t i = 0; i < idx->wal_len; ++i) {
+        free(idx->wal_ids[i]);
+        free(idx->wal_vecs[i]);
+    }
+    free(idx->wal_ids);
+    free(idx->wal_vecs);
     free(idx->data);
     free(idx);
+}
+
+uint64_t fso_fsvi_wal_count(const fso_fsvi *idx) { return idx->wal_len; }
+uint32_t fso_fsvi_wal_doc_id(const fso_fsvi *idx, uint64_t i, const char **ptr) {
+    *ptr = idx->wal_ids[i];
+    return (uint32_t)strlen(idx->wal_ids[i]);
+}
+
+/* VectorIndex::append -> append_batch_impl (lib.rs:2569-2720) for one entry. */
+int fso_fsvi_append(fso_fsvi *idx, const char *doc_id, const float *vector, size_t len) {
+    if (len != idx->dim) return FSO_ERR_DIMENSION_MISMATCH;
+    for (size_t i = 0; i < len; ++i)
+        if (!isfinite(vector[i])) return FSO_ERR_INVALID_CONFIG;
+    if (!fso_vector_signal_usable(vector, len)) return FSO_ERR_INVALID_CONFIG;
+    size_t dl = strlen(doc_id);
+    if (dl > 0xffff) return FSO_ERR_INVALID_CONFIG;
+    /* supersede older resident copies */
+    size_t w = 0;
+    for (size_t i = 0; i < idx->wal_len; ++i) {
+        if (strcmp(idx->wal_ids[i], doc_id) == 0) {
+            free(idx->wal_ids[i]);
+            free(idx->wal_vecs[i]);
+        } else {
+            idx->wal_ids[w] = idx->wal_ids[i];
+            idx->wal_vecs[w] = idx->wal_vecs[i];
+            ++w;
+        }
+    }
+    idx->wal_len = w;
+    if (idx->wal_len == idx->wal_cap) {
+        idx->wal_cap = idx->wal_cap ? idx->wal_cap * 2 : 8;
+        idx->wal_ids = (char **)realloc(idx->wal_ids, idx->wal_cap * sizeof(char *));
+        idx->wal_vecs = (float **)realloc(idx->wal_vecs, idx->wal_cap * sizeof(float *));
+    }
+    idx->wal_ids[idx->wal_len] = strdup(doc_id);
+    idx->wal_vecs[idx->wal_len] = (float *)malloc(len * sizeof(float));
+    memcpy(idx->wal_vecs[idx->wal_len], vector, len * sizeof(float));
+    idx->wal_len++;
+    /* tombstone the first live main row with this doc id */
+    for (uint64_t r = 0; r < idx->record_count; ++r) {
+        const char *p;
+        uint32_t l = fso_fsvi_doc_id(idx, r, &p);
+        if (l == dl && memcmp(p, doc_id, dl) == 0 && (fso_fsvi_flags(idx, r) & 1u) == 0) {
+            fso_fsvi_set_flags(idx, r, (uint16_t)(fso_fsvi_flags(idx, r) | 1u));
+            break;
+        }
+    }
+    return FSO_OK;
 }
 uint64_t fso_fsvi_record_count(const fso_fsvi *idx) { return idx->record_count; }
 uint32_t fso_fsvi_dimension(const fso_fsvi *idx) { return idx->dim; }
@@ -783,39 +868,81 @@ void fso_fsvi_set_flags(fso_fsvi *idx, uint64_t row, uint16_t flags) {
     put16(idx->data + idx->records_offset + row * 16 + 14, flags);
 }
 
-/* search_top_k (search.rs:192-206) -> resolve_sorted_entries (search.rs:1503-1558):
- * skip tombstoned winners, then keep only the first (= best) hit per doc id. */
+/* search_top_k (search.rs:192-206, 426-494) -> resolve_sorted_entries (search.rs:1503-1558):
+ * main scan (tombstones skipped), WAL entries scored with dot_product_f32_f32 and merged into the same
+ * size-k selection with their WAL-tagged index (always greater than a main index, wal.rs:557-569), then
+ * winners resolved: WAL hits get the virtual index record_count + i, main winners shadowed by a resident WAL
+ * entry with the same doc id are dropped, and only the first (best) hit per doc id is kept. */
 size_t fso_fsvi_search(const fso_fsvi *idx, const float *q, size_t k, int hreduce,
                        uint32_t *out_rows, float *out_scores) {
     uint64_t n = idx->record_count;
-    if (k == 0 || n == 0 || idx->quant != 1) return 0;
+    if (k == 0 || (n == 0 && idx->wal_len == 0) || idx->quant != 1) return 0;
     uint64_t words = (n + 63) / 64;
-    uint64_t *live = (uint64_t *)calloc((size_t)words, 8);
+    uint64_t *live = (uint64_t *)calloc((size_t)(words ? words : 1), 8);
     for (uint64_t r = 0; r < n; ++r)
         if ((fso_fsvi_flags(idx, r) & 1u) == 0) live[r >> 6] |= 1ull << (r & 63);
-    size_t kk = k < n ? k : (size_t)n;
-    uint32_t *rows = (uint32_t *)malloc(sizeof(uint32_t) * (kk ? kk : 1));
-    float *scores = (float *)malloc(sizeof(float) * (kk ? kk : 1));
-    size_t got = fso_search_top_k(fso_fsvi_slab(idx), n, idx->dim, live, q, k, 10000, 1024, 1, 1,
-                                  hreduce, rows, scores);
-    size_t outn = 0;
-    for (size_t i = 0; i < got; ++i) {
-        const char *di;
-        uint32_t dl = fso_fsvi_doc_id(idx, rows[i], &di);
-        int dup = 0;
-        for (size_t j = 0; j < outn && !dup; ++j) {
-            const char *dj;
-            uint32_t lj = fso_fsvi_doc_id(idx, out_rows[j], &dj);
-            if (lj == dl && memcmp(di, dj, dl) == 0) dup = 1;
+    size_t cap = (k < n ? k : (size_t)n) + idx->wal_len + 1;
+    entry_t *cand = (entry_t *)malloc(sizeof(entry_t) * cap);
+    size_t nc = 0;
+    if (n > 0) {
+        size_t kk = k < n ? k : (size_t)n;
+        uint32_t *rows = (uint32_t *)malloc(sizeof(uint32_t) * kk);
+        float *scores = (float *)malloc(sizeof(float) * kk);
+        size_t got = fso_search_top_k(fso_fsvi_slab(idx), n, idx->dim, live, q, k, 10000, 1024, 1, 1, hreduce,
+                                      rows, scores);
+        for (size_t i = 0; i < got; ++i) {
+            cand[nc].row = rows[i];
+            cand[nc].score = scores[i];
+            ++nc;
         }
+        free(rows);
+        free(scores);
+    }
+    const uint64_t wal_tag = 1ull << 63;
+    for (size_t i = 0; i < idx->wal_len; ++i) {
+        float s = fso_dot_f32_f32(idx->wal_vecs[i], q, idx->dim, hreduce);
+        if (!isfinite(s)) continue; /* search.rs:1466-1470 */
+        cand[nc].row = wal_tag | i;
+        cand[nc].score = s;
+        ++nc;
+    }
+    qsort(cand, nc, sizeof(entry_t), cmp_best_first);
+    if (nc > k) nc = k; /* the size-k heap keeps exactly the k best of main U wal */
+    size_t outn = 0;
+    const char **seen = (const char **)malloc(sizeof(char *) * (nc ? nc : 1));
+    uint32_t *seen_len = (uint32_t *)malloc(sizeof(uint32_t) * (nc ? nc : 1));
+    for (size_t i = 0; i < nc; ++i) {
+        const char *di;
+        uint32_t dl;
+        uint32_t index;
+        if (cand[i].row & wal_tag) {
+            size_t wi = (size_t)(cand[i].row & ~wal_tag);
+            di = idx->wal_ids[wi];
+            dl = (uint32_t)strlen(di);
+            index = (uint32_t)(n + wi);
+        } else {
+            if (fso_fsvi_flags(idx, cand[i].row) & 1u) continue;
+            dl = fso_fsvi_doc_id(idx, cand[i].row, &di);
+            int shadowed = 0;
+            for (size_t w = 0; w < idx->wal_len && !shadowed; ++w)
+                if (strlen(idx->wal_ids[w]) == dl && memcmp(idx->wal_ids[w], di, dl) == 0) shadowed = 1;
+            if (shadowed) continue;
+            index = (uint32_t)cand[i].row;
+        }
+        int dup = 0;
+        for (size_t j = 0; j < outn && !dup; ++j)
+            if (seen_len[j] == dl && memcmp(seen[j], di, dl) == 0) dup = 1;
         if (dup) continue;
-        out_rows[outn] = rows[i];
-        out_scores[outn] = scores[i];
+        seen[outn] = di;
+        seen_len[outn] = dl;
+        out_rows[outn] = index;
+        out_scores[outn] = cand[i].score;
         ++outn;
     }
+    free(seen);
+    free(seen_len);
+    free(cand);
     free(live);
-    free(rows);
-    free(scores);
     return outn;
 }
 

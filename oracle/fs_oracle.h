@@ -57,6 +57,10 @@ float fso_dot_f16_f32(const uint8_t *row_le, const float *q, size_t dim, int hre
 float fso_dot_f16_f32_fast(const uint8_t *row_le, const float *q, size_t dim, int hreduce);
 int fso_has_avx2_f16c(void);
 
+/* dot_product_f32_f32 (simd.rs:134-222): groups of 32 into four accumulators, (a0+a1)+(a2+a3), leftover
+ * 8-chunks added to the sum, horizontal reduce, scalar tail with separate multiply and add. */
+float fso_dot_f32_f32(const float *a, const float *b, size_t n, int hreduce);
+
 /* ---- ordering (search.rs:91-126, 1655-1686) ---- */
 /* 1 if (row_a,score_a) ranks strictly before (row_b,score_b) in best-first order. */
 int fso_ranks_before(uint64_t row_a, float score_a, uint64_t row_b, float score_b);
@@ -107,6 +111,13 @@ const uint8_t *fso_fsvi_slab(const fso_fsvi *idx);
 uint32_t fso_fsvi_doc_id(const fso_fsvi *idx, uint64_t row, const char **ptr);
 uint16_t fso_fsvi_flags(const fso_fsvi *idx, uint64_t row);
 void fso_fsvi_set_flags(fso_fsvi *idx, uint64_t row, uint16_t flags); /* in-memory soft delete */
+/* VectorIndex::append (lib.rs:2532-2720): validates (FSO_ERR_DIMENSION_MISMATCH / FSO_ERR_INVALID_CONFIG),
+ * supersedes a resident WAL entry with the same doc id, tombstones the first live main row with that doc id,
+ * and makes the f32 vector immediately searchable (scan_wal, search.rs:1449-1475). */
+int fso_fsvi_append(fso_fsvi *idx, const char *doc_id, const float *vector, size_t len);
+uint64_t fso_fsvi_wal_count(const fso_fsvi *idx);
+/* doc id of a WAL entry (virtual row record_count + i). */
+uint32_t fso_fsvi_wal_doc_id(const fso_fsvi *idx, uint64_t i, const char **ptr);
 /* search_top_k + resolve_hits incl. tombstone skip and post-top-k doc-id dedup (search.rs:1493-1558). */
 size_t fso_fsvi_search(const fso_fsvi *idx, const float *q, size_t k, int hreduce,
                        uint32_t *out_rows, float *out_scores);

@@ -98,6 +98,14 @@ def lib() -> C.CDLL:
         L.fso_fsvi_set_flags.argtypes = [C.c_void_p, C.c_uint64, C.c_uint16]
         L.fso_fsvi_search.restype = C.c_size_t
         L.fso_fsvi_search.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        L.fso_dot_f32_f32.restype = C.c_float
+        L.fso_dot_f32_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        L.fso_fsvi_append.restype = C.c_int
+        L.fso_fsvi_append.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
+        L.fso_fsvi_wal_count.restype = C.c_uint64
+        L.fso_fsvi_wal_count.argtypes = [C.c_void_p]
+        L.fso_fsvi_wal_doc_id.restype = C.c_uint32
+        L.fso_fsvi_wal_doc_id.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
         L.fso_fixture_hashmix.restype = C.c_float
         L.fso_fixture_hashmix.argtypes = [C.c_uint64, C.c_uint64]
         L.fso_raw_vector.argtypes = [C.c_uint64, C.c_uint32, C.c_void_p]
@@ -136,6 +144,13 @@ def dot_f16_f32(row_u16: np.ndarray, q: np.ndarray, hreduce: int = HREDUCE_SSE2,
     assert row.size == q.size
     fn = lib().fso_dot_f16_f32_fast if fast else lib().fso_dot_f16_f32
     return fn(_p(row), _p(q), q.size, hreduce)
+
+
+def dot_f32_f32(a: np.ndarray, b: np.ndarray, hreduce: int = HREDUCE_SSE2) -> float:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    assert a.size == b.size
+    return lib().fso_dot_f32_f32(_p(a), _p(b), a.size, hreduce)
 
 
 def live_bitmap(live_bool: np.ndarray) -> np.ndarray:
@@ -259,8 +274,20 @@ class Fsvi:
 
     def doc_id(self, row: int) -> str:
         p = C.c_void_p()
-        ln = lib().fso_fsvi_doc_id(self.h, row, C.byref(p))
+        n = self.record_count
+        if row >= n:  # WAL virtual row (search.rs:1579-1596)
+            ln = lib().fso_fsvi_wal_doc_id(self.h, row - n, C.byref(p))
+        else:
+            ln = lib().fso_fsvi_doc_id(self.h, row, C.byref(p))
         return C.string_at(p.value, ln).decode()
+
+    def append(self, doc_id: str, vector) -> int:
+        v = np.ascontiguousarray(vector, dtype=np.float32)
+        return lib().fso_fsvi_append(self.h, doc_id.encode(), _p(v), v.size)
+
+    @property
+    def wal_record_count(self) -> int:
+        return lib().fso_fsvi_wal_count(self.h)
 
     def flags(self, row: int) -> int:
         return lib().fso_fsvi_flags(self.h, row)
@@ -277,7 +304,7 @@ class Fsvi:
         q = np.ascontiguousarray(q, dtype=np.float32)
         if q.size != self.dimension:
             raise ValueError(f"DimensionMismatch expected={self.dimension} found={q.size}")
-        cap = max(1, min(k, self.record_count))
+        cap = max(1, min(k, self.record_count + self.wal_record_count))
         rows = np.empty(cap, dtype=np.uint32)
         scores = np.empty(cap, dtype=np.float32)
         cnt = lib().fso_fsvi_search(self.h, _p(q), k, hreduce, _p(rows), _p(scores))

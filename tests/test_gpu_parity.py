@@ -320,3 +320,39 @@ def test_config2_1m_x_384_clustered_corpus(fa, oracle):
         for qi in range(queries.shape[0]):
             er, es = oracle.search_top_k(slab, queries[qi], k, nthreads=8)
             assert np.array_equal(rows[qi], er) and np.array_equal(bits(scores[qi]), bits(es))
+
+
+def test_wal_overlay_matches_oracle(fa, oracle, tmp_path):
+    # scan_wal + resolve (search.rs:1449-1475,1503-1596); repro_wal_shadow_bug.rs; search.rs:2688-2738
+    p = str(tmp_path / "w.fsvi")
+    oracle.fsvi_write(p, [("doc-a", [1.0, 0.0])])
+    g = fa.VectorIndex.open(p)
+    g.append("doc-a", [0.0, 1.0])
+    hits = g.search_top_k([1.0, 0.0], 1)
+    assert len(hits) == 1 and hits[0].doc_id == "doc-a" and abs(hits[0].score) < 1.2e-7 and hits[0].index == 1
+    with pytest.raises(fa.DimensionMismatch):
+        g.append("x", [1.0])
+    with pytest.raises(fa.InvalidConfig):
+        g.append("x", [np.nan, 0.0])
+    with pytest.raises(fa.InvalidConfig):
+        g.append("x", [0.0, 0.0])
+
+    rng = np.random.default_rng(61)
+    rows = [(f"doc-{i:03}", rng.standard_normal(40).astype(np.float32).tolist()) for i in range(300)]
+    p2 = str(tmp_path / "w2.fsvi")
+    oracle.fsvi_write(p2, rows)
+    o = oracle.Fsvi(p2)
+    g = fa.VectorIndex.open(p2)
+    for j in range(25):
+        did = f"doc-{(j * 7) % 300:03}" if j % 2 else f"new-{j}"
+        v = rng.standard_normal(40).astype(np.float32)
+        assert o.append(did, v) == 0
+        g.append(did, v)
+    assert g.wal_record_count() == o.wal_record_count
+    for qi in range(6):
+        q = rng.standard_normal(40).astype(np.float32)
+        for k in (1, 5, 50, 400):
+            oh, os_ = o.search_top_k(q, k)
+            gh = g.search_top_k(q, k)
+            assert [(h.index, h.doc_id) for h in gh] == [(h[0], h[2]) for h in oh]
+            assert np.array_equal(bits([h.score for h in gh]), bits(os_))

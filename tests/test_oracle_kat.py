@@ -380,3 +380,68 @@ def test_bench_generator(oracle):
     assert abs(float(np.linalg.norm(q)) - 1.0) < 1e-5
     # (noise 0.30 * uniform[-1,1) dominates the unit centroid, so clusters barely separate: low-margin scores)
     assert np.all(np.abs(w @ q) < 0.5)
+
+
+# ---------------------------------------------------------------- WAL overlay
+def test_dot_f32_f32_reference_order(oracle):
+    # simd.rs:134-222; scalar check as the reference's simd_matches_scalar tests (:3030-3042)
+    rng = np.random.default_rng(13)
+    for n in (0, 1, 5, 8, 9, 31, 32, 33, 40, 47, 64, 100, 256, 384, 385):
+        a = rng.standard_normal(n).astype(np.float32)
+        b = rng.standard_normal(n).astype(np.float32)
+        got = np.float32(oracle.dot_f32_f32(a, b))
+        # independent numpy statement of the same order
+        groups, chunks = n // 32, n // 8
+        acc = np.zeros((4, 8), np.float32)
+        for g in range(groups):
+            for x in range(4):
+                sl = slice(g * 32 + x * 8, g * 32 + x * 8 + 8)
+                acc[x] = acc[x] + a[sl] * b[sl]
+        s = (acc[0] + acc[1]) + (acc[2] + acc[3])
+        for c in range(groups * 4, chunks):
+            s = s + a[c * 8:c * 8 + 8] * b[c * 8:c * 8 + 8]
+        r = np.float32(((s[0] + s[2]) + (s[1] + s[3])) + ((s[4] + s[6]) + (s[5] + s[7])))
+        for i in range(chunks * 8, n):
+            r = np.float32(r + np.float32(a[i] * b[i]))
+        assert got.view(np.uint32) == r.view(np.uint32), n
+        assert abs(float(got) - float(np.dot(a.astype(np.float64), b.astype(np.float64)))) < 1e-4
+
+
+def test_wal_append_shadows_sealed_record(oracle, tmp_path):
+    # repro_wal_shadow_bug.rs:23-58 / search.rs:3054-3076 (restated on an F16 main index)
+    p = str(tmp_path / "w.fsvi")
+    oracle.fsvi_write(p, [("doc-a", [1.0, 0.0])])
+    idx = oracle.Fsvi(p)
+    assert idx.append("doc-a", [0.0, 1.0]) == 0
+    hits, _ = idx.search_top_k([1.0, 0.0], 1)
+    assert len(hits) == 1 and hits[0][2] == "doc-a" and abs(hits[0][1]) < 1.2e-7
+    assert hits[0][0] == 1  # virtual index record_count + wal_idx (search.rs:1579-1590)
+
+
+def test_collect_all_matches_heap_prefix_with_wal(oracle, tmp_path):
+    # search.rs:2688-2738
+    p = str(tmp_path / "cw.fsvi")
+    oracle.fsvi_write(p, [(f"doc-{i:03}", [float(48 - i), 0, 0, 0]) for i in range(48)])
+    idx = oracle.Fsvi(p)
+    for d, v in (("wal-top", 200.0), ("wal-mid", 24.5), ("wal-tail", -1.0)):
+        assert idx.append(d, [v, 0, 0, 0]) == 0
+    total = idx.record_count + idx.wal_record_count
+    allh, _ = idx.search_top_k([1.0, 0, 0, 0], total + 10)
+    heap, _ = idx.search_top_k([1.0, 0, 0, 0], total - 5)
+    assert len(allh) == total and allh[0][2] == "wal-top" and len(heap) == total - 5
+    assert [(h[0], h[2]) for h in heap] == [(h[0], h[2]) for h in allh[:total - 5]]
+    assert allh[-1][2] == "wal-tail"
+
+
+def test_wal_append_validation_and_supersede(oracle, tmp_path):
+    # lib.rs:2574-2600 validation; :2641-2647 resident supersede (last write wins)
+    p = str(tmp_path / "v.fsvi")
+    oracle.fsvi_write(p, [("a", [1.0, 0, 0, 0]), ("b", [0.5, 0, 0, 0])])
+    idx = oracle.Fsvi(p)
+    assert idx.append("x", [1.0, 0, 0]) == oracle.ERR_DIMENSION_MISMATCH
+    assert idx.append("x", [np.nan, 0, 0, 0]) == oracle.ERR_INVALID_CONFIG
+    assert idx.append("x", [0.0, 0, 0, 0]) == oracle.ERR_INVALID_CONFIG
+    assert idx.append("x", [0.9, 0, 0, 0]) == 0 and idx.append("x", [0.1, 0, 0, 0]) == 0
+    assert idx.wal_record_count == 1
+    hits, _ = idx.search_top_k([1.0, 0, 0, 0], 10)
+    assert [h[2] for h in hits] == ["a", "b", "x"] and abs(hits[2][1] - 0.1) < 1e-6
