@@ -64,6 +64,9 @@ SIGNATURES = {
     "fsgpu_bert_create": (_i32, [_i32, _vp, _vp, C.POINTER(_vp)]),
     "fsgpu_bert_destroy": (None, [_vp]),
     "fsgpu_bert_embed": (_i32, [_vp, _vp, _vp, _u32, _vp]),
+    "fsgpu_rrf_fuse": (_i32, [_vp, _u32, _vp, _u32, C.c_double, C.c_double, C.c_double, _i32, _u32, _u32, _vp,
+                              C.POINTER(_u32)]),
+    "fsgpu_blend_two_tier": (_i32, [_vp, _u32, _vp, _u32, C.c_float, _vp, C.POINTER(_u32)]),
     "fsgpu_index_set_profiling": (_i32, [_vp, _i32]),
     "fsgpu_index_scan_time": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(_u64), _i32]),
     "fsgpu_index_set_variant": (_i32, [_vp, _i32]),

@@ -183,6 +183,41 @@ void fsgpu_bert_destroy(fsgpu_bert *m);
  * fastembed_embedder.rs:416-426).  out is [n, hidden]. */
 fsgpu_status fsgpu_bert_embed(fsgpu_bert *m, const int32_t *ids, const uint32_t *offsets, uint32_t n, float *out);
 
+/* ---- host-side rank fusion (O(k), CPU, no GPU needed) ---- */
+/* One ranked hit: ScoredResult / VectorHit as the fusion code reads them
+ * (crates/frankensearch-core/src/types.rs:88-134): doc id (not NUL-terminated), score, vector row index. */
+typedef struct fsgpu_scored_doc {
+    const char *doc_id;
+    uint32_t doc_id_len;
+    float score;
+    uint32_t index;
+} fsgpu_scored_doc;
+/* FusedHit (types.rs:3892-3925); ranks are -1 when absent, semantic_index 0xffffffff when absent;
+ * doc_id points into the caller's input arrays. */
+typedef struct fsgpu_fused_hit {
+    const char *doc_id;
+    uint32_t doc_id_len;
+    double rrf_score;
+    int64_t lexical_rank, semantic_rank;
+    uint32_t semantic_index;
+    float lexical_score, semantic_score;
+    uint8_t in_both_sources;
+} fsgpu_fused_hit;
+#define FSGPU_RRF_TIEBREAK_LEXICAL_THEN_ID 0 /* RrfTiebreak::LexicalThenId (default, rrf.rs:52-66) */
+#define FSGPU_RRF_TIEBREAK_HASH 1            /* RrfTiebreak::Hash */
+/* rrf_fuse (crates/frankensearch-fusion/src/rrf.rs:368-560): score = sum over lanes of weight/(k+rank+1);
+ * order (rrf desc, in_both desc, lexical score desc | doc-id hash, doc_id asc); window = offset..offset+limit.
+ * Non-finite / negative k -> 60; non-finite / non-positive weights -> 1.  out holds `limit` entries. */
+fsgpu_status fsgpu_rrf_fuse(const fsgpu_scored_doc *lexical, uint32_t n_lexical, const fsgpu_scored_doc *semantic,
+                            uint32_t n_semantic, double k, double lexical_weight, double semantic_weight,
+                            int32_t tiebreak, uint32_t limit, uint32_t offset, fsgpu_fused_hit *out,
+                            uint32_t *out_count);
+/* blend_two_tier (crates/frankensearch-fusion/src/blend.rs:107-195): per-list min-max normalisation,
+ * alpha*quality + (1-alpha)*fast (single-source docs keep their normalised score), order (score desc, doc_id asc).
+ * out holds n_fast + n_quality entries. */
+fsgpu_status fsgpu_blend_two_tier(const fsgpu_scored_doc *fast, uint32_t n_fast, const fsgpu_scored_doc *quality,
+                                  uint32_t n_quality, float blend_factor, fsgpu_scored_doc *out, uint32_t *out_count);
+
 /* ---- instrumentation ---- */
 /* When enabled, HIP events bracket the scan kernel of every fsgpu_search_topk* call. */
 fsgpu_status fsgpu_index_set_profiling(fsgpu_index *idx, int32_t enabled);
