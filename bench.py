@@ -113,6 +113,50 @@ def cpu_baseline_and_parity(slab_dev: torch.Tensor, queries: torch.Tensor, k: in
     }
 
 
+def two_tier_section(quality_index, rows: int, k: int, device, local_rank: int):
+    """BASELINE config 3 shape on one GPU: potion fast tier (10M x 256) + MiniLM quality tier (10M x 384), RRF
+    with a deterministic stub lexical list (BM25 stays on the CPU in the reference and is not built here).
+    Sequential single-query latency of the Initial (phase 0) and Refined (phase 1) deliveries."""
+    import frankensearch_amd as fa
+    from frankensearch_amd.two_tier import SyncTwoTierSearcher
+    from oracle import bert_oracle  # only its seeded synthetic-weight generator (no real weights exist offline)
+
+    fast_dim = 256
+    fast_slab = gen_corpus(0, rows, fast_dim, device)
+    fast_index = fa.VectorIndex.from_device_slab(fast_slab.data_ptr(), rows, fast_dim, device=local_rank,
+                                                 keepalive=fast_slab)
+    rng = np.random.default_rng(0)
+    table = rng.standard_normal((500_353, fast_dim)).astype(np.float32)   # potion-multilingual-128M shape
+    m2v = fa.Model2VecEmbedder(table, device=local_rank)
+    bert = fa.NativeEmbedder(bert_oracle.random_weights(1, 30522, 384, 6, 1536), device=local_rank)
+    searcher = SyncTwoTierSearcher(fast_index, quality_index, m2v, bert, lambda r: f"doc-{r:08d}")
+    p0, p1 = [], []
+    for i in range(48):
+        fast_ids = rng.integers(0, 500_353, int(rng.integers(4, 24))).tolist()
+        qual_ids = [101] + rng.integers(1000, 30000, int(rng.integers(6, 31))).tolist() + [102]
+        lexical = [(f"doc-{int(r):08d}", float(30 - j)) for j, r in enumerate(rng.choice(rows, 3 * k, replace=False))]
+        out = searcher.search(fast_ids, qual_ids, k, lexical)
+        if i >= 8:
+            p0.append(out.metrics.phase1_total_ms)
+            p1.append(out.metrics.phase1_total_ms + out.metrics.phase2_total_ms)
+    p0.sort()
+    p1.sort()
+    m = out.metrics
+    res = {
+        "workload": f"{rows}x256 fast tier + {rows}x384 quality tier, top-{k}, fetch {3 * k}, stub lexical list, "
+                    "sequential single queries through the host-pointer ABI",
+        "phase0_p50_ms": p0[len(p0) // 2],
+        "phase1_p50_ms": p1[len(p1) // 2],
+        "sequential_queries_per_sec": 1e3 / p1[len(p1) // 2],
+        "last_breakdown_ms": {"fast_embed": m.fast_embed_ms, "fast_search": m.fast_search_ms,
+                              "quality_embed": m.quality_embed_ms, "quality_search": m.quality_search_ms,
+                              "blend": m.blend_ms},
+    }
+    fast_index.close()
+    del fast_slab
+    return res
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,6 +168,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=2, help="queries per step (one scan pass serves up to 4)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-two-tier", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -233,6 +278,10 @@ def main() -> None:
         }
         if lat:
             line["p50_latency_ms_single_query"] = lat[len(lat) // 2]
+        if world == 1 and not args.no_two_tier:
+            tt = two_tier_section(index, args.rows, k, device, local_rank)
+            line["two_tier"] = tt
+            line["p50_phase1_latency_ms"] = tt["phase1_p50_ms"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_and_parity(slab, queries, k, args.rows, fa.VectorIndex)
         print(json.dumps(line), flush=True)
