@@ -165,7 +165,7 @@ def main() -> None:
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=2, help="queries per step (one scan pass serves up to 4)")
+    ap.add_argument("--batch", type=int, default=4, help="queries per step (one exact scan pass serves 4)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-two-tier", action="store_true")
@@ -177,10 +177,17 @@ def main() -> None:
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ngpu = torch.cuda.device_count()
+    backend = os.environ.get("FSGPU_BENCH_BACKEND", "nccl")  # "gloo": single-GPU rehearsal of the N>1 path only
+    if backend != "nccl":
+        local_rank = local_rank % max(ngpu, 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from __graft_entry__ import build
     if rank == 0:

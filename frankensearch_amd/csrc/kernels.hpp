@@ -40,6 +40,9 @@ size_t scan_lds_bytes(int dim, int nq, int kcap);
 int scan_occupancy_blocks_per_cu(int dim, int nq, int kcap, bool force_runtime_dim);
 hipError_t launch_scan_topk(const ScanArgs& args, int nq, int kcap, int grid, hipStream_t stream,
                             bool force_runtime_dim, bool plain_loads);
+// scan_mq_kernel.hip: 4 / 8 queries per pass (dim 128/256/384); occupancy != nullptr only queries residency.
+bool scan_mq_supported(int dim, int nq, int kcap);
+hipError_t launch_scan_mq(const ScanArgs& args, int nq, int kcap, int grid, hipStream_t stream, int* occupancy);
 hipError_t launch_merge_topk(const MergeArgs& args, int nq, hipStream_t stream);
 hipError_t launch_score_rows(const ScanArgs& args, u64* out_packed, int q_index, int grid, hipStream_t stream);
 hipError_t launch_packed_to_sortkey(u64* data, size_t n, hipStream_t stream);

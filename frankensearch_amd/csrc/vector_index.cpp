@@ -475,9 +475,26 @@ SearchError VectorIndex::fused_search(const float* queries_dev, uint32_t nq, uin
     uint32_t done = 0;
     while (done < nq) {
         const uint32_t left = nq - done;
-        int pass = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
-        if (scan_lds_bytes((int)dim_, pass, kcap) > 150 * 1024) pass = 1;
-        const int per_cu = scan_occupancy_blocks_per_cu((int)dim_, pass, kcap, variant == 1);
+        // queries per pass: 8 / 4 through the multi-query kernel, else 2 / 1 through the register-resident kernel
+        int pass = left >= 2 ? 2 : 1;
+        bool mq = false;
+        if (variant != 3 && variant != 1) {
+            if (left >= 8 && kcap == 64 && scan_mq_supported((int)dim_, 8, kcap)) {
+                pass = 8;
+                mq = true;
+            } else if (left >= 4 && scan_mq_supported((int)dim_, 4, kcap)) {
+                pass = 4;
+                mq = true;
+            }
+        }
+        if (!mq && left >= 4 && scan_lds_bytes((int)dim_, 4, kcap) <= 150 * 1024 && (variant == 3)) pass = 4;
+        int per_cu = 1;
+        if (mq) {
+            ScanArgs probe = base_args(queries_dev, allow_dev);
+            FSGPU_HIP(launch_scan_mq(probe, pass, kcap, 1, stream, &per_cu));
+        } else {
+            per_cu = scan_occupancy_blocks_per_cu((int)dim_, pass, kcap, variant == 1);
+        }
         int grid = num_cus_ * per_cu;
         if (const char* env = std::getenv("FSGPU_GRID_BLOCKS")) {  // tuning experiments only
             const int forced = std::atoi(env);
@@ -497,7 +514,8 @@ SearchError VectorIndex::fused_search(const float* queries_dev, uint32_t nq, uin
             FSGPU_HIP(hipEventCreate(&e1));
             FSGPU_HIP(hipEventRecord(e0, stream));
         }
-        FSGPU_HIP(launch_scan_topk(a, pass, kcap, grid, stream, variant == 1, variant == 2));
+        if (mq) FSGPU_HIP(launch_scan_mq(a, pass, kcap, grid, stream, nullptr));
+        else FSGPU_HIP(launch_scan_topk(a, pass, kcap, grid, stream, variant == 1, variant == 2));
         if (profiling) {
             FSGPU_HIP(hipEventRecord(e1, stream));
             events_.emplace_back(e0, e1);

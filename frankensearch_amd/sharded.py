@@ -100,7 +100,14 @@ class ShardedVectorIndex:
             gathered = local.unsqueeze(0)
         else:
             # dim-0 concatenation form (accepted by both RCCL and gloo), viewed as [W, B, k]
-            flat = torch.empty((self.world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
-            dist.all_gather_into_tensor(flat, local, group=self.group)
+            if local.is_cuda and dist.get_backend(self.group) == "gloo":
+                # rehearsal path (no RCCL): stage through the host
+                host = torch.empty((self.world * local.shape[0], local.shape[1]), dtype=local.dtype)
+                dist.all_gather_into_tensor(host, local.cpu(), group=self.group)
+                flat = host.to(local.device)
+            else:
+                flat = torch.empty((self.world * local.shape[0], local.shape[1]), dtype=local.dtype,
+                                   device=local.device)
+                dist.all_gather_into_tensor(flat, local, group=self.group)
             gathered = flat.view(self.world, local.shape[0], local.shape[1])
         return self.backend.merge(gathered, k)
