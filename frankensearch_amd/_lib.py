@@ -54,6 +54,7 @@ SIGNATURES = {
     "fsgpu_search_topk_packed_device": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "fsgpu_merge_topk_device": (_i32, [_i32, _vp, _u32, _u32, _u32, _u64, _u64, _u32, _vp, _vp, _vp, _vp]),
     "fsgpu_search_topk_classified": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, C.POINTER(_u32), C.POINTER(_i32)]),
+    "fsgpu_search_topk_int8_two_pass": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),
     "fsgpu_search_hits": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),
     "fsgpu_gather_dot": (_i32, [_vp, _vp, _u32, _vp, _u32, _vp]),
     "fsgpu_encode_f32_to_f16": (_i32, [_i32, _vp, _u64, _vp]),

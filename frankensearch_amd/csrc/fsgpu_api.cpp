@@ -239,6 +239,20 @@ fsgpu_status fsgpu_search_hits(fsgpu_index* idx, const float* query, uint32_t qu
     });
 }
 
+// VectorIndex::search_top_k_int8_two_pass (search.rs:514-661)
+fsgpu_status fsgpu_search_topk_int8_two_pass(fsgpu_index* idx, const float* query, uint32_t query_len, uint32_t k,
+                                             uint32_t candidate_multiplier, uint32_t* out_rows, float* out_scores,
+                                             uint32_t* out_count) {
+    if (!idx || !query || !out_count) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    *out_count = 0;
+    if (k && (!out_rows || !out_scores)) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.search_top_k_int8_two_pass(query, query_len, k, candidate_multiplier, out_rows,
+                                                           out_scores, out_count));
+    });
+}
+
 // VectorIndex::append (lib.rs:2532-2720)
 fsgpu_status fsgpu_index_wal_append(fsgpu_index* idx, const char* doc_id, uint32_t doc_id_len, const float* vector,
                                     uint32_t vector_len) {

@@ -1,0 +1,281 @@
+// int8_kernels.hip — the reference's production fast-tier path: int8 pass-1 scan + exact f16 rescore
+// (VectorIndex::search_top_k_int8_two_pass, crates/frankensearch-index/src/search.rs:514-661).
+//
+//   slab quantiser   quantize_f16_le_bytes_to_i8_generic  simd.rs:1865-1886  (ONE corpus-wide max-abs scale,
+//                    round() half away from zero, clamp +-127, NaN -> 0)
+//   pass-1 dot       dot_i8_i8                            simd.rs:757,1240-1286 (exact i32)
+//   pass-1 order     int8_heap_key / int8_heap_key_from_f32  search.rs:141-156 (score desc, row asc; the score is
+//                    compared as f32 once dim > 1040)
+// The int8 dot is integer-exact, so ANY summation order gives the reference's bits: v_dot4_i32_i8 over 16-byte
+// lane chunks, quad-reduced with DPP adds.  Converting the i32 dot to f32 is exact up to dim 1040 and is exactly
+// the reference's `score as f32` key beyond, so the same packed-f32 top-k machinery as the f16 scan serves both
+// branches.  HBM traffic is N*dim bytes per pass — half of the f16 scan.
+#include "scan_common.hpp"
+
+namespace fsgpu {
+
+using namespace scan_detail;
+
+namespace {
+
+__device__ __forceinline__ int quad_sum_i32(int v) {
+    v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);
+    v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);
+    return v;
+}
+
+__device__ __forceinline__ signed char quant_i8(float x, float scale) {
+    float v = roundf(x * scale);  // half away from zero, like f32::round
+    if (v != v) return 0;         // Rust `as i8` maps NaN to 0
+    v = fminf(fmaxf(v, -127.0f), 127.0f);
+    return (signed char)(int)v;
+}
+
+}  // namespace
+
+// max |f16| over the slab (f32::max ignores NaN, so does fmaxf); result accumulated with an integer atomic max
+// on the non-negative float's bits.
+__global__ __launch_bounds__(256) void slab_maxabs_kernel(const unsigned short* __restrict__ slab, size_t n_values,
+                                                          unsigned int* __restrict__ out_bits) {
+    float m = 0.f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t nvec = n_values / 8;
+    const u32x4* v = reinterpret_cast<const u32x4*>(slab);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        const half8 h = __builtin_bit_cast(half8, v[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf((float)h[j]));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (size_t i = nvec * 8; i < n_values; ++i)
+            m = fmaxf(m, fabsf((float)__builtin_bit_cast(_Float16, slab[i])));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));
+}
+
+__global__ __launch_bounds__(256) void quantize_slab_i8_kernel(const unsigned short* __restrict__ slab, size_t n_values,
+                                                               const unsigned int* __restrict__ max_bits,
+                                                               signed char* __restrict__ out) {
+    const float max_abs = __uint_as_float(*max_bits);
+    const bool zero = !(max_abs > 0.0f);
+    const float scale = zero ? 0.f : 127.0f / max_abs;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t nvec = n_values / 8;
+    const u32x4* v = reinterpret_cast<const u32x4*>(slab);
+    typedef signed char i8x8 __attribute__((ext_vector_type(8)));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        const half8 h = __builtin_bit_cast(half8, v[i]);
+        i8x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = zero ? (signed char)0 : quant_i8((float)h[j], scale);
+        reinterpret_cast<i8x8*>(out)[i] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (size_t i = nvec * 8; i < n_values; ++i)
+            out[i] = zero ? (signed char)0 : quant_i8((float)__builtin_bit_cast(_Float16, slab[i]), scale);
+}
+
+// Pass 1, fused with the wave top-k (dim % 64 == 0).  A lane is (row r, quarter a): chunk c = 4g+a is 16 int8.
+template <int DIM, int KCAP>
+__global__ __launch_bounds__(256) void scan_i8_topk_kernel(ScanArgs args, const signed char* __restrict__ slab_i8,
+                                                           const signed char* __restrict__ query_i8) {
+    constexpr int CAP = 2 * KCAP;
+    constexpr int G = DIM / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* bufs = reinterpret_cast<u64*>(smem);  // [wave][CAP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, a = lane & 3, r = lane >> 2;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 q[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) q[g] = reinterpret_cast<const i32x4*>(query_i8)[4 * g + a];
+    WaveTopK<CAP> tk;
+    tk.init(bufs + (size_t)wave * CAP);
+    u64 thr = 0;
+    const uint32_t nrows = args.nrows;
+    const uint32_t ntiles = (nrows + kRowsPerTile - 1) / kRowsPerTile;
+    const uint32_t nwaves = gridDim.x * kWavesPerBlock;
+    const int k = (int)args.k;
+    auto load_tile = [&](uint32_t tile, i32x4 (&w)[G]) {
+        uint32_t row = tile * kRowsPerTile + r;
+        row = row < nrows ? row : nrows - 1;
+        const i32x4* p = reinterpret_cast<const i32x4*>(slab_i8 + (size_t)row * DIM) + a;
+#pragma unroll
+        for (int g = 0; g < G; ++g) w[g] = p[4 * g];
+    };
+    auto tile_words = [&](uint32_t tile, u64& live_word, u64& allow_word) {
+        const uint32_t w64 = (tile * kRowsPerTile) >> 6;
+        live_word = args.live ? args.live[w64] : ~0ull;
+        allow_word = args.allow ? args.allow[w64] : ~0ull;
+    };
+    auto compute_tile = [&](uint32_t tile, const i32x4 (&w)[G], u64 live_word, u64 allow_word) {
+        int acc = 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_sdot4(w[g][j], q[g][j], acc, false);
+        const int dot = quad_sum_i32(acc);
+        const uint32_t row = tile * kRowsPerTile + r;
+        bool valid = row < nrows && a == 0;
+        valid = valid && ((live_word >> (row & 63)) & 1ull) && ((allow_word >> (row & 63)) & 1ull);
+        const u64 packed = pack((float)dot, args.row_base + row);
+        bool cand = valid && sortkey(packed) > thr;
+        u64 m = __ballot(cand);
+        if (m == 0) return;
+        if (tk.count + (int)__popcll(m) > CAP) {
+            thr = tk.compact(k, lane);
+            cand = cand && sortkey(packed) > thr;
+            m = __ballot(cand);
+        }
+        if (cand) tk.buf[tk.count + (int)__popcll(m & ((1ull << lane) - 1ull))] = packed;
+        tk.count += (int)__popcll(m);
+    };
+    {
+        i32x4 wa[G], wb[G];
+        u64 la = ~0ull, aa = ~0ull, lb = ~0ull, ab = ~0ull;
+        uint32_t tile = blockIdx.x * kWavesPerBlock + wave;
+        if (tile < ntiles) {
+            load_tile(tile, wa);
+            tile_words(tile, la, aa);
+        }
+        while (tile < ntiles) {
+            uint32_t next = tile + nwaves;
+            if (next < ntiles) {
+                load_tile(next, wb);
+                tile_words(next, lb, ab);
+            }
+            compute_tile(tile, wa, la, aa);
+            tile = next;
+            if (tile >= ntiles) break;
+            next = tile + nwaves;
+            if (next < ntiles) {
+                load_tile(next, wa);
+                tile_words(next, la, aa);
+            }
+            compute_tile(tile, wb, lb, ab);
+            tile = next;
+        }
+    }
+    (void)tk.compact(k, lane);
+    __syncthreads();
+    if (wave == 0) {
+        u64* dst = bufs;
+        for (int w = 1; w < kWavesPerBlock; ++w) {
+            const u64* src = bufs + (size_t)w * CAP;
+            for (int i = lane; i < KCAP; i += 64) {
+                const u64 xx = dst[i], yy = src[KCAP - 1 - i];
+                dst[i] = sortkey(xx) >= sortkey(yy) ? xx : yy;
+            }
+            for (int i = KCAP + lane; i < CAP; i += 64) dst[i] = kEmpty;
+            wave_sort_desc<CAP>(dst, lane);
+        }
+        u64* out = args.partial + (size_t)blockIdx.x * k;
+        for (int i = lane; i < k; i += 64) out[i] = dst[i];
+    }
+}
+
+// General pass 1: one packed entry per row (any dim; candidate counts beyond the fused tiers).
+__global__ __launch_bounds__(256) void score_rows_i8_kernel(ScanArgs args, const signed char* __restrict__ slab_i8,
+                                                            const signed char* __restrict__ query_i8,
+                                                            u64* __restrict__ out_packed) {
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= args.nrows) return;
+    bool valid = true;
+    if (args.live) valid = valid && ((args.live[row >> 6] >> (row & 63)) & 1ull);
+    if (args.allow) valid = valid && ((args.allow[row >> 6] >> (row & 63)) & 1ull);
+    if (!valid) {
+        out_packed[row] = kEmpty;
+        return;
+    }
+    const signed char* p = slab_i8 + (size_t)row * args.dim;
+    int dot = 0;
+    for (uint32_t i = 0; i < args.dim; ++i) dot += (int)p[i] * (int)query_i8[i];
+    out_packed[row] = pack((float)dot, args.row_base + row);
+}
+
+// rows of packed entries -> u32 row ids (kEmpty -> 0xffffffff)
+__global__ void packed_rows_kernel(const u64* __restrict__ packed, uint32_t n, uint32_t* __restrict__ rows) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rows[i] = (uint32_t)packed[i];
+}
+
+// (rows, exact scores) -> packed entries for the final merge; rows 0xffffffff stay kEmpty
+__global__ void pack_hits_kernel(const uint32_t* __restrict__ rows, const float* __restrict__ scores, uint32_t n,
+                                 u64* __restrict__ packed) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) packed[i] = rows[i] == 0xffffffffu ? kEmpty : pack(scores[i], rows[i]);
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------------
+
+hipError_t launch_quantize_slab_i8(const void* slab_f16, size_t n_values, unsigned int* max_bits_dev, void* out_i8,
+                                   hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(max_bits_dev, 0, 4, stream);
+    if (e != hipSuccess) return e;
+    const int grid = 2048;
+    hipLaunchKernelGGL(slab_maxabs_kernel, dim3(grid), dim3(256), 0, stream, static_cast<const unsigned short*>(slab_f16),
+                       n_values, max_bits_dev);
+    hipLaunchKernelGGL(quantize_slab_i8_kernel, dim3(grid), dim3(256), 0, stream,
+                       static_cast<const unsigned short*>(slab_f16), n_values, max_bits_dev,
+                       static_cast<signed char*>(out_i8));
+    return hipGetLastError();
+}
+
+bool scan_i8_fused_supported(int dim, int kcap) {
+    return (dim == 128 || dim == 256 || dim == 384 || dim == 512 || dim == 768) && (kcap == 64 || kcap == 256);
+}
+
+template <int DIM, int KCAP>
+static hipError_t launch_i8_t(const ScanArgs& args, const void* slab_i8, const void* query_i8, int grid,
+                              hipStream_t stream, int* occupancy) {
+    const size_t lds = (size_t)kWavesPerBlock * 2 * KCAP * 8;
+    auto kern = scan_i8_topk_kernel<DIM, KCAP>;
+    if (occupancy) {
+        int blocks = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, 256, lds) != hipSuccess || blocks < 1) blocks = 1;
+        *occupancy = blocks;
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, args, static_cast<const signed char*>(slab_i8),
+                       static_cast<const signed char*>(query_i8));
+    return hipGetLastError();
+}
+
+template <int KCAP>
+static hipError_t launch_i8_dim(const ScanArgs& args, const void* slab_i8, const void* query_i8, int grid,
+                                hipStream_t stream, int* occupancy) {
+    switch (args.dim) {
+        case 128: return launch_i8_t<128, KCAP>(args, slab_i8, query_i8, grid, stream, occupancy);
+        case 256: return launch_i8_t<256, KCAP>(args, slab_i8, query_i8, grid, stream, occupancy);
+        case 384: return launch_i8_t<384, KCAP>(args, slab_i8, query_i8, grid, stream, occupancy);
+        case 512: return launch_i8_t<512, KCAP>(args, slab_i8, query_i8, grid, stream, occupancy);
+        case 768: return launch_i8_t<768, KCAP>(args, slab_i8, query_i8, grid, stream, occupancy);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_scan_i8(const ScanArgs& args, const void* slab_i8, const void* query_i8, int kcap, int grid,
+                          hipStream_t stream, int* occupancy) {
+    if (kcap == 64) return launch_i8_dim<64>(args, slab_i8, query_i8, grid, stream, occupancy);
+    if (kcap == 256) return launch_i8_dim<256>(args, slab_i8, query_i8, grid, stream, occupancy);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_score_rows_i8(const ScanArgs& args, const void* slab_i8, const void* query_i8, u64* out_packed,
+                                hipStream_t stream) {
+    hipLaunchKernelGGL(score_rows_i8_kernel, dim3((args.nrows + 255) / 256), dim3(256), 0, stream, args,
+                       static_cast<const signed char*>(slab_i8), static_cast<const signed char*>(query_i8), out_packed);
+    return hipGetLastError();
+}
+
+hipError_t launch_packed_rows(const u64* packed, uint32_t n, uint32_t* rows, hipStream_t stream) {
+    hipLaunchKernelGGL(packed_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, packed, n, rows);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_hits(const uint32_t* rows, const float* scores, uint32_t n, u64* packed, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_hits_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, rows, scores, n, packed);
+    return hipGetLastError();
+}
+
+}  // namespace fsgpu

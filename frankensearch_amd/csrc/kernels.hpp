@@ -34,6 +34,7 @@ struct MergeArgs {
     float* out_scores;      // [nq, out_stride]
     uint32_t* out_counts;   // [nq]
     u64* out_packed;        // optional [nq, out_stride] packed copy of the result (kEmpty padded)
+    uint32_t lists_sorted = 1;  // 0: the lists are NOT best-first (disables the head/tail pruning bounds)
 };
 
 size_t scan_lds_bytes(int dim, int nq, int kcap);
@@ -60,6 +61,17 @@ hipError_t sort_keys_desc(void* temp, size_t temp_bytes, const u64* keys_in, u64
 // m2v_kernels.hip
 hipError_t launch_m2v_embed(const float* table, uint32_t vocab, uint32_t dim, const uint32_t* ids,
                             const uint32_t* offsets, uint32_t n, float* out, hipStream_t stream);
+
+// int8_kernels.hip
+hipError_t launch_quantize_slab_i8(const void* slab_f16, size_t n_values, unsigned int* max_bits_dev, void* out_i8,
+                                   hipStream_t stream);
+bool scan_i8_fused_supported(int dim, int kcap);
+hipError_t launch_scan_i8(const ScanArgs& args, const void* slab_i8, const void* query_i8, int kcap, int grid,
+                          hipStream_t stream, int* occupancy);
+hipError_t launch_score_rows_i8(const ScanArgs& args, const void* slab_i8, const void* query_i8, u64* out_packed,
+                                hipStream_t stream);
+hipError_t launch_packed_rows(const u64* packed, uint32_t n, uint32_t* rows, hipStream_t stream);
+hipError_t launch_pack_hits(const uint32_t* rows, const float* scores, uint32_t n, u64* packed, hipStream_t stream);
 
 // bert_kernels.hip
 hipError_t launch_bert_embed_ln(const int32_t* ids, const int32_t* positions, const float* word, const float* pos,

@@ -350,7 +350,8 @@ __global__ __launch_bounds__(NT) void merge_topk_kernel(MergeArgs args) {
     int cnt;
     if (total <= (size_t)MCAP) {
         u64* hkeys = buf + (MCAP - HCAP);  // aliased: dead before survivors are appended
-        const bool use_heads = nlists >= (uint32_t)k && nlists <= (uint32_t)HCAP;
+        const bool sorted_lists = args.lists_sorted != 0;
+        const bool use_heads = sorted_lists && nlists >= (uint32_t)k && nlists <= (uint32_t)HCAP;
         for (int j = tid; j < HCAP; j += NT) s_rank[j] = 0;
         u64 e[PER];
         uint32_t pos[PER], lst[PER];
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(NT) void merge_topk_kernel(MergeArgs args) {
         for (int x = 0; x < PER; ++x) {
             const bool real = e[x] != kEmpty;
             const u64 key = real ? sortkey(e[x]) : 0ull;
-            if (real && pos[x] == (uint32_t)(k - 1)) best_tail = key > best_tail ? key : best_tail;
+            if (sorted_lists && real && pos[x] == (uint32_t)(k - 1)) best_tail = key > best_tail ? key : best_tail;
             if (use_heads && pos[x] == 0 && tid + x * NT < total32) hkeys[lst[x]] = key;
         }
         // wave max of best_tail, then one LDS atomic per wave

@@ -109,7 +109,8 @@ VectorIndex::~VectorIndex() {
     }
     if (stream_) (void)hipStreamDestroy(stream_);
     for (DeviceBuffer* b : {&slab_own_, &live_own_, &ws_partial_, &ws_queries_, &ws_allow_, &ws_rows_, &ws_scores_,
-                            &ws_counts_, &ws_keys_a_, &ws_keys_b_, &ws_sort_tmp_, &ws_gather_rows_, &ws_gather_out_})
+                            &ws_counts_, &ws_keys_a_, &ws_keys_b_, &ws_sort_tmp_, &ws_gather_rows_, &ws_gather_out_,
+                            &i8_slab_, &i8_max_, &ws_i8_query_, &ws_cand_packed_, &ws_cand_rows_, &ws_cand_scores_})
         b->release();
 }
 
@@ -639,6 +640,162 @@ SearchError VectorIndex::gather_dot(const float* query, uint32_t query_len, cons
                                 static_cast<float*>(ws_gather_out_.ptr), stream_));
     FSGPU_HIP(hipMemcpyAsync(out, ws_gather_out_.ptr, (size_t)n * 4, hipMemcpyDeviceToHost, stream_));
     FSGPU_HIP(hipStreamSynchronize(stream_));
+    return ok();
+}
+
+// search_top_k_int8_two_pass_impl (crates/frankensearch-index/src/search.rs:589-661)
+SearchError VectorIndex::search_top_k_int8_two_pass(const float* query, uint32_t query_len, uint32_t k,
+                                                    uint32_t multiplier, uint32_t* out_rows, float* out_scores,
+                                                    uint32_t* out_count) {
+    *out_count = 0;
+    // anything the fast path does not cover goes through the exact search (search.rs:579-585)
+    if (k == 0 || nrows_ == 0 || !wal_.empty()) {
+        if (has_doc_ids()) return search_hits(query, query_len, k, out_rows, out_scores, out_count);
+        FSGPU_TRY(ensure_query_dimension(query_len));
+        if (k == 0 || nrows_ == 0) return ok();
+        return search_top_k(query, 1, query_len, k, nullptr, out_rows, out_scores, out_count);
+    }
+    FSGPU_TRY(ensure_query_dimension(query_len));
+    FSGPU_HIP(hipSetDevice(device_));
+    const size_t n = (size_t)nrows_;
+    if (!i8_ready_) {  // VectorIndex::int8_slab() is built lazily, once
+        FSGPU_TRY(i8_slab_.reserve(n * dim_));
+        FSGPU_TRY(i8_max_.reserve(4));
+        FSGPU_HIP(launch_quantize_slab_i8(slab_dev_, n * dim_, static_cast<unsigned int*>(i8_max_.ptr), i8_slab_.ptr,
+                                          stream_));
+        i8_ready_ = true;
+    }
+    const uint64_t mult = multiplier ? multiplier : 1;
+    uint64_t cc64 = std::min<uint64_t>((uint64_t)k * mult, nrows_);
+    cc64 = std::max<uint64_t>(cc64, std::min<uint64_t>(k, nrows_));
+    const uint32_t cc = (uint32_t)cc64;
+    const uint32_t k_eff = (uint32_t)std::min<uint64_t>(k, nrows_);
+    // quantize_i8_query (search.rs:1616-1626): the query's own max-abs scale, round half away, clamp
+    std::vector<signed char> qi(dim_, 0);
+    {
+        float max_abs = 0.f;
+        for (uint32_t i = 0; i < dim_; ++i) {
+            const float v = std::fabs(query[i]);
+            if (v > max_abs) max_abs = v;
+        }
+        if (max_abs > 0.f) {
+            const float scale = 127.0f / max_abs;
+            for (uint32_t i = 0; i < dim_; ++i) {
+                float v = std::round(query[i] * scale);
+                if (v != v) v = 0.f;
+                v = std::min(std::max(v, -127.0f), 127.0f);
+                qi[i] = (signed char)(int)v;
+            }
+        }
+    }
+    FSGPU_TRY(ws_i8_query_.reserve(dim_));
+    FSGPU_TRY(ws_queries_.reserve((size_t)dim_ * 4));
+    FSGPU_TRY(ws_cand_packed_.reserve((size_t)cc * 8));
+    FSGPU_TRY(ws_cand_rows_.reserve((size_t)cc * 4));
+    FSGPU_TRY(ws_cand_scores_.reserve((size_t)cc * 4));
+    FSGPU_TRY(ws_rows_.reserve((size_t)k * 4));
+    FSGPU_TRY(ws_scores_.reserve((size_t)k * 4));
+    FSGPU_TRY(ws_counts_.reserve(4));
+    FSGPU_HIP(hipMemcpyAsync(ws_i8_query_.ptr, qi.data(), dim_, hipMemcpyHostToDevice, stream_));
+    FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, query, (size_t)dim_ * 4, hipMemcpyHostToDevice, stream_));
+    ScanArgs a = base_args(static_cast<const float*>(ws_queries_.ptr), nullptr);
+    u64* cand_packed = static_cast<u64*>(ws_cand_packed_.ptr);
+    uint32_t* cand_rows = static_cast<uint32_t*>(ws_cand_rows_.ptr);
+    float* cand_scores = static_cast<float*>(ws_cand_scores_.ptr);
+    // ---- pass 1: top-cc rows by the int8 dot ----
+    const int kcap = cc <= 64 ? 64 : 256;
+    if (cc <= 256 && scan_i8_fused_supported((int)dim_, kcap)) {
+        int per_cu = 1;
+        FSGPU_HIP(launch_scan_i8(a, i8_slab_.ptr, ws_i8_query_.ptr, kcap, 1, stream_, &per_cu));
+        int grid = num_cus_ * per_cu;
+        const int max_useful = (int)(((nrows_ + 15) / 16 + 3) / 4);
+        if (grid > max_useful) grid = max_useful;
+        if (grid < 1) grid = 1;
+        FSGPU_TRY(ws_partial_.reserve((size_t)grid * cc * 8));
+        a.partial = static_cast<u64*>(ws_partial_.ptr);
+        a.k = cc;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (profiling) {
+            FSGPU_HIP(hipEventCreate(&e0));
+            FSGPU_HIP(hipEventCreate(&e1));
+            FSGPU_HIP(hipEventRecord(e0, stream_));
+        }
+        FSGPU_HIP(launch_scan_i8(a, i8_slab_.ptr, ws_i8_query_.ptr, kcap, grid, stream_, nullptr));
+        if (profiling) {
+            FSGPU_HIP(hipEventRecord(e1, stream_));
+            events_.emplace_back(e0, e1);
+        }
+        MergeArgs m;
+        m.lists = a.partial;
+        m.q_stride = (uint64_t)grid * cc;
+        m.l_stride = cc;
+        m.nlists = (uint32_t)grid;
+        m.list_len = cc;
+        m.k = cc;
+        m.out_stride = cc;
+        m.out_rows = cand_rows;
+        m.out_scores = nullptr;
+        m.out_counts = nullptr;
+        m.out_packed = nullptr;
+        FSGPU_HIP(launch_merge_topk(m, 1, stream_));
+    } else {
+        FSGPU_TRY(ws_keys_a_.reserve(n * 8));
+        FSGPU_TRY(ws_keys_b_.reserve(n * 8));
+        size_t tmp_bytes = 0;
+        FSGPU_HIP(sort_keys_desc_temp_bytes(n, &tmp_bytes));
+        FSGPU_TRY(ws_sort_tmp_.reserve(tmp_bytes));
+        u64* keys_a = static_cast<u64*>(ws_keys_a_.ptr);
+        u64* keys_b = static_cast<u64*>(ws_keys_b_.ptr);
+        FSGPU_HIP(launch_score_rows_i8(a, i8_slab_.ptr, ws_i8_query_.ptr, keys_a, stream_));
+        FSGPU_HIP(launch_packed_to_sortkey(keys_a, n, stream_));
+        FSGPU_HIP(sort_keys_desc(ws_sort_tmp_.ptr, ws_sort_tmp_.bytes, keys_a, keys_b, n, stream_));
+        FSGPU_HIP(launch_sorted_keys_to_rows(keys_b, cc, cand_rows, static_cast<uint32_t*>(ws_counts_.ptr), stream_));
+    }
+    // ---- pass 2: exact f16 rescore of the candidates, then the usual best-first selection of k ----
+    FSGPU_HIP(hipMemsetAsync(cand_scores, 0, (size_t)cc * 4, stream_));
+    FSGPU_HIP(launch_gather_dot(a, cand_rows, cc, cand_scores, stream_));
+    FSGPU_HIP(launch_pack_hits(cand_rows, cand_scores, cc, cand_packed, stream_));
+    MergeArgs m2;
+    m2.lists = cand_packed;
+    m2.q_stride = cc;
+    m2.l_stride = cc;
+    m2.nlists = 1;
+    m2.list_len = cc;
+    m2.k = k_eff;
+    m2.out_stride = k;
+    m2.out_rows = static_cast<uint32_t*>(ws_rows_.ptr);
+    m2.out_scores = static_cast<float*>(ws_scores_.ptr);
+    m2.out_counts = static_cast<uint32_t*>(ws_counts_.ptr);
+    m2.out_packed = nullptr;
+    m2.lists_sorted = 0;  // candidates arrive in pass-1 (int8) order
+    FSGPU_HIP(launch_merge_topk(m2, 1, stream_));
+    std::vector<uint32_t> rows(k);
+    std::vector<float> scores(k);
+    uint32_t count = 0;
+    FSGPU_HIP(hipMemcpyAsync(rows.data(), ws_rows_.ptr, (size_t)k * 4, hipMemcpyDeviceToHost, stream_));
+    FSGPU_HIP(hipMemcpyAsync(scores.data(), ws_scores_.ptr, (size_t)k * 4, hipMemcpyDeviceToHost, stream_));
+    FSGPU_HIP(hipMemcpyAsync(&count, ws_counts_.ptr, 4, hipMemcpyDeviceToHost, stream_));
+    FSGPU_HIP(hipStreamSynchronize(stream_));
+    // resolve_hits (search.rs:1503-1558): first (best) hit per doc id when the index knows doc ids
+    uint32_t outn = 0;
+    for (uint32_t i = 0; i < count; ++i) {
+        bool dup = false;
+        if (has_doc_ids()) {
+            const size_t r = (size_t)(rows[i] - row_base_);
+            const char* di = doc_blob_.data() + doc_offsets_[r];
+            const size_t dl = (size_t)(doc_offsets_[r + 1] - doc_offsets_[r]);
+            for (uint32_t j = 0; j < outn && !dup; ++j) {
+                const size_t rj = (size_t)(out_rows[j] - row_base_);
+                const size_t lj = (size_t)(doc_offsets_[rj + 1] - doc_offsets_[rj]);
+                dup = lj == dl && std::memcmp(doc_blob_.data() + doc_offsets_[rj], di, dl) == 0;
+            }
+        }
+        if (dup) continue;
+        out_rows[outn] = rows[i];
+        out_scores[outn] = scores[i];
+        ++outn;
+    }
+    *out_count = outn;
     return ok();
 }
 

@@ -63,6 +63,10 @@ class VectorIndex {
     // rows, host merge of the resident WAL entries, WAL shadowing and doc-id dedup.  Needs a doc-id table.
     SearchError search_hits(const float* query, uint32_t query_len, uint32_t k, uint32_t* out_rows, float* out_scores,
                             uint32_t* out_count);
+    // VectorIndex::search_top_k_int8_two_pass (search.rs:514-661): int8 pass-1 over the lazily built int8 slab,
+    // exact f16 rescore of the k*multiplier candidates; falls back to the exact search when a WAL is resident.
+    SearchError search_top_k_int8_two_pass(const float* query, uint32_t query_len, uint32_t k, uint32_t multiplier,
+                                           uint32_t* out_rows, float* out_scores, uint32_t* out_count);
     // VectorIndex::append (lib.rs:2532-2720): resident WAL entry, immediately searchable.
     SearchError wal_append(const char* doc_id, uint32_t len, const float* vector, uint32_t vector_len);
     uint64_t wal_record_count() const { return wal_.size(); }
@@ -102,7 +106,9 @@ class VectorIndex {
     hipStream_t stream_ = nullptr;
     // workspaces (grown on demand, reused)
     DeviceBuffer ws_partial_, ws_queries_, ws_allow_, ws_rows_, ws_scores_, ws_counts_, ws_keys_a_, ws_keys_b_,
-        ws_sort_tmp_, ws_gather_rows_, ws_gather_out_;
+        ws_sort_tmp_, ws_gather_rows_, ws_gather_out_, i8_slab_, i8_max_, ws_i8_query_, ws_cand_packed_,
+        ws_cand_rows_, ws_cand_scores_;
+    bool i8_ready_ = false;
     // profiling events
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events_;
     // FSVI host-side tables

@@ -153,6 +153,15 @@ fsgpu_status fsgpu_search_topk_classified(fsgpu_index *idx, const float *query, 
  * record_count + wal index.  out_* hold up to k entries. */
 fsgpu_status fsgpu_search_hits(fsgpu_index *idx, const float *query, uint32_t query_len, uint32_t k,
                                uint32_t *out_rows, float *out_scores, uint32_t *out_count);
+/* VectorIndex::search_top_k_int8_two_pass(query, k, candidate_multiplier) (search.rs:514-661) — the reference's
+ * production default for the fast tier (two_tier.rs:1332-1337, multiplier 3): pass 1 scans a lazily built int8
+ * slab (one corpus-wide max-abs scale, simd.rs:1865-1886) with the integer-exact dot and keeps the top
+ * max(min(k*mult, N), min(k, N)) rows under (int score desc, row asc); pass 2 re-scores those rows with the exact
+ * f16 dot and selects k under the usual order; doc-id dedup when the index has a doc-id table.  Falls back to the
+ * exact search when a WAL is resident.  Halves the HBM bytes of a pass (N*dim). */
+fsgpu_status fsgpu_search_topk_int8_two_pass(fsgpu_index *idx, const float *query, uint32_t query_len, uint32_t k,
+                                             uint32_t candidate_multiplier, uint32_t *out_rows, float *out_scores,
+                                             uint32_t *out_count);
 /* VectorIndex::dot_query_at (lib.rs:3229-3239) over a row list, as used by
  * TwoTierIndex::quality_scores_for_hits (two_tier.rs:1566-1631).  rows are global ids. */
 fsgpu_status fsgpu_gather_dot(fsgpu_index *idx, const float *query, uint32_t query_len, const uint32_t *rows,

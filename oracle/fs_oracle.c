@@ -473,6 +473,119 @@ int fso_classify_query(const float *q, size_t qlen, uint32_t dim, size_t k, int 
     return FSO_OK;
 }
 
+/* ------------------------------------------------------------------------- */
+/* int8 two-pass                                                              */
+/* ------------------------------------------------------------------------- */
+
+static inline int8_t quant_i8(float x, float scale) {
+    /* (x * scale).round().clamp(-127, 127) as i8 — Rust `as` maps NaN to 0 */
+    float v = roundf(x * scale);
+    if (isnan(v)) return 0;
+    if (v > 127.0f) v = 127.0f;
+    if (v < -127.0f) v = -127.0f;
+    return (int8_t)v;
+}
+
+/* quantize_f16_le_bytes_to_i8_generic (simd.rs:1865-1886) */
+void fso_quantize_slab_i8(const uint8_t *slab, uint64_t n_values, int8_t *out) {
+    float max_abs = 0.0f;
+    for (uint64_t i = 0; i < n_values; ++i) {
+        float v = fabsf(fso_f16_to_f32(load_le16(slab + 2 * i)));
+        if (v > max_abs) max_abs = v; /* f32::max ignores NaN */
+    }
+    if (!(max_abs > 0.0f)) {
+        memset(out, 0, (size_t)n_values);
+        return;
+    }
+    float scale = 127.0f / max_abs;
+    for (uint64_t i = 0; i < n_values; ++i) out[i] = quant_i8(fso_f16_to_f32(load_le16(slab + 2 * i)), scale);
+}
+
+/* quantize_i8_query (search.rs:1616-1626) */
+void fso_quantize_query_i8(const float *q, size_t dim, int8_t *out) {
+    float max_abs = 0.0f;
+    for (size_t i = 0; i < dim; ++i) {
+        float v = fabsf(q[i]);
+        if (v > max_abs) max_abs = v;
+    }
+    if (!(max_abs > 0.0f)) {
+        memset(out, 0, dim);
+        return;
+    }
+    float scale = 127.0f / max_abs;
+    for (size_t i = 0; i < dim; ++i) out[i] = quant_i8(q[i], scale);
+}
+
+/* dot_i8_i8 (simd.rs:757, 1240-1286): exact i32 sum */
+int32_t fso_dot_i8_i8(const int8_t *a, const int8_t *b, size_t n) {
+    int32_t s = 0;
+    for (size_t i = 0; i < n; ++i) s += (int32_t)a[i] * (int32_t)b[i];
+    return s;
+}
+
+typedef struct {
+    uint64_t row;
+    uint32_t desc_key; /* int8_heap_key's high word: smaller = better */
+} i8cand_t;
+
+static int cmp_i8cand(const void *pa, const void *pb) {
+    const i8cand_t *a = (const i8cand_t *)pa, *b = (const i8cand_t *)pb;
+    if (a->desc_key != b->desc_key) return a->desc_key < b->desc_key ? -1 : 1;
+    return a->row < b->row ? -1 : (a->row > b->row);
+}
+
+/* search_top_k_int8_two_pass_impl (search.rs:589-661), int8_heap_key / _from_f32 (:141-156),
+ * MAX_EXACT_I8_DOT_DIM = 1040 (:130-134). */
+size_t fso_search_int8_two_pass(const uint8_t *slab, const int8_t *slab_i8, uint64_t nrows, uint32_t dim,
+                                const uint64_t *live, const float *q, size_t k, size_t candidate_multiplier,
+                                int hreduce, uint32_t *out_rows, float *out_scores) {
+    if (k == 0 || nrows == 0) return 0;
+    size_t mult = candidate_multiplier ? candidate_multiplier : 1;
+    size_t cc = k * mult;
+    if (cc > nrows) cc = (size_t)nrows;
+    size_t kmin = k < nrows ? k : (size_t)nrows;
+    if (cc < kmin) cc = kmin;
+    int8_t *qi = (int8_t *)malloc(dim ? dim : 1);
+    fso_quantize_query_i8(q, dim, qi);
+    i8cand_t *all = (i8cand_t *)malloc(sizeof(i8cand_t) * (size_t)nrows);
+    size_t n = 0;
+    for (uint64_t r = 0; r < nrows; ++r) {
+        if (!row_live(live, r)) continue;
+        int32_t dot = fso_dot_i8_i8(slab_i8 + r * dim, qi, dim);
+        uint32_t asc;
+        if (dim <= 1040) {
+            asc = (uint32_t)dot ^ 0x80000000u;
+        } else {
+            float f = (float)dot;
+            uint32_t bits = f32_bits(f);
+            uint32_t mask = (uint32_t)(-(int32_t)(bits >> 31)) | 0x80000000u;
+            asc = bits ^ mask;
+        }
+        all[n].row = r;
+        all[n].desc_key = ~asc;
+        ++n;
+    }
+    qsort(all, n, sizeof(i8cand_t), cmp_i8cand); /* the bounded heap keeps exactly the cc smallest keys */
+    if (n > cc) n = cc;
+    heap_t heap;
+    heap_init(&heap, k + 1);
+    size_t stride = (size_t)dim * 2;
+    for (size_t i = 0; i < n; ++i) {
+        entry_t e = {all[i].row, fso_dot_f16_f32(slab + all[i].row * stride, q, dim, hreduce)};
+        insert_candidate(&heap, e, k);
+    }
+    qsort(heap.v, heap.len, sizeof(entry_t), cmp_best_first);
+    size_t outn = heap.len;
+    for (size_t i = 0; i < outn; ++i) {
+        out_rows[i] = (uint32_t)heap.v[i].row;
+        out_scores[i] = heap.v[i].score;
+    }
+    heap_free(&heap);
+    free(all);
+    free(qi);
+    return outn;
+}
+
 /* VectorIndex::dot_query_at (lib.rs:3229-3239) over a row list (two_tier.rs:1566-1631). */
 void fso_gather_dot(const uint8_t *slab, uint32_t dim, const float *q, const uint32_t *rows,
                     size_t n, int hreduce, float *out) {

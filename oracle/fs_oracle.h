@@ -80,6 +80,20 @@ size_t fso_search_top_k(const uint8_t *slab, uint64_t nrows, uint32_t dim, const
  * *zero_signal: 0 none, 1 CallerRequestedZeroK, 2 ZeroNormQuery. */
 int fso_classify_query(const float *q, size_t qlen, uint32_t dim, size_t k, int *zero_signal);
 
+/* ---- int8 two-pass (search.rs:514-661; simd.rs:757-1286,1865-1886) ---- */
+/* quantize_f16_le_bytes_to_i8_generic: ONE corpus-wide max-abs scale, round() half away from zero, clamp +-127. */
+void fso_quantize_slab_i8(const uint8_t *slab_f16_le, uint64_t n_values, int8_t *out);
+/* quantize_i8_query (search.rs:1616-1626): the query's own max-abs scale. */
+void fso_quantize_query_i8(const float *q, size_t dim, int8_t *out);
+int32_t fso_dot_i8_i8(const int8_t *a, const int8_t *b, size_t n);
+/* search_top_k_int8_two_pass without WAL / doc-id resolution: pass 1 keeps the top
+ * candidate_count = max(min(k*mult, n), min(k, n)) rows by (int score desc [as f32 when dim > 1040], row asc),
+ * pass 2 re-scores them with the exact f16 dot and selects the top k under the usual order.
+ * slab_i8 is the output of fso_quantize_slab_i8 for the same slab.  Returns the hit count. */
+size_t fso_search_int8_two_pass(const uint8_t *slab, const int8_t *slab_i8, uint64_t nrows, uint32_t dim,
+                                const uint64_t *live, const float *q, size_t k, size_t candidate_multiplier,
+                                int hreduce, uint32_t *out_rows, float *out_scores);
+
 /* gather-dot: VectorIndex::dot_query_at (lib.rs:3229-3239) for a list of rows. */
 void fso_gather_dot(const uint8_t *slab, uint32_t dim, const float *q, const uint32_t *rows,
                     size_t n, int hreduce, float *out);

@@ -106,6 +106,13 @@ def lib() -> C.CDLL:
         L.fso_fsvi_wal_count.argtypes = [C.c_void_p]
         L.fso_fsvi_wal_doc_id.restype = C.c_uint32
         L.fso_fsvi_wal_doc_id.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+        L.fso_quantize_slab_i8.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        L.fso_quantize_query_i8.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.fso_dot_i8_i8.restype = C.c_int32
+        L.fso_dot_i8_i8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.fso_search_int8_two_pass.restype = C.c_size_t
+        L.fso_search_int8_two_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
+                                               C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         L.fso_fixture_hashmix.restype = C.c_float
         L.fso_fixture_hashmix.argtypes = [C.c_uint64, C.c_uint64]
         L.fso_raw_vector.argtypes = [C.c_uint64, C.c_uint32, C.c_void_p]
@@ -180,6 +187,44 @@ def search_top_k(slab_u16: np.ndarray, q: np.ndarray, k: int, live: np.ndarray |
     cnt = lib().fso_search_top_k(_p(slab), n, dim, _p(bm) if bm is not None else None, _p(q), k,
                                  parallel_threshold, chunk_size, int(parallel_enabled), nthreads, hreduce,
                                  _p(rows), _p(scores))
+    return rows[:cnt].copy(), scores[:cnt].copy()
+
+
+def quantize_slab_i8(slab_u16: np.ndarray) -> np.ndarray:
+    slab = np.ascontiguousarray(slab_u16, dtype=np.uint16)
+    out = np.empty(slab.shape, dtype=np.int8)
+    lib().fso_quantize_slab_i8(_p(slab), slab.size, _p(out))
+    return out
+
+
+def quantize_query_i8(q: np.ndarray) -> np.ndarray:
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    out = np.empty(q.size, dtype=np.int8)
+    lib().fso_quantize_query_i8(_p(q), q.size, _p(out))
+    return out
+
+
+def dot_i8_i8(a: np.ndarray, b: np.ndarray) -> int:
+    a = np.ascontiguousarray(a, dtype=np.int8)
+    b = np.ascontiguousarray(b, dtype=np.int8)
+    return lib().fso_dot_i8_i8(_p(a), _p(b), a.size)
+
+
+def search_int8_two_pass(slab_u16: np.ndarray, q: np.ndarray, k: int, candidate_multiplier: int = 3,
+                         live: np.ndarray | None = None, slab_i8: np.ndarray | None = None,
+                         hreduce: int = HREDUCE_SSE2):
+    """VectorIndex::search_top_k_int8_two_pass (search.rs:514-661) on a raw slab (no WAL, no doc-id dedup)."""
+    slab = np.ascontiguousarray(slab_u16, dtype=np.uint16)
+    n, dim = slab.shape
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    if slab_i8 is None:
+        slab_i8 = quantize_slab_i8(slab)
+    cap = max(1, min(k, n))
+    rows = np.empty(cap, dtype=np.uint32)
+    scores = np.empty(cap, dtype=np.float32)
+    bm = live_bitmap(np.asarray(live, dtype=bool)) if live is not None else None
+    cnt = lib().fso_search_int8_two_pass(_p(slab), _p(slab_i8), n, dim, _p(bm) if bm is not None else None, _p(q), k,
+                                         candidate_multiplier, hreduce, _p(rows), _p(scores))
     return rows[:cnt].copy(), scores[:cnt].copy()
 
 

@@ -356,3 +356,38 @@ def test_wal_overlay_matches_oracle(fa, oracle, tmp_path):
             gh = g.search_top_k(q, k)
             assert [(h.index, h.doc_id) for h in gh] == [(h[0], h[2]) for h in oh]
             assert np.array_equal(bits([h.score for h in gh]), bits(os_))
+
+
+def test_int8_two_pass_matches_oracle(fa, oracle, tmp_path):
+    # search.rs:514-661; keep-all fixture (search.rs:1815-1859); slab quantiser simd.rs:1865-1886
+    rng = np.random.default_rng(71)
+    slab = oracle.encode_f32_to_f16(oracle.fixture_hashmix(300, 8))
+    idx = fa.VectorIndex.from_slab(slab)
+    for qi in range(8):
+        q = np.array([(((qi * 7 + j * 3) % 11) / 11.0) - 0.5 for j in range(8)], dtype=np.float32)
+        er, es = oracle.search_int8_two_pass(slab, q, 10, 50)
+        gh = idx.search_top_k_int8_two_pass(q, 10, 50)
+        assert [h.index for h in gh] == er.tolist() and np.array_equal(bits([h.score for h in gh]), bits(es))
+    for n, dim in ((20000, 384), (7001, 256), (3000, 128), (5000, 40), (900, 768)):
+        slab = rand_slab(rng, n, dim)
+        si8 = oracle.quantize_slab_i8(slab)
+        live = rng.random(n) > 0.1
+        idx = fa.VectorIndex.from_slab(slab, live=live)
+        for k, mult in ((10, 3), (1, 1), (30, 5), (64, 3), (100, 3), (10, 0)):
+            q = rng.standard_normal(dim).astype(np.float32)
+            er, es = oracle.search_int8_two_pass(slab, q, k, mult, live=live, slab_i8=si8)
+            gh = idx.search_top_k_int8_two_pass(q, k, mult)
+            assert [h.index for h in gh] == er.tolist(), (n, dim, k, mult)
+            assert np.array_equal(bits([h.score for h in gh]), bits(es))
+    # FSVI + WAL: falls back to the exact path (search.rs:579-585)
+    p = str(tmp_path / "i8.fsvi")
+    rows = [(f"doc-{i:03}", rng.standard_normal(64).astype(np.float32).tolist()) for i in range(200)]
+    oracle.fsvi_write(p, rows)
+    g, o = fa.VectorIndex.open(p), oracle.Fsvi(p)
+    q = rng.standard_normal(64).astype(np.float32)
+    er, es = oracle.search_int8_two_pass(o.slab(), q, 10, 3)
+    gh = g.search_top_k_int8_two_pass(q, 10, 3)
+    assert [h.index for h in gh] == er.tolist() and gh[0].doc_id == o.doc_id(int(er[0]))
+    g.append("fresh", rng.standard_normal(64).astype(np.float32))
+    o.append("fresh", np.zeros(64, np.float32) + 1)  # only to mirror the WAL presence
+    assert [h.index for h in g.search_top_k_int8_two_pass(q, 10, 3)] == [h.index for h in g.search_top_k(q, 10)]

@@ -445,3 +445,59 @@ def test_wal_append_validation_and_supersede(oracle, tmp_path):
     assert idx.wal_record_count == 1
     hits, _ = idx.search_top_k([1.0, 0, 0, 0], 10)
     assert [h[2] for h in hits] == ["a", "b", "x"] and abs(hits[2][1] - 0.1) < 1e-6
+
+
+# ---------------------------------------------------------------- int8 two-pass
+def test_int8_quantizers(oracle):
+    # simd.rs:1865-1886 (one corpus-wide scale, round half away, clamp) and search.rs:1616-1626
+    slab = np.array([[1.0, -0.5, 0.25, 0.0], [0.00390625, -1.0, 0.5039, 0.5]], np.float16)
+    qi = oracle.quantize_slab_i8(slab.view(np.uint16))
+    want = np.clip(np.sign(slab.astype(np.float32)) * np.floor(np.abs(slab.astype(np.float32) * np.float32(127.0)) + 0.5), -127, 127)
+    assert np.array_equal(qi, want.astype(np.int8))
+    assert np.all(oracle.quantize_slab_i8(np.zeros((3, 4), np.uint16)) == 0)
+    q = np.array([0.2, -0.4, 0.1, 0.0], np.float32)
+    assert oracle.quantize_query_i8(q).tolist() == [64, -127, 32, 0]     # 0.2*317.5=63.5 -> 64 (half away)
+    assert np.all(oracle.quantize_query_i8(np.zeros(4, np.float32)) == 0)
+    rng = np.random.default_rng(2)
+    a, b = rng.integers(-127, 128, 384).astype(np.int8), rng.integers(-127, 128, 384).astype(np.int8)
+    assert oracle.dot_i8_i8(a, b) == int(np.dot(a.astype(np.int64), b.astype(np.int64)))   # simd.rs:2776 dot_i8_i8_matches_scalar
+
+
+def test_int8_two_pass_keep_all_matches_exact(oracle):
+    # search.rs:1815-1859: 300 x 8 hash-mixed rows, mult=50 keeps all -> identical to the exact search
+    slab = oracle.encode_f32_to_f16(oracle.fixture_hashmix(300, 8))
+    for qi in range(8):
+        q = np.array([(((qi * 7 + j * 3) % 11) / 11.0) - 0.5 for j in range(8)], dtype=np.float32)
+        er, es = oracle.search_top_k(slab, q, 10)
+        ar, a_s = oracle.search_int8_two_pass(slab, q, 10, 50)
+        assert np.array_equal(er, ar) and np.array_equal(es.view(np.uint32), a_s.view(np.uint32))
+
+
+def test_int8_two_pass_recall_on_clustered_fixture(oracle):
+    # search.rs:1927-2006 recall guard shape (16 clusters x 4000 x 384): int8 mult=3 recall@10 vs exact
+    rng = np.random.default_rng(4)
+    cent = rng.standard_normal((16, 384)).astype(np.float32)
+    cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+    rows = cent[np.arange(8000) % 16] + 0.1 * rng.standard_normal((8000, 384)).astype(np.float32)
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    slab = oracle.encode_f32_to_f16(rows)
+    si8 = oracle.quantize_slab_i8(slab)
+    hits = 0
+    for qi in range(10):
+        q = cent[qi] + 0.1 * rng.standard_normal(384).astype(np.float32)
+        q /= np.linalg.norm(q)
+        er, _ = oracle.search_top_k(slab, q, 10)
+        ar, _ = oracle.search_int8_two_pass(slab, q, 10, 3, slab_i8=si8)
+        hits += len(set(er.tolist()) & set(ar.tolist()))
+    assert hits >= 95   # >= 0.95 recall@10
+
+
+def test_int8_two_pass_tombstones_and_small_n(oracle):
+    rng = np.random.default_rng(6)
+    slab = rng.standard_normal((50, 16)).astype(np.float16).view(np.uint16)
+    q = rng.standard_normal(16).astype(np.float32)
+    live = np.ones(50, bool)
+    live[:10] = False
+    r, s = oracle.search_int8_two_pass(slab, q, 100, 3, live=live)     # candidate_count clamps to n
+    er, es = oracle.search_top_k(slab, q, 100, live=live)
+    assert np.array_equal(r, er) and np.array_equal(s.view(np.uint32), es.view(np.uint32))
