@@ -119,7 +119,7 @@ def two_tier_section(quality_index, rows: int, k: int, device, local_rank: int):
     Sequential single-query latency of the Initial (phase 0) and Refined (phase 1) deliveries."""
     import frankensearch_amd as fa
     from frankensearch_amd.two_tier import SyncTwoTierSearcher
-    from oracle import bert_oracle  # only its seeded synthetic-weight generator (no real weights exist offline)
+    from frankensearch_amd.synthetic import random_bert_weights  # seeded synthetic weights (none exist offline)
 
     fast_dim = 256
     fast_slab = gen_corpus(0, rows, fast_dim, device)
@@ -128,7 +128,7 @@ def two_tier_section(quality_index, rows: int, k: int, device, local_rank: int):
     rng = np.random.default_rng(0)
     table = rng.standard_normal((500_353, fast_dim)).astype(np.float32)   # potion-multilingual-128M shape
     m2v = fa.Model2VecEmbedder(table, device=local_rank)
-    bert = fa.NativeEmbedder(bert_oracle.random_weights(1, 30522, 384, 6, 1536), device=local_rank)
+    bert = fa.NativeEmbedder(random_bert_weights(1, 30522, 384, 6, 1536), device=local_rank)
     searcher = SyncTwoTierSearcher(fast_index, quality_index, m2v, bert, lambda r: f"doc-{r:08d}")
     p0, p1 = [], []
     for i in range(48):
@@ -155,6 +155,32 @@ def two_tier_section(quality_index, rows: int, k: int, device, local_rank: int):
     fast_index.close()
     del fast_slab
     return res
+
+
+def int8_section(index, rows: int, dim: int, k: int, queries):
+    """The reference's production fast-tier path (search_top_k_int8_two_pass, multiplier 3) on the same corpus:
+    pass-1 int8 scan (N*dim bytes) + exact f16 rescore.  Sequential single queries, host-pointer ABI."""
+    q = queries[:24].cpu().numpy()
+    index.search_top_k_int8_two_pass(q[0], k, 3)   # builds the int8 slab (lazy, once)
+    index.set_profiling(True)
+    index.scan_time(reset=True)
+    lat = []
+    for i in range(24):
+        t0 = time.perf_counter()
+        index.search_top_k_int8_two_pass(q[i], k, 3)
+        lat.append((time.perf_counter() - t0) * 1e3)
+    index.set_profiling(False)
+    scan_ms, launches = index.scan_time(reset=True)
+    lat = sorted(lat[4:])
+    per = scan_ms / max(launches, 1)
+    gbps = rows * dim / (per * 1e-3) / 1e9 if per > 0 else 0.0
+    recall = 0
+    for i in range(8):
+        exact = {h.index for h in index.search_top_k(q[i], k)}
+        recall += len(exact & {h.index for h in index.search_top_k_int8_two_pass(q[i], k, 3)})
+    return {"p50_latency_ms": lat[len(lat) // 2], "pass1_kernel_ms": per, "pass1_GBps": gbps,
+            "pass1_frac_of_hbm_peak": gbps / HBM_PEAK_GBPS, "algorithmic_bytes": rows * dim,
+            "recall_at_k_vs_exact": recall / (8 * k)}
 
 
 def main() -> None:
@@ -286,6 +312,7 @@ def main() -> None:
         if lat:
             line["p50_latency_ms_single_query"] = lat[len(lat) // 2]
         if world == 1 and not args.no_two_tier:
+            line["int8_two_pass"] = int8_section(index, args.rows, args.dim, k, queries)
             tt = two_tier_section(index, args.rows, k, device, local_rank)
             line["two_tier"] = tt
             line["p50_phase1_latency_ms"] = tt["phase1_p50_ms"]

@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import frankensearch_amd as fa
-from oracle import bert_oracle
+from frankensearch_amd.synthetic import random_bert_weights
 
 rng = np.random.default_rng(0)
 B = int(os.environ.get("B", "256"))
@@ -20,7 +20,7 @@ t0 = time.perf_counter()
 for _ in range(50): m2v.embed_token_ids(qs[0])
 print(f"{(time.perf_counter()-t0)/50*1e3:.3f} ms")
 
-w = bert_oracle.random_weights(1, 30522, 384, 6, 1536)
+w = random_bert_weights(1, 30522, 384, 6, 1536)
 bert = fa.NativeEmbedder(w)
 batch = [[101] + rng.integers(1000, 30000, int(rng.integers(6, 31))).tolist() + [102] for _ in range(B)]
 tokens = sum(len(b) for b in batch)

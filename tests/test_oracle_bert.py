@@ -43,3 +43,12 @@ def test_oracle_invariants():
     # bare and bert.-prefixed keys are the same model (native.rs:1466-1476)
     w2 = {("bert." + k): v for k, v in w.items()}
     assert np.array_equal(bert_oracle.embed_forward(w2, batch, 2), out)
+
+
+def test_product_synthetic_generator_matches_oracle_generator():
+    """frankensearch_amd.synthetic (used by bench.py) and the oracle's generator are the same function of the seed."""
+    from frankensearch_amd.synthetic import random_bert_weights
+    from oracle import bert_oracle
+    a = random_bert_weights(9, 50, 128, 1, 256)
+    b = bert_oracle.random_weights(9, 50, 128, 1, 256)
+    assert a.keys() == b.keys() and all(np.array_equal(a[k], b[k]) for k in a)
