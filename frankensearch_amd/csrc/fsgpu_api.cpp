@@ -172,6 +172,39 @@ fsgpu_status fsgpu_search_topk_device(fsgpu_index* idx, const float* queries_dev
     });
 }
 
+fsgpu_status fsgpu_search_topk_batched(fsgpu_index* idx, const float* queries, uint32_t nq, uint32_t query_len,
+                                       uint32_t k, const uint64_t* allow_bitmap, uint32_t* out_rows, float* out_scores,
+                                       uint32_t* out_counts, uint32_t* out_fallbacks) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    if (nq && (!queries || !out_counts || (k && (!out_rows || !out_scores))))
+        return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.search_top_k_batched(queries, nq, query_len, k, allow_bitmap, out_rows, out_scores,
+                                                     out_counts, out_fallbacks));
+    });
+}
+
+fsgpu_status fsgpu_search_topk_batched_device(fsgpu_index* idx, const float* queries_dev, uint32_t nq,
+                                              uint32_t query_len, uint32_t k, const uint64_t* allow_bitmap_dev,
+                                              uint32_t* out_rows_dev, float* out_scores_dev, uint32_t* out_counts_dev,
+                                              void* hip_stream, uint32_t* out_fallbacks) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    if (nq && (!queries_dev || !out_counts_dev || (k && (!out_rows_dev || !out_scores_dev))))
+        return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        if (k == 0 || idx->impl.record_count() == 0) {
+            if (hipMemsetAsync(out_counts_dev, 0, (size_t)nq * 4, static_cast<hipStream_t>(hip_stream)) != hipSuccess)
+                return fail(FSGPU_ERR_DEVICE, "hipMemsetAsync failed");
+            return FSGPU_OK;
+        }
+        return finish(idx->impl.search_top_k_batched_device(queries_dev, nq, query_len, k, allow_bitmap_dev, out_rows_dev,
+                                                            out_scores_dev, out_counts_dev,
+                                                            static_cast<hipStream_t>(hip_stream), out_fallbacks));
+    });
+}
+
 fsgpu_status fsgpu_search_topk_packed_device(fsgpu_index* idx, const float* queries_dev, uint32_t nq,
                                              uint32_t query_len, uint32_t k, const uint64_t* allow_bitmap_dev,
                                              uint64_t* out_packed_dev, void* hip_stream) {

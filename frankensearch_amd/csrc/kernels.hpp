@@ -35,6 +35,7 @@ struct MergeArgs {
     uint32_t* out_counts;   // [nq]
     u64* out_packed;        // optional [nq, out_stride] packed copy of the result (kEmpty padded)
     uint32_t lists_sorted = 1;  // 0: the lists are NOT best-first (disables the head/tail pruning bounds)
+    const uint32_t* list_counts = nullptr;  // optional [nq]: valid entries of each query's (single) list
 };
 
 size_t scan_lds_bytes(int dim, int nq, int kcap);
@@ -61,6 +62,33 @@ hipError_t sort_keys_desc(void* temp, size_t temp_bytes, const u64* keys_in, u64
 // m2v_kernels.hip
 hipError_t launch_m2v_embed(const float* table, uint32_t vocab, uint32_t dim, const uint32_t* ids,
                             const uint32_t* offsets, uint32_t n, float* out, hipStream_t stream);
+
+// mfma_scan.hip — batched approximate scan on the matrix cores + exact re-score helpers
+struct MfmaScanArgs {
+    const void* slab;          // [nrows, dim] f16
+    const u64* live;           // may be null
+    const u64* allow;          // may be null
+    const void* queries;       // [nq_pad, dim] f16 (rows >= nq are zero)
+    const float* tau;          // [nq_pad] candidate threshold per query (ignored in dense mode)
+    u64* cand;                 // [nq_pad, cap] packed approximate candidates
+    uint32_t* counts;          // [nq_pad]
+    u64* dense;                // dense mode: [nq_pad, row_end - row_begin] packed approximate scores
+    uint32_t row_begin, row_end;  // row_begin % 16 == 0
+    uint32_t dim, cap, row_base;
+};
+
+bool scan_mfma_supported(int dim);
+hipError_t launch_scan_mfma(const MfmaScanArgs& args, int nqt, int grid, hipStream_t stream, int* occupancy);
+hipError_t launch_max_row_norm(const void* slab, uint32_t nrows, uint32_t dim, unsigned int* out_bits, hipStream_t stream);
+hipError_t launch_prepare_queries(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim,
+                                  const unsigned int* max_norm_bits, void* qh, float* delta, hipStream_t stream);
+hipError_t launch_tau_from_selection(const u64* sel, const uint32_t* sel_counts, uint32_t stride, uint32_t k,
+                                     const float* delta, float* tau, uint32_t nq_pad, hipStream_t stream);
+hipError_t launch_clamp_counts(uint32_t* counts, uint32_t cap, uint32_t* overflow, uint32_t nq_pad, hipStream_t stream);
+hipError_t launch_margin_check(const u64* sel, const uint32_t* sel_counts, uint32_t kc, uint32_t k, const float* delta,
+                               uint32_t* overflow, uint32_t nq_pad, hipStream_t stream);
+hipError_t launch_gather_dot_batch(const ScanArgs& args, const uint32_t* rows, uint32_t per, uint32_t nq,
+                                   u64* out_packed, hipStream_t stream);
 
 // int8_kernels.hip
 hipError_t launch_quantize_slab_i8(const void* slab_f16, size_t n_values, unsigned int* max_bits_dev, void* out_i8,

@@ -1,0 +1,374 @@
+// mfma_scan.hip — batched f16 cosine scan on the matrix cores: 64 queries per pass over the slab, with results
+// that are still BIT-IDENTICAL to the reference CPU path.
+//
+// The exact VALU kernels (scan_kernels.hip, scan_mq_kernel.hip) reproduce the reference's f32 operation order and
+// top out at 4-8 queries per HBM pass.  Here the contraction slab[rows,dim] x queries[dim,64] runs on
+// v_mfma_f32_16x16x32_f16 with the queries rounded to f16, which gives only APPROXIMATE scores a(r,q).  Exactness
+// is recovered by a provable filter + exact re-score (the same pass-1 / pass-2 shape the reference ships for int8,
+// crates/frankensearch-index/src/search.rs:589-661):
+//
+//   |a(r,q) - s(r,q)| <= delta_q = (2^-11 (1+2^-11) + dim 2^-23) * max_row_norm * |q| + sqrt(dim) 2^-25 * max_row_norm
+//       (f16 rounding of the query: relative 2^-11 per element, Cauchy-Schwarz over the row; f32 accumulation of
+//        exact f16 x f16 products inside the MFMA; f16-subnormal query elements)
+//   so every true top-k row has a >= a_k - 2 delta_q, where a_k is the k-th largest approximate score of ANY
+//   subset of rows (a subset's k-th best is a lower bound of the corpus' k-th best).
+//
+// Pipeline per group of <= 64 queries (host side in vector_index.cpp):
+//   stage A: dense approximate scores of the first rows  -> k-th best -> tau_q = a_k - 2 delta_q
+//   stage B: next row range, rows with a >= tau_q appended to per-query candidate lists -> tighter tau_q
+//   stage C: the rest of the slab with the final tau_q (a few hundred survivors per query out of 10M rows)
+//   select the KC best approximate candidates, verify the margin (a_KC < a_k - 2 delta_q, else the query is re-run on
+//   the exact kernel), re-score those rows with the exact-order dot (gather kernel) and select k under the
+//   reference order.  The final rows AND score bits therefore equal the exact path's.
+//
+// Kernel mapping: a wave owns 16-row tiles (12 KB at dim 384, double-buffered in registers); the A fragment of the
+// MFMA is K-contiguous, i.e. a lane's 16 bytes of its slab row — loaded straight from HBM; the 64 f16 queries sit
+// in LDS ([64][dim+8] halves: the 16-byte pad staggers rows across banks) and are read as B fragments with one
+// ds_read_b128 per (k-step, query tile).  Algorithmic bytes per pass are still N*dim*2: at 64 queries the kernel is
+// HBM-bound (MFMA ~16 % busy), the ridge sits near 200 queries.
+#include "scan_common.hpp"
+
+namespace fsgpu {
+
+using namespace scan_detail;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int DIM, int NQT>
+__global__ __launch_bounds__(256) void scan_mfma_kernel(MfmaScanArgs args) {
+    constexpr int KS = DIM / 32;        // MFMA k-steps
+    constexpr int QSTRIDE = DIM + 8;    // halves per query row in LDS (16-byte pad)
+    constexpr int NQ = NQT * 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    _Float16* qs = reinterpret_cast<_Float16*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 15;  // A: row inside the tile / B: query inside the query tile / C: column (query)
+    const int fk = lane >> 4;    // k-group (8 halves each) / C: row group (4 rows each)
+    {   // stage the queries: 16-byte pieces, coalesced
+        const u32x4* src = static_cast<const u32x4*>(args.queries);
+        constexpr int PIECES = DIM / 8;
+        for (int i = tid; i < NQ * PIECES; i += 256) {
+            const int q = i / PIECES, p = i - q * PIECES;
+            *reinterpret_cast<u32x4*>(qs + (size_t)q * QSTRIDE + p * 8) = src[(size_t)q * PIECES + p];
+        }
+    }
+    __syncthreads();
+    float tau[NQT];
+#pragma unroll
+    for (int nt = 0; nt < NQT; ++nt) tau[nt] = args.dense ? -INFINITY : args.tau[nt * 16 + frow];
+
+    const uint32_t first_tile = args.row_begin / 16;
+    const uint32_t ntiles = (args.row_end - args.row_begin + 15) / 16;
+    const uint32_t nwaves = gridDim.x * kWavesPerBlock;
+    const unsigned char* slab = reinterpret_cast<const unsigned char*>(args.slab);
+    constexpr size_t row_bytes = (size_t)DIM * 2;
+    const uint32_t last_row = args.row_end - 1;
+
+    auto load_tile = [&](uint32_t t, half8 (&w)[KS]) {
+        uint32_t row = (first_tile + t) * 16 + frow;
+        row = row < args.row_end ? row : last_row;
+        const half8* p = reinterpret_cast<const half8*>(slab + (size_t)row * row_bytes) + fk;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) w[ks] = p[ks * 4];
+    };
+    auto tile_words = [&](uint32_t t, u64& live_word, u64& allow_word) {
+        const uint32_t w64 = ((first_tile + t) * 16) >> 6;
+        live_word = args.live ? args.live[w64] : ~0ull;
+        allow_word = args.allow ? args.allow[w64] : ~0ull;
+    };
+    auto compute_tile = [&](uint32_t t, const half8 (&w)[KS], u64 live_word, u64 allow_word) {
+        f32x4 acc[NQT];
+#pragma unroll
+        for (int nt = 0; nt < NQT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int nt = 0; nt < NQT; ++nt) {
+                const half8 b = *reinterpret_cast<const half8*>(qs + (size_t)(nt * 16 + frow) * QSTRIDE + ks * 32 + fk * 8);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ks], b, acc[nt], 0, 0, 0);
+            }
+            // keep the B-fragment reads of later k-steps below this point: unconstrained, hipcc hoists all KS*NQT
+            // ds_read_b128 to the top of the tile (192 extra registers at dim 384 -> one wave per SIMD)
+            if constexpr (NQT == 4)
+                asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])::"memory");
+        }
+        // C layout: column (query) = lane & 15, row = (lane >> 4) * 4 + reg
+        const uint32_t row0 = (first_tile + t) * 16 + fk * 4;
+        bool valid[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t row = row0 + r;
+            valid[r] = row < args.row_end && ((live_word >> (row & 63)) & 1ull) && ((allow_word >> (row & 63)) & 1ull);
+        }
+        if (args.dense) {
+            const size_t span = args.row_end - args.row_begin;
+#pragma unroll
+            for (int nt = 0; nt < NQT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t row = row0 + r;
+                    if (row < args.row_end)
+                        args.dense[(size_t)(nt * 16 + frow) * span + (row - args.row_begin)] =
+                            valid[r] ? pack(acc[nt][r], args.row_base + row) : kEmpty;
+                }
+            return;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NQT; ++nt) {
+            const float th = tau[nt];
+            bool any = false;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) any = any || (valid[r] && acc[nt][r] >= th);
+            if (!any) continue;  // per-lane: survivors are a few hundred rows out of the whole slab
+            const int q = nt * 16 + frow;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (valid[r] && acc[nt][r] >= th) {
+                    // a list that already overflowed sends its query to the exact path: stop feeding it
+                    if (__hip_atomic_load(&args.counts[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > args.cap) continue;
+                    const uint32_t pos = atomicAdd(&args.counts[q], 1u);
+                    if (pos < args.cap) args.cand[(size_t)q * args.cap + pos] = pack(acc[nt][r], args.row_base + row0 + r);
+                }
+        }
+    };
+
+    half8 wa[KS], wb[KS];
+    u64 la = ~0ull, aa = ~0ull, lb = ~0ull, ab = ~0ull;
+    uint32_t t = blockIdx.x * kWavesPerBlock + wave;
+    if (t < ntiles) {
+        load_tile(t, wa);
+        tile_words(t, la, aa);
+    }
+    while (t < ntiles) {
+        uint32_t next = t + nwaves;
+        if (next < ntiles) {
+            load_tile(next, wb);
+            tile_words(next, lb, ab);
+        }
+        compute_tile(t, wa, la, aa);
+        t = next;
+        if (t >= ntiles) break;
+        next = t + nwaves;
+        if (next < ntiles) {
+            load_tile(next, wa);
+            tile_words(next, la, aa);
+        }
+        compute_tile(t, wb, lb, ab);
+        t = next;
+    }
+}
+
+// max over rows of the f32 Euclidean norm (order-free upper bound use only), as float bits via atomic max.
+__global__ __launch_bounds__(256) void max_row_norm_kernel(const unsigned short* __restrict__ slab, uint32_t nrows,
+                                                           uint32_t dim, unsigned int* __restrict__ out_bits) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_gid = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * 256) >> 6;
+    float m = 0.f;
+    for (uint32_t row = wave_gid; row < nrows; row += nwaves) {
+        const _Float16* p = reinterpret_cast<const _Float16*>(slab) + (size_t)row * dim;
+        float s = 0.f;
+        for (uint32_t i = lane; i < dim; i += 64) {
+            const float v = (float)p[i];
+            s += v * v;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        m = fmaxf(m, s);
+    }
+    if (lane == 0) atomicMax(out_bits, __float_as_uint(sqrtf(m) * 1.0001f));
+}
+
+// f32 queries -> zero-padded f16 rows + the per-query error bound delta_q (see header).
+__global__ __launch_bounds__(256) void prepare_queries_kernel(const float* __restrict__ q, uint32_t nq, uint32_t nq_pad,
+                                                              uint32_t dim, const unsigned int* __restrict__ max_norm_bits,
+                                                              _Float16* __restrict__ qh, float* __restrict__ delta) {
+    __shared__ float red[4];
+    const uint32_t b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float s = 0.f;
+    for (uint32_t i = tid; i < dim; i += 256) {
+        const float v = b < nq ? q[(size_t)b * dim + i] : 0.f;
+        qh[(size_t)b * dim + i] = (_Float16)v;
+        s += v * v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+        const float qnorm = sqrtf(red[0] + red[1] + red[2] + red[3]) * 1.0001f;
+        const float mx = __uint_as_float(*max_norm_bits);
+        const float rel = 4.8852e-4f /* 2^-11 (1 + 2^-11) */ + (float)dim * 1.1920929e-7f /* 2^-23 */;
+        float d = rel * mx * qnorm + sqrtf((float)dim) * 2.9802322e-8f /* 2^-25 */ * mx;
+        // padding rows, all-zero and non-finite queries cannot be certified: negative delta = "skip" marker
+        if (b >= nq || !(qnorm > 0.f) || !__builtin_isfinite(d)) d = -1.0f;
+        delta[b] = d;
+        (void)nq_pad;
+    }
+}
+
+// tau_q from a best-first approximate selection: the k-th best approximate score minus 2 delta_q (-inf when fewer
+// than k rows were seen).  `sel` is [nq_pad, stride] packed, counts the number of valid entries per query.
+__global__ void tau_from_selection_kernel(const u64* __restrict__ sel, const uint32_t* __restrict__ sel_counts,
+                                          uint32_t stride, uint32_t k, const float* __restrict__ delta,
+                                          float* __restrict__ tau, uint32_t nq_pad) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq_pad) return;
+    float t = -INFINITY;
+    if (delta[q] < 0.f) {  // skipped query: no candidates at all (answered by the exact path or padding)
+        tau[q] = INFINITY;
+        return;
+    }
+    if (sel_counts[q] >= k) {
+        const float ak = __uint_as_float((uint32_t)(sel[(size_t)q * stride + (k - 1)] >> 32));
+        t = ak - 2.0f * delta[q];
+        if (!(t == t)) t = -INFINITY;
+    }
+    tau[q] = t;
+}
+
+// Candidate bookkeeping between stages: clamp counts to cap, flag overflow.
+__global__ void clamp_counts_kernel(uint32_t* __restrict__ counts, uint32_t cap, uint32_t* __restrict__ overflow,
+                                    uint32_t nq_pad) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq_pad) return;
+    if (counts[q] > cap) {
+        overflow[q] = 1;
+        counts[q] = cap;
+    }
+}
+
+// Margin check on the KC best approximate candidates: the set is complete iff it holds fewer than KC entries or its
+// last entry is already below a_k - 2 delta (then every row outside the set is below the threshold too).
+__global__ void margin_check_kernel(const u64* __restrict__ sel, const uint32_t* __restrict__ sel_counts, uint32_t kc,
+                                    uint32_t k, const float* __restrict__ delta, uint32_t total_candidates_cap,
+                                    const uint32_t* __restrict__ cand_counts, uint32_t* __restrict__ overflow,
+                                    uint32_t nq_pad) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq_pad) return;
+    if (delta[q] < 0.f) {
+        overflow[q] = 1;
+        return;
+    }
+    const uint32_t n = sel_counts[q];
+    if (n < kc || n < k) return;  // every candidate is in the set (fewer than k: the exact path decides)
+    (void)total_candidates_cap;
+    (void)cand_counts;
+    const float ak = __uint_as_float((uint32_t)(sel[(size_t)q * kc + (k - 1)] >> 32));
+    const float alast = __uint_as_float((uint32_t)(sel[(size_t)q * kc + (kc - 1)] >> 32));
+    if (!(alast < ak - 2.0f * delta[q])) overflow[q] = 1;
+}
+
+// Exact-order dot of (query b, row) pairs: rows [nq, per] (0xffffffff = none) -> packed exact entries.
+__global__ __launch_bounds__(256) void gather_dot_batch_kernel(ScanArgs args, const uint32_t* __restrict__ rows,
+                                                               uint32_t per, uint32_t nq, u64* __restrict__ out_packed) {
+    const int dim = (int)args.dim;
+    const int tid = threadIdx.x, lane = tid & 63, a = lane & 3;
+    const uint32_t item = (blockIdx.x * 256 + tid) >> 2;
+    const uint32_t total = per * nq;
+    const bool in_range = item < total;
+    const uint32_t b = in_range ? item / per : 0;
+    const uint32_t grow = in_range ? rows[item] : 0xffffffffu;
+    uint32_t row = grow - args.row_base;
+    const bool mine = in_range && grow != 0xffffffffu && row < args.nrows;
+    if (!mine) row = 0;
+    const float* q = args.queries + (size_t)b * dim;
+    const u32x4* p = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(args.slab) + (size_t)row * dim * 2);
+    const int chunks = dim >> 3, groups = chunks >> 2, leftover = chunks & 3;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int g = 0; g < groups; ++g) {
+        const u32x4 w = p[4 * g + a];
+        const float4* qp = reinterpret_cast<const float4*>(q + 32 * g + 8 * a);
+        chunk_mac(acc, w, qp[0], qp[1]);
+    }
+    if (a == 0)
+        for (int c = 4 * groups; c < 4 * groups + leftover; ++c) {
+            const u32x4 w = p[c];
+            const float4* qp = reinterpret_cast<const float4*>(q + 8 * c);
+            chunk_mac(acc, w, qp[0], qp[1]);
+        }
+    const float s = quad_finish(acc, args.hreduce);
+    if (in_range && a == 0) out_packed[item] = mine ? pack(s, grow) : kEmpty;
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------------
+
+bool scan_mfma_supported(int dim) { return dim == 128 || dim == 256 || dim == 384; }
+
+template <int DIM, int NQT>
+static hipError_t launch_mfma_t(const MfmaScanArgs& args, int grid, hipStream_t stream, int* occupancy) {
+    const size_t lds = (size_t)NQT * 16 * (DIM + 8) * 2;
+    auto kern = scan_mfma_kernel<DIM, NQT>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    if (occupancy) {
+        int blocks = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, 256, lds) != hipSuccess || blocks < 1) blocks = 1;
+        *occupancy = blocks;
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, args);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_mfma(const MfmaScanArgs& args, int nqt, int grid, hipStream_t stream, int* occupancy) {
+    if (nqt == 4) {
+        switch (args.dim) {
+            case 128: return launch_mfma_t<128, 4>(args, grid, stream, occupancy);
+            case 256: return launch_mfma_t<256, 4>(args, grid, stream, occupancy);
+            case 384: return launch_mfma_t<384, 4>(args, grid, stream, occupancy);
+            default: break;
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_max_row_norm(const void* slab, uint32_t nrows, uint32_t dim, unsigned int* out_bits, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(out_bits, 0, 4, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(max_row_norm_kernel, dim3(2048), dim3(256), 0, stream, static_cast<const unsigned short*>(slab),
+                       nrows, dim, out_bits);
+    return hipGetLastError();
+}
+
+hipError_t launch_prepare_queries(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim,
+                                  const unsigned int* max_norm_bits, void* qh, float* delta, hipStream_t stream) {
+    hipLaunchKernelGGL(prepare_queries_kernel, dim3(nq_pad), dim3(256), 0, stream, q, nq, nq_pad, dim, max_norm_bits,
+                       static_cast<_Float16*>(qh), delta);
+    return hipGetLastError();
+}
+
+hipError_t launch_tau_from_selection(const u64* sel, const uint32_t* sel_counts, uint32_t stride, uint32_t k,
+                                     const float* delta, float* tau, uint32_t nq_pad, hipStream_t stream) {
+    hipLaunchKernelGGL(tau_from_selection_kernel, dim3((nq_pad + 63) / 64), dim3(64), 0, stream, sel, sel_counts, stride, k,
+                       delta, tau, nq_pad);
+    return hipGetLastError();
+}
+
+hipError_t launch_clamp_counts(uint32_t* counts, uint32_t cap, uint32_t* overflow, uint32_t nq_pad, hipStream_t stream) {
+    hipLaunchKernelGGL(clamp_counts_kernel, dim3((nq_pad + 63) / 64), dim3(64), 0, stream, counts, cap, overflow, nq_pad);
+    return hipGetLastError();
+}
+
+hipError_t launch_margin_check(const u64* sel, const uint32_t* sel_counts, uint32_t kc, uint32_t k, const float* delta,
+                               uint32_t* overflow, uint32_t nq_pad, hipStream_t stream) {
+    hipLaunchKernelGGL(margin_check_kernel, dim3((nq_pad + 63) / 64), dim3(64), 0, stream, sel, sel_counts, kc, k, delta,
+                       0u, nullptr, overflow, nq_pad);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_dot_batch(const ScanArgs& args, const uint32_t* rows, uint32_t per, uint32_t nq,
+                                   u64* out_packed, hipStream_t stream) {
+    const size_t lanes = (size_t)per * nq * 4;
+    hipLaunchKernelGGL(gather_dot_batch_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream, args, rows, per,
+                       nq, out_packed);
+    return hipGetLastError();
+}
+
+}  // namespace fsgpu

@@ -361,7 +361,8 @@ __global__ __launch_bounds__(NT) void merge_topk_kernel(MergeArgs args) {
             e[x] = kEmpty;
             lst[x] = i / list_len;
             pos[x] = i - lst[x] * list_len;
-            if (i < total32) e[x] = in[(size_t)lst[x] * args.l_stride + pos[x]];
+            if (i < total32 && (!args.list_counts || pos[x] < args.list_counts[q]))
+                e[x] = in[(size_t)lst[x] * args.l_stride + pos[x]];
         }
         __syncthreads();
         u64 best_tail = 0;

@@ -110,7 +110,9 @@ VectorIndex::~VectorIndex() {
     if (stream_) (void)hipStreamDestroy(stream_);
     for (DeviceBuffer* b : {&slab_own_, &live_own_, &ws_partial_, &ws_queries_, &ws_allow_, &ws_rows_, &ws_scores_,
                             &ws_counts_, &ws_keys_a_, &ws_keys_b_, &ws_sort_tmp_, &ws_gather_rows_, &ws_gather_out_,
-                            &i8_slab_, &i8_max_, &ws_i8_query_, &ws_cand_packed_, &ws_cand_rows_, &ws_cand_scores_})
+                            &i8_slab_, &i8_max_, &ws_i8_query_, &ws_cand_packed_, &ws_cand_rows_, &ws_cand_scores_,
+                            &mf_max_norm_, &mf_qh_, &mf_delta_, &mf_tau_, &mf_cand_, &mf_counts_, &mf_dense_, &mf_sel_,
+                            &mf_sel_counts_, &mf_overflow_, &mf_rows_, &mf_exact_})
         b->release();
 }
 
@@ -639,6 +641,211 @@ SearchError VectorIndex::gather_dot(const float* query, uint32_t query_len, cons
     FSGPU_HIP(launch_gather_dot(a, static_cast<const uint32_t*>(ws_gather_rows_.ptr), n,
                                 static_cast<float*>(ws_gather_out_.ptr), stream_));
     FSGPU_HIP(hipMemcpyAsync(out, ws_gather_out_.ptr, (size_t)n * 4, hipMemcpyDeviceToHost, stream_));
+    FSGPU_HIP(hipStreamSynchronize(stream_));
+    return ok();
+}
+
+// Batched search on the matrix cores; see mfma_scan.hip for the error bound that makes the result exact.
+SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, uint32_t nq, uint32_t query_len,
+                                                     uint32_t k, const uint64_t* allow_dev, uint32_t* out_rows_dev,
+                                                     float* out_scores_dev, uint32_t* out_counts_dev,
+                                                     hipStream_t stream, uint32_t* fallbacks) {
+    if (fallbacks) *fallbacks = 0;
+    FSGPU_TRY(ensure_query_dimension(query_len));
+    if (nq == 0) return ok();
+    constexpr uint32_t G = 64;        // queries per pass
+    constexpr uint32_t CAPQ = 8192;   // candidate slots per query (= the merge kernel's single-sort capacity)
+    constexpr uint32_t KC = 256;      // approximate candidates re-scored exactly
+    constexpr uint32_t RA = 4096;     // stage A rows (dense)
+    constexpr uint32_t RB = 131072;   // stage B end row
+    const bool usable = scan_mfma_supported((int)dim_) && k >= 1 && k <= 64 && nrows_ >= 2 * RA;
+    if (!usable) {
+        if (fallbacks) *fallbacks = nq;
+        return search_top_k_device(queries_dev, nq, query_len, k, allow_dev, out_rows_dev, out_scores_dev,
+                                   out_counts_dev, stream);
+    }
+    FSGPU_HIP(hipSetDevice(device_));
+    const uint32_t N = (uint32_t)nrows_;
+    if (!mf_norm_ready_) {
+        FSGPU_TRY(mf_max_norm_.reserve(4));
+        FSGPU_HIP(launch_max_row_norm(slab_dev_, N, dim_, static_cast<unsigned int*>(mf_max_norm_.ptr), stream));
+        mf_norm_ready_ = true;
+    }
+    FSGPU_TRY(mf_qh_.reserve((size_t)G * dim_ * 2));
+    FSGPU_TRY(mf_delta_.reserve(G * 4));
+    FSGPU_TRY(mf_tau_.reserve(G * 4));
+    FSGPU_TRY(mf_cand_.reserve((size_t)G * CAPQ * 8));
+    FSGPU_TRY(mf_counts_.reserve(G * 4));
+    FSGPU_TRY(mf_dense_.reserve((size_t)G * RA * 8));
+    FSGPU_TRY(mf_sel_.reserve((size_t)G * KC * 8));
+    FSGPU_TRY(mf_sel_counts_.reserve(G * 4));
+    FSGPU_TRY(mf_overflow_.reserve(G * 4));
+    FSGPU_TRY(mf_rows_.reserve((size_t)G * KC * 4));
+    FSGPU_TRY(mf_exact_.reserve((size_t)G * KC * 8));
+    int per_cu = 1;
+    MfmaScanArgs probe{};
+    probe.dim = dim_;
+    FSGPU_HIP(launch_scan_mfma(probe, 4, 1, stream, &per_cu));
+    const int full_grid = num_cus_ * per_cu;
+    auto grid_for = [&](uint32_t rows) {
+        int g = (int)(((rows + 15) / 16 + 3) / 4);
+        if (g > full_grid) g = full_grid;
+        return g < 1 ? 1 : g;
+    };
+    float* delta = static_cast<float*>(mf_delta_.ptr);
+    float* tau = static_cast<float*>(mf_tau_.ptr);
+    u64* cand = static_cast<u64*>(mf_cand_.ptr);
+    uint32_t* counts = static_cast<uint32_t*>(mf_counts_.ptr);
+    u64* sel = static_cast<u64*>(mf_sel_.ptr);
+    uint32_t* sel_counts = static_cast<uint32_t*>(mf_sel_counts_.ptr);
+    uint32_t* overflow = static_cast<uint32_t*>(mf_overflow_.ptr);
+    uint32_t total_fallbacks = 0;
+    for (uint32_t g0 = 0; g0 < nq; g0 += G) {
+        const uint32_t ng = std::min(G, nq - g0);
+        const float* qg = queries_dev + (size_t)g0 * dim_;
+        FSGPU_HIP(launch_prepare_queries(qg, ng, G, dim_, static_cast<const unsigned int*>(mf_max_norm_.ptr), mf_qh_.ptr,
+                                         delta, stream));
+        FSGPU_HIP(hipMemsetAsync(counts, 0, G * 4, stream));
+        FSGPU_HIP(hipMemsetAsync(overflow, 0, G * 4, stream));
+        MfmaScanArgs a{};
+        a.slab = slab_dev_;
+        a.live = reinterpret_cast<const u64*>(live_dev_);
+        a.allow = reinterpret_cast<const u64*>(allow_dev);
+        a.queries = mf_qh_.ptr;
+        a.tau = tau;
+        a.cand = cand;
+        a.counts = counts;
+        a.dim = dim_;
+        a.cap = CAPQ;
+        a.row_base = (uint32_t)row_base_;
+        // stage A: dense approximate scores of rows [0, RA) -> k-th best -> tau
+        a.dense = static_cast<u64*>(mf_dense_.ptr);
+        a.row_begin = 0;
+        a.row_end = RA;
+        FSGPU_HIP(launch_scan_mfma(a, 4, grid_for(RA), stream, nullptr));
+        MergeArgs m{};
+        m.lists = a.dense;
+        m.q_stride = RA;
+        m.l_stride = RA;
+        m.nlists = 1;
+        m.list_len = RA;
+        m.k = k;
+        m.out_stride = KC;
+        m.out_rows = nullptr;
+        m.out_scores = nullptr;
+        m.out_counts = sel_counts;
+        m.out_packed = sel;
+        m.lists_sorted = 0;
+        FSGPU_HIP(launch_merge_topk(m, (int)G, stream));
+        FSGPU_HIP(launch_tau_from_selection(sel, sel_counts, KC, k, delta, tau, G, stream));
+        // stage B: candidates of rows [0, RB) above tau -> tighter tau
+        a.dense = nullptr;
+        a.row_begin = 0;
+        a.row_end = std::min(RB, N);
+        FSGPU_HIP(launch_scan_mfma(a, 4, grid_for(a.row_end), stream, nullptr));
+        FSGPU_HIP(launch_clamp_counts(counts, CAPQ, overflow, G, stream));
+        MergeArgs mb{};
+        mb.lists = cand;
+        mb.q_stride = CAPQ;
+        mb.l_stride = CAPQ;
+        mb.nlists = 1;
+        mb.list_len = CAPQ;
+        mb.k = k;
+        mb.out_stride = KC;
+        mb.out_counts = sel_counts;
+        mb.out_packed = sel;
+        mb.lists_sorted = 0;
+        mb.list_counts = counts;
+        if (a.row_end < N) {
+            FSGPU_HIP(launch_merge_topk(mb, (int)G, stream));
+            FSGPU_HIP(launch_tau_from_selection(sel, sel_counts, KC, k, delta, tau, G, stream));
+            // stage C: the rest of the slab
+            a.row_begin = a.row_end;
+            a.row_end = N;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (profiling) {
+                FSGPU_HIP(hipEventCreate(&e0));
+                FSGPU_HIP(hipEventCreate(&e1));
+                FSGPU_HIP(hipEventRecord(e0, stream));
+            }
+            FSGPU_HIP(launch_scan_mfma(a, 4, full_grid, stream, nullptr));
+            if (profiling) {
+                FSGPU_HIP(hipEventRecord(e1, stream));
+                events_.emplace_back(e0, e1);
+            }
+            FSGPU_HIP(launch_clamp_counts(counts, CAPQ, overflow, G, stream));
+        }
+        // the KC best approximate candidates, margin check, exact re-score, final selection
+        mb.k = KC;
+        FSGPU_HIP(launch_merge_topk(mb, (int)G, stream));
+        FSGPU_HIP(launch_margin_check(sel, sel_counts, KC, k, delta, overflow, G, stream));
+        uint32_t* cand_rows = static_cast<uint32_t*>(mf_rows_.ptr);
+        FSGPU_HIP(launch_packed_rows(sel, G * KC, cand_rows, stream));
+        ScanArgs ga = base_args(qg, nullptr);
+        u64* exact = static_cast<u64*>(mf_exact_.ptr);
+        FSGPU_HIP(launch_gather_dot_batch(ga, cand_rows, KC, ng, exact, stream));
+        MergeArgs mf{};
+        mf.lists = exact;
+        mf.q_stride = KC;
+        mf.l_stride = KC;
+        mf.nlists = 1;
+        mf.list_len = KC;
+        mf.k = std::min<uint32_t>(k, N);
+        mf.out_stride = k;
+        mf.out_rows = out_rows_dev + (size_t)g0 * k;
+        mf.out_scores = out_scores_dev + (size_t)g0 * k;
+        mf.out_counts = out_counts_dev + g0;
+        mf.out_packed = nullptr;
+        mf.lists_sorted = 0;
+        FSGPU_HIP(launch_merge_topk(mf, (int)ng, stream));
+        // fallback decision on the host: margin/capacity overflow, or fewer than k finite candidates
+        std::vector<uint32_t> ovf(G), got(G);
+        FSGPU_HIP(hipMemcpyAsync(ovf.data(), overflow, G * 4, hipMemcpyDeviceToHost, stream));
+        FSGPU_HIP(hipMemcpyAsync(got.data(), sel_counts, G * 4, hipMemcpyDeviceToHost, stream));
+        FSGPU_HIP(hipStreamSynchronize(stream));
+        for (uint32_t i = 0; i < ng; ++i) {
+            if (ovf[i] || got[i] < std::min<uint32_t>(k, N)) {
+                ++total_fallbacks;
+                FSGPU_TRY(search_top_k_device(qg + (size_t)i * dim_, 1, query_len, k, allow_dev,
+                                              out_rows_dev + (size_t)(g0 + i) * k, out_scores_dev + (size_t)(g0 + i) * k,
+                                              out_counts_dev + g0 + i, stream));
+            }
+        }
+    }
+    if (fallbacks) *fallbacks = total_fallbacks;
+    return ok();
+}
+
+SearchError VectorIndex::search_top_k_batched(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
+                                              const uint64_t* allow, uint32_t* out_rows, float* out_scores,
+                                              uint32_t* out_counts, uint32_t* fallbacks) {
+    if (fallbacks) *fallbacks = 0;
+    FSGPU_TRY(ensure_query_dimension(query_len));
+    if (nq == 0) return ok();
+    if (k == 0 || nrows_ == 0) {
+        for (uint32_t q = 0; q < nq; ++q) out_counts[q] = 0;
+        return ok();
+    }
+    FSGPU_HIP(hipSetDevice(device_));
+    const size_t qbytes = (size_t)nq * dim_ * 4;
+    FSGPU_TRY(ws_queries_.reserve(qbytes));
+    FSGPU_TRY(ws_rows_.reserve((size_t)nq * k * 4));
+    FSGPU_TRY(ws_scores_.reserve((size_t)nq * k * 4));
+    FSGPU_TRY(ws_counts_.reserve((size_t)nq * 4));
+    FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, queries, qbytes, hipMemcpyHostToDevice, stream_));
+    const uint64_t* allow_dev = nullptr;
+    if (allow) {
+        const size_t words = (size_t)((nrows_ + 63) / 64);
+        FSGPU_TRY(ws_allow_.reserve(words * 8));
+        FSGPU_HIP(hipMemcpyAsync(ws_allow_.ptr, allow, words * 8, hipMemcpyHostToDevice, stream_));
+        allow_dev = static_cast<const uint64_t*>(ws_allow_.ptr);
+    }
+    FSGPU_TRY(search_top_k_batched_device(static_cast<const float*>(ws_queries_.ptr), nq, query_len, k, allow_dev,
+                                          static_cast<uint32_t*>(ws_rows_.ptr), static_cast<float*>(ws_scores_.ptr),
+                                          static_cast<uint32_t*>(ws_counts_.ptr), stream_, fallbacks));
+    FSGPU_HIP(hipMemcpyAsync(out_rows, ws_rows_.ptr, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream_));
+    FSGPU_HIP(hipMemcpyAsync(out_scores, ws_scores_.ptr, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream_));
+    FSGPU_HIP(hipMemcpyAsync(out_counts, ws_counts_.ptr, (size_t)nq * 4, hipMemcpyDeviceToHost, stream_));
     FSGPU_HIP(hipStreamSynchronize(stream_));
     return ok();
 }

@@ -53,6 +53,16 @@ class VectorIndex {
     SearchError search_top_k_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
                                     const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
                                     uint32_t* out_counts_dev, hipStream_t stream);
+    // Batched search on the matrix cores (mfma_scan.hip): groups of 64 queries per HBM pass, approximate f16-query
+    // scores filtered by a proven margin and re-scored in the reference order, so the outputs equal
+    // search_top_k_device bit for bit.  Queries it cannot serve (k > 64, unsupported dim, margin overflow) run on the
+    // exact kernels.  Synchronises the stream (the fallback decision is taken on the host).
+    SearchError search_top_k_batched_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
+                                            const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
+                                            uint32_t* out_counts_dev, hipStream_t stream, uint32_t* fallbacks);
+    SearchError search_top_k_batched(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
+                                     const uint64_t* allow, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
+                                     uint32_t* fallbacks);
     // Shard-local search whose result stays packed (score bits << 32 | global row; ~0 padding) for the
     // cross-GPU exchange: out_packed_dev is [nq, k].  Fused tiers only (k <= 256, dim % 8 == 0).
     SearchError search_top_k_packed_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
@@ -107,8 +117,10 @@ class VectorIndex {
     // workspaces (grown on demand, reused)
     DeviceBuffer ws_partial_, ws_queries_, ws_allow_, ws_rows_, ws_scores_, ws_counts_, ws_keys_a_, ws_keys_b_,
         ws_sort_tmp_, ws_gather_rows_, ws_gather_out_, i8_slab_, i8_max_, ws_i8_query_, ws_cand_packed_,
-        ws_cand_rows_, ws_cand_scores_;
+        ws_cand_rows_, ws_cand_scores_, mf_max_norm_, mf_qh_, mf_delta_, mf_tau_, mf_cand_, mf_counts_, mf_dense_,
+        mf_sel_, mf_sel_counts_, mf_overflow_, mf_rows_, mf_exact_;
     bool i8_ready_ = false;
+    bool mf_norm_ready_ = false;
     // profiling events
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events_;
     // FSVI host-side tables

@@ -127,6 +127,18 @@ fsgpu_status fsgpu_search_topk_device(fsgpu_index *idx, const float *queries_dev
                                       uint32_t query_len, uint32_t k, const uint64_t *allow_bitmap_dev,
                                       uint32_t *out_rows_dev, float *out_scores_dev, uint32_t *out_counts_dev,
                                       void *hip_stream);
+/* Throughput form of fsgpu_search_topk for large query batches: groups of 64 queries share ONE pass over the
+ * slab on the matrix cores (f16-rounded queries, v_mfma_f32_16x16x32_f16); rows that could reach the top k under a
+ * proven error bound are re-scored in the reference's exact order, so rows and score bits are IDENTICAL to
+ * fsgpu_search_topk.  Queries the batched path cannot certify (k > 64, unsupported dimension, margin overflow) are
+ * answered by the exact kernels; *out_fallbacks (optional) counts them.  The _device form synchronises hip_stream. */
+fsgpu_status fsgpu_search_topk_batched(fsgpu_index *idx, const float *queries, uint32_t nq, uint32_t query_len,
+                                       uint32_t k, const uint64_t *allow_bitmap, uint32_t *out_rows, float *out_scores,
+                                       uint32_t *out_counts, uint32_t *out_fallbacks);
+fsgpu_status fsgpu_search_topk_batched_device(fsgpu_index *idx, const float *queries_dev, uint32_t nq,
+                                              uint32_t query_len, uint32_t k, const uint64_t *allow_bitmap_dev,
+                                              uint32_t *out_rows_dev, float *out_scores_dev, uint32_t *out_counts_dev,
+                                              void *hip_stream, uint32_t *out_fallbacks);
 /* Shard-local search for the multi-GPU path (the reference partitions the same way per
  * rayon chunk, search.rs:1020-1035): like fsgpu_search_topk_device but the result stays PACKED,
  * out_packed_dev[q*k+i] = (f32 score bits << 32) | global row, best first, ~0ull padding — one

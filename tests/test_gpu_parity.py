@@ -391,3 +391,38 @@ def test_int8_two_pass_matches_oracle(fa, oracle, tmp_path):
     g.append("fresh", rng.standard_normal(64).astype(np.float32))
     o.append("fresh", np.zeros(64, np.float32) + 1)  # only to mirror the WAL presence
     assert [h.index for h in g.search_top_k_int8_two_pass(q, 10, 3)] == [h.index for h in g.search_top_k(q, 10)]
+
+
+def test_batched_mfma_search_is_bit_exact(fa, oracle):
+    # fsgpu_search_topk_batched must equal the exact path (hence the oracle) bit for bit
+    rng = np.random.default_rng(83)
+    for n, dim in ((200_000, 384), (150_001, 256), (60_000, 128)):
+        cent = rng.standard_normal((32, dim)).astype(np.float32)
+        cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+        rows = cent[rng.integers(0, 32, n)] + 0.3 * rng.standard_normal((n, dim)).astype(np.float32) / np.sqrt(dim)
+        rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+        slab = rows.astype(np.float16).view(np.uint16)
+        live = rng.random(n) > 0.05
+        idx = fa.VectorIndex.from_slab(slab, live=live)
+        nq = 70
+        q = cent[rng.integers(0, 32, nq)] + 0.3 * rng.standard_normal((nq, dim)).astype(np.float32) / np.sqrt(dim)
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        q[5] = 0.0           # zero-norm query -> exact fallback
+        q[6] *= 37.5         # non-unit query
+        for k in (10, 1, 33):
+            br, bs, bc, fb = idx.search_batched(q, k)
+            er, es, ec = idx.search_batch(q, k)
+            assert np.array_equal(bc, ec) and np.array_equal(br, er) and np.array_equal(bits(bs), bits(es)), (n, dim, k)
+            assert fb < nq // 2, fb      # the matrix-core path must actually serve most queries
+        # and against the oracle directly for a few
+        for qi in (0, 6, 69):
+            orow, osc = oracle.search_top_k(slab, q[qi], 10, live=live)
+            br, bs, bc, _ = idx.search_batched(q, 10)
+            assert np.array_equal(br[qi], orow) and np.array_equal(bits(bs[qi]), bits(osc))
+    # small index / large k -> transparently the exact path
+    slab = rand_slab(rng, 3000, 384)
+    idx = fa.VectorIndex.from_slab(slab)
+    q = rng.standard_normal((3, 384)).astype(np.float32)
+    br, bs, bc, fb = idx.search_batched(q, 10)
+    er, es, ec = idx.search_batch(q, 10)
+    assert fb == 3 and np.array_equal(br, er) and np.array_equal(bits(bs), bits(es))
