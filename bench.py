@@ -193,6 +193,8 @@ def main() -> None:
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="queries per step (one exact scan pass serves 4)")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--batched", action="store_true",
+                    help="serve each step through the matrix-core batched path (64 queries per HBM pass, exact results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-two-tier", action="store_true")
     args = ap.parse_args()
@@ -226,15 +228,22 @@ def main() -> None:
     lo, hi = shard_range(args.rows, rank, world)
     slab = gen_corpus(lo, hi, args.dim, device)
     pool = 64
-    queries = gen_queries(max(pool, args.batch), args.dim, device)
+    queries = gen_queries(max(pool, args.batch) + args.batch, args.dim, device)
     index = fa.VectorIndex.from_device_slab(slab.data_ptr(), hi - lo, args.dim, device=local_rank, row_base=lo,
                                             keepalive=slab)
     index.set_variant(args.variant)
     sharded = ShardedVectorIndex(GpuShardBackend(index, device))
     B, k = args.batch, args.k
 
+    backend = sharded.backend
+    fallbacks = [0]
+
     def step(i: int):
         s = (i * B) % (queries.shape[0] - B + 1)
+        if args.batched and world == 1:
+            out = backend.search_batched(queries[s:s + B], k)
+            fallbacks[0] += backend.last_fallbacks
+            return out
         return sharded.search(queries[s:s + B], k)
 
     for i in range(args.warmup):
@@ -295,6 +304,8 @@ def main() -> None:
                 "rows": args.rows, "dim": args.dim, "k": k, "queries_per_step": B,
                 "parallelism": f"row-shard x{world}" + (" + all-gather(top-k) over RCCL" if world > 1 else ""),
                 "kernel_variant": args.variant,
+                "path": "matrix-core batched + exact re-score" if args.batched else "exact VALU scan",
+                "exact_fallback_queries": fallbacks[0] if args.batched else None,
             },
             "roofline": {
                 "bound": "hbm",

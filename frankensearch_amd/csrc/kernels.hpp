@@ -71,12 +71,13 @@ struct MfmaScanArgs {
     const void* queries;       // [nq_pad, dim] f16 (rows >= nq are zero)
     const float* tau;          // [nq_pad] candidate threshold per query (ignored in dense mode)
     u64* cand;                 // [nq_pad, cap] packed approximate candidates
-    uint32_t* counts;          // [nq_pad]
+    uint32_t* counts;          // [nq_pad * kMfmaCountStride] append counters, one cache line per query
     u64* dense;                // dense mode: [nq_pad, row_end - row_begin] packed approximate scores
     uint32_t row_begin, row_end;  // row_begin % 16 == 0
     uint32_t dim, cap, row_base;
 };
 
+constexpr uint32_t kMfmaCountStride = 32;  // uint32 slots between per-query counters (128 bytes)
 bool scan_mfma_supported(int dim);
 hipError_t launch_scan_mfma(const MfmaScanArgs& args, int nqt, int grid, hipStream_t stream, int* occupancy);
 hipError_t launch_max_row_norm(const void* slab, uint32_t nrows, uint32_t dim, unsigned int* out_bits, hipStream_t stream);
@@ -84,7 +85,8 @@ hipError_t launch_prepare_queries(const float* q, uint32_t nq, uint32_t nq_pad, 
                                   const unsigned int* max_norm_bits, void* qh, float* delta, hipStream_t stream);
 hipError_t launch_tau_from_selection(const u64* sel, const uint32_t* sel_counts, uint32_t stride, uint32_t k,
                                      const float* delta, float* tau, uint32_t nq_pad, hipStream_t stream);
-hipError_t launch_clamp_counts(uint32_t* counts, uint32_t cap, uint32_t* overflow, uint32_t nq_pad, hipStream_t stream);
+hipError_t launch_clamp_counts(const uint32_t* counters, uint32_t* counts, uint32_t cap, uint32_t* overflow,
+                               uint32_t nq_pad, hipStream_t stream);
 hipError_t launch_margin_check(const u64* sel, const uint32_t* sel_counts, uint32_t kc, uint32_t k, const float* delta,
                                uint32_t* overflow, uint32_t nq_pad, hipStream_t stream);
 hipError_t launch_gather_dot_batch(const ScanArgs& args, const uint32_t* rows, uint32_t per, uint32_t nq,

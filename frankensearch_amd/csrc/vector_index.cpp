@@ -112,7 +112,7 @@ VectorIndex::~VectorIndex() {
                             &ws_counts_, &ws_keys_a_, &ws_keys_b_, &ws_sort_tmp_, &ws_gather_rows_, &ws_gather_out_,
                             &i8_slab_, &i8_max_, &ws_i8_query_, &ws_cand_packed_, &ws_cand_rows_, &ws_cand_scores_,
                             &mf_max_norm_, &mf_qh_, &mf_delta_, &mf_tau_, &mf_cand_, &mf_counts_, &mf_dense_, &mf_sel_,
-                            &mf_sel_counts_, &mf_overflow_, &mf_rows_, &mf_exact_})
+                            &mf_sel_counts_, &mf_overflow_, &mf_rows_, &mf_exact_, &mf_counters_})
         b->release();
 }
 
@@ -676,6 +676,7 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
     FSGPU_TRY(mf_tau_.reserve(G * 4));
     FSGPU_TRY(mf_cand_.reserve((size_t)G * CAPQ * 8));
     FSGPU_TRY(mf_counts_.reserve(G * 4));
+    FSGPU_TRY(mf_counters_.reserve((size_t)G * kMfmaCountStride * 4));
     FSGPU_TRY(mf_dense_.reserve((size_t)G * RA * 8));
     FSGPU_TRY(mf_sel_.reserve((size_t)G * KC * 8));
     FSGPU_TRY(mf_sel_counts_.reserve(G * 4));
@@ -705,7 +706,8 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
         const float* qg = queries_dev + (size_t)g0 * dim_;
         FSGPU_HIP(launch_prepare_queries(qg, ng, G, dim_, static_cast<const unsigned int*>(mf_max_norm_.ptr), mf_qh_.ptr,
                                          delta, stream));
-        FSGPU_HIP(hipMemsetAsync(counts, 0, G * 4, stream));
+        uint32_t* counters = static_cast<uint32_t*>(mf_counters_.ptr);
+        FSGPU_HIP(hipMemsetAsync(counters, 0, (size_t)G * kMfmaCountStride * 4, stream));
         FSGPU_HIP(hipMemsetAsync(overflow, 0, G * 4, stream));
         MfmaScanArgs a{};
         a.slab = slab_dev_;
@@ -714,7 +716,7 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
         a.queries = mf_qh_.ptr;
         a.tau = tau;
         a.cand = cand;
-        a.counts = counts;
+        a.counts = counters;
         a.dim = dim_;
         a.cap = CAPQ;
         a.row_base = (uint32_t)row_base_;
@@ -743,7 +745,7 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
         a.row_begin = 0;
         a.row_end = std::min(RB, N);
         FSGPU_HIP(launch_scan_mfma(a, 4, grid_for(a.row_end), stream, nullptr));
-        FSGPU_HIP(launch_clamp_counts(counts, CAPQ, overflow, G, stream));
+        FSGPU_HIP(launch_clamp_counts(counters, counts, CAPQ, overflow, G, stream));
         MergeArgs mb{};
         mb.lists = cand;
         mb.q_stride = CAPQ;
@@ -773,7 +775,7 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
                 FSGPU_HIP(hipEventRecord(e1, stream));
                 events_.emplace_back(e0, e1);
             }
-            FSGPU_HIP(launch_clamp_counts(counts, CAPQ, overflow, G, stream));
+            FSGPU_HIP(launch_clamp_counts(counters, counts, CAPQ, overflow, G, stream));
         }
         // the KC best approximate candidates, margin check, exact re-score, final selection
         mb.k = KC;

@@ -70,6 +70,24 @@ class GpuShardBackend:
                                                   scores.data_ptr(), counts.data_ptr(), stream))
         return rows, scores, counts
 
+    def search_batched(self, queries: torch.Tensor, k: int):
+        """Throughput path: 64 queries per HBM pass on the matrix cores, exact results (synchronises the stream)."""
+        import ctypes as C
+        from . import _lib
+        from .errors import check
+
+        b, dim = queries.shape
+        rows = torch.empty((b, k), dtype=torch.int32, device=self.device)
+        scores = torch.empty((b, k), dtype=torch.float32, device=self.device)
+        counts = torch.empty((b,), dtype=torch.int32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        fb = C.c_uint32()
+        check(_lib.lib().fsgpu_search_topk_batched_device(self.index._h, queries.data_ptr(), b, dim, k, None,
+                                                          rows.data_ptr(), scores.data_ptr(), counts.data_ptr(), stream,
+                                                          C.byref(fb)))
+        self.last_fallbacks = fb.value
+        return rows, scores, counts
+
     def merge(self, gathered: torch.Tensor, k: int):
         from . import _lib
         from .errors import check
