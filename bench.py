@@ -232,7 +232,7 @@ def main() -> None:
     index = fa.VectorIndex.from_device_slab(slab.data_ptr(), hi - lo, args.dim, device=local_rank, row_base=lo,
                                             keepalive=slab)
     index.set_variant(args.variant)
-    sharded = ShardedVectorIndex(GpuShardBackend(index, device))
+    sharded = ShardedVectorIndex(GpuShardBackend(index, device, batched=args.batched))
     B, k = args.batch, args.k
 
     backend = sharded.backend
@@ -240,11 +240,10 @@ def main() -> None:
 
     def step(i: int):
         s = (i * B) % (queries.shape[0] - B + 1)
-        if args.batched and world == 1:
-            out = backend.search_batched(queries[s:s + B], k)
+        out = sharded.search(queries[s:s + B], k)
+        if args.batched:
             fallbacks[0] += backend.last_fallbacks
-            return out
-        return sharded.search(queries[s:s + B], k)
+        return out
 
     for i in range(args.warmup):
         step(i)

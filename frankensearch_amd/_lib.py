@@ -53,6 +53,7 @@ SIGNATURES = {
     "fsgpu_search_topk_device": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp]),
     "fsgpu_search_topk_batched": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, C.POINTER(_u32)]),
     "fsgpu_search_topk_batched_device": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u32)]),
+    "fsgpu_search_topk_batched_packed_device": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, C.POINTER(_u32)]),
     "fsgpu_search_topk_packed_device": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "fsgpu_merge_topk_device": (_i32, [_i32, _vp, _u32, _u32, _u32, _u64, _u64, _u32, _vp, _vp, _vp, _vp]),
     "fsgpu_search_topk_classified": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, C.POINTER(_u32), C.POINTER(_i32)]),

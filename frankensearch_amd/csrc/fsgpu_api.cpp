@@ -205,6 +205,26 @@ fsgpu_status fsgpu_search_topk_batched_device(fsgpu_index* idx, const float* que
     });
 }
 
+fsgpu_status fsgpu_search_topk_batched_packed_device(fsgpu_index* idx, const float* queries_dev, uint32_t nq,
+                                                     uint32_t query_len, uint32_t k, const uint64_t* allow_bitmap_dev,
+                                                     uint64_t* out_packed_dev, void* hip_stream, uint32_t* out_fallbacks) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    if (nq && k && (!queries_dev || !out_packed_dev)) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    if (k > 256) return fail(FSGPU_ERR_INVALID_CONFIG, "packed shard search supports k <= 256");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        if (nq == 0 || k == 0) return FSGPU_OK;
+        if (idx->impl.record_count() == 0) {
+            if (hipMemsetAsync(out_packed_dev, 0xff, (size_t)nq * k * 8, static_cast<hipStream_t>(hip_stream)) != hipSuccess)
+                return fail(FSGPU_ERR_DEVICE, "hipMemsetAsync failed");
+            return FSGPU_OK;
+        }
+        return finish(idx->impl.search_top_k_batched_device(queries_dev, nq, query_len, k, allow_bitmap_dev, nullptr,
+                                                            nullptr, nullptr, static_cast<hipStream_t>(hip_stream),
+                                                            out_fallbacks, out_packed_dev));
+    });
+}
+
 fsgpu_status fsgpu_search_topk_packed_device(fsgpu_index* idx, const float* queries_dev, uint32_t nq,
                                              uint32_t query_len, uint32_t k, const uint64_t* allow_bitmap_dev,
                                              uint64_t* out_packed_dev, void* hip_stream) {

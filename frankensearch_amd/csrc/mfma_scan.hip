@@ -34,8 +34,11 @@ using namespace scan_detail;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int DIM, int NQT>
-__global__ __launch_bounds__(256) void scan_mfma_kernel(MfmaScanArgs args) {
+// STAGE only separates the kernel symbols (0 = dense sample, 1 = bounded range, 2 = main pass) so profiles report the
+// dominant main-pass launches on their own; 0 also makes the dense branch compile-time.
+template <int DIM, int NQT, int WPB, int STAGE, int RT, bool PF>
+__global__ __launch_bounds__(WPB * 64) void scan_mfma_kernel(MfmaScanArgs args) {
+    constexpr int NT = WPB * 64;
     constexpr int KS = DIM / 32;        // MFMA k-steps
     constexpr int QSTRIDE = DIM + 8;    // halves per query row in LDS (16-byte pad)
     constexpr int NQ = NQT * 16;
@@ -47,19 +50,30 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(MfmaScanArgs args) {
     {   // stage the queries: 16-byte pieces, coalesced
         const u32x4* src = static_cast<const u32x4*>(args.queries);
         constexpr int PIECES = DIM / 8;
-        for (int i = tid; i < NQ * PIECES; i += 256) {
+        for (int i = tid; i < NQ * PIECES; i += NT) {
             const int q = i / PIECES, p = i - q * PIECES;
             *reinterpret_cast<u32x4*>(qs + (size_t)q * QSTRIDE + p * 8) = src[(size_t)q * PIECES + p];
         }
     }
+    // per-block candidate staging (stages 1/2): LDS atomics only; one global list per (query, block) is written at
+    // the end.  (Appending through global atomics serialises on the per-query counter: ~0.18 us per append.)
+    int* lcnt = reinterpret_cast<int*>(smem + (size_t)NQ * QSTRIDE * 2);
+    u64* lbuf = reinterpret_cast<u64*>(smem + (size_t)NQ * QSTRIDE * 2 + (size_t)NQ * 4);
+    const int slots = (int)args.slots;
+    if (STAGE != 0) {
+        for (int i = tid; i < NQ; i += NT) lcnt[i] = 0;
+        for (int i = tid; i < NQ * slots; i += NT) lbuf[i] = kEmpty;
+    }
     __syncthreads();
     float tau[NQT];
 #pragma unroll
-    for (int nt = 0; nt < NQT; ++nt) tau[nt] = args.dense ? -INFINITY : args.tau[nt * 16 + frow];
+    for (int nt = 0; nt < NQT; ++nt) tau[nt] = STAGE == 0 ? -INFINITY : args.tau[nt * 16 + frow];
 
-    const uint32_t first_tile = args.row_begin / 16;
-    const uint32_t ntiles = (args.row_end - args.row_begin + 15) / 16;
-    const uint32_t nwaves = gridDim.x * kWavesPerBlock;
+    // A wave iteration covers RT consecutive 16-row sub-tiles: every B fragment read from LDS feeds RT MFMAs, so
+    // the LDS traffic per row falls by RT (at 128 queries the B reads, 96 KB per 16 rows, are what bounds RT = 1).
+    constexpr uint32_t TROWS = 16 * RT;
+    const uint32_t ntiles = (args.row_end - args.row_begin + TROWS - 1) / TROWS;
+    const uint32_t nwaves = gridDim.x * WPB;
     const unsigned char* slab = reinterpret_cast<const unsigned char*>(args.slab);
     constexpr size_t row_bytes = (size_t)DIM * 2;
     const uint32_t last_row = args.row_end - 1;
@@ -71,12 +85,15 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(MfmaScanArgs args) {
     // across lanes with ds_bpermute right before use: destination lane d reads source lane ((d&15)<<2)|(d>>4).
     const int lrow = lane >> 2, lchunk = lane & 3;
     const int perm_addr = ((((lane & 15) << 2) | (lane >> 4)) << 2);  // byte address for ds_bpermute
-    auto load_tile = [&](uint32_t t, half8 (&w)[KS]) {
-        uint32_t row = (first_tile + t) * 16 + lrow;
-        row = row < args.row_end ? row : last_row;
-        const half8* p = reinterpret_cast<const half8*>(slab + (size_t)row * row_bytes) + lchunk;
+    auto load_tile = [&](uint32_t t, half8 (&w)[RT][KS]) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) w[ks] = p[ks * 4];
+        for (int s = 0; s < RT; ++s) {
+            uint32_t row = args.row_begin + t * TROWS + s * 16 + lrow;
+            row = row < args.row_end ? row : last_row;
+            const half8* p = reinterpret_cast<const half8*>(slab + (size_t)row * row_bytes) + lchunk;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) w[s][ks] = p[ks * 4];
+        }
     };
     auto to_fragment = [&](const half8& v) {
         typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -88,92 +105,126 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(MfmaScanArgs args) {
         y[3] = __builtin_amdgcn_ds_bpermute(perm_addr, x[3]);
         return __builtin_bit_cast(half8, y);
     };
+    // row ranges start on multiples of 64 (host contract), so the TROWS <= 64 rows of a tile share one bitmap word
     auto tile_words = [&](uint32_t t, u64& live_word, u64& allow_word) {
-        const uint32_t w64 = ((first_tile + t) * 16) >> 6;
+        const uint32_t w64 = (args.row_begin + t * TROWS) >> 6;
         live_word = args.live ? args.live[w64] : ~0ull;
         allow_word = args.allow ? args.allow[w64] : ~0ull;
     };
-    auto compute_tile = [&](uint32_t t, const half8 (&w)[KS], u64 live_word, u64 allow_word) {
-        f32x4 acc[NQT];
+    auto compute_tile = [&](uint32_t t, const half8 (&w)[RT][KS], u64 live_word, u64 allow_word) {
+        f32x4 acc[RT][NQT];
 #pragma unroll
-        for (int nt = 0; nt < NQT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < RT; ++s)
+#pragma unroll
+            for (int nt = 0; nt < NQT; ++nt) acc[s][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const half8 afrag = to_fragment(w[ks]);
+            half8 afrag[RT];
+#pragma unroll
+            for (int s = 0; s < RT; ++s) afrag[s] = to_fragment(w[s][ks]);
 #pragma unroll
             for (int nt = 0; nt < NQT; ++nt) {
                 const half8 b = *reinterpret_cast<const half8*>(qs + (size_t)(nt * 16 + frow) * QSTRIDE + ks * 32 + fk * 8);
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, b, acc[nt], 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < RT; ++s)
+                    acc[s][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[s], b, acc[s][nt], 0, 0, 0);
             }
             // keep the B-fragment reads of later k-steps below this point: unconstrained, hipcc hoists all KS*NQT
             // ds_read_b128 to the top of the tile (192 extra registers at dim 384 -> one wave per SIMD)
-            if constexpr (NQT == 4)
-                asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])::"memory");
+#pragma unroll
+            for (int s = 0; s < RT; ++s) {
+                if constexpr (NQT == 4)
+                    asm volatile("" : "+v"(acc[s][0]), "+v"(acc[s][1]), "+v"(acc[s][2]), "+v"(acc[s][3])::"memory");
+                else
+                    asm volatile("" : "+v"(acc[s][0]), "+v"(acc[s][1]), "+v"(acc[s][2]), "+v"(acc[s][3]), "+v"(acc[s][4]),
+                                      "+v"(acc[s][5]), "+v"(acc[s][6]), "+v"(acc[s][7])::"memory");
+            }
         }
-        // C layout: column (query) = lane & 15, row = (lane >> 4) * 4 + reg
-        const uint32_t row0 = (first_tile + t) * 16 + fk * 4;
-        bool valid[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint32_t row = row0 + r;
-            valid[r] = row < args.row_end && ((live_word >> (row & 63)) & 1ull) && ((allow_word >> (row & 63)) & 1ull);
-        }
-        if (args.dense) {
-            const size_t span = args.row_end - args.row_begin;
+        for (int s = 0; s < RT; ++s) {
+            // C layout: column (query) = lane & 15, row = (lane >> 4) * 4 + reg
+            const uint32_t row0 = args.row_begin + t * TROWS + s * 16 + fk * 4;
+            bool valid[4];
 #pragma unroll
-            for (int nt = 0; nt < NQT; ++nt)
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t row = row0 + r;
+                valid[r] = row < args.row_end && ((live_word >> (row & 63)) & 1ull) && ((allow_word >> (row & 63)) & 1ull);
+            }
+            if constexpr (STAGE == 0) {
+                const size_t span = args.row_end - args.row_begin;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const uint32_t row = row0 + r;
-                    if (row < args.row_end)
-                        args.dense[(size_t)(nt * 16 + frow) * span + (row - args.row_begin)] =
-                            valid[r] ? pack(acc[nt][r], args.row_base + row) : kEmpty;
+                for (int nt = 0; nt < NQT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const uint32_t row = row0 + r;
+                        if (row < args.row_end)
+                            args.dense[(size_t)(nt * 16 + frow) * span + (row - args.row_begin)] =
+                                valid[r] ? pack(acc[s][nt][r], args.row_base + row) : kEmpty;
+                    }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < NQT; ++nt) {
+                    const float th = tau[nt];
+                    bool any = false;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) any = any || (valid[r] && acc[s][nt][r] >= th);
+                    if (!any) continue;  // per-lane: survivors are a few hundred rows out of the whole slab
+                    const int q = nt * 16 + frow;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (valid[r] && acc[s][nt][r] >= th) {
+                            const int pos = atomicAdd(&lcnt[q], 1);
+                            if (pos < slots) lbuf[q * slots + pos] = pack(acc[s][nt][r], args.row_base + row0 + r);
+                            else args.overflow[q] = 1;  // this query goes to the exact path
+                        }
                 }
-            return;
-        }
-#pragma unroll
-        for (int nt = 0; nt < NQT; ++nt) {
-            const float th = tau[nt];
-            bool any = false;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) any = any || (valid[r] && acc[nt][r] >= th);
-            if (!any) continue;  // per-lane: survivors are a few hundred rows out of the whole slab
-            const int q = nt * 16 + frow;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (valid[r] && acc[nt][r] >= th) {
-                    // a list that already overflowed sends its query to the exact path: stop feeding it
-                    uint32_t* counter = args.counts + (size_t)q * kMfmaCountStride;  // one cache line per query
-                    if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > args.cap) continue;
-                    const uint32_t pos = atomicAdd(counter, 1u);
-                    if (pos < args.cap) args.cand[(size_t)q * args.cap + pos] = pack(acc[nt][r], args.row_base + row0 + r);
-                }
+            }
         }
     };
 
-    half8 wa[KS], wb[KS];
-    u64 la = ~0ull, aa = ~0ull, lb = ~0ull, ab = ~0ull;
-    uint32_t t = blockIdx.x * kWavesPerBlock + wave;
-    if (t < ntiles) {
-        load_tile(t, wa);
-        tile_words(t, la, aa);
+    if constexpr (PF) {
+        // register double buffer: the next tile's loads are in flight while this one is on the matrix cores
+        half8 wa[RT][KS], wb[RT][KS];
+        u64 la = ~0ull, aa = ~0ull, lb = ~0ull, ab = ~0ull;
+        uint32_t t = blockIdx.x * WPB + wave;
+        if (t < ntiles) {
+            load_tile(t, wa);
+            tile_words(t, la, aa);
+        }
+        while (t < ntiles) {
+            uint32_t next = t + nwaves;
+            if (next < ntiles) {
+                load_tile(next, wb);
+                tile_words(next, lb, ab);
+            }
+            compute_tile(t, wa, la, aa);
+            t = next;
+            if (t >= ntiles) break;
+            next = t + nwaves;
+            if (next < ntiles) {
+                load_tile(next, wa);
+                tile_words(next, la, aa);
+            }
+            compute_tile(t, wb, lb, ab);
+            t = next;
+        }
+    } else {
+        // single buffer: the other resident waves of the SIMD cover the load latency
+        half8 wa[RT][KS];
+        u64 la = ~0ull, aa = ~0ull;
+        for (uint32_t t = blockIdx.x * WPB + wave; t < ntiles; t += nwaves) {
+            load_tile(t, wa);
+            tile_words(t, la, aa);
+            compute_tile(t, wa, la, aa);
+        }
     }
-    while (t < ntiles) {
-        uint32_t next = t + nwaves;
-        if (next < ntiles) {
-            load_tile(next, wb);
-            tile_words(next, lb, ab);
+    if (STAGE != 0) {
+        __syncthreads();
+        // one list of `slots` entries per (query, block), kEmpty padded: [q][block][slots]
+        for (int i = tid; i < NQ * slots; i += NT) {
+            const int q = i / slots, j = i - q * slots;
+            args.cand[((size_t)q * gridDim.x + blockIdx.x) * slots + j] = lbuf[i];
         }
-        compute_tile(t, wa, la, aa);
-        t = next;
-        if (t >= ntiles) break;
-        next = t + nwaves;
-        if (next < ntiles) {
-            load_tile(next, wa);
-            tile_words(next, la, aa);
-        }
-        compute_tile(t, wb, lb, ab);
-        t = next;
     }
 }
 
@@ -247,21 +298,6 @@ __global__ void tau_from_selection_kernel(const u64* __restrict__ sel, const uin
     tau[q] = t;
 }
 
-// Candidate bookkeeping between stages: padded atomic counters -> dense per-query counts clamped to cap; flags
-// capacity overflow.  (The counters are one cache line apart: appends to a shared line serialise in one L2
-// channel — measured 0.45 ms for 22k appends — while separate lines proceed in parallel.)
-__global__ void clamp_counts_kernel(const uint32_t* __restrict__ counters, uint32_t* __restrict__ counts, uint32_t cap,
-                                    uint32_t* __restrict__ overflow, uint32_t nq_pad) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq_pad) return;
-    uint32_t c = counters[(size_t)q * kMfmaCountStride];
-    if (c > cap) {
-        overflow[q] = 1;
-        c = cap;
-    }
-    counts[q] = c;
-}
-
 // Margin check on the KC best approximate candidates: the set is complete iff it holds fewer than KC entries or its
 // last entry is already below a_k - 2 delta (then every row outside the set is below the threshold too).
 __global__ void margin_check_kernel(const u64* __restrict__ sel, const uint32_t* __restrict__ sel_counts, uint32_t kc,
@@ -321,10 +357,10 @@ __global__ __launch_bounds__(256) void gather_dot_batch_kernel(ScanArgs args, co
 
 bool scan_mfma_supported(int dim) { return dim == 128 || dim == 256 || dim == 384; }
 
-template <int DIM, int NQT>
-static hipError_t launch_mfma_t(const MfmaScanArgs& args, int grid, hipStream_t stream, int* occupancy) {
-    const size_t lds = (size_t)NQT * 16 * (DIM + 8) * 2;
-    auto kern = scan_mfma_kernel<DIM, NQT>;
+template <int DIM, int NQT, int WPB, int STAGE, int RT, bool PF>
+static hipError_t launch_mfma_s(const MfmaScanArgs& args, int grid, hipStream_t stream, int* occupancy) {
+    const size_t lds = (size_t)NQT * 16 * (DIM + 8) * 2 + (STAGE ? (size_t)NQT * 16 * (4 + 8 * kMfmaMaxSlots) : 0);
+    auto kern = scan_mfma_kernel<DIM, NQT, WPB, STAGE, RT, PF>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -332,24 +368,48 @@ static hipError_t launch_mfma_t(const MfmaScanArgs& args, int grid, hipStream_t 
     }
     if (occupancy) {
         int blocks = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, 256, lds) != hipSuccess || blocks < 1) blocks = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, WPB * 64, lds) != hipSuccess || blocks < 1) blocks = 1;
         *occupancy = blocks;
         return hipSuccess;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, args);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WPB * 64), lds, stream, args);
     return hipGetLastError();
 }
 
-hipError_t launch_scan_mfma(const MfmaScanArgs& args, int nqt, int grid, hipStream_t stream, int* occupancy) {
-    if (nqt == 4) {
-        switch (args.dim) {
-            case 128: return launch_mfma_t<128, 4>(args, grid, stream, occupancy);
-            case 256: return launch_mfma_t<256, 4>(args, grid, stream, occupancy);
-            case 384: return launch_mfma_t<384, 4>(args, grid, stream, occupancy);
-            default: break;
-        }
+template <int DIM, int NQT, int WPB, int RT, bool PF>
+static hipError_t launch_mfma_t(const MfmaScanArgs& args, int grid, hipStream_t stream, int* occupancy) {
+    if (args.dense) return launch_mfma_s<DIM, NQT, WPB, 0, 1, true>(args, grid, stream, occupancy);
+    if (args.row_begin == 0) return launch_mfma_s<DIM, NQT, WPB, 1, RT, PF>(args, grid, stream, occupancy);
+    return launch_mfma_s<DIM, NQT, WPB, 2, RT, PF>(args, grid, stream, occupancy);
+}
+
+// Shapes (nqt = query tiles of 16; wpb = waves per block; rt = 16-row sub-tiles per wave iteration):
+//   shape 0: nqt 4, wpb 4, rt 1, register double buffer   (64 queries)
+//   shape 1: nqt 8, wpb 8, rt 1, register double buffer   (128 queries, 100 KB LDS -> one block per CU)
+//   shape 2: nqt 8, wpb 8, rt 2, single buffer            (128 queries, half the LDS reads per row)
+//   shape 3: nqt 8, wpb 4, rt 2, register double buffer   (one wave per SIMD, 512 registers)
+int scan_mfma_waves_per_block(int shape) { return shape == 0 || shape == 3 ? 4 : 8; }
+int scan_mfma_rows_per_tile(int shape) { return shape >= 2 ? 32 : 16; }
+int scan_mfma_query_tiles(int shape) { return shape == 0 ? 4 : 8; }
+
+template <int DIM>
+static hipError_t launch_mfma_d(const MfmaScanArgs& args, int shape, int grid, hipStream_t stream, int* occupancy) {
+    switch (shape) {
+        case 0: return launch_mfma_t<DIM, 4, 4, 1, true>(args, grid, stream, occupancy);
+        case 1: return launch_mfma_t<DIM, 8, 8, 1, true>(args, grid, stream, occupancy);
+        case 2: return launch_mfma_t<DIM, 8, 8, 2, false>(args, grid, stream, occupancy);
+        case 3: return launch_mfma_t<DIM, 8, 4, 2, true>(args, grid, stream, occupancy);
+        default: return hipErrorInvalidValue;
     }
-    return hipErrorInvalidValue;
+}
+
+hipError_t launch_scan_mfma(const MfmaScanArgs& args, int shape, int grid, hipStream_t stream, int* occupancy) {
+    switch (args.dim) {
+        case 128: return launch_mfma_d<128>(args, shape, grid, stream, occupancy);
+        case 256: return launch_mfma_d<256>(args, shape, grid, stream, occupancy);
+        case 384: return launch_mfma_d<384>(args, shape, grid, stream, occupancy);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_max_row_norm(const void* slab, uint32_t nrows, uint32_t dim, unsigned int* out_bits, hipStream_t stream) {
@@ -371,13 +431,6 @@ hipError_t launch_tau_from_selection(const u64* sel, const uint32_t* sel_counts,
                                      const float* delta, float* tau, uint32_t nq_pad, hipStream_t stream) {
     hipLaunchKernelGGL(tau_from_selection_kernel, dim3((nq_pad + 63) / 64), dim3(64), 0, stream, sel, sel_counts, stride, k,
                        delta, tau, nq_pad);
-    return hipGetLastError();
-}
-
-hipError_t launch_clamp_counts(const uint32_t* counters, uint32_t* counts, uint32_t cap, uint32_t* overflow,
-                               uint32_t nq_pad, hipStream_t stream) {
-    hipLaunchKernelGGL(clamp_counts_kernel, dim3((nq_pad + 63) / 64), dim3(64), 0, stream, counters, counts, cap, overflow,
-                       nq_pad);
     return hipGetLastError();
 }
 

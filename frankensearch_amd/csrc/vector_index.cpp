@@ -649,18 +649,27 @@ SearchError VectorIndex::gather_dot(const float* query, uint32_t query_len, cons
 SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, uint32_t nq, uint32_t query_len,
                                                      uint32_t k, const uint64_t* allow_dev, uint32_t* out_rows_dev,
                                                      float* out_scores_dev, uint32_t* out_counts_dev,
-                                                     hipStream_t stream, uint32_t* fallbacks) {
+                                                     hipStream_t stream, uint32_t* fallbacks, uint64_t* out_packed_dev) {
     if (fallbacks) *fallbacks = 0;
     FSGPU_TRY(ensure_query_dimension(query_len));
     if (nq == 0) return ok();
-    constexpr uint32_t G = 64;        // queries per pass
+    constexpr uint32_t GMAX = 128;    // queries per pass: 128, or 64 for small batches / tails
     constexpr uint32_t CAPQ = 8192;   // candidate slots per query (= the merge kernel's single-sort capacity)
     constexpr uint32_t KC = 256;      // approximate candidates re-scored exactly
-    constexpr uint32_t RA = 4096;     // stage A rows (dense)
-    constexpr uint32_t RB = 131072;   // stage B end row
-    const bool usable = scan_mfma_supported((int)dim_) && k >= 1 && k <= 64 && nrows_ >= 2 * RA;
+    uint32_t RA = 4096;               // stage A rows (dense sample; <= 8192)
+    uint32_t RB = 131072;             // stage B end row
+    if (const char* e = std::getenv("FSGPU_RA")) RA = (uint32_t)std::atoi(e);  // tuning experiments only
+    if (const char* e = std::getenv("FSGPU_RB")) RB = (uint32_t)std::atoi(e);
+    constexpr uint32_t RA_MAX = 8192;
+    if (RA < 256 || RA > RA_MAX || (RA & 63)) RA = 4096;
+    if (RB < RA || (RB & 63)) RB = 131072;   // row ranges start on bitmap-word boundaries
+    const bool usable = scan_mfma_supported((int)dim_) && k >= 1 && k <= 64 && nrows_ >= 2 * RA && variant != 4;
     if (!usable) {
         if (fallbacks) *fallbacks = nq;
+        if (out_packed_dev) {
+            FSGPU_TRY(search_top_k_packed_device(queries_dev, nq, query_len, k, allow_dev, out_packed_dev, stream));
+            if (!out_rows_dev) return ok();
+        }
         return search_top_k_device(queries_dev, nq, query_len, k, allow_dev, out_rows_dev, out_scores_dev,
                                    out_counts_dev, stream);
     }
@@ -671,43 +680,48 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
         FSGPU_HIP(launch_max_row_norm(slab_dev_, N, dim_, static_cast<unsigned int*>(mf_max_norm_.ptr), stream));
         mf_norm_ready_ = true;
     }
-    FSGPU_TRY(mf_qh_.reserve((size_t)G * dim_ * 2));
-    FSGPU_TRY(mf_delta_.reserve(G * 4));
-    FSGPU_TRY(mf_tau_.reserve(G * 4));
-    FSGPU_TRY(mf_cand_.reserve((size_t)G * CAPQ * 8));
-    FSGPU_TRY(mf_counts_.reserve(G * 4));
-    FSGPU_TRY(mf_counters_.reserve((size_t)G * kMfmaCountStride * 4));
-    FSGPU_TRY(mf_dense_.reserve((size_t)G * RA * 8));
-    FSGPU_TRY(mf_sel_.reserve((size_t)G * KC * 8));
-    FSGPU_TRY(mf_sel_counts_.reserve(G * 4));
-    FSGPU_TRY(mf_overflow_.reserve(G * 4));
-    FSGPU_TRY(mf_rows_.reserve((size_t)G * KC * 4));
-    FSGPU_TRY(mf_exact_.reserve((size_t)G * KC * 8));
-    int per_cu = 1;
+    FSGPU_TRY(mf_qh_.reserve((size_t)GMAX * dim_ * 2));
+    FSGPU_TRY(mf_delta_.reserve(GMAX * 4));
+    FSGPU_TRY(mf_tau_.reserve(GMAX * 4));
+    FSGPU_TRY(mf_cand_.reserve((size_t)GMAX * CAPQ * 8));
+    FSGPU_TRY(mf_counts_.reserve(GMAX * 4));
+    FSGPU_TRY(mf_dense_.reserve((size_t)GMAX * RA_MAX * 8));
+    FSGPU_TRY(mf_sel_.reserve((size_t)GMAX * KC * 8));
+    FSGPU_TRY(mf_sel_counts_.reserve(GMAX * 4));
+    FSGPU_TRY(mf_overflow_.reserve(GMAX * 4));
+    FSGPU_TRY(mf_rows_.reserve((size_t)GMAX * KC * 4));
+    FSGPU_TRY(mf_exact_.reserve((size_t)GMAX * KC * 8));
+    int wide_shape = 2;               // 128-query kernel shape (mfma_scan.hip)
+    if (const char* e = std::getenv("FSGPU_MFMA_SHAPE")) wide_shape = std::atoi(e);
+    if (wide_shape < 1 || wide_shape > 3) wide_shape = 2;
+    int per_cu4 = 1, per_cu8 = 1;
     MfmaScanArgs probe{};
     probe.dim = dim_;
-    FSGPU_HIP(launch_scan_mfma(probe, 4, 1, stream, &per_cu));
-    const int full_grid = num_cus_ * per_cu;
-    auto grid_for = [&](uint32_t rows) {
-        int g = (int)(((rows + 15) / 16 + 3) / 4);
-        if (g > full_grid) g = full_grid;
-        return g < 1 ? 1 : g;
-    };
+    probe.row_begin = 64;  // the main-pass instantiation
+    FSGPU_HIP(launch_scan_mfma(probe, 0, 1, stream, &per_cu4));
+    FSGPU_HIP(launch_scan_mfma(probe, wide_shape, 1, stream, &per_cu8));
     float* delta = static_cast<float*>(mf_delta_.ptr);
     float* tau = static_cast<float*>(mf_tau_.ptr);
     u64* cand = static_cast<u64*>(mf_cand_.ptr);
-    uint32_t* counts = static_cast<uint32_t*>(mf_counts_.ptr);
-    u64* sel = static_cast<u64*>(mf_sel_.ptr);
     uint32_t* sel_counts = static_cast<uint32_t*>(mf_sel_counts_.ptr);
     uint32_t* overflow = static_cast<uint32_t*>(mf_overflow_.ptr);
     uint32_t total_fallbacks = 0;
-    for (uint32_t g0 = 0; g0 < nq; g0 += G) {
-        const uint32_t ng = std::min(G, nq - g0);
+    for (uint32_t g0 = 0; g0 < nq;) {
+        const uint32_t left = nq - g0;
+        const int nqt = (left > 64 && variant != 5) ? wide_shape : 0;   // kernel shape: 128 or 64 queries per pass
+        const uint32_t G = (uint32_t)scan_mfma_query_tiles(nqt) * 16;
+        const uint32_t ng = std::min(G, left);
+        const int wpb = scan_mfma_waves_per_block(nqt);
+        const int full_grid = num_cus_ * (nqt ? per_cu8 : per_cu4);
+        auto grid_for = [&](uint32_t rows, uint32_t tile_rows) {
+            int g = (int)(((rows + tile_rows - 1) / tile_rows + wpb - 1) / wpb);
+            if (g > full_grid) g = full_grid;
+            return g < 1 ? 1 : g;
+        };
+        const uint32_t tile_rows = (uint32_t)scan_mfma_rows_per_tile(nqt);
         const float* qg = queries_dev + (size_t)g0 * dim_;
         FSGPU_HIP(launch_prepare_queries(qg, ng, G, dim_, static_cast<const unsigned int*>(mf_max_norm_.ptr), mf_qh_.ptr,
                                          delta, stream));
-        uint32_t* counters = static_cast<uint32_t*>(mf_counters_.ptr);
-        FSGPU_HIP(hipMemsetAsync(counters, 0, (size_t)G * kMfmaCountStride * 4, stream));
         FSGPU_HIP(hipMemsetAsync(overflow, 0, G * 4, stream));
         MfmaScanArgs a{};
         a.slab = slab_dev_;
@@ -716,15 +730,15 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
         a.queries = mf_qh_.ptr;
         a.tau = tau;
         a.cand = cand;
-        a.counts = counters;
+        a.overflow = overflow;
         a.dim = dim_;
-        a.cap = CAPQ;
         a.row_base = (uint32_t)row_base_;
-        // stage A: dense approximate scores of rows [0, RA) -> k-th best -> tau
+        // stage A: dense approximate scores of rows [0, RA) -> k-th best -> tau (fused into the selection kernel)
         a.dense = static_cast<u64*>(mf_dense_.ptr);
         a.row_begin = 0;
         a.row_end = RA;
-        FSGPU_HIP(launch_scan_mfma(a, 4, grid_for(RA), stream, nullptr));
+        a.slots = 0;
+        FSGPU_HIP(launch_scan_mfma(a, nqt, grid_for(RA, 16), stream, nullptr));
         MergeArgs m{};
         m.lists = a.dense;
         m.q_stride = RA;
@@ -732,57 +746,66 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
         m.nlists = 1;
         m.list_len = RA;
         m.k = k;
-        m.out_stride = KC;
-        m.out_rows = nullptr;
-        m.out_scores = nullptr;
-        m.out_counts = sel_counts;
-        m.out_packed = sel;
+        m.out_stride = k;
         m.lists_sorted = 0;
+        m.delta = delta;
+        m.tau_out = tau;
+        m.tau_k = k;
         FSGPU_HIP(launch_merge_topk(m, (int)G, stream));
-        FSGPU_HIP(launch_tau_from_selection(sel, sel_counts, KC, k, delta, tau, G, stream));
-        // stage B: candidates of rows [0, RB) above tau -> tighter tau
+        // stage B: rows [0, RB) above tau, one candidate list per (query, block) -> best KC + tighter tau
         a.dense = nullptr;
         a.row_begin = 0;
         a.row_end = std::min(RB, N);
-        FSGPU_HIP(launch_scan_mfma(a, 4, grid_for(a.row_end), stream, nullptr));
-        FSGPU_HIP(launch_clamp_counts(counters, counts, CAPQ, overflow, G, stream));
+        const int grid_b = grid_for(a.row_end, tile_rows);
+        a.slots = std::min<uint32_t>(kMfmaMaxSlots, (CAPQ - KC) / (uint32_t)grid_b);
+        FSGPU_HIP(launch_scan_mfma(a, nqt, grid_b, stream, nullptr));
+        uint32_t* cand_rows = static_cast<uint32_t*>(mf_rows_.ptr);
+        u64* sel_b = static_cast<u64*>(mf_sel_.ptr);
         MergeArgs mb{};
         mb.lists = cand;
-        mb.q_stride = CAPQ;
-        mb.l_stride = CAPQ;
-        mb.nlists = 1;
-        mb.list_len = CAPQ;
-        mb.k = k;
+        mb.q_stride = (uint64_t)grid_b * a.slots;
+        mb.l_stride = a.slots;
+        mb.nlists = (uint32_t)grid_b;
+        mb.list_len = a.slots;
+        mb.k = KC;
         mb.out_stride = KC;
-        mb.out_counts = sel_counts;
-        mb.out_packed = sel;
         mb.lists_sorted = 0;
-        mb.list_counts = counts;
+        mb.delta = delta;
+        mb.overflow = overflow;
         if (a.row_end < N) {
+            mb.out_packed = sel_b;  // stage B's best KC stay in the pool
+            mb.tau_out = tau;
+            mb.tau_k = k;
             FSGPU_HIP(launch_merge_topk(mb, (int)G, stream));
-            FSGPU_HIP(launch_tau_from_selection(sel, sel_counts, KC, k, delta, tau, G, stream));
             // stage C: the rest of the slab
             a.row_begin = a.row_end;
             a.row_end = N;
+            a.slots = std::min<uint32_t>(kMfmaMaxSlots, (CAPQ - KC) / (uint32_t)full_grid);
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (profiling) {
                 FSGPU_HIP(hipEventCreate(&e0));
                 FSGPU_HIP(hipEventCreate(&e1));
                 FSGPU_HIP(hipEventRecord(e0, stream));
             }
-            FSGPU_HIP(launch_scan_mfma(a, 4, full_grid, stream, nullptr));
+            FSGPU_HIP(launch_scan_mfma(a, nqt, full_grid, stream, nullptr));
             if (profiling) {
                 FSGPU_HIP(hipEventRecord(e1, stream));
                 events_.emplace_back(e0, e1);
             }
-            FSGPU_HIP(launch_clamp_counts(counters, counts, CAPQ, overflow, G, stream));
+            mb.q_stride = (uint64_t)full_grid * a.slots;
+            mb.l_stride = a.slots;
+            mb.nlists = (uint32_t)full_grid;
+            mb.list_len = a.slots;
+            mb.extra = sel_b;
+            mb.extra_len = KC;
+            mb.out_packed = nullptr;
+            mb.tau_out = nullptr;
         }
-        // the KC best approximate candidates, margin check, exact re-score, final selection
-        mb.k = KC;
+        // the KC best approximate candidates (+ margin check, + their row ids), exact re-score, final selection
+        mb.margin_k = k;
+        mb.out_rows = cand_rows;
+        mb.out_counts = sel_counts;
         FSGPU_HIP(launch_merge_topk(mb, (int)G, stream));
-        FSGPU_HIP(launch_margin_check(sel, sel_counts, KC, k, delta, overflow, G, stream));
-        uint32_t* cand_rows = static_cast<uint32_t*>(mf_rows_.ptr);
-        FSGPU_HIP(launch_packed_rows(sel, G * KC, cand_rows, stream));
         ScanArgs ga = base_args(qg, nullptr);
         u64* exact = static_cast<u64*>(mf_exact_.ptr);
         FSGPU_HIP(launch_gather_dot_batch(ga, cand_rows, KC, ng, exact, stream));
@@ -794,10 +817,10 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
         mf.list_len = KC;
         mf.k = std::min<uint32_t>(k, N);
         mf.out_stride = k;
-        mf.out_rows = out_rows_dev + (size_t)g0 * k;
-        mf.out_scores = out_scores_dev + (size_t)g0 * k;
-        mf.out_counts = out_counts_dev + g0;
-        mf.out_packed = nullptr;
+        mf.out_rows = out_rows_dev ? out_rows_dev + (size_t)g0 * k : nullptr;
+        mf.out_scores = out_scores_dev ? out_scores_dev + (size_t)g0 * k : nullptr;
+        mf.out_counts = out_counts_dev ? out_counts_dev + g0 : nullptr;
+        mf.out_packed = out_packed_dev ? reinterpret_cast<u64*>(out_packed_dev) + (size_t)g0 * k : nullptr;
         mf.lists_sorted = 0;
         FSGPU_HIP(launch_merge_topk(mf, (int)ng, stream));
         // fallback decision on the host: margin/capacity overflow, or fewer than k finite candidates
@@ -808,11 +831,16 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
         for (uint32_t i = 0; i < ng; ++i) {
             if (ovf[i] || got[i] < std::min<uint32_t>(k, N)) {
                 ++total_fallbacks;
-                FSGPU_TRY(search_top_k_device(qg + (size_t)i * dim_, 1, query_len, k, allow_dev,
-                                              out_rows_dev + (size_t)(g0 + i) * k, out_scores_dev + (size_t)(g0 + i) * k,
-                                              out_counts_dev + g0 + i, stream));
+                const uint32_t k_eff = std::min<uint32_t>(k, N);
+                const size_t o = (size_t)(g0 + i) * k;
+                FSGPU_TRY(fused_search(qg + (size_t)i * dim_, 1, k, k_eff, allow_dev,
+                                       out_rows_dev ? out_rows_dev + o : nullptr,
+                                       out_scores_dev ? out_scores_dev + o : nullptr,
+                                       out_counts_dev ? out_counts_dev + g0 + i : nullptr,
+                                       out_packed_dev ? reinterpret_cast<u64*>(out_packed_dev) + o : nullptr, stream));
             }
         }
+        g0 += ng;
     }
     if (fallbacks) *fallbacks = total_fallbacks;
     return ok();

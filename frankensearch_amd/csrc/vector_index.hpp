@@ -59,7 +59,8 @@ class VectorIndex {
     // exact kernels.  Synchronises the stream (the fallback decision is taken on the host).
     SearchError search_top_k_batched_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
                                             const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
-                                            uint32_t* out_counts_dev, hipStream_t stream, uint32_t* fallbacks);
+                                            uint32_t* out_counts_dev, hipStream_t stream, uint32_t* fallbacks,
+                                            uint64_t* out_packed_dev = nullptr);
     SearchError search_top_k_batched(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
                                      const uint64_t* allow, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
                                      uint32_t* fallbacks);

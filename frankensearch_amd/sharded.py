@@ -40,11 +40,14 @@ class ShardBackend(Protocol):
 class GpuShardBackend:
     """libfsgpu.so on the current torch device / current stream."""
 
-    def __init__(self, index, device: torch.device):
+    def __init__(self, index, device: torch.device, batched: bool = False):
         self.index = index
         self.device = device
+        self.batched = batched        # serve through the matrix-core batched path (64 queries per HBM pass)
+        self.last_fallbacks = 0
 
     def search_packed(self, queries: torch.Tensor, k: int) -> torch.Tensor:
+        import ctypes as C
         from . import _lib
         from .errors import check
 
@@ -52,8 +55,14 @@ class GpuShardBackend:
         b, dim = queries.shape
         out = torch.empty((b, k), dtype=torch.int64, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        check(_lib.lib().fsgpu_search_topk_packed_device(self.index._h, queries.data_ptr(), b, dim, k, None,
-                                                         out.data_ptr(), stream))
+        if self.batched:
+            fb = C.c_uint32()
+            check(_lib.lib().fsgpu_search_topk_batched_packed_device(self.index._h, queries.data_ptr(), b, dim, k, None,
+                                                                     out.data_ptr(), stream, C.byref(fb)))
+            self.last_fallbacks = fb.value
+        else:
+            check(_lib.lib().fsgpu_search_topk_packed_device(self.index._h, queries.data_ptr(), b, dim, k, None,
+                                                             out.data_ptr(), stream))
         return out
 
     def search_unsharded(self, queries: torch.Tensor, k: int):
@@ -61,6 +70,8 @@ class GpuShardBackend:
         from . import _lib
         from .errors import check
 
+        if self.batched:
+            return self.search_batched(queries, k)
         b, dim = queries.shape
         rows = torch.empty((b, k), dtype=torch.int32, device=self.device)
         scores = torch.empty((b, k), dtype=torch.float32, device=self.device)

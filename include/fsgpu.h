@@ -146,6 +146,11 @@ fsgpu_status fsgpu_search_topk_batched_device(fsgpu_index *idx, const float *que
 fsgpu_status fsgpu_search_topk_packed_device(fsgpu_index *idx, const float *queries_dev, uint32_t nq,
                                              uint32_t query_len, uint32_t k, const uint64_t *allow_bitmap_dev,
                                              uint64_t *out_packed_dev, void *hip_stream);
+/* Batched (matrix-core) form of fsgpu_search_topk_packed_device: same packed output, same exact results, 64 queries
+ * per pass.  Synchronises hip_stream. */
+fsgpu_status fsgpu_search_topk_batched_packed_device(fsgpu_index *idx, const float *queries_dev, uint32_t nq,
+                                                     uint32_t query_len, uint32_t k, const uint64_t *allow_bitmap_dev,
+                                                     uint64_t *out_packed_dev, void *hip_stream, uint32_t *out_fallbacks);
 /* Merge of gathered packed lists = merge_partial_heaps + resolve_hits sort (search.rs:1704-1720,1493-1501)
  * across shards: entry (q, l, i) is lists_dev[q*q_stride + l*l_stride + i]; selects the k best per query
  * under the reference order.  For an all-gather result laid out [nlists][nq][list_len]:

@@ -420,7 +420,7 @@ def test_batched_mfma_search_is_bit_exact(fa, oracle):
             br, bs, bc, _ = idx.search_batched(q, 10)
             assert np.array_equal(br[qi], orow) and np.array_equal(bits(bs[qi]), bits(osc))
     # small index / large k -> transparently the exact path
-    slab = rand_slab(rng, 3000, 384)
+    slab = rand_slab(rng, 1500, 384)
     idx = fa.VectorIndex.from_slab(slab)
     q = rng.standard_normal((3, 384)).astype(np.float32)
     br, bs, bc, fb = idx.search_batched(q, 10)
