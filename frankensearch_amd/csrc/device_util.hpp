@@ -49,6 +49,54 @@ __device__ __forceinline__ float quad_xor2(float v) {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));  // [2,3,0,1]
 }
 
+// Wave-wide unsigned max through DPP (row_shr 1/2/4/8 fold each row of 16 into its last lane, row_bcast15/31 carry
+// rows 0->1, 2->3 and 1->2,3), read back from lane 63: no LDS traffic, ~10 VALU ops.  Returned value is wave-uniform.
+__device__ __forceinline__ uint32_t wave_umax32(uint32_t v) {
+    int x = (int)v;
+#define FSGPU_DPP_MAX(ctrl, row_mask)                                                                \
+    {                                                                                                \
+        const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, x, ctrl, row_mask, 0xF, false);  \
+        x = (int)(t > (uint32_t)x ? t : (uint32_t)x);                                                \
+    }
+    FSGPU_DPP_MAX(0x111, 0xF)  // row_shr:1
+    FSGPU_DPP_MAX(0x112, 0xF)  // row_shr:2
+    FSGPU_DPP_MAX(0x114, 0xF)  // row_shr:4
+    FSGPU_DPP_MAX(0x118, 0xF)  // row_shr:8
+    FSGPU_DPP_MAX(0x142, 0xA)  // row_bcast:15 into rows 1 and 3
+    FSGPU_DPP_MAX(0x143, 0xC)  // row_bcast:31 into rows 2 and 3
+#undef FSGPU_DPP_MAX
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+}
+
+// Wave-wide max of 64-bit sort keys (0 = none): high words first, then the low words of the lanes that tie on it.
+__device__ __forceinline__ u64 wave_max_key(u64 m) {
+    const uint32_t hi = (uint32_t)(m >> 32), lo = (uint32_t)m;
+    const uint32_t mh = wave_umax32(hi);
+    const uint32_t ml = wave_umax32(hi == mh ? lo : 0u);
+    return ((u64)mh << 32) | ml;
+}
+
+// The wave's k best of PER entries per lane, best first, into out[0..k) (pre-filled with kEmpty by the caller).
+// key[] = sortkey or 0 for holes; keys are unique, so each round retires exactly one entry.
+template <int PER>
+__device__ __forceinline__ void wave_extract_topk(u64 (&key)[PER], const u64 (&e)[PER], int k, u64* out) {
+    for (int r = 0; r < k; ++r) {
+        u64 m = key[0];
+#pragma unroll
+        for (int x = 1; x < PER; ++x) m = key[x] > m ? key[x] : m;
+        const u64 wm = wave_max_key(m);
+        if (wm == 0ull) break;  // wave-uniform: nothing left
+        if (m == wm) {
+#pragma unroll
+            for (int x = 0; x < PER; ++x)
+                if (key[x] == wm) {
+                    out[r] = e[x];
+                    key[x] = 0ull;
+                }
+        }
+    }
+}
+
 // wide::f32x8::reduce_add (third-party; simd.rs:439,563).  mode 0 = SSE2 build order, 1 = AVX order.
 __device__ __forceinline__ float hreduce8(const float (&v)[8], int mode) {
     if (mode == 1) {

@@ -427,7 +427,15 @@ fsgpu_status fsgpu_index_scan_time(fsgpu_index* idx, double* total_ms, uint64_t*
     if (!idx || !total_ms || !launches) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
     return guarded([&]() -> fsgpu_status {
         std::lock_guard<std::mutex> lock(idx->impl.mutex());
-        return finish(idx->impl.scan_time(total_ms, launches, reset != 0));
+        return finish(idx->impl.scan_time(total_ms, launches, nullptr, reset != 0));
+    });
+}
+
+fsgpu_status fsgpu_index_scan_stats(fsgpu_index* idx, double* total_ms, uint64_t* launches, uint64_t* rows, int32_t reset) {
+    if (!idx || !total_ms || !launches || !rows) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.scan_time(total_ms, launches, rows, reset != 0));
     });
 }
 

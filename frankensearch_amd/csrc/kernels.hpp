@@ -62,6 +62,11 @@ hipError_t launch_packed_to_sortkey(u64* data, size_t n, hipStream_t stream);
 hipError_t launch_sorted_keys_to_rows(const u64* keys, uint32_t k, uint32_t* out_rows, uint32_t* out_count,
                                       hipStream_t stream);
 hipError_t launch_gather_dot(const ScanArgs& args, const uint32_t* rows, uint32_t n, float* out, hipStream_t stream);
+hipError_t launch_gather_queries(const float* src, const uint32_t* idx, uint32_t n, uint32_t dim, float* dst,
+                                 hipStream_t stream);
+hipError_t launch_scatter_hits(const uint32_t* idx, uint32_t n, uint32_t k, const uint32_t* src_rows,
+                               const float* src_scores, const uint32_t* src_counts, uint32_t* dst_rows,
+                               float* dst_scores, uint32_t* dst_counts, u64* dst_packed, hipStream_t stream);
 hipError_t launch_encode_f16(const float* src, size_t n, unsigned short* dst, hipStream_t stream);
 hipError_t launch_widen_f16(const unsigned short* src, size_t n, float* dst, hipStream_t stream);
 
@@ -83,10 +88,44 @@ struct MfmaScanArgs {
     const float* tau;          // [nq_pad] candidate threshold per query (ignored in dense mode)
     u64* cand;                 // [nq_pad, gridDim.x, slots] packed approximate candidates, one list per block
     uint32_t* overflow;        // [nq_pad] set when a block's list for a query overflows its slots
-    u64* dense;                // dense mode: [nq_pad, row_end - row_begin] packed approximate scores
-    uint32_t row_begin, row_end;  // row_begin % 16 == 0
-    uint32_t dim, slots, row_base;  // slots <= kMfmaMaxSlots
+    u64* dense;                // stage 0: [nq_pad, group_count * 64] packed approximate scores of the sample
+    uint32_t nrows;            // rows in the slab
+    uint32_t stage;            // 0 = dense sample, 1 = thresholded sample, 2 = main pass (everything stage 1 skipped)
+    uint32_t group_stride, group_count;  // the sample, in 64-row groups: {j * group_stride : j < group_count}
+    uint32_t dim, slots, row_base;       // slots <= kMfmaMaxSlots
 };
+
+// select_kernel (mfma_scan.hip): per query, the k-th best of <= 8192 packed approximate entries without sorting them
+// (k rounds of wave arg-max per wave, k more over the 16 waves' winners) -> tau = a_k - 2 delta; the entries at or
+// above tau are the query's candidates.  Two uses:
+//   threshold step (slab == null): tau_out for the next scan stage, candidates optionally kept as a pool;
+//   finish step (slab != null): the <= kSelectPool candidates are re-scored with the exact-order dot right in the block (one
+//   quad per candidate) and the best k_out exact entries are emitted best first.
+struct SelectArgs {
+    const u64* lists;          // [nq][nlists][list_len] (strides below), kEmpty = hole
+    uint64_t q_stride;         // entries between queries
+    uint32_t l_stride, nlists, list_len;
+    const u64* extra;          // [nq, extra_len] more entries per query (may be null)
+    uint32_t extra_len;
+    uint32_t k;                // 1..64
+    const float* delta;        // [nq] error bound; < 0 = query is skipped (tau = +inf, overflow set)
+    float* tau_out;            // [nq] (may be null)
+    u64* pool_out;             // [nq, kSelectPool] candidates, kEmpty padded (may be null)
+    uint32_t* cand_counts;     // [nq] number of candidates, unclamped (may be null)
+    uint32_t* overflow;        // [nq] set when there are more than kSelectPool candidates
+    // finish step
+    const void* slab;          // [nrows, dim] f16
+    const float* queries;      // [nq, dim] f32
+    uint32_t dim, nrows, row_base;
+    int hreduce;
+    uint32_t k_out, out_stride;
+    uint32_t* out_rows;        // [nq, out_stride] (may be null; 0xffffffff padding)
+    float* out_scores;         // [nq, out_stride] (may be null)
+    u64* out_packed;           // [nq, out_stride] (may be null; kEmpty padding)
+    uint32_t* out_counts;      // [nq] (may be null)
+};
+constexpr uint32_t kSelectPool = 1024;
+hipError_t launch_select(const SelectArgs& args, int nq, hipStream_t stream);
 
 constexpr uint32_t kMfmaMaxSlots = 32;  // candidate slots per (block, query) staged in LDS
 bool scan_mfma_supported(int dim);

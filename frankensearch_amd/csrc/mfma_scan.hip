@@ -44,7 +44,8 @@ __global__ __launch_bounds__(WPB * 64) void scan_mfma_kernel(MfmaScanArgs args) 
     constexpr int NQ = NQT * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16* qs = reinterpret_cast<_Float16*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the tile index arithmetic stays on the SALU
     const int frow = lane & 15;  // A: row inside the tile / B: query inside the query tile / C: column (query)
     const int fk = lane >> 4;    // k-group (8 halves each) / C: row group (4 rows each)
     {   // stage the queries: 16-byte pieces, coalesced
@@ -72,11 +73,25 @@ __global__ __launch_bounds__(WPB * 64) void scan_mfma_kernel(MfmaScanArgs args) 
     // A wave iteration covers RT consecutive 16-row sub-tiles: every B fragment read from LDS feeds RT MFMAs, so
     // the LDS traffic per row falls by RT (at 128 queries the B reads, 96 KB per 16 rows, are what bounds RT = 1).
     constexpr uint32_t TROWS = 16 * RT;
-    const uint32_t ntiles = (args.row_end - args.row_begin + TROWS - 1) / TROWS;
+    constexpr uint32_t TPG = 64 / TROWS;  // tiles per 64-row group (one live/allow bitmap word)
+    // Row coverage, in 64-row groups.  Sample launches (stages 0/1) visit groups {j * group_stride : j < group_count},
+    // spread over the whole slab so that the threshold they produce is representative even when neighbouring rows are
+    // correlated (documents arrive in topical runs); the main pass (stage 2) visits every group that stage 1 did not.
+    const uint32_t ntiles = STAGE == 2 ? (args.nrows + TROWS - 1) / TROWS : args.group_count * TPG;
     const uint32_t nwaves = gridDim.x * WPB;
     const unsigned char* slab = reinterpret_cast<const unsigned char*>(args.slab);
     constexpr size_t row_bytes = (size_t)DIM * 2;
-    const uint32_t last_row = args.row_end - 1;
+    const uint32_t last_row = args.nrows - 1;
+    auto tile_row0 = [&](uint32_t t) -> uint32_t {
+        if (STAGE == 2) return t * TROWS;
+        return (t / TPG) * args.group_stride * 64 + (t % TPG) * TROWS;
+    };
+    auto tile_skipped = [&](uint32_t t) -> bool {  // main pass: the group was covered by the stage-1 sample
+        if (STAGE != 2) return false;
+        const uint32_t g = (t * TROWS) >> 6;
+        const uint32_t j = g / args.group_stride;
+        return j * args.group_stride == g && j < args.group_count;
+    };
 
     // HBM side: the coalesced quad layout of the exact kernels — lane (r = lane>>2, a = lane&3) fetches chunk 4ks+a
     // of row r, so four consecutive lanes read 64 contiguous bytes.  The MFMA wants lane (row = lane&15,
@@ -88,8 +103,8 @@ __global__ __launch_bounds__(WPB * 64) void scan_mfma_kernel(MfmaScanArgs args) 
     auto load_tile = [&](uint32_t t, half8 (&w)[RT][KS]) {
 #pragma unroll
         for (int s = 0; s < RT; ++s) {
-            uint32_t row = args.row_begin + t * TROWS + s * 16 + lrow;
-            row = row < args.row_end ? row : last_row;
+            uint32_t row = tile_row0(t) + s * 16 + lrow;
+            row = row < args.nrows ? row : last_row;
             const half8* p = reinterpret_cast<const half8*>(slab + (size_t)row * row_bytes) + lchunk;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) w[s][ks] = p[ks * 4];
@@ -105,9 +120,8 @@ __global__ __launch_bounds__(WPB * 64) void scan_mfma_kernel(MfmaScanArgs args) 
         y[3] = __builtin_amdgcn_ds_bpermute(perm_addr, x[3]);
         return __builtin_bit_cast(half8, y);
     };
-    // row ranges start on multiples of 64 (host contract), so the TROWS <= 64 rows of a tile share one bitmap word
     auto tile_words = [&](uint32_t t, u64& live_word, u64& allow_word) {
-        const uint32_t w64 = (args.row_begin + t * TROWS) >> 6;
+        const uint32_t w64 = tile_row0(t) >> 6;
         live_word = args.live ? args.live[w64] : ~0ull;
         allow_word = args.allow ? args.allow[w64] : ~0ull;
     };
@@ -143,24 +157,22 @@ __global__ __launch_bounds__(WPB * 64) void scan_mfma_kernel(MfmaScanArgs args) 
 #pragma unroll
         for (int s = 0; s < RT; ++s) {
             // C layout: column (query) = lane & 15, row = (lane >> 4) * 4 + reg
-            const uint32_t row0 = args.row_begin + t * TROWS + s * 16 + fk * 4;
+            const uint32_t row0 = tile_row0(t) + s * 16 + fk * 4;
             bool valid[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const uint32_t row = row0 + r;
-                valid[r] = row < args.row_end && ((live_word >> (row & 63)) & 1ull) && ((allow_word >> (row & 63)) & 1ull);
+                valid[r] = row < args.nrows && ((live_word >> (row & 63)) & 1ull) && ((allow_word >> (row & 63)) & 1ull);
             }
             if constexpr (STAGE == 0) {
-                const size_t span = args.row_end - args.row_begin;
+                const size_t span = (size_t)args.group_count * 64;  // dense slot = position inside the sample
+                const uint32_t pos0 = t * TROWS + s * 16 + fk * 4;
 #pragma unroll
                 for (int nt = 0; nt < NQT; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const uint32_t row = row0 + r;
-                        if (row < args.row_end)
-                            args.dense[(size_t)(nt * 16 + frow) * span + (row - args.row_begin)] =
-                                valid[r] ? pack(acc[s][nt][r], args.row_base + row) : kEmpty;
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        args.dense[(size_t)(nt * 16 + frow) * span + pos0 + r] =
+                            valid[r] ? pack(acc[s][nt][r], args.row_base + row0 + r) : kEmpty;
             } else {
 #pragma unroll
                 for (int nt = 0; nt < NQT; ++nt) {
@@ -182,17 +194,23 @@ __global__ __launch_bounds__(WPB * 64) void scan_mfma_kernel(MfmaScanArgs args) 
         }
     };
 
+    // Tile t belongs to block t % gridDim.x: a run of neighbouring rows (one topic's documents, typically the rows a
+    // query's candidates cluster in) is spread over many blocks' candidate lists instead of overflowing one.
+    auto next_tile = [&](uint32_t t) -> uint32_t {  // the wave's next tile at or after t that is not skipped
+        while (t < ntiles && tile_skipped(t)) t += nwaves;
+        return t;
+    };
     if constexpr (PF) {
         // register double buffer: the next tile's loads are in flight while this one is on the matrix cores
         half8 wa[RT][KS], wb[RT][KS];
         u64 la = ~0ull, aa = ~0ull, lb = ~0ull, ab = ~0ull;
-        uint32_t t = blockIdx.x * WPB + wave;
+        uint32_t t = next_tile(wave * gridDim.x + blockIdx.x);
         if (t < ntiles) {
             load_tile(t, wa);
             tile_words(t, la, aa);
         }
         while (t < ntiles) {
-            uint32_t next = t + nwaves;
+            uint32_t next = next_tile(t + nwaves);
             if (next < ntiles) {
                 load_tile(next, wb);
                 tile_words(next, lb, ab);
@@ -200,7 +218,7 @@ __global__ __launch_bounds__(WPB * 64) void scan_mfma_kernel(MfmaScanArgs args) 
             compute_tile(t, wa, la, aa);
             t = next;
             if (t >= ntiles) break;
-            next = t + nwaves;
+            next = next_tile(t + nwaves);
             if (next < ntiles) {
                 load_tile(next, wa);
                 tile_words(next, la, aa);
@@ -212,7 +230,7 @@ __global__ __launch_bounds__(WPB * 64) void scan_mfma_kernel(MfmaScanArgs args) 
         // single buffer: the other resident waves of the SIMD cover the load latency
         half8 wa[RT][KS];
         u64 la = ~0ull, aa = ~0ull;
-        for (uint32_t t = blockIdx.x * WPB + wave; t < ntiles; t += nwaves) {
+        for (uint32_t t = next_tile(wave * gridDim.x + blockIdx.x); t < ntiles; t = next_tile(t + nwaves)) {
             load_tile(t, wa);
             tile_words(t, la, aa);
             compute_tile(t, wa, la, aa);
@@ -224,6 +242,158 @@ __global__ __launch_bounds__(WPB * 64) void scan_mfma_kernel(MfmaScanArgs args) 
         for (int i = tid; i < NQ * slots; i += NT) {
             const int q = i / slots, j = i - q * slots;
             args.cand[((size_t)q * gridDim.x + blockIdx.x) * slots + j] = lbuf[i];
+        }
+    }
+}
+
+// Selection without a full sort (see SelectArgs).  1024 threads hold their entries in registers; every wave extracts
+// its k largest sortkeys (wave_extract_topk), wave 0 repeats that over the 16 x k winners: its picks are the block's
+// top-k, best first.  A few microseconds, against 35-50 us for sorting the few hundred survivors these stages see.
+constexpr int kSelThreads = 1024;
+constexpr int kSelPer = 8;
+constexpr int kSelWaves = kSelThreads / 64;
+
+// top[0..k) <- the block's k best entries, best first (kEmpty padded).  key[] is consumed.  Ends on a barrier.
+template <int PER>
+__device__ __forceinline__ void block_select_topk(const u64 (&e)[PER], u64 (&key)[PER], int k, u64* win, u64* top, int tid) {
+    constexpr int NT = kSelThreads, NW = kSelWaves;
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int j = tid; j < NW * k; j += NT) win[j] = kEmpty;
+    if (tid < 64) top[tid] = kEmpty;
+    __syncthreads();
+    wave_extract_topk<PER>(key, e, k, win + wave * k);
+    __syncthreads();
+    if (wave == 0) {
+        u64 e2[NW], key2[NW];  // NW * k <= 64 * NW winners
+#pragma unroll
+        for (int x = 0; x < NW; ++x) {
+            const int i = lane + x * 64;
+            e2[x] = i < NW * k ? win[i] : kEmpty;
+            key2[x] = e2[x] != kEmpty ? sortkey(e2[x]) : 0ull;
+        }
+        wave_extract_topk<NW>(key2, e2, k, top);
+    }
+    __syncthreads();
+}
+
+template <bool FINISH>
+__global__ __launch_bounds__(kSelThreads) void select_kernel(SelectArgs args) {
+    constexpr int NT = kSelThreads, PER = kSelPer, NW = kSelWaves, POOL = (int)kSelectPool;
+    static_assert(POOL == NT, "one pool entry per thread in the final selection");
+    __shared__ u64 win[NW * 64];   // per-wave winners [wave][round]
+    __shared__ u64 top[64];        // block top-k, best first
+    __shared__ u64 pool[POOL];     // candidates (finish step: replaced by their exact entries)
+    __shared__ int s_count;
+    __shared__ float s_tau;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = blockIdx.x;
+    const int k = (int)args.k;
+    const u64* in = args.lists + (size_t)q * args.q_stride;
+    const uint32_t lists32 = args.nlists * args.list_len;
+    const uint32_t total32 = lists32 + args.extra_len;
+    if (tid == 0) s_count = 0;
+    u64 e[PER], key[PER];
+#pragma unroll
+    for (int x = 0; x < PER; ++x) {
+        const uint32_t i = tid + x * NT;
+        e[x] = kEmpty;
+        if (i < lists32) {
+            const uint32_t l = i / args.list_len;
+            e[x] = in[(size_t)l * args.l_stride + (i - l * args.list_len)];
+        } else if (i < total32) {
+            e[x] = args.extra[(size_t)q * args.extra_len + (i - lists32)];
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < PER; ++x) key[x] = e[x] != kEmpty ? sortkey(e[x]) : 0ull;
+    pool[tid] = kEmpty;
+    block_select_topk<PER>(e, key, k, win, top, tid);
+    if (tid == 0) {
+        const float d = args.delta[q];
+        float t = -INFINITY;   // fewer than k entries: everything is a candidate
+        if (d < 0.f) {
+            t = INFINITY;      // skipped query (padding / zero / non-finite): the exact path answers it
+            if (args.overflow) args.overflow[q] = 1;
+        } else if (top[k - 1] != kEmpty) {
+            t = __uint_as_float((uint32_t)(top[k - 1] >> 32)) - 2.0f * d;
+            if (!(t == t)) t = -INFINITY;
+        }
+        s_tau = t;
+        if (args.tau_out) args.tau_out[q] = t;
+    }
+    __syncthreads();
+    if (!FINISH && !args.pool_out && !args.cand_counts) return;
+    const float tau = s_tau;
+#pragma unroll
+    for (int x = 0; x < PER; ++x) {
+        const bool ok = e[x] != kEmpty && __uint_as_float((uint32_t)(e[x] >> 32)) >= tau;
+        const u64 m = __ballot(ok);
+        if (m) {
+            int wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&s_count, (int)__popcll(m));
+            wbase = __shfl(wbase, 0);
+            const int pos = wbase + (int)__popcll(m & ((1ull << lane) - 1ull));
+            if (ok && pos < POOL) pool[pos] = e[x];
+        }
+    }
+    __syncthreads();
+    const int ncand = s_count;
+    if (tid == 0) {
+        if (args.cand_counts) args.cand_counts[q] = (uint32_t)ncand;
+        if (ncand > POOL && args.overflow) args.overflow[q] = 1;
+    }
+    if (args.pool_out) args.pool_out[(size_t)q * POOL + tid] = pool[tid];
+    if constexpr (FINISH) {
+        // exact-order re-score (dot_product_f16_bytes_f32 order, as gather_dot_batch_kernel): one quad per candidate,
+        // 256 candidates per sweep; the entry is replaced by its exact counterpart in place
+        const int dim = (int)args.dim;
+        const int a = tid & 3;
+        const int nc = ncand < POOL ? ncand : POOL;
+        const float* qv = args.queries + (size_t)q * dim;
+        const int chunks = dim >> 3, groups = chunks >> 2, leftover = chunks & 3;
+        for (int c0 = 0; c0 < nc; c0 += NT / 4) {  // block-uniform trip count
+            const int c = c0 + (tid >> 2);
+            const u64 mine_e = c < nc ? pool[c] : kEmpty;
+            const uint32_t grow = (uint32_t)mine_e;
+            uint32_t row = grow - args.row_base;
+            const bool mine = mine_e != kEmpty && row < args.nrows;
+            if (!mine) row = 0;
+            const u32x4* p = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(args.slab) + (size_t)row * dim * 2);
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+            for (int g = 0; g < groups; ++g) {
+                const u32x4 w = p[4 * g + a];
+                const float4* qp = reinterpret_cast<const float4*>(qv + 32 * g + 8 * a);
+                chunk_mac(acc, w, qp[0], qp[1]);
+            }
+            if (a == 0)
+                for (int ch = 4 * groups; ch < 4 * groups + leftover; ++ch) {
+                    const u32x4 w = p[ch];
+                    const float4* qp = reinterpret_cast<const float4*>(qv + 8 * ch);
+                    chunk_mac(acc, w, qp[0], qp[1]);
+                }
+            const float sc = quad_finish(acc, args.hreduce);
+            if (a == 0 && c < nc) pool[c] = mine ? pack(sc, grow) : kEmpty;  // only this quad touches pool[c]
+        }
+        __syncthreads();
+        u64 e3[1], key3[1];
+        e3[0] = pool[tid];
+        key3[0] = e3[0] != kEmpty ? sortkey(e3[0]) : 0ull;
+        const int ko = (int)args.k_out;
+        block_select_topk<1>(e3, key3, ko, win, top, tid);
+        if (tid < 64) {
+            int n = 0;
+            for (int j = lane; j < (int)args.out_stride; j += 64) {
+                const u64 cnd = j < ko ? top[j] : kEmpty;
+                if (args.out_rows) args.out_rows[(size_t)q * args.out_stride + j] = (uint32_t)cnd;
+                if (args.out_scores) args.out_scores[(size_t)q * args.out_stride + j] = __uint_as_float((uint32_t)(cnd >> 32));
+                if (args.out_packed) args.out_packed[(size_t)q * args.out_stride + j] = cnd;
+                n += cnd != kEmpty ? 1 : 0;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off);
+            if (lane == 0 && args.out_counts) args.out_counts[q] = (uint32_t)n;
         }
     }
 }
@@ -378,8 +548,8 @@ static hipError_t launch_mfma_s(const MfmaScanArgs& args, int grid, hipStream_t 
 
 template <int DIM, int NQT, int WPB, int RT, bool PF>
 static hipError_t launch_mfma_t(const MfmaScanArgs& args, int grid, hipStream_t stream, int* occupancy) {
-    if (args.dense) return launch_mfma_s<DIM, NQT, WPB, 0, 1, true>(args, grid, stream, occupancy);
-    if (args.row_begin == 0) return launch_mfma_s<DIM, NQT, WPB, 1, RT, PF>(args, grid, stream, occupancy);
+    if (args.stage == 0) return launch_mfma_s<DIM, NQT, WPB, 0, 1, true>(args, grid, stream, occupancy);
+    if (args.stage == 1) return launch_mfma_s<DIM, NQT, WPB, 1, RT, PF>(args, grid, stream, occupancy);
     return launch_mfma_s<DIM, NQT, WPB, 2, RT, PF>(args, grid, stream, occupancy);
 }
 
@@ -410,6 +580,19 @@ hipError_t launch_scan_mfma(const MfmaScanArgs& args, int shape, int grid, hipSt
         case 384: return launch_mfma_d<384>(args, shape, grid, stream, occupancy);
         default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_select(const SelectArgs& args, int nq, hipStream_t stream) {
+    if (args.k < 1 || args.k > 64 || !args.delta ||
+        (uint64_t)args.nlists * args.list_len + args.extra_len > (uint64_t)kSelThreads * kSelPer)
+        return hipErrorInvalidValue;
+    if (args.slab) {
+        if (args.k_out < 1 || args.k_out > 64 || (args.dim & 7)) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(select_kernel<true>, dim3(nq), dim3(kSelThreads), 0, stream, args);
+    } else {
+        hipLaunchKernelGGL(select_kernel<false>, dim3(nq), dim3(kSelThreads), 0, stream, args);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_max_row_norm(const void* slab, uint32_t nrows, uint32_t dim, unsigned int* out_bits, hipStream_t stream) {

@@ -747,6 +747,44 @@ hipError_t launch_encode_f16(const float* src, size_t n, unsigned short* dst, hi
     return hipGetLastError();
 }
 
+// Batched-path fallbacks: the queries the matrix-core path could not certify are compacted, answered together by
+// the exact kernels (8 per pass) and written back to their slots.
+__global__ void gather_queries_kernel(const float* __restrict__ src, const uint32_t* __restrict__ idx, uint32_t dim,
+                                      float* __restrict__ dst) {
+    const uint32_t j = blockIdx.x;
+    for (uint32_t i = threadIdx.x; i < dim; i += blockDim.x) dst[(size_t)j * dim + i] = src[(size_t)idx[j] * dim + i];
+}
+
+__global__ void scatter_hits_kernel(const uint32_t* __restrict__ idx, uint32_t k, const uint32_t* __restrict__ src_rows,
+                                    const float* __restrict__ src_scores, const uint32_t* __restrict__ src_counts,
+                                    uint32_t* __restrict__ dst_rows, float* __restrict__ dst_scores,
+                                    uint32_t* __restrict__ dst_counts, u64* __restrict__ dst_packed) {
+    const uint32_t j = blockIdx.x, q = idx[j];
+    const uint32_t n = src_counts[j];
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
+        const uint32_t r = src_rows[(size_t)j * k + i];
+        const float sc = src_scores[(size_t)j * k + i];
+        if (dst_rows) dst_rows[(size_t)q * k + i] = i < n ? r : 0xffffffffu;
+        if (dst_scores) dst_scores[(size_t)q * k + i] = sc;
+        if (dst_packed) dst_packed[(size_t)q * k + i] = i < n ? pack(sc, r) : kEmpty;
+    }
+    if (threadIdx.x == 0 && dst_counts) dst_counts[q] = n;
+}
+
+hipError_t launch_gather_queries(const float* src, const uint32_t* idx, uint32_t n, uint32_t dim, float* dst,
+                                 hipStream_t stream) {
+    hipLaunchKernelGGL(gather_queries_kernel, dim3(n), dim3(128), 0, stream, src, idx, dim, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_hits(const uint32_t* idx, uint32_t n, uint32_t k, const uint32_t* src_rows,
+                               const float* src_scores, const uint32_t* src_counts, uint32_t* dst_rows,
+                               float* dst_scores, uint32_t* dst_counts, u64* dst_packed, hipStream_t stream) {
+    hipLaunchKernelGGL(scatter_hits_kernel, dim3(n), dim3(64), 0, stream, idx, k, src_rows, src_scores, src_counts, dst_rows,
+                       dst_scores, dst_counts, dst_packed);
+    return hipGetLastError();
+}
+
 hipError_t launch_widen_f16(const unsigned short* src, size_t n, float* dst, hipStream_t stream) {
     hipLaunchKernelGGL(widen_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, n, dst);
     return hipGetLastError();

@@ -111,9 +111,10 @@ VectorIndex::~VectorIndex() {
     for (DeviceBuffer* b : {&slab_own_, &live_own_, &ws_partial_, &ws_queries_, &ws_allow_, &ws_rows_, &ws_scores_,
                             &ws_counts_, &ws_keys_a_, &ws_keys_b_, &ws_sort_tmp_, &ws_gather_rows_, &ws_gather_out_,
                             &i8_slab_, &i8_max_, &ws_i8_query_, &ws_cand_packed_, &ws_cand_rows_, &ws_cand_scores_,
-                            &mf_max_norm_, &mf_qh_, &mf_delta_, &mf_tau_, &mf_cand_, &mf_counts_, &mf_dense_, &mf_sel_,
-                            &mf_sel_counts_, &mf_overflow_, &mf_rows_, &mf_exact_, &mf_counters_})
+                            &mf_max_norm_, &mf_qh_, &mf_delta_, &mf_tau_, &mf_cand_, &mf_dense_, &mf_sel_,
+                            &mf_fallback_})
         b->release();
+    if (mf_flags_host_) (void)hipHostFree(mf_flags_host_);
 }
 
 SearchError VectorIndex::common_init(int device) {
@@ -522,6 +523,7 @@ SearchError VectorIndex::fused_search(const float* queries_dev, uint32_t nq, uin
         if (profiling) {
             FSGPU_HIP(hipEventRecord(e1, stream));
             events_.emplace_back(e0, e1);
+            profiled_rows_ += nrows_;
         }
         MergeArgs m;
         m.lists = a.partial;
@@ -655,15 +657,18 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
     if (nq == 0) return ok();
     constexpr uint32_t GMAX = 128;    // queries per pass: 128, or 64 for small batches / tails
     constexpr uint32_t CAPQ = 8192;   // candidate slots per query (= the merge kernel's single-sort capacity)
-    constexpr uint32_t KC = 256;      // approximate candidates re-scored exactly
-    uint32_t RA = 4096;               // stage A rows (dense sample; <= 8192)
-    uint32_t RB = 131072;             // stage B end row
+    constexpr uint32_t KC = kSelectPool;  // approximate candidates re-scored exactly (at most)
+    uint32_t RA = 4096;               // stage A sample rows (dense; <= 8192)
+    uint32_t RB = 131072;             // stage B sample rows (upper bound; shrinks with the slab, see below)
     if (const char* e = std::getenv("FSGPU_RA")) RA = (uint32_t)std::atoi(e);  // tuning experiments only
     if (const char* e = std::getenv("FSGPU_RB")) RB = (uint32_t)std::atoi(e);
     constexpr uint32_t RA_MAX = 8192;
     if (RA < 256 || RA > RA_MAX || (RA & 63)) RA = 4096;
-    if (RB < RA || (RB & 63)) RB = 131072;   // row ranges start on bitmap-word boundaries
-    const bool usable = scan_mfma_supported((int)dim_) && k >= 1 && k <= 64 && nrows_ >= 2 * RA && variant != 4;
+    // B = about 1/64 of the slab, between 8 RA and the cap, a multiple of RA, at most a quarter of the slab
+    RB = std::min<uint32_t>(RB, std::max<uint32_t>(8 * RA, (uint32_t)(nrows_ / 64)));
+    RB = std::min<uint32_t>(RB, (uint32_t)(nrows_ / 4));
+    RB = std::max<uint32_t>(RA, RB / RA * RA);
+    const bool usable = scan_mfma_supported((int)dim_) && k >= 1 && k <= 64 && nrows_ >= 4 * (uint64_t)RA && variant != 4;
     if (!usable) {
         if (fallbacks) *fallbacks = nq;
         if (out_packed_dev) {
@@ -684,45 +689,54 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
     FSGPU_TRY(mf_delta_.reserve(GMAX * 4));
     FSGPU_TRY(mf_tau_.reserve(GMAX * 4));
     FSGPU_TRY(mf_cand_.reserve((size_t)GMAX * CAPQ * 8));
-    FSGPU_TRY(mf_counts_.reserve(GMAX * 4));
     FSGPU_TRY(mf_dense_.reserve((size_t)GMAX * RA_MAX * 8));
     FSGPU_TRY(mf_sel_.reserve((size_t)GMAX * KC * 8));
-    FSGPU_TRY(mf_sel_counts_.reserve(GMAX * 4));
-    FSGPU_TRY(mf_overflow_.reserve(GMAX * 4));
-    FSGPU_TRY(mf_rows_.reserve((size_t)GMAX * KC * 4));
-    FSGPU_TRY(mf_exact_.reserve((size_t)GMAX * KC * 8));
-    int wide_shape = 2;               // 128-query kernel shape (mfma_scan.hip)
-    if (const char* e = std::getenv("FSGPU_MFMA_SHAPE")) wide_shape = std::atoi(e);
-    if (wide_shape < 1 || wide_shape > 3) wide_shape = 2;
-    int per_cu4 = 1, per_cu8 = 1;
-    MfmaScanArgs probe{};
-    probe.dim = dim_;
-    probe.row_begin = 64;  // the main-pass instantiation
-    FSGPU_HIP(launch_scan_mfma(probe, 0, 1, stream, &per_cu4));
-    FSGPU_HIP(launch_scan_mfma(probe, wide_shape, 1, stream, &per_cu8));
+    if (mf_shape_ < 0) {
+        mf_shape_ = 2;                // 128-query kernel shape (mfma_scan.hip)
+        if (const char* e = std::getenv("FSGPU_MFMA_SHAPE")) mf_shape_ = std::atoi(e);  // tuning experiments only
+        if (mf_shape_ < 1 || mf_shape_ > 3) mf_shape_ = 2;
+        MfmaScanArgs probe{};
+        probe.dim = dim_;
+        probe.stage = 2;  // the main-pass instantiation
+        FSGPU_HIP(launch_scan_mfma(probe, 0, 1, stream, &mf_per_cu_narrow_));
+        FSGPU_HIP(launch_scan_mfma(probe, mf_shape_, 1, stream, &mf_per_cu_wide_));
+    }
+    // per-query verdicts, written by the kernels straight into pinned host memory and read after ONE stream
+    // synchronisation for the whole batch: [0, cap) = overflow flags, [cap, 2 cap) = candidate counts
+    const uint32_t flag_cap = (nq + GMAX - 1) / GMAX * GMAX + GMAX;
+    if (flag_cap > mf_flags_cap_) {
+        if (mf_flags_host_) (void)hipHostFree(mf_flags_host_);
+        mf_flags_host_ = nullptr;
+        mf_flags_cap_ = 0;
+        FSGPU_HIP(hipHostMalloc(reinterpret_cast<void**>(&mf_flags_host_), (size_t)flag_cap * 8, hipHostMallocMapped));
+        mf_flags_cap_ = flag_cap;
+    }
+    uint32_t* overflow_all = mf_flags_host_;
+    uint32_t* counts_all = mf_flags_host_ + mf_flags_cap_;
+    std::memset(mf_flags_host_, 0, (size_t)mf_flags_cap_ * 8);
     float* delta = static_cast<float*>(mf_delta_.ptr);
     float* tau = static_cast<float*>(mf_tau_.ptr);
     u64* cand = static_cast<u64*>(mf_cand_.ptr);
-    uint32_t* sel_counts = static_cast<uint32_t*>(mf_sel_counts_.ptr);
-    uint32_t* overflow = static_cast<uint32_t*>(mf_overflow_.ptr);
-    uint32_t total_fallbacks = 0;
+    u64* pool = static_cast<u64*>(mf_sel_.ptr);
+    const uint32_t k_eff = std::min<uint32_t>(k, N);
     for (uint32_t g0 = 0; g0 < nq;) {
         const uint32_t left = nq - g0;
-        const int nqt = (left > 64 && variant != 5) ? wide_shape : 0;   // kernel shape: 128 or 64 queries per pass
-        const uint32_t G = (uint32_t)scan_mfma_query_tiles(nqt) * 16;
+        const int shape = (left > 64 && variant != 5) ? mf_shape_ : 0;   // 128 or 64 queries per pass
+        const uint32_t G = (uint32_t)scan_mfma_query_tiles(shape) * 16;
         const uint32_t ng = std::min(G, left);
-        const int wpb = scan_mfma_waves_per_block(nqt);
-        const int full_grid = num_cus_ * (nqt ? per_cu8 : per_cu4);
+        const int wpb = scan_mfma_waves_per_block(shape);
+        const int full_grid = num_cus_ * (shape ? mf_per_cu_wide_ : mf_per_cu_narrow_);
         auto grid_for = [&](uint32_t rows, uint32_t tile_rows) {
             int g = (int)(((rows + tile_rows - 1) / tile_rows + wpb - 1) / wpb);
             if (g > full_grid) g = full_grid;
             return g < 1 ? 1 : g;
         };
-        const uint32_t tile_rows = (uint32_t)scan_mfma_rows_per_tile(nqt);
+        const uint32_t tile_rows = (uint32_t)scan_mfma_rows_per_tile(shape);
         const float* qg = queries_dev + (size_t)g0 * dim_;
+        uint32_t* overflow = overflow_all + g0;
+        uint32_t* cand_counts = counts_all + g0;
         FSGPU_HIP(launch_prepare_queries(qg, ng, G, dim_, static_cast<const unsigned int*>(mf_max_norm_.ptr), mf_qh_.ptr,
                                          delta, stream));
-        FSGPU_HIP(hipMemsetAsync(overflow, 0, G * 4, stream));
         MfmaScanArgs a{};
         a.slab = slab_dev_;
         a.live = reinterpret_cast<const u64*>(live_dev_);
@@ -733,53 +747,51 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
         a.overflow = overflow;
         a.dim = dim_;
         a.row_base = (uint32_t)row_base_;
-        // stage A: dense approximate scores of rows [0, RA) -> k-th best -> tau (fused into the selection kernel)
+        // samples, in 64-row groups spread evenly over the slab: B = every stride_b-th group, A = a subset of B
+        const uint32_t groups_a = RA / 64, groups_b = RB / 64;
+        const uint32_t stride_b = (N / 64) / groups_b;  // >= 4
+        a.nrows = N;
+        // stage A: dense approximate scores of the A sample -> tau = (k-th best) - 2 delta
         a.dense = static_cast<u64*>(mf_dense_.ptr);
-        a.row_begin = 0;
-        a.row_end = RA;
+        a.stage = 0;
+        a.group_stride = stride_b * (groups_b / groups_a);
+        a.group_count = groups_a;
         a.slots = 0;
-        FSGPU_HIP(launch_scan_mfma(a, nqt, grid_for(RA, 16), stream, nullptr));
-        MergeArgs m{};
-        m.lists = a.dense;
-        m.q_stride = RA;
-        m.l_stride = RA;
-        m.nlists = 1;
-        m.list_len = RA;
-        m.k = k;
-        m.out_stride = k;
-        m.lists_sorted = 0;
-        m.delta = delta;
-        m.tau_out = tau;
-        m.tau_k = k;
-        FSGPU_HIP(launch_merge_topk(m, (int)G, stream));
-        // stage B: rows [0, RB) above tau, one candidate list per (query, block) -> best KC + tighter tau
+        FSGPU_HIP(launch_scan_mfma(a, shape, grid_for(RA, 16), stream, nullptr));
+        SelectArgs sa{};
+        sa.lists = a.dense;
+        sa.q_stride = RA;
+        sa.l_stride = RA;
+        sa.nlists = 1;
+        sa.list_len = RA;
+        sa.k = k;
+        sa.delta = delta;
+        sa.tau_out = tau;
+        FSGPU_HIP(launch_select(sa, (int)G, stream));
+        // stage B: the B sample's rows at or above tau, one short list per (query, block) -> tighter tau; the rows
+        // still at or above it form the pool carried into the last selection
         a.dense = nullptr;
-        a.row_begin = 0;
-        a.row_end = std::min(RB, N);
-        const int grid_b = grid_for(a.row_end, tile_rows);
+        a.stage = 1;
+        a.group_stride = stride_b;
+        a.group_count = groups_b;
+        const int grid_b = grid_for(RB, tile_rows);
         a.slots = std::min<uint32_t>(kMfmaMaxSlots, (CAPQ - KC) / (uint32_t)grid_b);
-        FSGPU_HIP(launch_scan_mfma(a, nqt, grid_b, stream, nullptr));
-        uint32_t* cand_rows = static_cast<uint32_t*>(mf_rows_.ptr);
-        u64* sel_b = static_cast<u64*>(mf_sel_.ptr);
-        MergeArgs mb{};
-        mb.lists = cand;
-        mb.q_stride = (uint64_t)grid_b * a.slots;
-        mb.l_stride = a.slots;
-        mb.nlists = (uint32_t)grid_b;
-        mb.list_len = a.slots;
-        mb.k = KC;
-        mb.out_stride = KC;
-        mb.lists_sorted = 0;
-        mb.delta = delta;
-        mb.overflow = overflow;
-        if (a.row_end < N) {
-            mb.out_packed = sel_b;  // stage B's best KC stay in the pool
-            mb.tau_out = tau;
-            mb.tau_k = k;
-            FSGPU_HIP(launch_merge_topk(mb, (int)G, stream));
-            // stage C: the rest of the slab
-            a.row_begin = a.row_end;
-            a.row_end = N;
+        FSGPU_HIP(launch_scan_mfma(a, shape, grid_b, stream, nullptr));
+        SelectArgs sb{};
+        sb.lists = cand;
+        sb.q_stride = (uint64_t)grid_b * a.slots;
+        sb.l_stride = a.slots;
+        sb.nlists = (uint32_t)grid_b;
+        sb.list_len = a.slots;
+        sb.k = k;
+        sb.delta = delta;
+        sb.overflow = overflow;
+        {
+            sb.tau_out = tau;
+            sb.pool_out = pool;
+            FSGPU_HIP(launch_select(sb, (int)G, stream));
+            // stage C: every group the B sample did not cover
+            a.stage = 2;
             a.slots = std::min<uint32_t>(kMfmaMaxSlots, (CAPQ - KC) / (uint32_t)full_grid);
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (profiling) {
@@ -787,60 +799,65 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
                 FSGPU_HIP(hipEventCreate(&e1));
                 FSGPU_HIP(hipEventRecord(e0, stream));
             }
-            FSGPU_HIP(launch_scan_mfma(a, nqt, full_grid, stream, nullptr));
+            FSGPU_HIP(launch_scan_mfma(a, shape, full_grid, stream, nullptr));
             if (profiling) {
                 FSGPU_HIP(hipEventRecord(e1, stream));
                 events_.emplace_back(e0, e1);
+                profiled_rows_ += N - RB;
             }
-            mb.q_stride = (uint64_t)full_grid * a.slots;
-            mb.l_stride = a.slots;
-            mb.nlists = (uint32_t)full_grid;
-            mb.list_len = a.slots;
-            mb.extra = sel_b;
-            mb.extra_len = KC;
-            mb.out_packed = nullptr;
-            mb.tau_out = nullptr;
+            sb.q_stride = (uint64_t)full_grid * a.slots;
+            sb.l_stride = a.slots;
+            sb.nlists = (uint32_t)full_grid;
+            sb.list_len = a.slots;
+            sb.extra = pool;
+            sb.extra_len = KC;
+            sb.tau_out = nullptr;
+            sb.pool_out = nullptr;
         }
-        // the KC best approximate candidates (+ margin check, + their row ids), exact re-score, final selection
-        mb.margin_k = k;
-        mb.out_rows = cand_rows;
-        mb.out_counts = sel_counts;
-        FSGPU_HIP(launch_merge_topk(mb, (int)G, stream));
-        ScanArgs ga = base_args(qg, nullptr);
-        u64* exact = static_cast<u64*>(mf_exact_.ptr);
-        FSGPU_HIP(launch_gather_dot_batch(ga, cand_rows, KC, ng, exact, stream));
-        MergeArgs mf{};
-        mf.lists = exact;
-        mf.q_stride = KC;
-        mf.l_stride = KC;
-        mf.nlists = 1;
-        mf.list_len = KC;
-        mf.k = std::min<uint32_t>(k, N);
-        mf.out_stride = k;
-        mf.out_rows = out_rows_dev ? out_rows_dev + (size_t)g0 * k : nullptr;
-        mf.out_scores = out_scores_dev ? out_scores_dev + (size_t)g0 * k : nullptr;
-        mf.out_counts = out_counts_dev ? out_counts_dev + g0 : nullptr;
-        mf.out_packed = out_packed_dev ? reinterpret_cast<u64*>(out_packed_dev) + (size_t)g0 * k : nullptr;
-        mf.lists_sorted = 0;
-        FSGPU_HIP(launch_merge_topk(mf, (int)ng, stream));
-        // fallback decision on the host: margin/capacity overflow, or fewer than k finite candidates
-        std::vector<uint32_t> ovf(G), got(G);
-        FSGPU_HIP(hipMemcpyAsync(ovf.data(), overflow, G * 4, hipMemcpyDeviceToHost, stream));
-        FSGPU_HIP(hipMemcpyAsync(got.data(), sel_counts, G * 4, hipMemcpyDeviceToHost, stream));
-        FSGPU_HIP(hipStreamSynchronize(stream));
-        for (uint32_t i = 0; i < ng; ++i) {
-            if (ovf[i] || got[i] < std::min<uint32_t>(k, N)) {
-                ++total_fallbacks;
-                const uint32_t k_eff = std::min<uint32_t>(k, N);
-                const size_t o = (size_t)(g0 + i) * k;
-                FSGPU_TRY(fused_search(qg + (size_t)i * dim_, 1, k, k_eff, allow_dev,
-                                       out_rows_dev ? out_rows_dev + o : nullptr,
-                                       out_scores_dev ? out_scores_dev + o : nullptr,
-                                       out_counts_dev ? out_counts_dev + g0 + i : nullptr,
-                                       out_packed_dev ? reinterpret_cast<u64*>(out_packed_dev) + o : nullptr, stream));
-            }
-        }
+        // finish: every row whose approximate score is within 2 delta of the k-th best (more than KC of them: the
+        // query goes to the exact path) is re-scored in the reference's order; the best k exact entries are the answer
+        sb.cand_counts = cand_counts;
+        sb.slab = slab_dev_;
+        sb.queries = qg;
+        sb.dim = dim_;
+        sb.nrows = N;
+        sb.row_base = (uint32_t)row_base_;
+        sb.hreduce = hreduce;
+        sb.k_out = k_eff;
+        sb.out_stride = k;
+        sb.out_rows = out_rows_dev ? out_rows_dev + (size_t)g0 * k : nullptr;
+        sb.out_scores = out_scores_dev ? out_scores_dev + (size_t)g0 * k : nullptr;
+        sb.out_counts = out_counts_dev ? out_counts_dev + g0 : nullptr;
+        sb.out_packed = out_packed_dev ? reinterpret_cast<u64*>(out_packed_dev) + (size_t)g0 * k : nullptr;
+        FSGPU_HIP(launch_select(sb, (int)ng, stream));
         g0 += ng;
+    }
+    // fallback decision on the host: margin/capacity overflow, or fewer than k candidates
+    FSGPU_HIP(hipStreamSynchronize(stream));
+    std::vector<uint32_t> fb;
+    for (uint32_t i = 0; i < nq; ++i)
+        if (overflow_all[i] || counts_all[i] < k_eff) fb.push_back(i);
+    const uint32_t total_fallbacks = (uint32_t)fb.size();
+    if (total_fallbacks) {
+        // compact the uncertified queries, answer them with the exact kernels (8 per pass), scatter the hits back
+        const size_t nf = fb.size();
+        auto align_up = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
+        const size_t o_idx = 0, o_q = align_up(o_idx + nf * 4, 256), o_rows = align_up(o_q + nf * dim_ * 4, 256),
+                     o_scores = align_up(o_rows + nf * k * 4, 256), o_counts = align_up(o_scores + nf * k * 4, 256),
+                     total = align_up(o_counts + nf * 4, 256);
+        FSGPU_TRY(mf_fallback_.reserve(total));
+        unsigned char* base = static_cast<unsigned char*>(mf_fallback_.ptr);
+        uint32_t* idx_dev = reinterpret_cast<uint32_t*>(base + o_idx);
+        float* q_dev = reinterpret_cast<float*>(base + o_q);
+        uint32_t* rows_dev = reinterpret_cast<uint32_t*>(base + o_rows);
+        float* scores_dev = reinterpret_cast<float*>(base + o_scores);
+        uint32_t* counts_dev = reinterpret_cast<uint32_t*>(base + o_counts);
+        FSGPU_HIP(hipMemcpyAsync(idx_dev, fb.data(), nf * 4, hipMemcpyHostToDevice, stream));
+        FSGPU_HIP(hipStreamSynchronize(stream));  // fb is a stack-owned pageable buffer
+        FSGPU_HIP(launch_gather_queries(queries_dev, idx_dev, (uint32_t)nf, dim_, q_dev, stream));
+        FSGPU_TRY(fused_search(q_dev, (uint32_t)nf, k, k_eff, allow_dev, rows_dev, scores_dev, counts_dev, nullptr, stream));
+        FSGPU_HIP(launch_scatter_hits(idx_dev, (uint32_t)nf, k, rows_dev, scores_dev, counts_dev, out_rows_dev,
+                                      out_scores_dev, out_counts_dev, reinterpret_cast<u64*>(out_packed_dev), stream));
     }
     if (fallbacks) *fallbacks = total_fallbacks;
     return ok();
@@ -961,6 +978,7 @@ SearchError VectorIndex::search_top_k_int8_two_pass(const float* query, uint32_t
         if (profiling) {
             FSGPU_HIP(hipEventRecord(e1, stream_));
             events_.emplace_back(e0, e1);
+            profiled_rows_ += nrows_;
         }
         MergeArgs m;
         m.lists = a.partial;
@@ -1036,7 +1054,7 @@ SearchError VectorIndex::search_top_k_int8_two_pass(const float* query, uint32_t
     return ok();
 }
 
-SearchError VectorIndex::scan_time(double* total_ms, uint64_t* launches, bool reset) {
+SearchError VectorIndex::scan_time(double* total_ms, uint64_t* launches, uint64_t* rows, bool reset) {
     FSGPU_HIP(hipSetDevice(device_));
     double sum = 0.0;
     for (auto& ev : events_) {
@@ -1047,7 +1065,9 @@ SearchError VectorIndex::scan_time(double* total_ms, uint64_t* launches, bool re
     }
     *total_ms = sum;
     *launches = events_.size();
+    if (rows) *rows = profiled_rows_;
     if (reset) {
+        profiled_rows_ = 0;
         for (auto& ev : events_) {
             (void)hipEventDestroy(ev.first);
             (void)hipEventDestroy(ev.second);

@@ -91,7 +91,7 @@ class VectorIndex {
     int32_t hreduce = 0;
     int32_t variant = 0;
     bool profiling = false;
-    SearchError scan_time(double* total_ms, uint64_t* launches, bool reset);
+    SearchError scan_time(double* total_ms, uint64_t* launches, uint64_t* rows, bool reset);
 
   private:
     SearchError ensure_query_dimension(uint32_t query_len) const;
@@ -118,12 +118,16 @@ class VectorIndex {
     // workspaces (grown on demand, reused)
     DeviceBuffer ws_partial_, ws_queries_, ws_allow_, ws_rows_, ws_scores_, ws_counts_, ws_keys_a_, ws_keys_b_,
         ws_sort_tmp_, ws_gather_rows_, ws_gather_out_, i8_slab_, i8_max_, ws_i8_query_, ws_cand_packed_,
-        ws_cand_rows_, ws_cand_scores_, mf_max_norm_, mf_qh_, mf_delta_, mf_tau_, mf_cand_, mf_counts_, mf_dense_,
-        mf_sel_, mf_sel_counts_, mf_overflow_, mf_rows_, mf_exact_, mf_counters_;
+        ws_cand_rows_, ws_cand_scores_, mf_max_norm_, mf_qh_, mf_delta_, mf_tau_, mf_cand_, mf_dense_, mf_sel_,
+        mf_fallback_;
     bool i8_ready_ = false;
     bool mf_norm_ready_ = false;
+    int mf_shape_ = -1, mf_per_cu_narrow_ = 1, mf_per_cu_wide_ = 1;  // batched-scan launch shapes (probed once)
+    uint32_t* mf_flags_host_ = nullptr;                              // pinned per-query verdicts of the batched scan
+    uint32_t mf_flags_cap_ = 0;
     // profiling events
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events_;
+    uint64_t profiled_rows_ = 0;  // slab rows streamed by the timed launches
     // FSVI host-side tables
     std::vector<uint64_t> live_host_;
     std::vector<uint64_t> doc_hashes_;

@@ -225,6 +225,12 @@ class VectorIndex:
         check(_lib.lib().fsgpu_index_scan_time(self._h, C.byref(ms), C.byref(n), int(reset)))
         return ms.value, n.value
 
+    def scan_stats(self, reset: bool = True) -> Tuple[float, int, int]:
+        """(total ms, launches, slab rows streamed) of the timed scan launches since the last reset."""
+        ms, n, rows = C.c_double(), C.c_uint64(), C.c_uint64()
+        check(_lib.lib().fsgpu_index_scan_stats(self._h, C.byref(ms), C.byref(n), C.byref(rows), int(reset)))
+        return ms.value, n.value, rows.value
+
     def set_variant(self, variant: int) -> None:
         check(_lib.lib().fsgpu_index_set_variant(self._h, variant))
 

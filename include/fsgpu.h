@@ -249,6 +249,10 @@ fsgpu_status fsgpu_blend_two_tier(const fsgpu_scored_doc *fast, uint32_t n_fast,
 fsgpu_status fsgpu_index_set_profiling(fsgpu_index *idx, int32_t enabled);
 /* Sum of scan-kernel time (ms) and number of scan launches since the last reset; synchronises. */
 fsgpu_status fsgpu_index_scan_time(fsgpu_index *idx, double *total_ms, uint64_t *launches, int32_t reset);
+/* Same, plus the number of slab rows those launches streamed (the batched path's timed main pass skips the rows its
+ * sampling stage already covered), so that bytes/launch can be stated exactly. */
+fsgpu_status fsgpu_index_scan_stats(fsgpu_index *idx, double *total_ms, uint64_t *launches, uint64_t *rows,
+                                    int32_t reset);
 /* Selects the scan kernel variant (0 = default) — used by bench A/B runs only. */
 fsgpu_status fsgpu_index_set_variant(fsgpu_index *idx, int32_t variant);
 

@@ -426,3 +426,35 @@ def test_batched_mfma_search_is_bit_exact(fa, oracle):
     br, bs, bc, fb = idx.search_batched(q, 10)
     er, es, ec = idx.search_batch(q, 10)
     assert fb == 3 and np.array_equal(br, er) and np.array_equal(bits(bs), bits(es))
+
+
+@pytest.mark.gpu
+def test_batched_mfma_wide_groups_topical_rows_and_filters(fa, oracle):
+    # 200 queries = one 128-query pass + one 64-query pass + a ragged tail; rows arrive in topical runs (sorted by
+    # cluster), so a threshold sampled from the head of the slab would be useless — the strided samples must cope;
+    # duplicates force score ties (lower row wins); an allow mask and k up to 64 ride along.
+    rng = np.random.default_rng(97)
+    n, dim = 300_037, 384
+    cent = rng.standard_normal((48, dim)).astype(np.float32)
+    cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+    cid = np.sort(rng.integers(0, 48, n))
+    rows = cent[cid] + 0.25 * rng.standard_normal((n, dim)).astype(np.float32) / np.sqrt(dim)
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    rows[1000:1040] = rows[999]            # 41 identical rows
+    rows[n - 5:] = rows[17]                # duplicates of an early row at the very end (partial last group)
+    slab = rows.astype(np.float16).view(np.uint16)
+    idx = fa.VectorIndex.from_slab(slab)
+    nq = 200
+    q = cent[rng.integers(0, 48, nq)] + 0.25 * rng.standard_normal((nq, dim)).astype(np.float32) / np.sqrt(dim)
+    q[3] = rows[999]                       # hits the run of identical rows
+    q[4] = rows[17]
+    allow = rng.random(n) > 0.5
+    for k, mask in ((10, None), (64, None), (10, allow), (7, allow)):
+        br, bs, bc, fb = idx.search_batched(q, k, allow=mask)
+        er, es, ec = idx.search_batch(q, k, mask)
+        assert np.array_equal(bc, ec) and np.array_equal(br, er) and np.array_equal(bits(bs), bits(es)), (k, mask is None)
+        assert fb < nq // 4, fb
+    br, bs, bc, _ = idx.search_batched(q, 10)
+    for qi in (3, 4, 130, 199):
+        orow, osc = oracle.search_top_k(slab, q[qi], 10)
+        assert np.array_equal(br[qi], orow) and np.array_equal(bits(bs[qi]), bits(osc))
