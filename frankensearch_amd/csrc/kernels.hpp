@@ -35,18 +35,6 @@ struct MergeArgs {
     uint32_t* out_counts;   // [nq]
     u64* out_packed;        // optional [nq, out_stride] packed copy of the result (kEmpty padded)
     uint32_t lists_sorted = 1;  // 0: the lists are NOT best-first (disables the head/tail pruning bounds)
-    const uint32_t* list_counts = nullptr;  // optional [nq]: valid entries of each query's (single) list
-    // ---- optional fused steps of the batched (matrix-core) pipeline, see mfma_scan.hip ----
-    const uint32_t* padded_counters = nullptr;  // append counters one cache line apart: count = min(counter, cap)
-    uint32_t counter_stride = 0, counter_cap = 0;
-    uint32_t* counts_out = nullptr;             // [nq] clamped counts written back (for later merges)
-    uint32_t* overflow = nullptr;               // [nq] set to 1 on capacity / margin overflow or skipped query
-    const float* delta = nullptr;               // [nq] per-query error bound (< 0: query skipped)
-    float* tau_out = nullptr;                   // [nq] tau = score(k-th) - 2 delta  (tau_k-th entry; -inf if fewer)
-    uint32_t tau_k = 0;
-    uint32_t margin_k = 0;                      // != 0: flag overflow unless the selection provably holds the top margin_k
-    const u64* extra = nullptr;                 // optional [nq, extra_len] additional (unsorted) entries per query
-    uint32_t extra_len = 0;
 };
 
 size_t scan_lds_bytes(int dim, int nq, int kcap);
@@ -137,12 +125,6 @@ hipError_t launch_scan_mfma(const MfmaScanArgs& args, int shape, int grid, hipSt
 hipError_t launch_max_row_norm(const void* slab, uint32_t nrows, uint32_t dim, unsigned int* out_bits, hipStream_t stream);
 hipError_t launch_prepare_queries(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim,
                                   const unsigned int* max_norm_bits, void* qh, float* delta, hipStream_t stream);
-hipError_t launch_tau_from_selection(const u64* sel, const uint32_t* sel_counts, uint32_t stride, uint32_t k,
-                                     const float* delta, float* tau, uint32_t nq_pad, hipStream_t stream);
-hipError_t launch_margin_check(const u64* sel, const uint32_t* sel_counts, uint32_t kc, uint32_t k, const float* delta,
-                               uint32_t* overflow, uint32_t nq_pad, hipStream_t stream);
-hipError_t launch_gather_dot_batch(const ScanArgs& args, const uint32_t* rows, uint32_t per, uint32_t nq,
-                                   u64* out_packed, hipStream_t stream);
 
 // int8_kernels.hip
 hipError_t launch_quantize_slab_i8(const void* slab_f16, size_t n_values, unsigned int* max_bits_dev, void* out_i8,

@@ -1,8 +1,8 @@
-// mfma_scan.hip — batched f16 cosine scan on the matrix cores: 64 queries per pass over the slab, with results
-// that are still BIT-IDENTICAL to the reference CPU path.
+// mfma_scan.hip — batched f16 cosine scan on the matrix cores: 64 or 128 queries per pass over the slab, with
+// results that are still BIT-IDENTICAL to the reference CPU path.
 //
 // The exact VALU kernels (scan_kernels.hip, scan_mq_kernel.hip) reproduce the reference's f32 operation order and
-// top out at 4-8 queries per HBM pass.  Here the contraction slab[rows,dim] x queries[dim,64] runs on
+// top out at 4-8 queries per HBM pass.  Here the contraction slab[rows,dim] x queries[dim,NQ] runs on
 // v_mfma_f32_16x16x32_f16 with the queries rounded to f16, which gives only APPROXIMATE scores a(r,q).  Exactness
 // is recovered by a provable filter + exact re-score (the same pass-1 / pass-2 shape the reference ships for int8,
 // crates/frankensearch-index/src/search.rs:589-661):
@@ -13,19 +13,23 @@
 //   so every true top-k row has a >= a_k - 2 delta_q, where a_k is the k-th largest approximate score of ANY
 //   subset of rows (a subset's k-th best is a lower bound of the corpus' k-th best).
 //
-// Pipeline per group of <= 64 queries (host side in vector_index.cpp):
-//   stage A: dense approximate scores of the first rows  -> k-th best -> tau_q = a_k - 2 delta_q
-//   stage B: next row range, rows with a >= tau_q appended to per-query candidate lists -> tighter tau_q
-//   stage C: the rest of the slab with the final tau_q (a few hundred survivors per query out of 10M rows)
-//   select the KC best approximate candidates, verify the margin (a_KC < a_k - 2 delta_q, else the query is re-run on
-//   the exact kernel), re-score those rows with the exact-order dot (gather kernel) and select k under the
-//   reference order.  The final rows AND score bits therefore equal the exact path's.
+// Pipeline per group of 64 / 128 queries (host side: VectorIndex::search_top_k_batched_device):
+//   stage A  dense approximate scores of a 4096-row sample        -> select: tau_q = a_k - 2 delta_q
+//   stage B  a ~N/64-row sample (superset of A), rows with a >= tau_q kept -> select: tighter tau_q + candidate pool
+//   stage C  every row B did not visit, with the final tau_q (a few hundred survivors per query out of 10M rows)
+//   finish   a_k over pool + survivors; the rows with a >= a_k - 2 delta_q (at most kSelectPool, else the query is
+//            handed to the exact kernels) are re-scored with the exact-order dot inside the block and the best k
+//            exact entries are emitted: rows AND score bits equal the exact path's.
+//   The samples are 64-row groups spread evenly over the slab, so tau is representative even when neighbouring
+//   rows are correlated.  Candidates are staged in LDS and written as one short list per (query, block): appending
+//   through global atomics serialises on the counter's cache line (~0.18 us per append, measured).
 //
-// Kernel mapping: a wave owns 16-row tiles (12 KB at dim 384, double-buffered in registers); the A fragment of the
-// MFMA is K-contiguous, i.e. a lane's 16 bytes of its slab row — loaded straight from HBM; the 64 f16 queries sit
-// in LDS ([64][dim+8] halves: the 16-byte pad staggers rows across banks) and are read as B fragments with one
-// ds_read_b128 per (k-step, query tile).  Algorithmic bytes per pass are still N*dim*2: at 64 queries the kernel is
-// HBM-bound (MFMA ~16 % busy), the ridge sits near 200 queries.
+// Kernel mapping: a wave owns 16- or 32-row tiles (12/24 KB at dim 384); loads use the coalesced quad layout of the
+// exact kernels and are transposed into the MFMA's A-fragment layout with ds_bpermute; the f16 queries sit in LDS
+// ([NQ][dim+8] halves: the 16-byte pad staggers rows across banks) and are read as B fragments with one
+// ds_read_b128 per (k-step, query tile), each feeding one MFMA per 16-row sub-tile.  Algorithmic bytes per pass are
+// still N*dim*2.  At 64 queries the kernel is HBM-bound; at 128 queries the B-fragment reads (96 KB of LDS traffic
+// per 16 rows) bound the 16-row tiling, the 32-row tiling halves them and is HBM-bound again.
 #include "scan_common.hpp"
 
 namespace fsgpu {
@@ -448,81 +452,6 @@ __global__ __launch_bounds__(256) void prepare_queries_kernel(const float* __res
     }
 }
 
-// tau_q from a best-first approximate selection: the k-th best approximate score minus 2 delta_q (-inf when fewer
-// than k rows were seen).  `sel` is [nq_pad, stride] packed, counts the number of valid entries per query.
-__global__ void tau_from_selection_kernel(const u64* __restrict__ sel, const uint32_t* __restrict__ sel_counts,
-                                          uint32_t stride, uint32_t k, const float* __restrict__ delta,
-                                          float* __restrict__ tau, uint32_t nq_pad) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq_pad) return;
-    float t = -INFINITY;
-    if (delta[q] < 0.f) {  // skipped query: no candidates at all (answered by the exact path or padding)
-        tau[q] = INFINITY;
-        return;
-    }
-    if (sel_counts[q] >= k) {
-        const float ak = __uint_as_float((uint32_t)(sel[(size_t)q * stride + (k - 1)] >> 32));
-        t = ak - 2.0f * delta[q];
-        if (!(t == t)) t = -INFINITY;
-    }
-    tau[q] = t;
-}
-
-// Margin check on the KC best approximate candidates: the set is complete iff it holds fewer than KC entries or its
-// last entry is already below a_k - 2 delta (then every row outside the set is below the threshold too).
-__global__ void margin_check_kernel(const u64* __restrict__ sel, const uint32_t* __restrict__ sel_counts, uint32_t kc,
-                                    uint32_t k, const float* __restrict__ delta, uint32_t total_candidates_cap,
-                                    const uint32_t* __restrict__ cand_counts, uint32_t* __restrict__ overflow,
-                                    uint32_t nq_pad) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq_pad) return;
-    if (delta[q] < 0.f) {
-        overflow[q] = 1;
-        return;
-    }
-    const uint32_t n = sel_counts[q];
-    if (n < kc || n < k) return;  // every candidate is in the set (fewer than k: the exact path decides)
-    (void)total_candidates_cap;
-    (void)cand_counts;
-    const float ak = __uint_as_float((uint32_t)(sel[(size_t)q * kc + (k - 1)] >> 32));
-    const float alast = __uint_as_float((uint32_t)(sel[(size_t)q * kc + (kc - 1)] >> 32));
-    if (!(alast < ak - 2.0f * delta[q])) overflow[q] = 1;
-}
-
-// Exact-order dot of (query b, row) pairs: rows [nq, per] (0xffffffff = none) -> packed exact entries.
-__global__ __launch_bounds__(256) void gather_dot_batch_kernel(ScanArgs args, const uint32_t* __restrict__ rows,
-                                                               uint32_t per, uint32_t nq, u64* __restrict__ out_packed) {
-    const int dim = (int)args.dim;
-    const int tid = threadIdx.x, lane = tid & 63, a = lane & 3;
-    const uint32_t item = (blockIdx.x * 256 + tid) >> 2;
-    const uint32_t total = per * nq;
-    const bool in_range = item < total;
-    const uint32_t b = in_range ? item / per : 0;
-    const uint32_t grow = in_range ? rows[item] : 0xffffffffu;
-    uint32_t row = grow - args.row_base;
-    const bool mine = in_range && grow != 0xffffffffu && row < args.nrows;
-    if (!mine) row = 0;
-    const float* q = args.queries + (size_t)b * dim;
-    const u32x4* p = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(args.slab) + (size_t)row * dim * 2);
-    const int chunks = dim >> 3, groups = chunks >> 2, leftover = chunks & 3;
-    float acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int g = 0; g < groups; ++g) {
-        const u32x4 w = p[4 * g + a];
-        const float4* qp = reinterpret_cast<const float4*>(q + 32 * g + 8 * a);
-        chunk_mac(acc, w, qp[0], qp[1]);
-    }
-    if (a == 0)
-        for (int c = 4 * groups; c < 4 * groups + leftover; ++c) {
-            const u32x4 w = p[c];
-            const float4* qp = reinterpret_cast<const float4*>(q + 8 * c);
-            chunk_mac(acc, w, qp[0], qp[1]);
-        }
-    const float s = quad_finish(acc, args.hreduce);
-    if (in_range && a == 0) out_packed[item] = mine ? pack(s, grow) : kEmpty;
-}
-
 // ---- launchers ----------------------------------------------------------------------------------------------
 
 bool scan_mfma_supported(int dim) { return dim == 128 || dim == 256 || dim == 384; }
@@ -607,28 +536,6 @@ hipError_t launch_prepare_queries(const float* q, uint32_t nq, uint32_t nq_pad, 
                                   const unsigned int* max_norm_bits, void* qh, float* delta, hipStream_t stream) {
     hipLaunchKernelGGL(prepare_queries_kernel, dim3(nq_pad), dim3(256), 0, stream, q, nq, nq_pad, dim, max_norm_bits,
                        static_cast<_Float16*>(qh), delta);
-    return hipGetLastError();
-}
-
-hipError_t launch_tau_from_selection(const u64* sel, const uint32_t* sel_counts, uint32_t stride, uint32_t k,
-                                     const float* delta, float* tau, uint32_t nq_pad, hipStream_t stream) {
-    hipLaunchKernelGGL(tau_from_selection_kernel, dim3((nq_pad + 63) / 64), dim3(64), 0, stream, sel, sel_counts, stride, k,
-                       delta, tau, nq_pad);
-    return hipGetLastError();
-}
-
-hipError_t launch_margin_check(const u64* sel, const uint32_t* sel_counts, uint32_t kc, uint32_t k, const float* delta,
-                               uint32_t* overflow, uint32_t nq_pad, hipStream_t stream) {
-    hipLaunchKernelGGL(margin_check_kernel, dim3((nq_pad + 63) / 64), dim3(64), 0, stream, sel, sel_counts, kc, k, delta,
-                       0u, nullptr, overflow, nq_pad);
-    return hipGetLastError();
-}
-
-hipError_t launch_gather_dot_batch(const ScanArgs& args, const uint32_t* rows, uint32_t per, uint32_t nq,
-                                   u64* out_packed, hipStream_t stream) {
-    const size_t lanes = (size_t)per * nq * 4;
-    hipLaunchKernelGGL(gather_dot_batch_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream, args, rows, per,
-                       nq, out_packed);
     return hipGetLastError();
 }
 

@@ -340,25 +340,12 @@ __global__ __launch_bounds__(NT) void merge_topk_kernel(MergeArgs args) {
     const u64* in = args.lists + (size_t)q * args.q_stride;
     const uint32_t list_len = args.list_len;
     const uint32_t nlists = args.nlists;
-    const size_t total = (size_t)nlists * list_len + args.extra_len;   // extra entries are appended after the lists
+    const size_t total = (size_t)nlists * list_len;
     const uint32_t total32 = (uint32_t)total;
-    const uint32_t lists32 = nlists * list_len;
     const int k = (int)args.k;
     if (tid == 0) {
         s_count = 0;
         s_thr = 0;
-    }
-    // valid prefix of the (single) list: explicit counts, or the padded append counters clamped to the capacity
-    uint32_t valid_len = list_len;
-    if (args.list_counts) valid_len = args.list_counts[q];
-    if (args.padded_counters) {
-        uint32_t c = args.padded_counters[(size_t)q * args.counter_stride];
-        if (c > args.counter_cap) {
-            c = args.counter_cap;
-            if (tid == 0 && args.overflow) args.overflow[q] = 1;
-        }
-        valid_len = c;
-        if (tid == 0 && args.counts_out) args.counts_out[q] = c;
     }
     int cnt;
     if (total <= (size_t)MCAP) {
@@ -374,12 +361,7 @@ __global__ __launch_bounds__(NT) void merge_topk_kernel(MergeArgs args) {
             e[x] = kEmpty;
             lst[x] = i / list_len;
             pos[x] = i - lst[x] * list_len;
-            if (i < lists32) {
-                if (pos[x] < valid_len) e[x] = in[(size_t)lst[x] * args.l_stride + pos[x]];
-            } else if (i < total32) {
-                e[x] = args.extra[(size_t)q * args.extra_len + (i - lists32)];
-                pos[x] = 0xffffffffu;  // neither a head nor a tail
-            }
+            if (i < total32) e[x] = in[(size_t)lst[x] * args.l_stride + pos[x]];
         }
         __syncthreads();
         u64 best_tail = 0;
@@ -388,7 +370,7 @@ __global__ __launch_bounds__(NT) void merge_topk_kernel(MergeArgs args) {
             const bool real = e[x] != kEmpty;
             const u64 key = real ? sortkey(e[x]) : 0ull;
             if (sorted_lists && real && pos[x] == (uint32_t)(k - 1)) best_tail = key > best_tail ? key : best_tail;
-            if (use_heads && pos[x] == 0 && tid + x * NT < lists32) hkeys[lst[x]] = key;
+            if (use_heads && pos[x] == 0 && tid + x * NT < total32) hkeys[lst[x]] = key;
         }
         // wave max of best_tail, then one LDS atomic per wave
 #pragma unroll
@@ -442,11 +424,9 @@ __global__ __launch_bounds__(NT) void merge_topk_kernel(MergeArgs args) {
         for (uint32_t base = 0; base < total32; base += NT) {
             const uint32_t i = base + tid;
             u64 c = kEmpty;
-            if (i < lists32) {
+            if (i < total32) {
                 const uint32_t l = i / list_len;
                 c = in[(size_t)l * args.l_stride + (i - l * list_len)];
-            } else if (i < total32) {
-                c = args.extra[(size_t)q * args.extra_len + (i - lists32)];
             }
             const bool ok = c != kEmpty && sortkey(c) > s_thr;
             if (ok) {
@@ -486,28 +466,6 @@ __global__ __launch_bounds__(NT) void merge_topk_kernel(MergeArgs args) {
         if (args.out_packed) args.out_packed[(size_t)q * args.out_stride + j] = c;
     }
     if (tid == 0 && args.out_counts) args.out_counts[q] = (uint32_t)n;
-    if (tid == 0 && args.delta) {
-        const float d = args.delta[q];
-        if (args.tau_out) {  // candidate threshold for the next stage (mfma_scan.hip header)
-            float t = -INFINITY;
-            if (d < 0.f) t = INFINITY;
-            else if ((uint32_t)cnt >= args.tau_k && args.tau_k >= 1) {
-                t = __uint_as_float((uint32_t)(buf[args.tau_k - 1] >> 32)) - 2.0f * d;
-                if (!(t == t)) t = -INFINITY;
-            }
-            args.tau_out[q] = t;
-        }
-        if (args.margin_k && args.overflow) {
-            // the selection is complete iff it holds fewer than k entries (all candidates are in) or its last entry
-            // is already below a_margin_k - 2 delta
-            if (d < 0.f) args.overflow[q] = 1;
-            else if ((uint32_t)n >= (uint32_t)k && (uint32_t)n >= args.margin_k) {
-                const float ak = __uint_as_float((uint32_t)(buf[args.margin_k - 1] >> 32));
-                const float alast = __uint_as_float((uint32_t)(buf[k - 1] >> 32));
-                if (!(alast < ak - 2.0f * d)) args.overflow[q] = 1;
-            }
-        }
-    }
 }
 
 // packed -> sortkey (in place), for the general path's radix sort; and the inverse for rows.

@@ -347,16 +347,12 @@ typedef struct {
     dot_fn dot;
     heap_t *heaps;       /* one per chunk (top-k mode) */
     entry_t *collect;    /* collect-all mode: slot per row, row==UINT64_MAX when dead */
-    size_t next;         /* work counter */
-    pthread_mutex_t mu;
+    size_t next;         /* work counter (atomic) */
 } scan_job_t;
 
-static void *scan_worker(void *arg) {
-    scan_job_t *job = (scan_job_t *)arg;
+static void scan_worker_body(scan_job_t *job) {
     for (;;) {
-        pthread_mutex_lock(&job->mu);
-        size_t c = job->next++;
-        pthread_mutex_unlock(&job->mu);
+        size_t c = __atomic_fetch_add(&job->next, 1, __ATOMIC_RELAXED);
         if (c >= job->chunk_count) break;
         uint64_t start = (uint64_t)c * job->chunk_size;
         uint64_t end = start + job->chunk_size;
@@ -378,23 +374,67 @@ static void *scan_worker(void *arg) {
                              job->hreduce, job->dot, &job->heaps[c]);
         }
     }
+}
+
+/* Persistent worker pool (the reference scans chunks on rayon's persistent pool, search.rs:1013-1036): workers are
+ * created once and parked on a condition variable, so a query does not pay thread creation.  Jobs are serialised. */
+#define FSO_MAX_WORKERS 512
+static struct {
+    pthread_mutex_t mu;
+    pthread_cond_t start, done;
+    pthread_t th[FSO_MAX_WORKERS];
+    int nworkers;          /* threads created so far */
+    unsigned long gen;     /* job generation */
+    int want;              /* workers that take part in the current job */
+    int remaining;         /* participants still running */
+    scan_job_t *job;
+} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, 0, 0, 0, NULL};
+static pthread_mutex_t g_job_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static void *pool_worker(void *arg) {
+    const int me = (int)(intptr_t)arg;
+    unsigned long seen = 0;
+    pthread_mutex_lock(&g_pool.mu);
+    for (;;) {
+        while (g_pool.gen == seen) pthread_cond_wait(&g_pool.start, &g_pool.mu);
+        seen = g_pool.gen;
+        if (me >= g_pool.want) continue;
+        scan_job_t *job = g_pool.job;
+        pthread_mutex_unlock(&g_pool.mu);
+        scan_worker_body(job);
+        pthread_mutex_lock(&g_pool.mu);
+        if (--g_pool.remaining == 0) pthread_cond_signal(&g_pool.done);
+    }
     return NULL;
 }
 
 static void run_job(scan_job_t *job, int nthreads) {
     if (nthreads < 1) nthreads = 1;
     if ((size_t)nthreads > job->chunk_count) nthreads = (int)(job->chunk_count ? job->chunk_count : 1);
-    pthread_mutex_init(&job->mu, NULL);
+    if (nthreads > FSO_MAX_WORKERS + 1) nthreads = FSO_MAX_WORKERS + 1;
     job->next = 0;
     if (nthreads == 1) {
-        scan_worker(job);
-    } else {
-        pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
-        for (int i = 0; i < nthreads; ++i) pthread_create(&th[i], NULL, scan_worker, job);
-        for (int i = 0; i < nthreads; ++i) pthread_join(th[i], NULL);
-        free(th);
+        scan_worker_body(job);
+        return;
     }
-    pthread_mutex_destroy(&job->mu);
+    pthread_mutex_lock(&g_job_mu);
+    pthread_mutex_lock(&g_pool.mu);
+    while (g_pool.nworkers < nthreads - 1) {
+        if (pthread_create(&g_pool.th[g_pool.nworkers], NULL, pool_worker, (void *)(intptr_t)g_pool.nworkers) != 0) break;
+        pthread_detach(g_pool.th[g_pool.nworkers]);
+        g_pool.nworkers++;
+    }
+    g_pool.job = job;
+    g_pool.want = nthreads - 1 < g_pool.nworkers ? nthreads - 1 : g_pool.nworkers;
+    g_pool.remaining = g_pool.want;
+    g_pool.gen++;
+    pthread_cond_broadcast(&g_pool.start);
+    pthread_mutex_unlock(&g_pool.mu);
+    scan_worker_body(job);  /* the caller is a worker too */
+    pthread_mutex_lock(&g_pool.mu);
+    while (g_pool.remaining > 0) pthread_cond_wait(&g_pool.done, &g_pool.mu);
+    pthread_mutex_unlock(&g_pool.mu);
+    pthread_mutex_unlock(&g_job_mu);
 }
 
 /* search_top_k_internal (search.rs:426-494) for a main index with no WAL and no filter,
