@@ -84,15 +84,7 @@ def cpu_baseline_and_parity(slab_dev: torch.Tensor, queries: torch.Tensor, k: in
 
     oracle.build()
     sample = int(min(slab_dev.shape[0], 2_500_000))
-    staged = slab_dev[:sample].contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
-    # re-home the sample with a parallel first touch so its pages spread over the host's NUMA nodes (the D2H copy
-    # leaves them on one node, which caps the CPU scan at that node's memory bandwidth)
-    from concurrent.futures import ThreadPoolExecutor
-    host = np.empty_like(staged)
-    step = 8192
-    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 1, 64)) as ex:
-        list(ex.map(lambda lo: host.__setitem__(slice(lo, lo + step), staged[lo:lo + step]), range(0, sample, step)))
-    del staged
+    host = slab_dev[:sample].contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
     cores = os.cpu_count() or 1
     nq = 32
     q_host = queries[:nq].cpu().numpy()
@@ -152,9 +144,9 @@ def cpu_baseline_and_parity(slab_dev: torch.Tensor, queries: torch.Tensor, k: in
 def two_tier_section(quality_index, rows: int, k: int, device, local_rank: int):
     """BASELINE config 3 shape on one GPU: potion fast tier (10M x 256) + MiniLM quality tier (10M x 384), RRF
     with a deterministic stub lexical list (BM25 stays on the CPU in the reference and is not built here).
-    Sequential single-query latency of the Initial (phase 0) and Refined (phase 1) deliveries."""
+    Latency of the Initial (phase 0) and Refined (phase 1) deliveries for one caller at a time, and end-to-end
+    queries/sec with many concurrent callers."""
     import frankensearch_amd as fa
-    from frankensearch_amd.two_tier import SyncTwoTierSearcher
     from frankensearch_amd.synthetic import random_bert_weights  # seeded synthetic weights (none exist offline)
 
     fast_dim = 256
@@ -165,29 +157,40 @@ def two_tier_section(quality_index, rows: int, k: int, device, local_rank: int):
     table = rng.standard_normal((500_353, fast_dim)).astype(np.float32)   # potion-multilingual-128M shape
     m2v = fa.Model2VecEmbedder(table, device=local_rank)
     bert = fa.NativeEmbedder(random_bert_weights(1, 30522, 384, 6, 1536), device=local_rank)
-    searcher = SyncTwoTierSearcher(fast_index, quality_index, m2v, bert, lambda r: f"doc-{r:08d}")
-    p0, p1 = [], []
-    for i in range(48):
-        fast_ids = rng.integers(0, 500_353, int(rng.integers(4, 24))).tolist()
-        qual_ids = [101] + rng.integers(1000, 30000, int(rng.integers(6, 31))).tolist() + [102]
-        lexical = [(f"doc-{int(r):08d}", float(30 - j)) for j, r in enumerate(rng.choice(rows, 3 * k, replace=False))]
-        out = searcher.search(fast_ids, qual_ids, k, lexical)
-        if i >= 8:
-            p0.append(out.metrics.phase1_total_ms)
-            p1.append(out.metrics.phase1_total_ms + out.metrics.phase2_total_ms)
-    p0.sort()
-    p1.sort()
-    m = out.metrics
+    # the host side is native: libfshost.so = the reference's SyncTwoTierSearcher flow in C++ over the C ABI, driven by
+    # native threads the way a multi-threaded Rust host would drive it (include/fshost.h)
+    from frankensearch_amd.host import NativeTwoTierSearcher
+    searcher = NativeTwoTierSearcher(fast_index, quality_index, m2v, bert, doc_id_mode=1)
+    seq = searcher.run_load(threads=1, queries=200, warmup_queries=16, k=k, fast_vocab=500_353, corpus_rows=rows)
+    # concurrent callers, coalesced inside the library into batched launches (fsgpu_*_set_coalescing)
+    threads, max_batch, wait_us = 512, 128, 1000
+    fast_index.set_coalescing(max_batch, wait_us)
+    quality_index.set_coalescing(max_batch, wait_us)
+    m2v.set_coalescing(2 * max_batch, wait_us // 2)
+    bert.set_coalescing(2 * max_batch, wait_us)
+    con = searcher.run_load(threads=threads, queries=60_000, warmup_queries=2 * threads, k=k, fast_vocab=500_353,
+                            corpus_rows=rows)
+    fb, fr = fast_index.coalescing_stats()
+    qb, qr = quality_index.coalescing_stats()
+    quality_index.set_coalescing(0, 0)
     res = {
-        "workload": f"{rows}x256 fast tier + {rows}x384 quality tier, top-{k}, fetch {3 * k}, stub lexical list, "
-                    "sequential single queries through the host-pointer ABI",
-        "phase0_p50_ms": p0[len(p0) // 2],
-        "phase1_p50_ms": p1[len(p1) // 2],
-        "sequential_queries_per_sec": 1e3 / p1[len(p1) // 2],
-        "last_breakdown_ms": {"fast_embed": m.fast_embed_ms, "fast_search": m.fast_search_ms,
-                              "quality_embed": m.quality_embed_ms, "quality_search": m.quality_search_ms,
-                              "blend": m.blend_ms},
+        "workload": f"{rows}x256 fast tier + {rows}x384 quality tier, top-{k}, fetch {3 * k} per tier, stub lexical list of "
+                    f"{3 * k}, RRF + blend on the host; per-query C ABI calls from native threads (libfshost.so)",
+        "phase0_p50_ms": seq.phase0_p50_ms,
+        "phase1_p50_ms": seq.phase1_p50_ms,
+        "sequential_queries_per_sec": seq.queries_per_sec,
+        "sequential_breakdown_ms": {"fast_embed": seq.mean_fast_embed_ms, "fast_search": seq.mean_fast_search_ms,
+                                    "quality_embed": seq.mean_quality_embed_ms, "quality_search": seq.mean_quality_search_ms,
+                                    "fusion": seq.mean_fusion_ms},
+        "concurrent": {
+            "threads": threads, "coalescing": {"max_batch": max_batch, "max_wait_us": wait_us},
+            "queries_per_sec": con.queries_per_sec, "completed": con.completed, "failed": con.failed,
+            "phase0_p50_ms": con.phase0_p50_ms, "phase0_p95_ms": con.phase0_p95_ms,
+            "phase1_p50_ms": con.phase1_p50_ms, "phase1_p95_ms": con.phase1_p95_ms, "phase1_p99_ms": con.phase1_p99_ms,
+            "mean_queries_per_scan_batch": {"fast": fr / max(fb, 1), "quality": qr / max(qb, 1)},
+        },
     }
+    searcher.close()
     fast_index.close()
     del fast_slab
     return res
@@ -367,6 +370,7 @@ def main() -> None:
             tt = two_tier_section(index, args.rows, k, device, local_rank)
             line["two_tier"] = tt
             line["p50_phase1_latency_ms"] = tt["phase1_p50_ms"]
+            line["end_to_end_queries_per_sec"] = tt["concurrent"]["queries_per_sec"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_and_parity(slab, queries, k, args.rows, fa.VectorIndex)
         print(json.dumps(line), flush=True)

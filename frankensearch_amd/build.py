@@ -18,7 +18,11 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 SOURCES = ["scan_kernels.hip", "scan_mq_kernel.hip", "int8_kernels.hip", "mfma_scan.hip", "sort_general.hip", "m2v_kernels.hip", "bert_kernels.hip", "vector_index.cpp",
            "bert_embedder.cpp", "fusion.cpp", "fsgpu_api.cpp"]
-HEADERS = ["device_util.hpp", "scan_common.hpp", "kernels.hpp", "vector_index.hpp", "bert_embedder.hpp"]
+HEADERS = ["device_util.hpp", "scan_common.hpp", "kernels.hpp", "vector_index.hpp", "bert_embedder.hpp", "coalescer.hpp"]
+# libfshost.so: the C++ host-side mirror of the reference's two-tier searcher, over the C ABI only (include/fshost.h)
+HOST_LIB = os.path.join(HERE, "libfshost.so")
+HOST_SOURCES = ["host/two_tier_searcher.cpp", "host/load_driver.cpp", "host/fshost_api.cpp"]
+HOST_HEADERS = ["host/two_tier_searcher.hpp"]
 # -ffp-contract=off: the scan must issue a separate multiply and add (reference order, simd.rs:398-446).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-result", "-x", "hip"]
@@ -61,7 +65,21 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+    build_host(force, verbose)
     return LIB
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    """g++ only: libfshost.so has no device code; it links libfsgpu.so (found next to it through $ORIGIN)."""
+    deps = [os.path.join(CSRC, s) for s in HOST_SOURCES + HOST_HEADERS] + [os.path.join(INCLUDE, "fshost.h"),
+                                                                           os.path.join(INCLUDE, "fsgpu.h"), LIB, __file__]
+    if force or _stale(HOST_LIB, deps):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread", "-I", INCLUDE, "-o", HOST_LIB] + \
+              [os.path.join(CSRC, s) for s in HOST_SOURCES] + ["-L", HERE, "-lfsgpu", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return HOST_LIB
 
 
 if __name__ == "__main__":

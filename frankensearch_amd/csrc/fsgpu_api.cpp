@@ -9,17 +9,52 @@
 #include <string>
 #include <vector>
 
+#include <mutex>
+
 #include "bert_embedder.hpp"
+#include "coalescer.hpp"
 #include "vector_index.hpp"
+
+// One in-flight single-item call, parked in a Coalescer until a leader serves it (coalescer.hpp).
+struct CoalescedCall : fsgpu::CoalescedRequest {
+    fsgpu_status status = FSGPU_OK;
+    std::string detail;
+};
+struct SearchCall : CoalescedCall {
+    const float* query = nullptr;
+    uint32_t k = 0;
+    uint32_t* out_rows = nullptr;
+    float* out_scores = nullptr;
+    uint32_t* out_count = nullptr;
+};
+template <class Id>
+struct EmbedCall : CoalescedCall {
+    const Id* ids = nullptr;
+    uint32_t len = 0;
+    float* out = nullptr;
+};
 
 struct fsgpu_index {
     fsgpu::VectorIndex impl;
+    fsgpu::Coalescer<SearchCall> coalescer;
+    // leader-only staging (guarded by impl.mutex())
+    std::vector<float> co_queries, co_scores;
+    std::vector<uint32_t> co_rows, co_counts;
 };
 struct fsgpu_m2v {
     fsgpu::Model2VecEmbedder impl;
+    fsgpu::Coalescer<EmbedCall<uint32_t>> coalescer;
+    std::mutex co_mu;
+    std::vector<uint32_t> co_ids, co_offsets;
+    std::vector<float> co_out;
 };
 struct fsgpu_bert {
     fsgpu::NativeEmbedder impl;
+    fsgpu::Coalescer<EmbedCall<int32_t>> coalescer;
+    std::mutex co_mu;
+    std::vector<int32_t> co_ids;
+    std::vector<uint32_t> co_offsets;
+    std::vector<float> co_out;
 };
 
 namespace {
@@ -47,6 +82,33 @@ fsgpu_status guarded(F&& body) {
         return FSGPU_ERR_DEVICE;
     } catch (...) {
         return fail(FSGPU_ERR_DEVICE, "unknown exception");
+    }
+}
+
+// Runs one coalesced batch of single-text embed calls through embed_batch (ids concatenated, offsets rebuilt).
+template <class Handle, class Id>
+void run_embed_batch(Handle* h, uint32_t dim, std::vector<EmbedCall<Id>*>& batch) {
+    std::lock_guard<std::mutex> lock(h->co_mu);
+    h->co_ids.clear();
+    h->co_offsets.assign(1, 0u);
+    for (auto* c : batch) {
+        h->co_ids.insert(h->co_ids.end(), c->ids, c->ids + c->len);
+        h->co_offsets.push_back((uint32_t)h->co_ids.size());
+    }
+    h->co_out.resize((size_t)batch.size() * dim);
+    fsgpu_status st = FSGPU_ERR_DEVICE;
+    std::string detail;
+    try {
+        fsgpu::SearchError e = h->impl.embed_batch(h->co_ids.data(), h->co_offsets.data(), (uint32_t)batch.size(), h->co_out.data());
+        st = e.code;
+        detail = e.detail;
+    } catch (const std::exception& ex) {
+        detail = ex.what();
+    }
+    for (size_t i = 0; i < batch.size(); ++i) {
+        batch[i]->status = st;
+        batch[i]->detail = detail;
+        if (st == FSGPU_OK) std::memcpy(batch[i]->out, h->co_out.data() + i * dim, (size_t)dim * 4);
     }
 }
 
@@ -152,10 +214,73 @@ fsgpu_status fsgpu_search_topk(fsgpu_index* idx, const float* queries, uint32_t 
     if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
     if (nq && (!queries || !out_counts || (k && (!out_rows || !out_scores))))
         return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    if (idx->coalescer.enabled() && nq == 1 && !allow_bitmap && k >= 1 && k <= 64 && query_len == idx->impl.dimension()) {
+        // concurrent single-query callers ride one batched pass (results are bit-identical to the direct path)
+        return guarded([&]() -> fsgpu_status {
+            SearchCall call;
+            call.query = queries;
+            call.k = k;
+            call.out_rows = out_rows;
+            call.out_scores = out_scores;
+            call.out_count = out_counts;
+            idx->coalescer.submit(
+                &call,
+                [idx](std::vector<SearchCall*>& batch) {
+                    std::lock_guard<std::mutex> lock(idx->impl.mutex());
+                    const uint32_t n = (uint32_t)batch.size(), dim = idx->impl.dimension(), kk = batch[0]->k;
+                    idx->co_queries.resize((size_t)n * dim);
+                    idx->co_rows.resize((size_t)n * kk);
+                    idx->co_scores.resize((size_t)n * kk);
+                    idx->co_counts.resize(n);
+                    for (uint32_t i = 0; i < n; ++i)
+                        std::memcpy(idx->co_queries.data() + (size_t)i * dim, batch[i]->query, (size_t)dim * 4);
+                    fsgpu_status st = FSGPU_ERR_DEVICE;
+                    std::string detail;
+                    try {
+                        uint32_t fb = 0;
+                        // up to four callers: one pass of the exact multi-query kernel is quicker than the staged
+                        // matrix-core pipeline; beyond that the batched path serves 128 per pass
+                        fsgpu::SearchError e =
+                            n <= 4 ? idx->impl.search_top_k(idx->co_queries.data(), n, dim, kk, nullptr, idx->co_rows.data(),
+                                                            idx->co_scores.data(), idx->co_counts.data())
+                                   : idx->impl.search_top_k_batched(idx->co_queries.data(), n, dim, kk, nullptr,
+                                                                    idx->co_rows.data(), idx->co_scores.data(),
+                                                                    idx->co_counts.data(), &fb);
+                        st = e.code;
+                        detail = e.detail;
+                    } catch (const std::exception& ex) {
+                        detail = ex.what();
+                    }
+                    for (uint32_t i = 0; i < n; ++i) {
+                        batch[i]->status = st;
+                        batch[i]->detail = detail;
+                        if (st != FSGPU_OK) continue;
+                        std::memcpy(batch[i]->out_rows, idx->co_rows.data() + (size_t)i * kk, (size_t)kk * 4);
+                        std::memcpy(batch[i]->out_scores, idx->co_scores.data() + (size_t)i * kk, (size_t)kk * 4);
+                        *batch[i]->out_count = idx->co_counts[i];
+                    }
+                },
+                [](const SearchCall& a, const SearchCall& b) { return a.k == b.k; });
+            if (call.status != FSGPU_OK) g_last_error = call.detail;
+            return call.status;
+        });
+    }
     return guarded([&]() -> fsgpu_status {
         std::lock_guard<std::mutex> lock(idx->impl.mutex());
         return finish(idx->impl.search_top_k(queries, nq, query_len, k, allow_bitmap, out_rows, out_scores, out_counts));
     });
+}
+
+fsgpu_status fsgpu_index_set_coalescing(fsgpu_index* idx, uint32_t max_batch, uint32_t max_wait_us) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    idx->coalescer.configure(max_batch, max_wait_us);
+    return FSGPU_OK;
+}
+
+fsgpu_status fsgpu_index_coalescing_stats(fsgpu_index* idx, uint64_t* batches, uint64_t* requests) {
+    if (!idx || !batches || !requests) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    idx->coalescer.stats(batches, requests);
+    return FSGPU_OK;
 }
 
 fsgpu_status fsgpu_search_topk_device(fsgpu_index* idx, const float* queries_dev, uint32_t nq, uint32_t query_len,
@@ -390,7 +515,26 @@ void fsgpu_m2v_destroy(fsgpu_m2v* m) { delete m; }
 
 fsgpu_status fsgpu_m2v_embed(fsgpu_m2v* m, const uint32_t* ids, const uint32_t* offsets, uint32_t n, float* out) {
     if (!m) return fail(FSGPU_ERR_NULL_ARGUMENT, "embedder is null");
+    if (m->coalescer.enabled() && n == 1 && offsets && out && (ids || offsets[1] == offsets[0])) {
+        return guarded([&]() -> fsgpu_status {
+            EmbedCall<uint32_t> call;
+            call.ids = ids ? ids + offsets[0] : nullptr;
+            call.len = offsets[1] - offsets[0];
+            call.out = out;
+            m->coalescer.submit(
+                &call, [m](std::vector<EmbedCall<uint32_t>*>& batch) { run_embed_batch(m, m->impl.dimension(), batch); },
+                [](const EmbedCall<uint32_t>&, const EmbedCall<uint32_t>&) { return true; });
+            if (call.status != FSGPU_OK) g_last_error = call.detail;
+            return call.status;
+        });
+    }
     return guarded([&]() -> fsgpu_status { return finish(m->impl.embed_batch(ids, offsets, n, out)); });
+}
+
+fsgpu_status fsgpu_m2v_set_coalescing(fsgpu_m2v* m, uint32_t max_batch, uint32_t max_wait_us) {
+    if (!m) return fail(FSGPU_ERR_NULL_ARGUMENT, "embedder is null");
+    m->coalescer.configure(max_batch, max_wait_us);
+    return FSGPU_OK;
 }
 
 fsgpu_status fsgpu_bert_create(int32_t device, const fsgpu_bert_config* config, const fsgpu_bert_weights* weights,
@@ -413,7 +557,26 @@ void fsgpu_bert_destroy(fsgpu_bert* m) { delete m; }
 
 fsgpu_status fsgpu_bert_embed(fsgpu_bert* m, const int32_t* ids, const uint32_t* offsets, uint32_t n, float* out) {
     if (!m) return fail(FSGPU_ERR_NULL_ARGUMENT, "embedder is null");
+    if (m->coalescer.enabled() && n == 1 && offsets && out && (ids || offsets[1] == offsets[0])) {
+        return guarded([&]() -> fsgpu_status {
+            EmbedCall<int32_t> call;
+            call.ids = ids ? ids + offsets[0] : nullptr;
+            call.len = offsets[1] - offsets[0];
+            call.out = out;
+            m->coalescer.submit(
+                &call, [m](std::vector<EmbedCall<int32_t>*>& batch) { run_embed_batch(m, m->impl.dimension(), batch); },
+                [](const EmbedCall<int32_t>&, const EmbedCall<int32_t>&) { return true; });
+            if (call.status != FSGPU_OK) g_last_error = call.detail;
+            return call.status;
+        });
+    }
     return guarded([&]() -> fsgpu_status { return finish(m->impl.embed_batch(ids, offsets, n, out)); });
+}
+
+fsgpu_status fsgpu_bert_set_coalescing(fsgpu_bert* m, uint32_t max_batch, uint32_t max_wait_us) {
+    if (!m) return fail(FSGPU_ERR_NULL_ARGUMENT, "embedder is null");
+    m->coalescer.configure(max_batch, max_wait_us);
+    return FSGPU_OK;
 }
 
 fsgpu_status fsgpu_index_set_profiling(fsgpu_index* idx, int32_t enabled) {

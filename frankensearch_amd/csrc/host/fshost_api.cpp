@@ -1,0 +1,64 @@
+// fshost_api.cpp — extern "C" surface of libfshost.so (include/fshost.h).
+#include <cstring>
+#include <exception>
+#include <string>
+
+#include "two_tier_searcher.hpp"
+
+namespace fshost {
+fsgpu_status run_load(const SyncTwoTierSearcher& searcher, const fshost_load_config& cfg, fshost_load_result* res);
+}
+
+struct fshost_two_tier {
+    fshost::SyncTwoTierSearcher impl;
+};
+
+extern "C" {
+
+fsgpu_status fshost_two_tier_create(fsgpu_index* fast_index, fsgpu_index* quality_index, fsgpu_m2v* fast_embedder,
+                                    fsgpu_bert* quality_embedder, const fshost_two_tier_config* config,
+                                    fshost_two_tier** out) {
+    if (!fast_index || !quality_index || !fast_embedder || !quality_embedder || !config || !out) return FSGPU_ERR_NULL_ARGUMENT;
+    try {
+        *out = new fshost_two_tier{fshost::SyncTwoTierSearcher(fast_index, quality_index, fast_embedder, quality_embedder, *config)};
+    } catch (const std::exception&) {
+        return FSGPU_ERR_DEVICE;
+    }
+    return FSGPU_OK;
+}
+
+void fshost_two_tier_destroy(fshost_two_tier* s) { delete s; }
+
+fsgpu_status fshost_two_tier_search(fshost_two_tier* s, const uint32_t* fast_token_ids, uint32_t n_fast_ids,
+                                    const int32_t* quality_token_ids, uint32_t n_quality_ids, uint32_t k,
+                                    const fsgpu_scored_doc* lexical, uint32_t n_lexical, fshost_hit* initial_out,
+                                    uint32_t* n_initial, fshost_hit* final_out, uint32_t* n_final, fshost_metrics* metrics) {
+    if (!s || !n_initial || !n_final || (k && (!initial_out || !final_out))) return FSGPU_ERR_NULL_ARGUMENT;
+    try {
+        fshost::Outcome out;
+        std::string detail;
+        const fsgpu_status st = s->impl.search(fast_token_ids, n_fast_ids, quality_token_ids, n_quality_ids, k, lexical,
+                                               n_lexical, &out, &detail);
+        if (st != FSGPU_OK) return st;
+        *n_initial = (uint32_t)out.initial.size();
+        *n_final = (uint32_t)out.final_results.size();
+        if (!out.initial.empty()) std::memcpy(initial_out, out.initial.data(), out.initial.size() * sizeof(fshost_hit));
+        if (!out.final_results.empty())
+            std::memcpy(final_out, out.final_results.data(), out.final_results.size() * sizeof(fshost_hit));
+        if (metrics) *metrics = out.metrics;
+        return FSGPU_OK;
+    } catch (const std::exception&) {
+        return FSGPU_ERR_DEVICE;
+    }
+}
+
+fsgpu_status fshost_run_load(fshost_two_tier* s, const fshost_load_config* config, fshost_load_result* result) {
+    if (!s || !config || !result) return FSGPU_ERR_NULL_ARGUMENT;
+    try {
+        return fshost::run_load(s->impl, *config, result);
+    } catch (const std::exception&) {
+        return FSGPU_ERR_DEVICE;
+    }
+}
+
+}  // extern "C"

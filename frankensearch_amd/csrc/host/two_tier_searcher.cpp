@@ -1,0 +1,172 @@
+// two_tier_searcher.cpp — see two_tier_searcher.hpp.  Calls only functions declared in include/fsgpu.h.
+#include "two_tier_searcher.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <unordered_map>
+
+namespace fshost {
+
+namespace {
+
+double ms_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+std::vector<fsgpu_scored_doc> view(const std::vector<Hit>& hits) {
+    std::vector<fsgpu_scored_doc> v(hits.size());
+    for (size_t i = 0; i < hits.size(); ++i)
+        v[i] = fsgpu_scored_doc{hits[i].doc_id.data(), (uint32_t)hits[i].doc_id.size(), hits[i].score, hits[i].index};
+    return v;
+}
+
+fsgpu_status copy_out(const std::vector<fsgpu_fused_hit>& fused, uint32_t n, std::vector<fshost_hit>* out, std::string* detail) {
+    out->resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const fsgpu_fused_hit& f = fused[i];
+        fshost_hit& h = (*out)[i];
+        if (f.doc_id_len > FSHOST_DOC_ID_MAX) {
+            *detail = "doc id longer than FSHOST_DOC_ID_MAX";
+            return FSGPU_ERR_INVALID_CONFIG;
+        }
+        std::memcpy(h.doc_id, f.doc_id, f.doc_id_len);
+        h.doc_id[f.doc_id_len] = 0;
+        h.rrf_score = f.rrf_score;
+        h.lexical_rank = f.lexical_rank;
+        h.semantic_rank = f.semantic_rank;
+        h.semantic_index = f.semantic_index;
+        h.lexical_score = f.lexical_score;
+        h.semantic_score = f.semantic_score;
+        h.in_both_sources = f.in_both_sources;
+    }
+    return FSGPU_OK;
+}
+
+}  // namespace
+
+SyncTwoTierSearcher::SyncTwoTierSearcher(fsgpu_index* fast, fsgpu_index* quality, fsgpu_m2v* fast_embedder,
+                                         fsgpu_bert* quality_embedder, const fshost_two_tier_config& cfg)
+    : fast_(fast), quality_(quality), m2v_(fast_embedder), bert_(quality_embedder), cfg_(cfg) {
+    fast_dim_ = fsgpu_index_dimension(fast_);
+    quality_dim_ = fsgpu_index_dimension(quality_);
+}
+
+// VectorIndex::search_top_k -> Vec<VectorHit> with doc ids resolved (search.rs:192-206, 1503-1558).
+fsgpu_status SyncTwoTierSearcher::tier_hits(fsgpu_index* index, const std::vector<float>& vec, uint32_t fetch,
+                                            std::vector<Hit>* hits, std::string* detail) const {
+    std::vector<uint32_t> rows(fetch);
+    std::vector<float> scores(fetch);
+    uint32_t count = 0;
+    fsgpu_status st = fsgpu_search_topk(index, vec.data(), 1, (uint32_t)vec.size(), fetch, nullptr, rows.data(), scores.data(), &count);
+    if (st != FSGPU_OK) {
+        *detail = fsgpu_last_error();
+        return st;
+    }
+    hits->clear();
+    hits->reserve(count);
+    char buf[32];
+    for (uint32_t i = 0; i < count; ++i) {
+        Hit h;
+        h.score = scores[i];
+        h.index = rows[i];
+        if (cfg_.doc_id_mode == 1) {
+            const int n = std::snprintf(buf, sizeof buf, "doc-%08u", rows[i]);
+            h.doc_id.assign(buf, (size_t)n);
+        } else {
+            const char* p = nullptr;
+            uint32_t len = 0;
+            st = fsgpu_index_doc_id(index, rows[i], &p, &len);
+            if (st != FSGPU_OK) {
+                *detail = fsgpu_last_error();
+                return st;
+            }
+            h.doc_id.assign(p, len);
+        }
+        hits->push_back(std::move(h));
+    }
+    return FSGPU_OK;
+}
+
+fsgpu_status SyncTwoTierSearcher::search(const uint32_t* fast_ids, uint32_t n_fast, const int32_t* quality_ids,
+                                         uint32_t n_quality, uint32_t k, const fsgpu_scored_doc* lexical, uint32_t n_lexical,
+                                         Outcome* out, std::string* detail) const {
+    using clock = std::chrono::steady_clock;
+    const uint32_t mult = std::max<uint32_t>(cfg_.candidate_multiplier, 1);
+    const uint32_t fetch = std::max(k * mult, k);  // candidate_count (rrf.rs:113-115)
+    fshost_metrics& m = out->metrics;
+    const auto t0 = clock::now();
+    // ---- phase 0 / Initial ----
+    std::vector<float> fast_vec(fast_dim_);
+    const uint32_t fast_off[2] = {0, n_fast};
+    fsgpu_status st = fsgpu_m2v_embed(m2v_, fast_ids, fast_off, 1, fast_vec.data());
+    if (st != FSGPU_OK) {
+        *detail = fsgpu_last_error();
+        return st;
+    }
+    m.fast_embed_ms = ms_since(t0);
+    const auto t1 = clock::now();
+    std::vector<Hit> fast_hits;
+    st = tier_hits(fast_, fast_vec, fetch, &fast_hits, detail);
+    if (st != FSGPU_OK) return st;
+    m.fast_search_ms = ms_since(t1);
+    const std::vector<fsgpu_scored_doc> fast_view = view(fast_hits);
+    std::vector<fsgpu_fused_hit> fused(k ? k : 1);
+    uint32_t n = 0;
+    st = fsgpu_rrf_fuse(lexical, n_lexical, fast_view.data(), (uint32_t)fast_view.size(), cfg_.rrf_k, 1.0, 1.0,
+                        FSGPU_RRF_TIEBREAK_LEXICAL_THEN_ID, k, 0, fused.data(), &n);
+    if (st != FSGPU_OK) {
+        *detail = fsgpu_last_error();
+        return st;
+    }
+    st = copy_out(fused, n, &out->initial, detail);
+    if (st != FSGPU_OK) return st;
+    m.phase1_total_ms = ms_since(t0);
+    // ---- phase 1 / Refined ----
+    const auto t3 = clock::now();
+    std::vector<float> quality_vec(quality_dim_);
+    const uint32_t q_off[2] = {0, n_quality};
+    st = fsgpu_bert_embed(bert_, quality_ids, q_off, 1, quality_vec.data());
+    if (st != FSGPU_OK) {
+        *detail = fsgpu_last_error();
+        return st;
+    }
+    m.quality_embed_ms = ms_since(t3);
+    const auto t4 = clock::now();
+    std::vector<Hit> quality_hits;  // the `Retrieved` pool (sync_searcher.rs:810-813)
+    st = tier_hits(quality_, quality_vec, fetch, &quality_hits, detail);
+    if (st != FSGPU_OK) return st;
+    m.quality_search_ms = ms_since(t4);
+    const auto t5 = clock::now();
+    const std::vector<fsgpu_scored_doc> quality_view = view(quality_hits);
+    std::vector<fsgpu_scored_doc> blended(fast_view.size() + quality_view.size() + 1);
+    uint32_t nb = 0;
+    st = fsgpu_blend_two_tier(fast_view.data(), (uint32_t)fast_view.size(), quality_view.data(), (uint32_t)quality_view.size(),
+                              cfg_.quality_weight, blended.data(), &nb);
+    if (st != FSGPU_OK) {
+        *detail = fsgpu_last_error();
+        return st;
+    }
+    // blended hits carry the fast-tier row of their doc (sync_searcher.rs:880-891)
+    std::unordered_map<std::string, uint32_t> fast_index_of;
+    fast_index_of.reserve(fast_hits.size() * 2);
+    for (const Hit& h : fast_hits) fast_index_of.emplace(h.doc_id, h.index);
+    for (uint32_t i = 0; i < nb; ++i) {
+        auto it = fast_index_of.find(std::string(blended[i].doc_id, blended[i].doc_id_len));
+        blended[i].index = it == fast_index_of.end() ? 0xffffffffu : it->second;
+    }
+    m.blend_ms = ms_since(t5);
+    st = fsgpu_rrf_fuse(lexical, n_lexical, blended.data(), nb, cfg_.rrf_k, 1.0, 1.0, FSGPU_RRF_TIEBREAK_LEXICAL_THEN_ID, k, 0,
+                        fused.data(), &n);
+    if (st != FSGPU_OK) {
+        *detail = fsgpu_last_error();
+        return st;
+    }
+    st = copy_out(fused, n, &out->final_results, detail);
+    if (st != FSGPU_OK) return st;
+    m.phase2_total_ms = ms_since(t3);
+    return FSGPU_OK;
+}
+
+}  // namespace fshost

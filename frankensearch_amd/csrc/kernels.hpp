@@ -75,7 +75,10 @@ struct MfmaScanArgs {
     const void* queries;       // [nq_pad, dim] f16 (rows >= nq are zero)
     const float* tau;          // [nq_pad] candidate threshold per query (ignored in dense mode)
     u64* cand;                 // [nq_pad, gridDim.x, slots] packed approximate candidates, one list per block
-    uint32_t* overflow;        // [nq_pad] set when a block's list for a query overflows its slots
+    u64* spill;                // [nq_pad, spill_cap] candidates that did not fit their block's list
+    uint32_t* spill_count;     // [nq_pad * kMfmaSpillCountStride] append counters, one cache line apart
+    uint32_t spill_cap;
+    uint32_t* overflow;        // [nq_pad] set when a query's spill area overflows too
     u64* dense;                // stage 0: [nq_pad, group_count * 64] packed approximate scores of the sample
     uint32_t nrows;            // rows in the slab
     uint32_t stage;            // 0 = dense sample, 1 = thresholded sample, 2 = main pass (everything stage 1 skipped)
@@ -83,7 +86,7 @@ struct MfmaScanArgs {
     uint32_t dim, slots, row_base;       // slots <= kMfmaMaxSlots
 };
 
-// select_kernel (mfma_scan.hip): per query, the k-th best of <= 8192 packed approximate entries without sorting them
+// select_kernel (mfma_scan.hip): per query, the k-th best of the packed approximate entries without sorting them
 // (k rounds of wave arg-max per wave, k more over the 16 waves' winners) -> tau = a_k - 2 delta; the entries at or
 // above tau are the query's candidates.  Two uses:
 //   threshold step (slab == null): tau_out for the next scan stage, candidates optionally kept as a pool;
@@ -95,6 +98,9 @@ struct SelectArgs {
     uint32_t l_stride, nlists, list_len;
     const u64* extra;          // [nq, extra_len] more entries per query (may be null)
     uint32_t extra_len;
+    const u64* spill;          // [nq, spill_cap] spilled entries (may be null); valid prefix = min(count, spill_cap)
+    const uint32_t* spill_count;  // [nq * kMfmaSpillCountStride]
+    uint32_t spill_cap;
     uint32_t k;                // 1..64
     const float* delta;        // [nq] error bound; < 0 = query is skipped (tau = +inf, overflow set)
     float* tau_out;            // [nq] (may be null)
@@ -115,7 +121,8 @@ struct SelectArgs {
 constexpr uint32_t kSelectPool = 1024;
 hipError_t launch_select(const SelectArgs& args, int nq, hipStream_t stream);
 
-constexpr uint32_t kMfmaMaxSlots = 32;  // candidate slots per (block, query) staged in LDS
+constexpr uint32_t kMfmaMaxSlots = 32;           // candidate slots per (block, query) staged in LDS
+constexpr uint32_t kMfmaSpillCountStride = 16;  // uint32 counters 64 bytes apart
 bool scan_mfma_supported(int dim);
 // shape: see mfma_scan.hip (0 = 64 queries; 1..3 = 128 queries with different row tiling / buffering)
 int scan_mfma_waves_per_block(int shape);

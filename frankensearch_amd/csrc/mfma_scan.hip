@@ -190,51 +190,74 @@ __global__ __launch_bounds__(WPB * 64) void scan_mfma_kernel(MfmaScanArgs args) 
                     for (int r = 0; r < 4; ++r)
                         if (valid[r] && acc[s][nt][r] >= th) {
                             const int pos = atomicAdd(&lcnt[q], 1);
-                            if (pos < slots) lbuf[q * slots + pos] = pack(acc[s][nt][r], args.row_base + row0 + r);
-                            else args.overflow[q] = 1;  // this query goes to the exact path
+                            const u64 entry = pack(acc[s][nt][r], args.row_base + row0 + r);
+                            if (pos < slots) {
+                                lbuf[q * slots + pos] = entry;
+                            } else {
+                                // the block's list is full: spill to the query's global overflow area (rare, so the
+                                // serialised global atomic does not matter); beyond that the exact path answers
+                                const uint32_t g = atomicAdd(&args.spill_count[q * kMfmaSpillCountStride], 1u);
+                                if (g < args.spill_cap) args.spill[(size_t)q * args.spill_cap + g] = entry;
+                                else args.overflow[q] = 1;
+                            }
                         }
                 }
             }
         }
     };
 
-    // Tile t belongs to block t % gridDim.x: a run of neighbouring rows (one topic's documents, typically the rows a
-    // query's candidates cluster in) is spread over many blocks' candidate lists instead of overflowing one.
-    auto next_tile = [&](uint32_t t) -> uint32_t {  // the wave's next tile at or after t that is not skipped
-        while (t < ntiles && tile_skipped(t)) t += nwaves;
-        return t;
+    // Work item u = round * gridDim.x + block; the tile it names is rotated by the round number inside its round:
+    // tile = round * grid + (block - round) mod grid.  Neighbouring tiles go to different blocks (a run of
+    // neighbouring rows — one topic's documents, typically where a query's candidates cluster — is spread over many
+    // blocks' candidate lists), and rows that recur with a power-of-two period do not keep landing in the same blocks.
+    const uint32_t grid = gridDim.x;
+    const uint32_t nitems = (ntiles + grid - 1) / grid * grid;
+    auto tile_of = [&](uint32_t u) -> uint32_t {
+        const uint32_t round = u / grid, blk = u - round * grid;
+        const uint32_t rot = round % grid;
+        return round * grid + (blk >= rot ? blk - rot : blk + grid - rot);
     };
+    auto next_item = [&](uint32_t u) -> uint32_t {  // the wave's next work item at or after u that names a tile to scan
+        while (u < nitems) {
+            const uint32_t t = tile_of(u);
+            if (t < ntiles && !tile_skipped(t)) break;
+            u += nwaves;
+        }
+        return u;
+    };
+    const uint32_t u0 = wave * grid + blockIdx.x;
     if constexpr (PF) {
         // register double buffer: the next tile's loads are in flight while this one is on the matrix cores
         half8 wa[RT][KS], wb[RT][KS];
         u64 la = ~0ull, aa = ~0ull, lb = ~0ull, ab = ~0ull;
-        uint32_t t = next_tile(wave * gridDim.x + blockIdx.x);
-        if (t < ntiles) {
-            load_tile(t, wa);
-            tile_words(t, la, aa);
+        uint32_t u = next_item(u0);
+        if (u < nitems) {
+            load_tile(tile_of(u), wa);
+            tile_words(tile_of(u), la, aa);
         }
-        while (t < ntiles) {
-            uint32_t next = next_tile(t + nwaves);
-            if (next < ntiles) {
-                load_tile(next, wb);
-                tile_words(next, lb, ab);
+        while (u < nitems) {
+            uint32_t next = next_item(u + nwaves);
+            if (next < nitems) {
+                load_tile(tile_of(next), wb);
+                tile_words(tile_of(next), lb, ab);
             }
-            compute_tile(t, wa, la, aa);
-            t = next;
-            if (t >= ntiles) break;
-            next = next_tile(t + nwaves);
-            if (next < ntiles) {
-                load_tile(next, wa);
-                tile_words(next, la, aa);
+            compute_tile(tile_of(u), wa, la, aa);
+            u = next;
+            if (u >= nitems) break;
+            next = next_item(u + nwaves);
+            if (next < nitems) {
+                load_tile(tile_of(next), wa);
+                tile_words(tile_of(next), la, aa);
             }
-            compute_tile(t, wb, lb, ab);
-            t = next;
+            compute_tile(tile_of(u), wb, lb, ab);
+            u = next;
         }
     } else {
         // single buffer: the other resident waves of the SIMD cover the load latency
         half8 wa[RT][KS];
         u64 la = ~0ull, aa = ~0ull;
-        for (uint32_t t = next_tile(wave * gridDim.x + blockIdx.x); t < ntiles; t = next_tile(t + nwaves)) {
+        for (uint32_t u = next_item(u0); u < nitems; u = next_item(u + nwaves)) {
+            const uint32_t t = tile_of(u);
             load_tile(t, wa);
             tile_words(t, la, aa);
             compute_tile(t, wa, la, aa);
@@ -250,94 +273,122 @@ __global__ __launch_bounds__(WPB * 64) void scan_mfma_kernel(MfmaScanArgs args) 
     }
 }
 
-// Selection without a full sort (see SelectArgs).  1024 threads hold their entries in registers; every wave extracts
-// its k largest sortkeys (wave_extract_topk), wave 0 repeats that over the 16 x k winners: its picks are the block's
-// top-k, best first.  A few microseconds, against 35-50 us for sorting the few hundred survivors these stages see.
+// Selection without a full sort (see SelectArgs).  1024 threads hold 8 entries each in registers (8,192 per pass;
+// longer inputs take more passes); every wave keeps its k largest sortkeys so far (wave_extract_topk over its new
+// entries plus its previous winners), wave 0 repeats that over the 16 x k winners: its picks are the block's top-k,
+// best first.  ~20 us, against 35-50 us for sorting the few hundred survivors these stages see.
 constexpr int kSelThreads = 1024;
 constexpr int kSelPer = 8;
 constexpr int kSelWaves = kSelThreads / 64;
 
-// top[0..k) <- the block's k best entries, best first (kEmpty padded).  key[] is consumed.  Ends on a barrier.
+// One pass of the per-wave extraction: dst[0..k) <- the wave's k best among e[] and prev[0..k) (its earlier winners).
 template <int PER>
-__device__ __forceinline__ void block_select_topk(const u64 (&e)[PER], u64 (&key)[PER], int k, u64* win, u64* top, int tid) {
-    constexpr int NT = kSelThreads, NW = kSelWaves;
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int j = tid; j < NW * k; j += NT) win[j] = kEmpty;
-    if (tid < 64) top[tid] = kEmpty;
-    __syncthreads();
-    wave_extract_topk<PER>(key, e, k, win + wave * k);
-    __syncthreads();
-    if (wave == 0) {
-        u64 e2[NW], key2[NW];  // NW * k <= 64 * NW winners
+__device__ __forceinline__ void wave_select_pass(const u64 (&e)[PER], int k, const u64* prev, u64* dst, int lane) {
+    u64 ee[PER + 1], key[PER + 1];
 #pragma unroll
-        for (int x = 0; x < NW; ++x) {
-            const int i = lane + x * 64;
-            e2[x] = i < NW * k ? win[i] : kEmpty;
-            key2[x] = e2[x] != kEmpty ? sortkey(e2[x]) : 0ull;
-        }
-        wave_extract_topk<NW>(key2, e2, k, top);
+    for (int x = 0; x < PER; ++x) ee[x] = e[x];
+    ee[PER] = (prev && lane < k) ? prev[lane] : kEmpty;
+#pragma unroll
+    for (int x = 0; x <= PER; ++x) key[x] = ee[x] != kEmpty ? sortkey(ee[x]) : 0ull;
+    if (lane < k) dst[lane] = kEmpty;
+    wave_lds_fence();
+    wave_extract_topk<PER + 1>(key, ee, k, dst);
+    wave_lds_fence();
+}
+
+// top[0..k) <- the k best of the 16 waves' winner lists win[wave * k + j], best first (kEmpty padded).  Wave 0 only.
+__device__ __forceinline__ void merge_wave_winners(const u64* win, int k, u64* top, int lane) {
+    constexpr int NW = kSelWaves;
+    u64 e2[NW], key2[NW];  // NW * k <= 64 * NW winners
+#pragma unroll
+    for (int x = 0; x < NW; ++x) {
+        const int i = lane + x * 64;
+        e2[x] = i < NW * k ? win[i] : kEmpty;
+        key2[x] = e2[x] != kEmpty ? sortkey(e2[x]) : 0ull;
     }
-    __syncthreads();
+    top[lane] = kEmpty;
+    wave_lds_fence();
+    wave_extract_topk<NW>(key2, e2, k, top);
+    wave_lds_fence();
 }
 
 template <bool FINISH>
 __global__ __launch_bounds__(kSelThreads) void select_kernel(SelectArgs args) {
     constexpr int NT = kSelThreads, PER = kSelPer, NW = kSelWaves, POOL = (int)kSelectPool;
     static_assert(POOL == NT, "one pool entry per thread in the final selection");
-    __shared__ u64 win[NW * 64];   // per-wave winners [wave][round]
-    __shared__ u64 top[64];        // block top-k, best first
-    __shared__ u64 pool[POOL];     // candidates (finish step: replaced by their exact entries)
+    __shared__ u64 win[2][NW * 64];  // per-wave winners [wave][rank], ping-pong across passes
+    __shared__ u64 top[64];          // block top-k, best first
+    __shared__ u64 pool[POOL];       // candidates (finish step: replaced by their exact entries)
     __shared__ int s_count;
     __shared__ float s_tau;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
     const int k = (int)args.k;
     const u64* in = args.lists + (size_t)q * args.q_stride;
     const uint32_t lists32 = args.nlists * args.list_len;
-    const uint32_t total32 = lists32 + args.extra_len;
-    if (tid == 0) s_count = 0;
-    u64 e[PER], key[PER];
-#pragma unroll
-    for (int x = 0; x < PER; ++x) {
-        const uint32_t i = tid + x * NT;
-        e[x] = kEmpty;
-        if (i < lists32) {
-            const uint32_t l = i / args.list_len;
-            e[x] = in[(size_t)l * args.l_stride + (i - l * args.list_len)];
-        } else if (i < total32) {
-            e[x] = args.extra[(size_t)q * args.extra_len + (i - lists32)];
-        }
+    const uint32_t extra_end = lists32 + args.extra_len;
+    uint32_t nspill = 0;
+    if (args.spill) {
+        nspill = args.spill_count[(size_t)q * kMfmaSpillCountStride];
+        nspill = nspill < args.spill_cap ? nspill : args.spill_cap;
     }
+    const uint32_t total32 = extra_end + nspill;
+    const int npass = total32 ? (int)((total32 + NT * PER - 1) / (NT * PER)) : 1;
+    auto load_pass = [&](int p, u64 (&e)[PER]) {
 #pragma unroll
-    for (int x = 0; x < PER; ++x) key[x] = e[x] != kEmpty ? sortkey(e[x]) : 0ull;
-    pool[tid] = kEmpty;
-    block_select_topk<PER>(e, key, k, win, top, tid);
-    if (tid == 0) {
-        const float d = args.delta[q];
-        float t = -INFINITY;   // fewer than k entries: everything is a candidate
-        if (d < 0.f) {
-            t = INFINITY;      // skipped query (padding / zero / non-finite): the exact path answers it
-            if (args.overflow) args.overflow[q] = 1;
-        } else if (top[k - 1] != kEmpty) {
-            t = __uint_as_float((uint32_t)(top[k - 1] >> 32)) - 2.0f * d;
-            if (!(t == t)) t = -INFINITY;
+        for (int x = 0; x < PER; ++x) {
+            const uint32_t i = (uint32_t)p * (NT * PER) + tid + x * NT;
+            e[x] = kEmpty;
+            if (i < lists32) {
+                const uint32_t l = i / args.list_len;
+                e[x] = in[(size_t)l * args.l_stride + (i - l * args.list_len)];
+            } else if (i < extra_end) {
+                e[x] = args.extra[(size_t)q * args.extra_len + (i - lists32)];
+            } else if (i < total32) {
+                e[x] = args.spill[(size_t)q * args.spill_cap + (i - extra_end)];
+            }
         }
-        s_tau = t;
-        if (args.tau_out) args.tau_out[q] = t;
+    };
+    if (tid == 0) s_count = 0;
+    pool[tid] = kEmpty;
+    u64 e[PER];
+    for (int p = 0; p < npass; ++p) {  // block-uniform
+        load_pass(p, e);
+        wave_select_pass<PER>(e, k, p ? win[(p - 1) & 1] + wave * k : nullptr, win[p & 1] + wave * k, lane);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        merge_wave_winners(win[(npass - 1) & 1], k, top, lane);
+        if (lane == 0) {
+            const float d = args.delta[q];
+            float t = -INFINITY;   // fewer than k entries: everything is a candidate
+            if (d < 0.f) {
+                t = INFINITY;      // skipped query (padding / zero / non-finite): the exact path answers it
+                if (args.overflow) args.overflow[q] = 1;
+            } else if (top[k - 1] != kEmpty) {
+                t = __uint_as_float((uint32_t)(top[k - 1] >> 32)) - 2.0f * d;
+                if (!(t == t)) t = -INFINITY;
+            }
+            s_tau = t;
+            if (args.tau_out) args.tau_out[q] = t;
+        }
     }
     __syncthreads();
     if (!FINISH && !args.pool_out && !args.cand_counts) return;
     const float tau = s_tau;
+    for (int p = 0; p < npass; ++p) {
+        if (npass > 1) load_pass(p, e);  // a single pass still has its entries in registers
 #pragma unroll
-    for (int x = 0; x < PER; ++x) {
-        const bool ok = e[x] != kEmpty && __uint_as_float((uint32_t)(e[x] >> 32)) >= tau;
-        const u64 m = __ballot(ok);
-        if (m) {
-            int wbase = 0;
-            if (lane == 0) wbase = atomicAdd(&s_count, (int)__popcll(m));
-            wbase = __shfl(wbase, 0);
-            const int pos = wbase + (int)__popcll(m & ((1ull << lane) - 1ull));
-            if (ok && pos < POOL) pool[pos] = e[x];
+        for (int x = 0; x < PER; ++x) {
+            const bool ok = e[x] != kEmpty && __uint_as_float((uint32_t)(e[x] >> 32)) >= tau;
+            const u64 m = __ballot(ok);
+            if (m) {
+                int wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&s_count, (int)__popcll(m));
+                wbase = __shfl(wbase, 0);
+                const int pos = wbase + (int)__popcll(m & ((1ull << lane) - 1ull));
+                if (ok && pos < POOL) pool[pos] = e[x];
+            }
         }
     }
     __syncthreads();
@@ -348,7 +399,7 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(SelectArgs args) {
     }
     if (args.pool_out) args.pool_out[(size_t)q * POOL + tid] = pool[tid];
     if constexpr (FINISH) {
-        // exact-order re-score (dot_product_f16_bytes_f32 order, as gather_dot_batch_kernel): one quad per candidate,
+        // exact-order re-score (dot_product_f16_bytes_f32 order, as gather_dot_kernel): one quad per candidate,
         // 256 candidates per sweep; the entry is replaced by its exact counterpart in place
         const int dim = (int)args.dim;
         const int a = tid & 3;
@@ -381,12 +432,13 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(SelectArgs args) {
             if (a == 0 && c < nc) pool[c] = mine ? pack(sc, grow) : kEmpty;  // only this quad touches pool[c]
         }
         __syncthreads();
-        u64 e3[1], key3[1];
-        e3[0] = pool[tid];
-        key3[0] = e3[0] != kEmpty ? sortkey(e3[0]) : 0ull;
         const int ko = (int)args.k_out;
-        block_select_topk<1>(e3, key3, ko, win, top, tid);
-        if (tid < 64) {
+        u64 e3[1];
+        e3[0] = pool[tid];
+        wave_select_pass<1>(e3, ko, nullptr, win[0] + wave * ko, lane);
+        __syncthreads();
+        if (wave == 0) {
+            merge_wave_winners(win[0], ko, top, lane);
             int n = 0;
             for (int j = lane; j < (int)args.out_stride; j += 64) {
                 const u64 cnd = j < ko ? top[j] : kEmpty;
@@ -512,8 +564,7 @@ hipError_t launch_scan_mfma(const MfmaScanArgs& args, int shape, int grid, hipSt
 }
 
 hipError_t launch_select(const SelectArgs& args, int nq, hipStream_t stream) {
-    if (args.k < 1 || args.k > 64 || !args.delta ||
-        (uint64_t)args.nlists * args.list_len + args.extra_len > (uint64_t)kSelThreads * kSelPer)
+    if (args.k < 1 || args.k > 64 || !args.delta || (uint64_t)args.nlists * args.list_len > 0x7fffffffull)
         return hipErrorInvalidValue;
     if (args.slab) {
         if (args.k_out < 1 || args.k_out > 64 || (args.dim & 7)) return hipErrorInvalidValue;

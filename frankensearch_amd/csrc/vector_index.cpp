@@ -112,7 +112,7 @@ VectorIndex::~VectorIndex() {
                             &ws_counts_, &ws_keys_a_, &ws_keys_b_, &ws_sort_tmp_, &ws_gather_rows_, &ws_gather_out_,
                             &i8_slab_, &i8_max_, &ws_i8_query_, &ws_cand_packed_, &ws_cand_rows_, &ws_cand_scores_,
                             &mf_max_norm_, &mf_qh_, &mf_delta_, &mf_tau_, &mf_cand_, &mf_dense_, &mf_sel_,
-                            &mf_fallback_})
+                            &mf_fallback_, &mf_spill_})
         b->release();
     if (mf_flags_host_) (void)hipHostFree(mf_flags_host_);
 }
@@ -656,7 +656,8 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
     FSGPU_TRY(ensure_query_dimension(query_len));
     if (nq == 0) return ok();
     constexpr uint32_t GMAX = 128;    // queries per pass: 128, or 64 for small batches / tails
-    constexpr uint32_t CAPQ = 8192;   // candidate slots per query (= the merge kernel's single-sort capacity)
+    constexpr uint32_t CAPQ = 8192;   // entries one selection pass covers: block lists + pool fit it at the wide shape
+    constexpr uint32_t SPILL = 4096;  // per-query overflow area for candidates that did not fit their block's list
     constexpr uint32_t KC = kSelectPool;  // approximate candidates re-scored exactly (at most)
     uint32_t RA = 4096;               // stage A sample rows (dense; <= 8192)
     uint32_t RB = 131072;             // stage B sample rows (upper bound; shrinks with the slab, see below)
@@ -688,7 +689,7 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
     FSGPU_TRY(mf_qh_.reserve((size_t)GMAX * dim_ * 2));
     FSGPU_TRY(mf_delta_.reserve(GMAX * 4));
     FSGPU_TRY(mf_tau_.reserve(GMAX * 4));
-    FSGPU_TRY(mf_cand_.reserve((size_t)GMAX * CAPQ * 8));
+    FSGPU_TRY(mf_spill_.reserve((size_t)GMAX * SPILL * 8 + (size_t)GMAX * kMfmaSpillCountStride * 4));
     FSGPU_TRY(mf_dense_.reserve((size_t)GMAX * RA_MAX * 8));
     FSGPU_TRY(mf_sel_.reserve((size_t)GMAX * KC * 8));
     if (mf_shape_ < 0) {
@@ -716,7 +717,8 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
     std::memset(mf_flags_host_, 0, (size_t)mf_flags_cap_ * 8);
     float* delta = static_cast<float*>(mf_delta_.ptr);
     float* tau = static_cast<float*>(mf_tau_.ptr);
-    u64* cand = static_cast<u64*>(mf_cand_.ptr);
+    u64* spill = static_cast<u64*>(mf_spill_.ptr);
+    uint32_t* spill_count = reinterpret_cast<uint32_t*>(spill + (size_t)GMAX * SPILL);
     u64* pool = static_cast<u64*>(mf_sel_.ptr);
     const uint32_t k_eff = std::min<uint32_t>(k, N);
     for (uint32_t g0 = 0; g0 < nq;) {
@@ -737,6 +739,13 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
         uint32_t* cand_counts = counts_all + g0;
         FSGPU_HIP(launch_prepare_queries(qg, ng, G, dim_, static_cast<const unsigned int*>(mf_max_norm_.ptr), mf_qh_.ptr,
                                          delta, stream));
+        // one candidate list of `slots` entries per (query, block); 16..32 slots, sized so that lists + pool fit one
+        // selection pass when the grid allows (the wide shape's 256 blocks do)
+        auto slots_for = [&](int grid) {
+            return std::min<uint32_t>(kMfmaMaxSlots, std::max<uint32_t>(16, (CAPQ - KC) / (uint32_t)grid));
+        };
+        FSGPU_TRY(mf_cand_.reserve((size_t)G * full_grid * kMfmaMaxSlots * 8));
+        u64* cand = static_cast<u64*>(mf_cand_.ptr);
         MfmaScanArgs a{};
         a.slab = slab_dev_;
         a.live = reinterpret_cast<const u64*>(live_dev_);
@@ -744,6 +753,9 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
         a.queries = mf_qh_.ptr;
         a.tau = tau;
         a.cand = cand;
+        a.spill = spill;
+        a.spill_count = spill_count;
+        a.spill_cap = SPILL;
         a.overflow = overflow;
         a.dim = dim_;
         a.row_base = (uint32_t)row_base_;
@@ -775,7 +787,8 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
         a.group_stride = stride_b;
         a.group_count = groups_b;
         const int grid_b = grid_for(RB, tile_rows);
-        a.slots = std::min<uint32_t>(kMfmaMaxSlots, (CAPQ - KC) / (uint32_t)grid_b);
+        a.slots = slots_for(grid_b);
+        FSGPU_HIP(hipMemsetAsync(spill_count, 0, (size_t)G * kMfmaSpillCountStride * 4, stream));
         FSGPU_HIP(launch_scan_mfma(a, shape, grid_b, stream, nullptr));
         SelectArgs sb{};
         sb.lists = cand;
@@ -786,13 +799,17 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
         sb.k = k;
         sb.delta = delta;
         sb.overflow = overflow;
+        sb.spill = spill;
+        sb.spill_count = spill_count;
+        sb.spill_cap = SPILL;
         {
             sb.tau_out = tau;
             sb.pool_out = pool;
             FSGPU_HIP(launch_select(sb, (int)G, stream));
             // stage C: every group the B sample did not cover
             a.stage = 2;
-            a.slots = std::min<uint32_t>(kMfmaMaxSlots, (CAPQ - KC) / (uint32_t)full_grid);
+            a.slots = slots_for(full_grid);
+            FSGPU_HIP(hipMemsetAsync(spill_count, 0, (size_t)G * kMfmaSpillCountStride * 4, stream));
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (profiling) {
                 FSGPU_HIP(hipEventCreate(&e0));
@@ -837,6 +854,17 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
     std::vector<uint32_t> fb;
     for (uint32_t i = 0; i < nq; ++i)
         if (overflow_all[i] || counts_all[i] < k_eff) fb.push_back(i);
+    if (std::getenv("FSGPU_DEBUG_BATCHED")) {
+        uint32_t big = 0, slot = 0, few = 0, mx = 0;
+        for (uint32_t i = 0; i < nq; ++i) {
+            if (counts_all[i] > KC) ++big;
+            else if (overflow_all[i]) ++slot;
+            if (counts_all[i] < k_eff) ++few;
+            mx = std::max(mx, counts_all[i]);
+        }
+        std::fprintf(stderr, "[fsgpu batched] nq=%u k=%u fallbacks=%zu  pool_overflow=%u  slot_or_skip=%u  few=%u  max_cand=%u\n", nq, k,
+                     fb.size(), big, slot, few, mx);
+    }
     const uint32_t total_fallbacks = (uint32_t)fb.size();
     if (total_fallbacks) {
         // compact the uncertified queries, answer them with the exact kernels (8 per pass), scatter the hits back

@@ -119,7 +119,7 @@ class VectorIndex {
     DeviceBuffer ws_partial_, ws_queries_, ws_allow_, ws_rows_, ws_scores_, ws_counts_, ws_keys_a_, ws_keys_b_,
         ws_sort_tmp_, ws_gather_rows_, ws_gather_out_, i8_slab_, i8_max_, ws_i8_query_, ws_cand_packed_,
         ws_cand_rows_, ws_cand_scores_, mf_max_norm_, mf_qh_, mf_delta_, mf_tau_, mf_cand_, mf_dense_, mf_sel_,
-        mf_fallback_;
+        mf_fallback_, mf_spill_;
     bool i8_ready_ = false;
     bool mf_norm_ready_ = false;
     int mf_shape_ = -1, mf_per_cu_narrow_ = 1, mf_per_cu_wide_ = 1;  // batched-scan launch shapes (probed once)

@@ -44,6 +44,9 @@ class Model2VecEmbedder:
         check(_lib.lib().fsgpu_m2v_embed(self._h, flat.ctypes.data, offsets.ctypes.data, n, out.ctypes.data))
         return out
 
+    def set_coalescing(self, max_batch: int, max_wait_us: int = 100) -> None:
+        check(_lib.lib().fsgpu_m2v_set_coalescing(self._h, max_batch, max_wait_us))
+
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:
             _lib.lib().fsgpu_m2v_destroy(self._h)
@@ -142,6 +145,9 @@ class NativeEmbedder:
         out = np.empty((n, self._dim), dtype=np.float32)
         check(_lib.lib().fsgpu_bert_embed(self._h, flat.ctypes.data, offsets.ctypes.data, n, out.ctypes.data))
         return out
+
+    def set_coalescing(self, max_batch: int, max_wait_us: int = 200) -> None:
+        check(_lib.lib().fsgpu_bert_set_coalescing(self._h, max_batch, max_wait_us))
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:

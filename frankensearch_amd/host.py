@@ -1,0 +1,156 @@
+"""ctypes binding of libfshost.so — the C++ host-side mirror of the reference's two-phase searcher
+(include/fshost.h; crates/frankensearch-fusion/src/sync_searcher.rs:616-943) and its native load generator.
+
+libfshost.so contains no GPU code: it calls only the C ABI of libfsgpu.so, from native threads, the way the Rust
+host of INTEGRATION.md would."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .errors import check
+from .fusion import FusedHit
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfshost.so")
+DOC_ID_MAX = 63
+
+
+class _Config(C.Structure):
+    _fields_ = [("quality_weight", C.c_float), ("rrf_k", C.c_double), ("candidate_multiplier", C.c_uint32),
+                ("doc_id_mode", C.c_int32)]
+
+
+class _Hit(C.Structure):
+    _fields_ = [("doc_id", C.c_char * (DOC_ID_MAX + 1)), ("rrf_score", C.c_double), ("lexical_rank", C.c_int64),
+                ("semantic_rank", C.c_int64), ("semantic_index", C.c_uint32), ("lexical_score", C.c_float),
+                ("semantic_score", C.c_float), ("in_both_sources", C.c_uint8)]
+
+
+class _Metrics(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("fast_embed_ms", "fast_search_ms", "phase1_total_ms", "quality_embed_ms",
+                                          "quality_search_ms", "blend_ms", "phase2_total_ms")]
+
+
+class _ScoredDoc(C.Structure):
+    _fields_ = [("doc_id", C.c_char_p), ("doc_id_len", C.c_uint32), ("score", C.c_float), ("index", C.c_uint32)]
+
+
+class _LoadConfig(C.Structure):
+    _fields_ = [("threads", C.c_uint32), ("queries", C.c_uint32), ("warmup_queries", C.c_uint32), ("k", C.c_uint32),
+                ("fast_vocab", C.c_uint32), ("quality_vocab", C.c_uint32), ("corpus_rows", C.c_uint64), ("seed", C.c_uint64)]
+
+
+class _LoadResult(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "wall_seconds", "queries_per_sec", "phase0_p50_ms", "phase0_p95_ms", "phase0_p99_ms", "phase1_p50_ms",
+        "phase1_p95_ms", "phase1_p99_ms", "mean_fast_embed_ms", "mean_fast_search_ms", "mean_quality_embed_ms",
+        "mean_quality_search_ms", "mean_fusion_ms")] + [("completed", C.c_uint64), ("failed", C.c_uint64),
+                                                  ("first_error", C.c_char * 160)]
+
+
+SYMBOLS = ("fshost_two_tier_create", "fshost_two_tier_destroy", "fshost_two_tier_search", "fshost_run_load")
+_handle = None
+
+
+def lib() -> C.CDLL:
+    global _handle
+    if _handle is None:
+        _lib.lib()  # libfsgpu.so first (and its loud failure when missing)
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `python -m frankensearch_amd.build`")
+        h = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        h.fshost_two_tier_create.restype = C.c_int32
+        h.fshost_two_tier_create.argtypes = [C.c_void_p] * 4 + [C.POINTER(_Config), C.POINTER(C.c_void_p)]
+        h.fshost_two_tier_destroy.restype = None
+        h.fshost_two_tier_destroy.argtypes = [C.c_void_p]
+        h.fshost_two_tier_search.restype = C.c_int32
+        h.fshost_two_tier_search.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
+                                             C.POINTER(_ScoredDoc), C.c_uint32, C.POINTER(_Hit), C.POINTER(C.c_uint32),
+                                             C.POINTER(_Hit), C.POINTER(C.c_uint32), C.POINTER(_Metrics)]
+        h.fshost_run_load.restype = C.c_int32
+        h.fshost_run_load.argtypes = [C.c_void_p, C.POINTER(_LoadConfig), C.POINTER(_LoadResult)]
+        _handle = h
+    return _handle
+
+
+@dataclass
+class LoadResult:
+    wall_seconds: float
+    queries_per_sec: float
+    phase0_p50_ms: float
+    phase0_p95_ms: float
+    phase0_p99_ms: float
+    phase1_p50_ms: float
+    phase1_p95_ms: float
+    phase1_p99_ms: float
+    mean_fast_embed_ms: float
+    mean_fast_search_ms: float
+    mean_quality_embed_ms: float
+    mean_quality_search_ms: float
+    mean_fusion_ms: float
+    completed: int
+    failed: int
+    first_error: str = ""
+
+
+def _fused(h: _Hit) -> FusedHit:
+    return FusedHit(h.doc_id.decode(), h.rrf_score, None if h.lexical_rank < 0 else int(h.lexical_rank),
+                    None if h.semantic_rank < 0 else int(h.semantic_rank),
+                    None if h.semantic_index == 0xFFFFFFFF else int(h.semantic_index),
+                    h.lexical_score if h.lexical_rank >= 0 else None,
+                    h.semantic_score if h.semantic_rank >= 0 else None, bool(h.in_both_sources))
+
+
+class NativeTwoTierSearcher:
+    """SyncTwoTierSearcher in C++ over the C ABI (doc_id_mode: 0 = FSVI doc-id tables, 1 = "doc-%08u" of the row)."""
+
+    def __init__(self, fast_index, quality_index, fast_embedder, quality_embedder, quality_weight: float = 0.7,
+                 rrf_k: float = 60.0, candidate_multiplier: int = 3, doc_id_mode: int = 0):
+        self._keep = (fast_index, quality_index, fast_embedder, quality_embedder)
+        cfg = _Config(quality_weight, rrf_k, candidate_multiplier, doc_id_mode)
+        h = C.c_void_p()
+        check(lib().fshost_two_tier_create(fast_index._h, quality_index._h, fast_embedder._h, quality_embedder._h,
+                                           C.byref(cfg), C.byref(h)))
+        self._h = h
+
+    def search(self, fast_token_ids: Sequence[int], quality_token_ids: Sequence[int], k: int,
+               lexical: Optional[Sequence[Tuple[str, float]]] = None):
+        f = np.ascontiguousarray(fast_token_ids, dtype=np.uint32)
+        q = np.ascontiguousarray(quality_token_ids, dtype=np.int32)
+        lex = list(lexical or [])
+        ids = [d.encode() for d, _ in lex]
+        arr = (_ScoredDoc * max(len(lex), 1))()
+        for i, (b, (_, s)) in enumerate(zip(ids, lex)):
+            arr[i] = _ScoredDoc(b, len(b), s, 0)
+        ini, fin = (_Hit * max(k, 1))(), (_Hit * max(k, 1))()
+        ni, nf, m = C.c_uint32(), C.c_uint32(), _Metrics()
+        check(lib().fshost_two_tier_search(self._h, f.ctypes.data, f.size, q.ctypes.data, q.size, k, arr, len(lex), ini,
+                                           C.byref(ni), fin, C.byref(nf), C.byref(m)))
+        metrics = {n: getattr(m, n) for n, _ in _Metrics._fields_}
+        return [_fused(ini[i]) for i in range(ni.value)], [_fused(fin[i]) for i in range(nf.value)], metrics
+
+    def run_load(self, threads: int, queries: int, warmup_queries: int, k: int, fast_vocab: int, corpus_rows: int,
+                 quality_vocab: int = 30000, seed: int = 1) -> LoadResult:
+        cfg = _LoadConfig(threads, queries, warmup_queries, k, fast_vocab, quality_vocab, corpus_rows, seed)
+        res = _LoadResult()
+        check(lib().fshost_run_load(self._h, C.byref(cfg), C.byref(res)))
+        d = {n: getattr(res, n) for n, _ in _LoadResult._fields_}
+        d["first_error"] = d["first_error"].decode(errors="replace")
+        return LoadResult(**d)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().fshost_two_tier_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -231,6 +231,15 @@ class VectorIndex:
         check(_lib.lib().fsgpu_index_scan_stats(self._h, C.byref(ms), C.byref(n), C.byref(rows), int(reset)))
         return ms.value, n.value, rows.value
 
+    def set_coalescing(self, max_batch: int, max_wait_us: int = 200) -> None:
+        """Gather concurrent single-query `search_top_k` callers into one batched pass (0 = off)."""
+        check(_lib.lib().fsgpu_index_set_coalescing(self._h, max_batch, max_wait_us))
+
+    def coalescing_stats(self) -> Tuple[int, int]:
+        b, r = C.c_uint64(), C.c_uint64()
+        check(_lib.lib().fsgpu_index_coalescing_stats(self._h, C.byref(b), C.byref(r)))
+        return b.value, r.value
+
     def set_variant(self, variant: int) -> None:
         check(_lib.lib().fsgpu_index_set_variant(self._h, variant))
 

@@ -244,6 +244,19 @@ fsgpu_status fsgpu_rrf_fuse(const fsgpu_scored_doc *lexical, uint32_t n_lexical,
 fsgpu_status fsgpu_blend_two_tier(const fsgpu_scored_doc *fast, uint32_t n_fast, const fsgpu_scored_doc *quality,
                                   uint32_t n_quality, float blend_factor, fsgpu_scored_doc *out, uint32_t *out_count);
 
+/* ---- dynamic batching of concurrent callers ---- */
+/* The reference's seams are per-query calls made by many host threads at once (VectorIndex::search_top_k takes &self,
+ * crates/frankensearch-index/src/search.rs:192; SyncEmbed::embed_sync, crates/frankensearch-core/src/traits.rs:401-582;
+ * the MiniLM backends serialise callers on a mutex, crates/frankensearch-rerank/src/native_embedder.rs:40-50).  With
+ * coalescing enabled, single-item calls that are in flight together (fsgpu_search_topk with nq = 1, no allow bitmap,
+ * k <= 64; fsgpu_m2v_embed / fsgpu_bert_embed with n = 1) are gathered into one batched launch: up to max_batch
+ * items, waiting at most max_wait_us for the batch to fill.  Results are bit-identical to the unbatched calls.
+ * max_batch = 0 turns it off (the default).  No threads are created: the first waiting caller runs the batch. */
+fsgpu_status fsgpu_index_set_coalescing(fsgpu_index *idx, uint32_t max_batch, uint32_t max_wait_us);
+fsgpu_status fsgpu_index_coalescing_stats(fsgpu_index *idx, uint64_t *batches, uint64_t *requests);
+fsgpu_status fsgpu_m2v_set_coalescing(fsgpu_m2v *m, uint32_t max_batch, uint32_t max_wait_us);
+fsgpu_status fsgpu_bert_set_coalescing(fsgpu_bert *m, uint32_t max_batch, uint32_t max_wait_us);
+
 /* ---- instrumentation ---- */
 /* When enabled, HIP events bracket the scan kernel of every fsgpu_search_topk* call. */
 fsgpu_status fsgpu_index_set_profiling(fsgpu_index *idx, int32_t enabled);

@@ -1,0 +1,90 @@
+/* fshost.h — host-side mirror of the reference's two-phase searcher, written in C++ over the fsgpu C ABI.
+ *
+ * The reference's host is Rust and no Rust toolchain exists in this environment, so the code that would sit above
+ * libfsgpu.so in a real deployment (crates/frankensearch-fusion/src/sync_searcher.rs:616-943, the SyncTwoTierSearcher
+ * flow; fsfs shape crates/frankensearch-fsfs/src/runtime.rs:8185-8355) is restated here in C++, calling ONLY the
+ * functions declared in fsgpu.h — exactly what the Rust shim of INTEGRATION.md would call.  It exists so that the
+ * end-to-end metric (queries/sec and phase-0 / phase-1 latency with many concurrent callers) can be measured from
+ * native threads, the way a multi-threaded Rust host drives the library.  libfshost.so has no GPU code of its own.
+ */
+#ifndef FSHOST_H
+#define FSHOST_H
+
+#include "fsgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fshost_two_tier fshost_two_tier;
+
+/* TwoTierConfig defaults: crates/frankensearch-core/src/config.rs:169-176. */
+typedef struct fshost_two_tier_config {
+    float quality_weight;          /* 0.7 */
+    double rrf_k;                  /* 60 */
+    uint32_t candidate_multiplier; /* 3 */
+    int32_t doc_id_mode;           /* 0 = the indexes' FSVI doc-id tables (fsgpu_index_doc_id); 1 = "doc-%08u" of the row */
+} fshost_two_tier_config;
+
+#define FSHOST_DOC_ID_MAX 63
+/* FusedHit (crates/frankensearch-core/src/types.rs:3892-3925) with the doc id copied out. */
+typedef struct fshost_hit {
+    char doc_id[FSHOST_DOC_ID_MAX + 1]; /* NUL-terminated */
+    double rrf_score;
+    int64_t lexical_rank, semantic_rank; /* -1 when absent */
+    uint32_t semantic_index;             /* 0xffffffff when absent */
+    float lexical_score, semantic_score;
+    uint8_t in_both_sources;
+} fshost_hit;
+
+/* TwoTierMetrics (crates/frankensearch-core/src/config.rs:465-480); milliseconds. */
+typedef struct fshost_metrics {
+    double fast_embed_ms, fast_search_ms, phase1_total_ms; /* library name of the Initial stage */
+    double quality_embed_ms, quality_search_ms, blend_ms, phase2_total_ms;
+} fshost_metrics;
+
+/* The handles stay owned by the caller and must outlive the searcher. */
+fsgpu_status fshost_two_tier_create(fsgpu_index *fast_index, fsgpu_index *quality_index, fsgpu_m2v *fast_embedder,
+                                    fsgpu_bert *quality_embedder, const fshost_two_tier_config *config,
+                                    fshost_two_tier **out);
+void fshost_two_tier_destroy(fshost_two_tier *s);
+
+/* SyncTwoTierSearcher::search (sync_searcher.rs:616-943): phase 0 = fast embed -> fast-tier top-(k*mult) -> RRF with
+ * the lexical list; phase 1 = quality embed -> quality-tier top-(k*mult) -> blend_two_tier -> RRF again.
+ * initial_out / final_out hold k entries each.  Thread-safe: any number of concurrent callers. */
+fsgpu_status fshost_two_tier_search(fshost_two_tier *s, const uint32_t *fast_token_ids, uint32_t n_fast_ids,
+                                    const int32_t *quality_token_ids, uint32_t n_quality_ids, uint32_t k,
+                                    const fsgpu_scored_doc *lexical, uint32_t n_lexical, fshost_hit *initial_out,
+                                    uint32_t *n_initial, fshost_hit *final_out, uint32_t *n_final,
+                                    fshost_metrics *metrics);
+
+/* Closed-loop load generator: `threads` native threads each issue fshost_two_tier_search calls back to back on
+ * synthetic queries (SURVEY §8d config 5 shapes: fast ids uniform in [0, fast_vocab), 4-23 tokens; quality ids
+ * [CLS] + uniform [1000, quality_vocab) + [SEP], 8-32 tokens; stub lexical list of 3k "doc-%08u" ids), the way a
+ * multi-threaded host drives the per-query API. */
+typedef struct fshost_load_config {
+    uint32_t threads;
+    uint32_t queries;        /* timed queries in total */
+    uint32_t warmup_queries; /* untimed, in total */
+    uint32_t k;
+    uint32_t fast_vocab;
+    uint32_t quality_vocab;  /* quality ids are uniform in [1000, quality_vocab); 30000 for MiniLM's WordPiece table */
+    uint64_t corpus_rows;    /* for the stub lexical list */
+    uint64_t seed;
+} fshost_load_config;
+
+typedef struct fshost_load_result {
+    double wall_seconds, queries_per_sec;
+    double phase0_p50_ms, phase0_p95_ms, phase0_p99_ms; /* query start -> initial results */
+    double phase1_p50_ms, phase1_p95_ms, phase1_p99_ms; /* query start -> refined results */
+    double mean_fast_embed_ms, mean_fast_search_ms, mean_quality_embed_ms, mean_quality_search_ms, mean_fusion_ms;
+    uint64_t completed, failed;
+    char first_error[160];   /* detail of the first failed query, if any */
+} fshost_load_result;
+
+fsgpu_status fshost_run_load(fshost_two_tier *s, const fshost_load_config *config, fshost_load_result *result);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSHOST_H */

@@ -46,3 +46,102 @@ def test_two_tier_flow_matches_oracle_pipeline(oracle):
         assert [h.doc_id for h in out.final_results] == [h.doc_id for h in want_final]
         assert [h.rrf_score for h in out.final_results] == [h.rrf_score for h in want_final]
         assert out.metrics.phase2_total_ms > 0 and out.metrics.phase1_total_ms > 0
+
+
+def _small_two_tier(fa, rng, n=40000):
+    from frankensearch_amd.synthetic import random_bert_weights
+    fast_slab = rng.standard_normal((n, 256)).astype(np.float16).view(np.uint16)
+    qual_slab = rng.standard_normal((n, 384)).astype(np.float16).view(np.uint16)
+    table = rng.standard_normal((5000, 256)).astype(np.float32)
+    w = random_bert_weights(5, 3000, 384, 6, 1536)
+    return (fa.VectorIndex.from_slab(fast_slab), fa.VectorIndex.from_slab(qual_slab), fa.Model2VecEmbedder(table),
+            fa.NativeEmbedder(w))
+
+
+def test_native_host_searcher_equals_python_mirror():
+    # libfshost.so (C++ over the C ABI, native threads) must deliver exactly what the Python mirror does
+    import frankensearch_amd as fa
+    from frankensearch_amd.build import build
+    from frankensearch_amd.host import NativeTwoTierSearcher
+    from frankensearch_amd.two_tier import SyncTwoTierSearcher, TwoTierConfig
+
+    build()
+    rng = np.random.default_rng(11)
+    n = 40000
+    fast, qual, m2v, bert = _small_two_tier(fa, rng, n)
+    doc = lambda r: f"doc-{r:08d}"
+    py = SyncTwoTierSearcher(fast, qual, m2v, bert, doc, TwoTierConfig())
+    native = NativeTwoTierSearcher(fast, qual, m2v, bert, doc_id_mode=1)
+    for trial in range(6):
+        fast_ids = rng.integers(0, 5000, int(rng.integers(1, 20))).tolist()
+        qual_ids = [101] + rng.integers(1000, 3000, int(rng.integers(2, 25))).tolist() + [102]
+        lexical = [(doc(int(r)), float(30 - i)) for i, r in enumerate(rng.choice(n, 30, replace=False))]
+        if trial == 5:
+            lexical = []
+        want = py.search(fast_ids, qual_ids, 10, lexical)
+        ini, fin, metrics = native.search(fast_ids, qual_ids, 10, lexical)
+        assert ini == want.initial_results
+        assert fin == want.final_results
+        assert metrics["phase2_total_ms"] > 0
+
+
+def test_coalesced_concurrent_callers_get_identical_results():
+    # many threads calling the per-query ABI at once are served by shared batched passes; every caller must still get
+    # exactly the answer the unbatched call gives
+    import threading
+
+    import frankensearch_amd as fa
+    from frankensearch_amd.build import build
+
+    build()
+    rng = np.random.default_rng(13)
+    n, dim = 120_000, 384
+    slab = rng.standard_normal((n, dim)).astype(np.float16).view(np.uint16)
+    idx = fa.VectorIndex.from_slab(slab)
+    nq = 96
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    want = [idx.search_batch(q[i], 10 if i % 3 else 7) for i in range(nq)]
+    idx.set_coalescing(64, 20_000)
+    got = [None] * nq
+    errs = []
+
+    def call(i):
+        try:
+            got[i] = idx.search_batch(q[i], 10 if i % 3 else 7)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=call, args=(i,)) for i in range(nq)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(nq):
+        for a, b in zip(got[i], want[i]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), i
+    batches, requests = idx.coalescing_stats()
+    assert requests == nq and batches < nq // 2, (batches, requests)
+    idx.set_coalescing(0, 0)
+
+
+def test_native_load_generator_runs_with_coalescing():
+    import frankensearch_amd as fa
+    from frankensearch_amd.build import build
+    from frankensearch_amd.host import NativeTwoTierSearcher
+
+    build()
+    rng = np.random.default_rng(17)
+    fast, qual, m2v, bert = _small_two_tier(fa, rng, 40000)
+    for h, mb, wait in ((fast, 128, 300), (qual, 128, 300)):
+        h.set_coalescing(mb, wait)
+    m2v.set_coalescing(256, 100)
+    bert.set_coalescing(256, 300)
+    native = NativeTwoTierSearcher(fast, qual, m2v, bert, doc_id_mode=1)
+    res = native.run_load(threads=64, queries=640, warmup_queries=64, k=10, fast_vocab=5000, corpus_rows=40000,
+                          quality_vocab=3000)
+    assert res.completed == 640 and res.failed == 0, res.first_error
+    assert res.queries_per_sec > 0 and res.phase1_p50_ms >= res.phase0_p50_ms > 0
+    b, r = qual.coalescing_stats()
+    assert r >= 640 and b < r
