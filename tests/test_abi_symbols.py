@@ -30,6 +30,26 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in _lib.lib().fsgpu_version()
 
 
+def test_host_library_exports_every_declared_symbol_and_has_no_device_code():
+    # libfshost.so (include/fshost.h): the C++ host-side mirror; it must export its ABI, link libfsgpu.so and carry no
+    # GPU code object of its own
+    import ctypes
+    import subprocess
+    from frankensearch_amd import host
+    from frankensearch_amd.build import build
+
+    build()
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "fshost.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(fshost_[a-z0-9_]+)\s*\(", text)))
+    assert set(names) == set(host.SYMBOLS)
+    L = host.lib()
+    for name in names:
+        assert hasattr(L, name), f"{name} declared in include/fshost.h but not exported"
+    needed = subprocess.check_output(["readelf", "-d", host.LIB_PATH]).decode()
+    assert "libfsgpu.so" in needed
+    assert "libamdhip64" not in needed, "the host mirror must reach the GPU only through the fsgpu C ABI"
+
+
 def test_scan_kernel_has_no_fused_multiply_add():
     """The scan must issue separate v_mul/v_add (reference order, simd.rs:398-446): check the ISA."""
     import subprocess
