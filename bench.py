@@ -222,6 +222,36 @@ def int8_section(index, rows: int, dim: int, k: int, queries):
             "recall_at_k_vs_exact": recall / (8 * k)}
 
 
+def mrl_section(index, rows: int, dim: int, k: int, queries):
+    """MRL truncated scan (mrl.rs): the kernel reads the first search_dims of every row — N*search_dims*2 bytes."""
+    q = queries[:24].cpu().numpy()
+    out = {}
+    for sd in (128,):
+        exact = [set(index.search_batch(q[i], k)[0][0].tolist()) for i in range(8)]
+        index.scan_stats(reset=True)
+        index.set_profiling(True)
+        lat, hit = [], 0
+        for i in range(24):
+            t0 = time.perf_counter()
+            hits = index.mrl_search(q[i], k, search_dims=sd)
+            lat.append((time.perf_counter() - t0) * 1e3)
+            if i < 8:
+                hit += len(exact[i] & {h.index for h in hits})
+        index.set_profiling(False)
+        ms, launches, _ = index.scan_stats(reset=True)
+        per = ms / max(launches, 1)
+        alg = rows * sd * 2
+        lat = sorted(lat[4:])
+        out[f"search_dims_{sd}"] = {
+            "p50_latency_ms": lat[len(lat) // 2], "pass1_kernel_ms": per, "algorithmic_bytes": alg,
+            "pass1_GBps": alg / (per * 1e-3) / 1e9 if per > 0 else 0.0,
+            "pass1_frac_of_hbm_peak": alg / (per * 1e-3) / 1e9 / HBM_PEAK_GBPS if per > 0 else 0.0,
+            "recall_at_k_vs_exact": hit / (8 * k),
+            "note": "synthetic corpus is not Matryoshka-trained: recall here only shows the plumbing",
+        }
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -367,6 +397,7 @@ def main() -> None:
             line["p50_latency_ms_single_query"] = lat[len(lat) // 2]
         if world == 1 and not args.no_two_tier:
             line["int8_two_pass"] = int8_section(index, args.rows, args.dim, k, queries)
+            line["mrl"] = mrl_section(index, args.rows, args.dim, k, queries)
             tt = two_tier_section(index, args.rows, k, device, local_rank)
             line["two_tier"] = tt
             line["p50_phase1_latency_ms"] = tt["phase1_p50_ms"]

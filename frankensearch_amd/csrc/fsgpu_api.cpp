@@ -417,6 +417,29 @@ fsgpu_status fsgpu_search_hits(fsgpu_index* idx, const float* query, uint32_t qu
     });
 }
 
+// VectorIndex::mrl_search_with_stats (mrl.rs:241-395)
+fsgpu_status fsgpu_search_mrl(fsgpu_index* idx, const float* query, uint32_t query_len, uint32_t k, uint32_t search_dims,
+                              uint32_t rescore_dims, uint32_t rescore_top_k, uint32_t* out_rows, float* out_scores,
+                              uint32_t* out_count, fsgpu_mrl_stats* stats) {
+    if (!idx || !query || !out_count) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    *out_count = 0;
+    if (k && (!out_rows || !out_scores)) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        fsgpu::VectorIndex::MrlStats st;
+        const fsgpu_status rc = finish(idx->impl.mrl_search(query, query_len, k, search_dims, rescore_dims, rescore_top_k,
+                                                            out_rows, out_scores, out_count, &st));
+        if (stats) {
+            stats->scan_dims = st.scan_dims;
+            stats->rescore_dims = st.rescore_dims;
+            stats->candidates_rescored = st.candidates_rescored;
+            stats->records_scanned = st.records_scanned;
+            stats->fell_back_to_full = st.fell_back_to_full ? 1 : 0;
+        }
+        return rc;
+    });
+}
+
 // VectorIndex::search_top_k_int8_two_pass (search.rs:514-661)
 fsgpu_status fsgpu_search_topk_int8_two_pass(fsgpu_index* idx, const float* query, uint32_t query_len, uint32_t k,
                                              uint32_t candidate_multiplier, uint32_t* out_rows, float* out_scores,

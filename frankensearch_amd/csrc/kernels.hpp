@@ -20,6 +20,7 @@ struct ScanArgs {
     uint32_t k;
     uint32_t row_base;      // added to local rows (shard offset)
     int32_t hreduce;        // FSGPU_HREDUCE_*
+    uint32_t row_stride;    // bytes between rows (>= dim*2); the MRL truncated scan reads a prefix of every row
 };
 
 struct MergeArgs {

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs args) {
     const uint32_t nwaves = gridDim.x * kWavesPerBlock;
     const uint32_t wave_gid = blockIdx.x * kWavesPerBlock + wave;
     const unsigned char* slab = reinterpret_cast<const unsigned char*>(args.slab);
-    const size_t row_bytes = (size_t)dim * 2;
+    const size_t row_bytes = args.row_stride;
     const int k = (int)args.k;
     const int hreduce = args.hreduce;
     // lanes with a == 0 carry the candidates; those of query x sit at bit positions 4*NQ*r + 4*x
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void score_rows_generic_kernel(ScanArgs args, 
         out_packed[row] = kEmpty;
         return;
     }
-    const _Float16* hp = reinterpret_cast<const _Float16*>(args.slab) + (size_t)row * dim;
+    const _Float16* hp = reinterpret_cast<const _Float16*>(reinterpret_cast<const unsigned char*>(args.slab) + (size_t)row * args.row_stride);
     const float* q = args.queries + (size_t)q_index * dim;
     float s[4][8];
 #pragma unroll
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void score_rows_kernel(ScanArgs args, u64* out
     const uint32_t ntiles = (nrows + kRowsPerTile - 1) / kRowsPerTile;
     const uint32_t nwaves = gridDim.x * kWavesPerBlock;
     const unsigned char* slab = reinterpret_cast<const unsigned char*>(args.slab);
-    const size_t row_bytes = (size_t)dim * 2;
+    const size_t row_bytes = args.row_stride;
     const int chunks = dim >> 3, groups = chunks >> 2, leftover = chunks & 3;
     for (uint32_t tile = blockIdx.x * kWavesPerBlock + wave; tile < ntiles; tile += nwaves) {
         const uint32_t row = tile * kRowsPerTile + r;
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void gather_dot_kernel(ScanArgs args, const ui
     const int chunks = dim >> 3, groups = chunks >> 2, leftover = chunks & 3;
     float s;
     if ((dim & 7) == 0) {
-        const u32x4* p = reinterpret_cast<const u32x4*>(slab + (size_t)row * dim * 2);
+        const u32x4* p = reinterpret_cast<const u32x4*>(slab + (size_t)row * args.row_stride);
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void gather_dot_kernel(ScanArgs args, const ui
         s = quad_finish(acc, args.hreduce);
     } else {
         // unaligned rows: lane a still owns accumulator a, element loads
-        const _Float16* hp = reinterpret_cast<const _Float16*>(slab) + (size_t)row * dim;
+        const _Float16* hp = reinterpret_cast<const _Float16*>(slab + (size_t)row * args.row_stride);
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;

@@ -469,6 +469,7 @@ ScanArgs VectorIndex::base_args(const float* queries_dev, const uint64_t* allow_
     a.k = 0;
     a.row_base = (uint32_t)row_base_;
     a.hreduce = hreduce;
+    a.row_stride = row_stride_ ? row_stride_ : dim_ * 2;
     return a;
 }
 
@@ -482,7 +483,7 @@ SearchError VectorIndex::fused_search(const float* queries_dev, uint32_t nq, uin
         // queries per pass: 8 / 4 through the multi-query kernel, else 2 / 1 through the register-resident kernel
         int pass = left >= 2 ? 2 : 1;
         bool mq = false;
-        if (variant != 3 && variant != 1) {
+        if (variant != 3 && variant != 1 && (!row_stride_ || row_stride_ == dim_ * 2)) {
             if (left >= 8 && kcap == 64 && scan_mq_supported((int)dim_, 8, kcap)) {
                 pass = 8;
                 mq = true;
@@ -669,7 +670,8 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
     RB = std::min<uint32_t>(RB, std::max<uint32_t>(8 * RA, (uint32_t)(nrows_ / 64)));
     RB = std::min<uint32_t>(RB, (uint32_t)(nrows_ / 4));
     RB = std::max<uint32_t>(RA, RB / RA * RA);
-    const bool usable = scan_mfma_supported((int)dim_) && k >= 1 && k <= 64 && nrows_ >= 4 * (uint64_t)RA && variant != 4;
+    const bool usable = scan_mfma_supported((int)dim_) && k >= 1 && k <= 64 && nrows_ >= 4 * (uint64_t)RA && variant != 4 &&
+                        (!row_stride_ || row_stride_ == dim_ * 2);
     if (!usable) {
         if (fallbacks) *fallbacks = nq;
         if (out_packed_dev) {
@@ -922,6 +924,125 @@ SearchError VectorIndex::search_top_k_batched(const float* queries, uint32_t nq,
     FSGPU_HIP(hipMemcpyAsync(out_scores, ws_scores_.ptr, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream_));
     FSGPU_HIP(hipMemcpyAsync(out_counts, ws_counts_.ptr, (size_t)nq * 4, hipMemcpyDeviceToHost, stream_));
     FSGPU_HIP(hipStreamSynchronize(stream_));
+    return ok();
+}
+
+// A strided view of this index: same slab, same live bitmap, rows read over their first `dims` dimensions only.
+VectorIndex* VectorIndex::mrl_view(uint32_t dims) {
+    auto it = views_.find(dims);
+    if (it == views_.end()) {
+        auto v = std::make_unique<VectorIndex>();
+        if (!v->init_device(device_, dims, nrows_, slab_dev_, live_dev_, row_base_).ok()) return nullptr;
+        v->row_stride_ = dim_ * 2;
+        it = views_.emplace(dims, std::move(v)).first;
+    }
+    VectorIndex* v = it->second.get();
+    v->slab_dev_ = slab_dev_;   // re-bind: the live bitmap may have been re-uploaded since the view was made
+    v->live_dev_ = live_dev_;
+    v->hreduce = hreduce;
+    v->profiling = profiling;
+    return v;
+}
+
+// VectorIndex::mrl_search_with_stats (crates/frankensearch-index/src/mrl.rs:241-395).
+SearchError VectorIndex::mrl_search(const float* query, uint32_t query_len, uint32_t k, uint32_t search_dims,
+                                    uint32_t rescore_dims, uint32_t rescore_top_k, uint32_t* out_rows, float* out_scores,
+                                    uint32_t* out_count, MrlStats* stats) {
+    *out_count = 0;
+    MrlStats st;
+    FSGPU_TRY(ensure_query_dimension(query_len));
+    if (search_dims == 0) return make_error(FSGPU_ERR_INVALID_CONFIG, "search_dims must be at least 1");
+    if (search_dims >= dim_) {  // no truncation benefit: the standard search (mrl.rs:283-296)
+        st.scan_dims = st.rescore_dims = dim_;
+        st.records_scanned = nrows_ + wal_.size();
+        st.fell_back_to_full = true;
+        if (stats) *stats = st;
+        if (has_doc_ids()) return search_hits(query, query_len, k, out_rows, out_scores, out_count);
+        if (k == 0 || nrows_ == 0) return ok();
+        return search_top_k(query, 1, query_len, k, nullptr, out_rows, out_scores, out_count);
+    }
+    if (k == 0 || (nrows_ == 0 && wal_.empty())) {
+        if (stats) *stats = st;
+        return ok();
+    }
+    uint32_t rdims = (rescore_dims == 0 || rescore_dims > dim_) ? dim_ : rescore_dims;  // mrl.rs:92-105
+    if (rdims < search_dims) rdims = search_dims;
+    const uint64_t rtop64 = rescore_top_k ? rescore_top_k : (uint64_t)k * 3;             // mrl.rs:108-114
+    const uint32_t rtop = (uint32_t)std::min<uint64_t>(rtop64, 0x7fffffffull);
+    struct Cand {
+        uint64_t index;  // main row, or WAL-tagged (top bit, wal.rs:557-569)
+        float score;
+    };
+    const uint64_t wal_tag = 1ull << 63;
+    std::vector<Cand> cand;
+    // phase 1: truncated scan of the main rows on the GPU (prefix view), top rtop
+    if (nrows_ > 0) {
+        VectorIndex* view = mrl_view(search_dims);
+        if (!view) return make_error(FSGPU_ERR_DEVICE, "cannot create the truncated view");
+        std::vector<uint32_t> rows(rtop);  // search_top_k pads every query's output to k entries
+        std::vector<float> scores(rtop);
+        uint32_t count = 0;
+        FSGPU_TRY(view->search_top_k(query, 1, search_dims, rtop, nullptr, rows.data(), scores.data(), &count));
+        for (uint32_t i = 0; i < count; ++i) cand.push_back(Cand{rows[i], scores[i]});
+        // the view's timed launches count as this index's (fsgpu_index_scan_stats)
+        for (auto& ev : view->events_) events_.push_back(ev);
+        view->events_.clear();
+        profiled_rows_ += view->profiled_rows_;
+        view->profiled_rows_ = 0;
+    }
+    // resident WAL entries: truncated f32 dot, non-finite scores skipped (mrl.rs:539-583)
+    for (size_t w = 0; w < wal_.size(); ++w) {
+        const float s = dot_f32_f32(wal_[w].embedding.data(), query, search_dims, hreduce);
+        if (!std::isfinite(s)) continue;
+        cand.push_back(Cand{wal_tag | w, s});
+    }
+    auto best_first = [](const Cand& a, const Cand& b) {
+        const uint32_t ka = host_score_ord(a.score), kb = host_score_ord(b.score);
+        if (ka != kb) return ka > kb;
+        return a.index < b.index;
+    };
+    std::sort(cand.begin(), cand.end(), best_first);
+    if (cand.size() > rtop) cand.resize(rtop);
+    st.scan_dims = search_dims;
+    st.rescore_dims = rdims;
+    st.candidates_rescored = (uint32_t)cand.size();
+    st.records_scanned = nrows_ + wal_.size();
+    // phase 2: rescore over rdims (mrl.rs:587-618)
+    std::vector<uint32_t> main_rows;
+    for (const Cand& c : cand)
+        if (!(c.index & wal_tag)) main_rows.push_back((uint32_t)c.index);
+    std::vector<float> main_scores(main_rows.size());
+    if (!main_rows.empty()) {
+        if (rdims == dim_) {
+            FSGPU_TRY(gather_dot(query, dim_, main_rows.data(), (uint32_t)main_rows.size(), main_scores.data()));
+        } else {
+            VectorIndex* rv = mrl_view(rdims);
+            if (!rv) return make_error(FSGPU_ERR_DEVICE, "cannot create the rescore view");
+            FSGPU_TRY(rv->gather_dot(query, rdims, main_rows.data(), (uint32_t)main_rows.size(), main_scores.data()));
+        }
+    }
+    size_t mi = 0;
+    for (Cand& c : cand) {
+        if (c.index & wal_tag) c.score = dot_f32_f32(wal_[(size_t)(c.index & ~wal_tag)].embedding.data(), query, rdims, hreduce);
+        else c.score = main_scores[mi++];
+    }
+    std::sort(cand.begin(), cand.end(), best_first);
+    if (cand.size() > k) cand.resize(k);
+    // resolve_mrl_hits (mrl.rs:642-683): WAL hits at the virtual index, deleted rows dropped; no dedup, no shadowing
+    uint32_t n = 0;
+    for (const Cand& c : cand) {
+        if (c.index & wal_tag) {
+            out_rows[n] = (uint32_t)(nrows_ + (c.index & ~wal_tag));
+        } else {
+            const size_t r = (size_t)(c.index - row_base_);
+            if (!live_host_.empty() && !((live_host_[r >> 6] >> (r & 63)) & 1ull)) continue;
+            out_rows[n] = (uint32_t)c.index;
+        }
+        out_scores[n] = c.score;
+        ++n;
+    }
+    *out_count = n;
+    if (stats) *stats = st;
     return ok();
 }
 

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -78,6 +80,16 @@ class VectorIndex {
     // exact f16 rescore of the k*multiplier candidates; falls back to the exact search when a WAL is resident.
     SearchError search_top_k_int8_two_pass(const float* query, uint32_t query_len, uint32_t k, uint32_t multiplier,
                                            uint32_t* out_rows, float* out_scores, uint32_t* out_count);
+    // VectorIndex::mrl_search_with_stats (crates/frankensearch-index/src/mrl.rs:241-395): truncated scan over the first
+    // search_dims dimensions (a strided view of the same slab), resident WAL entries, rescore over rescore_dims, top-k.
+    struct MrlStats {
+        uint32_t scan_dims = 0, rescore_dims = 0, candidates_rescored = 0;
+        uint64_t records_scanned = 0;
+        bool fell_back_to_full = false;
+    };
+    SearchError mrl_search(const float* query, uint32_t query_len, uint32_t k, uint32_t search_dims, uint32_t rescore_dims,
+                           uint32_t rescore_top_k, uint32_t* out_rows, float* out_scores, uint32_t* out_count,
+                           MrlStats* stats);
     // VectorIndex::append (lib.rs:2532-2720): resident WAL entry, immediately searchable.
     SearchError wal_append(const char* doc_id, uint32_t len, const float* vector, uint32_t vector_len);
     uint64_t wal_record_count() const { return wal_.size(); }
@@ -91,6 +103,7 @@ class VectorIndex {
     int32_t hreduce = 0;
     int32_t variant = 0;
     bool profiling = false;
+    VectorIndex* mrl_view(uint32_t dims);  // strided prefix view of this slab (created on first use)
     SearchError scan_time(double* total_ms, uint64_t* launches, uint64_t* rows, bool reset);
 
   private:
@@ -110,6 +123,8 @@ class VectorIndex {
     uint32_t dim_ = 0;
     uint64_t nrows_ = 0;
     uint64_t row_base_ = 0;
+    uint32_t row_stride_ = 0;  // bytes between rows; dim_*2 except for the MRL prefix views
+    std::map<uint32_t, std::unique_ptr<VectorIndex>> views_;  // strided prefix views of this slab, by dimension
     const void* slab_dev_ = nullptr;
     const uint64_t* live_dev_ = nullptr;
     bool owns_slab_ = false;

@@ -47,6 +47,11 @@ def pack_bitmap(mask: np.ndarray) -> np.ndarray:
     return np.packbits(padded, bitorder="little").view(np.uint64).copy()
 
 
+class _MrlStats(C.Structure):
+    _fields_ = [("scan_dims", C.c_uint32), ("rescore_dims", C.c_uint32), ("candidates_rescored", C.c_uint32),
+                ("records_scanned", C.c_uint64), ("fell_back_to_full", C.c_int32)]
+
+
 class VectorIndex:
     def __init__(self, handle: int, keepalive=None):
         self._h = C.c_void_p(handle)
@@ -185,6 +190,28 @@ class VectorIndex:
                                                       C.byref(n), C.byref(z)))
         hits = [VectorHit(int(rows[i]), float(scores[i])) for i in range(n.value)]
         return ClassifiedHits(hits, _ZERO_SIGNAL.get(z.value))
+
+    def mrl_search(self, query: Sequence[float], limit: int, search_dims: int = 64, rescore_dims: int = 0,
+                   rescore_top_k: int = 0, with_stats: bool = False):
+        """VectorIndex::mrl_search / mrl_search_with_stats (mrl.rs:241-395; MrlConfig defaults :79-87)."""
+        q = np.ascontiguousarray(query, dtype=np.float32).reshape(-1)
+        cap = max(limit, 1)
+        rows = np.empty(cap, dtype=np.uint32)
+        scores = np.empty(cap, dtype=np.float32)
+        n = C.c_uint32()
+        st = _MrlStats()
+        check(_lib.lib().fsgpu_search_mrl(self._h, _ptr(q), q.size, limit, search_dims, rescore_dims, rescore_top_k,
+                                          _ptr(rows), _ptr(scores), C.byref(n), C.addressof(st)))
+        ids = self._has_doc_ids()
+        nrec = self.record_count if not callable(self.record_count) else self.record_count()
+        hits = [VectorHit(int(rows[i]), float(scores[i]),
+                          self.doc_id_at(int(rows[i])) if ids and int(rows[i]) < nrec else None)
+                for i in range(n.value)]
+        if with_stats:
+            return hits, {"scan_dims": st.scan_dims, "rescore_dims": st.rescore_dims,
+                          "candidates_rescored": st.candidates_rescored, "records_scanned": st.records_scanned,
+                          "fell_back_to_full": bool(st.fell_back_to_full)}
+        return hits
 
     def search_top_k_int8_two_pass(self, query: Sequence[float], k: int, candidate_multiplier: int = 3
                                    ) -> List[VectorHit]:

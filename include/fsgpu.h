@@ -244,6 +244,24 @@ fsgpu_status fsgpu_rrf_fuse(const fsgpu_scored_doc *lexical, uint32_t n_lexical,
 fsgpu_status fsgpu_blend_two_tier(const fsgpu_scored_doc *fast, uint32_t n_fast, const fsgpu_scored_doc *quality,
                                   uint32_t n_quality, float blend_factor, fsgpu_scored_doc *out, uint32_t *out_count);
 
+/* ---- MRL: truncated scan + full-dimension rescore ---- */
+/* MrlSearchStats (crates/frankensearch-index/src/mrl.rs:122-139). */
+typedef struct fsgpu_mrl_stats {
+    uint32_t scan_dims, rescore_dims, candidates_rescored;
+    uint64_t records_scanned;
+    int32_t fell_back_to_full;
+} fsgpu_mrl_stats;
+/* VectorIndex::mrl_search_with_stats (mrl.rs:241-395) with MrlConfig{search_dims, rescore_dims, rescore_top_k}
+ * (:55-115; 0 = full dimension / 3*k): phase 1 scores only the first search_dims dimensions of every live row (the
+ * kernel reads that prefix of each row: N*search_dims*2 bytes instead of N*dim*2) and keeps the top rescore_top_k,
+ * resident WAL entries join with their truncated f32 dot; phase 2 re-scores the candidates over rescore_dims and
+ * returns the best k, best first (WAL hits at the virtual index record_count + i; no doc-id dedup, as the reference).
+ * search_dims >= dimension falls back to the standard search; search_dims == 0 is FSGPU_ERR_INVALID_CONFIG.
+ * out_rows / out_scores hold k entries; stats may be NULL. */
+fsgpu_status fsgpu_search_mrl(fsgpu_index *idx, const float *query, uint32_t query_len, uint32_t k, uint32_t search_dims,
+                              uint32_t rescore_dims, uint32_t rescore_top_k, uint32_t *out_rows, float *out_scores,
+                              uint32_t *out_count, fsgpu_mrl_stats *stats);
+
 /* ---- dynamic batching of concurrent callers ---- */
 /* The reference's seams are per-query calls made by many host threads at once (VectorIndex::search_top_k takes &self,
  * crates/frankensearch-index/src/search.rs:192; SyncEmbed::embed_sync, crates/frankensearch-core/src/traits.rs:401-582;

@@ -626,6 +626,58 @@ size_t fso_search_int8_two_pass(const uint8_t *slab, const int8_t *slab_i8, uint
     return outn;
 }
 
+/* VectorIndex::mrl_search_with_stats (crates/frankensearch-index/src/mrl.rs:241-395): truncated scan over the first
+ * search_dims dimensions keeping the top rescore_top_k (0 = 3 * limit) under (nan_safe(score) desc, index asc)
+ * (:160-207, :468-537), resident WAL entries scored with the truncated f32 dot and skipped when non-finite (:539-583),
+ * every candidate re-scored over rescore_dims (0 or > dim = full; never fewer than search_dims, :92-105) with the f16 dot
+ * on the row's leading bytes or the f32 dot for WAL entries (:587-618), sorted by (score desc, index asc), truncated to
+ * limit, WAL hits reported at the virtual index nrows + i (:642-683).  No doc-id dedup and no WAL shadowing here.
+ * The caller handles search_dims >= dim (plain search_top_k) and limit == 0.  wal_vecs may be NULL. */
+size_t fso_mrl_search(const uint8_t *slab, uint64_t nrows, uint32_t dim, const uint64_t *live, const float *const *wal_vecs,
+                      size_t wal_len, const float *q, size_t limit, size_t search_dims, size_t rescore_dims,
+                      size_t rescore_top_k, int hreduce, uint32_t *out_rows, float *out_scores) {
+    if (limit == 0 || (nrows == 0 && wal_len == 0) || search_dims == 0 || search_dims >= dim) return 0;
+    size_t rdims = (rescore_dims == 0 || rescore_dims > dim) ? dim : rescore_dims;
+    if (rdims < search_dims) rdims = search_dims;
+    size_t rtop = rescore_top_k ? rescore_top_k : limit * 3;
+    const uint64_t wal_tag = 1ull << 63;
+    size_t stride = (size_t)dim * 2;
+    heap_t heap;
+    heap_init(&heap, rtop + 1);
+    float cutoff = -INFINITY;
+    for (uint64_t r = 0; r < nrows; ++r) {
+        if (!row_live(live, r)) continue;
+        float score = fso_dot_f16_f32(slab + r * stride, q, search_dims, hreduce);
+        if (heap.len < rtop || score_key(score) >= cutoff) {
+            entry_t e = {r, score};
+            insert_candidate(&heap, e, rtop);
+            if (heap.len >= rtop && heap.len > 0) cutoff = score_key(heap.v[0].score);
+        }
+    }
+    for (size_t w = 0; w < wal_len; ++w) {
+        float score = fso_dot_f32_f32(wal_vecs[w], q, search_dims, hreduce);
+        if (!isfinite(score)) continue;
+        entry_t e = {wal_tag | (uint64_t)w, score};
+        insert_candidate(&heap, e, rtop);
+    }
+    for (size_t i = 0; i < heap.len; ++i) {
+        uint64_t idx = heap.v[i].row;
+        if (idx & wal_tag) heap.v[i].score = fso_dot_f32_f32(wal_vecs[idx & ~wal_tag], q, rdims, hreduce);
+        else heap.v[i].score = fso_dot_f16_f32(slab + idx * stride, q, rdims, hreduce);
+    }
+    qsort(heap.v, heap.len, sizeof(entry_t), cmp_best_first);
+    size_t n = heap.len < limit ? heap.len : limit;
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t idx = heap.v[i].row;
+        out_rows[i] = (idx & wal_tag) ? (uint32_t)(nrows + (idx & ~wal_tag)) : (uint32_t)idx;
+        out_scores[i] = heap.v[i].score;
+    }
+    heap_free(&heap);
+    return n;
+}
+
+
+
 /* VectorIndex::dot_query_at (lib.rs:3229-3239) over a row list (two_tier.rs:1566-1631). */
 void fso_gather_dot(const uint8_t *slab, uint32_t dim, const float *q, const uint32_t *rows,
                     size_t n, int hreduce, float *out) {

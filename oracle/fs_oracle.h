@@ -152,6 +152,11 @@ void fso_clustered_query(uint64_t q, uint32_t dim, uint32_t clusters, float nois
 void fso_m2v_embed(const float *table, uint32_t vocab, uint32_t dim, const uint32_t *ids,
                    size_t n_ids, float *out);
 
+/* mrl.rs:241-395 — truncated scan + rescore (see fs_oracle.c). */
+size_t fso_mrl_search(const uint8_t *slab, uint64_t nrows, uint32_t dim, const uint64_t *live, const float *const *wal_vecs,
+                      size_t wal_len, const float *q, size_t limit, size_t search_dims, size_t rescore_dims,
+                      size_t rescore_top_k, int hreduce, uint32_t *out_rows, float *out_scores);
+
 #ifdef __cplusplus
 }
 #endif

@@ -190,6 +190,40 @@ def search_top_k(slab_u16: np.ndarray, q: np.ndarray, k: int, live: np.ndarray |
     return rows[:cnt].copy(), scores[:cnt].copy()
 
 
+def mrl_search(slab_u16: np.ndarray, q: np.ndarray, limit: int, search_dims: int, rescore_dims: int = 0,
+               rescore_top_k: int = 0, live: np.ndarray | None = None, wal: list | None = None,
+               hreduce: int = HREDUCE_SSE2):
+    """VectorIndex::mrl_search (mrl.rs:241-395): truncated scan + rescore.  `wal` = resident f32 embeddings; their hits
+    come back at the virtual index N + i.  Falls back to search_top_k when search_dims >= dim (mrl.rs:283-296) — only
+    valid here without WAL entries.  Returns (rows uint32[count], scores float32[count])."""
+    slab = np.ascontiguousarray(slab_u16, dtype=np.uint16)
+    n, dim = slab.shape
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    if q.size != dim:
+        raise ValueError(f"DimensionMismatch expected={dim} found={q.size}")
+    if search_dims == 0:
+        raise ValueError("InvalidConfig search_dims must be at least 1")
+    if search_dims >= dim:
+        assert not wal
+        return search_top_k(slab, q, limit, live=live, hreduce=hreduce)
+    wal = [np.ascontiguousarray(w, dtype=np.float32) for w in (wal or [])]
+    cap = max(1, limit)
+    rows = np.empty(cap, dtype=np.uint32)
+    scores = np.empty(cap, dtype=np.float32)
+    bm = None
+    if live is not None:
+        bm = live_bitmap(np.asarray(live, dtype=bool)) if live.dtype != np.uint64 else live
+    ptrs = (C.c_void_p * max(len(wal), 1))(*[w.ctypes.data for w in wal])
+    L = lib()
+    L.fso_mrl_search.restype = C.c_size_t
+    L.fso_mrl_search.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                 C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    cnt = L.fso_mrl_search(slab.ctypes.data, n, dim, bm.ctypes.data if bm is not None else None, ptrs, len(wal),
+                           q.ctypes.data, limit, search_dims, rescore_dims, rescore_top_k, hreduce, rows.ctypes.data,
+                           scores.ctypes.data)
+    return rows[:cnt].copy(), scores[:cnt].copy()
+
+
 def quantize_slab_i8(slab_u16: np.ndarray) -> np.ndarray:
     slab = np.ascontiguousarray(slab_u16, dtype=np.uint16)
     out = np.empty(slab.shape, dtype=np.int8)

@@ -458,3 +458,57 @@ def test_batched_mfma_wide_groups_topical_rows_and_filters(fa, oracle):
     for qi in (3, 4, 130, 199):
         orow, osc = oracle.search_top_k(slab, q[qi], 10)
         assert np.array_equal(br[qi], orow) and np.array_equal(bits(bs[qi]), bits(osc))
+
+
+@pytest.mark.gpu
+def test_mrl_search_matches_oracle(fa, oracle, tmp_path):
+    # VectorIndex::mrl_search (crates/frankensearch-index/src/mrl.rs:241-395): truncated scan over a strided prefix of
+    # every row + rescore; rows and score bits must equal the oracle's for every MrlConfig shape
+    rng = np.random.default_rng(101)
+    n, dim = 30_011, 384
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    rows[:, :64] *= 3.0                                   # Matryoshka-like: the leading dimensions carry the signal
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    rows[500] = rows[20]                                  # exact duplicate: tie broken by the lower row
+    slab = rows.astype(np.float16).view(np.uint16)
+    live = rng.random(n) > 0.1
+    idx = fa.VectorIndex.from_slab(slab, live=live)
+    for qi in range(4):
+        q = rows[rng.integers(0, n)] + 0.1 * rng.standard_normal(dim).astype(np.float32)
+        for sd, rd, rt, k in ((64, 0, 0, 10), (128, 0, 0, 10), (256, 0, 0, 7), (20, 0, 0, 10), (64, 200, 0, 10),
+                              (128, 64, 0, 5), (64, 0, 500, 10), (8, 0, n, 10), (64, 0, 0, 1), (384, 0, 0, 10),
+                              (999, 0, 0, 10)):
+            er, es = oracle.mrl_search(slab, q, k, sd, rd, rt, live=live)
+            hits, st = idx.mrl_search(q, k, sd, rd, rt, with_stats=True)
+            assert [h.index for h in hits] == er.tolist(), (qi, sd, rd, rt, k)
+            assert np.array_equal(bits([h.score for h in hits]), bits(es)), (qi, sd, rd, rt, k)
+            assert st["fell_back_to_full"] == (sd >= dim)
+            if sd < dim:
+                assert st["scan_dims"] == sd and st["rescore_dims"] == max(sd, rd if 0 < rd <= dim else dim)
+                assert st["candidates_rescored"] == min(rt if rt else 3 * k, int(live.sum()))
+    assert idx.mrl_search(q, 0, 64) == []
+    with pytest.raises(fa.InvalidConfig):
+        idx.mrl_search(q, 10, 0)
+    with pytest.raises(fa.DimensionMismatch):
+        idx.mrl_search(q[:100], 10, 64)
+    # FSVI file with resident WAL entries and a tombstone (mrl.rs:1162-1221)
+    rows40 = [(f"doc-{i:03}", rng.standard_normal(40).astype(np.float32)) for i in range(200)]
+    p = str(tmp_path / "mrl.fsvi")
+    oracle.fsvi_write(p, [(d, v.tolist()) for d, v in rows40])
+    g = fa.VectorIndex.open(p)
+    o = oracle.Fsvi(p)
+    wal = []
+    for j in range(6):
+        v = rng.standard_normal(40).astype(np.float32)
+        g.append(f"new-{j}", v)
+        wal.append(v)
+    g.soft_delete(g.doc_id_at(17))
+    oslab = o.slab()          # rows in file order (sorted by doc-id hash), as the GPU index holds them
+    live2 = np.ones(200, bool)
+    live2[17] = False
+    for sd, k in ((8, 5), (16, 12), (24, 3), (16, 300)):
+        q = rng.standard_normal(40).astype(np.float32)
+        er, es = oracle.mrl_search(oslab, q, k, sd, live=live2, wal=wal)
+        hits = g.mrl_search(q, k, sd)
+        assert [h.index for h in hits] == er.tolist() and np.array_equal(bits([h.score for h in hits]), bits(es))
+        assert all(h.doc_id is not None for h in hits if h.index < 200)

@@ -501,3 +501,74 @@ def test_int8_two_pass_tombstones_and_small_n(oracle):
     r, s = oracle.search_int8_two_pass(slab, q, 100, 3, live=live)     # candidate_count clamps to n
     er, es = oracle.search_top_k(slab, q, 100, live=live)
     assert np.array_equal(r, er) and np.array_equal(s.view(np.uint32), es.view(np.uint32))
+
+
+# ---- MRL truncated scan + rescore (crates/frankensearch-index/src/mrl.rs tests, restated) -------------------------
+def _f16(rows):
+    return np.asarray(rows, dtype=np.float32).astype(np.float16).view(np.uint16)
+
+
+def test_mrl_basic_top1_and_rescore_order(oracle):
+    # mrl_search_returns_correct_top_1 (mrl.rs:739-772)
+    dim = 16
+    slab = _f16([[1.0] * dim, [0.5] * dim, [0.1] * dim])
+    rows, scores = oracle.mrl_search(slab, np.ones(dim, np.float32), 1, search_dims=8)
+    assert rows.tolist() == [0] and scores[0] == 16.0
+    # mrl_results_ordered_by_rescore (mrl.rs:1351-1386): descending, scored over the FULL dimension
+    def signal(sig):
+        v = np.full(dim, 0.01, np.float32)
+        v[:8] = sig
+        return v / np.linalg.norm(v)
+    slab = _f16([signal(1.0), signal(0.7), signal(0.3)])
+    q = signal(1.0)
+    rows, scores = oracle.mrl_search(slab, q, 3, search_dims=4)
+    assert len(rows) == 3 and np.all(np.diff(scores) <= 0)
+    full = [oracle.dot_f16_f32(slab[r], q) for r in rows]
+    assert scores.tolist() == full
+
+
+def test_mrl_rescore_all_equals_exact_search(oracle):
+    # mrl_search_parallel_path_covers_all_records (mrl.rs:775-820): rescore_top_k = N is lossless
+    dim, n = 16, 12_000
+    i = np.arange(n)[:, None]
+    d = np.arange(dim)[None, :]
+    slab = _f16(((i * 31 + d * 7) % 97) / 97.0)
+    q = ((np.arange(dim) + 1.0) / 16.0).astype(np.float32)
+    mrl_rows, mrl_scores = oracle.mrl_search(slab, q, 10, search_dims=8, rescore_top_k=n)
+    ex_rows, ex_scores = oracle.search_top_k(slab, q, 10)
+    assert np.array_equal(mrl_rows, ex_rows) and np.array_equal(mrl_scores.view(np.uint32), ex_scores.view(np.uint32))
+
+
+def test_mrl_config_resolution_tombstones_wal_and_fallback(oracle):
+    dim = 16
+    slab = _f16([[1.0] * dim, [0.8] * dim, [0.5] * dim, [0.3] * dim])
+    q = np.ones(dim, np.float32)
+    # mrl_search_explicit_rescore_top_k (mrl.rs:1776-1806): only the two best truncated candidates are re-scored
+    rows, _ = oracle.mrl_search(slab, q, 2, search_dims=8, rescore_top_k=2)
+    assert rows.tolist() == [0, 1]
+    # mrl_search_explicit_rescore_dims (mrl.rs:1809-1835): scores are over 12 dims
+    two = _f16([[1.0] * dim, [0.5] * dim])
+    rows, scores = oracle.mrl_search(two, q, 2, search_dims=4, rescore_dims=12)
+    assert rows.tolist() == [0, 1] and scores.tolist() == [12.0, 6.0]
+    # effective_rescore_dims never drops below search_dims (mrl.rs:92-105)
+    _, scores = oracle.mrl_search(two, q, 2, search_dims=8, rescore_dims=4)
+    assert scores.tolist() == [8.0, 4.0]
+    # mrl_search_excludes_tombstoned (mrl.rs:1162-1191)
+    rows, _ = oracle.mrl_search(slab, q, 4, search_dims=8, live=np.array([False, True, True, True]))
+    assert rows.tolist() == [1, 2, 3]
+    # mrl_search_includes_wal_entries (mrl.rs:1194-1221): WAL hits surface at the virtual index N + i
+    rows, scores = oracle.mrl_search(slab, q, 2, search_dims=8, wal=[np.full(dim, 2.0, np.float32)])
+    assert rows.tolist() == [4, 0] and scores.tolist() == [32.0, 16.0]
+    # a non-finite truncated WAL score is skipped (mrl.rs:563-567)
+    bad = np.full(dim, 2.0, np.float32)
+    bad[0] = np.inf
+    rows, _ = oracle.mrl_search(slab, q, 2, search_dims=8, wal=[bad])
+    assert rows.tolist() == [0, 1]
+    # search_dims >= dimension falls back to the plain search (mrl.rs:283-296); 0 is rejected (:272-278)
+    rows, scores = oracle.mrl_search(slab, q, 2, search_dims=16)
+    assert rows.tolist() == [0, 1] and scores[0] == 16.0
+    with pytest.raises(ValueError):
+        oracle.mrl_search(slab, q, 2, search_dims=0)
+    # non-aligned search_dims (mrl.rs:1060-1088): scalar tail
+    rows, scores = oracle.mrl_search(slab, q, 4, search_dims=5)
+    assert rows.tolist() == [0, 1, 2, 3]
