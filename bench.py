@@ -196,29 +196,33 @@ def two_tier_section(quality_index, rows: int, k: int, device, local_rank: int):
     return res
 
 
-def int8_section(index, rows: int, dim: int, k: int, queries):
-    """The reference's production fast-tier path (search_top_k_int8_two_pass, multiplier 3) on the same corpus:
-    pass-1 int8 scan (N*dim bytes) + exact f16 rescore.  Sequential single queries, host-pointer ABI."""
+def quantized_section(index, rows: int, dim: int, k: int, queries, bits: int, mult: int):
+    """Two-pass searches of the reference on the same corpus: quantised pass-1 scan + exact f16 rescore.
+    bits 8 = search_top_k_int8_two_pass (the production fast-tier path, multiplier 3; N*dim bytes per pass),
+    bits 4 = search_top_k_4bit_two_pass (multiplier 5 as the reference's bench; N*dim/2 bytes).
+    Sequential single queries, host-pointer ABI."""
+    fn = index.search_top_k_int8_two_pass if bits == 8 else index.search_top_k_4bit_two_pass
     q = queries[:24].cpu().numpy()
-    index.search_top_k_int8_two_pass(q[0], k, 3)   # builds the int8 slab (lazy, once)
+    fn(q[0], k, mult)   # builds the quantised slab (lazy, once)
     index.set_profiling(True)
     index.scan_time(reset=True)
     lat = []
     for i in range(24):
         t0 = time.perf_counter()
-        index.search_top_k_int8_two_pass(q[i], k, 3)
+        fn(q[i], k, mult)
         lat.append((time.perf_counter() - t0) * 1e3)
     index.set_profiling(False)
     scan_ms, launches, scan_rows = index.scan_stats(reset=True)
     lat = sorted(lat[4:])
     per = scan_ms / max(launches, 1)
-    gbps = rows * dim / (per * 1e-3) / 1e9 if per > 0 else 0.0
+    alg = rows * dim * bits // 8
+    gbps = alg / (per * 1e-3) / 1e9 if per > 0 else 0.0
     recall = 0
     for i in range(8):
         exact = {h.index for h in index.search_top_k(q[i], k)}
-        recall += len(exact & {h.index for h in index.search_top_k_int8_two_pass(q[i], k, 3)})
-    return {"p50_latency_ms": lat[len(lat) // 2], "pass1_kernel_ms": per, "pass1_GBps": gbps,
-            "pass1_frac_of_hbm_peak": gbps / HBM_PEAK_GBPS, "algorithmic_bytes": rows * dim,
+        recall += len(exact & {h.index for h in fn(q[i], k, mult)})
+    return {"candidate_multiplier": mult, "p50_latency_ms": lat[len(lat) // 2], "pass1_kernel_ms": per, "pass1_GBps": gbps,
+            "pass1_frac_of_hbm_peak": gbps / HBM_PEAK_GBPS, "algorithmic_bytes": alg,
             "recall_at_k_vs_exact": recall / (8 * k)}
 
 
@@ -396,7 +400,8 @@ def main() -> None:
         if lat:
             line["p50_latency_ms_single_query"] = lat[len(lat) // 2]
         if world == 1 and not args.no_two_tier:
-            line["int8_two_pass"] = int8_section(index, args.rows, args.dim, k, queries)
+            line["int8_two_pass"] = quantized_section(index, args.rows, args.dim, k, queries, 8, 3)
+            line["fourbit_two_pass"] = quantized_section(index, args.rows, args.dim, k, queries, 4, 5)
             line["mrl"] = mrl_section(index, args.rows, args.dim, k, queries)
             tt = two_tier_section(index, args.rows, k, device, local_rank)
             line["two_tier"] = tt

@@ -417,6 +417,20 @@ fsgpu_status fsgpu_search_hits(fsgpu_index* idx, const float* query, uint32_t qu
     });
 }
 
+// VectorIndex::search_top_k_4bit_two_pass (search.rs:876-946)
+fsgpu_status fsgpu_search_topk_4bit_two_pass(fsgpu_index* idx, const float* query, uint32_t query_len, uint32_t k,
+                                             uint32_t candidate_multiplier, uint32_t* out_rows, float* out_scores,
+                                             uint32_t* out_count) {
+    if (!idx || !query || !out_count) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    *out_count = 0;
+    if (k && (!out_rows || !out_scores)) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.search_top_k_4bit_two_pass(query, query_len, k, candidate_multiplier, out_rows,
+                                                           out_scores, out_count));
+    });
+}
+
 // VectorIndex::mrl_search_with_stats (mrl.rs:241-395)
 fsgpu_status fsgpu_search_mrl(fsgpu_index* idx, const float* query, uint32_t query_len, uint32_t k, uint32_t search_dims,
                               uint32_t rescore_dims, uint32_t rescore_top_k, uint32_t* out_rows, float* out_scores,

@@ -10,6 +10,10 @@
 // lane chunks, quad-reduced with DPP adds.  Converting the i32 dot to f32 is exact up to dim 1040 and is exactly
 // the reference's `score as f32` key beyond, so the same packed-f32 top-k machinery as the f16 scan serves both
 // branches.  HBM traffic is N*dim bytes per pass — half of the f16 scan.
+//
+// The 4-bit two-pass (search_top_k_4bit_two_pass, search.rs:860-1000; simd.rs:1286-1556, 1886-1900, 2153-2215) is the
+// same shape on a quarter of the bytes: packed signed nibbles (corpus-wide scale 7/max_abs), v_dot8_i32_i4, then the
+// exact f16 rescore.  The kernels below are templated on the element width.
 #include "scan_common.hpp"
 
 namespace fsgpu {
@@ -29,6 +33,14 @@ __device__ __forceinline__ signed char quant_i8(float x, float scale) {
     if (v != v) return 0;         // Rust `as i8` maps NaN to 0
     v = fminf(fmaxf(v, -127.0f), 127.0f);
     return (signed char)(int)v;
+}
+
+// nibble_of_4bit (simd.rs:1892-1896): round half away from zero, clamp +-7, NaN -> 0, two's complement low nibble
+__device__ __forceinline__ uint32_t quant_nibble(float x, float scale) {
+    float v = roundf(x * scale);
+    if (v != v) return 0u;
+    v = fminf(fmaxf(v, -7.0f), 7.0f);
+    return (uint32_t)(int)v & 0xFu;
 }
 
 }  // namespace
@@ -76,12 +88,48 @@ __global__ __launch_bounds__(256) void quantize_slab_i8_kernel(const unsigned sh
             out[i] = zero ? (signed char)0 : quant_i8((float)__builtin_bit_cast(_Float16, slab[i]), scale);
 }
 
-// Pass 1, fused with the wave top-k (dim % 64 == 0).  A lane is (row r, quarter a): chunk c = 4g+a is 16 int8.
-template <int DIM, int KCAP>
+// pack_f16_le_bytes_to_4bit (simd.rs:2153-2215): scale 7/max_abs (0 when max_abs <= 1e-9), low nibble = even dim.
+// Even dims: 8 values -> one 32-bit word anywhere in the slab (rows are whole bytes).
+__global__ __launch_bounds__(256) void pack_slab_4bit_kernel(const unsigned short* __restrict__ slab, uint64_t count,
+                                                             uint32_t dim, const unsigned int* __restrict__ max_bits,
+                                                             unsigned char* __restrict__ out) {
+    const float max_abs = __uint_as_float(*max_bits);
+    const float scale = max_abs > 1e-9f ? 7.0f / max_abs : 0.f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    if ((dim & 7) == 0) {
+        const size_t nvec = (size_t)count * dim / 8;
+        const u32x4* v = reinterpret_cast<const u32x4*>(slab);
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+            const half8 h = __builtin_bit_cast(half8, v[i]);
+            uint32_t w = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w |= quant_nibble((float)h[j], scale) << (4 * j);
+            reinterpret_cast<uint32_t*>(out)[i] = w;
+        }
+    } else {  // any dim: one thread per output byte, rows padded to ceil(dim/2) bytes
+        const uint32_t bpv = (dim + 1) / 2;
+        const size_t nbytes = (size_t)count * bpv;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes; i += stride) {
+            const size_t row = i / bpv;
+            const uint32_t d = (uint32_t)(i - row * bpv) * 2;
+            const unsigned short* p = slab + row * dim + d;
+            uint32_t b = quant_nibble((float)__builtin_bit_cast(_Float16, p[0]), scale);
+            if (d + 1 < dim) b |= quant_nibble((float)__builtin_bit_cast(_Float16, p[1]), scale) << 4;
+            out[i] = (unsigned char)b;
+        }
+    }
+}
+
+// Pass 1, fused with the wave top-k (row bytes % 64 == 0).  A lane is (row r, quarter a): chunk c = 4g+a is 16 bytes
+// = 16 int8 (BITS 8, v_dot4_i32_i8) or 32 signed nibbles (BITS 4, v_dot8_i32_i4; both operands use the same
+// low-nibble-first packing, so nibble j of a word meets nibble j of the query word).
+template <int DIM, int KCAP, int BITS = 8>
 __global__ __launch_bounds__(256) void scan_i8_topk_kernel(ScanArgs args, const signed char* __restrict__ slab_i8,
                                                            const signed char* __restrict__ query_i8) {
     constexpr int CAP = 2 * KCAP;
-    constexpr int G = DIM / 64;
+    constexpr int ROW_BYTES = DIM * BITS / 8;
+    constexpr int G = ROW_BYTES / 64;
+    static_assert(ROW_BYTES % 64 == 0, "row must be a whole number of 64-byte quad steps");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* bufs = reinterpret_cast<u64*>(smem);  // [wave][CAP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, a = lane & 3, r = lane >> 2;
@@ -99,7 +147,7 @@ __global__ __launch_bounds__(256) void scan_i8_topk_kernel(ScanArgs args, const 
     auto load_tile = [&](uint32_t tile, i32x4 (&w)[G]) {
         uint32_t row = tile * kRowsPerTile + r;
         row = row < nrows ? row : nrows - 1;
-        const i32x4* p = reinterpret_cast<const i32x4*>(slab_i8 + (size_t)row * DIM) + a;
+        const i32x4* p = reinterpret_cast<const i32x4*>(slab_i8 + (size_t)row * ROW_BYTES) + a;
 #pragma unroll
         for (int g = 0; g < G; ++g) w[g] = p[4 * g];
     };
@@ -113,7 +161,9 @@ __global__ __launch_bounds__(256) void scan_i8_topk_kernel(ScanArgs args, const 
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_sdot4(w[g][j], q[g][j], acc, false);
+            for (int j = 0; j < 4; ++j)
+                acc = BITS == 8 ? __builtin_amdgcn_sdot4(w[g][j], q[g][j], acc, false)
+                                : __builtin_amdgcn_sdot8(w[g][j], q[g][j], acc, false);
         const int dot = quad_sum_i32(acc);
         const uint32_t row = tile * kRowsPerTile + r;
         bool valid = row < nrows && a == 0;
@@ -193,6 +243,30 @@ __global__ __launch_bounds__(256) void score_rows_i8_kernel(ScanArgs args, const
     out_packed[row] = pack((float)dot, args.row_base + row);
 }
 
+// General 4-bit pass 1: one packed entry per row (any dim).  dot_4bit_prepared_generic semantics (simd.rs:1519-1546).
+__global__ __launch_bounds__(256) void score_rows_4bit_kernel(ScanArgs args, const unsigned char* __restrict__ slab_4bit,
+                                                              const unsigned char* __restrict__ query_4bit,
+                                                              u64* __restrict__ out_packed) {
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= args.nrows) return;
+    bool valid = true;
+    if (args.live) valid = valid && ((args.live[row >> 6] >> (row & 63)) & 1ull);
+    if (args.allow) valid = valid && ((args.allow[row >> 6] >> (row & 63)) & 1ull);
+    if (!valid) {
+        out_packed[row] = kEmpty;
+        return;
+    }
+    const uint32_t bpv = (args.dim + 1) / 2;
+    const unsigned char* p = slab_4bit + (size_t)row * bpv;
+    int dot = 0;
+    for (uint32_t i = 0; i < bpv; ++i) {
+        const int sl = (int)(((p[i] & 0xF) ^ 8) - 8), sh = (int)(((p[i] >> 4) ^ 8) - 8);
+        const int ql = (int)(((query_4bit[i] & 0xF) ^ 8) - 8), qh = (int)(((query_4bit[i] >> 4) ^ 8) - 8);
+        dot += sl * ql + sh * qh;
+    }
+    out_packed[row] = pack((float)dot, args.row_base + row);
+}
+
 // rows of packed entries -> u32 row ids (kEmpty -> 0xffffffff)
 __global__ void packed_rows_kernel(const u64* __restrict__ packed, uint32_t n, uint32_t* __restrict__ rows) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -218,6 +292,67 @@ hipError_t launch_quantize_slab_i8(const void* slab_f16, size_t n_values, unsign
     hipLaunchKernelGGL(quantize_slab_i8_kernel, dim3(grid), dim3(256), 0, stream,
                        static_cast<const unsigned short*>(slab_f16), n_values, max_bits_dev,
                        static_cast<signed char*>(out_i8));
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_slab_4bit(const void* slab_f16, uint64_t count, uint32_t dim, unsigned int* max_bits_dev,
+                                 void* out_4bit, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(max_bits_dev, 0, 4, stream);
+    if (e != hipSuccess) return e;
+    const int grid = 2048;
+    hipLaunchKernelGGL(slab_maxabs_kernel, dim3(grid), dim3(256), 0, stream, static_cast<const unsigned short*>(slab_f16),
+                       (size_t)count * dim, max_bits_dev);
+    hipLaunchKernelGGL(pack_slab_4bit_kernel, dim3(grid), dim3(256), 0, stream,
+                       static_cast<const unsigned short*>(slab_f16), count, dim, max_bits_dev,
+                       static_cast<unsigned char*>(out_4bit));
+    return hipGetLastError();
+}
+
+bool scan_4bit_fused_supported(int dim, int kcap) {
+    return (dim == 128 || dim == 256 || dim == 384 || dim == 512 || dim == 768) && (kcap == 64 || kcap == 256);
+}
+
+template <int DIM, int KCAP>
+static hipError_t launch_4bit_t(const ScanArgs& args, const void* slab_4bit, const void* query_4bit, int grid,
+                                hipStream_t stream, int* occupancy) {
+    const size_t lds = (size_t)kWavesPerBlock * 2 * KCAP * 8;
+    auto kern = scan_i8_topk_kernel<DIM, KCAP, 4>;
+    if (occupancy) {
+        int blocks = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, 256, lds) != hipSuccess || blocks < 1) blocks = 1;
+        *occupancy = blocks;
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, args, static_cast<const signed char*>(slab_4bit),
+                       static_cast<const signed char*>(query_4bit));
+    return hipGetLastError();
+}
+
+template <int KCAP>
+static hipError_t launch_4bit_dim(const ScanArgs& args, const void* slab, const void* query, int grid, hipStream_t stream,
+                                  int* occupancy) {
+    switch (args.dim) {
+        case 128: return launch_4bit_t<128, KCAP>(args, slab, query, grid, stream, occupancy);
+        case 256: return launch_4bit_t<256, KCAP>(args, slab, query, grid, stream, occupancy);
+        case 384: return launch_4bit_t<384, KCAP>(args, slab, query, grid, stream, occupancy);
+        case 512: return launch_4bit_t<512, KCAP>(args, slab, query, grid, stream, occupancy);
+        case 768: return launch_4bit_t<768, KCAP>(args, slab, query, grid, stream, occupancy);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_scan_4bit(const ScanArgs& args, const void* slab_4bit, const void* query_4bit, int kcap, int grid,
+                            hipStream_t stream, int* occupancy) {
+    if (kcap == 64) return launch_4bit_dim<64>(args, slab_4bit, query_4bit, grid, stream, occupancy);
+    if (kcap == 256) return launch_4bit_dim<256>(args, slab_4bit, query_4bit, grid, stream, occupancy);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_score_rows_4bit(const ScanArgs& args, const void* slab_4bit, const void* query_4bit, u64* out_packed,
+                                  hipStream_t stream) {
+    hipLaunchKernelGGL(score_rows_4bit_kernel, dim3((args.nrows + 255) / 256), dim3(256), 0, stream, args,
+                       static_cast<const unsigned char*>(slab_4bit), static_cast<const unsigned char*>(query_4bit),
+                       out_packed);
     return hipGetLastError();
 }
 

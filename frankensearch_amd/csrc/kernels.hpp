@@ -138,6 +138,14 @@ hipError_t launch_prepare_queries(const float* q, uint32_t nq, uint32_t nq_pad, 
 hipError_t launch_quantize_slab_i8(const void* slab_f16, size_t n_values, unsigned int* max_bits_dev, void* out_i8,
                                    hipStream_t stream);
 bool scan_i8_fused_supported(int dim, int kcap);
+// 4-bit two-pass (int8_kernels.hip, BITS = 4)
+hipError_t launch_pack_slab_4bit(const void* slab_f16, uint64_t count, uint32_t dim, unsigned int* max_bits_dev,
+                                 void* out_4bit, hipStream_t stream);
+bool scan_4bit_fused_supported(int dim, int kcap);
+hipError_t launch_scan_4bit(const ScanArgs& args, const void* slab_4bit, const void* query_4bit, int kcap, int grid,
+                            hipStream_t stream, int* occupancy);
+hipError_t launch_score_rows_4bit(const ScanArgs& args, const void* slab_4bit, const void* query_4bit, u64* out_packed,
+                                  hipStream_t stream);
 hipError_t launch_scan_i8(const ScanArgs& args, const void* slab_i8, const void* query_i8, int kcap, int grid,
                           hipStream_t stream, int* occupancy);
 hipError_t launch_score_rows_i8(const ScanArgs& args, const void* slab_i8, const void* query_i8, u64* out_packed,

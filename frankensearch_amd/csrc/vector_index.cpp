@@ -110,7 +110,7 @@ VectorIndex::~VectorIndex() {
     if (stream_) (void)hipStreamDestroy(stream_);
     for (DeviceBuffer* b : {&slab_own_, &live_own_, &ws_partial_, &ws_queries_, &ws_allow_, &ws_rows_, &ws_scores_,
                             &ws_counts_, &ws_keys_a_, &ws_keys_b_, &ws_sort_tmp_, &ws_gather_rows_, &ws_gather_out_,
-                            &i8_slab_, &i8_max_, &ws_i8_query_, &ws_cand_packed_, &ws_cand_rows_, &ws_cand_scores_,
+                            &i8_slab_, &n4_slab_, &i8_max_, &ws_i8_query_, &ws_cand_packed_, &ws_cand_rows_, &ws_cand_scores_,
                             &mf_max_norm_, &mf_qh_, &mf_delta_, &mf_tau_, &mf_cand_, &mf_dense_, &mf_sel_,
                             &mf_fallback_, &mf_spill_})
         b->release();
@@ -1050,6 +1050,20 @@ SearchError VectorIndex::mrl_search(const float* query, uint32_t query_len, uint
 SearchError VectorIndex::search_top_k_int8_two_pass(const float* query, uint32_t query_len, uint32_t k,
                                                     uint32_t multiplier, uint32_t* out_rows, float* out_scores,
                                                     uint32_t* out_count) {
+    return quantized_two_pass(query, query_len, k, multiplier, 8, out_rows, out_scores, out_count);
+}
+
+// search_top_k_4bit_two_pass (crates/frankensearch-index/src/search.rs:876-946)
+SearchError VectorIndex::search_top_k_4bit_two_pass(const float* query, uint32_t query_len, uint32_t k,
+                                                    uint32_t multiplier, uint32_t* out_rows, float* out_scores,
+                                                    uint32_t* out_count) {
+    return quantized_two_pass(query, query_len, k, multiplier, 4, out_rows, out_scores, out_count);
+}
+
+// Shared body of the int8 (bits = 8) and 4-bit (bits = 4) two-pass searches: quantised pass 1 over the lazily built
+// slab, exact f16 rescore of the candidates, best-first selection of k.
+SearchError VectorIndex::quantized_two_pass(const float* query, uint32_t query_len, uint32_t k, uint32_t multiplier,
+                                            int bits, uint32_t* out_rows, float* out_scores, uint32_t* out_count) {
     *out_count = 0;
     // anything the fast path does not cover goes through the exact search (search.rs:579-585)
     if (k == 0 || nrows_ == 0 || !wal_.empty()) {
@@ -1061,37 +1075,51 @@ SearchError VectorIndex::search_top_k_int8_two_pass(const float* query, uint32_t
     FSGPU_TRY(ensure_query_dimension(query_len));
     FSGPU_HIP(hipSetDevice(device_));
     const size_t n = (size_t)nrows_;
-    if (!i8_ready_) {  // VectorIndex::int8_slab() is built lazily, once
+    const uint32_t qbytes = bits == 8 ? dim_ : (dim_ + 1) / 2;  // quantised bytes per vector
+    if (bits == 8 && !i8_ready_) {  // VectorIndex::int8_slab() is built lazily, once
         FSGPU_TRY(i8_slab_.reserve(n * dim_));
         FSGPU_TRY(i8_max_.reserve(4));
         FSGPU_HIP(launch_quantize_slab_i8(slab_dev_, n * dim_, static_cast<unsigned int*>(i8_max_.ptr), i8_slab_.ptr,
                                           stream_));
         i8_ready_ = true;
     }
+    if (bits == 4 && !n4_ready_) {  // VectorIndex::nibbles_slab() (search.rs:988-1000)
+        FSGPU_TRY(n4_slab_.reserve(n * qbytes));
+        FSGPU_TRY(i8_max_.reserve(4));
+        FSGPU_HIP(launch_pack_slab_4bit(slab_dev_, nrows_, dim_, static_cast<unsigned int*>(i8_max_.ptr), n4_slab_.ptr,
+                                        stream_));
+        n4_ready_ = true;
+    }
+    const void* qslab = bits == 8 ? i8_slab_.ptr : n4_slab_.ptr;
     const uint64_t mult = multiplier ? multiplier : 1;
     uint64_t cc64 = std::min<uint64_t>((uint64_t)k * mult, nrows_);
     cc64 = std::max<uint64_t>(cc64, std::min<uint64_t>(k, nrows_));
     const uint32_t cc = (uint32_t)cc64;
     const uint32_t k_eff = (uint32_t)std::min<uint64_t>(k, nrows_);
-    // quantize_i8_query (search.rs:1616-1626): the query's own max-abs scale, round half away, clamp
-    std::vector<signed char> qi(dim_, 0);
+    // quantize_i8_query (search.rs:1616-1626) / pack_4bit_query (:1640-1653): the query's own max-abs scale, round half
+    // away from zero, clamp; NaN -> 0
+    std::vector<unsigned char> qi(qbytes, 0);
     {
         float max_abs = 0.f;
         for (uint32_t i = 0; i < dim_; ++i) {
             const float v = std::fabs(query[i]);
             if (v > max_abs) max_abs = v;
         }
-        if (max_abs > 0.f) {
-            const float scale = 127.0f / max_abs;
+        const float lim = bits == 8 ? 127.0f : 7.0f;
+        const bool usable = bits == 8 ? max_abs > 0.f : max_abs > 1e-9f;
+        const float scale = usable ? lim / max_abs : 0.f;
+        if (bits == 4 || usable) {
             for (uint32_t i = 0; i < dim_; ++i) {
                 float v = std::round(query[i] * scale);
                 if (v != v) v = 0.f;
-                v = std::min(std::max(v, -127.0f), 127.0f);
-                qi[i] = (signed char)(int)v;
+                v = std::min(std::max(v, -lim), lim);
+                const int qv = (int)v;
+                if (bits == 8) qi[i] = (unsigned char)(signed char)qv;
+                else qi[i / 2] |= (unsigned char)((qv & 0xF) << ((i & 1) ? 4 : 0));
             }
         }
     }
-    FSGPU_TRY(ws_i8_query_.reserve(dim_));
+    FSGPU_TRY(ws_i8_query_.reserve(qbytes));
     FSGPU_TRY(ws_queries_.reserve((size_t)dim_ * 4));
     FSGPU_TRY(ws_cand_packed_.reserve((size_t)cc * 8));
     FSGPU_TRY(ws_cand_rows_.reserve((size_t)cc * 4));
@@ -1099,7 +1127,7 @@ SearchError VectorIndex::search_top_k_int8_two_pass(const float* query, uint32_t
     FSGPU_TRY(ws_rows_.reserve((size_t)k * 4));
     FSGPU_TRY(ws_scores_.reserve((size_t)k * 4));
     FSGPU_TRY(ws_counts_.reserve(4));
-    FSGPU_HIP(hipMemcpyAsync(ws_i8_query_.ptr, qi.data(), dim_, hipMemcpyHostToDevice, stream_));
+    FSGPU_HIP(hipMemcpyAsync(ws_i8_query_.ptr, qi.data(), qbytes, hipMemcpyHostToDevice, stream_));
     FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, query, (size_t)dim_ * 4, hipMemcpyHostToDevice, stream_));
     ScanArgs a = base_args(static_cast<const float*>(ws_queries_.ptr), nullptr);
     u64* cand_packed = static_cast<u64*>(ws_cand_packed_.ptr);
@@ -1107,9 +1135,14 @@ SearchError VectorIndex::search_top_k_int8_two_pass(const float* query, uint32_t
     float* cand_scores = static_cast<float*>(ws_cand_scores_.ptr);
     // ---- pass 1: top-cc rows by the int8 dot ----
     const int kcap = cc <= 64 ? 64 : 256;
-    if (cc <= 256 && scan_i8_fused_supported((int)dim_, kcap)) {
+    auto launch_pass1 = [&](int grid, int* occ) {
+        return bits == 8 ? launch_scan_i8(a, qslab, ws_i8_query_.ptr, kcap, grid, stream_, occ)
+                         : launch_scan_4bit(a, qslab, ws_i8_query_.ptr, kcap, grid, stream_, occ);
+    };
+    const bool fused = bits == 8 ? scan_i8_fused_supported((int)dim_, kcap) : scan_4bit_fused_supported((int)dim_, kcap);
+    if (cc <= 256 && fused) {
         int per_cu = 1;
-        FSGPU_HIP(launch_scan_i8(a, i8_slab_.ptr, ws_i8_query_.ptr, kcap, 1, stream_, &per_cu));
+        FSGPU_HIP(launch_pass1(1, &per_cu));
         int grid = num_cus_ * per_cu;
         const int max_useful = (int)(((nrows_ + 15) / 16 + 3) / 4);
         if (grid > max_useful) grid = max_useful;
@@ -1123,7 +1156,7 @@ SearchError VectorIndex::search_top_k_int8_two_pass(const float* query, uint32_t
             FSGPU_HIP(hipEventCreate(&e1));
             FSGPU_HIP(hipEventRecord(e0, stream_));
         }
-        FSGPU_HIP(launch_scan_i8(a, i8_slab_.ptr, ws_i8_query_.ptr, kcap, grid, stream_, nullptr));
+        FSGPU_HIP(launch_pass1(grid, nullptr));
         if (profiling) {
             FSGPU_HIP(hipEventRecord(e1, stream_));
             events_.emplace_back(e0, e1);
@@ -1150,7 +1183,8 @@ SearchError VectorIndex::search_top_k_int8_two_pass(const float* query, uint32_t
         FSGPU_TRY(ws_sort_tmp_.reserve(tmp_bytes));
         u64* keys_a = static_cast<u64*>(ws_keys_a_.ptr);
         u64* keys_b = static_cast<u64*>(ws_keys_b_.ptr);
-        FSGPU_HIP(launch_score_rows_i8(a, i8_slab_.ptr, ws_i8_query_.ptr, keys_a, stream_));
+        if (bits == 8) FSGPU_HIP(launch_score_rows_i8(a, qslab, ws_i8_query_.ptr, keys_a, stream_));
+        else FSGPU_HIP(launch_score_rows_4bit(a, qslab, ws_i8_query_.ptr, keys_a, stream_));
         FSGPU_HIP(launch_packed_to_sortkey(keys_a, n, stream_));
         FSGPU_HIP(sort_keys_desc(ws_sort_tmp_.ptr, ws_sort_tmp_.bytes, keys_a, keys_b, n, stream_));
         FSGPU_HIP(launch_sorted_keys_to_rows(keys_b, cc, cand_rows, static_cast<uint32_t*>(ws_counts_.ptr), stream_));

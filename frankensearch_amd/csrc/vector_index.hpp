@@ -80,6 +80,10 @@ class VectorIndex {
     // exact f16 rescore of the k*multiplier candidates; falls back to the exact search when a WAL is resident.
     SearchError search_top_k_int8_two_pass(const float* query, uint32_t query_len, uint32_t k, uint32_t multiplier,
                                            uint32_t* out_rows, float* out_scores, uint32_t* out_count);
+    // VectorIndex::search_top_k_4bit_two_pass (search.rs:876-946): packed signed-nibble pass-1 (a quarter of the f16
+    // bytes), exact f16 rescore; same fallbacks.
+    SearchError search_top_k_4bit_two_pass(const float* query, uint32_t query_len, uint32_t k, uint32_t multiplier,
+                                           uint32_t* out_rows, float* out_scores, uint32_t* out_count);
     // VectorIndex::mrl_search_with_stats (crates/frankensearch-index/src/mrl.rs:241-395): truncated scan over the first
     // search_dims dimensions (a strided view of the same slab), resident WAL entries, rescore over rescore_dims, top-k.
     struct MrlStats {
@@ -108,6 +112,8 @@ class VectorIndex {
 
   private:
     SearchError ensure_query_dimension(uint32_t query_len) const;
+    SearchError quantized_two_pass(const float* query, uint32_t query_len, uint32_t k, uint32_t multiplier, int bits,
+                                   uint32_t* out_rows, float* out_scores, uint32_t* out_count);
     SearchError common_init(int device);
     SearchError fused_search(const float* queries_dev, uint32_t nq, uint32_t k_out, uint32_t k_eff,
                              const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
@@ -132,10 +138,10 @@ class VectorIndex {
     hipStream_t stream_ = nullptr;
     // workspaces (grown on demand, reused)
     DeviceBuffer ws_partial_, ws_queries_, ws_allow_, ws_rows_, ws_scores_, ws_counts_, ws_keys_a_, ws_keys_b_,
-        ws_sort_tmp_, ws_gather_rows_, ws_gather_out_, i8_slab_, i8_max_, ws_i8_query_, ws_cand_packed_,
+        ws_sort_tmp_, ws_gather_rows_, ws_gather_out_, i8_slab_, n4_slab_, i8_max_, ws_i8_query_, ws_cand_packed_,
         ws_cand_rows_, ws_cand_scores_, mf_max_norm_, mf_qh_, mf_delta_, mf_tau_, mf_cand_, mf_dense_, mf_sel_,
         mf_fallback_, mf_spill_;
-    bool i8_ready_ = false;
+    bool i8_ready_ = false, n4_ready_ = false;
     bool mf_norm_ready_ = false;
     int mf_shape_ = -1, mf_per_cu_narrow_ = 1, mf_per_cu_wide_ = 1;  // batched-scan launch shapes (probed once)
     uint32_t* mf_flags_host_ = nullptr;                              // pinned per-query verdicts of the batched scan

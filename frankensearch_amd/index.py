@@ -226,6 +226,19 @@ class VectorIndex:
         return [VectorHit(int(rows[i]), float(scores[i]), self.doc_id_at(int(rows[i])) if has_ids else None)
                 for i in range(n.value)]
 
+    def search_top_k_4bit_two_pass(self, query: Sequence[float], k: int, candidate_multiplier: int = 5
+                                   ) -> List[VectorHit]:
+        """search.rs:876-946 — packed 4-bit pass-1 + exact f16 rescore."""
+        q = np.ascontiguousarray(query, dtype=np.float32).reshape(-1)
+        rows = np.empty(max(k, 1), dtype=np.uint32)
+        scores = np.empty(max(k, 1), dtype=np.float32)
+        n = C.c_uint32()
+        check(_lib.lib().fsgpu_search_topk_4bit_two_pass(self._h, _ptr(q), q.size, k, candidate_multiplier, _ptr(rows),
+                                                         _ptr(scores), C.byref(n)))
+        has_ids = self._has_doc_ids()
+        return [VectorHit(int(rows[i]), float(scores[i]), self.doc_id_at(int(rows[i])) if has_ids else None)
+                for i in range(n.value)]
+
     def dot_query_at(self, index: int, query: Sequence[float]) -> float:
         """lib.rs:3229-3239"""
         return float(self.gather_dot(query, [index])[0])

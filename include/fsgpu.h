@@ -179,6 +179,13 @@ fsgpu_status fsgpu_search_hits(fsgpu_index *idx, const float *query, uint32_t qu
 fsgpu_status fsgpu_search_topk_int8_two_pass(fsgpu_index *idx, const float *query, uint32_t query_len, uint32_t k,
                                              uint32_t candidate_multiplier, uint32_t *out_rows, float *out_scores,
                                              uint32_t *out_count);
+/* VectorIndex::search_top_k_4bit_two_pass (crates/frankensearch-index/src/search.rs:876-946): pass 1 over a packed
+ * signed-4-bit slab (dim/2 bytes per vector, one corpus-wide scale 7/max_abs, simd.rs:2153-2215; exact integer nibble
+ * dot, simd.rs:1338-1556) keeps the top k*candidate_multiplier, pass 2 re-scores them with the exact f16 dot.  Same
+ * arguments, outputs and fallbacks (WAL resident, k = 0, empty index -> exact search) as the int8 variant. */
+fsgpu_status fsgpu_search_topk_4bit_two_pass(fsgpu_index *idx, const float *query, uint32_t query_len, uint32_t k,
+                                             uint32_t candidate_multiplier, uint32_t *out_rows, float *out_scores,
+                                             uint32_t *out_count);
 /* VectorIndex::dot_query_at (lib.rs:3229-3239) over a row list, as used by
  * TwoTierIndex::quality_scores_for_hits (two_tier.rs:1566-1631).  rows are global ids. */
 fsgpu_status fsgpu_gather_dot(fsgpu_index *idx, const float *query, uint32_t query_len, const uint32_t *rows,

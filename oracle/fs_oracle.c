@@ -626,6 +626,111 @@ size_t fso_search_int8_two_pass(const uint8_t *slab, const int8_t *slab_i8, uint
     return outn;
 }
 
+/* ---- 4-bit two-pass (search.rs:860-1000; simd.rs:1286-1556, 1886-1900, 2153-2215) ---- */
+/* nibble_of_4bit / nibble_of (simd.rs:1892-1896, search.rs:1632-1635): round half away from zero, clamp +-7, NaN -> 0
+ * (Rust `as i8`), 4-bit two's complement in the low nibble. */
+static uint8_t nibble_of(float value, float scale) {
+    float v = roundf(value * scale);
+    if (v != v) return 0;
+    if (v < -7.0f) v = -7.0f;
+    if (v > 7.0f) v = 7.0f;
+    return (uint8_t)((int8_t)v) & 0x0F;
+}
+static int32_t nibble_lo(uint8_t b) { return (int32_t)(int8_t)((b & 0x0F) ^ 0x08) - 8; }   /* simd.rs:1290-1298 */
+static int32_t nibble_hi(uint8_t b) { return (int32_t)(int8_t)((b >> 4) ^ 0x08) - 8; }
+
+/* pack_f16_le_bytes_to_4bit (simd.rs:2153-2215): ONE corpus-wide max-abs scale 7/max (0 when max <= 1e-9; f32::max
+ * ignores NaN), dim.div_ceil(2) bytes per vector, low nibble = even dim. */
+void fso_pack_slab_4bit(const uint8_t *slab_f16, uint64_t count, uint32_t dim, uint8_t *out) {
+    if (dim == 0) return;
+    float max_abs = 0.0f;
+    uint64_t n = count * dim;
+    for (uint64_t i = 0; i < n; ++i) {
+        float v = fabsf(fso_f16_to_f32((uint16_t)(slab_f16[2 * i] | (slab_f16[2 * i + 1] << 8))));
+        if (v > max_abs) max_abs = v; /* NaN compares false: ignored, like f32::max */
+    }
+    float scale = max_abs > 1e-9f ? 7.0f / max_abs : 0.0f;
+    size_t bpv = (dim + 1) / 2;
+    memset(out, 0, (size_t)count * bpv);
+    for (uint64_t v = 0; v < count; ++v)
+        for (uint32_t d = 0; d < dim; ++d) {
+            uint64_t i = v * dim + d;
+            float x = fso_f16_to_f32((uint16_t)(slab_f16[2 * i] | (slab_f16[2 * i + 1] << 8)));
+            uint8_t nib = nibble_of(x, scale);
+            out[v * bpv + d / 2] |= (d % 2 == 0) ? nib : (uint8_t)(nib << 4);
+        }
+}
+
+/* pack_4bit_query (search.rs:1640-1653): the query's own max-abs scale. */
+void fso_pack_query_4bit(const float *q, uint32_t dim, uint8_t *out) {
+    float max_abs = 0.0f;
+    for (uint32_t d = 0; d < dim; ++d) {
+        float v = fabsf(q[d]);
+        if (v > max_abs) max_abs = v;
+    }
+    float scale = max_abs > 1e-9f ? 7.0f / max_abs : 0.0f;
+    memset(out, 0, (dim + 1) / 2);
+    for (uint32_t d = 0; d < dim; ++d) {
+        uint8_t nib = nibble_of(q[d], scale);
+        out[d / 2] |= (d % 2 == 0) ? nib : (uint8_t)(nib << 4);
+    }
+}
+
+/* dot_packed_4bit / dot_4bit_prepared (simd.rs:1338-1556): exact integer sum of nibble products. */
+int32_t fso_dot_4bit(const uint8_t *stored, const uint8_t *query, size_t nbytes) {
+    int32_t sum = 0;
+    for (size_t i = 0; i < nbytes; ++i)
+        sum += nibble_lo(stored[i]) * nibble_lo(query[i]) + nibble_hi(stored[i]) * nibble_hi(query[i]);
+    return sum;
+}
+
+/* search_top_k_4bit_two_pass (search.rs:876-946) + nibble_scan_range (:951-983): pass 1 keeps the top
+ * candidate_count = max(min(k * max(mult, 1), N), min(k, N)) by (dot as f32) under the HeapEntry order (score desc, row
+ * asc), pass 2 re-scores them with the exact f16 dot and selects k.  Raw-slab form: no doc ids, so resolve_hits'
+ * dedup has nothing to merge. */
+size_t fso_search_4bit_two_pass(const uint8_t *slab, const uint8_t *slab_4bit, uint64_t nrows, uint32_t dim,
+                                const uint64_t *live, const float *q, size_t k, size_t candidate_multiplier, int hreduce,
+                                uint32_t *out_rows, float *out_scores) {
+    if (k == 0 || nrows == 0) return 0;
+    size_t mult = candidate_multiplier ? candidate_multiplier : 1;
+    size_t cc = k * mult;
+    if (cc > nrows) cc = (size_t)nrows;
+    size_t kmin = k < nrows ? k : (size_t)nrows;
+    if (cc < kmin) cc = kmin;
+    size_t bpv = (dim + 1) / 2;
+    uint8_t *qp = (uint8_t *)malloc(bpv ? bpv : 1);
+    fso_pack_query_4bit(q, dim, qp);
+    heap_t cand;
+    heap_init(&cand, cc + 1);
+    float cutoff = -INFINITY;
+    for (uint64_t r = 0; r < nrows; ++r) {
+        if (!row_live(live, r)) continue;
+        float score = (float)fso_dot_4bit(slab_4bit + r * bpv, qp, bpv);
+        if (cand.len < cc || score_key(score) >= cutoff) {
+            entry_t e = {r, score};
+            insert_candidate(&cand, e, cc);
+            if (cand.len >= cc && cand.len > 0) cutoff = score_key(cand.v[0].score);
+        }
+    }
+    heap_t heap;
+    heap_init(&heap, k + 1);
+    size_t stride = (size_t)dim * 2;
+    for (size_t i = 0; i < cand.len; ++i) {
+        entry_t e = {cand.v[i].row, fso_dot_f16_f32(slab + cand.v[i].row * stride, q, dim, hreduce)};
+        insert_candidate(&heap, e, k);
+    }
+    qsort(heap.v, heap.len, sizeof(entry_t), cmp_best_first);
+    size_t outn = heap.len;
+    for (size_t i = 0; i < outn; ++i) {
+        out_rows[i] = (uint32_t)heap.v[i].row;
+        out_scores[i] = heap.v[i].score;
+    }
+    heap_free(&heap);
+    heap_free(&cand);
+    free(qp);
+    return outn;
+}
+
 /* VectorIndex::mrl_search_with_stats (crates/frankensearch-index/src/mrl.rs:241-395): truncated scan over the first
  * search_dims dimensions keeping the top rescore_top_k (0 = 3 * limit) under (nan_safe(score) desc, index asc)
  * (:160-207, :468-537), resident WAL entries scored with the truncated f32 dot and skipped when non-finite (:539-583),

@@ -152,6 +152,13 @@ void fso_clustered_query(uint64_t q, uint32_t dim, uint32_t clusters, float nois
 void fso_m2v_embed(const float *table, uint32_t vocab, uint32_t dim, const uint32_t *ids,
                    size_t n_ids, float *out);
 
+/* 4-bit two-pass (search.rs:860-1000; simd.rs:1286-1556, 2153-2215). */
+void fso_pack_slab_4bit(const uint8_t *slab_f16, uint64_t count, uint32_t dim, uint8_t *out);
+void fso_pack_query_4bit(const float *q, uint32_t dim, uint8_t *out);
+int32_t fso_dot_4bit(const uint8_t *stored, const uint8_t *query, size_t nbytes);
+size_t fso_search_4bit_two_pass(const uint8_t *slab, const uint8_t *slab_4bit, uint64_t nrows, uint32_t dim,
+                                const uint64_t *live, const float *q, size_t k, size_t candidate_multiplier, int hreduce,
+                                uint32_t *out_rows, float *out_scores);
 /* mrl.rs:241-395 — truncated scan + rescore (see fs_oracle.c). */
 size_t fso_mrl_search(const uint8_t *slab, uint64_t nrows, uint32_t dim, const uint64_t *live, const float *const *wal_vecs,
                       size_t wal_len, const float *q, size_t limit, size_t search_dims, size_t rescore_dims,

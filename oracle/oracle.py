@@ -190,6 +190,61 @@ def search_top_k(slab_u16: np.ndarray, q: np.ndarray, k: int, live: np.ndarray |
     return rows[:cnt].copy(), scores[:cnt].copy()
 
 
+def pack_slab_4bit(slab_u16: np.ndarray) -> np.ndarray:
+    """pack_f16_le_bytes_to_4bit (simd.rs:2153-2215): [N, ceil(dim/2)] uint8."""
+    slab = np.ascontiguousarray(slab_u16, dtype=np.uint16)
+    n, dim = slab.shape
+    out = np.empty((n, (dim + 1) // 2), dtype=np.uint8)
+    L = lib()
+    L.fso_pack_slab_4bit.restype = None
+    L.fso_pack_slab_4bit.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
+    L.fso_pack_slab_4bit(slab.ctypes.data, n, dim, out.ctypes.data)
+    return out
+
+
+def pack_query_4bit(q: np.ndarray) -> np.ndarray:
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    out = np.empty((q.size + 1) // 2, dtype=np.uint8)
+    L = lib()
+    L.fso_pack_query_4bit.restype = None
+    L.fso_pack_query_4bit.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    L.fso_pack_query_4bit(q.ctypes.data, q.size, out.ctypes.data)
+    return out
+
+
+def dot_4bit(a: np.ndarray, b: np.ndarray) -> int:
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    L = lib()
+    L.fso_dot_4bit.restype = C.c_int32
+    L.fso_dot_4bit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    return int(L.fso_dot_4bit(a.ctypes.data, b.ctypes.data, a.size))
+
+
+def search_4bit_two_pass(slab_u16: np.ndarray, q: np.ndarray, k: int, candidate_multiplier: int,
+                         live: np.ndarray | None = None, hreduce: int = HREDUCE_SSE2):
+    """search_top_k_4bit_two_pass (search.rs:876-946) on a raw slab -> (rows, scores)."""
+    slab = np.ascontiguousarray(slab_u16, dtype=np.uint16)
+    n, dim = slab.shape
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    if q.size != dim:
+        raise ValueError(f"DimensionMismatch expected={dim} found={q.size}")
+    nib = pack_slab_4bit(slab)
+    cap = max(1, min(k, n))
+    rows = np.empty(cap, dtype=np.uint32)
+    scores = np.empty(cap, dtype=np.float32)
+    bm = None
+    if live is not None:
+        bm = live_bitmap(np.asarray(live, dtype=bool)) if live.dtype != np.uint64 else live
+    L = lib()
+    L.fso_search_4bit_two_pass.restype = C.c_size_t
+    L.fso_search_4bit_two_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
+                                           C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    cnt = L.fso_search_4bit_two_pass(slab.ctypes.data, nib.ctypes.data, n, dim, bm.ctypes.data if bm is not None else None,
+                                     q.ctypes.data, k, candidate_multiplier, hreduce, rows.ctypes.data, scores.ctypes.data)
+    return rows[:cnt].copy(), scores[:cnt].copy()
+
+
 def mrl_search(slab_u16: np.ndarray, q: np.ndarray, limit: int, search_dims: int, rescore_dims: int = 0,
                rescore_top_k: int = 0, live: np.ndarray | None = None, wal: list | None = None,
                hreduce: int = HREDUCE_SSE2):

@@ -512,3 +512,42 @@ def test_mrl_search_matches_oracle(fa, oracle, tmp_path):
         hits = g.mrl_search(q, k, sd)
         assert [h.index for h in hits] == er.tolist() and np.array_equal(bits([h.score for h in hits]), bits(es))
         assert all(h.doc_id is not None for h in hits if h.index < 200)
+
+
+@pytest.mark.gpu
+def test_4bit_two_pass_matches_oracle(fa, oracle, tmp_path):
+    # search.rs:876-946; keep-all fixture (search.rs:2010-2053); slab packer simd.rs:2153-2215
+    slab = oracle.encode_f32_to_f16(oracle.fixture_hashmix(300, 70))       # dim 70: generic path, partial last byte
+    idx = fa.VectorIndex.from_slab(slab)
+    for qi in range(8):
+        q = np.array([(((qi * 7 + j * 3) % 11) / 11.0) - 0.5 for j in range(70)], dtype=np.float32)
+        er, es = oracle.search_4bit_two_pass(slab, q, 10, 50)
+        gh = idx.search_top_k_4bit_two_pass(q, 10, 50)
+        assert [h.index for h in gh] == er.tolist() and np.array_equal(bits([h.score for h in gh]), bits(es))
+        xr, _ = oracle.search_top_k(slab, q, 10)
+        assert [h.index for h in gh] == xr.tolist()                       # keep-all == exact
+    rng = np.random.default_rng(73)
+    for n, dim in ((20_000, 384), (9_000, 256), (5_003, 128), (700, 512), (1_000, 24), (1_000, 33)):
+        rows = rng.standard_normal((n, dim)).astype(np.float32)
+        rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+        rows[7] = rows[3]                                                  # tie: lower row first
+        slab = rows.astype(np.float16).view(np.uint16)
+        live = rng.random(n) > 0.07
+        idx = fa.VectorIndex.from_slab(slab, live=live)
+        for qi in range(3):
+            q = rows[rng.integers(0, n)] + 0.2 * rng.standard_normal(dim).astype(np.float32)
+            if qi == 2:
+                q[5] = np.nan                                              # NaN query element quantises to 0
+            for k, mult in ((10, 5), (1, 1), (10, 20), (7, 0), (40, 3), (10, 100)):
+                er, es = oracle.search_4bit_two_pass(slab, q, k, mult, live=live)
+                gh = idx.search_top_k_4bit_two_pass(q, k, mult)
+                assert [h.index for h in gh] == er.tolist(), (n, dim, qi, k, mult)
+                assert np.array_equal(bits([h.score for h in gh]), bits(es)), (n, dim, qi, k, mult)
+    assert idx.search_top_k_4bit_two_pass(q, 0, 5) == []
+    with pytest.raises(fa.DimensionMismatch):
+        idx.search_top_k_4bit_two_pass(q[:5], 3, 5)
+    # all-zero slab: scale 0, every nibble 0
+    z = fa.VectorIndex.from_slab(np.zeros((100, 128), np.uint16))
+    er, es = oracle.search_4bit_two_pass(np.zeros((100, 128), np.uint16), np.ones(128, np.float32), 5, 3)
+    gh = z.search_top_k_4bit_two_pass(np.ones(128, np.float32), 5, 3)
+    assert [h.index for h in gh] == er.tolist()

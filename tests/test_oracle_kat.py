@@ -572,3 +572,46 @@ def test_mrl_config_resolution_tombstones_wal_and_fallback(oracle):
     # non-aligned search_dims (mrl.rs:1060-1088): scalar tail
     rows, scores = oracle.mrl_search(slab, q, 4, search_dims=5)
     assert rows.tolist() == [0, 1, 2, 3]
+
+
+# ---- 4-bit two-pass (search.rs:860-1000, simd.rs:1286-1556, 2153-2215) ---------------------------------------------
+def test_4bit_dot_matches_scalar_and_extremes(oracle):
+    # dot_packed_4bit_matches_scalar (simd.rs:2799-2833)
+    def lo(b):
+        return ((b & 0x0F) ^ 0x08) - 8
+    def hi(b):
+        return ((b >> 4) ^ 0x08) - 8
+    for n in (0, 1, 5, 15, 16, 17, 32, 33, 192, 193):
+        s = np.array([(i * 37 + 11) % 256 for i in range(n)], dtype=np.uint8)
+        q = np.array([(i * 53 + 7) % 256 for i in range(n)], dtype=np.uint8)
+        want = sum(lo(int(a)) * lo(int(b)) + hi(int(a)) * hi(int(b)) for a, b in zip(s, q))
+        assert oracle.dot_4bit(s, q) == want, n
+    a = np.full(16, 0x99, dtype=np.uint8)       # all nibbles = -7: each dim contributes 49
+    assert oracle.dot_4bit(a, a) == 32 * 49
+
+
+def test_4bit_packing_rules(oracle):
+    # nibble_of_4bit (simd.rs:1892-1896): round half away from zero, clamp +-7, two's complement nibble, low = even dim;
+    # one corpus-wide scale 7 / max_abs (pack_f16_le_bytes_to_4bit_generic, simd.rs:2153-2215)
+    slab = np.array([[1.0, -1.0, 0.5, 0.0714285, 0.25]], dtype=np.float32).astype(np.float16).view(np.uint16)
+    packed = oracle.pack_slab_4bit(slab)
+    # scale 7: 1 -> 7, -1 -> -7 (0x9), 0.5 -> 3.5 -> 4 (half away), 0.0714 -> 0.49995 -> 0, 0.25 -> 1.75 -> 2
+    assert packed.shape == (1, 3) and packed[0].tolist() == [0x97, 0x04, 0x02]
+    q = oracle.pack_query_4bit(np.array([0.2, -0.1, np.nan, 0.05], dtype=np.float32))   # own scale 7/0.2; NaN -> 0
+    assert q.tolist() == [0xC7, 0x20]   # 0.2 -> 7; -0.1 -> -3.5 -> -4 (0xC); NaN -> 0; 0.05 -> 1.75 -> 2
+    assert oracle.pack_slab_4bit(np.zeros((2, 4), np.uint16)).tolist() == [[0, 0], [0, 0]]   # max_abs <= 1e-9 -> scale 0
+
+
+def test_4bit_two_pass_keep_all_equals_exact(oracle):
+    # search.rs:2010-2053: dim 70 (partial last byte), 300 hash-mix rows, mult 50 keeps every row -> equals exact search
+    dim, count = 70, 300
+    slab = oracle.encode_f32_to_f16(oracle.fixture_hashmix(count, dim))
+    for qi in range(8):
+        q = np.array([(((qi * 7 + j * 3) % 11) / 11.0) - 0.5 for j in range(dim)], dtype=np.float32)
+        er, es = oracle.search_top_k(slab, q, 10)
+        ar, as_ = oracle.search_4bit_two_pass(slab, q, 10, 50)
+        assert np.array_equal(er, ar) and np.array_equal(es.view(np.uint32), as_.view(np.uint32))
+    # a small multiplier is a real approximation: results are still exact-scored and best-first
+    ar, as_ = oracle.search_4bit_two_pass(slab, q, 10, 2)
+    assert len(ar) == 10 and np.all(np.diff(as_) <= 0)
+    assert as_.tolist() == [oracle.dot_f16_f32(slab[r], q) for r in ar]
