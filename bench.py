@@ -160,35 +160,46 @@ def two_tier_section(quality_index, rows: int, k: int, device, local_rank: int):
     # the host side is native: libfshost.so = the reference's SyncTwoTierSearcher flow in C++ over the C ABI, driven by
     # native threads the way a multi-threaded Rust host would drive it (include/fshost.h)
     from frankensearch_amd.host import NativeTwoTierSearcher
-    searcher = NativeTwoTierSearcher(fast_index, quality_index, m2v, bert, doc_id_mode=1)
+    # fast tier through search_top_k_int8_two_pass(query, fetch, 3): the reference's default (two_tier.rs:1318-1337)
+    searcher = NativeTwoTierSearcher(fast_index, quality_index, m2v, bert, doc_id_mode=1, fast_tier_int8_multiplier=3)
     seq = searcher.run_load(threads=1, queries=200, warmup_queries=16, k=k, fast_vocab=500_353, corpus_rows=rows)
     # concurrent callers, coalesced inside the library into batched launches (fsgpu_*_set_coalescing)
-    threads, max_batch, wait_us = 512, 128, 1000
+    max_batch, wait_us = 128, 1000
     fast_index.set_coalescing(max_batch, wait_us)
     quality_index.set_coalescing(max_batch, wait_us)
     m2v.set_coalescing(2 * max_batch, wait_us // 2)
     bert.set_coalescing(2 * max_batch, wait_us)
-    con = searcher.run_load(threads=threads, queries=60_000, warmup_queries=2 * threads, k=k, fast_vocab=500_353,
-                            corpus_rows=rows)
-    fb, fr = fast_index.coalescing_stats()
-    qb, qr = quality_index.coalescing_stats()
+
+    def concurrent(threads: int, queries: int):
+        fb0, fr0 = fast_index.coalescing_stats()
+        qb0, qr0 = quality_index.coalescing_stats()
+        con = searcher.run_load(threads=threads, queries=queries, warmup_queries=2 * threads, k=k, fast_vocab=500_353,
+                                corpus_rows=rows)
+        fb, fr = fast_index.coalescing_stats()
+        qb, qr = quality_index.coalescing_stats()
+        return {
+            "threads": threads, "coalescing": {"max_batch": max_batch, "max_wait_us": wait_us},
+            "queries_per_sec": con.queries_per_sec, "completed": con.completed, "failed": con.failed,
+            "phase0_p50_ms": con.phase0_p50_ms, "phase0_p95_ms": con.phase0_p95_ms,
+            "phase1_p50_ms": con.phase1_p50_ms, "phase1_p95_ms": con.phase1_p95_ms, "phase1_p99_ms": con.phase1_p99_ms,
+            "mean_queries_per_scan_batch": {"fast": (fr - fr0) / max(fb - fb0, 1), "quality": (qr - qr0) / max(qb - qb0, 1)},
+        }
+
+    con = concurrent(256, 40_000)
+    con_hi = concurrent(1024, 80_000)
     quality_index.set_coalescing(0, 0)
     res = {
-        "workload": f"{rows}x256 fast tier + {rows}x384 quality tier, top-{k}, fetch {3 * k} per tier, stub lexical list of "
-                    f"{3 * k}, RRF + blend on the host; per-query C ABI calls from native threads (libfshost.so)",
+        "workload": f"{rows}x256 fast tier (int8 two-pass, multiplier 3) + {rows}x384 quality tier (exact), top-{k}, fetch "
+                    f"{3 * k} per tier, stub lexical list of {3 * k}, RRF + blend on the host; per-query C ABI calls from "
+                    "native threads (libfshost.so)",
         "phase0_p50_ms": seq.phase0_p50_ms,
         "phase1_p50_ms": seq.phase1_p50_ms,
         "sequential_queries_per_sec": seq.queries_per_sec,
         "sequential_breakdown_ms": {"fast_embed": seq.mean_fast_embed_ms, "fast_search": seq.mean_fast_search_ms,
                                     "quality_embed": seq.mean_quality_embed_ms, "quality_search": seq.mean_quality_search_ms,
                                     "fusion": seq.mean_fusion_ms},
-        "concurrent": {
-            "threads": threads, "coalescing": {"max_batch": max_batch, "max_wait_us": wait_us},
-            "queries_per_sec": con.queries_per_sec, "completed": con.completed, "failed": con.failed,
-            "phase0_p50_ms": con.phase0_p50_ms, "phase0_p95_ms": con.phase0_p95_ms,
-            "phase1_p50_ms": con.phase1_p50_ms, "phase1_p95_ms": con.phase1_p95_ms, "phase1_p99_ms": con.phase1_p99_ms,
-            "mean_queries_per_scan_batch": {"fast": fr / max(fb, 1), "quality": qr / max(qb, 1)},
-        },
+        "concurrent": con,
+        "concurrent_1024_threads": con_hi,
     }
     searcher.close()
     fast_index.close()
@@ -221,9 +232,33 @@ def quantized_section(index, rows: int, dim: int, k: int, queries, bits: int, mu
     for i in range(8):
         exact = {h.index for h in index.search_top_k(q[i], k)}
         recall += len(exact & {h.index for h in fn(q[i], k, mult)})
-    return {"candidate_multiplier": mult, "p50_latency_ms": lat[len(lat) // 2], "pass1_kernel_ms": per, "pass1_GBps": gbps,
-            "pass1_frac_of_hbm_peak": gbps / HBM_PEAK_GBPS, "algorithmic_bytes": alg,
-            "recall_at_k_vs_exact": recall / (8 * k)}
+    out = {"candidate_multiplier": mult, "p50_latency_ms": lat[len(lat) // 2], "pass1_kernel_ms": per, "pass1_GBps": gbps,
+           "pass1_frac_of_hbm_peak": gbps / HBM_PEAK_GBPS, "algorithmic_bytes": alg,
+           "recall_at_k_vs_exact": recall / (8 * k)}
+    if bits == 8:
+        # the same search for a whole batch: int8 pass 1 on the matrix cores, 128 queries per pass over the int8 slab
+        qb = queries[:1024].cpu().numpy()
+        index.search_int8_two_pass_batched(qb, k, mult)
+        index.scan_stats(reset=True)
+        index.set_profiling(True)
+        t0 = time.perf_counter()
+        reps, fb = 8, 0
+        for _ in range(reps):
+            fb += index.search_int8_two_pass_batched(qb, k, mult)[3]
+        dt = time.perf_counter() - t0
+        index.set_profiling(False)
+        ms, launches, srows = index.scan_stats(reset=True)
+        per_b = ms / max(launches, 1)
+        alg_b = srows // max(launches, 1) * dim
+        one = index.search_int8_two_pass_batched(qb[:16], k, mult)
+        same = all([h.index for h in fn(qb[i], k, mult)] == one[0][i, :one[2][i]].tolist() for i in range(16))
+        out["batched"] = {"queries_per_step": len(qb), "queries_per_sec": reps * len(qb) / dt,
+                          "pass1_kernel_ms": per_b, "algorithmic_bytes": alg_b,
+                          "pass1_GBps": alg_b / (per_b * 1e-3) / 1e9 if per_b > 0 else 0.0,
+                          "pass1_frac_of_hbm_peak": alg_b / (per_b * 1e-3) / 1e9 / HBM_PEAK_GBPS if per_b > 0 else 0.0,
+                          "per_query_fallbacks": fb, "equals_per_query_search": bool(same),
+                          "note": "host-pointer ABI: includes H2D of the queries and D2H of the hits"}
+    return out
 
 
 def mrl_section(index, rows: int, dim: int, k: int, queries):
@@ -406,7 +441,7 @@ def main() -> None:
             tt = two_tier_section(index, args.rows, k, device, local_rank)
             line["two_tier"] = tt
             line["p50_phase1_latency_ms"] = tt["phase1_p50_ms"]
-            line["end_to_end_queries_per_sec"] = tt["concurrent"]["queries_per_sec"]
+            line["end_to_end_queries_per_sec"] = tt["concurrent_1024_threads"]["queries_per_sec"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_and_parity(slab, queries, k, args.rows, fa.VectorIndex)
         print(json.dumps(line), flush=True)

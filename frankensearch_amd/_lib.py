@@ -73,6 +73,7 @@ SIGNATURES = {
     "fsgpu_blend_two_tier": (_i32, [_vp, _u32, _vp, _u32, C.c_float, _vp, C.POINTER(_u32)]),
     "fsgpu_index_set_profiling": (_i32, [_vp, _i32]),
     "fsgpu_index_scan_time": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(_u64), _i32]),
+    "fsgpu_search_topk_int8_two_pass_batched": (_i32, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, C.POINTER(_u32)]),
     "fsgpu_search_topk_4bit_two_pass": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),
     "fsgpu_search_mrl": (_i32, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, C.POINTER(_u32), _vp]),
     "fsgpu_index_set_coalescing": (_i32, [_vp, _u32, _u32]),

@@ -23,6 +23,7 @@ struct CoalescedCall : fsgpu::CoalescedRequest {
 struct SearchCall : CoalescedCall {
     const float* query = nullptr;
     uint32_t k = 0;
+    uint32_t int8_mult = 0;  // 0 = exact search, else search_top_k_int8_two_pass with this multiplier
     uint32_t* out_rows = nullptr;
     float* out_scores = nullptr;
     uint32_t* out_count = nullptr;
@@ -110,6 +111,67 @@ void run_embed_batch(Handle* h, uint32_t dim, std::vector<EmbedCall<Id>*>& batch
         batch[i]->detail = detail;
         if (st == FSGPU_OK) std::memcpy(batch[i]->out, h->co_out.data() + i * dim, (size_t)dim * 4);
     }
+}
+
+// One single-query call parked in the index's coalescer: concurrent callers ride one batched pass (results are
+// bit-identical to the direct path).  int8_mult 0 = exact search, else the int8 two-pass with that multiplier.
+fsgpu_status coalesced_search(fsgpu_index* idx, const float* query, uint32_t k, uint32_t int8_mult, uint32_t* out_rows,
+                              float* out_scores, uint32_t* out_count) {
+    return guarded([&]() -> fsgpu_status {
+        SearchCall call;
+        call.query = query;
+        call.k = k;
+        call.int8_mult = int8_mult;
+        call.out_rows = out_rows;
+        call.out_scores = out_scores;
+        call.out_count = out_count;
+        idx->coalescer.submit(
+            &call,
+            [idx](std::vector<SearchCall*>& batch) {
+                std::lock_guard<std::mutex> lock(idx->impl.mutex());
+                const uint32_t n = (uint32_t)batch.size(), dim = idx->impl.dimension(), kk = batch[0]->k;
+                const uint32_t mult = batch[0]->int8_mult;
+                idx->co_queries.resize((size_t)n * dim);
+                idx->co_rows.resize((size_t)n * kk);
+                idx->co_scores.resize((size_t)n * kk);
+                idx->co_counts.resize(n);
+                for (uint32_t i = 0; i < n; ++i)
+                    std::memcpy(idx->co_queries.data() + (size_t)i * dim, batch[i]->query, (size_t)dim * 4);
+                fsgpu_status st = FSGPU_ERR_DEVICE;
+                std::string detail;
+                try {
+                    uint32_t fb = 0;
+                    fsgpu::SearchError e;
+                    if (mult) {
+                        e = idx->impl.search_top_k_int8_batched(idx->co_queries.data(), n, dim, kk, mult, idx->co_rows.data(),
+                                                                idx->co_scores.data(), idx->co_counts.data(), &fb);
+                    } else if (n <= 4) {
+                        // up to four callers: one pass of the exact multi-query kernel is quicker than the staged
+                        // matrix-core pipeline; beyond that the batched path serves 128 per pass
+                        e = idx->impl.search_top_k(idx->co_queries.data(), n, dim, kk, nullptr, idx->co_rows.data(),
+                                                   idx->co_scores.data(), idx->co_counts.data());
+                    } else {
+                        e = idx->impl.search_top_k_batched(idx->co_queries.data(), n, dim, kk, nullptr, idx->co_rows.data(),
+                                                           idx->co_scores.data(), idx->co_counts.data(), &fb);
+                    }
+                    st = e.code;
+                    detail = e.detail;
+                } catch (const std::exception& ex) {
+                    detail = ex.what();
+                }
+                for (uint32_t i = 0; i < n; ++i) {
+                    batch[i]->status = st;
+                    batch[i]->detail = detail;
+                    if (st != FSGPU_OK) continue;
+                    std::memcpy(batch[i]->out_rows, idx->co_rows.data() + (size_t)i * kk, (size_t)kk * 4);
+                    std::memcpy(batch[i]->out_scores, idx->co_scores.data() + (size_t)i * kk, (size_t)kk * 4);
+                    *batch[i]->out_count = idx->co_counts[i];
+                }
+            },
+            [](const SearchCall& a, const SearchCall& b) { return a.k == b.k && a.int8_mult == b.int8_mult; });
+        if (call.status != FSGPU_OK) g_last_error = call.detail;
+        return call.status;
+    });
 }
 
 }  // namespace
@@ -214,57 +276,8 @@ fsgpu_status fsgpu_search_topk(fsgpu_index* idx, const float* queries, uint32_t 
     if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
     if (nq && (!queries || !out_counts || (k && (!out_rows || !out_scores))))
         return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
-    if (idx->coalescer.enabled() && nq == 1 && !allow_bitmap && k >= 1 && k <= 64 && query_len == idx->impl.dimension()) {
-        // concurrent single-query callers ride one batched pass (results are bit-identical to the direct path)
-        return guarded([&]() -> fsgpu_status {
-            SearchCall call;
-            call.query = queries;
-            call.k = k;
-            call.out_rows = out_rows;
-            call.out_scores = out_scores;
-            call.out_count = out_counts;
-            idx->coalescer.submit(
-                &call,
-                [idx](std::vector<SearchCall*>& batch) {
-                    std::lock_guard<std::mutex> lock(idx->impl.mutex());
-                    const uint32_t n = (uint32_t)batch.size(), dim = idx->impl.dimension(), kk = batch[0]->k;
-                    idx->co_queries.resize((size_t)n * dim);
-                    idx->co_rows.resize((size_t)n * kk);
-                    idx->co_scores.resize((size_t)n * kk);
-                    idx->co_counts.resize(n);
-                    for (uint32_t i = 0; i < n; ++i)
-                        std::memcpy(idx->co_queries.data() + (size_t)i * dim, batch[i]->query, (size_t)dim * 4);
-                    fsgpu_status st = FSGPU_ERR_DEVICE;
-                    std::string detail;
-                    try {
-                        uint32_t fb = 0;
-                        // up to four callers: one pass of the exact multi-query kernel is quicker than the staged
-                        // matrix-core pipeline; beyond that the batched path serves 128 per pass
-                        fsgpu::SearchError e =
-                            n <= 4 ? idx->impl.search_top_k(idx->co_queries.data(), n, dim, kk, nullptr, idx->co_rows.data(),
-                                                            idx->co_scores.data(), idx->co_counts.data())
-                                   : idx->impl.search_top_k_batched(idx->co_queries.data(), n, dim, kk, nullptr,
-                                                                    idx->co_rows.data(), idx->co_scores.data(),
-                                                                    idx->co_counts.data(), &fb);
-                        st = e.code;
-                        detail = e.detail;
-                    } catch (const std::exception& ex) {
-                        detail = ex.what();
-                    }
-                    for (uint32_t i = 0; i < n; ++i) {
-                        batch[i]->status = st;
-                        batch[i]->detail = detail;
-                        if (st != FSGPU_OK) continue;
-                        std::memcpy(batch[i]->out_rows, idx->co_rows.data() + (size_t)i * kk, (size_t)kk * 4);
-                        std::memcpy(batch[i]->out_scores, idx->co_scores.data() + (size_t)i * kk, (size_t)kk * 4);
-                        *batch[i]->out_count = idx->co_counts[i];
-                    }
-                },
-                [](const SearchCall& a, const SearchCall& b) { return a.k == b.k; });
-            if (call.status != FSGPU_OK) g_last_error = call.detail;
-            return call.status;
-        });
-    }
+    if (idx->coalescer.enabled() && nq == 1 && !allow_bitmap && k >= 1 && k <= 64 && query_len == idx->impl.dimension())
+        return coalesced_search(idx, queries, k, 0, out_rows, out_scores, out_counts);
     return guarded([&]() -> fsgpu_status {
         std::lock_guard<std::mutex> lock(idx->impl.mutex());
         return finish(idx->impl.search_top_k(queries, nq, query_len, k, allow_bitmap, out_rows, out_scores, out_counts));
@@ -417,6 +430,19 @@ fsgpu_status fsgpu_search_hits(fsgpu_index* idx, const float* query, uint32_t qu
     });
 }
 
+fsgpu_status fsgpu_search_topk_int8_two_pass_batched(fsgpu_index* idx, const float* queries, uint32_t nq, uint32_t query_len,
+                                                     uint32_t k, uint32_t candidate_multiplier, uint32_t* out_rows,
+                                                     float* out_scores, uint32_t* out_counts, uint32_t* out_fallbacks) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    if (nq && (!queries || !out_counts || (k && (!out_rows || !out_scores))))
+        return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.search_top_k_int8_batched(queries, nq, query_len, k, candidate_multiplier, out_rows,
+                                                          out_scores, out_counts, out_fallbacks));
+    });
+}
+
 // VectorIndex::search_top_k_4bit_two_pass (search.rs:876-946)
 fsgpu_status fsgpu_search_topk_4bit_two_pass(fsgpu_index* idx, const float* query, uint32_t query_len, uint32_t k,
                                              uint32_t candidate_multiplier, uint32_t* out_rows, float* out_scores,
@@ -461,6 +487,9 @@ fsgpu_status fsgpu_search_topk_int8_two_pass(fsgpu_index* idx, const float* quer
     if (!idx || !query || !out_count) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
     *out_count = 0;
     if (k && (!out_rows || !out_scores)) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    if (idx->coalescer.enabled() && k >= 1 && k <= 64 && query_len == idx->impl.dimension() && !idx->impl.has_doc_ids() &&
+        idx->impl.wal_record_count() == 0)
+        return coalesced_search(idx, query, k, candidate_multiplier ? candidate_multiplier : 1, out_rows, out_scores, out_count);
     return guarded([&]() -> fsgpu_status {
         std::lock_guard<std::mutex> lock(idx->impl.mutex());
         return finish(idx->impl.search_top_k_int8_two_pass(query, query_len, k, candidate_multiplier, out_rows,

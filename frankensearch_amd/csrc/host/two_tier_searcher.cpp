@@ -55,11 +55,15 @@ SyncTwoTierSearcher::SyncTwoTierSearcher(fsgpu_index* fast, fsgpu_index* quality
 
 // VectorIndex::search_top_k -> Vec<VectorHit> with doc ids resolved (search.rs:192-206, 1503-1558).
 fsgpu_status SyncTwoTierSearcher::tier_hits(fsgpu_index* index, const std::vector<float>& vec, uint32_t fetch,
-                                            std::vector<Hit>* hits, std::string* detail) const {
+                                            uint32_t int8_multiplier, std::vector<Hit>* hits, std::string* detail) const {
     std::vector<uint32_t> rows(fetch);
     std::vector<float> scores(fetch);
     uint32_t count = 0;
-    fsgpu_status st = fsgpu_search_topk(index, vec.data(), 1, (uint32_t)vec.size(), fetch, nullptr, rows.data(), scores.data(), &count);
+    fsgpu_status st =
+        int8_multiplier
+            ? fsgpu_search_topk_int8_two_pass(index, vec.data(), (uint32_t)vec.size(), fetch, int8_multiplier, rows.data(),
+                                              scores.data(), &count)
+            : fsgpu_search_topk(index, vec.data(), 1, (uint32_t)vec.size(), fetch, nullptr, rows.data(), scores.data(), &count);
     if (st != FSGPU_OK) {
         *detail = fsgpu_last_error();
         return st;
@@ -108,7 +112,7 @@ fsgpu_status SyncTwoTierSearcher::search(const uint32_t* fast_ids, uint32_t n_fa
     m.fast_embed_ms = ms_since(t0);
     const auto t1 = clock::now();
     std::vector<Hit> fast_hits;
-    st = tier_hits(fast_, fast_vec, fetch, &fast_hits, detail);
+    st = tier_hits(fast_, fast_vec, fetch, cfg_.fast_tier_int8_multiplier, &fast_hits, detail);
     if (st != FSGPU_OK) return st;
     m.fast_search_ms = ms_since(t1);
     const std::vector<fsgpu_scored_doc> fast_view = view(fast_hits);
@@ -135,7 +139,7 @@ fsgpu_status SyncTwoTierSearcher::search(const uint32_t* fast_ids, uint32_t n_fa
     m.quality_embed_ms = ms_since(t3);
     const auto t4 = clock::now();
     std::vector<Hit> quality_hits;  // the `Retrieved` pool (sync_searcher.rs:810-813)
-    st = tier_hits(quality_, quality_vec, fetch, &quality_hits, detail);
+    st = tier_hits(quality_, quality_vec, fetch, 0, &quality_hits, detail);
     if (st != FSGPU_OK) return st;
     m.quality_search_ms = ms_since(t4);
     const auto t5 = clock::now();

@@ -30,8 +30,8 @@ class SyncTwoTierSearcher {
                         const fsgpu_scored_doc* lexical, uint32_t n_lexical, Outcome* out, std::string* detail) const;
 
   private:
-    fsgpu_status tier_hits(fsgpu_index* index, const std::vector<float>& vec, uint32_t fetch, std::vector<Hit>* hits,
-                           std::string* detail) const;
+    fsgpu_status tier_hits(fsgpu_index* index, const std::vector<float>& vec, uint32_t fetch, uint32_t int8_multiplier,
+                           std::vector<Hit>* hits, std::string* detail) const;
     fsgpu_index* fast_;
     fsgpu_index* quality_;
     fsgpu_m2v* m2v_;

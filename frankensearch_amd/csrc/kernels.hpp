@@ -85,6 +85,7 @@ struct MfmaScanArgs {
     uint32_t stage;            // 0 = dense sample, 1 = thresholded sample, 2 = main pass (everything stage 1 skipped)
     uint32_t group_stride, group_count;  // the sample, in 64-row groups: {j * group_stride : j < group_count}
     uint32_t dim, slots, row_base;       // slots <= kMfmaMaxSlots
+    uint32_t elem_bytes;                 // 2 = f16 slab / f16 queries (0 means 2), 1 = int8 slab / int8 queries
 };
 
 // select_kernel (mfma_scan.hip): per query, the k-th best of the packed approximate entries without sorting them
@@ -102,12 +103,13 @@ struct SelectArgs {
     const u64* spill;          // [nq, spill_cap] spilled entries (may be null); valid prefix = min(count, spill_cap)
     const uint32_t* spill_count;  // [nq * kMfmaSpillCountStride]
     uint32_t spill_cap;
-    uint32_t k;                // 1..64
+    uint32_t k;                // 1..kSelectMaxK
     const float* delta;        // [nq] error bound; < 0 = query is skipped (tau = +inf, overflow set)
     float* tau_out;            // [nq] (may be null)
     u64* pool_out;             // [nq, kSelectPool] candidates, kEmpty padded (may be null)
     uint32_t* cand_counts;     // [nq] number of candidates, unclamped (may be null)
     uint32_t* overflow;        // [nq] set when there are more than kSelectPool candidates
+    uint32_t take_topk;        // != 0: the candidates are the k best entries themselves (exact pass-1 scores)
     // finish step
     const void* slab;          // [nrows, dim] f16
     const float* queries;      // [nq, dim] f32
@@ -120,7 +122,10 @@ struct SelectArgs {
     uint32_t* out_counts;      // [nq] (may be null)
 };
 constexpr uint32_t kSelectPool = 1024;
+constexpr uint32_t kSelectMaxK = 128;   // largest rank a selection can anchor on (k, or k * multiplier in int8 mode)
 hipError_t launch_select(const SelectArgs& args, int nq, hipStream_t stream);
+hipError_t launch_prepare_queries_i8(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, void* qi8, float* delta,
+                                     hipStream_t stream);
 
 constexpr uint32_t kMfmaMaxSlots = 32;           // candidate slots per (block, query) staged in LDS
 constexpr uint32_t kMfmaSpillCountStride = 16;  // uint32 counters 64 bytes apart

@@ -30,6 +30,8 @@
 // ds_read_b128 per (k-step, query tile), each feeding one MFMA per 16-row sub-tile.  Algorithmic bytes per pass are
 // still N*dim*2.  At 64 queries the kernel is HBM-bound; at 128 queries the B-fragment reads (96 KB of LDS traffic
 // per 16 rows) bound the 16-row tiling, the 32-row tiling halves them and is HBM-bound again.
+#include <type_traits>
+
 #include "scan_common.hpp"
 
 namespace fsgpu {
@@ -40,8 +42,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // STAGE only separates the kernel symbols (0 = dense sample, 1 = bounded range, 2 = main pass) so profiles report the
 // dominant main-pass launches on their own; 0 also makes the dense branch compile-time.
-template <int DIM, int NQT, int WPB, int STAGE, int RT, bool PF>
+// EB = bytes per slab element: 2 = f16 rows against f16-rounded queries (v_mfma_f32_16x16x32_f16, approximate scores),
+// 1 = the int8 slab against int8 queries (v_mfma_i32_16x16x64_i8, EXACT integer scores: the reference's int8 pass 1,
+// search.rs:589-661).  Everything else is byte-level and shared: a lane's 16-byte fragment is 8 halves or 16 int8.
+template <int DIM_E, int NQT, int WPB, int STAGE, int RT, bool PF, int EB = 2>
 __global__ __launch_bounds__(WPB * 64) void scan_mfma_kernel(MfmaScanArgs args) {
+    constexpr int DIM = DIM_E * EB / 2;  // row length in 2-byte units
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    using acc_t = std::conditional_t<EB == 2, f32x4, i32x4>;
     constexpr int NT = WPB * 64;
     constexpr int KS = DIM / 32;        // MFMA k-steps
     constexpr int QSTRIDE = DIM + 8;    // halves per query row in LDS (16-byte pad)
@@ -130,11 +138,11 @@ __global__ __launch_bounds__(WPB * 64) void scan_mfma_kernel(MfmaScanArgs args) 
         allow_word = args.allow ? args.allow[w64] : ~0ull;
     };
     auto compute_tile = [&](uint32_t t, const half8 (&w)[RT][KS], u64 live_word, u64 allow_word) {
-        f32x4 acc[RT][NQT];
+        acc_t acc[RT][NQT];
 #pragma unroll
         for (int s = 0; s < RT; ++s)
 #pragma unroll
-            for (int nt = 0; nt < NQT; ++nt) acc[s][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < NQT; ++nt) acc[s][nt] = acc_t{0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             half8 afrag[RT];
@@ -145,7 +153,11 @@ __global__ __launch_bounds__(WPB * 64) void scan_mfma_kernel(MfmaScanArgs args) 
                 const half8 b = *reinterpret_cast<const half8*>(qs + (size_t)(nt * 16 + frow) * QSTRIDE + ks * 32 + fk * 8);
 #pragma unroll
                 for (int s = 0; s < RT; ++s)
-                    acc[s][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[s], b, acc[s][nt], 0, 0, 0);
+                    if constexpr (EB == 2)
+                        acc[s][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[s], b, acc[s][nt], 0, 0, 0);
+                    else
+                        acc[s][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, afrag[s]),
+                                                                           __builtin_bit_cast(i32x4, b), acc[s][nt], 0, 0, 0);
             }
             // keep the B-fragment reads of later k-steps below this point: unconstrained, hipcc hoists all KS*NQT
             // ds_read_b128 to the top of the tile (192 extra registers at dim 384 -> one wave per SIMD)
@@ -176,21 +188,23 @@ __global__ __launch_bounds__(WPB * 64) void scan_mfma_kernel(MfmaScanArgs args) 
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         args.dense[(size_t)(nt * 16 + frow) * span + pos0 + r] =
-                            valid[r] ? pack(acc[s][nt][r], args.row_base + row0 + r) : kEmpty;
+                            valid[r] ? pack((float)acc[s][nt][r], args.row_base + row0 + r) : kEmpty;
             } else {
 #pragma unroll
                 for (int nt = 0; nt < NQT; ++nt) {
                     const float th = tau[nt];
-                    bool any = false;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) any = any || (valid[r] && acc[s][nt][r] >= th);
-                    if (!any) continue;  // per-lane: survivors are a few hundred rows out of the whole slab
+                    // cheap reject first: the best of the lane's four rows against the threshold (max ignores NaN);
+                    // survivors are a few hundred rows out of the whole slab
+                    auto m = acc[s][nt][0] > acc[s][nt][1] ? acc[s][nt][0] : acc[s][nt][1];
+                    m = acc[s][nt][2] > m ? acc[s][nt][2] : m;
+                    m = acc[s][nt][3] > m ? acc[s][nt][3] : m;
+                    if (!((float)m >= th)) continue;
                     const int q = nt * 16 + frow;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (valid[r] && acc[s][nt][r] >= th) {
+                        if (valid[r] && (float)acc[s][nt][r] >= th) {
                             const int pos = atomicAdd(&lcnt[q], 1);
-                            const u64 entry = pack(acc[s][nt][r], args.row_base + row0 + r);
+                            const u64 entry = pack((float)acc[s][nt][r], args.row_base + row0 + r);
                             if (pos < slots) {
                                 lbuf[q * slots + pos] = entry;
                             } else {
@@ -282,42 +296,49 @@ constexpr int kSelPer = 8;
 constexpr int kSelWaves = kSelThreads / 64;
 
 // One pass of the per-wave extraction: dst[0..k) <- the wave's k best among e[] and prev[0..k) (its earlier winners).
-template <int PER>
+// KL = ceil(KMAX / 64): how many of the previous winners each lane carries.
+template <int PER, int KL>
 __device__ __forceinline__ void wave_select_pass(const u64 (&e)[PER], int k, const u64* prev, u64* dst, int lane) {
-    u64 ee[PER + 1], key[PER + 1];
+    u64 ee[PER + KL], key[PER + KL];
 #pragma unroll
     for (int x = 0; x < PER; ++x) ee[x] = e[x];
-    ee[PER] = (prev && lane < k) ? prev[lane] : kEmpty;
 #pragma unroll
-    for (int x = 0; x <= PER; ++x) key[x] = ee[x] != kEmpty ? sortkey(ee[x]) : 0ull;
-    if (lane < k) dst[lane] = kEmpty;
+    for (int c = 0; c < KL; ++c) ee[PER + c] = (prev && lane + 64 * c < k) ? prev[lane + 64 * c] : kEmpty;
+#pragma unroll
+    for (int x = 0; x < PER + KL; ++x) key[x] = ee[x] != kEmpty ? sortkey(ee[x]) : 0ull;
+#pragma unroll
+    for (int c = 0; c < KL; ++c)
+        if (lane + 64 * c < k) dst[lane + 64 * c] = kEmpty;
     wave_lds_fence();
-    wave_extract_topk<PER + 1>(key, ee, k, dst);
+    wave_extract_topk<PER + KL>(key, ee, k, dst);
     wave_lds_fence();
 }
 
 // top[0..k) <- the k best of the 16 waves' winner lists win[wave * k + j], best first (kEmpty padded).  Wave 0 only.
+template <int KL>
 __device__ __forceinline__ void merge_wave_winners(const u64* win, int k, u64* top, int lane) {
     constexpr int NW = kSelWaves;
-    u64 e2[NW], key2[NW];  // NW * k <= 64 * NW winners
+    u64 e2[NW * KL], key2[NW * KL];  // NW * k <= 64 * NW * KL winners
 #pragma unroll
-    for (int x = 0; x < NW; ++x) {
+    for (int x = 0; x < NW * KL; ++x) {
         const int i = lane + x * 64;
         e2[x] = i < NW * k ? win[i] : kEmpty;
         key2[x] = e2[x] != kEmpty ? sortkey(e2[x]) : 0ull;
     }
-    top[lane] = kEmpty;
+#pragma unroll
+    for (int c = 0; c < KL; ++c) top[lane + 64 * c] = kEmpty;
     wave_lds_fence();
-    wave_extract_topk<NW>(key2, e2, k, top);
+    wave_extract_topk<NW * KL>(key2, e2, k, top);
     wave_lds_fence();
 }
 
-template <bool FINISH>
+// KL = 1: k <= 64; KL = 2: k <= 128 (the int8 fast tier asks for 3 x 30 = 90 candidates).
+template <bool FINISH, int KL>
 __global__ __launch_bounds__(kSelThreads) void select_kernel(SelectArgs args) {
     constexpr int NT = kSelThreads, PER = kSelPer, NW = kSelWaves, POOL = (int)kSelectPool;
     static_assert(POOL == NT, "one pool entry per thread in the final selection");
-    __shared__ u64 win[2][NW * 64];  // per-wave winners [wave][rank], ping-pong across passes
-    __shared__ u64 top[64];          // block top-k, best first
+    __shared__ u64 win[2][NW * 64 * KL];  // per-wave winners [wave][rank], ping-pong across passes
+    __shared__ u64 top[64 * KL];          // block top-k, best first
     __shared__ u64 pool[POOL];       // candidates (finish step: replaced by their exact entries)
     __shared__ int s_count;
     __shared__ float s_tau;
@@ -354,11 +375,11 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(SelectArgs args) {
     u64 e[PER];
     for (int p = 0; p < npass; ++p) {  // block-uniform
         load_pass(p, e);
-        wave_select_pass<PER>(e, k, p ? win[(p - 1) & 1] + wave * k : nullptr, win[p & 1] + wave * k, lane);
+        wave_select_pass<PER, KL>(e, k, p ? win[(p - 1) & 1] + wave * k : nullptr, win[p & 1] + wave * k, lane);
     }
     __syncthreads();
     if (wave == 0) {
-        merge_wave_winners(win[(npass - 1) & 1], k, top, lane);
+        merge_wave_winners<KL>(win[(npass - 1) & 1], k, top, lane);
         if (lane == 0) {
             const float d = args.delta[q];
             float t = -INFINITY;   // fewer than k entries: everything is a candidate
@@ -392,6 +413,17 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(SelectArgs args) {
         }
     }
     __syncthreads();
+    if (args.take_topk) {
+        // exact scores (int8 pass 1): the candidates are precisely the block's k best entries under the reference
+        // order, ties at the k-th score included only by row order — not everything at or above the k-th score
+        pool[tid] = tid < k ? top[tid] : kEmpty;
+        if (tid == 0) {
+            int n = 0;
+            while (n < k && top[n] != kEmpty) ++n;
+            s_count = n;
+        }
+        __syncthreads();
+    }
     const int ncand = s_count;
     if (tid == 0) {
         if (args.cand_counts) args.cand_counts[q] = (uint32_t)ncand;
@@ -435,10 +467,10 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(SelectArgs args) {
         const int ko = (int)args.k_out;
         u64 e3[1];
         e3[0] = pool[tid];
-        wave_select_pass<1>(e3, ko, nullptr, win[0] + wave * ko, lane);
+        wave_select_pass<1, 1>(e3, ko, nullptr, win[0] + wave * ko, lane);
         __syncthreads();
         if (wave == 0) {
-            merge_wave_winners(win[0], ko, top, lane);
+            merge_wave_winners<1>(win[0], ko, top, lane);
             int n = 0;
             for (int j = lane; j < (int)args.out_stride; j += 64) {
                 const u64 cnd = j < ko ? top[j] : kEmpty;
@@ -504,14 +536,43 @@ __global__ __launch_bounds__(256) void prepare_queries_kernel(const float* __res
     }
 }
 
+// quantize_i8_query (search.rs:1616-1626) for a group of queries: per-query max-abs scale 127/max (f32::max ignores
+// NaN), round half away from zero, clamp, NaN -> 0; an all-zero (or empty-max) query quantises to zeros.  Padding rows
+// are zero and marked "skip" (delta < 0); real queries get delta = 0: the int8 scores are exact.
+__global__ __launch_bounds__(256) void prepare_queries_i8_kernel(const float* __restrict__ q, uint32_t nq, uint32_t dim,
+                                                                 signed char* __restrict__ qi8, float* __restrict__ delta) {
+    __shared__ float red[4];
+    const uint32_t b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float m = 0.f;
+    if (b < nq)
+        for (uint32_t i = tid; i < dim; i += 256) m = fmaxf(m, fabsf(q[(size_t)b * dim + i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    const float max_abs = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const bool zero = b >= nq || !(max_abs > 0.0f);
+    const float scale = zero ? 0.f : 127.0f / max_abs;
+    for (uint32_t i = tid; i < dim; i += 256) {
+        signed char o = 0;
+        if (!zero) {
+            float v = roundf(q[(size_t)b * dim + i] * scale);
+            if (v == v) o = (signed char)(int)fminf(fmaxf(v, -127.0f), 127.0f);
+        }
+        qi8[(size_t)b * dim + i] = o;
+    }
+    if (tid == 0) delta[b] = b < nq ? 0.0f : -1.0f;
+}
+
 // ---- launchers ----------------------------------------------------------------------------------------------
 
 bool scan_mfma_supported(int dim) { return dim == 128 || dim == 256 || dim == 384; }
 
-template <int DIM, int NQT, int WPB, int STAGE, int RT, bool PF>
+template <int DIM, int NQT, int WPB, int STAGE, int RT, bool PF, int EB>
 static hipError_t launch_mfma_s(const MfmaScanArgs& args, int grid, hipStream_t stream, int* occupancy) {
-    const size_t lds = (size_t)NQT * 16 * (DIM + 8) * 2 + (STAGE ? (size_t)NQT * 16 * (4 + 8 * kMfmaMaxSlots) : 0);
-    auto kern = scan_mfma_kernel<DIM, NQT, WPB, STAGE, RT, PF>;
+    const size_t lds = (size_t)NQT * 16 * (DIM * EB + 16) + (STAGE ? (size_t)NQT * 16 * (4 + 8 * kMfmaMaxSlots) : 0);
+    auto kern = scan_mfma_kernel<DIM, NQT, WPB, STAGE, RT, PF, EB>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -527,11 +588,11 @@ static hipError_t launch_mfma_s(const MfmaScanArgs& args, int grid, hipStream_t 
     return hipGetLastError();
 }
 
-template <int DIM, int NQT, int WPB, int RT, bool PF>
+template <int DIM, int NQT, int WPB, int RT, bool PF, int EB>
 static hipError_t launch_mfma_t(const MfmaScanArgs& args, int grid, hipStream_t stream, int* occupancy) {
-    if (args.stage == 0) return launch_mfma_s<DIM, NQT, WPB, 0, 1, true>(args, grid, stream, occupancy);
-    if (args.stage == 1) return launch_mfma_s<DIM, NQT, WPB, 1, RT, PF>(args, grid, stream, occupancy);
-    return launch_mfma_s<DIM, NQT, WPB, 2, RT, PF>(args, grid, stream, occupancy);
+    if (args.stage == 0) return launch_mfma_s<DIM, NQT, WPB, 0, 1, true, EB>(args, grid, stream, occupancy);
+    if (args.stage == 1) return launch_mfma_s<DIM, NQT, WPB, 1, RT, PF, EB>(args, grid, stream, occupancy);
+    return launch_mfma_s<DIM, NQT, WPB, 2, RT, PF, EB>(args, grid, stream, occupancy);
 }
 
 // Shapes (nqt = query tiles of 16; wpb = waves per block; rt = 16-row sub-tiles per wave iteration):
@@ -539,38 +600,60 @@ static hipError_t launch_mfma_t(const MfmaScanArgs& args, int grid, hipStream_t 
 //   shape 1: nqt 8, wpb 8, rt 1, register double buffer   (128 queries, 100 KB LDS -> one block per CU)
 //   shape 2: nqt 8, wpb 8, rt 2, single buffer            (128 queries, half the LDS reads per row)
 //   shape 3: nqt 8, wpb 4, rt 2, register double buffer   (one wave per SIMD, 512 registers)
+//   shape 4: nqt 8, wpb 8, rt 4, single buffer            (int8 only: 64-row tiles = the same 24 KB per wave as shape 2 on f16)
 int scan_mfma_waves_per_block(int shape) { return shape == 0 || shape == 3 ? 4 : 8; }
-int scan_mfma_rows_per_tile(int shape) { return shape >= 2 ? 32 : 16; }
+int scan_mfma_rows_per_tile(int shape) { return shape == 4 ? 64 : (shape >= 2 ? 32 : 16); }
 int scan_mfma_query_tiles(int shape) { return shape == 0 ? 4 : 8; }
 
-template <int DIM>
+template <int DIM, int EB>
 static hipError_t launch_mfma_d(const MfmaScanArgs& args, int shape, int grid, hipStream_t stream, int* occupancy) {
     switch (shape) {
-        case 0: return launch_mfma_t<DIM, 4, 4, 1, true>(args, grid, stream, occupancy);
-        case 1: return launch_mfma_t<DIM, 8, 8, 1, true>(args, grid, stream, occupancy);
-        case 2: return launch_mfma_t<DIM, 8, 8, 2, false>(args, grid, stream, occupancy);
-        case 3: return launch_mfma_t<DIM, 8, 4, 2, true>(args, grid, stream, occupancy);
+        case 0: return launch_mfma_t<DIM, 4, 4, 1, true, EB>(args, grid, stream, occupancy);
+        case 1: return launch_mfma_t<DIM, 8, 8, 1, true, EB>(args, grid, stream, occupancy);
+        case 2: return launch_mfma_t<DIM, 8, 8, 2, false, EB>(args, grid, stream, occupancy);
+        case 3: return launch_mfma_t<DIM, 8, 4, 2, true, EB>(args, grid, stream, occupancy);
+        case 4:
+            if constexpr (EB == 1) return launch_mfma_t<DIM, 8, 8, 4, false, EB>(args, grid, stream, occupancy);
+            return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }
 
 hipError_t launch_scan_mfma(const MfmaScanArgs& args, int shape, int grid, hipStream_t stream, int* occupancy) {
+    if (args.elem_bytes == 1) {
+        switch (args.dim) {
+            case 128: return launch_mfma_d<128, 1>(args, shape, grid, stream, occupancy);
+            case 256: return launch_mfma_d<256, 1>(args, shape, grid, stream, occupancy);
+            case 384: return launch_mfma_d<384, 1>(args, shape, grid, stream, occupancy);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (args.dim) {
-        case 128: return launch_mfma_d<128>(args, shape, grid, stream, occupancy);
-        case 256: return launch_mfma_d<256>(args, shape, grid, stream, occupancy);
-        case 384: return launch_mfma_d<384>(args, shape, grid, stream, occupancy);
+        case 128: return launch_mfma_d<128, 2>(args, shape, grid, stream, occupancy);
+        case 256: return launch_mfma_d<256, 2>(args, shape, grid, stream, occupancy);
+        case 384: return launch_mfma_d<384, 2>(args, shape, grid, stream, occupancy);
         default: return hipErrorInvalidValue;
     }
 }
 
+hipError_t launch_prepare_queries_i8(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, void* qi8, float* delta,
+                                     hipStream_t stream) {
+    hipLaunchKernelGGL(prepare_queries_i8_kernel, dim3(nq_pad), dim3(256), 0, stream, q, nq, dim,
+                       static_cast<signed char*>(qi8), delta);
+    return hipGetLastError();
+}
+
 hipError_t launch_select(const SelectArgs& args, int nq, hipStream_t stream) {
-    if (args.k < 1 || args.k > 64 || !args.delta || (uint64_t)args.nlists * args.list_len > 0x7fffffffull)
+    if (args.k < 1 || args.k > kSelectMaxK || !args.delta || (uint64_t)args.nlists * args.list_len > 0x7fffffffull)
         return hipErrorInvalidValue;
+    const bool wide = args.k > 64;
     if (args.slab) {
         if (args.k_out < 1 || args.k_out > 64 || (args.dim & 7)) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(select_kernel<true>, dim3(nq), dim3(kSelThreads), 0, stream, args);
+        if (wide) hipLaunchKernelGGL((select_kernel<true, 2>), dim3(nq), dim3(kSelThreads), 0, stream, args);
+        else hipLaunchKernelGGL((select_kernel<true, 1>), dim3(nq), dim3(kSelThreads), 0, stream, args);
     } else {
-        hipLaunchKernelGGL(select_kernel<false>, dim3(nq), dim3(kSelThreads), 0, stream, args);
+        if (wide) hipLaunchKernelGGL((select_kernel<false, 2>), dim3(nq), dim3(kSelThreads), 0, stream, args);
+        else hipLaunchKernelGGL((select_kernel<false, 1>), dim3(nq), dim3(kSelThreads), 0, stream, args);
     }
     return hipGetLastError();
 }

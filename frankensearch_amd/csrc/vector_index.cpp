@@ -112,7 +112,7 @@ VectorIndex::~VectorIndex() {
                             &ws_counts_, &ws_keys_a_, &ws_keys_b_, &ws_sort_tmp_, &ws_gather_rows_, &ws_gather_out_,
                             &i8_slab_, &n4_slab_, &i8_max_, &ws_i8_query_, &ws_cand_packed_, &ws_cand_rows_, &ws_cand_scores_,
                             &mf_max_norm_, &mf_qh_, &mf_delta_, &mf_tau_, &mf_cand_, &mf_dense_, &mf_sel_,
-                            &mf_fallback_, &mf_spill_})
+                            &mf_fallback_, &mf_spill_, &mf_io_})
         b->release();
     if (mf_flags_host_) (void)hipHostFree(mf_flags_host_);
 }
@@ -653,6 +653,27 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
                                                      uint32_t k, const uint64_t* allow_dev, uint32_t* out_rows_dev,
                                                      float* out_scores_dev, uint32_t* out_counts_dev,
                                                      hipStream_t stream, uint32_t* fallbacks, uint64_t* out_packed_dev) {
+    return batched_impl(queries_dev, nq, query_len, k, allow_dev, out_rows_dev, out_scores_dev, out_counts_dev, stream,
+                        fallbacks, out_packed_dev, 0);
+}
+
+// int8 pass 1 on the matrix cores for a whole batch (exact integer scores), exact f16 rescore, top-k: the batched form of
+// search_top_k_int8_two_pass (search.rs:514-661).  multiplier 0 counts as 1, as in the reference.
+SearchError VectorIndex::search_top_k_int8_batched_device(const float* queries_dev, uint32_t nq, uint32_t query_len,
+                                                          uint32_t k, uint32_t multiplier, uint32_t* out_rows_dev,
+                                                          float* out_scores_dev, uint32_t* out_counts_dev,
+                                                          hipStream_t stream, uint32_t* fallbacks) {
+    return batched_impl(queries_dev, nq, query_len, k, nullptr, out_rows_dev, out_scores_dev, out_counts_dev, stream,
+                        fallbacks, nullptr, multiplier ? multiplier : 1);
+}
+
+// int8_mult == 0: f16 slab, f16-rounded queries, approximate scores + proven margin (mfma_scan.hip header).
+// int8_mult >= 1: int8 slab, int8 queries, exact integer scores; the k * int8_mult best rows are the candidates.
+SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
+                                      const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
+                                      uint32_t* out_counts_dev, hipStream_t stream, uint32_t* fallbacks,
+                                      uint64_t* out_packed_dev, uint32_t int8_mult) {
+    const bool i8 = int8_mult != 0;
     if (fallbacks) *fallbacks = 0;
     FSGPU_TRY(ensure_query_dimension(query_len));
     if (nq == 0) return ok();
@@ -670,8 +691,28 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
     RB = std::min<uint32_t>(RB, std::max<uint32_t>(8 * RA, (uint32_t)(nrows_ / 64)));
     RB = std::min<uint32_t>(RB, (uint32_t)(nrows_ / 4));
     RB = std::max<uint32_t>(RA, RB / RA * RA);
-    const bool usable = scan_mfma_supported((int)dim_) && k >= 1 && k <= 64 && nrows_ >= 4 * (uint64_t)RA && variant != 4 &&
+    // int8 mode: candidate_count of the reference (search.rs:603-607)
+    uint64_t cc64 = std::min<uint64_t>((uint64_t)k * (i8 ? int8_mult : 1), nrows_);
+    cc64 = std::max<uint64_t>(cc64, std::min<uint64_t>(k, nrows_));
+    const uint32_t ksel = i8 ? (uint32_t)std::min<uint64_t>(cc64, 0xffffffffull) : k;  // rank that anchors the selections
+    const bool usable = scan_mfma_supported((int)dim_) && k >= 1 && k <= 64 && ksel <= kSelectMaxK && nrows_ >= 4 * (uint64_t)RA && variant != 4 &&
                         (!row_stride_ || row_stride_ == dim_ * 2);
+    if (!usable && i8) {
+        // per-query int8 two-pass through host staging (rare shapes: huge candidate counts, tiny or odd-dimension slabs)
+        std::vector<float> q((size_t)nq * dim_), sc((size_t)nq * k);
+        std::vector<uint32_t> rw((size_t)nq * k, 0xffffffffu), cnt(nq);
+        FSGPU_HIP(hipMemcpyAsync(q.data(), queries_dev, q.size() * 4, hipMemcpyDeviceToHost, stream));
+        FSGPU_HIP(hipStreamSynchronize(stream));
+        for (uint32_t i = 0; i < nq; ++i)
+            FSGPU_TRY(quantized_two_pass(q.data() + (size_t)i * dim_, dim_, k, int8_mult, 8, rw.data() + (size_t)i * k,
+                                         sc.data() + (size_t)i * k, &cnt[i]));
+        if (out_rows_dev) FSGPU_HIP(hipMemcpyAsync(out_rows_dev, rw.data(), rw.size() * 4, hipMemcpyHostToDevice, stream));
+        if (out_scores_dev) FSGPU_HIP(hipMemcpyAsync(out_scores_dev, sc.data(), sc.size() * 4, hipMemcpyHostToDevice, stream));
+        if (out_counts_dev) FSGPU_HIP(hipMemcpyAsync(out_counts_dev, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice, stream));
+        FSGPU_HIP(hipStreamSynchronize(stream));
+        if (fallbacks) *fallbacks = nq;
+        return ok();
+    }
     if (!usable) {
         if (fallbacks) *fallbacks = nq;
         if (out_packed_dev) {
@@ -683,7 +724,14 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
     }
     FSGPU_HIP(hipSetDevice(device_));
     const uint32_t N = (uint32_t)nrows_;
-    if (!mf_norm_ready_) {
+    if (i8 && !i8_ready_) {  // VectorIndex::int8_slab(): built lazily, once
+        FSGPU_TRY(i8_slab_.reserve((size_t)nrows_ * dim_));
+        FSGPU_TRY(i8_max_.reserve(4));
+        FSGPU_HIP(launch_quantize_slab_i8(slab_dev_, (size_t)nrows_ * dim_, static_cast<unsigned int*>(i8_max_.ptr),
+                                          i8_slab_.ptr, stream));
+        i8_ready_ = true;
+    }
+    if (!i8 && !mf_norm_ready_) {
         FSGPU_TRY(mf_max_norm_.reserve(4));
         FSGPU_HIP(launch_max_row_norm(slab_dev_, N, dim_, static_cast<unsigned int*>(mf_max_norm_.ptr), stream));
         mf_norm_ready_ = true;
@@ -703,6 +751,12 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
         probe.stage = 2;  // the main-pass instantiation
         FSGPU_HIP(launch_scan_mfma(probe, 0, 1, stream, &mf_per_cu_narrow_));
         FSGPU_HIP(launch_scan_mfma(probe, mf_shape_, 1, stream, &mf_per_cu_wide_));
+        probe.elem_bytes = 1;
+        mf_shape_i8_ = 4;             // int8 rows are half as long: 64-row tiles keep 24 KB in flight per wave
+        if (const char* e = std::getenv("FSGPU_MFMA_SHAPE_I8")) mf_shape_i8_ = std::atoi(e);  // tuning experiments only
+        if (mf_shape_i8_ < 1 || mf_shape_i8_ > 4) mf_shape_i8_ = 4;
+        FSGPU_HIP(launch_scan_mfma(probe, 0, 1, stream, &mf_per_cu_narrow_i8_));
+        FSGPU_HIP(launch_scan_mfma(probe, mf_shape_i8_, 1, stream, &mf_per_cu_wide_i8_));
     }
     // per-query verdicts, written by the kernels straight into pinned host memory and read after ONE stream
     // synchronisation for the whole batch: [0, cap) = overflow flags, [cap, 2 cap) = candidate counts
@@ -725,11 +779,12 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
     const uint32_t k_eff = std::min<uint32_t>(k, N);
     for (uint32_t g0 = 0; g0 < nq;) {
         const uint32_t left = nq - g0;
-        const int shape = (left > 64 && variant != 5) ? mf_shape_ : 0;   // 128 or 64 queries per pass
+        const int shape = (left > 64 && variant != 5) ? (i8 ? mf_shape_i8_ : mf_shape_) : 0;   // 128 or 64 queries per pass
         const uint32_t G = (uint32_t)scan_mfma_query_tiles(shape) * 16;
         const uint32_t ng = std::min(G, left);
         const int wpb = scan_mfma_waves_per_block(shape);
-        const int full_grid = num_cus_ * (shape ? mf_per_cu_wide_ : mf_per_cu_narrow_);
+        const int full_grid = num_cus_ * (i8 ? (shape ? mf_per_cu_wide_i8_ : mf_per_cu_narrow_i8_)
+                                            : (shape ? mf_per_cu_wide_ : mf_per_cu_narrow_));
         auto grid_for = [&](uint32_t rows, uint32_t tile_rows) {
             int g = (int)(((rows + tile_rows - 1) / tile_rows + wpb - 1) / wpb);
             if (g > full_grid) g = full_grid;
@@ -739,8 +794,10 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
         const float* qg = queries_dev + (size_t)g0 * dim_;
         uint32_t* overflow = overflow_all + g0;
         uint32_t* cand_counts = counts_all + g0;
-        FSGPU_HIP(launch_prepare_queries(qg, ng, G, dim_, static_cast<const unsigned int*>(mf_max_norm_.ptr), mf_qh_.ptr,
-                                         delta, stream));
+        if (i8) FSGPU_HIP(launch_prepare_queries_i8(qg, ng, G, dim_, mf_qh_.ptr, delta, stream));
+        else
+            FSGPU_HIP(launch_prepare_queries(qg, ng, G, dim_, static_cast<const unsigned int*>(mf_max_norm_.ptr),
+                                             mf_qh_.ptr, delta, stream));
         // one candidate list of `slots` entries per (query, block); 16..32 slots, sized so that lists + pool fit one
         // selection pass when the grid allows (the wide shape's 256 blocks do)
         auto slots_for = [&](int grid) {
@@ -749,7 +806,8 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
         FSGPU_TRY(mf_cand_.reserve((size_t)G * full_grid * kMfmaMaxSlots * 8));
         u64* cand = static_cast<u64*>(mf_cand_.ptr);
         MfmaScanArgs a{};
-        a.slab = slab_dev_;
+        a.slab = i8 ? i8_slab_.ptr : slab_dev_;
+        a.elem_bytes = i8 ? 1 : 2;
         a.live = reinterpret_cast<const u64*>(live_dev_);
         a.allow = reinterpret_cast<const u64*>(allow_dev);
         a.queries = mf_qh_.ptr;
@@ -778,7 +836,7 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
         sa.l_stride = RA;
         sa.nlists = 1;
         sa.list_len = RA;
-        sa.k = k;
+        sa.k = ksel;
         sa.delta = delta;
         sa.tau_out = tau;
         FSGPU_HIP(launch_select(sa, (int)G, stream));
@@ -798,7 +856,8 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
         sb.l_stride = a.slots;
         sb.nlists = (uint32_t)grid_b;
         sb.list_len = a.slots;
-        sb.k = k;
+        sb.k = ksel;
+        sb.take_topk = i8 ? 1 : 0;
         sb.delta = delta;
         sb.overflow = overflow;
         sb.spill = spill;
@@ -823,6 +882,7 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
                 FSGPU_HIP(hipEventRecord(e1, stream));
                 events_.emplace_back(e0, e1);
                 profiled_rows_ += N - RB;
+                profiled_elem_bytes_ = i8 ? 1 : 2;
             }
             sb.q_stride = (uint64_t)full_grid * a.slots;
             sb.l_stride = a.slots;
@@ -868,7 +928,22 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
                      fb.size(), big, slot, few, mx);
     }
     const uint32_t total_fallbacks = (uint32_t)fb.size();
-    if (total_fallbacks) {
+    if (total_fallbacks && i8) {
+        // list/spill overflow (a pile of tied scores at the threshold): the per-query int8 two-pass answers those
+        std::vector<float> qh(dim_), sc(k);
+        std::vector<uint32_t> rw(k);
+        for (uint32_t i : fb) {
+            uint32_t cnt = 0;
+            FSGPU_HIP(hipMemcpyAsync(qh.data(), queries_dev + (size_t)i * dim_, (size_t)dim_ * 4, hipMemcpyDeviceToHost, stream));
+            FSGPU_HIP(hipStreamSynchronize(stream));
+            std::fill(rw.begin(), rw.end(), 0xffffffffu);
+            FSGPU_TRY(quantized_two_pass(qh.data(), dim_, k, int8_mult, 8, rw.data(), sc.data(), &cnt));
+            if (out_rows_dev) FSGPU_HIP(hipMemcpyAsync(out_rows_dev + (size_t)i * k, rw.data(), (size_t)k * 4, hipMemcpyHostToDevice, stream));
+            if (out_scores_dev) FSGPU_HIP(hipMemcpyAsync(out_scores_dev + (size_t)i * k, sc.data(), (size_t)k * 4, hipMemcpyHostToDevice, stream));
+            if (out_counts_dev) FSGPU_HIP(hipMemcpyAsync(out_counts_dev + i, &cnt, 4, hipMemcpyHostToDevice, stream));
+            FSGPU_HIP(hipStreamSynchronize(stream));
+        }
+    } else if (total_fallbacks) {
         // compact the uncertified queries, answer them with the exact kernels (8 per pass), scatter the hits back
         const size_t nf = fb.size();
         auto align_up = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
@@ -923,6 +998,42 @@ SearchError VectorIndex::search_top_k_batched(const float* queries, uint32_t nq,
     FSGPU_HIP(hipMemcpyAsync(out_rows, ws_rows_.ptr, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream_));
     FSGPU_HIP(hipMemcpyAsync(out_scores, ws_scores_.ptr, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream_));
     FSGPU_HIP(hipMemcpyAsync(out_counts, ws_counts_.ptr, (size_t)nq * 4, hipMemcpyDeviceToHost, stream_));
+    FSGPU_HIP(hipStreamSynchronize(stream_));
+    return ok();
+}
+
+SearchError VectorIndex::search_top_k_int8_batched(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
+                                                   uint32_t multiplier, uint32_t* out_rows, float* out_scores,
+                                                   uint32_t* out_counts, uint32_t* fallbacks) {
+    if (fallbacks) *fallbacks = 0;
+    FSGPU_TRY(ensure_query_dimension(query_len));
+    if (nq == 0) return ok();
+    // what the fast path does not cover goes through the per-query search, like the reference (search.rs:579-585);
+    // an index with a doc-id table also does (resolve_hits dedups by doc id there)
+    if (k == 0 || nrows_ == 0 || !wal_.empty() || has_doc_ids()) {
+        for (uint32_t i = 0; i < nq; ++i)
+            FSGPU_TRY(search_top_k_int8_two_pass(queries + (size_t)i * dim_, query_len, k, multiplier,
+                                                 out_rows + (size_t)i * k, out_scores + (size_t)i * k, &out_counts[i]));
+        if (fallbacks) *fallbacks = nq;
+        return ok();
+    }
+    FSGPU_HIP(hipSetDevice(device_));
+    // dedicated staging: the per-query fallback inside reuses the ws_* workspaces
+    auto align_up = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
+    const size_t o_q = 0, o_rows = align_up((size_t)nq * dim_ * 4, 256), o_scores = align_up(o_rows + (size_t)nq * k * 4, 256),
+                 o_counts = align_up(o_scores + (size_t)nq * k * 4, 256), total = align_up(o_counts + (size_t)nq * 4, 256);
+    FSGPU_TRY(mf_io_.reserve(total));
+    unsigned char* base = static_cast<unsigned char*>(mf_io_.ptr);
+    float* q_dev = reinterpret_cast<float*>(base + o_q);
+    uint32_t* rows_dev = reinterpret_cast<uint32_t*>(base + o_rows);
+    float* scores_dev = reinterpret_cast<float*>(base + o_scores);
+    uint32_t* counts_dev = reinterpret_cast<uint32_t*>(base + o_counts);
+    FSGPU_HIP(hipMemcpyAsync(q_dev, queries, (size_t)nq * dim_ * 4, hipMemcpyHostToDevice, stream_));
+    FSGPU_TRY(search_top_k_int8_batched_device(q_dev, nq, query_len, k, multiplier, rows_dev, scores_dev, counts_dev,
+                                               stream_, fallbacks));
+    FSGPU_HIP(hipMemcpyAsync(out_rows, rows_dev, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream_));
+    FSGPU_HIP(hipMemcpyAsync(out_scores, scores_dev, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream_));
+    FSGPU_HIP(hipMemcpyAsync(out_counts, counts_dev, (size_t)nq * 4, hipMemcpyDeviceToHost, stream_));
     FSGPU_HIP(hipStreamSynchronize(stream_));
     return ok();
 }

@@ -66,6 +66,14 @@ class VectorIndex {
     SearchError search_top_k_batched(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
                                      const uint64_t* allow, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
                                      uint32_t* fallbacks);
+    // Batched search_top_k_int8_two_pass (search.rs:514-661): int8 pass 1 on the matrix cores (exact integer scores, so the
+    // k*multiplier candidates are exactly the reference's), exact f16 rescore, top-k.  No doc-id dedup (raw row ids).
+    SearchError search_top_k_int8_batched_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
+                                                 uint32_t multiplier, uint32_t* out_rows_dev, float* out_scores_dev,
+                                                 uint32_t* out_counts_dev, hipStream_t stream, uint32_t* fallbacks);
+    SearchError search_top_k_int8_batched(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
+                                          uint32_t multiplier, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
+                                          uint32_t* fallbacks);
     // Shard-local search whose result stays packed (score bits << 32 | global row; ~0 padding) for the
     // cross-GPU exchange: out_packed_dev is [nq, k].  Fused tiers only (k <= 256, dim % 8 == 0).
     SearchError search_top_k_packed_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
@@ -112,6 +120,9 @@ class VectorIndex {
 
   private:
     SearchError ensure_query_dimension(uint32_t query_len) const;
+    SearchError batched_impl(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k, const uint64_t* allow_dev,
+                             uint32_t* out_rows_dev, float* out_scores_dev, uint32_t* out_counts_dev, hipStream_t stream,
+                             uint32_t* fallbacks, uint64_t* out_packed_dev, uint32_t int8_mult);
     SearchError quantized_two_pass(const float* query, uint32_t query_len, uint32_t k, uint32_t multiplier, int bits,
                                    uint32_t* out_rows, float* out_scores, uint32_t* out_count);
     SearchError common_init(int device);
@@ -140,15 +151,17 @@ class VectorIndex {
     DeviceBuffer ws_partial_, ws_queries_, ws_allow_, ws_rows_, ws_scores_, ws_counts_, ws_keys_a_, ws_keys_b_,
         ws_sort_tmp_, ws_gather_rows_, ws_gather_out_, i8_slab_, n4_slab_, i8_max_, ws_i8_query_, ws_cand_packed_,
         ws_cand_rows_, ws_cand_scores_, mf_max_norm_, mf_qh_, mf_delta_, mf_tau_, mf_cand_, mf_dense_, mf_sel_,
-        mf_fallback_, mf_spill_;
+        mf_fallback_, mf_spill_, mf_io_;
     bool i8_ready_ = false, n4_ready_ = false;
     bool mf_norm_ready_ = false;
-    int mf_shape_ = -1, mf_per_cu_narrow_ = 1, mf_per_cu_wide_ = 1;  // batched-scan launch shapes (probed once)
+    int mf_shape_i8_ = 4;
+    int mf_shape_ = -1, mf_per_cu_narrow_ = 1, mf_per_cu_wide_ = 1, mf_per_cu_narrow_i8_ = 1, mf_per_cu_wide_i8_ = 1;  // batched-scan launch shapes (probed once)
     uint32_t* mf_flags_host_ = nullptr;                              // pinned per-query verdicts of the batched scan
     uint32_t mf_flags_cap_ = 0;
     // profiling events
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events_;
     uint64_t profiled_rows_ = 0;  // slab rows streamed by the timed launches
+    uint32_t profiled_elem_bytes_ = 2;
     // FSVI host-side tables
     std::vector<uint64_t> live_host_;
     std::vector<uint64_t> doc_hashes_;

@@ -179,6 +179,15 @@ fsgpu_status fsgpu_search_hits(fsgpu_index *idx, const float *query, uint32_t qu
 fsgpu_status fsgpu_search_topk_int8_two_pass(fsgpu_index *idx, const float *query, uint32_t query_len, uint32_t k,
                                              uint32_t candidate_multiplier, uint32_t *out_rows, float *out_scores,
                                              uint32_t *out_count);
+/* Batched search_top_k_int8_two_pass: nq queries share each pass over the int8 slab (int8 MFMA, exact integer
+ * scores: the k*candidate_multiplier candidates of every query are exactly the reference's), then the exact f16 rescore
+ * and the best-first selection of k.  Outputs as fsgpu_search_topk ([nq, k] rows / scores, [nq] counts).  Row-level
+ * results: indexes with a doc-id table, a resident WAL, k = 0 or shapes the matrix-core kernel does not cover are
+ * answered query by query through fsgpu_search_topk_int8_two_pass (counted in *out_fallbacks, may be NULL). */
+fsgpu_status fsgpu_search_topk_int8_two_pass_batched(fsgpu_index *idx, const float *queries, uint32_t nq, uint32_t query_len,
+                                                     uint32_t k, uint32_t candidate_multiplier, uint32_t *out_rows,
+                                                     float *out_scores, uint32_t *out_counts, uint32_t *out_fallbacks);
+
 /* VectorIndex::search_top_k_4bit_two_pass (crates/frankensearch-index/src/search.rs:876-946): pass 1 over a packed
  * signed-4-bit slab (dim/2 bytes per vector, one corpus-wide scale 7/max_abs, simd.rs:2153-2215; exact integer nibble
  * dot, simd.rs:1338-1556) keeps the top k*candidate_multiplier, pass 2 re-scores them with the exact f16 dot.  Same

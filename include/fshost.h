@@ -24,6 +24,9 @@ typedef struct fshost_two_tier_config {
     double rrf_k;                  /* 60 */
     uint32_t candidate_multiplier; /* 3 */
     int32_t doc_id_mode;           /* 0 = the indexes' FSVI doc-id tables (fsgpu_index_doc_id); 1 = "doc-%08u" of the row */
+    uint32_t fast_tier_int8_multiplier; /* 0 = exact f16 scan of the fast tier; n = search_top_k_int8_two_pass(query, fetch, n),
+                                         * the reference's default with n = FAST_TIER_MULT = 3 (two_tier.rs:1318-1337,
+                                         * sync_searcher::search_fast_hits) */
 } fshost_two_tier_config;
 
 #define FSHOST_DOC_ID_MAX 63

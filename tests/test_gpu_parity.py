@@ -551,3 +551,49 @@ def test_4bit_two_pass_matches_oracle(fa, oracle, tmp_path):
     er, es = oracle.search_4bit_two_pass(np.zeros((100, 128), np.uint16), np.ones(128, np.float32), 5, 3)
     gh = z.search_top_k_4bit_two_pass(np.ones(128, np.float32), 5, 3)
     assert [h.index for h in gh] == er.tolist()
+
+
+@pytest.mark.gpu
+def test_int8_two_pass_batched_equals_per_query_and_oracle(fa, oracle):
+    # the batched int8 pass 1 runs on the int8 MFMA: scores are exact integers, so every query must get exactly the
+    # candidates — hence exactly the hits — of search_top_k_int8_two_pass (search.rs:514-661)
+    rng = np.random.default_rng(107)
+    for n, dim in ((150_001, 384), (60_000, 256), (40_000, 128)):
+        cent = rng.standard_normal((24, dim)).astype(np.float32)
+        cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+        rows = cent[rng.integers(0, 24, n)] + 0.3 * rng.standard_normal((n, dim)).astype(np.float32) / np.sqrt(dim)
+        rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+        rows[4000:4030] = rows[3999]                       # a run of identical rows: int8 AND f16 ties, row order decides
+        slab = rows.astype(np.float16).view(np.uint16)
+        live = rng.random(n) > 0.05
+        idx = fa.VectorIndex.from_slab(slab, live=live)
+        nq = 150
+        q = cent[rng.integers(0, 24, nq)] + 0.3 * rng.standard_normal((nq, dim)).astype(np.float32) / np.sqrt(dim)
+        q[2] = rows[3999]
+        q[5] = 0.0                                         # all-zero query: every int8 score ties at 0
+        q[6] *= 11.0
+        q[7, 3] = np.nan
+        for k, mult in ((10, 3), (10, 1), (1, 5), (20, 3), (7, 0), (30, 3), (25, 5)):   # up to 125 candidates
+            br, bs, bc, fb = idx.search_int8_two_pass_batched(q, k, mult)
+            assert fb < nq // 3, (n, dim, k, mult, fb)
+            for qi in list(range(12)) + [64, 127, 128, 149]:
+                hits = idx.search_top_k_int8_two_pass(q[qi], k, mult)
+                assert [h.index for h in hits] == br[qi, :bc[qi]].tolist(), (n, dim, k, mult, qi)
+                assert np.array_equal(bits([h.score for h in hits]), bits(bs[qi, :bc[qi]])), (n, dim, k, mult, qi)
+        i8 = oracle.quantize_slab_i8(slab)
+        br, bs, bc, _ = idx.search_int8_two_pass_batched(q, 10, 3)
+        for qi in (0, 2, 6, 100):
+            er, es = oracle.search_int8_two_pass(slab, q[qi], 10, 3, live=live, slab_i8=i8)
+            assert np.array_equal(br[qi, :bc[qi]], er) and np.array_equal(bits(bs[qi, :bc[qi]]), bits(es)), (n, dim, qi)
+    # shapes the matrix-core path does not cover fall back per query, same answers
+    small = fa.VectorIndex.from_slab(slab[:3000])
+    br, bs, bc, fb = small.search_int8_two_pass_batched(q[:9], 10, 3)
+    assert fb == 9
+    for qi in range(9):
+        hits = small.search_top_k_int8_two_pass(q[qi], 10, 3)
+        assert [h.index for h in hits] == br[qi, :bc[qi]].tolist()
+    br, bs, bc, fb = idx.search_int8_two_pass_batched(q[:5], 50, 3)     # k * mult = 150 > 128 candidates
+    assert fb == 5
+    for qi in range(5):
+        hits = idx.search_top_k_int8_two_pass(q[qi], 50, 3)
+        assert [h.index for h in hits] == br[qi, :bc[qi]].tolist()

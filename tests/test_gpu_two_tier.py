@@ -123,6 +123,29 @@ def test_coalesced_concurrent_callers_get_identical_results():
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), i
     batches, requests = idx.coalescing_stats()
     assert requests == nq and batches < nq // 2, (batches, requests)
+    # the int8 two-pass rides the same coalescer (the reference's fast-tier default: fetch 30, multiplier 3)
+    idx.set_coalescing(0, 0)
+    want8 = [idx.search_top_k_int8_two_pass(q[i], 30, 3) for i in range(nq)]
+    idx.set_coalescing(64, 20_000)
+    got8 = [None] * nq
+
+    def call8(i):
+        try:
+            got8[i] = idx.search_top_k_int8_two_pass(q[i], 30, 3)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=call8, args=(i,)) for i in range(nq)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(nq):
+        assert [(h.index, np.float32(h.score).view(np.uint32)) for h in got8[i]] == \
+               [(h.index, np.float32(h.score).view(np.uint32)) for h in want8[i]], i
+    b2, r2 = idx.coalescing_stats()
+    assert r2 == 2 * nq and b2 - batches < nq // 2
     idx.set_coalescing(0, 0)
 
 
