@@ -17,12 +17,26 @@
 // straight from L2 — no LDS staging or transposition.  A wave owns a 64x64 output tile (4x4 MFMA tiles,
 // 64 accumulator registers), a 256-thread block owns 128x128, fragments for step k+1 are in flight while step
 // k's 16 MFMAs issue.
+#include <cstdlib>
+
 #include "device_util.hpp"
 #include "kernels.hpp"
 
 namespace fsgpu {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// GEMM kernel choice (see launch_bert_gemm): a handful of tokens -> 32x64 direct-fragment tiles (2), otherwise the
+// LDS-tiled 64x128 kernel (6); the other shapes are kept for tuning runs (FSGPU_BERT_GEMM_SHAPE).
+static int bert_gemm_shape_override() {
+    static const int v = [] {
+        const char* e = std::getenv("FSGPU_BERT_GEMM_SHAPE");
+        return e ? std::atoi(e) : -1;
+    }();
+    return v;
+}
+#define FSGPU_BERT_GEMM_SHAPE(M, N) \
+    (bert_gemm_shape_override() >= 0 ? bert_gemm_shape_override() : ((M) <= 64 ? 2 : 6))
 
 namespace {
 
@@ -122,66 +136,180 @@ __global__ __launch_bounds__(256) void bert_add_ln_kernel(float* __restrict__ x_
 
 // C[M,N] = A[M,K] (f16) x W[N,K]^T (f16) + bias, f32 accumulate on MFMA.
 // EPI 0: f32 output.  EPI 1: GELU then f16 output (FFN up-projection).
-template <int EPI>
+// A 256-thread block is 2 x 2 waves; a wave owns a (16 WM) x (16 WN) output tile.  The k-loop is latency-bound (the
+// operands come straight from L2 and a block has only four waves), so fragments are prefetched DEPTH - 1 steps ahead
+// through a register ring; DEPTH is a power of two and K/32 a multiple of it (K is 384 or 1536 here).
+template <int EPI, int WM, int WN, int DEPTH>
 __global__ __launch_bounds__(256) void bert_gemm_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ out_f32,
                                                         _Float16* __restrict__ out_h, int M, int N, int K) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * 128 + wm * 64;
-    const int n0 = blockIdx.x * 128 + wn * 64;
+    const int m0 = blockIdx.y * (32 * WM) + wm * (16 * WM);
+    const int n0 = blockIdx.x * (32 * WN) + wn * (16 * WN);
     const int fr = lane & 15;        // fragment row (A) / column (B)
     const int fk = (lane >> 4) * 8;  // k offset inside the 32-wide step
-    const half8* ap[4];
-    const half8* bp[4];
+    const half8* ap[WM];
+    const half8* bp[WN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < WM; ++i) {
         int row = m0 + i * 16 + fr;
         row = row < M ? row : M - 1;
         ap[i] = reinterpret_cast<const half8*>(A + (size_t)row * K + fk);
-        bp[i] = reinterpret_cast<const half8*>(W + (size_t)(n0 + i * 16 + fr) * K + fk);
     }
-    f32x4 acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    half8 a_cur[4], b_cur[4], a_nxt[4], b_nxt[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        a_cur[i] = ap[i][0];
-        b_cur[i] = bp[i][0];
+    for (int j = 0; j < WN; ++j) {
+        int col = n0 + j * 16 + fr;
+        col = col < N ? col : N - 1;
+        bp[j] = reinterpret_cast<const half8*>(W + (size_t)col * K + fk);
     }
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    half8 ar[DEPTH][WM], br[DEPTH][WN];
     const int ksteps = K / 32;
-    for (int ks = 0; ks < ksteps; ++ks) {
-        if (ks + 1 < ksteps) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a_nxt[i] = ap[i][(ks + 1) * 4];  // 32 halves = 4 half8
-                b_nxt[i] = bp[i][(ks + 1) * 4];
-            }
+    for (int d = 0; d < DEPTH - 1; ++d)
+        if (d < ksteps) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i) ar[d][i] = ap[i][d * 4];  // 32 halves = 4 half8
+#pragma unroll
+            for (int j = 0; j < WN; ++j) br[d][j] = bp[j][d * 4];
         }
+    for (int ks0 = 0; ks0 < ksteps; ks0 += DEPTH) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int u = 0; u < DEPTH; ++u) {
+            const int ks = ks0 + u;
+            const int pf = ks + DEPTH - 1;  // step whose fragments are requested now
+            constexpr int kRing = DEPTH;
+            const int slot_pf = (u + DEPTH - 1) % kRing;
+            if (pf < ksteps) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur[i], b_cur[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < WM; ++i) ar[slot_pf][i] = ap[i][pf * 4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            a_cur[i] = a_nxt[i];
-            b_cur[i] = b_nxt[i];
+                for (int j = 0; j < WN; ++j) br[slot_pf][j] = bp[j][pf * 4];
+            }
+            if (ks < ksteps) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[u][i], br[u][j], acc[i][j], 0, 0, 0);
+            }
         }
     }
     // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
     const int crow = (lane >> 4) * 4;
     const int ccol = lane & 15;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < WN; ++j) {
         const int col = n0 + j * 16 + ccol;
+        if (col >= N) continue;
         const float bv = bias[col];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < WM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + i * 16 + crow + r;
+                if (row < M) {
+                    const float y = acc[i][j][r] + bv;
+                    if (EPI == 0) out_f32[(size_t)row * N + col] = y;
+                    else out_h[(size_t)row * N + col] = (_Float16)gelu_as(y);
+                }
+            }
+        }
+    }
+}
+
+// LDS-tiled variant for token counts that fill the chip.  Loading MFMA fragments straight from global memory makes
+// every wave-load touch 16 rows (16 x 64-byte segments): the texture-address path, not L2 or the matrix cores, then
+// bounds the kernel near 150 TFLOP/s.  Here the 256 threads fetch the (BM x 32) and (BN x 32) operand slices of a
+// k-step with fully coalesced 16-byte loads (four threads per 64-byte row slice), park them in LDS with an 80-byte row
+// pitch (fragment reads are then bank-conflict-free) and every wave reads its fragments from LDS; each global element
+// is fetched once per block instead of twice.  Two LDS stages: the loads of step k+1 are in flight during step k.
+template <int EPI, int WM, int WN>
+__global__ __launch_bounds__(256) void bert_gemm_lds_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+                                                            const float* __restrict__ bias, float* __restrict__ out_f32,
+                                                            _Float16* __restrict__ out_h, int M, int N, int K) {
+    constexpr int BM = 32 * WM, BN = 32 * WN;
+    constexpr int PITCH = 40;                       // halves per LDS row: 32 data + 8 pad (80 bytes)
+    constexpr int A_LOADS = BM * 4 / 256;           // 16-byte pieces per thread per k-step
+    constexpr int B_LOADS = BN * 4 / 256;
+    static_assert(A_LOADS >= 1 && B_LOADS >= 1, "tile too small for 256 loader threads");
+    __shared__ __attribute__((aligned(16))) _Float16 As[2][BM * PITCH];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[2][BN * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    // loader mapping: piece p = tid + 256 * x -> row p / 4, 16-byte column p % 4
+    const half8* ag[A_LOADS];
+    const half8* bg[B_LOADS];
+    int a_off[A_LOADS], b_off[B_LOADS];
+#pragma unroll
+    for (int x = 0; x < A_LOADS; ++x) {
+        const int p = tid + 256 * x, r = p >> 2, c = p & 3;
+        int row = bm0 + r;
+        row = row < M ? row : M - 1;
+        ag[x] = reinterpret_cast<const half8*>(A + (size_t)row * K) + c;
+        a_off[x] = r * PITCH + c * 8;
+    }
+#pragma unroll
+    for (int x = 0; x < B_LOADS; ++x) {
+        const int p = tid + 256 * x, r = p >> 2, c = p & 3;
+        int col = bn0 + r;
+        col = col < N ? col : N - 1;
+        bg[x] = reinterpret_cast<const half8*>(W + (size_t)col * K) + c;
+        b_off[x] = r * PITCH + c * 8;
+    }
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ksteps = K / 32;
+    half8 ra[A_LOADS], rb[B_LOADS];
+#pragma unroll
+    for (int x = 0; x < A_LOADS; ++x) ra[x] = ag[x][0];
+#pragma unroll
+    for (int x = 0; x < B_LOADS; ++x) rb[x] = bg[x][0];
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int st = ks & 1;
+#pragma unroll
+        for (int x = 0; x < A_LOADS; ++x) *reinterpret_cast<half8*>(&As[st][a_off[x]]) = ra[x];
+#pragma unroll
+        for (int x = 0; x < B_LOADS; ++x) *reinterpret_cast<half8*>(&Bs[st][b_off[x]]) = rb[x];
+        if (ks + 1 < ksteps) {
+#pragma unroll
+            for (int x = 0; x < A_LOADS; ++x) ra[x] = ag[x][(ks + 1) * 4];
+#pragma unroll
+            for (int x = 0; x < B_LOADS; ++x) rb[x] = bg[x][(ks + 1) * 4];
+        }
+        __syncthreads();  // stage st is complete; stage st^1 (read during the previous step) may now be overwritten
+        half8 af[WM], bf[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+            af[i] = *reinterpret_cast<const half8*>(&As[st][(wm * 16 * WM + i * 16 + fr) * PITCH + fk]);
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+            bf[j] = *reinterpret_cast<const half8*>(&Bs[st][(wn * 16 * WN + j * 16 + fr) * PITCH + fk]);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    const int crow = (lane >> 4) * 4, ccol = lane & 15;
+    const int m0 = bm0 + wm * 16 * WM, n0 = bn0 + wn * 16 * WN;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int col = n0 + j * 16 + ccol;
+        if (col >= N) continue;
+        const float bv = bias[col];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + i * 16 + crow + r;
@@ -327,15 +455,53 @@ hipError_t launch_bert_add_ln(float* x_f32, const float* delta, const float* lnw
     return hipGetLastError();
 }
 
+template <int EPI, int WM, int WN>
+static void launch_gemm_lds(const void* a_h, const void* w_h, const float* bias, float* out_f32, void* out_h, int M, int N,
+                            int K, hipStream_t stream) {
+    const dim3 grid((N + 32 * WN - 1) / (32 * WN), (M + 32 * WM - 1) / (32 * WM));
+    hipLaunchKernelGGL((bert_gemm_lds_kernel<EPI, WM, WN>), grid, dim3(256), 0, stream, static_cast<const _Float16*>(a_h),
+                       static_cast<const _Float16*>(w_h), bias, out_f32, static_cast<_Float16*>(out_h), M, N, K);
+}
+
+template <int EPI, int WM, int WN, int DEPTH>
+static void launch_gemm_t(const void* a_h, const void* w_h, const float* bias, float* out_f32, void* out_h, int M, int N,
+                          int K, hipStream_t stream) {
+    const dim3 grid((N + 32 * WN - 1) / (32 * WN), (M + 32 * WM - 1) / (32 * WM));
+    hipLaunchKernelGGL((bert_gemm_kernel<EPI, WM, WN, DEPTH>), grid, dim3(256), 0, stream, static_cast<const _Float16*>(a_h),
+                       static_cast<const _Float16*>(w_h), bias, out_f32, static_cast<_Float16*>(out_h), M, N, K);
+}
+
+// Measured on MI355X, 256 queries (5.2k tokens) per forward: direct 128x128 1.49 ms, LDS 128x128 1.25 ms, LDS 64x128
+// 1.15 ms, LDS 64x64 1.16 ms; single query: direct 32x64 0.41 ms, LDS 64x128 0.46 ms.
 hipError_t launch_bert_gemm(const void* a_h, const void* w_h, const float* bias, float* out_f32, void* out_h, int M,
                             int N, int K, bool gelu_half_out, hipStream_t stream) {
-    const dim3 grid(N / 128, (M + 127) / 128);
-    if (gelu_half_out)
-        hipLaunchKernelGGL(bert_gemm_kernel<1>, grid, dim3(256), 0, stream, static_cast<const _Float16*>(a_h),
-                           static_cast<const _Float16*>(w_h), bias, out_f32, static_cast<_Float16*>(out_h), M, N, K);
-    else
-        hipLaunchKernelGGL(bert_gemm_kernel<0>, grid, dim3(256), 0, stream, static_cast<const _Float16*>(a_h),
-                           static_cast<const _Float16*>(w_h), bias, out_f32, static_cast<_Float16*>(out_h), M, N, K);
+    const int mode = gelu_half_out ? 1 : 0;
+    const int shape = FSGPU_BERT_GEMM_SHAPE(M, N);
+    if (shape == 5) {   // LDS-tiled 128 x 128
+        if (mode) launch_gemm_lds<1, 4, 4>(a_h, w_h, bias, out_f32, out_h, M, N, K, stream);
+        else launch_gemm_lds<0, 4, 4>(a_h, w_h, bias, out_f32, out_h, M, N, K, stream);
+    } else if (shape == 6) {   // LDS-tiled 64 x 128
+        if (mode) launch_gemm_lds<1, 2, 4>(a_h, w_h, bias, out_f32, out_h, M, N, K, stream);
+        else launch_gemm_lds<0, 2, 4>(a_h, w_h, bias, out_f32, out_h, M, N, K, stream);
+    } else if (shape == 7) {   // LDS-tiled 64 x 64
+        if (mode) launch_gemm_lds<1, 2, 2>(a_h, w_h, bias, out_f32, out_h, M, N, K, stream);
+        else launch_gemm_lds<0, 2, 2>(a_h, w_h, bias, out_f32, out_h, M, N, K, stream);
+    } else if (shape == 0) {
+        if (mode) launch_gemm_t<1, 4, 4, 2>(a_h, w_h, bias, out_f32, out_h, M, N, K, stream);
+        else launch_gemm_t<0, 4, 4, 2>(a_h, w_h, bias, out_f32, out_h, M, N, K, stream);
+    } else if (shape == 3) {
+        if (mode) launch_gemm_t<1, 4, 4, 4>(a_h, w_h, bias, out_f32, out_h, M, N, K, stream);
+        else launch_gemm_t<0, 4, 4, 4>(a_h, w_h, bias, out_f32, out_h, M, N, K, stream);
+    } else if (shape == 4) {
+        if (mode) launch_gemm_t<1, 2, 4, 4>(a_h, w_h, bias, out_f32, out_h, M, N, K, stream);
+        else launch_gemm_t<0, 2, 4, 4>(a_h, w_h, bias, out_f32, out_h, M, N, K, stream);
+    } else if (shape == 1) {
+        if (mode) launch_gemm_t<1, 2, 2, 4>(a_h, w_h, bias, out_f32, out_h, M, N, K, stream);
+        else launch_gemm_t<0, 2, 2, 4>(a_h, w_h, bias, out_f32, out_h, M, N, K, stream);
+    } else {
+        if (mode) launch_gemm_t<1, 1, 2, 4>(a_h, w_h, bias, out_f32, out_h, M, N, K, stream);
+        else launch_gemm_t<0, 1, 2, 4>(a_h, w_h, bias, out_f32, out_h, M, N, K, stream);
+    }
     return hipGetLastError();
 }
 
