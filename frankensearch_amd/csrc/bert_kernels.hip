@@ -397,6 +397,131 @@ __global__ __launch_bounds__(256) void bert_attention_kernel(const float* __rest
     }
 }
 
+// Matrix-core attention, one wave per (document, head, 16-query tile), keys streamed in blocks of 32 with an online
+// softmax (flash-attention order of operations; same mathematics as fused_attention, native.rs:366-432):
+//   S = Q K^T            two v_mfma_f32_16x16x32_f16 per key block (the head dimension is exactly one k-step)
+//   online softmax       row max / sum with DPP all-reduces over the 16 lanes that share a query row; exp((s - m) scale)
+//   O += P V             P goes through a per-wave LDS tile to become an A fragment; the V block is staged transposed
+//                        in LDS (f16) so that a lane's 16 bytes are 8 consecutive keys of one output dimension
+// Q, K, V and P enter the MFMAs as f16 (f32 accumulate); softmax statistics and the output accumulators stay f32.
+// Any sequence length works; short queries cost one key block.  Replaces the VALU kernel above (kept for A/B runs).
+namespace {
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false)));
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));
+    return v;
+}
+__device__ __forceinline__ half8 load8_as_half(const float* p) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    half8 h;
+    h[0] = (_Float16)a.x; h[1] = (_Float16)a.y; h[2] = (_Float16)a.z; h[3] = (_Float16)a.w;
+    h[4] = (_Float16)b.x; h[5] = (_Float16)b.y; h[6] = (_Float16)b.z; h[7] = (_Float16)b.w;
+    return h;
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void bert_attention_mfma_kernel(const float* __restrict__ qkv,
+                                                                  const uint32_t* __restrict__ offsets,
+                                                                  _Float16* __restrict__ ctx_h, int hidden, float scale) {
+    constexpr int PP = 40;  // halves per LDS row (32 + 8 pad: conflict-free 16-byte fragment reads)
+    __shared__ __attribute__((aligned(16))) _Float16 Pl[4][16 * PP];
+    __shared__ __attribute__((aligned(16))) _Float16 Vt[4][32 * PP];
+    const int doc = blockIdx.x, head = blockIdx.y;
+    const uint32_t t0 = offsets[doc];
+    const int S = (int)(offsets[doc + 1] - t0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q0 = (blockIdx.z * 4 + wave) * 16;
+    if (q0 >= S) return;  // wave-uniform; no block-level synchronisation below
+    const int stride = 3 * hidden;
+    const int fr = lane & 15, kg = lane >> 4;
+    _Float16* P = Pl[wave];
+    _Float16* V = Vt[wave];
+    const float* base = qkv + (size_t)t0 * stride + head * 32;
+    // Q fragment: query q0 + fr (clamped; rows past the end are never written), dims kg*8..+8
+    const int qrow = q0 + fr < S ? q0 + fr : S - 1;
+    const half8 aq = load8_as_half(base + (size_t)qrow * stride + kg * 8);
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+    float m[4], l[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        m[r] = -INFINITY;
+        l[r] = 0.f;
+    }
+    for (int k0 = 0; k0 < S; k0 += 32) {
+        // scores of the 16 queries against keys k0..k0+31
+        f32x4 s[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int key = k0 + j * 16 + fr;
+            const int krow = key < S ? key : S - 1;
+            const half8 bk = load8_as_half(base + (size_t)krow * stride + hidden + kg * 8);
+            s[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aq, bk, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            if (key >= S) s[j] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // C column = key = lane & 15
+        }
+        // V block -> LDS, transposed: lane (key = lane & 31, half = lane >> 5) owns 16 dims of one key
+        {
+            const int key = k0 + (lane & 31), hf = lane >> 5;
+            const int vrow = key < S ? key : S - 1;
+            const float4* vp = reinterpret_cast<const float4*>(base + (size_t)vrow * stride + 2 * hidden + hf * 16);
+            const bool live = key < S;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const float4 v = vp[x];
+                const int d = hf * 16 + x * 4;
+                V[(d + 0) * PP + (lane & 31)] = live ? (_Float16)v.x : (_Float16)0.f;
+                V[(d + 1) * PP + (lane & 31)] = live ? (_Float16)v.y : (_Float16)0.f;
+                V[(d + 2) * PP + (lane & 31)] = live ? (_Float16)v.z : (_Float16)0.f;
+                V[(d + 3) * PP + (lane & 31)] = live ? (_Float16)v.w : (_Float16)0.f;
+            }
+        }
+        // online softmax; C layout: row = kg * 4 + r (query), col = fr (key inside the 16-key tile)
+        float p[2][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float mx = row16_max(fmaxf(s[0][r], s[1][r]));
+            const float mn = fmaxf(m[r], mx);
+            const float corr = __expf((m[r] - mn) * scale);
+            p[0][r] = __expf((s[0][r] - mn) * scale);
+            p[1][r] = __expf((s[1][r] - mn) * scale);
+            l[r] = l[r] * corr + row16_sum(p[0][r] + p[1][r]);
+            m[r] = mn;
+            o0[r] *= corr;
+            o1[r] *= corr;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[(kg * 4 + r) * PP + j * 16 + fr] = (_Float16)p[j][r];
+        wave_lds_fence();
+        const half8 ap = *reinterpret_cast<const half8*>(&P[fr * PP + kg * 8]);          // A: query fr, keys kg*8..+8
+        const half8 bv0 = *reinterpret_cast<const half8*>(&V[fr * PP + kg * 8]);         // B: dim fr, keys kg*8..+8
+        const half8 bv1 = *reinterpret_cast<const half8*>(&V[(16 + fr) * PP + kg * 8]);  // B: dim 16 + fr
+        o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ap, bv0, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ap, bv1, o1, 0, 0, 0);
+        wave_lds_fence();  // the next block overwrites P and V
+    }
+    // C layout of the outputs: row = kg * 4 + r (query), col = fr (dim inside the tile)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int q = q0 + kg * 4 + r;
+        if (q < S) {
+            const float inv = 1.0f / l[r];
+            _Float16* dst = ctx_h + (size_t)(t0 + q) * hidden + head * 32;
+            dst[fr] = (_Float16)(o0[r] * inv);
+            dst[16 + fr] = (_Float16)(o1[r] * inv);
+        }
+    }
+}
+
 // Mean over all tokens of a document, then L2 (native.rs:1209-1235; zero guard of
 // fastembed_embedder.rs:416-426).  One block per document.
 __global__ __launch_bounds__(256) void bert_pool_kernel(const float* __restrict__ x, const uint32_t* __restrict__ offsets,
@@ -512,6 +637,15 @@ size_t bert_attention_lds_bytes(int max_seq) {
 
 hipError_t launch_bert_attention(const float* qkv, const uint32_t* offsets, void* ctx_h, int n_docs, int heads,
                                  int hidden, int max_seq, float scale, hipStream_t stream) {
+    static const bool valu = [] {
+        const char* e = std::getenv("FSGPU_BERT_ATTN");  // "valu" = the f32 VALU kernel (A/B runs)
+        return e && e[0] == 'v';
+    }();
+    if (!valu) {
+        hipLaunchKernelGGL(bert_attention_mfma_kernel, dim3(n_docs, heads, (max_seq + 63) / 64), dim3(256), 0, stream, qkv,
+                           offsets, static_cast<_Float16*>(ctx_h), hidden, scale);
+        return hipGetLastError();
+    }
     const size_t lds = bert_attention_lds_bytes(max_seq);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bert_attention_kernel),
