@@ -26,7 +26,7 @@ m2v = fa.Model2VecEmbedder(table, device=0)
 bert = fa.NativeEmbedder(random_bert_weights(1, 30522, 384, 6, 1536), device=0)
 native = NativeTwoTierSearcher(fast, quality, m2v, bert, doc_id_mode=1,
                                fast_tier_int8_multiplier=int(os.environ.get("FAST_INT8", "3")))
-for threads, mb, wait in ((1, 0, 0), (256, 128, 1000), (512, 128, 1000), (1024, 128, 1000)):
+for threads, mb, wait in ((1, 0, 0), (256, 128, 1000), (1024, 128, 1000), (2048, 128, 1000)):
     fast.set_coalescing(mb, wait)
     quality.set_coalescing(mb, wait)
     m2v.set_coalescing(2 * mb, wait // 2)
