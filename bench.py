@@ -432,6 +432,17 @@ def main() -> None:
                 "launches": launches,
             },
         }
+        # HBM traffic per launch of the dominant kernel: PMC counters need their own rocprofv3 run, so the figure comes
+        # from the committed summary of that run (scripts/pmc_summary.py), for the default workload only
+        pmc_path = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")
+        if world == 1 and args.rows == 10_000_000 and args.dim == 384 and os.path.exists(pmc_path):
+            want = "scan_mfma_kernel<384, 8, 8, 2" if args.batched else ("scan_mq_topk_kernel<384" if B >= 4 else "scan_topk_kernel<384, 1")
+            for e in json.load(open(pmc_path)):
+                if e.get("counter") == "FETCH_SIZE" and want in e.get("kernel", "") and "hbm_read_bytes_corrected" in e:
+                    line["roofline"]["traffic"] = e["hbm_read_bytes_corrected"]
+                    line["roofline"]["traffic_source"] = ("profiles/r01/pmc_summary.json: rocprofv3 --pmc FETCH_SIZE of this "
+                                                          "command, KiB x 1024 x 2 (gfx950 correction)")
+                    break
         if lat:
             line["p50_latency_ms_single_query"] = lat[len(lat) // 2]
         if world == 1 and not args.no_two_tier:

@@ -448,6 +448,10 @@ def test_batched_mfma_wide_groups_topical_rows_and_filters(fa, oracle):
     q = cent[rng.integers(0, 48, nq)] + 0.25 * rng.standard_normal((nq, dim)).astype(np.float32) / np.sqrt(dim)
     q[3] = rows[999]                       # hits the run of identical rows
     q[4] = rows[17]
+    q[8, 3] = np.nan                       # non-finite queries cannot be certified: exact path, same bits
+    q[9, 0] = np.inf
+    q[10] *= 1e30                          # f16-overflowing query
+    q[11] *= 1e-30                         # f16-subnormal / underflowing query
     allow = rng.random(n) > 0.5
     for k, mask in ((10, None), (64, None), (10, allow), (7, allow)):
         br, bs, bc, fb = idx.search_batched(q, k, allow=mask)
