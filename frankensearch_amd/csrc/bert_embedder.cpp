@@ -2,6 +2,7 @@
 // Layer order follows encoder_layer_raw (crates/frankensearch-rerank/src/native.rs:587-626).
 #include "bert_embedder.hpp"
 
+#include <cstdlib>
 #include <string>
 
 namespace fsgpu {
@@ -135,21 +136,37 @@ SearchError NativeEmbedder::forward(uint32_t n_docs, uint32_t tokens, uint32_t m
                                   static_cast<const float*>(type_.ptr), static_cast<const float*>(emb_ln_w_.ptr),
                                   static_cast<const float*>(emb_ln_b_.ptr), x, x_h_.ptr, T, H, eps, stream_));
     const float scale = 0.17677669f;  // ATTN_SCALE_F32 = 1/sqrt(32) (native.rs:44)
+    static const bool no_fuse = std::getenv("FSGPU_BERT_NO_FUSED_LN") != nullptr;  // A/B runs
+    // a batch fills the chip with 32-row blocks; a single query (a few tokens) would run each projection on ONE block
+    // and is quicker through the 32x64-tile GEMM + the stand-alone add+LN kernel (measured 0.36 vs 0.43 ms)
+    const bool fused_ln = !no_fuse && T > 256 && bert_gemm_ln_supported(H) && (H % 32 == 0) && (I % 32 == 0);
     for (Layer& l : layers_) {
         BERT_HIP(launch_bert_gemm(x_h_.ptr, l.qkv_w.ptr, static_cast<const float*>(l.qkv_b.ptr), qkv, nullptr, T, 3 * H, H,
                                   false, stream_));
         BERT_HIP(launch_bert_attention(qkv, offs, ctx_h_.ptr, (int)n_docs, (int)cfg_.heads, H, (int)max_seq, scale,
                                        stream_));
-        BERT_HIP(launch_bert_gemm(ctx_h_.ptr, l.ao_w.ptr, static_cast<const float*>(l.ao_b.ptr), tmp, nullptr, T, H, H,
-                                  false, stream_));
-        BERT_HIP(launch_bert_add_ln(x, tmp, static_cast<const float*>(l.ln1_w.ptr), static_cast<const float*>(l.ln1_b.ptr),
-                                    x_h_.ptr, T, H, eps, stream_));
+        if (fused_ln) {
+            BERT_HIP(launch_bert_gemm_ln(ctx_h_.ptr, l.ao_w.ptr, static_cast<const float*>(l.ao_b.ptr), x, x_h_.ptr,
+                                         static_cast<const float*>(l.ln1_w.ptr), static_cast<const float*>(l.ln1_b.ptr), T, H,
+                                         H, eps, stream_));
+        } else {
+            BERT_HIP(launch_bert_gemm(ctx_h_.ptr, l.ao_w.ptr, static_cast<const float*>(l.ao_b.ptr), tmp, nullptr, T, H, H,
+                                      false, stream_));
+            BERT_HIP(launch_bert_add_ln(x, tmp, static_cast<const float*>(l.ln1_w.ptr),
+                                        static_cast<const float*>(l.ln1_b.ptr), x_h_.ptr, T, H, eps, stream_));
+        }
         BERT_HIP(launch_bert_gemm(x_h_.ptr, l.i_w.ptr, static_cast<const float*>(l.i_b.ptr), nullptr, inter_h_.ptr, T, I, H,
                                   true, stream_));
-        BERT_HIP(launch_bert_gemm(inter_h_.ptr, l.o_w.ptr, static_cast<const float*>(l.o_b.ptr), tmp, nullptr, T, H, I,
-                                  false, stream_));
-        BERT_HIP(launch_bert_add_ln(x, tmp, static_cast<const float*>(l.ln2_w.ptr), static_cast<const float*>(l.ln2_b.ptr),
-                                    x_h_.ptr, T, H, eps, stream_));
+        if (fused_ln) {
+            BERT_HIP(launch_bert_gemm_ln(inter_h_.ptr, l.o_w.ptr, static_cast<const float*>(l.o_b.ptr), x, x_h_.ptr,
+                                         static_cast<const float*>(l.ln2_w.ptr), static_cast<const float*>(l.ln2_b.ptr), T, H,
+                                         I, eps, stream_));
+        } else {
+            BERT_HIP(launch_bert_gemm(inter_h_.ptr, l.o_w.ptr, static_cast<const float*>(l.o_b.ptr), tmp, nullptr, T, H, I,
+                                      false, stream_));
+            BERT_HIP(launch_bert_add_ln(x, tmp, static_cast<const float*>(l.ln2_w.ptr),
+                                        static_cast<const float*>(l.ln2_b.ptr), x_h_.ptr, T, H, eps, stream_));
+        }
     }
     BERT_HIP(launch_bert_pool(x, offs, static_cast<float*>(out_.ptr), (int)n_docs, H, stream_));
     return SearchError{};

@@ -224,6 +224,30 @@ __global__ __launch_bounds__(256) void bert_gemm_kernel(const _Float16* __restri
     }
 }
 
+namespace {
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false)));
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));
+    return v;
+}
+__device__ __forceinline__ half8 load8_as_half(const float* p) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    half8 h;
+    h[0] = (_Float16)a.x; h[1] = (_Float16)a.y; h[2] = (_Float16)a.z; h[3] = (_Float16)a.w;
+    h[4] = (_Float16)b.x; h[5] = (_Float16)b.y; h[6] = (_Float16)b.z; h[7] = (_Float16)b.w;
+    return h;
+}
+}  // namespace
+
 // LDS-tiled variant for token counts that fill the chip.  Loading MFMA fragments straight from global memory makes
 // every wave-load touch 16 rows (16 x 64-byte segments): the texture-address path, not L2 or the matrix cores, then
 // bounds the kernel near 150 TFLOP/s.  Here the 256 threads fetch the (BM x 32) and (BN x 32) operand slices of a
@@ -323,6 +347,142 @@ __global__ __launch_bounds__(256) void bert_gemm_lds_kernel(const _Float16* __re
     }
 }
 
+// x = LayerNorm(x + A W^T + bias): the N = hidden projections (attention output, FFN down) with add_ln_raw
+// (native.rs:560-578) as their epilogue.  A block owns 32 complete rows (hidden = 64 CT columns; wave w holds columns
+// [16 CT w, 16 CT (w + 1))), so the row statistics are a DPP reduction over the 16 lanes of a row inside each wave plus
+// one LDS exchange across the four waves — two passes (mean, then centred variance) like the stand-alone kernel.
+// Same LDS-tiled k-loop as bert_gemm_lds_kernel.  Saves the f32 round trip of the projection and a launch.
+template <int CT>
+__global__ __launch_bounds__(256) void bert_gemm_ln_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+                                                           const float* __restrict__ bias, float* __restrict__ x_f32,
+                                                           _Float16* __restrict__ x_h, const float* __restrict__ lnw,
+                                                           const float* __restrict__ lnb, int M, int K, float eps) {
+    constexpr int H = 64 * CT, BM = 32, PITCH = 40;
+    constexpr int B_LOADS = H * 4 / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gl_smem[];
+    _Float16* As = reinterpret_cast<_Float16*>(gl_smem);             // [2][BM * PITCH]
+    _Float16* Bs = As + 2 * BM * PITCH;                               // [2][H * PITCH]
+    float* red = reinterpret_cast<float*>(Bs + 2 * H * PITCH);        // [BM][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bm0 = blockIdx.x * BM;
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    const half8* ag = nullptr;
+    int a_off = 0;
+    if (tid < BM * 4) {
+        const int r = tid >> 2, c = tid & 3;
+        int row = bm0 + r;
+        row = row < M ? row : M - 1;
+        ag = reinterpret_cast<const half8*>(A + (size_t)row * K) + c;
+        a_off = r * PITCH + c * 8;
+    }
+    const half8* bg[B_LOADS];
+    int b_off[B_LOADS];
+#pragma unroll
+    for (int x = 0; x < B_LOADS; ++x) {
+        const int p = tid + 256 * x, r = p >> 2, c = p & 3;
+        bg[x] = reinterpret_cast<const half8*>(W + (size_t)r * K) + c;
+        b_off[x] = r * PITCH + c * 8;
+    }
+    f32x4 acc[2][CT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ksteps = K / 32;
+    half8 ra = {}, rb[B_LOADS];
+    if (ag) ra = ag[0];
+#pragma unroll
+    for (int x = 0; x < B_LOADS; ++x) rb[x] = bg[x][0];
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int st = ks & 1;
+        if (ag) *reinterpret_cast<half8*>(&As[st * BM * PITCH + a_off]) = ra;
+#pragma unroll
+        for (int x = 0; x < B_LOADS; ++x) *reinterpret_cast<half8*>(&Bs[st * H * PITCH + b_off[x]]) = rb[x];
+        if (ks + 1 < ksteps) {
+            if (ag) ra = ag[(ks + 1) * 4];
+#pragma unroll
+            for (int x = 0; x < B_LOADS; ++x) rb[x] = bg[x][(ks + 1) * 4];
+        }
+        __syncthreads();
+        half8 af[2], bf[CT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const half8*>(&As[st * BM * PITCH + (i * 16 + fr) * PITCH + fk]);
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+            bf[j] = *reinterpret_cast<const half8*>(&Bs[st * H * PITCH + (wave * 16 * CT + j * 16 + fr) * PITCH + fk]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    // epilogue: y = acc + bias + residual; C layout: row = i*16 + (lane>>4)*4 + r, col = wave*16*CT + j*16 + (lane&15)
+    const int rg = lane >> 4, ccol = lane & 15;
+    float psum[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int row = bm0 + i * 16 + rg * 4 + r;
+            row = row < M ? row : M - 1;
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const int col = wave * 16 * CT + j * 16 + ccol;
+                const float y = (acc[i][j][r] + bias[col]) + x_f32[(size_t)row * H + col];
+                acc[i][j][r] = y;
+                sum += y;
+            }
+            psum[i][r] = row16_sum(sum);
+        }
+    __syncthreads();  // the k-loop's LDS reads are done (red does not alias, but keep the phases apart)
+    if (ccol == 0)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(i * 16 + rg * 4 + r) * 4 + wave] = psum[i][r];
+    __syncthreads();
+    float mean[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* p = red + (i * 16 + rg * 4 + r) * 4;
+            mean[i][r] = ((p[0] + p[1]) + (p[2] + p[3])) / (float)H;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const float d = acc[i][j][r] - mean[i][r];
+                q += d * d;
+            }
+            q = row16_sum(q);
+            if (ccol == 0) red[(i * 16 + rg * 4 + r) * 4 + wave] = q;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = bm0 + i * 16 + rg * 4 + r;
+            if (row >= M) continue;
+            const float* p = red + (i * 16 + rg * 4 + r) * 4;
+            const float var = ((p[0] + p[1]) + (p[2] + p[3])) / (float)H;
+            const float inv = 1.0f / sqrtf(var + eps);
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const int col = wave * 16 * CT + j * 16 + ccol;
+                const float y = (acc[i][j][r] - mean[i][r]) * inv * lnw[col] + lnb[col];
+                x_f32[(size_t)row * H + col] = y;
+                x_h[(size_t)row * H + col] = (_Float16)y;
+            }
+        }
+}
+
 // Per-document, per-head self-attention (fused_attention, native.rs:366-432): softmax(scale * Q K^T) V over all
 // tokens of the document, no mask.  grid = (doc, head); K and V of the head sit in LDS (row stride 33 floats,
 // conflict-free); each wave owns query rows wave, wave+4, ...  f32 throughout; context written as f16 (the
@@ -405,30 +565,6 @@ __global__ __launch_bounds__(256) void bert_attention_kernel(const float* __rest
 //                        in LDS (f16) so that a lane's 16 bytes are 8 consecutive keys of one output dimension
 // Q, K, V and P enter the MFMAs as f16 (f32 accumulate); softmax statistics and the output accumulators stay f32.
 // Any sequence length works; short queries cost one key block.  Replaces the VALU kernel above (kept for A/B runs).
-namespace {
-__device__ __forceinline__ float row16_max(float v) {
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false)));
-    return v;
-}
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));
-    return v;
-}
-__device__ __forceinline__ half8 load8_as_half(const float* p) {
-    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
-    half8 h;
-    h[0] = (_Float16)a.x; h[1] = (_Float16)a.y; h[2] = (_Float16)a.z; h[3] = (_Float16)a.w;
-    h[4] = (_Float16)b.x; h[5] = (_Float16)b.y; h[6] = (_Float16)b.z; h[7] = (_Float16)b.w;
-    return h;
-}
-}  // namespace
-
 __global__ __launch_bounds__(256) void bert_attention_mfma_kernel(const float* __restrict__ qkv,
                                                                   const uint32_t* __restrict__ offsets,
                                                                   _Float16* __restrict__ ctx_h, int hidden, float scale) {
@@ -628,6 +764,34 @@ hipError_t launch_bert_gemm(const void* a_h, const void* w_h, const float* bias,
         else launch_gemm_t<0, 1, 2, 4>(a_h, w_h, bias, out_f32, out_h, M, N, K, stream);
     }
     return hipGetLastError();
+}
+
+// Fused projection + residual + LayerNorm for hidden = 384 / 256 / 128 (other widths: GEMM then bert_add_ln).
+bool bert_gemm_ln_supported(int hidden) { return hidden == 384 || hidden == 256 || hidden == 128; }
+
+template <int CT>
+static hipError_t launch_gemm_ln_t(const void* a_h, const void* w_h, const float* bias, float* x_f32, void* x_h,
+                                   const float* lnw, const float* lnb, int M, int K, float eps, hipStream_t stream) {
+    constexpr int H = 64 * CT;
+    const size_t lds = (size_t)2 * 32 * 40 * 2 + (size_t)2 * H * 40 * 2 + 32 * 4 * 4;
+    auto kern = bert_gemm_ln_kernel<CT>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((M + 31) / 32), dim3(256), lds, stream, static_cast<const _Float16*>(a_h),
+                       static_cast<const _Float16*>(w_h), bias, x_f32, static_cast<_Float16*>(x_h), lnw, lnb, M, K, eps);
+    return hipGetLastError();
+}
+
+hipError_t launch_bert_gemm_ln(const void* a_h, const void* w_h, const float* bias, float* x_f32, void* x_h,
+                               const float* lnw, const float* lnb, int M, int hidden, int K, float eps, hipStream_t stream) {
+    switch (hidden) {
+        case 384: return launch_gemm_ln_t<6>(a_h, w_h, bias, x_f32, x_h, lnw, lnb, M, K, eps, stream);
+        case 256: return launch_gemm_ln_t<4>(a_h, w_h, bias, x_f32, x_h, lnw, lnb, M, K, eps, stream);
+        case 128: return launch_gemm_ln_t<2>(a_h, w_h, bias, x_f32, x_h, lnw, lnb, M, K, eps, stream);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 size_t bert_attention_lds_bytes(int max_seq) {

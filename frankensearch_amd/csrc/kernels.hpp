@@ -164,6 +164,9 @@ hipError_t launch_bert_embed_ln(const int32_t* ids, const int32_t* positions, co
                                 int tokens, int hidden, float eps, hipStream_t stream);
 hipError_t launch_bert_add_ln(float* x_f32, const float* delta, const float* lnw, const float* lnb, void* x_h, int tokens,
                               int hidden, float eps, hipStream_t stream);
+bool bert_gemm_ln_supported(int hidden);
+hipError_t launch_bert_gemm_ln(const void* a_h, const void* w_h, const float* bias, float* x_f32, void* x_h,
+                               const float* lnw, const float* lnb, int M, int hidden, int K, float eps, hipStream_t stream);
 hipError_t launch_bert_gemm(const void* a_h, const void* w_h, const float* bias, float* out_f32, void* out_h, int M,
                             int N, int K, bool gelu_half_out, hipStream_t stream);
 hipError_t launch_bert_attention(const float* qkv, const uint32_t* offsets, void* ctx_h, int n_docs, int heads,
