@@ -57,6 +57,8 @@ hipError_t launch_scatter_hits(const uint32_t* idx, uint32_t n, uint32_t k, cons
                                const float* src_scores, const uint32_t* src_counts, uint32_t* dst_rows,
                                float* dst_scores, uint32_t* dst_counts, u64* dst_packed, hipStream_t stream);
 hipError_t launch_encode_f16(const float* src, size_t n, unsigned short* dst, hipStream_t stream);
+hipError_t launch_encode_rows_f16(const float* src, const uint32_t* perm, uint64_t n, uint32_t dim, unsigned short* dst,
+                                  hipStream_t stream);
 hipError_t launch_widen_f16(const unsigned short* src, size_t n, float* dst, hipStream_t stream);
 
 // sort_general.hip (rocPRIM radix sort, descending u64 keys) — the large-k / collect-all path.

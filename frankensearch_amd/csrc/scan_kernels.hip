@@ -559,6 +559,18 @@ __global__ void encode_f16_kernel(const float* src, size_t n, unsigned short* ds
     }
 }
 
+// Same conversion for whole rows taken in a given order (FSVI writer: rows land in (hash, doc_id) order).
+__global__ void encode_rows_f16_kernel(const float* __restrict__ src, const uint32_t* __restrict__ perm, uint64_t n, uint32_t dim,
+                                       unsigned short* __restrict__ dst) {
+    const uint64_t row = blockIdx.x;
+    if (row >= n) return;
+    const float* s = src + (size_t)perm[row] * dim;
+    for (uint32_t d = threadIdx.x; d < dim; d += blockDim.x) {
+        const _Float16 h = (_Float16)s[d];
+        dst[(size_t)row * dim + d] = __builtin_bit_cast(unsigned short, h);
+    }
+}
+
 // f16 -> f32 widen (widen8_f16_lanes, simd.rs:63-82): exact.
 __global__ void widen_f16_kernel(const unsigned short* src, size_t n, float* dst) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -702,6 +714,12 @@ hipError_t launch_gather_dot(const ScanArgs& args, const uint32_t* rows, uint32_
 
 hipError_t launch_encode_f16(const float* src, size_t n, unsigned short* dst, hipStream_t stream) {
     hipLaunchKernelGGL(encode_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, n, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_encode_rows_f16(const float* src, const uint32_t* perm, uint64_t n, uint32_t dim, unsigned short* dst,
+                                  hipStream_t stream) {
+    hipLaunchKernelGGL(encode_rows_f16_kernel, dim3((unsigned)n), dim3(128), 0, stream, src, perm, n, dim, dst);
     return hipGetLastError();
 }
 

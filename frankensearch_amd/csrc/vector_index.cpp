@@ -181,6 +181,128 @@ SearchError VectorIndex::set_live_bitmap(const uint64_t* live) {
     return ok();
 }
 
+// VectorIndexWriter::write_record + finish for FSVI v1 (crates/frankensearch-index/src/lib.rs:3637-3672, 3752-3943;
+// header :5714-5768): records are validated (finite, usable signal, doc id <= u16 bytes), STABLY sorted by
+// (FNV-1a(doc_id), doc_id) (:3753-3762), and written as header | 16-byte records | string table | pad to 64 | f16 slab.
+// The f32 -> f16 conversion (round to nearest even, simd.rs:2245-2305) of the slab runs on the GPU, row-permuted into file
+// order; everything else is host bookkeeping.
+SearchError write_fsvi_v1(const char* path, const char* embedder_id, const char* embedder_revision, uint32_t dim, uint64_t n,
+                          const char* const* doc_ids, const uint32_t* doc_id_lens, const float* vectors,
+                          uint8_t compaction_gen, int device) {
+    if (!path || !embedder_id || !embedder_revision || (n && (!doc_ids || !vectors)))
+        return make_error(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    if (dim == 0) return make_error(FSGPU_ERR_INVALID_CONFIG, "dimension must be greater than zero");
+    const size_t idl = std::strlen(embedder_id), rvl = std::strlen(embedder_revision);
+    if (idl > 0xffff || rvl > 0xffff) return make_error(FSGPU_ERR_INVALID_CONFIG, "embedder id / revision must fit in u16");
+    struct Pending {
+        uint64_t hash;
+        const char* id;
+        uint32_t len;
+        uint64_t seq;
+    };
+    std::vector<Pending> recs((size_t)n);
+    uint64_t strings_len = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const float* v = vectors + (size_t)i * dim;
+        float norm_sq = 0.f;
+        for (uint32_t d = 0; d < dim; ++d) {
+            if (!std::isfinite(v[d])) return make_error(FSGPU_ERR_INVALID_CONFIG, "all embedding values must be finite");
+            const float pq = v[d] * v[d];
+            norm_sq = norm_sq + pq;
+        }
+        if (!(norm_sq > 0.0f) || !std::isfinite(norm_sq))
+            return make_error(FSGPU_ERR_INVALID_CONFIG, "embedding norm must be non-zero and finite");
+        const size_t len = doc_id_lens ? doc_id_lens[i] : std::strlen(doc_ids[i]);
+        if (len > 0xffff) return make_error(FSGPU_ERR_INVALID_CONFIG, "doc_id byte length must fit in u16");
+        recs[(size_t)i] = Pending{fnv1a(doc_ids[i], len), doc_ids[i], (uint32_t)len, i};
+        strings_len += len;
+    }
+    if (strings_len > 0xffffffffull) return make_error(FSGPU_ERR_INVALID_CONFIG, "string table exceeds u32 offsets");
+    std::stable_sort(recs.begin(), recs.end(), [](const Pending& a, const Pending& b) {
+        if (a.hash != b.hash) return a.hash < b.hash;
+        const int c = std::memcmp(a.id, b.id, std::min(a.len, b.len));
+        if (c != 0) return c < 0;
+        return a.len < b.len;
+    });
+    const size_t header_len = 4 + 2 + 2 + idl + 2 + rvl + 4 + 1 + 3 + 8 + 8 + 4;
+    const uint64_t pre = (uint64_t)header_len + n * 16 + strings_len;
+    const uint64_t vectors_offset = (pre + 63) / 64 * 64;
+    const size_t slab_bytes = (size_t)n * dim * 2;
+    std::vector<uint8_t> buf((size_t)vectors_offset + slab_bytes, 0);
+    auto put = [&](size_t at, uint64_t v, int bytes) {
+        for (int b = 0; b < bytes; ++b) buf[at + b] = (uint8_t)(v >> (8 * b));
+    };
+    size_t c = 0;
+    std::memcpy(buf.data(), "FSVI", 4);
+    c += 4;
+    put(c, 1, 2);
+    c += 2;
+    put(c, idl, 2);
+    c += 2;
+    std::memcpy(buf.data() + c, embedder_id, idl);
+    c += idl;
+    put(c, rvl, 2);
+    c += 2;
+    std::memcpy(buf.data() + c, embedder_revision, rvl);
+    c += rvl;
+    put(c, dim, 4);
+    c += 4;
+    buf[c++] = 1;  // Quantization::F16 (lib.rs:203-208)
+    buf[c++] = compaction_gen;
+    put(c, 0, 2);  // publication nonce
+    c += 2;
+    put(c, n, 8);
+    c += 8;
+    put(c, vectors_offset, 8);
+    c += 8;
+    put(c, crc32_ieee(buf.data(), c), 4);
+    c += 4;
+    size_t str_off = 0;
+    const size_t str_base = c + (size_t)n * 16;
+    std::vector<uint32_t> perm((size_t)n);
+    for (uint64_t i = 0; i < n; ++i) {
+        const Pending& r = recs[(size_t)i];
+        put(c + (size_t)i * 16, r.hash, 8);
+        put(c + (size_t)i * 16 + 8, str_off, 4);
+        put(c + (size_t)i * 16 + 12, r.len, 2);
+        put(c + (size_t)i * 16 + 14, 0, 2);
+        std::memcpy(buf.data() + str_base + str_off, r.id, r.len);
+        str_off += r.len;
+        perm[(size_t)i] = (uint32_t)r.seq;
+    }
+    if (n) {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+            return make_error(FSGPU_ERR_NO_DEVICE, "no HIP device visible (libfsgpu has no CPU fallback)");
+        if (device < 0 || device >= count) return make_error(FSGPU_ERR_INVALID_CONFIG, "device ordinal out of range");
+        FSGPU_HIP(hipSetDevice(device));
+        DeviceBuffer src, pidx, dst;
+        SearchError e = src.reserve((size_t)n * dim * 4);
+        if (e.ok()) e = pidx.reserve((size_t)n * 4);
+        if (e.ok()) e = dst.reserve(slab_bytes);
+        hipError_t he = hipSuccess;
+        if (e.ok()) {
+            he = hipMemcpy(src.ptr, vectors, (size_t)n * dim * 4, hipMemcpyHostToDevice);
+            if (he == hipSuccess) he = hipMemcpy(pidx.ptr, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+            if (he == hipSuccess)
+                he = launch_encode_rows_f16(static_cast<const float*>(src.ptr), static_cast<const uint32_t*>(pidx.ptr), n, dim,
+                                            static_cast<unsigned short*>(dst.ptr), nullptr);
+            if (he == hipSuccess) he = hipMemcpy(buf.data() + vectors_offset, dst.ptr, slab_bytes, hipMemcpyDeviceToHost);
+        }
+        src.release();
+        pidx.release();
+        dst.release();
+        if (!e.ok()) return e;
+        if (he != hipSuccess) return make_error(FSGPU_ERR_DEVICE, hipGetErrorString(he));
+    }
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return make_error(FSGPU_ERR_IO, std::string("cannot create ") + path);
+    const size_t w = std::fwrite(buf.data(), 1, buf.size(), f);
+    std::fclose(f);
+    if (w != buf.size()) return make_error(FSGPU_ERR_IO, std::string("short write to ") + path);
+    return ok();
+}
+
 // VectorIndex::open for FSVI v1 (lib.rs:1747-1816, parse_header :4049-4144).
 SearchError VectorIndex::open_fsvi(const char* path, int device) {
     if (!path) return make_error(FSGPU_ERR_NULL_ARGUMENT, "path is null");

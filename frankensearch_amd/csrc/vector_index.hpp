@@ -31,6 +31,11 @@ struct DeviceBuffer {
     void release();
 };
 
+// VectorIndexWriter for FSVI v1 (lib.rs:3637-3672, 3752-3943): validate, stable-sort by (FNV-1a(doc_id), doc_id), write.
+SearchError write_fsvi_v1(const char* path, const char* embedder_id, const char* embedder_revision, uint32_t dim, uint64_t n,
+                          const char* const* doc_ids, const uint32_t* doc_id_lens, const float* vectors,
+                          uint8_t compaction_gen, int device);
+
 class VectorIndex {
   public:
     VectorIndex() = default;

@@ -201,6 +201,16 @@ fsgpu_status fsgpu_gather_dot(fsgpu_index *idx, const float *query, uint32_t que
                               uint32_t n, float *out_scores);
 
 /* ---- index build helpers ---- */
+/* VectorIndexWriter::write_record + finish for FSVI v1 (crates/frankensearch-index/src/lib.rs:3637-3672, 3752-3943): every
+ * vector must be finite with a usable norm and every doc id fit in u16 bytes (else FSGPU_ERR_INVALID_CONFIG, nothing
+ * written); records are stably sorted by (FNV-1a(doc_id), doc_id) and written as header (CRC32) | 16-byte records | string
+ * table | pad to 64 | little-endian f16 slab (f32 -> f16 round-to-nearest-even on `device`).  The bytes equal the
+ * reference writer's for the same input.  doc_id_lens may be NULL (NUL-terminated ids).  n may exceed the GPU grid limit
+ * only in theory (n < 2^31). */
+fsgpu_status fsgpu_fsvi_write(const char *path, const char *embedder_id, const char *embedder_revision, uint32_t dim,
+                              uint64_t n, const char *const *doc_ids, const uint32_t *doc_id_lens, const float *vectors,
+                              uint8_t compaction_gen, int32_t device);
+
 /* encode_f32_to_f16_extend (simd.rs:2245-2305): f32 -> f16 round-to-nearest-even on the GPU. */
 fsgpu_status fsgpu_encode_f32_to_f16(int32_t device, const float *src, uint64_t n, uint16_t *dst);
 /* f16 -> f32 widen (simd.rs:63-94), exposed for the exhaustive 65,536-pattern parity test. */

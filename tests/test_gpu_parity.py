@@ -601,3 +601,44 @@ def test_int8_two_pass_batched_equals_per_query_and_oracle(fa, oracle):
     for qi in range(5):
         hits = idx.search_top_k_int8_two_pass(q[qi], 50, 3)
         assert [h.index for h in hits] == br[qi, :bc[qi]].tolist()
+
+
+@pytest.mark.gpu
+def test_fsvi_writer_bytes_equal_reference_layout_and_config1_roundtrip(fa, oracle, tmp_path):
+    # VectorIndexWriter (lib.rs:3637-3672, 3752-3943): the product writer must emit exactly the bytes the oracle's
+    # restatement of the reference writer does — duplicate doc ids keep insertion order (stable sort), ids of different
+    # lengths, a compaction generation — and reject what the reference rejects.
+    rng = np.random.default_rng(113)
+    rows = [(f"doc-{(i * 7919) % 613:04d}" + ("x" * (i % 5)), rng.standard_normal(40).astype(np.float32)) for i in range(600)]
+    rows[10] = (rows[3][0], rows[10][1])               # duplicate doc id: last write lands after the first
+    rows[11] = ("", rows[11][1])                       # empty doc id is legal in v1
+    p_ref, p_gpu = str(tmp_path / "ref.fsvi"), str(tmp_path / "gpu.fsvi")
+    assert oracle.fsvi_write(p_ref, [(d, v.tolist()) for d, v in rows], "potion", "rev-1", 3) == 0
+    fa.write_fsvi(p_gpu, rows, "potion", "rev-1", 3)
+    assert open(p_ref, "rb").read() == open(p_gpu, "rb").read()
+    for bad in (np.full(40, np.nan, np.float32), np.zeros(40, np.float32), np.full(40, 3e38, np.float32)):
+        with pytest.raises(fa.InvalidConfig):
+            fa.write_fsvi(str(tmp_path / "bad.fsvi"), [("a", bad)])
+    with pytest.raises(fa.InvalidConfig):
+        fa.write_fsvi(str(tmp_path / "bad.fsvi"), [("d" * 70000, rows[0][1])])
+    # BASELINE config 1 in miniature: token-id docs -> Model2Vec pool on the GPU -> FSVI write -> reopen ->
+    # exact top-10; every stage equal to the oracle pipeline
+    vocab, dim, ndocs = 4096, 256, 3000
+    table = np.fromfunction(lambda r, c: ((r * 0.1 + c * 0.01) % 1.7) - 0.8, (vocab, dim)).astype(np.float32)
+    docs = [rng.integers(0, vocab, int(rng.integers(3, 40))).tolist() for _ in range(ndocs)]
+    m = fa.Model2VecEmbedder(table)
+    emb = m.embed_batch_token_ids(docs)
+    want = np.stack([oracle.m2v_embed(table, d) for d in docs])
+    assert np.array_equal(emb.view(np.uint32), want.view(np.uint32))
+    named = [(f"doc-{i:05d}", emb[i]) for i in range(ndocs)]
+    p1, p2 = str(tmp_path / "c1_gpu.fsvi"), str(tmp_path / "c1_ref.fsvi")
+    fa.write_fsvi(p1, named, "potion-multilingual-128M", "a28f4ee", 0)
+    assert oracle.fsvi_write(p2, [(d, v.tolist()) for d, v in named], "potion-multilingual-128M", "a28f4ee", 0) == 0
+    assert open(p1, "rb").read() == open(p2, "rb").read()
+    g, o = fa.VectorIndex.open(p1), oracle.Fsvi(p1)
+    for qi in range(5):
+        q = oracle.m2v_embed(table, rng.integers(0, vocab, 9).tolist())
+        oh, os_ = o.search_top_k(q, 10)
+        gh = g.search_top_k(q, 10)
+        assert [(h.index, h.doc_id) for h in gh] == [(h[0], h[2]) for h in oh]
+        assert np.array_equal(bits([h.score for h in gh]), bits(os_))
