@@ -88,6 +88,26 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_torch_hip_runtime() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so under the SONAME libfsgpu.so also needs.  Whichever copy is
+    loaded first serves the whole process; if that is the system one, a later `import torch` finds no GPU
+    (torch.cuda.is_available() is False).  When torch is installed, load ITS runtime first so that the order of imports
+    does not matter (bench.py / sharded.py hand torch device pointers to this library)."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass  # fall back to the loader's own resolution
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
@@ -95,6 +115,7 @@ def lib() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -m frankensearch_amd.build` "
                 "(the HIP library is the product; there is no CPU fallback)")
+        _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the ABI and the header drift apart

@@ -809,6 +809,17 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     if (const char* e = std::getenv("FSGPU_RB")) RB = (uint32_t)std::atoi(e);
     constexpr uint32_t RA_MAX = 8192;
     if (RA < 256 || RA > RA_MAX || (RA & 63)) RA = 4096;
+    // Small slabs (a row shard of a multi-GPU index): a dense sample of 8192 rows already gives a threshold that lets
+    // only ~k N / 8192 rows of the main pass through, so the second sampling stage (a launch plus a selection, ~55 us)
+    // is skipped when that many candidates fit the block lists comfortably.
+    bool skip_b = false;
+    if (!std::getenv("FSGPU_RA") && !std::getenv("FSGPU_NO_SKIP_B") && nrows_ <= 4'000'000 && nrows_ >= 4 * (uint64_t)RA_MAX) {
+        const uint64_t expect = (uint64_t)std::max<uint32_t>(k, 1) * (i8 ? std::max<uint32_t>(int8_mult, 1) : 1) * (nrows_ / RA_MAX);
+        if (expect <= 4096) {
+            RA = RA_MAX;
+            skip_b = true;
+        }
+    }
     // B = about 1/64 of the slab, between 8 RA and the cap, a multiple of RA, at most a quarter of the slab
     RB = std::min<uint32_t>(RB, std::max<uint32_t>(8 * RA, (uint32_t)(nrows_ / 64)));
     RB = std::min<uint32_t>(RB, (uint32_t)(nrows_ / 4));
@@ -970,8 +981,10 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         a.group_count = groups_b;
         const int grid_b = grid_for(RB, tile_rows);
         a.slots = slots_for(grid_b);
-        FSGPU_HIP(hipMemsetAsync(spill_count, 0, (size_t)G * kMfmaSpillCountStride * 4, stream));
-        FSGPU_HIP(launch_scan_mfma(a, shape, grid_b, stream, nullptr));
+        if (!skip_b) {
+            FSGPU_HIP(hipMemsetAsync(spill_count, 0, (size_t)G * kMfmaSpillCountStride * 4, stream));
+            FSGPU_HIP(launch_scan_mfma(a, shape, grid_b, stream, nullptr));
+        }
         SelectArgs sb{};
         sb.lists = cand;
         sb.q_stride = (uint64_t)grid_b * a.slots;
@@ -986,9 +999,14 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         sb.spill_count = spill_count;
         sb.spill_cap = SPILL;
         {
-            sb.tau_out = tau;
-            sb.pool_out = pool;
-            FSGPU_HIP(launch_select(sb, (int)G, stream));
+            if (!skip_b) {
+                sb.tau_out = tau;
+                sb.pool_out = pool;
+                FSGPU_HIP(launch_select(sb, (int)G, stream));
+            } else {
+                a.group_stride = 1;  // nothing was sampled by a stage B: the main pass visits every group
+                a.group_count = 0;
+            }
             // stage C: every group the B sample did not cover
             a.stage = 2;
             a.slots = slots_for(full_grid);
@@ -1003,15 +1021,15 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
             if (profiling) {
                 FSGPU_HIP(hipEventRecord(e1, stream));
                 events_.emplace_back(e0, e1);
-                profiled_rows_ += N - RB;
+                profiled_rows_ += skip_b ? N : N - RB;
                 profiled_elem_bytes_ = i8 ? 1 : 2;
             }
             sb.q_stride = (uint64_t)full_grid * a.slots;
             sb.l_stride = a.slots;
             sb.nlists = (uint32_t)full_grid;
             sb.list_len = a.slots;
-            sb.extra = pool;
-            sb.extra_len = KC;
+            sb.extra = skip_b ? nullptr : pool;
+            sb.extra_len = skip_b ? 0 : KC;
             sb.tau_out = nullptr;
             sb.pool_out = nullptr;
         }
