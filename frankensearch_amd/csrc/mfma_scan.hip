@@ -30,6 +30,7 @@
 // ds_read_b128 per (k-step, query tile), each feeding one MFMA per 16-row sub-tile.  Algorithmic bytes per pass are
 // still N*dim*2.  At 64 queries the kernel is HBM-bound; at 128 queries the B-fragment reads (96 KB of LDS traffic
 // per 16 rows) bound the 16-row tiling, the 32-row tiling halves them and is HBM-bound again.
+#include <cstdlib>
 #include <type_traits>
 
 #include "scan_common.hpp"
@@ -332,13 +333,18 @@ __device__ __forceinline__ void merge_wave_winners(const u64* win, int k, u64* t
     wave_lds_fence();
 }
 
-// KL = 1: k <= 64; KL = 2: k <= 128 (the int8 fast tier asks for 3 x 30 = 90 candidates).
-template <bool FINISH, int KL>
+// SORTED = false: the extraction scheme above; its cost grows with k^2 (k rounds over lists that grow with k), fine up
+// to k ~ 32.  SORTED = true (larger k: the int8 fast tier anchors on 3 x 30 = 90 candidates): the non-empty entries
+// are compacted into LDS and bitonic-sorted by the whole block; top-k, threshold and candidate prefix fall out.
+constexpr int kSelSortCap = 8192;   // live entries the sorted variant holds (dynamic LDS: 64 KB)
+template <bool FINISH, bool SORTED>
 __global__ __launch_bounds__(kSelThreads) void select_kernel(SelectArgs args) {
-    constexpr int NT = kSelThreads, PER = kSelPer, NW = kSelWaves, POOL = (int)kSelectPool;
+    constexpr int NT = kSelThreads, PER = kSelPer, NW = kSelWaves, POOL = (int)kSelectPool, KL = 1;
     static_assert(POOL == NT, "one pool entry per thread in the final selection");
     __shared__ u64 win[2][NW * 64 * KL];  // per-wave winners [wave][rank], ping-pong across passes
-    __shared__ u64 top[64 * KL];          // block top-k, best first
+    __shared__ u64 top[64 * KL];          // block top-k, best first (extraction scheme)
+    extern __shared__ __attribute__((aligned(16))) unsigned char sel_dyn[];
+    u64* sbuf = reinterpret_cast<u64*>(sel_dyn);  // [kSelSortCap] in the sorted variant, unused otherwise
     __shared__ u64 pool[POOL];       // candidates (finish step: replaced by their exact entries)
     __shared__ int s_count;
     __shared__ float s_tau;
@@ -373,58 +379,116 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(SelectArgs args) {
     if (tid == 0) s_count = 0;
     pool[tid] = kEmpty;
     u64 e[PER];
-    for (int p = 0; p < npass; ++p) {  // block-uniform
-        load_pass(p, e);
-        wave_select_pass<PER, KL>(e, k, p ? win[(p - 1) & 1] + wave * k : nullptr, win[p & 1] + wave * k, lane);
-    }
-    __syncthreads();
-    if (wave == 0) {
-        merge_wave_winners<KL>(win[(npass - 1) & 1], k, top, lane);
-        if (lane == 0) {
+    int ncand = 0;
+    if constexpr (SORTED) {
+        __syncthreads();
+        for (int p = 0; p < npass; ++p) {  // block-uniform
+            load_pass(p, e);
+#pragma unroll
+            for (int x = 0; x < PER; ++x) {
+                const bool ok = e[x] != kEmpty;
+                const u64 m = __ballot(ok);
+                if (m) {
+                    int wbase = 0;
+                    if (lane == 0) wbase = atomicAdd(&s_count, (int)__popcll(m));
+                    wbase = __shfl(wbase, 0);
+                    const int pos = wbase + (int)__popcll(m & ((1ull << lane) - 1ull));
+                    if (ok && pos < kSelSortCap) sbuf[pos] = e[x];
+                }
+            }
+        }
+        __syncthreads();
+        int cnt = s_count;
+        if (cnt > kSelSortCap) {  // more live entries than the sort holds: the per-query path answers this one
+            if (tid == 0 && args.overflow) args.overflow[q] = 1;
+            cnt = kSelSortCap;
+        }
+        int np2 = 64;
+        while (np2 < cnt) np2 <<= 1;
+        for (int j = cnt + tid; j < np2; j += NT) sbuf[j] = kEmpty;
+        block_sort_desc_rt<NT>(sbuf, np2, tid);
+        if (tid == 0) {
             const float d = args.delta[q];
             float t = -INFINITY;   // fewer than k entries: everything is a candidate
             if (d < 0.f) {
                 t = INFINITY;      // skipped query (padding / zero / non-finite): the exact path answers it
                 if (args.overflow) args.overflow[q] = 1;
-            } else if (top[k - 1] != kEmpty) {
-                t = __uint_as_float((uint32_t)(top[k - 1] >> 32)) - 2.0f * d;
+            } else if (k <= cnt) {
+                t = __uint_as_float((uint32_t)(sbuf[k - 1] >> 32)) - 2.0f * d;
                 if (!(t == t)) t = -INFINITY;
             }
             s_tau = t;
+            s_count = 0;
             if (args.tau_out) args.tau_out[q] = t;
         }
-    }
-    __syncthreads();
-    if (!FINISH && !args.pool_out && !args.cand_counts) return;
-    const float tau = s_tau;
-    for (int p = 0; p < npass; ++p) {
-        if (npass > 1) load_pass(p, e);  // a single pass still has its entries in registers
-#pragma unroll
-        for (int x = 0; x < PER; ++x) {
-            const bool ok = e[x] != kEmpty && __uint_as_float((uint32_t)(e[x] >> 32)) >= tau;
-            const u64 m = __ballot(ok);
-            if (m) {
-                int wbase = 0;
-                if (lane == 0) wbase = atomicAdd(&s_count, (int)__popcll(m));
-                wbase = __shfl(wbase, 0);
-                const int pos = wbase + (int)__popcll(m & ((1ull << lane) - 1ull));
-                if (ok && pos < POOL) pool[pos] = e[x];
-            }
+        __syncthreads();
+        if (!FINISH && !args.pool_out && !args.cand_counts) return;
+        const float tau = s_tau;
+        if (args.take_topk) {
+            ncand = cnt < k ? cnt : k;  // exact scores: the candidates are the k best entries themselves
+        } else {
+            // sorted by (score desc, row asc): the entries at or above tau are a prefix
+            for (int j = tid; j < cnt; j += NT)
+                if (__uint_as_float((uint32_t)(sbuf[j] >> 32)) >= tau) atomicMax(&s_count, j + 1);
+            __syncthreads();
+            ncand = s_count;
         }
-    }
-    __syncthreads();
-    if (args.take_topk) {
-        // exact scores (int8 pass 1): the candidates are precisely the block's k best entries under the reference
-        // order, ties at the k-th score included only by row order — not everything at or above the k-th score
-        pool[tid] = tid < k ? top[tid] : kEmpty;
-        if (tid == 0) {
-            int n = 0;
-            while (n < k && top[n] != kEmpty) ++n;
-            s_count = n;
+        pool[tid] = tid < ncand && tid < kSelSortCap ? sbuf[tid] : kEmpty;
+        __syncthreads();
+    } else {
+        for (int p = 0; p < npass; ++p) {  // block-uniform
+            load_pass(p, e);
+            wave_select_pass<PER, KL>(e, k, p ? win[(p - 1) & 1] + wave * k : nullptr, win[p & 1] + wave * k, lane);
         }
         __syncthreads();
+        if (wave == 0) {
+            merge_wave_winners<KL>(win[(npass - 1) & 1], k, top, lane);
+            if (lane == 0) {
+                const float d = args.delta[q];
+                float t = -INFINITY;   // fewer than k entries: everything is a candidate
+                if (d < 0.f) {
+                    t = INFINITY;      // skipped query (padding / zero / non-finite): the exact path answers it
+                    if (args.overflow) args.overflow[q] = 1;
+                } else if (top[k - 1] != kEmpty) {
+                    t = __uint_as_float((uint32_t)(top[k - 1] >> 32)) - 2.0f * d;
+                    if (!(t == t)) t = -INFINITY;
+                }
+                s_tau = t;
+                if (args.tau_out) args.tau_out[q] = t;
+            }
+        }
+        __syncthreads();
+        if (!FINISH && !args.pool_out && !args.cand_counts) return;
+        const float tau = s_tau;
+        for (int p = 0; p < npass; ++p) {
+            if (npass > 1) load_pass(p, e);  // a single pass still has its entries in registers
+#pragma unroll
+            for (int x = 0; x < PER; ++x) {
+                const bool ok = e[x] != kEmpty && __uint_as_float((uint32_t)(e[x] >> 32)) >= tau;
+                const u64 m = __ballot(ok);
+                if (m) {
+                    int wbase = 0;
+                    if (lane == 0) wbase = atomicAdd(&s_count, (int)__popcll(m));
+                    wbase = __shfl(wbase, 0);
+                    const int pos = wbase + (int)__popcll(m & ((1ull << lane) - 1ull));
+                    if (ok && pos < POOL) pool[pos] = e[x];
+                }
+            }
+        }
+        __syncthreads();
+        if (args.take_topk) {
+            // exact scores (int8 pass 1): the candidates are precisely the block's k best entries under the reference
+            // order, ties at the k-th score included only by row order — not everything at or above the k-th score
+            pool[tid] = tid < k ? top[tid] : kEmpty;
+            if (tid == 0) {
+                int n = 0;
+                while (n < k && top[n] != kEmpty) ++n;
+                s_count = n;
+            }
+            __syncthreads();
+        }
+        ncand = s_count;
     }
-    const int ncand = s_count;
     if (tid == 0) {
         if (args.cand_counts) args.cand_counts[q] = (uint32_t)ncand;
         if (ncand > POOL && args.overflow) args.overflow[q] = 1;
@@ -646,14 +710,29 @@ hipError_t launch_prepare_queries_i8(const float* q, uint32_t nq, uint32_t nq_pa
 hipError_t launch_select(const SelectArgs& args, int nq, hipStream_t stream) {
     if (args.k < 1 || args.k > kSelectMaxK || !args.delta || (uint64_t)args.nlists * args.list_len > 0x7fffffffull)
         return hipErrorInvalidValue;
-    const bool wide = args.k > 64;
+    static const int sort_above = [] {
+        const char* e = std::getenv("FSGPU_SELECT_SORT_ABOVE");  // tuning experiments only
+        return e ? std::atoi(e) : 32;
+    }();
+    const bool sorted = (int)args.k > sort_above || args.k > 64;
+    constexpr size_t sort_lds = (size_t)kSelSortCap * 8;
+    static bool attr_done = false;
+    if (!attr_done) {  // 64 KB of dynamic LDS on top of the static arrays needs the opt-in
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel<true, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel<false, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds);
+        if (e1 != hipSuccess) return e1;
+        if (e2 != hipSuccess) return e2;
+        attr_done = true;
+    }
     if (args.slab) {
         if (args.k_out < 1 || args.k_out > 64 || (args.dim & 7)) return hipErrorInvalidValue;
-        if (wide) hipLaunchKernelGGL((select_kernel<true, 2>), dim3(nq), dim3(kSelThreads), 0, stream, args);
-        else hipLaunchKernelGGL((select_kernel<true, 1>), dim3(nq), dim3(kSelThreads), 0, stream, args);
+        if (sorted) hipLaunchKernelGGL((select_kernel<true, true>), dim3(nq), dim3(kSelThreads), sort_lds, stream, args);
+        else hipLaunchKernelGGL((select_kernel<true, false>), dim3(nq), dim3(kSelThreads), 0, stream, args);
     } else {
-        if (wide) hipLaunchKernelGGL((select_kernel<false, 2>), dim3(nq), dim3(kSelThreads), 0, stream, args);
-        else hipLaunchKernelGGL((select_kernel<false, 1>), dim3(nq), dim3(kSelThreads), 0, stream, args);
+        if (sorted) hipLaunchKernelGGL((select_kernel<false, true>), dim3(nq), dim3(kSelThreads), sort_lds, stream, args);
+        else hipLaunchKernelGGL((select_kernel<false, false>), dim3(nq), dim3(kSelThreads), 0, stream, args);
     }
     return hipGetLastError();
 }

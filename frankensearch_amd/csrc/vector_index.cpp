@@ -820,8 +820,13 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
             skip_b = true;
         }
     }
-    // B = about 1/64 of the slab, between 8 RA and the cap, a multiple of RA, at most a quarter of the slab
-    RB = std::min<uint32_t>(RB, std::max<uint32_t>(8 * RA, (uint32_t)(nrows_ / 64)));
+    // The main pass lets ~ksel N / RB rows through and stage B ~ksel RB / RA: both must stay in the low thousands (block
+    // lists, spill area, the selection's capacity), so the samples grow with the rank the selections anchor on.
+    const uint32_t ksel_est = std::max<uint32_t>(k, 1) * (int8_mult ? int8_mult : 1);
+    const uint32_t grow = std::getenv("FSGPU_RB") ? 1 : std::min<uint32_t>(4, (ksel_est + 15) / 16);
+    if (!std::getenv("FSGPU_RA") && ksel_est > 32) RA = RA_MAX;
+    // B = about 1/64 of the slab (times the growth), between 8 RA and the cap, a multiple of RA, at most a quarter of it
+    RB = std::min<uint32_t>(RB * grow, std::max<uint32_t>(8 * RA, (uint32_t)(nrows_ / 64) * grow));
     RB = std::min<uint32_t>(RB, (uint32_t)(nrows_ / 4));
     RB = std::max<uint32_t>(RA, RB / RA * RA);
     // int8 mode: candidate_count of the reference (search.rs:603-607)
