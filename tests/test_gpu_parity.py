@@ -642,3 +642,40 @@ def test_fsvi_writer_bytes_equal_reference_layout_and_config1_roundtrip(fa, orac
         gh = g.search_top_k(q, 10)
         assert [(h.index, h.doc_id) for h in gh] == [(h[0], h[2]) for h in oh]
         assert np.array_equal(bits([h.score for h in gh]), bits(os_))
+
+
+@pytest.mark.gpu
+def test_edge_cases_of_the_batched_and_two_pass_entry_points(fa, oracle):
+    # empty batches, k = 0, k > N, fully tombstoned and one-row indexes must behave like the per-query exact search
+    rng = np.random.default_rng(127)
+    dim = 128
+    slab = rng.standard_normal((50, dim)).astype(np.float16).view(np.uint16)
+    q = rng.standard_normal((5, dim)).astype(np.float32)
+    idx = fa.VectorIndex.from_slab(slab)
+    for fn in (idx.search_batched, lambda qq, k: idx.search_int8_two_pass_batched(qq, k, 3)):
+        r, s, c, fb = fn(q[:0], 10)
+        assert r.shape[0] == 0 and c.shape[0] == 0
+        r, s, c, fb = fn(q, 0)
+        assert c.tolist() == [0] * 5
+        r, s, c, fb = fn(q, 60)                                   # k > N: everything, best first
+        assert c.tolist() == [50] * 5
+        for i in range(5):
+            er, es = oracle.search_top_k(slab, q[i], 60)
+            assert np.array_equal(r[i, :50], er)
+    assert idx.search_top_k_4bit_two_pass(q[0], 60, 5) != [] and len(idx.search_top_k_4bit_two_pass(q[0], 60, 5)) == 50
+    assert len(idx.mrl_search(q[0], 60, 64)) == 50
+    dead = fa.VectorIndex.from_slab(slab, live=np.zeros(50, bool))
+    assert dead.search_batched(q, 5)[2].tolist() == [0] * 5
+    assert dead.search_int8_two_pass_batched(q, 5, 3)[2].tolist() == [0] * 5
+    assert dead.mrl_search(q[0], 5, 64) == [] and dead.search_top_k_4bit_two_pass(q[0], 5, 5) == []
+    one = fa.VectorIndex.from_slab(slab[:1])
+    r, s, c, _ = one.search_batched(q, 3)
+    assert c.tolist() == [1] * 5 and r[:, 0].tolist() == [0] * 5
+    big = rng.standard_normal((40_000, dim)).astype(np.float16).view(np.uint16)
+    live = np.zeros(40_000, bool)
+    live[[5, 777, 39_999]] = True                               # three live rows in a slab the matrix-core path accepts
+    sparse = fa.VectorIndex.from_slab(big, live=live)
+    r, s, c, fb = sparse.search_batched(np.tile(q, (20, 1)), 10)
+    assert c.tolist() == [3] * 100 and set(r[0, :3].tolist()) == {5, 777, 39_999}
+    r8, s8, c8, _ = sparse.search_int8_two_pass_batched(np.tile(q, (20, 1)), 10, 3)
+    assert c8.tolist() == [3] * 100 and np.array_equal(r8[:, :3], r[:, :3])
