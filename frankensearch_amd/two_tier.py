@@ -23,6 +23,9 @@ class TwoTierConfig:
     quality_weight: float = 0.7
     rrf_k: float = 60.0
     candidate_multiplier: int = 3
+    # 0 = exact f16 scan of the fast tier; n = search_top_k_int8_two_pass(query, fetch, n) — the reference's default with
+    # n = FAST_TIER_MULT = 3 (crates/frankensearch-index/src/two_tier.rs:1318-1337; sync_searcher::search_fast_hits)
+    fast_tier_int8_multiplier: int = 0
 
 
 @dataclass
@@ -54,7 +57,10 @@ class SyncTwoTierSearcher:
         self.doc_id_of = doc_id_of
         self.config = config or TwoTierConfig()
 
-    def _hits(self, index, vec: np.ndarray, fetch: int) -> List[Tuple[str, float, int]]:
+    def _hits(self, index, vec: np.ndarray, fetch: int, int8_multiplier: int = 0) -> List[Tuple[str, float, int]]:
+        if int8_multiplier:
+            return [(self.doc_id_of(h.index), h.score, h.index)
+                    for h in index.search_top_k_int8_two_pass(vec, fetch, int8_multiplier)]
         rows, scores, counts = index.search_batch(vec, fetch)
         n = int(counts[0])
         return [(self.doc_id_of(int(rows[0, i])), float(scores[0, i]), int(rows[0, i])) for i in range(n)]
@@ -68,7 +74,7 @@ class SyncTwoTierSearcher:
         t0 = time.perf_counter()
         fast_vec = self.fast_embedder.embed_token_ids(fast_token_ids)
         t1 = time.perf_counter()
-        fast_hits = self._hits(self.fast_index, fast_vec, fetch)
+        fast_hits = self._hits(self.fast_index, fast_vec, fetch, cfg.fast_tier_int8_multiplier)
         t2 = time.perf_counter()
         initial = fusion.rrf_fuse(lex, fast_hits, k, 0, k=cfg.rrf_k)
         t3 = time.perf_counter()

@@ -83,6 +83,53 @@ def test_native_host_searcher_equals_python_mirror():
         assert ini == want.initial_results
         assert fin == want.final_results
         assert metrics["phase2_total_ms"] > 0
+    # the reference's default fast tier (int8 two-pass, multiplier 3) through both hosts
+    py8 = SyncTwoTierSearcher(fast, qual, m2v, bert, doc, TwoTierConfig(fast_tier_int8_multiplier=3))
+    native8 = NativeTwoTierSearcher(fast, qual, m2v, bert, doc_id_mode=1, fast_tier_int8_multiplier=3)
+    for trial in range(3):
+        fast_ids = rng.integers(0, 5000, 12).tolist()
+        qual_ids = [101] + rng.integers(1000, 3000, 9).tolist() + [102]
+        lexical = [(doc(int(r)), float(30 - i)) for i, r in enumerate(rng.choice(n, 30, replace=False))]
+        want = py8.search(fast_ids, qual_ids, 10, lexical)
+        ini, fin, _ = native8.search(fast_ids, qual_ids, 10, lexical)
+        assert ini == want.initial_results and fin == want.final_results
+
+
+def test_native_host_searcher_over_fsvi_files_with_doc_id_tables(tmp_path):
+    # doc ids come from the indexes' own FSVI tables (doc_id_mode 0); the files are written by the product writer
+    import frankensearch_amd as fa
+    from frankensearch_amd.build import build
+    from frankensearch_amd.host import NativeTwoTierSearcher
+    from frankensearch_amd.synthetic import random_bert_weights
+    from frankensearch_amd.two_tier import SyncTwoTierSearcher, TwoTierConfig
+
+    build()
+    rng = np.random.default_rng(19)
+    n = 3000
+    ids = [f"note-{i:05d}-{'x' * (i % 4)}" for i in range(n)]
+    fast_rows = rng.standard_normal((n, 256)).astype(np.float32)
+    qual_rows = rng.standard_normal((n, 384)).astype(np.float32)
+    pf, pq = str(tmp_path / "vector.fast.idx"), str(tmp_path / "vector.quality.idx")
+    fa.write_fsvi(pf, list(zip(ids, fast_rows)), "potion", "r1")
+    fa.write_fsvi(pq, list(zip(ids, qual_rows)), "minilm", "r1")
+    fast, qual = fa.VectorIndex.open(pf), fa.VectorIndex.open(pq)
+    m2v = fa.Model2VecEmbedder(rng.standard_normal((5000, 256)).astype(np.float32))
+    bert = fa.NativeEmbedder(random_bert_weights(5, 3000, 384, 6, 1536))
+    native = NativeTwoTierSearcher(fast, qual, m2v, bert, doc_id_mode=0)
+    # the Python mirror resolves a tier's rows through that tier's own table, as the native searcher does
+    class Py(SyncTwoTierSearcher):
+        def _hits(self, index, vec, fetch, int8_multiplier=0):
+            rows, scores, counts = index.search_batch(vec, fetch)
+            return [(index.doc_id_at(int(rows[0, i])), float(scores[0, i]), int(rows[0, i])) for i in range(int(counts[0]))]
+    py = Py(fast, qual, m2v, bert, lambda r: "", TwoTierConfig())
+    for trial in range(4):
+        fast_ids = rng.integers(0, 5000, 8).tolist()
+        qual_ids = [101] + rng.integers(1000, 3000, 7).tolist() + [102]
+        lexical = [(ids[int(r)], float(30 - i)) for i, r in enumerate(rng.choice(n, 30, replace=False))]
+        want = py.search(fast_ids, qual_ids, 10, lexical)
+        ini, fin, _ = native.search(fast_ids, qual_ids, 10, lexical)
+        assert ini == want.initial_results and fin == want.final_results
+        assert all(h.doc_id.startswith("note-") for h in fin)
 
 
 def test_coalesced_concurrent_callers_get_identical_results():
