@@ -1,4 +1,4 @@
-run() { python bench.py --steps 100 --warmup 5 --no-cpu-baseline "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('qps=%.0f step=%.3fms scan=%.4fms frac=%.3f' % (d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['frac']))"; }
+run() { python bench.py --exact --steps 100 --warmup 5 --no-cpu-baseline --no-two-tier "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('qps=%.0f step=%.3fms scan=%.4fms frac=%.3f' % (d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['frac']))"; }
 echo "B1 nt"; run --batch 1
 echo "B1 plain"; run --batch 1 --variant 2
 echo "B2 nt"; run --batch 2
