@@ -251,7 +251,7 @@ __device__ __forceinline__ half8 load8_as_half(const float* p) {
 // LDS-tiled variant for token counts that fill the chip.  Loading MFMA fragments straight from global memory makes
 // every wave-load touch 16 rows (16 x 64-byte segments): the texture-address path, not L2 or the matrix cores, then
 // bounds the kernel near 150 TFLOP/s.  Here the 256 threads fetch the (BM x 32) and (BN x 32) operand slices of a
-// k-step with fully coalesced 16-byte loads (four threads per 64-byte row slice), park them in LDS with an 80-byte row
+// k-step with fully coalesced 16-byte loads (four threads per 64-byte row slice), park them in LDS with a 96-byte row
 // pitch (fragment reads are then bank-conflict-free) and every wave reads its fragments from LDS; each global element
 // is fetched once per block instead of twice.  Two LDS stages: the loads of step k+1 are in flight during step k.
 template <int EPI, int WM, int WN>
@@ -259,7 +259,9 @@ __global__ __launch_bounds__(256) void bert_gemm_lds_kernel(const _Float16* __re
                                                             const float* __restrict__ bias, float* __restrict__ out_f32,
                                                             _Float16* __restrict__ out_h, int M, int N, int K) {
     constexpr int BM = 32 * WM, BN = 32 * WN;
-    constexpr int PITCH = 40;                       // halves per LDS row: 32 data + 8 pad (80 bytes)
+    constexpr int PITCH = 48;                       // halves per LDS row: 32 data + 16 pad (96 bytes = 6 slots: the
+                                                    // four non-contiguous 16-lane groups of ds_read_b128 are conflict-free
+                                                    // iff pitch/16 mod 16 is 2, 6, 10 or 14; 80 bytes was 2-way conflicted)
     constexpr int A_LOADS = BM * 4 / 256;           // 16-byte pieces per thread per k-step
     constexpr int B_LOADS = BN * 4 / 256;
     static_assert(A_LOADS >= 1 && B_LOADS >= 1, "tile too small for 256 loader threads");
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(256) void bert_gemm_ln_kernel(const _Float16* __res
                                                            const float* __restrict__ bias, float* __restrict__ x_f32,
                                                            _Float16* __restrict__ x_h, const float* __restrict__ lnw,
                                                            const float* __restrict__ lnb, int M, int K, float eps) {
-    constexpr int H = 64 * CT, BM = 32, PITCH = 40;
+    constexpr int H = 64 * CT, BM = 32, PITCH = 48;
     constexpr int B_LOADS = H * 4 / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char gl_smem[];
     _Float16* As = reinterpret_cast<_Float16*>(gl_smem);             // [2][BM * PITCH]
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(256) void bert_attention_kernel(const float* __rest
 __global__ __launch_bounds__(256) void bert_attention_mfma_kernel(const float* __restrict__ qkv,
                                                                   const uint32_t* __restrict__ offsets,
                                                                   _Float16* __restrict__ ctx_h, int hidden, float scale) {
-    constexpr int PP = 40;  // halves per LDS row (32 + 8 pad: conflict-free 16-byte fragment reads)
+    constexpr int PP = 48;  // halves per LDS row (32 + 16 pad = 6 slots: conflict-free ds_read_b128 fragment reads)
     __shared__ __attribute__((aligned(16))) _Float16 Pl[4][16 * PP];
     __shared__ __attribute__((aligned(16))) _Float16 Vt[4][32 * PP];
     const int doc = blockIdx.x, head = blockIdx.y;
@@ -773,7 +775,7 @@ template <int CT>
 static hipError_t launch_gemm_ln_t(const void* a_h, const void* w_h, const float* bias, float* x_f32, void* x_h,
                                    const float* lnw, const float* lnb, int M, int K, float eps, hipStream_t stream) {
     constexpr int H = 64 * CT;
-    const size_t lds = (size_t)2 * 32 * 40 * 2 + (size_t)2 * H * 40 * 2 + 32 * 4 * 4;
+    const size_t lds = (size_t)2 * 32 * 48 * 2 + (size_t)2 * H * 48 * 2 + 32 * 4 * 4;
     auto kern = bert_gemm_ln_kernel<CT>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
