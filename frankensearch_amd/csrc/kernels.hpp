@@ -136,6 +136,7 @@ bool scan_mfma_supported(int dim);
 int scan_mfma_waves_per_block(int shape);
 int scan_mfma_rows_per_tile(int shape);
 int scan_mfma_query_tiles(int shape);
+int scan_mfma_max_slots(int shape);  // LDS staging capacity per (query, block)
 hipError_t launch_scan_mfma(const MfmaScanArgs& args, int shape, int grid, hipStream_t stream, int* occupancy);
 hipError_t launch_max_row_norm(const void* slab, uint32_t nrows, uint32_t dim, unsigned int* out_bits, hipStream_t stream);
 hipError_t launch_prepare_queries(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim,

@@ -167,13 +167,9 @@ __global__ __launch_bounds__(WPB * 64) void scan_mfma_kernel(MfmaScanArgs args) 
             // keep the B-fragment reads of later k-steps below this point: unconstrained, hipcc hoists all KS*NQT
             // ds_read_b128 to the top of the tile (192 extra registers at dim 384 -> one wave per SIMD)
 #pragma unroll
-            for (int s = 0; s < RT; ++s) {
-                if constexpr (NQT == 4)
-                    asm volatile("" : "+v"(acc[s][0]), "+v"(acc[s][1]), "+v"(acc[s][2]), "+v"(acc[s][3])::"memory");
-                else
-                    asm volatile("" : "+v"(acc[s][0]), "+v"(acc[s][1]), "+v"(acc[s][2]), "+v"(acc[s][3]), "+v"(acc[s][4]),
-                                      "+v"(acc[s][5]), "+v"(acc[s][6]), "+v"(acc[s][7])::"memory");
-            }
+            for (int s = 0; s < RT; ++s)
+#pragma unroll
+                for (int nt = 0; nt < NQT; ++nt) asm volatile("" : "+v"(acc[s][nt])::"memory");
         }
 #pragma unroll
         for (int s = 0; s < RT; ++s) {
@@ -639,7 +635,9 @@ bool scan_mfma_supported(int dim) { return dim == 128 || dim == 256 || dim == 38
 
 template <int DIM, int NQT, int WPB, int STAGE, int RT, bool PF, int EB>
 static hipError_t launch_mfma_s(const MfmaScanArgs& args, int grid, hipStream_t stream, int* occupancy) {
-    const size_t lds = (size_t)NQT * 16 * (DIM * EB + 32) + (STAGE ? (size_t)NQT * 16 * (4 + 8 * kMfmaMaxSlots) : 0);
+    // candidate staging: 32 slots per (query, block), 16 for the 160-query shape (the query tile takes 128 KB there)
+    constexpr size_t kSlots = NQT > 8 ? 16 : kMfmaMaxSlots;
+    const size_t lds = (size_t)NQT * 16 * (DIM * EB + 32) + (STAGE ? (size_t)NQT * 16 * (4 + 8 * kSlots) : 0);
     auto kern = scan_mfma_kernel<DIM, NQT, WPB, STAGE, RT, PF, EB>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -669,9 +667,11 @@ static hipError_t launch_mfma_t(const MfmaScanArgs& args, int grid, hipStream_t 
 //   shape 2: nqt 8, wpb 8, rt 2, single buffer            (128 queries, half the LDS reads per row)
 //   shape 3: nqt 8, wpb 4, rt 2, register double buffer   (one wave per SIMD, 512 registers)
 //   shape 4: nqt 8, wpb 8, rt 4, single buffer            (int8 only: 64-row tiles = the same 24 KB per wave as shape 2 on f16)
+//   shape 5: nqt 10, wpb 8, rt 2, single buffer           (160 queries: 128 KB of LDS for the query tile)
 int scan_mfma_waves_per_block(int shape) { return shape == 0 || shape == 3 ? 4 : 8; }
-int scan_mfma_rows_per_tile(int shape) { return shape == 4 ? 64 : (shape >= 2 ? 32 : 16); }
-int scan_mfma_query_tiles(int shape) { return shape == 0 ? 4 : 8; }
+int scan_mfma_rows_per_tile(int shape) { return shape == 4 ? 64 : (shape >= 2 ? 32 : 16); }  // shape 5: 32
+int scan_mfma_query_tiles(int shape) { return shape == 0 ? 4 : (shape == 5 ? 10 : 8); }
+int scan_mfma_max_slots(int shape) { return shape == 5 ? 16 : (int)kMfmaMaxSlots; }
 
 template <int DIM, int EB>
 static hipError_t launch_mfma_d(const MfmaScanArgs& args, int shape, int grid, hipStream_t stream, int* occupancy) {
@@ -683,6 +683,7 @@ static hipError_t launch_mfma_d(const MfmaScanArgs& args, int shape, int grid, h
         case 4:
             if constexpr (EB == 1) return launch_mfma_t<DIM, 8, 8, 4, false, EB>(args, grid, stream, occupancy);
             return hipErrorInvalidValue;
+        case 5: return launch_mfma_t<DIM, 10, 8, 2, false, EB>(args, grid, stream, occupancy);
         default: return hipErrorInvalidValue;
     }
 }

@@ -159,7 +159,8 @@ class VectorIndex {
         mf_fallback_, mf_spill_, mf_io_;
     bool i8_ready_ = false, n4_ready_ = false;
     bool mf_norm_ready_ = false;
-    int mf_shape_i8_ = 4;
+    int mf_shape_i8_ = 4, mf_per_cu_160_ = 1, mf_per_cu_160_i8_ = 1;
+    bool mf_use_160_ = false;
     int mf_shape_ = -1, mf_per_cu_narrow_ = 1, mf_per_cu_wide_ = 1, mf_per_cu_narrow_i8_ = 1, mf_per_cu_wide_i8_ = 1;  // batched-scan launch shapes (probed once)
     uint32_t* mf_flags_host_ = nullptr;                              // pinned per-query verdicts of the batched scan
     uint32_t mf_flags_cap_ = 0;
