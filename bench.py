@@ -185,6 +185,7 @@ def two_tier_section(quality_index, rows: int, k: int, device, local_rank: int):
             "mean_queries_per_scan_batch": {"fast": (fr - fr0) / max(fb - fb0, 1), "quality": (qr - qr0) / max(qb - qb0, 1)},
         }
 
+    con_lo = concurrent(64, 20_000)
     con = concurrent(256, 40_000)
     con_hi = concurrent(1024, 80_000)
     quality_index.set_coalescing(0, 0)
@@ -198,6 +199,7 @@ def two_tier_section(quality_index, rows: int, k: int, device, local_rank: int):
         "sequential_breakdown_ms": {"fast_embed": seq.mean_fast_embed_ms, "fast_search": seq.mean_fast_search_ms,
                                     "quality_embed": seq.mean_quality_embed_ms, "quality_search": seq.mean_quality_search_ms,
                                     "fusion": seq.mean_fusion_ms},
+        "concurrent_64_threads": con_lo,
         "concurrent": con,
         "concurrent_1024_threads": con_hi,
     }

@@ -4,9 +4,10 @@
 // &self and is called concurrently, crates/frankensearch-index/src/search.rs:192; the MiniLM backends serialise
 // callers on a mutex, crates/frankensearch-rerank/src/native_embedder.rs:40-50).  On the GPU one pass over the slab
 // serves 128 queries for the price of one, so the library gathers the callers that are in flight at the same time
-// into one batched launch: a waiting thread becomes the leader, waits until the batch is full or the oldest request
-// has waited max_wait_us, runs the batch and wakes exactly the callers it served plus the next leader (every request
-// sleeps on its own condition variable: with a thousand parked callers a shared one is a thundering herd).
+// into one batched launch: a waiting thread becomes the leader, waits until the batch is full, the oldest request
+// has waited max_wait_us or arrivals have paused for max_wait_us / 8, runs the batch and wakes exactly the callers it
+// served plus the next leader (every request sleeps on its own condition variable: with a thousand parked callers a
+// shared one is a thundering herd).
 // No extra threads are created.
 #pragma once
 
@@ -51,6 +52,7 @@ class Coalescer {
         r->done = false;
         r->arrival_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now().time_since_epoch()).count();
         pending_.push_back(r);
+        last_arrival_ns_ = r->arrival_ns;
         if (leader_ && pending_.size() >= (max_batch_ ? max_batch_ : 1)) leader_->cv.notify_one();  // batch is full
         while (!r->done) {
             if (leader_) {
@@ -59,10 +61,19 @@ class Coalescer {
             }
             leader_ = r;
             const size_t cap = max_batch_ ? max_batch_ : 1;
-            // wait for the batch to fill, but never longer than max_wait_us past the oldest request's arrival
+            // wait for the batch to fill, but never longer than max_wait_us past the oldest request's arrival — and stop
+            // early once arrivals have paused for an eighth of that window: with a handful of callers the batch is
+            // complete as soon as all of them are parked, and waiting out the window would only add latency
             const auto deadline = clock::time_point(std::chrono::nanoseconds(pending_.front()->arrival_ns)) +
                                   std::chrono::microseconds(max_wait_us_);
-            while (pending_.size() < cap && clock::now() < deadline) r->cv.wait_until(lk, deadline);
+            const auto gap = std::chrono::nanoseconds((int64_t)max_wait_us_ * 1000 / 8);
+            for (;;) {
+                if (pending_.size() >= cap) break;
+                const auto now = clock::now();
+                const auto quiet = clock::time_point(std::chrono::nanoseconds(last_arrival_ns_)) + gap;
+                if (now >= deadline || now >= quiet) break;
+                r->cv.wait_until(lk, quiet < deadline ? quiet : deadline);
+            }
             std::vector<Req*> batch;
             Req* head = pending_.front();
             for (auto it = pending_.begin(); it != pending_.end() && batch.size() < cap;) {
@@ -95,6 +106,7 @@ class Coalescer {
     Req* leader_ = nullptr;
     uint32_t max_batch_ = 0, max_wait_us_ = 0;
     uint64_t batches_ = 0, requests_ = 0;
+    int64_t last_arrival_ns_ = 0;
 };
 
 }  // namespace fsgpu

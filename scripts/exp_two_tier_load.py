@@ -26,12 +26,12 @@ m2v = fa.Model2VecEmbedder(table, device=0)
 bert = fa.NativeEmbedder(random_bert_weights(1, 30522, 384, 6, 1536), device=0)
 native = NativeTwoTierSearcher(fast, quality, m2v, bert, doc_id_mode=1,
                                fast_tier_int8_multiplier=int(os.environ.get("FAST_INT8", "3")))
-for threads, mb, wait in ((1, 0, 0), (256, 128, 1000), (1024, 128, 1000), (2048, 128, 1000)):
+for threads, mb, wait in ((1, 0, 0), (1, 128, 1000), (8, 128, 1000), (64, 128, 1000), (256, 128, 1000), (1024, 128, 1000)):
     fast.set_coalescing(mb, wait)
     quality.set_coalescing(mb, wait)
     m2v.set_coalescing(2 * mb, wait // 2)
     bert.set_coalescing(2 * mb, wait)
-    nq = 200 if threads == 1 else 40_000
+    nq = 200 if threads == 1 else (4000 if threads < 100 else 40_000)
     r = native.run_load(threads=threads, queries=nq, warmup_queries=max(threads * 2, 64), k=10, fast_vocab=500_353,
                         corpus_rows=rows)
     print(f"threads={threads:5d} batch={mb:4d} wait={wait:5d}us  qps={r.queries_per_sec:9.1f}  p0 p50={r.phase0_p50_ms:7.3f} "
