@@ -419,23 +419,52 @@ __global__ __launch_bounds__(NT) void merge_topk_kernel(MergeArgs args) {
         __syncthreads();
         cnt = s_count;
     } else {
-        // threshold-tightening stream (compacts whenever the buffer nearly fills)
+        // More entries than one register pass holds (many block lists x a large k).  For best-first lists the best k-th
+        // entry of any list is a lower bound of the global k-th best, which prunes almost everything up front; the
+        // stream then appends the survivors, four entries per thread between barriers, and only re-sorts (tightening
+        // the threshold) if the buffer nearly fills.
         __syncthreads();
-        for (uint32_t base = 0; base < total32; base += NT) {
-            const uint32_t i = base + tid;
-            u64 c = kEmpty;
-            if (i < total32) {
-                const uint32_t l = i / list_len;
-                c = in[(size_t)l * args.l_stride + (i - l * list_len)];
+        if (args.lists_sorted && list_len >= (uint32_t)k) {
+            u64 best = 0;
+            for (uint32_t l = tid; l < nlists; l += NT) {
+                const u64 c = in[(size_t)l * args.l_stride + (k - 1)];
+                if (c != kEmpty) {
+                    const u64 key = sortkey(c);
+                    best = key > best ? key : best;
+                }
             }
-            const bool ok = c != kEmpty && sortkey(c) > s_thr;
-            if (ok) {
-                const int pos1 = atomicAdd(&s_count, 1);
-                buf[pos1] = c;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const u64 other = __shfl_xor(best, off);
+                best = other > best ? other : best;
             }
+            if (lane == 0 && best) atomicMax(&s_thr, best);
             __syncthreads();
-            if (s_count > MCAP - NT) {  // block-uniform
-                const int have = s_count;
+            if (tid == 0 && s_thr) s_thr -= 1;  // the loop keeps keys > s_thr: the bound entry itself stays
+            __syncthreads();
+        }
+        constexpr int U = 4;
+        for (uint32_t base = 0; base < total32; base += NT * U) {
+            u64 c[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t i = base + u * NT + tid;
+                c[u] = kEmpty;
+                if (i < total32) {
+                    const uint32_t l = i / list_len;
+                    c[u] = in[(size_t)l * args.l_stride + (i - l * list_len)];
+                }
+            }
+            const u64 thr = s_thr;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (c[u] != kEmpty && sortkey(c[u]) > thr) {
+                    const int pos1 = atomicAdd(&s_count, 1);
+                    if (pos1 < MCAP) buf[pos1] = c[u];
+                }
+            __syncthreads();
+            if (s_count > MCAP - NT * U) {  // block-uniform
+                const int have = s_count < MCAP ? s_count : MCAP;
                 for (int j = have + tid; j < MCAP; j += NT) buf[j] = kEmpty;
                 block_sort_desc<MCAP, NT>(buf, tid);
                 if (tid == 0) {
