@@ -424,13 +424,23 @@ __global__ __launch_bounds__(NT) void merge_topk_kernel(MergeArgs args) {
         // stream then appends the survivors, four entries per thread between barriers, and only re-sorts (tightening
         // the threshold) if the buffer nearly fills.
         __syncthreads();
-        if (args.lists_sorted && list_len >= (uint32_t)k) {
+        if (args.lists_sorted) {
+            // the same two bounds as the one-pass path, from a pre-pass over list heads and k-th entries only
+            u64* hkeys = buf + (MCAP - HCAP);  // dead before the survivors reach that part of the buffer
+            const bool use_heads = nlists >= (uint32_t)k && nlists <= (uint32_t)HCAP;
+            for (int j = tid; j < HCAP; j += NT) s_rank[j] = 0;
             u64 best = 0;
             for (uint32_t l = tid; l < nlists; l += NT) {
-                const u64 c = in[(size_t)l * args.l_stride + (k - 1)];
-                if (c != kEmpty) {
-                    const u64 key = sortkey(c);
-                    best = key > best ? key : best;
+                if (list_len >= (uint32_t)k) {
+                    const u64 c = in[(size_t)l * args.l_stride + (k - 1)];
+                    if (c != kEmpty) {
+                        const u64 key = sortkey(c);
+                        best = key > best ? key : best;
+                    }
+                }
+                if (use_heads) {
+                    const u64 c0 = in[(size_t)l * args.l_stride];
+                    hkeys[l] = c0 != kEmpty ? sortkey(c0) : 0ull;
                 }
             }
 #pragma unroll
@@ -440,6 +450,29 @@ __global__ __launch_bounds__(NT) void merge_topk_kernel(MergeArgs args) {
             }
             if (lane == 0 && best) atomicMax(&s_thr, best);
             __syncthreads();
+            if (use_heads) {
+                uint32_t np2 = 1;
+                while (np2 < nlists) np2 <<= 1;
+                const uint32_t P = NT / np2 > 0 ? NT / np2 : 1;
+                const uint32_t heads_per_round = NT / P;
+                for (uint32_t h0 = 0; h0 < nlists; h0 += heads_per_round) {
+                    const uint32_t h = h0 + tid / P;
+                    const uint32_t part = tid % P;
+                    if (h < nlists) {
+                        const u64 mine = hkeys[h];
+                        const uint32_t span = (nlists + P - 1) / P;
+                        const uint32_t j0 = part * span, j1 = j0 + span < nlists ? j0 + span : nlists;
+                        int greater = 0;
+#pragma unroll 4
+                        for (uint32_t j = j0; j < j1; ++j) greater += hkeys[j] > mine ? 1 : 0;
+                        if (greater) atomicAdd(&s_rank[h], greater);
+                    }
+                }
+                __syncthreads();
+                for (uint32_t h = tid; h < nlists; h += NT)
+                    if (hkeys[h] != 0 && s_rank[h] == k - 1) atomicMax(&s_thr, hkeys[h]);  // k-th largest head
+                __syncthreads();
+            }
             if (tid == 0 && s_thr) s_thr -= 1;  // the loop keeps keys > s_thr: the bound entry itself stays
             __syncthreads();
         }

@@ -52,3 +52,7 @@ run(512, 64, 1, "k64")
 run(512, 256, 1, "k256")
 run(8, 10, 2, "cross-shard")
 run(512, 10, 1, "heavy-overlap", heavy=True)
+run(512, 30, 1, "k30")
+run(1024, 30, 1, "k30 x1024 lists")
+run(2048, 30, 1, "k30 x2048 lists")
+run(512, 90, 1, "k90")
