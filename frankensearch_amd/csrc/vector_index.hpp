@@ -125,6 +125,7 @@ class VectorIndex {
 
   private:
     SearchError ensure_query_dimension(uint32_t query_len) const;
+    void* pinned_io();
     SearchError batched_impl(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k, const uint64_t* allow_dev,
                              uint32_t* out_rows_dev, float* out_scores_dev, uint32_t* out_counts_dev, hipStream_t stream,
                              uint32_t* fallbacks, uint64_t* out_packed_dev, uint32_t int8_mult);
@@ -162,6 +163,9 @@ class VectorIndex {
     int mf_shape_i8_ = 4, mf_per_cu_160_ = 1, mf_per_cu_160_i8_ = 1;
     bool mf_use_160_ = false;
     int mf_shape_ = -1, mf_per_cu_narrow_ = 1, mf_per_cu_wide_ = 1, mf_per_cu_narrow_i8_ = 1, mf_per_cu_wide_i8_ = 1;  // batched-scan launch shapes (probed once)
+    static constexpr size_t kPinnedIoBytes = 256 * 1024;
+    void* io_host_ = nullptr;  // pinned staging for the single-query latency paths
+    bool io_failed_ = false;
     uint32_t* mf_flags_host_ = nullptr;                              // pinned per-query verdicts of the batched scan
     uint32_t mf_flags_cap_ = 0;
     // profiling events
