@@ -3,6 +3,7 @@
 #include "bert_embedder.hpp"
 
 #include <cstdlib>
+#include <cstring>
 #include <string>
 
 namespace fsgpu {
@@ -32,6 +33,7 @@ SearchError hip_err(hipError_t e, const char* what) {
 NativeEmbedder::~NativeEmbedder() {
     if (device_ >= 0) (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamDestroy(stream_);
+    if (io_host_) (void)hipHostFree(io_host_);
     for (DeviceBuffer* b : {&word_, &pos_, &type_, &emb_ln_w_, &emb_ln_b_, &ids_, &positions_, &offsets_, &x_f32_, &x_h_,
                             &qkv_f32_, &ctx_h_, &tmp_f32_, &inter_h_, &out_})
         b->release();
@@ -168,7 +170,7 @@ SearchError NativeEmbedder::forward(uint32_t n_docs, uint32_t tokens, uint32_t m
                                         static_cast<const float*>(l.ln2_b.ptr), x_h_.ptr, T, H, eps, stream_));
         }
     }
-    BERT_HIP(launch_bert_pool(x, offs, static_cast<float*>(out_.ptr), (int)n_docs, H, stream_));
+    BERT_HIP(launch_bert_pool(x, offs, pooled_out_ ? pooled_out_ : static_cast<float*>(out_.ptr), (int)n_docs, H, stream_));
     return SearchError{};
 }
 
@@ -206,6 +208,33 @@ SearchError NativeEmbedder::embed_batch(const int32_t* ids, const uint32_t* offs
     BERT_TRY(positions_.reserve((size_t)total * 4));
     BERT_TRY(offsets_.reserve((size_t)(n + 1) * 4));
     BERT_TRY(out_.reserve((size_t)n * H * 4));
+    // Small calls (queries): inputs go through one pinned block (DMA instead of the runtime's pageable staging) and the
+    // pooled vectors are read back from pinned memory the pool kernel wrote — no D2H copy.
+    const size_t in_bytes = ((size_t)total * 8 + (size_t)(n + 1) * 4 + 255) & ~(size_t)255;
+    const size_t out_bytes = (size_t)n * H * 4;
+    if (in_bytes + out_bytes <= kPinnedIoBytes) {
+        if (!io_host_ && !io_failed_ && hipHostMalloc(&io_host_, kPinnedIoBytes, hipHostMallocMapped) != hipSuccess) {
+            io_host_ = nullptr;
+            io_failed_ = true;
+            (void)hipGetLastError();
+        }
+    }
+    if (io_host_ && in_bytes + out_bytes <= kPinnedIoBytes) {
+        unsigned char* io = static_cast<unsigned char*>(io_host_);
+        std::memcpy(io, ids + base, (size_t)total * 4);
+        std::memcpy(io + (size_t)total * 4, positions.data(), (size_t)total * 4);
+        std::memcpy(io + (size_t)total * 8, offs.data(), (size_t)(n + 1) * 4);
+        BERT_HIP(hipMemcpyAsync(ids_.ptr, io, (size_t)total * 4, hipMemcpyHostToDevice, stream_));
+        BERT_HIP(hipMemcpyAsync(positions_.ptr, io + (size_t)total * 4, (size_t)total * 4, hipMemcpyHostToDevice, stream_));
+        BERT_HIP(hipMemcpyAsync(offsets_.ptr, io + (size_t)total * 8, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, stream_));
+        pooled_out_ = reinterpret_cast<float*>(io + in_bytes);
+        SearchError fe = forward(n, total, max_seq);
+        pooled_out_ = nullptr;
+        if (!fe.ok()) return fe;
+        BERT_HIP(hipStreamSynchronize(stream_));
+        std::memcpy(out, io + in_bytes, out_bytes);
+        return SearchError{};
+    }
     BERT_HIP(hipMemcpyAsync(ids_.ptr, ids + base, (size_t)total * 4, hipMemcpyHostToDevice, stream_));
     BERT_HIP(hipMemcpyAsync(positions_.ptr, positions.data(), (size_t)total * 4, hipMemcpyHostToDevice, stream_));
     BERT_HIP(hipMemcpyAsync(offsets_.ptr, offs.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, stream_));

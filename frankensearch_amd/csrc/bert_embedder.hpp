@@ -37,6 +37,11 @@ class NativeEmbedder {
     std::vector<Layer> layers_;
     // workspaces
     DeviceBuffer ids_, positions_, offsets_, x_f32_, x_h_, qkv_f32_, ctx_h_, tmp_f32_, inter_h_, out_;
+    // pinned staging for small calls (see embed_batch)
+    static constexpr size_t kPinnedIoBytes = 512 * 1024;
+    void* io_host_ = nullptr;
+    bool io_failed_ = false;
+    float* pooled_out_ = nullptr;  // where the pool kernel writes during a pinned call
 };
 
 }  // namespace fsgpu
