@@ -29,7 +29,7 @@ def env():
 
     dev = torch.device("cuda", 0)
     slab = bench.gen_corpus(0, N, DIM, dev)
-    queries = bench.gen_queries(8, DIM, dev)
+    queries = bench.gen_queries(200, DIM, dev)
     idx = fa.VectorIndex.from_device_slab(slab.data_ptr(), N, DIM, device=0, keepalive=slab)
     return {"torch": torch, "fa": fa, "slab": slab, "queries": queries, "idx": idx, "dev": dev}
 
@@ -101,6 +101,32 @@ def test_shards_with_row_base_merge_to_whole(env):
     assert np.array_equal(rows.cpu().numpy().view(np.uint32), whole_rows)
     assert np.array_equal(bits(scores.cpu().numpy()), bits(whole_scores))
     assert np.all(counts.cpu().numpy() == K)
+
+
+def test_batched_shards_merge_to_whole(env):
+    # the bench's N > 1 path: every rank answers the whole batch on its 1.25M-row shard through the batched matrix-core
+    # scan (small shards skip the second sampling stage), packed hits are gathered and merged
+    torch, fa, slab, idx = env["torch"], env["fa"], env["slab"], env["idx"]
+    from frankensearch_amd.sharded import GpuShardBackend, shard_range
+    q = env["queries"][:200].contiguous()
+    whole_rows, whole_scores, _, fb = idx.search_batched(q.cpu().numpy(), K)
+    exact_rows, exact_scores, _ = idx.search_batch(q[:16].cpu().numpy(), K)
+    assert np.array_equal(whole_rows[:16], exact_rows) and np.array_equal(bits(whole_scores[:16]), bits(exact_scores))
+    world = 8
+    lists, backends, fallbacks = [], [], 0
+    for r in range(world):
+        lo, hi = shard_range(N, r, world)
+        sub = fa.VectorIndex.from_device_slab(slab[lo:hi].data_ptr(), hi - lo, DIM, device=0, row_base=lo, keepalive=slab)
+        be = GpuShardBackend(sub, env["dev"], batched=True)
+        backends.append(be)
+        lists.append(be.search_packed(q, K))
+        fallbacks += be.last_fallbacks
+    gathered = torch.stack(lists).contiguous()
+    rows, scores, counts = backends[0].merge(gathered, K)
+    torch.cuda.synchronize()
+    assert np.array_equal(rows.cpu().numpy().view(np.uint32), whole_rows)
+    assert np.array_equal(bits(scores.cpu().numpy()), bits(whole_scores))
+    assert fallbacks < 200
 
 
 def test_tombstone_removes_exactly_the_deleted_rows(env):
