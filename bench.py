@@ -39,6 +39,15 @@ CLUSTERS = 64
 NOISE = 0.30
 
 
+def baseline_metric() -> str:
+    """BASELINE.json's metric string (value = queries/sec of the exact top-k search; the p50 phase-1 latency it also names
+    is reported next to it as p50_phase1_latency_ms)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except (OSError, ValueError, KeyError):
+        return "queries/sec + p50 phase-1 latency, 10Mx384 f16 corpus, 1/2/4/8 MI355X"
+
+
 def gen_chunk(chunk: int, dim: int, device) -> torch.Tensor:
     """Synthetic clustered unit vectors, same recipe as the reference bench generator
     (frankensearch/benches/fsvi_4bit_vs_incumbent.rs:56-101: 64 centroids + 0.30 * uniform noise, L2
@@ -400,7 +409,7 @@ def main() -> None:
         alg_bytes = scan_rows // max(launches, 1) * args.dim * 2   # rows the timed kernel streams per launch
         achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
         line = {
-            "metric": "queries/sec, f16 cosine scan + top-k, 10Mx384 f16 corpus",
+            "metric": baseline_metric(),
             "value": args.steps * B / elapsed,
             "unit": "queries/sec",
             "n_gpus": world,
