@@ -41,6 +41,31 @@ SearchError hip_fail(hipError_t e, const char* what) {
         if (!_s.ok()) return _s;   \
     } while (0)
 
+// Tuning / debugging knobs, read from the environment ONCE (getenv is not safe against concurrent setenv, and these are
+// experiment switches, not configuration): see scripts/exp_*.
+struct Knobs {
+    int grid_blocks = 0, ra = 0, rb = 0, mfma_shape = 0, mfma_shape_i8 = 0;
+    bool no_skip_b = false, use_160 = false, debug_batched = false;
+    Knobs() {
+        auto num = [](const char* name) {
+            const char* e = std::getenv(name);
+            return e ? std::atoi(e) : 0;
+        };
+        grid_blocks = num("FSGPU_GRID_BLOCKS");
+        ra = num("FSGPU_RA");
+        rb = num("FSGPU_RB");
+        mfma_shape = num("FSGPU_MFMA_SHAPE");
+        mfma_shape_i8 = num("FSGPU_MFMA_SHAPE_I8");
+        no_skip_b = std::getenv("FSGPU_NO_SKIP_B") != nullptr;
+        use_160 = std::getenv("FSGPU_USE_160") != nullptr;
+        debug_batched = std::getenv("FSGPU_DEBUG_BATCHED") != nullptr;
+    }
+};
+const Knobs& knobs() {
+    static const Knobs k;
+    return k;
+}
+
 SearchError make_error(int32_t code, std::string detail) {
     SearchError e;
     e.code = code;
@@ -636,10 +661,7 @@ SearchError VectorIndex::fused_search(const float* queries_dev, uint32_t nq, uin
             per_cu = scan_occupancy_blocks_per_cu((int)dim_, pass, kcap, variant == 1);
         }
         int grid = num_cus_ * per_cu;
-        if (const char* env = std::getenv("FSGPU_GRID_BLOCKS")) {  // tuning experiments only
-            const int forced = std::atoi(env);
-            if (forced > 0) grid = forced;
-        }
+        if (knobs().grid_blocks > 0) grid = knobs().grid_blocks;  // tuning experiments only
         const uint32_t ntiles_pass = (uint32_t)((nrows_ + (16 / pass) - 1) / (16 / pass));
         const int max_useful = (int)((ntiles_pass + 3) / 4);
         if (grid > max_useful) grid = max_useful;
@@ -838,15 +860,15 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     constexpr uint32_t KC = kSelectPool;  // approximate candidates re-scored exactly (at most)
     uint32_t RA = 4096;               // stage A sample rows (dense; <= 8192)
     uint32_t RB = 131072;             // stage B sample rows (upper bound; shrinks with the slab, see below)
-    if (const char* e = std::getenv("FSGPU_RA")) RA = (uint32_t)std::atoi(e);  // tuning experiments only
-    if (const char* e = std::getenv("FSGPU_RB")) RB = (uint32_t)std::atoi(e);
+    if (knobs().ra > 0) RA = (uint32_t)knobs().ra;  // tuning experiments only
+    if (knobs().rb > 0) RB = (uint32_t)knobs().rb;
     constexpr uint32_t RA_MAX = 8192;
     if (RA < 256 || RA > RA_MAX || (RA & 63)) RA = 4096;
     // Small slabs (a row shard of a multi-GPU index): a dense sample of 8192 rows already gives a threshold that lets
     // only ~k N / 8192 rows of the main pass through, so the second sampling stage (a launch plus a selection, ~55 us)
     // is skipped when that many candidates fit the block lists comfortably.
     bool skip_b = false;
-    if (!std::getenv("FSGPU_RA") && !std::getenv("FSGPU_NO_SKIP_B") && nrows_ <= 4'000'000 && nrows_ >= 4 * (uint64_t)RA_MAX) {
+    if (knobs().ra <= 0 && !knobs().no_skip_b && nrows_ <= 4'000'000 && nrows_ >= 4 * (uint64_t)RA_MAX) {
         const uint64_t expect = (uint64_t)std::max<uint32_t>(k, 1) * (i8 ? std::max<uint32_t>(int8_mult, 1) : 1) * (nrows_ / RA_MAX);
         if (expect <= 4096) {
             RA = RA_MAX;
@@ -856,8 +878,8 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     // The main pass lets ~ksel N / RB rows through and stage B ~ksel RB / RA: both must stay in the low thousands (block
     // lists, spill area, the selection's capacity), so the samples grow with the rank the selections anchor on.
     const uint32_t ksel_est = std::max<uint32_t>(k, 1) * (int8_mult ? int8_mult : 1);
-    const uint32_t grow = std::getenv("FSGPU_RB") ? 1 : std::min<uint32_t>(4, (ksel_est + 15) / 16);
-    if (!std::getenv("FSGPU_RA") && ksel_est > 32) RA = RA_MAX;
+    const uint32_t grow = knobs().rb > 0 ? 1 : std::min<uint32_t>(4, (ksel_est + 15) / 16);
+    if (knobs().ra <= 0 && ksel_est > 32) RA = RA_MAX;
     // B = about 1/64 of the slab (times the growth), between 8 RA and the cap, a multiple of RA, at most a quarter of it
     RB = std::min<uint32_t>(RB * grow, std::max<uint32_t>(8 * RA, (uint32_t)(nrows_ / 64) * grow));
     RB = std::min<uint32_t>(RB, (uint32_t)(nrows_ / 4));
@@ -915,7 +937,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     FSGPU_TRY(mf_sel_.reserve((size_t)GMAX * KC * 8));
     if (mf_shape_ < 0) {
         mf_shape_ = 2;                // 128-query kernel shape (mfma_scan.hip)
-        if (const char* e = std::getenv("FSGPU_MFMA_SHAPE")) mf_shape_ = std::atoi(e);  // tuning experiments only
+        if (knobs().mfma_shape) mf_shape_ = knobs().mfma_shape;  // tuning experiments only
         if (mf_shape_ < 1 || mf_shape_ > 3) mf_shape_ = 2;
         MfmaScanArgs probe{};
         probe.dim = dim_;
@@ -924,13 +946,13 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         FSGPU_HIP(launch_scan_mfma(probe, mf_shape_, 1, stream, &mf_per_cu_wide_));
         probe.elem_bytes = 1;
         mf_shape_i8_ = 4;             // int8 rows are half as long: 64-row tiles keep 24 KB in flight per wave
-        if (const char* e = std::getenv("FSGPU_MFMA_SHAPE_I8")) mf_shape_i8_ = std::atoi(e);  // tuning experiments only
+        if (knobs().mfma_shape_i8) mf_shape_i8_ = knobs().mfma_shape_i8;  // tuning experiments only
         if (mf_shape_i8_ < 1 || mf_shape_i8_ > 4) mf_shape_i8_ = 4;
         FSGPU_HIP(launch_scan_mfma(probe, 0, 1, stream, &mf_per_cu_narrow_i8_));
         FSGPU_HIP(launch_scan_mfma(probe, mf_shape_i8_, 1, stream, &mf_per_cu_wide_i8_));
         // 160-query shape: measured 1.49 ms per pass at 10M x 384 (0.64 of HBM peak) against 1.26 ms at 128 queries
         // (0.75) — 7 % more queries per second, but the pass is no longer HBM-bound; opt-in (FSGPU_USE_160=1)
-        mf_use_160_ = std::getenv("FSGPU_USE_160") != nullptr;
+        mf_use_160_ = knobs().use_160;
         FSGPU_HIP(launch_scan_mfma(probe, 5, 1, stream, &mf_per_cu_160_i8_));
         probe.elem_bytes = 2;
         FSGPU_HIP(launch_scan_mfma(probe, 5, 1, stream, &mf_per_cu_160_));
@@ -1103,7 +1125,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     std::vector<uint32_t> fb;
     for (uint32_t i = 0; i < nq; ++i)
         if (overflow_all[i] || counts_all[i] < k_eff) fb.push_back(i);
-    if (std::getenv("FSGPU_DEBUG_BATCHED")) {
+    if (knobs().debug_batched) {
         uint32_t big = 0, slot = 0, few = 0, mx = 0;
         for (uint32_t i = 0; i < nq; ++i) {
             if (counts_all[i] > KC) ++big;
