@@ -678,6 +678,14 @@ fsgpu_status fsgpu_index_scan_stats(fsgpu_index* idx, double* total_ms, uint64_t
     });
 }
 
+fsgpu_status fsgpu_index_filter_stats(fsgpu_index* idx, uint64_t* gathered, uint64_t* scanned) {
+    if (!idx || !gathered || !scanned) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(idx->impl.mutex());
+    *gathered = idx->impl.filter_gathered;
+    *scanned = idx->impl.filter_scanned;
+    return FSGPU_OK;
+}
+
 fsgpu_status fsgpu_index_set_variant(fsgpu_index* idx, int32_t variant) {
     if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
     std::lock_guard<std::mutex> lock(idx->impl.mutex());

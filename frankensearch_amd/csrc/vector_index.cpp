@@ -734,6 +734,55 @@ SearchError VectorIndex::general_search(const float* queries_dev, uint32_t nq, u
     return ok();
 }
 
+// try_gather_filtered / scan_gather_positions (crates/frankensearch-index/src/search.rs:1114-1255): when a filter lets
+// through fewer than 1/GATHER_SELECTIVITY_DIVISOR (= 50) of the rows, only those rows are scored (same dot, same order,
+// same (score, row) selection), so the bytes read are cnt * dim * 2 instead of N * dim * 2.  `rows_dev` holds the
+// allowed, live rows (global ids, ascending).
+SearchError VectorIndex::gather_search(const float* queries_dev, uint32_t nq, uint32_t k, const uint32_t* rows_dev,
+                                       uint32_t n, uint32_t* out_rows_dev, float* out_scores_dev,
+                                       uint32_t* out_counts_dev, hipStream_t stream) {
+    const uint32_t k_eff = std::min<uint32_t>(k, n);
+    FSGPU_TRY(ws_gather_out_.reserve((size_t)n * 4));
+    FSGPU_TRY(ws_keys_a_.reserve((size_t)n * 8));
+    float* scores = static_cast<float*>(ws_gather_out_.ptr);
+    u64* packed = static_cast<u64*>(ws_keys_a_.ptr);
+    FSGPU_HIP(hipMemsetAsync(out_rows_dev, 0xff, (size_t)nq * k * 4, stream));
+    FSGPU_HIP(hipMemsetAsync(out_scores_dev, 0xff, (size_t)nq * k * 4, stream));
+    for (uint32_t q = 0; q < nq; ++q) {
+        ScanArgs g = base_args(queries_dev + (size_t)q * dim_, nullptr);
+        FSGPU_HIP(launch_gather_dot(g, rows_dev, n, scores, stream));
+        FSGPU_HIP(launch_pack_hits(rows_dev, scores, n, packed, stream));
+        if (n <= 8192 && k_eff <= 256) {
+            MergeArgs m;
+            m.lists = packed;
+            m.q_stride = n;
+            m.l_stride = n;
+            m.nlists = 1;
+            m.list_len = n;
+            m.k = k_eff;
+            m.out_stride = k;
+            m.out_rows = out_rows_dev + (size_t)q * k;
+            m.out_scores = out_scores_dev + (size_t)q * k;
+            m.out_counts = out_counts_dev + q;
+            m.out_packed = nullptr;
+            m.lists_sorted = 0;
+            FSGPU_HIP(launch_merge_topk(m, 1, stream));
+        } else {
+            FSGPU_TRY(ws_keys_b_.reserve((size_t)n * 8));
+            size_t tmp_bytes = 0;
+            FSGPU_HIP(sort_keys_desc_temp_bytes(n, &tmp_bytes));
+            FSGPU_TRY(ws_sort_tmp_.reserve(tmp_bytes));
+            u64* keys_b = static_cast<u64*>(ws_keys_b_.ptr);
+            FSGPU_HIP(launch_packed_to_sortkey(packed, n, stream));
+            FSGPU_HIP(sort_keys_desc(ws_sort_tmp_.ptr, ws_sort_tmp_.bytes, packed, keys_b, n, stream));
+            uint32_t* rows_q = out_rows_dev + (size_t)q * k;
+            FSGPU_HIP(launch_sorted_keys_to_rows(keys_b, k_eff, rows_q, out_counts_dev + q, stream));
+            FSGPU_HIP(launch_gather_dot(g, rows_q, k_eff, out_scores_dev + (size_t)q * k, stream));
+        }
+    }
+    return ok();
+}
+
 SearchError VectorIndex::search_top_k_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
                                              const uint64_t* allow_dev, uint32_t* out_rows_dev,
                                              float* out_scores_dev, uint32_t* out_counts_dev, hipStream_t stream) {
@@ -788,15 +837,54 @@ SearchError VectorIndex::search_top_k(const float* queries, uint32_t nq, uint32_
     FSGPU_TRY(ws_counts_.reserve((size_t)nq * 4));
     FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, queries, qbytes, hipMemcpyHostToDevice, stream_));
     const uint64_t* allow_dev = nullptr;
+    bool gathered = false;
     if (allow) {
         const size_t words = (size_t)((nrows_ + 63) / 64);
-        FSGPU_TRY(ws_allow_.reserve(words * 8));
-        FSGPU_HIP(hipMemcpyAsync(ws_allow_.ptr, allow, words * 8, hipMemcpyHostToDevice, stream_));
-        allow_dev = static_cast<const uint64_t*>(ws_allow_.ptr);
+        // selective filter: score only the allowed rows (GATHER_SELECTIVITY_DIVISOR = 50, search.rs:1667,1136-1139);
+        // needs the tombstone bitmap on the host (absent only for indexes created over a device-resident bitmap)
+        const bool live_known = live_dev_ == nullptr || !live_host_.empty();
+        uint64_t cnt = 0;
+        if (live_known && variant != 6) {
+            for (size_t w = 0; w < words; ++w) {
+                uint64_t bitsw = allow[w];
+                if (!live_host_.empty()) bitsw &= live_host_[w];
+                if (w + 1 == words && (nrows_ & 63)) bitsw &= (1ull << (nrows_ & 63)) - 1ull;
+                cnt += (uint64_t)__builtin_popcountll(bitsw);
+            }
+        }
+        if (live_known && variant != 6 && cnt > 0 && cnt * 50 < nrows_) {
+            std::vector<uint32_t> rows_host;
+            rows_host.reserve((size_t)cnt);
+            for (size_t w = 0; w < words; ++w) {
+                uint64_t bitsw = allow[w];
+                if (!live_host_.empty()) bitsw &= live_host_[w];
+                if (w + 1 == words && (nrows_ & 63)) bitsw &= (1ull << (nrows_ & 63)) - 1ull;
+                while (bitsw) {
+                    const int b = __builtin_ctzll(bitsw);
+                    rows_host.push_back((uint32_t)(row_base_ + w * 64 + (size_t)b));
+                    bitsw &= bitsw - 1;
+                }
+            }
+            FSGPU_TRY(ws_gather_rows_.reserve(rows_host.size() * 4));
+            FSGPU_HIP(hipMemcpyAsync(ws_gather_rows_.ptr, rows_host.data(), rows_host.size() * 4, hipMemcpyHostToDevice, stream_));
+            FSGPU_HIP(hipStreamSynchronize(stream_));  // rows_host is freed at the end of this block
+            FSGPU_TRY(gather_search(static_cast<const float*>(ws_queries_.ptr), nq, k,
+                                    static_cast<const uint32_t*>(ws_gather_rows_.ptr), (uint32_t)rows_host.size(),
+                                    static_cast<uint32_t*>(ws_rows_.ptr), static_cast<float*>(ws_scores_.ptr),
+                                    static_cast<uint32_t*>(ws_counts_.ptr), stream_));
+            gathered = true;
+            ++filter_gathered;
+        } else {
+            FSGPU_TRY(ws_allow_.reserve(words * 8));
+            FSGPU_HIP(hipMemcpyAsync(ws_allow_.ptr, allow, words * 8, hipMemcpyHostToDevice, stream_));
+            allow_dev = static_cast<const uint64_t*>(ws_allow_.ptr);
+            ++filter_scanned;
+        }
     }
-    FSGPU_TRY(search_top_k_device(static_cast<const float*>(ws_queries_.ptr), nq, query_len, k, allow_dev,
-                                  static_cast<uint32_t*>(ws_rows_.ptr), static_cast<float*>(ws_scores_.ptr),
-                                  static_cast<uint32_t*>(ws_counts_.ptr), stream_));
+    if (!gathered)
+        FSGPU_TRY(search_top_k_device(static_cast<const float*>(ws_queries_.ptr), nq, query_len, k, allow_dev,
+                                      static_cast<uint32_t*>(ws_rows_.ptr), static_cast<float*>(ws_scores_.ptr),
+                                      static_cast<uint32_t*>(ws_counts_.ptr), stream_));
     FSGPU_HIP(hipMemcpyAsync(out_rows, ws_rows_.ptr, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream_));
     FSGPU_HIP(hipMemcpyAsync(out_scores, ws_scores_.ptr, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream_));
     FSGPU_HIP(hipMemcpyAsync(out_counts, ws_counts_.ptr, (size_t)nq * 4, hipMemcpyDeviceToHost, stream_));

@@ -119,6 +119,7 @@ class VectorIndex {
     int device() const { return device_; }
     int32_t hreduce = 0;
     int32_t variant = 0;
+    uint64_t filter_gathered = 0, filter_scanned = 0;  // filtered host searches by path
     bool profiling = false;
     VectorIndex* mrl_view(uint32_t dims);  // strided prefix view of this slab (created on first use)
     SearchError scan_time(double* total_ms, uint64_t* launches, uint64_t* rows, bool reset);
@@ -135,6 +136,8 @@ class VectorIndex {
     SearchError fused_search(const float* queries_dev, uint32_t nq, uint32_t k_out, uint32_t k_eff,
                              const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
                              uint32_t* out_counts_dev, u64* out_packed_dev, hipStream_t stream);
+    SearchError gather_search(const float* queries_dev, uint32_t nq, uint32_t k, const uint32_t* rows_dev, uint32_t n,
+                              uint32_t* out_rows_dev, float* out_scores_dev, uint32_t* out_counts_dev, hipStream_t stream);
     SearchError general_search(const float* queries_dev, uint32_t nq, uint32_t k_out, uint32_t k_eff,
                                const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
                                uint32_t* out_counts_dev, hipStream_t stream);

@@ -39,7 +39,9 @@ def _ptr(a) -> Optional[int]:
 
 
 def pack_bitmap(mask: np.ndarray) -> np.ndarray:
-    """bool[N] -> uint64 words (bit r of word r//64 = mask[r])."""
+    """bool[N] -> uint64 words (bit r of word r//64 = mask[r]); uint64 input is taken as already packed."""
+    if isinstance(mask, np.ndarray) and mask.dtype == np.uint64:
+        return np.ascontiguousarray(mask)
     mask = np.asarray(mask, dtype=bool)
     words = (mask.size + 63) // 64
     padded = np.zeros(words * 64, dtype=np.uint8)
@@ -285,6 +287,12 @@ class VectorIndex:
         ms, n, rows = C.c_double(), C.c_uint64(), C.c_uint64()
         check(_lib.lib().fsgpu_index_scan_stats(self._h, C.byref(ms), C.byref(n), C.byref(rows), int(reset)))
         return ms.value, n.value, rows.value
+
+    def filter_stats(self) -> Tuple[int, int]:
+        """(filtered searches answered by scoring only the allowed rows, by the masked full scan)."""
+        g, s = C.c_uint64(), C.c_uint64()
+        check(_lib.lib().fsgpu_index_filter_stats(self._h, C.byref(g), C.byref(s)))
+        return g.value, s.value
 
     def set_coalescing(self, max_batch: int, max_wait_us: int = 200) -> None:
         """Gather concurrent single-query `search_top_k` callers into one batched pass (0 = off)."""

@@ -310,6 +310,9 @@ fsgpu_status fsgpu_index_scan_time(fsgpu_index *idx, double *total_ms, uint64_t 
  * sampling stage already covered), so that bytes/launch can be stated exactly. */
 fsgpu_status fsgpu_index_scan_stats(fsgpu_index *idx, double *total_ms, uint64_t *launches, uint64_t *rows,
                                     int32_t reset);
+/* Filtered searches (allow bitmap given) answered by scoring only the allowed rows (try_gather_filtered,
+ * crates/frankensearch-index/src/search.rs:1114-1180: taken when allowed * 50 < rows) and by the masked full scan. */
+fsgpu_status fsgpu_index_filter_stats(fsgpu_index *idx, uint64_t *gathered, uint64_t *scanned);
 /* Selects the scan kernel variant (0 = default) — used by bench A/B runs only. */
 fsgpu_status fsgpu_index_set_variant(fsgpu_index *idx, int32_t variant);
 

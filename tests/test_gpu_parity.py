@@ -679,3 +679,43 @@ def test_edge_cases_of_the_batched_and_two_pass_entry_points(fa, oracle):
     assert c.tolist() == [3] * 100 and set(r[0, :3].tolist()) == {5, 777, 39_999}
     r8, s8, c8, _ = sparse.search_int8_two_pass_batched(np.tile(q, (20, 1)), 10, 3)
     assert c8.tolist() == [3] * 100 and np.array_equal(r8[:, :3], r[:, :3])
+
+
+@pytest.mark.gpu
+def test_selective_filter_scores_only_the_allowed_rows(fa, oracle):
+    # try_gather_filtered (search.rs:1114-1180): allowed * 50 < rows -> only the allowed rows are read; the result must be
+    # the one the masked full scan gives (same dot order, same (score, row) selection), tombstones included
+    rng = np.random.default_rng(77)
+    n, dim = 300_000, 384
+    slab = rand_slab(rng, n, dim)
+    slab[1000:1040] = slab[999]  # ties across allowed rows: the lower row wins
+    q = rng.standard_normal((3, dim)).astype(np.float32)
+    live = rng.random(n) > 0.1
+    for allowed, k, want_gather in ((40, 10, True), (40, 64, True), (5000, 10, True), (5000, 300, True),
+                                    (5999, 10, True), (6001, 10, False), (9000, 1000, False)):
+        allow = np.zeros(n, bool)
+        allow[rng.choice(n, allowed, replace=False)] = True
+        if allowed == 40:
+            allow[:] = False
+            allow[990:1030] = True
+        for lv in (None, live):
+            idx = fa.VectorIndex.from_slab(slab, live=lv)
+            rows, scores, counts = idx.search_batch(q, k, allow=allow)
+            g, s = idx.filter_stats()
+            eff = allow if lv is None else (allow & lv)
+            cnt = int(eff.sum())
+            assert (g, s) == ((1, 0) if cnt * 50 < n and cnt > 0 else (0, 1)), (allowed, cnt, g, s)
+            if lv is None:
+                assert (g == 1) == want_gather
+            for qi in range(3):
+                er, es = oracle.search_top_k(slab, q[qi], k, live=eff)
+                m = int(counts[qi])
+                assert m == len(er) == min(k, cnt)
+                assert np.array_equal(rows[qi, :m], er) and np.array_equal(bits(scores[qi, :m]), bits(es))
+                assert np.all(rows[qi, m:] == 0xFFFFFFFF)
+            idx.close()
+    # nothing allowed: the masked scan answers (empty result)
+    idx = fa.VectorIndex.from_slab(slab)
+    rows, scores, counts = idx.search_batch(q, 5, allow=np.zeros(n, bool))
+    assert np.all(counts == 0) and idx.filter_stats() == (0, 1)
+    idx.close()
