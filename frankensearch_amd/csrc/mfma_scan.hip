@@ -65,6 +65,21 @@ __global__ __launch_bounds__(WPB * 64) void scan_mfma_kernel(MfmaScanArgs args) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the tile index arithmetic stays on the SALU
     const int frow = lane & 15;  // A: row inside the tile / B: query inside the query tile / C: column (query)
     const int fk = lane >> 4;    // k-group (8 halves each) / C: row group (4 rows each)
+    if (gridDim.y > 1) {
+        // several query groups in one launch (the sample stages of a large batch): blockIdx.y picks the group, whose
+        // per-query arrays follow the previous group's
+        const size_t grp = blockIdx.y;
+        args.queries = static_cast<const unsigned char*>(args.queries) + grp * NQ * (size_t)DIM * 2;
+        args.tau += grp * NQ;
+        if (STAGE == 0) {
+            args.dense += grp * NQ * (size_t)args.group_count * 64;
+        } else {
+            args.cand += grp * NQ * (size_t)gridDim.x * args.slots;
+            args.spill += grp * NQ * (size_t)args.spill_cap;
+            args.spill_count += grp * NQ * kMfmaSpillCountStride;
+            args.overflow += grp * NQ;
+        }
+    }
     {   // stage the queries: 16-byte pieces, coalesced
         const u32x4* src = static_cast<const u32x4*>(args.queries);
         constexpr int PIECES = DIM / 8;
@@ -650,7 +665,7 @@ static hipError_t launch_mfma_s(const MfmaScanArgs& args, int grid, hipStream_t 
         *occupancy = blocks;
         return hipSuccess;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WPB * 64), lds, stream, args);
+    hipLaunchKernelGGL(kern, dim3(grid, args.groups ? args.groups : 1), dim3(WPB * 64), lds, stream, args);
     return hipGetLastError();
 }
 

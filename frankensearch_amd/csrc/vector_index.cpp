@@ -44,7 +44,7 @@ SearchError hip_fail(hipError_t e, const char* what) {
 // Tuning / debugging knobs, read from the environment ONCE (getenv is not safe against concurrent setenv, and these are
 // experiment switches, not configuration): see scripts/exp_*.
 struct Knobs {
-    int grid_blocks = 0, ra = 0, rb = 0, mfma_shape = 0, mfma_shape_i8 = 0;
+    int grid_blocks = 0, ra = 0, rb = 0, mfma_shape = 0, mfma_shape_i8 = 0, round = 0;
     bool no_skip_b = false, use_160 = false, debug_batched = false;
     Knobs() {
         auto num = [](const char* name) {
@@ -54,6 +54,7 @@ struct Knobs {
         grid_blocks = num("FSGPU_GRID_BLOCKS");
         ra = num("FSGPU_RA");
         rb = num("FSGPU_RB");
+        round = num("FSGPU_ROUND");
         mfma_shape = num("FSGPU_MFMA_SHAPE");
         mfma_shape_i8 = num("FSGPU_MFMA_SHAPE_I8");
         no_skip_b = std::getenv("FSGPU_NO_SKIP_B") != nullptr;
@@ -1017,12 +1018,17 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         FSGPU_HIP(launch_max_row_norm(slab_dev_, N, dim_, static_cast<unsigned int*>(mf_max_norm_.ptr), stream));
         mf_norm_ready_ = true;
     }
-    FSGPU_TRY(mf_qh_.reserve((size_t)GMAX * dim_ * 2));
-    FSGPU_TRY(mf_delta_.reserve(GMAX * 4));
-    FSGPU_TRY(mf_tau_.reserve(GMAX * 4));
-    FSGPU_TRY(mf_spill_.reserve((size_t)GMAX * SPILL * 8 + (size_t)GMAX * kMfmaSpillCountStride * 4));
-    FSGPU_TRY(mf_dense_.reserve((size_t)GMAX * RA_MAX * 8));
-    FSGPU_TRY(mf_sel_.reserve((size_t)GMAX * KC * 8));
+    // A large batch is answered a "round" of up to QCAP queries at a time: the sample stages and every selection of
+    // a round are single launches over all its query groups (one block per query: 1024 blocks fill the chip where a
+    // group's 128 leave half the CUs idle), only the main pass is one launch per group.
+    const uint32_t round_cap = knobs().round >= (int)GMAX ? (uint32_t)knobs().round : 1024;  // tuning experiments only
+    const uint32_t QCAP = std::min<uint32_t>(round_cap, std::max<uint32_t>(GMAX, (nq + 127) / 128 * 128));
+    FSGPU_TRY(mf_qh_.reserve((size_t)QCAP * dim_ * 2));
+    FSGPU_TRY(mf_delta_.reserve(QCAP * 4));
+    FSGPU_TRY(mf_tau_.reserve(QCAP * 4));
+    FSGPU_TRY(mf_spill_.reserve((size_t)QCAP * SPILL * 8 + (size_t)QCAP * kMfmaSpillCountStride * 4));
+    FSGPU_TRY(mf_dense_.reserve((size_t)QCAP * RA_MAX * 8));
+    FSGPU_TRY(mf_sel_.reserve((size_t)QCAP * KC * 8));
     if (mf_shape_ < 0) {
         mf_shape_ = 2;                // 128-query kernel shape (mfma_scan.hip)
         if (knobs().mfma_shape) mf_shape_ = knobs().mfma_shape;  // tuning experiments only
@@ -1061,7 +1067,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     float* delta = static_cast<float*>(mf_delta_.ptr);
     float* tau = static_cast<float*>(mf_tau_.ptr);
     u64* spill = static_cast<u64*>(mf_spill_.ptr);
-    uint32_t* spill_count = reinterpret_cast<uint32_t*>(spill + (size_t)GMAX * SPILL);
+    uint32_t* spill_count = reinterpret_cast<uint32_t*>(spill + (size_t)QCAP * SPILL);
     u64* pool = static_cast<u64*>(mf_sel_.ptr);
     const uint32_t k_eff = std::min<uint32_t>(k, N);
     for (uint32_t g0 = 0; g0 < nq;) {
@@ -1069,7 +1075,10 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         // 160, 128 or 64 queries per pass
         const int shape = (left > 64 && variant != 5) ? ((left > 128 && mf_use_160_) ? 5 : (i8 ? mf_shape_i8_ : mf_shape_)) : 0;
         const uint32_t G = (uint32_t)scan_mfma_query_tiles(shape) * 16;
-        const uint32_t ng = std::min(G, left);
+        // this round: `ngroups` groups of G queries (the last one may be partly padding), QP query slots, ng real queries
+        const uint32_t ngroups = left >= G ? std::min<uint32_t>(left / G, QCAP / G) : 1;
+        const uint32_t QP = ngroups * G;
+        const uint32_t ng = std::min(QP, left);
         const int wpb = scan_mfma_waves_per_block(shape);
         const int per_cu = shape == 5 ? (i8 ? mf_per_cu_160_i8_ : mf_per_cu_160_)
                                       : (i8 ? (shape ? mf_per_cu_wide_i8_ : mf_per_cu_narrow_i8_)
@@ -1084,16 +1093,16 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         const float* qg = queries_dev + (size_t)g0 * dim_;
         uint32_t* overflow = overflow_all + g0;
         uint32_t* cand_counts = counts_all + g0;
-        if (i8) FSGPU_HIP(launch_prepare_queries_i8(qg, ng, G, dim_, mf_qh_.ptr, delta, stream));
+        if (i8) FSGPU_HIP(launch_prepare_queries_i8(qg, ng, QP, dim_, mf_qh_.ptr, delta, stream));
         else
-            FSGPU_HIP(launch_prepare_queries(qg, ng, G, dim_, static_cast<const unsigned int*>(mf_max_norm_.ptr),
+            FSGPU_HIP(launch_prepare_queries(qg, ng, QP, dim_, static_cast<const unsigned int*>(mf_max_norm_.ptr),
                                              mf_qh_.ptr, delta, stream));
         // one candidate list of `slots` entries per (query, block); 16..32 slots, sized so that lists + pool fit one
         // selection pass when the grid allows (the wide shape's 256 blocks do)
         auto slots_for = [&](int grid) {
             return std::min<uint32_t>((uint32_t)scan_mfma_max_slots(shape), std::max<uint32_t>(16, (CAPQ - KC) / (uint32_t)grid));
         };
-        FSGPU_TRY(mf_cand_.reserve((size_t)G * full_grid * kMfmaMaxSlots * 8));
+        FSGPU_TRY(mf_cand_.reserve((size_t)QP * full_grid * kMfmaMaxSlots * 8));
         u64* cand = static_cast<u64*>(mf_cand_.ptr);
         MfmaScanArgs a{};
         a.slab = i8 ? i8_slab_.ptr : slab_dev_;
@@ -1119,6 +1128,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         a.group_stride = stride_b * (groups_b / groups_a);
         a.group_count = groups_a;
         a.slots = 0;
+        a.groups = ngroups;
         FSGPU_HIP(launch_scan_mfma(a, shape, grid_for(RA, 16), stream, nullptr));
         SelectArgs sa{};
         sa.lists = a.dense;
@@ -1129,7 +1139,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         sa.k = ksel;
         sa.delta = delta;
         sa.tau_out = tau;
-        FSGPU_HIP(launch_select(sa, (int)G, stream));
+        FSGPU_HIP(launch_select(sa, (int)QP, stream));
         // stage B: the B sample's rows at or above tau, one short list per (query, block) -> tighter tau; the rows
         // still at or above it form the pool carried into the last selection
         a.dense = nullptr;
@@ -1139,7 +1149,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         const int grid_b = grid_for(RB, tile_rows);
         a.slots = slots_for(grid_b);
         if (!skip_b) {
-            FSGPU_HIP(hipMemsetAsync(spill_count, 0, (size_t)G * kMfmaSpillCountStride * 4, stream));
+            FSGPU_HIP(hipMemsetAsync(spill_count, 0, (size_t)QP * kMfmaSpillCountStride * 4, stream));
             FSGPU_HIP(launch_scan_mfma(a, shape, grid_b, stream, nullptr));
         }
         SelectArgs sb{};
@@ -1159,7 +1169,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
             if (!skip_b) {
                 sb.tau_out = tau;
                 sb.pool_out = pool;
-                FSGPU_HIP(launch_select(sb, (int)G, stream));
+                FSGPU_HIP(launch_select(sb, (int)QP, stream));
             } else {
                 a.group_stride = 1;  // nothing was sampled by a stage B: the main pass visits every group
                 a.group_count = 0;
@@ -1167,19 +1177,29 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
             // stage C: every group the B sample did not cover
             a.stage = 2;
             a.slots = slots_for(full_grid);
-            FSGPU_HIP(hipMemsetAsync(spill_count, 0, (size_t)G * kMfmaSpillCountStride * 4, stream));
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (profiling) {
-                FSGPU_HIP(hipEventCreate(&e0));
-                FSGPU_HIP(hipEventCreate(&e1));
-                FSGPU_HIP(hipEventRecord(e0, stream));
-            }
-            FSGPU_HIP(launch_scan_mfma(a, shape, full_grid, stream, nullptr));
-            if (profiling) {
-                FSGPU_HIP(hipEventRecord(e1, stream));
-                events_.emplace_back(e0, e1);
-                profiled_rows_ += skip_b ? N : N - RB;
-                profiled_elem_bytes_ = i8 ? 1 : 2;
+            FSGPU_HIP(hipMemsetAsync(spill_count, 0, (size_t)QP * kMfmaSpillCountStride * 4, stream));
+            a.groups = 1;
+            for (uint32_t j = 0; j < ngroups; ++j) {  // one pass over the slab per query group
+                MfmaScanArgs c = a;
+                c.queries = static_cast<const unsigned char*>(mf_qh_.ptr) + (size_t)j * G * dim_ * (i8 ? 1 : 2);
+                c.tau = tau + (size_t)j * G;
+                c.cand = cand + (size_t)j * G * full_grid * a.slots;
+                c.spill = spill + (size_t)j * G * SPILL;
+                c.spill_count = spill_count + (size_t)j * G * kMfmaSpillCountStride;
+                c.overflow = overflow + (size_t)j * G;
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (profiling) {
+                    FSGPU_HIP(hipEventCreate(&e0));
+                    FSGPU_HIP(hipEventCreate(&e1));
+                    FSGPU_HIP(hipEventRecord(e0, stream));
+                }
+                FSGPU_HIP(launch_scan_mfma(c, shape, full_grid, stream, nullptr));
+                if (profiling) {
+                    FSGPU_HIP(hipEventRecord(e1, stream));
+                    events_.emplace_back(e0, e1);
+                    profiled_rows_ += skip_b ? N : N - RB;
+                    profiled_elem_bytes_ = i8 ? 1 : 2;
+                }
             }
             sb.q_stride = (uint64_t)full_grid * a.slots;
             sb.l_stride = a.slots;
