@@ -353,7 +353,7 @@ __device__ __forceinline__ void merge_wave_winners(const u64* win, int k, u64* t
 // are compacted into LDS and bitonic-sorted by the whole block; top-k, threshold and candidate prefix fall out.
 constexpr int kSelSortCap = 8192;   // live entries the sorted variant holds (dynamic LDS: 64 KB)
 template <bool FINISH, bool SORTED>
-__global__ __launch_bounds__(kSelThreads) void select_kernel(SelectArgs args) {
+__global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(SelectArgs args) {
     constexpr int NT = kSelThreads, PER = kSelPer, NW = kSelWaves, POOL = (int)kSelectPool, KL = 1;
     static_assert(POOL == NT, "one pool entry per thread in the final selection");
     __shared__ u64 win[2][NW * 64 * KL];  // per-wave winners [wave][rank], ping-pong across passes
