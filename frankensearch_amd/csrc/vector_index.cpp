@@ -1179,7 +1179,9 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
             a.slots = slots_for(full_grid);
             FSGPU_HIP(hipMemsetAsync(spill_count, 0, (size_t)QP * kMfmaSpillCountStride * 4, stream));
             a.groups = 1;
-            for (uint32_t j = 0; j < ngroups; ++j) {  // one pass over the slab per query group
+            // one pass over the slab per query group, one launch each (all groups in one launch — a group's blocks taking
+            // over the CUs the previous group's leave — measured 1.5 % slower at 10M rows: two groups' streams interleave)
+            for (uint32_t j = 0; j < ngroups; ++j) {
                 MfmaScanArgs c = a;
                 c.queries = static_cast<const unsigned char*>(mf_qh_.ptr) + (size_t)j * G * dim_ * (i8 ? 1 : 2);
                 c.tau = tau + (size_t)j * G;
