@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <future>
 #include <unordered_map>
 
 namespace fshost {
@@ -101,6 +102,17 @@ fsgpu_status SyncTwoTierSearcher::search(const uint32_t* fast_ids, uint32_t n_fa
     const uint32_t fetch = std::max(k * mult, k);  // candidate_count (rrf.rs:113-115)
     fshost_metrics& m = out->metrics;
     const auto t0 = clock::now();
+    // quality embedding: needed by phase 1 only, optionally computed while phase 0 runs
+    std::vector<float> quality_vec(quality_dim_);
+    const uint32_t q_off[2] = {0, n_quality};
+    std::string quality_err;
+    auto embed_quality = [&]() -> fsgpu_status {
+        const fsgpu_status s = fsgpu_bert_embed(bert_, quality_ids, q_off, 1, quality_vec.data());
+        if (s != FSGPU_OK) quality_err = fsgpu_last_error();  // thread-local: read on the thread that made the call
+        return s;
+    };
+    std::future<fsgpu_status> quality_future;  // declared after what the task touches: joined first on every return path
+    if (cfg_.prefetch_quality_embed) quality_future = std::async(std::launch::async, embed_quality);
     // ---- phase 0 / Initial ----
     std::vector<float> fast_vec(fast_dim_);
     const uint32_t fast_off[2] = {0, n_fast};
@@ -129,11 +141,9 @@ fsgpu_status SyncTwoTierSearcher::search(const uint32_t* fast_ids, uint32_t n_fa
     m.phase1_total_ms = ms_since(t0);
     // ---- phase 1 / Refined ----
     const auto t3 = clock::now();
-    std::vector<float> quality_vec(quality_dim_);
-    const uint32_t q_off[2] = {0, n_quality};
-    st = fsgpu_bert_embed(bert_, quality_ids, q_off, 1, quality_vec.data());
+    st = quality_future.valid() ? quality_future.get() : embed_quality();
     if (st != FSGPU_OK) {
-        *detail = fsgpu_last_error();
+        *detail = quality_err;
         return st;
     }
     m.quality_embed_ms = ms_since(t3);

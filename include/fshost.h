@@ -27,6 +27,10 @@ typedef struct fshost_two_tier_config {
     uint32_t fast_tier_int8_multiplier; /* 0 = exact f16 scan of the fast tier; n = search_top_k_int8_two_pass(query, fetch, n),
                                          * the reference's default with n = FAST_TIER_MULT = 3 (two_tier.rs:1318-1337,
                                          * sync_searcher::search_fast_hits) */
+    int32_t prefetch_quality_embed;     /* != 0: the quality-tier (MiniLM) embedding of the query is started on a helper
+                                         * thread when the search begins and joined at the start of phase 1, so it
+                                         * overlaps the fast tier's scan (same results; for latency with few callers —
+                                         * with many, coalescing fills the GPU and the extra thread only costs) */
 } fshost_two_tier_config;
 
 #define FSHOST_DOC_ID_MAX 63
