@@ -331,21 +331,29 @@ __device__ __forceinline__ void wave_select_pass(const u64 (&e)[PER], int k, con
 }
 
 // top[0..k) <- the k best of the 16 waves' winner lists win[wave * k + j], best first (kEmpty padded).  Wave 0 only.
-template <int KL>
-__device__ __forceinline__ void merge_wave_winners(const u64* win, int k, u64* top, int lane) {
+// E = winners a lane holds (16 k <= 64 E): the rounds cost ~6 E + 36 instructions each and run on ONE wave — the serial
+// tail of every selection — so the usual small ranks (k <= 16: 160 winners) take E = 4 instead of the general 16.
+template <int E>
+__device__ __forceinline__ void merge_wave_winners_e(const u64* win, int k, u64* top, int lane) {
     constexpr int NW = kSelWaves;
-    u64 e2[NW * KL], key2[NW * KL];  // NW * k <= 64 * NW * KL winners
+    u64 e2[E], key2[E];
 #pragma unroll
-    for (int x = 0; x < NW * KL; ++x) {
+    for (int x = 0; x < E; ++x) {
         const int i = lane + x * 64;
         e2[x] = i < NW * k ? win[i] : kEmpty;
         key2[x] = e2[x] != kEmpty ? sortkey(e2[x]) : 0ull;
     }
-#pragma unroll
-    for (int c = 0; c < KL; ++c) top[lane + 64 * c] = kEmpty;
+    top[lane] = kEmpty;
     wave_lds_fence();
-    wave_extract_topk<NW * KL>(key2, e2, k, top);
+    wave_extract_topk<E>(key2, e2, k, top);
     wave_lds_fence();
+}
+template <int KL>
+__device__ __forceinline__ void merge_wave_winners(const u64* win, int k, u64* top, int lane) {
+    static_assert(KL == 1, "ranks up to 64");
+    if (k <= 16) merge_wave_winners_e<4>(win, k, top, lane);
+    else if (k <= 32) merge_wave_winners_e<8>(win, k, top, lane);
+    else merge_wave_winners_e<kSelWaves>(win, k, top, lane);
 }
 
 // SORTED = false: the extraction scheme above; its cost grows with k^2 (k rounds over lists that grow with k), fine up

@@ -24,3 +24,14 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / iters
 print(f"shards={shards} rows={rows}: {dt*1e3:.3f} ms per 1024 queries, fallbacks={be.last_fallbacks}; "
       f"floor {rows*dim*2*8/8e12*1e3:.3f} ms (8 passes at 8 TB/s)")
+# the merge every rank runs on the all-gathered lists ([W, B, k] packed hits)
+local = be.search_packed(q, 10)
+gathered = torch.stack([local] * shards).contiguous()
+for _ in range(3):
+    be.merge(gathered, 10)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(50):
+    be.merge(gathered, 10)
+torch.cuda.synchronize()
+print(f"merge of {shards} x 1024 x 10 packed hits: {(time.perf_counter() - t0) / 50 * 1e3:.3f} ms")
