@@ -82,6 +82,7 @@ SIGNATURES = {
     "fsgpu_m2v_set_coalescing": (_i32, [_vp, _u32, _u32]),
     "fsgpu_bert_set_coalescing": (_i32, [_vp, _u32, _u32]),
     "fsgpu_index_scan_stats": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(_u64), C.POINTER(_u64), _i32]),
+    "fsgpu_index_allow_bitmap_for_hashes": (_i32, [_vp, C.POINTER(_u64), _u32, C.POINTER(_u64), C.POINTER(_u64)]),
     "fsgpu_index_filter_stats": (_i32, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "fsgpu_index_set_variant": (_i32, [_vp, _i32]),
 }

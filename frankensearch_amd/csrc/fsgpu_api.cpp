@@ -262,6 +262,15 @@ fsgpu_status fsgpu_index_soft_delete(fsgpu_index* idx, const char* doc_id, uint3
     });
 }
 
+fsgpu_status fsgpu_index_allow_bitmap_for_hashes(const fsgpu_index* idx, const uint64_t* hashes, uint32_t n,
+                                                 uint64_t* allow_bitmap_out, uint64_t* rows_matched) {
+    if (!idx || (!hashes && n) || !allow_bitmap_out) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(const_cast<fsgpu_index*>(idx)->impl.mutex());
+        return finish(idx->impl.allow_bitmap_for_hashes(hashes, n, allow_bitmap_out, rows_matched));
+    });
+}
+
 fsgpu_status fsgpu_index_set_live_bitmap(fsgpu_index* idx, const uint64_t* live_bitmap) {
     if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
     return guarded([&]() -> fsgpu_status {

@@ -599,6 +599,27 @@ SearchError VectorIndex::soft_delete(const char* doc_id, uint32_t len, int32_t* 
     return ok();
 }
 
+// gather_positions_for_hashes (search.rs:1146-1164) as a row bitmap: the rows of each hash are one run of the
+// (hash, doc_id)-sorted record table (hash_range, search.rs:1166-1198).
+SearchError VectorIndex::allow_bitmap_for_hashes(const uint64_t* hashes, uint32_t n, uint64_t* bitmap_out,
+                                                 uint64_t* matched) const {
+    if (doc_hashes_.empty() && nrows_ != 0) return make_error(FSGPU_ERR_INVALID_CONFIG, "index has no record table");
+    const size_t words = (size_t)((nrows_ + 63) / 64);
+    std::memset(bitmap_out, 0, words * 8);
+    uint64_t count = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        auto lo = std::lower_bound(doc_hashes_.begin(), doc_hashes_.end(), hashes[i]);
+        for (auto it = lo; it != doc_hashes_.end() && *it == hashes[i]; ++it) {
+            const size_t r = (size_t)(it - doc_hashes_.begin());
+            const uint64_t bit = 1ull << (r & 63);
+            if (!(bitmap_out[r >> 6] & bit)) ++count;  // a hash may be listed twice
+            bitmap_out[r >> 6] |= bit;
+        }
+    }
+    if (matched) *matched = count;
+    return ok();
+}
+
 // 256 KB of pinned, device-visible host memory per index for the latency paths (allocated on first use).
 void* VectorIndex::pinned_io() {
     if (!io_host_ && !io_failed_) {

@@ -112,6 +112,7 @@ class VectorIndex {
     uint64_t wal_record_count() const { return wal_.size(); }
     SearchError doc_id_at(uint32_t row, const char** ptr, uint32_t* len) const;
     SearchError soft_delete(const char* doc_id, uint32_t len, int32_t* deleted);
+    SearchError allow_bitmap_for_hashes(const uint64_t* hashes, uint32_t n, uint64_t* bitmap_out, uint64_t* matched) const;
     SearchError set_live_bitmap(const uint64_t* live);
     bool has_doc_ids() const { return !doc_offsets_.empty(); }
 

@@ -288,6 +288,15 @@ class VectorIndex:
         check(_lib.lib().fsgpu_index_scan_stats(self._h, C.byref(ms), C.byref(n), C.byref(rows), int(reset)))
         return ms.value, n.value, rows.value
 
+    def allow_bitmap_for_hashes(self, hashes: Sequence[int]) -> Tuple[np.ndarray, int]:
+        """`SearchFilter::candidate_hashes` (FNV-1a doc-id hashes) -> (packed allow bitmap, rows matched)."""
+        h = np.ascontiguousarray(hashes, dtype=np.uint64)
+        bm = np.zeros((self.record_count() + 63) // 64, dtype=np.uint64)
+        m = C.c_uint64()
+        check(_lib.lib().fsgpu_index_allow_bitmap_for_hashes(self._h, h.ctypes.data_as(C.POINTER(C.c_uint64)), h.size,
+                                                             bm.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(m)))
+        return bm, m.value
+
     def filter_stats(self) -> Tuple[int, int]:
         """(filtered searches answered by scoring only the allowed rows, by the masked full scan)."""
         g, s = C.c_uint64(), C.c_uint64()

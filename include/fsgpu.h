@@ -103,6 +103,13 @@ fsgpu_status fsgpu_index_set_hreduce(fsgpu_index *idx, int32_t mode);
 fsgpu_status fsgpu_index_doc_id(const fsgpu_index *idx, uint32_t row, const char **ptr, uint32_t *len);
 /* VectorIndex::soft_delete (lib.rs, tombstone flag): clears the live bit(s) of doc_id; *deleted = 1 if any. */
 fsgpu_status fsgpu_index_soft_delete(fsgpu_index *idx, const char *doc_id, uint32_t doc_id_len, int32_t *deleted);
+/* SearchFilter::candidate_hashes -> rows (gather_positions_for_hashes / hash_range, search.rs:1146-1198): sets, in
+ * allow_bitmap_out (ceil(record_count / 64) words, cleared first), the bit of every main row whose record hash
+ * (FNV-1a 64 of the doc id, lib.rs:6120-6127) is one of `hashes` — a binary search per hash in the (hash, doc_id)-
+ * sorted record table.  The bitmap is what fsgpu_search_topk takes as its filter (tombstoned rows are masked there).
+ * FSVI-opened indexes only.  *rows_matched (may be NULL) = bits set. */
+fsgpu_status fsgpu_index_allow_bitmap_for_hashes(const fsgpu_index *idx, const uint64_t *hashes, uint32_t n,
+                                                 uint64_t *allow_bitmap_out, uint64_t *rows_matched);
 /* VectorIndex::append (lib.rs:2532-2720): a resident WAL entry (f32 vector, immediately searchable through
  * fsgpu_search_hits with the reference's scan_wal / shadowing rules, search.rs:1449-1475,1503-1558); supersedes a
  * resident entry with the same doc id and tombstones the first live main row with that doc id.  The WAL *file*

@@ -719,3 +719,35 @@ def test_selective_filter_scores_only_the_allowed_rows(fa, oracle):
     rows, scores, counts = idx.search_batch(q, 5, allow=np.zeros(n, bool))
     assert np.all(counts == 0) and idx.filter_stats() == (0, 1)
     idx.close()
+
+
+@pytest.mark.gpu
+def test_candidate_hash_filter_through_the_record_table(fa, oracle, tmp_path):
+    # SearchFilter::candidate_hashes -> rows by binary search in the (hash, doc_id)-sorted record table
+    # (gather_positions_for_hashes, search.rs:1146-1198), then the filtered search; duplicate doc ids share a hash run
+    rng = np.random.default_rng(43)
+    n, dim = 6000, 64
+    ids = [f"doc-{i % 5800:05}" for i in range(n)]  # 200 duplicated ids
+    vecs = rng.standard_normal((n, dim)).astype(np.float32)
+    p = str(tmp_path / "h.fsvi")
+    assert oracle.fsvi_write(p, [(ids[i], vecs[i].tolist()) for i in range(n)], "emb", "r1") == 0
+    o = oracle.Fsvi(p)
+    g = fa.VectorIndex.open(p)
+    row_ids = [o.doc_id(r) for r in range(n)]
+    for wanted in (["doc-00007", "doc-00100", "doc-05799", "doc-00007", "no-such-doc"],      # selective: gathered
+                   [f"doc-{i:05}" for i in range(0, 5800, 3)]):                              # a third: masked scan
+        hashes = [oracle.fnv1a64(w.encode()) for w in wanted]
+        bm, matched = g.allow_bitmap_for_hashes(hashes)
+        want_rows = np.array([rid in set(wanted) for rid in row_ids])
+        assert matched == int(want_rows.sum())
+        assert np.array_equal(np.unpackbits(bm.view(np.uint8), bitorder="little")[:n].astype(bool), want_rows)
+        q = rng.standard_normal((2, dim)).astype(np.float32)
+        rows, scores, counts = g.search_batch(q, 10, allow=bm)
+        slab = np.array(o.slab())
+        for qi in range(2):
+            # the oracle's filtered scan over the same file (doc-id dedup is a search_top_k matter, not search_batch's)
+            er, es = oracle.search_top_k(slab, q[qi], 10, live=want_rows)
+            m = int(counts[qi])
+            assert m == len(er) and np.array_equal(rows[qi, :m], er) and np.array_equal(bits(scores[qi, :m]), bits(es))
+    g.close()
+
