@@ -1,0 +1,102 @@
+// f32_kernels.hip — Quantization::F32 slabs (FSVI quantization byte 0, crates/frankensearch-index/src/lib.rs:203-208):
+// rows are raw little-endian f32.  F16 is the reference's default and the format every BASELINE config uses; F32 files
+// are served through the general path only (score every row -> radix sort -> top k), which keeps `VectorIndex::open`
+// total over FSVI v1 without a second family of fused kernels.
+//
+// dot_product_f32_bytes_f32 (simd.rs:581-702): four 8-lane accumulators over groups of 32 elements, separate multiply
+// and add (this file is compiled with -ffp-contract=off like the others), (acc0+acc1)+(acc2+acc3), THEN the leftover
+// 8-element chunks are added to that sum (the f16 kernel adds them to acc0 before the combine), reduce_add, and a
+// fused multiply-add for the last dim % 8 elements.
+//
+// Mapping: a quad of lanes per row; lane a owns accumulator a, i.e. elements [32 g + 8 a, 32 g + 8 a + 8) of every
+// group — the four lanes of a quad read 128 contiguous bytes.  The combine is two DPP quad butterflies (IEEE add is
+// commutative, so all four lanes end with the same bits); leftovers and tail are computed redundantly by the quad.
+#include "kernels.hpp"
+#include "scan_common.hpp"
+
+namespace fsgpu {
+
+using namespace scan_detail;
+
+// GATHER = false: item i is row i of the slab; out_packed[i] = (score, row_base + i) or kEmpty when the row is
+//   tombstoned / filtered.  GATHER = true: item i is rows[i] (a global id; ids outside the shard are skipped),
+//   out_scores[i] = the dot.
+template <bool GATHER>
+__global__ __launch_bounds__(256) void dot_rows_f32_kernel(ScanArgs args, const uint32_t* __restrict__ rows, uint32_t n,
+                                                           u64* __restrict__ out_packed, float* __restrict__ out_scores,
+                                                           int q_index) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* qs = reinterpret_cast<float*>(smem);
+    const int dim = (int)args.dim;
+    const int tid = threadIdx.x, a = tid & 3;
+    for (int i = tid; i < dim; i += 256) qs[i] = args.queries[(size_t)q_index * dim + i];
+    __syncthreads();
+    const uint32_t item = (blockIdx.x * 256u + (uint32_t)tid) >> 2;
+    const bool in_range = item < n;
+    uint32_t row = in_range ? (GATHER ? rows[item] - args.row_base : item) : 0;  // wraps for ids below the shard base
+    const bool mine = in_range && row < args.nrows;
+    if (!mine) row = 0;
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(args.slab) + (size_t)row * args.row_stride;
+    const float* w = reinterpret_cast<const float*>(base);
+    const bool vec = (args.row_stride & 15u) == 0;  // 16-byte aligned rows: dwordx4 loads
+    const int chunks = dim >> 3, groups = chunks >> 2;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int g = 0; g < groups; ++g) {
+        const int e = 32 * g + 8 * a;
+        float x[8];
+        if (vec) {
+            const float4 lo = *reinterpret_cast<const float4*>(w + e), hi = *reinterpret_cast<const float4*>(w + e + 4);
+            x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w;
+            x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = w[e + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float p = x[j] * qs[e + j];
+            acc[j] = acc[j] + p;
+        }
+    }
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float u = acc[j] + quad_xor1(acc[j]);  // lanes 0,1: acc0+acc1   lanes 2,3: acc2+acc3
+        v[j] = u + quad_xor2(u);                     // (acc0+acc1)+(acc2+acc3)
+    }
+    for (int c = 4 * groups; c < chunks; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float p = w[8 * c + j] * qs[8 * c + j];
+            v[j] = v[j] + p;
+        }
+    float s = hreduce8(v, args.hreduce);
+    for (int i = chunks * 8; i < dim; ++i) s = __builtin_fmaf(w[i], qs[i], s);
+    if (a != 0 || !in_range) return;
+    if (GATHER) {
+        if (mine) out_scores[item] = s;
+    } else {
+        bool valid = true;
+        if (args.live) valid = valid && ((args.live[row >> 6] >> (row & 63)) & 1ull);
+        if (args.allow) valid = valid && ((args.allow[row >> 6] >> (row & 63)) & 1ull);
+        out_packed[item] = valid ? pack(s, args.row_base + row) : kEmpty;
+    }
+}
+
+hipError_t launch_score_rows_f32(const ScanArgs& args, u64* out_packed, int q_index, hipStream_t stream) {
+    const unsigned blocks = (unsigned)(((uint64_t)args.nrows * 4 + 255) / 256);
+    hipLaunchKernelGGL((dot_rows_f32_kernel<false>), dim3(blocks ? blocks : 1), dim3(256), (size_t)args.dim * 4, stream,
+                       args, nullptr, args.nrows, out_packed, nullptr, q_index);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_dot_f32(const ScanArgs& args, const uint32_t* rows, uint32_t n, float* out, hipStream_t stream) {
+    const unsigned blocks = (unsigned)(((uint64_t)n * 4 + 255) / 256);
+    hipLaunchKernelGGL((dot_rows_f32_kernel<true>), dim3(blocks ? blocks : 1), dim3(256), (size_t)args.dim * 4, stream,
+                       args, rows, n, nullptr, out, 0);
+    return hipGetLastError();
+}
+
+}  // namespace fsgpu

@@ -573,6 +573,16 @@ fsgpu_status fsgpu_fsvi_write(const char* path, const char* embedder_id, const c
     });
 }
 
+fsgpu_status fsgpu_fsvi_write_quant(const char* path, const char* embedder_id, const char* embedder_revision, uint32_t dim,
+                                    uint64_t n, const char* const* doc_ids, const uint32_t* doc_id_lens,
+                                    const float* vectors, uint8_t compaction_gen, int32_t device, uint8_t quantization) {
+    if (n >= 0x7fffffffull) return fail(FSGPU_ERR_INVALID_CONFIG, "record count must fit the launch grid");
+    return guarded([&]() -> fsgpu_status {
+        return finish(fsgpu::write_fsvi_v1(path, embedder_id, embedder_revision, dim, n, doc_ids, doc_id_lens, vectors,
+                                           compaction_gen, device, quantization));
+    });
+}
+
 fsgpu_status fsgpu_encode_f32_to_f16(int32_t device, const float* src, uint64_t n, uint16_t* dst) {
     return convert_on_device(device, src, 4, n, dst, 2, true);
 }

@@ -61,6 +61,10 @@ hipError_t launch_encode_rows_f16(const float* src, const uint32_t* perm, uint64
                                   hipStream_t stream);
 hipError_t launch_widen_f16(const unsigned short* src, size_t n, float* dst, hipStream_t stream);
 
+// f32_kernels.hip — Quantization::F32 slabs: every row's packed (score, row) entry, and the gathered dot
+hipError_t launch_score_rows_f32(const ScanArgs& args, u64* out_packed, int q_index, hipStream_t stream);
+hipError_t launch_gather_dot_f32(const ScanArgs& args, const uint32_t* rows, uint32_t n, float* out, hipStream_t stream);
+
 // sort_general.hip (rocPRIM radix sort, descending u64 keys) — the large-k / collect-all path.
 hipError_t sort_keys_desc_temp_bytes(size_t n, size_t* temp_bytes);
 hipError_t sort_keys_desc(void* temp, size_t temp_bytes, const u64* keys_in, u64* keys_out, size_t n,

@@ -160,7 +160,7 @@ SearchError VectorIndex::common_init(int device) {
 }
 
 SearchError VectorIndex::init_host(int device, uint32_t dim, uint64_t nrows, const void* slab, const uint64_t* live,
-                                   uint64_t row_base) {
+                                   uint64_t row_base, bool f32_rows) {
     if (dim == 0) return make_error(FSGPU_ERR_INVALID_CONFIG, "dimension must be greater than zero");
     if (nrows + row_base >= 0xffffffffull)
         return make_error(FSGPU_ERR_INVALID_CONFIG, "row ids must fit in u32 (VectorHit.index)");
@@ -169,7 +169,8 @@ SearchError VectorIndex::init_host(int device, uint32_t dim, uint64_t nrows, con
     dim_ = dim;
     nrows_ = nrows;
     row_base_ = row_base;
-    const size_t bytes = (size_t)nrows * dim * 2;
+    f32_ = f32_rows;
+    const size_t bytes = (size_t)nrows * dim * (f32_rows ? 4 : 2);
     FSGPU_TRY(slab_own_.reserve(bytes));
     if (bytes) FSGPU_HIP(hipMemcpy(slab_own_.ptr, slab, bytes, hipMemcpyHostToDevice));
     slab_dev_ = slab_own_.ptr;
@@ -215,7 +216,8 @@ SearchError VectorIndex::set_live_bitmap(const uint64_t* live) {
 // order; everything else is host bookkeeping.
 SearchError write_fsvi_v1(const char* path, const char* embedder_id, const char* embedder_revision, uint32_t dim, uint64_t n,
                           const char* const* doc_ids, const uint32_t* doc_id_lens, const float* vectors,
-                          uint8_t compaction_gen, int device) {
+                          uint8_t compaction_gen, int device, uint8_t quantization) {
+    if (quantization > 1) return make_error(FSGPU_ERR_INVALID_CONFIG, "quantization must be 0 (F32) or 1 (F16)");
     if (!path || !embedder_id || !embedder_revision || (n && (!doc_ids || !vectors)))
         return make_error(FSGPU_ERR_NULL_ARGUMENT, "null argument");
     if (dim == 0) return make_error(FSGPU_ERR_INVALID_CONFIG, "dimension must be greater than zero");
@@ -254,7 +256,7 @@ SearchError write_fsvi_v1(const char* path, const char* embedder_id, const char*
     const size_t header_len = 4 + 2 + 2 + idl + 2 + rvl + 4 + 1 + 3 + 8 + 8 + 4;
     const uint64_t pre = (uint64_t)header_len + n * 16 + strings_len;
     const uint64_t vectors_offset = (pre + 63) / 64 * 64;
-    const size_t slab_bytes = (size_t)n * dim * 2;
+    const size_t slab_bytes = (size_t)n * dim * (quantization == 1 ? 2 : 4);
     std::vector<uint8_t> buf((size_t)vectors_offset + slab_bytes, 0);
     auto put = [&](size_t at, uint64_t v, int bytes) {
         for (int b = 0; b < bytes; ++b) buf[at + b] = (uint8_t)(v >> (8 * b));
@@ -274,7 +276,7 @@ SearchError write_fsvi_v1(const char* path, const char* embedder_id, const char*
     c += rvl;
     put(c, dim, 4);
     c += 4;
-    buf[c++] = 1;  // Quantization::F16 (lib.rs:203-208)
+    buf[c++] = quantization;  // Quantization::{F32 = 0, F16 = 1} (lib.rs:203-208)
     buf[c++] = compaction_gen;
     put(c, 0, 2);  // publication nonce
     c += 2;
@@ -297,7 +299,11 @@ SearchError write_fsvi_v1(const char* path, const char* embedder_id, const char*
         str_off += r.len;
         perm[(size_t)i] = (uint32_t)r.seq;
     }
-    if (n) {
+    if (n && quantization == 0) {
+        // Quantization::F32: the rows as they are, little-endian (write_vector_slab, lib.rs:6017-6024), in sorted order
+        for (uint64_t i = 0; i < n; ++i)
+            std::memcpy(buf.data() + vectors_offset + (size_t)i * dim * 4, vectors + (size_t)perm[(size_t)i] * dim, (size_t)dim * 4);
+    } else if (n) {
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
             return make_error(FSGPU_ERR_NO_DEVICE, "no HIP device visible (libfsgpu has no CPU fallback)");
@@ -381,12 +387,11 @@ SearchError VectorIndex::open_fsvi(const char* path, int device) {
     const uint32_t want_crc = read_le<uint32_t>(&data[c]);
     if (crc32_ieee(data.data(), c) != want_crc) return corrupt("header CRC mismatch");
     c += 4;
-    if (quant != 1)
-        return make_error(FSGPU_ERR_INVALID_CONFIG, "only Quantization::F16 slabs are accelerated (found F32)");
+    const uint64_t elem = quant == 1 ? 2 : 4;  // Quantization::{F32 = 0, F16 = 1} (lib.rs:203-208)
     const size_t records_offset = c;
     const uint64_t strings_offset = records_offset + record_count * 16;
     if (strings_offset > vectors_offset || vectors_offset % 64 != 0 ||
-        vectors_offset + record_count * dim * 2 > data.size())
+        vectors_offset + record_count * dim * elem > data.size())
         return corrupt("record table / vector slab out of bounds");
 
     std::vector<uint64_t> live((size_t)((record_count + 63) / 64), 0);
@@ -404,7 +409,7 @@ SearchError VectorIndex::open_fsvi(const char* path, int device) {
         if ((flags & 0x0001u) == 0) live[(size_t)(r >> 6)] |= 1ull << (r & 63);
     }
     doc_offsets_[(size_t)record_count] = doc_blob_.size();
-    return init_host(device, dim, record_count, data.data() + vectors_offset, live.data(), 0);
+    return init_host(device, dim, record_count, data.data() + vectors_offset, live.data(), 0, quant == 0);
 }
 
 SearchError VectorIndex::doc_id_at(uint32_t row, const char** ptr, uint32_t* len) const {
@@ -651,7 +656,7 @@ ScanArgs VectorIndex::base_args(const float* queries_dev, const uint64_t* allow_
     a.k = 0;
     a.row_base = (uint32_t)row_base_;
     a.hreduce = hreduce;
-    a.row_stride = row_stride_ ? row_stride_ : dim_ * 2;
+    a.row_stride = row_stride_ ? row_stride_ : dim_ * (f32_ ? 4 : 2);
     return a;
 }
 
@@ -725,6 +730,10 @@ SearchError VectorIndex::fused_search(const float* queries_dev, uint32_t nq, uin
 
 // Large-k / collect-all (search.rs:449-473) and dims that are not a multiple of 8: score every row,
 // radix-sort the integer sortkeys, re-score the winners for their exact f32 bits (keeps NaN scores).
+hipError_t VectorIndex::gather_dot_any(const ScanArgs& a, const uint32_t* rows, uint32_t n, float* out, hipStream_t stream) const {
+    return f32_ ? launch_gather_dot_f32(a, rows, n, out, stream) : launch_gather_dot(a, rows, n, out, stream);
+}
+
 SearchError VectorIndex::general_search(const float* queries_dev, uint32_t nq, uint32_t k_out, uint32_t k_eff,
                                         const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
                                         uint32_t* out_counts_dev, hipStream_t stream) {
@@ -744,14 +753,15 @@ SearchError VectorIndex::general_search(const float* queries_dev, uint32_t nq, u
         ScanArgs a = base_args(queries_dev, allow_dev);
         u64* keys_a = static_cast<u64*>(ws_keys_a_.ptr);
         u64* keys_b = static_cast<u64*>(ws_keys_b_.ptr);
-        FSGPU_HIP(launch_score_rows(a, keys_a, (int)q, grid, stream));
+        if (f32_) FSGPU_HIP(launch_score_rows_f32(a, keys_a, (int)q, stream));
+        else FSGPU_HIP(launch_score_rows(a, keys_a, (int)q, grid, stream));
         FSGPU_HIP(launch_packed_to_sortkey(keys_a, n, stream));
         FSGPU_HIP(sort_keys_desc(ws_sort_tmp_.ptr, ws_sort_tmp_.bytes, keys_a, keys_b, n, stream));
         uint32_t* rows_q = out_rows_dev + (size_t)q * k_out;
         FSGPU_HIP(launch_sorted_keys_to_rows(keys_b, k_eff, rows_q, out_counts_dev + q, stream));
         ScanArgs g = base_args(queries_dev + (size_t)q * dim_, nullptr);
         // rows beyond the count are 0xffffffff -> outside the shard -> left as padding
-        FSGPU_HIP(launch_gather_dot(g, rows_q, k_eff, out_scores_dev + (size_t)q * k_out, stream));
+        FSGPU_HIP(gather_dot_any(g, rows_q, k_eff, out_scores_dev + (size_t)q * k_out, stream));
     }
     return ok();
 }
@@ -772,7 +782,7 @@ SearchError VectorIndex::gather_search(const float* queries_dev, uint32_t nq, ui
     FSGPU_HIP(hipMemsetAsync(out_scores_dev, 0xff, (size_t)nq * k * 4, stream));
     for (uint32_t q = 0; q < nq; ++q) {
         ScanArgs g = base_args(queries_dev + (size_t)q * dim_, nullptr);
-        FSGPU_HIP(launch_gather_dot(g, rows_dev, n, scores, stream));
+        FSGPU_HIP(gather_dot_any(g, rows_dev, n, scores, stream));
         FSGPU_HIP(launch_pack_hits(rows_dev, scores, n, packed, stream));
         if (n <= 8192 && k_eff <= 256) {
             MergeArgs m;
@@ -799,7 +809,7 @@ SearchError VectorIndex::gather_search(const float* queries_dev, uint32_t nq, ui
             FSGPU_HIP(sort_keys_desc(ws_sort_tmp_.ptr, ws_sort_tmp_.bytes, packed, keys_b, n, stream));
             uint32_t* rows_q = out_rows_dev + (size_t)q * k;
             FSGPU_HIP(launch_sorted_keys_to_rows(keys_b, k_eff, rows_q, out_counts_dev + q, stream));
-            FSGPU_HIP(launch_gather_dot(g, rows_q, k_eff, out_scores_dev + (size_t)q * k, stream));
+            FSGPU_HIP(gather_dot_any(g, rows_q, k_eff, out_scores_dev + (size_t)q * k, stream));
         }
     }
     return ok();
@@ -816,7 +826,7 @@ SearchError VectorIndex::search_top_k_device(const float* queries_dev, uint32_t 
         return ok();
     }
     const uint32_t k_eff = (uint64_t)k < nrows_ ? k : (uint32_t)nrows_;
-    if (dim_ % 8 == 0 && k_eff <= 256)
+    if (!f32_ && dim_ % 8 == 0 && k_eff <= 256)
         return fused_search(queries_dev, nq, k, k_eff, allow_dev, out_rows_dev, out_scores_dev, out_counts_dev, nullptr,
                             stream);
     return general_search(queries_dev, nq, k, k_eff, allow_dev, out_rows_dev, out_scores_dev, out_counts_dev, stream);
@@ -928,8 +938,8 @@ SearchError VectorIndex::gather_dot(const float* query, uint32_t query_len, cons
     FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, query, (size_t)dim_ * 4, hipMemcpyHostToDevice, stream_));
     FSGPU_HIP(hipMemcpyAsync(ws_gather_rows_.ptr, rows, (size_t)n * 4, hipMemcpyHostToDevice, stream_));
     ScanArgs a = base_args(static_cast<const float*>(ws_queries_.ptr), nullptr);
-    FSGPU_HIP(launch_gather_dot(a, static_cast<const uint32_t*>(ws_gather_rows_.ptr), n,
-                                static_cast<float*>(ws_gather_out_.ptr), stream_));
+    FSGPU_HIP(gather_dot_any(a, static_cast<const uint32_t*>(ws_gather_rows_.ptr), n,
+                             static_cast<float*>(ws_gather_out_.ptr), stream_));
     FSGPU_HIP(hipMemcpyAsync(out, ws_gather_out_.ptr, (size_t)n * 4, hipMemcpyDeviceToHost, stream_));
     FSGPU_HIP(hipStreamSynchronize(stream_));
     return ok();
@@ -999,7 +1009,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     cc64 = std::max<uint64_t>(cc64, std::min<uint64_t>(k, nrows_));
     const uint32_t ksel = i8 ? (uint32_t)std::min<uint64_t>(cc64, 0xffffffffull) : k;  // rank that anchors the selections
     const bool usable = scan_mfma_supported((int)dim_) && k >= 1 && k <= 64 && ksel <= kSelectMaxK && nrows_ >= 4 * (uint64_t)RA && variant != 4 &&
-                        (!row_stride_ || row_stride_ == dim_ * 2);
+                        !f32_ && (!row_stride_ || row_stride_ == dim_ * 2);
     if (!usable && i8) {
         // per-query int8 two-pass through host staging (rare shapes: huge candidate counts, tiny or odd-dimension slabs)
         std::vector<float> q((size_t)nq * dim_), sc((size_t)nq * k);
@@ -1384,7 +1394,8 @@ VectorIndex* VectorIndex::mrl_view(uint32_t dims) {
     if (it == views_.end()) {
         auto v = std::make_unique<VectorIndex>();
         if (!v->init_device(device_, dims, nrows_, slab_dev_, live_dev_, row_base_).ok()) return nullptr;
-        v->row_stride_ = dim_ * 2;
+        v->row_stride_ = dim_ * (f32_ ? 4 : 2);
+        v->f32_ = f32_;
         it = views_.emplace(dims, std::move(v)).first;
     }
     VectorIndex* v = it->second.get();
@@ -1517,7 +1528,7 @@ SearchError VectorIndex::quantized_two_pass(const float* query, uint32_t query_l
                                             int bits, uint32_t* out_rows, float* out_scores, uint32_t* out_count) {
     *out_count = 0;
     // anything the fast path does not cover goes through the exact search (search.rs:579-585)
-    if (k == 0 || nrows_ == 0 || !wal_.empty()) {
+    if (k == 0 || nrows_ == 0 || !wal_.empty() || f32_) {  // ... || quantization != F16
         if (has_doc_ids()) return search_hits(query, query_len, k, out_rows, out_scores, out_count);
         FSGPU_TRY(ensure_query_dimension(query_len));
         if (k == 0 || nrows_ == 0) return ok();
@@ -1796,10 +1807,10 @@ SearchError VectorIndex::search_top_k_packed_device(const float* queries_dev, ui
         return e;
     }
     if (nq == 0 || k == 0) return SearchError{};
-    if (dim_ % 8 != 0 || k > 256) {
+    if (dim_ % 8 != 0 || k > 256 || f32_) {
         SearchError e;
         e.code = FSGPU_ERR_INVALID_CONFIG;
-        e.detail = "packed shard search supports k <= 256 and dim % 8 == 0";
+        e.detail = "packed shard search supports F16 slabs, k <= 256 and dim % 8 == 0";
         return e;
     }
     if (hipSetDevice(device_) != hipSuccess) {

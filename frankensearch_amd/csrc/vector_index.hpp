@@ -34,7 +34,7 @@ struct DeviceBuffer {
 // VectorIndexWriter for FSVI v1 (lib.rs:3637-3672, 3752-3943): validate, stable-sort by (FNV-1a(doc_id), doc_id), write.
 SearchError write_fsvi_v1(const char* path, const char* embedder_id, const char* embedder_revision, uint32_t dim, uint64_t n,
                           const char* const* doc_ids, const uint32_t* doc_id_lens, const float* vectors,
-                          uint8_t compaction_gen, int device);
+                          uint8_t compaction_gen, int device, uint8_t quantization = 1);
 
 class VectorIndex {
   public:
@@ -44,8 +44,10 @@ class VectorIndex {
     VectorIndex& operator=(const VectorIndex&) = delete;
 
     // VectorIndex::open for a raw slab (host copy) / an adopted device slab / an FSVI v1 file.
+    // f32_rows: the slab holds raw little-endian f32 rows (Quantization::F32) instead of f16
     SearchError init_host(int device, uint32_t dim, uint64_t nrows, const void* slab, const uint64_t* live,
-                          uint64_t row_base);
+                          uint64_t row_base, bool f32_rows = false);
+    bool f32_rows() const { return f32_; }
     SearchError init_device(int device, uint32_t dim, uint64_t nrows, const void* slab_dev, const uint64_t* live_dev,
                             uint64_t row_base);
     SearchError open_fsvi(const char* path, int device);
@@ -137,6 +139,7 @@ class VectorIndex {
     SearchError fused_search(const float* queries_dev, uint32_t nq, uint32_t k_out, uint32_t k_eff,
                              const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
                              uint32_t* out_counts_dev, u64* out_packed_dev, hipStream_t stream);
+    hipError_t gather_dot_any(const ScanArgs& a, const uint32_t* rows, uint32_t n, float* out, hipStream_t stream) const;
     SearchError gather_search(const float* queries_dev, uint32_t nq, uint32_t k, const uint32_t* rows_dev, uint32_t n,
                               uint32_t* out_rows_dev, float* out_scores_dev, uint32_t* out_counts_dev, hipStream_t stream);
     SearchError general_search(const float* queries_dev, uint32_t nq, uint32_t k_out, uint32_t k_eff,
@@ -155,6 +158,7 @@ class VectorIndex {
     const void* slab_dev_ = nullptr;
     const uint64_t* live_dev_ = nullptr;
     bool owns_slab_ = false;
+    bool f32_ = false;  // Quantization::F32 slab: served by the general path (f32_kernels.hip)
     DeviceBuffer slab_own_, live_own_;
     hipStream_t stream_ = nullptr;
     // workspaces (grown on demand, reused)

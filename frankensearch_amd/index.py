@@ -323,8 +323,9 @@ class VectorIndex:
 
 
 def write_fsvi(path: str, rows, embedder_id: str = "test", embedder_revision: str = "", compaction_gen: int = 0,
-               device: int = 0) -> None:
-    """VectorIndexWriter (lib.rs:3637-3672, 3752-3943): rows = [(doc_id, vector), ...] -> FSVI v1 file."""
+               device: int = 0, quantization: int = 1) -> None:
+    """VectorIndexWriter (lib.rs:3637-3672, 3752-3943): rows = [(doc_id, vector), ...] -> FSVI v1 file
+    (quantization 1 = F16, the default; 0 = F32)."""
     rows = list(rows)
     n = len(rows)
     dim = len(rows[0][1]) if n else 1
@@ -332,9 +333,9 @@ def write_fsvi(path: str, rows, embedder_id: str = "test", embedder_revision: st
     vec = np.ascontiguousarray([v for _, v in rows], dtype=np.float32).reshape(n, dim) if n else np.zeros((0, dim), np.float32)
     arr = (C.c_char_p * max(n, 1))(*ids)
     lens = np.array([len(b) for b in ids], dtype=np.uint32)
-    check(_lib.lib().fsgpu_fsvi_write(path.encode(), embedder_id.encode(), embedder_revision.encode(), dim, n,
-                                      C.cast(arr, C.c_void_p), _ptr(lens) if n else None, _ptr(vec) if n else None,
-                                      compaction_gen, device))
+    check(_lib.lib().fsgpu_fsvi_write_quant(path.encode(), embedder_id.encode(), embedder_revision.encode(), dim, n,
+                                            C.cast(arr, C.c_void_p), _ptr(lens) if n else None, _ptr(vec) if n else None,
+                                            compaction_gen, device, quantization))
 
 
 def encode_f32_to_f16(src: np.ndarray, device: int = 0) -> np.ndarray:

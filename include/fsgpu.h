@@ -218,6 +218,13 @@ fsgpu_status fsgpu_fsvi_write(const char *path, const char *embedder_id, const c
                               uint64_t n, const char *const *doc_ids, const uint32_t *doc_id_lens, const float *vectors,
                               uint8_t compaction_gen, int32_t device);
 
+/* The same writer for either Quantization (lib.rs:203-208): quantization 1 = F16 (as above), 0 = F32 (rows stored as raw
+ * little-endian f32, write_vector_slab lib.rs:6017-6024).  F32 files open and search like F16 ones (dot_product_f32_bytes_f32,
+ * simd.rs:581-702), through the general path only: F16 is the reference's default and the accelerated format. */
+fsgpu_status fsgpu_fsvi_write_quant(const char *path, const char *embedder_id, const char *embedder_revision, uint32_t dim,
+                                    uint64_t n, const char *const *doc_ids, const uint32_t *doc_id_lens,
+                                    const float *vectors, uint8_t compaction_gen, int32_t device, uint8_t quantization);
+
 /* encode_f32_to_f16_extend (simd.rs:2245-2305): f32 -> f16 round-to-nearest-even on the GPU. */
 fsgpu_status fsgpu_encode_f32_to_f16(int32_t device, const float *src, uint64_t n, uint16_t *dst);
 /* f16 -> f32 widen (simd.rs:63-94), exposed for the exhaustive 65,536-pattern parity test. */

@@ -162,6 +162,41 @@ float fso_dot_f16_f32(const uint8_t *row, const float *q, size_t dim, int hreduc
     return result;
 }
 
+/* dot_product_f32_bytes_f32 (crates/frankensearch-index/src/simd.rs:581-702): rows of a Quantization::F32 slab.
+ * Four 8-lane accumulators over groups of 32 elements (separate multiply and add), (acc0+acc1)+(acc2+acc3), the
+ * leftover 8-element chunks added to that SUM (not to acc0 as in the f16 kernel), reduce_add, fused scalar tail. */
+float fso_dot_f32_bytes_f32(const uint8_t *row, const float *q, size_t dim, int hreduce) {
+    size_t groups = dim / 32, chunks = dim / 8;
+    float acc[4][8];
+    memset(acc, 0, sizeof acc);
+    for (size_t g = 0; g < groups; ++g)
+        for (int x = 0; x < 4; ++x)
+            for (int j = 0; j < 8; ++j) {
+                size_t o = g * 32 + (size_t)x * 8 + (size_t)j;
+                float w;
+                memcpy(&w, row + 4 * o, 4); /* f32::from_le_bytes on a little-endian host */
+                float p = w * q[o];
+                acc[x][j] = acc[x][j] + p;
+            }
+    float sum[8];
+    for (int j = 0; j < 8; ++j) sum[j] = (acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j]);
+    for (size_t c = groups * 4; c < chunks; ++c)
+        for (int j = 0; j < 8; ++j) {
+            size_t o = c * 8 + (size_t)j;
+            float w;
+            memcpy(&w, row + 4 * o, 4);
+            float p = w * q[o];
+            sum[j] = sum[j] + p;
+        }
+    float result = hreduce8(sum, hreduce);
+    for (size_t i = chunks * 8; i < dim; ++i) {
+        float w;
+        memcpy(&w, row + 4 * i, 4);
+        result = fmaf(w, q[i], result);
+    }
+    return result;
+}
+
 /* dot_product_f32_f32 (crates/frankensearch-index/src/simd.rs:134-222). */
 float fso_dot_f32_f32(const float *a, const float *b, size_t n, int hreduce) {
     size_t groups = n / 32, chunks = n / 8;
@@ -320,10 +355,9 @@ static inline int row_live(const uint64_t *live, uint64_t row) {
 typedef float (*dot_fn)(const uint8_t *, const float *, size_t, int);
 
 /* scan_range_chunk (search.rs:1257-1327), F16 arm, including the `>= cutoff` fast path. */
-static void scan_range_chunk(const uint8_t *slab, uint32_t dim, const uint64_t *live, uint64_t start,
+static void scan_range_chunk(const uint8_t *slab, uint32_t dim, size_t stride, const uint64_t *live, uint64_t start,
                              uint64_t end, const float *q, size_t limit, int hreduce, dot_fn dot,
                              heap_t *heap) {
-    size_t stride = (size_t)dim * 2;
     float cutoff = -INFINITY;
     for (uint64_t index = start; index < end; ++index) {
         if (!row_live(live, index)) continue;
@@ -339,6 +373,7 @@ static void scan_range_chunk(const uint8_t *slab, uint32_t dim, const uint64_t *
 typedef struct {
     const uint8_t *slab;
     uint32_t dim;
+    size_t stride;       /* bytes per row: dim * 2 (F16) or dim * 4 (F32) */
     const uint64_t *live;
     uint64_t nrows;
     const float *q;
@@ -358,7 +393,7 @@ static void scan_worker_body(scan_job_t *job) {
         uint64_t end = start + job->chunk_size;
         if (end > job->nrows) end = job->nrows;
         if (job->collect) {
-            size_t stride = (size_t)job->dim * 2;
+            size_t stride = job->stride;
             for (uint64_t r = start; r < end; ++r) {
                 if (!row_live(job->live, r)) {
                     job->collect[r].row = UINT64_MAX;
@@ -370,7 +405,7 @@ static void scan_worker_body(scan_job_t *job) {
         } else {
             size_t cap = job->limit < (size_t)(end - start) ? job->limit : (size_t)(end - start);
             heap_init(&job->heaps[c], cap + 1);
-            scan_range_chunk(job->slab, job->dim, job->live, start, end, job->q, job->limit,
+            scan_range_chunk(job->slab, job->dim, job->stride, job->live, start, end, job->q, job->limit,
                              job->hreduce, job->dot, &job->heaps[c]);
         }
     }
@@ -439,19 +474,41 @@ static void run_job(scan_job_t *job, int nthreads) {
 
 /* search_top_k_internal (search.rs:426-494) for a main index with no WAL and no filter,
  * scan_parallel (:1013-1036), merge_partial_heaps (:1704-1720), resolve_hits sort (:1493-1501). */
+static size_t search_top_k_impl(const uint8_t *slab, size_t stride, dot_fn dot, uint64_t nrows, uint32_t dim,
+                                const uint64_t *live, const float *q, size_t k, size_t parallel_threshold,
+                                size_t chunk_size, int parallel_enabled, int nthreads, int hreduce,
+                                uint32_t *out_rows, float *out_scores);
+
 size_t fso_search_top_k(const uint8_t *slab, uint64_t nrows, uint32_t dim, const uint64_t *live,
                         const float *q, size_t k, size_t parallel_threshold, size_t chunk_size,
                         int parallel_enabled, int nthreads, int hreduce, uint32_t *out_rows,
                         float *out_scores) {
+    dot_fn dot = fso_has_avx2_f16c() ? fso_dot_f16_f32_fast : fso_dot_f16_f32;
+    return search_top_k_impl(slab, (size_t)dim * 2, dot, nrows, dim, live, q, k, parallel_threshold, chunk_size,
+                             parallel_enabled, nthreads, hreduce, out_rows, out_scores);
+}
+
+/* The same search over a Quantization::F32 slab (scan_range_chunk's F32 arm, search.rs:1293-1325). */
+size_t fso_search_top_k_f32(const uint8_t *slab, uint64_t nrows, uint32_t dim, const uint64_t *live,
+                            const float *q, size_t k, int nthreads, int hreduce, uint32_t *out_rows,
+                            float *out_scores) {
+    return search_top_k_impl(slab, (size_t)dim * 4, fso_dot_f32_bytes_f32, nrows, dim, live, q, k, 10000, 1024, 1,
+                             nthreads, hreduce, out_rows, out_scores);
+}
+
+static size_t search_top_k_impl(const uint8_t *slab, size_t stride, dot_fn dot, uint64_t nrows, uint32_t dim,
+                                const uint64_t *live, const float *q, size_t k, size_t parallel_threshold,
+                                size_t chunk_size, int parallel_enabled, int nthreads, int hreduce,
+                                uint32_t *out_rows, float *out_scores) {
     if (k == 0 || nrows == 0) return 0;
     if (chunk_size == 0) chunk_size = 1;
     int use_parallel = parallel_enabled && nrows >= parallel_threshold;
-    dot_fn dot = fso_has_avx2_f16c() ? fso_dot_f16_f32_fast : fso_dot_f16_f32;
 
     scan_job_t job;
     memset(&job, 0, sizeof job);
     job.slab = slab;
     job.dim = dim;
+    job.stride = stride;
     job.live = live;
     job.nrows = nrows;
     job.q = q;
@@ -911,7 +968,15 @@ static uint64_t get64(const uint8_t *p) { return (uint64_t)get32(p) | ((uint64_t
 int fso_fsvi_write(const char *path, const char *embedder_id, const char *embedder_revision,
                    uint32_t dim, uint64_t n, const char *const *doc_ids, const float *vectors,
                    uint8_t compaction_gen) {
-    if (dim == 0) return FSO_ERR_INVALID_CONFIG;
+    return fso_fsvi_write_quant(path, embedder_id, embedder_revision, dim, n, doc_ids, vectors, compaction_gen, 1);
+}
+
+/* quantization: 1 = F16 (the default), 0 = F32 (raw little-endian f32 rows, write_vector_slab lib.rs:6017-6024). */
+int fso_fsvi_write_quant(const char *path, const char *embedder_id, const char *embedder_revision,
+                         uint32_t dim, uint64_t n, const char *const *doc_ids, const float *vectors,
+                         uint8_t compaction_gen, uint8_t quantization) {
+    if (dim == 0 || quantization > 1) return FSO_ERR_INVALID_CONFIG;
+    const size_t elem = quantization == 1 ? 2 : 4;
     pending_t *recs = (pending_t *)malloc(sizeof(pending_t) * (size_t)(n ? n : 1));
     size_t strings_len = 0;
     for (uint64_t i = 0; i < n; ++i) {
@@ -944,7 +1009,7 @@ int fso_fsvi_write(const char *path, const char *embedder_id, const char *embedd
     size_t records_bytes = (size_t)n * 16;
     uint64_t pre = (uint64_t)header_len + records_bytes + strings_len;
     uint64_t vectors_offset = fso_align_up(pre, 64);
-    size_t total = (size_t)vectors_offset + (size_t)n * dim * 2;
+    size_t total = (size_t)vectors_offset + (size_t)n * dim * elem;
     uint8_t *buf = (uint8_t *)calloc(total ? total : 1, 1);
 
     size_t c = 0;
@@ -962,7 +1027,7 @@ int fso_fsvi_write(const char *path, const char *embedder_id, const char *embedd
     c += rvl;
     put32(buf + c, dim);
     c += 4;
-    buf[c++] = 1; /* Quantization::F16 (lib.rs:203-208) */
+    buf[c++] = quantization; /* Quantization::{F32 = 0, F16 = 1} (lib.rs:203-208) */
     buf[c++] = compaction_gen;
     put16(buf + c, 0); /* publication nonce */
     c += 2;
@@ -986,7 +1051,10 @@ int fso_fsvi_write(const char *path, const char *embedder_id, const char *embedd
     }
     uint8_t *slab = buf + vectors_offset;
     for (uint64_t i = 0; i < n; ++i)
-        for (uint32_t d = 0; d < dim; ++d) put16(slab + ((size_t)i * dim + d) * 2, fso_f32_to_f16(recs[i].vec[d]));
+        for (uint32_t d = 0; d < dim; ++d) {
+            if (quantization == 1) put16(slab + ((size_t)i * dim + d) * 2, fso_f32_to_f16(recs[i].vec[d]));
+            else memcpy(slab + ((size_t)i * dim + d) * 4, &recs[i].vec[d], 4); /* to_le_bytes, little-endian host */
+        }
     free(recs);
 
     FILE *f = fopen(path, "wb");
@@ -1162,6 +1230,7 @@ int fso_fsvi_append(fso_fsvi *idx, const char *doc_id, const float *vector, size
     }
     return FSO_OK;
 }
+uint8_t fso_fsvi_quantization(const fso_fsvi *idx) { return idx->quant; }
 uint64_t fso_fsvi_record_count(const fso_fsvi *idx) { return idx->record_count; }
 uint32_t fso_fsvi_dimension(const fso_fsvi *idx) { return idx->dim; }
 uint64_t fso_fsvi_vectors_offset(const fso_fsvi *idx) { return idx->vectors_offset; }
@@ -1186,7 +1255,7 @@ void fso_fsvi_set_flags(fso_fsvi *idx, uint64_t row, uint16_t flags) {
 size_t fso_fsvi_search(const fso_fsvi *idx, const float *q, size_t k, int hreduce,
                        uint32_t *out_rows, float *out_scores) {
     uint64_t n = idx->record_count;
-    if (k == 0 || (n == 0 && idx->wal_len == 0) || idx->quant != 1) return 0;
+    if (k == 0 || (n == 0 && idx->wal_len == 0)) return 0;
     uint64_t words = (n + 63) / 64;
     uint64_t *live = (uint64_t *)calloc((size_t)(words ? words : 1), 8);
     for (uint64_t r = 0; r < n; ++r)
@@ -1198,8 +1267,10 @@ size_t fso_fsvi_search(const fso_fsvi *idx, const float *q, size_t k, int hreduc
         size_t kk = k < n ? k : (size_t)n;
         uint32_t *rows = (uint32_t *)malloc(sizeof(uint32_t) * kk);
         float *scores = (float *)malloc(sizeof(float) * kk);
-        size_t got = fso_search_top_k(fso_fsvi_slab(idx), n, idx->dim, live, q, k, 10000, 1024, 1, 1, hreduce,
-                                      rows, scores);
+        size_t got = idx->quant == 1 ? fso_search_top_k(fso_fsvi_slab(idx), n, idx->dim, live, q, k, 10000, 1024, 1, 1,
+                                                        hreduce, rows, scores)
+                                     : fso_search_top_k_f32(fso_fsvi_slab(idx), n, idx->dim, live, q, k, 1, hreduce, rows,
+                                                            scores);
         for (size_t i = 0; i < got; ++i) {
             cand[nc].row = rows[i];
             cand[nc].score = scores[i];

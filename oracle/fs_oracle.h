@@ -75,6 +75,12 @@ size_t fso_search_top_k(const uint8_t *slab, uint64_t nrows, uint32_t dim, const
                         int parallel_enabled, int nthreads, int hreduce, uint32_t *out_rows,
                         float *out_scores);
 
+/* dot_product_f32_bytes_f32 (simd.rs:581-702) and the scan over a Quantization::F32 slab. */
+float fso_dot_f32_bytes_f32(const uint8_t *row, const float *q, size_t dim, int hreduce);
+size_t fso_search_top_k_f32(const uint8_t *slab, uint64_t nrows, uint32_t dim, const uint64_t *live,
+                            const float *q, size_t k, int nthreads, int hreduce, uint32_t *out_rows,
+                            float *out_scores);
+
 /* search_top_k_classified's input validation (search.rs:227-261):
  * returns FSO_OK, FSO_ERR_DIMENSION_MISMATCH or FSO_ERR_INVALID_CONFIG;
  * *zero_signal: 0 none, 1 CallerRequestedZeroK, 2 ZeroNormQuery. */
@@ -115,6 +121,10 @@ typedef struct fso_fsvi fso_fsvi;
 int fso_fsvi_write(const char *path, const char *embedder_id, const char *embedder_revision,
                    uint32_t dim, uint64_t n, const char *const *doc_ids, const float *vectors,
                    uint8_t compaction_gen);
+int fso_fsvi_write_quant(const char *path, const char *embedder_id, const char *embedder_revision,
+                         uint32_t dim, uint64_t n, const char *const *doc_ids, const float *vectors,
+                         uint8_t compaction_gen, uint8_t quantization /* 1 = F16, 0 = F32 */);
+uint8_t fso_fsvi_quantization(const fso_fsvi *idx);
 int fso_fsvi_open(const char *path, fso_fsvi **out);
 void fso_fsvi_close(fso_fsvi *idx);
 uint64_t fso_fsvi_record_count(const fso_fsvi *idx);

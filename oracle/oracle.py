@@ -358,16 +358,55 @@ def l2_normalize(v: np.ndarray) -> np.ndarray:
 
 
 # ---- FSVI ----
-def fsvi_write(path: str, rows, embedder_id: str = "hash", revision: str = "test", compaction_gen: int = 1) -> int:
-    """rows: list of (doc_id, vector) like the reference test helper write_index (search.rs:1784-1799)."""
+def fsvi_write(path: str, rows, embedder_id: str = "hash", revision: str = "test", compaction_gen: int = 1,
+               quantization: int = 1) -> int:
+    """rows: list of (doc_id, vector) like the reference test helper write_index (search.rs:1784-1799);
+    quantization 1 = F16 (default), 0 = F32."""
     n = len(rows)
     dim = len(rows[0][1]) if n else 0
     if n == 0:
         return ERR_INVALID_CONFIG
     ids = (C.c_char_p * n)(*[r[0].encode() for r in rows])
     vecs = np.ascontiguousarray(np.array([r[1] for r in rows], dtype=np.float32))
-    return lib().fso_fsvi_write(path.encode(), embedder_id.encode(), revision.encode(), dim, n, ids, _p(vecs),
-                                compaction_gen)
+    L = lib()
+    L.fso_fsvi_write_quant.restype = C.c_int
+    L.fso_fsvi_write_quant.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint64,
+                                       C.POINTER(C.c_char_p), C.c_void_p, C.c_uint8, C.c_uint8]
+    return L.fso_fsvi_write_quant(path.encode(), embedder_id.encode(), revision.encode(), dim, n, ids, _p(vecs),
+                                  compaction_gen, quantization)
+
+
+def dot_f32_bytes_f32(row_f32: np.ndarray, q: np.ndarray, hreduce: int = HREDUCE_SSE2) -> float:
+    """dot_product_f32_bytes_f32 (simd.rs:581-702) of one Quantization::F32 row."""
+    row = np.ascontiguousarray(row_f32, dtype="<f4")
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    L = lib()
+    L.fso_dot_f32_bytes_f32.restype = C.c_float
+    L.fso_dot_f32_bytes_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    return float(L.fso_dot_f32_bytes_f32(row.ctypes.data, q.ctypes.data, q.size, hreduce))
+
+
+def search_top_k_f32(slab_f32: np.ndarray, q: np.ndarray, k: int, live: np.ndarray | None = None, nthreads: int = 1,
+                     hreduce: int = HREDUCE_SSE2):
+    """search_top_k over a Quantization::F32 slab ([N, dim] float32): (rows, scores) best first."""
+    slab = np.ascontiguousarray(slab_f32, dtype="<f4")
+    n, dim = slab.shape
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    if q.size != dim:
+        raise ValueError(f"DimensionMismatch expected={dim} found={q.size}")
+    cap = max(1, min(k, n))
+    rows = np.empty(cap, dtype=np.uint32)
+    scores = np.empty(cap, dtype=np.float32)
+    bm = None
+    if live is not None:
+        bm = live_bitmap(np.asarray(live, dtype=bool)) if live.dtype != np.uint64 else live
+    L = lib()
+    L.fso_search_top_k_f32.restype = C.c_size_t
+    L.fso_search_top_k_f32.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
+                                       C.c_int, C.c_void_p, C.c_void_p]
+    cnt = L.fso_search_top_k_f32(slab.ctypes.data, n, dim, bm.ctypes.data if bm is not None else None, q.ctypes.data, k,
+                                 nthreads, hreduce, rows.ctypes.data, scores.ctypes.data)
+    return rows[:cnt].copy(), scores[:cnt].copy()
 
 
 class Fsvi:

@@ -751,3 +751,69 @@ def test_candidate_hash_filter_through_the_record_table(fa, oracle, tmp_path):
             assert m == len(er) and np.array_equal(rows[qi, :m], er) and np.array_equal(bits(scores[qi, :m]), bits(es))
     g.close()
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim", [7, 40, 100, 384])
+def test_f32_quantized_fsvi_files_open_and_search_like_the_reference(fa, oracle, tmp_path, dim):
+    # Quantization::F32 (lib.rs:203-208): dot_product_f32_bytes_f32 (simd.rs:581-702) — leftover chunks join the sum
+    # AFTER the accumulators are combined, fused tail; served by the general path.  Writer bytes == the oracle writer's.
+    rng = np.random.default_rng(100 + dim)
+    n = 2500
+    vecs = rng.standard_normal((n, dim)).astype(np.float32)
+    vecs[17] = vecs[11]  # a tie: the lower row wins
+    ids = [f"doc-{i % 2400:05}" for i in range(n)]  # 100 duplicated doc ids
+    rows_in = [(ids[i], vecs[i].tolist()) for i in range(n)]
+    pg, po = str(tmp_path / "g.fsvi"), str(tmp_path / "o.fsvi")
+    fa.write_fsvi(pg, rows_in, "emb", "r1", compaction_gen=1, quantization=0)
+    assert oracle.fsvi_write(po, rows_in, "emb", "r1", quantization=0) == 0
+    assert open(pg, "rb").read() == open(po, "rb").read()
+    o = oracle.Fsvi(po)
+    g = fa.VectorIndex.open(pg)
+    slab = np.frombuffer(open(po, "rb").read()[o.vectors_offset:], dtype="<f4").reshape(n, dim)
+    q = rng.standard_normal((3, dim)).astype(np.float32)
+    for k in (1, 10, 300, n + 5):
+        rows, scores, counts = g.search_batch(q, k)
+        for qi in range(3):
+            er, es = oracle.search_top_k_f32(slab, q[qi], k)
+            m = int(counts[qi])
+            assert m == len(er) and np.array_equal(rows[qi, :m], er) and np.array_equal(bits(scores[qi, :m]), bits(es))
+    # doc-id dedup + tombstones through search_top_k / soft_delete, against the oracle's file search
+    for qi in range(3):
+        oh, os_ = o.search_top_k(q[qi], 20)
+        gh = g.search_top_k(q[qi], 20)
+        assert [(h.index, h.doc_id) for h in gh] == [(h[0], h[2]) for h in oh]
+        assert np.array_equal(bits([h.score for h in gh]), bits(os_))
+    # filters: a selective one (gathered rows) and a broad one (masked scan)
+    for allowed in (20, 1500):
+        allow = np.zeros(n, bool)
+        allow[rng.choice(n, allowed, replace=False)] = True
+        rows, scores, counts = g.search_batch(q[:1], 10, allow=allow)
+        er, es = oracle.search_top_k_f32(slab, q[0], 10, live=allow)
+        assert np.array_equal(rows[0, :counts[0]], er) and np.array_equal(bits(scores[0, :counts[0]]), bits(es))
+    # dot_query_at, the two-pass entry points (the reference falls back to the exact scan for F32, search.rs:579-585)
+    # and the batched entry point all answer with the exact F32 result
+    pick = rng.choice(n, 33, replace=False).astype(np.uint32)
+    want = np.array([oracle.dot_f32_bytes_f32(slab[r], q[0]) for r in pick], np.float32)
+    assert np.array_equal(bits(g.gather_dot(q[0], pick)), bits(want))
+    exact = g.search_top_k(q[1], 10)
+    for hits in (g.search_top_k_int8_two_pass(q[1], 10, 3), g.search_top_k_4bit_two_pass(q[1], 10, 5)):
+        assert [(h.index, h.doc_id) for h in hits] == [(h.index, h.doc_id) for h in exact]
+        assert np.array_equal(bits([h.score for h in hits]), bits([h.score for h in exact]))
+    br, bs, bc, fb = g.search_batched(np.repeat(q, 30, axis=0), 10)
+    for qi in range(3):
+        e_r, e_s = oracle.search_top_k_f32(slab, q[qi], 10)
+        assert np.array_equal(br[qi * 30], e_r) and np.array_equal(bits(bs[qi * 30]), bits(e_s))
+    g.close()
+
+
+@pytest.mark.gpu
+def test_mrl_search_on_an_f32_index(fa, oracle, tmp_path):
+    # mrl.rs:1700-1740 (mrl_search_f32_quantization): 16 dims, scan 8
+    p = str(tmp_path / "m.fsvi")
+    fa.write_fsvi(p, [("doc-a", [1.0] * 16), ("doc-b", [0.5] * 16)], "test", "mrl-test", quantization=0)
+    g = fa.VectorIndex.open(p)
+    hits, stats = g.mrl_search([1.0] * 16, 2, search_dims=8, rescore_dims=0, rescore_top_k=0, with_stats=True)
+    assert [h.doc_id for h in hits] == ["doc-a", "doc-b"]
+    assert stats["scan_dims"] == 8 and not stats["fell_back_to_full"]
+    g.close()

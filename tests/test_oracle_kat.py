@@ -615,3 +615,67 @@ def test_4bit_two_pass_keep_all_equals_exact(oracle):
     ar, as_ = oracle.search_4bit_two_pass(slab, q, 10, 2)
     assert len(ar) == 10 and np.all(np.diff(as_) <= 0)
     assert as_.tolist() == [oracle.dot_f16_f32(slab[r], q) for r in ar]
+
+
+def _f32_bytes_dot_numpy(row, q):
+    """dot_product_f32_bytes_f32 (simd.rs:581-702) step by step in numpy float32 (SSE2 reduce_add order)."""
+    f = np.float32
+    dim = q.size
+    groups, chunks = dim // 32, dim // 8
+    acc = np.zeros((4, 8), f)
+    for g in range(groups):
+        for x in range(4):
+            o = g * 32 + x * 8
+            acc[x] = acc[x] + row[o:o + 8] * q[o:o + 8]  # separate multiply and add in float32
+    s = (acc[0] + acc[1]) + (acc[2] + acc[3])
+    for c in range(groups * 4, chunks):
+        s = s + row[c * 8:c * 8 + 8] * q[c * 8:c * 8 + 8]
+    r = f((f(s[0] + s[2]) + f(s[1] + s[3])) + (f(s[4] + s[6]) + f(s[5] + s[7])))
+    for i in range(chunks * 8, dim):
+        r = f(np.float64(row[i]) * np.float64(q[i]) + np.float64(r))  # fused: one rounding (exact product in f64)
+    return r
+
+
+def test_f32_bytes_dot_order_and_tail(oracle):
+    rng = np.random.default_rng(5)
+    for dim in (1, 3, 7, 8, 9, 16, 31, 32, 33, 40, 63, 64, 100, 256, 384, 390):
+        for _ in range(4):
+            row = rng.standard_normal(dim).astype(np.float32)
+            q = rng.standard_normal(dim).astype(np.float32)
+            got = np.float32(oracle.dot_f32_bytes_f32(row, q))
+            assert got.view(np.uint32) == _f32_bytes_dot_numpy(row, q).view(np.uint32), dim
+    # NaN propagates; leftover chunks join the SUM after the accumulators are combined (unlike the f16 kernel)
+    assert np.isnan(oracle.dot_f32_bytes_f32(np.array([np.nan] + [0.0] * 7, np.float32), np.ones(8, np.float32)))
+
+
+def test_f32_fsvi_round_trip_and_search(oracle, tmp_path):
+    # Quantization::F32 (lib.rs:203-208, write_vector_slab :6017-6024): raw little-endian f32 rows, same header / records
+    rng = np.random.default_rng(6)
+    n, dim = 300, 40
+    vecs = rng.standard_normal((n, dim)).astype(np.float32)
+    ids = [f"doc-{i:04}" for i in range(n)]
+    p = str(tmp_path / "f32.fsvi")
+    assert oracle.fsvi_write(p, [(ids[i], vecs[i].tolist()) for i in range(n)], "emb", "r1", quantization=0) == 0
+    raw = open(p, "rb").read()
+    assert raw[:4] == b"FSVI" and raw[4 + 2 + 2 + 3 + 2 + 2 + 4] == 0  # quantization byte after id/revision/dim
+    o = oracle.Fsvi(p)
+    order = [ids.index(o.doc_id(r)) for r in range(n)]
+    slab = np.frombuffer(raw[o.vectors_offset:], dtype="<f4").reshape(n, dim)
+    assert np.array_equal(slab.view(np.uint32), vecs[order].view(np.uint32))   # bit-for-bit, in (hash, doc_id) order
+    q = rng.standard_normal(dim).astype(np.float32)
+    hits, scores = o.search_top_k(q, 10)
+    rows, sc = oracle.search_top_k_f32(slab, q, 10)
+    assert [h[0] for h in hits] == rows.tolist() and np.array_equal(scores.view(np.uint32), sc.view(np.uint32))
+    want = np.argsort(-(slab.astype(np.float64) @ q.astype(np.float64)), kind="stable")[:10]
+    assert rows.tolist() == want.tolist()
+    assert np.allclose(sc, (slab.astype(np.float64) @ q)[want], atol=1e-5)
+    # ties -> lower row, NaN rows last, tombstones skipped (the same selection rules as the F16 arm)
+    slab2 = slab.copy()
+    slab2[5] = slab2[3]
+    slab2[9, 0] = np.nan
+    live = np.ones(n, bool)
+    live[int(rows[0])] = False
+    r2, s2 = oracle.search_top_k_f32(slab2, q, n, live=live)
+    assert int(rows[0]) not in r2.tolist() and r2[-1] == 9 and len(r2) == n - 1
+    i3, i5 = r2.tolist().index(3), r2.tolist().index(5)
+    assert i5 == i3 + 1
