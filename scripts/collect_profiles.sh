@@ -1,0 +1,43 @@
+#!/bin/bash
+# Regenerates the evidence kept under profiles/<round>/ (run on the GPU box through gpurun; results land in
+# gpurun_out/<round>/ and are copied to profiles/<round>/ afterwards).  Counter passes are separate runs with
+# --pmc only (never combined with trace domains).
+R=${1:-r01}
+OUT=gpurun_out/$R
+mkdir -p $OUT
+export TMPDIR=/tmp
+(lscpu | head -20; echo; cat /sys/fs/cgroup/cpu.max 2>/dev/null; nproc) > $OUT/host_cpu.txt 2>&1
+python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+python bench.py --batch 128 --no-cpu-baseline --no-two-tier 2>/dev/null | tail -1 > $OUT/bench_batched_b128.json
+python bench.py --exact --batch 1 --no-cpu-baseline --no-two-tier 2>/dev/null | tail -1 > $OUT/bench_exact_b1.json
+python bench.py --exact --batch 4 --no-cpu-baseline --no-two-tier 2>/dev/null | tail -1 > $OUT/bench_exact_b4.json
+# per-kernel time of the default bench command
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- \
+    python bench.py --no-cpu-baseline --no-two-tier > $OUT/bench_under_trace.json 2> $OUT/bench_trace.err
+# HBM traffic of the same command (FETCH_SIZE / WRITE_SIZE, separate passes)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- \
+    python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-two-tier > $OUT/bench_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- \
+    python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-two-tier > $OUT/bench_pmc_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_b1 -o bench -- \
+    python bench.py --exact --batch 1 --steps 5 --warmup 2 --no-cpu-baseline --no-two-tier > $OUT/bench_pmc_fetch_b1.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_b4 -o bench -- \
+    python bench.py --exact --batch 4 --steps 5 --warmup 2 --no-cpu-baseline --no-two-tier > $OUT/bench_pmc_fetch_b4.log 2>&1
+for d in pmc_fetch pmc_write pmc_fetch_b1 pmc_fetch_b4; do python scripts/pmc_summary.py $OUT/$d $OUT/$d.json > /dev/null; done
+python - <<PY
+import json
+out = []
+for d in ("pmc_fetch", "pmc_write", "pmc_fetch_b1", "pmc_fetch_b4"):
+    for e in json.load(open("$OUT/%s.json" % d)):
+        if "fsgpu" in e["kernel"]:
+            e["run"] = d
+            out.append(e)
+json.dump(out, open("$OUT/pmc_summary.json", "w"), indent=1)
+PY
+# matrix-core / LDS counters of the scan kernels
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -o bench -- \
+    python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-two-tier > $OUT/bench_pmc_sq.log 2>&1
+python scripts/pmc_summary.py $OUT/pmc_sq $OUT/pmc_sq.json > /dev/null
+# encoders
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/enc_trace -o enc -- python scripts/bench_encoders.py > $OUT/enc.log 2>&1
+ls -R $OUT | head -60
