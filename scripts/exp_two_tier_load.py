@@ -26,7 +26,11 @@ m2v = fa.Model2VecEmbedder(table, device=0)
 bert = fa.NativeEmbedder(random_bert_weights(1, 30522, 384, 6, 1536), device=0)
 native = NativeTwoTierSearcher(fast, quality, m2v, bert, doc_id_mode=1,
                                fast_tier_int8_multiplier=int(os.environ.get("FAST_INT8", "3")))
-for threads, mb, wait in ((1, 0, 0), (1, 128, 1000), (8, 128, 1000), (64, 128, 1000), (256, 128, 1000), (1024, 128, 1000)):
+SWEEP = os.environ.get("SWEEP")
+cases = ((1, 0, 0), (1, 128, 1000), (8, 128, 1000), (64, 128, 1000), (256, 128, 1000), (1024, 128, 1000))
+if SWEEP:  # "threads:batch:wait,..."
+    cases = tuple(tuple(int(x) for x in c.split(":")) for c in SWEEP.split(","))
+for threads, mb, wait in cases:
     fast.set_coalescing(mb, wait)
     quality.set_coalescing(mb, wait)
     m2v.set_coalescing(2 * mb, wait // 2)
