@@ -142,3 +142,29 @@ def test_tombstone_removes_exactly_the_deleted_rows(env):
     keep = [i for i in range(20) if i not in (0, 3, 7)]
     assert r2[0].tolist() == rows[0, keep].tolist()
     assert np.array_equal(bits(s2[0]), bits(scores[0, keep]))
+
+
+def test_ragged_multi_group_rounds_equal_the_per_query_searches(env):
+    # 1,101 queries = one round of eight full 128-query groups + a 77-query tail group; every sample stage and selection of
+    # the round is a single launch over all groups, so group boundaries (per-group offsets of the candidate lists, spill
+    # areas, thresholds) are what this pins — for the f16 path and for the int8 two-pass path
+    torch, idx = env["torch"], env["idx"]
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    q = bench.gen_queries(1101, DIM, env["dev"]).cpu().numpy()
+    rows, scores, counts, fb = idx.search_batched(q, K)
+    assert np.all(counts == K) and fb < 20
+    pick = list(range(0, 1101, 41)) + [127, 128, 255, 256, 1023, 1024, 1100]
+    er, es, _ = idx.search_batch(q[pick], K)
+    assert np.array_equal(rows[pick], er) and np.array_equal(bits(scores[pick]), bits(es))
+    # every answer is sorted, duplicate-free, and its scores are the exact dots of its rows
+    assert np.all(np.diff(scores, axis=1) <= 0)
+    for qi in range(0, 1101, 97):
+        assert len(set(rows[qi].tolist())) == K
+        assert np.array_equal(bits(idx.gather_dot(q[qi], rows[qi])), bits(scores[qi]))
+    r8, s8, c8, fb8 = idx.search_int8_two_pass_batched(q[:300], K, 3)
+    for qi in (0, 127, 128, 255, 256, 299):
+        hits = idx.search_top_k_int8_two_pass(q[qi], K, 3)
+        assert [h.index for h in hits] == r8[qi].tolist()
+        assert np.array_equal(bits([h.score for h in hits]), bits(s8[qi]))
