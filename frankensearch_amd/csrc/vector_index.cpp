@@ -1767,7 +1767,12 @@ SearchError Model2VecEmbedder::init(int device, const float* table, uint32_t voc
     device_ = device;
     vocab_ = vocab;
     dim_ = dim;
-    FSGPU_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    {
+        // short gather kernel vs the scans' chip-filling launches on other streams: highest priority (see bert_embedder.cpp)
+        int least = 0, greatest = 0;
+        FSGPU_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        FSGPU_HIP(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, greatest));
+    }
     FSGPU_TRY(table_.reserve((size_t)vocab * dim * 4));
     FSGPU_HIP(hipMemcpy(table_.ptr, table, (size_t)vocab * dim * 4, hipMemcpyHostToDevice));
     return ok();
