@@ -92,6 +92,8 @@ struct MfmaScanArgs {
     uint32_t group_stride, group_count;  // the sample, in 64-row groups: {j * group_stride : j < group_count}
     uint32_t dim, slots, row_base;       // slots <= kMfmaMaxSlots
     uint32_t elem_bytes;                 // 2 = f16 slab / f16 queries (0 means 2), 1 = int8 slab / int8 queries
+    uint32_t reverse;                    // main pass: walk the slab from its end (alternate passes re-read what the
+                                         // previous pass left in the Infinity Cache)
     uint32_t groups;                     // sample stages: query groups answered by one launch (gridDim.y; 0 means 1) —
                                          // group g's queries/tau/cand/spill/overflow/dense follow group g-1's
 };

@@ -245,7 +245,8 @@ __global__ __launch_bounds__(WPB * 64) void scan_mfma_kernel(MfmaScanArgs args) 
     auto tile_of = [&](uint32_t u) -> uint32_t {
         const uint32_t round = u / grid, blk = u - round * grid;
         const uint32_t rot = round % grid;
-        return round * grid + (blk >= rot ? blk - rot : blk + grid - rot);
+        const uint32_t t = round * grid + (blk >= rot ? blk - rot : blk + grid - rot);
+        return args.reverse ? nitems - 1 - t : t;  // items past the last tile are skipped either way
     };
     auto next_item = [&](uint32_t u) -> uint32_t {  // the wave's next work item at or after u that names a tile to scan
         while (u < nitems) {

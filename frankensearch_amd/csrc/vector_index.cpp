@@ -45,7 +45,7 @@ SearchError hip_fail(hipError_t e, const char* what) {
 // experiment switches, not configuration): see scripts/exp_*.
 struct Knobs {
     int grid_blocks = 0, ra = 0, rb = 0, mfma_shape = 0, mfma_shape_i8 = 0, round = 0, i8_per_cu = 0;
-    bool no_skip_b = false, use_160 = false, debug_batched = false;
+    bool no_skip_b = false, use_160 = false, debug_batched = false, no_reverse = false;
     Knobs() {
         auto num = [](const char* name) {
             const char* e = std::getenv(name);
@@ -59,6 +59,7 @@ struct Knobs {
         mfma_shape = num("FSGPU_MFMA_SHAPE");
         mfma_shape_i8 = num("FSGPU_MFMA_SHAPE_I8");
         no_skip_b = std::getenv("FSGPU_NO_SKIP_B") != nullptr;
+        no_reverse = std::getenv("FSGPU_NO_REVERSE") != nullptr;
         use_160 = std::getenv("FSGPU_USE_160") != nullptr;
         debug_batched = std::getenv("FSGPU_DEBUG_BATCHED") != nullptr;
     }
@@ -1221,6 +1222,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
                 c.spill = spill + (size_t)j * G * SPILL;
                 c.spill_count = spill_count + (size_t)j * G * kMfmaSpillCountStride;
                 c.overflow = overflow + (size_t)j * G;
+                c.reverse = knobs().no_reverse ? 0 : (mf_pass_parity_++ & 1);  // consecutive passes alternate direction
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (profiling) {
                     FSGPU_HIP(hipEventCreate(&e0));

@@ -178,6 +178,7 @@ class VectorIndex {
     uint32_t mf_flags_cap_ = 0;
     // profiling events
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events_;
+    uint32_t mf_pass_parity_ = 0;  // main passes of the batched path alternate their direction over the slab
     uint64_t profiled_rows_ = 0;  // slab rows streamed by the timed launches
     uint32_t profiled_elem_bytes_ = 2;
     // FSVI host-side tables
