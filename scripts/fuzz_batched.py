@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of the batched matrix-core paths against the per-query kernels (run on the GPU box).
+
+Every case draws a corpus shape, a data kind (gaussian / clustered with exact duplicates / few distinct rows / topical runs),
+tombstones, an optional allow bitmap, a batch size that exercises multi-group rounds with ragged tails, and k; the batched
+f16 answer must equal the exact kernels' bit for bit for every query, and the batched int8 two-pass must equal the
+per-query int8 two-pass.
+"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import frankensearch_amd as fa
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
+rng = np.random.default_rng(seed)
+t_end = time.time() + budget
+cases = bad = 0
+while time.time() < t_end:
+    dim = int(rng.choice([128, 256, 384]))
+    n = int(rng.integers(33_000, 300_000))
+    kind = int(rng.integers(0, 4))
+    if kind == 0:
+        x = rng.standard_normal((n, dim)).astype(np.float32)
+    elif kind == 1:   # clusters with exact duplicates: ties and crowded thresholds
+        cent = rng.standard_normal((64, dim)).astype(np.float32)
+        x = cent[rng.integers(0, 64, n)] + (rng.standard_normal((n, dim)) * 0.05).astype(np.float32)
+        dup = rng.integers(0, n, n // 20)
+        x[dup] = x[(dup * 7 + 1) % n]
+    elif kind == 2:   # very few distinct rows: pool overflow -> exact fallback
+        base = rng.standard_normal((int(rng.integers(3, 40)), dim)).astype(np.float32)
+        x = base[rng.integers(0, base.shape[0], n)]
+    else:             # topical runs: neighbouring rows alike
+        cent = rng.standard_normal((n // 500 + 1, dim)).astype(np.float32)
+        x = cent[np.arange(n) // 500] + (rng.standard_normal((n, dim)) * 0.1).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True) + 1e-9
+    slab = x.astype(np.float16).view(np.uint16)
+    live = None if rng.random() < 0.5 else (rng.random(n) > 0.2)
+    allow = None if rng.random() < 0.6 else (rng.random(n) > float(rng.choice([0.3, 0.9])))
+    nq = int(rng.choice([1, 5, 63, 64, 65, 127, 128, 129, 200, 256, 257, 300, 511, 640, 700]))
+    k = int(rng.choice([1, 2, 10, 30, 33, 64]))
+    q = x[rng.integers(0, n, nq)] + (rng.standard_normal((nq, dim)) * 0.2).astype(np.float32)
+    if nq > 3:
+        q[1] = 0.0                      # zero query
+        q[2] *= 37.5                    # non-unit query
+    idx = fa.VectorIndex.from_slab(slab, live=live)
+    br, bs, bc, fb = idx.search_batched(q, k, allow=allow)
+    ok = True
+    for s0 in range(0, nq, 64):
+        er, es, ec = idx.search_batch(q[s0:s0 + 64], k, allow=allow)
+        sl = slice(s0, min(nq, s0 + 64))
+        if not (np.array_equal(bc[sl], ec) and np.array_equal(br[sl], er) and
+                np.array_equal(bs[sl].view(np.uint32), es.view(np.uint32))):
+            ok = False
+    if allow is None:
+        mult = int(rng.choice([1, 3, 5]))
+        r8, s8, c8, fb8 = idx.search_int8_two_pass_batched(q, k, mult)
+        for qi in rng.choice(nq, min(nq, 6), replace=False):
+            hits = idx.search_top_k_int8_two_pass(q[qi], k, mult)
+            if [h.index for h in hits] != r8[qi, :c8[qi]].tolist() or \
+               not np.array_equal(np.array([h.score for h in hits], np.float32).view(np.uint32), s8[qi, :c8[qi]].view(np.uint32)):
+                ok = False
+    cases += 1
+    if not ok:
+        bad += 1
+        print(f"MISMATCH seed={seed} case={cases} dim={dim} n={n} kind={kind} nq={nq} k={k} live={live is not None} allow={allow is not None} fb={fb}", flush=True)
+    idx.close()
+print(f"seed={seed}: {cases} cases, {bad} mismatches")
+sys.exit(1 if bad else 0)

@@ -817,3 +817,16 @@ def test_mrl_search_on_an_f32_index(fa, oracle, tmp_path):
     assert [h.doc_id for h in hits] == ["doc-a", "doc-b"]
     assert stats["scan_dims"] == 8 and not stats["fell_back_to_full"]
     g.close()
+
+
+@pytest.mark.gpu
+def test_randomised_batched_cases_equal_the_per_query_kernels(fa):
+    # scripts/fuzz_batched.py: random corpus shapes / data kinds (duplicates, few distinct rows, topical runs) /
+    # tombstones / filters / ragged multi-group batches; 700 cases ran clean when this was added, a short slice runs here
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_batched.py"), "7", "12"], capture_output=True,
+                         text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "0 mismatches" in res.stdout
