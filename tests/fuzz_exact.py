@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Randomised parity of the exact search entry points against the CPU oracle (run on the GPU box; the oracle is the
+checker here, exactly as in tests/)."""
+import os, sys, time, tempfile
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import frankensearch_amd as fa
+from oracle import oracle
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
+rng = np.random.default_rng(seed)
+t_end = time.time() + budget
+cases = bad = 0
+tmp = tempfile.mkdtemp()
+bits = lambda a: np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+while time.time() < t_end:
+    n = int(rng.choice([1, 2, 15, 16, 17, 100, 1000, 5000, 20000]))
+    dim = int(rng.choice([1, 3, 7, 8, 12, 32, 40, 100, 128, 256, 384, 390]))
+    f32 = rng.random() < 0.3
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    if n > 20 and rng.random() < 0.4:
+        x[rng.integers(0, n, n // 4)] = x[0]          # ties
+    if n > 5 and rng.random() < 0.2:
+        x[rng.integers(0, n)] *= np.float32(1e4)       # an outlier
+    nq = int(rng.integers(1, 10))
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    k = int(rng.choice([1, 2, 10, 64, 65, 256, 257, n, n + 3]))
+    live = None if rng.random() < 0.5 else (rng.random(n) > 0.3)
+    allow = None if rng.random() < 0.5 else (rng.random(n) > float(rng.choice([0.5, 0.99])))
+    eff = None
+    if live is not None or allow is not None:
+        eff = np.ones(n, bool)
+        if live is not None: eff &= live
+        if allow is not None: eff &= allow
+    ok = True
+    if f32:
+        if live is not None:
+            continue  # FSVI files start with every row live
+        p = os.path.join(tmp, "f.fsvi")
+        if not np.all(np.linalg.norm(x, axis=1) > 1e-3):
+            continue
+        fa.write_fsvi(p, [(f"d{i:06}", x[i].tolist()) for i in range(n)], "e", "r", quantization=0)
+        o = oracle.Fsvi(p)
+        slab = np.frombuffer(open(p, "rb").read()[o.vectors_offset:], dtype="<f4").reshape(n, dim)
+        idx = fa.VectorIndex.open(p)
+        rows, scores, counts = idx.search_batch(q, k, allow=allow)
+        for qi in range(nq):
+            er, es = oracle.search_top_k_f32(slab, q[qi], k, live=eff)
+            m = int(counts[qi])
+            if m != len(er) or not np.array_equal(rows[qi, :m], er) or not np.array_equal(bits(scores[qi, :m]), bits(es)):
+                ok = False
+    else:
+        slab = x.astype(np.float16).view(np.uint16)
+        idx = fa.VectorIndex.from_slab(slab, live=live)
+        rows, scores, counts = idx.search_batch(q, k, allow=allow)
+        for qi in range(nq):
+            er, es = oracle.search_top_k(slab, q[qi], k, live=eff)
+            m = int(counts[qi])
+            if m != len(er) or not np.array_equal(rows[qi, :m], er) or not np.array_equal(bits(scores[qi, :m]), bits(es)):
+                ok = False
+    cases += 1
+    if not ok:
+        bad += 1
+        print(f"MISMATCH seed={seed} case={cases} n={n} dim={dim} f32={f32} nq={nq} k={k} live={live is not None} allow={allow is not None}", flush=True)
+    idx.close()
+print(f"seed={seed}: {cases} cases, {bad} mismatches")
+sys.exit(1 if bad else 0)

@@ -830,3 +830,16 @@ def test_randomised_batched_cases_equal_the_per_query_kernels(fa):
                          text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "0 mismatches" in res.stdout
+
+
+@pytest.mark.gpu
+def test_randomised_exact_cases_equal_the_oracle(fa, oracle):
+    # tests/fuzz_exact.py: random sizes / dims (incl. unaligned) / k tiers / ties / outliers / tombstones / filters / F32
+    # files against the oracle; 15,000 cases ran clean when this was added, a short slice runs here
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = subprocess.run([sys.executable, os.path.join(here, "fuzz_exact.py"), "11", "10"], capture_output=True, text=True,
+                         timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "0 mismatches" in res.stdout
