@@ -34,6 +34,38 @@ while time.time() < t_end:
         if live is not None: eff &= live
         if allow is not None: eff &= allow
     ok = True
+    if n >= 15 and dim >= 3 and rng.random() < 0.25:
+        # a file index with duplicate doc ids, soft deletes and resident WAL entries (superseding and new ids):
+        # search_top_k + resolve_hits (dedup, shadowing, tombstones; search.rs:1449-1596) against the oracle's
+        if not np.all(np.linalg.norm(x, axis=1) > 1e-3):
+            continue
+        p = os.path.join(tmp, "w.fsvi")
+        ids = [f"d{i % max(1, n - n // 10):06}" for i in range(n)]
+        fa.write_fsvi(p, [(ids[i], x[i].tolist()) for i in range(n)], "e", "r", quantization=0 if f32 else 1)
+        o = oracle.Fsvi(p)
+        g = fa.VectorIndex.open(p)
+        for _ in range(int(rng.integers(0, 6))):
+            did = ids[int(rng.integers(0, n))]
+            assert o.soft_delete(did) == g.soft_delete(did)
+        for j in range(int(rng.integers(0, 8))):
+            did = ids[int(rng.integers(0, n))] if j % 2 else f"new-{j}"
+            v = rng.standard_normal(dim).astype(np.float32)
+            assert o.append(did, v) == 0
+            g.append(did, v)
+        for qi in range(min(nq, 3)):
+            kk = int(min(k, 300))
+            oh, os_ = o.search_top_k(q[qi], kk)
+            gh = g.search_top_k(q[qi], kk)
+            if [(h.index, h.doc_id) for h in gh] != [(h[0], h[2]) for h in oh] or \
+               not np.array_equal(bits([h.score for h in gh]), bits(os_)):
+                ok = False
+        cases += 1
+        if not ok:
+            bad += 1
+            print(f"MISMATCH(file) seed={seed} case={cases} n={n} dim={dim} f32={f32} k={k}", flush=True)
+        g.close()
+        o.close()
+        continue
     if f32:
         if live is not None:
             continue  # FSVI files start with every row live
