@@ -85,6 +85,22 @@ while time.time() < t_end:
     else:
         slab = x.astype(np.float16).view(np.uint16)
         idx = fa.VectorIndex.from_slab(slab, live=live)
+        if allow is None and rng.random() < 0.35:
+            # the quantised two-pass searches and the MRL search of the same index against the oracle's
+            kk = int(min(k, 200))
+            mult = int(rng.choice([1, 3, 5]))
+            sd = int(rng.integers(1, dim + 2))
+            rd = int(rng.choice([0, sd, dim]))
+            rk = int(rng.choice([0, kk, 3 * kk]))
+            for qi in range(min(nq, 2)):
+                checks = [(idx.search_top_k_int8_two_pass(q[qi], kk, mult), oracle.search_int8_two_pass(slab, q[qi], kk, mult, live=live)),
+                          (idx.search_top_k_4bit_two_pass(q[qi], kk, mult), oracle.search_4bit_two_pass(slab, q[qi], kk, mult, live=live)),
+                          (idx.mrl_search(q[qi], kk, search_dims=sd, rescore_dims=rd, rescore_top_k=rk),
+                           oracle.mrl_search(slab, q[qi], kk, sd, rd, rk, live=live))]
+                for name, (hits, (er, es)) in zip(("int8", "4bit", "mrl"), checks):
+                    if [h.index for h in hits] != er.tolist() or not np.array_equal(bits([h.score for h in hits]), bits(es)):
+                        ok = False
+                        print(f"  {name} differs: n={n} dim={dim} k={kk} mult={mult} sd={sd} rd={rd} rk={rk}", flush=True)
         rows, scores, counts = idx.search_batch(q, k, allow=allow)
         for qi in range(nq):
             er, es = oracle.search_top_k(slab, q[qi], k, live=eff)
