@@ -43,6 +43,8 @@ while time.time() < t_end:
     if nq > 3:
         q[1] = 0.0                      # zero query
         q[2] *= 37.5                    # non-unit query
+        if rng.random() < 0.3:
+            q[3, int(rng.integers(0, dim))] = rng.choice([np.nan, np.inf])  # non-finite: answered by the exact kernels
     idx = fa.VectorIndex.from_slab(slab, live=live)
     br, bs, bc, fb = idx.search_batched(q, k, allow=allow)
     ok = True

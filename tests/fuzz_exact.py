@@ -25,6 +25,10 @@ while time.time() < t_end:
         x[rng.integers(0, n)] *= np.float32(1e4)       # an outlier
     nq = int(rng.integers(1, 10))
     q = rng.standard_normal((nq, dim)).astype(np.float32)
+    if rng.random() < 0.1:   # non-finite query elements: search_top_k does not reject them (only _classified does)
+        q[0, int(rng.integers(0, dim))] = rng.choice([np.nan, np.inf, -np.inf])
+    if rng.random() < 0.05:
+        q[-1] = 0.0
     k = int(rng.choice([1, 2, 10, 64, 65, 256, 257, n, n + 3]))
     live = None if rng.random() < 0.5 else (rng.random(n) > 0.3)
     allow = None if rng.random() < 0.5 else (rng.random(n) > float(rng.choice([0.5, 0.99])))
