@@ -689,6 +689,10 @@ SearchError VectorIndex::fused_search(const float* queries_dev, uint32_t nq, uin
         } else {
             per_cu = scan_occupancy_blocks_per_cu((int)dim_, pass, kcap, variant == 1);
         }
+        // strided views (the MRL truncated scan reads a short prefix of every row): the small-dimension kernels fit 8
+        // blocks per CU, but that many waves thrash — 4 per CU up to 64 dims and 2 beyond measured best (10M x 384 slab,
+        // search_dims 64: 0.57 -> 0.44 ms per query; 32: 0.41 -> 0.33 ms; 128: 0.58 -> 0.55 ms)
+        if (row_stride_ && row_stride_ != dim_ * 2) per_cu = std::min(per_cu, dim_ <= 64 ? 4 : 2);
         int grid = num_cus_ * per_cu;
         if (knobs().grid_blocks > 0) grid = knobs().grid_blocks;  // tuning experiments only
         const uint32_t ntiles_pass = (uint32_t)((nrows_ + (16 / pass) - 1) / (16 / pass));

@@ -17,4 +17,6 @@ def p50(f):
 print(f"grid={os.environ.get('FSGPU_GRID_BLOCKS')}: exact k=10 {p50(lambda i: idx.search_batch(q[i % 16], 10)):.3f} ms, "
       f"exact k=30 {p50(lambda i: idx.search_batch(q[i % 16], 30)):.3f} ms, "
       f"mrl128 {p50(lambda i: idx.mrl_search(q[i % 16], 10, search_dims=128)):.3f} ms, "
-      f"mrl64 {p50(lambda i: idx.mrl_search(q[i % 16], 10, search_dims=64)):.3f} ms")
+      f"mrl64 {p50(lambda i: idx.mrl_search(q[i % 16], 10, search_dims=64)):.3f} ms, "
+      f"mrl256 {p50(lambda i: idx.mrl_search(q[i % 16], 10, search_dims=256)):.3f} ms, "
+      f"mrl32 {p50(lambda i: idx.mrl_search(q[i % 16], 10, search_dims=32)):.3f} ms")
