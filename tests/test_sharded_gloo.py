@@ -71,7 +71,8 @@ def _worker(rank, world, port, n, dim, k, ret):
     from frankensearch_amd.sharded import ShardedVectorIndex, shard_range
     rng = np.random.default_rng(5)
     slab = rng.standard_normal((n, dim)).astype(np.float16).view(np.uint16)
-    slab[3] = slab[n - 2]  # a cross-shard tie
+    if n > 4:
+        slab[3] = slab[n - 2]  # a cross-shard tie
     queries = rng.standard_normal((3, dim)).astype(np.float32)
     lo, hi = shard_range(n, rank, world)
     idx = ShardedVectorIndex(OracleShardBackend(slab[lo:hi], lo))
@@ -86,9 +87,10 @@ def _worker(rank, world, port, n, dim, k, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,k", [(1001, 10), (7, 10), (64, 64)])
-def test_world2_allgather_merge_equals_unsharded_oracle(oracle, n, k):
-    world, dim = 2, 40
+@pytest.mark.parametrize("n,k,world", [(1001, 10, 2), (7, 10, 2), (64, 64, 2), (1001, 10, 3), (3, 5, 4)])
+def test_world2_allgather_merge_equals_unsharded_oracle(oracle, n, k, world):
+    # world 3: uneven shards; (3 rows, 4 ranks): one rank owns no row at all
+    dim = 40
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), n, dim, k, ret), nprocs=world, join=True)
