@@ -309,6 +309,36 @@ def mrl_section(index, rows: int, dim: int, k: int, queries):
     return out
 
 
+def config5_section(index, rows: int, k: int, local_rank: int, batches: int = 20):
+    """BASELINE config 5 on the rows this GPU holds: 256 token-id queries per batch (lengths uniform 8-32 incl.
+    [CLS]=101 / [SEP]=102, ids uniform in [1000, 30000)) -> MiniLM-L6 forward on the GPU -> batched exact scan
+    -> top-k.  Random-init weights of the MiniLM-L6 shape; the embeddings go through the host-pointer ABI (393 KB per batch)."""
+    import frankensearch_amd as fa
+    from frankensearch_amd.synthetic import random_bert_weights
+    bert = fa.NativeEmbedder(random_bert_weights(1, 30522, 384, 6, 1536), device=local_rank)
+    rng = np.random.default_rng(5)
+    def batch():
+        return [[101] + rng.integers(1000, 30000, int(rng.integers(6, 31))).tolist() + [102] for _ in range(256)]
+    sets = [batch() for _ in range(4)]
+    for b in sets[:2]:
+        index.search_batched(bert.embed_batch_token_ids(b), k)
+    enc_ms, scan_ms = [], []
+    t0 = time.perf_counter()
+    for i in range(batches):
+        t1 = time.perf_counter()
+        emb = bert.embed_batch_token_ids(sets[i % 4])
+        t2 = time.perf_counter()
+        rows_out, scores, counts, fb = index.search_batched(emb, k)
+        t3 = time.perf_counter()
+        enc_ms.append((t2 - t1) * 1e3)
+        scan_ms.append((t3 - t2) * 1e3)
+    dt = time.perf_counter() - t0
+    return {"workload": f"256 token-id queries per batch -> MiniLM-L6 on the GPU -> batched exact scan of {rows}x384 f16, top-{k}",
+            "queries_per_sec": batches * 256 / dt, "encode_ms_per_batch": float(np.median(enc_ms)),
+            "scan_ms_per_batch": float(np.median(scan_ms)), "tokens_per_batch": sum(len(x) for x in sets[0]),
+            "all_counts_full": bool(np.all(counts == k))}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -325,6 +355,9 @@ def main() -> None:
     ap.add_argument("--batched", action="store_true", help="(default) the matrix-core batched path; kept for old command lines")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-two-tier", action="store_true")
+    ap.add_argument("--config5", action="store_true",
+                    help="also time BASELINE config 5 (batch-256 on-GPU MiniLM encoding + scan) on this rank's rows; "
+                         "quoted for --rows 50000000")
     args = ap.parse_args()
     args.batched = not args.exact
     if args.batch is None:
@@ -467,6 +500,8 @@ def main() -> None:
         # oracle's workers for a while (measured: 120-150 GB/s instead of ~290 GB/s on the same 16 threads)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_and_parity(slab, queries, k, args.rows, fa.VectorIndex)
+        if world == 1 and args.config5:
+            line["config5"] = config5_section(index, args.rows, k, local_rank)
         if world == 1 and not args.no_two_tier:
             line["int8_two_pass"] = quantized_section(index, args.rows, args.dim, k, queries, 8, 3)
             line["fourbit_two_pass"] = quantized_section(index, args.rows, args.dim, k, queries, 4, 5)
