@@ -25,7 +25,11 @@ ERR_EMBEDDING_FAILED = 9
 ZERO_SIGNAL_NONE = 0
 ZERO_SIGNAL_CALLER_REQUESTED_ZERO_K = 1
 ZERO_SIGNAL_ZERO_NORM_QUERY = 2
-ZERO_SIGNAL_NO_MATCH = 3
+ZERO_SIGNAL_FILTER_ELIMINATED_ALL = 3
+ZERO_SIGNAL_NEWLY_CREATED_EMPTY = 4
+ZERO_SIGNAL_ALL_TOMBSTONED = 5
+ZERO_SIGNAL_WAL_ONLY_NO_LIVE_RECORDS = 6
+ZERO_SIGNAL_NO_USABLE_VECTORS = 7
 
 HREDUCE_SSE2 = 0
 HREDUCE_AVX = 1

@@ -11,6 +11,7 @@
 // No extra threads are created.
 #pragma once
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdint>
@@ -23,6 +24,7 @@ namespace fsgpu {
 // Base of a request type: the coalescer's bookkeeping.
 struct CoalescedRequest {
     bool done = false;
+    bool exec_threw = false;  // exec() left through an exception: the request was NOT served (callers report an error)
     int64_t arrival_ns = 0;
     std::condition_variable cv;
 };
@@ -33,10 +35,10 @@ class Coalescer {
     // max_batch == 0 disables coalescing (callers go straight to the unbatched path).
     void configure(uint32_t max_batch, uint32_t max_wait_us) {
         std::lock_guard<std::mutex> lock(mu_);
-        max_batch_ = max_batch;
+        max_batch_.store(max_batch, std::memory_order_relaxed);
         max_wait_us_ = max_wait_us;
     }
-    bool enabled() const { return max_batch_ != 0; }
+    bool enabled() const { return max_batch_.load(std::memory_order_relaxed) != 0; }  // read without the lock
     void stats(uint64_t* batches, uint64_t* requests) {
         std::lock_guard<std::mutex> lock(mu_);
         *batches = batches_;
@@ -50,17 +52,20 @@ class Coalescer {
         using clock = std::chrono::steady_clock;
         std::unique_lock<std::mutex> lk(mu_);
         r->done = false;
+        r->exec_threw = false;
         r->arrival_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now().time_since_epoch()).count();
         pending_.push_back(r);
         last_arrival_ns_ = r->arrival_ns;
-        if (leader_ && pending_.size() >= (max_batch_ ? max_batch_ : 1)) leader_->cv.notify_one();  // batch is full
+        const uint32_t max_batch = max_batch_.load(std::memory_order_relaxed);
+        if (leader_ && pending_.size() >= (max_batch ? max_batch : 1)) leader_->cv.notify_one();  // batch is full
         while (!r->done) {
             if (leader_) {
                 r->cv.wait(lk);
                 continue;
             }
             leader_ = r;
-            const size_t cap = max_batch_ ? max_batch_ : 1;
+            const uint32_t mb = max_batch_.load(std::memory_order_relaxed);
+            const size_t cap = mb ? mb : 1;
             // wait for the batch to fill, but never longer than max_wait_us past the oldest request's arrival — and stop
             // early once arrivals have paused for an eighth of that window: with a handful of callers the batch is
             // complete as soon as all of them are parked, and waiting out the window would only add latency
@@ -87,10 +92,18 @@ class Coalescer {
             ++batches_;
             requests_ += batch.size();
             lk.unlock();
-            exec(batch);
+            // exec must not strand the batch: whatever it throws, every member is released (marked unserved) and the
+            // leadership is handed on — otherwise the members would sleep forever behind a leader that no longer exists
+            bool threw = false;
+            try {
+                exec(batch);
+            } catch (...) {
+                threw = true;
+            }
             lk.lock();
             leader_ = nullptr;
             for (Req* b : batch) {
+                b->exec_threw = threw;
                 b->done = true;
                 if (b != r) b->cv.notify_one();
             }
@@ -104,7 +117,8 @@ class Coalescer {
     std::mutex mu_;
     std::deque<Req*> pending_;
     Req* leader_ = nullptr;
-    uint32_t max_batch_ = 0, max_wait_us_ = 0;
+    std::atomic<uint32_t> max_batch_{0};
+    uint32_t max_wait_us_ = 0;
     uint64_t batches_ = 0, requests_ = 0;
     int64_t last_arrival_ns_ = 0;
 };

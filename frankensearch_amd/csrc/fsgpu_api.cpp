@@ -90,21 +90,23 @@ fsgpu_status guarded(F&& body) {
 template <class Handle, class Id>
 void run_embed_batch(Handle* h, uint32_t dim, std::vector<EmbedCall<Id>*>& batch) {
     std::lock_guard<std::mutex> lock(h->co_mu);
-    h->co_ids.clear();
-    h->co_offsets.assign(1, 0u);
-    for (auto* c : batch) {
-        h->co_ids.insert(h->co_ids.end(), c->ids, c->ids + c->len);
-        h->co_offsets.push_back((uint32_t)h->co_ids.size());
-    }
-    h->co_out.resize((size_t)batch.size() * dim);
     fsgpu_status st = FSGPU_ERR_DEVICE;
     std::string detail;
     try {
+        h->co_ids.clear();
+        h->co_offsets.assign(1, 0u);
+        for (auto* c : batch) {
+            h->co_ids.insert(h->co_ids.end(), c->ids, c->ids + c->len);
+            h->co_offsets.push_back((uint32_t)h->co_ids.size());
+        }
+        h->co_out.resize((size_t)batch.size() * dim);
         fsgpu::SearchError e = h->impl.embed_batch(h->co_ids.data(), h->co_offsets.data(), (uint32_t)batch.size(), h->co_out.data());
         st = e.code;
         detail = e.detail;
     } catch (const std::exception& ex) {
         detail = ex.what();
+    } catch (...) {
+        detail = "unknown exception";
     }
     for (size_t i = 0; i < batch.size(); ++i) {
         batch[i]->status = st;
@@ -131,15 +133,15 @@ fsgpu_status coalesced_search(fsgpu_index* idx, const float* query, uint32_t k, 
                 std::lock_guard<std::mutex> lock(idx->impl.mutex());
                 const uint32_t n = (uint32_t)batch.size(), dim = idx->impl.dimension(), kk = batch[0]->k;
                 const uint32_t mult = batch[0]->int8_mult;
-                idx->co_queries.resize((size_t)n * dim);
-                idx->co_rows.resize((size_t)n * kk);
-                idx->co_scores.resize((size_t)n * kk);
-                idx->co_counts.resize(n);
-                for (uint32_t i = 0; i < n; ++i)
-                    std::memcpy(idx->co_queries.data() + (size_t)i * dim, batch[i]->query, (size_t)dim * 4);
                 fsgpu_status st = FSGPU_ERR_DEVICE;
                 std::string detail;
                 try {
+                    idx->co_queries.resize((size_t)n * dim);
+                    idx->co_rows.resize((size_t)n * kk);
+                    idx->co_scores.resize((size_t)n * kk);
+                    idx->co_counts.resize(n);
+                    for (uint32_t i = 0; i < n; ++i)
+                        std::memcpy(idx->co_queries.data() + (size_t)i * dim, batch[i]->query, (size_t)dim * 4);
                     uint32_t fb = 0;
                     fsgpu::SearchError e;
                     if (mult) {
@@ -158,6 +160,8 @@ fsgpu_status coalesced_search(fsgpu_index* idx, const float* query, uint32_t k, 
                     detail = e.detail;
                 } catch (const std::exception& ex) {
                     detail = ex.what();
+                } catch (...) {
+                    detail = "unknown exception";
                 }
                 for (uint32_t i = 0; i < n; ++i) {
                     batch[i]->status = st;
@@ -169,6 +173,7 @@ fsgpu_status coalesced_search(fsgpu_index* idx, const float* query, uint32_t k, 
                 }
             },
             [](const SearchCall& a, const SearchCall& b) { return a.k == b.k && a.int8_mult == b.int8_mult; });
+        if (call.exec_threw) return fail(FSGPU_ERR_DEVICE, "coalesced batch failed before this request was served");
         if (call.status != FSGPU_OK) g_last_error = call.detail;
         return call.status;
     });
@@ -422,8 +427,18 @@ fsgpu_status fsgpu_search_topk_classified(fsgpu_index* idx, const float* query, 
         *zero_signal = FSGPU_ZERO_SIGNAL_ZERO_NORM_QUERY;
         return FSGPU_OK;
     }
-    fsgpu_status st = fsgpu_search_topk(idx, query, 1, query_len, k, nullptr, out_rows, out_scores, out_count);
-    if (st == FSGPU_OK && *out_count == 0) *zero_signal = FSGPU_ZERO_SIGNAL_NO_MATCH;
+    const bool table = idx->impl.has_doc_ids();
+    fsgpu_status st = table ? fsgpu_search_hits(idx, query, query_len, k, out_rows, out_scores, out_count)
+                            : fsgpu_search_topk(idx, query, 1, query_len, k, nullptr, out_rows, out_scores, out_count);
+    if (st == FSGPU_OK && *out_count == 0) {
+        // ZeroSignalState::empty_result_reason without a filter (config.rs:696-740).  The exact scan returns every live row
+        // (a NaN score still ranks, search.rs:1655-1661), so an empty result means no live main record: the census the
+        // reference computes lazily reduces to the record and WAL counts.
+        const uint64_t records = idx->impl.record_count(), wal = idx->impl.wal_record_count();
+        *zero_signal = records == 0 && wal == 0 ? FSGPU_ZERO_SIGNAL_NEWLY_CREATED_EMPTY
+                       : wal == 0               ? FSGPU_ZERO_SIGNAL_ALL_TOMBSTONED
+                                                : FSGPU_ZERO_SIGNAL_WAL_ONLY_NO_LIVE_RECORDS;
+    }
     return st;
 }
 
@@ -619,6 +634,7 @@ fsgpu_status fsgpu_m2v_embed(fsgpu_m2v* m, const uint32_t* ids, const uint32_t* 
             m->coalescer.submit(
                 &call, [m](std::vector<EmbedCall<uint32_t>*>& batch) { run_embed_batch(m, m->impl.dimension(), batch); },
                 [](const EmbedCall<uint32_t>&, const EmbedCall<uint32_t>&) { return true; });
+            if (call.exec_threw) return fail(FSGPU_ERR_DEVICE, "coalesced batch failed before this request was served");
             if (call.status != FSGPU_OK) g_last_error = call.detail;
             return call.status;
         });
@@ -661,6 +677,7 @@ fsgpu_status fsgpu_bert_embed(fsgpu_bert* m, const int32_t* ids, const uint32_t*
             m->coalescer.submit(
                 &call, [m](std::vector<EmbedCall<int32_t>*>& batch) { run_embed_batch(m, m->impl.dimension(), batch); },
                 [](const EmbedCall<int32_t>&, const EmbedCall<int32_t>&) { return true; });
+            if (call.exec_threw) return fail(FSGPU_ERR_DEVICE, "coalesced batch failed before this request was served");
             if (call.status != FSGPU_OK) g_last_error = call.detail;
             return call.status;
         });

@@ -60,10 +60,15 @@ fsgpu_status SyncTwoTierSearcher::tier_hits(fsgpu_index* index, const std::vecto
     std::vector<uint32_t> rows(fetch);
     std::vector<float> scores(fetch);
     uint32_t count = 0;
+    // an index with a doc-id table (doc_id_mode 0) goes through fsgpu_search_hits = search_top_k + scan_wal + resolve_hits
+    // (resident WAL entries, shadowing, post-top-k doc-id dedup, search.rs:1493-1558), as the int8 branch does inside the
+    // library; a raw slab (synthetic doc ids) has neither a WAL nor duplicate ids, so the row-level search is the same thing
     fsgpu_status st =
         int8_multiplier
             ? fsgpu_search_topk_int8_two_pass(index, vec.data(), (uint32_t)vec.size(), fetch, int8_multiplier, rows.data(),
                                               scores.data(), &count)
+        : cfg_.doc_id_mode == 0
+            ? fsgpu_search_hits(index, vec.data(), (uint32_t)vec.size(), fetch, rows.data(), scores.data(), &count)
             : fsgpu_search_topk(index, vec.data(), 1, (uint32_t)vec.size(), fetch, nullptr, rows.data(), scores.data(), &count);
     if (st != FSGPU_OK) {
         *detail = fsgpu_last_error();
@@ -99,7 +104,9 @@ fsgpu_status SyncTwoTierSearcher::search(const uint32_t* fast_ids, uint32_t n_fa
                                          Outcome* out, std::string* detail) const {
     using clock = std::chrono::steady_clock;
     const uint32_t mult = std::max<uint32_t>(cfg_.candidate_multiplier, 1);
-    const uint32_t fetch = std::max(k * mult, k);  // candidate_count (rrf.rs:113-115)
+    // candidate_count (rrf.rs:113-115): limit.saturating_mul(multiplier).max(limit)
+    const uint64_t wide_fetch = (uint64_t)k * mult;
+    const uint32_t fetch = std::max<uint32_t>(wide_fetch > 0xffffffffull ? 0xffffffffu : (uint32_t)wide_fetch, k);
     fshost_metrics& m = out->metrics;
     const auto t0 = clock::now();
     // quality embedding: needed by phase 1 only, optionally computed while phase 0 runs

@@ -339,6 +339,39 @@ SearchError write_fsvi_v1(const char* path, const char* embedder_id, const char*
 }
 
 // VectorIndex::open for FSVI v1 (lib.rs:1747-1816, parse_header :4049-4144).
+namespace {
+// std::str::from_utf8 (the header strings, lib.rs:4073-4095): well-formed UTF-8 only — no overlongs, surrogates or > U+10FFFF.
+bool valid_utf8(const uint8_t* p, size_t n) {
+    size_t i = 0;
+    while (i < n) {
+        const uint8_t b = p[i];
+        if (b < 0x80) {
+            ++i;
+            continue;
+        }
+        size_t extra;
+        uint32_t cp, min;
+        if ((b & 0xe0) == 0xc0) {
+            extra = 1, cp = b & 0x1f, min = 0x80;
+        } else if ((b & 0xf0) == 0xe0) {
+            extra = 2, cp = b & 0x0f, min = 0x800;
+        } else if ((b & 0xf8) == 0xf0) {
+            extra = 3, cp = b & 0x07, min = 0x10000;
+        } else {
+            return false;
+        }
+        if (i + extra >= n) return false;  // truncated sequence
+        for (size_t j = 1; j <= extra; ++j) {
+            if ((p[i + j] & 0xc0) != 0x80) return false;
+            cp = (cp << 6) | (p[i + j] & 0x3f);
+        }
+        if (cp < min || cp > 0x10ffff || (cp >= 0xd800 && cp <= 0xdfff)) return false;
+        i += extra + 1;
+    }
+    return true;
+}
+}  // namespace
+
 SearchError VectorIndex::open_fsvi(const char* path, int device) {
     if (!path) return make_error(FSGPU_ERR_NULL_ARGUMENT, "path is null");
     FILE* f = std::fopen(path, "rb");
@@ -369,6 +402,7 @@ SearchError VectorIndex::open_fsvi(const char* path, int device) {
         const size_t len = read_le<uint16_t>(&data[c]);
         c += 2;
         if (!need(len)) return corrupt(std::string("truncated header (") + field + ")");
+        if (!valid_utf8(&data[c], len)) return corrupt(std::string("invalid UTF-8 in ") + field);  // lib.rs:4073-4095
         c += len;
     }
     if (!need(4)) return corrupt("truncated header (dimension)");
@@ -391,10 +425,22 @@ SearchError VectorIndex::open_fsvi(const char* path, int device) {
     c += 4;
     const uint64_t elem = quant == 1 ? 2 : 4;  // Quantization::{F32 = 0, F16 = 1} (lib.rs:203-208)
     const size_t records_offset = c;
-    const uint64_t strings_offset = records_offset + record_count * 16;
-    if (strings_offset > vectors_offset || vectors_offset % 64 != 0 ||
-        vectors_offset + record_count * dim * elem > data.size())
-        return corrupt("record table / vector slab out of bounds");
+    // checked arithmetic as in VectorIndex::open (lib.rs:1782-1816): a crafted header with a valid CRC must end in
+    // IndexCorrupted, not in a wrapped bound that passes.  (The v1 reader does not require an aligned vectors_offset;
+    // the slab is copied into a fresh device allocation, so the kernels' 16-byte loads do not depend on it.)
+    uint64_t records_bytes = 0, strings_offset = 0, vector_bytes = 0, required_len = 0;
+    if (__builtin_mul_overflow(record_count, (uint64_t)16, &records_bytes)) return corrupt("record table size overflow");
+    if (__builtin_add_overflow((uint64_t)records_offset, records_bytes, &strings_offset))
+        return corrupt("record table offset overflow");
+    if (vectors_offset < strings_offset)
+        return corrupt("vectors_offset points inside the record table/string table region");
+    if (__builtin_mul_overflow(record_count, (uint64_t)dim, &vector_bytes) ||
+        __builtin_mul_overflow(vector_bytes, elem, &vector_bytes))
+        return corrupt("vector slab size overflow");
+    if (__builtin_add_overflow(vectors_offset, vector_bytes, &required_len)) return corrupt("vector slab end overflow");
+    if (data.size() < required_len)
+        return corrupt("truncated file: have " + std::to_string(data.size()) + " bytes, need at least " +
+                       std::to_string(required_len) + " bytes");
 
     std::vector<uint64_t> live((size_t)((record_count + 63) / 64), 0);
     doc_hashes_.resize((size_t)record_count);
@@ -603,6 +649,13 @@ SearchError VectorIndex::soft_delete(const char* doc_id, uint32_t len, int32_t* 
         FSGPU_TRY(set_live_bitmap(copy.data()));
         *deleted = 1;
     }
+    // step 2 of soft_delete_batch (lib.rs:2358-2373): resident WAL versions of the document go too and count as deleted —
+    // after wal_append the main row is already tombstoned, and the WAL entry is what keeps the document searchable
+    const size_t before = wal_.size();
+    wal_.erase(std::remove_if(wal_.begin(), wal_.end(),
+                              [&](const WalEntry& e) { return e.doc_id.size() == len && std::memcmp(e.doc_id.data(), doc_id, len) == 0; }),
+               wal_.end());
+    if (wal_.size() != before) *deleted = 1;
     return ok();
 }
 
@@ -1796,6 +1849,9 @@ SearchError Model2VecEmbedder::embed_batch(const uint32_t* ids, const uint32_t* 
     for (uint32_t i = 0; i < n; ++i)
         if (offsets[i + 1] < offsets[i]) return make_error(FSGPU_ERR_INVALID_CONFIG, "offsets must be non-decreasing");
     const uint32_t total = offsets[n];
+    // the reference embedder is immutable and lock-free (model2vec_embedder.rs:55-58); here the staging buffers and the
+    // stream are per handle, so concurrent callers take turns (fsgpu.h: calls on one handle serialise internally)
+    std::lock_guard<std::mutex> lock(mu_);
     FSGPU_HIP(hipSetDevice(device_));
     FSGPU_TRY(ids_.reserve((size_t)(total ? total : 1) * 4));
     FSGPU_TRY(offsets_.reserve((size_t)(n + 1) * 4));

@@ -31,7 +31,8 @@ class ClassifiedHits:
     zero_signal: Optional[str]
 
 
-_ZERO_SIGNAL = {1: "CallerRequestedZeroK", 2: "ZeroNormQuery", 3: "NoMatch"}
+_ZERO_SIGNAL = {1: "CallerRequestedZeroK", 2: "ZeroNormQuery", 3: "FilterEliminatedAll", 4: "NewlyCreatedEmpty",
+                5: "AllTombstoned", 6: "WalOnlyNoLiveRecords", 7: "NoUsableVectors"}
 
 
 def _ptr(a) -> Optional[int]:

@@ -46,7 +46,14 @@ typedef int32_t fsgpu_status;
 #define FSGPU_ZERO_SIGNAL_NONE 0
 #define FSGPU_ZERO_SIGNAL_CALLER_REQUESTED_ZERO_K 1
 #define FSGPU_ZERO_SIGNAL_ZERO_NORM_QUERY 2
-#define FSGPU_ZERO_SIGNAL_NO_MATCH 3
+/* empty_result_reason (crates/frankensearch-core/src/config.rs:696-740) for a well-formed search that came back empty.  The
+ * classified entry point takes no filter, so FILTER_ELIMINATED_ALL and NO_USABLE_VECTORS (an exact scan returns every live
+ * row, whatever its score) are listed for callers that classify filtered searches themselves. */
+#define FSGPU_ZERO_SIGNAL_FILTER_ELIMINATED_ALL 3
+#define FSGPU_ZERO_SIGNAL_NEWLY_CREATED_EMPTY 4      /* no main records, no WAL entries */
+#define FSGPU_ZERO_SIGNAL_ALL_TOMBSTONED 5           /* every main record tombstoned, no WAL entry */
+#define FSGPU_ZERO_SIGNAL_WAL_ONLY_NO_LIVE_RECORDS 6 /* no live main record; the WAL entries produced no usable hit */
+#define FSGPU_ZERO_SIGNAL_NO_USABLE_VECTORS 7
 
 /* Order of the final 8-lane horizontal add (`wide::f32x8::reduce_add`, simd.rs:439,563).
  * SSE2 is the reference's default build (no +avx2 in .cargo/config.toml). */
@@ -101,7 +108,8 @@ uint32_t fsgpu_index_dimension(const fsgpu_index *idx);    /* VectorIndex::dimen
 fsgpu_status fsgpu_index_set_hreduce(fsgpu_index *idx, int32_t mode);
 /* doc id of a global row (FSVI-opened indexes only; pointer valid until destroy; not NUL-terminated). */
 fsgpu_status fsgpu_index_doc_id(const fsgpu_index *idx, uint32_t row, const char **ptr, uint32_t *len);
-/* VectorIndex::soft_delete (lib.rs, tombstone flag): clears the live bit(s) of doc_id; *deleted = 1 if any. */
+/* VectorIndex::soft_delete = soft_delete_batch(&[id]) > 0 (lib.rs:2303-2397): clears the live bit of every main row with
+ * that doc id AND drops its resident WAL entries; *deleted = 1 if anything went live -> deleted. */
 fsgpu_status fsgpu_index_soft_delete(fsgpu_index *idx, const char *doc_id, uint32_t doc_id_len, int32_t *deleted);
 /* SearchFilter::candidate_hashes -> rows (gather_positions_for_hashes / hash_range, search.rs:1146-1198): sets, in
  * allow_bitmap_out (ceil(record_count / 64) words, cleared first), the bit of every main row whose record hash
@@ -167,7 +175,8 @@ fsgpu_status fsgpu_merge_topk_device(int32_t device, const uint64_t *lists_dev, 
                                      uint32_t *out_rows_dev, float *out_scores_dev, uint32_t *out_counts_dev,
                                      void *hip_stream);
 /* search_top_k_classified (search.rs:227-261): validates the query (non-finite -> INVALID_CONFIG),
- * reports the ZeroSignalReason, then searches one query. */
+ * reports the ZeroSignalReason, then searches one query (through fsgpu_search_hits when the index has a doc-id
+ * table, so resident WAL entries count; row-level otherwise). */
 fsgpu_status fsgpu_search_topk_classified(fsgpu_index *idx, const float *query, uint32_t query_len, uint32_t k,
                                           uint32_t *out_rows, float *out_scores, uint32_t *out_count,
                                           int32_t *zero_signal);

@@ -1189,6 +1189,35 @@ uint32_t fso_fsvi_wal_doc_id(const fso_fsvi *idx, uint64_t i, const char **ptr) 
     return (uint32_t)strlen(idx->wal_ids[i]);
 }
 
+/* VectorIndex::soft_delete_batch (lib.rs:2313-2397) for one doc id: every live main record with that id is
+ * tombstoned (step 1, :2328-2356), every resident WAL entry with that id is dropped (step 2, :2358-2373); the return
+ * value is the number of records that went live -> deleted, WAL entries included. */
+size_t fso_fsvi_soft_delete(fso_fsvi *idx, const char *doc_id) {
+    size_t deleted = 0, dl = strlen(doc_id);
+    for (uint64_t r = 0; r < idx->record_count; ++r) {
+        const char *p;
+        uint32_t l = fso_fsvi_doc_id(idx, r, &p);
+        if (l == dl && memcmp(p, doc_id, dl) == 0 && (fso_fsvi_flags(idx, r) & 1u) == 0) {
+            fso_fsvi_set_flags(idx, r, (uint16_t)(fso_fsvi_flags(idx, r) | 1u));
+            ++deleted;
+        }
+    }
+    size_t w = 0;
+    for (size_t i = 0; i < idx->wal_len; ++i) {
+        if (strcmp(idx->wal_ids[i], doc_id) == 0) {
+            free(idx->wal_ids[i]);
+            free(idx->wal_vecs[i]);
+            ++deleted;
+        } else {
+            idx->wal_ids[w] = idx->wal_ids[i];
+            idx->wal_vecs[w] = idx->wal_vecs[i];
+            ++w;
+        }
+    }
+    idx->wal_len = w;
+    return deleted;
+}
+
 /* VectorIndex::append -> append_batch_impl (lib.rs:2569-2720) for one entry. */
 int fso_fsvi_append(fso_fsvi *idx, const char *doc_id, const float *vector, size_t len) {
     if (len != idx->dim) return FSO_ERR_DIMENSION_MISMATCH;

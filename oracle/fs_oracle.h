@@ -139,6 +139,9 @@ void fso_fsvi_set_flags(fso_fsvi *idx, uint64_t row, uint16_t flags); /* in-memo
  * supersedes a resident WAL entry with the same doc id, tombstones the first live main row with that doc id,
  * and makes the f32 vector immediately searchable (scan_wal, search.rs:1449-1475). */
 int fso_fsvi_append(fso_fsvi *idx, const char *doc_id, const float *vector, size_t len);
+/* VectorIndex::soft_delete_batch (lib.rs:2313-2397) for one id: tombstones the live main records, drops the resident WAL
+ * entries; returns how many records went live -> deleted. */
+size_t fso_fsvi_soft_delete(fso_fsvi *idx, const char *doc_id);
 uint64_t fso_fsvi_wal_count(const fso_fsvi *idx);
 /* doc id of a WAL entry (virtual row record_count + i). */
 uint32_t fso_fsvi_wal_doc_id(const fso_fsvi *idx, uint64_t i, const char **ptr);

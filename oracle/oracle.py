@@ -100,6 +100,8 @@ def lib() -> C.CDLL:
         L.fso_fsvi_search.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         L.fso_dot_f32_f32.restype = C.c_float
         L.fso_dot_f32_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        L.fso_fsvi_soft_delete.restype = C.c_size_t
+        L.fso_fsvi_soft_delete.argtypes = [C.c_void_p, C.c_char_p]
         L.fso_fsvi_append.restype = C.c_int
         L.fso_fsvi_append.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
         L.fso_fsvi_wal_count.restype = C.c_uint64
@@ -466,12 +468,8 @@ class Fsvi:
         return lib().fso_fsvi_flags(self.h, row)
 
     def soft_delete(self, doc_id: str) -> bool:
-        hit = False
-        for r in range(self.record_count):
-            if self.doc_id(r) == doc_id and (self.flags(r) & 1) == 0:
-                lib().fso_fsvi_set_flags(self.h, r, self.flags(r) | 1)
-                hit = True
-        return hit
+        # VectorIndex::soft_delete = soft_delete_batch(&[id]) > 0 (lib.rs:2303-2305): main rows AND resident WAL entries
+        return lib().fso_fsvi_soft_delete(self.h, doc_id.encode()) > 0
 
     def search_top_k(self, q, k: int, hreduce: int = HREDUCE_SSE2):
         q = np.ascontiguousarray(q, dtype=np.float32)

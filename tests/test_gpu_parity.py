@@ -220,6 +220,18 @@ def test_reference_known_answers_through_fsvi(fa, oracle, tmp_path):
     with pytest.raises(fa.InvalidConfig):
         idx.search_top_k_classified([np.inf, 0, 0, 0], 3)
     assert idx.search_top_k_classified([1.0, 0, 0, 0], 3).zero_signal is None
+    # empty_result_reason (config.rs:696-740): all tombstoned -> WAL only -> (hit again)
+    assert idx.soft_delete("doc-b") and idx.soft_delete("doc-c")
+    assert idx.search_top_k_classified([1.0, 0, 0, 0], 3).zero_signal == "AllTombstoned"
+    idx.append("w", [0.0, 1.0, 0, 0])
+    got = idx.search_top_k_classified([1.0, 0, 0, 0], 3)
+    assert got.zero_signal is None and [h.index for h in got.hits] == [3]
+    assert idx.soft_delete("w")
+    assert idx.search_top_k_classified([1.0, 0, 0, 0], 3).zero_signal == "AllTombstoned"
+    pe = str(tmp_path / "empty.fsvi")
+    fa.write_fsvi(pe, [])  # an empty writer.finish() (dimension 1)
+    assert fa.VectorIndex.open(pe).search_top_k_classified([1.0], 3).zero_signal == "NewlyCreatedEmpty"
+    idx = fa.VectorIndex.open(p)
     # NaN query through the unclassified path: all NaN, index ascending
     hits = idx.search_top_k([np.nan, 0, 0, 0], 3)
     assert all(np.isnan(h.score) for h in hits) and [h.index for h in hits] == sorted(h.index for h in hits)
@@ -320,6 +332,38 @@ def test_config2_1m_x_384_clustered_corpus(fa, oracle):
         for qi in range(queries.shape[0]):
             er, es = oracle.search_top_k(slab, queries[qi], k, nthreads=8)
             assert np.array_equal(rows[qi], er) and np.array_equal(bits(scores[qi]), bits(es))
+
+
+def test_soft_delete_purges_resident_wal_entries(fa, oracle, tmp_path):
+    # lib.rs:10064-10138 (soft_delete_removes_wal_only_record..., soft_delete_clears_pending_wal_updates_for_same_doc_id):
+    # step 2 of soft_delete_batch (lib.rs:2358-2373) — same sequence on the oracle and on the GPU index
+    p = str(tmp_path / "sd1.fsvi")
+    oracle.fsvi_write(p, [("main-0", [1.0, 1.0, 1.0, 1.0])])
+    g = fa.VectorIndex.open(p)
+    g.append("wal-only", [0.0, 1.0, 0.0, 0.0])
+    assert g.wal_record_count() == 1 and g.soft_delete("wal-only") and g.wal_record_count() == 0
+    assert all(h.doc_id != "wal-only" for h in g.search_top_k([0.0, 1.0, 0.0, 0.0], 10))
+    assert not g.soft_delete("wal-only")
+
+    rng = np.random.default_rng(77)
+    rows = [(f"doc-{i:03}", rng.standard_normal(16).astype(np.float32).tolist()) for i in range(120)]
+    p2 = str(tmp_path / "sd2.fsvi")
+    oracle.fsvi_write(p2, rows)
+    o, g = oracle.Fsvi(p2), fa.VectorIndex.open(p2)
+    for step in range(60):
+        did = f"doc-{int(rng.integers(0, 140)):03}"
+        if rng.random() < 0.5:
+            v = rng.standard_normal(16).astype(np.float32)
+            assert o.append(did, v) == 0
+            g.append(did, v)
+        else:
+            assert o.soft_delete(did) == g.soft_delete(did), (step, did)
+        assert o.wal_record_count == g.wal_record_count()
+        q = rng.standard_normal(16).astype(np.float32)
+        want, ws = o.search_top_k(q, 12)
+        got = g.search_top_k(q, 12)
+        assert [(h.index, h.doc_id) for h in got] == [(w[0], w[2]) for w in want], step
+        assert np.array_equal(np.array([h.score for h in got], np.float32).view(np.uint32), ws.view(np.uint32))
 
 
 def test_wal_overlay_matches_oracle(fa, oracle, tmp_path):

@@ -418,6 +418,28 @@ def test_wal_append_shadows_sealed_record(oracle, tmp_path):
     assert hits[0][0] == 1  # virtual index record_count + wal_idx (search.rs:1579-1590)
 
 
+def test_soft_delete_purges_resident_wal_entries(oracle, tmp_path):
+    # lib.rs:10064-10098 soft_delete_removes_wal_only_record_and_persists (in-memory half) and
+    # lib.rs:10101-10138 soft_delete_clears_pending_wal_updates_for_same_doc_id
+    p = str(tmp_path / "sd1.fsvi")
+    oracle.fsvi_write(p, [("main-0", [1.0, 1.0, 1.0, 1.0])])
+    idx = oracle.Fsvi(p)
+    assert idx.append("wal-only", [0.0, 1.0, 0.0, 0.0]) == 0 and idx.wal_record_count == 1
+    assert idx.soft_delete("wal-only") and idx.wal_record_count == 0
+    hits, _ = idx.search_top_k([0.0, 1.0, 0.0, 0.0], 10)
+    assert all(h[2] != "wal-only" for h in hits)
+    assert not idx.soft_delete("wal-only")
+
+    p = str(tmp_path / "sd2.fsvi")
+    oracle.fsvi_write(p, [("doc-a", [1.0, 0.0, 0.0, 0.0])])
+    idx = oracle.Fsvi(p)
+    assert idx.append("doc-a", [0.0, 1.0, 0.0, 0.0]) == 0 and idx.append("doc-b", [0.0, 0.0, 1.0, 0.0]) == 0
+    assert idx.wal_record_count == 2
+    assert idx.soft_delete("doc-a") and idx.wal_record_count == 1
+    hits, _ = idx.search_top_k([0.0, 1.0, 0.0, 0.0], 10)
+    assert all(h[2] != "doc-a" for h in hits) and any(h[2] == "doc-b" for h in hits)
+
+
 def test_collect_all_matches_heap_prefix_with_wal(oracle, tmp_path):
     # search.rs:2688-2738
     p = str(tmp_path / "cw.fsvi")
