@@ -34,7 +34,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-CHUNK_ROWS = 250_000    # corpus generation granule (seeded per chunk -> identical corpus for any N)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 matrix-core peak (same guide)
+PROFILE_ROUND = "r02"   # profiles/<round>/pmc_summary.json: the PMC pass that belongs to this build's kernels
 CLUSTERS = 64
 NOISE = 0.30
 
@@ -48,43 +49,42 @@ def baseline_metric() -> str:
         return "queries/sec + p50 phase-1 latency, 10Mx384 f16 corpus, 1/2/4/8 MI355X"
 
 
-def gen_chunk(chunk: int, dim: int, device) -> torch.Tensor:
-    """Synthetic clustered unit vectors, same recipe as the reference bench generator
-    (frankensearch/benches/fsvi_4bit_vs_incumbent.rs:56-101: 64 centroids + 0.30 * uniform noise, L2
-    normalised, then f32 -> f16 RNE), generated on the GPU with a per-chunk seed."""
-    g = torch.Generator(device=device)
-    g.manual_seed(0xC0000000)
-    cent = torch.rand((CLUSTERS, dim), generator=g, device=device) * 2 - 1
-    cent = cent / cent.norm(dim=1, keepdim=True)
-    g.manual_seed(1 + chunk)
-    noise = torch.rand((CHUNK_ROWS, dim), generator=g, device=device) * 2 - 1
-    rows = torch.arange(chunk * CHUNK_ROWS, (chunk + 1) * CHUNK_ROWS, device=device) % CLUSTERS
-    v = cent[rows] + NOISE * noise
-    v = v / v.norm(dim=1, keepdim=True)
-    return v.to(torch.float16)
+def _fixture(first: int, n: int, dim: int, device, seed_base: int, as_f16: bool) -> torch.Tensor:
+    """The reference's own bench generator (frankensearch/benches/fsvi_4bit_vs_incumbent.rs:56-101,344-365: xorshift64
+    raw_vector, 64 normalised centroids, row i = normalize(centroid[i % 64] + 0.30 * raw_vector(i + 1)), f32 -> f16 RNE;
+    queries = make_vector(centroids, q % 64, 0xdead0000 + q)) run by a small HIP kernel straight into HBM
+    (fsgpu_bench_fixture_device): any row range of the corpus is the same bytes whatever the number of shards."""
+    from frankensearch_amd import _lib
+    from frankensearch_amd.errors import check
 
-
-def gen_corpus(lo: int, hi: int, dim: int, device) -> torch.Tensor:
-    out = torch.empty((hi - lo, dim), dtype=torch.float16, device=device)
-    c0, c1 = lo // CHUNK_ROWS, (hi + CHUNK_ROWS - 1) // CHUNK_ROWS
-    for c in range(c0, c1):
-        ch = gen_chunk(c, dim, device)
-        a, b = max(lo, c * CHUNK_ROWS), min(hi, (c + 1) * CHUNK_ROWS)
-        out[a - lo:b - lo] = ch[a - c * CHUNK_ROWS:b - c * CHUNK_ROWS]
-        del ch
+    out = torch.empty((n, dim), dtype=torch.float16 if as_f16 else torch.float32, device=device)
+    check(_lib.lib().fsgpu_bench_fixture_device(device.index or 0, first, n, dim, CLUSTERS, NOISE, seed_base, 1 if as_f16 else 0,
+                                                out.data_ptr(), None))
     return out
 
 
+def gen_corpus(lo: int, hi: int, dim: int, device) -> torch.Tensor:
+    return _fixture(lo, hi - lo, dim, device, 1, True)
+
+
 def gen_queries(n: int, dim: int, device) -> torch.Tensor:
-    g = torch.Generator(device=device)
-    g.manual_seed(0xDEAD0000)
-    cent = torch.rand((CLUSTERS, dim), generator=torch.Generator(device=device).manual_seed(0xC0000000),
-                      device=device) * 2 - 1
-    cent = cent / cent.norm(dim=1, keepdim=True)
-    noise = torch.rand((n, dim), generator=g, device=device) * 2 - 1
-    v = cent[torch.arange(n, device=device) % CLUSTERS] + NOISE * noise
-    v = v / v.norm(dim=1, keepdim=True)
-    return v.to(torch.float32).contiguous()
+    return _fixture(0, n, dim, device, 0xDEAD0000, False)
+
+
+def measured_copy_gbps(device) -> float:
+    """What a plain device-to-device copy reaches on THIS box (read + written bytes per second), BASELINE.md section 3: the
+    vendor peak is 8 TB/s, a float4 copy measures about 6.3 (MI355X_MICROARCH.md)."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=device)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def cpu_baseline_and_parity(slab_dev: torch.Tensor, queries: torch.Tensor, k: int, rows_total: int, index_cls):
@@ -127,24 +127,52 @@ def cpu_baseline_and_parity(slab_dev: torch.Tensor, queries: torch.Tensor, k: in
             if best is None or dt1 < best[0]:
                 best = (dt1, cand)
         nthreads = best[1]
-    t0 = time.perf_counter()
+    # the corpus IS the reference bench recipe: a 4,096-row prefix (and the queries) against the oracle's restatement
+    prefix_ok = bool(np.array_equal(host[:4096], oracle.clustered_corpus_f16(0, min(4096, sample), slab_dev.shape[1])) and
+                     all(np.array_equal(q_host[i], oracle.clustered_query(i, slab_dev.shape[1])) for i in range(4)))
+    for qi in range(3):                                  # warm-up passes (BASELINE.md section 2 protocol)
+        oracle.search_top_k(host, q_host[qi], k, nthreads=nthreads)
     ok = True
+    per_query = []
+    t0 = time.perf_counter()
     for qi in range(nq):
+        t1 = time.perf_counter()
         er, es = oracle.search_top_k(host, q_host[qi], k, nthreads=nthreads)
+        per_query.append(time.perf_counter() - t1)
         ok &= bool(np.array_equal(g_rows[qi, :len(er)], er) and
                    np.array_equal(g_scores[qi, :len(es)].view(np.uint32), es.view(np.uint32)))
     dt = time.perf_counter() - t0
+    # one thread (anchor: the reference's published 18.9 GB/s per thread, docs/PERF_LEDGER.md:2149) on a smaller sample
+    one_rows = min(sample, 250_000)
+    oracle.search_top_k(host[:one_rows], q_host[0], k, nthreads=1)
+    t1 = time.perf_counter()
+    for qi in range(6):
+        oracle.search_top_k(host[:one_rows], q_host[qi], k, nthreads=1)
+    one_gbps = one_rows * slab_dev.shape[1] * 2 * 6 / (time.perf_counter() - t1) / 1e9
     sub.close()
     qps_sample = nq / dt
-    gbps = sample * slab_dev.shape[1] * 2 * nq / dt / 1e9
+    row_bytes = slab_dev.shape[1] * 2
+    gbps = sample * row_bytes * nq / dt / 1e9
+    lat = np.sort(np.array(per_query)) * (rows_total / sample)   # scaled to a pass over the full corpus
+    try:
+        model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except (OSError, StopIteration):
+        model = "unknown"
     return {
         "value": qps_sample * sample / rows_total,
         "unit": "queries/sec",
         "cores": nthreads,
         "kind": "port",
-        "sample": f"{nq} queries x first {sample} rows of the same corpus, one at a time; value scaled by "
-                  f"{sample}/{rows_total} to the full corpus; {gbps:.1f} GB/s of f16 on {nthreads} threads "
-                  f"({cores} host cpus visible, cgroup quota {quota if quota is not None else 'none'})",
+        "sample": f"{nq} queries x first {sample} rows of the same corpus, one at a time, after 3 warm-up passes; value scaled "
+                  f"by {sample}/{rows_total} to the full corpus; {gbps:.1f} GB/s of f16 on {nthreads} threads "
+                  f"({cores} host cpus visible, cgroup quota {quota if quota is not None else 'none'}; {model})",
+        "GBps": gbps,
+        "one_thread_GBps": one_gbps,
+        "p50_ms_full_corpus_scaled": float(lat[len(lat) // 2] * 1e3),
+        "p95_ms_full_corpus_scaled": float(lat[min(len(lat) - 1, int(len(lat) * 0.95))] * 1e3),
+        "cpu_model": model,
+        "host_cpus_visible": cores,
+        "corpus_prefix_equals_reference_recipe": prefix_ok,
         "parity_bit_exact": ok,
         "batched_path_equals_exact_path": batched_ok,
     }
@@ -339,6 +367,69 @@ def config5_section(index, rows: int, k: int, local_rank: int, batches: int = 20
             "all_counts_full": bool(np.all(counts == k))}
 
 
+def sharded_handle_main(args) -> None:
+    """`bench.py --sharded-handle --gpus N`: ONE process drives N devices through fsgpu_sharded_* (row shards adopted from
+    device memory, host-pointer queries, RCCL all-gather + merge inside the library).  Prints one JSON object."""
+    from __graft_entry__ import build
+    build()
+    import frankensearch_amd as fa
+
+    n = args.gpus
+    if torch.cuda.device_count() < n:
+        sys.exit(f"bench.py --sharded-handle --gpus {n}: only {torch.cuda.device_count()} GPU(s) visible")
+    per = (args.rows + n - 1) // n
+    slabs, rows = [], []
+    for r in range(n):
+        lo, hi = min(args.rows, r * per), min(args.rows, (r + 1) * per)
+        slabs.append(gen_corpus(lo, hi, args.dim, torch.device("cuda", r)))
+        rows.append(hi - lo)
+    idx = fa.NativeShardedIndex.from_device_slabs(list(range(n)), args.dim, rows, [t.data_ptr() for t in slabs], keepalive=slabs)
+    B, k = args.batch, args.k
+    q = gen_queries(2 * B, args.dim, torch.device("cuda", 0)).cpu().numpy()
+    for i in range(max(args.warmup, 2)):
+        out = idx.search_batch(q[(i % 2) * B:(i % 2) * B + B], k, batched=args.batched)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = idx.search_batch(q[(i % 2) * B:(i % 2) * B + B], k, batched=args.batched)
+    dt = time.perf_counter() - t0
+    # the answer must not depend on the sharding: one unsharded index over the first shard-0 rows cannot check that, so
+    # compare a few queries with a 1-shard handle over ALL rows when they fit one device comfortably
+    same = None
+    if args.rows * args.dim * 2 <= 64 << 30 and n > 1:
+        whole = fa.VectorIndex.from_device_slab(gen_corpus(0, args.rows, args.dim, torch.device("cuda", 0)).data_ptr(), args.rows,
+                                                args.dim, device=0)
+        wr, ws, _ = whole.search_batch(q[:8], k)
+        sr, ss, _ = idx.search_batch(q[:8], k)[:3]
+        same = bool(np.array_equal(wr, sr) and np.array_equal(ws.view(np.uint32), ss.view(np.uint32)))
+    print(json.dumps({"queries_per_sec": args.steps * B / dt, "ms_per_step": dt / args.steps * 1e3, "n_gpus": n,
+                      "queries_per_step": B, "rows": args.rows, "steps": args.steps,
+                      "exchange": "rccl ncclAllGather" if idx.exchange_mode() == 1 else "peer copies",
+                      "path": "matrix-core batched" if args.batched else "exact VALU scan",
+                      "equals_unsharded_bits": same, "all_counts_full": bool(np.all(out[2] == min(k, args.rows))),
+                      "note": "host-pointer C ABI: each step includes staging + H2D of the queries and D2H of the hits"}), flush=True)
+
+
+def sharded_handle_leg(args, world: int):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--sharded-handle", "--gpus", str(world), "--rows", str(args.rows), "--dim",
+           str(args.dim), "--k", str(args.k), "--batch", str(args.batch), "--steps", str(min(args.steps, 50)), "--warmup", "3"]
+    if args.exact:
+        cmd.append("--exact")
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE",
+                        "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "GROUP_WORLD_SIZE", "ROLE_NAME")}
+    try:
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+        last = [l for l in res.stdout.splitlines() if l.startswith("{")]
+        if res.returncode == 0 and last:
+            return json.loads(last[-1])
+        return {"error": f"rc={res.returncode}", "stderr_tail": res.stderr[-400:]}
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out after 240 s"}
+    except (OSError, ValueError) as e:
+        return {"error": str(e)}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -358,10 +449,34 @@ def main() -> None:
     ap.add_argument("--config5", action="store_true",
                     help="also time BASELINE config 5 (batch-256 on-GPU MiniLM encoding + scan) on this rank's rows; "
                          "quoted for --rows 50000000")
+    ap.add_argument("--sharded-handle", action="store_true",
+                    help="time the in-library sharded handle (fsgpu_sharded_*: ONE process, --gpus devices, RCCL all-gather "
+                         "inside libfsgpu.so) instead of the one-process-per-GPU launcher; prints its own JSON line")
+    ap.add_argument("--no-sharded-handle", action="store_true", help="skip the sharded-handle leg of an N > 1 run")
     args = ap.parse_args()
     args.batched = not args.exact
     if args.batch is None:
         args.batch = 1024 if args.batched else 4
+
+    if args.sharded_handle:
+        return sharded_handle_main(args)
+    backend = os.environ.get("FSGPU_BENCH_BACKEND", "nccl")  # "gloo": single-GPU rehearsal of the N>1 path only
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by hand: start the N ranks ourselves (the driver's torch.distributed.run line sets
+        # WORLD_SIZE and lands in the branch below)
+        ngpu = torch.cuda.device_count()
+        if backend == "nccl" and ngpu < args.gpus:
+            sys.exit(f"bench.py --gpus {args.gpus}: only {ngpu} GPU(s) visible to this process")
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -369,8 +484,12 @@ def main() -> None:
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; the launcher's world size is what runs and what "
+              "n_gpus reports", file=sys.stderr)
     ngpu = torch.cuda.device_count()
-    backend = os.environ.get("FSGPU_BENCH_BACKEND", "nccl")  # "gloo": single-GPU rehearsal of the N>1 path only
+    if backend == "nccl" and world > ngpu:
+        sys.exit(f"bench.py: {world} ranks but only {ngpu} GPU(s) visible (one rank per GPU)")
     if backend != "nccl":
         local_rank = local_rank % max(ngpu, 1)
     torch.cuda.set_device(local_rank)
@@ -396,29 +515,49 @@ def main() -> None:
     index = fa.VectorIndex.from_device_slab(slab.data_ptr(), hi - lo, args.dim, device=local_rank, row_base=lo,
                                             keepalive=slab)
     index.set_variant(args.variant)
-    sharded = ShardedVectorIndex(GpuShardBackend(index, device, batched=args.batched))
+    # N > 1: the all-gather + merge of step i are enqueued on a side stream and run underneath the scan of step i + 1
+    sharded = ShardedVectorIndex(GpuShardBackend(index, device, batched=args.batched), overlap=world > 1)
     B, k = args.batch, args.k
 
-    backend = sharded.backend
+    shard_backend = sharded.backend
     fallbacks = [0]
 
-    def step(i: int):
+    def batch_of(i: int):
         s = (i * B) % (queries.shape[0] - B + 1)
-        out = sharded.search(queries[s:s + B], k)
-        if args.batched:
-            fallbacks[0] += backend.last_fallbacks
+        return queries[s:s + B]
+
+    def run_steps(first: int, n: int):
+        """n whole searches; returns the last step's (rows, scores, counts).  Every step's result is complete when this
+        returns (the caller synchronises the device)."""
+        out = None
+        if world == 1:
+            for i in range(first, first + n):
+                out = sharded.search(batch_of(i), k)
+                if args.batched:
+                    fallbacks[0] += shard_backend.last_fallbacks
+            return out
+        pending = None
+        for i in range(first, first + n):
+            local = sharded.search_begin(batch_of(i), k)      # this rank's scan of step i (under it: step i-1's exchange)
+            if args.batched:
+                fallbacks[0] += shard_backend.last_fallbacks
+            if pending is not None:
+                pending[3].synchronize()
+            pending = sharded.search_end(local, k)            # enqueue all-gather + merge of step i, do not wait
+        if pending is not None:
+            pending[3].synchronize()
+            out = pending[:3]
         return out
 
-    for i in range(args.warmup):
-        step(i)
+    run_steps(0, args.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     index.set_profiling(True)
+    fallbacks[0] = 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(i)
+    out = run_steps(args.warmup, args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -483,17 +622,33 @@ def main() -> None:
                 "launches": launches,
             },
         }
-        # HBM traffic per launch of the dominant kernel: PMC counters need their own rocprofv3 run, so the figure comes
-        # from the committed summary of that run (scripts/pmc_summary.py), for the default workload only
-        pmc_path = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")
+        # The step against its own two roofs: every query group streams the slab once (HBM) and contracts it with its
+        # queries on the matrix cores (2 * rows * dim flops per query); the step cannot beat max(bytes / 8 TB/s, flops / peak)
+        if args.batched:
+            passes = launches / max(args.steps, 1)
+            t_hbm = passes * alg_bytes / (HBM_PEAK_GBPS * 1e9)
+            t_mfma = 2.0 * (hi - lo) * args.dim * B / (MFMA_F16_PEAK_TFLOPS * 1e12)
+            bound_s = max(t_hbm, t_mfma)
+            line["roofline"]["joint"] = {
+                "hbm_ms": t_hbm * 1e3, "mfma_ms": t_mfma * 1e3, "bound_ms": bound_s * 1e3, "bound": "hbm" if t_hbm >= t_mfma else "mfma",
+                "frac": bound_s / (elapsed / args.steps), "passes_per_step": passes, "queries_per_pass": B / max(passes, 1e-9),
+                "note": "max(slab bytes streamed per step / 8 TB/s, 2*rows*dim*queries flops / 2.5 PFLOP/s dense f16) / measured step time",
+            }
+            line["config"]["exact_fallback_rate"] = fallbacks[0] / max(args.steps * B, 1)
+        # HBM traffic per launch of the dominant kernel: PMC counters need their own rocprofv3 run, so the figure comes from
+        # THIS round's committed summary of that run (scripts/pmc_summary.py) and only when it names the kernel this build
+        # launches; a stale or missing summary leaves traffic null
+        pmc_path = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_summary.json")
         if world == 1 and args.rows == 10_000_000 and args.dim == 384 and os.path.exists(pmc_path):
-            want = "scan_mfma_kernel<384, 8, 8, 2" if args.batched else ("scan_mq_topk_kernel<384" if B >= 4 else "scan_topk_kernel<384, 1")
+            want = fa._lib.lib().fsgpu_last_main_pass_kernel().decode() if args.batched else ("scan_mq_topk_kernel<384" if B >= 4 else "scan_topk_kernel<384, 1")
             for e in json.load(open(pmc_path)):
-                if e.get("counter") == "FETCH_SIZE" and want in e.get("kernel", "") and "hbm_read_bytes_corrected" in e:
+                if e.get("counter") == "FETCH_SIZE" and want and want in e.get("kernel", "") and "hbm_read_bytes_corrected" in e:
                     line["roofline"]["traffic"] = e["hbm_read_bytes_corrected"]
-                    line["roofline"]["traffic_source"] = ("profiles/r01/pmc_summary.json: rocprofv3 --pmc FETCH_SIZE of this "
-                                                          "command, KiB x 1024 x 2 (gfx950 correction)")
+                    line["roofline"]["traffic_source"] = (f"profiles/{PROFILE_ROUND}/pmc_summary.json: rocprofv3 --pmc FETCH_SIZE of "
+                                                          f"this command for {e['kernel'][:60]}, KiB x 1024 x 2 (gfx950 correction)")
                     break
+        if world == 1:
+            line["roofline"]["measured_copy_GBps"] = measured_copy_gbps(device)
         if lat:
             line["p50_latency_ms_single_query"] = lat[len(lat) // 2]
         # the CPU baseline runs before the thousand-thread load test below: after it the container's CPU quota throttles the
@@ -510,10 +665,15 @@ def main() -> None:
             line["two_tier"] = tt
             line["p50_phase1_latency_ms"] = tt["phase1_p50_ms"]
             line["end_to_end_queries_per_sec"] = tt["concurrent_1024_threads"]["queries_per_sec"]
-        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if world > 1 and backend == "nccl" and not args.no_sharded_handle:
+            # the same search through ONE C-ABI handle (fsgpu_sharded_*: RCCL inside libfsgpu.so), timed in a child
+            # process with a hard limit once the ranks have left their GPUs — a problem there cannot cost the line above
+            line["sharded_handle"] = sharded_handle_leg(args, world)
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -7,9 +7,9 @@ from . import _lib
 from .embed import Model2VecEmbedder, NativeEmbedder
 from .errors import (DeviceError, DimensionMismatch, IndexCorrupted, IndexVersionMismatch, InvalidConfig, IoError,
                      NoDevice, SearchError)
-from .index import (ClassifiedHits, VectorHit, VectorIndex, encode_f32_to_f16, pack_bitmap, widen_f16_to_f32,
+from .index import (ClassifiedHits, NativeShardedIndex, VectorHit, VectorIndex, encode_f32_to_f16, pack_bitmap, widen_f16_to_f32,
                     write_fsvi)
 
-__all__ = ["write_fsvi", "VectorIndex", "VectorHit", "ClassifiedHits", "Model2VecEmbedder", "NativeEmbedder", "SearchError", "DimensionMismatch",
+__all__ = ["write_fsvi", "VectorIndex", "NativeShardedIndex", "VectorHit", "ClassifiedHits", "Model2VecEmbedder", "NativeEmbedder", "SearchError", "DimensionMismatch",
            "InvalidConfig", "IndexCorrupted", "IndexVersionMismatch", "IoError", "DeviceError", "NoDevice",
            "encode_f32_to_f16", "widen_f16_to_f32", "pack_bitmap", "_lib"]

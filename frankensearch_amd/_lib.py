@@ -33,6 +33,7 @@ ZERO_SIGNAL_NO_USABLE_VECTORS = 7
 
 HREDUCE_SSE2 = 0
 HREDUCE_AVX = 1
+HREDUCE_SEQ = 2
 
 _vp, _u32, _u64, _i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
 
@@ -41,6 +42,7 @@ SIGNATURES = {
     "fsgpu_version": (C.c_char_p, []),
     "fsgpu_device_count": (_i32, []),
     "fsgpu_last_error": (C.c_char_p, []),
+    "fsgpu_last_main_pass_kernel": (C.c_char_p, []),
     "fsgpu_index_create": (_i32, [_i32, _u32, _u64, _vp, _vp, _u64, C.POINTER(_vp)]),
     "fsgpu_index_create_device": (_i32, [_i32, _u32, _u64, _vp, _vp, _u64, C.POINTER(_vp)]),
     "fsgpu_index_open_fsvi": (_i32, [C.c_char_p, _i32, C.POINTER(_vp)]),
@@ -60,10 +62,22 @@ SIGNATURES = {
     "fsgpu_search_topk_batched_packed_device": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, C.POINTER(_u32)]),
     "fsgpu_search_topk_packed_device": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "fsgpu_merge_topk_device": (_i32, [_i32, _vp, _u32, _u32, _u32, _u64, _u64, _u32, _vp, _vp, _vp, _vp]),
+    "fsgpu_sharded_create": (_i32, [_vp, _u32, _u32, _u64, _vp, _vp, _i32, C.POINTER(_vp)]),
+    "fsgpu_sharded_create_device": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _i32, C.POINTER(_vp)]),
+    "fsgpu_sharded_destroy": (None, [_vp]),
+    "fsgpu_sharded_record_count": (_u64, [_vp]),
+    "fsgpu_sharded_dimension": (_u32, [_vp]),
+    "fsgpu_sharded_shard_count": (_u32, [_vp]),
+    "fsgpu_sharded_exchange_mode": (_i32, [_vp]),
+    "fsgpu_sharded_shard_range": (_i32, [_vp, _u32, C.POINTER(_u64), C.POINTER(_u64)]),
+    "fsgpu_sharded_set_hreduce": (_i32, [_vp, _i32]),
+    "fsgpu_sharded_search_topk": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "fsgpu_sharded_search_topk_batched": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, C.POINTER(_u32)]),
     "fsgpu_search_topk_classified": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, C.POINTER(_u32), C.POINTER(_i32)]),
     "fsgpu_search_topk_int8_two_pass": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),
     "fsgpu_search_hits": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),
     "fsgpu_gather_dot": (_i32, [_vp, _vp, _u32, _vp, _u32, _vp]),
+    "fsgpu_bench_fixture_device": (_i32, [_i32, _u64, _u64, _u32, _u32, C.c_float, _u64, _i32, _vp, _vp]),
     "fsgpu_encode_f32_to_f16": (_i32, [_i32, _vp, _u64, _vp]),
     "fsgpu_widen_f16_to_f32": (_i32, [_i32, _vp, _u64, _vp]),
     "fsgpu_m2v_create": (_i32, [_i32, _vp, _u32, _u32, C.POINTER(_vp)]),

@@ -16,9 +16,9 @@ OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libfsgpu.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
-SOURCES = ["scan_kernels.hip", "scan_mq_kernel.hip", "int8_kernels.hip", "f32_kernels.hip", "mfma_scan.hip", "sort_general.hip", "m2v_kernels.hip", "bert_kernels.hip", "vector_index.cpp",
+SOURCES = ["scan_kernels.hip", "scan_mq_kernel.hip", "int8_kernels.hip", "f32_kernels.hip", "mfma_scan.hip", "sort_general.hip", "m2v_kernels.hip", "bert_kernels.hip", "bench_fixture.hip", "vector_index.cpp", "sharded_index.cpp",
            "bert_embedder.cpp", "fusion.cpp", "fsgpu_api.cpp"]
-HEADERS = ["device_util.hpp", "scan_common.hpp", "kernels.hpp", "vector_index.hpp", "bert_embedder.hpp", "coalescer.hpp"]
+HEADERS = ["device_util.hpp", "scan_common.hpp", "kernels.hpp", "vector_index.hpp", "bert_embedder.hpp", "coalescer.hpp", "sharded_index.hpp"]
 # libfshost.so: the C++ host-side mirror of the reference's two-tier searcher, over the C ABI only (include/fshost.h)
 HOST_LIB = os.path.join(HERE, "libfshost.so")
 HOST_SOURCES = ["host/two_tier_searcher.cpp", "host/load_driver.cpp", "host/fshost_api.cpp"]
@@ -61,7 +61,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=min(4, len(sources))) as pool:
         objs = list(pool.map(compile_one, sources))
     if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-pthread"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

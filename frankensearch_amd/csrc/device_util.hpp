@@ -97,8 +97,14 @@ __device__ __forceinline__ void wave_extract_topk(u64 (&key)[PER], const u64 (&e
     }
 }
 
-// wide::f32x8::reduce_add (third-party; simd.rs:439,563).  mode 0 = SSE2 build order, 1 = AVX order.
+// wide::f32x8::reduce_add (third-party; simd.rs:439,563).  mode 0 = SSE2 build order, 1 = AVX order, 2 = two sequential
+// 4-lane sums (f32x8 = a.reduce_add() + b.reduce_add() with a left-to-right f32x4 sum).
 __device__ __forceinline__ float hreduce8(const float (&v)[8], int mode) {
+    if (mode == 2) {
+        float a = ((v[0] + v[1]) + v[2]) + v[3];
+        float b = ((v[4] + v[5]) + v[6]) + v[7];
+        return a + b;
+    }
     if (mode == 1) {
         float a = v[0] + v[4], b = v[1] + v[5], c = v[2] + v[6], d = v[3] + v[7];
         float lo = a + c, hi = b + d;

@@ -13,6 +13,7 @@
 
 #include "bert_embedder.hpp"
 #include "coalescer.hpp"
+#include "sharded_index.hpp"
 #include "vector_index.hpp"
 
 // One in-flight single-item call, parked in a Coalescer until a leader serves it (coalescer.hpp).
@@ -41,6 +42,9 @@ struct fsgpu_index {
     // leader-only staging (guarded by impl.mutex())
     std::vector<float> co_queries, co_scores;
     std::vector<uint32_t> co_rows, co_counts;
+};
+struct fsgpu_sharded {
+    fsgpu::ShardedIndex impl;
 };
 struct fsgpu_m2v {
     fsgpu::Model2VecEmbedder impl;
@@ -193,6 +197,8 @@ int32_t fsgpu_device_count(void) {
 
 const char* fsgpu_last_error(void) { return g_last_error.c_str(); }
 
+const char* fsgpu_last_main_pass_kernel(void) { return fsgpu::last_main_pass_kernel(); }
+
 fsgpu_status fsgpu_index_create(int32_t device, uint32_t dim, uint64_t nrows, const void* slab_f16_le,
                                 const uint64_t* live_bitmap, uint64_t row_base, fsgpu_index** out) {
     if (!out) return fail(FSGPU_ERR_NULL_ARGUMENT, "out is null");
@@ -247,8 +253,7 @@ uint32_t fsgpu_index_dimension(const fsgpu_index* idx) { return idx ? idx->impl.
 
 fsgpu_status fsgpu_index_set_hreduce(fsgpu_index* idx, int32_t mode) {
     if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
-    if (mode != FSGPU_HREDUCE_SSE2 && mode != FSGPU_HREDUCE_AVX)
-        return fail(FSGPU_ERR_INVALID_CONFIG, "unknown hreduce mode");
+    if (mode < FSGPU_HREDUCE_SSE2 || mode > FSGPU_HREDUCE_SEQ) return fail(FSGPU_ERR_INVALID_CONFIG, "unknown hreduce mode");
     std::lock_guard<std::mutex> lock(idx->impl.mutex());
     idx->impl.hreduce = mode;
     return FSGPU_OK;
@@ -404,6 +409,82 @@ fsgpu_status fsgpu_merge_topk_device(int32_t device, const uint64_t* lists_dev, 
 }
 
 // search_top_k_classified (crates/frankensearch-index/src/search.rs:227-261)
+// ---- row-sharded index: one handle, one call per search (sharded_index.cpp) ----
+fsgpu_status fsgpu_sharded_create(const int32_t* devices, uint32_t ndev, uint32_t dim, uint64_t nrows, const void* slab_f16_le,
+                                  const uint64_t* live_bitmap, int32_t exchange, fsgpu_sharded** out) {
+    if (!out) return fail(FSGPU_ERR_NULL_ARGUMENT, "out is null");
+    *out = nullptr;
+    return guarded([&]() -> fsgpu_status {
+        auto* h = new fsgpu_sharded();
+        fsgpu::SearchError e = h->impl.init_host(devices, ndev, dim, nrows, slab_f16_le, live_bitmap, exchange);
+        if (!e.ok()) {
+            delete h;
+            return finish(e);
+        }
+        *out = h;
+        return FSGPU_OK;
+    });
+}
+
+fsgpu_status fsgpu_sharded_create_device(const int32_t* devices, uint32_t ndev, uint32_t dim, const uint64_t* shard_rows,
+                                         const void* const* shard_slabs_dev, const uint64_t* const* shard_live_dev,
+                                         int32_t exchange, fsgpu_sharded** out) {
+    if (!out) return fail(FSGPU_ERR_NULL_ARGUMENT, "out is null");
+    *out = nullptr;
+    return guarded([&]() -> fsgpu_status {
+        auto* h = new fsgpu_sharded();
+        fsgpu::SearchError e = h->impl.init_device(devices, ndev, dim, shard_rows, shard_slabs_dev, shard_live_dev, exchange);
+        if (!e.ok()) {
+            delete h;
+            return finish(e);
+        }
+        *out = h;
+        return FSGPU_OK;
+    });
+}
+
+void fsgpu_sharded_destroy(fsgpu_sharded* idx) { delete idx; }
+uint64_t fsgpu_sharded_record_count(const fsgpu_sharded* idx) { return idx ? idx->impl.record_count() : 0; }
+uint32_t fsgpu_sharded_dimension(const fsgpu_sharded* idx) { return idx ? idx->impl.dimension() : 0; }
+uint32_t fsgpu_sharded_shard_count(const fsgpu_sharded* idx) { return idx ? idx->impl.shard_count() : 0; }
+int32_t fsgpu_sharded_exchange_mode(const fsgpu_sharded* idx) { return idx ? idx->impl.exchange_mode() : 0; }
+
+fsgpu_status fsgpu_sharded_shard_range(const fsgpu_sharded* idx, uint32_t shard, uint64_t* row_lo, uint64_t* row_hi) {
+    if (!idx || !row_lo || !row_hi) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    if (!idx->impl.shard_range(shard, row_lo, row_hi)) return fail(FSGPU_ERR_INVALID_CONFIG, "shard ordinal out of range");
+    return FSGPU_OK;
+}
+
+fsgpu_status fsgpu_sharded_set_hreduce(fsgpu_sharded* idx, int32_t mode) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    if (mode < FSGPU_HREDUCE_SSE2 || mode > FSGPU_HREDUCE_SEQ) return fail(FSGPU_ERR_INVALID_CONFIG, "unknown hreduce mode");
+    std::lock_guard<std::mutex> lock(idx->impl.mutex());
+    idx->impl.set_hreduce(mode);
+    return FSGPU_OK;
+}
+
+static fsgpu_status sharded_search(fsgpu_sharded* idx, const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
+                                   bool batched, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
+                                   uint32_t* out_fallbacks) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    if (nq && (!queries || !out_counts || (k && (!out_rows || !out_scores)))) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.search(queries, nq, query_len, k, batched, out_rows, out_scores, out_counts, out_fallbacks));
+    });
+}
+
+fsgpu_status fsgpu_sharded_search_topk(fsgpu_sharded* idx, const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
+                                       uint32_t* out_rows, float* out_scores, uint32_t* out_counts) {
+    return sharded_search(idx, queries, nq, query_len, k, false, out_rows, out_scores, out_counts, nullptr);
+}
+
+fsgpu_status fsgpu_sharded_search_topk_batched(fsgpu_sharded* idx, const float* queries, uint32_t nq, uint32_t query_len,
+                                               uint32_t k, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
+                                               uint32_t* out_fallbacks) {
+    return sharded_search(idx, queries, nq, query_len, k, true, out_rows, out_scores, out_counts, out_fallbacks);
+}
+
 fsgpu_status fsgpu_search_topk_classified(fsgpu_index* idx, const float* query, uint32_t query_len, uint32_t k,
                                           uint32_t* out_rows, float* out_scores, uint32_t* out_count,
                                           int32_t* zero_signal) {
@@ -595,6 +676,29 @@ fsgpu_status fsgpu_fsvi_write_quant(const char* path, const char* embedder_id, c
     return guarded([&]() -> fsgpu_status {
         return finish(fsgpu::write_fsvi_v1(path, embedder_id, embedder_revision, dim, n, doc_ids, doc_id_lens, vectors,
                                            compaction_gen, device, quantization));
+    });
+}
+
+fsgpu_status fsgpu_bench_fixture_device(int32_t device, uint64_t first, uint64_t n, uint32_t dim, uint32_t clusters, float noise,
+                                        uint64_t seed_base, int32_t as_f16, void* out_dev, void* hip_stream) {
+    if (n && !out_dev) return fail(FSGPU_ERR_NULL_ARGUMENT, "out_dev is null");
+    if (dim == 0 || clusters == 0) return fail(FSGPU_ERR_INVALID_CONFIG, "dim and clusters must be positive");
+    return guarded([&]() -> fsgpu_status {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(FSGPU_ERR_NO_DEVICE, "no HIP device visible");
+        if (device < 0 || device >= count) return fail(FSGPU_ERR_INVALID_CONFIG, "device ordinal out of range");
+        if (hipSetDevice(device) != hipSuccess) return fail(FSGPU_ERR_DEVICE, "hipSetDevice failed");
+        fsgpu::DeviceBuffer cent;
+        fsgpu::SearchError e = cent.reserve((size_t)clusters * dim * 4);
+        if (!e.ok()) return finish(e);
+        hipStream_t st = static_cast<hipStream_t>(hip_stream);
+        hipError_t he = fsgpu::launch_bench_fixture(first, n, dim, clusters, noise, seed_base, static_cast<float*>(cent.ptr),
+                                                    as_f16 ? static_cast<unsigned short*>(out_dev) : nullptr,
+                                                    as_f16 ? nullptr : static_cast<float*>(out_dev), st);
+        if (he == hipSuccess) he = hipStreamSynchronize(st);
+        cent.release();
+        if (he != hipSuccess) return fail(FSGPU_ERR_DEVICE, hipGetErrorString(he));
+        return FSGPU_OK;
     });
 }
 

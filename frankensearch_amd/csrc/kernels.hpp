@@ -57,6 +57,11 @@ hipError_t launch_scatter_hits(const uint32_t* idx, uint32_t n, uint32_t k, cons
                                const float* src_scores, const uint32_t* src_counts, uint32_t* dst_rows,
                                float* dst_scores, uint32_t* dst_counts, u64* dst_packed, hipStream_t stream);
 hipError_t launch_encode_f16(const float* src, size_t n, unsigned short* dst, hipStream_t stream);
+// The reference's bench corpus / queries (frankensearch/benches/fsvi_4bit_vs_incumbent.rs:56-101,344-365) written straight into
+// device memory: vectors first .. first+n with seeds seed_base + index, as f16 rows (out_f16) or f32 queries (out_f32).
+// centroid_scratch holds clusters * dim floats.
+hipError_t launch_bench_fixture(uint64_t first, uint64_t n, uint32_t dim, uint32_t clusters, float noise, uint64_t seed_base,
+                                float* centroid_scratch, unsigned short* out_f16, float* out_f32, hipStream_t stream);
 hipError_t launch_encode_rows_f16(const float* src, const uint32_t* perm, uint64_t n, uint32_t dim, unsigned short* dst,
                                   hipStream_t stream);
 hipError_t launch_widen_f16(const unsigned short* src, size_t n, float* dst, hipStream_t stream);
@@ -140,6 +145,7 @@ hipError_t launch_prepare_queries_i8(const float* q, uint32_t nq, uint32_t nq_pa
 constexpr uint32_t kMfmaMaxSlots = 32;           // candidate slots per (block, query) staged in LDS
 constexpr uint32_t kMfmaSpillCountStride = 16;  // uint32 counters 64 bytes apart
 bool scan_mfma_supported(int dim);
+const char* last_main_pass_kernel();  // template instantiation of the last batched main pass launched, as rocprofv3 names it
 // shape: see mfma_scan.hip (0 = 64 queries; 1..3 = 128 queries with different row tiling / buffering)
 int scan_mfma_waves_per_block(int shape);
 int scan_mfma_rows_per_tile(int shape);

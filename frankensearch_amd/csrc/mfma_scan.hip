@@ -30,7 +30,9 @@
 // ds_read_b128 per (k-step, query tile), each feeding one MFMA per 16-row sub-tile.  Algorithmic bytes per pass are
 // still N*dim*2.  At 64 queries the kernel is HBM-bound; at 128 queries the B-fragment reads (96 KB of LDS traffic
 // per 16 rows) bound the 16-row tiling, the 32-row tiling halves them and is HBM-bound again.
+#include <atomic>
 #include <cstdlib>
+#include <string>
 #include <type_traits>
 
 #include "scan_common.hpp"
@@ -655,6 +657,9 @@ __global__ __launch_bounds__(256) void prepare_queries_i8_kernel(const float* __
 
 // ---- launchers ----------------------------------------------------------------------------------------------
 
+static std::atomic<const char*> g_last_main_pass_kernel{""};
+const char* last_main_pass_kernel() { return g_last_main_pass_kernel.load(std::memory_order_relaxed); }
+
 bool scan_mfma_supported(int dim) { return dim == 128 || dim == 256 || dim == 384; }
 
 template <int DIM, int NQT, int WPB, int STAGE, int RT, bool PF, int EB>
@@ -673,6 +678,14 @@ static hipError_t launch_mfma_s(const MfmaScanArgs& args, int grid, hipStream_t 
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, WPB * 64, lds) != hipSuccess || blocks < 1) blocks = 1;
         *occupancy = blocks;
         return hipSuccess;
+    }
+    if (STAGE == 2) {
+        // the instantiation the main pass runs, spelled as rocprofv3 prints it: bench.py matches a committed PMC summary
+        // against it and refuses a figure that belongs to another kernel
+        static const std::string name = "scan_mfma_kernel<" + std::to_string(DIM) + ", " + std::to_string(NQT) + ", " +
+                                        std::to_string(WPB) + ", " + std::to_string(STAGE) + ", " + std::to_string(RT) + ", " +
+                                        (PF ? "true" : "false") + ", " + std::to_string(EB) + ">";
+        g_last_main_pass_kernel.store(name.c_str(), std::memory_order_relaxed);
     }
     hipLaunchKernelGGL(kern, dim3(grid, args.groups ? args.groups : 1), dim3(WPB * 64), lds, stream, args);
     return hipGetLastError();

@@ -497,7 +497,11 @@ float dot_f32_f32(const float* a, const float* b, size_t n, int hreduce) {
             v[j] = v[j] + p;
         }
     float result;
-    if (hreduce == FSGPU_HREDUCE_AVX) {
+    if (hreduce == FSGPU_HREDUCE_SEQ) {
+        const float lo = ((v[0] + v[1]) + v[2]) + v[3];
+        const float hi = ((v[4] + v[5]) + v[6]) + v[7];
+        result = lo + hi;
+    } else if (hreduce == FSGPU_HREDUCE_AVX) {
         const float s0 = v[0] + v[4], s1 = v[1] + v[5], s2 = v[2] + v[6], s3 = v[3] + v[7];
         const float lo = s0 + s2, hi = s1 + s3;
         result = lo + hi;

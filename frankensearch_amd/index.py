@@ -323,6 +323,93 @@ class VectorIndex:
         return _lib.lib().fsgpu_index_doc_id(self._h, 0, C.byref(p), C.byref(n)) == 0
 
 
+class NativeShardedIndex:
+    """fsgpu_sharded: the row-sharded index behind ONE C-ABI handle (include/fsgpu.h): one shard, stream and host thread per
+    device, RCCL all-gather of the packed per-shard top-k, merge on the root (search.rs:1013-1036,1704-1720 at GPU granularity).
+    (The one-process-per-GPU form used by `bench.py --gpus N` is frankensearch_amd/sharded.py.)"""
+
+    EXCHANGE_AUTO, EXCHANGE_RCCL, EXCHANGE_PEER_COPY = 0, 1, 2
+
+    def __init__(self, handle: int, keepalive=None):
+        self._h = C.c_void_p(handle)
+        self._keepalive = keepalive
+
+    @classmethod
+    def from_slab(cls, slab_f16: np.ndarray, devices: Sequence[int], live: Optional[np.ndarray] = None,
+                  exchange: int = 0) -> "NativeShardedIndex":
+        slab = np.ascontiguousarray(slab_f16)
+        if slab.dtype == np.float16:
+            slab = slab.view(np.uint16)
+        if slab.dtype != np.uint16 or slab.ndim != 2:
+            raise TypeError("slab must be a 2-D uint16/float16 array")
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        bm = pack_bitmap(live) if live is not None else None
+        h = C.c_void_p()
+        check(_lib.lib().fsgpu_sharded_create(_ptr(devs), devs.size, slab.shape[1], slab.shape[0], _ptr(slab), _ptr(bm),
+                                              exchange, C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_device_slabs(cls, devices: Sequence[int], dim: int, shard_rows: Sequence[int], slab_ptrs: Sequence[int],
+                          exchange: int = 0, keepalive=None) -> "NativeShardedIndex":
+        """Adopts per-device resident shards (e.g. torch tensors' data_ptr())."""
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        rows = np.ascontiguousarray(shard_rows, dtype=np.uint64)
+        ptrs = np.ascontiguousarray(slab_ptrs, dtype=np.uint64)
+        h = C.c_void_p()
+        check(_lib.lib().fsgpu_sharded_create_device(_ptr(devs), devs.size, dim, _ptr(rows), _ptr(ptrs), None, exchange,
+                                                     C.byref(h)))
+        return cls(h.value, keepalive)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.lib().fsgpu_sharded_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def record_count(self) -> int:
+        return _lib.lib().fsgpu_sharded_record_count(self._h)
+
+    def dimension(self) -> int:
+        return _lib.lib().fsgpu_sharded_dimension(self._h)
+
+    def shard_count(self) -> int:
+        return _lib.lib().fsgpu_sharded_shard_count(self._h)
+
+    def exchange_mode(self) -> int:
+        return _lib.lib().fsgpu_sharded_exchange_mode(self._h)
+
+    def shard_range(self, shard: int) -> Tuple[int, int]:
+        lo, hi = C.c_uint64(), C.c_uint64()
+        check(_lib.lib().fsgpu_sharded_shard_range(self._h, shard, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def set_hreduce(self, mode: int) -> None:
+        check(_lib.lib().fsgpu_sharded_set_hreduce(self._h, mode))
+
+    def search_batch(self, queries: np.ndarray, k: int, batched: bool = False):
+        """[nq, dim] f32 -> rows [nq, k] u32, scores [nq, k] f32, counts [nq] u32 (+ fallbacks when batched)."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        nq = q.shape[0]
+        rows = np.full((nq, max(k, 1)), 0xFFFFFFFF, dtype=np.uint32)
+        scores = np.zeros((nq, max(k, 1)), dtype=np.float32)
+        counts = np.zeros(nq, dtype=np.uint32)
+        if batched:
+            fb = C.c_uint32()
+            check(_lib.lib().fsgpu_sharded_search_topk_batched(self._h, _ptr(q), nq, q.shape[1], k, _ptr(rows), _ptr(scores),
+                                                               _ptr(counts), C.byref(fb)))
+            return rows[:, :k], scores[:, :k], counts, fb.value
+        check(_lib.lib().fsgpu_sharded_search_topk(self._h, _ptr(q), nq, q.shape[1], k, _ptr(rows), _ptr(scores), _ptr(counts)))
+        return rows[:, :k], scores[:, :k], counts
+
+
 def write_fsvi(path: str, rows, embedder_id: str = "test", embedder_revision: str = "", compaction_gen: int = 0,
                device: int = 0, quantization: int = 1) -> None:
     """VectorIndexWriter (lib.rs:3637-3672, 3752-3943): rows = [(doc_id, vector), ...] -> FSVI v1 file

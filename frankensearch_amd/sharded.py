@@ -114,29 +114,60 @@ class GpuShardBackend:
 
 
 class ShardedVectorIndex:
-    """One process per GPU; `search` is collective: every rank calls it with the same queries."""
+    """One process per GPU; `search` is collective: every rank calls it with the same queries.
 
-    def __init__(self, backend: ShardBackend, group: Optional[dist.ProcessGroup] = None):
+    `search_begin` / `search_end` split a search into the shard-local scan and the exchange + merge.  With
+    `overlap=True` (CUDA tensors) the second half is enqueued on a side stream without blocking the host, so a caller that
+    begins step i+1 right after ending step i runs the all-gather and the merge of step i underneath the scan of step
+    i+1 (the batched scan synchronises only its own stream); `search_end` then returns tensors that are complete once the
+    returned event has fired."""
+
+    def __init__(self, backend: ShardBackend, group: Optional[dist.ProcessGroup] = None, overlap: bool = False):
         self.backend = backend
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.overlap = overlap
+        self._side = None
+
+    def search_begin(self, queries: torch.Tensor, k: int) -> torch.Tensor:
+        """[B, dim] -> this shard's packed [B, k] list (global rows, best first)."""
+        return self.backend.search_packed(queries, k)
+
+    def _gather(self, local: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return local.unsqueeze(0)
+        # dim-0 concatenation form (accepted by both RCCL and gloo), viewed as [W, B, k]
+        if local.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal path (no RCCL): stage through the host
+            host = torch.empty((self.world * local.shape[0], local.shape[1]), dtype=local.dtype)
+            dist.all_gather_into_tensor(host, local.cpu(), group=self.group)
+            flat = host.to(local.device)
+        else:
+            flat = torch.empty((self.world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(flat, local, group=self.group)
+        return flat.view(self.world, local.shape[0], local.shape[1])
+
+    def search_end(self, local: torch.Tensor, k: int):
+        """All-gather of the W packed lists + merge.  Returns (rows, scores, counts[, event when overlap is on])."""
+        if not (self.overlap and local.is_cuda):
+            return self.backend.merge(self._gather(local), k)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=local.device)
+        side = self._side
+        side.wait_stream(torch.cuda.current_stream(local.device))   # the scan that produced `local`
+        local.record_stream(side)
+        with torch.cuda.stream(side):
+            out = self.backend.merge(self._gather(local), k)
+            done = torch.cuda.Event()
+            done.record(side)
+        return out + (done,)
 
     def search(self, queries: torch.Tensor, k: int):
         if self.world == 1 and hasattr(self.backend, "search_unsharded"):
             return self.backend.search_unsharded(queries, k)
-        local = self.backend.search_packed(queries, k)  # [B, k]
-        if self.world == 1:
-            gathered = local.unsqueeze(0)
-        else:
-            # dim-0 concatenation form (accepted by both RCCL and gloo), viewed as [W, B, k]
-            if local.is_cuda and dist.get_backend(self.group) == "gloo":
-                # rehearsal path (no RCCL): stage through the host
-                host = torch.empty((self.world * local.shape[0], local.shape[1]), dtype=local.dtype)
-                dist.all_gather_into_tensor(host, local.cpu(), group=self.group)
-                flat = host.to(local.device)
-            else:
-                flat = torch.empty((self.world * local.shape[0], local.shape[1]), dtype=local.dtype,
-                                   device=local.device)
-                dist.all_gather_into_tensor(flat, local, group=self.group)
-            gathered = flat.view(self.world, local.shape[0], local.shape[1])
-        return self.backend.merge(gathered, k)
+        local = self.search_begin(queries, k)  # [B, k]
+        out = self.search_end(local, k)
+        if len(out) == 4:
+            out[3].synchronize()
+            out = out[:3]
+        return out

@@ -59,6 +59,9 @@ typedef int32_t fsgpu_status;
  * SSE2 is the reference's default build (no +avx2 in .cargo/config.toml). */
 #define FSGPU_HREDUCE_SSE2 0 /* ((v0+v2)+(v1+v3)) + ((v4+v6)+(v5+v7)) */
 #define FSGPU_HREDUCE_AVX 1  /* ((v0+v4)+(v2+v6)) + ((v1+v5)+(v3+v7)) */
+#define FSGPU_HREDUCE_SEQ 2  /* (((v0+v1)+v2)+v3) + (((v4+v5)+v6)+v7): f32x8 as a.reduce_add() + b.reduce_add() over a
+                              * left-to-right f32x4 sum (the fallback shape `wide` has shipped); INTEGRATION.md shows how a
+                              * maintainer finds out which of the three the Rust build uses */
 
 typedef struct fsgpu_index fsgpu_index;     /* device-resident VectorIndex (lib.rs:819) */
 typedef struct fsgpu_m2v fsgpu_m2v;         /* Model2VecEmbedder (embed/src/model2vec_embedder.rs:55) */
@@ -216,6 +219,44 @@ fsgpu_status fsgpu_search_topk_4bit_two_pass(fsgpu_index *idx, const float *quer
 fsgpu_status fsgpu_gather_dot(fsgpu_index *idx, const float *query, uint32_t query_len, const uint32_t *rows,
                               uint32_t n, float *out_scores);
 
+/* ---- row-sharded index over the GPUs of one node ---- */
+/* The reference's only partitioning is scan_parallel's contiguous row chunks merged by merge_partial_heaps
+ * (crates/frankensearch-index/src/search.rs:1013-1036,1704-1720).  A sharded handle is the same shape across GPUs, inside the
+ * library, so that the host makes ONE call per search: shard r (on devices[r]) owns the contiguous rows
+ * [r*ceil(N/ndev), ...) and reports global row ids; queries are replicated; each shard scans on its own stream from its own
+ * host thread; one ncclAllGather (RCCL over xGMI, nq*k*8 bytes per shard) gathers the packed per-shard top-k lists and the
+ * root device merges them under the reference order.  Results are identical to an unsharded index over the same rows. */
+typedef struct fsgpu_sharded fsgpu_sharded;
+#define FSGPU_EXCHANGE_AUTO 0      /* RCCL when the devices are distinct and librccl.so.1 loads, else peer copies */
+#define FSGPU_EXCHANGE_RCCL 1      /* ncclCommInitAll + ncclAllGather; creation fails if RCCL cannot be used */
+#define FSGPU_EXCHANGE_PEER_COPY 2 /* device-to-device copies into the root's gather buffer (also: several shards on ONE
+                                      device, a rehearsal of the N-way path on fewer GPUs — RCCL wants one rank per device) */
+/* VectorIndex::open for a host slab of nrows x dim little-endian f16 rows, split over devices[0..ndev).  live_bitmap as in
+ * fsgpu_index_create (bit r = global row r is live; NULL = all live). */
+fsgpu_status fsgpu_sharded_create(const int32_t *devices, uint32_t ndev, uint32_t dim, uint64_t nrows, const void *slab_f16_le,
+                                  const uint64_t *live_bitmap, int32_t exchange, fsgpu_sharded **out);
+/* Zero-copy variant: shard r adopts (does not free) shard_rows[r] rows already resident on devices[r] (shard_live_dev and its
+ * entries may be NULL); global row ids follow the order of the shards. */
+fsgpu_status fsgpu_sharded_create_device(const int32_t *devices, uint32_t ndev, uint32_t dim, const uint64_t *shard_rows,
+                                         const void *const *shard_slabs_dev, const uint64_t *const *shard_live_dev,
+                                         int32_t exchange, fsgpu_sharded **out);
+void fsgpu_sharded_destroy(fsgpu_sharded *idx);
+uint64_t fsgpu_sharded_record_count(const fsgpu_sharded *idx);
+uint32_t fsgpu_sharded_dimension(const fsgpu_sharded *idx);
+uint32_t fsgpu_sharded_shard_count(const fsgpu_sharded *idx);
+int32_t fsgpu_sharded_exchange_mode(const fsgpu_sharded *idx); /* FSGPU_EXCHANGE_RCCL or FSGPU_EXCHANGE_PEER_COPY, as chosen */
+fsgpu_status fsgpu_sharded_shard_range(const fsgpu_sharded *idx, uint32_t shard, uint64_t *row_lo, uint64_t *row_hi);
+fsgpu_status fsgpu_sharded_set_hreduce(fsgpu_sharded *idx, int32_t mode);
+/* VectorIndex::search_top_k(query, limit, None) for nq host queries over all shards (exact kernels); outputs as
+ * fsgpu_search_topk.  k <= 256 and dim % 8 == 0 (the packed lists of the fused tiers are what travels). */
+fsgpu_status fsgpu_sharded_search_topk(fsgpu_sharded *idx, const float *queries, uint32_t nq, uint32_t query_len, uint32_t k,
+                                       uint32_t *out_rows, float *out_scores, uint32_t *out_counts);
+/* Same answers through the matrix-core batched path of every shard (fsgpu_search_topk_batched); *out_fallbacks (optional) sums
+ * the per-shard exact fallbacks. */
+fsgpu_status fsgpu_sharded_search_topk_batched(fsgpu_sharded *idx, const float *queries, uint32_t nq, uint32_t query_len,
+                                               uint32_t k, uint32_t *out_rows, float *out_scores, uint32_t *out_counts,
+                                               uint32_t *out_fallbacks);
+
 /* ---- index build helpers ---- */
 /* VectorIndexWriter::write_record + finish for FSVI v1 (crates/frankensearch-index/src/lib.rs:3637-3672, 3752-3943): every
  * vector must be finite with a usable norm and every doc id fit in u16 bytes (else FSGPU_ERR_INVALID_CONFIG, nothing
@@ -238,6 +279,16 @@ fsgpu_status fsgpu_fsvi_write_quant(const char *path, const char *embedder_id, c
 fsgpu_status fsgpu_encode_f32_to_f16(int32_t device, const float *src, uint64_t n, uint16_t *dst);
 /* f16 -> f32 widen (simd.rs:63-94), exposed for the exhaustive 65,536-pattern parity test. */
 fsgpu_status fsgpu_widen_f16_to_f32(int32_t device, const uint16_t *src, uint64_t n, float *dst);
+
+/* ---- bench / test fixture ---- */
+/* The reference's own bench generator (frankensearch/benches/fsvi_4bit_vs_incumbent.rs:56-101,344-365) run on the GPU so that
+ * a 10M- or 50M-row corpus never crosses PCIe: xorshift64 raw_vector, `clusters` normalised centroids
+ * (seed 0xc0000000 + c), vector i = normalize(centroid[i % clusters] + noise * raw_vector(seed_base + i)) for
+ * i in [first, first + n).  as_f16 = 1: out_dev receives n x dim little-endian f16 rows (corpus: seed_base 1);
+ * as_f16 = 0: n x dim f32 (queries: seed_base 0xdead0000).  The bytes equal the CPU generator's (same operation order).
+ * hip_stream may be NULL (default stream); the call returns after the kernels have finished. */
+fsgpu_status fsgpu_bench_fixture_device(int32_t device, uint64_t first, uint64_t n, uint32_t dim, uint32_t clusters, float noise,
+                                        uint64_t seed_base, int32_t as_f16, void *out_dev, void *hip_stream);
 
 /* ---- Model2Vec (potion) ---- */
 /* Model2VecEmbedder (embed/src/model2vec_embedder.rs:55-58): table is [vocab,dim] f32 row-major (host). */
@@ -336,6 +387,9 @@ fsgpu_status fsgpu_index_scan_stats(fsgpu_index *idx, double *total_ms, uint64_t
 /* Filtered searches (allow bitmap given) answered by scoring only the allowed rows (try_gather_filtered,
  * crates/frankensearch-index/src/search.rs:1114-1180: taken when allowed * 50 < rows) and by the masked full scan. */
 fsgpu_status fsgpu_index_filter_stats(fsgpu_index *idx, uint64_t *gathered, uint64_t *scanned);
+/* Name of the template instantiation the last batched main pass launched in this process ran ("" before the first one), spelled as
+ * rocprofv3 prints it: lets bench.py tie a committed PMC summary to the kernel that actually ran. */
+const char *fsgpu_last_main_pass_kernel(void);
 /* Selects the scan kernel variant (0 = default) — used by bench A/B runs only. */
 fsgpu_status fsgpu_index_set_variant(fsgpu_index *idx, int32_t variant);
 

@@ -111,6 +111,11 @@ static inline uint16_t load_le16(const uint8_t *p) { return (uint16_t)(p[0] | ((
 
 static inline float hreduce8(const float v[8], int mode) {
     /* wide::f32x8::reduce_add — third-party, see fs_oracle.h. */
+    if (mode == FSO_HREDUCE_SEQ) {
+        float a = ((v[0] + v[1]) + v[2]) + v[3];
+        float b = ((v[4] + v[5]) + v[6]) + v[7];
+        return a + b;
+    }
     if (mode == FSO_HREDUCE_AVX) {
         float a = v[0] + v[4], b = v[1] + v[5], c = v[2] + v[6], d = v[3] + v[7];
         float lo = a + c, hi = b + d;

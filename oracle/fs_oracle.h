@@ -36,6 +36,7 @@ extern "C" {
 /* Horizontal-reduce order of the final 8-lane vector (see header comment). */
 #define FSO_HREDUCE_SSE2 0 /* ((v0+v2)+(v1+v3)) + ((v4+v6)+(v5+v7)) */
 #define FSO_HREDUCE_AVX 1  /* ((v0+v4)+(v2+v6)) + ((v1+v5)+(v3+v7)) */
+#define FSO_HREDUCE_SEQ 2  /* (((v0+v1)+v2)+v3) + (((v4+v5)+v6)+v7): f32x8 = a.reduce_add() + b.reduce_add(), sequential f32x4 */
 
 /* Status codes mirror SearchError variants (crates/frankensearch-core/src/error.rs:57-176). */
 #define FSO_OK 0

@@ -34,7 +34,11 @@ float fso_dot_f16_f32_avx2_impl(const uint8_t *row, const float *q, size_t dim, 
     float v[8];
     _mm256_storeu_ps(v, sum);
     float result;
-    if (hreduce == FSO_HREDUCE_AVX) {
+    if (hreduce == FSO_HREDUCE_SEQ) {
+        float a = ((v[0] + v[1]) + v[2]) + v[3];
+        float b = ((v[4] + v[5]) + v[6]) + v[7];
+        result = a + b;
+    } else if (hreduce == FSO_HREDUCE_AVX) {
         float a = v[0] + v[4], b = v[1] + v[5], cc = v[2] + v[6], d = v[3] + v[7];
         float lo = a + cc, hi = b + d;
         result = lo + hi;

@@ -17,6 +17,7 @@ _SO = os.path.join(_HERE, "_build", "libfsoracle.so")
 
 HREDUCE_SSE2 = 0
 HREDUCE_AVX = 1
+HREDUCE_SEQ = 2
 
 OK = 0
 ERR_DIMENSION_MISMATCH = 1

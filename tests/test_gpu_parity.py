@@ -191,6 +191,22 @@ def test_hreduce_avx_order(fa, oracle):
     assert_same(fa, oracle, slab, q, 300, hreduce=1)
 
 
+def test_hreduce_sequential_order(fa, oracle):
+    # FSGPU_HREDUCE_SEQ: f32x8::reduce_add as two left-to-right f32x4 sums (simd.rs:439,563; `wide` is not vendored)
+    rng = np.random.default_rng(32)
+    slab = rand_slab(rng, 5000, 384)
+    q = rng.standard_normal((5, 384)).astype(np.float32)
+    assert_same(fa, oracle, slab, q, 10, hreduce=2)
+    assert_same(fa, oracle, slab, q, 300, hreduce=2)
+    idx = fa.VectorIndex.from_slab(slab)
+    idx.set_hreduce(2)
+    many = rng.standard_normal((70, 384)).astype(np.float32)
+    brows, bscores, _, _ = idx.search_batched(many, 10)
+    for qi in (0, 13, 69):
+        er, es = oracle.search_top_k(slab, many[qi], 10, hreduce=2)
+        assert np.array_equal(brows[qi], er) and np.array_equal(bits(bscores[qi]), bits(es))
+
+
 def test_runtime_dim_kernel_variant(fa, oracle):
     rng = np.random.default_rng(37)
     slab = rand_slab(rng, 9001, 384)

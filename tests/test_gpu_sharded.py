@@ -1,0 +1,139 @@
+"""The row-sharded index behind ONE C-ABI handle (fsgpu_sharded_*) against the oracle and against the
+unsharded index: bit-exact row ids and f32 score bits.
+
+Reference shape: scan_parallel's contiguous chunks + merge_partial_heaps
+(crates/frankensearch-index/src/search.rs:1013-1036,1704-1720) and its test parallel_matches_sequential (:2084-2113).
+On a one-GPU box the N-way logic is rehearsed with several shards on device 0 (peer-copy exchange; RCCL wants one rank per
+device) and RCCL itself with a 1-rank communicator; with >= 2 GPUs visible the real all-gather runs over
+min(visible, 8) devices.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import frankensearch_amd as fa_mod
+    from frankensearch_amd.build import build
+
+    build()
+    assert fa_mod._lib.lib().fsgpu_device_count() >= 1, "no GPU visible"
+    return fa_mod
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def rand_slab(rng, n, dim):
+    return rng.standard_normal((n, dim)).astype(np.float16).view(np.uint16)
+
+
+def check_against_oracle(oracle, slab, live, queries, k, rows, scores, counts, hreduce=0):
+    for qi in range(queries.shape[0]):
+        er, es = oracle.search_top_k(slab, queries[qi], k, live=live, hreduce=hreduce)
+        assert int(counts[qi]) == len(er), (qi, counts[qi], len(er))
+        assert np.array_equal(rows[qi, :len(er)], er), qi
+        assert np.array_equal(bits(scores[qi, :len(es)]), bits(es)), qi
+
+
+@pytest.mark.parametrize("shards", [1, 2, 3, 8])
+def test_virtual_shards_on_one_device_match_oracle(fa, oracle, shards):
+    rng = np.random.default_rng(100 + shards)
+    n, dim = 20_011, 64   # not a multiple of the shard count or of 64: ragged last shard, bitmap words split across shards
+    slab = rand_slab(rng, n, dim)
+    slab[7] = slab[n - 1]            # a tie across the first and the last shard: lower row wins
+    live = rng.random(n) > 0.1
+    q = rng.standard_normal((5, dim)).astype(np.float32)
+    idx = fa.NativeShardedIndex.from_slab(slab, [0] * shards, live=live, exchange=fa.NativeShardedIndex.EXCHANGE_PEER_COPY)
+    assert idx.shard_count() == shards and idx.record_count() == n and idx.dimension() == dim
+    per = (n + shards - 1) // shards
+    assert [idx.shard_range(r) for r in range(shards)] == [(min(n, r * per), min(n, (r + 1) * per)) for r in range(shards)]
+    for k in (1, 10, 100, 256):
+        rows, scores, counts = idx.search_batch(q, k)
+        check_against_oracle(oracle, slab, live, q, k, rows, scores, counts)
+    with pytest.raises(fa.DimensionMismatch):
+        idx.search_batch(q[:, :32], 3)
+    with pytest.raises(fa.InvalidConfig):
+        idx.search_batch(q, 300)     # the exchange carries the fused tiers' packed lists
+    idx.set_hreduce(2)
+    rows, scores, counts = idx.search_batch(q, 10)
+    check_against_oracle(oracle, slab, live, q, 10, rows, scores, counts, hreduce=2)
+    idx.close()
+
+
+def test_more_shards_than_rows_and_empty_index(fa, oracle):
+    rng = np.random.default_rng(5)
+    slab = rand_slab(rng, 3, 16)
+    q = rng.standard_normal((2, 16)).astype(np.float32)
+    idx = fa.NativeShardedIndex.from_slab(slab, [0] * 5, exchange=2)
+    rows, scores, counts = idx.search_batch(q, 10)      # k > N: collect-all semantics, 3 hits
+    check_against_oracle(oracle, slab, None, q, 10, rows, scores, counts)
+    assert counts.tolist() == [3, 3]
+    empty = fa.NativeShardedIndex.from_slab(np.zeros((0, 16), np.uint16), [0, 0], exchange=2)
+    assert empty.search_batch(q, 4)[2].tolist() == [0, 0]
+
+
+def test_batched_path_through_the_sharded_handle(fa, oracle):
+    # every shard large enough for the matrix-core batched path (>= 4 x 8192 rows); same answers as the exact kernels
+    rng = np.random.default_rng(9)
+    n, dim, k = 140_000, 128, 10
+    slab = oracle.clustered_corpus_f16(0, n, dim)
+    q = np.stack([oracle.clustered_query(i, dim) for i in range(150)])
+    whole = fa.VectorIndex.from_slab(slab)
+    wr, ws, wc = whole.search_batch(q, k)
+    for shards in (1, 2, 4):
+        idx = fa.NativeShardedIndex.from_slab(slab, [0] * shards, exchange=2)
+        rows, scores, counts, fb = idx.search_batch(q, k, batched=True)
+        assert np.array_equal(rows, wr) and np.array_equal(bits(scores), bits(ws)) and np.array_equal(counts, wc)
+        er, es, ec = idx.search_batch(q[:9], k)
+        assert np.array_equal(er, wr[:9]) and np.array_equal(bits(es), bits(ws[:9]))
+        idx.close()
+    for qi in (0, 77, 149):
+        orow, osc = oracle.search_top_k(slab, q[qi], k)
+        assert np.array_equal(wr[qi], orow) and np.array_equal(bits(ws[qi]), bits(osc))
+
+
+def test_rccl_all_gather_over_the_visible_devices(fa, oracle):
+    """ncclCommInitAll + ncclAllGather inside libfsgpu.so: world = min(visible GPUs, 8) (1 on a one-GPU box: a 1-rank
+    communicator still goes through RCCL's init, the collective launch and the gather layout)."""
+    world = min(fa._lib.lib().fsgpu_device_count(), 8)
+    rng = np.random.default_rng(12)
+    n, dim, k = 50_000, 384, 10
+    slab = rand_slab(rng, n, dim)
+    q = rng.standard_normal((12, dim)).astype(np.float32)
+    idx = fa.NativeShardedIndex.from_slab(slab, list(range(world)), exchange=fa.NativeShardedIndex.EXCHANGE_RCCL)
+    assert idx.exchange_mode() == fa.NativeShardedIndex.EXCHANGE_RCCL and idx.shard_count() == world
+    rows, scores, counts = idx.search_batch(q, k)
+    check_against_oracle(oracle, slab, None, q, k, rows, scores, counts)
+    brows, bscores, bcounts, _ = idx.search_batch(q, k, batched=True)
+    assert np.array_equal(brows, rows) and np.array_equal(bits(bscores), bits(scores))
+    # many calls back to back: the workers, the staging buffer and the communicator are reused
+    for _ in range(20):
+        r2, s2, _ = idx.search_batch(q, k)
+        assert np.array_equal(r2, rows) and np.array_equal(bits(s2), bits(scores))
+    idx.close()
+    with pytest.raises(fa.InvalidConfig):
+        fa.NativeShardedIndex.from_slab(slab, [0, 0], exchange=fa.NativeShardedIndex.EXCHANGE_RCCL)  # one rank per device
+
+
+def test_multi_gpu_matches_unsharded_bit_for_bit(fa, oracle):
+    world = min(fa._lib.lib().fsgpu_device_count(), 8)
+    if world < 2:
+        pytest.skip("needs >= 2 GPUs (the driver's multi-GPU box); the one-GPU rehearsal is test_virtual_shards_*")
+    n, dim, k = 400_000, 384, 10
+    slab = oracle.clustered_corpus_f16(0, n, dim)
+    q = np.stack([oracle.clustered_query(i, dim) for i in range(200)])
+    whole = fa.VectorIndex.from_slab(slab)
+    wr, ws, wc = whole.search_batch(q, k)
+    idx = fa.NativeShardedIndex.from_slab(slab, list(range(world)))   # EXCHANGE_AUTO must pick RCCL here
+    assert idx.exchange_mode() == fa.NativeShardedIndex.EXCHANGE_RCCL
+    rows, scores, counts = idx.search_batch(q, k)
+    assert np.array_equal(rows, wr) and np.array_equal(bits(scores), bits(ws)) and np.array_equal(counts, wc)
+    rows, scores, counts, _ = idx.search_batch(q, k, batched=True)
+    assert np.array_equal(rows, wr) and np.array_equal(bits(scores), bits(ws))
+    peer = fa.NativeShardedIndex.from_slab(slab, list(range(world)), exchange=2)
+    rows, scores, counts = peer.search_batch(q, k)
+    assert np.array_equal(rows, wr) and np.array_equal(bits(scores), bits(ws))

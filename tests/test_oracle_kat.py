@@ -93,6 +93,40 @@ def test_f32_to_f16_rne_matches_ieee(oracle):
 
 
 # ---------------------------------------------------------------- dot
+def rust_dot_bits_vectors():
+    """The 16 fixed (row, query) pairs of the INTEGRATION.md `#[test]` a maintainer runs in the Rust workspace to print
+    dot_product_f16_bytes_f32(...).to_bits() (simd.rs:361-446): dim 8*(1 + i % 6) so every lane of the final 8-lane add
+    (wide::f32x8::reduce_add, simd.rs:439,563) carries a different magnitude; values are small integers / 64 and exact in f16."""
+    out = []
+    for i in range(16):
+        dim = 8 * (1 + i % 6)
+        row = np.array([((i * 37 + j * 11) % 29 - 14) / 64.0 for j in range(dim)], dtype=np.float16)
+        q = np.array([np.float32((i * 13 + j * 7) % 23 - 11) / np.float32(7.0) for j in range(dim)], dtype=np.float32)  # f32 division, as in Rust
+        out.append((row.view(np.uint16), q))
+    return out
+
+
+def test_hreduce_modes_disagree_on_the_fixed_vectors(oracle):
+    # the golden file can only pin the order if the three candidate orders give different bits somewhere
+    bits = [[int(np.float32(oracle.dot_f16_f32(r, q, m)).view(np.uint32)) for r, q in rust_dot_bits_vectors()] for m in (0, 1, 2)]
+    assert bits[0] != bits[1] and bits[0] != bits[2] and bits[1] != bits[2]
+
+
+def test_rust_dot_bits_golden_selects_the_hreduce_mode(oracle):
+    """tests/golden/rust_dot_bits.json = {"bits": [16 u32]} as printed by the Rust test in INTEGRATION.md.  Absent in this
+    repo (no Rust toolchain here): the order of wide::f32x8::reduce_add stays UNPINNED and the test is skipped."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "rust_dot_bits.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/rust_dot_bits.json not provided (see INTEGRATION.md)")
+    want = [int(b) for b in json.load(open(path))["bits"]]
+    matches = [m for m in (0, 1, 2)
+               if [int(np.float32(oracle.dot_f16_f32(r, q, m)).view(np.uint32)) for r, q in rust_dot_bits_vectors()] == want]
+    assert matches, "none of FSGPU_HREDUCE_{SSE2,AVX,SEQ} reproduces the Rust bits: a fourth order is in use"
+    print("Rust build uses hreduce mode", matches[0])
+
+
 def numpy_dot_reference_order(row_u16, q, hreduce=0):
     """Independent numpy statement of simd.rs:532-571 (each numpy f32 op is one IEEE op)."""
     dim = q.size
@@ -112,8 +146,10 @@ def numpy_dot_reference_order(row_u16, q, hreduce=0):
     v = (s[0] + s[1]) + (s[2] + s[3])
     if hreduce == 0:
         r = ((v[0] + v[2]) + (v[1] + v[3])) + ((v[4] + v[6]) + (v[5] + v[7]))
-    else:
+    elif hreduce == 1:
         r = ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]))
+    else:
+        r = (((v[0] + v[1]) + v[2]) + v[3]) + (((v[4] + v[5]) + v[6]) + v[7])
     r = np.float32(r)
     for i in range(chunks * 8, dim):
         r = np.float32(np.float64(w[i]) * np.float64(q[i]) + np.float64(r))  # fma: exact product, one rounding
@@ -124,7 +160,7 @@ def numpy_dot_reference_order(row_u16, q, hreduce=0):
 def test_dot_matches_numpy_restatement_and_fast_path_bitwise(oracle, dim):
     # simd.rs:2423 avx2_f16dot_matches_generic (bit-identical across many shapes)
     rng = np.random.default_rng(dim + 3)
-    for hreduce in (0, 1):
+    for hreduce in (0, 1, 2):
         for _ in range(4):
             row = rng.standard_normal(dim).astype(np.float16).view(np.uint16)
             q = rng.standard_normal(dim).astype(np.float32)

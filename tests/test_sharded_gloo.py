@@ -77,6 +77,9 @@ def _worker(rank, world, port, n, dim, k, ret):
     lo, hi = shard_range(n, rank, world)
     idx = ShardedVectorIndex(OracleShardBackend(slab[lo:hi], lo))
     rows, scores, counts = idx.search(torch.from_numpy(queries), k)
+    # the two halves bench.py pipelines (scan of step i+1 over the exchange of step i) give the same answer
+    r2, s2, c2 = idx.search_end(idx.search_begin(torch.from_numpy(queries), k), k)
+    assert torch.equal(r2, rows) and torch.equal(c2, counts) and torch.equal(s2.view(torch.int32), scores.view(torch.int32))
     if rank == 0:
         ret["rows"] = rows.numpy().view(np.uint32).copy()
         ret["scores"] = scores.numpy().copy()
