@@ -143,7 +143,7 @@ def cpu_baseline_and_parity(slab_dev: torch.Tensor, queries: torch.Tensor, k: in
                    np.array_equal(g_scores[qi, :len(es)].view(np.uint32), es.view(np.uint32)))
     dt = time.perf_counter() - t0
     # one thread (anchor: the reference's published 18.9 GB/s per thread, docs/PERF_LEDGER.md:2149) on a smaller sample
-    one_rows = min(sample, 250_000)
+    one_rows = min(sample, 1_500_000)   # 1.15 GB of rows: past the host's last-level cache
     oracle.search_top_k(host[:one_rows], q_host[0], k, nthreads=1)
     t1 = time.perf_counter()
     for qi in range(6):
@@ -673,6 +673,14 @@ def main() -> None:
             # the same search through ONE C-ABI handle (fsgpu_sharded_*: RCCL inside libfsgpu.so), timed in a child
             # process with a hard limit once the ranks have left their GPUs — a problem there cannot cost the line above
             line["sharded_handle"] = sharded_handle_leg(args, world)
+        # RCCL prints its version banner through C stdio, which sits in libc's buffer until exit when stdout is a pipe: push
+        # it out first so that the JSON line is the last thing on stdout
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(line), flush=True)
 
 

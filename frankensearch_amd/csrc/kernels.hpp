@@ -144,7 +144,13 @@ hipError_t launch_prepare_queries_i8(const float* q, uint32_t nq, uint32_t nq_pa
 
 constexpr uint32_t kMfmaMaxSlots = 32;           // candidate slots per (block, query) staged in LDS
 constexpr uint32_t kMfmaSpillCountStride = 16;  // uint32 counters 64 bytes apart
+constexpr uint32_t kWideSlots = 16;               // ... by the register-resident-query main pass (mfma_wide.hip)
 bool scan_mfma_supported(int dim);
+// mfma_wide.hip: main pass with the queries in registers and the row tiles in an LDS-DMA ring; query_tiles 2 = 256, 3 = 384
+// queries per launch; one candidate list of args.slots <= kWideSlots entries per (query, block)
+bool scan_wide_supported(int dim, int elem_bytes);
+hipError_t launch_scan_wide(const MfmaScanArgs& args, int query_tiles, int grid, hipStream_t stream, int* occupancy);
+void note_main_pass_kernel(const char* name);  // remembers the instantiation the last main pass ran (last_main_pass_kernel)
 const char* last_main_pass_kernel();  // template instantiation of the last batched main pass launched, as rocprofv3 names it
 // shape: see mfma_scan.hip (0 = 64 queries; 1..3 = 128 queries with different row tiling / buffering)
 int scan_mfma_waves_per_block(int shape);

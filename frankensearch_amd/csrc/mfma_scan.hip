@@ -659,6 +659,7 @@ __global__ __launch_bounds__(256) void prepare_queries_i8_kernel(const float* __
 
 static std::atomic<const char*> g_last_main_pass_kernel{""};
 const char* last_main_pass_kernel() { return g_last_main_pass_kernel.load(std::memory_order_relaxed); }
+void note_main_pass_kernel(const char* name) { g_last_main_pass_kernel.store(name, std::memory_order_relaxed); }
 
 bool scan_mfma_supported(int dim) { return dim == 128 || dim == 256 || dim == 384; }
 

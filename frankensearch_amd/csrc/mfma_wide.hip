@@ -1,0 +1,394 @@
+// mfma_wide.hip — the main pass of the batched scan at 256 / 384 queries per pass over the slab.
+//
+// scan_mfma_kernel (mfma_scan.hip) keeps the f16 queries of a group in LDS (800 bytes each): 128 queries fill 100 KB, so
+// one pass over the slab serves 128 queries and the step is HBM-bound with the matrix pipe mostly idle.  Here the roles
+// are swapped:
+//   * the QUERIES live in registers: each of the block's 8 waves owns QT query tiles of 16 (QT = 2: 32 queries, 256 per
+//     block) and keeps their B fragments for the whole dimension resident (QT x dim/32 x 4 VGPRs = 96 at dim 384);
+//   * the ROWS go through LDS: a ring of row tiles is filled by LDS-DMA (global_load_lds_dwordx4: no staging registers,
+//     no ds_write pass, no ds_bpermute transpose) in the coalesced quad layout of the exact kernels (four consecutive
+//     lanes fetch 64 contiguous bytes), several tiles ahead of the tile being consumed; every wave reads each row tile's
+//     A fragments with ds_read_b128 and multiplies them with its own queries.
+// One s_barrier per tile; the DMA queue is never drained inside the loop (counted s_waitcnt vmcnt).  The DMA and its
+// waits are inline asm: hipcc would otherwise wait for the newest LDS-DMA before every ds_read (it cannot tell the ring
+// slots apart), which serialises load and compute.
+//
+// LDS image of one DMA instruction (1 KB = 16 rows x 64 bytes = one MFMA k-step of a 16-row sub-tile): the DMA writes
+// lane-linear (lane L at L*16), lane L = 4p + c fetches the 16-byte chunk c ^ f(p) of row p, f(p) = (4 - (p >> 2)) & 3.
+// A fragment lane (row i, k-group g) then reads position i*64 + ((g ^ f(i)) * 16): with this swizzle each of the four
+// 16-lane groups ds_read_b128 is served in ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...; MI355X_MICROARCH.md, LDS)
+// covers all 64 banks exactly once.
+//
+// Arithmetic, candidate filter and outputs are those of scan_mfma_kernel's main pass (approximate f16-query scores or
+// exact int8 scores, rows at or above tau kept in per-(query, block) lists), so the selection / exact re-score that
+// follows is unchanged and the final hits are still bit-identical to the reference order.  The live / allow bitmaps
+// are consulted only for the few rows that pass the threshold, and those rows are appended straight to the block's
+// global list (LDS keeps one counter per query), which leaves the LDS to the ring.
+#include <atomic>
+#include <cstdlib>
+#include <string>
+#include <type_traits>
+
+#include "scan_common.hpp"
+
+namespace fsgpu {
+
+using namespace scan_detail;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// One LDS-DMA: every lane's 16 bytes at gsrc land at lds_dst + lane * 16 (lds_dst wave-uniform).  Invisible to hipcc's
+// s_waitcnt bookkeeping: counted by hand below (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+}  // namespace
+
+// ROWB = bytes per slab row (dim * 2 for f16 rows, dim for int8 rows), EB as in scan_mfma_kernel, QT = query tiles of 16
+// per wave (8 waves: 128 * QT queries per pass), NSLOT = ring slots.
+//
+// Schedule of one tile (NC chunks of CK k-steps x 2 sub-tiles; fragments double-buffered in registers):
+//     [entry: chunk 0's fragment reads are already in flight — issued during the previous tile]
+//     reads(chunk 1) | MFMA(chunk 0) | s_waitcnt vmcnt + s_barrier: tile n+1 has landed for everyone and tile n-1's slot is
+//     free -> DMA(tile n+NSLOT-1) | reads(chunk 2) | MFMA(chunk 1) | ... | reads(chunk 0 of tile n+1) | MFMA(last chunk)
+// so neither the LDS latency nor the barrier sits between two MFMA groups of a wave with nothing else to issue.
+template <int ROWB, int EB, int QT, int NSLOT, int DBG = 0>   // DBG (timing experiments only): 1 = no MFMAs, 2 = no DMA
+__global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
+    using acc_t = std::conditional_t<EB == 2, f32x4, i32x4>;
+    constexpr int WPB = 8, NT = WPB * 64;
+    constexpr int KS = ROWB / 64;                                   // MFMA k-steps (64 bytes of a row each)
+    constexpr int TR = ROWB >= 512 ? 32 : 64;                       // rows per tile
+    constexpr int RS = TR / 16;                                     // 16-row sub-tiles per tile
+    constexpr int NI = RS * KS;                                     // DMA instructions per tile (1 KB each)
+    constexpr int PW = NI / WPB;                                    // ... per wave
+    static_assert(NI % WPB == 0 && PW >= 1, "a tile's DMA instructions divide evenly over the 8 waves");
+    static_assert(RS % 2 == 0, "sub-tiles are consumed in pairs");
+    constexpr int CK = KS == 12 ? 3 : (KS >= 2 ? KS / 2 : 1);       // k-steps per chunk
+    constexpr int NCH = KS / CK;                                    // chunks per sub-tile pair
+    constexpr int NC = (RS / 2) * NCH;                              // chunks per tile
+    static_assert(KS % CK == 0 && NC % 2 == 0, "an even number of chunks per tile: the register double buffer starts every tile in the same phase");
+    static_assert(NSLOT >= 4, "tile n is consumed while n+1 .. n+NSLOT-2 are in flight and n-1's slot is being refilled");
+    constexpr int TILE_BYTES = TR * ROWB;
+    constexpr int NQ = WPB * QT * 16;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const uint32_t ring = (uint32_t)(uintptr_t)smem;                // LDS byte address of the ring (low half of the flat address)
+    int* lcnt = reinterpret_cast<int*>(smem + (size_t)NSLOT * TILE_BYTES);   // entries appended per query by this block
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fk = lane >> 4;
+    const int slots = (int)args.slots;
+    for (int i = tid; i < NQ; i += NT) lcnt[i] = 0;
+
+    // this wave's queries: B fragments for the whole dimension, resident in registers
+    const int q0 = wave * QT * 16;
+    half8 bq[QT][KS];
+    float tau[QT];
+    {
+        const unsigned char* qbase = static_cast<const unsigned char*>(args.queries);
+#pragma unroll
+        for (int nt = 0; nt < QT; ++nt) {
+            const unsigned char* qp = qbase + (size_t)(q0 + nt * 16 + frow) * ROWB + fk * 16;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bq[nt][ks] = *reinterpret_cast<const half8*>(qp + ks * 64);
+            tau[nt] = args.tau[q0 + nt * 16 + frow];
+        }
+        // the fragments must have ARRIVED before the first DMA is issued: hipcc places the wait for a load at its first use,
+        // which is inside the tile loop — a vmcnt(0) there would drain the DMA ring on every iteration
+#pragma unroll
+        for (int nt = 0; nt < QT; ++nt) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(bq[nt][ks]));
+            asm volatile("" : "+v"(tau[nt]));
+        }
+    }
+
+    // Tiles: this block's n-th tile is n * grid + ((block - n) mod grid) — neighbouring tiles go to different blocks (a run
+    // of similar rows spreads over many blocks' lists) and the rotation keeps rows that recur with a power-of-two period
+    // from landing in the same blocks; args.reverse walks the slab from its end.  The whole slab is visited (the rows of
+    // the stage-1 sample included: the sample only tightened tau, its pool is not merged for this kernel), so the
+    // sequence needs no skip test and is advanced with a handful of scalar adds.
+    const uint32_t ntiles = (args.nrows + TR - 1) / TR;
+    const uint32_t grid = gridDim.x;
+    const uint32_t rounds = (ntiles + grid - 1) / grid;
+    const uint32_t last_row = args.nrows - 1;
+    const unsigned char* slab = reinterpret_cast<const unsigned char*>(args.slab);
+    struct Cursor {
+        uint32_t n, base, rot;   // round, n * grid, n mod grid
+    };
+    auto cursor_tile = [&](const Cursor& c) -> uint32_t {   // >= ntiles: nothing to scan in this round
+        const uint32_t b = blockIdx.x;
+        const uint32_t t = c.base + (b >= c.rot ? b - c.rot : b + grid - c.rot);
+        return args.reverse ? rounds * grid - 1 - t : t;
+    };
+    auto cursor_next = [&](Cursor& c) {
+        ++c.n;
+        c.base += grid;
+        c.rot = c.rot + 1 == grid ? 0 : c.rot + 1;
+    };
+    // the first / next round at or after the cursor whose tile exists (only the first or the last round can be ragged)
+    auto cursor_seek = [&](Cursor& c) {
+        while (c.n < rounds && cursor_tile(c) >= ntiles) cursor_next(c);
+    };
+
+    // DMA of one tile into a ring slot: wave w issues instructions j = w * PW + x, instruction j = (sub-tile j / KS,
+    // k-step j % KS).  Rows past the end are clamped to the last row (their scores are discarded below).
+    const int dma_p = lane >> 2, dma_c = lane & 3;
+    const int dma_chunk = dma_c ^ ((4 - (dma_p >> 2)) & 3);
+    auto issue_tile = [&](uint32_t t, uint32_t slot) {
+        const uint32_t row0 = t * TR;
+#pragma unroll
+        for (int x = 0; x < PW; ++x) {
+            const int j = wave * PW + x;
+            const int s = j / KS, ks = j - s * KS;
+            uint32_t row = row0 + s * 16 + dma_p;
+            row = row < args.nrows ? row : last_row;
+            const unsigned char* g = slab + (size_t)row * ROWB + ks * 64 + dma_chunk * 16;
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(ring + slot * TILE_BYTES + (uint32_t)j * 1024u);
+            if constexpr (DBG != 2) glds16(g, dst);
+            else asm volatile("" ::"v"(g), "s"(dst));
+        }
+    };
+
+    // fragment reads of chunk c (sub-tile pair c / NCH, k-steps (c % NCH) * CK ...) of a ring slot
+    const uint32_t a_off = (uint32_t)frow * 64u + (uint32_t)((fk ^ ((4 - (frow >> 2)) & 3)) << 4);
+    auto read_chunk = [&](uint32_t slot, int c, half8 (&f)[2][CK]) {
+        const unsigned char* base = smem + (size_t)slot * TILE_BYTES + a_off;
+        const int sp = (c / NCH) * 2, k0 = (c % NCH) * CK;
+#pragma unroll
+        for (int kk = 0; kk < CK; ++kk)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) f[h][kk] = *reinterpret_cast<const half8*>(base + ((sp + h) * KS + k0 + kk) * 1024);
+    };
+    auto mfma_chunk = [&](int c, const half8 (&f)[2][CK], acc_t (&acc)[2][QT]) {
+        const int k0 = (c % NCH) * CK;
+        if constexpr (DBG == 1) {
+#pragma unroll
+            for (int kk = 0; kk < CK; ++kk)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) asm volatile("" ::"v"(f[h][kk]));
+            return;
+        }
+#pragma unroll
+        for (int kk = 0; kk < CK; ++kk)
+#pragma unroll
+            for (int nt = 0; nt < QT; ++nt)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    if constexpr (EB == 2)
+                        acc[h][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[h][kk], bq[nt][k0 + kk], acc[h][nt], 0, 0, 0);
+                    else
+                        acc[h][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, f[h][kk]),
+                                                                           __builtin_bit_cast(i32x4, bq[nt][k0 + kk]), acc[h][nt], 0, 0, 0);
+    };
+    // rows of a finished sub-tile pair at or above the threshold -> the block's list of their query (straight to global
+    // memory: a few entries per query and block, so LDS holds only the counters)
+    auto emit_pair = [&](uint32_t t, int sp, const acc_t (&acc)[2][QT]) {
+        // one test for the whole pair: does any of the lane's 8 x QT scores reach its query's threshold?  (max ignores
+        // NaN, and NaN >= tau is false: a NaN score never passes, as in scan_mfma_kernel)
+        bool any = false;
+#pragma unroll
+        for (int nt = 0; nt < QT; ++nt) {
+            auto m = acc[0][nt][0];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (EB == 2) m = __builtin_fmaxf(m, acc[h][nt][r]);
+                    else m = acc[h][nt][r] > m ? acc[h][nt][r] : m;
+                }
+            any |= (float)m >= tau[nt];
+        }
+        if (!any) return;  // almost always: survivors are a few hundred rows of the slab
+        if constexpr (DBG == 2) {  // (the ring holds stale bytes in the no-DMA timing experiment: keep the scores live, append nothing)
+            lcnt[q0 + frow] = 0;
+            return;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // C layout: column (query) = lane & 15, row = (lane >> 4) * 4 + reg
+            const uint32_t row0 = t * TR + (sp + h) * 16 + fk * 4;
+#pragma unroll
+            for (int nt = 0; nt < QT; ++nt) {
+                const float th = tau[nt];
+                const int q = q0 + nt * 16 + frow;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (!((float)acc[h][nt][r] >= th)) continue;
+                    const uint32_t row = row0 + r;
+                    if (row >= args.nrows) continue;
+                    if (args.live && !((args.live[row >> 6] >> (row & 63)) & 1ull)) continue;
+                    if (args.allow && !((args.allow[row >> 6] >> (row & 63)) & 1ull)) continue;
+                    const int pos = atomicAdd(&lcnt[q], 1);
+                    const u64 entry = pack((float)acc[h][nt][r], args.row_base + row);
+                    if (pos < slots) {
+                        args.cand[((size_t)q * gridDim.x + blockIdx.x) * slots + pos] = entry;
+                    } else {
+                        const uint32_t g = atomicAdd(&args.spill_count[q * kMfmaSpillCountStride], 1u);
+                        if (g < args.spill_cap) args.spill[(size_t)q * args.spill_cap + g] = entry;
+                        else args.overflow[q] = 1;
+                    }
+                }
+            }
+        }
+    };
+
+    __syncthreads();  // counters initialised (no DMA in flight yet)
+    Cursor cl{0, 0, 0};   // next tile to fetch
+    cursor_seek(cl);
+    Cursor cc = cl;       // next tile to consume
+    // prologue: NSLOT - 1 tiles in flight (tile j -> slot j mod NSLOT throughout).  Past the last real tile the DMA count
+    // is kept up with dummy tiles (the last tile again) so that the counted waits below stay exact.
+    auto fetch_next = [&](uint32_t slot) {
+        const bool real = cl.n < rounds;
+        issue_tile(real ? cursor_tile(cl) : ntiles - 1, slot);
+        if (real) {
+            cursor_next(cl);
+            cursor_seek(cl);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < NSLOT - 1; ++j) fetch_next((uint32_t)j);
+    half8 fa[2][2][CK];   // fragment double buffer: [buffer][sub-tile of the pair][k-step of the chunk]
+    wait_vmcnt<PW*(NSLOT - 2)>();          // this wave's share of tile 0 has landed ...
+    __builtin_amdgcn_s_barrier();          // ... and everyone's
+    asm volatile("" ::: "memory");
+    read_chunk(0, 0, fa[0]);
+    uint32_t slot = 0;
+    while (cc.n < rounds) {
+        const uint32_t slot_next = slot + 1 == NSLOT ? 0 : slot + 1;
+        const uint32_t t = cursor_tile(cc);
+        acc_t acc[2][QT];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (c % NCH == 0) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int nt = 0; nt < QT; ++nt) acc[h][nt] = acc_t{0, 0, 0, 0};
+            }
+            // the NEXT chunk's fragment reads go out before this chunk's MFMAs (the next tile's first chunk after the last)
+            if (c + 1 < NC) read_chunk(slot, c + 1, fa[(c + 1) & 1]);
+            else read_chunk(slot_next, 0, fa[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_chunk(c, fa[c & 1], acc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c == 0) {
+                // tile n+1: this wave's DMAs have landed (tiles n+2 .. n+NSLOT-2 may still be in flight), then everyone's;
+                // every wave is also past its last read of tile n-1, whose slot takes tile n+NSLOT-1
+                wait_vmcnt<PW*(NSLOT - 3)>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            // The DMA issue (address arithmetic + PW LDS-DMA instructions: a stretch without MFMAs) is staggered between
+            // the two waves that share a SIMD (waves w and w + 4): one right after the barrier, the other a chunk later,
+            // so that the matrix pipe always has one of them feeding it.
+            if (NC >= 2 && c <= 1) {
+                if ((wave >= 4) == (c == 1)) fetch_next(slot == 0 ? NSLOT - 1 : slot - 1);
+            } else if (NC < 2 && c == 0) {
+                fetch_next(slot == 0 ? NSLOT - 1 : slot - 1);
+            }
+            if (c % NCH == NCH - 1) emit_pair(t, (c / NCH) * 2, acc);
+        }
+        cursor_next(cc);
+        cursor_seek(cc);
+        slot = slot_next;
+    }
+    wait_vmcnt<0>();  // no DMA may outlive the block's LDS allocation
+    __syncthreads();
+    // pad the block's lists: [q][block][slots], kEmpty beyond the entries appended
+    for (int i = tid; i < NQ * slots; i += NT) {
+        const int q = i / slots, j = i - q * slots;
+        if (j >= lcnt[q]) args.cand[((size_t)q * gridDim.x + blockIdx.x) * slots + j] = kEmpty;
+    }
+}
+
+// ---- launcher ----------------------------------------------------------------------------------------------------
+
+namespace {
+
+template <int ROWB, int EB, int QT, int NSLOT, int DBG = 0>
+hipError_t launch_wide_t(const MfmaScanArgs& args, int grid, hipStream_t stream, int* occupancy) {
+    constexpr int TR = ROWB >= 512 ? 32 : 64;
+    constexpr size_t ring = (size_t)NSLOT * TR * ROWB;
+    const size_t lds = ring + (size_t)QT * 128 * 4;   // the row-tile ring + one append counter per query
+    auto kern = scan_wide_kernel<ROWB, EB, QT, NSLOT, DBG>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    if (occupancy) {
+        int blocks = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, 512, lds) != hipSuccess || blocks < 1) blocks = 1;
+        *occupancy = blocks;
+        return hipSuccess;
+    }
+    if (args.slots > kWideSlots) return hipErrorInvalidValue;
+    static const std::string name = "scan_wide_kernel<" + std::to_string(ROWB) + ", " + std::to_string(EB) + ", " +
+                                    std::to_string(QT) + ", " + std::to_string(NSLOT) + ">";
+    note_main_pass_kernel(name.c_str());
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, args);
+    return hipGetLastError();
+}
+
+template <int EB, int QT>
+hipError_t launch_wide_d(const MfmaScanArgs& args, int grid, hipStream_t stream, int* occupancy) {
+    switch (args.dim * EB / 2) {  // row length in 2-byte units
+        case 384: {
+            static const int dbg = [] { const char* e = std::getenv("FSGPU_WIDE_DBG"); return e ? std::atoi(e) : 0; }();  // timing experiments only
+            if constexpr (EB == 2 && QT == 2) {
+                if (dbg == 1) return launch_wide_t<768, EB, QT, 6, 1>(args, grid, stream, occupancy);
+                if (dbg == 2) return launch_wide_t<768, EB, QT, 6, 2>(args, grid, stream, occupancy);
+            }
+            return launch_wide_t<768, EB, QT, 6>(args, grid, stream, occupancy);   // 6 x 24 KB
+        }
+        case 256: return launch_wide_t<512, EB, QT, 8>(args, grid, stream, occupancy);   // 8 x 16 KB
+        case 192: return launch_wide_t<384, EB, QT, 6>(args, grid, stream, occupancy);   // 6 x 24 KB
+        case 128: return launch_wide_t<256, EB, QT, 8>(args, grid, stream, occupancy);   // 8 x 16 KB
+        case 64: return launch_wide_t<128, EB, QT, 8>(args, grid, stream, occupancy);    // 8 x 8 KB
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+bool scan_wide_supported(int dim, int elem_bytes) {
+    const int rowb = dim * elem_bytes;
+    return rowb == 768 || rowb == 512 || rowb == 384 || rowb == 256 || rowb == 128;
+}
+
+// query_tiles = QT (2: 256 queries per pass, 3: 384)
+hipError_t launch_scan_wide(const MfmaScanArgs& args, int query_tiles, int grid, hipStream_t stream, int* occupancy) {
+    const int eb = args.elem_bytes == 1 ? 1 : 2;
+    if (!scan_wide_supported((int)args.dim, eb)) return hipErrorInvalidValue;
+    if (eb == 2) {
+        if (query_tiles == 2) return launch_wide_d<2, 2>(args, grid, stream, occupancy);
+        if (query_tiles == 3) return launch_wide_d<2, 3>(args, grid, stream, occupancy);
+    } else {
+        if (query_tiles == 2) return launch_wide_d<1, 2>(args, grid, stream, occupancy);
+        if (query_tiles == 3) return launch_wide_d<1, 3>(args, grid, stream, occupancy);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace fsgpu

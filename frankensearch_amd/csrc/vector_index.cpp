@@ -45,6 +45,7 @@ SearchError hip_fail(hipError_t e, const char* what) {
 // experiment switches, not configuration): see scripts/exp_*.
 struct Knobs {
     int grid_blocks = 0, ra = 0, rb = 0, mfma_shape = 0, mfma_shape_i8 = 0, round = 0, i8_per_cu = 0;
+    int wide = -1;  // FSGPU_WIDE: 0 = never the register-resident-query main pass, 2 / 3 = its query tiles per wave
     bool no_skip_b = false, use_160 = false, debug_batched = false, no_reverse = false;
     Knobs() {
         auto num = [](const char* name) {
@@ -58,6 +59,7 @@ struct Knobs {
         i8_per_cu = num("FSGPU_I8_PER_CU");
         mfma_shape = num("FSGPU_MFMA_SHAPE");
         mfma_shape_i8 = num("FSGPU_MFMA_SHAPE_I8");
+        if (std::getenv("FSGPU_WIDE")) wide = num("FSGPU_WIDE");
         no_skip_b = std::getenv("FSGPU_NO_SKIP_B") != nullptr;
         no_reverse = std::getenv("FSGPU_NO_REVERSE") != nullptr;
         use_160 = std::getenv("FSGPU_USE_160") != nullptr;
@@ -1145,6 +1147,9 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         probe.elem_bytes = 2;
         FSGPU_HIP(launch_scan_mfma(probe, 5, 1, stream, &mf_per_cu_160_));
     }
+    // the register-resident-query main pass (mfma_wide.hip): 256 queries per launch by default
+    const int wide_pref = knobs().wide >= 0 ? knobs().wide : 2;
+    const bool wide_ok = (wide_pref == 2 || wide_pref == 3) && scan_wide_supported((int)dim_, i8 ? 1 : 2) && variant != 5 && variant != 6;
     // per-query verdicts, written by the kernels straight into pinned host memory and read after ONE stream
     // synchronisation for the whole batch: [0, cap) = overflow flags, [cap, 2 cap) = candidate counts
     const uint32_t flag_cap = (nq + GMAX - 1) / GMAX * GMAX + GMAX;
@@ -1166,11 +1171,18 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     const uint32_t k_eff = std::min<uint32_t>(k, N);
     for (uint32_t g0 = 0; g0 < nq;) {
         const uint32_t left = nq - g0;
+        // Main pass at 384 / 256 queries per launch (mfma_wide.hip: queries in registers, row tiles through an LDS-DMA
+        // ring) when that many are left; the sample stages then run as sub-groups of 128 on the LDS-query kernel.
+        int wide_qt = 0;
+        if (wide_ok && left >= 256) wide_qt = (wide_pref == 3 && left >= 384) ? 3 : 2;
         // 160, 128 or 64 queries per pass
-        const int shape = (left > 64 && variant != 5) ? ((left > 128 && mf_use_160_) ? 5 : (i8 ? mf_shape_i8_ : mf_shape_)) : 0;
+        const int shape = wide_qt ? (i8 ? mf_shape_i8_ : mf_shape_)
+                                  : (left > 64 && variant != 5) ? ((left > 128 && mf_use_160_) ? 5 : (i8 ? mf_shape_i8_ : mf_shape_)) : 0;
         const uint32_t G = (uint32_t)scan_mfma_query_tiles(shape) * 16;
+        const uint32_t wide_mult = wide_qt ? (uint32_t)wide_qt : 1;   // sample groups per main-pass launch
         // this round: `ngroups` groups of G queries (the last one may be partly padding), QP query slots, ng real queries
-        const uint32_t ngroups = left >= G ? std::min<uint32_t>(left / G, QCAP / G) : 1;
+        uint32_t ngroups = left >= G ? std::min<uint32_t>(left / G, QCAP / G) : 1;
+        if (wide_qt) ngroups = ngroups / wide_mult * wide_mult;
         const uint32_t QP = ngroups * G;
         const uint32_t ng = std::min(QP, left);
         const int wpb = scan_mfma_waves_per_block(shape);
@@ -1196,7 +1208,8 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         auto slots_for = [&](int grid) {
             return std::min<uint32_t>((uint32_t)scan_mfma_max_slots(shape), std::max<uint32_t>(16, (CAPQ - KC) / (uint32_t)grid));
         };
-        FSGPU_TRY(mf_cand_.reserve((size_t)QP * full_grid * kMfmaMaxSlots * 8));
+        const int wide_grid = num_cus_ * mf_per_cu_wide_main_;
+        FSGPU_TRY(mf_cand_.reserve((size_t)QP * std::max(full_grid, wide_grid) * kMfmaMaxSlots * 8));
         u64* cand = static_cast<u64*>(mf_cand_.ptr);
         MfmaScanArgs a{};
         a.slab = i8 ? i8_slab_.ptr : slab_dev_;
@@ -1270,19 +1283,25 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
             }
             // stage C: every group the B sample did not cover
             a.stage = 2;
-            a.slots = slots_for(full_grid);
+            const int main_grid = wide_qt ? wide_grid : full_grid;
+            if (wide_qt) {  // the wide main pass visits every row (no skip test in its loop): stage B only tightened tau
+                a.group_stride = 1;
+                a.group_count = 0;
+            }
+            a.slots = wide_qt ? std::min<uint32_t>(kWideSlots, std::max<uint32_t>(8, (CAPQ - KC) / (uint32_t)main_grid)) : slots_for(full_grid);
             FSGPU_HIP(hipMemsetAsync(spill_count, 0, (size_t)QP * kMfmaSpillCountStride * 4, stream));
             a.groups = 1;
             // one pass over the slab per query group, one launch each (all groups in one launch — a group's blocks taking
             // over the CUs the previous group's leave — measured 1.5 % slower at 10M rows: two groups' streams interleave)
-            for (uint32_t j = 0; j < ngroups; ++j) {
+            const uint32_t GM = G * wide_mult;  // queries per main-pass launch
+            for (uint32_t j = 0; j < ngroups / wide_mult; ++j) {
                 MfmaScanArgs c = a;
-                c.queries = static_cast<const unsigned char*>(mf_qh_.ptr) + (size_t)j * G * dim_ * (i8 ? 1 : 2);
-                c.tau = tau + (size_t)j * G;
-                c.cand = cand + (size_t)j * G * full_grid * a.slots;
-                c.spill = spill + (size_t)j * G * SPILL;
-                c.spill_count = spill_count + (size_t)j * G * kMfmaSpillCountStride;
-                c.overflow = overflow + (size_t)j * G;
+                c.queries = static_cast<const unsigned char*>(mf_qh_.ptr) + (size_t)j * GM * dim_ * (i8 ? 1 : 2);
+                c.tau = tau + (size_t)j * GM;
+                c.cand = cand + (size_t)j * GM * main_grid * a.slots;
+                c.spill = spill + (size_t)j * GM * SPILL;
+                c.spill_count = spill_count + (size_t)j * GM * kMfmaSpillCountStride;
+                c.overflow = overflow + (size_t)j * GM;
                 c.reverse = knobs().no_reverse ? 0 : (mf_pass_parity_++ & 1);  // consecutive passes alternate direction
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (profiling) {
@@ -1290,20 +1309,21 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
                     FSGPU_HIP(hipEventCreate(&e1));
                     FSGPU_HIP(hipEventRecord(e0, stream));
                 }
-                FSGPU_HIP(launch_scan_mfma(c, shape, full_grid, stream, nullptr));
+                if (wide_qt) FSGPU_HIP(launch_scan_wide(c, wide_qt, main_grid, stream, nullptr));
+                else FSGPU_HIP(launch_scan_mfma(c, shape, full_grid, stream, nullptr));
                 if (profiling) {
                     FSGPU_HIP(hipEventRecord(e1, stream));
                     events_.emplace_back(e0, e1);
-                    profiled_rows_ += skip_b ? N : N - RB;
+                    profiled_rows_ += (skip_b || wide_qt) ? N : N - RB;
                     profiled_elem_bytes_ = i8 ? 1 : 2;
                 }
             }
-            sb.q_stride = (uint64_t)full_grid * a.slots;
+            sb.q_stride = (uint64_t)main_grid * a.slots;
             sb.l_stride = a.slots;
-            sb.nlists = (uint32_t)full_grid;
+            sb.nlists = (uint32_t)main_grid;
             sb.list_len = a.slots;
-            sb.extra = skip_b ? nullptr : pool;
-            sb.extra_len = skip_b ? 0 : KC;
+            sb.extra = (skip_b || wide_qt) ? nullptr : pool;
+            sb.extra_len = (skip_b || wide_qt) ? 0 : KC;
             sb.tau_out = nullptr;
             sb.pool_out = nullptr;
         }

@@ -170,6 +170,7 @@ class VectorIndex {
     bool mf_norm_ready_ = false;
     int mf_shape_i8_ = 4, mf_per_cu_160_ = 1, mf_per_cu_160_i8_ = 1;
     bool mf_use_160_ = false;
+    int mf_per_cu_wide_main_ = 1;  // mfma_wide.hip: one 512-thread block per CU (its LDS ring + candidate lists take ~130 KB)
     int mf_shape_ = -1, mf_per_cu_narrow_ = 1, mf_per_cu_wide_ = 1, mf_per_cu_narrow_i8_ = 1, mf_per_cu_wide_i8_ = 1;  // batched-scan launch shapes (probed once)
     static constexpr size_t kPinnedIoBytes = 256 * 1024;
     void* io_host_ = nullptr;  // pinned staging for the single-query latency paths
