@@ -82,7 +82,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     constexpr int PW = NI / WPB;                                    // ... per wave
     static_assert(NI % WPB == 0 && PW >= 1, "a tile's DMA instructions divide evenly over the 8 waves");
     static_assert(RS % 2 == 0, "sub-tiles are consumed in pairs");
-    constexpr int CK = KS == 12 ? 3 : (KS >= 2 ? KS / 2 : 1);       // k-steps per chunk
+    constexpr int CK = KS == 12 ? (QT >= 3 ? 2 : 3) : (KS >= 2 ? KS / 2 : 1);   // k-steps per chunk (fewer at QT = 3: registers)
     constexpr int NCH = KS / CK;                                    // chunks per sub-tile pair
     constexpr int NC = (RS / 2) * NCH;                              // chunks per tile
     static_assert(KS % CK == 0 && NC % 2 == 0, "an even number of chunks per tile: the register double buffer starts every tile in the same phase");

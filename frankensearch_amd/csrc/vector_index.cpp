@@ -1148,7 +1148,9 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         FSGPU_HIP(launch_scan_mfma(probe, 5, 1, stream, &mf_per_cu_160_));
     }
     // the register-resident-query main pass (mfma_wide.hip): 256 queries per launch by default
-    const int wide_pref = knobs().wide >= 0 ? knobs().wide : 2;
+    // (384 per launch when that many queries are left: the matrix pipe is the bound there and fewer passes leave it more of
+    // the power budget — measured 148 k against 130 k queries/s at 10M x 384)
+    const int wide_pref = knobs().wide >= 0 ? knobs().wide : 3;
     const bool wide_ok = (wide_pref == 2 || wide_pref == 3) && scan_wide_supported((int)dim_, i8 ? 1 : 2) && variant != 5 && variant != 6;
     // per-query verdicts, written by the kernels straight into pinned host memory and read after ONE stream
     // synchronisation for the whole batch: [0, cap) = overflow flags, [cap, 2 cap) = candidate counts
