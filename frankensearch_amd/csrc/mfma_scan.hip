@@ -602,14 +602,22 @@ __global__ __launch_bounds__(256) void prepare_queries_kernel(const float* __res
                                                               uint32_t dim, const unsigned int* __restrict__ max_norm_bits,
                                                               _Float16* __restrict__ qh, float* __restrict__ delta) {
     __shared__ float red[4];
+    __shared__ int unrepresentable;
     const uint32_t b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) unrepresentable = 0;
+    __syncthreads();
     float s = 0.f;
+    bool bad = false;
     for (uint32_t i = tid; i < dim; i += 256) {
         const float v = b < nq ? q[(size_t)b * dim + i] : 0.f;
         qh[(size_t)b * dim + i] = (_Float16)v;
         s += v * v;
+        // |v| above the largest finite f16 (65504) rounds to +-inf (and NaN stays NaN): the approximate scores of such a
+        // query are inf / NaN and the error bound says nothing about them — the exact kernels answer it
+        bad |= !(fabsf(v) <= 65504.0f);
     }
+    if (__any(bad) && lane == 0) unrepresentable = 1;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) red[wave] = s;
@@ -620,7 +628,7 @@ __global__ __launch_bounds__(256) void prepare_queries_kernel(const float* __res
         const float rel = 4.8852e-4f /* 2^-11 (1 + 2^-11) */ + (float)dim * 1.1920929e-7f /* 2^-23 */;
         float d = rel * mx * qnorm + sqrtf((float)dim) * 2.9802322e-8f /* 2^-25 */ * mx;
         // padding rows, all-zero and non-finite queries cannot be certified: negative delta = "skip" marker
-        if (b >= nq || !(qnorm > 0.f) || !__builtin_isfinite(d)) d = -1.0f;
+        if (b >= nq || !(qnorm > 0.f) || !__builtin_isfinite(d) || unrepresentable) d = -1.0f;
         delta[b] = d;
         (void)nq_pad;
     }

@@ -45,6 +45,10 @@ while time.time() < t_end:
         q[2] *= 37.5                    # non-unit query
         if rng.random() < 0.3:
             q[3, int(rng.integers(0, dim))] = rng.choice([np.nan, np.inf])  # non-finite: answered by the exact kernels
+        if nq > 6:
+            q[4, int(rng.integers(0, dim))] = float(rng.choice([65520.0, -7e4, 3e5]))   # finite, but +-inf as f16
+            q[5] = (rng.standard_normal(dim) * float(rng.choice([3e-6, 1e-9]))).astype(np.float32)  # f16 subnormals / zeros
+            q[6, :: int(rng.integers(2, 9))] = 1.5e-6
     idx = fa.VectorIndex.from_slab(slab, live=live)
     br, bs, bc, fb = idx.search_batched(q, k, allow=allow)
     ok = True

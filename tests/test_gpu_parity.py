@@ -524,6 +524,71 @@ def test_batched_mfma_wide_groups_topical_rows_and_filters(fa, oracle):
         assert np.array_equal(br[qi], orow) and np.array_equal(bits(bs[qi]), bits(osc))
 
 
+def test_config2_batched_1m_rows_against_the_oracle(fa, oracle):
+    """BASELINE config 2: 1M x 384 f16 (the reference bench corpus, generated on the GPU), top-10, batches of 8 / 64 / 256
+    queries through the batched matrix-core path (256 takes the register-resident-query main pass) — every hit of a spread of
+    queries against the oracle, the rest against the exact kernels."""
+    import ctypes as C
+    import torch
+    n, dim, k = 1_000_000, 384, 10
+    slab_t = torch.empty((n, dim), dtype=torch.float16, device="cuda:0")
+    fa._lib.lib().fsgpu_bench_fixture_device(0, 0, n, dim, 64, C.c_float(0.30), 1, 1, slab_t.data_ptr(), None)
+    host = slab_t.view(torch.int16).cpu().numpy().view(np.uint16)
+    assert np.array_equal(host[:2048], oracle.clustered_corpus_f16(0, 2048, dim))
+    idx = fa.VectorIndex.from_device_slab(slab_t.data_ptr(), n, dim, device=0, keepalive=slab_t)
+    q = np.stack([oracle.clustered_query(i, dim) for i in range(256)])
+    for b in (8, 64, 256):
+        br, bs, bc, fb = idx.search_batched(q[:b], k)
+        assert np.all(bc == k) and fb <= b // 8
+        er, es, _ = idx.search_batch(q[:min(b, 64)], k)
+        assert np.array_equal(br[:min(b, 64)], er) and np.array_equal(bits(bs[:min(b, 64)]), bits(es))
+        for qi in sorted({0, b // 2, b - 1}):
+            orow, osc = oracle.search_top_k(host, q[qi], k, nthreads=8)
+            assert np.array_equal(br[qi], orow) and np.array_equal(bits(bs[qi]), bits(osc)), (b, qi)
+
+
+def test_batched_certificate_edges_overflow_subnormals_and_near_duplicates(fa, oracle):
+    """The batched path is exact only through its certificate (|a - s| <= delta, mfma_scan.hip header); the cases where the
+    certificate cannot hold or cannot separate must end on the exact kernels and still return the oracle's bits:
+      * finite queries with one or a few elements above 65504 (their f16 image is +-inf) — marked uncertifiable up front;
+      * queries made of f16-subnormal / underflowing elements (approximate scores collapse to ~0);
+      * a corpus with >= 5000 rows within 2 delta of the k-th score: the candidate pool (1024) overflows -> exact fallback."""
+    rng = np.random.default_rng(123)
+    n, dim, k = 120_000, 384, 10
+    base = rng.standard_normal(dim).astype(np.float32)
+    base /= np.linalg.norm(base)
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    # 6000 near-duplicates of `base`, spread over the slab: scores against base differ by ~1e-4, far inside 2 delta ~ 1e-3
+    dup = rng.choice(n, 6000, replace=False)
+    rows[dup] = base + (1e-4 * rng.standard_normal((6000, dim))).astype(np.float32)
+    slab = rows.astype(np.float16).view(np.uint16)
+    idx = fa.VectorIndex.from_slab(slab)
+    nq = 300                                  # one 256-query wide pass + a 64-query tail
+    q = rows[rng.integers(0, n, nq)] + (0.2 * rng.standard_normal((nq, dim))).astype(np.float32)
+    q[0] = base                               # sits on the near-duplicate cluster: pool overflow
+    q[1] = base * 3.0
+    q[2, 5] = 70000.0                         # one element above the f16 range, the rest ordinary
+    q[3] = q[3] * 1e3
+    q[3, 7] = -1.0e5
+    q[4] = (rng.standard_normal(dim) * 3e-6).astype(np.float32)     # every element an f16 subnormal
+    q[5] = (rng.standard_normal(dim) * 1e-9).astype(np.float32)     # every element underflows to f16 zero
+    q[6, ::2] = 2e-6                          # half subnormal, half ordinary
+    q[257] = base                             # the same hard query in the tail group
+    br, bs, bc, fb = idx.search_batched(q, k)
+    er, es, ec = idx.search_batch(q, k)
+    assert np.array_equal(bc, ec) and np.array_equal(br, er) and np.array_equal(bits(bs), bits(es))
+    assert fb >= 4, fb                        # q0, q1, q257 (pool overflow) and q2, q3 (f16 overflow) at least
+    for qi in (0, 2, 3, 4, 5, 6, 257):
+        orow, osc = oracle.search_top_k(slab, q[qi], k)
+        assert np.array_equal(br[qi], orow) and np.array_equal(bits(bs[qi]), bits(osc)), qi
+    # the int8 batched pass 1 is integer-exact: a pile of tied int8 scores at the threshold must not lose a candidate
+    r8, s8, c8, _ = idx.search_int8_two_pass_batched(q[:260], k, 3)
+    for qi in (0, 1, 7, 257):
+        hits = idx.search_top_k_int8_two_pass(q[qi], k, 3)
+        assert [h.index for h in hits] == r8[qi, :c8[qi]].tolist(), qi
+
+
 @pytest.mark.gpu
 def test_mrl_search_matches_oracle(fa, oracle, tmp_path):
     # VectorIndex::mrl_search (crates/frankensearch-index/src/mrl.rs:241-395): truncated scan over a strided prefix of
