@@ -2,13 +2,15 @@
 # Regenerates the evidence kept under profiles/<round>/ (run on the GPU box through gpurun; results land in
 # gpurun_out/<round>/ and are copied to profiles/<round>/ afterwards).  Counter passes are separate runs with
 # --pmc only (never combined with trace domains).
-R=${1:-r01}
+R=${1:-r02}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
 (lscpu | head -20; echo; cat /sys/fs/cgroup/cpu.max 2>/dev/null; nproc) > $OUT/host_cpu.txt 2>&1
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python bench.py --batch 128 --no-cpu-baseline --no-two-tier 2>/dev/null | tail -1 > $OUT/bench_batched_b128.json
+python bench.py --batch 1152 --no-cpu-baseline --no-two-tier 2>/dev/null | tail -1 > $OUT/bench_batched_b1152.json
+FSGPU_WIDE=0 python bench.py --no-cpu-baseline --no-two-tier 2>/dev/null | tail -1 > $OUT/bench_batched_lds_queries_128.json
 python bench.py --exact --batch 1 --no-cpu-baseline --no-two-tier 2>/dev/null | tail -1 > $OUT/bench_exact_b1.json
 python bench.py --exact --batch 4 --no-cpu-baseline --no-two-tier 2>/dev/null | tail -1 > $OUT/bench_exact_b4.json
 # per-kernel time of the default bench command
@@ -35,7 +37,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_fetch_b1", "pmc_fetch_b4"):
 json.dump(out, open("$OUT/pmc_summary.json", "w"), indent=1)
 PY
 # matrix-core / LDS counters of the scan kernels
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -o bench -- \
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o bench -- \
     python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-two-tier > $OUT/bench_pmc_sq.log 2>&1
 python scripts/pmc_summary.py $OUT/pmc_sq $OUT/pmc_sq.json > /dev/null
 # encoders
