@@ -2,6 +2,7 @@
 // Layer order follows encoder_layer_raw (crates/frankensearch-rerank/src/native.rs:587-626).
 #include "bert_embedder.hpp"
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -32,10 +33,11 @@ SearchError hip_err(hipError_t e, const char* what) {
 
 NativeEmbedder::~NativeEmbedder() {
     if (device_ >= 0) (void)hipSetDevice(device_);
+    drop_graphs();
     if (stream_) (void)hipStreamDestroy(stream_);
     if (io_host_) (void)hipHostFree(io_host_);
     for (DeviceBuffer* b : {&word_, &pos_, &type_, &emb_ln_w_, &emb_ln_b_, &ids_, &positions_, &offsets_, &x_f32_, &x_h_,
-                            &qkv_f32_, &ctx_h_, &tmp_f32_, &inter_h_, &out_})
+                            &qkv_f32_, &ctx_h_, &tmp_f32_, &inter_h_, &out_, &q_x_, &q_parts_})
         b->release();
     for (Layer& l : layers_)
         for (DeviceBuffer* b : {&l.qkv_w, &l.ao_w, &l.i_w, &l.o_w, &l.qkv_b, &l.ao_b, &l.ln1_w, &l.ln1_b, &l.i_b, &l.o_b,
@@ -127,15 +129,123 @@ SearchError NativeEmbedder::init(int device, const fsgpu_bert_config& cfg, const
     return SearchError{};
 }
 
+void NativeEmbedder::drop_graphs() {
+    for (auto& kv : graphs_)
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    graphs_.clear();
+}
+
+// Workspaces for `tokens` tokens.  Calls that may be graph-captured share buffers sized for kGraphMaxTokens, so a captured
+// graph's pointers stay valid; a larger call that has to move a buffer drops the graphs.
+SearchError NativeEmbedder::reserve_workspaces(uint32_t tokens) {
+    const size_t H = cfg_.hidden, I = cfg_.inter;
+    const size_t T = tokens <= kGraphMaxTokens ? kGraphMaxTokens : tokens;
+    const void* before[] = {x_f32_.ptr, x_h_.ptr, qkv_f32_.ptr, ctx_h_.ptr, tmp_f32_.ptr, inter_h_.ptr};
+    BERT_TRY(x_f32_.reserve(T * H * 4));
+    BERT_TRY(x_h_.reserve(T * H * 2));
+    BERT_TRY(qkv_f32_.reserve(T * 3 * H * 4));
+    BERT_TRY(ctx_h_.reserve(T * H * 2));
+    BERT_TRY(tmp_f32_.reserve(T * H * 4));
+    BERT_TRY(inter_h_.reserve(T * I * 2));
+    const void* after[] = {x_f32_.ptr, x_h_.ptr, qkv_f32_.ptr, ctx_h_.ptr, tmp_f32_.ptr, inter_h_.ptr};
+    for (int i = 0; i < 6; ++i)
+        if (before[i] && before[i] != after[i]) {
+            drop_graphs();
+            break;
+        }
+    return SearchError{};
+}
+
+bool NativeEmbedder::query_path(uint32_t tokens) const {
+    static const bool off = std::getenv("FSGPU_BERT_NO_QUERY_PATH") != nullptr;  // A/B runs
+    return !off && tokens <= 32 && bert_query_path_supported((int)cfg_.hidden, (int)cfg_.inter, (int)cfg_.heads);
+}
+
+// Query-sized inputs (<= 32 tokens in total): 4 launches per layer + the pooling, see bert_query_kernels.hip.
+SearchError NativeEmbedder::forward_query(uint32_t n_docs, uint32_t tokens) {
+    const int H = (int)cfg_.hidden, I = (int)cfg_.inter;
+    BERT_TRY(q_x_.reserve((size_t)2 * 32 * H * 4));
+    BERT_TRY(q_parts_.reserve((size_t)4 * 32 * H * 4));
+    float* X[2] = {static_cast<float*>(q_x_.ptr), static_cast<float*>(q_x_.ptr) + 32 * H};
+    float* parts = static_cast<float*>(q_parts_.ptr);
+    BertQueryArgs base{};
+    base.tokens = (int)tokens;
+    base.n_docs = (int)n_docs;
+    base.offsets = q_offsets_ ? q_offsets_ : static_cast<const uint32_t*>(offsets_.ptr);
+    base.eps = cfg_.ln_eps;
+    base.attn_scale = 0.17677669f;  // ATTN_SCALE_F32 = 1/sqrt(32) (native.rs:44)
+    const Layer* prev = nullptr;
+    for (Layer& l : layers_) {
+        BertQueryArgs k1 = base;   // [pending LN2 | embedding LN] -> QKV of each head -> attention -> ctx
+        if (!prev) {
+            k1.ids = q_ids_ ? q_ids_ : static_cast<const int32_t*>(ids_.ptr);
+            k1.positions = q_positions_ ? q_positions_ : static_cast<const int32_t*>(positions_.ptr);
+            k1.word = static_cast<const float*>(word_.ptr);
+            k1.pos = static_cast<const float*>(pos_.ptr);
+            k1.type0 = static_cast<const float*>(type_.ptr);
+            k1.lnw = static_cast<const float*>(emb_ln_w_.ptr);
+            k1.lnb = static_cast<const float*>(emb_ln_b_.ptr);
+        } else {
+            k1.x_in = X[1];
+            k1.parts = parts;
+            k1.n_parts = 4;
+            k1.prev_bias = static_cast<const float*>(prev->o_b.ptr);
+            k1.lnw = static_cast<const float*>(prev->ln2_w.ptr);
+            k1.lnb = static_cast<const float*>(prev->ln2_b.ptr);
+        }
+        k1.x_out = X[0];
+        k1.w = static_cast<const _Float16*>(l.qkv_w.ptr);
+        k1.ldw = H;
+        k1.bias = static_cast<const float*>(l.qkv_b.ptr);
+        k1.out_h = static_cast<_Float16*>(ctx_h_.ptr);
+        BERT_HIP(launch_bert_q_qkv_attn(k1, (int)cfg_.heads, stream_));
+        BertQueryArgs k2 = base;   // out-projection -> one partial slab
+        k2.a_h = static_cast<const _Float16*>(ctx_h_.ptr);
+        k2.lda = H;
+        k2.w = static_cast<const _Float16*>(l.ao_w.ptr);
+        k2.ldw = H;
+        k2.n = H;
+        k2.out_f32 = parts;
+        BERT_HIP(launch_bert_q_gemm(k2, 0, stream_));
+        BertQueryArgs k3 = base;   // x = LN1(x + slab + bias) -> FFN-up + GELU
+        k3.x_in = X[0];
+        k3.x_out = X[1];
+        k3.parts = parts;
+        k3.n_parts = 1;
+        k3.prev_bias = static_cast<const float*>(l.ao_b.ptr);
+        k3.lnw = static_cast<const float*>(l.ln1_w.ptr);
+        k3.lnb = static_cast<const float*>(l.ln1_b.ptr);
+        k3.w = static_cast<const _Float16*>(l.i_w.ptr);
+        k3.ldw = H;
+        k3.n = I;
+        k3.bias = static_cast<const float*>(l.i_b.ptr);
+        k3.out_h = static_cast<_Float16*>(inter_h_.ptr);
+        BERT_HIP(launch_bert_q_gemm(k3, 1, stream_));
+        BertQueryArgs k4 = base;   // FFN-down, K split 4 ways -> four partial slabs
+        k4.a_h = static_cast<const _Float16*>(inter_h_.ptr);
+        k4.lda = I;
+        k4.w = static_cast<const _Float16*>(l.o_w.ptr);
+        k4.ldw = I;
+        k4.n = H;
+        k4.out_f32 = parts;
+        BERT_HIP(launch_bert_q_gemm(k4, 2, stream_));
+        prev = &l;
+    }
+    BertQueryArgs kp = base;       // x = LN2(x + slabs + bias) -> mean per text -> L2
+    kp.x_in = X[1];
+    kp.parts = parts;
+    kp.n_parts = 4;
+    kp.prev_bias = static_cast<const float*>(prev->o_b.ptr);
+    kp.lnw = static_cast<const float*>(prev->ln2_w.ptr);
+    kp.lnb = static_cast<const float*>(prev->ln2_b.ptr);
+    BERT_HIP(launch_bert_q_pool(kp, pooled_out_ ? pooled_out_ : static_cast<float*>(out_.ptr), stream_));
+    return SearchError{};
+}
+
 SearchError NativeEmbedder::forward(uint32_t n_docs, uint32_t tokens, uint32_t max_seq) {
     const int H = (int)cfg_.hidden, I = (int)cfg_.inter, T = (int)tokens;
     const float eps = cfg_.ln_eps;
-    BERT_TRY(x_f32_.reserve((size_t)T * H * 4));
-    BERT_TRY(x_h_.reserve((size_t)T * H * 2));
-    BERT_TRY(qkv_f32_.reserve((size_t)T * 3 * H * 4));
-    BERT_TRY(ctx_h_.reserve((size_t)T * H * 2));
-    BERT_TRY(tmp_f32_.reserve((size_t)T * H * 4));
-    BERT_TRY(inter_h_.reserve((size_t)T * I * 2));
+    if (query_path(tokens)) return forward_query(n_docs, tokens);
     float* x = static_cast<float*>(x_f32_.ptr);
     float* tmp = static_cast<float*>(tmp_f32_.ptr);
     float* qkv = static_cast<float*>(qkv_f32_.ptr);
@@ -211,10 +321,22 @@ SearchError NativeEmbedder::embed_batch(const int32_t* ids, const uint32_t* offs
             positions[t] = (int32_t)(t - offs[i]);  // positions restart at 0 per input (native.rs:1159-1167)
         }
     BERT_HIP(hipSetDevice(device_));
-    BERT_TRY(ids_.reserve((size_t)total * 4));
-    BERT_TRY(positions_.reserve((size_t)total * 4));
-    BERT_TRY(offsets_.reserve((size_t)(n + 1) * 4));
-    BERT_TRY(out_.reserve((size_t)n * H * 4));
+    {
+        // (graph-eligible calls share buffers of the graph-eligible maximum: see reserve_workspaces)
+        const bool small = total <= kGraphMaxTokens;
+        const void* before[] = {ids_.ptr, positions_.ptr, offsets_.ptr, out_.ptr};
+        BERT_TRY(ids_.reserve((size_t)(small ? kGraphMaxTokens : total) * 4));
+        BERT_TRY(positions_.reserve((size_t)(small ? kGraphMaxTokens : total) * 4));
+        BERT_TRY(offsets_.reserve((size_t)((small ? kGraphMaxTokens : n) + 1) * 4));
+        BERT_TRY(out_.reserve((size_t)(small && n <= kGraphMaxTokens ? kGraphMaxTokens : n) * H * 4));
+        const void* after[] = {ids_.ptr, positions_.ptr, offsets_.ptr, out_.ptr};
+        for (int i = 0; i < 4; ++i)
+            if (before[i] && before[i] != after[i]) {
+                drop_graphs();
+                break;
+            }
+    }
+    BERT_TRY(reserve_workspaces(total));
     // Small calls (queries): inputs go through one pinned block (DMA instead of the runtime's pageable staging) and the
     // pooled vectors are read back from pinned memory the pool kernel wrote — no D2H copy.
     const size_t in_bytes = ((size_t)total * 8 + (size_t)(n + 1) * 4 + 255) & ~(size_t)255;
@@ -231,13 +353,62 @@ SearchError NativeEmbedder::embed_batch(const int32_t* ids, const uint32_t* offs
         std::memcpy(io, ids + base, (size_t)total * 4);
         std::memcpy(io + (size_t)total * 4, positions.data(), (size_t)total * 4);
         std::memcpy(io + (size_t)total * 8, offs.data(), (size_t)(n + 1) * 4);
-        BERT_HIP(hipMemcpyAsync(ids_.ptr, io, (size_t)total * 4, hipMemcpyHostToDevice, stream_));
-        BERT_HIP(hipMemcpyAsync(positions_.ptr, io + (size_t)total * 4, (size_t)total * 4, hipMemcpyHostToDevice, stream_));
-        BERT_HIP(hipMemcpyAsync(offsets_.ptr, io + (size_t)total * 8, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, stream_));
-        pooled_out_ = reinterpret_cast<float*>(io + in_bytes);
-        SearchError fe = forward(n, total, max_seq);
-        pooled_out_ = nullptr;
-        if (!fe.ok()) return fe;
+        auto enqueue = [&]() -> SearchError {
+            const bool direct = query_path(total);
+            if (direct) {
+                // a query's few dozen ids are read by the first kernel straight from the pinned block (mapped into the
+                // device's address space): three copy nodes of ~4 us each cost more than the forward's first stage
+                q_ids_ = reinterpret_cast<const int32_t*>(io);
+                q_positions_ = reinterpret_cast<const int32_t*>(io + (size_t)total * 4);
+                q_offsets_ = reinterpret_cast<const uint32_t*>(io + (size_t)total * 8);
+            } else {
+                BERT_HIP(hipMemcpyAsync(ids_.ptr, io, (size_t)total * 4, hipMemcpyHostToDevice, stream_));
+                BERT_HIP(hipMemcpyAsync(positions_.ptr, io + (size_t)total * 4, (size_t)total * 4, hipMemcpyHostToDevice, stream_));
+                BERT_HIP(hipMemcpyAsync(offsets_.ptr, io + (size_t)total * 8, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, stream_));
+            }
+            pooled_out_ = reinterpret_cast<float*>(io + in_bytes);
+            SearchError fe = forward(n, total, max_seq);
+            pooled_out_ = nullptr;
+            q_ids_ = q_positions_ = nullptr;
+            q_offsets_ = nullptr;
+            return fe;
+        };
+        static const bool no_graph = std::getenv("FSGPU_BERT_NO_GRAPH") != nullptr;  // A/B runs
+        bool replayed = false;
+        if (graphs_enabled_ && !no_graph && total <= kGraphMaxTokens) {
+            const auto key = std::make_tuple(n, total, max_seq);
+            auto it = graphs_.find(key);
+            if (it == graphs_.end()) {
+                if (graphs_.size() >= kGraphMaxEntries) drop_graphs();
+                it = graphs_.emplace(key, GraphEntry{}).first;
+            }
+            GraphEntry& ge = it->second;
+            ++ge.seen;
+            if (!ge.exec && ge.seen >= 2) {
+                // second sighting of this shape (the first ran eagerly, so every one-time kernel attribute is set): capture
+                hipGraph_t graph = nullptr;
+                hipError_t ce = hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal);
+                if (ce == hipSuccess) {
+                    SearchError fe = enqueue();
+                    ce = hipStreamEndCapture(stream_, &graph);
+                    if (fe.ok() && ce == hipSuccess && graph) ce = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
+                    else if (ce == hipSuccess) ce = hipErrorUnknown;
+                    if (graph) (void)hipGraphDestroy(graph);
+                }
+                if (ce != hipSuccess) {   // capture is an optimisation: fall back to eager launches for good
+                    if (std::getenv("FSGPU_DEBUG_GRAPH")) std::fprintf(stderr, "[fsgpu bert] graph capture failed: %s\n", hipGetErrorString(ce));
+                    (void)hipGetLastError();
+                    if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
+                    ge.exec = nullptr;
+                    graphs_enabled_ = false;
+                }
+            }
+            if (ge.exec) {
+                BERT_HIP(hipGraphLaunch(ge.exec, stream_));
+                replayed = true;
+            }
+        }
+        if (!replayed) BERT_TRY(enqueue());
         BERT_HIP(hipStreamSynchronize(stream_));
         std::memcpy(out, io + in_bytes, out_bytes);
         return SearchError{};

@@ -4,7 +4,9 @@
 #pragma once
 
 #include <cstdint>
+#include <map>
 #include <mutex>
+#include <tuple>
 #include <vector>
 
 #include "../../include/fsgpu.h"
@@ -28,6 +30,10 @@ class NativeEmbedder {
     SearchError upload_f32(DeviceBuffer& dst, const float* src, size_t n);
     SearchError upload_f16(DeviceBuffer& dst, const float* src, size_t n, DeviceBuffer& staging);
     SearchError forward(uint32_t n_docs, uint32_t tokens, uint32_t max_seq);
+    SearchError forward_query(uint32_t n_docs, uint32_t tokens);   // <= 32 tokens: 25 launches (bert_query_kernels.hip)
+    bool query_path(uint32_t tokens) const;
+    SearchError reserve_workspaces(uint32_t tokens);
+    void drop_graphs();
 
     std::mutex mu_;
     int device_ = -1;
@@ -36,12 +42,26 @@ class NativeEmbedder {
     DeviceBuffer word_, pos_, type_, emb_ln_w_, emb_ln_b_;
     std::vector<Layer> layers_;
     // workspaces
-    DeviceBuffer ids_, positions_, offsets_, x_f32_, x_h_, qkv_f32_, ctx_h_, tmp_f32_, inter_h_, out_;
+    DeviceBuffer ids_, positions_, offsets_, x_f32_, x_h_, qkv_f32_, ctx_h_, tmp_f32_, inter_h_, out_, q_x_, q_parts_;
     // pinned staging for small calls (see embed_batch)
     static constexpr size_t kPinnedIoBytes = 512 * 1024;
     void* io_host_ = nullptr;
     bool io_failed_ = false;
     float* pooled_out_ = nullptr;  // where the pool kernel writes during a pinned call
+    const int32_t *q_ids_ = nullptr, *q_positions_ = nullptr;  // query path of a pinned call: inputs read in place
+    const uint32_t* q_offsets_ = nullptr;
+    // Query-sized calls replay a captured hipGraph of the whole call (three H2D copies + the ~44 kernels of the forward):
+    // the chain is launch-bound, and a replay costs one submission instead of one per kernel.  One graph per call shape
+    // (texts, tokens, longest text), built the second time a shape is seen; every buffer a graph names is allocated at its
+    // graph-eligible maximum up front, and the graphs are dropped if a larger call ever moves one.
+    struct GraphEntry {
+        hipGraphExec_t exec = nullptr;
+        uint32_t seen = 0;
+    };
+    static constexpr uint32_t kGraphMaxTokens = 8192;
+    static constexpr size_t kGraphMaxEntries = 128;
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, GraphEntry> graphs_;
+    bool graphs_enabled_ = true;
 };
 
 }  // namespace fsgpu

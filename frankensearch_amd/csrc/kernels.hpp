@@ -198,4 +198,35 @@ hipError_t launch_bert_pool(const float* x, const uint32_t* offsets, float* out,
                             hipStream_t stream);
 hipError_t launch_bert_to_half(const float* src, void* dst, size_t n, hipStream_t stream);
 
+// bert_query_kernels.hip: the MiniLM-L6 forward for at most 32 tokens in 25 launches (4 per layer + the pooling), every
+// add+LayerNorm riding in the prologue of the GEMM that consumes it.  One argument block serves all stages; a stage reads
+// the fields it needs.
+struct BertQueryArgs {
+    int tokens, n_docs;              // tokens <= 32
+    const uint32_t* offsets;         // [n_docs + 1]
+    // first stage: embedding gather + LayerNorm instead of the pending add+LayerNorm (ids != null)
+    const int32_t* ids;
+    const int32_t* positions;
+    const float *word, *pos, *type0;
+    // pending add+LayerNorm: x = LN(x_in + sum of n_parts slabs of parts ([slab][32][384] f32) + prev_bias)
+    const float* x_in;
+    float* x_out;                    // the block that owns it stores the normalised rows here (null: nobody does)
+    const float* parts;
+    int n_parts;
+    const float *prev_bias, *lnw, *lnb;
+    float eps, attn_scale;
+    // GEMM: A rows from a_h (f16, leading dimension lda) unless the stage has a LayerNorm prologue; W [n, ldw] f16; bias [n]
+    const _Float16* a_h;
+    int lda;
+    const _Float16* w;
+    int ldw, n;
+    const float* bias;
+    float* out_f32;                  // partial slabs [slab][32][n]
+    _Float16* out_h;                 // f16 rows [tokens][n]
+};
+bool bert_query_path_supported(int hidden, int inter, int heads);
+hipError_t launch_bert_q_qkv_attn(const BertQueryArgs& a, int heads, hipStream_t stream);
+hipError_t launch_bert_q_gemm(const BertQueryArgs& a, int mode, hipStream_t stream);
+hipError_t launch_bert_q_pool(const BertQueryArgs& a, float* out, hipStream_t stream);
+
 }  // namespace fsgpu
