@@ -9,7 +9,9 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
 #include <mutex>
+#include <shared_mutex>
 
 #include "bert_embedder.hpp"
 #include "coalescer.hpp"
@@ -38,6 +40,13 @@ struct EmbedCall : CoalescedCall {
 
 struct fsgpu_index {
     fsgpu::VectorIndex impl;
+    // Lanes (vector_index.hpp): row-level searches from different host threads run on replicas of the index, each behind
+    // its own mutex; state_mu is held shared by a search on a replica and exclusively by whatever changes the index
+    // (tombstones, WAL, live bitmap, hreduce / variant), which then re-syncs the replicas.
+    std::shared_mutex state_mu;
+    std::mutex lanes_mu;
+    std::atomic<bool> lanes_ready{false};
+    std::atomic<uint32_t> lane_rr{0};
     fsgpu::Coalescer<SearchCall> coalescer;
     // leader-only staging (guarded by impl.mutex())
     std::vector<float> co_queries, co_scores;
@@ -254,8 +263,10 @@ uint32_t fsgpu_index_dimension(const fsgpu_index* idx) { return idx ? idx->impl.
 fsgpu_status fsgpu_index_set_hreduce(fsgpu_index* idx, int32_t mode) {
     if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
     if (mode < FSGPU_HREDUCE_SSE2 || mode > FSGPU_HREDUCE_SEQ) return fail(FSGPU_ERR_INVALID_CONFIG, "unknown hreduce mode");
+    std::unique_lock<std::shared_mutex> state(idx->state_mu);
     std::lock_guard<std::mutex> lock(idx->impl.mutex());
     idx->impl.hreduce = mode;
+    idx->impl.sync_replicas();
     return FSGPU_OK;
 }
 
@@ -267,8 +278,11 @@ fsgpu_status fsgpu_index_doc_id(const fsgpu_index* idx, uint32_t row, const char
 fsgpu_status fsgpu_index_soft_delete(fsgpu_index* idx, const char* doc_id, uint32_t doc_id_len, int32_t* deleted) {
     if (!idx || !doc_id || !deleted) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
     return guarded([&]() -> fsgpu_status {
+        std::unique_lock<std::shared_mutex> state(idx->state_mu);
         std::lock_guard<std::mutex> lock(idx->impl.mutex());
-        return finish(idx->impl.soft_delete(doc_id, doc_id_len, deleted));
+        const fsgpu::SearchError e = idx->impl.soft_delete(doc_id, doc_id_len, deleted);
+        idx->impl.sync_replicas();   // the live bitmap may have been re-uploaded
+        return finish(e);
     });
 }
 
@@ -284,8 +298,11 @@ fsgpu_status fsgpu_index_allow_bitmap_for_hashes(const fsgpu_index* idx, const u
 fsgpu_status fsgpu_index_set_live_bitmap(fsgpu_index* idx, const uint64_t* live_bitmap) {
     if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
     return guarded([&]() -> fsgpu_status {
+        std::unique_lock<std::shared_mutex> state(idx->state_mu);
         std::lock_guard<std::mutex> lock(idx->impl.mutex());
-        return finish(idx->impl.set_live_bitmap(live_bitmap));
+        const fsgpu::SearchError e = idx->impl.set_live_bitmap(live_bitmap);
+        idx->impl.sync_replicas();
+        return finish(e);
     });
 }
 
@@ -298,8 +315,32 @@ fsgpu_status fsgpu_search_topk(fsgpu_index* idx, const float* queries, uint32_t 
     if (idx->coalescer.enabled() && nq == 1 && !allow_bitmap && k >= 1 && k <= 64 && query_len == idx->impl.dimension())
         return coalesced_search(idx, queries, k, 0, out_rows, out_scores, out_counts);
     return guarded([&]() -> fsgpu_status {
-        std::lock_guard<std::mutex> lock(idx->impl.mutex());
-        return finish(idx->impl.search_top_k(queries, nq, query_len, k, allow_bitmap, out_rows, out_scores, out_counts));
+        // this index if it is free, else a free replica, else queue on one of the lanes in turn
+        std::shared_lock<std::shared_mutex> state(idx->state_mu);
+        std::unique_lock<std::mutex> lock(idx->impl.mutex(), std::try_to_lock);
+        fsgpu::VectorIndex* lane = &idx->impl;
+        if (!lock.owns_lock()) {
+            if (!idx->lanes_ready.load(std::memory_order_acquire)) {
+                std::lock_guard<std::mutex> init(idx->lanes_mu);
+                if (!idx->lanes_ready.load(std::memory_order_relaxed)) {
+                    std::lock_guard<std::mutex> primary(idx->impl.mutex());   // the replicas copy the primary's state
+                    fsgpu::SearchError e = idx->impl.ensure_replicas();
+                    if (!e.ok()) return finish(e);
+                    idx->lanes_ready.store(true, std::memory_order_release);
+                }
+            }
+            const size_t n = idx->impl.replica_count();
+            for (size_t i = 0; i < n && !lock.owns_lock(); ++i) {
+                lock = std::unique_lock<std::mutex>(idx->impl.replica(i)->mutex(), std::try_to_lock);
+                if (lock.owns_lock()) lane = idx->impl.replica(i);
+            }
+            if (!lock.owns_lock()) {
+                const uint32_t pick = idx->lane_rr.fetch_add(1, std::memory_order_relaxed) % (uint32_t)(n + 1);
+                lane = pick == 0 ? &idx->impl : idx->impl.replica(pick - 1);
+                lock = std::unique_lock<std::mutex>(lane->mutex());
+            }
+        }
+        return finish(lane->search_top_k(queries, nq, query_len, k, allow_bitmap, out_rows, out_scores, out_counts));
     });
 }
 
@@ -607,8 +648,11 @@ fsgpu_status fsgpu_index_wal_append(fsgpu_index* idx, const char* doc_id, uint32
                                     uint32_t vector_len) {
     if (!idx || !doc_id || !vector) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
     return guarded([&]() -> fsgpu_status {
+        std::unique_lock<std::shared_mutex> state(idx->state_mu);
         std::lock_guard<std::mutex> lock(idx->impl.mutex());
-        return finish(idx->impl.wal_append(doc_id, doc_id_len, vector, vector_len));
+        const fsgpu::SearchError e = idx->impl.wal_append(doc_id, doc_id_len, vector, vector_len);
+        idx->impl.sync_replicas();   // the shadowed main row was tombstoned
+        return finish(e);
     });
 }
 
@@ -820,16 +864,23 @@ fsgpu_status fsgpu_index_scan_stats(fsgpu_index* idx, double* total_ms, uint64_t
 
 fsgpu_status fsgpu_index_filter_stats(fsgpu_index* idx, uint64_t* gathered, uint64_t* scanned) {
     if (!idx || !gathered || !scanned) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    std::unique_lock<std::shared_mutex> state(idx->state_mu);   // no search is running on any lane
     std::lock_guard<std::mutex> lock(idx->impl.mutex());
     *gathered = idx->impl.filter_gathered;
     *scanned = idx->impl.filter_scanned;
+    for (size_t i = 0; i < idx->impl.replica_count(); ++i) {
+        *gathered += idx->impl.replica(i)->filter_gathered;
+        *scanned += idx->impl.replica(i)->filter_scanned;
+    }
     return FSGPU_OK;
 }
 
 fsgpu_status fsgpu_index_set_variant(fsgpu_index* idx, int32_t variant) {
     if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    std::unique_lock<std::shared_mutex> state(idx->state_mu);
     std::lock_guard<std::mutex> lock(idx->impl.mutex());
     idx->impl.variant = variant;
+    idx->impl.sync_replicas();
     return FSGPU_OK;
 }
 

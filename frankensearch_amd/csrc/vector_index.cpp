@@ -1492,6 +1492,27 @@ VectorIndex* VectorIndex::mrl_view(uint32_t dims) {
     return v;
 }
 
+SearchError VectorIndex::ensure_replicas() {
+    while (replicas_.size() + 1 < kLanes) {
+        auto v = std::make_unique<VectorIndex>();
+        FSGPU_TRY(v->init_device(device_, dim_, nrows_, slab_dev_, live_dev_, row_base_));
+        v->row_stride_ = row_stride_;
+        v->f32_ = f32_;
+        replicas_.push_back(std::move(v));
+    }
+    sync_replicas();
+    return ok();
+}
+
+void VectorIndex::sync_replicas() {
+    for (auto& v : replicas_) {
+        v->slab_dev_ = slab_dev_;
+        v->live_dev_ = live_dev_;
+        v->hreduce = hreduce;
+        v->variant = variant;
+    }
+}
+
 // VectorIndex::mrl_search_with_stats (crates/frankensearch-index/src/mrl.rs:241-395).
 SearchError VectorIndex::mrl_search(const float* query, uint32_t query_len, uint32_t k, uint32_t search_dims,
                                     uint32_t rescore_dims, uint32_t rescore_top_k, uint32_t* out_rows, float* out_scores,

@@ -125,6 +125,14 @@ class VectorIndex {
     uint64_t filter_gathered = 0, filter_scanned = 0;  // filtered host searches by path
     bool profiling = false;
     VectorIndex* mrl_view(uint32_t dims);  // strided prefix view of this slab (created on first use)
+    // Concurrent callers (the reference's scan is `&self`, lock-free, any number of callers: search.rs:192): replicas of this
+    // index over the SAME slab and live bitmap, each with its own stream, workspaces and mutex, so that row-level searches from
+    // different host threads run side by side instead of queueing on one stream.  The caller holds the owner's state lock.
+    static constexpr size_t kLanes = 4;                // this index + 3 replicas
+    SearchError ensure_replicas();                      // idempotent
+    VectorIndex* replica(size_t i) { return i < replicas_.size() ? replicas_[i].get() : nullptr; }
+    size_t replica_count() const { return replicas_.size(); }
+    void sync_replicas();                               // after a mutation: live bitmap pointer, hreduce, variant
     SearchError scan_time(double* total_ms, uint64_t* launches, uint64_t* rows, bool reset);
 
   private:
@@ -155,6 +163,7 @@ class VectorIndex {
     uint64_t row_base_ = 0;
     uint32_t row_stride_ = 0;  // bytes between rows; dim_*2 except for the MRL prefix views
     std::map<uint32_t, std::unique_ptr<VectorIndex>> views_;  // strided prefix views of this slab, by dimension
+    std::vector<std::unique_ptr<VectorIndex>> replicas_;      // lanes for concurrent row-level searches
     const void* slab_dev_ = nullptr;
     const uint64_t* live_dev_ = nullptr;
     bool owns_slab_ = false;

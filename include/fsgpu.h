@@ -10,7 +10,10 @@
  *   - every function returns an fsgpu_status (0 = OK); no exception crosses the boundary;
  *   - fsgpu_last_error() returns the calling thread's last failure detail (UTF-8);
  *   - all pointers are caller-owned unless stated; "_dev" pointers are HIP device pointers;
- *   - handles may be used from many host threads; calls on one handle serialise internally;
+ *   - handles may be used from many host threads.  fsgpu_search_topk calls (row-level searches, filtered or not) from
+ *     different threads run side by side on up to four lanes of an index (own HIP stream and workspaces each) — the
+ *     reference's scan is `&self` and lock-free (search.rs:192); every other call on a handle serialises internally, and
+ *     calls that change an index (tombstones, WAL, live bitmap) wait for the searches in flight;
  *   - row ids are GLOBAL physical row ids (row_base + local row), u32 like VectorHit.index
  *     (crates/frankensearch-core/src/types.rs:88-95);
  *   - result order is the reference's: score descending with NaN ranked as -inf, f32 total
