@@ -378,6 +378,18 @@ fsgpu_status fsgpu_index_coalescing_stats(fsgpu_index *idx, uint64_t *batches, u
 fsgpu_status fsgpu_m2v_set_coalescing(fsgpu_m2v *m, uint32_t max_batch, uint32_t max_wait_us);
 fsgpu_status fsgpu_bert_set_coalescing(fsgpu_bert *m, uint32_t max_batch, uint32_t max_wait_us);
 
+/* ---- experiment switches ----
+ * Environment variables read ONCE per process by libfsgpu.so.  None changes a result; they select kernel variants for A/B
+ * measurements (scripts/exp_*, scripts/prof_wide.sh) and are listed here so that nothing in the product path is hidden:
+ *   FSGPU_WIDE=0|2|3            batched main pass: 0 = queries in LDS (128 per pass), 2 / 3 = queries in registers (256 / 384)
+ *   FSGPU_WIDE_DBG=1..4         timing skeletons of that kernel (no MFMAs / no DMA / ...): answers are NOT valid
+ *   FSGPU_USE_160, FSGPU_MFMA_SHAPE, FSGPU_MFMA_SHAPE_I8   shapes of the LDS-query kernel
+ *   FSGPU_RA, FSGPU_RB, FSGPU_ROUND, FSGPU_NO_SKIP_B, FSGPU_NO_REVERSE   sample sizes / round size / pass direction
+ *   FSGPU_GRID_BLOCKS, FSGPU_I8_PER_CU   grid sizes of the exact kernels
+ *   FSGPU_SELECT_SORT_ABOVE     rank above which select_kernel sorts instead of extracting
+ *   FSGPU_BERT_GEMM_SHAPE, FSGPU_BERT_ATTN, FSGPU_BERT_NO_FUSED_LN, FSGPU_BERT_NO_GRAPH, FSGPU_BERT_NO_QUERY_PATH   encoder paths
+ *   FSGPU_DEBUG_BATCHED, FSGPU_DEBUG_GRAPH   one-line diagnostics on stderr */
+
 /* ---- instrumentation ---- */
 /* When enabled, HIP events bracket the scan kernel of every fsgpu_search_topk* call. */
 fsgpu_status fsgpu_index_set_profiling(fsgpu_index *idx, int32_t enabled);
