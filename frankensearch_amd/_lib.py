@@ -96,6 +96,7 @@ SIGNATURES = {
     "fsgpu_fsvi_write": (_i32, [C.c_char_p, C.c_char_p, C.c_char_p, _u32, _u64, _vp, _vp, _vp, C.c_uint8, _i32]),
     "fsgpu_fsvi_write_quant": (_i32, [C.c_char_p, C.c_char_p, C.c_char_p, _u32, _u64, _vp, _vp, _vp, C.c_uint8, _i32,
                                C.c_uint8]),
+    "fsgpu_search_mrl_batched": (_i32, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, C.POINTER(_u32)]),
     "fsgpu_search_mrl": (_i32, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, C.POINTER(_u32), _vp]),
     "fsgpu_index_set_coalescing": (_i32, [_vp, _u32, _u32]),
     "fsgpu_index_coalescing_stats": (_i32, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),

@@ -51,7 +51,7 @@ hipError_t launch_packed_to_sortkey(u64* data, size_t n, hipStream_t stream);
 hipError_t launch_sorted_keys_to_rows(const u64* keys, uint32_t k, uint32_t* out_rows, uint32_t* out_count,
                                       hipStream_t stream);
 hipError_t launch_gather_dot(const ScanArgs& args, const uint32_t* rows, uint32_t n, float* out, hipStream_t stream);
-hipError_t launch_gather_queries(const float* src, const uint32_t* idx, uint32_t n, uint32_t dim, float* dst,
+hipError_t launch_gather_queries(const float* src, const uint32_t* idx, uint32_t n, uint32_t dim, uint32_t src_stride, float* dst,
                                  hipStream_t stream);
 hipError_t launch_scatter_hits(const uint32_t* idx, uint32_t n, uint32_t k, const uint32_t* src_rows,
                                const float* src_scores, const uint32_t* src_counts, uint32_t* dst_rows,
@@ -99,6 +99,8 @@ struct MfmaScanArgs {
     uint32_t elem_bytes;                 // 2 = f16 slab / f16 queries (0 means 2), 1 = int8 slab / int8 queries
     uint32_t reverse;                    // main pass: walk the slab from its end (alternate passes re-read what the
                                          // previous pass left in the Infinity Cache)
+    uint32_t row_stride;                 // bytes between rows; 0 = dense (dim * elem_bytes).  MRL prefix views scan the first
+                                         // dim dimensions of rows that are row_stride bytes apart
     uint32_t groups;                     // sample stages: query groups answered by one launch (gridDim.y; 0 means 1) —
                                          // group g's queries/tau/cand/spill/overflow/dense follow group g-1's
 };
@@ -127,8 +129,10 @@ struct SelectArgs {
     uint32_t take_topk;        // != 0: the candidates are the k best entries themselves (exact pass-1 scores)
     // finish step
     const void* slab;          // [nrows, dim] f16
-    const float* queries;      // [nq, dim] f32
+    const float* queries;      // [nq, q_stride_f] f32 (the first dim of each are used)
     uint32_t dim, nrows, row_base;
+    uint32_t row_stride;       // bytes between slab rows; 0 = dim * 2
+    uint32_t query_stride;     // floats between queries; 0 = dim
     int hreduce;
     uint32_t k_out, out_stride;
     uint32_t* out_rows;        // [nq, out_stride] (may be null; 0xffffffff padding)
@@ -158,8 +162,9 @@ int scan_mfma_rows_per_tile(int shape);
 int scan_mfma_query_tiles(int shape);
 int scan_mfma_max_slots(int shape);  // LDS staging capacity per (query, block)
 hipError_t launch_scan_mfma(const MfmaScanArgs& args, int shape, int grid, hipStream_t stream, int* occupancy);
-hipError_t launch_max_row_norm(const void* slab, uint32_t nrows, uint32_t dim, unsigned int* out_bits, hipStream_t stream);
-hipError_t launch_prepare_queries(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim,
+hipError_t launch_max_row_norm(const void* slab, uint32_t nrows, uint32_t dim, uint32_t row_stride_bytes, unsigned int* out_bits,
+                               hipStream_t stream);
+hipError_t launch_prepare_queries(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t q_stride,
                                   const unsigned int* max_norm_bits, void* qh, float* delta, hipStream_t stream);
 
 // int8_kernels.hip

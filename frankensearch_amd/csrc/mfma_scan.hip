@@ -114,7 +114,7 @@ __global__ __launch_bounds__(WPB * 64) void scan_mfma_kernel(MfmaScanArgs args) 
     const uint32_t ntiles = STAGE == 2 ? (args.nrows + TROWS - 1) / TROWS : args.group_count * TPG;
     const uint32_t nwaves = gridDim.x * WPB;
     const unsigned char* slab = reinterpret_cast<const unsigned char*>(args.slab);
-    constexpr size_t row_bytes = (size_t)DIM * 2;
+    const size_t row_bytes = args.row_stride ? (size_t)args.row_stride : (size_t)DIM * 2;
     const uint32_t last_row = args.nrows - 1;
     auto tile_row0 = [&](uint32_t t) -> uint32_t {
         if (STAGE == 2) return t * TROWS;
@@ -526,7 +526,8 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
         const int dim = (int)args.dim;
         const int a = tid & 3;
         const int nc = ncand < POOL ? ncand : POOL;
-        const float* qv = args.queries + (size_t)q * dim;
+        const float* qv = args.queries + (size_t)q * (args.query_stride ? args.query_stride : (uint32_t)dim);
+        const size_t row_pitch = args.row_stride ? (size_t)args.row_stride : (size_t)dim * 2;
         const int chunks = dim >> 3, groups = chunks >> 2, leftover = chunks & 3;
         for (int c0 = 0; c0 < nc; c0 += NT / 4) {  // block-uniform trip count
             const int c = c0 + (tid >> 2);
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
             uint32_t row = grow - args.row_base;
             const bool mine = mine_e != kEmpty && row < args.nrows;
             if (!mine) row = 0;
-            const u32x4* p = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(args.slab) + (size_t)row * dim * 2);
+            const u32x4* p = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(args.slab) + (size_t)row * row_pitch);
             float acc[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = 0.f;
@@ -578,13 +579,14 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
 
 // max over rows of the f32 Euclidean norm (order-free upper bound use only), as float bits via atomic max.
 __global__ __launch_bounds__(256) void max_row_norm_kernel(const unsigned short* __restrict__ slab, uint32_t nrows,
-                                                           uint32_t dim, unsigned int* __restrict__ out_bits) {
+                                                           uint32_t dim, uint32_t row_stride_halves,
+                                                           unsigned int* __restrict__ out_bits) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave_gid = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * 256) >> 6;
     float m = 0.f;
     for (uint32_t row = wave_gid; row < nrows; row += nwaves) {
-        const _Float16* p = reinterpret_cast<const _Float16*>(slab) + (size_t)row * dim;
+        const _Float16* p = reinterpret_cast<const _Float16*>(slab) + (size_t)row * row_stride_halves;
         float s = 0.f;
         for (uint32_t i = lane; i < dim; i += 64) {
             const float v = (float)p[i];
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(256) void max_row_norm_kernel(const unsigned short*
 }
 
 // f32 queries -> zero-padded f16 rows + the per-query error bound delta_q (see header).
-__global__ __launch_bounds__(256) void prepare_queries_kernel(const float* __restrict__ q, uint32_t nq, uint32_t nq_pad,
+__global__ __launch_bounds__(256) void prepare_queries_kernel(const float* __restrict__ q, uint32_t nq, uint32_t q_stride,
                                                               uint32_t dim, const unsigned int* __restrict__ max_norm_bits,
                                                               _Float16* __restrict__ qh, float* __restrict__ delta) {
     __shared__ float red[4];
@@ -610,7 +612,7 @@ __global__ __launch_bounds__(256) void prepare_queries_kernel(const float* __res
     float s = 0.f;
     bool bad = false;
     for (uint32_t i = tid; i < dim; i += 256) {
-        const float v = b < nq ? q[(size_t)b * dim + i] : 0.f;
+        const float v = b < nq ? q[(size_t)b * q_stride + i] : 0.f;
         qh[(size_t)b * dim + i] = (_Float16)v;
         s += v * v;
         // |v| above the largest finite f16 (65504) rounds to +-inf (and NaN stays NaN): the approximate scores of such a
@@ -630,7 +632,6 @@ __global__ __launch_bounds__(256) void prepare_queries_kernel(const float* __res
         // padding rows, all-zero and non-finite queries cannot be certified: negative delta = "skip" marker
         if (b >= nq || !(qnorm > 0.f) || !__builtin_isfinite(d) || unrepresentable) d = -1.0f;
         delta[b] = d;
-        (void)nq_pad;
     }
 }
 
@@ -669,7 +670,7 @@ static std::atomic<const char*> g_last_main_pass_kernel{""};
 const char* last_main_pass_kernel() { return g_last_main_pass_kernel.load(std::memory_order_relaxed); }
 void note_main_pass_kernel(const char* name) { g_last_main_pass_kernel.store(name, std::memory_order_relaxed); }
 
-bool scan_mfma_supported(int dim) { return dim == 128 || dim == 256 || dim == 384; }
+bool scan_mfma_supported(int dim) { return dim == 64 || dim == 128 || dim == 256 || dim == 384; }
 
 template <int DIM, int NQT, int WPB, int STAGE, int RT, bool PF, int EB>
 static hipError_t launch_mfma_s(const MfmaScanArgs& args, int grid, hipStream_t stream, int* occupancy) {
@@ -737,6 +738,7 @@ static hipError_t launch_mfma_d(const MfmaScanArgs& args, int shape, int grid, h
 hipError_t launch_scan_mfma(const MfmaScanArgs& args, int shape, int grid, hipStream_t stream, int* occupancy) {
     if (args.elem_bytes == 1) {
         switch (args.dim) {
+            case 64: return launch_mfma_d<64, 1>(args, shape, grid, stream, occupancy);
             case 128: return launch_mfma_d<128, 1>(args, shape, grid, stream, occupancy);
             case 256: return launch_mfma_d<256, 1>(args, shape, grid, stream, occupancy);
             case 384: return launch_mfma_d<384, 1>(args, shape, grid, stream, occupancy);
@@ -744,6 +746,7 @@ hipError_t launch_scan_mfma(const MfmaScanArgs& args, int shape, int grid, hipSt
         }
     }
     switch (args.dim) {
+        case 64: return launch_mfma_d<64, 2>(args, shape, grid, stream, occupancy);
         case 128: return launch_mfma_d<128, 2>(args, shape, grid, stream, occupancy);
         case 256: return launch_mfma_d<256, 2>(args, shape, grid, stream, occupancy);
         case 384: return launch_mfma_d<384, 2>(args, shape, grid, stream, occupancy);
@@ -788,17 +791,18 @@ hipError_t launch_select(const SelectArgs& args, int nq, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_max_row_norm(const void* slab, uint32_t nrows, uint32_t dim, unsigned int* out_bits, hipStream_t stream) {
+hipError_t launch_max_row_norm(const void* slab, uint32_t nrows, uint32_t dim, uint32_t row_stride_bytes, unsigned int* out_bits,
+                               hipStream_t stream) {
     hipError_t e = hipMemsetAsync(out_bits, 0, 4, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(max_row_norm_kernel, dim3(2048), dim3(256), 0, stream, static_cast<const unsigned short*>(slab),
-                       nrows, dim, out_bits);
+                       nrows, dim, row_stride_bytes ? row_stride_bytes / 2 : dim, out_bits);
     return hipGetLastError();
 }
 
-hipError_t launch_prepare_queries(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim,
+hipError_t launch_prepare_queries(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t q_stride,
                                   const unsigned int* max_norm_bits, void* qh, float* delta, hipStream_t stream) {
-    hipLaunchKernelGGL(prepare_queries_kernel, dim3(nq_pad), dim3(256), 0, stream, q, nq, nq_pad, dim, max_norm_bits,
+    hipLaunchKernelGGL(prepare_queries_kernel, dim3(nq_pad), dim3(256), 0, stream, q, nq, q_stride ? q_stride : dim, dim, max_norm_bits,
                        static_cast<_Float16*>(qh), delta);
     return hipGetLastError();
 }

@@ -131,6 +131,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     const uint32_t rounds = (ntiles + grid - 1) / grid;
     const uint32_t last_row = args.nrows - 1;
     const unsigned char* slab = reinterpret_cast<const unsigned char*>(args.slab);
+    const size_t row_pitch = args.row_stride ? (size_t)args.row_stride : (size_t)ROWB;   // MRL prefix views: rows further apart
     struct Cursor {
         uint32_t n, base, rot;   // round, n * grid, n mod grid
     };
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
             const int s = j / KS, ks = j - s * KS;
             uint32_t row = row0 + s * 16 + dma_p;
             row = row < args.nrows ? row : last_row;
-            const unsigned char* g = slab + (size_t)row * ROWB + ks * 64 + dma_chunk * 16;
+            const unsigned char* g = slab + (size_t)row * row_pitch + ks * 64 + dma_chunk * 16;
             const uint32_t dst = __builtin_amdgcn_readfirstlane(ring + slot * TILE_BYTES + (uint32_t)j * 1024u);
             if constexpr (DBG != 2) glds16(g, dst);
             else asm volatile("" ::"v"(g), "s"(dst));

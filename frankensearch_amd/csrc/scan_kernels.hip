@@ -788,9 +788,9 @@ hipError_t launch_encode_rows_f16(const float* src, const uint32_t* perm, uint64
 // Batched-path fallbacks: the queries the matrix-core path could not certify are compacted, answered together by
 // the exact kernels (8 per pass) and written back to their slots.
 __global__ void gather_queries_kernel(const float* __restrict__ src, const uint32_t* __restrict__ idx, uint32_t dim,
-                                      float* __restrict__ dst) {
+                                      uint32_t src_stride, float* __restrict__ dst) {
     const uint32_t j = blockIdx.x;
-    for (uint32_t i = threadIdx.x; i < dim; i += blockDim.x) dst[(size_t)j * dim + i] = src[(size_t)idx[j] * dim + i];
+    for (uint32_t i = threadIdx.x; i < dim; i += blockDim.x) dst[(size_t)j * dim + i] = src[(size_t)idx[j] * src_stride + i];
 }
 
 __global__ void scatter_hits_kernel(const uint32_t* __restrict__ idx, uint32_t k, const uint32_t* __restrict__ src_rows,
@@ -809,9 +809,9 @@ __global__ void scatter_hits_kernel(const uint32_t* __restrict__ idx, uint32_t k
     if (threadIdx.x == 0 && dst_counts) dst_counts[q] = n;
 }
 
-hipError_t launch_gather_queries(const float* src, const uint32_t* idx, uint32_t n, uint32_t dim, float* dst,
+hipError_t launch_gather_queries(const float* src, const uint32_t* idx, uint32_t n, uint32_t dim, uint32_t src_stride, float* dst,
                                  hipStream_t stream) {
-    hipLaunchKernelGGL(gather_queries_kernel, dim3(n), dim3(128), 0, stream, src, idx, dim, dst);
+    hipLaunchKernelGGL(gather_queries_kernel, dim3(n), dim3(128), 0, stream, src, idx, dim, src_stride ? src_stride : dim, dst);
     return hipGetLastError();
 }
 

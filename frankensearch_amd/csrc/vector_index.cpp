@@ -1016,7 +1016,7 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
                                                      float* out_scores_dev, uint32_t* out_counts_dev,
                                                      hipStream_t stream, uint32_t* fallbacks, uint64_t* out_packed_dev) {
     return batched_impl(queries_dev, nq, query_len, k, allow_dev, out_rows_dev, out_scores_dev, out_counts_dev, stream,
-                        fallbacks, out_packed_dev, 0);
+                        fallbacks, out_packed_dev, 0, 0);
 }
 
 // int8 pass 1 on the matrix cores for a whole batch (exact integer scores), exact f16 rescore, top-k: the batched form of
@@ -1026,7 +1026,7 @@ SearchError VectorIndex::search_top_k_int8_batched_device(const float* queries_d
                                                           float* out_scores_dev, uint32_t* out_counts_dev,
                                                           hipStream_t stream, uint32_t* fallbacks) {
     return batched_impl(queries_dev, nq, query_len, k, nullptr, out_rows_dev, out_scores_dev, out_counts_dev, stream,
-                        fallbacks, nullptr, multiplier ? multiplier : 1);
+                        fallbacks, nullptr, multiplier ? multiplier : 1, 0);
 }
 
 // int8_mult == 0: f16 slab, f16-rounded queries, approximate scores + proven margin (mfma_scan.hip header).
@@ -1034,8 +1034,10 @@ SearchError VectorIndex::search_top_k_int8_batched_device(const float* queries_d
 SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
                                       const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
                                       uint32_t* out_counts_dev, hipStream_t stream, uint32_t* fallbacks,
-                                      uint64_t* out_packed_dev, uint32_t int8_mult) {
+                                      uint64_t* out_packed_dev, uint32_t int8_mult, uint32_t query_stride) {
+    // query_stride: floats between queries (0 = dim): an MRL prefix view searches the first dim_ dimensions of full-length queries
     const bool i8 = int8_mult != 0;
+    const uint32_t qs = query_stride ? query_stride : dim_;
     if (fallbacks) *fallbacks = 0;
     FSGPU_TRY(ensure_query_dimension(query_len));
     if (nq == 0) return ok();
@@ -1067,14 +1069,25 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     if (knobs().ra <= 0 && ksel_est > 32) RA = RA_MAX;
     // B = about 1/64 of the slab (times the growth), between 8 RA and the cap, a multiple of RA, at most a quarter of it
     RB = std::min<uint32_t>(RB * grow, std::max<uint32_t>(8 * RA, (uint32_t)(nrows_ / 64) * grow));
+    if (knobs().rb <= 0) {
+        // ... and large enough that the main pass lets ~1,000 rows per query through (ksel N / RB): beyond that the per-block
+        // lists and the spill area of the hottest queries overflow (50M rows, k = 10: 10 of 1,024 queries fell back to the
+        // exact kernels with the 131,072-row cap, none with 488k — a sample pass of 0.4 ms per 1,024 queries next to 37 ms)
+        const uint64_t need = (uint64_t)ksel_est * nrows_ / 1024;
+        if (need > RB) {
+            RB = (uint32_t)std::min<uint64_t>(need, nrows_ / 8);
+            if (knobs().ra <= 0) RA = RA_MAX;   // keeps the sample stage's own survivors (ksel RB / RA) in the hundreds
+        }
+    }
     RB = std::min<uint32_t>(RB, (uint32_t)(nrows_ / 4));
     RB = std::max<uint32_t>(RA, RB / RA * RA);
     // int8 mode: candidate_count of the reference (search.rs:603-607)
     uint64_t cc64 = std::min<uint64_t>((uint64_t)k * (i8 ? int8_mult : 1), nrows_);
     cc64 = std::max<uint64_t>(cc64, std::min<uint64_t>(k, nrows_));
     const uint32_t ksel = i8 ? (uint32_t)std::min<uint64_t>(cc64, 0xffffffffull) : k;  // rank that anchors the selections
+    const bool strided = row_stride_ && row_stride_ != dim_ * 2;   // an MRL prefix view
     const bool usable = scan_mfma_supported((int)dim_) && k >= 1 && k <= 64 && ksel <= kSelectMaxK && nrows_ >= 4 * (uint64_t)RA && variant != 4 &&
-                        !f32_ && (!row_stride_ || row_stride_ == dim_ * 2);
+                        !f32_ && (!strided || (!i8 && qs >= dim_)) && (query_stride == 0 || !i8);
     if (!usable && i8) {
         // per-query int8 two-pass through host staging (rare shapes: huge candidate counts, tiny or odd-dimension slabs)
         std::vector<float> q((size_t)nq * dim_), sc((size_t)nq * k);
@@ -1091,6 +1104,8 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         if (fallbacks) *fallbacks = nq;
         return ok();
     }
+    if (!usable && query_stride)
+        return make_error(FSGPU_ERR_INVALID_CONFIG, "strided queries need the matrix-core path (caller falls back per query)");
     if (!usable) {
         if (fallbacks) *fallbacks = nq;
         if (out_packed_dev) {
@@ -1111,7 +1126,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     }
     if (!i8 && !mf_norm_ready_) {
         FSGPU_TRY(mf_max_norm_.reserve(4));
-        FSGPU_HIP(launch_max_row_norm(slab_dev_, N, dim_, static_cast<unsigned int*>(mf_max_norm_.ptr), stream));
+        FSGPU_HIP(launch_max_row_norm(slab_dev_, N, dim_, strided ? row_stride_ : 0, static_cast<unsigned int*>(mf_max_norm_.ptr), stream));
         mf_norm_ready_ = true;
     }
     // A large batch is answered a "round" of up to QCAP queries at a time: the sample stages and every selection of
@@ -1198,12 +1213,12 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
             return g < 1 ? 1 : g;
         };
         const uint32_t tile_rows = (uint32_t)scan_mfma_rows_per_tile(shape);
-        const float* qg = queries_dev + (size_t)g0 * dim_;
+        const float* qg = queries_dev + (size_t)g0 * qs;
         uint32_t* overflow = overflow_all + g0;
         uint32_t* cand_counts = counts_all + g0;
         if (i8) FSGPU_HIP(launch_prepare_queries_i8(qg, ng, QP, dim_, mf_qh_.ptr, delta, stream));
         else
-            FSGPU_HIP(launch_prepare_queries(qg, ng, QP, dim_, static_cast<const unsigned int*>(mf_max_norm_.ptr),
+            FSGPU_HIP(launch_prepare_queries(qg, ng, QP, dim_, qs, static_cast<const unsigned int*>(mf_max_norm_.ptr),
                                              mf_qh_.ptr, delta, stream));
         // one candidate list of `slots` entries per (query, block); 16..32 slots, sized so that lists + pool fit one
         // selection pass when the grid allows (the wide shape's 256 blocks do)
@@ -1226,6 +1241,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         a.spill_cap = SPILL;
         a.overflow = overflow;
         a.dim = dim_;
+        a.row_stride = strided ? row_stride_ : 0;
         a.row_base = (uint32_t)row_base_;
         // samples, in 64-row groups spread evenly over the slab: B = every stride_b-th group, A = a subset of B
         const uint32_t groups_a = RA / 64, groups_b = RB / 64;
@@ -1335,6 +1351,8 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         sb.slab = slab_dev_;
         sb.queries = qg;
         sb.dim = dim_;
+        sb.row_stride = strided ? row_stride_ : 0;
+        sb.query_stride = qs;
         sb.nrows = N;
         sb.row_base = (uint32_t)row_base_;
         sb.hreduce = hreduce;
@@ -1395,7 +1413,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         uint32_t* counts_dev = reinterpret_cast<uint32_t*>(base + o_counts);
         FSGPU_HIP(hipMemcpyAsync(idx_dev, fb.data(), nf * 4, hipMemcpyHostToDevice, stream));
         FSGPU_HIP(hipStreamSynchronize(stream));  // fb is a stack-owned pageable buffer
-        FSGPU_HIP(launch_gather_queries(queries_dev, idx_dev, (uint32_t)nf, dim_, q_dev, stream));
+        FSGPU_HIP(launch_gather_queries(queries_dev, idx_dev, (uint32_t)nf, dim_, qs, q_dev, stream));
         FSGPU_TRY(fused_search(q_dev, (uint32_t)nf, k, k_eff, allow_dev, rows_dev, scores_dev, counts_dev, nullptr, stream));
         FSGPU_HIP(launch_scatter_hits(idx_dev, (uint32_t)nf, k, rows_dev, scores_dev, counts_dev, out_rows_dev,
                                       out_scores_dev, out_counts_dev, reinterpret_cast<u64*>(out_packed_dev), stream));
@@ -1612,6 +1630,89 @@ SearchError VectorIndex::mrl_search(const float* query, uint32_t query_len, uint
     }
     *out_count = n;
     if (stats) *stats = st;
+    return ok();
+}
+
+// mrl_search for a whole batch (mrl.rs:241-395 per query): phase 1 is the batched matrix-core scan of the prefix view (the
+// first search_dims dimensions of every row, rows dim_ * 2 bytes apart, full-length queries read through a stride) with
+// k = rescore_top_k — exact top-rtop of the truncated scores, as the per-query scan gives; phase 2 re-scores each query's
+// candidates over rescore_dims in one select_kernel launch (exact-order dot, best k emitted).  Indexes with resident WAL
+// entries, F32 slabs and shapes the matrix-core path does not cover are answered query by query.
+SearchError VectorIndex::mrl_search_batched(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k, uint32_t search_dims,
+                                            uint32_t rescore_dims, uint32_t rescore_top_k, uint32_t* out_rows, float* out_scores,
+                                            uint32_t* out_counts, uint32_t* fallbacks) {
+    if (fallbacks) *fallbacks = 0;
+    FSGPU_TRY(ensure_query_dimension(query_len));
+    if (search_dims == 0) return make_error(FSGPU_ERR_INVALID_CONFIG, "search_dims must be at least 1");
+    if (nq == 0) return ok();
+    uint32_t rdims = (rescore_dims == 0 || rescore_dims > dim_) ? dim_ : rescore_dims;  // mrl.rs:92-105
+    if (rdims < search_dims) rdims = search_dims;
+    const uint64_t rtop64 = rescore_top_k ? rescore_top_k : (uint64_t)k * 3;             // mrl.rs:108-114
+    const bool fast = search_dims < dim_ && k >= 1 && k <= 64 && rtop64 >= 1 && rtop64 <= 64 && wal_.empty() && !f32_ && nrows_ > 0 &&
+                      scan_mfma_supported((int)search_dims) && (rdims % 8 == 0) && nrows_ >= 4 * 8192ull && variant != 4 &&
+                      row_stride_ == 0;
+    if (!fast) {
+        for (uint32_t i = 0; i < nq; ++i)
+            FSGPU_TRY(mrl_search(queries + (size_t)i * dim_, query_len, k, search_dims, rescore_dims, rescore_top_k,
+                                 out_rows + (size_t)i * k, out_scores + (size_t)i * k, &out_counts[i], nullptr));
+        if (fallbacks) *fallbacks = nq;
+        return ok();
+    }
+    const uint32_t rtop = (uint32_t)rtop64;
+    VectorIndex* view = mrl_view(search_dims);
+    if (!view) return make_error(FSGPU_ERR_DEVICE, "cannot create the truncated view");
+    FSGPU_HIP(hipSetDevice(device_));
+    auto align_up = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
+    const size_t o_q = 0, o_packed = align_up((size_t)nq * dim_ * 4, 256), o_zero = align_up(o_packed + (size_t)nq * rtop * 8, 256),
+                 o_rows = align_up(o_zero + (size_t)nq * 4, 256), o_scores = align_up(o_rows + (size_t)nq * k * 4, 256),
+                 o_counts = align_up(o_scores + (size_t)nq * k * 4, 256), total = align_up(o_counts + (size_t)nq * 4, 256);
+    FSGPU_TRY(mf_io_.reserve(total));
+    unsigned char* base = static_cast<unsigned char*>(mf_io_.ptr);
+    float* q_dev = reinterpret_cast<float*>(base + o_q);
+    u64* packed = reinterpret_cast<u64*>(base + o_packed);
+    float* zero = reinterpret_cast<float*>(base + o_zero);
+    uint32_t* rows_dev = reinterpret_cast<uint32_t*>(base + o_rows);
+    float* scores_dev = reinterpret_cast<float*>(base + o_scores);
+    uint32_t* counts_dev = reinterpret_cast<uint32_t*>(base + o_counts);
+    FSGPU_HIP(hipMemcpyAsync(q_dev, queries, (size_t)nq * dim_ * 4, hipMemcpyHostToDevice, stream_));
+    FSGPU_HIP(hipMemsetAsync(zero, 0, (size_t)nq * 4, stream_));
+    view->hreduce = hreduce;
+    uint32_t fb = 0;
+    FSGPU_TRY(view->batched_impl(q_dev, nq, search_dims, rtop, nullptr, nullptr, nullptr, nullptr, stream_, &fb,
+                                 reinterpret_cast<uint64_t*>(packed), 0, dim_));
+    for (auto& ev : view->events_) events_.push_back(ev);   // the view's timed launches count as this index's
+    view->events_.clear();
+    profiled_rows_ += view->profiled_rows_;
+    view->profiled_rows_ = 0;
+    // phase 2 (mrl.rs:587-618): every candidate re-scored over rdims in the reference's order, best k per query
+    SelectArgs s{};
+    s.lists = packed;
+    s.q_stride = rtop;
+    s.l_stride = rtop;
+    s.nlists = 1;
+    s.list_len = rtop;
+    s.k = rtop;
+    s.take_topk = 1;          // the list IS the candidate set
+    s.delta = zero;
+    s.slab = slab_dev_;
+    s.queries = q_dev;
+    s.dim = rdims;
+    s.row_stride = rdims == dim_ ? 0 : dim_ * 2;
+    s.query_stride = dim_;
+    s.nrows = (uint32_t)nrows_;
+    s.row_base = (uint32_t)row_base_;
+    s.hreduce = hreduce;
+    s.k_out = (uint32_t)std::min<uint64_t>(k, nrows_);
+    s.out_stride = k;
+    s.out_rows = rows_dev;
+    s.out_scores = scores_dev;
+    s.out_counts = counts_dev;
+    FSGPU_HIP(launch_select(s, (int)nq, stream_));
+    FSGPU_HIP(hipMemcpyAsync(out_rows, rows_dev, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream_));
+    FSGPU_HIP(hipMemcpyAsync(out_scores, scores_dev, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream_));
+    FSGPU_HIP(hipMemcpyAsync(out_counts, counts_dev, (size_t)nq * 4, hipMemcpyDeviceToHost, stream_));
+    FSGPU_HIP(hipStreamSynchronize(stream_));
+    if (fallbacks) *fallbacks = fb;
     return ok();
 }
 

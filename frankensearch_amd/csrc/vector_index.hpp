@@ -109,6 +109,10 @@ class VectorIndex {
     SearchError mrl_search(const float* query, uint32_t query_len, uint32_t k, uint32_t search_dims, uint32_t rescore_dims,
                            uint32_t rescore_top_k, uint32_t* out_rows, float* out_scores, uint32_t* out_count,
                            MrlStats* stats);
+    // mrl_search for nq host queries at once: batched truncated scan on the matrix cores + one re-score launch (no stats)
+    SearchError mrl_search_batched(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k, uint32_t search_dims,
+                                   uint32_t rescore_dims, uint32_t rescore_top_k, uint32_t* out_rows, float* out_scores,
+                                   uint32_t* out_counts, uint32_t* fallbacks);
     // VectorIndex::append (lib.rs:2532-2720): resident WAL entry, immediately searchable.
     SearchError wal_append(const char* doc_id, uint32_t len, const float* vector, uint32_t vector_len);
     uint64_t wal_record_count() const { return wal_.size(); }
@@ -140,7 +144,7 @@ class VectorIndex {
     void* pinned_io();
     SearchError batched_impl(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k, const uint64_t* allow_dev,
                              uint32_t* out_rows_dev, float* out_scores_dev, uint32_t* out_counts_dev, hipStream_t stream,
-                             uint32_t* fallbacks, uint64_t* out_packed_dev, uint32_t int8_mult);
+                             uint32_t* fallbacks, uint64_t* out_packed_dev, uint32_t int8_mult, uint32_t query_stride);
     SearchError quantized_two_pass(const float* query, uint32_t query_len, uint32_t k, uint32_t multiplier, int bits,
                                    uint32_t* out_rows, float* out_scores, uint32_t* out_count);
     SearchError common_init(int device);

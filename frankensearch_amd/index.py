@@ -194,6 +194,19 @@ class VectorIndex:
         hits = [VectorHit(int(rows[i]), float(scores[i])) for i in range(n.value)]
         return ClassifiedHits(hits, _ZERO_SIGNAL.get(z.value))
 
+    def mrl_search_batched(self, queries: np.ndarray, limit: int, search_dims: int = 64, rescore_dims: int = 0,
+                           rescore_top_k: int = 0):
+        """fsgpu_search_mrl_batched: mrl_search (mrl.rs:241-395) for a batch -> rows [nq, k], scores, counts, fallbacks."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        nq = q.shape[0]
+        rows = np.full((nq, max(limit, 1)), 0xFFFFFFFF, dtype=np.uint32)
+        scores = np.zeros((nq, max(limit, 1)), dtype=np.float32)
+        counts = np.zeros(nq, dtype=np.uint32)
+        fb = C.c_uint32()
+        check(_lib.lib().fsgpu_search_mrl_batched(self._h, _ptr(q), nq, q.shape[1], limit, search_dims, rescore_dims, rescore_top_k,
+                                                  _ptr(rows), _ptr(scores), _ptr(counts), C.byref(fb)))
+        return rows[:, :limit], scores[:, :limit], counts, fb.value
+
     def mrl_search(self, query: Sequence[float], limit: int, search_dims: int = 64, rescore_dims: int = 0,
                    rescore_top_k: int = 0, with_stats: bool = False):
         """VectorIndex::mrl_search / mrl_search_with_stats (mrl.rs:241-395; MrlConfig defaults :79-87)."""

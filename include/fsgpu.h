@@ -365,6 +365,15 @@ fsgpu_status fsgpu_search_mrl(fsgpu_index *idx, const float *query, uint32_t que
                               uint32_t rescore_dims, uint32_t rescore_top_k, uint32_t *out_rows, float *out_scores,
                               uint32_t *out_count, fsgpu_mrl_stats *stats);
 
+/* fsgpu_search_mrl for nq queries at once (row-level results, no stats): the truncated scan of phase 1 runs on the matrix cores
+ * for the whole batch (mfma_scan.hip / mfma_wide.hip over the strided prefix of every row: N*search_dims*2 bytes per 256-384
+ * queries), phase 2 re-scores every query's rescore_top_k candidates in one launch.  Outputs as fsgpu_search_topk ([nq, k]
+ * rows / scores, [nq] counts); hits equal fsgpu_search_mrl's for each query.  Resident WAL entries, rescore_top_k > 64,
+ * k > 64 or unsupported search_dims (not 64 / 128 / 256) are answered query by query (*out_fallbacks, may be NULL). */
+fsgpu_status fsgpu_search_mrl_batched(fsgpu_index *idx, const float *queries, uint32_t nq, uint32_t query_len, uint32_t k,
+                                      uint32_t search_dims, uint32_t rescore_dims, uint32_t rescore_top_k, uint32_t *out_rows,
+                                      float *out_scores, uint32_t *out_counts, uint32_t *out_fallbacks);
+
 /* ---- dynamic batching of concurrent callers ---- */
 /* The reference's seams are per-query calls made by many host threads at once (VectorIndex::search_top_k takes &self,
  * crates/frankensearch-index/src/search.rs:192; SyncEmbed::embed_sync, crates/frankensearch-core/src/traits.rs:401-582;

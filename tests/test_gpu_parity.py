@@ -547,6 +547,39 @@ def test_config2_batched_1m_rows_against_the_oracle(fa, oracle):
             assert np.array_equal(br[qi], orow) and np.array_equal(bits(bs[qi]), bits(osc)), (b, qi)
 
 
+def test_mrl_batched_equals_per_query_and_oracle(fa, oracle):
+    # fsgpu_search_mrl_batched = mrl_search (mrl.rs:241-395) for a batch: the truncated scan on the matrix cores over the
+    # strided prefix view, one re-score launch; every hit (rows and score bits) against the per-query call and the oracle
+    rng = np.random.default_rng(202)
+    n, dim = 150_000, 384
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    rows[:, :64] *= 3.0
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    rows[700] = rows[33]                                   # exact duplicate: tie broken by the lower row
+    slab = rows.astype(np.float16).view(np.uint16)
+    live = rng.random(n) > 0.1
+    idx = fa.VectorIndex.from_slab(slab, live=live)
+    nq = 300                                               # one 256-query wide pass + a 64-query tail
+    q = rows[rng.integers(0, n, nq)] + 0.1 * rng.standard_normal((nq, dim)).astype(np.float32)
+    q[5] = 0.0
+    for sd, rd, rt, k in ((64, 0, 0, 10), (128, 0, 0, 10), (256, 0, 0, 7), (64, 128, 40, 10), (128, 0, 64, 20)):
+        br, bs, bc, fb = idx.mrl_search_batched(q, k, sd, rd, rt)
+        assert fb < nq // 4, (sd, fb)
+        for qi in list(range(0, nq, 29)) + [5, 255, 256, 299]:
+            hits = idx.mrl_search(q[qi], k, sd, rd, rt)
+            assert [h.index for h in hits] == br[qi, :bc[qi]].tolist(), (sd, rd, rt, k, qi)
+            assert np.array_equal(bits([h.score for h in hits]), bits(bs[qi, :bc[qi]])), (sd, rd, rt, k, qi)
+        for qi in (0, 131, 299):
+            er, es = oracle.mrl_search(slab, q[qi], k, sd, rd, rt, live=live)
+            assert br[qi, :bc[qi]].tolist() == er.tolist() and np.array_equal(bits(bs[qi, :bc[qi]]), bits(es)), (sd, qi)
+    # shapes the batched path does not cover go query by query and still agree
+    br, bs, bc, fb = idx.mrl_search_batched(q[:9], 10, 20, 0, 0)
+    assert fb == 9
+    for qi in range(9):
+        hits = idx.mrl_search(q[qi], 10, 20)
+        assert [h.index for h in hits] == br[qi, :bc[qi]].tolist()
+
+
 def test_batched_certificate_edges_overflow_subnormals_and_near_duplicates(fa, oracle):
     """The batched path is exact only through its certificate (|a - s| <= delta, mfma_scan.hip header); the cases where the
     certificate cannot hold or cannot separate must end on the exact kernels and still return the oracle's bits:
