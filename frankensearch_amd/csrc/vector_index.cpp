@@ -1166,7 +1166,9 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     // (384 per launch when that many queries are left: the matrix pipe is the bound there and fewer passes leave it more of
     // the power budget — measured 148 k against 130 k queries/s at 10M x 384)
     const int wide_pref = knobs().wide >= 0 ? knobs().wide : 3;
-    const bool wide_ok = (wide_pref == 2 || wide_pref == 3) && scan_wide_supported((int)dim_, i8 ? 1 : 2) && variant != 5 && variant != 6;
+    // 6: 384 queries per launch on FOUR waves of 96 queries (f16 rows of 768 bytes only; otherwise as 3)
+    const bool wide_ok = (wide_pref == 2 || wide_pref == 3 || wide_pref == 6) && scan_wide_supported((int)dim_, i8 ? 1 : 2) && variant != 5 && variant != 6;
+    const bool wide_four_waves = wide_pref == 6 && !i8 && dim_ == 384;
     // per-query verdicts, written by the kernels straight into pinned host memory and read after ONE stream
     // synchronisation for the whole batch: [0, cap) = overflow flags, [cap, 2 cap) = candidate counts
     const uint32_t flag_cap = (nq + GMAX - 1) / GMAX * GMAX + GMAX;
@@ -1191,7 +1193,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         // Main pass at 384 / 256 queries per launch (mfma_wide.hip: queries in registers, row tiles through an LDS-DMA
         // ring) when that many are left; the sample stages then run as sub-groups of 128 on the LDS-query kernel.
         int wide_qt = 0;
-        if (wide_ok && left >= 256) wide_qt = (wide_pref == 3 && left >= 384) ? 3 : 2;
+        if (wide_ok && left >= 256) wide_qt = (wide_pref != 2 && left >= 384) ? 3 : 2;   // 128-query groups per launch
         // 160, 128 or 64 queries per pass
         const int shape = wide_qt ? (i8 ? mf_shape_i8_ : mf_shape_)
                                   : (left > 64 && variant != 5) ? ((left > 128 && mf_use_160_) ? 5 : (i8 ? mf_shape_i8_ : mf_shape_)) : 0;
@@ -1327,7 +1329,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
                     FSGPU_HIP(hipEventCreate(&e1));
                     FSGPU_HIP(hipEventRecord(e0, stream));
                 }
-                if (wide_qt) FSGPU_HIP(launch_scan_wide(c, wide_qt, main_grid, stream, nullptr));
+                if (wide_qt) FSGPU_HIP(launch_scan_wide(c, (wide_qt == 3 && wide_four_waves) ? 6 : wide_qt, main_grid, stream, nullptr));
                 else FSGPU_HIP(launch_scan_mfma(c, shape, full_grid, stream, nullptr));
                 if (profiling) {
                     FSGPU_HIP(hipEventRecord(e1, stream));
