@@ -27,6 +27,7 @@ struct SearchCall : CoalescedCall {
     const float* query = nullptr;
     uint32_t k = 0;
     uint32_t int8_mult = 0;  // 0 = exact search, else search_top_k_int8_two_pass with this multiplier
+    const uint64_t* allow = nullptr;  // the caller's allow bitmap (host words): calls that pass the SAME bitmap share a batch
     uint32_t* out_rows = nullptr;
     float* out_scores = nullptr;
     uint32_t* out_count = nullptr;
@@ -131,12 +132,13 @@ void run_embed_batch(Handle* h, uint32_t dim, std::vector<EmbedCall<Id>*>& batch
 // One single-query call parked in the index's coalescer: concurrent callers ride one batched pass (results are
 // bit-identical to the direct path).  int8_mult 0 = exact search, else the int8 two-pass with that multiplier.
 fsgpu_status coalesced_search(fsgpu_index* idx, const float* query, uint32_t k, uint32_t int8_mult, uint32_t* out_rows,
-                              float* out_scores, uint32_t* out_count) {
+                              float* out_scores, uint32_t* out_count, const uint64_t* allow = nullptr) {
     return guarded([&]() -> fsgpu_status {
         SearchCall call;
         call.query = query;
         call.k = k;
         call.int8_mult = int8_mult;
+        call.allow = allow;
         call.out_rows = out_rows;
         call.out_scores = out_scores;
         call.out_count = out_count;
@@ -146,6 +148,7 @@ fsgpu_status coalesced_search(fsgpu_index* idx, const float* query, uint32_t k, 
                 std::lock_guard<std::mutex> lock(idx->impl.mutex());
                 const uint32_t n = (uint32_t)batch.size(), dim = idx->impl.dimension(), kk = batch[0]->k;
                 const uint32_t mult = batch[0]->int8_mult;
+                const uint64_t* allow_bm = batch[0]->allow;   // one filter for the whole batch (compatible() below)
                 fsgpu_status st = FSGPU_ERR_DEVICE;
                 std::string detail;
                 try {
@@ -162,11 +165,11 @@ fsgpu_status coalesced_search(fsgpu_index* idx, const float* query, uint32_t k, 
                                                                 idx->co_scores.data(), idx->co_counts.data(), &fb);
                     } else if (n <= 4) {
                         // up to four callers: one pass of the exact multi-query kernel is quicker than the staged
-                        // matrix-core pipeline; beyond that the batched path serves 128 per pass
-                        e = idx->impl.search_top_k(idx->co_queries.data(), n, dim, kk, nullptr, idx->co_rows.data(),
+                        // matrix-core pipeline; beyond that the batched path serves 128 and more per pass
+                        e = idx->impl.search_top_k(idx->co_queries.data(), n, dim, kk, allow_bm, idx->co_rows.data(),
                                                    idx->co_scores.data(), idx->co_counts.data());
                     } else {
-                        e = idx->impl.search_top_k_batched(idx->co_queries.data(), n, dim, kk, nullptr, idx->co_rows.data(),
+                        e = idx->impl.search_top_k_batched(idx->co_queries.data(), n, dim, kk, allow_bm, idx->co_rows.data(),
                                                            idx->co_scores.data(), idx->co_counts.data(), &fb);
                     }
                     st = e.code;
@@ -185,7 +188,7 @@ fsgpu_status coalesced_search(fsgpu_index* idx, const float* query, uint32_t k, 
                     *batch[i]->out_count = idx->co_counts[i];
                 }
             },
-            [](const SearchCall& a, const SearchCall& b) { return a.k == b.k && a.int8_mult == b.int8_mult; });
+            [](const SearchCall& a, const SearchCall& b) { return a.k == b.k && a.int8_mult == b.int8_mult && a.allow == b.allow; });
         if (call.exec_threw) return fail(FSGPU_ERR_DEVICE, "coalesced batch failed before this request was served");
         if (call.status != FSGPU_OK) g_last_error = call.detail;
         return call.status;
@@ -312,8 +315,8 @@ fsgpu_status fsgpu_search_topk(fsgpu_index* idx, const float* queries, uint32_t 
     if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
     if (nq && (!queries || !out_counts || (k && (!out_rows || !out_scores))))
         return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
-    if (idx->coalescer.enabled() && nq == 1 && !allow_bitmap && k >= 1 && k <= 64 && query_len == idx->impl.dimension())
-        return coalesced_search(idx, queries, k, 0, out_rows, out_scores, out_counts);
+    if (idx->coalescer.enabled() && nq == 1 && k >= 1 && k <= 64 && query_len == idx->impl.dimension())
+        return coalesced_search(idx, queries, k, 0, out_rows, out_scores, out_counts, allow_bitmap);
     return guarded([&]() -> fsgpu_status {
         // this index if it is free, else a free replica, else queue on one of the lanes in turn
         std::shared_lock<std::shared_mutex> state(idx->state_mu);

@@ -378,8 +378,9 @@ fsgpu_status fsgpu_search_mrl_batched(fsgpu_index *idx, const float *queries, ui
 /* The reference's seams are per-query calls made by many host threads at once (VectorIndex::search_top_k takes &self,
  * crates/frankensearch-index/src/search.rs:192; SyncEmbed::embed_sync, crates/frankensearch-core/src/traits.rs:401-582;
  * the MiniLM backends serialise callers on a mutex, crates/frankensearch-rerank/src/native_embedder.rs:40-50).  With
- * coalescing enabled, single-item calls that are in flight together (fsgpu_search_topk with nq = 1, no allow bitmap,
- * k <= 64; fsgpu_m2v_embed / fsgpu_bert_embed with n = 1) are gathered into one batched launch: up to max_batch
+ * coalescing enabled, single-item calls that are in flight together (fsgpu_search_topk with nq = 1 and k <= 64 — filtered
+ * callers share a batch when they pass the SAME allow bitmap, i.e. the same pointer; fsgpu_m2v_embed / fsgpu_bert_embed
+ * with n = 1) are gathered into one batched launch: up to max_batch
  * items, waiting at most max_wait_us for the batch to fill.  Results are bit-identical to the unbatched calls.
  * max_batch = 0 turns it off (the default).  No threads are created: the first waiting caller runs the batch. */
 fsgpu_status fsgpu_index_set_coalescing(fsgpu_index *idx, uint32_t max_batch, uint32_t max_wait_us);

@@ -23,7 +23,9 @@ q = x[rng.integers(0, n, NQ)] + (rng.standard_normal((NQ, dim)) * 0.2).astype(np
 ks = rng.choice([1, 7, 10, 30, 64], NQ)
 texts = [rng.integers(0, 5000, int(rng.integers(1, 30))).tolist() for _ in range(NQ)]
 toks = [[101] + rng.integers(1000, 2000, int(rng.integers(2, 30))).tolist() + [102] for _ in range(NQ)]
+shared = [fa.pack_bitmap(rng.random(n) > 0.5) for _ in range(3)]   # filters several callers share (same uint64 array = same pointer)
 want_exact = [idx.search_batch(q[i], int(ks[i])) for i in range(NQ)]
+want_filt = [idx.search_batch(q[i], int(ks[i]), allow=shared[i % 3]) for i in range(NQ)]
 want_i8 = [idx.search_top_k_int8_two_pass(q[i], int(ks[i]), 3) for i in range(NQ)]
 want_m2v = [m2v.embed_token_ids(texts[i]) for i in range(NQ)]
 want_bert = [bert.embed_token_ids(toks[i]) for i in range(NQ)]
@@ -35,7 +37,7 @@ while time.time() < t_end:
     idx.set_coalescing(mb, wait); m2v.set_coalescing(mb, wait); bert.set_coalescing(mb, wait)
     nthreads = int(rng.choice([3, 16, 64, 200]))
     picks = rng.integers(0, NQ, (nthreads, 6))
-    kinds = rng.integers(0, 4, (nthreads, 6))
+    kinds = rng.integers(0, 5, (nthreads, 6))
     def work(t):
         for i, kind in zip(picks[t], kinds[t]):
             try:
@@ -46,6 +48,9 @@ while time.time() < t_end:
                     got = idx.search_top_k_int8_two_pass(q[i], int(ks[i]), 3)
                     ok = [(h.index, np.float32(h.score).view(np.uint32)) for h in got] == \
                          [(h.index, np.float32(h.score).view(np.uint32)) for h in want_i8[i]]
+                elif kind == 4:
+                    got = idx.search_batch(q[i], int(ks[i]), allow=shared[i % 3])
+                    ok = all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(got, want_filt[i]))
                 elif kind == 2:
                     ok = np.array_equal(m2v.embed_token_ids(texts[i]).view(np.uint32), want_m2v[i].view(np.uint32))
                 else:
