@@ -148,7 +148,7 @@ hipError_t launch_prepare_queries_i8(const float* q, uint32_t nq, uint32_t nq_pa
 
 constexpr uint32_t kMfmaMaxSlots = 32;           // candidate slots per (block, query) staged in LDS
 constexpr uint32_t kMfmaSpillCountStride = 16;  // uint32 counters 64 bytes apart
-constexpr uint32_t kWideSlots = 16;               // ... by the register-resident-query main pass (mfma_wide.hip)
+constexpr uint32_t kWideSlots = 32;               // ... by the register-resident-query main pass (mfma_wide.hip)
 bool scan_mfma_supported(int dim);
 // mfma_wide.hip: main pass with the queries in registers and the row tiles in an LDS-DMA ring; query_tiles 2 = 256, 3 = 384
 // queries per launch; one candidate list of args.slots <= kWideSlots entries per (query, block)

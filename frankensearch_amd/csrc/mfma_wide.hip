@@ -28,7 +28,6 @@
 #include <cstdlib>
 #include <string>
 #include <type_traits>
-#include <utility>
 
 #include "scan_common.hpp"
 
@@ -56,12 +55,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
         : "memory");
 }
 
-// f(integral_constant<0>), f(integral_constant<1>), ... : a loop whose index is a compile-time constant in every iteration
-template <class F, int... Is>
-__device__ __forceinline__ void for_each_index(F&& f, std::integer_sequence<int, Is...>) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
@@ -79,17 +72,15 @@ __device__ __forceinline__ void wait_vmcnt() {
 //     free -> DMA(tile n+NSLOT-1) | reads(chunk 2) | MFMA(chunk 1) | ... | reads(chunk 0 of tile n+1) | MFMA(last chunk)
 // so neither the LDS latency nor the barrier sits between two MFMA groups of a wave with nothing else to issue.
 template <int ROWB, int EB, int QT, int NSLOT, int DBG = 0>   // DBG (timing experiments only): 1 = no MFMAs, 2 = no DMA
-__global__ __launch_bounds__(QT >= 6 ? 256 : 512) void scan_wide_kernel(MfmaScanArgs args) {
+__global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     using acc_t = std::conditional_t<EB == 2, f32x4, i32x4>;
-    // QT >= 6: four waves (one per SIMD, up to 512 registers each) of QT * 16 queries — a fragment read feeds QT MFMAs and
-    // the loop carries ~0.5 other instructions per MFMA instead of ~2
-    constexpr int WPB = QT >= 6 ? 4 : 8, NT = WPB * 64;
+    constexpr int WPB = 8, NT = WPB * 64;
     constexpr int KS = ROWB / 64;                                   // MFMA k-steps (64 bytes of a row each)
     constexpr int TR = ROWB >= 512 ? 32 : 64;                       // rows per tile
     constexpr int RS = TR / 16;                                     // 16-row sub-tiles per tile
     constexpr int NI = RS * KS;                                     // DMA instructions per tile (1 KB each)
     constexpr int PW = NI / WPB;                                    // ... per wave
-    static_assert(NI % WPB == 0 && PW >= 1, "a tile's DMA instructions divide evenly over the waves");
+    static_assert(NI % WPB == 0 && PW >= 1, "a tile's DMA instructions divide evenly over the 8 waves");
     static_assert(RS % 2 == 0, "sub-tiles are consumed in pairs");
     constexpr int CK = KS == 12 ? (QT >= 3 ? 2 : 3) : (KS >= 2 ? KS / 2 : 1);   // k-steps per chunk (fewer at QT = 3: registers)
     constexpr int NCH = KS / CK;                                    // chunks per sub-tile pair
@@ -287,23 +278,21 @@ __global__ __launch_bounds__(QT >= 6 ? 256 : 512) void scan_wide_kernel(MfmaScan
         const uint32_t slot_next = slot + 1 == NSLOT ? 0 : slot + 1;
         const uint32_t t = cursor_tile(cc);
         acc_t acc[2][QT];
-        // the chunks as a compile-time sequence (not an unrolled loop: with QT = 8 the loop body passes hipcc's unroll
-        // threshold, the chunk index stays a run-time value and the query fragments land in scratch memory)
-        auto chunk = [&](auto cidx) {
-            constexpr int c = decltype(cidx)::value;
-            if constexpr (c % NCH == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (c % NCH == 0) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int nt = 0; nt < QT; ++nt) acc[h][nt] = acc_t{0, 0, 0, 0};
             }
             // the NEXT chunk's fragment reads go out before this chunk's MFMAs (the next tile's first chunk after the last)
-            if constexpr (c + 1 < NC) read_chunk(slot, c + 1, fa[(c + 1) & 1]);
+            if (c + 1 < NC) read_chunk(slot, c + 1, fa[(c + 1) & 1]);
             else read_chunk(slot_next, 0, fa[0]);
             __builtin_amdgcn_sched_barrier(0);
             mfma_chunk(c, fa[c & 1], acc);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (c == 0) {
+            if (c == 0) {
                 // tile n+1: this wave's DMAs have landed (tiles n+2 .. n+NSLOT-2 may still be in flight), then everyone's;
                 // every wave is also past its last read of tile n-1, whose slot takes tile n+NSLOT-1
                 wait_vmcnt<PW*(NSLOT - 3)>();
@@ -311,15 +300,15 @@ __global__ __launch_bounds__(QT >= 6 ? 256 : 512) void scan_wide_kernel(MfmaScan
                 asm volatile("" ::: "memory");
             }
             // The DMA issue (address arithmetic + PW LDS-DMA instructions: a stretch without MFMAs) is staggered between
-            // the two waves that share a SIMD (waves w and w + 4): one right after the barrier, the other a chunk later.
-            if constexpr (c <= 1 && NC >= 2) {
-                if (WPB == 4 ? c == 0 : (wave >= 4) == (c == 1)) fetch_next(slot == 0 ? NSLOT - 1 : slot - 1);
-            } else if constexpr (NC < 2 && c == 0) {
+            // the two waves that share a SIMD (waves w and w + 4): one right after the barrier, the other a chunk later,
+            // so that the matrix pipe always has one of them feeding it.
+            if (NC >= 2 && c <= 1) {
+                if ((wave >= 4) == (c == 1)) fetch_next(slot == 0 ? NSLOT - 1 : slot - 1);
+            } else if (NC < 2 && c == 0) {
                 fetch_next(slot == 0 ? NSLOT - 1 : slot - 1);
             }
-            if constexpr (c % NCH == NCH - 1) emit_pair(t, (c / NCH) * 2, acc);
-        };
-        for_each_index(chunk, std::make_integer_sequence<int, NC>{});
+            if (c % NCH == NCH - 1) emit_pair(t, (c / NCH) * 2, acc);
+        }
         cursor_next(cc);
         cursor_seek(cc);
         slot = slot_next;
@@ -341,8 +330,7 @@ template <int ROWB, int EB, int QT, int NSLOT, int DBG = 0>
 hipError_t launch_wide_t(const MfmaScanArgs& args, int grid, hipStream_t stream, int* occupancy) {
     constexpr int TR = ROWB >= 512 ? 32 : 64;
     constexpr size_t ring = (size_t)NSLOT * TR * ROWB;
-    constexpr int kThreads = QT >= 6 ? 256 : 512;
-    const size_t lds = ring + (size_t)QT * 16 * (kThreads / 64) * 4;   // the row-tile ring + one append counter per query
+    const size_t lds = ring + (size_t)QT * 128 * 4;   // the row-tile ring + one append counter per query
     auto kern = scan_wide_kernel<ROWB, EB, QT, NSLOT, DBG>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -352,7 +340,7 @@ hipError_t launch_wide_t(const MfmaScanArgs& args, int grid, hipStream_t stream,
     }
     if (occupancy) {
         int blocks = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, kThreads, lds) != hipSuccess || blocks < 1) blocks = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, 512, lds) != hipSuccess || blocks < 1) blocks = 1;
         *occupancy = blocks;
         return hipSuccess;
     }
@@ -360,7 +348,7 @@ hipError_t launch_wide_t(const MfmaScanArgs& args, int grid, hipStream_t stream,
     static const std::string name = "scan_wide_kernel<" + std::to_string(ROWB) + ", " + std::to_string(EB) + ", " +
                                     std::to_string(QT) + ", " + std::to_string(NSLOT) + ">";
     note_main_pass_kernel(name.c_str());
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, args);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, args);
     return hipGetLastError();
 }
 
@@ -397,14 +385,9 @@ hipError_t launch_scan_wide(const MfmaScanArgs& args, int query_tiles, int grid,
     if (eb == 2) {
         if (query_tiles == 2) return launch_wide_d<2, 2>(args, grid, stream, occupancy);
         if (query_tiles == 3) return launch_wide_d<2, 3>(args, grid, stream, occupancy);
-        // experiment (FSGPU_WIDE=6): the same 384 queries on FOUR waves of 96 (one per SIMD, 499 registers, a fragment read
-        // feeds 6 MFMAs): measured 3.14 ms against 2.62 ms for 8 waves of 48 — one compiler-scheduled wave per SIMD does not
-        // keep the matrix pipe fed
-        if (query_tiles == 6 && args.dim == 384) return launch_wide_t<768, 2, 6, 6>(args, grid, stream, occupancy);
     } else {
         if (query_tiles == 2) return launch_wide_d<1, 2>(args, grid, stream, occupancy);
         if (query_tiles == 3) return launch_wide_d<1, 3>(args, grid, stream, occupancy);
-
     }
     return hipErrorInvalidValue;
 }

@@ -1073,7 +1073,9 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         // ... and large enough that the main pass lets ~1,000 rows per query through (ksel N / RB): beyond that the per-block
         // lists and the spill area of the hottest queries overflow (50M rows, k = 10: 10 of 1,024 queries fell back to the
         // exact kernels with the 131,072-row cap, none with 488k — a sample pass of 0.4 ms per 1,024 queries next to 37 ms)
-        const uint64_t need = (uint64_t)ksel_est * nrows_ / 1024;
+        // (bounded so that the sample stage's own survivors, ksel RB / RA, stay within its lists too: a rank of 90 — the int8
+        // fast tier's 3 x 30 candidates — already runs a 524k-row sample)
+        const uint64_t need = std::min<uint64_t>((uint64_t)ksel_est * nrows_ / 1024, (uint64_t)6000 * RA_MAX / ksel_est);
         if (need > RB) {
             RB = (uint32_t)std::min<uint64_t>(need, nrows_ / 8);
             if (knobs().ra <= 0) RA = RA_MAX;   // keeps the sample stage's own survivors (ksel RB / RA) in the hundreds
@@ -1166,9 +1168,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     // (384 per launch when that many queries are left: the matrix pipe is the bound there and fewer passes leave it more of
     // the power budget — measured 148 k against 130 k queries/s at 10M x 384)
     const int wide_pref = knobs().wide >= 0 ? knobs().wide : 3;
-    // 6: 384 queries per launch on FOUR waves of 96 queries (f16 rows of 768 bytes only; otherwise as 3)
-    const bool wide_ok = (wide_pref == 2 || wide_pref == 3 || wide_pref == 6) && scan_wide_supported((int)dim_, i8 ? 1 : 2) && variant != 5 && variant != 6;
-    const bool wide_four_waves = wide_pref == 6 && !i8 && dim_ == 384;
+    const bool wide_ok = (wide_pref == 2 || wide_pref == 3) && scan_wide_supported((int)dim_, i8 ? 1 : 2) && variant != 5 && variant != 6;
     // per-query verdicts, written by the kernels straight into pinned host memory and read after ONE stream
     // synchronisation for the whole batch: [0, cap) = overflow flags, [cap, 2 cap) = candidate counts
     const uint32_t flag_cap = (nq + GMAX - 1) / GMAX * GMAX + GMAX;
@@ -1308,7 +1308,10 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
                 a.group_stride = 1;
                 a.group_count = 0;
             }
-            a.slots = wide_qt ? std::min<uint32_t>(kWideSlots, std::max<uint32_t>(8, (CAPQ - KC) / (uint32_t)main_grid)) : slots_for(full_grid);
+            // (the wide pass appends to global lists: 16 slots per (query, block) keep lists + pool inside one selection pass;
+            // ranks above 32 — the int8 fast tier anchors on 90 — let ~1,700 rows per query through and get 32)
+            a.slots = wide_qt ? (ksel_est > 32 ? kWideSlots : std::min<uint32_t>(16, std::max<uint32_t>(8, (CAPQ - KC) / (uint32_t)main_grid)))
+                              : slots_for(full_grid);
             FSGPU_HIP(hipMemsetAsync(spill_count, 0, (size_t)QP * kMfmaSpillCountStride * 4, stream));
             a.groups = 1;
             // one pass over the slab per query group, one launch each (all groups in one launch — a group's blocks taking
@@ -1329,7 +1332,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
                     FSGPU_HIP(hipEventCreate(&e1));
                     FSGPU_HIP(hipEventRecord(e0, stream));
                 }
-                if (wide_qt) FSGPU_HIP(launch_scan_wide(c, (wide_qt == 3 && wide_four_waves) ? 6 : wide_qt, main_grid, stream, nullptr));
+                if (wide_qt) FSGPU_HIP(launch_scan_wide(c, wide_qt, main_grid, stream, nullptr));
                 else FSGPU_HIP(launch_scan_mfma(c, shape, full_grid, stream, nullptr));
                 if (profiling) {
                     FSGPU_HIP(hipEventRecord(e1, stream));
@@ -1382,6 +1385,8 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         }
         std::fprintf(stderr, "[fsgpu batched] nq=%u k=%u fallbacks=%zu  pool_overflow=%u  slot_or_skip=%u  few=%u  max_cand=%u\n", nq, k,
                      fb.size(), big, slot, few, mx);
+        for (size_t j = 0; j < fb.size() && j < 4; ++j)
+            std::fprintf(stderr, "    query %u: overflow=%u candidates=%u\n", fb[j], overflow_all[fb[j]], counts_all[fb[j]]);
     }
     const uint32_t total_fallbacks = (uint32_t)fb.size();
     if (total_fallbacks && i8) {

@@ -391,8 +391,7 @@ fsgpu_status fsgpu_bert_set_coalescing(fsgpu_bert *m, uint32_t max_batch, uint32
 /* ---- experiment switches ----
  * Environment variables read ONCE per process by libfsgpu.so.  None changes a result; they select kernel variants for A/B
  * measurements (scripts/exp_*, scripts/prof_wide.sh) and are listed here so that nothing in the product path is hidden:
- *   FSGPU_WIDE=0|2|3|6          batched main pass: 0 = queries in LDS (128 per pass), 2 / 3 = queries in registers (256 / 384),
- *                               6 = 384 on four waves of 96 queries (slower: kept as a measured experiment)
+ *   FSGPU_WIDE=0|2|3            batched main pass: 0 = queries in LDS (128 per pass), 2 / 3 = queries in registers (256 / 384)
  *   FSGPU_WIDE_DBG=1..4         timing skeletons of that kernel (no MFMAs / no DMA / ...): answers are NOT valid
  *   FSGPU_USE_160, FSGPU_MFMA_SHAPE, FSGPU_MFMA_SHAPE_I8   shapes of the LDS-query kernel
  *   FSGPU_RA, FSGPU_RB, FSGPU_ROUND, FSGPU_NO_SKIP_B, FSGPU_NO_REVERSE   sample sizes / round size / pass direction
