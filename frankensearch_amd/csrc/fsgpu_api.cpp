@@ -273,6 +273,26 @@ fsgpu_status fsgpu_index_set_hreduce(fsgpu_index* idx, int32_t mode) {
     return FSGPU_OK;
 }
 
+fsgpu_status fsgpu_index_set_batched_filter(fsgpu_index* idx, int32_t filter) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    if (filter < FSGPU_FILTER_AUTO || filter > FSGPU_FILTER_INT8) return fail(FSGPU_ERR_INVALID_CONFIG, "unknown batched filter");
+    std::unique_lock<std::shared_mutex> state(idx->state_mu);
+    std::lock_guard<std::mutex> lock(idx->impl.mutex());
+    idx->impl.batched_filter = filter;
+    return FSGPU_OK;
+}
+
+fsgpu_status fsgpu_index_batched_filter_stats(fsgpu_index* idx, uint64_t* int8_queries, uint64_t* refiltered_f16,
+                                              int32_t* int8_active) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    std::unique_lock<std::shared_mutex> state(idx->state_mu);
+    std::lock_guard<std::mutex> lock(idx->impl.mutex());
+    if (int8_queries) *int8_queries = idx->impl.i8f_queries;
+    if (refiltered_f16) *refiltered_f16 = idx->impl.i8f_refiltered;
+    if (int8_active) *int8_active = idx->impl.int8_filter_active() ? 1 : 0;
+    return FSGPU_OK;
+}
+
 fsgpu_status fsgpu_index_doc_id(const fsgpu_index* idx, uint32_t row, const char** ptr, uint32_t* len) {
     if (!idx || !ptr || !len) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
     return finish(idx->impl.doc_id_at(row, ptr, len));

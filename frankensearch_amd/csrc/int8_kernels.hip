@@ -88,6 +88,60 @@ __global__ __launch_bounds__(256) void quantize_slab_i8_kernel(const unsigned sh
             out[i] = zero ? (signed char)0 : quant_i8((float)__builtin_bit_cast(_Float16, slab[i]), scale);
 }
 
+// What the int8 slab misses of the f16 slab, measured once per slab so that integer scores can serve as a PROVABLE
+// filter for the exact search (mfma_scan.hip, "int8 filter").  With c = fl(127 / max_abs) — the f32 scale the quantiser
+// used — every element is x = (r + eps) / c; this kernel bounds, over all rows, the quantisation error and the size of
+// the integer rows:
+//   out[0]  float bits of max_row sum_i (|fl(x c) - r| + 8e-6)^2   (8e-6 covers the rounding of the product x c)
+//   out[1]  max_row sum_i |r_i|
+//   out[2]  max_row sum_i r_i^2
+//   out[3]  != 0 when the slab holds a NaN or an infinity (no bound exists then)
+// One wave per row, grid-stride; upper bounds only (order-free), accumulated with integer atomic max.
+__global__ __launch_bounds__(256) void i8_slab_stats_kernel(const unsigned short* __restrict__ slab,
+                                                            const signed char* __restrict__ slab_i8, uint32_t nrows,
+                                                            uint32_t dim, const unsigned int* __restrict__ max_bits,
+                                                            unsigned int* __restrict__ out) {
+    const float max_abs = __uint_as_float(*max_bits);
+    const float scale = max_abs > 0.0f ? 127.0f / max_abs : 0.f;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_gid = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * 256) >> 6;
+    float e2max = 0.f;
+    unsigned int r1max = 0, r2max = 0, bad = 0;
+    for (uint32_t row = wave_gid; row < nrows; row += nwaves) {
+        const _Float16* p = reinterpret_cast<const _Float16*>(slab) + (size_t)row * dim;
+        const signed char* pi = slab_i8 + (size_t)row * dim;
+        float e2 = 0.f;
+        unsigned int r1 = 0, r2 = 0;
+        for (uint32_t i = lane; i < dim; i += 64) {
+            const float x = (float)p[i];
+            const int r = (int)pi[i];
+            if (!(fabsf(x) <= 65504.0f)) bad = 1;
+            const float e = fabsf(x * scale - (float)r) + 8e-6f;
+            e2 += e * e;
+            r1 += (unsigned int)(r < 0 ? -r : r);
+            r2 += (unsigned int)(r * r);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            e2 += __shfl_xor(e2, off);
+            r1 += __shfl_xor(r1, off);
+            r2 += __shfl_xor(r2, off);
+        }
+        e2max = fmaxf(e2max, e2);
+        r1max = r1 > r1max ? r1 : r1max;
+        r2max = r2 > r2max ? r2 : r2max;
+    }
+    bad = __any(bad) ? 1u : 0u;
+    if (lane == 0) {
+        if (e2max == e2max) atomicMax(&out[0], __float_as_uint(e2max));
+        else bad = 1;
+        atomicMax(&out[1], r1max);
+        atomicMax(&out[2], r2max);
+        if (bad) atomicOr(&out[3], 1u);
+    }
+}
+
 // pack_f16_le_bytes_to_4bit (simd.rs:2153-2215): scale 7/max_abs (0 when max_abs <= 1e-9), low nibble = even dim.
 // Even dims: 8 values -> one 32-bit word anywhere in the slab (rows are whole bytes).
 __global__ __launch_bounds__(256) void pack_slab_4bit_kernel(const unsigned short* __restrict__ slab, uint64_t count,
@@ -292,6 +346,15 @@ hipError_t launch_quantize_slab_i8(const void* slab_f16, size_t n_values, unsign
     hipLaunchKernelGGL(quantize_slab_i8_kernel, dim3(grid), dim3(256), 0, stream,
                        static_cast<const unsigned short*>(slab_f16), n_values, max_bits_dev,
                        static_cast<signed char*>(out_i8));
+    return hipGetLastError();
+}
+
+hipError_t launch_i8_slab_stats(const void* slab_f16, const void* slab_i8, uint32_t nrows, uint32_t dim,
+                                const unsigned int* max_bits_dev, unsigned int* stats_dev, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(stats_dev, 0, 16, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(i8_slab_stats_kernel, dim3(2048), dim3(256), 0, stream, static_cast<const unsigned short*>(slab_f16),
+                       static_cast<const signed char*>(slab_i8), nrows, dim, max_bits_dev, stats_dev);
     return hipGetLastError();
 }
 

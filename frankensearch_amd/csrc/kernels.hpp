@@ -145,6 +145,11 @@ constexpr uint32_t kSelectMaxK = 128;   // largest rank a selection can anchor o
 hipError_t launch_select(const SelectArgs& args, int nq, hipStream_t stream);
 hipError_t launch_prepare_queries_i8(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, void* qi8, float* delta,
                                      hipStream_t stream);
+// the same quantiser for the int8 FILTER of the exact search: delta = a proven bound on |int8 score - exact score / (row
+// scale x query scale)| from the slab statistics of launch_i8_slab_stats (see mfma_scan.hip)
+hipError_t launch_prepare_queries_i8_filter(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t q_stride,
+                                            const unsigned int* slab_max_bits, const unsigned int* slab_stats, void* qi8,
+                                            float* delta, hipStream_t stream);
 
 constexpr uint32_t kMfmaMaxSlots = 32;           // candidate slots per (block, query) staged in LDS
 constexpr uint32_t kMfmaSpillCountStride = 16;  // uint32 counters 64 bytes apart
@@ -170,6 +175,10 @@ hipError_t launch_prepare_queries(const float* q, uint32_t nq, uint32_t nq_pad, 
 // int8_kernels.hip
 hipError_t launch_quantize_slab_i8(const void* slab_f16, size_t n_values, unsigned int* max_bits_dev, void* out_i8,
                                    hipStream_t stream);
+// bounds on what the int8 slab misses of the f16 slab (int8 filter of the exact batched search): stats_dev[0..4) =
+// { f32 bits of max_row sum eps^2, max_row sum |r|, max_row sum r^2, non-finite flag }
+hipError_t launch_i8_slab_stats(const void* slab_f16, const void* slab_i8, uint32_t nrows, uint32_t dim,
+                                const unsigned int* max_bits_dev, unsigned int* stats_dev, hipStream_t stream);
 bool scan_i8_fused_supported(int dim, int kcap);
 // 4-bit two-pass (int8_kernels.hip, BITS = 4)
 hipError_t launch_pack_slab_4bit(const void* slab_f16, uint64_t count, uint32_t dim, unsigned int* max_bits_dev,

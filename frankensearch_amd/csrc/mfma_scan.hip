@@ -664,6 +664,101 @@ __global__ __launch_bounds__(256) void prepare_queries_i8_kernel(const float* __
     if (tid == 0) delta[b] = b < nq ? 0.0f : -1.0f;
 }
 
+// The int8 FILTER of the exact search: the same query quantiser (per-query max-abs scale c_q = fl(127 / max), round half
+// away from zero), but the integer scores are not the answer — they select the rows whose exact score is then computed
+// in the reference's order, and delta_q is a PROVEN bound on how far an integer score can sit from the exact one.
+//
+// With the slab scale c_s (int8_kernels.hip: x_i = (r_i + eps_i) / c_s) and q_i = (p_i + eta_i) / c_q, the real-number dot
+// is  S = (idot + sum eps_i p_i + sum r_i eta_i + sum eps_i eta_i) / (c_s c_q), so in units of the integer score
+//     |idot - S c_s c_q| <= min(0.5' |p|_1, E2 |p|_2) + min(0.5' R1, H2 R2) + min(0.25' dim, E2 H2)
+// (0.5' = 0.5 + the rounding of the scaled product; E2 / R1 / R2 = the slab's measured maxima over rows of |eps|_2, |r|_1,
+// |r|_2; H2 = |eta|_2 measured here; Hoelder with (inf, 1) or Cauchy-Schwarz, whichever is smaller), and the reference's
+// f32 score differs from S by at most dim 2^-23 |x|_2 |q|_2 + dim 2^-149 (rounded products and sums in ANY order; products
+// may underflow), i.e. dim 2^-23 (R2 + E2)(P2 + H2) + dim 2^-149 c_s c_q in integer-score units.  c_s c_q > 0 is common to
+// all rows of a query, so ranking by S c_s c_q is ranking by S, and the two-sided margin argument of the header applies
+// verbatim with delta_q = that sum (inflated by 1e-3, + 1 for the f32 subtraction a_k - 2 delta; the integer scores convert
+// to f32 exactly up to dim 1040).  Queries with an element that is not finite or above 65504 (an f32 product could
+// overflow), zero queries, padding, and every query of a slab that holds a non-finite value or only zeros are marked
+// "skip" (delta < 0): the f16 filter or the exact kernels answer them.
+__global__ __launch_bounds__(256) void prepare_queries_i8_filter_kernel(const float* __restrict__ q, uint32_t nq, uint32_t q_stride,
+                                                                        uint32_t dim, const unsigned int* __restrict__ slab_max_bits,
+                                                                        const unsigned int* __restrict__ slab_stats,
+                                                                        signed char* __restrict__ qi8, float* __restrict__ delta) {
+    __shared__ float redf[4];
+    __shared__ unsigned int redu[2][4];
+    __shared__ int s_bad;
+    const uint32_t b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_bad = 0;
+    float m = 0.f;
+    bool bad = false;
+    if (b < nq)
+        for (uint32_t i = tid; i < dim; i += 256) {
+            const float v = q[(size_t)b * q_stride + i];
+            m = fmaxf(m, fabsf(v));
+            bad |= !(fabsf(v) <= 65504.0f);
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0) redf[wave] = m;
+    __syncthreads();
+    if (__any(bad) && lane == 0) s_bad = 1;
+    const float max_abs = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    const bool zero = b >= nq || !(max_abs > 0.0f);
+    const float scale = zero ? 0.f : 127.0f / max_abs;
+    float h2 = 0.f;
+    unsigned int p1 = 0, p2 = 0;
+    for (uint32_t i = tid; i < dim; i += 256) {
+        signed char o = 0;
+        if (!zero) {
+            const float y = q[(size_t)b * q_stride + i] * scale;
+            float v = roundf(y);
+            if (v == v) {
+                v = fminf(fmaxf(v, -127.0f), 127.0f);
+                o = (signed char)(int)v;
+                const float e = fabsf(y - v) + 8e-6f;
+                h2 += e * e;
+            }
+        }
+        const int oi = (int)o;
+        p1 += (unsigned int)(oi < 0 ? -oi : oi);
+        p2 += (unsigned int)(oi * oi);
+        qi8[(size_t)b * dim + i] = o;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        h2 += __shfl_xor(h2, off);
+        p1 += __shfl_xor(p1, off);
+        p2 += __shfl_xor(p2, off);
+    }
+    __syncthreads();  // everyone has read redf
+    if (lane == 0) {
+        redf[wave] = h2;
+        redu[0][wave] = p1;
+        redu[1][wave] = p2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double slab_max = (double)__uint_as_float(*slab_max_bits);
+        const double E2 = sqrt((double)__uint_as_float(slab_stats[0])) * 1.001;
+        const double R1 = (double)slab_stats[1];
+        const double R2 = sqrt((double)slab_stats[2]);
+        const bool slab_bad = slab_stats[3] != 0 || !(slab_max > 0.0) || !(slab_max <= 65504.0);
+        const double H2 = sqrt((double)(redf[0] + redf[1] + redf[2] + redf[3])) * 1.001;
+        const double P1 = (double)(redu[0][0] + redu[0][1] + redu[0][2] + redu[0][3]);
+        const double P2 = sqrt((double)(redu[1][0] + redu[1][1] + redu[1][2] + redu[1][3]));
+        const double n = (double)dim;
+        const double c_s = 127.0 / slab_max * 1.000001, c_q = (double)scale * 1.000001;
+        double d = fmin(0.50001 * P1, E2 * P2) + fmin(0.50001 * R1, H2 * R2) + fmin(0.25001 * n, E2 * H2);
+        d += n * 1.1920929e-7 /* 2^-23 */ * (R2 + E2) * (P2 + H2) + n * 1.5e-45 /* > 2^-149 */ * c_s * c_q;
+        d = d * 1.001 + 1.0;
+        float out = (float)d;
+        if (!((double)out >= d)) out = __uint_as_float(__float_as_uint(out) + 1u);  // round up
+        if (zero || s_bad || slab_bad || dim > 1040u || !__builtin_isfinite(out) || !(out < 1.0e9f)) out = -1.0f;
+        delta[b] = out;
+    }
+}
+
 // ---- launchers ----------------------------------------------------------------------------------------------
 
 static std::atomic<const char*> g_last_main_pass_kernel{""};
@@ -758,6 +853,14 @@ hipError_t launch_prepare_queries_i8(const float* q, uint32_t nq, uint32_t nq_pa
                                      hipStream_t stream) {
     hipLaunchKernelGGL(prepare_queries_i8_kernel, dim3(nq_pad), dim3(256), 0, stream, q, nq, dim,
                        static_cast<signed char*>(qi8), delta);
+    return hipGetLastError();
+}
+
+hipError_t launch_prepare_queries_i8_filter(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t q_stride,
+                                            const unsigned int* slab_max_bits, const unsigned int* slab_stats, void* qi8,
+                                            float* delta, hipStream_t stream) {
+    hipLaunchKernelGGL(prepare_queries_i8_filter_kernel, dim3(nq_pad), dim3(256), 0, stream, q, nq, q_stride ? q_stride : dim, dim,
+                       slab_max_bits, slab_stats, static_cast<signed char*>(qi8), delta);
     return hipGetLastError();
 }
 

@@ -46,6 +46,8 @@ SearchError hip_fail(hipError_t e, const char* what) {
 struct Knobs {
     int grid_blocks = 0, ra = 0, rb = 0, mfma_shape = 0, mfma_shape_i8 = 0, round = 0, i8_per_cu = 0;
     int wide = -1;  // FSGPU_WIDE: 0 = never the register-resident-query main pass, 2 / 3 = its query tiles per wave
+    int filter = 0;     // FSGPU_FILTER: "f16" (1) / "i8" (2) pin the filter of the exact batched search; unset = automatic
+    int i8f_growth = 0; // FSGPU_I8F_GROWTH: sample growth factor of the int8 filter (default 4)
     bool no_skip_b = false, use_160 = false, debug_batched = false, no_reverse = false;
     Knobs() {
         auto num = [](const char* name) {
@@ -60,6 +62,8 @@ struct Knobs {
         mfma_shape = num("FSGPU_MFMA_SHAPE");
         mfma_shape_i8 = num("FSGPU_MFMA_SHAPE_I8");
         if (std::getenv("FSGPU_WIDE")) wide = num("FSGPU_WIDE");
+        if (const char* f = std::getenv("FSGPU_FILTER")) filter = std::strcmp(f, "f16") == 0 ? 1 : std::strcmp(f, "i8") == 0 ? 2 : 0;
+        i8f_growth = num("FSGPU_I8F_GROWTH");
         no_skip_b = std::getenv("FSGPU_NO_SKIP_B") != nullptr;
         no_reverse = std::getenv("FSGPU_NO_REVERSE") != nullptr;
         use_160 = std::getenv("FSGPU_USE_160") != nullptr;
@@ -142,7 +146,7 @@ VectorIndex::~VectorIndex() {
                             &ws_counts_, &ws_keys_a_, &ws_keys_b_, &ws_sort_tmp_, &ws_gather_rows_, &ws_gather_out_,
                             &i8_slab_, &n4_slab_, &i8_max_, &ws_i8_query_, &ws_cand_packed_, &ws_cand_rows_, &ws_cand_scores_,
                             &mf_max_norm_, &mf_qh_, &mf_delta_, &mf_tau_, &mf_cand_, &mf_dense_, &mf_sel_,
-                            &mf_fallback_, &mf_spill_, &mf_io_})
+                            &mf_fallback_, &mf_fallback2_, &mf_spill_, &mf_io_, &i8_stats_})
         b->release();
     if (mf_flags_host_) (void)hipHostFree(mf_flags_host_);
     if (io_host_) (void)hipHostFree(io_host_);
@@ -1015,8 +1019,40 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
                                                      uint32_t k, const uint64_t* allow_dev, uint32_t* out_rows_dev,
                                                      float* out_scores_dev, uint32_t* out_counts_dev,
                                                      hipStream_t stream, uint32_t* fallbacks, uint64_t* out_packed_dev) {
+    // Which approximate scores filter the slab: the int8 slab on the integer matrix cores (half the bytes, half the MFMA
+    // instructions of the f16 filter; a wider proven margin) unless this index has shown that its margin lets too many rows
+    // through (outlier dimensions stretch the corpus-wide int8 scale), the caller forced one, or the shape is not covered.
+    const bool strided = row_stride_ && row_stride_ != dim_ * 2;
+    bool i8f = batched_filter != 1 && !i8f_disabled_ && !f32_ && !strided && variant == 0 && knobs().filter != 1 &&
+               scan_mfma_supported((int)dim_) && k >= 1 && k <= 64 && nrows_ >= 4 * 8192ull;
+    if (batched_filter == 0 && knobs().filter == 0 && nq < 16) i8f = false;  // a few queries: the exact kernels' territory anyway
+    if (i8f && !i8_ready_ && batched_filter != 2) {
+        // the int8 copy of the slab (half its size again) is built on first use; no room for it: the f16 filter needs none
+        FSGPU_HIP(hipSetDevice(device_));
+        if (!i8_slab_.reserve((size_t)nrows_ * dim_).ok()) {
+            (void)hipGetLastError();
+            i8f_disabled_ = true;
+            i8f = false;
+        }
+    }
+    if (i8f) {
+        uint32_t refiltered = 0;
+        SearchError e = batched_impl(queries_dev, nq, query_len, k, allow_dev, out_rows_dev, out_scores_dev, out_counts_dev, stream,
+                                     fallbacks, out_packed_dev, 0, 0, true, &refiltered);
+        if (e.ok()) {
+            i8f_queries += nq;
+            i8f_refiltered += refiltered;
+            // more than 1/8 of a batch uncertified twice in a row: the int8 margin does not suit this corpus
+            if (nq >= 16 && (uint64_t)refiltered * 8 > nq) {
+                if (++i8f_strikes_ >= 2 && batched_filter == 0 && knobs().filter == 0) i8f_disabled_ = true;
+            } else {
+                i8f_strikes_ = 0;
+            }
+        }
+        return e;
+    }
     return batched_impl(queries_dev, nq, query_len, k, allow_dev, out_rows_dev, out_scores_dev, out_counts_dev, stream,
-                        fallbacks, out_packed_dev, 0, 0);
+                        fallbacks, out_packed_dev, 0, 0, false, nullptr);
 }
 
 // int8 pass 1 on the matrix cores for a whole batch (exact integer scores), exact f16 rescore, top-k: the batched form of
@@ -1026,17 +1062,22 @@ SearchError VectorIndex::search_top_k_int8_batched_device(const float* queries_d
                                                           float* out_scores_dev, uint32_t* out_counts_dev,
                                                           hipStream_t stream, uint32_t* fallbacks) {
     return batched_impl(queries_dev, nq, query_len, k, nullptr, out_rows_dev, out_scores_dev, out_counts_dev, stream,
-                        fallbacks, nullptr, multiplier ? multiplier : 1, 0);
+                        fallbacks, nullptr, multiplier ? multiplier : 1, 0, false, nullptr);
 }
 
 // int8_mult == 0: f16 slab, f16-rounded queries, approximate scores + proven margin (mfma_scan.hip header).
 // int8_mult >= 1: int8 slab, int8 queries, exact integer scores; the k * int8_mult best rows are the candidates.
+// i8_filter (int8_mult == 0): int8 slab and queries as the FILTER of the exact search — integer scores + the proven margin of
+//                 prepare_queries_i8_filter_kernel; queries it cannot certify are re-filtered on the f16 path (*refiltered).
 SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
                                       const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
                                       uint32_t* out_counts_dev, hipStream_t stream, uint32_t* fallbacks,
-                                      uint64_t* out_packed_dev, uint32_t int8_mult, uint32_t query_stride) {
+                                      uint64_t* out_packed_dev, uint32_t int8_mult, uint32_t query_stride, bool i8_filter,
+                                      uint32_t* refiltered) {
     // query_stride: floats between queries (0 = dim): an MRL prefix view searches the first dim_ dimensions of full-length queries
-    const bool i8 = int8_mult != 0;
+    const bool i8f = i8_filter && int8_mult == 0;
+    const bool i8 = int8_mult != 0 || i8f;
+    if (refiltered) *refiltered = 0;
     const uint32_t qs = query_stride ? query_stride : dim_;
     if (fallbacks) *fallbacks = 0;
     FSGPU_TRY(ensure_query_dimension(query_len));
@@ -1068,7 +1109,9 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     }
     // The main pass lets ~ksel N / RB rows through and stage B ~ksel RB / RA: both must stay in the low thousands (block
     // lists, spill area, the selection's capacity), so the samples grow with the rank the selections anchor on.
-    const uint32_t ksel_est = std::max<uint32_t>(k, 1) * (int8_mult ? int8_mult : 1);
+    // (the int8 filter's margin lets a few times as many rows through each stage as its rank alone would: sized like a larger rank)
+    const uint32_t i8f_growth = knobs().i8f_growth > 0 ? (uint32_t)knobs().i8f_growth : 4;
+    const uint32_t ksel_est = std::max<uint32_t>(k, 1) * (int8_mult ? int8_mult : 1) * (i8f ? i8f_growth : 1);
     const uint32_t grow = knobs().rb > 0 ? 1 : std::min<uint32_t>(4, (ksel_est + 15) / 16);
     if (knobs().ra <= 0 && ksel_est > 32) RA = RA_MAX;
     // B = about 1/64 of the slab (times the growth), between 8 RA and the cap, a multiple of RA, at most a quarter of it
@@ -1088,12 +1131,15 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     RB = std::min<uint32_t>(RB, (uint32_t)(nrows_ / 4));
     RB = std::max<uint32_t>(RA, RB / RA * RA);
     // int8 mode: candidate_count of the reference (search.rs:603-607)
-    uint64_t cc64 = std::min<uint64_t>((uint64_t)k * (i8 ? int8_mult : 1), nrows_);
+    uint64_t cc64 = std::min<uint64_t>((uint64_t)k * (int8_mult ? int8_mult : 1), nrows_);
     cc64 = std::max<uint64_t>(cc64, std::min<uint64_t>(k, nrows_));
-    const uint32_t ksel = i8 ? (uint32_t)std::min<uint64_t>(cc64, 0xffffffffull) : k;  // rank that anchors the selections
+    const uint32_t ksel = int8_mult ? (uint32_t)std::min<uint64_t>(cc64, 0xffffffffull) : k;  // rank that anchors the selections
     const bool strided = row_stride_ && row_stride_ != dim_ * 2;   // an MRL prefix view
     const bool usable = scan_mfma_supported((int)dim_) && k >= 1 && k <= 64 && ksel <= kSelectMaxK && nrows_ >= 4 * (uint64_t)RA && variant != 4 &&
                         !f32_ && (!strided || (!i8 && qs >= dim_)) && (query_stride == 0 || !i8);
+    if (!usable && i8f)   // shapes the matrix-core path does not cover: the f16 branch below sorts them out
+        return batched_impl(queries_dev, nq, query_len, k, allow_dev, out_rows_dev, out_scores_dev, out_counts_dev, stream, fallbacks,
+                            out_packed_dev, 0, query_stride, false, nullptr);
     if (!usable && i8) {
         // per-query int8 two-pass through host staging (rare shapes: huge candidate counts, tiny or odd-dimension slabs)
         std::vector<float> q((size_t)nq * dim_), sc((size_t)nq * k);
@@ -1129,6 +1175,12 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         FSGPU_HIP(launch_quantize_slab_i8(slab_dev_, (size_t)nrows_ * dim_, static_cast<unsigned int*>(i8_max_.ptr),
                                           i8_slab_.ptr, stream));
         i8_ready_ = true;
+    }
+    if (i8f && !i8_stats_ready_) {
+        FSGPU_TRY(i8_stats_.reserve(16));
+        FSGPU_HIP(launch_i8_slab_stats(slab_dev_, i8_slab_.ptr, N, dim_, static_cast<const unsigned int*>(i8_max_.ptr),
+                                       static_cast<unsigned int*>(i8_stats_.ptr), stream));
+        i8_stats_ready_ = true;
     }
     if (!i8 && !mf_norm_ready_) {
         FSGPU_TRY(mf_max_norm_.reserve(4));
@@ -1222,7 +1274,10 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         const float* qg = queries_dev + (size_t)g0 * qs;
         uint32_t* overflow = overflow_all + g0;
         uint32_t* cand_counts = counts_all + g0;
-        if (i8) FSGPU_HIP(launch_prepare_queries_i8(qg, ng, QP, dim_, mf_qh_.ptr, delta, stream));
+        if (i8f)
+            FSGPU_HIP(launch_prepare_queries_i8_filter(qg, ng, QP, dim_, qs, static_cast<const unsigned int*>(i8_max_.ptr),
+                                                       static_cast<const unsigned int*>(i8_stats_.ptr), mf_qh_.ptr, delta, stream));
+        else if (i8) FSGPU_HIP(launch_prepare_queries_i8(qg, ng, QP, dim_, mf_qh_.ptr, delta, stream));
         else
             FSGPU_HIP(launch_prepare_queries(qg, ng, QP, dim_, qs, static_cast<const unsigned int*>(mf_max_norm_.ptr),
                                              mf_qh_.ptr, delta, stream));
@@ -1290,7 +1345,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         sb.nlists = (uint32_t)grid_b;
         sb.list_len = a.slots;
         sb.k = ksel;
-        sb.take_topk = i8 ? 1 : 0;
+        sb.take_topk = (i8 && !i8f) ? 1 : 0;
         sb.delta = delta;
         sb.overflow = overflow;
         sb.spill = spill;
@@ -1393,7 +1448,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
             std::fprintf(stderr, "    query %u: overflow=%u candidates=%u\n", fb[j], overflow_all[fb[j]], counts_all[fb[j]]);
     }
     const uint32_t total_fallbacks = (uint32_t)fb.size();
-    if (total_fallbacks && i8) {
+    if (total_fallbacks && i8 && !i8f) {
         // list/spill overflow (a pile of tied scores at the threshold): the per-query int8 two-pass answers those
         std::vector<float> qh(dim_), sc(k);
         std::vector<uint32_t> rw(k);
@@ -1415,8 +1470,10 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         const size_t o_idx = 0, o_q = align_up(o_idx + nf * 4, 256), o_rows = align_up(o_q + nf * dim_ * 4, 256),
                      o_scores = align_up(o_rows + nf * k * 4, 256), o_counts = align_up(o_scores + nf * k * 4, 256),
                      total = align_up(o_counts + nf * 4, 256);
-        FSGPU_TRY(mf_fallback_.reserve(total));
-        unsigned char* base = static_cast<unsigned char*>(mf_fallback_.ptr);
+        // (the int8 filter hands its leftovers to a nested f16-filter call, which may itself use mf_fallback_)
+        DeviceBuffer& fbuf = i8f ? mf_fallback2_ : mf_fallback_;
+        FSGPU_TRY(fbuf.reserve(total));
+        unsigned char* base = static_cast<unsigned char*>(fbuf.ptr);
         uint32_t* idx_dev = reinterpret_cast<uint32_t*>(base + o_idx);
         float* q_dev = reinterpret_cast<float*>(base + o_q);
         uint32_t* rows_dev = reinterpret_cast<uint32_t*>(base + o_rows);
@@ -1425,6 +1482,19 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         FSGPU_HIP(hipMemcpyAsync(idx_dev, fb.data(), nf * 4, hipMemcpyHostToDevice, stream));
         FSGPU_HIP(hipStreamSynchronize(stream));  // fb is a stack-owned pageable buffer
         FSGPU_HIP(launch_gather_queries(queries_dev, idx_dev, (uint32_t)nf, dim_, qs, q_dev, stream));
+        if (i8f && nf > 8) {
+            // rows within the int8 margin of the k-th best did not fit the lists (or the query cannot be certified on the int8
+            // slab at all): the f16 filter, whose margin is ~20 x narrower, answers these as a batch of its own
+            uint32_t inner_fb = 0;
+            FSGPU_TRY(batched_impl(q_dev, (uint32_t)nf, query_len, k, allow_dev, rows_dev, scores_dev, counts_dev, stream, &inner_fb,
+                                   nullptr, 0, 0, false, nullptr));
+            if (refiltered) *refiltered = (uint32_t)nf;
+            if (fallbacks) *fallbacks = inner_fb;
+            FSGPU_HIP(launch_scatter_hits(idx_dev, (uint32_t)nf, k, rows_dev, scores_dev, counts_dev, out_rows_dev,
+                                          out_scores_dev, out_counts_dev, reinterpret_cast<u64*>(out_packed_dev), stream));
+            return ok();
+        }
+        if (i8f && refiltered) *refiltered = (uint32_t)nf;
         FSGPU_TRY(fused_search(q_dev, (uint32_t)nf, k, k_eff, allow_dev, rows_dev, scores_dev, counts_dev, nullptr, stream));
         FSGPU_HIP(launch_scatter_hits(idx_dev, (uint32_t)nf, k, rows_dev, scores_dev, counts_dev, out_rows_dev,
                                       out_scores_dev, out_counts_dev, reinterpret_cast<u64*>(out_packed_dev), stream));
@@ -1690,7 +1760,7 @@ SearchError VectorIndex::mrl_search_batched(const float* queries, uint32_t nq, u
     view->hreduce = hreduce;
     uint32_t fb = 0;
     FSGPU_TRY(view->batched_impl(q_dev, nq, search_dims, rtop, nullptr, nullptr, nullptr, nullptr, stream_, &fb,
-                                 reinterpret_cast<uint64_t*>(packed), 0, dim_));
+                                 reinterpret_cast<uint64_t*>(packed), 0, dim_, false, nullptr));
     for (auto& ev : view->events_) events_.push_back(ev);   // the view's timed launches count as this index's
     view->events_.clear();
     profiled_rows_ += view->profiled_rows_;

@@ -128,6 +128,10 @@ class VectorIndex {
     int32_t variant = 0;
     uint64_t filter_gathered = 0, filter_scanned = 0;  // filtered host searches by path
     bool profiling = false;
+    // filter of the exact batched search (fsgpu_index_set_batched_filter): 0 = automatic, 1 = f16 slab, 2 = int8 slab
+    int32_t batched_filter = 0;
+    uint64_t i8f_queries = 0, i8f_refiltered = 0;  // queries the int8 filter took / handed on to the f16 filter
+    bool int8_filter_active() const { return batched_filter != 1 && !i8f_disabled_; }
     VectorIndex* mrl_view(uint32_t dims);  // strided prefix view of this slab (created on first use)
     // Concurrent callers (the reference's scan is `&self`, lock-free, any number of callers: search.rs:192): replicas of this
     // index over the SAME slab and live bitmap, each with its own stream, workspaces and mutex, so that row-level searches from
@@ -144,7 +148,8 @@ class VectorIndex {
     void* pinned_io();
     SearchError batched_impl(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k, const uint64_t* allow_dev,
                              uint32_t* out_rows_dev, float* out_scores_dev, uint32_t* out_counts_dev, hipStream_t stream,
-                             uint32_t* fallbacks, uint64_t* out_packed_dev, uint32_t int8_mult, uint32_t query_stride);
+                             uint32_t* fallbacks, uint64_t* out_packed_dev, uint32_t int8_mult, uint32_t query_stride,
+                             bool i8_filter, uint32_t* refiltered);
     SearchError quantized_two_pass(const float* query, uint32_t query_len, uint32_t k, uint32_t multiplier, int bits,
                                    uint32_t* out_rows, float* out_scores, uint32_t* out_count);
     SearchError common_init(int device);
@@ -178,8 +183,10 @@ class VectorIndex {
     DeviceBuffer ws_partial_, ws_queries_, ws_allow_, ws_rows_, ws_scores_, ws_counts_, ws_keys_a_, ws_keys_b_,
         ws_sort_tmp_, ws_gather_rows_, ws_gather_out_, i8_slab_, n4_slab_, i8_max_, ws_i8_query_, ws_cand_packed_,
         ws_cand_rows_, ws_cand_scores_, mf_max_norm_, mf_qh_, mf_delta_, mf_tau_, mf_cand_, mf_dense_, mf_sel_,
-        mf_fallback_, mf_spill_, mf_io_;
-    bool i8_ready_ = false, n4_ready_ = false;
+        mf_fallback_, mf_fallback2_, mf_spill_, mf_io_, i8_stats_;
+    bool i8_ready_ = false, n4_ready_ = false, i8_stats_ready_ = false;
+    bool i8f_disabled_ = false;   // the int8 filter left too many queries uncertified on this slab (or its copy does not fit)
+    uint32_t i8f_strikes_ = 0;
     bool mf_norm_ready_ = false;
     int mf_shape_i8_ = 4, mf_per_cu_160_ = 1, mf_per_cu_160_i8_ = 1;
     bool mf_use_160_ = false;

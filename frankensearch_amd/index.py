@@ -112,6 +112,15 @@ class VectorIndex:
     def set_hreduce(self, mode: int) -> None:
         check(_lib.lib().fsgpu_index_set_hreduce(self._h, mode))
 
+    def set_batched_filter(self, filter: int) -> None:
+        """0 = automatic, 1 = f16 slab, 2 = int8 slab as the filter of search_batched (results identical either way)."""
+        check(_lib.lib().fsgpu_index_set_batched_filter(self._h, filter))
+
+    def batched_filter_stats(self) -> dict:
+        q, r, a = C.c_uint64(0), C.c_uint64(0), C.c_int32(0)
+        check(_lib.lib().fsgpu_index_batched_filter_stats(self._h, C.byref(q), C.byref(r), C.byref(a)))
+        return {"int8_queries": q.value, "refiltered_f16": r.value, "int8_active": bool(a.value)}
+
     def doc_id_at(self, row: int) -> str:
         p, n = C.c_void_p(), C.c_uint32()
         check(_lib.lib().fsgpu_index_doc_id(self._h, row, C.byref(p), C.byref(n)))

@@ -153,6 +153,20 @@ fsgpu_status fsgpu_search_topk_device(fsgpu_index *idx, const float *queries_dev
  * proven error bound are re-scored in the reference's exact order, so rows and score bits are IDENTICAL to
  * fsgpu_search_topk.  Queries the batched path cannot certify (k > 64, unsupported dimension, margin overflow) are
  * answered by the exact kernels; *out_fallbacks (optional) counts them.  The _device form synchronises hip_stream. */
+/* The filter those passes score with is chosen per index (FSGPU_FILTER_AUTO): batches of 16 queries and more are
+ * filtered on an int8 copy of the slab (built on first use, half the slab's size again; v_mfma_i32_16x16x64_i8: half the
+ * bytes and half the matrix instructions per row) under a bound measured from the slab and each query (mfma_scan.hip,
+ * prepare_queries_i8_filter_kernel); queries whose margin lets too many rows through are re-filtered on the f16 slab, and an
+ * index where that happens to more than 1/8 of a batch twice in a row (or that has no room for the copy) stays with the
+ * f16 filter.  Either way the emitted rows and score bits are the exact search's. */
+#define FSGPU_FILTER_AUTO 0
+#define FSGPU_FILTER_F16 1
+#define FSGPU_FILTER_INT8 2
+fsgpu_status fsgpu_index_set_batched_filter(fsgpu_index *idx, int32_t filter);
+/* Queries the int8 filter has taken so far, how many of them it handed on to the f16 filter, and whether the index still
+ * uses it (any pointer may be null). */
+fsgpu_status fsgpu_index_batched_filter_stats(fsgpu_index *idx, uint64_t *int8_queries, uint64_t *refiltered_f16,
+                                              int32_t *int8_active);
 fsgpu_status fsgpu_search_topk_batched(fsgpu_index *idx, const float *queries, uint32_t nq, uint32_t query_len,
                                        uint32_t k, const uint64_t *allow_bitmap, uint32_t *out_rows, float *out_scores,
                                        uint32_t *out_counts, uint32_t *out_fallbacks);
@@ -395,6 +409,7 @@ fsgpu_status fsgpu_bert_set_coalescing(fsgpu_bert *m, uint32_t max_batch, uint32
  *   FSGPU_WIDE_DBG=1..4         timing skeletons of that kernel (no MFMAs / no DMA / ...): answers are NOT valid
  *   FSGPU_USE_160, FSGPU_MFMA_SHAPE, FSGPU_MFMA_SHAPE_I8   shapes of the LDS-query kernel
  *   FSGPU_RA, FSGPU_RB, FSGPU_ROUND, FSGPU_NO_SKIP_B, FSGPU_NO_REVERSE   sample sizes / round size / pass direction
+ *   FSGPU_FILTER (f16 | i8), FSGPU_I8F_GROWTH   pin the filter of the exact batched search / its sample growth
  *   FSGPU_GRID_BLOCKS, FSGPU_I8_PER_CU   grid sizes of the exact kernels
  *   FSGPU_SELECT_SORT_ABOVE     rank above which select_kernel sorts instead of extracting
  *   FSGPU_BERT_GEMM_SHAPE, FSGPU_BERT_ATTN, FSGPU_BERT_NO_FUSED_LN, FSGPU_BERT_NO_GRAPH, FSGPU_BERT_NO_QUERY_PATH   encoder paths

@@ -3,8 +3,8 @@
 
 Every case draws a corpus shape, a data kind (gaussian / clustered with exact duplicates / few distinct rows / topical runs),
 tombstones, an optional allow bitmap, a batch size that exercises multi-group rounds with ragged tails, and k; the batched
-f16 answer must equal the exact kernels' bit for bit for every query, and the batched int8 two-pass must equal the
-per-query int8 two-pass.
+answer under BOTH filters (int8 slab, f16 slab) must equal the exact kernels' bit for bit for every query, and the batched
+int8 two-pass must equal the per-query int8 two-pass.  Some corpora get outlier dimensions or a non-finite value.
 """
 import os, sys, time
 import numpy as np
@@ -16,6 +16,7 @@ budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
 rng = np.random.default_rng(seed)
 t_end = time.time() + budget
 cases = bad = 0
+tot_q = tot_r = 0
 while time.time() < t_end:
     dim = int(rng.choice([128, 256, 384]))
     n = int(rng.integers(33_000, 300_000))
@@ -49,15 +50,32 @@ while time.time() < t_end:
             q[4, int(rng.integers(0, dim))] = float(rng.choice([65520.0, -7e4, 3e5]))   # finite, but +-inf as f16
             q[5] = (rng.standard_normal(dim) * float(rng.choice([3e-6, 1e-9]))).astype(np.float32)  # f16 subnormals / zeros
             q[6, :: int(rng.integers(2, 9))] = 1.5e-6
+    outl = rng.random()
+    if outl < 0.25:    # outlier dimensions (as real embedding models have): they stretch the corpus-wide int8 scale
+        cols = rng.integers(0, dim, int(rng.integers(1, 4)))
+        x[:, cols] *= float(rng.choice([4.0, 12.0]))
+        x /= np.linalg.norm(x, axis=1, keepdims=True) + 1e-9
+        slab = x.astype(np.float16).view(np.uint16)
+    elif outl < 0.30:  # a non-finite value in the slab: no int8 bound exists, the f16 filter / exact kernels answer
+        slab = slab.copy()
+        slab[int(rng.integers(0, n)), int(rng.integers(0, dim))] = int(rng.choice([0x7c00, 0xfc00, 0x7e00]))
     idx = fa.VectorIndex.from_slab(slab, live=live)
-    br, bs, bc, fb = idx.search_batched(q, k, allow=allow)
     ok = True
-    for s0 in range(0, nq, 64):
-        er, es, ec = idx.search_batch(q[s0:s0 + 64], k, allow=allow)
-        sl = slice(s0, min(nq, s0 + 64))
-        if not (np.array_equal(bc[sl], ec) and np.array_equal(br[sl], er) and
-                np.array_equal(bs[sl].view(np.uint32), es.view(np.uint32))):
-            ok = False
+    exact = [idx.search_batch(q[s0:s0 + 64], k, allow=allow) for s0 in range(0, nq, 64)]
+    fb = []
+    for filt in (2, 1):   # int8 filter, f16 filter: both must give the exact kernels' rows and score bits
+        idx.set_batched_filter(filt)
+        br, bs, bc, f = idx.search_batched(q, k, allow=allow)
+        fb.append(f)
+        for j, s0 in enumerate(range(0, nq, 64)):
+            er, es, ec = exact[j]
+            sl = slice(s0, min(nq, s0 + 64))
+            if not (np.array_equal(bc[sl], ec) and np.array_equal(br[sl], er) and
+                    np.array_equal(bs[sl].view(np.uint32), es.view(np.uint32))):
+                ok = False
+    st = idx.batched_filter_stats()
+    tot_q += st["int8_queries"]
+    tot_r += st["refiltered_f16"]
     if allow is None:
         mult = int(rng.choice([1, 3, 5]))
         r8, s8, c8, fb8 = idx.search_int8_two_pass_batched(q, k, mult)
@@ -71,5 +89,5 @@ while time.time() < t_end:
         bad += 1
         print(f"MISMATCH seed={seed} case={cases} dim={dim} n={n} kind={kind} nq={nq} k={k} live={live is not None} allow={allow is not None} fb={fb}", flush=True)
     idx.close()
-print(f"seed={seed}: {cases} cases, {bad} mismatches")
+print(f"seed={seed}: {cases} cases, {bad} mismatches; int8 filter took {tot_q} queries, handed {tot_r} on to the f16 filter")
 sys.exit(1 if bad else 0)
