@@ -26,6 +26,9 @@ HOST_HEADERS = ["host/two_tier_searcher.hpp"]
 # -ffp-contract=off: the scan must issue a separate multiply and add (reference order, simd.rs:398-446).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-result", "-x", "hip"]
+# mfma_wide.hip: the tile loop of the 640-query int8 shape must unroll completely (its register-resident query fragments
+# are indexed by the chunk counter: left rolled they land in scratch), which is past LLVM's default pragma-unroll budget
+EXTRA_FLAGS = {"mfma_wide.hip": ["-mllvm", "-pragma-unroll-threshold=200000"]}
 
 
 def _hipcc() -> str:
@@ -52,7 +55,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         path = os.path.join(CSRC, src)
         if force or _stale(obj, [path] + common):
-            cmd = [hipcc] + FLAGS + ["-I", INCLUDE, "-c", path, "-o", obj]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-I", INCLUDE, "-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)

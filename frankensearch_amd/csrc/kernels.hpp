@@ -158,6 +158,7 @@ bool scan_mfma_supported(int dim);
 // mfma_wide.hip: main pass with the queries in registers and the row tiles in an LDS-DMA ring; query_tiles 2 = 256, 3 = 384
 // queries per launch; one candidate list of args.slots <= kWideSlots entries per (query, block)
 bool scan_wide_supported(int dim, int elem_bytes);
+int scan_wide_max_query_tiles(int dim, int elem_bytes);  // 3 for f16 rows of 384 dimensions, 5 for their int8 form
 hipError_t launch_scan_wide(const MfmaScanArgs& args, int query_tiles, int grid, hipStream_t stream, int* occupancy);
 void note_main_pass_kernel(const char* name);  // remembers the instantiation the last main pass ran (last_main_pass_kernel)
 const char* last_main_pass_kernel();  // template instantiation of the last batched main pass launched, as rocprofv3 names it

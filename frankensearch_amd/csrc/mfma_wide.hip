@@ -82,7 +82,8 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     constexpr int PW = NI / WPB;                                    // ... per wave
     static_assert(NI % WPB == 0 && PW >= 1, "a tile's DMA instructions divide evenly over the 8 waves");
     static_assert(RS % 2 == 0, "sub-tiles are consumed in pairs");
-    constexpr int CK = KS == 12 ? (QT >= 3 ? 2 : 3) : (KS >= 2 ? KS / 2 : 1);   // k-steps per chunk (fewer at QT = 3: registers)
+    // k-steps per chunk (fewer where the resident queries leave fewer registers for the fragment double buffer)
+    constexpr int CK = KS == 12 ? (QT >= 3 ? 2 : 3) : KS == 6 ? (QT >= 5 ? 1 : 3) : KS == 4 ? (QT >= 7 ? 1 : 2) : (KS >= 2 ? KS / 2 : 1);
     constexpr int NCH = KS / CK;                                    // chunks per sub-tile pair
     constexpr int NC = (RS / 2) * NCH;                              // chunks per tile
     static_assert(KS % CK == 0 && NC % 2 == 0, "an even number of chunks per tile: the register double buffer starts every tile in the same phase");
@@ -354,16 +355,20 @@ hipError_t launch_wide_t(const MfmaScanArgs& args, int grid, hipStream_t stream,
 
 template <int EB, int QT>
 hipError_t launch_wide_d(const MfmaScanArgs& args, int grid, hipStream_t stream, int* occupancy) {
+    // resident query fragments: QT x (row bytes / 64) x 4 registers per lane; 144 is what fits next to the accumulators and
+    // the fragment double buffer (f16 rows of 768 bytes: 3 tiles; int8 rows of 384 bytes: 6)
+    if (QT * (int)(args.dim * EB / 64) * 4 > 144) return hipErrorInvalidValue;
     switch (args.dim * EB / 2) {  // row length in 2-byte units
-        case 384: {
+        case 384: if constexpr (QT <= 3) {
             static const int dbg = [] { const char* e = std::getenv("FSGPU_WIDE_DBG"); return e ? std::atoi(e) : 0; }();  // timing experiments only
             if constexpr (EB == 2 && QT == 2) {
                 if (dbg == 1) return launch_wide_t<768, EB, QT, 6, 1>(args, grid, stream, occupancy);
                 if (dbg == 2) return launch_wide_t<768, EB, QT, 6, 2>(args, grid, stream, occupancy);
             }
             return launch_wide_t<768, EB, QT, 6>(args, grid, stream, occupancy);   // 6 x 24 KB
-        }
-        case 256: return launch_wide_t<512, EB, QT, 8>(args, grid, stream, occupancy);   // 8 x 16 KB
+        } else return hipErrorInvalidValue;
+        case 256: if constexpr (QT <= 4) return launch_wide_t<512, EB, QT, 8>(args, grid, stream, occupancy);   // 8 x 16 KB
+                  else return hipErrorInvalidValue;
         case 192: return launch_wide_t<384, EB, QT, 6>(args, grid, stream, occupancy);   // 6 x 24 KB
         case 128: return launch_wide_t<256, EB, QT, 8>(args, grid, stream, occupancy);   // 8 x 16 KB
         case 64: return launch_wide_t<128, EB, QT, 8>(args, grid, stream, occupancy);    // 8 x 8 KB
@@ -378,16 +383,26 @@ bool scan_wide_supported(int dim, int elem_bytes) {
     return rowb == 768 || rowb == 512 || rowb == 384 || rowb == 256 || rowb == 128;
 }
 
-// query_tiles = QT (2: 256 queries per pass, 3: 384)
+// largest query_tiles a row length admits (registers: see launch_wide_d), capped at 5
+int scan_wide_max_query_tiles(int dim, int elem_bytes) {
+    const int per_tile = dim * elem_bytes / 64 * 4;
+    const int fit = per_tile > 0 ? 144 / per_tile : 0;
+    if (elem_bytes != 1) return fit > 3 ? 3 : fit;   // f16 rows: 2 and 3 are built
+    return fit > 5 ? 5 : fit;   // (6 tiles of int8 rows of 384 bytes compile to 256 registers + 36 spilled)
+}
+
+// query_tiles = QT (2: 256 queries per pass, 3: 384, 4: 512, 5: 640 — as many as scan_wide_max_query_tiles allows)
 hipError_t launch_scan_wide(const MfmaScanArgs& args, int query_tiles, int grid, hipStream_t stream, int* occupancy) {
     const int eb = args.elem_bytes == 1 ? 1 : 2;
-    if (!scan_wide_supported((int)args.dim, eb)) return hipErrorInvalidValue;
+    if (!scan_wide_supported((int)args.dim, eb) || query_tiles > scan_wide_max_query_tiles((int)args.dim, eb)) return hipErrorInvalidValue;
     if (eb == 2) {
         if (query_tiles == 2) return launch_wide_d<2, 2>(args, grid, stream, occupancy);
         if (query_tiles == 3) return launch_wide_d<2, 3>(args, grid, stream, occupancy);
     } else {
         if (query_tiles == 2) return launch_wide_d<1, 2>(args, grid, stream, occupancy);
         if (query_tiles == 3) return launch_wide_d<1, 3>(args, grid, stream, occupancy);
+        if (query_tiles == 4) return launch_wide_d<1, 4>(args, grid, stream, occupancy);
+        if (query_tiles == 5) return launch_wide_d<1, 5>(args, grid, stream, occupancy);
     }
     return hipErrorInvalidValue;
 }

@@ -47,6 +47,7 @@ struct Knobs {
     int grid_blocks = 0, ra = 0, rb = 0, mfma_shape = 0, mfma_shape_i8 = 0, round = 0, i8_per_cu = 0;
     int wide = -1;  // FSGPU_WIDE: 0 = never the register-resident-query main pass, 2 / 3 = its query tiles per wave
     int filter = 0;     // FSGPU_FILTER: "f16" (1) / "i8" (2) pin the filter of the exact batched search; unset = automatic
+    int wide_max = 0;   // FSGPU_WIDE_MAX: cap on the query tiles per wave of the wide main pass (default: what the registers hold)
     int i8f_growth = 0; // FSGPU_I8F_GROWTH: sample growth factor of the int8 filter (default 4)
     bool no_skip_b = false, use_160 = false, debug_batched = false, no_reverse = false;
     Knobs() {
@@ -64,6 +65,7 @@ struct Knobs {
         if (std::getenv("FSGPU_WIDE")) wide = num("FSGPU_WIDE");
         if (const char* f = std::getenv("FSGPU_FILTER")) filter = std::strcmp(f, "f16") == 0 ? 1 : std::strcmp(f, "i8") == 0 ? 2 : 0;
         i8f_growth = num("FSGPU_I8F_GROWTH");
+        wide_max = num("FSGPU_WIDE_MAX");
         no_skip_b = std::getenv("FSGPU_NO_SKIP_B") != nullptr;
         no_reverse = std::getenv("FSGPU_NO_REVERSE") != nullptr;
         use_160 = std::getenv("FSGPU_USE_160") != nullptr;
@@ -1224,6 +1226,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     // (384 per launch when that many queries are left: the matrix pipe is the bound there and fewer passes leave it more of
     // the power budget — measured 148 k against 130 k queries/s at 10M x 384)
     const int wide_pref = knobs().wide >= 0 ? knobs().wide : 3;
+    const uint32_t wide_max = (uint32_t)std::max(2, std::min(knobs().wide_max > 0 ? knobs().wide_max : 5, scan_wide_max_query_tiles((int)dim_, i8 ? 1 : 2)));
     const bool wide_ok = (wide_pref == 2 || wide_pref == 3) && scan_wide_supported((int)dim_, i8 ? 1 : 2) && variant != 5 && variant != 6;
     // per-query verdicts, written by the kernels straight into pinned host memory and read after ONE stream
     // synchronisation for the whole batch: [0, cap) = overflow flags, [cap, 2 cap) = candidate counts
@@ -1249,7 +1252,13 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         // Main pass at 384 / 256 queries per launch (mfma_wide.hip: queries in registers, row tiles through an LDS-DMA
         // ring) when that many are left; the sample stages then run as sub-groups of 128 on the LDS-query kernel.
         int wide_qt = 0;
-        if (wide_ok && left >= 256) wide_qt = (wide_pref != 2 && left >= 384) ? 3 : 2;   // 128-query groups per launch
+        if (wide_ok && left >= 256) {   // 128-query groups per launch
+            // as many as the registers hold (f16 rows of 384 dimensions: 3, their int8 form: 5), the round's groups spread evenly
+            // over its passes (8 groups: 3 + 3 + 2 on f16 rows, 4 + 4 on int8 rows)
+            const uint32_t groups_left = std::min<uint32_t>(left / 128, QCAP / 128);
+            const uint32_t passes = (groups_left + wide_max - 1) / wide_max;
+            wide_qt = wide_pref == 2 ? 2 : (int)((groups_left + passes - 1) / passes);
+        }
         // 160, 128 or 64 queries per pass
         const int shape = wide_qt ? (i8 ? mf_shape_i8_ : mf_shape_)
                                   : (left > 64 && variant != 5) ? ((left > 128 && mf_use_160_) ? 5 : (i8 ? mf_shape_i8_ : mf_shape_)) : 0;

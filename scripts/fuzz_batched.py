@@ -38,7 +38,7 @@ while time.time() < t_end:
     slab = x.astype(np.float16).view(np.uint16)
     live = None if rng.random() < 0.5 else (rng.random(n) > 0.2)
     allow = None if rng.random() < 0.6 else (rng.random(n) > float(rng.choice([0.3, 0.9])))
-    nq = int(rng.choice([1, 5, 63, 64, 65, 127, 128, 129, 200, 256, 257, 300, 511, 640, 700]))
+    nq = int(rng.choice([1, 5, 63, 64, 65, 127, 128, 129, 200, 256, 257, 300, 511, 520, 640, 700, 1030]))
     k = int(rng.choice([1, 2, 10, 30, 33, 64]))
     q = x[rng.integers(0, n, nq)] + (rng.standard_normal((nq, dim)) * 0.2).astype(np.float32)
     if nq > 3:
