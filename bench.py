@@ -35,6 +35,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 matrix-core peak (same guide)
+MFMA_I8_PEAK_TOPS = 5000.0     # v_mfma_i32_16x16x64_i8 issues at twice the f16 rate (the guide's microbenchmark: >= 3944 TOPS)
 PROFILE_ROUND = "r02"   # profiles/<round>/pmc_summary.json: the PMC pass that belongs to this build's kernels
 CLUSTERS = 64
 NOISE = 0.30
@@ -571,6 +572,7 @@ def main() -> None:
         dist.barrier()
     index.set_profiling(True)
     fallbacks[0] = 0
+    filt0 = index.batched_filter_stats()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = run_steps(args.warmup, args.steps)
@@ -580,6 +582,15 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     index.set_profiling(False)
     scan_ms, launches, scan_rows = index.scan_stats(reset=True)
+    filt1 = index.batched_filter_stats()
+    # which approximate scores filtered the slab in the timed steps: the int8 copy (integer matrix cores, 1 byte per element)
+    # or the f16 slab itself; the emitted rows and score bits are the exact search's either way
+    i8_queries = filt1["int8_queries"] - filt0["int8_queries"]
+    i8_refiltered = filt1["refiltered_f16"] - filt0["refiltered_f16"]
+    int8_filter = args.batched and i8_queries * 2 > args.steps * args.batch
+    eb = 1 if int8_filter else 2
+    mfma_peak = MFMA_I8_PEAK_TOPS if int8_filter else MFMA_F16_PEAK_TFLOPS
+    mfma_unit = "TOP/s" if int8_filter else "TFLOP/s"
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -601,7 +612,7 @@ def main() -> None:
         sc = scores.cpu().numpy()
         assert np.all(np.diff(sc, axis=1) <= 0), "results must be best-first"
         per_launch_ms = scan_ms / max(launches, 1)
-        alg_bytes = scan_rows // max(launches, 1) * args.dim * 2   # rows the timed kernel streams per launch
+        alg_bytes = scan_rows // max(launches, 1) * args.dim * eb   # rows the timed kernel streams per launch x bytes per row
         achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
         line = {
             "metric": baseline_metric(),
@@ -614,7 +625,7 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f16 x f32 -> f32",
+            "dtype": "f16 x f32 -> f32" + (" (every emitted score, in the reference's operation order); candidate filter i8 x i8 -> i32" if int8_filter else ""),
             "data": "synthetic",
             "config": {
                 "workload": f"{args.rows}x{args.dim} f16 corpus (clustered unit vectors), exact brute-force cosine "
@@ -622,7 +633,10 @@ def main() -> None:
                 "rows": args.rows, "dim": args.dim, "k": k, "queries_per_step": B,
                 "parallelism": f"row-shard x{world}" + (" + all-gather(top-k) over RCCL" if world > 1 else ""),
                 "kernel_variant": args.variant,
-                "path": "matrix-core batched + exact re-score" if args.batched else "exact VALU scan",
+                "path": ("matrix-core batched (" + ("int8 slab filter, proven margin" if int8_filter else "f16 filter, proven margin") +
+                         ") + exact re-score") if args.batched else "exact VALU scan",
+                "filter": ("int8" if int8_filter else "f16") if args.batched else None,
+                "filter_refiltered_on_f16_queries": i8_refiltered if int8_filter else None,
                 "exact_fallback_queries": fallbacks[0] if args.batched else None,
             },
             "roofline": {
@@ -645,32 +659,34 @@ def main() -> None:
             flops = 2.0 * (scan_rows / launches) * args.dim * q_per_launch
             tflops = flops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
             hbm = dict(line["roofline"])
-            if tflops / MFMA_F16_PEAK_TFLOPS > achieved / HBM_PEAK_GBPS:
+            if tflops / mfma_peak > achieved / HBM_PEAK_GBPS:
                 line["roofline"] = {
-                    "bound": "mfma", "achieved": tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tflops / MFMA_F16_PEAK_TFLOPS, "traffic": None,
+                    "bound": "mfma", "achieved": tflops, "peak": mfma_peak, "unit": mfma_unit,
+                    "frac": tflops / mfma_peak, "traffic": None,
                     "kernel": "scan_wide_kernel / scan_mfma_kernel (main pass, average over the step's launches)",
                     "algorithmic_flops_per_launch": flops, "queries_per_launch": q_per_launch,
                     "avg_launch_ms": per_launch_ms, "launches": launches,
                     "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                             "algorithmic_bytes_per_launch": alg_bytes},
-                    "note": "f16 MFMA on this data sustains ~1.39 PFLOP/s with nothing else in the kernel (DESIGN 3.1e: clocks drop "
-                            "under the matrix load), so frac is measured against a roof the chip does not reach on real data",
+                    "note": ("v_mfma_i32_16x16x64_i8 sustains ~4.2 POP/s on random operands with nothing else in the kernel"
+                             if int8_filter else "v_mfma_f32_16x16x32_f16 sustains ~1.85 PFLOP/s on random operands with nothing else in the kernel") +
+                            " (profiles/r02/mfma_rate.txt, DESIGN 3.1e: clocks drop under the matrix load), so frac is measured "
+                            "against a roof the chip does not reach on real data",
                 }
             else:
-                line["roofline"]["mfma"] = {"achieved": tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                            "frac": tflops / MFMA_F16_PEAK_TFLOPS}
+                line["roofline"]["mfma"] = {"achieved": tflops, "peak": mfma_peak, "unit": mfma_unit, "frac": tflops / mfma_peak}
         # The step against its own two roofs: every query group streams the slab once (HBM) and contracts it with its
         # queries on the matrix cores (2 * rows * dim flops per query); the step cannot beat max(bytes / 8 TB/s, flops / peak)
         if args.batched:
             passes = launches / max(args.steps, 1)
             t_hbm = passes * alg_bytes / (HBM_PEAK_GBPS * 1e9)
-            t_mfma = 2.0 * (hi - lo) * args.dim * B / (MFMA_F16_PEAK_TFLOPS * 1e12)
+            t_mfma = 2.0 * (hi - lo) * args.dim * B / (mfma_peak * 1e12)
             bound_s = max(t_hbm, t_mfma)
             line["roofline"]["joint"] = {
                 "hbm_ms": t_hbm * 1e3, "mfma_ms": t_mfma * 1e3, "bound_ms": bound_s * 1e3, "bound": "hbm" if t_hbm >= t_mfma else "mfma",
                 "frac": bound_s / (elapsed / args.steps), "passes_per_step": passes, "queries_per_pass": B / max(passes, 1e-9),
-                "note": "max(slab bytes streamed per step / 8 TB/s, 2*rows*dim*queries flops / 2.5 PFLOP/s dense f16) / measured step time",
+                "note": "max(filter-slab bytes streamed per step / 8 TB/s, 2*rows*dim*queries ops / " +
+                        ("5 POP/s dense int8" if int8_filter else "2.5 PFLOP/s dense f16") + ") / measured step time",
             }
             line["config"]["exact_fallback_rate"] = fallbacks[0] / max(args.steps * B, 1)
         # HBM traffic per launch of the dominant kernel: PMC counters need their own rocprofv3 run, so the figure comes from

@@ -52,6 +52,7 @@ SIGNATURES = {
     "fsgpu_index_set_hreduce": (_i32, [_vp, _i32]),
     "fsgpu_index_set_batched_filter": (_i32, [_vp, _i32]),
     "fsgpu_index_batched_filter_stats": (_i32, [_vp, _vp, _vp, _vp]),
+    "fsgpu_index_int8_filter_bound": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp]),
     "fsgpu_index_doc_id": (_i32, [_vp, _u32, C.POINTER(_vp), C.POINTER(_u32)]),
     "fsgpu_index_soft_delete": (_i32, [_vp, C.c_char_p, _u32, C.POINTER(_i32)]),
     "fsgpu_index_wal_append": (_i32, [_vp, C.c_char_p, _u32, _vp, _u32]),

@@ -293,6 +293,17 @@ fsgpu_status fsgpu_index_batched_filter_stats(fsgpu_index* idx, uint64_t* int8_q
     return FSGPU_OK;
 }
 
+fsgpu_status fsgpu_index_int8_filter_bound(fsgpu_index* idx, const float* queries, uint32_t nq, uint32_t query_len, float* out_delta,
+                                           float* out_query_scale, float* out_slab_scale, int8_t* out_queries_i8, int8_t* out_slab_i8) {
+    if (!idx || (nq && !queries)) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::unique_lock<std::shared_mutex> state(idx->state_mu);
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.int8_filter_bound(queries, nq, query_len, out_delta, out_query_scale, out_slab_scale, out_queries_i8,
+                                                  out_slab_i8));
+    });
+}
+
 fsgpu_status fsgpu_index_doc_id(const fsgpu_index* idx, uint32_t row, const char** ptr, uint32_t* len) {
     if (!idx || !ptr || !len) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
     return finish(idx->impl.doc_id_at(row, ptr, len));

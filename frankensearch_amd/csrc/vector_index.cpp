@@ -1025,7 +1025,7 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
     // instructions of the f16 filter; a wider proven margin) unless this index has shown that its margin lets too many rows
     // through (outlier dimensions stretch the corpus-wide int8 scale), the caller forced one, or the shape is not covered.
     const bool strided = row_stride_ && row_stride_ != dim_ * 2;
-    bool i8f = batched_filter != 1 && !i8f_disabled_ && !f32_ && !strided && variant == 0 && knobs().filter != 1 &&
+    bool i8f = batched_filter != 1 && (batched_filter == 2 || !i8f_disabled_) && !f32_ && !strided && variant == 0 && knobs().filter != 1 &&
                scan_mfma_supported((int)dim_) && k >= 1 && k <= 64 && nrows_ >= 4 * 8192ull;
     if (batched_filter == 0 && knobs().filter == 0 && nq < 16) i8f = false;  // a few queries: the exact kernels' territory anyway
     if (i8f && !i8_ready_ && batched_filter != 2) {
@@ -1055,6 +1055,49 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
     }
     return batched_impl(queries_dev, nq, query_len, k, allow_dev, out_rows_dev, out_scores_dev, out_counts_dev, stream,
                         fallbacks, out_packed_dev, 0, 0, false, nullptr);
+}
+
+SearchError VectorIndex::int8_filter_bound(const float* queries, uint32_t nq, uint32_t query_len, float* out_delta,
+                                           float* out_query_scale, float* out_slab_scale, int8_t* out_queries_i8, int8_t* out_slab_i8) {
+    FSGPU_TRY(ensure_query_dimension(query_len));
+    if (f32_ || (row_stride_ && row_stride_ != dim_ * 2) || nrows_ == 0 || nrows_ > 0xffffffffull)
+        return make_error(FSGPU_ERR_INVALID_CONFIG, "the int8 filter serves f16 slabs only");
+    FSGPU_HIP(hipSetDevice(device_));
+    if (!i8_ready_) {
+        FSGPU_TRY(i8_slab_.reserve((size_t)nrows_ * dim_));
+        FSGPU_TRY(i8_max_.reserve(4));
+        FSGPU_HIP(launch_quantize_slab_i8(slab_dev_, (size_t)nrows_ * dim_, static_cast<unsigned int*>(i8_max_.ptr), i8_slab_.ptr, stream_));
+        i8_ready_ = true;
+    }
+    if (!i8_stats_ready_) {
+        FSGPU_TRY(i8_stats_.reserve(16));
+        FSGPU_HIP(launch_i8_slab_stats(slab_dev_, i8_slab_.ptr, (uint32_t)nrows_, dim_, static_cast<const unsigned int*>(i8_max_.ptr),
+                                       static_cast<unsigned int*>(i8_stats_.ptr), stream_));
+        i8_stats_ready_ = true;
+    }
+    float slab_max = 0.f;
+    FSGPU_HIP(hipMemcpyAsync(&slab_max, i8_max_.ptr, 4, hipMemcpyDeviceToHost, stream_));
+    if (nq) {
+        FSGPU_TRY(ws_queries_.reserve((size_t)nq * dim_ * 4));
+        FSGPU_TRY(mf_qh_.reserve((size_t)nq * dim_ * 2));
+        FSGPU_TRY(mf_delta_.reserve((size_t)nq * 4));
+        FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, queries, (size_t)nq * dim_ * 4, hipMemcpyHostToDevice, stream_));
+        FSGPU_HIP(launch_prepare_queries_i8_filter(static_cast<const float*>(ws_queries_.ptr), nq, nq, dim_, dim_,
+                                                   static_cast<const unsigned int*>(i8_max_.ptr), static_cast<const unsigned int*>(i8_stats_.ptr),
+                                                   mf_qh_.ptr, static_cast<float*>(mf_delta_.ptr), stream_));
+        if (out_delta) FSGPU_HIP(hipMemcpyAsync(out_delta, mf_delta_.ptr, (size_t)nq * 4, hipMemcpyDeviceToHost, stream_));
+        if (out_queries_i8) FSGPU_HIP(hipMemcpyAsync(out_queries_i8, mf_qh_.ptr, (size_t)nq * dim_, hipMemcpyDeviceToHost, stream_));
+    }
+    if (out_slab_i8) FSGPU_HIP(hipMemcpyAsync(out_slab_i8, i8_slab_.ptr, (size_t)nrows_ * dim_, hipMemcpyDeviceToHost, stream_));
+    FSGPU_HIP(hipStreamSynchronize(stream_));
+    if (out_slab_scale) *out_slab_scale = slab_max > 0.f ? 127.0f / slab_max : 0.f;
+    if (out_query_scale)
+        for (uint32_t i = 0; i < nq; ++i) {   // quantize_i8_query's scale, as the kernel computes it
+            float m = 0.f;
+            for (uint32_t d = 0; d < dim_; ++d) m = std::fmax(m, std::fabs(queries[(size_t)i * dim_ + d]));
+            out_query_scale[i] = m > 0.f ? 127.0f / m : 0.f;
+        }
+    return ok();
 }
 
 // int8 pass 1 on the matrix cores for a whole batch (exact integer scores), exact f16 rescore, top-k: the batched form of

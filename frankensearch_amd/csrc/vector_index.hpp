@@ -131,7 +131,12 @@ class VectorIndex {
     // filter of the exact batched search (fsgpu_index_set_batched_filter): 0 = automatic, 1 = f16 slab, 2 = int8 slab
     int32_t batched_filter = 0;
     uint64_t i8f_queries = 0, i8f_refiltered = 0;  // queries the int8 filter took / handed on to the f16 filter
-    bool int8_filter_active() const { return batched_filter != 1 && !i8f_disabled_; }
+    bool int8_filter_active() const { return batched_filter == 2 || (batched_filter == 0 && !i8f_disabled_); }
+    // The certificate of the int8 filter, for inspection: per query the bound delta on |int8 score - exact score x slab scale
+    // x query scale| (< 0: not certifiable) and the query scale 127 / max|q|; the slab scale 127 / max|x|; the quantised queries
+    // (nq x dim int8) and, when out_slab_i8 is given, the int8 slab (nrows x dim).  Builds the int8 slab if need be.
+    SearchError int8_filter_bound(const float* queries, uint32_t nq, uint32_t query_len, float* out_delta, float* out_query_scale,
+                                  float* out_slab_scale, int8_t* out_queries_i8, int8_t* out_slab_i8);
     VectorIndex* mrl_view(uint32_t dims);  // strided prefix view of this slab (created on first use)
     // Concurrent callers (the reference's scan is `&self`, lock-free, any number of callers: search.rs:192): replicas of this
     // index over the SAME slab and live bitmap, each with its own stream, workspaces and mutex, so that row-level searches from

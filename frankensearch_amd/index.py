@@ -56,9 +56,15 @@ class _MrlStats(C.Structure):
 
 
 class VectorIndex:
+    # filter of search_batched applied to every new handle (0 = the library's automatic choice); the test-suite pins it to
+    # run the same cases under the int8 and the f16 filter
+    default_batched_filter = 0
+
     def __init__(self, handle: int, keepalive=None):
         self._h = C.c_void_p(handle)
         self._keepalive = keepalive
+        if type(self).default_batched_filter:
+            self.set_batched_filter(type(self).default_batched_filter)
 
     # ---- constructors -------------------------------------------------------------------------
     @classmethod
@@ -115,6 +121,20 @@ class VectorIndex:
     def set_batched_filter(self, filter: int) -> None:
         """0 = automatic, 1 = f16 slab, 2 = int8 slab as the filter of search_batched (results identical either way)."""
         check(_lib.lib().fsgpu_index_set_batched_filter(self._h, filter))
+
+    def int8_filter_bound(self, queries: np.ndarray, want_slab: bool = False):
+        """(delta[nq], query_scale[nq], slab_scale, queries_i8[nq, dim], slab_i8 or None): the int8 filter's certificate."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        q = q.reshape(-1, q.shape[-1])
+        nq, dim = q.shape
+        delta = np.empty(nq, np.float32)
+        qscale = np.empty(nq, np.float32)
+        sscale = C.c_float(0)
+        qi8 = np.empty((nq, dim), np.int8)
+        slab = np.empty((self.record_count(), dim), np.int8) if want_slab else None
+        check(_lib.lib().fsgpu_index_int8_filter_bound(self._h, _ptr(q), nq, dim, _ptr(delta), _ptr(qscale), C.byref(sscale), _ptr(qi8),
+                                                       _ptr(slab)))
+        return delta, qscale, sscale.value, qi8, slab
 
     def batched_filter_stats(self) -> dict:
         q, r, a = C.c_uint64(0), C.c_uint64(0), C.c_int32(0)

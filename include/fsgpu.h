@@ -167,6 +167,13 @@ fsgpu_status fsgpu_index_set_batched_filter(fsgpu_index *idx, int32_t filter);
  * uses it (any pointer may be null). */
 fsgpu_status fsgpu_index_batched_filter_stats(fsgpu_index *idx, uint64_t *int8_queries, uint64_t *refiltered_f16,
                                               int32_t *int8_active);
+/* The int8 filter's certificate, for inspection (tests/test_gpu_int8_filter.py checks it against float64 arithmetic): per
+ * query the bound out_delta[q] >= |int8 score - exact score * slab scale * query scale| over every row (< 0: the query
+ * cannot be certified and goes to the f16 filter), the scales 127 / max|q| and 127 / max|x|, the quantised queries
+ * [nq, dim] and the int8 slab [rows, dim] (any output may be null).  Builds the int8 copy if it does not exist yet. */
+fsgpu_status fsgpu_index_int8_filter_bound(fsgpu_index *idx, const float *queries, uint32_t nq, uint32_t query_len,
+                                           float *out_delta, float *out_query_scale, float *out_slab_scale,
+                                           int8_t *out_queries_i8, int8_t *out_slab_i8);
 fsgpu_status fsgpu_search_topk_batched(fsgpu_index *idx, const float *queries, uint32_t nq, uint32_t query_len,
                                        uint32_t k, const uint64_t *allow_bitmap, uint32_t *out_rows, float *out_scores,
                                        uint32_t *out_counts, uint32_t *out_fallbacks);

@@ -1,0 +1,209 @@
+"""The int8 filter of the exact batched search (mfma_scan.hip: prepare_queries_i8_filter_kernel; int8_kernels.hip:
+i8_slab_stats_kernel).
+
+The batched search scores the slab approximately on the matrix cores and re-scores, in the reference's operation order
+(crates/frankensearch-index/src/simd.rs:398-446), every row that could reach the top k under a PROVEN bound on the
+approximation error.  With the int8 copy of the slab as the filter that bound comes from measured statistics of the copy and
+of each quantised query.  These tests check (1) the bound itself, against float64 arithmetic and against the exact kernels'
+scores, on benign and hostile data; (2) that the hits are the exact search's bit for bit whichever filter ran, including
+the hand-over of uncertified queries to the f16 filter and the cases no int8 bound exists for; (3) the automatic choice.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import frankensearch_amd as fa_mod
+    from frankensearch_amd.build import build
+
+    build()
+    assert fa_mod._lib.lib().fsgpu_device_count() >= 1, "no GPU visible"
+    return fa_mod
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def unit_rows(rng, n, dim):
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+
+def corpora(rng, n, dim):
+    base = unit_rows(rng, n, dim)
+    yield "gaussian unit rows", base
+    out = base.copy()
+    out[:, rng.integers(0, dim, 3)] *= 12.0          # outlier dimensions stretch the corpus-wide scale
+    yield "outlier dimensions", out / np.linalg.norm(out, axis=1, keepdims=True)
+    yield "tiny magnitudes", base * 3e-3
+    yield "large magnitudes", base * 180.0
+    cent = unit_rows(rng, 16, dim)
+    clustered = cent[rng.integers(0, 16, n)] + 0.3 * rng.standard_normal((n, dim)).astype(np.float32) / np.sqrt(dim)
+    yield "clusters", clustered
+    sparse = base * (rng.random((n, dim)) < 0.1)       # mostly zeros: quantisation error far below the worst case
+    yield "sparse rows", sparse.astype(np.float32)
+    one = np.zeros((n, dim), np.float32)
+    one[np.arange(n), rng.integers(0, dim, n)] = rng.choice([-1.0, 1.0], n)
+    one[::3] = base[::3]
+    yield "one-hot and dense rows mixed", one
+
+
+def hostile_queries(rng, rows, dim):
+    nq = 24
+    q = rows[rng.integers(0, rows.shape[0], nq)] + (0.2 * rng.standard_normal((nq, dim))).astype(np.float32)
+    q[1] *= 37.5
+    q[2] *= 1e-6
+    q[3] = 0.0
+    q[3, 7] = 1.0                                     # one-hot: |p|_1 far below sqrt(dim) |p|_2
+    q[4] = np.sign(q[4]) * 0.25                       # every element at the scale's edge: |eta| ~ 0
+    q[5] = np.sign(q[5]) * ((rng.integers(0, 126, dim) + 0.5) / 127.0).astype(np.float32)   # ... half a step off a level:
+    q[5, 0] = 1.0                                                                              # worst-case eta
+    q[6, :] = 0.003
+    q[6, 0] = 1.0                                     # one dominant element: the rest quantises to zero
+    q[7] = rng.standard_normal(dim).astype(np.float32) * 900.0
+    return q
+
+
+@pytest.mark.parametrize("dim", [128, 384])
+def test_bound_covers_every_row_against_float64_and_the_exact_kernels(fa, oracle, dim):
+    rng = np.random.default_rng(1000 + dim)
+    n = 12_000
+    worst = 0.0
+    for name, rows in corpora(rng, n, dim):
+        slab = rows.astype(np.float16).view(np.uint16)
+        idx = fa.VectorIndex.from_slab(slab)
+        q = hostile_queries(rng, rows, dim)
+        delta, qscale, sscale, qi8, slab_i8 = idx.int8_filter_bound(q, want_slab=True)
+        # the filter uses the reference's quantisers (simd.rs:1865-1886, search.rs:1616-1626): same bytes as the oracle's
+        assert np.array_equal(slab_i8, oracle.quantize_slab_i8(slab)), name
+        for i in range(q.shape[0]):
+            assert np.array_equal(qi8[i], oracle.quantize_query_i8(q[i])), (name, i)
+        assert np.all(delta > 0), (name, delta)       # all of these are certifiable
+        idot = slab_i8.astype(np.int64) @ qi8.astype(np.int64).T                       # [n, nq], exact
+        x64 = slab.view(np.float16).astype(np.float64)
+        s64 = x64 @ q.astype(np.float64).T                                             # real-number scores
+        unit = np.float64(sscale) * qscale.astype(np.float64)                          # integer-score units per score unit
+        err64 = np.abs(idot - s64 * unit[None, :])
+        assert np.all(err64 <= delta[None, :].astype(np.float64)), (name, float((err64 / delta[None, :]).max()))
+        # ... and the scores the exact kernels emit (the reference's f32 operation order) sit inside the same bound
+        for i in (0, 1, 2, 5, 7):
+            exact = idx.gather_dot(q[i], np.arange(n, dtype=np.uint32)).astype(np.float64)
+            assert np.all(np.abs(idot[:, i] - exact * unit[i]) <= float(delta[i])), (name, i)
+        worst = max(worst, float((err64 / delta[None, :]).max()))
+        idx.close()
+    # the bound is not vacuous: somewhere the measured error comes within a factor of a few of it
+    assert worst > 0.05, worst
+
+
+def test_uncertifiable_inputs_are_marked_and_still_answered_exactly(fa, oracle):
+    rng = np.random.default_rng(7)
+    n, dim, k = 70_000, 384, 10
+    rows = unit_rows(rng, n, dim)
+    q = rows[rng.integers(0, n, 40)] + (0.2 * rng.standard_normal((40, dim))).astype(np.float32)
+    q[0] = 0.0                       # zero query
+    q[1, 3] = np.nan
+    q[2, 5] = np.inf
+    q[3, 9] = 70000.0                # finite, but an f32 product with an f16 element could overflow past the bound's reach
+    q[4] *= 1e-38                    # scales overflow: no finite bound
+    slab = rows.astype(np.float16).view(np.uint16)
+    idx = fa.VectorIndex.from_slab(slab)
+    delta = idx.int8_filter_bound(q)[0]
+    assert np.all(delta[:5] < 0) and np.all(delta[5:] > 0), delta[:8]
+    idx.set_batched_filter(2)
+    br, bs, bc, fb = idx.search_batched(q, k)
+    er, es, ec = idx.search_batch(q, k)
+    assert np.array_equal(bc, ec) and np.array_equal(br, er) and np.array_equal(bits(bs), bits(es))
+    st = idx.batched_filter_stats()
+    assert st["int8_queries"] == 40 and 5 <= st["refiltered_f16"] <= 8, st
+    for qi in (0, 3, 4, 17):
+        orow, osc = oracle.search_top_k(slab, q[qi], k)
+        assert np.array_equal(br[qi], orow) and np.array_equal(bits(bs[qi]), bits(osc)), qi
+    idx.close()
+    # a slab with a NaN, an infinity, or nothing but zeros has no int8 bound at all: every query is handed on
+    for poison in (0x7e00, 0x7c00, 0xfc00, None):
+        bad = slab.copy()
+        if poison is None:
+            bad[:] = 0
+        else:
+            bad[12345, 17] = poison
+        idx = fa.VectorIndex.from_slab(bad)
+        assert np.all(idx.int8_filter_bound(q)[0] < 0)
+        idx.set_batched_filter(2)
+        br, bs, bc, fb = idx.search_batched(q, k)
+        er, es, ec = idx.search_batch(q, k)
+        assert np.array_equal(bc, ec) and np.array_equal(br, er) and np.array_equal(bits(bs), bits(es)), poison
+        assert idx.batched_filter_stats()["refiltered_f16"] == 40
+        idx.close()
+
+
+def test_both_filters_emit_the_exact_search_bits_on_ties_filters_and_tombstones(fa, oracle):
+    rng = np.random.default_rng(11)
+    n, dim = 220_003, 384
+    cent = unit_rows(rng, 40, dim)
+    # (the reference bench's recipe: unit centroids + noise of 0.3 per ELEMENT, so neighbours in a cluster spread over ~0.05 in
+    # cosine — tighter clusters than the int8 margin are the subject of the last test)
+    rows = cent[np.sort(rng.integers(0, 40, n))] + 0.3 * rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    rows[5000:5060] = rows[4999]          # a run of identical rows: integer AND exact scores tie, lower row wins
+    rows[n - 3:] = rows[4999]
+    slab = rows.astype(np.float16).view(np.uint16)
+    live = rng.random(n) > 0.1
+    allow = rng.random(n) > 0.5
+    nq = 530                              # 4 groups on the 512-query int8 shape + a ragged tail
+    q = cent[rng.integers(0, 40, nq)] + 0.3 * rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+    q[2] = rows[4999]
+    idx = fa.VectorIndex.from_slab(slab, live=live)
+    for k, mask in ((10, None), (64, None), (1, allow), (10, allow)):
+        exact = [idx.search_batch(q[s:s + 64], k, allow=mask) for s in range(0, nq, 64)]
+        er = np.concatenate([e[0] for e in exact])
+        es = np.concatenate([e[1] for e in exact])
+        ec = np.concatenate([e[2] for e in exact])
+        for filt in (2, 1, 0):
+            idx.set_batched_filter(filt)
+            br, bs, bc, fb = idx.search_batched(q, k, allow=mask)
+            assert np.array_equal(bc, ec) and np.array_equal(br, er) and np.array_equal(bits(bs), bits(es)), (k, filt)
+            assert fb < nq // 8, (k, filt, fb)
+    eff = live & allow
+    for qi in (2, 300, 529):
+        orow, osc = oracle.search_top_k(slab, q[qi], 10, live=eff)
+        assert np.array_equal(br[qi], orow) and np.array_equal(bits(bs[qi]), bits(osc)), qi
+    st = idx.batched_filter_stats()
+    assert st["int8_queries"] >= 8 * nq and st["refiltered_f16"] * 8 < st["int8_queries"], st
+    idx.close()
+
+
+def test_automatic_choice_leaves_the_int8_filter_when_its_margin_does_not_separate(fa, oracle):
+    """6,000 rows whose scores against queries near their centre spread by ~2e-3: twenty times the f16 filter's margin, a
+    fraction of the int8 one's.  The int8 filter cannot cut that cluster down to its candidate pool, hands those queries to
+    the f16 filter (which can), and after two such batches the index stays with the f16 filter."""
+    rng = np.random.default_rng(5)
+    n, dim, k = 100_000, 384, 10
+    rows = unit_rows(rng, n, dim)
+    base = unit_rows(rng, 1, dim)[0]
+    members = rng.choice(n, 6000, replace=False)
+    rows[members] = base + 0.2 * rng.standard_normal((6000, dim)).astype(np.float32) / np.sqrt(dim)
+    rows[members] /= np.linalg.norm(rows[members], axis=1, keepdims=True)
+    slab = rows.astype(np.float16).view(np.uint16)
+    idx = fa.VectorIndex.from_slab(slab)
+    nq = 64
+    q = base + 0.2 * rng.standard_normal((nq, dim)).astype(np.float32) / np.sqrt(dim)
+    er, es, ec = idx.search_batch(q, k)
+    assert idx.batched_filter_stats()["int8_active"]
+    for round_ in range(3):
+        br, bs, bc, fb = idx.search_batched(q, k)
+        assert np.array_equal(bc, ec) and np.array_equal(br, er) and np.array_equal(bits(bs), bits(es)), round_
+        assert fb <= 2, fb                           # the f16 filter certifies them: no exact-kernel passes
+    st = idx.batched_filter_stats()
+    assert st["int8_queries"] == 2 * nq and st["refiltered_f16"] > nq and not st["int8_active"], st
+    # pinned to int8 it keeps trying (and keeps handing on): same bits
+    idx.set_batched_filter(2)
+    br, bs, bc, fb = idx.search_batched(q, k)
+    assert np.array_equal(br, er) and np.array_equal(bits(bs), bits(es))
+    assert idx.batched_filter_stats()["int8_queries"] == 3 * nq
+    orow, osc = oracle.search_top_k(slab, q[0], k)
+    assert np.array_equal(br[0], orow) and np.array_equal(bits(bs[0]), bits(osc))
+    idx.close()

@@ -22,6 +22,15 @@ def fa():
     return fa_mod
 
 
+@pytest.fixture(params=["int8 filter", "f16 filter"])
+def batched_filter(request, fa):
+    """The batched search under each of its two filters (include/fsgpu.h, FSGPU_FILTER_*): every index a test creates is pinned
+    to it; the results must be the exact search's either way."""
+    fa.VectorIndex.default_batched_filter = 2 if request.param == "int8 filter" else 1
+    yield request.param
+    fa.VectorIndex.default_batched_filter = 0
+
+
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
@@ -453,7 +462,7 @@ def test_int8_two_pass_matches_oracle(fa, oracle, tmp_path):
     assert [h.index for h in g.search_top_k_int8_two_pass(q, 10, 3)] == [h.index for h in g.search_top_k(q, 10)]
 
 
-def test_batched_mfma_search_is_bit_exact(fa, oracle):
+def test_batched_mfma_search_is_bit_exact(fa, oracle, batched_filter):
     # fsgpu_search_topk_batched must equal the exact path (hence the oracle) bit for bit
     rng = np.random.default_rng(83)
     for n, dim in ((200_000, 384), (150_001, 256), (60_000, 128)):
@@ -489,7 +498,7 @@ def test_batched_mfma_search_is_bit_exact(fa, oracle):
 
 
 @pytest.mark.gpu
-def test_batched_mfma_wide_groups_topical_rows_and_filters(fa, oracle):
+def test_batched_mfma_wide_groups_topical_rows_and_filters(fa, oracle, batched_filter):
     # 200 queries = one 128-query pass + one 64-query pass + a ragged tail; rows arrive in topical runs (sorted by
     # cluster), so a threshold sampled from the head of the slab would be useless — the strided samples must cope;
     # duplicates force score ties (lower row wins); an allow mask and k up to 64 ride along.
@@ -524,7 +533,7 @@ def test_batched_mfma_wide_groups_topical_rows_and_filters(fa, oracle):
         assert np.array_equal(br[qi], orow) and np.array_equal(bits(bs[qi]), bits(osc))
 
 
-def test_config2_batched_1m_rows_against_the_oracle(fa, oracle):
+def test_config2_batched_1m_rows_against_the_oracle(fa, oracle, batched_filter):
     """BASELINE config 2: 1M x 384 f16 (the reference bench corpus, generated on the GPU), top-10, batches of 8 / 64 / 256
     queries through the batched matrix-core path (256 takes the register-resident-query main pass) — every hit of a spread of
     queries against the oracle, the rest against the exact kernels."""
@@ -580,7 +589,7 @@ def test_mrl_batched_equals_per_query_and_oracle(fa, oracle):
         assert [h.index for h in hits] == br[qi, :bc[qi]].tolist()
 
 
-def test_batched_certificate_edges_overflow_subnormals_and_near_duplicates(fa, oracle):
+def test_batched_certificate_edges_overflow_subnormals_and_near_duplicates(fa, oracle, batched_filter):
     """The batched path is exact only through its certificate (|a - s| <= delta, mfma_scan.hip header); the cases where the
     certificate cannot hold or cannot separate must end on the exact kernels and still return the oracle's bits:
       * finite queries with one or a few elements above 65504 (their f16 image is +-inf) — marked uncertifiable up front;
@@ -803,7 +812,7 @@ def test_fsvi_writer_bytes_equal_reference_layout_and_config1_roundtrip(fa, orac
 
 
 @pytest.mark.gpu
-def test_edge_cases_of_the_batched_and_two_pass_entry_points(fa, oracle):
+def test_edge_cases_of_the_batched_and_two_pass_entry_points(fa, oracle, batched_filter):
     # empty batches, k = 0, k > N, fully tombstoned and one-row indexes must behave like the per-query exact search
     rng = np.random.default_rng(127)
     dim = 128
