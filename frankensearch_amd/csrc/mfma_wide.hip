@@ -127,7 +127,14 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     // from landing in the same blocks; args.reverse walks the slab from its end.  The whole slab is visited (the rows of
     // the stage-1 sample included: the sample only tightened tau, its pool is not merged for this kernel), so the
     // sequence needs no skip test and is advanced with a handful of scalar adds.
-    const uint32_t ntiles = (args.nrows + TR - 1) / TR;
+    // A sample stage (args.group_count != 0) visits 64-row groups group_stride apart instead: the same tile sequence over
+    // the sample's tiles, each mapped to its place in the slab.
+    constexpr uint32_t TPG = 64 / TR;   // tiles per 64-row sample group
+    const bool sampled = args.group_count != 0;
+    const uint32_t ntiles = sampled ? args.group_count * TPG : (args.nrows + TR - 1) / TR;
+    auto tile_row0 = [&](uint32_t t) -> uint32_t {
+        return sampled ? (t / TPG) * args.group_stride * 64u + (t % TPG) * TR : t * TR;
+    };
     const uint32_t grid = gridDim.x;
     const uint32_t rounds = (ntiles + grid - 1) / grid;
     const uint32_t last_row = args.nrows - 1;
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     const int dma_p = lane >> 2, dma_c = lane & 3;
     const int dma_chunk = dma_c ^ ((4 - (dma_p >> 2)) & 3);
     auto issue_tile = [&](uint32_t t, uint32_t slot) {
-        const uint32_t row0 = t * TR;
+        const uint32_t row0 = tile_row0(t);
 #pragma unroll
         for (int x = 0; x < PW; ++x) {
             const int j = wave * PW + x;
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             // C layout: column (query) = lane & 15, row = (lane >> 4) * 4 + reg
-            const uint32_t row0 = t * TR + (sp + h) * 16 + fk * 4;
+            const uint32_t row0 = tile_row0(t) + (sp + h) * 16 + fk * 4;
 #pragma unroll
             for (int nt = 0; nt < QT; ++nt) {
                 const float th = tau[nt];

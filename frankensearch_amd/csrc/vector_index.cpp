@@ -49,7 +49,7 @@ struct Knobs {
     int filter = 0;     // FSGPU_FILTER: "f16" (1) / "i8" (2) pin the filter of the exact batched search; unset = automatic
     int wide_max = 0;   // FSGPU_WIDE_MAX: cap on the query tiles per wave of the wide main pass (default: what the registers hold)
     int i8f_growth = 0; // FSGPU_I8F_GROWTH: sample growth factor of the int8 filter (default 4)
-    bool no_skip_b = false, use_160 = false, debug_batched = false, no_reverse = false;
+    bool no_skip_b = false, use_160 = false, debug_batched = false, no_reverse = false, no_wide_b = false;
     Knobs() {
         auto num = [](const char* name) {
             const char* e = std::getenv(name);
@@ -67,6 +67,7 @@ struct Knobs {
         i8f_growth = num("FSGPU_I8F_GROWTH");
         wide_max = num("FSGPU_WIDE_MAX");
         no_skip_b = std::getenv("FSGPU_NO_SKIP_B") != nullptr;
+        no_wide_b = std::getenv("FSGPU_NO_WIDE_B") != nullptr;
         no_reverse = std::getenv("FSGPU_NO_REVERSE") != nullptr;
         use_160 = std::getenv("FSGPU_USE_160") != nullptr;
         debug_batched = std::getenv("FSGPU_DEBUG_BATCHED") != nullptr;
@@ -1386,15 +1387,35 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         a.group_count = groups_b;
         const int grid_b = grid_for(RB, tile_rows);
         a.slots = slots_for(grid_b);
+        // (a wide round samples on the register-resident-query kernel too: one launch per main-pass group, the same lists)
+        const bool wide_b = wide_qt && !skip_b && !knobs().no_wide_b;
+        const int wide_grid_b = std::min(wide_grid, (int)std::max<uint32_t>(1, RB / 64 / 4));   // at least 4 sample groups per block
+        if (wide_b) a.slots = kWideSlots;
         if (!skip_b) {
             FSGPU_HIP(hipMemsetAsync(spill_count, 0, (size_t)QP * kMfmaSpillCountStride * 4, stream));
-            FSGPU_HIP(launch_scan_mfma(a, shape, grid_b, stream, nullptr));
+            if (wide_b) {
+                const uint32_t GM = G * wide_mult;
+                for (uint32_t j = 0; j < ngroups / wide_mult; ++j) {
+                    MfmaScanArgs c = a;
+                    c.groups = 1;
+                    c.queries = static_cast<const unsigned char*>(mf_qh_.ptr) + (size_t)j * GM * dim_ * (i8 ? 1 : 2);
+                    c.tau = tau + (size_t)j * GM;
+                    c.cand = cand + (size_t)j * GM * wide_grid_b * a.slots;
+                    c.spill = spill + (size_t)j * GM * SPILL;
+                    c.spill_count = spill_count + (size_t)j * GM * kMfmaSpillCountStride;
+                    c.overflow = overflow + (size_t)j * GM;
+                    FSGPU_HIP(launch_scan_wide(c, wide_qt, wide_grid_b, stream, nullptr));
+                }
+            } else {
+                FSGPU_HIP(launch_scan_mfma(a, shape, grid_b, stream, nullptr));
+            }
         }
+        const int lists_b = wide_b ? wide_grid_b : grid_b;
         SelectArgs sb{};
         sb.lists = cand;
-        sb.q_stride = (uint64_t)grid_b * a.slots;
+        sb.q_stride = (uint64_t)lists_b * a.slots;
         sb.l_stride = a.slots;
-        sb.nlists = (uint32_t)grid_b;
+        sb.nlists = (uint32_t)lists_b;
         sb.list_len = a.slots;
         sb.k = ksel;
         sb.take_topk = (i8 && !i8f) ? 1 : 0;
