@@ -695,10 +695,16 @@ def main() -> None:
         pmc_path = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_summary.json")
         if world == 1 and args.rows == 10_000_000 and args.dim == 384 and os.path.exists(pmc_path):
             want = fa._lib.lib().fsgpu_last_main_pass_kernel().decode()
+            main_only = False
             if want.startswith("scan_wide_kernel"):
-                want = want.rsplit(",", 3)[0]   # a step mixes the 384- and 256-query instantiations: same rows, same bytes
+                # row bytes and element width identify the pass; a step may mix query-tile counts (same rows, same bytes), and
+                # the sample stage is its own instantiation (last template argument 3), not the main pass (0)
+                want = ",".join(want.split(",")[:2]) + ","
+                main_only = True
             want = want if args.batched else ("scan_mq_topk_kernel<384" if B >= 4 else "scan_topk_kernel<384, 1")
             for e in json.load(open(pmc_path)):
+                if main_only and ", 0>(" not in e.get("kernel", ""):
+                    continue
                 if e.get("counter") == "FETCH_SIZE" and want and want in e.get("kernel", "") and "hbm_read_bytes_corrected" in e:
                     line["roofline"]["traffic"] = e["hbm_read_bytes_corrected"]
                     line["roofline"]["traffic_source"] = (f"profiles/{PROFILE_ROUND}/pmc_summary.json: rocprofv3 --pmc FETCH_SIZE of "

@@ -95,6 +95,7 @@ SIGNATURES = {
     "fsgpu_index_set_profiling": (_i32, [_vp, _i32]),
     "fsgpu_index_scan_time": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(_u64), _i32]),
     "fsgpu_search_topk_int8_two_pass_batched": (_i32, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, C.POINTER(_u32)]),
+    "fsgpu_search_topk_4bit_two_pass_batched": (_i32, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, C.POINTER(_u32)]),
     "fsgpu_search_topk_4bit_two_pass": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),
     "fsgpu_fsvi_write": (_i32, [C.c_char_p, C.c_char_p, C.c_char_p, _u32, _u64, _vp, _vp, _vp, C.c_uint8, _i32]),
     "fsgpu_fsvi_write_quant": (_i32, [C.c_char_p, C.c_char_p, C.c_char_p, _u32, _u64, _vp, _vp, _vp, C.c_uint8, _i32,

@@ -623,6 +623,19 @@ fsgpu_status fsgpu_search_topk_int8_two_pass_batched(fsgpu_index* idx, const flo
     });
 }
 
+fsgpu_status fsgpu_search_topk_4bit_two_pass_batched(fsgpu_index* idx, const float* queries, uint32_t nq, uint32_t query_len,
+                                                     uint32_t k, uint32_t candidate_multiplier, uint32_t* out_rows,
+                                                     float* out_scores, uint32_t* out_counts, uint32_t* out_fallbacks) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    if (nq && (!queries || !out_counts || (k && (!out_rows || !out_scores))))
+        return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.search_top_k_int8_batched(queries, nq, query_len, k, candidate_multiplier, out_rows,
+                                                          out_scores, out_counts, out_fallbacks, 4));
+    });
+}
+
 // VectorIndex::search_top_k_4bit_two_pass (search.rs:876-946)
 fsgpu_status fsgpu_search_topk_4bit_two_pass(fsgpu_index* idx, const float* query, uint32_t query_len, uint32_t k,
                                              uint32_t candidate_multiplier, uint32_t* out_rows, float* out_scores,

@@ -88,6 +88,30 @@ __global__ __launch_bounds__(256) void quantize_slab_i8_kernel(const unsigned sh
             out[i] = zero ? (signed char)0 : quant_i8((float)__builtin_bit_cast(_Float16, slab[i]), scale);
 }
 
+// The 4-bit levels of pack_f16_le_bytes_to_4bit (simd.rs:2153-2215: scale 7/max_abs, 0 when max_abs <= 1e-9; round half away
+// from zero, clamp +-7, NaN -> 0) kept one per BYTE: the batched 4-bit pass 1 runs them through the int8 matrix-core kernels
+// (the nibble dot is the same integer either way, and that pass is bound by matrix instructions, not by bytes).
+__global__ __launch_bounds__(256) void quantize_slab_4bit_levels_kernel(const unsigned short* __restrict__ slab, size_t n_values,
+                                                                        const unsigned int* __restrict__ max_bits,
+                                                                        signed char* __restrict__ out) {
+    const float max_abs = __uint_as_float(*max_bits);
+    const float scale = max_abs > 1e-9f ? 7.0f / max_abs : 0.f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t nvec = n_values / 8;
+    const u32x4* v = reinterpret_cast<const u32x4*>(slab);
+    typedef signed char i8x8 __attribute__((ext_vector_type(8)));
+    auto level = [&](float x) { return (signed char)((int)(quant_nibble(x, scale) << 28) >> 28); };   // sign-extended nibble
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        const half8 h = __builtin_bit_cast(half8, v[i]);
+        i8x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = level((float)h[j]);
+        reinterpret_cast<i8x8*>(out)[i] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (size_t i = nvec * 8; i < n_values; ++i) out[i] = level((float)__builtin_bit_cast(_Float16, slab[i]));
+}
+
 // What the int8 slab misses of the f16 slab, measured once per slab so that integer scores can serve as a PROVABLE
 // filter for the exact search (mfma_scan.hip, "int8 filter").  With c = fl(127 / max_abs) — the f32 scale the quantiser
 // used — every element is x = (r + eps) / c; this kernel bounds, over all rows, the quantisation error and the size of
@@ -346,6 +370,18 @@ hipError_t launch_quantize_slab_i8(const void* slab_f16, size_t n_values, unsign
     hipLaunchKernelGGL(quantize_slab_i8_kernel, dim3(grid), dim3(256), 0, stream,
                        static_cast<const unsigned short*>(slab_f16), n_values, max_bits_dev,
                        static_cast<signed char*>(out_i8));
+    return hipGetLastError();
+}
+
+hipError_t launch_quantize_slab_4bit_levels(const void* slab_f16, size_t n_values, unsigned int* max_bits_dev, void* out_i8,
+                                            hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(max_bits_dev, 0, 4, stream);
+    if (e != hipSuccess) return e;
+    const int grid = 2048;
+    hipLaunchKernelGGL(slab_maxabs_kernel, dim3(grid), dim3(256), 0, stream, static_cast<const unsigned short*>(slab_f16),
+                       n_values, max_bits_dev);
+    hipLaunchKernelGGL(quantize_slab_4bit_levels_kernel, dim3(grid), dim3(256), 0, stream,
+                       static_cast<const unsigned short*>(slab_f16), n_values, max_bits_dev, static_cast<signed char*>(out_i8));
     return hipGetLastError();
 }
 

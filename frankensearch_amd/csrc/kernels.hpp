@@ -143,8 +143,9 @@ struct SelectArgs {
 constexpr uint32_t kSelectPool = 1024;
 constexpr uint32_t kSelectMaxK = 128;   // largest rank a selection can anchor on (k, or k * multiplier in int8 mode)
 hipError_t launch_select(const SelectArgs& args, int nq, hipStream_t stream);
+// bits = 8: quantize_i8_query (scale 127/max when max > 0); bits = 4: pack_4bit_query's levels (scale 7/max when max > 1e-9), one per byte
 hipError_t launch_prepare_queries_i8(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, void* qi8, float* delta,
-                                     hipStream_t stream);
+                                     hipStream_t stream, int bits = 8);
 // the same quantiser for the int8 FILTER of the exact search: delta = a proven bound on |int8 score - exact score / (row
 // scale x query scale)| from the slab statistics of launch_i8_slab_stats (see mfma_scan.hip)
 hipError_t launch_prepare_queries_i8_filter(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t q_stride,
@@ -176,6 +177,9 @@ hipError_t launch_prepare_queries(const float* q, uint32_t nq, uint32_t nq_pad, 
 // int8_kernels.hip
 hipError_t launch_quantize_slab_i8(const void* slab_f16, size_t n_values, unsigned int* max_bits_dev, void* out_i8,
                                    hipStream_t stream);
+// 4-bit levels (-7..7, the reference's nibble quantiser) one per byte: the batched 4-bit pass 1 reuses the int8 matrix-core kernels
+hipError_t launch_quantize_slab_4bit_levels(const void* slab_f16, size_t n_values, unsigned int* max_bits_dev, void* out_i8,
+                                            hipStream_t stream);
 // bounds on what the int8 slab misses of the f16 slab (int8 filter of the exact batched search): stats_dev[0..4) =
 // { f32 bits of max_row sum eps^2, max_row sum |r|, max_row sum r^2, non-finite flag }
 hipError_t launch_i8_slab_stats(const void* slab_f16, const void* slab_i8, uint32_t nrows, uint32_t dim,

@@ -638,8 +638,10 @@ __global__ __launch_bounds__(256) void prepare_queries_kernel(const float* __res
 // quantize_i8_query (search.rs:1616-1626) for a group of queries: per-query max-abs scale 127/max (f32::max ignores
 // NaN), round half away from zero, clamp, NaN -> 0; an all-zero (or empty-max) query quantises to zeros.  Padding rows
 // are zero and marked "skip" (delta < 0); real queries get delta = 0: the int8 scores are exact.
+// (lim = 7, floor = 1e-9: the levels of pack_4bit_query, search.rs:1640-1653, one per byte — the batched 4-bit pass 1)
 __global__ __launch_bounds__(256) void prepare_queries_i8_kernel(const float* __restrict__ q, uint32_t nq, uint32_t dim,
-                                                                 signed char* __restrict__ qi8, float* __restrict__ delta) {
+                                                                 signed char* __restrict__ qi8, float* __restrict__ delta,
+                                                                 float lim, float floor) {
     __shared__ float red[4];
     const uint32_t b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -651,13 +653,13 @@ __global__ __launch_bounds__(256) void prepare_queries_i8_kernel(const float* __
     if (lane == 0) red[wave] = m;
     __syncthreads();
     const float max_abs = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    const bool zero = b >= nq || !(max_abs > 0.0f);
-    const float scale = zero ? 0.f : 127.0f / max_abs;
+    const bool zero = b >= nq || !(max_abs > floor);
+    const float scale = zero ? 0.f : lim / max_abs;
     for (uint32_t i = tid; i < dim; i += 256) {
         signed char o = 0;
         if (!zero) {
             float v = roundf(q[(size_t)b * dim + i] * scale);
-            if (v == v) o = (signed char)(int)fminf(fmaxf(v, -127.0f), 127.0f);
+            if (v == v) o = (signed char)(int)fminf(fmaxf(v, -lim), lim);
         }
         qi8[(size_t)b * dim + i] = o;
     }
@@ -850,9 +852,9 @@ hipError_t launch_scan_mfma(const MfmaScanArgs& args, int shape, int grid, hipSt
 }
 
 hipError_t launch_prepare_queries_i8(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, void* qi8, float* delta,
-                                     hipStream_t stream) {
+                                     hipStream_t stream, int bits) {
     hipLaunchKernelGGL(prepare_queries_i8_kernel, dim3(nq_pad), dim3(256), 0, stream, q, nq, dim,
-                       static_cast<signed char*>(qi8), delta);
+                       static_cast<signed char*>(qi8), delta, bits == 4 ? 7.0f : 127.0f, bits == 4 ? 1e-9f : 0.0f);
     return hipGetLastError();
 }
 

@@ -71,7 +71,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 //     reads(chunk 1) | MFMA(chunk 0) | s_waitcnt vmcnt + s_barrier: tile n+1 has landed for everyone and tile n-1's slot is
 //     free -> DMA(tile n+NSLOT-1) | reads(chunk 2) | MFMA(chunk 1) | ... | reads(chunk 0 of tile n+1) | MFMA(last chunk)
 // so neither the LDS latency nor the barrier sits between two MFMA groups of a wave with nothing else to issue.
-template <int ROWB, int EB, int QT, int NSLOT, int DBG = 0>   // DBG (timing experiments only): 1 = no MFMAs, 2 = no DMA
+// DBG: 0 = the main pass; 3 = a sample stage (its own instantiation, so that profiles tell the two apart and the main pass
+// carries no trace of the sample mapping); 1 = no MFMAs, 2 = no DMA (timing experiments only)
+template <int ROWB, int EB, int QT, int NSLOT, int DBG = 0>
 __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     using acc_t = std::conditional_t<EB == 2, f32x4, i32x4>;
     constexpr int WPB = 8, NT = WPB * 64;
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     // A sample stage (args.group_count != 0) visits 64-row groups group_stride apart instead: the same tile sequence over
     // the sample's tiles, each mapped to its place in the slab.
     constexpr uint32_t TPG = 64 / TR;   // tiles per 64-row sample group
-    const bool sampled = args.group_count != 0;
+    constexpr bool sampled = DBG == 3;
     const uint32_t ntiles = sampled ? args.group_count * TPG : (args.nrows + TR - 1) / TR;
     auto tile_row0 = [&](uint32_t t) -> uint32_t {
         return sampled ? (t / TPG) * args.group_stride * 64u + (t % TPG) * TR : t * TR;
@@ -355,18 +357,19 @@ hipError_t launch_wide_t(const MfmaScanArgs& args, int grid, hipStream_t stream,
     if (args.slots > kWideSlots) return hipErrorInvalidValue;
     static const std::string name = "scan_wide_kernel<" + std::to_string(ROWB) + ", " + std::to_string(EB) + ", " +
                                     std::to_string(QT) + ", " + std::to_string(NSLOT) + ">";
-    note_main_pass_kernel(name.c_str());
+    if (DBG != 3) note_main_pass_kernel(name.c_str());
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, args);
     return hipGetLastError();
 }
 
-template <int EB, int QT>
+template <int EB, int QT, int MODE = 0>
 hipError_t launch_wide_d(const MfmaScanArgs& args, int grid, hipStream_t stream, int* occupancy) {
     // resident query fragments: QT x (row bytes / 64) x 4 registers per lane; 144 is what fits next to the accumulators and
     // the fragment double buffer (f16 rows of 768 bytes: 3 tiles; int8 rows of 384 bytes: 6)
     if (QT * (int)(args.dim * EB / 64) * 4 > 144) return hipErrorInvalidValue;
     switch (args.dim * EB / 2) {  // row length in 2-byte units
         case 384: if constexpr (QT <= 3) {
+            if constexpr (MODE != 0) return launch_wide_t<768, EB, QT, 6, MODE>(args, grid, stream, occupancy);
             static const int dbg = [] { const char* e = std::getenv("FSGPU_WIDE_DBG"); return e ? std::atoi(e) : 0; }();  // timing experiments only
             if constexpr (EB == 2 && QT == 2) {
                 if (dbg == 1) return launch_wide_t<768, EB, QT, 6, 1>(args, grid, stream, occupancy);
@@ -374,11 +377,11 @@ hipError_t launch_wide_d(const MfmaScanArgs& args, int grid, hipStream_t stream,
             }
             return launch_wide_t<768, EB, QT, 6>(args, grid, stream, occupancy);   // 6 x 24 KB
         } else return hipErrorInvalidValue;
-        case 256: if constexpr (QT <= 4) return launch_wide_t<512, EB, QT, 8>(args, grid, stream, occupancy);   // 8 x 16 KB
+        case 256: if constexpr (QT <= 4) return launch_wide_t<512, EB, QT, 8, MODE>(args, grid, stream, occupancy);   // 8 x 16 KB
                   else return hipErrorInvalidValue;
-        case 192: return launch_wide_t<384, EB, QT, 6>(args, grid, stream, occupancy);   // 6 x 24 KB
-        case 128: return launch_wide_t<256, EB, QT, 8>(args, grid, stream, occupancy);   // 8 x 16 KB
-        case 64: return launch_wide_t<128, EB, QT, 8>(args, grid, stream, occupancy);    // 8 x 8 KB
+        case 192: return launch_wide_t<384, EB, QT, 6, MODE>(args, grid, stream, occupancy);   // 6 x 24 KB
+        case 128: return launch_wide_t<256, EB, QT, 8, MODE>(args, grid, stream, occupancy);   // 8 x 16 KB
+        case 64: return launch_wide_t<128, EB, QT, 8, MODE>(args, grid, stream, occupancy);    // 8 x 8 KB
         default: return hipErrorInvalidValue;
     }
 }
@@ -402,14 +405,15 @@ int scan_wide_max_query_tiles(int dim, int elem_bytes) {
 hipError_t launch_scan_wide(const MfmaScanArgs& args, int query_tiles, int grid, hipStream_t stream, int* occupancy) {
     const int eb = args.elem_bytes == 1 ? 1 : 2;
     if (!scan_wide_supported((int)args.dim, eb) || query_tiles > scan_wide_max_query_tiles((int)args.dim, eb)) return hipErrorInvalidValue;
+    const bool sample = args.group_count != 0;   // a sample stage: 64-row groups group_stride apart
     if (eb == 2) {
-        if (query_tiles == 2) return launch_wide_d<2, 2>(args, grid, stream, occupancy);
-        if (query_tiles == 3) return launch_wide_d<2, 3>(args, grid, stream, occupancy);
+        if (query_tiles == 2) return sample ? launch_wide_d<2, 2, 3>(args, grid, stream, occupancy) : launch_wide_d<2, 2>(args, grid, stream, occupancy);
+        if (query_tiles == 3) return sample ? launch_wide_d<2, 3, 3>(args, grid, stream, occupancy) : launch_wide_d<2, 3>(args, grid, stream, occupancy);
     } else {
-        if (query_tiles == 2) return launch_wide_d<1, 2>(args, grid, stream, occupancy);
-        if (query_tiles == 3) return launch_wide_d<1, 3>(args, grid, stream, occupancy);
-        if (query_tiles == 4) return launch_wide_d<1, 4>(args, grid, stream, occupancy);
-        if (query_tiles == 5) return launch_wide_d<1, 5>(args, grid, stream, occupancy);
+        if (query_tiles == 2) return sample ? launch_wide_d<1, 2, 3>(args, grid, stream, occupancy) : launch_wide_d<1, 2>(args, grid, stream, occupancy);
+        if (query_tiles == 3) return sample ? launch_wide_d<1, 3, 3>(args, grid, stream, occupancy) : launch_wide_d<1, 3>(args, grid, stream, occupancy);
+        if (query_tiles == 4) return sample ? launch_wide_d<1, 4, 3>(args, grid, stream, occupancy) : launch_wide_d<1, 4>(args, grid, stream, occupancy);
+        if (query_tiles == 5) return sample ? launch_wide_d<1, 5, 3>(args, grid, stream, occupancy) : launch_wide_d<1, 5>(args, grid, stream, occupancy);
     }
     return hipErrorInvalidValue;
 }

@@ -149,7 +149,7 @@ VectorIndex::~VectorIndex() {
                             &ws_counts_, &ws_keys_a_, &ws_keys_b_, &ws_sort_tmp_, &ws_gather_rows_, &ws_gather_out_,
                             &i8_slab_, &n4_slab_, &i8_max_, &ws_i8_query_, &ws_cand_packed_, &ws_cand_rows_, &ws_cand_scores_,
                             &mf_max_norm_, &mf_qh_, &mf_delta_, &mf_tau_, &mf_cand_, &mf_dense_, &mf_sel_,
-                            &mf_fallback_, &mf_fallback2_, &mf_spill_, &mf_io_, &i8_stats_})
+                            &mf_fallback_, &mf_fallback2_, &mf_spill_, &mf_io_, &i8_stats_, &n4u_slab_})
         b->release();
     if (mf_flags_host_) (void)hipHostFree(mf_flags_host_);
     if (io_host_) (void)hipHostFree(io_host_);
@@ -1103,12 +1103,14 @@ SearchError VectorIndex::int8_filter_bound(const float* queries, uint32_t nq, ui
 
 // int8 pass 1 on the matrix cores for a whole batch (exact integer scores), exact f16 rescore, top-k: the batched form of
 // search_top_k_int8_two_pass (search.rs:514-661).  multiplier 0 counts as 1, as in the reference.
+// bits = 4: the batched form of search_top_k_4bit_two_pass (search.rs:876-946) — the same pipeline over the 4-bit levels, kept one
+// per byte so that the int8 matrix-core kernels serve them (that pass is bound by matrix instructions, not by bytes).
 SearchError VectorIndex::search_top_k_int8_batched_device(const float* queries_dev, uint32_t nq, uint32_t query_len,
                                                           uint32_t k, uint32_t multiplier, uint32_t* out_rows_dev,
                                                           float* out_scores_dev, uint32_t* out_counts_dev,
-                                                          hipStream_t stream, uint32_t* fallbacks) {
+                                                          hipStream_t stream, uint32_t* fallbacks, int bits) {
     return batched_impl(queries_dev, nq, query_len, k, nullptr, out_rows_dev, out_scores_dev, out_counts_dev, stream,
-                        fallbacks, nullptr, multiplier ? multiplier : 1, 0, false, nullptr);
+                        fallbacks, nullptr, multiplier ? multiplier : 1, 0, false, nullptr, bits == 4 ? 4 : 8);
 }
 
 // int8_mult == 0: f16 slab, f16-rounded queries, approximate scores + proven margin (mfma_scan.hip header).
@@ -1119,7 +1121,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
                                       const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
                                       uint32_t* out_counts_dev, hipStream_t stream, uint32_t* fallbacks,
                                       uint64_t* out_packed_dev, uint32_t int8_mult, uint32_t query_stride, bool i8_filter,
-                                      uint32_t* refiltered) {
+                                      uint32_t* refiltered, int bits) {
     // query_stride: floats between queries (0 = dim): an MRL prefix view searches the first dim_ dimensions of full-length queries
     const bool i8f = i8_filter && int8_mult == 0;
     const bool i8 = int8_mult != 0 || i8f;
@@ -1193,7 +1195,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         FSGPU_HIP(hipMemcpyAsync(q.data(), queries_dev, q.size() * 4, hipMemcpyDeviceToHost, stream));
         FSGPU_HIP(hipStreamSynchronize(stream));
         for (uint32_t i = 0; i < nq; ++i)
-            FSGPU_TRY(quantized_two_pass(q.data() + (size_t)i * dim_, dim_, k, int8_mult, 8, rw.data() + (size_t)i * k,
+            FSGPU_TRY(quantized_two_pass(q.data() + (size_t)i * dim_, dim_, k, int8_mult, bits, rw.data() + (size_t)i * k,
                                          sc.data() + (size_t)i * k, &cnt[i]));
         if (out_rows_dev) FSGPU_HIP(hipMemcpyAsync(out_rows_dev, rw.data(), rw.size() * 4, hipMemcpyHostToDevice, stream));
         if (out_scores_dev) FSGPU_HIP(hipMemcpyAsync(out_scores_dev, sc.data(), sc.size() * 4, hipMemcpyHostToDevice, stream));
@@ -1215,7 +1217,14 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     }
     FSGPU_HIP(hipSetDevice(device_));
     const uint32_t N = (uint32_t)nrows_;
-    if (i8 && !i8_ready_) {  // VectorIndex::int8_slab(): built lazily, once
+    if (i8 && bits == 4 && !n4u_ready_) {  // the 4-bit levels of VectorIndex::nibbles_slab(), one per byte: built lazily, once
+        FSGPU_TRY(n4u_slab_.reserve((size_t)nrows_ * dim_));
+        FSGPU_TRY(i8_max_.reserve(4));
+        FSGPU_HIP(launch_quantize_slab_4bit_levels(slab_dev_, (size_t)nrows_ * dim_, static_cast<unsigned int*>(i8_max_.ptr),
+                                                   n4u_slab_.ptr, stream));
+        n4u_ready_ = true;
+    }
+    if (i8 && bits != 4 && !i8_ready_) {  // VectorIndex::int8_slab(): built lazily, once
         FSGPU_TRY(i8_slab_.reserve((size_t)nrows_ * dim_));
         FSGPU_TRY(i8_max_.reserve(4));
         FSGPU_HIP(launch_quantize_slab_i8(slab_dev_, (size_t)nrows_ * dim_, static_cast<unsigned int*>(i8_max_.ptr),
@@ -1330,7 +1339,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         if (i8f)
             FSGPU_HIP(launch_prepare_queries_i8_filter(qg, ng, QP, dim_, qs, static_cast<const unsigned int*>(i8_max_.ptr),
                                                        static_cast<const unsigned int*>(i8_stats_.ptr), mf_qh_.ptr, delta, stream));
-        else if (i8) FSGPU_HIP(launch_prepare_queries_i8(qg, ng, QP, dim_, mf_qh_.ptr, delta, stream));
+        else if (i8) FSGPU_HIP(launch_prepare_queries_i8(qg, ng, QP, dim_, mf_qh_.ptr, delta, stream, bits));
         else
             FSGPU_HIP(launch_prepare_queries(qg, ng, QP, dim_, qs, static_cast<const unsigned int*>(mf_max_norm_.ptr),
                                              mf_qh_.ptr, delta, stream));
@@ -1343,7 +1352,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         FSGPU_TRY(mf_cand_.reserve((size_t)QP * std::max(full_grid, wide_grid) * kMfmaMaxSlots * 8));
         u64* cand = static_cast<u64*>(mf_cand_.ptr);
         MfmaScanArgs a{};
-        a.slab = i8 ? i8_slab_.ptr : slab_dev_;
+        a.slab = i8 ? (bits == 4 ? n4u_slab_.ptr : i8_slab_.ptr) : slab_dev_;
         a.elem_bytes = i8 ? 1 : 2;
         a.live = reinterpret_cast<const u64*>(live_dev_);
         a.allow = reinterpret_cast<const u64*>(allow_dev);
@@ -1530,7 +1539,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
             FSGPU_HIP(hipMemcpyAsync(qh.data(), queries_dev + (size_t)i * dim_, (size_t)dim_ * 4, hipMemcpyDeviceToHost, stream));
             FSGPU_HIP(hipStreamSynchronize(stream));
             std::fill(rw.begin(), rw.end(), 0xffffffffu);
-            FSGPU_TRY(quantized_two_pass(qh.data(), dim_, k, int8_mult, 8, rw.data(), sc.data(), &cnt));
+            FSGPU_TRY(quantized_two_pass(qh.data(), dim_, k, int8_mult, bits, rw.data(), sc.data(), &cnt));
             if (out_rows_dev) FSGPU_HIP(hipMemcpyAsync(out_rows_dev + (size_t)i * k, rw.data(), (size_t)k * 4, hipMemcpyHostToDevice, stream));
             if (out_scores_dev) FSGPU_HIP(hipMemcpyAsync(out_scores_dev + (size_t)i * k, sc.data(), (size_t)k * 4, hipMemcpyHostToDevice, stream));
             if (out_counts_dev) FSGPU_HIP(hipMemcpyAsync(out_counts_dev + i, &cnt, 4, hipMemcpyHostToDevice, stream));
@@ -1612,7 +1621,7 @@ SearchError VectorIndex::search_top_k_batched(const float* queries, uint32_t nq,
 
 SearchError VectorIndex::search_top_k_int8_batched(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
                                                    uint32_t multiplier, uint32_t* out_rows, float* out_scores,
-                                                   uint32_t* out_counts, uint32_t* fallbacks) {
+                                                   uint32_t* out_counts, uint32_t* fallbacks, int bits) {
     if (fallbacks) *fallbacks = 0;
     FSGPU_TRY(ensure_query_dimension(query_len));
     if (nq == 0) return ok();
@@ -1620,8 +1629,10 @@ SearchError VectorIndex::search_top_k_int8_batched(const float* queries, uint32_
     // an index with a doc-id table also does (resolve_hits dedups by doc id there)
     if (k == 0 || nrows_ == 0 || !wal_.empty() || has_doc_ids()) {
         for (uint32_t i = 0; i < nq; ++i)
-            FSGPU_TRY(search_top_k_int8_two_pass(queries + (size_t)i * dim_, query_len, k, multiplier,
-                                                 out_rows + (size_t)i * k, out_scores + (size_t)i * k, &out_counts[i]));
+            FSGPU_TRY(bits == 4 ? search_top_k_4bit_two_pass(queries + (size_t)i * dim_, query_len, k, multiplier,
+                                                             out_rows + (size_t)i * k, out_scores + (size_t)i * k, &out_counts[i])
+                                : search_top_k_int8_two_pass(queries + (size_t)i * dim_, query_len, k, multiplier,
+                                                             out_rows + (size_t)i * k, out_scores + (size_t)i * k, &out_counts[i]));
         if (fallbacks) *fallbacks = nq;
         return ok();
     }
@@ -1638,7 +1649,7 @@ SearchError VectorIndex::search_top_k_int8_batched(const float* queries, uint32_
     uint32_t* counts_dev = reinterpret_cast<uint32_t*>(base + o_counts);
     FSGPU_HIP(hipMemcpyAsync(q_dev, queries, (size_t)nq * dim_ * 4, hipMemcpyHostToDevice, stream_));
     FSGPU_TRY(search_top_k_int8_batched_device(q_dev, nq, query_len, k, multiplier, rows_dev, scores_dev, counts_dev,
-                                               stream_, fallbacks));
+                                               stream_, fallbacks, bits));
     FSGPU_HIP(hipMemcpyAsync(out_rows, rows_dev, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream_));
     FSGPU_HIP(hipMemcpyAsync(out_scores, scores_dev, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream_));
     FSGPU_HIP(hipMemcpyAsync(out_counts, counts_dev, (size_t)nq * 4, hipMemcpyDeviceToHost, stream_));

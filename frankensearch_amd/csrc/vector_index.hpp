@@ -77,10 +77,11 @@ class VectorIndex {
     // k*multiplier candidates are exactly the reference's), exact f16 rescore, top-k.  No doc-id dedup (raw row ids).
     SearchError search_top_k_int8_batched_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
                                                  uint32_t multiplier, uint32_t* out_rows_dev, float* out_scores_dev,
-                                                 uint32_t* out_counts_dev, hipStream_t stream, uint32_t* fallbacks);
+                                                 uint32_t* out_counts_dev, hipStream_t stream, uint32_t* fallbacks, int bits = 8);
+    // bits = 4: batched search_top_k_4bit_two_pass (search.rs:876-946)
     SearchError search_top_k_int8_batched(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
                                           uint32_t multiplier, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
-                                          uint32_t* fallbacks);
+                                          uint32_t* fallbacks, int bits = 8);
     // Shard-local search whose result stays packed (score bits << 32 | global row; ~0 padding) for the
     // cross-GPU exchange: out_packed_dev is [nq, k].  Fused tiers only (k <= 256, dim % 8 == 0).
     SearchError search_top_k_packed_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
@@ -154,7 +155,7 @@ class VectorIndex {
     SearchError batched_impl(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k, const uint64_t* allow_dev,
                              uint32_t* out_rows_dev, float* out_scores_dev, uint32_t* out_counts_dev, hipStream_t stream,
                              uint32_t* fallbacks, uint64_t* out_packed_dev, uint32_t int8_mult, uint32_t query_stride,
-                             bool i8_filter, uint32_t* refiltered);
+                             bool i8_filter, uint32_t* refiltered, int bits = 8);
     SearchError quantized_two_pass(const float* query, uint32_t query_len, uint32_t k, uint32_t multiplier, int bits,
                                    uint32_t* out_rows, float* out_scores, uint32_t* out_count);
     SearchError common_init(int device);
@@ -188,8 +189,8 @@ class VectorIndex {
     DeviceBuffer ws_partial_, ws_queries_, ws_allow_, ws_rows_, ws_scores_, ws_counts_, ws_keys_a_, ws_keys_b_,
         ws_sort_tmp_, ws_gather_rows_, ws_gather_out_, i8_slab_, n4_slab_, i8_max_, ws_i8_query_, ws_cand_packed_,
         ws_cand_rows_, ws_cand_scores_, mf_max_norm_, mf_qh_, mf_delta_, mf_tau_, mf_cand_, mf_dense_, mf_sel_,
-        mf_fallback_, mf_fallback2_, mf_spill_, mf_io_, i8_stats_;
-    bool i8_ready_ = false, n4_ready_ = false, i8_stats_ready_ = false;
+        mf_fallback_, mf_fallback2_, mf_spill_, mf_io_, i8_stats_, n4u_slab_;
+    bool i8_ready_ = false, n4_ready_ = false, i8_stats_ready_ = false, n4u_ready_ = false;
     bool i8f_disabled_ = false;   // the int8 filter left too many queries uncertified on this slab (or its copy does not fit)
     uint32_t i8f_strikes_ = 0;
     bool mf_norm_ready_ = false;

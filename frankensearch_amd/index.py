@@ -271,7 +271,11 @@ class VectorIndex:
         return [VectorHit(int(rows[i]), float(scores[i]), self.doc_id_at(int(rows[i])) if has_ids else None)
                 for i in range(n.value)]
 
-    def search_int8_two_pass_batched(self, queries: np.ndarray, limit: int, candidate_multiplier: int = 3):
+    def search_4bit_two_pass_batched(self, queries: np.ndarray, limit: int, candidate_multiplier: int = 5):
+        """Batched search_top_k_4bit_two_pass -> (rows [nq, limit], scores, counts, fallbacks)."""
+        return self.search_int8_two_pass_batched(queries, limit, candidate_multiplier, bits=4)
+
+    def search_int8_two_pass_batched(self, queries: np.ndarray, limit: int, candidate_multiplier: int = 3, bits: int = 8):
         """Batched search_top_k_int8_two_pass (int8 MFMA pass 1 shared by the whole batch):
         -> (rows [nq, limit], scores, counts, fallbacks)."""
         q = np.ascontiguousarray(queries, dtype=np.float32)
@@ -282,8 +286,8 @@ class VectorIndex:
         scores = np.full((nq, max(limit, 1)), np.nan, dtype=np.float32)
         counts = np.zeros(nq, dtype=np.uint32)
         fb = C.c_uint32()
-        check(_lib.lib().fsgpu_search_topk_int8_two_pass_batched(self._h, _ptr(q), nq, qlen, limit, candidate_multiplier,
-                                                                 _ptr(rows), _ptr(scores), _ptr(counts), C.byref(fb)))
+        fn = _lib.lib().fsgpu_search_topk_4bit_two_pass_batched if bits == 4 else _lib.lib().fsgpu_search_topk_int8_two_pass_batched
+        check(fn(self._h, _ptr(q), nq, qlen, limit, candidate_multiplier, _ptr(rows), _ptr(scores), _ptr(counts), C.byref(fb)))
         return rows[:, :limit], scores[:, :limit], counts, fb.value
 
     def search_top_k_4bit_two_pass(self, query: Sequence[float], k: int, candidate_multiplier: int = 5

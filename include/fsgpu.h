@@ -238,6 +238,13 @@ fsgpu_status fsgpu_search_topk_int8_two_pass_batched(fsgpu_index *idx, const flo
 fsgpu_status fsgpu_search_topk_4bit_two_pass(fsgpu_index *idx, const float *query, uint32_t query_len, uint32_t k,
                                              uint32_t candidate_multiplier, uint32_t *out_rows, float *out_scores,
                                              uint32_t *out_count);
+/* Batched search_top_k_4bit_two_pass: as fsgpu_search_topk_int8_two_pass_batched, with the reference's 4-bit quantisers
+ * (slab scale 7/max_abs, pack_4bit_query).  The nibble dot is an exact integer, so the levels are kept one per byte (built on
+ * first use, rows x dim bytes) and run through the same int8 matrix-core pass — which is bound by matrix instructions, not
+ * by bytes — giving exactly the reference's k*candidate_multiplier candidates; then the exact f16 rescore. */
+fsgpu_status fsgpu_search_topk_4bit_two_pass_batched(fsgpu_index *idx, const float *queries, uint32_t nq, uint32_t query_len,
+                                                     uint32_t k, uint32_t candidate_multiplier, uint32_t *out_rows,
+                                                     float *out_scores, uint32_t *out_counts, uint32_t *out_fallbacks);
 /* VectorIndex::dot_query_at (lib.rs:3229-3239) over a row list, as used by
  * TwoTierIndex::quality_scores_for_hits (two_tier.rs:1566-1631).  rows are global ids. */
 fsgpu_status fsgpu_gather_dot(fsgpu_index *idx, const float *query, uint32_t query_len, const uint32_t *rows,

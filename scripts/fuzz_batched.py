@@ -84,6 +84,14 @@ while time.time() < t_end:
             if [h.index for h in hits] != r8[qi, :c8[qi]].tolist() or \
                not np.array_equal(np.array([h.score for h in hits], np.float32).view(np.uint32), s8[qi, :c8[qi]].view(np.uint32)):
                 ok = False
+        if rng.random() < 0.5:
+            mult4 = int(rng.choice([1, 5]))
+            r4, s4, c4, fb4 = idx.search_4bit_two_pass_batched(q, k, mult4)
+            for qi in rng.choice(nq, min(nq, 4), replace=False):
+                hits = idx.search_top_k_4bit_two_pass(q[qi], k, mult4)
+                if [h.index for h in hits] != r4[qi, :c4[qi]].tolist() or \
+                   not np.array_equal(np.array([h.score for h in hits], np.float32).view(np.uint32), s4[qi, :c4[qi]].view(np.uint32)):
+                    ok = False
     cases += 1
     if not ok:
         bad += 1

@@ -771,6 +771,47 @@ def test_int8_two_pass_batched_equals_per_query_and_oracle(fa, oracle):
 
 
 @pytest.mark.gpu
+def test_4bit_two_pass_batched_equals_per_query_and_oracle(fa, oracle):
+    # the batched 4-bit pass 1 (search.rs:876-946) runs the nibble levels through the int8 matrix-core pass: the nibble dot is
+    # an exact integer, so every query must get exactly the candidates — hence the hits — of search_top_k_4bit_two_pass.
+    # 4-bit scores tie in droves (15 levels): the row-order tie-break at the candidate cut is what this exercises.
+    rng = np.random.default_rng(211)
+    for n, dim in ((150_001, 384), (50_000, 128)):
+        cent = rng.standard_normal((24, dim)).astype(np.float32)
+        cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+        rows = cent[rng.integers(0, 24, n)] + 0.3 * rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+        rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+        rows[4000:4030] = rows[3999]
+        slab = rows.astype(np.float16).view(np.uint16)
+        live = rng.random(n) > 0.05
+        idx = fa.VectorIndex.from_slab(slab, live=live)
+        nq = 300                                               # a 256-query wide pass + a tail
+        q = cent[rng.integers(0, 24, nq)] + 0.3 * rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+        q[2] = rows[3999]
+        q[5] = 0.0
+        q[6] *= 11.0
+        q[7, 3] = np.nan
+        q[8] *= 1e-10                                          # max |q| <= 1e-9: pack_4bit_query's scale is 0, all levels 0
+        for k, mult in ((10, 5), (10, 1), (1, 5), (7, 0), (25, 5)):
+            br, bs, bc, fb = idx.search_4bit_two_pass_batched(q, k, mult)
+            assert fb < nq // 3, (n, dim, k, mult, fb)
+            for qi in list(range(12)) + [64, 255, 256, 299]:
+                hits = idx.search_top_k_4bit_two_pass(q[qi], k, mult)
+                assert [h.index for h in hits] == br[qi, :bc[qi]].tolist(), (n, dim, k, mult, qi)
+                assert np.array_equal(bits([h.score for h in hits]), bits(bs[qi, :bc[qi]])), (n, dim, k, mult, qi)
+        br, bs, bc, _ = idx.search_4bit_two_pass_batched(q, 10, 5)
+        for qi in (0, 2, 6, 8, 100):
+            er, es = oracle.search_4bit_two_pass(slab, q[qi], 10, 5, live=live)
+            assert np.array_equal(br[qi, :bc[qi]], er) and np.array_equal(bits(bs[qi, :bc[qi]]), bits(es)), (n, dim, qi)
+    small = fa.VectorIndex.from_slab(slab[:3000])              # not covered by the matrix-core path: per query, same answers
+    br, bs, bc, fb = small.search_4bit_two_pass_batched(q[:9], 10, 5)
+    assert fb == 9
+    for qi in range(9):
+        hits = small.search_top_k_4bit_two_pass(q[qi], 10, 5)
+        assert [h.index for h in hits] == br[qi, :bc[qi]].tolist()
+
+
+@pytest.mark.gpu
 def test_fsvi_writer_bytes_equal_reference_layout_and_config1_roundtrip(fa, oracle, tmp_path):
     # VectorIndexWriter (lib.rs:3637-3672, 3752-3943): the product writer must emit exactly the bytes the oracle's
     # restatement of the reference writer does — duplicate doc ids keep insertion order (stable sort), ids of different
