@@ -215,9 +215,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     auto emit_pair = [&](uint32_t t, int sp, const acc_t (&acc)[2][QT]) {
         // one test for the whole pair: does any of the lane's 8 x QT scores reach its query's threshold?  (max ignores
         // NaN, and NaN >= tau is false: a NaN score never passes, as in scan_mfma_kernel)
-        bool any = false;
-#pragma unroll
-        for (int nt = 0; nt < QT; ++nt) {
+        auto lane_max = [&](int nt) {
             auto m = acc[0][nt][0];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -226,38 +224,53 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
                     if constexpr (EB == 2) m = __builtin_fmaxf(m, acc[h][nt][r]);
                     else m = acc[h][nt][r] > m ? acc[h][nt][r] : m;
                 }
-            any |= (float)m >= tau[nt];
-        }
+            return (float)m;
+        };
+        bool any = false;
+#pragma unroll
+        for (int nt = 0; nt < QT; ++nt) any |= lane_max(nt) >= tau[nt];
         if (!any) return;  // almost always: survivors are a few hundred rows of the slab
         if constexpr (DBG == 2) {  // (the ring holds stale bytes in the no-DMA timing experiment: keep the scores live, append nothing)
             lcnt[q0 + frow] = 0;
             return;
         }
+        auto append = [&](int q, float score, uint32_t row) {
+            if (row >= args.nrows) return;
+            if (args.live && !((args.live[row >> 6] >> (row & 63)) & 1ull)) return;
+            if (args.allow && !((args.allow[row >> 6] >> (row & 63)) & 1ull)) return;
+            const int pos = atomicAdd(&lcnt[q], 1);
+            const u64 entry = pack(score, args.row_base + row);
+            if (pos < slots) {
+                args.cand[((size_t)q * gridDim.x + blockIdx.x) * slots + pos] = entry;
+            } else {
+                const uint32_t g = atomicAdd(&args.spill_count[q * kMfmaSpillCountStride], 1u);
+                if (g < args.spill_cap) args.spill[(size_t)q * args.spill_cap + g] = entry;
+                else args.overflow[q] = 1;
+            }
+        };
+        // C layout: column (query) = lane & 15, row = (lane >> 4) * 4 + reg
+        const uint32_t row00 = tile_row0(t) + sp * 16 + fk * 4;
+        if constexpr (EB == 2 && QT >= 3) {   // (the 384-query f16 shape has no register to spare for the per-tile test below)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            // C layout: column (query) = lane & 15, row = (lane >> 4) * 4 + reg
-            const uint32_t row0 = tile_row0(t) + (sp + h) * 16 + fk * 4;
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int nt = 0; nt < QT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if ((float)acc[h][nt][r] >= tau[nt]) append(q0 + nt * 16 + frow, (float)acc[h][nt][r], row00 + h * 16 + r);
+        } else {
+            // query tiles first: a wave gets here for ONE passing score as a rule, and the tiles without one are skipped as a
+            // whole — on a 1.25M-row shard, where 512 queries x ~800 survivors meet 8 x fewer tiles than at 10M rows, this slow
+            // path is entered ~20 times per tile
 #pragma unroll
             for (int nt = 0; nt < QT; ++nt) {
                 const float th = tau[nt];
-                const int q = q0 + nt * 16 + frow;
+                if (!(lane_max(nt) >= th)) continue;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (!((float)acc[h][nt][r] >= th)) continue;
-                    const uint32_t row = row0 + r;
-                    if (row >= args.nrows) continue;
-                    if (args.live && !((args.live[row >> 6] >> (row & 63)) & 1ull)) continue;
-                    if (args.allow && !((args.allow[row >> 6] >> (row & 63)) & 1ull)) continue;
-                    const int pos = atomicAdd(&lcnt[q], 1);
-                    const u64 entry = pack((float)acc[h][nt][r], args.row_base + row);
-                    if (pos < slots) {
-                        args.cand[((size_t)q * gridDim.x + blockIdx.x) * slots + pos] = entry;
-                    } else {
-                        const uint32_t g = atomicAdd(&args.spill_count[q * kMfmaSpillCountStride], 1u);
-                        if (g < args.spill_cap) args.spill[(size_t)q * args.spill_cap + g] = entry;
-                        else args.overflow[q] = 1;
-                    }
-                }
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if ((float)acc[h][nt][r] >= th) append(q0 + nt * 16 + frow, (float)acc[h][nt][r], row00 + h * 16 + r);
             }
         }
     };

@@ -47,6 +47,7 @@ struct Knobs {
     int grid_blocks = 0, ra = 0, rb = 0, mfma_shape = 0, mfma_shape_i8 = 0, round = 0, i8_per_cu = 0;
     int wide = -1;  // FSGPU_WIDE: 0 = never the register-resident-query main pass, 2 / 3 = its query tiles per wave
     int filter = 0;     // FSGPU_FILTER: "f16" (1) / "i8" (2) pin the filter of the exact batched search; unset = automatic
+    int slots_b = 0, slots_main = 0;   // FSGPU_SLOTS_B / FSGPU_SLOTS_MAIN: list slots per (query, block) of the wide kernel's stages
     int wide_max = 0;   // FSGPU_WIDE_MAX: cap on the query tiles per wave of the wide main pass (default: what the registers hold)
     int i8f_growth = 0; // FSGPU_I8F_GROWTH: sample growth factor of the int8 filter (default 4)
     bool no_skip_b = false, use_160 = false, debug_batched = false, no_reverse = false, no_wide_b = false;
@@ -66,6 +67,8 @@ struct Knobs {
         if (const char* f = std::getenv("FSGPU_FILTER")) filter = std::strcmp(f, "f16") == 0 ? 1 : std::strcmp(f, "i8") == 0 ? 2 : 0;
         i8f_growth = num("FSGPU_I8F_GROWTH");
         wide_max = num("FSGPU_WIDE_MAX");
+        slots_b = std::min(num("FSGPU_SLOTS_B"), (int)kWideSlots);
+        slots_main = std::min(num("FSGPU_SLOTS_MAIN"), (int)kWideSlots);
         no_skip_b = std::getenv("FSGPU_NO_SKIP_B") != nullptr;
         no_wide_b = std::getenv("FSGPU_NO_WIDE_B") != nullptr;
         no_reverse = std::getenv("FSGPU_NO_REVERSE") != nullptr;
@@ -1399,7 +1402,10 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         // (a wide round samples on the register-resident-query kernel too: one launch per main-pass group, the same lists)
         const bool wide_b = wide_qt && !skip_b && !knobs().no_wide_b;
         const int wide_grid_b = std::min(wide_grid, (int)std::max<uint32_t>(1, RB / 64 / 4));   // at least 4 sample groups per block
-        if (wide_b) a.slots = kWideSlots;
+        // (a row shard's stages are short: the lists' padding and the selection's reads are a visible part of them — 8 / 16 slots
+        // there, overflow goes to the spill area; 1.25M rows: 0.809 -> 0.789 ms per 1,024 queries, nothing at 10M)
+        const bool short_stages = nrows_ < 4'000'000;
+        if (wide_b) a.slots = knobs().slots_b > 0 ? (uint32_t)knobs().slots_b : short_stages ? 8 : kWideSlots;
         if (!skip_b) {
             FSGPU_HIP(hipMemsetAsync(spill_count, 0, (size_t)QP * kMfmaSpillCountStride * 4, stream));
             if (wide_b) {
@@ -1451,7 +1457,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
             }
             // (the wide pass appends to global lists: 16 slots per (query, block) keep lists + pool inside one selection pass;
             // ranks above 32 — the int8 fast tier anchors on 90 — let ~1,700 rows per query through and get 32)
-            a.slots = wide_qt ? (ksel_est > 32 ? kWideSlots : std::min<uint32_t>(16, std::max<uint32_t>(8, (CAPQ - KC) / (uint32_t)main_grid)))
+            a.slots = wide_qt ? (knobs().slots_main > 0 ? (uint32_t)knobs().slots_main : ksel_est > 32 ? (short_stages && i8f ? 16 : kWideSlots) : std::min<uint32_t>(16, std::max<uint32_t>(8, (CAPQ - KC) / (uint32_t)main_grid)))
                               : slots_for(full_grid);
             FSGPU_HIP(hipMemsetAsync(spill_count, 0, (size_t)QP * kMfmaSpillCountStride * 4, stream));
             a.groups = 1;

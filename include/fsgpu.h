@@ -424,6 +424,7 @@ fsgpu_status fsgpu_bert_set_coalescing(fsgpu_bert *m, uint32_t max_batch, uint32
  *   FSGPU_USE_160, FSGPU_MFMA_SHAPE, FSGPU_MFMA_SHAPE_I8   shapes of the LDS-query kernel
  *   FSGPU_RA, FSGPU_RB, FSGPU_ROUND, FSGPU_NO_SKIP_B, FSGPU_NO_REVERSE   sample sizes / round size / pass direction
  *   FSGPU_FILTER (f16 | i8), FSGPU_I8F_GROWTH   pin the filter of the exact batched search / its sample growth
+ *   FSGPU_WIDE_MAX, FSGPU_SLOTS_B, FSGPU_SLOTS_MAIN, FSGPU_NO_WIDE_B   wide main pass: query tiles per wave, list slots, sample stage
  *   FSGPU_GRID_BLOCKS, FSGPU_I8_PER_CU   grid sizes of the exact kernels
  *   FSGPU_SELECT_SORT_ABOVE     rank above which select_kernel sorts instead of extracting
  *   FSGPU_BERT_GEMM_SHAPE, FSGPU_BERT_ATTN, FSGPU_BERT_NO_FUSED_LN, FSGPU_BERT_NO_GRAPH, FSGPU_BERT_NO_QUERY_PATH   encoder paths
