@@ -220,7 +220,10 @@ def two_tier_section(quality_index, rows: int, k: int, device, local_rank: int):
                                 corpus_rows=rows)
         fb, fr = fast_index.coalescing_stats()
         qb, qr = quality_index.coalescing_stats()
+        filt = quality_index.batched_filter_stats()
         return {
+            "quality_tier_filter": {"int8_active": filt["int8_active"], "int8_queries_so_far": filt["int8_queries"],
+                                    "refiltered_on_f16_so_far": filt["refiltered_f16"]},
             "threads": threads, "coalescing": {"max_batch": max_batch, "max_wait_us": wait_us},
             "queries_per_sec": con.queries_per_sec, "completed": con.completed, "failed": con.failed,
             "phase0_p50_ms": con.phase0_p50_ms, "phase0_p95_ms": con.phase0_p95_ms,

@@ -127,6 +127,10 @@ struct SelectArgs {
     uint32_t* cand_counts;     // [nq] number of candidates, unclamped (may be null)
     uint32_t* overflow;        // [nq] set when there are more than kSelectPool candidates
     uint32_t take_topk;        // != 0: the candidates are the k best entries themselves (exact pass-1 scores)
+    // threshold step with the finish fields set and anchor_unit != null (int8 filter): the candidates are re-scored exactly and
+    // tau_out = max(a_k - 2 delta, S_k * anchor_unit[q] - delta), S_k = the k-th best EXACT score among them — k real rows score
+    // at least S_k, so every true top-k row's approximate score is at least S_k in filter units minus ONE delta
+    const float* anchor_unit;  // [nq] filter-score units per exact-score unit (slab scale x query scale); null = off
     // finish step
     const void* slab;          // [nrows, dim] f16
     const float* queries;      // [nq, q_stride_f] f32 (the first dim of each are used)
@@ -150,7 +154,7 @@ hipError_t launch_prepare_queries_i8(const float* q, uint32_t nq, uint32_t nq_pa
 // scale x query scale)| from the slab statistics of launch_i8_slab_stats (see mfma_scan.hip)
 hipError_t launch_prepare_queries_i8_filter(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t q_stride,
                                             const unsigned int* slab_max_bits, const unsigned int* slab_stats, void* qi8,
-                                            float* delta, hipStream_t stream);
+                                            float* delta, hipStream_t stream, float* unit_out = nullptr);
 
 constexpr uint32_t kMfmaMaxSlots = 32;           // candidate slots per (block, query) staged in LDS
 constexpr uint32_t kMfmaSpillCountStride = 16;  // uint32 counters 64 bytes apart

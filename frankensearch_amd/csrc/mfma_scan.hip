@@ -213,9 +213,14 @@ __global__ __launch_bounds__(WPB * 64) void scan_mfma_kernel(MfmaScanArgs args) 
                     const float th = tau[nt];
                     // cheap reject first: the best of the lane's four rows against the threshold (max ignores NaN);
                     // survivors are a few hundred rows out of the whole slab
-                    auto m = acc[s][nt][0] > acc[s][nt][1] ? acc[s][nt][0] : acc[s][nt][1];
-                    m = acc[s][nt][2] > m ? acc[s][nt][2] : m;
-                    m = acc[s][nt][3] > m ? acc[s][nt][3] : m;
+                    // (fmaxf, not a comparison chain: `a > NaN ? a : NaN` keeps the NaN, and a row with a NaN element — its score is
+                    // NaN, it ranks last — would take the three rows that share its lane down with it)
+                    auto m = acc[s][nt][0];
+#pragma unroll
+                    for (int r = 1; r < 4; ++r) {
+                        if constexpr (EB == 2) m = __builtin_fmaxf(m, acc[s][nt][r]);
+                        else m = acc[s][nt][r] > m ? acc[s][nt][r] : m;
+                    }
                     if (!((float)m >= th)) continue;
                     const int q = nt * 16 + frow;
 #pragma unroll
@@ -562,6 +567,20 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
         __syncthreads();
         if (wave == 0) {
             merge_wave_winners<1>(win[0], ko, top, lane);
+            if (args.anchor_unit && args.tau_out && lane == 0) {
+                // the k-th best exact score among real rows is a lower bound on the final k-th best; in filter units, minus one
+                // delta (and the rounding of the product), it bounds every true top-k row's approximate score from below
+                const float d = args.delta[q];
+                const u64 kth = top[ko - 1];
+                float t = s_tau;
+                if (d >= 0.f && kth != kEmpty) {
+                    const float sk = __uint_as_float((uint32_t)(kth >> 32));
+                    const float v = sk * args.anchor_unit[q];
+                    const float te = v - d - fabsf(v) * 1e-6f - 1.0f;
+                    if (te == te && te > t) t = te;
+                }
+                args.tau_out[q] = t;
+            }
             int n = 0;
             for (int j = lane; j < (int)args.out_stride; j += 64) {
                 const u64 cnd = j < ko ? top[j] : kEmpty;
@@ -685,7 +704,8 @@ __global__ __launch_bounds__(256) void prepare_queries_i8_kernel(const float* __
 __global__ __launch_bounds__(256) void prepare_queries_i8_filter_kernel(const float* __restrict__ q, uint32_t nq, uint32_t q_stride,
                                                                         uint32_t dim, const unsigned int* __restrict__ slab_max_bits,
                                                                         const unsigned int* __restrict__ slab_stats,
-                                                                        signed char* __restrict__ qi8, float* __restrict__ delta) {
+                                                                        signed char* __restrict__ qi8, float* __restrict__ delta,
+                                                                        float* __restrict__ unit_out) {
     __shared__ float redf[4];
     __shared__ unsigned int redu[2][4];
     __shared__ int s_bad;
@@ -758,6 +778,8 @@ __global__ __launch_bounds__(256) void prepare_queries_i8_filter_kernel(const fl
         if (!((double)out >= d)) out = __uint_as_float(__float_as_uint(out) + 1u);  // round up
         if (zero || s_bad || slab_bad || dim > 1040u || !__builtin_isfinite(out) || !(out < 1.0e9f)) out = -1.0f;
         delta[b] = out;
+        // integer-score units per exact-score unit, for thresholds anchored on exact scores (select_kernel, anchor_unit)
+        if (unit_out) unit_out[b] = out < 0.f ? 0.f : (127.0f / __uint_as_float(*slab_max_bits)) * scale;
     }
 }
 
@@ -860,9 +882,9 @@ hipError_t launch_prepare_queries_i8(const float* q, uint32_t nq, uint32_t nq_pa
 
 hipError_t launch_prepare_queries_i8_filter(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t q_stride,
                                             const unsigned int* slab_max_bits, const unsigned int* slab_stats, void* qi8,
-                                            float* delta, hipStream_t stream) {
+                                            float* delta, hipStream_t stream, float* unit_out) {
     hipLaunchKernelGGL(prepare_queries_i8_filter_kernel, dim3(nq_pad), dim3(256), 0, stream, q, nq, q_stride ? q_stride : dim, dim,
-                       slab_max_bits, slab_stats, static_cast<signed char*>(qi8), delta);
+                       slab_max_bits, slab_stats, static_cast<signed char*>(qi8), delta, unit_out);
     return hipGetLastError();
 }
 

@@ -50,7 +50,7 @@ struct Knobs {
     int slots_b = 0, slots_main = 0;   // FSGPU_SLOTS_B / FSGPU_SLOTS_MAIN: list slots per (query, block) of the wide kernel's stages
     int wide_max = 0;   // FSGPU_WIDE_MAX: cap on the query tiles per wave of the wide main pass (default: what the registers hold)
     int i8f_growth = 0; // FSGPU_I8F_GROWTH: sample growth factor of the int8 filter (default 4)
-    bool no_skip_b = false, use_160 = false, debug_batched = false, no_reverse = false, no_wide_b = false;
+    bool no_skip_b = false, use_160 = false, debug_batched = false, no_reverse = false, no_wide_b = false, no_anchor = false;
     Knobs() {
         auto num = [](const char* name) {
             const char* e = std::getenv(name);
@@ -71,6 +71,7 @@ struct Knobs {
         slots_main = std::min(num("FSGPU_SLOTS_MAIN"), (int)kWideSlots);
         no_skip_b = std::getenv("FSGPU_NO_SKIP_B") != nullptr;
         no_wide_b = std::getenv("FSGPU_NO_WIDE_B") != nullptr;
+        no_anchor = std::getenv("FSGPU_NO_ANCHOR") != nullptr;
         no_reverse = std::getenv("FSGPU_NO_REVERSE") != nullptr;
         use_160 = std::getenv("FSGPU_USE_160") != nullptr;
         debug_batched = std::getenv("FSGPU_DEBUG_BATCHED") != nullptr;
@@ -1252,7 +1253,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     const uint32_t QCAP = std::min<uint32_t>(round_cap, std::max<uint32_t>(GMAX, (nq + 127) / 128 * 128));
     FSGPU_TRY(mf_qh_.reserve((size_t)QCAP * dim_ * 2));
     FSGPU_TRY(mf_delta_.reserve(QCAP * 4));
-    FSGPU_TRY(mf_tau_.reserve(QCAP * 4));
+    FSGPU_TRY(mf_tau_.reserve(QCAP * 8));
     FSGPU_TRY(mf_spill_.reserve((size_t)QCAP * SPILL * 8 + (size_t)QCAP * kMfmaSpillCountStride * 4));
     FSGPU_TRY(mf_dense_.reserve((size_t)QCAP * RA_MAX * 8));
     FSGPU_TRY(mf_sel_.reserve((size_t)QCAP * KC * 8));
@@ -1299,6 +1300,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     std::memset(mf_flags_host_, 0, (size_t)mf_flags_cap_ * 8);
     float* delta = static_cast<float*>(mf_delta_.ptr);
     float* tau = static_cast<float*>(mf_tau_.ptr);
+    float* unit = tau + QCAP;   // int8 filter: integer-score units per exact-score unit, per query
     u64* spill = static_cast<u64*>(mf_spill_.ptr);
     uint32_t* spill_count = reinterpret_cast<uint32_t*>(spill + (size_t)QCAP * SPILL);
     u64* pool = static_cast<u64*>(mf_sel_.ptr);
@@ -1341,7 +1343,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         uint32_t* cand_counts = counts_all + g0;
         if (i8f)
             FSGPU_HIP(launch_prepare_queries_i8_filter(qg, ng, QP, dim_, qs, static_cast<const unsigned int*>(i8_max_.ptr),
-                                                       static_cast<const unsigned int*>(i8_stats_.ptr), mf_qh_.ptr, delta, stream));
+                                                       static_cast<const unsigned int*>(i8_stats_.ptr), mf_qh_.ptr, delta, stream, unit));
         else if (i8) FSGPU_HIP(launch_prepare_queries_i8(qg, ng, QP, dim_, mf_qh_.ptr, delta, stream, bits));
         else
             FSGPU_HIP(launch_prepare_queries(qg, ng, QP, dim_, qs, static_cast<const unsigned int*>(mf_max_norm_.ptr),
@@ -1390,6 +1392,25 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         sa.k = ksel;
         sa.delta = delta;
         sa.tau_out = tau;
+        // int8 filter: the sample stages' thresholds are anchored on EXACT scores (their candidates are re-scored from the f16
+        // slab right in the selection): one delta below the k-th best instead of two — the margin's multiplier on the rows each
+        // stage lets through is exponential in it
+        const bool anchor = i8f && !knobs().no_anchor;
+        auto set_rescore = [&](SelectArgs& x) {
+            x.slab = slab_dev_;
+            x.queries = qg;
+            x.dim = dim_;
+            x.row_stride = 0;
+            x.query_stride = qs;
+            x.nrows = N;
+            x.row_base = (uint32_t)row_base_;
+            x.hreduce = hreduce;
+            x.k_out = k_eff;
+        };
+        if (anchor) {
+            set_rescore(sa);
+            sa.anchor_unit = unit;
+        }
         FSGPU_HIP(launch_select(sa, (int)QP, stream));
         // stage B: the B sample's rows at or above tau, one short list per (query, block) -> tighter tau; the rows
         // still at or above it form the pool carried into the last selection
@@ -1443,7 +1464,12 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
             if (!skip_b) {
                 sb.tau_out = tau;
                 sb.pool_out = pool;
+                if (anchor) {
+                    set_rescore(sb);
+                    sb.anchor_unit = unit;
+                }
                 FSGPU_HIP(launch_select(sb, (int)QP, stream));
+                sb.anchor_unit = nullptr;
             } else {
                 a.group_stride = 1;  // nothing was sampled by a stage B: the main pass visits every group
                 a.group_count = 0;

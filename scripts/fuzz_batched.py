@@ -73,6 +73,13 @@ while time.time() < t_end:
             if not (np.array_equal(bc[sl], ec) and np.array_equal(br[sl], er) and
                     np.array_equal(bs[sl].view(np.uint32), es.view(np.uint32))):
                 ok = False
+                for qi in range(sl.start, sl.stop):
+                    j0 = qi - sl.start
+                    if not (bc[qi] == ec[j0] and np.array_equal(br[qi], er[j0]) and np.array_equal(bs[qi].view(np.uint32), es[j0].view(np.uint32))):
+                        bad_at = np.nonzero(br[qi] != er[j0])[0]
+                        print(f"  filter={filt} query={qi} counts {bc[qi]} vs {ec[j0]} first differing rank {bad_at[:3]} got {br[qi][bad_at[:3]]} "
+                              f"{bs[qi][bad_at[:3]]} want {er[j0][bad_at[:3]]} {es[j0][bad_at[:3]]}", flush=True)
+                        break
     st = idx.batched_filter_stats()
     tot_q += st["int8_queries"]
     tot_r += st["refiltered_f16"]
@@ -95,6 +102,9 @@ while time.time() < t_end:
     cases += 1
     if not ok:
         bad += 1
+        if os.environ.get("FUZZ_DUMP_DIR"):
+            np.savez_compressed(os.path.join(os.environ["FUZZ_DUMP_DIR"], f"fuzz_fail_{seed}_{cases}.npz"), slab=slab, q=q, k=k,
+                                live=live if live is not None else np.zeros(0, bool), allow=allow if allow is not None else np.zeros(0, bool))
         print(f"MISMATCH seed={seed} case={cases} dim={dim} n={n} kind={kind} nq={nq} k={k} live={live is not None} allow={allow is not None} fb={fb}", flush=True)
     idx.close()
 print(f"seed={seed}: {cases} cases, {bad} mismatches; int8 filter took {tot_q} queries, handed {tot_r} on to the f16 filter")

@@ -207,3 +207,30 @@ def test_automatic_choice_leaves_the_int8_filter_when_its_margin_does_not_separa
     orow, osc = oracle.search_top_k(slab, q[0], k)
     assert np.array_equal(br[0], orow) and np.array_equal(bits(bs[0]), bits(osc))
     idx.close()
+
+
+def test_rows_next_to_a_nan_row_keep_their_place(fa, oracle):
+    """A row with a NaN element scores NaN and ranks last (score_key, search.rs:1655-1686) — its NEIGHBOURS must not be affected.
+    (Found by scripts/fuzz_batched.py once it drew slabs with non-finite values: the LDS-query kernel rejected a lane's four rows
+    together when the second of them scored NaN — `a > NaN ? a : NaN` — so the best hits next to a poisoned row went missing on
+    the f16 filter.)  The planted NaN rows sit at every position of a four-row group, right next to each query's best hits."""
+    rng = np.random.default_rng(61)
+    n, dim, k = 60_000, 128, 10
+    rows = unit_rows(rng, n, dim)
+    targets = np.array([4000, 8001, 12002, 16003, 20004, 24005, 28006, 32007], dtype=np.int64)   # all residues mod 4 (and mod 16)
+    q = np.tile(rows[targets], (40, 1))[:300] + (0.05 * rng.standard_normal((300, dim))).astype(np.float32) / np.sqrt(dim)
+    slab = rows.astype(np.float16).view(np.uint16).copy()
+    for t in targets:                      # poison the rows around each target, never the target itself
+        for off in (-2, -1, 1, 2):
+            slab[t + off, int(rng.integers(0, dim))] = 0x7e00
+    idx = fa.VectorIndex.from_slab(slab)
+    for nq in (70, 128, 300):              # 64-query, 128-query and wide main passes
+        er, es, ec = [np.concatenate(z) for z in zip(*[idx.search_batch(q[s:min(s + 64, nq)], k) for s in range(0, nq, 64)])]
+        assert all(int(er[i, 0]) == int(targets[i % 8]) for i in range(nq))      # the target is the best hit (exact kernels)
+        for filt in (1, 2):
+            idx.set_batched_filter(filt)
+            br, bs, bc, fb = idx.search_batched(q[:nq], k)
+            assert np.array_equal(bc, ec) and np.array_equal(br, er) and np.array_equal(bits(bs), bits(es)), (nq, filt)
+    orow, osc = oracle.search_top_k(slab, q[3], k)
+    assert np.array_equal(br[3], orow) and np.array_equal(bits(bs[3]), bits(osc))
+    idx.close()
