@@ -51,6 +51,7 @@ SIGNATURES = {
     "fsgpu_index_dimension": (_u32, [_vp]),
     "fsgpu_index_set_hreduce": (_i32, [_vp, _i32]),
     "fsgpu_index_set_batched_filter": (_i32, [_vp, _i32]),
+    "fsgpu_index_set_int8_latency": (_i32, [_vp, _i32]),
     "fsgpu_index_batched_filter_stats": (_i32, [_vp, _vp, _vp, _vp]),
     "fsgpu_index_int8_filter_bound": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp]),
     "fsgpu_index_doc_id": (_i32, [_vp, _u32, C.POINTER(_vp), C.POINTER(_u32)]),

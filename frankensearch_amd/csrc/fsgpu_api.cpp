@@ -282,6 +282,14 @@ fsgpu_status fsgpu_index_set_batched_filter(fsgpu_index* idx, int32_t filter) {
     return FSGPU_OK;
 }
 
+fsgpu_status fsgpu_index_set_int8_latency(fsgpu_index* idx, int32_t enabled) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    std::unique_lock<std::shared_mutex> state(idx->state_mu);
+    std::lock_guard<std::mutex> lock(idx->impl.mutex());
+    idx->impl.int8_latency = enabled != 0;
+    return FSGPU_OK;
+}
+
 fsgpu_status fsgpu_index_batched_filter_stats(fsgpu_index* idx, uint64_t* int8_queries, uint64_t* refiltered_f16,
                                               int32_t* int8_active) {
     if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");

@@ -52,6 +52,9 @@ SyncTwoTierSearcher::SyncTwoTierSearcher(fsgpu_index* fast, fsgpu_index* quality
     : fast_(fast), quality_(quality), m2v_(fast_embedder), bert_(quality_embedder), cfg_(cfg) {
     fast_dim_ = fsgpu_index_dimension(fast_);
     quality_dim_ = fsgpu_index_dimension(quality_);
+    // the quality tier's exact search is phase 1's longest leg (one HBM pass over the f16 slab): a lone caller's query goes
+    // through the int8 filter + exact re-score instead — the same hits from half the bytes (fsgpu.h)
+    (void)fsgpu_index_set_int8_latency(quality_, 1);
 }
 
 // VectorIndex::search_top_k -> Vec<VectorHit> with doc ids resolved (search.rs:192-206, 1503-1558).

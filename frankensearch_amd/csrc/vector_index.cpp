@@ -932,8 +932,18 @@ SearchError VectorIndex::search_top_k(const float* queries, uint32_t nq, uint32_
         uint32_t* counts_pin = reinterpret_cast<uint32_t*>(scores_pin + (size_t)nq * k);
         std::memcpy(q_pin, queries, qbytes);
         FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, q_pin, qbytes, hipMemcpyHostToDevice, stream_));
-        FSGPU_TRY(search_top_k_device(static_cast<const float*>(ws_queries_.ptr), nq, query_len, k, nullptr, rows_pin,
-                                      scores_pin, counts_pin, stream_));
+        // opted in (fsgpu_index_set_int8_latency): the same hits through the int8 filter + exact re-score — half the bytes of the
+        // exact kernel's pass; anything that path does not cover falls through to the exact kernels inside it
+        const bool via_filter = int8_latency && batched_filter != 1 && !i8f_disabled_ && k <= 64 && nq <= 16 && !f32_ &&
+                                !(row_stride_ && row_stride_ != dim_ * 2) && nrows_ >= 4 * 8192ull;
+        if (via_filter) {
+            uint32_t fb = 0;
+            FSGPU_TRY(search_top_k_batched_device(static_cast<const float*>(ws_queries_.ptr), nq, query_len, k, nullptr, rows_pin,
+                                                  scores_pin, counts_pin, stream_, &fb));
+        } else {
+            FSGPU_TRY(search_top_k_device(static_cast<const float*>(ws_queries_.ptr), nq, query_len, k, nullptr, rows_pin,
+                                          scores_pin, counts_pin, stream_));
+        }
         FSGPU_HIP(hipStreamSynchronize(stream_));
         std::memcpy(out_rows, rows_pin, (size_t)nq * k * 4);
         std::memcpy(out_scores, scores_pin, (size_t)nq * k * 4);
@@ -1032,7 +1042,9 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
     const bool strided = row_stride_ && row_stride_ != dim_ * 2;
     bool i8f = batched_filter != 1 && (batched_filter == 2 || !i8f_disabled_) && !f32_ && !strided && variant == 0 && knobs().filter != 1 &&
                scan_mfma_supported((int)dim_) && k >= 1 && k <= 64 && nrows_ >= 4 * 8192ull;
-    if (batched_filter == 0 && knobs().filter == 0 && nq < 16) i8f = false;  // a few queries: the exact kernels' territory anyway
+    // a few queries are not worth BUILDING the int8 copy for; once it exists (or the host asked for the int8 latency path) they
+    // are answered from it too: one query 0.88 ms against 1.29 ms on the exact kernel at 10M x 384
+    if (batched_filter == 0 && knobs().filter == 0 && nq < 16 && !(i8_ready_ && i8_stats_ready_) && !int8_latency) i8f = false;
     if (i8f && !i8_ready_ && batched_filter != 2) {
         // the int8 copy of the slab (half its size again) is built on first use; no room for it: the f16 filter needs none
         FSGPU_HIP(hipSetDevice(device_));

@@ -131,6 +131,8 @@ class VectorIndex {
     bool profiling = false;
     // filter of the exact batched search (fsgpu_index_set_batched_filter): 0 = automatic, 1 = f16 slab, 2 = int8 slab
     int32_t batched_filter = 0;
+    // fsgpu_index_set_int8_latency: unfiltered fsgpu_search_topk calls of a few queries go through the int8 filter too
+    bool int8_latency = false;
     uint64_t i8f_queries = 0, i8f_refiltered = 0;  // queries the int8 filter took / handed on to the f16 filter
     bool int8_filter_active() const { return batched_filter == 2 || (batched_filter == 0 && !i8f_disabled_); }
     // The certificate of the int8 filter, for inspection: per query the bound delta on |int8 score - exact score x slab scale

@@ -122,6 +122,10 @@ class VectorIndex:
         """0 = automatic, 1 = f16 slab, 2 = int8 slab as the filter of search_batched (results identical either way)."""
         check(_lib.lib().fsgpu_index_set_batched_filter(self._h, filter))
 
+    def set_int8_latency(self, enabled: bool) -> None:
+        """Unfiltered search_batch calls of a few queries go through the int8 filter + exact re-score (same hits, half the bytes)."""
+        check(_lib.lib().fsgpu_index_set_int8_latency(self._h, int(enabled)))
+
     def int8_filter_bound(self, queries: np.ndarray, want_slab: bool = False):
         """(delta[nq], query_scale[nq], slab_scale, queries_i8[nq, dim], slab_i8 or None): the int8 filter's certificate."""
         q = np.ascontiguousarray(queries, dtype=np.float32)

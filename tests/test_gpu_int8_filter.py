@@ -234,3 +234,43 @@ def test_rows_next_to_a_nan_row_keep_their_place(fa, oracle):
     orow, osc = oracle.search_top_k(slab, q[3], k)
     assert np.array_equal(br[3], orow) and np.array_equal(bits(bs[3]), bits(osc))
     idx.close()
+
+
+def test_int8_latency_path_returns_the_exact_kernels_answers(fa, oracle):
+    """fsgpu_index_set_int8_latency: few-query fsgpu_search_topk calls through the int8 filter + exact re-score — every output
+    word (rows, score bits, counts, padding) as the exact kernels give it, incl. queries the filter cannot certify, k above the
+    number of live rows, and a filtered call (which keeps the exact path)."""
+    rng = np.random.default_rng(77)
+    n, dim = 90_000, 384
+    rows = unit_rows(rng, n, dim)
+    slab = rows.astype(np.float16).view(np.uint16)
+    live = np.zeros(n, bool)
+    live[rng.choice(n, 40_000, replace=False)] = True
+    q = rows[rng.integers(0, n, 16)] + (0.2 * rng.standard_normal((16, dim))).astype(np.float32)
+    q[1] = 0.0
+    q[2, 7] = np.nan
+    q[3] *= 250.0
+    a, b = fa.VectorIndex.from_slab(slab, live=live), fa.VectorIndex.from_slab(slab, live=live)
+    b.set_int8_latency(True)
+    for nq in (1, 3, 16):
+        for k in (1, 10, 64):
+            ra, sa, ca = a.search_batch(q[:nq], k)
+            rb, sb, cb = b.search_batch(q[:nq], k)
+            assert np.array_equal(ca, cb) and np.array_equal(ra, rb) and np.array_equal(bits(sa), bits(sb)), (nq, k)
+    assert b.batched_filter_stats()["int8_queries"] > 0          # it did take the filter path
+    allow = rng.random(n) > 0.5
+    ra, sa, ca = a.search_batch(q[:4], 10, allow=allow)
+    rb, sb, cb = b.search_batch(q[:4], 10, allow=allow)
+    assert np.array_equal(ra, rb) and np.array_equal(bits(sa), bits(sb))
+    orow, osc = oracle.search_top_k(slab, q[5], 10, live=live)
+    rb, sb, cb = b.search_batch(q[5], 10)
+    assert np.array_equal(rb[0], orow) and np.array_equal(bits(sb[0]), bits(osc))
+    sparse_live = np.zeros(n, bool)
+    sparse_live[:7] = True                                          # 7 live rows, k = 10: counts and padding
+    c, d = fa.VectorIndex.from_slab(slab, live=sparse_live), fa.VectorIndex.from_slab(slab, live=sparse_live)
+    d.set_int8_latency(True)
+    rc, sc, cc = c.search_batch(q[:2], 10)
+    rd, sd, cd = d.search_batch(q[:2], 10)
+    assert cc.tolist() == [7, 7] and np.array_equal(cc, cd) and np.array_equal(rc[:, :7], rd[:, :7]) and np.array_equal(bits(sc[:, :7]), bits(sd[:, :7]))
+    for i in (a, b, c, d):
+        i.close()
