@@ -1,0 +1,15 @@
+#!/bin/bash
+# Copies the summaries of scripts/collect_profiles.sh from gpurun_out/<round>/ (scratch) into profiles/<round>/ (tracked).
+R=${1:-r02}
+SRC=gpurun_out/$R
+DST=profiles/$R
+mkdir -p $DST
+cp $SRC/bench_*.json $SRC/host_cpu.txt $SRC/pmc_summary.json $DST/ 2>/dev/null
+rm -f $DST/bench_under_trace.err
+cp $SRC/trace/bench_kernel_stats.csv $DST/bench_kernel_stats.csv
+cp $SRC/trace/bench_domain_stats.csv $DST/bench_domain_stats.csv
+cp $SRC/enc_trace/enc_kernel_stats.csv $DST/encoder_kernel_stats.csv
+grep -E '^(m2v|bert)' $SRC/enc.log > $DST/enc_bench.txt
+cp $SRC/pmc_sq.json $DST/scan_sq_pmc_raw.json
+[ -f $SRC/gputest.log ] && grep -E "passed|failed|real" $SRC/gputest.log > $DST/gputest_summary.txt
+ls $DST
