@@ -1,7 +1,7 @@
 // f32_kernels.hip — Quantization::F32 slabs (FSVI quantization byte 0, crates/frankensearch-index/src/lib.rs:203-208):
 // rows are raw little-endian f32.  F16 is the reference's default and the format every BASELINE config uses; F32 files
-// are served through the general path only (score every row -> radix sort -> top k), which keeps `VectorIndex::open`
-// total over FSVI v1 without a second family of fused kernels.
+// have one fused scan + top-k kernel (scan_topk_f32_kernel, one query per pass, k <= 256, dim % 8 == 0) and the general
+// path (score every row -> radix sort -> top k) for everything else.
 //
 // dot_product_f32_bytes_f32 (simd.rs:581-702): four 8-lane accumulators over groups of 32 elements, separate multiply
 // and add (this file is compiled with -ffp-contract=off like the others), (acc0+acc1)+(acc2+acc3), THEN the leftover
@@ -83,6 +83,124 @@ __global__ __launch_bounds__(256) void dot_rows_f32_kernel(ScanArgs args, const 
         if (args.allow) valid = valid && ((args.allow[row >> 6] >> (row & 63)) & 1ull);
         out_packed[item] = valid ? pack(s, args.row_base + row) : kEmpty;
     }
+}
+
+// Fused scan + top-k over an F32 slab, one query per pass: the f32 counterpart of scan_topk_kernel's runtime-dimension body
+// (scan_kernels.hip) — same lane mapping (a quad per row, 16 rows per wave tile, grid-stride tiles), same threshold-gated wave
+// candidate buffer and block fold, the arithmetic of dot_rows_f32_kernel above.  Writes one best-first list of k entries per
+// block to args.partial; merge_topk_kernel finishes.  dim % 8 == 0.
+template <int KCAP>
+__global__ __launch_bounds__(256) void scan_topk_f32_kernel(ScanArgs args) {
+    constexpr int CAP = 2 * KCAP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int dim = (int)args.dim;
+    float* qs = reinterpret_cast<float*>(smem);                                              // [dim]
+    u64* bufs = reinterpret_cast<u64*>(smem + (((size_t)dim * 4 + 15) & ~(size_t)15));       // [wave][CAP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int a = lane & 3, r = lane >> 2;
+    for (int i = tid; i < dim; i += 256) qs[i] = args.queries[i];
+    __syncthreads();
+    WaveTopK<CAP> tk;
+    tk.init(bufs + (size_t)wave * CAP);
+    u64 thr = 0;
+    const uint32_t nrows = args.nrows;
+    const uint32_t ntiles = (nrows + kRowsPerTile - 1) / kRowsPerTile;
+    const uint32_t nwaves = gridDim.x * kWavesPerBlock;
+    const unsigned char* slab = reinterpret_cast<const unsigned char*>(args.slab);
+    const size_t row_bytes = args.row_stride;
+    const bool vec = (args.row_stride & 15u) == 0;
+    const int k = (int)args.k;
+    const int chunks = dim >> 3, groups = chunks >> 2;
+    for (uint32_t tile = blockIdx.x * kWavesPerBlock + wave; tile < ntiles; tile += nwaves) {
+        const uint32_t row = tile * kRowsPerTile + r;
+        const uint32_t rowc = row < nrows ? row : nrows - 1;
+        const float* w = reinterpret_cast<const float*>(slab + (size_t)rowc * row_bytes);
+        const uint32_t w64 = (tile * kRowsPerTile) >> 6;
+        const u64 live_word = args.live ? args.live[w64] : ~0ull;
+        const u64 allow_word = args.allow ? args.allow[w64] : ~0ull;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll 4
+        for (int g = 0; g < groups; ++g) {
+            const int e = 32 * g + 8 * a;
+            float x[8];
+            if (vec) {
+                const float4 lo = *reinterpret_cast<const float4*>(w + e), hi = *reinterpret_cast<const float4*>(w + e + 4);
+                x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w;
+                x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = w[e + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float p = x[j] * qs[e + j];
+                acc[j] = acc[j] + p;
+            }
+        }
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float u = acc[j] + quad_xor1(acc[j]);
+            v[j] = u + quad_xor2(u);
+        }
+        for (int c = 4 * groups; c < chunks; ++c)   // leftover chunks join AFTER the combine (simd.rs:581-702)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float p = w[8 * c + j] * qs[8 * c + j];
+                v[j] = v[j] + p;
+            }
+        const float score = hreduce8(v, args.hreduce);
+        const bool valid = row < nrows && ((live_word >> (row & 63)) & 1ull) && ((allow_word >> (row & 63)) & 1ull);
+        const u64 packed = pack(score, args.row_base + row);
+        bool cand = valid && a == 0 && sortkey(packed) > thr;
+        u64 m = __ballot(cand);
+        if (m == 0) continue;
+        if (tk.count + (int)__popcll(m) > CAP) {
+            thr = tk.compact(k, lane);
+            cand = cand && sortkey(packed) > thr;
+            m = __ballot(cand);
+        }
+        if (cand) tk.buf[tk.count + (int)__popcll(m & ((1ull << lane) - 1ull))] = packed;
+        tk.count += (int)__popcll(m);
+    }
+    (void)tk.compact(k, lane);
+    __syncthreads();
+    if (wave == 0) {   // fold the four waves' best-first lists: elementwise max of A[i] and B[KCAP-1-i], re-sort
+        u64* dst = bufs;
+        for (int w = 1; w < kWavesPerBlock; ++w) {
+            const u64* src = bufs + (size_t)w * CAP;
+            for (int i = lane; i < KCAP; i += 64) {
+                const u64 xx = dst[i], yy = src[KCAP - 1 - i];
+                dst[i] = sortkey(xx) >= sortkey(yy) ? xx : yy;
+            }
+            for (int i = KCAP + lane; i < CAP; i += 64) dst[i] = kEmpty;
+            wave_sort_desc<CAP>(dst, lane);
+        }
+        u64* out = args.partial + (size_t)blockIdx.x * k;
+        for (int i = lane; i < k; i += 64) out[i] = dst[i];
+    }
+}
+
+template <int KCAP>
+static hipError_t launch_f32_t(const ScanArgs& args, int grid, hipStream_t stream, int* occupancy) {
+    const size_t lds = (((size_t)args.dim * 4 + 15) & ~(size_t)15) + (size_t)kWavesPerBlock * 2 * KCAP * 8;
+    auto kern = scan_topk_f32_kernel<KCAP>;
+    if (occupancy) {
+        int blocks = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, 256, lds) != hipSuccess || blocks < 1) blocks = 1;
+        *occupancy = blocks;
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, args);
+    return hipGetLastError();
+}
+
+// kcap 64 or 256 (k <= kcap); occupancy != null: only reports the resident blocks per CU
+hipError_t launch_scan_topk_f32(const ScanArgs& args, int kcap, int grid, hipStream_t stream, int* occupancy) {
+    if ((args.dim & 7) || args.dim * 4 > 48 * 1024) return hipErrorInvalidValue;
+    return kcap <= 64 ? launch_f32_t<64>(args, grid, stream, occupancy) : launch_f32_t<256>(args, grid, stream, occupancy);
 }
 
 hipError_t launch_score_rows_f32(const ScanArgs& args, u64* out_packed, int q_index, hipStream_t stream) {

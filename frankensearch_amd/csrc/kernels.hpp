@@ -67,6 +67,8 @@ hipError_t launch_encode_rows_f16(const float* src, const uint32_t* perm, uint64
 hipError_t launch_widen_f16(const unsigned short* src, size_t n, float* dst, hipStream_t stream);
 
 // f32_kernels.hip — Quantization::F32 slabs: every row's packed (score, row) entry, and the gathered dot
+// fused scan + top-k over an F32 slab (one query per pass; lists to args.partial like launch_scan_topk); kcap 64 / 256
+hipError_t launch_scan_topk_f32(const ScanArgs& args, int kcap, int grid, hipStream_t stream, int* occupancy);
 hipError_t launch_score_rows_f32(const ScanArgs& args, u64* out_packed, int q_index, hipStream_t stream);
 hipError_t launch_gather_dot_f32(const ScanArgs& args, const uint32_t* rows, uint32_t n, float* out, hipStream_t stream);
 

@@ -740,9 +740,9 @@ SearchError VectorIndex::fused_search(const float* queries_dev, uint32_t nq, uin
     while (done < nq) {
         const uint32_t left = nq - done;
         // queries per pass: 8 / 4 through the multi-query kernel, else 2 / 1 through the register-resident kernel
-        int pass = left >= 2 ? 2 : 1;
+        int pass = left >= 2 && !f32_ ? 2 : 1;   // (F32 slabs: one fused kernel, one query per pass)
         bool mq = false;
-        if (variant != 3 && variant != 1 && (!row_stride_ || row_stride_ == dim_ * 2)) {
+        if (!f32_ && variant != 3 && variant != 1 && (!row_stride_ || row_stride_ == dim_ * 2)) {
             if (left >= 8 && kcap == 64 && scan_mq_supported((int)dim_, 8, kcap)) {
                 pass = 8;
                 mq = true;
@@ -753,7 +753,11 @@ SearchError VectorIndex::fused_search(const float* queries_dev, uint32_t nq, uin
         }
         if (!mq && left >= 4 && scan_lds_bytes((int)dim_, 4, kcap) <= 150 * 1024 && (variant == 3)) pass = 4;
         int per_cu = 1;
-        if (mq) {
+        if (f32_) {
+            ScanArgs probe = base_args(queries_dev, allow_dev);
+            FSGPU_HIP(launch_scan_topk_f32(probe, kcap, 1, stream, &per_cu));
+            per_cu = std::min(per_cu, 4);
+        } else if (mq) {
             ScanArgs probe = base_args(queries_dev, allow_dev);
             FSGPU_HIP(launch_scan_mq(probe, pass, kcap, 1, stream, &per_cu));
         } else {
@@ -762,7 +766,7 @@ SearchError VectorIndex::fused_search(const float* queries_dev, uint32_t nq, uin
         // strided views (the MRL truncated scan reads a short prefix of every row): the small-dimension kernels fit 8
         // blocks per CU, but that many waves thrash — 4 per CU up to 64 dims and 2 beyond measured best (10M x 384 slab,
         // search_dims 64: 0.57 -> 0.44 ms per query; 32: 0.41 -> 0.33 ms; 128: 0.58 -> 0.55 ms)
-        if (row_stride_ && row_stride_ != dim_ * 2) per_cu = std::min(per_cu, dim_ <= 64 ? 4 : 2);
+        if (!f32_ && row_stride_ && row_stride_ != dim_ * 2) per_cu = std::min(per_cu, dim_ <= 64 ? 4 : 2);
         int grid = num_cus_ * per_cu;
         if (knobs().grid_blocks > 0) grid = knobs().grid_blocks;  // tuning experiments only
         const uint32_t ntiles_pass = (uint32_t)((nrows_ + (16 / pass) - 1) / (16 / pass));
@@ -779,7 +783,8 @@ SearchError VectorIndex::fused_search(const float* queries_dev, uint32_t nq, uin
             FSGPU_HIP(hipEventCreate(&e1));
             FSGPU_HIP(hipEventRecord(e0, stream));
         }
-        if (mq) FSGPU_HIP(launch_scan_mq(a, pass, kcap, grid, stream, nullptr));
+        if (f32_) FSGPU_HIP(launch_scan_topk_f32(a, kcap, grid, stream, nullptr));
+        else if (mq) FSGPU_HIP(launch_scan_mq(a, pass, kcap, grid, stream, nullptr));
         else FSGPU_HIP(launch_scan_topk(a, pass, kcap, grid, stream, variant == 1, variant == 2));
         if (profiling) {
             FSGPU_HIP(hipEventRecord(e1, stream));
@@ -902,7 +907,7 @@ SearchError VectorIndex::search_top_k_device(const float* queries_dev, uint32_t 
         return ok();
     }
     const uint32_t k_eff = (uint64_t)k < nrows_ ? k : (uint32_t)nrows_;
-    if (!f32_ && dim_ % 8 == 0 && k_eff <= 256)
+    if (dim_ % 8 == 0 && k_eff <= 256 && (!f32_ || dim_ <= 8192))
         return fused_search(queries_dev, nq, k, k_eff, allow_dev, out_rows_dev, out_scores_dev, out_counts_dev, nullptr,
                             stream);
     return general_search(queries_dev, nq, k, k_eff, allow_dev, out_rows_dev, out_scores_dev, out_counts_dev, stream);

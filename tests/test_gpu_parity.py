@@ -1016,6 +1016,44 @@ def test_f32_quantized_fsvi_files_open_and_search_like_the_reference(fa, oracle,
 
 
 @pytest.mark.gpu
+def test_f32_fused_scan_at_scale_matches_the_oracle(fa, oracle, tmp_path):
+    # scan_topk_f32_kernel (f32_kernels.hip): the fused scan + top-k of Quantization::F32 slabs — enough rows for every wave
+    # to fill and compact its candidate buffer many times, ties, tombstones, a broad allow mask, k tiers up to the fused
+    # limit (256) and beyond (general path), dims with and without leftover chunks (384 = 12 groups, 136 = 4 groups + 1 chunk)
+    rng = np.random.default_rng(4242)
+    for n, dim in ((120_000, 384), (90_001, 136)):
+        vecs = rng.standard_normal((n, dim)).astype(np.float32)
+        vecs[5000:5040] = vecs[4999]                       # a run of identical rows: the lower row wins
+        vecs[n - 1] = vecs[4999]
+        ids = [f"d{i:06}" for i in range(n)]
+        path = str(tmp_path / f"big{dim}.fsvi")
+        fa.write_fsvi(path, zip(ids, vecs), "emb", "r1", quantization=0)
+        g = fa.VectorIndex.open(path)
+        raw = open(path, "rb").read()
+        off = oracle.Fsvi(path).vectors_offset
+        slab = np.frombuffer(raw[off:], dtype="<f4").reshape(n, dim)   # file order (sorted by doc-id hash), as the index sees it
+        q = rng.standard_normal((5, dim)).astype(np.float32)
+        q[1] = slab[4999] if np.array_equal(slab[4999], slab[5000]) else vecs[4999]
+        allow = rng.random(n) > 0.4
+        for k in (1, 10, 64, 256, 300):
+            rows, scores, counts = g.search_batch(q, k)
+            for qi in range(5):
+                er, es = oracle.search_top_k_f32(slab, q[qi], k)
+                m = int(counts[qi])
+                assert m == len(er) and np.array_equal(rows[qi, :m], er) and np.array_equal(bits(scores[qi, :m]), bits(es)), (dim, k, qi)
+        rows, scores, counts = g.search_batch(q, 10, allow=allow)
+        for qi in range(5):
+            er, es = oracle.search_top_k_f32(slab, q[qi], 10, live=allow)
+            assert np.array_equal(rows[qi, :10], er) and np.array_equal(bits(scores[qi, :10]), bits(es)), (dim, qi)
+        g.set_hreduce(2)
+        rows, scores, counts = g.search_batch(q[:2], 10)
+        for qi in range(2):
+            er, es = oracle.search_top_k_f32(slab, q[qi], 10, hreduce=2)
+            assert np.array_equal(rows[qi, :10], er) and np.array_equal(bits(scores[qi, :10]), bits(es)), (dim, qi)
+        g.close()
+
+
+@pytest.mark.gpu
 def test_mrl_search_on_an_f32_index(fa, oracle, tmp_path):
     # mrl.rs:1700-1740 (mrl_search_f32_quantization): 16 dims, scan 8
     p = str(tmp_path / "m.fsvi")
