@@ -133,6 +133,10 @@ struct SelectArgs {
     // tau_out = max(a_k - 2 delta, S_k * anchor_unit[q] - delta), S_k = the k-th best EXACT score among them — k real rows score
     // at least S_k, so every true top-k row's approximate score is at least S_k in filter units minus ONE delta
     const float* anchor_unit;  // [nq] filter-score units per exact-score unit (slab scale x query scale); null = off
+    uint32_t big_pool;         // finish step: re-score up to 8,192 candidates per query (sorted variant) instead of kSelectPool
+    uint32_t* pool_flag;       // [nq] device memory (may be null).  big_pool == 0: a query with more than kSelectPool candidates
+                               // sets its flag INSTEAD of `overflow`; big_pool != 0: only flagged queries are processed (second
+                               // chance of the finish, launched right behind the first over the same lists)
     // finish step
     const void* slab;          // [nrows, dim] f16
     const float* queries;      // [nq, q_stride_f] f32 (the first dim of each are used)

@@ -381,6 +381,7 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
     __shared__ float s_tau;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
+    if (args.big_pool && args.pool_flag && args.pool_flag[q] == 0) return;   // second chance: only the queries the first finish flagged
     const int k = (int)args.k;
     const u64* in = args.lists + (size_t)q * args.q_stride;
     const uint32_t lists32 = args.nlists * args.list_len;
@@ -520,9 +521,14 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
         }
         ncand = s_count;
     }
+    // big pool (sorted variant's finish): the candidates stay in the sort buffer — up to kSelSortCap of them are re-scored
+    // exactly instead of POOL (a tight cluster puts thousands of rows inside the int8 filter's margin)
+    const bool big = FINISH && SORTED && args.big_pool != 0 && !args.take_topk;
+    const int pool_cap = big ? kSelSortCap : POOL;
     if (tid == 0) {
         if (args.cand_counts) args.cand_counts[q] = (uint32_t)ncand;
-        if (ncand > POOL && args.overflow) args.overflow[q] = 1;
+        if (!big && args.pool_flag) args.pool_flag[q] = ncand > pool_cap ? 1u : 0u;   // ... the big-pool launch behind this one takes it
+        else if (ncand > pool_cap && args.overflow) args.overflow[q] = 1;
     }
     if (args.pool_out) args.pool_out[(size_t)q * POOL + tid] = pool[tid];
     if constexpr (FINISH) {
@@ -530,13 +536,14 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
         // 256 candidates per sweep; the entry is replaced by its exact counterpart in place
         const int dim = (int)args.dim;
         const int a = tid & 3;
-        const int nc = ncand < POOL ? ncand : POOL;
+        const int nc = ncand < pool_cap ? ncand : pool_cap;
+        u64* cbuf = big ? sbuf : pool;   // (big: sbuf[0, ncand) are the candidates, best approximate score first)
         const float* qv = args.queries + (size_t)q * (args.query_stride ? args.query_stride : (uint32_t)dim);
         const size_t row_pitch = args.row_stride ? (size_t)args.row_stride : (size_t)dim * 2;
         const int chunks = dim >> 3, groups = chunks >> 2, leftover = chunks & 3;
         for (int c0 = 0; c0 < nc; c0 += NT / 4) {  // block-uniform trip count
             const int c = c0 + (tid >> 2);
-            const u64 mine_e = c < nc ? pool[c] : kEmpty;
+            const u64 mine_e = c < nc ? cbuf[c] : kEmpty;
             const uint32_t grow = (uint32_t)mine_e;
             uint32_t row = grow - args.row_base;
             const bool mine = mine_e != kEmpty && row < args.nrows;
@@ -557,16 +564,25 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
                     chunk_mac(acc, w, qp[0], qp[1]);
                 }
             const float sc = quad_finish(acc, args.hreduce);
-            if (a == 0 && c < nc) pool[c] = mine ? pack(sc, grow) : kEmpty;  // only this quad touches pool[c]
+            if (a == 0 && c < nc) cbuf[c] = mine ? pack(sc, grow) : kEmpty;  // only this quad touches its entry
         }
         __syncthreads();
         const int ko = (int)args.k_out;
-        u64 e3[1];
-        e3[0] = pool[tid];
-        wave_select_pass<1, 1>(e3, ko, nullptr, win[0] + wave * ko, lane);
+        if (big) {
+            // the exact entries, sorted again: the first k_out are the answer
+            int np = 64;
+            while (np < nc) np <<= 1;
+            for (int j = nc + tid; j < np; j += NT) sbuf[j] = kEmpty;
+            block_sort_desc_rt<NT>(sbuf, np, tid);
+            if (tid < 64) top[tid] = tid < ko && tid < np ? sbuf[tid] : kEmpty;
+        } else {
+            u64 e3[1];
+            e3[0] = pool[tid];
+            wave_select_pass<1, 1>(e3, ko, nullptr, win[0] + wave * ko, lane);
+        }
         __syncthreads();
         if (wave == 0) {
-            merge_wave_winners<1>(win[0], ko, top, lane);
+            if (!big) merge_wave_winners<1>(win[0], ko, top, lane);
             if (args.anchor_unit && args.tau_out && lane == 0) {
                 // the k-th best exact score among real rows is a lower bound on the final k-th best; in filter units, minus one
                 // delta (and the rounding of the product), it bounds every true top-k row's approximate score from below
@@ -895,7 +911,7 @@ hipError_t launch_select(const SelectArgs& args, int nq, hipStream_t stream) {
         const char* e = std::getenv("FSGPU_SELECT_SORT_ABOVE");  // tuning experiments only
         return e ? std::atoi(e) : 32;
     }();
-    const bool sorted = (int)args.k > sort_above || args.k > 64;
+    const bool sorted = (int)args.k > sort_above || args.k > 64 || (args.big_pool && args.slab && !args.take_topk);
     constexpr size_t sort_lds = (size_t)kSelSortCap * 8;
     static bool attr_done = false;
     if (!attr_done) {  // 64 KB of dynamic LDS on top of the static arrays needs the opt-in

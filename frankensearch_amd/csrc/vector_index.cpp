@@ -51,6 +51,7 @@ struct Knobs {
     int wide_max = 0;   // FSGPU_WIDE_MAX: cap on the query tiles per wave of the wide main pass (default: what the registers hold)
     int i8f_growth = 0; // FSGPU_I8F_GROWTH: sample growth factor of the int8 filter (default 4)
     bool no_skip_b = false, use_160 = false, debug_batched = false, no_reverse = false, no_wide_b = false, no_anchor = false;
+    bool no_big_pool = false;
     Knobs() {
         auto num = [](const char* name) {
             const char* e = std::getenv(name);
@@ -72,6 +73,7 @@ struct Knobs {
         no_skip_b = std::getenv("FSGPU_NO_SKIP_B") != nullptr;
         no_wide_b = std::getenv("FSGPU_NO_WIDE_B") != nullptr;
         no_anchor = std::getenv("FSGPU_NO_ANCHOR") != nullptr;
+        no_big_pool = std::getenv("FSGPU_NO_BIG_POOL") != nullptr;
         no_reverse = std::getenv("FSGPU_NO_REVERSE") != nullptr;
         use_160 = std::getenv("FSGPU_USE_160") != nullptr;
         debug_batched = std::getenv("FSGPU_DEBUG_BATCHED") != nullptr;
@@ -1270,7 +1272,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     const uint32_t QCAP = std::min<uint32_t>(round_cap, std::max<uint32_t>(GMAX, (nq + 127) / 128 * 128));
     FSGPU_TRY(mf_qh_.reserve((size_t)QCAP * dim_ * 2));
     FSGPU_TRY(mf_delta_.reserve(QCAP * 4));
-    FSGPU_TRY(mf_tau_.reserve(QCAP * 8));
+    FSGPU_TRY(mf_tau_.reserve(QCAP * 12));
     FSGPU_TRY(mf_spill_.reserve((size_t)QCAP * SPILL * 8 + (size_t)QCAP * kMfmaSpillCountStride * 4));
     FSGPU_TRY(mf_dense_.reserve((size_t)QCAP * RA_MAX * 8));
     FSGPU_TRY(mf_sel_.reserve((size_t)QCAP * KC * 8));
@@ -1318,10 +1320,12 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     float* delta = static_cast<float*>(mf_delta_.ptr);
     float* tau = static_cast<float*>(mf_tau_.ptr);
     float* unit = tau + QCAP;   // int8 filter: integer-score units per exact-score unit, per query
+    uint32_t* pool_flag = reinterpret_cast<uint32_t*>(unit + QCAP);   // finish: candidates did not fit the pool (per query of the round)
     u64* spill = static_cast<u64*>(mf_spill_.ptr);
     uint32_t* spill_count = reinterpret_cast<uint32_t*>(spill + (size_t)QCAP * SPILL);
     u64* pool = static_cast<u64*>(mf_sel_.ptr);
     const uint32_t k_eff = std::min<uint32_t>(k, N);
+    bool sb_big_pool_last = false;
     for (uint32_t g0 = 0; g0 < nq;) {
         const uint32_t left = nq - g0;
         // Main pass at 384 / 256 queries per launch (mfma_wide.hip: queries in registers, row tiles through an LDS-DMA
@@ -1543,6 +1547,11 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         // finish: every row whose approximate score is within 2 delta of the k-th best (more than KC of them: the
         // query goes to the exact path) is re-scored in the reference's order; the best k exact entries are the answer
         sb.cand_counts = cand_counts;
+        // the int8 filter's margin (and whatever it hands on to the f16 filter) can put thousands of rows within reach of the k-th
+        // score: the finish re-scores up to 8,192 of them per query instead of 1,024
+        const bool second_chance = (i8f || hard_batch_) && !knobs().no_big_pool;
+        sb_big_pool_last = second_chance;
+        sb.pool_flag = second_chance ? pool_flag : nullptr;
         sb.slab = slab_dev_;
         sb.queries = qg;
         sb.dim = dim_;
@@ -1558,6 +1567,10 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         sb.out_counts = out_counts_dev ? out_counts_dev + g0 : nullptr;
         sb.out_packed = out_packed_dev ? reinterpret_cast<u64*>(out_packed_dev) + (size_t)g0 * k : nullptr;
         FSGPU_HIP(launch_select(sb, (int)ng, stream));
+        if (second_chance) {   // queries whose candidates did not fit the pool: the sorted finish over the same lists (others return at once)
+            sb.big_pool = 1;
+            FSGPU_HIP(launch_select(sb, (int)ng, stream));
+        }
         g0 += ng;
     }
     // fallback decision on the host: margin/capacity overflow, or fewer than k candidates
@@ -1568,7 +1581,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     if (knobs().debug_batched) {
         uint32_t big = 0, slot = 0, few = 0, mx = 0;
         for (uint32_t i = 0; i < nq; ++i) {
-            if (counts_all[i] > KC) ++big;
+            if (counts_all[i] > (sb_big_pool_last ? 8192u : KC)) ++big;
             else if (overflow_all[i]) ++slot;
             if (counts_all[i] < k_eff) ++few;
             mx = std::max(mx, counts_all[i]);
@@ -1617,8 +1630,11 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
             // rows within the int8 margin of the k-th best did not fit the lists (or the query cannot be certified on the int8
             // slab at all): the f16 filter, whose margin is ~20 x narrower, answers these as a batch of its own
             uint32_t inner_fb = 0;
-            FSGPU_TRY(batched_impl(q_dev, (uint32_t)nf, query_len, k, allow_dev, rows_dev, scores_dev, counts_dev, stream, &inner_fb,
-                                   nullptr, 0, 0, false, nullptr));
+            hard_batch_ = true;
+            const SearchError inner = batched_impl(q_dev, (uint32_t)nf, query_len, k, allow_dev, rows_dev, scores_dev, counts_dev, stream,
+                                                   &inner_fb, nullptr, 0, 0, false, nullptr);
+            hard_batch_ = false;
+            FSGPU_TRY(inner);
             if (refiltered) *refiltered = (uint32_t)nf;
             if (fallbacks) *fallbacks = inner_fb;
             FSGPU_HIP(launch_scatter_hits(idx_dev, (uint32_t)nf, k, rows_dev, scores_dev, counts_dev, out_rows_dev,

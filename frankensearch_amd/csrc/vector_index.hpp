@@ -193,6 +193,7 @@ class VectorIndex {
         ws_cand_rows_, ws_cand_scores_, mf_max_norm_, mf_qh_, mf_delta_, mf_tau_, mf_cand_, mf_dense_, mf_sel_,
         mf_fallback_, mf_fallback2_, mf_spill_, mf_io_, i8_stats_, n4u_slab_;
     bool i8_ready_ = false, n4_ready_ = false, i8_stats_ready_ = false, n4u_ready_ = false;
+    bool hard_batch_ = false;     // the batch in flight is the int8 filter's leftovers (nested f16-filter call)
     bool i8f_disabled_ = false;   // the int8 filter left too many queries uncertified on this slab (or its copy does not fit)
     uint32_t i8f_strikes_ = 0;
     bool mf_norm_ready_ = false;

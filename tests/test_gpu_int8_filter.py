@@ -177,36 +177,40 @@ def test_both_filters_emit_the_exact_search_bits_on_ties_filters_and_tombstones(
 
 
 def test_automatic_choice_leaves_the_int8_filter_when_its_margin_does_not_separate(fa, oracle):
-    """6,000 rows whose scores against queries near their centre spread by ~2e-3: twenty times the f16 filter's margin, a
-    fraction of the int8 one's.  The int8 filter cannot cut that cluster down to its candidate pool, hands those queries to
-    the f16 filter (which can), and after two such batches the index stays with the f16 filter."""
+    """Rows whose scores against queries near their centre spread by ~2e-3: twenty times the f16 filter's margin, a fraction of
+    the int8 one's.  A cluster of 6,000 such rows sits entirely inside the int8 margin but inside its finish's reach (8,192
+    candidates re-scored exactly per query): answered on the int8 filter.  A cluster of 20,000 is beyond it: those queries
+    are handed to the f16 filter (which separates them), and after two such batches the index stays with the f16 filter."""
     rng = np.random.default_rng(5)
-    n, dim, k = 100_000, 384, 10
-    rows = unit_rows(rng, n, dim)
+    n, dim, k = 120_000, 384, 10
     base = unit_rows(rng, 1, dim)[0]
-    members = rng.choice(n, 6000, replace=False)
-    rows[members] = base + 0.2 * rng.standard_normal((6000, dim)).astype(np.float32) / np.sqrt(dim)
-    rows[members] /= np.linalg.norm(rows[members], axis=1, keepdims=True)
-    slab = rows.astype(np.float16).view(np.uint16)
-    idx = fa.VectorIndex.from_slab(slab)
     nq = 64
     q = base + 0.2 * rng.standard_normal((nq, dim)).astype(np.float32) / np.sqrt(dim)
-    er, es, ec = idx.search_batch(q, k)
-    assert idx.batched_filter_stats()["int8_active"]
-    for round_ in range(3):
-        br, bs, bc, fb = idx.search_batched(q, k)
-        assert np.array_equal(bc, ec) and np.array_equal(br, er) and np.array_equal(bits(bs), bits(es)), round_
-        assert fb <= 2, fb                           # the f16 filter certifies them: no exact-kernel passes
-    st = idx.batched_filter_stats()
-    assert st["int8_queries"] == 2 * nq and st["refiltered_f16"] > nq and not st["int8_active"], st
-    # pinned to int8 it keeps trying (and keeps handing on): same bits
-    idx.set_batched_filter(2)
-    br, bs, bc, fb = idx.search_batched(q, k)
-    assert np.array_equal(br, er) and np.array_equal(bits(bs), bits(es))
-    assert idx.batched_filter_stats()["int8_queries"] == 3 * nq
-    orow, osc = oracle.search_top_k(slab, q[0], k)
-    assert np.array_equal(br[0], orow) and np.array_equal(bits(bs[0]), bits(osc))
-    idx.close()
+    for members_n, handed_on in ((6000, False), (20_000, True)):
+        rows = unit_rows(rng, n, dim)
+        members = rng.choice(n, members_n, replace=False)
+        rows[members] = base + 0.2 * rng.standard_normal((members_n, dim)).astype(np.float32) / np.sqrt(dim)
+        rows[members] /= np.linalg.norm(rows[members], axis=1, keepdims=True)
+        slab = rows.astype(np.float16).view(np.uint16)
+        idx = fa.VectorIndex.from_slab(slab)
+        er, es, ec = idx.search_batch(q, k)
+        assert idx.batched_filter_stats()["int8_active"]
+        for round_ in range(3):
+            br, bs, bc, fb = idx.search_batched(q, k)
+            assert np.array_equal(bc, ec) and np.array_equal(br, er) and np.array_equal(bits(bs), bits(es)), (members_n, round_)
+            assert fb <= 2, fb                       # certified by one filter or the other: no exact-kernel passes
+        st = idx.batched_filter_stats()
+        if handed_on:
+            assert st["int8_queries"] == 2 * nq and st["refiltered_f16"] > nq and not st["int8_active"], st
+            idx.set_batched_filter(2)                # pinned to int8 it keeps trying (and keeps handing on): same bits
+            br, bs, bc, fb = idx.search_batched(q, k)
+            assert np.array_equal(br, er) and np.array_equal(bits(bs), bits(es))
+            assert idx.batched_filter_stats()["int8_queries"] == 3 * nq
+        else:
+            assert st["int8_queries"] == 3 * nq and st["refiltered_f16"] <= 2 and st["int8_active"], st
+        orow, osc = oracle.search_top_k(slab, q[0], k)
+        assert np.array_equal(br[0], orow) and np.array_equal(bits(bs[0]), bits(osc))
+        idx.close()
 
 
 def test_rows_next_to_a_nan_row_keep_their_place(fa, oracle):

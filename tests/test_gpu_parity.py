@@ -620,7 +620,9 @@ def test_batched_certificate_edges_overflow_subnormals_and_near_duplicates(fa, o
     br, bs, bc, fb = idx.search_batched(q, k)
     er, es, ec = idx.search_batch(q, k)
     assert np.array_equal(bc, ec) and np.array_equal(br, er) and np.array_equal(bits(bs), bits(es))
-    assert fb >= 4, fb                        # q0, q1, q257 (pool overflow) and q2, q3 (f16 overflow) at least
+    # q2, q3 (f16 overflow) at least; on the f16 filter also q0, q1, q257 (its pool of 1,024 overflows — the int8 filter's finish
+    # re-scores up to 8,192 candidates and takes the 6,000 near-duplicates in its stride)
+    assert fb >= (2 if batched_filter == "int8 filter" else 4), fb
     for qi in (0, 2, 3, 4, 5, 6, 257):
         orow, osc = oracle.search_top_k(slab, q[qi], k)
         assert np.array_equal(br[qi], orow) and np.array_equal(bits(bs[qi]), bits(osc)), qi
