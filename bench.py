@@ -206,6 +206,11 @@ def two_tier_section(quality_index, rows: int, k: int, device, local_rank: int):
                                         prefetch_quality_embed=True)
     seq = prefetching.run_load(threads=1, queries=200, warmup_queries=16, k=k, fast_vocab=500_353, corpus_rows=rows)
     prefetching.close()
+    # ... and so does the quality tier's search (nothing in it depends on phase 0): phase 0 later, phase 1 earlier
+    speculative = NativeTwoTierSearcher(fast_index, quality_index, m2v, bert, doc_id_mode=1, fast_tier_int8_multiplier=3,
+                                        prefetch_quality_embed=2)
+    seq_spec = speculative.run_load(threads=1, queries=200, warmup_queries=16, k=k, fast_vocab=500_353, corpus_rows=rows)
+    speculative.close()
     # concurrent callers, coalesced inside the library into batched launches (fsgpu_*_set_coalescing)
     max_batch, wait_us = 128, 1000
     fast_index.set_coalescing(max_batch, wait_us)
@@ -242,6 +247,8 @@ def two_tier_section(quality_index, rows: int, k: int, device, local_rank: int):
         "phase0_p50_ms": seq.phase0_p50_ms,
         "phase1_p50_ms": seq.phase1_p50_ms,
         "sequential_queries_per_sec": seq.queries_per_sec,
+        "sequential_with_quality_search_prefetch": {"phase0_p50_ms": seq_spec.phase0_p50_ms, "phase1_p50_ms": seq_spec.phase1_p50_ms,
+                                                    "queries_per_sec": seq_spec.queries_per_sec},
         "sequential_without_quality_embed_prefetch": {"phase0_p50_ms": seq_plain.phase0_p50_ms,
                                                       "phase1_p50_ms": seq_plain.phase1_p50_ms},
         "sequential_breakdown_ms": {"fast_embed": seq.mean_fast_embed_ms, "fast_search": seq.mean_fast_search_ms,
@@ -729,7 +736,13 @@ def main() -> None:
             line["mrl"] = mrl_section(index, args.rows, args.dim, k, queries)
             tt = two_tier_section(index, args.rows, k, device, local_rank)
             line["two_tier"] = tt
-            line["p50_phase1_latency_ms"] = tt["phase1_p50_ms"]
+            # a lone caller whose host overlaps the quality tier's embedding AND search with phase 0 (fshost_two_tier_config::
+            # prefetch_quality_embed = 2: same results, both scans share the GPU); the same caller with only the embedding
+            # overlapped, or nothing, is in two_tier.phase1_p50_ms / sequential_without_quality_embed_prefetch
+            spec = tt["sequential_with_quality_search_prefetch"]
+            line["p50_phase1_latency_ms"] = spec["phase1_p50_ms"]
+            line["p50_phase0_latency_ms"] = spec["phase0_p50_ms"]
+            line["p50_phase1_latency_policy"] = "quality-tier embedding and search started with the query (prefetch_quality_embed = 2)"
             line["end_to_end_queries_per_sec"] = tt["concurrent_1024_threads"]["queries_per_sec"]
     if world > 1:
         dist.barrier()

@@ -121,8 +121,22 @@ fsgpu_status SyncTwoTierSearcher::search(const uint32_t* fast_ids, uint32_t n_fa
         if (s != FSGPU_OK) quality_err = fsgpu_last_error();  // thread-local: read on the thread that made the call
         return s;
     };
+    // prefetch_quality_embed == 2: the helper goes on to the quality tier's search as well (it depends on nothing phase 0
+    // produces): both tiers' scans then share the GPU, phase 0 is delivered a little later and phase 1 much earlier
+    std::vector<Hit> quality_hits;  // the `Retrieved` pool (sync_searcher.rs:810-813)
+    std::string quality_search_err;
+    bool quality_searched = false;
+    auto embed_and_search_quality = [&]() -> fsgpu_status {
+        fsgpu_status s = embed_quality();
+        if (s != FSGPU_OK) return s;
+        s = tier_hits(quality_, quality_vec, fetch, 0, &quality_hits, &quality_search_err);
+        if (s != FSGPU_OK) quality_err = quality_search_err;
+        quality_searched = s == FSGPU_OK;
+        return s;
+    };
     std::future<fsgpu_status> quality_future;  // declared after what the task touches: joined first on every return path
-    if (cfg_.prefetch_quality_embed) quality_future = std::async(std::launch::async, embed_quality);
+    if (cfg_.prefetch_quality_embed >= 2) quality_future = std::async(std::launch::async, embed_and_search_quality);
+    else if (cfg_.prefetch_quality_embed) quality_future = std::async(std::launch::async, embed_quality);
     // ---- phase 0 / Initial ----
     std::vector<float> fast_vec(fast_dim_);
     const uint32_t fast_off[2] = {0, n_fast};
@@ -158,9 +172,10 @@ fsgpu_status SyncTwoTierSearcher::search(const uint32_t* fast_ids, uint32_t n_fa
     }
     m.quality_embed_ms = ms_since(t3);
     const auto t4 = clock::now();
-    std::vector<Hit> quality_hits;  // the `Retrieved` pool (sync_searcher.rs:810-813)
-    st = tier_hits(quality_, quality_vec, fetch, 0, &quality_hits, detail);
-    if (st != FSGPU_OK) return st;
+    if (!quality_searched) {
+        st = tier_hits(quality_, quality_vec, fetch, 0, &quality_hits, detail);
+        if (st != FSGPU_OK) return st;
+    }
     m.quality_search_ms = ms_since(t4);
     const auto t5 = clock::now();
     const std::vector<fsgpu_scored_doc> quality_view = view(quality_hits);

@@ -30,7 +30,10 @@ typedef struct fshost_two_tier_config {
     int32_t prefetch_quality_embed;     /* != 0: the quality-tier (MiniLM) embedding of the query is started on a helper
                                          * thread when the search begins and joined at the start of phase 1, so it
                                          * overlaps the fast tier's scan (same results; for latency with few callers —
-                                         * with many, coalescing fills the GPU and the extra thread only costs) */
+                                         * with many, coalescing fills the GPU and the extra thread only costs).
+                                         * 2: the helper also runs the quality tier's search (it needs nothing phase 0
+                                         * produces): the two scans share the GPU, phase 0 arrives a little later and
+                                         * phase 1 much earlier */
 } fshost_two_tier_config;
 
 #define FSHOST_DOC_ID_MAX 63
