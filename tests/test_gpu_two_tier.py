@@ -104,7 +104,17 @@ def test_native_host_searcher_equals_python_mirror():
         want = py8.search(fast_ids, qual_ids, 10, lexical)
         ini, fin, _ = eager.search(fast_ids, qual_ids, 10, lexical)
         assert ini == want.initial_results and fin == want.final_results
-    for searcher in (native8, eager):
+    # ... and the quality tier's search as well (prefetch_quality_embed = 2): same results, same error reporting
+    speculative = NativeTwoTierSearcher(fast, qual, m2v, bert, doc_id_mode=1, fast_tier_int8_multiplier=3,
+                                        prefetch_quality_embed=2)
+    for trial in range(4):
+        fast_ids = rng.integers(0, 5000, 12).tolist()
+        qual_ids = [101] + rng.integers(1000, 3000, 9).tolist() + [102]
+        lexical = [(doc(int(r)), float(30 - i)) for i, r in enumerate(rng.choice(n, 30, replace=False))]
+        want = py8.search(fast_ids, qual_ids, 10, lexical)
+        ini, fin, _ = speculative.search(fast_ids, qual_ids, 10, lexical)
+        assert ini == want.initial_results and fin == want.final_results
+    for searcher in (native8, eager, speculative):
         with pytest.raises(Exception) as err:
             searcher.search([1, 2, 3], [101, 10_000_000, 102], 10, [])
         assert str(err.value)
