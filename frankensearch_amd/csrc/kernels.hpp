@@ -133,6 +133,14 @@ struct SelectArgs {
     // tau_out = max(a_k - 2 delta, S_k * anchor_unit[q] - delta), S_k = the k-th best EXACT score among them — k real rows score
     // at least S_k, so every true top-k row's approximate score is at least S_k in filter units minus ONE delta
     const float* anchor_unit;  // [nq] filter-score units per exact-score unit (slab scale x query scale); null = off
+    // A sample stage whose survivors only ANCHOR the next threshold (the wide main pass visits every row anyway) may emit any
+    // subset of rows — k real rows with exact scores bound the final k-th best whichever rows they are: heur_rank != 0 makes
+    // tau_out the approximate score at that rank with NO margin (a few dozen rows of the next, larger sample pass instead of
+    // thousands), tau_floor_out keeps the proven threshold, and the next selection falls back to it (tau_floor_in) when fewer
+    // than k rows came through
+    uint32_t heur_rank;
+    float* tau_floor_out;      // [nq] (may be null)
+    const float* tau_floor_in; // [nq] (may be null)
     uint32_t big_pool;         // finish step: re-score up to 8,192 candidates per query (sorted variant) instead of kSelectPool
     uint32_t* pool_flag;       // [nq] device memory (may be null).  big_pool == 0: a query with more than kSelectPool candidates
                                // sets its flag INSTEAD of `overflow`; big_pool != 0: only flagged queries are processed (second

@@ -448,9 +448,16 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
             } else if (k <= cnt) {
                 t = __uint_as_float((uint32_t)(sbuf[k - 1] >> 32)) - 2.0f * d;
                 if (!(t == t)) t = -INFINITY;
+            } else if (args.tau_floor_in) {
+                t = args.tau_floor_in[q];
             }
             s_tau = t;
             s_count = 0;
+            if (args.tau_floor_out) args.tau_floor_out[q] = t;
+            if (args.heur_rank && d >= 0.f && (int)args.heur_rank <= cnt) {
+                const float th = __uint_as_float((uint32_t)(sbuf[args.heur_rank - 1] >> 32));
+                if (th == th && th > t) t = th;
+            }
             if (args.tau_out) args.tau_out[q] = t;
         }
         __syncthreads();
@@ -484,8 +491,15 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
                 } else if (top[k - 1] != kEmpty) {
                     t = __uint_as_float((uint32_t)(top[k - 1] >> 32)) - 2.0f * d;
                     if (!(t == t)) t = -INFINITY;
+                } else if (args.tau_floor_in) {
+                    t = args.tau_floor_in[q];
                 }
                 s_tau = t;
+                if (args.tau_floor_out) args.tau_floor_out[q] = t;
+                if (args.heur_rank && d >= 0.f && (int)args.heur_rank <= k && top[args.heur_rank - 1] != kEmpty) {
+                    const float th = __uint_as_float((uint32_t)(top[args.heur_rank - 1] >> 32));
+                    if (th == th && th > t) t = th;
+                }
                 if (args.tau_out) args.tau_out[q] = t;
             }
         }

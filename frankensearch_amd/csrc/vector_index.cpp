@@ -51,7 +51,8 @@ struct Knobs {
     int wide_max = 0;   // FSGPU_WIDE_MAX: cap on the query tiles per wave of the wide main pass (default: what the registers hold)
     int i8f_growth = 0; // FSGPU_I8F_GROWTH: sample growth factor of the int8 filter (default 4)
     bool no_skip_b = false, use_160 = false, debug_batched = false, no_reverse = false, no_wide_b = false, no_anchor = false;
-    bool no_big_pool = false;
+    bool no_big_pool = false, no_heur_b = false;
+    int heur_rank = 0;   // FSGPU_HEUR_RANK: rank of the first sample whose score gates the anchoring-only second sample (default 4)
     Knobs() {
         auto num = [](const char* name) {
             const char* e = std::getenv(name);
@@ -74,6 +75,8 @@ struct Knobs {
         no_wide_b = std::getenv("FSGPU_NO_WIDE_B") != nullptr;
         no_anchor = std::getenv("FSGPU_NO_ANCHOR") != nullptr;
         no_big_pool = std::getenv("FSGPU_NO_BIG_POOL") != nullptr;
+        no_heur_b = std::getenv("FSGPU_NO_HEUR_B") != nullptr;
+        heur_rank = num("FSGPU_HEUR_RANK");
         no_reverse = std::getenv("FSGPU_NO_REVERSE") != nullptr;
         use_160 = std::getenv("FSGPU_USE_160") != nullptr;
         debug_batched = std::getenv("FSGPU_DEBUG_BATCHED") != nullptr;
@@ -1272,7 +1275,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     const uint32_t QCAP = std::min<uint32_t>(round_cap, std::max<uint32_t>(GMAX, (nq + 127) / 128 * 128));
     FSGPU_TRY(mf_qh_.reserve((size_t)QCAP * dim_ * 2));
     FSGPU_TRY(mf_delta_.reserve(QCAP * 4));
-    FSGPU_TRY(mf_tau_.reserve(QCAP * 12));
+    FSGPU_TRY(mf_tau_.reserve(QCAP * 16));
     FSGPU_TRY(mf_spill_.reserve((size_t)QCAP * SPILL * 8 + (size_t)QCAP * kMfmaSpillCountStride * 4));
     FSGPU_TRY(mf_dense_.reserve((size_t)QCAP * RA_MAX * 8));
     FSGPU_TRY(mf_sel_.reserve((size_t)QCAP * KC * 8));
@@ -1320,7 +1323,8 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     float* delta = static_cast<float*>(mf_delta_.ptr);
     float* tau = static_cast<float*>(mf_tau_.ptr);
     float* unit = tau + QCAP;   // int8 filter: integer-score units per exact-score unit, per query
-    uint32_t* pool_flag = reinterpret_cast<uint32_t*>(unit + QCAP);   // finish: candidates did not fit the pool (per query of the round)
+    uint32_t* pool_flag = reinterpret_cast<uint32_t*>(unit + QCAP);
+    float* tau_floor = reinterpret_cast<float*>(pool_flag + QCAP);   // the first sample's proven threshold, kept next to a heuristic one   // finish: candidates did not fit the pool (per query of the round)
     u64* spill = static_cast<u64*>(mf_spill_.ptr);
     uint32_t* spill_count = reinterpret_cast<uint32_t*>(spill + (size_t)QCAP * SPILL);
     u64* pool = static_cast<u64*>(mf_sel_.ptr);
@@ -1428,7 +1432,17 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
             x.hreduce = hreduce;
             x.k_out = k_eff;
         };
-        if (anchor) {
+        // (a wide round's second sample only anchors the main pass's threshold — that pass visits every row — so it may take ANY
+        // subset of the sample: the rows above the first sample's ~9th best score WITHOUT a margin, half as many as the proven
+        // threshold lets through, and the first selection needs no exact re-score)
+        const bool heur_b = anchor && wide_qt != 0 && !skip_b && !knobs().no_wide_b && !knobs().no_heur_b && ksel >= 8;
+        if (heur_b) {
+            // rank r of the first sample: the second sample holds RB / RA x as many rows above that score as the first (r, up to
+            // an order statistic's spread ~ Gamma(r)), and k of them are needed — r = 8 + k / 8 puts "fewer than k came through"
+            // (which only costs that query a looser threshold) below 1e-7 per query for k <= 64 and RB / RA >= 48
+            sa.heur_rank = knobs().heur_rank > 0 ? (uint32_t)std::min<int>(knobs().heur_rank, (int)ksel) : std::min<uint32_t>(ksel, 8 + k / 8);
+            sa.tau_floor_out = tau_floor;
+        } else if (anchor) {
             set_rescore(sa);
             sa.anchor_unit = unit;
         }
@@ -1489,8 +1503,10 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
                     set_rescore(sb);
                     sb.anchor_unit = unit;
                 }
+                if (heur_b) sb.tau_floor_in = tau_floor;
                 FSGPU_HIP(launch_select(sb, (int)QP, stream));
                 sb.anchor_unit = nullptr;
+                sb.tau_floor_in = nullptr;
             } else {
                 a.group_stride = 1;  // nothing was sampled by a stage B: the main pass visits every group
                 a.group_count = 0;
