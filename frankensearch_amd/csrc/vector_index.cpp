@@ -1435,12 +1435,13 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         // (a wide round's second sample only anchors the main pass's threshold — that pass visits every row — so it may take ANY
         // subset of the sample: the rows above the first sample's ~9th best score WITHOUT a margin, half as many as the proven
         // threshold lets through, and the first selection needs no exact re-score)
-        const bool heur_b = anchor && wide_qt != 0 && !skip_b && !knobs().no_wide_b && !knobs().no_heur_b && ksel >= 8;
+        // (the int8 two-pass takes the same shortcut: its threshold is the ksel-th best integer score of whatever subset came through)
+        const bool heur_b = (anchor || (i8 && !i8f)) && wide_qt != 0 && !skip_b && !knobs().no_wide_b && !knobs().no_heur_b && ksel >= 8;
         if (heur_b) {
             // rank r of the first sample: the second sample holds RB / RA x as many rows above that score as the first (r, up to
             // an order statistic's spread ~ Gamma(r)), and k of them are needed — r = 8 + k / 8 puts "fewer than k came through"
             // (which only costs that query a looser threshold) below 1e-7 per query for k <= 64 and RB / RA >= 48
-            sa.heur_rank = knobs().heur_rank > 0 ? (uint32_t)std::min<int>(knobs().heur_rank, (int)ksel) : std::min<uint32_t>(ksel, 8 + k / 8);
+            sa.heur_rank = knobs().heur_rank > 0 ? (uint32_t)std::min<int>(knobs().heur_rank, (int)ksel) : std::min<uint32_t>(ksel, 8 + ksel / 8);
             sa.tau_floor_out = tau_floor;
         } else if (anchor) {
             set_rescore(sa);
