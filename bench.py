@@ -641,7 +641,8 @@ def main() -> None:
                 "workload": f"{args.rows}x{args.dim} f16 corpus (clustered unit vectors), exact brute-force cosine "
                             f"top-{k}, {B} queries per step, rows sharded {world} way(s)",
                 "rows": args.rows, "dim": args.dim, "k": k, "queries_per_step": B,
-                "parallelism": f"row-shard x{world}" + (" + all-gather(top-k) over RCCL" if world > 1 else ""),
+                "parallelism": f"row-shard x{world}" + ((" + all-gather(top-k) over RCCL" if backend == "nccl" else
+                                                          f" + all-gather(top-k) over {backend} (single-GPU rehearsal)") if world > 1 else ""),
                 "kernel_variant": args.variant,
                 "path": ("matrix-core batched (" + ("int8 slab filter, proven margin" if int8_filter else "f16 filter, proven margin") +
                          ") + exact re-score") if args.batched else "exact VALU scan",
