@@ -83,6 +83,13 @@ def test_bound_covers_every_row_against_float64_and_the_exact_kernels(fa, oracle
         for i in range(q.shape[0]):
             assert np.array_equal(qi8[i], oracle.quantize_query_i8(q[i])), (name, i)
         assert np.all(delta > 0), (name, delta)       # all of these are certifiable
+        # the kernels' delta is the one oracle/filter_bound.py restates (whose own CPU test checks it against float64)
+        from oracle import filter_bound as fb
+        stats = fb.slab_stats(slab)
+        assert abs(float(stats[0]) - sscale) <= 1e-6 * sscale, name
+        for i in range(q.shape[0]):
+            want = fb.query_bound(q[i], stats, dim)[0]
+            assert abs(float(delta[i]) - want) <= 2e-3 * want + 2.0, (name, i, float(delta[i]), want)
         idot = slab_i8.astype(np.int64) @ qi8.astype(np.int64).T                       # [n, nq], exact
         x64 = slab.view(np.float16).astype(np.float64)
         s64 = x64 @ q.astype(np.float64).T                                             # real-number scores
