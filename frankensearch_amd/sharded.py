@@ -122,11 +122,15 @@ class ShardedVectorIndex:
     i+1 (the batched scan synchronises only its own stream); `search_end` then returns tensors that are complete once the
     returned event has fired."""
 
-    def __init__(self, backend: ShardBackend, group: Optional[dist.ProcessGroup] = None, overlap: bool = False):
+    def __init__(self, backend: ShardBackend, group: Optional[dist.ProcessGroup] = None, overlap: bool = False,
+                 force_collective: bool = False):
         self.backend = backend
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.overlap = overlap
+        # a one-rank group normally skips the all-gather; the single-GPU rehearsal of the N-rank path turns it on so that the
+        # collective (RCCL), the side stream and the merge of the gathered layout all run
+        self.force_collective = force_collective and dist.is_initialized()
         self._side = None
 
     def search_begin(self, queries: torch.Tensor, k: int) -> torch.Tensor:
@@ -134,7 +138,7 @@ class ShardedVectorIndex:
         return self.backend.search_packed(queries, k)
 
     def _gather(self, local: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             return local.unsqueeze(0)
         # dim-0 concatenation form (accepted by both RCCL and gloo), viewed as [W, B, k]
         if local.is_cuda and dist.get_backend(self.group) == "gloo":
@@ -163,7 +167,7 @@ class ShardedVectorIndex:
         return out + (done,)
 
     def search(self, queries: torch.Tensor, k: int):
-        if self.world == 1 and hasattr(self.backend, "search_unsharded"):
+        if self.world == 1 and not self.force_collective and hasattr(self.backend, "search_unsharded"):
             return self.backend.search_unsharded(queries, k)
         local = self.search_begin(queries, k)  # [B, k]
         out = self.search_end(local, k)

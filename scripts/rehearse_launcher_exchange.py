@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Single-GPU rehearsal of the per-rank path of `bench.py --gpus N` with a ONE-rank RCCL process group: shard-local batched
+scan -> all_gather_into_tensor (RCCL) -> merge of the gathered [W, B, k] lists on a side stream underneath the next step's scan.
+Every step's hits must equal the unsharded index's, bit for bit.  Run by tests/test_gpu_sharded.py in a process of its own."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import frankensearch_amd as fa
+from frankensearch_amd.sharded import GpuShardBackend, ShardedVectorIndex
+from oracle import oracle
+
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+if "MASTER_PORT" not in os.environ:
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+    sock.close()
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+device = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+bits = lambda a: np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+n, dim, k, nq = 300_000, 384, 10, 600
+oracle.build()
+slab = oracle.clustered_corpus_f16(0, n, dim)
+q = np.stack([oracle.clustered_query(i, dim) for i in range(nq)])
+whole = fa.VectorIndex.from_slab(slab)
+want = [whole.search_batch(q[s:s + 64], k) for s in range(0, nq, 64)]
+wr = np.concatenate([w[0] for w in want])
+ws = np.concatenate([w[1] for w in want])
+index = fa.VectorIndex.from_slab(slab)
+sharded = ShardedVectorIndex(GpuShardBackend(index, device, batched=True), overlap=True, force_collective=True)
+tq = torch.from_numpy(q).to(device)
+pending, outs = None, []
+for step in range(4):                         # the bench's loop: scan of step i over the exchange of step i - 1
+    local = sharded.search_begin(tq, k)
+    if pending is not None:
+        pending[3].synchronize()
+        outs.append(pending[:3])
+    pending = sharded.search_end(local, k)
+pending[3].synchronize()
+outs.append(pending[:3])
+outs.append(sharded.search(tq, k))            # the blocking form goes through the collective too
+for rows, scores, counts in outs:
+    assert np.array_equal(rows.cpu().numpy().astype(np.uint32), wr), "rows differ"
+    assert np.array_equal(bits(scores.cpu().numpy()), bits(ws)), "score bits differ"
+    assert int(counts.min().item()) == k
+dist.barrier()
+dist.destroy_process_group()
+print("exchange path OK: %d steps over a 1-rank RCCL group equal the unsharded index" % len(outs), flush=True)

@@ -7,6 +7,8 @@ On a one-GPU box the N-way logic is rehearsed with several shards on device 0 (p
 device) and RCCL itself with a 1-rank communicator; with >= 2 GPUs visible the real all-gather runs over
 min(visible, 8) devices.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -117,6 +119,20 @@ def test_rccl_all_gather_over_the_visible_devices(fa, oracle):
     idx.close()
     with pytest.raises(fa.InvalidConfig):
         fa.NativeShardedIndex.from_slab(slab, [0, 0], exchange=fa.NativeShardedIndex.EXCHANGE_RCCL)  # one rank per device
+
+
+def test_torch_rccl_group_of_one_rank_runs_the_launcher_exchange_path(fa):
+    """What `bench.py --gpus N` does on every rank, rehearsed with a ONE-rank RCCL process group (all this box has): the
+    shard-local batched scan, `all_gather_into_tensor` over RCCL and the merge of the gathered [W, B, k] layout on a side stream
+    underneath the next step's scan (search_begin / search_end), results equal to the unsharded index bit for bit.  In a process
+    of its own (scripts/rehearse_launcher_exchange.py): torch's process group and the library's own communicators are not mixed."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    res = subprocess.run([sys.executable, os.path.join(root, "scripts", "rehearse_launcher_exchange.py")], capture_output=True,
+                         text=True, timeout=600, env=env)
+    assert res.returncode == 0 and "exchange path OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
 
 
 def test_multi_gpu_matches_unsharded_bit_for_bit(fa, oracle):
