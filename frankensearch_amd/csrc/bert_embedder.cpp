@@ -40,7 +40,7 @@ NativeEmbedder::~NativeEmbedder() {
                             &qkv_f32_, &ctx_h_, &tmp_f32_, &inter_h_, &out_, &q_x_, &q_parts_})
         b->release();
     for (Layer& l : layers_)
-        for (DeviceBuffer* b : {&l.qkv_w, &l.ao_w, &l.i_w, &l.o_w, &l.qkv_b, &l.ao_b, &l.ln1_w, &l.ln1_b, &l.i_b, &l.o_b,
+        for (DeviceBuffer* b : {&l.qkv_w, &l.ao_w, &l.i_w, &l.o_w, &l.qkv_wp, &l.ao_wp, &l.i_wp, &l.o_wp, &l.qkv_b, &l.ao_b, &l.ln1_w, &l.ln1_b, &l.i_b, &l.o_b,
                                 &l.ln2_w, &l.ln2_b})
             b->release();
 }
@@ -59,6 +59,12 @@ SearchError NativeEmbedder::upload_f16(DeviceBuffer& dst, const float* src, size
     BERT_HIP(hipMemcpy(staging.ptr, src, n * 4, hipMemcpyHostToDevice));
     BERT_HIP(launch_bert_to_half(static_cast<const float*>(staging.ptr), dst.ptr, n, nullptr));
     BERT_HIP(hipDeviceSynchronize());
+    return SearchError{};
+}
+
+SearchError NativeEmbedder::pack_weights(DeviceBuffer& dst, const DeviceBuffer& src, int N, int K) {
+    BERT_TRY(dst.reserve((size_t)N * K * 2));
+    BERT_HIP(launch_bert_pack_w(src.ptr, dst.ptr, N, K, nullptr));
     return SearchError{};
 }
 
@@ -126,6 +132,20 @@ SearchError NativeEmbedder::init(int device, const fsgpu_bert_config& cfg, const
         }
     }
     staging.release();
+    // Fragment-order copies for the batch path (bert_gemm_w.hip): +2 bytes per weight (22 MB for MiniLM-L6).
+    // FSGPU_BERT_GEMM_V1 keeps the LDS-tiled kernels of bert_kernels.hip (A/B runs).
+    const int Hi = (int)H, Ii = (int)I;
+    if (!std::getenv("FSGPU_BERT_GEMM_V1") && bert_gemm_w_supported(3 * Hi, Hi) && bert_gemm_w_supported(Ii, Hi) &&
+        bert_gemm_ln_w_supported(Hi, Hi) && bert_gemm_ln_w_supported(Hi, Ii)) {
+        for (Layer& l : layers_) {
+            BERT_TRY(pack_weights(l.qkv_wp, l.qkv_w, 3 * Hi, Hi));
+            BERT_TRY(pack_weights(l.ao_wp, l.ao_w, Hi, Hi));
+            BERT_TRY(pack_weights(l.i_wp, l.i_w, Ii, Hi));
+            BERT_TRY(pack_weights(l.o_wp, l.o_w, Hi, Ii));
+        }
+        BERT_HIP(hipDeviceSynchronize());
+        packed_ = true;
+    }
     return SearchError{};
 }
 
@@ -259,7 +279,34 @@ SearchError NativeEmbedder::forward(uint32_t n_docs, uint32_t tokens, uint32_t m
     // a batch fills the chip with 32-row blocks; a single query (a few tokens) would run each projection on ONE block
     // and is quicker through the 32x64-tile GEMM + the stand-alone add+LN kernel (measured 0.36 vs 0.43 ms)
     const bool fused_ln = !no_fuse && T > 256 && bert_gemm_ln_supported(H) && (H % 32 == 0) && (I % 32 == 0);
+    // a batch: every linear over the fragment-order weights (bert_gemm_w.hip) — 5 launches per layer
+    const bool packed = packed_ && T > 256;
     for (Layer& l : layers_) {
+        if (packed) {
+            // Q, K, V leave the projection as f16 (what the attention's matrix-core operands are rounded to anyway) in the
+            // first half of the f32 QKV workspace
+            BERT_HIP(launch_bert_gemm_w(x_h_.ptr, l.qkv_wp.ptr, static_cast<const float*>(l.qkv_b.ptr), nullptr, qkv, T, 3 * H, H,
+                                        2, stream_));
+            BERT_HIP(launch_bert_attention_h(qkv, offs, ctx_h_.ptr, (int)n_docs, (int)cfg_.heads, H, (int)max_seq, scale,
+                                             stream_));
+            BERT_HIP(launch_bert_gemm_ln_w(ctx_h_.ptr, l.ao_wp.ptr, static_cast<const float*>(l.ao_b.ptr), x, x_h_.ptr,
+                                           static_cast<const float*>(l.ln1_w.ptr), static_cast<const float*>(l.ln1_b.ptr), T, H,
+                                           H, eps, stream_));
+            static const bool split_ffn = std::getenv("FSGPU_BERT_SPLIT_FFN") != nullptr;   // A/B runs: two launches
+            if (!split_ffn && bert_ffn_w_supported(H, I)) {
+                BERT_HIP(launch_bert_ffn_w(l.i_wp.ptr, static_cast<const float*>(l.i_b.ptr), l.o_wp.ptr,
+                                           static_cast<const float*>(l.o_b.ptr), x, x_h_.ptr,
+                                           static_cast<const float*>(l.ln2_w.ptr), static_cast<const float*>(l.ln2_b.ptr), T, H,
+                                           I, eps, stream_));
+                continue;
+            }
+            BERT_HIP(launch_bert_gemm_w(x_h_.ptr, l.i_wp.ptr, static_cast<const float*>(l.i_b.ptr), nullptr, inter_h_.ptr, T, I,
+                                        H, 1, stream_));
+            BERT_HIP(launch_bert_gemm_ln_w(inter_h_.ptr, l.o_wp.ptr, static_cast<const float*>(l.o_b.ptr), x, x_h_.ptr,
+                                           static_cast<const float*>(l.ln2_w.ptr), static_cast<const float*>(l.ln2_b.ptr), T, H,
+                                           I, eps, stream_));
+            continue;
+        }
         BERT_HIP(launch_bert_gemm(x_h_.ptr, l.qkv_w.ptr, static_cast<const float*>(l.qkv_b.ptr), qkv, nullptr, T, 3 * H, H,
                                   false, stream_));
         BERT_HIP(launch_bert_attention(qkv, offs, ctx_h_.ptr, (int)n_docs, (int)cfg_.heads, H, (int)max_seq, scale,

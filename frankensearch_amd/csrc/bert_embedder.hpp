@@ -25,10 +25,12 @@ class NativeEmbedder {
   private:
     struct Layer {
         DeviceBuffer qkv_w, ao_w, i_w, o_w;              // f16 [N,K]
+        DeviceBuffer qkv_wp, ao_wp, i_wp, o_wp;          // the same weights in matrix-core fragment order (bert_gemm_w.hip)
         DeviceBuffer qkv_b, ao_b, ln1_w, ln1_b, i_b, o_b, ln2_w, ln2_b;  // f32
     };
     SearchError upload_f32(DeviceBuffer& dst, const float* src, size_t n);
     SearchError upload_f16(DeviceBuffer& dst, const float* src, size_t n, DeviceBuffer& staging);
+    SearchError pack_weights(DeviceBuffer& dst, const DeviceBuffer& src, int N, int K);
     SearchError forward(uint32_t n_docs, uint32_t tokens, uint32_t max_seq);
     SearchError forward_query(uint32_t n_docs, uint32_t tokens);   // <= 32 tokens: 25 launches (bert_query_kernels.hip)
     bool query_path(uint32_t tokens) const;
@@ -62,6 +64,7 @@ class NativeEmbedder {
     static constexpr size_t kGraphMaxEntries = 128;
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, GraphEntry> graphs_;
     bool graphs_enabled_ = true;
+    bool packed_ = false;  // every layer has its fragment-order copies: the batch path runs bert_gemm_w.hip
 };
 
 }  // namespace fsgpu

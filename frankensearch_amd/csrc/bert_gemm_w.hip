@@ -1,0 +1,667 @@
+// bert_gemm_w.hip — the batch-path linears of the MiniLM-class encoder (encoder_layer_raw, native.rs:587-626: QKV, attention
+// output + add_ln_raw, FFN up + GELU, FFN down + add_ln_raw) with the weights PRE-PACKED in matrix-core fragment order.
+//
+// Why: at 5k tokens these GEMMs are 1.5-6 GFLOP each with K = 384 — a block's whole k-loop is a dozen steps, and the
+// LDS-tiled kernels of bert_kernels.hip (one barrier and one global round trip per 32-wide k-step, prefetch depth 1) spend
+// their time waiting: 250-275 TFLOP/s.  Here nothing in the k-loop waits on memory:
+//   * the weights never change, so at model load they are re-laid so that the B fragment of one (16-column tile, k-step) —
+//     lane l holds W[16 t + (l & 15)][32 ks + 8 (l >> 4) .. + 8] — is one contiguous 1 KB run.  A wave fetches its fragments
+//     with perfectly coalesced 16-byte loads straight into registers: no LDS staging, no barrier, no 16-rows-per-load
+//     address pattern.  K = hidden: a wave holds its whole weight slice (24 fragments for K = 384) before the first MFMA;
+//     K = inter (FFN down): the fragments stream through a register ring six k-steps deep, private to the wave;
+//   * the activation tile of a block (BM rows x the WHOLE K) is fetched once, with every load issued up front, parked in
+//     LDS at a conflict-free pitch, and one barrier later each wave runs its k-loop on LDS reads and MFMAs alone.
+// The MFMA operands are swapped (D = W_frag x A_frag^T) so a lane ends up with FOUR CONSECUTIVE output columns of one row:
+// bias, residual and LayerNorm weights are float4 loads, the stores are 16 (f32) / 8 (f16) bytes per lane.
+//
+// Same arithmetic as bert_kernels.hip (f16 x f16 -> f32 v_mfma_f32_16x16x32_f16, f32 bias / GELU / residual / LayerNorm);
+// tolerance against the f32 oracle asserted in tests/test_gpu_bert.py.
+#include <cstdlib>
+
+#include "device_util.hpp"
+#include "kernels.hpp"
+
+namespace fsgpu {
+
+#ifndef FSGPU_LN_RING
+#define FSGPU_LN_RING 12
+#endif
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// exact-form GELU with the Abramowitz-Stegun 7.1.26 erf (native.rs:190-200) — the formula of bert_kernels.hip, with the
+// hardware reciprocal (1 ulp) in place of the IEEE division and fused multiply-adds (this file is built without contraction): the result is rounded to f16 two lines later, and the
+// epilogue's 32 GELUs per lane were a quarter of the FFN-up kernel
+__device__ __forceinline__ float gelu_as_w(float x) {
+    const float z = x * 0.70710678118654752440f;
+    const float az = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+    const float poly =
+        t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.0614054f, -1.453152f), 1.4214137f), -0.28449673f), 0.2548296f);
+    const float erf_abs = fmaf(-poly, __expf(-(z * z)), 1.0f);
+    const float erf = copysignf(erf_abs, z);
+    const float hx = 0.5f * x;
+    return fmaf(hx, erf, hx);
+}
+
+}  // namespace
+
+// [N, K] f16 row-major -> fragment order: piece ((t * K/32 + ks) * 64 + lane) = W[16 t + (lane & 15)][32 ks + 8 (lane >> 4) ..+8]
+__global__ void bert_pack_w_kernel(const _Float16* __restrict__ src, _Float16* __restrict__ dst, int N, int K) {
+    const size_t piece = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ksteps = K / 32;
+    if (piece >= (size_t)(N / 16) * ksteps * 64) return;
+    const int lane = (int)(piece & 63);
+    const size_t tk = piece >> 6;
+    const int ks = (int)(tk % ksteps), t = (int)(tk / ksteps);
+    const half8 v = *reinterpret_cast<const half8*>(src + (size_t)(t * 16 + (lane & 15)) * K + ks * 32 + (lane >> 4) * 8);
+    reinterpret_cast<half8*>(dst)[piece] = v;
+}
+
+// C[M, N] = A[M, K] W^T + bias for K = 32 KS = hidden.  Block = 64 rows x 128 columns, wave w = 64 rows x columns
+// [32 w, 32 w + 32).  EPI 0: f32 output; EPI 1: GELU, f16 output; EPI 2: f16 output.
+template <int EPI, int KS>
+__global__ __launch_bounds__(256) void bert_gemm_w_kernel(const _Float16* __restrict__ A, const half8* __restrict__ Wp,
+                                                          const float* __restrict__ bias, float* __restrict__ out_f32,
+                                                          _Float16* __restrict__ out_h, int M, int N, int dbg) {
+    constexpr int K = 32 * KS, BM = 64;
+    constexpr int PITCH = K + 16;                      // halves: (2 K + 32) / 16 = K / 8 + 2 slots, = 2 mod 16 for K % 128 == 0
+    constexpr int PIECES = K / 8;                      // 16-byte pieces per row
+    constexpr int A_LOADS = BM * PIECES / 256;
+    static_assert(BM * PIECES % 256 == 0, "tile must divide among 256 loader threads");
+    __shared__ __attribute__((aligned(16))) _Float16 As[BM * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * 128 + wave * 32;
+    // this wave's whole weight slice: 2 column tiles x KS k-steps, each fragment a contiguous 1 KB run
+    half8 wf[2][KS];
+    {
+        const half8* wp = Wp + (size_t)(bn0 / 16) * KS * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) wf[j][ks] = (dbg & 16) ? half8{} + (_Float16)lane : wp[(j * KS + ks) * 64];
+    }
+    // the block's activation tile: rows bm0 .. bm0 + 63 are one contiguous run of A (clamped at M)
+    {
+        half8 ra[A_LOADS];
+#pragma unroll
+        for (int x = 0; x < A_LOADS; ++x) {
+            const int p = tid + 256 * x, r = p / PIECES, c = p % PIECES;
+            int row = bm0 + r;
+            row = row < M ? row : M - 1;
+            ra[x] = (dbg & 8) ? half8{} + (_Float16)row : *(reinterpret_cast<const half8*>(A + (size_t)row * K) + c);
+        }
+#pragma unroll
+        for (int x = 0; x < A_LOADS; ++x) {
+            const int p = tid + 256 * x, r = p / PIECES, c = p % PIECES;
+            *reinterpret_cast<half8*>(&As[r * PITCH + c * 8]) = ra[x];
+        }
+    }
+    __syncthreads();
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    if (!(dbg & 2))
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        half8 af[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const half8*>(&As[(i * 16 + fr) * PITCH + ks * 32 + fk]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][ks], af[i], acc[i][j], 0, 0, 0);
+    }
+    // D = W_frag x A_frag^T: lane holds output row (lane & 15) of the m-tile, columns 4 (lane >> 4) .. + 3 of the n-tile
+    const int cq = (lane >> 4) * 4;
+    if (EPI == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = bn0 + j * 16 + cq;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = bm0 + i * 16 + fr;
+                if (row < M && !(dbg & 1)) *reinterpret_cast<f32x4*>(out_f32 + (size_t)row * N + col) = acc[i][j] + bv;
+            }
+        }
+        return;
+    }
+    // f16 outputs leave through LDS (the activation tile's space): a lane's 8 bytes of 16 different rows per store
+    // instruction made the stores half of the kernel; transposed, 16 lanes write 256 contiguous bytes of a row
+    constexpr int CP = 128 + 8;  // halves per row of the output tile (272 bytes)
+    __syncthreads();             // every wave is done reading the activation tile
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + bn0 + j * 16 + cq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 y = acc[i][j] + bv;
+            half4 h;
+            h[0] = (_Float16)(EPI == 1 && !(dbg & 4) ? gelu_as_w(y[0]) : y[0]);
+            h[1] = (_Float16)(EPI == 1 && !(dbg & 4) ? gelu_as_w(y[1]) : y[1]);
+            h[2] = (_Float16)(EPI == 1 && !(dbg & 4) ? gelu_as_w(y[2]) : y[2]);
+            h[3] = (_Float16)(EPI == 1 && !(dbg & 4) ? gelu_as_w(y[3]) : y[3]);
+            *reinterpret_cast<half4*>(&As[(i * 16 + fr) * CP + wave * 32 + j * 16 + cq]) = h;
+        }
+    }
+    __syncthreads();
+    if (dbg & 1) return;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = it * 16 + (tid >> 4), c = (tid & 15) * 8;
+        const int row = bm0 + r;
+        if (row < M)
+            *reinterpret_cast<half8*>(out_h + (size_t)row * N + blockIdx.x * 128 + c) = *reinterpret_cast<const half8*>(&As[r * CP + c]);
+    }
+}
+
+// x = LayerNorm(x + A W^T + bias) (add_ln_raw, native.rs:560-578) for N = hidden = 64 CT, any K % 32 == 0.  A block owns 32
+// complete rows; wave w owns columns [16 CT w, 16 CT (w + 1)).  The 32 x K activation tile sits in LDS for the whole kernel;
+// the wave's weight fragments stream through a register ring RING k-steps deep (no barrier in the k-loop).  Row statistics:
+// in-lane over the lane's columns, two xor-shuffles over the four column quads, one LDS exchange over the four waves; two
+// passes (mean, then centred variance) like bert_add_ln_kernel.
+template <int CT, int RING>
+__global__ __launch_bounds__(256) void bert_gemm_ln_w_kernel(const _Float16* __restrict__ A, const half8* __restrict__ Wp,
+                                                             const float* __restrict__ bias, float* __restrict__ x_f32,
+                                                             _Float16* __restrict__ x_h, const float* __restrict__ lnw,
+                                                             const float* __restrict__ lnb, int M, int K, float eps, int dbg) {
+    constexpr int H = 64 * CT, BM = 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char glw_smem[];
+    float* red = reinterpret_cast<float*>(glw_smem);                          // [BM][4]
+    _Float16* As = reinterpret_cast<_Float16*>(glw_smem + BM * 4 * 4);        // [BM][K + 16]
+    constexpr int XP = H + 4;                                                 // floats per row of the residual / output tile
+    float* Xs = reinterpret_cast<float*>(glw_smem + BM * 4 * 4 + (size_t)BM * (K + 16) * 2);   // [BM][XP]
+    const int pitch = K + 16, pieces = K / 8, ksteps = K / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bm0 = blockIdx.x * BM;
+    const half8* wp = Wp + (size_t)(wave * CT) * ksteps * 64 + lane;          // fragment (j, ks) at wp[(j * ksteps + ks) * 64]
+    half8 wr[RING][CT];
+#pragma unroll
+    for (int d = 0; d < RING; ++d)
+        if (d < ksteps)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) wr[d][j] = (dbg & 16) ? half8{} + (_Float16)lane : wp[((size_t)j * ksteps + d) * 64];
+    // activation tile: 32 rows x K, every load in flight before the first LDS write (up to 24 pieces per thread: K = 1536 in one round)
+    for (int p0 = 0; p0 < BM * pieces; p0 += 256 * 24) {
+        half8 ra[24];
+#pragma unroll
+        for (int x = 0; x < 24; ++x) {
+            const int p = p0 + tid + 256 * x;
+            if (p < BM * pieces) {
+                const int r = p / pieces, c = p - r * pieces;
+                int row = bm0 + r;
+                row = row < M ? row : M - 1;
+                ra[x] = (dbg & 8) ? half8{} + (_Float16)row : *(reinterpret_cast<const half8*>(A + (size_t)row * K) + c);
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 24; ++x) {
+            const int p = p0 + tid + 256 * x;
+            if (p < BM * pieces) {
+                const int r = p / pieces, c = p - r * pieces;
+                *reinterpret_cast<half8*>(&As[r * pitch + c * 8]) = ra[x];
+            }
+        }
+    }
+    // the residual rows, fetched row-contiguous like everything else; the epilogue reads them (and returns the new rows)
+    // through LDS, so no global access of this kernel touches 16 rows per instruction
+    {
+        constexpr int XL = BM * (H / 4) / 256;
+        f32x4 rx[XL];
+#pragma unroll
+        for (int x = 0; x < XL; ++x) {
+            const int p = tid + 256 * x, r = p / (H / 4), c4 = p % (H / 4);
+            int row = bm0 + r;
+            row = row < M ? row : M - 1;
+            rx[x] = *(reinterpret_cast<const f32x4*>(x_f32 + (size_t)row * H) + c4);
+        }
+#pragma unroll
+        for (int x = 0; x < XL; ++x) {
+            const int p = tid + 256 * x, r = p / (H / 4), c4 = p % (H / 4);
+            *reinterpret_cast<f32x4*>(&Xs[r * XP + c4 * 4]) = rx[x];
+        }
+    }
+    __syncthreads();
+    f32x4 acc[2][CT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    for (int ks0 = (dbg & 2) ? ksteps : 0; ks0 < ksteps; ks0 += RING) {
+#pragma unroll
+        for (int d = 0; d < RING; ++d) {
+            const int ks = ks0 + d;
+            if (ks < ksteps) {
+                half8 af[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const half8*>(&As[(i * 16 + fr) * pitch + ks * 32 + fk]);
+#pragma unroll
+                for (int j = 0; j < CT; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[d][j], af[i], acc[i][j], 0, 0, 0);
+                if (ks + RING < ksteps && !(dbg & 16))
+#pragma unroll
+                    for (int j = 0; j < CT; ++j) wr[d][j] = wp[((size_t)j * ksteps + ks + RING) * 64];
+            }
+        }
+    }
+    // epilogue.  Lane: rows i * 16 + fr (i = 0, 1), columns wave * 16 CT + j * 16 + cq .. + 3
+    const int cq = (lane >> 4) * 4;
+    float psum[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            const int col = wave * 16 * CT + j * 16 + cq;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + col);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(&Xs[(i * 16 + fr) * XP + col]);
+            const f32x4 y = (acc[i][j] + bv) + xv;
+            acc[i][j] = y;
+            s += (y[0] + y[1]) + (y[2] + y[3]);
+        }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        psum[i] = s;
+    }
+    if (lane < 16) {
+        red[(0 * 16 + lane) * 4 + wave] = psum[0];
+        red[(1 * 16 + lane) * 4 + wave] = psum[1];
+    }
+    __syncthreads();
+    float mean[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float* p = red + (i * 16 + fr) * 4;
+        mean[i] = ((p[0] + p[1]) + (p[2] + p[3])) / (float)H;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            const f32x4 d = acc[i][j] - mean[i];
+            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+        q += __shfl_xor(q, 16);
+        q += __shfl_xor(q, 32);
+        if (lane < 16) red[(i * 16 + lane) * 4 + wave] = q;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float* p = red + (i * 16 + fr) * 4;
+        const float var = ((p[0] + p[1]) + (p[2] + p[3])) / (float)H;
+        const float inv = 1.0f / sqrtf(var + eps);
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            const int col = wave * 16 * CT + j * 16 + cq;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(lnw + col);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(lnb + col);
+            *reinterpret_cast<f32x4*>(&Xs[(i * 16 + fr) * XP + col]) = (acc[i][j] - mean[i]) * inv * g + b;   // own element
+        }
+    }
+    __syncthreads();
+    if (dbg & 1) return;
+    constexpr int XL = BM * (H / 4) / 256;
+#pragma unroll
+    for (int x = 0; x < XL; ++x) {
+        const int pp = tid + 256 * x, r = pp / (H / 4), c4 = pp % (H / 4);
+        const int row = bm0 + r;
+        if (row >= M) continue;
+        const f32x4 y = *reinterpret_cast<const f32x4*>(&Xs[r * XP + c4 * 4]);
+        *(reinterpret_cast<f32x4*>(x_f32 + (size_t)row * H) + c4) = y;
+        half4 h;
+        h[0] = (_Float16)y[0];
+        h[1] = (_Float16)y[1];
+        h[2] = (_Float16)y[2];
+        h[3] = (_Float16)y[3];
+        *(reinterpret_cast<half4*>(x_h + (size_t)row * H) + c4) = h;
+    }
+}
+
+// The whole feed-forward block of a layer in one launch: x = LayerNorm(x + GELU(x W1^T + b1) W2^T + b2)
+// (encoder_layer_raw, native.rs:606-626) for hidden = 64 CT.  A 512-thread block owns 32 complete rows:
+//   phase 0  the f32 rows of x -> LDS (they are the residual AND, rounded to f16 per fragment, the up-projection's A operand:
+//            every wave keeps all its A fragments — 2 row tiles x hidden/32 k-steps — in registers for the whole phase);
+//   phase 1  wave w computes intermediate columns [inter/8 w, inter/8 (w + 1)) two 16-column tiles at a time, W1 fragments
+//            streaming through a register ring half a chunk deep; bias + GELU -> f16 -> the 32 x inter tile in LDS.  The
+//            intermediate activations (16 MB per layer at 5k tokens) never leave the CU;
+//   phase 2  the down-projection over that tile, W2 fragments through a second ring (its first loads are issued before the
+//            barrier that ends phase 1), then the LayerNorm epilogue of bert_gemm_ln_w_kernel over 8 waves.
+// One launch, one 8 MB read and one 12 MB write per layer instead of two launches moving 56 MB.
+template <int CT>
+__global__ __launch_bounds__(512) void bert_ffn_w_kernel(const half8* __restrict__ W1p, const float* __restrict__ b1,
+                                                         const half8* __restrict__ W2p, const float* __restrict__ b2,
+                                                         float* __restrict__ x_f32, _Float16* __restrict__ x_h,
+                                                         const float* __restrict__ lnw, const float* __restrict__ lnb, int M,
+                                                         int I, float eps) {
+    constexpr int H = 64 * CT, BM = 32, NW = 8;
+    constexpr int KS1 = H / 32;            // k-steps of the up-projection
+    constexpr int R1 = KS1 / 2;            // ring depth (k-steps) of the W1 stream
+    constexpr int NT2 = 4 * CT / NW;       // 16-column tiles of the output per wave
+    constexpr int R2 = 6;                  // ring depth of the W2 stream
+    constexpr int XP = H + 4;              // floats per row of the residual / output tile
+    static_assert(KS1 % 2 == 0 && (4 * CT) % NW == 0, "hidden must be a multiple of 128");
+    extern __shared__ __attribute__((aligned(16))) unsigned char ffn_smem[];
+    float* red = reinterpret_cast<float*>(ffn_smem);                                      // [BM][NW]
+    float* Xs = reinterpret_cast<float*>(ffn_smem + BM * NW * 4);                         // [BM][XP]
+    _Float16* Is = reinterpret_cast<_Float16*>(ffn_smem + BM * NW * 4 + BM * XP * 4);     // [BM][I + 16]
+    const int ip = I + 16, ksteps2 = I / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bm0 = blockIdx.x * BM;
+    const int fr = lane & 15, q = lane >> 4, cq = q * 4;
+    const int tpw = I / 16 / NW;           // intermediate tiles per wave (a multiple of 2)
+    const int nchunks = tpw / 2;
+    // W1 stream of this wave: fragment (chunk c, tile j, k-step ks) at w1[((2 c + j) * KS1 + ks) * 64]
+    const half8* w1 = W1p + (size_t)(wave * tpw) * KS1 * 64 + lane;
+    half8 r1[R1][2];
+#pragma unroll
+    for (int d = 0; d < R1; ++d)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) r1[d][j] = w1[(j * KS1 + d) * 64];
+    // phase 0: rows of x -> LDS (row-contiguous loads)
+    {
+        constexpr int XL = BM * (H / 4) / 512;
+        f32x4 rx[XL];
+#pragma unroll
+        for (int x = 0; x < XL; ++x) {
+            const int p = tid + 512 * x, r = p / (H / 4), c4 = p % (H / 4);
+            int row = bm0 + r;
+            row = row < M ? row : M - 1;
+            rx[x] = *(reinterpret_cast<const f32x4*>(x_f32 + (size_t)row * H) + c4);
+        }
+#pragma unroll
+        for (int x = 0; x < XL; ++x) {
+            const int p = tid + 512 * x, r = p / (H / 4), c4 = p % (H / 4);
+            *reinterpret_cast<f32x4*>(&Xs[r * XP + c4 * 4]) = rx[x];
+        }
+    }
+    __syncthreads();
+    // phase 1
+    {
+        half8 a1[2][KS1];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                const float* src = &Xs[(i * 16 + fr) * XP + ks * 32 + q * 8];
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+                half8 h;
+                h[0] = (_Float16)lo[0]; h[1] = (_Float16)lo[1]; h[2] = (_Float16)lo[2]; h[3] = (_Float16)lo[3];
+                h[4] = (_Float16)hi[0]; h[5] = (_Float16)hi[1]; h[6] = (_Float16)hi[2]; h[7] = (_Float16)hi[3];
+                a1[i][ks] = h;
+            }
+        for (int c = 0; c < nchunks; ++c) {
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const half8* wc = w1 + (size_t)(2 * c) * KS1 * 64;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                const int d = ks % R1;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r1[d][j], a1[i][ks], acc[i][j], 0, 0, 0);
+                // refill the slot with the fragment R1 steps ahead: same chunk (ks + R1 < KS1) or the next one
+                if (ks + R1 < KS1) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) r1[d][j] = wc[(j * KS1 + ks + R1) * 64];
+                } else if (c + 1 < nchunks) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) r1[d][j] = wc[((2 + j) * KS1 + ks + R1 - KS1) * 64];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = (wave * tpw + 2 * c + j) * 16 + cq;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(b1 + col);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const f32x4 y = acc[i][j] + bv;
+                    half4 h;
+                    h[0] = (_Float16)gelu_as_w(y[0]);
+                    h[1] = (_Float16)gelu_as_w(y[1]);
+                    h[2] = (_Float16)gelu_as_w(y[2]);
+                    h[3] = (_Float16)gelu_as_w(y[3]);
+                    *reinterpret_cast<half4*>(&Is[(i * 16 + fr) * ip + col]) = h;
+                }
+            }
+        }
+    }
+    // phase 2: W2 fragment (tile j, k-step ks) at w2[(j * ksteps2 + ks) * 64]
+    const half8* w2 = W2p + (size_t)(wave * NT2) * ksteps2 * 64 + lane;
+    half8 r2[R2][NT2];
+#pragma unroll
+    for (int d = 0; d < R2; ++d)
+        if (d < ksteps2)
+#pragma unroll
+            for (int j = 0; j < NT2; ++j) r2[d][j] = w2[((size_t)j * ksteps2 + d) * 64];
+    __syncthreads();   // the intermediate tile is complete
+    f32x4 acc[2][NT2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ks0 = 0; ks0 < ksteps2; ks0 += R2) {
+#pragma unroll
+        for (int d = 0; d < R2; ++d) {
+            const int ks = ks0 + d;
+            if (ks < ksteps2) {
+                half8 af[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const half8*>(&Is[(i * 16 + fr) * ip + ks * 32 + q * 8]);
+#pragma unroll
+                for (int j = 0; j < NT2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r2[d][j], af[i], acc[i][j], 0, 0, 0);
+                if (ks + R2 < ksteps2)
+#pragma unroll
+                    for (int j = 0; j < NT2; ++j) r2[d][j] = w2[((size_t)j * ksteps2 + ks + R2) * 64];
+            }
+        }
+    }
+    // epilogue: rows i * 16 + fr, columns wave * 16 NT2 + j * 16 + cq .. + 3
+    float psum[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT2; ++j) {
+            const int col = wave * 16 * NT2 + j * 16 + cq;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + col);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(&Xs[(i * 16 + fr) * XP + col]);
+            const f32x4 y = (acc[i][j] + bv) + xv;
+            acc[i][j] = y;
+            s += (y[0] + y[1]) + (y[2] + y[3]);
+        }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        psum[i] = s;
+    }
+    if (lane < 16) {
+        red[(0 * 16 + lane) * NW + wave] = psum[0];
+        red[(1 * 16 + lane) * NW + wave] = psum[1];
+    }
+    __syncthreads();
+    float mean[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float* p = red + (i * 16 + fr) * NW;
+        mean[i] = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) / (float)H;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float qs = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT2; ++j) {
+            const f32x4 d = acc[i][j] - mean[i];
+            qs += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+        qs += __shfl_xor(qs, 16);
+        qs += __shfl_xor(qs, 32);
+        if (lane < 16) red[(i * 16 + lane) * NW + wave] = qs;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float* p = red + (i * 16 + fr) * NW;
+        const float var = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) / (float)H;
+        const float inv = 1.0f / sqrtf(var + eps);
+#pragma unroll
+        for (int j = 0; j < NT2; ++j) {
+            const int col = wave * 16 * NT2 + j * 16 + cq;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(lnw + col);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(lnb + col);
+            *reinterpret_cast<f32x4*>(&Xs[(i * 16 + fr) * XP + col]) = (acc[i][j] - mean[i]) * inv * g + b;   // own element
+        }
+    }
+    __syncthreads();
+    constexpr int XL = BM * (H / 4) / 512;
+#pragma unroll
+    for (int x = 0; x < XL; ++x) {
+        const int pp = tid + 512 * x, r = pp / (H / 4), c4 = pp % (H / 4);
+        const int row = bm0 + r;
+        if (row >= M) continue;
+        const f32x4 y = *reinterpret_cast<const f32x4*>(&Xs[r * XP + c4 * 4]);
+        *(reinterpret_cast<f32x4*>(x_f32 + (size_t)row * H) + c4) = y;
+        half4 h;
+        h[0] = (_Float16)y[0];
+        h[1] = (_Float16)y[1];
+        h[2] = (_Float16)y[2];
+        h[3] = (_Float16)y[3];
+        *(reinterpret_cast<half4*>(x_h + (size_t)row * H) + c4) = h;
+    }
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------
+
+static int gw_dbg() {
+    static const int v = [] {
+        const char* e = std::getenv("FSGPU_GW_DBG");
+        return e ? std::atoi(e) : 0;
+    }();
+    return v;
+}
+
+hipError_t launch_bert_pack_w(const void* w_h, void* packed_h, int N, int K, hipStream_t stream) {
+    if (N % 16 != 0 || K % 32 != 0) return hipErrorInvalidValue;
+    const size_t pieces = (size_t)(N / 16) * (K / 32) * 64;
+    hipLaunchKernelGGL(bert_pack_w_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, stream,
+                       static_cast<const _Float16*>(w_h), static_cast<_Float16*>(packed_h), N, K);
+    return hipGetLastError();
+}
+
+// K = hidden in {128, 256, 384}, N % 128 == 0
+bool bert_gemm_w_supported(int N, int K) { return (K == 128 || K == 256 || K == 384) && N % 128 == 0; }
+
+template <int EPI, int KS>
+static void launch_gemm_w_t(const void* a_h, const void* wp, const float* bias, float* out_f32, void* out_h, int M, int N,
+                            hipStream_t stream) {
+    hipLaunchKernelGGL((bert_gemm_w_kernel<EPI, KS>), dim3(N / 128, (M + 63) / 64), dim3(256), 0, stream,
+                       static_cast<const _Float16*>(a_h), static_cast<const half8*>(wp), bias, out_f32,
+                       static_cast<_Float16*>(out_h), M, N, gw_dbg());
+}
+
+hipError_t launch_bert_gemm_w(const void* a_h, const void* wp, const float* bias, float* out_f32, void* out_h, int M, int N,
+                              int K, int epilogue, hipStream_t stream) {
+    if (!bert_gemm_w_supported(N, K) || epilogue < 0 || epilogue > 2) return hipErrorInvalidValue;
+#define FSGPU_GW(E)                                                                            \
+    do {                                                                                       \
+        if (K == 384) launch_gemm_w_t<E, 12>(a_h, wp, bias, out_f32, out_h, M, N, stream);     \
+        else if (K == 256) launch_gemm_w_t<E, 8>(a_h, wp, bias, out_f32, out_h, M, N, stream); \
+        else launch_gemm_w_t<E, 4>(a_h, wp, bias, out_f32, out_h, M, N, stream);               \
+    } while (0)
+    if (epilogue == 0) FSGPU_GW(0);
+    else if (epilogue == 1) FSGPU_GW(1);
+    else FSGPU_GW(2);
+#undef FSGPU_GW
+    return hipGetLastError();
+}
+
+static size_t gemm_ln_w_lds(int hidden, int K) {
+    return (size_t)32 * 4 * 4 + (size_t)32 * (K + 16) * 2 + (size_t)32 * (hidden + 4) * 4;
+}
+
+// hidden in {128, 256, 384}; the 32 x K activation tile and the 32 x hidden residual tile must fit the 160 KB of LDS
+bool bert_gemm_ln_w_supported(int hidden, int K) {
+    return (hidden == 384 || hidden == 256 || hidden == 128) && K % 32 == 0 && K >= 32 &&
+           gemm_ln_w_lds(hidden, K) <= (size_t)160 * 1024;
+}
+
+template <int CT>
+static hipError_t launch_gemm_ln_w_t(const void* a_h, const void* wp, const float* bias, float* x_f32, void* x_h,
+                                     const float* lnw, const float* lnb, int M, int K, float eps, hipStream_t stream) {
+    const size_t lds = gemm_ln_w_lds(64 * CT, K);
+    auto kern = bert_gemm_ln_w_kernel<CT, FSGPU_LN_RING>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((M + 31) / 32), dim3(256), lds, stream, static_cast<const _Float16*>(a_h),
+                       static_cast<const half8*>(wp), bias, x_f32, static_cast<_Float16*>(x_h), lnw, lnb, M, K, eps, gw_dbg());
+    return hipGetLastError();
+}
+
+hipError_t launch_bert_gemm_ln_w(const void* a_h, const void* wp, const float* bias, float* x_f32, void* x_h,
+                                 const float* lnw, const float* lnb, int M, int hidden, int K, float eps, hipStream_t stream) {
+    if (!bert_gemm_ln_w_supported(hidden, K)) return hipErrorInvalidValue;
+    switch (hidden) {
+        case 384: return launch_gemm_ln_w_t<6>(a_h, wp, bias, x_f32, x_h, lnw, lnb, M, K, eps, stream);
+        case 256: return launch_gemm_ln_w_t<4>(a_h, wp, bias, x_f32, x_h, lnw, lnb, M, K, eps, stream);
+        default: return launch_gemm_ln_w_t<2>(a_h, wp, bias, x_f32, x_h, lnw, lnb, M, K, eps, stream);
+    }
+}
+
+static size_t ffn_w_lds(int hidden, int inter) {
+    return (size_t)32 * 8 * 4 + (size_t)32 * (hidden + 4) * 4 + (size_t)32 * (inter + 16) * 2;
+}
+
+// hidden in {128, 256, 384}; inter a multiple of 256 (8 waves x 2 tiles); residual + intermediate tiles within 160 KB of LDS
+bool bert_ffn_w_supported(int hidden, int inter) {
+    return (hidden == 384 || hidden == 256 || hidden == 128) && inter >= 256 && inter % 256 == 0 &&
+           ffn_w_lds(hidden, inter) <= (size_t)160 * 1024;
+}
+
+template <int CT>
+static hipError_t launch_ffn_w_t(const void* w1p, const float* b1, const void* w2p, const float* b2, float* x_f32, void* x_h,
+                                 const float* lnw, const float* lnb, int M, int I, float eps, hipStream_t stream) {
+    const size_t lds = ffn_w_lds(64 * CT, I);
+    auto kern = bert_ffn_w_kernel<CT>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((M + 31) / 32), dim3(512), lds, stream, static_cast<const half8*>(w1p), b1,
+                       static_cast<const half8*>(w2p), b2, x_f32, static_cast<_Float16*>(x_h), lnw, lnb, M, I, eps);
+    return hipGetLastError();
+}
+
+hipError_t launch_bert_ffn_w(const void* w1p, const float* b1, const void* w2p, const float* b2, float* x_f32, void* x_h,
+                             const float* lnw, const float* lnb, int M, int hidden, int inter, float eps, hipStream_t stream) {
+    if (!bert_ffn_w_supported(hidden, inter)) return hipErrorInvalidValue;
+    switch (hidden) {
+        case 384: return launch_ffn_w_t<6>(w1p, b1, w2p, b2, x_f32, x_h, lnw, lnb, M, inter, eps, stream);
+        case 256: return launch_ffn_w_t<4>(w1p, b1, w2p, b2, x_f32, x_h, lnw, lnb, M, inter, eps, stream);
+        default: return launch_ffn_w_t<2>(w1p, b1, w2p, b2, x_f32, x_h, lnw, lnb, M, inter, eps, stream);
+    }
+}
+
+}  // namespace fsgpu

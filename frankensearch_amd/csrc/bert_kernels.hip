@@ -246,6 +246,7 @@ __device__ __forceinline__ half8 load8_as_half(const float* p) {
     h[4] = (_Float16)b.x; h[5] = (_Float16)b.y; h[6] = (_Float16)b.z; h[7] = (_Float16)b.w;
     return h;
 }
+__device__ __forceinline__ half8 load8_as_half(const _Float16* p) { return *reinterpret_cast<const half8*>(p); }
 }  // namespace
 
 // LDS-tiled variant for token counts that fill the chip.  Loading MFMA fragments straight from global memory makes
@@ -567,7 +568,10 @@ __global__ __launch_bounds__(256) void bert_attention_kernel(const float* __rest
 //                        in LDS (f16) so that a lane's 16 bytes are 8 consecutive keys of one output dimension
 // Q, K, V and P enter the MFMAs as f16 (f32 accumulate); softmax statistics and the output accumulators stay f32.
 // Any sequence length works; short queries cost one key block.  Replaces the VALU kernel above (kept for A/B runs).
-__global__ __launch_bounds__(256) void bert_attention_mfma_kernel(const float* __restrict__ qkv,
+// QT = float: Q, K, V as the f32 projection wrote them (rounded to f16 here); QT = _Float16: the projection's epilogue
+// already rounded them (bert_gemm_w.hip) — the same values at half the bytes.
+template <typename QT>
+__global__ __launch_bounds__(256) void bert_attention_mfma_kernel(const QT* __restrict__ qkv,
                                                                   const uint32_t* __restrict__ offsets,
                                                                   _Float16* __restrict__ ctx_h, int hidden, float scale) {
     constexpr int PP = 48;  // halves per LDS row (32 + 16 pad = 6 slots: conflict-free ds_read_b128 fragment reads)
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(256) void bert_attention_mfma_kernel(const float* _
     const int fr = lane & 15, kg = lane >> 4;
     _Float16* P = Pl[wave];
     _Float16* V = Vt[wave];
-    const float* base = qkv + (size_t)t0 * stride + head * 32;
+    const QT* base = qkv + (size_t)t0 * stride + head * 32;
     // Q fragment: query q0 + fr (clamped; rows past the end are never written), dims kg*8..+8
     const int qrow = q0 + fr < S ? q0 + fr : S - 1;
     const half8 aq = load8_as_half(base + (size_t)qrow * stride + kg * 8);
@@ -609,16 +613,13 @@ __global__ __launch_bounds__(256) void bert_attention_mfma_kernel(const float* _
         {
             const int key = k0 + (lane & 31), hf = lane >> 5;
             const int vrow = key < S ? key : S - 1;
-            const float4* vp = reinterpret_cast<const float4*>(base + (size_t)vrow * stride + 2 * hidden + hf * 16);
+            const QT* vp = base + (size_t)vrow * stride + 2 * hidden + hf * 16;
             const bool live = key < S;
+            const half8 v0 = load8_as_half(vp), v1 = load8_as_half(vp + 8);
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const float4 v = vp[x];
-                const int d = hf * 16 + x * 4;
-                V[(d + 0) * PP + (lane & 31)] = live ? (_Float16)v.x : (_Float16)0.f;
-                V[(d + 1) * PP + (lane & 31)] = live ? (_Float16)v.y : (_Float16)0.f;
-                V[(d + 2) * PP + (lane & 31)] = live ? (_Float16)v.z : (_Float16)0.f;
-                V[(d + 3) * PP + (lane & 31)] = live ? (_Float16)v.w : (_Float16)0.f;
+            for (int x = 0; x < 8; ++x) {
+                V[(hf * 16 + x) * PP + (lane & 31)] = live ? v0[x] : (_Float16)0.f;
+                V[(hf * 16 + 8 + x) * PP + (lane & 31)] = live ? v1[x] : (_Float16)0.f;
             }
         }
         // online softmax; C layout: row = kg * 4 + r (query), col = fr (key inside the 16-key tile)
@@ -676,7 +677,17 @@ __global__ __launch_bounds__(256) void bert_pool_kernel(const float* __restrict_
         const int d = tid + 256 * i;
         float acc = 0.f;
         if (d < hidden && n > 0) {
-            for (uint32_t t = t0; t < t1; ++t) acc += x[(size_t)t * hidden + d];
+            // left-to-right sum; the loads of eight tokens are independent and in flight together (a text of 20 tokens was
+            // 20 dependent round trips)
+            uint32_t t = t0;
+            for (; t + 8 <= t1; t += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = x[(size_t)(t + u) * hidden + d];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            for (; t < t1; ++t) acc += x[(size_t)t * hidden + d];
             acc *= 1.0f / (float)n;
         }
         vals[i] = acc;
@@ -801,6 +812,13 @@ size_t bert_attention_lds_bytes(int max_seq) {
     return ((size_t)max_seq * 33 * 2 + (size_t)4 * spad) * sizeof(float);
 }
 
+hipError_t launch_bert_attention_h(const void* qkv_h, const uint32_t* offsets, void* ctx_h, int n_docs, int heads,
+                                   int hidden, int max_seq, float scale, hipStream_t stream) {
+    hipLaunchKernelGGL(bert_attention_mfma_kernel<_Float16>, dim3(n_docs, heads, (max_seq + 63) / 64), dim3(256), 0, stream,
+                       static_cast<const _Float16*>(qkv_h), offsets, static_cast<_Float16*>(ctx_h), hidden, scale);
+    return hipGetLastError();
+}
+
 hipError_t launch_bert_attention(const float* qkv, const uint32_t* offsets, void* ctx_h, int n_docs, int heads,
                                  int hidden, int max_seq, float scale, hipStream_t stream) {
     static const bool valu = [] {
@@ -808,7 +826,7 @@ hipError_t launch_bert_attention(const float* qkv, const uint32_t* offsets, void
         return e && e[0] == 'v';
     }();
     if (!valu) {
-        hipLaunchKernelGGL(bert_attention_mfma_kernel, dim3(n_docs, heads, (max_seq + 63) / 64), dim3(256), 0, stream, qkv,
+        hipLaunchKernelGGL(bert_attention_mfma_kernel<float>, dim3(n_docs, heads, (max_seq + 63) / 64), dim3(256), 0, stream, qkv,
                            offsets, static_cast<_Float16*>(ctx_h), hidden, scale);
         return hipGetLastError();
     }

@@ -231,9 +231,25 @@ hipError_t launch_bert_gemm(const void* a_h, const void* w_h, const float* bias,
                             int N, int K, bool gelu_half_out, hipStream_t stream);
 hipError_t launch_bert_attention(const float* qkv, const uint32_t* offsets, void* ctx_h, int n_docs, int heads,
                                  int hidden, int max_seq, float scale, hipStream_t stream);
+hipError_t launch_bert_attention_h(const void* qkv_h, const uint32_t* offsets, void* ctx_h, int n_docs, int heads,
+                                   int hidden, int max_seq, float scale, hipStream_t stream);   // Q, K, V already f16
 hipError_t launch_bert_pool(const float* x, const uint32_t* offsets, float* out, int n_docs, int hidden,
                             hipStream_t stream);
 hipError_t launch_bert_to_half(const float* src, void* dst, size_t n, hipStream_t stream);
+
+// bert_gemm_w.hip: batch-path linears over weights pre-packed in matrix-core fragment order
+hipError_t launch_bert_pack_w(const void* w_h, void* packed_h, int N, int K, hipStream_t stream);
+bool bert_gemm_w_supported(int N, int K);
+// epilogue 0: f32 output; 1: GELU, f16 output; 2: f16 output
+hipError_t launch_bert_gemm_w(const void* a_h, const void* wp, const float* bias, float* out_f32, void* out_h, int M, int N,
+                              int K, int epilogue, hipStream_t stream);
+bool bert_gemm_ln_w_supported(int hidden, int K);
+hipError_t launch_bert_gemm_ln_w(const void* a_h, const void* wp, const float* bias, float* x_f32, void* x_h,
+                                 const float* lnw, const float* lnb, int M, int hidden, int K, float eps, hipStream_t stream);
+// the whole feed-forward block (up-projection, GELU, down-projection, residual, LayerNorm) in one launch
+bool bert_ffn_w_supported(int hidden, int inter);
+hipError_t launch_bert_ffn_w(const void* w1p, const float* b1, const void* w2p, const float* b2, float* x_f32, void* x_h,
+                             const float* lnw, const float* lnb, int M, int hidden, int inter, float eps, hipStream_t stream);
 
 // bert_query_kernels.hip: the MiniLM-L6 forward for at most 32 tokens in 25 launches (4 per layer + the pooling), every
 // add+LayerNorm riding in the prologue of the GEMM that consumes it.  One argument block serves all stages; a stage reads

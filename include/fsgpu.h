@@ -433,6 +433,9 @@ fsgpu_status fsgpu_bert_set_coalescing(fsgpu_bert *m, uint32_t max_batch, uint32
  *   FSGPU_GRID_BLOCKS, FSGPU_I8_PER_CU   grid sizes of the exact kernels
  *   FSGPU_SELECT_SORT_ABOVE     rank above which select_kernel sorts instead of extracting
  *   FSGPU_BERT_GEMM_SHAPE, FSGPU_BERT_ATTN, FSGPU_BERT_NO_FUSED_LN, FSGPU_BERT_NO_GRAPH, FSGPU_BERT_NO_QUERY_PATH   encoder paths
+ *   FSGPU_BERT_GEMM_V1          batches through the LDS-tiled GEMMs of bert_kernels.hip instead of the fragment-order weights
+ *   FSGPU_BERT_SPLIT_FFN        the feed-forward block as two launches (FFN up, FFN down + LayerNorm) instead of one
+ *   FSGPU_GW_DBG=<bits>         TIMING ONLY, results are wrong: phases of the fragment-order GEMMs switched off (scripts/ubench/enc_dbg.sh)
  *   FSGPU_DEBUG_BATCHED, FSGPU_DEBUG_GRAPH   one-line diagnostics on stderr */
 
 /* ---- instrumentation ---- */
