@@ -279,7 +279,7 @@ SearchError NativeEmbedder::forward(uint32_t n_docs, uint32_t tokens, uint32_t m
     // a batch fills the chip with 32-row blocks; a single query (a few tokens) would run each projection on ONE block
     // and is quicker through the 32x64-tile GEMM + the stand-alone add+LN kernel (measured 0.36 vs 0.43 ms)
     const bool fused_ln = !no_fuse && T > 256 && bert_gemm_ln_supported(H) && (H % 32 == 0) && (I % 32 == 0);
-    // a batch: every linear over the fragment-order weights (bert_gemm_w.hip) — 5 launches per layer
+    // a batch: every linear over the fragment-order weights (bert_gemm_w.hip) — 3 launches per layer (QKV, attention, the rest)
     const bool packed = packed_ && T > 256;
     for (Layer& l : layers_) {
         if (packed) {
@@ -289,6 +289,17 @@ SearchError NativeEmbedder::forward(uint32_t n_docs, uint32_t tokens, uint32_t m
                                         2, stream_));
             BERT_HIP(launch_bert_attention_h(qkv, offs, ctx_h_.ptr, (int)n_docs, (int)cfg_.heads, H, (int)max_seq, scale,
                                              stream_));
+            static const bool split_ao = std::getenv("FSGPU_BERT_SPLIT_AO") != nullptr;     // A/B runs: output projection apart
+            static const bool split_ffn0 = std::getenv("FSGPU_BERT_SPLIT_FFN") != nullptr;
+            if (!split_ao && !split_ffn0 && bert_post_attn_w_supported(H, I)) {
+                BERT_HIP(launch_bert_post_attn_w(ctx_h_.ptr, l.ao_wp.ptr, static_cast<const float*>(l.ao_b.ptr),
+                                                 static_cast<const float*>(l.ln1_w.ptr), static_cast<const float*>(l.ln1_b.ptr),
+                                                 l.i_wp.ptr, static_cast<const float*>(l.i_b.ptr), l.o_wp.ptr,
+                                                 static_cast<const float*>(l.o_b.ptr), x, x_h_.ptr,
+                                                 static_cast<const float*>(l.ln2_w.ptr), static_cast<const float*>(l.ln2_b.ptr), T, H,
+                                                 I, eps, stream_));
+                continue;
+            }
             BERT_HIP(launch_bert_gemm_ln_w(ctx_h_.ptr, l.ao_wp.ptr, static_cast<const float*>(l.ao_b.ptr), x, x_h_.ptr,
                                            static_cast<const float*>(l.ln1_w.ptr), static_cast<const float*>(l.ln1_b.ptr), T, H,
                                            H, eps, stream_));

@@ -333,114 +333,247 @@ __global__ __launch_bounds__(256) void bert_gemm_ln_w_kernel(const _Float16* __r
 
 // The whole feed-forward block of a layer in one launch: x = LayerNorm(x + GELU(x W1^T + b1) W2^T + b2)
 // (encoder_layer_raw, native.rs:606-626) for hidden = 64 CT.  A 512-thread block owns 32 complete rows:
-//   phase 0  the f32 rows of x -> LDS (they are the residual AND, rounded to f16 per fragment, the up-projection's A operand:
-//            every wave keeps all its A fragments — 2 row tiles x hidden/32 k-steps — in registers for the whole phase);
-//   phase 1  wave w computes intermediate columns [inter/8 w, inter/8 (w + 1)) two 16-column tiles at a time, W1 fragments
-//            streaming through a register ring half a chunk deep; bias + GELU -> f16 -> the 32 x inter tile in LDS.  The
-//            intermediate activations (16 MB per layer at 5k tokens) never leave the CU;
-//   phase 2  the down-projection over that tile, W2 fragments through a second ring (its first loads are issued before the
-//            barrier that ends phase 1), then the LayerNorm epilogue of bert_gemm_ln_w_kernel over 8 waves.
-// One launch, one 8 MB read and one 12 MB write per layer instead of two launches moving 56 MB.
-template <int CT>
-__global__ __launch_bounds__(512) void bert_ffn_w_kernel(const half8* __restrict__ W1p, const float* __restrict__ b1,
+//   phase 0  the f16 rows of x -> LDS (the up-projection's A operand);
+//   phase 1  wave w computes intermediate columns [inter/8 w, inter/8 (w + 1)) CH 16-column tiles at a time, W1 fragments
+//            streaming through a register ring one whole chunk deep (both projections are bound by the latency of the
+//            weight stream — ~1.3 us under load —, so what counts is bytes in flight: 8 waves x KS1 x CH KB);
+//            bias + GELU -> f16 -> the 32 x inter tile in LDS.  The intermediate activations (16 MB per layer at 5k
+//            tokens) never leave the CU;
+//   phase 2  the down-projection over that tile, W2 fragments through a second ring (its first loads, and the f32 residual
+//            rows, are requested before the barrier that ends phase 1), then the LayerNorm epilogue of
+//            bert_gemm_ln_w_kernel over 8 waves; the residual / output tile reuses the intermediate tile's LDS.
+// One launch, 12 MB read and 12 MB written per layer instead of two launches moving 56 MB.
+// AO = true puts the attention-output projection and the first LayerNorm in front (phase A): everything of a layer after the
+// attention is then this one launch, and the rows between the two LayerNorms exist only in registers and LDS.
+template <int CT, int CH, bool AO>
+__global__ __launch_bounds__(512) void bert_ffn_w_kernel(const _Float16* __restrict__ ctx, const half8* __restrict__ W0p,
+                                                         const float* __restrict__ b0, const float* __restrict__ ln0w,
+                                                         const float* __restrict__ ln0b, const half8* __restrict__ W1p,
+                                                         const float* __restrict__ b1,
                                                          const half8* __restrict__ W2p, const float* __restrict__ b2,
                                                          float* __restrict__ x_f32, _Float16* __restrict__ x_h,
                                                          const float* __restrict__ lnw, const float* __restrict__ lnb, int M,
                                                          int I, float eps) {
     constexpr int H = 64 * CT, BM = 32, NW = 8;
-    constexpr int KS1 = H / 32;            // k-steps of the up-projection
-    constexpr int R1 = KS1 / 2;            // ring depth (k-steps) of the W1 stream
+    constexpr int KS1 = H / 32;            // k-steps of the up-projection = ring depth of the W1 stream
     constexpr int NT2 = 4 * CT / NW;       // 16-column tiles of the output per wave
-    constexpr int R2 = 6;                  // ring depth of the W2 stream
+    constexpr int R2 = AO ? 8 : 12;        // ring depth of the W2 stream (AO also carries the rows between the LayerNorms)
     constexpr int XP = H + 4;              // floats per row of the residual / output tile
-    static_assert(KS1 % 2 == 0 && (4 * CT) % NW == 0, "hidden must be a multiple of 128");
+    constexpr int HP = H + 16;             // halves per row of the f16 x tile
+    constexpr int XL = BM * (H / 4) / 512; // float4 pieces of the residual tile per thread
+    static_assert((4 * CT) % NW == 0, "hidden must be a multiple of 128");
     extern __shared__ __attribute__((aligned(16))) unsigned char ffn_smem[];
     float* red = reinterpret_cast<float*>(ffn_smem);                                      // [BM][NW]
-    float* Xs = reinterpret_cast<float*>(ffn_smem + BM * NW * 4);                         // [BM][XP]
-    _Float16* Is = reinterpret_cast<_Float16*>(ffn_smem + BM * NW * 4 + BM * XP * 4);     // [BM][I + 16]
+    _Float16* Xh = reinterpret_cast<_Float16*>(ffn_smem + BM * NW * 4);                   // [BM][HP]
+    _Float16* Is = Xh + BM * HP;                                                          // [BM][I + 16]
+    float* Xs = reinterpret_cast<float*>(Is);                                             // [BM][XP], after phase 2
     const int ip = I + 16, ksteps2 = I / 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bm0 = blockIdx.x * BM;
     const int fr = lane & 15, q = lane >> 4, cq = q * 4;
-    const int tpw = I / 16 / NW;           // intermediate tiles per wave (a multiple of 2)
-    const int nchunks = tpw / 2;
-    // W1 stream of this wave: fragment (chunk c, tile j, k-step ks) at w1[((2 c + j) * KS1 + ks) * 64]
+    const int tpw = I / 16 / NW;           // intermediate tiles per wave (a multiple of CH)
+    const int nchunks = tpw / CH;
+    // W1 stream of this wave: fragment (chunk c, tile j, k-step ks) at w1[((CH c + j) * KS1 + ks) * 64]
     const half8* w1 = W1p + (size_t)(wave * tpw) * KS1 * 64 + lane;
-    half8 r1[R1][2];
+    half8 r1[KS1][CH];
+    if (!AO)
 #pragma unroll
-    for (int d = 0; d < R1; ++d)
+        for (int ks = 0; ks < KS1; ++ks)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) r1[d][j] = w1[(j * KS1 + d) * 64];
-    // phase 0: rows of x -> LDS (row-contiguous loads)
-    {
-        constexpr int XL = BM * (H / 4) / 512;
-        f32x4 rx[XL];
+            for (int j = 0; j < CH; ++j) r1[ks][j] = w1[(j * KS1 + ks) * 64];
+    f32x4 x1[2][NT2];                      // AO: the rows after the first LayerNorm (this lane's elements), the FFN's residual
+    if (AO) {
+        // phase A: x1 = LayerNorm(x + ctx W0^T + b0) (attention output projection, add_ln_raw) — bert_gemm_ln_w_kernel's work
+        // on 8 waves, its f16 result going straight into the x tile of phase 1 and its f32 result staying in registers.
+        // The context tile and the f32 residual rows borrow the intermediate tile's LDS.
+        _Float16* Cs = Is;                                                    // [BM][HP]
+        float* Xa = reinterpret_cast<float*>(Is + BM * HP);                   // [BM][XP]
+        const half8* w0 = W0p + (size_t)(wave * NT2) * KS1 * 64 + lane;      // fragment (tile j, k-step ks) at w0[(j KS1 + ks) 64]
+        half8 r0[KS1][NT2];
 #pragma unroll
-        for (int x = 0; x < XL; ++x) {
-            const int p = tid + 512 * x, r = p / (H / 4), c4 = p % (H / 4);
-            int row = bm0 + r;
-            row = row < M ? row : M - 1;
-            rx[x] = *(reinterpret_cast<const f32x4*>(x_f32 + (size_t)row * H) + c4);
+        for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+            for (int j = 0; j < NT2; ++j) r0[ks][j] = w0[(j * KS1 + ks) * 64];
+        {
+            constexpr int PIECES = H / 8, AL = (BM * PIECES + 511) / 512;
+            half8 ra[AL];
+            f32x4 rx[XL];
+#pragma unroll
+            for (int x = 0; x < AL; ++x) {
+                const int p = tid + 512 * x;
+                if (p < BM * PIECES) {
+                    const int r = p / PIECES, c = p % PIECES;
+                    int row = bm0 + r;
+                    row = row < M ? row : M - 1;
+                    ra[x] = *(reinterpret_cast<const half8*>(ctx + (size_t)row * H) + c);
+                }
+            }
+#pragma unroll
+            for (int x = 0; x < XL; ++x) {
+                const int p = tid + 512 * x, r = p / (H / 4), c4 = p % (H / 4);
+                int row = bm0 + r;
+                row = row < M ? row : M - 1;
+                rx[x] = *(reinterpret_cast<const f32x4*>(x_f32 + (size_t)row * H) + c4);
+            }
+#pragma unroll
+            for (int x = 0; x < AL; ++x) {
+                const int p = tid + 512 * x;
+                if (p < BM * PIECES) {
+                    const int r = p / PIECES, c = p % PIECES;
+                    *reinterpret_cast<half8*>(&Cs[r * HP + c * 8]) = ra[x];
+                }
+            }
+#pragma unroll
+            for (int x = 0; x < XL; ++x) {
+                const int p = tid + 512 * x, r = p / (H / 4), c4 = p % (H / 4);
+                *reinterpret_cast<f32x4*>(&Xa[r * XP + c4 * 4]) = rx[x];
+            }
         }
-#pragma unroll
-        for (int x = 0; x < XL; ++x) {
-            const int p = tid + 512 * x, r = p / (H / 4), c4 = p % (H / 4);
-            *reinterpret_cast<f32x4*>(&Xs[r * XP + c4 * 4]) = rx[x];
-        }
-    }
-    __syncthreads();
-    // phase 1
-    {
-        half8 a1[2][KS1];
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) {
-                const float* src = &Xs[(i * 16 + fr) * XP + ks * 32 + q * 8];
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
-                half8 h;
-                h[0] = (_Float16)lo[0]; h[1] = (_Float16)lo[1]; h[2] = (_Float16)lo[2]; h[3] = (_Float16)lo[3];
-                h[4] = (_Float16)hi[0]; h[5] = (_Float16)hi[1]; h[6] = (_Float16)hi[2]; h[7] = (_Float16)hi[3];
-                a1[i][ks] = h;
+            for (int j = 0; j < NT2; ++j) x1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            half8 af[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const half8*>(&Cs[(i * 16 + fr) * HP + ks * 32 + q * 8]);
+#pragma unroll
+            for (int j = 0; j < NT2; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    x1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r0[ks][j], af[i], x1[i][j], 0, 0, 0);
+        }
+        float ps[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT2; ++j) {
+                const int col = wave * 16 * NT2 + j * 16 + cq;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(b0 + col);
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(&Xa[(i * 16 + fr) * XP + col]);
+                const f32x4 y = (x1[i][j] + bv) + xv;
+                x1[i][j] = y;
+                sm += (y[0] + y[1]) + (y[2] + y[3]);
             }
-        for (int c = 0; c < nchunks; ++c) {
-            f32x4 acc[2][2];
+            sm += __shfl_xor(sm, 16);
+            sm += __shfl_xor(sm, 32);
+            ps[i] = sm;
+        }
+        if (lane < 16) {
+            red[(0 * 16 + lane) * NW + wave] = ps[0];
+            red[(1 * 16 + lane) * NW + wave] = ps[1];
+        }
+        __syncthreads();
+        float mu[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+            const float* p = red + (i * 16 + fr) * NW;
+            mu[i] = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) / (float)H;
+        }
+        __syncthreads();
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const half8* wc = w1 + (size_t)(2 * c) * KS1 * 64;
+        for (int i = 0; i < 2; ++i) {
+            float qs = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) {
-                const int d = ks % R1;
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r1[d][j], a1[i][ks], acc[i][j], 0, 0, 0);
-                // refill the slot with the fragment R1 steps ahead: same chunk (ks + R1 < KS1) or the next one
-                if (ks + R1 < KS1) {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) r1[d][j] = wc[(j * KS1 + ks + R1) * 64];
-                } else if (c + 1 < nchunks) {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) r1[d][j] = wc[((2 + j) * KS1 + ks + R1 - KS1) * 64];
-                }
+            for (int j = 0; j < NT2; ++j) {
+                const f32x4 d = x1[i][j] - mu[i];
+                qs += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
             }
+            qs += __shfl_xor(qs, 16);
+            qs += __shfl_xor(qs, 32);
+            if (lane < 16) red[(i * 16 + lane) * NW + wave] = qs;
+        }
+        __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = (wave * tpw + 2 * c + j) * 16 + cq;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(b1 + col);
+        for (int i = 0; i < 2; ++i) {
+            const float* p = red + (i * 16 + fr) * NW;
+            const float var = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) / (float)H;
+            const float inv = 1.0f / sqrtf(var + eps);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const f32x4 y = acc[i][j] + bv;
-                    half4 h;
-                    h[0] = (_Float16)gelu_as_w(y[0]);
-                    h[1] = (_Float16)gelu_as_w(y[1]);
-                    h[2] = (_Float16)gelu_as_w(y[2]);
-                    h[3] = (_Float16)gelu_as_w(y[3]);
-                    *reinterpret_cast<half4*>(&Is[(i * 16 + fr) * ip + col]) = h;
-                }
+            for (int j = 0; j < NT2; ++j) {
+                const int col = wave * 16 * NT2 + j * 16 + cq;
+                const f32x4 g = *reinterpret_cast<const f32x4*>(ln0w + col);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(ln0b + col);
+                const f32x4 y = (x1[i][j] - mu[i]) * inv * g + b;
+                x1[i][j] = y;
+                half4 h;
+                h[0] = (_Float16)y[0];
+                h[1] = (_Float16)y[1];
+                h[2] = (_Float16)y[2];
+                h[3] = (_Float16)y[3];
+                *reinterpret_cast<half4*>(&Xh[(i * 16 + fr) * HP + col]) = h;
+            }
+        }
+        __syncthreads();   // the x tile is complete; the statistics buffer and the borrowed LDS are free again
+    } else {
+    // phase 0: f16 rows of x -> LDS (one contiguous run of x_h, clamped at M)
+    {
+        constexpr int PIECES = H / 8, AL = (BM * PIECES + 511) / 512;
+        half8 ra[AL];
+#pragma unroll
+        for (int x = 0; x < AL; ++x) {
+            const int p = tid + 512 * x;
+            if (p < BM * PIECES) {
+                const int r = p / PIECES, c = p % PIECES;
+                int row = bm0 + r;
+                row = row < M ? row : M - 1;
+                ra[x] = *(reinterpret_cast<const half8*>(x_h + (size_t)row * H) + c);
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < AL; ++x) {
+            const int p = tid + 512 * x;
+            if (p < BM * PIECES) {
+                const int r = p / PIECES, c = p % PIECES;
+                *reinterpret_cast<half8*>(&Xh[r * HP + c * 8]) = ra[x];
+            }
+        }
+    }
+    __syncthreads();
+    }
+    // phase 1
+    if (AO)
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+            for (int j = 0; j < CH; ++j) r1[ks][j] = w1[(j * KS1 + ks) * 64];
+    for (int c = 0; c < nchunks; ++c) {
+        f32x4 acc[2][CH];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < CH; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const half8* wn = w1 + (size_t)(CH * (c + 1)) * KS1 * 64;   // the next chunk
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            half8 af[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const half8*>(&Xh[(i * 16 + fr) * HP + ks * 32 + q * 8]);
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r1[ks][j], af[i], acc[i][j], 0, 0, 0);
+            if (c + 1 < nchunks)
+#pragma unroll
+                for (int j = 0; j < CH; ++j) r1[ks][j] = wn[(j * KS1 + ks) * 64];
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int col = (wave * tpw + CH * c + j) * 16 + cq;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(b1 + col);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f32x4 y = acc[i][j] + bv;
+                half4 h;
+                h[0] = (_Float16)gelu_as_w(y[0]);
+                h[1] = (_Float16)gelu_as_w(y[1]);
+                h[2] = (_Float16)gelu_as_w(y[2]);
+                h[3] = (_Float16)gelu_as_w(y[3]);
+                *reinterpret_cast<half4*>(&Is[(i * 16 + fr) * ip + col]) = h;
             }
         }
     }
@@ -452,6 +585,15 @@ __global__ __launch_bounds__(512) void bert_ffn_w_kernel(const half8* __restrict
         if (d < ksteps2)
 #pragma unroll
             for (int j = 0; j < NT2; ++j) r2[d][j] = w2[((size_t)j * ksteps2 + d) * 64];
+    f32x4 rx[XL];                          // !AO: the residual rows, row-contiguous; parked in LDS after the k-loop
+    if (!AO)
+#pragma unroll
+        for (int x = 0; x < XL; ++x) {
+            const int p = tid + 512 * x, r = p / (H / 4), c4 = p % (H / 4);
+            int row = bm0 + r;
+            row = row < M ? row : M - 1;
+            rx[x] = *(reinterpret_cast<const f32x4*>(x_f32 + (size_t)row * H) + c4);
+        }
     __syncthreads();   // the intermediate tile is complete
     f32x4 acc[2][NT2];
 #pragma unroll
@@ -477,6 +619,15 @@ __global__ __launch_bounds__(512) void bert_ffn_w_kernel(const half8* __restrict
             }
         }
     }
+    __syncthreads();   // every wave is done with the intermediate tile: its space becomes the residual / output tile
+    if (!AO) {
+#pragma unroll
+        for (int x = 0; x < XL; ++x) {
+            const int p = tid + 512 * x, r = p / (H / 4), c4 = p % (H / 4);
+            *reinterpret_cast<f32x4*>(&Xs[r * XP + c4 * 4]) = rx[x];
+        }
+        __syncthreads();
+    }
     // epilogue: rows i * 16 + fr, columns wave * 16 NT2 + j * 16 + cq .. + 3
     float psum[2];
 #pragma unroll
@@ -486,7 +637,7 @@ __global__ __launch_bounds__(512) void bert_ffn_w_kernel(const half8* __restrict
         for (int j = 0; j < NT2; ++j) {
             const int col = wave * 16 * NT2 + j * 16 + cq;
             const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + col);
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(&Xs[(i * 16 + fr) * XP + col]);
+            const f32x4 xv = AO ? x1[i][j] : *reinterpret_cast<const f32x4*>(&Xs[(i * 16 + fr) * XP + col]);
             const f32x4 y = (acc[i][j] + bv) + xv;
             acc[i][j] = y;
             s += (y[0] + y[1]) + (y[2] + y[3]);
@@ -534,7 +685,6 @@ __global__ __launch_bounds__(512) void bert_ffn_w_kernel(const half8* __restrict
         }
     }
     __syncthreads();
-    constexpr int XL = BM * (H / 4) / 512;
 #pragma unroll
     for (int x = 0; x < XL; ++x) {
         const int pp = tid + 512 * x, r = pp / (H / 4), c4 = pp % (H / 4);
@@ -631,25 +781,30 @@ hipError_t launch_bert_gemm_ln_w(const void* a_h, const void* wp, const float* b
 }
 
 static size_t ffn_w_lds(int hidden, int inter) {
-    return (size_t)32 * 8 * 4 + (size_t)32 * (hidden + 4) * 4 + (size_t)32 * (inter + 16) * 2;
+    return (size_t)32 * 8 * 4 + (size_t)32 * (hidden + 16) * 2 + (size_t)32 * (inter + 16) * 2;
 }
 
-// hidden in {128, 256, 384}; inter a multiple of 256 (8 waves x 2 tiles); residual + intermediate tiles within 160 KB of LDS
+// hidden in {128, 256, 384}; inter a multiple of 256 (8 waves x chunks of 2 tiles; of 384 for the 3-tile chunks) and at least
+// as wide as the f32 residual tile that later reuses its LDS; f16 x tile + intermediate tile within 160 KB
 bool bert_ffn_w_supported(int hidden, int inter) {
     return (hidden == 384 || hidden == 256 || hidden == 128) && inter >= 256 && inter % 256 == 0 &&
-           ffn_w_lds(hidden, inter) <= (size_t)160 * 1024;
+           (size_t)(inter + 16) * 2 >= (size_t)(hidden + 4) * 4 && ffn_w_lds(hidden, inter) <= (size_t)160 * 1024;
 }
 
-template <int CT>
-static hipError_t launch_ffn_w_t(const void* w1p, const float* b1, const void* w2p, const float* b2, float* x_f32, void* x_h,
+template <int CT, bool AO>
+static hipError_t launch_ffn_w_t(const void* ctx_h, const void* w0p, const float* b0, const float* ln0w, const float* ln0b,
+                                 const void* w1p, const float* b1, const void* w2p, const float* b2, float* x_f32, void* x_h,
                                  const float* lnw, const float* lnb, int M, int I, float eps, hipStream_t stream) {
     const size_t lds = ffn_w_lds(64 * CT, I);
-    auto kern = bert_ffn_w_kernel<CT>;
+    // three 16-column tiles per chunk when the wave's share divides, else two; the AO form (which also carries the rows
+    // between the LayerNorms in registers) always two: with three, hidden = 384 spills
+    auto kern = (!AO && (I / 16 / 8) % 3 == 0) ? bert_ffn_w_kernel<CT, 3, AO> : bert_ffn_w_kernel<CT, 2, AO>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3((M + 31) / 32), dim3(512), lds, stream, static_cast<const half8*>(w1p), b1,
+    hipLaunchKernelGGL(kern, dim3((M + 31) / 32), dim3(512), lds, stream, static_cast<const _Float16*>(ctx_h),
+                       static_cast<const half8*>(w0p), b0, ln0w, ln0b, static_cast<const half8*>(w1p), b1,
                        static_cast<const half8*>(w2p), b2, x_f32, static_cast<_Float16*>(x_h), lnw, lnb, M, I, eps);
     return hipGetLastError();
 }
@@ -658,9 +813,27 @@ hipError_t launch_bert_ffn_w(const void* w1p, const float* b1, const void* w2p, 
                              const float* lnw, const float* lnb, int M, int hidden, int inter, float eps, hipStream_t stream) {
     if (!bert_ffn_w_supported(hidden, inter)) return hipErrorInvalidValue;
     switch (hidden) {
-        case 384: return launch_ffn_w_t<6>(w1p, b1, w2p, b2, x_f32, x_h, lnw, lnb, M, inter, eps, stream);
-        case 256: return launch_ffn_w_t<4>(w1p, b1, w2p, b2, x_f32, x_h, lnw, lnb, M, inter, eps, stream);
-        default: return launch_ffn_w_t<2>(w1p, b1, w2p, b2, x_f32, x_h, lnw, lnb, M, inter, eps, stream);
+        case 384: return launch_ffn_w_t<6, false>(nullptr, nullptr, nullptr, nullptr, nullptr, w1p, b1, w2p, b2, x_f32, x_h, lnw, lnb, M, inter, eps, stream);
+        case 256: return launch_ffn_w_t<4, false>(nullptr, nullptr, nullptr, nullptr, nullptr, w1p, b1, w2p, b2, x_f32, x_h, lnw, lnb, M, inter, eps, stream);
+        default: return launch_ffn_w_t<2, false>(nullptr, nullptr, nullptr, nullptr, nullptr, w1p, b1, w2p, b2, x_f32, x_h, lnw, lnb, M, inter, eps, stream);
+    }
+}
+
+// the borrowed LDS of phase A (context tile + f32 residual tile) must fit inside the intermediate tile
+bool bert_post_attn_w_supported(int hidden, int inter) {
+    return bert_ffn_w_supported(hidden, inter) &&
+           (size_t)(inter + 16) * 2 >= (size_t)(hidden + 16) * 2 + (size_t)(hidden + 4) * 4;
+}
+
+hipError_t launch_bert_post_attn_w(const void* ctx_h, const void* w0p, const float* b0, const float* ln0w, const float* ln0b,
+                                   const void* w1p, const float* b1, const void* w2p, const float* b2, float* x_f32, void* x_h,
+                                   const float* lnw, const float* lnb, int M, int hidden, int inter, float eps,
+                                   hipStream_t stream) {
+    if (!bert_post_attn_w_supported(hidden, inter)) return hipErrorInvalidValue;
+    switch (hidden) {
+        case 384: return launch_ffn_w_t<6, true>(ctx_h, w0p, b0, ln0w, ln0b, w1p, b1, w2p, b2, x_f32, x_h, lnw, lnb, M, inter, eps, stream);
+        case 256: return launch_ffn_w_t<4, true>(ctx_h, w0p, b0, ln0w, ln0b, w1p, b1, w2p, b2, x_f32, x_h, lnw, lnb, M, inter, eps, stream);
+        default: return launch_ffn_w_t<2, true>(ctx_h, w0p, b0, ln0w, ln0b, w1p, b1, w2p, b2, x_f32, x_h, lnw, lnb, M, inter, eps, stream);
     }
 }
 

@@ -250,6 +250,12 @@ hipError_t launch_bert_gemm_ln_w(const void* a_h, const void* wp, const float* b
 bool bert_ffn_w_supported(int hidden, int inter);
 hipError_t launch_bert_ffn_w(const void* w1p, const float* b1, const void* w2p, const float* b2, float* x_f32, void* x_h,
                              const float* lnw, const float* lnb, int M, int hidden, int inter, float eps, hipStream_t stream);
+// everything of a layer after the attention in one launch: output projection + LayerNorm, then the feed-forward block
+bool bert_post_attn_w_supported(int hidden, int inter);
+hipError_t launch_bert_post_attn_w(const void* ctx_h, const void* w0p, const float* b0, const float* ln0w, const float* ln0b,
+                                   const void* w1p, const float* b1, const void* w2p, const float* b2, float* x_f32, void* x_h,
+                                   const float* lnw, const float* lnb, int M, int hidden, int inter, float eps,
+                                   hipStream_t stream);
 
 // bert_query_kernels.hip: the MiniLM-L6 forward for at most 32 tokens in 25 launches (4 per layer + the pooling), every
 // add+LayerNorm riding in the prologue of the GEMM that consumes it.  One argument block serves all stages; a stage reads
