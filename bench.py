@@ -374,14 +374,19 @@ def config5_section(index, rows: int, k: int, local_rank: int, batches: int = 20
     rng = np.random.default_rng(5)
     def batch():
         return [[101] + rng.integers(1000, 30000, int(rng.integers(6, 31))).tolist() + [102] for _ in range(256)]
-    sets = [batch() for _ in range(4)]
-    for b in sets[:2]:
-        index.search_batched(bert.embed_batch_token_ids(b), k)
+    def flat(b):   # the C ABI's argument shape (what a host holds after tokenising): concatenated ids + offsets
+        offs = np.zeros(len(b) + 1, dtype=np.uint32)
+        offs[1:] = np.cumsum([len(x) for x in b])
+        return np.concatenate([np.asarray(x, dtype=np.int32) for x in b]), offs
+    sets = [flat(batch()) for _ in range(4)]
+    emb = np.empty((256, 384), dtype=np.float32)
+    for ids, offs in sets[:2]:
+        index.search_batched(bert.embed_flat(ids, offs, emb), k)
     enc_ms, scan_ms = [], []
     t0 = time.perf_counter()
     for i in range(batches):
         t1 = time.perf_counter()
-        emb = bert.embed_batch_token_ids(sets[i % 4])
+        bert.embed_flat(sets[i % 4][0], sets[i % 4][1], emb)
         t2 = time.perf_counter()
         rows_out, scores, counts, fb = index.search_batched(emb, k)
         t3 = time.perf_counter()
@@ -390,7 +395,7 @@ def config5_section(index, rows: int, k: int, local_rank: int, batches: int = 20
     dt = time.perf_counter() - t0
     return {"workload": f"256 token-id queries per batch -> MiniLM-L6 on the GPU -> batched exact scan of {rows}x384 f16, top-{k}",
             "queries_per_sec": batches * 256 / dt, "encode_ms_per_batch": float(np.median(enc_ms)),
-            "scan_ms_per_batch": float(np.median(scan_ms)), "tokens_per_batch": sum(len(x) for x in sets[0]),
+            "scan_ms_per_batch": float(np.median(scan_ms)), "tokens_per_batch": int(sets[0][0].size),
             "all_counts_full": bool(np.all(counts == k))}
 
 

@@ -87,3 +87,22 @@ def test_batch_256_queries_config5_shape(fa):
     got = m.embed_batch_token_ids(batch)
     want = bert_oracle.embed_forward(w, batch[:24], 6)
     check(got[:24], want)
+
+
+@pytest.mark.parametrize("hidden,inter,layers", [(256, 1024, 2), (128, 384, 2), (384, 1280, 1)])
+def test_batch_path_other_widths(fa, hidden, inter, layers):
+    """The fragment-order batch kernels (bert_gemm_w.hip) at the other supported widths: hidden 256 (the one-launch
+    post-attention kernel with 2-tile chunks), inter 384 (not a multiple of 256: FFN up and FFN down + LayerNorm as
+    separate launches), inter 1280 (chunks of two); token counts that are not multiples of the 32 / 64-row tiles."""
+    from oracle import bert_oracle
+    rng = np.random.default_rng(hidden + inter)
+    w = bert_oracle.random_weights(31, 3000, hidden, layers, inter)
+    m = fa.NativeEmbedder(w)
+    lens = [int(x) for x in rng.integers(3, 40, 40)] + [1, 129]
+    batch = [[101] + rng.integers(1000, 3000, n - 1).tolist() for n in lens]
+    assert sum(lens) > 256 and sum(lens) % 32 != 0
+    got = m.embed_batch_token_ids(batch)
+    check(got, bert_oracle.embed_forward(w, batch, layers))
+    # a text alone (query path or small-batch kernels) agrees with the same text inside the batch
+    for i in (0, 7, 41):
+        assert float(np.sum(m.embed_token_ids(batch[i]) * got[i])) > 0.9999
