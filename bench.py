@@ -451,13 +451,13 @@ def sharded_handle_leg(args, world: int):
            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE",
                         "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "GROUP_WORLD_SIZE", "ROLE_NAME")}
     try:
-        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150)
         last = [l for l in res.stdout.splitlines() if l.startswith("{")]
         if res.returncode == 0 and last:
             return json.loads(last[-1])
         return {"error": f"rc={res.returncode}", "stderr_tail": res.stderr[-400:]}
     except subprocess.TimeoutExpired:
-        return {"error": "timed out after 240 s"}
+        return {"error": "timed out after 150 s"}
     except (OSError, ValueError) as e:
         return {"error": str(e)}
 

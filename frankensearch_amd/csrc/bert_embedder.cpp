@@ -280,7 +280,12 @@ SearchError NativeEmbedder::forward(uint32_t n_docs, uint32_t tokens, uint32_t m
     // and is quicker through the 32x64-tile GEMM + the stand-alone add+LN kernel (measured 0.36 vs 0.43 ms)
     const bool fused_ln = !no_fuse && T > 256 && bert_gemm_ln_supported(H) && (H % 32 == 0) && (I % 32 == 0);
     // a batch: every linear over the fragment-order weights (bert_gemm_w.hip) — 3 launches per layer (QKV, attention, the rest)
-    const bool packed = packed_ && T > 256;
+    static const int packed_min = [] {
+        // above the query path's 32 tokens every size is quicker here (2 queries 0.37 -> 0.30 ms, 12 queries 0.47 -> 0.32 ms)
+        const char* e = std::getenv("FSGPU_BERT_PACKED_MIN_TOKENS");   // tuning runs
+        return e ? std::atoi(e) : 32;
+    }();
+    const bool packed = packed_ && T > packed_min;
     for (Layer& l : layers_) {
         if (packed) {
             // Q, K, V leave the projection as f16 (what the attention's matrix-core operands are rounded to anyway) in the

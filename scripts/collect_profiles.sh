@@ -47,4 +47,10 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE 
 python scripts/pmc_summary.py $OUT/pmc_sq $OUT/pmc_sq.json > /dev/null
 # encoders
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/enc_trace -o enc -- python scripts/bench_encoders.py > $OUT/enc.log 2>&1
+python scripts/bench_encoders.py > $OUT/enc_untraced.log 2>&1
+# matrix-pipe utilisation of the encoder kernels (counter pass apart from the trace)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/enc_pmc -o enc -- python scripts/bench_encoders.py > $OUT/enc_pmc.log 2>&1
+python scripts/encoder_pmc_summary.py $OUT/enc_trace $OUT/enc_pmc $OUT/encoder_mfma_pmc.json > $OUT/encoder_mfma_pmc.txt 2>&1
+# the GPU suite on the same box
+( time python -m pytest tests -m gpu -q ) > $OUT/gputest.log 2>&1
 ls -R $OUT | head -60

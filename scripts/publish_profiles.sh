@@ -9,7 +9,8 @@ rm -f $DST/bench_under_trace.err
 cp $SRC/trace/bench_kernel_stats.csv $DST/bench_kernel_stats.csv
 cp $SRC/trace/bench_domain_stats.csv $DST/bench_domain_stats.csv
 cp $SRC/enc_trace/enc_kernel_stats.csv $DST/encoder_kernel_stats.csv
-grep -E '^(m2v|bert)' $SRC/enc.log > $DST/enc_bench.txt
+grep -E '^(m2v|bert)' $SRC/enc_untraced.log > $DST/enc_bench.txt
+cp $SRC/encoder_mfma_pmc.json $DST/encoder_mfma_pmc.json 2>/dev/null
 cp $SRC/pmc_sq.json $DST/scan_sq_pmc_raw.json
 [ -f $SRC/gputest.log ] && grep -E "passed|failed|real" $SRC/gputest.log > $DST/gputest_summary.txt
 ls $DST
