@@ -262,10 +262,54 @@ SearchError NativeEmbedder::forward_query(uint32_t n_docs, uint32_t tokens) {
     return SearchError{};
 }
 
+SearchError NativeEmbedder::forward_packed_range(uint32_t d0, uint32_t d1, uint32_t t0, uint32_t t1, uint32_t max_seq,
+                                                 hipStream_t stream) {
+    const int H = (int)cfg_.hidden, I = (int)cfg_.inter, T = (int)(t1 - t0);
+    const float eps = cfg_.ln_eps;
+    if (T <= 0 || d1 <= d0) return SearchError{};
+    float* xa = static_cast<float*>(x_f32_.ptr);                       // whole buffers: attention and pooling index tokens absolutely
+    _Float16* xh = static_cast<_Float16*>(x_h_.ptr);
+    _Float16* qkv = static_cast<_Float16*>(qkv_f32_.ptr);              // f16 Q, K, V in the first half of the f32 workspace
+    _Float16* ctx = static_cast<_Float16*>(ctx_h_.ptr);
+    float* x = xa + (size_t)t0 * H;
+    _Float16* x_h = xh + (size_t)t0 * H;
+    const uint32_t* offs = static_cast<const uint32_t*>(offsets_.ptr) + d0;
+    BERT_HIP(launch_bert_embed_ln(static_cast<const int32_t*>(ids_.ptr) + t0, static_cast<const int32_t*>(positions_.ptr) + t0,
+                                  static_cast<const float*>(word_.ptr), static_cast<const float*>(pos_.ptr),
+                                  static_cast<const float*>(type_.ptr), static_cast<const float*>(emb_ln_w_.ptr),
+                                  static_cast<const float*>(emb_ln_b_.ptr), x, x_h, T, H, eps, stream));
+    const float scale = 0.17677669f;  // ATTN_SCALE_F32 = 1/sqrt(32) (native.rs:44)
+    for (Layer& l : layers_) {
+        BERT_HIP(launch_bert_gemm_w(x_h, l.qkv_wp.ptr, static_cast<const float*>(l.qkv_b.ptr), nullptr, qkv + (size_t)t0 * 3 * H, T,
+                                    3 * H, H, 2, stream));
+        BERT_HIP(launch_bert_attention_h(qkv, offs, ctx, (int)(d1 - d0), (int)cfg_.heads, H, (int)max_seq, scale, stream));
+        BERT_HIP(launch_bert_post_attn_w(ctx + (size_t)t0 * H, l.ao_wp.ptr, static_cast<const float*>(l.ao_b.ptr),
+                                         static_cast<const float*>(l.ln1_w.ptr), static_cast<const float*>(l.ln1_b.ptr),
+                                         l.i_wp.ptr, static_cast<const float*>(l.i_b.ptr), l.o_wp.ptr,
+                                         static_cast<const float*>(l.o_b.ptr), x, x_h, static_cast<const float*>(l.ln2_w.ptr),
+                                         static_cast<const float*>(l.ln2_b.ptr), T, H, I, eps, stream));
+    }
+    float* out = (pooled_out_ ? pooled_out_ : static_cast<float*>(out_.ptr)) + (size_t)d0 * H;
+    BERT_HIP(launch_bert_pool(xa, offs, out, (int)(d1 - d0), H, stream));
+    return SearchError{};
+}
+
 SearchError NativeEmbedder::forward(uint32_t n_docs, uint32_t tokens, uint32_t max_seq) {
     const int H = (int)cfg_.hidden, I = (int)cfg_.inter, T = (int)tokens;
     const float eps = cfg_.ln_eps;
     if (query_path(tokens)) return forward_query(n_docs, tokens);
+    {
+        static const bool ab = std::getenv("FSGPU_BERT_SPLIT_AO") || std::getenv("FSGPU_BERT_SPLIT_FFN");   // A/B runs below
+        static const int packed_min0 = [] {
+            const char* e = std::getenv("FSGPU_BERT_PACKED_MIN_TOKENS");
+            return e ? std::atoi(e) : 32;
+        }();
+        if (packed_ && !ab && (int)tokens > packed_min0 && bert_post_attn_w_supported((int)cfg_.hidden, (int)cfg_.inter)) {
+            // (the batch as two halves on two streams — most kernels fill only part of the chip — was tried: the branches of
+            // the replayed graph did not overlap and 256 queries went from 0.43 to 0.50 ms)
+            return forward_packed_range(0, n_docs, 0, tokens, max_seq, stream_);
+        }
+    }
     float* x = static_cast<float*>(x_f32_.ptr);
     float* tmp = static_cast<float*>(tmp_f32_.ptr);
     float* qkv = static_cast<float*>(qkv_f32_.ptr);

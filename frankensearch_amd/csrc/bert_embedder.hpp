@@ -32,6 +32,8 @@ class NativeEmbedder {
     SearchError upload_f16(DeviceBuffer& dst, const float* src, size_t n, DeviceBuffer& staging);
     SearchError pack_weights(DeviceBuffer& dst, const DeviceBuffer& src, int N, int K);
     SearchError forward(uint32_t n_docs, uint32_t tokens, uint32_t max_seq);
+    // the fragment-order batch path over texts [d0, d1) = tokens [t0, t1) on `stream` (bert_gemm_w.hip)
+    SearchError forward_packed_range(uint32_t d0, uint32_t d1, uint32_t t0, uint32_t t1, uint32_t max_seq, hipStream_t stream);
     SearchError forward_query(uint32_t n_docs, uint32_t tokens);   // <= 32 tokens: 25 launches (bert_query_kernels.hip)
     bool query_path(uint32_t tokens) const;
     SearchError reserve_workspaces(uint32_t tokens);
