@@ -212,7 +212,7 @@ def two_tier_section(quality_index, rows: int, k: int, device, local_rank: int):
     seq_spec = speculative.run_load(threads=1, queries=200, warmup_queries=16, k=k, fast_vocab=500_353, corpus_rows=rows)
     speculative.close()
     # concurrent callers, coalesced inside the library into batched launches (fsgpu_*_set_coalescing)
-    max_batch, wait_us = 128, 1000
+    max_batch, wait_us = 256, 1000   # 1,024 callers: 49 k queries/s at 128, 55 k at 256, 54 k at 512 (scripts/exp_two_tier_load.py)
     fast_index.set_coalescing(max_batch, wait_us)
     quality_index.set_coalescing(max_batch, wait_us)
     m2v.set_coalescing(2 * max_batch, wait_us // 2)
