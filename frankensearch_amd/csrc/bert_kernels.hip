@@ -661,49 +661,171 @@ __global__ __launch_bounds__(256) void bert_attention_mfma_kernel(const QT* __re
     }
 }
 
+// Attention for f16 Q, K, V with the keys and values of a (document, head) resident in LDS (documents are at most 512
+// tokens: 32 KB of K + 33 KB of V^T), shared by the block's four waves and by all their query tiles — the kernel above
+// re-fetches and re-transposes every key block once per wave.  Nothing but K and V goes through LDS:
+//   S^T = K Q^T          (A = K fragment from LDS, B = Q fragment in registers): a lane ends up with the scores of ONE query
+//                        (lane & 15) against keys 4 (lane >> 4) .. + 3 of each 16-key tile, so the online softmax's row
+//                        max is in-lane + two xor-shuffles, the row sum stays a per-lane partial until the end, and the
+//   O^T += V^T P^T       exponentials ARE the B fragment of the second product (the reduction index may be permuted freely
+//                        as long as both operands agree: the V^T fragment is read as two 8-byte runs of the same keys);
+//                        its output layout has the lane's query again, so the rescale factor applies in place.
+// K rows are 64 bytes, stored unpadded with the 16-byte chunk index XOR-swizzled by (key >> 2) & 3: conflict-free b128 reads.
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void bert_attention_lds_kernel(const _Float16* __restrict__ qkv,
+                                                                 const uint32_t* __restrict__ offsets,
+                                                                 _Float16* __restrict__ ctx_h, int hidden, float scale,
+                                                                 int vt_offset, int vp, int zsplit) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char attl_smem[];
+    _Float16* Ks = reinterpret_cast<_Float16*>(attl_smem);   // [S32][32], chunk-swizzled
+    _Float16* Vt = Ks + vt_offset;                            // [32][vp]
+    const int doc = blockIdx.x, head = blockIdx.y;
+    const uint32_t t0 = offsets[doc];
+    const int S = (int)(offsets[doc + 1] - t0);
+    if (S == 0) return;
+    const int S32 = (S + 31) & ~31;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int stride = 3 * hidden;
+    const _Float16* base = qkv + (size_t)t0 * stride + head * 32;
+    for (int p = tid; p < S32 * 4; p += 256) {
+        const int key = p >> 2, c = p & 3;
+        const bool live = key < S;
+        const _Float16* src = base + (size_t)(live ? key : S - 1) * stride + c * 8;
+        const half8 kv = *reinterpret_cast<const half8*>(src + hidden);
+        half8 vv = *reinterpret_cast<const half8*>(src + 2 * hidden);
+        if (!live) vv = half8{};
+        *reinterpret_cast<half8*>(&Ks[key * 32 + ((c ^ ((key >> 2) & 3)) * 8)]) = kv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Vt[(c * 8 + e) * vp + key] = vv[e];
+    }
+    __syncthreads();
+    const int fr = lane & 15, kg = lane >> 4;
+    const int ntiles = (S + 15) >> 4;
+    for (int tile = blockIdx.z * 4 + wave; tile < ntiles; tile += 4 * zsplit) {
+        const int q0 = tile * 16;
+        const int qrow = q0 + fr < S ? q0 + fr : S - 1;
+        const half8 bq = *reinterpret_cast<const half8*>(base + (size_t)qrow * stride + kg * 8);
+        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+        float m = -INFINITY, l = 0.f;
+        for (int k0 = 0; k0 < S32; k0 += 32) {
+            f32x4 sc[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int key = k0 + j * 16 + fr;
+                const half8 ak = *reinterpret_cast<const half8*>(&Ks[key * 32 + ((kg ^ ((key >> 2) & 3)) * 8)]);
+                sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ak, bq, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            }
+            if (k0 + 32 > S) {   // only the last key block can hold keys past the end (wave-uniform)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (k0 + j * 16 + kg * 4 + r >= S) sc[j][r] = -INFINITY;
+            }
+            float mx = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])),
+                             fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn = fmaxf(m, mx);
+            // exp((s - mn) scale) as exp2(s c - mn c), c = scale log2(e): one fused multiply-add and one v_exp_f32 per score
+            // (the softmax is VALU-bound here: 32-wide heads give the matrix cores 128 flops per exponential)
+            const float c2 = scale * 1.44269504088896340736f;
+            const float mc = mn * c2;
+            const float corr = __builtin_amdgcn_exp2f(fmaf(m, c2, -mc));
+            half8 bp;
+            float ps = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(sc[j][r], c2, -mc));
+                    ps += pv;
+                    bp[j * 4 + r] = (_Float16)pv;
+                }
+            l = l * corr + ps;
+            m = mn;
+            o0 *= corr;
+            o1 *= corr;
+            // V^T fragments: dim fr (and 16 + fr), keys k0 + 4 kg .. + 3 and k0 + 16 + 4 kg .. + 3 — the keys of bp's slots
+            const half4v a00 = *reinterpret_cast<const half4v*>(&Vt[fr * vp + k0 + kg * 4]);
+            const half4v a01 = *reinterpret_cast<const half4v*>(&Vt[fr * vp + k0 + 16 + kg * 4]);
+            const half4v a10 = *reinterpret_cast<const half4v*>(&Vt[(16 + fr) * vp + k0 + kg * 4]);
+            const half4v a11 = *reinterpret_cast<const half4v*>(&Vt[(16 + fr) * vp + k0 + 16 + kg * 4]);
+            const half8 av0 = {a00[0], a00[1], a00[2], a00[3], a01[0], a01[1], a01[2], a01[3]};
+            const half8 av1 = {a10[0], a10[1], a10[2], a10[3], a11[0], a11[1], a11[2], a11[3]};
+            o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(av0, bp, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(av1, bp, o1, 0, 0, 0);
+        }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        if (q0 + fr < S) {
+            const float inv = 1.0f / l;
+            _Float16* dst = ctx_h + (size_t)(t0 + q0 + fr) * hidden + head * 32 + kg * 4;
+            half4v h0, h1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                h0[r] = (_Float16)(o0[r] * inv);
+                h1[r] = (_Float16)(o1[r] * inv);
+            }
+            *reinterpret_cast<half4v*>(dst) = h0;
+            *reinterpret_cast<half4v*>(dst + 16) = h1;
+        }
+    }
+}
+
 // Mean over all tokens of a document, then L2 (native.rs:1209-1235; zero guard of
-// fastembed_embedder.rs:416-426).  One block per document.
-__global__ __launch_bounds__(256) void bert_pool_kernel(const float* __restrict__ x, const uint32_t* __restrict__ offsets,
-                                                        float* __restrict__ out, int hidden) {
-    __shared__ float red[4];
+// fastembed_embedder.rs:416-426).  One 1,024-thread block per document: wave w sums tokens w, w + 16, ... (a lane holds
+// dims lane + 64 i; eight tokens' loads in flight), the sixteen partial rows meet in LDS and are added in wave order — a
+// fixed order, so the result does not depend on scheduling.  (One thread per dim walking all tokens was 54 us for a
+// 512-token document: 64 dependent round trips.)
+__global__ __launch_bounds__(1024) void bert_pool_kernel(const float* __restrict__ x, const uint32_t* __restrict__ offsets,
+                                                         float* __restrict__ out, int hidden) {
+    constexpr int NWV = 16;
+    extern __shared__ float pool_part[];   // [NWV][hidden]
+    __shared__ float red[NWV];
     const int doc = blockIdx.x;
     const uint32_t t0 = offsets[doc], t1 = offsets[doc + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = (int)(t1 - t0);
-    float vals[4];
-    float sq = 0.f;
+    const int per = hidden >> 6;           // hidden % 64 == 0, <= 1024
+    float acc[kMaxPerLane];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int d = tid + 256 * i;
-        float acc = 0.f;
-        if (d < hidden && n > 0) {
-            // left-to-right sum; the loads of eight tokens are independent and in flight together (a text of 20 tokens was
-            // 20 dependent round trips)
-            uint32_t t = t0;
-            for (; t + 8 <= t1; t += 8) {
-                float v[8];
+    for (int i = 0; i < kMaxPerLane; ++i) acc[i] = 0.f;
+    uint32_t t = t0 + wave;
+    for (; t + 3 * NWV < t1; t += 4 * NWV) {
+        float v[4][kMaxPerLane];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = x[(size_t)(t + u) * hidden + d];
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc += v[u];
-            }
-            for (; t < t1; ++t) acc += x[(size_t)t * hidden + d];
-            acc *= 1.0f / (float)n;
-        }
-        vals[i] = acc;
-        sq += acc * acc;
+            for (int i = 0; i < kMaxPerLane; ++i)
+                if (i < per) v[u][i] = x[(size_t)(t + u * NWV) * hidden + lane + 64 * i];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < kMaxPerLane; ++i)
+                if (i < per) acc[i] += v[u][i];
     }
-    sq = wave_sum(sq);
+    for (; t < t1; t += NWV)
+#pragma unroll
+        for (int i = 0; i < kMaxPerLane; ++i)
+            if (i < per) acc[i] += x[(size_t)t * hidden + lane + 64 * i];
+#pragma unroll
+    for (int i = 0; i < kMaxPerLane; ++i)
+        if (i < per) pool_part[wave * hidden + lane + 64 * i] = acc[i];
+    __syncthreads();
+    float val = 0.f;
+    if (tid < hidden && n > 0) {
+        for (int w = 0; w < NWV; ++w) val += pool_part[w * hidden + tid];
+        val *= 1.0f / (float)n;
+    }
+    float sq = wave_sum(val * val);
     if (lane == 0) red[wave] = sq;
     __syncthreads();
-    const float norm_sq = (red[0] + red[1]) + (red[2] + red[3]);
+    float norm_sq = 0.f;
+    for (int w = 0; w < NWV; ++w) norm_sq += red[w];
     float scale = 0.f;
     if (__builtin_isfinite(norm_sq) && norm_sq > 1.1920929e-7f) scale = 1.0f / sqrtf(norm_sq);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int d = tid + 256 * i;
-        if (d < hidden) out[(size_t)doc * hidden + d] = vals[i] * scale;
-    }
+    if (tid < hidden) out[(size_t)doc * hidden + tid] = val * scale;
 }
 
 // f32 -> f16 copy of a weight matrix (RNE), done once at model load.
@@ -814,6 +936,27 @@ size_t bert_attention_lds_bytes(int max_seq) {
 
 hipError_t launch_bert_attention_h(const void* qkv_h, const uint32_t* offsets, void* ctx_h, int n_docs, int heads,
                                    int hidden, int max_seq, float scale, hipStream_t stream) {
+    static const bool wave_private = [] {
+        const char* e = std::getenv("FSGPU_BERT_ATTN");  // "w" = the kernel with per-wave K / V staging (A/B runs)
+        return e && e[0] == 'w';
+    }();
+    if (!wave_private && max_seq <= 512) {
+        const int s32 = (max_seq + 31) & ~31;
+        const int vp = ((max_seq + 127) & ~127) + 8;     // dword pitch = 4 mod 64: the two 8-byte fragment reads are conflict-free
+        const int vt_offset = s32 * 32;
+        const size_t lds = (size_t)vt_offset * 2 + (size_t)32 * vp * 2;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bert_attention_lds_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        // long documents, few blocks: two blocks per (document, head), each staging K / V and taking every other 64 queries
+        const int zsplit = (max_seq > 128 && n_docs * heads < 512) ? 2 : 1;
+        hipLaunchKernelGGL(bert_attention_lds_kernel, dim3(n_docs, heads, zsplit), dim3(256), lds, stream,
+                           static_cast<const _Float16*>(qkv_h), offsets, static_cast<_Float16*>(ctx_h), hidden, scale, vt_offset,
+                           vp, zsplit);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(bert_attention_mfma_kernel<_Float16>, dim3(n_docs, heads, (max_seq + 63) / 64), dim3(256), 0, stream,
                        static_cast<const _Float16*>(qkv_h), offsets, static_cast<_Float16*>(ctx_h), hidden, scale);
     return hipGetLastError();
@@ -843,7 +986,13 @@ hipError_t launch_bert_attention(const float* qkv, const uint32_t* offsets, void
 
 hipError_t launch_bert_pool(const float* x, const uint32_t* offsets, float* out, int n_docs, int hidden,
                             hipStream_t stream) {
-    hipLaunchKernelGGL(bert_pool_kernel, dim3(n_docs), dim3(256), 0, stream, x, offsets, out, hidden);
+    const size_t lds = (size_t)16 * hidden * sizeof(float);
+    if (lds + 256 > 64 * 1024) {   // hidden = 1024: the partial rows alone are 64 KB
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bert_pool_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(bert_pool_kernel, dim3(n_docs), dim3(1024), lds, stream, x, offsets, out, hidden);
     return hipGetLastError();
 }
 
