@@ -106,3 +106,17 @@ def test_batch_path_other_widths(fa, hidden, inter, layers):
     # a text alone (query path or small-batch kernels) agrees with the same text inside the batch
     for i in (0, 7, 41):
         assert float(np.sum(m.embed_token_ids(batch[i]) * got[i])) > 0.9999
+
+
+def test_large_batch_equals_its_parts(fa):
+    """A call too large for the pinned staging block and the graph cache (130 x 512 tokens: pageable H2D / D2H, eager
+    launches) returns, text for text, the bits of the same texts embedded 26 at a time: every row's arithmetic is independent
+    of how many rows share the launch."""
+    from frankensearch_amd.synthetic import random_bert_weights
+    rng = np.random.default_rng(17)
+    m = fa.NativeEmbedder(random_bert_weights(3, 3000, 384, 2, 1536))
+    docs = [[101] + rng.integers(1000, 3000, int(n) - 2).tolist() + [102] for n in rng.integers(400, 513, 130)]
+    whole = m.embed_batch_token_ids(docs)
+    parts = np.concatenate([m.embed_batch_token_ids(docs[i:i + 26]) for i in range(0, 130, 26)])
+    assert np.array_equal(whole.view(np.uint32), parts.view(np.uint32))
+    assert np.allclose(np.linalg.norm(whole, axis=1), 1.0, atol=1e-4)
