@@ -773,6 +773,53 @@ __global__ __launch_bounds__(256) void bert_attention_lds_kernel(const _Float16*
     }
 }
 
+// word + position + token_type(0) embedding gather, then LayerNorm (native.rs:1176-1192), sixteen lanes per token: a lane
+// fetches its share of the three rows as float4s (every load of the token in flight together), the row statistics are DPP
+// reductions over the sixteen lanes, the stores are 16 (f32) and 8 (f16) bytes per lane.  PER = hidden / 64 float4s per lane.
+template <int PER>
+__global__ __launch_bounds__(256) void bert_embed_ln16_kernel(const int32_t* __restrict__ ids,
+                                                              const int32_t* __restrict__ positions,
+                                                              const float* __restrict__ word, const float* __restrict__ pos,
+                                                              const float* __restrict__ type0, const float* __restrict__ lnw,
+                                                              const float* __restrict__ lnb, float* __restrict__ x_f32,
+                                                              _Float16* __restrict__ x_h, int tokens, float eps) {
+    constexpr int H = 64 * PER;
+    const int li = threadIdx.x & 15;
+    const int t = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int tc = t < tokens ? t : tokens - 1;   // dead groups recompute the last token and store nothing
+    const float4* wr = reinterpret_cast<const float4*>(word + (size_t)ids[tc] * H);
+    const float4* pr = reinterpret_cast<const float4*>(pos + (size_t)positions[tc] * H);
+    const float4* tr = reinterpret_cast<const float4*>(type0);
+    float4 v[PER];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const float4 a = wr[li + 16 * j], b = pr[li + 16 * j], c = tr[li + 16 * j];
+        v[j] = make_float4((a.x + b.x) + c.x, (a.y + b.y) + c.y, (a.z + b.z) + c.z, (a.w + b.w) + c.w);
+        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+    const float mean = row16_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const float dx = v[j].x - mean, dy = v[j].y - mean, dz = v[j].z - mean, dw = v[j].w - mean;
+        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+    const float inv = 1.0f / sqrtf(row16_sum(q) / (float)H + eps);
+    if (t >= tokens) return;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const float4 g = reinterpret_cast<const float4*>(lnw)[li + 16 * j], b = reinterpret_cast<const float4*>(lnb)[li + 16 * j];
+        const float4 y = make_float4((v[j].x - mean) * inv * g.x + b.x, (v[j].y - mean) * inv * g.y + b.y,
+                                     (v[j].z - mean) * inv * g.z + b.z, (v[j].w - mean) * inv * g.w + b.w);
+        reinterpret_cast<float4*>(x_f32 + (size_t)t * H)[li + 16 * j] = y;
+        h4 h;
+        h[0] = (_Float16)y.x; h[1] = (_Float16)y.y; h[2] = (_Float16)y.z; h[3] = (_Float16)y.w;
+        reinterpret_cast<h4*>(x_h + (size_t)t * H)[li + 16 * j] = h;
+    }
+}
+
 // Mean over all tokens of a document, then L2 (native.rs:1209-1235; zero guard of
 // fastembed_embedder.rs:416-426).  One 1,024-thread block per document: wave w sums tokens w, w + 16, ... (a lane holds
 // dims lane + 64 i; eight tokens' loads in flight), the sixteen partial rows meet in LDS and are added in wave order — a
@@ -839,8 +886,25 @@ __global__ void bert_to_half_kernel(const float* __restrict__ src, _Float16* __r
 hipError_t launch_bert_embed_ln(const int32_t* ids, const int32_t* positions, const float* word, const float* pos,
                                 const float* type0, const float* lnw, const float* lnb, float* x_f32, void* x_h,
                                 int tokens, int hidden, float eps, hipStream_t stream) {
-    hipLaunchKernelGGL(bert_embed_ln_kernel, dim3((tokens + 3) / 4), dim3(256), 0, stream, ids, positions, word, pos,
-                       type0, lnw, lnb, x_f32, static_cast<_Float16*>(x_h), tokens, hidden, eps);
+    static const bool wave_per_token = std::getenv("FSGPU_BERT_EMBED_V1") != nullptr;   // A/B runs
+    _Float16* xh = static_cast<_Float16*>(x_h);
+    const dim3 g16((tokens + 15) / 16);
+    if (wave_per_token || tokens <= 0) {
+        hipLaunchKernelGGL(bert_embed_ln_kernel, dim3((tokens + 3) / 4), dim3(256), 0, stream, ids, positions, word, pos, type0, lnw,
+                           lnb, x_f32, xh, tokens, hidden, eps);
+    } else if (hidden == 384) {
+        hipLaunchKernelGGL(bert_embed_ln16_kernel<6>, g16, dim3(256), 0, stream, ids, positions, word, pos, type0, lnw, lnb, x_f32, xh,
+                           tokens, eps);
+    } else if (hidden == 256) {
+        hipLaunchKernelGGL(bert_embed_ln16_kernel<4>, g16, dim3(256), 0, stream, ids, positions, word, pos, type0, lnw, lnb, x_f32, xh,
+                           tokens, eps);
+    } else if (hidden == 128) {
+        hipLaunchKernelGGL(bert_embed_ln16_kernel<2>, g16, dim3(256), 0, stream, ids, positions, word, pos, type0, lnw, lnb, x_f32, xh,
+                           tokens, eps);
+    } else {
+        hipLaunchKernelGGL(bert_embed_ln_kernel, dim3((tokens + 3) / 4), dim3(256), 0, stream, ids, positions, word, pos, type0, lnw,
+                           lnb, x_f32, xh, tokens, hidden, eps);
+    }
     return hipGetLastError();
 }
 
