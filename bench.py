@@ -568,18 +568,12 @@ def main() -> None:
                 if args.batched:
                     fallbacks[0] += shard_backend.last_fallbacks
             return out
-        pending = None
-        for i in range(first, first + n):
-            local = sharded.search_begin(batch_of(i), k)      # this rank's scan of step i (under it: step i-1's exchange)
+        def count_fallbacks():
             if args.batched:
                 fallbacks[0] += shard_backend.last_fallbacks
-            if pending is not None:
-                pending[3].synchronize()
-            pending = sharded.search_end(local, k)            # enqueue all-gather + merge of step i, do not wait
-        if pending is not None:
-            pending[3].synchronize()
-            out = pending[:3]
-        return out
+        # this rank's scan of step i; inside it (after its kernels are enqueued, before it blocks) the all-gather + merge of step
+        # i - 1 are enqueued on the side stream (ShardedVectorIndex.search_steps)
+        return sharded.search_steps(batch_of, first, n, k, after_scan=count_fallbacks)
 
     run_steps(0, args.warmup)
     torch.cuda.synchronize()

@@ -93,6 +93,7 @@ SIGNATURES = {
     "fsgpu_rrf_fuse": (_i32, [_vp, _u32, _vp, _u32, C.c_double, C.c_double, C.c_double, _i32, _u32, _u32, _vp,
                               C.POINTER(_u32)]),
     "fsgpu_blend_two_tier": (_i32, [_vp, _u32, _vp, _u32, C.c_float, _vp, C.POINTER(_u32)]),
+    "fsgpu_index_set_after_enqueue_hook": (_i32, [_vp, _vp, _vp]),
     "fsgpu_index_set_profiling": (_i32, [_vp, _i32]),
     "fsgpu_index_scan_time": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(_u64), _i32]),
     "fsgpu_search_topk_int8_two_pass_batched": (_i32, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, C.POINTER(_u32)]),

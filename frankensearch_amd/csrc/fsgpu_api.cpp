@@ -906,6 +906,14 @@ fsgpu_status fsgpu_bert_set_coalescing(fsgpu_bert* m, uint32_t max_batch, uint32
     return FSGPU_OK;
 }
 
+fsgpu_status fsgpu_index_set_after_enqueue_hook(fsgpu_index* idx, fsgpu_after_enqueue_fn fn, void* ctx) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    std::lock_guard<std::mutex> lock(idx->impl.mutex());
+    idx->impl.after_enqueue_fn = fn;
+    idx->impl.after_enqueue_ctx = ctx;
+    return FSGPU_OK;
+}
+
 fsgpu_status fsgpu_index_set_profiling(fsgpu_index* idx, int32_t enabled) {
     if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
     std::lock_guard<std::mutex> lock(idx->impl.mutex());

@@ -1590,6 +1590,12 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         }
         g0 += ng;
     }
+    // everything of this search is enqueued: the caller's window for host work that should run under it (one shot, outer call only)
+    if (after_enqueue_fn && !hard_batch_) {
+        void (*fn)(void*) = after_enqueue_fn;
+        after_enqueue_fn = nullptr;
+        fn(after_enqueue_ctx);
+    }
     // fallback decision on the host: margin/capacity overflow, or fewer than k candidates
     FSGPU_HIP(hipStreamSynchronize(stream));
     std::vector<uint32_t> fb;

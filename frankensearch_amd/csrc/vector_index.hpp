@@ -129,6 +129,9 @@ class VectorIndex {
     int32_t variant = 0;
     uint64_t filter_gathered = 0, filter_scanned = 0;  // filtered host searches by path
     bool profiling = false;
+    // one-shot hook of the next batched search (fsgpu_index_set_after_enqueue_hook): called before the search blocks on its stream
+    void (*after_enqueue_fn)(void*) = nullptr;
+    void* after_enqueue_ctx = nullptr;
     // filter of the exact batched search (fsgpu_index_set_batched_filter): 0 = automatic, 1 = f16 slab, 2 = int8 slab
     int32_t batched_filter = 0;
     // fsgpu_index_set_int8_latency: unfiltered fsgpu_search_topk calls of a few queries go through the int8 filter too

@@ -39,6 +39,7 @@ class ShardBackend(Protocol):
 
 class GpuShardBackend:
     """libfsgpu.so on the current torch device / current stream."""
+    supports_after_enqueue = True   # search_packed(after_enqueue=...): see ShardedVectorIndex.search_steps
 
     def __init__(self, index, device: torch.device, batched: bool = False):
         self.index = index
@@ -46,7 +47,9 @@ class GpuShardBackend:
         self.batched = batched        # serve through the matrix-core batched path (64 queries per HBM pass)
         self.last_fallbacks = 0
 
-    def search_packed(self, queries: torch.Tensor, k: int) -> torch.Tensor:
+    def search_packed(self, queries: torch.Tensor, k: int, after_enqueue=None) -> torch.Tensor:
+        """after_enqueue: called (on this thread) once the scan's kernels are enqueued and before the call blocks on its stream
+        (fsgpu_index_set_after_enqueue_hook) — batched path only; `self.hook_fired` tells whether it ran."""
         import ctypes as C
         from . import _lib
         from .errors import check
@@ -55,10 +58,27 @@ class GpuShardBackend:
         b, dim = queries.shape
         out = torch.empty((b, k), dtype=torch.int64, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.hook_fired = False
         if self.batched:
             fb = C.c_uint32()
-            check(_lib.lib().fsgpu_search_topk_batched_packed_device(self.index._h, queries.data_ptr(), b, dim, k, None,
-                                                                     out.data_ptr(), stream, C.byref(fb)))
+            cb, err = None, []
+            if after_enqueue is not None:
+                def _run(_ctx):
+                    self.hook_fired = True
+                    try:
+                        after_enqueue()
+                    except BaseException as e:   # must not unwind through the C frame
+                        err.append(e)
+                cb = C.CFUNCTYPE(None, C.c_void_p)(_run)
+                check(_lib.lib().fsgpu_index_set_after_enqueue_hook(self.index._h, C.cast(cb, C.c_void_p), None))
+            try:
+                check(_lib.lib().fsgpu_search_topk_batched_packed_device(self.index._h, queries.data_ptr(), b, dim, k, None,
+                                                                         out.data_ptr(), stream, C.byref(fb)))
+            finally:
+                if cb is not None:
+                    _lib.lib().fsgpu_index_set_after_enqueue_hook(self.index._h, None, None)
+            if err:
+                raise err[0]
             self.last_fallbacks = fb.value
         else:
             check(_lib.lib().fsgpu_search_topk_packed_device(self.index._h, queries.data_ptr(), b, dim, k, None,
@@ -133,9 +153,51 @@ class ShardedVectorIndex:
         self.force_collective = force_collective and dist.is_initialized()
         self._side = None
 
-    def search_begin(self, queries: torch.Tensor, k: int) -> torch.Tensor:
+    def search_begin(self, queries: torch.Tensor, k: int, after_enqueue=None) -> torch.Tensor:
         """[B, dim] -> this shard's packed [B, k] list (global rows, best first)."""
-        return self.backend.search_packed(queries, k)
+        if after_enqueue is None or not getattr(self.backend, "supports_after_enqueue", False):
+            return self.backend.search_packed(queries, k)   # (the caller sees that the hook did not run and does its work itself)
+        return self.backend.search_packed(queries, k, after_enqueue=after_enqueue)
+
+    def search_steps(self, batch_of, first: int, n: int, k: int, after_scan=None, keep_all: bool = False):
+        """n whole searches (queries batch_of(i), i = first .. first + n - 1) as a pipeline: the all-gather + merge of step i - 1
+        are enqueued on the side stream from inside the scan call of step i, in the window after its kernels are enqueued and
+        before it blocks on its stream — the exchange's GPU work AND its host work run under the scan.  Returns the last step's
+        (rows, scores, counts) — or every step's with keep_all — complete when this returns."""
+        outs, pending, prev = [], None, None
+        state = {"pending": None}
+
+        def wait(p):
+            if len(p) == 4:
+                p[3].synchronize()
+            return p[:3]
+
+        for i in range(first, first + n):
+            if pending is not None:
+                done = wait(pending)              # the exchange enqueued a whole scan ago
+                if keep_all:
+                    outs.append(done)
+            hook = None
+            if prev is not None:
+                def hook(prev=prev):
+                    state["pending"] = self.search_end(prev, k, scan_done=True)
+            state["pending"] = None
+            local = self.search_begin(batch_of(i), k, after_enqueue=hook)
+            if after_scan is not None:
+                after_scan()
+            if prev is not None:
+                # (a search that left the matrix-core path returns without calling the hook)
+                pending = state["pending"] if state["pending"] is not None else self.search_end(prev, k)
+            prev = local
+        if pending is not None:
+            done = wait(pending)
+            if keep_all:
+                outs.append(done)
+        last = None
+        if prev is not None:
+            last = wait(self.search_end(prev, k))
+            outs.append(last)
+        return outs if keep_all else last
 
     def _gather(self, local: torch.Tensor) -> torch.Tensor:
         if self.world == 1 and not self.force_collective:
@@ -151,14 +213,17 @@ class ShardedVectorIndex:
             dist.all_gather_into_tensor(flat, local, group=self.group)
         return flat.view(self.world, local.shape[0], local.shape[1])
 
-    def search_end(self, local: torch.Tensor, k: int):
-        """All-gather of the W packed lists + merge.  Returns (rows, scores, counts[, event when overlap is on])."""
+    def search_end(self, local: torch.Tensor, k: int, scan_done: bool = False):
+        """All-gather of the W packed lists + merge.  Returns (rows, scores, counts[, event when overlap is on]).
+        scan_done: the scan that produced `local` has completed (its call synchronised its stream) — the side stream does not
+        wait for the current stream, which by now may hold the NEXT scan's kernels."""
         if not (self.overlap and local.is_cuda):
             return self.backend.merge(self._gather(local), k)
         if self._side is None:
             self._side = torch.cuda.Stream(device=local.device)
         side = self._side
-        side.wait_stream(torch.cuda.current_stream(local.device))   # the scan that produced `local`
+        if not scan_done:
+            side.wait_stream(torch.cuda.current_stream(local.device))   # the scan that produced `local`
         local.record_stream(side)
         with torch.cuda.stream(side):
             out = self.backend.merge(self._gather(local), k)

@@ -198,6 +198,13 @@ fsgpu_status fsgpu_search_topk_packed_device(fsgpu_index *idx, const float *quer
 fsgpu_status fsgpu_search_topk_batched_packed_device(fsgpu_index *idx, const float *queries_dev, uint32_t nq,
                                                      uint32_t query_len, uint32_t k, const uint64_t *allow_bitmap_dev,
                                                      uint64_t *out_packed_dev, void *hip_stream, uint32_t *out_fallbacks);
+/* One-shot hook for the NEXT batched search on this handle: `fn(ctx)` is called on the calling thread once every kernel of
+ * that search is enqueued and before the call blocks on its stream (it has to read the certificate flags back).  A launcher
+ * that pipelines steps uses the window to enqueue the PREVIOUS step's exchange (all-gather + merge on another stream), so
+ * that host work runs under the scan instead of between two scans.  The hook must not call into this handle.  A search that
+ * leaves the matrix-core path (odd shapes) returns without calling it; the hook is cleared either way. */
+typedef void (*fsgpu_after_enqueue_fn)(void *ctx);
+fsgpu_status fsgpu_index_set_after_enqueue_hook(fsgpu_index *idx, fsgpu_after_enqueue_fn fn, void *ctx);
 /* Merge of gathered packed lists = merge_partial_heaps + resolve_hits sort (search.rs:1704-1720,1493-1501)
  * across shards: entry (q, l, i) is lists_dev[q*q_stride + l*l_stride + i]; selects the k best per query
  * under the reference order.  For an all-gather result laid out [nlists][nq][list_len]:

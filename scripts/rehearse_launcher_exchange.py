@@ -37,8 +37,12 @@ ws = np.concatenate([w[1] for w in want])
 index = fa.VectorIndex.from_slab(slab)
 sharded = ShardedVectorIndex(GpuShardBackend(index, device, batched=True), overlap=True, force_collective=True)
 tq = torch.from_numpy(q).to(device)
-pending, outs = None, []
-for step in range(4):                         # the bench's loop: scan of step i over the exchange of step i - 1
+# the bench's loop (ShardedVectorIndex.search_steps): the exchange of step i - 1 enqueued from inside the scan call of step i
+outs = sharded.search_steps(lambda i: tq, 0, 4, k, keep_all=True)
+assert len(outs) == 4 and sharded.backend.hook_fired, "the after-enqueue hook did not run"
+# ... and the begin / end form by hand
+pending = None
+for step in range(3):
     local = sharded.search_begin(tq, k)
     if pending is not None:
         pending[3].synchronize()

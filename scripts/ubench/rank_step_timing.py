@@ -21,12 +21,16 @@ rows, B, k, steps = int(os.environ.get("ROWS", 1_250_000)), 1024, 10, 100
 slab = bench.gen_corpus(0, rows, 384, device)
 queries = bench.gen_queries(2 * B, 384, device)
 index = fa.VectorIndex.from_device_slab(slab.data_ptr(), rows, 384, device=0, keepalive=slab)
-for label, force in (("no exchange", False), ("all-gather + merge on the side stream", True)):
-    sh = ShardedVectorIndex(GpuShardBackend(index, device, batched=True), overlap=force, force_collective=force)
+for label, force in (("no exchange", 0), ("all-gather + merge enqueued between two scans", 1),
+                     ("all-gather + merge enqueued from inside the next scan call (bench.py)", 2)):
+    sh = ShardedVectorIndex(GpuShardBackend(index, device, batched=True), overlap=bool(force), force_collective=bool(force))
+    batch_of = lambda i: queries[(i % 2) * B:(i % 2) * B + B]
     def run(n):
+        if force == 2:
+            sh.search_steps(batch_of, 0, n, k); return
         pending = None
         for i in range(n):
-            qb = queries[(i % 2) * B:(i % 2) * B + B]
+            qb = batch_of(i)
             if not force:
                 sh.search(qb, k); continue
             local = sh.search_begin(qb, k)

@@ -80,6 +80,9 @@ def _worker(rank, world, port, n, dim, k, ret):
     # the two halves bench.py pipelines (scan of step i+1 over the exchange of step i) give the same answer
     r2, s2, c2 = idx.search_end(idx.search_begin(torch.from_numpy(queries), k), k)
     assert torch.equal(r2, rows) and torch.equal(c2, counts) and torch.equal(s2.view(torch.int32), scores.view(torch.int32))
+    # ... and the launcher's step loop (a backend without the after-enqueue window: the loop does the exchange itself)
+    for r3, s3, c3 in idx.search_steps(lambda i: torch.from_numpy(queries), 0, 3, k, keep_all=True):
+        assert torch.equal(r3, rows) and torch.equal(c3, counts) and torch.equal(s3.view(torch.int32), scores.view(torch.int32))
     if rank == 0:
         ret["rows"] = rows.numpy().view(np.uint32).copy()
         ret["scores"] = scores.numpy().copy()
