@@ -46,6 +46,8 @@ class GpuShardBackend:
         self.device = device
         self.batched = batched        # serve through the matrix-core batched path (64 queries per HBM pass)
         self.last_fallbacks = 0
+        self.hook_fired = False
+        self._cb = self._cb_ptr = self._hook = self._hook_error = None
 
     def search_packed(self, queries: torch.Tensor, k: int, after_enqueue=None) -> torch.Tensor:
         """after_enqueue: called (on this thread) once the scan's kernels are enqueued and before the call blocks on its stream
@@ -61,24 +63,26 @@ class GpuShardBackend:
         self.hook_fired = False
         if self.batched:
             fb = C.c_uint32()
-            cb, err = None, []
             if after_enqueue is not None:
-                def _run(_ctx):
-                    self.hook_fired = True
-                    try:
-                        after_enqueue()
-                    except BaseException as e:   # must not unwind through the C frame
-                        err.append(e)
-                cb = C.CFUNCTYPE(None, C.c_void_p)(_run)
-                check(_lib.lib().fsgpu_index_set_after_enqueue_hook(self.index._h, C.cast(cb, C.c_void_p), None))
+                if self._cb is None:   # one C callback object per backend; what it runs is whatever the call in flight set
+                    def _run(_ctx):
+                        self.hook_fired = True
+                        try:
+                            self._hook()
+                        except BaseException as e:   # must not unwind through the C frame
+                            self._hook_error = e
+                    self._cb = C.CFUNCTYPE(None, C.c_void_p)(_run)
+                    self._cb_ptr = C.cast(self._cb, C.c_void_p)
+                self._hook, self._hook_error = after_enqueue, None
+                check(_lib.lib().fsgpu_index_set_after_enqueue_hook(self.index._h, self._cb_ptr, None))
             try:
                 check(_lib.lib().fsgpu_search_topk_batched_packed_device(self.index._h, queries.data_ptr(), b, dim, k, None,
                                                                          out.data_ptr(), stream, C.byref(fb)))
             finally:
-                if cb is not None:
+                if after_enqueue is not None and not self.hook_fired:   # (the library clears a hook it has called)
                     _lib.lib().fsgpu_index_set_after_enqueue_hook(self.index._h, None, None)
-            if err:
-                raise err[0]
+            if after_enqueue is not None and self._hook_error is not None:
+                raise self._hook_error
             self.last_fallbacks = fb.value
         else:
             check(_lib.lib().fsgpu_search_topk_packed_device(self.index._h, queries.data_ptr(), b, dim, k, None,
