@@ -16,8 +16,6 @@
 //
 // Same arithmetic as bert_kernels.hip (f16 x f16 -> f32 v_mfma_f32_16x16x32_f16, f32 bias / GELU / residual / LayerNorm);
 // tolerance against the f32 oracle asserted in tests/test_gpu_bert.py.
-#include <cstdlib>
-
 #include "device_util.hpp"
 #include "kernels.hpp"
 
@@ -66,7 +64,7 @@ __global__ void bert_pack_w_kernel(const _Float16* __restrict__ src, _Float16* _
 template <int EPI, int KS>
 __global__ __launch_bounds__(256) void bert_gemm_w_kernel(const _Float16* __restrict__ A, const half8* __restrict__ Wp,
                                                           const float* __restrict__ bias, float* __restrict__ out_f32,
-                                                          _Float16* __restrict__ out_h, int M, int N, int dbg) {
+                                                          _Float16* __restrict__ out_h, int M, int N) {
     constexpr int K = 32 * KS, BM = 64;
     constexpr int PITCH = K + 16;                      // halves: (2 K + 32) / 16 = K / 8 + 2 slots, = 2 mod 16 for K % 128 == 0
     constexpr int PIECES = K / 8;                      // 16-byte pieces per row
@@ -82,7 +80,7 @@ __global__ __launch_bounds__(256) void bert_gemm_w_kernel(const _Float16* __rest
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) wf[j][ks] = (dbg & 16) ? half8{} + (_Float16)lane : wp[(j * KS + ks) * 64];
+            for (int ks = 0; ks < KS; ++ks) wf[j][ks] = wp[(j * KS + ks) * 64];
     }
     // the block's activation tile: rows bm0 .. bm0 + 63 are one contiguous run of A (clamped at M)
     {
@@ -92,7 +90,7 @@ __global__ __launch_bounds__(256) void bert_gemm_w_kernel(const _Float16* __rest
             const int p = tid + 256 * x, r = p / PIECES, c = p % PIECES;
             int row = bm0 + r;
             row = row < M ? row : M - 1;
-            ra[x] = (dbg & 8) ? half8{} + (_Float16)row : *(reinterpret_cast<const half8*>(A + (size_t)row * K) + c);
+            ra[x] = *(reinterpret_cast<const half8*>(A + (size_t)row * K) + c);
         }
 #pragma unroll
         for (int x = 0; x < A_LOADS; ++x) {
@@ -107,7 +105,6 @@ __global__ __launch_bounds__(256) void bert_gemm_w_kernel(const _Float16* __rest
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fk = (lane >> 4) * 8;
-    if (!(dbg & 2))
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         half8 af[4];
@@ -129,7 +126,7 @@ __global__ __launch_bounds__(256) void bert_gemm_w_kernel(const _Float16* __rest
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = bm0 + i * 16 + fr;
-                if (row < M && !(dbg & 1)) *reinterpret_cast<f32x4*>(out_f32 + (size_t)row * N + col) = acc[i][j] + bv;
+                if (row < M) *reinterpret_cast<f32x4*>(out_f32 + (size_t)row * N + col) = acc[i][j] + bv;
             }
         }
         return;
@@ -145,15 +142,14 @@ __global__ __launch_bounds__(256) void bert_gemm_w_kernel(const _Float16* __rest
         for (int i = 0; i < 4; ++i) {
             const f32x4 y = acc[i][j] + bv;
             half4 h;
-            h[0] = (_Float16)(EPI == 1 && !(dbg & 4) ? gelu_as_w(y[0]) : y[0]);
-            h[1] = (_Float16)(EPI == 1 && !(dbg & 4) ? gelu_as_w(y[1]) : y[1]);
-            h[2] = (_Float16)(EPI == 1 && !(dbg & 4) ? gelu_as_w(y[2]) : y[2]);
-            h[3] = (_Float16)(EPI == 1 && !(dbg & 4) ? gelu_as_w(y[3]) : y[3]);
+            h[0] = (_Float16)(EPI == 1 ? gelu_as_w(y[0]) : y[0]);
+            h[1] = (_Float16)(EPI == 1 ? gelu_as_w(y[1]) : y[1]);
+            h[2] = (_Float16)(EPI == 1 ? gelu_as_w(y[2]) : y[2]);
+            h[3] = (_Float16)(EPI == 1 ? gelu_as_w(y[3]) : y[3]);
             *reinterpret_cast<half4*>(&As[(i * 16 + fr) * CP + wave * 32 + j * 16 + cq]) = h;
         }
     }
     __syncthreads();
-    if (dbg & 1) return;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int r = it * 16 + (tid >> 4), c = (tid & 15) * 8;
@@ -172,7 +168,7 @@ template <int CT, int RING>
 __global__ __launch_bounds__(256) void bert_gemm_ln_w_kernel(const _Float16* __restrict__ A, const half8* __restrict__ Wp,
                                                              const float* __restrict__ bias, float* __restrict__ x_f32,
                                                              _Float16* __restrict__ x_h, const float* __restrict__ lnw,
-                                                             const float* __restrict__ lnb, int M, int K, float eps, int dbg) {
+                                                             const float* __restrict__ lnb, int M, int K, float eps) {
     constexpr int H = 64 * CT, BM = 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char glw_smem[];
     float* red = reinterpret_cast<float*>(glw_smem);                          // [BM][4]
@@ -188,7 +184,7 @@ __global__ __launch_bounds__(256) void bert_gemm_ln_w_kernel(const _Float16* __r
     for (int d = 0; d < RING; ++d)
         if (d < ksteps)
 #pragma unroll
-            for (int j = 0; j < CT; ++j) wr[d][j] = (dbg & 16) ? half8{} + (_Float16)lane : wp[((size_t)j * ksteps + d) * 64];
+            for (int j = 0; j < CT; ++j) wr[d][j] = wp[((size_t)j * ksteps + d) * 64];
     // activation tile: 32 rows x K, every load in flight before the first LDS write (up to 24 pieces per thread: K = 1536 in one round)
     for (int p0 = 0; p0 < BM * pieces; p0 += 256 * 24) {
         half8 ra[24];
@@ -199,7 +195,7 @@ __global__ __launch_bounds__(256) void bert_gemm_ln_w_kernel(const _Float16* __r
                 const int r = p / pieces, c = p - r * pieces;
                 int row = bm0 + r;
                 row = row < M ? row : M - 1;
-                ra[x] = (dbg & 8) ? half8{} + (_Float16)row : *(reinterpret_cast<const half8*>(A + (size_t)row * K) + c);
+                ra[x] = *(reinterpret_cast<const half8*>(A + (size_t)row * K) + c);
             }
         }
 #pragma unroll
@@ -236,7 +232,7 @@ __global__ __launch_bounds__(256) void bert_gemm_ln_w_kernel(const _Float16* __r
 #pragma unroll
         for (int j = 0; j < CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fk = (lane >> 4) * 8;
-    for (int ks0 = (dbg & 2) ? ksteps : 0; ks0 < ksteps; ks0 += RING) {
+    for (int ks0 = 0; ks0 < ksteps; ks0 += RING) {
 #pragma unroll
         for (int d = 0; d < RING; ++d) {
             const int ks = ks0 + d;
@@ -249,7 +245,7 @@ __global__ __launch_bounds__(256) void bert_gemm_ln_w_kernel(const _Float16* __r
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[d][j], af[i], acc[i][j], 0, 0, 0);
-                if (ks + RING < ksteps && !(dbg & 16))
+                if (ks + RING < ksteps)
 #pragma unroll
                     for (int j = 0; j < CT; ++j) wr[d][j] = wp[((size_t)j * ksteps + ks + RING) * 64];
             }
@@ -313,7 +309,6 @@ __global__ __launch_bounds__(256) void bert_gemm_ln_w_kernel(const _Float16* __r
         }
     }
     __syncthreads();
-    if (dbg & 1) return;
     constexpr int XL = BM * (H / 4) / 256;
 #pragma unroll
     for (int x = 0; x < XL; ++x) {
@@ -703,14 +698,6 @@ __global__ __launch_bounds__(512) void bert_ffn_w_kernel(const _Float16* __restr
 
 // ---- launchers ------------------------------------------------------------------------------------------
 
-static int gw_dbg() {
-    static const int v = [] {
-        const char* e = std::getenv("FSGPU_GW_DBG");
-        return e ? std::atoi(e) : 0;
-    }();
-    return v;
-}
-
 hipError_t launch_bert_pack_w(const void* w_h, void* packed_h, int N, int K, hipStream_t stream) {
     if (N % 16 != 0 || K % 32 != 0) return hipErrorInvalidValue;
     const size_t pieces = (size_t)(N / 16) * (K / 32) * 64;
@@ -727,7 +714,7 @@ static void launch_gemm_w_t(const void* a_h, const void* wp, const float* bias, 
                             hipStream_t stream) {
     hipLaunchKernelGGL((bert_gemm_w_kernel<EPI, KS>), dim3(N / 128, (M + 63) / 64), dim3(256), 0, stream,
                        static_cast<const _Float16*>(a_h), static_cast<const half8*>(wp), bias, out_f32,
-                       static_cast<_Float16*>(out_h), M, N, gw_dbg());
+                       static_cast<_Float16*>(out_h), M, N);
 }
 
 hipError_t launch_bert_gemm_w(const void* a_h, const void* wp, const float* bias, float* out_f32, void* out_h, int M, int N,
@@ -766,7 +753,7 @@ static hipError_t launch_gemm_ln_w_t(const void* a_h, const void* wp, const floa
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((M + 31) / 32), dim3(256), lds, stream, static_cast<const _Float16*>(a_h),
-                       static_cast<const half8*>(wp), bias, x_f32, static_cast<_Float16*>(x_h), lnw, lnb, M, K, eps, gw_dbg());
+                       static_cast<const half8*>(wp), bias, x_f32, static_cast<_Float16*>(x_h), lnw, lnb, M, K, eps);
     return hipGetLastError();
 }
 

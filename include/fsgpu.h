@@ -446,7 +446,6 @@ fsgpu_status fsgpu_bert_set_coalescing(fsgpu_bert *m, uint32_t max_batch, uint32
  *   FSGPU_BERT_ATTN=w|valu      attention with per-wave K / V staging, or the f32 VALU kernel (V1 path), instead of K / V resident in LDS
  *   FSGPU_BERT_EMBED_V1         embedding gather + LayerNorm with a wave per token instead of sixteen lanes per token
  *   FSGPU_BERT_SPLIT_AO         attention-output projection + LayerNorm as its own launch instead of the head of the FFN launch
- *   FSGPU_GW_DBG=<bits>         TIMING ONLY, results are wrong: phases of the fragment-order GEMMs switched off (scripts/ubench/enc_dbg.sh)
  *   FSGPU_DEBUG_BATCHED, FSGPU_DEBUG_GRAPH   one-line diagnostics on stderr */
 
 /* ---- instrumentation ---- */

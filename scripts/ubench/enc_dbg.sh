@@ -1,10 +1,12 @@
 #!/bin/bash
-# per-kernel durations of the batch-256 forward with phases of the fragment-order GEMMs switched off (FSGPU_GW_DBG);
+# per-kernel durations of the batch-256 forward (argument: a label, e.g. 0).  The phase-ablation switch this script drove
+# while the kernels were designed (FSGPU_GW_DBG: no stores / no MFMA loop / no GELU / no A loads / no W loads) was removed from
+# the kernels afterwards; what it measured is recorded in DESIGN 3.5.
 # the LN GEMM is reported separately for its two uses (attention output K = hidden, FFN down K = inter)
 export TMPDIR=/tmp
 O=gpurun_out/encdbg; mkdir -p $O
 for d in "$@"; do
-  FSGPU_GW_DBG=$d rocprofv3 --kernel-trace --stats --output-format csv -d $O/t$d -o enc -- python scripts/ubench/enc_batch.py > $O/log$d.txt 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/t$d -o enc -- python scripts/ubench/enc_batch.py > $O/log$d.txt 2>&1
   echo "== dbg $d: $(grep 'bert batch' $O/log$d.txt)"
   python - <<PY
 import csv, collections
