@@ -45,8 +45,20 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+def _extra_defs() -> list[str]:
+    """FSGPU_BUILD_DEFS="-DFSGPU_EXPERIMENTS ..." builds the lab variants (timing skeletons, A/B switches read from the
+    environment); the default build ships none of them."""
+    return os.environ.get("FSGPU_BUILD_DEFS", "").split()
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
+    # objects built with other definitions are stale
+    stamp = os.path.join(OBJ, "defs.txt")
+    defs = " ".join(_extra_defs())
+    old = open(stamp).read() if os.path.exists(stamp) else ""
+    if old != defs:
+        force = True
     sources = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     common = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "fsgpu.h"), __file__]
     hipcc = _hipcc()
@@ -55,7 +67,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         path = os.path.join(CSRC, src)
         if force or _stale(obj, [path] + common):
-            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-I", INCLUDE, "-c", path, "-o", obj]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + _extra_defs() + ["-I", INCLUDE, "-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
@@ -68,6 +80,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(defs)
     build_host(force, verbose)
     return LIB
 

@@ -55,6 +55,47 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
         : "memory");
 }
 
+// N LDS-DMAs of one wave behind ONE scalar base: lane offsets in VGPRs (constant for the whole kernel), destinations 1 KB
+// apart from lds_dst on.  m0 is saved / restored once per group; no vector address arithmetic per instruction.
+template <int N>
+__device__ __forceinline__ void glds16_group(uint64_t sbase, const uint32_t (&voff)[N], uint32_t lds_dst) {
+    static_assert(N >= 1 && N <= 3, "a wave issues 1..3 DMA instructions per tile");
+    unsigned keep;
+    // (one asm statement: hipcc must not get to place anything that reads m0 between the pieces)
+    if constexpr (N == 1)
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %3, %2\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep) : "s"(lds_dst), "s"(sbase), "v"(voff[0]) : "memory");
+    else if constexpr (N == 2)
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %3, %2\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %4, %2\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep) : "s"(lds_dst), "s"(sbase), "v"(voff[0]), "v"(voff[1]) : "memory", "scc");
+    else
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %3, %2\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %4, %2\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %5, %2\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep) : "s"(lds_dst), "s"(sbase), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]) : "memory", "scc");
+}
+
+// The smallest integer c with (s >= c) == ((float)s >= t) for every integer |s| <= 2^24 (scores of the int8 rows this
+// kernel takes: at most 768 x 127 x 127): ceil(t), clamped so that s - c cannot overflow; NaN / +inf: nothing passes.
+__device__ __forceinline__ int ceil_threshold(float t) {
+    if (!(t <= 33554432.0f)) return 1 << 25;
+    if (t < -33554432.0f) return -(1 << 25);
+    return (int)ceilf(t);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
@@ -72,8 +113,29 @@ __device__ __forceinline__ void wait_vmcnt() {
 //     free -> DMA(tile n+NSLOT-1) | reads(chunk 2) | MFMA(chunk 1) | ... | reads(chunk 0 of tile n+1) | MFMA(last chunk)
 // so neither the LDS latency nor the barrier sits between two MFMA groups of a wave with nothing else to issue.
 // DBG: 0 = the main pass; 3 = a sample stage (its own instantiation, so that profiles tell the two apart and the main pass
-// carries no trace of the sample mapping); 1 = no MFMAs, 2 = no DMA (timing experiments only)
-template <int ROWB, int EB, int QT, int NSLOT, int DBG = 0>
+// carries no trace of the sample mapping); 1 = no MFMAs, 2 = no DMA (timing experiments only: -DFSGPU_EXPERIMENTS)
+//
+// OPT (bit set):
+//   kOptLag    the two waves that share a SIMD (w and w + 4) meet the tile's barrier at DIFFERENT points of their chunk sequence
+//              (waves 0-3 after chunk 0, waves 4-7 after chunk NC/2 - 1 and its threshold test), so that one wave's stretch
+//              without matrix instructions (DMA issue, threshold test, barrier) lies beside the other's MFMA chunks instead of
+//              beside the same stretch of its twin.  The ring accounting does not change: at the barrier of tile n every wave
+//              is past tile n - 1 and tile n + 1 has landed.
+//   kOptNegTau int8 rows: the accumulators start at -ceil(tau) instead of 0, so "some score of the pair reaches its query's
+//              threshold" is ONE sign test on the maximum of the lane's 8 x QT accumulators (v_max3_i32) instead of QT
+//              maxima, conversions and compares.  (s >= ceil(tau)) == ((float)s >= tau) for these integer scores.
+//   kOptSaddr  DMA addresses = one scalar tile base + per-lane offsets that are constant for the whole kernel
+//              (global_load_lds_dwordx4 v, s[..]); only a tile that crosses the end of the slab computes clamped addresses.
+//   kOptSplit  (needs kOptNegTau; row tiles of two sub-tile pairs or more) the loop is organised by QUERY-TILE halves instead of
+//              k-step chunks: a pair's fragments for ALL its k-steps sit in registers (2 x KS x 4 VGPRs, what the chunk
+//              double buffer took), phase 1 multiplies them with the first half of the wave's query tiles, phase 2 with the
+//              second half — and as phase 2 retires a k-step's fragments, the next pair's fragments of that k-step are read
+//              into the same registers (a rolling prefetch).  The threshold test of a finished half then lies in the shadow
+//              of the OTHER half's MFMAs (phase-1 scores are tested during phase 2, phase-2 scores during the next pair's
+//              phase 1), the LDS reads are spread one pair per four MFMAs, and nothing but the barrier interrupts the matrix
+//              stream of a wave.
+constexpr int kOptLag = 1, kOptNegTau = 2, kOptSaddr = 4, kOptSplit = 8;
+template <int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG = 0>
 __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     using acc_t = std::conditional_t<EB == 2, f32x4, i32x4>;
     constexpr int WPB = 8, NT = WPB * 64;
@@ -90,6 +152,16 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     constexpr int NC = (RS / 2) * NCH;                              // chunks per tile
     static_assert(KS % CK == 0 && NC % 2 == 0, "an even number of chunks per tile: the register double buffer starts every tile in the same phase");
     static_assert(NSLOT >= 4, "tile n is consumed while n+1 .. n+NSLOT-2 are in flight and n-1's slot is being refilled");
+    // (shapes whose resident queries already fill the register file take no option that costs registers)
+    constexpr bool ROOM = QT * KS * 4 + 4 * CK * 4 + 8 * QT <= 190;
+    constexpr bool LAG = (OPT & kOptLag) != 0 && NC >= 4;
+    constexpr bool NEGTAU = (OPT & kOptNegTau) != 0 && EB == 1 && ROOM;
+    constexpr bool SADDR = (OPT & kOptSaddr) != 0 && ROOM;
+    // registers: resident queries + fragments + accumulators must leave room for addresses and the append path
+    constexpr bool SPLIT = (OPT & kOptSplit) != 0 && NEGTAU && RS >= 4 && QT >= 2 && DBG != 1 && QT * KS * 4 + 2 * KS * 4 + 9 * QT <= 200;
+    // -ceil(tau) kept in all four registers of an accumulator (the first MFMA of a pair takes it as C: no initialising moves) where
+    // 4 x QT more registers fit; else one register per query tile and four moves per accumulator (in the MFMAs' shadow when SPLIT)
+    constexpr bool NT4 = NEGTAU && !SPLIT && QT * KS * 4 + 4 * CK * 4 + 12 * QT <= 200 && QT * KS * 4 <= 96;
     constexpr int TILE_BYTES = TR * ROWB;
     constexpr int NQ = WPB * QT * 16;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -105,6 +177,8 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     const int q0 = wave * QT * 16;
     half8 bq[QT][KS];
     float tau[QT];
+    int ctau[QT];       // NEGTAU: ceil(tau) as an integer ...
+    i32x4 ntau4[QT];    // ... and its negative in all four accumulator registers of a (sub-tile, query tile)
     {
         const unsigned char* qbase = static_cast<const unsigned char*>(args.queries);
 #pragma unroll
@@ -113,6 +187,8 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) bq[nt][ks] = *reinterpret_cast<const half8*>(qp + ks * 64);
             tau[nt] = args.tau[q0 + nt * 16 + frow];
+            ctau[nt] = ceil_threshold(tau[nt]);
+            if constexpr (NT4) ntau4[nt] = i32x4{-ctau[nt], -ctau[nt], -ctau[nt], -ctau[nt]};
         }
         // the fragments must have ARRIVED before the first DMA is issued: hipcc places the wait for a load at its first use,
         // which is inside the tile loop — a vmcnt(0) there would drain the DMA ring on every iteration
@@ -121,6 +197,8 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(bq[nt][ks]));
             asm volatile("" : "+v"(tau[nt]));
+            if constexpr (NT4) asm volatile("" : "+v"(ntau4[nt]));
+            else if constexpr (NEGTAU) asm volatile("" : "+v"(ctau[nt]));
         }
     }
 
@@ -155,17 +233,31 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
         c.base += grid;
         c.rot = c.rot + 1 == grid ? 0 : c.rot + 1;
     };
-    // the first / next round at or after the cursor whose tile exists (only the first or the last round can be ragged)
-    auto cursor_seek = [&](Cursor& c) {
-        while (c.n < rounds && cursor_tile(c) >= ntiles) cursor_next(c);
-    };
+    // Every block walks all `rounds` rounds; in the first or the last round (the only ragged ones) a block's tile may not exist:
+    // it then fetches the last tile again (the counted waits stay exact) and discards the scores — no search loop, a handful of
+    // scalar operations per tile.
 
     // DMA of one tile into a ring slot: wave w issues instructions j = w * PW + x, instruction j = (sub-tile j / KS,
     // k-step j % KS).  Rows past the end are clamped to the last row (their scores are discarded below).
     const int dma_p = lane >> 2, dma_c = lane & 3;
     const int dma_chunk = dma_c ^ ((4 - (dma_p >> 2)) & 3);
+    uint32_t dma_off[PW];   // SADDR: this lane's byte offset from the tile's first row, per instruction of the wave
+#pragma unroll
+    for (int x = 0; x < PW; ++x) {
+        const int j = wave * PW + x;
+        const int s = j / KS, ks = j - s * KS;
+        dma_off[x] = (uint32_t)(s * 16 + dma_p) * (uint32_t)row_pitch + (uint32_t)(ks * 64 + dma_chunk * 16);
+    }
     auto issue_tile = [&](uint32_t t, uint32_t slot) {
-        const uint32_t row0 = tile_row0(t);
+        const uint32_t row0 = __builtin_amdgcn_readfirstlane(tile_row0(t));
+        if constexpr (SADDR && DBG != 2) {
+            if (row0 + TR <= args.nrows) {   // (wave-uniform) every row of the tile exists: no clamp, no vector address arithmetic
+                const uint64_t sbase = (uint64_t)(uintptr_t)slab + (uint64_t)row0 * row_pitch;
+                const uint32_t dst = __builtin_amdgcn_readfirstlane(ring + slot * TILE_BYTES + (uint32_t)(wave * PW) * 1024u);
+                glds16_group<PW>(sbase, dma_off, dst);
+                return;
+            }
+        }
 #pragma unroll
         for (int x = 0; x < PW; ++x) {
             const int j = wave * PW + x;
@@ -181,9 +273,21 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
 
     // fragment reads of chunk c (sub-tile pair c / NCH, k-steps (c % NCH) * CK ...) of a ring slot
     const uint32_t a_off = (uint32_t)frow * 64u + (uint32_t)((fk ^ ((4 - (frow >> 2)) & 3)) << 4);
+    [[maybe_unused]] bool frag_ready = false;   // (DBG 5)
     auto read_chunk = [&](uint32_t slot, int c, half8 (&f)[2][CK]) {
         const unsigned char* base = smem + (size_t)slot * TILE_BYTES + a_off;
         const int sp = (c / NCH) * 2, k0 = (c % NCH) * CK;
+#ifdef FSGPU_EXPERIMENTS
+        if constexpr (DBG == 5) {   // timing skeleton: the fragments stay what the prologue read
+            if (frag_ready) {
+#pragma unroll
+                for (int kk = 0; kk < CK; ++kk)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(f[h][kk]));
+                return;
+            }
+        }
+#endif
 #pragma unroll
         for (int kk = 0; kk < CK; ++kk)
 #pragma unroll
@@ -191,6 +295,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     };
     auto mfma_chunk = [&](int c, const half8 (&f)[2][CK], acc_t (&acc)[2][QT]) {
         const int k0 = (c % NCH) * CK;
+#ifdef FSGPU_EXPERIMENTS
         if constexpr (DBG == 1) {
 #pragma unroll
             for (int kk = 0; kk < CK; ++kk)
@@ -198,6 +303,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
                 for (int h = 0; h < 2; ++h) asm volatile("" ::"v"(f[h][kk]));
             return;
         }
+#endif
 #pragma unroll
         for (int kk = 0; kk < CK; ++kk)
 #pragma unroll
@@ -212,94 +318,205 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     };
     // rows of a finished sub-tile pair at or above the threshold -> the block's list of their query (straight to global
     // memory: a few entries per query and block, so LDS holds only the counters)
-    auto emit_pair = [&](uint32_t t, int sp, const acc_t (&acc)[2][QT]) {
-        // one test for the whole pair: does any of the lane's 8 x QT scores reach its query's threshold?  (max ignores
-        // NaN, and NaN >= tau is false: a NaN score never passes, as in scan_mfma_kernel)
-        auto lane_max = [&](int nt) {
-            auto m = acc[0][nt][0];
+    auto lane_max = [&](const acc_t (&acc)[2][QT], int nt) {
+        auto m = acc[0][nt][0];
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if constexpr (EB == 2) m = __builtin_fmaxf(m, acc[h][nt][r]);
-                    else m = acc[h][nt][r] > m ? acc[h][nt][r] : m;
-                }
-            return (float)m;
-        };
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (EB == 2) m = __builtin_fmaxf(m, acc[h][nt][r]);   // (max ignores NaN, and NaN >= tau is false: a NaN
+                else m = acc[h][nt][r] > m ? acc[h][nt][r] : m;                 // score never passes, as in scan_mfma_kernel)
+            }
+        return m;
+    };
+    // NEGTAU: the accumulators hold score - ceil(tau), a score passes iff its accumulator is >= 0
+    auto passes = [&](int nt, auto v) {
+        if constexpr (NEGTAU) return v >= 0;
+        else return (float)v >= tau[nt];
+    };
+    auto score_of = [&](int nt, auto v) {
+        if constexpr (NEGTAU) return (float)(v + ctau[nt]);
+        else return (float)v;
+    };
+    // does any of the lane's 8 scores per query tile in [nt_lo, nt_hi) reach its query's threshold?
+    auto any_passes = [&](const acc_t (&acc)[2][QT], int nt_lo, int nt_hi) {
         bool any = false;
+        if constexpr (NEGTAU) {
+            int m = lane_max(acc, nt_lo);
 #pragma unroll
-        for (int nt = 0; nt < QT; ++nt) any |= lane_max(nt) >= tau[nt];
-        if (!any) return;  // almost always: survivors are a few hundred rows of the slab
-        if constexpr (DBG == 2) {  // (the ring holds stale bytes in the no-DMA timing experiment: keep the scores live, append nothing)
+            for (int nt = nt_lo + 1; nt < nt_hi; ++nt) {
+                const int x = lane_max(acc, nt);
+                m = x > m ? x : m;
+            }
+            any = m >= 0;
+        } else {
+#pragma unroll
+            for (int nt = nt_lo; nt < nt_hi; ++nt) any |= passes(nt, lane_max(acc, nt));
+        }
+        return any;
+    };
+    auto append = [&](int q, float score, uint32_t row) {
+        if (row >= args.nrows) return;
+        if (args.live && !((args.live[row >> 6] >> (row & 63)) & 1ull)) return;
+        if (args.allow && !((args.allow[row >> 6] >> (row & 63)) & 1ull)) return;
+        const int pos = atomicAdd(&lcnt[q], 1);
+        const u64 entry = pack(score, args.row_base + row);
+        if (pos < slots) {
+            args.cand[((size_t)q * gridDim.x + blockIdx.x) * slots + pos] = entry;
+        } else {
+            const uint32_t g = atomicAdd(&args.spill_count[q * kMfmaSpillCountStride], 1u);
+            if (g < args.spill_cap) args.spill[(size_t)q * args.spill_cap + g] = entry;
+            else args.overflow[q] = 1;
+        }
+    };
+    // the slow path: a lane with a passing score among the query tiles [nt_lo, nt_hi) of sub-tile pair sp of tile t
+    auto emit_tiles = [&](uint32_t t, int sp, const acc_t (&acc)[2][QT], int nt_lo, int nt_hi) {
+#ifdef FSGPU_EXPERIMENTS
+        if constexpr (DBG == 2 || DBG == 4 || DBG == 5) {  // (timing skeletons read stale bytes: keep the scores live, append nothing)
             lcnt[q0 + frow] = 0;
             return;
         }
-        auto append = [&](int q, float score, uint32_t row) {
-            if (row >= args.nrows) return;
-            if (args.live && !((args.live[row >> 6] >> (row & 63)) & 1ull)) return;
-            if (args.allow && !((args.allow[row >> 6] >> (row & 63)) & 1ull)) return;
-            const int pos = atomicAdd(&lcnt[q], 1);
-            const u64 entry = pack(score, args.row_base + row);
-            if (pos < slots) {
-                args.cand[((size_t)q * gridDim.x + blockIdx.x) * slots + pos] = entry;
-            } else {
-                const uint32_t g = atomicAdd(&args.spill_count[q * kMfmaSpillCountStride], 1u);
-                if (g < args.spill_cap) args.spill[(size_t)q * args.spill_cap + g] = entry;
-                else args.overflow[q] = 1;
-            }
-        };
+#endif
         // C layout: column (query) = lane & 15, row = (lane >> 4) * 4 + reg
         const uint32_t row00 = tile_row0(t) + sp * 16 + fk * 4;
         if constexpr (EB == 2 && QT >= 3) {   // (the 384-query f16 shape has no register to spare for the per-tile test below)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int nt = 0; nt < QT; ++nt)
+                for (int nt = nt_lo; nt < nt_hi; ++nt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if ((float)acc[h][nt][r] >= tau[nt]) append(q0 + nt * 16 + frow, (float)acc[h][nt][r], row00 + h * 16 + r);
+                        if (passes(nt, acc[h][nt][r])) append(q0 + nt * 16 + frow, score_of(nt, acc[h][nt][r]), row00 + h * 16 + r);
         } else {
             // query tiles first: a wave gets here for ONE passing score as a rule, and the tiles without one are skipped as a
             // whole — on a 1.25M-row shard, where 512 queries x ~800 survivors meet 8 x fewer tiles than at 10M rows, this slow
             // path is entered ~20 times per tile
 #pragma unroll
-            for (int nt = 0; nt < QT; ++nt) {
-                const float th = tau[nt];
-                if (!(lane_max(nt) >= th)) continue;
+            for (int nt = nt_lo; nt < nt_hi; ++nt) {
+                if (!passes(nt, lane_max(acc, nt))) continue;
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if ((float)acc[h][nt][r] >= th) append(q0 + nt * 16 + frow, (float)acc[h][nt][r], row00 + h * 16 + r);
+                        if (passes(nt, acc[h][nt][r])) append(q0 + nt * 16 + frow, score_of(nt, acc[h][nt][r]), row00 + h * 16 + r);
             }
         }
+    };
+    auto emit_pair = [&](uint32_t t, int sp, const acc_t (&acc)[2][QT]) {
+        // one test for the whole pair; almost always negative: survivors are a few hundred rows of the slab
+        if (any_passes(acc, 0, QT)) emit_tiles(t, sp, acc, 0, QT);
     };
 
     __syncthreads();  // counters initialised (no DMA in flight yet)
     Cursor cl{0, 0, 0};   // next tile to fetch
-    cursor_seek(cl);
     Cursor cc = cl;       // next tile to consume
-    // prologue: NSLOT - 1 tiles in flight (tile j -> slot j mod NSLOT throughout).  Past the last real tile the DMA count
-    // is kept up with dummy tiles (the last tile again) so that the counted waits below stay exact.
+    // prologue: NSLOT - 1 tiles in flight (tile j -> slot j mod NSLOT throughout).  Past the last round the DMA count is kept
+    // up with dummy tiles (the last tile again) so that the counted waits below stay exact.
     auto fetch_next = [&](uint32_t slot) {
-        const bool real = cl.n < rounds;
-        issue_tile(real ? cursor_tile(cl) : ntiles - 1, slot);
-        if (real) {
-            cursor_next(cl);
-            cursor_seek(cl);
-        }
+        uint32_t t = cl.n < rounds ? cursor_tile(cl) : ntiles;
+        t = t < ntiles ? t : ntiles - 1;
+        issue_tile(t, slot);
+        if (cl.n < rounds) cursor_next(cl);
     };
 #pragma unroll
     for (int j = 0; j < NSLOT - 1; ++j) fetch_next((uint32_t)j);
+    if constexpr (SPLIT) {
+        constexpr int NP = RS / 2;                  // sub-tile pairs per tile
+        constexpr int QA = QT / 2;                  // phase 1: query tiles [0, QA), phase 2: [QA, QT)
+        half8 f[2][KS];                             // the current pair's fragments: [sub-tile of the pair][k-step]
+        acc_t acc[2][QT];
+        auto read_frag = [&](uint32_t sl, int pair, int kk) {
+            const unsigned char* base = smem + (size_t)sl * TILE_BYTES + a_off;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) f[h][kk] = *reinterpret_cast<const half8*>(base + ((pair * 2 + h) * KS + kk) * 1024);
+        };
+        auto mfma_step = [&](int kk, int nt_lo, int nt_hi) {
+#pragma unroll
+            for (int nt = nt_lo; nt < nt_hi; ++nt)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    acc[h][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, f[h][kk]),
+                                                                       __builtin_bit_cast(i32x4, bq[nt][kk]), acc[h][nt], 0, 0, 0);
+        };
+        auto init_acc = [&](int nt_lo, int nt_hi) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int nt = nt_lo; nt < nt_hi; ++nt) acc[h][nt] = i32x4{-ctau[nt], -ctau[nt], -ctau[nt], -ctau[nt]};
+        };
+        wait_vmcnt<PW*(NSLOT - 2)>();          // this wave's share of tile 0 has landed ...
+        __builtin_amdgcn_s_barrier();          // ... and everyone's
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) read_frag(0, 0, kk);
+        init_acc(0, QT);                        // (so that the first, void, test of the second half reads defined values)
+        uint32_t slot = 0;
+        uint32_t tB = 0;                        // tile of the pair whose second-half scores are still to be tested
+        bool existsB = false;
+        while (cc.n < rounds) {
+            const uint32_t slot_next = slot + 1 == NSLOT ? 0 : slot + 1;
+            const uint32_t t = cursor_tile(cc);
+            const bool tile_exists = t < ntiles;   // (wave-uniform) else: the ring slot holds the last tile again, nothing is emitted
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                constexpr int TK = KS >= 4 ? 2 : 0;   // the k-step after which a phase carries the other half's test
+                // ---- phase 1: query tiles [0, QA); the previous pair's tiles [QA, QT) are tested in its shadow
+                init_acc(0, QA);
+                bool anyB = false;
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    mfma_step(kk, 0, QA);
+                    if (kk == TK) anyB = any_passes(acc, QA, QT);
+                    if (p == 0 && kk == 0) {
+                        // The tile's barrier.  Tile n+1: this wave's DMAs have landed (tiles n+2 .. n+NSLOT-2 may still be in
+                        // flight), then everyone's; every wave is also past its last read of tile n-1 (this tile's first pair was
+                        // read behind them and has been waited for), whose slot takes tile n+NSLOT-1.
+                        wait_vmcnt<PW*(NSLOT - 3)>();
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                    }
+                    if (p == 0 && kk == (KS >= 3 ? 2 : KS - 1)) fetch_next(slot == 0 ? NSLOT - 1 : slot - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (existsB && anyB) emit_tiles(tB, ((p + NP - 1) % NP) * 2, acc, QA, QT);
+                // ---- phase 2: query tiles [QA, QT); the next pair's fragments roll in behind each k-step; this pair's tiles
+                // [0, QA) are tested in its shadow
+                init_acc(QA, QT);
+                bool anyA = false;
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    mfma_step(kk, QA, QT);
+                    if (p + 1 < NP) read_frag(slot, p + 1, kk);
+                    else read_frag(slot_next, 0, kk);
+                    if (kk == TK) anyA = any_passes(acc, 0, QA);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (tile_exists && anyA) emit_tiles(t, p * 2, acc, 0, QA);
+                tB = t;
+                existsB = tile_exists;
+            }
+            cursor_next(cc);
+            slot = slot_next;
+        }
+        if (existsB && any_passes(acc, QA, QT)) emit_tiles(tB, (NP - 1) * 2, acc, QA, QT);
+    } else {
     half8 fa[2][2][CK];   // fragment double buffer: [buffer][sub-tile of the pair][k-step of the chunk]
+    const bool late = LAG && wave >= 4;
     wait_vmcnt<PW*(NSLOT - 2)>();          // this wave's share of tile 0 has landed ...
     __builtin_amdgcn_s_barrier();          // ... and everyone's
     asm volatile("" ::: "memory");
     read_chunk(0, 0, fa[0]);
+#ifdef FSGPU_EXPERIMENTS
+    if constexpr (DBG == 5) {
+        read_chunk(0, 1, fa[1]);
+        frag_ready = true;
+    }
+#endif
     uint32_t slot = 0;
     while (cc.n < rounds) {
         const uint32_t slot_next = slot + 1 == NSLOT ? 0 : slot + 1;
         const uint32_t t = cursor_tile(cc);
+        const bool tile_exists = t < ntiles;   // (wave-uniform) else: the ring slot holds the last tile again, nothing is emitted
         acc_t acc[2][QT];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -307,7 +524,11 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int nt = 0; nt < QT; ++nt) acc[h][nt] = acc_t{0, 0, 0, 0};
+                    for (int nt = 0; nt < QT; ++nt) {
+                        if constexpr (NT4) acc[h][nt] = ntau4[nt];
+                        else if constexpr (NEGTAU) acc[h][nt] = acc_t{-ctau[nt], -ctau[nt], -ctau[nt], -ctau[nt]};
+                        else acc[h][nt] = acc_t{0, 0, 0, 0};
+                    }
             }
             // the NEXT chunk's fragment reads go out before this chunk's MFMAs (the next tile's first chunk after the last)
             if (c + 1 < NC) read_chunk(slot, c + 1, fa[(c + 1) & 1]);
@@ -315,26 +536,32 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
             __builtin_amdgcn_sched_barrier(0);
             mfma_chunk(c, fa[c & 1], acc);
             __builtin_amdgcn_sched_barrier(0);
-            if (c == 0) {
-                // tile n+1: this wave's DMAs have landed (tiles n+2 .. n+NSLOT-2 may still be in flight), then everyone's;
-                // every wave is also past its last read of tile n-1, whose slot takes tile n+NSLOT-1
+            if (c % NCH == NCH - 1 && tile_exists) emit_pair(t, (c / NCH) * 2, acc);
+            // The tile's barrier.  Tile n+1: this wave's DMAs have landed (tiles n+2 .. n+NSLOT-2 may still be in flight), then
+            // everyone's; every wave is also past its last read of tile n-1, whose slot takes tile n+NSLOT-1.
+            // LAG: waves 4-7 get here one or more chunks later in their own sequence than waves 0-3 (after chunk NC/2 - 1 and
+            // its threshold test), so the twin waves of a SIMD run out of phase; both statements above still hold for them.
+            constexpr int CB = NC / 2 - 1;   // the late group's barrier chunk
+            bool at_barrier = c == 0;
+            if constexpr (LAG) at_barrier = late ? c == CB : c == 0;
+            if (at_barrier && DBG != 4) {   // (DBG 4: timing skeleton without the tile's wait and barrier)
                 wait_vmcnt<PW*(NSLOT - 3)>();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
-            // The DMA issue (address arithmetic + PW LDS-DMA instructions: a stretch without MFMAs) is staggered between
-            // the two waves that share a SIMD (waves w and w + 4): one right after the barrier, the other a chunk later,
-            // so that the matrix pipe always has one of them feeding it.
-            if (NC >= 2 && c <= 1) {
+            // The DMA issue (a stretch without MFMAs) is staggered between the two waves that share a SIMD (waves w and
+            // w + 4): the early group right after the barrier, the late group a chunk after its own.
+            if constexpr (LAG) {
+                if (late ? c == CB + 1 : c == 0) fetch_next(slot == 0 ? NSLOT - 1 : slot - 1);
+            } else if (NC >= 2 && c <= 1) {
                 if ((wave >= 4) == (c == 1)) fetch_next(slot == 0 ? NSLOT - 1 : slot - 1);
             } else if (NC < 2 && c == 0) {
                 fetch_next(slot == 0 ? NSLOT - 1 : slot - 1);
             }
-            if (c % NCH == NCH - 1) emit_pair(t, (c / NCH) * 2, acc);
         }
         cursor_next(cc);
-        cursor_seek(cc);
         slot = slot_next;
+    }
     }
     wait_vmcnt<0>();  // no DMA may outlive the block's LDS allocation
     __syncthreads();
@@ -349,12 +576,26 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
 
 namespace {
 
-template <int ROWB, int EB, int QT, int NSLOT, int DBG = 0>
+// what the shipped kernels are built with (measured: profiles/r03/wide_opt_ab.txt)
+#ifdef FSGPU_WIDE_OPT_DEFAULT
+constexpr int kWideOptDefault = FSGPU_WIDE_OPT_DEFAULT;
+#else
+constexpr int kWideOptDefault = 0;
+#endif
+
+#ifdef FSGPU_EXPERIMENTS
+int wide_env(const char* name) {
+    const char* e = std::getenv(name);
+    return e ? std::atoi(e) : -1;
+}
+#endif
+
+template <int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG = 0>
 hipError_t launch_wide_t(const MfmaScanArgs& args, int grid, hipStream_t stream, int* occupancy) {
     constexpr int TR = ROWB >= 512 ? 32 : 64;
     constexpr size_t ring = (size_t)NSLOT * TR * ROWB;
     const size_t lds = ring + (size_t)QT * 128 * 4;   // the row-tile ring + one append counter per query
-    auto kern = scan_wide_kernel<ROWB, EB, QT, NSLOT, DBG>;
+    auto kern = scan_wide_kernel<ROWB, EB, QT, NSLOT, OPT, DBG>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -369,7 +610,7 @@ hipError_t launch_wide_t(const MfmaScanArgs& args, int grid, hipStream_t stream,
     }
     if (args.slots > kWideSlots) return hipErrorInvalidValue;
     static const std::string name = "scan_wide_kernel<" + std::to_string(ROWB) + ", " + std::to_string(EB) + ", " +
-                                    std::to_string(QT) + ", " + std::to_string(NSLOT) + ">";
+                                    std::to_string(QT) + ", " + std::to_string(NSLOT) + ", " + std::to_string(OPT) + ">";
     if (DBG != 3) note_main_pass_kernel(name.c_str());
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, args);
     return hipGetLastError();
@@ -380,21 +621,48 @@ hipError_t launch_wide_d(const MfmaScanArgs& args, int grid, hipStream_t stream,
     // resident query fragments: QT x (row bytes / 64) x 4 registers per lane; 144 is what fits next to the accumulators and
     // the fragment double buffer (f16 rows of 768 bytes: 3 tiles; int8 rows of 384 bytes: 6)
     if (QT * (int)(args.dim * EB / 64) * 4 > 144) return hipErrorInvalidValue;
+    constexpr int O = kWideOptDefault;
     switch (args.dim * EB / 2) {  // row length in 2-byte units
         case 384: if constexpr (QT <= 3) {
-            if constexpr (MODE != 0) return launch_wide_t<768, EB, QT, 6, MODE>(args, grid, stream, occupancy);
-            static const int dbg = [] { const char* e = std::getenv("FSGPU_WIDE_DBG"); return e ? std::atoi(e) : 0; }();  // timing experiments only
-            if constexpr (EB == 2 && QT == 2) {
-                if (dbg == 1) return launch_wide_t<768, EB, QT, 6, 1>(args, grid, stream, occupancy);
-                if (dbg == 2) return launch_wide_t<768, EB, QT, 6, 2>(args, grid, stream, occupancy);
+#ifdef FSGPU_EXPERIMENTS
+            if constexpr (MODE == 0 && EB == 2 && QT == 2) {   // timing skeletons: answers are NOT valid
+                static const int dbg = wide_env("FSGPU_WIDE_DBG");
+                if (dbg == 1) return launch_wide_t<768, EB, QT, 6, O, 1>(args, grid, stream, occupancy);
+                if (dbg == 2) return launch_wide_t<768, EB, QT, 6, O, 2>(args, grid, stream, occupancy);
             }
-            return launch_wide_t<768, EB, QT, 6>(args, grid, stream, occupancy);   // 6 x 24 KB
+#endif
+            return launch_wide_t<768, EB, QT, 6, O, MODE>(args, grid, stream, occupancy);   // 6 x 24 KB
         } else return hipErrorInvalidValue;
-        case 256: if constexpr (QT <= 4) return launch_wide_t<512, EB, QT, 8, MODE>(args, grid, stream, occupancy);   // 8 x 16 KB
+        case 256: if constexpr (QT <= 4) return launch_wide_t<512, EB, QT, 8, O, MODE>(args, grid, stream, occupancy);   // 8 x 16 KB
                   else return hipErrorInvalidValue;
-        case 192: return launch_wide_t<384, EB, QT, 6, MODE>(args, grid, stream, occupancy);   // 6 x 24 KB
-        case 128: return launch_wide_t<256, EB, QT, 8, MODE>(args, grid, stream, occupancy);   // 8 x 16 KB
-        case 64: return launch_wide_t<128, EB, QT, 8, MODE>(args, grid, stream, occupancy);    // 8 x 8 KB
+        case 192:
+#ifdef FSGPU_EXPERIMENTS
+            if constexpr (EB == 1 && QT == 4) {   // A/B runs of the kernel's options on the bench shape (int8 rows of 384 dimensions)
+                static const int opt = wide_env("FSGPU_WIDE_OPT");
+                static const int dbg = wide_env("FSGPU_WIDE_DBG");
+                if constexpr (MODE == 0) {
+                    if (dbg == 1) return launch_wide_t<384, EB, QT, 6, 7, 1>(args, grid, stream, occupancy);
+                    if (dbg == 2) return launch_wide_t<384, EB, QT, 6, 7, 2>(args, grid, stream, occupancy);
+                    if (dbg == 4) return launch_wide_t<384, EB, QT, 6, 7, 4>(args, grid, stream, occupancy);
+                    if (dbg == 5) return launch_wide_t<384, EB, QT, 6, 7, 5>(args, grid, stream, occupancy);
+                }
+                switch (opt) {
+                    case 0: return launch_wide_t<384, EB, QT, 6, 0, MODE>(args, grid, stream, occupancy);
+                    case 1: return launch_wide_t<384, EB, QT, 6, 1, MODE>(args, grid, stream, occupancy);
+                    case 2: return launch_wide_t<384, EB, QT, 6, 2, MODE>(args, grid, stream, occupancy);
+                    case 3: return launch_wide_t<384, EB, QT, 6, 3, MODE>(args, grid, stream, occupancy);
+                    case 4: return launch_wide_t<384, EB, QT, 6, 4, MODE>(args, grid, stream, occupancy);
+                    case 5: return launch_wide_t<384, EB, QT, 6, 5, MODE>(args, grid, stream, occupancy);
+                    case 6: return launch_wide_t<384, EB, QT, 6, 6, MODE>(args, grid, stream, occupancy);
+                    case 7: return launch_wide_t<384, EB, QT, 6, 7, MODE>(args, grid, stream, occupancy);
+                    case 14: return launch_wide_t<384, EB, QT, 6, 14, MODE>(args, grid, stream, occupancy);
+                    default: break;
+                }
+            }
+#endif
+            return launch_wide_t<384, EB, QT, 6, O, MODE>(args, grid, stream, occupancy);   // 6 x 24 KB
+        case 128: return launch_wide_t<256, EB, QT, 8, O, MODE>(args, grid, stream, occupancy);   // 8 x 16 KB
+        case 64: return launch_wide_t<128, EB, QT, 8, O, MODE>(args, grid, stream, occupancy);    // 8 x 8 KB
         default: return hipErrorInvalidValue;
     }
 }

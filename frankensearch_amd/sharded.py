@@ -156,19 +156,29 @@ class ShardedVectorIndex:
         # collective (RCCL), the side stream and the merge of the gathered layout all run
         self.force_collective = force_collective and dist.is_initialized()
         self._side = None
+        self._scan_event = None   # recorded on the scan's stream right after the last search_begin returned (CUDA only)
 
     def search_begin(self, queries: torch.Tensor, k: int, after_enqueue=None) -> torch.Tensor:
         """[B, dim] -> this shard's packed [B, k] list (global rows, best first)."""
         if after_enqueue is None or not getattr(self.backend, "supports_after_enqueue", False):
-            return self.backend.search_packed(queries, k)   # (the caller sees that the hook did not run and does its work itself)
-        return self.backend.search_packed(queries, k, after_enqueue=after_enqueue)
+            local = self.backend.search_packed(queries, k)   # (the caller sees that the hook did not run and does its work itself)
+        else:
+            local = self.backend.search_packed(queries, k, after_enqueue=after_enqueue)
+        # The batched scan synchronises its stream before it decides on fallbacks, but the fallback work itself (exact kernels, the
+        # nested f16 re-filter, the scatter of their hits into `local`) is only ENQUEUED when the call returns.  This event covers
+        # that tail — and nothing of the next scan, whose kernels are enqueued after it.
+        self._scan_event = None
+        if self.overlap and local.is_cuda:
+            self._scan_event = torch.cuda.Event()
+            self._scan_event.record(torch.cuda.current_stream(local.device))
+        return local
 
     def search_steps(self, batch_of, first: int, n: int, k: int, after_scan=None, keep_all: bool = False):
         """n whole searches (queries batch_of(i), i = first .. first + n - 1) as a pipeline: the all-gather + merge of step i - 1
         are enqueued on the side stream from inside the scan call of step i, in the window after its kernels are enqueued and
         before it blocks on its stream — the exchange's GPU work AND its host work run under the scan.  Returns the last step's
         (rows, scores, counts) — or every step's with keep_all — complete when this returns."""
-        outs, pending, prev = [], None, None
+        outs, pending, prev, prev_event = [], None, None, None
         state = {"pending": None}
 
         def wait(p):
@@ -183,23 +193,24 @@ class ShardedVectorIndex:
                     outs.append(done)
             hook = None
             if prev is not None:
-                def hook(prev=prev):
-                    state["pending"] = self.search_end(prev, k, scan_done=True)
+                def hook(prev=prev, prev_event=prev_event):
+                    state["pending"] = self.search_end(prev, k, scan_event=prev_event)
             state["pending"] = None
             local = self.search_begin(batch_of(i), k, after_enqueue=hook)
+            local_event = self._scan_event
             if after_scan is not None:
                 after_scan()
             if prev is not None:
                 # (a search that left the matrix-core path returns without calling the hook)
-                pending = state["pending"] if state["pending"] is not None else self.search_end(prev, k)
-            prev = local
+                pending = state["pending"] if state["pending"] is not None else self.search_end(prev, k, scan_event=prev_event)
+            prev, prev_event = local, local_event
         if pending is not None:
             done = wait(pending)
             if keep_all:
                 outs.append(done)
         last = None
         if prev is not None:
-            last = wait(self.search_end(prev, k))
+            last = wait(self.search_end(prev, k, scan_event=prev_event))
             outs.append(last)
         return outs if keep_all else last
 
@@ -217,16 +228,19 @@ class ShardedVectorIndex:
             dist.all_gather_into_tensor(flat, local, group=self.group)
         return flat.view(self.world, local.shape[0], local.shape[1])
 
-    def search_end(self, local: torch.Tensor, k: int, scan_done: bool = False):
+    def search_end(self, local: torch.Tensor, k: int, scan_event=None):
         """All-gather of the W packed lists + merge.  Returns (rows, scores, counts[, event when overlap is on]).
-        scan_done: the scan that produced `local` has completed (its call synchronised its stream) — the side stream does not
-        wait for the current stream, which by now may hold the NEXT scan's kernels."""
+        scan_event: recorded on the scan's stream when the call that produced `local` returned (search_begin): the side stream
+        waits for exactly that — the scan AND whatever fallback work it left enqueued — instead of for the whole current stream,
+        which by now may hold the NEXT scan's kernels."""
         if not (self.overlap and local.is_cuda):
             return self.backend.merge(self._gather(local), k)
         if self._side is None:
             self._side = torch.cuda.Stream(device=local.device)
         side = self._side
-        if not scan_done:
+        if scan_event is not None:
+            side.wait_event(scan_event)
+        else:
             side.wait_stream(torch.cuda.current_stream(local.device))   # the scan that produced `local`
         local.record_stream(side)
         with torch.cuda.stream(side):

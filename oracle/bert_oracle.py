@@ -155,3 +155,76 @@ def random_weights(seed: int, vocab: int, hidden: int, layers: int, inter: int, 
         w[f"{p}.output.LayerNorm.weight"] = (1.0 + 0.1 * rng.standard_normal(hidden)).astype(F)
         w[f"{p}.output.LayerNorm.bias"] = t(hidden)
     return w
+
+
+# ---- the same forward in C (oracle/bert_oracle_c.c): multi-threaded, the encoder cpu_baseline of bench.py -------------------
+def _c_weights(weights: Dict[str, np.ndarray], num_layers: int, eps: float = 1e-12):
+    """(struct, keepalive) for fso_bert_forward from HF-layout weights."""
+    import ctypes as C
+
+    w = normalise_keys(weights)
+    fp = C.POINTER(C.c_float)
+
+    class Layer(C.Structure):
+        _fields_ = [(n, fp) for n in ("wqkv", "bqkv", "wo", "bo", "ln1_w", "ln1_b", "w1", "b1", "w2", "b2", "ln2_w", "ln2_b")]
+
+    class Weights(C.Structure):
+        _fields_ = [("vocab", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32), ("inter", C.c_int32),
+                    ("max_pos", C.c_int32), ("eps", C.c_float), ("word", fp), ("pos", fp), ("type0", fp),
+                    ("emb_ln_w", fp), ("emb_ln_b", fp), ("layer", C.POINTER(Layer))]
+
+    keep = []
+
+    def ptr(a):
+        a = np.ascontiguousarray(a, dtype=F)
+        keep.append(a)
+        return a.ctypes.data_as(fp)
+
+    layers = (Layer * num_layers)()
+    for i in range(num_layers):
+        p = f"bert.encoder.layer.{i}"
+        layers[i].wqkv = ptr(np.concatenate([w[f"{p}.attention.self.{n}.weight"] for n in ("query", "key", "value")], axis=0))
+        layers[i].bqkv = ptr(np.concatenate([w[f"{p}.attention.self.{n}.bias"] for n in ("query", "key", "value")], axis=0))
+        layers[i].wo, layers[i].bo = ptr(w[f"{p}.attention.output.dense.weight"]), ptr(w[f"{p}.attention.output.dense.bias"])
+        layers[i].ln1_w, layers[i].ln1_b = ptr(w[f"{p}.attention.output.LayerNorm.weight"]), ptr(w[f"{p}.attention.output.LayerNorm.bias"])
+        layers[i].w1, layers[i].b1 = ptr(w[f"{p}.intermediate.dense.weight"]), ptr(w[f"{p}.intermediate.dense.bias"])
+        layers[i].w2, layers[i].b2 = ptr(w[f"{p}.output.dense.weight"]), ptr(w[f"{p}.output.dense.bias"])
+        layers[i].ln2_w, layers[i].ln2_b = ptr(w[f"{p}.output.LayerNorm.weight"]), ptr(w[f"{p}.output.LayerNorm.bias"])
+    word = w["bert.embeddings.word_embeddings.weight"]
+    s = Weights()
+    s.vocab, s.hidden, s.layers = word.shape[0], word.shape[1], num_layers
+    s.inter = w["bert.encoder.layer.0.intermediate.dense.weight"].shape[0] if num_layers else 0
+    s.max_pos = w["bert.embeddings.position_embeddings.weight"].shape[0]
+    s.eps = eps
+    s.word, s.pos = ptr(word), ptr(w["bert.embeddings.position_embeddings.weight"])
+    s.type0 = ptr(w["bert.embeddings.token_type_embeddings.weight"][0])
+    s.emb_ln_w, s.emb_ln_b = ptr(w["bert.embeddings.LayerNorm.weight"]), ptr(w["bert.embeddings.LayerNorm.bias"])
+    s.layer = layers
+    keep.append(layers)
+    return s, keep
+
+
+class CForward:
+    """fso_bert_forward bound once to a weight set: `run(batch, nthreads)` -> [n_docs, H] f32."""
+
+    def __init__(self, weights: Dict[str, np.ndarray], num_layers: int):
+        import ctypes as C
+        from oracle import oracle
+
+        oracle.build()
+        self._lib = oracle.lib()
+        self._w, self._keep = _c_weights(weights, num_layers)
+        self._hidden = int(self._w.hidden)
+        self._lib.fso_bert_forward.restype = C.c_int
+        self._lib.fso_bert_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+
+    def run(self, batch: Sequence[Sequence[int]], nthreads: int = 1) -> np.ndarray:
+        import ctypes as C
+
+        lens = [len(b) for b in batch]
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+        ids = np.concatenate([np.asarray(b, dtype=np.int32) for b in batch if len(b)]) if sum(lens) else np.zeros(1, np.int32)
+        out = np.zeros((len(batch), self._hidden), dtype=F)
+        rc = self._lib.fso_bert_forward(C.byref(self._w), ids.ctypes.data, offsets.ctypes.data, len(batch), nthreads, out.ctypes.data)
+        assert rc == 0, rc
+        return out

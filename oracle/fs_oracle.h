@@ -178,6 +178,26 @@ size_t fso_mrl_search(const uint8_t *slab, uint64_t nrows, uint32_t dim, const u
                       size_t wal_len, const float *q, size_t limit, size_t search_dims, size_t rescore_dims,
                       size_t rescore_top_k, int hreduce, uint32_t *out_rows, float *out_scores);
 
+/* ---- MiniLM-class encoder, f32 (bert_oracle_c.c; crates/frankensearch-rerank/src/native.rs:587-626,1142-1236) ---- */
+typedef struct {
+    const float *wqkv, *bqkv;     /* [3H, H] (query, key, value stacked, native.rs:1359-1602), [3H] */
+    const float *wo, *bo;         /* attention.output.dense [H, H], [H] */
+    const float *ln1_w, *ln1_b;   /* attention.output.LayerNorm */
+    const float *w1, *b1;         /* intermediate.dense [I, H], [I] */
+    const float *w2, *b2;         /* output.dense [H, I], [H] */
+    const float *ln2_w, *ln2_b;   /* output.LayerNorm */
+} fso_bert_layer;
+typedef struct {
+    int32_t vocab, hidden, layers, inter, max_pos;
+    float eps;
+    const float *word, *pos, *type0, *emb_ln_w, *emb_ln_b;
+    const fso_bert_layer *layer;  /* [layers] */
+} fso_bert_weights;
+/* ids: all documents' token ids back to back; offsets: [n_docs + 1] into ids; out: [n_docs, hidden] unit vectors (zeros for
+ * an empty document).  nthreads workers share the batch in blocks of ~128 tokens.  0 on success. */
+int fso_bert_forward(const fso_bert_weights *w, const int32_t *ids, const uint32_t *offsets, uint32_t n_docs, int nthreads,
+                     float *out);
+
 #ifdef __cplusplus
 }
 #endif

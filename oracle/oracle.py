@@ -32,7 +32,7 @@ PARALLEL_CHUNK_SIZE = 1_024  # search.rs:25
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (idempotent)."""
-    srcs = [os.path.join(_HERE, f) for f in ("fs_oracle.c", "fs_oracle_avx2.c", "fs_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("fs_oracle.c", "fs_oracle_avx2.c", "bert_oracle_c.c", "fs_oracle.h", "Makefile")]
     stale = force or not os.path.exists(_SO) or any(
         os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs
     )

@@ -55,6 +55,30 @@ for rows, scores, counts in outs:
     assert np.array_equal(rows.cpu().numpy().astype(np.uint32), wr), "rows differ"
     assert np.array_equal(bits(scores.cpu().numpy()), bits(ws)), "score bits differ"
     assert int(counts.min().item()) == k
+# The fallback tail.  A corpus of a handful of distinct rows overflows every candidate pool: the batched call synchronises its
+# stream, decides on the fallbacks and returns with the exact kernels + the scatter of their hits only ENQUEUED.  The exchange of
+# step i - 1, enqueued from inside the scan call of step i, must wait for that tail (search_begin's event) — every step has its own
+# queries, so a merge of a half-written list cannot pass for the right answer.
+rng = np.random.default_rng(5)
+n2, nq2, steps2 = 200_000, 300, 5
+base = rng.standard_normal((7, dim)).astype(np.float32)
+x = base[rng.integers(0, 7, n2)]
+x /= np.linalg.norm(x, axis=1, keepdims=True)
+slab2 = x.astype(np.float16).view(np.uint16)
+whole2 = fa.VectorIndex.from_slab(slab2)
+index2 = fa.VectorIndex.from_slab(slab2)
+sharded2 = ShardedVectorIndex(GpuShardBackend(index2, device, batched=True), overlap=True, force_collective=True)
+qs2 = [(x[rng.integers(0, n2, nq2)] + 0.2 * rng.standard_normal((nq2, dim))).astype(np.float32) for _ in range(steps2)]
+tqs2 = [torch.from_numpy(a).to(device) for a in qs2]
+fallbacks = []
+outs2 = sharded2.search_steps(lambda i: tqs2[i], 0, steps2, k, keep_all=True,
+                              after_scan=lambda: fallbacks.append(sharded2.backend.last_fallbacks))
+assert len(outs2) == steps2 and min(fallbacks) > 0, fallbacks
+for i, (rows, scores, counts) in enumerate(outs2):
+    want2 = [whole2.search_batch(qs2[i][s0:s0 + 64], k) for s0 in range(0, nq2, 64)]
+    assert np.array_equal(rows.cpu().numpy().astype(np.uint32), np.concatenate([w[0] for w in want2])), f"fallback step {i}: rows differ"
+    assert np.array_equal(bits(scores.cpu().numpy()), bits(np.concatenate([w[1] for w in want2]))), f"fallback step {i}: score bits differ"
 dist.barrier()
 dist.destroy_process_group()
-print("exchange path OK: %d steps over a 1-rank RCCL group equal the unsharded index" % len(outs), flush=True)
+print("exchange path OK: %d steps over a 1-rank RCCL group equal the unsharded index (+ %d steps with %d..%d fallbacks each)"
+      % (len(outs), steps2, min(fallbacks), max(fallbacks)), flush=True)

@@ -52,3 +52,23 @@ def test_product_synthetic_generator_matches_oracle_generator():
     a = random_bert_weights(9, 50, 128, 1, 256)
     b = bert_oracle.random_weights(9, 50, 128, 1, 256)
     assert a.keys() == b.keys() and all(np.array_equal(a[k], b[k]) for k in a)
+
+
+@pytest.mark.parametrize("name", ["tiny", "minilm_shape"])
+def test_c_restatement_matches_numpy_oracle_and_golden(name):
+    """oracle/bert_oracle_c.c (the multi-threaded encoder CPU baseline of bench.py) is the same f32 forward: equal to the numpy
+    oracle within f32 reassociation, equal to the transformers goldens within the oracle's own tolerance, whatever the thread count."""
+    from oracle import bert_oracle
+    g = np.load(GOLD)
+    seed, vocab, hidden, layers, inter = (int(x) for x in g[f"{name}_config"])
+    w = bert_oracle.random_weights(seed, vocab, hidden, layers, inter)
+    batch = load_batch(g) + [[], [101, 102]]
+    want = bert_oracle.embed_forward(w, batch, layers)
+    c = bert_oracle.CForward(w, layers)
+    for threads in (1, 3, 8):
+        got = c.run(batch, threads)
+        assert got.shape == want.shape
+        assert np.max(np.abs(got - want)) < 5e-6, threads
+        assert np.all(got[len(batch) - 2] == 0)
+    gold = g[f"{name}_expected"]
+    assert np.max(np.abs(c.run(load_batch(g), 2) - gold)) < 2e-5
