@@ -36,7 +36,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 matrix-core peak (same guide)
 MFMA_I8_PEAK_TOPS = 5000.0     # v_mfma_i32_16x16x64_i8 issues at twice the f16 rate (the guide's microbenchmark: >= 3944 TOPS)
-PROFILE_ROUND = "r02"   # profiles/<round>/pmc_summary.json: the PMC pass that belongs to this build's kernels
+PROFILE_ROUND = "r03"   # profiles/<round>/pmc_summary.json: the PMC pass that belongs to this build's kernels
 CLUSTERS = 64
 NOISE = 0.30
 
@@ -88,12 +88,14 @@ def measured_copy_gbps(device) -> float:
     return 2.0 * n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def cpu_baseline_and_parity(slab_dev: torch.Tensor, queries: torch.Tensor, k: int, rows_total: int, index_cls):
-    """Oracle (AVX2+F16C restatement, all host cores) on the first `sample` rows; also the parity checker."""
+def cpu_baseline_and_parity(slab_dev: torch.Tensor, queries: torch.Tensor, k: int, rows_total: int, index_cls,
+                            sample_rows: int = 1 << 62):
+    """Oracle (AVX2+F16C restatement, the host cores this container may use) on the SAME slab, one query
+    at a time; also the parity checker: the exact kernels' and the batched path's answers against it, rows and f32 bits."""
     from oracle import oracle
 
     oracle.build()
-    sample = int(min(slab_dev.shape[0], 2_500_000))
+    sample = int(min(slab_dev.shape[0], sample_rows))   # default: the whole slab (7.68 GB of host memory at 10M x 384)
     host = slab_dev[:sample].contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
     cores = os.cpu_count() or 1
     nq = 32
@@ -143,6 +145,12 @@ def cpu_baseline_and_parity(slab_dev: torch.Tensor, queries: torch.Tensor, k: in
         ok &= bool(np.array_equal(g_rows[qi, :len(er)], er) and
                    np.array_equal(g_scores[qi, :len(es)].view(np.uint32), es.view(np.uint32)))
     dt = time.perf_counter() - t0
+    # the batched matrix-core path against the oracle directly (not through the exact kernels): 8 more queries of its batch
+    batched_vs_oracle = True
+    for qi in (32, 33, 63, 64, 100, 127, 128, 159):
+        er, es = oracle.search_top_k(host, q_many[qi], k, nthreads=nthreads)
+        batched_vs_oracle &= bool(np.array_equal(b_rows[qi, :len(er)], er) and
+                                  np.array_equal(b_scores[qi, :len(es)].view(np.uint32), es.view(np.uint32)))
     # one thread (anchor: the reference's published 18.9 GB/s per thread, docs/PERF_LEDGER.md:2149) on a smaller sample
     one_rows = min(sample, 1_500_000)   # 1.15 GB of rows: past the host's last-level cache
     oracle.search_top_k(host[:one_rows], q_host[0], k, nthreads=1)
@@ -164,18 +172,250 @@ def cpu_baseline_and_parity(slab_dev: torch.Tensor, queries: torch.Tensor, k: in
         "unit": "queries/sec",
         "cores": nthreads,
         "kind": "port",
-        "sample": f"{nq} queries x first {sample} rows of the same corpus, one at a time, after 3 warm-up passes; value scaled "
-                  f"by {sample}/{rows_total} to the full corpus; {gbps:.1f} GB/s of f16 on {nthreads} threads "
+        "sample": f"{nq} queries x {'all' if sample == rows_total else 'the first'} {sample} rows of the same corpus, one at a time, "
+                  f"after 3 warm-up passes" + ("" if sample == rows_total else f"; value scaled by {sample}/{rows_total} to the full corpus") +
+                  f"; {gbps:.1f} GB/s of f16 on {nthreads} threads "
                   f"({cores} host cpus visible, cgroup quota {quota if quota is not None else 'none'}; {model})",
         "GBps": gbps,
         "one_thread_GBps": one_gbps,
-        "p50_ms_full_corpus_scaled": float(lat[len(lat) // 2] * 1e3),
-        "p95_ms_full_corpus_scaled": float(lat[min(len(lat) - 1, int(len(lat) * 0.95))] * 1e3),
+        "p50_ms_per_query": float(lat[len(lat) // 2] * 1e3),
+        "p95_ms_per_query": float(lat[min(len(lat) - 1, int(len(lat) * 0.95))] * 1e3),
         "cpu_model": model,
         "host_cpus_visible": cores,
         "corpus_prefix_equals_reference_recipe": prefix_ok,
         "parity_bit_exact": ok,
         "batched_path_equals_exact_path": batched_ok,
+        "batched_path_equals_oracle_8_queries": batched_vs_oracle,
+        "rows_scanned_per_query": sample,
+    }
+
+
+CHUNK = 1_000_000   # the adversarial corpora are generated in fixed 1M-row chunks, each from its own seed
+
+
+def _chunks(lo: int, hi: int):
+    c = lo // CHUNK
+    while c * CHUNK < hi:
+        a, b = max(lo, c * CHUNK), min(hi, (c + 1) * CHUNK)
+        yield c, a - c * CHUNK, b - c * CHUNK, a - lo, b - lo
+        c += 1
+
+
+def gen_uniform_corpus(lo: int, hi: int, dim: int, device) -> torch.Tensor:
+    """SURVEY 8d's adversarial low-separation case: uniform-random unit vectors (seeded per 1M-row chunk), f32 -> f16 RNE.
+    No cluster structure: the k-th best of 10M scores sits ~5 sigma out (0.26 at dim 384) with thousands of rows within a few
+    hundredths below it — the candidate filter's margin has the least to work with."""
+    out = torch.empty((hi - lo, dim), dtype=torch.float16, device=device)
+    for c, a, b, oa, ob in _chunks(lo, hi):
+        g = torch.Generator(device=device)
+        g.manual_seed(0x5EED0000 + c)
+        x = torch.randn((min(CHUNK, max(b, 1)), dim), generator=g, device=device, dtype=torch.float32)[a:b]
+        out[oa:ob] = (x / x.norm(dim=1, keepdim=True)).half()
+    return out
+
+
+OUTLIER_DIMS = (3, 57, 101, 160, 222, 287, 313, 380)
+
+
+def gen_outlier_corpus(lo: int, hi: int, dim: int, device) -> torch.Tensor:
+    """Anisotropic corpus with outlier dimensions, as trained embedding models have: 256 clusters of Zipf sizes (cluster c
+    holds ~1/(c+1) of the rows), noise 0.30, then 8 fixed dimensions scaled x10 before the normalisation — they carry most of
+    every row's norm and stretch the corpus-wide int8 scale, so the other 376 dimensions quantise to a handful of levels."""
+    g0 = torch.Generator(device=device)
+    g0.manual_seed(0x0D1A)
+    cent = torch.randn((256, dim), generator=g0, device=device, dtype=torch.float32)
+    cent /= cent.norm(dim=1, keepdim=True)
+    w = 1.0 / torch.arange(1, 257, device=device, dtype=torch.float64)
+    cdf = torch.cumsum(w / w.sum(), 0).float()
+    scale = torch.ones(dim, device=device)
+    scale[[d for d in OUTLIER_DIMS if d < dim]] = 10.0
+    out = torch.empty((hi - lo, dim), dtype=torch.float16, device=device)
+    for c, a, b, oa, ob in _chunks(lo, hi):
+        g = torch.Generator(device=device)
+        g.manual_seed(0x0D1A0000 + c)
+        n = min(CHUNK, max(b, 1))
+        u = torch.rand((n,), generator=g, device=device)
+        cl = torch.searchsorted(cdf, u).clamp_(max=255)
+        x = cent[cl] + 0.30 * torch.randn((n, dim), generator=g, device=device, dtype=torch.float32)
+        x = (x * scale)[a:b]
+        out[oa:ob] = (x / x.norm(dim=1, keepdim=True)).half()
+    return out
+
+
+def adversarial_queries(kind: str, slab: torch.Tensor, n: int, device) -> torch.Tensor:
+    g = torch.Generator(device=device)
+    g.manual_seed(0xAD7 + len(kind))
+    dim = slab.shape[1]
+    if kind == "uniform":
+        q = torch.randn((n, dim), generator=g, device=device, dtype=torch.float32)
+    else:   # a stored row plus noise: every query has true neighbours inside its cluster
+        pick = torch.randint(0, slab.shape[0], (n,), generator=g, device=device)
+        q = slab[pick].float() + 0.2 / (dim ** 0.5) * torch.randn((n, dim), generator=g, device=device, dtype=torch.float32)
+    return (q / q.norm(dim=1, keepdim=True)).contiguous()
+
+
+def _oracle_threads() -> int:
+    cores = os.cpu_count() or 1
+    try:
+        mx, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if mx != "max":
+            return max(1, min(cores, int(int(mx) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(cores, 16)
+
+
+def adversarial_section(kind: str, rows: int, dim: int, k: int, device, local_rank: int, steps: int = 6):
+    """The batched exact search on a corpus the candidate filter likes least: throughput, how often the int8
+    filter hands queries back, exact fallbacks — and EIGHT of the batched answers at full size against the oracle directly
+    (rows and f32 score bits), plus the rest of a batch against the exact kernels."""
+    import frankensearch_amd as fa
+    from oracle import oracle
+
+    slab = gen_uniform_corpus(0, rows, dim, device) if kind == "uniform" else gen_outlier_corpus(0, rows, dim, device)
+    B = 1024
+    queries = adversarial_queries(kind, slab, 2 * B, device)
+    index = fa.VectorIndex.from_device_slab(slab.data_ptr(), rows, dim, device=local_rank, keepalive=slab)
+    backend_cls = __import__("frankensearch_amd.sharded", fromlist=["GpuShardBackend"]).GpuShardBackend
+    be = backend_cls(index, device, batched=True)
+    fb = 0
+    for i in range(2):
+        be.search_batched(queries[(i % 2) * B:(i % 2) * B + B], k)
+    f0 = index.batched_filter_stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = be.search_batched(queries[(i % 2) * B:(i % 2) * B + B], k)
+        fb += be.last_fallbacks
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    f1 = index.batched_filter_stats()
+    last = ((steps - 1) % 2) * B
+    g_rows, g_scores = out[0].cpu().numpy().astype(np.uint32), out[1].cpu().numpy()
+    # the oracle on the same bytes, 8 queries of the last step at full size
+    host = slab.contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
+    qh = queries[last:last + B].cpu().numpy()
+    nthreads = _oracle_threads()
+    ok = True
+    picks = [0, 1, 2, 3, 511, 512, 1000, 1023]
+    for qi in picks:
+        er, es = oracle.search_top_k(host, qh[qi], k, nthreads=nthreads)
+        ok &= bool(np.array_equal(g_rows[qi, :len(er)], er) and np.array_equal(g_scores[qi, :len(es)].view(np.uint32), es.view(np.uint32)))
+    del host
+    # ... and 64 more against the exact kernels (a different code path over the same slab)
+    e_rows, e_scores, _ = index.search_batch(qh[64:128], k)
+    same = bool(np.array_equal(g_rows[64:128], e_rows) and np.array_equal(g_scores[64:128].view(np.uint32), e_scores.view(np.uint32)))
+    kth = float(np.median(g_scores[:, k - 1]))
+    res = {"corpus": kind, "rows": rows, "queries_per_step": B, "queries_per_sec": steps * B / dt, "ms_per_step": dt / steps * 1e3,
+           "int8_filter_active_after": bool(f1["int8_active"]), "int8_filter_queries": f1["int8_queries"] - f0["int8_queries"],
+           "refiltered_on_f16_queries": f1["refiltered_f16"] - f0["refiltered_f16"], "exact_fallback_queries": fb,
+           "median_kth_score": kth, "batched_equals_oracle_rows_and_bits": ok, "oracle_checked_queries": len(picks),
+           "batched_equals_exact_kernels_64_queries": same}
+    index.close()
+    del slab
+    torch.cuda.empty_cache()
+    return res
+
+
+def exact_scan_roofline(index, queries, k: int, rows: int, dim: int, device):
+    """The north-star's HBM target, timed in THIS run: the exact f16 kernel (scan_topk_kernel, one query per pass over the f16
+    slab, reference operation order) with HIP events on its launch stream; algorithmic bytes = rows x dim x 2 per launch."""
+    from frankensearch_amd.sharded import GpuShardBackend
+    be = GpuShardBackend(index, device, batched=False)
+    for i in range(3):
+        be.search_unsharded(queries[i:i + 1], k)
+    torch.cuda.synchronize()
+    index.scan_stats(reset=True)
+    index.set_profiling(True)
+    n = 30
+    for i in range(n):
+        be.search_unsharded(queries[i:i + 1], k)
+    torch.cuda.synchronize()
+    index.set_profiling(False)
+    ms, launches, srows = index.scan_stats(reset=True)
+    per = ms / max(launches, 1)
+    alg = srows // max(launches, 1) * dim * 2
+    gbps = alg / (per * 1e-3) / 1e9 if per > 0 else 0.0
+    return {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+            "kernel": "scan_topk_kernel<384, 1, 64> (exact f16 scan + wave top-k, one query per pass)", "avg_launch_ms": per,
+            "launches": launches, "algorithmic_bytes_per_launch": alg, "traffic": None,
+            "note": "north_star: >= 0.70 of the HBM roofline on the 10M x 384 f16 cosine scan"}
+
+
+def encoder_section(device, local_rank: int):
+    """Encoders next to their CPU baselines: MiniLM-L6 (random-init weights of that shape) on 256 query-like
+    texts through the C ABI, against the oracle's multi-threaded f32 C restatement of the same forward (kind "port") on a 64-text
+    sample; Model2Vec pooling (potion shape) against the oracle's per-text pool.  Outputs cross-checked in the same run."""
+    import frankensearch_amd as fa
+    from frankensearch_amd.synthetic import random_bert_weights
+    from oracle import bert_oracle, oracle
+
+    w = random_bert_weights(1, 30522, 384, 6, 1536)
+    bert = fa.NativeEmbedder(w, device=local_rank)
+    rng = np.random.default_rng(5)
+    texts = [[101] + rng.integers(1000, 30000, int(rng.integers(6, 31))).tolist() + [102] for _ in range(256)]
+    offs = np.zeros(257, dtype=np.uint32)
+    offs[1:] = np.cumsum([len(t) for t in texts])
+    ids = np.concatenate([np.asarray(t, dtype=np.int32) for t in texts])
+    emb = np.empty((256, 384), dtype=np.float32)
+    for _ in range(3):
+        bert.embed_flat(ids, offs, emb)
+    lat = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        bert.embed_flat(ids, offs, emb)
+        lat.append((time.perf_counter() - t0) * 1e3)
+    gpu_ms = float(np.median(lat))
+    one = []
+    for i in range(24):
+        t0 = time.perf_counter()
+        bert.embed_flat(ids[offs[i]:offs[i + 1]], np.array([0, offs[i + 1] - offs[i]], dtype=np.uint32), emb[:1])
+        one.append((time.perf_counter() - t0) * 1e3)
+    bert.embed_flat(ids, offs, emb)
+    nthreads = _oracle_threads()
+    cpu = bert_oracle.CForward(w, 6)
+    sample = 64
+    cpu.run(texts[:8], nthreads)
+    t0 = time.perf_counter()
+    want = cpu.run(texts[:sample], nthreads)
+    cpu_dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cpu.run(texts[:4], 1)
+    cpu_one = (time.perf_counter() - t0) / 4
+    err = float(np.max(np.abs(emb[:sample] - want)))
+    cos = float(np.min(np.sum(emb[:sample] * want, axis=1)))
+    bert.close()
+    # Model2Vec (potion-multilingual-128M shape: 500,353 x 256 table)
+    table = np.random.default_rng(0).standard_normal((500_353, 256)).astype(np.float32)
+    m2v = fa.Model2VecEmbedder(table, device=local_rank)
+    docs = [rng.integers(0, 500_353, int(rng.integers(4, 33))).astype(np.uint32) for _ in range(256)]
+    moffs = np.zeros(257, dtype=np.uint32)
+    moffs[1:] = np.cumsum([len(d) for d in docs])
+    mids = np.concatenate(docs)
+    mout = np.empty((256, 256), dtype=np.float32)
+    for _ in range(3):
+        m2v.embed_flat(mids, moffs, mout)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        m2v.embed_flat(mids, moffs, mout)
+    m_gpu = (time.perf_counter() - t0) / 20
+    t0 = time.perf_counter()
+    mwant = np.stack([oracle.m2v_embed(table, d) for d in docs])
+    m_cpu = time.perf_counter() - t0
+    m_ok = bool(np.array_equal(mout.view(np.uint32), mwant.view(np.uint32)))
+    m2v.close()
+    return {
+        "minilm_l6": {"texts_per_batch": 256, "tokens_per_batch": int(ids.size), "gpu_ms_per_batch": gpu_ms,
+                      "gpu_texts_per_sec": 256 / (gpu_ms * 1e-3), "gpu_single_text_p50_ms": float(np.median(one)),
+                      "max_abs_err_vs_cpu_f32": err, "min_cosine_vs_cpu_f32": cos,
+                      "cpu_baseline": {"value": sample / cpu_dt, "unit": "texts/sec", "cores": nthreads, "kind": "port",
+                                       "sample": f"{sample} of the same 256 texts, one call, oracle/bert_oracle_c.c (f32, AVX2 FMA, "
+                                                 f"{nthreads} threads over ~128-token blocks); the reference's native backend and its "
+                                                 "ONNX backend cannot be built here",
+                                       "single_text_ms_one_thread": cpu_one * 1e3}},
+        "model2vec": {"texts_per_batch": 256, "gpu_ms_per_batch": m_gpu * 1e3, "gpu_texts_per_sec": 256 / m_gpu, "bit_exact_vs_cpu": m_ok,
+                      "cpu_baseline": {"value": 256 / m_cpu, "unit": "texts/sec", "cores": 1, "kind": "port",
+                                       "sample": "the same 256 texts, one thread, oracle fso_m2v_embed per text"}},
     }
 
 
@@ -199,16 +439,26 @@ def two_tier_section(quality_index, rows: int, k: int, device, local_rank: int):
     # native threads the way a multi-threaded Rust host would drive it (include/fshost.h)
     from frankensearch_amd.host import NativeTwoTierSearcher
     # fast tier through search_top_k_int8_two_pass(query, fetch, 3): the reference's default (two_tier.rs:1318-1337)
-    searcher = NativeTwoTierSearcher(fast_index, quality_index, m2v, bert, doc_id_mode=1, fast_tier_int8_multiplier=3)
+    # (quality_int8_latency: a lone caller's quality-tier search goes through the int8 filter + exact re-score — same hits)
+    searcher = NativeTwoTierSearcher(fast_index, quality_index, m2v, bert, doc_id_mode=1, fast_tier_int8_multiplier=3,
+                                     quality_int8_latency=True)
     seq_plain = searcher.run_load(threads=1, queries=200, warmup_queries=16, k=k, fast_vocab=500_353, corpus_rows=rows)
+    # the reference's phase 2 for an UNATTESTED quality tier — every FSVI v1 pair (sync_searcher.rs:810-818): the fast pool is
+    # re-scored on the quality tier (quality_scores_for_hits: a gather of 3k rows) instead of a second scan
+    rescored = NativeTwoTierSearcher(fast_index, quality_index, m2v, bert, doc_id_mode=1, fast_tier_int8_multiplier=3, quality_pool=1)
+    seq_resc = rescored.run_load(threads=1, queries=200, warmup_queries=16, k=k, fast_vocab=500_353, corpus_rows=rows)
+    rescored_pre = NativeTwoTierSearcher(fast_index, quality_index, m2v, bert, doc_id_mode=1, fast_tier_int8_multiplier=3, quality_pool=1,
+                                         prefetch_quality_embed=True)
+    seq_resc_pre = rescored_pre.run_load(threads=1, queries=200, warmup_queries=16, k=k, fast_vocab=500_353, corpus_rows=rows)
+    rescored_pre.close()
     # a lone caller: the MiniLM embedding of the query starts with the search and overlaps the fast tier's scan
     prefetching = NativeTwoTierSearcher(fast_index, quality_index, m2v, bert, doc_id_mode=1, fast_tier_int8_multiplier=3,
-                                        prefetch_quality_embed=True)
+                                        prefetch_quality_embed=True, quality_int8_latency=True)
     seq = prefetching.run_load(threads=1, queries=200, warmup_queries=16, k=k, fast_vocab=500_353, corpus_rows=rows)
     prefetching.close()
     # ... and so does the quality tier's search (nothing in it depends on phase 0): phase 0 later, phase 1 earlier
     speculative = NativeTwoTierSearcher(fast_index, quality_index, m2v, bert, doc_id_mode=1, fast_tier_int8_multiplier=3,
-                                        prefetch_quality_embed=2)
+                                        prefetch_quality_embed=2, quality_int8_latency=True)
     seq_spec = speculative.run_load(threads=1, queries=200, warmup_queries=16, k=k, fast_vocab=500_353, corpus_rows=rows)
     speculative.close()
     # concurrent callers, coalesced inside the library into batched launches (fsgpu_*_set_coalescing)
@@ -236,6 +486,7 @@ def two_tier_section(quality_index, rows: int, k: int, device, local_rank: int):
             "mean_queries_per_scan_batch": {"fast": (fr - fr0) / max(fb - fb0, 1), "quality": (qr - qr0) / max(qb - qb0, 1)},
         }
 
+    rescored.close()
     con_lo = concurrent(64, 20_000)
     con = concurrent(256, 40_000)
     con_hi = concurrent(1024, 80_000)
@@ -251,6 +502,11 @@ def two_tier_section(quality_index, rows: int, k: int, device, local_rank: int):
                                                     "queries_per_sec": seq_spec.queries_per_sec},
         "sequential_without_quality_embed_prefetch": {"phase0_p50_ms": seq_plain.phase0_p50_ms,
                                                       "phase1_p50_ms": seq_plain.phase1_p50_ms},
+        "rescored_fast_pool": {"phase0_p50_ms": seq_resc.phase0_p50_ms, "phase1_p50_ms": seq_resc.phase1_p50_ms,
+                               "queries_per_sec": seq_resc.queries_per_sec, "mean_quality_rescore_ms": seq_resc.mean_quality_search_ms,
+                               "phase1_p50_ms_with_quality_embed_prefetch": seq_resc_pre.phase1_p50_ms,
+                               "note": "SyncQualityPool::RescoredFastPool (unattested / FSVI v1 pairs): quality_scores_for_hits "
+                                       "gathers the fast pool's rows on the quality tier, blend_two_tier_aligned"},
         "sequential_breakdown_ms": {"fast_embed": seq.mean_fast_embed_ms, "fast_search": seq.mean_fast_search_ms,
                                     "quality_embed": seq.mean_quality_embed_ms, "quality_search": seq.mean_quality_search_ms,
                                     "fusion": seq.mean_fusion_ms},
@@ -478,6 +734,8 @@ def main() -> None:
     ap.add_argument("--batched", action="store_true", help="(default) the matrix-core batched path; kept for old command lines")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-two-tier", action="store_true")
+    ap.add_argument("--no-adversarial", action="store_true", help="skip the uniform-random / outlier-dimension corpus sections")
+    ap.add_argument("--no-encoders", action="store_true", help="skip the encoder section (GPU vs CPU baseline)")
     ap.add_argument("--config5", action="store_true",
                     help="also time BASELINE config 5 (batch-256 on-GPU MiniLM encoding + scan) on this rank's rows; "
                          "quoted for --rows 50000000")
@@ -726,8 +984,16 @@ def main() -> None:
             line["p50_latency_ms_single_query"] = lat[len(lat) // 2]
         # the CPU baseline runs before the thousand-thread load test below: after it the container's CPU quota throttles the
         # oracle's workers for a while (measured: 120-150 GB/s instead of ~290 GB/s on the same 16 threads)
+        if world == 1 and args.batched and not args.exact:
+            # the north-star's HBM target in the same run: the exact f16 kernel, one query per pass over the f16 slab
+            line["roofline"]["exact_f16_scan"] = exact_scan_roofline(index, queries, k, hi - lo, args.dim, device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_and_parity(slab, queries, k, args.rows, fa.VectorIndex)
+        if world == 1 and not args.no_adversarial and args.rows >= 1_000_000 and args.batched:
+            line["adversarial_corpora"] = {kind: adversarial_section(kind, args.rows, args.dim, k, device, local_rank)
+                                           for kind in ("uniform", "outlier")}
+        if world == 1 and not args.no_encoders:
+            line["encoders"] = encoder_section(device, local_rank)
         if world == 1 and args.config5:
             line["config5"] = config5_section(index, args.rows, k, local_rank)
         if world == 1 and not args.no_two_tier:
@@ -739,10 +1005,17 @@ def main() -> None:
             # a lone caller whose host overlaps the quality tier's embedding AND search with phase 0 (fshost_two_tier_config::
             # prefetch_quality_embed = 2: same results, both scans share the GPU); the same caller with only the embedding
             # overlapped, or nothing, is in two_tier.phase1_p50_ms / sequential_without_quality_embed_prefetch
+            # headline: the reference-shaped flow — phase 2 starts when phase 1 has been delivered (searcher.rs:1111,2111); the
+            # lone caller whose host overlaps the quality tier's embedding (and search) with phase 0 is a sub-field
+            plain = tt["sequential_without_quality_embed_prefetch"]
             spec = tt["sequential_with_quality_search_prefetch"]
-            line["p50_phase1_latency_ms"] = spec["phase1_p50_ms"]
-            line["p50_phase0_latency_ms"] = spec["phase0_p50_ms"]
-            line["p50_phase1_latency_policy"] = "quality-tier embedding and search started with the query (prefetch_quality_embed = 2)"
+            line["p50_phase1_latency_ms"] = plain["phase1_p50_ms"]
+            line["p50_phase0_latency_ms"] = plain["phase0_p50_ms"]
+            line["p50_phase1_latency_policy"] = "reference order: quality-tier embedding and search start after the phase-0 delivery"
+            line["p50_phase1_latency_speculative_ms"] = {"quality_embed_prefetched": tt["phase1_p50_ms"],
+                                                         "quality_embed_and_search_prefetched": spec["phase1_p50_ms"]}
+            # the reference's flow for FSVI v1 pairs (unattested quality tier): phase 2 re-scores the fast pool (a gather)
+            line["p50_phase1_latency_rescored_fast_pool_ms"] = tt["rescored_fast_pool"]["phase1_p50_ms"]
             line["end_to_end_queries_per_sec"] = tt["concurrent_1024_threads"]["queries_per_sec"]
     if world > 1:
         dist.barrier()

@@ -77,6 +77,18 @@ SIGNATURES = {
     "fsgpu_sharded_set_hreduce": (_i32, [_vp, _i32]),
     "fsgpu_sharded_search_topk": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "fsgpu_sharded_search_topk_batched": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, C.POINTER(_u32)]),
+    "fsgpu_sharded_search": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "fsgpu_sharded_search_begin": (_i32, [_vp, _vp, C.POINTER(_u64)]),
+    "fsgpu_sharded_search_end": (_i32, [_vp, _u64, _vp, _vp, _vp, _vp]),
+    "fsgpu_sharded_quant_scale_max": (C.c_float, [_vp]),
+    "fsgpu_sharded_open_fsvi": (_i32, [C.c_char_p, _vp, _u32, _i32, C.POINTER(_vp)]),
+    "fsgpu_sharded_set_live_bitmap": (_i32, [_vp, _vp]),
+    "fsgpu_sharded_soft_delete": (_i32, [_vp, C.c_char_p, _u32, C.POINTER(_i32)]),
+    "fsgpu_sharded_wal_append": (_i32, [_vp, C.c_char_p, _u32, _vp, _u32]),
+    "fsgpu_sharded_wal_record_count": (_u64, [_vp]),
+    "fsgpu_sharded_doc_id": (_i32, [_vp, _u32, C.POINTER(_vp), C.POINTER(_u32)]),
+    "fsgpu_sharded_search_hits": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),
+    "fsgpu_sharded_gather_dot": (_i32, [_vp, _vp, _u32, _vp, _u32, _vp]),
     "fsgpu_search_topk_classified": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, C.POINTER(_u32), C.POINTER(_i32)]),
     "fsgpu_search_topk_int8_two_pass": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),
     "fsgpu_search_hits": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),
@@ -93,6 +105,13 @@ SIGNATURES = {
     "fsgpu_rrf_fuse": (_i32, [_vp, _u32, _vp, _u32, C.c_double, C.c_double, C.c_double, _i32, _u32, _u32, _vp,
                               C.POINTER(_u32)]),
     "fsgpu_blend_two_tier": (_i32, [_vp, _u32, _vp, _u32, C.c_float, _vp, C.POINTER(_u32)]),
+    "fsgpu_blend_two_tier_aligned": (_i32, [_vp, _u32, _vp, _vp, C.c_float, _vp, C.POINTER(_u32)]),
+    "fsgpu_alignment_create": (_i32, [_vp, _vp, C.POINTER(_vp)]),
+    "fsgpu_alignment_destroy": (None, [_vp]),
+    "fsgpu_alignment_kind": (_i32, [_vp]),
+    "fsgpu_alignment_quality_row": (C.c_int64, [_vp, _u64]),
+    "fsgpu_alignment_unmatched_quality_docs": (_u64, [_vp]),
+    "fsgpu_quality_scores_for_hits": (_i32, [_vp, _vp, _vp, _vp, _u32, _vp, _u32, _vp, _vp]),
     "fsgpu_index_set_after_enqueue_hook": (_i32, [_vp, _vp, _vp]),
     "fsgpu_index_set_profiling": (_i32, [_vp, _i32]),
     "fsgpu_index_scan_time": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(_u64), _i32]),

@@ -17,6 +17,7 @@
 #include "coalescer.hpp"
 #include "sharded_index.hpp"
 #include "vector_index.hpp"
+#include "two_tier_index.hpp"
 
 // One in-flight single-item call, parked in a Coalescer until a leader serves it (coalescer.hpp).
 struct CoalescedCall : fsgpu::CoalescedRequest {
@@ -52,6 +53,9 @@ struct fsgpu_index {
     // leader-only staging (guarded by impl.mutex())
     std::vector<float> co_queries, co_scores;
     std::vector<uint32_t> co_rows, co_counts;
+};
+struct fsgpu_alignment {
+    fsgpu::QualityAlignment impl;
 };
 struct fsgpu_sharded {
     fsgpu::ShardedIndex impl;
@@ -546,15 +550,59 @@ fsgpu_status fsgpu_sharded_set_hreduce(fsgpu_sharded* idx, int32_t mode) {
     return FSGPU_OK;
 }
 
+static fsgpu::ShardedIndex::Request sharded_request(const fsgpu_sharded_request* rq) {
+    fsgpu::ShardedIndex::Request r;
+    r.queries = rq->queries;
+    r.nq = rq->nq;
+    r.k = rq->k;
+    r.mode = static_cast<fsgpu::ShardedIndex::Mode>(rq->mode);
+    r.multiplier = rq->candidate_multiplier;
+    r.allow = rq->allow_bitmap;
+    return r;
+}
+
+static fsgpu_status check_sharded_request(const fsgpu_sharded* idx, const fsgpu_sharded_request* rq) {
+    if (!idx || !rq) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    if (rq->nq && !rq->queries) return fail(FSGPU_ERR_NULL_ARGUMENT, "queries is null");
+    if (rq->mode < FSGPU_SHARDED_EXACT || rq->mode > FSGPU_SHARDED_4BIT_TWO_PASS) return fail(FSGPU_ERR_INVALID_CONFIG, "unknown search mode");
+    return FSGPU_OK;
+}
+
+fsgpu_status fsgpu_sharded_search(fsgpu_sharded* idx, const fsgpu_sharded_request* request, uint32_t* out_rows, float* out_scores,
+                                  uint32_t* out_counts, uint32_t* out_fallbacks) {
+    const fsgpu_status c = check_sharded_request(idx, request);
+    if (c != FSGPU_OK) return c;
+    if (request->nq && (!out_counts || (request->k && (!out_rows || !out_scores)))) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.search(sharded_request(request), request->query_len, out_rows, out_scores, out_counts, out_fallbacks));
+    });
+}
+
+fsgpu_status fsgpu_sharded_search_begin(fsgpu_sharded* idx, const fsgpu_sharded_request* request, uint64_t* out_ticket) {
+    const fsgpu_status c = check_sharded_request(idx, request);
+    if (c != FSGPU_OK) return c;
+    if (!out_ticket) return fail(FSGPU_ERR_NULL_ARGUMENT, "ticket is null");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.begin(sharded_request(request), request->query_len, out_ticket));
+    });
+}
+
+fsgpu_status fsgpu_sharded_search_end(fsgpu_sharded* idx, uint64_t ticket, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
+                                      uint32_t* out_fallbacks) {
+    if (!idx || !out_counts) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.end(ticket, out_rows, out_scores, out_counts, out_fallbacks));
+    });
+}
+
 static fsgpu_status sharded_search(fsgpu_sharded* idx, const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
                                    bool batched, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
                                    uint32_t* out_fallbacks) {
-    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
-    if (nq && (!queries || !out_counts || (k && (!out_rows || !out_scores)))) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
-    return guarded([&]() -> fsgpu_status {
-        std::lock_guard<std::mutex> lock(idx->impl.mutex());
-        return finish(idx->impl.search(queries, nq, query_len, k, batched, out_rows, out_scores, out_counts, out_fallbacks));
-    });
+    fsgpu_sharded_request rq{queries, nq, query_len, k, batched ? FSGPU_SHARDED_BATCHED : FSGPU_SHARDED_EXACT, 0, nullptr};
+    return fsgpu_sharded_search(idx, &rq, out_rows, out_scores, out_counts, out_fallbacks);
 }
 
 fsgpu_status fsgpu_sharded_search_topk(fsgpu_sharded* idx, const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
@@ -566,6 +614,77 @@ fsgpu_status fsgpu_sharded_search_topk_batched(fsgpu_sharded* idx, const float* 
                                                uint32_t k, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
                                                uint32_t* out_fallbacks) {
     return sharded_search(idx, queries, nq, query_len, k, true, out_rows, out_scores, out_counts, out_fallbacks);
+}
+
+float fsgpu_sharded_quant_scale_max(const fsgpu_sharded* idx) { return idx ? idx->impl.quant_scale_max() : 0.0f; }
+
+fsgpu_status fsgpu_sharded_open_fsvi(const char* path, const int32_t* devices, uint32_t ndev, int32_t exchange, fsgpu_sharded** out) {
+    if (!out || !path || !devices) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(FSGPU_ERR_NO_DEVICE, "no HIP device visible (libfsgpu has no CPU fallback)");
+    return guarded([&]() -> fsgpu_status {
+        auto* h = new fsgpu_sharded();
+        fsgpu::SearchError e = h->impl.open_fsvi(path, devices, ndev, exchange);
+        if (!e.ok()) {
+            delete h;
+            return finish(e);
+        }
+        *out = h;
+        return FSGPU_OK;
+    });
+}
+
+fsgpu_status fsgpu_sharded_set_live_bitmap(fsgpu_sharded* idx, const uint64_t* live_bitmap) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.set_live_bitmap(live_bitmap));
+    });
+}
+
+fsgpu_status fsgpu_sharded_soft_delete(fsgpu_sharded* idx, const char* doc_id, uint32_t doc_id_len, int32_t* out_deleted) {
+    if (!idx || !out_deleted || (doc_id_len && !doc_id)) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.soft_delete(doc_id, doc_id_len, out_deleted));
+    });
+}
+
+fsgpu_status fsgpu_sharded_wal_append(fsgpu_sharded* idx, const char* doc_id, uint32_t doc_id_len, const float* vector,
+                                      uint32_t vector_len) {
+    if (!idx || !vector || (doc_id_len && !doc_id)) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.wal_append(doc_id, doc_id_len, vector, vector_len));
+    });
+}
+
+uint64_t fsgpu_sharded_wal_record_count(const fsgpu_sharded* idx) { return idx ? idx->impl.wal_record_count() : 0; }
+
+fsgpu_status fsgpu_sharded_doc_id(const fsgpu_sharded* idx, uint32_t row, const char** out_ptr, uint32_t* out_len) {
+    if (!idx || !out_ptr || !out_len) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return finish(idx->impl.doc_id_at(row, out_ptr, out_len));
+}
+
+fsgpu_status fsgpu_sharded_search_hits(fsgpu_sharded* idx, const float* query, uint32_t query_len, uint32_t k, uint32_t* out_rows,
+                                       float* out_scores, uint32_t* out_count) {
+    if (!idx || !query || !out_count || (k && (!out_rows || !out_scores))) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.search_hits(query, query_len, k, out_rows, out_scores, out_count));
+    });
+}
+
+fsgpu_status fsgpu_sharded_gather_dot(fsgpu_sharded* idx, const float* query, uint32_t query_len, const uint32_t* rows, uint32_t n,
+                                      float* out_scores) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    if (n && (!query || !rows || !out_scores)) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.gather_dot(query, query_len, rows, n, out_scores));
+    });
 }
 
 fsgpu_status fsgpu_search_topk_classified(fsgpu_index* idx, const float* query, uint32_t query_len, uint32_t k,
@@ -732,6 +851,41 @@ fsgpu_status fsgpu_gather_dot(fsgpu_index* idx, const float* query, uint32_t que
     return guarded([&]() -> fsgpu_status {
         std::lock_guard<std::mutex> lock(idx->impl.mutex());
         return finish(idx->impl.gather_dot(query, query_len, rows, n, out_scores));
+    });
+}
+
+fsgpu_status fsgpu_alignment_create(fsgpu_index* fast, fsgpu_index* quality, fsgpu_alignment** out) {
+    if (!fast || !quality || !out) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    *out = nullptr;
+    return guarded([&]() -> fsgpu_status {
+        auto a = std::make_unique<fsgpu_alignment>();
+        std::shared_lock<std::shared_mutex> lf(fast->state_mu);
+        std::shared_lock<std::shared_mutex> lq(quality->state_mu, std::defer_lock);
+        if (quality != fast) lq.lock();
+        const fsgpu_status st = finish(a->impl.build(fast->impl, quality->impl));
+        if (st == FSGPU_OK) *out = a.release();
+        return st;
+    });
+}
+
+void fsgpu_alignment_destroy(fsgpu_alignment* a) { delete a; }
+int32_t fsgpu_alignment_kind(const fsgpu_alignment* a) { return a ? (int32_t)a->impl.kind() : FSGPU_ALIGNMENT_NONE; }
+int64_t fsgpu_alignment_quality_row(const fsgpu_alignment* a, uint64_t fast_row) { return a ? a->impl.quality_row(fast_row) : -1; }
+uint64_t fsgpu_alignment_unmatched_quality_docs(const fsgpu_alignment* a) { return a ? a->impl.unmatched_quality_docs() : 0; }
+
+fsgpu_status fsgpu_quality_scores_for_hits(fsgpu_index* fast, fsgpu_index* quality, const fsgpu_alignment* alignment,
+                                           const float* query, uint32_t query_len, const fsgpu_scored_doc* hits, uint32_t n,
+                                           float* out_scores, uint8_t* out_present) {
+    if (!fast || !quality || !alignment) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    if (n && (!query || !hits || !out_scores || !out_present)) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::vector<fsgpu::HitRef> refs(n);
+        for (uint32_t i = 0; i < n; ++i) refs[i] = fsgpu::HitRef{hits[i].doc_id, hits[i].doc_id_len, hits[i].index};
+        std::shared_lock<std::shared_mutex> lf(fast->state_mu);
+        std::shared_lock<std::shared_mutex> lq(quality->state_mu, std::defer_lock);
+        if (quality != fast) lq.lock();
+        return finish(fsgpu::quality_scores_for_hits(fast->impl, quality->impl, alignment->impl, query, query_len, refs.data(), n,
+                                                     out_scores, out_present));
     });
 }
 

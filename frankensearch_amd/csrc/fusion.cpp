@@ -236,3 +236,79 @@ extern "C" fsgpu_status fsgpu_blend_two_tier(const fsgpu_scored_doc* fast, uint3
     *out_count = (uint32_t)blended.size();
     return FSGPU_OK;
 }
+
+// blend_two_tier_aligned (blend.rs:213-294): the same normalisation, merge and order as fsgpu_blend_two_tier with the quality tier
+// given as per-position optional scores of the fast hits themselves.
+extern "C" fsgpu_status fsgpu_blend_two_tier_aligned(const fsgpu_scored_doc* fast, uint32_t n_fast, const float* quality_scores,
+                                                      const uint8_t* quality_present, float blend_factor, fsgpu_scored_doc* out,
+                                                      uint32_t* out_count) {
+    if (!out_count || (n_fast && (!fast || !out || !quality_scores || !quality_present))) return FSGPU_ERR_NULL_ARGUMENT;
+    *out_count = 0;
+    const float alpha = std::isfinite(blend_factor) ? std::min(std::max(blend_factor, 0.0f), 1.0f) : 0.7f;
+    struct Bounds {
+        float min = std::numeric_limits<float>::infinity(), max = -std::numeric_limits<float>::infinity(), range = 0.f;
+        bool saw = false;
+        void add(float v) {
+            if (std::isfinite(v)) {
+                min = std::min(min, v);
+                max = std::max(max, v);
+                saw = true;
+            }
+        }
+        float apply(float s) const {
+            if (!saw || !std::isfinite(s)) return 0.0f;
+            const float v = range > 1.1920929e-7f ? (s - min) / range : 1.0f;
+            return std::min(std::max(v, 0.0f), 1.0f);
+        }
+    } fb, qb;
+    for (uint32_t i = 0; i < n_fast; ++i) {
+        fb.add(fast[i].score);
+        if (quality_present[i]) qb.add(quality_scores[i]);
+    }
+    fb.range = fb.max - fb.min;
+    qb.range = qb.max - qb.min;
+    struct Pair {
+        std::string_view doc;
+        float fast = 0.f, quality = 0.f;
+        bool has_fast = false, has_quality = false;
+        uint32_t index = 0;
+    };
+    std::unordered_map<std::string_view, size_t> slot;
+    std::vector<Pair> merged;
+    merged.reserve((size_t)n_fast * 13 / 10 + 1);
+    for (uint32_t i = 0; i < n_fast; ++i) {
+        auto it = slot.find(sv(fast[i]));
+        if (it == slot.end()) {
+            Pair p;
+            p.doc = sv(fast[i]);
+            p.index = fast[i].index;
+            it = slot.emplace(p.doc, merged.size()).first;
+            merged.push_back(p);
+        }
+        Pair& p = merged[it->second];
+        if (!p.has_fast) {   // best-first input: the first (best) score and its index
+            p.fast = fb.apply(fast[i].score);
+            p.has_fast = true;
+            p.index = fast[i].index;
+        }
+        if (quality_present[i] && !p.has_quality) {
+            p.quality = qb.apply(quality_scores[i]);
+            p.has_quality = true;
+        }
+    }
+    std::vector<fsgpu_scored_doc> blended(merged.size());
+    for (size_t i = 0; i < merged.size(); ++i) {
+        const Pair& p = merged[i];
+        float score = p.has_quality ? std::fmaf(alpha, p.quality, (1.0f - alpha) * p.fast) : p.fast;
+        if (!std::isfinite(score)) score = 0.0f;
+        blended[i] = fsgpu_scored_doc{p.doc.data(), (uint32_t)p.doc.size(), score, p.index};
+    }
+    std::sort(blended.begin(), blended.end(), [](const fsgpu_scored_doc& a, const fsgpu_scored_doc& b) {
+        const int32_t x = total_key32(a.score), y = total_key32(b.score);
+        if (x != y) return x > y;
+        return std::string_view(a.doc_id, a.doc_id_len) < std::string_view(b.doc_id, b.doc_id_len);
+    });
+    std::copy(blended.begin(), blended.end(), out);
+    *out_count = (uint32_t)blended.size();
+    return FSGPU_OK;
+}

@@ -11,6 +11,7 @@ fsgpu_status run_load(const SyncTwoTierSearcher& searcher, const fshost_load_con
 
 struct fshost_two_tier {
     fshost::SyncTwoTierSearcher impl;
+    fshost_two_tier(fsgpu_index* f, fsgpu_index* q, fsgpu_m2v* m, fsgpu_bert* b, const fshost_two_tier_config& c) : impl(f, q, m, b, c) {}
 };
 
 extern "C" {
@@ -20,7 +21,13 @@ fsgpu_status fshost_two_tier_create(fsgpu_index* fast_index, fsgpu_index* qualit
                                     fshost_two_tier** out) {
     if (!fast_index || !quality_index || !fast_embedder || !quality_embedder || !config || !out) return FSGPU_ERR_NULL_ARGUMENT;
     try {
-        *out = new fshost_two_tier{fshost::SyncTwoTierSearcher(fast_index, quality_index, fast_embedder, quality_embedder, *config)};
+        auto* s = new fshost_two_tier(fast_index, quality_index, fast_embedder, quality_embedder, *config);
+        if (s->impl.init_status() != FSGPU_OK) {   // the alignment of a re-scored pair / the int8 latency switch failed
+            const fsgpu_status st = s->impl.init_status();
+            delete s;
+            return st;
+        }
+        *out = s;
     } catch (const std::exception&) {
         return FSGPU_ERR_DEVICE;
     }

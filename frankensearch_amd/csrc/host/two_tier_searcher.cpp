@@ -52,9 +52,22 @@ SyncTwoTierSearcher::SyncTwoTierSearcher(fsgpu_index* fast, fsgpu_index* quality
     : fast_(fast), quality_(quality), m2v_(fast_embedder), bert_(quality_embedder), cfg_(cfg) {
     fast_dim_ = fsgpu_index_dimension(fast_);
     quality_dim_ = fsgpu_index_dimension(quality_);
-    // the quality tier's exact search is phase 1's longest leg (one HBM pass over the f16 slab): a lone caller's query goes
-    // through the int8 filter + exact re-score instead — the same hits from half the bytes (fsgpu.h)
-    (void)fsgpu_index_set_int8_latency(quality_, 1);
+    // opt-in: the quality tier's exact search is phase 1's longest leg (one HBM pass over the f16 slab); with the int8 latency
+    // path a lone caller's query goes through the int8 filter + exact re-score instead — the same hits from half the bytes.
+    // It is a setting of the CALLER's handle (and costs it an int8 copy of the slab): switched off again in the destructor.
+    if (cfg_.quality_int8_latency && cfg_.quality_pool == FSHOST_POOL_RETRIEVED) {
+        init_status_ = fsgpu_index_set_int8_latency(quality_, 1);
+        if (init_status_ != FSGPU_OK) init_detail_ = fsgpu_last_error();
+    }
+    if (init_status_ == FSGPU_OK && cfg_.quality_pool == FSHOST_POOL_RESCORED) {
+        init_status_ = fsgpu_alignment_create(fast_, quality_, &alignment_);   // two_tier.rs:750-866, once per pair
+        if (init_status_ != FSGPU_OK) init_detail_ = fsgpu_last_error();
+    }
+}
+
+SyncTwoTierSearcher::~SyncTwoTierSearcher() {
+    if (alignment_) fsgpu_alignment_destroy(alignment_);
+    if (cfg_.quality_int8_latency && cfg_.quality_pool == FSHOST_POOL_RETRIEVED) (void)fsgpu_index_set_int8_latency(quality_, 0);
 }
 
 // VectorIndex::search_top_k -> Vec<VectorHit> with doc ids resolved (search.rs:192-206, 1503-1558).
@@ -106,6 +119,10 @@ fsgpu_status SyncTwoTierSearcher::search(const uint32_t* fast_ids, uint32_t n_fa
                                          uint32_t n_quality, uint32_t k, const fsgpu_scored_doc* lexical, uint32_t n_lexical,
                                          Outcome* out, std::string* detail) const {
     using clock = std::chrono::steady_clock;
+    if (init_status_ != FSGPU_OK) {
+        *detail = init_detail_;
+        return init_status_;
+    }
     const uint32_t mult = std::max<uint32_t>(cfg_.candidate_multiplier, 1);
     // candidate_count (rrf.rs:113-115): limit.saturating_mul(multiplier).max(limit)
     const uint64_t wide_fetch = (uint64_t)k * mult;
@@ -135,7 +152,8 @@ fsgpu_status SyncTwoTierSearcher::search(const uint32_t* fast_ids, uint32_t n_fa
         return s;
     };
     std::future<fsgpu_status> quality_future;  // declared after what the task touches: joined first on every return path
-    if (cfg_.prefetch_quality_embed >= 2) quality_future = std::async(std::launch::async, embed_and_search_quality);
+    const bool rescored = cfg_.quality_pool == FSHOST_POOL_RESCORED;   // (its quality scores need phase 0's hits: only the embedding can run ahead)
+    if (cfg_.prefetch_quality_embed >= 2 && !rescored) quality_future = std::async(std::launch::async, embed_and_search_quality);
     else if (cfg_.prefetch_quality_embed) quality_future = std::async(std::launch::async, embed_quality);
     // ---- phase 0 / Initial ----
     std::vector<float> fast_vec(fast_dim_);
@@ -172,6 +190,39 @@ fsgpu_status SyncTwoTierSearcher::search(const uint32_t* fast_ids, uint32_t n_fa
     }
     m.quality_embed_ms = ms_since(t3);
     const auto t4 = clock::now();
+    std::vector<fsgpu_scored_doc> blended(fast_view.size() + (size_t)fetch + 1);
+    uint32_t nb = 0;
+    if (rescored) {
+        // SyncQualityPool::RescoredFastPool (sync_searcher.rs:814-818): quality_scores_for_hits over the fast pool, then the
+        // aligned blend (:862-866)
+        std::vector<float> qscores(fast_view.size() + 1);
+        std::vector<uint8_t> qpresent(fast_view.size() + 1);
+        st = fsgpu_quality_scores_for_hits(fast_, quality_, alignment_, quality_vec.data(), quality_dim_, fast_view.data(),
+                                           (uint32_t)fast_view.size(), qscores.data(), qpresent.data());
+        if (st != FSGPU_OK) {
+            *detail = fsgpu_last_error();
+            return st;
+        }
+        m.quality_search_ms = ms_since(t4);
+        const auto t5r = clock::now();
+        st = fsgpu_blend_two_tier_aligned(fast_view.data(), (uint32_t)fast_view.size(), qscores.data(), qpresent.data(),
+                                          cfg_.quality_weight, blended.data(), &nb);
+        if (st != FSGPU_OK) {
+            *detail = fsgpu_last_error();
+            return st;
+        }
+        m.blend_ms = ms_since(t5r);
+        st = fsgpu_rrf_fuse(lexical, n_lexical, blended.data(), nb, cfg_.rrf_k, 1.0, 1.0, FSGPU_RRF_TIEBREAK_LEXICAL_THEN_ID, k, 0,
+                            fused.data(), &n);
+        if (st != FSGPU_OK) {
+            *detail = fsgpu_last_error();
+            return st;
+        }
+        st = copy_out(fused, n, &out->final_results, detail);
+        if (st != FSGPU_OK) return st;
+        m.phase2_total_ms = ms_since(t3);
+        return FSGPU_OK;
+    }
     if (!quality_searched) {
         st = tier_hits(quality_, quality_vec, fetch, 0, &quality_hits, detail);
         if (st != FSGPU_OK) return st;
@@ -179,8 +230,7 @@ fsgpu_status SyncTwoTierSearcher::search(const uint32_t* fast_ids, uint32_t n_fa
     m.quality_search_ms = ms_since(t4);
     const auto t5 = clock::now();
     const std::vector<fsgpu_scored_doc> quality_view = view(quality_hits);
-    std::vector<fsgpu_scored_doc> blended(fast_view.size() + quality_view.size() + 1);
-    uint32_t nb = 0;
+    blended.resize(fast_view.size() + quality_view.size() + 1);
     st = fsgpu_blend_two_tier(fast_view.data(), (uint32_t)fast_view.size(), quality_view.data(), (uint32_t)quality_view.size(),
                               cfg_.quality_weight, blended.data(), &nb);
     if (st != FSGPU_OK) {

@@ -25,6 +25,11 @@ class SyncTwoTierSearcher {
   public:
     SyncTwoTierSearcher(fsgpu_index* fast, fsgpu_index* quality, fsgpu_m2v* fast_embedder, fsgpu_bert* quality_embedder,
                         const fshost_two_tier_config& cfg);
+    ~SyncTwoTierSearcher();
+    SyncTwoTierSearcher(const SyncTwoTierSearcher&) = delete;
+    SyncTwoTierSearcher& operator=(const SyncTwoTierSearcher&) = delete;
+    fsgpu_status init_status() const { return init_status_; }
+    const std::string& init_detail() const { return init_detail_; }
     // Returns an fsgpu status; `detail` is filled on failure.
     fsgpu_status search(const uint32_t* fast_ids, uint32_t n_fast, const int32_t* quality_ids, uint32_t n_quality, uint32_t k,
                         const fsgpu_scored_doc* lexical, uint32_t n_lexical, Outcome* out, std::string* detail) const;
@@ -38,6 +43,9 @@ class SyncTwoTierSearcher {
     fsgpu_bert* bert_;
     fshost_two_tier_config cfg_;
     uint32_t fast_dim_, quality_dim_;
+    fsgpu_alignment* alignment_ = nullptr;   // quality_pool == FSHOST_POOL_RESCORED: QualityAlignment of the pair, computed once
+    fsgpu_status init_status_ = FSGPU_OK;
+    std::string init_detail_;
 };
 
 }  // namespace fshost

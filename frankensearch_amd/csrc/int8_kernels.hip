@@ -360,13 +360,23 @@ __global__ void pack_hits_kernel(const uint32_t* __restrict__ rows, const float*
 
 // ---- launchers ----------------------------------------------------------------------------------------------
 
-hipError_t launch_quantize_slab_i8(const void* slab_f16, size_t n_values, unsigned int* max_bits_dev, void* out_i8,
-                                   hipStream_t stream) {
+// One corpus-wide max-abs (simd.rs:1865-1886) into max_bits_dev (f32 bits).  A sharded index reduces the shards' values to the
+// corpus-wide one (ncclAllReduce(max)) and then quantises with max_ready = true.
+hipError_t launch_slab_maxabs(const void* slab_f16, size_t n_values, unsigned int* max_bits_dev, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(max_bits_dev, 0, 4, stream);
     if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(slab_maxabs_kernel, dim3(2048), dim3(256), 0, stream, static_cast<const unsigned short*>(slab_f16), n_values,
+                       max_bits_dev);
+    return hipGetLastError();
+}
+
+hipError_t launch_quantize_slab_i8(const void* slab_f16, size_t n_values, unsigned int* max_bits_dev, void* out_i8,
+                                   hipStream_t stream, bool max_ready) {
     const int grid = 2048;
-    hipLaunchKernelGGL(slab_maxabs_kernel, dim3(grid), dim3(256), 0, stream, static_cast<const unsigned short*>(slab_f16),
-                       n_values, max_bits_dev);
+    if (!max_ready) {
+        hipError_t e = launch_slab_maxabs(slab_f16, n_values, max_bits_dev, stream);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(quantize_slab_i8_kernel, dim3(grid), dim3(256), 0, stream,
                        static_cast<const unsigned short*>(slab_f16), n_values, max_bits_dev,
                        static_cast<signed char*>(out_i8));
@@ -374,12 +384,12 @@ hipError_t launch_quantize_slab_i8(const void* slab_f16, size_t n_values, unsign
 }
 
 hipError_t launch_quantize_slab_4bit_levels(const void* slab_f16, size_t n_values, unsigned int* max_bits_dev, void* out_i8,
-                                            hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(max_bits_dev, 0, 4, stream);
-    if (e != hipSuccess) return e;
+                                            hipStream_t stream, bool max_ready) {
     const int grid = 2048;
-    hipLaunchKernelGGL(slab_maxabs_kernel, dim3(grid), dim3(256), 0, stream, static_cast<const unsigned short*>(slab_f16),
-                       n_values, max_bits_dev);
+    if (!max_ready) {
+        hipError_t e = launch_slab_maxabs(slab_f16, n_values, max_bits_dev, stream);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(quantize_slab_4bit_levels_kernel, dim3(grid), dim3(256), 0, stream,
                        static_cast<const unsigned short*>(slab_f16), n_values, max_bits_dev, static_cast<signed char*>(out_i8));
     return hipGetLastError();
@@ -395,12 +405,12 @@ hipError_t launch_i8_slab_stats(const void* slab_f16, const void* slab_i8, uint3
 }
 
 hipError_t launch_pack_slab_4bit(const void* slab_f16, uint64_t count, uint32_t dim, unsigned int* max_bits_dev,
-                                 void* out_4bit, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(max_bits_dev, 0, 4, stream);
-    if (e != hipSuccess) return e;
+                                 void* out_4bit, hipStream_t stream, bool max_ready) {
     const int grid = 2048;
-    hipLaunchKernelGGL(slab_maxabs_kernel, dim3(grid), dim3(256), 0, stream, static_cast<const unsigned short*>(slab_f16),
-                       (size_t)count * dim, max_bits_dev);
+    if (!max_ready) {
+        hipError_t e = launch_slab_maxabs(slab_f16, (size_t)count * dim, max_bits_dev, stream);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(pack_slab_4bit_kernel, dim3(grid), dim3(256), 0, stream,
                        static_cast<const unsigned short*>(slab_f16), count, dim, max_bits_dev,
                        static_cast<unsigned char*>(out_4bit));

@@ -157,10 +157,23 @@ struct SelectArgs {
     float* out_scores;         // [nq, out_stride] (may be null)
     u64* out_packed;           // [nq, out_stride] (may be null; kEmpty padding)
     uint32_t* out_counts;      // [nq] (may be null)
+    // finish step with take_topk (the two-pass searches): the k candidates themselves, for a row-sharded index whose root
+    // repeats the selection over all shards' candidates — position i of both lists is the same row: its pass-1 entry
+    // (integer score as f32 bits) and its exact entry; kEmpty beyond the candidates.  [nq, k] each, may be null.
+    u64* cand_approx_out;
+    u64* cand_exact_out;
+    uint32_t cand_out_stride;  // entries between queries in both (>= k)
 };
 constexpr uint32_t kSelectPool = 1024;
 constexpr uint32_t kSelectMaxK = 128;   // largest rank a selection can anchor on (k, or k * multiplier in int8 mode)
 hipError_t launch_select(const SelectArgs& args, int nq, hipStream_t stream);
+// Root of a row-sharded two-pass search (search.rs:514-661 over W shards): per query, the W x cc candidate pairs (pass-1 entry,
+// exact entry; shard s's lists [nq][cc] start shard_pitch entries after shard s-1's, kEmpty padded) -> the cc best by the pass-1
+// order (integer score desc, row asc: exactly the unsharded candidate set, whose members are each in their own shard's top cc)
+// -> the k best of those by the exact order.
+hipError_t launch_two_pass_merge(const u64* approx_lists, const u64* exact_lists, uint32_t nshards, uint64_t shard_pitch, uint32_t nq,
+                                 uint32_t cc, uint32_t k, uint32_t out_stride, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
+                                 hipStream_t stream);
 // bits = 8: quantize_i8_query (scale 127/max when max > 0); bits = 4: pack_4bit_query's levels (scale 7/max when max > 1e-9), one per byte
 hipError_t launch_prepare_queries_i8(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, void* qi8, float* delta,
                                      hipStream_t stream, int bits = 8);
@@ -193,11 +206,13 @@ hipError_t launch_prepare_queries(const float* q, uint32_t nq, uint32_t nq_pad, 
                                   const unsigned int* max_norm_bits, void* qh, float* delta, hipStream_t stream);
 
 // int8_kernels.hip
+// max_ready: *max_bits_dev already holds the (corpus-wide) max-abs — a sharded index reduces the shards' values first
+hipError_t launch_slab_maxabs(const void* slab_f16, size_t n_values, unsigned int* max_bits_dev, hipStream_t stream);
 hipError_t launch_quantize_slab_i8(const void* slab_f16, size_t n_values, unsigned int* max_bits_dev, void* out_i8,
-                                   hipStream_t stream);
+                                   hipStream_t stream, bool max_ready = false);
 // 4-bit levels (-7..7, the reference's nibble quantiser) one per byte: the batched 4-bit pass 1 reuses the int8 matrix-core kernels
 hipError_t launch_quantize_slab_4bit_levels(const void* slab_f16, size_t n_values, unsigned int* max_bits_dev, void* out_i8,
-                                            hipStream_t stream);
+                                            hipStream_t stream, bool max_ready = false);
 // bounds on what the int8 slab misses of the f16 slab (int8 filter of the exact batched search): stats_dev[0..4) =
 // { f32 bits of max_row sum eps^2, max_row sum |r|, max_row sum r^2, non-finite flag }
 hipError_t launch_i8_slab_stats(const void* slab_f16, const void* slab_i8, uint32_t nrows, uint32_t dim,
@@ -205,7 +220,7 @@ hipError_t launch_i8_slab_stats(const void* slab_f16, const void* slab_i8, uint3
 bool scan_i8_fused_supported(int dim, int kcap);
 // 4-bit two-pass (int8_kernels.hip, BITS = 4)
 hipError_t launch_pack_slab_4bit(const void* slab_f16, uint64_t count, uint32_t dim, unsigned int* max_bits_dev,
-                                 void* out_4bit, hipStream_t stream);
+                                 void* out_4bit, hipStream_t stream, bool max_ready = false);
 bool scan_4bit_fused_supported(int dim, int kcap);
 hipError_t launch_scan_4bit(const ScanArgs& args, const void* slab_4bit, const void* query_4bit, int kcap, int grid,
                             hipStream_t stream, int* occupancy);

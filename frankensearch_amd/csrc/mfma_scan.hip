@@ -546,6 +546,7 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
     }
     if (args.pool_out) args.pool_out[(size_t)q * POOL + tid] = pool[tid];
     if constexpr (FINISH) {
+        if (args.cand_approx_out && args.take_topk && tid < k) args.cand_approx_out[(size_t)q * args.cand_out_stride + tid] = pool[tid];
         // exact-order re-score (dot_product_f16_bytes_f32 order, as gather_dot_kernel): one quad per candidate,
         // 256 candidates per sweep; the entry is replaced by its exact counterpart in place
         const int dim = (int)args.dim;
@@ -581,6 +582,7 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
             if (a == 0 && c < nc) cbuf[c] = mine ? pack(sc, grow) : kEmpty;  // only this quad touches its entry
         }
         __syncthreads();
+        if (args.cand_exact_out && args.take_topk && tid < k) args.cand_exact_out[(size_t)q * args.cand_out_stride + tid] = pool[tid];
         const int ko = (int)args.k_out;
         if (big) {
             // the exact entries, sorted again: the first k_out are the answer
@@ -915,6 +917,87 @@ hipError_t launch_prepare_queries_i8_filter(const float* q, uint32_t nq, uint32_
                                             float* delta, hipStream_t stream, float* unit_out) {
     hipLaunchKernelGGL(prepare_queries_i8_filter_kernel, dim3(nq_pad), dim3(256), 0, stream, q, nq, q_stride ? q_stride : dim, dim,
                        slab_max_bits, slab_stats, static_cast<signed char*>(qi8), delta, unit_out);
+    return hipGetLastError();
+}
+
+// Root of a row-sharded two-pass search: one block per query, up to 1,024 candidate pairs.
+__global__ __launch_bounds__(256) void two_pass_merge_kernel(const u64* __restrict__ approx_lists, const u64* __restrict__ exact_lists,
+                                                             uint32_t nshards, uint64_t shard_pitch, uint32_t nq, uint32_t cc, uint32_t k,
+                                                             uint32_t out_stride,
+                                                             uint32_t* __restrict__ out_rows, float* __restrict__ out_scores,
+                                                             uint32_t* __restrict__ out_counts) {
+    __shared__ u64 akey[1024];    // pass-1 sort keys, then the exact sort keys of the chosen candidates
+    __shared__ u64 aval[1024];    // the exact entry that travels with each key
+    const uint32_t q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint32_t total = nshards * cc;   // <= 1024 (checked by the launcher)
+    int np = 64;
+    while ((uint32_t)np < total) np <<= 1;
+    for (int i = tid; i < np; i += 256) {
+        u64 ka = 0, ve = kEmpty;
+        if ((uint32_t)i < total) {
+            const uint32_t s = (uint32_t)i / cc, j = (uint32_t)i - s * cc;
+            const u64 a = approx_lists[(size_t)s * shard_pitch + (size_t)q * cc + j];
+            if (a != kEmpty) {
+                ka = sortkey(a);
+                ve = exact_lists[(size_t)s * shard_pitch + (size_t)q * cc + j];
+            }
+        }
+        akey[i] = ka;
+        aval[i] = ve;
+    }
+    __syncthreads();
+    // bitonic sort by pass-1 key, descending (keys of real rows are distinct; empty slots have key 0 and sink)
+    auto sort_pairs = [&](int n) {
+        for (int size = 2; size <= n; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int i = tid; i < n / 2; i += 256) {
+                    const int lo = (i / stride) * stride * 2 + (i % stride), hi = lo + stride;
+                    const bool desc = ((lo & size) == 0);
+                    const u64 x = akey[lo], y = akey[hi];
+                    if ((x < y) == desc) {
+                        akey[lo] = y;
+                        akey[hi] = x;
+                        const u64 t = aval[lo];
+                        aval[lo] = aval[hi];
+                        aval[hi] = t;
+                    }
+                }
+                __syncthreads();
+            }
+    };
+    sort_pairs(np);
+    // the first cc entries are the corpus-wide pass-1 candidates: re-key them by their exact entries
+    int np2 = 64;
+    while ((uint32_t)np2 < cc) np2 <<= 1;
+    for (int i = tid; i < np2; i += 256) {
+        const bool real = (uint32_t)i < cc && akey[i] != 0 && aval[i] != kEmpty;
+        const u64 v = real ? aval[i] : kEmpty;
+        akey[i] = real ? sortkey(v) : 0;
+        aval[i] = v;
+    }
+    __syncthreads();
+    sort_pairs(np2);
+    uint32_t n = 0;
+    for (uint32_t j = (uint32_t)tid; j < out_stride; j += 256) {
+        const u64 v = j < k && j < (uint32_t)np2 && akey[j] != 0 ? aval[j] : kEmpty;
+        if (out_rows) out_rows[(size_t)q * out_stride + j] = (uint32_t)v;
+        if (out_scores) out_scores[(size_t)q * out_stride + j] = __uint_as_float((uint32_t)(v >> 32));
+    }
+    if (tid == 0 && out_counts) {
+        const uint32_t lim = k < (uint32_t)np2 ? k : (uint32_t)np2;
+        while (n < lim && akey[n] != 0) ++n;
+        out_counts[q] = n;
+    }
+}
+
+hipError_t launch_two_pass_merge(const u64* approx_lists, const u64* exact_lists, uint32_t nshards, uint64_t shard_pitch, uint32_t nq,
+                                 uint32_t cc, uint32_t k, uint32_t out_stride, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
+                                 hipStream_t stream) {
+    if (nq == 0) return hipSuccess;
+    if (cc == 0 || (uint64_t)nshards * cc > 1024 || k > cc) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(two_pass_merge_kernel, dim3(nq), dim3(256), 0, stream, approx_lists, exact_lists, nshards, shard_pitch, nq, cc, k,
+                       out_stride, out_rows, out_scores, out_counts);
     return hipGetLastError();
 }
 

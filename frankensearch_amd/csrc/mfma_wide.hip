@@ -116,11 +116,6 @@ __device__ __forceinline__ void wait_vmcnt() {
 // carries no trace of the sample mapping); 1 = no MFMAs, 2 = no DMA (timing experiments only: -DFSGPU_EXPERIMENTS)
 //
 // OPT (bit set):
-//   kOptLag    the two waves that share a SIMD (w and w + 4) meet the tile's barrier at DIFFERENT points of their chunk sequence
-//              (waves 0-3 after chunk 0, waves 4-7 after chunk NC/2 - 1 and its threshold test), so that one wave's stretch
-//              without matrix instructions (DMA issue, threshold test, barrier) lies beside the other's MFMA chunks instead of
-//              beside the same stretch of its twin.  The ring accounting does not change: at the barrier of tile n every wave
-//              is past tile n - 1 and tile n + 1 has landed.
 //   kOptNegTau int8 rows: the accumulators start at -ceil(tau) instead of 0, so "some score of the pair reaches its query's
 //              threshold" is ONE sign test on the maximum of the lane's 8 x QT accumulators (v_max3_i32) instead of QT
 //              maxima, conversions and compares.  (s >= ceil(tau)) == ((float)s >= tau) for these integer scores.
@@ -134,7 +129,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 //              of the OTHER half's MFMAs (phase-1 scores are tested during phase 2, phase-2 scores during the next pair's
 //              phase 1), the LDS reads are spread one pair per four MFMAs, and nothing but the barrier interrupts the matrix
 //              stream of a wave.
-constexpr int kOptLag = 1, kOptNegTau = 2, kOptSaddr = 4, kOptSplit = 8;
+constexpr int kOptNegTau = 2, kOptSaddr = 4, kOptSplit = 8;   // (bit 1 was a barrier-phase shift between the SIMD twins: measured null, removed)
 template <int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG = 0>
 __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     using acc_t = std::conditional_t<EB == 2, f32x4, i32x4>;
@@ -154,7 +149,6 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     static_assert(NSLOT >= 4, "tile n is consumed while n+1 .. n+NSLOT-2 are in flight and n-1's slot is being refilled");
     // (shapes whose resident queries already fill the register file take no option that costs registers)
     constexpr bool ROOM = QT * KS * 4 + 4 * CK * 4 + 8 * QT <= 190;
-    constexpr bool LAG = (OPT & kOptLag) != 0 && NC >= 4;
     constexpr bool NEGTAU = (OPT & kOptNegTau) != 0 && EB == 1 && ROOM;
     constexpr bool SADDR = (OPT & kOptSaddr) != 0 && ROOM;
     // registers: resident queries + fragments + accumulators must leave room for addresses and the append path
@@ -221,17 +215,17 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     const unsigned char* slab = reinterpret_cast<const unsigned char*>(args.slab);
     const size_t row_pitch = args.row_stride ? (size_t)args.row_stride : (size_t)ROWB;   // MRL prefix views: rows further apart
     struct Cursor {
-        uint32_t n, base, rot;   // round, n * grid, n mod grid
+        uint32_t n, t, j;   // round, tile number n * grid + j in forward order, j = (block - n) mod grid
     };
+    const uint32_t rev_top = rounds * grid - 1;
     auto cursor_tile = [&](const Cursor& c) -> uint32_t {   // >= ntiles: nothing to scan in this round
-        const uint32_t b = blockIdx.x;
-        const uint32_t t = c.base + (b >= c.rot ? b - c.rot : b + grid - c.rot);
-        return args.reverse ? rounds * grid - 1 - t : t;
+        return args.reverse ? rev_top - c.t : c.t;
     };
-    auto cursor_next = [&](Cursor& c) {
+    auto cursor_next = [&](Cursor& c) {   // four scalar operations per tile
+        const bool wrap = c.j == 0;
+        c.t += wrap ? 2 * grid - 1 : grid - 1;
+        c.j = wrap ? grid - 1 : c.j - 1;
         ++c.n;
-        c.base += grid;
-        c.rot = c.rot + 1 == grid ? 0 : c.rot + 1;
     };
     // Every block walks all `rounds` rounds; in the first or the last round (the only ragged ones) a block's tile may not exist:
     // it then fetches the last tile again (the counted waits stay exact) and discards the scores — no search loop, a handful of
@@ -274,8 +268,8 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     // fragment reads of chunk c (sub-tile pair c / NCH, k-steps (c % NCH) * CK ...) of a ring slot
     const uint32_t a_off = (uint32_t)frow * 64u + (uint32_t)((fk ^ ((4 - (frow >> 2)) & 3)) << 4);
     [[maybe_unused]] bool frag_ready = false;   // (DBG 5)
-    auto read_chunk = [&](uint32_t slot, int c, half8 (&f)[2][CK]) {
-        const unsigned char* base = smem + (size_t)slot * TILE_BYTES + a_off;
+    auto slot_base = [&](uint32_t slot) { return smem + (size_t)slot * TILE_BYTES + a_off; };   // one address per tile, not per chunk
+    auto read_chunk = [&](const unsigned char* base, int c, half8 (&f)[2][CK]) {
         const int sp = (c / NCH) * 2, k0 = (c % NCH) * CK;
 #ifdef FSGPU_EXPERIMENTS
         if constexpr (DBG == 5) {   // timing skeleton: the fragments stay what the prologue read
@@ -377,6 +371,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
             return;
         }
 #endif
+        if (t >= ntiles) return;   // (wave-uniform) a ragged round: the slot holds the last tile again
         // C layout: column (query) = lane & 15, row = (lane >> 4) * 4 + reg
         const uint32_t row00 = tile_row0(t) + sp * 16 + fk * 4;
         if constexpr (EB == 2 && QT >= 3) {   // (the 384-query f16 shape has no register to spare for the per-tile test below)
@@ -408,8 +403,8 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     };
 
     __syncthreads();  // counters initialised (no DMA in flight yet)
-    Cursor cl{0, 0, 0};   // next tile to fetch
-    Cursor cc = cl;       // next tile to consume
+    Cursor cl{0, blockIdx.x, blockIdx.x};   // next tile to fetch
+    Cursor cc = cl;                         // next tile to consume
     // prologue: NSLOT - 1 tiles in flight (tile j -> slot j mod NSLOT throughout).  Past the last round the DMA count is kept
     // up with dummy tiles (the last tile again) so that the counted waits below stay exact.
     auto fetch_next = [&](uint32_t slot) {
@@ -425,8 +420,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
         constexpr int QA = QT / 2;                  // phase 1: query tiles [0, QA), phase 2: [QA, QT)
         half8 f[2][KS];                             // the current pair's fragments: [sub-tile of the pair][k-step]
         acc_t acc[2][QT];
-        auto read_frag = [&](uint32_t sl, int pair, int kk) {
-            const unsigned char* base = smem + (size_t)sl * TILE_BYTES + a_off;
+        auto read_frag = [&](const unsigned char* base, int pair, int kk) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) f[h][kk] = *reinterpret_cast<const half8*>(base + ((pair * 2 + h) * KS + kk) * 1024);
         };
@@ -448,15 +442,15 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
         __builtin_amdgcn_s_barrier();          // ... and everyone's
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) read_frag(0, 0, kk);
+        for (int kk = 0; kk < KS; ++kk) read_frag(slot_base(0), 0, kk);
         init_acc(0, QT);                        // (so that the first, void, test of the second half reads defined values)
-        uint32_t slot = 0;
-        uint32_t tB = 0;                        // tile of the pair whose second-half scores are still to be tested
-        bool existsB = false;
+        uint32_t slot = 0, slot_prev = NSLOT - 1;
+        const unsigned char* cur = slot_base(0);
+        uint32_t tB = ntiles;                   // tile of the pair whose second-half scores are still to be tested (none yet)
         while (cc.n < rounds) {
             const uint32_t slot_next = slot + 1 == NSLOT ? 0 : slot + 1;
-            const uint32_t t = cursor_tile(cc);
-            const bool tile_exists = t < ntiles;   // (wave-uniform) else: the ring slot holds the last tile again, nothing is emitted
+            const unsigned char* nxt = slot_base(slot_next);
+            const uint32_t t = cursor_tile(cc);   // (a ragged round's missing tile is recognised in the slow path: emit_tiles)
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 constexpr int TK = KS >= 4 ? 2 : 0;   // the k-step after which a phase carries the other half's test
@@ -475,10 +469,10 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
                         __builtin_amdgcn_s_barrier();
                         asm volatile("" ::: "memory");
                     }
-                    if (p == 0 && kk == (KS >= 3 ? 2 : KS - 1)) fetch_next(slot == 0 ? NSLOT - 1 : slot - 1);
+                    if (p == 0 && kk == (KS >= 3 ? 2 : KS - 1)) fetch_next(slot_prev);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (existsB && anyB) emit_tiles(tB, ((p + NP - 1) % NP) * 2, acc, QA, QT);
+                if (anyB) emit_tiles(tB, ((p + NP - 1) % NP) * 2, acc, QA, QT);
                 // ---- phase 2: query tiles [QA, QT); the next pair's fragments roll in behind each k-step; this pair's tiles
                 // [0, QA) are tested in its shadow
                 init_acc(QA, QT);
@@ -486,37 +480,38 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) {
                     mfma_step(kk, QA, QT);
-                    if (p + 1 < NP) read_frag(slot, p + 1, kk);
-                    else read_frag(slot_next, 0, kk);
+                    if (p + 1 < NP) read_frag(cur, p + 1, kk);
+                    else read_frag(nxt, 0, kk);
                     if (kk == TK) anyA = any_passes(acc, 0, QA);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (tile_exists && anyA) emit_tiles(t, p * 2, acc, 0, QA);
+                if (anyA) emit_tiles(t, p * 2, acc, 0, QA);
                 tB = t;
-                existsB = tile_exists;
             }
             cursor_next(cc);
+            slot_prev = slot;
             slot = slot_next;
+            cur = nxt;
         }
-        if (existsB && any_passes(acc, QA, QT)) emit_tiles(tB, (NP - 1) * 2, acc, QA, QT);
+        if (any_passes(acc, QA, QT)) emit_tiles(tB, (NP - 1) * 2, acc, QA, QT);
     } else {
     half8 fa[2][2][CK];   // fragment double buffer: [buffer][sub-tile of the pair][k-step of the chunk]
-    const bool late = LAG && wave >= 4;
     wait_vmcnt<PW*(NSLOT - 2)>();          // this wave's share of tile 0 has landed ...
     __builtin_amdgcn_s_barrier();          // ... and everyone's
     asm volatile("" ::: "memory");
-    read_chunk(0, 0, fa[0]);
+    read_chunk(slot_base(0), 0, fa[0]);
 #ifdef FSGPU_EXPERIMENTS
     if constexpr (DBG == 5) {
-        read_chunk(0, 1, fa[1]);
+        read_chunk(slot_base(0), 1, fa[1]);
         frag_ready = true;
     }
 #endif
-    uint32_t slot = 0;
+    uint32_t slot = 0, slot_prev = NSLOT - 1;
+    const unsigned char* cur = slot_base(0);
     while (cc.n < rounds) {
         const uint32_t slot_next = slot + 1 == NSLOT ? 0 : slot + 1;
-        const uint32_t t = cursor_tile(cc);
-        const bool tile_exists = t < ntiles;   // (wave-uniform) else: the ring slot holds the last tile again, nothing is emitted
+        const unsigned char* nxt = slot_base(slot_next);
+        const uint32_t t = cursor_tile(cc);   // (a ragged round's missing tile is recognised in the slow path: emit_tiles)
         acc_t acc[2][QT];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -531,36 +526,31 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
                     }
             }
             // the NEXT chunk's fragment reads go out before this chunk's MFMAs (the next tile's first chunk after the last)
-            if (c + 1 < NC) read_chunk(slot, c + 1, fa[(c + 1) & 1]);
-            else read_chunk(slot_next, 0, fa[0]);
+            if (c + 1 < NC) read_chunk(cur, c + 1, fa[(c + 1) & 1]);
+            else read_chunk(nxt, 0, fa[0]);
             __builtin_amdgcn_sched_barrier(0);
             mfma_chunk(c, fa[c & 1], acc);
             __builtin_amdgcn_sched_barrier(0);
-            if (c % NCH == NCH - 1 && tile_exists) emit_pair(t, (c / NCH) * 2, acc);
+            if (c % NCH == NCH - 1) emit_pair(t, (c / NCH) * 2, acc);
             // The tile's barrier.  Tile n+1: this wave's DMAs have landed (tiles n+2 .. n+NSLOT-2 may still be in flight), then
             // everyone's; every wave is also past its last read of tile n-1, whose slot takes tile n+NSLOT-1.
-            // LAG: waves 4-7 get here one or more chunks later in their own sequence than waves 0-3 (after chunk NC/2 - 1 and
-            // its threshold test), so the twin waves of a SIMD run out of phase; both statements above still hold for them.
-            constexpr int CB = NC / 2 - 1;   // the late group's barrier chunk
-            bool at_barrier = c == 0;
-            if constexpr (LAG) at_barrier = late ? c == CB : c == 0;
-            if (at_barrier && DBG != 4) {   // (DBG 4: timing skeleton without the tile's wait and barrier)
+            if (c == 0 && DBG != 4) {   // (DBG 4: timing skeleton without the tile's wait and barrier)
                 wait_vmcnt<PW*(NSLOT - 3)>();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
             // The DMA issue (a stretch without MFMAs) is staggered between the two waves that share a SIMD (waves w and
-            // w + 4): the early group right after the barrier, the late group a chunk after its own.
-            if constexpr (LAG) {
-                if (late ? c == CB + 1 : c == 0) fetch_next(slot == 0 ? NSLOT - 1 : slot - 1);
-            } else if (NC >= 2 && c <= 1) {
-                if ((wave >= 4) == (c == 1)) fetch_next(slot == 0 ? NSLOT - 1 : slot - 1);
+            // w + 4): one right after the barrier, the other a chunk later.
+            if (NC >= 2 && c <= 1) {
+                if ((wave >= 4) == (c == 1)) fetch_next(slot_prev);
             } else if (NC < 2 && c == 0) {
-                fetch_next(slot == 0 ? NSLOT - 1 : slot - 1);
+                fetch_next(slot_prev);
             }
         }
         cursor_next(cc);
+        slot_prev = slot;
         slot = slot_next;
+        cur = nxt;
     }
     }
     wait_vmcnt<0>();  // no DMA may outlive the block's LDS allocation
@@ -576,11 +566,12 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
 
 namespace {
 
-// what the shipped kernels are built with (measured: profiles/r03/wide_opt_ab.txt)
+// what the shipped kernels are built with: neg-tau + scalar-base DMA + query-tile-split loop wherever the shape's registers allow
+// (measured on the bench shape, profiles/r03/wide_opt_ab.txt: 1.49 ms -> 1.38 ms per 512 queries at 10M x 384)
 #ifdef FSGPU_WIDE_OPT_DEFAULT
 constexpr int kWideOptDefault = FSGPU_WIDE_OPT_DEFAULT;
 #else
-constexpr int kWideOptDefault = 0;
+constexpr int kWideOptDefault = kOptNegTau | kOptSaddr | kOptSplit;
 #endif
 
 #ifdef FSGPU_EXPERIMENTS
@@ -641,20 +632,16 @@ hipError_t launch_wide_d(const MfmaScanArgs& args, int grid, hipStream_t stream,
                 static const int opt = wide_env("FSGPU_WIDE_OPT");
                 static const int dbg = wide_env("FSGPU_WIDE_DBG");
                 if constexpr (MODE == 0) {
-                    if (dbg == 1) return launch_wide_t<384, EB, QT, 6, 7, 1>(args, grid, stream, occupancy);
-                    if (dbg == 2) return launch_wide_t<384, EB, QT, 6, 7, 2>(args, grid, stream, occupancy);
-                    if (dbg == 4) return launch_wide_t<384, EB, QT, 6, 7, 4>(args, grid, stream, occupancy);
-                    if (dbg == 5) return launch_wide_t<384, EB, QT, 6, 7, 5>(args, grid, stream, occupancy);
+                    if (dbg == 1) return launch_wide_t<384, EB, QT, 6, 6, 1>(args, grid, stream, occupancy);
+                    if (dbg == 2) return launch_wide_t<384, EB, QT, 6, 6, 2>(args, grid, stream, occupancy);
+                    if (dbg == 4) return launch_wide_t<384, EB, QT, 6, 6, 4>(args, grid, stream, occupancy);
+                    if (dbg == 5) return launch_wide_t<384, EB, QT, 6, 6, 5>(args, grid, stream, occupancy);
                 }
                 switch (opt) {
                     case 0: return launch_wide_t<384, EB, QT, 6, 0, MODE>(args, grid, stream, occupancy);
-                    case 1: return launch_wide_t<384, EB, QT, 6, 1, MODE>(args, grid, stream, occupancy);
                     case 2: return launch_wide_t<384, EB, QT, 6, 2, MODE>(args, grid, stream, occupancy);
-                    case 3: return launch_wide_t<384, EB, QT, 6, 3, MODE>(args, grid, stream, occupancy);
                     case 4: return launch_wide_t<384, EB, QT, 6, 4, MODE>(args, grid, stream, occupancy);
-                    case 5: return launch_wide_t<384, EB, QT, 6, 5, MODE>(args, grid, stream, occupancy);
                     case 6: return launch_wide_t<384, EB, QT, 6, 6, MODE>(args, grid, stream, occupancy);
-                    case 7: return launch_wide_t<384, EB, QT, 6, 7, MODE>(args, grid, stream, occupancy);
                     case 14: return launch_wide_t<384, EB, QT, 6, 14, MODE>(args, grid, stream, occupancy);
                     default: break;
                 }

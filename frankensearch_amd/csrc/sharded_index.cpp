@@ -46,6 +46,10 @@ struct Rccl {
     void* lib = nullptr;
     ncclResult_t (*comm_init_all)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*all_gather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*all_reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*group_start)() = nullptr;
+    ncclResult_t (*group_end)() = nullptr;
+    ncclResult_t (*comm_abort)(ncclComm_t) = nullptr;
     ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
     const char* (*error_string)(ncclResult_t) = nullptr;
     std::string why;  // why it is unavailable
@@ -70,10 +74,14 @@ struct Rccl {
         }
         r.comm_init_all = reinterpret_cast<decltype(r.comm_init_all)>(dlsym(r.lib, "ncclCommInitAll"));
         r.all_gather = reinterpret_cast<decltype(r.all_gather)>(dlsym(r.lib, "ncclAllGather"));
+        r.all_reduce = reinterpret_cast<decltype(r.all_reduce)>(dlsym(r.lib, "ncclAllReduce"));
+        r.group_start = reinterpret_cast<decltype(r.group_start)>(dlsym(r.lib, "ncclGroupStart"));
+        r.group_end = reinterpret_cast<decltype(r.group_end)>(dlsym(r.lib, "ncclGroupEnd"));
+        r.comm_abort = reinterpret_cast<decltype(r.comm_abort)>(dlsym(r.lib, "ncclCommAbort"));
         r.comm_destroy = reinterpret_cast<decltype(r.comm_destroy)>(dlsym(r.lib, "ncclCommDestroy"));
         r.error_string = reinterpret_cast<decltype(r.error_string)>(dlsym(r.lib, "ncclGetErrorString"));
-        if (!r.comm_init_all || !r.all_gather || !r.comm_destroy || !r.error_string) {
-            r.why = "librccl.so.1 lacks ncclCommInitAll / ncclAllGather / ncclCommDestroy / ncclGetErrorString";
+        if (!r.comm_init_all || !r.all_gather || !r.all_reduce || !r.group_start || !r.group_end || !r.comm_destroy || !r.error_string) {
+            r.why = "librccl.so.1 lacks ncclCommInitAll / ncclAllGather / ncclAllReduce / ncclGroupStart / ncclGroupEnd / ncclCommDestroy";
             r.lib = nullptr;
         }
         return r;
@@ -107,11 +115,23 @@ ShardedIndex::~ShardedIndex() {
         if (s->worker.joinable()) s->worker.join();
     for (auto& s : shards_) {
         if (s->device >= 0) (void)hipSetDevice(s->device);
+        if (s->stream) (void)hipStreamSynchronize(s->stream);
+        if (s->xstream) (void)hipStreamSynchronize(s->xstream);
         if (s->comm && Rccl::get().ok()) (void)Rccl::get().comm_destroy(static_cast<ncclComm_t>(s->comm));
+        for (Slot& sl : s->slot) {
+            for (DeviceBuffer* b : {&sl.queries, &sl.packed, &sl.gathered, &sl.allow}) b->release();
+            if (sl.scan_done) (void)hipEventDestroy(sl.scan_done);
+            if (sl.sent) (void)hipEventDestroy(sl.sent);
+        }
+        if (s->xstream) (void)hipStreamDestroy(s->xstream);
         if (s->stream) (void)hipStreamDestroy(s->stream);
-        for (DeviceBuffer* b : {&s->queries, &s->packed, &s->gathered, &s->out_rows, &s->out_scores, &s->out_counts}) b->release();
     }
-    if (stage_host_) (void)hipHostFree(stage_host_);
+    if (!shards_.empty()) (void)hipSetDevice(shards_[0]->device);
+    for (RootSlot& r : root_) {
+        for (DeviceBuffer* b : {&r.out_rows, &r.out_scores, &r.out_counts}) b->release();
+        if (r.stage) (void)hipHostFree(r.stage);
+        if (r.done) (void)hipEventDestroy(r.done);
+    }
 }
 
 SearchError ShardedIndex::init_host(const int32_t* devices, uint32_t ndev, uint32_t dim, uint64_t nrows, const void* slab_f16,
@@ -159,6 +179,28 @@ SearchError ShardedIndex::init_device(const int32_t* devices, uint32_t ndev, uin
     return finish_init(exchange);
 }
 
+// VectorIndex::open (lib.rs:1747-1909) for a sharded index: the file is read and validated once; its record table, doc-id
+// strings, tombstone flags (and later its WAL) stay in the catalog, the F16 slab is split over the devices.
+SearchError ShardedIndex::open_fsvi(const char* path, const int32_t* devices, uint32_t ndev, int32_t exchange) {
+    if (!devices || ndev == 0) return make_err(FSGPU_ERR_INVALID_CONFIG, "at least one device is required");
+    catalog_ = std::make_unique<VectorIndex>();
+    VectorIndex::FsviImage img;
+    SH_TRY(catalog_->open_fsvi_catalog(path, &img));
+    if (img.f32_rows) return make_err(FSGPU_ERR_INVALID_CONFIG, "a sharded index needs an F16 slab (Quantization::F16)");
+    const std::vector<uint64_t>& live = catalog_->live_host();
+    SH_TRY(init_host(devices, ndev, img.dim, img.nrows, img.bytes.data() + img.slab_offset, live.empty() ? nullptr : live.data(), exchange));
+    // hits of the catalog's search_top_k (WAL merge, shadowing, dedup) come from the shards
+    catalog_->topk_override = [this](const float* q, uint32_t k, uint32_t* rows, float* scores, uint32_t* count) -> SearchError {
+        Request rq;
+        rq.queries = q;
+        rq.nq = 1;
+        rq.k = k;
+        rq.mode = kExact;
+        return search(rq, dim_, rows, scores, count, nullptr);
+    };
+    return SearchError{};
+}
+
 SearchError ShardedIndex::finish_init(int32_t exchange) {
     if (exchange < 0 || exchange > 2) return make_err(FSGPU_ERR_INVALID_CONFIG, "exchange must be 0 (auto), 1 (RCCL) or 2 (peer copies)");
     const uint32_t w = (uint32_t)shards_.size();
@@ -168,7 +210,14 @@ SearchError ShardedIndex::finish_init(int32_t exchange) {
     for (auto& s : shards_) {
         SH_HIP(hipSetDevice(s->device));
         SH_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        SH_HIP(hipStreamCreateWithFlags(&s->xstream, hipStreamNonBlocking));
+        for (Slot& sl : s->slot) {
+            SH_HIP(hipEventCreateWithFlags(&sl.scan_done, hipEventDisableTiming));
+            SH_HIP(hipEventCreateWithFlags(&sl.sent, hipEventDisableTiming));
+        }
     }
+    SH_HIP(hipSetDevice(shards_[0]->device));
+    for (RootSlot& r : root_) SH_HIP(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
     // RCCL wants one rank per device; several shards on one device (a rehearsal of the N-way path on fewer GPUs)
     // exchange their lists with plain device-to-device copies instead
     if (exchange == 1 && !distinct) return make_err(FSGPU_ERR_INVALID_CONFIG, "RCCL exchange needs distinct devices");
@@ -216,26 +265,31 @@ bool ShardedIndex::shard_range(uint32_t shard, uint64_t* lo, uint64_t* hi) const
 
 void ShardedIndex::set_hreduce(int32_t mode) {
     for (auto& s : shards_) s->index.hreduce = mode;
+    if (catalog_) catalog_->hreduce = mode;
 }
 
-// One host thread per shard: HIP's current device is per thread, the batched search synchronises its stream, and
-// RCCL's single-process mode wants one caller per rank.
+uint32_t ShardedIndex::owner_of(uint64_t row) const {
+    for (uint32_t r = 0; r < shards_.size(); ++r)
+        if (row >= shards_[r]->lo && row < shards_[r]->lo + shards_[r]->rows) return r;
+    return (uint32_t)shards_.size();
+}
+
+// One host thread per shard: HIP's current device is per thread and the batched search blocks on its own stream.  A worker
+// runs its shard's scan call and records `scan_done` behind it; the exchange is the calling thread's business.
 void ShardedIndex::worker_main(uint32_t r) {
     Shard& s = *shards_[r];
     (void)hipSetDevice(s.device);
     uint64_t seen = 0;
     for (;;) {
-        int phase;
         {
             std::unique_lock<std::mutex> lk(mu_);
             cv_work_.wait(lk, [&] { return generation_ != seen; });
             seen = generation_;
             if (stop_) return;
-            phase = phase_;
         }
         SearchError e;
         try {
-            e = phase == 1 ? shard_search(s) : shard_exchange(r);
+            e = shard_search(s, r);
         } catch (const std::exception& ex) {
             e = make_err(FSGPU_ERR_DEVICE, ex.what());
         } catch (...) {
@@ -249,123 +303,342 @@ void ShardedIndex::worker_main(uint32_t r) {
     }
 }
 
-void ShardedIndex::run_phase(int phase) {
+void ShardedIndex::run_scans() {
     std::unique_lock<std::mutex> lk(mu_);
-    phase_ = phase;
     pending_ = (uint32_t)shards_.size();
     ++generation_;
     cv_work_.notify_all();
     cv_done_.wait(lk, [&] { return pending_ == 0; });
 }
 
-// Phase 1: this shard's packed best-first lists [nq, k] (global row ids, ~0 padding), stream drained on return.
-SearchError ShardedIndex::shard_search(Shard& s) {
+// This shard's list(s) for the job: packed best-first [nq, k] (global row ids, ~0 padding) — or, for the two-pass modes, the
+// candidate pairs [2][nq, cc] — then `scan_done` on the scan stream: whatever the search call left enqueued (the batched path
+// returns with its fallback work only enqueued) is in front of it.
+SearchError ShardedIndex::shard_search(Shard& s, uint32_t r) {
     const Job& j = job_;
-    const size_t qbytes = (size_t)j.nq * dim_ * 4, lbytes = (size_t)j.nq * j.k * 8;
+    Slot& sl = s.slot[j.slot];
+    const bool two_pass = j.mode == kInt8TwoPass || j.mode == kFourBitTwoPass;
+    const uint64_t cc = two_pass ? std::max<uint64_t>((uint64_t)j.k * (j.multiplier ? j.multiplier : 1), j.k) : j.k;
+    const size_t qbytes = (size_t)j.nq * dim_ * 4, lbytes = (size_t)j.nq * cc * 8 * (two_pass ? 2 : 1);
     SH_HIP(hipSetDevice(s.device));
-    SH_TRY(s.queries.reserve(qbytes));
-    SH_TRY(s.packed.reserve(lbytes));
-    SH_HIP(hipMemcpyAsync(s.queries.ptr, j.queries, qbytes, hipMemcpyHostToDevice, s.stream));
+    SH_HIP(hipMemcpyAsync(sl.queries.ptr, j.queries, qbytes, hipMemcpyHostToDevice, s.stream));
+    const uint64_t* allow_dev = nullptr;
+    if (j.has_allow && s.rows) {
+        const RootSlot& rs = root_[j.slot];
+        size_t off = 0;
+        for (uint32_t x = 0; x < r; ++x) off += (size_t)((shards_[x]->rows + 63) / 64);
+        SH_HIP(hipMemcpyAsync(sl.allow.ptr, rs.allow_slices.data() + off, (size_t)((s.rows + 63) / 64) * 8, hipMemcpyHostToDevice, s.stream));
+        allow_dev = static_cast<const uint64_t*>(sl.allow.ptr);
+    }
     s.fallbacks = 0;
+    uint64_t* packed = static_cast<uint64_t*>(sl.packed.ptr);
+    const float* qd = static_cast<const float*>(sl.queries.ptr);
     if (s.rows == 0) {
-        SH_HIP(hipMemsetAsync(s.packed.ptr, 0xff, lbytes, s.stream));
-    } else if (j.batched) {
-        SH_TRY(s.index.search_top_k_batched_device(static_cast<const float*>(s.queries.ptr), j.nq, dim_, j.k, nullptr, nullptr,
-                                                   nullptr, nullptr, s.stream, &s.fallbacks,
-                                                   static_cast<uint64_t*>(s.packed.ptr)));
+        SH_HIP(hipMemsetAsync(packed, 0xff, lbytes, s.stream));
+    } else if (two_pass) {
+        SH_TRY(s.index.two_pass_candidates_device(qd, j.nq, dim_, j.k, j.multiplier, j.mode == kFourBitTwoPass ? 4 : 8, packed,
+                                                  packed + (size_t)j.nq * cc, s.stream, &s.fallbacks));
+    } else if (j.mode == kBatched) {
+        SH_TRY(s.index.search_top_k_batched_device(qd, j.nq, dim_, j.k, allow_dev, nullptr, nullptr, nullptr, s.stream, &s.fallbacks,
+                                                   packed));
     } else {
-        SH_TRY(s.index.search_top_k_packed_device(static_cast<const float*>(s.queries.ptr), j.nq, dim_, j.k, nullptr,
-                                                  static_cast<uint64_t*>(s.packed.ptr), s.stream));
+        SH_TRY(s.index.search_top_k_packed_device(qd, j.nq, dim_, j.k, allow_dev, packed, s.stream));
     }
-    SH_HIP(hipStreamSynchronize(s.stream));
+    SH_HIP(hipEventRecord(sl.scan_done, s.stream));
     return SearchError{};
 }
 
-// Phase 2 (entered only when every shard's phase 1 succeeded — a rank missing from the collective would hang the
-// others): the W lists land in gather layout [W][nq][k] — on every device through ncclAllGather, or on the root only
-// through device-to-device copies.
-SearchError ShardedIndex::shard_exchange(uint32_t r) {
-    Shard& s = *shards_[r];
-    const Job& j = job_;
+// The corpus-wide max-abs of the quantisers (simd.rs:1865-1886 computes ONE scale over the whole slab): every shard's own
+// max-abs, reduced with ncclAllReduce(max) over the shards' communicators (4 bytes) — or on the host when the
+// shards exchange by peer copies —, then adopted by every shard as THE scale of its int8 / 4-bit copies.
+SearchError ShardedIndex::ensure_quant_scale() {
+    if (quant_ready_) return SearchError{};
     const uint32_t w = (uint32_t)shards_.size();
-    const size_t count = (size_t)j.nq * j.k, lbytes = count * 8;
-    SH_HIP(hipSetDevice(s.device));
-    if (use_rccl_) {
-        SH_TRY(s.gathered.reserve(lbytes * w));
-        Rccl& rc = Rccl::get();
-        const ncclResult_t st = rc.all_gather(s.packed.ptr, s.gathered.ptr, count, ncclUint64, static_cast<ncclComm_t>(s.comm), s.stream);
-        if (st != ncclSuccess) return make_err(FSGPU_ERR_DEVICE, std::string("ncclAllGather: ") + rc.error_string(st));
-    } else {
-        Shard& root = *shards_[0];
-        SH_HIP(hipMemcpyAsync(static_cast<unsigned char*>(root.gathered.ptr) + (size_t)r * lbytes, s.packed.ptr, lbytes,
-                              hipMemcpyDeviceToDevice, s.stream));
+    std::vector<unsigned int*> bits(w, nullptr);
+    for (uint32_t r = 0; r < w; ++r) {
+        SH_HIP(hipSetDevice(shards_[r]->device));
+        SH_TRY(shards_[r]->index.compute_local_quant_max(&bits[r], shards_[r]->stream));
     }
-    SH_HIP(hipStreamSynchronize(s.stream));
+    unsigned int global_bits = 0;
+    if (use_rccl_ && w > 1) {
+        Rccl& rc = Rccl::get();
+        // (max over non-negative f32 values: reduced as floats)
+        ncclResult_t st = rc.group_start();
+        for (uint32_t r = 0; r < w && st == ncclSuccess; ++r)
+            st = rc.all_reduce(bits[r], bits[r], 1, ncclFloat32, ncclMax, static_cast<ncclComm_t>(shards_[r]->comm), shards_[r]->stream);
+        const ncclResult_t st2 = rc.group_end();
+        if (st != ncclSuccess || st2 != ncclSuccess)
+            return make_err(FSGPU_ERR_DEVICE, std::string("ncclAllReduce(max): ") + rc.error_string(st != ncclSuccess ? st : st2));
+        SH_HIP(hipSetDevice(shards_[0]->device));
+        SH_HIP(hipMemcpyAsync(&global_bits, bits[0], 4, hipMemcpyDeviceToHost, shards_[0]->stream));
+        for (uint32_t r = 0; r < w; ++r) {
+            SH_HIP(hipSetDevice(shards_[r]->device));
+            SH_HIP(hipStreamSynchronize(shards_[r]->stream));
+        }
+    } else {
+        std::vector<unsigned int> local(w, 0);
+        for (uint32_t r = 0; r < w; ++r) {
+            SH_HIP(hipSetDevice(shards_[r]->device));
+            SH_HIP(hipMemcpyAsync(&local[r], bits[r], 4, hipMemcpyDeviceToHost, shards_[r]->stream));
+            SH_HIP(hipStreamSynchronize(shards_[r]->stream));
+        }
+        for (unsigned int b : local) global_bits = std::max(global_bits, b);   // non-negative floats order like their bits
+        for (uint32_t r = 0; r < w; ++r) {
+            SH_HIP(hipSetDevice(shards_[r]->device));
+            SH_HIP(hipMemcpyAsync(bits[r], &global_bits, 4, hipMemcpyHostToDevice, shards_[r]->stream));
+            SH_HIP(hipStreamSynchronize(shards_[r]->stream));
+        }
+    }
+    for (auto& s : shards_) s->index.adopt_global_quant_max();
+    std::memcpy(&quant_max_, &global_bits, 4);
+    quant_ready_ = true;
     return SearchError{};
 }
 
-SearchError ShardedIndex::search(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k, bool batched,
-                                 uint32_t* out_rows, float* out_scores, uint32_t* out_counts, uint32_t* fallbacks) {
-    if (fallbacks) *fallbacks = 0;
+// The exchange + merge of one slot, enqueued by the calling thread with no host wait in between: every shard's exchange stream
+// waits for that shard's scan_done event; the lists travel (ncclAllGather inside ONE group call / peer copies into the root's
+// gather buffer); the root's exchange stream merges them and copies the hits into the slot's pinned block; `done` marks the end.
+SearchError ShardedIndex::enqueue_exchange(int slot, uint32_t nq, uint32_t k) {
+    const uint32_t w = (uint32_t)shards_.size();
+    const Job& j = job_;
+    const bool two_pass = j.mode == kInt8TwoPass || j.mode == kFourBitTwoPass;
+    const uint64_t cc = two_pass ? std::max<uint64_t>((uint64_t)k * (j.multiplier ? j.multiplier : 1), k) : k;
+    const size_t count = (size_t)nq * cc * (two_pass ? 2 : 1), lbytes = count * 8;
+    Shard& root = *shards_[0];
+    RootSlot& rs = root_[slot];
+    for (uint32_t r = 0; r < w; ++r) {
+        SH_HIP(hipSetDevice(shards_[r]->device));
+        SH_HIP(hipStreamWaitEvent(shards_[r]->xstream, shards_[r]->slot[slot].scan_done, 0));
+    }
+    if (w > 1 && use_rccl_) {
+        Rccl& rc = Rccl::get();
+        ncclResult_t st = rc.group_start();
+        for (uint32_t r = 0; r < w && st == ncclSuccess; ++r) {
+            Slot& sl = shards_[r]->slot[slot];
+            st = rc.all_gather(sl.packed.ptr, sl.gathered.ptr, count, ncclUint64, static_cast<ncclComm_t>(shards_[r]->comm), shards_[r]->xstream);
+        }
+        const ncclResult_t st2 = rc.group_end();
+        if (st != ncclSuccess || st2 != ncclSuccess) {
+            // a communicator that saw a failed call is unusable: abort them all so that nothing stays parked in a collective
+            if (rc.comm_abort)
+                for (auto& s : shards_)
+                    if (s->comm) {
+                        (void)rc.comm_abort(static_cast<ncclComm_t>(s->comm));
+                        s->comm = nullptr;
+                    }
+            return make_err(FSGPU_ERR_DEVICE, std::string("ncclAllGather: ") + rc.error_string(st != ncclSuccess ? st : st2));
+        }
+    } else if (w > 1) {
+        for (uint32_t r = 0; r < w; ++r) {
+            Shard& s = *shards_[r];
+            SH_HIP(hipSetDevice(s.device));
+            SH_HIP(hipMemcpyAsync(static_cast<unsigned char*>(root.slot[slot].gathered.ptr) + (size_t)r * lbytes, s.slot[slot].packed.ptr,
+                                  lbytes, hipMemcpyDeviceToDevice, s.xstream));
+            SH_HIP(hipEventRecord(s.slot[slot].sent, s.xstream));
+        }
+        SH_HIP(hipSetDevice(root.device));
+        for (uint32_t r = 1; r < w; ++r) SH_HIP(hipStreamWaitEvent(root.xstream, shards_[r]->slot[slot].sent, 0));
+    }
+    // merge_partial_heaps across shards (search.rs:1704-1720) on the root; one shard: its own list is the answer, the merge
+    // only unpacks it.  Two-pass modes: the corpus-wide candidate selection, then the exact top-k (launch_two_pass_merge).
+    SH_HIP(hipSetDevice(root.device));
+    const uint64_t* lists = static_cast<const uint64_t*>(w > 1 ? root.slot[slot].gathered.ptr : root.slot[slot].packed.ptr);
+    uint32_t* d_rows = static_cast<uint32_t*>(rs.out_rows.ptr);
+    float* d_scores = static_cast<float*>(rs.out_scores.ptr);
+    uint32_t* d_counts = static_cast<uint32_t*>(rs.out_counts.ptr);
+    if (two_pass) {
+        // gather layout: shard s's block [approx nq*cc | exact nq*cc] at s * 2*nq*cc
+        const u64* pairs = reinterpret_cast<const u64*>(lists);
+        SH_HIP(launch_two_pass_merge(pairs, pairs + (size_t)nq * cc, w, (uint64_t)2 * nq * cc, nq, (uint32_t)cc, k, k, d_rows, d_scores,
+                                     d_counts, root.xstream));
+    } else {
+        SH_TRY(merge_packed_lists_device(root.device, lists, nq, w, k, k, (uint64_t)nq * k, k, d_rows, d_scores, d_counts, root.xstream));
+    }
+    const size_t qbytes = (size_t)nq * dim_ * 4, hbytes = (size_t)nq * k * 4, cbytes = (size_t)nq * 4;
+    unsigned char* stage = static_cast<unsigned char*>(rs.stage);
+    SH_HIP(hipMemcpyAsync(stage + qbytes, d_rows, hbytes, hipMemcpyDeviceToHost, root.xstream));
+    SH_HIP(hipMemcpyAsync(stage + qbytes + hbytes, d_scores, hbytes, hipMemcpyDeviceToHost, root.xstream));
+    SH_HIP(hipMemcpyAsync(stage + qbytes + 2 * hbytes, d_counts, cbytes, hipMemcpyDeviceToHost, root.xstream));
+    SH_HIP(hipEventRecord(rs.done, root.xstream));
+    return SearchError{};
+}
+
+SearchError ShardedIndex::begin(const Request& rq, uint32_t query_len, uint64_t* ticket) {
+    if (!ticket) return make_err(FSGPU_ERR_NULL_ARGUMENT, "ticket is null");
+    *ticket = 0;
     if (query_len != dim_)
         return make_err(FSGPU_ERR_DIMENSION_MISMATCH, "expected " + std::to_string(dim_) + ", found " + std::to_string(query_len));
-    if (nq == 0) return SearchError{};
-    if (k == 0 || nrows_ == 0) {
-        for (uint32_t q = 0; q < nq; ++q) out_counts[q] = 0;
-        return SearchError{};
+    const bool two_pass = rq.mode == kInt8TwoPass || rq.mode == kFourBitTwoPass;
+    const uint64_t cc = two_pass ? std::max<uint64_t>((uint64_t)rq.k * (rq.multiplier ? rq.multiplier : 1), rq.k) : rq.k;
+    if (rq.nq && rq.k && nrows_) {
+        if (dim_ % 8 != 0 || rq.k > 256)
+            return make_err(FSGPU_ERR_INVALID_CONFIG, "the sharded search exchanges the fused tiers' packed lists: k <= 256 and dim % 8 == 0");
+        if (two_pass && (cc > 256 || cc * shards_.size() > 1024))
+            return make_err(FSGPU_ERR_INVALID_CONFIG, "sharded two-pass: k * multiplier <= 256 and shards * k * multiplier <= 1024");
+        if (two_pass && rq.allow) return make_err(FSGPU_ERR_INVALID_CONFIG, "the two-pass searches take no filter (search.rs:514-661)");
     }
-    if (dim_ % 8 != 0 || k > 256)
-        return make_err(FSGPU_ERR_INVALID_CONFIG, "the sharded search exchanges the fused tiers' packed lists: k <= 256 and dim % 8 == 0");
+    const int slot = (int)(next_ticket_ % kSlots);
+    RootSlot& rs = root_[slot];
+    if (rs.pending) return make_err(FSGPU_ERR_INVALID_CONFIG, "two searches are already in flight on this handle: end one first");
     const uint32_t w = (uint32_t)shards_.size();
     Shard& root = *shards_[0];
+    rs.nq = rq.nq;
+    rs.k = rq.k;
+    rs.fallbacks = 0;
+    rs.ticket = next_ticket_;
+    if (rq.nq == 0 || rq.k == 0 || nrows_ == 0) {   // nothing to enqueue: end() reports empty results
+        rs.pending = true;
+        rs.nq = rq.k == 0 || nrows_ == 0 ? rq.nq : 0;
+        rs.k = 0;
+        *ticket = next_ticket_++;
+        return SearchError{};
+    }
+    if (two_pass) SH_TRY(ensure_quant_scale());
     // pinned staging: [queries | rows | scores | counts]
-    const size_t qbytes = (size_t)nq * dim_ * 4, hbytes = (size_t)nq * k * 4, cbytes = (size_t)nq * 4;
+    const size_t qbytes = (size_t)rq.nq * dim_ * 4, hbytes = (size_t)rq.nq * rq.k * 4, cbytes = (size_t)rq.nq * 4;
     const size_t need = qbytes + 2 * hbytes + cbytes;
     SH_HIP(hipSetDevice(root.device));
-    if (need > stage_bytes_) {
-        if (stage_host_) (void)hipHostFree(stage_host_);
-        stage_host_ = nullptr;
-        stage_bytes_ = 0;
-        SH_HIP(hipHostMalloc(&stage_host_, need, hipHostMallocPortable));
-        stage_bytes_ = need;
+    if (need > rs.stage_bytes) {
+        if (rs.stage) (void)hipHostFree(rs.stage);
+        rs.stage = nullptr;
+        rs.stage_bytes = 0;
+        SH_HIP(hipHostMalloc(&rs.stage, need, hipHostMallocPortable));
+        rs.stage_bytes = need;
     }
-    unsigned char* stage = static_cast<unsigned char*>(stage_host_);
-    std::memcpy(stage, queries, qbytes);
-    job_.queries = reinterpret_cast<const float*>(stage);
-    job_.nq = nq;
-    job_.k = k;
-    job_.batched = batched;
+    std::memcpy(rs.stage, rq.queries, qbytes);
+    // EVERY reservation a shard or the exchange needs happens here, on the calling thread, before any work is enqueued: a
+    // failed allocation must not leave some ranks inside a collective that others never enter
+    const size_t lbytes = (size_t)rq.nq * cc * 8 * (two_pass ? 2 : 1);
+    for (uint32_t r = 0; r < w; ++r) {
+        Slot& sl = shards_[r]->slot[slot];
+        SH_HIP(hipSetDevice(shards_[r]->device));
+        SH_TRY(sl.queries.reserve(qbytes));
+        SH_TRY(sl.packed.reserve(lbytes));
+        if (w > 1 && (use_rccl_ || r == 0)) SH_TRY(sl.gathered.reserve(lbytes * w));
+        if (rq.allow && shards_[r]->rows) SH_TRY(sl.allow.reserve((size_t)((shards_[r]->rows + 63) / 64) * 8));
+    }
+    SH_HIP(hipSetDevice(root.device));
+    SH_TRY(rs.out_rows.reserve(hbytes));
+    SH_TRY(rs.out_scores.reserve(hbytes));
+    SH_TRY(rs.out_counts.reserve(cbytes));
+    rs.allow_slices.clear();
+    if (rq.allow)
+        for (uint32_t r = 0; r < w; ++r) {
+            const std::vector<uint64_t> sl = shards_[r]->rows ? slice_bitmap(rq.allow, shards_[r]->lo, shards_[r]->rows) : std::vector<uint64_t>();
+            rs.allow_slices.insert(rs.allow_slices.end(), sl.begin(), sl.end());
+        }
+    job_.queries = static_cast<const float*>(rs.stage);
+    job_.nq = rq.nq;
+    job_.k = rq.k;
+    job_.multiplier = rq.multiplier;
+    job_.mode = rq.mode;
+    job_.slot = slot;
+    job_.has_allow = rq.allow != nullptr;
     for (auto& s : shards_) s->error = SearchError{};
-    if (!use_rccl_) SH_TRY(root.gathered.reserve((size_t)nq * k * 8 * w));  // before any shard copies into it
-    run_phase(1);
+    run_scans();
     for (auto& s : shards_)
-        if (!s->error.ok()) return s->error;
-    if (w > 1) {
-        run_phase(2);
-        for (auto& s : shards_)
-            if (!s->error.ok()) return s->error;
+        if (!s->error.ok()) return s->error;   // nothing has entered a collective yet
+    for (auto& s : shards_) rs.fallbacks += s->fallbacks;
+    SH_TRY(enqueue_exchange(slot, rq.nq, rq.k));
+    rs.pending = true;
+    *ticket = next_ticket_++;
+    return SearchError{};
+}
+
+SearchError ShardedIndex::end(uint64_t ticket, uint32_t* out_rows, float* out_scores, uint32_t* out_counts, uint32_t* fallbacks) {
+    if (fallbacks) *fallbacks = 0;
+    const int slot = (int)(ticket % kSlots);
+    RootSlot& rs = root_[slot];
+    if (!rs.pending || rs.ticket != ticket) return make_err(FSGPU_ERR_INVALID_CONFIG, "no search with this ticket is in flight");
+    rs.pending = false;
+    if (rs.k == 0) {   // k == 0, an empty index or an empty batch
+        for (uint32_t q = 0; q < rs.nq; ++q) out_counts[q] = 0;
+        return SearchError{};
     }
-    // merge_partial_heaps across shards (search.rs:1704-1720) on the root; one shard: its own list is the answer,
-    // the merge only unpacks it
-    SH_TRY(root.out_rows.reserve(hbytes));
-    SH_TRY(root.out_scores.reserve(hbytes));
-    SH_TRY(root.out_counts.reserve(cbytes));
-    const uint64_t* lists = static_cast<const uint64_t*>(w > 1 ? root.gathered.ptr : root.packed.ptr);
-    SH_TRY(merge_packed_lists_device(root.device, lists, nq, w, k, k, (uint64_t)nq * k, k, static_cast<uint32_t*>(root.out_rows.ptr),
-                                     static_cast<float*>(root.out_scores.ptr), static_cast<uint32_t*>(root.out_counts.ptr),
-                                     root.stream));
-    unsigned char* h_rows = stage + qbytes;
-    unsigned char* h_scores = h_rows + hbytes;
-    unsigned char* h_counts = h_scores + hbytes;
-    SH_HIP(hipMemcpyAsync(h_rows, root.out_rows.ptr, hbytes, hipMemcpyDeviceToHost, root.stream));
-    SH_HIP(hipMemcpyAsync(h_scores, root.out_scores.ptr, hbytes, hipMemcpyDeviceToHost, root.stream));
-    SH_HIP(hipMemcpyAsync(h_counts, root.out_counts.ptr, cbytes, hipMemcpyDeviceToHost, root.stream));
-    SH_HIP(hipStreamSynchronize(root.stream));
-    std::memcpy(out_rows, h_rows, hbytes);
-    std::memcpy(out_scores, h_scores, hbytes);
-    std::memcpy(out_counts, h_counts, cbytes);
-    if (fallbacks)
-        for (auto& s : shards_) *fallbacks += s->fallbacks;
+    SH_HIP(hipSetDevice(shards_[0]->device));
+    SH_HIP(hipEventSynchronize(rs.done));
+    const size_t qbytes = (size_t)rs.nq * dim_ * 4, hbytes = (size_t)rs.nq * rs.k * 4, cbytes = (size_t)rs.nq * 4;
+    const unsigned char* stage = static_cast<const unsigned char*>(rs.stage);
+    std::memcpy(out_rows, stage + qbytes, hbytes);
+    std::memcpy(out_scores, stage + qbytes + hbytes, hbytes);
+    std::memcpy(out_counts, stage + qbytes + 2 * hbytes, cbytes);
+    if (fallbacks) *fallbacks = rs.fallbacks;
+    return SearchError{};
+}
+
+SearchError ShardedIndex::search(const Request& rq, uint32_t query_len, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
+                                 uint32_t* fallbacks) {
+    uint64_t t = 0;
+    SH_TRY(begin(rq, query_len, &t));
+    return end(t, out_rows, out_scores, out_counts, fallbacks);
+}
+
+SearchError ShardedIndex::push_live_slices(const std::vector<uint64_t>& live) {
+    for (auto& s : shards_) {
+        if (!s->rows) continue;
+        const std::vector<uint64_t> bits = slice_bitmap(live.data(), s->lo, s->rows);
+        SH_TRY(s->index.set_live_bitmap(bits.data()));
+    }
+    return SearchError{};
+}
+
+SearchError ShardedIndex::set_live_bitmap(const uint64_t* live) {
+    for (const RootSlot& r : root_)
+        if (r.pending) return make_err(FSGPU_ERR_INVALID_CONFIG, "a search is in flight on this handle: end it first");
+    if (!live) {
+        for (auto& s : shards_) SH_TRY(s->index.set_live_bitmap(nullptr));
+        if (catalog_) SH_TRY(catalog_->set_live_bitmap(nullptr));
+        return SearchError{};
+    }
+    const std::vector<uint64_t> copy(live, live + (size_t)((nrows_ + 63) / 64));
+    if (catalog_) SH_TRY(catalog_->set_live_bitmap(copy.data()));
+    return push_live_slices(copy);
+}
+
+SearchError ShardedIndex::soft_delete(const char* doc_id, uint32_t len, int32_t* deleted) {
+    if (!catalog_) return make_err(FSGPU_ERR_INVALID_CONFIG, "index has no doc-id table");
+    SH_TRY(catalog_->soft_delete(doc_id, len, deleted));
+    if (*deleted && !catalog_->live_host().empty()) return push_live_slices(catalog_->live_host());
+    return SearchError{};
+}
+
+SearchError ShardedIndex::wal_append(const char* doc_id, uint32_t len, const float* vector, uint32_t vector_len) {
+    if (!catalog_) return make_err(FSGPU_ERR_INVALID_CONFIG, "index has no doc-id table");
+    SH_TRY(catalog_->wal_append(doc_id, len, vector, vector_len));   // tombstones the main row it supersedes (lib.rs:2665-2710)
+    if (!catalog_->live_host().empty()) return push_live_slices(catalog_->live_host());
+    return SearchError{};
+}
+
+SearchError ShardedIndex::doc_id_at(uint32_t row, const char** ptr, uint32_t* len) const {
+    if (!catalog_) return make_err(FSGPU_ERR_INVALID_CONFIG, "index has no doc-id table");
+    return catalog_->doc_id_at(row, ptr, len);
+}
+
+SearchError ShardedIndex::search_hits(const float* query, uint32_t query_len, uint32_t k, uint32_t* out_rows, float* out_scores,
+                                      uint32_t* out_count) {
+    if (!catalog_) return make_err(FSGPU_ERR_INVALID_CONFIG, "index has no doc-id table");
+    return catalog_->search_hits(query, query_len, k, out_rows, out_scores, out_count);   // its top-k comes from the shards
+}
+
+// dot_query_at over global rows: every row goes to the shard that owns it, one gather launch per shard touched.
+SearchError ShardedIndex::gather_dot(const float* query, uint32_t query_len, const uint32_t* rows, uint32_t n, float* out) {
+    if (query_len != dim_)
+        return make_err(FSGPU_ERR_DIMENSION_MISMATCH, "expected " + std::to_string(dim_) + ", found " + std::to_string(query_len));
+    std::vector<std::vector<uint32_t>> by_shard(shards_.size()), slot(shards_.size());
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t r = owner_of(rows[i]);
+        if (r >= shards_.size()) return make_err(FSGPU_ERR_INVALID_CONFIG, "row index out of range for dot_query_at");
+        by_shard[r].push_back(rows[i]);
+        slot[r].push_back(i);
+    }
+    std::vector<float> tmp;
+    for (uint32_t r = 0; r < shards_.size(); ++r) {
+        if (by_shard[r].empty()) continue;
+        tmp.resize(by_shard[r].size());
+        std::lock_guard<std::mutex> lock(shards_[r]->index.mutex());
+        SH_TRY(shards_[r]->index.gather_dot(query, query_len, by_shard[r].data(), (uint32_t)by_shard[r].size(), tmp.data()));
+        for (size_t x = 0; x < tmp.size(); ++x) out[slot[r][x]] = tmp[x];
+    }
     return SearchError{};
 }
 

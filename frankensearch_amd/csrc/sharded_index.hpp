@@ -4,9 +4,17 @@
 // (scan_parallel + merge_partial_heaps, crates/frankensearch-index/src/search.rs:1013-1036,1704-1720).  The same
 // shape across the GPUs of a node, inside the library so that a host makes one call: shard r owns the contiguous
 // rows [r*ceil(N/W), ...) and reports GLOBAL row ids (the (score, row) tie-break is shard-invariant); the queries are
-// replicated; every shard produces packed [nq, k] hits on its own stream from its own host thread; ONE ncclAllGather
-// (RCCL over xGMI, nq*k*8 bytes per shard) puts the W lists on every device; the root merges them with
-// merge_topk_kernel under the reference order.  No all-reduce, no row exchange.
+// replicated; every shard produces packed [nq, k] hits on its own stream; ONE ncclAllGather (RCCL over xGMI, nq*k*8 bytes
+// per shard) puts the W lists on every device; the root merges them with merge_topk_kernel under the reference order.
+// No row exchange.  The only other collective is the 4-byte ncclAllReduce(max) that gives the int8 / 4-bit quantisers their
+// ONE corpus-wide scale (simd.rs:1865-1886), once per index.
+//
+// A search is begin() + end().  begin() hands the queries to the shard workers (one host thread per shard: HIP's current
+// device is per thread and the batched scan blocks on its own stream), and as soon as their scans are ENQUEUED-and-returned the
+// calling thread enqueues the exchange — one ncclGroupStart .. ncclAllGather x W .. ncclGroupEnd on the shards' EXCHANGE
+// streams, each behind an event its shard's scan stream recorded — then the merge and the copy of the hits to pinned host
+// memory on the root's exchange stream.  Nothing between scan, all-gather and merge waits on the host; end() waits for ONE
+// event.  Two tickets may be in flight, so the exchange + merge of search i run underneath the scan of search i + 1.
 #pragma once
 
 #include <condition_variable>
@@ -33,11 +41,36 @@ class ShardedIndex {
                           const uint64_t* live, int32_t exchange);
     SearchError init_device(const int32_t* devices, uint32_t ndev, uint32_t dim, const uint64_t* shard_rows,
                             const void* const* slabs_dev, const uint64_t* const* live_dev, int32_t exchange);
+    // VectorIndex::open for an FSVI v1 file (F16 slab), rows split over the devices; keeps the record table / doc ids / WAL
+    SearchError open_fsvi(const char* path, const int32_t* devices, uint32_t ndev, int32_t exchange);
 
-    // search_top_k over nq host queries: exact kernels (batched = false) or the matrix-core batched path (results
-    // identical).  k <= 256, dim % 8 == 0 (the fused tiers; the packed lists are what travels).
-    SearchError search(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k, bool batched, uint32_t* out_rows,
-                       float* out_scores, uint32_t* out_counts, uint32_t* fallbacks);
+    // what a search runs on every shard before the lists are exchanged
+    enum Mode : int32_t { kExact = 0, kBatched = 1, kInt8TwoPass = 2, kFourBitTwoPass = 3 };
+    struct Request {
+        const float* queries = nullptr;   // [nq, dim] host
+        uint32_t nq = 0, k = 0;
+        Mode mode = kExact;
+        uint32_t multiplier = 0;          // candidate_multiplier of the two-pass modes
+        const uint64_t* allow = nullptr;  // [ceil(N/64)] index-wide allow bitmap (a precomputed SearchFilter), may be null
+    };
+    // search_top_k{,_batched,_int8_two_pass,...} over nq host queries.  k <= 256, dim % 8 == 0 (the fused tiers; the packed
+    // lists are what travels).  begin() returns a ticket; at most two may be pending; end() in ticket order.
+    SearchError begin(const Request& rq, uint32_t query_len, uint64_t* ticket);
+    SearchError end(uint64_t ticket, uint32_t* out_rows, float* out_scores, uint32_t* out_counts, uint32_t* fallbacks);
+    SearchError search(const Request& rq, uint32_t query_len, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
+                       uint32_t* fallbacks);
+
+    // index-wide tombstone bitmap (1 bit per row, set = live): split per shard
+    SearchError set_live_bitmap(const uint64_t* live);
+    // VectorIndex::soft_delete / append / doc ids / search_top_k with WAL + dedup: need open_fsvi's tables
+    SearchError soft_delete(const char* doc_id, uint32_t len, int32_t* deleted);
+    SearchError wal_append(const char* doc_id, uint32_t len, const float* vector, uint32_t vector_len);
+    SearchError doc_id_at(uint32_t row, const char** ptr, uint32_t* len) const;
+    SearchError search_hits(const float* query, uint32_t query_len, uint32_t k, uint32_t* out_rows, float* out_scores,
+                            uint32_t* out_count);
+    uint64_t wal_record_count() const { return catalog_ ? catalog_->wal_record_count() : 0; }
+    // dot_query_at over global row ids, routed to the owning shards
+    SearchError gather_dot(const float* query, uint32_t query_len, const uint32_t* rows, uint32_t n, float* out);
 
     uint64_t record_count() const { return nrows_; }
     uint32_t dimension() const { return dim_; }
@@ -45,46 +78,72 @@ class ShardedIndex {
     int32_t exchange_mode() const { return use_rccl_ ? 1 : 2; }
     bool shard_range(uint32_t shard, uint64_t* lo, uint64_t* hi) const;
     void set_hreduce(int32_t mode);
+    // the corpus-wide max-abs the quantised copies of every shard are built from (0 until a two-pass search asked for it)
+    float quant_scale_max() const { return quant_max_; }
     std::mutex& mutex() { return call_mu_; }
 
   private:
+    static constexpr int kSlots = 2;   // tickets in flight
+    struct Slot {
+        DeviceBuffer queries, packed, gathered, allow;
+        hipEvent_t scan_done = nullptr;   // recorded on the scan stream when the shard's search call returned
+        hipEvent_t sent = nullptr;        // peer copies: this shard's list has reached the root's gather buffer
+    };
     struct Shard {
         int device = -1;
         uint64_t lo = 0, rows = 0;
         VectorIndex index;
-        hipStream_t stream = nullptr;
-        DeviceBuffer queries, packed, gathered, out_rows, out_scores, out_counts;
-        void* comm = nullptr;  // ncclComm_t
+        hipStream_t stream = nullptr;    // scan
+        hipStream_t xstream = nullptr;   // exchange (+ merge and D2H on the root)
+        Slot slot[kSlots];
+        void* comm = nullptr;            // ncclComm_t
         std::thread worker;
         SearchError error;
         uint32_t fallbacks = 0;
     };
+    struct RootSlot {
+        DeviceBuffer out_rows, out_scores, out_counts;
+        void* stage = nullptr;           // pinned: [queries | rows | scores | counts]
+        size_t stage_bytes = 0;
+        hipEvent_t done = nullptr;
+        bool pending = false;
+        uint64_t ticket = 0;
+        uint32_t nq = 0, k = 0, fallbacks = 0;
+        std::vector<uint64_t> allow_slices;   // per-shard slices of the request's allow bitmap, back to back (host)
+    };
     struct Job {
         const float* queries = nullptr;  // pinned staging
-        uint32_t nq = 0, k = 0;
-        bool batched = false;
+        uint32_t nq = 0, k = 0, multiplier = 0;
+        Mode mode = kExact;
+        int slot = 0;
+        bool has_allow = false;
     };
 
     SearchError finish_init(int32_t exchange);
     void worker_main(uint32_t r);
-    void run_phase(int phase);  // wakes the workers for one phase of the current job and waits for all of them
-    SearchError shard_search(Shard& s);
-    SearchError shard_exchange(uint32_t r);
+    void run_scans();                    // wakes the workers for the current job and waits until every scan call has returned
+    SearchError shard_search(Shard& s, uint32_t r);
+    SearchError enqueue_exchange(int slot, uint32_t nq, uint32_t k);
+    SearchError ensure_quant_scale();    // corpus-wide max-abs: ncclAllReduce(max) / host max, once
+    SearchError push_live_slices(const std::vector<uint64_t>& live);
+    uint32_t owner_of(uint64_t row) const;
 
     uint32_t dim_ = 0;
     uint64_t nrows_ = 0;
     std::vector<std::unique_ptr<Shard>> shards_;
+    RootSlot root_[kSlots];
     bool use_rccl_ = false;
-    // one search at a time per handle (the workers and staging buffers are per handle)
+    bool quant_ready_ = false;
+    float quant_max_ = 0.f;
+    std::unique_ptr<VectorIndex> catalog_;   // open_fsvi: record table, doc ids, tombstones, WAL (no device state)
+    // one begin/end at a time per handle (the workers and staging buffers are per handle)
     std::mutex call_mu_;
-    void* stage_host_ = nullptr;  // pinned: queries in, hits out
-    size_t stage_bytes_ = 0;
+    uint64_t next_ticket_ = 1;
     Job job_;
-    // phase hand-off between the calling thread and the shard workers
+    // hand-off between the calling thread and the shard workers
     std::mutex mu_;
     std::condition_variable cv_work_, cv_done_;
     uint64_t generation_ = 0;
-    int phase_ = 0;
     uint32_t pending_ = 0;
     bool stop_ = false;
 };

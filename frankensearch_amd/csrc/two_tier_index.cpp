@@ -1,0 +1,156 @@
+// two_tier_index.cpp — see two_tier_index.hpp.
+#include "two_tier_index.hpp"
+
+#include <cstring>
+#include <mutex>
+#include <string_view>
+
+#include "../../include/fsgpu.h"
+
+namespace fsgpu {
+
+namespace {
+SearchError err(int32_t code, std::string detail) {
+    SearchError e;
+    e.code = code;
+    e.detail = std::move(detail);
+    return e;
+}
+std::string_view doc_of(const VectorIndex& idx, uint64_t row) {
+    const char* p = nullptr;
+    uint32_t len = 0;
+    (void)idx.doc_id_at((uint32_t)row, &p, &len);
+    return std::string_view(p, len);
+}
+}  // namespace
+
+SearchError QualityAlignment::build(const VectorIndex& fast, const VectorIndex& quality) {
+    const uint64_t f_count = fast.record_count(), q_count = quality.record_count();
+    fast_rows_ = f_count;
+    map_.clear();
+    unmatched_ = 0;
+    if (!fast.has_doc_ids() || !quality.has_doc_ids()) {
+        // raw slabs: row i of one tier is row i of the other (the writer emits both tiers from one document order)
+        kind_ = kAligned;
+        if (q_count < f_count) {   // fast rows past the quality tier have no quality vector
+            kind_ = kMapping;
+            map_.resize(f_count);
+            for (uint64_t i = 0; i < f_count; ++i) map_[i] = i < q_count ? (int64_t)i : -1;
+        }
+        return SearchError{};
+    }
+    kind_ = kAligned;
+    uint64_t f = 0, q = 0;
+    auto ensure_mapping = [&](uint64_t upto) {
+        if (kind_ == kAligned) {
+            kind_ = kMapping;
+            map_.resize(upto);
+            for (uint64_t i = 0; i < upto; ++i) map_[i] = (int64_t)i;
+        }
+    };
+    auto push_none = [&](uint64_t at) {
+        ensure_mapping(at);
+        map_.push_back(-1);
+    };
+    while (f < f_count && q < q_count) {
+        if (fast.row_tombstoned(f)) {
+            push_none(f);
+            ++f;
+            continue;
+        }
+        if (quality.row_tombstoned(q)) {
+            ++q;
+            continue;
+        }
+        if (kind_ == kAligned && f != q) ensure_mapping(f);
+        const uint64_t fh = fast.doc_hash_at(f), qh = quality.doc_hash_at(q);
+        if (fh < qh) {            // fast has the doc, quality lacks it
+            push_none(f);
+            ++f;
+        } else if (fh > qh) {
+            ++unmatched_;
+            ++q;
+        } else {
+            const std::string_view fd = doc_of(fast, f), qd = doc_of(quality, q);
+            const int c = fd.compare(qd);
+            if (c == 0) {
+                if (kind_ == kMapping) map_.push_back((int64_t)q);
+                ++f;
+                ++q;
+            } else if (c < 0) {
+                push_none(f);
+                ++f;
+            } else {
+                ++unmatched_;
+                ++q;
+            }
+        }
+    }
+    if (f < f_count) {            // trailing fast docs
+        ensure_mapping(f);
+        map_.resize(f_count, -1);
+    }
+    for (; q < q_count; ++q)
+        if (!quality.row_tombstoned(q)) ++unmatched_;
+    return SearchError{};
+}
+
+int64_t QualityAlignment::quality_row(uint64_t fast_row) const {
+    if (fast_row >= fast_rows_) return -1;   // score_quality_for_fast_index: fast_idx >= doc_count -> None
+    switch (kind_) {
+        case kAligned: return (int64_t)fast_row;
+        case kMapping: return fast_row < map_.size() ? map_[fast_row] : -1;
+        default: return -1;
+    }
+}
+
+SearchError quality_scores_for_hits(const VectorIndex& fast, VectorIndex& quality, const QualityAlignment& align,
+                                    const float* query, uint32_t query_len, const HitRef* hits, uint32_t n, float* out_scores,
+                                    uint8_t* out_present) {
+    if (query_len != quality.dimension())
+        return err(FSGPU_ERR_DIMENSION_MISMATCH,
+                   "expected " + std::to_string(quality.dimension()) + ", found " + std::to_string(query_len));
+    std::lock_guard<std::mutex> lock(quality.mutex());
+    std::vector<uint32_t> rows, slot;
+    rows.reserve(n);
+    slot.reserve(n);
+    const bool ids = quality.has_doc_ids();
+    for (uint32_t i = 0; i < n; ++i) {
+        out_present[i] = 0;
+        out_scores[i] = 0.0f;
+        const HitRef& h = hits[i];
+        // the quality WAL's latest entry of this document wins (resident f32 vector, host dot in the reference's order)
+        if (ids && h.doc_id) {
+            const int64_t w = quality.wal_latest(h.doc_id, h.doc_id_len);
+            if (w >= 0) {
+                out_scores[i] = quality.wal_dot((size_t)w, query);
+                out_present[i] = 1;
+                continue;
+            }
+        }
+        int64_t fast_idx = -1;
+        if (h.index == 0xffffffffu) {
+            if (fast.has_doc_ids() && h.doc_id) fast_idx = fast.find_index_by_doc_id(h.doc_id, h.doc_id_len);
+        } else if (h.index < fast.record_count()) {
+            fast_idx = h.index;
+        }
+        int64_t qrow = fast_idx >= 0 ? align.quality_row((uint64_t)fast_idx) : -1;
+        if (qrow < 0 && ids && h.doc_id) qrow = quality.find_index_by_doc_id(h.doc_id, h.doc_id_len);
+        if (qrow >= 0 && (uint64_t)qrow < quality.record_count()) {
+            rows.push_back((uint32_t)qrow);
+            slot.push_back(i);
+        }
+    }
+    if (!rows.empty()) {
+        std::vector<float> dots(rows.size());
+        SearchError e = quality.gather_dot(query, query_len, rows.data(), (uint32_t)rows.size(), dots.data());
+        if (!e.ok()) return e;
+        for (size_t j = 0; j < rows.size(); ++j) {
+            out_scores[slot[j]] = dots[j];
+            out_present[slot[j]] = 1;
+        }
+    }
+    return SearchError{};
+}
+
+}  // namespace fsgpu

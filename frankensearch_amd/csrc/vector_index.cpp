@@ -220,6 +220,10 @@ SearchError VectorIndex::set_live_bitmap(const uint64_t* live) {
         live_host_.clear();
         return ok();
     }
+    if (catalog_only_) {   // (the shards hold the device copies: sharded_index.cpp pushes the slices)
+        live_host_.assign(live, live + (size_t)((nrows_ + 63) / 64));
+        return ok();
+    }
     FSGPU_HIP(hipSetDevice(device_));
     const size_t words = (size_t)((nrows_ + 63) / 64);
     live_host_.assign(live, live + words);
@@ -390,7 +394,16 @@ bool valid_utf8(const uint8_t* p, size_t n) {
 }
 }  // namespace
 
-SearchError VectorIndex::open_fsvi(const char* path, int device) {
+SearchError VectorIndex::open_fsvi(const char* path, int device) { return open_fsvi_impl(path, device, nullptr); }
+
+// The same reader for a row-SHARDED index (sharded_index.cpp): this object keeps the record table, the doc-id strings, the
+// tombstone bitmap and the WAL of the whole file — it resolves, deduplicates and shadows hits — while the slab goes to the shards.
+SearchError VectorIndex::open_fsvi_catalog(const char* path, FsviImage* image) {
+    if (!image) return make_error(FSGPU_ERR_NULL_ARGUMENT, "image is null");
+    return open_fsvi_impl(path, -1, image);
+}
+
+SearchError VectorIndex::open_fsvi_impl(const char* path, int device, FsviImage* image) {
     if (!path) return make_error(FSGPU_ERR_NULL_ARGUMENT, "path is null");
     FILE* f = std::fopen(path, "rb");
     if (!f) return make_error(FSGPU_ERR_IO, std::string("cannot open ") + path);
@@ -475,6 +488,20 @@ SearchError VectorIndex::open_fsvi(const char* path, int device) {
         if ((flags & 0x0001u) == 0) live[(size_t)(r >> 6)] |= 1ull << (r & 63);
     }
     doc_offsets_[(size_t)record_count] = doc_blob_.size();
+    if (image) {   // catalog of a sharded index: no device copy here
+        catalog_only_ = true;
+        dim_ = dim;
+        nrows_ = record_count;
+        row_base_ = 0;
+        f32_ = quant == 0;
+        live_host_ = live;
+        image->dim = dim;
+        image->nrows = record_count;
+        image->f32_rows = quant == 0;
+        image->slab_offset = (size_t)vectors_offset;
+        image->bytes = std::move(data);
+        return ok();
+    }
     return init_host(device, dim, record_count, data.data() + vectors_offset, live.data(), 0, quant == 0);
 }
 
@@ -599,7 +626,8 @@ SearchError VectorIndex::search_hits(const float* query, uint32_t query_len, uin
         std::vector<uint32_t> rows(k);
         std::vector<float> scores(k);
         uint32_t count = 0;
-        FSGPU_TRY(search_top_k(query, 1, query_len, k, nullptr, rows.data(), scores.data(), &count));
+        if (topk_override) FSGPU_TRY(topk_override(query, k, rows.data(), scores.data(), &count));   // the shards' merged top-k
+        else FSGPU_TRY(search_top_k(query, 1, query_len, k, nullptr, rows.data(), scores.data(), &count));
         for (uint32_t i = 0; i < count; ++i) cand.push_back(Cand{rows[i], scores[i]});
     }
     for (size_t w = 0; w < wal_.size(); ++w) {
@@ -646,6 +674,29 @@ SearchError VectorIndex::search_hits(const float* query, uint32_t query_len, uin
     }
     *out_count = n;
     return ok();
+}
+
+int64_t VectorIndex::find_index_by_doc_id(const char* doc_id, uint32_t len) const {
+    if (doc_offsets_.empty()) return -1;
+    const uint64_t h = fnv1a(doc_id, len);
+    auto lo = std::lower_bound(doc_hashes_.begin(), doc_hashes_.end(), h);
+    for (auto it = lo; it != doc_hashes_.end() && *it == h; ++it) {
+        const size_t r = (size_t)(it - doc_hashes_.begin());
+        if (row_tombstoned(r)) continue;
+        const size_t dl = (size_t)(doc_offsets_[r + 1] - doc_offsets_[r]);
+        if (dl == len && std::memcmp(doc_blob_.data() + doc_offsets_[r], doc_id, len) == 0) return (int64_t)r;
+    }
+    return -1;
+}
+
+int64_t VectorIndex::wal_latest(const char* doc_id, uint32_t len) const {
+    for (size_t i = wal_.size(); i-- > 0;)
+        if (wal_[i].doc_id.size() == len && std::memcmp(wal_[i].doc_id.data(), doc_id, len) == 0) return (int64_t)i;
+    return -1;
+}
+
+float VectorIndex::wal_dot(size_t wal_index, const float* query) const {
+    return dot_f32_f32(wal_[wal_index].embedding.data(), query, dim_, hreduce);
 }
 
 SearchError VectorIndex::soft_delete(const char* doc_id, uint32_t len, int32_t* deleted) {
@@ -1029,6 +1080,23 @@ SearchError VectorIndex::gather_dot(const float* query, uint32_t query_len, cons
             return make_error(FSGPU_ERR_INVALID_CONFIG, "row index out of range for dot_query_at");
     FSGPU_HIP(hipSetDevice(device_));
     FSGPU_TRY(ws_queries_.reserve((size_t)dim_ * 4));
+    // Latency path (quality_scores_for_hits re-scores a few dozen rows per query): query through the pinned staging block, the
+    // row ids read and the dots written by the kernel straight in pinned host memory — one H2D copy, one launch, one synchronisation.
+    const size_t qbytes = (size_t)dim_ * 4, qpad = (qbytes + 63) & ~(size_t)63;
+    if (qpad + (size_t)n * 8 + 128 <= kPinnedIoBytes && pinned_io() != nullptr) {
+        unsigned char* io = static_cast<unsigned char*>(io_host_);
+        float* q_pin = reinterpret_cast<float*>(io);
+        uint32_t* rows_pin = reinterpret_cast<uint32_t*>(io + qpad);
+        float* out_pin = reinterpret_cast<float*>(rows_pin + n);
+        std::memcpy(q_pin, query, qbytes);
+        std::memcpy(rows_pin, rows, (size_t)n * 4);
+        FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, q_pin, qbytes, hipMemcpyHostToDevice, stream_));
+        ScanArgs g = base_args(static_cast<const float*>(ws_queries_.ptr), nullptr);
+        FSGPU_HIP(gather_dot_any(g, rows_pin, n, out_pin, stream_));
+        FSGPU_HIP(hipStreamSynchronize(stream_));
+        std::memcpy(out, out_pin, (size_t)n * 4);
+        return ok();
+    }
     FSGPU_TRY(ws_gather_rows_.reserve((size_t)n * 4));
     FSGPU_TRY(ws_gather_out_.reserve((size_t)n * 4));
     FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, query, (size_t)dim_ * 4, hipMemcpyHostToDevice, stream_));
@@ -1093,7 +1161,7 @@ SearchError VectorIndex::int8_filter_bound(const float* queries, uint32_t nq, ui
     if (!i8_ready_) {
         FSGPU_TRY(i8_slab_.reserve((size_t)nrows_ * dim_));
         FSGPU_TRY(i8_max_.reserve(4));
-        FSGPU_HIP(launch_quantize_slab_i8(slab_dev_, (size_t)nrows_ * dim_, static_cast<unsigned int*>(i8_max_.ptr), i8_slab_.ptr, stream_));
+        FSGPU_HIP(launch_quantize_slab_i8(slab_dev_, (size_t)nrows_ * dim_, static_cast<unsigned int*>(i8_max_.ptr), i8_slab_.ptr, stream_, quant_max_ready_));
         i8_ready_ = true;
     }
     if (!i8_stats_ready_) {
@@ -1127,6 +1195,23 @@ SearchError VectorIndex::int8_filter_bound(const float* queries, uint32_t nq, ui
     return ok();
 }
 
+// The shard's own max-abs into the quantisers' scale word (device), for a sharded index to reduce across shards
+// (ncclAllReduce(max), SURVEY 8f-1: the reference quantises with ONE corpus-wide scale, simd.rs:1865-1886).
+SearchError VectorIndex::compute_local_quant_max(unsigned int** max_bits_dev, hipStream_t stream) {
+    FSGPU_HIP(hipSetDevice(device_));
+    FSGPU_TRY(i8_max_.reserve(4));
+    if (nrows_ == 0 || f32_) FSGPU_HIP(hipMemsetAsync(i8_max_.ptr, 0, 4, stream));
+    else FSGPU_HIP(launch_slab_maxabs(slab_dev_, (size_t)nrows_ * dim_, static_cast<unsigned int*>(i8_max_.ptr), stream));
+    *max_bits_dev = static_cast<unsigned int*>(i8_max_.ptr);
+    return ok();
+}
+
+// The scale word now holds the CORPUS-wide max-abs: every quantised copy is (re)built from it, on first use.
+void VectorIndex::adopt_global_quant_max() {
+    quant_max_ready_ = true;
+    i8_ready_ = n4_ready_ = n4u_ready_ = i8_stats_ready_ = false;
+}
+
 // int8 pass 1 on the matrix cores for a whole batch (exact integer scores), exact f16 rescore, top-k: the batched form of
 // search_top_k_int8_two_pass (search.rs:514-661).  multiplier 0 counts as 1, as in the reference.
 // bits = 4: the batched form of search_top_k_4bit_two_pass (search.rs:876-946) — the same pipeline over the 4-bit levels, kept one
@@ -1137,6 +1222,38 @@ SearchError VectorIndex::search_top_k_int8_batched_device(const float* queries_d
                                                           hipStream_t stream, uint32_t* fallbacks, int bits) {
     return batched_impl(queries_dev, nq, query_len, k, nullptr, out_rows_dev, out_scores_dev, out_counts_dev, stream,
                         fallbacks, nullptr, multiplier ? multiplier : 1, 0, false, nullptr, bits == 4 ? 4 : 8);
+}
+
+SearchError VectorIndex::two_pass_candidates_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
+                                                    uint32_t multiplier, int bits, uint64_t* approx_out_dev, uint64_t* exact_out_dev,
+                                                    hipStream_t stream, uint32_t* fallbacks) {
+    if (fallbacks) *fallbacks = 0;
+    FSGPU_TRY(ensure_query_dimension(query_len));
+    if (nq == 0) return ok();
+    const uint64_t mult = multiplier ? multiplier : 1;
+    const uint64_t cc = std::max<uint64_t>((uint64_t)k * mult, k);
+    if (cc > 256 || k == 0) return make_error(FSGPU_ERR_INVALID_CONFIG, "sharded two-pass: 1 <= k, k * multiplier <= 256");
+    FSGPU_HIP(hipSetDevice(device_));
+    FSGPU_HIP(hipMemsetAsync(approx_out_dev, 0xff, (size_t)nq * cc * 8, stream));
+    FSGPU_HIP(hipMemsetAsync(exact_out_dev, 0xff, (size_t)nq * cc * 8, stream));
+    if (nrows_ == 0 || f32_) {
+        FSGPU_HIP(hipStreamSynchronize(stream));
+        return f32_ ? make_error(FSGPU_ERR_INVALID_CONFIG, "two-pass searches need an F16 slab") : ok();
+    }
+    FSGPU_TRY(mf_io_.reserve((size_t)nq * (k * 8 + 4)));   // the shard-local top-k the pass also produces (not used by the root)
+    uint32_t* rows = static_cast<uint32_t*>(mf_io_.ptr);
+    float* scores = reinterpret_cast<float*>(rows + (size_t)nq * k);
+    uint32_t* counts = reinterpret_cast<uint32_t*>(scores + (size_t)nq * k);
+    tp_approx_out_ = reinterpret_cast<u64*>(approx_out_dev);
+    tp_exact_out_ = reinterpret_cast<u64*>(exact_out_dev);
+    tp_stride_ = (uint32_t)cc;
+    const SearchError e = batched_impl(queries_dev, nq, query_len, k, nullptr, rows, scores, counts, stream, fallbacks, nullptr,
+                                       (uint32_t)mult, 0, false, nullptr, bits == 4 ? 4 : 8);
+    tp_approx_out_ = tp_exact_out_ = nullptr;
+    tp_stride_ = 0;
+    FSGPU_TRY(e);
+    FSGPU_HIP(hipStreamSynchronize(stream));
+    return ok();
 }
 
 // int8_mult == 0: f16 slab, f16-rounded queries, approximate scores + proven margin (mfma_scan.hip header).
@@ -1222,7 +1339,8 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         FSGPU_HIP(hipStreamSynchronize(stream));
         for (uint32_t i = 0; i < nq; ++i)
             FSGPU_TRY(quantized_two_pass(q.data() + (size_t)i * dim_, dim_, k, int8_mult, bits, rw.data() + (size_t)i * k,
-                                         sc.data() + (size_t)i * k, &cnt[i]));
+                                         sc.data() + (size_t)i * k, &cnt[i], tp_approx_out_ ? tp_approx_out_ + (size_t)i * tp_stride_ : nullptr,
+                                         tp_exact_out_ ? tp_exact_out_ + (size_t)i * tp_stride_ : nullptr));
         if (out_rows_dev) FSGPU_HIP(hipMemcpyAsync(out_rows_dev, rw.data(), rw.size() * 4, hipMemcpyHostToDevice, stream));
         if (out_scores_dev) FSGPU_HIP(hipMemcpyAsync(out_scores_dev, sc.data(), sc.size() * 4, hipMemcpyHostToDevice, stream));
         if (out_counts_dev) FSGPU_HIP(hipMemcpyAsync(out_counts_dev, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice, stream));
@@ -1247,14 +1365,14 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         FSGPU_TRY(n4u_slab_.reserve((size_t)nrows_ * dim_));
         FSGPU_TRY(i8_max_.reserve(4));
         FSGPU_HIP(launch_quantize_slab_4bit_levels(slab_dev_, (size_t)nrows_ * dim_, static_cast<unsigned int*>(i8_max_.ptr),
-                                                   n4u_slab_.ptr, stream));
+                                                   n4u_slab_.ptr, stream, quant_max_ready_));
         n4u_ready_ = true;
     }
     if (i8 && bits != 4 && !i8_ready_) {  // VectorIndex::int8_slab(): built lazily, once
         FSGPU_TRY(i8_slab_.reserve((size_t)nrows_ * dim_));
         FSGPU_TRY(i8_max_.reserve(4));
         FSGPU_HIP(launch_quantize_slab_i8(slab_dev_, (size_t)nrows_ * dim_, static_cast<unsigned int*>(i8_max_.ptr),
-                                          i8_slab_.ptr, stream));
+                                          i8_slab_.ptr, stream, quant_max_ready_));
         i8_ready_ = true;
     }
     if (i8f && !i8_stats_ready_) {
@@ -1583,6 +1701,11 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         sb.out_scores = out_scores_dev ? out_scores_dev + (size_t)g0 * k : nullptr;
         sb.out_counts = out_counts_dev ? out_counts_dev + g0 : nullptr;
         sb.out_packed = out_packed_dev ? reinterpret_cast<u64*>(out_packed_dev) + (size_t)g0 * k : nullptr;
+        if (int8_mult && tp_approx_out_) {   // a sharded index's shard: the candidate pairs themselves (two_pass_candidates_device)
+            sb.cand_approx_out = tp_approx_out_ + (size_t)g0 * tp_stride_;
+            sb.cand_exact_out = tp_exact_out_ + (size_t)g0 * tp_stride_;
+            sb.cand_out_stride = tp_stride_;
+        }
         FSGPU_HIP(launch_select(sb, (int)ng, stream));
         if (second_chance) {   // queries whose candidates did not fit the pool: the sorted finish over the same lists (others return at once)
             sb.big_pool = 1;
@@ -1624,7 +1747,9 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
             FSGPU_HIP(hipMemcpyAsync(qh.data(), queries_dev + (size_t)i * dim_, (size_t)dim_ * 4, hipMemcpyDeviceToHost, stream));
             FSGPU_HIP(hipStreamSynchronize(stream));
             std::fill(rw.begin(), rw.end(), 0xffffffffu);
-            FSGPU_TRY(quantized_two_pass(qh.data(), dim_, k, int8_mult, bits, rw.data(), sc.data(), &cnt));
+            FSGPU_TRY(quantized_two_pass(qh.data(), dim_, k, int8_mult, bits, rw.data(), sc.data(), &cnt,
+                                         tp_approx_out_ ? tp_approx_out_ + (size_t)i * tp_stride_ : nullptr,
+                                         tp_exact_out_ ? tp_exact_out_ + (size_t)i * tp_stride_ : nullptr));
             if (out_rows_dev) FSGPU_HIP(hipMemcpyAsync(out_rows_dev + (size_t)i * k, rw.data(), (size_t)k * 4, hipMemcpyHostToDevice, stream));
             if (out_scores_dev) FSGPU_HIP(hipMemcpyAsync(out_scores_dev + (size_t)i * k, sc.data(), (size_t)k * 4, hipMemcpyHostToDevice, stream));
             if (out_counts_dev) FSGPU_HIP(hipMemcpyAsync(out_counts_dev + i, &cnt, 4, hipMemcpyHostToDevice, stream));
@@ -1781,6 +1906,8 @@ void VectorIndex::sync_replicas() {
         v->live_dev_ = live_dev_;
         v->hreduce = hreduce;
         v->variant = variant;
+        v->int8_latency = int8_latency;       // (every lane answers a call the same way, whichever one it lands on)
+        v->batched_filter = batched_filter;
     }
 }
 
@@ -1986,10 +2113,11 @@ SearchError VectorIndex::search_top_k_4bit_two_pass(const float* query, uint32_t
 // Shared body of the int8 (bits = 8) and 4-bit (bits = 4) two-pass searches: quantised pass 1 over the lazily built
 // slab, exact f16 rescore of the candidates, best-first selection of k.
 SearchError VectorIndex::quantized_two_pass(const float* query, uint32_t query_len, uint32_t k, uint32_t multiplier,
-                                            int bits, uint32_t* out_rows, float* out_scores, uint32_t* out_count) {
+                                            int bits, uint32_t* out_rows, float* out_scores, uint32_t* out_count,
+                                            u64* approx_out_dev, u64* exact_out_dev) {
     *out_count = 0;
     // anything the fast path does not cover goes through the exact search (search.rs:579-585)
-    if (k == 0 || nrows_ == 0 || !wal_.empty() || f32_) {  // ... || quantization != F16
+    if (!approx_out_dev && (k == 0 || nrows_ == 0 || !wal_.empty() || f32_)) {  // ... || quantization != F16
         if (has_doc_ids()) return search_hits(query, query_len, k, out_rows, out_scores, out_count);
         FSGPU_TRY(ensure_query_dimension(query_len));
         if (k == 0 || nrows_ == 0) return ok();
@@ -2003,14 +2131,14 @@ SearchError VectorIndex::quantized_two_pass(const float* query, uint32_t query_l
         FSGPU_TRY(i8_slab_.reserve(n * dim_));
         FSGPU_TRY(i8_max_.reserve(4));
         FSGPU_HIP(launch_quantize_slab_i8(slab_dev_, n * dim_, static_cast<unsigned int*>(i8_max_.ptr), i8_slab_.ptr,
-                                          stream_));
+                                          stream_, quant_max_ready_));
         i8_ready_ = true;
     }
     if (bits == 4 && !n4_ready_) {  // VectorIndex::nibbles_slab() (search.rs:988-1000)
         FSGPU_TRY(n4_slab_.reserve(n * qbytes));
         FSGPU_TRY(i8_max_.reserve(4));
         FSGPU_HIP(launch_pack_slab_4bit(slab_dev_, nrows_, dim_, static_cast<unsigned int*>(i8_max_.ptr), n4_slab_.ptr,
-                                        stream_));
+                                        stream_, quant_max_ready_));
         n4_ready_ = true;
     }
     const void* qslab = bits == 8 ? i8_slab_.ptr : n4_slab_.ptr;
@@ -2111,9 +2239,10 @@ SearchError VectorIndex::quantized_two_pass(const float* query, uint32_t query_l
         m.out_rows = cand_rows;
         m.out_scores = nullptr;
         m.out_counts = nullptr;
-        m.out_packed = nullptr;
+        m.out_packed = approx_out_dev;   // (a sharded index's root wants the pass-1 entries themselves)
         FSGPU_HIP(launch_merge_topk(m, 1, stream_));
     } else {
+        if (approx_out_dev) return make_error(FSGPU_ERR_INVALID_CONFIG, "sharded two-pass: k * multiplier <= 256 and a fused dimension");
         FSGPU_TRY(ws_keys_a_.reserve(n * 8));
         FSGPU_TRY(ws_keys_b_.reserve(n * 8));
         size_t tmp_bytes = 0;
@@ -2131,6 +2260,7 @@ SearchError VectorIndex::quantized_two_pass(const float* query, uint32_t query_l
     FSGPU_HIP(hipMemsetAsync(cand_scores, 0, (size_t)cc * 4, stream_));
     FSGPU_HIP(launch_gather_dot(a, cand_rows, cc, cand_scores, stream_));
     FSGPU_HIP(launch_pack_hits(cand_rows, cand_scores, cc, cand_packed, stream_));
+    if (exact_out_dev) FSGPU_HIP(hipMemcpyAsync(exact_out_dev, cand_packed, (size_t)cc * 8, hipMemcpyDeviceToDevice, stream_));
     MergeArgs m2;
     m2.lists = cand_packed;
     m2.q_stride = cc;

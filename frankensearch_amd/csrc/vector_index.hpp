@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -51,6 +52,18 @@ class VectorIndex {
     SearchError init_device(int device, uint32_t dim, uint64_t nrows, const void* slab_dev, const uint64_t* live_dev,
                             uint64_t row_base);
     SearchError open_fsvi(const char* path, int device);
+    // catalog of a row-sharded index: the file's tables stay here (doc ids, tombstones, WAL, hit resolution), the slab is handed
+    // back in `image` for the shards; topk_override replaces this object's own scan inside search_hits
+    struct FsviImage {
+        std::vector<uint8_t> bytes;
+        size_t slab_offset = 0;
+        uint32_t dim = 0;
+        uint64_t nrows = 0;
+        bool f32_rows = false;
+    };
+    SearchError open_fsvi_catalog(const char* path, FsviImage* image);
+    std::function<SearchError(const float* query, uint32_t k, uint32_t* rows, float* scores, uint32_t* count)> topk_override;
+    const std::vector<uint64_t>& live_host() const { return live_host_; }
 
     uint64_t record_count() const { return nrows_; }
     uint32_t dimension() const { return dim_; }
@@ -82,6 +95,13 @@ class VectorIndex {
     SearchError search_top_k_int8_batched(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
                                           uint32_t multiplier, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
                                           uint32_t* fallbacks, int bits = 8);
+    // Shard-local HALF of a two-pass search (bits 8: search_top_k_int8_two_pass, 4: search_top_k_4bit_two_pass) for a row-sharded
+    // index: this shard's cc = max(k * multiplier, k) pass-1 candidates per query as two aligned packed lists [nq, cc] — position
+    // i is one row: its pass-1 entry (integer score as f32 bits | global row) and its exact entry; kEmpty beyond the candidates.
+    // The root repeats the selection over all shards' candidates (launch_two_pass_merge).  Synchronises the stream.
+    SearchError two_pass_candidates_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
+                                           uint32_t multiplier, int bits, uint64_t* approx_out_dev, uint64_t* exact_out_dev,
+                                           hipStream_t stream, uint32_t* fallbacks);
     // Shard-local search whose result stays packed (score bits << 32 | global row; ~0 padding) for the
     // cross-GPU exchange: out_packed_dev is [nq, k].  Fused tiers only (k <= 256, dim % 8 == 0).
     SearchError search_top_k_packed_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
@@ -122,6 +142,14 @@ class VectorIndex {
     SearchError allow_bitmap_for_hashes(const uint64_t* hashes, uint32_t n, uint64_t* bitmap_out, uint64_t* matched) const;
     SearchError set_live_bitmap(const uint64_t* live);
     bool has_doc_ids() const { return !doc_offsets_.empty(); }
+    // record-table accessors for the two-tier alignment (two_tier.rs:758-840) and quality_scores_for_hits (:1566-1631)
+    bool row_tombstoned(uint64_t r) const { return !live_host_.empty() && !((live_host_[r >> 6] >> (r & 63)) & 1ull); }
+    uint64_t doc_hash_at(uint64_t r) const { return doc_hashes_[r]; }
+    // VectorIndex::find_index_by_doc_id (lib.rs:3395-3421): first LIVE main row with this doc id, -1 if none
+    int64_t find_index_by_doc_id(const char* doc_id, uint32_t len) const;
+    // latest resident WAL entry of a doc id (-1 if none) and its dot_product_f32_f32 with a query
+    int64_t wal_latest(const char* doc_id, uint32_t len) const;
+    float wal_dot(size_t wal_index, const float* query) const;
 
     std::mutex& mutex() { return mu_; }
     int device() const { return device_; }
@@ -143,6 +171,10 @@ class VectorIndex {
     // (nq x dim int8) and, when out_slab_i8 is given, the int8 slab (nrows x dim).  Builds the int8 slab if need be.
     SearchError int8_filter_bound(const float* queries, uint32_t nq, uint32_t query_len, float* out_delta, float* out_query_scale,
                                   float* out_slab_scale, int8_t* out_queries_i8, int8_t* out_slab_i8);
+    // a row shard of a larger index: its max-abs for the cross-shard reduction, then the corpus-wide value adopted as THE scale
+    SearchError compute_local_quant_max(unsigned int** max_bits_dev, hipStream_t stream);
+    void adopt_global_quant_max();
+    hipStream_t stream() const { return stream_; }
     VectorIndex* mrl_view(uint32_t dims);  // strided prefix view of this slab (created on first use)
     // Concurrent callers (the reference's scan is `&self`, lock-free, any number of callers: search.rs:192): replicas of this
     // index over the SAME slab and live bitmap, each with its own stream, workspaces and mutex, so that row-level searches from
@@ -156,13 +188,15 @@ class VectorIndex {
 
   private:
     SearchError ensure_query_dimension(uint32_t query_len) const;
+    SearchError open_fsvi_impl(const char* path, int device, FsviImage* image);
     void* pinned_io();
     SearchError batched_impl(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k, const uint64_t* allow_dev,
                              uint32_t* out_rows_dev, float* out_scores_dev, uint32_t* out_counts_dev, hipStream_t stream,
                              uint32_t* fallbacks, uint64_t* out_packed_dev, uint32_t int8_mult, uint32_t query_stride,
                              bool i8_filter, uint32_t* refiltered, int bits = 8);
     SearchError quantized_two_pass(const float* query, uint32_t query_len, uint32_t k, uint32_t multiplier, int bits,
-                                   uint32_t* out_rows, float* out_scores, uint32_t* out_count);
+                                   uint32_t* out_rows, float* out_scores, uint32_t* out_count, u64* approx_out_dev = nullptr,
+                                   u64* exact_out_dev = nullptr);
     SearchError common_init(int device);
     SearchError fused_search(const float* queries_dev, uint32_t nq, uint32_t k_out, uint32_t k_eff,
                              const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
@@ -188,6 +222,7 @@ class VectorIndex {
     const uint64_t* live_dev_ = nullptr;
     bool owns_slab_ = false;
     bool f32_ = false;  // Quantization::F32 slab: served by the general path (f32_kernels.hip)
+    bool catalog_only_ = false;  // the tables of a sharded index: no device state of its own
     DeviceBuffer slab_own_, live_own_;
     hipStream_t stream_ = nullptr;
     // workspaces (grown on demand, reused)
@@ -196,6 +231,10 @@ class VectorIndex {
         ws_cand_rows_, ws_cand_scores_, mf_max_norm_, mf_qh_, mf_delta_, mf_tau_, mf_cand_, mf_dense_, mf_sel_,
         mf_fallback_, mf_fallback2_, mf_spill_, mf_io_, i8_stats_, n4u_slab_;
     bool i8_ready_ = false, n4_ready_ = false, i8_stats_ready_ = false, n4u_ready_ = false;
+    bool quant_max_ready_ = false;   // i8_max_ holds a corpus-wide max-abs handed in by a sharded index: the quantisers keep it
+    u64* tp_approx_out_ = nullptr;   // two_pass_candidates_device: where the batch in flight leaves its candidate pairs
+    u64* tp_exact_out_ = nullptr;
+    uint32_t tp_stride_ = 0;         // entries between queries in both
     bool hard_batch_ = false;     // the batch in flight is the int8 filter's leftovers (nested f16-filter call)
     bool i8f_disabled_ = false;   // the int8 filter left too many queries uncertified on this slab (or its copy does not fit)
     uint32_t i8f_strikes_ = 0;

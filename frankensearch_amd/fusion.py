@@ -72,3 +72,17 @@ def blend_two_tier(fast: Sequence[Tuple[str, float, int]], quality: Sequence[Tup
     n = C.c_uint32()
     check(_lib.lib().fsgpu_blend_two_tier(fa, len(fast), qa, len(quality), blend_factor, out, C.byref(n)))
     return [(C.string_at(out[i].doc_id, out[i].doc_id_len).decode(), out[i].score, out[i].index) for i in range(n.value)]
+
+
+def blend_two_tier_aligned(fast: Sequence[Tuple[str, float, int]], quality_scores: Sequence[Optional[float]],
+                           blend_factor: float) -> List[Tuple[str, float, int]]:
+    """blend_two_tier_aligned (blend.rs:213-294): quality_scores[i] is the optional quality score of fast[i]."""
+    import numpy as np
+    fa, fk = _pack(fast)
+    qs = np.array([0.0 if q is None else q for q in quality_scores], dtype=np.float32)
+    qp = np.array([q is not None for q in quality_scores], dtype=np.uint8)
+    out = (_ScoredDoc * max(len(fast), 1))()
+    n = C.c_uint32()
+    check(_lib.lib().fsgpu_blend_two_tier_aligned(fa, len(fast), qs.ctypes.data if len(fast) else None,
+                                                  qp.ctypes.data if len(fast) else None, blend_factor, out, C.byref(n)))
+    return [(C.string_at(out[i].doc_id, out[i].doc_id_len).decode(), out[i].score, out[i].index) for i in range(n.value)]

@@ -24,7 +24,7 @@ DOC_ID_MAX = 63
 class _Config(C.Structure):
     _fields_ = [("quality_weight", C.c_float), ("rrf_k", C.c_double), ("candidate_multiplier", C.c_uint32),
                 ("doc_id_mode", C.c_int32), ("fast_tier_int8_multiplier", C.c_uint32),
-                ("prefetch_quality_embed", C.c_int32)]
+                ("prefetch_quality_embed", C.c_int32), ("quality_pool", C.c_int32), ("quality_int8_latency", C.c_int32)]
 
 
 class _Hit(C.Structure):
@@ -113,10 +113,13 @@ class NativeTwoTierSearcher:
 
     def __init__(self, fast_index, quality_index, fast_embedder, quality_embedder, quality_weight: float = 0.7,
                  rrf_k: float = 60.0, candidate_multiplier: int = 3, doc_id_mode: int = 0,
-                 fast_tier_int8_multiplier: int = 0, prefetch_quality_embed: bool = False):
+                 fast_tier_int8_multiplier: int = 0, prefetch_quality_embed: bool = False, quality_pool: int = 0,
+                 quality_int8_latency: bool = False):
+        """quality_pool: 0 = Retrieved (independent quality-tier search; attested FSVI v2 pairs), 1 = RescoredFastPool
+        (quality_scores_for_hits over the fast pool: every FSVI v1 pair) — sync_searcher.rs:810-818."""
         self._keep = (fast_index, quality_index, fast_embedder, quality_embedder)
         cfg = _Config(quality_weight, rrf_k, candidate_multiplier, doc_id_mode, fast_tier_int8_multiplier,
-                      int(prefetch_quality_embed))
+                      int(prefetch_quality_embed), int(quality_pool), int(quality_int8_latency))
         h = C.c_void_p()
         check(lib().fshost_two_tier_create(fast_index._h, quality_index._h, fast_embedder._h, quality_embedder._h,
                                            C.byref(cfg), C.byref(h)))

@@ -459,6 +459,97 @@ class NativeShardedIndex:
         check(_lib.lib().fsgpu_sharded_search_topk(self._h, _ptr(q), nq, q.shape[1], k, _ptr(rows), _ptr(scores), _ptr(counts)))
         return rows[:, :k], scores[:, :k], counts
 
+    # ---- the general form: fsgpu_sharded_search / _begin / _end ------------------------------------------------------
+    EXACT, BATCHED, INT8_TWO_PASS, FOURBIT_TWO_PASS = 0, 1, 2, 3
+
+    class _Request(C.Structure):
+        _fields_ = [("queries", C.c_void_p), ("nq", C.c_uint32), ("query_len", C.c_uint32), ("k", C.c_uint32),
+                    ("mode", C.c_int32), ("candidate_multiplier", C.c_uint32), ("allow_bitmap", C.c_void_p)]
+
+    def _request(self, queries, k, mode, multiplier, allow):
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        bm = pack_bitmap(allow) if allow is not None else None
+        rq = self._Request(q.ctypes.data, q.shape[0], q.shape[1], k, mode, multiplier, bm.ctypes.data if bm is not None else None)
+        return rq, (q, bm)
+
+    @staticmethod
+    def _outputs(nq, k):
+        return (np.full((nq, max(k, 1)), 0xFFFFFFFF, dtype=np.uint32), np.zeros((nq, max(k, 1)), dtype=np.float32),
+                np.zeros(nq, dtype=np.uint32))
+
+    def search(self, queries: np.ndarray, k: int, mode: int = 0, candidate_multiplier: int = 0, allow: Optional[np.ndarray] = None):
+        """search_top_k(query, limit, filter) / the two-pass searches for a batch -> rows, scores, counts, fallbacks."""
+        rq, keep = self._request(queries, k, mode, candidate_multiplier, allow)
+        rows, scores, counts = self._outputs(rq.nq, k)
+        fb = C.c_uint32()
+        check(_lib.lib().fsgpu_sharded_search(self._h, C.byref(rq), _ptr(rows), _ptr(scores), _ptr(counts), C.byref(fb)))
+        return rows[:, :k], scores[:, :k], counts, fb.value
+
+    def search_begin(self, queries: np.ndarray, k: int, mode: int = 0, candidate_multiplier: int = 0,
+                     allow: Optional[np.ndarray] = None):
+        rq, keep = self._request(queries, k, mode, candidate_multiplier, allow)
+        t = C.c_uint64()
+        check(_lib.lib().fsgpu_sharded_search_begin(self._h, C.byref(rq), C.byref(t)))
+        return (t.value, rq.nq, k)
+
+    def search_end(self, ticket):
+        t, nq, k = ticket
+        rows, scores, counts = self._outputs(nq, k)
+        fb = C.c_uint32()
+        check(_lib.lib().fsgpu_sharded_search_end(self._h, t, _ptr(rows), _ptr(scores), _ptr(counts), C.byref(fb)))
+        return rows[:, :k], scores[:, :k], counts, fb.value
+
+    def quant_scale_max(self) -> float:
+        return float(_lib.lib().fsgpu_sharded_quant_scale_max(self._h))
+
+    @classmethod
+    def open(cls, path: str, devices: Sequence[int], exchange: int = 0) -> "NativeShardedIndex":
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        h = C.c_void_p()
+        check(_lib.lib().fsgpu_sharded_open_fsvi(path.encode(), _ptr(devs), devs.size, exchange, C.byref(h)))
+        return cls(h.value)
+
+    def set_live(self, live: Optional[np.ndarray]) -> None:
+        bm = pack_bitmap(live) if live is not None else None
+        check(_lib.lib().fsgpu_sharded_set_live_bitmap(self._h, _ptr(bm)))
+
+    def soft_delete(self, doc_id: str) -> bool:
+        b = doc_id.encode()
+        d = C.c_int32()
+        check(_lib.lib().fsgpu_sharded_soft_delete(self._h, b, len(b), C.byref(d)))
+        return bool(d.value)
+
+    def append(self, doc_id: str, vector: Sequence[float]) -> None:
+        b = doc_id.encode()
+        v = np.ascontiguousarray(vector, dtype=np.float32)
+        check(_lib.lib().fsgpu_sharded_wal_append(self._h, b, len(b), _ptr(v), v.size))
+
+    def wal_record_count(self) -> int:
+        return _lib.lib().fsgpu_sharded_wal_record_count(self._h)
+
+    def doc_id_at(self, row: int) -> str:
+        p, n = C.c_void_p(), C.c_uint32()
+        check(_lib.lib().fsgpu_sharded_doc_id(self._h, row, C.byref(p), C.byref(n)))
+        return C.string_at(p.value, n.value).decode()
+
+    def search_top_k(self, query: Sequence[float], limit: int) -> List[VectorHit]:
+        """VectorIndex::search_top_k with the resident WAL, shadowing and doc-id dedup (fsgpu_sharded_search_hits)."""
+        q = np.ascontiguousarray(query, dtype=np.float32)
+        rows = np.zeros(max(limit, 1), dtype=np.uint32)
+        scores = np.zeros(max(limit, 1), dtype=np.float32)
+        n = C.c_uint32()
+        check(_lib.lib().fsgpu_sharded_search_hits(self._h, _ptr(q), q.size, limit, _ptr(rows), _ptr(scores), C.byref(n)))
+        return [VectorHit(int(rows[i]), float(scores[i]), self.doc_id_at(int(rows[i]))) for i in range(n.value)]
+
+    def gather_dot(self, query: Sequence[float], rows: Sequence[int]) -> np.ndarray:
+        q = np.ascontiguousarray(query, dtype=np.float32)
+        r = np.ascontiguousarray(rows, dtype=np.uint32)
+        out = np.zeros(r.size, dtype=np.float32)
+        check(_lib.lib().fsgpu_sharded_gather_dot(self._h, _ptr(q), q.size, _ptr(r), r.size, _ptr(out)))
+        return out
+
 
 def write_fsvi(path: str, rows, embedder_id: str = "test", embedder_revision: str = "", compaction_gen: int = 0,
                device: int = 0, quantization: int = 1) -> None:

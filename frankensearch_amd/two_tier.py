@@ -3,8 +3,11 @@
 
   phase 0 / "Initial":  fast embed (potion Model2Vec) -> fast-tier scan (fetch = k * candidate_multiplier) ->
                         RRF with the lexical list
-  phase 1 / "Refined":  quality embed (MiniLM) -> quality-tier scan (the `Retrieved` pool, sync_searcher.rs:810-813)
-                        -> blend_two_tier(fast, quality, quality_weight) -> RRF with the lexical list again
+  phase 1 / "Refined":  quality embed (MiniLM) -> the quality pool (sync_searcher.rs:810-818) -> blend -> RRF with the lexical
+                        list again.  The pool is `Retrieved` (an independent quality-tier scan + blend_two_tier) only when the
+                        quality tier's space identity is ATTESTED (an admitted FSVI v2 artifact); every FSVI v1 artifact takes
+                        `RescoredFastPool`: TwoTierIndex::quality_scores_for_hits gather-rescores the fast pool on the quality
+                        tier (two_tier.rs:1566-1631) and blend_two_tier_aligned blends it (blend.rs:213-294).
 Lexical (BM25) search is the caller's: it stays on the CPU in the reference and is passed in as a ranked list.
 Defaults follow TwoTierConfig (crates/frankensearch-core/src/config.rs:169-176)."""
 from __future__ import annotations
@@ -15,7 +18,13 @@ from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from . import fusion
+import ctypes as C
+
+from . import _lib, fusion
+from .errors import check
+
+POOL_RETRIEVED = 0   # SyncQualityPool::Retrieved: attested quality tier (FSVI v2 admission) — independent retrieval
+POOL_RESCORED = 1    # SyncQualityPool::RescoredFastPool: legacy / unattested pair (every FSVI v1 artifact)
 
 
 @dataclass
@@ -26,6 +35,49 @@ class TwoTierConfig:
     # 0 = exact f16 scan of the fast tier; n = search_top_k_int8_two_pass(query, fetch, n) — the reference's default with
     # n = FAST_TIER_MULT = 3 (crates/frankensearch-index/src/two_tier.rs:1318-1337; sync_searcher::search_fast_hits)
     fast_tier_int8_multiplier: int = 0
+    quality_pool: int = POOL_RETRIEVED
+
+
+class TwoTierIndex:
+    """The fast / quality pairing of crates/frankensearch-index/src/two_tier.rs: QualityAlignment (:404-409, computed at open by
+    the merge walk :750-866) and quality_scores_for_hits (:1566-1631), over fsgpu_alignment_* / fsgpu_quality_scores_for_hits."""
+    NONE, ALIGNED, MAPPING = 0, 1, 2
+
+    def __init__(self, fast_index, quality_index):
+        self.fast, self.quality = fast_index, quality_index
+        h = C.c_void_p()
+        check(_lib.lib().fsgpu_alignment_create(fast_index._h, quality_index._h, C.byref(h)))
+        self._a = h.value
+
+    def close(self) -> None:
+        if getattr(self, "_a", None):
+            _lib.lib().fsgpu_alignment_destroy(self._a)
+            self._a = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def alignment_kind(self) -> int:
+        return int(_lib.lib().fsgpu_alignment_kind(self._a))
+
+    def quality_row(self, fast_row: int) -> Optional[int]:
+        r = int(_lib.lib().fsgpu_alignment_quality_row(self._a, fast_row))
+        return None if r < 0 else r
+
+    def unmatched_quality_docs(self) -> int:
+        return int(_lib.lib().fsgpu_alignment_unmatched_quality_docs(self._a))
+
+    def quality_scores_for_hits(self, query: Sequence[float], hits: Sequence[Tuple[str, float, int]]) -> List[Optional[float]]:
+        q = np.ascontiguousarray(query, dtype=np.float32)
+        arr, keep = fusion._pack(hits)
+        scores = np.zeros(max(len(hits), 1), dtype=np.float32)
+        present = np.zeros(max(len(hits), 1), dtype=np.uint8)
+        check(_lib.lib().fsgpu_quality_scores_for_hits(self.fast._h, self.quality._h, self._a, q.ctypes.data, q.size, arr,
+                                                       len(hits), scores.ctypes.data, present.ctypes.data))
+        return [float(scores[i]) if present[i] else None for i in range(len(hits))]
 
 
 @dataclass
@@ -56,6 +108,7 @@ class SyncTwoTierSearcher:
         self.fast_embedder, self.quality_embedder = fast_embedder, quality_embedder
         self.doc_id_of = doc_id_of
         self.config = config or TwoTierConfig()
+        self.pair = TwoTierIndex(fast_index, quality_index) if self.config.quality_pool == POOL_RESCORED else None
 
     def _hits(self, index, vec: np.ndarray, fetch: int, int8_multiplier: int = 0) -> List[Tuple[str, float, int]]:
         if int8_multiplier:
@@ -81,11 +134,17 @@ class SyncTwoTierSearcher:
         m.fast_embed_ms, m.fast_search_ms, m.phase1_total_ms = (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t0) * 1e3
         quality_vec = self.quality_embedder.embed_token_ids(quality_token_ids)
         t4 = time.perf_counter()
-        quality_hits = self._hits(self.quality_index, quality_vec, fetch)
-        t5 = time.perf_counter()
-        blended = fusion.blend_two_tier(fast_hits, quality_hits, cfg.quality_weight)
-        fast_index_of = {d: i for d, _, i in fast_hits}
-        blended = [(d, s, fast_index_of.get(d, 0xFFFFFFFF)) for d, s, _ in blended]   # sync_searcher.rs:880-891
+        if self.pair is not None:   # RescoredFastPool: the fast pool re-scored on the quality tier (a gather, not a scan)
+            scores = self.pair.quality_scores_for_hits(quality_vec, fast_hits)
+            quality_hits = [(d, q, i) for (d, _, i), q in zip(fast_hits, scores) if q is not None]
+            t5 = time.perf_counter()
+            blended = fusion.blend_two_tier_aligned(fast_hits, scores, cfg.quality_weight)
+        else:
+            quality_hits = self._hits(self.quality_index, quality_vec, fetch)
+            t5 = time.perf_counter()
+            blended = fusion.blend_two_tier(fast_hits, quality_hits, cfg.quality_weight)
+            fast_index_of = {d: i for d, _, i in fast_hits}
+            blended = [(d, s, fast_index_of.get(d, 0xFFFFFFFF)) for d, s, _ in blended]   # sync_searcher.rs:880-891
         t6 = time.perf_counter()
         final = fusion.rrf_fuse(lex, blended, k, 0, k=cfg.rrf_k)
         t7 = time.perf_counter()

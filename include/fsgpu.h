@@ -266,9 +266,11 @@ fsgpu_status fsgpu_gather_dot(fsgpu_index *idx, const float *query, uint32_t que
 /* The reference's only partitioning is scan_parallel's contiguous row chunks merged by merge_partial_heaps
  * (crates/frankensearch-index/src/search.rs:1013-1036,1704-1720).  A sharded handle is the same shape across GPUs, inside the
  * library, so that the host makes ONE call per search: shard r (on devices[r]) owns the contiguous rows
- * [r*ceil(N/ndev), ...) and reports global row ids; queries are replicated; each shard scans on its own stream from its own
- * host thread; one ncclAllGather (RCCL over xGMI, nq*k*8 bytes per shard) gathers the packed per-shard top-k lists and the
- * root device merges them under the reference order.  Results are identical to an unsharded index over the same rows. */
+ * [r*ceil(N/ndev), ...) and reports global row ids; queries are replicated; each shard scans on its own stream; one
+ * ncclAllGather (RCCL over xGMI, nq*k*8 bytes per shard; issued for all shards inside one ncclGroupStart/End from the calling
+ * thread, on per-shard exchange streams behind an event of the scan — no host wait between scan, all-gather and merge) gathers
+ * the packed per-shard top-k lists and the root device merges them under the reference order.  Results are identical to an
+ * unsharded index over the same rows, for every entry point below. */
 typedef struct fsgpu_sharded fsgpu_sharded;
 #define FSGPU_EXCHANGE_AUTO 0      /* RCCL when the devices are distinct and librccl.so.1 loads, else peer copies */
 #define FSGPU_EXCHANGE_RCCL 1      /* ncclCommInitAll + ncclAllGather; creation fails if RCCL cannot be used */
@@ -299,6 +301,55 @@ fsgpu_status fsgpu_sharded_search_topk(fsgpu_sharded *idx, const float *queries,
 fsgpu_status fsgpu_sharded_search_topk_batched(fsgpu_sharded *idx, const float *queries, uint32_t nq, uint32_t query_len,
                                                uint32_t k, uint32_t *out_rows, float *out_scores, uint32_t *out_counts,
                                                uint32_t *out_fallbacks);
+/* The general form: VectorIndex::search_top_k(query, limit, filter) (search.rs:192-206) and the two-pass searches
+ * (search.rs:514-661, 876-946) on one object.
+ *   mode  FSGPU_SHARDED_EXACT / _BATCHED: the exact kernels / the matrix-core batched path of every shard; allow_bitmap (optional)
+ *         is the index-wide precomputed SearchFilter (bit r = global row r may be returned, filter.rs:19-56), split per shard
+ *         like the live bitmap.
+ *         FSGPU_SHARDED_INT8_TWO_PASS / _4BIT_TWO_PASS: search_top_k_int8_two_pass / search_top_k_4bit_two_pass for the batch.
+ *         Every shard quantises with the ONE corpus-wide scale of the reference (simd.rs:1865-1886: max-abs over the whole slab —
+ *         an ncclAllReduce(max) of 4 bytes over the shards, once per index) and hands its k*candidate_multiplier pass-1
+ *         candidates to the root as (pass-1 entry, exact entry) pairs; the root takes the corpus-wide k*candidate_multiplier
+ *         best by the pass-1 order — exactly the unsharded candidate set — and the k best of those by the exact order.
+ *         k*candidate_multiplier <= 256, shards*k*candidate_multiplier <= 1024, no filter.
+ * fsgpu_sharded_search = begin + end.  begin returns once the shards' scans have been issued and the exchange + merge are
+ * ENQUEUED behind them; end waits for that one search.  Two searches may be in flight per handle (end them in order), so the
+ * exchange and merge of one run underneath the scan of the next. */
+#define FSGPU_SHARDED_EXACT 0
+#define FSGPU_SHARDED_BATCHED 1
+#define FSGPU_SHARDED_INT8_TWO_PASS 2
+#define FSGPU_SHARDED_4BIT_TWO_PASS 3
+typedef struct fsgpu_sharded_request {
+    const float *queries;          /* [nq, query_len] host */
+    uint32_t nq, query_len, k;
+    int32_t mode;
+    uint32_t candidate_multiplier; /* two-pass modes (0 counts as 1, as in the reference) */
+    const uint64_t *allow_bitmap;  /* ceil(N/64) words or NULL */
+} fsgpu_sharded_request;
+fsgpu_status fsgpu_sharded_search(fsgpu_sharded *idx, const fsgpu_sharded_request *request, uint32_t *out_rows, float *out_scores,
+                                  uint32_t *out_counts, uint32_t *out_fallbacks);
+fsgpu_status fsgpu_sharded_search_begin(fsgpu_sharded *idx, const fsgpu_sharded_request *request, uint64_t *out_ticket);
+fsgpu_status fsgpu_sharded_search_end(fsgpu_sharded *idx, uint64_t ticket, uint32_t *out_rows, float *out_scores,
+                                      uint32_t *out_counts, uint32_t *out_fallbacks);
+/* the corpus-wide max-abs the shards' int8 / 4-bit copies are built from (0 before the first two-pass search) */
+float fsgpu_sharded_quant_scale_max(const fsgpu_sharded *idx);
+/* VectorIndex::open (lib.rs:1747-1909) of an FSVI v1 file with an F16 slab, rows split over the devices.  The handle keeps the
+ * record table, the doc-id strings and the tombstone flags, so the doc-id level calls below work as on fsgpu_index. */
+fsgpu_status fsgpu_sharded_open_fsvi(const char *path, const int32_t *devices, uint32_t ndev, int32_t exchange, fsgpu_sharded **out);
+/* index-wide tombstone bitmap (bit r = global row r is live; NULL = all live), split per shard */
+fsgpu_status fsgpu_sharded_set_live_bitmap(fsgpu_sharded *idx, const uint64_t *live_bitmap);
+/* soft_delete / append / doc ids / search_top_k with the resident WAL, shadowing and doc-id dedup (fsgpu_index_soft_delete,
+ * fsgpu_index_wal_append, fsgpu_index_doc_id, fsgpu_search_hits): handles opened with fsgpu_sharded_open_fsvi */
+fsgpu_status fsgpu_sharded_soft_delete(fsgpu_sharded *idx, const char *doc_id, uint32_t doc_id_len, int32_t *out_deleted);
+fsgpu_status fsgpu_sharded_wal_append(fsgpu_sharded *idx, const char *doc_id, uint32_t doc_id_len, const float *vector,
+                                      uint32_t vector_len);
+uint64_t fsgpu_sharded_wal_record_count(const fsgpu_sharded *idx);
+fsgpu_status fsgpu_sharded_doc_id(const fsgpu_sharded *idx, uint32_t row, const char **out_ptr, uint32_t *out_len);
+fsgpu_status fsgpu_sharded_search_hits(fsgpu_sharded *idx, const float *query, uint32_t query_len, uint32_t k, uint32_t *out_rows,
+                                       float *out_scores, uint32_t *out_count);
+/* dot_query_at over global row ids, each routed to the shard that owns it (fsgpu_gather_dot) */
+fsgpu_status fsgpu_sharded_gather_dot(fsgpu_sharded *idx, const float *query, uint32_t query_len, const uint32_t *rows, uint32_t n,
+                                      float *out_scores);
 
 /* ---- index build helpers ---- */
 /* VectorIndexWriter::write_record + finish for FSVI v1 (crates/frankensearch-index/src/lib.rs:3637-3672, 3752-3943): every
@@ -386,6 +437,39 @@ fsgpu_status fsgpu_rrf_fuse(const fsgpu_scored_doc *lexical, uint32_t n_lexical,
  * out holds n_fast + n_quality entries. */
 fsgpu_status fsgpu_blend_two_tier(const fsgpu_scored_doc *fast, uint32_t n_fast, const fsgpu_scored_doc *quality,
                                   uint32_t n_quality, float blend_factor, fsgpu_scored_doc *out, uint32_t *out_count);
+/* blend_two_tier_aligned (blend.rs:213-294; the vector-index specialisation :296-358 gives the same output for unique doc ids):
+ * the quality tier as per-position scores of the SAME hits — quality_scores[i] belongs to fast[i] and counts only where
+ * quality_present[i] != 0 (the Option<f32> of quality_scores_for_hits).  Fast bounds over all fast scores, quality bounds over
+ * the present scores, first occurrence of a doc id wins both slots.  out holds n_fast entries. */
+fsgpu_status fsgpu_blend_two_tier_aligned(const fsgpu_scored_doc *fast, uint32_t n_fast, const float *quality_scores,
+                                          const uint8_t *quality_present, float blend_factor, fsgpu_scored_doc *out,
+                                          uint32_t *out_count);
+
+/* ---- TwoTierIndex: the pairing of a fast and a quality index (crates/frankensearch-index/src/two_tier.rs) ---- */
+/* QualityAlignment (two_tier.rs:404-409), computed once when the pair is opened (two_tier.rs:750-866): both record tables are
+ * sorted by (FNV-1a(doc_id), doc_id), so one merge pass — tombstoned rows skipped on either side — maps every fast row to its
+ * quality row; the result stays ALIGNED (fast row i = quality row i) until the first divergence and becomes a per-row MAPPING
+ * after it.  Raw slabs (no record table) pair by row.  The indexes stay owned by the caller and must outlive the alignment;
+ * rebuild it after a tombstone update of either index (the reference computes it at open). */
+typedef struct fsgpu_alignment fsgpu_alignment;
+#define FSGPU_ALIGNMENT_NONE 0
+#define FSGPU_ALIGNMENT_ALIGNED 1
+#define FSGPU_ALIGNMENT_MAPPING 2
+fsgpu_status fsgpu_alignment_create(fsgpu_index *fast, fsgpu_index *quality, fsgpu_alignment **out);
+void fsgpu_alignment_destroy(fsgpu_alignment *a);
+int32_t fsgpu_alignment_kind(const fsgpu_alignment *a);
+/* quality_index_for_fast_index (two_tier.rs:1975-1981): -1 when the fast row has no quality row */
+int64_t fsgpu_alignment_quality_row(const fsgpu_alignment *a, uint64_t fast_row);
+uint64_t fsgpu_alignment_unmatched_quality_docs(const fsgpu_alignment *a);
+/* TwoTierIndex::quality_scores_for_hits (two_tier.rs:1566-1631): the phase-2 scoring of an UNATTESTED quality tier — every
+ * FSVI v1 artifact (sync_searcher.rs:810-818).  Per fast hit: the quality WAL's latest resident entry of the doc id
+ * (dot_product_f32_f32 on the host), else the aligned quality row (hit.index == 0xffffffff looks the fast row up by doc id
+ * first), else the quality index's own live row of that doc id; main rows are scored by ONE gather launch of
+ * dot_product_f16_bytes_f32 in the scan's operation order (dot_query_at).  out_present[i] == 0 is the reference's None.
+ * hits[i].doc_id may be null for raw-slab pairs.  FSGPU_ERR_DIMENSION_MISMATCH when query_len is not the quality dimension. */
+fsgpu_status fsgpu_quality_scores_for_hits(fsgpu_index *fast, fsgpu_index *quality, const fsgpu_alignment *alignment,
+                                           const float *query, uint32_t query_len, const fsgpu_scored_doc *hits, uint32_t n,
+                                           float *out_scores, uint8_t *out_present);
 
 /* ---- MRL: truncated scan + full-dimension rescore ---- */
 /* MrlSearchStats (crates/frankensearch-index/src/mrl.rs:122-139). */

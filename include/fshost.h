@@ -34,7 +34,20 @@ typedef struct fshost_two_tier_config {
                                          * 2: the helper also runs the quality tier's search (it needs nothing phase 0
                                          * produces): the two scans share the GPU, phase 0 arrives a little later and
                                          * phase 1 much earlier */
+    int32_t quality_pool;               /* FSHOST_POOL_RETRIEVED (0): the quality tier is searched independently and blended with
+                                         * blend_two_tier — the reference's branch for an ATTESTED quality space (an admitted FSVI
+                                         * v2 artifact), sync_searcher.rs:810-813.  FSHOST_POOL_RESCORED (1): the reference's
+                                         * branch for every unattested pair — all FSVI v1 artifacts —: the fast pool is re-scored
+                                         * on the quality tier (TwoTierIndex::quality_scores_for_hits, two_tier.rs:1566-1631: a
+                                         * gather of ~k*multiplier rows instead of a scan) and blended with blend_two_tier_aligned
+                                         * (sync_searcher.rs:814-818,862-866).  The alignment is computed at create. */
+    int32_t quality_int8_latency;       /* != 0: a lone caller's quality-tier search goes through the int8 filter + exact re-score
+                                         * (fsgpu_index_set_int8_latency on the quality handle while the searcher lives: the same
+                                         * hits from half the bytes, at +50 % device memory for the int8 copy); 0 leaves the
+                                         * caller's handle as it is */
 } fshost_two_tier_config;
+#define FSHOST_POOL_RETRIEVED 0
+#define FSHOST_POOL_RESCORED 1
 
 #define FSHOST_DOC_ID_MAX 63
 /* FusedHit (crates/frankensearch-core/src/types.rs:3892-3925) with the doc id copied out. */

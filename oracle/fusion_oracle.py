@@ -139,3 +139,80 @@ def blend_two_tier(fast: Sequence[Tuple[str, float, int]], quality: Sequence[Tup
         out.append((doc, float(score), e["index"]))
     out.sort(key=lambda h: (-_total_order_key(h[1]), h[0].encode()))
     return out
+
+
+def blend_two_tier_aligned(fast: Sequence[Tuple[str, float, int]], quality_scores: Sequence[Optional[float]],
+                           blend_factor: float) -> List[Tuple[str, float, int]]:
+    """blend_two_tier_aligned (blend.rs:213-294): quality_scores[i] is the Option<f32> quality score of fast[i].  The reference
+    documents it as bit-identical to blend_two_tier(fast, Some-filtered projection of fast): that is how it is restated."""
+    subset = [(doc, q, index) for (doc, _, index), q in zip(fast, quality_scores) if q is not None]
+    return blend_two_tier(fast, subset, blend_factor)
+
+
+def quality_alignment(fast_records: Sequence[Tuple[int, str, bool]], quality_records: Sequence[Tuple[int, str, bool]]):
+    """The merge walk of TwoTierIndex::assemble_opened (two_tier.rs:750-866).  records: [(doc_id_hash, doc_id, tombstoned)] in
+    table order (sorted by (hash, doc_id)).  Returns ("aligned", None) or ("mapping", [quality row or None per fast row])."""
+    kind, mapping = "aligned", None
+    f = q = 0
+    fc, qc = len(fast_records), len(quality_records)
+
+    def ensure_mapping(upto):
+        nonlocal kind, mapping
+        if kind == "aligned":
+            kind, mapping = "mapping", list(range(upto))
+
+    while f < fc and q < qc:
+        fh, fd, ft = fast_records[f]
+        qh, qd, qt = quality_records[q]
+        if ft:
+            ensure_mapping(f)
+            mapping.append(None)
+            f += 1
+            continue
+        if qt:
+            q += 1
+            continue
+        if kind == "aligned" and f != q:
+            ensure_mapping(f)
+        if fh < qh or (fh == qh and fd.encode() < qd.encode()):
+            ensure_mapping(f)
+            mapping.append(None)
+            f += 1
+        elif fh > qh or (fh == qh and fd.encode() > qd.encode()):
+            q += 1
+        else:
+            if kind == "mapping":
+                mapping.append(q)
+            f += 1
+            q += 1
+    if f < fc:
+        ensure_mapping(f)
+        mapping.extend([None] * (fc - len(mapping)))
+    return kind, mapping
+
+
+def quality_scores_for_hits(hits: Sequence[Tuple[str, float, int]], alignment, fast_count: int, quality_dot,
+                            quality_find=None, fast_find=None, quality_wal=None) -> List[Optional[float]]:
+    """TwoTierIndex::quality_scores_for_hits (two_tier.rs:1566-1631).  hits: [(doc_id, score, fast index)];
+    alignment = quality_alignment(...) result; quality_dot(row) = dot_query_at; quality_find / fast_find(doc_id) = the index's
+    find_index_by_doc_id; quality_wal(doc_id) = score of the quality WAL's latest entry of that doc or None."""
+    kind, mapping = alignment
+    out = []
+    for doc, _, index in hits:
+        score = quality_wal(doc) if quality_wal else None
+        if score is None:
+            fast_idx = None
+            if index == 0xFFFFFFFF:
+                fast_idx = fast_find(doc) if fast_find else None
+            elif index < fast_count:
+                fast_idx = index
+            if fast_idx is not None and fast_idx < fast_count:
+                qrow = fast_idx if kind == "aligned" else (mapping[fast_idx] if fast_idx < len(mapping) else None)
+                if qrow is not None:
+                    score = quality_dot(qrow)
+        if score is None and quality_find:
+            qrow = quality_find(doc)
+            if qrow is not None:
+                score = quality_dot(qrow)
+        out.append(score)
+    return out

@@ -6,7 +6,7 @@ OUT=${1:-gpurun_out/ab}; OPTS=${2:-"0 1 2 3 4 5 6 7"}; ROUNDS=${3:-2}
 mkdir -p $OUT
 for r in $(seq 1 $ROUNDS); do
   for o in $OPTS; do
-    FSGPU_WIDE_OPT=$o python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-two-tier > $OUT/opt${o}_r$r.json 2> $OUT/opt${o}_r$r.err
+    FSGPU_WIDE_OPT=$o python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-two-tier --no-adversarial --no-encoders > $OUT/opt${o}_r$r.json 2> $OUT/opt${o}_r$r.err
     python - <<PY
 import json
 try:
@@ -19,7 +19,7 @@ PY
   done
 done | tee $OUT/summary.txt
 for dbg in 1 2; do
-  FSGPU_WIDE_OPT=7 FSGPU_WIDE_DBG=$dbg python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-two-tier > $OUT/dbg$dbg.json 2> $OUT/dbg$dbg.err
+  FSGPU_WIDE_OPT=7 FSGPU_WIDE_DBG=$dbg python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-two-tier --no-adversarial --no-encoders > $OUT/dbg$dbg.json 2> $OUT/dbg$dbg.err
   python - <<PY | tee -a $OUT/summary.txt
 import json
 try:

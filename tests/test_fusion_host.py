@@ -75,3 +75,35 @@ def test_blend_reference_known_answers(fusion):
     b = fusion.blend_two_tier([("a", 10.0, 0), ("b", 1.0, 1)], [("a", 1.0, 0), ("b", 10.0, 1)], 0.7)
     assert [d for d, _, _ in b] == ["b", "a"]
     assert fusion.blend_two_tier([], [], 0.7) == []
+
+
+def test_aligned_blend_matches_oracle_and_reference_known_answers(fusion):
+    """fsgpu_blend_two_tier_aligned (blend.rs:213-294) vs the oracle: the reference's own cases (duplicate doc id, None scores,
+    NaN blend factor: blend.rs:578-646) and randomised pools."""
+    from oracle import fusion_oracle as fo
+    fast = [("a", 0.90, 0), ("b", 0.70, 1), ("c", 0.50, 2), ("d", 0.30, 3), ("a", 0.20, 9), ("e", 0.10, 4)]
+    scores = [0.10, None, 0.95, 0.40, 0.99, None]
+    for alpha in (0.0, 0.3, 0.7, 1.0, math.nan):
+        got, want = fusion.blend_two_tier_aligned(fast, scores, alpha), fo.blend_two_tier_aligned(fast, scores, alpha)
+        assert [(d, i) for d, _, i in got] == [(d, i) for d, _, i in want]
+        assert [np.float32(s).view(np.uint32) for _, s, _ in got] == [np.float32(s).view(np.uint32) for _, s, _ in want]
+        # ... which the reference proves equal to the materialised path
+        subset = [(d, q, i) for (d, _, i), q in zip(fast, scores) if q is not None]
+        mat = fusion.blend_two_tier(fast, subset, alpha)
+        assert [(d, np.float32(s).view(np.uint32), i) for d, s, i in got] == [(d, np.float32(s).view(np.uint32), i) for d, s, i in mat]
+    assert fusion.blend_two_tier_aligned([], [], 0.7) == []
+    rng = np.random.default_rng(21)
+    for trial in range(60):
+        n = int(rng.integers(1, 90))
+        pool = [f"d{i:03}" for i in range(60 if trial % 3 else 400)]
+        fast = sorted(((str(rng.choice(pool)), float(np.float32(rng.normal())), int(rng.integers(0, 900))) for _ in range(n)),
+                      key=lambda h: -h[1])
+        scores = [None if rng.random() < 0.3 else float(np.float32(rng.normal())) for _ in range(n)]
+        if trial % 5 == 0:
+            scores[0] = math.nan
+        if trial % 11 == 0:
+            scores = [None] * n
+        alpha = float(rng.choice([0.7, 0.0, 1.0, 0.35, math.nan, -2.0]))
+        got, want = fusion.blend_two_tier_aligned(fast, scores, alpha), fo.blend_two_tier_aligned(fast, scores, alpha)
+        assert [(d, np.float32(s).view(np.uint32), i) for d, s, i in got] == \
+               [(d, np.float32(s).view(np.uint32), i) for d, s, i in want], trial

@@ -153,3 +153,129 @@ def test_multi_gpu_matches_unsharded_bit_for_bit(fa, oracle):
     peer = fa.NativeShardedIndex.from_slab(slab, list(range(world)), exchange=2)
     rows, scores, counts = peer.search_batch(q, k)
     assert np.array_equal(rows, wr) and np.array_equal(bits(scores), bits(ws))
+
+
+@pytest.mark.parametrize("shards", [1, 2, 3, 8])
+def test_every_entry_point_of_the_sharded_handle_equals_the_unsharded_index(fa, oracle, shards):
+    """search_top_k(query, limit, filter) (search.rs:192-206, filter.rs:19-56), tombstone updates, dot_query_at routing and the
+    int8 / 4-bit two-pass searches (search.rs:514-661, 876-946; ONE corpus-wide scale, simd.rs:1865-1886) on the sharded handle:
+    row ids and f32 score bits of the unsharded index, whatever the number of shards — ragged last shard, bitmap words split
+    across shards, two-pass candidates included."""
+    S = fa.NativeShardedIndex
+    rng = np.random.default_rng(300 + shards)
+    n, dim, k = 150_011, 128, 10
+    slab = oracle.clustered_corpus_f16(0, n, dim)
+    # one shard holds the corpus-wide max-abs: without the cross-shard reduction the others would quantise with finer scales
+    slab[n - 5, 7] = np.float16(1.75).view(np.uint16)
+    q = np.stack([oracle.clustered_query(i, dim) for i in range(70)])
+    live = rng.random(n) > 0.15
+    allow = rng.random(n) > 0.5
+    whole = fa.VectorIndex.from_slab(slab, live=live)
+    idx = S.from_slab(slab, [0] * shards, live=live, exchange=S.EXCHANGE_PEER_COPY)
+    # filtered searches, exact kernels and matrix-core batched path
+    wr, ws, wc = whole.search_batch(q, k, allow=allow)
+    for mode in (S.EXACT, S.BATCHED):
+        rows, scores, counts, _ = idx.search(q, k, mode, allow=allow)
+        assert np.array_equal(rows, wr) and np.array_equal(bits(scores), bits(ws)) and np.array_equal(counts, wc), mode
+    # a selective filter (the unsharded index gathers; the shards mask or gather as they see fit)
+    few = np.zeros(n, bool)
+    few[rng.choice(n, 900, replace=False)] = True
+    fr, fs, fc = whole.search_batch(q[:6], k, allow=few)
+    rows, scores, counts, _ = idx.search(q[:6], k, S.EXACT, allow=few)
+    assert np.array_equal(rows, fr) and np.array_equal(bits(scores), bits(fs)) and np.array_equal(counts, fc)
+    # tombstone update through the handle
+    live2 = live.copy()
+    live2[wr[:, 0]] = False          # every query loses its best hit
+    whole.set_live(live2)
+    idx.set_live(live2)
+    wr2, ws2, wc2 = whole.search_batch(q, k)
+    rows, scores, counts, _ = idx.search(q, k, S.BATCHED)
+    assert np.array_equal(rows, wr2) and np.array_equal(bits(scores), bits(ws2)) and not np.array_equal(wr2, wr)
+    idx.set_live(None)
+    whole.set_live(None)
+    # dot_query_at over rows of every shard (quality_scores_for_hits on a sharded quality tier)
+    pick = rng.choice(n, 200, replace=False).astype(np.uint32)
+    pick[:3] = (0, n - 1, n // 2)
+    assert np.array_equal(bits(idx.gather_dot(q[3], pick)), bits(whole.gather_dot(q[3], pick)))
+    # two-pass searches: the unsharded candidates, hence the unsharded hits
+    for mode, mult, per_query in ((S.INT8_TWO_PASS, 3, whole.search_top_k_int8_two_pass), (S.FOURBIT_TWO_PASS, 5, whole.search_top_k_4bit_two_pass),
+                                  (S.INT8_TWO_PASS, 1, whole.search_top_k_int8_two_pass)):
+        rows, scores, counts, _ = idx.search(q, k, mode, candidate_multiplier=mult)
+        for qi in range(q.shape[0]):
+            hits = per_query(q[qi], k, mult)
+            assert [h.index for h in hits] == rows[qi, :counts[qi]].tolist(), (mode, mult, qi)
+            assert np.array_equal(bits([h.score for h in hits]), bits(scores[qi, :counts[qi]])), (mode, mult, qi)
+        er, es = (oracle.search_int8_two_pass if mode == S.INT8_TWO_PASS else oracle.search_4bit_two_pass)(slab, q[0], k, mult)
+        assert np.array_equal(rows[0, :counts[0]], er) and np.array_equal(bits(scores[0, :counts[0]]), bits(es))
+    assert np.float32(idx.quant_scale_max()) == np.float32(np.abs(slab.view(np.float16).astype(np.float32)).max())
+    # begin / end: two searches in flight, ended in order; a third begin is refused until one has ended
+    t0 = idx.search_begin(q[:40], k, S.BATCHED)
+    t1 = idx.search_begin(q[40:], 7, S.EXACT, allow=allow)
+    with pytest.raises(fa.InvalidConfig):
+        idx.search_begin(q[:2], k)
+    r0 = idx.search_end(t0)
+    r1 = idx.search_end(t1)
+    w0, w1 = whole.search_batch(q[:40], k), whole.search_batch(q[40:], 7, allow=allow)
+    assert np.array_equal(r0[0], w0[0]) and np.array_equal(bits(r0[1]), bits(w0[1]))
+    assert np.array_equal(r1[0], w1[0]) and np.array_equal(bits(r1[1]), bits(w1[1])) and np.array_equal(r1[2], w1[2])
+    with pytest.raises(fa.InvalidConfig):
+        idx.search(q, 100, S.INT8_TWO_PASS, candidate_multiplier=3)     # k * multiplier > 256
+    idx.close()
+
+
+def test_two_pass_on_tiny_and_ragged_shards(fa, oracle):
+    # more shards than rows, fewer rows than candidates: still the unsharded answer
+    S = fa.NativeShardedIndex
+    rng = np.random.default_rng(77)
+    for n, shards in ((5, 8), (40, 3), (700, 8)):
+        slab = rand_slab(rng, n, 64)
+        q = rng.standard_normal((4, 64)).astype(np.float32)
+        whole = fa.VectorIndex.from_slab(slab)
+        idx = S.from_slab(slab, [0] * shards, exchange=2)
+        for mode, mult, fn in ((S.INT8_TWO_PASS, 3, whole.search_top_k_int8_two_pass), (S.FOURBIT_TWO_PASS, 5, whole.search_top_k_4bit_two_pass)):
+            rows, scores, counts, _ = idx.search(q, 10, mode, candidate_multiplier=mult)
+            for qi in range(4):
+                hits = fn(q[qi], 10, mult)
+                assert [h.index for h in hits] == rows[qi, :counts[qi]].tolist(), (n, shards, mode, qi)
+                assert np.array_equal(bits([h.score for h in hits]), bits(scores[qi, :counts[qi]]))
+        idx.close()
+
+
+def test_sharded_fsvi_open_doc_ids_soft_delete_and_wal(fa, oracle, tmp_path):
+    """fsgpu_sharded_open_fsvi: the file's record table, doc ids, tombstones and WAL live on the handle; search_top_k with WAL
+    merge, shadowing and doc-id dedup (search.rs:426-494, 1449-1558) equals the unsharded VectorIndex.open of the same file."""
+    S = fa.NativeShardedIndex
+    rng = np.random.default_rng(91)
+    n, dim = 4000, 64
+    ids = [f"doc-{i % 3700:05d}" for i in range(n)]            # 300 duplicate doc ids
+    vecs = rng.standard_normal((n, dim)).astype(np.float32)
+    p = str(tmp_path / "sharded.fsvi")
+    fa.write_fsvi(p, list(zip(ids, vecs)), "potion", "r1")
+    whole = fa.VectorIndex.open(p)
+    for shards in (1, 3, 8):
+        idx = S.open(p, [0] * shards, exchange=2)
+        assert idx.record_count() == n and idx.dimension() == dim and idx.shard_count() == shards
+        assert [idx.doc_id_at(r) for r in (0, 1, n - 1)] == [whole.doc_id_at(r) for r in (0, 1, n - 1)]
+        q = rng.standard_normal((6, dim)).astype(np.float32)
+
+        def same(limit=12):
+            for qi in range(q.shape[0]):
+                a, b = idx.search_top_k(q[qi], limit), whole.search_top_k(q[qi], limit)
+                assert [(h.index, h.doc_id) for h in a] == [(h.index, h.doc_id) for h in b], (shards, qi)
+                assert np.array_equal(bits([h.score for h in a]), bits([h.score for h in b]))
+        same()
+        best = whole.search_top_k(q[0], 1)[0].doc_id
+        assert idx.soft_delete(best) and whole.soft_delete(best)
+        assert not idx.soft_delete("no-such-doc")
+        same()
+        fresh = rng.standard_normal(dim).astype(np.float32)
+        second = whole.search_top_k(q[1], 1)[0].doc_id
+        for h in (idx, whole):
+            h.append("brand-new", q[2] * 3.0)                  # a WAL-only document that wins query 2
+            h.append(second, fresh)                            # supersedes a main row
+        assert idx.wal_record_count() == whole.wal_record_count() == 2
+        same()
+        assert idx.search_top_k(q[2], 3)[0].doc_id == "brand-new"
+        idx.close()
+        whole.close()
+        whole = fa.VectorIndex.open(p)

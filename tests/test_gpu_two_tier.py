@@ -240,3 +240,147 @@ def test_native_load_generator_runs_with_coalescing():
     assert res.queries_per_sec > 0 and res.phase1_p50_ms >= res.phase0_p50_ms > 0
     b, r = qual.coalescing_stats()
     assert r >= 640 and b < r
+
+
+def _fsvi_pair(fa, tmp_path, rng, fast_ids, qual_ids, tag):
+    fast_rows = rng.standard_normal((len(fast_ids), 64)).astype(np.float32)
+    qual_rows = rng.standard_normal((len(qual_ids), 128)).astype(np.float32)
+    pf, pq = str(tmp_path / f"{tag}.fast.idx"), str(tmp_path / f"{tag}.quality.idx")
+    fa.write_fsvi(pf, list(zip(fast_ids, fast_rows)), "potion", "r1")
+    fa.write_fsvi(pq, list(zip(qual_ids, qual_rows)), "minilm", "r1")
+    return fa.VectorIndex.open(pf), fa.VectorIndex.open(pq)
+
+
+def _oracle_pairing(oracle, fusion_oracle, fast, qual, fast_dead=(), qual_dead=()):
+    """Alignment + the accessors quality_scores_for_hits needs, from the product indexes' own tables through the oracle."""
+    def records(idx, dead):
+        out = []
+        for r in range(idx.record_count()):
+            d = idx.doc_id_at(r)
+            out.append((fusion_oracle._fnv(d), d, d in dead))
+        return out
+    frec, qrec = records(fast, fast_dead), records(qual, qual_dead)
+    align = fusion_oracle.quality_alignment(frec, qrec)
+
+    def find(recs):
+        def f(doc):
+            for i, (_, d, t) in enumerate(recs):
+                if d == doc and not t:
+                    return i
+            return None
+        return f
+    return align, find(frec), find(qrec), len(frec)
+
+
+def test_quality_alignment_and_rescored_fast_pool_match_the_reference_flow(oracle, tmp_path):
+    """TwoTierIndex's pairing (two_tier.rs:404-409, 750-866) and quality_scores_for_hits (:1566-1631) through the C ABI, against
+    the oracle's restatement: the reference's own cases first (two_tier.rs:3337-3398, 5630-5672), then a pair with missing
+    documents, tombstones on both sides, a quality-side WAL entry and hits without a fast row."""
+    import frankensearch_amd as fa
+    from frankensearch_amd.build import build
+    from frankensearch_amd.two_tier import TwoTierIndex
+    from oracle import fusion_oracle
+
+    build()
+    rng = np.random.default_rng(41)
+    # quality_alignment_handles_partial_coverage: the quality tier omits doc-b
+    pf, pq = str(tmp_path / "kat.fast.idx"), str(tmp_path / "kat.quality.idx")
+    fa.write_fsvi(pf, [("doc-a", [1.0, 0, 0, 0, 0, 0, 0, 0]), ("doc-b", [0, 1.0, 0, 0, 0, 0, 0, 0]), ("doc-c", [0, 0, 1.0, 0, 0, 0, 0, 0])])
+    fa.write_fsvi(pq, [("doc-c", [0, 1.0, 0, 0, 0, 0, 0, 0]), ("doc-a", [1.0, 0, 0, 0, 0, 0, 0, 0])])
+    fast, qual = fa.VectorIndex.open(pf), fa.VectorIndex.open(pq)
+    pair = TwoTierIndex(fast, qual)
+    row_of = {fast.doc_id_at(r): r for r in range(3)}
+    assert pair.quality_row(row_of["doc-a"]) is not None and pair.quality_row(row_of["doc-c"]) is not None
+    assert pair.quality_row(row_of["doc-b"]) is None and pair.quality_row(3) is None
+    hits = [(d, 0.0, row_of[d]) for d in ("doc-a", "doc-b", "doc-c")]
+    s = pair.quality_scores_for_hits([1.0, 0, 0, 0, 0, 0, 0, 0], hits)
+    assert abs(s[0] - 1.0) < 1e-6 and s[1] is None and abs(s[2]) < 1e-6
+    with pytest.raises(fa.DimensionMismatch):
+        pair.quality_scores_for_hits([1.0, 0.0], hits)                     # two_tier.rs:4892
+    assert pair.quality_scores_for_hits([1.0, 0, 0, 0, 0, 0, 0, 0], []) == []   # :5614
+    # quality_scores_full_coverage: identical id sets stay ALIGNED
+    f2, q2 = _fsvi_pair(fa, tmp_path, rng, ["doc-a", "doc-b"], ["doc-a", "doc-b"], "full")
+    assert TwoTierIndex(f2, q2).alignment_kind() == TwoTierIndex.ALIGNED
+    # a larger pair: 3,000 documents, the quality tier lacks every 7th and has 40 of its own; tombstones on both sides
+    ids = [f"note-{i:05d}-{'y' * (i % 3)}" for i in range(3000)]
+    q_ids = [d for i, d in enumerate(ids) if i % 7 != 3] + [f"extra-{i:03d}" for i in range(40)]
+    fast, qual = _fsvi_pair(fa, tmp_path, rng, ids, q_ids, "big")
+    fast_dead = {ids[i] for i in (5, 77, 1500, 2999)}
+    qual_dead = {ids[i] for i in (8, 77, 2000)}
+    for d in fast_dead:
+        assert fast.soft_delete(d)
+    for d in qual_dead:
+        assert qual.soft_delete(d)
+    pair = TwoTierIndex(fast, qual)     # (computed at open in the reference: after the tombstones are in place)
+    align, fast_find, qual_find, fcount = _oracle_pairing(oracle, fusion_oracle, fast, qual, fast_dead, qual_dead)
+    assert pair.alignment_kind() == (TwoTierIndex.ALIGNED if align[0] == "aligned" else TwoTierIndex.MAPPING) == TwoTierIndex.MAPPING
+    for r in range(fcount):
+        want = r if align[0] == "aligned" else align[1][r]
+        assert pair.quality_row(r) == want, r
+    assert pair.unmatched_quality_docs() >= 40
+    qslab = oracle.Fsvi(str(tmp_path / "big.quality.idx")).slab()
+    query = rng.standard_normal(128).astype(np.float32)
+    # a quality-side WAL entry shadows the main row of its document (the latest entry wins)
+    wal_doc = ids[10]
+    wal_vec = rng.standard_normal(128).astype(np.float32)
+    qual.append(wal_doc, rng.standard_normal(128).astype(np.float32))
+    qual.append(wal_doc, wal_vec)
+    wal_score = oracle.dot_f32_f32(wal_vec, query)
+    picks = rng.choice(fcount, 60, replace=False).tolist() + [fast_find(ids[10])]
+    hits = [(fast.doc_id_at(r), float(rng.normal()), r) for r in picks]
+    hits += [(ids[20], 0.0, 0xFFFFFFFF), ("extra-007", 0.0, 0xFFFFFFFF), ("nowhere", 0.0, 0xFFFFFFFF), (ids[30], 0.0, fcount + 5)]
+    got = pair.quality_scores_for_hits(query, hits)
+    want = fusion_oracle.quality_scores_for_hits(
+        hits, align, fcount, lambda r: float(oracle.dot_f16_f32(qslab[r], query)), quality_find=qual_find, fast_find=fast_find,
+        quality_wal=lambda d: float(wal_score) if d == wal_doc else None)
+    assert [g is None for g in got] == [w is None for w in want]
+    assert [np.float32(g).view(np.uint32) for g in got if g is not None] == [np.float32(w).view(np.uint32) for w in want if w is not None]
+    assert any(g is None for g in got)
+    assert np.float32(got[len(picks) - 1]).view(np.uint32) == np.float32(wal_score).view(np.uint32)   # the WAL's latest entry
+
+
+def test_rescored_fast_pool_searchers_equal_the_oracle_pipeline(oracle):
+    """The phase-2 flow of an unattested (FSVI v1) pair end to end — SyncQualityPool::RescoredFastPool, sync_searcher.rs:814-818,
+    862-866: Python mirror == libfshost (native) == the oracle pipeline, for aligned raw slabs and a shorter quality tier."""
+    import frankensearch_amd as fa
+    from frankensearch_amd.build import build
+    from frankensearch_amd.host import NativeTwoTierSearcher
+    from frankensearch_amd.two_tier import POOL_RESCORED, SyncTwoTierSearcher, TwoTierConfig
+    from oracle import fusion_oracle
+
+    build()
+    rng = np.random.default_rng(43)
+    n, nq_rows = 30000, 27000                      # the quality tier covers the first 27,000 documents only
+    fast_slab = rng.standard_normal((n, 256)).astype(np.float16).view(np.uint16)
+    qual_slab = rng.standard_normal((nq_rows, 384)).astype(np.float16).view(np.uint16)
+    fast, qual, m2v, bert = _small_two_tier(fa, rng, 64)
+    fast, qual = fa.VectorIndex.from_slab(fast_slab), fa.VectorIndex.from_slab(qual_slab)
+    doc = lambda r: f"doc-{r:08d}"
+    py = SyncTwoTierSearcher(fast, qual, m2v, bert, doc, TwoTierConfig(quality_pool=POOL_RESCORED))
+    native = NativeTwoTierSearcher(fast, qual, m2v, bert, doc_id_mode=1, quality_pool=1)
+    native_pre = NativeTwoTierSearcher(fast, qual, m2v, bert, doc_id_mode=1, quality_pool=1, prefetch_quality_embed=2)
+    missing = 0
+    for trial in range(6):
+        fast_ids = rng.integers(0, 5000, 9).tolist()
+        qual_ids = [101] + rng.integers(1000, 3000, 10).tolist() + [102]
+        lexical = [(doc(int(r)), float(30 - i)) for i, r in enumerate(rng.choice(n, 25, replace=False))]
+        k = 10
+        out = py.search(fast_ids, qual_ids, k, lexical)
+        fv = m2v.embed_token_ids(fast_ids)
+        fr, fs = oracle.search_top_k(fast_slab, fv, 30)
+        fast_hits = [(doc(int(r)), float(x), int(r)) for r, x in zip(fr, fs)]
+        assert out.fast_hits == fast_hits
+        qv = bert.embed_token_ids(qual_ids)
+        scores = [float(oracle.dot_f16_f32(qual_slab[r], qv)) if r < nq_rows else None for _, _, r in fast_hits]
+        missing += sum(s is None for s in scores)
+        blended = fusion_oracle.blend_two_tier_aligned(fast_hits, scores, 0.7)
+        assert [(d, np.float32(s).view(np.uint32), i) for d, s, i in out.blended] == \
+               [(d, np.float32(s).view(np.uint32), i) for d, s, i in blended]
+        want_final = fusion_oracle.rrf_fuse(lexical, blended, k)
+        assert [h.doc_id for h in out.final_results] == [h.doc_id for h in want_final]
+        assert [h.rrf_score for h in out.final_results] == [h.rrf_score for h in want_final]
+        for s in (native, native_pre):
+            ini, fin, metrics = s.search(fast_ids, qual_ids, k, lexical)
+            assert ini == out.initial_results and fin == out.final_results
+            assert metrics["quality_search_ms"] > 0
+    assert missing > 0   # some fast hits had no quality vector (the reference's None)

@@ -96,3 +96,56 @@ def test_blend_known_answers():
     bd = fo.blend_two_tier([sem("a", 1.0, 0)], [sem("a", 1.0, 0)], 0.7)
     assert abs(bn[0][1] - bd[0][1]) <= EPS
     assert fo.blend_two_tier([], [], 0.7) == []                                               # :851
+
+
+def hit(doc, s, index):
+    return (doc, s, index)
+
+
+def test_aligned_blend_known_answers():
+    # blend.rs:578-629: blend_two_tier_aligned == blend_two_tier(fast, Some-filtered projection), duplicate doc id included
+    fast = [hit("a", 0.90, 0), hit("b", 0.70, 1), hit("c", 0.50, 2), hit("d", 0.30, 3), hit("a", 0.20, 9), hit("e", 0.10, 4)]
+    scores = [0.10, None, 0.95, 0.40, 0.99, None]
+    for alpha in (0.0, 0.3, 0.7, 1.0, math.nan):
+        b = fo.blend_two_tier_aligned(fast, scores, alpha)
+        assert len(b) == 5 and sorted(d for d, _, _ in b) == ["a", "b", "c", "d", "e"]
+        assert next(i for d, _, i in b if d == "a") == 0            # first occurrence's index
+    # quality only where present; the bounds run over ALL present scores — the ignored duplicate's 0.99 included
+    b = fo.blend_two_tier_aligned(fast, scores, 1.0)
+    assert b[0][0] == "c" and abs(b[0][1] - (0.95 - 0.10) / (0.99 - 0.10)) <= EPS
+    # blend.rs:631-646: no quality scores -> the fast-only blend; empty inputs
+    fast2 = [hit("a", 0.9, 0), hit("b", 0.1, 1)]
+    assert fo.blend_two_tier_aligned(fast2, [None, None], 0.7) == fo.blend_two_tier(fast2, [], 0.7)
+    assert fo.blend_two_tier_aligned([], [], 0.7) == []
+
+
+def _records(ids, tomb=()):
+    recs = sorted(((fo._fnv(d), d) for d in ids), key=lambda r: (r[0], r[1].encode()))
+    return [(h, d, d in tomb) for h, d in recs]
+
+
+def test_quality_alignment_known_answers():
+    # two_tier.rs:3337-3398 (quality_alignment_handles_partial_coverage): the quality tier omits doc-b
+    fast = _records(["doc-a", "doc-b", "doc-c"])
+    qual = _records(["doc-c", "doc-a"])
+    kind, mapping = fo.quality_alignment(fast, qual)
+    qrow = {d: i for i, (_, d, _) in enumerate(qual)}
+    for i, (_, d, _) in enumerate(fast):
+        got = i if kind == "aligned" else mapping[i]
+        assert got == qrow.get(d), (d, kind, mapping)
+    dots = {qrow["doc-a"]: 1.0, qrow["doc-c"]: 0.0}
+    hits = [(d, 0.0, i) for i, (_, d, _) in enumerate(fast)]
+    scores = fo.quality_scores_for_hits(hits, (kind, mapping), len(fast), lambda r: dots[r])
+    by_doc = {d: s for (d, _, _), s in zip(hits, scores)}
+    assert by_doc == {"doc-a": 1.0, "doc-b": None, "doc-c": 0.0}
+    # two_tier.rs:5630-5672 (full coverage): identical id sets stay ALIGNED
+    kind, mapping = fo.quality_alignment(_records(["doc-a", "doc-b"]), _records(["doc-a", "doc-b"]))
+    assert kind == "aligned" and mapping is None
+    # tombstoned rows on either side are skipped; a tombstoned fast row has no quality row
+    fast = _records([f"d{i}" for i in range(8)], tomb={"d3"})
+    qual = _records([f"d{i}" for i in range(8)], tomb={"d5"})
+    kind, mapping = fo.quality_alignment(fast, qual)
+    assert kind == "mapping"
+    for i, (_, d, t) in enumerate(fast):
+        want = None if (t or d == "d5") else next(j for j, (_, qd, _) in enumerate(qual) if qd == d)
+        assert mapping[i] == want, (d, mapping)
