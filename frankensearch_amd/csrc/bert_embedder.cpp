@@ -1,5 +1,6 @@
 // bert_embedder.cpp — orchestration of the BERT forward on one GPU (see bert_kernels.hip for the arithmetic).
 // Layer order follows encoder_layer_raw (crates/frankensearch-rerank/src/native.rs:587-626).
+#include "lab_env.hpp"
 #include "bert_embedder.hpp"
 
 #include <cstdio>
@@ -135,7 +136,7 @@ SearchError NativeEmbedder::init(int device, const fsgpu_bert_config& cfg, const
     // Fragment-order copies for the batch path (bert_gemm_w.hip): +2 bytes per weight (22 MB for MiniLM-L6).
     // FSGPU_BERT_GEMM_V1 keeps the LDS-tiled kernels of bert_kernels.hip (A/B runs).
     const int Hi = (int)H, Ii = (int)I;
-    if (!std::getenv("FSGPU_BERT_GEMM_V1") && bert_gemm_w_supported(3 * Hi, Hi) && bert_gemm_w_supported(Ii, Hi) &&
+    if (!fsgpu::lab_env("FSGPU_BERT_GEMM_V1") && bert_gemm_w_supported(3 * Hi, Hi) && bert_gemm_w_supported(Ii, Hi) &&
         bert_gemm_ln_w_supported(Hi, Hi) && bert_gemm_ln_w_supported(Hi, Ii)) {
         for (Layer& l : layers_) {
             BERT_TRY(pack_weights(l.qkv_wp, l.qkv_w, 3 * Hi, Hi));
@@ -177,7 +178,7 @@ SearchError NativeEmbedder::reserve_workspaces(uint32_t tokens) {
 }
 
 bool NativeEmbedder::query_path(uint32_t tokens) const {
-    static const bool off = std::getenv("FSGPU_BERT_NO_QUERY_PATH") != nullptr;  // A/B runs
+    static const bool off = fsgpu::lab_env("FSGPU_BERT_NO_QUERY_PATH") != nullptr;  // A/B runs
     return !off && tokens <= 32 && bert_query_path_supported((int)cfg_.hidden, (int)cfg_.inter, (int)cfg_.heads);
 }
 
@@ -299,9 +300,9 @@ SearchError NativeEmbedder::forward(uint32_t n_docs, uint32_t tokens, uint32_t m
     const float eps = cfg_.ln_eps;
     if (query_path(tokens)) return forward_query(n_docs, tokens);
     {
-        static const bool ab = std::getenv("FSGPU_BERT_SPLIT_AO") || std::getenv("FSGPU_BERT_SPLIT_FFN");   // A/B runs below
+        static const bool ab = fsgpu::lab_env("FSGPU_BERT_SPLIT_AO") || fsgpu::lab_env("FSGPU_BERT_SPLIT_FFN");   // A/B runs below
         static const int packed_min0 = [] {
-            const char* e = std::getenv("FSGPU_BERT_PACKED_MIN_TOKENS");
+            const char* e = fsgpu::lab_env("FSGPU_BERT_PACKED_MIN_TOKENS");
             return e ? std::atoi(e) : 32;
         }();
         if (packed_ && !ab && (int)tokens > packed_min0 && bert_post_attn_w_supported((int)cfg_.hidden, (int)cfg_.inter)) {
@@ -319,14 +320,14 @@ SearchError NativeEmbedder::forward(uint32_t n_docs, uint32_t tokens, uint32_t m
                                   static_cast<const float*>(type_.ptr), static_cast<const float*>(emb_ln_w_.ptr),
                                   static_cast<const float*>(emb_ln_b_.ptr), x, x_h_.ptr, T, H, eps, stream_));
     const float scale = 0.17677669f;  // ATTN_SCALE_F32 = 1/sqrt(32) (native.rs:44)
-    static const bool no_fuse = std::getenv("FSGPU_BERT_NO_FUSED_LN") != nullptr;  // A/B runs
+    static const bool no_fuse = fsgpu::lab_env("FSGPU_BERT_NO_FUSED_LN") != nullptr;  // A/B runs
     // a batch fills the chip with 32-row blocks; a single query (a few tokens) would run each projection on ONE block
     // and is quicker through the 32x64-tile GEMM + the stand-alone add+LN kernel (measured 0.36 vs 0.43 ms)
     const bool fused_ln = !no_fuse && T > 256 && bert_gemm_ln_supported(H) && (H % 32 == 0) && (I % 32 == 0);
     // a batch: every linear over the fragment-order weights (bert_gemm_w.hip) — 3 launches per layer (QKV, attention, the rest)
     static const int packed_min = [] {
         // above the query path's 32 tokens every size is quicker here (2 queries 0.37 -> 0.30 ms, 12 queries 0.47 -> 0.32 ms)
-        const char* e = std::getenv("FSGPU_BERT_PACKED_MIN_TOKENS");   // tuning runs
+        const char* e = fsgpu::lab_env("FSGPU_BERT_PACKED_MIN_TOKENS");   // tuning runs
         return e ? std::atoi(e) : 32;
     }();
     const bool packed = packed_ && T > packed_min;
@@ -338,8 +339,8 @@ SearchError NativeEmbedder::forward(uint32_t n_docs, uint32_t tokens, uint32_t m
                                         2, stream_));
             BERT_HIP(launch_bert_attention_h(qkv, offs, ctx_h_.ptr, (int)n_docs, (int)cfg_.heads, H, (int)max_seq, scale,
                                              stream_));
-            static const bool split_ao = std::getenv("FSGPU_BERT_SPLIT_AO") != nullptr;     // A/B runs: output projection apart
-            static const bool split_ffn0 = std::getenv("FSGPU_BERT_SPLIT_FFN") != nullptr;
+            static const bool split_ao = fsgpu::lab_env("FSGPU_BERT_SPLIT_AO") != nullptr;     // A/B runs: output projection apart
+            static const bool split_ffn0 = fsgpu::lab_env("FSGPU_BERT_SPLIT_FFN") != nullptr;
             if (!split_ao && !split_ffn0 && bert_post_attn_w_supported(H, I)) {
                 BERT_HIP(launch_bert_post_attn_w(ctx_h_.ptr, l.ao_wp.ptr, static_cast<const float*>(l.ao_b.ptr),
                                                  static_cast<const float*>(l.ln1_w.ptr), static_cast<const float*>(l.ln1_b.ptr),
@@ -352,7 +353,7 @@ SearchError NativeEmbedder::forward(uint32_t n_docs, uint32_t tokens, uint32_t m
             BERT_HIP(launch_bert_gemm_ln_w(ctx_h_.ptr, l.ao_wp.ptr, static_cast<const float*>(l.ao_b.ptr), x, x_h_.ptr,
                                            static_cast<const float*>(l.ln1_w.ptr), static_cast<const float*>(l.ln1_b.ptr), T, H,
                                            H, eps, stream_));
-            static const bool split_ffn = std::getenv("FSGPU_BERT_SPLIT_FFN") != nullptr;   // A/B runs: two launches
+            static const bool split_ffn = fsgpu::lab_env("FSGPU_BERT_SPLIT_FFN") != nullptr;   // A/B runs: two launches
             if (!split_ffn && bert_ffn_w_supported(H, I)) {
                 BERT_HIP(launch_bert_ffn_w(l.i_wp.ptr, static_cast<const float*>(l.i_b.ptr), l.o_wp.ptr,
                                            static_cast<const float*>(l.o_b.ptr), x, x_h_.ptr,

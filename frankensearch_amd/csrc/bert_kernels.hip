@@ -17,6 +17,7 @@
 // straight from L2 — no LDS staging or transposition.  A wave owns a 64x64 output tile (4x4 MFMA tiles,
 // 64 accumulator registers), a 256-thread block owns 128x128, fragments for step k+1 are in flight while step
 // k's 16 MFMAs issue.
+#include "lab_env.hpp"
 #include <cstdlib>
 
 #include "device_util.hpp"
@@ -30,7 +31,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // LDS-tiled 64x128 kernel (6); the other shapes are kept for tuning runs (FSGPU_BERT_GEMM_SHAPE).
 static int bert_gemm_shape_override() {
     static const int v = [] {
-        const char* e = std::getenv("FSGPU_BERT_GEMM_SHAPE");
+        const char* e = fsgpu::lab_env("FSGPU_BERT_GEMM_SHAPE");
         return e ? std::atoi(e) : -1;
     }();
     return v;
@@ -886,7 +887,7 @@ __global__ void bert_to_half_kernel(const float* __restrict__ src, _Float16* __r
 hipError_t launch_bert_embed_ln(const int32_t* ids, const int32_t* positions, const float* word, const float* pos,
                                 const float* type0, const float* lnw, const float* lnb, float* x_f32, void* x_h,
                                 int tokens, int hidden, float eps, hipStream_t stream) {
-    static const bool wave_per_token = std::getenv("FSGPU_BERT_EMBED_V1") != nullptr;   // A/B runs
+    static const bool wave_per_token = fsgpu::lab_env("FSGPU_BERT_EMBED_V1") != nullptr;   // A/B runs
     _Float16* xh = static_cast<_Float16*>(x_h);
     const dim3 g16((tokens + 15) / 16);
     if (wave_per_token || tokens <= 0) {
@@ -1001,7 +1002,7 @@ size_t bert_attention_lds_bytes(int max_seq) {
 hipError_t launch_bert_attention_h(const void* qkv_h, const uint32_t* offsets, void* ctx_h, int n_docs, int heads,
                                    int hidden, int max_seq, float scale, hipStream_t stream) {
     static const bool wave_private = [] {
-        const char* e = std::getenv("FSGPU_BERT_ATTN");  // "w" = the kernel with per-wave K / V staging (A/B runs)
+        const char* e = fsgpu::lab_env("FSGPU_BERT_ATTN");  // "w" = the kernel with per-wave K / V staging (A/B runs)
         return e && e[0] == 'w';
     }();
     if (!wave_private && max_seq <= 512) {
@@ -1029,7 +1030,7 @@ hipError_t launch_bert_attention_h(const void* qkv_h, const uint32_t* offsets, v
 hipError_t launch_bert_attention(const float* qkv, const uint32_t* offsets, void* ctx_h, int n_docs, int heads,
                                  int hidden, int max_seq, float scale, hipStream_t stream) {
     static const bool valu = [] {
-        const char* e = std::getenv("FSGPU_BERT_ATTN");  // "valu" = the f32 VALU kernel (A/B runs)
+        const char* e = fsgpu::lab_env("FSGPU_BERT_ATTN");  // "valu" = the f32 VALU kernel (A/B runs)
         return e && e[0] == 'v';
     }();
     if (!valu) {

@@ -39,6 +39,14 @@ class Coalescer {
         max_wait_us_ = max_wait_us;
     }
     bool enabled() const { return max_batch_.load(std::memory_order_relaxed) != 0; }  // read without the lock
+    // whether a parked request satisfies pred (a caller that only wants to join an EXISTING compatible batch asks first)
+    template <class Pred>
+    bool any_pending(Pred&& pred) {
+        std::lock_guard<std::mutex> lock(mu_);
+        for (Req* r : pending_)
+            if (pred(*r)) return true;
+        return false;
+    }
     void stats(uint64_t* batches, uint64_t* requests) {
         std::lock_guard<std::mutex> lock(mu_);
         *batches = batches_;

@@ -717,7 +717,13 @@ fsgpu_status fsgpu_search_topk_classified(fsgpu_index* idx, const float* query, 
         // ZeroSignalState::empty_result_reason without a filter (config.rs:696-740).  The exact scan returns every live row
         // (a NaN score still ranks, search.rs:1655-1661), so an empty result means no live main record: the census the
         // reference computes lazily reduces to the record and WAL counts.
-        const uint64_t records = idx->impl.record_count(), wal = idx->impl.wal_record_count();
+        // (the counts are read under the state lock a concurrent fsgpu_index_wal_append / soft_delete takes exclusively)
+        uint64_t records, wal;
+        {
+            std::shared_lock<std::shared_mutex> state(idx->state_mu);
+            records = idx->impl.record_count();
+            wal = idx->impl.wal_record_count();
+        }
         *zero_signal = records == 0 && wal == 0 ? FSGPU_ZERO_SIGNAL_NEWLY_CREATED_EMPTY
                        : wal == 0               ? FSGPU_ZERO_SIGNAL_ALL_TOMBSTONED
                                                 : FSGPU_ZERO_SIGNAL_WAL_ONLY_NO_LIVE_RECORDS;

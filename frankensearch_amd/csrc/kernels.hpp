@@ -49,7 +49,7 @@ hipError_t launch_merge_topk(const MergeArgs& args, int nq, hipStream_t stream);
 hipError_t launch_score_rows(const ScanArgs& args, u64* out_packed, int q_index, int grid, hipStream_t stream);
 hipError_t launch_packed_to_sortkey(u64* data, size_t n, hipStream_t stream);
 hipError_t launch_sorted_keys_to_rows(const u64* keys, uint32_t k, uint32_t* out_rows, uint32_t* out_count,
-                                      hipStream_t stream);
+                                      hipStream_t stream, u64* out_packed = nullptr);
 hipError_t launch_gather_dot(const ScanArgs& args, const uint32_t* rows, uint32_t n, float* out, hipStream_t stream);
 hipError_t launch_gather_queries(const float* src, const uint32_t* idx, uint32_t n, uint32_t dim, uint32_t src_stride, float* dst,
                                  hipStream_t stream);
@@ -105,6 +105,8 @@ struct MfmaScanArgs {
                                          // dim dimensions of rows that are row_stride bytes apart
     uint32_t groups;                     // sample stages: query groups answered by one launch (gridDim.y; 0 means 1) —
                                          // group g's queries/tau/cand/spill/overflow/dense follow group g-1's
+    uint32_t* cand_count;                // mfma_wide.hip: [nq_pad, gridDim.x] entries in each (query, block) list, clamped to
+                                         // slots (may be null: the lists are then padded with kEmpty instead)
 };
 
 // select_kernel (mfma_scan.hip): per query, the k-th best of the packed approximate entries without sorting them
@@ -117,6 +119,8 @@ struct SelectArgs {
     const u64* lists;          // [nq][nlists][list_len] (strides below), kEmpty = hole
     uint64_t q_stride;         // entries between queries
     uint32_t l_stride, nlists, list_len;
+    const uint32_t* list_counts;  // [nq][nlists] valid entries at the head of each list (may be null: every slot is read and
+                                  // kEmpty marks the holes) — the register-resident-query scan writes counts instead of padding
     const u64* extra;          // [nq, extra_len] more entries per query (may be null)
     uint32_t extra_len;
     const u64* spill;          // [nq, spill_cap] spilled entries (may be null); valid prefix = min(count, spill_cap)

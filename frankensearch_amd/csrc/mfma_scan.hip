@@ -384,6 +384,13 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
     if (args.big_pool && args.pool_flag && args.pool_flag[q] == 0) return;   // second chance: only the queries the first finish flagged
     const int k = (int)args.k;
     const u64* in = args.lists + (size_t)q * args.q_stride;
+    const uint32_t* cnts = args.list_counts ? args.list_counts + (size_t)q * args.nlists : nullptr;
+    constexpr uint32_t kSelCntCap = 512;
+    __shared__ uint32_t s_cnt[kSelCntCap];   // the query's list lengths: one coalesced read instead of a dependent one per slot
+    if (cnts) {
+        for (uint32_t i = tid; i < args.nlists && i < kSelCntCap; i += NT) s_cnt[i] = cnts[i];
+        __syncthreads();
+    }
     const uint32_t lists32 = args.nlists * args.list_len;
     const uint32_t extra_end = lists32 + args.extra_len;
     uint32_t nspill = 0;
@@ -399,8 +406,9 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
             const uint32_t i = (uint32_t)p * (NT * PER) + tid + x * NT;
             e[x] = kEmpty;
             if (i < lists32) {
-                const uint32_t l = i / args.list_len;
-                e[x] = in[(size_t)l * args.l_stride + (i - l * args.list_len)];
+                // (list lengths, staged in LDS below: only the slots that hold an entry are read — a few percent of them)
+                const uint32_t l = i / args.list_len, j = i - l * args.list_len;
+                if (!cnts || j < (l < kSelCntCap ? s_cnt[l] : cnts[l])) e[x] = in[(size_t)l * args.l_stride + j];
             } else if (i < extra_end) {
                 e[x] = args.extra[(size_t)q * args.extra_len + (i - lists32)];
             } else if (i < total32) {
@@ -1004,10 +1012,14 @@ hipError_t launch_two_pass_merge(const u64* approx_lists, const u64* exact_lists
 hipError_t launch_select(const SelectArgs& args, int nq, hipStream_t stream) {
     if (args.k < 1 || args.k > kSelectMaxK || !args.delta || (uint64_t)args.nlists * args.list_len > 0x7fffffffull)
         return hipErrorInvalidValue;
+#ifdef FSGPU_EXPERIMENTS
     static const int sort_above = [] {
         const char* e = std::getenv("FSGPU_SELECT_SORT_ABOVE");  // tuning experiments only
         return e ? std::atoi(e) : 32;
     }();
+#else
+    constexpr int sort_above = 32;   // ranks above it compact + bitonic-sort instead of extracting
+#endif
     const bool sorted = (int)args.k > sort_above || args.k > 64 || (args.big_pool && args.slab && !args.take_topk);
     constexpr size_t sort_lds = (size_t)kSelSortCap * 8;
     static bool attr_done = false;

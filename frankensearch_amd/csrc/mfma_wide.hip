@@ -129,30 +129,52 @@ __device__ __forceinline__ void wait_vmcnt() {
 //              of the OTHER half's MFMAs (phase-1 scores are tested during phase 2, phase-2 scores during the next pair's
 //              phase 1), the LDS reads are spread one pair per four MFMAs, and nothing but the barrier interrupts the matrix
 //              stream of a wave.
-constexpr int kOptNegTau = 2, kOptSaddr = 4, kOptSplit = 8;   // (bit 1 was a barrier-phase shift between the SIMD twins: measured null, removed)
+//   kOptBig    (with kOptSplit, main pass only) row tiles of 128 rows in a ring of THREE slots (the same 144 KB): half as many
+//              barriers, tile cursors and DMA bookkeeping per row; tile n is consumed while n+1 is landing and n-1's slot takes
+//              n+2 — one tile of lookahead is 4-5 us of matrix work, well past the HBM latency.
+constexpr int kOptNegTau = 2, kOptSaddr = 4, kOptSplit = 8, kOptBig = 16;
+
+// k-steps per chunk of the chunk loop (fewer where the resident queries leave fewer registers for the fragment double buffer)
+constexpr int wide_chunk_ksteps(int KS, int QT) {
+    return KS == 12 ? (QT >= 3 ? 2 : 3) : KS == 6 ? (QT >= 5 ? 1 : 3) : KS == 4 ? (QT >= 7 ? 1 : 2) : (KS >= 2 ? KS / 2 : 1);
+}
+// shapes whose resident queries already fill the register file take no option that costs registers
+constexpr bool wide_room(int ROWB, int QT) {
+    const int KS = ROWB / 64;
+    return QT * KS * 4 + 4 * wide_chunk_ksteps(KS, QT) * 4 + 8 * QT <= 190;
+}
+// the query-tile-split loop: int8 rows with neg-tau, tiles of two pairs or more, and registers for a whole pair's fragments
+constexpr bool wide_split_ok(int ROWB, int EB, int QT, int OPT, int DBG) {
+    const int KS = ROWB / 64;
+    return (OPT & kOptSplit) != 0 && (OPT & kOptNegTau) != 0 && EB == 1 && wide_room(ROWB, QT) && ROWB < 512 && QT >= 2 && DBG != 1 &&
+           QT * KS * 4 + 2 * KS * 4 + 9 * QT <= 200;
+}
+// 128-row tiles in a three-slot ring: the main pass of a shape that runs the split loop
+constexpr bool wide_big_ok(int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG) {
+    return (OPT & kOptBig) != 0 && wide_split_ok(ROWB, EB, QT, OPT, DBG) && DBG == 0 && NSLOT == 3;
+}   // (bit 1 was a barrier-phase shift between the SIMD twins: measured null, removed)
 template <int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG = 0>
 __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     using acc_t = std::conditional_t<EB == 2, f32x4, i32x4>;
     constexpr int WPB = 8, NT = WPB * 64;
     constexpr int KS = ROWB / 64;                                   // MFMA k-steps (64 bytes of a row each)
-    constexpr int TR = ROWB >= 512 ? 32 : 64;                       // rows per tile
+    constexpr bool BIG = wide_big_ok(ROWB, EB, QT, NSLOT, OPT, DBG);
+    constexpr int TR = BIG ? 128 : ROWB >= 512 ? 32 : 64;           // rows per tile
     constexpr int RS = TR / 16;                                     // 16-row sub-tiles per tile
     constexpr int NI = RS * KS;                                     // DMA instructions per tile (1 KB each)
     constexpr int PW = NI / WPB;                                    // ... per wave
     static_assert(NI % WPB == 0 && PW >= 1, "a tile's DMA instructions divide evenly over the 8 waves");
     static_assert(RS % 2 == 0, "sub-tiles are consumed in pairs");
-    // k-steps per chunk (fewer where the resident queries leave fewer registers for the fragment double buffer)
-    constexpr int CK = KS == 12 ? (QT >= 3 ? 2 : 3) : KS == 6 ? (QT >= 5 ? 1 : 3) : KS == 4 ? (QT >= 7 ? 1 : 2) : (KS >= 2 ? KS / 2 : 1);
+    constexpr int CK = wide_chunk_ksteps(KS, QT);
     constexpr int NCH = KS / CK;                                    // chunks per sub-tile pair
     constexpr int NC = (RS / 2) * NCH;                              // chunks per tile
     static_assert(KS % CK == 0 && NC % 2 == 0, "an even number of chunks per tile: the register double buffer starts every tile in the same phase");
-    static_assert(NSLOT >= 4, "tile n is consumed while n+1 .. n+NSLOT-2 are in flight and n-1's slot is being refilled");
-    // (shapes whose resident queries already fill the register file take no option that costs registers)
-    constexpr bool ROOM = QT * KS * 4 + 4 * CK * 4 + 8 * QT <= 190;
+    static_assert(NSLOT >= 3, "tile n is consumed while n+1 .. n+NSLOT-2 are in flight and n-1's slot is being refilled");
+    constexpr bool ROOM = wide_room(ROWB, QT);
     constexpr bool NEGTAU = (OPT & kOptNegTau) != 0 && EB == 1 && ROOM;
     constexpr bool SADDR = (OPT & kOptSaddr) != 0 && ROOM;
-    // registers: resident queries + fragments + accumulators must leave room for addresses and the append path
-    constexpr bool SPLIT = (OPT & kOptSplit) != 0 && NEGTAU && RS >= 4 && QT >= 2 && DBG != 1 && QT * KS * 4 + 2 * KS * 4 + 9 * QT <= 200;
+    constexpr bool SPLIT = wide_split_ok(ROWB, EB, QT, OPT, DBG);
+    static_assert(!SPLIT || (NEGTAU && RS >= 4), "the split loop runs on neg-tau accumulators over tiles of two pairs or more");
     // -ceil(tau) kept in all four registers of an accumulator (the first MFMA of a pair takes it as C: no initialising moves) where
     // 4 x QT more registers fit; else one register per query tile and four moves per accumulator (in the MFMAs' shadow when SPLIT)
     constexpr bool NT4 = NEGTAU && !SPLIT && QT * KS * 4 + 4 * CK * 4 + 12 * QT <= 200 && QT * KS * 4 <= 96;
@@ -203,7 +225,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     // sequence needs no skip test and is advanced with a handful of scalar adds.
     // A sample stage (args.group_count != 0) visits 64-row groups group_stride apart instead: the same tile sequence over
     // the sample's tiles, each mapped to its place in the slab.
-    constexpr uint32_t TPG = 64 / TR;   // tiles per 64-row sample group
+    constexpr uint32_t TPG = TR <= 64 ? 64 / TR : 1;   // tiles per 64-row sample group (128-row tiles never sample)
     constexpr bool sampled = DBG == 3;
     const uint32_t ntiles = sampled ? args.group_count * TPG : (args.nrows + TR - 1) / TR;
     auto tile_row0 = [&](uint32_t t) -> uint32_t {
@@ -235,25 +257,27 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     // k-step j % KS).  Rows past the end are clamped to the last row (their scores are discarded below).
     const int dma_p = lane >> 2, dma_c = lane & 3;
     const int dma_chunk = dma_c ^ ((4 - (dma_p >> 2)) & 3);
-    uint32_t dma_off[PW];   // SADDR: this lane's byte offset from the tile's first row, per instruction of the wave
+    constexpr int PARTS = (PW + 2) / 3, PP = PW / PARTS;   // a wave's DMA instructions go out in groups of at most three
+    static_assert(PW % PARTS == 0, "a tile's DMA instructions per wave split evenly into groups");
+    uint32_t dma_off[PARTS][PP];   // SADDR: this lane's byte offset from the tile's first row, per instruction of the wave
 #pragma unroll
     for (int x = 0; x < PW; ++x) {
         const int j = wave * PW + x;
         const int s = j / KS, ks = j - s * KS;
-        dma_off[x] = (uint32_t)(s * 16 + dma_p) * (uint32_t)row_pitch + (uint32_t)(ks * 64 + dma_chunk * 16);
+        dma_off[x / PP][x % PP] = (uint32_t)(s * 16 + dma_p) * (uint32_t)row_pitch + (uint32_t)(ks * 64 + dma_chunk * 16);
     }
-    auto issue_tile = [&](uint32_t t, uint32_t slot) {
+    auto issue_part = [&](uint32_t t, uint32_t slot, int part) {
         const uint32_t row0 = __builtin_amdgcn_readfirstlane(tile_row0(t));
         if constexpr (SADDR && DBG != 2) {
             if (row0 + TR <= args.nrows) {   // (wave-uniform) every row of the tile exists: no clamp, no vector address arithmetic
                 const uint64_t sbase = (uint64_t)(uintptr_t)slab + (uint64_t)row0 * row_pitch;
-                const uint32_t dst = __builtin_amdgcn_readfirstlane(ring + slot * TILE_BYTES + (uint32_t)(wave * PW) * 1024u);
-                glds16_group<PW>(sbase, dma_off, dst);
+                const uint32_t dst = __builtin_amdgcn_readfirstlane(ring + slot * TILE_BYTES + (uint32_t)(wave * PW + part * PP) * 1024u);
+                glds16_group<PP>(sbase, dma_off[part], dst);
                 return;
             }
         }
 #pragma unroll
-        for (int x = 0; x < PW; ++x) {
+        for (int x = part * PP; x < part * PP + PP; ++x) {
             const int j = wave * PW + x;
             const int s = j / KS, ks = j - s * KS;
             uint32_t row = row0 + s * 16 + dma_p;
@@ -407,11 +431,15 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     Cursor cc = cl;                         // next tile to consume
     // prologue: NSLOT - 1 tiles in flight (tile j -> slot j mod NSLOT throughout).  Past the last round the DMA count is kept
     // up with dummy tiles (the last tile again) so that the counted waits below stay exact.
-    auto fetch_next = [&](uint32_t slot) {
+    auto fetch_part = [&](uint32_t slot, int part) {   // part PARTS - 1 completes the tile and moves the cursor on
         uint32_t t = cl.n < rounds ? cursor_tile(cl) : ntiles;
         t = t < ntiles ? t : ntiles - 1;
-        issue_tile(t, slot);
-        if (cl.n < rounds) cursor_next(cl);
+        issue_part(t, slot, part);
+        if (part == PARTS - 1 && cl.n < rounds) cursor_next(cl);
+    };
+    auto fetch_next = [&](uint32_t slot) {
+#pragma unroll
+        for (int part = 0; part < PARTS; ++part) fetch_part(slot, part);
     };
 #pragma unroll
     for (int j = 0; j < NSLOT - 1; ++j) fetch_next((uint32_t)j);
@@ -469,7 +497,8 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
                         __builtin_amdgcn_s_barrier();
                         asm volatile("" ::: "memory");
                     }
-                    if (p == 0 && kk == (KS >= 3 ? 2 : KS - 1)) fetch_next(slot_prev);
+                    // the refill of tile n-1's slot: one group of DMA instructions per pair, behind a few MFMAs of its phase 1
+                    if (p < PARTS && kk == (KS >= 3 ? 2 : KS - 1)) fetch_part(slot_prev, p);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (anyB) emit_tiles(tB, ((p + NP - 1) % NP) * 2, acc, QA, QT);
@@ -555,6 +584,15 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     }
     wait_vmcnt<0>();  // no DMA may outlive the block's LDS allocation
     __syncthreads();
+    if (args.cand_count) {
+        // the lists' lengths instead of padding: the selection reads only what was appended (2 KB per block instead of
+        // NQ x slots x 8 bytes — 128 KB at 512 queries x 32 slots)
+        for (int q = tid; q < NQ; q += NT) {
+            const int c = lcnt[q];
+            args.cand_count[(size_t)q * gridDim.x + blockIdx.x] = (uint32_t)(c < slots ? c : slots);
+        }
+        return;
+    }
     // pad the block's lists: [q][block][slots], kEmpty beyond the entries appended
     for (int i = tid; i < NQ * slots; i += NT) {
         const int q = i / slots, j = i - q * slots;
@@ -566,12 +604,13 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
 
 namespace {
 
-// what the shipped kernels are built with: neg-tau + scalar-base DMA + query-tile-split loop wherever the shape's registers allow
-// (measured on the bench shape, profiles/r03/wide_opt_ab.txt: 1.49 ms -> 1.38 ms per 512 queries at 10M x 384)
+// what the shipped kernels are built with: neg-tau + scalar-base DMA + query-tile-split loop wherever the shape's registers allow,
+// 128-row tiles in a three-slot ring for the main pass of those shapes
+// (measured on the bench shape, profiles/r03/wide_opt_ab_run*.txt: 1.49 ms -> 1.33 ms per 512 queries at 10M x 384)
 #ifdef FSGPU_WIDE_OPT_DEFAULT
 constexpr int kWideOptDefault = FSGPU_WIDE_OPT_DEFAULT;
 #else
-constexpr int kWideOptDefault = kOptNegTau | kOptSaddr | kOptSplit;
+constexpr int kWideOptDefault = kOptNegTau | kOptSaddr | kOptSplit | kOptBig;
 #endif
 
 #ifdef FSGPU_EXPERIMENTS
@@ -583,7 +622,8 @@ int wide_env(const char* name) {
 
 template <int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG = 0>
 hipError_t launch_wide_t(const MfmaScanArgs& args, int grid, hipStream_t stream, int* occupancy) {
-    constexpr int TR = ROWB >= 512 ? 32 : 64;
+    constexpr bool BIG = wide_big_ok(ROWB, EB, QT, NSLOT, OPT, DBG);
+    constexpr int TR = BIG ? 128 : ROWB >= 512 ? 32 : 64;
     constexpr size_t ring = (size_t)NSLOT * TR * ROWB;
     const size_t lds = ring + (size_t)QT * 128 * 4;   // the row-tile ring + one append counter per query
     auto kern = scan_wide_kernel<ROWB, EB, QT, NSLOT, OPT, DBG>;
@@ -607,6 +647,13 @@ hipError_t launch_wide_t(const MfmaScanArgs& args, int grid, hipStream_t stream,
     return hipGetLastError();
 }
 
+// the main pass (MODE 0) of a shape that runs the split loop takes the 128-row / three-slot form; everything else NSLOT slots
+template <int ROWB, int EB, int QT, int NSLOT, int O, int MODE>
+hipError_t launch_wide_pick(const MfmaScanArgs& args, int grid, hipStream_t stream, int* occupancy) {
+    if constexpr (MODE == 0 && wide_big_ok(ROWB, EB, QT, 3, O, 0)) return launch_wide_t<ROWB, EB, QT, 3, O, 0>(args, grid, stream, occupancy);
+    else return launch_wide_t<ROWB, EB, QT, NSLOT, O & ~kOptBig, MODE>(args, grid, stream, occupancy);
+}
+
 template <int EB, int QT, int MODE = 0>
 hipError_t launch_wide_d(const MfmaScanArgs& args, int grid, hipStream_t stream, int* occupancy) {
     // resident query fragments: QT x (row bytes / 64) x 4 registers per lane; 144 is what fits next to the accumulators and
@@ -622,7 +669,7 @@ hipError_t launch_wide_d(const MfmaScanArgs& args, int grid, hipStream_t stream,
                 if (dbg == 2) return launch_wide_t<768, EB, QT, 6, O, 2>(args, grid, stream, occupancy);
             }
 #endif
-            return launch_wide_t<768, EB, QT, 6, O, MODE>(args, grid, stream, occupancy);   // 6 x 24 KB
+            return launch_wide_t<768, EB, QT, 6, O & ~kOptBig, MODE>(args, grid, stream, occupancy);   // 6 x 24 KB
         } else return hipErrorInvalidValue;
         case 256: if constexpr (QT <= 4) return launch_wide_t<512, EB, QT, 8, O, MODE>(args, grid, stream, occupancy);   // 8 x 16 KB
                   else return hipErrorInvalidValue;
@@ -643,13 +690,16 @@ hipError_t launch_wide_d(const MfmaScanArgs& args, int grid, hipStream_t stream,
                     case 4: return launch_wide_t<384, EB, QT, 6, 4, MODE>(args, grid, stream, occupancy);
                     case 6: return launch_wide_t<384, EB, QT, 6, 6, MODE>(args, grid, stream, occupancy);
                     case 14: return launch_wide_t<384, EB, QT, 6, 14, MODE>(args, grid, stream, occupancy);
+                    case 30:   // 128-row tiles, three slots: the main pass only (a sample stage visits 64-row groups)
+                        if constexpr (MODE == 0) return launch_wide_t<384, EB, QT, 3, 30, MODE>(args, grid, stream, occupancy);
+                        else return launch_wide_t<384, EB, QT, 6, 14, MODE>(args, grid, stream, occupancy);
                     default: break;
                 }
             }
 #endif
-            return launch_wide_t<384, EB, QT, 6, O, MODE>(args, grid, stream, occupancy);   // 6 x 24 KB
-        case 128: return launch_wide_t<256, EB, QT, 8, O, MODE>(args, grid, stream, occupancy);   // 8 x 16 KB
-        case 64: return launch_wide_t<128, EB, QT, 8, O, MODE>(args, grid, stream, occupancy);    // 8 x 8 KB
+            return launch_wide_pick<384, EB, QT, 6, O, MODE>(args, grid, stream, occupancy);   // 6 x 24 KB (3 x 48 KB)
+        case 128: return launch_wide_pick<256, EB, QT, 8, O, MODE>(args, grid, stream, occupancy);   // 8 x 16 KB (3 x 32 KB)
+        case 64: return launch_wide_pick<128, EB, QT, 8, O, MODE>(args, grid, stream, occupancy);    // 8 x 8 KB (3 x 16 KB)
         default: return hipErrorInvalidValue;
     }
 }

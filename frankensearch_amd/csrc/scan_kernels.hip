@@ -539,12 +539,18 @@ __global__ void packed_to_sortkey_kernel(u64* data, size_t n) {
     }
 }
 
-// General-path epilogue: first k sorted sortkeys -> rows (+count of real entries).
-__global__ void sorted_keys_to_rows_kernel(const u64* keys, uint32_t k, uint32_t* out_rows, uint32_t* out_count) {
+// General-path epilogue: first k sorted sortkeys -> rows (+count of real entries) (+ the packed entries themselves: the
+// inverse of sortkey() — exact for every non-NaN score, which is all an integer pass-1 score can be).
+__global__ void sorted_keys_to_rows_kernel(const u64* keys, uint32_t k, uint32_t* out_rows, uint32_t* out_count, u64* out_packed) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < k) {
         const u64 key = keys[i];
         out_rows[i] = key ? ~(uint32_t)key : 0xffffffffu;
+        if (out_packed) {
+            const uint32_t ord = (uint32_t)(key >> 32);
+            const uint32_t bits = (ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord;
+            out_packed[i] = key ? (((u64)bits << 32) | (uint32_t)~(uint32_t)key) : kEmpty;
+        }
         // count = number of non-zero keys among the first k (zeros sort last)
         if (key != 0 && (i + 1 == k || keys[i + 1] == 0)) *out_count = i + 1;
         if (i == 0 && key == 0) *out_count = 0;
@@ -761,9 +767,9 @@ hipError_t launch_packed_to_sortkey(u64* data, size_t n, hipStream_t stream) {
 }
 
 hipError_t launch_sorted_keys_to_rows(const u64* keys, uint32_t k, uint32_t* out_rows, uint32_t* out_count,
-                                      hipStream_t stream) {
+                                      hipStream_t stream, u64* out_packed) {
     hipLaunchKernelGGL(sorted_keys_to_rows_kernel, dim3((k + 255) / 256), dim3(256), 0, stream, keys, k, out_rows,
-                       out_count);
+                       out_count, out_packed);
     return hipGetLastError();
 }
 

@@ -41,8 +41,9 @@ SearchError hip_fail(hipError_t e, const char* what) {
         if (!_s.ok()) return _s;   \
     } while (0)
 
-// Tuning / debugging knobs, read from the environment ONCE (getenv is not safe against concurrent setenv, and these are
-// experiment switches, not configuration): see scripts/exp_*.
+// Switches read from the environment ONCE (getenv is not safe against concurrent setenv).  A default build reads three:
+// FSGPU_WIDE, FSGPU_FILTER, FSGPU_DEBUG_BATCHED (documented in include/fsgpu.h).  Everything else is a tuning / A-B knob of the
+// lab and exists only in builds with -DFSGPU_EXPERIMENTS (FSGPU_BUILD_DEFS, frankensearch_amd/build.py; scripts/exp_*).
 struct Knobs {
     int grid_blocks = 0, ra = 0, rb = 0, mfma_shape = 0, mfma_shape_i8 = 0, round = 0, i8_per_cu = 0;
     int wide = -1;  // FSGPU_WIDE: 0 = never the register-resident-query main pass, 2 / 3 = its query tiles per wave
@@ -54,8 +55,13 @@ struct Knobs {
     bool no_big_pool = false, no_heur_b = false;
     int heur_rank = 0;   // FSGPU_HEUR_RANK: rank of the first sample whose score gates the anchoring-only second sample (default 4)
     Knobs() {
-        auto num = [](const char* name) {
-            const char* e = std::getenv(name);
+        auto env = [](const char* name) { return std::getenv(name); };
+        if (const char* w = env("FSGPU_WIDE")) wide = std::atoi(w);
+        if (const char* f = env("FSGPU_FILTER")) filter = std::strcmp(f, "f16") == 0 ? 1 : std::strcmp(f, "i8") == 0 ? 2 : 0;
+        debug_batched = env("FSGPU_DEBUG_BATCHED") != nullptr;
+#ifdef FSGPU_EXPERIMENTS
+        auto num = [&](const char* name) {
+            const char* e = env(name);
             return e ? std::atoi(e) : 0;
         };
         grid_blocks = num("FSGPU_GRID_BLOCKS");
@@ -65,21 +71,19 @@ struct Knobs {
         i8_per_cu = num("FSGPU_I8_PER_CU");
         mfma_shape = num("FSGPU_MFMA_SHAPE");
         mfma_shape_i8 = num("FSGPU_MFMA_SHAPE_I8");
-        if (std::getenv("FSGPU_WIDE")) wide = num("FSGPU_WIDE");
-        if (const char* f = std::getenv("FSGPU_FILTER")) filter = std::strcmp(f, "f16") == 0 ? 1 : std::strcmp(f, "i8") == 0 ? 2 : 0;
         i8f_growth = num("FSGPU_I8F_GROWTH");
         wide_max = num("FSGPU_WIDE_MAX");
         slots_b = std::min(num("FSGPU_SLOTS_B"), (int)kWideSlots);
         slots_main = std::min(num("FSGPU_SLOTS_MAIN"), (int)kWideSlots);
-        no_skip_b = std::getenv("FSGPU_NO_SKIP_B") != nullptr;
-        no_wide_b = std::getenv("FSGPU_NO_WIDE_B") != nullptr;
-        no_anchor = std::getenv("FSGPU_NO_ANCHOR") != nullptr;
-        no_big_pool = std::getenv("FSGPU_NO_BIG_POOL") != nullptr;
-        no_heur_b = std::getenv("FSGPU_NO_HEUR_B") != nullptr;
+        no_skip_b = env("FSGPU_NO_SKIP_B") != nullptr;
+        no_wide_b = env("FSGPU_NO_WIDE_B") != nullptr;
+        no_anchor = env("FSGPU_NO_ANCHOR") != nullptr;
+        no_big_pool = env("FSGPU_NO_BIG_POOL") != nullptr;
+        no_heur_b = env("FSGPU_NO_HEUR_B") != nullptr;
         heur_rank = num("FSGPU_HEUR_RANK");
-        no_reverse = std::getenv("FSGPU_NO_REVERSE") != nullptr;
-        use_160 = std::getenv("FSGPU_USE_160") != nullptr;
-        debug_batched = std::getenv("FSGPU_DEBUG_BATCHED") != nullptr;
+        no_reverse = env("FSGPU_NO_REVERSE") != nullptr;
+        use_160 = env("FSGPU_USE_160") != nullptr;
+#endif
     }
 };
 const Knobs& knobs() {
@@ -158,7 +162,7 @@ VectorIndex::~VectorIndex() {
                             &ws_counts_, &ws_keys_a_, &ws_keys_b_, &ws_sort_tmp_, &ws_gather_rows_, &ws_gather_out_,
                             &i8_slab_, &n4_slab_, &i8_max_, &ws_i8_query_, &ws_cand_packed_, &ws_cand_rows_, &ws_cand_scores_,
                             &mf_max_norm_, &mf_qh_, &mf_delta_, &mf_tau_, &mf_cand_, &mf_dense_, &mf_sel_,
-                            &mf_fallback_, &mf_fallback2_, &mf_spill_, &mf_io_, &i8_stats_, &n4u_slab_})
+                            &mf_fallback_, &mf_fallback2_, &mf_spill_, &mf_io_, &i8_stats_, &n4u_slab_, &mf_cand_count_})
         b->release();
     if (mf_flags_host_) (void)hipHostFree(mf_flags_host_);
     if (io_host_) (void)hipHostFree(io_host_);
@@ -1499,6 +1503,8 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         const int wide_grid = num_cus_ * mf_per_cu_wide_main_;
         FSGPU_TRY(mf_cand_.reserve((size_t)QP * std::max(full_grid, wide_grid) * kMfmaMaxSlots * 8));
         u64* cand = static_cast<u64*>(mf_cand_.ptr);
+        FSGPU_TRY(mf_cand_count_.reserve((size_t)QP * wide_grid * 4));   // the wide kernels' list lengths (no padding)
+        uint32_t* cand_count = static_cast<uint32_t*>(mf_cand_count_.ptr);
         MfmaScanArgs a{};
         a.slab = i8 ? (bits == 4 ? n4u_slab_.ptr : i8_slab_.ptr) : slab_dev_;
         a.elem_bytes = i8 ? 1 : 2;
@@ -1591,6 +1597,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
                     c.queries = static_cast<const unsigned char*>(mf_qh_.ptr) + (size_t)j * GM * dim_ * (i8 ? 1 : 2);
                     c.tau = tau + (size_t)j * GM;
                     c.cand = cand + (size_t)j * GM * wide_grid_b * a.slots;
+                    c.cand_count = cand_count + (size_t)j * GM * wide_grid_b;
                     c.spill = spill + (size_t)j * GM * SPILL;
                     c.spill_count = spill_count + (size_t)j * GM * kMfmaSpillCountStride;
                     c.overflow = overflow + (size_t)j * GM;
@@ -1607,6 +1614,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         sb.l_stride = a.slots;
         sb.nlists = (uint32_t)lists_b;
         sb.list_len = a.slots;
+        sb.list_counts = wide_b ? cand_count : nullptr;
         sb.k = ksel;
         sb.take_topk = (i8 && !i8f) ? 1 : 0;
         sb.delta = delta;
@@ -1651,6 +1659,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
                 c.queries = static_cast<const unsigned char*>(mf_qh_.ptr) + (size_t)j * GM * dim_ * (i8 ? 1 : 2);
                 c.tau = tau + (size_t)j * GM;
                 c.cand = cand + (size_t)j * GM * main_grid * a.slots;
+                c.cand_count = wide_qt ? cand_count + (size_t)j * GM * main_grid : nullptr;
                 c.spill = spill + (size_t)j * GM * SPILL;
                 c.spill_count = spill_count + (size_t)j * GM * kMfmaSpillCountStride;
                 c.overflow = overflow + (size_t)j * GM;
@@ -1674,6 +1683,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
             sb.l_stride = a.slots;
             sb.nlists = (uint32_t)main_grid;
             sb.list_len = a.slots;
+            sb.list_counts = wide_qt ? cand_count : nullptr;
             sb.extra = (skip_b || wide_qt) ? nullptr : pool;
             sb.extra_len = (skip_b || wide_qt) ? 0 : KC;
             sb.tau_out = nullptr;
@@ -2242,7 +2252,6 @@ SearchError VectorIndex::quantized_two_pass(const float* query, uint32_t query_l
         m.out_packed = approx_out_dev;   // (a sharded index's root wants the pass-1 entries themselves)
         FSGPU_HIP(launch_merge_topk(m, 1, stream_));
     } else {
-        if (approx_out_dev) return make_error(FSGPU_ERR_INVALID_CONFIG, "sharded two-pass: k * multiplier <= 256 and a fused dimension");
         FSGPU_TRY(ws_keys_a_.reserve(n * 8));
         FSGPU_TRY(ws_keys_b_.reserve(n * 8));
         size_t tmp_bytes = 0;
@@ -2254,7 +2263,7 @@ SearchError VectorIndex::quantized_two_pass(const float* query, uint32_t query_l
         else FSGPU_HIP(launch_score_rows_4bit(a, qslab, ws_i8_query_.ptr, keys_a, stream_));
         FSGPU_HIP(launch_packed_to_sortkey(keys_a, n, stream_));
         FSGPU_HIP(sort_keys_desc(ws_sort_tmp_.ptr, ws_sort_tmp_.bytes, keys_a, keys_b, n, stream_));
-        FSGPU_HIP(launch_sorted_keys_to_rows(keys_b, cc, cand_rows, static_cast<uint32_t*>(ws_counts_.ptr), stream_));
+        FSGPU_HIP(launch_sorted_keys_to_rows(keys_b, cc, cand_rows, static_cast<uint32_t*>(ws_counts_.ptr), stream_, approx_out_dev));
     }
     // ---- pass 2: exact f16 rescore of the candidates, then the usual best-first selection of k ----
     FSGPU_HIP(hipMemsetAsync(cand_scores, 0, (size_t)cc * 4, stream_));

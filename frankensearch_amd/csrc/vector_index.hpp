@@ -229,7 +229,7 @@ class VectorIndex {
     DeviceBuffer ws_partial_, ws_queries_, ws_allow_, ws_rows_, ws_scores_, ws_counts_, ws_keys_a_, ws_keys_b_,
         ws_sort_tmp_, ws_gather_rows_, ws_gather_out_, i8_slab_, n4_slab_, i8_max_, ws_i8_query_, ws_cand_packed_,
         ws_cand_rows_, ws_cand_scores_, mf_max_norm_, mf_qh_, mf_delta_, mf_tau_, mf_cand_, mf_dense_, mf_sel_,
-        mf_fallback_, mf_fallback2_, mf_spill_, mf_io_, i8_stats_, n4u_slab_;
+        mf_fallback_, mf_fallback2_, mf_spill_, mf_io_, i8_stats_, n4u_slab_, mf_cand_count_;
     bool i8_ready_ = false, n4_ready_ = false, i8_stats_ready_ = false, n4u_ready_ = false;
     bool quant_max_ready_ = false;   // i8_max_ holds a corpus-wide max-abs handed in by a sharded index: the quantisers keep it
     u64* tp_approx_out_ = nullptr;   // two_pass_candidates_device: where the batch in flight leaves its candidate pairs

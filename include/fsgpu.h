@@ -512,25 +512,21 @@ fsgpu_status fsgpu_index_coalescing_stats(fsgpu_index *idx, uint64_t *batches, u
 fsgpu_status fsgpu_m2v_set_coalescing(fsgpu_m2v *m, uint32_t max_batch, uint32_t max_wait_us);
 fsgpu_status fsgpu_bert_set_coalescing(fsgpu_bert *m, uint32_t max_batch, uint32_t max_wait_us);
 
-/* ---- experiment switches ----
- * Environment variables read ONCE per process by libfsgpu.so.  None changes a result; they select kernel variants for A/B
- * measurements (scripts/exp_*, scripts/prof_wide.sh) and are listed here so that nothing in the product path is hidden:
- *   FSGPU_WIDE=0|2|3            batched main pass: 0 = queries in LDS (128 per pass), 2 / 3 = queries in registers (256 / 384)
- *   FSGPU_WIDE_DBG=1..4         timing skeletons of that kernel (no MFMAs / no DMA / ...): answers are NOT valid
- *   FSGPU_USE_160, FSGPU_MFMA_SHAPE, FSGPU_MFMA_SHAPE_I8   shapes of the LDS-query kernel
- *   FSGPU_RA, FSGPU_RB, FSGPU_ROUND, FSGPU_NO_SKIP_B, FSGPU_NO_REVERSE   sample sizes / round size / pass direction
- *   FSGPU_FILTER (f16 | i8), FSGPU_I8F_GROWTH   pin the filter of the exact batched search / its sample growth
- *   FSGPU_WIDE_MAX, FSGPU_SLOTS_B, FSGPU_SLOTS_MAIN, FSGPU_NO_WIDE_B   wide main pass: query tiles per wave, list slots, sample stage
- *   FSGPU_GRID_BLOCKS, FSGPU_I8_PER_CU   grid sizes of the exact kernels
- *   FSGPU_SELECT_SORT_ABOVE     rank above which select_kernel sorts instead of extracting
- *   FSGPU_BERT_GEMM_SHAPE, FSGPU_BERT_ATTN, FSGPU_BERT_NO_FUSED_LN, FSGPU_BERT_NO_GRAPH, FSGPU_BERT_NO_QUERY_PATH   encoder paths
- *   FSGPU_BERT_GEMM_V1          batches through the LDS-tiled GEMMs of bert_kernels.hip instead of the fragment-order weights
- *   FSGPU_BERT_SPLIT_FFN        the feed-forward block as two launches (FFN up, FFN down + LayerNorm) instead of one
- *   FSGPU_BERT_PACKED_MIN_TOKENS=<n>   token count above which a call takes the fragment-order batch kernels (default 32)
- *   FSGPU_BERT_ATTN=w|valu      attention with per-wave K / V staging, or the f32 VALU kernel (V1 path), instead of K / V resident in LDS
- *   FSGPU_BERT_EMBED_V1         embedding gather + LayerNorm with a wave per token instead of sixteen lanes per token
- *   FSGPU_BERT_SPLIT_AO         attention-output projection + LayerNorm as its own launch instead of the head of the FFN launch
- *   FSGPU_DEBUG_BATCHED, FSGPU_DEBUG_GRAPH   one-line diagnostics on stderr */
+/* Environment switches (read once, at first use).
+ * A default build reads five:
+ *   FSGPU_WIDE=0|2|3            batched main pass: 0 = queries in LDS (128 per pass), 2 / 3 = queries in registers (256 / 384 on f16 rows)
+ *   FSGPU_FILTER=f16|i8         pin the candidate filter of the exact batched search (as fsgpu_index_set_batched_filter does per index)
+ *   FSGPU_DEBUG_BATCHED         one line per batched search on stderr (fallback census)
+ *   FSGPU_BERT_NO_GRAPH         the query-sized encoder calls launch eagerly instead of replaying a captured hipGraph
+ *   FSGPU_DEBUG_GRAPH           say why a graph capture failed
+ * Everything else is a tuning / A-B switch of the lab and exists only in builds with -DFSGPU_EXPERIMENTS
+ * (FSGPU_BUILD_DEFS="-DFSGPU_EXPERIMENTS" python -m frankensearch_amd.build; scripts/exp_*, scripts/r03/): FSGPU_WIDE_OPT and
+ * FSGPU_WIDE_DBG (options and timing skeletons of the wide main pass — skeleton answers are NOT valid), FSGPU_USE_160,
+ * FSGPU_MFMA_SHAPE{,_I8}, FSGPU_RA, FSGPU_RB, FSGPU_ROUND, FSGPU_NO_SKIP_B, FSGPU_NO_REVERSE, FSGPU_I8F_GROWTH, FSGPU_WIDE_MAX,
+ * FSGPU_SLOTS_B, FSGPU_SLOTS_MAIN, FSGPU_NO_WIDE_B, FSGPU_NO_ANCHOR, FSGPU_NO_BIG_POOL, FSGPU_NO_HEUR_B, FSGPU_HEUR_RANK,
+ * FSGPU_GRID_BLOCKS, FSGPU_I8_PER_CU, FSGPU_SELECT_SORT_ABOVE, FSGPU_BERT_GEMM_SHAPE, FSGPU_BERT_ATTN, FSGPU_BERT_NO_FUSED_LN,
+ * FSGPU_BERT_NO_QUERY_PATH, FSGPU_BERT_GEMM_V1, FSGPU_BERT_SPLIT_FFN, FSGPU_BERT_SPLIT_AO, FSGPU_BERT_PACKED_MIN_TOKENS,
+ * FSGPU_BERT_EMBED_V1. */
 
 /* ---- instrumentation ---- */
 /* When enabled, HIP events bracket the scan kernel of every fsgpu_search_topk* call. */

@@ -228,3 +228,38 @@ class CForward:
         rc = self._lib.fso_bert_forward(C.byref(self._w), ids.ctypes.data, offsets.ctypes.data, len(batch), nthreads, out.ctypes.data)
         assert rc == 0, rc
         return out
+
+
+def heavy_tailed_weights(seed: int, vocab: int, hidden: int, layers: int, inter: int, max_pos: int = 512) -> Dict[str, np.ndarray]:
+    """Synthetic weights with the statistics trained MiniLM / BERT checkpoints are known for and Gaussian ones lack: a few OUTLIER
+    CHANNELS of the residual stream (LayerNorm gains of 8-20 on 4 fixed hidden dimensions, offsets of +-2 there), log-normal
+    LayerNorm gains elsewhere, Student-t (3 d.o.f.) weight entries, and down-scaled columns of the linears that read the outlier
+    channels — the activations those channels carry are 10-50 x the rest, which is what an f16 operand path has to survive."""
+    rng = np.random.default_rng(seed)
+    w = random_weights(seed, vocab, hidden, layers, inter, max_pos)
+    outl = rng.choice(hidden, 4, replace=False)
+
+    def ln(prefix):
+        g = np.exp(0.35 * rng.standard_normal(hidden)).astype(F)
+        g[outl] = rng.uniform(8.0, 20.0, 4).astype(F) * rng.choice([-1.0, 1.0], 4).astype(F)
+        b = (0.1 * rng.standard_normal(hidden)).astype(F)
+        b[outl] = rng.choice([-2.0, 2.0], 4).astype(F)
+        w[f"{prefix}.weight"], w[f"{prefix}.bias"] = g, b
+
+    def heavy(name, s):
+        shape = w[name].shape
+        t = rng.standard_t(3, size=shape).astype(F) * F(s / np.sqrt(3.0))
+        t[..., outl] *= F(0.12)     # the columns that read the outlier channels
+        w[name] = t
+
+    ln("embeddings.LayerNorm")
+    for layer in range(layers):
+        p = f"encoder.layer.{layer}"
+        for name in ("query", "key", "value"):
+            heavy(f"{p}.attention.self.{name}.weight", 0.07)
+        heavy(f"{p}.attention.output.dense.weight", 0.05)
+        ln(f"{p}.attention.output.LayerNorm")
+        heavy(f"{p}.intermediate.dense.weight", 0.05)
+        w[f"{p}.output.dense.weight"] = (rng.standard_t(3, size=(hidden, inter)).astype(F) * F(0.04 / np.sqrt(3.0)))
+        ln(f"{p}.output.LayerNorm")
+    return w

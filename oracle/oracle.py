@@ -511,6 +511,26 @@ def clustered_query(q: int, dim: int, clusters: int = 64, noise: float = 0.30) -
     return out
 
 
+def recall_fixture(dim: int = 384, count: int = 4000):
+    """The reference's recall fixture (search.rs:1931-1967, int8_two_pass_maddubs_preserves_recall_vs_flat): 16 hash-mixed
+    centroids, `count` rows = normalize(centroid[i % 16] + 0.15 jitter) — the same integer mixing.  -> (centroids, rows) f32."""
+    j = np.arange(dim, dtype=np.uint64)
+
+    def mix(a, mul_a, mul_j):
+        s = (np.uint64(a) * np.uint64(mul_a)) ^ (j * np.uint64(mul_j))
+        s ^= s >> np.uint64(13)
+        return ((s & np.uint64(0xFFFF)).astype(np.float32) / np.float32(65535.0)) - np.float32(0.5)
+
+    def normalize(v):
+        n = max(float(np.sqrt(np.sum(v.astype(np.float32) ** 2, dtype=np.float32))), 1e-9)
+        return (v / np.float32(n)).astype(np.float32)
+
+    with np.errstate(over="ignore"):
+        cent = np.stack([normalize(mix(c + 1, 0x9E37, 40503)) for c in range(16)])
+        rows = np.stack([normalize(cent[i % 16] + np.float32(0.15) * mix(i + 1, 2654435761, 7)) for i in range(count)])
+    return cent, rows
+
+
 # ---- Model2Vec ----
 def m2v_embed(table: np.ndarray, ids) -> np.ndarray:
     table = np.ascontiguousarray(table, dtype=np.float32)

@@ -120,3 +120,22 @@ def test_large_batch_equals_its_parts(fa):
     parts = np.concatenate([m.embed_batch_token_ids(docs[i:i + 26]) for i in range(0, 130, 26)])
     assert np.array_equal(whole.view(np.uint32), parts.view(np.uint32))
     assert np.allclose(np.linalg.norm(whole, axis=1), 1.0, atol=1e-4)
+
+
+def test_outlier_channels_heavy_tails_and_512_token_documents(fa):
+    """Weights with the statistics of TRAINED checkpoints (oracle.bert_oracle.heavy_tailed_weights: outlier channels with
+    LayerNorm gains of 8-20, Student-t weights, activations of +-50 next to a median of 0.6): the f16 operand tiles and the f16
+    intermediate tile of the batch kernels, the query path and 512-token documents must hold the same tolerance."""
+    from oracle import bert_oracle
+    rng = np.random.default_rng(29)
+    w = bert_oracle.heavy_tailed_weights(41, 3000, 384, 6, 1536)
+    m = fa.NativeEmbedder(w)
+    ref = bert_oracle.CForward(w, 6)
+    queries = [[101] + rng.integers(1000, 3000, int(n)).tolist() + [102] for n in rng.integers(3, 30, 64)]
+    check(m.embed_batch_token_ids(queries), ref.run(queries, 8))
+    for i in (0, 5, 63):                                       # the <= 32-token query path, one text at a time
+        check(m.embed_token_ids(queries[i])[None, :], ref.run([queries[i]], 1))
+    docs = [[101] + rng.integers(1000, 3000, int(n) - 2).tolist() + [102] for n in (512, 512, 300, 129, 64, 33)]
+    check(m.embed_batch_token_ids(docs), ref.run(docs, 8))
+    # the numpy oracle and its C restatement agree on these weights too (the C one is what the long documents are held against)
+    assert np.max(np.abs(ref.run(queries[:6], 2) - bert_oracle.embed_forward(w, queries[:6], 6))) < 1e-5

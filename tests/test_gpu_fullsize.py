@@ -168,3 +168,33 @@ def test_ragged_multi_group_rounds_equal_the_per_query_searches(env):
         hits = idx.search_top_k_int8_two_pass(q[qi], K, 3)
         assert [h.index for h in hits] == r8[qi].tolist()
         assert np.array_equal(bits([h.score for h in hits]), bits(s8[qi]))
+
+
+def test_batched_answers_equal_the_oracle_directly_at_full_size(env, oracle):
+    """Eight answers of a 1,024-query batched search (matrix-core path, int8 filter, exact re-score) at 10M rows against the
+    ORACLE on the same bytes — not against the per-query HIP kernels: rows and f32 score bits."""
+    idx, q = env["idx"], env["queries"]
+    import bench
+
+    host = env["slab"].contiguous().view(env["torch"].int16).cpu().numpy().view(np.uint16)
+    qh = bench.gen_queries(1024, DIM, env["dev"]).cpu().numpy()
+    rows, scores, counts, fb = idx.search_batched(qh, K)
+    threads = bench._oracle_threads()
+    for qi in (0, 1, 255, 256, 511, 512, 777, 1023):
+        er, es = oracle.search_top_k(host, qh[qi], K, nthreads=threads)
+        assert counts[qi] == K and np.array_equal(rows[qi], er) and np.array_equal(bits(scores[qi]), bits(es)), qi
+    st = idx.batched_filter_stats()
+    assert st["int8_active"] and st["int8_queries"] >= 1024
+
+
+@pytest.mark.parametrize("kind", ["uniform", "outlier"])
+def test_adversarial_corpora_at_full_size(env, kind):
+    """SURVEY 8d's low-separation corpus (uniform-random unit vectors) and an anisotropic one with outlier dimensions and Zipf
+    cluster sizes, 10M x 384 each: the batched path — whichever filter it ends up on, whatever it re-filters or hands to the
+    exact kernels — returns the oracle's rows and score bits (8 answers against the oracle, 64 against the exact kernels)."""
+    import bench
+
+    res = bench.adversarial_section(kind, N, DIM, K, env["dev"], 0, steps=2)
+    assert res["batched_equals_oracle_rows_and_bits"] and res["oracle_checked_queries"] == 8, res
+    assert res["batched_equals_exact_kernels_64_queries"], res
+    assert res["queries_per_sec"] > 0

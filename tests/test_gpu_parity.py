@@ -1091,3 +1091,31 @@ def test_randomised_exact_cases_equal_the_oracle(fa, oracle):
                          timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "0 mismatches" in res.stdout
+
+
+@pytest.mark.gpu
+def test_reference_recall_fixture_on_the_gpu_paths(fa, oracle):
+    # search.rs:1927-2006: on this corpus the int8 two-pass (multipliers 3 and 5) must reach recall@10 = 1.0 against the flat
+    # search, for the first four centroids as queries; here additionally every path is held to the oracle's rows and bits
+    cent, rows = oracle.recall_fixture()
+    slab = oracle.encode_f32_to_f16(rows)
+    idx = fa.VectorIndex.from_slab(slab)
+    for c in range(4):
+        q = cent[c]
+        er, es = oracle.search_top_k(slab, q, 10)
+        hits = idx.search_top_k(q, 10)
+        assert [h.index for h in hits] == er.tolist() and np.array_equal(bits([h.score for h in hits]), bits(es))
+        for mult in (3, 5):
+            tr, ts = oracle.search_int8_two_pass(slab, q, 10, mult)
+            th = idx.search_top_k_int8_two_pass(q, 10, mult)
+            assert [h.index for h in th] == tr.tolist() and np.array_equal(bits([h.score for h in th]), bits(ts))
+            assert set(tr.tolist()) == set(er.tolist()), (c, mult)          # recall@10 == 1.0, as the reference asserts
+    # the batched forms over the same fixture (64 jittered queries): exact filter paths and the batched int8 two-pass
+    q = np.stack([rows[i * 61] for i in range(64)])
+    br, bs, bc, _ = idx.search_batched(q, 10)
+    r8, s8, c8, _ = idx.search_int8_two_pass_batched(q, 10, 3)
+    for qi in range(64):
+        er, es = oracle.search_top_k(slab, q[qi], 10)
+        assert np.array_equal(br[qi], er) and np.array_equal(bits(bs[qi]), bits(es)), qi
+        tr, ts = oracle.search_int8_two_pass(slab, q[qi], 10, 3)
+        assert np.array_equal(r8[qi, :c8[qi]], tr) and np.array_equal(bits(s8[qi, :c8[qi]]), bits(ts)), qi

@@ -550,6 +550,18 @@ def test_int8_two_pass_recall_on_clustered_fixture(oracle):
     assert hits >= 95   # >= 0.95 recall@10
 
 
+def test_int8_two_pass_reference_recall_fixture(oracle):
+    # search.rs:1927-2006 (int8_two_pass_maddubs_preserves_recall_vs_flat), the reference's own fixture restated: recall@10 of the
+    # int8 two-pass against the flat search is exactly 1.0 for the first four centroids as queries, multipliers 3 and 5
+    cent, rows = oracle.recall_fixture()
+    slab = oracle.encode_f32_to_f16(rows)
+    for c in range(4):
+        er, _ = oracle.search_top_k(slab, cent[c], 10)
+        for mult in (3, 5):
+            tr, _ = oracle.search_int8_two_pass(slab, cent[c], 10, mult)
+            assert set(tr.tolist()) == set(er.tolist()), (c, mult)
+
+
 def test_int8_two_pass_tombstones_and_small_n(oracle):
     rng = np.random.default_rng(6)
     slab = rng.standard_normal((50, 16)).astype(np.float16).view(np.uint16)
