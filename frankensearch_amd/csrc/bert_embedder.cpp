@@ -37,8 +37,9 @@ NativeEmbedder::~NativeEmbedder() {
     drop_graphs();
     if (stream_) (void)hipStreamDestroy(stream_);
     if (io_host_) (void)hipHostFree(io_host_);
+    if (docs_io_) (void)hipHostFree(docs_io_);
     for (DeviceBuffer* b : {&word_, &pos_, &type_, &emb_ln_w_, &emb_ln_b_, &ids_, &positions_, &offsets_, &x_f32_, &x_h_,
-                            &qkv_f32_, &ctx_h_, &tmp_f32_, &inter_h_, &out_, &q_x_, &q_parts_})
+                            &qkv_f32_, &ctx_h_, &tmp_f32_, &inter_h_, &out_, &q_x_, &q_parts_, &docs_layers_, &docs_in_, &docs_out_})
         b->release();
     for (Layer& l : layers_)
         for (DeviceBuffer* b : {&l.qkv_w, &l.ao_w, &l.i_w, &l.o_w, &l.qkv_wp, &l.ao_wp, &l.i_wp, &l.o_wp, &l.qkv_b, &l.ao_b, &l.ln1_w, &l.ln1_b, &l.i_b, &l.o_b,
@@ -146,6 +147,29 @@ SearchError NativeEmbedder::init(int device, const fsgpu_bert_config& cfg, const
         }
         BERT_HIP(hipDeviceSynchronize());
         packed_ = true;
+        if (bert_docs_w_supported(Hi, Ii, (int)cfg.heads)) {
+            // the one-launch forward of short texts (bert_docs_w.hip) walks a device table of the layers' pointers
+            std::vector<BertDocsLayer> table;
+            for (Layer& l : layers_) {
+                BertDocsLayer t{};
+                t.qkv_wp = l.qkv_wp.ptr;
+                t.ao_wp = l.ao_wp.ptr;
+                t.i_wp = l.i_wp.ptr;
+                t.o_wp = l.o_wp.ptr;
+                t.qkv_b = static_cast<const float*>(l.qkv_b.ptr);
+                t.ao_b = static_cast<const float*>(l.ao_b.ptr);
+                t.ln1_w = static_cast<const float*>(l.ln1_w.ptr);
+                t.ln1_b = static_cast<const float*>(l.ln1_b.ptr);
+                t.i_b = static_cast<const float*>(l.i_b.ptr);
+                t.o_b = static_cast<const float*>(l.o_b.ptr);
+                t.ln2_w = static_cast<const float*>(l.ln2_w.ptr);
+                t.ln2_b = static_cast<const float*>(l.ln2_b.ptr);
+                table.push_back(t);
+            }
+            BERT_TRY(docs_layers_.reserve(table.size() * sizeof(BertDocsLayer)));
+            BERT_HIP(hipMemcpy(docs_layers_.ptr, table.data(), table.size() * sizeof(BertDocsLayer), hipMemcpyHostToDevice));
+            docs_ready_ = true;
+        }
     }
     return SearchError{};
 }
@@ -399,6 +423,128 @@ SearchError NativeEmbedder::forward(uint32_t n_docs, uint32_t tokens, uint32_t m
     return SearchError{};
 }
 
+bool NativeEmbedder::docs_path(uint32_t tokens, uint32_t max_seq) const {
+    static const bool off = fsgpu::lab_env("FSGPU_BERT_NO_DOCS_PATH") != nullptr;  // A/B runs
+    return !off && docs_ready_ && tokens > 32 && max_seq <= 32;
+}
+
+// Every text at most 32 tokens long (a batch of queries): ONE launch for the whole forward (bert_docs_w.hip).  Consecutive texts
+// are packed greedily into row blocks of at most 32 tokens; a block never splits a text.  ids: this call's tokens; offs: the
+// call's offsets rebased to 0.
+SearchError NativeEmbedder::embed_docs(const int32_t* ids, const std::vector<uint32_t>& offs, uint32_t n, uint32_t total, float* out) {
+    const size_t H = cfg_.hidden;
+    std::vector<uint32_t> blk_tok, blk_doc;
+    blk_tok.reserve(n + 1);
+    blk_doc.reserve(n + 1);
+    blk_tok.push_back(0);
+    blk_doc.push_back(0);
+    uint32_t rows = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t len = offs[i + 1] - offs[i];
+        if (rows + len > 32) {   // (rows > 0 here: len <= 32)
+            blk_tok.push_back(offs[i]);
+            blk_doc.push_back(i);
+            rows = 0;
+        }
+        rows += len;
+    }
+    blk_tok.push_back(total);
+    blk_doc.push_back(n);
+    const uint32_t nblocks = (uint32_t)blk_tok.size() - 1;
+    // the blocks' rows, laid out so that a block needs ONE read of the inputs before its embedding gather: token id (-1 = padding),
+    // rows of the block << 16 | position inside the text << 8 | the text's index among the block's non-empty texts
+    std::vector<int32_t> row_id((size_t)nblocks * 32, -1);
+    std::vector<uint32_t> row_meta((size_t)nblocks * 32, 0u);
+    for (uint32_t b = 0; b < nblocks; ++b) {
+        const uint32_t t0 = blk_tok[b], nrows = blk_tok[b + 1] - t0;
+        uint32_t local = 0;
+        for (uint32_t r = 0; r < 32; ++r) row_meta[(size_t)b * 32 + r] = nrows << 16;
+        for (uint32_t i = blk_doc[b]; i < blk_doc[b + 1]; ++i) {
+            if (offs[i + 1] == offs[i]) continue;
+            for (uint32_t t = offs[i]; t < offs[i + 1]; ++t) {
+                row_id[(size_t)b * 32 + (t - t0)] = ids[t];
+                row_meta[(size_t)b * 32 + (t - t0)] |= ((t - offs[i]) << 8) | local;
+            }
+            ++local;
+        }
+    }
+    // one input block: [offsets | blk_tok | blk_doc | row_id | row_meta]
+    const size_t o_tok = (size_t)(n + 1) * 4, o_doc = o_tok + (size_t)(nblocks + 1) * 4, o_rid = o_doc + (size_t)(nblocks + 1) * 4,
+                 o_rmeta = o_rid + (size_t)nblocks * 32 * 4;
+    const size_t in_bytes = (o_rmeta + (size_t)nblocks * 32 * 4 + 255) & ~(size_t)255;
+    const size_t out_bytes = (size_t)n * H * 4;
+    const bool pinned = in_bytes + out_bytes <= kDocsIoBytes;
+    if (pinned && !docs_io_ && !docs_io_failed_ && hipHostMalloc(&docs_io_, kDocsIoBytes, hipHostMallocMapped) != hipSuccess) {
+        docs_io_ = nullptr;
+        docs_io_failed_ = true;
+        (void)hipGetLastError();
+    }
+    BertDocsArgs a{};
+    a.word = static_cast<const float*>(word_.ptr);
+    a.pos = static_cast<const float*>(pos_.ptr);
+    a.type0 = static_cast<const float*>(type_.ptr);
+    a.emb_lnw = static_cast<const float*>(emb_ln_w_.ptr);
+    a.emb_lnb = static_cast<const float*>(emb_ln_b_.ptr);
+    a.layers = static_cast<const BertDocsLayer*>(docs_layers_.ptr);
+    a.nlayers = (int)cfg_.layers;
+    a.eps = cfg_.ln_eps;
+    a.attn_scale = 0.17677669f;  // ATTN_SCALE_F32 = 1/sqrt(32) (native.rs:44)
+    auto fill = [&](unsigned char* dst) {
+        std::memcpy(dst, offs.data(), (size_t)(n + 1) * 4);
+        std::memcpy(dst + o_tok, blk_tok.data(), (size_t)(nblocks + 1) * 4);
+        std::memcpy(dst + o_doc, blk_doc.data(), (size_t)(nblocks + 1) * 4);
+        std::memcpy(dst + o_rid, row_id.data(), row_id.size() * 4);
+        std::memcpy(dst + o_rmeta, row_meta.data(), row_meta.size() * 4);
+    };
+    auto point = [&](const unsigned char* base) {
+        a.offsets = reinterpret_cast<const uint32_t*>(base);
+        a.blk_tok = reinterpret_cast<const uint32_t*>(base + o_tok);
+        a.blk_doc = reinterpret_cast<const uint32_t*>(base + o_doc);
+        a.row_id = reinterpret_cast<const int32_t*>(base + o_rid);
+        a.row_meta = reinterpret_cast<const uint32_t*>(base + o_rmeta);
+    };
+    if (pinned && docs_io_) {
+        // the blocks read their rows in place from the pinned block (mapped into the device's address
+        // space) and the pooled vectors land in it: no copy in either direction
+        unsigned char* io = static_cast<unsigned char*>(docs_io_);
+        fill(io);
+        point(io);
+        a.out = reinterpret_cast<float*>(io + in_bytes);
+#ifdef FSGPU_EXPERIMENTS
+        static const bool trace = fsgpu::lab_env("FSGPU_BERT_DOCS_STAMPS") != nullptr;   // per-phase shader clocks of block 0
+        static unsigned long long* stamps = nullptr;
+        if (trace && !stamps) (void)hipHostMalloc(reinterpret_cast<void**>(&stamps), 128 * 8, hipHostMallocMapped);
+        if (trace && stamps) {
+            std::memset(stamps, 0, 128 * 8);
+            a.stamps = stamps;
+        }
+#endif
+        BERT_HIP(launch_bert_docs_w(a, nblocks, stream_));
+        BERT_HIP(hipStreamSynchronize(stream_));
+#ifdef FSGPU_EXPERIMENTS
+        if (a.stamps) {
+            std::fprintf(stderr, "[docs stamps]");
+            for (int i = 1; i < 4 + 8 * (int)cfg_.layers; ++i)
+                std::fprintf(stderr, " %lld", a.stamps[i] ? (long long)(a.stamps[i] - a.stamps[0]) : -1ll);
+            std::fprintf(stderr, "\n");
+        }
+#endif
+        std::memcpy(out, io + in_bytes, out_bytes);
+        return SearchError{};
+    }
+    std::vector<unsigned char> host(in_bytes);
+    fill(host.data());
+    BERT_TRY(docs_in_.reserve(in_bytes));
+    BERT_TRY(docs_out_.reserve(out_bytes));   // (not out_: captured graphs name that one)
+    BERT_HIP(hipMemcpyAsync(docs_in_.ptr, host.data(), in_bytes, hipMemcpyHostToDevice, stream_));
+    point(static_cast<const unsigned char*>(docs_in_.ptr));
+    a.out = static_cast<float*>(docs_out_.ptr);
+    BERT_HIP(launch_bert_docs_w(a, nblocks, stream_));
+    BERT_HIP(hipMemcpyAsync(out, docs_out_.ptr, out_bytes, hipMemcpyDeviceToHost, stream_));
+    BERT_HIP(hipStreamSynchronize(stream_));
+    return SearchError{};
+}
+
 SearchError NativeEmbedder::embed_batch(const int32_t* ids, const uint32_t* offsets, uint32_t n, float* out) {
     if (n == 0) return SearchError{};
     if (!offsets || !out) return err(FSGPU_ERR_NULL_ARGUMENT, "offsets/out is null");
@@ -429,6 +575,7 @@ SearchError NativeEmbedder::embed_batch(const int32_t* ids, const uint32_t* offs
             positions[t] = (int32_t)(t - offs[i]);  // positions restart at 0 per input (native.rs:1159-1167)
         }
     BERT_HIP(hipSetDevice(device_));
+    if (docs_path(total, max_seq)) return embed_docs(ids + base, offs, n, total, out);
     {
         // (graph-eligible calls share buffers of the graph-eligible maximum: see reserve_workspaces)
         const bool small = total <= kGraphMaxTokens;

@@ -36,6 +36,8 @@ class NativeEmbedder {
     SearchError forward_packed_range(uint32_t d0, uint32_t d1, uint32_t t0, uint32_t t1, uint32_t max_seq, hipStream_t stream);
     SearchError forward_query(uint32_t n_docs, uint32_t tokens);   // <= 32 tokens: 25 launches (bert_query_kernels.hip)
     bool query_path(uint32_t tokens) const;
+    bool docs_path(uint32_t tokens, uint32_t max_seq) const;       // every text <= 32 tokens: ONE launch (bert_docs_w.hip)
+    SearchError embed_docs(const int32_t* ids, const std::vector<uint32_t>& offs, uint32_t n, uint32_t total, float* out);
     SearchError reserve_workspaces(uint32_t tokens);
     void drop_graphs();
 
@@ -67,6 +69,11 @@ class NativeEmbedder {
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, GraphEntry> graphs_;
     bool graphs_enabled_ = true;
     bool packed_ = false;  // every layer has its fragment-order copies: the batch path runs bert_gemm_w.hip
+    DeviceBuffer docs_layers_, docs_in_, docs_out_;   // bert_docs_w.hip: the layers' pointer table; inputs of a call too large for the pinned block
+    bool docs_ready_ = false;
+    static constexpr size_t kDocsIoBytes = 2 * 1024 * 1024;   // pinned block of the one-launch path: row tables in, pooled vectors out
+    void* docs_io_ = nullptr;
+    bool docs_io_failed_ = false;
 };
 
 }  // namespace fsgpu

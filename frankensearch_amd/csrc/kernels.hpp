@@ -307,4 +307,27 @@ hipError_t launch_bert_q_qkv_attn(const BertQueryArgs& a, int heads, hipStream_t
 hipError_t launch_bert_q_gemm(const BertQueryArgs& a, int mode, hipStream_t stream);
 hipError_t launch_bert_q_pool(const BertQueryArgs& a, float* out, hipStream_t stream);
 
+// bert_docs_w.hip: the whole MiniLM-L6 forward of a batch of texts of at most 32 tokens each in ONE launch — a 32-row block
+// owns whole texts, so the six layers chain inside the kernel (native.rs:1142-1236)
+struct BertDocsLayer {           // device pointers of one encoder layer: fragment-order f16 weights (bert_pack_w_kernel), f32 vectors
+    const void *qkv_wp, *ao_wp, *i_wp, *o_wp;
+    const float *qkv_b, *ao_b, *ln1_w, *ln1_b, *i_b, *o_b, *ln2_w, *ln2_b;
+};
+struct BertDocsArgs {
+    const uint32_t* offsets;     // [n_docs + 1] text i owns tokens [offsets[i], offsets[i + 1])
+    const uint32_t* blk_tok;     // [nblocks + 1] first token of each row block: boundaries on text boundaries, at most 32 apart
+    const uint32_t* blk_doc;     // [nblocks + 1] first text of each row block
+    const int32_t* row_id;       // [nblocks * 32] token id of each row of each block, -1 = padding row
+    const uint32_t* row_meta;    // [nblocks * 32] rows of the block << 16 | position inside its text << 8 | its text's index among
+                                 // the block's non-empty texts
+    const float *word, *pos, *type0, *emb_lnw, *emb_lnb;
+    const BertDocsLayer* layers; // [nlayers], device memory
+    int nlayers;
+    float eps, attn_scale;
+    float* out;                  // [n_docs][hidden] pooled, L2-normalised
+    unsigned long long* stamps;  // lab builds (FSGPU_EXPERIMENTS): shader-clock stamps of block 0's phases; null otherwise
+};
+bool bert_docs_w_supported(int hidden, int inter, int heads);
+hipError_t launch_bert_docs_w(const BertDocsArgs& a, uint32_t nblocks, hipStream_t stream);
+
 }  // namespace fsgpu

@@ -139,3 +139,64 @@ def test_outlier_channels_heavy_tails_and_512_token_documents(fa):
     check(m.embed_batch_token_ids(docs), ref.run(docs, 8))
     # the numpy oracle and its C restatement agree on these weights too (the C one is what the long documents are held against)
     assert np.max(np.abs(ref.run(queries[:6], 2) - bert_oracle.embed_forward(w, queries[:6], 6))) < 1e-5
+
+
+def test_one_launch_path_short_texts(fa):
+    """Every text <= 32 tokens and more than 32 tokens in all: the whole forward is ONE launch (bert_docs_w.hip: a 32-row block
+    owns whole texts).  Block packing edge cases — texts of exactly 32 tokens, 1-token texts (32 texts in one block), empty texts
+    at the start / middle / end / a whole block of them, a text that does not fit the rest of its block — against the f32 oracle,
+    and against the batch path (the same texts with a 40-token text appended, which routes the call to the multi-launch kernels)."""
+    from oracle import bert_oracle
+    rng = np.random.default_rng(31)
+    w = bert_oracle.random_weights(27, 3000, 384, 6, 1536)
+    m = fa.NativeEmbedder(w)
+    ref = bert_oracle.CForward(w, 6)
+
+    def text(n):
+        if n == 0:
+            return []
+        if n == 1:
+            return [101]
+        return [101] + rng.integers(1000, 3000, n - 2).tolist() + [102]
+
+    cases = [
+        [32, 32, 32, 1],
+        [1] * 70,
+        [0, 0, 5, 0, 27, 6, 0, 0, 31, 2, 0],
+        [0] * 40 + [20, 20] + [0] * 3,
+        [17, 16, 15, 18, 32, 1, 31, 2, 30, 3, 9, 9, 9, 9, 9],
+        [int(x) for x in rng.integers(0, 33, 300)],
+    ]
+    for lens in cases:
+        batch = [text(n) for n in lens]
+        assert sum(lens) > 32 and max(lens) <= 32
+        got = m.embed_batch_token_ids(batch)
+        check(got, ref.run(batch, 8))
+        # the multi-launch batch path on the same texts (+ one 40-token text that disqualifies the call from the one-launch path)
+        other = m.embed_batch_token_ids(batch + [text(40)])[:-1]
+        assert np.max(np.abs(got - other)) <= 1e-3, np.max(np.abs(got - other))
+        # a text's embedding does not depend on what shares its block or its call (up to the summation order of the attention's
+        # matrix-core reductions, which follows the text's row offset inside its block)
+        alone = m.embed_batch_token_ids([batch[-1], text(32), text(32)])[0] if lens[-1] else np.zeros(384, np.float32)
+        assert np.max(np.abs(got[-1] - alone)) <= 2e-4
+
+
+def test_one_launch_path_outlier_weights_and_large_calls(fa):
+    """The one-launch path on the heavy-tailed weight set (f16 Q/K/V, context and intermediate tiles in LDS), and a call too large
+    for the pinned staging block (4,000 texts: pageable H2D / D2H) equal to its parts."""
+    from oracle import bert_oracle
+    rng = np.random.default_rng(37)
+    w = bert_oracle.heavy_tailed_weights(43, 3000, 384, 6, 1536)
+    m = fa.NativeEmbedder(w)
+    ref = bert_oracle.CForward(w, 6)
+    queries = [[101] + rng.integers(1000, 3000, int(n)).tolist() + [102] for n in rng.integers(3, 31, 96)]
+    check(m.embed_batch_token_ids(queries), ref.run(queries, 8))
+    many = [[101] + rng.integers(1000, 3000, int(n)).tolist() + [102] for n in rng.integers(1, 31, 4000)]
+    whole = m.embed_batch_token_ids(many)
+    parts = np.concatenate([m.embed_batch_token_ids(many[i:i + 250]) for i in range(0, 4000, 250)])
+    # (a text's row offset inside its block differs between the two packings, and with it the summation order of the attention's
+    # matrix-core reductions: equal up to that)
+    assert np.max(np.abs(whole - parts)) <= 2e-4
+    again = m.embed_batch_token_ids(many)
+    assert np.array_equal(whole.view(np.uint32), again.view(np.uint32))
+    check(whole[:16], ref.run(many[:16], 8))
