@@ -46,6 +46,10 @@ hipError_t launch_scan_topk(const ScanArgs& args, int nq, int kcap, int grid, hi
 bool scan_mq_supported(int dim, int nq, int kcap);
 hipError_t launch_scan_mq(const ScanArgs& args, int nq, int kcap, int grid, hipStream_t stream, int* occupancy);
 hipError_t launch_merge_topk(const MergeArgs& args, int nq, hipStream_t stream);
+// one query read from HOST memory at launch time (it travels in the kernel's argument block: no H2D copy); dim <= 512, kcap 64 / 256
+constexpr int kKernargQueryDims = 512;
+bool scan_kernarg_query_supported(int dim, int kcap);
+hipError_t launch_scan_topk_host_query(const ScanArgs& args, const float* query_host, int kcap, int grid, hipStream_t stream);
 hipError_t launch_score_rows(const ScanArgs& args, u64* out_packed, int q_index, int grid, hipStream_t stream);
 hipError_t launch_packed_to_sortkey(u64* data, size_t n, hipStream_t stream);
 hipError_t launch_sorted_keys_to_rows(const u64* keys, uint32_t k, uint32_t* out_rows, uint32_t* out_count,

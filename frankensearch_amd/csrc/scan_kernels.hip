@@ -22,6 +22,8 @@
 // at the end and one sorted list per block goes to HBM for the final merge kernel.
 #pragma clang fp contract(off)
 
+#include <cstring>
+
 #include "scan_common.hpp"
 
 namespace fsgpu {
@@ -36,8 +38,10 @@ using namespace scan_detail;
 //         load the same 16 bytes (coalesced by the TA into one fetch) but multiply by different
 //         queries.  Per-lane arithmetic is identical for every NQ.
 // KCAP:   capacity tier of the per-wave / per-block lists (k <= KCAP); CAP = 2*KCAP.
-template <int DIM_CT, int NQ, int KCAP, bool NT_LOADS = false>
-__global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs args) {
+// qsrc: where the block reads its NQ queries from — args.queries (device memory), or for the one-query latency path the
+// kernel's own argument block (scan_topk_kq_kernel below)
+template <int DIM_CT, int NQ, int KCAP, bool NT_LOADS>
+__device__ __forceinline__ void scan_topk_body(const ScanArgs& args, const float* __restrict__ qsrc) {
     constexpr int CAP = 2 * KCAP;
     constexpr int kRows = kRowsPerTile / NQ;  // rows per wave tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -52,7 +56,7 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs args) {
     const int b = (lane >> 2) & (NQ - 1);
     const int r = lane / (4 * NQ);
 
-    for (int i = tid; i < NQ * dim; i += 256) qs[i] = args.queries[i];
+    for (int i = tid; i < NQ * dim; i += 256) qs[i] = qsrc[i];
     __syncthreads();
 
     WaveTopK<CAP> tk[NQ];
@@ -210,6 +214,26 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs args) {
     __syncthreads();
     for (int x = wave; x < NQ; x += kWavesPerBlock) {
         u64* dst = bufs + ((size_t)0 * NQ + x) * CAP;
+        if (kWavesPerBlock * k <= CAP) {
+            // small ranks (k <= CAP / 4): the four sorted lists' first k entries side by side in wave 0's buffer and ONE sort of
+            // the next power of two (k = 10: 64 entries, 21 compare-exchange steps) instead of three folds of 28 steps each over
+            // CAP entries — this tail is on the critical path of every block, and every block ends at the same time
+            const int n = kWavesPerBlock * k;
+            int np2 = 64;
+            while (np2 < n) np2 <<= 1;
+            for (int i = k + lane; i < np2; i += 64) {
+                u64 v = kEmpty;
+                if (i < n) {
+                    const int w = i / k;
+                    v = bufs[((size_t)w * NQ + x) * CAP + (i - w * k)];
+                }
+                dst[i] = v;
+            }
+            wave_sort_desc_rt(dst, np2, lane);
+            u64* out = args.partial + ((size_t)x * gridDim.x + blockIdx.x) * k;
+            for (int i = lane; i < k; i += 64) out[i] = dst[i];
+            continue;
+        }
         for (int w = 1; w < kWavesPerBlock; ++w) {
             const u64* src = bufs + ((size_t)w * NQ + x) * CAP;
             // top-KCAP of two best-first lists: elementwise max of A[i] and B[KCAP-1-i], then re-sort
@@ -224,6 +248,21 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs args) {
         u64* out = args.partial + ((size_t)x * gridDim.x + blockIdx.x) * k;
         for (int i = lane; i < k; i += 64) out[i] = dst[i];
     }
+}
+
+template <int DIM_CT, int NQ, int KCAP, bool NT_LOADS = false>
+__global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs args) {
+    scan_topk_body<DIM_CT, NQ, KCAP, NT_LOADS>(args, args.queries);
+}
+
+// One query, carried in the kernel's argument block (the dispatch packet's kernarg segment): the latency path of a lone caller
+// needs no H2D copy in front of the scan — the launch itself delivers the 4 dim bytes.  dim <= kKernargQueryDims.
+struct KernargQuery {
+    float q[kKernargQueryDims];
+};
+template <int DIM_CT, int KCAP>
+__global__ __launch_bounds__(256) void scan_topk_kq_kernel(ScanArgs args, KernargQuery kq) {
+    scan_topk_body<DIM_CT, 1, KCAP, false>(args, kq.q);
 }
 
 // Thread-per-row fallback for dimensions that are not a multiple of 8 (rows are not 16-byte aligned).
@@ -332,6 +371,7 @@ __global__ __launch_bounds__(NT) void merge_topk_kernel(MergeArgs args) {
     __shared__ int s_count;
     __shared__ u64 s_thr;
     __shared__ int s_rank[2048];
+    __shared__ u64 s_gmax[64];
     constexpr int HCAP = 2048;
     constexpr int PER = MCAP / NT;
     const int tid = threadIdx.x;
@@ -380,7 +420,29 @@ __global__ __launch_bounds__(NT) void merge_topk_kernel(MergeArgs args) {
         }
         if (lane == 0 && best_tail) atomicMax(&s_thr, best_tail);
         __syncthreads();
-        if (use_heads) {
+        // Small ranks over at most NT lists (a lone query's exact scan: ~1,000 block lists x k = 10): the EXACT k-th largest head
+        // below costs every thread a pass over all heads (~7 us of this kernel's 25); any k distinct entries bound the k-th best
+        // from below, so the k-th largest of the maxima of the heads' 16-lane groups serves — a dozen more survivors for the final
+        // one-wave sort, three barriers instead of the ranking.
+        const uint32_t ngroups = (nlists + 15) / 16;
+        const bool quick_heads = use_heads && nlists <= (uint32_t)NT && ngroups <= 64 && (uint32_t)k <= ngroups;
+        if (quick_heads) {
+            u64 h = (uint32_t)tid < nlists ? hkeys[tid] : 0ull;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const u64 o = __shfl_xor(h, off);
+                h = o > h ? o : h;
+            }
+            if ((tid & 15) == 0 && (uint32_t)(tid >> 4) < ngroups) s_gmax[tid >> 4] = h;
+            __syncthreads();
+            if (tid < 64) {
+                const u64 mine = (uint32_t)tid < ngroups ? s_gmax[tid] : 0ull;
+                int greater = 0;
+                for (uint32_t j = 0; j < ngroups; ++j) greater += s_gmax[j] > mine ? 1 : 0;
+                if (mine != 0 && greater == k - 1) atomicMax(&s_thr, mine);   // keys are unique: at most one group has this rank
+            }
+            __syncthreads();
+        } else if (use_heads) {
             // rank heads: P threads share one head, each scanning a slice of the head array (broadcast reads)
             uint32_t np2 = 1;
             while (np2 < nlists) np2 <<= 1;
@@ -695,6 +757,41 @@ hipError_t launch_scan_topk(const ScanArgs& args, int nq, int kcap, int grid, hi
     return hipErrorInvalidValue;
 }
 
+template <int DIM_CT, int KCAP>
+static hipError_t launch_scan_kq_t(const ScanArgs& args, const KernargQuery& kq, int grid, hipStream_t stream) {
+    const size_t lds = scan_lds_bytes(DIM_CT ? DIM_CT : (int)args.dim, 1, KCAP);
+    auto kern = scan_topk_kq_kernel<DIM_CT, KCAP>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, args, kq);
+    return hipGetLastError();
+}
+
+bool scan_kernarg_query_supported(int dim, int kcap) { return dim % 8 == 0 && dim <= kKernargQueryDims && (kcap == 64 || kcap == 256); }
+
+// one query from HOST memory (copied into the launch's argument block); same kernel body, grid and lists as launch_scan_topk(nq = 1)
+hipError_t launch_scan_topk_host_query(const ScanArgs& args, const float* query_host, int kcap, int grid, hipStream_t stream) {
+    if (!scan_kernarg_query_supported((int)args.dim, kcap)) return hipErrorInvalidValue;
+    KernargQuery kq;
+    std::memcpy(kq.q, query_host, (size_t)args.dim * 4);
+#define FSGPU_KQ(KCAP_)                                                                      \
+    if (kcap == KCAP_) {                                                                     \
+        switch (args.dim) {                                                                  \
+            case 128: return launch_scan_kq_t<128, KCAP_>(args, kq, grid, stream);           \
+            case 256: return launch_scan_kq_t<256, KCAP_>(args, kq, grid, stream);           \
+            case 384: return launch_scan_kq_t<384, KCAP_>(args, kq, grid, stream);           \
+            case 512: return launch_scan_kq_t<512, KCAP_>(args, kq, grid, stream);           \
+            default: return launch_scan_kq_t<0, KCAP_>(args, kq, grid, stream);              \
+        }                                                                                    \
+    }
+    FSGPU_KQ(64)
+    FSGPU_KQ(256)
+#undef FSGPU_KQ
+    return hipErrorInvalidValue;
+}
+
 template <int DIM_CT, int NQ, int KCAP>
 static int occupancy_t(int dim) {
     int blocks = 0;
@@ -736,18 +833,23 @@ int scan_occupancy_blocks_per_cu(int dim, int nq, int kcap, bool force_runtime_d
     return 1;
 }
 
-hipError_t launch_merge_topk(const MergeArgs& args, int nq, hipStream_t stream) {
-    constexpr int MCAP = 8192, NT = 1024;
+template <int MCAP>
+static hipError_t launch_merge_t(const MergeArgs& args, int nq, hipStream_t stream) {
+    constexpr int NT = 1024;
     auto kern = merge_topk_kernel<MCAP, NT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, MCAP * 8);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MCAP * 8);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(nq), dim3(NT), MCAP * 8, stream, args);
     return hipGetLastError();
+}
+
+hipError_t launch_merge_topk(const MergeArgs& args, int nq, hipStream_t stream) {
+    // The exact scan's grid of one resident wave of blocks (1,024 on 256 CUs) x k = 10 is 10,240 entries: just past the
+    // 8,192-entry one-pass form, whose streaming fallback took 25 us of a 1M-row query's 185.  Up to 16,384 entries the one-pass
+    // form runs with 16 entries per thread (128 KB of LDS for the worst case of nothing pruned).
+    const size_t total = (size_t)args.nlists * args.list_len;
+    if (total > 8192 && total <= 16384) return launch_merge_t<16384>(args, nq, stream);
+    return launch_merge_t<8192>(args, nq, stream);
 }
 
 hipError_t launch_score_rows(const ScanArgs& args, u64* out_packed, int q_index, int grid, hipStream_t stream) {

@@ -845,6 +845,7 @@ SearchError VectorIndex::fused_search(const float* queries_dev, uint32_t nq, uin
         }
         if (f32_) FSGPU_HIP(launch_scan_topk_f32(a, kcap, grid, stream, nullptr));
         else if (mq) FSGPU_HIP(launch_scan_mq(a, pass, kcap, grid, stream, nullptr));
+        else if (host_query_hint_ && nq == 1) FSGPU_HIP(launch_scan_topk_host_query(a, host_query_hint_, kcap, grid, stream));
         else FSGPU_HIP(launch_scan_topk(a, pass, kcap, grid, stream, variant == 1, variant == 2));
         if (profiling) {
             FSGPU_HIP(hipEventRecord(e1, stream));
@@ -995,19 +996,28 @@ SearchError VectorIndex::search_top_k(const float* queries, uint32_t nq, uint32_
         uint32_t* rows_pin = reinterpret_cast<uint32_t*>(io + ((qbytes + 63) & ~(size_t)63));
         float* scores_pin = reinterpret_cast<float*>(rows_pin + (size_t)nq * k);
         uint32_t* counts_pin = reinterpret_cast<uint32_t*>(scores_pin + (size_t)nq * k);
-        std::memcpy(q_pin, queries, qbytes);
-        FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, q_pin, qbytes, hipMemcpyHostToDevice, stream_));
         // opted in (fsgpu_index_set_int8_latency): the same hits through the int8 filter + exact re-score — half the bytes of the
         // exact kernel's pass; anything that path does not cover falls through to the exact kernels inside it
         const bool via_filter = int8_latency && batched_filter != 1 && !i8f_disabled_ && k <= 64 && nq <= 16 && !f32_ &&
                                 !(row_stride_ && row_stride_ != dim_ * 2) && nrows_ >= 4 * 8192ull;
+        // a lone query of a fused-kernel shape travels in the scan kernel's argument block: no H2D copy in front of the scan
+        const uint32_t k_lat = (uint64_t)k < nrows_ ? k : (uint32_t)nrows_;
+        const bool in_kernarg = nq == 1 && !via_filter && !f32_ && dim_ % 8 == 0 && k_lat <= 256 && variant == 0 &&
+                                scan_kernarg_query_supported((int)dim_, k_lat <= 64 ? 64 : 256);
+        if (!in_kernarg) {
+            std::memcpy(q_pin, queries, qbytes);
+            FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, q_pin, qbytes, hipMemcpyHostToDevice, stream_));
+        }
         if (via_filter) {
             uint32_t fb = 0;
             FSGPU_TRY(search_top_k_batched_device(static_cast<const float*>(ws_queries_.ptr), nq, query_len, k, nullptr, rows_pin,
                                                   scores_pin, counts_pin, stream_, &fb));
         } else {
-            FSGPU_TRY(search_top_k_device(static_cast<const float*>(ws_queries_.ptr), nq, query_len, k, nullptr, rows_pin,
-                                          scores_pin, counts_pin, stream_));
+            host_query_hint_ = in_kernarg ? queries : nullptr;
+            const SearchError se = search_top_k_device(static_cast<const float*>(ws_queries_.ptr), nq, query_len, k, nullptr, rows_pin,
+                                                       scores_pin, counts_pin, stream_);
+            host_query_hint_ = nullptr;
+            FSGPU_TRY(se);
         }
         FSGPU_HIP(hipStreamSynchronize(stream_));
         std::memcpy(out_rows, rows_pin, (size_t)nq * k * 4);

@@ -245,6 +245,7 @@ class VectorIndex {
     int mf_shape_ = -1, mf_per_cu_narrow_ = 1, mf_per_cu_wide_ = 1, mf_per_cu_narrow_i8_ = 1, mf_per_cu_wide_i8_ = 1;  // batched-scan launch shapes (probed once)
     static constexpr size_t kPinnedIoBytes = 256 * 1024;
     void* io_host_ = nullptr;  // pinned staging for the single-query latency paths
+    const float* host_query_hint_ = nullptr;   // search_top_k's lone query, still in host memory: fused_search launches the scan with it in the argument block
     bool io_failed_ = false;
     uint32_t* mf_flags_host_ = nullptr;                              // pinned per-query verdicts of the batched scan
     uint32_t mf_flags_cap_ = 0;
