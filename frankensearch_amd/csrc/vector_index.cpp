@@ -1270,32 +1270,132 @@ SearchError VectorIndex::two_pass_candidates_device(const float* queries_dev, ui
     return ok();
 }
 
+// ---- the batched (matrix-core) search: prepare -> per round { sample -> main -> finish } -> fallback -------------------------
+//
 // int8_mult == 0: f16 slab, f16-rounded queries, approximate scores + proven margin (mfma_scan.hip header).
 // int8_mult >= 1: int8 slab, int8 queries, exact integer scores; the k * int8_mult best rows are the candidates.
 // i8_filter (int8_mult == 0): int8 slab and queries as the FILTER of the exact search — integer scores + the proven margin of
 //                 prepare_queries_i8_filter_kernel; queries it cannot certify are re-filtered on the f16 path (*refiltered).
+
+// What one call fixes for all its rounds: the arguments, the sample sizes, the workspaces.
+struct VectorIndex::BatchedPlan {
+    static constexpr uint32_t GMAX = 160;    // queries per pass: 128 (160 opt-in), or 64 for small batches / tails
+    static constexpr uint32_t CAPQ = 8192;   // entries one selection pass covers: block lists + pool fit it at the wide shape
+    static constexpr uint32_t SPILL = 4096;  // per-query overflow area for candidates that did not fit their block's list
+    static constexpr uint32_t KC = kSelectPool;  // approximate candidates re-scored exactly (at most)
+    static constexpr uint32_t RA_MAX = 8192;
+    // arguments
+    const float* queries_dev = nullptr;
+    uint32_t nq = 0, query_len = 0, k = 0;
+    const uint64_t* allow_dev = nullptr;
+    uint32_t* out_rows_dev = nullptr;
+    float* out_scores_dev = nullptr;
+    uint32_t* out_counts_dev = nullptr;
+    hipStream_t stream = nullptr;
+    uint32_t* fallbacks = nullptr;
+    uint64_t* out_packed_dev = nullptr;
+    uint32_t int8_mult = 0, query_stride = 0;
+    uint32_t* refiltered = nullptr;
+    int bits = 8;
+    // derived
+    bool i8f = false, i8 = false, strided = false, skip_b = false, wide_ok = false;
+    uint32_t qs = 0;                  // floats between queries
+    uint32_t RA = 4096;               // stage A sample rows (dense; <= 8192)
+    uint32_t RB = 131072;             // stage B sample rows (upper bound; shrinks with the slab)
+    uint32_t ksel_est = 0, ksel = 0;  // the rank the selections anchor on (estimate incl. the int8 filter's growth; exact)
+    uint32_t N = 0, QCAP = 0, wide_max = 0, k_eff = 0;
+    int wide_pref = 3;
+    // per-query verdicts, written by the kernels straight into pinned host memory and read after ONE stream synchronisation
+    uint32_t *overflow_all = nullptr, *counts_all = nullptr;
+    float *delta = nullptr, *tau = nullptr, *unit = nullptr, *tau_floor = nullptr;
+    uint32_t* pool_flag = nullptr;
+    u64 *spill = nullptr, *pool = nullptr;
+    uint32_t* spill_count = nullptr;
+    bool big_pool_last = false;       // the last round's finish had the second-chance launch (debug print only)
+};
+
+// One round: up to QCAP queries — the sample stages and every selection are single launches over all its query groups, only the
+// main pass is one launch per group.
+struct VectorIndex::BatchedRound {
+    uint32_t g0 = 0;                  // first query of the round
+    int wide_qt = 0, shape = 0, wpb = 0, full_grid = 0, wide_grid = 0;
+    uint32_t G = 0, wide_mult = 1, ngroups = 0, QP = 0, ng = 0, tile_rows = 0;
+    const float* qg = nullptr;
+    uint32_t *overflow = nullptr, *cand_counts = nullptr, *cand_count = nullptr;
+    u64* cand = nullptr;
+    MfmaScanArgs a{};
+    SelectArgs sb{};
+    bool anchor = false, short_stages = false;
+    int grid_for(uint32_t rows, uint32_t tile) const {
+        int g = (int)(((rows + tile - 1) / tile + wpb - 1) / wpb);
+        if (g > full_grid) g = full_grid;
+        return g < 1 ? 1 : g;
+    }
+    // one candidate list of `slots` entries per (query, block); 16..32 slots, sized so that lists + pool fit one selection pass
+    // when the grid allows (the wide shape's 256 blocks do)
+    uint32_t slots_for(int grid) const {
+        return std::min<uint32_t>((uint32_t)scan_mfma_max_slots(shape),
+                                  std::max<uint32_t>(16, (BatchedPlan::CAPQ - BatchedPlan::KC) / (uint32_t)grid));
+    }
+};
+
 SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
                                       const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
                                       uint32_t* out_counts_dev, hipStream_t stream, uint32_t* fallbacks,
                                       uint64_t* out_packed_dev, uint32_t int8_mult, uint32_t query_stride, bool i8_filter,
                                       uint32_t* refiltered, int bits) {
-    // query_stride: floats between queries (0 = dim): an MRL prefix view searches the first dim_ dimensions of full-length queries
-    const bool i8f = i8_filter && int8_mult == 0;
-    const bool i8 = int8_mult != 0 || i8f;
+    BatchedPlan p;
+    p.queries_dev = queries_dev;
+    p.nq = nq;
+    p.query_len = query_len;
+    p.k = k;
+    p.allow_dev = allow_dev;
+    p.out_rows_dev = out_rows_dev;
+    p.out_scores_dev = out_scores_dev;
+    p.out_counts_dev = out_counts_dev;
+    p.stream = stream;
+    p.fallbacks = fallbacks;
+    p.out_packed_dev = out_packed_dev;
+    p.int8_mult = int8_mult;
+    p.query_stride = query_stride;   // floats between queries (0 = dim): an MRL prefix view searches the first dim_ dimensions of full-length queries
+    p.refiltered = refiltered;
+    p.bits = bits;
+    p.i8f = i8_filter && int8_mult == 0;
+    p.i8 = int8_mult != 0 || p.i8f;
     if (refiltered) *refiltered = 0;
-    const uint32_t qs = query_stride ? query_stride : dim_;
     if (fallbacks) *fallbacks = 0;
     FSGPU_TRY(ensure_query_dimension(query_len));
     if (nq == 0) return ok();
-    constexpr uint32_t GMAX = 160;    // queries per pass: 128 (160 opt-in), or 64 for small batches / tails
-    constexpr uint32_t CAPQ = 8192;   // entries one selection pass covers: block lists + pool fit it at the wide shape
-    constexpr uint32_t SPILL = 4096;  // per-query overflow area for candidates that did not fit their block's list
-    constexpr uint32_t KC = kSelectPool;  // approximate candidates re-scored exactly (at most)
-    uint32_t RA = 4096;               // stage A sample rows (dense; <= 8192)
-    uint32_t RB = 131072;             // stage B sample rows (upper bound; shrinks with the slab, see below)
+    bool done = false;
+    FSGPU_TRY(batched_prepare(p, &done));
+    if (done) return ok();
+    for (uint32_t g0 = 0; g0 < nq;) {
+        BatchedRound r;
+        FSGPU_TRY(batched_round_setup(p, r, g0));
+        FSGPU_TRY(batched_sample(p, r));
+        FSGPU_TRY(batched_main(p, r));
+        FSGPU_TRY(batched_finish(p, r));
+        g0 += r.ng;
+    }
+    // everything of this search is enqueued: the caller's window for host work that should run under it (one shot, outer call only)
+    if (after_enqueue_fn && !hard_batch_) {
+        void (*fn)(void*) = after_enqueue_fn;
+        after_enqueue_fn = nullptr;
+        fn(after_enqueue_ctx);
+    }
+    return batched_fallback(p);
+}
+
+// Stage "prepare": the sample sizes, the shapes the matrix-core path does not cover (answered here, *done = true), the lazily
+// built quantised copies and statistics, the workspaces.
+SearchError VectorIndex::batched_prepare(BatchedPlan& p, bool* done) {
+    *done = false;
+    const uint32_t nq = p.nq, k = p.k;
+    p.qs = p.query_stride ? p.query_stride : dim_;
+    uint32_t RA = 4096, RB = 131072;
     if (knobs().ra > 0) RA = (uint32_t)knobs().ra;  // tuning experiments only
     if (knobs().rb > 0) RB = (uint32_t)knobs().rb;
-    constexpr uint32_t RA_MAX = 8192;
+    constexpr uint32_t RA_MAX = BatchedPlan::RA_MAX;
     if (RA < 256 || RA > RA_MAX || (RA & 63)) RA = 4096;
     // Small slabs (a row shard of a multi-GPU index): a dense sample of 8192 rows already gives a threshold that lets
     // only ~k N / 8192 rows of the main pass through, so the second sampling stage (a launch plus a selection, ~55 us)
@@ -1304,9 +1404,9 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     // (Not when the main pass is the register-resident-query kernel, i.e. for batches of 256 and more: a row that passes its
     // threshold costs that kernel's 160-instruction tile loop a divergent append, and the looser threshold of a skipped stage
     // B lets 4 x as many through — 1.25M-row shard, 1,024 queries: main pass 0.366 -> 0.329 ms, 2.5M: 0.741 -> 0.642 ms.)
-    const bool wide_main = knobs().wide != 0 && nq >= 256 && scan_wide_supported((int)dim_, i8 ? 1 : 2) && variant != 5 && variant != 6;
+    const bool wide_main = knobs().wide != 0 && nq >= 256 && scan_wide_supported((int)dim_, p.i8 ? 1 : 2) && variant != 5 && variant != 6;
     if (knobs().ra <= 0 && !knobs().no_skip_b && !wide_main && nrows_ <= 4'000'000 && nrows_ >= 4 * (uint64_t)RA_MAX) {
-        const uint64_t expect = (uint64_t)std::max<uint32_t>(k, 1) * (i8 ? std::max<uint32_t>(int8_mult, 1) : 1) * (nrows_ / RA_MAX);
+        const uint64_t expect = (uint64_t)std::max<uint32_t>(k, 1) * (p.i8 ? std::max<uint32_t>(p.int8_mult, 1) : 1) * (nrows_ / RA_MAX);
         if (expect <= 4096) {
             RA = RA_MAX;
             skip_b = true;
@@ -1316,7 +1416,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     // lists, spill area, the selection's capacity), so the samples grow with the rank the selections anchor on.
     // (the int8 filter's margin lets a few times as many rows through each stage as its rank alone would: sized like a larger rank)
     const uint32_t i8f_growth = knobs().i8f_growth > 0 ? (uint32_t)knobs().i8f_growth : 4;
-    const uint32_t ksel_est = std::max<uint32_t>(k, 1) * (int8_mult ? int8_mult : 1) * (i8f ? i8f_growth : 1);
+    const uint32_t ksel_est = std::max<uint32_t>(k, 1) * (p.int8_mult ? p.int8_mult : 1) * (p.i8f ? i8f_growth : 1);
     const uint32_t grow = knobs().rb > 0 ? 1 : std::min<uint32_t>(4, (ksel_est + 15) / 16);
     if (knobs().ra <= 0 && ksel_est > 32) RA = RA_MAX;
     // B = about 1/64 of the slab (times the growth), between 8 RA and the cap, a multiple of RA, at most a quarter of it
@@ -1335,76 +1435,56 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     }
     RB = std::min<uint32_t>(RB, (uint32_t)(nrows_ / 4));
     RB = std::max<uint32_t>(RA, RB / RA * RA);
+    p.RA = RA;
+    p.RB = RB;
+    p.skip_b = skip_b;
+    p.ksel_est = ksel_est;
     // int8 mode: candidate_count of the reference (search.rs:603-607)
-    uint64_t cc64 = std::min<uint64_t>((uint64_t)k * (int8_mult ? int8_mult : 1), nrows_);
+    uint64_t cc64 = std::min<uint64_t>((uint64_t)k * (p.int8_mult ? p.int8_mult : 1), nrows_);
     cc64 = std::max<uint64_t>(cc64, std::min<uint64_t>(k, nrows_));
-    const uint32_t ksel = int8_mult ? (uint32_t)std::min<uint64_t>(cc64, 0xffffffffull) : k;  // rank that anchors the selections
-    const bool strided = row_stride_ && row_stride_ != dim_ * 2;   // an MRL prefix view
-    const bool usable = scan_mfma_supported((int)dim_) && k >= 1 && k <= 64 && ksel <= kSelectMaxK && nrows_ >= 4 * (uint64_t)RA && variant != 4 &&
-                        !f32_ && (!strided || (!i8 && qs >= dim_)) && (query_stride == 0 || !i8);
-    if (!usable && i8f)   // shapes the matrix-core path does not cover: the f16 branch below sorts them out
-        return batched_impl(queries_dev, nq, query_len, k, allow_dev, out_rows_dev, out_scores_dev, out_counts_dev, stream, fallbacks,
-                            out_packed_dev, 0, query_stride, false, nullptr);
-    if (!usable && i8) {
-        // per-query int8 two-pass through host staging (rare shapes: huge candidate counts, tiny or odd-dimension slabs)
-        std::vector<float> q((size_t)nq * dim_), sc((size_t)nq * k);
-        std::vector<uint32_t> rw((size_t)nq * k, 0xffffffffu), cnt(nq);
-        FSGPU_HIP(hipMemcpyAsync(q.data(), queries_dev, q.size() * 4, hipMemcpyDeviceToHost, stream));
-        FSGPU_HIP(hipStreamSynchronize(stream));
-        for (uint32_t i = 0; i < nq; ++i)
-            FSGPU_TRY(quantized_two_pass(q.data() + (size_t)i * dim_, dim_, k, int8_mult, bits, rw.data() + (size_t)i * k,
-                                         sc.data() + (size_t)i * k, &cnt[i], tp_approx_out_ ? tp_approx_out_ + (size_t)i * tp_stride_ : nullptr,
-                                         tp_exact_out_ ? tp_exact_out_ + (size_t)i * tp_stride_ : nullptr));
-        if (out_rows_dev) FSGPU_HIP(hipMemcpyAsync(out_rows_dev, rw.data(), rw.size() * 4, hipMemcpyHostToDevice, stream));
-        if (out_scores_dev) FSGPU_HIP(hipMemcpyAsync(out_scores_dev, sc.data(), sc.size() * 4, hipMemcpyHostToDevice, stream));
-        if (out_counts_dev) FSGPU_HIP(hipMemcpyAsync(out_counts_dev, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice, stream));
-        FSGPU_HIP(hipStreamSynchronize(stream));
-        if (fallbacks) *fallbacks = nq;
-        return ok();
-    }
-    if (!usable && query_stride)
-        return make_error(FSGPU_ERR_INVALID_CONFIG, "strided queries need the matrix-core path (caller falls back per query)");
+    p.ksel = p.int8_mult ? (uint32_t)std::min<uint64_t>(cc64, 0xffffffffull) : k;  // rank that anchors the selections
+    p.strided = row_stride_ && row_stride_ != dim_ * 2;   // an MRL prefix view
+    const bool usable = scan_mfma_supported((int)dim_) && k >= 1 && k <= 64 && p.ksel <= kSelectMaxK && nrows_ >= 4 * (uint64_t)RA && variant != 4 &&
+                        !f32_ && (!p.strided || (!p.i8 && p.qs >= dim_)) && (p.query_stride == 0 || !p.i8);
     if (!usable) {
-        if (fallbacks) *fallbacks = nq;
-        if (out_packed_dev) {
-            FSGPU_TRY(search_top_k_packed_device(queries_dev, nq, query_len, k, allow_dev, out_packed_dev, stream));
-            if (!out_rows_dev) return ok();
-        }
-        return search_top_k_device(queries_dev, nq, query_len, k, allow_dev, out_rows_dev, out_scores_dev,
-                                   out_counts_dev, stream);
+        *done = true;
+        return batched_unusable(p);
     }
     FSGPU_HIP(hipSetDevice(device_));
-    const uint32_t N = (uint32_t)nrows_;
-    if (i8 && bits == 4 && !n4u_ready_) {  // the 4-bit levels of VectorIndex::nibbles_slab(), one per byte: built lazily, once
+    p.N = (uint32_t)nrows_;
+    hipStream_t stream = p.stream;
+    if (p.i8 && p.bits == 4 && !n4u_ready_) {  // the 4-bit levels of VectorIndex::nibbles_slab(), one per byte: built lazily, once
         FSGPU_TRY(n4u_slab_.reserve((size_t)nrows_ * dim_));
         FSGPU_TRY(i8_max_.reserve(4));
         FSGPU_HIP(launch_quantize_slab_4bit_levels(slab_dev_, (size_t)nrows_ * dim_, static_cast<unsigned int*>(i8_max_.ptr),
                                                    n4u_slab_.ptr, stream, quant_max_ready_));
         n4u_ready_ = true;
     }
-    if (i8 && bits != 4 && !i8_ready_) {  // VectorIndex::int8_slab(): built lazily, once
+    if (p.i8 && p.bits != 4 && !i8_ready_) {  // VectorIndex::int8_slab(): built lazily, once
         FSGPU_TRY(i8_slab_.reserve((size_t)nrows_ * dim_));
         FSGPU_TRY(i8_max_.reserve(4));
         FSGPU_HIP(launch_quantize_slab_i8(slab_dev_, (size_t)nrows_ * dim_, static_cast<unsigned int*>(i8_max_.ptr),
                                           i8_slab_.ptr, stream, quant_max_ready_));
         i8_ready_ = true;
     }
-    if (i8f && !i8_stats_ready_) {
+    if (p.i8f && !i8_stats_ready_) {
         FSGPU_TRY(i8_stats_.reserve(16));
-        FSGPU_HIP(launch_i8_slab_stats(slab_dev_, i8_slab_.ptr, N, dim_, static_cast<const unsigned int*>(i8_max_.ptr),
+        FSGPU_HIP(launch_i8_slab_stats(slab_dev_, i8_slab_.ptr, p.N, dim_, static_cast<const unsigned int*>(i8_max_.ptr),
                                        static_cast<unsigned int*>(i8_stats_.ptr), stream));
         i8_stats_ready_ = true;
     }
-    if (!i8 && !mf_norm_ready_) {
+    if (!p.i8 && !mf_norm_ready_) {
         FSGPU_TRY(mf_max_norm_.reserve(4));
-        FSGPU_HIP(launch_max_row_norm(slab_dev_, N, dim_, strided ? row_stride_ : 0, static_cast<unsigned int*>(mf_max_norm_.ptr), stream));
+        FSGPU_HIP(launch_max_row_norm(slab_dev_, p.N, dim_, p.strided ? row_stride_ : 0, static_cast<unsigned int*>(mf_max_norm_.ptr), stream));
         mf_norm_ready_ = true;
     }
     // A large batch is answered a "round" of up to QCAP queries at a time: the sample stages and every selection of
     // a round are single launches over all its query groups (one block per query: 1024 blocks fill the chip where a
     // group's 128 leave half the CUs idle), only the main pass is one launch per group.
+    constexpr uint32_t GMAX = BatchedPlan::GMAX, SPILL = BatchedPlan::SPILL, KC = BatchedPlan::KC;
     const uint32_t round_cap = knobs().round >= (int)GMAX ? (uint32_t)knobs().round : 1024;  // tuning experiments only
     const uint32_t QCAP = std::min<uint32_t>(round_cap, std::max<uint32_t>(GMAX, (nq + 127) / 128 * 128));
+    p.QCAP = QCAP;
     FSGPU_TRY(mf_qh_.reserve((size_t)QCAP * dim_ * 2));
     FSGPU_TRY(mf_delta_.reserve(QCAP * 4));
     FSGPU_TRY(mf_tau_.reserve(QCAP * 16));
@@ -1436,9 +1516,9 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     // the register-resident-query main pass (mfma_wide.hip): 256 queries per launch by default
     // (384 per launch when that many queries are left: the matrix pipe is the bound there and fewer passes leave it more of
     // the power budget — measured 148 k against 130 k queries/s at 10M x 384)
-    const int wide_pref = knobs().wide >= 0 ? knobs().wide : 3;
-    const uint32_t wide_max = (uint32_t)std::max(2, std::min(knobs().wide_max > 0 ? knobs().wide_max : 5, scan_wide_max_query_tiles((int)dim_, i8 ? 1 : 2)));
-    const bool wide_ok = (wide_pref == 2 || wide_pref == 3) && scan_wide_supported((int)dim_, i8 ? 1 : 2) && variant != 5 && variant != 6;
+    p.wide_pref = knobs().wide >= 0 ? knobs().wide : 3;
+    p.wide_max = (uint32_t)std::max(2, std::min(knobs().wide_max > 0 ? knobs().wide_max : 5, scan_wide_max_query_tiles((int)dim_, p.i8 ? 1 : 2)));
+    p.wide_ok = (p.wide_pref == 2 || p.wide_pref == 3) && scan_wide_supported((int)dim_, p.i8 ? 1 : 2) && variant != 5 && variant != 6;
     // per-query verdicts, written by the kernels straight into pinned host memory and read after ONE stream
     // synchronisation for the whole batch: [0, cap) = overflow flags, [cap, 2 cap) = candidate counts
     const uint32_t flag_cap = (nq + GMAX - 1) / GMAX * GMAX + GMAX;
@@ -1449,330 +1529,392 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         FSGPU_HIP(hipHostMalloc(reinterpret_cast<void**>(&mf_flags_host_), (size_t)flag_cap * 8, hipHostMallocMapped));
         mf_flags_cap_ = flag_cap;
     }
-    uint32_t* overflow_all = mf_flags_host_;
-    uint32_t* counts_all = mf_flags_host_ + mf_flags_cap_;
+    p.overflow_all = mf_flags_host_;
+    p.counts_all = mf_flags_host_ + mf_flags_cap_;
     std::memset(mf_flags_host_, 0, (size_t)mf_flags_cap_ * 8);
-    float* delta = static_cast<float*>(mf_delta_.ptr);
-    float* tau = static_cast<float*>(mf_tau_.ptr);
-    float* unit = tau + QCAP;   // int8 filter: integer-score units per exact-score unit, per query
-    uint32_t* pool_flag = reinterpret_cast<uint32_t*>(unit + QCAP);
-    float* tau_floor = reinterpret_cast<float*>(pool_flag + QCAP);   // the first sample's proven threshold, kept next to a heuristic one   // finish: candidates did not fit the pool (per query of the round)
-    u64* spill = static_cast<u64*>(mf_spill_.ptr);
-    uint32_t* spill_count = reinterpret_cast<uint32_t*>(spill + (size_t)QCAP * SPILL);
-    u64* pool = static_cast<u64*>(mf_sel_.ptr);
-    const uint32_t k_eff = std::min<uint32_t>(k, N);
-    bool sb_big_pool_last = false;
-    for (uint32_t g0 = 0; g0 < nq;) {
-        const uint32_t left = nq - g0;
-        // Main pass at 384 / 256 queries per launch (mfma_wide.hip: queries in registers, row tiles through an LDS-DMA
-        // ring) when that many are left; the sample stages then run as sub-groups of 128 on the LDS-query kernel.
-        int wide_qt = 0;
-        if (wide_ok && left >= 256) {   // 128-query groups per launch
-            // as many as the registers hold (f16 rows of 384 dimensions: 3, their int8 form: 5), the round's groups spread evenly
-            // over its passes (8 groups: 3 + 3 + 2 on f16 rows, 4 + 4 on int8 rows)
-            const uint32_t groups_left = std::min<uint32_t>(left / 128, QCAP / 128);
-            const uint32_t passes = (groups_left + wide_max - 1) / wide_max;
-            wide_qt = wide_pref == 2 ? 2 : (int)((groups_left + passes - 1) / passes);
-        }
-        // 160, 128 or 64 queries per pass
-        const int shape = wide_qt ? (i8 ? mf_shape_i8_ : mf_shape_)
-                                  : (left > 64 && variant != 5) ? ((left > 128 && mf_use_160_) ? 5 : (i8 ? mf_shape_i8_ : mf_shape_)) : 0;
-        const uint32_t G = (uint32_t)scan_mfma_query_tiles(shape) * 16;
-        const uint32_t wide_mult = wide_qt ? (uint32_t)wide_qt : 1;   // sample groups per main-pass launch
-        // this round: `ngroups` groups of G queries (the last one may be partly padding), QP query slots, ng real queries
-        uint32_t ngroups = left >= G ? std::min<uint32_t>(left / G, QCAP / G) : 1;
-        if (wide_qt) ngroups = ngroups / wide_mult * wide_mult;
-        const uint32_t QP = ngroups * G;
-        const uint32_t ng = std::min(QP, left);
-        const int wpb = scan_mfma_waves_per_block(shape);
-        const int per_cu = shape == 5 ? (i8 ? mf_per_cu_160_i8_ : mf_per_cu_160_)
-                                      : (i8 ? (shape ? mf_per_cu_wide_i8_ : mf_per_cu_narrow_i8_)
-                                            : (shape ? mf_per_cu_wide_ : mf_per_cu_narrow_));
-        const int full_grid = num_cus_ * per_cu;
-        auto grid_for = [&](uint32_t rows, uint32_t tile_rows) {
-            int g = (int)(((rows + tile_rows - 1) / tile_rows + wpb - 1) / wpb);
-            if (g > full_grid) g = full_grid;
-            return g < 1 ? 1 : g;
-        };
-        const uint32_t tile_rows = (uint32_t)scan_mfma_rows_per_tile(shape);
-        const float* qg = queries_dev + (size_t)g0 * qs;
-        uint32_t* overflow = overflow_all + g0;
-        uint32_t* cand_counts = counts_all + g0;
-        if (i8f)
-            FSGPU_HIP(launch_prepare_queries_i8_filter(qg, ng, QP, dim_, qs, static_cast<const unsigned int*>(i8_max_.ptr),
-                                                       static_cast<const unsigned int*>(i8_stats_.ptr), mf_qh_.ptr, delta, stream, unit));
-        else if (i8) FSGPU_HIP(launch_prepare_queries_i8(qg, ng, QP, dim_, mf_qh_.ptr, delta, stream, bits));
-        else
-            FSGPU_HIP(launch_prepare_queries(qg, ng, QP, dim_, qs, static_cast<const unsigned int*>(mf_max_norm_.ptr),
-                                             mf_qh_.ptr, delta, stream));
-        // one candidate list of `slots` entries per (query, block); 16..32 slots, sized so that lists + pool fit one
-        // selection pass when the grid allows (the wide shape's 256 blocks do)
-        auto slots_for = [&](int grid) {
-            return std::min<uint32_t>((uint32_t)scan_mfma_max_slots(shape), std::max<uint32_t>(16, (CAPQ - KC) / (uint32_t)grid));
-        };
-        const int wide_grid = num_cus_ * mf_per_cu_wide_main_;
-        FSGPU_TRY(mf_cand_.reserve((size_t)QP * std::max(full_grid, wide_grid) * kMfmaMaxSlots * 8));
-        u64* cand = static_cast<u64*>(mf_cand_.ptr);
-        FSGPU_TRY(mf_cand_count_.reserve((size_t)QP * wide_grid * 4));   // the wide kernels' list lengths (no padding)
-        uint32_t* cand_count = static_cast<uint32_t*>(mf_cand_count_.ptr);
-        MfmaScanArgs a{};
-        a.slab = i8 ? (bits == 4 ? n4u_slab_.ptr : i8_slab_.ptr) : slab_dev_;
-        a.elem_bytes = i8 ? 1 : 2;
-        a.live = reinterpret_cast<const u64*>(live_dev_);
-        a.allow = reinterpret_cast<const u64*>(allow_dev);
-        a.queries = mf_qh_.ptr;
-        a.tau = tau;
-        a.cand = cand;
-        a.spill = spill;
-        a.spill_count = spill_count;
-        a.spill_cap = SPILL;
-        a.overflow = overflow;
-        a.dim = dim_;
-        a.row_stride = strided ? row_stride_ : 0;
-        a.row_base = (uint32_t)row_base_;
-        // samples, in 64-row groups spread evenly over the slab: B = every stride_b-th group, A = a subset of B
-        const uint32_t groups_a = RA / 64, groups_b = RB / 64;
-        const uint32_t stride_b = (N / 64) / groups_b;  // >= 4
-        a.nrows = N;
-        // stage A: dense approximate scores of the A sample -> tau = (k-th best) - 2 delta
-        a.dense = static_cast<u64*>(mf_dense_.ptr);
-        a.stage = 0;
-        a.group_stride = stride_b * (groups_b / groups_a);
-        a.group_count = groups_a;
-        a.slots = 0;
-        a.groups = ngroups;
-        FSGPU_HIP(launch_scan_mfma(a, shape, grid_for(RA, 16), stream, nullptr));
-        SelectArgs sa{};
-        sa.lists = a.dense;
-        sa.q_stride = RA;
-        sa.l_stride = RA;
-        sa.nlists = 1;
-        sa.list_len = RA;
-        sa.k = ksel;
-        sa.delta = delta;
-        sa.tau_out = tau;
-        // int8 filter: the sample stages' thresholds are anchored on EXACT scores (their candidates are re-scored from the f16
-        // slab right in the selection): one delta below the k-th best instead of two — the margin's multiplier on the rows each
-        // stage lets through is exponential in it
-        const bool anchor = i8f && !knobs().no_anchor;
-        auto set_rescore = [&](SelectArgs& x) {
-            x.slab = slab_dev_;
-            x.queries = qg;
-            x.dim = dim_;
-            x.row_stride = 0;
-            x.query_stride = qs;
-            x.nrows = N;
-            x.row_base = (uint32_t)row_base_;
-            x.hreduce = hreduce;
-            x.k_out = k_eff;
-        };
-        // (a wide round's second sample only anchors the main pass's threshold — that pass visits every row — so it may take ANY
-        // subset of the sample: the rows above the first sample's ~9th best score WITHOUT a margin, half as many as the proven
-        // threshold lets through, and the first selection needs no exact re-score)
-        // (the int8 two-pass takes the same shortcut: its threshold is the ksel-th best integer score of whatever subset came through)
-        const bool heur_b = (anchor || (i8 && !i8f)) && wide_qt != 0 && !skip_b && !knobs().no_wide_b && !knobs().no_heur_b && ksel >= 8;
-        if (heur_b) {
-            // rank r of the first sample: the second sample holds RB / RA x as many rows above that score as the first (r, up to
-            // an order statistic's spread ~ Gamma(r)), and k of them are needed — r = 8 + k / 8 puts "fewer than k came through"
-            // (which only costs that query a looser threshold) below 1e-7 per query for k <= 64 and RB / RA >= 48
-            sa.heur_rank = knobs().heur_rank > 0 ? (uint32_t)std::min<int>(knobs().heur_rank, (int)ksel) : std::min<uint32_t>(ksel, 8 + ksel / 8);
-            sa.tau_floor_out = tau_floor;
-        } else if (anchor) {
-            set_rescore(sa);
-            sa.anchor_unit = unit;
-        }
-        FSGPU_HIP(launch_select(sa, (int)QP, stream));
-        // stage B: the B sample's rows at or above tau, one short list per (query, block) -> tighter tau; the rows
-        // still at or above it form the pool carried into the last selection
-        a.dense = nullptr;
-        a.stage = 1;
-        a.group_stride = stride_b;
-        a.group_count = groups_b;
-        const int grid_b = grid_for(RB, tile_rows);
-        a.slots = slots_for(grid_b);
-        // (a wide round samples on the register-resident-query kernel too: one launch per main-pass group, the same lists)
-        const bool wide_b = wide_qt && !skip_b && !knobs().no_wide_b;
-        const int wide_grid_b = std::min(wide_grid, (int)std::max<uint32_t>(1, RB / 64 / 4));   // at least 4 sample groups per block
-        // (a row shard's stages are short: the lists' padding and the selection's reads are a visible part of them — 8 / 16 slots
-        // there, overflow goes to the spill area; 1.25M rows: 0.809 -> 0.789 ms per 1,024 queries, nothing at 10M)
-        const bool short_stages = nrows_ < 4'000'000;
-        if (wide_b) a.slots = knobs().slots_b > 0 ? (uint32_t)knobs().slots_b : short_stages ? 8 : kWideSlots;
-        if (!skip_b) {
-            FSGPU_HIP(hipMemsetAsync(spill_count, 0, (size_t)QP * kMfmaSpillCountStride * 4, stream));
-            if (wide_b) {
-                const uint32_t GM = G * wide_mult;
-                for (uint32_t j = 0; j < ngroups / wide_mult; ++j) {
-                    MfmaScanArgs c = a;
-                    c.groups = 1;
-                    c.queries = static_cast<const unsigned char*>(mf_qh_.ptr) + (size_t)j * GM * dim_ * (i8 ? 1 : 2);
-                    c.tau = tau + (size_t)j * GM;
-                    c.cand = cand + (size_t)j * GM * wide_grid_b * a.slots;
-                    c.cand_count = cand_count + (size_t)j * GM * wide_grid_b;
-                    c.spill = spill + (size_t)j * GM * SPILL;
-                    c.spill_count = spill_count + (size_t)j * GM * kMfmaSpillCountStride;
-                    c.overflow = overflow + (size_t)j * GM;
-                    FSGPU_HIP(launch_scan_wide(c, wide_qt, wide_grid_b, stream, nullptr));
-                }
-            } else {
-                FSGPU_HIP(launch_scan_mfma(a, shape, grid_b, stream, nullptr));
-            }
-        }
-        const int lists_b = wide_b ? wide_grid_b : grid_b;
-        SelectArgs sb{};
-        sb.lists = cand;
-        sb.q_stride = (uint64_t)lists_b * a.slots;
-        sb.l_stride = a.slots;
-        sb.nlists = (uint32_t)lists_b;
-        sb.list_len = a.slots;
-        sb.list_counts = wide_b ? cand_count : nullptr;
-        sb.k = ksel;
-        sb.take_topk = (i8 && !i8f) ? 1 : 0;
-        sb.delta = delta;
-        sb.overflow = overflow;
-        sb.spill = spill;
-        sb.spill_count = spill_count;
-        sb.spill_cap = SPILL;
-        {
-            if (!skip_b) {
-                sb.tau_out = tau;
-                sb.pool_out = pool;
-                if (anchor) {
-                    set_rescore(sb);
-                    sb.anchor_unit = unit;
-                }
-                if (heur_b) sb.tau_floor_in = tau_floor;
-                FSGPU_HIP(launch_select(sb, (int)QP, stream));
-                sb.anchor_unit = nullptr;
-                sb.tau_floor_in = nullptr;
-            } else {
-                a.group_stride = 1;  // nothing was sampled by a stage B: the main pass visits every group
-                a.group_count = 0;
-            }
-            // stage C: every group the B sample did not cover
-            a.stage = 2;
-            const int main_grid = wide_qt ? wide_grid : full_grid;
-            if (wide_qt) {  // the wide main pass visits every row (no skip test in its loop): stage B only tightened tau
-                a.group_stride = 1;
-                a.group_count = 0;
-            }
-            // (the wide pass appends to global lists: 16 slots per (query, block) keep lists + pool inside one selection pass;
-            // ranks above 32 — the int8 fast tier anchors on 90 — let ~1,700 rows per query through and get 32)
-            a.slots = wide_qt ? (knobs().slots_main > 0 ? (uint32_t)knobs().slots_main : ksel_est > 32 ? (short_stages && i8f ? 16 : kWideSlots) : std::min<uint32_t>(16, std::max<uint32_t>(8, (CAPQ - KC) / (uint32_t)main_grid)))
-                              : slots_for(full_grid);
-            FSGPU_HIP(hipMemsetAsync(spill_count, 0, (size_t)QP * kMfmaSpillCountStride * 4, stream));
-            a.groups = 1;
-            // one pass over the slab per query group, one launch each (all groups in one launch — a group's blocks taking
-            // over the CUs the previous group's leave — measured 1.5 % slower at 10M rows: two groups' streams interleave)
-            const uint32_t GM = G * wide_mult;  // queries per main-pass launch
-            for (uint32_t j = 0; j < ngroups / wide_mult; ++j) {
+    p.delta = static_cast<float*>(mf_delta_.ptr);
+    p.tau = static_cast<float*>(mf_tau_.ptr);
+    p.unit = p.tau + QCAP;   // int8 filter: integer-score units per exact-score unit, per query
+    p.pool_flag = reinterpret_cast<uint32_t*>(p.unit + QCAP);   // finish: candidates did not fit the pool (per query of the round)
+    p.tau_floor = reinterpret_cast<float*>(p.pool_flag + QCAP);   // the first sample's proven threshold, kept next to a heuristic one
+    p.spill = static_cast<u64*>(mf_spill_.ptr);
+    p.spill_count = reinterpret_cast<uint32_t*>(p.spill + (size_t)QCAP * SPILL);
+    p.pool = static_cast<u64*>(mf_sel_.ptr);
+    p.k_eff = std::min<uint32_t>(k, p.N);
+    return ok();
+}
+
+// Shapes the matrix-core path does not cover: answered by the per-query kernels (or handed to the f16 branch).
+SearchError VectorIndex::batched_unusable(BatchedPlan& p) {
+    const uint32_t nq = p.nq, k = p.k;
+    hipStream_t stream = p.stream;
+    if (p.i8f)   // the f16 branch sorts them out
+        return batched_impl(p.queries_dev, nq, p.query_len, k, p.allow_dev, p.out_rows_dev, p.out_scores_dev, p.out_counts_dev, stream,
+                            p.fallbacks, p.out_packed_dev, 0, p.query_stride, false, nullptr);
+    if (p.i8) {
+        // per-query int8 two-pass through host staging (rare shapes: huge candidate counts, tiny or odd-dimension slabs)
+        std::vector<float> q((size_t)nq * dim_), sc((size_t)nq * k);
+        std::vector<uint32_t> rw((size_t)nq * k, 0xffffffffu), cnt(nq);
+        FSGPU_HIP(hipMemcpyAsync(q.data(), p.queries_dev, q.size() * 4, hipMemcpyDeviceToHost, stream));
+        FSGPU_HIP(hipStreamSynchronize(stream));
+        for (uint32_t i = 0; i < nq; ++i)
+            FSGPU_TRY(quantized_two_pass(q.data() + (size_t)i * dim_, dim_, k, p.int8_mult, p.bits, rw.data() + (size_t)i * k,
+                                         sc.data() + (size_t)i * k, &cnt[i], tp_approx_out_ ? tp_approx_out_ + (size_t)i * tp_stride_ : nullptr,
+                                         tp_exact_out_ ? tp_exact_out_ + (size_t)i * tp_stride_ : nullptr));
+        if (p.out_rows_dev) FSGPU_HIP(hipMemcpyAsync(p.out_rows_dev, rw.data(), rw.size() * 4, hipMemcpyHostToDevice, stream));
+        if (p.out_scores_dev) FSGPU_HIP(hipMemcpyAsync(p.out_scores_dev, sc.data(), sc.size() * 4, hipMemcpyHostToDevice, stream));
+        if (p.out_counts_dev) FSGPU_HIP(hipMemcpyAsync(p.out_counts_dev, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice, stream));
+        FSGPU_HIP(hipStreamSynchronize(stream));
+        if (p.fallbacks) *p.fallbacks = nq;
+        return ok();
+    }
+    if (p.query_stride)
+        return make_error(FSGPU_ERR_INVALID_CONFIG, "strided queries need the matrix-core path (caller falls back per query)");
+    if (p.fallbacks) *p.fallbacks = nq;
+    if (p.out_packed_dev) {
+        FSGPU_TRY(search_top_k_packed_device(p.queries_dev, nq, p.query_len, k, p.allow_dev, p.out_packed_dev, stream));
+        if (!p.out_rows_dev) return ok();
+    }
+    return search_top_k_device(p.queries_dev, nq, p.query_len, k, p.allow_dev, p.out_rows_dev, p.out_scores_dev, p.out_counts_dev, stream);
+}
+
+// The geometry of the round that starts at query g0, the prepared (rounded / quantised) queries, the scan arguments every stage shares.
+SearchError VectorIndex::batched_round_setup(const BatchedPlan& p, BatchedRound& r, uint32_t g0) {
+    const bool i8 = p.i8;
+    hipStream_t stream = p.stream;
+    r.g0 = g0;
+    const uint32_t left = p.nq - g0;
+    // Main pass at 384 / 256 queries per launch (mfma_wide.hip: queries in registers, row tiles through an LDS-DMA
+    // ring) when that many are left; the sample stages then run as sub-groups of 128 on the LDS-query kernel.
+    r.wide_qt = 0;
+    if (p.wide_ok && left >= 256) {   // 128-query groups per launch
+        // as many as the registers hold (f16 rows of 384 dimensions: 3, their int8 form: 5), the round's groups spread evenly
+        // over its passes (8 groups: 3 + 3 + 2 on f16 rows, 4 + 4 on int8 rows)
+        const uint32_t groups_left = std::min<uint32_t>(left / 128, p.QCAP / 128);
+        const uint32_t passes = (groups_left + p.wide_max - 1) / p.wide_max;
+        r.wide_qt = p.wide_pref == 2 ? 2 : (int)((groups_left + passes - 1) / passes);
+    }
+    // 160, 128 or 64 queries per pass
+    r.shape = r.wide_qt ? (i8 ? mf_shape_i8_ : mf_shape_)
+                        : (left > 64 && variant != 5) ? ((left > 128 && mf_use_160_) ? 5 : (i8 ? mf_shape_i8_ : mf_shape_)) : 0;
+    r.G = (uint32_t)scan_mfma_query_tiles(r.shape) * 16;
+    r.wide_mult = r.wide_qt ? (uint32_t)r.wide_qt : 1;   // sample groups per main-pass launch
+    // this round: `ngroups` groups of G queries (the last one may be partly padding), QP query slots, ng real queries
+    r.ngroups = left >= r.G ? std::min<uint32_t>(left / r.G, p.QCAP / r.G) : 1;
+    if (r.wide_qt) r.ngroups = r.ngroups / r.wide_mult * r.wide_mult;
+    r.QP = r.ngroups * r.G;
+    r.ng = std::min(r.QP, left);
+    r.wpb = scan_mfma_waves_per_block(r.shape);
+    const int per_cu = r.shape == 5 ? (i8 ? mf_per_cu_160_i8_ : mf_per_cu_160_)
+                                    : (i8 ? (r.shape ? mf_per_cu_wide_i8_ : mf_per_cu_narrow_i8_)
+                                          : (r.shape ? mf_per_cu_wide_ : mf_per_cu_narrow_));
+    r.full_grid = num_cus_ * per_cu;
+    r.tile_rows = (uint32_t)scan_mfma_rows_per_tile(r.shape);
+    r.qg = p.queries_dev + (size_t)g0 * p.qs;
+    r.overflow = p.overflow_all + g0;
+    r.cand_counts = p.counts_all + g0;
+    if (p.i8f)
+        FSGPU_HIP(launch_prepare_queries_i8_filter(r.qg, r.ng, r.QP, dim_, p.qs, static_cast<const unsigned int*>(i8_max_.ptr),
+                                                   static_cast<const unsigned int*>(i8_stats_.ptr), mf_qh_.ptr, p.delta, stream, p.unit));
+    else if (i8) FSGPU_HIP(launch_prepare_queries_i8(r.qg, r.ng, r.QP, dim_, mf_qh_.ptr, p.delta, stream, p.bits));
+    else
+        FSGPU_HIP(launch_prepare_queries(r.qg, r.ng, r.QP, dim_, p.qs, static_cast<const unsigned int*>(mf_max_norm_.ptr),
+                                         mf_qh_.ptr, p.delta, stream));
+    r.wide_grid = num_cus_ * mf_per_cu_wide_main_;
+    FSGPU_TRY(mf_cand_.reserve((size_t)r.QP * std::max(r.full_grid, r.wide_grid) * kMfmaMaxSlots * 8));
+    r.cand = static_cast<u64*>(mf_cand_.ptr);
+    FSGPU_TRY(mf_cand_count_.reserve((size_t)r.QP * r.wide_grid * 4));   // the wide kernels' list lengths (no padding)
+    r.cand_count = static_cast<uint32_t*>(mf_cand_count_.ptr);
+    MfmaScanArgs& a = r.a;
+    a = MfmaScanArgs{};
+    a.slab = i8 ? (p.bits == 4 ? n4u_slab_.ptr : i8_slab_.ptr) : slab_dev_;
+    a.elem_bytes = i8 ? 1 : 2;
+    a.live = reinterpret_cast<const u64*>(live_dev_);
+    a.allow = reinterpret_cast<const u64*>(p.allow_dev);
+    a.queries = mf_qh_.ptr;
+    a.tau = p.tau;
+    a.cand = r.cand;
+    a.spill = p.spill;
+    a.spill_count = p.spill_count;
+    a.spill_cap = BatchedPlan::SPILL;
+    a.overflow = r.overflow;
+    a.dim = dim_;
+    a.row_stride = p.strided ? row_stride_ : 0;
+    a.row_base = (uint32_t)row_base_;
+    a.nrows = p.N;
+    // (a row shard's stages are short: the lists' padding and the selection's reads are a visible part of them — 8 / 16 slots
+    // there, overflow goes to the spill area; 1.25M rows: 0.809 -> 0.789 ms per 1,024 queries, nothing at 10M)
+    r.short_stages = nrows_ < 4'000'000;
+    // int8 filter: the sample stages' thresholds are anchored on EXACT scores (their candidates are re-scored from the f16
+    // slab right in the selection): one delta below the k-th best instead of two — the margin's multiplier on the rows each
+    // stage lets through is exponential in it
+    r.anchor = p.i8f && !knobs().no_anchor;
+    return ok();
+}
+
+// Stage "sample": A = dense approximate scores of a small sample -> a first threshold; B = the rows of a larger sample at or above
+// it, one short list per (query, block) -> the threshold the main pass runs with.  Samples are 64-row groups spread evenly over
+// the slab: B = every stride_b-th group, A = a subset of B.
+SearchError VectorIndex::batched_sample(const BatchedPlan& p, BatchedRound& r) {
+    constexpr uint32_t SPILL = BatchedPlan::SPILL;
+    hipStream_t stream = p.stream;
+    const bool i8 = p.i8, i8f = p.i8f, skip_b = p.skip_b;
+    const uint32_t N = p.N, RA = p.RA, RB = p.RB, QP = r.QP, ksel = p.ksel;
+    MfmaScanArgs& a = r.a;
+    const uint32_t groups_a = RA / 64, groups_b = RB / 64;
+    const uint32_t stride_b = (N / 64) / groups_b;  // >= 4
+    // stage A: dense approximate scores of the A sample -> tau = (k-th best) - 2 delta
+    a.dense = static_cast<u64*>(mf_dense_.ptr);
+    a.stage = 0;
+    a.group_stride = stride_b * (groups_b / groups_a);
+    a.group_count = groups_a;
+    a.slots = 0;
+    a.groups = r.ngroups;
+    FSGPU_HIP(launch_scan_mfma(a, r.shape, r.grid_for(RA, 16), stream, nullptr));
+    SelectArgs sa{};
+    sa.lists = a.dense;
+    sa.q_stride = RA;
+    sa.l_stride = RA;
+    sa.nlists = 1;
+    sa.list_len = RA;
+    sa.k = ksel;
+    sa.delta = p.delta;
+    sa.tau_out = p.tau;
+    auto set_rescore = [&](SelectArgs& x) {
+        x.slab = slab_dev_;
+        x.queries = r.qg;
+        x.dim = dim_;
+        x.row_stride = 0;
+        x.query_stride = p.qs;
+        x.nrows = N;
+        x.row_base = (uint32_t)row_base_;
+        x.hreduce = hreduce;
+        x.k_out = p.k_eff;
+    };
+    // (a wide round's second sample only anchors the main pass's threshold — that pass visits every row — so it may take ANY
+    // subset of the sample: the rows above the first sample's ~9th best score WITHOUT a margin, half as many as the proven
+    // threshold lets through, and the first selection needs no exact re-score)
+    // (the int8 two-pass takes the same shortcut: its threshold is the ksel-th best integer score of whatever subset came through)
+    const bool heur_b = (r.anchor || (i8 && !i8f)) && r.wide_qt != 0 && !skip_b && !knobs().no_wide_b && !knobs().no_heur_b && ksel >= 8;
+    if (heur_b) {
+        // rank r of the first sample: the second sample holds RB / RA x as many rows above that score as the first (r, up to
+        // an order statistic's spread ~ Gamma(r)), and k of them are needed — r = 8 + k / 8 puts "fewer than k came through"
+        // (which only costs that query a looser threshold) below 1e-7 per query for k <= 64 and RB / RA >= 48
+        sa.heur_rank = knobs().heur_rank > 0 ? (uint32_t)std::min<int>(knobs().heur_rank, (int)ksel) : std::min<uint32_t>(ksel, 8 + ksel / 8);
+        sa.tau_floor_out = p.tau_floor;
+    } else if (r.anchor) {
+        set_rescore(sa);
+        sa.anchor_unit = p.unit;
+    }
+    FSGPU_HIP(launch_select(sa, (int)QP, stream));
+    // stage B: the B sample's rows at or above tau, one short list per (query, block) -> tighter tau; the rows
+    // still at or above it form the pool carried into the last selection
+    a.dense = nullptr;
+    a.stage = 1;
+    a.group_stride = stride_b;
+    a.group_count = groups_b;
+    const int grid_b = r.grid_for(RB, r.tile_rows);
+    a.slots = r.slots_for(grid_b);
+    // (a wide round samples on the register-resident-query kernel too: one launch per main-pass group, the same lists)
+    const bool wide_b = r.wide_qt && !skip_b && !knobs().no_wide_b;
+    const int wide_grid_b = std::min(r.wide_grid, (int)std::max<uint32_t>(1, RB / 64 / 4));   // at least 4 sample groups per block
+    if (wide_b) a.slots = knobs().slots_b > 0 ? (uint32_t)knobs().slots_b : r.short_stages ? 8 : kWideSlots;
+    if (!skip_b) {
+        FSGPU_HIP(hipMemsetAsync(p.spill_count, 0, (size_t)QP * kMfmaSpillCountStride * 4, stream));
+        if (wide_b) {
+            const uint32_t GM = r.G * r.wide_mult;
+            for (uint32_t j = 0; j < r.ngroups / r.wide_mult; ++j) {
                 MfmaScanArgs c = a;
+                c.groups = 1;
                 c.queries = static_cast<const unsigned char*>(mf_qh_.ptr) + (size_t)j * GM * dim_ * (i8 ? 1 : 2);
-                c.tau = tau + (size_t)j * GM;
-                c.cand = cand + (size_t)j * GM * main_grid * a.slots;
-                c.cand_count = wide_qt ? cand_count + (size_t)j * GM * main_grid : nullptr;
-                c.spill = spill + (size_t)j * GM * SPILL;
-                c.spill_count = spill_count + (size_t)j * GM * kMfmaSpillCountStride;
-                c.overflow = overflow + (size_t)j * GM;
-                c.reverse = knobs().no_reverse ? 0 : (mf_pass_parity_++ & 1);  // consecutive passes alternate direction
-                hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (profiling) {
-                    FSGPU_HIP(hipEventCreate(&e0));
-                    FSGPU_HIP(hipEventCreate(&e1));
-                    FSGPU_HIP(hipEventRecord(e0, stream));
-                }
-                if (wide_qt) FSGPU_HIP(launch_scan_wide(c, wide_qt, main_grid, stream, nullptr));
-                else FSGPU_HIP(launch_scan_mfma(c, shape, full_grid, stream, nullptr));
-                if (profiling) {
-                    FSGPU_HIP(hipEventRecord(e1, stream));
-                    events_.emplace_back(e0, e1);
-                    profiled_rows_ += (skip_b || wide_qt) ? N : N - RB;
-                    profiled_elem_bytes_ = i8 ? 1 : 2;
-                }
+                c.tau = p.tau + (size_t)j * GM;
+                c.cand = r.cand + (size_t)j * GM * wide_grid_b * a.slots;
+                c.cand_count = r.cand_count + (size_t)j * GM * wide_grid_b;
+                c.spill = p.spill + (size_t)j * GM * SPILL;
+                c.spill_count = p.spill_count + (size_t)j * GM * kMfmaSpillCountStride;
+                c.overflow = r.overflow + (size_t)j * GM;
+                FSGPU_HIP(launch_scan_wide(c, r.wide_qt, wide_grid_b, stream, nullptr));
             }
-            sb.q_stride = (uint64_t)main_grid * a.slots;
-            sb.l_stride = a.slots;
-            sb.nlists = (uint32_t)main_grid;
-            sb.list_len = a.slots;
-            sb.list_counts = wide_qt ? cand_count : nullptr;
-            sb.extra = (skip_b || wide_qt) ? nullptr : pool;
-            sb.extra_len = (skip_b || wide_qt) ? 0 : KC;
-            sb.tau_out = nullptr;
-            sb.pool_out = nullptr;
+        } else {
+            FSGPU_HIP(launch_scan_mfma(a, r.shape, grid_b, stream, nullptr));
         }
-        // finish: every row whose approximate score is within 2 delta of the k-th best (more than KC of them: the
-        // query goes to the exact path) is re-scored in the reference's order; the best k exact entries are the answer
-        sb.cand_counts = cand_counts;
-        // the int8 filter's margin (and whatever it hands on to the f16 filter) can put thousands of rows within reach of the k-th
-        // score: the finish re-scores up to 8,192 of them per query instead of 1,024
-        const bool second_chance = (i8f || hard_batch_) && !knobs().no_big_pool;
-        sb_big_pool_last = second_chance;
-        sb.pool_flag = second_chance ? pool_flag : nullptr;
-        sb.slab = slab_dev_;
-        sb.queries = qg;
-        sb.dim = dim_;
-        sb.row_stride = strided ? row_stride_ : 0;
-        sb.query_stride = qs;
-        sb.nrows = N;
-        sb.row_base = (uint32_t)row_base_;
-        sb.hreduce = hreduce;
-        sb.k_out = k_eff;
-        sb.out_stride = k;
-        sb.out_rows = out_rows_dev ? out_rows_dev + (size_t)g0 * k : nullptr;
-        sb.out_scores = out_scores_dev ? out_scores_dev + (size_t)g0 * k : nullptr;
-        sb.out_counts = out_counts_dev ? out_counts_dev + g0 : nullptr;
-        sb.out_packed = out_packed_dev ? reinterpret_cast<u64*>(out_packed_dev) + (size_t)g0 * k : nullptr;
-        if (int8_mult && tp_approx_out_) {   // a sharded index's shard: the candidate pairs themselves (two_pass_candidates_device)
-            sb.cand_approx_out = tp_approx_out_ + (size_t)g0 * tp_stride_;
-            sb.cand_exact_out = tp_exact_out_ + (size_t)g0 * tp_stride_;
-            sb.cand_out_stride = tp_stride_;
-        }
-        FSGPU_HIP(launch_select(sb, (int)ng, stream));
-        if (second_chance) {   // queries whose candidates did not fit the pool: the sorted finish over the same lists (others return at once)
-            sb.big_pool = 1;
-            FSGPU_HIP(launch_select(sb, (int)ng, stream));
-        }
-        g0 += ng;
     }
-    // everything of this search is enqueued: the caller's window for host work that should run under it (one shot, outer call only)
-    if (after_enqueue_fn && !hard_batch_) {
-        void (*fn)(void*) = after_enqueue_fn;
-        after_enqueue_fn = nullptr;
-        fn(after_enqueue_ctx);
+    const int lists_b = wide_b ? wide_grid_b : grid_b;
+    SelectArgs& sb = r.sb;
+    sb = SelectArgs{};
+    sb.lists = r.cand;
+    sb.q_stride = (uint64_t)lists_b * a.slots;
+    sb.l_stride = a.slots;
+    sb.nlists = (uint32_t)lists_b;
+    sb.list_len = a.slots;
+    sb.list_counts = wide_b ? r.cand_count : nullptr;
+    sb.k = ksel;
+    sb.take_topk = (i8 && !i8f) ? 1 : 0;
+    sb.delta = p.delta;
+    sb.overflow = r.overflow;
+    sb.spill = p.spill;
+    sb.spill_count = p.spill_count;
+    sb.spill_cap = SPILL;
+    if (!skip_b) {
+        sb.tau_out = p.tau;
+        sb.pool_out = p.pool;
+        if (r.anchor) {
+            set_rescore(sb);
+            sb.anchor_unit = p.unit;
+        }
+        if (heur_b) sb.tau_floor_in = p.tau_floor;
+        FSGPU_HIP(launch_select(sb, (int)QP, stream));
+        sb.anchor_unit = nullptr;
+        sb.tau_floor_in = nullptr;
     }
-    // fallback decision on the host: margin/capacity overflow, or fewer than k candidates
+    return ok();
+}
+
+// Stage "main": every row (the wide pass) or every group the B sample did not cover against the round's thresholds; one launch per
+// query group, candidates into per-(query, block) lists + the spill area.
+SearchError VectorIndex::batched_main(const BatchedPlan& p, BatchedRound& r) {
+    constexpr uint32_t SPILL = BatchedPlan::SPILL, CAPQ = BatchedPlan::CAPQ, KC = BatchedPlan::KC;
+    hipStream_t stream = p.stream;
+    MfmaScanArgs& a = r.a;
+    SelectArgs& sb = r.sb;
+    if (p.skip_b) {
+        a.group_stride = 1;  // nothing was sampled by a stage B: the main pass visits every group
+        a.group_count = 0;
+    }
+    // stage C: every group the B sample did not cover
+    a.stage = 2;
+    const int main_grid = r.wide_qt ? r.wide_grid : r.full_grid;
+    if (r.wide_qt) {  // the wide main pass visits every row (no skip test in its loop): stage B only tightened tau
+        a.group_stride = 1;
+        a.group_count = 0;
+    }
+    // (the wide pass appends to global lists: 16 slots per (query, block) keep lists + pool inside one selection pass;
+    // ranks above 32 — the int8 fast tier anchors on 90 — let ~1,700 rows per query through and get 32)
+    a.slots = r.wide_qt ? (knobs().slots_main > 0 ? (uint32_t)knobs().slots_main
+                           : p.ksel_est > 32 ? (r.short_stages && p.i8f ? 16 : kWideSlots)
+                                             : std::min<uint32_t>(16, std::max<uint32_t>(8, (CAPQ - KC) / (uint32_t)main_grid)))
+                        : r.slots_for(r.full_grid);
+    FSGPU_HIP(hipMemsetAsync(p.spill_count, 0, (size_t)r.QP * kMfmaSpillCountStride * 4, stream));
+    a.groups = 1;
+    // one pass over the slab per query group, one launch each (all groups in one launch — a group's blocks taking
+    // over the CUs the previous group's leave — measured 1.5 % slower at 10M rows: two groups' streams interleave)
+    const uint32_t GM = r.G * r.wide_mult;  // queries per main-pass launch
+    for (uint32_t j = 0; j < r.ngroups / r.wide_mult; ++j) {
+        MfmaScanArgs c = a;
+        c.queries = static_cast<const unsigned char*>(mf_qh_.ptr) + (size_t)j * GM * dim_ * (p.i8 ? 1 : 2);
+        c.tau = p.tau + (size_t)j * GM;
+        c.cand = r.cand + (size_t)j * GM * main_grid * a.slots;
+        c.cand_count = r.wide_qt ? r.cand_count + (size_t)j * GM * main_grid : nullptr;
+        c.spill = p.spill + (size_t)j * GM * SPILL;
+        c.spill_count = p.spill_count + (size_t)j * GM * kMfmaSpillCountStride;
+        c.overflow = r.overflow + (size_t)j * GM;
+        c.reverse = knobs().no_reverse ? 0 : (mf_pass_parity_++ & 1);  // consecutive passes alternate direction
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (profiling) {
+            FSGPU_HIP(hipEventCreate(&e0));
+            FSGPU_HIP(hipEventCreate(&e1));
+            FSGPU_HIP(hipEventRecord(e0, stream));
+        }
+        if (r.wide_qt) FSGPU_HIP(launch_scan_wide(c, r.wide_qt, main_grid, stream, nullptr));
+        else FSGPU_HIP(launch_scan_mfma(c, r.shape, r.full_grid, stream, nullptr));
+        if (profiling) {
+            FSGPU_HIP(hipEventRecord(e1, stream));
+            events_.emplace_back(e0, e1);
+            profiled_rows_ += (p.skip_b || r.wide_qt) ? p.N : p.N - p.RB;
+            profiled_elem_bytes_ = p.i8 ? 1 : 2;
+        }
+    }
+    sb.q_stride = (uint64_t)main_grid * a.slots;
+    sb.l_stride = a.slots;
+    sb.nlists = (uint32_t)main_grid;
+    sb.list_len = a.slots;
+    sb.list_counts = r.wide_qt ? r.cand_count : nullptr;
+    sb.extra = (p.skip_b || r.wide_qt) ? nullptr : p.pool;
+    sb.extra_len = (p.skip_b || r.wide_qt) ? 0 : KC;
+    sb.tau_out = nullptr;
+    sb.pool_out = nullptr;
+    return ok();
+}
+
+// Stage "finish": every row whose approximate score is within 2 delta of the k-th best (more than KC of them: the query goes to
+// the exact path) is re-scored in the reference's order; the best k exact entries are the answer.
+SearchError VectorIndex::batched_finish(BatchedPlan& p, BatchedRound& r) {
+    hipStream_t stream = p.stream;
+    SelectArgs& sb = r.sb;
+    const uint32_t k = p.k, g0 = r.g0;
+    sb.cand_counts = r.cand_counts;
+    // the int8 filter's margin (and whatever it hands on to the f16 filter) can put thousands of rows within reach of the k-th
+    // score: the finish re-scores up to 8,192 of them per query instead of 1,024
+    const bool second_chance = (p.i8f || hard_batch_) && !knobs().no_big_pool;
+    p.big_pool_last = second_chance;
+    sb.pool_flag = second_chance ? p.pool_flag : nullptr;
+    sb.slab = slab_dev_;
+    sb.queries = r.qg;
+    sb.dim = dim_;
+    sb.row_stride = p.strided ? row_stride_ : 0;
+    sb.query_stride = p.qs;
+    sb.nrows = p.N;
+    sb.row_base = (uint32_t)row_base_;
+    sb.hreduce = hreduce;
+    sb.k_out = p.k_eff;
+    sb.out_stride = k;
+    sb.out_rows = p.out_rows_dev ? p.out_rows_dev + (size_t)g0 * k : nullptr;
+    sb.out_scores = p.out_scores_dev ? p.out_scores_dev + (size_t)g0 * k : nullptr;
+    sb.out_counts = p.out_counts_dev ? p.out_counts_dev + g0 : nullptr;
+    sb.out_packed = p.out_packed_dev ? reinterpret_cast<u64*>(p.out_packed_dev) + (size_t)g0 * k : nullptr;
+    if (p.int8_mult && tp_approx_out_) {   // a sharded index's shard: the candidate pairs themselves (two_pass_candidates_device)
+        sb.cand_approx_out = tp_approx_out_ + (size_t)g0 * tp_stride_;
+        sb.cand_exact_out = tp_exact_out_ + (size_t)g0 * tp_stride_;
+        sb.cand_out_stride = tp_stride_;
+    }
+    FSGPU_HIP(launch_select(sb, (int)r.ng, stream));
+    if (second_chance) {   // queries whose candidates did not fit the pool: the sorted finish over the same lists (others return at once)
+        sb.big_pool = 1;
+        FSGPU_HIP(launch_select(sb, (int)r.ng, stream));
+    }
+    return ok();
+}
+
+// Stage "fallback": ONE stream synchronisation for the whole batch, then the host reads the per-query verdicts — margin / capacity
+// overflow, or fewer than k candidates — and the uncertified queries are answered by the exact kernels (the int8 filter hands a
+// larger set to the f16 filter first; the int8 two-pass to its per-query form).
+SearchError VectorIndex::batched_fallback(BatchedPlan& p) {
+    constexpr uint32_t KC = BatchedPlan::KC;
+    hipStream_t stream = p.stream;
+    const uint32_t nq = p.nq, k = p.k, k_eff = p.k_eff;
     FSGPU_HIP(hipStreamSynchronize(stream));
     std::vector<uint32_t> fb;
     for (uint32_t i = 0; i < nq; ++i)
-        if (overflow_all[i] || counts_all[i] < k_eff) fb.push_back(i);
+        if (p.overflow_all[i] || p.counts_all[i] < k_eff) fb.push_back(i);
     if (knobs().debug_batched) {
         uint32_t big = 0, slot = 0, few = 0, mx = 0;
         for (uint32_t i = 0; i < nq; ++i) {
-            if (counts_all[i] > (sb_big_pool_last ? 8192u : KC)) ++big;
-            else if (overflow_all[i]) ++slot;
-            if (counts_all[i] < k_eff) ++few;
-            mx = std::max(mx, counts_all[i]);
+            if (p.counts_all[i] > (p.big_pool_last ? 8192u : KC)) ++big;
+            else if (p.overflow_all[i]) ++slot;
+            if (p.counts_all[i] < k_eff) ++few;
+            mx = std::max(mx, p.counts_all[i]);
         }
         std::fprintf(stderr, "[fsgpu batched] nq=%u k=%u fallbacks=%zu  pool_overflow=%u  slot_or_skip=%u  few=%u  max_cand=%u\n", nq, k,
                      fb.size(), big, slot, few, mx);
         for (size_t j = 0; j < fb.size() && j < 4; ++j)
-            std::fprintf(stderr, "    query %u: overflow=%u candidates=%u\n", fb[j], overflow_all[fb[j]], counts_all[fb[j]]);
+            std::fprintf(stderr, "    query %u: overflow=%u candidates=%u\n", fb[j], p.overflow_all[fb[j]], p.counts_all[fb[j]]);
     }
     const uint32_t total_fallbacks = (uint32_t)fb.size();
-    if (total_fallbacks && i8 && !i8f) {
+    if (total_fallbacks && p.i8 && !p.i8f) {
         // list/spill overflow (a pile of tied scores at the threshold): the per-query int8 two-pass answers those
         std::vector<float> qh(dim_), sc(k);
         std::vector<uint32_t> rw(k);
         for (uint32_t i : fb) {
             uint32_t cnt = 0;
-            FSGPU_HIP(hipMemcpyAsync(qh.data(), queries_dev + (size_t)i * dim_, (size_t)dim_ * 4, hipMemcpyDeviceToHost, stream));
+            FSGPU_HIP(hipMemcpyAsync(qh.data(), p.queries_dev + (size_t)i * dim_, (size_t)dim_ * 4, hipMemcpyDeviceToHost, stream));
             FSGPU_HIP(hipStreamSynchronize(stream));
             std::fill(rw.begin(), rw.end(), 0xffffffffu);
-            FSGPU_TRY(quantized_two_pass(qh.data(), dim_, k, int8_mult, bits, rw.data(), sc.data(), &cnt,
+            FSGPU_TRY(quantized_two_pass(qh.data(), dim_, k, p.int8_mult, p.bits, rw.data(), sc.data(), &cnt,
                                          tp_approx_out_ ? tp_approx_out_ + (size_t)i * tp_stride_ : nullptr,
                                          tp_exact_out_ ? tp_exact_out_ + (size_t)i * tp_stride_ : nullptr));
-            if (out_rows_dev) FSGPU_HIP(hipMemcpyAsync(out_rows_dev + (size_t)i * k, rw.data(), (size_t)k * 4, hipMemcpyHostToDevice, stream));
-            if (out_scores_dev) FSGPU_HIP(hipMemcpyAsync(out_scores_dev + (size_t)i * k, sc.data(), (size_t)k * 4, hipMemcpyHostToDevice, stream));
-            if (out_counts_dev) FSGPU_HIP(hipMemcpyAsync(out_counts_dev + i, &cnt, 4, hipMemcpyHostToDevice, stream));
+            if (p.out_rows_dev) FSGPU_HIP(hipMemcpyAsync(p.out_rows_dev + (size_t)i * k, rw.data(), (size_t)k * 4, hipMemcpyHostToDevice, stream));
+            if (p.out_scores_dev) FSGPU_HIP(hipMemcpyAsync(p.out_scores_dev + (size_t)i * k, sc.data(), (size_t)k * 4, hipMemcpyHostToDevice, stream));
+            if (p.out_counts_dev) FSGPU_HIP(hipMemcpyAsync(p.out_counts_dev + i, &cnt, 4, hipMemcpyHostToDevice, stream));
             FSGPU_HIP(hipStreamSynchronize(stream));
         }
     } else if (total_fallbacks) {
@@ -1783,7 +1925,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
                      o_scores = align_up(o_rows + nf * k * 4, 256), o_counts = align_up(o_scores + nf * k * 4, 256),
                      total = align_up(o_counts + nf * 4, 256);
         // (the int8 filter hands its leftovers to a nested f16-filter call, which may itself use mf_fallback_)
-        DeviceBuffer& fbuf = i8f ? mf_fallback2_ : mf_fallback_;
+        DeviceBuffer& fbuf = p.i8f ? mf_fallback2_ : mf_fallback_;
         FSGPU_TRY(fbuf.reserve(total));
         unsigned char* base = static_cast<unsigned char*>(fbuf.ptr);
         uint32_t* idx_dev = reinterpret_cast<uint32_t*>(base + o_idx);
@@ -1793,28 +1935,28 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         uint32_t* counts_dev = reinterpret_cast<uint32_t*>(base + o_counts);
         FSGPU_HIP(hipMemcpyAsync(idx_dev, fb.data(), nf * 4, hipMemcpyHostToDevice, stream));
         FSGPU_HIP(hipStreamSynchronize(stream));  // fb is a stack-owned pageable buffer
-        FSGPU_HIP(launch_gather_queries(queries_dev, idx_dev, (uint32_t)nf, dim_, qs, q_dev, stream));
-        if (i8f && nf > 8) {
+        FSGPU_HIP(launch_gather_queries(p.queries_dev, idx_dev, (uint32_t)nf, dim_, p.qs, q_dev, stream));
+        if (p.i8f && nf > 8) {
             // rows within the int8 margin of the k-th best did not fit the lists (or the query cannot be certified on the int8
             // slab at all): the f16 filter, whose margin is ~20 x narrower, answers these as a batch of its own
             uint32_t inner_fb = 0;
             hard_batch_ = true;
-            const SearchError inner = batched_impl(q_dev, (uint32_t)nf, query_len, k, allow_dev, rows_dev, scores_dev, counts_dev, stream,
+            const SearchError inner = batched_impl(q_dev, (uint32_t)nf, p.query_len, k, p.allow_dev, rows_dev, scores_dev, counts_dev, stream,
                                                    &inner_fb, nullptr, 0, 0, false, nullptr);
             hard_batch_ = false;
             FSGPU_TRY(inner);
-            if (refiltered) *refiltered = (uint32_t)nf;
-            if (fallbacks) *fallbacks = inner_fb;
-            FSGPU_HIP(launch_scatter_hits(idx_dev, (uint32_t)nf, k, rows_dev, scores_dev, counts_dev, out_rows_dev,
-                                          out_scores_dev, out_counts_dev, reinterpret_cast<u64*>(out_packed_dev), stream));
+            if (p.refiltered) *p.refiltered = (uint32_t)nf;
+            if (p.fallbacks) *p.fallbacks = inner_fb;
+            FSGPU_HIP(launch_scatter_hits(idx_dev, (uint32_t)nf, k, rows_dev, scores_dev, counts_dev, p.out_rows_dev,
+                                          p.out_scores_dev, p.out_counts_dev, reinterpret_cast<u64*>(p.out_packed_dev), stream));
             return ok();
         }
-        if (i8f && refiltered) *refiltered = (uint32_t)nf;
-        FSGPU_TRY(fused_search(q_dev, (uint32_t)nf, k, k_eff, allow_dev, rows_dev, scores_dev, counts_dev, nullptr, stream));
-        FSGPU_HIP(launch_scatter_hits(idx_dev, (uint32_t)nf, k, rows_dev, scores_dev, counts_dev, out_rows_dev,
-                                      out_scores_dev, out_counts_dev, reinterpret_cast<u64*>(out_packed_dev), stream));
+        if (p.i8f && p.refiltered) *p.refiltered = (uint32_t)nf;
+        FSGPU_TRY(fused_search(q_dev, (uint32_t)nf, k, k_eff, p.allow_dev, rows_dev, scores_dev, counts_dev, nullptr, stream));
+        FSGPU_HIP(launch_scatter_hits(idx_dev, (uint32_t)nf, k, rows_dev, scores_dev, counts_dev, p.out_rows_dev,
+                                      p.out_scores_dev, p.out_counts_dev, reinterpret_cast<u64*>(p.out_packed_dev), stream));
     }
-    if (fallbacks) *fallbacks = total_fallbacks;
+    if (p.fallbacks) *p.fallbacks = total_fallbacks;
     return ok();
 }
 

@@ -194,6 +194,16 @@ class VectorIndex {
                              uint32_t* out_rows_dev, float* out_scores_dev, uint32_t* out_counts_dev, hipStream_t stream,
                              uint32_t* fallbacks, uint64_t* out_packed_dev, uint32_t int8_mult, uint32_t query_stride,
                              bool i8_filter, uint32_t* refiltered, int bits = 8);
+    // ... and its stages (vector_index.cpp): what a call fixes for all its rounds, one round's geometry and arguments
+    struct BatchedPlan;
+    struct BatchedRound;
+    SearchError batched_prepare(BatchedPlan& p, bool* done);
+    SearchError batched_unusable(BatchedPlan& p);
+    SearchError batched_round_setup(const BatchedPlan& p, BatchedRound& r, uint32_t g0);
+    SearchError batched_sample(const BatchedPlan& p, BatchedRound& r);
+    SearchError batched_main(const BatchedPlan& p, BatchedRound& r);
+    SearchError batched_finish(BatchedPlan& p, BatchedRound& r);
+    SearchError batched_fallback(BatchedPlan& p);
     SearchError quantized_two_pass(const float* query, uint32_t query_len, uint32_t k, uint32_t multiplier, int bits,
                                    uint32_t* out_rows, float* out_scores, uint32_t* out_count, u64* approx_out_dev = nullptr,
                                    u64* exact_out_dev = nullptr);
