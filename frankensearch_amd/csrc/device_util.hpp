@@ -30,6 +30,12 @@ __device__ __forceinline__ u64 sortkey(u64 packed) {
     return ((u64)score_ord((uint32_t)(packed >> 32)) << 32) | (uint32_t)(~(uint32_t)packed);
 }
 
+// the f32 score bits a sortkey was made from (a NaN score comes back as -inf: that is how it ranks)
+__device__ __forceinline__ uint32_t score_from_sortkey(u64 key) {
+    const uint32_t ord = (uint32_t)(key >> 32);
+    return (ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord;
+}
+
 __device__ __forceinline__ u64 pack(float score, uint32_t row) {
     return ((u64)__float_as_uint(score) << 32) | row;
 }

@@ -171,6 +171,7 @@ struct SelectArgs {
     u64* cand_approx_out;
     u64* cand_exact_out;
     uint32_t cand_out_stride;  // entries between queries in both (>= k)
+    unsigned long long* stamps;   // lab builds (FSGPU_EXPERIMENTS): shader clocks of block 0's phases; null otherwise
 };
 constexpr uint32_t kSelectPool = 1024;
 constexpr uint32_t kSelectMaxK = 128;   // largest rank a selection can anchor on (k, or k * multiplier in int8 mode)

@@ -368,6 +368,18 @@ __device__ __forceinline__ void merge_wave_winners(const u64* win, int k, u64* t
 // to k ~ 32.  SORTED = true (larger k: the int8 fast tier anchors on 3 x 30 = 90 candidates): the non-empty entries
 // are compacted into LDS and bitonic-sorted by the whole block; top-k, threshold and candidate prefix fall out.
 constexpr int kSelSortCap = 8192;   // live entries the sorted variant holds (dynamic LDS: 64 KB)
+constexpr int kSelQueryLds = 1024;  // dimensions of the re-score's query kept in LDS (longer queries are read in place)
+#ifdef FSGPU_EXPERIMENTS
+#define SEL_STAMP(slot)                                                                                            \
+    do {                                                                                                             \
+        if (args.stamps && (blockIdx.x & 255) == 0 && blockIdx.x < 1024 && threadIdx.x == 0)                    \
+            args.stamps[(blockIdx.x >> 8) * 16 + (slot)] = (unsigned long long)clock64();                              \
+    } while (0)
+#else
+#define SEL_STAMP(slot) \
+    do {                \
+    } while (0)
+#endif
 template <bool FINISH, bool SORTED>
 __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(SelectArgs args) {
     constexpr int NT = kSelThreads, PER = kSelPer, NW = kSelWaves, POOL = (int)kSelectPool, KL = 1;
@@ -379,10 +391,25 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
     __shared__ u64 pool[POOL];       // candidates (finish step: replaced by their exact entries)
     __shared__ int s_count;
     __shared__ float s_tau;
+    __shared__ u64 s_gmax[64];
+    __shared__ __attribute__((aligned(16))) float s_q[FINISH ? kSelQueryLds : 4];
+    __shared__ int s_quick;
+    __shared__ u64 s_kth[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
+    SEL_STAMP(0);
     if (args.big_pool && args.pool_flag && args.pool_flag[q] == 0) return;   // second chance: only the queries the first finish flagged
     const int k = (int)args.k;
+    const float dq = args.delta[q];   // (requested here: its round trip runs underneath the entries')
+    if constexpr (FINISH) {
+        // the query of the exact re-score, parked in LDS (read by every candidate's quad); visible after the barriers below
+        // (only for a query that can have candidates: the padding slots of a round's last group — delta < 0 — lie past the end
+        // of the caller's query array)
+        if (args.queries && (int)args.dim <= kSelQueryLds && dq >= 0.f) {
+            const float* qsrc = args.queries + (size_t)q * (args.query_stride ? args.query_stride : args.dim);
+            for (int i = tid; i < (int)args.dim; i += NT) s_q[i] = qsrc[i];
+        }
+    }
     const u64* in = args.lists + (size_t)q * args.q_stride;
     const uint32_t* cnts = args.list_counts ? args.list_counts + (size_t)q * args.nlists : nullptr;
     constexpr uint32_t kSelCntCap = 512;
@@ -483,12 +510,82 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
         pool[tid] = tid < ncand && tid < kSelSortCap ? sbuf[tid] : kEmpty;
         __syncthreads();
     } else {
+        SEL_STAMP(1);
+        // The threshold only has to lie AT OR BELOW (k-th best approximate score) - 2 delta: any k distinct entries bound the
+        // k-th best from below.  In a selection that re-scores its candidates exactly (FINISH) and needs neither the exact top-k
+        // of the approximate scores (take_topk) nor a rank of them (heur_rank), the k-th largest of the maxima of 64 interleaved
+        // groups of the entries serves: ~9 k cycles instead of the ~30 k of the extraction rounds + the one-wave merge of their
+        // winners (lab stamps, scripts/r03/select_lab.sh: 80 k -> ~55 k cycles per query block together with the re-score's
+        // batched loads), at the price of a few more candidates for the exact re-score.  Selections whose threshold GATES a scan
+        // (the sample stages without an exact anchor) keep the exact rank: a looser gate there costs the append-bound sample
+        // pass more than the selection saves (measured: +0.11 ms per 1,024 queries).
+        const bool quick_bound = FINISH && !args.take_topk && !args.heur_rank && npass == 1 && k <= 32;
+        bool quick_ok = false;
+        if (quick_bound) {
+            load_pass(0, e);
+            SEL_STAMP(2);
+            // 64 groups along the diagonals of the (list, slot) grid — thread (list mod 64, slot) feeds group (list + slot) mod 64:
+            // every group draws on all lists' heads evenly (lists fill from slot 0), and the entries of ONE list — a cluster's
+            // best rows sit together in one block's list — land in different groups, so a topical corpus does not collapse the bound
+            if (tid < 64) s_gmax[tid] = 0ull;
+            u64 h = 0;
+#pragma unroll
+            for (int x = 0; x < PER; ++x) {
+                const u64 key = e[x] != kEmpty ? sortkey(e[x]) : 0ull;
+                h = key > h ? key : h;
+            }
+            __syncthreads();
+            if (h != 0) atomicMax(&s_gmax[((tid >> 4) + (tid & 15)) & 63], h);
+            __syncthreads();
+            if (wave == 0) {
+                // rank of each of the 64 group maxima among them: every value visits every lane through a scalar register
+                const u64 mine = s_gmax[lane];
+                const uint32_t mlo = (uint32_t)mine, mhi = (uint32_t)(mine >> 32);
+                int greater = 0;
+#pragma unroll 8
+                for (int j = 0; j < 64; ++j) {
+                    const u64 v = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)mhi, j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)mlo, j);
+                    greater += v > mine ? 1 : 0;
+                }
+                const bool enough = __popcll(__ballot(mine != 0)) >= k;
+                if (lane == 0) s_quick = enough ? 1 : 0;
+                // keys are unique: exactly one group maximum has each rank
+                if (enough && mine != 0 && greater == k - 1) s_kth[0] = mine;
+                if (enough && args.heur_rank && mine != 0 && greater == (int)args.heur_rank - 1) s_kth[1] = mine;
+                wave_lds_fence();
+                if (enough && lane == 0) {
+                    float t;
+                    if (dq < 0.f) {
+                        t = INFINITY;      // skipped query (padding / zero / non-finite): the exact path answers it
+                        if (args.overflow) args.overflow[q] = 1;
+                    } else {
+                        t = __uint_as_float(score_from_sortkey(s_kth[0])) - 2.0f * dq;
+                        if (!(t == t)) t = -INFINITY;
+                    }
+                    s_tau = t;
+                    if (args.tau_floor_out) args.tau_floor_out[q] = t;
+                    // (the heuristic gate of an anchoring-only sample stage: the score at that rank WITHOUT a margin — here the
+                    // rank among the group maxima, a few ranks lower in the whole list; the proven floor above keeps it honest)
+                    if (args.heur_rank && dq >= 0.f) {
+                        const float th = __uint_as_float(score_from_sortkey(s_kth[1]));
+                        if (th == th && th > t) t = th;
+                    }
+                    if (args.tau_out) args.tau_out[q] = t;
+                }
+            }
+            __syncthreads();
+            quick_ok = s_quick != 0;
+        }
+        if (!quick_ok) {
         for (int p = 0; p < npass; ++p) {  // block-uniform
-            load_pass(p, e);
+            if (!(quick_bound && p == 0)) load_pass(p, e);
+            if (p == 0) SEL_STAMP(2);
             wave_select_pass<PER, KL>(e, k, p ? win[(p - 1) & 1] + wave * k : nullptr, win[p & 1] + wave * k, lane);
         }
         __syncthreads();
-        if (wave == 0) {
+        SEL_STAMP(3);
+        }
+        if (!quick_ok && wave == 0) {
             merge_wave_winners<KL>(win[(npass - 1) & 1], k, top, lane);
             if (lane == 0) {
                 const float d = args.delta[q];
@@ -512,6 +609,7 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
             }
         }
         __syncthreads();
+        SEL_STAMP(4);
         if (!FINISH && !args.pool_out && !args.cand_counts) return;
         const float tau = s_tau;
         for (int p = 0; p < npass; ++p) {
@@ -543,6 +641,7 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
         }
         ncand = s_count;
     }
+    SEL_STAMP(5);
     // big pool (sorted variant's finish): the candidates stay in the sort buffer — up to kSelSortCap of them are re-scored
     // exactly instead of POOL (a tight cluster puts thousands of rows inside the int8 filter's margin)
     const bool big = FINISH && SORTED && args.big_pool != 0 && !args.take_topk;
@@ -561,7 +660,7 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
         const int a = tid & 3;
         const int nc = ncand < pool_cap ? ncand : pool_cap;
         u64* cbuf = big ? sbuf : pool;   // (big: sbuf[0, ncand) are the candidates, best approximate score first)
-        const float* qv = args.queries + (size_t)q * (args.query_stride ? args.query_stride : (uint32_t)dim);
+        const float* qv = dim <= kSelQueryLds ? s_q : args.queries + (size_t)q * (args.query_stride ? args.query_stride : (uint32_t)dim);
         const size_t row_pitch = args.row_stride ? (size_t)args.row_stride : (size_t)dim * 2;
         const int chunks = dim >> 3, groups = chunks >> 2, leftover = chunks & 3;
         for (int c0 = 0; c0 < nc; c0 += NT / 4) {  // block-uniform trip count
@@ -575,10 +674,19 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
             float acc[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-            for (int g = 0; g < groups; ++g) {
-                const u32x4 w = p[4 * g + a];
-                const float4* qp = reinterpret_cast<const float4*>(qv + 32 * g + 8 * a);
-                chunk_mac(acc, w, qp[0], qp[1]);
+            // (four groups' slab loads in flight at a time: the loop was one HBM round trip per group — 12 for 384 dimensions,
+            // ~20 k cycles of the finish's 80 k; the query's chunks come from LDS.  64 VGPRs per thread at this block size.)
+            for (int g0 = 0; g0 < groups; g0 += 4) {
+                u32x4 w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (g0 + j < groups) w[j] = p[4 * (g0 + j) + a];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (g0 + j < groups) {
+                        const float4* qp = reinterpret_cast<const float4*>(qv + 32 * (g0 + j) + 8 * a);
+                        chunk_mac(acc, w[j], qp[0], qp[1]);
+                    }
             }
             if (a == 0)
                 for (int ch = 4 * groups; ch < 4 * groups + leftover; ++ch) {
@@ -590,6 +698,8 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
             if (a == 0 && c < nc) cbuf[c] = mine ? pack(sc, grow) : kEmpty;  // only this quad touches its entry
         }
         __syncthreads();
+        SEL_STAMP(6);
+        if (args.stamps && (blockIdx.x & 255) == 0 && blockIdx.x < 1024 && threadIdx.x == 0) args.stamps[(blockIdx.x >> 8) * 16 + 15] = (unsigned long long)nc;
         if (args.cand_exact_out && args.take_topk && tid < k) args.cand_exact_out[(size_t)q * args.cand_out_stride + tid] = pool[tid];
         const int ko = (int)args.k_out;
         if (big) {
@@ -599,14 +709,48 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
             for (int j = nc + tid; j < np; j += NT) sbuf[j] = kEmpty;
             block_sort_desc_rt<NT>(sbuf, np, tid);
             if (tid < 64) top[tid] = tid < ko && tid < np ? sbuf[tid] : kEmpty;
+        } else if (nc <= 64) {
+            // the usual case (a few dozen candidates, all in pool[0, 64)): wave 0's picks ARE the block's top-k
+            // (by rank: every key visits every lane through a scalar register; keys are unique, so the ranks are a permutation)
+            if (wave == 0) {
+                const u64 mine_e = pool[lane];
+                const u64 mine = mine_e != kEmpty ? sortkey(mine_e) : 0ull;
+                const uint32_t mlo = (uint32_t)mine, mhi = (uint32_t)(mine >> 32);
+                int greater = 0;
+#pragma unroll 8
+                for (int j = 0; j < 64; ++j) {
+                    const u64 v = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)mhi, j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)mlo, j);
+                    greater += v > mine ? 1 : 0;
+                }
+                top[lane] = kEmpty;
+                wave_lds_fence();
+                if (mine != 0 && greater < ko) top[greater] = mine_e;
+                wave_lds_fence();
+            }
+        } else if (nc <= 256) {
+            // up to 256 candidates: the same by four waves, the keys broadcast from LDS (the winners' buffer is free here)
+            u64* keys = win[0];
+            const u64 mine_e = tid < 256 ? pool[tid] : kEmpty;
+            const u64 mine = mine_e != kEmpty ? sortkey(mine_e) : 0ull;
+            if (tid < 256) keys[tid] = mine;
+            if (tid < 64) top[tid] = kEmpty;
+            __syncthreads();
+            if (tid < 256 && mine != 0) {
+                int greater = 0;
+                const int nj = (nc + 7) & ~7;   // (the candidates are pool[0, nc))
+#pragma unroll 8
+                for (int j = 0; j < nj; ++j) greater += keys[j] > mine ? 1 : 0;
+                if (greater < ko) top[greater] = mine_e;
+            }
         } else {
             u64 e3[1];
             e3[0] = pool[tid];
             wave_select_pass<1, 1>(e3, ko, nullptr, win[0] + wave * ko, lane);
         }
         __syncthreads();
+        SEL_STAMP(7);
         if (wave == 0) {
-            if (!big) merge_wave_winners<1>(win[0], ko, top, lane);
+            if (!big && nc > 256) merge_wave_winners<1>(win[0], ko, top, lane);
             if (args.anchor_unit && args.tau_out && lane == 0) {
                 // the k-th best exact score among real rows is a lower bound on the final k-th best; in filter units, minus one
                 // delta (and the rounding of the product), it bounds every true top-k row's approximate score from below
@@ -633,6 +777,7 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
             for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off);
             if (lane == 0 && args.out_counts) args.out_counts[q] = (uint32_t)n;
         }
+        SEL_STAMP(8);
     }
 }
 

@@ -15,6 +15,7 @@
 #include <cstring>
 
 #include "../../include/fsgpu.h"
+#include "lab_env.hpp"
 
 namespace fsgpu {
 
@@ -1867,7 +1868,23 @@ SearchError VectorIndex::batched_finish(BatchedPlan& p, BatchedRound& r) {
         sb.cand_exact_out = tp_exact_out_ + (size_t)g0 * tp_stride_;
         sb.cand_out_stride = tp_stride_;
     }
+#ifdef FSGPU_EXPERIMENTS
+    static unsigned long long* sel_stamps = nullptr;   // FSGPU_SELECT_STAMPS=1: shader clocks of the phases of blocks 0, 256, 512, 768 of the finish
+    if (fsgpu::lab_env("FSGPU_SELECT_STAMPS") && !sel_stamps) (void)hipHostMalloc(reinterpret_cast<void**>(&sel_stamps), 64 * 8, hipHostMallocMapped);
+    if (sel_stamps) {
+        if (sel_stamps[8]) {
+            for (int b = 0; b < 4; ++b) {
+                std::fprintf(stderr, "[select stamps] block %4d start %+8lld:", b * 256, (long long)(sel_stamps[b * 16] - sel_stamps[0]));
+                for (int i = 1; i <= 8; ++i) std::fprintf(stderr, " %lld", (long long)(sel_stamps[b * 16 + i] - sel_stamps[b * 16]));
+                std::fprintf(stderr, " nc=%lld\n", (long long)sel_stamps[b * 16 + 15]);
+            }
+        }
+        std::memset(sel_stamps, 0, 64 * 8);
+        sb.stamps = sel_stamps;
+    }
+#endif
     FSGPU_HIP(launch_select(sb, (int)r.ng, stream));
+    sb.stamps = nullptr;
     if (second_chance) {   // queries whose candidates did not fit the pool: the sorted finish over the same lists (others return at once)
         sb.big_pool = 1;
         FSGPU_HIP(launch_select(sb, (int)r.ng, stream));
