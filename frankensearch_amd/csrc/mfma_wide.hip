@@ -257,7 +257,9 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     // k-step j % KS).  Rows past the end are clamped to the last row (their scores are discarded below).
     const int dma_p = lane >> 2, dma_c = lane & 3;
     const int dma_chunk = dma_c ^ ((4 - (dma_p >> 2)) & 3);
-    constexpr int PARTS = (PW + 2) / 3, PP = PW / PARTS;   // a wave's DMA instructions go out in groups of at most three
+    // a wave's DMA instructions go out in groups of at most three (groups of two / one measured 1.36 / 1.40 ms per 512 queries
+    // against 1.33 with three: every group is an M0 write + its loads in the MFMA stream)
+    constexpr int PARTS = (PW + 2) / 3, PP = PW / PARTS;
     static_assert(PW % PARTS == 0, "a tile's DMA instructions per wave split evenly into groups");
     uint32_t dma_off[PARTS][PP];   // SADDR: this lane's byte offset from the tile's first row, per instruction of the wave
 #pragma unroll
@@ -498,7 +500,14 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
                         asm volatile("" ::: "memory");
                     }
                     // the refill of tile n-1's slot: one group of DMA instructions per pair, behind a few MFMAs of its phase 1
-                    if (p < PARTS && kk == (KS >= 3 ? 2 : KS - 1)) fetch_part(slot_prev, p);
+                    // (all of them behind the first pair's first MFMAs was measured: 1.43 instead of 1.36 ms — the DMA's LDS writes
+                    // then collide with the pair's fragment reads)
+                    {
+                        constexpr int IPP = (PARTS + NP - 1) / NP;   // issue points per pair
+                        constexpr int K1 = KS >= 3 ? 2 : KS - 1, K2 = KS >= 5 ? 4 : K1;
+                        if (kk == K1 && p * IPP < PARTS) fetch_part(slot_prev, p * IPP);
+                        if (IPP > 1 && K2 != K1 && kk == K2 && p * IPP + 1 < PARTS) fetch_part(slot_prev, p * IPP + 1);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (anyB) emit_tiles(tB, ((p + NP - 1) % NP) * 2, acc, QA, QT);

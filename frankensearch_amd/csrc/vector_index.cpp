@@ -1699,9 +1699,10 @@ SearchError VectorIndex::batched_sample(const BatchedPlan& p, BatchedRound& r) {
     const bool heur_b = (r.anchor || (i8 && !i8f)) && r.wide_qt != 0 && !skip_b && !knobs().no_wide_b && !knobs().no_heur_b && ksel >= 8;
     if (heur_b) {
         // rank r of the first sample: the second sample holds RB / RA x as many rows above that score as the first (r, up to
-        // an order statistic's spread ~ Gamma(r)), and k of them are needed — r = 8 + k / 8 puts "fewer than k came through"
-        // (which only costs that query a looser threshold) below 1e-7 per query for k <= 64 and RB / RA >= 48
-        sa.heur_rank = knobs().heur_rank > 0 ? (uint32_t)std::min<int>(knobs().heur_rank, (int)ksel) : std::min<uint32_t>(ksel, 8 + ksel / 8);
+        // an order statistic's spread ~ Gamma(r)), and k of them are needed — r = 5 + k / 8 puts "fewer than k came through"
+        // (which only costs that query a looser threshold) near 1e-6 per query for k <= 64 and RB / RA >= 47; every rank less is
+        // ~47 fewer appends per query in the append-bound sample pass (r = 9 -> 6 at k = 10: 0.7 % of a step, scripts/r03/sweep_rb.sh)
+        sa.heur_rank = knobs().heur_rank > 0 ? (uint32_t)std::min<int>(knobs().heur_rank, (int)ksel) : std::min<uint32_t>(ksel, 5 + ksel / 8);
         sa.tau_floor_out = p.tau_floor;
     } else if (r.anchor) {
         set_rescore(sa);
