@@ -16,7 +16,7 @@ python bench.py --exact --batch 4 --no-cpu-baseline --no-two-tier 2>/dev/null | 
 FSGPU_FILTER=f16 python bench.py --no-cpu-baseline --no-two-tier 2>/dev/null | tail -1 > $OUT/bench_batched_f16_filter.json
 python bench.py --rows 1000000 --no-cpu-baseline --no-two-tier 2>/dev/null | tail -1 > $OUT/bench_config2_1m.json
 python bench.py --rows 1250000 --no-cpu-baseline --no-two-tier 2>/dev/null | tail -1 > $OUT/bench_shard_1m25.json
-python bench.py --rows 50000000 --config5 --no-cpu-baseline --no-two-tier 2>/dev/null | tail -1 > $OUT/bench_config5_50m.json
+python bench.py --rows 50000000 --config5 --no-adversarial --no-encoders --no-cpu-baseline --no-two-tier 2>/dev/null | tail -1 > $OUT/bench_config5_50m.json
 python bench.py --sharded-handle --gpus 1 2>/dev/null | grep queries_per_sec | tail -1 > $OUT/bench_sharded_handle_1gpu.json
 # per-kernel time of the default bench command
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- \
