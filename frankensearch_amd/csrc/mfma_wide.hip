@@ -153,6 +153,13 @@ constexpr bool wide_split_ok(int ROWB, int EB, int QT, int OPT, int DBG) {
 constexpr bool wide_big_ok(int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG) {
     return (OPT & kOptBig) != 0 && wide_split_ok(ROWB, EB, QT, OPT, DBG) && DBG == 0 && NSLOT == 3;
 }   // (bit 1 was a barrier-phase shift between the SIMD twins: measured null, removed)
+// one 64-bit word through the scalar cache (wave-uniform address): counted by lgkmcnt, not by the vmcnt the DMA ring lives on
+__device__ __forceinline__ u64 sload_u64(const u64* p) {
+    u64 w;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(p) : "memory");
+    return w;
+}
+
 template <int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG = 0>
 __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     using acc_t = std::conditional_t<EB == 2, f32x4, i32x4>;
@@ -375,10 +382,11 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
         }
         return any;
     };
-    auto append = [&](int q, float score, uint32_t row) {
+    // mask: the tombstone and allow bits of the 64 rows around `row` (emit_tiles fetched the words with SCALAR loads: a vector load
+    // here would be waited for with vmcnt(0), i.e. behind every DMA in flight — filtered batches paid ~10 % for that)
+    auto append = [&](int q, float score, uint32_t row, u64 mask) {
         if (row >= args.nrows) return;
-        if (args.live && !((args.live[row >> 6] >> (row & 63)) & 1ull)) return;
-        if (args.allow && !((args.allow[row >> 6] >> (row & 63)) & 1ull)) return;
+        if (!((mask >> (row & 63)) & 1ull)) return;
         const int pos = atomicAdd(&lcnt[q], 1);
         const u64 entry = pack(score, args.row_base + row);
         if (pos < slots) {
@@ -399,7 +407,15 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
 #endif
         if (t >= ntiles) return;   // (wave-uniform) a ragged round: the slot holds the last tile again
         // C layout: column (query) = lane & 15, row = (lane >> 4) * 4 + reg
-        const uint32_t row00 = tile_row0(t) + sp * 16 + fk * 4;
+        const uint32_t pair_row0 = tile_row0(t) + sp * 16;   // wave-uniform, a multiple of 32: the pair's 32 rows share one bitmap word
+        const uint32_t row00 = pair_row0 + fk * 4;
+        u64 mask = ~0ull;
+        if (args.live || args.allow) {
+            uint32_t wi = pair_row0 >> 6;   // (a ragged last tile: the pair may start past the last row — its rows are rejected below)
+            wi = __builtin_amdgcn_readfirstlane(wi < (last_row >> 6) ? wi : (last_row >> 6));
+            if (args.live) mask &= sload_u64(args.live + wi);
+            if (args.allow) mask &= sload_u64(args.allow + wi);
+        }
         if constexpr (EB == 2 && QT >= 3) {   // (the 384-query f16 shape has no register to spare for the per-tile test below)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -407,7 +423,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
                 for (int nt = nt_lo; nt < nt_hi; ++nt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (passes(nt, acc[h][nt][r])) append(q0 + nt * 16 + frow, score_of(nt, acc[h][nt][r]), row00 + h * 16 + r);
+                        if (passes(nt, acc[h][nt][r])) append(q0 + nt * 16 + frow, score_of(nt, acc[h][nt][r]), row00 + h * 16 + r, mask);
         } else {
             // query tiles first: a wave gets here for ONE passing score as a rule, and the tiles without one are skipped as a
             // whole — on a 1.25M-row shard, where 512 queries x ~800 survivors meet 8 x fewer tiles than at 10M rows, this slow
@@ -419,7 +435,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (passes(nt, acc[h][nt][r])) append(q0 + nt * 16 + frow, score_of(nt, acc[h][nt][r]), row00 + h * 16 + r);
+                        if (passes(nt, acc[h][nt][r])) append(q0 + nt * 16 + frow, score_of(nt, acc[h][nt][r]), row00 + h * 16 + r, mask);
             }
         }
     };
