@@ -1012,6 +1012,15 @@ def main() -> None:
         if world == 1 and args.batched and not args.exact:
             # the north-star's HBM target in the same run: the exact f16 kernel, one query per pass over the f16 slab
             line["roofline"]["exact_f16_scan"] = exact_scan_roofline(index, queries, k, hi - lo, args.dim, device)
+            if args.rows == 10_000_000 and args.dim == 384 and os.path.exists(pmc_path):
+                # HBM bytes of that kernel from this round's counter pass of `bench.py --exact --batch 1` (the same kernel, slab and launch shape)
+                for e in json.load(open(pmc_path)):
+                    if (e.get("counter") == "FETCH_SIZE" and e.get("run") == "pmc_fetch_b1" and "scan_topk_kernel<384, 1, 64" in e.get("kernel", "")
+                            and "hbm_read_bytes_corrected" in e):
+                        line["roofline"]["exact_f16_scan"]["traffic"] = e["hbm_read_bytes_corrected"]
+                        line["roofline"]["exact_f16_scan"]["traffic_source"] = (
+                            f"profiles/{PROFILE_ROUND}/pmc_summary.json (run pmc_fetch_b1): rocprofv3 --pmc FETCH_SIZE, KiB x 1024 x 2 (gfx950 correction)")
+                        break
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_and_parity(slab, queries, k, args.rows, fa.VectorIndex)
         if world == 1 and not args.no_adversarial and args.rows >= 1_000_000 and args.batched:
