@@ -705,6 +705,21 @@ def sharded_handle_main(args) -> None:
     for i in range(args.steps):
         out = idx.search_batch(q[(i % 2) * B:(i % 2) * B + B], k, batched=args.batched)
     dt = time.perf_counter() - t0
+    # the same steps through begin / end, two searches in flight: the exchange + merge of step i run underneath the scan of step i + 1
+    mode = idx.BATCHED if args.batched else idx.EXACT
+    pend = idx.search_begin(q[:B], k, mode)
+    idx.search_end(pend)
+    t1 = time.perf_counter()
+    pend = idx.search_begin(q[:B], k, mode)
+    for i in range(1, args.steps):
+        nxt = idx.search_begin(q[(i % 2) * B:(i % 2) * B + B], k, mode)
+        piped = idx.search_end(pend)
+        pend = nxt
+    piped = idx.search_end(pend)
+    dt_piped = time.perf_counter() - t1
+    last = q[((args.steps - 1) % 2) * B:((args.steps - 1) % 2) * B + B]
+    ref = idx.search_batch(last, k, batched=args.batched)
+    piped_same = bool(np.array_equal(piped[0], ref[0]) and np.array_equal(piped[1].view(np.uint32), ref[1].view(np.uint32)))
     # the answer must not depend on the sharding: one unsharded index over the first shard-0 rows cannot check that, so
     # compare a few queries with a 1-shard handle over ALL rows when they fit one device comfortably
     same = None
@@ -714,7 +729,9 @@ def sharded_handle_main(args) -> None:
         wr, ws, _ = whole.search_batch(q[:8], k)
         sr, ss, _ = idx.search_batch(q[:8], k)[:3]
         same = bool(np.array_equal(wr, sr) and np.array_equal(ws.view(np.uint32), ss.view(np.uint32)))
-    print(json.dumps({"queries_per_sec": args.steps * B / dt, "ms_per_step": dt / args.steps * 1e3, "n_gpus": n,
+    print(json.dumps({"queries_per_sec": args.steps * B / dt, "ms_per_step": dt / args.steps * 1e3,
+                      "pipelined_begin_end": {"queries_per_sec": args.steps * B / dt_piped, "ms_per_step": dt_piped / args.steps * 1e3,
+                                              "in_flight": 2, "hits_equal_blocking_call": piped_same}, "n_gpus": n,
                       "queries_per_step": B, "rows": args.rows, "steps": args.steps,
                       "exchange": "rccl ncclAllGather" if idx.exchange_mode() == 1 else "peer copies",
                       "path": "matrix-core batched" if args.batched else "exact VALU scan",
