@@ -156,7 +156,7 @@ constexpr bool wide_big_ok(int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG
 // one 64-bit word through the scalar cache (wave-uniform address): counted by lgkmcnt, not by the vmcnt the DMA ring lives on
 __device__ __forceinline__ u64 sload_u64(const u64* p) {
     u64 w;
-    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(p) : "memory");
+    asm volatile("s_load_dwordx2 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(w) : "s"(p) : "memory");   // (glc: past the scalar cache)
     return w;
 }
 

@@ -285,3 +285,26 @@ def test_int8_latency_path_returns_the_exact_kernels_answers(fa, oracle):
     assert cc.tolist() == [7, 7] and np.array_equal(cc, cd) and np.array_equal(rc[:, :7], rd[:, :7]) and np.array_equal(bits(sc[:, :7]), bits(sd[:, :7]))
     for i in (a, b, c, d):
         i.close()
+
+
+def test_repeated_batches_return_the_same_bits(fa):
+    """The same 520-query batch (one 512-query round on the register-resident-query kernels + an 8-query tail round; tombstones;
+    k = 30: selections with a few hundred candidates) forty times under each filter: every repetition must return the exact
+    kernels' rows and score bits.  (scripts/r03/determinism.py is the long form of this check.)"""
+    rng = np.random.default_rng(7)
+    dim, n, nq, k = 384, 118_597, 520, 30
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    live = rng.random(n) > 0.2
+    q = x[rng.integers(0, n, nq)] + (rng.standard_normal((nq, dim)) * 0.2).astype(np.float32)
+    idx = fa.VectorIndex.from_slab(x.astype(np.float16).view(np.uint16), live=live)
+    exact = [idx.search_batch(q[s:s + 64], k) for s in range(0, nq, 64)]
+    er = np.concatenate([e[0] for e in exact])
+    es = np.concatenate([e[1] for e in exact])
+    for filt in (2, 1):
+        idx.set_batched_filter(filt)
+        for rep in range(40):
+            br, bs, bc, _ = idx.search_batched(q, k)
+            assert np.array_equal(br, er), (filt, rep)
+            assert np.array_equal(bs.view(np.uint32), es.view(np.uint32)), (filt, rep)
+    idx.close()
