@@ -519,7 +519,10 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
         // batched loads), at the price of a few more candidates for the exact re-score.  Selections whose threshold GATES a scan
         // (the sample stages without an exact anchor) keep the exact rank: a looser gate there costs the append-bound sample
         // pass more than the selection saves (measured: +0.11 ms per 1,024 queries).
-        const bool quick_bound = FINISH && !args.take_topk && !args.heur_rank && npass == 1 && k <= 32;
+        // (... and the first sample's selection of a wide round, whose only products are the proven floor and the HEURISTIC gate of
+        // the anchoring-only second sample: the gate's rank taken among the group maxima sits a fraction of a rank lower)
+        const bool gate_only = !FINISH && args.heur_rank != 0 && (int)args.heur_rank <= k && !args.pool_out && !args.cand_counts;
+        const bool quick_bound = !args.take_topk && npass == 1 && k <= 32 && (FINISH ? args.heur_rank == 0 : gate_only);
         bool quick_ok = false;
         if (quick_bound) {
             load_pass(0, e);
