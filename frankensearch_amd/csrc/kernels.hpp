@@ -171,6 +171,7 @@ struct SelectArgs {
     u64* cand_approx_out;
     u64* cand_exact_out;
     uint32_t cand_out_stride;  // entries between queries in both (>= k)
+    uint32_t valid_queries;       // blocks q >= this are padding slots whose query lies past the caller's array (0 = every block's query exists)
     unsigned long long* stamps;   // lab builds (FSGPU_EXPERIMENTS): shader clocks of block 0's phases; null otherwise
 };
 constexpr uint32_t kSelectPool = 1024;

@@ -400,52 +400,89 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
     SEL_STAMP(0);
     if (args.big_pool && args.pool_flag && args.pool_flag[q] == 0) return;   // second chance: only the queries the first finish flagged
     const int k = (int)args.k;
-    const float dq = args.delta[q];   // (requested here: its round trip runs underneath the entries')
-    if constexpr (FINISH) {
-        // the query of the exact re-score, parked in LDS (read by every candidate's quad); visible after the barriers below
-        // (only for a query that can have candidates: the padding slots of a round's last group — delta < 0 — lie past the end
-        // of the caller's query array)
-        if (args.queries && (int)args.dim <= kSelQueryLds && dq >= 0.f) {
-            const float* qsrc = args.queries + (size_t)q * (args.query_stride ? args.query_stride : args.dim);
-            for (int i = tid; i < (int)args.dim; i += NT) s_q[i] = qsrc[i];
-        }
-    }
+    // Everything the block needs first is REQUESTED first, in one round trip: the list lengths, the entries of the lists' first four
+    // slots (speculatively — most lists hold fewer than four; what lies beyond a list's length is masked once the lengths are in), the
+    // spill count, delta, the re-score's query.  (They used to be four dependent round trips: delta -> query -> lengths -> entries.)
     const u64* in = args.lists + (size_t)q * args.q_stride;
     const uint32_t* cnts = args.list_counts ? args.list_counts + (size_t)q * args.nlists : nullptr;
     constexpr uint32_t kSelCntCap = 512;
+    constexpr uint32_t kSpecSlots = 4;
     __shared__ uint32_t s_cnt[kSelCntCap];   // the query's list lengths: one coalesced read instead of a dependent one per slot
-    if (cnts) {
-        for (uint32_t i = tid; i < args.nlists && i < kSelCntCap; i += NT) s_cnt[i] = cnts[i];
-        __syncthreads();
-    }
     const uint32_t lists32 = args.nlists * args.list_len;
-    const uint32_t extra_end = lists32 + args.extra_len;
-    uint32_t nspill = 0;
-    if (args.spill) {
-        nspill = args.spill_count[(size_t)q * kMfmaSpillCountStride];
-        nspill = nspill < args.spill_cap ? nspill : args.spill_cap;
+    uint32_t my_cnt = 0;
+    if (cnts && (uint32_t)tid < args.nlists && (uint32_t)tid < kSelCntCap) my_cnt = cnts[tid];
+    u64 e[PER];
+    const bool spec = cnts != nullptr && !SORTED;
+    if (spec) {
+#pragma unroll
+        for (int x = 0; x < PER; ++x) {
+            const uint32_t i = tid + x * NT;
+            e[x] = kEmpty;
+            if (i < lists32) {
+                const uint32_t l = i / args.list_len, j = i - l * args.list_len;
+                if (j < kSpecSlots) e[x] = in[(size_t)l * args.l_stride + j];
+            }
+        }
     }
+    uint32_t nspill = 0;
+    if (args.spill) nspill = args.spill_count[(size_t)q * kMfmaSpillCountStride];
+    const float dq = args.delta[q];
+    float qreg[(kSelQueryLds + NT - 1) / NT];
+    // (the padding slots of a round's last group lie past the end of the caller's query array: valid_queries bounds the read)
+    const bool stage_q = FINISH && args.queries && (int)args.dim <= kSelQueryLds && (args.valid_queries == 0 || (uint32_t)q < args.valid_queries);
+    if constexpr (FINISH) {
+        if (stage_q) {
+            const float* qsrc = args.queries + (size_t)q * (args.query_stride ? args.query_stride : args.dim);
+#pragma unroll
+            for (int x = 0; x < (kSelQueryLds + NT - 1) / NT; ++x) qreg[x] = tid + x * NT < (int)args.dim ? qsrc[tid + x * NT] : 0.f;
+        }
+    }
+    if (cnts) {
+        if ((uint32_t)tid < args.nlists && (uint32_t)tid < kSelCntCap) s_cnt[tid] = my_cnt;
+        for (uint32_t i = tid + NT; i < args.nlists && i < kSelCntCap; i += NT) s_cnt[i] = cnts[i];
+    }
+    if constexpr (FINISH) {
+        // the query of the exact re-score, parked in LDS (read by every candidate's quad); visible after the barriers below
+        if (stage_q) {
+#pragma unroll
+            for (int x = 0; x < (kSelQueryLds + NT - 1) / NT; ++x)
+                if (tid + x * NT < (int)args.dim) s_q[tid + x * NT] = qreg[x];
+        }
+    }
+    if (cnts) __syncthreads();
+    const uint32_t extra_end = lists32 + args.extra_len;
+    nspill = nspill < args.spill_cap ? nspill : args.spill_cap;
     const uint32_t total32 = extra_end + nspill;
     const int npass = total32 ? (int)((total32 + NT * PER - 1) / (NT * PER)) : 1;
-    auto load_pass = [&](int p, u64 (&e)[PER]) {
+    // first = the first load of pass 0 after the speculative requests above: slots below kSpecSlots are already in e
+    auto load_pass = [&](int p, u64 (&e)[PER], bool first = false) {
 #pragma unroll
         for (int x = 0; x < PER; ++x) {
             const uint32_t i = (uint32_t)p * (NT * PER) + tid + x * NT;
-            e[x] = kEmpty;
+            const bool have = first && spec && p == 0;
+            if (!have) e[x] = kEmpty;
             if (i < lists32) {
-                // (list lengths, staged in LDS below: only the slots that hold an entry are read — a few percent of them)
+                // (list lengths, staged in LDS above: only the slots that hold an entry are read — a few percent of them)
                 const uint32_t l = i / args.list_len, j = i - l * args.list_len;
-                if (!cnts || j < (l < kSelCntCap ? s_cnt[l] : cnts[l])) e[x] = in[(size_t)l * args.l_stride + j];
+                const bool in_list = !cnts || j < (l < kSelCntCap ? s_cnt[l] : cnts[l]);
+                if (have && j < kSpecSlots) {
+                    if (!in_list) e[x] = kEmpty;
+                } else if (in_list) {
+                    e[x] = in[(size_t)l * args.l_stride + j];
+                } else {
+                    e[x] = kEmpty;
+                }
             } else if (i < extra_end) {
                 e[x] = args.extra[(size_t)q * args.extra_len + (i - lists32)];
             } else if (i < total32) {
                 e[x] = args.spill[(size_t)q * args.spill_cap + (i - extra_end)];
+            } else {
+                e[x] = kEmpty;
             }
         }
     };
     if (tid == 0) s_count = 0;
     pool[tid] = kEmpty;
-    u64 e[PER];
     int ncand = 0;
     if constexpr (SORTED) {
         __syncthreads();
@@ -525,7 +562,7 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
         const bool quick_bound = !args.take_topk && npass == 1 && k <= 32 && (FINISH ? args.heur_rank == 0 : gate_only);
         bool quick_ok = false;
         if (quick_bound) {
-            load_pass(0, e);
+            load_pass(0, e, true);
             SEL_STAMP(2);
             // 64 groups along the diagonals of the (list, slot) grid — thread (list mod 64, slot) feeds group (list + slot) mod 64:
             // every group draws on all lists' heads evenly (lists fill from slot 0), and the entries of ONE list — a cluster's
@@ -581,7 +618,7 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
         }
         if (!quick_ok) {
         for (int p = 0; p < npass; ++p) {  // block-uniform
-            if (!(quick_bound && p == 0)) load_pass(p, e);
+            if (!(quick_bound && p == 0)) load_pass(p, e, p == 0);
             if (p == 0) SEL_STAMP(2);
             wave_select_pass<PER, KL>(e, k, p ? win[(p - 1) & 1] + wave * k : nullptr, win[p & 1] + wave * k, lane);
         }

@@ -1708,6 +1708,7 @@ SearchError VectorIndex::batched_sample(const BatchedPlan& p, BatchedRound& r) {
         set_rescore(sa);
         sa.anchor_unit = p.unit;
     }
+    sa.valid_queries = r.ng;   // (the launch covers the round's padded query slots)
     FSGPU_HIP(launch_select(sa, (int)QP, stream));
     // stage B: the B sample's rows at or above tau, one short list per (query, block) -> tighter tau; the rows
     // still at or above it form the pool carried into the last selection
@@ -1765,7 +1766,9 @@ SearchError VectorIndex::batched_sample(const BatchedPlan& p, BatchedRound& r) {
             sb.anchor_unit = p.unit;
         }
         if (heur_b) sb.tau_floor_in = p.tau_floor;
+        sb.valid_queries = r.ng;   // (the launch covers the round's padded query slots)
         FSGPU_HIP(launch_select(sb, (int)QP, stream));
+        sb.valid_queries = 0;
         sb.anchor_unit = nullptr;
         sb.tau_floor_in = nullptr;
     }
