@@ -368,6 +368,7 @@ __device__ __forceinline__ void merge_wave_winners(const u64* win, int k, u64* t
 // to k ~ 32.  SORTED = true (larger k: the int8 fast tier anchors on 3 x 30 = 90 candidates): the non-empty entries
 // are compacted into LDS and bitonic-sorted by the whole block; top-k, threshold and candidate prefix fall out.
 constexpr int kSelSortCap = 8192;   // live entries the sorted variant holds (dynamic LDS: 64 KB)
+constexpr int kRescoreBatch = 6;    // slab loads of a candidate row in flight at a time (a row of 384 dimensions: two round trips; 4: -1 % of a step, 12: spills, -2.5 %)
 constexpr int kSelQueryLds = 1024;  // dimensions of the re-score's query kept in LDS (longer queries are read in place)
 #ifdef FSGPU_EXPERIMENTS
 #define SEL_STAMP(slot)                                                                                            \
@@ -714,15 +715,15 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
             float acc[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-            // (four groups' slab loads in flight at a time: the loop was one HBM round trip per group — 12 for 384 dimensions,
+            // (kRescoreBatch groups' slab loads in flight at a time: the loop was one HBM round trip per group — 12 for 384 dimensions,
             // ~20 k cycles of the finish's 80 k; the query's chunks come from LDS.  64 VGPRs per thread at this block size.)
-            for (int g0 = 0; g0 < groups; g0 += 4) {
-                u32x4 w[4];
+            for (int g0 = 0; g0 < groups; g0 += kRescoreBatch) {
+                u32x4 w[kRescoreBatch];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < kRescoreBatch; ++j)
                     if (g0 + j < groups) w[j] = p[4 * (g0 + j) + a];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < kRescoreBatch; ++j)
                     if (g0 + j < groups) {
                         const float4* qp = reinterpret_cast<const float4*>(qv + 32 * (g0 + j) + 8 * a);
                         chunk_mac(acc, w[j], qp[0], qp[1]);
