@@ -444,6 +444,13 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
         if (any_passes(acc, 0, QT)) emit_tiles(t, sp, acc, 0, QT);
     };
 
+    // The append path reads the tombstone / allow words with SCALAR loads (sload_u64).  The scalar data cache is not invalidated
+    // between the kernels of a stream the way the vector L1 is — compiler-made scalar loads only ever touch kernel arguments and
+    // constants — so a line cached by an earlier kernel (the previous call's allow bitmap in the same workspace; a closed index's
+    // bitmap at a reused address) could be served stale: one repetition in ~30,000 returned a filtered-out row or lost an allowed
+    // one (scripts/r03/determinism.py).  Every wave therefore invalidates the scalar cache once before its first bitmap word; the
+    // bitmaps do not change while the kernel runs.
+    if (args.live || args.allow) asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();  // counters initialised (no DMA in flight yet)
     Cursor cl{0, blockIdx.x, blockIdx.x};   // next tile to fetch
     Cursor cc = cl;                         // next tile to consume
