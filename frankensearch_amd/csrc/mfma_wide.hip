@@ -413,8 +413,13 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
         if (args.live || args.allow) {
             uint32_t wi = pair_row0 >> 6;   // (a ragged last tile: the pair may start past the last row — its rows are rejected below)
             wi = __builtin_amdgcn_readfirstlane(wi < (last_row >> 6) ? wi : (last_row >> 6));
+#ifdef FSGPU_LAB_VECTOR_BITMAP   // (lab: the r03 state before the scalar loads — waits behind every DMA in flight)
+            if (args.live) mask &= __builtin_nontemporal_load(args.live + wi);
+            if (args.allow) mask &= __builtin_nontemporal_load(args.allow + wi);
+#else
             if (args.live) mask &= sload_u64(args.live + wi);
             if (args.allow) mask &= sload_u64(args.allow + wi);
+#endif
         }
         if constexpr (EB == 2 && QT >= 3) {   // (the 384-query f16 shape has no register to spare for the per-tile test below)
 #pragma unroll
@@ -450,7 +455,9 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     // bitmap at a reused address) could be served stale: one repetition in ~30,000 returned a filtered-out row or lost an allowed
     // one (scripts/r03/determinism.py).  Every wave therefore invalidates the scalar cache once before its first bitmap word; the
     // bitmaps do not change while the kernel runs.
+#ifndef FSGPU_LAB_NO_DCACHE_INV
     if (args.live || args.allow) asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     __syncthreads();  // counters initialised (no DMA in flight yet)
     Cursor cl{0, blockIdx.x, blockIdx.x};   // next tile to fetch
     Cursor cc = cl;                         // next tile to consume
