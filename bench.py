@@ -620,83 +620,144 @@ def mrl_section(index, rows: int, dim: int, k: int, queries):
     return out
 
 
-def config5_section(index, rows: int, k: int, local_rank: int, batches: int = 20):
-    """BASELINE config 5 end to end on one GPU: batches of 256 token-id queries (lengths uniform 8..32 incl.
-    [CLS]=101 / [SEP]=102, ids uniform in [1000, 30000)) -> MiniLM-L6 forward on the GPU -> batched exact scan
-    -> top-k.  Random-init weights of the MiniLM-L6 shape; the embeddings go through the host-pointer ABI (393 KB per batch).
-    Two forms: one scan per 256-query batch (r01 / r02's figure), and the scan fed 512-query groups — two encoder batches per
-    pass of the slab, what the register-resident-query main pass is built for (r02 verdict, item 6)."""
+def config5_section(index, rows: int, k: int, local_rank: int):
+    """BASELINE config 5 end to end on one GPU (random-init weights of the MiniLM-L6 shape): see config5_stream_section."""
     import frankensearch_amd as fa
     from frankensearch_amd.synthetic import random_bert_weights
     bert = fa.NativeEmbedder(random_bert_weights(1, 30522, 384, 6, 1536), device=local_rank)
-    rng = np.random.default_rng(5)
-    def batch():
-        return [[101] + rng.integers(1000, 30000, int(rng.integers(6, 31))).tolist() + [102] for _ in range(256)]
-    def flat(b):   # the C ABI's argument shape (what a host holds after tokenising): concatenated ids + offsets
-        offs = np.zeros(len(b) + 1, dtype=np.uint32)
-        offs[1:] = np.cumsum([len(x) for x in b])
-        return np.concatenate([np.asarray(x, dtype=np.int32) for x in b]), offs
-    sets = [flat(batch()) for _ in range(4)]
-    emb = np.empty((512, 384), dtype=np.float32)
-    for ids, offs in sets[:2]:
-        index.search_batched(bert.embed_flat(ids, offs, emb[:256]), k)
-    enc_ms, scan_ms = [], []
-    t0 = time.perf_counter()
-    for i in range(batches):
-        t1 = time.perf_counter()
-        bert.embed_flat(sets[i % 4][0], sets[i % 4][1], emb[:256])
-        t2 = time.perf_counter()
-        rows_out, scores, counts, fb = index.search_batched(emb[:256], k)
-        t3 = time.perf_counter()
-        enc_ms.append((t2 - t1) * 1e3)
-        scan_ms.append((t3 - t2) * 1e3)
-    dt = time.perf_counter() - t0
-    out = {"workload": f"256 token-id queries per batch -> MiniLM-L6 on the GPU -> batched exact scan of {rows}x384 f16, top-{k}",
-           "queries_per_sec": batches * 256 / dt, "encode_ms_per_batch": float(np.median(enc_ms)),
-           "scan_ms_per_batch": float(np.median(scan_ms)), "tokens_per_batch": int(sets[0][0].size),
-           "all_counts_full": bool(np.all(counts == k))}
-    # two encoder batches per scan pass
-    index.search_batched(emb, k)
-    enc2, scan2 = [], []
-    t0 = time.perf_counter()
-    for i in range(batches):
-        t1 = time.perf_counter()
-        bert.embed_flat(sets[(2 * i) % 4][0], sets[(2 * i) % 4][1], emb[:256])
-        bert.embed_flat(sets[(2 * i + 1) % 4][0], sets[(2 * i + 1) % 4][1], emb[256:])
-        t2 = time.perf_counter()
-        rows2, scores2, counts2, fb2 = index.search_batched(emb, k)
-        t3 = time.perf_counter()
-        enc2.append((t2 - t1) * 1e3)
-        scan2.append((t3 - t2) * 1e3)
-    dt2 = time.perf_counter() - t0
-    # the pairing changes nothing about a query's answer: the second half of the last pair against its own 256-query search
-    alone = index.search_batched(emb[256:], k)
-    out["scan_fed_512_query_groups"] = {
-        "workload": "two 256-query encoder batches -> one 512-query pass of the slab",
-        "queries_per_sec": batches * 512 / dt2, "encode_ms_per_two_batches": float(np.median(enc2)),
-        "scan_ms_per_512_queries": float(np.median(scan2)), "all_counts_full": bool(np.all(counts2 == k)),
-        "hits_equal_256_query_search": bool(np.array_equal(rows2[256:], alone[0]) and
-                                            np.array_equal(scores2[256:].view(np.uint32), alone[1].view(np.uint32)))}
+    out = config5_stream_section(fa, index, bert, rows, k)
+    bert.close()
+    return out
+
+
+def _shard_devices(n: int, virtual: bool):
+    """One shard per GPU — or, for the single-GPU rehearsal of the N-way path, n virtual shards on device 0 (peer copies)."""
+    return [0] * n if virtual else list(range(n))
+
+
+def _sharded_from_generator(fa, devices, rows: int, dim: int, exchange: int):
+    """A row-sharded handle over the bench corpus: every shard's rows are generated in place on its device (contiguous ceil split)."""
+    n = len(devices)
+    per = (rows + n - 1) // n
+    slabs, counts = [], []
+    for r, dev in enumerate(devices):
+        lo, hi = min(rows, r * per), min(rows, (r + 1) * per)
+        slabs.append(gen_corpus(lo, hi, dim, torch.device("cuda", dev)))
+        counts.append(hi - lo)
+    return fa.NativeShardedIndex.from_device_slabs(devices, dim, counts, [t.data_ptr() for t in slabs], exchange=exchange, keepalive=slabs)
+
+
+def two_tier_sharded_section(fa, devices, quality_index, rows: int, k: int, exchange: int):
+    """BASELINE config 3's flow with BOTH tiers row-sharded over the node: potion fast tier rows x 256 (sharded int8
+    two-pass: the corpus-wide candidate set) + MiniLM quality tier rows x 384 (sharded exact search, or the fast pool re-scored by
+    a gather routed to the owning shards), encoders on device 0, RRF + blend on the host — libfshost's SyncTwoTierSearcher over two
+    fsgpu_sharded handles (fshost_two_tier_create_sharded), per-query C ABI calls from native threads."""
+    from frankensearch_amd.host import NativeTwoTierSearcher
+    from frankensearch_amd.synthetic import random_bert_weights
+
+    fast_index = _sharded_from_generator(fa, devices, rows, 256, exchange)
+    table = np.random.default_rng(0).standard_normal((500_353, 256)).astype(np.float32)   # potion-multilingual-128M shape
+    m2v = fa.Model2VecEmbedder(table, device=devices[0])
+    bert = fa.NativeEmbedder(random_bert_weights(1, 30522, 384, 6, 1536), device=devices[0])
+    common = dict(doc_id_mode=1, fast_tier_int8_multiplier=3)
+    load = dict(queries=200, warmup_queries=16, k=k, fast_vocab=500_353, corpus_rows=rows)
+    plain = NativeTwoTierSearcher(fast_index, quality_index, m2v, bert, **common)
+    seq_plain = plain.run_load(threads=1, **load)
+    rescored = NativeTwoTierSearcher(fast_index, quality_index, m2v, bert, quality_pool=1, **common)
+    seq_resc = rescored.run_load(threads=1, **load)
+    rescored.close()
+    spec = NativeTwoTierSearcher(fast_index, quality_index, m2v, bert, prefetch_quality_embed=2, **common)
+    seq_spec = spec.run_load(threads=1, **load)
+    spec.close()
+    max_batch, wait_us = 256, 1000
+    fast_index.set_coalescing(max_batch, wait_us)
+    quality_index.set_coalescing(max_batch, wait_us)
+    m2v.set_coalescing(2 * max_batch, wait_us // 2)
+    bert.set_coalescing(2 * max_batch, wait_us)
+    fb0, fr0 = fast_index.coalescing_stats()
+    qb0, qr0 = quality_index.coalescing_stats()
+    con = plain.run_load(threads=1024, queries=60_000, warmup_queries=2048, k=k, fast_vocab=500_353, corpus_rows=rows)
+    fb, fr = fast_index.coalescing_stats()
+    qb, qr = quality_index.coalescing_stats()
+    quality_index.set_coalescing(0, 0)
+    plain.close()
+    res = {
+        "workload": f"{rows}x256 fast tier (sharded int8 two-pass, multiplier 3) + {rows}x384 quality tier (sharded exact), both row-sharded "
+                    f"{len(devices)} way(s), top-{k}, fetch {3 * k} per tier, stub lexical list of {3 * k}, RRF + blend on the host; per-query "
+                    "C ABI calls from native threads (libfshost.so over fsgpu_sharded handles)",
+        "shards": len(devices),
+        "phase0_p50_ms": seq_plain.phase0_p50_ms, "phase1_p50_ms": seq_plain.phase1_p50_ms,
+        "sequential_queries_per_sec": seq_plain.queries_per_sec,
+        "sequential_breakdown_ms": {"fast_embed": seq_plain.mean_fast_embed_ms, "fast_search": seq_plain.mean_fast_search_ms,
+                                    "quality_embed": seq_plain.mean_quality_embed_ms, "quality_search": seq_plain.mean_quality_search_ms,
+                                    "fusion": seq_plain.mean_fusion_ms},
+        "sequential_with_quality_search_prefetch": {"phase0_p50_ms": seq_spec.phase0_p50_ms, "phase1_p50_ms": seq_spec.phase1_p50_ms},
+        "rescored_fast_pool": {"phase0_p50_ms": seq_resc.phase0_p50_ms, "phase1_p50_ms": seq_resc.phase1_p50_ms,
+                               "mean_quality_rescore_ms": seq_resc.mean_quality_search_ms},
+        "concurrent_1024_threads": {"queries_per_sec": con.queries_per_sec, "completed": con.completed, "failed": con.failed,
+                                    "first_error": con.first_error, "phase0_p50_ms": con.phase0_p50_ms, "phase1_p50_ms": con.phase1_p50_ms,
+                                    "phase1_p99_ms": con.phase1_p99_ms, "coalescing": {"max_batch": max_batch, "max_wait_us": wait_us},
+                                    "mean_queries_per_scan_batch": {"fast": (fr - fr0) / max(fb - fb0, 1), "quality": (qr - qr0) / max(qb - qb0, 1)}},
+    }
+    fast_index.close()
+    m2v.close()
+    bert.close()
+    return res
+
+
+def config5_batches(n_batches: int, seed: int = 5):
+    """SURVEY 8d config 5 queries: token lengths uniform 8..32 incl. [CLS]=101 / [SEP]=102, ids uniform in [1000, 30000); flat ids +
+    cumulative offsets over n_batches x 256 texts (the C ABI's argument shape)."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(8, 33, n_batches * 256)
+    offs = np.zeros(lens.size + 1, dtype=np.uint32)
+    offs[1:] = np.cumsum(lens)
+    ids = rng.integers(1000, 30000, int(offs[-1])).astype(np.int32)
+    ids[offs[:-1]] = 101
+    ids[offs[1:] - 1] = 102
+    return ids, offs
+
+
+def config5_stream_section(fa, index, bert, rows: int, k: int, n_batches: int = 24):
+    """BASELINE config 5 end to end through the native pipeline (fshost_embed_search_stream): batches of 256 token-id queries ->
+    MiniLM-L6 on the GPU -> batched exact top-k, the encode of group g + 1 running under the search of group g; two encoder batches
+    per pass of the slab.  `index` is an fsgpu_index or a row-sharded handle."""
+    from frankensearch_amd.host import embed_search_stream
+    ids, offs = config5_batches(n_batches)
+    embed_search_stream(bert, index, ids[:offs[512]], offs[:513], 256, k, group=2, overlap=True, want_hits=False)   # warm-up
+    out = {}
+    hits = {}
+    for name, group, overlap in (("serial_one_scan_per_batch", 1, False), ("serial_two_batches_per_scan", 2, False),
+                                 ("overlapped_two_batches_per_scan", 2, True)):
+        r, s, c, st = embed_search_stream(bert, index, ids, offs, 256, k, group=group, overlap=overlap)
+        hits[name] = (r, s)
+        out[name] = {"queries_per_sec": st["queries_per_sec"], "encode_ms_per_group": st["mean_encode_ms"],
+                     "search_ms_per_group": st["mean_search_ms"], "groups": int(st["groups"]), "exact_fallbacks": int(st["exact_fallbacks"]),
+                     "all_counts_full": bool(np.all(c == k))}
+    base = hits["serial_one_scan_per_batch"]
+    same = all(np.array_equal(h[0], base[0]) and np.array_equal(h[1].view(np.uint32), base[1].view(np.uint32)) for h in hits.values())
+    out["workload"] = (f"{n_batches} batches of 256 token-id queries ({int(offs[-1])} tokens) -> MiniLM-L6 on the GPU -> batched exact "
+                       f"scan of {rows}x384 f16, top-{k}; native pipeline (libfshost), host-pointer C ABI")
+    out["queries_per_sec"] = out["overlapped_two_batches_per_scan"]["queries_per_sec"]
+    out["hits_identical_across_forms"] = bool(same)
     return out
 
 
 def sharded_handle_main(args) -> None:
     """`bench.py --sharded-handle --gpus N`: ONE process drives N devices through fsgpu_sharded_* (row shards adopted from
-    device memory, host-pointer queries, RCCL all-gather + merge inside the library).  Prints one JSON object."""
+    device memory, host-pointer queries, RCCL all-gather + merge inside the library) — the scan, then the metric's second half over
+    sharded handles: the two-tier flow (phase 0 + phase 1) and config 5 (on-GPU MiniLM encoding + 50M x 384 scan).  Prints one JSON
+    object.  --virtual-shards: N shards on device 0 exchanged by peer copies (the single-GPU rehearsal)."""
     from __graft_entry__ import build
     build()
     import frankensearch_amd as fa
 
     n = args.gpus
-    if torch.cuda.device_count() < n:
+    if not args.virtual_shards and torch.cuda.device_count() < n:
         sys.exit(f"bench.py --sharded-handle --gpus {n}: only {torch.cuda.device_count()} GPU(s) visible")
-    per = (args.rows + n - 1) // n
-    slabs, rows = [], []
-    for r in range(n):
-        lo, hi = min(args.rows, r * per), min(args.rows, (r + 1) * per)
-        slabs.append(gen_corpus(lo, hi, args.dim, torch.device("cuda", r)))
-        rows.append(hi - lo)
-    idx = fa.NativeShardedIndex.from_device_slabs(list(range(n)), args.dim, rows, [t.data_ptr() for t in slabs], keepalive=slabs)
+    devices = _shard_devices(n, args.virtual_shards)
+    exchange = fa.NativeShardedIndex.EXCHANGE_PEER_COPY if args.virtual_shards else fa.NativeShardedIndex.EXCHANGE_AUTO
+    idx = _sharded_from_generator(fa, devices, args.rows, args.dim, exchange)
     B, k = args.batch, args.k
     q = gen_queries(2 * B, args.dim, torch.device("cuda", 0)).cpu().numpy()
     for i in range(max(args.warmup, 2)):
@@ -720,42 +781,68 @@ def sharded_handle_main(args) -> None:
     last = q[((args.steps - 1) % 2) * B:((args.steps - 1) % 2) * B + B]
     ref = idx.search_batch(last, k, batched=args.batched)
     piped_same = bool(np.array_equal(piped[0], ref[0]) and np.array_equal(piped[1].view(np.uint32), ref[1].view(np.uint32)))
-    # the answer must not depend on the sharding: one unsharded index over the first shard-0 rows cannot check that, so
-    # compare a few queries with a 1-shard handle over ALL rows when they fit one device comfortably
+    # the answer must not depend on the sharding: a few queries against ONE index over all rows when they fit a device comfortably
     same = None
     if args.rows * args.dim * 2 <= 64 << 30 and n > 1:
-        whole = fa.VectorIndex.from_device_slab(gen_corpus(0, args.rows, args.dim, torch.device("cuda", 0)).data_ptr(), args.rows,
-                                                args.dim, device=0)
+        whole_slab = gen_corpus(0, args.rows, args.dim, torch.device("cuda", 0))
+        whole = fa.VectorIndex.from_device_slab(whole_slab.data_ptr(), args.rows, args.dim, device=0, keepalive=whole_slab)
         wr, ws, _ = whole.search_batch(q[:8], k)
         sr, ss, _ = idx.search_batch(q[:8], k)[:3]
         same = bool(np.array_equal(wr, sr) and np.array_equal(ws.view(np.uint32), ss.view(np.uint32)))
-    print(json.dumps({"queries_per_sec": args.steps * B / dt, "ms_per_step": dt / args.steps * 1e3,
-                      "pipelined_begin_end": {"queries_per_sec": args.steps * B / dt_piped, "ms_per_step": dt_piped / args.steps * 1e3,
-                                              "in_flight": 2, "hits_equal_blocking_call": piped_same}, "n_gpus": n,
-                      "queries_per_step": B, "rows": args.rows, "steps": args.steps,
-                      "exchange": "rccl ncclAllGather" if idx.exchange_mode() == 1 else "peer copies",
-                      "path": "matrix-core batched" if args.batched else "exact VALU scan",
-                      "equals_unsharded_bits": same, "all_counts_full": bool(np.all(out[2] == min(k, args.rows))),
-                      "note": "host-pointer C ABI: each step includes staging + H2D of the queries and D2H of the hits"}), flush=True)
+        whole.close()
+        del whole_slab
+        torch.cuda.empty_cache()
+    res = {"queries_per_sec": args.steps * B / dt, "ms_per_step": dt / args.steps * 1e3,
+           "pipelined_begin_end": {"queries_per_sec": args.steps * B / dt_piped, "ms_per_step": dt_piped / args.steps * 1e3,
+                                   "in_flight": 2, "hits_equal_blocking_call": piped_same}, "n_gpus": n,
+           "virtual_shards_on_one_device": bool(args.virtual_shards),
+           "queries_per_step": B, "rows": args.rows, "steps": args.steps,
+           "exchange": "rccl ncclAllGather" if idx.exchange_mode() == 1 else "peer copies",
+           "path": "matrix-core batched" if args.batched else "exact VALU scan",
+           "equals_unsharded_bits": same, "all_counts_full": bool(np.all(out[2] == min(k, args.rows))),
+           "note": "host-pointer C ABI: each step includes staging + H2D of the queries and D2H of the hits"}
+    if not args.no_two_tier and args.dim == 384:
+        try:
+            res["two_tier"] = two_tier_sharded_section(fa, devices, idx, args.rows, k, exchange)
+        except Exception as e:   # noqa: BLE001 — a failing section must not cost the scan figures above
+            res["two_tier"] = {"error": f"{type(e).__name__}: {e}"}
+    idx.close()
+    del idx
+    torch.cuda.empty_cache()
+    if not args.no_config5 and args.dim == 384:
+        try:
+            from frankensearch_amd.synthetic import random_bert_weights
+            big = _sharded_from_generator(fa, devices, args.config5_rows, 384, exchange)
+            bert = fa.NativeEmbedder(random_bert_weights(1, 30522, 384, 6, 1536), device=devices[0])
+            res["config5"] = config5_stream_section(fa, big, bert, args.config5_rows, k)
+            res["config5"]["shards"] = n
+            big.close()
+            bert.close()
+        except Exception as e:   # noqa: BLE001
+            res["config5"] = {"error": f"{type(e).__name__}: {e}"}
+    print(json.dumps(res), flush=True)
 
 
-def sharded_handle_leg(args, world: int):
+def sharded_handle_leg(args, world: int, virtual: bool):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--sharded-handle", "--gpus", str(world), "--rows", str(args.rows), "--dim",
-           str(args.dim), "--k", str(args.k), "--batch", str(args.batch), "--steps", str(min(args.steps, 50)), "--warmup", "3"]
-    if args.exact:
-        cmd.append("--exact")
+           str(args.dim), "--k", str(args.k), "--batch", str(args.batch), "--steps", str(min(args.steps, 50)), "--warmup", "3",
+           "--config5-rows", str(args.config5_rows)]
+    for flag, on in (("--exact", args.exact), ("--virtual-shards", virtual), ("--no-two-tier", args.no_two_tier), ("--no-config5", args.no_config5)):
+        if on:
+            cmd.append(flag)
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE",
                         "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "GROUP_WORLD_SIZE", "ROLE_NAME")}
+    limit = 420
     try:
-        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150)
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=limit)
         last = [l for l in res.stdout.splitlines() if l.startswith("{")]
         if res.returncode == 0 and last:
             return json.loads(last[-1])
         return {"error": f"rc={res.returncode}", "stderr_tail": res.stderr[-400:]}
     except subprocess.TimeoutExpired:
-        return {"error": "timed out after 150 s"}
+        return {"error": f"timed out after {limit} s"}
     except (OSError, ValueError) as e:
         return {"error": str(e)}
 
@@ -785,6 +872,10 @@ def main() -> None:
                     help="time the in-library sharded handle (fsgpu_sharded_*: ONE process, --gpus devices, RCCL all-gather "
                          "inside libfsgpu.so) instead of the one-process-per-GPU launcher; prints its own JSON line")
     ap.add_argument("--no-sharded-handle", action="store_true", help="skip the sharded-handle leg of an N > 1 run")
+    ap.add_argument("--virtual-shards", action="store_true",
+                    help="--sharded-handle: --gpus shards on device 0 exchanged by peer copies (single-GPU rehearsal of the N-way handle)")
+    ap.add_argument("--no-config5", action="store_true", help="skip config 5 (encode + 50M x 384 scan) in the sharded-handle leg")
+    ap.add_argument("--config5-rows", type=int, default=50_000_000, help="rows of the config 5 corpus in the sharded-handle leg")
     args = ap.parse_args()
     args.batched = not args.exact
     if args.batch is None:
@@ -1026,10 +1117,13 @@ def main() -> None:
             line["p50_latency_ms_single_query"] = lat[len(lat) // 2]
         # the CPU baseline runs before the thousand-thread load test below: after it the container's CPU quota throttles the
         # oracle's workers for a while (measured: 120-150 GB/s instead of ~290 GB/s on the same 16 threads)
-        if world == 1 and args.batched and not args.exact:
+        if args.batched and not args.exact:
             # the north-star's HBM target in the same run: the exact f16 kernel, one query per pass over the f16 slab
+            # (N > 1: over rank 0's shard — every rank streams its own shard at this rate)
             line["roofline"]["exact_f16_scan"] = exact_scan_roofline(index, queries, k, hi - lo, args.dim, device)
-            if args.rows == 10_000_000 and args.dim == 384 and os.path.exists(pmc_path):
+            if world > 1:
+                line["roofline"]["exact_f16_scan"]["note"] += f"; measured on rank 0's shard ({hi - lo} of {args.rows} rows)"
+            if world == 1 and args.rows == 10_000_000 and args.dim == 384 and os.path.exists(pmc_path):
                 # HBM bytes of that kernel from this round's counter pass of `bench.py --exact --batch 1` (the same kernel, slab and launch shape)
                 for e in json.load(open(pmc_path)):
                     if (e.get("counter") == "FETCH_SIZE" and e.get("run") == "pmc_fetch_b1" and "scan_topk_kernel<384, 1, 64" in e.get("kernel", "")
@@ -1038,7 +1132,8 @@ def main() -> None:
                         line["roofline"]["exact_f16_scan"]["traffic_source"] = (
                             f"profiles/{PROFILE_ROUND}/pmc_summary.json (run pmc_fetch_b1): rocprofv3 --pmc FETCH_SIZE, KiB x 1024 x 2 (gfx950 correction)")
                         break
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
+            # N > 1: rank 0 times the port on ITS shard (the first rows of the same corpus) and scales to the full corpus
             line["cpu_baseline"] = cpu_baseline_and_parity(slab, queries, k, args.rows, fa.VectorIndex)
         if world == 1 and not args.no_adversarial and args.rows >= 1_000_000 and args.batched:
             line["adversarial_corpora"] = {kind: adversarial_section(kind, args.rows, args.dim, k, device, local_rank)
@@ -1072,10 +1167,25 @@ def main() -> None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        if world > 1 and backend == "nccl" and not args.no_sharded_handle:
-            # the same search through ONE C-ABI handle (fsgpu_sharded_*: RCCL inside libfsgpu.so), timed in a child
-            # process with a hard limit once the ranks have left their GPUs — a problem there cannot cost the line above
-            line["sharded_handle"] = sharded_handle_leg(args, world)
+        if world > 1 and not args.no_sharded_handle:
+            # the same search through ONE C-ABI handle (fsgpu_sharded_*: RCCL inside libfsgpu.so) and, over such handles, the
+            # metric's second half — the two-tier flow (phase 0 + phase 1) and config 5 —, in a child process with a hard limit
+            # once the ranks have left their GPUs: a problem there cannot cost the line above.  Under the gloo rehearsal the
+            # child puts its shards on device 0 (peer copies).
+            leg = sharded_handle_leg(args, world, virtual=backend != "nccl")
+            tt, c5 = leg.pop("two_tier", None), leg.pop("config5", None)
+            line["sharded_handle"] = leg
+            if tt is not None:
+                line["two_tier"] = tt
+                if "error" not in tt:
+                    line["p50_phase1_latency_ms"] = tt["phase1_p50_ms"]
+                    line["p50_phase0_latency_ms"] = tt["phase0_p50_ms"]
+                    line["p50_phase1_latency_policy"] = "reference order: quality-tier embedding and search start after the phase-0 delivery"
+                    line["p50_phase1_latency_speculative_ms"] = {"quality_embed_and_search_prefetched": tt["sequential_with_quality_search_prefetch"]["phase1_p50_ms"]}
+                    line["p50_phase1_latency_rescored_fast_pool_ms"] = tt["rescored_fast_pool"]["phase1_p50_ms"]
+                    line["end_to_end_queries_per_sec"] = tt["concurrent_1024_threads"]["queries_per_sec"]
+            if c5 is not None:
+                line["config5"] = c5
         # RCCL prints its version banner through C stdio, which sits in libc's buffer until exit when stdout is a pipe: push
         # it out first so that the JSON line is the last thing on stdout
         sys.stdout.flush()

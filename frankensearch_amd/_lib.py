@@ -81,6 +81,10 @@ SIGNATURES = {
     "fsgpu_sharded_search_begin": (_i32, [_vp, _vp, C.POINTER(_u64)]),
     "fsgpu_sharded_search_end": (_i32, [_vp, _u64, _vp, _vp, _vp, _vp]),
     "fsgpu_sharded_quant_scale_max": (C.c_float, [_vp]),
+    "fsgpu_sharded_set_coalescing": (_i32, [_vp, _u32, _u32]),
+    "fsgpu_sharded_coalescing_stats": (_i32, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "fsgpu_sharded_alignment_create": (_i32, [_vp, _vp, C.POINTER(_vp)]),
+    "fsgpu_sharded_quality_scores_for_hits": (_i32, [_vp, _vp, _vp, _vp, _u32, _vp, _u32, _vp, _vp]),
     "fsgpu_sharded_open_fsvi": (_i32, [C.c_char_p, _vp, _u32, _i32, C.POINTER(_vp)]),
     "fsgpu_sharded_set_live_bitmap": (_i32, [_vp, _vp]),
     "fsgpu_sharded_soft_delete": (_i32, [_vp, C.c_char_p, _u32, C.POINTER(_i32)]),
@@ -98,9 +102,11 @@ SIGNATURES = {
     "fsgpu_widen_f16_to_f32": (_i32, [_i32, _vp, _u64, _vp]),
     "fsgpu_m2v_create": (_i32, [_i32, _vp, _u32, _u32, C.POINTER(_vp)]),
     "fsgpu_m2v_destroy": (None, [_vp]),
+    "fsgpu_m2v_dimension": (_u32, [_vp]),
     "fsgpu_m2v_embed": (_i32, [_vp, _vp, _vp, _u32, _vp]),
     "fsgpu_bert_create": (_i32, [_i32, _vp, _vp, C.POINTER(_vp)]),
     "fsgpu_bert_destroy": (None, [_vp]),
+    "fsgpu_bert_dimension": (_u32, [_vp]),
     "fsgpu_bert_embed": (_i32, [_vp, _vp, _vp, _u32, _vp]),
     "fsgpu_rrf_fuse": (_i32, [_vp, _u32, _vp, _u32, C.c_double, C.c_double, C.c_double, _i32, _u32, _u32, _vp,
                               C.POINTER(_u32)]),

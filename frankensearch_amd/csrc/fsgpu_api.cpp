@@ -59,6 +59,10 @@ struct fsgpu_alignment {
 };
 struct fsgpu_sharded {
     fsgpu::ShardedIndex impl;
+    // single-query fsgpu_sharded_search calls in flight together ride one batched search of the shards (fsgpu_sharded_set_coalescing)
+    fsgpu::Coalescer<SearchCall> coalescer;
+    std::vector<float> co_queries, co_scores;   // leader-only staging (guarded by impl.mutex())
+    std::vector<uint32_t> co_rows, co_counts;
 };
 struct fsgpu_m2v {
     fsgpu::Model2VecEmbedder impl;
@@ -193,6 +197,66 @@ fsgpu_status coalesced_search(fsgpu_index* idx, const float* query, uint32_t k, 
                 }
             },
             [](const SearchCall& a, const SearchCall& b) { return a.k == b.k && a.int8_mult == b.int8_mult && a.allow == b.allow; });
+        if (call.exec_threw) return fail(FSGPU_ERR_DEVICE, "coalesced batch failed before this request was served");
+        if (call.status != FSGPU_OK) g_last_error = call.detail;
+        return call.status;
+    });
+}
+
+// The sharded twin of coalesced_search: one single-query request (exact, or the int8 two-pass with call.int8_mult) parked in the
+// handle's coalescer; the leader runs ONE search of the shards for the whole batch — more than four exact callers take the
+// matrix-core batched mode, whose rows and score bits are the exact kernels' — and hands every caller its own hits.
+fsgpu_status coalesced_sharded_search(fsgpu_sharded* idx, const float* query, uint32_t query_len, uint32_t k, uint32_t int8_mult,
+                                      uint32_t* out_rows, float* out_scores, uint32_t* out_count) {
+    return guarded([&]() -> fsgpu_status {
+        SearchCall call;
+        call.query = query;
+        call.k = k;
+        call.int8_mult = int8_mult;
+        call.out_rows = out_rows;
+        call.out_scores = out_scores;
+        call.out_count = out_count;
+        idx->coalescer.submit(
+            &call,
+            [idx, query_len](std::vector<SearchCall*>& batch) {
+                std::lock_guard<std::mutex> lock(idx->impl.mutex());
+                const uint32_t n = (uint32_t)batch.size(), dim = idx->impl.dimension(), kk = batch[0]->k;
+                fsgpu_status st = FSGPU_ERR_DEVICE;
+                std::string detail;
+                try {
+                    idx->co_queries.resize((size_t)n * dim);
+                    idx->co_rows.resize((size_t)n * kk);
+                    idx->co_scores.resize((size_t)n * kk);
+                    idx->co_counts.resize(n);
+                    for (uint32_t i = 0; i < n; ++i)
+                        std::memcpy(idx->co_queries.data() + (size_t)i * dim, batch[i]->query, (size_t)dim * 4);
+                    fsgpu::ShardedIndex::Request rq;
+                    rq.queries = idx->co_queries.data();
+                    rq.nq = n;
+                    rq.k = kk;
+                    rq.multiplier = batch[0]->int8_mult;
+                    rq.mode = batch[0]->int8_mult ? fsgpu::ShardedIndex::kInt8TwoPass
+                              : n <= 4            ? fsgpu::ShardedIndex::kExact
+                                                  : fsgpu::ShardedIndex::kBatched;
+                    const fsgpu::SearchError e =
+                        idx->impl.search(rq, query_len, idx->co_rows.data(), idx->co_scores.data(), idx->co_counts.data(), nullptr);
+                    st = e.code;
+                    detail = e.detail;
+                } catch (const std::exception& ex) {
+                    detail = ex.what();
+                } catch (...) {
+                    detail = "unknown exception";
+                }
+                for (uint32_t i = 0; i < n; ++i) {
+                    batch[i]->status = st;
+                    batch[i]->detail = detail;
+                    if (st != FSGPU_OK) continue;
+                    std::memcpy(batch[i]->out_rows, idx->co_rows.data() + (size_t)i * kk, (size_t)kk * 4);
+                    std::memcpy(batch[i]->out_scores, idx->co_scores.data() + (size_t)i * kk, (size_t)kk * 4);
+                    *batch[i]->out_count = idx->co_counts[i];
+                }
+            },
+            [](const SearchCall& a, const SearchCall& b) { return a.k == b.k && a.int8_mult == b.int8_mult; });
         if (call.exec_threw) return fail(FSGPU_ERR_DEVICE, "coalesced batch failed before this request was served");
         if (call.status != FSGPU_OK) g_last_error = call.detail;
         return call.status;
@@ -573,10 +637,31 @@ fsgpu_status fsgpu_sharded_search(fsgpu_sharded* idx, const fsgpu_sharded_reques
     const fsgpu_status c = check_sharded_request(idx, request);
     if (c != FSGPU_OK) return c;
     if (request->nq && (!out_counts || (request->k && (!out_rows || !out_scores)))) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    // concurrent single-query callers share one search of the shards (same hits: the batched mode is exact, the two-pass
+    // candidates are per query)
+    if (idx->coalescer.enabled() && request->nq == 1 && request->k >= 1 && request->k <= 64 && !request->allow_bitmap &&
+        request->query_len == idx->impl.dimension() && idx->impl.record_count() > 0 &&
+        (request->mode == FSGPU_SHARDED_EXACT || request->mode == FSGPU_SHARDED_INT8_TWO_PASS)) {
+        if (out_fallbacks) *out_fallbacks = 0;
+        const uint32_t mult = request->mode == FSGPU_SHARDED_INT8_TWO_PASS ? (request->candidate_multiplier ? request->candidate_multiplier : 1) : 0;
+        return coalesced_sharded_search(idx, request->queries, request->query_len, request->k, mult, out_rows, out_scores, out_counts);
+    }
     return guarded([&]() -> fsgpu_status {
         std::lock_guard<std::mutex> lock(idx->impl.mutex());
         return finish(idx->impl.search(sharded_request(request), request->query_len, out_rows, out_scores, out_counts, out_fallbacks));
     });
+}
+
+fsgpu_status fsgpu_sharded_set_coalescing(fsgpu_sharded* idx, uint32_t max_batch, uint32_t max_wait_us) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    idx->coalescer.configure(max_batch, max_wait_us);
+    return FSGPU_OK;
+}
+
+fsgpu_status fsgpu_sharded_coalescing_stats(fsgpu_sharded* idx, uint64_t* batches, uint64_t* requests) {
+    if (!idx || !batches || !requests) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    idx->coalescer.stats(batches, requests);
+    return FSGPU_OK;
 }
 
 fsgpu_status fsgpu_sharded_search_begin(fsgpu_sharded* idx, const fsgpu_sharded_request* request, uint64_t* out_ticket) {
@@ -895,6 +980,45 @@ fsgpu_status fsgpu_quality_scores_for_hits(fsgpu_index* fast, fsgpu_index* quali
     });
 }
 
+// The same pairing over two row-sharded handles: the walk runs over their catalogs (fsgpu_sharded_open_fsvi) — raw shards pair by
+// row —, the re-scoring gathers dot_query_at on the shards that own the quality rows (fsgpu_sharded_gather_dot).
+fsgpu_status fsgpu_sharded_alignment_create(fsgpu_sharded* fast, fsgpu_sharded* quality, fsgpu_alignment** out) {
+    if (!fast || !quality || !out) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    *out = nullptr;
+    return guarded([&]() -> fsgpu_status {
+        auto a = std::make_unique<fsgpu_alignment>();
+        std::unique_lock<std::mutex> lf(fast->impl.mutex());
+        std::unique_lock<std::mutex> lq(quality->impl.mutex(), std::defer_lock);
+        if (quality != fast) lq.lock();
+        const fsgpu_status st = finish(a->impl.build(fast->impl.catalog(), fast->impl.record_count(), quality->impl.catalog(),
+                                                     quality->impl.record_count()));
+        if (st == FSGPU_OK) *out = a.release();
+        return st;
+    });
+}
+
+fsgpu_status fsgpu_sharded_quality_scores_for_hits(fsgpu_sharded* fast, fsgpu_sharded* quality, const fsgpu_alignment* alignment,
+                                                   const float* query, uint32_t query_len, const fsgpu_scored_doc* hits, uint32_t n,
+                                                   float* out_scores, uint8_t* out_present) {
+    if (!fast || !quality || !alignment) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    if (n && (!query || !hits || !out_scores || !out_present)) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::vector<fsgpu::HitRef> refs(n);
+        for (uint32_t i = 0; i < n; ++i) refs[i] = fsgpu::HitRef{hits[i].doc_id, hits[i].doc_id_len, hits[i].index};
+        // (the fast side is only read through its immutable record table; the quality handle is held for the gather)
+        std::lock_guard<std::mutex> lq(quality->impl.mutex());
+        fsgpu::QualityTierView view;
+        view.table = quality->impl.catalog();
+        view.rows = quality->impl.record_count();
+        view.dim = quality->impl.dimension();
+        view.gather = [quality](const float* q, uint32_t len, const uint32_t* rows, uint32_t cnt, float* out) {
+            return quality->impl.gather_dot(q, len, rows, cnt, out);
+        };
+        return finish(fsgpu::quality_scores_for_hits(fast->impl.catalog(), fast->impl.record_count(), view, alignment->impl, query,
+                                                     query_len, refs.data(), n, out_scores, out_present));
+    });
+}
+
 static fsgpu_status convert_on_device(int32_t device, const void* src, size_t src_elem, uint64_t n, void* dst,
                                       size_t dst_elem, bool encode) {
     if (n == 0) return FSGPU_OK;
@@ -997,6 +1121,7 @@ fsgpu_status fsgpu_m2v_create(int32_t device, const float* table, uint32_t vocab
 }
 
 void fsgpu_m2v_destroy(fsgpu_m2v* m) { delete m; }
+uint32_t fsgpu_m2v_dimension(const fsgpu_m2v* m) { return m ? m->impl.dimension() : 0; }
 
 fsgpu_status fsgpu_m2v_embed(fsgpu_m2v* m, const uint32_t* ids, const uint32_t* offsets, uint32_t n, float* out) {
     if (!m) return fail(FSGPU_ERR_NULL_ARGUMENT, "embedder is null");
@@ -1040,6 +1165,7 @@ fsgpu_status fsgpu_bert_create(int32_t device, const fsgpu_bert_config* config, 
 }
 
 void fsgpu_bert_destroy(fsgpu_bert* m) { delete m; }
+uint32_t fsgpu_bert_dimension(const fsgpu_bert* m) { return m ? m->impl.dimension() : 0; }
 
 fsgpu_status fsgpu_bert_embed(fsgpu_bert* m, const int32_t* ids, const uint32_t* offsets, uint32_t n, float* out) {
     if (!m) return fail(FSGPU_ERR_NULL_ARGUMENT, "embedder is null");

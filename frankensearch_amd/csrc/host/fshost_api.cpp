@@ -7,18 +7,21 @@
 
 namespace fshost {
 fsgpu_status run_load(const SyncTwoTierSearcher& searcher, const fshost_load_config& cfg, fshost_load_result* res);
+fsgpu_status embed_search_stream(fsgpu_bert* encoder, fsgpu_index* index, fsgpu_sharded* sharded, const int32_t* ids,
+                                 const uint32_t* offsets, uint32_t batch, uint32_t n_batches, uint32_t group, uint32_t k, bool overlap,
+                                 uint32_t* out_rows, float* out_scores, uint32_t* out_counts, fshost_stream_result* result);
 }
 
 struct fshost_two_tier {
     fshost::SyncTwoTierSearcher impl;
     fshost_two_tier(fsgpu_index* f, fsgpu_index* q, fsgpu_m2v* m, fsgpu_bert* b, const fshost_two_tier_config& c) : impl(f, q, m, b, c) {}
+    fshost_two_tier(fsgpu_sharded* f, fsgpu_sharded* q, fsgpu_m2v* m, fsgpu_bert* b, const fshost_two_tier_config& c) : impl(f, q, m, b, c) {}
 };
 
-extern "C" {
-
-fsgpu_status fshost_two_tier_create(fsgpu_index* fast_index, fsgpu_index* quality_index, fsgpu_m2v* fast_embedder,
-                                    fsgpu_bert* quality_embedder, const fshost_two_tier_config* config,
-                                    fshost_two_tier** out) {
+namespace {
+template <class IndexHandle>
+fsgpu_status create_searcher(IndexHandle* fast_index, IndexHandle* quality_index, fsgpu_m2v* fast_embedder, fsgpu_bert* quality_embedder,
+                             const fshost_two_tier_config* config, fshost_two_tier** out) {
     if (!fast_index || !quality_index || !fast_embedder || !quality_embedder || !config || !out) return FSGPU_ERR_NULL_ARGUMENT;
     try {
         auto* s = new fshost_two_tier(fast_index, quality_index, fast_embedder, quality_embedder, *config);
@@ -32,6 +35,21 @@ fsgpu_status fshost_two_tier_create(fsgpu_index* fast_index, fsgpu_index* qualit
         return FSGPU_ERR_DEVICE;
     }
     return FSGPU_OK;
+}
+}  // namespace
+
+extern "C" {
+
+fsgpu_status fshost_two_tier_create(fsgpu_index* fast_index, fsgpu_index* quality_index, fsgpu_m2v* fast_embedder,
+                                    fsgpu_bert* quality_embedder, const fshost_two_tier_config* config,
+                                    fshost_two_tier** out) {
+    return create_searcher(fast_index, quality_index, fast_embedder, quality_embedder, config, out);
+}
+
+fsgpu_status fshost_two_tier_create_sharded(fsgpu_sharded* fast_index, fsgpu_sharded* quality_index, fsgpu_m2v* fast_embedder,
+                                            fsgpu_bert* quality_embedder, const fshost_two_tier_config* config,
+                                            fshost_two_tier** out) {
+    return create_searcher(fast_index, quality_index, fast_embedder, quality_embedder, config, out);
 }
 
 void fshost_two_tier_destroy(fshost_two_tier* s) { delete s; }
@@ -52,7 +70,10 @@ fsgpu_status fshost_two_tier_search(fshost_two_tier* s, const uint32_t* fast_tok
         if (!out.initial.empty()) std::memcpy(initial_out, out.initial.data(), out.initial.size() * sizeof(fshost_hit));
         if (!out.final_results.empty())
             std::memcpy(final_out, out.final_results.data(), out.final_results.size() * sizeof(fshost_hit));
-        if (metrics) *metrics = out.metrics;
+        if (metrics) {
+            *metrics = out.metrics;
+            metrics->refinement_failed = out.refinement_failed ? 1 : 0;
+        }
         return FSGPU_OK;
     } catch (const std::exception&) {
         return FSGPU_ERR_DEVICE;
@@ -63,6 +84,20 @@ fsgpu_status fshost_run_load(fshost_two_tier* s, const fshost_load_config* confi
     if (!s || !config || !result) return FSGPU_ERR_NULL_ARGUMENT;
     try {
         return fshost::run_load(s->impl, *config, result);
+    } catch (const std::exception&) {
+        return FSGPU_ERR_DEVICE;
+    }
+}
+
+fsgpu_status fshost_embed_search_stream(fsgpu_bert* encoder, fsgpu_index* index, fsgpu_sharded* sharded, const int32_t* ids,
+                                        const uint32_t* offsets, uint32_t batch, uint32_t n_batches, uint32_t group, uint32_t k,
+                                        int32_t overlap, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
+                                        fshost_stream_result* result) {
+    if (!encoder || !ids || !offsets || !result || (index == nullptr) == (sharded == nullptr)) return FSGPU_ERR_NULL_ARGUMENT;
+    if (batch == 0 || group == 0 || k == 0) return FSGPU_ERR_INVALID_CONFIG;
+    try {
+        return fshost::embed_search_stream(encoder, index, sharded, ids, offsets, batch, n_batches, group, k, overlap != 0, out_rows,
+                                           out_scores, out_counts, result);
     } catch (const std::exception&) {
         return FSGPU_ERR_DEVICE;
     }

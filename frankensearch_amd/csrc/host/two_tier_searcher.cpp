@@ -47,45 +47,77 @@ fsgpu_status copy_out(const std::vector<fsgpu_fused_hit>& fused, uint32_t n, std
 
 }  // namespace
 
+fsgpu_status Tier::search_rows(const float* query, uint32_t len, uint32_t fetch, uint32_t int8_multiplier, uint32_t* rows, float* scores,
+                               uint32_t* count) const {
+    if (index)
+        return int8_multiplier ? fsgpu_search_topk_int8_two_pass(index, query, len, fetch, int8_multiplier, rows, scores, count)
+                               : fsgpu_search_topk(index, query, 1, len, fetch, nullptr, rows, scores, count);
+    fsgpu_sharded_request rq{query, 1, len, fetch, int8_multiplier ? FSGPU_SHARDED_INT8_TWO_PASS : FSGPU_SHARDED_EXACT, int8_multiplier, nullptr};
+    return fsgpu_sharded_search(sharded, &rq, rows, scores, count, nullptr);
+}
+
+fsgpu_status Tier::search_hits(const float* query, uint32_t len, uint32_t fetch, uint32_t* rows, float* scores, uint32_t* count) const {
+    return index ? fsgpu_search_hits(index, query, len, fetch, rows, scores, count)
+                 : fsgpu_sharded_search_hits(sharded, query, len, fetch, rows, scores, count);
+}
+
+fsgpu_status Tier::doc_id(uint32_t row, const char** ptr, uint32_t* len) const {
+    return index ? fsgpu_index_doc_id(index, row, ptr, len) : fsgpu_sharded_doc_id(sharded, row, ptr, len);
+}
+
 SyncTwoTierSearcher::SyncTwoTierSearcher(fsgpu_index* fast, fsgpu_index* quality, fsgpu_m2v* fast_embedder,
                                          fsgpu_bert* quality_embedder, const fshost_two_tier_config& cfg)
-    : fast_(fast), quality_(quality), m2v_(fast_embedder), bert_(quality_embedder), cfg_(cfg) {
-    fast_dim_ = fsgpu_index_dimension(fast_);
-    quality_dim_ = fsgpu_index_dimension(quality_);
+    : m2v_(fast_embedder), bert_(quality_embedder), cfg_(cfg) {
+    fast_.index = fast;
+    quality_.index = quality;
+    init();
+}
+
+SyncTwoTierSearcher::SyncTwoTierSearcher(fsgpu_sharded* fast, fsgpu_sharded* quality, fsgpu_m2v* fast_embedder,
+                                         fsgpu_bert* quality_embedder, const fshost_two_tier_config& cfg)
+    : m2v_(fast_embedder), bert_(quality_embedder), cfg_(cfg) {
+    fast_.sharded = fast;
+    quality_.sharded = quality;
+    init();
+}
+
+void SyncTwoTierSearcher::init() {
+    fast_dim_ = fast_.dimension();
+    quality_dim_ = quality_.dimension();
     // opt-in: the quality tier's exact search is phase 1's longest leg (one HBM pass over the f16 slab); with the int8 latency
     // path a lone caller's query goes through the int8 filter + exact re-score instead — the same hits from half the bytes.
     // It is a setting of the CALLER's handle (and costs it an int8 copy of the slab): switched off again in the destructor.
-    if (cfg_.quality_int8_latency && cfg_.quality_pool == FSHOST_POOL_RETRIEVED) {
-        init_status_ = fsgpu_index_set_int8_latency(quality_, 1);
+    // (A sharded quality tier scans 1/W of the rows per GPU: its exact pass is already the short leg, the switch does not exist.)
+    if (cfg_.quality_int8_latency && cfg_.quality_pool == FSHOST_POOL_RETRIEVED && quality_.index) {
+        init_status_ = fsgpu_index_set_int8_latency(quality_.index, 1);
         if (init_status_ != FSGPU_OK) init_detail_ = fsgpu_last_error();
     }
     if (init_status_ == FSGPU_OK && cfg_.quality_pool == FSHOST_POOL_RESCORED) {
-        init_status_ = fsgpu_alignment_create(fast_, quality_, &alignment_);   // two_tier.rs:750-866, once per pair
+        // two_tier.rs:750-866, once per pair
+        init_status_ = fast_.index ? fsgpu_alignment_create(fast_.index, quality_.index, &alignment_)
+                                   : fsgpu_sharded_alignment_create(fast_.sharded, quality_.sharded, &alignment_);
         if (init_status_ != FSGPU_OK) init_detail_ = fsgpu_last_error();
     }
 }
 
 SyncTwoTierSearcher::~SyncTwoTierSearcher() {
     if (alignment_) fsgpu_alignment_destroy(alignment_);
-    if (cfg_.quality_int8_latency && cfg_.quality_pool == FSHOST_POOL_RETRIEVED) (void)fsgpu_index_set_int8_latency(quality_, 0);
+    if (cfg_.quality_int8_latency && cfg_.quality_pool == FSHOST_POOL_RETRIEVED && quality_.index)
+        (void)fsgpu_index_set_int8_latency(quality_.index, 0);
 }
 
 // VectorIndex::search_top_k -> Vec<VectorHit> with doc ids resolved (search.rs:192-206, 1503-1558).
-fsgpu_status SyncTwoTierSearcher::tier_hits(fsgpu_index* index, const std::vector<float>& vec, uint32_t fetch,
+fsgpu_status SyncTwoTierSearcher::tier_hits(const Tier& tier, const std::vector<float>& vec, uint32_t fetch,
                                             uint32_t int8_multiplier, std::vector<Hit>* hits, std::string* detail) const {
     std::vector<uint32_t> rows(fetch);
     std::vector<float> scores(fetch);
     uint32_t count = 0;
-    // an index with a doc-id table (doc_id_mode 0) goes through fsgpu_search_hits = search_top_k + scan_wal + resolve_hits
+    // an index with a doc-id table (doc_id_mode 0) goes through search_hits = search_top_k + scan_wal + resolve_hits
     // (resident WAL entries, shadowing, post-top-k doc-id dedup, search.rs:1493-1558), as the int8 branch does inside the
     // library; a raw slab (synthetic doc ids) has neither a WAL nor duplicate ids, so the row-level search is the same thing
-    fsgpu_status st =
-        int8_multiplier
-            ? fsgpu_search_topk_int8_two_pass(index, vec.data(), (uint32_t)vec.size(), fetch, int8_multiplier, rows.data(),
-                                              scores.data(), &count)
-        : cfg_.doc_id_mode == 0
-            ? fsgpu_search_hits(index, vec.data(), (uint32_t)vec.size(), fetch, rows.data(), scores.data(), &count)
-            : fsgpu_search_topk(index, vec.data(), 1, (uint32_t)vec.size(), fetch, nullptr, rows.data(), scores.data(), &count);
+    fsgpu_status st = int8_multiplier || cfg_.doc_id_mode != 0
+                          ? tier.search_rows(vec.data(), (uint32_t)vec.size(), fetch, int8_multiplier, rows.data(), scores.data(), &count)
+                          : tier.search_hits(vec.data(), (uint32_t)vec.size(), fetch, rows.data(), scores.data(), &count);
     if (st != FSGPU_OK) {
         *detail = fsgpu_last_error();
         return st;
@@ -103,7 +135,7 @@ fsgpu_status SyncTwoTierSearcher::tier_hits(fsgpu_index* index, const std::vecto
         } else {
             const char* p = nullptr;
             uint32_t len = 0;
-            st = fsgpu_index_doc_id(index, rows[i], &p, &len);
+            st = tier.doc_id(rows[i], &p, &len);
             if (st != FSGPU_OK) {
                 *detail = fsgpu_last_error();
                 return st;
@@ -128,9 +160,13 @@ fsgpu_status SyncTwoTierSearcher::search(const uint32_t* fast_ids, uint32_t n_fa
     const uint64_t wide_fetch = (uint64_t)k * mult;
     const uint32_t fetch = std::max<uint32_t>(wide_fetch > 0xffffffffull ? 0xffffffffu : (uint32_t)wide_fetch, k);
     fshost_metrics& m = out->metrics;
+    out->refinement_failed = false;
+    out->skip_reason.clear();
     const auto t0 = clock::now();
     // quality embedding: needed by phase 1 only, optionally computed while phase 0 runs
-    std::vector<float> quality_vec(quality_dim_);
+    // (a vector has its EMBEDDER's dimension; an index of another dimension answers DimensionMismatch — search.rs:1602-1610 — which
+    // fails phase 0 on the fast tier and is a RefinementFailed outcome on the quality tier)
+    std::vector<float> quality_vec(fsgpu_bert_dimension(bert_));
     const uint32_t q_off[2] = {0, n_quality};
     std::string quality_err;
     auto embed_quality = [&]() -> fsgpu_status {
@@ -142,21 +178,21 @@ fsgpu_status SyncTwoTierSearcher::search(const uint32_t* fast_ids, uint32_t n_fa
     // produces): both tiers' scans then share the GPU, phase 0 is delivered a little later and phase 1 much earlier
     std::vector<Hit> quality_hits;  // the `Retrieved` pool (sync_searcher.rs:810-813)
     std::string quality_search_err;
-    bool quality_searched = false;
+    bool quality_searched = false, quality_search_failed = false;
     auto embed_and_search_quality = [&]() -> fsgpu_status {
         fsgpu_status s = embed_quality();
-        if (s != FSGPU_OK) return s;
+        if (s != FSGPU_OK) return s;   // the embedding's failure is the search's (embed_sync's error propagates)
         s = tier_hits(quality_, quality_vec, fetch, 0, &quality_hits, &quality_search_err);
-        if (s != FSGPU_OK) quality_err = quality_search_err;
         quality_searched = s == FSGPU_OK;
-        return s;
+        quality_search_failed = s != FSGPU_OK;   // the pool's failure is a RefinementFailed outcome, decided in phase 1
+        return FSGPU_OK;
     };
     std::future<fsgpu_status> quality_future;  // declared after what the task touches: joined first on every return path
     const bool rescored = cfg_.quality_pool == FSHOST_POOL_RESCORED;   // (its quality scores need phase 0's hits: only the embedding can run ahead)
     if (cfg_.prefetch_quality_embed >= 2 && !rescored) quality_future = std::async(std::launch::async, embed_and_search_quality);
     else if (cfg_.prefetch_quality_embed) quality_future = std::async(std::launch::async, embed_quality);
     // ---- phase 0 / Initial ----
-    std::vector<float> fast_vec(fast_dim_);
+    std::vector<float> fast_vec(fsgpu_m2v_dimension(m2v_));
     const uint32_t fast_off[2] = {0, n_fast};
     fsgpu_status st = fsgpu_m2v_embed(m2v_, fast_ids, fast_off, 1, fast_vec.data());
     if (st != FSGPU_OK) {
@@ -183,6 +219,15 @@ fsgpu_status SyncTwoTierSearcher::search(const uint32_t* fast_ids, uint32_t n_fa
     m.phase1_total_ms = ms_since(t0);
     // ---- phase 1 / Refined ----
     const auto t3 = clock::now();
+    // The quality pool failing — scoring, gathering, the quality tier's search — does not fail the search: the reference records
+    // SearchPhase::RefinementFailed / skip_reason and returns the phase-0 results as final_results (sync_searcher.rs:820-839)
+    auto refinement_failed = [&](Outcome* o, clock::time_point started) -> fsgpu_status {
+        o->refinement_failed = true;
+        o->skip_reason = quality_search_failed ? quality_search_err : std::string(fsgpu_last_error());
+        o->final_results = o->initial;
+        o->metrics.phase2_total_ms = ms_since(started);
+        return FSGPU_OK;
+    };
     st = quality_future.valid() ? quality_future.get() : embed_quality();
     if (st != FSGPU_OK) {
         *detail = quality_err;
@@ -197,12 +242,12 @@ fsgpu_status SyncTwoTierSearcher::search(const uint32_t* fast_ids, uint32_t n_fa
         // aligned blend (:862-866)
         std::vector<float> qscores(fast_view.size() + 1);
         std::vector<uint8_t> qpresent(fast_view.size() + 1);
-        st = fsgpu_quality_scores_for_hits(fast_, quality_, alignment_, quality_vec.data(), quality_dim_, fast_view.data(),
-                                           (uint32_t)fast_view.size(), qscores.data(), qpresent.data());
-        if (st != FSGPU_OK) {
-            *detail = fsgpu_last_error();
-            return st;
-        }
+        st = fast_.index ? fsgpu_quality_scores_for_hits(fast_.index, quality_.index, alignment_, quality_vec.data(),
+                                                         (uint32_t)quality_vec.size(), fast_view.data(), (uint32_t)fast_view.size(), qscores.data(), qpresent.data())
+                         : fsgpu_sharded_quality_scores_for_hits(fast_.sharded, quality_.sharded, alignment_, quality_vec.data(),
+                                                                 (uint32_t)quality_vec.size(), fast_view.data(), (uint32_t)fast_view.size(),
+                                                                 qscores.data(), qpresent.data());
+        if (st != FSGPU_OK) return refinement_failed(out, t3);
         m.quality_search_ms = ms_since(t4);
         const auto t5r = clock::now();
         st = fsgpu_blend_two_tier_aligned(fast_view.data(), (uint32_t)fast_view.size(), qscores.data(), qpresent.data(),
@@ -223,9 +268,10 @@ fsgpu_status SyncTwoTierSearcher::search(const uint32_t* fast_ids, uint32_t n_fa
         m.phase2_total_ms = ms_since(t3);
         return FSGPU_OK;
     }
+    if (quality_search_failed) return refinement_failed(out, t3);
     if (!quality_searched) {
         st = tier_hits(quality_, quality_vec, fetch, 0, &quality_hits, detail);
-        if (st != FSGPU_OK) return st;
+        if (st != FSGPU_OK) return refinement_failed(out, t3);
     }
     m.quality_search_ms = ms_since(t4);
     const auto t5 = clock::now();

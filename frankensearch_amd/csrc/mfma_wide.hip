@@ -102,6 +102,24 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// the arrive / wait counters of kOptFlags (LDS byte addresses; hipcc's s_waitcnt bookkeeping does not see these, so each waits itself)
+__device__ __forceinline__ void flag_post(uint32_t lds_addr, int lane) {
+    asm volatile("" ::: "memory");   // the wave's earlier LDS reads stay in front of the post (the LDS serves a wave's operations in order)
+    if (lane == 0) {
+        const uint32_t one = 1;
+        asm volatile("ds_add_u32 %0, %1" ::"v"(lds_addr), "v"(one) : "memory");
+    }
+}
+__device__ __forceinline__ void flag_wait(uint32_t lds_addr, uint32_t target) {
+    for (;;) {
+        uint32_t v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_addr) : "memory");
+        if ((uint32_t)__builtin_amdgcn_readfirstlane(v) >= target) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
+
 }  // namespace
 
 // ROWB = bytes per slab row (dim * 2 for f16 rows, dim for int8 rows), EB as in scan_mfma_kernel, QT = query tiles of 16
@@ -132,7 +150,15 @@ __device__ __forceinline__ void wait_vmcnt() {
 //   kOptBig    (with kOptSplit, main pass only) row tiles of 128 rows in a ring of THREE slots (the same 144 KB): half as many
 //              barriers, tile cursors and DMA bookkeeping per row; tile n is consumed while n+1 is landing and n-1's slot takes
 //              n+2 — one tile of lookahead is 4-5 us of matrix work, well past the HBM latency.
-constexpr int kOptNegTau = 2, kOptSaddr = 4, kOptSplit = 8, kOptBig = 16;
+//   kOptFlags  (with kOptBig) no block-wide s_barrier in the tile loop: two LDS counters per ring slot — `landed` (waves whose share
+//              of the tile's DMA is in LDS) and `freed` (waves past their last read of the tile) — are posted EARLY and waited for
+//              LATE.  A wave posts landed(n+1) at the start of tile n (its share went out a whole tile earlier) and needs
+//              everyone's only before it reads tile n+1's first fragments at the END of tile n; it posts freed(n) one sub-tile pair
+//              before the end of tile n and the refill of that slot waits for everyone's a few MFMAs into tile n+1.  The eight
+//              waves therefore drift up to about a tile apart instead of meeting at every tile: a wave held up in the append path
+//              (a scalar bitmap load, an LDS atomic, a store — ~5 events per tile at 10M rows, ~40 on a 1.25M-row shard) no longer
+//              stops the other seven, and the two waves of a SIMD no longer stop together.
+constexpr int kOptNegTau = 2, kOptSaddr = 4, kOptSplit = 8, kOptBig = 16, kOptFlags = 32;
 
 // k-steps per chunk of the chunk loop (fewer where the resident queries leave fewer registers for the fragment double buffer)
 constexpr int wide_chunk_ksteps(int KS, int QT) {
@@ -166,6 +192,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     constexpr int WPB = 8, NT = WPB * 64;
     constexpr int KS = ROWB / 64;                                   // MFMA k-steps (64 bytes of a row each)
     constexpr bool BIG = wide_big_ok(ROWB, EB, QT, NSLOT, OPT, DBG);
+    constexpr bool FLAGS = BIG && (OPT & kOptFlags) != 0;
     constexpr int TR = BIG ? 128 : ROWB >= 512 ? 32 : 64;           // rows per tile
     constexpr int RS = TR / 16;                                     // 16-row sub-tiles per tile
     constexpr int NI = RS * KS;                                     // DMA instructions per tile (1 KB each)
@@ -190,11 +217,14 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const uint32_t ring = (uint32_t)(uintptr_t)smem;                // LDS byte address of the ring (low half of the flat address)
     int* lcnt = reinterpret_cast<int*>(smem + (size_t)NSLOT * TILE_BYTES);   // entries appended per query by this block
+    // kOptFlags: landed[slot] at flags + 4 slot, freed[slot] at flags + 16 + 4 slot (counts of waves, monotonic: 8 per use of the slot)
+    const uint32_t flags = ring + (uint32_t)(NSLOT * TILE_BYTES + NQ * 4);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fk = lane >> 4;
     const int slots = (int)args.slots;
     for (int i = tid; i < NQ; i += NT) lcnt[i] = 0;
+    if (FLAGS && tid < 8) lcnt[NQ + tid] = 0;
 
     // this wave's queries: B fragments for the whole dimension, resident in registers
     const int q0 = wave * QT * 16;
@@ -499,8 +529,13 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
                 for (int nt = nt_lo; nt < nt_hi; ++nt) acc[h][nt] = i32x4{-ctau[nt], -ctau[nt], -ctau[nt], -ctau[nt]};
         };
         wait_vmcnt<PW*(NSLOT - 2)>();          // this wave's share of tile 0 has landed ...
-        __builtin_amdgcn_s_barrier();          // ... and everyone's
-        asm volatile("" ::: "memory");
+        if constexpr (FLAGS) {
+            flag_post(flags, lane);
+            flag_wait(flags, WPB);             // ... and everyone's
+        } else {
+            __builtin_amdgcn_s_barrier();      // ... and everyone's
+            asm volatile("" ::: "memory");
+        }
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) read_frag(slot_base(0), 0, kk);
         init_acc(0, QT);                        // (so that the first, void, test of the second half reads defined values)
@@ -526,8 +561,12 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
                         // flight), then everyone's; every wave is also past its last read of tile n-1 (this tile's first pair was
                         // read behind them and has been waited for), whose slot takes tile n+NSLOT-1.
                         wait_vmcnt<PW*(NSLOT - 3)>();
-                        __builtin_amdgcn_s_barrier();
-                        asm volatile("" ::: "memory");
+                        if constexpr (FLAGS) {
+                            flag_post(flags + slot_next * 4, lane);   // this wave's share of tile n+1 is in LDS (posted a tile early)
+                        } else {
+                            __builtin_amdgcn_s_barrier();
+                            asm volatile("" ::: "memory");
+                        }
                     }
                     // the refill of tile n-1's slot: one group of DMA instructions per pair, behind a few MFMAs of its phase 1
                     // (all of them behind the first pair's first MFMAs was measured: 1.43 instead of 1.36 ms — the DMA's LDS writes
@@ -535,6 +574,11 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
                     {
                         constexpr int IPP = (PARTS + NP - 1) / NP;   // issue points per pair
                         constexpr int K1 = KS >= 3 ? 2 : KS - 1, K2 = KS >= 5 ? 4 : K1;
+                        if constexpr (FLAGS) {
+                            // tile n-1's slot takes tile n+2 once EVERY wave is past its last read of tile n-1 (posted a pair before
+                            // the end of that tile: in the common case long ago)
+                            if (p == 0 && kk == K1 && cc.n >= 1) flag_wait(flags + 16 + slot_prev * 4, WPB * ((cc.n - 1) / NSLOT + 1));
+                        }
                         if (kk == K1 && p * IPP < PARTS) fetch_part(slot_prev, p * IPP);
                         if (IPP > 1 && K2 != K1 && kk == K2 && p * IPP + 1 < PARTS) fetch_part(slot_prev, p * IPP + 1);
                     }
@@ -548,10 +592,16 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) {
                     mfma_step(kk, QA, QT);
+                    if constexpr (FLAGS) {   // the next tile's first fragments: everyone's share of it must be in LDS
+                        if (p + 1 == NP && kk == 0) flag_wait(flags + slot_next * 4, WPB * ((cc.n + 1) / NSLOT + 1));
+                    }
                     if (p + 1 < NP) read_frag(cur, p + 1, kk);
                     else read_frag(nxt, 0, kk);
                     if (kk == TK) anyA = any_passes(acc, 0, QA);
                     __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (FLAGS) {   // this wave's last read of the tile is out (the last pair's fragments): its slot may be refilled
+                    if (p + 2 == NP) flag_post(flags + 16 + slot * 4, lane);
                 }
                 if (anyA) emit_tiles(t, p * 2, acc, 0, QA);
                 tB = t;
@@ -664,7 +714,7 @@ hipError_t launch_wide_t(const MfmaScanArgs& args, int grid, hipStream_t stream,
     constexpr bool BIG = wide_big_ok(ROWB, EB, QT, NSLOT, OPT, DBG);
     constexpr int TR = BIG ? 128 : ROWB >= 512 ? 32 : 64;
     constexpr size_t ring = (size_t)NSLOT * TR * ROWB;
-    const size_t lds = ring + (size_t)QT * 128 * 4;   // the row-tile ring + one append counter per query
+    const size_t lds = ring + (size_t)QT * 128 * 4 + 64;   // the row-tile ring + one append counter per query + the ring's arrive / wait counters
     auto kern = scan_wide_kernel<ROWB, EB, QT, NSLOT, OPT, DBG>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -690,7 +740,7 @@ hipError_t launch_wide_t(const MfmaScanArgs& args, int grid, hipStream_t stream,
 template <int ROWB, int EB, int QT, int NSLOT, int O, int MODE>
 hipError_t launch_wide_pick(const MfmaScanArgs& args, int grid, hipStream_t stream, int* occupancy) {
     if constexpr (MODE == 0 && wide_big_ok(ROWB, EB, QT, 3, O, 0)) return launch_wide_t<ROWB, EB, QT, 3, O, 0>(args, grid, stream, occupancy);
-    else return launch_wide_t<ROWB, EB, QT, NSLOT, O & ~kOptBig, MODE>(args, grid, stream, occupancy);
+    else return launch_wide_t<ROWB, EB, QT, NSLOT, O & ~(kOptBig | kOptFlags), MODE>(args, grid, stream, occupancy);
 }
 
 template <int EB, int QT, int MODE = 0>
@@ -708,9 +758,9 @@ hipError_t launch_wide_d(const MfmaScanArgs& args, int grid, hipStream_t stream,
                 if (dbg == 2) return launch_wide_t<768, EB, QT, 6, O, 2>(args, grid, stream, occupancy);
             }
 #endif
-            return launch_wide_t<768, EB, QT, 6, O & ~kOptBig, MODE>(args, grid, stream, occupancy);   // 6 x 24 KB
+            return launch_wide_t<768, EB, QT, 6, O & ~(kOptBig | kOptFlags), MODE>(args, grid, stream, occupancy);   // 6 x 24 KB
         } else return hipErrorInvalidValue;
-        case 256: if constexpr (QT <= 4) return launch_wide_t<512, EB, QT, 8, O, MODE>(args, grid, stream, occupancy);   // 8 x 16 KB
+        case 256: if constexpr (QT <= 4) return launch_wide_t<512, EB, QT, 8, O & ~kOptFlags, MODE>(args, grid, stream, occupancy);   // 8 x 16 KB
                   else return hipErrorInvalidValue;
         case 192:
 #ifdef FSGPU_EXPERIMENTS

@@ -597,6 +597,9 @@ SearchError ShardedIndex::set_live_bitmap(const uint64_t* live) {
 
 SearchError ShardedIndex::soft_delete(const char* doc_id, uint32_t len, int32_t* deleted) {
     if (!catalog_) return make_err(FSGPU_ERR_INVALID_CONFIG, "index has no doc-id table");
+    // (the shards' scan streams do not wait for the blocking copy that rewrites a live bitmap: a begun search must be ended first)
+    for (const RootSlot& r : root_)
+        if (r.pending) return make_err(FSGPU_ERR_INVALID_CONFIG, "a search is in flight on this handle: end it first");
     SH_TRY(catalog_->soft_delete(doc_id, len, deleted));
     if (*deleted && !catalog_->live_host().empty()) return push_live_slices(catalog_->live_host());
     return SearchError{};
@@ -604,6 +607,8 @@ SearchError ShardedIndex::soft_delete(const char* doc_id, uint32_t len, int32_t*
 
 SearchError ShardedIndex::wal_append(const char* doc_id, uint32_t len, const float* vector, uint32_t vector_len) {
     if (!catalog_) return make_err(FSGPU_ERR_INVALID_CONFIG, "index has no doc-id table");
+    for (const RootSlot& r : root_)
+        if (r.pending) return make_err(FSGPU_ERR_INVALID_CONFIG, "a search is in flight on this handle: end it first");
     SH_TRY(catalog_->wal_append(doc_id, len, vector, vector_len));   // tombstones the main row it supersedes (lib.rs:2665-2710)
     if (!catalog_->live_host().empty()) return push_live_slices(catalog_->live_host());
     return SearchError{};

@@ -74,6 +74,8 @@ class ShardedIndex {
 
     uint64_t record_count() const { return nrows_; }
     uint32_t dimension() const { return dim_; }
+    // the tables of an FSVI-opened handle (record table, doc ids, tombstones, WAL); null for raw shards
+    const VectorIndex* catalog() const { return catalog_.get(); }
     uint32_t shard_count() const { return (uint32_t)shards_.size(); }
     int32_t exchange_mode() const { return use_rccl_ ? 1 : 2; }
     bool shard_range(uint32_t shard, uint64_t* lo, uint64_t* hi) const;

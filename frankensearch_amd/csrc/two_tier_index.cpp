@@ -4,6 +4,7 @@
 #include <cstring>
 #include <mutex>
 #include <string_view>
+#include <unordered_map>
 
 #include "../../include/fsgpu.h"
 
@@ -25,11 +26,14 @@ std::string_view doc_of(const VectorIndex& idx, uint64_t row) {
 }  // namespace
 
 SearchError QualityAlignment::build(const VectorIndex& fast, const VectorIndex& quality) {
-    const uint64_t f_count = fast.record_count(), q_count = quality.record_count();
+    return build(&fast, fast.record_count(), &quality, quality.record_count());
+}
+
+SearchError QualityAlignment::build(const VectorIndex* fast_table, uint64_t f_count, const VectorIndex* quality_table, uint64_t q_count) {
     fast_rows_ = f_count;
     map_.clear();
     unmatched_ = 0;
-    if (!fast.has_doc_ids() || !quality.has_doc_ids()) {
+    if (!fast_table || !quality_table || !fast_table->has_doc_ids() || !quality_table->has_doc_ids()) {
         // raw slabs: row i of one tier is row i of the other (the writer emits both tiers from one document order)
         kind_ = kAligned;
         if (q_count < f_count) {   // fast rows past the quality tier have no quality vector
@@ -39,6 +43,8 @@ SearchError QualityAlignment::build(const VectorIndex& fast, const VectorIndex& 
         }
         return SearchError{};
     }
+    const VectorIndex& fast = *fast_table;
+    const VectorIndex& quality = *quality_table;
     kind_ = kAligned;
     uint64_t f = 0, q = 0;
     auto ensure_mapping = [&](uint64_t upto) {
@@ -104,46 +110,56 @@ int64_t QualityAlignment::quality_row(uint64_t fast_row) const {
     }
 }
 
-SearchError quality_scores_for_hits(const VectorIndex& fast, VectorIndex& quality, const QualityAlignment& align,
-                                    const float* query, uint32_t query_len, const HitRef* hits, uint32_t n, float* out_scores,
-                                    uint8_t* out_present) {
-    if (query_len != quality.dimension())
-        return err(FSGPU_ERR_DIMENSION_MISMATCH,
-                   "expected " + std::to_string(quality.dimension()) + ", found " + std::to_string(query_len));
-    std::lock_guard<std::mutex> lock(quality.mutex());
+SearchError quality_scores_for_hits(const VectorIndex* fast_table, uint64_t fast_rows, const QualityTierView& quality,
+                                    const QualityAlignment& align, const float* query, uint32_t query_len, const HitRef* hits,
+                                    uint32_t n, float* out_scores, uint8_t* out_present) {
+    if (query_len != quality.dim)
+        return err(FSGPU_ERR_DIMENSION_MISMATCH, "expected " + std::to_string(quality.dim) + ", found " + std::to_string(query_len));
     std::vector<uint32_t> rows, slot;
     rows.reserve(n);
     slot.reserve(n);
-    const bool ids = quality.has_doc_ids();
+    const VectorIndex* qt = quality.table;
+    const bool ids = qt && qt->has_doc_ids();
+    // doc id -> latest resident WAL entry, once per call (two_tier.rs:1583-1595): a forward insert keeps the highest index, which
+    // is what a reverse scan per hit would find; an empty WAL (the compacted, common case) costs nothing
+    std::unordered_map<std::string_view, size_t> wal_latest;
+    if (ids) {
+        const size_t w = (size_t)qt->wal_record_count();
+        wal_latest.reserve(w);
+        for (size_t i = 0; i < w; ++i) wal_latest[qt->wal_doc_id(i)] = i;
+    }
     for (uint32_t i = 0; i < n; ++i) {
         out_present[i] = 0;
         out_scores[i] = 0.0f;
         const HitRef& h = hits[i];
         // the quality WAL's latest entry of this document wins (resident f32 vector, host dot in the reference's order)
-        if (ids && h.doc_id) {
-            const int64_t w = quality.wal_latest(h.doc_id, h.doc_id_len);
-            if (w >= 0) {
-                out_scores[i] = quality.wal_dot((size_t)w, query);
+        if (!wal_latest.empty() && h.doc_id) {
+            auto it = wal_latest.find(std::string_view(h.doc_id, h.doc_id_len));
+            if (it != wal_latest.end()) {
+                out_scores[i] = qt->wal_dot(it->second, query);
                 out_present[i] = 1;
                 continue;
             }
         }
         int64_t fast_idx = -1;
         if (h.index == 0xffffffffu) {
-            if (fast.has_doc_ids() && h.doc_id) fast_idx = fast.find_index_by_doc_id(h.doc_id, h.doc_id_len);
-        } else if (h.index < fast.record_count()) {
+            if (fast_table && fast_table->has_doc_ids() && h.doc_id) fast_idx = fast_table->find_index_by_doc_id(h.doc_id, h.doc_id_len);
+        } else if (h.index < fast_rows) {
             fast_idx = h.index;
         }
         int64_t qrow = fast_idx >= 0 ? align.quality_row((uint64_t)fast_idx) : -1;
-        if (qrow < 0 && ids && h.doc_id) qrow = quality.find_index_by_doc_id(h.doc_id, h.doc_id_len);
-        if (qrow >= 0 && (uint64_t)qrow < quality.record_count()) {
+        if (qrow >= 0 && (uint64_t)qrow >= quality.rows)   // dot_query_at surfaces this (lib.rs:3229-3239): not a silent None
+            return err(FSGPU_ERR_INVALID_CONFIG, "quality row " + std::to_string(qrow) + " of fast row " + std::to_string(fast_idx) +
+                                                 " is out of range for dot_query_at (" + std::to_string(quality.rows) + " records)");
+        if (qrow < 0 && ids && h.doc_id) qrow = qt->find_index_by_doc_id(h.doc_id, h.doc_id_len);
+        if (qrow >= 0) {
             rows.push_back((uint32_t)qrow);
             slot.push_back(i);
         }
     }
     if (!rows.empty()) {
         std::vector<float> dots(rows.size());
-        SearchError e = quality.gather_dot(query, query_len, rows.data(), (uint32_t)rows.size(), dots.data());
+        SearchError e = quality.gather(query, query_len, rows.data(), (uint32_t)rows.size(), dots.data());
         if (!e.ok()) return e;
         for (size_t j = 0; j < rows.size(); ++j) {
             out_scores[slot[j]] = dots[j];
@@ -151,6 +167,20 @@ SearchError quality_scores_for_hits(const VectorIndex& fast, VectorIndex& qualit
         }
     }
     return SearchError{};
+}
+
+SearchError quality_scores_for_hits(const VectorIndex& fast, VectorIndex& quality, const QualityAlignment& align,
+                                    const float* query, uint32_t query_len, const HitRef* hits, uint32_t n, float* out_scores,
+                                    uint8_t* out_present) {
+    std::lock_guard<std::mutex> lock(quality.mutex());
+    QualityTierView view;
+    view.table = &quality;
+    view.rows = quality.record_count();
+    view.dim = quality.dimension();
+    view.gather = [&quality](const float* q, uint32_t len, const uint32_t* rows, uint32_t cnt, float* out) {
+        return quality.gather_dot(q, len, rows, cnt, out);
+    };
+    return quality_scores_for_hits(&fast, fast.record_count(), view, align, query, query_len, hits, n, out_scores, out_present);
 }
 
 }  // namespace fsgpu

@@ -8,6 +8,7 @@
 #pragma once
 
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 #include "vector_index.hpp"
@@ -19,6 +20,9 @@ class QualityAlignment {
     enum Kind : int32_t { kNone = 0, kAligned = 1, kMapping = 2 };
     // Raw slabs (no record table) pair by row: Aligned.  Indexes with record tables take the reference's merge walk.
     SearchError build(const VectorIndex& fast, const VectorIndex& quality);
+    // the same walk over the tables of a row-sharded pair: each side is the handle's catalog (record table, doc ids, tombstones;
+    // sharded_index.hpp) or null for raw shards, which pair by row like raw slabs
+    SearchError build(const VectorIndex* fast_table, uint64_t fast_rows, const VectorIndex* quality_table, uint64_t quality_rows);
     Kind kind() const { return kind_; }
     // quality_index_for_fast_index (two_tier.rs:1975-1981): -1 = none
     int64_t quality_row(uint64_t fast_row) const;
@@ -36,6 +40,19 @@ struct HitRef {
     uint32_t doc_id_len;
     uint32_t index;  // fast-tier row, or 0xffffffff
 };
+
+// The quality tier as the re-scoring sees it: the tables that resolve a doc id (the index itself, a sharded handle's catalog, or
+// null for raw slabs) and a gather of dot_query_at over GLOBAL main rows (VectorIndex::gather_dot; ShardedIndex::gather_dot routes
+// every row to the shard that owns it).
+struct QualityTierView {
+    const VectorIndex* table = nullptr;
+    uint64_t rows = 0;
+    uint32_t dim = 0;
+    std::function<SearchError(const float* query, uint32_t query_len, const uint32_t* rows, uint32_t n, float* out)> gather;
+};
+SearchError quality_scores_for_hits(const VectorIndex* fast_table, uint64_t fast_rows, const QualityTierView& quality,
+                                    const QualityAlignment& align, const float* query, uint32_t query_len, const HitRef* hits,
+                                    uint32_t n, float* out_scores, uint8_t* out_present);
 
 // out_scores[i] is valid iff out_present[i] != 0.  Takes the quality index's mutex for the gather.
 SearchError quality_scores_for_hits(const VectorIndex& fast, VectorIndex& quality, const QualityAlignment& align,

@@ -1154,9 +1154,19 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
         if (e.ok()) {
             i8f_queries += nq;
             i8f_refiltered += refiltered;
-            // more than 1/8 of a batch uncertified twice in a row: the int8 margin does not suit this corpus
+            // More than 1/8 of a batch uncertified.  What overflows on a corpus with a dense score tail (outlier dimensions, big
+            // clusters) is the MAIN pass's lists: the rows within the margin of the k-th best number a few hundred whatever the
+            // corpus size, but the main pass runs on the threshold of a 1/25 sample and lets N / RB times as many through
+            // (scripts/r04/i8_bound_study.py).  So the first answer is a larger second sample for this index — 2 x, then 4 x: half /
+            // a quarter as many survivors for +0.1 / +0.3 ms of sampling per 512-query pass at 10M rows — and only an index that
+            // still hands an eighth of its batches on twice in a row at 4 x goes to the f16 filter.
             if (nq >= 16 && (uint64_t)refiltered * 8 > nq) {
-                if (++i8f_strikes_ >= 2 && batched_filter == 0 && knobs().filter == 0) i8f_disabled_ = true;
+                if (i8f_sample_boost_ < 4 && nq >= 256) {
+                    i8f_sample_boost_ *= 2;
+                    i8f_strikes_ = 0;
+                } else if (++i8f_strikes_ >= 2 && batched_filter == 0 && knobs().filter == 0) {
+                    i8f_disabled_ = true;
+                }
             } else {
                 i8f_strikes_ = 0;
             }
@@ -1434,6 +1444,9 @@ SearchError VectorIndex::batched_prepare(BatchedPlan& p, bool* done) {
             if (knobs().ra <= 0) RA = RA_MAX;   // keeps the sample stage's own survivors (ksel RB / RA) in the hundreds
         }
     }
+    // (an index whose int8 margin overflowed the main pass's lists samples more: its wide rounds gate the second sample by rank,
+    // so that stage's own survivors stay in the hundreds — see search_top_k_batched_device)
+    if (p.i8f && wide_main && i8f_sample_boost_ > 1 && knobs().rb <= 0) RB = (uint32_t)std::min<uint64_t>((uint64_t)RB * i8f_sample_boost_, nrows_ / 6);
     RB = std::min<uint32_t>(RB, (uint32_t)(nrows_ / 4));
     RB = std::max<uint32_t>(RA, RB / RA * RA);
     p.RA = RA;

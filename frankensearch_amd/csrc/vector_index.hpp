@@ -150,6 +150,7 @@ class VectorIndex {
     // latest resident WAL entry of a doc id (-1 if none) and its dot_product_f32_f32 with a query
     int64_t wal_latest(const char* doc_id, uint32_t len) const;
     float wal_dot(size_t wal_index, const float* query) const;
+    const std::string& wal_doc_id(size_t wal_index) const { return wal_[wal_index].doc_id; }
 
     std::mutex& mutex() { return mu_; }
     int device() const { return device_; }
@@ -248,6 +249,7 @@ class VectorIndex {
     bool hard_batch_ = false;     // the batch in flight is the int8 filter's leftovers (nested f16-filter call)
     bool i8f_disabled_ = false;   // the int8 filter left too many queries uncertified on this slab (or its copy does not fit)
     uint32_t i8f_strikes_ = 0;
+    uint32_t i8f_sample_boost_ = 1;   // 1, 2, 4: the second sample of the int8 filter's wide rounds grows before the filter is given up
     bool mf_norm_ready_ = false;
     int mf_shape_i8_ = 4, mf_per_cu_160_ = 1, mf_per_cu_160_i8_ = 1;
     bool mf_use_160_ = false;

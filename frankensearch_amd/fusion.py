@@ -79,6 +79,8 @@ def blend_two_tier_aligned(fast: Sequence[Tuple[str, float, int]], quality_score
     """blend_two_tier_aligned (blend.rs:213-294): quality_scores[i] is the optional quality score of fast[i]."""
     import numpy as np
     fa, fk = _pack(fast)
+    # a position past the end of quality_scores is None (quality_scores.get(i), blend.rs:246); extra scores have no hit to belong to
+    quality_scores = (list(quality_scores) + [None] * len(fast))[:len(fast)]
     qs = np.array([0.0 if q is None else q for q in quality_scores], dtype=np.float32)
     qp = np.array([q is not None for q in quality_scores], dtype=np.uint8)
     out = (_ScoredDoc * max(len(fast), 1))()

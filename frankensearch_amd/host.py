@@ -35,7 +35,12 @@ class _Hit(C.Structure):
 
 class _Metrics(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("fast_embed_ms", "fast_search_ms", "phase1_total_ms", "quality_embed_ms",
-                                          "quality_search_ms", "blend_ms", "phase2_total_ms")]
+                                          "quality_search_ms", "blend_ms", "phase2_total_ms")] + [("refinement_failed", C.c_int32)]
+
+
+class _StreamResult(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("wall_seconds", "queries_per_sec", "mean_encode_ms", "mean_search_ms")] + \
+               [(n, C.c_uint64) for n in ("queries", "groups", "exact_fallbacks")]
 
 
 class _ScoredDoc(C.Structure):
@@ -55,7 +60,8 @@ class _LoadResult(C.Structure):
                                                   ("first_error", C.c_char * 160)]
 
 
-SYMBOLS = ("fshost_two_tier_create", "fshost_two_tier_destroy", "fshost_two_tier_search", "fshost_run_load")
+SYMBOLS = ("fshost_two_tier_create", "fshost_two_tier_create_sharded", "fshost_two_tier_destroy", "fshost_two_tier_search",
+           "fshost_run_load", "fshost_embed_search_stream")
 _handle = None
 
 
@@ -68,6 +74,12 @@ def lib() -> C.CDLL:
         h = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
         h.fshost_two_tier_create.restype = C.c_int32
         h.fshost_two_tier_create.argtypes = [C.c_void_p] * 4 + [C.POINTER(_Config), C.POINTER(C.c_void_p)]
+        h.fshost_two_tier_create_sharded.restype = C.c_int32
+        h.fshost_two_tier_create_sharded.argtypes = [C.c_void_p] * 4 + [C.POINTER(_Config), C.POINTER(C.c_void_p)]
+        h.fshost_embed_search_stream.restype = C.c_int32
+        h.fshost_embed_search_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                                 C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.POINTER(_StreamResult)]
         h.fshost_two_tier_destroy.restype = None
         h.fshost_two_tier_destroy.argtypes = [C.c_void_p]
         h.fshost_two_tier_search.restype = C.c_int32
@@ -121,8 +133,10 @@ class NativeTwoTierSearcher:
         cfg = _Config(quality_weight, rrf_k, candidate_multiplier, doc_id_mode, fast_tier_int8_multiplier,
                       int(prefetch_quality_embed), int(quality_pool), int(quality_int8_latency))
         h = C.c_void_p()
-        check(lib().fshost_two_tier_create(fast_index._h, quality_index._h, fast_embedder._h, quality_embedder._h,
-                                           C.byref(cfg), C.byref(h)))
+        from .index import NativeShardedIndex
+        # two row-sharded handles (fsgpu_sharded over the GPUs of the node) or two indexes: the same searcher either way
+        create = lib().fshost_two_tier_create_sharded if isinstance(fast_index, NativeShardedIndex) else lib().fshost_two_tier_create
+        check(create(fast_index._h, quality_index._h, fast_embedder._h, quality_embedder._h, C.byref(cfg), C.byref(h)))
         self._h = h
 
     def search(self, fast_token_ids: Sequence[int], quality_token_ids: Sequence[int], k: int,
@@ -160,3 +174,27 @@ class NativeTwoTierSearcher:
             self.close()
         except Exception:
             pass
+
+
+def embed_search_stream(encoder, index, ids: np.ndarray, offsets: np.ndarray, batch: int, k: int, group: int = 1,
+                        overlap: bool = True, want_hits: bool = True):
+    """BASELINE config 5's serving loop in native code (fshost_embed_search_stream): token-id batches -> MiniLM on the GPU ->
+    batched exact top-k, the encode of group g + 1 overlapped with the search of group g.  `index` is a VectorIndex or a
+    NativeShardedIndex.  Returns (rows, scores, counts, stats dict)."""
+    from .index import NativeShardedIndex
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+    n_texts = offsets.size - 1
+    if n_texts % batch:
+        raise ValueError("the number of texts must be a multiple of the batch size")
+    n_batches = n_texts // batch
+    rows = np.empty((n_texts, k), dtype=np.uint32) if want_hits else None
+    scores = np.empty((n_texts, k), dtype=np.float32) if want_hits else None
+    counts = np.empty(n_texts, dtype=np.uint32) if want_hits else None
+    res = _StreamResult()
+    sharded = isinstance(index, NativeShardedIndex)
+    check(lib().fshost_embed_search_stream(encoder._h, None if sharded else index._h, index._h if sharded else None, ids.ctypes.data,
+                                           offsets.ctypes.data, batch, n_batches, group, k, int(overlap),
+                                           rows.ctypes.data if want_hits else None, scores.ctypes.data if want_hits else None,
+                                           counts.ctypes.data if want_hits else None, C.byref(res)))
+    return rows, scores, counts, {n: getattr(res, n) for n, _ in _StreamResult._fields_}

@@ -550,6 +550,15 @@ class NativeShardedIndex:
         check(_lib.lib().fsgpu_sharded_gather_dot(self._h, _ptr(q), q.size, _ptr(r), r.size, _ptr(out)))
         return out
 
+    def set_coalescing(self, max_batch: int, max_wait_us: int) -> None:
+        """Concurrent single-query searches ride one search of the shards (fsgpu_sharded_set_coalescing)."""
+        check(_lib.lib().fsgpu_sharded_set_coalescing(self._h, max_batch, max_wait_us))
+
+    def coalescing_stats(self) -> Tuple[int, int]:
+        b, r = C.c_uint64(), C.c_uint64()
+        check(_lib.lib().fsgpu_sharded_coalescing_stats(self._h, C.byref(b), C.byref(r)))
+        return b.value, r.value
+
 
 def write_fsvi(path: str, rows, embedder_id: str = "test", embedder_revision: str = "", compaction_gen: int = 0,
                device: int = 0, quantization: int = 1) -> None:

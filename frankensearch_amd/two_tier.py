@@ -44,9 +44,16 @@ class TwoTierIndex:
     NONE, ALIGNED, MAPPING = 0, 1, 2
 
     def __init__(self, fast_index, quality_index):
+        """Both unsharded (VectorIndex) or both row-sharded handles (NativeShardedIndex: fsgpu_sharded_alignment_create /
+        fsgpu_sharded_quality_scores_for_hits — SURVEY 8e: the tiers shard identically, re-scored rows go to their shards)."""
+        from .index import NativeShardedIndex
         self.fast, self.quality = fast_index, quality_index
+        self.sharded = isinstance(fast_index, NativeShardedIndex)
+        if self.sharded != isinstance(quality_index, NativeShardedIndex):
+            raise TypeError("a fast / quality pair is either two indexes or two sharded handles")
         h = C.c_void_p()
-        check(_lib.lib().fsgpu_alignment_create(fast_index._h, quality_index._h, C.byref(h)))
+        create = _lib.lib().fsgpu_sharded_alignment_create if self.sharded else _lib.lib().fsgpu_alignment_create
+        check(create(fast_index._h, quality_index._h, C.byref(h)))
         self._a = h.value
 
     def close(self) -> None:
@@ -75,8 +82,9 @@ class TwoTierIndex:
         arr, keep = fusion._pack(hits)
         scores = np.zeros(max(len(hits), 1), dtype=np.float32)
         present = np.zeros(max(len(hits), 1), dtype=np.uint8)
-        check(_lib.lib().fsgpu_quality_scores_for_hits(self.fast._h, self.quality._h, self._a, q.ctypes.data, q.size, arr,
-                                                       len(hits), scores.ctypes.data, present.ctypes.data))
+        fn = _lib.lib().fsgpu_sharded_quality_scores_for_hits if self.sharded else _lib.lib().fsgpu_quality_scores_for_hits
+        check(fn(self.fast._h, self.quality._h, self._a, q.ctypes.data, q.size, arr, len(hits), scores.ctypes.data,
+                 present.ctypes.data))
         return [float(scores[i]) if present[i] else None for i in range(len(hits))]
 
 

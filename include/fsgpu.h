@@ -331,6 +331,12 @@ fsgpu_status fsgpu_sharded_search(fsgpu_sharded *idx, const fsgpu_sharded_reques
 fsgpu_status fsgpu_sharded_search_begin(fsgpu_sharded *idx, const fsgpu_sharded_request *request, uint64_t *out_ticket);
 fsgpu_status fsgpu_sharded_search_end(fsgpu_sharded *idx, uint64_t ticket, uint32_t *out_rows, float *out_scores,
                                       uint32_t *out_counts, uint32_t *out_fallbacks);
+/* Dynamic batching of concurrent callers on a sharded handle (as fsgpu_index_set_coalescing): fsgpu_sharded_search calls with
+ * nq = 1, k <= 64, no allow bitmap and mode EXACT or INT8_TWO_PASS that are in flight together ride ONE search of the shards (more
+ * than four exact callers take the BATCHED mode — the same rows and score bits; two-pass callers one two-pass batch with their
+ * multiplier).  max_batch = 0 turns it off (the default). */
+fsgpu_status fsgpu_sharded_set_coalescing(fsgpu_sharded *idx, uint32_t max_batch, uint32_t max_wait_us);
+fsgpu_status fsgpu_sharded_coalescing_stats(fsgpu_sharded *idx, uint64_t *batches, uint64_t *requests);
 /* the corpus-wide max-abs the shards' int8 / 4-bit copies are built from (0 before the first two-pass search) */
 float fsgpu_sharded_quant_scale_max(const fsgpu_sharded *idx);
 /* VectorIndex::open (lib.rs:1747-1909) of an FSVI v1 file with an F16 slab, rows split over the devices.  The handle keeps the
@@ -388,6 +394,7 @@ fsgpu_status fsgpu_bench_fixture_device(int32_t device, uint64_t first, uint64_t
 /* Model2VecEmbedder (embed/src/model2vec_embedder.rs:55-58): table is [vocab,dim] f32 row-major (host). */
 fsgpu_status fsgpu_m2v_create(int32_t device, const float *table, uint32_t vocab, uint32_t dim, fsgpu_m2v **out);
 void fsgpu_m2v_destroy(fsgpu_m2v *m);
+uint32_t fsgpu_m2v_dimension(const fsgpu_m2v *m); /* Embedder::dimension (crates/frankensearch-core/src/traits.rs:220-370) */
 /* embed_batch_sync over token ids (model2vec_embedder.rs:310-335,409-419,435-451): text i owns
  * ids[offsets[i]..offsets[i+1]); out is [n,dim].  Empty / all-OOV texts give zeros. */
 fsgpu_status fsgpu_m2v_embed(fsgpu_m2v *m, const uint32_t *ids, const uint32_t *offsets, uint32_t n, float *out);
@@ -397,6 +404,7 @@ fsgpu_status fsgpu_m2v_embed(fsgpu_m2v *m, const uint32_t *ids, const uint32_t *
 fsgpu_status fsgpu_bert_create(int32_t device, const fsgpu_bert_config *config, const fsgpu_bert_weights *weights,
                                fsgpu_bert **out);
 void fsgpu_bert_destroy(fsgpu_bert *m);
+uint32_t fsgpu_bert_dimension(const fsgpu_bert *m); /* Embedder::dimension: the model's hidden size */
 /* embed_batch_sync over token ids (native_embedder.rs:218-255 -> Model::embed_forward native.rs:1142-1236):
  * text i owns ids[offsets[i]..offsets[i+1]) (already tokenised WITH special tokens and truncated to <= 512,
  * no padding); every returned token is mean-pooled, then L2-normalised (zeros for empty / zero-norm,
@@ -470,6 +478,15 @@ uint64_t fsgpu_alignment_unmatched_quality_docs(const fsgpu_alignment *a);
 fsgpu_status fsgpu_quality_scores_for_hits(fsgpu_index *fast, fsgpu_index *quality, const fsgpu_alignment *alignment,
                                            const float *query, uint32_t query_len, const fsgpu_scored_doc *hits, uint32_t n,
                                            float *out_scores, uint8_t *out_present);
+
+/* TwoTierIndex over two row-sharded handles (fast and quality slabs shard identically).  The alignment walk reads the
+ * handles' catalogs (fsgpu_sharded_open_fsvi; raw shards pair by row); quality_scores_for_hits resolves WAL entries and doc ids
+ * there and gathers dot_query_at on the shards that own the quality rows (one gather launch per shard touched).  Same outputs
+ * as fsgpu_quality_scores_for_hits over unsharded indexes with the same rows. */
+fsgpu_status fsgpu_sharded_alignment_create(fsgpu_sharded *fast, fsgpu_sharded *quality, fsgpu_alignment **out);
+fsgpu_status fsgpu_sharded_quality_scores_for_hits(fsgpu_sharded *fast, fsgpu_sharded *quality, const fsgpu_alignment *alignment,
+                                                   const float *query, uint32_t query_len, const fsgpu_scored_doc *hits, uint32_t n,
+                                                   float *out_scores, uint8_t *out_present);
 
 /* ---- MRL: truncated scan + full-dimension rescore ---- */
 /* MrlSearchStats (crates/frankensearch-index/src/mrl.rs:122-139). */

@@ -64,12 +64,23 @@ typedef struct fshost_hit {
 typedef struct fshost_metrics {
     double fast_embed_ms, fast_search_ms, phase1_total_ms; /* library name of the Initial stage */
     double quality_embed_ms, quality_search_ms, blend_ms, phase2_total_ms;
+    int32_t refinement_failed; /* SearchPhase::RefinementFailed (sync_searcher.rs:820-839): the quality pool could not be produced
+                                * (a failing quality-tier search / quality_scores_for_hits); the search still returns FSGPU_OK and
+                                * final_out holds the initial results, as the reference's final_results does */
 } fshost_metrics;
 
 /* The handles stay owned by the caller and must outlive the searcher. */
 fsgpu_status fshost_two_tier_create(fsgpu_index *fast_index, fsgpu_index *quality_index, fsgpu_m2v *fast_embedder,
                                     fsgpu_bert *quality_embedder, const fshost_two_tier_config *config,
                                     fshost_two_tier **out);
+/* The same searcher over two ROW-SHARDED tiers (fsgpu_sharded handles over the GPUs of one node, SURVEY 8e: the fast and quality
+ * slabs shard identically).  Fast tier: fsgpu_sharded_search in INT8_TWO_PASS mode (the corpus-wide candidate set of
+ * search_top_k_int8_two_pass) or EXACT; quality tier: EXACT (Retrieved) or fsgpu_sharded_quality_scores_for_hits — a gather routed to
+ * the shards that own the rows (RescoredFastPool); doc ids from the handles' catalogs (doc_id_mode 0) or synthetic (1).  Fused
+ * results equal the unsharded searcher's over the same rows.  quality_int8_latency is ignored (a shard's exact pass is 1/W of the slab). */
+fsgpu_status fshost_two_tier_create_sharded(fsgpu_sharded *fast_index, fsgpu_sharded *quality_index, fsgpu_m2v *fast_embedder,
+                                            fsgpu_bert *quality_embedder, const fshost_two_tier_config *config,
+                                            fshost_two_tier **out);
 void fshost_two_tier_destroy(fshost_two_tier *s);
 
 /* SyncTwoTierSearcher::search (sync_searcher.rs:616-943): phase 0 = fast embed -> fast-tier top-(k*mult) -> RRF with
@@ -106,6 +117,24 @@ typedef struct fshost_load_result {
 } fshost_load_result;
 
 fsgpu_status fshost_run_load(fshost_two_tier *s, const fshost_load_config *config, fshost_load_result *result);
+
+/* BASELINE config 5's serving loop: batches of token-id queries -> MiniLM forward on the GPU (fsgpu_bert_embed) ->
+ * batched exact top-k of the embeddings (fsgpu_search_topk_batched on an index, or fsgpu_sharded_search in BATCHED mode on a
+ * row-sharded handle; exactly one of `index` / `sharded` is non-null).  overlap != 0: a second host thread encodes group g + 1
+ * while group g is searched (what a Rust host's rayon::join of the two stages does; the encoder's stream has the higher
+ * priority, so its short kernels are not queued behind the chip-filling scan launches); overlap == 0 runs the two stages in
+ * turn on the calling thread.  Text t owns ids[offsets[t] .. offsets[t + 1]); the texts are taken batch by batch, `group`
+ * batches per search (1: one search per encoder batch; 2: two encoder batches share each pass over the slab).  out_* hold
+ * [n_batches * batch, k] rows / scores and [n_batches * batch] counts (any may be NULL). */
+typedef struct fshost_stream_result {
+    double wall_seconds, queries_per_sec;
+    double mean_encode_ms, mean_search_ms; /* per group */
+    uint64_t queries, groups, exact_fallbacks;
+} fshost_stream_result;
+fsgpu_status fshost_embed_search_stream(fsgpu_bert *encoder, fsgpu_index *index, fsgpu_sharded *sharded, const int32_t *ids,
+                                        const uint32_t *offsets, uint32_t batch, uint32_t n_batches, uint32_t group, uint32_t k,
+                                        int32_t overlap, uint32_t *out_rows, float *out_scores, uint32_t *out_counts,
+                                        fshost_stream_result *result);
 
 #ifdef __cplusplus
 }

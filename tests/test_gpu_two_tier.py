@@ -384,3 +384,236 @@ def test_rescored_fast_pool_searchers_equal_the_oracle_pipeline(oracle):
             assert ini == out.initial_results and fin == out.final_results
             assert metrics["quality_search_ms"] > 0
     assert missing > 0   # some fast hits had no quality vector (the reference's None)
+
+
+def _same_hits(a, b):
+    return [(h.index, np.float32(h.score).view(np.uint32)) for h in a] == [(h.index, np.float32(h.score).view(np.uint32)) for h in b]
+
+
+def test_two_tier_flow_over_eight_virtual_shards_equals_the_unsharded_flow():
+    """The whole phase-0 + phase-1 flow (sync_searcher.rs:616-943) with BOTH tiers behind row-sharded handles — eight shards on
+    this one GPU, exchanged by peer copies (the rehearsal of the 8-GPU form, SURVEY 8e: the tiers shard identically) — must deliver
+    the unsharded flow's fused hits bit for bit: doc ids, rrf scores, ranks.  Fast tier = int8 two-pass (corpus-wide candidate
+    set), quality pool Retrieved (sharded exact search) and RescoredFastPool (fsgpu_sharded_quality_scores_for_hits: the gather
+    routed to the owning shards)."""
+    import frankensearch_amd as fa
+    from frankensearch_amd.build import build
+    from frankensearch_amd.host import NativeTwoTierSearcher
+
+    build()
+    rng = np.random.default_rng(51)
+    n, nq_rows = 41_003, 39_000                          # ragged shards; the quality tier covers fewer documents
+    fast_slab = rng.standard_normal((n, 256)).astype(np.float16).view(np.uint16)
+    qual_slab = rng.standard_normal((n, 384)).astype(np.float16).view(np.uint16)
+    _, _, m2v, bert = _small_two_tier(fa, rng, 64)
+    P = fa.NativeShardedIndex.EXCHANGE_PEER_COPY
+    doc = lambda r: f"doc-{r:08d}"
+    for pool, qrows in ((0, n), (1, nq_rows), (1, n)):
+        fast, qual = fa.VectorIndex.from_slab(fast_slab), fa.VectorIndex.from_slab(qual_slab[:qrows])
+        sfast = fa.NativeShardedIndex.from_slab(fast_slab, [0] * 8, exchange=P)
+        squal = fa.NativeShardedIndex.from_slab(qual_slab[:qrows], [0] * 8, exchange=P)
+        assert sfast.shard_count() == 8
+        one = NativeTwoTierSearcher(fast, qual, m2v, bert, doc_id_mode=1, fast_tier_int8_multiplier=3, quality_pool=pool)
+        eight = NativeTwoTierSearcher(sfast, squal, m2v, bert, doc_id_mode=1, fast_tier_int8_multiplier=3, quality_pool=pool)
+        exact8 = NativeTwoTierSearcher(sfast, squal, m2v, bert, doc_id_mode=1, fast_tier_int8_multiplier=0, quality_pool=pool,
+                                       prefetch_quality_embed=2)
+        exact1 = NativeTwoTierSearcher(fast, qual, m2v, bert, doc_id_mode=1, fast_tier_int8_multiplier=0, quality_pool=pool)
+        for trial in range(5):
+            fast_ids = rng.integers(0, 5000, int(rng.integers(2, 20))).tolist()
+            qual_ids = [101] + rng.integers(1000, 3000, int(rng.integers(3, 25))).tolist() + [102]
+            lexical = [(doc(int(r)), float(30 - i)) for i, r in enumerate(rng.choice(n, 30, replace=False))]
+            k = 10
+            ini1, fin1, _ = one.search(fast_ids, qual_ids, k, lexical)
+            ini8, fin8, m8 = eight.search(fast_ids, qual_ids, k, lexical)
+            assert ini8 == ini1 and fin8 == fin1, (pool, qrows, trial)
+            assert [h.rrf_score for h in fin8] == [h.rrf_score for h in fin1]
+            assert m8["refinement_failed"] == 0 and m8["phase2_total_ms"] > 0
+            ie1, fe1, _ = exact1.search(fast_ids, qual_ids, k, lexical)
+            ie8, fe8, _ = exact8.search(fast_ids, qual_ids, k, lexical)
+            assert ie8 == ie1 and fe8 == fe1
+        for s in (one, eight, exact1, exact8):
+            s.close()
+        for h in (fast, qual, sfast, squal):
+            h.close()
+
+
+def test_sharded_two_tier_over_fsvi_catalogs_with_tombstones_and_a_quality_wal(tmp_path):
+    """doc_id_mode 0 over fsgpu_sharded_open_fsvi handles: doc ids, tombstones and the WAL live in the handles' catalogs; the
+    alignment walk (two_tier.rs:750-866) runs over them and the re-scoring resolves WAL entries / doc ids there.  Equal to the
+    unsharded pair opened from the same files, after the same soft deletes and appends."""
+    import frankensearch_amd as fa
+    from frankensearch_amd.build import build
+    from frankensearch_amd.host import NativeTwoTierSearcher
+    from frankensearch_amd.synthetic import random_bert_weights
+    from frankensearch_amd.two_tier import TwoTierIndex
+
+    build()
+    rng = np.random.default_rng(53)
+    n = 3000
+    ids = [f"note-{i:05d}-{'z' * (i % 4)}" for i in range(n)]
+    q_ids = [d for i, d in enumerate(ids) if i % 9 != 4] + [f"only-quality-{i:03d}" for i in range(25)]
+    fast_rows = rng.standard_normal((n, 256)).astype(np.float32)
+    qual_rows = rng.standard_normal((len(q_ids), 384)).astype(np.float32)
+    pf, pq = str(tmp_path / "vector.fast.idx"), str(tmp_path / "vector.quality.idx")
+    fa.write_fsvi(pf, list(zip(ids, fast_rows)), "potion", "r1")
+    fa.write_fsvi(pq, list(zip(q_ids, qual_rows)), "minilm", "r1")
+    P = fa.NativeShardedIndex.EXCHANGE_PEER_COPY
+    fast, qual = fa.VectorIndex.open(pf), fa.VectorIndex.open(pq)
+    sfast, squal = fa.NativeShardedIndex.open(pf, [0] * 3, exchange=P), fa.NativeShardedIndex.open(pq, [0] * 3, exchange=P)
+    for d in (ids[5], ids[77], ids[1500]):
+        assert fast.soft_delete(d) and sfast.soft_delete(d)
+    for d in (ids[8], ids[2000]):
+        assert qual.soft_delete(d) and squal.soft_delete(d)
+    wal_vec = rng.standard_normal(384).astype(np.float32)
+    for h in (qual, squal):
+        h.append(ids[10], rng.standard_normal(384).astype(np.float32))
+        h.append(ids[10], wal_vec)
+    p1, p3 = TwoTierIndex(fast, qual), TwoTierIndex(sfast, squal)
+    assert p1.alignment_kind() == p3.alignment_kind() == TwoTierIndex.MAPPING
+    assert [p1.quality_row(r) for r in range(n + 2)] == [p3.quality_row(r) for r in range(n + 2)]
+    assert p1.unmatched_quality_docs() == p3.unmatched_quality_docs() >= 25
+    query = rng.standard_normal(384).astype(np.float32)
+    row10 = next(r for r in range(n) if fast.doc_id_at(r) == ids[10])
+    hits = [(fast.doc_id_at(r), 0.0, r) for r in rng.choice(n, 50, replace=False).tolist() + [row10]]
+    hits += [(ids[20], 0.0, 0xFFFFFFFF), ("only-quality-007", 0.0, 0xFFFFFFFF), ("nowhere", 0.0, 0xFFFFFFFF), (ids[30], 0.0, n + 5)]
+    s1, s3 = p1.quality_scores_for_hits(query, hits), p3.quality_scores_for_hits(query, hits)
+    assert [x is None for x in s1] == [x is None for x in s3] and any(x is None for x in s1)
+    assert [np.float32(x).view(np.uint32) for x in s1 if x is not None] == [np.float32(x).view(np.uint32) for x in s3 if x is not None]
+    m2v = fa.Model2VecEmbedder(rng.standard_normal((5000, 256)).astype(np.float32))
+    bert = fa.NativeEmbedder(random_bert_weights(5, 3000, 384, 6, 1536))
+    for pool in (0, 1):
+        one = NativeTwoTierSearcher(fast, qual, m2v, bert, doc_id_mode=0, quality_pool=pool)
+        three = NativeTwoTierSearcher(sfast, squal, m2v, bert, doc_id_mode=0, quality_pool=pool)
+        for trial in range(4):
+            fast_ids = rng.integers(0, 5000, 8).tolist()
+            qual_ids = [101] + rng.integers(1000, 3000, 7).tolist() + [102]
+            lexical = [(ids[int(r)], float(30 - i)) for i, r in enumerate(rng.choice(n, 30, replace=False))]
+            i1, f1, _ = one.search(fast_ids, qual_ids, 10, lexical)
+            i3, f3, _ = three.search(fast_ids, qual_ids, 10, lexical)
+            assert i3 == i1 and f3 == f1, (pool, trial)
+            assert all(h.doc_id.startswith(("note-", "only-quality-")) for h in f3)
+        one.close()
+        three.close()
+    # a search begun on the handle is in flight: soft_delete / append must refuse to rewrite the shards' bitmaps under it
+    t = sfast.search_begin(rng.standard_normal((4, 256)).astype(np.float32), 5)
+    with pytest.raises(fa.InvalidConfig):
+        sfast.soft_delete(ids[40])
+    with pytest.raises(fa.InvalidConfig):
+        sfast.append(ids[41], rng.standard_normal(256).astype(np.float32))
+    sfast.search_end(t)
+    assert sfast.soft_delete(ids[40])
+
+
+def test_refinement_failure_returns_the_initial_results():
+    """sync_searcher.rs:820-839: a quality pool that cannot be produced (here: the quality index has another dimension than the
+    quality embedder, so search_top_k / quality_scores_for_hits answer DimensionMismatch) is a RefinementFailed outcome — the search
+    succeeds and final_results are the phase-0 results.  The same mismatch on the FAST tier fails the search."""
+    import frankensearch_amd as fa
+    from frankensearch_amd.build import build
+    from frankensearch_amd.host import NativeTwoTierSearcher
+
+    build()
+    rng = np.random.default_rng(57)
+    n = 20_000
+    fast_slab = rng.standard_normal((n, 256)).astype(np.float16).view(np.uint16)
+    wrong_quality = rng.standard_normal((n, 128)).astype(np.float16).view(np.uint16)   # the encoder emits 384 dimensions
+    _, _, m2v, bert = _small_two_tier(fa, rng, 64)
+    P = fa.NativeShardedIndex.EXCHANGE_PEER_COPY
+    pairs = [(fa.VectorIndex.from_slab(fast_slab), fa.VectorIndex.from_slab(wrong_quality)),
+             (fa.NativeShardedIndex.from_slab(fast_slab, [0] * 2, exchange=P), fa.NativeShardedIndex.from_slab(wrong_quality, [0] * 2, exchange=P))]
+    doc = lambda r: f"doc-{r:08d}"
+    for fast, qual in pairs:
+        for pool in (0, 1):
+            for prefetch in (0, 2):
+                s = NativeTwoTierSearcher(fast, qual, m2v, bert, doc_id_mode=1, quality_pool=pool, prefetch_quality_embed=prefetch)
+                lexical = [(doc(int(r)), float(30 - i)) for i, r in enumerate(rng.choice(n, 20, replace=False))]
+                ini, fin, m = s.search(rng.integers(0, 5000, 9).tolist(), [101, 1500, 1600, 102], 10, lexical)
+                assert m["refinement_failed"] == 1 and len(ini) == 10 and fin == ini
+                s.close()
+        bad = NativeTwoTierSearcher(qual, fast, m2v, bert, doc_id_mode=1)   # the FAST tier's dimension is wrong: an error
+        with pytest.raises(fa.DimensionMismatch):
+            bad.search([1, 2, 3], [101, 1500, 102], 10, [])
+        bad.close()
+
+
+def test_sharded_handle_coalesces_concurrent_single_query_callers():
+    """fsgpu_sharded_set_coalescing: single-query exact and int8 two-pass searches in flight together ride ONE search of the shards
+    (the batched mode / one two-pass batch) and every caller gets exactly the hits of the lone call."""
+    import threading
+
+    import frankensearch_amd as fa
+    from frankensearch_amd.build import build
+
+    build()
+    rng = np.random.default_rng(59)
+    n, dim, nq = 90_001, 384, 80
+    slab = rng.standard_normal((n, dim)).astype(np.float16).view(np.uint16)
+    idx = fa.NativeShardedIndex.from_slab(slab, [0] * 4, exchange=fa.NativeShardedIndex.EXCHANGE_PEER_COPY)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    want = [idx.search(q[i], 10) for i in range(nq)]
+    want8 = [idx.search(q[i], 30, idx.INT8_TWO_PASS, 3) for i in range(nq)]
+    idx.set_coalescing(64, 20_000)
+    got, got8, errs = [None] * nq, [None] * nq, []
+
+    def call(i):
+        try:
+            got[i] = idx.search(q[i], 10)
+            got8[i] = idx.search(q[i], 30, idx.INT8_TWO_PASS, 3)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=call, args=(i,)) for i in range(nq)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(nq):
+        for g, w in ((got[i], want[i]), (got8[i], want8[i])):
+            assert np.array_equal(g[0], w[0]) and np.array_equal(g[1].view(np.uint32), w[1].view(np.uint32)) and np.array_equal(g[2], w[2]), i
+    batches, requests = idx.coalescing_stats()
+    assert requests == 2 * nq and batches < nq, (batches, requests)
+    idx.set_coalescing(0, 0)
+    idx.close()
+
+
+def test_embed_search_stream_overlapped_equals_the_stages_in_turn():
+    """fshost_embed_search_stream (BASELINE config 5's loop): token-id batches -> MiniLM on the GPU -> batched exact top-k, with the
+    encode of group g + 1 running under the search of group g.  The overlapped pipeline, the serial one, the sharded handle and a
+    step-by-step drive of the same C ABI calls all return the same rows and score bits."""
+    import frankensearch_amd as fa
+    from frankensearch_amd.build import build
+    from frankensearch_amd.host import embed_search_stream
+
+    build()
+    rng = np.random.default_rng(61)
+    n, batch, nb, k = 60_000, 64, 5, 10
+    slab = rng.standard_normal((n, 384)).astype(np.float16).view(np.uint16)
+    _, _, _, bert = _small_two_tier(fa, rng, 64)
+    texts = [[101] + rng.integers(1000, 3000, int(rng.integers(6, 31))).tolist() + [102] for _ in range(batch * nb)]
+    offs = np.zeros(len(texts) + 1, dtype=np.uint32)
+    offs[1:] = np.cumsum([len(t) for t in texts])
+    ids = np.concatenate([np.asarray(t, dtype=np.int32) for t in texts])
+    idx = fa.VectorIndex.from_slab(slab)
+    sh = fa.NativeShardedIndex.from_slab(slab, [0] * 8, exchange=fa.NativeShardedIndex.EXCHANGE_PEER_COPY)
+    # step by step: one embed call and one batched search per encoder batch
+    want_r, want_s = [], []
+    for b in range(nb):
+        lo, hi = b * batch, (b + 1) * batch
+        emb = np.empty((batch, 384), dtype=np.float32)
+        bert.embed_flat(ids[offs[lo]:offs[hi]], (offs[lo:hi + 1] - offs[lo]).astype(np.uint32), emb)
+        r, s, c, _ = idx.search_batched(emb, k)
+        assert np.all(c == k)
+        want_r.append(r)
+        want_s.append(s)
+    want_r, want_s = np.concatenate(want_r), np.concatenate(want_s)
+    for target in (idx, sh):
+        for group in (1, 2):
+            for overlap in (False, True):
+                r, s, c, stats = embed_search_stream(bert, target, ids, offs, batch, k, group=group, overlap=overlap)
+                assert np.array_equal(r, want_r) and np.array_equal(s.view(np.uint32), want_s.view(np.uint32)), (group, overlap)
+                assert np.all(c == k) and stats["queries"] == batch * nb and stats["groups"] == (nb + group - 1) // group
+                assert stats["queries_per_sec"] > 0
+    idx.close()
+    sh.close()
