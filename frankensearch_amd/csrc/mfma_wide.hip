@@ -182,9 +182,45 @@ constexpr bool wide_big_ok(int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG
 // one 64-bit word through the scalar cache (wave-uniform address): counted by lgkmcnt, not by the vmcnt the DMA ring lives on
 __device__ __forceinline__ u64 sload_u64(const u64* p) {
     u64 w;
+#ifdef FSGPU_LAB_SLOAD_NOGLC
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(w) : "s"(p) : "memory");
+#else
     asm volatile("s_load_dwordx2 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(w) : "s"(p) : "memory");   // (glc: past the scalar cache)
+#endif
     return w;
 }
+#ifdef FSGPU_LAB_BITMAP_CHECK
+// lab: every bitmap word of the append path is fetched through the scalar path AND through the vector path; a disagreement is
+// recorded (up to 64 records of 8 words: block, wave, word index, which bitmap, scalar value, vector value, scalar value read
+// again, vector value read again) — scripts/r04/bitmap_soak.py prints them through fsgpu_lab_bitmap_debug
+__device__ unsigned long long g_bm_dbg[64 * 8];
+__device__ unsigned int g_bm_dbg_n;
+__device__ __forceinline__ u64 vload_u64(const u64* p) {
+    u64 w;
+    asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w) : "v"(p) : "memory");
+    return w;
+}
+__device__ __noinline__ void bm_check(const u64* pv, u64 sv, uint32_t wi, int which, int wave) {
+    const uint64_t pa = (uint64_t)(uintptr_t)pv;   // (a function argument arrives in vector registers: back to a scalar pointer)
+    const u64* p = reinterpret_cast<const u64*>((uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pa >> 32)) << 32) |
+                                                            (uint32_t)__builtin_amdgcn_readfirstlane((int)pa)));
+    const u64 vv = vload_u64(p);
+    if (vv == sv) return;
+    if ((threadIdx.x & 63) != (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x & 63)) return;   // first active lane only
+    const unsigned n = atomicAdd(&g_bm_dbg_n, 1u);
+    if (n >= 64) return;
+    const u64 sv2 = sload_u64(p), vv2 = vload_u64(p);
+    unsigned long long* r = g_bm_dbg + n * 8;
+    r[0] = blockIdx.x;
+    r[1] = (unsigned)wave;
+    r[2] = wi;
+    r[3] = (unsigned long long)which | ((unsigned long long)(uintptr_t)p << 8);
+    r[4] = sv;
+    r[5] = vv;
+    r[6] = sv2;
+    r[7] = vv2;
+}
+#endif
 
 template <int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG = 0>
 __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
@@ -446,6 +482,17 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
 #ifdef FSGPU_LAB_VECTOR_BITMAP   // (lab: the r03 state before the scalar loads — waits behind every DMA in flight)
             if (args.live) mask &= __builtin_nontemporal_load(args.live + wi);
             if (args.allow) mask &= __builtin_nontemporal_load(args.allow + wi);
+#elif defined(FSGPU_LAB_BITMAP_CHECK)
+            if (args.live) {
+                const u64 sv = sload_u64(args.live + wi);
+                bm_check(args.live + wi, sv, wi, 0, wave);
+                mask &= sv;
+            }
+            if (args.allow) {
+                const u64 sv = sload_u64(args.allow + wi);
+                bm_check(args.allow + wi, sv, wi, 1, wave);
+                mask &= sv;
+            }
 #else
             if (args.live) mask &= sload_u64(args.live + wi);
             if (args.allow) mask &= sload_u64(args.allow + wi);
@@ -794,6 +841,16 @@ hipError_t launch_wide_d(const MfmaScanArgs& args, int grid, hipStream_t stream,
 }
 
 }  // namespace
+
+#ifdef FSGPU_LAB_BITMAP_CHECK
+extern "C" int fsgpu_lab_bitmap_debug(unsigned long long* out, int cap_records) {
+    unsigned int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_bm_dbg_n), 4) != hipSuccess) return -1;
+    const int take = (int)(n < 64u ? n : 64u) < cap_records ? (int)(n < 64u ? n : 64u) : cap_records;
+    if (take > 0 && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bm_dbg), (size_t)take * 64) != hipSuccess) return -1;
+    return (int)n;
+}
+#endif
 
 bool scan_wide_supported(int dim, int elem_bytes) {
     const int rowb = dim * elem_bytes;

@@ -49,4 +49,15 @@ while time.time() < t_end:
                 print(f"seed {seed - 1} case {case} (dim {dim} n {n} nq {nq} k {k} live {live is not None} allow {allow is not None}) rep {r}: "
                       f"queries {w[:8].tolist()} waves {sorted(set((w % 512 // 64).tolist()))} extra rows {extra} missing rows {missing}", flush=True)
         idx.close()
+# a lab build with -DFSGPU_LAB_BITMAP_CHECK records every bitmap word whose scalar-path value differed from its vector-path value
+import ctypes
+L = fa._lib.lib()
+if hasattr(L, "fsgpu_lab_bitmap_debug"):
+    buf = (ctypes.c_uint64 * (64 * 8))()
+    n = L.fsgpu_lab_bitmap_debug(buf, 64)
+    print(f"bitmap words whose scalar load disagreed with the vector load: {n}")
+    for i in range(max(0, min(n, 64))):
+        r = buf[i * 8:(i + 1) * 8]
+        print(f"  block {r[0]:3d} wave {r[1]} word {r[2]:6d} bitmap {'allow' if r[3] & 0xff else 'live '} addr 0x{r[3] >> 8:x}: scalar 0x{r[4]:016x} "
+              f"vector 0x{r[5]:016x} | again: scalar 0x{r[6]:016x} vector 0x{r[7]:016x} | differing bits {bin(r[4] ^ r[5]).count('1')}")
 print(f"bitmap_soak: {reps_total} repetitions over {cases} indexes in {budget:.0f} s, {bad} differing", flush=True)
