@@ -1056,8 +1056,11 @@ def main() -> None:
         if args.batched and launches:
             # the main-pass kernel against BOTH of its roofs: it streams rows * dim * 2 bytes and contracts them with the
             # queries of its launch on the matrix cores; the roof that asks for more time is the one that bounds it
+            # (a launch of the register-resident-query kernel takes ALL of a step's 512-query groups — gridDim.y passes over the slab —,
+            # so its rows streamed are passes x shard rows while every query still meets every row once)
             q_per_launch = args.steps * B / launches
-            flops = 2.0 * (scan_rows / launches) * args.dim * q_per_launch
+            passes_per_launch = (scan_rows / launches) / max(hi - lo, 1)
+            flops = 2.0 * (hi - lo) * args.dim * q_per_launch
             tflops = flops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
             hbm = dict(line["roofline"])
             if tflops / mfma_peak > achieved / HBM_PEAK_GBPS:
@@ -1065,7 +1068,7 @@ def main() -> None:
                     "bound": "mfma", "achieved": tflops, "peak": mfma_peak, "unit": mfma_unit,
                     "frac": tflops / mfma_peak, "traffic": None,
                     "kernel": "scan_wide_kernel / scan_mfma_kernel (main pass, average over the step's launches)",
-                    "algorithmic_flops_per_launch": flops, "queries_per_launch": q_per_launch,
+                    "algorithmic_flops_per_launch": flops, "queries_per_launch": q_per_launch, "passes_over_the_slab_per_launch": passes_per_launch,
                     "avg_launch_ms": per_launch_ms, "launches": launches,
                     "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                             "algorithmic_bytes_per_launch": alg_bytes},
@@ -1079,8 +1082,9 @@ def main() -> None:
         # The step against its own two roofs: every query group streams the slab once (HBM) and contracts it with its
         # queries on the matrix cores (2 * rows * dim flops per query); the step cannot beat max(bytes / 8 TB/s, flops / peak)
         if args.batched:
-            passes = launches / max(args.steps, 1)
-            t_hbm = passes * alg_bytes / (HBM_PEAK_GBPS * 1e9)
+            launches_per_step = launches / max(args.steps, 1)
+            passes = scan_rows / max(args.steps, 1) / max(hi - lo, 1)   # passes over the slab per step
+            t_hbm = launches_per_step * alg_bytes / (HBM_PEAK_GBPS * 1e9)
             t_mfma = 2.0 * (hi - lo) * args.dim * B / (mfma_peak * 1e12)
             bound_s = max(t_hbm, t_mfma)
             line["roofline"]["joint"] = {

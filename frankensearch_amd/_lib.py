@@ -21,6 +21,7 @@ ERR_DEVICE = 6
 ERR_NO_DEVICE = 7
 ERR_NULL_ARGUMENT = 8
 ERR_EMBEDDING_FAILED = 9
+ERR_MODEL_LOAD_FAILED = 10
 
 ZERO_SIGNAL_NONE = 0
 ZERO_SIGNAL_CALLER_REQUESTED_ZERO_K = 1
@@ -105,6 +106,7 @@ SIGNATURES = {
     "fsgpu_m2v_dimension": (_u32, [_vp]),
     "fsgpu_m2v_embed": (_i32, [_vp, _vp, _vp, _u32, _vp]),
     "fsgpu_bert_create": (_i32, [_i32, _vp, _vp, C.POINTER(_vp)]),
+    "fsgpu_bert_create_safetensors": (_i32, [_i32, _vp, _u64, C.c_float, C.POINTER(_vp)]),
     "fsgpu_bert_destroy": (None, [_vp]),
     "fsgpu_bert_dimension": (_u32, [_vp]),
     "fsgpu_bert_embed": (_i32, [_vp, _vp, _vp, _u32, _vp]),

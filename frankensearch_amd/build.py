@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libfsgpu.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 SOURCES = ["scan_kernels.hip", "scan_mq_kernel.hip", "int8_kernels.hip", "f32_kernels.hip", "mfma_scan.hip", "mfma_wide.hip", "sort_general.hip", "m2v_kernels.hip", "bert_kernels.hip", "bert_gemm_w.hip", "bert_docs_w.hip", "bert_query_kernels.hip", "bench_fixture.hip", "vector_index.cpp", "two_tier_index.cpp", "sharded_index.cpp",
-           "bert_embedder.cpp", "fusion.cpp", "fsgpu_api.cpp"]
+           "bert_embedder.cpp", "safetensors.cpp", "fusion.cpp", "fsgpu_api.cpp"]
 HEADERS = ["device_util.hpp", "scan_common.hpp", "kernels.hpp", "vector_index.hpp", "bert_embedder.hpp", "coalescer.hpp", "sharded_index.hpp", "two_tier_index.hpp", "lab_env.hpp"]
 # libfshost.so: the C++ host-side mirror of the reference's two-tier searcher, over the C ABI only (include/fshost.h)
 HOST_LIB = os.path.join(HERE, "libfshost.so")
@@ -38,11 +38,33 @@ def _hipcc() -> str:
     return "hipcc"
 
 
-def _stale(target: str, deps: list[str]) -> bool:
-    if not os.path.exists(target):
+def _digest(paths: list[str], extra: str = "") -> str:
+    """sha256 over the CONTENT of the inputs (and the command line that turns them into the target): a copy of the tree to another
+    machine — the GPU box — changes every mtime and no content, and must rebuild exactly what its sources no longer match."""
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        h.update(os.path.basename(p).encode())
+        if os.path.exists(p):
+            with open(p, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
+def _stale(target: str, deps: list[str], extra: str = "") -> bool:
+    """The target is missing, or the digest recorded next to it (<target>.sha256) is not that of its inputs."""
+    stamp = target + ".sha256"
+    if not os.path.exists(target) or not os.path.exists(stamp):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    try:
+        return open(stamp).read().strip() != _digest(deps, extra)
+    except OSError:
+        return True
+
+
+def _record(target: str, deps: list[str], extra: str = "") -> None:
+    with open(target + ".sha256", "w") as f:
+        f.write(_digest(deps, extra))
 
 
 def _extra_defs() -> list[str]:
@@ -53,49 +75,47 @@ def _extra_defs() -> list[str]:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    # objects built with other definitions are stale
-    stamp = os.path.join(OBJ, "defs.txt")
-    defs = " ".join(_extra_defs())
-    old = open(stamp).read() if os.path.exists(stamp) else ""
-    if old != defs:
-        force = True
     sources = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    common = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "fsgpu.h"), __file__]
+    # (every object depends on every header: the kernels' argument structs and the C ABI are shared)
+    common = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "fsgpu.h")]
     hipcc = _hipcc()
 
     def compile_one(src: str) -> str:
         obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         path = os.path.join(CSRC, src)
-        if force or _stale(obj, [path] + common):
-            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + _extra_defs() + ["-I", INCLUDE, "-c", path, "-o", obj]
+        flags = FLAGS + EXTRA_FLAGS.get(src, []) + _extra_defs()   # lab definitions are part of the digest: other defs, other object
+        if force or _stale(obj, [path] + common, " ".join(flags)):
+            cmd = [hipcc] + flags + ["-I", INCLUDE, "-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
+            _record(obj, [path] + common, " ".join(flags))
         return obj
 
     with ThreadPoolExecutor(max_workers=min(4, len(sources))) as pool:
         objs = list(pool.map(compile_one, sources))
-    if force or _stale(LIB, objs):
+    stamps = [o + ".sha256" for o in objs]   # the library is its objects: linked again when any object was rebuilt
+    if force or _stale(LIB, stamps):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-pthread"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
-    with open(stamp, "w") as f:
-        f.write(defs)
+        _record(LIB, stamps)
     build_host(force, verbose)
     return LIB
 
 
 def build_host(force: bool = False, verbose: bool = False) -> str:
     """g++ only: libfshost.so has no device code; it links libfsgpu.so (found next to it through $ORIGIN)."""
-    deps = [os.path.join(CSRC, s) for s in HOST_SOURCES + HOST_HEADERS] + [os.path.join(INCLUDE, "fshost.h"),
-                                                                           os.path.join(INCLUDE, "fsgpu.h"), LIB, __file__]
-    if force or _stale(HOST_LIB, deps):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread", "-I", INCLUDE, "-o", HOST_LIB] + \
-              [os.path.join(CSRC, s) for s in HOST_SOURCES] + ["-L", HERE, "-lfsgpu", "-Wl,-rpath,$ORIGIN"]
+    # (libfshost links libfsgpu by name and calls it through the C ABI only: it depends on the headers, not on the library's bytes)
+    deps = [os.path.join(CSRC, s) for s in HOST_SOURCES + HOST_HEADERS] + [os.path.join(INCLUDE, "fshost.h"), os.path.join(INCLUDE, "fsgpu.h")]
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread", "-I", INCLUDE, "-o", HOST_LIB] + \
+          [os.path.join(CSRC, s) for s in HOST_SOURCES] + ["-L", HERE, "-lfsgpu", "-Wl,-rpath,$ORIGIN"]
+    if force or _stale(HOST_LIB, deps, " ".join(cmd)):
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+        _record(HOST_LIB, deps, " ".join(cmd))
     return HOST_LIB
 
 

@@ -18,6 +18,9 @@ class NativeEmbedder {
   public:
     ~NativeEmbedder();
     SearchError init(int device, const fsgpu_bert_config& cfg, const fsgpu_bert_weights& w);
+    // NativeEmbedder::load's weight contract: a safetensors blob in HuggingFace key layout (safetensors.cpp; parse_weights,
+    // crates/frankensearch-rerank/src/native.rs:1359-1602).  device < 0 validates the blob only.
+    SearchError init_safetensors(int device, const void* blob, uint64_t blob_len, float ln_eps);
     // ids: concatenated token ids; text i owns ids[offsets[i]..offsets[i+1]).  out: [n, hidden] f32.
     SearchError embed_batch(const int32_t* ids, const uint32_t* offsets, uint32_t n, float* out);
     uint32_t dimension() const { return cfg_.hidden; }

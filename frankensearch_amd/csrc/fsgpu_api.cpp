@@ -1164,6 +1164,25 @@ fsgpu_status fsgpu_bert_create(int32_t device, const fsgpu_bert_config* config, 
     });
 }
 
+fsgpu_status fsgpu_bert_create_safetensors(int32_t device, const void* blob, uint64_t blob_len, float ln_eps, fsgpu_bert** out) {
+    if (!out || !blob) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    *out = nullptr;
+    return guarded([&]() -> fsgpu_status {
+        auto h = std::make_unique<fsgpu_bert>();
+        // the blob first (a malformed model file is reported as such on any host), then the device
+        fsgpu::SearchError e = h->impl.init_safetensors(-1, blob, blob_len, ln_eps);
+        if (!e.ok()) return finish(e);
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+            return fail(FSGPU_ERR_NO_DEVICE, "no HIP device visible (libfsgpu has no CPU fallback)");
+        if (device < 0 || device >= count) return fail(FSGPU_ERR_INVALID_CONFIG, "device ordinal out of range");
+        e = h->impl.init_safetensors(device, blob, blob_len, ln_eps);
+        if (!e.ok()) return finish(e);
+        *out = h.release();
+        return FSGPU_OK;
+    });
+}
+
 void fsgpu_bert_destroy(fsgpu_bert* m) { delete m; }
 uint32_t fsgpu_bert_dimension(const fsgpu_bert* m) { return m ? m->impl.dimension() : 0; }
 

@@ -131,6 +131,8 @@ struct SelectArgs {
     const uint32_t* spill_count;  // [nq * kMfmaSpillCountStride]
     uint32_t spill_cap;
     uint32_t k;                // 1..kSelectMaxK
+    uint32_t* spill_reset;     // [nq * kMfmaSpillCountStride] (may be null) the query's spill counter is ZEROED once this selection has
+                               // read what it needs: the next scan stage appends from 0 again — no memset launch between the stages
     const float* delta;        // [nq] error bound; < 0 = query is skipped (tau = +inf, overflow set)
     float* tau_out;            // [nq] (may be null)
     u64* pool_out;             // [nq, kSelectPool] candidates, kEmpty padded (may be null)

@@ -400,6 +400,10 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
     const int q = blockIdx.x;
     SEL_STAMP(0);
     if (args.big_pool && args.pool_flag && args.pool_flag[q] == 0) return;   // second chance: only the queries the first finish flagged
+    // (called where every thread is past the barriers behind its read of the spill count)
+    auto reset_spill = [&]() {
+        if (tid == 0 && args.spill_reset) args.spill_reset[(size_t)q * kMfmaSpillCountStride] = 0u;
+    };
     const int k = (int)args.k;
     // Everything the block needs first is REQUESTED first, in one round trip: the list lengths, the entries of the lists' first four
     // slots (speculatively — most lists hold fewer than four; what lies beyond a list's length is masked once the lengths are in), the
@@ -534,7 +538,10 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
             if (args.tau_out) args.tau_out[q] = t;
         }
         __syncthreads();
-        if (!FINISH && !args.pool_out && !args.cand_counts) return;
+        if (!FINISH && !args.pool_out && !args.cand_counts) {
+            reset_spill();
+            return;
+        }
         const float tau = s_tau;
         if (args.take_topk) {
             ncand = cnt < k ? cnt : k;  // exact scores: the candidates are the k best entries themselves
@@ -651,7 +658,10 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
         }
         __syncthreads();
         SEL_STAMP(4);
-        if (!FINISH && !args.pool_out && !args.cand_counts) return;
+        if (!FINISH && !args.pool_out && !args.cand_counts) {
+            reset_spill();
+            return;
+        }
         const float tau = s_tau;
         for (int p = 0; p < npass; ++p) {
             if (npass > 1) load_pass(p, e);  // a single pass still has its entries in registers
@@ -693,6 +703,7 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
         else if (ncand > pool_cap && args.overflow) args.overflow[q] = 1;
     }
     if (args.pool_out) args.pool_out[(size_t)q * POOL + tid] = pool[tid];
+    if constexpr (!FINISH) reset_spill();
     if constexpr (FINISH) {
         if (args.cand_approx_out && args.take_topk && tid < k) args.cand_approx_out[(size_t)q * args.cand_out_stride + tid] = pool[tid];
         // exact-order re-score (dot_product_f16_bytes_f32 order, as gather_dot_kernel): one quad per candidate,

@@ -250,6 +250,20 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     constexpr bool NT4 = NEGTAU && !SPLIT && QT * KS * 4 + 4 * CK * 4 + 12 * QT <= 200 && QT * KS * 4 <= 96;
     constexpr int TILE_BYTES = TR * ROWB;
     constexpr int NQ = WPB * QT * 16;
+    if (gridDim.y > 1) {
+        // several query groups in ONE launch (args.groups = gridDim.y): group g's queries / thresholds / lists / spill area follow group
+        // g - 1's, its blocks take over the CUs as the previous group's blocks leave them (one block per CU is resident) — no launch
+        // ramp and no chip-wide tail between two passes over the slab; consecutive groups walk the slab in opposite directions
+        const uint32_t grp = blockIdx.y;
+        args.queries = static_cast<const unsigned char*>(args.queries) + (size_t)grp * NQ * ROWB;
+        args.tau += (size_t)grp * NQ;
+        args.cand += (size_t)grp * NQ * gridDim.x * args.slots;
+        if (args.cand_count) args.cand_count += (size_t)grp * NQ * gridDim.x;
+        args.spill += (size_t)grp * NQ * args.spill_cap;
+        args.spill_count += (size_t)grp * NQ * kMfmaSpillCountStride;
+        args.overflow += (size_t)grp * NQ;
+        args.reverse ^= grp & 1u;
+    }
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const uint32_t ring = (uint32_t)(uintptr_t)smem;                // LDS byte address of the ring (low half of the flat address)
     int* lcnt = reinterpret_cast<int*>(smem + (size_t)NSLOT * TILE_BYTES);   // entries appended per query by this block
@@ -779,7 +793,7 @@ hipError_t launch_wide_t(const MfmaScanArgs& args, int grid, hipStream_t stream,
     static const std::string name = "scan_wide_kernel<" + std::to_string(ROWB) + ", " + std::to_string(EB) + ", " +
                                     std::to_string(QT) + ", " + std::to_string(NSLOT) + ", " + std::to_string(OPT) + ">";
     if (DBG != 3) note_main_pass_kernel(name.c_str());
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, args);
+    hipLaunchKernelGGL(kern, dim3(grid, args.groups ? args.groups : 1), dim3(512), lds, stream, args);
     return hipGetLastError();
 }
 

@@ -1722,6 +1722,7 @@ SearchError VectorIndex::batched_sample(const BatchedPlan& p, BatchedRound& r) {
         sa.anchor_unit = p.unit;
     }
     sa.valid_queries = r.ng;   // (the launch covers the round's padded query slots)
+    sa.spill_reset = p.spill_count;   // the round's spill counters start at zero for the stage that follows (B, or the main pass)
     FSGPU_HIP(launch_select(sa, (int)QP, stream));
     // stage B: the B sample's rows at or above tau, one short list per (query, block) -> tighter tau; the rows
     // still at or above it form the pool carried into the last selection
@@ -1736,21 +1737,18 @@ SearchError VectorIndex::batched_sample(const BatchedPlan& p, BatchedRound& r) {
     const int wide_grid_b = std::min(r.wide_grid, (int)std::max<uint32_t>(1, RB / 64 / 4));   // at least 4 sample groups per block
     if (wide_b) a.slots = knobs().slots_b > 0 ? (uint32_t)knobs().slots_b : r.short_stages ? 8 : kWideSlots;
     if (!skip_b) {
-        FSGPU_HIP(hipMemsetAsync(p.spill_count, 0, (size_t)QP * kMfmaSpillCountStride * 4, stream));
         if (wide_b) {
-            const uint32_t GM = r.G * r.wide_mult;
-            for (uint32_t j = 0; j < r.ngroups / r.wide_mult; ++j) {
-                MfmaScanArgs c = a;
-                c.groups = 1;
-                c.queries = static_cast<const unsigned char*>(mf_qh_.ptr) + (size_t)j * GM * dim_ * (i8 ? 1 : 2);
-                c.tau = p.tau + (size_t)j * GM;
-                c.cand = r.cand + (size_t)j * GM * wide_grid_b * a.slots;
-                c.cand_count = r.cand_count + (size_t)j * GM * wide_grid_b;
-                c.spill = p.spill + (size_t)j * GM * SPILL;
-                c.spill_count = p.spill_count + (size_t)j * GM * kMfmaSpillCountStride;
-                c.overflow = r.overflow + (size_t)j * GM;
-                FSGPU_HIP(launch_scan_wide(c, r.wide_qt, wide_grid_b, stream, nullptr));
-            }
+            // ONE launch for all the round's main-pass groups (gridDim.y: group g's arrays follow group g - 1's, mfma_wide.hip)
+            MfmaScanArgs c = a;
+            c.groups = r.ngroups / r.wide_mult;
+            c.queries = mf_qh_.ptr;
+            c.tau = p.tau;
+            c.cand = r.cand;
+            c.cand_count = r.cand_count;
+            c.spill = p.spill;
+            c.spill_count = p.spill_count;
+            c.overflow = r.overflow;
+            FSGPU_HIP(launch_scan_wide(c, r.wide_qt, wide_grid_b, stream, nullptr));
         } else {
             FSGPU_HIP(launch_scan_mfma(a, r.shape, grid_b, stream, nullptr));
         }
@@ -1780,7 +1778,9 @@ SearchError VectorIndex::batched_sample(const BatchedPlan& p, BatchedRound& r) {
         }
         if (heur_b) sb.tau_floor_in = p.tau_floor;
         sb.valid_queries = r.ng;   // (the launch covers the round's padded query slots)
+        sb.spill_reset = p.spill_count;   // ... and at zero again for the main pass
         FSGPU_HIP(launch_select(sb, (int)QP, stream));
+        sb.spill_reset = nullptr;
         sb.valid_queries = 0;
         sb.anchor_unit = nullptr;
         sb.tau_floor_in = nullptr;
@@ -1812,12 +1812,42 @@ SearchError VectorIndex::batched_main(const BatchedPlan& p, BatchedRound& r) {
                            : p.ksel_est > 32 ? (r.short_stages && p.i8f ? 16 : kWideSlots)
                                              : std::min<uint32_t>(16, std::max<uint32_t>(8, (CAPQ - KC) / (uint32_t)main_grid)))
                         : r.slots_for(r.full_grid);
-    FSGPU_HIP(hipMemsetAsync(p.spill_count, 0, (size_t)r.QP * kMfmaSpillCountStride * 4, stream));
+    // (the spill counters were zeroed by the selection in front of this stage: SelectArgs::spill_reset)
     a.groups = 1;
     // one pass over the slab per query group, one launch each (all groups in one launch — a group's blocks taking
     // over the CUs the previous group's leave — measured 1.5 % slower at 10M rows: two groups' streams interleave)
     const uint32_t GM = r.G * r.wide_mult;  // queries per main-pass launch
-    for (uint32_t j = 0; j < r.ngroups / r.wide_mult; ++j) {
+    // The register-resident-query kernel takes ALL the round's groups in one launch (gridDim.y = passes over the slab): a group's
+    // blocks start on a CU as the previous group's block leaves it, so a step pays one launch ramp and one chip-wide tail instead of
+    // one per 512 queries — what a 1.25M-row shard, whose pass is 0.2 ms, feels most.
+    const uint32_t wide_groups = r.wide_qt ? r.ngroups / r.wide_mult : 0;
+    if (wide_groups) {
+        MfmaScanArgs c = a;
+        c.groups = wide_groups;
+        c.queries = mf_qh_.ptr;
+        c.tau = p.tau;
+        c.cand = r.cand;
+        c.cand_count = r.cand_count;
+        c.spill = p.spill;
+        c.spill_count = p.spill_count;
+        c.overflow = r.overflow;
+        c.reverse = knobs().no_reverse ? 0 : (mf_pass_parity_ & 1);   // group g walks in direction (parity + g) & 1
+        mf_pass_parity_ += wide_groups;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (profiling) {
+            FSGPU_HIP(hipEventCreate(&e0));
+            FSGPU_HIP(hipEventCreate(&e1));
+            FSGPU_HIP(hipEventRecord(e0, stream));
+        }
+        FSGPU_HIP(launch_scan_wide(c, r.wide_qt, main_grid, stream, nullptr));
+        if (profiling) {
+            FSGPU_HIP(hipEventRecord(e1, stream));
+            events_.emplace_back(e0, e1);
+            profiled_rows_ += (uint64_t)p.N * wide_groups;   // every group streams the whole slab
+            profiled_elem_bytes_ = p.i8 ? 1 : 2;
+        }
+    }
+    for (uint32_t j = 0; !wide_groups && j < r.ngroups / r.wide_mult; ++j) {
         MfmaScanArgs c = a;
         c.queries = static_cast<const unsigned char*>(mf_qh_.ptr) + (size_t)j * GM * dim_ * (p.i8 ? 1 : 2);
         c.tau = p.tau + (size_t)j * GM;

@@ -131,9 +131,23 @@ class NativeEmbedder:
         self._h = h
 
     @classmethod
-    def from_safetensors(cls, path: str, device: int = 0) -> "NativeEmbedder":
-        from safetensors.numpy import load_file
-        return cls(load_file(path), device=device)
+    def from_safetensors(cls, path: str, device: int = 0, ln_eps: float = 1e-12) -> "NativeEmbedder":
+        """NativeEmbedder::load (native_embedder.rs:60-116): the model file goes to the library as it is — the safetensors header and
+        the HuggingFace key layout are parsed behind the C ABI (fsgpu_bert_create_safetensors = parse_weights, native.rs:1359-1602)."""
+        with open(path, "rb") as f:
+            return cls.from_safetensors_bytes(f.read(), device=device, ln_eps=ln_eps)
+
+    @classmethod
+    def from_safetensors_bytes(cls, blob: bytes, device: int = 0, ln_eps: float = 1e-12) -> "NativeEmbedder":
+        buf = np.frombuffer(blob, dtype=np.uint8)   # (numpy's buffer of a bytes object is 16-byte aligned past its header: checked by the library)
+        if buf.ctypes.data % 8:
+            buf = np.require(buf.copy(), requirements=["ALIGNED"])
+        self = cls.__new__(cls)
+        h = C.c_void_p()
+        check(_lib.lib().fsgpu_bert_create_safetensors(device, buf.ctypes.data, buf.size, ln_eps, C.byref(h)))
+        self._h = h
+        self._dim = int(_lib.lib().fsgpu_bert_dimension(h))
+        return self
 
     def dimension(self) -> int:
         return self._dim

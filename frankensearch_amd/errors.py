@@ -44,8 +44,12 @@ class EmbeddingFailed(SearchError):
     code = _lib.ERR_EMBEDDING_FAILED
 
 
+class ModelLoadFailed(SearchError):
+    code = _lib.ERR_MODEL_LOAD_FAILED
+
+
 _BY_CODE = {c.code: c for c in (DimensionMismatch, InvalidConfig, IndexCorrupted, IndexVersionMismatch, IoError,
-                                DeviceError, NoDevice, NullArgument, EmbeddingFailed)}
+                                DeviceError, NoDevice, NullArgument, EmbeddingFailed, ModelLoadFailed)}
 
 
 def check(status: int) -> None:

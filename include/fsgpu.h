@@ -44,6 +44,7 @@ typedef int32_t fsgpu_status;
 #define FSGPU_ERR_NO_DEVICE 7              /* no gfx950 device visible */
 #define FSGPU_ERR_NULL_ARGUMENT 8
 #define FSGPU_ERR_EMBEDDING_FAILED 9       /* SearchError::EmbeddingFailed */
+#define FSGPU_ERR_MODEL_LOAD_FAILED 10     /* SearchError::ModelLoadFailed{path,source} */
 
 /* ZeroSignalReason of search_top_k_classified (search.rs:227-261). */
 #define FSGPU_ZERO_SIGNAL_NONE 0
@@ -403,6 +404,15 @@ fsgpu_status fsgpu_m2v_embed(fsgpu_m2v *m, const uint32_t *ids, const uint32_t *
 /* NativeEmbedder::load (native_embedder.rs:60-116): copies the weights to the GPU (linears as f16). */
 fsgpu_status fsgpu_bert_create(int32_t device, const fsgpu_bert_config *config, const fsgpu_bert_weights *weights,
                                fsgpu_bert **out);
+/* The same from the model file itself — NativeEmbedder::load -> parse_weights (native.rs:1359-1602): `blob` is a safetensors file
+ * (8-byte little-endian header length, JSON header, tensor bytes) in HuggingFace key layout.  F32 tensors only are read (I64
+ * position_ids etc. are skipped); bare `embeddings.*` / `encoder.*` keys count as `bert.`-prefixed; pooler / classifier tensors
+ * are ignored.  The model's shape comes from the tensors (vocab x hidden, layers by counting, inter, heads = hidden / 32, max_pos =
+ * min(rows of the position table, 512)); ln_eps <= 0 means 1e-12.  A malformed blob / a missing or mis-shaped tensor is
+ * FSGPU_ERR_MODEL_LOAD_FAILED with the reference's wording in fsgpu_last_error(); the blob is validated BEFORE a device is looked
+ * for.  The tensor data must be 4-byte aligned in `blob` (it is when the file is read into a buffer malloc returned: the header
+ * is padded to 8 bytes). */
+fsgpu_status fsgpu_bert_create_safetensors(int32_t device, const void *blob, uint64_t blob_len, float ln_eps, fsgpu_bert **out);
 void fsgpu_bert_destroy(fsgpu_bert *m);
 uint32_t fsgpu_bert_dimension(const fsgpu_bert *m); /* Embedder::dimension: the model's hidden size */
 /* embed_batch_sync over token ids (native_embedder.rs:218-255 -> Model::embed_forward native.rs:1142-1236):

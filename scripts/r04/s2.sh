@@ -1,7 +1,8 @@
 #!/bin/bash
 # GPU session 2 of round 4: new two-tier / sharded tests, diagnostic soaks of the bitmap loads, flags A/B, adversarial corpora, gloo rehearsal
 O=gpurun_out/r04s2; mkdir -p $O
-( time python -m pytest tests/test_gpu_two_tier.py tests/test_gpu_sharded.py tests/test_gpu_config3_fullsize.py -m gpu -x -q ) > $O/pytest_new.txt 2>&1; tail -15 $O/pytest_new.txt
+( time python -m pytest tests/test_gpu_two_tier.py tests/test_gpu_sharded.py tests/test_gpu_int8_filter.py tests/test_gpu_config3_fullsize.py -m gpu -x -q ) > $O/pytest_new.txt 2>&1; tail -15 $O/pytest_new.txt
+python scripts/fuzz_batched.py 91 60 > $O/fuzz_batched.txt 2>&1; tail -2 $O/fuzz_batched.txt
 cp frankensearch_amd/libfsgpu.so /tmp/base.so
 cp frankensearch_amd/libfsgpu_variant_bmcheck.so frankensearch_amd/libfsgpu.so
 python scripts/r04/bitmap_soak.py 480 100 > $O/soak_bmcheck.txt 2>&1; echo "== bmcheck"; tail -40 $O/soak_bmcheck.txt
@@ -21,3 +22,4 @@ for kname, a in d["adversarial_corpora"].items():
     print(kname, {x: a[x] for x in ("queries_per_sec", "int8_filter_active_after", "int8_filter_queries", "refiltered_on_f16_queries", "exact_fallback_queries", "batched_equals_oracle_rows_and_bits", "batched_equals_exact_kernels_64_queries")})
 PY
 ( time FSGPU_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --warmup 3 --config5-rows 6000000 ) > $O/rehearsal_gloo2.txt 2>&1; tail -c 3000 $O/rehearsal_gloo2.txt
+( time python -m pytest tests -m gpu -q -x ) > $O/pytest_all.txt 2>&1; tail -8 $O/pytest_all.txt

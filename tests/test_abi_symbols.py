@@ -106,3 +106,70 @@ def test_product_never_imports_oracle():
                 assert "fs_oracle" not in text and "fso_" not in text, f
                 if f.endswith(".py"):
                     assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
+
+
+def _safetensors_blob(tensors, metadata=None):
+    """A safetensors file image: 8-byte little-endian header length, JSON header (padded with spaces to 8 bytes), tensor bytes."""
+    import json
+    import struct
+    header, data, off = {}, b"", 0
+    if metadata:
+        header["__metadata__"] = metadata
+    for name, arr in tensors.items():
+        raw = np.ascontiguousarray(arr).tobytes()
+        dtype = {"float32": "F32", "int64": "I64", "float16": "F16"}[str(arr.dtype)]
+        header[name] = {"dtype": dtype, "shape": list(arr.shape), "data_offsets": [off, off + len(raw)]}
+        data += raw
+        off += len(raw)
+    h = json.dumps(header, separators=(",", ":")).encode()
+    h += b" " * ((8 - len(h) % 8) % 8)
+    return struct.pack("<Q", len(h)) + h + data
+
+
+def _tiny_bert_tensors(prefix="", hidden=64, layers=2, inter=128, vocab=50, max_pos=40):
+    rng = np.random.default_rng(0)
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)
+    t = {f"{prefix}embeddings.word_embeddings.weight": f(vocab, hidden), f"{prefix}embeddings.position_embeddings.weight": f(max_pos, hidden),
+         f"{prefix}embeddings.token_type_embeddings.weight": f(2, hidden), f"{prefix}embeddings.LayerNorm.weight": f(hidden),
+         f"{prefix}embeddings.LayerNorm.bias": f(hidden), f"{prefix}embeddings.position_ids": np.arange(max_pos, dtype=np.int64)[None, :]}
+    for l in range(layers):
+        p = f"{prefix}encoder.layer.{l}."
+        for nm in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense"):
+            t[p + nm + ".weight"], t[p + nm + ".bias"] = f(hidden, hidden), f(hidden)
+        t[p + "intermediate.dense.weight"], t[p + "intermediate.dense.bias"] = f(inter, hidden), f(inter)
+        t[p + "output.dense.weight"], t[p + "output.dense.bias"] = f(hidden, inter), f(hidden)
+        for nm in ("attention.output.LayerNorm", "output.LayerNorm"):
+            t[p + nm + ".weight"], t[p + nm + ".bias"] = f(hidden), f(hidden)
+    return t
+
+
+def test_safetensors_blob_is_validated_before_a_device_is_needed():
+    """fsgpu_bert_create_safetensors = NativeEmbedder::load -> parse_weights (native.rs:1359-1602): a malformed model file is a
+    ModelLoadFailed on any host (the blob is parsed first); a well-formed one then asks for the GPU (NoDevice here)."""
+    import torch
+    import frankensearch_amd as fa
+
+    good = _safetensors_blob(_tiny_bert_tensors(), metadata={"format": "pt"})
+    good_prefixed = _safetensors_blob(_tiny_bert_tensors("bert."))
+    if not torch.cuda.is_available():
+        for blob in (good, good_prefixed):
+            with pytest.raises(fa.NoDevice):
+                fa.NativeEmbedder.from_safetensors_bytes(blob)
+    cases = {
+        "too small": b"\x01\x02",
+        "header length out of range": (1 << 40).to_bytes(8, "little") + b"{}",
+        "not an object": (2).to_bytes(8, "little") + b"[]",
+        "no F32 tensors": _safetensors_blob({"embeddings.position_ids": np.arange(4, dtype=np.int64)}),
+        "missing tensor": _safetensors_blob({k: v for k, v in _tiny_bert_tensors().items() if "layer.1.output.dense.bias" not in k}),
+        "bad shape": _safetensors_blob({**_tiny_bert_tensors(), "encoder.layer.0.attention.self.key.weight": np.zeros((64, 32), np.float32)}),
+        "hidden not a multiple of 32": _safetensors_blob(_tiny_bert_tensors(hidden=48)),
+    }
+    for why, blob in cases.items():
+        with pytest.raises(fa.ModelLoadFailed) as err:
+            fa.NativeEmbedder.from_safetensors_bytes(blob)
+        assert str(err.value), why
+    # out-of-range data offsets
+    t = _tiny_bert_tensors()
+    blob = bytearray(_safetensors_blob(t))
+    with pytest.raises(fa.ModelLoadFailed):
+        fa.NativeEmbedder.from_safetensors_bytes(bytes(blob[:len(blob) - 64]))

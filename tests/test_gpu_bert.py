@@ -200,3 +200,31 @@ def test_one_launch_path_outlier_weights_and_large_calls(fa):
     again = m.embed_batch_token_ids(many)
     assert np.array_equal(whole.view(np.uint32), again.view(np.uint32))
     check(whole[:16], ref.run(many[:16], 8))
+
+
+def test_model_file_blob_gives_the_same_embedder_as_the_tensor_struct(fa, tmp_path):
+    """fsgpu_bert_create_safetensors (NativeEmbedder::load -> parse_weights, native.rs:1359-1602): a safetensors file in the bare
+    sentence-transformers key layout and one in the `bert.`-prefixed cross-encoder layout (with position_ids, pooler tensors and
+    metadata in them) give bit for bit the embeddings of fsgpu_bert_create over the same tensors."""
+    from safetensors.numpy import save_file
+    from oracle import bert_oracle
+
+    w = bert_oracle.random_weights(11, 700, 128, 2, 512)
+    ref = fa.NativeEmbedder(w)
+    texts = [[101] + list(range(10, 40)) + [102], [101, 7, 8, 102], list(range(100, 160)), []]
+    want = ref.embed_batch_token_ids(texts)
+    for prefix in ("", "bert."):
+        tensors = {}
+        for k, v in w.items():
+            bare = k[len("bert."):] if k.startswith("bert.") else k
+            tensors[prefix + bare] = np.ascontiguousarray(v, dtype=np.float32)
+        tensors[prefix + "embeddings.position_ids"] = np.arange(512, dtype=np.int64)[None, :]
+        tensors[prefix + "pooler.dense.weight"] = np.zeros((128, 128), np.float32)
+        path = str(tmp_path / f"model_{len(prefix)}.safetensors")
+        save_file(tensors, path, metadata={"format": "pt"})
+        enc = fa.NativeEmbedder.from_safetensors(path)
+        assert enc.dimension() == 128
+        got = enc.embed_batch_token_ids(texts)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), prefix
+        enc.close()
+    ref.close()
