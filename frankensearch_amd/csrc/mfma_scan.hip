@@ -703,7 +703,7 @@ __global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(Sel
         else if (ncand > pool_cap && args.overflow) args.overflow[q] = 1;
     }
     if (args.pool_out) args.pool_out[(size_t)q * POOL + tid] = pool[tid];
-    if constexpr (!FINISH) reset_spill();
+    reset_spill();   // (threshold steps of either kind — a sample stage's selection with an exact anchor is a FINISH instantiation)
     if constexpr (FINISH) {
         if (args.cand_approx_out && args.take_topk && tid < k) args.cand_approx_out[(size_t)q * args.cand_out_stride + tid] = pool[tid];
         // exact-order re-score (dot_product_f16_bytes_f32 order, as gather_dot_kernel): one quad per candidate,

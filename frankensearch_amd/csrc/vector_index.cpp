@@ -1820,7 +1820,11 @@ SearchError VectorIndex::batched_main(const BatchedPlan& p, BatchedRound& r) {
     // The register-resident-query kernel takes ALL the round's groups in one launch (gridDim.y = passes over the slab): a group's
     // blocks start on a CU as the previous group's block leaves it, so a step pays one launch ramp and one chip-wide tail instead of
     // one per 512 queries — what a 1.25M-row shard, whose pass is 0.2 ms, feels most.
+#ifdef FSGPU_LAB_SPLIT_LAUNCHES   // lab: one launch per 512-query group, as before round 4 (same-box A/B of the merged launch)
+    const uint32_t wide_groups = 0;
+#else
     const uint32_t wide_groups = r.wide_qt ? r.ngroups / r.wide_mult : 0;
+#endif
     if (wide_groups) {
         MfmaScanArgs c = a;
         c.groups = wide_groups;
@@ -1863,8 +1867,12 @@ SearchError VectorIndex::batched_main(const BatchedPlan& p, BatchedRound& r) {
             FSGPU_HIP(hipEventCreate(&e1));
             FSGPU_HIP(hipEventRecord(e0, stream));
         }
-        if (r.wide_qt) FSGPU_HIP(launch_scan_wide(c, r.wide_qt, main_grid, stream, nullptr));
-        else FSGPU_HIP(launch_scan_mfma(c, r.shape, r.full_grid, stream, nullptr));
+        if (r.wide_qt) {
+            c.groups = 1;
+            FSGPU_HIP(launch_scan_wide(c, r.wide_qt, main_grid, stream, nullptr));
+        } else {
+            FSGPU_HIP(launch_scan_mfma(c, r.shape, r.full_grid, stream, nullptr));
+        }
         if (profiling) {
             FSGPU_HIP(hipEventRecord(e1, stream));
             events_.emplace_back(e0, e1);
