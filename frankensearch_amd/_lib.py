@@ -61,6 +61,11 @@ SIGNATURES = {
     "fsgpu_index_wal_record_count": (_u64, [_vp]),
     "fsgpu_index_set_live_bitmap": (_i32, [_vp, _vp]),
     "fsgpu_search_topk": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "fsgpu_allow_bitmap_create": (_i32, [_vp, _vp, C.POINTER(_vp)]),
+    "fsgpu_allow_bitmap_destroy": (None, [_vp]),
+    "fsgpu_allow_bitmap_allowed_rows": (_u64, [_vp]),
+    "fsgpu_search_topk_filtered": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "fsgpu_search_topk_batched_filtered": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, C.POINTER(_u32)]),
     "fsgpu_search_topk_device": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp]),
     "fsgpu_search_topk_batched": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, C.POINTER(_u32)]),
     "fsgpu_search_topk_batched_device": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u32)]),

@@ -29,6 +29,7 @@ struct SearchCall : CoalescedCall {
     uint32_t k = 0;
     uint32_t int8_mult = 0;  // 0 = exact search, else search_top_k_int8_two_pass with this multiplier
     const uint64_t* allow = nullptr;  // the caller's allow bitmap (host words): calls that pass the SAME bitmap share a batch
+    const uint64_t* allow_dev = nullptr;  // its resident device copy (fsgpu_allow_bitmap), if the caller keeps one
     uint32_t* out_rows = nullptr;
     float* out_scores = nullptr;
     uint32_t* out_count = nullptr;
@@ -56,6 +57,12 @@ struct fsgpu_index {
 };
 struct fsgpu_alignment {
     fsgpu::QualityAlignment impl;
+};
+struct fsgpu_allow_bitmap {   // a precomputed SearchFilter resident on an index's device
+    int device = -1;
+    uint64_t nrows = 0, allowed = 0;
+    std::vector<uint64_t> words;   // host copy: the selectivity rule (1/50) and the coalescer's batch key
+    fsgpu::DeviceBuffer dev;
 };
 struct fsgpu_sharded {
     fsgpu::ShardedIndex impl;
@@ -140,13 +147,14 @@ void run_embed_batch(Handle* h, uint32_t dim, std::vector<EmbedCall<Id>*>& batch
 // One single-query call parked in the index's coalescer: concurrent callers ride one batched pass (results are
 // bit-identical to the direct path).  int8_mult 0 = exact search, else the int8 two-pass with that multiplier.
 fsgpu_status coalesced_search(fsgpu_index* idx, const float* query, uint32_t k, uint32_t int8_mult, uint32_t* out_rows,
-                              float* out_scores, uint32_t* out_count, const uint64_t* allow = nullptr) {
+                              float* out_scores, uint32_t* out_count, const uint64_t* allow = nullptr, const uint64_t* allow_dev = nullptr) {
     return guarded([&]() -> fsgpu_status {
         SearchCall call;
         call.query = query;
         call.k = k;
         call.int8_mult = int8_mult;
         call.allow = allow;
+        call.allow_dev = allow_dev;
         call.out_rows = out_rows;
         call.out_scores = out_scores;
         call.out_count = out_count;
@@ -157,6 +165,7 @@ fsgpu_status coalesced_search(fsgpu_index* idx, const float* query, uint32_t k, 
                 const uint32_t n = (uint32_t)batch.size(), dim = idx->impl.dimension(), kk = batch[0]->k;
                 const uint32_t mult = batch[0]->int8_mult;
                 const uint64_t* allow_bm = batch[0]->allow;   // one filter for the whole batch (compatible() below)
+                const uint64_t* allow_res = batch[0]->allow_dev;
                 fsgpu_status st = FSGPU_ERR_DEVICE;
                 std::string detail;
                 try {
@@ -175,10 +184,10 @@ fsgpu_status coalesced_search(fsgpu_index* idx, const float* query, uint32_t k, 
                         // up to four callers: one pass of the exact multi-query kernel is quicker than the staged
                         // matrix-core pipeline; beyond that the batched path serves 128 and more per pass
                         e = idx->impl.search_top_k(idx->co_queries.data(), n, dim, kk, allow_bm, idx->co_rows.data(),
-                                                   idx->co_scores.data(), idx->co_counts.data());
+                                                   idx->co_scores.data(), idx->co_counts.data(), allow_res);
                     } else {
                         e = idx->impl.search_top_k_batched(idx->co_queries.data(), n, dim, kk, allow_bm, idx->co_rows.data(),
-                                                           idx->co_scores.data(), idx->co_counts.data(), &fb);
+                                                           idx->co_scores.data(), idx->co_counts.data(), &fb, allow_res);
                     }
                     st = e.code;
                     detail = e.detail;
@@ -416,14 +425,14 @@ fsgpu_status fsgpu_index_set_live_bitmap(fsgpu_index* idx, const uint64_t* live_
     });
 }
 
-fsgpu_status fsgpu_search_topk(fsgpu_index* idx, const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
-                               const uint64_t* allow_bitmap, uint32_t* out_rows, float* out_scores,
-                               uint32_t* out_counts) {
+static fsgpu_status search_topk_common(fsgpu_index* idx, const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
+                                       const uint64_t* allow_bitmap, const uint64_t* allow_resident_dev, uint32_t* out_rows,
+                                       float* out_scores, uint32_t* out_counts) {
     if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
     if (nq && (!queries || !out_counts || (k && (!out_rows || !out_scores))))
         return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
     if (idx->coalescer.enabled() && nq == 1 && k >= 1 && k <= 64 && query_len == idx->impl.dimension())
-        return coalesced_search(idx, queries, k, 0, out_rows, out_scores, out_counts, allow_bitmap);
+        return coalesced_search(idx, queries, k, 0, out_rows, out_scores, out_counts, allow_bitmap, allow_resident_dev);
     return guarded([&]() -> fsgpu_status {
         // this index if it is free, else a free replica, else queue on one of the lanes in turn
         std::shared_lock<std::shared_mutex> state(idx->state_mu);
@@ -450,7 +459,75 @@ fsgpu_status fsgpu_search_topk(fsgpu_index* idx, const float* queries, uint32_t 
                 lock = std::unique_lock<std::mutex>(lane->mutex());
             }
         }
-        return finish(lane->search_top_k(queries, nq, query_len, k, allow_bitmap, out_rows, out_scores, out_counts));
+        return finish(lane->search_top_k(queries, nq, query_len, k, allow_bitmap, out_rows, out_scores, out_counts, allow_resident_dev));
+    });
+}
+
+fsgpu_status fsgpu_search_topk(fsgpu_index* idx, const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
+                               const uint64_t* allow_bitmap, uint32_t* out_rows, float* out_scores,
+                               uint32_t* out_counts) {
+    return search_topk_common(idx, queries, nq, query_len, k, allow_bitmap, nullptr, out_rows, out_scores, out_counts);
+}
+
+// ---- resident filters: a precomputed SearchFilter uploaded once and reused (filter.rs:19-56; search.rs:1114-1255) ----
+fsgpu_status fsgpu_allow_bitmap_create(fsgpu_index* idx, const uint64_t* allow_bitmap, fsgpu_allow_bitmap** out) {
+    if (!idx || !allow_bitmap || !out) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    *out = nullptr;
+    return guarded([&]() -> fsgpu_status {
+        auto f = std::make_unique<fsgpu_allow_bitmap>();
+        f->device = idx->impl.device();
+        f->nrows = idx->impl.record_count();
+        const size_t words = (size_t)((f->nrows + 63) / 64);
+        f->words.assign(allow_bitmap, allow_bitmap + words);
+        if (words && (f->nrows & 63)) f->words.back() &= (1ull << (f->nrows & 63)) - 1ull;
+        for (uint64_t w : f->words) f->allowed += (uint64_t)__builtin_popcountll(w);
+        if (f->device < 0) return fail(FSGPU_ERR_NO_DEVICE, "index has no device");
+        if (hipSetDevice(f->device) != hipSuccess) return fail(FSGPU_ERR_DEVICE, "hipSetDevice failed");
+        fsgpu::SearchError e = f->dev.reserve(std::max<size_t>(words, 1) * 8);
+        if (!e.ok()) return finish(e);
+        if (words && hipMemcpy(f->dev.ptr, f->words.data(), words * 8, hipMemcpyHostToDevice) != hipSuccess) {
+            f->dev.release();
+            return fail(FSGPU_ERR_DEVICE, "upload of the allow bitmap failed");
+        }
+        *out = f.release();
+        return FSGPU_OK;
+    });
+}
+
+void fsgpu_allow_bitmap_destroy(fsgpu_allow_bitmap* f) {
+    if (!f) return;
+    if (f->device >= 0) (void)hipSetDevice(f->device);
+    f->dev.release();
+    delete f;
+}
+
+uint64_t fsgpu_allow_bitmap_allowed_rows(const fsgpu_allow_bitmap* f) { return f ? f->allowed : 0; }
+
+static fsgpu_status check_filter(const fsgpu_index* idx, const fsgpu_allow_bitmap* f) {
+    if (!idx || !f) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    if (f->device != idx->impl.device() || f->nrows != idx->impl.record_count())
+        return fail(FSGPU_ERR_INVALID_CONFIG, "the allow bitmap was made for another index (device or record count differ)");
+    return FSGPU_OK;
+}
+
+fsgpu_status fsgpu_search_topk_filtered(fsgpu_index* idx, const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
+                                        const fsgpu_allow_bitmap* filter, uint32_t* out_rows, float* out_scores, uint32_t* out_counts) {
+    const fsgpu_status c = check_filter(idx, filter);
+    if (c != FSGPU_OK) return c;
+    return search_topk_common(idx, queries, nq, query_len, k, filter->words.data(), static_cast<const uint64_t*>(filter->dev.ptr), out_rows,
+                              out_scores, out_counts);
+}
+
+fsgpu_status fsgpu_search_topk_batched_filtered(fsgpu_index* idx, const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
+                                                const fsgpu_allow_bitmap* filter, uint32_t* out_rows, float* out_scores,
+                                                uint32_t* out_counts, uint32_t* out_fallbacks) {
+    const fsgpu_status c = check_filter(idx, filter);
+    if (c != FSGPU_OK) return c;
+    if (nq && (!queries || !out_counts || (k && (!out_rows || !out_scores)))) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.search_top_k_batched(queries, nq, query_len, k, filter->words.data(), out_rows, out_scores, out_counts,
+                                                     out_fallbacks, static_cast<const uint64_t*>(filter->dev.ptr)));
     });
 }
 

@@ -977,7 +977,7 @@ SearchError VectorIndex::search_top_k_device(const float* queries_dev, uint32_t 
 
 SearchError VectorIndex::search_top_k(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
                                       const uint64_t* allow, uint32_t* out_rows, float* out_scores,
-                                      uint32_t* out_counts) {
+                                      uint32_t* out_counts, const uint64_t* allow_resident_dev) {
     FSGPU_TRY(ensure_query_dimension(query_len));
     if (nq == 0) return ok();
     if (k == 0 || nrows_ == 0) {
@@ -1068,6 +1068,9 @@ SearchError VectorIndex::search_top_k(const float* queries, uint32_t nq, uint32_
                                     static_cast<uint32_t*>(ws_counts_.ptr), stream_));
             gathered = true;
             ++filter_gathered;
+        } else if (allow_resident_dev) {
+            allow_dev = allow_resident_dev;   // uploaded once, when the filter was made resident
+            ++filter_scanned;
         } else {
             FSGPU_TRY(ws_allow_.reserve(words * 8));
             FSGPU_HIP(hipMemcpyAsync(ws_allow_.ptr, allow, words * 8, hipMemcpyHostToDevice, stream_));
@@ -2034,7 +2037,7 @@ SearchError VectorIndex::batched_fallback(BatchedPlan& p) {
 
 SearchError VectorIndex::search_top_k_batched(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
                                               const uint64_t* allow, uint32_t* out_rows, float* out_scores,
-                                              uint32_t* out_counts, uint32_t* fallbacks) {
+                                              uint32_t* out_counts, uint32_t* fallbacks, const uint64_t* allow_resident_dev) {
     if (fallbacks) *fallbacks = 0;
     FSGPU_TRY(ensure_query_dimension(query_len));
     if (nq == 0) return ok();
@@ -2049,8 +2052,8 @@ SearchError VectorIndex::search_top_k_batched(const float* queries, uint32_t nq,
     FSGPU_TRY(ws_scores_.reserve((size_t)nq * k * 4));
     FSGPU_TRY(ws_counts_.reserve((size_t)nq * 4));
     FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, queries, qbytes, hipMemcpyHostToDevice, stream_));
-    const uint64_t* allow_dev = nullptr;
-    if (allow) {
+    const uint64_t* allow_dev = allow ? allow_resident_dev : nullptr;
+    if (allow && !allow_dev) {
         const size_t words = (size_t)((nrows_ + 63) / 64);
         FSGPU_TRY(ws_allow_.reserve(words * 8));
         FSGPU_HIP(hipMemcpyAsync(ws_allow_.ptr, allow, words * 8, hipMemcpyHostToDevice, stream_));

@@ -69,8 +69,11 @@ class VectorIndex {
     uint32_t dimension() const { return dim_; }
 
     // search_top_k over nq queries (host pointers; synchronous).
+    // allow_resident_dev: the device copy of `allow` when the caller keeps one (fsgpu_allow_bitmap: a filter reused across
+    // searches is uploaded once, not per call); null = `allow` is uploaded for this call
     SearchError search_top_k(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
-                             const uint64_t* allow, uint32_t* out_rows, float* out_scores, uint32_t* out_counts);
+                             const uint64_t* allow, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
+                             const uint64_t* allow_resident_dev = nullptr);
     // same with device pointers, enqueued on `stream`.
     SearchError search_top_k_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
                                     const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
@@ -85,7 +88,7 @@ class VectorIndex {
                                             uint64_t* out_packed_dev = nullptr);
     SearchError search_top_k_batched(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
                                      const uint64_t* allow, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
-                                     uint32_t* fallbacks);
+                                     uint32_t* fallbacks, const uint64_t* allow_resident_dev = nullptr);
     // Batched search_top_k_int8_two_pass (search.rs:514-661): int8 pass 1 on the matrix cores (exact integer scores, so the
     // k*multiplier candidates are exactly the reference's), exact f16 rescore, top-k.  No doc-id dedup (raw row ids).
     SearchError search_top_k_int8_batched_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,

@@ -180,10 +180,19 @@ class VectorIndex:
         rows = np.full((nq, max(limit, 1)), 0xFFFFFFFF, dtype=np.uint32)
         scores = np.full((nq, max(limit, 1)), np.nan, dtype=np.float32)
         counts = np.zeros(nq, dtype=np.uint32)
+        if isinstance(allow, ResidentFilter):   # uploaded once (fsgpu_allow_bitmap): no per-call copy of the bitmap
+            check(_lib.lib().fsgpu_search_topk_filtered(self._h, _ptr(q), nq, qlen, limit, allow._h, _ptr(rows), _ptr(scores),
+                                                        _ptr(counts)))
+            return rows[:, :limit], scores[:, :limit], counts
         bm = pack_bitmap(allow) if allow is not None else None
         check(_lib.lib().fsgpu_search_topk(self._h, _ptr(q), nq, qlen, limit, _ptr(bm), _ptr(rows), _ptr(scores),
                                            _ptr(counts)))
         return rows[:, :limit], scores[:, :limit], counts
+
+    def resident_filter(self, allow: np.ndarray) -> "ResidentFilter":
+        """A precomputed SearchFilter (bool[N] allow mask) made resident on this index's device; pass it as `allow=` to
+        search_batch / search_batched any number of times."""
+        return ResidentFilter(self, allow)
 
     def search_batched(self, queries: np.ndarray, limit: int, allow: Optional[np.ndarray] = None):
         """Throughput path (64 queries per HBM pass on the matrix cores, exact results):
@@ -195,8 +204,12 @@ class VectorIndex:
         rows = np.full((nq, max(limit, 1)), 0xFFFFFFFF, dtype=np.uint32)
         scores = np.full((nq, max(limit, 1)), np.nan, dtype=np.float32)
         counts = np.zeros(nq, dtype=np.uint32)
-        bm = pack_bitmap(allow) if allow is not None else None
         fb = C.c_uint32()
+        if isinstance(allow, ResidentFilter):
+            check(_lib.lib().fsgpu_search_topk_batched_filtered(self._h, _ptr(q), nq, qlen, limit, allow._h, _ptr(rows), _ptr(scores),
+                                                                _ptr(counts), C.byref(fb)))
+            return rows[:, :limit], scores[:, :limit], counts, fb.value
+        bm = pack_bitmap(allow) if allow is not None else None
         check(_lib.lib().fsgpu_search_topk_batched(self._h, _ptr(q), nq, qlen, limit, _ptr(bm), _ptr(rows), _ptr(scores),
                                                    _ptr(counts), C.byref(fb)))
         return rows[:, :limit], scores[:, :limit], counts, fb.value
@@ -371,6 +384,32 @@ class VectorIndex:
         if self.record_count() + self.wal_record_count() == 0:
             return False
         return _lib.lib().fsgpu_index_doc_id(self._h, 0, C.byref(p), C.byref(n)) == 0
+
+
+class ResidentFilter:
+    """fsgpu_allow_bitmap: a precomputed SearchFilter (filter.rs:19-56) uploaded ONCE to an index's device and reused by any number
+    of searches — the per-call ABI copies the bitmap (1.25 MB at 10M rows) on every search."""
+
+    def __init__(self, index: "VectorIndex", allow: np.ndarray):
+        self._index = index
+        bm = pack_bitmap(allow)
+        h = C.c_void_p()
+        check(_lib.lib().fsgpu_allow_bitmap_create(index._h, _ptr(bm), C.byref(h)))
+        self._h = h
+
+    def allowed_rows(self) -> int:
+        return int(_lib.lib().fsgpu_allow_bitmap_allowed_rows(self._h))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.lib().fsgpu_allow_bitmap_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class NativeShardedIndex:

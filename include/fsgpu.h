@@ -144,6 +144,22 @@ fsgpu_status fsgpu_index_set_live_bitmap(fsgpu_index *idx, const uint64_t *live_
 fsgpu_status fsgpu_search_topk(fsgpu_index *idx, const float *queries, uint32_t nq, uint32_t query_len,
                                uint32_t k, const uint64_t *allow_bitmap, uint32_t *out_rows,
                                float *out_scores, uint32_t *out_counts);
+/* A SearchFilter is typically built once and reused by many queries (filter.rs:19-56; the filtered search paths search.rs:1114-1255
+ * take `Option<&dyn SearchFilter>` per call).  fsgpu_allow_bitmap is the precomputed filter made RESIDENT on the index's device:
+ * uploaded once (1.25 MB at 10M rows), then any number of fsgpu_search_topk_filtered / _batched_filtered calls use it without a
+ * per-call copy — same hits as fsgpu_search_topk{,_batched} with the same words, same 1/50 selective-gather rule, tombstones still
+ * masked at search time.  Concurrent single-query callers that pass the SAME handle share a coalesced batch.  The bitmap belongs to
+ * the index it was created for (device and record count are checked). */
+typedef struct fsgpu_allow_bitmap fsgpu_allow_bitmap;
+fsgpu_status fsgpu_allow_bitmap_create(fsgpu_index *idx, const uint64_t *allow_bitmap, fsgpu_allow_bitmap **out);
+void fsgpu_allow_bitmap_destroy(fsgpu_allow_bitmap *filter);
+uint64_t fsgpu_allow_bitmap_allowed_rows(const fsgpu_allow_bitmap *filter);
+fsgpu_status fsgpu_search_topk_filtered(fsgpu_index *idx, const float *queries, uint32_t nq, uint32_t query_len, uint32_t k,
+                                        const fsgpu_allow_bitmap *filter, uint32_t *out_rows, float *out_scores,
+                                        uint32_t *out_counts);
+fsgpu_status fsgpu_search_topk_batched_filtered(fsgpu_index *idx, const float *queries, uint32_t nq, uint32_t query_len,
+                                                uint32_t k, const fsgpu_allow_bitmap *filter, uint32_t *out_rows,
+                                                float *out_scores, uint32_t *out_counts, uint32_t *out_fallbacks);
 /* Same, all pointers device-resident, enqueued on `hip_stream` (a hipStream_t), no host sync. */
 fsgpu_status fsgpu_search_topk_device(fsgpu_index *idx, const float *queries_dev, uint32_t nq,
                                       uint32_t query_len, uint32_t k, const uint64_t *allow_bitmap_dev,

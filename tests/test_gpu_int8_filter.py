@@ -308,3 +308,31 @@ def test_repeated_batches_return_the_same_bits(fa):
             assert np.array_equal(br, er), (filt, rep)
             assert np.array_equal(bs.view(np.uint32), es.view(np.uint32)), (filt, rep)
     idx.close()
+
+
+def test_three_thousand_filtered_repetitions_return_the_same_bits(fa):
+    """The r03 failure — one filtered batch in ~16,000 with a wrong tombstone / allow word in the wide kernel's append path
+    (profiles/r04/bitmap_soak_noinv.txt: 10 in 161,737 without the per-wave scalar-cache invalidate, 0 in 160,400 with it, 0 with
+    vector loads) — guarded in the suite, not only by a builder-run soak: 3,000 repetitions of filtered 520-query batches (dim 384:
+    the shape every failing repetition had; tombstones, tombstones + allow bitmap) on the int8 filter, every one compared with the
+    exact kernels' rows and score bits.  (At the measured rate this length catches a regression to the unguarded loads with
+    probability ~1/6 per run; the soak scripts/r04/bitmap_soak.py is the long form.)"""
+    rng = np.random.default_rng(17)
+    dim, n, nq, k = 384, 150_011, 520, 30
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    slab = x.astype(np.float16).view(np.uint16)
+    live = rng.random(n) > 0.2
+    allow = rng.random(n) > 0.3
+    q = x[rng.integers(0, n, nq)] + (rng.standard_normal((nq, dim)) * 0.2).astype(np.float32)
+    idx = fa.VectorIndex.from_slab(slab, live=live)
+    idx.set_batched_filter(2)
+    for bitmap, reps in ((None, 1500), (allow, 1500)):
+        exact = [idx.search_batch(q[s:s + 64], k, allow=bitmap) for s in range(0, nq, 64)]
+        er = np.concatenate([e[0] for e in exact])
+        es = np.concatenate([e[1] for e in exact]).view(np.uint32)
+        for rep in range(reps):
+            br, bs, _, _ = idx.search_batched(q, k, allow=bitmap)
+            assert np.array_equal(br, er), (bitmap is not None, rep)
+            assert np.array_equal(bs.view(np.uint32), es), (bitmap is not None, rep)
+    idx.close()

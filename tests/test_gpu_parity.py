@@ -1119,3 +1119,65 @@ def test_reference_recall_fixture_on_the_gpu_paths(fa, oracle):
         assert np.array_equal(br[qi], er) and np.array_equal(bits(bs[qi]), bits(es)), qi
         tr, ts = oracle.search_int8_two_pass(slab, q[qi], 10, 3)
         assert np.array_equal(r8[qi, :c8[qi]], tr) and np.array_equal(bits(s8[qi, :c8[qi]]), bits(ts)), qi
+
+
+def test_resident_allow_bitmap_gives_the_per_call_bitmaps_hits(fa, oracle):
+    """fsgpu_allow_bitmap (a SearchFilter uploaded once, filter.rs:19-56): fsgpu_search_topk_filtered / _batched_filtered return the
+    hits of the per-call bitmap — a broad filter (masked scan), a selective one (fewer than 1/50 of the rows: the gather of
+    try_gather_filtered, search.rs:1114-1180), with tombstones that change AFTER the filter was made; the oracle agrees; concurrent
+    single-query callers that share the handle ride one coalesced batch; a bitmap of another index is refused."""
+    import threading
+    rng = np.random.default_rng(77)
+    n, dim = 120_077, 256
+    slab = rand_slab(rng, n, dim)
+    idx = fa.VectorIndex.from_slab(slab)
+    q = rng.standard_normal((96, dim)).astype(np.float32)
+    broad = rng.random(n) < 0.5
+    narrow = rng.random(n) < 0.01
+    for mask in (broad, narrow):
+        f = idx.resident_filter(mask)
+        assert f.allowed_rows() == int(mask.sum())
+        for live in (None, rng.random(n) > 0.1):
+            idx.set_live(live)
+            a = idx.search_batch(q[:9], 10, allow=mask)
+            b = idx.search_batch(q[:9], 10, allow=f)
+            for x, y in zip(a, b):
+                assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+            orow, osc = oracle.search_top_k(slab, q[3], 10, live=mask if live is None else (mask & live))
+            assert np.array_equal(b[0][3], orow) and np.array_equal(bits(b[1][3]), bits(osc))
+            a = idx.search_batched(q, 10, allow=mask)
+            b = idx.search_batched(q, 10, allow=f)
+            for x, y in zip(a[:3], b[:3]):
+                assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+        f.close()
+    idx.set_live(None)
+    # coalesced callers sharing one resident filter
+    f = idx.resident_filter(broad)
+    want = [idx.search_batch(q[i], 10, allow=f) for i in range(64)]
+    idx.set_coalescing(64, 20_000)
+    got, errs = [None] * 64, []
+
+    def call(i):
+        try:
+            got[i] = idx.search_batch(q[i], 10, allow=f)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=call, args=(i,)) for i in range(64)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(64):
+        for x, y in zip(got[i], want[i]):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), i
+    batches, requests = idx.coalescing_stats()
+    assert requests == 64 and batches < 32
+    idx.set_coalescing(0, 0)
+    other = fa.VectorIndex.from_slab(slab[:1000])
+    with pytest.raises(fa.InvalidConfig):
+        other.search_batch(q[0], 5, allow=f)
+    f.close()
+    other.close()
+    idx.close()
