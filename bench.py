@@ -727,13 +727,14 @@ def config5_stream_section(fa, index, bert, rows: int, k: int, n_batches: int = 
     embed_search_stream(bert, index, ids[:offs[512]], offs[:513], 256, k, group=2, overlap=True, want_hits=False)   # warm-up
     out = {}
     hits = {}
-    for name, group, overlap in (("serial_one_scan_per_batch", 1, False), ("serial_two_batches_per_scan", 2, False),
-                                 ("overlapped_two_batches_per_scan", 2, True)):
-        r, s, c, st = embed_search_stream(bert, index, ids, offs, 256, k, group=group, overlap=overlap)
+    for name, group, overlap, host in (("serial_one_scan_per_batch", 1, False, False), ("serial_two_batches_per_scan", 2, False, False),
+                                       ("overlapped_two_batches_per_scan_host_vectors", 2, True, True),
+                                       ("overlapped_two_batches_per_scan", 2, True, False)):
+        r, s, c, st = embed_search_stream(bert, index, ids, offs, 256, k, group=group, overlap=overlap, host_handoff=host)
         hits[name] = (r, s)
         out[name] = {"queries_per_sec": st["queries_per_sec"], "encode_ms_per_group": st["mean_encode_ms"],
                      "search_ms_per_group": st["mean_search_ms"], "groups": int(st["groups"]), "exact_fallbacks": int(st["exact_fallbacks"]),
-                     "all_counts_full": bool(np.all(c == k))}
+                     "embeddings_stay_in_device_memory": bool(st["device_resident_handoff"]), "all_counts_full": bool(np.all(c == k))}
     base = hits["serial_one_scan_per_batch"]
     same = all(np.array_equal(h[0], base[0]) and np.array_equal(h[1].view(np.uint32), base[1].view(np.uint32)) for h in hits.values())
     out["workload"] = (f"{n_batches} batches of 256 token-id queries ({int(offs[-1])} tokens) -> MiniLM-L6 on the GPU -> batched exact "

@@ -79,6 +79,7 @@ SIGNATURES = {
     "fsgpu_sharded_dimension": (_u32, [_vp]),
     "fsgpu_sharded_shard_count": (_u32, [_vp]),
     "fsgpu_sharded_exchange_mode": (_i32, [_vp]),
+    "fsgpu_sharded_device": (_i32, [_vp, _u32]),
     "fsgpu_sharded_shard_range": (_i32, [_vp, _u32, C.POINTER(_u64), C.POINTER(_u64)]),
     "fsgpu_sharded_set_hreduce": (_i32, [_vp, _i32]),
     "fsgpu_sharded_search_topk": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
@@ -113,6 +114,14 @@ SIGNATURES = {
     "fsgpu_bert_create": (_i32, [_i32, _vp, _vp, C.POINTER(_vp)]),
     "fsgpu_bert_create_safetensors": (_i32, [_i32, _vp, _u64, C.c_float, C.POINTER(_vp)]),
     "fsgpu_bert_destroy": (None, [_vp]),
+    "fsgpu_bert_embed_device": (_i32, [_vp, _vp, _vp, _u32, _vp]),
+    "fsgpu_m2v_embed_device": (_i32, [_vp, _vp, _vp, _u32, _vp]),
+    "fsgpu_search_topk_batched_device_queries": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, C.POINTER(_u32)]),
+    "fsgpu_device_malloc": (_i32, [_i32, _u64, C.POINTER(_vp)]),
+    "fsgpu_device_free": (_i32, [_i32, _vp]),
+    "fsgpu_bert_device": (_i32, [_vp]),
+    "fsgpu_m2v_device": (_i32, [_vp]),
+    "fsgpu_index_device": (_i32, [_vp]),
     "fsgpu_bert_dimension": (_u32, [_vp]),
     "fsgpu_bert_embed": (_i32, [_vp, _vp, _vp, _u32, _vp]),
     "fsgpu_rrf_fuse": (_i32, [_vp, _u32, _vp, _u32, C.c_double, C.c_double, C.c_double, _i32, _u32, _u32, _vp,

@@ -431,7 +431,8 @@ bool NativeEmbedder::docs_path(uint32_t tokens, uint32_t max_seq) const {
 // Every text at most 32 tokens long (a batch of queries): ONE launch for the whole forward (bert_docs_w.hip).  Consecutive texts
 // are packed greedily into row blocks of at most 32 tokens; a block never splits a text.  ids: this call's tokens; offs: the
 // call's offsets rebased to 0.
-SearchError NativeEmbedder::embed_docs(const int32_t* ids, const std::vector<uint32_t>& offs, uint32_t n, uint32_t total, float* out) {
+SearchError NativeEmbedder::embed_docs(const int32_t* ids, const std::vector<uint32_t>& offs, uint32_t n, uint32_t total, float* out,
+                                       float* out_dev) {
     const size_t H = cfg_.hidden;
     std::vector<uint32_t> blk_tok, blk_doc;
     blk_tok.reserve(n + 1);
@@ -509,7 +510,7 @@ SearchError NativeEmbedder::embed_docs(const int32_t* ids, const std::vector<uin
         unsigned char* io = static_cast<unsigned char*>(docs_io_);
         fill(io);
         point(io);
-        a.out = reinterpret_cast<float*>(io + in_bytes);
+        a.out = out_dev ? out_dev : reinterpret_cast<float*>(io + in_bytes);   // (device output: the pooled vectors stay in HBM)
 #ifdef FSGPU_EXPERIMENTS
         static const bool trace = fsgpu::lab_env("FSGPU_BERT_DOCS_STAMPS") != nullptr;   // per-phase shader clocks of block 0
         static unsigned long long* stamps = nullptr;
@@ -529,7 +530,8 @@ SearchError NativeEmbedder::embed_docs(const int32_t* ids, const std::vector<uin
             std::fprintf(stderr, "\n");
         }
 #endif
-        std::memcpy(out, io + in_bytes, out_bytes);
+        if (out_dev && out) BERT_HIP(hipMemcpy(out, out_dev, out_bytes, hipMemcpyDeviceToHost));
+        else if (out) std::memcpy(out, io + in_bytes, out_bytes);
         return SearchError{};
     }
     std::vector<unsigned char> host(in_bytes);
@@ -538,16 +540,16 @@ SearchError NativeEmbedder::embed_docs(const int32_t* ids, const std::vector<uin
     BERT_TRY(docs_out_.reserve(out_bytes));   // (not out_: captured graphs name that one)
     BERT_HIP(hipMemcpyAsync(docs_in_.ptr, host.data(), in_bytes, hipMemcpyHostToDevice, stream_));
     point(static_cast<const unsigned char*>(docs_in_.ptr));
-    a.out = static_cast<float*>(docs_out_.ptr);
+    a.out = out_dev ? out_dev : static_cast<float*>(docs_out_.ptr);
     BERT_HIP(launch_bert_docs_w(a, nblocks, stream_));
-    BERT_HIP(hipMemcpyAsync(out, docs_out_.ptr, out_bytes, hipMemcpyDeviceToHost, stream_));
+    if (out) BERT_HIP(hipMemcpyAsync(out, a.out, out_bytes, hipMemcpyDeviceToHost, stream_));
     BERT_HIP(hipStreamSynchronize(stream_));
     return SearchError{};
 }
 
-SearchError NativeEmbedder::embed_batch(const int32_t* ids, const uint32_t* offsets, uint32_t n, float* out) {
+SearchError NativeEmbedder::embed_batch(const int32_t* ids, const uint32_t* offsets, uint32_t n, float* out, float* out_dev) {
     if (n == 0) return SearchError{};
-    if (!offsets || !out) return err(FSGPU_ERR_NULL_ARGUMENT, "offsets/out is null");
+    if (!offsets || (!out && !out_dev)) return err(FSGPU_ERR_NULL_ARGUMENT, "offsets/out is null");
     std::lock_guard<std::mutex> lock(mu_);
     uint32_t max_seq = 0;
     for (uint32_t i = 0; i < n; ++i) {
@@ -561,7 +563,12 @@ SearchError NativeEmbedder::embed_batch(const int32_t* ids, const uint32_t* offs
     const uint32_t total = offsets[n] - base;
     const size_t H = cfg_.hidden;
     if (total == 0) {  // every text empty -> zeros (native.rs:1146-1148)
-        std::fill(out, out + (size_t)n * H, 0.0f);
+        if (out) std::fill(out, out + (size_t)n * H, 0.0f);
+        if (out_dev) {
+            BERT_HIP(hipSetDevice(device_));
+            BERT_HIP(hipMemsetAsync(out_dev, 0, (size_t)n * H * 4, stream_));
+            BERT_HIP(hipStreamSynchronize(stream_));
+        }
         return SearchError{};
     }
     if (!ids) return err(FSGPU_ERR_NULL_ARGUMENT, "ids is null");
@@ -575,7 +582,7 @@ SearchError NativeEmbedder::embed_batch(const int32_t* ids, const uint32_t* offs
             positions[t] = (int32_t)(t - offs[i]);  // positions restart at 0 per input (native.rs:1159-1167)
         }
     BERT_HIP(hipSetDevice(device_));
-    if (docs_path(total, max_seq)) return embed_docs(ids + base, offs, n, total, out);
+    if (docs_path(total, max_seq)) return embed_docs(ids + base, offs, n, total, out, out_dev);
     {
         // (graph-eligible calls share buffers of the graph-eligible maximum: see reserve_workspaces)
         const bool small = total <= kGraphMaxTokens;
@@ -664,15 +671,21 @@ SearchError NativeEmbedder::embed_batch(const int32_t* ids, const uint32_t* offs
             }
         }
         if (!replayed) BERT_TRY(enqueue());
+        // (device output of a graph-replayed call: the pool kernel's destination is baked into the graph — the pinned block —, so
+        // the few KB go back up from there behind it)
+        if (out_dev) BERT_HIP(hipMemcpyAsync(out_dev, io + in_bytes, out_bytes, hipMemcpyHostToDevice, stream_));
         BERT_HIP(hipStreamSynchronize(stream_));
-        std::memcpy(out, io + in_bytes, out_bytes);
+        if (out) std::memcpy(out, io + in_bytes, out_bytes);
         return SearchError{};
     }
     BERT_HIP(hipMemcpyAsync(ids_.ptr, ids + base, (size_t)total * 4, hipMemcpyHostToDevice, stream_));
     BERT_HIP(hipMemcpyAsync(positions_.ptr, positions.data(), (size_t)total * 4, hipMemcpyHostToDevice, stream_));
     BERT_HIP(hipMemcpyAsync(offsets_.ptr, offs.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, stream_));
-    BERT_TRY(forward(n, total, max_seq));
-    BERT_HIP(hipMemcpyAsync(out, out_.ptr, (size_t)n * H * 4, hipMemcpyDeviceToHost, stream_));
+    pooled_out_ = out_dev;   // (null: the pool kernel writes out_)
+    const SearchError fe = forward(n, total, max_seq);
+    pooled_out_ = nullptr;
+    BERT_TRY(fe);
+    if (out) BERT_HIP(hipMemcpyAsync(out, out_dev ? out_dev : out_.ptr, (size_t)n * H * 4, hipMemcpyDeviceToHost, stream_));
     BERT_HIP(hipStreamSynchronize(stream_));
     return SearchError{};
 }

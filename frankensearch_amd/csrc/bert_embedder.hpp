@@ -22,8 +22,11 @@ class NativeEmbedder {
     // crates/frankensearch-rerank/src/native.rs:1359-1602).  device < 0 validates the blob only.
     SearchError init_safetensors(int device, const void* blob, uint64_t blob_len, float ln_eps);
     // ids: concatenated token ids; text i owns ids[offsets[i]..offsets[i+1]).  out: [n, hidden] f32.
-    SearchError embed_batch(const int32_t* ids, const uint32_t* offsets, uint32_t n, float* out);
+    // out_dev (on this embedder's device, may be null): the pooled vectors are left in device memory — the hand-off to a search that
+    // takes device queries; out (may then be null): the host copy.  Either way the call returns when the forward has finished.
+    SearchError embed_batch(const int32_t* ids, const uint32_t* offsets, uint32_t n, float* out, float* out_dev = nullptr);
     uint32_t dimension() const { return cfg_.hidden; }
+    int device() const { return device_; }
 
   private:
     struct Layer {
@@ -40,7 +43,7 @@ class NativeEmbedder {
     SearchError forward_query(uint32_t n_docs, uint32_t tokens);   // <= 32 tokens: 25 launches (bert_query_kernels.hip)
     bool query_path(uint32_t tokens) const;
     bool docs_path(uint32_t tokens, uint32_t max_seq) const;       // every text <= 32 tokens: ONE launch (bert_docs_w.hip)
-    SearchError embed_docs(const int32_t* ids, const std::vector<uint32_t>& offs, uint32_t n, uint32_t total, float* out);
+    SearchError embed_docs(const int32_t* ids, const std::vector<uint32_t>& offs, uint32_t n, uint32_t total, float* out, float* out_dev);
     SearchError reserve_workspaces(uint32_t tokens);
     void drop_graphs();
 

@@ -676,6 +676,7 @@ uint64_t fsgpu_sharded_record_count(const fsgpu_sharded* idx) { return idx ? idx
 uint32_t fsgpu_sharded_dimension(const fsgpu_sharded* idx) { return idx ? idx->impl.dimension() : 0; }
 uint32_t fsgpu_sharded_shard_count(const fsgpu_sharded* idx) { return idx ? idx->impl.shard_count() : 0; }
 int32_t fsgpu_sharded_exchange_mode(const fsgpu_sharded* idx) { return idx ? idx->impl.exchange_mode() : 0; }
+int32_t fsgpu_sharded_device(const fsgpu_sharded* idx, uint32_t shard) { return idx ? idx->impl.shard_device(shard) : -1; }
 
 fsgpu_status fsgpu_sharded_shard_range(const fsgpu_sharded* idx, uint32_t shard, uint64_t* row_lo, uint64_t* row_hi) {
     if (!idx || !row_lo || !row_hi) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
@@ -694,6 +695,7 @@ fsgpu_status fsgpu_sharded_set_hreduce(fsgpu_sharded* idx, int32_t mode) {
 static fsgpu::ShardedIndex::Request sharded_request(const fsgpu_sharded_request* rq) {
     fsgpu::ShardedIndex::Request r;
     r.queries = rq->queries;
+    r.queries_dev = rq->queries_dev;
     r.nq = rq->nq;
     r.k = rq->k;
     r.mode = static_cast<fsgpu::ShardedIndex::Mode>(rq->mode);
@@ -704,7 +706,7 @@ static fsgpu::ShardedIndex::Request sharded_request(const fsgpu_sharded_request*
 
 static fsgpu_status check_sharded_request(const fsgpu_sharded* idx, const fsgpu_sharded_request* rq) {
     if (!idx || !rq) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
-    if (rq->nq && !rq->queries) return fail(FSGPU_ERR_NULL_ARGUMENT, "queries is null");
+    if (rq->nq && !rq->queries && !rq->queries_dev) return fail(FSGPU_ERR_NULL_ARGUMENT, "queries is null");
     if (rq->mode < FSGPU_SHARDED_EXACT || rq->mode > FSGPU_SHARDED_4BIT_TWO_PASS) return fail(FSGPU_ERR_INVALID_CONFIG, "unknown search mode");
     return FSGPU_OK;
 }
@@ -716,7 +718,7 @@ fsgpu_status fsgpu_sharded_search(fsgpu_sharded* idx, const fsgpu_sharded_reques
     if (request->nq && (!out_counts || (request->k && (!out_rows || !out_scores)))) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
     // concurrent single-query callers share one search of the shards (same hits: the batched mode is exact, the two-pass
     // candidates are per query)
-    if (idx->coalescer.enabled() && request->nq == 1 && request->k >= 1 && request->k <= 64 && !request->allow_bitmap &&
+    if (idx->coalescer.enabled() && request->nq == 1 && request->k >= 1 && request->k <= 64 && !request->allow_bitmap && request->queries &&
         request->query_len == idx->impl.dimension() && idx->impl.record_count() > 0 &&
         (request->mode == FSGPU_SHARDED_EXACT || request->mode == FSGPU_SHARDED_INT8_TWO_PASS)) {
         if (out_fallbacks) *out_fallbacks = 0;
@@ -763,7 +765,7 @@ fsgpu_status fsgpu_sharded_search_end(fsgpu_sharded* idx, uint64_t ticket, uint3
 static fsgpu_status sharded_search(fsgpu_sharded* idx, const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
                                    bool batched, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
                                    uint32_t* out_fallbacks) {
-    fsgpu_sharded_request rq{queries, nq, query_len, k, batched ? FSGPU_SHARDED_BATCHED : FSGPU_SHARDED_EXACT, 0, nullptr};
+    fsgpu_sharded_request rq{queries, nq, query_len, k, batched ? FSGPU_SHARDED_BATCHED : FSGPU_SHARDED_EXACT, 0, nullptr, nullptr};
     return fsgpu_sharded_search(idx, &rq, out_rows, out_scores, out_counts, out_fallbacks);
 }
 
@@ -1198,6 +1200,12 @@ fsgpu_status fsgpu_m2v_create(int32_t device, const float* table, uint32_t vocab
 }
 
 void fsgpu_m2v_destroy(fsgpu_m2v* m) { delete m; }
+
+fsgpu_status fsgpu_m2v_embed_device(fsgpu_m2v* m, const uint32_t* ids, const uint32_t* offsets, uint32_t n, float* out_dev) {
+    if (!m) return fail(FSGPU_ERR_NULL_ARGUMENT, "embedder is null");
+    if (n && !out_dev) return fail(FSGPU_ERR_NULL_ARGUMENT, "out_dev is null");
+    return guarded([&]() -> fsgpu_status { return finish(m->impl.embed_batch(ids, offsets, n, nullptr, out_dev)); });
+}
 uint32_t fsgpu_m2v_dimension(const fsgpu_m2v* m) { return m ? m->impl.dimension() : 0; }
 
 fsgpu_status fsgpu_m2v_embed(fsgpu_m2v* m, const uint32_t* ids, const uint32_t* offsets, uint32_t n, float* out) {
@@ -1261,6 +1269,45 @@ fsgpu_status fsgpu_bert_create_safetensors(int32_t device, const void* blob, uin
 }
 
 void fsgpu_bert_destroy(fsgpu_bert* m) { delete m; }
+
+fsgpu_status fsgpu_bert_embed_device(fsgpu_bert* m, const int32_t* ids, const uint32_t* offsets, uint32_t n, float* out_dev) {
+    if (!m) return fail(FSGPU_ERR_NULL_ARGUMENT, "embedder is null");
+    if (n && !out_dev) return fail(FSGPU_ERR_NULL_ARGUMENT, "out_dev is null");
+    return guarded([&]() -> fsgpu_status { return finish(m->impl.embed_batch(ids, offsets, n, nullptr, out_dev)); });
+}
+
+fsgpu_status fsgpu_device_malloc(int32_t device, uint64_t bytes, void** out) {
+    if (!out) return fail(FSGPU_ERR_NULL_ARGUMENT, "out is null");
+    *out = nullptr;
+    if (hipSetDevice(device) != hipSuccess) return fail(FSGPU_ERR_NO_DEVICE, "no such HIP device");
+    if (hipMalloc(out, bytes ? bytes : 1) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(FSGPU_ERR_DEVICE, "device allocation failed");
+    }
+    return FSGPU_OK;
+}
+
+fsgpu_status fsgpu_device_free(int32_t device, void* ptr) {
+    if (!ptr) return FSGPU_OK;
+    if (hipSetDevice(device) != hipSuccess) return fail(FSGPU_ERR_NO_DEVICE, "no such HIP device");
+    return hipFree(ptr) == hipSuccess ? FSGPU_OK : fail(FSGPU_ERR_DEVICE, "hipFree failed");
+}
+
+int32_t fsgpu_bert_device(const fsgpu_bert* m) { return m ? m->impl.device() : -1; }
+int32_t fsgpu_m2v_device(const fsgpu_m2v* m) { return m ? m->impl.device() : -1; }
+int32_t fsgpu_index_device(const fsgpu_index* idx) { return idx ? idx->impl.device() : -1; }
+
+fsgpu_status fsgpu_search_topk_batched_device_queries(fsgpu_index* idx, const float* queries_dev, uint32_t nq, uint32_t query_len,
+                                                      uint32_t k, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
+                                                      uint32_t* out_fallbacks) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    if (nq && (!queries_dev || !out_counts || (k && (!out_rows || !out_scores)))) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.search_top_k_batched(queries_dev, nq, query_len, k, nullptr, out_rows, out_scores, out_counts, out_fallbacks,
+                                                     nullptr, true));
+    });
+}
 uint32_t fsgpu_bert_dimension(const fsgpu_bert* m) { return m ? m->impl.dimension() : 0; }
 
 fsgpu_status fsgpu_bert_embed(fsgpu_bert* m, const int32_t* ids, const uint32_t* offsets, uint32_t n, float* out) {

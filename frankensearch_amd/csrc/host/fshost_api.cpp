@@ -9,7 +9,7 @@ namespace fshost {
 fsgpu_status run_load(const SyncTwoTierSearcher& searcher, const fshost_load_config& cfg, fshost_load_result* res);
 fsgpu_status embed_search_stream(fsgpu_bert* encoder, fsgpu_index* index, fsgpu_sharded* sharded, const int32_t* ids,
                                  const uint32_t* offsets, uint32_t batch, uint32_t n_batches, uint32_t group, uint32_t k, bool overlap,
-                                 uint32_t* out_rows, float* out_scores, uint32_t* out_counts, fshost_stream_result* result);
+                                 bool host_handoff, uint32_t* out_rows, float* out_scores, uint32_t* out_counts, fshost_stream_result* result);
 }
 
 struct fshost_two_tier {
@@ -96,8 +96,8 @@ fsgpu_status fshost_embed_search_stream(fsgpu_bert* encoder, fsgpu_index* index,
     if (!encoder || !ids || !offsets || !result || (index == nullptr) == (sharded == nullptr)) return FSGPU_ERR_NULL_ARGUMENT;
     if (batch == 0 || group == 0 || k == 0) return FSGPU_ERR_INVALID_CONFIG;
     try {
-        return fshost::embed_search_stream(encoder, index, sharded, ids, offsets, batch, n_batches, group, k, overlap != 0, out_rows,
-                                           out_scores, out_counts, result);
+        return fshost::embed_search_stream(encoder, index, sharded, ids, offsets, batch, n_batches, group, k, (overlap & 1) != 0,
+                                           (overlap & 2) != 0, out_rows, out_scores, out_counts, result);
     } catch (const std::exception&) {
         return FSGPU_ERR_DEVICE;
     }

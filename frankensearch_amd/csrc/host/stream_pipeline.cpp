@@ -21,13 +21,31 @@ double ms_between(std::chrono::steady_clock::time_point a, std::chrono::steady_c
 
 fsgpu_status embed_search_stream(fsgpu_bert* encoder, fsgpu_index* index, fsgpu_sharded* sharded, const int32_t* ids,
                                  const uint32_t* offsets, uint32_t batch, uint32_t n_batches, uint32_t group, uint32_t k, bool overlap,
-                                 uint32_t* out_rows, float* out_scores, uint32_t* out_counts, fshost_stream_result* result) {
+                                 bool host_handoff, uint32_t* out_rows, float* out_scores, uint32_t* out_counts, fshost_stream_result* result) {
     using clock = std::chrono::steady_clock;
     const uint32_t dim = index ? fsgpu_index_dimension(index) : fsgpu_sharded_dimension(sharded);
     const uint32_t n_groups = (n_batches + group - 1) / group;
     const size_t group_texts = (size_t)group * batch;
-    // two embedding buffers: the encoder fills one while the search reads the other
-    std::vector<float> emb[2] = {std::vector<float>(group_texts * dim), std::vector<float>(group_texts * dim)};
+    // two embedding buffers: the encoder fills one while the search reads the other.  When the encoder and the index (a sharded
+    // handle's root) share a device the vectors never leave HBM: fsgpu_bert_embed_device -> device queries of the search
+    // (fsgpu_search_topk_batched_device_queries / fsgpu_sharded_request::queries_dev); `host_handoff` keeps them on the host path.
+    const int32_t enc_dev = fsgpu_bert_device(encoder);
+    const int32_t idx_dev = index ? fsgpu_index_device(index) : fsgpu_sharded_device(sharded, 0);
+    float* emb_dev[2] = {nullptr, nullptr};
+    bool on_device = !host_handoff && enc_dev >= 0 && enc_dev == idx_dev;
+    if (on_device)
+        for (int b = 0; b < 2 && on_device; ++b)
+            if (fsgpu_device_malloc(enc_dev, (uint64_t)group_texts * dim * 4, reinterpret_cast<void**>(&emb_dev[b])) != FSGPU_OK) on_device = false;
+    struct FreeDev {
+        int32_t dev;
+        float** p;
+        ~FreeDev() {
+            for (int b = 0; b < 2; ++b)
+                if (p[b]) (void)fsgpu_device_free(dev, p[b]);
+        }
+    } free_dev{enc_dev, emb_dev};
+    std::vector<float> emb[2];
+    if (!on_device) emb[0].resize(group_texts * dim), emb[1].resize(group_texts * dim);
     std::vector<uint32_t> rows(group_texts * k), counts(group_texts), local_offsets;
     std::vector<float> scores(group_texts * k);
     std::mutex mu;
@@ -48,7 +66,9 @@ fsgpu_status embed_search_stream(fsgpu_bert* encoder, fsgpu_index* index, fsgpu_
         for (size_t b = t0; b < t1; b += batch) {
             offs.resize(batch + 1);
             for (uint32_t i = 0; i <= batch; ++i) offs[i] = offsets[b + i] - offsets[b];
-            const fsgpu_status st = fsgpu_bert_embed(encoder, ids + offsets[b], offs.data(), batch, emb[g & 1].data() + (b - t0) * dim);
+            const fsgpu_status st = on_device
+                                        ? fsgpu_bert_embed_device(encoder, ids + offsets[b], offs.data(), batch, emb_dev[g & 1] + (b - t0) * dim)
+                                        : fsgpu_bert_embed(encoder, ids + offsets[b], offs.data(), batch, emb[g & 1].data() + (b - t0) * dim);
             if (st != FSGPU_OK) return st;
         }
         return FSGPU_OK;
@@ -59,9 +79,11 @@ fsgpu_status embed_search_stream(fsgpu_bert* encoder, fsgpu_index* index, fsgpu_
         uint32_t fb = 0;
         fsgpu_status st;
         if (index) {
-            st = fsgpu_search_topk_batched(index, emb[g & 1].data(), nq, dim, k, nullptr, rows.data(), scores.data(), counts.data(), &fb);
+            st = on_device ? fsgpu_search_topk_batched_device_queries(index, emb_dev[g & 1], nq, dim, k, rows.data(), scores.data(), counts.data(), &fb)
+                           : fsgpu_search_topk_batched(index, emb[g & 1].data(), nq, dim, k, nullptr, rows.data(), scores.data(), counts.data(), &fb);
         } else {
-            fsgpu_sharded_request rq{emb[g & 1].data(), nq, dim, k, FSGPU_SHARDED_BATCHED, 0, nullptr};
+            fsgpu_sharded_request rq{on_device ? nullptr : emb[g & 1].data(), nq, dim, k, FSGPU_SHARDED_BATCHED, 0, nullptr,
+                                     on_device ? emb_dev[g & 1] : nullptr};
             st = fsgpu_sharded_search(sharded, &rq, rows.data(), scores.data(), counts.data(), &fb);
         }
         if (st != FSGPU_OK) return st;
@@ -144,6 +166,7 @@ fsgpu_status embed_search_stream(fsgpu_bert* encoder, fsgpu_index* index, fsgpu_
     result->mean_encode_ms = n_groups ? enc_ms / n_groups : 0.0;
     result->mean_search_ms = n_groups ? search_ms / n_groups : 0.0;
     result->exact_fallbacks = fallbacks;
+    result->device_resident_handoff = on_device ? 1 : 0;
     return status;
 }
 

@@ -238,8 +238,9 @@ SearchError ShardedIndex::finish_init(int32_t exchange) {
             }
         }
     }
-    if (!use_rccl_ && w > 1) {
-        // peer copies: let every shard's device write into the root's gather buffer
+    if (w > 1) {
+        // peer access to the root's memory: the peer-copy exchange writes into its gather buffer, and device-resident queries are
+        // fetched from it (without it HIP stages such copies through the host: slower, still correct)
         for (uint32_t r = 1; r < w; ++r) {
             if (shards_[r]->device == shards_[0]->device) continue;
             int can = 0;
@@ -247,7 +248,7 @@ SearchError ShardedIndex::finish_init(int32_t exchange) {
             if (can) {
                 SH_HIP(hipSetDevice(shards_[r]->device));
                 const hipError_t e = hipDeviceEnablePeerAccess(shards_[0]->device, 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return hip_err(e, "hipDeviceEnablePeerAccess");
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled && !use_rccl_) return hip_err(e, "hipDeviceEnablePeerAccess");
                 (void)hipGetLastError();
             }
         }
@@ -321,7 +322,15 @@ SearchError ShardedIndex::shard_search(Shard& s, uint32_t r) {
     const uint64_t cc = two_pass ? std::max<uint64_t>((uint64_t)j.k * (j.multiplier ? j.multiplier : 1), j.k) : j.k;
     const size_t qbytes = (size_t)j.nq * dim_ * 4, lbytes = (size_t)j.nq * cc * 8 * (two_pass ? 2 : 1);
     SH_HIP(hipSetDevice(s.device));
-    SH_HIP(hipMemcpyAsync(sl.queries.ptr, j.queries, qbytes, hipMemcpyHostToDevice, s.stream));
+    // host queries: every shard copies them over ITS OWN PCIe link from the pinned block (the copies run side by side); device
+    // queries: they are in the root's HBM already, the others fetch them peer to peer
+    const float* qd = static_cast<const float*>(sl.queries.ptr);
+    if (j.queries_dev) {
+        if (r == 0 || s.device == shards_[0]->device) qd = j.queries_dev;
+        else SH_HIP(hipMemcpyAsync(sl.queries.ptr, j.queries_dev, qbytes, hipMemcpyDeviceToDevice, s.stream));
+    } else {
+        SH_HIP(hipMemcpyAsync(sl.queries.ptr, j.queries, qbytes, hipMemcpyHostToDevice, s.stream));
+    }
     const uint64_t* allow_dev = nullptr;
     if (j.has_allow && s.rows) {
         const RootSlot& rs = root_[j.slot];
@@ -332,7 +341,6 @@ SearchError ShardedIndex::shard_search(Shard& s, uint32_t r) {
     }
     s.fallbacks = 0;
     uint64_t* packed = static_cast<uint64_t*>(sl.packed.ptr);
-    const float* qd = static_cast<const float*>(sl.queries.ptr);
     if (s.rows == 0) {
         SH_HIP(hipMemsetAsync(packed, 0xff, lbytes, s.stream));
     } else if (two_pass) {
@@ -505,7 +513,7 @@ SearchError ShardedIndex::begin(const Request& rq, uint32_t query_len, uint64_t*
         SH_HIP(hipHostMalloc(&rs.stage, need, hipHostMallocPortable));
         rs.stage_bytes = need;
     }
-    std::memcpy(rs.stage, rq.queries, qbytes);
+    if (!rq.queries_dev) std::memcpy(rs.stage, rq.queries, qbytes);
     // EVERY reservation a shard or the exchange needs happens here, on the calling thread, before any work is enqueued: a
     // failed allocation must not leave some ranks inside a collective that others never enter
     const size_t lbytes = (size_t)rq.nq * cc * 8 * (two_pass ? 2 : 1);
@@ -528,6 +536,7 @@ SearchError ShardedIndex::begin(const Request& rq, uint32_t query_len, uint64_t*
             rs.allow_slices.insert(rs.allow_slices.end(), sl.begin(), sl.end());
         }
     job_.queries = static_cast<const float*>(rs.stage);
+    job_.queries_dev = rq.queries_dev;
     job_.nq = rq.nq;
     job_.k = rq.k;
     job_.multiplier = rq.multiplier;

@@ -48,6 +48,9 @@ class ShardedIndex {
     enum Mode : int32_t { kExact = 0, kBatched = 1, kInt8TwoPass = 2, kFourBitTwoPass = 3 };
     struct Request {
         const float* queries = nullptr;   // [nq, dim] host
+        const float* queries_dev = nullptr;   // ... or already resident on the ROOT shard's device (an encoder's device output): no
+                                              // staging and no H2D copy; the other shards fetch them from the root over xGMI (peer
+                                              // copies on their scan streams).  Must stay unchanged until end().
         uint32_t nq = 0, k = 0;
         Mode mode = kExact;
         uint32_t multiplier = 0;          // candidate_multiplier of the two-pass modes
@@ -78,6 +81,7 @@ class ShardedIndex {
     const VectorIndex* catalog() const { return catalog_.get(); }
     uint32_t shard_count() const { return (uint32_t)shards_.size(); }
     int32_t exchange_mode() const { return use_rccl_ ? 1 : 2; }
+    int32_t shard_device(uint32_t shard) const { return shard < shards_.size() ? shards_[shard]->device : -1; }
     bool shard_range(uint32_t shard, uint64_t* lo, uint64_t* hi) const;
     void set_hreduce(int32_t mode);
     // the corpus-wide max-abs the quantised copies of every shard are built from (0 until a two-pass search asked for it)
@@ -115,6 +119,7 @@ class ShardedIndex {
     };
     struct Job {
         const float* queries = nullptr;  // pinned staging
+        const float* queries_dev = nullptr;   // the request's device-resident queries (root device), if any
         uint32_t nq = 0, k = 0, multiplier = 0;
         Mode mode = kExact;
         int slot = 0;

@@ -2037,7 +2037,8 @@ SearchError VectorIndex::batched_fallback(BatchedPlan& p) {
 
 SearchError VectorIndex::search_top_k_batched(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
                                               const uint64_t* allow, uint32_t* out_rows, float* out_scores,
-                                              uint32_t* out_counts, uint32_t* fallbacks, const uint64_t* allow_resident_dev) {
+                                              uint32_t* out_counts, uint32_t* fallbacks, const uint64_t* allow_resident_dev,
+                                              bool queries_on_device) {
     if (fallbacks) *fallbacks = 0;
     FSGPU_TRY(ensure_query_dimension(query_len));
     if (nq == 0) return ok();
@@ -2047,11 +2048,15 @@ SearchError VectorIndex::search_top_k_batched(const float* queries, uint32_t nq,
     }
     FSGPU_HIP(hipSetDevice(device_));
     const size_t qbytes = (size_t)nq * dim_ * 4;
-    FSGPU_TRY(ws_queries_.reserve(qbytes));
     FSGPU_TRY(ws_rows_.reserve((size_t)nq * k * 4));
     FSGPU_TRY(ws_scores_.reserve((size_t)nq * k * 4));
     FSGPU_TRY(ws_counts_.reserve((size_t)nq * 4));
-    FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, queries, qbytes, hipMemcpyHostToDevice, stream_));
+    const float* q_dev = queries;
+    if (!queries_on_device) {
+        FSGPU_TRY(ws_queries_.reserve(qbytes));
+        FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, queries, qbytes, hipMemcpyHostToDevice, stream_));
+        q_dev = static_cast<const float*>(ws_queries_.ptr);
+    }
     const uint64_t* allow_dev = allow ? allow_resident_dev : nullptr;
     if (allow && !allow_dev) {
         const size_t words = (size_t)((nrows_ + 63) / 64);
@@ -2059,7 +2064,7 @@ SearchError VectorIndex::search_top_k_batched(const float* queries, uint32_t nq,
         FSGPU_HIP(hipMemcpyAsync(ws_allow_.ptr, allow, words * 8, hipMemcpyHostToDevice, stream_));
         allow_dev = static_cast<const uint64_t*>(ws_allow_.ptr);
     }
-    FSGPU_TRY(search_top_k_batched_device(static_cast<const float*>(ws_queries_.ptr), nq, query_len, k, allow_dev,
+    FSGPU_TRY(search_top_k_batched_device(q_dev, nq, query_len, k, allow_dev,
                                           static_cast<uint32_t*>(ws_rows_.ptr), static_cast<float*>(ws_scores_.ptr),
                                           static_cast<uint32_t*>(ws_counts_.ptr), stream_, fallbacks));
     FSGPU_HIP(hipMemcpyAsync(out_rows, ws_rows_.ptr, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream_));
@@ -2610,9 +2615,9 @@ SearchError Model2VecEmbedder::init(int device, const float* table, uint32_t voc
     return ok();
 }
 
-SearchError Model2VecEmbedder::embed_batch(const uint32_t* ids, const uint32_t* offsets, uint32_t n, float* out) {
+SearchError Model2VecEmbedder::embed_batch(const uint32_t* ids, const uint32_t* offsets, uint32_t n, float* out, float* out_dev) {
     if (n == 0) return ok();
-    if (!offsets || !out) return make_error(FSGPU_ERR_NULL_ARGUMENT, "offsets/out is null");
+    if (!offsets || (!out && !out_dev)) return make_error(FSGPU_ERR_NULL_ARGUMENT, "offsets/out is null");
     for (uint32_t i = 0; i < n; ++i)
         if (offsets[i + 1] < offsets[i]) return make_error(FSGPU_ERR_INVALID_CONFIG, "offsets must be non-decreasing");
     const uint32_t total = offsets[n];
@@ -2627,8 +2632,8 @@ SearchError Model2VecEmbedder::embed_batch(const uint32_t* ids, const uint32_t* 
     FSGPU_HIP(hipMemcpyAsync(offsets_.ptr, offsets, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, stream_));
     FSGPU_HIP(launch_m2v_embed(static_cast<const float*>(table_.ptr), vocab_, dim_,
                                static_cast<const uint32_t*>(ids_.ptr), static_cast<const uint32_t*>(offsets_.ptr), n,
-                               static_cast<float*>(out_.ptr), stream_));
-    FSGPU_HIP(hipMemcpyAsync(out, out_.ptr, (size_t)n * dim_ * 4, hipMemcpyDeviceToHost, stream_));
+                               out_dev ? out_dev : static_cast<float*>(out_.ptr), stream_));   // (device output: the vectors stay in HBM)
+    if (out) FSGPU_HIP(hipMemcpyAsync(out, out_dev ? out_dev : out_.ptr, (size_t)n * dim_ * 4, hipMemcpyDeviceToHost, stream_));
     FSGPU_HIP(hipStreamSynchronize(stream_));
     return ok();
 }

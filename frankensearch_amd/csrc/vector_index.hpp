@@ -88,7 +88,8 @@ class VectorIndex {
                                             uint64_t* out_packed_dev = nullptr);
     SearchError search_top_k_batched(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
                                      const uint64_t* allow, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
-                                     uint32_t* fallbacks, const uint64_t* allow_resident_dev = nullptr);
+                                     uint32_t* fallbacks, const uint64_t* allow_resident_dev = nullptr,
+                                     bool queries_on_device = false);   // queries: a device pointer (an encoder's device output)
     // Batched search_top_k_int8_two_pass (search.rs:514-661): int8 pass 1 on the matrix cores (exact integer scores, so the
     // k*multiplier candidates are exactly the reference's), exact f16 rescore, top-k.  No doc-id dedup (raw row ids).
     SearchError search_top_k_int8_batched_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
@@ -286,8 +287,10 @@ class Model2VecEmbedder {
   public:
     ~Model2VecEmbedder();
     SearchError init(int device, const float* table, uint32_t vocab, uint32_t dim);
-    SearchError embed_batch(const uint32_t* ids, const uint32_t* offsets, uint32_t n, float* out);
+    // out_dev (on this embedder's device, may be null): the vectors are left in device memory; out (may then be null): host copy
+    SearchError embed_batch(const uint32_t* ids, const uint32_t* offsets, uint32_t n, float* out, float* out_dev = nullptr);
     uint32_t dimension() const { return dim_; }
+    int device() const { return device_; }
 
   private:
     std::mutex mu_;

@@ -40,7 +40,7 @@ class _Metrics(C.Structure):
 
 class _StreamResult(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("wall_seconds", "queries_per_sec", "mean_encode_ms", "mean_search_ms")] + \
-               [(n, C.c_uint64) for n in ("queries", "groups", "exact_fallbacks")]
+               [(n, C.c_uint64) for n in ("queries", "groups", "exact_fallbacks", "device_resident_handoff")]
 
 
 class _ScoredDoc(C.Structure):
@@ -177,7 +177,7 @@ class NativeTwoTierSearcher:
 
 
 def embed_search_stream(encoder, index, ids: np.ndarray, offsets: np.ndarray, batch: int, k: int, group: int = 1,
-                        overlap: bool = True, want_hits: bool = True):
+                        overlap: bool = True, want_hits: bool = True, host_handoff: bool = False):
     """BASELINE config 5's serving loop in native code (fshost_embed_search_stream): token-id batches -> MiniLM on the GPU ->
     batched exact top-k, the encode of group g + 1 overlapped with the search of group g.  `index` is a VectorIndex or a
     NativeShardedIndex.  Returns (rows, scores, counts, stats dict)."""
@@ -194,7 +194,7 @@ def embed_search_stream(encoder, index, ids: np.ndarray, offsets: np.ndarray, ba
     res = _StreamResult()
     sharded = isinstance(index, NativeShardedIndex)
     check(lib().fshost_embed_search_stream(encoder._h, None if sharded else index._h, index._h if sharded else None, ids.ctypes.data,
-                                           offsets.ctypes.data, batch, n_batches, group, k, int(overlap),
+                                           offsets.ctypes.data, batch, n_batches, group, k, int(overlap) | (2 if host_handoff else 0),
                                            rows.ctypes.data if want_hits else None, scores.ctypes.data if want_hits else None,
                                            counts.ctypes.data if want_hits else None, C.byref(res)))
     return rows, scores, counts, {n: getattr(res, n) for n, _ in _StreamResult._fields_}

@@ -503,14 +503,14 @@ class NativeShardedIndex:
 
     class _Request(C.Structure):
         _fields_ = [("queries", C.c_void_p), ("nq", C.c_uint32), ("query_len", C.c_uint32), ("k", C.c_uint32),
-                    ("mode", C.c_int32), ("candidate_multiplier", C.c_uint32), ("allow_bitmap", C.c_void_p)]
+                    ("mode", C.c_int32), ("candidate_multiplier", C.c_uint32), ("allow_bitmap", C.c_void_p), ("queries_dev", C.c_void_p)]
 
     def _request(self, queries, k, mode, multiplier, allow):
         q = np.ascontiguousarray(queries, dtype=np.float32)
         if q.ndim == 1:
             q = q[None, :]
         bm = pack_bitmap(allow) if allow is not None else None
-        rq = self._Request(q.ctypes.data, q.shape[0], q.shape[1], k, mode, multiplier, bm.ctypes.data if bm is not None else None)
+        rq = self._Request(q.ctypes.data, q.shape[0], q.shape[1], k, mode, multiplier, bm.ctypes.data if bm is not None else None, None)
         return rq, (q, bm)
 
     @staticmethod

@@ -307,6 +307,7 @@ uint64_t fsgpu_sharded_record_count(const fsgpu_sharded *idx);
 uint32_t fsgpu_sharded_dimension(const fsgpu_sharded *idx);
 uint32_t fsgpu_sharded_shard_count(const fsgpu_sharded *idx);
 int32_t fsgpu_sharded_exchange_mode(const fsgpu_sharded *idx); /* FSGPU_EXCHANGE_RCCL or FSGPU_EXCHANGE_PEER_COPY, as chosen */
+int32_t fsgpu_sharded_device(const fsgpu_sharded *idx, uint32_t shard); /* the HIP device of a shard (shard 0 = the root: merges, takes queries_dev) */
 fsgpu_status fsgpu_sharded_shard_range(const fsgpu_sharded *idx, uint32_t shard, uint64_t *row_lo, uint64_t *row_hi);
 fsgpu_status fsgpu_sharded_set_hreduce(fsgpu_sharded *idx, int32_t mode);
 /* VectorIndex::search_top_k(query, limit, None) for nq host queries over all shards (exact kernels); outputs as
@@ -342,6 +343,9 @@ typedef struct fsgpu_sharded_request {
     int32_t mode;
     uint32_t candidate_multiplier; /* two-pass modes (0 counts as 1, as in the reference) */
     const uint64_t *allow_bitmap;  /* ceil(N/64) words or NULL */
+    const float *queries_dev;      /* NULL, or the queries already RESIDENT on devices[0] (an encoder's device output,
+                                    * fsgpu_bert_embed_device): `queries` is then ignored — no staging, no H2D copy; the other shards
+                                    * fetch them from the root peer to peer (xGMI).  Must stay unchanged until the search has ended. */
 } fsgpu_sharded_request;
 fsgpu_status fsgpu_sharded_search(fsgpu_sharded *idx, const fsgpu_sharded_request *request, uint32_t *out_rows, float *out_scores,
                                   uint32_t *out_counts, uint32_t *out_fallbacks);
@@ -436,6 +440,24 @@ uint32_t fsgpu_bert_dimension(const fsgpu_bert *m); /* Embedder::dimension: the 
  * no padding); every returned token is mean-pooled, then L2-normalised (zeros for empty / zero-norm,
  * fastembed_embedder.rs:416-426).  out is [n, hidden]. */
 fsgpu_status fsgpu_bert_embed(fsgpu_bert *m, const int32_t *ids, const uint32_t *offsets, uint32_t n, float *out);
+
+/* ---- device-resident hand-offs: encoder -> search without the vectors crossing PCIe ---- */
+/* The reference's seam between the two is a host Vec<f32> (traits.rs:401-582 -> search.rs:192); on the GPU both ends live in HBM.
+ * fsgpu_bert_embed_device / fsgpu_m2v_embed_device are fsgpu_bert_embed / fsgpu_m2v_embed with the [n, dim] output left in device
+ * memory `out_dev` (on the embedder's device; complete when the call returns).  It feeds fsgpu_search_topk_device /
+ * fsgpu_search_topk_batched_device, fsgpu_search_topk_batched_device_queries (device queries, host results: what a serving loop
+ * wants), or a sharded search through fsgpu_sharded_request::queries_dev.  fsgpu_device_malloc / _free give a host that links
+ * nothing but this library the buffers for it. */
+fsgpu_status fsgpu_bert_embed_device(fsgpu_bert *m, const int32_t *ids, const uint32_t *offsets, uint32_t n, float *out_dev);
+fsgpu_status fsgpu_m2v_embed_device(fsgpu_m2v *m, const uint32_t *ids, const uint32_t *offsets, uint32_t n, float *out_dev);
+fsgpu_status fsgpu_search_topk_batched_device_queries(fsgpu_index *idx, const float *queries_dev, uint32_t nq, uint32_t query_len,
+                                                      uint32_t k, uint32_t *out_rows, float *out_scores, uint32_t *out_counts,
+                                                      uint32_t *out_fallbacks);
+fsgpu_status fsgpu_device_malloc(int32_t device, uint64_t bytes, void **out);
+fsgpu_status fsgpu_device_free(int32_t device, void *ptr);
+int32_t fsgpu_bert_device(const fsgpu_bert *m);
+int32_t fsgpu_m2v_device(const fsgpu_m2v *m);
+int32_t fsgpu_index_device(const fsgpu_index *idx);
 
 /* ---- host-side rank fusion (O(k), CPU, no GPU needed) ---- */
 /* One ranked hit: ScoredResult / VectorHit as the fusion code reads them

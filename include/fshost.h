@@ -123,13 +123,17 @@ fsgpu_status fshost_run_load(fshost_two_tier *s, const fshost_load_config *confi
  * row-sharded handle; exactly one of `index` / `sharded` is non-null).  overlap != 0: a second host thread encodes group g + 1
  * while group g is searched (what a Rust host's rayon::join of the two stages does; the encoder's stream has the higher
  * priority, so its short kernels are not queued behind the chip-filling scan launches); overlap == 0 runs the two stages in
- * turn on the calling thread.  Text t owns ids[offsets[t] .. offsets[t + 1]); the texts are taken batch by batch, `group`
+ * turn on the calling thread.  `overlap` is a bit set: 1 = overlapped, 2 = keep the embeddings on the HOST path (fsgpu_bert_embed ->
+ * host vectors -> host-pointer search).  Without bit 2, an encoder that shares its device with the index (a sharded handle's root
+ * shard) hands the vectors over in device memory: fsgpu_bert_embed_device -> fsgpu_search_topk_batched_device_queries /
+ * fsgpu_sharded_request::queries_dev (the other shards fetch them from the root peer to peer).  Text t owns ids[offsets[t] .. offsets[t + 1]); the texts are taken batch by batch, `group`
  * batches per search (1: one search per encoder batch; 2: two encoder batches share each pass over the slab).  out_* hold
  * [n_batches * batch, k] rows / scores and [n_batches * batch] counts (any may be NULL). */
 typedef struct fshost_stream_result {
     double wall_seconds, queries_per_sec;
     double mean_encode_ms, mean_search_ms; /* per group */
     uint64_t queries, groups, exact_fallbacks;
+    uint64_t device_resident_handoff; /* 1: the embeddings went from the encoder to the search in device memory */
 } fshost_stream_result;
 fsgpu_status fshost_embed_search_stream(fsgpu_bert *encoder, fsgpu_index *index, fsgpu_sharded *sharded, const int32_t *ids,
                                         const uint32_t *offsets, uint32_t batch, uint32_t n_batches, uint32_t group, uint32_t k,

@@ -611,9 +611,11 @@ def test_embed_search_stream_overlapped_equals_the_stages_in_turn():
     for target in (idx, sh):
         for group in (1, 2):
             for overlap in (False, True):
-                r, s, c, stats = embed_search_stream(bert, target, ids, offs, batch, k, group=group, overlap=overlap)
-                assert np.array_equal(r, want_r) and np.array_equal(s.view(np.uint32), want_s.view(np.uint32)), (group, overlap)
-                assert np.all(c == k) and stats["queries"] == batch * nb and stats["groups"] == (nb + group - 1) // group
-                assert stats["queries_per_sec"] > 0
+                for host_handoff in (False, True):   # the embeddings handed over in device memory / through host vectors
+                    r, s, c, stats = embed_search_stream(bert, target, ids, offs, batch, k, group=group, overlap=overlap,
+                                                         host_handoff=host_handoff)
+                    assert np.array_equal(r, want_r) and np.array_equal(s.view(np.uint32), want_s.view(np.uint32)), (group, overlap, host_handoff)
+                    assert np.all(c == k) and stats["queries"] == batch * nb and stats["groups"] == (nb + group - 1) // group
+                    assert stats["queries_per_sec"] > 0 and stats["device_resident_handoff"] == (0 if host_handoff else 1)
     idx.close()
     sh.close()
