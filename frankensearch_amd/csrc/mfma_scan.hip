@@ -221,7 +221,7 @@ __global__ __launch_bounds__(WPB * 64) void scan_mfma_kernel(MfmaScanArgs args) 
                         if constexpr (EB == 2) m = __builtin_fmaxf(m, acc[s][nt][r]);
                         else m = acc[s][nt][r] > m ? acc[s][nt][r] : m;
                     }
-                    if (!((float)m >= th)) continue;
+                    if (__builtin_expect(!((float)m >= th), 1)) continue;   // (expected: the append code goes out of line, the tile loop falls through)
                     const int q = nt * 16 + frow;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)

@@ -535,9 +535,12 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
             }
         }
     };
+    // (the slow paths are marked unexpected: left to itself hipcc lays every emit_tiles body out INSIDE the tile loop — nine copies of
+    // ~1,000 instructions between the MFMA groups, each skipped by a taken branch: the loop's 192 MFMAs spread over 7,000 instructions;
+    // with the hint the loop is ~480 contiguous instructions that fall through and the append code sits behind the function's end)
     auto emit_pair = [&](uint32_t t, int sp, const acc_t (&acc)[2][QT]) {
         // one test for the whole pair; almost always negative: survivors are a few hundred rows of the slab
-        if (any_passes(acc, 0, QT)) emit_tiles(t, sp, acc, 0, QT);
+        if (__builtin_expect(any_passes(acc, 0, QT), 0)) emit_tiles(t, sp, acc, 0, QT);
     };
 
     // The append path reads the tombstone / allow words with SCALAR loads (sload_u64).  The scalar data cache is not invalidated
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (anyB) emit_tiles(tB, ((p + NP - 1) % NP) * 2, acc, QA, QT);
+                if (__builtin_expect(anyB, 0)) emit_tiles(tB, ((p + NP - 1) % NP) * 2, acc, QA, QT);
                 // ---- phase 2: query tiles [QA, QT); the next pair's fragments roll in behind each k-step; this pair's tiles
                 // [0, QA) are tested in its shadow
                 init_acc(QA, QT);
@@ -664,7 +667,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
                 if constexpr (FLAGS) {   // this wave's last read of the tile is out (the last pair's fragments): its slot may be refilled
                     if (p + 2 == NP) flag_post(flags + 16 + slot * 4, lane);
                 }
-                if (anyA) emit_tiles(t, p * 2, acc, 0, QA);
+                if (__builtin_expect(anyA, 0)) emit_tiles(t, p * 2, acc, 0, QA);
                 tB = t;
             }
             cursor_next(cc);
@@ -672,7 +675,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
             slot = slot_next;
             cur = nxt;
         }
-        if (any_passes(acc, QA, QT)) emit_tiles(tB, (NP - 1) * 2, acc, QA, QT);
+        if (__builtin_expect(any_passes(acc, QA, QT), 0)) emit_tiles(tB, (NP - 1) * 2, acc, QA, QT);
     } else {
     half8 fa[2][2][CK];   // fragment double buffer: [buffer][sub-tile of the pair][k-step of the chunk]
     wait_vmcnt<PW*(NSLOT - 2)>();          // this wave's share of tile 0 has landed ...

@@ -1163,13 +1163,14 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
             // (scripts/r04/i8_bound_study.py).  So the first answer is a larger second sample for this index — 2 x, then 4 x: half /
             // a quarter as many survivors for +0.1 / +0.3 ms of sampling per 512-query pass at 10M rows — and only an index that
             // still hands an eighth of its batches on twice in a row at 4 x goes to the f16 filter.
-            if (nq >= 16 && (uint64_t)refiltered * 8 > nq) {
-                if (i8f_sample_boost_ < 4 && nq >= 256) {
-                    i8f_sample_boost_ *= 2;
-                    i8f_strikes_ = 0;
-                } else if (++i8f_strikes_ >= 2 && batched_filter == 0 && knobs().filter == 0) {
-                    i8f_disabled_ = true;
-                }
+            // (a handful of leftovers already costs a pass of their own over the f16 slab — as much as the 512 queries they came
+            // with —, so the sample grows as soon as more than 1 in 64 of a wide batch is handed on; the filter is given up only
+            // when an eighth still is, twice in a row, at the largest sample)
+            if (nq >= 256 && i8f_sample_boost_ < 4 && (uint64_t)refiltered * 64 > nq) {
+                i8f_sample_boost_ *= 2;
+                i8f_strikes_ = 0;
+            } else if (nq >= 16 && (uint64_t)refiltered * 8 > nq) {
+                if (++i8f_strikes_ >= 2 && batched_filter == 0 && knobs().filter == 0) i8f_disabled_ = true;
             } else {
                 i8f_strikes_ = 0;
             }
