@@ -1009,6 +1009,11 @@ SearchError VectorIndex::search_top_k(const float* queries, uint32_t nq, uint32_
             std::memcpy(q_pin, queries, qbytes);
             FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, q_pin, qbytes, hipMemcpyHostToDevice, stream_));
         }
+        if (via_filter && nq == 1 && k <= 32 && i8_ready_ && i8_stats_ready_ && variant == 0) {
+            bool certified = false;
+            FSGPU_TRY(certified_i8_lone_query(queries, k, out_rows, out_scores, out_counts, &certified));
+            if (certified) return ok();
+        }
         if (via_filter) {
             uint32_t fb = 0;
             FSGPU_TRY(search_top_k_batched_device(static_cast<const float*>(ws_queries_.ptr), nq, query_len, k, nullptr, rows_pin,
@@ -1086,6 +1091,111 @@ SearchError VectorIndex::search_top_k(const float* queries, uint32_t nq, uint32_
     FSGPU_HIP(hipMemcpyAsync(out_scores, ws_scores_.ptr, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream_));
     FSGPU_HIP(hipMemcpyAsync(out_counts, ws_counts_.ptr, (size_t)nq * 4, hipMemcpyDeviceToHost, stream_));
     FSGPU_HIP(hipStreamSynchronize(stream_));
+    return ok();
+}
+
+// See vector_index.hpp.  Same results as the exact kernels, bit for bit: the candidates are re-scored in the reference's order
+// (gather_dot_kernel) and the certificate is the int8 filter's proven bound (prepare_queries_i8_filter_kernel: the quantised query IS
+// quantize_i8_query's, the slab IS quantize_f16_le_bytes_to_i8's) applied to the list's own scores: every true top-k row has
+// idot >= idot_k - 2 delta, and the kept list is exactly the 256 largest idot.
+SearchError VectorIndex::certified_i8_lone_query(const float* query, uint32_t k, uint32_t* out_rows, float* out_scores,
+                                                 uint32_t* out_count, bool* certified) {
+    *certified = false;
+    constexpr uint32_t CC = 256;
+    const uint32_t k_eff = (uint32_t)std::min<uint64_t>(k, nrows_);
+    if (k_eff == 0 || nrows_ < 4 * CC || !scan_i8_fused_supported((int)dim_, 256) || pinned_io() == nullptr) return ok();
+    const size_t qbytes = (size_t)dim_ * 4;
+    const size_t o_out = (qbytes + 255) & ~(size_t)255, o_approx = (o_out + (size_t)k * 8 + 4 + 255) & ~(size_t)255,
+                 o_delta = o_approx + (size_t)CC * 8;
+    if (o_delta + 64 > kPinnedIoBytes) return ok();
+    unsigned char* io = static_cast<unsigned char*>(io_host_);
+    FSGPU_TRY(ws_i8_query_.reserve(dim_));
+    FSGPU_TRY(ws_queries_.reserve(qbytes));
+    FSGPU_TRY(ws_cand_packed_.reserve((size_t)CC * 8));
+    FSGPU_TRY(ws_cand_rows_.reserve((size_t)CC * 4));
+    FSGPU_TRY(ws_cand_scores_.reserve((size_t)CC * 4));
+    std::memcpy(io, query, qbytes);
+    FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, io, qbytes, hipMemcpyHostToDevice, stream_));
+    u64* approx_pin = reinterpret_cast<u64*>(io + o_approx);
+    float* delta_pin = reinterpret_cast<float*>(io + o_delta);
+    // the query quantised as the filter (and the reference's quantize_i8_query) does, and its bound, written where the host reads it
+    FSGPU_HIP(launch_prepare_queries_i8_filter(static_cast<const float*>(ws_queries_.ptr), 1, 1, dim_, dim_,
+                                               static_cast<const unsigned int*>(i8_max_.ptr), static_cast<const unsigned int*>(i8_stats_.ptr),
+                                               ws_i8_query_.ptr, delta_pin, stream_));
+    ScanArgs a = base_args(static_cast<const float*>(ws_queries_.ptr), nullptr);
+    int per_cu = 1;
+    FSGPU_HIP(launch_scan_i8(a, i8_slab_.ptr, ws_i8_query_.ptr, 256, 1, stream_, &per_cu));
+    per_cu = std::min(per_cu, knobs().i8_per_cu > 0 ? knobs().i8_per_cu : 1);
+    int grid = num_cus_ * per_cu;
+    const int max_useful = (int)(((nrows_ + 15) / 16 + 3) / 4);
+    grid = std::max(1, std::min(grid, max_useful));
+    FSGPU_TRY(ws_partial_.reserve((size_t)grid * CC * 8));
+    a.partial = static_cast<u64*>(ws_partial_.ptr);
+    a.k = CC;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (profiling) {
+        FSGPU_HIP(hipEventCreate(&e0));
+        FSGPU_HIP(hipEventCreate(&e1));
+        FSGPU_HIP(hipEventRecord(e0, stream_));
+    }
+    FSGPU_HIP(launch_scan_i8(a, i8_slab_.ptr, ws_i8_query_.ptr, 256, grid, stream_, nullptr));
+    if (profiling) {
+        FSGPU_HIP(hipEventRecord(e1, stream_));
+        events_.emplace_back(e0, e1);
+        profiled_rows_ += nrows_;
+        profiled_elem_bytes_ = 1;
+    }
+    uint32_t* cand_rows = static_cast<uint32_t*>(ws_cand_rows_.ptr);
+    float* cand_scores = static_cast<float*>(ws_cand_scores_.ptr);
+    u64* cand_packed = static_cast<u64*>(ws_cand_packed_.ptr);
+    MergeArgs m;
+    m.lists = a.partial;
+    m.q_stride = (uint64_t)grid * CC;
+    m.l_stride = CC;
+    m.nlists = (uint32_t)grid;
+    m.list_len = CC;
+    m.k = CC;
+    m.out_stride = CC;
+    m.out_rows = cand_rows;
+    m.out_scores = nullptr;
+    m.out_counts = nullptr;
+    m.out_packed = approx_pin;   // the 256 best (integer score, row) entries, best first: the certificate reads two of them
+    FSGPU_HIP(launch_merge_topk(m, 1, stream_));
+    FSGPU_HIP(hipMemsetAsync(cand_scores, 0, (size_t)CC * 4, stream_));
+    FSGPU_HIP(launch_gather_dot(a, cand_rows, CC, cand_scores, stream_));
+    FSGPU_HIP(launch_pack_hits(cand_rows, cand_scores, CC, cand_packed, stream_));
+    MergeArgs m2;
+    m2.lists = cand_packed;
+    m2.q_stride = CC;
+    m2.l_stride = CC;
+    m2.nlists = 1;
+    m2.list_len = CC;
+    m2.k = k_eff;
+    m2.out_stride = k;
+    m2.out_rows = reinterpret_cast<uint32_t*>(io + o_out);
+    m2.out_scores = reinterpret_cast<float*>(io + o_out + (size_t)k * 4);
+    m2.out_counts = reinterpret_cast<uint32_t*>(io + o_out + (size_t)k * 8);
+    m2.out_packed = nullptr;
+    m2.lists_sorted = 0;   // candidates arrive in integer-score order
+    FSGPU_HIP(launch_merge_topk(m2, 1, stream_));
+    FSGPU_HIP(hipStreamSynchronize(stream_));
+    const float delta = *delta_pin;
+    if (!(delta >= 0.f)) return ok();   // a query the bound cannot cover (zero, non-finite, a slab with non-finite values)
+    uint32_t valid = 0;
+    while (valid < CC && approx_pin[valid] != ~0ull) ++valid;   // (kEmpty: all ones)
+    if (valid >= CC) {
+        if (k_eff > CC) return ok();
+        float s_k, s_last;
+        const uint32_t bk = (uint32_t)(approx_pin[k_eff - 1] >> 32), bl = (uint32_t)(approx_pin[CC - 1] >> 32);
+        std::memcpy(&s_k, &bk, 4);
+        std::memcpy(&s_last, &bl, 4);
+        if (!(s_last < s_k - 2.0f * delta)) return ok();   // rows within the margin may lie beyond the list: the staged path decides
+    }   // (fewer than 256 entries: every live row is in the list)
+    std::memcpy(out_rows, m2.out_rows, (size_t)k * 4);
+    std::memcpy(out_scores, m2.out_scores, (size_t)k * 4);
+    *out_count = *m2.out_counts;
+    ++i8f_queries;
+    *certified = true;
     return ok();
 }
 

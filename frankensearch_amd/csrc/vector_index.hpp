@@ -212,6 +212,12 @@ class VectorIndex {
     SearchError quantized_two_pass(const float* query, uint32_t query_len, uint32_t k, uint32_t multiplier, int bits,
                                    uint32_t* out_rows, float* out_scores, uint32_t* out_count, u64* approx_out_dev = nullptr,
                                    u64* exact_out_dev = nullptr);
+    // The lone query of the int8 latency path: ONE fused pass over the int8 slab that keeps the 256 best integer scores
+    // (scan_i8_topk_kernel, 0.75 of HBM peak), their exact re-score, and a certificate — the 256th integer score lies more than
+    // 2 delta below the k-th, so every row that could reach the exact top k was among them.  *certified = false: nothing was
+    // written, the staged filter path answers.
+    SearchError certified_i8_lone_query(const float* query, uint32_t k, uint32_t* out_rows, float* out_scores, uint32_t* out_count,
+                                        bool* certified);
     SearchError common_init(int device);
     SearchError fused_search(const float* queries_dev, uint32_t nq, uint32_t k_out, uint32_t k_eff,
                              const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,

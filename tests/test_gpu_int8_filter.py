@@ -336,3 +336,34 @@ def test_three_thousand_filtered_repetitions_return_the_same_bits(fa):
             assert np.array_equal(br, er), (bitmap is not None, rep)
             assert np.array_equal(bs.view(np.uint32), es), (bitmap is not None, rep)
     idx.close()
+
+
+def test_lone_query_certified_single_pass_equals_the_exact_kernels(fa, oracle):
+    """The int8 latency path's lone query (fsgpu_index_set_int8_latency): one fused pass keeping the 256 best integer scores, exact
+    re-score, certificate (the 256th integer score more than 2 delta below the k-th).  Rows and score bits equal the exact kernels'
+    and the oracle's — on a corpus where the certificate holds, with tombstones, and on one where it cannot (thousands of rows
+    within the margin: the staged filter path answers, same bits)."""
+    rng = np.random.default_rng(23)
+    dim, n = 384, 200_003
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    dense = x.copy()
+    dense[5000:11000] = dense[5000] + (rng.standard_normal((6000, dim)) * 1e-3).astype(np.float32)   # 6,000 near-duplicates
+    for corpus, probe_row in ((x, 77), (dense, 5003)):
+        slab = corpus.astype(np.float16).view(np.uint16)
+        live = rng.random(n) > 0.1
+        a, b = fa.VectorIndex.from_slab(slab, live=live), fa.VectorIndex.from_slab(slab, live=live)
+        b.set_int8_latency(True)
+        q = corpus[rng.integers(0, n, 12)] + (rng.standard_normal((12, dim)) * 0.1).astype(np.float32)
+        q[0] = corpus[probe_row]
+        for rep in range(2):   # (the first call builds the int8 copy and its statistics through the staged path)
+            for k in (1, 10, 30):
+                for i in range(12):
+                    ra, sa, ca = a.search_batch(q[i], k)
+                    rb, sb, cb = b.search_batch(q[i], k)
+                    assert np.array_equal(ca, cb) and np.array_equal(ra, rb) and np.array_equal(bits(sa), bits(sb)), (rep, k, i)
+        orow, osc = oracle.search_top_k(slab, q[0], 10, live=live)
+        rb, sb, _ = b.search_batch(q[0], 10)
+        assert np.array_equal(rb[0], orow) and np.array_equal(bits(sb[0]), bits(osc))
+        a.close()
+        b.close()
