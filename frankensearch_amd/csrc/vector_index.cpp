@@ -1276,7 +1276,10 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
             // (a handful of leftovers already costs a pass of their own over the f16 slab — as much as the 512 queries they came
             // with —, so the sample grows as soon as more than 1 in 64 of a wide batch is handed on; the filter is given up only
             // when an eighth still is, twice in a row, at the largest sample)
-            if (nq >= 256 && i8f_sample_boost_ < 4 && (uint64_t)refiltered * 64 > nq) {
+            // (measured on the anisotropic / Zipf corpus at 10M rows, scripts/r04/outlier_census.py: 150 of 1,024 queries handed on at
+            // the base sample, 69 at 2 x, 580 at 4 x — the larger sample's own selection then overflows its candidate pool —, so 2 x is
+            // as far as it goes)
+            if (nq >= 256 && i8f_sample_boost_ < 2 && (uint64_t)refiltered * 64 > nq) {
                 i8f_sample_boost_ *= 2;
                 i8f_strikes_ = 0;
             } else if (nq >= 16 && (uint64_t)refiltered * 8 > nq) {
