@@ -36,7 +36,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 matrix-core peak (same guide)
 MFMA_I8_PEAK_TOPS = 5000.0     # v_mfma_i32_16x16x64_i8 issues at twice the f16 rate (the guide's microbenchmark: >= 3944 TOPS)
-PROFILE_ROUND = "r03"   # profiles/<round>/pmc_summary.json: the PMC pass that belongs to this build's kernels
+PROFILE_ROUND = "r04"   # profiles/<round>/pmc_summary.json: the PMC pass that belongs to this build's kernels
 CLUSTERS = 64
 NOISE = 0.30
 
@@ -372,6 +372,29 @@ def encoder_section(device, local_rank: int):
         bert.embed_flat(ids[offs[i]:offs[i + 1]], np.array([0, offs[i + 1] - offs[i]], dtype=np.uint32), emb[:1])
         one.append((time.perf_counter() - t0) * 1e3)
     bert.embed_flat(ids, offs, emb)
+    # the document shape of an index build (index_builder.rs:191,416): 32 texts x 512 tokens, a plain M = 16,384 GEMM chain
+    doc_ids = np.concatenate([np.concatenate([[101], rng.integers(1000, 30000, 510), [102]]).astype(np.int32) for _ in range(32)])
+    doc_offs = (np.arange(33) * 512).astype(np.uint32)
+    doc_emb = np.empty((32, 384), dtype=np.float32)
+    for _ in range(2):
+        bert.embed_flat(doc_ids, doc_offs, doc_emb)
+    dlat = []
+    for _ in range(8):
+        t0 = time.perf_counter()
+        bert.embed_flat(doc_ids, doc_offs, doc_emb)
+        dlat.append((time.perf_counter() - t0) * 1e3)
+    doc_ms = float(np.median(dlat))
+
+    def bert_flops(lengths):
+        """21.23 MFLOP per token in the linears + 6 layers x 4 S x 384 per token of attention (S = the text's length)."""
+        lengths = np.asarray(lengths, dtype=np.float64)
+        return float(np.sum(lengths * 21.23e6 + lengths * 6 * 4 * lengths * 384))
+
+    def enc_roofline(flops, ms):
+        tf = flops / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TFLOPS,
+                "algorithmic_flops": flops, "ms": ms,
+                "note": "whole forward at the C ABI (host pointers in and out) against the dense f16 matrix-core peak"}
     nthreads = _oracle_threads()
     cpu = bert_oracle.CForward(w, 6)
     sample = 64
@@ -408,6 +431,8 @@ def encoder_section(device, local_rank: int):
         "minilm_l6": {"texts_per_batch": 256, "tokens_per_batch": int(ids.size), "gpu_ms_per_batch": gpu_ms,
                       "gpu_texts_per_sec": 256 / (gpu_ms * 1e-3), "gpu_single_text_p50_ms": float(np.median(one)),
                       "max_abs_err_vs_cpu_f32": err, "min_cosine_vs_cpu_f32": cos,
+                      "roofline": enc_roofline(bert_flops(np.diff(offs)), gpu_ms),
+                      "documents_32x512": {"gpu_ms_per_batch": doc_ms, "tokens": 16384, "roofline": enc_roofline(bert_flops([512] * 32), doc_ms)},
                       "cpu_baseline": {"value": sample / cpu_dt, "unit": "texts/sec", "cores": nthreads, "kind": "port",
                                        "sample": f"{sample} of the same 256 texts, one call, oracle/bert_oracle_c.c (f32, AVX2 FMA, "
                                                  f"{nthreads} threads over ~128-token blocks); the reference's native backend and its "
