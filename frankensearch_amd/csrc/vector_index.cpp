@@ -1010,9 +1010,21 @@ SearchError VectorIndex::search_top_k(const float* queries, uint32_t nq, uint32_
             FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, q_pin, qbytes, hipMemcpyHostToDevice, stream_));
         }
         if (via_filter && nq == 1 && k <= 32 && i8_ready_ && i8_stats_ready_ && variant == 0) {
-            bool certified = false;
-            FSGPU_TRY(certified_i8_lone_query(queries, k, out_rows, out_scores, out_counts, &certified));
-            if (certified) return ok();
+            // A failed certificate costs a whole pass (queries with no neighbours to speak of: the 256th best score of 10M rows
+            // lies within the margin of the 10th), so the single pass backs off: after a failure the next 1, 2, 4 ... 64 lone queries
+            // go straight to the staged path; a success resets it.
+            if (cert_skip_ > 0) {
+                --cert_skip_;
+            } else {
+                bool certified = false;
+                FSGPU_TRY(certified_i8_lone_query(queries, k, out_rows, out_scores, out_counts, &certified));
+                if (certified) {
+                    cert_backoff_ = 0;
+                    return ok();
+                }
+                cert_backoff_ = cert_backoff_ ? std::min<uint32_t>(cert_backoff_ * 2, 64) : 1;
+                cert_skip_ = cert_backoff_;
+            }
         }
         if (via_filter) {
             uint32_t fb = 0;

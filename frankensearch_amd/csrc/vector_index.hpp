@@ -259,6 +259,7 @@ class VectorIndex {
     bool hard_batch_ = false;     // the batch in flight is the int8 filter's leftovers (nested f16-filter call)
     bool i8f_disabled_ = false;   // the int8 filter left too many queries uncertified on this slab (or its copy does not fit)
     uint32_t i8f_strikes_ = 0;
+    uint32_t cert_skip_ = 0, cert_backoff_ = 0;   // the lone query's single-pass certificate: calls still to skip / the current back-off
     uint32_t i8f_sample_boost_ = 1;   // 1 or 2: the second sample of the int8 filter's wide rounds grows before the filter is given up
     bool mf_norm_ready_ = false;
     int mf_shape_i8_ = 4, mf_per_cu_160_ = 1, mf_per_cu_160_i8_ = 1;
