@@ -2,7 +2,7 @@
 # Regenerates the evidence kept under profiles/<round>/ (run on the GPU box through gpurun; results land in
 # gpurun_out/<round>/ and are copied to profiles/<round>/ afterwards).  Counter passes are separate runs with
 # --pmc only (never combined with trace domains).
-R=${1:-r02}
+R=${1:-r04}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -17,7 +17,12 @@ FSGPU_FILTER=f16 python bench.py --no-cpu-baseline --no-two-tier 2>/dev/null | t
 python bench.py --rows 1000000 --no-cpu-baseline --no-two-tier 2>/dev/null | tail -1 > $OUT/bench_config2_1m.json
 python bench.py --rows 1250000 --no-cpu-baseline --no-two-tier 2>/dev/null | tail -1 > $OUT/bench_shard_1m25.json
 python bench.py --rows 50000000 --config5 --no-adversarial --no-encoders --no-cpu-baseline --no-two-tier 2>/dev/null | tail -1 > $OUT/bench_config5_50m.json
-python bench.py --sharded-handle --gpus 1 2>/dev/null | grep queries_per_sec | tail -1 > $OUT/bench_sharded_handle_1gpu.json
+python bench.py --sharded-handle --gpus 1 --no-config5 2>/dev/null | grep queries_per_sec | tail -1 > $OUT/bench_sharded_handle_1gpu.json
+# N > 1 rehearsed on the one GPU: two gloo ranks, the sharded-handle leg over two virtual shards (two-tier + config 5 over sharded handles)
+FSGPU_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --warmup 3 --config5-rows 6000000 2>/dev/null | tail -1 > $OUT/bench_rehearsal_gloo_2ranks.json
+python scripts/r04/filtered_tput.py > $OUT/filtered_tput.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_shard -o bench -- \
+    python bench.py --rows 1250000 --no-cpu-baseline --no-two-tier --no-adversarial --no-encoders > $OUT/bench_shard_under_trace.json 2> $OUT/bench_shard_trace.err
 # per-kernel time of the default bench command
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- \
     python bench.py --no-cpu-baseline --no-two-tier > $OUT/bench_under_trace.json 2> $OUT/bench_trace.err

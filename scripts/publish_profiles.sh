@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copies the summaries of scripts/collect_profiles.sh from gpurun_out/<round>/ (scratch) into profiles/<round>/ (tracked).
-R=${1:-r02}
+R=${1:-r04}
 SRC=gpurun_out/$R
 DST=profiles/$R
 mkdir -p $DST
@@ -8,6 +8,8 @@ cp $SRC/bench_*.json $SRC/host_cpu.txt $SRC/pmc_summary.json $DST/ 2>/dev/null
 rm -f $DST/bench_under_trace.err
 cp $SRC/trace/bench_kernel_stats.csv $DST/bench_kernel_stats.csv
 cp $SRC/trace/bench_domain_stats.csv $DST/bench_domain_stats.csv
+cp $SRC/trace_shard/bench_kernel_stats.csv $DST/bench_shard_1m25_kernel_stats.csv 2>/dev/null
+cp $SRC/filtered_tput.txt $DST/filtered_tput.txt 2>/dev/null
 cp $SRC/enc_trace/enc_kernel_stats.csv $DST/encoder_kernel_stats.csv
 grep -E '^(m2v|bert)' $SRC/enc_untraced.log > $DST/enc_bench.txt
 cp $SRC/encoder_mfma_pmc.json $DST/encoder_mfma_pmc.json 2>/dev/null
