@@ -8,6 +8,11 @@
 #include <cstring>
 #include <string>
 
+// rows (tokens) from which the batch path runs the post-attention block as three launches with a weight-stationary FFN-up GEMM
+#ifndef FSGPU_BERT_SPLIT_MIN_TOKENS
+#define FSGPU_BERT_SPLIT_MIN_TOKENS 6144
+#endif
+
 namespace fsgpu {
 
 namespace {
@@ -308,6 +313,20 @@ SearchError NativeEmbedder::forward_packed_range(uint32_t d0, uint32_t d1, uint3
         BERT_HIP(launch_bert_gemm_w(x_h, l.qkv_wp.ptr, static_cast<const float*>(l.qkv_b.ptr), nullptr, qkv + (size_t)t0 * 3 * H, T,
                                     3 * H, H, 2, stream));
         BERT_HIP(launch_bert_attention_h(qkv, offs, ctx, (int)(d1 - d0), (int)cfg_.heads, H, (int)max_seq, scale, stream));
+        if (T >= FSGPU_BERT_SPLIT_MIN_TOKENS && bert_gemm_ln_w_supported(H, H) && bert_gemm_ln_w_supported(H, I) && bert_gemm_w_supported(I, H)) {
+            // Thousands of rows (the documents of an index build): the one-launch post-attention block re-streams its 2.65 MB of
+            // weights for every 32 rows (1.36 GB out of the L2s per layer at 16k tokens: that IS its 90 us).  Here the FFN-up
+            // projection is the weight-stationary GEMM (bert_gemm_wp_kernel: a block keeps its weight slice in registers and
+            // walks the row tiles), its 16-bit activations go through L2 / the Infinity Cache, and the two LayerNorm projections
+            // stream their weights once per 32-row block.
+            _Float16* inter = static_cast<_Float16*>(inter_h_.ptr) + (size_t)t0 * I;
+            BERT_HIP(launch_bert_gemm_ln_w(ctx + (size_t)t0 * H, l.ao_wp.ptr, static_cast<const float*>(l.ao_b.ptr), x, x_h,
+                                           static_cast<const float*>(l.ln1_w.ptr), static_cast<const float*>(l.ln1_b.ptr), T, H, H, eps, stream));
+            BERT_HIP(launch_bert_gemm_w(x_h, l.i_wp.ptr, static_cast<const float*>(l.i_b.ptr), nullptr, inter, T, I, H, 1, stream));
+            BERT_HIP(launch_bert_gemm_ln_w(inter, l.o_wp.ptr, static_cast<const float*>(l.o_b.ptr), x, x_h,
+                                           static_cast<const float*>(l.ln2_w.ptr), static_cast<const float*>(l.ln2_b.ptr), T, H, I, eps, stream));
+            continue;
+        }
         BERT_HIP(launch_bert_post_attn_w(ctx + (size_t)t0 * H, l.ao_wp.ptr, static_cast<const float*>(l.ao_b.ptr),
                                          static_cast<const float*>(l.ln1_w.ptr), static_cast<const float*>(l.ln1_b.ptr),
                                          l.i_wp.ptr, static_cast<const float*>(l.i_b.ptr), l.o_wp.ptr,

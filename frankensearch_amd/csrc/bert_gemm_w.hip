@@ -16,11 +16,16 @@
 //
 // Same arithmetic as bert_kernels.hip (f16 x f16 -> f32 v_mfma_f32_16x16x32_f16, f32 bias / GELU / residual / LayerNorm);
 // tolerance against the f32 oracle asserted in tests/test_gpu_bert.py.
+#include <algorithm>
+
 #include "device_util.hpp"
 #include "kernels.hpp"
 
 namespace fsgpu {
 
+#ifndef FSGPU_GEMM_WP_MIN_TILES
+#define FSGPU_GEMM_WP_MIN_TILES 96   // 64-row tiles (6,144 rows) from which a K = hidden GEMM runs weight-stationary
+#endif
 #ifndef FSGPU_LN_RING
 #define FSGPU_LN_RING 12
 #endif
@@ -156,6 +161,120 @@ __global__ __launch_bounds__(256) void bert_gemm_w_kernel(const _Float16* __rest
         const int row = bm0 + r;
         if (row < M)
             *reinterpret_cast<half8*>(out_h + (size_t)row * N + blockIdx.x * 128 + c) = *reinterpret_cast<const half8*>(&As[r * CP + c]);
+    }
+}
+
+// The same GEMM for LARGE M (thousands of rows: the documents of an index build), WEIGHT-STATIONARY: bert_gemm_w_kernel re-reads a
+// wave's 24 KB weight slice for every 64-row tile — 2,304 blocks x 96 KB at M = 16,384, N = 1,152: the L2 -> CU weight stream and the
+// per-block prologue (weights, activation tile, barrier) are what that kernel's 29 us are made of.  Here a block keeps its 128-column
+// weight slice in registers for its whole life and walks the row tiles t = blockIdx.y, + gridDim.y, ...: the next tile's activations
+// are requested into registers before the current tile's MFMAs, outputs leave through their own LDS staging tile, two barriers per
+// tile.  Same arithmetic and epilogues (bit-identical outputs: the per-element operation order is unchanged).
+template <int EPI, int KS>
+__global__ __launch_bounds__(256, 2) void bert_gemm_wp_kernel(const _Float16* __restrict__ A, const half8* __restrict__ Wp,
+                                                           const float* __restrict__ bias, float* __restrict__ out_f32,
+                                                           _Float16* __restrict__ out_h, int M, int N) {
+    constexpr int K = 32 * KS, BM = 64;
+    constexpr int PITCH = K + 16;
+    constexpr int PIECES = K / 8;
+    constexpr int A_LOADS = BM * PIECES / 256;
+    constexpr int CP = 128 + 8;   // halves per row of the f16 output tile
+    static_assert(BM * PIECES % 256 == 0, "tile must divide among 256 loader threads");
+    __shared__ __attribute__((aligned(16))) _Float16 As[BM * PITCH];
+    __shared__ __attribute__((aligned(16))) _Float16 Os[EPI == 0 ? 8 : BM * CP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bn0 = blockIdx.x * 128 + wave * 32;
+    const int tiles = (M + BM - 1) / BM;
+    half8 wf[2][KS];
+    {
+        const half8* wp = Wp + (size_t)(bn0 / 16) * KS * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) wf[j][ks] = wp[(j * KS + ks) * 64];
+    }
+    const int fr = lane & 15, fk = (lane >> 4) * 8, cq = (lane >> 4) * 4;
+    f32x4 bv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const f32x4*>(bias + bn0 + j * 16 + cq);
+    half8 ra[A_LOADS];
+    auto fetch = [&](int t) {   // tile t's rows (clamped at M) into registers: every load in flight at once
+#pragma unroll
+        for (int x = 0; x < A_LOADS; ++x) {
+            const int p = tid + 256 * x, r = p / PIECES, c = p % PIECES;
+            int row = t * BM + r;
+            row = row < M ? row : M - 1;
+            ra[x] = *(reinterpret_cast<const half8*>(A + (size_t)row * K) + c);
+        }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int x = 0; x < A_LOADS; ++x) {
+            const int p = tid + 256 * x, r = p / PIECES, c = p % PIECES;
+            *reinterpret_cast<half8*>(&As[r * PITCH + c * 8]) = ra[x];
+        }
+    };
+    int t = blockIdx.y;
+    if (t >= tiles) return;
+    fetch(t);
+    park();
+    __syncthreads();
+    for (; t < tiles; t += gridDim.y) {
+        const int tn = t + (int)gridDim.y;
+        if (tn < tiles) fetch(tn);   // the next tile's activations travel under this tile's MFMAs
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            half8 af[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const half8*>(&As[(i * 16 + fr) * PITCH + ks * 32 + fk]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][ks], af[i], acc[i][j], 0, 0, 0);
+        }
+        const int bm0 = t * BM;
+        if (EPI == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = bn0 + j * 16 + cq;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = bm0 + i * 16 + fr;
+                    if (row < M) *reinterpret_cast<f32x4*>(out_f32 + (size_t)row * N + col) = acc[i][j] + bv[j];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 y = acc[i][j] + bv[j];
+                    half4 h;
+                    h[0] = (_Float16)(EPI == 1 ? gelu_as_w(y[0]) : y[0]);
+                    h[1] = (_Float16)(EPI == 1 ? gelu_as_w(y[1]) : y[1]);
+                    h[2] = (_Float16)(EPI == 1 ? gelu_as_w(y[2]) : y[2]);
+                    h[3] = (_Float16)(EPI == 1 ? gelu_as_w(y[3]) : y[3]);
+                    *reinterpret_cast<half4*>(&Os[(i * 16 + fr) * CP + wave * 32 + j * 16 + cq]) = h;
+                }
+        }
+        __syncthreads();   // every wave is done reading As (and the output tile is complete)
+        if (tn < tiles) park();
+        if (EPI != 0) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = it * 16 + (tid >> 4), c = (tid & 15) * 8;
+                const int row = bm0 + r;
+                if (row < M)
+                    *reinterpret_cast<half8*>(out_h + (size_t)row * N + blockIdx.x * 128 + c) = *reinterpret_cast<const half8*>(&Os[r * CP + c]);
+            }
+        }
+        __syncthreads();   // the next tile is parked; the output tile may be overwritten
     }
 }
 
@@ -712,6 +831,18 @@ bool bert_gemm_w_supported(int N, int K) { return (K == 128 || K == 256 || K == 
 template <int EPI, int KS>
 static void launch_gemm_w_t(const void* a_h, const void* wp, const float* bias, float* out_f32, void* out_h, int M, int N,
                             hipStream_t stream) {
+    // large M: the weight-stationary form — about three blocks per CU, each walking its share of the row tiles
+    const int tiles = (M + 63) / 64, cols = N / 128;
+    if (tiles >= FSGPU_GEMM_WP_MIN_TILES && cols >= 1) {
+        int device = 0, cus = 256;
+        if (hipGetDevice(&device) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+        int rows_per_col = std::max(1, (2 * cus + cols - 1) / cols);   // 2 blocks per CU: 68 KB of LDS and ~200 VGPRs each
+        rows_per_col = std::min(rows_per_col, tiles);
+        hipLaunchKernelGGL((bert_gemm_wp_kernel<EPI, KS>), dim3(cols, rows_per_col), dim3(256), 0, stream,
+                           static_cast<const _Float16*>(a_h), static_cast<const half8*>(wp), bias, out_f32,
+                           static_cast<_Float16*>(out_h), M, N);
+        return;
+    }
     hipLaunchKernelGGL((bert_gemm_w_kernel<EPI, KS>), dim3(N / 128, (M + 63) / 64), dim3(256), 0, stream,
                        static_cast<const _Float16*>(a_h), static_cast<const half8*>(wp), bias, out_f32,
                        static_cast<_Float16*>(out_h), M, N);

@@ -228,3 +228,23 @@ def test_model_file_blob_gives_the_same_embedder_as_the_tensor_struct(fa, tmp_pa
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), prefix
         enc.close()
     ref.close()
+
+
+def test_index_build_batches_of_thousands_of_tokens(fa):
+    """Calls of >= 6,144 tokens (documents of an index build, index_builder.rs:191,416) take the large-M form of the batch path: the
+    weight-stationary QKV / FFN-up GEMMs (bert_gemm_wp_kernel) and the post-attention block as three launches.  Same tolerance
+    against the f32 C oracle, on benign and heavy-tailed weights; ragged lengths and a row count that is not a multiple of the 64-row
+    tile; a smaller call of the same documents (the fused 32-row-block kernels) agrees within the tolerance too."""
+    from oracle import bert_oracle
+    rng = np.random.default_rng(31)
+    for w in (bert_oracle.random_weights(7, 3000, 384, 6, 1536), bert_oracle.heavy_tailed_weights(43, 3000, 384, 6, 1536)):
+        m = fa.NativeEmbedder(w)
+        ref = bert_oracle.CForward(w, 6)
+        lens = [512] * 10 + [int(n) for n in rng.integers(40, 400, 14)] + [33, 77]   # 5,120 + ~3,000 + 110 tokens
+        docs = [[101] + rng.integers(1000, 3000, n - 2).tolist() + [102] for n in lens]
+        assert sum(lens) >= 6144 and sum(lens) % 64 != 0
+        got = m.embed_batch_token_ids(docs)
+        check(got, ref.run(docs, 16))
+        small = np.concatenate([m.embed_batch_token_ids(docs[i:i + 4]) for i in range(0, len(docs), 4)])
+        assert np.max(np.abs(got - small)) <= ABS_MAX and np.all(np.sum(got * small, axis=1) >= COS_MIN)
+        m.close()
