@@ -9,8 +9,11 @@
 #include <string>
 
 // rows (tokens) from which the batch path runs the post-attention block as three launches with a weight-stationary FFN-up GEMM
+// instead of the fused bert_ffn_w_kernel.  OFF by default: on 32 x 512 tokens the three launches measured 1.440 ms against the fused
+// kernel's 1.153 ms (profiles/r04/enc_large_m_ab.txt) — the intermediate's round trip through HBM costs more than the
+// weight-stationary GEMM saves.  Kept for A/B builds (-DFSGPU_BERT_SPLIT_MIN_TOKENS=6144).
 #ifndef FSGPU_BERT_SPLIT_MIN_TOKENS
-#define FSGPU_BERT_SPLIT_MIN_TOKENS 6144
+#define FSGPU_BERT_SPLIT_MIN_TOKENS (1 << 30)
 #endif
 
 namespace fsgpu {
