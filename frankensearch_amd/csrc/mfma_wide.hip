@@ -57,9 +57,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
 
 // N LDS-DMAs of one wave behind ONE scalar base: lane offsets in VGPRs (constant for the whole kernel), destinations 1 KB
 // apart from lds_dst on.  m0 is saved / restored once per group; no vector address arithmetic per instruction.
+// a wave-uniform 64-bit value into scalar registers whatever instructions computed it (an "s" operand of inline asm is not
+// moved there by the compiler: a value it kept in vector registers fails to assemble — seen when the tile loop was restructured)
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 template <int N>
-__device__ __forceinline__ void glds16_group(uint64_t sbase, const uint32_t (&voff)[N], uint32_t lds_dst) {
+__device__ __forceinline__ void glds16_group(uint64_t sbase_any, const uint32_t (&voff)[N], uint32_t lds_dst) {
     static_assert(N >= 1 && N <= 3, "a wave issues 1..3 DMA instructions per tile");
+    const uint64_t sbase = uniform_u64(sbase_any);
     unsigned keep;
     // (one asm statement: hipcc must not get to place anything that reads m0 between the pieces)
     if constexpr (N == 1)
@@ -177,10 +184,11 @@ constexpr bool wide_split_ok(int ROWB, int EB, int QT, int OPT, int DBG) {
 }
 // 128-row tiles in a three-slot ring: the main pass of a shape that runs the split loop
 constexpr bool wide_big_ok(int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG) {
-    return (OPT & kOptBig) != 0 && wide_split_ok(ROWB, EB, QT, OPT, DBG) && DBG == 0 && NSLOT == 3;
+    return (OPT & kOptBig) != 0 && wide_split_ok(ROWB, EB, QT, OPT, DBG) && (DBG == 0 || DBG >= 16) && NSLOT == 3;
 }   // (bit 1 was a barrier-phase shift between the SIMD twins: measured null, removed)
 // one 64-bit word through the scalar cache (wave-uniform address): counted by lgkmcnt, not by the vmcnt the DMA ring lives on
-__device__ __forceinline__ u64 sload_u64(const u64* p) {
+__device__ __forceinline__ u64 sload_u64(const u64* pv) {
+    const u64* p = reinterpret_cast<const u64*>((uintptr_t)uniform_u64((uint64_t)(uintptr_t)pv));
     u64 w;
 #ifdef FSGPU_LAB_SLOAD_NOGLC
     asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(w) : "s"(p) : "memory");
@@ -244,6 +252,14 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     constexpr bool NEGTAU = (OPT & kOptNegTau) != 0 && EB == 1 && ROOM;
     constexpr bool SADDR = (OPT & kOptSaddr) != 0 && ROOM;
     constexpr bool SPLIT = wide_split_ok(ROWB, EB, QT, OPT, DBG);
+    // Timing skeletons of the split loop (experiments builds, scripts/r04/skeletons.sh; their answers are not valid).  DBG in [16, 32):
+    // a bit set on 16 — 1 no DMA, 2 no per-tile wait + barrier, 4 no fragment reads in the loop, 8 no threshold tests; the append path
+    // is one LDS store.  DBG >= 32: everything real but the append path, a bit set on 32 — 1 no global store, 2 no LDS counter (slot 0),
+    // 4 an empty append (the per-lane tests still run).
+    constexpr bool SK = DBG >= 16 && DBG < 32;
+    constexpr bool SK_NO_DMA = DBG == 2 || (SK && (DBG & 1)), SK_NO_SYNC = SK && (DBG & 2), SK_NO_READS = SK && (DBG & 4), SK_NO_TEST = SK && (DBG & 8);
+    constexpr bool AK = DBG >= 32;
+    [[maybe_unused]] constexpr bool AK_NO_STORE = AK && (DBG & 1), AK_NO_ATOMIC = AK && (DBG & 2), AK_NO_BODY = AK && (DBG & 4);
     static_assert(!SPLIT || (NEGTAU && RS >= 4), "the split loop runs on neg-tau accumulators over tiles of two pairs or more");
     // -ceil(tau) kept in all four registers of an accumulator (the first MFMA of a pair takes it as C: no initialising moves) where
     // 4 x QT more registers fit; else one register per query tile and four moves per accumulator (in the MFMAs' shadow when SPLIT)
@@ -357,7 +373,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     }
     auto issue_part = [&](uint32_t t, uint32_t slot, int part) {
         const uint32_t row0 = __builtin_amdgcn_readfirstlane(tile_row0(t));
-        if constexpr (SADDR && DBG != 2) {
+        if constexpr (SADDR && !SK_NO_DMA) {
             if (row0 + TR <= args.nrows) {   // (wave-uniform) every row of the tile exists: no clamp, no vector address arithmetic
                 const uint64_t sbase = (uint64_t)(uintptr_t)slab + (uint64_t)row0 * row_pitch;
                 const uint32_t dst = __builtin_amdgcn_readfirstlane(ring + slot * TILE_BYTES + (uint32_t)(wave * PW + part * PP) * 1024u);
@@ -373,7 +389,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
             row = row < args.nrows ? row : last_row;
             const unsigned char* g = slab + (size_t)row * row_pitch + ks * 64 + dma_chunk * 16;
             const uint32_t dst = __builtin_amdgcn_readfirstlane(ring + slot * TILE_BYTES + (uint32_t)j * 1024u);
-            if constexpr (DBG != 2) glds16(g, dst);
+            if constexpr (!SK_NO_DMA) glds16(g, dst);
             else asm volatile("" ::"v"(g), "s"(dst));
         }
     };
@@ -467,6 +483,20 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     auto append = [&](int q, float score, uint32_t row, u64 mask) {
         if (row >= args.nrows) return;
         if (!((mask >> (row & 63)) & 1ull)) return;
+#ifdef FSGPU_EXPERIMENTS
+        if constexpr (AK_NO_BODY) {
+            asm volatile("" ::"v"(q), "v"(score), "v"(row));
+            return;
+        }
+        if constexpr (AK_NO_ATOMIC || AK_NO_STORE) {
+            int p0 = 0;
+            if constexpr (!AK_NO_ATOMIC) p0 = atomicAdd(&lcnt[q], 1);
+            const u64 e0 = pack(score, args.row_base + row);
+            if constexpr (AK_NO_STORE) asm volatile("" ::"v"(p0), "v"(e0));
+            else args.cand[((size_t)q * gridDim.x + blockIdx.x) * slots + (p0 < slots ? p0 : 0)] = e0;
+            return;
+        }
+#endif
         const int pos = atomicAdd(&lcnt[q], 1);
         const u64 entry = pack(score, args.row_base + row);
         if (pos < slots) {
@@ -480,7 +510,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     // the slow path: a lane with a passing score among the query tiles [nt_lo, nt_hi) of sub-tile pair sp of tile t
     auto emit_tiles = [&](uint32_t t, int sp, const acc_t (&acc)[2][QT], int nt_lo, int nt_hi) {
 #ifdef FSGPU_EXPERIMENTS
-        if constexpr (DBG == 2 || DBG == 4 || DBG == 5) {  // (timing skeletons read stale bytes: keep the scores live, append nothing)
+        if constexpr (DBG == 2 || DBG == 4 || DBG == 5 || SK) {  // (timing skeletons read stale bytes: keep the scores live, append nothing)
             lcnt[q0 + frow] = 0;
             return;
         }
@@ -574,9 +604,28 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
         constexpr int QA = QT / 2;                  // phase 1: query tiles [0, QA), phase 2: [QA, QT)
         half8 f[2][KS];                             // the current pair's fragments: [sub-tile of the pair][k-step]
         acc_t acc[2][QT];
+        [[maybe_unused]] bool sk_loop = false;
         auto read_frag = [&](const unsigned char* base, int pair, int kk) {
+            if constexpr (SK_NO_READS) {
+                if (sk_loop) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(f[h][kk]));
+                    return;
+                }
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) f[h][kk] = *reinterpret_cast<const half8*>(base + ((pair * 2 + h) * KS + kk) * 1024);
+        };
+        auto sk_any = [&](int nt_lo, int nt_hi) {   // (skeleton without tests: the scores stay live, nothing is compared)
+            if constexpr (SK_NO_TEST) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int nt = nt_lo; nt < nt_hi; ++nt) asm volatile("" ::"v"(acc[h][nt]));
+                return false;
+            } else {
+                return any_passes(acc, nt_lo, nt_hi);
+            }
         };
         auto mfma_step = [&](int kk, int nt_lo, int nt_hi) {
 #pragma unroll
@@ -603,6 +652,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) read_frag(slot_base(0), 0, kk);
         init_acc(0, QT);                        // (so that the first, void, test of the second half reads defined values)
+        if constexpr (SK_NO_READS) sk_loop = true;
         uint32_t slot = 0, slot_prev = NSLOT - 1;
         const unsigned char* cur = slot_base(0);
         uint32_t tB = ntiles;                   // tile of the pair whose second-half scores are still to be tested (none yet)
@@ -619,8 +669,8 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) {
                     mfma_step(kk, 0, QA);
-                    if (kk == TK) anyB = any_passes(acc, QA, QT);
-                    if (p == 0 && kk == 0) {
+                    if (kk == TK) anyB = sk_any(QA, QT);
+                    if (p == 0 && kk == 0 && !SK_NO_SYNC) {
                         // The tile's barrier.  Tile n+1: this wave's DMAs have landed (tiles n+2 .. n+NSLOT-2 may still be in
                         // flight), then everyone's; every wave is also past its last read of tile n-1 (this tile's first pair was
                         // read behind them and has been waited for), whose slot takes tile n+NSLOT-1.
@@ -661,7 +711,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
                     }
                     if (p + 1 < NP) read_frag(cur, p + 1, kk);
                     else read_frag(nxt, 0, kk);
-                    if (kk == TK) anyA = any_passes(acc, 0, QA);
+                    if (kk == TK) anyA = sk_any(0, QA);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (FLAGS) {   // this wave's last read of the tile is out (the last pair's fragments): its slot may be refilled
@@ -847,6 +897,14 @@ hipError_t launch_wide_d(const MfmaScanArgs& args, int grid, hipStream_t stream,
                         if constexpr (MODE == 0) return launch_wide_t<384, EB, QT, 3, 30, MODE>(args, grid, stream, occupancy);
                         else return launch_wide_t<384, EB, QT, 6, 14, MODE>(args, grid, stream, occupancy);
                     default: break;
+                }
+                if constexpr (MODE == 0) {   // skeletons of the shipped main pass (scripts/r04/skeletons.sh, skeleton_clocks.sh)
+                    switch (dbg) {
+#define FSGPU_SK(D) case D: return launch_wide_t<384, EB, QT, 3, O, D>(args, grid, stream, occupancy);
+                        FSGPU_SK(16) FSGPU_SK(17) FSGPU_SK(18) FSGPU_SK(20) FSGPU_SK(24) FSGPU_SK(31) FSGPU_SK(33) FSGPU_SK(35) FSGPU_SK(36)
+#undef FSGPU_SK
+                        default: break;
+                    }
                 }
             }
 #endif

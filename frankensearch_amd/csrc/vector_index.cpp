@@ -54,6 +54,7 @@ struct Knobs {
     int i8f_growth = 0; // FSGPU_I8F_GROWTH: sample growth factor of the int8 filter (default 4)
     bool no_skip_b = false, use_160 = false, debug_batched = false, no_reverse = false, no_wide_b = false, no_anchor = false;
     bool no_big_pool = false, no_heur_b = false;
+    int rb_pct = 0;      // FSGPU_RB_PCT: the second sample's size in percent of what the plan chose (tuning experiments only)
     int heur_rank = 0;   // FSGPU_HEUR_RANK: rank of the first sample whose score gates the anchoring-only second sample (default 4)
     Knobs() {
         auto env = [](const char* name) { return std::getenv(name); };
@@ -68,6 +69,7 @@ struct Knobs {
         grid_blocks = num("FSGPU_GRID_BLOCKS");
         ra = num("FSGPU_RA");
         rb = num("FSGPU_RB");
+        rb_pct = num("FSGPU_RB_PCT");
         round = num("FSGPU_ROUND");
         i8_per_cu = num("FSGPU_I8_PER_CU");
         mfma_shape = num("FSGPU_MFMA_SHAPE");
@@ -1576,6 +1578,7 @@ SearchError VectorIndex::batched_prepare(BatchedPlan& p, bool* done) {
     // (an index whose int8 margin overflowed the main pass's lists samples more: its wide rounds gate the second sample by rank,
     // so that stage's own survivors stay in the hundreds — see search_top_k_batched_device)
     if (p.i8f && wide_main && i8f_sample_boost_ > 1 && knobs().rb <= 0) RB = (uint32_t)std::min<uint64_t>((uint64_t)RB * i8f_sample_boost_, nrows_ / 6);
+    if (knobs().rb_pct > 0) RB = (uint32_t)std::min<uint64_t>((uint64_t)RB * (uint32_t)knobs().rb_pct / 100, nrows_ / 4);
     RB = std::min<uint32_t>(RB, (uint32_t)(nrows_ / 4));
     RB = std::max<uint32_t>(RA, RB / RA * RA);
     p.RA = RA;
