@@ -996,7 +996,10 @@ def main() -> None:
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    index.set_profiling(True)
+    # (every 4th step's main launch is bracketed by HIP events on its stream: a pair idles the stream ~6 us on either side)
+    profile_period = 4 if args.steps >= 16 and args.batched and B <= 1024 else 1   # (larger batches take several rounds per call)
+    timed_steps = (args.steps + profile_period - 1) // profile_period   # steps whose main launch carries the event pair
+    index.set_profiling(profile_period if profile_period > 1 else True)
     fallbacks[0] = 0
     filt0 = index.batched_filter_stats()
     torch.cuda.synchronize()
@@ -1077,6 +1080,8 @@ def main() -> None:
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": per_launch_ms,
                 "launches": launches,
+                "timed": f"HIP events on the kernel's stream around the main launch of every {profile_period}. step of the timed region" if profile_period > 1
+                         else "HIP events on the kernel's stream around every launch of the timed region",
             },
         }
         if args.batched and launches:
@@ -1084,7 +1089,7 @@ def main() -> None:
             # queries of its launch on the matrix cores; the roof that asks for more time is the one that bounds it
             # (a launch of the register-resident-query kernel takes ALL of a step's 512-query groups — gridDim.y passes over the slab —,
             # so its rows streamed are passes x shard rows while every query still meets every row once)
-            q_per_launch = args.steps * B / launches
+            q_per_launch = timed_steps * B / launches
             passes_per_launch = (scan_rows / launches) / max(hi - lo, 1)
             flops = 2.0 * (hi - lo) * args.dim * q_per_launch
             tflops = flops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
@@ -1108,8 +1113,8 @@ def main() -> None:
         # The step against its own two roofs: every query group streams the slab once (HBM) and contracts it with its
         # queries on the matrix cores (2 * rows * dim flops per query); the step cannot beat max(bytes / 8 TB/s, flops / peak)
         if args.batched:
-            launches_per_step = launches / max(args.steps, 1)
-            passes = scan_rows / max(args.steps, 1) / max(hi - lo, 1)   # passes over the slab per step
+            launches_per_step = launches / max(timed_steps, 1)
+            passes = scan_rows / max(timed_steps, 1) / max(hi - lo, 1)   # passes over the slab per step
             t_hbm = launches_per_step * alg_bytes / (HBM_PEAK_GBPS * 1e9)
             t_mfma = 2.0 * (hi - lo) * args.dim * B / (mfma_peak * 1e12)
             bound_s = max(t_hbm, t_mfma)

@@ -1347,6 +1347,8 @@ fsgpu_status fsgpu_index_set_profiling(fsgpu_index* idx, int32_t enabled) {
     if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
     std::lock_guard<std::mutex> lock(idx->impl.mutex());
     idx->impl.profiling = enabled != 0;
+    idx->impl.profile_period = enabled > 1 ? enabled : 1;
+    idx->impl.profile_tick_ = 0;
     return FSGPU_OK;
 }
 

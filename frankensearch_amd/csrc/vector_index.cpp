@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 
 #include "../../include/fsgpu.h"
@@ -1927,6 +1928,8 @@ SearchError VectorIndex::batched_main(const BatchedPlan& p, BatchedRound& r) {
     hipStream_t stream = p.stream;
     MfmaScanArgs& a = r.a;
     SelectArgs& sb = r.sb;
+    // (an event pair idles the stream ~6 us on either side of a launch: with a period, the main launches of every n-th call are timed)
+    const bool profiling = this->profiling && (profile_period <= 1 || profile_tick_++ % (uint32_t)profile_period == 0);
     if (p.skip_b) {
         a.group_stride = 1;  // nothing was sampled by a stage B: the main pass visits every group
         a.group_count = 0;
@@ -2086,6 +2089,8 @@ SearchError VectorIndex::batched_fallback(BatchedPlan& p) {
     constexpr uint32_t KC = BatchedPlan::KC;
     hipStream_t stream = p.stream;
     const uint32_t nq = p.nq, k = p.k, k_eff = p.k_eff;
+    // (polling the stream with hipStreamQuery before blocking was measured: no change at 10M rows or on a 1.25M-row shard,
+    // profiles/r04/step_overheads.txt — the runtime's wait is already an active one for waits this short)
     FSGPU_HIP(hipStreamSynchronize(stream));
     std::vector<uint32_t> fb;
     for (uint32_t i = 0; i < nq; ++i)

@@ -162,6 +162,8 @@ class VectorIndex {
     int32_t variant = 0;
     uint64_t filter_gathered = 0, filter_scanned = 0;  // filtered host searches by path
     bool profiling = false;
+    int profile_period = 1;   // fsgpu_index_set_profiling(n > 1): the merged main launch of every n-th batched step is timed
+    uint32_t profile_tick_ = 0;
     // one-shot hook of the next batched search (fsgpu_index_set_after_enqueue_hook): called before the search blocks on its stream
     void (*after_enqueue_fn)(void*) = nullptr;
     void* after_enqueue_ctx = nullptr;

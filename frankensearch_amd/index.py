@@ -338,7 +338,8 @@ class VectorIndex:
                                                   out_rows_ptr, out_scores_ptr, out_counts_ptr, stream))
 
     # ---- instrumentation ----------------------------------------------------------------------
-    def set_profiling(self, enabled: bool) -> None:
+    def set_profiling(self, enabled) -> None:
+        """True / False, or an int n > 1: time every n-th main launch of the batched search only."""
         check(_lib.lib().fsgpu_index_set_profiling(self._h, int(enabled)))
 
     def scan_time(self, reset: bool = True) -> Tuple[float, int]:

@@ -594,7 +594,8 @@ fsgpu_status fsgpu_bert_set_coalescing(fsgpu_bert *m, uint32_t max_batch, uint32
  * FSGPU_BERT_EMBED_V1. */
 
 /* ---- instrumentation ---- */
-/* When enabled, HIP events bracket the scan kernel of every fsgpu_search_topk* call. */
+/* When enabled, HIP events bracket the scan kernel of every fsgpu_search_topk* call; enabled = n > 1: of the batched exact search's
+ * merged main launch only every n-th is bracketed (an event pair idles the stream ~6 us on either side of the launch). */
 fsgpu_status fsgpu_index_set_profiling(fsgpu_index *idx, int32_t enabled);
 /* Sum of scan-kernel time (ms) and number of scan launches since the last reset; synchronises. */
 fsgpu_status fsgpu_index_scan_time(fsgpu_index *idx, double *total_ms, uint64_t *launches, int32_t reset);
