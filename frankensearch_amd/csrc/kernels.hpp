@@ -179,6 +179,9 @@ struct SelectArgs {
 constexpr uint32_t kSelectPool = 1024;
 constexpr uint32_t kSelectMaxK = 128;   // largest rank a selection can anchor on (k, or k * multiplier in int8 mode)
 hipError_t launch_select(const SelectArgs& args, int nq, hipStream_t stream);
+// out[0] = the largest score at slot list_len - 1 of nlists best-first lists (kEmpty = the list is not full), -inf when no list is full:
+// no row outside the lists scores above it (the certified lone-query search, VectorIndex::certified_i8_lone_query)
+hipError_t launch_list_cut(const u64* lists, uint32_t nlists, uint32_t list_len, float* out, hipStream_t stream);
 // Root of a row-sharded two-pass search (search.rs:514-661 over W shards): per query, the W x cc candidate pairs (pass-1 entry,
 // exact entry; shard s's lists [nq][cc] start shard_pitch entries after shard s-1's, kEmpty padded) -> the cc best by the pass-1
 // order (integer score desc, row asc: exactly the unsharded candidate set, whose members are each in their own shard's top cc)

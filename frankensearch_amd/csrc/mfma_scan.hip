@@ -1206,6 +1206,35 @@ hipError_t launch_two_pass_merge(const u64* approx_lists, const u64* exact_lists
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void list_cut_kernel(const u64* __restrict__ lists, uint32_t nlists, uint32_t list_len, float* __restrict__ out) {
+    __shared__ u64 red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u64 m = 0;
+    for (uint32_t l = tid; l < nlists; l += 256) {
+        const u64 e = lists[(size_t)l * list_len + list_len - 1];
+        const u64 key = e != kEmpty ? sortkey(e) : 0ull;
+        m = key > m ? key : m;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const u64 o = __shfl_xor(m, off);
+        m = o > m ? o : m;
+    }
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) m = red[w] > m ? red[w] : m;
+        out[0] = m ? __uint_as_float(score_from_sortkey(m)) : -INFINITY;
+    }
+}
+
+hipError_t launch_list_cut(const u64* lists, uint32_t nlists, uint32_t list_len, float* out, hipStream_t stream) {
+    if (list_len == 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(list_cut_kernel, dim3(1), dim3(256), 0, stream, lists, nlists, list_len, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_select(const SelectArgs& args, int nq, hipStream_t stream) {
     if (args.k < 1 || args.k > kSelectMaxK || !args.delta || (uint64_t)args.nlists * args.list_len > 0x7fffffffull)
         return hipErrorInvalidValue;

@@ -1008,14 +1008,11 @@ SearchError VectorIndex::search_top_k(const float* queries, uint32_t nq, uint32_
         const uint32_t k_lat = (uint64_t)k < nrows_ ? k : (uint32_t)nrows_;
         const bool in_kernarg = nq == 1 && !via_filter && !f32_ && dim_ % 8 == 0 && k_lat <= 256 && variant == 0 &&
                                 scan_kernarg_query_supported((int)dim_, k_lat <= 64 ? 64 : 256);
-        if (!in_kernarg) {
-            std::memcpy(q_pin, queries, qbytes);
-            FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, q_pin, qbytes, hipMemcpyHostToDevice, stream_));
-        }
         if (via_filter && nq == 1 && k <= 32 && i8_ready_ && i8_stats_ready_ && variant == 0) {
-            // A failed certificate costs a whole pass (queries with no neighbours to speak of: the 256th best score of 10M rows
-            // lies within the margin of the 10th), so the single pass backs off: after a failure the next 1, 2, 4 ... 64 lone queries
-            // go straight to the staged path; a success resets it.
+            // A failed certificate costs a whole pass over the int8 copy (a query with more rows inside the margin than the finish
+            // holds, or so many in one block's share that its list dropped one), so the single pass backs off: after a failure the
+            // next 1, 2, 4 ... 64 lone queries go straight to the staged path; a success resets it.
+            // (the pass reads the query from the pinned staging block itself: no H2D copy in front of it)
             if (cert_skip_ > 0) {
                 --cert_skip_;
             } else {
@@ -1028,6 +1025,10 @@ SearchError VectorIndex::search_top_k(const float* queries, uint32_t nq, uint32_
                 cert_backoff_ = cert_backoff_ ? std::min<uint32_t>(cert_backoff_ * 2, 64) : 1;
                 cert_skip_ = cert_backoff_;
             }
+        }
+        if (!in_kernarg) {
+            std::memcpy(q_pin, queries, qbytes);
+            FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, q_pin, qbytes, hipMemcpyHostToDevice, stream_));
         }
         if (via_filter) {
             uint32_t fb = 0;
@@ -1115,100 +1116,92 @@ SearchError VectorIndex::search_top_k(const float* queries, uint32_t nq, uint32_
 // idot >= idot_k - 2 delta, and the kept list is exactly the 256 largest idot.
 SearchError VectorIndex::certified_i8_lone_query(const float* query, uint32_t k, uint32_t* out_rows, float* out_scores,
                                                  uint32_t* out_count, bool* certified) {
+    // Four launches behind one another, no copy, ONE synchronisation (the query and every result live in the pinned staging block,
+    // which the kernels address directly):
+    //   prepare   the query quantised as the filter does + its proven bound delta
+    //   scan      the int8 copy, every block keeps its LK best (integer score, row) entries
+    //   cut       the best score any block may have DROPPED: the maximum over the full lists' last entries
+    //   finish    select_kernel: tau = (k-th best approximate score) - 2 delta, the entries at or above it re-scored in the reference's
+    //             order from the f16 slab, the k best exact entries out
+    // The answer is the exact search's when every row whose approximate score reaches tau was in some list: cut < tau (a list that
+    // is not full dropped nothing), no more candidates than the finish holds, delta >= 0.  Otherwise the caller's staged path answers.
     *certified = false;
-    constexpr uint32_t CC = 256;
+    constexpr uint32_t LK = 32;
     const uint32_t k_eff = (uint32_t)std::min<uint64_t>(k, nrows_);
-    if (k_eff == 0 || nrows_ < 4 * CC || !scan_i8_fused_supported((int)dim_, 256) || pinned_io() == nullptr) return ok();
+    if (k_eff == 0 || k_eff > LK || nrows_ < 4096 || (dim_ & 7) || !scan_i8_fused_supported((int)dim_, 64) || pinned_io() == nullptr) return ok();
     const size_t qbytes = (size_t)dim_ * 4;
-    const size_t o_out = (qbytes + 255) & ~(size_t)255, o_approx = (o_out + (size_t)k * 8 + 4 + 255) & ~(size_t)255,
-                 o_delta = o_approx + (size_t)CC * 8;
-    if (o_delta + 64 > kPinnedIoBytes) return ok();
+    const size_t o_out = (qbytes + 255) & ~(size_t)255, o_flags = (o_out + (size_t)k * 8 + 4 + 255) & ~(size_t)255;
+    if (o_flags + 64 > kPinnedIoBytes) return ok();
     unsigned char* io = static_cast<unsigned char*>(io_host_);
     FSGPU_TRY(ws_i8_query_.reserve(dim_));
-    FSGPU_TRY(ws_queries_.reserve(qbytes));
-    FSGPU_TRY(ws_cand_packed_.reserve((size_t)CC * 8));
-    FSGPU_TRY(ws_cand_rows_.reserve((size_t)CC * 4));
-    FSGPU_TRY(ws_cand_scores_.reserve((size_t)CC * 4));
     std::memcpy(io, query, qbytes);
-    FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, io, qbytes, hipMemcpyHostToDevice, stream_));
-    u64* approx_pin = reinterpret_cast<u64*>(io + o_approx);
-    float* delta_pin = reinterpret_cast<float*>(io + o_delta);
-    // the query quantised as the filter (and the reference's quantize_i8_query) does, and its bound, written where the host reads it
-    FSGPU_HIP(launch_prepare_queries_i8_filter(static_cast<const float*>(ws_queries_.ptr), 1, 1, dim_, dim_,
-                                               static_cast<const unsigned int*>(i8_max_.ptr), static_cast<const unsigned int*>(i8_stats_.ptr),
-                                               ws_i8_query_.ptr, delta_pin, stream_));
-    ScanArgs a = base_args(static_cast<const float*>(ws_queries_.ptr), nullptr);
+    const float* q_pin = reinterpret_cast<const float*>(io);
+    float* delta_pin = reinterpret_cast<float*>(io + o_flags);
+    float* tau_pin = delta_pin + 1;
+    float* cut_pin = delta_pin + 2;
+    uint32_t* ncand_pin = reinterpret_cast<uint32_t*>(delta_pin + 3);
+    uint32_t* overflow_pin = reinterpret_cast<uint32_t*>(delta_pin + 4);
+    *overflow_pin = 0;
+    *ncand_pin = 0;
+    FSGPU_HIP(launch_prepare_queries_i8_filter(q_pin, 1, 1, dim_, dim_, static_cast<const unsigned int*>(i8_max_.ptr),
+                                               static_cast<const unsigned int*>(i8_stats_.ptr), ws_i8_query_.ptr, delta_pin, stream_));
+    ScanArgs a = base_args(q_pin, nullptr);
     int per_cu = 1;
-    FSGPU_HIP(launch_scan_i8(a, i8_slab_.ptr, ws_i8_query_.ptr, 256, 1, stream_, &per_cu));
-    per_cu = std::min(per_cu, knobs().i8_per_cu > 0 ? knobs().i8_per_cu : 1);
-    int grid = num_cus_ * per_cu;
+    FSGPU_HIP(launch_scan_i8(a, i8_slab_.ptr, ws_i8_query_.ptr, 64, 1, stream_, &per_cu));
+    (void)per_cu;   // one block per CU: 256 lists x 32 entries are ONE pass of the finish (8,192 entries)
+    int grid = num_cus_;
     const int max_useful = (int)(((nrows_ + 15) / 16 + 3) / 4);
     grid = std::max(1, std::min(grid, max_useful));
-    FSGPU_TRY(ws_partial_.reserve((size_t)grid * CC * 8));
+    FSGPU_TRY(ws_partial_.reserve((size_t)grid * LK * 8));
     a.partial = static_cast<u64*>(ws_partial_.ptr);
-    a.k = CC;
+    a.k = LK;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (profiling) {
         FSGPU_HIP(hipEventCreate(&e0));
         FSGPU_HIP(hipEventCreate(&e1));
         FSGPU_HIP(hipEventRecord(e0, stream_));
     }
-    FSGPU_HIP(launch_scan_i8(a, i8_slab_.ptr, ws_i8_query_.ptr, 256, grid, stream_, nullptr));
+    FSGPU_HIP(launch_scan_i8(a, i8_slab_.ptr, ws_i8_query_.ptr, 64, grid, stream_, nullptr));
     if (profiling) {
         FSGPU_HIP(hipEventRecord(e1, stream_));
         events_.emplace_back(e0, e1);
         profiled_rows_ += nrows_;
         profiled_elem_bytes_ = 1;
     }
-    uint32_t* cand_rows = static_cast<uint32_t*>(ws_cand_rows_.ptr);
-    float* cand_scores = static_cast<float*>(ws_cand_scores_.ptr);
-    u64* cand_packed = static_cast<u64*>(ws_cand_packed_.ptr);
-    MergeArgs m;
-    m.lists = a.partial;
-    m.q_stride = (uint64_t)grid * CC;
-    m.l_stride = CC;
-    m.nlists = (uint32_t)grid;
-    m.list_len = CC;
-    m.k = CC;
-    m.out_stride = CC;
-    m.out_rows = cand_rows;
-    m.out_scores = nullptr;
-    m.out_counts = nullptr;
-    m.out_packed = approx_pin;   // the 256 best (integer score, row) entries, best first: the certificate reads two of them
-    FSGPU_HIP(launch_merge_topk(m, 1, stream_));
-    FSGPU_HIP(hipMemsetAsync(cand_scores, 0, (size_t)CC * 4, stream_));
-    FSGPU_HIP(launch_gather_dot(a, cand_rows, CC, cand_scores, stream_));
-    FSGPU_HIP(launch_pack_hits(cand_rows, cand_scores, CC, cand_packed, stream_));
-    MergeArgs m2;
-    m2.lists = cand_packed;
-    m2.q_stride = CC;
-    m2.l_stride = CC;
-    m2.nlists = 1;
-    m2.list_len = CC;
-    m2.k = k_eff;
-    m2.out_stride = k;
-    m2.out_rows = reinterpret_cast<uint32_t*>(io + o_out);
-    m2.out_scores = reinterpret_cast<float*>(io + o_out + (size_t)k * 4);
-    m2.out_counts = reinterpret_cast<uint32_t*>(io + o_out + (size_t)k * 8);
-    m2.out_packed = nullptr;
-    m2.lists_sorted = 0;   // candidates arrive in integer-score order
-    FSGPU_HIP(launch_merge_topk(m2, 1, stream_));
+    FSGPU_HIP(launch_list_cut(a.partial, (uint32_t)grid, LK, cut_pin, stream_));
+    SelectArgs f{};
+    f.lists = a.partial;
+    f.q_stride = (uint64_t)grid * LK;
+    f.l_stride = LK;
+    f.nlists = (uint32_t)grid;
+    f.list_len = LK;
+    f.k = k_eff;
+    f.delta = delta_pin;
+    f.tau_out = tau_pin;
+    f.cand_counts = ncand_pin;
+    f.overflow = overflow_pin;
+    f.slab = slab_dev_;
+    f.queries = q_pin;
+    f.dim = dim_;
+    f.nrows = (uint32_t)nrows_;
+    f.row_base = (uint32_t)row_base_;
+    f.row_stride = (row_stride_ && row_stride_ != dim_ * 2) ? row_stride_ : 0;
+    f.hreduce = hreduce;
+    f.k_out = k_eff;
+    f.out_stride = k;
+    f.out_rows = reinterpret_cast<uint32_t*>(io + o_out);
+    f.out_scores = reinterpret_cast<float*>(io + o_out + (size_t)k * 4);
+    f.out_counts = reinterpret_cast<uint32_t*>(io + o_out + (size_t)k * 8);
+    FSGPU_HIP(launch_select(f, 1, stream_));
     FSGPU_HIP(hipStreamSynchronize(stream_));
-    const float delta = *delta_pin;
+    const float delta = *delta_pin, tau = *tau_pin, cut = *cut_pin;
     if (!(delta >= 0.f)) return ok();   // a query the bound cannot cover (zero, non-finite, a slab with non-finite values)
-    uint32_t valid = 0;
-    while (valid < CC && approx_pin[valid] != ~0ull) ++valid;   // (kEmpty: all ones)
-    if (valid >= CC) {
-        if (k_eff > CC) return ok();
-        float s_k, s_last;
-        const uint32_t bk = (uint32_t)(approx_pin[k_eff - 1] >> 32), bl = (uint32_t)(approx_pin[CC - 1] >> 32);
-        std::memcpy(&s_k, &bk, 4);
-        std::memcpy(&s_last, &bl, 4);
-        if (!(s_last < s_k - 2.0f * delta)) return ok();   // rows within the margin may lie beyond the list: the staged path decides
-    }   // (fewer than 256 entries: every live row is in the list)
-    std::memcpy(out_rows, m2.out_rows, (size_t)k * 4);
-    std::memcpy(out_scores, m2.out_scores, (size_t)k * 4);
-    *out_count = *m2.out_counts;
+    if (*overflow_pin != 0 || *ncand_pin > kSelectPool) return ok();   // more rows within the margin than the finish re-scores
+    if (!(cut < tau)) return ok();      // a block may have dropped a row within the margin (NaN compares false: not certified)
+    if (*f.out_counts < k_eff) return ok();
+    std::memcpy(out_rows, f.out_rows, (size_t)k * 4);
+    std::memcpy(out_scores, f.out_scores, (size_t)k * 4);
+    *out_count = *f.out_counts;
     ++i8f_queries;
     *certified = true;
     return ok();

@@ -339,17 +339,21 @@ def test_three_thousand_filtered_repetitions_return_the_same_bits(fa):
 
 
 def test_lone_query_certified_single_pass_equals_the_exact_kernels(fa, oracle):
-    """The int8 latency path's lone query (fsgpu_index_set_int8_latency): one fused pass keeping the 256 best integer scores, exact
-    re-score, certificate (the 256th integer score more than 2 delta below the k-th).  Rows and score bits equal the exact kernels'
-    and the oracle's — on a corpus where the certificate holds, with tombstones, and on one where it cannot (thousands of rows
-    within the margin: the staged filter path answers, same bits)."""
+    """The int8 latency path's lone query (fsgpu_index_set_int8_latency): one pass over the int8 copy in which every block keeps its 32
+    best integer scores, the finish re-scores the entries within 2 delta of the k-th best from the f16 slab, and the host certifies
+    the answer when no block can have dropped a row within that margin (the best of the full lists' last entries lies below the
+    threshold) and the candidates fit the finish.  Rows and score bits equal the exact kernels' and the oracle's — on a corpus where
+    the certificate holds, with tombstones; on one where thousands of rows lie within the margin (the staged filter path answers,
+    same bits); and on one where 40 near-duplicates sit in ONE block's share of the rows (its list of 32 drops eight of them)."""
     rng = np.random.default_rng(23)
     dim, n = 384, 200_003
     x = rng.standard_normal((n, dim)).astype(np.float32)
     x /= np.linalg.norm(x, axis=1, keepdims=True)
     dense = x.copy()
     dense[5000:11000] = dense[5000] + (rng.standard_normal((6000, dim)) * 1e-3).astype(np.float32)   # 6,000 near-duplicates
-    for corpus, probe_row in ((x, 77), (dense, 5003)):
+    one_block = x.copy()   # rows 448..511 are the tiles 28..31: with 256 blocks of 4 waves, all of them block 7's
+    one_block[448:488] = one_block[448] + (rng.standard_normal((40, dim)) * 1e-3).astype(np.float32)
+    for corpus, probe_row in ((x, 77), (dense, 5003), (one_block, 448)):
         slab = corpus.astype(np.float16).view(np.uint16)
         live = rng.random(n) > 0.1
         a, b = fa.VectorIndex.from_slab(slab, live=live), fa.VectorIndex.from_slab(slab, live=live)
@@ -357,7 +361,7 @@ def test_lone_query_certified_single_pass_equals_the_exact_kernels(fa, oracle):
         q = corpus[rng.integers(0, n, 12)] + (rng.standard_normal((12, dim)) * 0.1).astype(np.float32)
         q[0] = corpus[probe_row]
         for rep in range(2):   # (the first call builds the int8 copy and its statistics through the staged path)
-            for k in (1, 10, 30):
+            for k in (1, 10, 30, 32):
                 for i in range(12):
                     ra, sa, ca = a.search_batch(q[i], k)
                     rb, sb, cb = b.search_batch(q[i], k)
