@@ -2479,6 +2479,95 @@ SearchError VectorIndex::search_top_k_4bit_two_pass(const float* query, uint32_t
     return quantized_two_pass(query, query_len, k, multiplier, 4, out_rows, out_scores, out_count);
 }
 
+// The two-pass searches' lane for ONE caller (see quantized_two_pass).  query / qi: the f32 query and its quantised form (host);
+// rows / scores: [k] on the host.  *answered = false: nothing was written.
+SearchError VectorIndex::two_pass_lone_certified(const float* query, const unsigned char* qi, uint32_t qbytes, uint32_t k, uint32_t k_eff,
+                                                 uint32_t cc, int bits, const void* qslab, uint32_t* rows, float* scores, uint32_t* count,
+                                                 bool* answered) {
+    *answered = false;
+    constexpr uint32_t LK = 32;
+    const bool fused = bits == 8 ? scan_i8_fused_supported((int)dim_, 64) : scan_4bit_fused_supported((int)dim_, 64);
+    if (!fused || pinned_io() == nullptr) return ok();
+    const size_t fbytes = (size_t)dim_ * 4;
+    const size_t o_qi = (fbytes + 255) & ~(size_t)255, o_out = (o_qi + qbytes + 255) & ~(size_t)255,
+                 o_flags = (o_out + (size_t)k * 8 + 4 + 255) & ~(size_t)255;
+    if (o_flags + 64 > kPinnedIoBytes) return ok();
+    unsigned char* io = static_cast<unsigned char*>(io_host_);
+    std::memcpy(io, query, fbytes);
+    std::memcpy(io + o_qi, qi, qbytes);
+    const float* q_pin = reinterpret_cast<const float*>(io);
+    float* delta_pin = reinterpret_cast<float*>(io + o_flags);   // the pass-1 scores are the reference's own: no margin
+    float* tau_pin = delta_pin + 1;
+    float* cut_pin = delta_pin + 2;
+    uint32_t* ncand_pin = reinterpret_cast<uint32_t*>(delta_pin + 3);
+    uint32_t* overflow_pin = reinterpret_cast<uint32_t*>(delta_pin + 4);
+    *delta_pin = 0.f;
+    *overflow_pin = 0;
+    *ncand_pin = 0;
+    // (every wave of the scan reads the whole quantised query: from device memory, not over the bus; the finish's one block reads
+    // the f32 query where it lies)
+    FSGPU_TRY(ws_i8_query_.reserve(qbytes));
+    FSGPU_HIP(hipMemcpyAsync(ws_i8_query_.ptr, io + o_qi, qbytes, hipMemcpyHostToDevice, stream_));
+    ScanArgs a = base_args(q_pin, nullptr);
+    int grid = num_cus_;   // 256 lists x 32 entries: what the sorted selection holds in one piece
+    const int max_useful = (int)(((nrows_ + 15) / 16 + 3) / 4);
+    grid = std::max(1, std::min(grid, max_useful));
+    if ((size_t)grid * LK > 8192) return ok();
+    FSGPU_TRY(ws_partial_.reserve((size_t)grid * LK * 8));
+    a.partial = static_cast<u64*>(ws_partial_.ptr);
+    a.k = LK;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (profiling) {
+        FSGPU_HIP(hipEventCreate(&e0));
+        FSGPU_HIP(hipEventCreate(&e1));
+        FSGPU_HIP(hipEventRecord(e0, stream_));
+    }
+    if (bits == 8) FSGPU_HIP(launch_scan_i8(a, qslab, ws_i8_query_.ptr, 64, grid, stream_, nullptr));
+    else FSGPU_HIP(launch_scan_4bit(a, qslab, ws_i8_query_.ptr, 64, grid, stream_, nullptr));
+    if (profiling) {
+        FSGPU_HIP(hipEventRecord(e1, stream_));
+        events_.emplace_back(e0, e1);
+        profiled_rows_ += nrows_;
+    }
+    FSGPU_HIP(launch_list_cut(a.partial, (uint32_t)grid, LK, cut_pin, stream_));
+    SelectArgs f{};
+    f.lists = a.partial;
+    f.q_stride = (uint64_t)grid * LK;
+    f.l_stride = LK;
+    f.nlists = (uint32_t)grid;
+    f.list_len = LK;
+    f.k = cc;
+    f.take_topk = 1;
+    f.delta = delta_pin;
+    f.tau_out = tau_pin;
+    f.cand_counts = ncand_pin;
+    f.overflow = overflow_pin;
+    f.slab = slab_dev_;
+    f.queries = q_pin;
+    f.dim = dim_;
+    f.nrows = (uint32_t)nrows_;
+    f.row_base = (uint32_t)row_base_;
+    f.hreduce = hreduce;
+    f.k_out = k_eff;
+    f.out_stride = k;
+    f.out_rows = reinterpret_cast<uint32_t*>(io + o_out);
+    f.out_scores = reinterpret_cast<float*>(io + o_out + (size_t)k * 4);
+    f.out_counts = reinterpret_cast<uint32_t*>(io + o_out + (size_t)k * 8);
+    FSGPU_HIP(launch_select(f, 1, stream_));
+    FSGPU_HIP(hipStreamSynchronize(stream_));
+    const float tau = *tau_pin, cut = *cut_pin;   // tau: the cc-th best pass-1 score (delta = 0)
+    if (*overflow_pin != 0) return ok();
+    // complete when no list was full (nothing dropped) or the cc-th best entry outranks everything dropped — STRICTLY: a dropped row
+    // with the same integer score may have the smaller row id
+    const bool complete = cut == -INFINITY || cut < tau;
+    if (!complete) return ok();
+    std::memcpy(rows, f.out_rows, (size_t)k * 4);
+    std::memcpy(scores, f.out_scores, (size_t)k * 4);
+    *count = *f.out_counts;
+    *answered = true;
+    return ok();
+}
+
 // Shared body of the int8 (bits = 8) and 4-bit (bits = 4) two-pass searches: quantised pass 1 over the lazily built
 // slab, exact f16 rescore of the candidates, best-first selection of k.
 SearchError VectorIndex::quantized_two_pass(const float* query, uint32_t query_len, uint32_t k, uint32_t multiplier,
@@ -2539,6 +2628,31 @@ SearchError VectorIndex::quantized_two_pass(const float* query, uint32_t query_l
             }
         }
     }
+    std::vector<uint32_t> rows(k);
+    std::vector<float> scores(k);
+    uint32_t count = 0;
+    bool answered = false;
+    // The lone caller's lane: pass 1 keeping 32 entries per block, the selection's finish (candidates = the cc best pass-1 entries,
+    // exact re-score, k best) — three launches, nothing copied — certified on the host: the cc-th best pass-1 entry lies strictly
+    // above everything a block can have dropped.  Otherwise (and for a row-sharded index's shards, which hand the candidate pairs on)
+    // the general sequence below answers; a failed certificate backs off like the exact search's (certified_i8_lone_query).
+    // (worth it from 65 candidates on, where the general sequence's block lists no longer fit the one-pass merge — the two-tier
+    // host's fast tier fetches 30 x 3: 10M x 256 p50 0.59 -> 0.55 ms; below that both sequences measured the same)
+    if (!approx_out_dev && !exact_out_dev && cc > 64 && cc <= kSelectMaxK && k_eff <= 64 && k <= 64 && (dim_ & 7) == 0 && nrows_ >= 4096 &&
+        !(row_stride_ && row_stride_ != dim_ * 2) && variant == 0) {
+        if (tp_skip_ > 0) {
+            --tp_skip_;
+        } else {
+            FSGPU_TRY(two_pass_lone_certified(query, qi.data(), qbytes, k, k_eff, cc, bits, qslab, rows.data(), scores.data(), &count, &answered));
+            if (answered) {
+                tp_backoff_ = 0;
+            } else {
+                tp_backoff_ = tp_backoff_ ? std::min<uint32_t>(tp_backoff_ * 2, 64) : 1;
+                tp_skip_ = tp_backoff_;
+            }
+        }
+    }
+    if (!answered) {
     FSGPU_TRY(ws_i8_query_.reserve(qbytes));
     FSGPU_TRY(ws_queries_.reserve((size_t)dim_ * 4));
     FSGPU_TRY(ws_cand_packed_.reserve((size_t)cc * 8));
@@ -2650,9 +2764,6 @@ SearchError VectorIndex::quantized_two_pass(const float* query, uint32_t query_l
     m2.out_packed = nullptr;
     m2.lists_sorted = 0;  // candidates arrive in pass-1 (int8) order
     FSGPU_HIP(launch_merge_topk(m2, 1, stream_));
-    std::vector<uint32_t> rows(k);
-    std::vector<float> scores(k);
-    uint32_t count = 0;
     if (pin_out) {  // the last merge wrote into pinned host memory
         FSGPU_HIP(hipStreamSynchronize(stream_));
         std::memcpy(rows.data(), m2.out_rows, (size_t)k * 4);
@@ -2664,6 +2775,7 @@ SearchError VectorIndex::quantized_two_pass(const float* query, uint32_t query_l
         FSGPU_HIP(hipMemcpyAsync(&count, ws_counts_.ptr, 4, hipMemcpyDeviceToHost, stream_));
         FSGPU_HIP(hipStreamSynchronize(stream_));
     }
+    }   // (!answered)
     // resolve_hits (search.rs:1503-1558): first (best) hit per doc id when the index knows doc ids
     uint32_t outn = 0;
     for (uint32_t i = 0; i < count; ++i) {

@@ -220,6 +220,8 @@ class VectorIndex {
     // written, the staged filter path answers.
     SearchError certified_i8_lone_query(const float* query, uint32_t k, uint32_t* out_rows, float* out_scores, uint32_t* out_count,
                                         bool* certified);
+    SearchError two_pass_lone_certified(const float* query, const unsigned char* qi, uint32_t qbytes, uint32_t k, uint32_t k_eff, uint32_t cc,
+                                        int bits, const void* qslab, uint32_t* rows, float* scores, uint32_t* count, bool* answered);
     SearchError common_init(int device);
     SearchError fused_search(const float* queries_dev, uint32_t nq, uint32_t k_out, uint32_t k_eff,
                              const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
@@ -262,6 +264,7 @@ class VectorIndex {
     bool i8f_disabled_ = false;   // the int8 filter left too many queries uncertified on this slab (or its copy does not fit)
     uint32_t i8f_strikes_ = 0;
     uint32_t cert_skip_ = 0, cert_backoff_ = 0;   // the lone query's single-pass certificate: calls still to skip / the current back-off
+    uint32_t tp_skip_ = 0, tp_backoff_ = 0;       // ... and the two-pass searches' lone-caller lane
     uint32_t i8f_sample_boost_ = 1;   // 1 or 2: the second sample of the int8 filter's wide rounds grows before the filter is given up
     bool mf_norm_ready_ = false;
     int mf_shape_i8_ = 4, mf_per_cu_160_ = 1, mf_per_cu_160_i8_ = 1;
