@@ -1181,3 +1181,29 @@ def test_resident_allow_bitmap_gives_the_per_call_bitmaps_hits(fa, oracle):
     f.close()
     other.close()
     idx.close()
+
+
+def test_profiling_period_times_every_nth_batched_step(fa):
+    """fsgpu_index_set_profiling(n): of the batched search's main launches only those of every n-th call carry the HIP event pair
+    (what bench.py times the dominant kernel with); answers are the same with and without."""
+    rng = np.random.default_rng(5)
+    n, dim = 150_016, 384
+    slab = rand_slab(rng, n, dim)
+    idx = fa.VectorIndex.from_slab(slab)
+    q = rng.standard_normal((512, dim)).astype(np.float32)
+    ref = idx.search_batched(q, 10)
+    idx.scan_stats(reset=True)
+    for period, steps in ((True, 6), (4, 9)):
+        idx.set_profiling(period)
+        for _ in range(steps):
+            got = idx.search_batched(q, 10)
+        idx.set_profiling(False)
+        ms, launches, rows = idx.scan_stats(reset=True)
+        per_step = launches if period is True else launches
+        want_steps = steps if period is True else (steps + 3) // 4
+        assert launches % want_steps == 0 and launches >= want_steps, (period, launches)
+        assert rows == (launches // want_steps) * want_steps * n or rows % n == 0
+        assert ms > 0.0
+        for x, y in zip(ref[:3], got[:3]):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    idx.close()
