@@ -1037,7 +1037,7 @@ def main() -> None:
         # the same boundary with fsgpu_index_set_int8_latency: ONE pass over the int8 copy, the rows within the proven margin re-scored
         # from the f16 slab, the answer certified on the host (rows and score bits of the exact search; the staged path behind it)
         lat_i8, lat_i8_same = [], True
-        if args.batched:   # (the batched steps above built the int8 copy and its statistics)
+        if args.batched and int8_filter:   # (the batched steps above built the int8 copy and its statistics)
             exact_hits = [index.search_batch(q1[i], k) for i in range(8)]
             index.set_int8_latency(True)
             for i in range(72):
@@ -1115,7 +1115,7 @@ def main() -> None:
                     "frac": tflops / mfma_peak, "traffic": None,
                     "kernel": "scan_wide_kernel / scan_mfma_kernel (main pass, average over the step's launches)",
                     "algorithmic_flops_per_launch": flops, "queries_per_launch": q_per_launch, "passes_over_the_slab_per_launch": passes_per_launch,
-                    "avg_launch_ms": per_launch_ms, "launches": launches,
+                    "avg_launch_ms": per_launch_ms, "launches": launches, "timed": hbm.get("timed"),
                     "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                             "algorithmic_bytes_per_launch": alg_bytes},
                     "note": ("v_mfma_i32_16x16x64_i8 sustains ~4.2 POP/s on random operands with nothing else in the kernel"

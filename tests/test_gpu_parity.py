@@ -1193,17 +1193,18 @@ def test_profiling_period_times_every_nth_batched_step(fa):
     q = rng.standard_normal((512, dim)).astype(np.float32)
     ref = idx.search_batched(q, 10)
     idx.scan_stats(reset=True)
-    for period, steps in ((True, 6), (4, 9)):
+    per_step = None
+    for period, steps, timed in ((True, 6, 6), (4, 9, 3)):
         idx.set_profiling(period)
         for _ in range(steps):
             got = idx.search_batched(q, 10)
         idx.set_profiling(False)
         ms, launches, rows = idx.scan_stats(reset=True)
-        per_step = launches if period is True else launches
-        want_steps = steps if period is True else (steps + 3) // 4
-        assert launches % want_steps == 0 and launches >= want_steps, (period, launches)
-        assert rows == (launches // want_steps) * want_steps * n or rows % n == 0
-        assert ms > 0.0
+        if per_step is None:
+            assert launches >= steps and launches % steps == 0, launches
+            per_step = launches // steps
+        assert launches == timed * per_step, (period, launches, per_step)
+        assert ms > 0.0 and rows % n == 0 and rows >= launches * n
         for x, y in zip(ref[:3], got[:3]):
             assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
     idx.close()
