@@ -99,7 +99,9 @@ struct MfmaScanArgs {
     uint32_t* overflow;        // [nq_pad] set when a query's spill area overflows too
     u64* dense;                // stage 0: [nq_pad, group_count * 64] packed approximate scores of the sample
     uint32_t nrows;            // rows in the slab
-    uint32_t stage;            // 0 = dense sample, 1 = thresholded sample, 2 = main pass (everything stage 1 skipped)
+    uint32_t stage;            // 0 = dense sample, 1 = thresholded sample, 2 = main pass (everything stage 1 skipped),
+                               // 3 = (mfma_wide.hip, int8 rows) sample that writes each block's four best GROUPS per query into cand
+                               //     ([q][block][4]: best approximate score | first row of the group's 8 rows) — no thresholds, no lists
     uint32_t group_stride, group_count;  // the sample, in 64-row groups: {j * group_stride : j < group_count}
     uint32_t dim, slots, row_base;       // slots <= kMfmaMaxSlots
     uint32_t elem_bytes;                 // 2 = f16 slab / f16 queries (0 means 2), 1 = int8 slab / int8 queries
@@ -176,6 +178,32 @@ struct SelectArgs {
     uint32_t valid_queries;       // blocks q >= this are padding slots whose query lies past the caller's array (0 = every block's query exists)
     unsigned long long* stamps;   // lab builds (FSGPU_EXPERIMENTS): shader clocks of block 0's phases; null otherwise
 };
+// select_groups_kernel (mfma_scan.hip): the selection behind a group-maxima sample (MfmaScanArgs::stage == 3).  Per query: the
+// kGroupsTaken best of its nentries groups (packed best approximate score | first row of the group's 8 rows: rows g + {0..3} and
+// g + 16 + {0..3}) -> their live, allowed rows re-scored from the f16 slab in the reference's operation order -> S_k = the k-th best
+// exact score among them (k distinct real rows: a lower bound on the final k-th best) ->
+//   tau_out = max(a_k - 2 delta, S_k * anchor_unit - delta) in filter units (a_k: the k-th best group maximum),
+// exactly what select_kernel's exact-anchor step emits; the query's spill counter is reset for the scan stage that follows.
+// delta < 0 (padding / zero / non-finite query): tau = +inf and overflow[q] = 1 (the exact path answers it).
+struct GroupSelectArgs {
+    const u64* groups;         // [nq][nentries]
+    uint32_t nentries;         // <= 1024
+    uint32_t k;                // 1..64
+    const float* delta;        // [nq]
+    const float* anchor_unit;  // [nq] filter-score units per exact-score unit
+    float* tau_out;            // [nq]
+    uint32_t* overflow;        // [nq] (may be null)
+    uint32_t* spill_reset;     // [nq * kMfmaSpillCountStride] (may be null)
+    const void* slab;          // [nrows, dim] f16
+    const u64* live;           // may be null
+    const u64* allow;          // may be null
+    const float* queries;      // [nq, query_stride] f32
+    uint32_t dim, nrows, row_base, query_stride;
+    int hreduce;
+    uint32_t valid_queries;    // blocks q >= this are padding slots (0 = every block's query exists)
+};
+constexpr uint32_t kGroupsTaken = 24;
+hipError_t launch_select_groups(const GroupSelectArgs& args, int nq, hipStream_t stream);
 constexpr uint32_t kSelectPool = 1024;
 constexpr uint32_t kSelectMaxK = 128;   // largest rank a selection can anchor on (k, or k * multiplier in int8 mode)
 hipError_t launch_select(const SelectArgs& args, int nq, hipStream_t stream);
@@ -205,6 +233,7 @@ bool scan_mfma_supported(int dim);
 // mfma_wide.hip: main pass with the queries in registers and the row tiles in an LDS-DMA ring; query_tiles 2 = 256, 3 = 384
 // queries per launch; one candidate list of args.slots <= kWideSlots entries per (query, block)
 bool scan_wide_supported(int dim, int elem_bytes);
+bool scan_wide_group_maxima_supported(int dim, int query_tiles);   // MfmaScanArgs::stage == 3 (int8 rows): see select_groups
 int scan_wide_max_query_tiles(int dim, int elem_bytes);  // 3 for f16 rows of 384 dimensions, 5 for their int8 form
 hipError_t launch_scan_wide(const MfmaScanArgs& args, int query_tiles, int grid, hipStream_t stream, int* occupancy);
 void note_main_pass_kernel(const char* name);  // remembers the instantiation the last main pass ran (last_main_pass_kernel)

@@ -1206,6 +1206,132 @@ hipError_t launch_two_pass_merge(const u64* approx_lists, const u64* exact_lists
     return hipGetLastError();
 }
 
+// See GroupSelectArgs (kernels.hpp).  1,024 threads: one entry each -> every wave's 4 best -> wave 0 picks kGroupsTaken of the 64 ->
+// a quad per row of the taken groups (8 x 24 = 192 rows) re-scores it -> the k-th best by rank among the <= 256 exact entries.
+__global__ __launch_bounds__(1024) void select_groups_kernel(GroupSelectArgs args) {
+    constexpr int NT = 1024, NW = NT / 64, PERW = 4, M = (int)kGroupsTaken, NR = M * 8;
+    static_assert(NR * 4 <= NT && NR <= 256 && NW * PERW == 64, "a quad per candidate row; one winner per lane of wave 0");
+    __shared__ u64 win[NW * PERW];
+    __shared__ u64 top[64];
+    __shared__ u64 pool[256];
+    __shared__ u64 keys[256];
+    __shared__ __attribute__((aligned(16))) float s_q[kSelQueryLds];
+    __shared__ u64 s_kth;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x;
+    const int k = (int)args.k;
+    const float d = args.delta[q];
+    const bool real_query = args.valid_queries == 0 || (uint32_t)q < args.valid_queries;
+    const int dim = (int)args.dim;
+    if (real_query) {
+        const float* qsrc = args.queries + (size_t)q * (args.query_stride ? args.query_stride : args.dim);
+        for (int i = tid; i < dim && i < kSelQueryLds; i += NT) s_q[i] = qsrc[i];
+    }
+    u64 e[1], key[1];
+    e[0] = (uint32_t)tid < args.nentries ? args.groups[(size_t)q * args.nentries + tid] : kEmpty;
+    key[0] = e[0] != kEmpty ? sortkey(e[0]) : 0ull;
+    if (lane < PERW) win[wave * PERW + lane] = kEmpty;
+    if (tid < 256) pool[tid] = kEmpty;
+    if (tid == 0) s_kth = 0ull;
+    wave_lds_fence();
+    wave_extract_topk<1>(key, e, PERW, win + wave * PERW);
+    __syncthreads();
+    if (wave == 0) {
+        u64 e2[1], key2[1];
+        e2[0] = win[lane];
+        key2[0] = e2[0] != kEmpty ? sortkey(e2[0]) : 0ull;
+        top[lane] = kEmpty;
+        wave_lds_fence();
+        wave_extract_topk<1>(key2, e2, M, top);
+        wave_lds_fence();
+    }
+    __syncthreads();
+    // exact-order re-score (dot_product_f16_bytes_f32 order, as gather_dot_kernel and select_kernel's finish): a quad per row
+    {
+        const int c = tid >> 2, a = tid & 3;
+        const int gi = c >> 3, pos = c & 7;
+        const u64 ge = c < NR ? top[gi] : kEmpty;
+        const uint32_t grow = (uint32_t)ge + (uint32_t)((pos >> 2) * 16 + (pos & 3));
+        uint32_t row = grow - args.row_base;
+        bool mine = real_query && ge != kEmpty && row < args.nrows && dim <= kSelQueryLds;
+        if (mine && args.live) mine = ((args.live[row >> 6] >> (row & 63)) & 1ull) != 0;
+        if (mine && args.allow) mine = ((args.allow[row >> 6] >> (row & 63)) & 1ull) != 0;
+        // (every lane of a quad computes the same predicate: the quad shuffles below see whole quads)
+        if (!mine) row = 0;
+        const u32x4* p = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(args.slab) + (size_t)row * ((size_t)dim * 2));
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        const int chunks = dim >> 3, groups = chunks >> 2, leftover = chunks & 3;
+        for (int g0 = 0; g0 < groups; g0 += kRescoreBatch) {
+            u32x4 w[kRescoreBatch];
+#pragma unroll
+            for (int j = 0; j < kRescoreBatch; ++j)
+                if (g0 + j < groups) w[j] = p[4 * (g0 + j) + a];
+#pragma unroll
+            for (int j = 0; j < kRescoreBatch; ++j)
+                if (g0 + j < groups) {
+                    const float4* qp = reinterpret_cast<const float4*>(s_q + 32 * (g0 + j) + 8 * a);
+                    chunk_mac(acc, w[j], qp[0], qp[1]);
+                }
+        }
+        if (a == 0)
+            for (int ch = 4 * groups; ch < 4 * groups + leftover; ++ch) {
+                const u32x4 w = p[ch];
+                const float4* qp = reinterpret_cast<const float4*>(s_q + 8 * ch);
+                chunk_mac(acc, w, qp[0], qp[1]);
+            }
+        const float sc = quad_finish(acc, args.hreduce);
+        if (a == 0 && c < NR && mine) pool[c] = pack(sc, grow);
+    }
+    __syncthreads();
+    // the k-th best exact entry by rank (keys are unique: exactly one entry has each rank)
+    if (tid < 256) keys[tid] = pool[tid] != kEmpty ? sortkey(pool[tid]) : 0ull;
+    __syncthreads();
+    if (tid < NR) {
+        const u64 mine = keys[tid];
+        if (mine != 0ull) {
+            int greater = 0;
+#pragma unroll 8
+            for (int j = 0; j < NR; ++j) greater += keys[j] > mine ? 1 : 0;
+            if (greater == k - 1) s_kth = pool[tid];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float t = -INFINITY;   // fewer than k rows: everything is a candidate (the main pass's lists then overflow into the exact path)
+        if (d < 0.f || !real_query) {
+            t = INFINITY;      // skipped query (padding / zero / non-finite): the exact path answers it
+            if (args.overflow) args.overflow[q] = 1;
+        } else {
+            // the k-th best group maximum: k distinct rows score at least that (approximately) — rows, not necessarily LIVE or ALLOWED
+            // ones: with a bitmap only the exact anchor below (taken over live, allowed rows) stands
+            const u64 ak = (k <= M && !args.live && !args.allow) ? top[k - 1] : kEmpty;
+            if (ak != kEmpty) {
+                const float ta = __uint_as_float((uint32_t)(ak >> 32)) - 2.0f * d;
+                if (ta == ta) t = ta;
+            }
+            const u64 kth = s_kth;
+            if (kth != 0ull) {
+                const float sk = __uint_as_float((uint32_t)(kth >> 32));
+                const float v = sk * args.anchor_unit[q];
+                const float te = v - d - fabsf(v) * 1e-6f - 1.0f;
+                if (te == te && te > t) t = te;
+            }
+        }
+        args.tau_out[q] = t;
+        if (args.spill_reset) args.spill_reset[(size_t)q * kMfmaSpillCountStride] = 0u;
+    }
+}
+
+hipError_t launch_select_groups(const GroupSelectArgs& args, int nq, hipStream_t stream) {
+    if (args.k < 1 || args.k > kGroupsTaken || args.nentries == 0 || args.nentries > 1024 || (args.dim & 7) || args.dim > kSelQueryLds ||
+        !args.delta || !args.anchor_unit || !args.tau_out)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(select_groups_kernel, dim3(nq), dim3(1024), 0, stream, args);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void list_cut_kernel(const u64* __restrict__ lists, uint32_t nlists, uint32_t list_len, float* __restrict__ out) {
     __shared__ u64 red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

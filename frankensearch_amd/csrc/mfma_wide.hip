@@ -256,6 +256,12 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     // a bit set on 16 — 1 no DMA, 2 no per-tile wait + barrier, 4 no fragment reads in the loop, 8 no threshold tests; the append path
     // is one LDS store.  DBG >= 32: everything real but the append path, a bit set on 32 — 1 no global store, 2 no LDS counter (slot 0),
     // 4 an empty append (the per-lane tests still run).
+    // DBG 7: a SAMPLE stage that appends nothing — every lane keeps, per query tile, the best score it has seen and the sub-tile pair it
+    // saw it in (the lane's 8 rows of that pair: "a group"); the block writes its 4 groups per query ([q][block][4] in args.cand, kEmpty
+    // where a lane saw nothing) and select_groups_kernel (mfma_scan.hip) re-scores the best groups' rows exactly.  The groups of one
+    // query are disjoint row sets, so any k re-scored rows bound the k-th best score from below: no thresholds in, no lists, no
+    // divergent path in the loop.
+    constexpr bool GMAX = DBG == 7 && SPLIT && EB == 1;   // (built on the split loop over int8 rows: scan_wide_group_maxima_supported)
     constexpr bool SK = DBG >= 16 && DBG < 32;
     constexpr bool SK_NO_DMA = DBG == 2 || (SK && (DBG & 1)), SK_NO_SYNC = SK && (DBG & 2), SK_NO_READS = SK && (DBG & 4), SK_NO_TEST = SK && (DBG & 8);
     constexpr bool AK = DBG >= 32;
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
             const unsigned char* qp = qbase + (size_t)(q0 + nt * 16 + frow) * ROWB + fk * 16;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) bq[nt][ks] = *reinterpret_cast<const half8*>(qp + ks * 64);
-            tau[nt] = args.tau[q0 + nt * 16 + frow];
+            tau[nt] = GMAX ? 0.f : args.tau[q0 + nt * 16 + frow];   // (GMAX: the accumulators hold the scores themselves)
             ctau[nt] = ceil_threshold(tau[nt]);
             if constexpr (NT4) ntau4[nt] = i32x4{-ctau[nt], -ctau[nt], -ctau[nt], -ctau[nt]};
         }
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     // A sample stage (args.group_count != 0) visits 64-row groups group_stride apart instead: the same tile sequence over
     // the sample's tiles, each mapped to its place in the slab.
     constexpr uint32_t TPG = TR <= 64 ? 64 / TR : 1;   // tiles per 64-row sample group (128-row tiles never sample)
-    constexpr bool sampled = DBG == 3;
+    constexpr bool sampled = DBG == 3 || DBG == 7;
     const uint32_t ntiles = sampled ? args.group_count * TPG : (args.nrows + TR - 1) / TR;
     auto tile_row0 = [&](uint32_t t) -> uint32_t {
         return sampled ? (t / TPG) * args.group_stride * 64u + (t % TPG) * TR : t * TR;
@@ -656,6 +662,32 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
         uint32_t slot = 0, slot_prev = NSLOT - 1;
         const unsigned char* cur = slot_base(0);
         uint32_t tB = ntiles;                   // tile of the pair whose second-half scores are still to be tested (none yet)
+        // GMAX: the lane's best score per query tile so far and the first row of the sub-tile pair it was seen in
+        [[maybe_unused]] int gbest[QT];
+        [[maybe_unused]] uint32_t grow[QT];
+        if constexpr (GMAX) {
+#pragma unroll
+            for (int nt = 0; nt < QT; ++nt) {
+                gbest[nt] = -0x7fffffff - 1;
+                grow[nt] = 0;
+            }
+        }
+        auto gmax_update = [&](uint32_t tt, int sp, int nt_lo, int nt_hi) __attribute__((always_inline)) {
+            if constexpr (GMAX) {
+                const uint32_t g = tile_row0(tt < ntiles ? tt : 0u) + (uint32_t)sp * 16u;
+                // (wave-uniform) a ragged round's missing tile holds the last tile again, and a pair that reaches past the last row holds
+                // copies of it: neither may stand for a group — two groups must never report the same row
+                if (tt < ntiles && g + 32u <= args.nrows) {
+#pragma unroll
+                    for (int nt = nt_lo; nt < nt_hi; ++nt) {
+                        const int v = lane_max(acc, nt);
+                        const bool better = v > gbest[nt];
+                        gbest[nt] = better ? v : gbest[nt];
+                        grow[nt] = better ? g : grow[nt];
+                    }
+                }
+            }
+        };
         while (cc.n < rounds) {
             const uint32_t slot_next = slot + 1 == NSLOT ? 0 : slot + 1;
             const unsigned char* nxt = slot_base(slot_next);
@@ -669,7 +701,11 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) {
                     mfma_step(kk, 0, QA);
-                    if (kk == TK) anyB = sk_any(QA, QT);
+                    if constexpr (GMAX) {
+                        if (kk == TK) gmax_update(tB, ((p + NP - 1) % NP) * 2, QA, QT);
+                    } else {
+                        if (kk == TK) anyB = sk_any(QA, QT);
+                    }
                     if (p == 0 && kk == 0 && !SK_NO_SYNC) {
                         // The tile's barrier.  Tile n+1: this wave's DMAs have landed (tiles n+2 .. n+NSLOT-2 may still be in
                         // flight), then everyone's; every wave is also past its last read of tile n-1 (this tile's first pair was
@@ -711,7 +747,11 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
                     }
                     if (p + 1 < NP) read_frag(cur, p + 1, kk);
                     else read_frag(nxt, 0, kk);
-                    if (kk == TK) anyA = sk_any(0, QA);
+                    if constexpr (GMAX) {
+                        if (kk == TK) gmax_update(t, p * 2, 0, QA);
+                    } else {
+                        if (kk == TK) anyA = sk_any(0, QA);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (FLAGS) {   // this wave's last read of the tile is out (the last pair's fragments): its slot may be refilled
@@ -725,7 +765,20 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
             slot = slot_next;
             cur = nxt;
         }
-        if (__builtin_expect(any_passes(acc, QA, QT), 0)) emit_tiles(tB, (NP - 1) * 2, acc, QA, QT);
+        if constexpr (GMAX) {
+            gmax_update(tB, (NP - 1) * 2, QA, QT);
+            // the block's four groups per query: [q][block][lane >> 4]
+            wait_vmcnt<0>();
+#pragma unroll
+            for (int nt = 0; nt < QT; ++nt) {
+                const u64 e = gbest[nt] == -0x7fffffff - 1 ? kEmpty : pack((float)gbest[nt], args.row_base + grow[nt] + (uint32_t)fk * 4u);
+                args.cand[((size_t)(q0 + nt * 16 + frow) * gridDim.x + blockIdx.x) * 4 + fk] = e;
+            }
+            __syncthreads();   // (no DMA may outlive the block's LDS allocation: every wave has waited for its own above)
+            return;
+        } else {
+            if (__builtin_expect(any_passes(acc, QA, QT), 0)) emit_tiles(tB, (NP - 1) * 2, acc, QA, QT);
+        }
     } else {
     half8 fa[2][2][CK];   // fragment double buffer: [buffer][sub-tile of the pair][k-step of the chunk]
     wait_vmcnt<PW*(NSLOT - 2)>();          // this wave's share of tile 0 has landed ...
@@ -845,7 +898,7 @@ hipError_t launch_wide_t(const MfmaScanArgs& args, int grid, hipStream_t stream,
     if (args.slots > kWideSlots) return hipErrorInvalidValue;
     static const std::string name = "scan_wide_kernel<" + std::to_string(ROWB) + ", " + std::to_string(EB) + ", " +
                                     std::to_string(QT) + ", " + std::to_string(NSLOT) + ", " + std::to_string(OPT) + ">";
-    if (DBG != 3) note_main_pass_kernel(name.c_str());
+    if (DBG != 3 && DBG != 7) note_main_pass_kernel(name.c_str());
     hipLaunchKernelGGL(kern, dim3(grid, args.groups ? args.groups : 1), dim3(512), lds, stream, args);
     return hipGetLastError();
 }
@@ -932,6 +985,12 @@ bool scan_wide_supported(int dim, int elem_bytes) {
     return rowb == 768 || rowb == 512 || rowb == 384 || rowb == 256 || rowb == 128;
 }
 
+// int8 rows whose shape runs the query-tile-split loop (the group-maxima sample stage is built on it)
+bool scan_wide_group_maxima_supported(int dim, int query_tiles) {
+    return (dim == 384 || dim == 256 || dim == 128) && query_tiles >= 2 && query_tiles <= 5 &&
+           wide_split_ok(dim, 1, query_tiles, kWideOptDefault, 7);
+}
+
 // largest query_tiles a row length admits (registers: see launch_wide_d), capped at 5
 int scan_wide_max_query_tiles(int dim, int elem_bytes) {
     const int per_tile = dim * elem_bytes / 64 * 4;
@@ -945,6 +1004,14 @@ hipError_t launch_scan_wide(const MfmaScanArgs& args, int query_tiles, int grid,
     const int eb = args.elem_bytes == 1 ? 1 : 2;
     if (!scan_wide_supported((int)args.dim, eb) || query_tiles > scan_wide_max_query_tiles((int)args.dim, eb)) return hipErrorInvalidValue;
     const bool sample = args.group_count != 0;   // a sample stage: 64-row groups group_stride apart
+    if (sample && args.stage == 3) {             // ... that keeps group maxima instead of thresholded lists (int8 rows, split-loop shapes)
+        if (eb != 1 || !scan_wide_group_maxima_supported((int)args.dim, query_tiles)) return hipErrorInvalidValue;
+        if (query_tiles == 2) return launch_wide_d<1, 2, 7>(args, grid, stream, occupancy);
+        if (query_tiles == 3) return launch_wide_d<1, 3, 7>(args, grid, stream, occupancy);
+        if (query_tiles == 4) return launch_wide_d<1, 4, 7>(args, grid, stream, occupancy);
+        if (query_tiles == 5) return launch_wide_d<1, 5, 7>(args, grid, stream, occupancy);
+        return hipErrorInvalidValue;
+    }
     if (eb == 2) {
         if (query_tiles == 2) return sample ? launch_wide_d<2, 2, 3>(args, grid, stream, occupancy) : launch_wide_d<2, 2>(args, grid, stream, occupancy);
         if (query_tiles == 3) return sample ? launch_wide_d<2, 3, 3>(args, grid, stream, occupancy) : launch_wide_d<2, 3>(args, grid, stream, occupancy);
