@@ -371,3 +371,36 @@ def test_lone_query_certified_single_pass_equals_the_exact_kernels(fa, oracle):
         assert np.array_equal(rb[0], orow) and np.array_equal(bits(sb[0]), bits(osc))
         a.close()
         b.close()
+
+
+@pytest.mark.parametrize("dim", [128, 256, 384])
+def test_group_maxima_sample_stage_gives_the_exact_search_bits(fa, oracle, dim):
+    """The int8 filter's append-free sample stage (MfmaScanArgs::stage 3 + select_groups_kernel: every block reports its four best
+    groups of 8 rows per query, the best 24 groups' rows are re-scored exactly, tau = max(a_k - 2 delta, S_k x unit - delta)):
+    batches of 256 ... 1,030 queries (2-5 query tiles per wave, ragged tails), ranks up to 24 (25: the thresholded stages), heavy
+    tombstones (the anchor counts live rows only), a slab whose last sub-tile pair is incomplete and holds the best rows, runs of
+    identical rows — rows, score bits and counts equal the exact kernels'; one query per case against the oracle."""
+    rng = np.random.default_rng(1000 + dim)
+    n = 262_144 + 19                                   # the last pair of the slab is incomplete
+    cent = unit_rows(rng, 32, dim)
+    rows = cent[rng.integers(0, 32, n)] + 0.3 * rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    rows[70_000:70_040] = rows[69_999]                 # identical rows: the lower row wins
+    rows[n - 19:] = rows[123] + 1e-3 * rng.standard_normal((19, dim)).astype(np.float32)   # near-duplicates of a probe in the ragged tail
+    slab = rows.astype(np.float16).view(np.uint16)
+    for live in (None, rng.random(n) > 0.4):
+        idx = fa.VectorIndex.from_slab(slab, live=live)
+        idx.set_batched_filter(2)
+        for nq, k in ((256, 10), (384, 1), (640, 24), (1030, 10), (530, 25)):
+            q = cent[rng.integers(0, 32, nq)] + 0.3 * rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+            q[0] = rows[123]
+            q[1] = rows[69_999]
+            exact = [idx.search_batch(q[s:s + 64], k) for s in range(0, nq, 64)]
+            er, es, ec = (np.concatenate([e[i] for e in exact]) for i in range(3))
+            for rep in range(2):
+                br, bs, bc, fb = idx.search_batched(q, k)
+                assert np.array_equal(bc, ec) and np.array_equal(br, er) and np.array_equal(bits(bs), bits(es)), (dim, nq, k, live is not None, rep)
+                assert fb <= nq // 8, (nq, k, fb)
+            orow, osc = oracle.search_top_k(slab, q[0], k, live=live)
+            assert np.array_equal(br[0][:len(orow)], orow) and np.array_equal(bits(bs[0][:len(osc)]), bits(osc))
+        idx.close()
