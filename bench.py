@@ -883,6 +883,8 @@ def main() -> None:
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--batch", type=int, default=None,
                     help="queries per step (default: 1024 on the batched path = 8 passes of 128; 4 on the exact path)")
+    ap.add_argument("--blocking-steps", action="store_true",
+                    help="N = 1: one blocking fsgpu_search_topk_batched_device call per step instead of begin / end with one step enqueued ahead")
     ap.add_argument("--exact", action="store_true",
                     help="time the exact VALU kernels (4-8 queries per HBM pass) instead of the batched matrix-core path")
     ap.add_argument("--variant", type=int, default=0)
@@ -979,6 +981,20 @@ def main() -> None:
         """n whole searches; returns the last step's (rows, scores, counts).  Every step's result is complete when this
         returns (the caller synchronises the device)."""
         out = None
+        if world == 1 and args.batched and not args.blocking_steps:
+            # one step enqueued ahead (fsgpu_search_topk_batched_device_begin / _end): the GPU starts step i + 1 while the host is
+            # still reading step i's verdicts — the same K steps, each complete when this returns (the caller synchronises)
+            prev = None
+            for i in range(first, first + n):
+                cur = shard_backend.scan_begin(batch_of(i), k, packed=False)
+                if prev is not None:
+                    fallbacks[0] += shard_backend.scan_end(prev[1])
+                    out = prev[0]
+                prev = cur
+            if prev is not None:
+                fallbacks[0] += shard_backend.scan_end(prev[1])
+                out = prev[0]
+            return out
         if world == 1:
             for i in range(first, first + n):
                 out = sharded.search(batch_of(i), k)
@@ -1083,6 +1099,8 @@ def main() -> None:
                 "filter": ("int8" if int8_filter else "f16") if args.batched else None,
                 "filter_refiltered_on_f16_queries": i8_refiltered if int8_filter else None,
                 "exact_fallback_queries": fallbacks[0] if args.batched else None,
+                "host_loop": ("fsgpu_search_topk_batched_device_begin / _end, one step enqueued ahead" if args.batched and not args.blocking_steps
+                              else "one blocking call per step"),
             },
             "roofline": {
                 "bound": "hbm",

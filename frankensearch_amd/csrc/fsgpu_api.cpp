@@ -610,6 +610,29 @@ fsgpu_status fsgpu_search_topk_batched_packed_device(fsgpu_index* idx, const flo
     });
 }
 
+fsgpu_status fsgpu_search_topk_batched_device_begin(fsgpu_index* idx, const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
+                                                    const uint64_t* allow_bitmap_dev, uint32_t* out_rows_dev, float* out_scores_dev,
+                                                    uint32_t* out_counts_dev, uint64_t* out_packed_dev, void* hip_stream, int32_t* out_ticket) {
+    if (!idx || !out_ticket) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    if (nq == 0 || k == 0 || !queries_dev) return fail(FSGPU_ERR_INVALID_CONFIG, "a begun search needs queries and k >= 1");
+    if (out_packed_dev && k > 256) return fail(FSGPU_ERR_INVALID_CONFIG, "packed shard search supports k <= 256");
+    if (!out_packed_dev && !(out_rows_dev && out_scores_dev && out_counts_dev)) return fail(FSGPU_ERR_NULL_ARGUMENT, "no output");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        if (idx->impl.record_count() == 0) return fail(FSGPU_ERR_INVALID_CONFIG, "the index is empty: use the blocking form");
+        return finish(idx->impl.search_top_k_batched_device_begin(queries_dev, nq, query_len, k, allow_bitmap_dev, out_rows_dev, out_scores_dev,
+                                                                  out_counts_dev, static_cast<hipStream_t>(hip_stream), out_packed_dev, out_ticket));
+    });
+}
+
+fsgpu_status fsgpu_search_topk_batched_device_end(fsgpu_index* idx, int32_t ticket, uint32_t* out_fallbacks) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.search_top_k_batched_device_end(ticket, out_fallbacks));
+    });
+}
+
 fsgpu_status fsgpu_search_topk_packed_device(fsgpu_index* idx, const float* queries_dev, uint32_t nq,
                                              uint32_t query_len, uint32_t k, const uint64_t* allow_bitmap_dev,
                                              uint64_t* out_packed_dev, void* hip_stream) {

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <type_traits>
 
 #include "../../include/fsgpu.h"
 #include "lab_env.hpp"
@@ -162,6 +163,8 @@ VectorIndex::~VectorIndex() {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
     }
+    for (hipEvent_t& e : async_ev_)
+        if (e) (void)hipEventDestroy(e);
     if (stream_) (void)hipStreamDestroy(stream_);
     for (DeviceBuffer* b : {&slab_own_, &live_own_, &ws_partial_, &ws_queries_, &ws_allow_, &ws_rows_, &ws_scores_,
                             &ws_counts_, &ws_keys_a_, &ws_keys_b_, &ws_sort_tmp_, &ws_gather_rows_, &ws_gather_out_,
@@ -1273,7 +1276,21 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
         uint32_t refiltered = 0;
         SearchError e = batched_impl(queries_dev, nq, query_len, k, allow_dev, out_rows_dev, out_scores_dev, out_counts_dev, stream,
                                      fallbacks, out_packed_dev, 0, 0, true, &refiltered);
-        if (e.ok()) {
+        if (e.ok() && async_want_ >= 0 && async_state_[async_want_] == 1) {
+            async_i8f_[async_want_] = true;   // (the bookkeeping below happens in _end, once the verdicts are in)
+            return e;
+        }
+        if (e.ok()) i8f_account(nq, refiltered);
+        return e;
+    }
+    return batched_impl(queries_dev, nq, query_len, k, allow_dev, out_rows_dev, out_scores_dev, out_counts_dev, stream,
+                        fallbacks, out_packed_dev, 0, 0, false, nullptr);
+}
+
+// What a batch's verdicts teach the index about its int8 filter.
+void VectorIndex::i8f_account(uint32_t nq, uint32_t refiltered) {
+    {
+        {
             i8f_queries += nq;
             i8f_refiltered += refiltered;
             // More than 1/8 of a batch uncertified.  What overflows on a corpus with a dense score tail (outlier dimensions, big
@@ -1297,10 +1314,7 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
                 i8f_strikes_ = 0;
             }
         }
-        return e;
     }
-    return batched_impl(queries_dev, nq, query_len, k, allow_dev, out_rows_dev, out_scores_dev, out_counts_dev, stream,
-                        fallbacks, out_packed_dev, 0, 0, false, nullptr);
 }
 
 SearchError VectorIndex::int8_filter_bound(const float* queries, uint32_t nq, uint32_t query_len, float* out_delta,
@@ -1520,6 +1534,22 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         after_enqueue_fn = nullptr;
         fn(after_enqueue_ctx);
     }
+    if (async_want_ >= 0 && !hard_batch_) {
+        // fsgpu_search_topk_batched_device_begin: everything is enqueued — the verdicts are read (and the rare uncertified query
+        // answered) by _end, behind an event instead of a stream synchronisation, so that the caller can enqueue its next search first
+        const int t = async_want_;
+        static_assert(std::is_trivially_copyable<BatchedPlan>::value, "the parked plan is copied as bytes");
+        async_plan_[t].resize(sizeof(BatchedPlan));
+        std::memcpy(async_plan_[t].data(), &p, sizeof(BatchedPlan));
+        // (a DEVICE-scope release: the default event makes the GPU write back and invalidate its caches where it is recorded — ~30 us
+        // between this search's last kernel and the next search's first, the very gap the two halves exist to close.  What the host
+        // reads behind the event are the verdicts, which the kernels write to coherent pinned memory; the outputs in device memory
+        // are read by work that is ordered behind them on the GPU, or through copies that bring their own release.)
+        if (!async_ev_[t]) FSGPU_HIP(hipEventCreateWithFlags(&async_ev_[t], hipEventDisableTiming | hipEventReleaseToDevice));
+        FSGPU_HIP(hipEventRecord(async_ev_[t], p.stream));
+        async_state_[t] = 1;
+        return ok();
+    }
     return batched_fallback(p);
 }
 
@@ -1664,15 +1694,19 @@ SearchError VectorIndex::batched_prepare(BatchedPlan& p, bool* done) {
     // synchronisation for the whole batch: [0, cap) = overflow flags, [cap, 2 cap) = candidate counts
     const uint32_t flag_cap = (nq + GMAX - 1) / GMAX * GMAX + GMAX;
     if (flag_cap > mf_flags_cap_) {
+        // (three areas: blocking calls, and one per begun search — a begun search's verdicts must survive the next call's reset)
+        if (async_state_[0] == 1 || async_state_[1] == 1)
+            return make_error(FSGPU_ERR_INVALID_CONFIG, "a begun batched search is outstanding: end it before searching with a larger batch");
         if (mf_flags_host_) (void)hipHostFree(mf_flags_host_);
         mf_flags_host_ = nullptr;
         mf_flags_cap_ = 0;
-        FSGPU_HIP(hipHostMalloc(reinterpret_cast<void**>(&mf_flags_host_), (size_t)flag_cap * 8, hipHostMallocMapped));
+        FSGPU_HIP(hipHostMalloc(reinterpret_cast<void**>(&mf_flags_host_), (size_t)flag_cap * 8 * 3, hipHostMallocMapped));
         mf_flags_cap_ = flag_cap;
     }
-    p.overflow_all = mf_flags_host_;
-    p.counts_all = mf_flags_host_ + mf_flags_cap_;
-    std::memset(mf_flags_host_, 0, (size_t)mf_flags_cap_ * 8);
+    uint32_t* flags_area = mf_flags_host_ + (size_t)((async_want_ >= 0 && !hard_batch_) ? 1 + async_want_ : 0) * mf_flags_cap_ * 2;
+    p.overflow_all = flags_area;
+    p.counts_all = flags_area + mf_flags_cap_;
+    std::memset(flags_area, 0, (size_t)mf_flags_cap_ * 8);
     p.delta = static_cast<float*>(mf_delta_.ptr);
     p.tau = static_cast<float*>(mf_tau_.ptr);
     p.unit = p.tau + QCAP;   // int8 filter: integer-score units per exact-score unit, per query
@@ -2035,8 +2069,8 @@ SearchError VectorIndex::batched_main(const BatchedPlan& p, BatchedRound& r) {
         mf_pass_parity_ += wide_groups;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profiling) {
-            FSGPU_HIP(hipEventCreate(&e0));
-            FSGPU_HIP(hipEventCreate(&e1));
+            FSGPU_HIP(hipEventCreateWithFlags(&e0, hipEventReleaseToDevice));   // (timing only: no cache write-back around the launch)
+            FSGPU_HIP(hipEventCreateWithFlags(&e1, hipEventReleaseToDevice));
             FSGPU_HIP(hipEventRecord(e0, stream));
         }
         FSGPU_HIP(launch_scan_wide(c, r.wide_qt, main_grid, stream, nullptr));
@@ -2146,13 +2180,13 @@ SearchError VectorIndex::batched_finish(BatchedPlan& p, BatchedRound& r) {
 // Stage "fallback": ONE stream synchronisation for the whole batch, then the host reads the per-query verdicts — margin / capacity
 // overflow, or fewer than k candidates — and the uncertified queries are answered by the exact kernels (the int8 filter hands a
 // larger set to the f16 filter first; the int8 two-pass to its per-query form).
-SearchError VectorIndex::batched_fallback(BatchedPlan& p) {
+SearchError VectorIndex::batched_fallback(BatchedPlan& p, bool already_waited) {
     constexpr uint32_t KC = BatchedPlan::KC;
     hipStream_t stream = p.stream;
     const uint32_t nq = p.nq, k = p.k, k_eff = p.k_eff;
     // (polling the stream with hipStreamQuery before blocking was measured: no change at 10M rows or on a 1.25M-row shard,
     // profiles/r04/step_overheads.txt — the runtime's wait is already an active one for waits this short)
-    FSGPU_HIP(hipStreamSynchronize(stream));
+    if (!already_waited) FSGPU_HIP(hipStreamSynchronize(stream));
     std::vector<uint32_t> fb;
     for (uint32_t i = 0; i < nq; ++i)
         if (p.overflow_all[i] || p.counts_all[i] < k_eff) fb.push_back(i);
@@ -2227,6 +2261,56 @@ SearchError VectorIndex::batched_fallback(BatchedPlan& p) {
                                       p.out_scores_dev, p.out_counts_dev, reinterpret_cast<u64*>(p.out_packed_dev), stream));
     }
     if (p.fallbacks) *p.fallbacks = total_fallbacks;
+    return ok();
+}
+
+// The batched search in two halves (fsgpu_search_topk_batched_device_begin / _end): begin enqueues everything and returns a ticket;
+// end waits for THAT search's last kernel (an event — not the stream, which may already hold the caller's next search), reads the
+// verdicts and answers the rare uncertified query.  Two tickets at most; queries and outputs stay the caller's until end.
+SearchError VectorIndex::search_top_k_batched_device_begin(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
+                                                           const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
+                                                           uint32_t* out_counts_dev, hipStream_t stream, uint64_t* out_packed_dev,
+                                                           int32_t* ticket) {
+    int t = -1;
+    for (int i = 0; i < 2; ++i)
+        if (async_state_[i] == 0) {
+            t = i;
+            break;
+        }
+    if (t < 0) return make_error(FSGPU_ERR_INVALID_CONFIG, "two begun batched searches are outstanding: end one first");
+    async_state_[t] = 2;   // (complete unless batched_impl parks its plan: shapes answered by the per-query kernels finish inside)
+    async_i8f_[t] = false;
+    async_nq_[t] = nq;
+    async_fb_[t] = 0;
+    async_want_ = t;
+    const SearchError e = search_top_k_batched_device(queries_dev, nq, query_len, k, allow_dev, out_rows_dev, out_scores_dev, out_counts_dev,
+                                                      stream, &async_fb_[t], out_packed_dev);
+    async_want_ = -1;
+    if (!e.ok()) {
+        async_state_[t] = 0;
+        return e;
+    }
+    *ticket = t;
+    return ok();
+}
+
+SearchError VectorIndex::search_top_k_batched_device_end(int32_t ticket, uint32_t* fallbacks) {
+    if (ticket < 0 || ticket > 1 || async_state_[ticket] == 0) return make_error(FSGPU_ERR_INVALID_CONFIG, "no such begun batched search");
+    const int t = ticket;
+    if (async_state_[t] == 1) {
+        FSGPU_HIP(hipSetDevice(device_));
+        FSGPU_HIP(hipEventSynchronize(async_ev_[t]));
+        BatchedPlan p;
+        std::memcpy(&p, async_plan_[t].data(), sizeof(BatchedPlan));
+        uint32_t refiltered = 0;
+        p.refiltered = async_i8f_[t] ? &refiltered : nullptr;   // (begin's were the addresses of its own locals)
+        p.fallbacks = &async_fb_[t];
+        async_state_[t] = 0;   // (before the fallback: it may search again, blocking, on this index)
+        FSGPU_TRY(batched_fallback(p, true));
+        if (async_i8f_[t]) i8f_account(async_nq_[t], refiltered);
+    }
+    async_state_[t] = 0;
+    if (fallbacks) *fallbacks = async_fb_[t];
     return ok();
 }
 

@@ -86,6 +86,12 @@ class VectorIndex {
                                             const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
                                             uint32_t* out_counts_dev, hipStream_t stream, uint32_t* fallbacks,
                                             uint64_t* out_packed_dev = nullptr);
+    // ... in two halves: begin enqueues the whole search and returns a ticket (0 / 1; two may be outstanding), end waits for that
+    // search alone, reads the verdicts and runs the fallbacks.  Queries and outputs stay the caller's until end.
+    SearchError search_top_k_batched_device_begin(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
+                                                  const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
+                                                  uint32_t* out_counts_dev, hipStream_t stream, uint64_t* out_packed_dev, int32_t* ticket);
+    SearchError search_top_k_batched_device_end(int32_t ticket, uint32_t* fallbacks);
     SearchError search_top_k_batched(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
                                      const uint64_t* allow, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
                                      uint32_t* fallbacks, const uint64_t* allow_resident_dev = nullptr,
@@ -210,7 +216,8 @@ class VectorIndex {
     SearchError batched_sample(const BatchedPlan& p, BatchedRound& r);
     SearchError batched_main(const BatchedPlan& p, BatchedRound& r);
     SearchError batched_finish(BatchedPlan& p, BatchedRound& r);
-    SearchError batched_fallback(BatchedPlan& p);
+    SearchError batched_fallback(BatchedPlan& p, bool already_waited = false);
+    void i8f_account(uint32_t nq, uint32_t refiltered);
     SearchError quantized_two_pass(const float* query, uint32_t query_len, uint32_t k, uint32_t multiplier, int bits,
                                    uint32_t* out_rows, float* out_scores, uint32_t* out_count, u64* approx_out_dev = nullptr,
                                    u64* exact_out_dev = nullptr);
@@ -265,6 +272,13 @@ class VectorIndex {
     uint32_t i8f_strikes_ = 0;
     uint32_t cert_skip_ = 0, cert_backoff_ = 0;   // the lone query's single-pass certificate: calls still to skip / the current back-off
     uint32_t tp_skip_ = 0, tp_backoff_ = 0;       // ... and the two-pass searches' lone-caller lane
+    // search_top_k_batched_device_begin / _end: the ticket being begun (-1: none), per ticket 0 free / 1 plan parked / 2 finished inside begin
+    int async_want_ = -1;
+    uint8_t async_state_[2] = {0, 0};
+    bool async_i8f_[2] = {false, false};
+    uint32_t async_nq_[2] = {0, 0}, async_fb_[2] = {0, 0};
+    hipEvent_t async_ev_[2] = {nullptr, nullptr};
+    std::vector<unsigned char> async_plan_[2];   // the parked BatchedPlan (plain data: pointers and sizes), defined in the .cpp
     uint32_t i8f_sample_boost_ = 1;   // 1 or 2: the second sample of the int8 filter's wide rounds grows before the filter is given up
     bool mf_norm_ready_ = false;
     int mf_shape_i8_ = 4, mf_per_cu_160_ = 1, mf_per_cu_160_i8_ = 1;

@@ -218,6 +218,20 @@ fsgpu_status fsgpu_search_topk_packed_device(fsgpu_index *idx, const float *quer
 fsgpu_status fsgpu_search_topk_batched_packed_device(fsgpu_index *idx, const float *queries_dev, uint32_t nq,
                                                      uint32_t query_len, uint32_t k, const uint64_t *allow_bitmap_dev,
                                                      uint64_t *out_packed_dev, void *hip_stream, uint32_t *out_fallbacks);
+/* The batched searches in two halves, for a caller that keeps its GPU fed: _begin enqueues the WHOLE search on hip_stream and returns
+ * a ticket without waiting (0 / 1: two may be outstanding per index); _end waits for that search's last kernel — an event, not the
+ * stream, which may already hold the caller's next search —, reads the per-query verdicts and answers the rare uncertified query with
+ * the exact kernels, exactly as the blocking forms do at their end.  Outputs as in fsgpu_search_topk_batched_device (rows / scores /
+ * counts, each may be null) plus out_packed_dev as in the packed form (may be null); the queries and every output stay the caller's
+ * until _end.  Between a _begin and its _end the index may begin ONE more search; blocking calls on the same index are allowed
+ * (they queue behind).  The per-rank loop of `bench.py --gpus N` (frankensearch_amd/sharded.py) runs on these: the ~50 us between
+ * one blocking call's wake-up and the next call's first kernel were a tenth of a 1.25M-row shard's step.  No reference counterpart
+ * (the reference's scan is synchronous CPU code, search.rs:1013-1080). */
+fsgpu_status fsgpu_search_topk_batched_device_begin(fsgpu_index *idx, const float *queries_dev, uint32_t nq, uint32_t query_len,
+                                                    uint32_t k, const uint64_t *allow_bitmap_dev, uint32_t *out_rows_dev,
+                                                    float *out_scores_dev, uint32_t *out_counts_dev, uint64_t *out_packed_dev,
+                                                    void *hip_stream, int32_t *out_ticket);
+fsgpu_status fsgpu_search_topk_batched_device_end(fsgpu_index *idx, int32_t ticket, uint32_t *out_fallbacks);
 /* One-shot hook for the NEXT batched search on this handle: `fn(ctx)` is called on the calling thread once every kernel of
  * that search is enqueued and before the call blocks on its stream (it has to read the certificate flags back).  A launcher
  * that pipelines steps uses the window to enqueue the PREVIOUS step's exchange (all-gather + merge on another stream), so

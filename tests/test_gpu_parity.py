@@ -1208,3 +1208,63 @@ def test_profiling_period_times_every_nth_batched_step(fa):
         for x, y in zip(ref[:3], got[:3]):
             assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
     idx.close()
+
+
+def test_batched_search_in_two_halves_equals_the_blocking_call(fa):
+    """fsgpu_search_topk_batched_device_begin / _end: a search begun while another is outstanding, ended in order, gives the blocking
+    call's rows, score bits and counts (plain and packed outputs, with tombstones, queries the filter cannot certify included); a
+    third begin is refused; a ticket ends once."""
+    import torch
+    from frankensearch_amd.sharded import GpuShardBackend
+    from frankensearch_amd.errors import SearchError as FsgpuError
+    rng = np.random.default_rng(9)
+    n, dim = 180_011, 384
+    slab = rand_slab(rng, n, dim)
+    live = rng.random(n) > 0.05
+    idx = fa.VectorIndex.from_slab(slab, live=live)
+    dev = torch.device("cuda", 0)
+    be = GpuShardBackend(idx, dev, batched=True)
+    qs = []
+    for j in range(5):
+        q = rng.standard_normal((512 + 7 * j, dim)).astype(np.float32)
+        q[3] = 0.0                      # an uncertifiable query: answered by the exact kernels in _end
+        q[5, 0] = np.inf
+        qs.append(torch.from_numpy(q).to(dev))
+    want = [be.search_batched(q, 10) for q in qs]
+    want_packed = [be.search_packed(q, 10) for q in qs]
+    torch.cuda.synchronize()
+    for packed in (False, True):
+        got, prev = [], None
+        for q in qs:
+            cur = be.scan_begin(q, 10, packed=packed)
+            if prev is not None:
+                be.scan_end(prev[1])
+                got.append(prev[0])
+            prev = cur
+        be.scan_end(prev[1])
+        got.append(prev[0])
+        torch.cuda.synchronize()
+        for j in range(len(qs)):
+            if packed:
+                assert torch.equal(got[j], want_packed[j]), j
+            else:
+                for x, y in zip(got[j], want[j]):
+                    assert torch.equal(x.view(torch.int32), y.view(torch.int32)), j
+    a = be.scan_begin(qs[0], 10, packed=False)
+    b = be.scan_begin(qs[1], 10, packed=False)
+    with pytest.raises(FsgpuError):
+        be.scan_begin(qs[2], 10, packed=False)
+    # a blocking call in between is allowed (it queues behind the begun ones)
+    r = be.search_batched(qs[2], 10)
+    for x, y in zip(r, want[2]):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    be.scan_end(a[1])
+    be.scan_end(b[1])
+    with pytest.raises(FsgpuError):
+        be.scan_end(a[1])
+    torch.cuda.synchronize()
+    for x, y in zip(a[0], want[0]):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    for x, y in zip(b[0], want[1]):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    idx.close()
