@@ -1304,9 +1304,9 @@ __global__ __launch_bounds__(1024) void select_groups_kernel(GroupSelectArgs arg
             t = INFINITY;      // skipped query (padding / zero / non-finite): the exact path answers it
             if (args.overflow) args.overflow[q] = 1;
         } else {
-            // the k-th best group maximum: k distinct rows score at least that (approximately) — rows, not necessarily LIVE or ALLOWED
-            // ones: with a bitmap only the exact anchor below (taken over live, allowed rows) stands
-            const u64 ak = (k <= M && !args.live && !args.allow) ? top[k - 1] : kEmpty;
+            // the k-th best group maximum: k distinct rows score at least that (approximately); the sample pass takes its maxima over
+            // live, allowed rows only (a group whose rows are all filtered out reports nothing)
+            const u64 ak = k <= M ? top[k - 1] : kEmpty;
             if (ak != kEmpty) {
                 const float ta = __uint_as_float((uint32_t)(ak >> 32)) - 2.0f * d;
                 if (ta == ta) t = ta;

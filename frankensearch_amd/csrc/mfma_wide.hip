@@ -678,12 +678,40 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
                 // (wave-uniform) a ragged round's missing tile holds the last tile again, and a pair that reaches past the last row holds
                 // copies of it: neither may stand for a group — two groups must never report the same row
                 if (tt < ntiles && g + 32u <= args.nrows) {
+                    if (args.live || args.allow) {
+                        // tombstoned / filtered-out rows do not stand for their group: the pair's 32 rows share one bitmap word (scalar
+                        // loads), a lane's 8 rows are bits fk * 4 + r and 16 + fk * 4 + r of the pair's half of it
+                        u64 mask = ~0ull;
+                        if (args.live) mask &= sload_u64(args.live + (g >> 6));
+                        if (args.allow) mask &= sload_u64(args.allow + (g >> 6));
+                        const uint32_t lb = (uint32_t)(mask >> (g & 63u)) >> (fk * 4);
+                        bool keep[2][4];
 #pragma unroll
-                    for (int nt = nt_lo; nt < nt_hi; ++nt) {
-                        const int v = lane_max(acc, nt);
-                        const bool better = v > gbest[nt];
-                        gbest[nt] = better ? v : gbest[nt];
-                        grow[nt] = better ? g : grow[nt];
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) keep[h][rr] = ((lb >> (h * 16 + rr)) & 1u) != 0;
+#pragma unroll
+                        for (int nt = nt_lo; nt < nt_hi; ++nt) {
+                            int v = -0x7fffffff - 1;
+#pragma unroll
+                            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                                for (int rr = 0; rr < 4; ++rr) {
+                                    const int x = keep[h][rr] ? acc[h][nt][rr] : -0x7fffffff - 1;
+                                    v = x > v ? x : v;
+                                }
+                            const bool better = v > gbest[nt];
+                            gbest[nt] = better ? v : gbest[nt];
+                            grow[nt] = better ? g : grow[nt];
+                        }
+                    } else {
+#pragma unroll
+                        for (int nt = nt_lo; nt < nt_hi; ++nt) {
+                            const int v = lane_max(acc, nt);
+                            const bool better = v > gbest[nt];
+                            gbest[nt] = better ? v : gbest[nt];
+                            grow[nt] = better ? g : grow[nt];
+                        }
                     }
                 }
             }

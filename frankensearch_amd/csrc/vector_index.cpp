@@ -1843,11 +1843,10 @@ SearchError VectorIndex::batched_sample(const BatchedPlan& p, BatchedRound& r) {
     // the f16 slab: tau = max(a_k - 2 delta, S_k x unit - delta) exactly as the exact-anchor step below, with no first sample to gate
     // the second, no lists, no divergent append path in the sample's loop (stage A 0.05 ms + stage B 0.20 + its selection 0.07 per
     // 1,024 queries at 10M rows became 0.1 + 0.03).
-    // (not under an allow bitmap: a group's best row is as likely filtered out as the bitmap is sparse, and the threshold anchored on
-    // what is left of 24 groups let 1.7 x the rows through the main pass at 50 % allowed — 199 k against 308 k queries/s; the
-    // thresholded lists below only ever hold allowed rows.  Tombstones are a few percent of an index: they stay on this path.)
+    // (under a tombstone / allow bitmap the sample pass takes its maxima over live, allowed rows only: with the maxima over ALL rows a
+    // group's best row was as likely filtered out as the bitmap is sparse, and the threshold anchored on what was left of 24 groups
+    // let 1.7 x the rows through the main pass at 50 % allowed — 199 k against 308 k queries/s for the thresholded stages)
     const bool group_sample = r.anchor && r.wide_qt != 0 && !skip_b && !knobs().no_wide_b && !knobs().no_group_sample && ksel <= kGroupsTaken &&
-                              a.allow == nullptr &&
                               (dim_ & 7) == 0 && dim_ <= 1024 && scan_wide_group_maxima_supported((int)dim_, r.wide_qt);
     if (group_sample) {
         const int grid_g = std::min(r.wide_grid, (int)std::max<uint32_t>(1, RB / 64 / 4));   // at least 4 sample groups per block
