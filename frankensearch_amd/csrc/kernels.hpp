@@ -201,6 +201,8 @@ struct GroupSelectArgs {
     uint32_t dim, nrows, row_base, query_stride;
     int hreduce;
     uint32_t valid_queries;    // blocks q >= this are padding slots (0 = every block's query exists)
+    uint32_t rank_only;        // != 0 (the int8 two-pass, whose pass-1 scores are the reference's own): no re-score — tau_out = the k-th
+                               // best group maximum itself (k <= 64, delta = 0: k distinct rows score at least that); slab may be null
 };
 constexpr uint32_t kGroupsTaken = 24;
 hipError_t launch_select_groups(const GroupSelectArgs& args, int nq, hipStream_t stream);

@@ -1206,11 +1206,14 @@ hipError_t launch_two_pass_merge(const u64* approx_lists, const u64* exact_lists
     return hipGetLastError();
 }
 
-// See GroupSelectArgs (kernels.hpp).  1,024 threads: one entry each -> every wave's 4 best -> wave 0 picks kGroupsTaken of the 64 ->
-// a quad per row of the taken groups (8 x 24 = 192 rows) re-scores it -> the k-th best by rank among the <= 256 exact entries.
+// See GroupSelectArgs (kernels.hpp).  1,024 threads: one entry each -> every wave's PERW best -> wave 0 picks kGroupsTaken of those
+// (RANK: the k best, k <= 64, and that is all) -> a quad per row of the taken groups (8 x 24 = 192 rows) re-scores it -> the k-th best
+// by rank among the <= 256 exact entries.  PERW winners per wave: a small slab's sample fills only a few waves' worth of entries, and
+// the rank form needs 64 of them (8 / 16: from 192 / 256 entries on the picks are complete unless one wave holds more than PERW of them).
+template <bool RANK>
 __global__ __launch_bounds__(1024) void select_groups_kernel(GroupSelectArgs args) {
-    constexpr int NT = 1024, NW = NT / 64, PERW = 4, M = (int)kGroupsTaken, NR = M * 8;
-    static_assert(NR * 4 <= NT && NR <= 256 && NW * PERW == 64, "a quad per candidate row; one winner per lane of wave 0");
+    constexpr int NT = 1024, NW = NT / 64, PERW = RANK ? 16 : 8, W0 = NW * PERW / 64, M = (int)kGroupsTaken, NR = M * 8;
+    static_assert(NR * 4 <= NT && NR <= 256 && NW * PERW % 64 == 0, "a quad per candidate row; W0 winners per lane of wave 0");
     __shared__ u64 win[NW * PERW];
     __shared__ u64 top[64];
     __shared__ u64 pool[256];
@@ -1237,15 +1240,33 @@ __global__ __launch_bounds__(1024) void select_groups_kernel(GroupSelectArgs arg
     wave_extract_topk<1>(key, e, PERW, win + wave * PERW);
     __syncthreads();
     if (wave == 0) {
-        u64 e2[1], key2[1];
-        e2[0] = win[lane];
-        key2[0] = e2[0] != kEmpty ? sortkey(e2[0]) : 0ull;
+        u64 e2[W0], key2[W0];
+#pragma unroll
+        for (int x = 0; x < W0; ++x) {
+            e2[x] = win[lane + 64 * x];
+            key2[x] = e2[x] != kEmpty ? sortkey(e2[x]) : 0ull;
+        }
         top[lane] = kEmpty;
         wave_lds_fence();
-        wave_extract_topk<1>(key2, e2, M, top);
+        wave_extract_topk<W0>(key2, e2, RANK ? k : M, top);
         wave_lds_fence();
     }
     __syncthreads();
+    if constexpr (RANK) {
+        if (tid == 0) {
+            float t = -INFINITY;   // fewer than k groups: everything is a candidate
+            if (d < 0.f || !real_query) {
+                t = INFINITY;
+                if (args.overflow) args.overflow[q] = 1;
+            } else if (k <= 64 && top[k - 1] != kEmpty) {
+                const float ta = __uint_as_float((uint32_t)(top[k - 1] >> 32)) - 2.0f * d;
+                if (ta == ta) t = ta;
+            }
+            args.tau_out[q] = t;
+            if (args.spill_reset) args.spill_reset[(size_t)q * kMfmaSpillCountStride] = 0u;
+        }
+        return;
+    }
     // exact-order re-score (dot_product_f16_bytes_f32 order, as gather_dot_kernel and select_kernel's finish): a quad per row
     {
         const int c = tid >> 2, a = tid & 3;
@@ -1325,10 +1346,11 @@ __global__ __launch_bounds__(1024) void select_groups_kernel(GroupSelectArgs arg
 }
 
 hipError_t launch_select_groups(const GroupSelectArgs& args, int nq, hipStream_t stream) {
-    if (args.k < 1 || args.k > kGroupsTaken || args.nentries == 0 || args.nentries > 1024 || (args.dim & 7) || args.dim > kSelQueryLds ||
-        !args.delta || !args.anchor_unit || !args.tau_out)
+    if (args.k < 1 || args.nentries == 0 || args.nentries > 1024 || !args.delta || !args.tau_out) return hipErrorInvalidValue;
+    if (args.rank_only ? args.k > 64 : (args.k > kGroupsTaken || (args.dim & 7) || args.dim > kSelQueryLds || !args.anchor_unit || !args.slab))
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(select_groups_kernel, dim3(nq), dim3(1024), 0, stream, args);
+    if (args.rank_only) hipLaunchKernelGGL(select_groups_kernel<true>, dim3(nq), dim3(1024), 0, stream, args);
+    else hipLaunchKernelGGL(select_groups_kernel<false>, dim3(nq), dim3(1024), 0, stream, args);
     return hipGetLastError();
 }
 

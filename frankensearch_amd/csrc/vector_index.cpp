@@ -1846,11 +1846,15 @@ SearchError VectorIndex::batched_sample(const BatchedPlan& p, BatchedRound& r) {
     // (under a tombstone / allow bitmap the sample pass takes its maxima over live, allowed rows only: with the maxima over ALL rows a
     // group's best row was as likely filtered out as the bitmap is sparse, and the threshold anchored on what was left of 24 groups
     // let 1.7 x the rows through the main pass at 50 % allowed — 199 k against 308 k queries/s for the thresholded stages)
-    const bool group_sample = r.anchor && r.wide_qt != 0 && !skip_b && !knobs().no_wide_b && !knobs().no_group_sample && ksel <= kGroupsTaken &&
-                              (dim_ & 7) == 0 && dim_ <= 1024 && scan_wide_group_maxima_supported((int)dim_, r.wide_qt);
+    // (the batched int8 / 4-bit two-pass takes the same pass: its pass-1 scores are the reference's own, so the k x multiplier-th best
+    // group maximum IS a valid threshold — no re-score, ranks up to 64)
+    const bool rank_groups = i8 && !i8f && ksel <= 64;
+    const bool group_sample = (r.anchor ? ksel <= kGroupsTaken : rank_groups) && r.wide_qt != 0 && !skip_b && !knobs().no_wide_b &&
+                              !knobs().no_group_sample && (dim_ & 7) == 0 && dim_ <= 1024 && scan_wide_group_maxima_supported((int)dim_, r.wide_qt);
     if (group_sample) {
         const int grid_g = std::min(r.wide_grid, (int)std::max<uint32_t>(1, RB / 64 / 4));   // at least 4 sample groups per block
-        if (grid_g * 4 <= 1024) {
+        // (enough groups for the picks: the rank form needs ksel of them — and not all from a wave or two of the selection)
+        if (grid_g * 4 <= 1024 && (uint32_t)grid_g * 4 >= (r.anchor ? 96u : 4u * ksel)) {
             MfmaScanArgs c = a;
             c.dense = nullptr;
             c.stage = 3;
@@ -1885,6 +1889,7 @@ SearchError VectorIndex::batched_sample(const BatchedPlan& p, BatchedRound& r) {
             g.query_stride = p.qs;
             g.hreduce = hreduce;
             g.valid_queries = r.ng;
+            g.rank_only = r.anchor ? 0u : 1u;
             FSGPU_HIP(launch_select_groups(g, (int)QP, stream));
             a.dense = nullptr;
             a.stage = 1;
@@ -1895,7 +1900,7 @@ SearchError VectorIndex::batched_sample(const BatchedPlan& p, BatchedRound& r) {
             sb = SelectArgs{};
             sb.lists = r.cand;
             sb.k = ksel;
-            sb.take_topk = 0;
+            sb.take_topk = (i8 && !i8f) ? 1 : 0;
             sb.delta = p.delta;
             sb.overflow = r.overflow;
             sb.spill = p.spill;
