@@ -2653,13 +2653,8 @@ SearchError VectorIndex::two_pass_lone_certified(const float* query, const unsig
     std::memcpy(io + o_qi, qi, qbytes);
     const float* q_pin = reinterpret_cast<const float*>(io);
     float* delta_pin = reinterpret_cast<float*>(io + o_flags);   // the pass-1 scores are the reference's own: no margin
-    float* tau_pin = delta_pin + 1;
     float* cut_pin = delta_pin + 2;
-    uint32_t* ncand_pin = reinterpret_cast<uint32_t*>(delta_pin + 3);
-    uint32_t* overflow_pin = reinterpret_cast<uint32_t*>(delta_pin + 4);
     *delta_pin = 0.f;
-    *overflow_pin = 0;
-    *ncand_pin = 0;
     // (every wave of the scan reads the whole quantised query: from device memory, not over the bus; the finish's one block reads
     // the f32 query where it lies)
     FSGPU_TRY(ws_i8_query_.reserve(qbytes));
@@ -2686,40 +2681,62 @@ SearchError VectorIndex::two_pass_lone_certified(const float* query, const unsig
         profiled_rows_ += nrows_;
     }
     FSGPU_HIP(launch_list_cut(a.partial, (uint32_t)grid, LK, cut_pin, stream_));
-    SelectArgs f{};
-    f.lists = a.partial;
-    f.q_stride = (uint64_t)grid * LK;
-    f.l_stride = LK;
-    f.nlists = (uint32_t)grid;
-    f.list_len = LK;
-    f.k = cc;
-    f.take_topk = 1;
-    f.delta = delta_pin;
-    f.tau_out = tau_pin;
-    f.cand_counts = ncand_pin;
-    f.overflow = overflow_pin;
-    f.slab = slab_dev_;
-    f.queries = q_pin;
-    f.dim = dim_;
-    f.nrows = (uint32_t)nrows_;
-    f.row_base = (uint32_t)row_base_;
-    f.hreduce = hreduce;
-    f.k_out = k_eff;
-    f.out_stride = k;
-    f.out_rows = reinterpret_cast<uint32_t*>(io + o_out);
-    f.out_scores = reinterpret_cast<float*>(io + o_out + (size_t)k * 4);
-    f.out_counts = reinterpret_cast<uint32_t*>(io + o_out + (size_t)k * 8);
-    FSGPU_HIP(launch_select(f, 1, stream_));
+    // the cc best pass-1 entries of the 8,192 kept (ONE pass of the merge; the selection's sorted finish took 0.10 ms here), their exact
+    // scores, the k best of those — the general sequence's kernels over lists a third as long
+    FSGPU_TRY(ws_cand_packed_.reserve((size_t)cc * 8));
+    FSGPU_TRY(ws_cand_rows_.reserve((size_t)cc * 4));
+    FSGPU_TRY(ws_cand_scores_.reserve((size_t)cc * 4));
+    const size_t o_approx = (o_flags + 64 + 255) & ~(size_t)255;
+    if (o_approx + (size_t)cc * 8 > kPinnedIoBytes) return ok();
+    u64* approx_pin = reinterpret_cast<u64*>(io + o_approx);
+    uint32_t* cand_rows = static_cast<uint32_t*>(ws_cand_rows_.ptr);
+    float* cand_scores = static_cast<float*>(ws_cand_scores_.ptr);
+    u64* cand_packed = static_cast<u64*>(ws_cand_packed_.ptr);
+    MergeArgs m;
+    m.lists = a.partial;
+    m.q_stride = (uint64_t)grid * LK;
+    m.l_stride = LK;
+    m.nlists = (uint32_t)grid;
+    m.list_len = LK;
+    m.k = cc;
+    m.out_stride = cc;
+    m.out_rows = cand_rows;
+    m.out_scores = nullptr;
+    m.out_counts = nullptr;
+    m.out_packed = approx_pin;   // best first: the certificate reads the last one
+    FSGPU_HIP(launch_merge_topk(m, 1, stream_));
+    FSGPU_HIP(hipMemsetAsync(cand_scores, 0, (size_t)cc * 4, stream_));
+    FSGPU_HIP(launch_gather_dot(a, cand_rows, cc, cand_scores, stream_));
+    FSGPU_HIP(launch_pack_hits(cand_rows, cand_scores, cc, cand_packed, stream_));
+    MergeArgs m2;
+    m2.lists = cand_packed;
+    m2.q_stride = cc;
+    m2.l_stride = cc;
+    m2.nlists = 1;
+    m2.list_len = cc;
+    m2.k = k_eff;
+    m2.out_stride = k;
+    m2.out_rows = reinterpret_cast<uint32_t*>(io + o_out);
+    m2.out_scores = reinterpret_cast<float*>(io + o_out + (size_t)k * 4);
+    m2.out_counts = reinterpret_cast<uint32_t*>(io + o_out + (size_t)k * 8);
+    m2.out_packed = nullptr;
+    m2.lists_sorted = 0;  // candidates arrive in pass-1 order
+    FSGPU_HIP(launch_merge_topk(m2, 1, stream_));
     FSGPU_HIP(hipStreamSynchronize(stream_));
-    const float tau = *tau_pin, cut = *cut_pin;   // tau: the cc-th best pass-1 score (delta = 0)
-    if (*overflow_pin != 0) return ok();
+    const float cut = *cut_pin;
     // complete when no list was full (nothing dropped) or the cc-th best entry outranks everything dropped — STRICTLY: a dropped row
     // with the same integer score may have the smaller row id
-    const bool complete = cut == -INFINITY || cut < tau;
+    bool complete = cut == -INFINITY;
+    if (!complete && approx_pin[cc - 1] != ~0ull) {
+        float tau;
+        const uint32_t tb = (uint32_t)(approx_pin[cc - 1] >> 32);
+        std::memcpy(&tau, &tb, 4);
+        complete = cut < tau;
+    }
     if (!complete) return ok();
-    std::memcpy(rows, f.out_rows, (size_t)k * 4);
-    std::memcpy(scores, f.out_scores, (size_t)k * 4);
-    *count = *f.out_counts;
+    std::memcpy(rows, m2.out_rows, (size_t)k * 4);
+    std::memcpy(scores, m2.out_scores, (size_t)k * 4);
+    *count = *m2.out_counts;
     *answered = true;
     return ok();
 }
@@ -2793,7 +2810,7 @@ SearchError VectorIndex::quantized_two_pass(const float* query, uint32_t query_l
     // above everything a block can have dropped.  Otherwise (and for a row-sharded index's shards, which hand the candidate pairs on)
     // the general sequence below answers; a failed certificate backs off like the exact search's (certified_i8_lone_query).
     // (worth it from 65 candidates on, where the general sequence's block lists no longer fit the one-pass merge — the two-tier
-    // host's fast tier fetches 30 x 3: 10M x 256 p50 0.59 -> 0.55 ms; below that both sequences measured the same)
+    // host's fast tier fetches 30 x 3: 10M x 256 p50 0.59 -> 0.50 ms; below that both sequences measured the same)
     if (!approx_out_dev && !exact_out_dev && cc > 64 && cc <= kSelectMaxK && k_eff <= 64 && k <= 64 && (dim_ & 7) == 0 && nrows_ >= 4096 &&
         !(row_stride_ && row_stride_ != dim_ * 2) && variant == 0) {
         if (tp_skip_ > 0) {
