@@ -165,11 +165,7 @@ __device__ __forceinline__ void flag_wait(uint32_t lds_addr, uint32_t target) {
 //              waves therefore drift up to about a tile apart instead of meeting at every tile: a wave held up in the append path
 //              (a scalar bitmap load, an LDS atomic, a store — ~5 events per tile at 10M rows, ~40 on a 1.25M-row shard) no longer
 //              stops the other seven, and the two waves of a SIMD no longer stop together.
-//   kOptFair   (with kOptSplit; lab) the two waves of a SIMD keep pace: a wave publishes how many sub-tile pairs it has done (one LDS word per
-//              wave), reads its partner's (wave ^ 4) count a phase ahead of using it, and raises its priority (s_setprio) while it is
-//              BEHIND — under the oldest-first arbiter the older wave otherwise runs its tile alone and the younger one after it, each
-//              with nobody to fill its own bubbles.
-constexpr int kOptNegTau = 2, kOptSaddr = 4, kOptSplit = 8, kOptBig = 16, kOptFlags = 32, kOptFair = 512;
+constexpr int kOptNegTau = 2, kOptSaddr = 4, kOptSplit = 8, kOptBig = 16, kOptFlags = 32;
 
 // k-steps per chunk of the chunk loop (fewer where the resident queries leave fewer registers for the fragment double buffer)
 constexpr int wide_chunk_ksteps(int KS, int QT) {
@@ -301,7 +297,6 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     const int slots = (int)args.slots;
     for (int i = tid; i < NQ; i += NT) lcnt[i] = 0;
     if (FLAGS && tid < 8) lcnt[NQ + tid] = 0;
-    if (tid < 8) lcnt[NQ + 8 + tid] = 0;   // kOptFair: pairs done, per wave
 
     // this wave's queries: B fragments for the whole dimension, resident in registers
     const int q0 = wave * QT * 16;
@@ -667,9 +662,6 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
         uint32_t slot = 0, slot_prev = NSLOT - 1;
         const unsigned char* cur = slot_base(0);
         uint32_t tB = ntiles;                   // tile of the pair whose second-half scores are still to be tested (none yet)
-        constexpr bool FAIR = (OPT & kOptFair) != 0;
-        volatile int* fair_slot = lcnt + NQ + 8;
-        [[maybe_unused]] int fair_mine = 0, fair_seen = 0;
         // GMAX: the lane's best score per query tile so far and the first row of the sub-tile pair it was seen in
         [[maybe_unused]] int gbest[QT];
         [[maybe_unused]] uint32_t grow[QT];
@@ -731,14 +723,6 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 constexpr int TK = KS >= 4 ? 2 : 0;   // the k-step after which a phase carries the other half's test
-                if constexpr (FAIR) {
-                    // (the partner's count was read at the start of the previous pair's second phase: behind it -> ahead in the queue)
-                    ++fair_mine;
-                    const int partner = __builtin_amdgcn_readfirstlane(fair_seen);
-                    if (partner > fair_mine) __builtin_amdgcn_s_setprio(3);
-                    else __builtin_amdgcn_s_setprio(0);
-                    fair_slot[wave] = fair_mine;
-                }
                 // ---- phase 1: query tiles [0, QA); the previous pair's tiles [QA, QT) are tested in its shadow
                 init_acc(0, QA);
                 bool anyB = false;
@@ -783,7 +767,6 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
                 // [0, QA) are tested in its shadow
                 init_acc(QA, QT);
                 bool anyA = false;
-                if constexpr (FAIR) fair_seen = fair_slot[wave ^ 4];
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) {
                     mfma_step(kk, QA, QT);
