@@ -1210,10 +1210,12 @@ hipError_t launch_two_pass_merge(const u64* approx_lists, const u64* exact_lists
 // (RANK: the k best, k <= 64, and that is all) -> a quad per row of the taken groups (8 x 24 = 192 rows) re-scores it -> the k-th best
 // by rank among the <= 256 exact entries.  PERW winners per wave: a small slab's sample fills only a few waves' worth of entries, and
 // the rank form needs 64 of them (8 / 16: from 192 / 256 entries on the picks are complete unless one wave holds more than PERW of them).
+// 512 threads (two entries each): four blocks per CU, i.e. all of a 1,024-query round resident at once — the kernel is a chain of
+// dependent round trips per block, and with 1,024-thread blocks a round took two waves of blocks.
 template <bool RANK>
-__global__ __launch_bounds__(1024) void select_groups_kernel(GroupSelectArgs args) {
-    constexpr int NT = 1024, NW = NT / 64, PERW = RANK ? 16 : 8, W0 = NW * PERW / 64, M = (int)kGroupsTaken, NR = M * 8;
-    static_assert(NR * 4 <= NT && NR <= 256 && NW * PERW % 64 == 0, "a quad per candidate row; W0 winners per lane of wave 0");
+__global__ __launch_bounds__(512) void select_groups_kernel(GroupSelectArgs args) {
+    constexpr int NT = 512, NW = NT / 64, PERT = 1024 / NT, PERW = RANK ? 16 : 8, W0 = NW * PERW / 64, M = (int)kGroupsTaken, NR = M * 8;
+    static_assert(NR <= 256 && NR <= NT && NW * PERW % 64 == 0 && W0 >= 1, "W0 winners per lane of wave 0; the rank loop runs on NR threads");
     __shared__ u64 win[NW * PERW];
     __shared__ u64 top[64];
     __shared__ u64 pool[256];
@@ -1230,14 +1232,18 @@ __global__ __launch_bounds__(1024) void select_groups_kernel(GroupSelectArgs arg
         const float* qsrc = args.queries + (size_t)q * (args.query_stride ? args.query_stride : args.dim);
         for (int i = tid; i < dim && i < kSelQueryLds; i += NT) s_q[i] = qsrc[i];
     }
-    u64 e[1], key[1];
-    e[0] = (uint32_t)tid < args.nentries ? args.groups[(size_t)q * args.nentries + tid] : kEmpty;
-    key[0] = e[0] != kEmpty ? sortkey(e[0]) : 0ull;
+    u64 e[PERT], key[PERT];
+#pragma unroll
+    for (int x = 0; x < PERT; ++x) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)x * NT;
+        e[x] = i < args.nentries ? args.groups[(size_t)q * args.nentries + i] : kEmpty;
+        key[x] = e[x] != kEmpty ? sortkey(e[x]) : 0ull;
+    }
     if (lane < PERW) win[wave * PERW + lane] = kEmpty;
     if (tid < 256) pool[tid] = kEmpty;
     if (tid == 0) s_kth = 0ull;
     wave_lds_fence();
-    wave_extract_topk<1>(key, e, PERW, win + wave * PERW);
+    wave_extract_topk<PERT>(key, e, PERW, win + wave * PERW);
     __syncthreads();
     if (wave == 0) {
         u64 e2[W0], key2[W0];
@@ -1268,8 +1274,8 @@ __global__ __launch_bounds__(1024) void select_groups_kernel(GroupSelectArgs arg
         return;
     }
     // exact-order re-score (dot_product_f16_bytes_f32 order, as gather_dot_kernel and select_kernel's finish): a quad per row
-    {
-        const int c = tid >> 2, a = tid & 3;
+    for (int c0 = 0; c0 < NR; c0 += NT / 4) {   // (block-uniform: NR / (NT / 4) sweeps of a quad per row)
+        const int c = c0 + (tid >> 2), a = tid & 3;
         const int gi = c >> 3, pos = c & 7;
         const u64 ge = c < NR ? top[gi] : kEmpty;
         const uint32_t grow = (uint32_t)ge + (uint32_t)((pos >> 2) * 16 + (pos & 3));
@@ -1349,8 +1355,8 @@ hipError_t launch_select_groups(const GroupSelectArgs& args, int nq, hipStream_t
     if (args.k < 1 || args.nentries == 0 || args.nentries > 1024 || !args.delta || !args.tau_out) return hipErrorInvalidValue;
     if (args.rank_only ? args.k > 64 : (args.k > kGroupsTaken || (args.dim & 7) || args.dim > kSelQueryLds || !args.anchor_unit || !args.slab))
         return hipErrorInvalidValue;
-    if (args.rank_only) hipLaunchKernelGGL(select_groups_kernel<true>, dim3(nq), dim3(1024), 0, stream, args);
-    else hipLaunchKernelGGL(select_groups_kernel<false>, dim3(nq), dim3(1024), 0, stream, args);
+    if (args.rank_only) hipLaunchKernelGGL(select_groups_kernel<true>, dim3(nq), dim3(512), 0, stream, args);
+    else hipLaunchKernelGGL(select_groups_kernel<false>, dim3(nq), dim3(512), 0, stream, args);
     return hipGetLastError();
 }
 
