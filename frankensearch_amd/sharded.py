@@ -219,7 +219,7 @@ class ShardedVectorIndex:
         are enqueued on the side stream from inside the scan call of step i, in the window after its kernels are enqueued and
         before it blocks on its stream — the exchange's GPU work AND its host work run under the scan.  Returns the last step's
         (rows, scores, counts) — or every step's with keep_all — complete when this returns."""
-        if getattr(self.backend, "supports_pipelined_scans", False) and self.overlap:
+        if getattr(self.backend, "supports_pipelined_scans", False):
             return self._search_steps_pipelined(batch_of, first, n, k, after_scan, keep_all)
         outs, pending, prev, prev_event = [], None, None, None
         state = {"pending": None}
@@ -272,7 +272,7 @@ class ShardedVectorIndex:
             fb = be.scan_end(ticket)
             if after_scan is not None:
                 after_scan()
-            if fb:                     # its fallback work went to the stream only now: the exchange must wait for that too
+            if fb and local.is_cuda:   # its fallback work went to the stream only now: the exchange must wait for that too
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(local.device))
             return self.search_end(local, k, scan_event=ev)
@@ -284,8 +284,10 @@ class ShardedVectorIndex:
 
         for i in range(first, first + n):
             local, ticket = be.scan_begin(batch_of(i), k, packed=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(local.device))
+            ev = None
+            if local.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(local.device))
             if prev is not None:
                 nxt = finish(prev)     # ends step i - 1 (the GPU is already on step i), enqueues its exchange
                 if exch is not None:

@@ -63,6 +63,28 @@ class OracleShardBackend:
         return torch.from_numpy(rows.view(np.int32)), torch.from_numpy(scores), torch.from_numpy(counts)
 
 
+class PipelinedOracleBackend(OracleShardBackend):
+    """... with the scan in two halves (GpuShardBackend.scan_begin / scan_end): ShardedVectorIndex.search_steps then enqueues step
+    i + 1 before it ends step i — here the 'scan' simply happens in scan_begin, and every third one reports a fallback."""
+    supports_pipelined_scans = True
+
+    def __init__(self, slab, row_base):
+        super().__init__(slab, row_base)
+        self.begun, self.ended, self.last_fallbacks = 0, [], 0
+
+    def scan_begin(self, queries, k, packed):
+        assert packed
+        self.begun += 1
+        assert self.begun - len(self.ended) <= 2, "more than two scans outstanding"
+        return self.search_packed(queries, k), (self.begun, queries)
+
+    def scan_end(self, ticket):
+        assert ticket[0] == len(self.ended) + 1, "scans are ended in the order they were begun"
+        self.ended.append(ticket[0])
+        self.last_fallbacks = 1 if ticket[0] % 3 == 0 else 0
+        return self.last_fallbacks
+
+
 def _worker(rank, world, port, n, dim, k, ret):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -83,6 +105,15 @@ def _worker(rank, world, port, n, dim, k, ret):
     # ... and the launcher's step loop (a backend without the after-enqueue window: the loop does the exchange itself)
     for r3, s3, c3 in idx.search_steps(lambda i: torch.from_numpy(queries), 0, 3, k, keep_all=True):
         assert torch.equal(r3, rows) and torch.equal(c3, counts) and torch.equal(s3.view(torch.int32), scores.view(torch.int32))
+    # ... and the same loop over a backend whose scan comes in two halves (what the GPU ranks run)
+    pidx = ShardedVectorIndex(PipelinedOracleBackend(slab[lo:hi], lo))
+    seen = []
+    outs = pidx.search_steps(lambda i: torch.from_numpy(queries), 0, 5, k, after_scan=lambda: seen.append(pidx.backend.last_fallbacks), keep_all=True)
+    assert len(outs) == 5 and pidx.backend.ended == [1, 2, 3, 4, 5] and seen == [0, 0, 1, 0, 0]
+    for r4, s4, c4 in outs:
+        assert torch.equal(r4, rows) and torch.equal(c4, counts) and torch.equal(s4.view(torch.int32), scores.view(torch.int32))
+    last = pidx.search_steps(lambda i: torch.from_numpy(queries), 5, 1, k)
+    assert torch.equal(last[0], rows) and pidx.backend.ended[-1] == 6
     if rank == 0:
         ret["rows"] = rows.numpy().view(np.uint32).copy()
         ret["scores"] = scores.numpy().copy()
