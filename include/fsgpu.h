@@ -606,6 +606,7 @@ fsgpu_status fsgpu_bert_set_coalescing(fsgpu_bert *m, uint32_t max_batch, uint32
  * FSGPU_WIDE_DBG (options and timing skeletons of the wide main pass — skeleton answers are NOT valid), FSGPU_USE_160,
  * FSGPU_MFMA_SHAPE{,_I8}, FSGPU_RA, FSGPU_RB, FSGPU_ROUND, FSGPU_NO_SKIP_B, FSGPU_NO_REVERSE, FSGPU_I8F_GROWTH, FSGPU_WIDE_MAX,
  * FSGPU_SLOTS_B, FSGPU_SLOTS_MAIN, FSGPU_NO_WIDE_B, FSGPU_NO_ANCHOR, FSGPU_NO_BIG_POOL, FSGPU_NO_HEUR_B, FSGPU_HEUR_RANK,
+ * FSGPU_RB_PCT, FSGPU_NO_GROUP_SAMPLE, FSGPU_WIDE_OPT, FSGPU_WIDE_DBG,
  * FSGPU_GRID_BLOCKS, FSGPU_I8_PER_CU, FSGPU_SELECT_SORT_ABOVE, FSGPU_BERT_GEMM_SHAPE, FSGPU_BERT_ATTN, FSGPU_BERT_NO_FUSED_LN,
  * FSGPU_BERT_NO_QUERY_PATH, FSGPU_BERT_GEMM_V1, FSGPU_BERT_SPLIT_FFN, FSGPU_BERT_SPLIT_AO, FSGPU_BERT_PACKED_MIN_TOKENS,
  * FSGPU_BERT_EMBED_V1. */
