@@ -27,6 +27,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <string>
+#include <vector>
 #include <type_traits>
 
 #include "scan_common.hpp"
@@ -184,7 +185,7 @@ constexpr bool wide_split_ok(int ROWB, int EB, int QT, int OPT, int DBG) {
 }
 // 128-row tiles in a three-slot ring: the main pass of a shape that runs the split loop
 constexpr bool wide_big_ok(int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG) {
-    return (OPT & kOptBig) != 0 && wide_split_ok(ROWB, EB, QT, OPT, DBG) && (DBG == 0 || DBG >= 16) && NSLOT == 3;
+    return (OPT & kOptBig) != 0 && wide_split_ok(ROWB, EB, QT, OPT, DBG) && (DBG == 0 || DBG == 8 || DBG >= 16) && NSLOT == 3;
 }   // (bit 1 was a barrier-phase shift between the SIMD twins: measured null, removed)
 // one 64-bit word through the scalar cache (wave-uniform address): counted by lgkmcnt, not by the vmcnt the DMA ring lives on
 __device__ __forceinline__ u64 sload_u64(const u64* pv) {
@@ -266,6 +267,11 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     constexpr bool SK_NO_DMA = DBG == 2 || (SK && (DBG & 1)), SK_NO_SYNC = SK && (DBG & 2), SK_NO_READS = SK && (DBG & 4), SK_NO_TEST = SK && (DBG & 8);
     constexpr bool AK = DBG >= 32;
     [[maybe_unused]] constexpr bool AK_NO_STORE = AK && (DBG & 1), AK_NO_ATOMIC = AK && (DBG & 2), AK_NO_BODY = AK && (DBG & 4);
+    // DBG 8 (experiments builds, scripts/r04/wide_stamps.sh): the real kernel with s_memtime stamps — per wave the cycles of the whole
+    // tile loop, the cycles between arriving at a tile's wait + barrier and leaving it, the cycles inside the append path and its
+    // entries; written to args.dense as [block][wave][4] 64-bit words.  Answers stay valid; the stamps cost a few percent.
+    constexpr bool STAMPS = DBG == 8;
+    [[maybe_unused]] unsigned long long st_loop = 0, st_bar = 0;
     static_assert(!SPLIT || (NEGTAU && RS >= 4), "the split loop runs on neg-tau accumulators over tiles of two pairs or more");
     // -ceil(tau) kept in all four registers of an accumulator (the first MFMA of a pair takes it as C: no initialising moves) where
     // 4 x QT more registers fit; else one register per query tile and four moves per accumulator (in the MFMAs' shadow when SPLIT)
@@ -297,6 +303,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     const int slots = (int)args.slots;
     for (int i = tid; i < NQ; i += NT) lcnt[i] = 0;
     if (FLAGS && tid < 8) lcnt[NQ + tid] = 0;
+    if (STAMPS && tid < 32) lcnt[NQ + 16 + tid] = 0;
 
     // this wave's queries: B fragments for the whole dimension, resident in registers
     const int q0 = wave * QT * 16;
@@ -522,6 +529,8 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
         }
 #endif
         if (t >= ntiles) return;   // (wave-uniform) a ragged round: the slot holds the last tile again
+        [[maybe_unused]] unsigned long long st_in = 0;
+        if constexpr (STAMPS) st_in = __builtin_readcyclecounter();
         // C layout: column (query) = lane & 15, row = (lane >> 4) * 4 + reg
         const uint32_t pair_row0 = tile_row0(t) + sp * 16;   // wave-uniform, a multiple of 32: the pair's 32 rows share one bitmap word
         const uint32_t row00 = pair_row0 + fk * 4;
@@ -568,6 +577,14 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (passes(nt, acc[h][nt][r])) append(q0 + nt * 16 + frow, score_of(nt, acc[h][nt][r]), row00 + h * 16 + r, mask);
+            }
+        }
+        if constexpr (STAMPS) {   // (the lowest active lane books the excursion for its wave)
+            const unsigned long long dt = __builtin_readcyclecounter() - st_in;
+            if (lane == __builtin_ctzll(__ballot(true))) {
+                unsigned long long* st = reinterpret_cast<unsigned long long*>(lcnt + NQ + 16) + wave * 2;
+                atomicAdd(st, dt);
+                atomicAdd(st + 1, 1ull);
             }
         }
     };
@@ -716,6 +733,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
                 }
             }
         };
+        if constexpr (STAMPS) st_loop = __builtin_readcyclecounter();
         while (cc.n < rounds) {
             const uint32_t slot_next = slot + 1 == NSLOT ? 0 : slot + 1;
             const unsigned char* nxt = slot_base(slot_next);
@@ -738,6 +756,8 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
                         // The tile's barrier.  Tile n+1: this wave's DMAs have landed (tiles n+2 .. n+NSLOT-2 may still be in
                         // flight), then everyone's; every wave is also past its last read of tile n-1 (this tile's first pair was
                         // read behind them and has been waited for), whose slot takes tile n+NSLOT-1.
+                        [[maybe_unused]] unsigned long long st_a = 0;
+                        if constexpr (STAMPS) st_a = __builtin_readcyclecounter();
                         wait_vmcnt<PW*(NSLOT - 3)>();
                         if constexpr (FLAGS) {
                             flag_post(flags + slot_next * 4, lane);   // this wave's share of tile n+1 is in LDS (posted a tile early)
@@ -745,6 +765,7 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
                             __builtin_amdgcn_s_barrier();
                             asm volatile("" ::: "memory");
                         }
+                        if constexpr (STAMPS) st_bar += __builtin_readcyclecounter() - st_a;
                     }
                     // the refill of tile n-1's slot: one group of DMA instructions per pair, behind a few MFMAs of its phase 1
                     // (all of them behind the first pair's first MFMAs was measured: 1.43 instead of 1.36 ms — the DMA's LDS writes
@@ -868,6 +889,16 @@ __global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
     }
     wait_vmcnt<0>();  // no DMA may outlive the block's LDS allocation
     __syncthreads();
+    if constexpr (STAMPS) {
+        if (args.dense && lane == 0) {
+            const unsigned long long* st = reinterpret_cast<const unsigned long long*>(lcnt + NQ + 16) + wave * 2;
+            unsigned long long* out = reinterpret_cast<unsigned long long*>(args.dense) + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * WPB + wave) * 4;
+            out[0] = __builtin_readcyclecounter() - st_loop;
+            out[1] = st_bar;
+            out[2] = st[0];
+            out[3] = st[1];
+        }
+    }
     if (args.cand_count) {
         // the lists' lengths instead of padding: the selection reads only what was appended (2 KB per block instead of
         // NQ x slots x 8 bytes — 128 KB at 512 queries x 32 slots)
@@ -909,7 +940,7 @@ hipError_t launch_wide_t(const MfmaScanArgs& args, int grid, hipStream_t stream,
     constexpr bool BIG = wide_big_ok(ROWB, EB, QT, NSLOT, OPT, DBG);
     constexpr int TR = BIG ? 128 : ROWB >= 512 ? 32 : 64;
     constexpr size_t ring = (size_t)NSLOT * TR * ROWB;
-    const size_t lds = ring + (size_t)QT * 128 * 4 + 64;   // the row-tile ring + one append counter per query + the ring's arrive / wait counters
+    const size_t lds = ring + (size_t)QT * 128 * 4 + 64 + (DBG == 8 ? 256 : 0);   // the row-tile ring + one append counter per query + the ring's arrive / wait counters
     auto kern = scan_wide_kernel<ROWB, EB, QT, NSLOT, OPT, DBG>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -979,7 +1010,42 @@ hipError_t launch_wide_d(const MfmaScanArgs& args, int grid, hipStream_t stream,
                         else return launch_wide_t<384, EB, QT, 6, 14, MODE>(args, grid, stream, occupancy);
                     default: break;
                 }
-                if constexpr (MODE == 0) {   // skeletons of the shipped main pass (scripts/r04/skeletons.sh, skeleton_clocks.sh)
+                if constexpr (MODE == 0) {   // the shipped main pass with s_memtime stamps (scripts/r04/wide_stamps.sh): one line per launch
+                    if (dbg == 8 && !occupancy) {
+                        static unsigned long long* buf = nullptr;
+                        constexpr size_t kWords = 2 * 1024 * 8 * 4;   // [group][block][wave][4]
+                        if (!buf && hipMalloc(reinterpret_cast<void**>(&buf), kWords * 8) != hipSuccess) return hipErrorOutOfMemory;
+                        MfmaScanArgs a2 = args;
+                        a2.dense = reinterpret_cast<u64*>(buf);
+                        (void)hipMemsetAsync(buf, 0, kWords * 8, stream);
+                        const hipError_t e = launch_wide_t<384, EB, QT, 3, O, 8>(a2, grid, stream, nullptr);
+                        if (e != hipSuccess) return e;
+                        (void)hipStreamSynchronize(stream);
+                        const size_t nwaves = (size_t)grid * (args.groups ? args.groups : 1) * 8;
+                        std::vector<unsigned long long> h(nwaves * 4);
+                        (void)hipMemcpy(h.data(), buf, h.size() * 8, hipMemcpyDeviceToHost);
+                        double loop = 0, bar[2] = {0, 0}, slow[2] = {0, 0}, ent[2] = {0, 0}, lp[2] = {0, 0};
+                        int hist[10] = {0};
+                        for (size_t w = 0; w < nwaves; ++w) {
+                            const double L = (double)h[w * 4], B = (double)h[w * 4 + 1], S = (double)h[w * 4 + 2], E = (double)h[w * 4 + 3];
+                            if (L <= 0) continue;
+                            const int half = (w & 7) >= 4;
+                            loop += L;
+                            lp[half] += L;
+                            bar[half] += B;
+                            slow[half] += S;
+                            ent[half] += E;
+                            int b = (int)(10.0 * B / L);
+                            ++hist[b < 0 ? 0 : b > 9 ? 9 : b];
+                        }
+                        std::fprintf(stderr, "[wide stamps] waves %zu  loop cycles/wave %.0f | at the tile's wait + barrier: waves 0-3 %.1f %%, waves 4-7 %.1f %% | in the append path: "
+                                             "%.1f %% / %.1f %% (%.0f / %.0f entries per wave, %.0f cycles each) | waves by barrier share, deciles:",
+                                     nwaves, loop / nwaves, 100 * bar[0] / lp[0], 100 * bar[1] / lp[1], 100 * slow[0] / lp[0], 100 * slow[1] / lp[1],
+                                     ent[0] / (nwaves / 2), ent[1] / (nwaves / 2), (slow[0] + slow[1]) / std::max(1.0, ent[0] + ent[1]));
+                        for (int b = 0; b < 10; ++b) std::fprintf(stderr, " %d", hist[b]);
+                        std::fprintf(stderr, "\n");
+                        return hipSuccess;
+                    }
                     switch (dbg) {
 #define FSGPU_SK(D) case D: return launch_wide_t<384, EB, QT, 3, O, D>(args, grid, stream, occupancy);
                         FSGPU_SK(16) FSGPU_SK(17) FSGPU_SK(18) FSGPU_SK(20) FSGPU_SK(24) FSGPU_SK(31) FSGPU_SK(33) FSGPU_SK(35) FSGPU_SK(36)
