@@ -231,10 +231,10 @@ __device__ __noinline__ void bm_check(const u64* pv, u64 sv, uint32_t wi, int wh
 }
 #endif
 
-template <int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG = 0>
-__global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
+template <int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG = 0, int WPBT = 8>
+__global__ __launch_bounds__(WPBT * 64) void scan_wide_kernel(MfmaScanArgs args) {
     using acc_t = std::conditional_t<EB == 2, f32x4, i32x4>;
-    constexpr int WPB = 8, NT = WPB * 64;
+    constexpr int WPB = WPBT, NT = WPB * 64;   // (WPBT 16, lab: four waves per SIMD holding two query tiles each)
     constexpr int KS = ROWB / 64;                                   // MFMA k-steps (64 bytes of a row each)
     constexpr bool BIG = wide_big_ok(ROWB, EB, QT, NSLOT, OPT, DBG);
     constexpr bool FLAGS = BIG && (OPT & kOptFlags) != 0;
@@ -935,13 +935,13 @@ int wide_env(const char* name) {
 }
 #endif
 
-template <int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG = 0>
+template <int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG = 0, int WPBT = 8>
 hipError_t launch_wide_t(const MfmaScanArgs& args, int grid, hipStream_t stream, int* occupancy) {
     constexpr bool BIG = wide_big_ok(ROWB, EB, QT, NSLOT, OPT, DBG);
     constexpr int TR = BIG ? 128 : ROWB >= 512 ? 32 : 64;
     constexpr size_t ring = (size_t)NSLOT * TR * ROWB;
-    const size_t lds = ring + (size_t)QT * 128 * 4 + 64 + (DBG == 8 ? 256 : 0);   // the row-tile ring + one append counter per query + the ring's arrive / wait counters
-    auto kern = scan_wide_kernel<ROWB, EB, QT, NSLOT, OPT, DBG>;
+    const size_t lds = ring + (size_t)QT * WPBT * 16 * 4 + 64 + (DBG == 8 ? 256 : 0);   // the row-tile ring + one append counter per query + the ring's arrive / wait counters
+    auto kern = scan_wide_kernel<ROWB, EB, QT, NSLOT, OPT, DBG, WPBT>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -950,7 +950,7 @@ hipError_t launch_wide_t(const MfmaScanArgs& args, int grid, hipStream_t stream,
     }
     if (occupancy) {
         int blocks = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, 512, lds) != hipSuccess || blocks < 1) blocks = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, WPBT * 64, lds) != hipSuccess || blocks < 1) blocks = 1;
         *occupancy = blocks;
         return hipSuccess;
     }
@@ -958,7 +958,7 @@ hipError_t launch_wide_t(const MfmaScanArgs& args, int grid, hipStream_t stream,
     static const std::string name = "scan_wide_kernel<" + std::to_string(ROWB) + ", " + std::to_string(EB) + ", " +
                                     std::to_string(QT) + ", " + std::to_string(NSLOT) + ", " + std::to_string(OPT) + ">";
     if (DBG != 3 && DBG != 7) note_main_pass_kernel(name.c_str());
-    hipLaunchKernelGGL(kern, dim3(grid, args.groups ? args.groups : 1), dim3(512), lds, stream, args);
+    hipLaunchKernelGGL(kern, dim3(grid, args.groups ? args.groups : 1), dim3(WPBT * 64), lds, stream, args);
     return hipGetLastError();
 }
 
@@ -1054,6 +1054,10 @@ hipError_t launch_wide_d(const MfmaScanArgs& args, int grid, hipStream_t stream,
                     }
                 }
             }
+#endif
+#ifdef FSGPU_LAB_W16   // lab: the 512-query main pass as 16 waves of two query tiles (four waves per SIMD; 128 registers per wave: the
+                       // loop spills — 14 scratch accesses per tile behind the DMA ring's vmcnt — and measured 4.23 against 2.64 ms per launch)
+            if constexpr (EB == 1 && QT == 4 && MODE == 0) return launch_wide_t<384, 1, 2, 3, O, 0, 16>(args, grid, stream, occupancy);
 #endif
             return launch_wide_pick<384, EB, QT, 6, O, MODE>(args, grid, stream, occupancy);   // 6 x 24 KB (3 x 48 KB)
         case 128: return launch_wide_pick<256, EB, QT, 8, O, MODE>(args, grid, stream, occupancy);   // 8 x 16 KB (3 x 32 KB)
