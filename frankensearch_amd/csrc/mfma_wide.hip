@@ -231,8 +231,10 @@ __device__ __noinline__ void bm_check(const u64* pv, u64 sv, uint32_t wi, int wh
 }
 #endif
 
-template <int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG = 0, int WPBT = 8>
-__global__ __launch_bounds__(WPBT * 64) void scan_wide_kernel(MfmaScanArgs args) {
+// The kernel's body for ONE wave: QT query tiles starting at the block's query q0_wave; NQB = the block's queries (what its waves hold
+// together).  Every wave of a block runs the same tile sequence, DMA share and barriers whatever its QT (scan_wide_asym_kernel).
+template <int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG, int WPBT, int NQB>
+__device__ __forceinline__ void scan_wide_body(MfmaScanArgs args, const int q0_wave) {
     using acc_t = std::conditional_t<EB == 2, f32x4, i32x4>;
     constexpr int WPB = WPBT, NT = WPB * 64;   // (WPBT 16, lab: four waves per SIMD holding two query tiles each)
     constexpr int KS = ROWB / 64;                                   // MFMA k-steps (64 bytes of a row each)
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(WPBT * 64) void scan_wide_kernel(MfmaScanArgs args)
     // 4 x QT more registers fit; else one register per query tile and four moves per accumulator (in the MFMAs' shadow when SPLIT)
     constexpr bool NT4 = NEGTAU && !SPLIT && QT * KS * 4 + 4 * CK * 4 + 12 * QT <= 200 && QT * KS * 4 <= 96;
     constexpr int TILE_BYTES = TR * ROWB;
-    constexpr int NQ = WPB * QT * 16;
+    constexpr int NQ = NQB;
     if (gridDim.y > 1) {
         // several query groups in ONE launch (args.groups = gridDim.y): group g's queries / thresholds / lists / spill area follow group
         // g - 1's, its blocks take over the CUs as the previous group's blocks leave them (one block per CU is resident) — no launch
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(WPBT * 64) void scan_wide_kernel(MfmaScanArgs args)
     if (STAMPS && tid < 32) lcnt[NQ + 16 + tid] = 0;
 
     // this wave's queries: B fragments for the whole dimension, resident in registers
-    const int q0 = wave * QT * 16;
+    const int q0 = q0_wave;
     half8 bq[QT][KS];
     float tau[QT];
     int ctau[QT];       // NEGTAU: ceil(tau) as an integer ...
@@ -915,6 +917,20 @@ __global__ __launch_bounds__(WPBT * 64) void scan_wide_kernel(MfmaScanArgs args)
     }
 }
 
+template <int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG = 0, int WPBT = 8>
+__global__ __launch_bounds__(WPBT * 64) void scan_wide_kernel(MfmaScanArgs args) {
+    scan_wide_body<ROWB, EB, QT, NSLOT, OPT, DBG, WPBT, WPBT * QT * 16>(args, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * QT * 16);
+}
+
+// Lab (FSGPU_LAB_ASYM): the block's first four waves — the ones the oldest-first arbiter favours (profiles/r04/wide_stamps.txt: they wait
+// 36 % of their loop at the tile barrier) — hold QTA query tiles each, the last four QTB: 64 x (QTA + QTB) queries per block.
+template <int ROWB, int EB, int QTA, int QTB, int NSLOT, int OPT>
+__global__ __launch_bounds__(512) void scan_wide_asym_kernel(MfmaScanArgs args) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wave < 4) scan_wide_body<ROWB, EB, QTA, NSLOT, OPT, 0, 8, 64 * (QTA + QTB)>(args, wave * QTA * 16);
+    else scan_wide_body<ROWB, EB, QTB, NSLOT, OPT, 0, 8, 64 * (QTA + QTB)>(args, 64 * QTA + (wave - 4) * QTB * 16);
+}
+
 // ---- launcher ----------------------------------------------------------------------------------------------------
 
 namespace {
@@ -961,6 +977,25 @@ hipError_t launch_wide_t(const MfmaScanArgs& args, int grid, hipStream_t stream,
     hipLaunchKernelGGL(kern, dim3(grid, args.groups ? args.groups : 1), dim3(WPBT * 64), lds, stream, args);
     return hipGetLastError();
 }
+
+#ifdef FSGPU_LAB_ASYM
+template <int ROWB, int EB, int QTA, int QTB, int NSLOT, int OPT>
+hipError_t launch_wide_asym(const MfmaScanArgs& args, int grid, hipStream_t stream) {
+    constexpr size_t ring = (size_t)NSLOT * 64 * ROWB;
+    const size_t lds = ring + (size_t)64 * (QTA + QTB) * 4 + 64;
+    auto kern = scan_wide_asym_kernel<ROWB, EB, QTA, QTB, NSLOT, OPT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    if (args.slots > kWideSlots) return hipErrorInvalidValue;
+    note_main_pass_kernel("scan_wide_kernel<384, 1, asym>");
+    hipLaunchKernelGGL(kern, dim3(grid, args.groups ? args.groups : 1), dim3(512), lds, stream, args);
+    return hipGetLastError();
+}
+#endif
 
 // the main pass (MODE 0) of a shape that runs the split loop takes the 128-row / three-slot form; everything else NSLOT slots
 template <int ROWB, int EB, int QT, int NSLOT, int O, int MODE>
@@ -1054,6 +1089,9 @@ hipError_t launch_wide_d(const MfmaScanArgs& args, int grid, hipStream_t stream,
                     }
                 }
             }
+#endif
+#ifdef FSGPU_LAB_ASYM   // lab: 5 + 3 query tiles per SIMD pair, 64-row tiles in six slots, no 128-row form (the five-tile waves run the chunk loop)
+            if constexpr (EB == 1 && QT == 4 && MODE == 0) { if (!occupancy) return launch_wide_asym<384, 1, FSGPU_LAB_ASYM, 8 - FSGPU_LAB_ASYM, 6, O & ~(kOptBig | kOptFlags)>(args, grid, stream); }
 #endif
 #ifdef FSGPU_LAB_W16   // lab: the 512-query main pass as 16 waves of two query tiles (four waves per SIMD; 128 registers per wave: the
                        // loop spills — 14 scratch accesses per tile behind the DMA ring's vmcnt — and measured 4.23 against 2.64 ms per launch)
