@@ -236,7 +236,7 @@ __device__ __noinline__ void bm_check(const u64* pv, u64 sv, uint32_t wi, int wh
 template <int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG, int WPBT, int NQB>
 __device__ __forceinline__ void scan_wide_body(MfmaScanArgs args, const int q0_wave) {
     using acc_t = std::conditional_t<EB == 2, f32x4, i32x4>;
-    constexpr int WPB = WPBT, NT = WPB * 64;   // (WPBT 16, lab: four waves per SIMD holding two query tiles each)
+    constexpr int WPB = WPBT, NT = WPB * 64;   // (16 waves of two query tiles — four per SIMD, 128 registers each — spilled in the loop: 4.23 against 2.64 ms)
     constexpr int KS = ROWB / 64;                                   // MFMA k-steps (64 bytes of a row each)
     constexpr bool BIG = wide_big_ok(ROWB, EB, QT, NSLOT, OPT, DBG);
     constexpr bool FLAGS = BIG && (OPT & kOptFlags) != 0;
@@ -917,9 +917,9 @@ __device__ __forceinline__ void scan_wide_body(MfmaScanArgs args, const int q0_w
     }
 }
 
-template <int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG = 0, int WPBT = 8>
-__global__ __launch_bounds__(WPBT * 64) void scan_wide_kernel(MfmaScanArgs args) {
-    scan_wide_body<ROWB, EB, QT, NSLOT, OPT, DBG, WPBT, WPBT * QT * 16>(args, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * QT * 16);
+template <int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG = 0>
+__global__ __launch_bounds__(512) void scan_wide_kernel(MfmaScanArgs args) {
+    scan_wide_body<ROWB, EB, QT, NSLOT, OPT, DBG, 8, 8 * QT * 16>(args, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * QT * 16);
 }
 
 // Lab (FSGPU_LAB_ASYM): the block's first four waves — the ones the oldest-first arbiter favours (profiles/r04/wide_stamps.txt: they wait
@@ -951,13 +951,13 @@ int wide_env(const char* name) {
 }
 #endif
 
-template <int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG = 0, int WPBT = 8>
+template <int ROWB, int EB, int QT, int NSLOT, int OPT, int DBG = 0>
 hipError_t launch_wide_t(const MfmaScanArgs& args, int grid, hipStream_t stream, int* occupancy) {
     constexpr bool BIG = wide_big_ok(ROWB, EB, QT, NSLOT, OPT, DBG);
     constexpr int TR = BIG ? 128 : ROWB >= 512 ? 32 : 64;
     constexpr size_t ring = (size_t)NSLOT * TR * ROWB;
-    const size_t lds = ring + (size_t)QT * WPBT * 16 * 4 + 64 + (DBG == 8 ? 256 : 0);   // the row-tile ring + one append counter per query + the ring's arrive / wait counters
-    auto kern = scan_wide_kernel<ROWB, EB, QT, NSLOT, OPT, DBG, WPBT>;
+    const size_t lds = ring + (size_t)QT * 128 * 4 + 64 + (DBG == 8 ? 256 : 0);   // the row-tile ring + one append counter per query + the ring's arrive / wait counters
+    auto kern = scan_wide_kernel<ROWB, EB, QT, NSLOT, OPT, DBG>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -966,7 +966,7 @@ hipError_t launch_wide_t(const MfmaScanArgs& args, int grid, hipStream_t stream,
     }
     if (occupancy) {
         int blocks = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, WPBT * 64, lds) != hipSuccess || blocks < 1) blocks = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, 512, lds) != hipSuccess || blocks < 1) blocks = 1;
         *occupancy = blocks;
         return hipSuccess;
     }
@@ -974,7 +974,7 @@ hipError_t launch_wide_t(const MfmaScanArgs& args, int grid, hipStream_t stream,
     static const std::string name = "scan_wide_kernel<" + std::to_string(ROWB) + ", " + std::to_string(EB) + ", " +
                                     std::to_string(QT) + ", " + std::to_string(NSLOT) + ", " + std::to_string(OPT) + ">";
     if (DBG != 3 && DBG != 7) note_main_pass_kernel(name.c_str());
-    hipLaunchKernelGGL(kern, dim3(grid, args.groups ? args.groups : 1), dim3(WPBT * 64), lds, stream, args);
+    hipLaunchKernelGGL(kern, dim3(grid, args.groups ? args.groups : 1), dim3(512), lds, stream, args);
     return hipGetLastError();
 }
 
@@ -1092,10 +1092,6 @@ hipError_t launch_wide_d(const MfmaScanArgs& args, int grid, hipStream_t stream,
 #endif
 #ifdef FSGPU_LAB_ASYM   // lab: 5 + 3 query tiles per SIMD pair, 64-row tiles in six slots, no 128-row form (the five-tile waves run the chunk loop)
             if constexpr (EB == 1 && QT == 4 && MODE == 0) { if (!occupancy) return launch_wide_asym<384, 1, FSGPU_LAB_ASYM, 8 - FSGPU_LAB_ASYM, 6, O & ~(kOptBig | kOptFlags)>(args, grid, stream); }
-#endif
-#ifdef FSGPU_LAB_W16   // lab: the 512-query main pass as 16 waves of two query tiles (four waves per SIMD; 128 registers per wave: the
-                       // loop spills — 14 scratch accesses per tile behind the DMA ring's vmcnt — and measured 4.23 against 2.64 ms per launch)
-            if constexpr (EB == 1 && QT == 4 && MODE == 0) return launch_wide_t<384, 1, 2, 3, O, 0, 16>(args, grid, stream, occupancy);
 #endif
             return launch_wide_pick<384, EB, QT, 6, O, MODE>(args, grid, stream, occupancy);   // 6 x 24 KB (3 x 48 KB)
         case 128: return launch_wide_pick<256, EB, QT, 8, O, MODE>(args, grid, stream, occupancy);   // 8 x 16 KB (3 x 32 KB)
