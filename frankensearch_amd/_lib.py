@@ -76,6 +76,13 @@ SIGNATURES = {
     "fsgpu_merge_topk_device": (_i32, [_i32, _vp, _u32, _u32, _u32, _u64, _u64, _u32, _vp, _vp, _vp, _vp]),
     "fsgpu_sharded_create": (_i32, [_vp, _u32, _u32, _u64, _vp, _vp, _i32, C.POINTER(_vp)]),
     "fsgpu_sharded_create_device": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _i32, C.POINTER(_vp)]),
+    "fsgpu_sharded_create_grouped": (_i32, [_vp, _u32, _u32, _u32, _u64, _vp, _vp, _i32, C.POINTER(_vp)]),
+    "fsgpu_sharded_create_device_grouped": (_i32, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _i32, C.POINTER(_vp)]),
+    "fsgpu_sharded_open_fsvi_grouped": (_i32, [C.c_char_p, _vp, _u32, _u32, _i32, C.POINTER(_vp)]),
+    "fsgpu_sharded_query_groups": (_u32, [_vp]),
+    "fsgpu_sharded_row_shards": (_u32, [_vp]),
+    "fsgpu_sharded_set_int8_latency": (_i32, [_vp, _i32]),
+    "fsgpu_sharded_search_parts": (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     "fsgpu_sharded_destroy": (None, [_vp]),
     "fsgpu_sharded_record_count": (_u64, [_vp]),
     "fsgpu_sharded_dimension": (_u32, [_vp]),

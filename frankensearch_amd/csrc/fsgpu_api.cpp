@@ -661,13 +661,35 @@ fsgpu_status fsgpu_merge_topk_device(int32_t device, const uint64_t* lists_dev, 
 
 // search_top_k_classified (crates/frankensearch-index/src/search.rs:227-261)
 // ---- row-sharded index: one handle, one call per search (sharded_index.cpp) ----
-fsgpu_status fsgpu_sharded_create(const int32_t* devices, uint32_t ndev, uint32_t dim, uint64_t nrows, const void* slab_f16_le,
-                                  const uint64_t* live_bitmap, int32_t exchange, fsgpu_sharded** out) {
+fsgpu_status fsgpu_sharded_create_grouped(const int32_t* devices, uint32_t ndev, uint32_t query_groups, uint32_t dim, uint64_t nrows,
+                                          const void* slab_f16_le, const uint64_t* live_bitmap, int32_t exchange, fsgpu_sharded** out) {
     if (!out) return fail(FSGPU_ERR_NULL_ARGUMENT, "out is null");
     *out = nullptr;
     return guarded([&]() -> fsgpu_status {
         auto* h = new fsgpu_sharded();
-        fsgpu::SearchError e = h->impl.init_host(devices, ndev, dim, nrows, slab_f16_le, live_bitmap, exchange);
+        fsgpu::SearchError e = h->impl.init_host(devices, ndev, dim, nrows, slab_f16_le, live_bitmap, exchange, query_groups);
+        if (!e.ok()) {
+            delete h;
+            return finish(e);
+        }
+        *out = h;
+        return FSGPU_OK;
+    });
+}
+
+fsgpu_status fsgpu_sharded_create(const int32_t* devices, uint32_t ndev, uint32_t dim, uint64_t nrows, const void* slab_f16_le,
+                                  const uint64_t* live_bitmap, int32_t exchange, fsgpu_sharded** out) {
+    return fsgpu_sharded_create_grouped(devices, ndev, 1, dim, nrows, slab_f16_le, live_bitmap, exchange, out);
+}
+
+fsgpu_status fsgpu_sharded_create_device_grouped(const int32_t* devices, uint32_t ndev, uint32_t query_groups, uint32_t dim,
+                                                 const uint64_t* shard_rows, const void* const* shard_slabs_dev,
+                                                 const uint64_t* const* shard_live_dev, int32_t exchange, fsgpu_sharded** out) {
+    if (!out) return fail(FSGPU_ERR_NULL_ARGUMENT, "out is null");
+    *out = nullptr;
+    return guarded([&]() -> fsgpu_status {
+        auto* h = new fsgpu_sharded();
+        fsgpu::SearchError e = h->impl.init_device(devices, ndev, dim, shard_rows, shard_slabs_dev, shard_live_dev, exchange, query_groups);
         if (!e.ok()) {
             delete h;
             return finish(e);
@@ -680,17 +702,17 @@ fsgpu_status fsgpu_sharded_create(const int32_t* devices, uint32_t ndev, uint32_
 fsgpu_status fsgpu_sharded_create_device(const int32_t* devices, uint32_t ndev, uint32_t dim, const uint64_t* shard_rows,
                                          const void* const* shard_slabs_dev, const uint64_t* const* shard_live_dev,
                                          int32_t exchange, fsgpu_sharded** out) {
-    if (!out) return fail(FSGPU_ERR_NULL_ARGUMENT, "out is null");
-    *out = nullptr;
+    return fsgpu_sharded_create_device_grouped(devices, ndev, 1, dim, shard_rows, shard_slabs_dev, shard_live_dev, exchange, out);
+}
+
+uint32_t fsgpu_sharded_query_groups(const fsgpu_sharded* idx) { return idx ? idx->impl.query_groups() : 0; }
+uint32_t fsgpu_sharded_row_shards(const fsgpu_sharded* idx) { return idx ? idx->impl.row_shards() : 0; }
+
+fsgpu_status fsgpu_sharded_set_int8_latency(fsgpu_sharded* idx, int32_t enabled) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
     return guarded([&]() -> fsgpu_status {
-        auto* h = new fsgpu_sharded();
-        fsgpu::SearchError e = h->impl.init_device(devices, ndev, dim, shard_rows, shard_slabs_dev, shard_live_dev, exchange);
-        if (!e.ok()) {
-            delete h;
-            return finish(e);
-        }
-        *out = h;
-        return FSGPU_OK;
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.set_int8_latency(enabled != 0));
     });
 }
 
@@ -766,6 +788,27 @@ fsgpu_status fsgpu_sharded_coalescing_stats(fsgpu_sharded* idx, uint64_t* batche
     return FSGPU_OK;
 }
 
+// queries resident in parts on several devices (data-parallel encoders): request->queries / queries_dev are ignored
+fsgpu_status fsgpu_sharded_search_parts(fsgpu_sharded* idx, const fsgpu_sharded_request* request, const float* const* parts_dev,
+                                        const uint32_t* part_counts, const int32_t* part_devices, uint32_t n_parts, uint32_t* out_rows,
+                                        float* out_scores, uint32_t* out_counts, uint32_t* out_fallbacks) {
+    if (!idx || !request) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    if (request->mode < FSGPU_SHARDED_EXACT || request->mode > FSGPU_SHARDED_4BIT_TWO_PASS) return fail(FSGPU_ERR_INVALID_CONFIG, "unknown search mode");
+    if (request->nq && (!n_parts || !parts_dev || !part_counts || !part_devices)) return fail(FSGPU_ERR_NULL_ARGUMENT, "query parts are required");
+    if (request->nq && (!out_counts || (request->k && (!out_rows || !out_scores)))) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        fsgpu::ShardedIndex::Request r = sharded_request(request);
+        r.queries = nullptr;
+        r.queries_dev = nullptr;
+        r.parts_dev = parts_dev;
+        r.part_counts = part_counts;
+        r.part_devices = part_devices;
+        r.n_parts = n_parts;
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.search(r, request->query_len, out_rows, out_scores, out_counts, out_fallbacks));
+    });
+}
+
 fsgpu_status fsgpu_sharded_search_begin(fsgpu_sharded* idx, const fsgpu_sharded_request* request, uint64_t* out_ticket) {
     const fsgpu_status c = check_sharded_request(idx, request);
     if (c != FSGPU_OK) return c;
@@ -806,6 +849,11 @@ fsgpu_status fsgpu_sharded_search_topk_batched(fsgpu_sharded* idx, const float* 
 float fsgpu_sharded_quant_scale_max(const fsgpu_sharded* idx) { return idx ? idx->impl.quant_scale_max() : 0.0f; }
 
 fsgpu_status fsgpu_sharded_open_fsvi(const char* path, const int32_t* devices, uint32_t ndev, int32_t exchange, fsgpu_sharded** out) {
+    return fsgpu_sharded_open_fsvi_grouped(path, devices, ndev, 1, exchange, out);
+}
+
+fsgpu_status fsgpu_sharded_open_fsvi_grouped(const char* path, const int32_t* devices, uint32_t ndev, uint32_t query_groups, int32_t exchange,
+                                             fsgpu_sharded** out) {
     if (!out || !path || !devices) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
     *out = nullptr;
     int count = 0;
@@ -813,7 +861,7 @@ fsgpu_status fsgpu_sharded_open_fsvi(const char* path, const int32_t* devices, u
         return fail(FSGPU_ERR_NO_DEVICE, "no HIP device visible (libfsgpu has no CPU fallback)");
     return guarded([&]() -> fsgpu_status {
         auto* h = new fsgpu_sharded();
-        fsgpu::SearchError e = h->impl.open_fsvi(path, devices, ndev, exchange);
+        fsgpu::SearchError e = h->impl.open_fsvi(path, devices, ndev, exchange, query_groups);
         if (!e.ok()) {
             delete h;
             return finish(e);

@@ -7,7 +7,7 @@
 
 namespace fshost {
 fsgpu_status run_load(const SyncTwoTierSearcher& searcher, const fshost_load_config& cfg, fshost_load_result* res);
-fsgpu_status embed_search_stream(fsgpu_bert* encoder, fsgpu_index* index, fsgpu_sharded* sharded, const int32_t* ids,
+fsgpu_status embed_search_stream(fsgpu_bert* const* encoders, uint32_t n_encoders, fsgpu_index* index, fsgpu_sharded* sharded, const int32_t* ids,
                                  const uint32_t* offsets, uint32_t batch, uint32_t n_batches, uint32_t group, uint32_t k, bool overlap,
                                  bool host_handoff, uint32_t* out_rows, float* out_scores, uint32_t* out_counts, fshost_stream_result* result);
 }
@@ -96,8 +96,24 @@ fsgpu_status fshost_embed_search_stream(fsgpu_bert* encoder, fsgpu_index* index,
     if (!encoder || !ids || !offsets || !result || (index == nullptr) == (sharded == nullptr)) return FSGPU_ERR_NULL_ARGUMENT;
     if (batch == 0 || group == 0 || k == 0) return FSGPU_ERR_INVALID_CONFIG;
     try {
-        return fshost::embed_search_stream(encoder, index, sharded, ids, offsets, batch, n_batches, group, k, (overlap & 1) != 0,
+        return fshost::embed_search_stream(&encoder, 1, index, sharded, ids, offsets, batch, n_batches, group, k, (overlap & 1) != 0,
                                            (overlap & 2) != 0, out_rows, out_scores, out_counts, result);
+    } catch (const std::exception&) {
+        return FSGPU_ERR_DEVICE;
+    }
+}
+
+fsgpu_status fshost_embed_search_stream_dp(fsgpu_bert* const* encoders, uint32_t n_encoders, fsgpu_sharded* sharded, const int32_t* ids,
+                                           const uint32_t* offsets, uint32_t batch, uint32_t n_batches, uint32_t group, uint32_t k,
+                                           int32_t overlap, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
+                                           fshost_stream_result* result) {
+    if (!encoders || n_encoders == 0 || !sharded || !ids || !offsets || !result) return FSGPU_ERR_NULL_ARGUMENT;
+    for (uint32_t e = 0; e < n_encoders; ++e)
+        if (!encoders[e]) return FSGPU_ERR_NULL_ARGUMENT;
+    if (batch == 0 || group == 0 || k == 0) return FSGPU_ERR_INVALID_CONFIG;
+    try {
+        return fshost::embed_search_stream(encoders, n_encoders, nullptr, sharded, ids, offsets, batch, n_batches, group, k, (overlap & 1) != 0,
+                                           false, out_rows, out_scores, out_counts, result);
     } catch (const std::exception&) {
         return FSGPU_ERR_DEVICE;
     }

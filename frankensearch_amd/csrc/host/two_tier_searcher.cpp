@@ -87,9 +87,9 @@ void SyncTwoTierSearcher::init() {
     // opt-in: the quality tier's exact search is phase 1's longest leg (one HBM pass over the f16 slab); with the int8 latency
     // path a lone caller's query goes through the int8 filter + exact re-score instead — the same hits from half the bytes.
     // It is a setting of the CALLER's handle (and costs it an int8 copy of the slab): switched off again in the destructor.
-    // (A sharded quality tier scans 1/W of the rows per GPU: its exact pass is already the short leg, the switch does not exist.)
-    if (cfg_.quality_int8_latency && cfg_.quality_pool == FSHOST_POOL_RETRIEVED && quality_.index) {
-        init_status_ = fsgpu_index_set_int8_latency(quality_.index, 1);
+    // (A sharded quality tier takes the same switch on every shard: fsgpu_sharded_set_int8_latency.)
+    if (cfg_.quality_int8_latency && cfg_.quality_pool == FSHOST_POOL_RETRIEVED) {
+        init_status_ = quality_.index ? fsgpu_index_set_int8_latency(quality_.index, 1) : fsgpu_sharded_set_int8_latency(quality_.sharded, 1);
         if (init_status_ != FSGPU_OK) init_detail_ = fsgpu_last_error();
     }
     if (init_status_ == FSGPU_OK && cfg_.quality_pool == FSHOST_POOL_RESCORED) {
@@ -102,8 +102,10 @@ void SyncTwoTierSearcher::init() {
 
 SyncTwoTierSearcher::~SyncTwoTierSearcher() {
     if (alignment_) fsgpu_alignment_destroy(alignment_);
-    if (cfg_.quality_int8_latency && cfg_.quality_pool == FSHOST_POOL_RETRIEVED && quality_.index)
-        (void)fsgpu_index_set_int8_latency(quality_.index, 0);
+    if (cfg_.quality_int8_latency && cfg_.quality_pool == FSHOST_POOL_RETRIEVED) {
+        if (quality_.index) (void)fsgpu_index_set_int8_latency(quality_.index, 0);
+        else (void)fsgpu_sharded_set_int8_latency(quality_.sharded, 0);
+    }
 }
 
 // VectorIndex::search_top_k -> Vec<VectorHit> with doc ids resolved (search.rs:192-206, 1503-1558).

@@ -104,6 +104,9 @@ __device__ __forceinline__ int ceil_threshold(float t) {
     return (int)ceilf(t);
 }
 
+// a wave vote: true for every lane when the predicate holds in any lane
+__device__ __forceinline__ bool wave_any(bool x) { return __ballot(x) != 0; }
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
@@ -456,6 +459,11 @@ __device__ __forceinline__ void scan_wide_body(MfmaScanArgs args, const int q0_w
     };
     // rows of a finished sub-tile pair at or above the threshold -> the block's list of their query (straight to global
     // memory: a few entries per query and block, so LDS holds only the counters)
+    // byte offset of this lane's list for its wave's query tile 0: ((q * grid + block) * slots) * 8 — NQ x grid x slots x 8 <= 42 MB
+    const uint32_t list0 = (((uint32_t)q0_wave + (uint32_t)(threadIdx.x & 15)) * gridDim.x + blockIdx.x) * args.slots * 8u;
+    const uint32_t tile_step = 16u * gridDim.x * args.slots * 8u;   // ... per query tile (scalar)
+    uint32_t lcount = 0;   // entries this wave has appended to the block's list of each of its queries: 6 bits per query tile, saturating
+    static_assert(QT * 6 <= 32 && kWideSlots < 63, "one register holds the wave's list lengths");
     auto lane_max = [&](const acc_t (&acc)[2][QT], int nt) {
         auto m = acc[0][nt][0];
 #pragma unroll
@@ -493,36 +501,14 @@ __device__ __forceinline__ void scan_wide_body(MfmaScanArgs args, const int q0_w
         }
         return any;
     };
-    // mask: the tombstone and allow bits of the 64 rows around `row` (emit_tiles fetched the words with SCALAR loads: a vector load
-    // here would be waited for with vmcnt(0), i.e. behind every DMA in flight — filtered batches paid ~10 % for that)
-    auto append = [&](int q, float score, uint32_t row, u64 mask) {
-        if (row >= args.nrows) return;
-        if (!((mask >> (row & 63)) & 1ull)) return;
-#ifdef FSGPU_EXPERIMENTS
-        if constexpr (AK_NO_BODY) {
-            asm volatile("" ::"v"(q), "v"(score), "v"(row));
-            return;
-        }
-        if constexpr (AK_NO_ATOMIC || AK_NO_STORE) {
-            int p0 = 0;
-            if constexpr (!AK_NO_ATOMIC) p0 = atomicAdd(&lcnt[q], 1);
-            const u64 e0 = pack(score, args.row_base + row);
-            if constexpr (AK_NO_STORE) asm volatile("" ::"v"(p0), "v"(e0));
-            else args.cand[((size_t)q * gridDim.x + blockIdx.x) * slots + (p0 < slots ? p0 : 0)] = e0;
-            return;
-        }
-#endif
-        const int pos = atomicAdd(&lcnt[q], 1);
-        const u64 entry = pack(score, args.row_base + row);
-        if (pos < slots) {
-            args.cand[((size_t)q * gridDim.x + blockIdx.x) * slots + pos] = entry;
-        } else {
-            const uint32_t g = atomicAdd(&args.spill_count[q * kMfmaSpillCountStride], 1u);
-            if (g < args.spill_cap) args.spill[(size_t)q * args.spill_cap + g] = entry;
-            else args.overflow[q] = 1;
-        }
-    };
-    // the slow path: a lane with a passing score among the query tiles [nt_lo, nt_hi) of sub-tile pair sp of tile t
+    // The append path.  A query belongs to ONE wave (q = q0 + nt * 16 + frow), so the length of its (query, block) list needs no
+    // shared counter: it lives in a register — 6 bits per query tile in `lcount`, identical in the four lanes (fk = 0..3) that hold
+    // the query's column — and a passing score's slot comes from a wave vote: slot = count + passing lanes of the same column below
+    // this one.  The whole wave takes the excursion (the caller's test is a vote), nothing in it is waited for: no LDS atomic, no
+    // load — the list's address is the kernel argument's scalar base + a 32-bit lane offset (r04 kept eight 64-bit list / spill
+    // addresses per lane, which spilled: every entry paid a scratch reload + s_waitcnt vmcnt(0), i.e. a drain of the DMA ring the
+    // loop never drains — 1,600 cycles per entry, profiles/r04/wide_stamps.txt), the entry leaves through a store that nobody waits
+    // for, and only a list that overflows its slots (rare: the spill area) touches a returning global atomic.
     auto emit_tiles = [&](uint32_t t, int sp, const acc_t (&acc)[2][QT], int nt_lo, int nt_hi) {
 #ifdef FSGPU_EXPERIMENTS
         if constexpr (DBG == 2 || DBG == 4 || DBG == 5 || SK) {  // (timing skeletons read stale bytes: keep the scores live, append nothing)
@@ -533,13 +519,19 @@ __device__ __forceinline__ void scan_wide_body(MfmaScanArgs args, const int q0_w
         if (t >= ntiles) return;   // (wave-uniform) a ragged round: the slot holds the last tile again
         [[maybe_unused]] unsigned long long st_in = 0;
         if constexpr (STAMPS) st_in = __builtin_readcyclecounter();
+#ifdef FSGPU_LAB_APPEND_PRIO
+        // (lab) the partner wave of this SIMD keeps issuing matrix instructions; at equal priority the OLDER wave's vector instructions
+        // go first and an excursion on the younger one crawls (MI355X_MICROARCH.md, "Two waves per SIMD", item 2)
+        __builtin_amdgcn_s_setprio(FSGPU_LAB_APPEND_PRIO);
+#endif
         // C layout: column (query) = lane & 15, row = (lane >> 4) * 4 + reg
-        const uint32_t pair_row0 = tile_row0(t) + sp * 16;   // wave-uniform, a multiple of 32: the pair's 32 rows share one bitmap word
-        const uint32_t row00 = pair_row0 + fk * 4;
-        u64 mask = ~0ull;
+        const uint32_t pair_row0 = __builtin_amdgcn_readfirstlane(tile_row0(t) + sp * 16);   // a multiple of 32: the pair's 32 rows share one bitmap word
+        // the pair's 32 rows: bit i set = row pair_row0 + i exists, is live and allowed (scalar arithmetic)
+        uint32_t ok32 = pair_row0 + 32u <= args.nrows ? ~0u : pair_row0 >= args.nrows ? 0u : (1u << (args.nrows - pair_row0)) - 1u;
         if (args.live || args.allow) {
-            uint32_t wi = pair_row0 >> 6;   // (a ragged last tile: the pair may start past the last row — its rows are rejected below)
+            uint32_t wi = pair_row0 >> 6;   // (a ragged last tile: the pair may start past the last row — its rows are rejected above)
             wi = __builtin_amdgcn_readfirstlane(wi < (last_row >> 6) ? wi : (last_row >> 6));
+            u64 mask = ~0ull;
 #ifdef FSGPU_LAB_VECTOR_BITMAP   // (lab: the r03 state before the scalar loads — waits behind every DMA in flight)
             if (args.live) mask &= __builtin_nontemporal_load(args.live + wi);
             if (args.allow) mask &= __builtin_nontemporal_load(args.allow + wi);
@@ -558,32 +550,73 @@ __device__ __forceinline__ void scan_wide_body(MfmaScanArgs args, const int q0_w
             if (args.live) mask &= sload_u64(args.live + wi);
             if (args.allow) mask &= sload_u64(args.allow + wi);
 #endif
+            ok32 &= (uint32_t)(mask >> (pair_row0 & 32u));
         }
-        if constexpr (EB == 2 && QT >= 3) {   // (the 384-query f16 shape has no register to spare for the per-tile test below)
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int nt = nt_lo; nt < nt_hi; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (passes(nt, acc[h][nt][r])) append(q0 + nt * 16 + frow, score_of(nt, acc[h][nt][r]), row00 + h * 16 + r, mask);
-        } else {
-            // query tiles first: a wave gets here for ONE passing score as a rule, and the tiles without one are skipped as a
-            // whole — on a 1.25M-row shard, where 512 queries x ~800 survivors meet 8 x fewer tiles than at 10M rows, this slow
-            // path is entered ~20 times per tile
+        // Everything per lane below derives from three values made opaque HERE, so that hipcc computes it inside the excursion
+        // instead of keeping it in registers across the tile loop (which has none to spare).
+        uint32_t fk_v = (uint32_t)fk, frow_v = (uint32_t)frow, list_v = list0;
+        asm volatile("" : "+v"(fk_v), "+v"(frow_v), "+v"(list_v));
+        const uint32_t below_mask = (1u << fk_v) - 1u;
+        const uint32_t row00 = pair_row0 + fk_v * 4u;
+        unsigned char* const cand_bytes = reinterpret_cast<unsigned char*>(args.cand);
+        // one passing score: its slot from the vote, the entry stored, the column's count moved on in all four of its lanes
+        auto take = [&](int nt, int h, int r, bool pass, u64 vote) __attribute__((always_inline)) {
+            // the four lanes of this lane's query column: frow + 16 j
+            const uint32_t vlo = (uint32_t)vote >> frow_v, vhi = (uint32_t)(vote >> 32) >> frow_v;
+            const uint32_t col = (vlo & 1u) | ((vlo >> 15) & 2u) | ((vhi & 1u) << 2) | ((vhi >> 13) & 8u);
+            const uint32_t have = (lcount >> (6 * nt)) & 63u;
+            if (pass) {
+                const uint32_t pos = have + (uint32_t)__builtin_popcount(col & below_mask);
+                const u64 entry = pack(score_of(nt, acc[h][nt][r]), args.row_base + row00 + h * 16 + r);
+                if (__builtin_expect(pos < (uint32_t)slots, 1)) {
+                    *reinterpret_cast<u64*>(cand_bytes + (size_t)(uint32_t)(list_v + (uint32_t)nt * tile_step + pos * 8u)) = entry;
+                } else {
+                    const uint32_t q = (uint32_t)q0 + (uint32_t)nt * 16u + frow_v;
+                    const uint32_t g = atomicAdd(&args.spill_count[q * kMfmaSpillCountStride], 1u);
+                    if (g < args.spill_cap) args.spill[(size_t)q * args.spill_cap + g] = entry;
+                    else args.overflow[q] = 1;
+                }
+            }
+            const uint32_t now = have + (uint32_t)__builtin_popcount(col);
+            lcount = (lcount & ~(63u << (6 * nt))) | ((now < 63u ? now : 63u) << (6 * nt));
+        };
+        if (__builtin_expect(ok32 == ~0u, 1)) {
+            // every row of the pair exists, is live and allowed: the votes are the bare threshold tests, and the tests fall through
+            // (a vote that finds something branches out and back: one passing score per excursion is the rule)
 #pragma unroll
             for (int nt = nt_lo; nt < nt_hi; ++nt) {
-                if (!passes(nt, lane_max(acc, nt))) continue;
+                // query tiles first: the tiles without a passing score are skipped as a whole
+                if (!wave_any(passes(nt, lane_max(acc, nt)))) continue;
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (passes(nt, acc[h][nt][r])) append(q0 + nt * 16 + frow, score_of(nt, acc[h][nt][r]), row00 + h * 16 + r, mask);
+                    for (int r = 0; r < 4; ++r) {
+                        const bool pass = passes(nt, acc[h][nt][r]);
+                        const u64 vote = __ballot(pass);
+                        if (__builtin_expect(vote != 0, 0)) take(nt, h, r, pass, vote);
+                    }
+            }
+        } else {
+            const uint32_t lb = ok32 >> (fk_v * 4u);   // this lane's 8 rows: bits h * 16 + r of its view
+#pragma unroll
+            for (int nt = nt_lo; nt < nt_hi; ++nt) {
+                if (!wave_any(passes(nt, lane_max(acc, nt)))) continue;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool pass = passes(nt, acc[h][nt][r]) && ((lb >> (h * 16 + r)) & 1u);
+                        const u64 vote = __ballot(pass);
+                        if (__builtin_expect(vote != 0, 0)) take(nt, h, r, pass, vote);
+                    }
             }
         }
-        if constexpr (STAMPS) {   // (the lowest active lane books the excursion for its wave)
+#ifdef FSGPU_LAB_APPEND_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        if constexpr (STAMPS) {
             const unsigned long long dt = __builtin_readcyclecounter() - st_in;
-            if (lane == __builtin_ctzll(__ballot(true))) {
+            if (lane == 0) {
                 unsigned long long* st = reinterpret_cast<unsigned long long*>(lcnt + NQ + 16) + wave * 2;
                 atomicAdd(st, dt);
                 atomicAdd(st + 1, 1ull);
@@ -595,7 +628,7 @@ __device__ __forceinline__ void scan_wide_body(MfmaScanArgs args, const int q0_w
     // with the hint the loop is ~480 contiguous instructions that fall through and the append code sits behind the function's end)
     auto emit_pair = [&](uint32_t t, int sp, const acc_t (&acc)[2][QT]) {
         // one test for the whole pair; almost always negative: survivors are a few hundred rows of the slab
-        if (__builtin_expect(any_passes(acc, 0, QT), 0)) emit_tiles(t, sp, acc, 0, QT);
+        if (__builtin_expect(wave_any(any_passes(acc, 0, QT)), 0)) emit_tiles(t, sp, acc, 0, QT);
     };
 
     // The append path reads the tombstone / allow words with SCALAR loads (sload_u64).  The scalar data cache is not invalidated
@@ -785,7 +818,7 @@ __device__ __forceinline__ void scan_wide_body(MfmaScanArgs args, const int q0_w
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (__builtin_expect(anyB, 0)) emit_tiles(tB, ((p + NP - 1) % NP) * 2, acc, QA, QT);
+                if (__builtin_expect(wave_any(anyB), 0)) emit_tiles(tB, ((p + NP - 1) % NP) * 2, acc, QA, QT);
                 // ---- phase 2: query tiles [QA, QT); the next pair's fragments roll in behind each k-step; this pair's tiles
                 // [0, QA) are tested in its shadow
                 init_acc(QA, QT);
@@ -808,7 +841,7 @@ __device__ __forceinline__ void scan_wide_body(MfmaScanArgs args, const int q0_w
                 if constexpr (FLAGS) {   // this wave's last read of the tile is out (the last pair's fragments): its slot may be refilled
                     if (p + 2 == NP) flag_post(flags + 16 + slot * 4, lane);
                 }
-                if (__builtin_expect(anyA, 0)) emit_tiles(t, p * 2, acc, 0, QA);
+                if (__builtin_expect(wave_any(anyA), 0)) emit_tiles(t, p * 2, acc, 0, QA);
                 tB = t;
             }
             cursor_next(cc);
@@ -828,7 +861,7 @@ __device__ __forceinline__ void scan_wide_body(MfmaScanArgs args, const int q0_w
             __syncthreads();   // (no DMA may outlive the block's LDS allocation: every wave has waited for its own above)
             return;
         } else {
-            if (__builtin_expect(any_passes(acc, QA, QT), 0)) emit_tiles(tB, (NP - 1) * 2, acc, QA, QT);
+            if (__builtin_expect(wave_any(any_passes(acc, QA, QT)), 0)) emit_tiles(tB, (NP - 1) * 2, acc, QA, QT);
         }
     } else {
     half8 fa[2][2][CK];   // fragment double buffer: [buffer][sub-tile of the pair][k-step of the chunk]
@@ -890,6 +923,10 @@ __device__ __forceinline__ void scan_wide_body(MfmaScanArgs args, const int q0_w
     }
     }
     wait_vmcnt<0>();  // no DMA may outlive the block's LDS allocation
+    if (fk == 0) {    // the list lengths, from the registers of the lanes that hold each query's column
+#pragma unroll
+        for (int nt = 0; nt < QT; ++nt) lcnt[q0 + nt * 16 + frow] = (int)((lcount >> (6 * nt)) & 63u);
+    }
     __syncthreads();
     if constexpr (STAMPS) {
         if (args.dense && lane == 0) {

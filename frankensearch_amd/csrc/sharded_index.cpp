@@ -102,17 +102,17 @@ std::vector<uint64_t> slice_bitmap(const uint64_t* bits, uint64_t lo, uint64_t r
     return out;
 }
 
+// ---- host-side order (device_util.hpp's sortkey, restated for the lone query's host merge) ----
+uint64_t host_sortkey(uint64_t packed) {
+    uint32_t bits = (uint32_t)(packed >> 32);
+    if ((bits & 0x7fffffffu) > 0x7f800000u) bits = 0xff800000u;            // NaN ranks as -inf (score_key, search.rs:1655-1661)
+    const uint32_t ord = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);   // f32::total_cmp
+    return ((uint64_t)ord << 32) | (uint32_t)(~(uint32_t)packed);           // ties: the lower row first
+}
+
 }  // namespace
 
 ShardedIndex::~ShardedIndex() {
-    {
-        std::lock_guard<std::mutex> lk(mu_);
-        stop_ = true;
-        ++generation_;
-    }
-    cv_work_.notify_all();
-    for (auto& s : shards_)
-        if (s->worker.joinable()) s->worker.join();
     for (auto& s : shards_) {
         if (s->device >= 0) (void)hipSetDevice(s->device);
         if (s->stream) (void)hipStreamSynchronize(s->stream);
@@ -134,20 +134,32 @@ ShardedIndex::~ShardedIndex() {
     }
 }
 
+SearchError ShardedIndex::check_layout(uint32_t ndev, uint32_t query_groups) {
+    if (ndev == 0) return make_err(FSGPU_ERR_INVALID_CONFIG, "at least one device is required");
+    if (query_groups == 0 || ndev % query_groups != 0)
+        return make_err(FSGPU_ERR_INVALID_CONFIG, "query_groups must divide the number of devices (query groups x row shards)");
+    groups_ = query_groups;
+    row_shards_ = ndev / query_groups;
+    return SearchError{};
+}
+
 SearchError ShardedIndex::init_host(const int32_t* devices, uint32_t ndev, uint32_t dim, uint64_t nrows, const void* slab_f16,
-                                    const uint64_t* live, int32_t exchange) {
-    if (!devices || ndev == 0) return make_err(FSGPU_ERR_INVALID_CONFIG, "at least one device is required");
+                                    const uint64_t* live, int32_t exchange, uint32_t query_groups) {
+    if (!devices) return make_err(FSGPU_ERR_INVALID_CONFIG, "at least one device is required");
+    SH_TRY(check_layout(ndev, query_groups));
     if (dim == 0) return make_err(FSGPU_ERR_INVALID_CONFIG, "dimension must be greater than zero");
     if (nrows >= 0xffffffffull) return make_err(FSGPU_ERR_INVALID_CONFIG, "row ids must fit in u32 (VectorHit.index)");
     if (nrows > 0 && !slab_f16) return make_err(FSGPU_ERR_NULL_ARGUMENT, "slab is null");
     dim_ = dim;
     nrows_ = nrows;
-    // contiguous ceil split, exactly the chunking of scan_parallel (search.rs:1020-1035) at shard granularity
-    const uint64_t per = (nrows + ndev - 1) / ndev;
+    // contiguous ceil split, exactly the chunking of scan_parallel (search.rs:1020-1035) at shard granularity; with query groups
+    // every row shard is uploaded once per group
+    const uint64_t per = (nrows + row_shards_ - 1) / row_shards_;
     for (uint32_t r = 0; r < ndev; ++r) {
+        const uint32_t rs = r % row_shards_;
         auto s = std::make_unique<Shard>();
         s->device = devices[r];
-        s->lo = std::min<uint64_t>(nrows, (uint64_t)r * per);
+        s->lo = std::min<uint64_t>(nrows, (uint64_t)rs * per);
         s->rows = std::min<uint64_t>(nrows, s->lo + per) - s->lo;
         std::vector<uint64_t> bits;
         if (live && s->rows) bits = slice_bitmap(live, s->lo, s->rows);
@@ -159,36 +171,40 @@ SearchError ShardedIndex::init_host(const int32_t* devices, uint32_t ndev, uint3
 }
 
 SearchError ShardedIndex::init_device(const int32_t* devices, uint32_t ndev, uint32_t dim, const uint64_t* shard_rows,
-                                      const void* const* slabs_dev, const uint64_t* const* live_dev, int32_t exchange) {
-    if (!devices || ndev == 0 || !shard_rows || !slabs_dev)
-        return make_err(FSGPU_ERR_INVALID_CONFIG, "devices, shard_rows and slabs are required");
+                                      const void* const* slabs_dev, const uint64_t* const* live_dev, int32_t exchange, uint32_t query_groups) {
+    if (!devices || !shard_rows || !slabs_dev) return make_err(FSGPU_ERR_INVALID_CONFIG, "devices, shard_rows and slabs are required");
+    SH_TRY(check_layout(ndev, query_groups));
     if (dim == 0) return make_err(FSGPU_ERR_INVALID_CONFIG, "dimension must be greater than zero");
     dim_ = dim;
-    uint64_t lo = 0;
+    std::vector<uint64_t> los(row_shards_ + 1, 0);
+    for (uint32_t rs = 0; rs < row_shards_; ++rs) los[rs + 1] = los[rs] + shard_rows[rs];
+    if (los[row_shards_] >= 0xffffffffull) return make_err(FSGPU_ERR_INVALID_CONFIG, "row ids must fit in u32 (VectorHit.index)");
     for (uint32_t r = 0; r < ndev; ++r) {
+        const uint32_t rs = r % row_shards_;
+        if (shard_rows[r] != shard_rows[rs])
+            return make_err(FSGPU_ERR_INVALID_CONFIG, "with query groups, device r holds row shard r % (devices / groups): the same rows in every group");
         auto s = std::make_unique<Shard>();
         s->device = devices[r];
-        s->lo = lo;
+        s->lo = los[rs];
         s->rows = shard_rows[r];
-        lo += s->rows;
-        if (lo >= 0xffffffffull) return make_err(FSGPU_ERR_INVALID_CONFIG, "row ids must fit in u32 (VectorHit.index)");
         SH_TRY(s->index.init_device(s->device, dim, s->rows, slabs_dev[r], live_dev ? live_dev[r] : nullptr, s->lo));
         shards_.push_back(std::move(s));
     }
-    nrows_ = lo;
+    nrows_ = los[row_shards_];
     return finish_init(exchange);
 }
 
 // VectorIndex::open (lib.rs:1747-1909) for a sharded index: the file is read and validated once; its record table, doc-id
 // strings, tombstone flags (and later its WAL) stay in the catalog, the F16 slab is split over the devices.
-SearchError ShardedIndex::open_fsvi(const char* path, const int32_t* devices, uint32_t ndev, int32_t exchange) {
+SearchError ShardedIndex::open_fsvi(const char* path, const int32_t* devices, uint32_t ndev, int32_t exchange, uint32_t query_groups) {
     if (!devices || ndev == 0) return make_err(FSGPU_ERR_INVALID_CONFIG, "at least one device is required");
     catalog_ = std::make_unique<VectorIndex>();
     VectorIndex::FsviImage img;
     SH_TRY(catalog_->open_fsvi_catalog(path, &img));
     if (img.f32_rows) return make_err(FSGPU_ERR_INVALID_CONFIG, "a sharded index needs an F16 slab (Quantization::F16)");
     const std::vector<uint64_t>& live = catalog_->live_host();
-    SH_TRY(init_host(devices, ndev, img.dim, img.nrows, img.bytes.data() + img.slab_offset, live.empty() ? nullptr : live.data(), exchange));
+    SH_TRY(init_host(devices, ndev, img.dim, img.nrows, img.bytes.data() + img.slab_offset, live.empty() ? nullptr : live.data(), exchange,
+                     query_groups));
     // hits of the catalog's search_top_k (WAL merge, shadowing, dedup) come from the shards
     catalog_->topk_override = [this](const float* q, uint32_t k, uint32_t* rows, float* scores, uint32_t* count) -> SearchError {
         Request rq;
@@ -239,21 +255,21 @@ SearchError ShardedIndex::finish_init(int32_t exchange) {
         }
     }
     if (w > 1) {
-        // peer access to the root's memory: the peer-copy exchange writes into its gather buffer, and device-resident queries are
-        // fetched from it (without it HIP stages such copies through the host: slower, still correct)
-        for (uint32_t r = 1; r < w; ++r) {
-            if (shards_[r]->device == shards_[0]->device) continue;
-            int can = 0;
-            SH_HIP(hipDeviceCanAccessPeer(&can, shards_[r]->device, shards_[0]->device));
-            if (can) {
-                SH_HIP(hipSetDevice(shards_[r]->device));
-                const hipError_t e = hipDeviceEnablePeerAccess(shards_[0]->device, 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled && !use_rccl_) return hip_err(e, "hipDeviceEnablePeerAccess");
+        // peer access among the devices: the peer-copy exchange writes into the root's gather buffer, and device-resident queries
+        // (the root's, or the parts data-parallel encoders left on their devices) are fetched peer to peer — without it HIP stages
+        // such copies through the host: slower, still correct
+        for (uint32_t a = 0; a < w; ++a)
+            for (uint32_t b = 0; b < w; ++b) {
+                if (shards_[a]->device == shards_[b]->device) continue;
+                int can = 0;
+                SH_HIP(hipDeviceCanAccessPeer(&can, shards_[a]->device, shards_[b]->device));
+                if (!can) continue;
+                SH_HIP(hipSetDevice(shards_[a]->device));
+                const hipError_t e = hipDeviceEnablePeerAccess(shards_[b]->device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled && !use_rccl_ && b == 0) return hip_err(e, "hipDeviceEnablePeerAccess");
                 (void)hipGetLastError();
             }
-        }
     }
-    for (uint32_t r = 0; r < w; ++r) shards_[r]->worker = std::thread([this, r] { worker_main(r); });
     return SearchError{};
 }
 
@@ -269,91 +285,108 @@ void ShardedIndex::set_hreduce(int32_t mode) {
     if (catalog_) catalog_->hreduce = mode;
 }
 
-uint32_t ShardedIndex::owner_of(uint64_t row) const {
-    for (uint32_t r = 0; r < shards_.size(); ++r)
+SearchError ShardedIndex::set_int8_latency(bool on) {
+    for (const RootSlot& r : root_)
+        if (r.pending) return make_err(FSGPU_ERR_INVALID_CONFIG, "a search is in flight on this handle: end it first");
+    if (on) {
+        SH_TRY(ensure_quant_scale());   // the copies are built from ONE corpus-wide scale (simd.rs:1865-1886)
+        for (auto& s : shards_) {
+            if (!s->rows) continue;
+            SH_HIP(hipSetDevice(s->device));
+            SH_TRY(s->index.prepare_int8_latency());
+        }
+    }
+    for (auto& s : shards_) s->index.int8_latency = on;
+    return SearchError{};
+}
+
+uint32_t ShardedIndex::owner_of(uint64_t row) const {   // (the first group's copy of the row shard)
+    for (uint32_t r = 0; r < row_shards_ && r < shards_.size(); ++r)
         if (row >= shards_[r]->lo && row < shards_[r]->lo + shards_[r]->rows) return r;
     return (uint32_t)shards_.size();
 }
 
-// One host thread per shard: HIP's current device is per thread and the batched search blocks on its own stream.  A worker
-// runs its shard's scan call and records `scan_done` behind it; the exchange is the calling thread's business.
-void ShardedIndex::worker_main(uint32_t r) {
+// Rank r's share of a request, enqueued on its scan stream by the calling thread: its query group's slice of the batch against its
+// row shard, the result left packed — best-first [per, k] (global row ids, ~0 padding), or for the two-pass modes the candidate
+// pairs [2][per, cc] — and `scan_done` behind it.  The batched and two-pass searches go through their begin halves (their verdicts
+// are read in end()); the exact kernels are enqueue-only anyway.
+SearchError ShardedIndex::enqueue_scan(const Request& rq, uint32_t r, int slot) {
     Shard& s = *shards_[r];
-    (void)hipSetDevice(s.device);
-    uint64_t seen = 0;
-    for (;;) {
-        {
-            std::unique_lock<std::mutex> lk(mu_);
-            cv_work_.wait(lk, [&] { return generation_ != seen; });
-            seen = generation_;
-            if (stop_) return;
-        }
-        SearchError e;
-        try {
-            e = shard_search(s, r);
-        } catch (const std::exception& ex) {
-            e = make_err(FSGPU_ERR_DEVICE, ex.what());
-        } catch (...) {
-            e = make_err(FSGPU_ERR_DEVICE, "unknown exception in a shard worker");
-        }
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            if (!e.ok() && s.error.ok()) s.error = e;
-            if (--pending_ == 0) cv_done_.notify_one();
-        }
-    }
-}
-
-void ShardedIndex::run_scans() {
-    std::unique_lock<std::mutex> lk(mu_);
-    pending_ = (uint32_t)shards_.size();
-    ++generation_;
-    cv_work_.notify_all();
-    cv_done_.wait(lk, [&] { return pending_ == 0; });
-}
-
-// This shard's list(s) for the job: packed best-first [nq, k] (global row ids, ~0 padding) — or, for the two-pass modes, the
-// candidate pairs [2][nq, cc] — then `scan_done` on the scan stream: whatever the search call left enqueued (the batched path
-// returns with its fallback work only enqueued) is in front of it.
-SearchError ShardedIndex::shard_search(Shard& s, uint32_t r) {
-    const Job& j = job_;
-    Slot& sl = s.slot[j.slot];
-    const bool two_pass = j.mode == kInt8TwoPass || j.mode == kFourBitTwoPass;
-    const uint64_t cc = two_pass ? std::max<uint64_t>((uint64_t)j.k * (j.multiplier ? j.multiplier : 1), j.k) : j.k;
-    const size_t qbytes = (size_t)j.nq * dim_ * 4, lbytes = (size_t)j.nq * cc * 8 * (two_pass ? 2 : 1);
+    Slot& sl = s.slot[slot];
+    const RootSlot& rs = root_[slot];
+    const bool two_pass = rq.mode == kInt8TwoPass || rq.mode == kFourBitTwoPass;
+    const uint64_t cc = two_pass ? std::max<uint64_t>((uint64_t)rq.k * (rq.multiplier ? rq.multiplier : 1), rq.k) : rq.k;
+    const uint32_t per = rs.per, g = r / row_shards_, rsh = r % row_shards_;
+    const uint32_t q_lo = g * per, nqg = q_lo < rq.nq ? std::min(per, rq.nq - q_lo) : 0;
+    const size_t lbytes = (size_t)per * cc * 8 * (two_pass ? 2 : 1);
+    sl.ticket = -1;
     SH_HIP(hipSetDevice(s.device));
-    // host queries: every shard copies them over ITS OWN PCIe link from the pinned block (the copies run side by side); device
-    // queries: they are in the root's HBM already, the others fetch them peer to peer
-    const float* qd = static_cast<const float*>(sl.queries.ptr);
-    if (j.queries_dev) {
-        if (r == 0 || s.device == shards_[0]->device) qd = j.queries_dev;
-        else SH_HIP(hipMemcpyAsync(sl.queries.ptr, j.queries_dev, qbytes, hipMemcpyDeviceToDevice, s.stream));
-    } else {
-        SH_HIP(hipMemcpyAsync(sl.queries.ptr, j.queries, qbytes, hipMemcpyHostToDevice, s.stream));
-    }
-    const uint64_t* allow_dev = nullptr;
-    if (j.has_allow && s.rows) {
-        const RootSlot& rs = root_[j.slot];
-        size_t off = 0;
-        for (uint32_t x = 0; x < r; ++x) off += (size_t)((shards_[x]->rows + 63) / 64);
-        SH_HIP(hipMemcpyAsync(sl.allow.ptr, rs.allow_slices.data() + off, (size_t)((s.rows + 63) / 64) * 8, hipMemcpyHostToDevice, s.stream));
-        allow_dev = static_cast<const uint64_t*>(sl.allow.ptr);
-    }
-    s.fallbacks = 0;
     uint64_t* packed = static_cast<uint64_t*>(sl.packed.ptr);
-    if (s.rows == 0) {
-        SH_HIP(hipMemsetAsync(packed, 0xff, lbytes, s.stream));
-    } else if (two_pass) {
-        SH_TRY(s.index.two_pass_candidates_device(qd, j.nq, dim_, j.k, j.multiplier, j.mode == kFourBitTwoPass ? 4 : 8, packed,
-                                                  packed + (size_t)j.nq * cc, s.stream, &s.fallbacks));
-    } else if (j.mode == kBatched) {
-        SH_TRY(s.index.search_top_k_batched_device(qd, j.nq, dim_, j.k, allow_dev, nullptr, nullptr, nullptr, s.stream, &s.fallbacks,
-                                                   packed));
-    } else {
-        SH_TRY(s.index.search_top_k_packed_device(qd, j.nq, dim_, j.k, allow_dev, packed, s.stream));
+    if (nqg < per || s.rows == 0) SH_HIP(hipMemsetAsync(packed, 0xff, lbytes, s.stream));   // (queries this rank does not hold: empty lists)
+    if (nqg && s.rows) {
+        const size_t qbytes = (size_t)nqg * dim_ * 4;
+        // host queries: every rank copies its slice over ITS OWN PCIe link from the pinned block (the copies run side by side);
+        // device queries: in the root's HBM (or in parts on the encoders' devices): fetched peer to peer
+        const float* qd = static_cast<const float*>(sl.queries.ptr);
+        if (rq.n_parts) {
+            uint32_t at = 0;   // first query of the current part
+            for (uint32_t p = 0; p < rq.n_parts; ++p) {
+                const uint32_t lo = std::max(at, q_lo), hi = std::min(at + rq.part_counts[p], q_lo + nqg);
+                if (lo < hi) {
+                    const float* src = rq.parts_dev[p] + (size_t)(lo - at) * dim_;
+                    if (lo == q_lo && hi == q_lo + nqg && rq.part_devices[p] == s.device) {
+                        qd = src;   // the whole slice lies in one part on this very device: scanned in place
+                    } else {
+                        SH_HIP(hipMemcpyAsync(static_cast<float*>(sl.queries.ptr) + (size_t)(lo - q_lo) * dim_, src, (size_t)(hi - lo) * dim_ * 4,
+                                              hipMemcpyDeviceToDevice, s.stream));
+                    }
+                }
+                at += rq.part_counts[p];
+            }
+        } else if (rq.queries_dev) {
+            if (s.device == shards_[0]->device) qd = rq.queries_dev + (size_t)q_lo * dim_;
+            else SH_HIP(hipMemcpyAsync(sl.queries.ptr, rq.queries_dev + (size_t)q_lo * dim_, qbytes, hipMemcpyDeviceToDevice, s.stream));
+        } else {
+            SH_HIP(hipMemcpyAsync(sl.queries.ptr, static_cast<const float*>(rs.stage) + (size_t)q_lo * dim_, qbytes, hipMemcpyHostToDevice, s.stream));
+        }
+        const uint64_t* allow_dev = nullptr;
+        if (rq.allow) {
+            size_t off = 0;
+            for (uint32_t x = 0; x < rsh; ++x) off += (size_t)((shards_[x]->rows + 63) / 64);
+            SH_HIP(hipMemcpyAsync(sl.allow.ptr, rs.allow_slices.data() + off, (size_t)((s.rows + 63) / 64) * 8, hipMemcpyHostToDevice, s.stream));
+            allow_dev = static_cast<const uint64_t*>(sl.allow.ptr);
+        }
+        if (two_pass) {
+            SH_TRY(s.index.two_pass_candidates_device_begin(qd, nqg, dim_, rq.k, rq.multiplier, rq.mode == kFourBitTwoPass ? 4 : 8, packed,
+                                                            packed + (size_t)per * cc, s.stream, &sl.ticket));
+        } else if (rq.mode == kBatched) {
+            SH_TRY(s.index.search_top_k_batched_device_begin(qd, nqg, dim_, rq.k, allow_dev, nullptr, nullptr, nullptr, s.stream, packed, &sl.ticket));
+        } else {
+            SH_TRY(s.index.search_top_k_packed_device(qd, nqg, dim_, rq.k, allow_dev, packed, s.stream));
+        }
     }
     SH_HIP(hipEventRecord(sl.scan_done, s.stream));
     return SearchError{};
+}
+
+// Every rank's end half (the verdicts of its batched / two-pass search; the rare uncertified query answered by the exact kernels on
+// the rank's scan stream).  *late = queries answered that way: their lists were corrected after the exchange had been enqueued.
+SearchError ShardedIndex::end_scans(int slot, uint32_t* late) {
+    *late = 0;
+    const RootSlot& rs = root_[slot];
+    const bool two_pass = rs.mode == kInt8TwoPass || rs.mode == kFourBitTwoPass;
+    SearchError first;
+    for (auto& sp : shards_) {
+        Slot& sl = sp->slot[slot];
+        if (sl.ticket < 0) continue;
+        uint32_t fb = 0;
+        const SearchError e = two_pass ? sp->index.two_pass_candidates_device_end(sl.ticket, &fb)
+                                       : sp->index.search_top_k_batched_device_end(sl.ticket, &fb);
+        sl.ticket = -1;
+        if (!e.ok() && first.ok()) first = e;   // (every ticket is ended whatever the others reported)
+        *late += fb;
+    }
+    return first;
 }
 
 // The corpus-wide max-abs of the quantisers (simd.rs:1865-1886 computes ONE scale over the whole slab): every shard's own
@@ -403,17 +436,18 @@ SearchError ShardedIndex::ensure_quant_scale() {
     return SearchError{};
 }
 
-// The exchange + merge of one slot, enqueued by the calling thread with no host wait in between: every shard's exchange stream
-// waits for that shard's scan_done event; the lists travel (ncclAllGather inside ONE group call / peer copies into the root's
-// gather buffer); the root's exchange stream merges them and copies the hits into the slot's pinned block; `done` marks the end.
-SearchError ShardedIndex::enqueue_exchange(int slot, uint32_t nq, uint32_t k) {
+// The exchange + merge of one slot, enqueued by the calling thread with no host wait in between: every rank's exchange stream
+// waits for that rank's scan_done event; the lists travel (ncclAllGather inside ONE group call / peer copies into the root's
+// gather buffer); the root's exchange stream merges every query group's S lists and copies the hits into the slot's pinned block;
+// `done` marks the end.
+SearchError ShardedIndex::enqueue_exchange(int slot) {
     const uint32_t w = (uint32_t)shards_.size();
-    const Job& j = job_;
-    const bool two_pass = j.mode == kInt8TwoPass || j.mode == kFourBitTwoPass;
-    const uint64_t cc = two_pass ? std::max<uint64_t>((uint64_t)k * (j.multiplier ? j.multiplier : 1), k) : k;
-    const size_t count = (size_t)nq * cc * (two_pass ? 2 : 1), lbytes = count * 8;
-    Shard& root = *shards_[0];
     RootSlot& rs = root_[slot];
+    const uint32_t nq = rs.nq, k = rs.k, per = rs.per;
+    const bool two_pass = rs.mode == kInt8TwoPass || rs.mode == kFourBitTwoPass;
+    const uint64_t cc = two_pass ? std::max<uint64_t>((uint64_t)k * (rs.multiplier ? rs.multiplier : 1), k) : k;
+    const size_t count = (size_t)per * cc * (two_pass ? 2 : 1), lbytes = count * 8;   // one rank's list(s)
+    Shard& root = *shards_[0];
     for (uint32_t r = 0; r < w; ++r) {
         SH_HIP(hipSetDevice(shards_[r]->device));
         SH_HIP(hipStreamWaitEvent(shards_[r]->xstream, shards_[r]->slot[slot].scan_done, 0));
@@ -447,20 +481,27 @@ SearchError ShardedIndex::enqueue_exchange(int slot, uint32_t nq, uint32_t k) {
         SH_HIP(hipSetDevice(root.device));
         for (uint32_t r = 1; r < w; ++r) SH_HIP(hipStreamWaitEvent(root.xstream, shards_[r]->slot[slot].sent, 0));
     }
-    // merge_partial_heaps across shards (search.rs:1704-1720) on the root; one shard: its own list is the answer, the merge
-    // only unpacks it.  Two-pass modes: the corpus-wide candidate selection, then the exact top-k (launch_two_pass_merge).
+    // merge_partial_heaps across a group's row shards (search.rs:1704-1720) on the root; one row shard: its own list is the
+    // answer, the merge only unpacks it.  Two-pass modes: the corpus-wide candidate selection, then the exact top-k.
     SH_HIP(hipSetDevice(root.device));
     const uint64_t* lists = static_cast<const uint64_t*>(w > 1 ? root.slot[slot].gathered.ptr : root.slot[slot].packed.ptr);
     uint32_t* d_rows = static_cast<uint32_t*>(rs.out_rows.ptr);
     float* d_scores = static_cast<float*>(rs.out_scores.ptr);
     uint32_t* d_counts = static_cast<uint32_t*>(rs.out_counts.ptr);
-    if (two_pass) {
-        // gather layout: shard s's block [approx nq*cc | exact nq*cc] at s * 2*nq*cc
-        const u64* pairs = reinterpret_cast<const u64*>(lists);
-        SH_HIP(launch_two_pass_merge(pairs, pairs + (size_t)nq * cc, w, (uint64_t)2 * nq * cc, nq, (uint32_t)cc, k, k, d_rows, d_scores,
-                                     d_counts, root.xstream));
-    } else {
-        SH_TRY(merge_packed_lists_device(root.device, lists, nq, w, k, k, (uint64_t)nq * k, k, d_rows, d_scores, d_counts, root.xstream));
+    for (uint32_t g = 0; g < groups_; ++g) {
+        const uint32_t q_lo = g * per;
+        if (q_lo >= nq) break;
+        const uint32_t nqg = std::min(per, nq - q_lo);
+        const uint64_t* base = lists + (size_t)g * row_shards_ * count;   // rank g * S's list(s); the group's next S - 1 follow, `count` apart
+        if (two_pass) {
+            // a rank's block: [approx per * cc | exact per * cc]
+            const u64* pairs = reinterpret_cast<const u64*>(base);
+            SH_HIP(launch_two_pass_merge(pairs, pairs + (size_t)per * cc, row_shards_, (uint64_t)count, nqg, (uint32_t)cc, k, k,
+                                         d_rows + (size_t)q_lo * k, d_scores + (size_t)q_lo * k, d_counts + q_lo, root.xstream));
+        } else {
+            SH_TRY(merge_packed_lists_device(root.device, base, nqg, row_shards_, k, k, (uint64_t)count, k, d_rows + (size_t)q_lo * k,
+                                             d_scores + (size_t)q_lo * k, d_counts + q_lo, root.xstream));
+        }
     }
     const size_t qbytes = (size_t)nq * dim_ * 4, hbytes = (size_t)nq * k * 4, cbytes = (size_t)nq * 4;
     unsigned char* stage = static_cast<unsigned char*>(rs.stage);
@@ -468,6 +509,97 @@ SearchError ShardedIndex::enqueue_exchange(int slot, uint32_t nq, uint32_t k) {
     SH_HIP(hipMemcpyAsync(stage + qbytes + hbytes, d_scores, hbytes, hipMemcpyDeviceToHost, root.xstream));
     SH_HIP(hipMemcpyAsync(stage + qbytes + 2 * hbytes, d_counts, cbytes, hipMemcpyDeviceToHost, root.xstream));
     SH_HIP(hipEventRecord(rs.done, root.xstream));
+    return SearchError{};
+}
+
+// A lone query: one group's shards answer through their own latency lanes (VectorIndex::lone_*), all begun here.
+SearchError ShardedIndex::begin_lone(const Request& rq, int slot) {
+    RootSlot& rs = root_[slot];
+    rs.lone = true;
+    rs.lone_group = lone_rr_++ % groups_;
+    rs.lone_query.assign(rq.queries, rq.queries + dim_);
+    const bool two_pass = rq.mode == kInt8TwoPass || rq.mode == kFourBitTwoPass;
+    SearchError first;
+    uint32_t begun = 0;
+    for (uint32_t x = 0; x < row_shards_ && first.ok(); ++x) {
+        Shard& s = *shards_[rs.lone_group * row_shards_ + x];
+        first = two_pass ? s.index.lone_two_pass_begin(rs.lone_query.data(), rq.k, rq.multiplier, rq.mode == kFourBitTwoPass ? 4 : 8)
+                         : s.index.lone_exact_begin(rs.lone_query.data(), rq.k);
+        if (first.ok()) ++begun;
+    }
+    if (!first.ok()) {   // drain what was begun: a shard index holds one lone query at a time
+        std::vector<uint64_t> scratch(2 * 256);
+        std::vector<uint32_t> r32(rq.k + 1);
+        std::vector<float> f32(rq.k + 1);
+        uint32_t c = 0;
+        for (uint32_t x = 0; x < begun; ++x) {
+            Shard& s = *shards_[rs.lone_group * row_shards_ + x];
+            if (two_pass) (void)s.index.lone_two_pass_end(scratch.data(), scratch.data() + 256);
+            else (void)s.index.lone_exact_end(r32.data(), f32.data(), &c);
+        }
+        rs.lone = false;
+    }
+    return first;
+}
+
+// ... ended here, and merged on the host: exact = the k best of the shards' k-lists (merge_partial_heaps, search.rs:1704-1720);
+// two-pass = the cc best candidates by pass-1 key across the shards, re-keyed by their exact entries, the k best of those
+// (two_pass_merge_kernel's selection, on S x cc pairs).
+SearchError ShardedIndex::end_lone(RootSlot& rs, uint32_t* out_rows, float* out_scores, uint32_t* out_counts) {
+    const uint32_t k = rs.k;
+    const bool two_pass = rs.mode == kInt8TwoPass || rs.mode == kFourBitTwoPass;
+    const uint64_t cc = two_pass ? std::max<uint64_t>((uint64_t)k * (rs.multiplier ? rs.multiplier : 1), k) : k;
+    SearchError first;
+    std::vector<std::pair<uint64_t, uint64_t>> cand;   // (sort key to select by, the entry that is emitted)
+    std::vector<uint64_t> approx(cc), exact(cc);
+    std::vector<uint32_t> rows(k);
+    std::vector<float> scores(k);
+    for (uint32_t x = 0; x < row_shards_; ++x) {   // (every shard is ended, whatever the others reported)
+        Shard& s = *shards_[rs.lone_group * row_shards_ + x];
+        if (two_pass) {
+            const SearchError e = s.index.lone_two_pass_end(approx.data(), exact.data());
+            if (!e.ok()) {
+                if (first.ok()) first = e;
+                continue;
+            }
+            for (uint64_t i = 0; i < cc; ++i)
+                if (approx[i] != ~0ull && exact[i] != ~0ull) cand.emplace_back(host_sortkey(approx[i]), exact[i]);
+        } else {
+            uint32_t c = 0;
+            const SearchError e = s.index.lone_exact_end(rows.data(), scores.data(), &c);
+            if (!e.ok()) {
+                if (first.ok()) first = e;
+                continue;
+            }
+            for (uint32_t i = 0; i < c && i < k; ++i) {
+                uint32_t bits;
+                std::memcpy(&bits, &scores[i], 4);
+                const uint64_t entry = ((uint64_t)bits << 32) | rows[i];
+                cand.emplace_back(host_sortkey(entry), entry);
+            }
+        }
+    }
+    rs.lone = false;
+    if (!first.ok()) return first;
+    auto by_key = [](const std::pair<uint64_t, uint64_t>& a, const std::pair<uint64_t, uint64_t>& b) { return a.first > b.first; };
+    std::sort(cand.begin(), cand.end(), by_key);
+    if (two_pass) {
+        if (cand.size() > cc) cand.resize((size_t)cc);   // the corpus-wide pass-1 candidates ...
+        for (auto& c : cand) c.first = host_sortkey(c.second);   // ... re-keyed by their exact entries
+        std::sort(cand.begin(), cand.end(), by_key);
+    }
+    uint32_t n = 0;
+    for (; n < k && n < cand.size(); ++n) {
+        out_rows[n] = (uint32_t)cand[n].second;
+        const uint32_t bits = (uint32_t)(cand[n].second >> 32);
+        std::memcpy(&out_scores[n], &bits, 4);
+    }
+    for (uint32_t i = n; i < k; ++i) {   // the padding the device merge writes (kEmpty unpacked)
+        out_rows[i] = 0xffffffffu;
+        const uint32_t bits = 0xffffffffu;
+        std::memcpy(&out_scores[i], &bits, 4);
+    }
+    out_counts[0] = n;
     return SearchError{};
 }
 
@@ -481,9 +613,17 @@ SearchError ShardedIndex::begin(const Request& rq, uint32_t query_len, uint64_t*
     if (rq.nq && rq.k && nrows_) {
         if (dim_ % 8 != 0 || rq.k > 256)
             return make_err(FSGPU_ERR_INVALID_CONFIG, "the sharded search exchanges the fused tiers' packed lists: k <= 256 and dim % 8 == 0");
-        if (two_pass && (cc > 256 || cc * shards_.size() > 1024))
-            return make_err(FSGPU_ERR_INVALID_CONFIG, "sharded two-pass: k * multiplier <= 256 and shards * k * multiplier <= 1024");
+        if (two_pass && (cc > 256 || cc * row_shards_ > 1024))
+            return make_err(FSGPU_ERR_INVALID_CONFIG, "sharded two-pass: k * multiplier <= 256 and row shards * k * multiplier <= 1024");
         if (two_pass && rq.allow) return make_err(FSGPU_ERR_INVALID_CONFIG, "the two-pass searches take no filter (search.rs:514-661)");
+        if (rq.n_parts) {
+            if (!rq.parts_dev || !rq.part_counts || !rq.part_devices) return make_err(FSGPU_ERR_NULL_ARGUMENT, "query parts: pointers, counts and devices are required");
+            uint64_t total = 0;
+            for (uint32_t p = 0; p < rq.n_parts; ++p) total += rq.part_counts[p];
+            if (total != rq.nq) return make_err(FSGPU_ERR_INVALID_CONFIG, "query parts must add up to nq");
+        } else if (!rq.queries && !rq.queries_dev) {
+            return make_err(FSGPU_ERR_NULL_ARGUMENT, "queries is null");
+        }
     }
     const int slot = (int)(next_ticket_ % kSlots);
     RootSlot& rs = root_[slot];
@@ -494,6 +634,10 @@ SearchError ShardedIndex::begin(const Request& rq, uint32_t query_len, uint64_t*
     rs.k = rq.k;
     rs.fallbacks = 0;
     rs.ticket = next_ticket_;
+    rs.mode = rq.mode;
+    rs.multiplier = rq.multiplier;
+    rs.lone = false;
+    for (auto& s : shards_) s->slot[slot].ticket = -1;
     if (rq.nq == 0 || rq.k == 0 || nrows_ == 0) {   // nothing to enqueue: end() reports empty results
         rs.pending = true;
         rs.nq = rq.k == 0 || nrows_ == 0 ? rq.nq : 0;
@@ -502,6 +646,15 @@ SearchError ShardedIndex::begin(const Request& rq, uint32_t query_len, uint64_t*
         return SearchError{};
     }
     if (two_pass) SH_TRY(ensure_quant_scale());
+    if (rq.nq == 1 && rq.queries && !rq.queries_dev && !rq.n_parts && !rq.allow && rq.mode != kBatched) {
+        SH_TRY(begin_lone(rq, slot));
+        rs.pending = true;
+        *ticket = next_ticket_++;
+        return SearchError{};
+    }
+    // query groups: group g takes queries [g * per, (g + 1) * per) — the last groups may hold fewer, or none
+    const uint32_t per = (rq.nq + groups_ - 1) / groups_;
+    rs.per = per;
     // pinned staging: [queries | rows | scores | counts]
     const size_t qbytes = (size_t)rq.nq * dim_ * 4, hbytes = (size_t)rq.nq * rq.k * 4, cbytes = (size_t)rq.nq * 4;
     const size_t need = qbytes + 2 * hbytes + cbytes;
@@ -513,14 +666,14 @@ SearchError ShardedIndex::begin(const Request& rq, uint32_t query_len, uint64_t*
         SH_HIP(hipHostMalloc(&rs.stage, need, hipHostMallocPortable));
         rs.stage_bytes = need;
     }
-    if (!rq.queries_dev) std::memcpy(rs.stage, rq.queries, qbytes);
-    // EVERY reservation a shard or the exchange needs happens here, on the calling thread, before any work is enqueued: a
-    // failed allocation must not leave some ranks inside a collective that others never enter
-    const size_t lbytes = (size_t)rq.nq * cc * 8 * (two_pass ? 2 : 1);
+    if (!rq.queries_dev && !rq.n_parts) std::memcpy(rs.stage, rq.queries, qbytes);
+    // EVERY reservation a rank or the exchange needs happens here, before any work is enqueued: a failed allocation must not
+    // leave some ranks inside a collective that others never enter
+    const size_t lbytes = (size_t)per * cc * 8 * (two_pass ? 2 : 1);
     for (uint32_t r = 0; r < w; ++r) {
         Slot& sl = shards_[r]->slot[slot];
         SH_HIP(hipSetDevice(shards_[r]->device));
-        SH_TRY(sl.queries.reserve(qbytes));
+        SH_TRY(sl.queries.reserve((size_t)per * dim_ * 4));
         SH_TRY(sl.packed.reserve(lbytes));
         if (w > 1 && (use_rccl_ || r == 0)) SH_TRY(sl.gathered.reserve(lbytes * w));
         if (rq.allow && shards_[r]->rows) SH_TRY(sl.allow.reserve((size_t)((shards_[r]->rows + 63) / 64) * 8));
@@ -531,24 +684,18 @@ SearchError ShardedIndex::begin(const Request& rq, uint32_t query_len, uint64_t*
     SH_TRY(rs.out_counts.reserve(cbytes));
     rs.allow_slices.clear();
     if (rq.allow)
-        for (uint32_t r = 0; r < w; ++r) {
-            const std::vector<uint64_t> sl = shards_[r]->rows ? slice_bitmap(rq.allow, shards_[r]->lo, shards_[r]->rows) : std::vector<uint64_t>();
+        for (uint32_t x = 0; x < row_shards_; ++x) {
+            const std::vector<uint64_t> sl = shards_[x]->rows ? slice_bitmap(rq.allow, shards_[x]->lo, shards_[x]->rows) : std::vector<uint64_t>();
             rs.allow_slices.insert(rs.allow_slices.end(), sl.begin(), sl.end());
         }
-    job_.queries = static_cast<const float*>(rs.stage);
-    job_.queries_dev = rq.queries_dev;
-    job_.nq = rq.nq;
-    job_.k = rq.k;
-    job_.multiplier = rq.multiplier;
-    job_.mode = rq.mode;
-    job_.slot = slot;
-    job_.has_allow = rq.allow != nullptr;
-    for (auto& s : shards_) s->error = SearchError{};
-    run_scans();
-    for (auto& s : shards_)
-        if (!s->error.ok()) return s->error;   // nothing has entered a collective yet
-    for (auto& s : shards_) rs.fallbacks += s->fallbacks;
-    SH_TRY(enqueue_exchange(slot, rq.nq, rq.k));
+    SearchError first;
+    for (uint32_t r = 0; r < w && first.ok(); ++r) first = enqueue_scan(rq, r, slot);
+    if (!first.ok()) {   // nothing has entered a collective yet; the searches that were begun are ended so that their tickets are free again
+        uint32_t late = 0;
+        (void)end_scans(slot, &late);
+        return first;
+    }
+    SH_TRY(enqueue_exchange(slot));
     rs.pending = true;
     *ticket = next_ticket_++;
     return SearchError{};
@@ -564,8 +711,23 @@ SearchError ShardedIndex::end(uint64_t ticket, uint32_t* out_rows, float* out_sc
         for (uint32_t q = 0; q < rs.nq; ++q) out_counts[q] = 0;
         return SearchError{};
     }
+    if (rs.lone) return end_lone(rs, out_rows, out_scores, out_counts);
     SH_HIP(hipSetDevice(shards_[0]->device));
     SH_HIP(hipEventSynchronize(rs.done));
+    // the ranks' verdicts; a rank that had to answer an uncertified query did so on its scan stream AFTER its list had travelled:
+    // the corrected lists travel again (rare: the bench corpora never take this path)
+    uint32_t late = 0;
+    SH_TRY(end_scans(slot, &late));
+    rs.fallbacks = late;
+    if (late) {
+        for (auto& s : shards_) {
+            SH_HIP(hipSetDevice(s->device));
+            SH_HIP(hipEventRecord(s->slot[slot].scan_done, s->stream));
+        }
+        SH_TRY(enqueue_exchange(slot));
+        SH_HIP(hipSetDevice(shards_[0]->device));
+        SH_HIP(hipEventSynchronize(rs.done));
+    }
     const size_t qbytes = (size_t)rs.nq * dim_ * 4, hbytes = (size_t)rs.nq * rs.k * 4, cbytes = (size_t)rs.nq * 4;
     const unsigned char* stage = static_cast<const unsigned char*>(rs.stage);
     std::memcpy(out_rows, stage + qbytes, hbytes);

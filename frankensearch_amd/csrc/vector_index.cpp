@@ -170,7 +170,7 @@ VectorIndex::~VectorIndex() {
                             &ws_counts_, &ws_keys_a_, &ws_keys_b_, &ws_sort_tmp_, &ws_gather_rows_, &ws_gather_out_,
                             &i8_slab_, &n4_slab_, &i8_max_, &ws_i8_query_, &ws_cand_packed_, &ws_cand_rows_, &ws_cand_scores_,
                             &mf_max_norm_, &mf_qh_, &mf_delta_, &mf_tau_, &mf_cand_, &mf_dense_, &mf_sel_,
-                            &mf_fallback_, &mf_fallback2_, &mf_spill_, &mf_io_, &i8_stats_, &n4u_slab_, &mf_cand_count_})
+                            &mf_fallback_, &mf_fallback2_, &mf_spill_, &mf_io_, &mf_io2_, &i8_stats_, &n4u_slab_, &mf_cand_count_, &ws_pairs_})
         b->release();
     if (mf_flags_host_) (void)hipHostFree(mf_flags_host_);
     if (io_host_) (void)hipHostFree(io_host_);
@@ -227,6 +227,8 @@ SearchError VectorIndex::init_device(int device, uint32_t dim, uint64_t nrows, c
 }
 
 SearchError VectorIndex::set_live_bitmap(const uint64_t* live) {
+    if (async_state_[0] == 1 || async_state_[1] == 1)   // (its kernels read the live bitmap this call would rewrite)
+        return make_error(FSGPU_ERR_INVALID_CONFIG, "a begun batched search is outstanding on this index: end it first");
     if (!live) {
         live_dev_ = nullptr;
         live_host_.clear();
@@ -586,6 +588,8 @@ uint32_t host_score_ord(float score) {
 
 SearchError VectorIndex::wal_append(const char* doc_id, uint32_t len, const float* vector, uint32_t vector_len) {
     if (doc_offsets_.empty()) return make_error(FSGPU_ERR_INVALID_CONFIG, "index has no doc-id table");
+    if (async_state_[0] == 1 || async_state_[1] == 1)   // (its kernels read the live bitmap this call would rewrite)
+        return make_error(FSGPU_ERR_INVALID_CONFIG, "a begun batched search is outstanding on this index: end it first");
     if (vector_len != dim_)
         return make_error(FSGPU_ERR_DIMENSION_MISMATCH,
                           "expected " + std::to_string(dim_) + ", found " + std::to_string(vector_len));
@@ -714,6 +718,8 @@ float VectorIndex::wal_dot(size_t wal_index, const float* query) const {
 SearchError VectorIndex::soft_delete(const char* doc_id, uint32_t len, int32_t* deleted) {
     *deleted = 0;
     if (doc_offsets_.empty()) return make_error(FSGPU_ERR_INVALID_CONFIG, "index has no doc-id table");
+    if (async_state_[0] == 1 || async_state_[1] == 1)   // (its kernels read the live bitmap this call would rewrite)
+        return make_error(FSGPU_ERR_INVALID_CONFIG, "a begun batched search is outstanding on this index: end it first");
     const uint64_t h = fnv1a(doc_id, len);
     // rows are sorted by (hash, doc_id) (lib.rs:3758-3762): binary-search the hash run
     auto lo = std::lower_bound(doc_hashes_.begin(), doc_hashes_.end(), h);
@@ -994,6 +1000,12 @@ SearchError VectorIndex::search_top_k(const float* queries, uint32_t nq, uint32_
     FSGPU_HIP(hipSetDevice(device_));
     const size_t qbytes = (size_t)nq * dim_ * 4;
     FSGPU_TRY(ws_queries_.reserve(qbytes));
+    // A lone query without a filter: the two halves below (certified int8 pass / staged filter path / exact kernels with the query in
+    // the argument block), begun and ended at once.
+    if (nq == 1 && !allow) {
+        FSGPU_TRY(lone_exact_begin(queries, k));
+        return lone_exact_end(out_rows, out_scores, out_counts);
+    }
     // Latency path (a few queries, no filter): the queries go through a pinned staging block (true DMA instead of the
     // runtime's pageable-copy staging) and the last merge writes the hits straight into pinned host memory, so the call is
     // one H2D copy, the kernels and one stream synchronisation — no D2H copies (they cost ~90 us per call, measured).
@@ -1008,42 +1020,15 @@ SearchError VectorIndex::search_top_k(const float* queries, uint32_t nq, uint32_
         // exact kernel's pass; anything that path does not cover falls through to the exact kernels inside it
         const bool via_filter = int8_latency && batched_filter != 1 && !i8f_disabled_ && k <= 64 && nq <= 16 && !f32_ &&
                                 !(row_stride_ && row_stride_ != dim_ * 2) && nrows_ >= 4 * 8192ull;
-        // a lone query of a fused-kernel shape travels in the scan kernel's argument block: no H2D copy in front of the scan
-        const uint32_t k_lat = (uint64_t)k < nrows_ ? k : (uint32_t)nrows_;
-        const bool in_kernarg = nq == 1 && !via_filter && !f32_ && dim_ % 8 == 0 && k_lat <= 256 && variant == 0 &&
-                                scan_kernarg_query_supported((int)dim_, k_lat <= 64 ? 64 : 256);
-        if (via_filter && nq == 1 && k <= 32 && i8_ready_ && i8_stats_ready_ && variant == 0) {
-            // A failed certificate costs a whole pass over the int8 copy (a query with more rows inside the margin than the finish
-            // holds, or so many in one block's share that its list dropped one), so the single pass backs off: after a failure the
-            // next 1, 2, 4 ... 64 lone queries go straight to the staged path; a success resets it.
-            // (the pass reads the query from the pinned staging block itself: no H2D copy in front of it)
-            if (cert_skip_ > 0) {
-                --cert_skip_;
-            } else {
-                bool certified = false;
-                FSGPU_TRY(certified_i8_lone_query(queries, k, out_rows, out_scores, out_counts, &certified));
-                if (certified) {
-                    cert_backoff_ = 0;
-                    return ok();
-                }
-                cert_backoff_ = cert_backoff_ ? std::min<uint32_t>(cert_backoff_ * 2, 64) : 1;
-                cert_skip_ = cert_backoff_;
-            }
-        }
-        if (!in_kernarg) {
-            std::memcpy(q_pin, queries, qbytes);
-            FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, q_pin, qbytes, hipMemcpyHostToDevice, stream_));
-        }
+        std::memcpy(q_pin, queries, qbytes);
+        FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, q_pin, qbytes, hipMemcpyHostToDevice, stream_));
         if (via_filter) {
             uint32_t fb = 0;
             FSGPU_TRY(search_top_k_batched_device(static_cast<const float*>(ws_queries_.ptr), nq, query_len, k, nullptr, rows_pin,
                                                   scores_pin, counts_pin, stream_, &fb));
         } else {
-            host_query_hint_ = in_kernarg ? queries : nullptr;
-            const SearchError se = search_top_k_device(static_cast<const float*>(ws_queries_.ptr), nq, query_len, k, nullptr, rows_pin,
-                                                       scores_pin, counts_pin, stream_);
-            host_query_hint_ = nullptr;
-            FSGPU_TRY(se);
+            FSGPU_TRY(search_top_k_device(static_cast<const float*>(ws_queries_.ptr), nq, query_len, k, nullptr, rows_pin,
+                                          scores_pin, counts_pin, stream_));
         }
         FSGPU_HIP(hipStreamSynchronize(stream_));
         std::memcpy(out_rows, rows_pin, (size_t)nq * k * 4);
@@ -1120,16 +1105,23 @@ SearchError VectorIndex::search_top_k(const float* queries, uint32_t nq, uint32_
 // idot >= idot_k - 2 delta, and the kept list is exactly the 256 largest idot.
 SearchError VectorIndex::certified_i8_lone_query(const float* query, uint32_t k, uint32_t* out_rows, float* out_scores,
                                                  uint32_t* out_count, bool* certified) {
-    // Four launches behind one another, no copy, ONE synchronisation (the query and every result live in the pinned staging block,
-    // which the kernels address directly):
-    //   prepare   the query quantised as the filter does + its proven bound delta
-    //   scan      the int8 copy, every block keeps its LK best (integer score, row) entries
-    //   cut       the best score any block may have DROPPED: the maximum over the full lists' last entries
-    //   finish    select_kernel: tau = (k-th best approximate score) - 2 delta, the entries at or above it re-scored in the reference's
-    //             order from the f16 slab, the k best exact entries out
-    // The answer is the exact search's when every row whose approximate score reaches tau was in some list: cut < tau (a list that
-    // is not full dropped nothing), no more candidates than the finish holds, delta >= 0.  Otherwise the caller's staged path answers.
     *certified = false;
+    bool enqueued = false;
+    FSGPU_TRY(certified_i8_enqueue(query, k, &enqueued));
+    if (!enqueued) return ok();
+    return certified_i8_check(out_rows, out_scores, out_count, certified);
+}
+
+// Four launches behind one another, no copy (the query and every result live in the pinned staging block, which the kernels address
+// directly); nothing is waited for:
+//   prepare   the query quantised as the filter does + its proven bound delta
+//   scan      the int8 copy, every block keeps its LK best (integer score, row) entries
+//   cut       the best score any block may have DROPPED: the maximum over the full lists' last entries
+//   finish    select_kernel: tau = (k-th best approximate score) - 2 delta, the entries at or above it re-scored in the reference's
+//             order from the f16 slab, the k best exact entries out
+// *enqueued = false: a shape the pass does not cover, nothing was launched.
+SearchError VectorIndex::certified_i8_enqueue(const float* query, uint32_t k, bool* enqueued) {
+    *enqueued = false;
     constexpr uint32_t LK = 32;
     const uint32_t k_eff = (uint32_t)std::min<uint64_t>(k, nrows_);
     if (k_eff == 0 || k_eff > LK || nrows_ < 4096 || (dim_ & 7) || !scan_i8_fused_supported((int)dim_, 64) || pinned_io() == nullptr) return ok();
@@ -1197,17 +1189,170 @@ SearchError VectorIndex::certified_i8_lone_query(const float* query, uint32_t k,
     f.out_scores = reinterpret_cast<float*>(io + o_out + (size_t)k * 4);
     f.out_counts = reinterpret_cast<uint32_t*>(io + o_out + (size_t)k * 8);
     FSGPU_HIP(launch_select(f, 1, stream_));
+    cert_k_ = k;
+    *enqueued = true;
+    return ok();
+}
+
+// The other half: ONE synchronisation, then the certificate.  The answer is the exact search's when every row whose approximate score
+// reaches tau was in some list: cut < tau (a list that is not full dropped nothing), no more candidates than the finish holds,
+// delta >= 0.  Otherwise nothing is written and the caller's staged path answers.
+SearchError VectorIndex::certified_i8_check(uint32_t* out_rows, float* out_scores, uint32_t* out_count, bool* certified) {
+    *certified = false;
+    const uint32_t k = cert_k_;
+    const uint32_t k_eff = (uint32_t)std::min<uint64_t>(k, nrows_);
+    const size_t qbytes = (size_t)dim_ * 4;
+    const size_t o_out = (qbytes + 255) & ~(size_t)255, o_flags = (o_out + (size_t)k * 8 + 4 + 255) & ~(size_t)255;
+    unsigned char* io = static_cast<unsigned char*>(io_host_);
+    const float* delta_pin = reinterpret_cast<const float*>(io + o_flags);
+    const uint32_t* ncand_pin = reinterpret_cast<const uint32_t*>(delta_pin + 3);
+    const uint32_t* overflow_pin = reinterpret_cast<const uint32_t*>(delta_pin + 4);
+    const uint32_t* rows_pin = reinterpret_cast<const uint32_t*>(io + o_out);
+    const float* scores_pin = reinterpret_cast<const float*>(io + o_out + (size_t)k * 4);
+    const uint32_t* count_pin = reinterpret_cast<const uint32_t*>(io + o_out + (size_t)k * 8);
+    FSGPU_HIP(hipSetDevice(device_));
     FSGPU_HIP(hipStreamSynchronize(stream_));
-    const float delta = *delta_pin, tau = *tau_pin, cut = *cut_pin;
+    const float delta = delta_pin[0], tau = delta_pin[1], cut = delta_pin[2];
     if (!(delta >= 0.f)) return ok();   // a query the bound cannot cover (zero, non-finite, a slab with non-finite values)
     if (*overflow_pin != 0 || *ncand_pin > kSelectPool) return ok();   // more rows within the margin than the finish re-scores
     if (!(cut < tau)) return ok();      // a block may have dropped a row within the margin (NaN compares false: not certified)
-    if (*f.out_counts < k_eff) return ok();
-    std::memcpy(out_rows, f.out_rows, (size_t)k * 4);
-    std::memcpy(out_scores, f.out_scores, (size_t)k * 4);
-    *out_count = *f.out_counts;
+    if (*count_pin < k_eff) return ok();
+    std::memcpy(out_rows, rows_pin, (size_t)k * 4);
+    std::memcpy(out_scores, scores_pin, (size_t)k * 4);
+    *out_count = *count_pin;
     ++i8f_queries;
     *certified = true;
+    return ok();
+}
+
+// ---- a lone query in two halves (vector_index.hpp) ------------------------------------------------------------------------
+//
+// search_top_k for ONE host query without a filter: begin enqueues on the index's own stream and returns, end waits and writes the
+// hits.  What begin picks — the certified int8 pass, the staged filter path, the exact kernels — is what search_top_k always picked
+// for a lone caller; a row-sharded handle begins the query on every shard before it ends any.
+SearchError VectorIndex::lone_exact_begin(const float* query, uint32_t k) {
+    lone_ = LoneState{};
+    lone_.query = query;
+    lone_.k = k;
+    if (k == 0 || nrows_ == 0) {
+        lone_.kind = kLoneEmpty;
+        return ok();
+    }
+    FSGPU_HIP(hipSetDevice(device_));
+    const size_t qbytes = (size_t)dim_ * 4;
+    FSGPU_TRY(ws_queries_.reserve(qbytes));
+    const size_t io_need = qbytes + (size_t)k * 8 + 4 + 256;
+    if (io_need > kPinnedIoBytes || pinned_io() == nullptr) {
+        lone_.kind = kLoneUnpinned;
+        return ok();
+    }
+    unsigned char* io = static_cast<unsigned char*>(io_host_);
+    float* q_pin = reinterpret_cast<float*>(io);
+    uint32_t* rows_pin = reinterpret_cast<uint32_t*>(io + ((qbytes + 63) & ~(size_t)63));
+    float* scores_pin = reinterpret_cast<float*>(rows_pin + k);
+    uint32_t* counts_pin = reinterpret_cast<uint32_t*>(scores_pin + k);
+    // opted in (fsgpu_index_set_int8_latency): the same hits through the int8 filter + exact re-score — half the bytes of the
+    // exact kernel's pass; anything that path does not cover falls through to the exact kernels inside it
+    const bool via_filter = int8_latency && batched_filter != 1 && !i8f_disabled_ && k <= 64 && !f32_ &&
+                            !(row_stride_ && row_stride_ != dim_ * 2) && nrows_ >= 4 * 8192ull;
+    // a lone query of a fused-kernel shape travels in the scan kernel's argument block: no H2D copy in front of the scan
+    const uint32_t k_lat = (uint64_t)k < nrows_ ? k : (uint32_t)nrows_;
+    const bool in_kernarg = !via_filter && !f32_ && dim_ % 8 == 0 && k_lat <= 256 && variant == 0 &&
+                            scan_kernarg_query_supported((int)dim_, k_lat <= 64 ? 64 : 256);
+    if (via_filter && k <= 32 && i8_ready_ && i8_stats_ready_ && variant == 0) {
+        // A failed certificate costs a whole pass over the int8 copy (a query with more rows inside the margin than the finish
+        // holds, or so many in one block's share that its list dropped one), so the single pass backs off: after a failure the
+        // next 1, 2, 4 ... 64 lone queries go straight to the staged path; a success resets it.
+        // (the pass reads the query from the pinned staging block itself: no H2D copy in front of it)
+        if (cert_skip_ > 0) {
+            --cert_skip_;
+        } else {
+            bool enqueued = false;
+            FSGPU_TRY(certified_i8_enqueue(query, k, &enqueued));
+            if (enqueued) {
+                lone_.kind = kLoneCertified;
+                return ok();
+            }
+        }
+    }
+    if (via_filter && async_state_[0] != 0 && async_state_[1] != 0) {   // both tickets of the staged path are out: end() answers, blocking
+        lone_.kind = kLoneStagedBlocking;
+        return ok();
+    }
+    if (!in_kernarg) {
+        std::memcpy(q_pin, query, qbytes);
+        FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, q_pin, qbytes, hipMemcpyHostToDevice, stream_));
+    }
+    if (via_filter) {
+        FSGPU_TRY(search_top_k_batched_device_begin(static_cast<const float*>(ws_queries_.ptr), 1, dim_, k, nullptr, rows_pin, scores_pin,
+                                                    counts_pin, stream_, nullptr, &lone_.ticket));
+        lone_.kind = kLoneStaged;
+    } else {
+        host_query_hint_ = in_kernarg ? query : nullptr;
+        const SearchError se = search_top_k_device(static_cast<const float*>(ws_queries_.ptr), 1, dim_, k, nullptr, rows_pin, scores_pin,
+                                                   counts_pin, stream_);
+        host_query_hint_ = nullptr;
+        FSGPU_TRY(se);
+        lone_.kind = kLoneExact;
+    }
+    return ok();
+}
+
+SearchError VectorIndex::lone_exact_end(uint32_t* out_rows, float* out_scores, uint32_t* out_count) {
+    const LoneState st = lone_;
+    lone_ = LoneState{};
+    const uint32_t k = st.k;
+    if (st.kind == kLoneEmpty) {
+        *out_count = 0;
+        return ok();
+    }
+    if (st.kind == kLoneNone) return make_error(FSGPU_ERR_INVALID_CONFIG, "no lone query was begun on this index");
+    FSGPU_HIP(hipSetDevice(device_));
+    const size_t qbytes = (size_t)dim_ * 4;
+    if (st.kind == kLoneUnpinned) {   // no pinned staging block: pageable copies either side of the exact kernels
+        FSGPU_TRY(ws_rows_.reserve((size_t)k * 4));
+        FSGPU_TRY(ws_scores_.reserve((size_t)k * 4));
+        FSGPU_TRY(ws_counts_.reserve(4));
+        FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, st.query, qbytes, hipMemcpyHostToDevice, stream_));
+        FSGPU_TRY(search_top_k_device(static_cast<const float*>(ws_queries_.ptr), 1, dim_, k, nullptr, static_cast<uint32_t*>(ws_rows_.ptr),
+                                      static_cast<float*>(ws_scores_.ptr), static_cast<uint32_t*>(ws_counts_.ptr), stream_));
+        FSGPU_HIP(hipMemcpyAsync(out_rows, ws_rows_.ptr, (size_t)k * 4, hipMemcpyDeviceToHost, stream_));
+        FSGPU_HIP(hipMemcpyAsync(out_scores, ws_scores_.ptr, (size_t)k * 4, hipMemcpyDeviceToHost, stream_));
+        FSGPU_HIP(hipMemcpyAsync(out_count, ws_counts_.ptr, 4, hipMemcpyDeviceToHost, stream_));
+        FSGPU_HIP(hipStreamSynchronize(stream_));
+        return ok();
+    }
+    unsigned char* io = static_cast<unsigned char*>(io_host_);
+    float* q_pin = reinterpret_cast<float*>(io);
+    uint32_t* rows_pin = reinterpret_cast<uint32_t*>(io + ((qbytes + 63) & ~(size_t)63));
+    float* scores_pin = reinterpret_cast<float*>(rows_pin + k);
+    uint32_t* counts_pin = reinterpret_cast<uint32_t*>(scores_pin + k);
+    bool staged_blocking = st.kind == kLoneStagedBlocking;
+    if (st.kind == kLoneCertified) {
+        bool certified = false;
+        FSGPU_TRY(certified_i8_check(out_rows, out_scores, out_count, &certified));
+        if (certified) {
+            cert_backoff_ = 0;
+            return ok();
+        }
+        cert_backoff_ = cert_backoff_ ? std::min<uint32_t>(cert_backoff_ * 2, 64) : 1;
+        cert_skip_ = cert_backoff_;
+        staged_blocking = true;
+    }
+    if (staged_blocking) {   // the staged filter path, in one piece
+        std::memcpy(q_pin, st.query, qbytes);
+        FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, q_pin, qbytes, hipMemcpyHostToDevice, stream_));
+        uint32_t fb = 0;
+        FSGPU_TRY(search_top_k_batched_device(static_cast<const float*>(ws_queries_.ptr), 1, dim_, k, nullptr, rows_pin, scores_pin, counts_pin,
+                                              stream_, &fb));
+    } else if (st.kind == kLoneStaged) {
+        uint32_t fb = 0;
+        FSGPU_TRY(search_top_k_batched_device_end(st.ticket, &fb));
+    }
+    FSGPU_HIP(hipStreamSynchronize(stream_));
+    std::memcpy(out_rows, rows_pin, (size_t)k * 4);
+    std::memcpy(out_scores, scores_pin, (size_t)k * 4);
+    *out_count = *counts_pin;
     return ok();
 }
 
@@ -1285,6 +1430,33 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
     }
     return batched_impl(queries_dev, nq, query_len, k, allow_dev, out_rows_dev, out_scores_dev, out_counts_dev, stream,
                         fallbacks, out_packed_dev, 0, 0, false, nullptr);
+}
+
+// The int8 copy of the slab and its statistics (what the certified lone-query pass and the int8 filter read), built NOW instead of by
+// the first batched search: a row-sharded handle switches its shards to the int8 latency path in one go.
+SearchError VectorIndex::prepare_int8_latency() {
+    const bool strided = row_stride_ && row_stride_ != dim_ * 2;
+    if (f32_ || strided || nrows_ < 4 * 8192ull || !scan_mfma_supported((int)dim_) || i8f_disabled_) return ok();
+    FSGPU_HIP(hipSetDevice(device_));
+    if (!i8_ready_) {
+        if (!i8_slab_.reserve((size_t)nrows_ * dim_).ok()) {   // no room for the copy: the f16 paths need none
+            (void)hipGetLastError();
+            i8f_disabled_ = true;
+            return ok();
+        }
+        FSGPU_TRY(i8_max_.reserve(4));
+        FSGPU_HIP(launch_quantize_slab_i8(slab_dev_, (size_t)nrows_ * dim_, static_cast<unsigned int*>(i8_max_.ptr), i8_slab_.ptr, stream_,
+                                          quant_max_ready_));
+        i8_ready_ = true;
+    }
+    if (!i8_stats_ready_) {
+        FSGPU_TRY(i8_stats_.reserve(16));
+        FSGPU_HIP(launch_i8_slab_stats(slab_dev_, i8_slab_.ptr, (uint32_t)nrows_, dim_, static_cast<const unsigned int*>(i8_max_.ptr),
+                                       static_cast<unsigned int*>(i8_stats_.ptr), stream_));
+        i8_stats_ready_ = true;
+    }
+    FSGPU_HIP(hipStreamSynchronize(stream_));
+    return ok();
 }
 
 // What a batch's verdicts teach the index about its int8 filter.
@@ -1392,7 +1564,23 @@ SearchError VectorIndex::search_top_k_int8_batched_device(const float* queries_d
 SearchError VectorIndex::two_pass_candidates_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
                                                     uint32_t multiplier, int bits, uint64_t* approx_out_dev, uint64_t* exact_out_dev,
                                                     hipStream_t stream, uint32_t* fallbacks) {
-    if (fallbacks) *fallbacks = 0;
+    int32_t ticket = -1;
+    FSGPU_TRY(two_pass_candidates_device_begin(queries_dev, nq, query_len, k, multiplier, bits, approx_out_dev, exact_out_dev, stream, &ticket));
+    FSGPU_TRY(two_pass_candidates_device_end(ticket, fallbacks));
+    if (nq) {
+        FSGPU_HIP(hipSetDevice(device_));
+        FSGPU_HIP(hipStreamSynchronize(stream));
+    }
+    return ok();
+}
+
+// ... in two halves, like search_top_k_batched_device_begin / _end (the same two tickets): begin enqueues pass 1, the candidate
+// selection and the exact re-score; end waits for that search's event and answers what the batch could not (list overflow: a pile of
+// tied integer scores at the threshold) per query.  ticket -1: nothing was enqueued that end would have to wait for.
+SearchError VectorIndex::two_pass_candidates_device_begin(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
+                                                          uint32_t multiplier, int bits, uint64_t* approx_out_dev, uint64_t* exact_out_dev,
+                                                          hipStream_t stream, int32_t* ticket) {
+    *ticket = -1;
     FSGPU_TRY(ensure_query_dimension(query_len));
     if (nq == 0) return ok();
     const uint64_t mult = multiplier ? multiplier : 1;
@@ -1401,24 +1589,46 @@ SearchError VectorIndex::two_pass_candidates_device(const float* queries_dev, ui
     FSGPU_HIP(hipSetDevice(device_));
     FSGPU_HIP(hipMemsetAsync(approx_out_dev, 0xff, (size_t)nq * cc * 8, stream));
     FSGPU_HIP(hipMemsetAsync(exact_out_dev, 0xff, (size_t)nq * cc * 8, stream));
-    if (nrows_ == 0 || f32_) {
-        FSGPU_HIP(hipStreamSynchronize(stream));
-        return f32_ ? make_error(FSGPU_ERR_INVALID_CONFIG, "two-pass searches need an F16 slab") : ok();
-    }
-    FSGPU_TRY(mf_io_.reserve((size_t)nq * (k * 8 + 4)));   // the shard-local top-k the pass also produces (not used by the root)
-    uint32_t* rows = static_cast<uint32_t*>(mf_io_.ptr);
+    if (f32_) return make_error(FSGPU_ERR_INVALID_CONFIG, "two-pass searches need an F16 slab");
+    if (nrows_ == 0) return ok();
+    int t = -1;
+    for (int i = 0; i < 2; ++i)
+        if (async_state_[i] == 0) {
+            t = i;
+            break;
+        }
+    if (t < 0) return make_error(FSGPU_ERR_INVALID_CONFIG, "two begun batched searches are outstanding: end one first");
+    // the shard-local top-k the pass also produces (not used by the root): one area per ticket
+    DeviceBuffer& io = t == 0 ? mf_io_ : mf_io2_;
+    FSGPU_TRY(io.reserve((size_t)nq * (k * 8 + 4)));
+    uint32_t* rows = static_cast<uint32_t*>(io.ptr);
     float* scores = reinterpret_cast<float*>(rows + (size_t)nq * k);
     uint32_t* counts = reinterpret_cast<uint32_t*>(scores + (size_t)nq * k);
+    async_state_[t] = 2;
+    async_i8f_[t] = false;
+    async_nq_[t] = nq;
+    async_fb_[t] = 0;
+    async_want_ = t;
     tp_approx_out_ = reinterpret_cast<u64*>(approx_out_dev);
     tp_exact_out_ = reinterpret_cast<u64*>(exact_out_dev);
     tp_stride_ = (uint32_t)cc;
-    const SearchError e = batched_impl(queries_dev, nq, query_len, k, nullptr, rows, scores, counts, stream, fallbacks, nullptr,
+    const SearchError e = batched_impl(queries_dev, nq, query_len, k, nullptr, rows, scores, counts, stream, &async_fb_[t], nullptr,
                                        (uint32_t)mult, 0, false, nullptr, bits == 4 ? 4 : 8);
     tp_approx_out_ = tp_exact_out_ = nullptr;
     tp_stride_ = 0;
-    FSGPU_TRY(e);
-    FSGPU_HIP(hipStreamSynchronize(stream));
+    async_want_ = -1;
+    if (!e.ok()) {
+        async_state_[t] = 0;
+        return e;
+    }
+    *ticket = t;
     return ok();
+}
+
+SearchError VectorIndex::two_pass_candidates_device_end(int32_t ticket, uint32_t* fallbacks) {
+    if (fallbacks) *fallbacks = 0;
+    if (ticket < 0) return ok();
+    return search_top_k_batched_device_end(ticket, fallbacks);
 }
 
 // ---- the batched (matrix-core) search: prepare -> per round { sample -> main -> finish } -> fallback -------------------------
@@ -1463,6 +1673,9 @@ struct VectorIndex::BatchedPlan {
     u64 *spill = nullptr, *pool = nullptr;
     uint32_t* spill_count = nullptr;
     bool big_pool_last = false;       // the last round's finish had the second-chance launch (debug print only)
+    // two_pass_candidates_device: where this batch leaves its candidate pairs (a parked plan's fallback needs them in _end too)
+    u64 *tp_approx = nullptr, *tp_exact = nullptr;
+    uint32_t tp_stride = 0;
 };
 
 // One round: up to QCAP queries — the sample stages and every selection are single launches over all its query groups, only the
@@ -1513,10 +1726,21 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
     p.bits = bits;
     p.i8f = i8_filter && int8_mult == 0;
     p.i8 = int8_mult != 0 || p.i8f;
+    p.tp_approx = tp_approx_out_;
+    p.tp_exact = tp_exact_out_;
+    p.tp_stride = tp_stride_;
     if (refiltered) *refiltered = 0;
     if (fallbacks) *fallbacks = 0;
     FSGPU_TRY(ensure_query_dimension(query_len));
     if (nq == 0) return ok();
+    // Every batched search of this index — begun or blocking — works in ONE set of device workspaces (thresholds, candidate lists,
+    // spill areas, prepared queries): a search on another stream than an outstanding ticket's is ordered behind that ticket's last
+    // kernel (searches on the same stream queue behind it by themselves).
+    for (int t = 0; t < 2; ++t)
+        if (async_state_[t] == 1 && async_stream_[t] != stream && async_ev_[t]) {
+            FSGPU_HIP(hipSetDevice(device_));
+            FSGPU_HIP(hipStreamWaitEvent(stream, async_ev_[t], 0));
+        }
     bool done = false;
     FSGPU_TRY(batched_prepare(p, &done));
     if (done) return ok();
@@ -1547,6 +1771,7 @@ SearchError VectorIndex::batched_impl(const float* queries_dev, uint32_t nq, uin
         // are read by work that is ordered behind them on the GPU, or through copies that bring their own release.)
         if (!async_ev_[t]) FSGPU_HIP(hipEventCreateWithFlags(&async_ev_[t], hipEventDisableTiming | hipEventReleaseToDevice));
         FSGPU_HIP(hipEventRecord(async_ev_[t], p.stream));
+        async_stream_[t] = p.stream;
         async_state_[t] = 1;
         return ok();
     }
@@ -1734,8 +1959,8 @@ SearchError VectorIndex::batched_unusable(BatchedPlan& p) {
         FSGPU_HIP(hipStreamSynchronize(stream));
         for (uint32_t i = 0; i < nq; ++i)
             FSGPU_TRY(quantized_two_pass(q.data() + (size_t)i * dim_, dim_, k, p.int8_mult, p.bits, rw.data() + (size_t)i * k,
-                                         sc.data() + (size_t)i * k, &cnt[i], tp_approx_out_ ? tp_approx_out_ + (size_t)i * tp_stride_ : nullptr,
-                                         tp_exact_out_ ? tp_exact_out_ + (size_t)i * tp_stride_ : nullptr));
+                                         sc.data() + (size_t)i * k, &cnt[i], p.tp_approx ? p.tp_approx + (size_t)i * p.tp_stride : nullptr,
+                                         p.tp_exact ? p.tp_exact + (size_t)i * p.tp_stride : nullptr));
         if (p.out_rows_dev) FSGPU_HIP(hipMemcpyAsync(p.out_rows_dev, rw.data(), rw.size() * 4, hipMemcpyHostToDevice, stream));
         if (p.out_scores_dev) FSGPU_HIP(hipMemcpyAsync(p.out_scores_dev, sc.data(), sc.size() * 4, hipMemcpyHostToDevice, stream));
         if (p.out_counts_dev) FSGPU_HIP(hipMemcpyAsync(p.out_counts_dev, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice, stream));
@@ -2152,10 +2377,10 @@ SearchError VectorIndex::batched_finish(BatchedPlan& p, BatchedRound& r) {
     sb.out_scores = p.out_scores_dev ? p.out_scores_dev + (size_t)g0 * k : nullptr;
     sb.out_counts = p.out_counts_dev ? p.out_counts_dev + g0 : nullptr;
     sb.out_packed = p.out_packed_dev ? reinterpret_cast<u64*>(p.out_packed_dev) + (size_t)g0 * k : nullptr;
-    if (p.int8_mult && tp_approx_out_) {   // a sharded index's shard: the candidate pairs themselves (two_pass_candidates_device)
-        sb.cand_approx_out = tp_approx_out_ + (size_t)g0 * tp_stride_;
-        sb.cand_exact_out = tp_exact_out_ + (size_t)g0 * tp_stride_;
-        sb.cand_out_stride = tp_stride_;
+    if (p.int8_mult && p.tp_approx) {   // a sharded index's shard: the candidate pairs themselves (two_pass_candidates_device)
+        sb.cand_approx_out = p.tp_approx + (size_t)g0 * p.tp_stride;
+        sb.cand_exact_out = p.tp_exact + (size_t)g0 * p.tp_stride;
+        sb.cand_out_stride = p.tp_stride;
     }
 #ifdef FSGPU_EXPERIMENTS
     static unsigned long long* sel_stamps = nullptr;   // FSGPU_SELECT_STAMPS=1: shader clocks of the phases of blocks 0, 256, 512, 768 of the finish
@@ -2218,8 +2443,8 @@ SearchError VectorIndex::batched_fallback(BatchedPlan& p, bool already_waited) {
             FSGPU_HIP(hipStreamSynchronize(stream));
             std::fill(rw.begin(), rw.end(), 0xffffffffu);
             FSGPU_TRY(quantized_two_pass(qh.data(), dim_, k, p.int8_mult, p.bits, rw.data(), sc.data(), &cnt,
-                                         tp_approx_out_ ? tp_approx_out_ + (size_t)i * tp_stride_ : nullptr,
-                                         tp_exact_out_ ? tp_exact_out_ + (size_t)i * tp_stride_ : nullptr));
+                                         p.tp_approx ? p.tp_approx + (size_t)i * p.tp_stride : nullptr,
+                                         p.tp_exact ? p.tp_exact + (size_t)i * p.tp_stride : nullptr));
             if (p.out_rows_dev) FSGPU_HIP(hipMemcpyAsync(p.out_rows_dev + (size_t)i * k, rw.data(), (size_t)k * 4, hipMemcpyHostToDevice, stream));
             if (p.out_scores_dev) FSGPU_HIP(hipMemcpyAsync(p.out_scores_dev + (size_t)i * k, sc.data(), (size_t)k * 4, hipMemcpyHostToDevice, stream));
             if (p.out_counts_dev) FSGPU_HIP(hipMemcpyAsync(p.out_counts_dev + i, &cnt, 4, hipMemcpyHostToDevice, stream));
@@ -2641,13 +2866,26 @@ SearchError VectorIndex::two_pass_lone_certified(const float* query, const unsig
                                                  uint32_t cc, int bits, const void* qslab, uint32_t* rows, float* scores, uint32_t* count,
                                                  bool* answered) {
     *answered = false;
+    bool enqueued = false;
+    FSGPU_TRY(two_pass_lone_enqueue(query, qi, qbytes, k, k_eff, cc, bits, qslab, false, &enqueued));
+    if (!enqueued) return ok();
+    return two_pass_lone_check(rows, scores, count, nullptr, nullptr, answered);
+}
+
+// Enqueue only: pass 1 keeping 32 entries per block, the cut, the cc best pass-1 entries (best first, into pinned memory), their exact
+// scores, the k best of those.  want_pairs: the candidates' exact entries go to pinned memory as well, aligned with the pass-1 entries
+// (what a row-sharded handle's root merges).
+SearchError VectorIndex::two_pass_lone_enqueue(const float* query, const unsigned char* qi, uint32_t qbytes, uint32_t k, uint32_t k_eff,
+                                               uint32_t cc, int bits, const void* qslab, bool want_pairs, bool* enqueued) {
+    *enqueued = false;
     constexpr uint32_t LK = 32;
     const bool fused = bits == 8 ? scan_i8_fused_supported((int)dim_, 64) : scan_4bit_fused_supported((int)dim_, 64);
     if (!fused || pinned_io() == nullptr) return ok();
     const size_t fbytes = (size_t)dim_ * 4;
     const size_t o_qi = (fbytes + 255) & ~(size_t)255, o_out = (o_qi + qbytes + 255) & ~(size_t)255,
                  o_flags = (o_out + (size_t)k * 8 + 4 + 255) & ~(size_t)255;
-    if (o_flags + 64 > kPinnedIoBytes) return ok();
+    const size_t o_approx = (o_flags + 64 + 255) & ~(size_t)255, o_exact = (o_approx + (size_t)cc * 8 + 255) & ~(size_t)255;
+    if (o_exact + (size_t)cc * 8 > kPinnedIoBytes) return ok();
     unsigned char* io = static_cast<unsigned char*>(io_host_);
     std::memcpy(io, query, fbytes);
     std::memcpy(io + o_qi, qi, qbytes);
@@ -2655,16 +2893,19 @@ SearchError VectorIndex::two_pass_lone_certified(const float* query, const unsig
     float* delta_pin = reinterpret_cast<float*>(io + o_flags);   // the pass-1 scores are the reference's own: no margin
     float* cut_pin = delta_pin + 2;
     *delta_pin = 0.f;
-    // (every wave of the scan reads the whole quantised query: from device memory, not over the bus; the finish's one block reads
-    // the f32 query where it lies)
-    FSGPU_TRY(ws_i8_query_.reserve(qbytes));
-    FSGPU_HIP(hipMemcpyAsync(ws_i8_query_.ptr, io + o_qi, qbytes, hipMemcpyHostToDevice, stream_));
-    ScanArgs a = base_args(q_pin, nullptr);
     int grid = num_cus_;   // 256 lists x 32 entries: what the sorted selection holds in one piece
     const int max_useful = (int)(((nrows_ + 15) / 16 + 3) / 4);
     grid = std::max(1, std::min(grid, max_useful));
     if ((size_t)grid * LK > 8192) return ok();
+    // (every wave of the scan reads the whole quantised query: from device memory, not over the bus; the finish's one block reads
+    // the f32 query where it lies)
+    FSGPU_TRY(ws_i8_query_.reserve(qbytes));
     FSGPU_TRY(ws_partial_.reserve((size_t)grid * LK * 8));
+    FSGPU_TRY(ws_cand_packed_.reserve((size_t)cc * 8));
+    FSGPU_TRY(ws_cand_rows_.reserve((size_t)cc * 4));
+    FSGPU_TRY(ws_cand_scores_.reserve((size_t)cc * 4));
+    FSGPU_HIP(hipMemcpyAsync(ws_i8_query_.ptr, io + o_qi, qbytes, hipMemcpyHostToDevice, stream_));
+    ScanArgs a = base_args(q_pin, nullptr);
     a.partial = static_cast<u64*>(ws_partial_.ptr);
     a.k = LK;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -2683,12 +2924,8 @@ SearchError VectorIndex::two_pass_lone_certified(const float* query, const unsig
     FSGPU_HIP(launch_list_cut(a.partial, (uint32_t)grid, LK, cut_pin, stream_));
     // the cc best pass-1 entries of the 8,192 kept (ONE pass of the merge; the selection's sorted finish took 0.10 ms here), their exact
     // scores, the k best of those — the general sequence's kernels over lists a third as long
-    FSGPU_TRY(ws_cand_packed_.reserve((size_t)cc * 8));
-    FSGPU_TRY(ws_cand_rows_.reserve((size_t)cc * 4));
-    FSGPU_TRY(ws_cand_scores_.reserve((size_t)cc * 4));
-    const size_t o_approx = (o_flags + 64 + 255) & ~(size_t)255;
-    if (o_approx + (size_t)cc * 8 > kPinnedIoBytes) return ok();
     u64* approx_pin = reinterpret_cast<u64*>(io + o_approx);
+    u64* exact_pin = reinterpret_cast<u64*>(io + o_exact);
     uint32_t* cand_rows = static_cast<uint32_t*>(ws_cand_rows_.ptr);
     float* cand_scores = static_cast<float*>(ws_cand_scores_.ptr);
     u64* cand_packed = static_cast<u64*>(ws_cand_packed_.ptr);
@@ -2708,6 +2945,7 @@ SearchError VectorIndex::two_pass_lone_certified(const float* query, const unsig
     FSGPU_HIP(hipMemsetAsync(cand_scores, 0, (size_t)cc * 4, stream_));
     FSGPU_HIP(launch_gather_dot(a, cand_rows, cc, cand_scores, stream_));
     FSGPU_HIP(launch_pack_hits(cand_rows, cand_scores, cc, cand_packed, stream_));
+    if (want_pairs) FSGPU_HIP(launch_pack_hits(cand_rows, cand_scores, cc, exact_pin, stream_));
     MergeArgs m2;
     m2.lists = cand_packed;
     m2.q_stride = cc;
@@ -2722,22 +2960,173 @@ SearchError VectorIndex::two_pass_lone_certified(const float* query, const unsig
     m2.out_packed = nullptr;
     m2.lists_sorted = 0;  // candidates arrive in pass-1 order
     FSGPU_HIP(launch_merge_topk(m2, 1, stream_));
+    tp_lane_ = TwoPassLane{k, cc, o_out, o_flags, o_approx, o_exact};
+    *enqueued = true;
+    return ok();
+}
+
+// The other half: one synchronisation, then the certificate — complete when no list was full (nothing dropped) or the cc-th best entry
+// outranks everything dropped, STRICTLY: a dropped row with the same integer score may have the smaller row id.
+// approx_out / exact_out (may be null): the cc candidate pairs.
+SearchError VectorIndex::two_pass_lone_check(uint32_t* rows, float* scores, uint32_t* count, u64* approx_out, u64* exact_out, bool* answered) {
+    *answered = false;
+    const TwoPassLane L = tp_lane_;
+    unsigned char* io = static_cast<unsigned char*>(io_host_);
+    FSGPU_HIP(hipSetDevice(device_));
     FSGPU_HIP(hipStreamSynchronize(stream_));
-    const float cut = *cut_pin;
-    // complete when no list was full (nothing dropped) or the cc-th best entry outranks everything dropped — STRICTLY: a dropped row
-    // with the same integer score may have the smaller row id
+    const float cut = *(reinterpret_cast<const float*>(io + L.o_flags) + 2);
+    const u64* approx_pin = reinterpret_cast<const u64*>(io + L.o_approx);
     bool complete = cut == -INFINITY;
-    if (!complete && approx_pin[cc - 1] != ~0ull) {
+    if (!complete && approx_pin[L.cc - 1] != ~0ull) {
         float tau;
-        const uint32_t tb = (uint32_t)(approx_pin[cc - 1] >> 32);
+        const uint32_t tb = (uint32_t)(approx_pin[L.cc - 1] >> 32);
         std::memcpy(&tau, &tb, 4);
         complete = cut < tau;
     }
     if (!complete) return ok();
-    std::memcpy(rows, m2.out_rows, (size_t)k * 4);
-    std::memcpy(scores, m2.out_scores, (size_t)k * 4);
-    *count = *m2.out_counts;
+    if (rows) std::memcpy(rows, io + L.o_out, (size_t)L.k * 4);
+    if (scores) std::memcpy(scores, io + L.o_out + (size_t)L.k * 4, (size_t)L.k * 4);
+    if (count) *count = *reinterpret_cast<const uint32_t*>(io + L.o_out + (size_t)L.k * 8);
+    if (approx_out) std::memcpy(approx_out, approx_pin, (size_t)L.cc * 8);
+    if (exact_out) std::memcpy(exact_out, io + L.o_exact, (size_t)L.cc * 8);
     *answered = true;
+    return ok();
+}
+
+// quantize_i8_query (search.rs:1616-1626) / pack_4bit_query (:1640-1653): the query's own max-abs scale, round half away from zero,
+// clamp; NaN -> 0
+static void quantize_query_host(const float* query, uint32_t dim, int bits, std::vector<unsigned char>& qi) {
+    const uint32_t qbytes = bits == 8 ? dim : (dim + 1) / 2;
+    qi.assign(qbytes, 0);
+    float max_abs = 0.f;
+    for (uint32_t i = 0; i < dim; ++i) {
+        const float v = std::fabs(query[i]);
+        if (v > max_abs) max_abs = v;
+    }
+    const float lim = bits == 8 ? 127.0f : 7.0f;
+    const bool usable = bits == 8 ? max_abs > 0.f : max_abs > 1e-9f;
+    const float scale = usable ? lim / max_abs : 0.f;
+    if (bits == 4 || usable) {
+        for (uint32_t i = 0; i < dim; ++i) {
+            float v = std::round(query[i] * scale);
+            if (v != v) v = 0.f;
+            v = std::min(std::max(v, -lim), lim);
+            const int qv = (int)v;
+            if (bits == 8) qi[i] = (unsigned char)(signed char)qv;
+            else qi[i / 2] |= (unsigned char)((qv & 0xF) << ((i & 1) ? 4 : 0));
+        }
+    }
+}
+
+// The quantised copy a two-pass search scans, built lazily, once (VectorIndex::int8_slab() / nibbles_slab(), search.rs:988-1000).
+SearchError VectorIndex::ensure_two_pass_slab(int bits, const void** qslab) {
+    const size_t n = (size_t)nrows_;
+    const uint32_t qbytes = bits == 8 ? dim_ : (dim_ + 1) / 2;
+    if (bits == 8 && !i8_ready_) {
+        FSGPU_TRY(i8_slab_.reserve(n * dim_));
+        FSGPU_TRY(i8_max_.reserve(4));
+        FSGPU_HIP(launch_quantize_slab_i8(slab_dev_, n * dim_, static_cast<unsigned int*>(i8_max_.ptr), i8_slab_.ptr,
+                                          stream_, quant_max_ready_));
+        i8_ready_ = true;
+    }
+    if (bits == 4 && !n4_ready_) {
+        FSGPU_TRY(n4_slab_.reserve(n * qbytes));
+        FSGPU_TRY(i8_max_.reserve(4));
+        FSGPU_HIP(launch_pack_slab_4bit(slab_dev_, nrows_, dim_, static_cast<unsigned int*>(i8_max_.ptr), n4_slab_.ptr,
+                                        stream_, quant_max_ready_));
+        n4_ready_ = true;
+    }
+    *qslab = bits == 8 ? i8_slab_.ptr : n4_slab_.ptr;
+    return ok();
+}
+
+// One query of a row-sharded two-pass search, this shard's half, in two halves: begin enqueues (the lone caller's lane when the
+// shape allows, else the batched sequence with one query), end yields the shard's cc_out = max(k * multiplier, k) candidate pairs
+// (pass-1 entry, exact entry; kEmpty beyond the candidates) — what two_pass_candidates_device yields for one query.
+SearchError VectorIndex::lone_two_pass_begin(const float* query, uint32_t k, uint32_t multiplier, int bits) {
+    lone_ = LoneState{};
+    lone_.query = query;
+    lone_.k = k;
+    lone_.mult = multiplier ? multiplier : 1;
+    lone_.bits = bits == 4 ? 4 : 8;
+    const uint64_t cc_out64 = std::max<uint64_t>((uint64_t)k * lone_.mult, k);
+    if (cc_out64 > 256 || k == 0) return make_error(FSGPU_ERR_INVALID_CONFIG, "sharded two-pass: 1 <= k, k * multiplier <= 256");
+    lone_.cc_out = (uint32_t)cc_out64;
+    if (f32_) return make_error(FSGPU_ERR_INVALID_CONFIG, "two-pass searches need an F16 slab");
+    if (nrows_ == 0) {
+        lone_.kind = kLoneEmpty;
+        return ok();
+    }
+    FSGPU_HIP(hipSetDevice(device_));
+    const void* qslab = nullptr;
+    FSGPU_TRY(ensure_two_pass_slab(lone_.bits, &qslab));
+    uint64_t cc64 = std::min<uint64_t>((uint64_t)k * lone_.mult, nrows_);
+    cc64 = std::max<uint64_t>(cc64, std::min<uint64_t>(k, nrows_));
+    const uint32_t cc = (uint32_t)cc64, k_eff = (uint32_t)std::min<uint64_t>(k, nrows_);
+    lone_.cc = cc;
+    if (cc <= kSelectMaxK && k_eff <= 64 && k <= 64 && (dim_ & 7) == 0 && nrows_ >= 4096 && !(row_stride_ && row_stride_ != dim_ * 2) && variant == 0) {
+        if (tp_skip_ > 0) {
+            --tp_skip_;
+        } else {
+            std::vector<unsigned char> qi;
+            quantize_query_host(query, dim_, lone_.bits, qi);
+            bool enqueued = false;
+            FSGPU_TRY(two_pass_lone_enqueue(query, qi.data(), (uint32_t)qi.size(), k, k_eff, cc, lone_.bits, qslab, true, &enqueued));
+            if (enqueued) {
+                lone_.kind = kLoneTwoPassLane;
+                return ok();
+            }
+        }
+    }
+    FSGPU_TRY(ws_pairs_.reserve((size_t)lone_.cc_out * 16));
+    if (async_state_[0] != 0 && async_state_[1] != 0) {
+        lone_.kind = kLoneTwoPassBlocking;
+        return ok();
+    }
+    FSGPU_TRY(ws_queries_.reserve((size_t)dim_ * 4));
+    FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, query, (size_t)dim_ * 4, hipMemcpyHostToDevice, stream_));
+    u64* pairs = static_cast<u64*>(ws_pairs_.ptr);
+    FSGPU_TRY(two_pass_candidates_device_begin(static_cast<const float*>(ws_queries_.ptr), 1, dim_, k, lone_.mult, lone_.bits,
+                                               reinterpret_cast<uint64_t*>(pairs), reinterpret_cast<uint64_t*>(pairs + lone_.cc_out), stream_,
+                                               &lone_.ticket));
+    lone_.kind = kLoneTwoPassBatched;
+    return ok();
+}
+
+SearchError VectorIndex::lone_two_pass_end(uint64_t* out_approx, uint64_t* out_exact) {
+    const LoneState st = lone_;
+    lone_ = LoneState{};
+    if (st.kind == kLoneNone) return make_error(FSGPU_ERR_INVALID_CONFIG, "no lone query was begun on this index");
+    for (uint32_t i = 0; i < st.cc_out; ++i) out_approx[i] = out_exact[i] = ~0ull;
+    if (st.kind == kLoneEmpty) return ok();
+    FSGPU_HIP(hipSetDevice(device_));
+    bool blocking = st.kind == kLoneTwoPassBlocking;
+    if (st.kind == kLoneTwoPassLane) {
+        bool answered = false;
+        FSGPU_TRY(two_pass_lone_check(nullptr, nullptr, nullptr, reinterpret_cast<u64*>(out_approx), reinterpret_cast<u64*>(out_exact), &answered));
+        if (answered) {
+            tp_backoff_ = 0;
+            return ok();
+        }
+        tp_backoff_ = tp_backoff_ ? std::min<uint32_t>(tp_backoff_ * 2, 64) : 1;
+        tp_skip_ = tp_backoff_;
+        FSGPU_TRY(ws_pairs_.reserve((size_t)st.cc_out * 16));
+        blocking = true;
+    }
+    u64* pairs = static_cast<u64*>(ws_pairs_.ptr);
+    if (blocking) {   // the general sequence, in one piece (quantized_two_pass hands the pairs on when asked to)
+        FSGPU_HIP(hipMemsetAsync(pairs, 0xff, (size_t)st.cc_out * 16, stream_));
+        std::vector<uint32_t> rows(st.k);
+        std::vector<float> scores(st.k);
+        uint32_t cnt = 0;
+        FSGPU_TRY(quantized_two_pass(st.query, dim_, st.k, st.mult, st.bits, rows.data(), scores.data(), &cnt, pairs, pairs + st.cc_out));
+    } else {
+        uint32_t fb = 0;
+        FSGPU_TRY(two_pass_candidates_device_end(st.ticket, &fb));
+    }
+    FSGPU_HIP(hipMemcpyAsync(out_approx, pairs, (size_t)st.cc_out * 8, hipMemcpyDeviceToHost, stream_));
+    FSGPU_HIP(hipMemcpyAsync(out_exact, pairs + st.cc_out, (size_t)st.cc_out * 8, hipMemcpyDeviceToHost, stream_));
+    FSGPU_HIP(hipStreamSynchronize(stream_));
     return ok();
 }
 
@@ -2758,49 +3147,15 @@ SearchError VectorIndex::quantized_two_pass(const float* query, uint32_t query_l
     FSGPU_HIP(hipSetDevice(device_));
     const size_t n = (size_t)nrows_;
     const uint32_t qbytes = bits == 8 ? dim_ : (dim_ + 1) / 2;  // quantised bytes per vector
-    if (bits == 8 && !i8_ready_) {  // VectorIndex::int8_slab() is built lazily, once
-        FSGPU_TRY(i8_slab_.reserve(n * dim_));
-        FSGPU_TRY(i8_max_.reserve(4));
-        FSGPU_HIP(launch_quantize_slab_i8(slab_dev_, n * dim_, static_cast<unsigned int*>(i8_max_.ptr), i8_slab_.ptr,
-                                          stream_, quant_max_ready_));
-        i8_ready_ = true;
-    }
-    if (bits == 4 && !n4_ready_) {  // VectorIndex::nibbles_slab() (search.rs:988-1000)
-        FSGPU_TRY(n4_slab_.reserve(n * qbytes));
-        FSGPU_TRY(i8_max_.reserve(4));
-        FSGPU_HIP(launch_pack_slab_4bit(slab_dev_, nrows_, dim_, static_cast<unsigned int*>(i8_max_.ptr), n4_slab_.ptr,
-                                        stream_, quant_max_ready_));
-        n4_ready_ = true;
-    }
-    const void* qslab = bits == 8 ? i8_slab_.ptr : n4_slab_.ptr;
+    const void* qslab = nullptr;
+    FSGPU_TRY(ensure_two_pass_slab(bits, &qslab));
     const uint64_t mult = multiplier ? multiplier : 1;
     uint64_t cc64 = std::min<uint64_t>((uint64_t)k * mult, nrows_);
     cc64 = std::max<uint64_t>(cc64, std::min<uint64_t>(k, nrows_));
     const uint32_t cc = (uint32_t)cc64;
     const uint32_t k_eff = (uint32_t)std::min<uint64_t>(k, nrows_);
-    // quantize_i8_query (search.rs:1616-1626) / pack_4bit_query (:1640-1653): the query's own max-abs scale, round half
-    // away from zero, clamp; NaN -> 0
-    std::vector<unsigned char> qi(qbytes, 0);
-    {
-        float max_abs = 0.f;
-        for (uint32_t i = 0; i < dim_; ++i) {
-            const float v = std::fabs(query[i]);
-            if (v > max_abs) max_abs = v;
-        }
-        const float lim = bits == 8 ? 127.0f : 7.0f;
-        const bool usable = bits == 8 ? max_abs > 0.f : max_abs > 1e-9f;
-        const float scale = usable ? lim / max_abs : 0.f;
-        if (bits == 4 || usable) {
-            for (uint32_t i = 0; i < dim_; ++i) {
-                float v = std::round(query[i] * scale);
-                if (v != v) v = 0.f;
-                v = std::min(std::max(v, -lim), lim);
-                const int qv = (int)v;
-                if (bits == 8) qi[i] = (unsigned char)(signed char)qv;
-                else qi[i / 2] |= (unsigned char)((qv & 0xF) << ((i & 1) ? 4 : 0));
-            }
-        }
-    }
+    std::vector<unsigned char> qi;
+    quantize_query_host(query, dim_, bits, qi);
     std::vector<uint32_t> rows(k);
     std::vector<float> scores(k);
     uint32_t count = 0;

@@ -112,11 +112,26 @@ class VectorIndex {
     SearchError two_pass_candidates_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
                                            uint32_t multiplier, int bits, uint64_t* approx_out_dev, uint64_t* exact_out_dev,
                                            hipStream_t stream, uint32_t* fallbacks);
+    // ... in two halves (the tickets of search_top_k_batched_device_begin / _end): nothing is waited for in begin
+    SearchError two_pass_candidates_device_begin(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
+                                                 uint32_t multiplier, int bits, uint64_t* approx_out_dev, uint64_t* exact_out_dev,
+                                                 hipStream_t stream, int32_t* ticket);
+    SearchError two_pass_candidates_device_end(int32_t ticket, uint32_t* fallbacks);
     // Shard-local search whose result stays packed (score bits << 32 | global row; ~0 padding) for the
     // cross-GPU exchange: out_packed_dev is [nq, k].  Fused tiers only (k <= 256, dim % 8 == 0).
     SearchError search_top_k_packed_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
                                            const uint64_t* allow_dev, uint64_t* out_packed_dev, hipStream_t stream);
     SearchError gather_dot(const float* query, uint32_t query_len, const uint32_t* rows, uint32_t n, float* out);
+
+    // A lone query in two halves (one at a time per index, on the index's own stream): begin enqueues and returns, end waits and
+    // writes the hits — search_top_k(query, 1, ...) without a filter is exactly begin + end.  A row-sharded handle begins the query
+    // on every shard before it ends any, so the shards' passes run side by side from ONE host thread.
+    SearchError lone_exact_begin(const float* query, uint32_t k);
+    SearchError lone_exact_end(uint32_t* out_rows, float* out_scores, uint32_t* out_count);   // [k], [k], [1]
+    // ... of a two-pass search (bits 8: search_top_k_int8_two_pass, 4: search_top_k_4bit_two_pass), this shard's half: end yields
+    // max(k * multiplier, k) candidate pairs (pass-1 entry | exact entry, aligned; kEmpty beyond the candidates)
+    SearchError lone_two_pass_begin(const float* query, uint32_t k, uint32_t multiplier, int bits);
+    SearchError lone_two_pass_end(uint64_t* out_approx, uint64_t* out_exact);
 
     // search_top_k + scan_wal + resolve_hits (search.rs:426-494, 1449-1475, 1493-1558): GPU top-k of the main
     // rows, host merge of the resident WAL entries, WAL shadowing and doc-id dedup.  Needs a doc-id table.
@@ -177,6 +192,7 @@ class VectorIndex {
     int32_t batched_filter = 0;
     // fsgpu_index_set_int8_latency: unfiltered fsgpu_search_topk calls of a few queries go through the int8 filter too
     bool int8_latency = false;
+    SearchError prepare_int8_latency();   // builds the int8 copy + its statistics now (else: the first batched search does)
     uint64_t i8f_queries = 0, i8f_refiltered = 0;  // queries the int8 filter took / handed on to the f16 filter
     bool int8_filter_active() const { return batched_filter == 2 || (batched_filter == 0 && !i8f_disabled_); }
     // The certificate of the int8 filter, for inspection: per query the bound delta on |int8 score - exact score x slab scale
@@ -229,6 +245,31 @@ class VectorIndex {
                                         bool* certified);
     SearchError two_pass_lone_certified(const float* query, const unsigned char* qi, uint32_t qbytes, uint32_t k, uint32_t k_eff, uint32_t cc,
                                         int bits, const void* qslab, uint32_t* rows, float* scores, uint32_t* count, bool* answered);
+    // ... and the halves of both lanes (enqueue only / one synchronisation + the certificate)
+    SearchError certified_i8_enqueue(const float* query, uint32_t k, bool* enqueued);
+    SearchError certified_i8_check(uint32_t* out_rows, float* out_scores, uint32_t* out_count, bool* certified);
+    SearchError two_pass_lone_enqueue(const float* query, const unsigned char* qi, uint32_t qbytes, uint32_t k, uint32_t k_eff, uint32_t cc,
+                                      int bits, const void* qslab, bool want_pairs, bool* enqueued);
+    SearchError two_pass_lone_check(uint32_t* rows, float* scores, uint32_t* count, u64* approx_out, u64* exact_out, bool* answered);
+    SearchError ensure_two_pass_slab(int bits, const void** qslab);
+    enum LoneKind : int {
+        kLoneNone = 0, kLoneEmpty, kLoneUnpinned, kLoneCertified, kLoneStaged, kLoneStagedBlocking, kLoneExact,
+        kLoneTwoPassLane, kLoneTwoPassBatched, kLoneTwoPassBlocking
+    };
+    struct LoneState {   // the lone query in flight (lone_*_begin .. lone_*_end)
+        int kind = kLoneNone;
+        const float* query = nullptr;   // the caller's, valid until end
+        uint32_t k = 0, mult = 0, cc = 0, cc_out = 0;
+        int bits = 8;
+        int32_t ticket = -1;
+    };
+    LoneState lone_;
+    uint32_t cert_k_ = 0;   // k of the certified pass in flight
+    struct TwoPassLane {    // the two-pass lane in flight: its k, candidate count and offsets into the pinned staging block
+        uint32_t k = 0, cc = 0;
+        size_t o_out = 0, o_flags = 0, o_approx = 0, o_exact = 0;
+    };
+    TwoPassLane tp_lane_;
     SearchError common_init(int device);
     SearchError fused_search(const float* queries_dev, uint32_t nq, uint32_t k_out, uint32_t k_eff,
                              const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
@@ -261,7 +302,7 @@ class VectorIndex {
     DeviceBuffer ws_partial_, ws_queries_, ws_allow_, ws_rows_, ws_scores_, ws_counts_, ws_keys_a_, ws_keys_b_,
         ws_sort_tmp_, ws_gather_rows_, ws_gather_out_, i8_slab_, n4_slab_, i8_max_, ws_i8_query_, ws_cand_packed_,
         ws_cand_rows_, ws_cand_scores_, mf_max_norm_, mf_qh_, mf_delta_, mf_tau_, mf_cand_, mf_dense_, mf_sel_,
-        mf_fallback_, mf_fallback2_, mf_spill_, mf_io_, i8_stats_, n4u_slab_, mf_cand_count_;
+        mf_fallback_, mf_fallback2_, mf_spill_, mf_io_, mf_io2_, i8_stats_, n4u_slab_, mf_cand_count_, ws_pairs_;
     bool i8_ready_ = false, n4_ready_ = false, i8_stats_ready_ = false, n4u_ready_ = false;
     bool quant_max_ready_ = false;   // i8_max_ holds a corpus-wide max-abs handed in by a sharded index: the quantisers keep it
     u64* tp_approx_out_ = nullptr;   // two_pass_candidates_device: where the batch in flight leaves its candidate pairs
@@ -278,6 +319,7 @@ class VectorIndex {
     bool async_i8f_[2] = {false, false};
     uint32_t async_nq_[2] = {0, 0}, async_fb_[2] = {0, 0};
     hipEvent_t async_ev_[2] = {nullptr, nullptr};
+    hipStream_t async_stream_[2] = {nullptr, nullptr};   // the stream each outstanding ticket was enqueued on
     std::vector<unsigned char> async_plan_[2];   // the parked BatchedPlan (plain data: pointers and sizes), defined in the .cpp
     uint32_t i8f_sample_boost_ = 1;   // 1 or 2: the second sample of the int8 filter's wide rounds grows before the filter is given up
     bool mf_norm_ready_ = false;

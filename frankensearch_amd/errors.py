@@ -52,6 +52,11 @@ _BY_CODE = {c.code: c for c in (DimensionMismatch, InvalidConfig, IndexCorrupted
                                 DeviceError, NoDevice, NullArgument, EmbeddingFailed, ModelLoadFailed)}
 
 
+def error_for(status: int, detail: str) -> SearchError:
+    """The exception of a status code with a detail string the caller already holds (a call that failed on another thread)."""
+    return _BY_CODE.get(status, SearchError)(detail)
+
+
 def check(status: int) -> None:
     if status != _lib.OK:
         raise _BY_CODE.get(status, SearchError)(_lib.last_error())

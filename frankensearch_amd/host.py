@@ -40,7 +40,8 @@ class _Metrics(C.Structure):
 
 class _StreamResult(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("wall_seconds", "queries_per_sec", "mean_encode_ms", "mean_search_ms")] + \
-               [(n, C.c_uint64) for n in ("queries", "groups", "exact_fallbacks", "device_resident_handoff")]
+               [(n, C.c_uint64) for n in ("queries", "groups", "exact_fallbacks", "device_resident_handoff", "encoders")] + \
+               [("error_detail", C.c_char * 256)]
 
 
 class _ScoredDoc(C.Structure):
@@ -61,7 +62,7 @@ class _LoadResult(C.Structure):
 
 
 SYMBOLS = ("fshost_two_tier_create", "fshost_two_tier_create_sharded", "fshost_two_tier_destroy", "fshost_two_tier_search",
-           "fshost_run_load", "fshost_embed_search_stream")
+           "fshost_run_load", "fshost_embed_search_stream", "fshost_embed_search_stream_dp")
 _handle = None
 
 
@@ -80,6 +81,10 @@ def lib() -> C.CDLL:
         h.fshost_embed_search_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                                  C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.POINTER(_StreamResult)]
+        h.fshost_embed_search_stream_dp.restype = C.c_int32
+        h.fshost_embed_search_stream_dp.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                                    C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.POINTER(_StreamResult)]
         h.fshost_two_tier_destroy.restype = None
         h.fshost_two_tier_destroy.argtypes = [C.c_void_p]
         h.fshost_two_tier_search.restype = C.c_int32
@@ -193,8 +198,21 @@ def embed_search_stream(encoder, index, ids: np.ndarray, offsets: np.ndarray, ba
     counts = np.empty(n_texts, dtype=np.uint32) if want_hits else None
     res = _StreamResult()
     sharded = isinstance(index, NativeShardedIndex)
-    check(lib().fshost_embed_search_stream(encoder._h, None if sharded else index._h, index._h if sharded else None, ids.ctypes.data,
-                                           offsets.ctypes.data, batch, n_batches, group, k, int(overlap) | (2 if host_handoff else 0),
-                                           rows.ctypes.data if want_hits else None, scores.ctypes.data if want_hits else None,
-                                           counts.ctypes.data if want_hits else None, C.byref(res)))
-    return rows, scores, counts, {n: getattr(res, n) for n, _ in _StreamResult._fields_}
+    out = (rows.ctypes.data if want_hits else None, scores.ctypes.data if want_hits else None, counts.ctypes.data if want_hits else None)
+    if isinstance(encoder, (list, tuple)):
+        # data-parallel encoders over a sharded handle (fshost_embed_search_stream_dp): one per device, each embeds a slice of every group
+        if not sharded:
+            raise TypeError("data-parallel encoders need a NativeShardedIndex")
+        handles = (C.c_void_p * len(encoder))(*[e._h for e in encoder])
+        st = lib().fshost_embed_search_stream_dp(handles, len(encoder), index._h, ids.ctypes.data, offsets.ctypes.data, batch, n_batches,
+                                                 group, k, int(overlap), *out, C.byref(res))
+    else:
+        st = lib().fshost_embed_search_stream(encoder._h, None if sharded else index._h, index._h if sharded else None, ids.ctypes.data,
+                                              offsets.ctypes.data, batch, n_batches, group, k, int(overlap) | (2 if host_handoff else 0),
+                                              *out, C.byref(res))
+    if st != 0 and res.error_detail:
+        from .errors import error_for
+        raise error_for(st, res.error_detail.decode(errors="replace"))
+    check(st)
+    stats = {n: getattr(res, n) for n, _ in _StreamResult._fields_ if n != "error_detail"}
+    return rows, scores, counts, stats

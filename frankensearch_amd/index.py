@@ -414,8 +414,8 @@ class ResidentFilter:
 
 
 class NativeShardedIndex:
-    """fsgpu_sharded: the row-sharded index behind ONE C-ABI handle (include/fsgpu.h): one shard, stream and host thread per
-    device, RCCL all-gather of the packed per-shard top-k, merge on the root (search.rs:1013-1036,1704-1720 at GPU granularity).
+    """fsgpu_sharded: the row-sharded index behind ONE C-ABI handle (include/fsgpu.h): one shard and stream pair per
+    device (optionally query groups x row shards), everything enqueued by the calling thread, RCCL all-gather of the packed per-shard top-k, merge on the root (search.rs:1013-1036,1704-1720 at GPU granularity).
     (The one-process-per-GPU form used by `bench.py --gpus N` is frankensearch_amd/sharded.py.)"""
 
     EXCHANGE_AUTO, EXCHANGE_RCCL, EXCHANGE_PEER_COPY = 0, 1, 2
@@ -426,7 +426,7 @@ class NativeShardedIndex:
 
     @classmethod
     def from_slab(cls, slab_f16: np.ndarray, devices: Sequence[int], live: Optional[np.ndarray] = None,
-                  exchange: int = 0) -> "NativeShardedIndex":
+                  exchange: int = 0, query_groups: int = 1) -> "NativeShardedIndex":
         slab = np.ascontiguousarray(slab_f16)
         if slab.dtype == np.float16:
             slab = slab.view(np.uint16)
@@ -435,20 +435,21 @@ class NativeShardedIndex:
         devs = np.ascontiguousarray(devices, dtype=np.int32)
         bm = pack_bitmap(live) if live is not None else None
         h = C.c_void_p()
-        check(_lib.lib().fsgpu_sharded_create(_ptr(devs), devs.size, slab.shape[1], slab.shape[0], _ptr(slab), _ptr(bm),
-                                              exchange, C.byref(h)))
+        check(_lib.lib().fsgpu_sharded_create_grouped(_ptr(devs), devs.size, query_groups, slab.shape[1], slab.shape[0], _ptr(slab),
+                                                      _ptr(bm), exchange, C.byref(h)))
         return cls(h.value)
 
     @classmethod
     def from_device_slabs(cls, devices: Sequence[int], dim: int, shard_rows: Sequence[int], slab_ptrs: Sequence[int],
-                          exchange: int = 0, keepalive=None) -> "NativeShardedIndex":
-        """Adopts per-device resident shards (e.g. torch tensors' data_ptr())."""
+                          exchange: int = 0, keepalive=None, query_groups: int = 1) -> "NativeShardedIndex":
+        """Adopts per-device resident shards (e.g. torch tensors' data_ptr()); with query groups, device r holds row shard
+        r % (len(devices) // query_groups)."""
         devs = np.ascontiguousarray(devices, dtype=np.int32)
         rows = np.ascontiguousarray(shard_rows, dtype=np.uint64)
         ptrs = np.ascontiguousarray(slab_ptrs, dtype=np.uint64)
         h = C.c_void_p()
-        check(_lib.lib().fsgpu_sharded_create_device(_ptr(devs), devs.size, dim, _ptr(rows), _ptr(ptrs), None, exchange,
-                                                     C.byref(h)))
+        check(_lib.lib().fsgpu_sharded_create_device_grouped(_ptr(devs), devs.size, query_groups, dim, _ptr(rows), _ptr(ptrs), None,
+                                                             exchange, C.byref(h)))
         return cls(h.value, keepalive)
 
     def close(self) -> None:
@@ -470,6 +471,29 @@ class NativeShardedIndex:
 
     def shard_count(self) -> int:
         return _lib.lib().fsgpu_sharded_shard_count(self._h)
+
+    def query_groups(self) -> int:
+        return _lib.lib().fsgpu_sharded_query_groups(self._h)
+
+    def row_shards(self) -> int:
+        return _lib.lib().fsgpu_sharded_row_shards(self._h)
+
+    def set_int8_latency(self, on: bool = True) -> None:
+        """Lone exact queries through the certified int8 pass of every shard (fsgpu_sharded_set_int8_latency)."""
+        check(_lib.lib().fsgpu_sharded_set_int8_latency(self._h, 1 if on else 0))
+
+    def search_parts(self, parts: Sequence[Tuple[int, int, int]], dim: int, k: int, mode: int = 1):
+        """Queries resident in parts on several devices: parts = [(device pointer, count, device), ...] (fsgpu_sharded_search_parts)."""
+        ptrs = np.ascontiguousarray([p[0] for p in parts], dtype=np.uint64)
+        counts = np.ascontiguousarray([p[1] for p in parts], dtype=np.uint32)
+        devs = np.ascontiguousarray([p[2] for p in parts], dtype=np.int32)
+        nq = int(counts.sum())
+        rq = self._Request(None, nq, dim, k, mode, 0, None, None)
+        rows, scores, cnts = self._outputs(nq, k)
+        fb = C.c_uint32()
+        check(_lib.lib().fsgpu_sharded_search_parts(self._h, C.byref(rq), _ptr(ptrs), _ptr(counts), _ptr(devs), len(parts), _ptr(rows),
+                                                    _ptr(scores), _ptr(cnts), C.byref(fb)))
+        return rows[:, :k], scores[:, :k], cnts, fb.value
 
     def exchange_mode(self) -> int:
         return _lib.lib().fsgpu_sharded_exchange_mode(self._h)
@@ -545,10 +569,10 @@ class NativeShardedIndex:
         return float(_lib.lib().fsgpu_sharded_quant_scale_max(self._h))
 
     @classmethod
-    def open(cls, path: str, devices: Sequence[int], exchange: int = 0) -> "NativeShardedIndex":
+    def open(cls, path: str, devices: Sequence[int], exchange: int = 0, query_groups: int = 1) -> "NativeShardedIndex":
         devs = np.ascontiguousarray(devices, dtype=np.int32)
         h = C.c_void_p()
-        check(_lib.lib().fsgpu_sharded_open_fsvi(path.encode(), _ptr(devs), devs.size, exchange, C.byref(h)))
+        check(_lib.lib().fsgpu_sharded_open_fsvi_grouped(path.encode(), _ptr(devs), devs.size, query_groups, exchange, C.byref(h)))
         return cls(h.value)
 
     def set_live(self, live: Optional[np.ndarray]) -> None:

@@ -223,8 +223,11 @@ fsgpu_status fsgpu_search_topk_batched_packed_device(fsgpu_index *idx, const flo
  * stream, which may already hold the caller's next search —, reads the per-query verdicts and answers the rare uncertified query with
  * the exact kernels, exactly as the blocking forms do at their end.  Outputs as in fsgpu_search_topk_batched_device (rows / scores /
  * counts, each may be null) plus out_packed_dev as in the packed form (may be null); the queries and every output stay the caller's
- * until _end.  Between a _begin and its _end the index may begin ONE more search; blocking calls on the same index are allowed
- * (they queue behind).  The per-rank loop of `bench.py --gpus N` (frankensearch_amd/sharded.py) runs on these: the ~50 us between
+ * until _end.  Between a _begin and its _end the index may begin ONE more search; blocking calls on the same index are allowed:
+ * a batched search on another stream than an outstanding ticket's is ordered behind that ticket's last kernel on the device (all
+ * batched searches of an index share one set of workspaces), on the same stream it queues behind by itself.  Calls that CHANGE
+ * the index (fsgpu_index_set_live_bitmap, _soft_delete, _wal_append) are refused with FSGPU_ERR_INVALID_CONFIG while a ticket is
+ * outstanding.  The per-rank loop of `bench.py --gpus N` (frankensearch_amd/sharded.py) runs on these: the ~50 us between
  * one blocking call's wake-up and the next call's first kernel were a tenth of a 1.25M-row shard's step.  No reference counterpart
  * (the reference's scan is synchronous CPU code, search.rs:1013-1080). */
 fsgpu_status fsgpu_search_topk_batched_device_begin(fsgpu_index *idx, const float *queries_dev, uint32_t nq, uint32_t query_len,
@@ -319,10 +322,26 @@ fsgpu_status fsgpu_sharded_create(const int32_t *devices, uint32_t ndev, uint32_
 fsgpu_status fsgpu_sharded_create_device(const int32_t *devices, uint32_t ndev, uint32_t dim, const uint64_t *shard_rows,
                                          const void *const *shard_slabs_dev, const uint64_t *const *shard_live_dev,
                                          int32_t exchange, fsgpu_sharded **out);
+/* Hybrid layout (round 5): ndev = query_groups x row shards.  Device r holds row shard r % (ndev / query_groups) — every row shard is
+ * resident once per group (288 GB per GPU hold a 10M x 384 slab many times over) — and scans it for the queries of group
+ * r / (ndev / query_groups), a contiguous 1/query_groups of the batch.  A shard's step has a fixed part that does not shrink with its
+ * rows (sample, selections, launches): 2 groups x 4 row shards pay it over 2.5M rows and half the queries per device where 8 row
+ * shards pay it over 1.25M rows and every query.  Same results as the unsharded index; ONE all-gather over all devices, one merge per
+ * group.  The reference partitions rows only (scan_parallel, search.rs:1013-1036); splitting the QUERY batch as well has no
+ * counterpart there because its callers issue one query at a time.  query_groups = 1 is fsgpu_sharded_create{,_device} /
+ * fsgpu_sharded_open_fsvi.  _create_device_grouped: shard_rows / slabs / live per DEVICE; shard_rows[r] must equal
+ * shard_rows[r % row shards]. */
+fsgpu_status fsgpu_sharded_create_grouped(const int32_t *devices, uint32_t ndev, uint32_t query_groups, uint32_t dim, uint64_t nrows,
+                                          const void *slab_f16_le, const uint64_t *live_bitmap, int32_t exchange, fsgpu_sharded **out);
+fsgpu_status fsgpu_sharded_create_device_grouped(const int32_t *devices, uint32_t ndev, uint32_t query_groups, uint32_t dim,
+                                                 const uint64_t *shard_rows, const void *const *shard_slabs_dev,
+                                                 const uint64_t *const *shard_live_dev, int32_t exchange, fsgpu_sharded **out);
+uint32_t fsgpu_sharded_query_groups(const fsgpu_sharded *idx);
+uint32_t fsgpu_sharded_row_shards(const fsgpu_sharded *idx);
 void fsgpu_sharded_destroy(fsgpu_sharded *idx);
 uint64_t fsgpu_sharded_record_count(const fsgpu_sharded *idx);
 uint32_t fsgpu_sharded_dimension(const fsgpu_sharded *idx);
-uint32_t fsgpu_sharded_shard_count(const fsgpu_sharded *idx);
+uint32_t fsgpu_sharded_shard_count(const fsgpu_sharded *idx); /* devices: query groups x row shards */
 int32_t fsgpu_sharded_exchange_mode(const fsgpu_sharded *idx); /* FSGPU_EXCHANGE_RCCL or FSGPU_EXCHANGE_PEER_COPY, as chosen */
 int32_t fsgpu_sharded_device(const fsgpu_sharded *idx, uint32_t shard); /* the HIP device of a shard (shard 0 = the root: merges, takes queries_dev) */
 fsgpu_status fsgpu_sharded_shard_range(const fsgpu_sharded *idx, uint32_t shard, uint64_t *row_lo, uint64_t *row_hi);
@@ -347,9 +366,15 @@ fsgpu_status fsgpu_sharded_search_topk_batched(fsgpu_sharded *idx, const float *
  *         candidates to the root as (pass-1 entry, exact entry) pairs; the root takes the corpus-wide k*candidate_multiplier
  *         best by the pass-1 order — exactly the unsharded candidate set — and the k best of those by the exact order.
  *         k*candidate_multiplier <= 256, shards*k*candidate_multiplier <= 1024, no filter.
- * fsgpu_sharded_search = begin + end.  begin returns once the shards' scans have been issued and the exchange + merge are
- * ENQUEUED behind them; end waits for that one search.  Two searches may be in flight per handle (end them in order), so the
- * exchange and merge of one run underneath the scan of the next. */
+ * fsgpu_sharded_search = begin + end, both on the calling thread (no worker threads inside the handle): begin ENQUEUES every
+ * shard's scan on that shard's stream — the batched and two-pass searches through their begin halves, so no host wait sits between
+ * one search's last kernel and the next one's first — and the exchange + merge behind them; end waits for that one search, reads the
+ * shards' verdicts and, only if a shard had to answer an uncertified query late, sends the corrected lists through the exchange again.
+ * Two searches may be in flight per handle (end them in order), so the exchange and merge of one run underneath the scan of the next.
+ * A LONE query (nq = 1, host pointer, no filter, mode EXACT or a two-pass mode) takes the shards' latency lanes instead (certified
+ * int8 pass with fsgpu_sharded_set_int8_latency, two-pass lane): every shard of one query group answers into its own pinned block,
+ * all begun before any is waited for, and the calling thread merges the short lists — merge_partial_heaps on the host, where the
+ * reference runs it (search.rs:1704-1720); no collective, no merge launch, no D2H copy. */
 #define FSGPU_SHARDED_EXACT 0
 #define FSGPU_SHARDED_BATCHED 1
 #define FSGPU_SHARDED_INT8_TWO_PASS 2
@@ -366,6 +391,17 @@ typedef struct fsgpu_sharded_request {
 } fsgpu_sharded_request;
 fsgpu_status fsgpu_sharded_search(fsgpu_sharded *idx, const fsgpu_sharded_request *request, uint32_t *out_rows, float *out_scores,
                                   uint32_t *out_counts, uint32_t *out_fallbacks);
+/* The batch's queries resident in PARTS on several devices — data-parallel encoders ("Encoders: data-parallel over the
+ * query batch"): part p holds part_counts[p] consecutive queries on device part_devices[p] (fsgpu_bert_embed_device of that device's
+ * encoder); request->queries / queries_dev are ignored, the counts add up to request->nq.  Every device fetches the slice of its query
+ * group peer to peer over xGMI (in place when the slice is one part on that very device).  Blocking (begin + end). */
+fsgpu_status fsgpu_sharded_search_parts(fsgpu_sharded *idx, const fsgpu_sharded_request *request, const float *const *parts_dev,
+                                        const uint32_t *part_counts, const int32_t *part_devices, uint32_t n_parts, uint32_t *out_rows,
+                                        float *out_scores, uint32_t *out_counts, uint32_t *out_fallbacks);
+/* fsgpu_index_set_int8_latency for every shard: lone EXACT queries take ONE certified pass over the shard's int8 copy (built here,
+ * from the corpus-wide scale) + exact re-score instead of the exact kernel's pass over the f16 rows — same rows and score bits, half
+ * the bytes.  Off by default. */
+fsgpu_status fsgpu_sharded_set_int8_latency(fsgpu_sharded *idx, int32_t enabled);
 fsgpu_status fsgpu_sharded_search_begin(fsgpu_sharded *idx, const fsgpu_sharded_request *request, uint64_t *out_ticket);
 fsgpu_status fsgpu_sharded_search_end(fsgpu_sharded *idx, uint64_t ticket, uint32_t *out_rows, float *out_scores,
                                       uint32_t *out_counts, uint32_t *out_fallbacks);
@@ -380,6 +416,8 @@ float fsgpu_sharded_quant_scale_max(const fsgpu_sharded *idx);
 /* VectorIndex::open (lib.rs:1747-1909) of an FSVI v1 file with an F16 slab, rows split over the devices.  The handle keeps the
  * record table, the doc-id strings and the tombstone flags, so the doc-id level calls below work as on fsgpu_index. */
 fsgpu_status fsgpu_sharded_open_fsvi(const char *path, const int32_t *devices, uint32_t ndev, int32_t exchange, fsgpu_sharded **out);
+fsgpu_status fsgpu_sharded_open_fsvi_grouped(const char *path, const int32_t *devices, uint32_t ndev, uint32_t query_groups,
+                                             int32_t exchange, fsgpu_sharded **out);
 /* index-wide tombstone bitmap (bit r = global row r is live; NULL = all live), split per shard */
 fsgpu_status fsgpu_sharded_set_live_bitmap(fsgpu_sharded *idx, const uint64_t *live_bitmap);
 /* soft_delete / append / doc ids / search_top_k with the resident WAL, shadowing and doc-id dedup (fsgpu_index_soft_delete,

@@ -77,7 +77,7 @@ fsgpu_status fshost_two_tier_create(fsgpu_index *fast_index, fsgpu_index *qualit
  * slabs shard identically).  Fast tier: fsgpu_sharded_search in INT8_TWO_PASS mode (the corpus-wide candidate set of
  * search_top_k_int8_two_pass) or EXACT; quality tier: EXACT (Retrieved) or fsgpu_sharded_quality_scores_for_hits — a gather routed to
  * the shards that own the rows (RescoredFastPool); doc ids from the handles' catalogs (doc_id_mode 0) or synthetic (1).  Fused
- * results equal the unsharded searcher's over the same rows.  quality_int8_latency is ignored (a shard's exact pass is 1/W of the slab). */
+ * results equal the unsharded searcher's over the same rows.  quality_int8_latency switches every shard of the quality tier (fsgpu_sharded_set_int8_latency). */
 fsgpu_status fshost_two_tier_create_sharded(fsgpu_sharded *fast_index, fsgpu_sharded *quality_index, fsgpu_m2v *fast_embedder,
                                             fsgpu_bert *quality_embedder, const fshost_two_tier_config *config,
                                             fshost_two_tier **out);
@@ -134,11 +134,23 @@ typedef struct fshost_stream_result {
     double mean_encode_ms, mean_search_ms; /* per group */
     uint64_t queries, groups, exact_fallbacks;
     uint64_t device_resident_handoff; /* 1: the embeddings went from the encoder to the search in device memory */
+    uint64_t encoders;                /* encoder handles that shared every group's texts (1: the single-encoder form) */
+    char error_detail[256];           /* fsgpu_last_error of the call that failed, whichever thread made it ("" on success):
+                                       * fsgpu_last_error is thread-local and the encoders run on threads of their own */
 } fshost_stream_result;
 fsgpu_status fshost_embed_search_stream(fsgpu_bert *encoder, fsgpu_index *index, fsgpu_sharded *sharded, const int32_t *ids,
                                         const uint32_t *offsets, uint32_t batch, uint32_t n_batches, uint32_t group, uint32_t k,
                                         int32_t overlap, uint32_t *out_rows, float *out_scores, uint32_t *out_counts,
                                         fshost_stream_result *result);
+
+/* The same loop with DATA-PARALLEL encoders over a sharded handle ("Encoders: data-parallel over the query batch"): one
+ * encoder handle per device (any subset of the sharded handle's devices); encoder e embeds the e-th contiguous slice of every
+ * group's texts on its own device, the vectors stay there, and the search fetches each device's slice of its query group peer to
+ * peer (fsgpu_sharded_search_parts).  overlap bit 1 as above (bit 2 has no meaning here: there is no host path). */
+fsgpu_status fshost_embed_search_stream_dp(fsgpu_bert *const *encoders, uint32_t n_encoders, fsgpu_sharded *sharded, const int32_t *ids,
+                                           const uint32_t *offsets, uint32_t batch, uint32_t n_batches, uint32_t group, uint32_t k,
+                                           int32_t overlap, uint32_t *out_rows, float *out_scores, uint32_t *out_counts,
+                                           fshost_stream_result *result);
 
 #ifdef __cplusplus
 }
