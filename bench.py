@@ -764,19 +764,35 @@ def _shard_devices(n: int, virtual: bool):
     return [0] * n if virtual else list(range(n))
 
 
-def _sharded_from_generator(fa, devices, rows: int, dim: int, exchange: int):
-    """A row-sharded handle over the bench corpus: every shard's rows are generated in place on its device (contiguous ceil split)."""
+def _sharded_from_generator(fa, devices, rows: int, dim: int, exchange: int, query_groups: int = 1):
+    """A sharded handle over the bench corpus: every device's rows are generated in place (contiguous ceil split over the row
+    shards; with query groups, device r holds row shard r % (devices / groups) — virtual shards of one device share the tensor)."""
     n = len(devices)
-    per = (rows + n - 1) // n
-    slabs, counts = [], []
+    shards = n // query_groups
+    per = (rows + shards - 1) // shards
+    slabs, counts, made = [], [], {}
     for r, dev in enumerate(devices):
-        lo, hi = min(rows, r * per), min(rows, (r + 1) * per)
-        slabs.append(gen_corpus(lo, hi, dim, torch.device("cuda", dev)))
+        s = r % shards
+        lo, hi = min(rows, s * per), min(rows, (s + 1) * per)
+        if (dev, s) not in made:
+            made[(dev, s)] = gen_corpus(lo, hi, dim, torch.device("cuda", dev))
+        slabs.append(made[(dev, s)])
         counts.append(hi - lo)
-    return fa.NativeShardedIndex.from_device_slabs(devices, dim, counts, [t.data_ptr() for t in slabs], exchange=exchange, keepalive=slabs)
+    return fa.NativeShardedIndex.from_device_slabs(devices, dim, counts, [t.data_ptr() for t in slabs], exchange=exchange, keepalive=slabs,
+                                                   query_groups=query_groups)
 
 
-def two_tier_sharded_section(fa, devices, quality_index, rows: int, k: int, exchange: int):
+def default_query_groups(n_gpus: int) -> int:
+    """Query groups x row shards for an N-GPU run when --query-groups is not given (0 = auto).  A shard's step has a fixed part
+    (sample pass, selections, launches) that does not shrink with its rows, and its main pass runs further below the matrix-core
+    roof the shorter it is.  One GPU rehearsing ONE rank's share of every layout (profiles/r05/hybrid_layout_sweep.txt; 1,024 queries
+    over 10M x 384 per step, ms per step): N = 2: 1 x 2 1.507, 2 x 1 1.447 | N = 4: 1 x 4 0.824, 2 x 2 0.781, 4 x 1 0.925 |
+    N = 8: 1 x 8 0.490, 2 x 4 0.444, 4 x 2 0.511, 8 x 1 0.776.  Two query groups win at every N (8 GPUs: 2.31 M queries/s projected
+    against 2.09 M row-sharded 8 ways)."""
+    return 2 if n_gpus >= 2 and n_gpus % 2 == 0 else 1
+
+
+def two_tier_sharded_section(fa, devices, quality_index, rows: int, k: int, exchange: int, query_groups: int = 1):
     """BASELINE config 3's flow with BOTH tiers row-sharded over the node: potion fast tier rows x 256 (sharded int8
     two-pass: the corpus-wide candidate set) + MiniLM quality tier rows x 384 (sharded exact search, or the fast pool re-scored by
     a gather routed to the owning shards), encoders on device 0, RRF + blend on the host — libfshost's SyncTwoTierSearcher over two
@@ -784,7 +800,7 @@ def two_tier_sharded_section(fa, devices, quality_index, rows: int, k: int, exch
     from frankensearch_amd.host import NativeTwoTierSearcher
     from frankensearch_amd.synthetic import random_bert_weights
 
-    fast_index = _sharded_from_generator(fa, devices, rows, 256, exchange)
+    fast_index = _sharded_from_generator(fa, devices, rows, 256, exchange, query_groups)
     table = np.random.default_rng(0).standard_normal((500_353, 256)).astype(np.float32)   # potion-multilingual-128M shape
     m2v = fa.Model2VecEmbedder(table, device=devices[0])
     bert = fa.NativeEmbedder(random_bert_weights(1, 30522, 384, 6, 1536), device=devices[0])
@@ -849,28 +865,43 @@ def config5_batches(n_batches: int, seed: int = 5):
     return ids, offs
 
 
-def config5_stream_section(fa, index, bert, rows: int, k: int, n_batches: int = 24):
+def config5_stream_section(fa, index, bert, rows: int, k: int, n_batches: int = 24, encoders=None):
     """BASELINE config 5 end to end through the native pipeline (fshost_embed_search_stream): batches of 256 token-id queries ->
     MiniLM-L6 on the GPU -> batched exact top-k, the encode of group g + 1 running under the search of group g; two encoder batches
-    per pass of the slab.  `index` is an fsgpu_index or a row-sharded handle."""
+    per pass of the slab.  `index` is an fsgpu_index or a row-sharded handle.  encoders (a sharded handle only): one encoder per
+    device — the data-parallel form, every encoder embeds its slice of each group on its own device and the shards fetch
+    their query group's slice peer to peer."""
     from frankensearch_amd.host import embed_search_stream
     ids, offs = config5_batches(n_batches)
     embed_search_stream(bert, index, ids[:offs[512]], offs[:513], 256, k, group=2, overlap=True, want_hits=False)   # warm-up
     out = {}
     hits = {}
-    for name, group, overlap, host in (("serial_one_scan_per_batch", 1, False, False), ("serial_two_batches_per_scan", 2, False, False),
-                                       ("overlapped_two_batches_per_scan_host_vectors", 2, True, True),
-                                       ("overlapped_two_batches_per_scan", 2, True, False)):
-        r, s, c, st = embed_search_stream(bert, index, ids, offs, 256, k, group=group, overlap=overlap, host_handoff=host)
+    forms = [("serial_one_scan_per_batch", 1, False, False, bert), ("serial_two_batches_per_scan", 2, False, False, bert),
+             ("overlapped_two_batches_per_scan_host_vectors", 2, True, True, bert), ("overlapped_two_batches_per_scan", 2, True, False, bert)]
+    if encoders:
+        embed_search_stream(list(encoders), index, ids[:offs[512]], offs[:513], 256, k, group=2, overlap=True, want_hits=False)
+        forms.append(("overlapped_two_batches_per_scan_data_parallel_encoders", 2, True, False, list(encoders)))
+    for name, group, overlap, host, enc in forms:
+        r, s, c, st = embed_search_stream(enc, index, ids, offs, 256, k, group=group, overlap=overlap, host_handoff=host)
         hits[name] = (r, s)
         out[name] = {"queries_per_sec": st["queries_per_sec"], "encode_ms_per_group": st["mean_encode_ms"],
                      "search_ms_per_group": st["mean_search_ms"], "groups": int(st["groups"]), "exact_fallbacks": int(st["exact_fallbacks"]),
-                     "embeddings_stay_in_device_memory": bool(st["device_resident_handoff"]), "all_counts_full": bool(np.all(c == k))}
+                     "embeddings_stay_in_device_memory": bool(st["device_resident_handoff"]), "all_counts_full": bool(np.all(c == k)),
+                     "encoders": int(st["encoders"])}
     base = hits["serial_one_scan_per_batch"]
-    same = all(np.array_equal(h[0], base[0]) and np.array_equal(h[1].view(np.uint32), base[1].view(np.uint32)) for h in hits.values())
+    dp_name = "overlapped_two_batches_per_scan_data_parallel_encoders"
+    same = all(np.array_equal(h[0], base[0]) and np.array_equal(h[1].view(np.uint32), base[1].view(np.uint32))
+               for n, h in hits.items() if n != dp_name)
+    if dp_name in hits:
+        # an encoder's slice is a batch of its own size: the encoder picks its kernels by batch shape, so the embeddings agree to the
+        # encoder's tolerance (cos >= 0.999, 2e-3), not bit for bit — the hits are compared the same way
+        d = hits[dp_name]
+        out[dp_name]["top1_agreement_with_single_encoder"] = float(np.mean(d[0][:, 0] == base[0][:, 0]))
+        out[dp_name]["max_abs_score_difference"] = float(np.max(np.abs(d[1] - base[1])))
     out["workload"] = (f"{n_batches} batches of 256 token-id queries ({int(offs[-1])} tokens) -> MiniLM-L6 on the GPU -> batched exact "
                        f"scan of {rows}x384 f16, top-{k}; native pipeline (libfshost), host-pointer C ABI")
-    out["queries_per_sec"] = out["overlapped_two_batches_per_scan"]["queries_per_sec"]
+    best = "overlapped_two_batches_per_scan_data_parallel_encoders" if encoders else "overlapped_two_batches_per_scan"
+    out["queries_per_sec"] = max(out[best]["queries_per_sec"], out["overlapped_two_batches_per_scan"]["queries_per_sec"])
     out["hits_identical_across_forms"] = bool(same)
     return out
 
@@ -889,7 +920,10 @@ def sharded_handle_main(args) -> None:
         sys.exit(f"bench.py --sharded-handle --gpus {n}: only {torch.cuda.device_count()} GPU(s) visible")
     devices = _shard_devices(n, args.virtual_shards)
     exchange = fa.NativeShardedIndex.EXCHANGE_PEER_COPY if args.virtual_shards else fa.NativeShardedIndex.EXCHANGE_AUTO
-    idx = _sharded_from_generator(fa, devices, args.rows, args.dim, exchange)
+    groups = args.query_groups if args.query_groups > 0 else default_query_groups(n)
+    if n % groups:
+        sys.exit(f"bench.py --sharded-handle: --query-groups {groups} does not divide --gpus {n}")
+    idx = _sharded_from_generator(fa, devices, args.rows, args.dim, exchange, groups)
     B, k = args.batch, args.k
     q = gen_queries(2 * B, args.dim, torch.device("cuda", 0)).cpu().numpy()
     for i in range(max(args.warmup, 2)):
@@ -928,6 +962,7 @@ def sharded_handle_main(args) -> None:
            "pipelined_begin_end": {"queries_per_sec": args.steps * B / dt_piped, "ms_per_step": dt_piped / args.steps * 1e3,
                                    "in_flight": 2, "hits_equal_blocking_call": piped_same}, "n_gpus": n,
            "virtual_shards_on_one_device": bool(args.virtual_shards),
+           "layout": f"{groups} query group(s) x {n // groups} row shard(s)",
            "queries_per_step": B, "rows": args.rows, "steps": args.steps,
            "exchange": "rccl ncclAllGather" if idx.exchange_mode() == 1 else "peer copies",
            "path": "matrix-core batched" if args.batched else "exact VALU scan",
@@ -935,7 +970,7 @@ def sharded_handle_main(args) -> None:
            "note": "host-pointer C ABI: each step includes staging + H2D of the queries and D2H of the hits"}
     if not args.no_two_tier and args.dim == 384:
         try:
-            res["two_tier"] = two_tier_sharded_section(fa, devices, idx, args.rows, k, exchange)
+            res["two_tier"] = two_tier_sharded_section(fa, devices, idx, args.rows, k, exchange, groups)
         except Exception as e:   # noqa: BLE001 — a failing section must not cost the scan figures above
             res["two_tier"] = {"error": f"{type(e).__name__}: {e}"}
     idx.close()
@@ -944,12 +979,18 @@ def sharded_handle_main(args) -> None:
     if not args.no_config5 and args.dim == 384:
         try:
             from frankensearch_amd.synthetic import random_bert_weights
-            big = _sharded_from_generator(fa, devices, args.config5_rows, 384, exchange)
-            bert = fa.NativeEmbedder(random_bert_weights(1, 30522, 384, 6, 1536), device=devices[0])
-            res["config5"] = config5_stream_section(fa, big, bert, args.config5_rows, k)
+            big = _sharded_from_generator(fa, devices, args.config5_rows, 384, exchange, groups)
+            weights = random_bert_weights(1, 30522, 384, 6, 1536)
+            bert = fa.NativeEmbedder(weights, device=devices[0])
+            # one encoder per device: every device embeds 1/N of each batch and scans its shard — with the encoder on the root only,
+            # device 0 does both for the whole batch and is every step's straggler (the rehearsal on one GPU puts them all on device 0)
+            encoders = [bert] + [fa.NativeEmbedder(weights, device=d) for d in devices[1:]] if n > 1 else None
+            res["config5"] = config5_stream_section(fa, big, bert, args.config5_rows, k, encoders=encoders)
             res["config5"]["shards"] = n
+            res["config5"]["layout"] = f"{groups} query group(s) x {n // groups} row shard(s)"
             big.close()
-            bert.close()
+            for e in (encoders or [bert]):
+                e.close()
         except Exception as e:   # noqa: BLE001
             res["config5"] = {"error": f"{type(e).__name__}: {e}"}
     print(json.dumps(res), flush=True)
@@ -965,7 +1006,7 @@ def sharded_handle_leg(args, world: int, virtual: bool):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--sharded-handle", "--gpus", str(world), "--rows", str(args.rows), "--dim",
            str(args.dim), "--k", str(args.k), "--batch", str(args.batch), "--steps", str(min(args.steps, 50)), "--warmup", "3",
-           "--config5-rows", str(args.config5_rows)]
+           "--config5-rows", str(args.config5_rows), "--query-groups", str(args.query_groups)]
     for flag, on in (("--exact", args.exact), ("--virtual-shards", virtual), ("--no-two-tier", args.no_two_tier), ("--no-config5", args.no_config5)):
         if on:
             cmd.append(flag)
@@ -1018,6 +1059,9 @@ def main() -> None:
     ap.add_argument("--virtual-shards", action="store_true",
                     help="--sharded-handle: --gpus shards on device 0 exchanged by peer copies (single-GPU rehearsal of the N-way handle)")
     ap.add_argument("--no-config5", action="store_true", help="skip config 5 (encode + 50M x 384 scan) in the sharded-handle leg")
+    ap.add_argument("--query-groups", type=int, default=0,
+                    help="N > 1: query groups G of the hybrid layout (G groups x N/G row shards; every rank scans row shard rank %% (N/G) "
+                         "for 1/G of each batch).  0 = auto (default_query_groups), 1 = row shards only")
     ap.add_argument("--config5-rows", type=int, default=50_000_000, help="rows of the config 5 corpus in the sharded-handle leg")
     args = ap.parse_args()
     args.batched = not args.exact
@@ -1074,7 +1118,11 @@ def main() -> None:
     import frankensearch_amd as fa
     from frankensearch_amd.sharded import GpuShardBackend, ShardedVectorIndex, shard_range
 
-    lo, hi = shard_range(args.rows, rank, world)
+    groups = args.query_groups if args.query_groups > 0 else default_query_groups(world)
+    if world % groups:
+        sys.exit(f"bench.py: --query-groups {groups} does not divide the {world} ranks")
+    row_shards = world // groups
+    lo, hi = shard_range(args.rows, rank % row_shards, row_shards)   # rank r holds row shard r % S and serves query group r // S
     slab = gen_corpus(lo, hi, args.dim, device)
     pool = 64
     queries = gen_queries(max(pool, args.batch) + args.batch, args.dim, device)
@@ -1082,8 +1130,9 @@ def main() -> None:
                                             keepalive=slab)
     index.set_variant(args.variant)
     # N > 1: the all-gather + merge of step i are enqueued on a side stream and run underneath the scan of step i + 1
-    sharded = ShardedVectorIndex(GpuShardBackend(index, device, batched=args.batched), overlap=world > 1)
+    sharded = ShardedVectorIndex(GpuShardBackend(index, device, batched=args.batched), overlap=world > 1, query_groups=groups)
     B, k = args.batch, args.k
+    B_rank = (B + groups - 1) // groups   # queries this rank scans per step
 
     shard_backend = sharded.backend
     fallbacks = [0]
@@ -1160,16 +1209,28 @@ def main() -> None:
     lat = []
     if world == 1:
         q1 = queries[:32].cpu().numpy()
-        for i in range(40):
+        # fsgpu_search_topk as a host calls it: after the batched steps above the index holds the int8 copy of its slab, so a lone
+        # query takes ONE certified pass over it + the exact re-score (rows and score bits of the exact kernels); then the exact
+        # kernels themselves (fsgpu_search_topk_exact), and both against each other
+        for i in range(48):
             t1 = time.perf_counter()
             index.search_batch(q1[i % 32], k)
             lat.append((time.perf_counter() - t1) * 1e3)
         lat = sorted(lat[8:])
+        lat_exact, lone_same = [], True
+        for i in range(40):
+            t1 = time.perf_counter()
+            e = index.search_batch(q1[i % 32], k, exact=True)
+            lat_exact.append((time.perf_counter() - t1) * 1e3)
+            if i < 8:
+                r = index.search_batch(q1[i], k)
+                lone_same &= bool(np.array_equal(r[0], e[0]) and np.array_equal(r[1].view(np.uint32), e[1].view(np.uint32)))
+        lat_exact = sorted(lat_exact[8:])
         # the same boundary with fsgpu_index_set_int8_latency: ONE pass over the int8 copy, the rows within the proven margin re-scored
         # from the f16 slab, the answer certified on the host (rows and score bits of the exact search; the staged path behind it)
         lat_i8, lat_i8_same = [], True
         if args.batched and int8_filter:   # (the batched steps above built the int8 copy and its statistics)
-            exact_hits = [index.search_batch(q1[i], k) for i in range(8)]
+            exact_hits = [index.search_batch(q1[i], k, exact=True) for i in range(8)]
             index.set_int8_latency(True)
             for i in range(72):
                 t1 = time.perf_counter()
@@ -1204,9 +1265,9 @@ def main() -> None:
             "data": "synthetic",
             "config": {
                 "workload": f"{args.rows}x{args.dim} f16 corpus (clustered unit vectors), exact brute-force cosine "
-                            f"top-{k}, {B} queries per step, rows sharded {world} way(s)",
-                "rows": args.rows, "dim": args.dim, "k": k, "queries_per_step": B,
-                "parallelism": f"row-shard x{world}" + ((" + all-gather(top-k) over RCCL" if backend == "nccl" else
+                            f"top-{k}, {B} queries per step, rows sharded {row_shards} way(s)" + (f" x {groups} query groups" if groups > 1 else ""),
+                "rows": args.rows, "dim": args.dim, "k": k, "queries_per_step": B, "query_groups": groups, "row_shards": row_shards,
+                "parallelism": (f"row-shard x{world}" if groups == 1 else f"{groups} query groups x {row_shards} row shards") + ((" + all-gather(top-k) over RCCL" if backend == "nccl" else
                                                           f" + all-gather(top-k) over {backend} (single-GPU rehearsal)") if world > 1 else ""),
                 "kernel_variant": args.variant,
                 "path": ("matrix-core batched (" + ("int8 slab filter, proven margin" if int8_filter else "f16 filter, proven margin") +
@@ -1237,7 +1298,7 @@ def main() -> None:
             # queries of its launch on the matrix cores; the roof that asks for more time is the one that bounds it
             # (a launch of the register-resident-query kernel takes ALL of a step's 512-query groups — gridDim.y passes over the slab —,
             # so its rows streamed are passes x shard rows while every query still meets every row once)
-            q_per_launch = timed_steps * B / launches
+            q_per_launch = timed_steps * B_rank / launches
             passes_per_launch = (scan_rows / launches) / max(hi - lo, 1)
             flops = 2.0 * (hi - lo) * args.dim * q_per_launch
             tflops = flops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
@@ -1264,11 +1325,11 @@ def main() -> None:
             launches_per_step = launches / max(timed_steps, 1)
             passes = scan_rows / max(timed_steps, 1) / max(hi - lo, 1)   # passes over the slab per step
             t_hbm = launches_per_step * alg_bytes / (HBM_PEAK_GBPS * 1e9)
-            t_mfma = 2.0 * (hi - lo) * args.dim * B / (mfma_peak * 1e12)
+            t_mfma = 2.0 * (hi - lo) * args.dim * B_rank / (mfma_peak * 1e12)
             bound_s = max(t_hbm, t_mfma)
             line["roofline"]["joint"] = {
                 "hbm_ms": t_hbm * 1e3, "mfma_ms": t_mfma * 1e3, "bound_ms": bound_s * 1e3, "bound": "hbm" if t_hbm >= t_mfma else "mfma",
-                "frac": bound_s / (elapsed / args.steps), "passes_per_step": passes, "queries_per_pass": B / max(passes, 1e-9),
+                "frac": bound_s / (elapsed / args.steps), "passes_per_step": passes, "queries_per_pass": B_rank / max(passes, 1e-9),
                 "note": "max(filter-slab bytes streamed per step / 8 TB/s, 2*rows*dim*queries ops / " +
                         ("5 POP/s dense int8" if int8_filter else "2.5 PFLOP/s dense f16") + ") / measured step time",
             }
@@ -1298,6 +1359,10 @@ def main() -> None:
             line["roofline"]["measured_copy_GBps"] = measured_copy_gbps(device)
         if lat:
             line["p50_latency_ms_single_query"] = lat[len(lat) // 2]
+            line["p50_latency_ms_single_query_exact_kernels"] = {
+                "p50_ms": lat_exact[len(lat_exact) // 2], "default_path_hits_equal_exact_kernels_8_queries": lone_same,
+                "note": "fsgpu_search_topk_exact: the exact f16 kernels (one pass over the f16 slab); p50_latency_ms_single_query is "
+                        "fsgpu_search_topk, which answers a lone query of an index that holds the int8 copy with the certified pass over it"}
             if lat_i8:
                 line["p50_latency_ms_single_query_int8_certified"] = {
                     "p50_ms": lat_i8[len(lat_i8) // 2], "hits_equal_exact_kernels_8_queries": lat_i8_same,

@@ -61,6 +61,7 @@ SIGNATURES = {
     "fsgpu_index_wal_record_count": (_u64, [_vp]),
     "fsgpu_index_set_live_bitmap": (_i32, [_vp, _vp]),
     "fsgpu_search_topk": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "fsgpu_search_topk_exact": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
     "fsgpu_allow_bitmap_create": (_i32, [_vp, _vp, C.POINTER(_vp)]),
     "fsgpu_allow_bitmap_destroy": (None, [_vp]),
     "fsgpu_allow_bitmap_allowed_rows": (_u64, [_vp]),
@@ -179,12 +180,16 @@ def _share_torch_hip_runtime() -> None:
         spec = None
     if spec is None or not spec.origin:
         return
-    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
-    if os.path.exists(cand):
-        try:
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass  # fall back to the loader's own resolution
+    # ... and the same for RCCL (SONAME librccl.so.1 in both the wheel and /opt/rocm): the sharded handle dlopens it by that name.
+    # With the system copy loaded first, a later `import torch` binds to it instead of its own (another version), and the process
+    # aborts in the libraries' exit handlers ("double free or corruption" after `pytest tests/test_gpu_sharded.py` alone, round 5).
+    for name in ("libamdhip64.so", "librccl.so"):
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", name)
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass  # fall back to the loader's own resolution
 
 
 def lib() -> C.CDLL:

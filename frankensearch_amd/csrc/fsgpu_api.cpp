@@ -427,11 +427,11 @@ fsgpu_status fsgpu_index_set_live_bitmap(fsgpu_index* idx, const uint64_t* live_
 
 static fsgpu_status search_topk_common(fsgpu_index* idx, const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
                                        const uint64_t* allow_bitmap, const uint64_t* allow_resident_dev, uint32_t* out_rows,
-                                       float* out_scores, uint32_t* out_counts) {
+                                       float* out_scores, uint32_t* out_counts, bool exact_only = false) {
     if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
     if (nq && (!queries || !out_counts || (k && (!out_rows || !out_scores))))
         return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
-    if (idx->coalescer.enabled() && nq == 1 && k >= 1 && k <= 64 && query_len == idx->impl.dimension())
+    if (!exact_only && idx->coalescer.enabled() && nq == 1 && k >= 1 && k <= 64 && query_len == idx->impl.dimension())
         return coalesced_search(idx, queries, k, 0, out_rows, out_scores, out_counts, allow_bitmap, allow_resident_dev);
     return guarded([&]() -> fsgpu_status {
         // this index if it is free, else a free replica, else queue on one of the lanes in turn
@@ -459,8 +459,16 @@ static fsgpu_status search_topk_common(fsgpu_index* idx, const float* queries, u
                 lock = std::unique_lock<std::mutex>(lane->mutex());
             }
         }
-        return finish(lane->search_top_k(queries, nq, query_len, k, allow_bitmap, out_rows, out_scores, out_counts, allow_resident_dev));
+        lane->exact_only_ = exact_only;   // (under the lane's mutex)
+        const fsgpu::SearchError e = lane->search_top_k(queries, nq, query_len, k, allow_bitmap, out_rows, out_scores, out_counts, allow_resident_dev);
+        lane->exact_only_ = false;
+        return finish(e);
     });
+}
+
+fsgpu_status fsgpu_search_topk_exact(fsgpu_index* idx, const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
+                                     const uint64_t* allow_bitmap, uint32_t* out_rows, float* out_scores, uint32_t* out_counts) {
+    return search_topk_common(idx, queries, nq, query_len, k, allow_bitmap, nullptr, out_rows, out_scores, out_counts, true);
 }
 
 fsgpu_status fsgpu_search_topk(fsgpu_index* idx, const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,

@@ -1253,16 +1253,22 @@ SearchError VectorIndex::lone_exact_begin(const float* query, uint32_t k) {
     uint32_t* counts_pin = reinterpret_cast<uint32_t*>(scores_pin + k);
     // opted in (fsgpu_index_set_int8_latency): the same hits through the int8 filter + exact re-score — half the bytes of the
     // exact kernel's pass; anything that path does not cover falls through to the exact kernels inside it
-    const bool via_filter = int8_latency && batched_filter != 1 && !i8f_disabled_ && k <= 64 && !f32_ &&
-                            !(row_stride_ && row_stride_ != dim_ * 2) && nrows_ >= 4 * 8192ull;
+    const bool i8_shape = batched_filter != 1 && !i8f_disabled_ && !f32_ && !(row_stride_ && row_stride_ != dim_ * 2) && nrows_ >= 4 * 8192ull;
+    const bool via_filter = int8_latency && !exact_only_ && i8_shape && k <= 64;
+    // By default (round 5): an index that already HOLDS the int8 copy and its statistics — some batched search built them — answers a
+    // lone query with the certified pass over that copy too: the rows and score bits of the exact kernels from half the bytes
+    // (10M x 384: p50 0.67 against 1.27 ms; 1M: 0.12 against 0.17).  Nothing is built for it, an uncertified query goes to the exact
+    // kernels, and fsgpu_search_topk_exact keeps those kernels reachable as they are.
+    const bool by_default = !via_filter && !exact_only_ && i8_shape && k <= 32 && i8_ready_ && i8_stats_ready_ && variant == 0;
     // a lone query of a fused-kernel shape travels in the scan kernel's argument block: no H2D copy in front of the scan
     const uint32_t k_lat = (uint64_t)k < nrows_ ? k : (uint32_t)nrows_;
     const bool in_kernarg = !via_filter && !f32_ && dim_ % 8 == 0 && k_lat <= 256 && variant == 0 &&
                             scan_kernarg_query_supported((int)dim_, k_lat <= 64 ? 64 : 256);
-    if (via_filter && k <= 32 && i8_ready_ && i8_stats_ready_ && variant == 0) {
+    if ((via_filter && k <= 32 && i8_ready_ && i8_stats_ready_ && variant == 0) || by_default) {
         // A failed certificate costs a whole pass over the int8 copy (a query with more rows inside the margin than the finish
         // holds, or so many in one block's share that its list dropped one), so the single pass backs off: after a failure the
-        // next 1, 2, 4 ... 64 lone queries go straight to the staged path; a success resets it.
+        // next 1, 2, 4 ... 64 lone queries go straight to the staged path (the exact kernels when the pass is the default); a
+        // success resets it.
         // (the pass reads the query from the pinned staging block itself: no H2D copy in front of it)
         if (cert_skip_ > 0) {
             --cert_skip_;
@@ -1271,6 +1277,7 @@ SearchError VectorIndex::lone_exact_begin(const float* query, uint32_t k) {
             FSGPU_TRY(certified_i8_enqueue(query, k, &enqueued));
             if (enqueued) {
                 lone_.kind = kLoneCertified;
+                lone_.staged_behind = via_filter;
                 return ok();
             }
         }
@@ -1337,7 +1344,21 @@ SearchError VectorIndex::lone_exact_end(uint32_t* out_rows, float* out_scores, u
         }
         cert_backoff_ = cert_backoff_ ? std::min<uint32_t>(cert_backoff_ * 2, 64) : 1;
         cert_skip_ = cert_backoff_;
-        staged_blocking = true;
+        if (st.staged_behind) {
+            staged_blocking = true;
+        } else {   // the pass was the default, not an opt-in: the exact kernels answer
+            const uint32_t k_lat = (uint64_t)k < nrows_ ? k : (uint32_t)nrows_;
+            const bool in_kernarg = !f32_ && dim_ % 8 == 0 && k_lat <= 256 && variant == 0 && scan_kernarg_query_supported((int)dim_, k_lat <= 64 ? 64 : 256);
+            if (!in_kernarg) {
+                std::memcpy(q_pin, st.query, qbytes);
+                FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, q_pin, qbytes, hipMemcpyHostToDevice, stream_));
+            }
+            host_query_hint_ = in_kernarg ? st.query : nullptr;
+            const SearchError se = search_top_k_device(static_cast<const float*>(ws_queries_.ptr), 1, dim_, k, nullptr, rows_pin, scores_pin,
+                                                       counts_pin, stream_);
+            host_query_hint_ = nullptr;
+            FSGPU_TRY(se);
+        }
     }
     if (staged_blocking) {   // the staged filter path, in one piece
         std::memcpy(q_pin, st.query, qbytes);

@@ -192,6 +192,7 @@ class VectorIndex {
     int32_t batched_filter = 0;
     // fsgpu_index_set_int8_latency: unfiltered fsgpu_search_topk calls of a few queries go through the int8 filter too
     bool int8_latency = false;
+    bool exact_only_ = false;   // fsgpu_search_topk_exact: the call in flight takes the exact kernels whatever copies the index holds
     SearchError prepare_int8_latency();   // builds the int8 copy + its statistics now (else: the first batched search does)
     uint64_t i8f_queries = 0, i8f_refiltered = 0;  // queries the int8 filter took / handed on to the f16 filter
     bool int8_filter_active() const { return batched_filter == 2 || (batched_filter == 0 && !i8f_disabled_); }
@@ -262,6 +263,7 @@ class VectorIndex {
         uint32_t k = 0, mult = 0, cc = 0, cc_out = 0;
         int bits = 8;
         int32_t ticket = -1;
+        bool staged_behind = false;     // a failed certificate is followed by the staged filter path (opt-in) / the exact kernels (default)
     };
     LoneState lone_;
     uint32_t cert_k_ = 0;   // k of the certified pass in flight

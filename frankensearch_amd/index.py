@@ -170,9 +170,11 @@ class VectorIndex:
         check(_lib.lib().fsgpu_index_set_live_bitmap(self._h, _ptr(bm)))
 
     # ---- search -------------------------------------------------------------------------------
-    def search_batch(self, queries: np.ndarray, limit: int, allow: Optional[np.ndarray] = None
+    def search_batch(self, queries: np.ndarray, limit: int, allow: Optional[np.ndarray] = None, exact: bool = False
                      ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-        """nq queries at once -> (rows [nq,limit] u32, scores [nq,limit] f32, counts [nq] u32)."""
+        """nq queries at once -> (rows [nq,limit] u32, scores [nq,limit] f32, counts [nq] u32).
+        exact=True: fsgpu_search_topk_exact — the exact f16 kernels whatever copies the index holds (a lone query of an index that
+        holds the int8 copy is otherwise answered by the certified pass over it: same rows and score bits)."""
         q = np.ascontiguousarray(queries, dtype=np.float32)
         if q.ndim == 1:
             q = q[None, :]
@@ -185,8 +187,8 @@ class VectorIndex:
                                                         _ptr(counts)))
             return rows[:, :limit], scores[:, :limit], counts
         bm = pack_bitmap(allow) if allow is not None else None
-        check(_lib.lib().fsgpu_search_topk(self._h, _ptr(q), nq, qlen, limit, _ptr(bm), _ptr(rows), _ptr(scores),
-                                           _ptr(counts)))
+        fn = _lib.lib().fsgpu_search_topk_exact if exact else _lib.lib().fsgpu_search_topk
+        check(fn(self._h, _ptr(q), nq, qlen, limit, _ptr(bm), _ptr(rows), _ptr(scores), _ptr(counts)))
         return rows[:, :limit], scores[:, :limit], counts
 
     def resident_filter(self, allow: np.ndarray) -> "ResidentFilter":

@@ -8,6 +8,11 @@ ids, so the (score, row) tie-break is shard-invariant; queries are replicated; e
 B*k*8 bytes per rank; every rank merges the W lists with the reference order.  No all-reduce, no row
 exchange.
 
+Hybrid layout (round 5): W = G x S ranks as G query groups x S row shards — rank r scans row shard r % S (the caller builds its
+index over shard_range(N, r % S, S)) for the queries of group r // S, a contiguous ceil(B / G) of the batch; ONE all-gather of
+equal-sized lists over all W ranks, one merge per group over its S lists.  A shard's step has a fixed part that does not shrink
+with its rows, so fewer, larger row shards x several query groups can beat W row shards (every GPU holds the slab many times over).
+
 The compute backend is injected: `GpuShardBackend` (libfsgpu.so) in production; the CPU test suite
 injects an oracle-based stand-in to exercise the partitioning / collective / layout logic under gloo.
 """
@@ -188,10 +193,16 @@ class ShardedVectorIndex:
     returned event has fired."""
 
     def __init__(self, backend: ShardBackend, group: Optional[dist.ProcessGroup] = None, overlap: bool = False,
-                 force_collective: bool = False):
+                 force_collective: bool = False, query_groups: int = 1):
         self.backend = backend
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if query_groups < 1 or self.world % query_groups:
+            raise ValueError("query_groups must divide the world size (query groups x row shards)")
+        self.query_groups = query_groups
+        self.row_shards = self.world // query_groups
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.my_group = self.rank // self.row_shards
         self.overlap = overlap
         # a one-rank group normally skips the all-gather; the single-GPU rehearsal of the N-rank path turns it on so that the
         # collective (RCCL), the side stream and the merge of the gathered layout all run
@@ -199,12 +210,47 @@ class ShardedVectorIndex:
         self._side = None
         self._scan_event = None   # recorded on the scan's stream right after the last search_begin returned (CUDA only)
 
+    # ---- query groups: this rank's slice of a batch, and the padding that keeps every rank's list the same size -------------------
+    def _per(self, b: int) -> int:
+        return (b + self.query_groups - 1) // self.query_groups
+
+    def _my_queries(self, queries: torch.Tensor) -> torch.Tensor:
+        if self.query_groups == 1:
+            return queries
+        per = self._per(queries.shape[0])
+        return queries[self.my_group * per:(self.my_group + 1) * per].contiguous()
+
+    def _padded(self, local: Optional[torch.Tensor], b: int, k: int, like: torch.Tensor) -> torch.Tensor:
+        """[nqg, k] -> [per, k] (EMPTY lists for the queries this group does not hold: the last groups of a ragged batch)."""
+        per = self._per(b)
+        if local is not None and local.shape[0] == per:
+            return local
+        out = torch.full((per, k), EMPTY, dtype=torch.int64, device=like.device)
+        if local is not None and local.shape[0]:
+            out[:local.shape[0]] = local
+        return out
+
+    def _merge(self, gathered: torch.Tensor, b: int, k: int):
+        """[W, per, k] -> (rows, scores, counts) of the b queries: one merge per query group over its row shards' lists."""
+        if self.query_groups == 1:
+            return self.backend.merge(gathered, k)
+        per = gathered.shape[1]
+        parts = [self.backend.merge(gathered[g * self.row_shards:(g + 1) * self.row_shards].contiguous(), k)
+                 for g in range(self.query_groups) if g * per < b]
+        return tuple(torch.cat([p[i] for p in parts])[:b] for i in range(3))
+
     def search_begin(self, queries: torch.Tensor, k: int, after_enqueue=None) -> torch.Tensor:
-        """[B, dim] -> this shard's packed [B, k] list (global rows, best first)."""
-        if after_enqueue is None or not getattr(self.backend, "supports_after_enqueue", False):
-            local = self.backend.search_packed(queries, k)   # (the caller sees that the hook did not run and does its work itself)
+        """[B, dim] -> this rank's packed [ceil(B / G), k] list (global rows, best first) for its query group."""
+        b = queries.shape[0]
+        mine = self._my_queries(queries)
+        if mine.shape[0] == 0:
+            local = None   # a ragged batch left this group without queries (the caller's hook, if any, runs in search_steps)
+        elif after_enqueue is None or not getattr(self.backend, "supports_after_enqueue", False):
+            local = self.backend.search_packed(mine, k)   # (the caller sees that the hook did not run and does its work itself)
         else:
-            local = self.backend.search_packed(queries, k, after_enqueue=after_enqueue)
+            local = self.backend.search_packed(mine, k, after_enqueue=after_enqueue)
+        local = self._padded(local, b, k, queries)
+        self._batch = b
         # The batched scan synchronises its stream before it decides on fallbacks, but the fallback work itself (exact kernels, the
         # nested f16 re-filter, the scatter of their hits into `local`) is only ENQUEUED when the call returns.  This event covers
         # that tail — and nothing of the next scan, whose kernels are enqueued after it.
@@ -269,7 +315,7 @@ class ShardedVectorIndex:
 
         def finish(p):
             local, ticket, ev = p
-            fb = be.scan_end(ticket)
+            fb = be.scan_end(ticket) if ticket is not None else 0
             if after_scan is not None:
                 after_scan()
             if fb and local.is_cuda:   # its fallback work went to the stream only now: the exchange must wait for that too
@@ -283,7 +329,14 @@ class ShardedVectorIndex:
             return x[:3]
 
         for i in range(first, first + n):
-            local, ticket = be.scan_begin(batch_of(i), k, packed=True)
+            full = batch_of(i)
+            mine = self._my_queries(full)
+            if mine.shape[0]:
+                local, ticket = be.scan_begin(mine, k, packed=True)
+            else:
+                local, ticket = None, None
+            local = self._padded(local, full.shape[0], k, full)
+            self._batch = full.shape[0]
             ev = None
             if local.is_cuda:
                 ev = torch.cuda.Event()
@@ -328,8 +381,9 @@ class ShardedVectorIndex:
         scan_event: recorded on the scan's stream when the call that produced `local` returned (search_begin): the side stream
         waits for exactly that — the scan AND whatever fallback work it left enqueued — instead of for the whole current stream,
         which by now may hold the NEXT scan's kernels."""
+        b = getattr(self, "_batch", None) or local.shape[0]
         if not (self.overlap and local.is_cuda):
-            return self.backend.merge(self._gather(local), k)
+            return self._merge(self._gather(local), b, k)
         if self._side is None:
             self._side = torch.cuda.Stream(device=local.device)
         side = self._side
@@ -339,7 +393,7 @@ class ShardedVectorIndex:
             side.wait_stream(torch.cuda.current_stream(local.device))   # the scan that produced `local`
         local.record_stream(side)
         with torch.cuda.stream(side):
-            out = self.backend.merge(self._gather(local), k)
+            out = self._merge(self._gather(local), b, k)
             done = torch.cuda.Event()
             done.record(side)
         return out + (done,)

@@ -144,6 +144,13 @@ fsgpu_status fsgpu_index_set_live_bitmap(fsgpu_index *idx, const uint64_t *live_
 fsgpu_status fsgpu_search_topk(fsgpu_index *idx, const float *queries, uint32_t nq, uint32_t query_len,
                                uint32_t k, const uint64_t *allow_bitmap, uint32_t *out_rows,
                                float *out_scores, uint32_t *out_counts);
+/* The same search on the exact f16 kernels, whatever quantised copies the index holds.  fsgpu_search_topk itself answers a LONE
+ * unfiltered query (nq = 1, k <= 32) of an index that already holds the int8 copy of its slab — a batched search built it — with ONE
+ * certified pass over that copy + an exact re-score of the rows within the proven margin: the rows and f32 score bits of these kernels
+ * from half the bytes (a query the certificate does not cover goes to these kernels).  This entry is the checked kernels alone
+ * (no coalescing, no int8 pass): what the parity tests compare everything else with. */
+fsgpu_status fsgpu_search_topk_exact(fsgpu_index *idx, const float *queries, uint32_t nq, uint32_t query_len, uint32_t k,
+                                     const uint64_t *allow_bitmap, uint32_t *out_rows, float *out_scores, uint32_t *out_counts);
 /* A SearchFilter is typically built once and reused by many queries (filter.rs:19-56; the filtered search paths search.rs:1114-1255
  * take `Option<&dyn SearchFilter>` per call).  fsgpu_allow_bitmap is the precomputed filter made RESIDENT on the index's device:
  * uploaded once (1.25 MB at 10M rows), then any number of fsgpu_search_topk_filtered / _batched_filtered calls use it without a

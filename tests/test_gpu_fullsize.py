@@ -187,6 +187,28 @@ def test_batched_answers_equal_the_oracle_directly_at_full_size(env, oracle):
     assert st["int8_active"] and st["int8_queries"] >= 1024
 
 
+def test_default_lone_query_path_equals_the_oracle_at_full_size(env, oracle):
+    """fsgpu_search_topk for ONE query at 10M rows, as a host calls it by default: the index holds the int8 copy (the batched searches
+    of this module built it), so the query takes the certified pass over that copy + the exact re-score (round 5) — its rows and f32
+    score bits against the ORACLE on the same bytes, and against fsgpu_search_topk_exact (the exact f16 kernels)."""
+    idx = env["idx"]
+    import bench
+
+    host = env["slab"].contiguous().view(env["torch"].int16).cpu().numpy().view(np.uint16)
+    qh = bench.gen_queries(64, DIM, env["dev"]).cpu().numpy()
+    idx.search_batched(qh, K)   # (makes sure the copy and its statistics exist)
+    before = idx.batched_filter_stats()["int8_queries"]
+    threads = bench._oracle_threads()
+    for qi in range(12):
+        rows, scores, counts = idx.search_batch(qh[qi], K)
+        er2, es2, _ = idx.search_batch(qh[qi], K, exact=True)
+        assert np.array_equal(rows, er2) and np.array_equal(bits(scores), bits(es2)), qi
+        if qi < 6:
+            er, es = oracle.search_top_k(host, qh[qi], K, nthreads=threads)
+            assert counts[0] == K and np.array_equal(rows[0], er) and np.array_equal(bits(scores[0]), bits(es)), qi
+    assert idx.batched_filter_stats()["int8_queries"] - before >= 8   # the certified pass answered (the clustered bench corpus certifies)
+
+
 @pytest.mark.parametrize("kind", ["uniform", "outlier"])
 def test_adversarial_corpora_at_full_size(env, kind):
     """SURVEY 8d's low-separation corpus (uniform-random unit vectors) and an anisotropic one with outlier dimensions and Zipf

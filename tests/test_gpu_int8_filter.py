@@ -373,6 +373,45 @@ def test_lone_query_certified_single_pass_equals_the_exact_kernels(fa, oracle):
         b.close()
 
 
+@pytest.mark.parametrize("n", [200_003, 1_000_000])
+def test_default_lone_query_takes_the_certified_pass_once_the_int8_copy_exists(fa, oracle, n):
+    """Round 5: fsgpu_search_topk answers a lone unfiltered query with the certified int8 pass BY DEFAULT once the index holds the int8
+    copy of its slab and its statistics (a batched search builds them) — no opt-in, nothing built for it; before that, and for
+    fsgpu_search_topk_exact always, the exact f16 kernels.  Rows and score bits against the ORACLE (not only the exact kernels),
+    1M x 384 included (BASELINE config 2's size); tombstones; a query the certificate does not cover (a pile of near-duplicates) is
+    answered by the exact kernels with the same bits."""
+    rng = np.random.default_rng(29 + n)
+    dim, k = 384, 10
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    x[5000:11000] = x[5000] + (rng.standard_normal((6000, dim)) * 1e-3).astype(np.float32)   # 6,000 near-duplicates: not certifiable
+    slab = x.astype(np.float16).view(np.uint16)
+    live = rng.random(n) > 0.1
+    idx = fa.VectorIndex.from_slab(slab, live=live)
+    q = x[rng.integers(0, n, 40)] + (rng.standard_normal((40, dim)) * 0.1).astype(np.float32)
+    q[3] = x[5003]
+    assert idx.batched_filter_stats()["int8_queries"] == 0
+    first = idx.search_batch(q[0], k)                       # no copy yet: the exact kernels
+    assert idx.batched_filter_stats()["int8_queries"] == 0
+    idx.search_batched(q, k)                                # builds the int8 copy + statistics
+    base = idx.batched_filter_stats()["int8_queries"]
+    for i in range(16):
+        rows, scores, counts = idx.search_batch(q[i], k)
+        er, es, ec = idx.search_batch(q[i], k, exact=True)
+        assert np.array_equal(rows, er) and np.array_equal(bits(scores), bits(es)) and np.array_equal(counts, ec), i
+        if i < 6:
+            orow, osc = oracle.search_top_k(slab, q[i], k, live=live)
+            assert np.array_equal(rows[0], orow) and np.array_equal(bits(scores[0]), bits(osc)), i
+    assert np.array_equal(first[0], idx.search_batch(q[0], k)[0])
+    took = idx.batched_filter_stats()["int8_queries"] - base
+    assert took >= 8, took     # most of them were certified (query 3 is not; a failure backs the pass off for a few calls)
+    idx.set_batched_filter(1)   # the f16 filter pinned: no int8 pass either
+    mid = idx.batched_filter_stats()["int8_queries"]
+    idx.search_batch(q[1], k)
+    assert idx.batched_filter_stats()["int8_queries"] == mid
+    idx.close()
+
+
 @pytest.mark.parametrize("dim", [128, 256, 384])
 def test_group_maxima_sample_stage_gives_the_exact_search_bits(fa, oracle, dim):
     """The int8 filter's append-free sample stage (MfmaScanArgs::stage 3 + select_groups_kernel: every block reports its four best

@@ -155,14 +155,15 @@ def test_multi_gpu_matches_unsharded_bit_for_bit(fa, oracle):
     assert np.array_equal(rows, wr) and np.array_equal(bits(scores), bits(ws))
 
 
-@pytest.mark.parametrize("shards", [1, 2, 3, 8])
-def test_every_entry_point_of_the_sharded_handle_equals_the_unsharded_index(fa, oracle, shards):
+@pytest.mark.parametrize("groups,shards", [(1, 1), (1, 2), (1, 3), (1, 8), (2, 2), (2, 4), (4, 2), (3, 1)])
+def test_every_entry_point_of_the_sharded_handle_equals_the_unsharded_index(fa, oracle, groups, shards):
     """search_top_k(query, limit, filter) (search.rs:192-206, filter.rs:19-56), tombstone updates, dot_query_at routing and the
     int8 / 4-bit two-pass searches (search.rs:514-661, 876-946; ONE corpus-wide scale, simd.rs:1865-1886) on the sharded handle:
     row ids and f32 score bits of the unsharded index, whatever the number of shards — ragged last shard, bitmap words split
-    across shards, two-pass candidates included."""
+    across shards, two-pass candidates included — and whatever the layout: query groups x row shards (round 5: device r holds row
+    shard r % shards and scans it for 1 / groups of every batch; 2 x 4 is the 8-GPU layout `bench.py --gpus 8` runs)."""
     S = fa.NativeShardedIndex
-    rng = np.random.default_rng(300 + shards)
+    rng = np.random.default_rng(300 + shards + 16 * groups)
     n, dim, k = 150_011, 128, 10
     slab = oracle.clustered_corpus_f16(0, n, dim)
     # one shard holds the corpus-wide max-abs: without the cross-shard reduction the others would quantise with finer scales
@@ -171,7 +172,8 @@ def test_every_entry_point_of_the_sharded_handle_equals_the_unsharded_index(fa, 
     live = rng.random(n) > 0.15
     allow = rng.random(n) > 0.5
     whole = fa.VectorIndex.from_slab(slab, live=live)
-    idx = S.from_slab(slab, [0] * shards, live=live, exchange=S.EXCHANGE_PEER_COPY)
+    idx = S.from_slab(slab, [0] * (groups * shards), live=live, exchange=S.EXCHANGE_PEER_COPY, query_groups=groups)
+    assert idx.shard_count() == groups * shards and idx.query_groups() == groups and idx.row_shards() == shards
     # filtered searches, exact kernels and matrix-core batched path
     wr, ws, wc = whole.search_batch(q, k, allow=allow)
     for mode in (S.EXACT, S.BATCHED):
@@ -220,7 +222,55 @@ def test_every_entry_point_of_the_sharded_handle_equals_the_unsharded_index(fa, 
     assert np.array_equal(r1[0], w1[0]) and np.array_equal(bits(r1[1]), bits(w1[1])) and np.array_equal(r1[2], w1[2])
     with pytest.raises(fa.InvalidConfig):
         idx.search(q, 100, S.INT8_TWO_PASS, candidate_multiplier=3)     # k * multiplier > 256
+    # LONE queries (nq = 1): every shard of one group answers through its own latency lane — the exact kernels with the query in the
+    # argument block, the certified int8 pass once fsgpu_sharded_set_int8_latency is on, the two-pass lane — and the calling thread
+    # merges the short lists; groups take lone queries in turn.  Same rows and score bits as the unsharded index, tombstones included.
+    whole.set_live(live)
+    idx.set_live(live)
+    for lat in (False, True):
+        idx.set_int8_latency(lat)
+        for qi in range(2 * groups + 3):
+            wr1, ws1, wc1 = whole.search_batch(q[qi], k)
+            rows, scores, counts, _ = idx.search(q[qi], k, S.EXACT)
+            assert np.array_equal(rows, wr1) and np.array_equal(bits(scores), bits(ws1)) and np.array_equal(counts, wc1), (lat, qi)
+            for mode, mult, per_query in ((S.INT8_TWO_PASS, 3, whole.search_top_k_int8_two_pass), (S.FOURBIT_TWO_PASS, 5, whole.search_top_k_4bit_two_pass)):
+                rows, scores, counts, _ = idx.search(q[qi], k, mode, candidate_multiplier=mult)
+                hits = per_query(q[qi], k, mult)
+                assert [h.index for h in hits] == rows[0, :counts[0]].tolist(), (lat, mode, qi)
+                assert np.array_equal(bits([h.score for h in hits]), bits(scores[0, :counts[0]])), (lat, mode, qi)
+    # a lone query begun, a batch begun behind it, both ended in order
+    t0 = idx.search_begin(q[5], k, S.EXACT)
+    t1 = idx.search_begin(q[:33], k, S.BATCHED)
+    r0, r1 = idx.search_end(t0), idx.search_end(t1)
+    w0, w1 = whole.search_batch(q[5], k), whole.search_batch(q[:33], k)
+    assert np.array_equal(r0[0], w0[0]) and np.array_equal(bits(r0[1]), bits(w0[1]))
+    assert np.array_equal(r1[0], w1[0]) and np.array_equal(bits(r1[1]), bits(w1[1]))
     idx.close()
+
+
+def test_queries_resident_in_parts_on_the_devices(fa, oracle):
+    """fsgpu_sharded_search_parts: the batch's queries lie in parts in device memory (data-parallel encoders); every
+    device fetches its query group's slice — part boundaries and group boundaries do not coincide here."""
+    import torch
+    S = fa.NativeShardedIndex
+    rng = np.random.default_rng(9)
+    n, dim, k = 90_001, 128, 10
+    slab = oracle.clustered_corpus_f16(0, n, dim)
+    q = np.stack([oracle.clustered_query(i, dim) for i in range(200)])
+    whole = fa.VectorIndex.from_slab(slab)
+    want = whole.search_batch(q, k)
+    qd = torch.from_numpy(q).cuda()
+    for groups, shards in ((1, 4), (2, 2), (4, 1), (2, 4)):
+        idx = S.from_slab(slab, [0] * (groups * shards), exchange=S.EXCHANGE_PEER_COPY, query_groups=groups)
+        for cuts in ([200], [50, 150], [1, 66, 133], [7, 7, 7, 179]):
+            parts, at = [], 0
+            for c in cuts:
+                parts.append((qd[at:at + c].data_ptr(), c, 0))
+                at += c
+            for mode in (S.BATCHED, S.EXACT):
+                rows, scores, counts, _ = idx.search_parts(parts, dim, k, mode)
+                assert np.array_equal(rows, want[0]) and np.array_equal(bits(scores), bits(want[1])), (groups, shards, cuts, mode)
+        idx.close()
 
 
 def test_two_pass_on_tiny_and_ragged_shards(fa, oracle):

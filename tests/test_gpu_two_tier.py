@@ -617,5 +617,18 @@ def test_embed_search_stream_overlapped_equals_the_stages_in_turn():
                     assert np.array_equal(r, want_r) and np.array_equal(s.view(np.uint32), want_s.view(np.uint32)), (group, overlap, host_handoff)
                     assert np.all(c == k) and stats["queries"] == batch * nb and stats["groups"] == (nb + group - 1) // group
                     assert stats["queries_per_sec"] > 0 and stats["device_resident_handoff"] == (0 if host_handoff else 1)
+    # data-parallel encoders (fshost_embed_search_stream_dp): one encoder handle per device — three here, all on device 0,
+    # over 2 query groups x 4 row shards — each embeds its slice of every group, the search fetches the slices peer to peer
+    from frankensearch_amd.synthetic import random_bert_weights  # noqa: F401  (the helper's weights are reused below)
+    hy = fa.NativeShardedIndex.from_slab(slab, [0] * 8, exchange=fa.NativeShardedIndex.EXCHANGE_PEER_COPY, query_groups=2)
+    encoders = [bert, _small_two_tier(fa, np.random.default_rng(61), 64)[3], _small_two_tier(fa, np.random.default_rng(61), 64)[3]]
+    for target in (sh, hy):
+        for group in (1, 2):
+            for overlap in (False, True):
+                r, s, c, stats = embed_search_stream(encoders, target, ids, offs, batch, k, group=group, overlap=overlap)
+                assert stats["encoders"] == 3 and stats["device_resident_handoff"] == 1
+                # (an encoder's slice is a batch of its own: the embeddings agree to the encoder's tolerance, so compare through it)
+                assert np.mean(r[:, 0] == want_r[:, 0]) > 0.98 and np.allclose(s, want_s, atol=2e-3), (group, overlap)
+    hy.close()
     idx.close()
     sh.close()

@@ -140,6 +140,56 @@ def test_world2_allgather_merge_equals_unsharded_oracle(oracle, n, k, world):
         assert np.array_equal(ret["scores"][qi, :c].view(np.uint32), es.view(np.uint32))
 
 
+def _hybrid_worker(rank, world, port, groups, n, nq, dim, k, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from frankensearch_amd.sharded import ShardedVectorIndex, shard_range
+    rng = np.random.default_rng(11)
+    slab = rng.standard_normal((n, dim)).astype(np.float16).view(np.uint16)
+    slab[3] = slab[n - 2]  # a tie across row shards
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    shards = world // groups
+    lo, hi = shard_range(n, rank % shards, shards)   # rank r holds row shard r % S
+    idx = ShardedVectorIndex(OracleShardBackend(slab[lo:hi], lo), query_groups=groups)
+    rows, scores, counts = idx.search(torch.from_numpy(queries), k)
+    assert rows.shape == (nq, k)
+    # the two halves, and the pipelined step loop over a two-half backend (ragged batches: the last groups hold fewer queries, or none)
+    r2, s2, c2 = idx.search_end(idx.search_begin(torch.from_numpy(queries), k), k)
+    assert torch.equal(r2, rows) and torch.equal(c2, counts) and torch.equal(s2.view(torch.int32), scores.view(torch.int32))
+    pidx = ShardedVectorIndex(PipelinedOracleBackend(slab[lo:hi], lo), query_groups=groups)
+    for r4, s4, c4 in pidx.search_steps(lambda i: torch.from_numpy(queries), 0, 4, k, keep_all=True):
+        assert torch.equal(r4, rows) and torch.equal(c4, counts) and torch.equal(s4.view(torch.int32), scores.view(torch.int32))
+    for r3, s3, c3 in idx.search_steps(lambda i: torch.from_numpy(queries), 0, 3, k, keep_all=True):
+        assert torch.equal(r3, rows) and torch.equal(c3, counts) and torch.equal(s3.view(torch.int32), scores.view(torch.int32))
+    if rank == 0:
+        ret["rows"] = rows.numpy().view(np.uint32).copy()
+        ret["scores"] = scores.numpy().copy()
+        ret["counts"] = counts.numpy().copy()
+        ret["slab"] = slab
+        ret["queries"] = queries
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,groups,n,nq,k", [(4, 2, 1001, 7, 10), (4, 4, 500, 5, 10), (2, 2, 64, 1, 5), (4, 2, 37, 2, 64)])
+def test_query_groups_x_row_shards_equal_unsharded_oracle(oracle, world, groups, n, nq, k):
+    # the hybrid layout of round 5: world = query groups x row shards; (world 4, 2 groups) = 2 x 2, (4, 4) = four replicas each taking
+    # a quarter of the batch, nq 1 with 2 groups / nq 5 with 4: groups without a query take part in the all-gather with empty lists
+    dim = 40
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_hybrid_worker, args=(world, _free_port(), groups, n, nq, dim, k, ret), nprocs=world, join=True)
+    slab, queries = ret["slab"], ret["queries"]
+    for qi in range(queries.shape[0]):
+        er, es = oracle.search_top_k(slab, queries[qi], k)
+        c = int(ret["counts"][qi])
+        assert c == len(er)
+        assert np.array_equal(ret["rows"][qi, :c], er)
+        assert np.array_equal(ret["scores"][qi, :c].view(np.uint32), es.view(np.uint32))
+
+
 def test_shard_range_is_a_contiguous_partition():
     from frankensearch_amd.sharded import shard_range
     for n in (0, 1, 7, 8, 9, 10_000_000, 50_000_001):
