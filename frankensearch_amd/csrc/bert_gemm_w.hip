@@ -26,6 +26,12 @@ namespace fsgpu {
 #ifndef FSGPU_GEMM_WP_MIN_TILES
 #define FSGPU_GEMM_WP_MIN_TILES 96   // 64-row tiles (6,144 rows) from which a K = hidden GEMM runs weight-stationary
 #endif
+#ifndef FSGPU_GEMM_WQ_MIN_TILES
+#define FSGPU_GEMM_WQ_MIN_TILES 96   // 64-row tiles (6,144 rows) from which a K = hidden GEMM runs on the 32 x 64-per-wave weight-stationary kernel
+#endif
+#ifndef FSGPU_GEMM_BIG_MIN_TILES
+#define FSGPU_GEMM_BIG_MIN_TILES (1 << 30)  // 64-row tiles (6,144 rows) from which a K = hidden GEMM runs on the 128 x 128 weight-stationary kernel
+#endif
 #ifndef FSGPU_LN_RING
 #define FSGPU_LN_RING 12
 #endif
@@ -275,6 +281,133 @@ __global__ __launch_bounds__(256, 2) void bert_gemm_wp_kernel(const _Float16* __
             }
         }
         __syncthreads();   // the next tile is parked; the output tile may be overwritten
+    }
+}
+
+// Round 5: what the launcher picks for thousands of rows.  (A 128 x 128-tile form with one 512-register wave per SIMD and a 64 x 64
+// wave tile was built first and measured the same 30 us as bert_gemm_wp_kernel: one block per CU serialises a tile's phases — fetch,
+// park, matrix work, epilogue, stores.  What all forms had in common was the placement of their blocks: see the mapping below.)  A
+// block is 64 rows x 128 columns, wave (wr, wc) = rows [32 wr, +32) x columns [64 wc, +64): the same 192-register weight slice
+// (4 column tiles x KS k-steps), every activation fragment feeds FOUR matrix instructions (bert_gemm_wp_kernel: two — its four
+// waves read each row tile four times over, as much LDS time as matrix time), accumulators 32 registers, no staging registers for a
+// prefetch: ~250 registers -> two blocks per CU, and what hides one block's loads, barriers and stores is the OTHER block's matrix
+// work.  Same per-element arithmetic (bit-identical outputs).
+template <int EPI, int KS, int CT>
+__global__ __launch_bounds__(256, 2) void bert_gemm_wq_kernel(const _Float16* __restrict__ A, const half8* __restrict__ Wp,
+                                                              const float* __restrict__ bias, float* __restrict__ out_f32,
+                                                              _Float16* __restrict__ out_h, int M, int N, int qcols, int walkers) {
+    constexpr int K = 32 * KS, BM = 64;
+    constexpr int PITCH = K + 16;
+    constexpr int PIECES = K / 8;
+    constexpr int A_LOADS = BM * PIECES / 256;
+    constexpr int BN = 32 * CT;   // columns per block: two waves side by side, CT column tiles of 16 each
+    constexpr int CP = BN + 8;    // halves per row of the f16 output tile
+    static_assert(BM * PIECES % 256 == 0, "tile must divide among 256 loader threads");
+    __shared__ __attribute__((aligned(16))) _Float16 As[BM * PITCH];
+    __shared__ __attribute__((aligned(16))) _Float16 Os[EPI == 0 ? 8 : BM * CP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    // XCD-aware mapping (block b runs on XCD b % 8; every XCD has its own 4 MB L2): the qcols column blocks that read the SAME row
+    // tile sit on ONE XCD and walk the XCD's tiles in step — XCD c owns the row tiles t = c (mod 8), its blocks are (column block,
+    // walker) pairs, walker w of `walkers` takes every walkers-th of those tiles.  With the 2-D grid order every row tile was fetched
+    // by up to eight L2s, and at different times by the column blocks of one L2: TCC hit rate 44 %, 101 MB fetched from the fabric
+    // for 13.5 MB of operands (profiles/r05/encoder_pmc_before.txt) — that traffic, not the matrix pipe or LDS, was the kernel's time.
+    const int xcd = (int)(blockIdx.x & 7u), slot = (int)(blockIdx.x >> 3);
+    const int col_block = slot % qcols, walker = slot / qcols;
+    const int bn0 = col_block * BN + wc * 16 * CT;
+    const int tiles = (M + BM - 1) / BM;
+    const int stride = 8 * walkers;
+    int t = xcd + 8 * walker;
+    if (t >= tiles) return;
+    half8 wf[CT][KS];
+    {
+        const half8* wp = Wp + (size_t)(bn0 / 16) * KS * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) wf[j][ks] = wp[(j * KS + ks) * 64];
+    }
+    const int fr = lane & 15, fk = (lane >> 4) * 8, cq = (lane >> 4) * 4;
+    const _Float16* a_base = As + (wr * 32 + fr) * PITCH + fk;
+    for (; t < tiles; t += stride) {
+        {   // the tile's rows (clamped at M), parked at the conflict-free pitch — four loads in flight per lane at a time (16 registers:
+            // the weights hold 192 of the wave's 256; the other block of this CU computes meanwhile)
+            constexpr int CH = 4;
+            static_assert(A_LOADS % CH == 0, "the tile's loads split into groups of four");
+#pragma unroll
+            for (int x0 = 0; x0 < A_LOADS; x0 += CH) {
+                half8 ra[CH];
+#pragma unroll
+                for (int x = 0; x < CH; ++x) {
+                    const int p = tid + 256 * (x0 + x), r = p / PIECES, c = p % PIECES;
+                    int row = t * BM + r;
+                    row = row < M ? row : M - 1;
+                    ra[x] = *(reinterpret_cast<const half8*>(A + (size_t)row * K) + c);
+                }
+#pragma unroll
+                for (int x = 0; x < CH; ++x) {
+                    const int p = tid + 256 * (x0 + x), r = p / PIECES, c = p % PIECES;
+                    *reinterpret_cast<half8*>(&As[r * PITCH + c * 8]) = ra[x];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        f32x4 acc[2][CT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            half8 af[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const half8*>(a_base + i * 16 * PITCH + ks * 32);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < CT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j][ks], af[i], acc[i][j], 0, 0, 0);
+        }
+        const int bm0 = t * BM;
+        if (EPI == 0) {
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const int col = bn0 + j * 16 + cq;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = bm0 + wr * 32 + i * 16 + fr;
+                    if (row < M) *reinterpret_cast<f32x4*>(out_f32 + (size_t)row * N + col) = acc[i][j] + bv;
+                }
+            }
+            __syncthreads();   // every wave is done reading As: the next tile may be parked
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + bn0 + j * 16 + cq);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f32x4 y = acc[i][j] + bv;
+                half4 h;
+                h[0] = (_Float16)(EPI == 1 ? gelu_as_w(y[0]) : y[0]);
+                h[1] = (_Float16)(EPI == 1 ? gelu_as_w(y[1]) : y[1]);
+                h[2] = (_Float16)(EPI == 1 ? gelu_as_w(y[2]) : y[2]);
+                h[3] = (_Float16)(EPI == 1 ? gelu_as_w(y[3]) : y[3]);
+                *reinterpret_cast<half4*>(&Os[(wr * 32 + i * 16 + fr) * CP + wc * 16 * CT + j * 16 + cq]) = h;
+                __builtin_amdgcn_sched_barrier(0);   // (one output fragment at a time: the GELU chains must not pile up next to 192 weight registers)
+            }
+        }
+        __syncthreads();   // the output tile is complete, and every wave is done reading As
+        constexpr int OP = BN / 8;   // 16-byte pieces per output row
+        for (int p = tid; p < BM * OP; p += 256) {
+            const int r = p / OP, c = (p % OP) * 8;
+            const int row = bm0 + r;
+            if (row < M)
+                *reinterpret_cast<half8*>(out_h + (size_t)row * N + col_block * BN + c) = *reinterpret_cast<const half8*>(&Os[r * CP + c]);
+        }
+        // (the next iteration's park is behind these reads of Os only through its own barrier: Os and As are different arrays)
     }
 }
 
@@ -833,6 +966,24 @@ static void launch_gemm_w_t(const void* a_h, const void* wp, const float* bias, 
                             hipStream_t stream) {
     // large M: the weight-stationary form — about three blocks per CU, each walking its share of the row tiles
     const int tiles = (M + 63) / 64, cols = N / 128;
+    if (tiles >= FSGPU_GEMM_WQ_MIN_TILES && cols >= 1) {
+        // thousands of rows: 64 x 128 block tiles with 64 x 64... per wave 32 x 64, two blocks per CU, each walking its share of the row tiles
+        int device = 0, cus = 256;
+        if (hipGetDevice(&device) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+        constexpr int CT = KS >= 12 ? 3 : 4;          // column tiles per wave (see the kernel)
+        constexpr int BN = 32 * CT;
+        if (N % BN == 0) {
+            const int qcols = N / BN;
+            // per XCD: qcols column blocks x walkers row walkers on its cus / 8 CUs, two blocks per CU
+            const int per_xcd = std::max(2, 2 * cus / 8);
+            int walkers = std::max(1, per_xcd / qcols);
+            walkers = std::min(walkers, std::max(1, (tiles + 7) / 8));
+            hipLaunchKernelGGL((bert_gemm_wq_kernel<EPI, KS, CT>), dim3(8 * qcols * walkers), dim3(256), 0, stream,
+                               static_cast<const _Float16*>(a_h), static_cast<const half8*>(wp), bias, out_f32,
+                               static_cast<_Float16*>(out_h), M, N, qcols, walkers);
+            return;
+        }
+    }
     if (tiles >= FSGPU_GEMM_WP_MIN_TILES && cols >= 1) {
         int device = 0, cus = 256;
         if (hipGetDevice(&device) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);

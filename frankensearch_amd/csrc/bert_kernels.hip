@@ -688,16 +688,29 @@ __global__ __launch_bounds__(256) void bert_attention_lds_kernel(const _Float16*
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int stride = 3 * hidden;
     const _Float16* base = qkv + (size_t)t0 * stride + head * 32;
-    for (int p = tid; p < S32 * 4; p += 256) {
-        const int key = p >> 2, c = p & 3;
-        const bool live = key < S;
-        const _Float16* src = base + (size_t)(live ? key : S - 1) * stride + c * 8;
-        const half8 kv = *reinterpret_cast<const half8*>(src + hidden);
-        half8 vv = *reinterpret_cast<const half8*>(src + 2 * hidden);
-        if (!live) vv = half8{};
-        *reinterpret_cast<half8*>(&Ks[key * 32 + ((c ^ ((key >> 2) & 3)) * 8)]) = kv;
+    // K rows as they are (chunk-swizzled), V transposed.  A thread takes FOUR consecutive keys of one 16-byte chunk: the transposed
+    // values of a dimension are then 8 contiguous bytes — eight 8-byte stores per 4 keys where one key at a time needed 32 two-byte
+    // ones (round 5: SQ_LDS_BANK_CONFLICT was 46 % of the kernel's LDS cycles, nearly all of it this fill).
+    for (int g = tid; g < S32; g += 256) {
+        const int key0 = (g >> 2) * 4, c = g & 3;
+        half8 kv[4], vv[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) Vt[(c * 8 + e) * vp + key] = vv[e];
+        for (int i = 0; i < 4; ++i) {
+            const int key = key0 + i;
+            const bool live = key < S;
+            const _Float16* src = base + (size_t)(live ? key : S - 1) * stride + c * 8;
+            kv[i] = *reinterpret_cast<const half8*>(src + hidden);
+            vv[i] = *reinterpret_cast<const half8*>(src + 2 * hidden);
+            if (!live) vv[i] = half8{};
+        }
+        const int sw = (c ^ ((key0 >> 2) & 3)) * 8;   // (the four keys share key >> 2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<half8*>(&Ks[(key0 + i) * 32 + sw]) = kv[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const half4v t = {vv[0][e], vv[1][e], vv[2][e], vv[3][e]};
+            *reinterpret_cast<half4v*>(&Vt[(c * 8 + e) * vp + key0]) = t;
+        }
     }
     __syncthreads();
     const int fr = lane & 15, kg = lane >> 4;
