@@ -29,9 +29,6 @@ namespace fsgpu {
 #ifndef FSGPU_GEMM_WQ_MIN_TILES
 #define FSGPU_GEMM_WQ_MIN_TILES 96   // 64-row tiles (6,144 rows) from which a K = hidden GEMM runs on the 32 x 64-per-wave weight-stationary kernel
 #endif
-#ifndef FSGPU_GEMM_BIG_MIN_TILES
-#define FSGPU_GEMM_BIG_MIN_TILES (1 << 30)  // 64-row tiles (6,144 rows) from which a K = hidden GEMM runs on the 128 x 128 weight-stationary kernel
-#endif
 #ifndef FSGPU_LN_RING
 #define FSGPU_LN_RING 12
 #endif
@@ -311,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void bert_gemm_wq_kernel(const _Float16* __
     // tile sit on ONE XCD and walk the XCD's tiles in step — XCD c owns the row tiles t = c (mod 8), its blocks are (column block,
     // walker) pairs, walker w of `walkers` takes every walkers-th of those tiles.  With the 2-D grid order every row tile was fetched
     // by up to eight L2s, and at different times by the column blocks of one L2: TCC hit rate 44 %, 101 MB fetched from the fabric
-    // for 13.5 MB of operands (profiles/r05/encoder_pmc_before.txt) — that traffic, not the matrix pipe or LDS, was the kernel's time.
+    // for 13.5 MB of operands (profiles/r05/encoder_large_m_pmc.txt) — that traffic, not the matrix pipe or LDS, was the kernel's time.
     const int xcd = (int)(blockIdx.x & 7u), slot = (int)(blockIdx.x >> 3);
     const int col_block = slot % qcols, walker = slot / qcols;
     const int bn0 = col_block * BN + wc * 16 * CT;
