@@ -303,11 +303,12 @@ def adversarial_section(kind: str, rows: int, dim: int, k: int, device, local_ra
         ok &= bool(np.array_equal(g_rows[qi, :len(er)], er) and np.array_equal(g_scores[qi, :len(es)].view(np.uint32), es.view(np.uint32)))
     del host
     # ... and 64 more against the exact kernels (a different code path over the same slab)
-    e_rows, e_scores, _ = index.search_batch(qh[64:128], k)
+    e_rows, e_scores, _ = index.search_batch(qh[64:128], k, exact=True)
     same = bool(np.array_equal(g_rows[64:128], e_rows) and np.array_equal(g_scores[64:128].view(np.uint32), e_scores.view(np.uint32)))
     kth = float(np.median(g_scores[:, k - 1]))
     res = {"corpus": kind, "rows": rows, "queries_per_step": B, "queries_per_sec": steps * B / dt, "ms_per_step": dt / steps * 1e3,
-           "int8_filter_active_after": bool(f1["int8_active"]), "int8_filter_queries": f1["int8_queries"] - f0["int8_queries"],
+           "int8_filter_active_after": bool(f1["int8_active"]), "int8_filter_copy_rotated": bool(index.filter_rotated()),
+           "int8_filter_queries": f1["int8_queries"] - f0["int8_queries"],
            "refiltered_on_f16_queries": f1["refiltered_f16"] - f0["refiltered_f16"], "exact_fallback_queries": fb,
            "median_kth_score": kth, "batched_equals_oracle_rows_and_bits": ok, "oracle_checked_queries": len(picks),
            "batched_equals_exact_kernels_64_queries": same}

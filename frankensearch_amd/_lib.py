@@ -52,6 +52,8 @@ SIGNATURES = {
     "fsgpu_index_dimension": (_u32, [_vp]),
     "fsgpu_index_set_hreduce": (_i32, [_vp, _i32]),
     "fsgpu_index_set_batched_filter": (_i32, [_vp, _i32]),
+    "fsgpu_index_set_filter_rotation": (_i32, [_vp, _i32]),
+    "fsgpu_index_filter_rotated": (_i32, [_vp]),
     "fsgpu_index_set_int8_latency": (_i32, [_vp, _i32]),
     "fsgpu_index_batched_filter_stats": (_i32, [_vp, _vp, _vp, _vp]),
     "fsgpu_index_int8_filter_bound": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp]),
@@ -169,10 +171,14 @@ _lib = None
 
 
 def _share_torch_hip_runtime() -> None:
-    """PyTorch-ROCm wheels bundle their own libamdhip64.so under the SONAME libfsgpu.so also needs.  Whichever copy is
-    loaded first serves the whole process; if that is the system one, a later `import torch` finds no GPU
-    (torch.cuda.is_available() is False).  When torch is installed, load ITS runtime first so that the order of imports
-    does not matter (bench.py / sharded.py hand torch device pointers to this library)."""
+    """PyTorch-ROCm wheels bundle their own copies of the ROCm runtime libraries (libamdhip64, librccl, hsa-runtime, ...) under
+    the SONAMEs libfsgpu.so also resolves.  Whichever copy of a library is loaded first serves the whole process: with the system
+    HIP runtime first, a later `import torch` finds no GPU; with only SOME of the system copies first (libfsgpu loaded, then torch
+    loading the rest of its own set) the process has been seen to abort in the libraries' exit handlers ("double free or
+    corruption" after `pytest tests/test_gpu_sharded.py` alone, round 5 — the whole suite, where an earlier test file imports
+    torch first, was fine).  When torch is installed, import it BEFORE libfsgpu.so is loaded, so that the order of imports in the
+    caller does not matter (bench.py / sharded.py hand torch device pointers to this library anyway).  Loading RCCL alone ahead of
+    time is not an option: without a GPU its own exit handlers abort."""
     import importlib.util
     try:
         spec = importlib.util.find_spec("torch")
@@ -180,16 +186,17 @@ def _share_torch_hip_runtime() -> None:
         spec = None
     if spec is None or not spec.origin:
         return
-    # ... and the same for RCCL (SONAME librccl.so.1 in both the wheel and /opt/rocm): the sharded handle dlopens it by that name.
-    # With the system copy loaded first, a later `import torch` binds to it instead of its own (another version), and the process
-    # aborts in the libraries' exit handlers ("double free or corruption" after `pytest tests/test_gpu_sharded.py` alone, round 5).
-    for name in ("libamdhip64.so", "librccl.so"):
-        cand = os.path.join(os.path.dirname(spec.origin), "lib", name)
-        if os.path.exists(cand):
-            try:
-                C.CDLL(cand, mode=C.RTLD_GLOBAL)
-            except OSError:
-                pass  # fall back to the loader's own resolution
+    try:
+        import torch  # noqa: F401
+        return
+    except Exception:   # a broken torch install: fall back to its HIP runtime alone
+        pass
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass  # fall back to the loader's own resolution
 
 
 def lib() -> C.CDLL:

@@ -359,6 +359,21 @@ fsgpu_status fsgpu_index_set_batched_filter(fsgpu_index* idx, int32_t filter) {
     return FSGPU_OK;
 }
 
+fsgpu_status fsgpu_index_set_filter_rotation(fsgpu_index* idx, int32_t mode) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    if (mode < FSGPU_ROTATION_AUTO || mode > FSGPU_ROTATION_ON) return fail(FSGPU_ERR_INVALID_CONFIG, "unknown rotation mode");
+    std::unique_lock<std::shared_mutex> state(idx->state_mu);
+    std::lock_guard<std::mutex> lock(idx->impl.mutex());
+    idx->impl.filter_rotation = mode;
+    return FSGPU_OK;
+}
+
+int32_t fsgpu_index_filter_rotated(fsgpu_index* idx) {
+    if (!idx) return 0;
+    std::lock_guard<std::mutex> lock(idx->impl.mutex());
+    return idx->impl.filter_rotated() ? 1 : 0;
+}
+
 fsgpu_status fsgpu_index_set_int8_latency(fsgpu_index* idx, int32_t enabled) {
     if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
     std::unique_lock<std::shared_mutex> state(idx->state_mu);

@@ -166,6 +166,115 @@ __global__ __launch_bounds__(256) void i8_slab_stats_kernel(const unsigned short
     }
 }
 
+// ---- the int8 FILTER's rotated copy (round 5) ---------------------------------------------------------------------------------
+// One corpus-wide int8 scale is 127 / max|x|: a corpus with outlier channels (a few dimensions carrying most of every row's norm, as
+// trained embedding models have) quantises its other dimensions to a handful of levels, and the filter's proven margin — fixed in
+// integer units — grows in cosine units with 1 / (c_s c_q): 0.063 against 0.011 on the bench's two corpora, 1,000 rows within the
+// margin of the k-th best against 40 (scripts/r05/rotation_bound_study.py).  Dot products are invariant under an orthogonal map,
+// outlier channels are not: the filter's copy may hold quantised rows of R x, its queries R q — R a fixed random orthogonal matrix —
+// and x . q = (R x) . (R q).  The map is applied in f64 and rounded ONCE to f32, so what it adds to the bound is 2^-24-sized
+// (prepare_queries_i8_filter_kernel's extra_coeff); everything downstream — statistics, margin, thresholds — is the unrotated code on
+// the rotated numbers, and the exact re-score that decides rows and score bits never sees the rotation.
+//
+// out[r][d] = fl32( sum_j R[d][j] in[r][j] ) with the sum in f64; rt = R transposed ([j][d]: a thread's loads are coalesced).
+// One thread per output dimension, RB rows per block (their inputs in LDS as f64, read as broadcasts).  bad_to_nan (queries): a row
+// with an element that is not finite or above 65,504 comes out as NaN, so that the filter marks it uncertifiable as it does unrotated.
+template <typename IN, int RB>
+__global__ void rotate_rows_kernel(const IN* __restrict__ in, uint32_t nrows, uint32_t in_stride, uint32_t dim,
+                                   const double* __restrict__ rt, float* __restrict__ out, int bad_to_nan) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rot_smem[];
+    double* xs = reinterpret_cast<double*>(rot_smem);   // [RB][dim]
+    __shared__ int bad[RB];
+    const uint32_t row0 = blockIdx.x * RB;
+    const int d = threadIdx.x;
+    if (d < RB) bad[d] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < RB * dim; i += blockDim.x) {
+        const uint32_t rr = i / dim, j = i - rr * dim;
+        const uint32_t row = row0 + rr < nrows ? row0 + rr : nrows - 1;
+        const float v = (float)in[(size_t)row * in_stride + j];
+        if (bad_to_nan && !(fabsf(v) <= 65504.0f)) bad[rr] = 1;
+        xs[i] = (double)v;
+    }
+    __syncthreads();
+    double acc[RB];
+#pragma unroll
+    for (int rr = 0; rr < RB; ++rr) acc[rr] = 0.0;
+    for (uint32_t j = 0; j < dim; ++j) {
+        const double r = rt[(size_t)j * dim + d];
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) acc[rr] = fma(r, xs[rr * dim + j], acc[rr]);
+    }
+#pragma unroll
+    for (int rr = 0; rr < RB; ++rr)
+        if (row0 + rr < nrows) out[(size_t)(row0 + rr) * dim + d] = bad[rr] ? __builtin_nanf("") : (float)acc[rr];
+}
+
+// max |v| over f32 values, ACCUMULATED into *out_bits (the caller zeroes it once): fmaxf ignores NaN like f32::max
+__global__ __launch_bounds__(256) void maxabs_f32_kernel(const float* __restrict__ v, size_t n, unsigned int* __restrict__ out_bits) {
+    float m = 0.f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(v[i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));
+}
+
+// quantize_f16_le_bytes_to_i8_generic's rule (simd.rs:1865-1886: x * (127 / max), round half away, clamp, NaN -> 0) on f32 values
+__global__ __launch_bounds__(256) void quantize_f32_i8_kernel(const float* __restrict__ v, size_t n, const unsigned int* __restrict__ max_bits,
+                                                              signed char* __restrict__ out) {
+    const float max_abs = __uint_as_float(*max_bits);
+    const bool zero = !(max_abs > 0.0f);
+    const float scale = zero ? 0.f : 127.0f / max_abs;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = zero ? (signed char)0 : quant_i8(v[i], scale);
+}
+
+// i8_slab_stats_kernel on f32 rows, ACCUMULATED into out (the caller zeroes it once)
+__global__ __launch_bounds__(256) void i8_stats_f32_kernel(const float* __restrict__ rows, const signed char* __restrict__ rows_i8,
+                                                           uint32_t nrows, uint32_t dim, const unsigned int* __restrict__ max_bits,
+                                                           unsigned int* __restrict__ out) {
+    const float max_abs = __uint_as_float(*max_bits);
+    const float scale = max_abs > 0.0f ? 127.0f / max_abs : 0.f;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_gid = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * 256) >> 6;
+    float e2max = 0.f;
+    unsigned int r1max = 0, r2max = 0, bad = 0;
+    for (uint32_t row = wave_gid; row < nrows; row += nwaves) {
+        const float* p = rows + (size_t)row * dim;
+        const signed char* pi = rows_i8 + (size_t)row * dim;
+        float e2 = 0.f;
+        unsigned int r1 = 0, r2 = 0;
+        for (uint32_t i = lane; i < dim; i += 64) {
+            const float x = p[i];
+            const int r = (int)pi[i];
+            if (!(fabsf(x) <= 65504.0f)) bad = 1;
+            const float e = fabsf(x * scale - (float)r) + 8e-6f;
+            e2 += e * e;
+            r1 += (unsigned int)(r < 0 ? -r : r);
+            r2 += (unsigned int)(r * r);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            e2 += __shfl_xor(e2, off);
+            r1 += __shfl_xor(r1, off);
+            r2 += __shfl_xor(r2, off);
+        }
+        e2max = fmaxf(e2max, e2);
+        r1max = r1 > r1max ? r1 : r1max;
+        r2max = r2 > r2max ? r2 : r2max;
+    }
+    bad = __any(bad) ? 1u : 0u;
+    if (lane == 0) {
+        if (e2max == e2max) atomicMax(&out[0], __float_as_uint(e2max));
+        else bad = 1;
+        atomicMax(&out[1], r1max);
+        atomicMax(&out[2], r2max);
+        if (bad) atomicOr(&out[3], 1u);
+    }
+}
+
 // pack_f16_le_bytes_to_4bit (simd.rs:2153-2215): scale 7/max_abs (0 when max_abs <= 1e-9), low nibble = even dim.
 // Even dims: 8 values -> one 32-bit word anywhere in the slab (rows are whole bytes).
 __global__ __launch_bounds__(256) void pack_slab_4bit_kernel(const unsigned short* __restrict__ slab, uint64_t count,
@@ -401,6 +510,48 @@ hipError_t launch_i8_slab_stats(const void* slab_f16, const void* slab_i8, uint3
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(i8_slab_stats_kernel, dim3(2048), dim3(256), 0, stream, static_cast<const unsigned short*>(slab_f16),
                        static_cast<const signed char*>(slab_i8), nrows, dim, max_bits_dev, stats_dev);
+    return hipGetLastError();
+}
+
+template <typename IN>
+static hipError_t launch_rotate_rows_t(const IN* in, uint32_t nrows, uint32_t in_stride, uint32_t dim, const double* rt, float* out,
+                                       int bad_to_nan, hipStream_t stream) {
+    constexpr int RB = 16;
+    if (nrows == 0) return hipSuccess;
+    if (dim == 0 || dim > 1024) return hipErrorInvalidValue;
+    const size_t lds = (size_t)RB * dim * 8;
+    auto kern = rotate_rows_kernel<IN, RB>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((nrows + RB - 1) / RB), dim3(dim), lds, stream, in, nrows, in_stride, dim, rt, out, bad_to_nan);
+    return hipGetLastError();
+}
+
+hipError_t launch_rotate_rows_f16(const void* rows_f16, uint32_t nrows, uint32_t dim, const double* rt, float* out, hipStream_t stream) {
+    return launch_rotate_rows_t(static_cast<const _Float16*>(rows_f16), nrows, dim, dim, rt, out, 0, stream);
+}
+
+hipError_t launch_rotate_rows_f32(const float* rows, uint32_t nrows, uint32_t row_stride, uint32_t dim, const double* rt, float* out,
+                                  hipStream_t stream) {
+    return launch_rotate_rows_t(rows, nrows, row_stride ? row_stride : dim, dim, rt, out, 1, stream);
+}
+
+hipError_t launch_maxabs_f32(const float* v, size_t n, unsigned int* max_bits_dev, hipStream_t stream) {
+    hipLaunchKernelGGL(maxabs_f32_kernel, dim3(2048), dim3(256), 0, stream, v, n, max_bits_dev);
+    return hipGetLastError();
+}
+
+hipError_t launch_quantize_f32_i8(const float* v, size_t n, const unsigned int* max_bits_dev, void* out_i8, hipStream_t stream) {
+    hipLaunchKernelGGL(quantize_f32_i8_kernel, dim3(2048), dim3(256), 0, stream, v, n, max_bits_dev, static_cast<signed char*>(out_i8));
+    return hipGetLastError();
+}
+
+hipError_t launch_i8_stats_f32(const float* rows, const void* rows_i8, uint32_t nrows, uint32_t dim, const unsigned int* max_bits_dev,
+                               unsigned int* stats_dev, hipStream_t stream) {
+    hipLaunchKernelGGL(i8_stats_f32_kernel, dim3(2048), dim3(256), 0, stream, rows, static_cast<const signed char*>(rows_i8), nrows, dim,
+                       max_bits_dev, stats_dev);
     return hipGetLastError();
 }
 

@@ -226,7 +226,7 @@ hipError_t launch_prepare_queries_i8(const float* q, uint32_t nq, uint32_t nq_pa
 // scale x query scale)| from the slab statistics of launch_i8_slab_stats (see mfma_scan.hip)
 hipError_t launch_prepare_queries_i8_filter(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t q_stride,
                                             const unsigned int* slab_max_bits, const unsigned int* slab_stats, void* qi8,
-                                            float* delta, hipStream_t stream, float* unit_out = nullptr);
+                                            float* delta, hipStream_t stream, float* unit_out = nullptr, double extra_coeff = 0.0);
 
 constexpr uint32_t kMfmaMaxSlots = 32;           // candidate slots per (block, query) staged in LDS
 constexpr uint32_t kMfmaSpillCountStride = 16;  // uint32 counters 64 bytes apart
@@ -263,6 +263,17 @@ hipError_t launch_quantize_slab_4bit_levels(const void* slab_f16, size_t n_value
 // { f32 bits of max_row sum eps^2, max_row sum |r|, max_row sum r^2, non-finite flag }
 hipError_t launch_i8_slab_stats(const void* slab_f16, const void* slab_i8, uint32_t nrows, uint32_t dim,
                                 const unsigned int* max_bits_dev, unsigned int* stats_dev, hipStream_t stream);
+// the int8 filter's rotated copy (int8_kernels.hip): rows / queries through a fixed orthogonal map in f64, rounded once to f32;
+// rt = the map TRANSPOSED, [dim][dim] f64.  _f32: a row with an element that is not finite or above 65,504 comes out as NaN.
+hipError_t launch_rotate_rows_f16(const void* rows_f16, uint32_t nrows, uint32_t dim, const double* rt, float* out, hipStream_t stream);
+hipError_t launch_rotate_rows_f32(const float* rows, uint32_t nrows, uint32_t row_stride, uint32_t dim, const double* rt, float* out,
+                                  hipStream_t stream);
+// ... and the quantiser / statistics of launch_quantize_slab_i8 / launch_i8_slab_stats over f32 rows, chunk by chunk: max-abs and
+// statistics ACCUMULATE into words the caller zeroed
+hipError_t launch_maxabs_f32(const float* v, size_t n, unsigned int* max_bits_dev, hipStream_t stream);
+hipError_t launch_quantize_f32_i8(const float* v, size_t n, const unsigned int* max_bits_dev, void* out_i8, hipStream_t stream);
+hipError_t launch_i8_stats_f32(const float* rows, const void* rows_i8, uint32_t nrows, uint32_t dim, const unsigned int* max_bits_dev,
+                               unsigned int* stats_dev, hipStream_t stream);
 bool scan_i8_fused_supported(int dim, int kcap);
 // 4-bit two-pass (int8_kernels.hip, BITS = 4)
 hipError_t launch_pack_slab_4bit(const void* slab_f16, uint64_t count, uint32_t dim, unsigned int* max_bits_dev,

@@ -942,7 +942,7 @@ __global__ __launch_bounds__(256) void prepare_queries_i8_filter_kernel(const fl
                                                                         uint32_t dim, const unsigned int* __restrict__ slab_max_bits,
                                                                         const unsigned int* __restrict__ slab_stats,
                                                                         signed char* __restrict__ qi8, float* __restrict__ delta,
-                                                                        float* __restrict__ unit_out) {
+                                                                        float* __restrict__ unit_out, double extra_coeff) {
     __shared__ float redf[4];
     __shared__ unsigned int redu[2][4];
     __shared__ int s_bad;
@@ -1009,7 +1009,9 @@ __global__ __launch_bounds__(256) void prepare_queries_i8_filter_kernel(const fl
         const double n = (double)dim;
         const double c_s = 127.0 / slab_max * 1.000001, c_q = (double)scale * 1.000001;
         double d = fmin(0.50001 * P1, E2 * P2) + fmin(0.50001 * R1, H2 * R2) + fmin(0.25001 * n, E2 * H2);
-        d += n * 1.1920929e-7 /* 2^-23 */ * (R2 + E2) * (P2 + H2) + n * 1.5e-45 /* > 2^-149 */ * c_s * c_q;
+        // (extra_coeff: what a ROTATED filter copy adds — slab and queries went through an orthogonal map in f64 and were rounded once
+        // to f32: |x . q - x' . q'| <= (|R^T R - I| + 2.01 x 2^-24) |x| |q|, in the same units as the f32-accumulation term beside it)
+        d += (n * 1.1920929e-7 /* 2^-23 */ + extra_coeff) * (R2 + E2) * (P2 + H2) + n * 1.5e-45 /* > 2^-149 */ * c_s * c_q;
         d = d * 1.001 + 1.0;
         float out = (float)d;
         if (!((double)out >= d)) out = __uint_as_float(__float_as_uint(out) + 1u);  // round up
@@ -1119,9 +1121,9 @@ hipError_t launch_prepare_queries_i8(const float* q, uint32_t nq, uint32_t nq_pa
 
 hipError_t launch_prepare_queries_i8_filter(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t q_stride,
                                             const unsigned int* slab_max_bits, const unsigned int* slab_stats, void* qi8,
-                                            float* delta, hipStream_t stream, float* unit_out) {
+                                            float* delta, hipStream_t stream, float* unit_out, double extra_coeff) {
     hipLaunchKernelGGL(prepare_queries_i8_filter_kernel, dim3(nq_pad), dim3(256), 0, stream, q, nq, q_stride ? q_stride : dim, dim,
-                       slab_max_bits, slab_stats, static_cast<signed char*>(qi8), delta, unit_out);
+                       slab_max_bits, slab_stats, static_cast<signed char*>(qi8), delta, unit_out, extra_coeff);
     return hipGetLastError();
 }
 

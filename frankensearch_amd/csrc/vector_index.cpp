@@ -170,7 +170,8 @@ VectorIndex::~VectorIndex() {
                             &ws_counts_, &ws_keys_a_, &ws_keys_b_, &ws_sort_tmp_, &ws_gather_rows_, &ws_gather_out_,
                             &i8_slab_, &n4_slab_, &i8_max_, &ws_i8_query_, &ws_cand_packed_, &ws_cand_rows_, &ws_cand_scores_,
                             &mf_max_norm_, &mf_qh_, &mf_delta_, &mf_tau_, &mf_cand_, &mf_dense_, &mf_sel_,
-                            &mf_fallback_, &mf_fallback2_, &mf_spill_, &mf_io_, &mf_io2_, &i8_stats_, &n4u_slab_, &mf_cand_count_, &ws_pairs_})
+                            &mf_fallback_, &mf_fallback2_, &mf_spill_, &mf_io_, &mf_io2_, &i8_stats_, &n4u_slab_, &mf_cand_count_, &ws_pairs_,
+                            &i8f_slab_, &i8f_max_, &i8f_stats_, &rot_mat_, &rot_q_})
         b->release();
     if (mf_flags_host_) (void)hipHostFree(mf_flags_host_);
     if (io_host_) (void)hipHostFree(io_host_);
@@ -1139,11 +1140,10 @@ SearchError VectorIndex::certified_i8_enqueue(const float* query, uint32_t k, bo
     uint32_t* overflow_pin = reinterpret_cast<uint32_t*>(delta_pin + 4);
     *overflow_pin = 0;
     *ncand_pin = 0;
-    FSGPU_HIP(launch_prepare_queries_i8_filter(q_pin, 1, 1, dim_, dim_, static_cast<const unsigned int*>(i8_max_.ptr),
-                                               static_cast<const unsigned int*>(i8_stats_.ptr), ws_i8_query_.ptr, delta_pin, stream_));
+    FSGPU_TRY(prepare_filter_queries(q_pin, 1, 1, dim_, ws_i8_query_.ptr, delta_pin, nullptr, stream_));
     ScanArgs a = base_args(q_pin, nullptr);
     int per_cu = 1;
-    FSGPU_HIP(launch_scan_i8(a, i8_slab_.ptr, ws_i8_query_.ptr, 64, 1, stream_, &per_cu));
+    FSGPU_HIP(launch_scan_i8(a, filter_slab(), ws_i8_query_.ptr, 64, 1, stream_, &per_cu));
     (void)per_cu;   // one block per CU: 256 lists x 32 entries are ONE pass of the finish (8,192 entries)
     int grid = num_cus_;
     const int max_useful = (int)(((nrows_ + 15) / 16 + 3) / 4);
@@ -1157,7 +1157,7 @@ SearchError VectorIndex::certified_i8_enqueue(const float* query, uint32_t k, bo
         FSGPU_HIP(hipEventCreate(&e1));
         FSGPU_HIP(hipEventRecord(e0, stream_));
     }
-    FSGPU_HIP(launch_scan_i8(a, i8_slab_.ptr, ws_i8_query_.ptr, 64, grid, stream_, nullptr));
+    FSGPU_HIP(launch_scan_i8(a, filter_slab(), ws_i8_query_.ptr, 64, grid, stream_, nullptr));
     if (profiling) {
         FSGPU_HIP(hipEventRecord(e1, stream_));
         events_.emplace_back(e0, e1);
@@ -1259,12 +1259,12 @@ SearchError VectorIndex::lone_exact_begin(const float* query, uint32_t k) {
     // lone query with the certified pass over that copy too: the rows and score bits of the exact kernels from half the bytes
     // (10M x 384: p50 0.67 against 1.27 ms; 1M: 0.12 against 0.17).  Nothing is built for it, an uncertified query goes to the exact
     // kernels, and fsgpu_search_topk_exact keeps those kernels reachable as they are.
-    const bool by_default = !via_filter && !exact_only_ && i8_shape && k <= 32 && i8_ready_ && i8_stats_ready_ && variant == 0;
+    const bool by_default = !via_filter && !exact_only_ && i8_shape && k <= 32 && filter_ready() && variant == 0;
     // a lone query of a fused-kernel shape travels in the scan kernel's argument block: no H2D copy in front of the scan
     const uint32_t k_lat = (uint64_t)k < nrows_ ? k : (uint32_t)nrows_;
     const bool in_kernarg = !via_filter && !f32_ && dim_ % 8 == 0 && k_lat <= 256 && variant == 0 &&
                             scan_kernarg_query_supported((int)dim_, k_lat <= 64 ? 64 : 256);
-    if ((via_filter && k <= 32 && i8_ready_ && i8_stats_ready_ && variant == 0) || by_default) {
+    if ((via_filter && k <= 32 && filter_ready() && variant == 0) || by_default) {
         // A failed certificate costs a whole pass over the int8 copy (a query with more rows inside the margin than the finish
         // holds, or so many in one block's share that its list dropped one), so the single pass backs off: after a failure the
         // next 1, 2, 4 ... 64 lone queries go straight to the staged path (the exact kernels when the pass is the default); a
@@ -1428,15 +1428,12 @@ SearchError VectorIndex::search_top_k_batched_device(const float* queries_dev, u
                scan_mfma_supported((int)dim_) && k >= 1 && k <= 64 && nrows_ >= 4 * 8192ull;
     // a few queries are not worth BUILDING the int8 copy for; once it exists (or the host asked for the int8 latency path) they
     // are answered from it too: one query 0.88 ms against 1.29 ms on the exact kernel at 10M x 384
-    if (batched_filter == 0 && knobs().filter == 0 && nq < 16 && !(i8_ready_ && i8_stats_ready_) && !int8_latency) i8f = false;
-    if (i8f && !i8_ready_ && batched_filter != 2) {
-        // the int8 copy of the slab (half its size again) is built on first use; no room for it: the f16 filter needs none
-        FSGPU_HIP(hipSetDevice(device_));
-        if (!i8_slab_.reserve((size_t)nrows_ * dim_).ok()) {
-            (void)hipGetLastError();
-            i8f_disabled_ = true;
-            i8f = false;
-        }
+    if (batched_filter == 0 && knobs().filter == 0 && nq < 16 && !filter_ready() && !int8_latency) i8f = false;
+    if (i8f && !filter_ready()) {
+        // the int8 copy of the slab (half its size again; rotated when the slab has outlier channels) is built on first use; no room
+        // for it: the f16 filter needs none
+        FSGPU_TRY(ensure_filter_copy(stream));
+        if (!filter_ready()) i8f = false;
     }
     if (i8f) {
         uint32_t refiltered = 0;
@@ -1459,23 +1456,7 @@ SearchError VectorIndex::prepare_int8_latency() {
     const bool strided = row_stride_ && row_stride_ != dim_ * 2;
     if (f32_ || strided || nrows_ < 4 * 8192ull || !scan_mfma_supported((int)dim_) || i8f_disabled_) return ok();
     FSGPU_HIP(hipSetDevice(device_));
-    if (!i8_ready_) {
-        if (!i8_slab_.reserve((size_t)nrows_ * dim_).ok()) {   // no room for the copy: the f16 paths need none
-            (void)hipGetLastError();
-            i8f_disabled_ = true;
-            return ok();
-        }
-        FSGPU_TRY(i8_max_.reserve(4));
-        FSGPU_HIP(launch_quantize_slab_i8(slab_dev_, (size_t)nrows_ * dim_, static_cast<unsigned int*>(i8_max_.ptr), i8_slab_.ptr, stream_,
-                                          quant_max_ready_));
-        i8_ready_ = true;
-    }
-    if (!i8_stats_ready_) {
-        FSGPU_TRY(i8_stats_.reserve(16));
-        FSGPU_HIP(launch_i8_slab_stats(slab_dev_, i8_slab_.ptr, (uint32_t)nrows_, dim_, static_cast<const unsigned int*>(i8_max_.ptr),
-                                       static_cast<unsigned int*>(i8_stats_.ptr), stream_));
-        i8_stats_ready_ = true;
-    }
+    FSGPU_TRY(ensure_filter_copy(stream_));
     FSGPU_HIP(hipStreamSynchronize(stream_));
     return ok();
 }
@@ -1516,40 +1497,203 @@ SearchError VectorIndex::int8_filter_bound(const float* queries, uint32_t nq, ui
     if (f32_ || (row_stride_ && row_stride_ != dim_ * 2) || nrows_ == 0 || nrows_ > 0xffffffffull)
         return make_error(FSGPU_ERR_INVALID_CONFIG, "the int8 filter serves f16 slabs only");
     FSGPU_HIP(hipSetDevice(device_));
-    if (!i8_ready_) {
-        FSGPU_TRY(i8_slab_.reserve((size_t)nrows_ * dim_));
-        FSGPU_TRY(i8_max_.reserve(4));
-        FSGPU_HIP(launch_quantize_slab_i8(slab_dev_, (size_t)nrows_ * dim_, static_cast<unsigned int*>(i8_max_.ptr), i8_slab_.ptr, stream_, quant_max_ready_));
-        i8_ready_ = true;
-    }
-    if (!i8_stats_ready_) {
-        FSGPU_TRY(i8_stats_.reserve(16));
-        FSGPU_HIP(launch_i8_slab_stats(slab_dev_, i8_slab_.ptr, (uint32_t)nrows_, dim_, static_cast<const unsigned int*>(i8_max_.ptr),
-                                       static_cast<unsigned int*>(i8_stats_.ptr), stream_));
-        i8_stats_ready_ = true;
-    }
+    FSGPU_TRY(ensure_filter_copy(stream_, true));
+    if (!filter_ready()) return make_error(FSGPU_ERR_DEVICE, "no room for the int8 copy of the slab");
     float slab_max = 0.f;
-    FSGPU_HIP(hipMemcpyAsync(&slab_max, i8_max_.ptr, 4, hipMemcpyDeviceToHost, stream_));
+    FSGPU_HIP(hipMemcpyAsync(&slab_max, filter_max(), 4, hipMemcpyDeviceToHost, stream_));
+    std::vector<float> unit(nq, 0.f);
     if (nq) {
         FSGPU_TRY(ws_queries_.reserve((size_t)nq * dim_ * 4));
         FSGPU_TRY(mf_qh_.reserve((size_t)nq * dim_ * 2));
-        FSGPU_TRY(mf_delta_.reserve((size_t)nq * 4));
+        FSGPU_TRY(mf_delta_.reserve((size_t)nq * 8));
+        float* delta_dev = static_cast<float*>(mf_delta_.ptr);
         FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, queries, (size_t)nq * dim_ * 4, hipMemcpyHostToDevice, stream_));
-        FSGPU_HIP(launch_prepare_queries_i8_filter(static_cast<const float*>(ws_queries_.ptr), nq, nq, dim_, dim_,
-                                                   static_cast<const unsigned int*>(i8_max_.ptr), static_cast<const unsigned int*>(i8_stats_.ptr),
-                                                   mf_qh_.ptr, static_cast<float*>(mf_delta_.ptr), stream_));
-        if (out_delta) FSGPU_HIP(hipMemcpyAsync(out_delta, mf_delta_.ptr, (size_t)nq * 4, hipMemcpyDeviceToHost, stream_));
+        FSGPU_TRY(prepare_filter_queries(static_cast<const float*>(ws_queries_.ptr), nq, nq, dim_, mf_qh_.ptr, delta_dev, delta_dev + nq, stream_));
+        if (out_delta) FSGPU_HIP(hipMemcpyAsync(out_delta, delta_dev, (size_t)nq * 4, hipMemcpyDeviceToHost, stream_));
+        FSGPU_HIP(hipMemcpyAsync(unit.data(), delta_dev + nq, (size_t)nq * 4, hipMemcpyDeviceToHost, stream_));
         if (out_queries_i8) FSGPU_HIP(hipMemcpyAsync(out_queries_i8, mf_qh_.ptr, (size_t)nq * dim_, hipMemcpyDeviceToHost, stream_));
     }
-    if (out_slab_i8) FSGPU_HIP(hipMemcpyAsync(out_slab_i8, i8_slab_.ptr, (size_t)nrows_ * dim_, hipMemcpyDeviceToHost, stream_));
+    if (out_slab_i8) FSGPU_HIP(hipMemcpyAsync(out_slab_i8, filter_slab(), (size_t)nrows_ * dim_, hipMemcpyDeviceToHost, stream_));
     FSGPU_HIP(hipStreamSynchronize(stream_));
-    if (out_slab_scale) *out_slab_scale = slab_max > 0.f ? 127.0f / slab_max : 0.f;
+    const float slab_scale = slab_max > 0.f ? 127.0f / slab_max : 0.f;
+    if (out_slab_scale) *out_slab_scale = slab_scale;
     if (out_query_scale)
-        for (uint32_t i = 0; i < nq; ++i) {   // quantize_i8_query's scale, as the kernel computes it
-            float m = 0.f;
+        for (uint32_t i = 0; i < nq; ++i) {
+            if (i8f_rot_) {   // the scale of the ROTATED query: integer-score units per exact-score unit / the slab's scale
+                out_query_scale[i] = slab_scale > 0.f ? unit[i] / slab_scale : 0.f;
+                continue;
+            }
+            float m = 0.f;   // quantize_i8_query's scale, as the kernel computes it
             for (uint32_t d = 0; d < dim_; ++d) m = std::fmax(m, std::fabs(queries[(size_t)i * dim_ + d]));
             out_query_scale[i] = m > 0.f ? 127.0f / m : 0.f;
         }
+    return ok();
+}
+
+// ---- the int8 filter's copy of the slab --------------------------------------------------------------------------------------
+//
+// Unrotated (the default for slabs without outlier channels): the reference's own int8 slab (quantize_f16_le_bytes_to_i8_generic),
+// shared with the int8 two-pass search, + its statistics.  Rotated (round 5): a copy of its own — rows R x quantised with THEIR
+// max-abs — for slabs whose largest element is far above what an even spread of a row's norm over its dimensions gives: the
+// corpus-wide scale then wastes the int8 range on a few channels, and the filter's margin (fixed in integer units) is several times
+// wider in cosine units than it has to be (int8_kernels.hip; scripts/r05/rotation_bound_study.py: 0.063 -> 0.021 on the bench's
+// outlier corpus, 1,023 -> 83 rows within the margin of the k-th best).  Decided once per index, on first use.
+namespace {
+// a fixed random orthogonal matrix (seeded; modified Gram-Schmidt twice, in double) as its TRANSPOSE [j][d], and |R^T R - I|_F
+void make_rotation(uint32_t dim, std::vector<double>& rt, double* ortho_err) {
+    std::vector<double> r((size_t)dim * dim);
+    uint64_t st = 0x9E3779B97F4A7C15ull ^ ((uint64_t)dim << 32);
+    auto next = [&]() {   // splitmix64 -> two uniforms -> a normal (Box-Muller)
+        auto u64 = [&]() {
+            st += 0x9E3779B97F4A7C15ull;
+            uint64_t z = st;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            return z ^ (z >> 31);
+        };
+        const double u1 = ((double)(u64() >> 11) + 1.0) / 9007199254740993.0, u2 = (double)(u64() >> 11) / 9007199254740992.0;
+        return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
+    };
+    for (double& v : r) v = next();
+    for (int pass = 0; pass < 2; ++pass)
+        for (uint32_t i = 0; i < dim; ++i) {
+            double* ri = r.data() + (size_t)i * dim;
+            for (uint32_t j = 0; j < i; ++j) {
+                const double* rj = r.data() + (size_t)j * dim;
+                double d = 0.0;
+                for (uint32_t x = 0; x < dim; ++x) d += ri[x] * rj[x];
+                for (uint32_t x = 0; x < dim; ++x) ri[x] -= d * rj[x];
+            }
+            double n = 0.0;
+            for (uint32_t x = 0; x < dim; ++x) n += ri[x] * ri[x];
+            n = 1.0 / std::sqrt(n);
+            for (uint32_t x = 0; x < dim; ++x) ri[x] *= n;
+        }
+    // rows orthonormal <=> R R^T = I <=> R^T R = I; measured as |R R^T - I|_F (the two Frobenius norms agree for a square matrix
+    // up to the conditioning, which is 1 + O(err) here)
+    double err2 = 0.0;
+    for (uint32_t i = 0; i < dim; ++i)
+        for (uint32_t j = 0; j <= i; ++j) {
+            double d = 0.0;
+            for (uint32_t x = 0; x < dim; ++x) d += r[(size_t)i * dim + x] * r[(size_t)j * dim + x];
+            d -= i == j ? 1.0 : 0.0;
+            err2 += (i == j ? 1.0 : 2.0) * d * d;
+        }
+    *ortho_err = std::sqrt(err2);
+    rt.resize((size_t)dim * dim);
+    for (uint32_t d = 0; d < dim; ++d)
+        for (uint32_t j = 0; j < dim; ++j) rt[(size_t)j * dim + d] = r[(size_t)d * dim + j];
+}
+}  // namespace
+
+SearchError VectorIndex::ensure_filter_copy(hipStream_t stream, bool must) {
+    if (filter_ready()) return ok();
+    const bool strided = row_stride_ && row_stride_ != dim_ * 2;
+    if (f32_ || strided || nrows_ == 0) return ok();
+    FSGPU_HIP(hipSetDevice(device_));
+    if (!i8f_decided_) {
+        // rotate? the slab's largest |element| against the largest row norm spread evenly over the dimensions: a Gaussian-like row
+        // has max ~ 6 / sqrt(dim) of its norm (and so has every rotated row), the bench's outlier corpus 17.6 / sqrt(dim)
+        bool rot = filter_rotation == 2;
+        if (filter_rotation == 0 && dim_ >= 64 && dim_ <= 1024) {
+            FSGPU_TRY(i8f_max_.reserve(8));
+            unsigned int* w = static_cast<unsigned int*>(i8f_max_.ptr);
+            FSGPU_HIP(launch_slab_maxabs(slab_dev_, (size_t)nrows_ * dim_, w, stream));
+            FSGPU_HIP(launch_max_row_norm(slab_dev_, (uint32_t)nrows_, dim_, 0, w + 1, stream));
+            float host[2] = {0.f, 0.f};
+            FSGPU_HIP(hipMemcpyAsync(host, w, 8, hipMemcpyDeviceToHost, stream));
+            FSGPU_HIP(hipStreamSynchronize(stream));
+            rot = host[1] > 0.f && std::isfinite(host[0]) && std::isfinite(host[1]) &&
+                  (double)host[0] * std::sqrt((double)dim_) > kRotateRatio * (double)host[1];
+        }
+        i8f_rot_ = rot;
+        i8f_decided_ = true;
+    }
+    if (!i8f_rot_) {
+        if (!i8_ready_) {
+            if (!i8_slab_.reserve((size_t)nrows_ * dim_).ok()) {   // no room for the copy: the f16 paths need none
+                (void)hipGetLastError();
+                if (must) return make_error(FSGPU_ERR_DEVICE, "no room for the int8 copy of the slab");
+                i8f_disabled_ = true;
+                return ok();
+            }
+            FSGPU_TRY(i8_max_.reserve(4));
+            FSGPU_HIP(launch_quantize_slab_i8(slab_dev_, (size_t)nrows_ * dim_, static_cast<unsigned int*>(i8_max_.ptr), i8_slab_.ptr, stream,
+                                              quant_max_ready_));
+            i8_ready_ = true;
+        }
+        if (!i8_stats_ready_) {
+            FSGPU_TRY(i8_stats_.reserve(16));
+            FSGPU_HIP(launch_i8_slab_stats(slab_dev_, i8_slab_.ptr, (uint32_t)nrows_, dim_, static_cast<const unsigned int*>(i8_max_.ptr),
+                                           static_cast<unsigned int*>(i8_stats_.ptr), stream));
+            i8_stats_ready_ = true;
+        }
+        return ok();
+    }
+    // the rotated copy: R (f64, transposed) -> two passes over the slab in chunks of rows — max-abs of the rotated values, then
+    // quantise + statistics — through a chunk-sized f32 staging buffer
+    if (!i8f_slab_.reserve((size_t)nrows_ * dim_).ok()) {
+        (void)hipGetLastError();
+        if (must) return make_error(FSGPU_ERR_DEVICE, "no room for the int8 copy of the slab");
+        i8f_disabled_ = true;
+        return ok();
+    }
+    std::vector<double> rt;
+    double ortho_err = 0.0;
+    make_rotation(dim_, rt, &ortho_err);
+    rot_extra_coeff_ = (ortho_err + 2.01 * 5.9604644775390625e-8) * 1.001;   // |R^T R - I| + 2.01 x 2^-24 (two roundings to f32)
+    FSGPU_TRY(rot_mat_.reserve(rt.size() * 8));
+    FSGPU_HIP(hipMemcpyAsync(rot_mat_.ptr, rt.data(), rt.size() * 8, hipMemcpyHostToDevice, stream));
+    FSGPU_HIP(hipStreamSynchronize(stream));   // rt is a local
+    const uint32_t chunk = (uint32_t)std::min<uint64_t>(nrows_, 1u << 18);
+    DeviceBuffer tmp;
+    FSGPU_TRY(tmp.reserve((size_t)chunk * dim_ * 4));
+    FSGPU_TRY(i8f_max_.reserve(8));
+    FSGPU_TRY(i8f_stats_.reserve(16));
+    unsigned int* maxw = static_cast<unsigned int*>(i8f_max_.ptr);
+    unsigned int* stats = static_cast<unsigned int*>(i8f_stats_.ptr);
+    const double* rmat = static_cast<const double*>(rot_mat_.ptr);
+    float* t32 = static_cast<float*>(tmp.ptr);
+    const unsigned char* slab8 = static_cast<const unsigned char*>(slab_dev_);
+    SearchError err;
+    auto pass = [&](bool second) -> SearchError {
+        for (uint64_t r0 = 0; r0 < nrows_; r0 += chunk) {
+            const uint32_t n = (uint32_t)std::min<uint64_t>(chunk, nrows_ - r0);
+            FSGPU_HIP(launch_rotate_rows_f16(slab8 + (size_t)r0 * dim_ * 2, n, dim_, rmat, t32, stream));
+            if (!second) {
+                FSGPU_HIP(launch_maxabs_f32(t32, (size_t)n * dim_, maxw, stream));
+            } else {
+                signed char* dst = static_cast<signed char*>(i8f_slab_.ptr) + (size_t)r0 * dim_;
+                FSGPU_HIP(launch_quantize_f32_i8(t32, (size_t)n * dim_, maxw, dst, stream));
+                FSGPU_HIP(launch_i8_stats_f32(t32, dst, n, dim_, maxw, stats, stream));
+            }
+        }
+        return ok();
+    };
+    FSGPU_HIP(hipMemsetAsync(maxw, 0, 8, stream));
+    FSGPU_HIP(hipMemsetAsync(stats, 0, 16, stream));
+    err = pass(false);
+    if (err.ok()) err = pass(true);
+    FSGPU_HIP(hipStreamSynchronize(stream));   // the staging buffer goes away with this scope
+    tmp.release();
+    FSGPU_TRY(err);
+    i8f_ready_ = true;
+    return ok();
+}
+
+// The filter's queries: quantised as quantize_i8_query does + the proven bound delta (prepare_queries_i8_filter_kernel) — of the
+// ROTATED queries when the filter's copy is (the same map in f64, rounded once to f32; what that adds to the bound: rot_extra_coeff_).
+SearchError VectorIndex::prepare_filter_queries(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t q_stride, void* qi8, float* delta,
+                                                float* unit, hipStream_t stream) {
+    if (!i8f_rot_) {
+        FSGPU_HIP(launch_prepare_queries_i8_filter(q, nq, nq_pad, dim_, q_stride, filter_max(), filter_stats(), qi8, delta, stream, unit));
+        return ok();
+    }
+    FSGPU_TRY(rot_q_.reserve((size_t)std::max<uint32_t>(nq, 1) * dim_ * 4));
+    float* rq = static_cast<float*>(rot_q_.ptr);
+    FSGPU_HIP(launch_rotate_rows_f32(q, nq, q_stride, dim_, static_cast<const double*>(rot_mat_.ptr), rq, stream));
+    FSGPU_HIP(launch_prepare_queries_i8_filter(rq, nq, nq_pad, dim_, dim_, filter_max(), filter_stats(), qi8, delta, stream, unit,
+                                               rot_extra_coeff_));
     return ok();
 }
 
@@ -1877,18 +2021,14 @@ SearchError VectorIndex::batched_prepare(BatchedPlan& p, bool* done) {
                                                    n4u_slab_.ptr, stream, quant_max_ready_));
         n4u_ready_ = true;
     }
-    if (p.i8 && p.bits != 4 && !i8_ready_) {  // VectorIndex::int8_slab(): built lazily, once
+    if (p.i8f) {   // the filter's copy (rotated for slabs with outlier channels) + its statistics: built lazily, once
+        FSGPU_TRY(ensure_filter_copy(stream, true));
+    } else if (p.i8 && p.bits != 4 && !i8_ready_) {  // VectorIndex::int8_slab(): built lazily, once
         FSGPU_TRY(i8_slab_.reserve((size_t)nrows_ * dim_));
         FSGPU_TRY(i8_max_.reserve(4));
         FSGPU_HIP(launch_quantize_slab_i8(slab_dev_, (size_t)nrows_ * dim_, static_cast<unsigned int*>(i8_max_.ptr),
                                           i8_slab_.ptr, stream, quant_max_ready_));
         i8_ready_ = true;
-    }
-    if (p.i8f && !i8_stats_ready_) {
-        FSGPU_TRY(i8_stats_.reserve(16));
-        FSGPU_HIP(launch_i8_slab_stats(slab_dev_, i8_slab_.ptr, p.N, dim_, static_cast<const unsigned int*>(i8_max_.ptr),
-                                       static_cast<unsigned int*>(i8_stats_.ptr), stream));
-        i8_stats_ready_ = true;
     }
     if (!p.i8 && !mf_norm_ready_) {
         FSGPU_TRY(mf_max_norm_.reserve(4));
@@ -2035,8 +2175,7 @@ SearchError VectorIndex::batched_round_setup(const BatchedPlan& p, BatchedRound&
     r.overflow = p.overflow_all + g0;
     r.cand_counts = p.counts_all + g0;
     if (p.i8f)
-        FSGPU_HIP(launch_prepare_queries_i8_filter(r.qg, r.ng, r.QP, dim_, p.qs, static_cast<const unsigned int*>(i8_max_.ptr),
-                                                   static_cast<const unsigned int*>(i8_stats_.ptr), mf_qh_.ptr, p.delta, stream, p.unit));
+        FSGPU_TRY(prepare_filter_queries(r.qg, r.ng, r.QP, p.qs, mf_qh_.ptr, p.delta, p.unit, stream));
     else if (i8) FSGPU_HIP(launch_prepare_queries_i8(r.qg, r.ng, r.QP, dim_, mf_qh_.ptr, p.delta, stream, p.bits));
     else
         FSGPU_HIP(launch_prepare_queries(r.qg, r.ng, r.QP, dim_, p.qs, static_cast<const unsigned int*>(mf_max_norm_.ptr),
@@ -2048,7 +2187,7 @@ SearchError VectorIndex::batched_round_setup(const BatchedPlan& p, BatchedRound&
     r.cand_count = static_cast<uint32_t*>(mf_cand_count_.ptr);
     MfmaScanArgs& a = r.a;
     a = MfmaScanArgs{};
-    a.slab = i8 ? (p.bits == 4 ? n4u_slab_.ptr : i8_slab_.ptr) : slab_dev_;
+    a.slab = p.i8f ? filter_slab() : i8 ? (p.bits == 4 ? n4u_slab_.ptr : i8_slab_.ptr) : slab_dev_;
     a.elem_bytes = i8 ? 1 : 2;
     a.live = reinterpret_cast<const u64*>(live_dev_);
     a.allow = reinterpret_cast<const u64*>(p.allow_dev);

@@ -192,6 +192,10 @@ class VectorIndex {
     int32_t batched_filter = 0;
     // fsgpu_index_set_int8_latency: unfiltered fsgpu_search_topk calls of a few queries go through the int8 filter too
     bool int8_latency = false;
+    // fsgpu_index_set_filter_rotation: 0 = automatic (rotate the filter's copy when the slab has outlier channels), 1 = never, 2 = always.
+    // Takes effect when the filter's copy is built (first batched search / fsgpu_index_int8_filter_bound).
+    int32_t filter_rotation = 0;
+    bool filter_rotated() const { return i8f_rot_; }
     bool exact_only_ = false;   // fsgpu_search_topk_exact: the call in flight takes the exact kernels whatever copies the index holds
     SearchError prepare_int8_latency();   // builds the int8 copy + its statistics now (else: the first batched search does)
     uint64_t i8f_queries = 0, i8f_refiltered = 0;  // queries the int8 filter took / handed on to the f16 filter
@@ -253,6 +257,19 @@ class VectorIndex {
                                       int bits, const void* qslab, bool want_pairs, bool* enqueued);
     SearchError two_pass_lone_check(uint32_t* rows, float* scores, uint32_t* count, u64* approx_out, u64* exact_out, bool* answered);
     SearchError ensure_two_pass_slab(int bits, const void** qslab);
+    // the int8 filter's copy of the slab, its scale word and statistics: the reference's own int8 slab (shared with the two-pass
+    // search), or a ROTATED copy of its own (vector_index.cpp, "the int8 filter's copy of the slab")
+    static constexpr double kRotateRatio = 9.0;   // max |element| x sqrt(dim) / max row norm above which the copy is rotated
+    bool filter_ready() const { return i8f_rot_ ? i8f_ready_ : (i8_ready_ && i8_stats_ready_); }
+    const void* filter_slab() const { return i8f_rot_ ? i8f_slab_.ptr : i8_slab_.ptr; }
+    const unsigned int* filter_max() const { return static_cast<const unsigned int*>(i8f_rot_ ? i8f_max_.ptr : i8_max_.ptr); }
+    const unsigned int* filter_stats() const { return static_cast<const unsigned int*>(i8f_rot_ ? i8f_stats_.ptr : i8_stats_.ptr); }
+    SearchError ensure_filter_copy(hipStream_t stream, bool must = false);   // decides the rotation on first use; builds what is missing
+    SearchError prepare_filter_queries(const float* q, uint32_t nq, uint32_t nq_pad, uint32_t q_stride, void* qi8, float* delta, float* unit,
+                                       hipStream_t stream);
+    DeviceBuffer i8f_slab_, i8f_max_, i8f_stats_, rot_mat_, rot_q_;
+    bool i8f_decided_ = false, i8f_rot_ = false, i8f_ready_ = false;
+    double rot_extra_coeff_ = 0.0;
     enum LoneKind : int {
         kLoneNone = 0, kLoneEmpty, kLoneUnpinned, kLoneCertified, kLoneStaged, kLoneStagedBlocking, kLoneExact,
         kLoneTwoPassLane, kLoneTwoPassBatched, kLoneTwoPassBlocking

@@ -122,6 +122,13 @@ class VectorIndex:
         """0 = automatic, 1 = f16 slab, 2 = int8 slab as the filter of search_batched (results identical either way)."""
         check(_lib.lib().fsgpu_index_set_batched_filter(self._h, filter))
 
+    def set_filter_rotation(self, mode: int) -> None:
+        """0 = automatic, 1 = never, 2 = always: the int8 filter's copy is built from rotated rows (fsgpu_index_set_filter_rotation)."""
+        check(_lib.lib().fsgpu_index_set_filter_rotation(self._h, mode))
+
+    def filter_rotated(self) -> bool:
+        return bool(_lib.lib().fsgpu_index_filter_rotated(self._h))
+
     def set_int8_latency(self, enabled: bool) -> None:
         """Unfiltered search_batch calls of a few queries go through the int8 filter + exact re-score (same hits, half the bytes)."""
         check(_lib.lib().fsgpu_index_set_int8_latency(self._h, int(enabled)))

@@ -187,6 +187,19 @@ fsgpu_status fsgpu_search_topk_device(fsgpu_index *idx, const float *queries_dev
 #define FSGPU_FILTER_F16 1
 #define FSGPU_FILTER_INT8 2
 fsgpu_status fsgpu_index_set_batched_filter(fsgpu_index *idx, int32_t filter);
+/* The int8 filter's copy of a slab WITH OUTLIER CHANNELS (a few dimensions carrying most of every row's norm, as trained embedding
+ * models have) is built from ROTATED rows: one corpus-wide int8 scale (simd.rs:1865-1886) spends the int8 range on those channels, and
+ * the filter's proven margin — fixed in integer units — is then several times wider in cosine units than it has to be.  Dot products
+ * are invariant under an orthogonal map: the filter scores quantised R x against quantised R q (R fixed, random, applied in f64 and
+ * rounded once to f32; what that adds to the proven bound is 2^-24-sized), and the exact re-score that decides rows and score bits never
+ * sees the rotation.  AUTO (default): rotate when the slab's largest |element| x sqrt(dim) exceeds 9 x its largest row norm — decided
+ * once, when the copy is built (first batched search).  The reference has no counterpart (its int8 slab serves the two-pass search,
+ * which keeps the reference's own quantisation here too).  Takes effect for a copy that is not built yet. */
+#define FSGPU_ROTATION_AUTO 0
+#define FSGPU_ROTATION_OFF 1
+#define FSGPU_ROTATION_ON 2
+fsgpu_status fsgpu_index_set_filter_rotation(fsgpu_index *idx, int32_t mode);
+int32_t fsgpu_index_filter_rotated(fsgpu_index *idx); /* 1: the filter's copy of this index is the rotated one */
 /* Latency form of the same idea: with this set, unfiltered fsgpu_search_topk calls of up to 16 queries (k <= 64) are answered
  * through the int8 filter + exact re-score as well — the pass streams half the bytes, rows and score bits unchanged; the int8 copy is
  * built at the first such call.  A lone query (k <= 32) takes ONE certified pass: every block of the int8 scan keeps its 32 best entries,

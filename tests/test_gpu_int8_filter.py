@@ -76,6 +76,7 @@ def test_bound_covers_every_row_against_float64_and_the_exact_kernels(fa, oracle
     for name, rows in corpora(rng, n, dim):
         slab = rows.astype(np.float16).view(np.uint16)
         idx = fa.VectorIndex.from_slab(slab)
+        idx.set_filter_rotation(1)   # (the unrotated copy: the reference's own int8 slab; the rotated one has its own test below)
         q = hostile_queries(rng, rows, dim)
         delta, qscale, sscale, qi8, slab_i8 = idx.int8_filter_bound(q, want_slab=True)
         # the filter uses the reference's quantisers (simd.rs:1865-1886, search.rs:1616-1626): same bytes as the oracle's
@@ -104,6 +105,68 @@ def test_bound_covers_every_row_against_float64_and_the_exact_kernels(fa, oracle
         idx.close()
     # the bound is not vacuous: somewhere the measured error comes within a factor of a few of it
     assert worst > 0.05, worst
+
+
+@pytest.mark.parametrize("dim", [128, 384])
+def test_rotated_filter_copy_keeps_the_bound_and_the_exact_bits(fa, oracle, dim):
+    """Round 5: for a slab with outlier channels the filter's int8 copy holds quantised rows of R x (R a fixed random orthogonal
+    matrix, applied in f64, rounded once to f32) and scores them against quantised R q.  The PROVEN bound must still cover every
+    (row, query) pair — |idot - S c_s c_q| <= delta with S the real-number dot of the ORIGINAL row and query — on the seven corpora x
+    hostile queries, rotation forced on; the automatic rule picks the rotation for the outlier corpus and not for the Gaussian one;
+    on the outlier corpus the rotated margin is at most half the unrotated one in score units; and the batched search returns the
+    exact kernels' rows and score bits either way."""
+    rng = np.random.default_rng(2000 + dim)
+    n = 12_000
+    for name, rows in corpora(rng, n, dim):
+        slab = rows.astype(np.float16).view(np.uint16)
+        idx = fa.VectorIndex.from_slab(slab)
+        idx.set_filter_rotation(2)
+        q = hostile_queries(rng, rows, dim)
+        delta, qscale, sscale, qi8, slab_i8 = idx.int8_filter_bound(q, want_slab=True)
+        assert idx.filter_rotated()
+        assert np.all(delta > 0), (name, delta)
+        idot = slab_i8.astype(np.int64) @ qi8.astype(np.int64).T
+        x64 = slab.view(np.float16).astype(np.float64)
+        s64 = x64 @ q.astype(np.float64).T                                             # real-number scores of the ORIGINAL vectors
+        unit = np.float64(sscale) * qscale.astype(np.float64)
+        err64 = np.abs(idot - s64 * unit[None, :])
+        # (the query scale comes back through an f32 division: 1e-6 relative on S c_s c_q, far inside delta's + 1)
+        slack = 2e-6 * np.abs(s64 * unit[None, :])
+        assert np.all(err64 <= delta[None, :].astype(np.float64) + slack), (name, float((err64 / delta[None, :]).max()))
+        for i in (0, 1, 2, 5, 7):
+            exact = idx.gather_dot(q[i], np.arange(n, dtype=np.uint32)).astype(np.float64)
+            assert np.all(np.abs(idot[:, i] - exact * unit[i]) <= float(delta[i]) + 2e-6 * np.abs(exact * unit[i])), (name, i)
+        idx.close()
+    # the automatic rule, the margins, and the hits
+    k = 10
+    for name, rows in corpora(rng, 70_000, dim):
+        if name not in ("gaussian unit rows", "outlier dimensions"):
+            continue
+        slab = rows.astype(np.float16).view(np.uint16)
+        q = rows[rng.integers(0, rows.shape[0], 300)] + (0.2 * rng.standard_normal((300, dim)) / np.sqrt(dim)).astype(np.float32)
+        auto, off = fa.VectorIndex.from_slab(slab), fa.VectorIndex.from_slab(slab)
+        off.set_filter_rotation(1)
+        for idx in (auto, off):
+            idx.set_batched_filter(2)
+        d_auto, qs_auto, ss_auto, _, _ = auto.int8_filter_bound(q[:16])
+        d_off, qs_off, ss_off, _, _ = off.int8_filter_bound(q[:16])
+        assert auto.filter_rotated() == (name == "outlier dimensions") and not off.filter_rotated(), name
+        if name == "outlier dimensions":   # margins in score units: delta / (c_s c_q)
+            m_auto = np.median(d_auto / (ss_auto * qs_auto)), np.median(d_off / (ss_off * qs_off))
+            assert m_auto[0] < 0.5 * m_auto[1], m_auto
+        er, es, ec = [np.concatenate(z) for z in zip(*[auto.search_batch(q[s0:s0 + 60], k, exact=True) for s0 in range(0, 300, 60)])]
+        for idx in (auto, off):
+            br, bs, bc, fb = idx.search_batched(q, k)
+            assert np.array_equal(br, er) and np.array_equal(bits(bs), bits(es)) and np.array_equal(bc, ec), (name, idx is auto)
+        orow, osc = oracle.search_top_k(slab, q[0], k)
+        br, bs, _, _ = auto.search_batched(q[:16], k)
+        assert np.array_equal(br[0], orow) and np.array_equal(bits(bs[0]), bits(osc)), name
+        # a lone query through the certified pass over the (rotated) copy
+        for i in range(6):
+            r1 = auto.search_batch(q[i], k)
+            assert np.array_equal(r1[0][0], er[i]) and np.array_equal(bits(r1[1][0]), bits(es[i])), (name, i)
+        auto.close()
+        off.close()
 
 
 def test_uncertifiable_inputs_are_marked_and_still_answered_exactly(fa, oracle):
