@@ -16,9 +16,9 @@ OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libfsgpu.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
-SOURCES = ["scan_kernels.hip", "scan_mq_kernel.hip", "int8_kernels.hip", "f32_kernels.hip", "mfma_scan.hip", "mfma_wide.hip", "sort_general.hip", "m2v_kernels.hip", "bert_kernels.hip", "bert_gemm_w.hip", "bert_docs_w.hip", "bert_query_kernels.hip", "bench_fixture.hip", "vector_index.cpp", "two_tier_index.cpp", "sharded_index.cpp",
+SOURCES = ["scan_kernels.hip", "scan_mq_kernel.hip", "int8_kernels.hip", "f32_kernels.hip", "mfma_scan.hip", "mfma_wide.hip", "sort_general.hip", "m2v_kernels.hip", "bert_kernels.hip", "bert_gemm_w.hip", "bert_docs_w.hip", "bert_query_kernels.hip", "bench_fixture.hip", "vector_index.cpp", "vector_index_batched.cpp", "vector_index_lone.cpp", "two_tier_index.cpp", "sharded_index.cpp",
            "bert_embedder.cpp", "safetensors.cpp", "fusion.cpp", "fsgpu_api.cpp"]
-HEADERS = ["device_util.hpp", "scan_common.hpp", "kernels.hpp", "vector_index.hpp", "bert_embedder.hpp", "coalescer.hpp", "sharded_index.hpp", "two_tier_index.hpp", "lab_env.hpp"]
+HEADERS = ["device_util.hpp", "scan_common.hpp", "kernels.hpp", "vector_index.hpp", "vector_index_internal.hpp", "bert_embedder.hpp", "coalescer.hpp", "sharded_index.hpp", "two_tier_index.hpp", "lab_env.hpp"]
 # libfshost.so: the C++ host-side mirror of the reference's two-tier searcher, over the C ABI only (include/fshost.h)
 HOST_LIB = os.path.join(HERE, "libfshost.so")
 HOST_SOURCES = ["host/two_tier_searcher.cpp", "host/load_driver.cpp", "host/stream_pipeline.cpp", "host/fshost_api.cpp"]

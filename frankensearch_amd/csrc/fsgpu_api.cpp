@@ -1178,8 +1178,12 @@ fsgpu_status fsgpu_sharded_quality_scores_for_hits(fsgpu_sharded* fast, fsgpu_sh
     return guarded([&]() -> fsgpu_status {
         std::vector<fsgpu::HitRef> refs(n);
         for (uint32_t i = 0; i < n; ++i) refs[i] = fsgpu::HitRef{hits[i].doc_id, hits[i].doc_id_len, hits[i].index};
-        // (the fast side is only read through its immutable record table; the quality handle is held for the gather)
-        std::lock_guard<std::mutex> lq(quality->impl.mutex());
+        // The fast side is read through its record table AND its tombstones (find_index_by_doc_id), which fsgpu_sharded_soft_delete /
+        // _wal_append change under fast's mutex; the quality handle is held for the gather.  Fast first, then quality: the order of
+        // fsgpu_sharded_alignment_create.
+        std::unique_lock<std::mutex> lf(fast->impl.mutex());
+        std::unique_lock<std::mutex> lq(quality->impl.mutex(), std::defer_lock);
+        if (quality != fast) lq.lock();
         fsgpu::QualityTierView view;
         view.table = quality->impl.catalog();
         view.rows = quality->impl.record_count();

@@ -1048,7 +1048,7 @@ hipError_t launch_wide_d(const MfmaScanArgs& args, int grid, hipStream_t stream,
     if (QT * (int)(args.dim * EB / 64) * 4 > 144) return hipErrorInvalidValue;
     constexpr int O = kWideOptDefault;
     switch (args.dim * EB / 2) {  // row length in 2-byte units
-        case 384: if constexpr (QT <= 3) {
+        case 384: if constexpr (QT <= 3 && MODE != 7) {
 #ifdef FSGPU_EXPERIMENTS
             if constexpr (MODE == 0 && EB == 2 && QT == 2) {   // timing skeletons: answers are NOT valid
                 static const int dbg = wide_env("FSGPU_WIDE_DBG");
@@ -1058,9 +1058,12 @@ hipError_t launch_wide_d(const MfmaScanArgs& args, int grid, hipStream_t stream,
 #endif
             return launch_wide_t<768, EB, QT, 6, O & ~(kOptBig | kOptFlags), MODE>(args, grid, stream, occupancy);   // 6 x 24 KB
         } else return hipErrorInvalidValue;
-        case 256: if constexpr (QT <= 4) return launch_wide_t<512, EB, QT, 8, O & ~kOptFlags, MODE>(args, grid, stream, occupancy);   // 8 x 16 KB
+        case 256: if constexpr (QT <= 4 && MODE != 7) return launch_wide_t<512, EB, QT, 8, O & ~kOptFlags, MODE>(args, grid, stream, occupancy);   // 8 x 16 KB
                   else return hipErrorInvalidValue;
-        case 192:
+        // Rows of 384 / 256 bytes: the int8 copies of 384- and 256-dimensional slabs (MiniLM / the hash embedders, potion).  Their
+        // f16 forms (192 / 128 dimensions) and rows of 128 bytes are not shapes of the reference's embedders: those searches run on
+        // scan_mfma_kernel (queries in LDS), and so does a group-maxima stage the split loop cannot hold (5 tiles of 384 bytes).
+        case 192: if constexpr (EB != 1 || (MODE == 7 && !wide_split_ok(384, 1, QT, O, 7))) return hipErrorInvalidValue; else {
 #ifdef FSGPU_EXPERIMENTS
             if constexpr (EB == 1 && QT == 4) {   // A/B runs of the kernel's options on the bench shape (int8 rows of 384 dimensions)
                 static const int opt = wide_env("FSGPU_WIDE_OPT");
@@ -1131,8 +1134,9 @@ hipError_t launch_wide_d(const MfmaScanArgs& args, int grid, hipStream_t stream,
             if constexpr (EB == 1 && QT == 4 && MODE == 0) { if (!occupancy) return launch_wide_asym<384, 1, FSGPU_LAB_ASYM, 8 - FSGPU_LAB_ASYM, 6, O & ~(kOptBig | kOptFlags)>(args, grid, stream); }
 #endif
             return launch_wide_pick<384, EB, QT, 6, O, MODE>(args, grid, stream, occupancy);   // 6 x 24 KB (3 x 48 KB)
-        case 128: return launch_wide_pick<256, EB, QT, 8, O, MODE>(args, grid, stream, occupancy);   // 8 x 16 KB (3 x 32 KB)
-        case 64: return launch_wide_pick<128, EB, QT, 8, O, MODE>(args, grid, stream, occupancy);    // 8 x 8 KB (3 x 16 KB)
+        }
+        case 128: if constexpr (EB != 1 || (MODE == 7 && !wide_split_ok(256, 1, QT, O, 7))) return hipErrorInvalidValue;
+                  else return launch_wide_pick<256, EB, QT, 8, O, MODE>(args, grid, stream, occupancy);   // 8 x 16 KB (3 x 32 KB)
         default: return hipErrorInvalidValue;
     }
 }
@@ -1150,13 +1154,13 @@ extern "C" int fsgpu_lab_bitmap_debug(unsigned long long* out, int cap_records) 
 #endif
 
 bool scan_wide_supported(int dim, int elem_bytes) {
-    const int rowb = dim * elem_bytes;
-    return rowb == 768 || rowb == 512 || rowb == 384 || rowb == 256 || rowb == 128;
+    const int rowb = dim * elem_bytes;   // (the shapes launch_wide_d builds)
+    return rowb == 768 || rowb == 512 || (elem_bytes == 1 && (rowb == 384 || rowb == 256));
 }
 
 // int8 rows whose shape runs the query-tile-split loop (the group-maxima sample stage is built on it)
 bool scan_wide_group_maxima_supported(int dim, int query_tiles) {
-    return (dim == 384 || dim == 256 || dim == 128) && query_tiles >= 2 && query_tiles <= 5 &&
+    return (dim == 384 || dim == 256) && query_tiles >= 2 && query_tiles <= 5 &&
            wide_split_ok(dim, 1, query_tiles, kWideOptDefault, 7);
 }
 

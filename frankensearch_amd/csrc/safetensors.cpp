@@ -6,6 +6,7 @@
 // vocab x hidden from the word embeddings, layers by counting, inter from intermediate.dense, heads = hidden / 32 (native.rs:36-45).
 #include <cstdint>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <string>
 #include <vector>
@@ -127,7 +128,10 @@ SearchError NativeEmbedder::init_safetensors(int device, const void* blob, uint6
     if (header_len > blob_len - 8) return load_failed("safetensors header length out of range");
     const unsigned char* data = bytes + 8 + header_len;
     const uint64_t data_len = blob_len - 8 - header_len;
-    if ((reinterpret_cast<uintptr_t>(data) & 3u) != 0) return load_failed("safetensors tensor data is not 4-byte aligned in the blob");
+    // A tensor that does not start on a 4-byte address in the caller's blob (a header length that is not a multiple of 4: older
+    // writers, hand-made files) is copied to an aligned staging area; the reference decodes with f32::from_le_bytes at any
+    // alignment (native.rs parse_weights) and loads such files.
+    std::deque<std::vector<float>> staged;
     JsonCursor c{reinterpret_cast<const char*>(bytes + 8), reinterpret_cast<const char*>(bytes + 8 + header_len)};
     if (!c.eat('{')) return load_failed("safetensors header is not an object");
     std::map<std::string, Tensor> raw;
@@ -180,9 +184,15 @@ SearchError NativeEmbedder::init_safetensors(int device, const void* blob, uint6
                 if (dtype == "F32") {   // (everything else — I64 position_ids, F16 / BF16 exports — is skipped, as the reference does)
                     if (!have_offsets) return load_failed("safetensors tensor " + name + " missing data_offsets");
                     if (start > stop || stop > data_len) return load_failed("safetensors tensor " + name + " has out-of-range offsets");
-                    if (start & 3u) return load_failed("safetensors tensor " + name + " is not 4-byte aligned");
-                    t.data = reinterpret_cast<const float*>(data + start);
+                    if ((stop - start) & 3u) return load_failed("safetensors tensor " + name + " is not a whole number of f32 values");
                     t.count = (stop - start) / 4;
+                    if ((reinterpret_cast<uintptr_t>(data + start) & 3u) != 0) {
+                        staged.emplace_back((size_t)t.count);
+                        std::memcpy(staged.back().data(), data + start, (size_t)t.count * 4);
+                        t.data = staged.back().data();
+                    } else {
+                        t.data = reinterpret_cast<const float*>(data + start);
+                    }
                     const std::string key = (name.rfind("embeddings.", 0) == 0 || name.rfind("encoder.", 0) == 0) ? "bert." + name : name;
                     raw[key] = t;
                 }
@@ -205,7 +215,9 @@ SearchError NativeEmbedder::init_safetensors(int device, const void* blob, uint6
     auto shape_of = [&](const std::string& key, uint64_t* a, uint64_t* b) -> SearchError {
         auto it = raw.find(key);
         if (it == raw.end()) return load_failed("missing tensor " + key);
+        // (both extents fit 32 bits — what fsgpu_bert_config holds — so their product cannot wrap 64)
         if (it->second.shape.size() != 2 || it->second.shape[0] == 0 || it->second.shape[1] == 0 ||
+            it->second.shape[0] > UINT32_MAX || it->second.shape[1] > UINT32_MAX ||
             it->second.shape[0] * it->second.shape[1] != it->second.count)
             return load_failed("tensor " + key + " has a bad shape for its " + std::to_string(it->second.count) + " values");
         *a = it->second.shape[0];

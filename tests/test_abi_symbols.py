@@ -151,8 +151,13 @@ def test_safetensors_blob_is_validated_before_a_device_is_needed():
 
     good = _safetensors_blob(_tiny_bert_tensors(), metadata={"format": "pt"})
     good_prefixed = _safetensors_blob(_tiny_bert_tensors("bert."))
+    hlen = int.from_bytes(good[:8], "little")
+    header = good[8:8 + hlen].rstrip(b" ")
+    header = header[:-1] + b" " * ((1 - len(header)) % 4) + b"}"
+    unaligned = len(header).to_bytes(8, "little") + header + good[8 + hlen:]   # header length = 1 (mod 4): tensor bytes at odd addresses
+    assert len(header) % 4 == 1
     if not torch.cuda.is_available():
-        for blob in (good, good_prefixed):
+        for blob in (good, good_prefixed, unaligned):
             with pytest.raises(fa.NoDevice):
                 fa.NativeEmbedder.from_safetensors_bytes(blob)
     cases = {

@@ -227,6 +227,18 @@ def test_model_file_blob_gives_the_same_embedder_as_the_tensor_struct(fa, tmp_pa
         got = enc.embed_batch_token_ids(texts)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), prefix
         enc.close()
+        # the same file with a header whose length is not a multiple of 4 (older writers do not pad it): the tensor bytes sit at odd
+        # addresses; parse_weights decodes with f32::from_le_bytes at any alignment, the library stages such tensors
+        blob = open(path, "rb").read()
+        hlen = int.from_bytes(blob[:8], "little")
+        header = blob[8:8 + hlen].rstrip(b" ")
+        header = header[:-1] + b" " * ((1 - len(header)) % 4) + b"}"   # length = 1 (mod 4), still one JSON object
+        assert len(header) % 4 == 1
+        odd = len(header).to_bytes(8, "little") + header + blob[8 + hlen:]
+        enc = fa.NativeEmbedder.from_safetensors_bytes(odd)
+        got = enc.embed_batch_token_ids(texts)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), prefix + " (unaligned tensor data)"
+        enc.close()
     ref.close()
 
 
