@@ -28,7 +28,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-result", "-x", "hip"]
 # mfma_wide.hip: the tile loop of the 640-query int8 shape must unroll completely (its register-resident query fragments
 # are indexed by the chunk counter: left rolled they land in scratch), which is past LLVM's default pragma-unroll budget
-EXTRA_FLAGS = {"mfma_wide.hip": ["-mllvm", "-pragma-unroll-threshold=200000"]}
+# bert_kernels.hip / bert_query_kernels.hip: matrix-instruction results stay in ordinary registers (the compiler's default put the
+# attention's accumulators in AccVGPRs and moved them out and back around every softmax step: 40 of the loop's 165 instructions)
+EXTRA_FLAGS = {"mfma_wide.hip": ["-mllvm", "-pragma-unroll-threshold=200000"],
+               "bert_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               "bert_query_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc() -> str:

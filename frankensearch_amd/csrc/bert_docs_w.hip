@@ -92,16 +92,16 @@ __device__ __forceinline__ float d_row16_sum(float v) {
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));
     return v;
 }
-// exact-form GELU with the Abramowitz-Stegun 7.1.26 erf (native.rs:190-200), as bert_gemm_w.hip
+// GELU(x) = max(x, 0) - |x| 2^(q(|x| / sqrt 2) - 1), q the degree-5 fit of log2(erfc) — gelu_as_w of bert_gemm_w.hip (see there;
+// scripts/r05/fit_erf.py: 1.4e-6 from the reference's Abramowitz-Stegun 7.1.26 form, native.rs:190-200, before the rounding to f16)
 __device__ __forceinline__ float d_gelu(float x) {
-    const float z = x * 0.70710678118654752440f;
-    const float az = fabsf(z);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
-    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.0614054f, -1.453152f), 1.4214137f), -0.28449673f), 0.2548296f);
-    const float erf_abs = fmaf(-poly, __expf(-(z * z)), 1.0f);
-    const float erf = copysignf(erf_abs, z);
-    const float hx = 0.5f * x;
-    return fmaf(hx, erf, hx);
+    const float az = fabsf(x) * 0.70710678118654752440f;
+    float p = fmaf(az, -0.00294418f, 0.02959011f);
+    p = fmaf(p, az, -0.14866571f);
+    p = fmaf(p, az, -0.91850934f);
+    p = fmaf(p, az, -1.62788901f);
+    const float e_half = __builtin_amdgcn_exp2f(fmaf(p, az, -1.0f));
+    return fmaxf(x, 0.0f) - fabsf(x) * e_half;
 }
 
 // v = LayerNorm(v) over the 384 columns of each row (add_ln_raw's normalisation, native.rs:560-578; two passes: mean, then

@@ -38,19 +38,21 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-// exact-form GELU with the Abramowitz-Stegun 7.1.26 erf (native.rs:190-200) — the formula of bert_kernels.hip, with the
-// hardware reciprocal (1 ulp) in place of the IEEE division and fused multiply-adds (this file is built without contraction): the result is rounded to f16 two lines later, and the
-// epilogue's 32 GELUs per lane were a quarter of the FFN-up kernel
+// GELU(x) = x (1 + erf(x / sqrt 2)) / 2 (native.rs:190-200, where erf is Abramowitz-Stegun 7.1.26).  Here erf(|z|) = 1 - 2^q(|z|)
+// with q a degree-5 polynomial without constant term fitted to log2(erfc) on [0, 4] (scripts/r05/fit_erf.py: |error| <= 7e-7 against
+// erf, 1.1e-6 against the reference's f32 evaluation of 7.1.26 — the result is rounded to f16, 5e-4, two lines later; q(z) < 0 and
+// falls to -inf for all z > 0, so no clamp).  One transcendental and nine full-rate instructions per value:
+//   GELU(x) = max(x, 0) - |x| 2^(q(|z|) - 1)
+// where the 7.1.26 form takes a reciprocal, an exponential and thirteen more — the GELUs of the FFN-up epilogue were 30 % of the
+// post-attention block's life at 16k tokens (profiles/r05/ffn_stamps.txt).
 __device__ __forceinline__ float gelu_as_w(float x) {
-    const float z = x * 0.70710678118654752440f;
-    const float az = fabsf(z);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
-    const float poly =
-        t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.0614054f, -1.453152f), 1.4214137f), -0.28449673f), 0.2548296f);
-    const float erf_abs = fmaf(-poly, __expf(-(z * z)), 1.0f);
-    const float erf = copysignf(erf_abs, z);
-    const float hx = 0.5f * x;
-    return fmaf(hx, erf, hx);
+    const float az = fabsf(x) * 0.70710678118654752440f;
+    float p = fmaf(az, -0.00294418f, 0.02959011f);
+    p = fmaf(p, az, -0.14866571f);
+    p = fmaf(p, az, -0.91850934f);
+    p = fmaf(p, az, -1.62788901f);
+    const float e_half = __builtin_amdgcn_exp2f(fmaf(p, az, -1.0f));   // (1 - erf(|z|)) / 2
+    return fmaxf(x, 0.0f) - fabsf(x) * e_half;
 }
 
 }  // namespace
@@ -589,7 +591,12 @@ __global__ __launch_bounds__(256) void bert_gemm_ln_w_kernel(const _Float16* __r
 // One launch, 12 MB read and 12 MB written per layer instead of two launches moving 56 MB.
 // AO = true puts the attention-output projection and the first LayerNorm in front (phase A): everything of a layer after the
 // attention is then this one launch, and the rows between the two LayerNorms exist only in registers and LDS.
-template <int CT, int CH, bool AO>
+// IC = the intermediate size as a compile-time constant (0: the run-time argument I).  With IC every loop below unrolls completely and
+// the weight rings' refills are unconditional straight-line code: the compiler then counts the loads in flight exactly (s_waitcnt
+// vmcnt(N)).  With run-time trip counts and refills under a condition it cannot, and puts s_waitcnt vmcnt(0) at every loop head: the
+// W2 ring drained every R2 k-steps and the W1 ring at every chunk — one full L2 round trip each, ~36 of them in a block's life, which
+// IS most of that life (round 5, read off the ISA: profiles/r05/encoder_ring_waits.txt).
+template <int CT, int CH, bool AO, int IC = 0>
 __global__ __launch_bounds__(512) void bert_ffn_w_kernel(const _Float16* __restrict__ ctx, const half8* __restrict__ W0p,
                                                          const float* __restrict__ b0, const float* __restrict__ ln0w,
                                                          const float* __restrict__ ln0b, const half8* __restrict__ W1p,
@@ -597,8 +604,10 @@ __global__ __launch_bounds__(512) void bert_ffn_w_kernel(const _Float16* __restr
                                                          const half8* __restrict__ W2p, const float* __restrict__ b2,
                                                          float* __restrict__ x_f32, _Float16* __restrict__ x_h,
                                                          const float* __restrict__ lnw, const float* __restrict__ lnb, int M,
-                                                         int I, float eps) {
+                                                         int I_arg, float eps) {
     constexpr int H = 64 * CT, BM = 32, NW = 8;
+    constexpr bool FIXED = IC > 0;
+    const int I = FIXED ? IC : I_arg;
     constexpr int KS1 = H / 32;            // k-steps of the up-projection = ring depth of the W1 stream
     constexpr int NT2 = 4 * CT / NW;       // 16-column tiles of the output per wave
     constexpr int R2 = AO ? 8 : 12;        // ring depth of the W2 stream (AO also carries the rows between the LayerNorms)
@@ -784,12 +793,17 @@ __global__ __launch_bounds__(512) void bert_ffn_w_kernel(const _Float16* __restr
         for (int ks = 0; ks < KS1; ++ks)
 #pragma unroll
             for (int j = 0; j < CH; ++j) r1[ks][j] = w1[(j * KS1 + ks) * 64];
-    for (int c = 0; c < nchunks; ++c) {
+    auto chunk = [&](int c) {
         f32x4 acc[2][CH];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < CH; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (the chunk's biases are requested BEFORE the ring's refills: loads return in order, so waiting for them in the epilogue does
+        // not wait for the refills behind them)
+        f32x4 bvs[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) bvs[j] = *reinterpret_cast<const f32x4*>(b1 + (wave * tpw + CH * c + j) * 16 + cq);
         const half8* wn = w1 + (size_t)(CH * (c + 1)) * KS1 * 64;   // the next chunk
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) {
@@ -804,11 +818,14 @@ __global__ __launch_bounds__(512) void bert_ffn_w_kernel(const _Float16* __restr
             if (c + 1 < nchunks)
 #pragma unroll
                 for (int j = 0; j < CH; ++j) r1[ks][j] = wn[(j * KS1 + ks) * 64];
+#ifndef FSGPU_FFN_NO_SCHED
+            __builtin_amdgcn_sched_barrier(0);   // the refill is issued HERE, a ring's depth ahead of its use (left free, the scheduler sinks it next to the use)
+#endif
         }
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int col = (wave * tpw + CH * c + j) * 16 + cq;
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(b1 + col);
+            const f32x4 bv = bvs[j];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const f32x4 y = acc[i][j] + bv;
@@ -820,6 +837,13 @@ __global__ __launch_bounds__(512) void bert_ffn_w_kernel(const _Float16* __restr
                 *reinterpret_cast<half4*>(&Is[(i * 16 + fr) * ip + col]) = h;
             }
         }
+    };
+    if constexpr (FIXED) {
+#pragma unroll
+        for (int c = 0; c < IC / 16 / NW / CH; ++c) chunk(c);
+    } else {
+#pragma unroll 1
+        for (int c = 0; c < nchunks; ++c) chunk(c);
     }
     // phase 2: W2 fragment (tile j, k-step ks) at w2[(j * ksteps2 + ks) * 64]
     const half8* w2 = W2p + (size_t)(wave * NT2) * ksteps2 * 64 + lane;
@@ -844,7 +868,7 @@ __global__ __launch_bounds__(512) void bert_ffn_w_kernel(const _Float16* __restr
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NT2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int ks0 = 0; ks0 < ksteps2; ks0 += R2) {
+    auto ring_round = [&](int ks0) {
 #pragma unroll
         for (int d = 0; d < R2; ++d) {
             const int ks = ks0 + d;
@@ -860,8 +884,18 @@ __global__ __launch_bounds__(512) void bert_ffn_w_kernel(const _Float16* __restr
                 if (ks + R2 < ksteps2)
 #pragma unroll
                     for (int j = 0; j < NT2; ++j) r2[d][j] = w2[((size_t)j * ksteps2 + ks + R2) * 64];
+#ifndef FSGPU_FFN_NO_SCHED
+                __builtin_amdgcn_sched_barrier(0);
+#endif
             }
         }
+    };
+    if constexpr (FIXED) {
+#pragma unroll
+        for (int ks0 = 0; ks0 < IC / 32; ks0 += R2) ring_round(ks0);
+    } else {
+#pragma unroll 1
+        for (int ks0 = 0; ks0 < ksteps2; ks0 += R2) ring_round(ks0);
     }
     __syncthreads();   // every wave is done with the intermediate tile: its space becomes the residual / output tile
     if (!AO) {
@@ -943,6 +977,375 @@ __global__ __launch_bounds__(512) void bert_ffn_w_kernel(const _Float16* __restr
         h[3] = (_Float16)y[3];
         *(reinterpret_cast<half4*>(x_h + (size_t)row * H) + c4) = h;
     }
+}
+
+// The post-attention block of a layer (bert_ffn_w_kernel<CT, 2, true>) for LARGE M — the documents of an index build —, 64 rows per
+// block.  Why: that kernel streams the layer's 2.65 MB of packed weights out of L2 once per 32-row block, 1.36 GB per layer at
+// 16,384 tokens, and every 1 KB fragment a wave fetches feeds two matrix instructions: 25 B / clock / CU of weight stream is a fifth
+// of what four SIMDs consume at full rate (profiles/r05/encoder_large_m_pmc.txt: 88 us per layer, matrix pipe 0.20 busy, the L2s
+// delivering 15.4 TB/s).  With 64 rows a fragment feeds FOUR instructions and the block count halves: the same stream does twice
+// the work.  What had to change to fit 64 rows into 160 KB of LDS and 256 registers:
+//   * the intermediate tile holds HALF the intermediate columns at a time: up-projection + GELU of half h, then the down-projection's
+//     partial sums over that half (accumulators live across both halves), barrier, the other half;
+//   * the f32 residual of the first LayerNorm is read in FRAGMENT layout straight from global memory (64-byte runs per row) instead
+//     of through an LDS tile, and the rows between the two LayerNorms — the FFN's residual — go back to x_f32 in the same layout
+//     (the lane that wrote an element is the lane that reads it again in the epilogue: no barrier involved) instead of staying in 48
+//     registers through the FFN.
+// Same per-element arithmetic and operation order as bert_ffn_w_kernel: the outputs are bit-identical.
+// Lab (-DFSGPU_FFN_STAMPS): where a block of bert_ffn_w64_kernel spends its life.  Wave 0 and wave 7 of every block add the clock
+// at seven points to a device table (fsgpu_lab_ffn_stamps reads and clears it): phase A | up-projection + GELU of half 0 | down-
+// projection over half 0 | the same for half 1 | epilogue.
+#ifdef FSGPU_FFN_STAMPS
+__device__ unsigned long long g_ffn_stamps[2][8];
+#define FFN_STAMP(slot)                                                                                                        \
+    do {                                                                                                                         \
+        if ((threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 7))                                      \
+            atomicAdd(&g_ffn_stamps[(threadIdx.x >> 6) == 7][(slot)], (unsigned long long)__builtin_readcyclecounter());          \
+        if ((slot) == 6 && threadIdx.x == 0) atomicAdd(&g_ffn_stamps[0][7], 1ull);                                               \
+    } while (0)
+#else
+#define FFN_STAMP(slot) \
+    do {                \
+    } while (0)
+#endif
+
+template <int CT, int IC>   // IC = the intermediate size, a compile-time constant here (see bert_ffn_w_kernel)
+__global__ __launch_bounds__(512) void bert_ffn_w64_kernel(const _Float16* __restrict__ ctx, const half8* __restrict__ W0p,
+                                                           const float* __restrict__ b0, const float* __restrict__ ln0w,
+                                                           const float* __restrict__ ln0b, const half8* __restrict__ W1p,
+                                                           const float* __restrict__ b1, const half8* __restrict__ W2p,
+                                                           const float* __restrict__ b2, float* x_f32, _Float16* __restrict__ x_h,
+                                                           const float* __restrict__ lnw, const float* __restrict__ lnb, int M, int I_arg,
+                                                           float eps) {
+    constexpr int H = 64 * CT, BM = 64, RT = BM / 16, NW = 8, CH = 2, R2 = 8;
+    static_assert(IC > 0 && IC % 512 == 0, "halves of the intermediate in chunks of two tiles over 8 waves");
+    constexpr int I = IC;
+    (void)I_arg;
+    constexpr int KS1 = H / 32;            // k-steps of the up-projection = ring depth of the W1 stream
+    constexpr int NT2 = 4 * CT / NW;       // 16-column tiles of the output per wave
+    constexpr int XP = H + 4;              // floats per row of the output tile
+    constexpr int HP = H + 16;             // halves per row of the f16 x tile
+    constexpr int XL = BM * (H / 4) / 512; // float4 pieces of the output tile per thread
+    static_assert((4 * CT) % NW == 0, "hidden must be a multiple of 128");
+    extern __shared__ __attribute__((aligned(16))) unsigned char ffn_smem[];
+    float* red = reinterpret_cast<float*>(ffn_smem);                                      // [BM][NW]
+    _Float16* Xh = reinterpret_cast<_Float16*>(ffn_smem + BM * NW * 4);                   // [BM][HP]
+    _Float16* Is = Xh + BM * HP;                                                          // [BM][I / 2 + 16]
+    float* Xs = reinterpret_cast<float*>(Is);                                             // [BM][XP], after the last half
+    constexpr int IH = I / 2, ip = IH + 16, ksteps2 = I / 32, ksh = IH / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bm0 = blockIdx.x * BM;
+    const int fr = lane & 15, q = lane >> 4, cq = q * 4;
+    constexpr int tpw = IH / 16 / NW;      // intermediate tiles per wave and half (a multiple of CH)
+    constexpr int nchunks = tpw / CH;
+    constexpr int NSTEP = nchunks * KS1;   // (chunk, k-step) pairs of a half, the order the W1 stream is consumed in
+    constexpr int D1 = NSTEP < 8 ? NSTEP : 8;   // ring depth of the W1 stream in k-steps: CONTINUOUS over the chunks (a ring one whole chunk deep — 96 registers at hidden = 384 — does not fit next to 64 rows of accumulators)
+    FFN_STAMP(0);
+    int grow[RT];                          // this lane's rows (fragment layout), clamped at M
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const int r = bm0 + i * 16 + fr;
+        grow[i] = r < M ? r : M - 1;
+    }
+    // ---- phase A: x1 = LayerNorm(x + ctx W0^T + b0) -> f16 into the x tile, f32 back to x_f32 ----------------------------------
+    {
+        _Float16* Cs = Is;                                                    // [BM][HP], borrowed
+        const half8* w0 = W0p + (size_t)(wave * NT2) * KS1 * 64 + lane;      // fragment (tile j, k-step ks) at w0[(j KS1 + ks) 64]
+        constexpr int R0 = KS1 <= 8 ? KS1 : 6;   // W0 streams through a ring (the whole slice — 144 registers at hidden = 384 — does not fit next to 64 rows of accumulators)
+        static_assert(KS1 % R0 == 0, "ring depth divides the k-steps");
+        half8 r0[R0][NT2];
+#pragma unroll
+        for (int d = 0; d < R0; ++d)
+#pragma unroll
+            for (int j = 0; j < NT2; ++j) r0[d][j] = w0[(j * KS1 + d) * 64];
+        {
+            constexpr int PIECES = H / 8, AL = (BM * PIECES + 511) / 512;
+            half8 ra[AL];
+#pragma unroll
+            for (int x = 0; x < AL; ++x) {
+                const int p = tid + 512 * x;
+                if (p < BM * PIECES) {
+                    const int r = p / PIECES, c = p % PIECES;
+                    int row = bm0 + r;
+                    row = row < M ? row : M - 1;
+                    ra[x] = *(reinterpret_cast<const half8*>(ctx + (size_t)row * H) + c);
+                }
+            }
+#pragma unroll
+            for (int x = 0; x < AL; ++x) {
+                const int p = tid + 512 * x;
+                if (p < BM * PIECES) {
+                    const int r = p / PIECES, c = p % PIECES;
+                    *reinterpret_cast<half8*>(&Cs[r * HP + c * 8]) = ra[x];
+                }
+            }
+        }
+        __syncthreads();
+        f32x4 x1[RT][NT2];
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT2; ++j) x1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            const int d = ks % R0;
+            half8 af[RT];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) af[i] = *reinterpret_cast<const half8*>(&Cs[(i * 16 + fr) * HP + ks * 32 + q * 8]);
+#pragma unroll
+            for (int j = 0; j < NT2; ++j)
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+                    x1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r0[d][j], af[i], x1[i][j], 0, 0, 0);
+            if (ks + R0 < KS1)
+#pragma unroll
+                for (int j = 0; j < NT2; ++j) r0[d][j] = w0[(j * KS1 + ks + R0) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4 g0[NT2], be0[NT2];   // the LayerNorm's weights: a round trip that overlaps the row statistics
+#pragma unroll
+        for (int j = 0; j < NT2; ++j) {
+            const int col = wave * 16 * NT2 + j * 16 + cq;
+            g0[j] = *reinterpret_cast<const f32x4*>(ln0w + col);
+            be0[j] = *reinterpret_cast<const f32x4*>(ln0b + col);
+        }
+        float ps[RT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT2; ++j) {
+                const int col = wave * 16 * NT2 + j * 16 + cq;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(b0 + col);
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(x_f32 + (size_t)grow[i] * H + col);
+                const f32x4 y = (x1[i][j] + bv) + xv;
+                x1[i][j] = y;
+                sm += (y[0] + y[1]) + (y[2] + y[3]);
+            }
+            sm += __shfl_xor(sm, 16);
+            sm += __shfl_xor(sm, 32);
+            ps[i] = sm;
+        }
+        if (lane < 16)
+#pragma unroll
+            for (int i = 0; i < RT; ++i) red[(i * 16 + lane) * NW + wave] = ps[i];
+        __syncthreads();
+        float mu[RT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const float* p = red + (i * 16 + fr) * NW;
+            mu[i] = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) / (float)H;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            float qs = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT2; ++j) {
+                const f32x4 d = x1[i][j] - mu[i];
+                qs += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+            }
+            qs += __shfl_xor(qs, 16);
+            qs += __shfl_xor(qs, 32);
+            if (lane < 16) red[(i * 16 + lane) * NW + wave] = qs;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const float* p = red + (i * 16 + fr) * NW;
+            const float var = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) / (float)H;
+            const float inv = 1.0f / sqrtf(var + eps);
+            const bool real = bm0 + i * 16 + fr < M;
+#pragma unroll
+            for (int j = 0; j < NT2; ++j) {
+                const int col = wave * 16 * NT2 + j * 16 + cq;
+                const f32x4 g = g0[j];
+                const f32x4 b = be0[j];
+                const f32x4 y = (x1[i][j] - mu[i]) * inv * g + b;
+                if (real) *reinterpret_cast<f32x4*>(x_f32 + (size_t)grow[i] * H + col) = y;   // the FFN's residual: read back by this lane
+                half4 h;
+                h[0] = (_Float16)y[0];
+                h[1] = (_Float16)y[1];
+                h[2] = (_Float16)y[2];
+                h[3] = (_Float16)y[3];
+                *reinterpret_cast<half4*>(&Xh[(i * 16 + fr) * HP + col]) = h;
+            }
+        }
+    }
+    FFN_STAMP(1);
+    // the down-projection's accumulators, over both halves
+    f32x4 acc2[RT][NT2];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT2; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const half8* w2 = W2p + (size_t)(wave * NT2) * ksteps2 * 64 + lane;   // W2 fragment (tile j, k-step ks) at w2[(j * ksteps2 + ks) * 64]
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        // ---- phase 1: GELU(x1 W1^T + b1) over intermediate columns [IH h, IH (h + 1)) -> the intermediate tile ---------------------
+        // W1 stream of this wave: fragment (chunk c, tile j, k-step ks) at w1[((CH c + j) * KS1 + ks) * 64]
+        const half8* w1 = W1p + (size_t)(h * (IH / 16) + wave * tpw) * KS1 * 64 + lane;
+        half8 r1[D1][CH];
+#pragma unroll
+        for (int s0 = 0; s0 < D1; ++s0)
+#pragma unroll
+            for (int j = 0; j < CH; ++j) r1[s0][j] = w1[((CH * (s0 / KS1) + j) * KS1 + s0 % KS1) * 64];
+        __syncthreads();   // h = 0: the x tile is complete, the borrowed LDS is free; h = 1: every wave is done with the first half's tile
+#pragma unroll
+        for (int c = 0; c < nchunks; ++c) {
+            f32x4 acc[RT][CH];
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int j = 0; j < CH; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 bvs[CH];   // requested before the ring's refills (loads return in order)
+#pragma unroll
+            for (int j = 0; j < CH; ++j) bvs[j] = *reinterpret_cast<const f32x4*>(b1 + h * IH + (wave * tpw + CH * c + j) * 16 + cq);
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                const int st = c * KS1 + ks, slot = st % D1;
+                half8 af[RT];
+#pragma unroll
+                for (int i = 0; i < RT; ++i) af[i] = *reinterpret_cast<const half8*>(&Xh[(i * 16 + fr) * HP + ks * 32 + q * 8]);
+#pragma unroll
+                for (int j = 0; j < CH; ++j)
+#pragma unroll
+                    for (int i = 0; i < RT; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r1[slot][j], af[i], acc[i][j], 0, 0, 0);
+                if (st + D1 < NSTEP) {
+                    const int s2 = st + D1;
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) r1[slot][j] = w1[((CH * (s2 / KS1) + j) * KS1 + s2 % KS1) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);   // (the refill stays a ring's depth ahead of its use)
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int lcol = (wave * tpw + CH * c + j) * 16 + cq;   // within the half
+                const f32x4 bv = bvs[j];
+#pragma unroll
+                for (int i = 0; i < RT; ++i) {
+                    const f32x4 y = acc[i][j] + bv;
+                    half4 hh;
+                    hh[0] = (_Float16)gelu_as_w(y[0]);
+                    hh[1] = (_Float16)gelu_as_w(y[1]);
+                    hh[2] = (_Float16)gelu_as_w(y[2]);
+                    hh[3] = (_Float16)gelu_as_w(y[3]);
+                    *reinterpret_cast<half4*>(&Is[(i * 16 + fr) * ip + lcol]) = hh;
+                }
+            }
+        }
+        FFN_STAMP(2 + 2 * h);
+        // ---- phase 2: the down-projection's partial sums over this half ----------------------------------------------------------
+        half8 r2[R2][NT2];
+#pragma unroll
+        for (int d = 0; d < R2; ++d)
+            if (d < ksh)
+#pragma unroll
+                for (int j = 0; j < NT2; ++j) r2[d][j] = w2[((size_t)j * ksteps2 + h * ksh + d) * 64];
+        __syncthreads();   // the half's intermediate tile is complete (an LDS-only barrier that lets the requested fragments fly on: measured the same)
+        auto ring_round = [&](int ks0) {
+#pragma unroll
+            for (int d = 0; d < R2; ++d) {
+                const int ks = ks0 + d;
+                if (ks < ksh) {
+                    half8 af[RT];
+#pragma unroll
+                    for (int i = 0; i < RT; ++i) af[i] = *reinterpret_cast<const half8*>(&Is[(i * 16 + fr) * ip + ks * 32 + q * 8]);
+#pragma unroll
+                    for (int j = 0; j < NT2; ++j)
+#pragma unroll
+                        for (int i = 0; i < RT; ++i)
+                            acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r2[d][j], af[i], acc2[i][j], 0, 0, 0);
+                    if (ks + R2 < ksh)
+#pragma unroll
+                        for (int j = 0; j < NT2; ++j) r2[d][j] = w2[((size_t)j * ksteps2 + h * ksh + ks + R2) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+#pragma unroll
+        for (int ks0 = 0; ks0 < ksh; ks0 += R2) ring_round(ks0);
+        FFN_STAMP(3 + 2 * h);
+    }
+    // ---- epilogue: x = LayerNorm(x1 + acc2 + b2); rows i * 16 + fr, columns wave * 16 NT2 + j * 16 + cq .. + 3 ---------------------
+    f32x4 g2[NT2], be2[NT2];
+#pragma unroll
+    for (int j = 0; j < NT2; ++j) {   // (the LayerNorm's weights: a round trip that overlaps the row statistics)
+        const int col = wave * 16 * NT2 + j * 16 + cq;
+        g2[j] = *reinterpret_cast<const f32x4*>(lnw + col);
+        be2[j] = *reinterpret_cast<const f32x4*>(lnb + col);
+    }
+    float psum[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT2; ++j) {
+            const int col = wave * 16 * NT2 + j * 16 + cq;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + col);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x_f32 + (size_t)grow[i] * H + col);   // what this lane stored in phase A
+            const f32x4 y = (acc2[i][j] + bv) + xv;
+            acc2[i][j] = y;
+            s += (y[0] + y[1]) + (y[2] + y[3]);
+        }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        psum[i] = s;
+    }
+    if (lane < 16)
+#pragma unroll
+        for (int i = 0; i < RT; ++i) red[(i * 16 + lane) * NW + wave] = psum[i];
+    __syncthreads();   // (also: every wave is done with the last intermediate tile — its space becomes the output tile)
+    float mean[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const float* p = red + (i * 16 + fr) * NW;
+        mean[i] = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) / (float)H;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        float qs = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT2; ++j) {
+            const f32x4 d = acc2[i][j] - mean[i];
+            qs += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+        qs += __shfl_xor(qs, 16);
+        qs += __shfl_xor(qs, 32);
+        if (lane < 16) red[(i * 16 + lane) * NW + wave] = qs;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const float* p = red + (i * 16 + fr) * NW;
+        const float var = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) / (float)H;
+        const float inv = 1.0f / sqrtf(var + eps);
+#pragma unroll
+        for (int j = 0; j < NT2; ++j) {
+            const int col = wave * 16 * NT2 + j * 16 + cq;
+            const f32x4 g = g2[j];
+            const f32x4 b = be2[j];
+            *reinterpret_cast<f32x4*>(&Xs[(i * 16 + fr) * XP + col]) = (acc2[i][j] - mean[i]) * inv * g + b;   // own element
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int x = 0; x < XL; ++x) {
+        const int pp = tid + 512 * x, r = pp / (H / 4), c4 = pp % (H / 4);
+        const int row = bm0 + r;
+        if (row >= M) continue;
+        const f32x4 y = *reinterpret_cast<const f32x4*>(&Xs[r * XP + c4 * 4]);
+        *(reinterpret_cast<f32x4*>(x_f32 + (size_t)row * H) + c4) = y;
+        half4 hh;
+        hh[0] = (_Float16)y[0];
+        hh[1] = (_Float16)y[1];
+        hh[2] = (_Float16)y[2];
+        hh[3] = (_Float16)y[3];
+        *(reinterpret_cast<half4*>(x_h + (size_t)row * H) + c4) = hh;
+    }
+    FFN_STAMP(6);
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------
@@ -1065,6 +1468,9 @@ static hipError_t launch_ffn_w_t(const void* ctx_h, const void* w0p, const float
     // three 16-column tiles per chunk when the wave's share divides, else two; the AO form (which also carries the rows
     // between the LayerNorms in registers) always two: with three, hidden = 384 spills
     auto kern = (!AO && (I / 16 / 8) % 3 == 0) ? bert_ffn_w_kernel<CT, 3, AO> : bert_ffn_w_kernel<CT, 2, AO>;
+#ifndef FSGPU_FFN_NO_FIXED
+    if (AO && I == 4 * 64 * CT) kern = bert_ffn_w_kernel<CT, 2, true, 4 * 64 * CT>;   // the usual inter = 4 hidden: compile-time trip counts (see the kernel)
+#endif
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1091,16 +1497,60 @@ bool bert_post_attn_w_supported(int hidden, int inter) {
            (size_t)(inter + 16) * 2 >= (size_t)(hidden + 16) * 2 + (size_t)(hidden + 4) * 4;
 }
 
+// the 64-row form (bert_ffn_w64_kernel): halves of the intermediate in chunks of two tiles over 8 waves; the f32 output tile and the
+// borrowed context tile inside the half intermediate tile; everything within 160 KB
+static size_t ffn_w64_lds(int hidden, int inter) {
+    return (size_t)64 * 8 * 4 + (size_t)64 * (hidden + 16) * 2 + (size_t)64 * (inter / 2 + 16) * 2;
+}
+static bool ffn_w64_supported(int hidden, int inter) {
+    return (hidden == 384 || hidden == 256 || hidden == 128) && inter == 4 * hidden &&   // (built for the usual shape: compile-time trip counts)
+           (size_t)(inter / 2 + 16) * 2 >= (size_t)(hidden + 4) * 4 && ffn_w64_lds(hidden, inter) <= (size_t)160 * 1024;
+}
+
+template <int CT>
+static hipError_t launch_ffn_w64_t(const void* ctx_h, const void* w0p, const float* b0, const float* ln0w, const float* ln0b,
+                                   const void* w1p, const float* b1, const void* w2p, const float* b2, float* x_f32, void* x_h,
+                                   const float* lnw, const float* lnb, int M, int I, float eps, hipStream_t stream) {
+    const size_t lds = ffn_w64_lds(64 * CT, I);
+    auto kern = bert_ffn_w64_kernel<CT, 4 * 64 * CT>;   // (ffn_w64_supported: inter = 4 hidden)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)160 * 1024));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((M + 63) / 64), dim3(512), lds, stream, static_cast<const _Float16*>(ctx_h),
+                       static_cast<const half8*>(w0p), b0, ln0w, ln0b, static_cast<const half8*>(w1p), b1,
+                       static_cast<const half8*>(w2p), b2, x_f32, static_cast<_Float16*>(x_h), lnw, lnb, M, I, eps);
+    return hipGetLastError();
+}
+
+#ifndef FSGPU_FFN_W64_MIN_ROWS
+#define FSGPU_FFN_W64_MIN_ROWS 8193   // more 32-row blocks than one round of the chip's 256 CUs: from there 64-row blocks halve the weight stream
+#endif
+
 hipError_t launch_bert_post_attn_w(const void* ctx_h, const void* w0p, const float* b0, const float* ln0w, const float* ln0b,
                                    const void* w1p, const float* b1, const void* w2p, const float* b2, float* x_f32, void* x_h,
                                    const float* lnw, const float* lnb, int M, int hidden, int inter, float eps,
                                    hipStream_t stream) {
     if (!bert_post_attn_w_supported(hidden, inter)) return hipErrorInvalidValue;
+    if (M >= FSGPU_FFN_W64_MIN_ROWS && ffn_w64_supported(hidden, inter)) {
+        switch (hidden) {
+            case 384: return launch_ffn_w64_t<6>(ctx_h, w0p, b0, ln0w, ln0b, w1p, b1, w2p, b2, x_f32, x_h, lnw, lnb, M, inter, eps, stream);
+            case 256: return launch_ffn_w64_t<4>(ctx_h, w0p, b0, ln0w, ln0b, w1p, b1, w2p, b2, x_f32, x_h, lnw, lnb, M, inter, eps, stream);
+            default: return launch_ffn_w64_t<2>(ctx_h, w0p, b0, ln0w, ln0b, w1p, b1, w2p, b2, x_f32, x_h, lnw, lnb, M, inter, eps, stream);
+        }
+    }
     switch (hidden) {
         case 384: return launch_ffn_w_t<6, true>(ctx_h, w0p, b0, ln0w, ln0b, w1p, b1, w2p, b2, x_f32, x_h, lnw, lnb, M, inter, eps, stream);
         case 256: return launch_ffn_w_t<4, true>(ctx_h, w0p, b0, ln0w, ln0b, w1p, b1, w2p, b2, x_f32, x_h, lnw, lnb, M, inter, eps, stream);
         default: return launch_ffn_w_t<2, true>(ctx_h, w0p, b0, ln0w, ln0b, w1p, b1, w2p, b2, x_f32, x_h, lnw, lnb, M, inter, eps, stream);
     }
 }
+
+#ifdef FSGPU_FFN_STAMPS
+extern "C" int fsgpu_lab_ffn_stamps(unsigned long long* out16) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ffn_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    unsigned long long zero[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ffn_stamps), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 
 }  // namespace fsgpu

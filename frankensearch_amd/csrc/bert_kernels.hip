@@ -20,6 +20,8 @@
 #include "lab_env.hpp"
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "device_util.hpp"
 #include "kernels.hpp"
 
@@ -715,51 +717,36 @@ __global__ __launch_bounds__(256) void bert_attention_lds_kernel(const _Float16*
     __syncthreads();
     const int fr = lane & 15, kg = lane >> 4;
     const int ntiles = (S + 15) >> 4;
-    for (int tile = blockIdx.z * 4 + wave; tile < ntiles; tile += 4 * zsplit) {
-        const int q0 = tile * 16;
-        const int qrow = q0 + fr < S ? q0 + fr : S - 1;
-        const half8 bq = *reinterpret_cast<const half8*>(base + (size_t)qrow * stride + kg * 8);
-        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
-        float m = -INFINITY, l = 0.f;
-        for (int k0 = 0; k0 < S32; k0 += 32) {
-            f32x4 sc[2];
+    // TWO query tiles per wave and pass (tile and the one the wave would take next): the K and V^T fragments of a key block are read
+    // from LDS once for both, and the two softmax chains — each a string of dependent steps: matrix product, row maximum, exponentials,
+    // matrix product — interleave (round 5: with two waves per SIMD the loop waited on its own chain; 46 -> see profiles/r05).
+    constexpr int QT = 2;
+    const float c2 = scale * 1.44269504088896340736f;   // exp((s - m) scale) = exp2(s c2 - m c2)
+    for (int tile = blockIdx.z * 4 + wave; tile < ntiles; tile += 4 * zsplit * QT) {
+        int q0[QT];
+        half8 bq[QT];
+        f32x4 o0[QT], o1[QT];
+        float m[QT], l[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            q0[t] = (tile + t * 4 * zsplit) * 16;   // (a tile past the end recomputes the last row and stores nothing)
+            const int qrow = q0[t] + fr < S ? q0[t] + fr : S - 1;
+            bq[t] = *reinterpret_cast<const half8*>(base + (size_t)qrow * stride + kg * 8);
+            o0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            o1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            m[t] = -INFINITY;
+            l[t] = 0.f;
+        }
+        // one block of 32 keys; MASKED: the document's last block, which may hold keys past its end (peeled: left in the loop the
+        // compiler turns the wave-uniform test into eight compare + select pairs that every block pays for)
+        auto key_block = [&](int k0, auto masked_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
+            half8 ak[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int key = k0 + j * 16 + fr;
-                const half8 ak = *reinterpret_cast<const half8*>(&Ks[key * 32 + ((kg ^ ((key >> 2) & 3)) * 8)]);
-                sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ak, bq, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                ak[j] = *reinterpret_cast<const half8*>(&Ks[key * 32 + ((kg ^ ((key >> 2) & 3)) * 8)]);
             }
-            if (k0 + 32 > S) {   // only the last key block can hold keys past the end (wave-uniform)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (k0 + j * 16 + kg * 4 + r >= S) sc[j][r] = -INFINITY;
-            }
-            float mx = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])),
-                             fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mn = fmaxf(m, mx);
-            // exp((s - mn) scale) as exp2(s c - mn c), c = scale log2(e): one fused multiply-add and one v_exp_f32 per score
-            // (the softmax is VALU-bound here: 32-wide heads give the matrix cores 128 flops per exponential)
-            const float c2 = scale * 1.44269504088896340736f;
-            const float mc = mn * c2;
-            const float corr = __builtin_amdgcn_exp2f(fmaf(m, c2, -mc));
-            half8 bp;
-            float ps = 0.f;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(sc[j][r], c2, -mc));
-                    ps += pv;
-                    bp[j * 4 + r] = (_Float16)pv;
-                }
-            l = l * corr + ps;
-            m = mn;
-            o0 *= corr;
-            o1 *= corr;
             // V^T fragments: dim fr (and 16 + fr), keys k0 + 4 kg .. + 3 and k0 + 16 + 4 kg .. + 3 — the keys of bp's slots
             const half4v a00 = *reinterpret_cast<const half4v*>(&Vt[fr * vp + k0 + kg * 4]);
             const half4v a01 = *reinterpret_cast<const half4v*>(&Vt[fr * vp + k0 + 16 + kg * 4]);
@@ -767,22 +754,74 @@ __global__ __launch_bounds__(256) void bert_attention_lds_kernel(const _Float16*
             const half4v a11 = *reinterpret_cast<const half4v*>(&Vt[(16 + fr) * vp + k0 + 16 + kg * 4]);
             const half8 av0 = {a00[0], a00[1], a00[2], a00[3], a01[0], a01[1], a01[2], a01[3]};
             const half8 av1 = {a10[0], a10[1], a10[2], a10[3], a11[0], a11[1], a11[2], a11[3]};
-            o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(av0, bp, o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(av1, bp, o1, 0, 0, 0);
-        }
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
-        if (q0 + fr < S) {
-            const float inv = 1.0f / l;
-            _Float16* dst = ctx_h + (size_t)(t0 + q0 + fr) * hidden + head * 32 + kg * 4;
-            half4v h0, h1;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                h0[r] = (_Float16)(o0[r] * inv);
-                h1[r] = (_Float16)(o1[r] * inv);
+            for (int t = 0; t < QT; ++t) {
+                f32x4 sc[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ak[j], bq[t], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                if constexpr (MASKED) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (k0 + j * 16 + kg * 4 + r >= S) sc[j][r] = -INFINITY;
+                }
+                float mx = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])),
+                                 fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
+                {   // max over the four key quads of a query: lanes l, l ^ 16, l ^ 32, l ^ 48 — two row swaps in the VALU
+                    // (v_permlane16_swap / v_permlane32_swap) instead of two ds_bpermute round trips through the LDS in the middle of
+                    // the dependent chain
+                    const uint32_t u = __float_as_uint(mx);
+                    const auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+                    mx = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+                    const uint32_t v = __float_as_uint(mx);
+                    const auto r32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+                    mx = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+                }
+                const float mn = fmaxf(m[t], mx);
+                // one fused multiply-add and one v_exp_f32 per score (32-wide heads give the matrix cores 128 flops per exponential)
+                const float mc = mn * c2;
+                // (skipping the rescale while no query of the wave sees a new maximum was tried: the compiler turns the wave-uniform
+                // branch into nine selects behind the same multiplies)
+                const float corr = __builtin_amdgcn_exp2f(fmaf(m[t], c2, -mc));
+                half8 bp;
+                float ps = 0.f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(fmaf(sc[j][r], c2, -mc));
+                        ps += pv;
+                        bp[j * 4 + r] = (_Float16)pv;
+                    }
+                l[t] = l[t] * corr + ps;
+                m[t] = mn;
+                o0[t] *= corr;
+                o1[t] *= corr;
+                o0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av0, bp, o0[t], 0, 0, 0);
+                o1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av1, bp, o1[t], 0, 0, 0);
             }
-            *reinterpret_cast<half4v*>(dst) = h0;
-            *reinterpret_cast<half4v*>(dst + 16) = h1;
+        };
+        for (int k0 = 0; k0 < S32 - 32; k0 += 32) key_block(k0, std::false_type{});
+        if (S32 > S) key_block(S32 - 32, std::true_type{});
+        else key_block(S32 - 32, std::false_type{});
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            float lt = l[t];
+            lt += __shfl_xor(lt, 16);
+            lt += __shfl_xor(lt, 32);
+            if (q0[t] + fr < S) {
+                const float inv = 1.0f / lt;
+                _Float16* dst = ctx_h + (size_t)(t0 + q0[t] + fr) * hidden + head * 32 + kg * 4;
+                half4v h0, h1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    h0[r] = (_Float16)(o0[t][r] * inv);
+                    h1[r] = (_Float16)(o1[t][r] * inv);
+                }
+                *reinterpret_cast<half4v*>(dst) = h0;
+                *reinterpret_cast<half4v*>(dst + 16) = h1;
+            }
         }
     }
 }

@@ -2,7 +2,7 @@
 # Regenerates the evidence kept under profiles/<round>/ (run on the GPU box through gpurun; results land in
 # gpurun_out/<round>/ and are copied to profiles/<round>/ afterwards).  Counter passes are separate runs with
 # --pmc only (never combined with trace domains).
-R=${1:-r04}
+R=${1:-r05}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -20,6 +20,11 @@ python bench.py --rows 50000000 --config5 --no-adversarial --no-encoders --no-cp
 python bench.py --sharded-handle --gpus 1 --no-config5 2>/dev/null | grep queries_per_sec | tail -1 > $OUT/bench_sharded_handle_1gpu.json
 # N > 1 rehearsed on the one GPU: two gloo ranks, the sharded-handle leg over two virtual shards (two-tier + config 5 over sharded handles)
 FSGPU_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --warmup 3 --config5-rows 6000000 2>/dev/null | tail -1 > $OUT/bench_rehearsal_gloo_2ranks.json
+# round 5: the hybrid layout (query groups x row shards).  Eight virtual shards on the one GPU as 2 x 4 (the default for N = 8) and
+# as 1 x 8; four gloo ranks as 2 x 2 through the launcher's path.
+python bench.py --sharded-handle --virtual-shards --gpus 8 --no-config5 2>/dev/null | grep queries_per_sec | tail -1 > $OUT/bench_sharded_handle_8virtual_2x4.json
+python bench.py --sharded-handle --virtual-shards --gpus 8 --query-groups 1 --no-config5 2>/dev/null | grep queries_per_sec | tail -1 > $OUT/bench_sharded_handle_8virtual_1x8.json
+FSGPU_BENCH_BACKEND=gloo python bench.py --gpus 4 --steps 10 --warmup 3 --no-sharded-handle 2>/dev/null | tail -1 > $OUT/bench_rehearsal_gloo_4ranks_2x2.json
 python scripts/r04/filtered_tput.py > $OUT/filtered_tput.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_shard -o bench -- \
     python bench.py --rows 1250000 --no-cpu-baseline --no-two-tier --no-adversarial --no-encoders > $OUT/bench_shard_under_trace.json 2> $OUT/bench_shard_trace.err

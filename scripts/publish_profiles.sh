@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copies the summaries of scripts/collect_profiles.sh from gpurun_out/<round>/ (scratch) into profiles/<round>/ (tracked).
-R=${1:-r04}
+R=${1:-r05}
 SRC=gpurun_out/$R
 DST=profiles/$R
 mkdir -p $DST

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../.."
 name=$1; src=$2; defs=$3
 python -m frankensearch_amd.build >/dev/null
 obj=/tmp/fsgpu_variant_${name}_$(basename ${src%.*}).o
-extra=""; [ "$src" = mfma_wide.hip ] && extra="-mllvm -pragma-unroll-threshold=200000"
+extra=""; [ "$src" = mfma_wide.hip ] && extra="-mllvm -pragma-unroll-threshold=200000"; [ "$src" = bert_kernels.hip -o "$src" = bert_query_kernels.hip ] && extra="-mllvm -amdgpu-mfma-vgpr-form"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result -x hip $extra $defs \
     -I include -c frankensearch_amd/csrc/$src -o $obj
 objs=$(ls frankensearch_amd/_build/*.o | grep -v "/$(basename ${src%.*}).o")

@@ -13,7 +13,7 @@ offs[1:] = np.cumsum([len(b) for b in long])
 ids = np.concatenate([np.asarray(b, dtype=np.int32) for b in long])
 out = np.empty((32, 384), dtype=np.float32)
 n = int(os.environ.get("N", "10"))
-for _ in range(2):
+for _ in range(int(os.environ.get("WARM", "2"))):
     bert.embed_flat(ids, offs, out)
 t0 = time.perf_counter()
 for _ in range(n):

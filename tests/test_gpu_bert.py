@@ -242,6 +242,25 @@ def test_model_file_blob_gives_the_same_embedder_as_the_tensor_struct(fa, tmp_pa
     ref.close()
 
 
+def test_index_build_batches_of_more_than_8k_tokens_take_the_64_row_blocks(fa):
+    """Above 8,192 tokens (more 32-row blocks than one round of the chip's CUs) the post-attention block runs as 64-row blocks
+    (bert_ffn_w64_kernel: half the weight stream per token).  Same tolerance against the f32 C oracle for every hidden size the
+    kernel is built for, on benign and heavy-tailed weights; ragged lengths, a row count that is not a multiple of 64."""
+    from oracle import bert_oracle
+    rng = np.random.default_rng(57)
+    cases = [(bert_oracle.random_weights(9, 3000, 384, 6, 1536), 6), (bert_oracle.heavy_tailed_weights(47, 3000, 384, 3, 1536), 3),
+             (bert_oracle.random_weights(10, 3000, 256, 2, 1024), 2), (bert_oracle.random_weights(12, 3000, 128, 2, 512), 2)]
+    for w, layers in cases:
+        m = fa.NativeEmbedder(w)
+        ref = bert_oracle.CForward(w, layers)
+        lens = [512] * 14 + [int(n) for n in rng.integers(40, 400, 12)] + [33, 77]   # 7,168 + ~2,600 + 110 tokens
+        docs = [[101] + rng.integers(1000, 3000, n - 2).tolist() + [102] for n in lens]
+        assert sum(lens) > 8192 and sum(lens) % 64 != 0
+        got = m.embed_batch_token_ids(docs)
+        check(got, ref.run(docs, 16))
+        m.close()
+
+
 def test_index_build_batches_of_thousands_of_tokens(fa):
     """Calls of >= 6,144 tokens (documents of an index build, index_builder.rs:191,416) take the large-M form of the batch path: the
     weight-stationary QKV / FFN-up GEMMs (bert_gemm_wp_kernel) and the post-attention block as three launches.  Same tolerance
