@@ -1068,6 +1068,10 @@ def main() -> None:
     ap.add_argument("--config5-rows", type=int, default=50_000_000, help="rows of the config 5 corpus in the sharded-handle leg")
     args = ap.parse_args()
     args.batched = not args.exact
+    # Queries per step.  Default: 1,024 PER GPU on the batched path (the launcher branch below multiplies by the world size): every
+    # GPU-step is then the same work at every N — 1,024 queries against 10M rows' worth of (rows x queries) — and the line says
+    # "scaling": "weak".  An explicit --batch is the WHOLE job's step at any N ("strong").
+    args.batch_given = args.batch is not None
     if args.batch is None:
         args.batch = 1024 if args.batched else 4
 
@@ -1121,6 +1125,8 @@ def main() -> None:
     import frankensearch_amd as fa
     from frankensearch_amd.sharded import GpuShardBackend, ShardedVectorIndex, shard_range
 
+    if not args.batch_given and world > 1:
+        args.batch *= world
     groups = args.query_groups if args.query_groups > 0 else default_query_groups(world)
     if world % groups:
         sys.exit(f"bench.py: --query-groups {groups} does not divide the {world} ranks")
@@ -1180,7 +1186,7 @@ def main() -> None:
     if world > 1:
         dist.barrier()
     # (every 4th step's main launch is bracketed by HIP events on its stream: a pair idles the stream ~6 us on either side)
-    profile_period = 4 if args.steps >= 16 and args.batched and B <= 1024 else 1   # (larger batches take several rounds per call)
+    profile_period = 4 if args.steps >= 16 and args.batched and B_rank <= 1024 else 1   # (larger batches take several rounds per call)
     timed_steps = (args.steps + profile_period - 1) // profile_period   # steps whose main launch carries the event pair
     index.set_profiling(profile_period if profile_period > 1 else True)
     fallbacks[0] = 0
@@ -1262,14 +1268,15 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "strong" if args.batch_given else "weak",
             "vs_baseline": None,
             "dtype": "f16 x f32 -> f32" + (" (every emitted score, in the reference's operation order); candidate filter i8 x i8 -> i32" if int8_filter else ""),
             "data": "synthetic",
             "config": {
                 "workload": f"{args.rows}x{args.dim} f16 corpus (clustered unit vectors), exact brute-force cosine "
                             f"top-{k}, {B} queries per step, rows sharded {row_shards} way(s)" + (f" x {groups} query groups" if groups > 1 else ""),
-                "rows": args.rows, "dim": args.dim, "k": k, "queries_per_step": B, "query_groups": groups, "row_shards": row_shards,
+                "rows": args.rows, "dim": args.dim, "k": k, "queries_per_step": B, "queries_per_step_per_gpu": B / world,
+                "query_groups": groups, "row_shards": row_shards,
                 "parallelism": (f"row-shard x{world}" if groups == 1 else f"{groups} query groups x {row_shards} row shards") + ((" + all-gather(top-k) over RCCL" if backend == "nccl" else
                                                           f" + all-gather(top-k) over {backend} (single-GPU rehearsal)") if world > 1 else ""),
                 "kernel_variant": args.variant,
