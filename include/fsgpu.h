@@ -205,8 +205,9 @@ int32_t fsgpu_index_filter_rotated(fsgpu_index *idx); /* 1: the filter's copy of
  * built at the first such call.  A lone query (k <= 32) takes ONE certified pass: every block of the int8 scan keeps its 32 best entries,
  * the rows within the proven margin of the k-th are re-scored from the f16 slab, and the answer stands when no block can have dropped a
  * row within that margin (one query at 10M x 384: p50 0.67 ms against 1.26 ms; 1M x 384: 0.126 against 0.161); an uncertified query
- * takes the staged path.  Off by default (fsgpu_search_topk then runs the exact kernels only); the two-tier host (libfshost) sets it on
- * the quality tier. */
+ * takes the staged path.  Off by default: fsgpu_search_topk then takes the certified pass only for a lone query of an index whose int8
+ * copy a batched search has already built (see fsgpu_search_topk_exact above) and never builds the copy itself; the two-tier host
+ * (libfshost) sets it on the quality tier. */
 fsgpu_status fsgpu_index_set_int8_latency(fsgpu_index *idx, int32_t enabled);
 /* Queries the int8 filter has taken so far, how many of them it handed on to the f16 filter, and whether the index still
  * uses it (any pointer may be null). */

@@ -14,5 +14,6 @@ cp $SRC/enc_trace/enc_kernel_stats.csv $DST/encoder_kernel_stats.csv
 grep -E '^(m2v|bert)' $SRC/enc_untraced.log > $DST/enc_bench.txt
 cp $SRC/encoder_mfma_pmc.json $DST/encoder_mfma_pmc.json 2>/dev/null
 cp $SRC/pmc_sq.json $DST/scan_sq_pmc_raw.json
+cp $SRC/batch_overhead.txt $SRC/fuzz_fresh_seeds.txt $DST/ 2>/dev/null
 [ -f $SRC/gputest.log ] && grep -E "passed|failed|real" $SRC/gputest.log > $DST/gputest_summary.txt
 ls $DST
