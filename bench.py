@@ -826,7 +826,13 @@ def two_tier_sharded_section(fa, devices, quality_index, rows: int, k: int, exch
     bert.set_coalescing(2 * max_batch, wait_us)
     fb0, fr0 = fast_index.coalescing_stats()
     qb0, qr0 = quality_index.coalescing_stats()
-    con = plain.run_load(threads=1024, queries=60_000, warmup_queries=2048, k=k, fast_vocab=500_353, corpus_rows=rows)
+    # (the same ladder as the unsharded section — 64, 256, then 1,024 callers over 80,000 queries: the last rung alone, cold and over
+    # 60,000 queries, read 10 % low against it)
+    plain.run_load(threads=64, queries=20_000, warmup_queries=128, k=k, fast_vocab=500_353, corpus_rows=rows)
+    plain.run_load(threads=256, queries=40_000, warmup_queries=512, k=k, fast_vocab=500_353, corpus_rows=rows)
+    fb0, fr0 = fast_index.coalescing_stats()
+    qb0, qr0 = quality_index.coalescing_stats()
+    con = plain.run_load(threads=1024, queries=80_000, warmup_queries=2048, k=k, fast_vocab=500_353, corpus_rows=rows)
     fb, fr = fast_index.coalescing_stats()
     qb, qr = quality_index.coalescing_stats()
     quality_index.set_coalescing(0, 0)

@@ -6,6 +6,9 @@
 // never needs RCCL on its library path, and inside a PyTorch process the already loaded copy (same SONAME) is reused.
 #include "sharded_index.hpp"
 
+#include <chrono>
+#include <cstdio>
+
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -603,6 +606,30 @@ SearchError ShardedIndex::end_lone(RootSlot& rs, uint32_t* out_rows, float* out_
     return SearchError{};
 }
 
+#ifdef FSGPU_SHARDED_TIMING   // lab: where a search through the handle spends its host time (printed every 256 searches)
+namespace {
+struct ShTiming {
+    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t n = 0;
+    void add(int i, std::chrono::steady_clock::time_point a) { t[i] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); }
+    void done() {
+        if (++n % 256 == 0) {
+            std::fprintf(stderr, "[sharded timing] per search, us: stage copy %.1f | reservations %.1f | enqueue scans %.1f | enqueue exchange %.1f | wait %.1f | end scans %.1f | copy out %.1f\n",
+                         t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n, t[5] / n, t[6] / n);
+        }
+    }
+};
+ShTiming g_sh_timing;
+}  // namespace
+#define SH_T0() auto sh_t0 = std::chrono::steady_clock::now()
+#define SH_T(i) do { g_sh_timing.add((i), sh_t0); sh_t0 = std::chrono::steady_clock::now(); } while (0)
+#define SH_TDONE() g_sh_timing.done()
+#else
+#define SH_T0() do { } while (0)
+#define SH_T(i) do { } while (0)
+#define SH_TDONE() do { } while (0)
+#endif
+
 SearchError ShardedIndex::begin(const Request& rq, uint32_t query_len, uint64_t* ticket) {
     if (!ticket) return make_err(FSGPU_ERR_NULL_ARGUMENT, "ticket is null");
     *ticket = 0;
@@ -666,7 +693,9 @@ SearchError ShardedIndex::begin(const Request& rq, uint32_t query_len, uint64_t*
         SH_HIP(hipHostMalloc(&rs.stage, need, hipHostMallocPortable));
         rs.stage_bytes = need;
     }
+    SH_T0();
     if (!rq.queries_dev && !rq.n_parts) std::memcpy(rs.stage, rq.queries, qbytes);
+    SH_T(0);
     // EVERY reservation a rank or the exchange needs happens here, before any work is enqueued: a failed allocation must not
     // leave some ranks inside a collective that others never enter
     const size_t lbytes = (size_t)per * cc * 8 * (two_pass ? 2 : 1);
@@ -688,14 +717,17 @@ SearchError ShardedIndex::begin(const Request& rq, uint32_t query_len, uint64_t*
             const std::vector<uint64_t> sl = shards_[x]->rows ? slice_bitmap(rq.allow, shards_[x]->lo, shards_[x]->rows) : std::vector<uint64_t>();
             rs.allow_slices.insert(rs.allow_slices.end(), sl.begin(), sl.end());
         }
+    SH_T(1);
     SearchError first;
     for (uint32_t r = 0; r < w && first.ok(); ++r) first = enqueue_scan(rq, r, slot);
+    SH_T(2);
     if (!first.ok()) {   // nothing has entered a collective yet; the searches that were begun are ended so that their tickets are free again
         uint32_t late = 0;
         (void)end_scans(slot, &late);
         return first;
     }
     SH_TRY(enqueue_exchange(slot));
+    SH_T(3);
     rs.pending = true;
     *ticket = next_ticket_++;
     return SearchError{};
@@ -712,12 +744,15 @@ SearchError ShardedIndex::end(uint64_t ticket, uint32_t* out_rows, float* out_sc
         return SearchError{};
     }
     if (rs.lone) return end_lone(rs, out_rows, out_scores, out_counts);
+    SH_T0();
     SH_HIP(hipSetDevice(shards_[0]->device));
     SH_HIP(hipEventSynchronize(rs.done));
+    SH_T(4);
     // the ranks' verdicts; a rank that had to answer an uncertified query did so on its scan stream AFTER its list had travelled:
     // the corrected lists travel again (rare: the bench corpora never take this path)
     uint32_t late = 0;
     SH_TRY(end_scans(slot, &late));
+    SH_T(5);
     rs.fallbacks = late;
     if (late) {
         for (auto& s : shards_) {
@@ -733,6 +768,8 @@ SearchError ShardedIndex::end(uint64_t ticket, uint32_t* out_rows, float* out_sc
     std::memcpy(out_rows, stage + qbytes, hbytes);
     std::memcpy(out_scores, stage + qbytes + hbytes, hbytes);
     std::memcpy(out_counts, stage + qbytes + 2 * hbytes, cbytes);
+    SH_T(6);
+    SH_TDONE();
     if (fallbacks) *fallbacks = rs.fallbacks;
     return SearchError{};
 }
