@@ -165,6 +165,17 @@ def test_rotated_filter_copy_keeps_the_bound_and_the_exact_bits(fa, oracle, dim)
         for i in range(6):
             r1 = auto.search_batch(q[i], k)
             assert np.array_equal(r1[0][0], er[i]) and np.array_equal(bits(r1[1][0]), bits(es[i])), (name, i)
+        # an allow bitmap and tombstones over the same (rotated) copy: the filter sees them through the kernels' bitmaps, not through the copy
+        allow = rng.random(rows.shape[0]) < 0.5
+        fr_, fs_, fc_ = [np.concatenate(z) for z in zip(*[auto.search_batch(q[s0:s0 + 60], k, allow=allow, exact=True) for s0 in range(0, 300, 60)])]
+        br, bs, bc, fb = auto.search_batched(q, k, allow=allow)
+        assert np.array_equal(br, fr_) and np.array_equal(bits(bs), bits(fs_)) and np.array_equal(bc, fc_), (name, "allow bitmap")
+        live = rng.random(rows.shape[0]) < 0.9
+        auto.set_live(live)
+        lr, ls, lc = [np.concatenate(z) for z in zip(*[auto.search_batch(q[s0:s0 + 60], k, exact=True) for s0 in range(0, 300, 60)])]
+        br, bs, bc, fb = auto.search_batched(q, k)
+        assert np.array_equal(br, lr) and np.array_equal(bits(bs), bits(ls)) and np.array_equal(bc, lc), (name, "tombstones")
+        assert live[br[bc[:, None] > np.arange(k)[None, :]]].all(), name
         auto.close()
         off.close()
 
