@@ -1,6 +1,6 @@
 // f32_kernels.hip — Quantization::F32 slabs (FSVI quantization byte 0, crates/frankensearch-index/src/lib.rs:203-208):
 // rows are raw little-endian f32.  F16 is the reference's default and the format every BASELINE config uses; F32 files
-// have one fused scan + top-k kernel (scan_topk_f32_kernel, one query per pass, k <= 256, dim % 8 == 0) and the general
+// have one fused scan + top-k kernel (scan_topk_f32_kernel, 1 / 2 / 4 queries per pass, k <= 256, dim % 8 == 0) and the general
 // path (score every row -> radix sort -> top k) for everything else.
 //
 // dot_product_f32_bytes_f32 (simd.rs:581-702): four 8-lane accumulators over groups of 32 elements, separate multiply
@@ -85,24 +85,30 @@ __global__ __launch_bounds__(256) void dot_rows_f32_kernel(ScanArgs args, const 
     }
 }
 
-// Fused scan + top-k over an F32 slab, one query per pass: the f32 counterpart of scan_topk_kernel's runtime-dimension body
-// (scan_kernels.hip) — same lane mapping (a quad per row, 16 rows per wave tile, grid-stride tiles), same threshold-gated wave
-// candidate buffer and block fold, the arithmetic of dot_rows_f32_kernel above.  Writes one best-first list of k entries per
-// block to args.partial; merge_topk_kernel finishes.  dim % 8 == 0.
-template <int KCAP>
+// Fused scan + top-k over an F32 slab, NQ queries per pass over the rows (1, 2 or 4): the f32 counterpart of scan_topk_kernel's
+// runtime-dimension body (scan_kernels.hip) — same lane mapping (a quad per row, 16 rows per wave tile, grid-stride tiles), same
+// threshold-gated wave candidate buffers (one per query) and block fold, the arithmetic of dot_rows_f32_kernel above: a row's
+// elements are loaded ONCE and multiplied against every query of the pass (round 5; the r04 kernel was one query per pass — a batch
+// of B queries streamed the slab B times).  Queries at args.queries + q * dim; one best-first list of k entries per (query, block) at
+// args.partial + (q * gridDim.x + block) * k; merge_topk_kernel finishes.  dim % 8 == 0.
+template <int KCAP, int NQ>
 __global__ __launch_bounds__(256) void scan_topk_f32_kernel(ScanArgs args) {
     constexpr int CAP = 2 * KCAP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int dim = (int)args.dim;
-    float* qs = reinterpret_cast<float*>(smem);                                              // [dim]
-    u64* bufs = reinterpret_cast<u64*>(smem + (((size_t)dim * 4 + 15) & ~(size_t)15));       // [wave][CAP]
+    float* qs = reinterpret_cast<float*>(smem);                                                      // [NQ][dim]
+    u64* bufs = reinterpret_cast<u64*>(smem + (((size_t)NQ * dim * 4 + 15) & ~(size_t)15));         // [wave][NQ][CAP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int a = lane & 3, r = lane >> 2;
-    for (int i = tid; i < dim; i += 256) qs[i] = args.queries[i];
+    for (int i = tid; i < NQ * dim; i += 256) qs[i] = args.queries[i];
     __syncthreads();
-    WaveTopK<CAP> tk;
-    tk.init(bufs + (size_t)wave * CAP);
-    u64 thr = 0;
+    WaveTopK<CAP> tk[NQ];
+    u64 thr[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        tk[q].init(bufs + ((size_t)wave * NQ + q) * CAP);
+        thr[q] = 0;
+    }
     const uint32_t nrows = args.nrows;
     const uint32_t ntiles = (nrows + kRowsPerTile - 1) / kRowsPerTile;
     const uint32_t nwaves = gridDim.x * kWavesPerBlock;
@@ -118,10 +124,12 @@ __global__ __launch_bounds__(256) void scan_topk_f32_kernel(ScanArgs args) {
         const uint32_t w64 = (tile * kRowsPerTile) >> 6;
         const u64 live_word = args.live ? args.live[w64] : ~0ull;
         const u64 allow_word = args.allow ? args.allow[w64] : ~0ull;
-        float acc[8];
+        float acc[NQ][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-#pragma unroll 4
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[q][j] = 0.f;
+#pragma unroll 2
         for (int g = 0; g < groups; ++g) {
             const int e = 32 * g + 8 * a;
             float x[8];
@@ -134,43 +142,52 @@ __global__ __launch_bounds__(256) void scan_topk_f32_kernel(ScanArgs args) {
                 for (int j = 0; j < 8; ++j) x[j] = w[e + j];
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float p = x[j] * qs[e + j];
-                acc[j] = acc[j] + p;
-            }
-        }
-        float v[8];
+            for (int q = 0; q < NQ; ++q)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float u = acc[j] + quad_xor1(acc[j]);
-            v[j] = u + quad_xor2(u);
+                for (int j = 0; j < 8; ++j) {
+                    const float p = x[j] * qs[q * dim + e + j];
+                    acc[q][j] = acc[q][j] + p;
+                }
         }
-        for (int c = 4 * groups; c < chunks; ++c)   // leftover chunks join AFTER the combine (simd.rs:581-702)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float p = w[8 * c + j] * qs[8 * c + j];
-                v[j] = v[j] + p;
-            }
-        const float score = hreduce8(v, args.hreduce);
         const bool valid = row < nrows && ((live_word >> (row & 63)) & 1ull) && ((allow_word >> (row & 63)) & 1ull);
-        const u64 packed = pack(score, args.row_base + row);
-        bool cand = valid && a == 0 && sortkey(packed) > thr;
-        u64 m = __ballot(cand);
-        if (m == 0) continue;
-        if (tk.count + (int)__popcll(m) > CAP) {
-            thr = tk.compact(k, lane);
-            cand = cand && sortkey(packed) > thr;
-            m = __ballot(cand);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float u = acc[q][j] + quad_xor1(acc[q][j]);
+                v[j] = u + quad_xor2(u);
+            }
+            for (int c = 4 * groups; c < chunks; ++c)   // leftover chunks join AFTER the combine (simd.rs:581-702)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float p = w[8 * c + j] * qs[q * dim + 8 * c + j];
+                    v[j] = v[j] + p;
+                }
+            const float score = hreduce8(v, args.hreduce);
+            const u64 packed = pack(score, args.row_base + row);
+            bool cand = valid && a == 0 && sortkey(packed) > thr[q];
+            u64 m = __ballot(cand);
+            if (m == 0) continue;
+            if (tk[q].count + (int)__popcll(m) > CAP) {
+                thr[q] = tk[q].compact(k, lane);
+                cand = cand && sortkey(packed) > thr[q];
+                m = __ballot(cand);
+            }
+            if (cand) tk[q].buf[tk[q].count + (int)__popcll(m & ((1ull << lane) - 1ull))] = packed;
+            tk[q].count += (int)__popcll(m);
         }
-        if (cand) tk.buf[tk.count + (int)__popcll(m & ((1ull << lane) - 1ull))] = packed;
-        tk.count += (int)__popcll(m);
     }
-    (void)tk.compact(k, lane);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) (void)tk[q].compact(k, lane);
     __syncthreads();
-    if (wave == 0) {   // fold the four waves' best-first lists: elementwise max of A[i] and B[KCAP-1-i], re-sort
-        u64* dst = bufs;
+    // fold the four waves' best-first lists of a query: elementwise max of A[i] and B[KCAP-1-i], re-sort.  Wave q folds query q
+    // (NQ <= 4 = the block's waves); its destination is wave 0's buffer of that query.
+    if (wave < NQ) {
+        const int q = wave;
+        u64* dst = bufs + (size_t)q * CAP;
         for (int w = 1; w < kWavesPerBlock; ++w) {
-            const u64* src = bufs + (size_t)w * CAP;
+            const u64* src = bufs + ((size_t)w * NQ + q) * CAP;
             for (int i = lane; i < KCAP; i += 64) {
                 const u64 xx = dst[i], yy = src[KCAP - 1 - i];
                 dst[i] = sortkey(xx) >= sortkey(yy) ? xx : yy;
@@ -178,15 +195,20 @@ __global__ __launch_bounds__(256) void scan_topk_f32_kernel(ScanArgs args) {
             for (int i = KCAP + lane; i < CAP; i += 64) dst[i] = kEmpty;
             wave_sort_desc<CAP>(dst, lane);
         }
-        u64* out = args.partial + (size_t)blockIdx.x * k;
+        u64* out = args.partial + ((size_t)q * gridDim.x + blockIdx.x) * k;
         for (int i = lane; i < k; i += 64) out[i] = dst[i];
     }
 }
 
-template <int KCAP>
+template <int KCAP, int NQ>
 static hipError_t launch_f32_t(const ScanArgs& args, int grid, hipStream_t stream, int* occupancy) {
-    const size_t lds = (((size_t)args.dim * 4 + 15) & ~(size_t)15) + (size_t)kWavesPerBlock * 2 * KCAP * 8;
-    auto kern = scan_topk_f32_kernel<KCAP>;
+    static_assert(NQ <= kWavesPerBlock, "one wave folds one query's lists");
+    const size_t lds = (((size_t)NQ * args.dim * 4 + 15) & ~(size_t)15) + (size_t)kWavesPerBlock * NQ * 2 * KCAP * 8;
+    auto kern = scan_topk_f32_kernel<KCAP, NQ>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     if (occupancy) {
         int blocks = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, 256, lds) != hipSuccess || blocks < 1) blocks = 1;
@@ -197,10 +219,29 @@ static hipError_t launch_f32_t(const ScanArgs& args, int grid, hipStream_t strea
     return hipGetLastError();
 }
 
-// kcap 64 or 256 (k <= kcap); occupancy != null: only reports the resident blocks per CU
-hipError_t launch_scan_topk_f32(const ScanArgs& args, int kcap, int grid, hipStream_t stream, int* occupancy) {
-    if ((args.dim & 7) || args.dim * 4 > 48 * 1024) return hipErrorInvalidValue;
-    return kcap <= 64 ? launch_f32_t<64>(args, grid, stream, occupancy) : launch_f32_t<256>(args, grid, stream, occupancy);
+// largest number of queries (4, 2 or 1) one pass of the fused F32 kernel takes for this shape: the queries and the per-wave
+// candidate buffers must fit the LDS
+int scan_f32_queries_per_pass(int dim, int kcap, int want) {
+    for (int nq = 4; nq >= 1; nq >>= 1) {
+        if (nq > want) continue;
+        const size_t lds = (((size_t)nq * dim * 4 + 15) & ~(size_t)15) + (size_t)kWavesPerBlock * nq * 2 * (kcap <= 64 ? 64 : 256) * 8;
+        if (lds <= (size_t)144 * 1024) return nq;
+    }
+    return 1;
+}
+
+// kcap 64 or 256 (k <= kcap); nq queries per pass (1, 2 or 4: scan_f32_queries_per_pass); occupancy != null: only reports the
+// resident blocks per CU
+hipError_t launch_scan_topk_f32(const ScanArgs& args, int kcap, int nq, int grid, hipStream_t stream, int* occupancy) {
+    if ((args.dim & 7) || (size_t)nq * args.dim * 4 > (size_t)96 * 1024) return hipErrorInvalidValue;
+    if (kcap <= 64) {
+        if (nq == 4) return launch_f32_t<64, 4>(args, grid, stream, occupancy);
+        if (nq == 2) return launch_f32_t<64, 2>(args, grid, stream, occupancy);
+        return nq == 1 ? launch_f32_t<64, 1>(args, grid, stream, occupancy) : hipErrorInvalidValue;
+    }
+    if (nq == 4) return launch_f32_t<256, 4>(args, grid, stream, occupancy);
+    if (nq == 2) return launch_f32_t<256, 2>(args, grid, stream, occupancy);
+    return nq == 1 ? launch_f32_t<256, 1>(args, grid, stream, occupancy) : hipErrorInvalidValue;
 }
 
 hipError_t launch_score_rows_f32(const ScanArgs& args, u64* out_packed, int q_index, hipStream_t stream) {

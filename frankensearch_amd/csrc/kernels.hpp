@@ -72,7 +72,8 @@ hipError_t launch_widen_f16(const unsigned short* src, size_t n, float* dst, hip
 
 // f32_kernels.hip — Quantization::F32 slabs: every row's packed (score, row) entry, and the gathered dot
 // fused scan + top-k over an F32 slab (one query per pass; lists to args.partial like launch_scan_topk); kcap 64 / 256
-hipError_t launch_scan_topk_f32(const ScanArgs& args, int kcap, int grid, hipStream_t stream, int* occupancy);
+hipError_t launch_scan_topk_f32(const ScanArgs& args, int kcap, int nq, int grid, hipStream_t stream, int* occupancy);
+int scan_f32_queries_per_pass(int dim, int kcap, int want);   // 4, 2 or 1: what the LDS holds
 hipError_t launch_score_rows_f32(const ScanArgs& args, u64* out_packed, int q_index, hipStream_t stream);
 hipError_t launch_gather_dot_f32(const ScanArgs& args, const uint32_t* rows, uint32_t n, float* out, hipStream_t stream);
 

@@ -737,7 +737,8 @@ SearchError VectorIndex::fused_search(const float* queries_dev, uint32_t nq, uin
     while (done < nq) {
         const uint32_t left = nq - done;
         // queries per pass: 8 / 4 through the multi-query kernel, else 2 / 1 through the register-resident kernel
-        int pass = left >= 2 && !f32_ ? 2 : 1;   // (F32 slabs: one fused kernel, one query per pass)
+        int pass = left >= 2 && !f32_ ? 2 : 1;
+        if (f32_) pass = scan_f32_queries_per_pass((int)dim_, kcap, (int)std::min<uint32_t>(left, 4));   // F32 slabs: 4 / 2 / 1 queries per pass
         bool mq = false;
         if (!f32_ && variant != 3 && variant != 1 && (!row_stride_ || row_stride_ == dim_ * 2)) {
             if (left >= 8 && kcap == 64 && scan_mq_supported((int)dim_, 8, kcap)) {
@@ -752,7 +753,7 @@ SearchError VectorIndex::fused_search(const float* queries_dev, uint32_t nq, uin
         int per_cu = 1;
         if (f32_) {
             ScanArgs probe = base_args(queries_dev, allow_dev);
-            FSGPU_HIP(launch_scan_topk_f32(probe, kcap, 1, stream, &per_cu));
+            FSGPU_HIP(launch_scan_topk_f32(probe, kcap, pass, 1, stream, &per_cu));
             per_cu = std::min(per_cu, 4);
         } else if (mq) {
             ScanArgs probe = base_args(queries_dev, allow_dev);
@@ -780,7 +781,7 @@ SearchError VectorIndex::fused_search(const float* queries_dev, uint32_t nq, uin
             FSGPU_HIP(hipEventCreate(&e1));
             FSGPU_HIP(hipEventRecord(e0, stream));
         }
-        if (f32_) FSGPU_HIP(launch_scan_topk_f32(a, kcap, grid, stream, nullptr));
+        if (f32_) FSGPU_HIP(launch_scan_topk_f32(a, kcap, pass, grid, stream, nullptr));
         else if (mq) FSGPU_HIP(launch_scan_mq(a, pass, kcap, grid, stream, nullptr));
         else if (host_query_hint_ && nq == 1) FSGPU_HIP(launch_scan_topk_host_query(a, host_query_hint_, kcap, grid, stream));
         else FSGPU_HIP(launch_scan_topk(a, pass, kcap, grid, stream, variant == 1, variant == 2));
