@@ -766,8 +766,9 @@ __global__ __launch_bounds__(256) void bert_attention_lds_kernel(const _Float16*
                         for (int r = 0; r < 4; ++r)
                             if (k0 + j * 16 + kg * 4 + r >= S) sc[j][r] = -INFINITY;
                 }
-                float mx = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])),
-                                 fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
+                // (three-operand maxima: v_max3_f32)
+                const float m_a = fmaxf(fmaxf(sc[0][0], sc[0][1]), sc[0][2]), m_b = fmaxf(fmaxf(sc[0][3], sc[1][0]), sc[1][1]);
+                float mx = fmaxf(fmaxf(fmaxf(sc[1][2], sc[1][3]), m_a), m_b);
                 {   // max over the four key quads of a query: lanes l, l ^ 16, l ^ 32, l ^ 48 — two row swaps in the VALU
                     // (v_permlane16_swap / v_permlane32_swap) instead of two ds_bpermute round trips through the LDS in the middle of
                     // the dependent chain
@@ -784,16 +785,22 @@ __global__ __launch_bounds__(256) void bert_attention_lds_kernel(const _Float16*
                 // (skipping the rescale while no query of the wave sees a new maximum was tried: the compiler turns the wave-uniform
                 // branch into nine selects behind the same multiplies)
                 const float corr = __builtin_amdgcn_exp2f(fmaf(m[t], c2, -mc));
+                // (two scores per instruction where the ISA has a packed form: v_pk_fma_f32 for the exponents, v_pk_add_f32 for the row sum)
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
                 half8 bp;
-                float ps = 0.f;
+                f32x2 ps2 = {0.f, 0.f};
+                const f32x2 c2v = {c2, c2}, mcv = {-mc, -mc};
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float pv = __builtin_amdgcn_exp2f(fmaf(sc[j][r], c2, -mc));
-                        ps += pv;
-                        bp[j * 4 + r] = (_Float16)pv;
+                    for (int r = 0; r < 4; r += 2) {
+                        const f32x2 e = __builtin_elementwise_fma(f32x2{sc[j][r], sc[j][r + 1]}, c2v, mcv);
+                        const f32x2 pv = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+                        ps2 += pv;
+                        bp[j * 4 + r] = (_Float16)pv[0];
+                        bp[j * 4 + r + 1] = (_Float16)pv[1];
                     }
+                const float ps = ps2[0] + ps2[1];
                 l[t] = l[t] * corr + ps;
                 m[t] = mn;
                 o0[t] *= corr;
