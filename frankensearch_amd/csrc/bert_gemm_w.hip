@@ -818,9 +818,7 @@ __global__ __launch_bounds__(512) void bert_ffn_w_kernel(const _Float16* __restr
             if (c + 1 < nchunks)
 #pragma unroll
                 for (int j = 0; j < CH; ++j) r1[ks][j] = wn[(j * KS1 + ks) * 64];
-#ifndef FSGPU_FFN_NO_SCHED
-            __builtin_amdgcn_sched_barrier(0);   // the refill is issued HERE, a ring's depth ahead of its use (left free, the scheduler sinks it next to the use)
-#endif
+            __builtin_amdgcn_sched_barrier(0);   // the refill is issued HERE, a ring's depth ahead of its use (left free, the scheduler sinks it next to the use: profiles/r05/enc_loop_forms_ab.txt)
         }
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
@@ -884,9 +882,7 @@ __global__ __launch_bounds__(512) void bert_ffn_w_kernel(const _Float16* __restr
                 if (ks + R2 < ksteps2)
 #pragma unroll
                     for (int j = 0; j < NT2; ++j) r2[d][j] = w2[((size_t)j * ksteps2 + ks + R2) * 64];
-#ifndef FSGPU_FFN_NO_SCHED
                 __builtin_amdgcn_sched_barrier(0);
-#endif
             }
         }
     };
@@ -1468,9 +1464,7 @@ static hipError_t launch_ffn_w_t(const void* ctx_h, const void* w0p, const float
     // three 16-column tiles per chunk when the wave's share divides, else two; the AO form (which also carries the rows
     // between the LayerNorms in registers) always two: with three, hidden = 384 spills
     auto kern = (!AO && (I / 16 / 8) % 3 == 0) ? bert_ffn_w_kernel<CT, 3, AO> : bert_ffn_w_kernel<CT, 2, AO>;
-#ifndef FSGPU_FFN_NO_FIXED
     if (AO && I == 4 * 64 * CT) kern = bert_ffn_w_kernel<CT, 2, true, 4 * 64 * CT>;   // the usual inter = 4 hidden: compile-time trip counts (see the kernel)
-#endif
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
