@@ -63,7 +63,7 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d 
 python scripts/encoder_pmc_summary.py $OUT/enc_trace $OUT/enc_pmc $OUT/encoder_mfma_pmc.json > $OUT/encoder_mfma_pmc.txt 2>&1
 # what one coalesced batch costs through the sharded handle against the unsharded index; fresh-seed fuzzers on this build
 PYTHONPATH=. python scripts/r05/batch_overhead.py 2>&1 | grep "nq=" > $OUT/batch_overhead.txt
-( timeout 200 python scripts/fuzz_batched.py 9501 150 2>&1 | tail -2; timeout 160 python tests/fuzz_exact.py 9503 90 2>&1 | tail -2; timeout 200 python tests/fuzz_encoders.py 9504 120 2>&1 | tail -2 ) > $OUT/fuzz_fresh_seeds.txt 2>&1
+( timeout 200 python scripts/fuzz_batched.py 9501 150 2>&1 | tail -2; timeout 160 python tests/fuzz_exact.py 9503 90 2>&1 | tail -2; timeout 200 python tests/fuzz_encoders.py 9504 120 2>&1 | tail -2; timeout 200 python scripts/fuzz_sharded.py 9505 150 2>&1 | tail -1 ) > $OUT/fuzz_fresh_seeds.txt 2>&1
 # the GPU suite on the same box
 ( time python -m pytest tests -m gpu -q ) > $OUT/gputest.log 2>&1
 ls -R $OUT | head -60
