@@ -408,8 +408,10 @@ SearchError ShardedIndex::ensure_quant_scale() {
         Rccl& rc = Rccl::get();
         // (max over non-negative f32 values: reduced as floats)
         ncclResult_t st = rc.group_start();
-        for (uint32_t r = 0; r < w && st == ncclSuccess; ++r)
+        for (uint32_t r = 0; r < w && st == ncclSuccess; ++r) {
+            (void)hipSetDevice(shards_[r]->device);
             st = rc.all_reduce(bits[r], bits[r], 1, ncclFloat32, ncclMax, static_cast<ncclComm_t>(shards_[r]->comm), shards_[r]->stream);
+        }
         const ncclResult_t st2 = rc.group_end();
         if (st != ncclSuccess || st2 != ncclSuccess)
             return make_err(FSGPU_ERR_DEVICE, std::string("ncclAllReduce(max): ") + rc.error_string(st != ncclSuccess ? st : st2));
@@ -460,6 +462,7 @@ SearchError ShardedIndex::enqueue_exchange(int slot) {
         ncclResult_t st = rc.group_start();
         for (uint32_t r = 0; r < w && st == ncclSuccess; ++r) {
             Slot& sl = shards_[r]->slot[slot];
+            (void)hipSetDevice(shards_[r]->device);   // (one thread, W communicators: the device of each call's communicator is current when it is issued)
             st = rc.all_gather(sl.packed.ptr, sl.gathered.ptr, count, ncclUint64, static_cast<ncclComm_t>(shards_[r]->comm), shards_[r]->xstream);
         }
         const ncclResult_t st2 = rc.group_end();
