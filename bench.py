@@ -192,6 +192,86 @@ def cpu_baseline_and_parity(slab_dev: torch.Tensor, queries: torch.Tensor, k: in
 
 CHUNK = 1_000_000   # the adversarial corpora are generated in fixed 1M-row chunks, each from its own seed
 
+def slab_checksum(slab: torch.Tensor, row_lo: int) -> int:
+    """Position-sensitive checksum of a resident row shard (f16 bits as integers): sum over rows of (row's element sum) x
+    ((global row id mod 1,000,003) + 1), mod 2^63.  Every rank reports it for ITS slab; rank 0 recomputes it from rows it generates
+    itself — a rank holding the wrong rows (or a stale buffer) cannot produce the right number."""
+    total = 0
+    for a in range(0, slab.shape[0], CHUNK):
+        part = slab[a:a + CHUNK].view(torch.int16)
+        rs = torch.sum(part, dim=1, dtype=torch.int64)
+        w = (torch.arange(row_lo + a, row_lo + a + part.shape[0], device=slab.device, dtype=torch.int64) % 1_000_003) + 1
+        total = (total + int(torch.sum(rs * w).item())) & ((1 << 63) - 1)
+    return total
+
+
+def host_corpus(rows: int, dim: int, device) -> np.ndarray:
+    """The WHOLE bench corpus in host memory (rows x dim f16 bits; 7.68 GB at 10M x 384), generated on `device` in 1M-row pieces by
+    the same fixture kernel every rank built its shard with and copied out piece by piece: the oracle's input for the check of an
+    N-rank answer.  Nothing here touches another rank's memory."""
+    host = np.empty((rows, dim), dtype=np.uint16)
+    for a in range(0, rows, CHUNK):
+        b = min(rows, a + CHUNK)
+        piece = gen_corpus(a, b, dim, device)
+        host[a:b] = piece.view(torch.int16).cpu().numpy().view(np.uint16)
+        del piece
+    return host
+
+
+def device_identity(index: int) -> dict:
+    """What tells one GPU of the node from another in the record of an N-rank run: the HIP device's UUID / PCI address and, where
+    the kernel driver exposes it, the board's unique_id."""
+    out = {"device": index}
+    try:
+        p = torch.cuda.get_device_properties(index)
+        out["name"] = p.name
+        for attr in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id"):
+            if hasattr(p, attr):
+                out[attr] = str(getattr(p, attr))
+        if all(k in out for k in ("pci_bus_id", "pci_device_id", "pci_domain_id")):
+            bdf = f"{int(out['pci_domain_id']):04x}:{int(out['pci_bus_id']):02x}:{int(out['pci_device_id']):02x}.0"
+            out["pci"] = bdf
+            try:
+                out["unique_id"] = open(f"/sys/bus/pci/devices/{bdf}/unique_id").read().strip()
+            except OSError:
+                pass
+    except Exception as e:   # noqa: BLE001 — identification must never cost the line
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
+def oracle_threads_for_bench() -> int:
+    cores = os.cpu_count() or 1
+    try:
+        mx, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if mx != "max":
+            return max(1, min(cores, int(int(mx) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(cores, 32)
+
+
+def merged_answer_vs_oracle(host: np.ndarray, queries_host: np.ndarray, picks, rows, scores, counts, k: int) -> dict:
+    """The N-rank answer itself — what came out of the all-gather + merge of a timed step — against the oracle's search_top_k over
+    ALL rows of the corpus (search.rs:1013-1036 partitions, :1704-1720 merges: the result must be that of the unpartitioned scan):
+    row ids and f32 score bits of `picks` queries of that step."""
+    from oracle import oracle
+
+    oracle.build()
+    nthreads = oracle_threads_for_bench()
+    ok, bad = True, []
+    r, sc, c = rows.cpu().numpy(), scores.cpu().numpy(), counts.cpu().numpy()
+    for qi in picks:
+        er, es = oracle.search_top_k(host, queries_host[qi], k, nthreads=nthreads)
+        same = bool(int(c[qi]) == len(er) and np.array_equal(r[qi, :len(er)].astype(np.uint32), er.astype(np.uint32)) and
+                    np.array_equal(sc[qi, :len(es)].view(np.uint32), es.view(np.uint32)))
+        ok &= same
+        if not same:
+            bad.append(int(qi))
+    return {"equal": bool(ok), "queries_checked": [int(x) for x in picks], "mismatching_queries": bad, "oracle_threads": nthreads,
+            "rows_scanned_by_the_oracle_per_query": int(host.shape[0])}
+
+
 
 def _chunks(lo: int, hi: int):
     c = lo // CHUNK

@@ -187,7 +187,7 @@ __global__ void rotate_rows_kernel(const IN* __restrict__ in, uint32_t nrows, ui
     __shared__ int bad[RB];
     const uint32_t row0 = blockIdx.x * RB;
     const int d = threadIdx.x;
-    if (d < RB) bad[d] = 0;
+    for (int i = threadIdx.x; i < RB; i += blockDim.x) bad[i] = 0;   // (blockDim = dim may be smaller than RB)
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < RB * dim; i += blockDim.x) {
         const uint32_t rr = i / dim, j = i - rr * dim;

@@ -213,6 +213,15 @@ __device__ __forceinline__ u64 sload_u64(const u64* pv) {
                      : "s"(p)
                      : "memory");
     } while (w != w2 && ++tries < 8);
+    if (w != w2) {
+        // Eight disagreeing pairs: the scalar path is not to be believed for this word.  The word is fetched ONCE more through the
+        // vector path (system-coherent, past every cache) — the path round 4's soak never saw return a wrong value.  vmcnt(0) also
+        // drains this wave's DMA ring, which is always safe (the counted waits that follow find fewer loads outstanding, never more);
+        // never taken in any soak, so its cost is a cold branch.
+        u64 wv;
+        asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(wv) : "v"(p) : "memory");
+        w = uniform_u64(wv);
+    }
 #endif
     return w;
 }

@@ -127,7 +127,7 @@ ShardedIndex::~ShardedIndex() {
             if (sl.sent) (void)hipEventDestroy(sl.sent);
         }
         if (s->xstream) (void)hipStreamDestroy(s->xstream);
-        if (s->stream) (void)hipStreamDestroy(s->stream);
+        if (s->stream && s->owns_stream) (void)hipStreamDestroy(s->stream);
     }
     if (!shards_.empty()) (void)hipSetDevice(shards_[0]->device);
     for (RootSlot& r : root_) {
@@ -228,7 +228,14 @@ SearchError ShardedIndex::finish_init(int32_t exchange) {
         for (uint32_t b = a + 1; b < w; ++b) distinct &= shards_[a]->device != shards_[b]->device;
     for (auto& s : shards_) {
         SH_HIP(hipSetDevice(s->device));
-        SH_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        // ONE stream per shard for everything that touches the shard index's workspaces: the lone lanes run on the index's own stream
+        // (VectorIndex::lone_*), so the batch scans are enqueued there too — a lone ticket and a batch ticket in flight together are
+        // ordered by the stream instead of racing on ws_partial_ / rot_q_ / ws_queries_
+        s->stream = s->index.stream();
+        if (!s->stream) {
+            SH_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+            s->owns_stream = true;
+        }
         SH_HIP(hipStreamCreateWithFlags(&s->xstream, hipStreamNonBlocking));
         for (Slot& sl : s->slot) {
             SH_HIP(hipEventCreateWithFlags(&sl.scan_done, hipEventDisableTiming));
@@ -519,10 +526,10 @@ SearchError ShardedIndex::enqueue_exchange(int slot) {
 }
 
 // A lone query: one group's shards answer through their own latency lanes (VectorIndex::lone_*), all begun here.
-SearchError ShardedIndex::begin_lone(const Request& rq, int slot) {
+SearchError ShardedIndex::begin_lone(const Request& rq, int slot, uint32_t group) {
     RootSlot& rs = root_[slot];
     rs.lone = true;
-    rs.lone_group = lone_rr_++ % groups_;
+    rs.lone_group = group;
     rs.lone_query.assign(rq.queries, rq.queries + dim_);
     const bool two_pass = rq.mode == kInt8TwoPass || rq.mode == kFourBitTwoPass;
     SearchError first;
@@ -677,10 +684,24 @@ SearchError ShardedIndex::begin(const Request& rq, uint32_t query_len, uint64_t*
     }
     if (two_pass) SH_TRY(ensure_quant_scale());
     if (rq.nq == 1 && rq.queries && !rq.queries_dev && !rq.n_parts && !rq.allow && rq.mode != kBatched) {
-        SH_TRY(begin_lone(rq, slot));
-        rs.pending = true;
-        *ticket = next_ticket_++;
-        return SearchError{};
+        // A shard index holds ONE lone query at a time (one LoneState, one pinned block).  With another lone ticket still in flight
+        // on the group whose turn it is, this query goes to the next group — or, with a single group, down the collective path
+        // below (the same kernels' rows and score bits, a device merge instead of the host's): ADVICE r05, high.
+        uint32_t group = lone_rr_ % groups_;
+        bool lane_free = true;
+        for (int o = 0; o < kSlots; ++o) {
+            const RootSlot& other = root_[o];
+            if (o == slot || !other.pending || !other.lone || other.k == 0 || other.lone_group != group) continue;
+            if (groups_ > 1) group = (group + 1) % groups_;   // (kSlots = 2: one other ticket at most, the next group is free)
+            else lane_free = false;
+        }
+        if (lane_free) {
+            ++lone_rr_;
+            SH_TRY(begin_lone(rq, slot, group));
+            rs.pending = true;
+            *ticket = next_ticket_++;
+            return SearchError{};
+        }
     }
     // query groups: group g takes queries [g * per, (g + 1) * per) — the last groups may hold fewer, or none
     const uint32_t per = (rq.nq + groups_ - 1) / groups_;
@@ -729,7 +750,14 @@ SearchError ShardedIndex::begin(const Request& rq, uint32_t query_len, uint64_t*
         (void)end_scans(slot, &late);
         return first;
     }
-    SH_TRY(enqueue_exchange(slot));
+    {
+        const SearchError xe = enqueue_exchange(slot);
+        if (!xe.ok()) {   // the shards' begun searches are ended: each index has two tickets, a leaked one is gone for good
+            uint32_t late = 0;
+            (void)end_scans(slot, &late);
+            return xe;
+        }
+    }
     SH_T(3);
     rs.pending = true;
     *ticket = next_ticket_++;
@@ -748,13 +776,16 @@ SearchError ShardedIndex::end(uint64_t ticket, uint32_t* out_rows, float* out_sc
     }
     if (rs.lone) return end_lone(rs, out_rows, out_scores, out_counts);
     SH_T0();
-    SH_HIP(hipSetDevice(shards_[0]->device));
-    SH_HIP(hipEventSynchronize(rs.done));
+    hipError_t waited = hipSetDevice(shards_[0]->device);
+    if (waited == hipSuccess) waited = hipEventSynchronize(rs.done);
     SH_T(4);
     // the ranks' verdicts; a rank that had to answer an uncertified query did so on its scan stream AFTER its list had travelled:
-    // the corrected lists travel again (rare: the bench corpora never take this path)
+    // the corrected lists travel again (rare: the bench corpora never take this path).  The end halves run even when the wait
+    // failed: a ticket that is never ended is lost to its index.
     uint32_t late = 0;
-    SH_TRY(end_scans(slot, &late));
+    const SearchError ended = end_scans(slot, &late);
+    if (waited != hipSuccess) return hip_err(waited, "hipEventSynchronize(done)");
+    SH_TRY(ended);
     SH_T(5);
     rs.fallbacks = late;
     if (late) {

@@ -125,7 +125,8 @@ class ShardedIndex {
         int device = -1;
         uint64_t lo = 0, rows = 0;
         VectorIndex index;
-        hipStream_t stream = nullptr;    // scan
+        hipStream_t stream = nullptr;    // scan: the shard index's own stream (lone lanes and batch scans in ONE order)
+        bool owns_stream = false;
         hipStream_t xstream = nullptr;   // exchange (+ merge and D2H on the root)
         Slot slot[kSlots];
         void* comm = nullptr;            // ncclComm_t
@@ -153,7 +154,7 @@ class ShardedIndex {
     SearchError enqueue_scan(const Request& rq, uint32_t r, int slot);   // rank r's share of the request, on its scan stream
     SearchError enqueue_exchange(int slot);
     SearchError end_scans(int slot, uint32_t* fallbacks);                // every rank's end half; *fallbacks: queries answered late
-    SearchError begin_lone(const Request& rq, int slot);
+    SearchError begin_lone(const Request& rq, int slot, uint32_t group);
     SearchError end_lone(RootSlot& rs, uint32_t* out_rows, float* out_scores, uint32_t* out_counts);
     SearchError ensure_quant_scale();    // corpus-wide max-abs: ncclAllReduce(max) / host max, once
     SearchError push_live_slices(const std::vector<uint64_t>& live);

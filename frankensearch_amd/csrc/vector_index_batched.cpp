@@ -195,8 +195,11 @@ SearchError VectorIndex::ensure_filter_copy(hipStream_t stream, bool must) {
     if (!i8f_decided_) {
         // rotate? the slab's largest |element| against the largest row norm spread evenly over the dimensions: a Gaussian-like row
         // has max ~ 6 / sqrt(dim) of its norm (and so has every rotated row), the bench's outlier corpus 17.6 / sqrt(dim)
-        bool rot = filter_rotation == 2;
-        if (filter_rotation == 0 && dim_ >= 64 && dim_ <= 1024) {
+        // (the rotation kernels run one thread per dimension and a block of dimensions per row: 64 <= dim <= 1024 in EVERY mode —
+        // "always" on a shape outside it keeps the unrotated copy instead of failing every batched search: ADVICE r05)
+        const bool rot_shape = dim_ >= 64 && dim_ <= 1024;
+        bool rot = filter_rotation == 2 && rot_shape;
+        if (filter_rotation == 0 && rot_shape) {
             FSGPU_TRY(i8f_max_.reserve(8));
             unsigned int* w = static_cast<unsigned int*>(i8f_max_.ptr);
             FSGPU_HIP(launch_slab_maxabs(slab_dev_, (size_t)nrows_ * dim_, w, stream));

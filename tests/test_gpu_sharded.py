@@ -245,7 +245,91 @@ def test_every_entry_point_of_the_sharded_handle_equals_the_unsharded_index(fa, 
     w0, w1 = whole.search_batch(q[5], k), whole.search_batch(q[:33], k)
     assert np.array_equal(r0[0], w0[0]) and np.array_equal(bits(r0[1]), bits(w0[1]))
     assert np.array_equal(r1[0], w1[0]) and np.array_equal(bits(r1[1]), bits(w1[1]))
+    # TWO lone tickets in flight (the API's two tickets): with one query group both queries land on the same shards, whose index
+    # holds one lone query at a time — the second goes down the collective path; with several groups it takes the next group.
+    # Every mode pair, ended in order and in reverse; each ticket must return ITS query's hits.
+    for lat in (False, True):
+        idx.set_int8_latency(lat)
+        for (ma, mb) in ((S.EXACT, S.EXACT), (S.INT8_TWO_PASS, S.EXACT), (S.EXACT, S.FOURBIT_TWO_PASS), (S.INT8_TWO_PASS, S.INT8_TWO_PASS)):
+            for rev in (False, True):
+                ta = idx.search_begin(q[11], k, ma, candidate_multiplier=3)
+                tb = idx.search_begin(q[12], k, mb, candidate_multiplier=3)
+                if rev:
+                    rb, ra = idx.search_end(tb), idx.search_end(ta)
+                else:
+                    ra, rb = idx.search_end(ta), idx.search_end(tb)
+                for (res, qi, mode) in ((ra, 11, ma), (rb, 12, mb)):
+                    if mode == S.EXACT:
+                        w = whole.search_batch(q[qi], k)
+                        assert np.array_equal(res[0], w[0]) and np.array_equal(bits(res[1]), bits(w[1])), (lat, ma, mb, rev, qi)
+                    else:
+                        hits = (whole.search_top_k_int8_two_pass if mode == S.INT8_TWO_PASS else whole.search_top_k_4bit_two_pass)(q[qi], k, 3)
+                        assert [h.index for h in hits] == res[0][0, :res[2][0]].tolist(), (lat, ma, mb, rev, qi)
+                        assert np.array_equal(bits([h.score for h in hits]), bits(res[1][0, :res[2][0]])), (lat, ma, mb, rev, qi)
+        # a lone ticket and a batch ticket of every batch kind in flight together, in both orders: the lone lanes and the batch scans
+        # share the shard index's workspaces (ws_partial_, the quantised / rotated queries) and are ordered on ONE stream
+        for bmode in (S.EXACT, S.BATCHED, S.INT8_TWO_PASS):
+            for lone_first in (True, False):
+                if lone_first:
+                    tl = idx.search_begin(q[7], k, S.EXACT)
+                    tb = idx.search_begin(q[:40], k, bmode, candidate_multiplier=3)
+                    rl, rb = idx.search_end(tl), idx.search_end(tb)
+                else:
+                    tb = idx.search_begin(q[:40], k, bmode, candidate_multiplier=3)
+                    tl = idx.search_begin(q[7], k, S.EXACT)
+                    rb, rl = idx.search_end(tb), idx.search_end(tl)
+                w = whole.search_batch(q[7], k)
+                assert np.array_equal(rl[0], w[0]) and np.array_equal(bits(rl[1]), bits(w[1])), (lat, bmode, lone_first)
+                if bmode == S.INT8_TWO_PASS:
+                    for qi in (0, 17, 39):
+                        hits = whole.search_top_k_int8_two_pass(q[qi], k, 3)
+                        assert [h.index for h in hits] == rb[0][qi, :rb[2][qi]].tolist(), (lat, lone_first, qi)
+                else:
+                    wb = whole.search_batch(q[:40], k)
+                    assert np.array_equal(rb[0], wb[0]) and np.array_equal(bits(rb[1]), bits(wb[1])), (lat, bmode, lone_first)
     idx.close()
+
+
+def test_lone_and_batch_tickets_overlap_on_a_rotated_filter_copy(fa, oracle):
+    """The overlap cases above on a corpus with outlier channels: the batched search and the certified lone pass both go through the
+    ROTATED int8 filter copy (rot_q_ is a workspace the lone lane and the batch's begin half share)."""
+    S = fa.NativeShardedIndex
+    n, dim, k = 120_000, 384, 10
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    x[:, rng.integers(0, dim, 3)] *= 12.0          # outlier dimensions stretch the corpus-wide scale: the automatic rule rotates
+    slab = np.ascontiguousarray((x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float16)).view(np.uint16)
+    pick = rng.choice(n, 48, replace=False)
+    q = slab[pick].view(np.float16).astype(np.float32)
+    q += (0.05 * rng.standard_normal(q.shape)).astype(np.float32)
+    whole = fa.VectorIndex.from_slab(slab)
+    whole.search_batched(q[:40], k)
+    assert whole.filter_rotated()
+    for groups, shards in ((1, 2), (2, 2)):
+        idx = S.from_slab(slab, [0] * (groups * shards), exchange=S.EXCHANGE_PEER_COPY, query_groups=groups)
+        idx.set_int8_latency(True)
+        wb = whole.search_batch(q[:40], k)
+        for lone_first in (True, False):
+            if lone_first:
+                tl = idx.search_begin(q[41], k, S.EXACT)
+                tb = idx.search_begin(q[:40], k, S.BATCHED)
+                rl, rb = idx.search_end(tl), idx.search_end(tb)
+            else:
+                tb = idx.search_begin(q[:40], k, S.BATCHED)
+                tl = idx.search_begin(q[41], k, S.EXACT)
+                rb, rl = idx.search_end(tb), idx.search_end(tl)
+            w = whole.search_batch(q[41], k)
+            assert np.array_equal(rl[0], w[0]) and np.array_equal(bits(rl[1]), bits(w[1])), (groups, shards, lone_first)
+            assert np.array_equal(rb[0], wb[0]) and np.array_equal(bits(rb[1]), bits(wb[1])), (groups, shards, lone_first)
+        ta, tb2 = idx.search_begin(q[42], k, S.EXACT), idx.search_begin(q[43], k, S.EXACT)
+        ra, rb2 = idx.search_end(ta), idx.search_end(tb2)
+        for res, qi in ((ra, 42), (rb2, 43)):
+            w = whole.search_batch(q[qi], k)
+            assert np.array_equal(res[0], w[0]) and np.array_equal(bits(res[1]), bits(w[1])), (groups, shards, qi)
+        idx.close()
+    er, es = oracle.search_top_k(slab, q[41], k)
+    w = whole.search_batch(q[41], k)
+    assert np.array_equal(w[0][0], er) and np.array_equal(bits(w[1][0]), bits(es))
 
 
 def test_queries_resident_in_parts_on_the_devices(fa, oracle):
