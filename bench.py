@@ -434,7 +434,10 @@ def flatten_for_the_driver(line: dict) -> None:
     head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step")
     rest = {k: v for k, v in line.items() if k not in head}
     first = {k: line[k] for k in head if k in line}
-    for key in ("p50_latency_ms_single_query", "p50_phase1_latency_ms", "p50_phase0_latency_ms", "end_to_end_queries_per_sec"):
+    for key in ("p50_latency_ms_single_query", "p50_phase1_latency_ms", "p50_phase0_latency_ms", "end_to_end_queries_per_sec",
+                "end_to_end_many_queries_per_sec", "merged_answer_equals_oracle_8_queries", "sharded_handle_equals_oracle_8_queries",
+                "ranks_in_collective", "comm_backend", "rccl_version", "strong_scaling_queries_per_sec", "weak_scaling_queries_per_sec",
+                "single_shard_parity_bit_exact"):
         if key in rest and not isinstance(rest[key], dict):
             first[key] = rest.pop(key)
     line.clear()
@@ -1047,7 +1050,20 @@ def sharded_handle_main(args) -> None:
         whole.close()
         del whole_slab
         torch.cuda.empty_cache()
+    # ... and against the ORACLE over the whole corpus (the parent run computed its answers on the host and handed them over): exact
+    # kernels, the matrix-core batched path and a lone query through the handle
+    vs_oracle = None
+    if args.expect and os.path.exists(args.expect):
+        exp = np.load(args.expect)
+        q8 = exp["q"]
+        vs_oracle = bool(np.array_equal(q8, q[:8]))
+        for mode_ in (idx.EXACT, idx.BATCHED):
+            r8, s8, c8, _ = idx.search(q8, k, mode_)
+            vs_oracle &= bool(np.array_equal(r8.astype(np.uint32), exp["rows"]) and np.array_equal(s8.view(np.uint32), exp["bits"]))
+        r1, s1, c1, _ = idx.search(q8[3], k, idx.EXACT)
+        vs_oracle &= bool(np.array_equal(r1[0].astype(np.uint32), exp["rows"][3]) and np.array_equal(s1[0].view(np.uint32), exp["bits"][3]))
     res = {"queries_per_sec": args.steps * B / dt, "ms_per_step": dt / args.steps * 1e3,
+           "equals_oracle_8_queries": vs_oracle,
            "pipelined_begin_end": {"queries_per_sec": args.steps * B / dt_piped, "ms_per_step": dt_piped / args.steps * 1e3,
                                    "in_flight": 2, "hits_equal_blocking_call": piped_same}, "n_gpus": n,
            "virtual_shards_on_one_device": bool(args.virtual_shards),
@@ -1096,6 +1112,8 @@ def sharded_handle_leg(args, world: int, virtual: bool):
     cmd = [sys.executable, os.path.abspath(__file__), "--sharded-handle", "--gpus", str(world), "--rows", str(args.rows), "--dim",
            str(args.dim), "--k", str(args.k), "--batch", str(args.batch), "--steps", str(min(args.steps, 50)), "--warmup", "3",
            "--config5-rows", str(args.config5_rows), "--query-groups", str(args.query_groups)]
+    if getattr(args, "expect", None):
+        cmd += ["--expect", args.expect]
     for flag, on in (("--exact", args.exact), ("--virtual-shards", virtual), ("--no-two-tier", args.no_two_tier), ("--no-config5", args.no_config5)):
         if on:
             cmd.append(flag)
@@ -1152,7 +1170,19 @@ def main() -> None:
                     help="N > 1: query groups G of the hybrid layout (G groups x N/G row shards; every rank scans row shard rank %% (N/G) "
                          "for 1/G of each batch).  0 = auto (default_query_groups), 1 = row shards only")
     ap.add_argument("--config5-rows", type=int, default=50_000_000, help="rows of the config 5 corpus in the sharded-handle leg")
+    ap.add_argument("--strong", action="store_true",
+                    help="N > 1: the headline step is 1,024 queries for the WHOLE job at every N (\"scaling\": \"strong\") — the same as "
+                         "--batch 1024; without it the headline is 1,024 queries per GPU (weak) and the strong form is timed next to it "
+                         "and reported as `strong_scaling`")
+    ap.add_argument("--no-strong-leg", action="store_true", help="N > 1: skip the second timed loop (the other scaling form)")
+    ap.add_argument("--no-merged-check", action="store_true",
+                    help="N > 1: skip the check of the merged N-rank answer against the oracle over the whole corpus (7.68 GB of host memory at 10M x 384)")
+    ap.add_argument("--expect", type=str, default=None,
+                    help="--sharded-handle: an .npz with the oracle's answers (rows, score bits) for the first queries of the pool, written by the "
+                         "parent run: the handle's answers are compared with it (equals_oracle_8_queries)")
     args = ap.parse_args()
+    if args.strong and args.batch is None:
+        args.batch = 1024 if not args.exact else 4
     args.batched = not args.exact
     # Queries per step.  Default: 1,024 PER GPU on the batched path (the launcher branch below multiplies by the world size): every
     # GPU-step is then the same work at every N — 1,024 queries against 10M rows' worth of (rows x queries) — and the line says
@@ -1220,7 +1250,12 @@ def main() -> None:
     lo, hi = shard_range(args.rows, rank % row_shards, row_shards)   # rank r holds row shard r % S and serves query group r // S
     slab = gen_corpus(lo, hi, args.dim, device)
     pool = 64
-    queries = gen_queries(max(pool, args.batch) + args.batch, args.dim, device)
+    # (N > 1 times both scaling forms: the pool holds two steps of the larger one)
+    other_batch = 0
+    if world > 1 and args.batched and not args.no_strong_leg:
+        other_batch = 1024 if args.batch != 1024 else 1024 * world
+    big = max(args.batch, other_batch)
+    queries = gen_queries(max(pool, big) + big, args.dim, device)
     index = fa.VectorIndex.from_device_slab(slab.data_ptr(), hi - lo, args.dim, device=local_rank, row_base=lo,
                                             keepalive=slab)
     index.set_variant(args.variant)
@@ -1236,7 +1271,7 @@ def main() -> None:
         s = (i * B) % (queries.shape[0] - B + 1)
         return queries[s:s + B]
 
-    def run_steps(first: int, n: int):
+    def run_steps(first: int, n: int, batch_of=batch_of):
         """n whole searches; returns the last step's (rows, scores, counts).  Every step's result is complete when this
         returns (the caller synchronises the device)."""
         out = None
@@ -1299,6 +1334,48 @@ def main() -> None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- N > 1: what the collective really saw, the other scaling form, and the merged answer against the oracle ---------------------
+    multi = None
+    if world > 1:
+        multi = {}
+        # (1) one more all-gather of one word per rank, counted on arrival: the number of DISTINCT ranks whose word came back — not WORLD_SIZE
+        tag = torch.tensor([rank + 1], dtype=torch.int64, device=device)
+        got = sharded._gather(tag.view(1, 1)).reshape(-1).cpu().tolist()
+        multi["ranks_in_collective"] = len({int(x) for x in got if int(x) > 0})
+        multi["comm_backend"] = str(dist.get_backend())
+        try:
+            multi["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None
+        except Exception:   # noqa: BLE001
+            multi["rccl_version"] = None
+        ident = device_identity(local_rank)
+        ident.update({"rank": rank, "local_rank": local_rank, "row_shard": rank % row_shards, "query_group": rank // row_shards,
+                      "rows_lo": lo, "rows_hi": hi, "slab_checksum": slab_checksum(slab, lo), "pid": os.getpid()})
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        multi["ranks"] = idents
+        # (2) the other scaling form in the same run: 1,024 queries for the whole job (strong) when the headline is weak, and the reverse
+        if args.batched and not args.no_strong_leg:
+            B2 = other_batch
+            fb_keep = fallbacks[0]
+            if B2 and B2 != B and queries.shape[0] >= 2 * B2:
+                def batch_of2(i: int):
+                    s2 = (i * B2) % (queries.shape[0] - B2 + 1)
+                    return queries[s2:s2 + B2]
+                run_steps(0, max(3, min(args.warmup, 10)), batch_of2)
+                torch.cuda.synchronize()
+                dist.barrier()
+                t2 = time.perf_counter()
+                run_steps(3, args.steps, batch_of2)
+                torch.cuda.synchronize()
+                dist.barrier()
+                el2 = torch.tensor([time.perf_counter() - t2], dtype=torch.float64, device=device)
+                dist.all_reduce(el2, op=dist.ReduceOp.MAX)
+                el2 = float(el2.item())
+                fb2, fallbacks[0] = fallbacks[0] - fb_keep, fb_keep
+                multi["other_scaling"] = {"scaling": "strong" if B2 == 1024 else "weak", "exact_fallback_queries": fb2, "queries_per_step": B2, "queries_per_step_per_gpu": B2 / world,
+                                          "value": args.steps * B2 / el2, "unit": "queries/sec", "ms_per_step": el2 / args.steps * 1e3,
+                                          "steps": args.steps, "timed": "barrier + synchronize on both sides, max over ranks, as the headline"}
 
     # single-query latency through the host-pointer boundary (H2D query, scan, merge, D2H hits, sync)
     lat = []
@@ -1372,7 +1449,7 @@ def main() -> None:
                 "filter_refiltered_on_f16_queries": i8_refiltered if int8_filter else None,
                 "exact_fallback_queries": fallbacks[0] if args.batched else None,
                 "host_loop": ("fsgpu_search_topk_batched_device_begin / _end, one step enqueued ahead" if args.batched and not args.blocking_steps
-                              else "one blocking call per step"),
+                              else "one blocking call per step") + "; device-resident queries and hits (the host-pointer ABI's rate: int8_two_pass.batched / sharded_handle)",
             },
             "roofline": {
                 "bound": "hbm",
@@ -1484,6 +1561,60 @@ def main() -> None:
         if not args.no_cpu_baseline:
             # N > 1: rank 0 times the port on ITS shard (the first rows of the same corpus) and scales to the full corpus
             line["cpu_baseline"] = cpu_baseline_and_parity(slab, queries, k, args.rows, fa.VectorIndex)
+            if world > 1:
+                # (what that check covers at N > 1: a fresh single-shard index over rank 0's rows — the N-rank answer is checked below)
+                cb = line["cpu_baseline"]
+                cb["single_shard_parity_bit_exact"] = cb.pop("parity_bit_exact")
+                cb["parity_scope"] = f"rank 0's row shard ({hi - lo} rows) searched as a single-shard index; the merged N-rank answer: merged_answer_vs_oracle"
+                line["single_shard_parity_bit_exact"] = cb["single_shard_parity_bit_exact"]
+        if multi is not None:
+            line["ranks_in_collective"] = multi["ranks_in_collective"]
+            line["comm_backend"] = multi["comm_backend"]
+            line["rccl_version"] = multi["rccl_version"]
+            line["ranks"] = multi["ranks"]
+            line["device_unique_ids"] = [r.get("unique_id") or r.get("uuid") or r.get("pci") for r in multi["ranks"]]
+            if "other_scaling" in multi:
+                o = multi["other_scaling"]
+                line[o["scaling"] + "_scaling"] = o
+                line[o["scaling"] + "_scaling_queries_per_sec"] = o["value"]
+            # every row shard's hits must show up in a step's merged answer (1,024+ queries x k hits over evenly spread clusters)
+            per_shard = (args.rows + row_shards - 1) // row_shards
+            owners = np.unique(rows.cpu().numpy().astype(np.uint32).astype(np.int64)[counts.cpu().numpy() > 0] // per_shard)
+            line["row_shards_with_hits_in_the_merged_answer"] = int(owners.size)
+            if not args.no_merged_check:
+                # THE N-rank check: rank 0 rebuilds the whole corpus on the host from its own generator, verifies every rank's slab
+                # checksum against it, and compares 8 queries of the LAST TIMED STEP's merged output — the tensors the all-gather +
+                # merge left — with the oracle's search over all rows: row ids and f32 score bits
+                t_chk = time.perf_counter()
+                host = host_corpus(args.rows, args.dim, device)
+                slabs_ok = True
+                for r in multi["ranks"]:
+                    piece = torch.from_numpy(host[r["rows_lo"]:r["rows_hi"]].view(np.int16))
+                    slabs_ok &= slab_checksum(piece, r["rows_lo"]) == r["slab_checksum"]
+                last_batch = batch_of(args.warmup + args.steps - 1).cpu().numpy()
+                per_q = (B + groups - 1) // groups
+                picks = sorted({0, 1, per_q - 1, min(per_q, B - 1), min(per_q + 1, B - 1), B // 3, B - 2, B - 1})
+                chk = merged_answer_vs_oracle(host, last_batch, picks, rows, scores, counts, k)
+                chk["every_rank_slab_checksum_matches_rank0_regeneration"] = bool(slabs_ok)
+                chk["what"] = (f"rows and f32 score bits of {len(picks)} queries of the last timed step's merged output ({world} ranks, {groups} query "
+                               f"group(s) x {row_shards} row shard(s), all-gather over {multi['comm_backend']}) == oracle.search_top_k over all {args.rows} rows")
+                # the oracle's answers for the first pool queries travel to the sharded-handle leg (its own process): --expect
+                from oracle import oracle as _oracle
+                q8 = queries[:8].cpu().numpy()
+                exp_rows = np.full((8, k), 0xFFFFFFFF, dtype=np.uint32)
+                exp_bits = np.zeros((8, k), dtype=np.uint32)
+                for qi in range(8):
+                    er, es = _oracle.search_top_k(host, q8[qi], k, nthreads=chk["oracle_threads"])
+                    exp_rows[qi, :len(er)] = er
+                    exp_bits[qi, :len(es)] = es.view(np.uint32)
+                import tempfile
+                fd, args.expect = tempfile.mkstemp(prefix="fsgpu_expect_", suffix=".npz")
+                os.close(fd)
+                np.savez(args.expect, rows=exp_rows, bits=exp_bits, q=q8)
+                del host
+                chk["seconds"] = time.perf_counter() - t_chk
+                line["merged_answer_vs_oracle"] = chk
+                line["merged_answer_equals_oracle_8_queries"] = bool(chk["equal"] and slabs_ok)
         if world == 1 and not args.no_adversarial and args.rows >= 1_000_000 and args.batched:
             line["adversarial_corpora"] = {kind: adversarial_section(kind, args.rows, args.dim, k, device, local_rank)
                                            for kind in ("uniform", "outlier")}
@@ -1524,6 +1655,7 @@ def main() -> None:
             leg = sharded_handle_leg(args, world, virtual=backend != "nccl")
             tt, c5 = leg.pop("two_tier", None), leg.pop("config5", None)
             line["sharded_handle"] = leg
+            line["sharded_handle_equals_oracle_8_queries"] = leg.get("equals_oracle_8_queries")
             if tt is not None:
                 line["two_tier"] = tt
                 if "error" not in tt:
@@ -1535,6 +1667,11 @@ def main() -> None:
                     line["end_to_end_queries_per_sec"] = tt["concurrent_1024_threads"]["queries_per_sec"]
             if c5 is not None:
                 line["config5"] = c5
+        if getattr(args, "expect", None) and world > 1:
+            try:
+                os.unlink(args.expect)
+            except OSError:
+                pass
         flatten_for_the_driver(line)
         # RCCL prints its version banner through C stdio, which sits in libc's buffer until exit when stdout is a pipe: push
         # it out first so that the JSON line is the last thing on stdout
