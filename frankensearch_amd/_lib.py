@@ -129,6 +129,7 @@ SIGNATURES = {
     "fsgpu_bert_embed_device": (_i32, [_vp, _vp, _vp, _u32, _vp]),
     "fsgpu_m2v_embed_device": (_i32, [_vp, _vp, _vp, _u32, _vp]),
     "fsgpu_search_topk_batched_device_queries": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, C.POINTER(_u32)]),
+    "fsgpu_search_topk_int8_two_pass_batched_device_queries": (_i32, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, C.POINTER(_u32)]),
     "fsgpu_device_malloc": (_i32, [_i32, _u64, C.POINTER(_vp)]),
     "fsgpu_device_free": (_i32, [_i32, _vp]),
     "fsgpu_bert_device": (_i32, [_vp]),

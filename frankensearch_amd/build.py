@@ -21,7 +21,7 @@ SOURCES = ["scan_kernels.hip", "scan_mq_kernel.hip", "int8_kernels.hip", "f32_ke
 HEADERS = ["device_util.hpp", "scan_common.hpp", "kernels.hpp", "vector_index.hpp", "vector_index_internal.hpp", "bert_embedder.hpp", "coalescer.hpp", "sharded_index.hpp", "two_tier_index.hpp", "lab_env.hpp"]
 # libfshost.so: the C++ host-side mirror of the reference's two-tier searcher, over the C ABI only (include/fshost.h)
 HOST_LIB = os.path.join(HERE, "libfshost.so")
-HOST_SOURCES = ["host/two_tier_searcher.cpp", "host/load_driver.cpp", "host/stream_pipeline.cpp", "host/fshost_api.cpp"]
+HOST_SOURCES = ["host/two_tier_searcher.cpp", "host/two_tier_many.cpp", "host/load_driver.cpp", "host/stream_pipeline.cpp", "host/fshost_api.cpp"]
 HOST_HEADERS = ["host/two_tier_searcher.hpp"]
 # -ffp-contract=off: the scan must issue a separate multiply and add (reference order, simd.rs:398-446).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

@@ -1406,6 +1406,17 @@ fsgpu_status fsgpu_search_topk_batched_device_queries(fsgpu_index* idx, const fl
                                                      nullptr, true));
     });
 }
+fsgpu_status fsgpu_search_topk_int8_two_pass_batched_device_queries(fsgpu_index* idx, const float* queries_dev, uint32_t nq, uint32_t query_len,
+                                                                    uint32_t k, uint32_t candidate_multiplier, uint32_t* out_rows,
+                                                                    float* out_scores, uint32_t* out_counts, uint32_t* out_fallbacks) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    if (nq && (!queries_dev || !out_counts || (k && (!out_rows || !out_scores)))) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.search_top_k_int8_batched(queries_dev, nq, query_len, k, candidate_multiplier, out_rows, out_scores, out_counts,
+                                                          out_fallbacks, 8, true));
+    });
+}
 uint32_t fsgpu_bert_dimension(const fsgpu_bert* m) { return m ? m->impl.dimension() : 0; }
 
 fsgpu_status fsgpu_bert_embed(fsgpu_bert* m, const int32_t* ids, const uint32_t* offsets, uint32_t n, float* out) {

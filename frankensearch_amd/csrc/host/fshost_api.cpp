@@ -7,6 +7,7 @@
 
 namespace fshost {
 fsgpu_status run_load(const SyncTwoTierSearcher& searcher, const fshost_load_config& cfg, fshost_load_result* res);
+fsgpu_status run_load_many(const SyncTwoTierSearcher& searcher, const fshost_load_config& cfg, uint32_t chunk, fshost_many_result* res);
 fsgpu_status embed_search_stream(fsgpu_bert* const* encoders, uint32_t n_encoders, fsgpu_index* index, fsgpu_sharded* sharded, const int32_t* ids,
                                  const uint32_t* offsets, uint32_t batch, uint32_t n_batches, uint32_t group, uint32_t k, bool overlap,
                                  bool host_handoff, uint32_t* out_rows, float* out_scores, uint32_t* out_counts, fshost_stream_result* result);
@@ -80,10 +81,53 @@ fsgpu_status fshost_two_tier_search(fshost_two_tier* s, const uint32_t* fast_tok
     }
 }
 
+fsgpu_status fshost_two_tier_search_many(fshost_two_tier* s, const uint32_t* fast_token_ids, const uint32_t* fast_offsets,
+                                         const int32_t* quality_token_ids, const uint32_t* quality_offsets, uint32_t nq, uint32_t k,
+                                         const fsgpu_scored_doc* lexical, const uint32_t* lexical_offsets, uint32_t chunk,
+                                         uint32_t fusion_threads, fshost_hit* initial_out, uint32_t* n_initial, fshost_hit* final_out,
+                                         uint32_t* n_final, uint8_t* refinement_failed_out, float* fast_vectors_out,
+                                         float* quality_vectors_out, fshost_many_result* result) {
+    if (!s || !result) return FSGPU_ERR_NULL_ARGUMENT;
+    if (nq && (!fast_offsets || !quality_offsets || !n_initial || !n_final || (k && (!initial_out || !final_out)))) return FSGPU_ERR_NULL_ARGUMENT;
+    if ((lexical == nullptr) != (lexical_offsets == nullptr)) return FSGPU_ERR_NULL_ARGUMENT;
+    try {
+        fshost::SyncTwoTierSearcher::ManyArgs a;
+        a.fast_ids = fast_token_ids;
+        a.fast_offsets = fast_offsets;
+        a.quality_ids = quality_token_ids;
+        a.quality_offsets = quality_offsets;
+        a.nq = nq;
+        a.k = k;
+        a.lexical = lexical;
+        a.lexical_offsets = lexical_offsets;
+        a.chunk = chunk;
+        a.fusion_threads = fusion_threads;
+        a.initial_out = initial_out;
+        a.n_initial = n_initial;
+        a.final_out = final_out;
+        a.n_final = n_final;
+        a.refinement_failed = refinement_failed_out;
+        a.fast_vectors_out = fast_vectors_out;
+        a.quality_vectors_out = quality_vectors_out;
+        return s->impl.search_many(a, result);
+    } catch (const std::exception&) {
+        return FSGPU_ERR_DEVICE;
+    }
+}
+
 fsgpu_status fshost_run_load(fshost_two_tier* s, const fshost_load_config* config, fshost_load_result* result) {
     if (!s || !config || !result) return FSGPU_ERR_NULL_ARGUMENT;
     try {
         return fshost::run_load(s->impl, *config, result);
+    } catch (const std::exception&) {
+        return FSGPU_ERR_DEVICE;
+    }
+}
+
+fsgpu_status fshost_run_load_many(fshost_two_tier* s, const fshost_load_config* config, uint32_t chunk, fshost_many_result* result) {
+    if (!s || !config || !result) return FSGPU_ERR_NULL_ARGUMENT;
+    try {
+        return fshost::run_load_many(s->impl, *config, chunk, result);
     } catch (const std::exception&) {
         return FSGPU_ERR_DEVICE;
     }

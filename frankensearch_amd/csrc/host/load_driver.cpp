@@ -4,6 +4,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstring>
 #include <string>
 #include <thread>
 #include <vector>
@@ -146,6 +147,67 @@ fsgpu_status run_load(const SyncTwoTierSearcher& searcher, const fshost_load_con
             std::snprintf(res->first_error, sizeof res->first_error, "%s", s.first_error.c_str());
             break;
         }
+    return FSGPU_OK;
+}
+
+// The load generator's queries (same distributions, one stream) handed to search_many in ONE call: what a host with a queue of
+// requests does.  Timed: the search_many call (warm-up: one call over warmup_queries first).
+fsgpu_status run_load_many(const SyncTwoTierSearcher& searcher, const fshost_load_config& cfg, uint32_t chunk, fshost_many_result* res) {
+    if (cfg.k == 0 || cfg.fast_vocab == 0 || cfg.corpus_rows == 0 || cfg.quality_vocab <= 1000 || cfg.queries == 0) return FSGPU_ERR_INVALID_CONFIG;
+    const uint32_t total = cfg.queries + cfg.warmup_queries;
+    SplitMix64 rng{cfg.seed * 0x100000001b3ull + 0x5eed};
+    std::vector<uint32_t> fast_ids, fast_off(total + 1, 0), q_off(total + 1, 0), lex_off(total + 1, 0);
+    std::vector<int32_t> quality_ids;
+    const uint32_t nl = 3 * cfg.k;
+    std::vector<char> lex_text((size_t)total * nl * 12);   // "doc-%08u" is 12 characters
+    std::vector<fsgpu_scored_doc> lexical((size_t)total * nl);
+    for (uint32_t q = 0; q < total; ++q) {
+        const uint32_t nf = 4 + rng.below(20);
+        for (uint32_t i = 0; i < nf; ++i) fast_ids.push_back(rng.below(cfg.fast_vocab));
+        fast_off[q + 1] = (uint32_t)fast_ids.size();
+        const uint32_t nq = 8 + rng.below(25);
+        quality_ids.push_back(101);
+        for (uint32_t i = 1; i + 1 < nq; ++i) quality_ids.push_back(1000 + (int32_t)rng.below(cfg.quality_vocab - 1000));
+        quality_ids.push_back(102);
+        q_off[q + 1] = (uint32_t)quality_ids.size();
+        for (uint32_t j = 0; j < nl; ++j) {
+            char* p = lex_text.data() + ((size_t)q * nl + j) * 12;
+            char buf[16];
+            std::snprintf(buf, sizeof buf, "doc-%08u", (uint32_t)(rng.next() % cfg.corpus_rows));
+            std::memcpy(p, buf, 12);
+            lexical[(size_t)q * nl + j] = fsgpu_scored_doc{p, 12u, (float)(nl - j), 0u};
+        }
+        lex_off[q + 1] = (q + 1) * nl;
+    }
+    std::vector<fshost_hit> ini((size_t)std::max(cfg.queries, cfg.warmup_queries) * cfg.k), fin(ini.size());
+    std::vector<uint32_t> ni(std::max(cfg.queries, cfg.warmup_queries)), nf(ni.size());
+    SyncTwoTierSearcher::ManyArgs a;
+    a.k = cfg.k;
+    a.chunk = chunk;
+    a.fusion_threads = cfg.threads;
+    a.initial_out = ini.data();
+    a.n_initial = ni.data();
+    a.final_out = fin.data();
+    a.n_final = nf.data();
+    auto run = [&](uint32_t first, uint32_t n) {
+        a.fast_ids = fast_ids.data();
+        a.fast_offsets = fast_off.data() + first;
+        a.quality_ids = quality_ids.data();
+        a.quality_offsets = q_off.data() + first;
+        a.lexical = lexical.data();
+        a.lexical_offsets = lex_off.data() + first;
+        a.nq = n;
+        return searcher.search_many(a, res);
+    };
+    if (cfg.warmup_queries) {
+        const fsgpu_status st = run(0, cfg.warmup_queries);
+        if (st != FSGPU_OK) return st;
+    }
+    const fsgpu_status st = run(cfg.warmup_queries, cfg.queries);
+    if (st != FSGPU_OK) return st;
+    uint64_t full = 0;
+    for (uint32_t q = 0; q < cfg.queries; ++q) full += (ni[q] == cfg.k && nf[q] == cfg.k) ? 1 : 0;
+    res->queries_with_k_initial_and_refined_hits = full;
     return FSGPU_OK;
 }
 

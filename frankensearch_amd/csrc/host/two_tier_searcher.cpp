@@ -84,6 +84,7 @@ SyncTwoTierSearcher::SyncTwoTierSearcher(fsgpu_sharded* fast, fsgpu_sharded* qua
 void SyncTwoTierSearcher::init() {
     fast_dim_ = fast_.dimension();
     quality_dim_ = quality_.dimension();
+    quality_dim_vec_ = fsgpu_bert_dimension(bert_);   // a vector has its EMBEDDER's dimension (a mismatch is the index's to report)
     // opt-in: the quality tier's exact search is phase 1's longest leg (one HBM pass over the f16 slab); with the int8 latency
     // path a lone caller's query goes through the int8 filter + exact re-score instead — the same hits from half the bytes.
     // It is a setting of the CALLER's handle (and costs it an int8 copy of the slab): switched off again in the destructor.
@@ -124,6 +125,13 @@ fsgpu_status SyncTwoTierSearcher::tier_hits(const Tier& tier, const std::vector<
         *detail = fsgpu_last_error();
         return st;
     }
+    return hits_from_rows(tier, rows.data(), scores.data(), count, hits, detail);
+}
+
+// Vec<VectorHit> of one tier's row-level answer: doc ids resolved (search.rs:1503-1558) or synthesised (doc_id_mode 1)
+fsgpu_status SyncTwoTierSearcher::hits_from_rows(const Tier& tier, const uint32_t* rows, const float* scores, uint32_t count,
+                                                 std::vector<Hit>* hits, std::string* detail) const {
+    fsgpu_status st = FSGPU_OK;
     hits->clear();
     hits->reserve(count);
     char buf[32];
@@ -207,16 +215,7 @@ fsgpu_status SyncTwoTierSearcher::search(const uint32_t* fast_ids, uint32_t n_fa
     st = tier_hits(fast_, fast_vec, fetch, cfg_.fast_tier_int8_multiplier, &fast_hits, detail);
     if (st != FSGPU_OK) return st;
     m.fast_search_ms = ms_since(t1);
-    const std::vector<fsgpu_scored_doc> fast_view = view(fast_hits);
-    std::vector<fsgpu_fused_hit> fused(k ? k : 1);
-    uint32_t n = 0;
-    st = fsgpu_rrf_fuse(lexical, n_lexical, fast_view.data(), (uint32_t)fast_view.size(), cfg_.rrf_k, 1.0, 1.0,
-                        FSGPU_RRF_TIEBREAK_LEXICAL_THEN_ID, k, 0, fused.data(), &n);
-    if (st != FSGPU_OK) {
-        *detail = fsgpu_last_error();
-        return st;
-    }
-    st = copy_out(fused, n, &out->initial, detail);
+    st = fuse_initial(fast_hits, k, lexical, n_lexical, &out->initial, detail);
     if (st != FSGPU_OK) return st;
     m.phase1_total_ms = ms_since(t0);
     // ---- phase 1 / Refined ----
@@ -237,36 +236,14 @@ fsgpu_status SyncTwoTierSearcher::search(const uint32_t* fast_ids, uint32_t n_fa
     }
     m.quality_embed_ms = ms_since(t3);
     const auto t4 = clock::now();
-    std::vector<fsgpu_scored_doc> blended(fast_view.size() + (size_t)fetch + 1);
-    uint32_t nb = 0;
     if (rescored) {
         // SyncQualityPool::RescoredFastPool (sync_searcher.rs:814-818): quality_scores_for_hits over the fast pool, then the
         // aligned blend (:862-866)
-        std::vector<float> qscores(fast_view.size() + 1);
-        std::vector<uint8_t> qpresent(fast_view.size() + 1);
-        st = fast_.index ? fsgpu_quality_scores_for_hits(fast_.index, quality_.index, alignment_, quality_vec.data(),
-                                                         (uint32_t)quality_vec.size(), fast_view.data(), (uint32_t)fast_view.size(), qscores.data(), qpresent.data())
-                         : fsgpu_sharded_quality_scores_for_hits(fast_.sharded, quality_.sharded, alignment_, quality_vec.data(),
-                                                                 (uint32_t)quality_vec.size(), fast_view.data(), (uint32_t)fast_view.size(),
-                                                                 qscores.data(), qpresent.data());
-        if (st != FSGPU_OK) return refinement_failed(out, t3);
-        m.quality_search_ms = ms_since(t4);
-        const auto t5r = clock::now();
-        st = fsgpu_blend_two_tier_aligned(fast_view.data(), (uint32_t)fast_view.size(), qscores.data(), qpresent.data(),
-                                          cfg_.quality_weight, blended.data(), &nb);
-        if (st != FSGPU_OK) {
-            *detail = fsgpu_last_error();
-            return st;
-        }
-        m.blend_ms = ms_since(t5r);
-        st = fsgpu_rrf_fuse(lexical, n_lexical, blended.data(), nb, cfg_.rrf_k, 1.0, 1.0, FSGPU_RRF_TIEBREAK_LEXICAL_THEN_ID, k, 0,
-                            fused.data(), &n);
-        if (st != FSGPU_OK) {
-            *detail = fsgpu_last_error();
-            return st;
-        }
-        st = copy_out(fused, n, &out->final_results, detail);
+        bool failed = false;
+        st = fuse_final_rescored(fast_hits, quality_vec.data(), k, lexical, n_lexical, &out->final_results, &failed, detail);
+        if (failed) return refinement_failed(out, t3);
         if (st != FSGPU_OK) return st;
+        m.quality_search_ms = ms_since(t4);
         m.phase2_total_ms = ms_since(t3);
         return FSGPU_OK;
     }
@@ -277,10 +254,75 @@ fsgpu_status SyncTwoTierSearcher::search(const uint32_t* fast_ids, uint32_t n_fa
     }
     m.quality_search_ms = ms_since(t4);
     const auto t5 = clock::now();
+    st = fuse_final_retrieved(fast_hits, quality_hits, k, lexical, n_lexical, &out->final_results, detail);
+    if (st != FSGPU_OK) return st;
+    m.blend_ms = ms_since(t5);
+    m.phase2_total_ms = ms_since(t3);
+    return FSGPU_OK;
+}
+
+// Phase 1's fusion for SyncQualityPool::RescoredFastPool (sync_searcher.rs:814-818, 862-866): quality_scores_for_hits over the fast
+// pool (a gather on the quality tier), blend_two_tier_aligned, RRF.  *failed: the quality scores could not be produced — a
+// RefinementFailed outcome, not an error (sync_searcher.rs:820-839).
+fsgpu_status SyncTwoTierSearcher::fuse_final_rescored(const std::vector<Hit>& fast_hits, const float* quality_vec, uint32_t k,
+                                                      const fsgpu_scored_doc* lexical, uint32_t n_lexical, std::vector<fshost_hit>* final_results,
+                                                      bool* failed, std::string* detail) const {
+    *failed = false;
+    const std::vector<fsgpu_scored_doc> fast_view = view(fast_hits);
+    std::vector<float> qscores(fast_view.size() + 1);
+    std::vector<uint8_t> qpresent(fast_view.size() + 1);
+    fsgpu_status st = fast_.index ? fsgpu_quality_scores_for_hits(fast_.index, quality_.index, alignment_, quality_vec, quality_dim_vec_,
+                                                                  fast_view.data(), (uint32_t)fast_view.size(), qscores.data(), qpresent.data())
+                                  : fsgpu_sharded_quality_scores_for_hits(fast_.sharded, quality_.sharded, alignment_, quality_vec, quality_dim_vec_,
+                                                                          fast_view.data(), (uint32_t)fast_view.size(), qscores.data(), qpresent.data());
+    if (st != FSGPU_OK) {
+        *failed = true;
+        return st;
+    }
+    std::vector<fsgpu_scored_doc> blended(fast_view.size() + 1);
+    uint32_t nb = 0, n = 0;
+    st = fsgpu_blend_two_tier_aligned(fast_view.data(), (uint32_t)fast_view.size(), qscores.data(), qpresent.data(), cfg_.quality_weight,
+                                      blended.data(), &nb);
+    if (st != FSGPU_OK) {
+        *detail = fsgpu_last_error();
+        return st;
+    }
+    std::vector<fsgpu_fused_hit> fused(k ? k : 1);
+    st = fsgpu_rrf_fuse(lexical, n_lexical, blended.data(), nb, cfg_.rrf_k, 1.0, 1.0, FSGPU_RRF_TIEBREAK_LEXICAL_THEN_ID, k, 0,
+                        fused.data(), &n);
+    if (st != FSGPU_OK) {
+        *detail = fsgpu_last_error();
+        return st;
+    }
+    return copy_out(fused, n, final_results, detail);
+}
+
+// Phase 0's fusion (sync_searcher.rs:700-760): RRF of the lexical list with the fast tier's hits, k results.
+fsgpu_status SyncTwoTierSearcher::fuse_initial(const std::vector<Hit>& fast_hits, uint32_t k, const fsgpu_scored_doc* lexical,
+                                               uint32_t n_lexical, std::vector<fshost_hit>* initial, std::string* detail) const {
+    const std::vector<fsgpu_scored_doc> fast_view = view(fast_hits);
+    std::vector<fsgpu_fused_hit> fused(k ? k : 1);
+    uint32_t n = 0;
+    const fsgpu_status st = fsgpu_rrf_fuse(lexical, n_lexical, fast_view.data(), (uint32_t)fast_view.size(), cfg_.rrf_k, 1.0, 1.0,
+                                           FSGPU_RRF_TIEBREAK_LEXICAL_THEN_ID, k, 0, fused.data(), &n);
+    if (st != FSGPU_OK) {
+        *detail = fsgpu_last_error();
+        return st;
+    }
+    return copy_out(fused, n, initial, detail);
+}
+
+// Phase 1's fusion for SyncQualityPool::Retrieved (sync_searcher.rs:840-943): blend_two_tier of the two tiers' hits, the blended
+// hits carrying the fast-tier row of their doc, RRF with the lexical list again.
+fsgpu_status SyncTwoTierSearcher::fuse_final_retrieved(const std::vector<Hit>& fast_hits, const std::vector<Hit>& quality_hits, uint32_t k,
+                                                       const fsgpu_scored_doc* lexical, uint32_t n_lexical, std::vector<fshost_hit>* final_results,
+                                                       std::string* detail) const {
+    const std::vector<fsgpu_scored_doc> fast_view = view(fast_hits);
     const std::vector<fsgpu_scored_doc> quality_view = view(quality_hits);
-    blended.resize(fast_view.size() + quality_view.size() + 1);
-    st = fsgpu_blend_two_tier(fast_view.data(), (uint32_t)fast_view.size(), quality_view.data(), (uint32_t)quality_view.size(),
-                              cfg_.quality_weight, blended.data(), &nb);
+    std::vector<fsgpu_scored_doc> blended(fast_view.size() + quality_view.size() + 1);
+    uint32_t nb = 0, n = 0;
+    fsgpu_status st = fsgpu_blend_two_tier(fast_view.data(), (uint32_t)fast_view.size(), quality_view.data(), (uint32_t)quality_view.size(),
+                                           cfg_.quality_weight, blended.data(), &nb);
     if (st != FSGPU_OK) {
         *detail = fsgpu_last_error();
         return st;
@@ -293,17 +335,14 @@ fsgpu_status SyncTwoTierSearcher::search(const uint32_t* fast_ids, uint32_t n_fa
         auto it = fast_index_of.find(std::string(blended[i].doc_id, blended[i].doc_id_len));
         blended[i].index = it == fast_index_of.end() ? 0xffffffffu : it->second;
     }
-    m.blend_ms = ms_since(t5);
+    std::vector<fsgpu_fused_hit> fused(k ? k : 1);
     st = fsgpu_rrf_fuse(lexical, n_lexical, blended.data(), nb, cfg_.rrf_k, 1.0, 1.0, FSGPU_RRF_TIEBREAK_LEXICAL_THEN_ID, k, 0,
                         fused.data(), &n);
     if (st != FSGPU_OK) {
         *detail = fsgpu_last_error();
         return st;
     }
-    st = copy_out(fused, n, &out->final_results, detail);
-    if (st != FSGPU_OK) return st;
-    m.phase2_total_ms = ms_since(t3);
-    return FSGPU_OK;
+    return copy_out(fused, n, final_results, detail);
 }
 
 }  // namespace fshost

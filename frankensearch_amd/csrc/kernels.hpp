@@ -205,7 +205,9 @@ struct GroupSelectArgs {
     uint32_t rank_only;        // != 0 (the int8 two-pass, whose pass-1 scores are the reference's own): no re-score — tau_out = the k-th
                                // best group maximum itself (k <= 64, delta = 0: k distinct rows score at least that); slab may be null
 };
-constexpr uint32_t kGroupsTaken = 24;
+constexpr uint32_t kGroupsTaken = 24;      // groups whose rows are re-scored for ranks up to 24 (192 rows) ...
+constexpr uint32_t kGroupsTakenMax = 32;   // ... and up to 32 (256 rows: the two-tier flow's fetch of 3 x 10)
+constexpr uint32_t kGroupsRankMax = 128;   // rank-only form (int8 / 4-bit two-pass: k x multiplier candidates, 3 x 30 = 90)
 hipError_t launch_select_groups(const GroupSelectArgs& args, int nq, hipStream_t stream);
 constexpr uint32_t kSelectPool = 1024;
 constexpr uint32_t kSelectMaxK = 128;   // largest rank a selection can anchor on (k, or k * multiplier in int8 mode)

@@ -1214,12 +1214,17 @@ hipError_t launch_two_pass_merge(const u64* approx_lists, const u64* exact_lists
 // the rank form needs 64 of them (8 / 16: from 192 / 256 entries on the picks are complete unless one wave holds more than PERW of them).
 // 512 threads (two entries each): four blocks per CU, i.e. all of a 1,024-query round resident at once — the kernel is a chain of
 // dependent round trips per block, and with 1,024-thread blocks a round took two waves of blocks.
-template <bool RANK>
+// Round 6: two sizes of each form.  M = 32 groups taken (256 rows re-scored) serves ranks up to 32 — the two-tier flow fetches
+// k x candidate_multiplier = 30 per tier (rrf.rs:113-115) and used to fall back to the two thresholded sample stages for it (0.8 ms of a
+// 3.6 ms step at 10M rows against 0.3); KCAP = 128 serves the int8 two-pass at 3 x 30 = 90 candidates (32 winners per wave: the top
+// 90 of 1,024 entries put ~11 in a wave's 128 on average).
+template <bool RANK, int M, int KCAP>
 __global__ __launch_bounds__(512) void select_groups_kernel(GroupSelectArgs args) {
-    constexpr int NT = 512, NW = NT / 64, PERT = 1024 / NT, PERW = RANK ? 16 : 8, W0 = NW * PERW / 64, M = (int)kGroupsTaken, NR = M * 8;
+    constexpr int NT = 512, NW = NT / 64, PERT = 1024 / NT, PERW = RANK ? KCAP / 4 : 8, W0 = NW * PERW / 64, NR = M * 8;
     static_assert(NR <= 256 && NR <= NT && NW * PERW % 64 == 0 && W0 >= 1, "W0 winners per lane of wave 0; the rank loop runs on NR threads");
+    static_assert(M <= 64 && KCAP >= 64 && KCAP % 64 == 0 && (RANK || M <= NW * PERW), "wave 0 picks M (or k <= KCAP) of the waves' winners");
     __shared__ u64 win[NW * PERW];
-    __shared__ u64 top[64];
+    __shared__ u64 top[KCAP];
     __shared__ u64 pool[256];
     __shared__ u64 keys[256];
     __shared__ __attribute__((aligned(16))) float s_q[kSelQueryLds];
@@ -1254,9 +1259,10 @@ __global__ __launch_bounds__(512) void select_groups_kernel(GroupSelectArgs args
             e2[x] = win[lane + 64 * x];
             key2[x] = e2[x] != kEmpty ? sortkey(e2[x]) : 0ull;
         }
-        top[lane] = kEmpty;
+#pragma unroll
+        for (int x = 0; x < KCAP / 64; ++x) top[lane + 64 * x] = kEmpty;
         wave_lds_fence();
-        wave_extract_topk<W0>(key2, e2, RANK ? k : M, top);
+        wave_extract_topk<W0>(key2, e2, RANK ? (k < KCAP ? k : KCAP) : M, top);
         wave_lds_fence();
     }
     __syncthreads();
@@ -1266,7 +1272,7 @@ __global__ __launch_bounds__(512) void select_groups_kernel(GroupSelectArgs args
             if (d < 0.f || !real_query) {
                 t = INFINITY;
                 if (args.overflow) args.overflow[q] = 1;
-            } else if (k <= 64 && top[k - 1] != kEmpty) {
+            } else if (k <= KCAP && top[k - 1] != kEmpty) {
                 const float ta = __uint_as_float((uint32_t)(top[k - 1] >> 32)) - 2.0f * d;
                 if (ta == ta) t = ta;
             }
@@ -1355,10 +1361,16 @@ __global__ __launch_bounds__(512) void select_groups_kernel(GroupSelectArgs args
 
 hipError_t launch_select_groups(const GroupSelectArgs& args, int nq, hipStream_t stream) {
     if (args.k < 1 || args.nentries == 0 || args.nentries > 1024 || !args.delta || !args.tau_out) return hipErrorInvalidValue;
-    if (args.rank_only ? args.k > 64 : (args.k > kGroupsTaken || (args.dim & 7) || args.dim > kSelQueryLds || !args.anchor_unit || !args.slab))
+    if (args.rank_only ? args.k > kGroupsRankMax : (args.k > kGroupsTakenMax || (args.dim & 7) || args.dim > kSelQueryLds || !args.anchor_unit || !args.slab))
         return hipErrorInvalidValue;
-    if (args.rank_only) hipLaunchKernelGGL(select_groups_kernel<true>, dim3(nq), dim3(512), 0, stream, args);
-    else hipLaunchKernelGGL(select_groups_kernel<false>, dim3(nq), dim3(512), 0, stream, args);
+    constexpr int M0 = (int)kGroupsTaken, M1 = (int)kGroupsTakenMax;
+    if (args.rank_only) {
+        if (args.k <= 64) hipLaunchKernelGGL((select_groups_kernel<true, M0, 64>), dim3(nq), dim3(512), 0, stream, args);
+        else hipLaunchKernelGGL((select_groups_kernel<true, M0, (int)kGroupsRankMax>), dim3(nq), dim3(512), 0, stream, args);
+    } else {
+        if (args.k <= kGroupsTaken) hipLaunchKernelGGL((select_groups_kernel<false, M0, 64>), dim3(nq), dim3(512), 0, stream, args);
+        else hipLaunchKernelGGL((select_groups_kernel<false, M1, 64>), dim3(nq), dim3(512), 0, stream, args);
+    }
     return hipGetLastError();
 }
 

@@ -104,7 +104,7 @@ class VectorIndex {
     // bits = 4: batched search_top_k_4bit_two_pass (search.rs:876-946)
     SearchError search_top_k_int8_batched(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
                                           uint32_t multiplier, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
-                                          uint32_t* fallbacks, int bits = 8);
+                                          uint32_t* fallbacks, int bits = 8, bool queries_on_device = false);
     // Shard-local HALF of a two-pass search (bits 8: search_top_k_int8_two_pass, 4: search_top_k_4bit_two_pass) for a row-sharded
     // index: this shard's cc = max(k * multiplier, k) pass-1 candidates per query as two aligned packed lists [nq, cc] — position
     // i is one row: its pass-1 entry (integer score as f32 bits | global row) and its exact entry; kEmpty beyond the candidates.

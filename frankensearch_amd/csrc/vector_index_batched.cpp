@@ -837,13 +837,15 @@ SearchError VectorIndex::batched_sample(const BatchedPlan& p, BatchedRound& r) {
     // let 1.7 x the rows through the main pass at 50 % allowed — 199 k against 308 k queries/s for the thresholded stages)
     // (the batched int8 / 4-bit two-pass takes the same pass: its pass-1 scores are the reference's own, so the k x multiplier-th best
     // group maximum IS a valid threshold — no re-score, ranks up to 64)
-    const bool rank_groups = i8 && !i8f && ksel <= 64;
-    const bool group_sample = (r.anchor ? ksel <= kGroupsTaken : rank_groups) && r.wide_qt != 0 && !skip_b && !knobs().no_wide_b &&
+    // (round 6: ranks up to 32 with an anchor, up to 128 by rank — the two-tier flow's fetch of k x 3 = 30 per tier and the fast tier's
+    // 3 x 30 = 90 int8 candidates took the two thresholded stages + two selections below: 0.8 ms of a 3.6 ms step at 10M rows)
+    const bool rank_groups = i8 && !i8f && ksel <= kGroupsRankMax;
+    const bool group_sample = (r.anchor ? ksel <= kGroupsTakenMax : rank_groups) && r.wide_qt != 0 && !skip_b && !knobs().no_wide_b &&
                               !knobs().no_group_sample && (dim_ & 7) == 0 && dim_ <= 1024 && scan_wide_group_maxima_supported((int)dim_, r.wide_qt);
     if (group_sample) {
         const int grid_g = std::min(r.wide_grid, (int)std::max<uint32_t>(1, RB / 64 / 4));   // at least 4 sample groups per block
         // (enough groups for the picks: the rank form needs ksel of them — and not all from a wave or two of the selection)
-        if (grid_g * 4 <= 1024 && (uint32_t)grid_g * 4 >= (r.anchor ? 96u : 4u * ksel)) {
+        if (grid_g * 4 <= 1024 && (uint32_t)grid_g * 4 >= (r.anchor ? (ksel <= kGroupsTaken ? 96u : 128u) : std::max(4u * std::min(ksel, 64u), 2u * ksel))) {
             MfmaScanArgs c = a;
             c.dense = nullptr;
             c.stage = 3;
@@ -1356,13 +1358,20 @@ SearchError VectorIndex::search_top_k_batched(const float* queries, uint32_t nq,
 
 SearchError VectorIndex::search_top_k_int8_batched(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
                                                    uint32_t multiplier, uint32_t* out_rows, float* out_scores,
-                                                   uint32_t* out_counts, uint32_t* fallbacks, int bits) {
+                                                   uint32_t* out_counts, uint32_t* fallbacks, int bits, bool queries_on_device) {
     if (fallbacks) *fallbacks = 0;
     FSGPU_TRY(ensure_query_dimension(query_len));
     if (nq == 0) return ok();
     // what the fast path does not cover goes through the per-query search, like the reference (search.rs:579-585);
     // an index with a doc-id table also does (resolve_hits dedups by doc id there)
+    std::vector<float> host_copy;
     if (k == 0 || nrows_ == 0 || !wal_.empty() || has_doc_ids()) {
+        if (queries_on_device) {   // (the per-query entry points take host vectors)
+            host_copy.resize((size_t)nq * dim_);
+            FSGPU_HIP(hipSetDevice(device_));
+            FSGPU_HIP(hipMemcpy(host_copy.data(), queries, host_copy.size() * 4, hipMemcpyDeviceToHost));
+            queries = host_copy.data();
+        }
         for (uint32_t i = 0; i < nq; ++i)
             FSGPU_TRY(bits == 4 ? search_top_k_4bit_two_pass(queries + (size_t)i * dim_, query_len, k, multiplier,
                                                              out_rows + (size_t)i * k, out_scores + (size_t)i * k, &out_counts[i])
@@ -1382,8 +1391,12 @@ SearchError VectorIndex::search_top_k_int8_batched(const float* queries, uint32_
     uint32_t* rows_dev = reinterpret_cast<uint32_t*>(base + o_rows);
     float* scores_dev = reinterpret_cast<float*>(base + o_scores);
     uint32_t* counts_dev = reinterpret_cast<uint32_t*>(base + o_counts);
-    FSGPU_HIP(hipMemcpyAsync(q_dev, queries, (size_t)nq * dim_ * 4, hipMemcpyHostToDevice, stream_));
-    FSGPU_TRY(search_top_k_int8_batched_device(q_dev, nq, query_len, k, multiplier, rows_dev, scores_dev, counts_dev,
+    const float* q_in = queries;
+    if (!queries_on_device) {
+        FSGPU_HIP(hipMemcpyAsync(q_dev, queries, (size_t)nq * dim_ * 4, hipMemcpyHostToDevice, stream_));
+        q_in = q_dev;
+    }
+    FSGPU_TRY(search_top_k_int8_batched_device(q_in, nq, query_len, k, multiplier, rows_dev, scores_dev, counts_dev,
                                                stream_, fallbacks, bits));
     FSGPU_HIP(hipMemcpyAsync(out_rows, rows_dev, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream_));
     FSGPU_HIP(hipMemcpyAsync(out_scores, scores_dev, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream_));

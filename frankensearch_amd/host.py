@@ -61,8 +61,17 @@ class _LoadResult(C.Structure):
                                                   ("first_error", C.c_char * 160)]
 
 
+class _ManyResult(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("wall_seconds", "queries_per_sec", "mean_fast_embed_ms", "mean_fast_search_ms",
+                                          "mean_quality_embed_ms", "mean_quality_search_ms", "fusion_busy_ms_per_chunk",
+                                          "first_chunk_initial_ms", "first_chunk_refined_ms")] + \
+               [(n, C.c_uint64) for n in ("queries", "chunks", "chunk_queries", "fusion_threads", "refinement_failed", "fast_fallbacks",
+                                          "quality_fallbacks", "device_resident_handoff", "queries_with_k_initial_and_refined_hits")] + \
+               [("error_detail", C.c_char * 256)]
+
+
 SYMBOLS = ("fshost_two_tier_create", "fshost_two_tier_create_sharded", "fshost_two_tier_destroy", "fshost_two_tier_search",
-           "fshost_run_load", "fshost_embed_search_stream", "fshost_embed_search_stream_dp")
+           "fshost_two_tier_search_many", "fshost_run_load_many", "fshost_run_load", "fshost_embed_search_stream", "fshost_embed_search_stream_dp")
 _handle = None
 
 
@@ -93,6 +102,12 @@ def lib() -> C.CDLL:
                                              C.POINTER(_Hit), C.POINTER(C.c_uint32), C.POINTER(_Metrics)]
         h.fshost_run_load.restype = C.c_int32
         h.fshost_run_load.argtypes = [C.c_void_p, C.POINTER(_LoadConfig), C.POINTER(_LoadResult)]
+        h.fshost_run_load_many.restype = C.c_int32
+        h.fshost_run_load_many.argtypes = [C.c_void_p, C.POINTER(_LoadConfig), C.c_uint32, C.POINTER(_ManyResult)]
+        h.fshost_two_tier_search_many.restype = C.c_int32
+        h.fshost_two_tier_search_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                                  C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_ManyResult)]
         _handle = h
     return _handle
 
@@ -168,6 +183,70 @@ class NativeTwoTierSearcher:
         d = {n: getattr(res, n) for n, _ in _LoadResult._fields_}
         d["first_error"] = d["first_error"].decode(errors="replace")
         return LoadResult(**d)
+
+    def search_many(self, fast_token_ids: Sequence[Sequence[int]], quality_token_ids: Sequence[Sequence[int]], k: int,
+                    lexical: Optional[Sequence[Sequence[Tuple[str, float]]]] = None, chunk: int = 0, fusion_threads: int = 0,
+                    want_vectors: bool = False):
+        """fshost_two_tier_search_many: the two-phase flow for a list of queries in one call -> (initial hit lists, final hit lists,
+        refinement_failed flags, stats[, fast vectors, quality vectors])."""
+        nq = len(fast_token_ids)
+        assert len(quality_token_ids) == nq and (lexical is None or len(lexical) == nq)
+        f_off = np.zeros(nq + 1, dtype=np.uint32)
+        q_off = np.zeros(nq + 1, dtype=np.uint32)
+        f_off[1:] = np.cumsum([len(x) for x in fast_token_ids])
+        q_off[1:] = np.cumsum([len(x) for x in quality_token_ids])
+        f = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.uint32) for x in fast_token_ids]) if nq else np.zeros(0, np.uint32))
+        q = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.int32) for x in quality_token_ids]) if nq else np.zeros(0, np.int32))
+        lex_arr = lex_off = None
+        keep = []
+        if lexical is not None:
+            lex_off = np.zeros(nq + 1, dtype=np.uint32)
+            lex_off[1:] = np.cumsum([len(x) for x in lexical])
+            lex_arr = (_ScoredDoc * max(int(lex_off[-1]), 1))()
+            j = 0
+            for lst in lexical:
+                for d, s_ in lst:
+                    b = d.encode()
+                    keep.append(b)
+                    lex_arr[j] = _ScoredDoc(b, len(b), s_, 0)
+                    j += 1
+        ini, fin = (_Hit * max(nq * k, 1))(), (_Hit * max(nq * k, 1))()
+        ni, nf = np.zeros(nq, dtype=np.uint32), np.zeros(nq, dtype=np.uint32)
+        rf = np.zeros(nq, dtype=np.uint8)
+        fdim = _lib.lib().fsgpu_m2v_dimension(self._keep[2]._h)
+        qdim = _lib.lib().fsgpu_bert_dimension(self._keep[3]._h)
+        fv = np.empty((nq, fdim), dtype=np.float32) if want_vectors else None
+        qv = np.empty((nq, qdim), dtype=np.float32) if want_vectors else None
+        res = _ManyResult()
+        st = lib().fshost_two_tier_search_many(self._h, f.ctypes.data, f_off.ctypes.data, q.ctypes.data, q_off.ctypes.data, nq, k,
+                                               C.cast(lex_arr, C.c_void_p) if lex_arr is not None else None,
+                                               lex_off.ctypes.data if lex_off is not None else None, chunk, fusion_threads,
+                                               C.cast(ini, C.c_void_p), ni.ctypes.data, C.cast(fin, C.c_void_p), nf.ctypes.data, rf.ctypes.data,
+                                               fv.ctypes.data if want_vectors else None, qv.ctypes.data if want_vectors else None, C.byref(res))
+        if st != 0 and res.error_detail:
+            from .errors import error_for
+            raise error_for(st, res.error_detail.decode(errors="replace"))
+        check(st)
+        initial = [[_fused(ini[i * k + j]) for j in range(int(ni[i]))] for i in range(nq)]
+        final = [[_fused(fin[i * k + j]) for j in range(int(nf[i]))] for i in range(nq)]
+        stats = {n: getattr(res, n) for n, _ in _ManyResult._fields_ if n != "error_detail"}
+        stats["error_detail"] = res.error_detail.decode(errors="replace")
+        out = (initial, final, rf.astype(bool), stats)
+        return out + (fv, qv) if want_vectors else out
+
+    def run_load_many(self, queries: int, warmup_queries: int, k: int, fast_vocab: int, corpus_rows: int, chunk: int = 0,
+                      fusion_threads: int = 0, quality_vocab: int = 30000, seed: int = 1) -> dict:
+        """fshost_run_load_many: the load generator's synthetic queries through ONE fshost_two_tier_search_many call."""
+        cfg = _LoadConfig(fusion_threads, queries, warmup_queries, k, fast_vocab, quality_vocab, corpus_rows, seed)
+        res = _ManyResult()
+        st = lib().fshost_run_load_many(self._h, C.byref(cfg), chunk, C.byref(res))
+        if st != 0 and res.error_detail:
+            from .errors import error_for
+            raise error_for(st, res.error_detail.decode(errors="replace"))
+        check(st)
+        d = {n: getattr(res, n) for n, _ in _ManyResult._fields_ if n != "error_detail"}
+        d["error_detail"] = res.error_detail.decode(errors="replace")
+        return d
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -529,6 +529,13 @@ fsgpu_status fsgpu_m2v_embed_device(fsgpu_m2v *m, const uint32_t *ids, const uin
 fsgpu_status fsgpu_search_topk_batched_device_queries(fsgpu_index *idx, const float *queries_dev, uint32_t nq, uint32_t query_len,
                                                       uint32_t k, uint32_t *out_rows, float *out_scores, uint32_t *out_counts,
                                                       uint32_t *out_fallbacks);
+/* fsgpu_search_topk_int8_two_pass_batched (search.rs:514-661 for a batch) with the queries already in device memory — the fast tier
+ * of a many-queries two-tier flow takes the Model2Vec batch where fsgpu_m2v_embed_device left it (sync_searcher.rs:652-700 runs
+ * embed -> search_fast_hits back to back; here neither the vectors nor a wait crosses PCIe in between). */
+fsgpu_status fsgpu_search_topk_int8_two_pass_batched_device_queries(fsgpu_index *idx, const float *queries_dev, uint32_t nq,
+                                                                    uint32_t query_len, uint32_t k, uint32_t candidate_multiplier,
+                                                                    uint32_t *out_rows, float *out_scores, uint32_t *out_counts,
+                                                                    uint32_t *out_fallbacks);
 fsgpu_status fsgpu_device_malloc(int32_t device, uint64_t bytes, void **out);
 fsgpu_status fsgpu_device_free(int32_t device, void *ptr);
 int32_t fsgpu_bert_device(const fsgpu_bert *m);

@@ -92,6 +92,42 @@ fsgpu_status fshost_two_tier_search(fshost_two_tier *s, const uint32_t *fast_tok
                                     uint32_t *n_initial, fshost_hit *final_out, uint32_t *n_final,
                                     fshost_metrics *metrics);
 
+/* The same two-phase flow for MANY queries in one call — the throughput form (the reference's many-queries shapes:
+ * crates/frankensearch-index/benches/batched_query_scan.rs, crates/frankensearch-embed/src/batch_coalescer.rs:18-23; the per-query
+ * flow it must equal: sync_searcher.rs:616-943).  Query q owns fast_token_ids[fast_offsets[q] .. fast_offsets[q + 1]),
+ * quality_token_ids[quality_offsets[q] .. quality_offsets[q + 1]) and the lexical list lexical[lexical_offsets[q] ..
+ * lexical_offsets[q + 1]) (lexical / lexical_offsets may be NULL: no lexical source).  The queries run in chunks of `chunk` (0 = 1,024:
+ * two 512-query passes of the matrix-core scan) through a pipeline: Model2Vec batch -> fast tier batched (int8 two-pass with
+ * fast_tier_int8_multiplier, else the batched exact search) | MiniLM batch -> quality tier batched exact search, both tiers side by
+ * side on the GPU and one chunk ahead of each other's embeddings, the embeddings handed over in device memory; the per-query RRF /
+ * blend / RRF of a chunk runs on `fusion_threads` host threads (0 = automatic) as soon as its tiers have answered, with the functions
+ * fshost_two_tier_search runs.  initial_out / final_out: [nq * k] (query q's hits at q * k), n_initial / n_final: [nq];
+ * refinement_failed_out (may be NULL): [nq], 1 where the quality pool failed and final = initial (sync_searcher.rs:820-839).
+ * quality_vectors_out / fast_vectors_out (may be NULL): [nq, dim] — the embeddings the tiers were searched with (asking for them
+ * keeps that tier's vectors on the host path).
+ * Results: those of fshost_two_tier_search on the same tier answers; the tier answers are bit-identical to the per-query searches'
+ * for identical query vectors; the Model2Vec vectors are bit-identical whatever the batch; a text's MiniLM vector is within the
+ * encoder's tolerance (cos >= 0.999, 2e-3) of its single-text embedding (the encoder picks kernels by batch shape).
+ * doc_id_mode 0 (FSVI doc-id tables): exact tier searches go through fsgpu_search_hits query by query, as the per-query flow does.
+ * quality_pool FSHOST_POOL_RESCORED: phase 1 is the gather of quality_scores_for_hits per query on the fusion threads. */
+typedef struct fshost_many_result {
+    double wall_seconds, queries_per_sec;
+    double mean_fast_embed_ms, mean_fast_search_ms, mean_quality_embed_ms, mean_quality_search_ms; /* per chunk */
+    double fusion_busy_ms_per_chunk;   /* summed over the fusion threads */
+    double first_chunk_initial_ms, first_chunk_refined_ms; /* call start -> the first chunk's fast / quality tier answered */
+    uint64_t queries, chunks, chunk_queries, fusion_threads;
+    uint64_t refinement_failed, fast_fallbacks, quality_fallbacks;
+    uint64_t device_resident_handoff;  /* bit 0: fast-tier vectors stayed in HBM, bit 1: quality-tier vectors */
+    uint64_t queries_with_k_initial_and_refined_hits; /* fshost_run_load_many only */
+    char error_detail[256];
+} fshost_many_result;
+fsgpu_status fshost_two_tier_search_many(fshost_two_tier *s, const uint32_t *fast_token_ids, const uint32_t *fast_offsets,
+                                         const int32_t *quality_token_ids, const uint32_t *quality_offsets, uint32_t nq, uint32_t k,
+                                         const fsgpu_scored_doc *lexical, const uint32_t *lexical_offsets, uint32_t chunk,
+                                         uint32_t fusion_threads, fshost_hit *initial_out, uint32_t *n_initial, fshost_hit *final_out,
+                                         uint32_t *n_final, uint8_t *refinement_failed_out, float *fast_vectors_out,
+                                         float *quality_vectors_out, fshost_many_result *result);
+
 /* Closed-loop load generator: `threads` native threads each issue fshost_two_tier_search calls back to back on
  * synthetic queries (SURVEY §8d config 5 shapes: fast ids uniform in [0, fast_vocab), 4-23 tokens; quality ids
  * [CLS] + uniform [1000, quality_vocab) + [SEP], 8-32 tokens; stub lexical list of 3k "doc-%08u" ids), the way a
@@ -117,6 +153,10 @@ typedef struct fshost_load_result {
 } fshost_load_result;
 
 fsgpu_status fshost_run_load(fshost_two_tier *s, const fshost_load_config *config, fshost_load_result *result);
+/* The load generator's synthetic queries (config->queries of them, after one untimed call over config->warmup_queries) through ONE
+ * fshost_two_tier_search_many call: the throughput of the two-phase flow when the host has a queue of requests instead of a
+ * thread per request.  config->threads = fusion threads (0 = automatic). */
+fsgpu_status fshost_run_load_many(fshost_two_tier *s, const fshost_load_config *config, uint32_t chunk, fshost_many_result *result);
 
 /* BASELINE config 5's serving loop: batches of token-id queries -> MiniLM forward on the GPU (fsgpu_bert_embed) ->
  * batched exact top-k of the embeddings (fsgpu_search_topk_batched on an index, or fsgpu_sharded_search in BATCHED mode on a
