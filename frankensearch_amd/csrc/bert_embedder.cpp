@@ -447,7 +447,11 @@ SearchError NativeEmbedder::forward(uint32_t n_docs, uint32_t tokens, uint32_t m
 
 bool NativeEmbedder::docs_path(uint32_t tokens, uint32_t max_seq) const {
     static const bool off = fsgpu::lab_env("FSGPU_BERT_NO_DOCS_PATH") != nullptr;  // A/B runs
-    return !off && docs_ready_ && tokens > 32 && max_seq <= 32;
+    static const long max_tokens = [] {
+        const char* e = std::getenv("FSGPU_BERT_DOCS_MAX_TOKENS");   // TEMP (r06 experiment)
+        return e ? std::atol(e) : (1L << 30);
+    }();
+    return !off && docs_ready_ && tokens > 32 && max_seq <= 32 && (long)tokens <= max_tokens;
 }
 
 // Every text at most 32 tokens long (a batch of queries): ONE launch for the whole forward (bert_docs_w.hip).  Consecutive texts

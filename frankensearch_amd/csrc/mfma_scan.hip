@@ -318,6 +318,10 @@ __global__ __launch_bounds__(WPB * 64) void scan_mfma_kernel(MfmaScanArgs args) 
 constexpr int kSelThreads = 1024;
 constexpr int kSelPer = 8;
 constexpr int kSelWaves = kSelThreads / 64;
+#ifndef FSGPU_SEL_MIN_WAVES
+#define FSGPU_SEL_MIN_WAVES 8
+#endif
+constexpr int kSelMinWaves = FSGPU_SEL_MIN_WAVES;   // waves per SIMD the unsorted selection is compiled for (8: two blocks per CU, 64 registers)
 
 // One pass of the per-wave extraction: dst[0..k) <- the wave's k best among e[] and prev[0..k) (its earlier winners).
 // KL = ceil(KMAX / 64): how many of the previous winners each lane carries.
@@ -382,7 +386,7 @@ constexpr int kSelQueryLds = 1024;  // dimensions of the re-score's query kept i
     } while (0)
 #endif
 template <bool FINISH, bool SORTED>
-__global__ __launch_bounds__(kSelThreads, SORTED ? 4 : 8) void select_kernel(SelectArgs args) {
+__global__ __launch_bounds__(kSelThreads, SORTED ? 4 : kSelMinWaves) void select_kernel(SelectArgs args) {
     constexpr int NT = kSelThreads, PER = kSelPer, NW = kSelWaves, POOL = (int)kSelectPool, KL = 1;
     static_assert(POOL == NT, "one pool entry per thread in the final selection");
     __shared__ u64 win[2][NW * 64 * KL];  // per-wave winners [wave][rank], ping-pong across passes
