@@ -81,7 +81,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     sources = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     # (every object depends on every header: the kernels' argument structs and the C ABI are shared)
-    common = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "fsgpu.h")]
+    common = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "fsgpu.h"), os.path.join(INCLUDE, "fsgpu_lab.h")]
     hipcc = _hipcc()
 
     def compile_one(src: str) -> str:

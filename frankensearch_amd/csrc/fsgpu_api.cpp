@@ -1,6 +1,7 @@
 // fsgpu_api.cpp — the extern "C" boundary of libfsgpu.so (declared in include/fsgpu.h).
 // Plain pointers and sizes only; every entry point catches C++ exceptions and reports a status.
 #include "../../include/fsgpu.h"
+#include "../../include/fsgpu_lab.h"
 
 #include <cmath>
 #include <cstring>

@@ -477,16 +477,6 @@ fsgpu_status fsgpu_encode_f32_to_f16(int32_t device, const float *src, uint64_t 
 /* f16 -> f32 widen (simd.rs:63-94), exposed for the exhaustive 65,536-pattern parity test. */
 fsgpu_status fsgpu_widen_f16_to_f32(int32_t device, const uint16_t *src, uint64_t n, float *dst);
 
-/* ---- bench / test fixture ---- */
-/* The reference's own bench generator (frankensearch/benches/fsvi_4bit_vs_incumbent.rs:56-101,344-365) run on the GPU so that
- * a 10M- or 50M-row corpus never crosses PCIe: xorshift64 raw_vector, `clusters` normalised centroids
- * (seed 0xc0000000 + c), vector i = normalize(centroid[i % clusters] + noise * raw_vector(seed_base + i)) for
- * i in [first, first + n).  as_f16 = 1: out_dev receives n x dim little-endian f16 rows (corpus: seed_base 1);
- * as_f16 = 0: n x dim f32 (queries: seed_base 0xdead0000).  The bytes equal the CPU generator's (same operation order).
- * hip_stream may be NULL (default stream); the call returns after the kernels have finished. */
-fsgpu_status fsgpu_bench_fixture_device(int32_t device, uint64_t first, uint64_t n, uint32_t dim, uint32_t clusters, float noise,
-                                        uint64_t seed_base, int32_t as_f16, void *out_dev, void *hip_stream);
-
 /* ---- Model2Vec (potion) ---- */
 /* Model2VecEmbedder (embed/src/model2vec_embedder.rs:55-58): table is [vocab,dim] f32 row-major (host). */
 fsgpu_status fsgpu_m2v_create(int32_t device, const float *table, uint32_t vocab, uint32_t dim, fsgpu_m2v **out);
@@ -677,24 +667,8 @@ fsgpu_status fsgpu_bert_set_coalescing(fsgpu_bert *m, uint32_t max_batch, uint32
  * FSGPU_BERT_NO_QUERY_PATH, FSGPU_BERT_GEMM_V1, FSGPU_BERT_SPLIT_FFN, FSGPU_BERT_SPLIT_AO, FSGPU_BERT_PACKED_MIN_TOKENS,
  * FSGPU_BERT_EMBED_V1. */
 
-/* ---- instrumentation ---- */
-/* When enabled, HIP events bracket the scan kernel of every fsgpu_search_topk* call; enabled = n > 1: of the batched exact search's
- * merged main launch only every n-th is bracketed (an event pair idles the stream ~6 us on either side of the launch). */
-fsgpu_status fsgpu_index_set_profiling(fsgpu_index *idx, int32_t enabled);
-/* Sum of scan-kernel time (ms) and number of scan launches since the last reset; synchronises. */
-fsgpu_status fsgpu_index_scan_time(fsgpu_index *idx, double *total_ms, uint64_t *launches, int32_t reset);
-/* Same, plus the number of slab rows those launches streamed (the batched path's timed main pass skips the rows its
- * sampling stage already covered), so that bytes/launch can be stated exactly. */
-fsgpu_status fsgpu_index_scan_stats(fsgpu_index *idx, double *total_ms, uint64_t *launches, uint64_t *rows,
-                                    int32_t reset);
-/* Filtered searches (allow bitmap given) answered by scoring only the allowed rows (try_gather_filtered,
- * crates/frankensearch-index/src/search.rs:1114-1180: taken when allowed * 50 < rows) and by the masked full scan. */
-fsgpu_status fsgpu_index_filter_stats(fsgpu_index *idx, uint64_t *gathered, uint64_t *scanned);
-/* Name of the template instantiation the last batched main pass launched in this process ran ("" before the first one), spelled as
- * rocprofv3 prints it: lets bench.py tie a committed PMC summary to the kernel that actually ran. */
-const char *fsgpu_last_main_pass_kernel(void);
-/* Selects the scan kernel variant (0 = default) — used by bench A/B runs only. */
-fsgpu_status fsgpu_index_set_variant(fsgpu_index *idx, int32_t variant);
+/* Bench fixtures, kernel timers and A/B switches (fsgpu_bench_fixture_device, fsgpu_index_set_profiling / _scan_time / _scan_stats /
+ * _filter_stats, fsgpu_last_main_pass_kernel, fsgpu_index_set_variant) are not part of the drop-in surface: include/fsgpu_lab.h. */
 
 #ifdef __cplusplus
 }

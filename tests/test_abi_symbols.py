@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    text = open(os.path.join(ROOT, "include", "fsgpu.h")).read()
+def header_symbols(name="fsgpu.h"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(fsgpu_[a-z0-9_]+)\s*\(", text)))
 
@@ -23,10 +23,13 @@ def test_library_exports_every_declared_symbol():
     build()
     L = ctypes.CDLL(_lib.LIB_PATH)
     names = header_symbols()
+    lab = header_symbols("fsgpu_lab.h")   # bench fixtures, kernel timers, A/B switches: exported, but not part of the drop-in surface
     assert len(names) >= 25
-    for name in names:
-        assert hasattr(L, name), f"{name} declared in include/fsgpu.h but not exported"
-    assert set(names) == set(_lib.SIGNATURES), "python binding and header disagree"
+    for name in names + lab:
+        assert hasattr(L, name), f"{name} declared in include/ but not exported"
+    assert not set(names) & set(lab), "an entry point is declared in both headers"
+    assert {"fsgpu_index_set_variant", "fsgpu_bench_fixture_device", "fsgpu_last_main_pass_kernel", "fsgpu_index_scan_time"} <= set(lab)
+    assert set(names) | set(lab) == set(_lib.SIGNATURES), "python binding and headers disagree"
     assert b"gfx950" in _lib.lib().fsgpu_version()
 
 

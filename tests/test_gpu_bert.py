@@ -279,3 +279,18 @@ def test_index_build_batches_of_thousands_of_tokens(fa):
         small = np.concatenate([m.embed_batch_token_ids(docs[i:i + 4]) for i in range(0, len(docs), 4)])
         assert np.max(np.abs(got - small)) <= ABS_MAX and np.all(np.sum(got * small, axis=1) >= COS_MIN)
         m.close()
+
+
+def test_real_weights_conformance_script_on_a_model_directory_of_the_real_layout():
+    """scripts/conformance_minilm.py is what a maintainer points at the real all-MiniLM-L6-v2 files (model_manifest.rs:65-70,308-314:
+    the reference pins the model by a certificate over MODEL_CONFORMANCE_TEXTS_V1).  No weights exist here, so its --selftest builds a
+    directory of the same layout — model.safetensors, tokenizer.json, config.json — with seeded random weights of the architecture and runs
+    every step: tokenizers -> fsgpu_bert_create_safetensors + embed (alone and as a batch) against transformers f32 on the same file."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "scripts", "conformance_minilm.py"), "--selftest"], capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "PASSED" in res.stdout and res.stdout.count(" ok") == 8, res.stdout[-2000:]
