@@ -701,11 +701,46 @@ def two_tier_section(quality_index, rows: int, k: int, device, local_rank: int):
             "mean_queries_per_scan_batch": {"fast": (fr - fr0) / max(fb - fb0, 1), "quality": (qr - qr0) / max(qb - qb0, 1)},
         }
 
+    # the per-stage coalescers of libfsgpu (round 2-5's route for concurrent callers: four wake-ups per query): kept as a reference point
+    stage_coalescers = concurrent(1024, 40_000)
+    for h in (fast_index, quality_index, m2v, bert):
+        h.set_coalescing(0, 0)
+    # Round 6: the many-queries engine of libfshost.  (a) fshost_two_tier_search_many — one call, 64k queries, chunks of 1,024 through
+    # the four-stage pipeline; (b) the same engine behind the per-query call (fshost_two_tier_set_batching): concurrent callers are
+    # collected into chunks of up to 256 (the whole population below that, half of it above: DESIGN 3.7) and woken once per query.
+    searcher.run_load_many(queries=8192, warmup_queries=2048, k=k, fast_vocab=500_353, corpus_rows=rows)
+    many = searcher.run_load_many(queries=65_536, warmup_queries=4096, k=k, fast_vocab=500_353, corpus_rows=rows)
+    many_rescored = rescored.run_load_many(queries=16_384, warmup_queries=2048, k=k, fast_vocab=500_353, corpus_rows=rows)
     rescored.close()
-    con_lo = concurrent(64, 20_000)
-    con = concurrent(256, 40_000)
-    con_hi = concurrent(1024, 80_000)
-    quality_index.set_coalescing(0, 0)
+    batch_chunk, batch_wait_us = 256, 3000
+    searcher.set_batching(batch_chunk, batch_wait_us)
+
+    def batched_callers(threads: int, queries: int):
+        c0, r0 = searcher.batching_stats()
+        con = searcher.run_load(threads=threads, queries=queries, warmup_queries=2 * threads, k=k, fast_vocab=500_353, corpus_rows=rows)
+        c1, r1 = searcher.batching_stats()
+        return {"threads": threads, "batching": {"max_chunk": batch_chunk, "max_wait_us": batch_wait_us},
+                "queries_per_sec": con.queries_per_sec, "completed": con.completed, "failed": con.failed, "first_error": con.first_error,
+                "phase0_p50_ms": con.phase0_p50_ms, "phase0_p95_ms": con.phase0_p95_ms,
+                "phase1_p50_ms": con.phase1_p50_ms, "phase1_p95_ms": con.phase1_p95_ms, "phase1_p99_ms": con.phase1_p99_ms,
+                "mean_queries_per_chunk": (r1 - r0) / max(c1 - c0, 1)}
+
+    con_one = batched_callers(1, 300)
+    con_lo = batched_callers(64, 30_000)
+    con = batched_callers(256, 60_000)
+    con_hi = batched_callers(1024, 100_000)
+    searcher.set_batching(0, 0)
+
+    def many_fields(m):
+        return {"queries_per_sec": m["queries_per_sec"], "queries": m["queries"], "chunk_queries": m["chunk_queries"], "chunks": m["chunks"],
+                "per_chunk_ms": {"fast_embed": m["mean_fast_embed_ms"], "fast_search": m["mean_fast_search_ms"],
+                                 "quality_embed": m["mean_quality_embed_ms"], "quality_search": m["mean_quality_search_ms"],
+                                 "fusion_busy_summed_over_threads": m["fusion_busy_ms_per_chunk"]},
+                "fusion_threads": m["fusion_threads"], "first_chunk_initial_ms": m["first_chunk_initial_ms"],
+                "first_chunk_refined_ms": m["first_chunk_refined_ms"], "refinement_failed": m["refinement_failed"],
+                "exact_fallbacks": {"fast": m["fast_fallbacks"], "quality": m["quality_fallbacks"]},
+                "embeddings_stay_in_device_memory": {"fast": bool(m["device_resident_handoff"] & 1), "quality": bool(m["device_resident_handoff"] & 2)},
+                "queries_with_k_initial_and_refined_hits": m["queries_with_k_initial_and_refined_hits"]}
     res = {
         "workload": f"{rows}x256 fast tier (int8 two-pass, multiplier 3) + {rows}x384 quality tier (exact), top-{k}, fetch "
                     f"{3 * k} per tier, stub lexical list of {3 * k}, RRF + blend on the host; per-query C ABI calls from "
@@ -725,9 +760,14 @@ def two_tier_section(quality_index, rows: int, k: int, device, local_rank: int):
         "sequential_breakdown_ms": {"fast_embed": seq.mean_fast_embed_ms, "fast_search": seq.mean_fast_search_ms,
                                     "quality_embed": seq.mean_quality_embed_ms, "quality_search": seq.mean_quality_search_ms,
                                     "fusion": seq.mean_fusion_ms},
+        "many_queries_one_call": dict(many_fields(many), note="fshost_two_tier_search_many: Retrieved pool (an independent quality-tier search per "
+                                      "query, the headline flow); results = the per-query flow's on the same tier answers (tests/test_gpu_two_tier_many.py)"),
+        "many_queries_one_call_rescored_fast_pool": many_fields(many_rescored),
+        "concurrent_1_thread_batching_on": con_one,
         "concurrent_64_threads": con_lo,
         "concurrent": con,
         "concurrent_1024_threads": con_hi,
+        "concurrent_1024_threads_per_stage_coalescers": stage_coalescers,
     }
     searcher.close()
     fast_index.close()
@@ -902,23 +942,18 @@ def two_tier_sharded_section(fa, devices, quality_index, rows: int, k: int, exch
     seq_spec = spec.run_load(threads=1, **load)
     spec.close()
     quality_index.set_int8_latency(True)   # (spec's destructor switched it off; `plain` below still wants it)
-    max_batch, wait_us = 256, 1000
-    fast_index.set_coalescing(max_batch, wait_us)
-    quality_index.set_coalescing(max_batch, wait_us)
-    m2v.set_coalescing(2 * max_batch, wait_us // 2)
-    bert.set_coalescing(2 * max_batch, wait_us)
-    fb0, fr0 = fast_index.coalescing_stats()
-    qb0, qr0 = quality_index.coalescing_stats()
-    # (the same ladder as the unsharded section — 64, 256, then 1,024 callers over 80,000 queries: the last rung alone, cold and over
-    # 60,000 queries, read 10 % low against it)
-    plain.run_load(threads=64, queries=20_000, warmup_queries=128, k=k, fast_vocab=500_353, corpus_rows=rows)
-    plain.run_load(threads=256, queries=40_000, warmup_queries=512, k=k, fast_vocab=500_353, corpus_rows=rows)
-    fb0, fr0 = fast_index.coalescing_stats()
-    qb0, qr0 = quality_index.coalescing_stats()
+    # round 6: the many-queries engine over the sharded handles — one call over 32k queries, then 64 / 1,024 per-query callers batched
+    # by the engine (fshost_two_tier_set_batching), as in the unsharded section
+    plain.run_load_many(queries=4096, warmup_queries=1024, k=k, fast_vocab=500_353, corpus_rows=rows)
+    many = plain.run_load_many(queries=32_768, warmup_queries=2048, k=k, fast_vocab=500_353, corpus_rows=rows)
+    max_batch, wait_us = 256, 3000
+    plain.set_batching(max_batch, wait_us)
+    con_lo = plain.run_load(threads=64, queries=20_000, warmup_queries=128, k=k, fast_vocab=500_353, corpus_rows=rows)
+    plain.run_load(threads=256, queries=30_000, warmup_queries=512, k=k, fast_vocab=500_353, corpus_rows=rows)
+    c0, r0 = plain.batching_stats()
     con = plain.run_load(threads=1024, queries=80_000, warmup_queries=2048, k=k, fast_vocab=500_353, corpus_rows=rows)
-    fb, fr = fast_index.coalescing_stats()
-    qb, qr = quality_index.coalescing_stats()
-    quality_index.set_coalescing(0, 0)
+    c1, r1 = plain.batching_stats()
+    plain.set_batching(0, 0)
     plain.close()
     res = {
         "workload": f"{rows}x256 fast tier (sharded int8 two-pass, multiplier 3) + {rows}x384 quality tier (sharded exact), both row-sharded "
@@ -935,8 +970,15 @@ def two_tier_sharded_section(fa, devices, quality_index, rows: int, k: int, exch
                                "mean_quality_rescore_ms": seq_resc.mean_quality_search_ms},
         "concurrent_1024_threads": {"queries_per_sec": con.queries_per_sec, "completed": con.completed, "failed": con.failed,
                                     "first_error": con.first_error, "phase0_p50_ms": con.phase0_p50_ms, "phase1_p50_ms": con.phase1_p50_ms,
-                                    "phase1_p99_ms": con.phase1_p99_ms, "coalescing": {"max_batch": max_batch, "max_wait_us": wait_us},
-                                    "mean_queries_per_scan_batch": {"fast": (fr - fr0) / max(fb - fb0, 1), "quality": (qr - qr0) / max(qb - qb0, 1)}},
+                                    "phase1_p99_ms": con.phase1_p99_ms, "batching": {"max_chunk": max_batch, "max_wait_us": wait_us},
+                                    "mean_queries_per_chunk": (r1 - r0) / max(c1 - c0, 1)},
+        "concurrent_64_threads": {"queries_per_sec": con_lo.queries_per_sec, "failed": con_lo.failed, "phase0_p50_ms": con_lo.phase0_p50_ms,
+                                  "phase1_p50_ms": con_lo.phase1_p50_ms, "phase1_p99_ms": con_lo.phase1_p99_ms},
+        "many_queries_one_call": {"queries_per_sec": many["queries_per_sec"], "queries": many["queries"], "chunk_queries": many["chunk_queries"],
+                                  "per_chunk_ms": {"fast_embed": many["mean_fast_embed_ms"], "fast_search": many["mean_fast_search_ms"],
+                                                   "quality_embed": many["mean_quality_embed_ms"], "quality_search": many["mean_quality_search_ms"]},
+                                  "refinement_failed": many["refinement_failed"],
+                                  "queries_with_k_initial_and_refined_hits": many["queries_with_k_initial_and_refined_hits"]},
     }
     fast_index.close()
     m2v.close()
@@ -1643,6 +1685,11 @@ def main() -> None:
             # the reference's flow for FSVI v1 pairs (unattested quality tier): phase 2 re-scores the fast pool (a gather)
             line["p50_phase1_latency_rescored_fast_pool_ms"] = tt["rescored_fast_pool"]["phase1_p50_ms"]
             line["end_to_end_queries_per_sec"] = tt["concurrent_1024_threads"]["queries_per_sec"]
+            line["end_to_end_many_queries_per_sec"] = tt["many_queries_one_call"]["queries_per_sec"]
+            line["end_to_end_policy"] = ("end_to_end_queries_per_sec: 1,024 host threads, one blocking fshost_two_tier_search each, dynamic batching "
+                                         "(fshost_two_tier_set_batching); end_to_end_many_queries_per_sec: one fshost_two_tier_search_many call over 65,536 "
+                                         "queries; both phase 0 + phase 1, Retrieved pool, fast tier int8 two-pass x3, fetch 30 per tier")
+            line["p50_phase1_latency_ms_64_callers"] = tt["concurrent_64_threads"]["phase1_p50_ms"]
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -1665,6 +1712,8 @@ def main() -> None:
                     line["p50_phase1_latency_speculative_ms"] = {"quality_embed_and_search_prefetched": tt["sequential_with_quality_search_prefetch"]["phase1_p50_ms"]}
                     line["p50_phase1_latency_rescored_fast_pool_ms"] = tt["rescored_fast_pool"]["phase1_p50_ms"]
                     line["end_to_end_queries_per_sec"] = tt["concurrent_1024_threads"]["queries_per_sec"]
+                    if "many_queries_one_call" in tt:
+                        line["end_to_end_many_queries_per_sec"] = tt["many_queries_one_call"]["queries_per_sec"]
             if c5 is not None:
                 line["config5"] = c5
         if getattr(args, "expect", None) and world > 1:

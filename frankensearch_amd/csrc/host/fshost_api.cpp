@@ -115,6 +115,21 @@ fsgpu_status fshost_two_tier_search_many(fshost_two_tier* s, const uint32_t* fas
     }
 }
 
+fsgpu_status fshost_two_tier_set_batching(fshost_two_tier* s, uint32_t max_chunk, uint32_t max_wait_us) {
+    if (!s) return FSGPU_ERR_NULL_ARGUMENT;
+    try {
+        return s->impl.set_batching(max_chunk, max_wait_us);
+    } catch (const std::exception&) {
+        return FSGPU_ERR_DEVICE;
+    }
+}
+
+fsgpu_status fshost_two_tier_batching_stats(fshost_two_tier* s, uint64_t* chunks, uint64_t* requests) {
+    if (!s || !chunks || !requests) return FSGPU_ERR_NULL_ARGUMENT;
+    s->impl.batching_stats(chunks, requests);
+    return FSGPU_OK;
+}
+
 fsgpu_status fshost_run_load(fshost_two_tier* s, const fshost_load_config* config, fshost_load_result* result) {
     if (!s || !config || !result) return FSGPU_ERR_NULL_ARGUMENT;
     try {

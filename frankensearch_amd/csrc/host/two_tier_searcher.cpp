@@ -102,6 +102,7 @@ void SyncTwoTierSearcher::init() {
 }
 
 SyncTwoTierSearcher::~SyncTwoTierSearcher() {
+    stop_engine();   // the engine's threads use the handles below
     if (alignment_) fsgpu_alignment_destroy(alignment_);
     if (cfg_.quality_int8_latency && cfg_.quality_pool == FSHOST_POOL_RETRIEVED) {
         if (quality_.index) (void)fsgpu_index_set_int8_latency(quality_.index, 0);
@@ -160,6 +161,19 @@ fsgpu_status SyncTwoTierSearcher::hits_from_rows(const Tier& tier, const uint32_
 fsgpu_status SyncTwoTierSearcher::search(const uint32_t* fast_ids, uint32_t n_fast, const int32_t* quality_ids,
                                          uint32_t n_quality, uint32_t k, const fsgpu_scored_doc* lexical, uint32_t n_lexical,
                                          Outcome* out, std::string* detail) const {
+    if (init_status_ != FSGPU_OK) {
+        *detail = init_detail_;
+        return init_status_;
+    }
+    // dynamic batching (fshost_two_tier_set_batching): this caller's query rides the many-queries engine with whoever else is calling
+    if (batching_.load(std::memory_order_relaxed))
+        return engine(0)->search_one(fast_ids, n_fast, quality_ids, n_quality, k, lexical, n_lexical, out, detail);
+    return search_unbatched(fast_ids, n_fast, quality_ids, n_quality, k, lexical, n_lexical, out, detail);
+}
+
+fsgpu_status SyncTwoTierSearcher::search_unbatched(const uint32_t* fast_ids, uint32_t n_fast, const int32_t* quality_ids,
+                                                   uint32_t n_quality, uint32_t k, const fsgpu_scored_doc* lexical, uint32_t n_lexical,
+                                                   Outcome* out, std::string* detail) const {
     using clock = std::chrono::steady_clock;
     if (init_status_ != FSGPU_OK) {
         *detail = init_detail_;

@@ -71,7 +71,7 @@ class _ManyResult(C.Structure):
 
 
 SYMBOLS = ("fshost_two_tier_create", "fshost_two_tier_create_sharded", "fshost_two_tier_destroy", "fshost_two_tier_search",
-           "fshost_two_tier_search_many", "fshost_run_load_many", "fshost_run_load", "fshost_embed_search_stream", "fshost_embed_search_stream_dp")
+           "fshost_two_tier_search_many", "fshost_run_load_many", "fshost_two_tier_set_batching", "fshost_two_tier_batching_stats", "fshost_run_load", "fshost_embed_search_stream", "fshost_embed_search_stream_dp")
 _handle = None
 
 
@@ -102,6 +102,10 @@ def lib() -> C.CDLL:
                                              C.POINTER(_Hit), C.POINTER(C.c_uint32), C.POINTER(_Metrics)]
         h.fshost_run_load.restype = C.c_int32
         h.fshost_run_load.argtypes = [C.c_void_p, C.POINTER(_LoadConfig), C.POINTER(_LoadResult)]
+        h.fshost_two_tier_set_batching.restype = C.c_int32
+        h.fshost_two_tier_set_batching.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        h.fshost_two_tier_batching_stats.restype = C.c_int32
+        h.fshost_two_tier_batching_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         h.fshost_run_load_many.restype = C.c_int32
         h.fshost_run_load_many.argtypes = [C.c_void_p, C.POINTER(_LoadConfig), C.c_uint32, C.POINTER(_ManyResult)]
         h.fshost_two_tier_search_many.restype = C.c_int32
@@ -233,6 +237,15 @@ class NativeTwoTierSearcher:
         stats["error_detail"] = res.error_detail.decode(errors="replace")
         out = (initial, final, rf.astype(bool), stats)
         return out + (fv, qv) if want_vectors else out
+
+    def set_batching(self, max_chunk: int, max_wait_us: int = 200) -> None:
+        """fshost_two_tier_set_batching: concurrent search() callers ride the many-queries pipeline (0 = off)."""
+        check(lib().fshost_two_tier_set_batching(self._h, max_chunk, max_wait_us))
+
+    def batching_stats(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        check(lib().fshost_two_tier_batching_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def run_load_many(self, queries: int, warmup_queries: int, k: int, fast_vocab: int, corpus_rows: int, chunk: int = 0,
                       fusion_threads: int = 0, quality_vocab: int = 30000, seed: int = 1) -> dict:

@@ -128,6 +128,16 @@ fsgpu_status fshost_two_tier_search_many(fshost_two_tier *s, const uint32_t *fas
                                          uint32_t *n_final, uint8_t *refinement_failed_out, float *fast_vectors_out,
                                          float *quality_vectors_out, fshost_many_result *result);
 
+/* Dynamic batching of CONCURRENT fshost_two_tier_search callers through the many-queries pipeline above: a caller's query is queued,
+ * a collector turns whatever is queued into the next chunk (up to max_chunk queries of the same k; taken as soon as the pipeline has
+ * room, so chunks grow with the arrival rate and a lone caller's query leaves at once; with fewer than max_chunk queued it lingers
+ * while requests are still arriving, at most max_wait_us past the oldest), and the caller is woken ONCE, when its Refined list is
+ * written (the per-stage coalescers of libfsgpu wake it four times per query).  Results as fshost_two_tier_search_many's.  In this
+ * mode fshost_metrics carries phase1_total_ms (call -> Initial results written) and phase2_total_ms only.  max_chunk = 0 turns it
+ * off (the default).  Replaces batch_coalescer.rs:18-23's role for the whole two-phase flow. */
+fsgpu_status fshost_two_tier_set_batching(fshost_two_tier *s, uint32_t max_chunk, uint32_t max_wait_us);
+fsgpu_status fshost_two_tier_batching_stats(fshost_two_tier *s, uint64_t *chunks, uint64_t *requests);
+
 /* Closed-loop load generator: `threads` native threads each issue fshost_two_tier_search calls back to back on
  * synthetic queries (SURVEY §8d config 5 shapes: fast ids uniform in [0, fast_vocab), 4-23 tokens; quality ids
  * [CLS] + uniform [1000, quality_vocab) + [SEP], 8-32 tokens; stub lexical list of 3k "doc-%08u" ids), the way a

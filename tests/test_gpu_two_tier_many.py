@@ -198,3 +198,61 @@ def test_many_form_over_sharded_tiers_rescored_pool_doc_id_tables_and_failures(t
         t.close()
     for h in (ffast, fqual, fast, qual, wrong, m2v, bert):
         h.close()
+
+
+def test_concurrent_per_query_callers_ride_the_engine_with_dynamic_batching():
+    """fshost_two_tier_set_batching: fshost_two_tier_search calls from many host threads are collected into chunks and answered by the
+    many-queries engine, one wake-up per query.  Every caller gets ITS query's lists: the Initial list identical to the unbatched call's,
+    the Refined list identical up to the encoder's batch-shape tolerance; different k in flight together; errors reach their caller."""
+    import threading
+    import frankensearch_amd as fa
+    from frankensearch_amd.build import build
+    from frankensearch_amd.host import NativeTwoTierSearcher
+
+    build()
+    rng = np.random.default_rng(303)
+    n, nq = 40_000, 600
+    fast_slab, qual_slab, table, w = _small(fa, rng, n)
+    fast, qual = fa.VectorIndex.from_slab(fast_slab), fa.VectorIndex.from_slab(qual_slab)
+    m2v, bert = fa.Model2VecEmbedder(table), fa.NativeEmbedder(w)
+    fq, qq, lex = _queries(rng, nq, n)
+    s = NativeTwoTierSearcher(fast, qual, m2v, bert, doc_id_mode=1, fast_tier_int8_multiplier=3)
+    ks = [10 if i % 7 else 5 for i in range(nq)]
+    want = [s.search(fq[i], qq[i], ks[i], lex[i]) for i in range(nq)]
+    s.set_batching(256, 300)
+    got = [None] * nq
+    errors = []
+
+    def caller(tid, nthreads):
+        try:
+            for i in range(tid, nq, nthreads):
+                got[i] = s.search(fq[i], qq[i], ks[i], lex[i])
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    for nthreads in (1, 48):
+        got = [None] * nq
+        threads = [threading.Thread(target=caller, args=(t, nthreads)) for t in range(nthreads)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors[:2]
+        same = 0
+        for i in range(nq):
+            assert got[i][0] == want[i][0], (nthreads, i)
+            assert len(got[i][1]) == ks[i]
+            same += int([h.doc_id for h in got[i][1]] == [h.doc_id for h in want[i][1]])
+            assert got[i][2]["phase1_total_ms"] > 0 and got[i][2]["refinement_failed"] == 0
+        assert same >= 0.97 * nq, (nthreads, same)
+    chunks, requests = s.batching_stats()
+    assert requests == 2 * nq and chunks < requests     # the 48 callers shared chunks
+    # an out-of-vocabulary token fails ITS caller (and whoever shared the chunk's embedding call), not the searcher
+    with pytest.raises(Exception) as err:
+        s.search(fq[0], [101, 10_000_000, 102], 10, lex[0])
+    assert str(err.value)
+    assert s.search(fq[3], qq[3], ks[3], lex[3])[0] == want[3][0]
+    s.set_batching(0)
+    assert s.search(fq[4], qq[4], ks[4], lex[4])[0] == want[4][0]
+    for h in (s, fast, qual, m2v, bert):
+        h.close()
