@@ -147,6 +147,7 @@ SIGNATURES = {
     "fsgpu_alignment_quality_row": (C.c_int64, [_vp, _u64]),
     "fsgpu_alignment_unmatched_quality_docs": (_u64, [_vp]),
     "fsgpu_quality_scores_for_hits": (_i32, [_vp, _vp, _vp, _vp, _u32, _vp, _u32, _vp, _vp]),
+    "fsgpu_quality_scores_for_hits_batched": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "fsgpu_index_set_after_enqueue_hook": (_i32, [_vp, _vp, _vp]),
     "fsgpu_index_set_profiling": (_i32, [_vp, _i32]),
     "fsgpu_index_scan_time": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(_u64), _i32]),

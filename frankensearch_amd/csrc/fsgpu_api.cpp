@@ -1154,6 +1154,24 @@ fsgpu_status fsgpu_quality_scores_for_hits(fsgpu_index* fast, fsgpu_index* quali
     });
 }
 
+fsgpu_status fsgpu_quality_scores_for_hits_batched(fsgpu_index* fast, fsgpu_index* quality, const fsgpu_alignment* alignment,
+                                                   const float* queries, uint32_t nq, uint32_t query_len, const fsgpu_scored_doc* hits,
+                                                   const uint32_t* hit_offsets, float* out_scores, uint8_t* out_present) {
+    if (!fast || !quality || !alignment) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    if (nq && (!queries || !hit_offsets)) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    const uint32_t n = nq ? hit_offsets[nq] : 0;
+    if (n && (!hits || !out_scores || !out_present)) return fail(FSGPU_ERR_NULL_ARGUMENT, "null argument");
+    return guarded([&]() -> fsgpu_status {
+        std::vector<fsgpu::HitRef> refs(n);
+        for (uint32_t i = 0; i < n; ++i) refs[i] = fsgpu::HitRef{hits[i].doc_id, hits[i].doc_id_len, hits[i].index};
+        std::shared_lock<std::shared_mutex> lf(fast->state_mu);
+        std::shared_lock<std::shared_mutex> lq(quality->state_mu, std::defer_lock);
+        if (quality != fast) lq.lock();
+        return finish(fsgpu::quality_scores_for_hits_batched(fast->impl, quality->impl, alignment->impl, queries, nq, query_len, refs.data(),
+                                                             hit_offsets, out_scores, out_present));
+    });
+}
+
 // The same pairing over two row-sharded handles: the walk runs over their catalogs (fsgpu_sharded_open_fsvi) — raw shards pair by
 // row —, the re-scoring gathers dot_query_at on the shards that own the quality rows (fsgpu_sharded_gather_dot).
 fsgpu_status fsgpu_sharded_alignment_create(fsgpu_sharded* fast, fsgpu_sharded* quality, fsgpu_alignment** out) {

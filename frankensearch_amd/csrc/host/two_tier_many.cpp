@@ -107,6 +107,9 @@ struct ManyEngine::Chunk {
     std::atomic<uint32_t> tasks_left{0};
     std::atomic<int> status{FSGPU_OK}; // a failure of phase 0 / of an embedding: every query of the chunk reports it
     std::string detail;
+    std::vector<float> qscores;        // re-scored pool: the fast pool's quality scores, [n, fetch] ...
+    std::vector<uint8_t> qpresent;     // ... and whether a hit has one
+    std::vector<uint8_t> q_refinement_failed;   // ... per query: its scores could not be produced
     bool quality_failed = false;       // the quality pool failed: RefinementFailed for the chunk's queries
     std::string quality_detail;
     Batch* batch = nullptr;
@@ -143,6 +146,7 @@ ManyEngine::ManyEngine(const SyncTwoTierSearcher& s, uint32_t fusion_threads) : 
     threads_.emplace_back([this] { embed_stage(false); });
     threads_.emplace_back([this] { search_stage(true); });
     if (!rescored_) threads_.emplace_back([this] { search_stage(false); });
+    else threads_.emplace_back([this] { rescore_stage(); });
     for (uint32_t i = 0; i < n_workers_; ++i) threads_.emplace_back([this] { fusion_worker(); });
 }
 
@@ -367,7 +371,85 @@ void ManyEngine::push_tasks(Chunk* c, bool final) {
 }
 
 void ManyEngine::final_part_ready(Chunk* c) {
-    if (c->final_parts.fetch_add(1) + 1 == 2) push_tasks(c, true);
+    if (c->final_parts.fetch_add(1) + 1 != 2) return;
+    if (!rescored_) {
+        push_tasks(c, true);
+        return;
+    }
+    {   // the re-scored pool: the chunk's quality scores first (one gather launch), then the final fusion
+        std::lock_guard<std::mutex> lk(mu_);
+        rs_q_.push_back(c);
+    }
+    cv_.notify_all();
+}
+
+// SyncQualityPool::RescoredFastPool for a chunk (sync_searcher.rs:814-818 per query): quality_scores_for_hits of every query's fast pool
+// — fsgpu_quality_scores_for_hits_batched: one multi-query gather on the quality tier instead of a blocking call per query (a
+// sharded pair: the per-query call, routed to the owning shards).  A query whose scores cannot be produced is a RefinementFailed
+// outcome of THAT query: when the batched call fails the chunk is re-scored query by query to find which.
+void ManyEngine::rescore_stage() {
+    std::vector<Hit> hits;
+    std::vector<std::vector<Hit>> all;
+    std::vector<fsgpu_scored_doc> flat;
+    std::vector<uint32_t> offs;
+    std::string detail;
+    for (;;) {
+        Chunk* c = pop(rs_q_);
+        if (!c) return;
+        const auto b0 = clk::now();
+        if (c->status.load() == FSGPU_OK) {
+            const uint32_t n = c->n, fetch = c->fetch;
+            c->qscores.assign((size_t)n * fetch + 1, 0.0f);
+            c->qpresent.assign((size_t)n * fetch + 1, 0);
+            c->q_refinement_failed.assign(n, 0);
+            all.resize(n);
+            flat.clear();
+            offs.assign(1, 0);
+            fsgpu_status st = FSGPU_OK;
+            for (uint32_t i = 0; i < n && st == FSGPU_OK; ++i) {
+                st = s_.hits_from_rows(s_.fast_, c->f_rows.data() + (size_t)i * fetch, c->f_scores.data() + (size_t)i * fetch, c->f_counts[i], &all[i], &detail);
+                for (const Hit& h : all[i]) flat.push_back(fsgpu_scored_doc{h.doc_id.data(), (uint32_t)h.doc_id.size(), h.score, h.index});
+                offs.push_back((uint32_t)flat.size());
+            }
+            if (st != FSGPU_OK) {
+                int expect = FSGPU_OK;
+                if (c->status.compare_exchange_strong(expect, st)) c->detail = detail;
+            } else {
+                // (flat scores: query i's hit j at offs[i] + j; the fusion reads them at i * fetch + j)
+                std::vector<float> sc(flat.size() + 1);
+                std::vector<uint8_t> pr(flat.size() + 1);
+                bool batched_ok = false;
+                if (s_.fast_.index) {
+                    batched_ok = fsgpu_quality_scores_for_hits_batched(s_.fast_.index, s_.quality_.index, s_.alignment_, c->qvec.data(), n, qdim_,
+                                                                       flat.data(), offs.data(), sc.data(), pr.data()) == FSGPU_OK;
+                }
+                for (uint32_t i = 0; i < n; ++i) {
+                    const uint32_t h0 = offs[i], cnt = offs[i + 1] - h0;
+                    if (!batched_ok) {
+                        const fsgpu_status s1 =
+                            s_.fast_.index ? fsgpu_quality_scores_for_hits(s_.fast_.index, s_.quality_.index, s_.alignment_, c->qvec.data() + (size_t)i * qdim_, qdim_,
+                                                                           flat.data() + h0, cnt, sc.data() + h0, pr.data() + h0)
+                                           : fsgpu_sharded_quality_scores_for_hits(s_.fast_.sharded, s_.quality_.sharded, s_.alignment_,
+                                                                                   c->qvec.data() + (size_t)i * qdim_, qdim_, flat.data() + h0, cnt, sc.data() + h0,
+                                                                                   pr.data() + h0);
+                        if (s1 != FSGPU_OK) {
+                            c->q_refinement_failed[i] = 1;
+                            if (c->quality_detail.empty()) c->quality_detail = fsgpu_last_error();
+                            continue;
+                        }
+                    }
+                    std::memcpy(c->qscores.data() + (size_t)i * fetch, sc.data() + h0, (size_t)cnt * 4);
+                    std::memcpy(c->qpresent.data() + (size_t)i * fetch, pr.data() + h0, cnt);
+                }
+            }
+        }
+        if (c->batch) {
+            std::lock_guard<std::mutex> lk(c->batch->mu);
+            c->batch->t_qs += ms_between(b0, clk::now());
+            if (c->index == 0) c->batch->first_refined_ms = ms_between(c->batch->t_start, clk::now());
+        }
+        push_tasks(c, true);
+    }
 }
 
 void ManyEngine::fusion_worker() {
@@ -405,8 +487,10 @@ void ManyEngine::fusion_worker() {
             } else if (st == FSGPU_OK) {
                 refinement_failed = c->quality_failed;
                 if (!refinement_failed && rescored_) {
-                    st = s_.fuse_final_rescored(fast_hits, c->qvec.data() + (size_t)i * qdim_, k, q.lexical, q.n_lexical, &fused, &refinement_failed, &detail);
-                    if (refinement_failed) st = FSGPU_OK;
+                    refinement_failed = c->q_refinement_failed.empty() || c->q_refinement_failed[i] != 0;
+                    if (!refinement_failed)
+                        st = s_.fuse_final_rescored_scores(fast_hits, c->qscores.data() + (size_t)i * fetch, c->qpresent.data() + (size_t)i * fetch, k, q.lexical,
+                                                           q.n_lexical, &fused, &detail);
                 } else if (!refinement_failed) {
                     st = s_.hits_from_rows(s_.quality_, c->q_rows.data() + (size_t)i * fetch, c->q_scores.data() + (size_t)i * fetch, c->q_counts[i], &quality_hits,
                                            &detail);

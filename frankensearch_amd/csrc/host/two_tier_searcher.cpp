@@ -285,17 +285,26 @@ fsgpu_status SyncTwoTierSearcher::fuse_final_rescored(const std::vector<Hit>& fa
     const std::vector<fsgpu_scored_doc> fast_view = view(fast_hits);
     std::vector<float> qscores(fast_view.size() + 1);
     std::vector<uint8_t> qpresent(fast_view.size() + 1);
-    fsgpu_status st = fast_.index ? fsgpu_quality_scores_for_hits(fast_.index, quality_.index, alignment_, quality_vec, quality_dim_vec_,
-                                                                  fast_view.data(), (uint32_t)fast_view.size(), qscores.data(), qpresent.data())
-                                  : fsgpu_sharded_quality_scores_for_hits(fast_.sharded, quality_.sharded, alignment_, quality_vec, quality_dim_vec_,
-                                                                          fast_view.data(), (uint32_t)fast_view.size(), qscores.data(), qpresent.data());
+    const fsgpu_status st = fast_.index ? fsgpu_quality_scores_for_hits(fast_.index, quality_.index, alignment_, quality_vec, quality_dim_vec_,
+                                                                        fast_view.data(), (uint32_t)fast_view.size(), qscores.data(), qpresent.data())
+                                        : fsgpu_sharded_quality_scores_for_hits(fast_.sharded, quality_.sharded, alignment_, quality_vec, quality_dim_vec_,
+                                                                                fast_view.data(), (uint32_t)fast_view.size(), qscores.data(), qpresent.data());
     if (st != FSGPU_OK) {
         *failed = true;
         return st;
     }
+    return fuse_final_rescored_scores(fast_hits, qscores.data(), qpresent.data(), k, lexical, n_lexical, final_results, detail);
+}
+
+// ... the second half: blend_two_tier_aligned of the fast pool with its quality scores, RRF (sync_searcher.rs:862-918)
+fsgpu_status SyncTwoTierSearcher::fuse_final_rescored_scores(const std::vector<Hit>& fast_hits, const float* qscores, const uint8_t* qpresent, uint32_t k,
+                                                             const fsgpu_scored_doc* lexical, uint32_t n_lexical, std::vector<fshost_hit>* final_results,
+                                                             std::string* detail) const {
+    const std::vector<fsgpu_scored_doc> fast_view = view(fast_hits);
+    fsgpu_status st = FSGPU_OK;
     std::vector<fsgpu_scored_doc> blended(fast_view.size() + 1);
     uint32_t nb = 0, n = 0;
-    st = fsgpu_blend_two_tier_aligned(fast_view.data(), (uint32_t)fast_view.size(), qscores.data(), qpresent.data(), cfg_.quality_weight,
+    st = fsgpu_blend_two_tier_aligned(fast_view.data(), (uint32_t)fast_view.size(), qscores, qpresent, cfg_.quality_weight,
                                       blended.data(), &nb);
     if (st != FSGPU_OK) {
         *detail = fsgpu_last_error();

@@ -108,6 +108,9 @@ class SyncTwoTierSearcher {
                                       std::string* detail) const;
     fsgpu_status fuse_final_rescored(const std::vector<Hit>& fast_hits, const float* quality_vec, uint32_t k, const fsgpu_scored_doc* lexical,
                                      uint32_t n_lexical, std::vector<fshost_hit>* final_results, bool* failed, std::string* detail) const;
+    fsgpu_status fuse_final_rescored_scores(const std::vector<Hit>& fast_hits, const float* qscores, const uint8_t* qpresent, uint32_t k,
+                                            const fsgpu_scored_doc* lexical, uint32_t n_lexical, std::vector<fshost_hit>* final_results,
+                                            std::string* detail) const;
     Tier fast_, quality_;
     fsgpu_m2v* m2v_;
     fsgpu_bert* bert_;
@@ -150,6 +153,7 @@ class ManyEngine {
     Chunk* pop(std::deque<Chunk*>& q);
     void embed_stage(bool fast);
     void search_stage(bool fast);
+    void rescore_stage();
     fsgpu_status tier_search(const Tier& tier, bool rowlevel, uint32_t int8_mult, const float* vec_dev, const float* vec_host, uint32_t n, uint32_t dim,
                              uint32_t fetch, uint32_t* rows, float* scores, uint32_t* counts, uint32_t* fb, std::string* detail);
     void push_tasks(Chunk* c, bool final);
@@ -167,7 +171,7 @@ class ManyEngine {
     // stage queues + free slots
     std::mutex mu_;
     std::condition_variable cv_;
-    std::deque<Chunk*> fe_q_, fs_q_, qe_q_, qs_q_;
+    std::deque<Chunk*> fe_q_, fs_q_, qe_q_, qs_q_, rs_q_;
     std::deque<int> free_slots_;
     bool stop_ = false;
     // fusion pool

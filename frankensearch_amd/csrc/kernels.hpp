@@ -55,6 +55,8 @@ hipError_t launch_packed_to_sortkey(u64* data, size_t n, hipStream_t stream);
 hipError_t launch_sorted_keys_to_rows(const u64* keys, uint32_t k, uint32_t* out_rows, uint32_t* out_count,
                                       hipStream_t stream, u64* out_packed = nullptr);
 hipError_t launch_gather_dot(const ScanArgs& args, const uint32_t* rows, uint32_t n, float* out, hipStream_t stream);
+// (rows[i], qidx[i]) items against args.queries = [nq, dim]: one launch for a chunk of queries (dim % 8 == 0, f16 rows)
+hipError_t launch_gather_dot_mq(const ScanArgs& args, const uint32_t* rows, const uint32_t* qidx, uint32_t n, float* out, hipStream_t stream);
 hipError_t launch_gather_queries(const float* src, const uint32_t* idx, uint32_t n, uint32_t dim, uint32_t src_stride, float* dst,
                                  hipStream_t stream);
 hipError_t launch_scatter_hits(const uint32_t* idx, uint32_t n, uint32_t k, const uint32_t* src_rows,

@@ -680,6 +680,42 @@ __global__ __launch_bounds__(256) void gather_dot_kernel(ScanArgs args, const ui
     if (mine && a == 0) out[item] = s;
 }
 
+// gather-dot for MANY queries in one launch: item i = (row rows[i], query qidx[i]) — quality_scores_for_hits of a whole chunk of the
+// two-tier flow (two_tier.rs:1566-1631 per query; a chunk is ~1,024 x 30 items).  A quad per item, the operation order of
+// gather_dot_kernel (same bits); the quad reads its query's chunks from global memory (a query's 1.5 KB is shared by its ~30 items
+// and stays in the L1 / L2), so consecutive items need not share a query.  dim % 8 == 0, f16 rows.
+__global__ __launch_bounds__(256) void gather_dot_mq_kernel(ScanArgs args, const uint32_t* __restrict__ rows, const uint32_t* __restrict__ qidx,
+                                                            uint32_t n, float* __restrict__ out) {
+    const int dim = (int)args.dim;
+    const int tid = threadIdx.x, a = tid & 3;
+    const uint32_t item = (blockIdx.x * 256 + tid) >> 2;
+    const bool in_range = item < n;
+    uint32_t row = in_range ? rows[item] - args.row_base : 0;
+    const bool mine = in_range && row < args.nrows;
+    if (!mine) row = 0;
+    const float* qs = args.queries + (size_t)(in_range ? qidx[item] : 0) * dim;
+    const unsigned char* slab = reinterpret_cast<const unsigned char*>(args.slab);
+    const int chunks = dim >> 3, groups = chunks >> 2, leftover = chunks & 3;
+    const u32x4* p = reinterpret_cast<const u32x4*>(slab + (size_t)row * args.row_stride);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int g = 0; g < groups; ++g) {
+        const u32x4 w = p[4 * g + a];
+        const float4* qp = reinterpret_cast<const float4*>(qs + 32 * g + 8 * a);
+        chunk_mac(acc, w, qp[0], qp[1]);
+    }
+    if (a == 0) {
+        for (int c = 4 * groups; c < 4 * groups + leftover; ++c) {
+            const u32x4 w = p[c];
+            const float4* qp = reinterpret_cast<const float4*>(qs + 8 * c);
+            chunk_mac(acc, w, qp[0], qp[1]);
+        }
+    }
+    const float s = quad_finish(acc, args.hreduce);
+    if (mine && a == 0) out[item] = s;
+}
+
 // f32 -> f16 round-to-nearest-even (encode_f32_to_f16_extend, simd.rs:2245-2305): v_cvt_f16_f32 is RNE.
 __global__ void encode_f16_kernel(const float* src, size_t n, unsigned short* dst) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -879,6 +915,13 @@ hipError_t launch_gather_dot(const ScanArgs& args, const uint32_t* rows, uint32_
     const unsigned blocks = (unsigned)(((size_t)n * 4 + 255) / 256);
     hipLaunchKernelGGL(gather_dot_kernel, dim3(blocks ? blocks : 1), dim3(256), (size_t)args.dim * 4, stream, args,
                        rows, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_dot_mq(const ScanArgs& args, const uint32_t* rows, const uint32_t* qidx, uint32_t n, float* out, hipStream_t stream) {
+    if ((args.dim & 7) != 0) return hipErrorInvalidValue;
+    const unsigned blocks = (unsigned)(((size_t)n * 4 + 255) / 256);
+    hipLaunchKernelGGL(gather_dot_mq_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, args, rows, qidx, n, out);
     return hipGetLastError();
 }
 

@@ -183,4 +183,57 @@ SearchError quality_scores_for_hits(const VectorIndex& fast, VectorIndex& qualit
     return quality_scores_for_hits(&fast, fast.record_count(), view, align, query, query_len, hits, n, out_scores, out_present);
 }
 
+SearchError quality_scores_for_hits_batched(const VectorIndex& fast, VectorIndex& quality, const QualityAlignment& align, const float* queries,
+                                            uint32_t nq, uint32_t query_len, const HitRef* hits, const uint32_t* hit_offsets, float* out_scores,
+                                            uint8_t* out_present) {
+    std::lock_guard<std::mutex> lock(quality.mutex());
+    // pass 1: every query's resolution (WAL entries scored on the host, alignment, doc-id lookups) with a gather that only RECORDS which
+    // rows it was asked for; pass 2: one launch over all of them; pass 3: the dots land where the single-query function would have put them
+    std::vector<uint32_t> all_rows, all_q;
+    std::vector<uint32_t> first(nq + 1, 0);
+    QualityTierView view;
+    view.table = &quality;
+    view.rows = quality.record_count();
+    view.dim = quality.dimension();
+    uint32_t cur = 0;
+    view.gather = [&](const float*, uint32_t, const uint32_t* rows, uint32_t cnt, float* out) {
+        for (uint32_t i = 0; i < cnt; ++i) {
+            all_rows.push_back(rows[i]);
+            all_q.push_back(cur);
+            out[i] = 0.0f;
+        }
+        return SearchError{};
+    };
+    for (uint32_t q = 0; q < nq; ++q) {
+        cur = q;
+        first[q] = (uint32_t)all_rows.size();
+        const uint32_t h0 = hit_offsets[q], n = hit_offsets[q + 1] - h0;
+        SearchError e = quality_scores_for_hits(&fast, fast.record_count(), view, align, queries + (size_t)q * query_len, query_len, hits + h0, n,
+                                                out_scores + h0, out_present + h0);
+        if (!e.ok()) return e;
+    }
+    first[nq] = (uint32_t)all_rows.size();
+    if (all_rows.empty()) return SearchError{};
+    std::vector<float> dots(all_rows.size());
+    SearchError e = quality.gather_dot_batched(queries, nq, query_len, all_rows.data(), all_q.data(), (uint32_t)all_rows.size(), dots.data());
+    if (!e.ok()) return e;
+    // the single-query function gathers a query's main rows in hit order, skipping the hits it answered from the WAL or found no row
+    // for: replay that order (a hit took part in the gather iff it is present and was not scored by the WAL — its score is the 0 the
+    // recording gather wrote)
+    for (uint32_t q = 0; q < nq; ++q) {
+        cur = q;
+        uint32_t j = first[q];
+        // run the resolution again with a gather that hands out this query's slice of the dots
+        view.gather = [&](const float*, uint32_t, const uint32_t*, uint32_t cnt, float* out) {
+            for (uint32_t i = 0; i < cnt; ++i) out[i] = dots[j + i];
+            return SearchError{};
+        };
+        const uint32_t h0 = hit_offsets[q], n = hit_offsets[q + 1] - h0;
+        SearchError e2 = quality_scores_for_hits(&fast, fast.record_count(), view, align, queries + (size_t)q * query_len, query_len, hits + h0, n,
+                                                 out_scores + h0, out_present + h0);
+        if (!e2.ok()) return e2;
+    }
+    return SearchError{};
+}
+
 }  // namespace fsgpu

@@ -59,4 +59,11 @@ SearchError quality_scores_for_hits(const VectorIndex& fast, VectorIndex& qualit
                                     const float* query, uint32_t query_len, const HitRef* hits, uint32_t n, float* out_scores,
                                     uint8_t* out_present);
 
+// quality_scores_for_hits for a chunk of queries (the many-queries two-tier flow): query q owns hits[hit_offsets[q] .. hit_offsets[q + 1]);
+// the per-hit resolution is the function above's, the dots over main rows of ALL the queries run as ONE multi-query gather launch.
+// out_scores / out_present are flat, aligned with `hits`.
+SearchError quality_scores_for_hits_batched(const VectorIndex& fast, VectorIndex& quality, const QualityAlignment& align, const float* queries,
+                                            uint32_t nq, uint32_t query_len, const HitRef* hits, const uint32_t* hit_offsets, float* out_scores,
+                                            uint8_t* out_present);
+
 }  // namespace fsgpu

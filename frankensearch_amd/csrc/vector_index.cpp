@@ -1061,6 +1061,47 @@ SearchError VectorIndex::gather_dot(const float* query, uint32_t query_len, cons
     return ok();
 }
 
+SearchError VectorIndex::gather_dot_batched(const float* queries, uint32_t nq, uint32_t query_len, const uint32_t* rows, const uint32_t* qidx,
+                                            uint32_t n, float* out) {
+    FSGPU_TRY(ensure_query_dimension(query_len));
+    if (n == 0) return ok();
+    for (uint32_t i = 0; i < n; ++i) {
+        if (rows[i] < row_base_ || rows[i] - row_base_ >= nrows_)
+            return make_error(FSGPU_ERR_INVALID_CONFIG, "row index out of range for dot_query_at");
+        if (qidx[i] >= nq) return make_error(FSGPU_ERR_INVALID_CONFIG, "query index out of range");
+    }
+    if (f32_ || (dim_ & 7) != 0) {   // shapes the multi-query kernel does not cover: query by query (items of a query are consecutive or not)
+        std::vector<uint32_t> r1;
+        std::vector<float> o1;
+        for (uint32_t q = 0; q < nq; ++q) {
+            r1.clear();
+            for (uint32_t i = 0; i < n; ++i)
+                if (qidx[i] == q) r1.push_back(rows[i]);
+            if (r1.empty()) continue;
+            o1.resize(r1.size());
+            FSGPU_TRY(gather_dot(queries + (size_t)q * dim_, query_len, r1.data(), (uint32_t)r1.size(), o1.data()));
+            size_t j = 0;
+            for (uint32_t i = 0; i < n; ++i)
+                if (qidx[i] == q) out[i] = o1[j++];
+        }
+        return ok();
+    }
+    FSGPU_HIP(hipSetDevice(device_));
+    const size_t qbytes = (size_t)nq * dim_ * 4;
+    FSGPU_TRY(ws_queries_.reserve(qbytes));
+    FSGPU_TRY(ws_gather_rows_.reserve((size_t)n * 8));
+    FSGPU_TRY(ws_gather_out_.reserve((size_t)n * 4));
+    uint32_t* rows_dev = static_cast<uint32_t*>(ws_gather_rows_.ptr);
+    FSGPU_HIP(hipMemcpyAsync(ws_queries_.ptr, queries, qbytes, hipMemcpyHostToDevice, stream_));
+    FSGPU_HIP(hipMemcpyAsync(rows_dev, rows, (size_t)n * 4, hipMemcpyHostToDevice, stream_));
+    FSGPU_HIP(hipMemcpyAsync(rows_dev + n, qidx, (size_t)n * 4, hipMemcpyHostToDevice, stream_));
+    ScanArgs a = base_args(static_cast<const float*>(ws_queries_.ptr), nullptr);
+    FSGPU_HIP(launch_gather_dot_mq(a, rows_dev, rows_dev + n, n, static_cast<float*>(ws_gather_out_.ptr), stream_));
+    FSGPU_HIP(hipMemcpyAsync(out, ws_gather_out_.ptr, (size_t)n * 4, hipMemcpyDeviceToHost, stream_));
+    FSGPU_HIP(hipStreamSynchronize(stream_));
+    return ok();
+}
+
 // A strided view of this index: same slab, same live bitmap, rows read over their first `dims` dimensions only.
 VectorIndex* VectorIndex::mrl_view(uint32_t dims) {
     auto it = views_.find(dims);

@@ -122,6 +122,9 @@ class VectorIndex {
     SearchError search_top_k_packed_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
                                            const uint64_t* allow_dev, uint64_t* out_packed_dev, hipStream_t stream);
     SearchError gather_dot(const float* query, uint32_t query_len, const uint32_t* rows, uint32_t n, float* out);
+    // ... for MANY queries in one launch: out[i] = dot(queries[qidx[i]], row rows[i]) (host arrays; quality_scores_for_hits of a chunk)
+    SearchError gather_dot_batched(const float* queries, uint32_t nq, uint32_t query_len, const uint32_t* rows, const uint32_t* qidx, uint32_t n,
+                                   float* out);
 
     // A lone query in two halves (one at a time per index, on the index's own stream): begin enqueues and returns, end waits and
     // writes the hits — search_top_k(query, 1, ...) without a filter is exactly begin + end.  A row-sharded handle begins the query

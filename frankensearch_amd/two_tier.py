@@ -87,6 +87,21 @@ class TwoTierIndex:
                  present.ctypes.data))
         return [float(scores[i]) if present[i] else None for i in range(len(hits))]
 
+    def quality_scores_for_hits_batched(self, queries: np.ndarray, hit_lists: Sequence[Sequence[Tuple[str, float, int]]]) -> List[List[Optional[float]]]:
+        """fsgpu_quality_scores_for_hits_batched: quality_scores_for_hits for a chunk of queries, ONE gather launch (unsharded pairs)."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        nq = len(hit_lists)
+        assert q.ndim == 2 and q.shape[0] == nq and not self.sharded
+        flat = [h for hits in hit_lists for h in hits]
+        offs = np.zeros(nq + 1, dtype=np.uint32)
+        offs[1:] = np.cumsum([len(h) for h in hit_lists])
+        arr, keep = fusion._pack(flat)
+        scores = np.zeros(max(len(flat), 1), dtype=np.float32)
+        present = np.zeros(max(len(flat), 1), dtype=np.uint8)
+        check(_lib.lib().fsgpu_quality_scores_for_hits_batched(self.fast._h, self.quality._h, self._a, q.ctypes.data, nq, q.shape[1], arr,
+                                                               offs.ctypes.data, scores.ctypes.data, present.ctypes.data))
+        return [[float(scores[i]) if present[i] else None for i in range(int(offs[j]), int(offs[j + 1]))] for j in range(nq)]
+
 
 @dataclass
 class TwoTierMetrics:

@@ -599,6 +599,14 @@ uint64_t fsgpu_alignment_unmatched_quality_docs(const fsgpu_alignment *a);
 fsgpu_status fsgpu_quality_scores_for_hits(fsgpu_index *fast, fsgpu_index *quality, const fsgpu_alignment *alignment,
                                            const float *query, uint32_t query_len, const fsgpu_scored_doc *hits, uint32_t n,
                                            float *out_scores, uint8_t *out_present);
+/* quality_scores_for_hits for a CHUNK of queries (the many-queries two-tier flow, fshost_two_tier_search_many with
+ * FSHOST_POOL_RESCORED): query q owns hits[hit_offsets[q] .. hit_offsets[q + 1]) and queries[q * query_len ..); every hit is
+ * resolved as above (two_tier.rs:1566-1631), and the dots over the quality tier's main rows of ALL the queries run as ONE gather
+ * launch.  out_scores / out_present are aligned with `hits`.  Same scores, bit for bit, as nq calls of the function above. */
+fsgpu_status fsgpu_quality_scores_for_hits_batched(fsgpu_index *fast, fsgpu_index *quality, const fsgpu_alignment *alignment,
+                                                   const float *queries, uint32_t nq, uint32_t query_len,
+                                                   const fsgpu_scored_doc *hits, const uint32_t *hit_offsets, float *out_scores,
+                                                   uint8_t *out_present);
 
 /* TwoTierIndex over two row-sharded handles (fast and quality slabs shard identically).  The alignment walk reads the
  * handles' catalogs (fsgpu_sharded_open_fsvi; raw shards pair by row); quality_scores_for_hits resolves WAL entries and doc ids

@@ -337,6 +337,20 @@ def test_quality_alignment_and_rescored_fast_pool_match_the_reference_flow(oracl
     assert [np.float32(g).view(np.uint32) for g in got if g is not None] == [np.float32(w).view(np.uint32) for w in want if w is not None]
     assert any(g is None for g in got)
     assert np.float32(got[len(picks) - 1]).view(np.uint32) == np.float32(wal_score).view(np.uint32)   # the WAL's latest entry
+    # the chunked form (fsgpu_quality_scores_for_hits_batched: one multi-query gather launch for a whole chunk of the many-queries flow)
+    # gives every query the per-query call's scores, bit for bit — WAL hits, missing rows, rowless hits and empty lists included
+    queries = rng.standard_normal((9, 128)).astype(np.float32)
+    queries[0] = query
+    lists = [hits, [], hits[:5], hits[::-1]] + [[(fast.doc_id_at(int(r)), 0.0, int(r)) for r in rng.choice(fcount, int(rng.integers(1, 40)), replace=False)]
+                                               for _ in range(5)]
+    got_b = pair.quality_scores_for_hits_batched(queries, lists)
+    for qi, hl in enumerate(lists):
+        one = pair.quality_scores_for_hits(queries[qi], hl)
+        assert [g is None for g in got_b[qi]] == [w is None for w in one], qi
+        assert [np.float32(g).view(np.uint32) for g in got_b[qi] if g is not None] == [np.float32(w).view(np.uint32) for w in one if w is not None], qi
+    assert [None if g is None else int(np.float32(g).view(np.uint32)) for g in got_b[0]] == [None if g is None else int(np.float32(g).view(np.uint32)) for g in got]
+    with pytest.raises(fa.DimensionMismatch):
+        pair.quality_scores_for_hits_batched(queries[:, :64], lists)
 
 
 def test_rescored_fast_pool_searchers_equal_the_oracle_pipeline(oracle):
