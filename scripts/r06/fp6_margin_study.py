@@ -39,7 +39,11 @@ def q_i8(v, scale):
     return np.clip(np.rint(v * scale), -127, 127)
 
 
-for name, quant, top in (("int8", q_i8, 127.0), ("fp6 E2M3", q_fp6, 7.5)):
+def q_i4(v, scale):   # the reference's signed nibbles (simd.rs:2153-2215: scale 7 / max_abs)
+    return np.clip(np.rint(v * scale), -7, 7)
+
+
+for name, quant, top in (("int8", q_i8, 127.0), ("fp6 E2M3", q_fp6, 7.5), ("int4", q_i4, 7.0)):
     c_s = np.float32(top) / np.abs(xr).max()
     r = quant(xr, c_s)
     eps = xr * c_s - r
