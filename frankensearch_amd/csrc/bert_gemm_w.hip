@@ -610,7 +610,10 @@ __global__ __launch_bounds__(512) void bert_ffn_w_kernel(const _Float16* __restr
     const int I = FIXED ? IC : I_arg;
     constexpr int KS1 = H / 32;            // k-steps of the up-projection = ring depth of the W1 stream
     constexpr int NT2 = 4 * CT / NW;       // 16-column tiles of the output per wave
-    constexpr int R2 = AO ? 8 : 12;        // ring depth of the W2 stream (AO also carries the rows between the LayerNorms)
+#ifndef FSGPU_FFN_R2_AO
+#define FSGPU_FFN_R2_AO 8
+#endif
+    constexpr int R2 = AO ? FSGPU_FFN_R2_AO : 12;        // ring depth of the W2 stream (AO also carries the rows between the LayerNorms)
     constexpr int XP = H + 4;              // floats per row of the residual / output tile
     constexpr int HP = H + 16;             // halves per row of the f16 x tile
     constexpr int XL = BM * (H / 4) / 512; // float4 pieces of the residual tile per thread
@@ -1013,7 +1016,10 @@ __global__ __launch_bounds__(512) void bert_ffn_w64_kernel(const _Float16* __res
                                                            const float* __restrict__ b2, float* x_f32, _Float16* __restrict__ x_h,
                                                            const float* __restrict__ lnw, const float* __restrict__ lnb, int M, int I_arg,
                                                            float eps) {
-    constexpr int H = 64 * CT, BM = 64, RT = BM / 16, NW = 8, CH = 2, R2 = 8;
+#ifndef FSGPU_FFN64_R2
+#define FSGPU_FFN64_R2 8
+#endif
+    constexpr int H = 64 * CT, BM = 64, RT = BM / 16, NW = 8, CH = 2, R2 = FSGPU_FFN64_R2;
     static_assert(IC > 0 && IC % 512 == 0, "halves of the intermediate in chunks of two tiles over 8 waves");
     constexpr int I = IC;
     (void)I_arg;
