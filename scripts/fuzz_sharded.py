@@ -92,6 +92,25 @@ while time.time() < t_end:
         b = idx.search_end(t2)
         same(a, [ref[0][:h], ref[1][:h], ref[2][:h]], tag + " in flight 1")
         same(b, [ref[0][h:], ref[1][h:], ref[2][h:]], tag + " in flight 2")
+    if nq >= 2:   # two LONE tickets in flight, and a lone ticket with a batch ticket of any kind, in either order
+        one = lambda i: [ref[0][i:i + 1], ref[1][i:i + 1], ref[2][i:i + 1]]
+        ta, tb = idx.search_begin(q[0], k, S.EXACT), idx.search_begin(q[1], k, S.EXACT)
+        if rng.random() < 0.5:
+            rb, ra = idx.search_end(tb), idx.search_end(ta)
+        else:
+            ra, rb = idx.search_end(ta), idx.search_end(tb)
+        same(ra, one(0), tag + " lone + lone, first")
+        same(rb, one(1), tag + " lone + lone, second")
+        bmode = [S.EXACT, S.BATCHED][int(rng.integers(0, 2))]
+        nb = min(nq, 9) if bmode == S.EXACT else nq
+        if rng.random() < 0.5:
+            tl, tb = idx.search_begin(q[1], k, S.EXACT), idx.search_begin(q[:nb], k, bmode)
+            rl, rb = idx.search_end(tl), idx.search_end(tb)
+        else:
+            tb, tl = idx.search_begin(q[:nb], k, bmode), idx.search_begin(q[1], k, S.EXACT)
+            rb, rl = idx.search_end(tb), idx.search_end(tl)
+        same(rl, one(1), tag + f" lone beside a batch (mode {bmode})")
+        same(rb, [ref[0][:nb], ref[1][:nb], ref[2][:nb]], tag + f" batch beside a lone query (mode {bmode})")
     idx.close()
     whole.close()
 print(f"seed..{seed - 1}: {cases} cases, {checks} checks, {bad} mismatches", flush=True)

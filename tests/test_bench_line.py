@@ -45,3 +45,46 @@ def test_the_shipped_main_pass_kernel_spills_nothing():
 def test_default_layout_of_an_n_gpu_run():
     import bench
     assert [bench.default_query_groups(n) for n in (1, 2, 3, 4, 6, 8)] == [1, 2, 1, 2, 2, 2]
+
+
+def test_the_n_rank_checks_of_the_bench_catch_a_wrong_answer_and_a_wrong_slab():
+    """bench.py --gpus N (round 6): the merged N-rank answer of the last timed step is compared with the oracle over the WHOLE corpus, and
+    every rank's slab checksum with rank 0's regeneration.  Here on the CPU: the checker accepts the oracle's own answer, rejects one
+    swapped row / one changed score bit / a short count, and the checksum tells a shifted or corrupted shard from the right one."""
+    import numpy as np
+    import torch
+    import bench
+    from oracle import oracle
+
+    oracle.build()
+    n, dim, k = 30_000, 64, 10
+    slab = oracle.clustered_corpus_f16(0, n, dim)
+    q = np.stack([oracle.clustered_query(i, dim) for i in range(12)])
+    rows = np.zeros((12, k), np.int32)
+    scores = np.zeros((12, k), np.float32)
+    for i in range(12):
+        r, s = oracle.search_top_k(slab, q[i], k)
+        rows[i], scores[i] = r.astype(np.int32), s
+    counts = np.full(12, k, np.int32)
+    picks = [0, 1, 5, 6, 11]
+    t = lambda a: torch.from_numpy(a.copy())
+    ok = bench.merged_answer_vs_oracle(slab, q, picks, t(rows), t(scores), t(counts), k)
+    assert ok["equal"] and ok["mismatching_queries"] == [] and ok["rows_scanned_by_the_oracle_per_query"] == n
+    bad_rows = rows.copy()
+    bad_rows[5, [2, 3]] = bad_rows[5, [3, 2]]
+    assert bench.merged_answer_vs_oracle(slab, q, picks, t(bad_rows), t(scores), t(counts), k)["mismatching_queries"] == [5]
+    bad_scores = scores.copy()
+    bad_scores.view(np.uint32)[11, 9] ^= 1
+    assert bench.merged_answer_vs_oracle(slab, q, picks, t(rows), t(bad_scores), t(counts), k)["mismatching_queries"] == [11]
+    short = counts.copy()
+    short[0] = k - 1
+    assert not bench.merged_answer_vs_oracle(slab, q, picks, t(rows), t(scores), t(short), k)["equal"]
+    # slab checksums: position-sensitive at row granularity
+    piece = torch.from_numpy(slab[1000:9000].view(np.int16))
+    want = bench.slab_checksum(piece, 1000)
+    assert bench.slab_checksum(torch.from_numpy(slab[1000:9000].view(np.int16).copy()), 1000) == want
+    assert bench.slab_checksum(piece, 1001) != want                                             # the right rows at the wrong place
+    assert bench.slab_checksum(torch.from_numpy(slab[1001:9001].view(np.int16)), 1000) != want   # a shifted shard
+    corrupt = slab[1000:9000].copy()
+    corrupt[4321, 7] ^= 1
+    assert bench.slab_checksum(torch.from_numpy(corrupt.view(np.int16)), 1000) != want
