@@ -36,7 +36,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 matrix-core peak (same guide)
 MFMA_I8_PEAK_TOPS = 5000.0     # v_mfma_i32_16x16x64_i8 issues at twice the f16 rate (the guide's microbenchmark: >= 3944 TOPS)
-PROFILE_ROUND = "r05"   # profiles/<round>/pmc_summary.json: the PMC pass that belongs to this build's kernels
+PROFILE_ROUND = "r06"   # profiles/<round>/pmc_summary.json: the PMC pass that belongs to this build's kernels
 CLUSTERS = 64
 NOISE = 0.30
 

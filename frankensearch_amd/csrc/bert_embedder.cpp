@@ -447,8 +447,10 @@ SearchError NativeEmbedder::forward(uint32_t n_docs, uint32_t tokens, uint32_t m
 
 bool NativeEmbedder::docs_path(uint32_t tokens, uint32_t max_seq) const {
     static const bool off = fsgpu::lab_env("FSGPU_BERT_NO_DOCS_PATH") != nullptr;  // A/B runs
+    // (lab: above this many tokens a batch of short texts takes the three-launches-per-layer path instead — measured the same from
+    // 768 texts on and slower below: scripts/r06/exp_enc_paths.py)
     static const long max_tokens = [] {
-        const char* e = std::getenv("FSGPU_BERT_DOCS_MAX_TOKENS");   // TEMP (r06 experiment)
+        const char* e = fsgpu::lab_env("FSGPU_BERT_DOCS_MAX_TOKENS");
         return e ? std::atol(e) : (1L << 30);
     }();
     return !off && docs_ready_ && tokens > 32 && max_seq <= 32 && (long)tokens <= max_tokens;

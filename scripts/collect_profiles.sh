@@ -2,7 +2,7 @@
 # Regenerates the evidence kept under profiles/<round>/ (run on the GPU box through gpurun; results land in
 # gpurun_out/<round>/ and are copied to profiles/<round>/ afterwards).  Counter passes are separate runs with
 # --pmc only (never combined with trace domains).
-R=${1:-r05}
+R=${1:-r06}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -25,6 +25,17 @@ FSGPU_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --warmup 3 --config
 python bench.py --sharded-handle --virtual-shards --gpus 8 --no-config5 2>/dev/null | grep queries_per_sec | tail -1 > $OUT/bench_sharded_handle_8virtual_2x4.json
 python bench.py --sharded-handle --virtual-shards --gpus 8 --query-groups 1 --no-config5 2>/dev/null | grep queries_per_sec | tail -1 > $OUT/bench_sharded_handle_8virtual_1x8.json
 FSGPU_BENCH_BACKEND=gloo python bench.py --gpus 4 --steps 10 --warmup 3 --no-sharded-handle 2>/dev/null | tail -1 > $OUT/bench_rehearsal_gloo_4ranks_2x2.json
+FSGPU_BENCH_BACKEND=gloo python bench.py --gpus 8 --steps 5 --warmup 2 --no-sharded-handle 2>/dev/null | tail -1 > $OUT/bench_rehearsal_gloo_8ranks_2x4.json
+FSGPU_BENCH_BACKEND=gloo python bench.py --gpus 4 --steps 10 --warmup 3 --strong --no-sharded-handle 2>/dev/null | tail -1 > $OUT/bench_rehearsal_gloo_4ranks_2x2_strong.json
+# round 6: the many-queries engine (fshost_two_tier_search_many; dynamic batching of per-query callers), its stages alone, its GPU busy fraction
+python scripts/r06/exp_two_tier_many.py 2>&1 | grep "qps=" > $OUT/two_tier_many.txt
+python scripts/r06/exp_two_tier_batching.py 2>&1 | grep "threads=" > $OUT/two_tier_batching.txt
+python scripts/r06/prof_two_tier_stages.py 2>&1 | grep "ms per" > $OUT/two_tier_stages.txt
+CASES=0:1024:0 NQ=16384 rocprofv3 --kernel-trace --output-format csv -d $OUT/many_trace -o many -- python scripts/r06/exp_two_tier_many.py > $OUT/many_trace.log 2>&1
+python scripts/r06/gpu_busy.py $(find $OUT/many_trace -name "*kernel_trace.csv" | head -1) 0.25 > $OUT/two_tier_many_gpu_busy.txt 2>&1
+rm -rf $OUT/many_trace
+scripts/ubench/_build/fp6_skeleton > $OUT/fp6_skeleton.txt 2>&1
+python scripts/conformance_minilm.py --selftest > $OUT/conformance_selftest.txt 2>&1
 python scripts/r04/filtered_tput.py > $OUT/filtered_tput.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_shard -o bench -- \
     python bench.py --rows 1250000 --no-cpu-baseline --no-two-tier --no-adversarial --no-encoders > $OUT/bench_shard_under_trace.json 2> $OUT/bench_shard_trace.err
@@ -63,7 +74,7 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d 
 python scripts/encoder_pmc_summary.py $OUT/enc_trace $OUT/enc_pmc $OUT/encoder_mfma_pmc.json > $OUT/encoder_mfma_pmc.txt 2>&1
 # what one coalesced batch costs through the sharded handle against the unsharded index; fresh-seed fuzzers on this build
 PYTHONPATH=. python scripts/r05/batch_overhead.py 2>&1 | grep "nq=" > $OUT/batch_overhead.txt
-( timeout 200 python scripts/fuzz_batched.py 9501 150 2>&1 | tail -2; timeout 160 python tests/fuzz_exact.py 9503 90 2>&1 | tail -2; timeout 200 python tests/fuzz_encoders.py 9504 120 2>&1 | tail -2; timeout 200 python scripts/fuzz_sharded.py 9505 150 2>&1 | tail -1 ) > $OUT/fuzz_fresh_seeds.txt 2>&1
+( timeout 200 python scripts/fuzz_batched.py 9601 150 2>&1 | tail -2; timeout 160 python tests/fuzz_exact.py 9603 90 2>&1 | tail -2; timeout 200 python tests/fuzz_encoders.py 9604 120 2>&1 | tail -2; timeout 200 python scripts/fuzz_sharded.py 9605 150 2>&1 | tail -1 ) > $OUT/fuzz_fresh_seeds.txt 2>&1
 # the GPU suite on the same box
 ( time python -m pytest tests -m gpu -q ) > $OUT/gputest.log 2>&1
 ls -R $OUT | head -60
