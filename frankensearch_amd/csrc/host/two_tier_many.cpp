@@ -785,7 +785,7 @@ fsgpu_status ManyEngine::search_one(const uint32_t* fast_ids, uint32_t n_fast, c
     q.refinement_failed = &rf;
     {
         std::lock_guard<std::mutex> lk(rmu_);
-        if (server_stop_ || !max_chunk_) {
+        if (server_stop_ || !collector_.joinable()) {
             *detail = "dynamic batching is off";
             return FSGPU_ERR_INVALID_CONFIG;
         }
@@ -879,8 +879,9 @@ fsgpu_status SyncTwoTierSearcher::search_many(const ManyArgs& a, fshost_many_res
 
 fsgpu_status SyncTwoTierSearcher::set_batching(uint32_t max_chunk, uint32_t max_wait_us) {
     if (init_status_ != FSGPU_OK) return init_status_;
+    if (max_chunk == 0) batching_.store(false);   // (off: new callers take the per-query flow at once; what is queued is still answered)
     engine(0)->configure_batching(max_chunk, max_wait_us);
-    batching_.store(max_chunk != 0);
+    if (max_chunk != 0) batching_.store(true);
     return FSGPU_OK;
 }
 
