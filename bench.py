@@ -1621,7 +1621,8 @@ def main() -> None:
                 line[o["scaling"] + "_scaling_queries_per_sec"] = o["value"]
             # every row shard's hits must show up in a step's merged answer (1,024+ queries x k hits over evenly spread clusters)
             per_shard = (args.rows + row_shards - 1) // row_shards
-            owners = np.unique(rows.cpu().numpy().astype(np.uint32).astype(np.int64)[counts.cpu().numpy() > 0] // per_shard)
+            hit_rows = rows.cpu().numpy().astype(np.uint32).astype(np.int64)
+            owners = np.unique(hit_rows[hit_rows < args.rows] // per_shard)   # (padding entries are 0xffffffff)
             line["row_shards_with_hits_in_the_merged_answer"] = int(owners.size)
             if not args.no_merged_check:
                 # THE N-rank check: rank 0 rebuilds the whole corpus on the host from its own generator, verifies every rank's slab
