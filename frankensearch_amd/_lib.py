@@ -75,6 +75,7 @@ SIGNATURES = {
     "fsgpu_search_topk_batched_packed_device": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, C.POINTER(_u32)]),
     "fsgpu_search_topk_batched_device_begin": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32)]),
     "fsgpu_search_topk_batched_device_end": (_i32, [_vp, _i32, C.POINTER(_u32)]),
+    "fsgpu_search_topk_batched_device_end_late": (_i32, [_vp, _i32, C.POINTER(_u32), C.POINTER(_u32)]),
     "fsgpu_search_topk_packed_device": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "fsgpu_merge_topk_device": (_i32, [_i32, _vp, _u32, _u32, _u32, _u64, _u64, _u32, _vp, _vp, _vp, _vp]),
     "fsgpu_sharded_create": (_i32, [_vp, _u32, _u32, _u64, _vp, _vp, _i32, C.POINTER(_vp)]),

@@ -657,6 +657,14 @@ fsgpu_status fsgpu_search_topk_batched_device_end(fsgpu_index* idx, int32_t tick
     });
 }
 
+fsgpu_status fsgpu_search_topk_batched_device_end_late(fsgpu_index* idx, int32_t ticket, uint32_t* out_fallbacks, uint32_t* out_late_answers) {
+    if (!idx) return fail(FSGPU_ERR_NULL_ARGUMENT, "index is null");
+    return guarded([&]() -> fsgpu_status {
+        std::lock_guard<std::mutex> lock(idx->impl.mutex());
+        return finish(idx->impl.search_top_k_batched_device_end(ticket, out_fallbacks, out_late_answers));
+    });
+}
+
 fsgpu_status fsgpu_search_topk_packed_device(fsgpu_index* idx, const float* queries_dev, uint32_t nq,
                                              uint32_t query_len, uint32_t k, const uint64_t* allow_bitmap_dev,
                                              uint64_t* out_packed_dev, void* hip_stream) {

@@ -381,7 +381,10 @@ SearchError ShardedIndex::enqueue_scan(const Request& rq, uint32_t r, int slot) 
 
 // Every rank's end half (the verdicts of its batched / two-pass search; the rare uncertified query answered by the exact kernels on
 // the rank's scan stream).  *late = queries answered that way: their lists were corrected after the exchange had been enqueued.
-SearchError ShardedIndex::end_scans(int slot, uint32_t* late) {
+SearchError ShardedIndex::end_scans(int slot, uint32_t* late, uint32_t* fallbacks) {
+    uint32_t fb_sink = 0;
+    if (!fallbacks) fallbacks = &fb_sink;
+    *fallbacks = 0;
     *late = 0;
     const RootSlot& rs = root_[slot];
     const bool two_pass = rs.mode == kInt8TwoPass || rs.mode == kFourBitTwoPass;
@@ -389,12 +392,15 @@ SearchError ShardedIndex::end_scans(int slot, uint32_t* late) {
     for (auto& sp : shards_) {
         Slot& sl = sp->slot[slot];
         if (sl.ticket < 0) continue;
-        uint32_t fb = 0;
-        const SearchError e = two_pass ? sp->index.two_pass_candidates_device_end(sl.ticket, &fb)
-                                       : sp->index.search_top_k_batched_device_end(sl.ticket, &fb);
+        uint32_t fb = 0, late_here = 0;
+        const SearchError e = two_pass ? sp->index.two_pass_candidates_device_end(sl.ticket, &fb, &late_here)
+                                       : sp->index.search_top_k_batched_device_end(sl.ticket, &fb, &late_here);
         sl.ticket = -1;
         if (!e.ok() && first.ok()) first = e;   // (every ticket is ended whatever the others reported)
-        *late += fb;
+        // (late = every query answered in the end half: exact fallbacks AND queries re-filtered on the f16 slab — through round 5 only
+        // the fallbacks counted, and a re-filtered query's corrected list never travelled: scripts/fuzz_sharded.py, round 6)
+        *late += late_here;
+        *fallbacks += fb;
     }
     return first;
 }
@@ -782,12 +788,12 @@ SearchError ShardedIndex::end(uint64_t ticket, uint32_t* out_rows, float* out_sc
     // the ranks' verdicts; a rank that had to answer an uncertified query did so on its scan stream AFTER its list had travelled:
     // the corrected lists travel again (rare: the bench corpora never take this path).  The end halves run even when the wait
     // failed: a ticket that is never ended is lost to its index.
-    uint32_t late = 0;
-    const SearchError ended = end_scans(slot, &late);
+    uint32_t late = 0, exact_fallbacks = 0;
+    const SearchError ended = end_scans(slot, &late, &exact_fallbacks);
     if (waited != hipSuccess) return hip_err(waited, "hipEventSynchronize(done)");
     SH_TRY(ended);
     SH_T(5);
-    rs.fallbacks = late;
+    rs.fallbacks = exact_fallbacks;
     if (late) {
         for (auto& s : shards_) {
             SH_HIP(hipSetDevice(s->device));

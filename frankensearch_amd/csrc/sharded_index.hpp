@@ -153,7 +153,7 @@ class ShardedIndex {
     SearchError check_layout(uint32_t ndev, uint32_t query_groups);
     SearchError enqueue_scan(const Request& rq, uint32_t r, int slot);   // rank r's share of the request, on its scan stream
     SearchError enqueue_exchange(int slot);
-    SearchError end_scans(int slot, uint32_t* fallbacks);                // every rank's end half; *fallbacks: queries answered late
+    SearchError end_scans(int slot, uint32_t* late, uint32_t* fallbacks = nullptr);   // every rank's end half; *late: queries answered in it (their lists travel again), *fallbacks: by the exact kernels
     SearchError begin_lone(const Request& rq, int slot, uint32_t group);
     SearchError end_lone(RootSlot& rs, uint32_t* out_rows, float* out_scores, uint32_t* out_counts);
     SearchError ensure_quant_scale();    // corpus-wide max-abs: ncclAllReduce(max) / host max, once

@@ -91,7 +91,9 @@ class VectorIndex {
     SearchError search_top_k_batched_device_begin(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
                                                   const uint64_t* allow_dev, uint32_t* out_rows_dev, float* out_scores_dev,
                                                   uint32_t* out_counts_dev, hipStream_t stream, uint64_t* out_packed_dev, int32_t* ticket);
-    SearchError search_top_k_batched_device_end(int32_t ticket, uint32_t* fallbacks);
+    // late_answers (may be null): queries whose hits were written by work enqueued in END — exact fallbacks and queries the int8 filter
+    // handed to the f16 filter; a caller that ordered work behind begin's last kernel must order it again behind these
+    SearchError search_top_k_batched_device_end(int32_t ticket, uint32_t* fallbacks, uint32_t* late_answers = nullptr);
     SearchError search_top_k_batched(const float* queries, uint32_t nq, uint32_t query_len, uint32_t k,
                                      const uint64_t* allow, uint32_t* out_rows, float* out_scores, uint32_t* out_counts,
                                      uint32_t* fallbacks, const uint64_t* allow_resident_dev = nullptr,
@@ -116,7 +118,7 @@ class VectorIndex {
     SearchError two_pass_candidates_device_begin(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,
                                                  uint32_t multiplier, int bits, uint64_t* approx_out_dev, uint64_t* exact_out_dev,
                                                  hipStream_t stream, int32_t* ticket);
-    SearchError two_pass_candidates_device_end(int32_t ticket, uint32_t* fallbacks);
+    SearchError two_pass_candidates_device_end(int32_t ticket, uint32_t* fallbacks, uint32_t* late_answers = nullptr);
     // Shard-local search whose result stays packed (score bits << 32 | global row; ~0 padding) for the
     // cross-GPU exchange: out_packed_dev is [nq, k].  Fused tiers only (k <= 256, dim % 8 == 0).
     SearchError search_top_k_packed_device(const float* queries_dev, uint32_t nq, uint32_t query_len, uint32_t k,

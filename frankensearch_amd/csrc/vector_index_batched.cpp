@@ -394,10 +394,11 @@ SearchError VectorIndex::two_pass_candidates_device_begin(const float* queries_d
     return ok();
 }
 
-SearchError VectorIndex::two_pass_candidates_device_end(int32_t ticket, uint32_t* fallbacks) {
+SearchError VectorIndex::two_pass_candidates_device_end(int32_t ticket, uint32_t* fallbacks, uint32_t* late_answers) {
     if (fallbacks) *fallbacks = 0;
+    if (late_answers) *late_answers = 0;
     if (ticket < 0) return ok();
-    return search_top_k_batched_device_end(ticket, fallbacks);
+    return search_top_k_batched_device_end(ticket, fallbacks, late_answers);
 }
 
 // ---- the batched (matrix-core) search: prepare -> per round { sample -> main -> finish } -> fallback -------------------------
@@ -845,7 +846,13 @@ SearchError VectorIndex::batched_sample(const BatchedPlan& p, BatchedRound& r) {
     if (group_sample) {
         const int grid_g = std::min(r.wide_grid, (int)std::max<uint32_t>(1, RB / 64 / 4));   // at least 4 sample groups per block
         // (enough groups for the picks: the rank form needs ksel of them — and not all from a wave or two of the selection)
-        if (grid_g * 4 <= 1024 && (uint32_t)grid_g * 4 >= (r.anchor ? (ksel <= kGroupsTaken ? 96u : 128u) : std::max(4u * std::min(ksel, 64u), 2u * ksel))) {
+        // (the ranks round 6 added — above 24 with an anchor, above 64 by rank — only with the FULL 1,024-entry sample of a large slab: on a
+        // 43k-row slab the 30th best of 160 group maxima is so loose a threshold that 40 % of a batch overflowed its lists and was
+        // re-filtered on the f16 slab — results right, time wrong; scripts/fuzz_sharded.py found it through a second bug, see
+        // search_top_k_batched_device_end's late_answers)
+        const uint32_t entries = (uint32_t)grid_g * 4;
+        const bool extended = r.anchor ? ksel > kGroupsTaken : ksel > 64;
+        if (grid_g * 4 <= 1024 && entries >= (r.anchor ? 96u : 4u * std::min(ksel, 64u)) && (!extended || entries >= 1024)) {
             MfmaScanArgs c = a;
             c.dense = nullptr;
             c.stage = 3;
@@ -1297,7 +1304,8 @@ SearchError VectorIndex::search_top_k_batched_device_begin(const float* queries_
     return ok();
 }
 
-SearchError VectorIndex::search_top_k_batched_device_end(int32_t ticket, uint32_t* fallbacks) {
+SearchError VectorIndex::search_top_k_batched_device_end(int32_t ticket, uint32_t* fallbacks, uint32_t* late_answers) {
+    if (late_answers) *late_answers = 0;
     if (ticket < 0 || ticket > 1 || async_state_[ticket] == 0) return make_error(FSGPU_ERR_INVALID_CONFIG, "no such begun batched search");
     const int t = ticket;
     if (async_state_[t] == 1) {
@@ -1311,6 +1319,10 @@ SearchError VectorIndex::search_top_k_batched_device_end(int32_t ticket, uint32_
         async_state_[t] = 0;   // (before the fallback: it may search again, blocking, on this index)
         FSGPU_TRY(batched_fallback(p, true));
         if (async_i8f_[t]) i8f_account(async_nq_[t], refiltered);
+        // queries whose hits were written by work enqueued HERE, behind everything begin enqueued: answered by the exact kernels
+        // (counted in *fallbacks) or handed by the int8 filter to the f16 filter (re-filtered: certified there, so NOT a fallback) — a
+        // caller that chained work to begin's last kernel (a shard's exchange) has to chain it again behind these
+        if (late_answers) *late_answers = async_fb_[t] + refiltered;
     }
     async_state_[t] = 0;
     if (fallbacks) *fallbacks = async_fb_[t];

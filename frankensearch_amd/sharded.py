@@ -164,9 +164,12 @@ class GpuShardBackend:
         from . import _lib
         from .errors import check
 
-        fb = C.c_uint32()
-        check(_lib.lib().fsgpu_search_topk_batched_device_end(self.index._h, ticket[0], C.byref(fb)))
+        fb, late = C.c_uint32(), C.c_uint32()
+        check(_lib.lib().fsgpu_search_topk_batched_device_end_late(self.index._h, ticket[0], C.byref(fb), C.byref(late)))
         self.last_fallbacks = fb.value
+        # queries answered in the end half (exact fallbacks + re-filtered on the f16 slab): their hits were enqueued just now, so whatever
+        # was ordered behind begin's kernels (the exchange) has to be ordered behind these too
+        self.last_late_answers = late.value
         return fb.value
 
     def merge(self, gathered: torch.Tensor, k: int):
@@ -316,9 +319,10 @@ class ShardedVectorIndex:
         def finish(p):
             local, ticket, ev = p
             fb = be.scan_end(ticket) if ticket is not None else 0
+            late = max(fb, getattr(be, "last_late_answers", 0)) if ticket is not None else 0
             if after_scan is not None:
                 after_scan()
-            if fb and local.is_cuda:   # its fallback work went to the stream only now: the exchange must wait for that too
+            if late and local.is_cuda:   # hits written by work that went to the stream only now (fallbacks, re-filtered queries): the exchange must wait for that too
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(local.device))
             return self.search_end(local, k, scan_event=ev)

@@ -256,6 +256,12 @@ fsgpu_status fsgpu_search_topk_batched_device_begin(fsgpu_index *idx, const floa
                                                     float *out_scores_dev, uint32_t *out_counts_dev, uint64_t *out_packed_dev,
                                                     void *hip_stream, int32_t *out_ticket);
 fsgpu_status fsgpu_search_topk_batched_device_end(fsgpu_index *idx, int32_t ticket, uint32_t *out_fallbacks);
+/* ... the same, also reporting how many queries were ANSWERED IN THE END HALF — by the exact kernels (*out_fallbacks) or by the f16
+ * filter after the int8 filter handed them on (re-filtered: certified, not a fallback).  Their hits are written by work enqueued on
+ * hip_stream inside this call: a caller that chained work to the last kernel of _begin (a shard's all-gather behind an event recorded
+ * right after _begin returned) must chain it again when *out_late_answers != 0. */
+fsgpu_status fsgpu_search_topk_batched_device_end_late(fsgpu_index *idx, int32_t ticket, uint32_t *out_fallbacks,
+                                                       uint32_t *out_late_answers);
 /* One-shot hook for the NEXT batched search on this handle: `fn(ctx)` is called on the calling thread once every kernel of
  * that search is enqueued and before the call blocks on its stream (it has to read the certificate flags back).  A launcher
  * that pipelines steps uses the window to enqueue the PREVIOUS step's exchange (all-gather + merge on another stream), so

@@ -290,6 +290,41 @@ def test_every_entry_point_of_the_sharded_handle_equals_the_unsharded_index(fa, 
     idx.close()
 
 
+@pytest.mark.parametrize("n,dim,noise,clusters,nq,k", [(90_000, 256, 0.02, 4, 300, 10), (200_000, 384, 0.04, 24, 520, 33)])
+def test_queries_refiltered_in_the_end_half_travel_again(fa, oracle, n, dim, noise, clusters, nq, k):
+    """Tight clusters: the int8 filter's lists overflow and the END half of the shards' batched search hands those queries to the f16
+    filter, which certifies them (no exact fallback).  Their corrected lists are written AFTER the exchange was enqueued: the handle has
+    to exchange again (through round 5 it did so only for exact fallbacks — scripts/fuzz_sharded.py, round 6).  The unsharded twin
+    must show the case really re-filters; every layout must return its rows and score bits; small slabs with ranks 25..32 (the
+    extended group sample is for full-size samples only) ride along."""
+    S = fa.NativeShardedIndex
+    rng = np.random.default_rng(n + k)
+    cent = rng.standard_normal((clusters, dim)).astype(np.float32)
+    x = cent[rng.integers(0, clusters, n)] + (rng.standard_normal((n, dim)) * noise).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True) + 1e-9
+    slab = x.astype(np.float16).view(np.uint16)
+    q = x[rng.integers(0, n, nq)] + (rng.standard_normal((nq, dim)) * 0.15).astype(np.float32)
+    whole = fa.VectorIndex.from_slab(slab)
+    for kk in (k, 30):
+        ref = [np.concatenate(z) for z in zip(*[whole.search_batch(q[s0:s0 + 64], kk, exact=True) for s0 in range(0, nq, 64)])]
+        st0 = whole.batched_filter_stats()
+        r, s, c, fb = whole.search_batched(q, kk)
+        refiltered = whole.batched_filter_stats()["refiltered_f16"] - st0["refiltered_f16"]
+        assert np.array_equal(r, ref[0]) and np.array_equal(bits(s), bits(ref[1]))
+        if kk == k:
+            assert refiltered > 0, "the case no longer re-filters: pick another corpus"
+        for groups, shards in ((1, 1), (1, 2), (2, 2)):
+            idx = S.from_slab(slab, [0] * (groups * shards), exchange=S.EXCHANGE_PEER_COPY, query_groups=groups)
+            r2, s2, c2, _ = idx.search(q, kk, S.BATCHED)
+            assert np.array_equal(r2, ref[0]) and np.array_equal(bits(s2), bits(ref[1])), (kk, groups, shards)
+            t1 = idx.search_begin(q[:nq // 2], kk, S.BATCHED)
+            t2 = idx.search_begin(q[nq // 2:], kk, S.BATCHED)
+            a, b = idx.search_end(t1), idx.search_end(t2)
+            assert np.array_equal(np.concatenate([a[0], b[0]]), ref[0]) and np.array_equal(bits(np.concatenate([a[1], b[1]])), bits(ref[1])), (kk, groups, shards)
+            idx.close()
+    whole.close()
+
+
 def test_lone_and_batch_tickets_overlap_on_a_rotated_filter_copy(fa, oracle):
     """The overlap cases above on a corpus with outlier channels: the batched search and the certified lone pass both go through the
     ROTATED int8 filter copy (rot_q_ is a workspace the lone lane and the batch's begin half share)."""
