@@ -82,7 +82,7 @@ void VectorIndex::i8f_account(uint32_t nq, uint32_t refiltered) {
     //   * an eighth of a batch still handed on twice in a row: the index gives the int8 filter up for the f16 filter (unless the
     //     caller pinned the filter).
     // Since round 5 a slab with outlier channels gets a ROTATED int8 copy (ensure_filter_copy), which removes the usual cause.
-    if (nq >= 256 && i8f_sample_boost_ < 2 && (uint64_t)refiltered * 64 > nq) {
+    if (nq >= wide_min_queries() && i8f_sample_boost_ < 2 && (uint64_t)refiltered * 64 > nq) {
         i8f_sample_boost_ *= 2;
         i8f_strikes_ = 0;
     } else if (nq >= 16 && (uint64_t)refiltered * 8 > nq) {
@@ -566,7 +566,7 @@ SearchError VectorIndex::batched_prepare(BatchedPlan& p, bool* done) {
     // (Not when the main pass is the register-resident-query kernel, i.e. for batches of 256 and more: a row that passes its
     // threshold costs that kernel's 160-instruction tile loop a divergent append, and the looser threshold of a skipped stage
     // B lets 4 x as many through — 1.25M-row shard, 1,024 queries: main pass 0.366 -> 0.329 ms, 2.5M: 0.741 -> 0.642 ms.)
-    const bool wide_main = knobs().wide != 0 && nq >= 256 && scan_wide_supported((int)dim_, p.i8 ? 1 : 2) && variant != 5 && variant != 6;
+    const bool wide_main = knobs().wide != 0 && nq >= wide_min_queries() && scan_wide_supported((int)dim_, p.i8 ? 1 : 2) && variant != 5 && variant != 6;
     if (knobs().ra <= 0 && !knobs().no_skip_b && !wide_main && nrows_ <= 4'000'000 && nrows_ >= 4 * (uint64_t)RA_MAX) {
         const uint64_t expect = (uint64_t)std::max<uint32_t>(k, 1) * (p.i8 ? std::max<uint32_t>(p.int8_mult, 1) : 1) * (nrows_ / RA_MAX);
         if (expect <= 4096) {
@@ -663,9 +663,12 @@ SearchError VectorIndex::batched_prepare(BatchedPlan& p, bool* done) {
         FSGPU_HIP(launch_scan_mfma(probe, 0, 1, stream, &mf_per_cu_narrow_));
         FSGPU_HIP(launch_scan_mfma(probe, mf_shape_, 1, stream, &mf_per_cu_wide_));
         probe.elem_bytes = 1;
-        mf_shape_i8_ = 4;             // int8 rows are half as long: 64-row tiles keep 24 KB in flight per wave
+        // (rounds 3-5 ran int8 rows on shape 4 — 64-row tiles, 24 KB in flight per wave — whose main-pass instantiation spills inside
+        // its tile loop; round 6 measured shape 2 against it at 10M rows, 100..255 queries: 8-12 % faster on 256-dimension rows, 0-4 % on
+        // 384 — profiles/r06/lds_query_shape_ab.txt)
+        mf_shape_i8_ = 2;
         if (knobs().mfma_shape_i8) mf_shape_i8_ = knobs().mfma_shape_i8;  // tuning experiments only
-        if (mf_shape_i8_ < 1 || mf_shape_i8_ > 4) mf_shape_i8_ = 4;
+        if (mf_shape_i8_ < 1 || mf_shape_i8_ > 4) mf_shape_i8_ = 2;
         FSGPU_HIP(launch_scan_mfma(probe, 0, 1, stream, &mf_per_cu_narrow_i8_));
         FSGPU_HIP(launch_scan_mfma(probe, mf_shape_i8_, 1, stream, &mf_per_cu_wide_i8_));
         // 160-query shape: measured 1.49 ms per pass at 10M x 384 (0.64 of HBM peak) against 1.26 ms at 128 queries
@@ -753,10 +756,13 @@ SearchError VectorIndex::batched_round_setup(const BatchedPlan& p, BatchedRound&
     // Main pass at 384 / 256 queries per launch (mfma_wide.hip: queries in registers, row tiles through an LDS-DMA
     // ring) when that many are left; the sample stages then run as sub-groups of 128 on the LDS-query kernel.
     r.wide_qt = 0;
-    if (p.wide_ok && left >= 256) {   // 128-query groups per launch
+    if (p.wide_ok && left >= wide_min_queries()) {   // 128-query groups per launch
         // as many as the registers hold (f16 rows of 384 dimensions: 3, their int8 form: 5), the round's groups spread evenly
         // over its passes (8 groups: 3 + 3 + 2 on f16 rows, 4 + 4 on int8 rows)
-        const uint32_t groups_left = std::min<uint32_t>(left / 128, p.QCAP / 128);
+        // (the last group may be partly padding: 129..255 queries ride ONE 256-slot pass — the LDS-query kernel answered them as
+        // 128 + the rest in two passes over the slab, 1.69-1.91 ms against 0.92 per tier at 10M rows: the chunks the many-queries
+        // engine forms for 129..255 callers)
+        const uint32_t groups_left = std::min<uint32_t>((left + 127) / 128, p.QCAP / 128);
         const uint32_t passes = (groups_left + p.wide_max - 1) / p.wide_max;
         r.wide_qt = p.wide_pref == 2 ? 2 : (int)((groups_left + passes - 1) / passes);
     }
@@ -767,7 +773,11 @@ SearchError VectorIndex::batched_round_setup(const BatchedPlan& p, BatchedRound&
     r.wide_mult = r.wide_qt ? (uint32_t)r.wide_qt : 1;   // sample groups per main-pass launch
     // this round: `ngroups` groups of G queries (the last one may be partly padding), QP query slots, ng real queries
     r.ngroups = left >= r.G ? std::min<uint32_t>(left / r.G, p.QCAP / r.G) : 1;
-    if (r.wide_qt) r.ngroups = r.ngroups / r.wide_mult * r.wide_mult;
+    if (r.wide_qt) {   // whole launches: the padded tail rounds up when the slots exist, down otherwise
+        const uint32_t want = std::min<uint32_t>((left + r.G - 1) / r.G, p.QCAP / r.G);
+        r.ngroups = want / r.wide_mult * r.wide_mult;
+        if (r.ngroups < want && r.ngroups + r.wide_mult <= p.QCAP / r.G && left > r.ngroups * r.G) r.ngroups += r.wide_mult;
+    }
     r.QP = r.ngroups * r.G;
     r.ng = std::min(r.QP, left);
     r.wpb = scan_mfma_waves_per_block(r.shape);

@@ -48,6 +48,7 @@ struct Knobs {
     bool no_big_pool = false, no_heur_b = false, no_group_sample = false;
     int rb_pct = 0;      // FSGPU_RB_PCT: the second sample's size in percent of what the plan chose (tuning experiments only)
     int heur_rank = 0;   // FSGPU_HEUR_RANK: rank of the first sample whose score gates the anchoring-only second sample (default 4)
+    int wide_min = 0;    // FSGPU_WIDE_MIN: fewest queries left that take the register-resident-query main pass (default 129)
     Knobs() {
         auto env = [](const char* name) { return std::getenv(name); };
         if (const char* w = env("FSGPU_WIDE")) wide = std::atoi(w);
@@ -68,6 +69,7 @@ struct Knobs {
         mfma_shape_i8 = num("FSGPU_MFMA_SHAPE_I8");
         i8f_growth = num("FSGPU_I8F_GROWTH");
         wide_max = num("FSGPU_WIDE_MAX");
+        wide_min = num("FSGPU_WIDE_MIN");
         slots_b = std::min(num("FSGPU_SLOTS_B"), (int)kWideSlots);
         slots_main = std::min(num("FSGPU_SLOTS_MAIN"), (int)kWideSlots);
         no_skip_b = env("FSGPU_NO_SKIP_B") != nullptr;
@@ -86,6 +88,9 @@ inline const Knobs& knobs() {
     static const Knobs k;
     return k;
 }
+// Fewest queries that ride the register-resident-query main pass: one more than the LDS-query kernel answers in ONE pass over the slab
+// (the tail of a 256-slot launch is padding — batched_round_setup).
+inline uint32_t wide_min_queries() { return knobs().wide_min > 128 ? (uint32_t)knobs().wide_min : 129u; }
 
 }  // namespace detail
 }  // namespace fsgpu
