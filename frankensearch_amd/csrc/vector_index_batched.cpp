@@ -674,9 +674,11 @@ SearchError VectorIndex::batched_prepare(BatchedPlan& p, bool* done) {
         // 160-query shape: measured 1.49 ms per pass at 10M x 384 (0.64 of HBM peak) against 1.26 ms at 128 queries
         // (0.75) — 7 % more queries per second, but the pass is no longer HBM-bound; opt-in (FSGPU_USE_160=1)
         mf_use_160_ = knobs().use_160;
-        FSGPU_HIP(launch_scan_mfma(probe, 5, 1, stream, &mf_per_cu_160_i8_));
-        probe.elem_bytes = 2;
-        FSGPU_HIP(launch_scan_mfma(probe, 5, 1, stream, &mf_per_cu_160_));
+        if (mf_use_160_) {   // (experiments builds only: the shipped library does not carry the shape)
+            FSGPU_HIP(launch_scan_mfma(probe, 5, 1, stream, &mf_per_cu_160_i8_));
+            probe.elem_bytes = 2;
+            FSGPU_HIP(launch_scan_mfma(probe, 5, 1, stream, &mf_per_cu_160_));
+        }
     }
     // the register-resident-query main pass (mfma_wide.hip): 256 queries per launch by default
     // (384 per launch when that many queries are left: the matrix pipe is the bound there and fewer passes leave it more of

@@ -42,6 +42,19 @@ def test_the_shipped_main_pass_kernel_spills_nothing():
     assert res["vgpr_count"] <= 256, res
 
 
+def test_no_scan_kernel_of_the_shipped_library_spills():
+    """Round 6: the LDS-query shapes whose main-pass instantiations spilled (64-row tiles, 160 queries) are compiled into experiments
+    builds only — every scan kernel in the shipped libfsgpu.so keeps its state in registers (scripts/list_spills.py reads the notes)."""
+    import subprocess
+    from __graft_entry__ import build
+    build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.check_output([sys.executable, os.path.join(root, "scripts", "list_spills.py")], timeout=300).decode()
+    assert " kernels, " in out.splitlines()[0]
+    spilling = [l for l in out.splitlines()[1:] if "scan_" in l or "gather_" in l or "int8" in l]
+    assert spilling == [], spilling
+
+
 def test_default_layout_of_an_n_gpu_run():
     import bench
     assert [bench.default_query_groups(n) for n in (1, 2, 3, 4, 6, 8)] == [1, 2, 1, 2, 2, 2]
