@@ -117,6 +117,7 @@ SIGNATURES = {
     "fsgpu_search_topk_int8_two_pass": (_i32, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),
     "fsgpu_search_hits": (_i32, [_vp, _vp, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),
     "fsgpu_gather_dot": (_i32, [_vp, _vp, _u32, _vp, _u32, _vp]),
+    "fsgpu_lab_sort_keys_desc": (_i32, [_i32, _vp, _u64, _u64, _vp]),
     "fsgpu_bench_fixture_device": (_i32, [_i32, _u64, _u64, _u32, _u32, C.c_float, _u64, _i32, _vp, _vp]),
     "fsgpu_encode_f32_to_f16": (_i32, [_i32, _vp, _u64, _vp]),
     "fsgpu_widen_f16_to_f32": (_i32, [_i32, _vp, _u64, _vp]),

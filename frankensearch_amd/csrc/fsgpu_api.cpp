@@ -380,6 +380,7 @@ fsgpu_status fsgpu_index_set_int8_latency(fsgpu_index* idx, int32_t enabled) {
     std::unique_lock<std::shared_mutex> state(idx->state_mu);
     std::lock_guard<std::mutex> lock(idx->impl.mutex());
     idx->impl.int8_latency = enabled != 0;
+    if (enabled == FSGPU_INT8_LATENCY_BUILD_NOW) return finish(idx->impl.prepare_int8_latency());
     return FSGPU_OK;
 }
 
@@ -1296,6 +1297,37 @@ fsgpu_status fsgpu_bench_fixture_device(int32_t device, uint64_t first, uint64_t
                                                     as_f16 ? nullptr : static_cast<float*>(out_dev), st);
         if (he == hipSuccess) he = hipStreamSynchronize(st);
         cent.release();
+        if (he != hipSuccess) return fail(FSGPU_ERR_DEVICE, hipGetErrorString(he));
+        return FSGPU_OK;
+    });
+}
+
+fsgpu_status fsgpu_lab_sort_keys_desc(int32_t device, const uint64_t* keys, uint64_t n, uint64_t varying_bits, uint64_t* out_sorted) {
+    if (n && (!keys || !out_sorted)) return fail(FSGPU_ERR_NULL_ARGUMENT, "keys / out_sorted is null");
+    return guarded([&]() -> fsgpu_status {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(FSGPU_ERR_NO_DEVICE, "no HIP device visible");
+        if (device < 0 || device >= count) return fail(FSGPU_ERR_INVALID_CONFIG, "device ordinal out of range");
+        if (hipSetDevice(device) != hipSuccess) return fail(FSGPU_ERR_DEVICE, "hipSetDevice failed");
+        if (n == 0) return FSGPU_OK;
+        fsgpu::DeviceBuffer in, out, tmp;
+        size_t tmp_bytes = 0;
+        (void)fsgpu::sort_keys_desc_temp_bytes(n, &tmp_bytes);
+        fsgpu::SearchError e = in.reserve(n * 8);
+        if (e.ok()) e = out.reserve(n * 8);
+        if (e.ok()) e = tmp.reserve(tmp_bytes);
+        hipError_t he = hipSuccess;
+        if (e.ok()) {
+            he = hipMemcpy(in.ptr, keys, n * 8, hipMemcpyHostToDevice);
+            if (he == hipSuccess)
+                he = fsgpu::sort_keys_desc(tmp.ptr, tmp.bytes, static_cast<const fsgpu::u64*>(in.ptr), static_cast<fsgpu::u64*>(out.ptr), n, nullptr, varying_bits);
+            if (he == hipSuccess) he = hipStreamSynchronize(nullptr);
+            if (he == hipSuccess) he = hipMemcpy(out_sorted, out.ptr, n * 8, hipMemcpyDeviceToHost);
+        }
+        in.release();
+        out.release();
+        tmp.release();
+        if (!e.ok()) return finish(e);
         if (he != hipSuccess) return fail(FSGPU_ERR_DEVICE, hipGetErrorString(he));
         return FSGPU_OK;
     });

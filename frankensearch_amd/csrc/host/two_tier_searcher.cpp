@@ -90,7 +90,7 @@ void SyncTwoTierSearcher::init() {
     // It is a setting of the CALLER's handle (and costs it an int8 copy of the slab): switched off again in the destructor.
     // (A sharded quality tier takes the same switch on every shard: fsgpu_sharded_set_int8_latency.)
     if (cfg_.quality_int8_latency && cfg_.quality_pool == FSHOST_POOL_RETRIEVED) {
-        init_status_ = quality_.index ? fsgpu_index_set_int8_latency(quality_.index, 1) : fsgpu_sharded_set_int8_latency(quality_.sharded, 1);
+        init_status_ = quality_.index ? fsgpu_index_set_int8_latency(quality_.index, FSGPU_INT8_LATENCY_BUILD_NOW) : fsgpu_sharded_set_int8_latency(quality_.sharded, 1);
         if (init_status_ != FSGPU_OK) init_detail_ = fsgpu_last_error();
     }
     if (init_status_ == FSGPU_OK && cfg_.quality_pool == FSHOST_POOL_RESCORED) {

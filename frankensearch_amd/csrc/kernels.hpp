@@ -79,10 +79,11 @@ int scan_f32_queries_per_pass(int dim, int kcap, int want);   // 4, 2 or 1: what
 hipError_t launch_score_rows_f32(const ScanArgs& args, u64* out_packed, int q_index, hipStream_t stream);
 hipError_t launch_gather_dot_f32(const ScanArgs& args, const uint32_t* rows, uint32_t n, float* out, hipStream_t stream);
 
-// sort_general.hip (rocPRIM radix sort, descending u64 keys) — the large-k / collect-all path.
+// sort_general.hip (own LSD radix sort, descending u64 keys) — the large-k / collect-all path.
+// varying_bits: the key bits that can differ between two keys of the input (digits without any are skipped).
 hipError_t sort_keys_desc_temp_bytes(size_t n, size_t* temp_bytes);
 hipError_t sort_keys_desc(void* temp, size_t temp_bytes, const u64* keys_in, u64* keys_out, size_t n,
-                          hipStream_t stream);
+                          hipStream_t stream, u64 varying_bits = ~0ull);
 
 // m2v_kernels.hip
 hipError_t launch_m2v_embed(const float* table, uint32_t vocab, uint32_t dim, const uint32_t* ids,

@@ -836,7 +836,7 @@ SearchError VectorIndex::general_search(const float* queries_dev, uint32_t nq, u
         if (f32_) FSGPU_HIP(launch_score_rows_f32(a, keys_a, (int)q, stream));
         else FSGPU_HIP(launch_score_rows(a, keys_a, (int)q, grid, stream));
         FSGPU_HIP(launch_packed_to_sortkey(keys_a, n, stream));
-        FSGPU_HIP(sort_keys_desc(ws_sort_tmp_.ptr, ws_sort_tmp_.bytes, keys_a, keys_b, n, stream));
+        FSGPU_HIP(sort_keys_desc(ws_sort_tmp_.ptr, ws_sort_tmp_.bytes, keys_a, keys_b, n, stream, sortkey_varying_bits(live_dev_ || allow_dev)));
         uint32_t* rows_q = out_rows_dev + (size_t)q * k_out;
         FSGPU_HIP(launch_sorted_keys_to_rows(keys_b, k_eff, rows_q, out_counts_dev + q, stream));
         ScanArgs g = base_args(queries_dev + (size_t)q * dim_, nullptr);
@@ -886,7 +886,7 @@ SearchError VectorIndex::gather_search(const float* queries_dev, uint32_t nq, ui
             FSGPU_TRY(ws_sort_tmp_.reserve(tmp_bytes));
             u64* keys_b = static_cast<u64*>(ws_keys_b_.ptr);
             FSGPU_HIP(launch_packed_to_sortkey(packed, n, stream));
-            FSGPU_HIP(sort_keys_desc(ws_sort_tmp_.ptr, ws_sort_tmp_.bytes, packed, keys_b, n, stream));
+            FSGPU_HIP(sort_keys_desc(ws_sort_tmp_.ptr, ws_sort_tmp_.bytes, packed, keys_b, n, stream, sortkey_varying_bits(false)));   // (allowed, live rows only)
             uint32_t* rows_q = out_rows_dev + (size_t)q * k;
             FSGPU_HIP(launch_sorted_keys_to_rows(keys_b, k_eff, rows_q, out_counts_dev + q, stream));
             FSGPU_HIP(gather_dot_any(g, rows_q, k_eff, out_scores_dev + (size_t)q * k, stream));

@@ -202,6 +202,18 @@ class VectorIndex {
     int32_t filter_rotation = 0;
     bool filter_rotated() const { return i8f_rot_; }
     bool exact_only_ = false;   // fsgpu_search_topk_exact: the call in flight takes the exact kernels whatever copies the index holds
+    // Which bits of (score sortkey << 32 | ~row) can differ over this slab's rows: all of the score half, the row bits below the
+    // highest one in which the first and the last row id differ — unless empty entries (key 0: tombstoned / filtered rows) are among them.
+    uint64_t sortkey_varying_bits(bool may_hold_empty) const {
+        if (may_hold_empty || nrows_ == 0) return ~0ull;
+        const uint64_t lo = row_base_, hi = row_base_ + nrows_ - 1;
+        uint64_t x = (lo ^ hi) & 0xffffffffull, mask = 0;
+        while (x) {
+            mask = (mask << 1) | 1ull;
+            x >>= 1;
+        }
+        return 0xffffffff00000000ull | mask;
+    }
     SearchError prepare_int8_latency();   // builds the int8 copy + its statistics now (else: the first batched search does)
     uint64_t i8f_queries = 0, i8f_refiltered = 0;  // queries the int8 filter took / handed on to the f16 filter
     bool int8_filter_active() const { return batched_filter == 2 || (batched_filter == 0 && !i8f_disabled_); }

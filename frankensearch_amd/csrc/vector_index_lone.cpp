@@ -713,7 +713,7 @@ SearchError VectorIndex::quantized_two_pass(const float* query, uint32_t query_l
         if (bits == 8) FSGPU_HIP(launch_score_rows_i8(a, qslab, ws_i8_query_.ptr, keys_a, stream_));
         else FSGPU_HIP(launch_score_rows_4bit(a, qslab, ws_i8_query_.ptr, keys_a, stream_));
         FSGPU_HIP(launch_packed_to_sortkey(keys_a, n, stream_));
-        FSGPU_HIP(sort_keys_desc(ws_sort_tmp_.ptr, ws_sort_tmp_.bytes, keys_a, keys_b, n, stream_));
+        FSGPU_HIP(sort_keys_desc(ws_sort_tmp_.ptr, ws_sort_tmp_.bytes, keys_a, keys_b, n, stream_, sortkey_varying_bits(a.live || a.allow)));
         FSGPU_HIP(launch_sorted_keys_to_rows(keys_b, cc, cand_rows, static_cast<uint32_t*>(ws_counts_.ptr), stream_, approx_out_dev));
     }
     // ---- pass 2: exact f16 rescore of the candidates, then the usual best-first selection of k ----

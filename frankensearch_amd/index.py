@@ -129,9 +129,10 @@ class VectorIndex:
     def filter_rotated(self) -> bool:
         return bool(_lib.lib().fsgpu_index_filter_rotated(self._h))
 
-    def set_int8_latency(self, enabled: bool) -> None:
-        """Unfiltered search_batch calls of a few queries go through the int8 filter + exact re-score (same hits, half the bytes)."""
-        check(_lib.lib().fsgpu_index_set_int8_latency(self._h, int(enabled)))
+    def set_int8_latency(self, enabled: bool, build_now: bool = False) -> None:
+        """Unfiltered search_batch calls of a few queries go through the int8 filter + exact re-score (same hits, half the bytes).
+        build_now: the int8 copy is built before the call returns (FSGPU_INT8_LATENCY_BUILD_NOW) instead of at the first such search."""
+        check(_lib.lib().fsgpu_index_set_int8_latency(self._h, 2 if (enabled and build_now) else int(enabled)))
 
     def int8_filter_bound(self, queries: np.ndarray, want_slab: bool = False):
         """(delta[nq], query_scale[nq], slab_scale, queries_i8[nq, dim], slab_i8 or None): the int8 filter's certificate."""

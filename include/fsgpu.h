@@ -207,7 +207,10 @@ int32_t fsgpu_index_filter_rotated(fsgpu_index *idx); /* 1: the filter's copy of
  * row within that margin (one query at 10M x 384: p50 0.67 ms against 1.26 ms; 1M x 384: 0.126 against 0.161); an uncertified query
  * takes the staged path.  Off by default: fsgpu_search_topk then takes the certified pass only for a lone query of an index whose int8
  * copy a batched search has already built (see fsgpu_search_topk_exact above) and never builds the copy itself; the two-tier host
- * (libfshost) sets it on the quality tier. */
+ * (libfshost) sets it on the quality tier.
+ * enabled = FSGPU_INT8_LATENCY_BUILD_NOW: on, and the int8 copy + its statistics are built before the call returns (index-build work,
+ * ~4 ms per GB of slab), so that the latency of the first lone query does not depend on what was searched before it. */
+#define FSGPU_INT8_LATENCY_BUILD_NOW 2
 fsgpu_status fsgpu_index_set_int8_latency(fsgpu_index *idx, int32_t enabled);
 /* Queries the int8 filter has taken so far, how many of them it handed on to the f16 filter, and whether the index still
  * uses it (any pointer may be null). */

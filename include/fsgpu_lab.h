@@ -36,6 +36,10 @@ fsgpu_status fsgpu_index_filter_stats(fsgpu_index *idx, uint64_t *gathered, uint
 /* Name of the template instantiation the last batched main pass launched in this process ran ("" before the first one), spelled as
  * rocprofv3 prints it: lets bench.py tie a committed PMC summary to the kernel that actually ran. */
 const char *fsgpu_last_main_pass_kernel(void);
+/* The library's own descending radix sort of 64-bit sortkeys (csrc/sort_general.hip: the collect-all / large-k path,
+ * search.rs:449-473), host arrays in and out — so that tests can check it against a host sort at tile boundaries.  varying_bits: the
+ * bits in which two keys of the input may differ (~0 when unknown): a digit without one gets no pass. */
+fsgpu_status fsgpu_lab_sort_keys_desc(int32_t device, const uint64_t *keys, uint64_t n, uint64_t varying_bits, uint64_t *out_sorted);
 /* Selects the scan kernel variant (0 = default) — used by bench A/B runs only. */
 fsgpu_status fsgpu_index_set_variant(fsgpu_index *idx, int32_t variant);
 

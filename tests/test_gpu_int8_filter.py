@@ -486,6 +486,28 @@ def test_default_lone_query_takes_the_certified_pass_once_the_int8_copy_exists(f
     idx.close()
 
 
+def test_int8_latency_build_now_puts_the_first_lone_query_on_the_certified_pass(fa, oracle):
+    """FSGPU_INT8_LATENCY_BUILD_NOW (round 6): the int8 copy and its statistics are built inside fsgpu_index_set_int8_latency, so the
+    FIRST lone query already takes the certified int8 pass — its latency does not depend on which searches came before (r05 verdict).
+    Same rows and score bits as the oracle and as the exact kernels."""
+    rng = np.random.default_rng(61)
+    dim, n, k = 384, 200_003, 10
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    slab = x.astype(np.float16).view(np.uint16)
+    idx = fa.VectorIndex.from_slab(slab)
+    assert not idx.batched_filter_stats()["int8_active"] or idx.batched_filter_stats()["int8_queries"] == 0
+    idx.set_int8_latency(True, build_now=True)
+    q = x[rng.integers(0, n, 4)] + (rng.standard_normal((4, dim)) * 0.1).astype(np.float32)
+    rows, scores, counts = idx.search_batch(q[0], k)            # the very first search of this index
+    assert idx.batched_filter_stats()["int8_queries"] == 1      # ... was answered by the int8 pass
+    orow, osc = oracle.search_top_k(slab, q[0], k)
+    assert np.array_equal(rows[0], orow) and np.array_equal(bits(scores[0]), bits(osc)) and counts[0] == k
+    er, es, _ = idx.search_batch(q[0], k, exact=True)
+    assert np.array_equal(rows, er) and np.array_equal(bits(scores), bits(es))
+    idx.close()
+
+
 @pytest.mark.parametrize("dim", [128, 256, 384])
 def test_group_maxima_sample_stage_gives_the_exact_search_bits(fa, oracle, dim):
     """The int8 filter's append-free sample stage (MfmaScanArgs::stage 3 + select_groups_kernel: every block reports its four best
