@@ -45,9 +45,10 @@ NativeEmbedder::~NativeEmbedder() {
     drop_graphs();
     if (stream_) (void)hipStreamDestroy(stream_);
     if (io_host_) (void)hipHostFree(io_host_);
+    if (q_status_) (void)hipHostFree(q_status_);
     if (docs_io_) (void)hipHostFree(docs_io_);
     for (DeviceBuffer* b : {&word_, &pos_, &type_, &emb_ln_w_, &emb_ln_b_, &ids_, &positions_, &offsets_, &x_f32_, &x_h_,
-                            &qkv_f32_, &ctx_h_, &tmp_f32_, &inter_h_, &out_, &q_x_, &q_parts_, &docs_layers_, &docs_in_, &docs_out_})
+                            &qkv_f32_, &ctx_h_, &tmp_f32_, &inter_h_, &out_, &q_x_, &q_parts_, &q_stages_, &q_counter_, &docs_layers_, &docs_in_, &docs_out_})
         b->release();
     for (Layer& l : layers_)
         for (DeviceBuffer* b : {&l.qkv_w, &l.ao_w, &l.i_w, &l.o_w, &l.qkv_wp, &l.ao_wp, &l.i_wp, &l.o_wp, &l.qkv_b, &l.ao_b, &l.ln1_w, &l.ln1_b, &l.i_b, &l.o_b,
@@ -214,25 +215,44 @@ bool NativeEmbedder::query_path(uint32_t tokens) const {
     return !off && tokens <= 32 && bert_query_path_supported((int)cfg_.hidden, (int)cfg_.inter, (int)cfg_.heads);
 }
 
-// Query-sized inputs (<= 32 tokens in total): 4 launches per layer + the pooling, see bert_query_kernels.hip.
+bool NativeEmbedder::one_launch_path() const {
+    // (measured slower than the replayed graph of 25 launches — bert_query_kernels.hip —: opt-in, experiments builds only)
+    static const bool on = fsgpu::lab_env("FSGPU_BERT_ONE_LAUNCH") != nullptr;
+    return on && q_one_launch_ok_ && bert_q_one_launch_blocks() > 0;
+}
+
+// Query-sized inputs (<= 32 tokens in total): the 25 stages of bert_query_kernels.hip as 4 launches per layer + the pooling (replayed
+// from a captured graph by embed_batch) — or, in experiments builds, in ONE launch of 24 resident blocks with grid-wide barriers
+// between the stages (slower: see the kernel).
 SearchError NativeEmbedder::forward_query(uint32_t n_docs, uint32_t tokens) {
     const int H = (int)cfg_.hidden, I = (int)cfg_.inter;
     BERT_TRY(q_x_.reserve((size_t)2 * 32 * H * 4));
     BERT_TRY(q_parts_.reserve((size_t)4 * 32 * H * 4));
     float* X[2] = {static_cast<float*>(q_x_.ptr), static_cast<float*>(q_x_.ptr) + 32 * H};
     float* parts = static_cast<float*>(q_parts_.ptr);
+    const bool one = one_launch_path();
+    const uint32_t* offsets = q_offsets_ ? q_offsets_ : static_cast<const uint32_t*>(offsets_.ptr);
+    const int32_t* ids = q_ids_ ? q_ids_ : static_cast<const int32_t*>(ids_.ptr);
+    const int32_t* positions = q_positions_ ? q_positions_ : static_cast<const int32_t*>(positions_.ptr);
+    float* pooled = pooled_out_ ? pooled_out_ : static_cast<float*>(out_.ptr);
     BertQueryArgs base{};
-    base.tokens = (int)tokens;
-    base.n_docs = (int)n_docs;
-    base.offsets = q_offsets_ ? q_offsets_ : static_cast<const uint32_t*>(offsets_.ptr);
+    if (!one) {   // (the one-launch form passes the per-call fields in its own argument block: its stage table does not depend on them)
+        base.tokens = (int)tokens;
+        base.n_docs = (int)n_docs;
+        base.offsets = offsets;
+    }
     base.eps = cfg_.ln_eps;
     base.attn_scale = 0.17677669f;  // ATTN_SCALE_F32 = 1/sqrt(32) (native.rs:44)
+    std::vector<BertQueryArgs>& st = q_stages_host_[q_stages_flip_ ^ 1];
+    std::vector<unsigned char>& kinds = q_kinds_host_[q_stages_flip_ ^ 1];
+    st.clear();
+    kinds.clear();
     const Layer* prev = nullptr;
     for (Layer& l : layers_) {
         BertQueryArgs k1 = base;   // [pending LN2 | embedding LN] -> QKV of each head -> attention -> ctx
         if (!prev) {
-            k1.ids = q_ids_ ? q_ids_ : static_cast<const int32_t*>(ids_.ptr);
-            k1.positions = q_positions_ ? q_positions_ : static_cast<const int32_t*>(positions_.ptr);
+            k1.ids = one ? static_cast<const int32_t*>(ids_.ptr) : ids;   // (one launch: "non-null" marks the embedding stage)
+            k1.positions = one ? nullptr : positions;
             k1.word = static_cast<const float*>(word_.ptr);
             k1.pos = static_cast<const float*>(pos_.ptr);
             k1.type0 = static_cast<const float*>(type_.ptr);
@@ -251,7 +271,8 @@ SearchError NativeEmbedder::forward_query(uint32_t n_docs, uint32_t tokens) {
         k1.ldw = H;
         k1.bias = static_cast<const float*>(l.qkv_b.ptr);
         k1.out_h = static_cast<_Float16*>(ctx_h_.ptr);
-        BERT_HIP(launch_bert_q_qkv_attn(k1, (int)cfg_.heads, stream_));
+        st.push_back(k1);
+        kinds.push_back(0);
         BertQueryArgs k2 = base;   // out-projection -> one partial slab
         k2.a_h = static_cast<const _Float16*>(ctx_h_.ptr);
         k2.lda = H;
@@ -259,7 +280,8 @@ SearchError NativeEmbedder::forward_query(uint32_t n_docs, uint32_t tokens) {
         k2.ldw = H;
         k2.n = H;
         k2.out_f32 = parts;
-        BERT_HIP(launch_bert_q_gemm(k2, 0, stream_));
+        st.push_back(k2);
+        kinds.push_back(1);
         BertQueryArgs k3 = base;   // x = LN1(x + slab + bias) -> FFN-up + GELU
         k3.x_in = X[0];
         k3.x_out = X[1];
@@ -273,7 +295,8 @@ SearchError NativeEmbedder::forward_query(uint32_t n_docs, uint32_t tokens) {
         k3.n = I;
         k3.bias = static_cast<const float*>(l.i_b.ptr);
         k3.out_h = static_cast<_Float16*>(inter_h_.ptr);
-        BERT_HIP(launch_bert_q_gemm(k3, 1, stream_));
+        st.push_back(k3);
+        kinds.push_back(2);
         BertQueryArgs k4 = base;   // FFN-down, K split 4 ways -> four partial slabs
         k4.a_h = static_cast<const _Float16*>(inter_h_.ptr);
         k4.lda = I;
@@ -281,7 +304,8 @@ SearchError NativeEmbedder::forward_query(uint32_t n_docs, uint32_t tokens) {
         k4.ldw = I;
         k4.n = H;
         k4.out_f32 = parts;
-        BERT_HIP(launch_bert_q_gemm(k4, 2, stream_));
+        st.push_back(k4);
+        kinds.push_back(3);
         prev = &l;
     }
     BertQueryArgs kp = base;       // x = LN2(x + slabs + bias) -> mean per text -> L2
@@ -291,7 +315,40 @@ SearchError NativeEmbedder::forward_query(uint32_t n_docs, uint32_t tokens) {
     kp.prev_bias = static_cast<const float*>(prev->o_b.ptr);
     kp.lnw = static_cast<const float*>(prev->ln2_w.ptr);
     kp.lnb = static_cast<const float*>(prev->ln2_b.ptr);
-    BERT_HIP(launch_bert_q_pool(kp, pooled_out_ ? pooled_out_ : static_cast<float*>(out_.ptr), stream_));
+    st.push_back(kp);
+    kinds.push_back(4);
+    if (!one) {
+        for (size_t i = 0; i < st.size(); ++i) {
+            if (kinds[i] == 0) BERT_HIP(launch_bert_q_qkv_attn(st[i], (int)cfg_.heads, stream_));
+            else if (kinds[i] == 4) BERT_HIP(launch_bert_q_pool(st[i], pooled, stream_));
+            else BERT_HIP(launch_bert_q_gemm(st[i], (int)kinds[i] - 1, stream_));
+        }
+        return SearchError{};
+    }
+    // the stage table lives on the device; it is sent again only when a pointer in it has changed (a workspace moved)
+    const std::vector<BertQueryArgs>& sent = q_stages_host_[q_stages_flip_];
+    const size_t table_bytes = st.size() * sizeof(BertQueryArgs);
+    if (!q_status_) {
+        BERT_HIP(hipHostMalloc(reinterpret_cast<void**>(&q_status_), 64, hipHostMallocMapped));
+        *q_status_ = 0;
+        BERT_TRY(q_counter_.reserve(64));
+        BERT_HIP(hipMemsetAsync(q_counter_.ptr, 0, 64, stream_));
+        q_launches_ = 0;
+    }
+    if (sent.size() != st.size() || std::memcmp(sent.data(), st.data(), table_bytes) != 0 || !q_stages_.ptr) {
+        BERT_HIP(hipStreamSynchronize(stream_));   // (rare: nothing may still be reading the old table — or the host copy that fed it)
+        BERT_TRY(q_stages_.reserve(table_bytes + 256));
+        BERT_HIP(hipMemcpyAsync(q_stages_.ptr, st.data(), table_bytes, hipMemcpyHostToDevice, stream_));
+        BERT_HIP(hipMemcpyAsync(static_cast<char*>(q_stages_.ptr) + table_bytes, kinds.data(), kinds.size(), hipMemcpyHostToDevice, stream_));
+        BERT_HIP(hipStreamSynchronize(stream_));
+        q_stages_flip_ ^= 1;
+    }
+    const unsigned int barriers = (unsigned int)(st.size() - 1) * (unsigned int)bert_q_one_launch_blocks();
+    BERT_HIP(launch_bert_q_one_launch(static_cast<const BertQueryArgs*>(q_stages_.ptr),
+                                      static_cast<const unsigned char*>(q_stages_.ptr) + table_bytes, (int)st.size(), (int)tokens, (int)n_docs,
+                                      offsets, ids, positions, pooled, static_cast<unsigned int*>(q_counter_.ptr), q_launches_ * barriers,
+                                      q_status_, stream_));
+    ++q_launches_;
     return SearchError{};
 }
 
@@ -638,84 +695,97 @@ SearchError NativeEmbedder::embed_batch(const int32_t* ids, const uint32_t* offs
             (void)hipGetLastError();
         }
     }
-    if (io_host_ && in_bytes + out_bytes <= kPinnedIoBytes) {
-        unsigned char* io = static_cast<unsigned char*>(io_host_);
-        std::memcpy(io, ids + base, (size_t)total * 4);
-        std::memcpy(io + (size_t)total * 4, positions.data(), (size_t)total * 4);
-        std::memcpy(io + (size_t)total * 8, offs.data(), (size_t)(n + 1) * 4);
-        auto enqueue = [&]() -> SearchError {
-            const bool direct = query_path(total);
-            if (direct) {
-                // a query's few dozen ids are read by the first kernel straight from the pinned block (mapped into the
-                // device's address space): three copy nodes of ~4 us each cost more than the forward's first stage
-                q_ids_ = reinterpret_cast<const int32_t*>(io);
-                q_positions_ = reinterpret_cast<const int32_t*>(io + (size_t)total * 4);
-                q_offsets_ = reinterpret_cast<const uint32_t*>(io + (size_t)total * 8);
-            } else {
-                BERT_HIP(hipMemcpyAsync(ids_.ptr, io, (size_t)total * 4, hipMemcpyHostToDevice, stream_));
-                BERT_HIP(hipMemcpyAsync(positions_.ptr, io + (size_t)total * 4, (size_t)total * 4, hipMemcpyHostToDevice, stream_));
-                BERT_HIP(hipMemcpyAsync(offsets_.ptr, io + (size_t)total * 8, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, stream_));
-            }
-            pooled_out_ = reinterpret_cast<float*>(io + in_bytes);
-            SearchError fe = forward(n, total, max_seq);
-            pooled_out_ = nullptr;
-            q_ids_ = q_positions_ = nullptr;
-            q_offsets_ = nullptr;
-            return fe;
-        };
-        static const bool no_graph = std::getenv("FSGPU_BERT_NO_GRAPH") != nullptr;  // A/B runs
-        bool replayed = false;
-        if (graphs_enabled_ && !no_graph && total <= kGraphMaxTokens) {
-            const auto key = std::make_tuple(n, total, max_seq);
-            auto it = graphs_.find(key);
-            if (it == graphs_.end()) {
-                if (graphs_.size() >= kGraphMaxEntries) drop_graphs();
-                it = graphs_.emplace(key, GraphEntry{}).first;
-            }
-            GraphEntry& ge = it->second;
-            ++ge.seen;
-            if (!ge.exec && ge.seen >= 2) {
-                // second sighting of this shape (the first ran eagerly, so every one-time kernel attribute is set): capture
-                hipGraph_t graph = nullptr;
-                hipError_t ce = hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal);
-                if (ce == hipSuccess) {
-                    SearchError fe = enqueue();
-                    ce = hipStreamEndCapture(stream_, &graph);
-                    if (fe.ok() && ce == hipSuccess && graph) ce = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
-                    else if (ce == hipSuccess) ce = hipErrorUnknown;
-                    if (graph) (void)hipGraphDestroy(graph);
+    auto run_once = [&]() -> SearchError {
+        if (io_host_ && in_bytes + out_bytes <= kPinnedIoBytes) {
+            unsigned char* io = static_cast<unsigned char*>(io_host_);
+            std::memcpy(io, ids + base, (size_t)total * 4);
+            std::memcpy(io + (size_t)total * 4, positions.data(), (size_t)total * 4);
+            std::memcpy(io + (size_t)total * 8, offs.data(), (size_t)(n + 1) * 4);
+            auto enqueue = [&]() -> SearchError {
+                const bool direct = query_path(total);
+                if (direct) {
+                    // a query's few dozen ids are read by the first kernel straight from the pinned block (mapped into the
+                    // device's address space): three copy nodes of ~4 us each cost more than the forward's first stage
+                    q_ids_ = reinterpret_cast<const int32_t*>(io);
+                    q_positions_ = reinterpret_cast<const int32_t*>(io + (size_t)total * 4);
+                    q_offsets_ = reinterpret_cast<const uint32_t*>(io + (size_t)total * 8);
+                } else {
+                    BERT_HIP(hipMemcpyAsync(ids_.ptr, io, (size_t)total * 4, hipMemcpyHostToDevice, stream_));
+                    BERT_HIP(hipMemcpyAsync(positions_.ptr, io + (size_t)total * 4, (size_t)total * 4, hipMemcpyHostToDevice, stream_));
+                    BERT_HIP(hipMemcpyAsync(offsets_.ptr, io + (size_t)total * 8, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, stream_));
                 }
-                if (ce != hipSuccess) {   // capture is an optimisation: fall back to eager launches for good
-                    if (std::getenv("FSGPU_DEBUG_GRAPH")) std::fprintf(stderr, "[fsgpu bert] graph capture failed: %s\n", hipGetErrorString(ce));
-                    (void)hipGetLastError();
-                    if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
-                    ge.exec = nullptr;
-                    graphs_enabled_ = false;
+                pooled_out_ = reinterpret_cast<float*>(io + in_bytes);
+                SearchError fe = forward(n, total, max_seq);
+                pooled_out_ = nullptr;
+                q_ids_ = q_positions_ = nullptr;
+                q_offsets_ = nullptr;
+                return fe;
+            };
+            static const bool no_graph = std::getenv("FSGPU_BERT_NO_GRAPH") != nullptr;  // A/B runs
+            bool replayed = false;
+            // (the one-launch query forward is a single kernel whose barrier base changes per call: nothing to replay)
+        if (graphs_enabled_ && !no_graph && total <= kGraphMaxTokens && !(query_path(total) && one_launch_path())) {
+                const auto key = std::make_tuple(n, total, max_seq);
+                auto it = graphs_.find(key);
+                if (it == graphs_.end()) {
+                    if (graphs_.size() >= kGraphMaxEntries) drop_graphs();
+                    it = graphs_.emplace(key, GraphEntry{}).first;
+                }
+                GraphEntry& ge = it->second;
+                ++ge.seen;
+                if (!ge.exec && ge.seen >= 2) {
+                    // second sighting of this shape (the first ran eagerly, so every one-time kernel attribute is set): capture
+                    hipGraph_t graph = nullptr;
+                    hipError_t ce = hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal);
+                    if (ce == hipSuccess) {
+                        SearchError fe = enqueue();
+                        ce = hipStreamEndCapture(stream_, &graph);
+                        if (fe.ok() && ce == hipSuccess && graph) ce = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
+                        else if (ce == hipSuccess) ce = hipErrorUnknown;
+                        if (graph) (void)hipGraphDestroy(graph);
+                    }
+                    if (ce != hipSuccess) {   // capture is an optimisation: fall back to eager launches for good
+                        if (std::getenv("FSGPU_DEBUG_GRAPH")) std::fprintf(stderr, "[fsgpu bert] graph capture failed: %s\n", hipGetErrorString(ce));
+                        (void)hipGetLastError();
+                        if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
+                        ge.exec = nullptr;
+                        graphs_enabled_ = false;
+                    }
+                }
+                if (ge.exec) {
+                    BERT_HIP(hipGraphLaunch(ge.exec, stream_));
+                    replayed = true;
                 }
             }
-            if (ge.exec) {
-                BERT_HIP(hipGraphLaunch(ge.exec, stream_));
-                replayed = true;
-            }
+            if (!replayed) BERT_TRY(enqueue());
+            // (device output of a graph-replayed call: the pool kernel's destination is baked into the graph — the pinned block —, so
+            // the few KB go back up from there behind it)
+            if (out_dev) BERT_HIP(hipMemcpyAsync(out_dev, io + in_bytes, out_bytes, hipMemcpyHostToDevice, stream_));
+            BERT_HIP(hipStreamSynchronize(stream_));
+            if (out) std::memcpy(out, io + in_bytes, out_bytes);
+            return SearchError{};
         }
-        if (!replayed) BERT_TRY(enqueue());
-        // (device output of a graph-replayed call: the pool kernel's destination is baked into the graph — the pinned block —, so
-        // the few KB go back up from there behind it)
-        if (out_dev) BERT_HIP(hipMemcpyAsync(out_dev, io + in_bytes, out_bytes, hipMemcpyHostToDevice, stream_));
+        BERT_HIP(hipMemcpyAsync(ids_.ptr, ids + base, (size_t)total * 4, hipMemcpyHostToDevice, stream_));
+        BERT_HIP(hipMemcpyAsync(positions_.ptr, positions.data(), (size_t)total * 4, hipMemcpyHostToDevice, stream_));
+        BERT_HIP(hipMemcpyAsync(offsets_.ptr, offs.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, stream_));
+        pooled_out_ = out_dev;   // (null: the pool kernel writes out_)
+        const SearchError fe = forward(n, total, max_seq);
+        pooled_out_ = nullptr;
+        BERT_TRY(fe);
+        if (out) BERT_HIP(hipMemcpyAsync(out, out_dev ? out_dev : out_.ptr, (size_t)n * H * 4, hipMemcpyDeviceToHost, stream_));
         BERT_HIP(hipStreamSynchronize(stream_));
-        if (out) std::memcpy(out, io + in_bytes, out_bytes);
         return SearchError{};
+
+    };
+    SearchError re = run_once();
+    // (the one-launch query forward gave a grid-wide barrier up: never seen, but a wait that cannot end must not be the alternative —
+    // the result is discarded, the 25-launch form answers this call and every later one)
+    if (re.ok() && q_status_ && *q_status_ != 0) {
+        q_one_launch_ok_ = false;
+        *q_status_ = 0;
+        re = run_once();
     }
-    BERT_HIP(hipMemcpyAsync(ids_.ptr, ids + base, (size_t)total * 4, hipMemcpyHostToDevice, stream_));
-    BERT_HIP(hipMemcpyAsync(positions_.ptr, positions.data(), (size_t)total * 4, hipMemcpyHostToDevice, stream_));
-    BERT_HIP(hipMemcpyAsync(offsets_.ptr, offs.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, stream_));
-    pooled_out_ = out_dev;   // (null: the pool kernel writes out_)
-    const SearchError fe = forward(n, total, max_seq);
-    pooled_out_ = nullptr;
-    BERT_TRY(fe);
-    if (out) BERT_HIP(hipMemcpyAsync(out, out_dev ? out_dev : out_.ptr, (size_t)n * H * 4, hipMemcpyDeviceToHost, stream_));
-    BERT_HIP(hipStreamSynchronize(stream_));
-    return SearchError{};
+    return re;
 }
 
 }  // namespace fsgpu

@@ -42,6 +42,7 @@ class NativeEmbedder {
     SearchError forward_packed_range(uint32_t d0, uint32_t d1, uint32_t t0, uint32_t t1, uint32_t max_seq, hipStream_t stream);
     SearchError forward_query(uint32_t n_docs, uint32_t tokens);   // <= 32 tokens: 25 launches (bert_query_kernels.hip)
     bool query_path(uint32_t tokens) const;
+    bool one_launch_path() const;                                  // ... as ONE launch with grid-wide barriers (experiments builds)
     bool docs_path(uint32_t tokens, uint32_t max_seq) const;       // every text <= 32 tokens: ONE launch (bert_docs_w.hip)
     SearchError embed_docs(const int32_t* ids, const std::vector<uint32_t>& offs, uint32_t n, uint32_t total, float* out, float* out_dev);
     SearchError reserve_workspaces(uint32_t tokens);
@@ -62,6 +63,15 @@ class NativeEmbedder {
     float* pooled_out_ = nullptr;  // where the pool kernel writes during a pinned call
     const int32_t *q_ids_ = nullptr, *q_positions_ = nullptr;  // query path of a pinned call: inputs read in place
     const uint32_t* q_offsets_ = nullptr;
+    // the one-launch query forward: the stage table on the device (+ the host copies it was sent from / is compared with), the
+    // barrier counter, how many launches have used it, the mapped word a block raises when a barrier wait gave up
+    DeviceBuffer q_stages_, q_counter_;
+    std::vector<BertQueryArgs> q_stages_host_[2];
+    std::vector<unsigned char> q_kinds_host_[2];
+    int q_stages_flip_ = 0;
+    unsigned int q_launches_ = 0;
+    unsigned int* q_status_ = nullptr;
+    bool q_one_launch_ok_ = true;
     // Query-sized calls replay a captured hipGraph of the whole call (three H2D copies + the ~44 kernels of the forward):
     // the chain is launch-bound, and a replay costs one submission instead of one per kernel.  One graph per call shape
     // (texts, tokens, longest text), built the second time a shape is seen; every buffer a graph names is allocated at its

@@ -156,8 +156,8 @@ __device__ __forceinline__ void q_fill_tile_ln(const BertQueryArgs& a, _Float16*
 
 // A wave's weight fragments for columns c0 + 16 j .., K slice [k0, k0 + 384): all requested at once — before the prologue that
 // builds the A tile, so their memory round trip runs underneath it.  W is [N, ldw] f16 row-major (HF layout).
-template <int NT>
-__device__ __forceinline__ void q_load_b(const _Float16* __restrict__ W, int ldw, int k0, int c0, int lane, half8 (&b)[NT][QKS]) {
+template <int NT, int NW = NT>   // (NW: rows of the caller's register array, of which the first NT are used)
+__device__ __forceinline__ void q_load_b(const _Float16* __restrict__ W, int ldw, int k0, int c0, int lane, half8 (&b)[NW][QKS]) {
     const int fr = lane & 15, fk = (lane >> 4) * 8;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -167,8 +167,8 @@ __device__ __forceinline__ void q_load_b(const _Float16* __restrict__ W, int ldw
     }
 }
 // acc[ri][j] += tile rows (16 ri ..) x those columns
-template <int NT>
-__device__ __forceinline__ void q_gemm_384(const _Float16* tile, const half8 (&b)[NT][QKS], int lane, f32x4 (&acc)[2][NT]) {
+template <int NT, int NW = NT>
+__device__ __forceinline__ void q_gemm_384(const _Float16* tile, const half8 (&b)[NW][QKS], int lane, f32x4 (&acc)[2][NT]) {
     const int fr = lane & 15, fk = (lane >> 4) * 8;
 #pragma unroll
     for (int ks = 0; ks < QKS; ++ks) {
@@ -184,17 +184,40 @@ __device__ __forceinline__ void q_gemm_384(const _Float16* tile, const half8 (&b
 
 }  // namespace
 
-// K1: one block per head.  LN / embedding prologue -> Q, K, V of the head (waves 0..2: 32 columns each) -> attention.
-__global__ __launch_bounds__(256) void bert_q_qkv_attn_kernel(BertQueryArgs a) {
-    __shared__ __attribute__((aligned(16))) _Float16 tile[QROWS * QPITCH];       // 25 KB
-    __shared__ __attribute__((aligned(16))) _Float16 qs[QROWS][48], ks_[QROWS][48], vt[32][48], ps[QROWS][48];  // 96-byte pitch
-    __shared__ int doc_of[QROWS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int head = blockIdx.x;
-    // part 0 = Q, 1 = K, 2 = V (waves 0..2): columns part * 384 + head * 32 + [0, 32) of the stacked projection (native.rs:1500-1540)
+namespace {
+
+// LDS of the three stage shapes (the one-launch form carves them out of one block)
+struct QSmemAttn {
+    __attribute__((aligned(16))) _Float16 tile[QROWS * QPITCH];       // 25 KB
+    __attribute__((aligned(16))) _Float16 qs[QROWS][48], ks_[QROWS][48], vt[32][48], ps[QROWS][48];  // 96-byte pitch
+    int doc_of[QROWS];
+};
+struct QSmemGemm {
+    __attribute__((aligned(16))) _Float16 tile[QROWS * QPITCH];
+};
+struct QSmemPool {
+    __attribute__((aligned(16))) float xs[QROWS][QH];   // 48 KB: the normalised rows
+    float red[4];
+};
+
+// K1's weights: part 0 = Q, 1 = K, 2 = V (waves 0..2): columns part * 384 + head * 32 + [0, 32) of the stacked projection
+// (native.rs:1500-1540)
+__device__ __forceinline__ void q_attn_load(const BertQueryArgs& a, int head, int tid, half8 (&wb)[2][QKS]) {
+    const int lane = tid & 63, wave = tid >> 6;
     const int c0 = (wave < 3 ? wave : 0) * QH + head * 32;
-    half8 wb[2][QKS];
     if (wave < 3) q_load_b<2>(a.w, QH, 0, c0, lane, wb);
+}
+
+// K1: one block per head.  LN / embedding prologue -> Q, K, V of the head (waves 0..2: 32 columns each) -> attention.
+__device__ __forceinline__ void q_attn_compute(const BertQueryArgs& a, QSmemAttn& sm, int head, int tid, const half8 (&wb)[2][QKS]) {
+    _Float16* tile = sm.tile;
+    auto& qs = sm.qs;
+    auto& ks_ = sm.ks_;
+    auto& vt = sm.vt;
+    auto& ps = sm.ps;
+    int* doc_of = sm.doc_of;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int c0 = (wave < 3 ? wave : 0) * QH + head * 32;
     q_fill_tile_ln(a, tile, head == 0 && a.x_out != nullptr, tid);
     if (tid < QROWS) {
         int d = -1;
@@ -277,19 +300,34 @@ __global__ __launch_bounds__(256) void bert_q_qkv_attn_kernel(BertQueryArgs a) {
     }
 }
 
+}  // namespace
+
+__global__ __launch_bounds__(256) void bert_q_qkv_attn_kernel(BertQueryArgs a) {
+    __shared__ QSmemAttn sm;
+    half8 wb[2][QKS];
+    q_attn_load(a, (int)blockIdx.x, (int)threadIdx.x, wb);
+    q_attn_compute(a, sm, (int)blockIdx.x, (int)threadIdx.x, wb);
+}
+
+namespace {
+
 // K2 / K3 / K4.  PRO 0: the A tile is rows of a_h (f16, leading dimension lda), K slice blockIdx.y; PRO 1: pending-LN
 // prologue.  EPI 0: partial slab blockIdx.y of out_f32 ([slab][32][N], no bias); EPI 1: GELU(acc + bias) -> out_h (f16).
 // NT: 16-column tiles per wave (4 waves: 64 NT columns per block).
-template <int PRO, int EPI, int NT>
-__global__ __launch_bounds__(256) void bert_q_gemm_kernel(BertQueryArgs a) {
-    __shared__ __attribute__((aligned(16))) _Float16 tile[QROWS * QPITCH];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int k0 = blockIdx.y * QH;
-    const int c0 = (blockIdx.x * 4 + wave) * 16 * NT;
-    half8 wb[NT][QKS];
-    q_load_b<NT>(a.w, a.ldw, k0, c0, lane, wb);
+template <int NT, int NW = NT>
+__device__ __forceinline__ void q_gemm_load(const BertQueryArgs& a, int bx, int by, int tid, half8 (&wb)[NW][QKS]) {
+    const int lane = tid & 63, wave = tid >> 6;
+    q_load_b<NT, NW>(a.w, a.ldw, by * QH, (bx * 4 + wave) * 16 * NT, lane, wb);
+}
+
+template <int PRO, int EPI, int NT, int NW = NT>
+__device__ __forceinline__ void q_gemm_compute(const BertQueryArgs& a, QSmemGemm& sm, int bx, int by, int tid, const half8 (&wb)[NW][QKS]) {
+    _Float16* tile = sm.tile;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int k0 = by * QH;
+    const int c0 = (bx * 4 + wave) * 16 * NT;
     if constexpr (PRO == 1) {
-        q_fill_tile_ln(a, tile, blockIdx.x == 0 && a.x_out != nullptr, tid);
+        q_fill_tile_ln(a, tile, bx == 0 && a.x_out != nullptr, tid);
     } else {
         // 32 rows x 384 halves of the slice, 16-byte pieces (48 per row)
         for (int i = tid; i < QROWS * 48; i += 256) {
@@ -301,7 +339,7 @@ __global__ __launch_bounds__(256) void bert_q_gemm_kernel(BertQueryArgs a) {
     }
     __syncthreads();
     f32x4 acc[2][NT] = {};
-    q_gemm_384<NT>(tile, wb, lane, acc);
+    q_gemm_384<NT, NW>(tile, wb, lane, acc);
     const int fr = lane & 15, crow = (lane >> 4) * 4;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -313,18 +351,30 @@ __global__ __launch_bounds__(256) void bert_q_gemm_kernel(BertQueryArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const int row = ri * 16 + crow + r;
                 if (row >= a.tokens) continue;
-                if constexpr (EPI == 0) a.out_f32[((size_t)blockIdx.y * QROWS + row) * a.n + col] = acc[ri][j][r];
+                if constexpr (EPI == 0) a.out_f32[((size_t)by * QROWS + row) * a.n + col] = acc[ri][j][r];
                 else a.out_h[(size_t)row * a.n + col] = (_Float16)q_gelu(acc[ri][j][r] + bv);
             }
     }
 }
 
+}  // namespace
+
+template <int PRO, int EPI, int NT>
+__global__ __launch_bounds__(256) void bert_q_gemm_kernel(BertQueryArgs a) {
+    __shared__ QSmemGemm sm;
+    half8 wb[NT][QKS];
+    q_gemm_load<NT>(a, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, wb);
+    q_gemm_compute<PRO, EPI, NT>(a, sm, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, wb);
+}
+
+namespace {
+
 // Final stage: x = LN2(x + slabs + bias), mean over each text's tokens, L2 with the zero guard (native.rs:1209-1235;
 // fastembed_embedder.rs:416-426).  One block.
-__global__ __launch_bounds__(256) void bert_q_pool_kernel(BertQueryArgs a, float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float xs[QROWS][QH];   // 48 KB: the normalised rows
-    __shared__ float red[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void q_pool_compute(const BertQueryArgs& a, QSmemPool& sm, int tid, float* __restrict__ out) {
+    auto& xs = sm.xs;
+    float* red = sm.red;
+    const int lane = tid & 63, wave = tid >> 6;
     q_ln_rows<4>(a, nullptr, &xs[0][0], tid);
     __syncthreads();
     for (int doc = 0; doc < a.n_docs; ++doc) {
@@ -357,6 +407,151 @@ __global__ __launch_bounds__(256) void bert_q_pool_kernel(BertQueryArgs a, float
     }
 }
 
+}  // namespace
+
+__global__ __launch_bounds__(256) void bert_q_pool_kernel(BertQueryArgs a, float* __restrict__ out) {
+    __shared__ QSmemPool sm;
+    q_pool_compute(a, sm, (int)threadIdx.x, out);
+}
+
+// ---- the whole forward in ONE launch (experiments builds only: measured, slower, not shipped) -----------------------------------
+// The same 25 stages, run by 24 resident blocks that meet at a grid-wide barrier between stages instead of at a kernel boundary
+// (r05 verdict: "one persistent launch for the 6 layers"); a block requests the NEXT stage's weight fragments after it has arrived
+// and before it waits, so that memory round trip runs underneath the barrier instead of at the head of the stage.
+// Result (profiles/r06/encoder_one_launch_ab.txt, outputs bit-identical to the 25-launch form): 0.223 ms per 3-token query against
+// 0.191 ms for the replayed graph of 25 launches (32 tokens: 0.284 against 0.240).  A kernel boundary inside a replayed graph costs
+// ~4 us on this stack; a barrier across XCDs needs an agent-scope release (L2 write-back) and acquire (invalidate) in EVERY wave — with
+// them in one wave only the output is wrong (3e-3), with none at all (not coherent: a floor, not a design) 0.177 ms.  So even stage
+// data that bypassed the caches entirely could buy 7 % — the time is the 25 dependent stages (~7 us each: two or three memory round
+// trips), not their boundaries.  FSGPU_BERT_ONE_LAUNCH=1 in a build with -DFSGPU_EXPERIMENTS selects it.
+#ifdef FSGPU_EXPERIMENTS
+//   * stages[s]: the BertQueryArgs the host would have launched stage s with (device array, built once per workspace layout);
+//     the per-call fields (tokens, texts, offsets, ids, positions, the pooled output) travel in the kernel's argument block.
+//   * barrier: arrive = agent-scope release fence (L2 write-back: the next stage's readers sit on other XCDs) + one atomic add;
+//     wait = thread 0 polls the counter, the block's second s_barrier, an agent-scope acquire fence (invalidate).  The counter only
+//     grows: launch i waits for base + (s + 1) x blocks, base = i x 24 x blocks (wrap-safe signed difference).
+//   * the 24 blocks are co-resident on any idle-or-busy device (a block needs 49 KB of LDS of a CU's 160 and nothing else waits on
+//     them), but a poll loop that never ends would take the box down with it: after ~2^20 polls a block gives up, raises
+//     *status (mapped host memory), pushes the counter past every barrier still ahead and runs on without waiting; the host then
+//     discards the result, answers through the 25-launch form and stays there.
+struct BertQueryOneLaunchArgs {
+    const BertQueryArgs* stages;
+    const unsigned char* kinds;     // 0 attention (12 blocks), 1 out-projection (6), 2 FFN-up (24), 3 FFN-down (6 x 4), 4 pool (1)
+    int n_stages;
+    int tokens, n_docs;
+    const uint32_t* offsets;
+    const int32_t *ids, *positions;
+    float* out;
+    unsigned int* counter;          // device memory, zeroed once
+    unsigned int base;
+    unsigned int* status;           // mapped host word: 1 = a barrier timed out
+};
+
+namespace {
+
+constexpr int kOneLaunchBlocks = 24;
+
+__device__ __forceinline__ int q_stage_blocks(int kind) { return kind == 0 ? 12 : kind == 1 ? 6 : kind == 4 ? 1 : 24; }
+
+// A pointer read from the stage table is "generic" to the compiler (flat loads: both wait counters, an aperture check per access);
+// every one of them points into device memory, and saying so gets the global_load forms the 25-launch kernels use.
+template <class T>
+__device__ __forceinline__ T* q_global(T* ptr) {
+    return (T*)(__attribute__((address_space(1))) T*)ptr;
+}
+
+__device__ __forceinline__ BertQueryArgs q_stage_args(const BertQueryOneLaunchArgs& p, int s) {
+    BertQueryArgs a = p.stages[s];
+    a.tokens = p.tokens;
+    a.n_docs = p.n_docs;
+    a.offsets = p.offsets;
+    if (a.ids) {
+        a.ids = p.ids;
+        a.positions = p.positions;
+    }
+    a.word = q_global(a.word);
+    a.pos = q_global(a.pos);
+    a.type0 = q_global(a.type0);
+    a.x_in = q_global(a.x_in);
+    a.x_out = q_global(a.x_out);
+    a.parts = q_global(a.parts);
+    a.prev_bias = q_global(a.prev_bias);
+    a.lnw = q_global(a.lnw);
+    a.lnb = q_global(a.lnb);
+    a.a_h = q_global(a.a_h);
+    a.w = q_global(a.w);
+    a.bias = q_global(a.bias);
+    a.out_f32 = q_global(a.out_f32);
+    a.out_h = q_global(a.out_h);
+    return a;
+}
+
+// (two register sets, one per stage shape: with one array serving both the compiler kept it in scratch)
+__device__ __forceinline__ void q_stage_load(const BertQueryArgs& a, int kind, int b, int tid, half8 (&wa)[2][QKS], half8 (&wg)[1][QKS]) {
+    if (b >= q_stage_blocks(kind)) return;
+    if (kind == 0) q_attn_load(a, b, tid, wa);
+    else if (kind == 3) q_gemm_load<1>(a, b % 6, b / 6, tid, wg);
+    else if (kind != 4) q_gemm_load<1>(a, b, 0, tid, wg);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void bert_q_one_launch_kernel(BertQueryOneLaunchArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(QSmemPool) > sizeof(QSmemAttn) ? sizeof(QSmemPool) : sizeof(QSmemAttn)];
+    __shared__ int gave_up;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    if (tid == 0) gave_up = 0;
+    half8 wa[2][QKS], wg[1][QKS];
+    {
+        const BertQueryArgs a0 = q_stage_args(p, 0);
+        q_stage_load(a0, p.kinds[0], b, tid, wa, wg);
+    }
+    for (int s = 0; s < p.n_stages; ++s) {
+        const int kind = p.kinds[s];
+        const BertQueryArgs a = q_stage_args(p, s);
+        __syncthreads();   // (the previous stage's LDS is free; gave_up is set)
+        if (b < q_stage_blocks(kind)) {
+            if (kind == 0) q_attn_compute(a, *reinterpret_cast<QSmemAttn*>(smem), b, tid, wa);
+            else if (kind == 1) q_gemm_compute<0, 0, 1>(a, *reinterpret_cast<QSmemGemm*>(smem), b, 0, tid, wg);
+            else if (kind == 2) q_gemm_compute<1, 1, 1>(a, *reinterpret_cast<QSmemGemm*>(smem), b, 0, tid, wg);
+            else if (kind == 3) q_gemm_compute<0, 0, 1>(a, *reinterpret_cast<QSmemGemm*>(smem), b % 6, b / 6, tid, wg);
+            else q_pool_compute(a, *reinterpret_cast<QSmemPool*>(smem), tid, p.out);
+        }
+        if (s + 1 == p.n_stages) break;
+        // ---- arrive
+#ifndef FSGPU_Q1L_FENCE
+#define FSGPU_Q1L_FENCE 2   // 2: every wave fences; 1: thread 0's wave only (WRONG output: measured); 0: none (a timing floor, not coherent)
+#endif
+        if (FSGPU_Q1L_FENCE == 2 || (FSGPU_Q1L_FENCE == 1 && tid < 64)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_barrier();
+        if (tid == 0) (void)__hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- the next stage's weights: in flight while the block waits
+        const BertQueryArgs an = q_stage_args(p, s + 1);
+        q_stage_load(an, p.kinds[s + 1], b, tid, wa, wg);
+        // ---- wait
+        if (tid == 0 && !gave_up) {
+            const unsigned int target = p.base + (unsigned int)(s + 1) * (unsigned int)kOneLaunchBlocks;
+            unsigned int polls = 0;
+            while ((int)(__hip_atomic_load(p.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++polls > (1u << 20)) {
+                    gave_up = 1;
+                    __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    // (and lets every other block through all the barriers still ahead: the host resets the counter)
+                    (void)__hip_atomic_fetch_add(p.counter, 0x40000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+        if (FSGPU_Q1L_FENCE == 2 || (FSGPU_Q1L_FENCE == 1 && tid < 64)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+#endif  // FSGPU_EXPERIMENTS
+
 // ---- launchers ----------------------------------------------------------------------------------------------------
 
 bool bert_query_path_supported(int hidden, int inter, int heads) { return hidden == QH && inter == 4 * QH && heads * 32 == QH; }
@@ -375,6 +570,36 @@ hipError_t launch_bert_q_gemm(const BertQueryArgs& a, int mode, hipStream_t stre
     else hipLaunchKernelGGL((bert_q_gemm_kernel<0, 0, 1>), dim3(a.n / 64, 4), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
+
+#ifdef FSGPU_EXPERIMENTS
+int bert_q_one_launch_blocks() { return kOneLaunchBlocks; }
+
+hipError_t launch_bert_q_one_launch(const BertQueryArgs* stages_dev, const unsigned char* kinds_dev, int n_stages, int tokens, int n_docs,
+                                    const uint32_t* offsets, const int32_t* ids, const int32_t* positions, float* out,
+                                    unsigned int* counter_dev, unsigned int base, unsigned int* status_mapped, hipStream_t stream) {
+    BertQueryOneLaunchArgs p{};
+    p.stages = stages_dev;
+    p.kinds = kinds_dev;
+    p.n_stages = n_stages;
+    p.tokens = tokens;
+    p.n_docs = n_docs;
+    p.offsets = offsets;
+    p.ids = ids;
+    p.positions = positions;
+    p.out = out;
+    p.counter = counter_dev;
+    p.base = base;
+    p.status = status_mapped;
+    hipLaunchKernelGGL(bert_q_one_launch_kernel, dim3(kOneLaunchBlocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+#else
+int bert_q_one_launch_blocks() { return 0; }
+hipError_t launch_bert_q_one_launch(const BertQueryArgs*, const unsigned char*, int, int, int, const uint32_t*, const int32_t*, const int32_t*,
+                                    float*, unsigned int*, unsigned int, unsigned int*, hipStream_t) {
+    return hipErrorNotSupported;
+}
+#endif
 
 hipError_t launch_bert_q_pool(const BertQueryArgs& a, float* out, hipStream_t stream) {
     hipLaunchKernelGGL(bert_q_pool_kernel, dim3(1), dim3(256), 0, stream, a, out);

@@ -365,6 +365,11 @@ bool bert_query_path_supported(int hidden, int inter, int heads);
 hipError_t launch_bert_q_qkv_attn(const BertQueryArgs& a, int heads, hipStream_t stream);
 hipError_t launch_bert_q_gemm(const BertQueryArgs& a, int mode, hipStream_t stream);
 hipError_t launch_bert_q_pool(const BertQueryArgs& a, float* out, hipStream_t stream);
+// the same stages in ONE launch of bert_q_one_launch_blocks() resident blocks with grid-wide barriers between them
+int bert_q_one_launch_blocks();
+hipError_t launch_bert_q_one_launch(const BertQueryArgs* stages_dev, const unsigned char* kinds_dev, int n_stages, int tokens, int n_docs,
+                                    const uint32_t* offsets, const int32_t* ids, const int32_t* positions, float* out,
+                                    unsigned int* counter_dev, unsigned int base, unsigned int* status_mapped, hipStream_t stream);
 
 // bert_docs_w.hip: the whole MiniLM-L6 forward of a batch of texts of at most 32 tokens each in ONE launch — a 32-row block
 // owns whole texts, so the six layers chain inside the kernel (native.rs:1142-1236)
