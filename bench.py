@@ -1625,6 +1625,7 @@ def main() -> None:
             owners = np.unique(hit_rows[hit_rows < args.rows] // per_shard)   # (padding entries are 0xffffffff)
             line["row_shards_with_hits_in_the_merged_answer"] = int(owners.size)
             if not args.no_merged_check:
+              try:
                 # THE N-rank check: rank 0 rebuilds the whole corpus on the host from its own generator, verifies every rank's slab
                 # checksum against it, and compares 8 queries of the LAST TIMED STEP's merged output — the tensors the all-gather +
                 # merge left — with the oracle's search over all rows: row ids and f32 score bits
@@ -1658,6 +1659,9 @@ def main() -> None:
                 chk["seconds"] = time.perf_counter() - t_chk
                 line["merged_answer_vs_oracle"] = chk
                 line["merged_answer_equals_oracle_8_queries"] = bool(chk["equal"] and slabs_ok)
+              except Exception as e:   # (the check must not cost the measured line; a failed check reads as "not equal")
+                line["merged_answer_vs_oracle"] = {"error": f"{type(e).__name__}: {e}"}
+                line["merged_answer_equals_oracle_8_queries"] = False
         if world == 1 and not args.no_adversarial and args.rows >= 1_000_000 and args.batched:
             line["adversarial_corpora"] = {kind: adversarial_section(kind, args.rows, args.dim, k, device, local_rank)
                                            for kind in ("uniform", "outlier")}
