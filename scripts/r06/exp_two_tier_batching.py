@@ -24,7 +24,10 @@ m2v = fa.Model2VecEmbedder(table, device=0)
 bert = fa.NativeEmbedder(random_bert_weights(1, 30522, 384, 6, 1536), device=0)
 s = NativeTwoTierSearcher(fast, quality, m2v, bert, doc_id_mode=1, fast_tier_int8_multiplier=3)
 s.run_load_many(queries=8192, warmup_queries=2048, k=10, fast_vocab=500_353, corpus_rows=rows)   # builds the int8 copies, warms the engine
-cases = os.environ.get("CASES", "1:64:100,8:64:100,64:64:200,64:128:200,256:256:200,1024:256:200,1024:512:200,1024:1024:200,1024:512:50,2048:1024:200")
+# default: the setting bench.py ships (max_chunk 256, max_wait 3,000 us) over the caller counts, then two contrasts (a short wait starves
+# the chunks of a small population: 64 callers in chunks of 16; a larger cap for 2,048 callers)
+cases = os.environ.get("CASES", "1:256:3000,8:256:3000,64:256:3000,128:256:3000,200:256:3000,256:256:3000,512:256:3000,1024:256:3000,2048:256:3000,"
+                                "64:256:200,2048:1024:3000")
 for case in cases.split(","):
     threads, chunk, wait = (int(x) for x in case.split(":"))
     s.set_batching(chunk, wait)

@@ -539,3 +539,41 @@ def test_group_maxima_sample_stage_gives_the_exact_search_bits(fa, oracle, dim):
             orow, osc = oracle.search_top_k(slab, q[0], k, live=live)
             assert np.array_equal(br[0][:len(orow)], orow) and np.array_equal(bits(bs[0][:len(osc)]), bits(osc))
         idx.close()
+
+
+@pytest.mark.parametrize("dim", [256, 384])
+def test_batches_of_129_to_383_queries_ride_padded_wide_rounds_with_the_exact_bits(fa, oracle, dim):
+    """Round 6: a round of the batched search takes 128-query groups, and from 129 queries on the register-resident-query main pass —
+    the last group of a launch may be PADDING (129..255 queries = one 256-slot pass, 257..383 = one 384-slot pass; rounds 3-5 answered
+    them as 128 + the rest on the LDS-query kernel).  Padding slots must not append, select or count: rows, score bits and counts of
+    every real query equal the exact kernels' (and the oracle's for a probe), with and without tombstones, for the exact search
+    (both filters) and the int8 two-pass; a 1,024 + 200 batch crosses a round boundary into a padded round."""
+    rng = np.random.default_rng(4200 + dim)
+    n = 200_003
+    cent = unit_rows(rng, 32, dim)
+    rows = cent[rng.integers(0, 32, n)] + 0.3 * rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    slab = rows.astype(np.float16).view(np.uint16)
+    for live in (None, rng.random(n) > 0.3):
+        idx = fa.VectorIndex.from_slab(slab, live=live)
+        for nq, k in ((129, 10), (200, 10), (255, 30), (257, 10), (300, 1), (383, 24), (1024 + 200, 10)):
+            q = cent[rng.integers(0, 32, nq)] + 0.3 * rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+            q[nq - 1] = rows[123]                       # the last real query sits next to the padding
+            exact = [idx.search_batch(q[s:s + 64], k, exact=True) for s in range(0, nq, 64)]
+            er, es, ec = (np.concatenate([e[i] for e in exact]) for i in range(3))
+            for filt in (2, 1):
+                idx.set_batched_filter(filt)
+                br, bs, bc, fb = idx.search_batched(q, k)
+                assert br.shape[0] == nq
+                assert np.array_equal(bc, ec) and np.array_equal(br, er) and np.array_equal(bits(bs), bits(es)), (dim, nq, k, filt, live is not None)
+            orow, osc = oracle.search_top_k(slab, q[nq - 1], k, live=live)
+            assert np.array_equal(br[nq - 1][:len(orow)], orow) and np.array_equal(bits(bs[nq - 1][:len(osc)]), bits(osc))
+            if nq <= 300:
+                # the int8 two-pass (search.rs:571-661) per query against the batched form
+                tr, ts, tc = idx.search_int8_two_pass_batched(q, k, 3)[:3]
+                for i in (0, 127, 128, nq - 1):
+                    hits = idx.search_top_k_int8_two_pass(q[i], k, 3)
+                    assert tc[i] == len(hits), (dim, nq, i)
+                    assert [int(r) for r in tr[i][:len(hits)]] == [h.index for h in hits], (dim, nq, i)
+                    assert np.array_equal(bits(ts[i][:len(hits)]), bits(np.array([h.score for h in hits], np.float32))), (dim, nq, i)
+        idx.close()
