@@ -181,3 +181,18 @@ def test_safetensors_blob_is_validated_before_a_device_is_needed():
     blob = bytearray(_safetensors_blob(t))
     with pytest.raises(fa.ModelLoadFailed):
         fa.NativeEmbedder.from_safetensors_bytes(bytes(blob[:len(blob) - 64]))
+
+
+def test_integration_document_names_every_entry_point_of_the_product_headers():
+    """INTEGRATION.md shows the reference-side binding of the drop-in surface: every function include/fsgpu.h and include/fshost.h
+    declare appears in it (a new export without its binding line fails here)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = []
+    for header, prefix in (("fsgpu.h", "fsgpu_"), ("fshost.h", "fshost_")):
+        text = open(os.path.join(root, "include", header)).read()
+        for name in sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", text))):
+            if name not in doc and name != "fsgpu_status":   # (the return type, in a function-pointer typedef)
+                missing.append(name)
+    assert missing == [], missing
