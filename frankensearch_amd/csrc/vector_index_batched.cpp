@@ -769,8 +769,13 @@ SearchError VectorIndex::batched_round_setup(const BatchedPlan& p, BatchedRound&
         r.wide_qt = p.wide_pref == 2 ? 2 : (int)((groups_left + passes - 1) / passes);
     }
     // 160, 128 or 64 queries per pass
+    // (the exact search's int8 filter takes the 128-slot shape for ANY batch: at 10M rows 16..64 queries cost 0.80-0.81 ms on the
+    // 64-query shape against 0.69 ms for 65 on the 128-slot one at 256 dimensions, 1.01-1.04 against 0.95 at 384; the int8 two-pass,
+    // whose threshold is a rank in the sample rather than an anchored exact score, measured the other way round — 0.83 against 0.87 —
+    // and keeps the 64-query shape: profiles/r06/lds_query_shape_ab.txt)
+    const bool narrow_ok = !(p.i8f && !knobs().narrow_i8f);
     r.shape = r.wide_qt ? (i8 ? mf_shape_i8_ : mf_shape_)
-                        : (left > 64 && variant != 5) ? ((left > 128 && mf_use_160_) ? 5 : (i8 ? mf_shape_i8_ : mf_shape_)) : 0;
+                        : ((left > 64 || !narrow_ok) && variant != 5) ? ((left > 128 && mf_use_160_) ? 5 : (i8 ? mf_shape_i8_ : mf_shape_)) : 0;
     r.G = (uint32_t)scan_mfma_query_tiles(r.shape) * 16;
     r.wide_mult = r.wide_qt ? (uint32_t)r.wide_qt : 1;   // sample groups per main-pass launch
     // this round: `ngroups` groups of G queries (the last one may be partly padding), QP query slots, ng real queries

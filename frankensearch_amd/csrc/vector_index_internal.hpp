@@ -46,6 +46,7 @@ struct Knobs {
     int i8f_growth = 0; // FSGPU_I8F_GROWTH: sample growth factor of the int8 filter (default 4)
     bool no_skip_b = false, use_160 = false, debug_batched = false, no_reverse = false, no_wide_b = false, no_anchor = false;
     bool no_big_pool = false, no_heur_b = false, no_group_sample = false;
+    bool narrow_i8f = false;   // FSGPU_NARROW_I8F: batches of up to 64 queries of the int8-filtered exact search on the 64-query shape (rounds 2-5)
     int rb_pct = 0;      // FSGPU_RB_PCT: the second sample's size in percent of what the plan chose (tuning experiments only)
     int heur_rank = 0;   // FSGPU_HEUR_RANK: rank of the first sample whose score gates the anchoring-only second sample (default 4)
     int wide_min = 0;    // FSGPU_WIDE_MIN: fewest queries left that take the register-resident-query main pass (default 129)
@@ -78,6 +79,7 @@ struct Knobs {
         no_big_pool = env("FSGPU_NO_BIG_POOL") != nullptr;
         no_heur_b = env("FSGPU_NO_HEUR_B") != nullptr;
         no_group_sample = env("FSGPU_NO_GROUP_SAMPLE") != nullptr;
+        narrow_i8f = env("FSGPU_NARROW_I8F") != nullptr;
         heur_rank = num("FSGPU_HEUR_RANK");
         no_reverse = env("FSGPU_NO_REVERSE") != nullptr;
         use_160 = env("FSGPU_USE_160") != nullptr;
