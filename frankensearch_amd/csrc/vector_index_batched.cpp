@@ -566,7 +566,7 @@ SearchError VectorIndex::batched_prepare(BatchedPlan& p, bool* done) {
     // (Not when the main pass is the register-resident-query kernel, i.e. for batches of 256 and more: a row that passes its
     // threshold costs that kernel's 160-instruction tile loop a divergent append, and the looser threshold of a skipped stage
     // B lets 4 x as many through — 1.25M-row shard, 1,024 queries: main pass 0.366 -> 0.329 ms, 2.5M: 0.741 -> 0.642 ms.)
-    const bool wide_main = knobs().wide != 0 && nq >= wide_min_queries() && scan_wide_supported((int)dim_, p.i8 ? 1 : 2) && variant != 5 && variant != 6;
+    const bool wide_main = knobs().wide != 0 && nq >= wide_min_queries(p.i8 && !p.i8f) && scan_wide_supported((int)dim_, p.i8 ? 1 : 2) && variant != 5 && variant != 6;
     if (knobs().ra <= 0 && !knobs().no_skip_b && !wide_main && nrows_ <= 4'000'000 && nrows_ >= 4 * (uint64_t)RA_MAX) {
         const uint64_t expect = (uint64_t)std::max<uint32_t>(k, 1) * (p.i8 ? std::max<uint32_t>(p.int8_mult, 1) : 1) * (nrows_ / RA_MAX);
         if (expect <= 4096) {
@@ -645,7 +645,8 @@ SearchError VectorIndex::batched_prepare(BatchedPlan& p, bool* done) {
     // group's 128 leave half the CUs idle), only the main pass is one launch per group.
     constexpr uint32_t GMAX = BatchedPlan::GMAX, SPILL = BatchedPlan::SPILL, KC = BatchedPlan::KC;
     const uint32_t round_cap = knobs().round >= (int)GMAX ? (uint32_t)knobs().round : 1024;  // tuning experiments only
-    const uint32_t QCAP = std::min<uint32_t>(round_cap, std::max<uint32_t>(GMAX, (nq + 127) / 128 * 128));
+    // (at least the 256 slots of the smallest register-resident-query launch: 65..128 two-pass queries ride one, padded)
+    const uint32_t QCAP = std::min<uint32_t>(round_cap, std::max<uint32_t>(std::max<uint32_t>(GMAX, 256), (nq + 127) / 128 * 128));
     p.QCAP = QCAP;
     FSGPU_TRY(mf_qh_.reserve((size_t)QCAP * dim_ * 2));
     FSGPU_TRY(mf_delta_.reserve(QCAP * 4));
@@ -688,7 +689,7 @@ SearchError VectorIndex::batched_prepare(BatchedPlan& p, bool* done) {
     p.wide_ok = (p.wide_pref == 2 || p.wide_pref == 3) && scan_wide_supported((int)dim_, p.i8 ? 1 : 2) && variant != 5 && variant != 6;
     // per-query verdicts, written by the kernels straight into pinned host memory and read after ONE stream
     // synchronisation for the whole batch: [0, cap) = overflow flags, [cap, 2 cap) = candidate counts
-    const uint32_t flag_cap = (nq + GMAX - 1) / GMAX * GMAX + GMAX;
+    const uint32_t flag_cap = (nq + GMAX - 1) / GMAX * GMAX + 256;   // (a round's query slots may run up to 255 past its real queries)
     if (flag_cap > mf_flags_cap_) {
         // (three areas: blocking calls, and one per begun search — a begun search's verdicts must survive the next call's reset)
         if (async_state_[0] == 1 || async_state_[1] == 1)
@@ -758,7 +759,7 @@ SearchError VectorIndex::batched_round_setup(const BatchedPlan& p, BatchedRound&
     // Main pass at 384 / 256 queries per launch (mfma_wide.hip: queries in registers, row tiles through an LDS-DMA
     // ring) when that many are left; the sample stages then run as sub-groups of 128 on the LDS-query kernel.
     r.wide_qt = 0;
-    if (p.wide_ok && left >= wide_min_queries()) {   // 128-query groups per launch
+    if (p.wide_ok && left >= wide_min_queries(p.i8 && !p.i8f)) {   // 128-query groups per launch
         // as many as the registers hold (f16 rows of 384 dimensions: 3, their int8 form: 5), the round's groups spread evenly
         // over its passes (8 groups: 3 + 3 + 2 on f16 rows, 4 + 4 on int8 rows)
         // (the last group may be partly padding: 129..255 queries ride ONE 256-slot pass — the LDS-query kernel answered them as
@@ -766,7 +767,7 @@ SearchError VectorIndex::batched_round_setup(const BatchedPlan& p, BatchedRound&
         // engine forms for 129..255 callers)
         const uint32_t groups_left = std::min<uint32_t>((left + 127) / 128, p.QCAP / 128);
         const uint32_t passes = (groups_left + p.wide_max - 1) / p.wide_max;
-        r.wide_qt = p.wide_pref == 2 ? 2 : (int)((groups_left + passes - 1) / passes);
+        r.wide_qt = p.wide_pref == 2 ? 2 : std::max(2, (int)((groups_left + passes - 1) / passes));
     }
     // 160, 128 or 64 queries per pass
     // (the exact search's int8 filter takes the 128-slot shape for ANY batch: at 10M rows 16..64 queries cost 0.80-0.81 ms on the

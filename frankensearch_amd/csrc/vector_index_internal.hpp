@@ -92,7 +92,12 @@ inline const Knobs& knobs() {
 }
 // Fewest queries that ride the register-resident-query main pass: one more than the LDS-query kernel answers in ONE pass over the slab
 // (the tail of a 256-slot launch is padding — batched_round_setup).
-inline uint32_t wide_min_queries() { return knobs().wide_min > 128 ? (uint32_t)knobs().wide_min : 129u; }
+// The int8 TWO-PASS (its own pass-1 scores, no anchored threshold) crosses over earlier: 65..128 queries cost 0.86-0.89 ms on the 128-slot
+// LDS-query shape and 0.82 ms as a padded 256-slot pass at 10M x 256 (profiles/r06/lds_query_shape_ab.txt).
+inline uint32_t wide_min_queries(bool two_pass = false) {
+    if (knobs().wide_min > 64) return (uint32_t)knobs().wide_min;
+    return two_pass ? 65u : 129u;
+}
 
 }  // namespace detail
 }  // namespace fsgpu
