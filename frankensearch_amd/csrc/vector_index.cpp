@@ -92,11 +92,12 @@ VectorIndex::~VectorIndex() {
                             &ws_counts_, &ws_keys_a_, &ws_keys_b_, &ws_sort_tmp_, &ws_gather_rows_, &ws_gather_out_,
                             &i8_slab_, &n4_slab_, &i8_max_, &ws_i8_query_, &ws_cand_packed_, &ws_cand_rows_, &ws_cand_scores_,
                             &mf_max_norm_, &mf_qh_, &mf_delta_, &mf_tau_, &mf_cand_, &mf_dense_, &mf_sel_,
-                            &mf_fallback_, &mf_fallback2_, &mf_spill_, &mf_io_, &mf_io2_, &i8_stats_, &n4u_slab_, &mf_cand_count_, &ws_pairs_,
+                            &mf_fallback_, &mf_fallback2_, &mf_spill_, &mf_io_, &mf_io2_, &ws_out_, &i8_stats_, &n4u_slab_, &mf_cand_count_, &ws_pairs_,
                             &i8f_slab_, &i8f_max_, &i8f_stats_, &rot_mat_, &rot_q_})
         b->release();
     if (mf_flags_host_) (void)hipHostFree(mf_flags_host_);
     if (io_host_) (void)hipHostFree(io_host_);
+    if (batch_io_host_) (void)hipHostFree(batch_io_host_);
 }
 
 SearchError VectorIndex::common_init(int device) {
@@ -704,6 +705,27 @@ void* VectorIndex::pinned_io() {
         }
     }
     return io_host_;
+}
+
+// A pinned block for the results of batched searches at the host-pointer ABI (grows to what a call needs, up to 32 MB).
+void* VectorIndex::pinned_batch_io(size_t bytes) {
+    constexpr size_t kMax = 32u << 20;
+    if (bytes > kMax || batch_io_failed_) return nullptr;
+    if (bytes > batch_io_bytes_) {
+        if (batch_io_host_) (void)hipHostFree(batch_io_host_);
+        batch_io_host_ = nullptr;
+        batch_io_bytes_ = 0;
+        size_t want = 1u << 20;
+        while (want < bytes) want <<= 1;
+        if (hipHostMalloc(&batch_io_host_, want, hipHostMallocDefault) != hipSuccess) {
+            batch_io_host_ = nullptr;
+            batch_io_failed_ = true;
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        batch_io_bytes_ = want;
+    }
+    return batch_io_host_;
 }
 
 SearchError VectorIndex::ensure_query_dimension(uint32_t query_len) const {

@@ -339,6 +339,7 @@ class VectorIndex {
         ws_sort_tmp_, ws_gather_rows_, ws_gather_out_, i8_slab_, n4_slab_, i8_max_, ws_i8_query_, ws_cand_packed_,
         ws_cand_rows_, ws_cand_scores_, mf_max_norm_, mf_qh_, mf_delta_, mf_tau_, mf_cand_, mf_dense_, mf_sel_,
         mf_fallback_, mf_fallback2_, mf_spill_, mf_io_, mf_io2_, i8_stats_, n4u_slab_, mf_cand_count_, ws_pairs_;
+    DeviceBuffer ws_out_;   // rows | scores | counts of a blocking batched search (one block: one copy up)
     bool i8_ready_ = false, n4_ready_ = false, i8_stats_ready_ = false, n4u_ready_ = false;
     bool quant_max_ready_ = false;   // i8_max_ holds a corpus-wide max-abs handed in by a sharded index: the quantisers keep it
     u64* tp_approx_out_ = nullptr;   // two_pass_candidates_device: where the batch in flight leaves its candidate pairs
@@ -365,6 +366,12 @@ class VectorIndex {
     int mf_shape_ = -1, mf_per_cu_narrow_ = 1, mf_per_cu_wide_ = 1, mf_per_cu_narrow_i8_ = 1, mf_per_cu_wide_i8_ = 1;  // batched-scan launch shapes (probed once)
     static constexpr size_t kPinnedIoBytes = 256 * 1024;
     void* io_host_ = nullptr;  // pinned staging for the single-query latency paths
+    void* batch_io_host_ = nullptr;   // pinned block the results of batched searches come up through (pinned_batch_io)
+    size_t batch_io_bytes_ = 0;
+    bool batch_io_failed_ = false;
+    void* pinned_batch_io(size_t bytes);
+    SearchError fetch_batched_results(const unsigned char* base, size_t o_rows, size_t o_scores, size_t o_counts, size_t total, uint32_t nq,
+                                      uint32_t k, uint32_t* out_rows, float* out_scores, uint32_t* out_counts);
     const float* host_query_hint_ = nullptr;   // search_top_k's lone query, still in host memory: fused_search launches the scan with it in the argument block
     bool io_failed_ = false;
     uint32_t* mf_flags_host_ = nullptr;                              // pinned per-query verdicts of the batched scan
