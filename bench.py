@@ -775,6 +775,21 @@ def two_tier_section(quality_index, rows: int, k: int, device, local_rank: int):
     return res
 
 
+def host_pointer_section(index, k: int, queries, batch: int):
+    """The headline search at the host-pointer C ABI (fsgpu_search_topk_batched: the queries come from host memory and the hits go back
+    to it inside every call — the PCIe-inclusive rate; `value` is the device-resident one).  Same batch size, same index, 20 calls."""
+    qb = queries[:batch].cpu().numpy()
+    index.search_batched(qb, k)
+    t0 = time.perf_counter()
+    reps, fb = 20, 0
+    for _ in range(reps):
+        fb += index.search_batched(qb, k)[3]
+    dt = time.perf_counter() - t0
+    return {"queries_per_sec": reps * batch / dt, "ms_per_step": dt / reps * 1e3, "queries_per_step": batch, "exact_fallback_queries": int(fb),
+            "note": "fsgpu_search_topk_batched, one blocking call per step: H2D of the queries, the search, ONE D2H of rows | scores | counts "
+                    "through the index's pinned block, host memcpys to the caller's arrays"}
+
+
 def quantized_section(index, rows: int, dim: int, k: int, queries, bits: int, mult: int):
     """Two-pass searches of the reference on the same corpus: quantised pass-1 scan + exact f16 rescore.
     bits 8 = search_top_k_int8_two_pass (the production fast-tier path, multiplier 3; N*dim bytes per pass),
@@ -1491,7 +1506,7 @@ def main() -> None:
                 "filter_refiltered_on_f16_queries": i8_refiltered if int8_filter else None,
                 "exact_fallback_queries": fallbacks[0] if args.batched else None,
                 "host_loop": ("fsgpu_search_topk_batched_device_begin / _end, one step enqueued ahead" if args.batched and not args.blocking_steps
-                              else "one blocking call per step") + "; device-resident queries and hits (the host-pointer ABI's rate: int8_two_pass.batched / sharded_handle)",
+                              else "one blocking call per step") + "; device-resident queries and hits (the host-pointer ABI's rate: host_pointer_abi)",
             },
             "roofline": {
                 "bound": "hbm",
@@ -1669,6 +1684,9 @@ def main() -> None:
             line["encoders"] = encoder_section(device, local_rank)
         if world == 1 and args.config5:
             line["config5"] = config5_section(index, args.rows, k, local_rank)
+        if world == 1 and args.batched and not args.exact:
+            line["host_pointer_abi"] = host_pointer_section(index, k, queries, B)
+            line["host_pointer_abi_queries_per_sec"] = line["host_pointer_abi"]["queries_per_sec"]
         if world == 1 and not args.no_two_tier:
             line["int8_two_pass"] = quantized_section(index, args.rows, args.dim, k, queries, 8, 3)
             line["fourbit_two_pass"] = quantized_section(index, args.rows, args.dim, k, queries, 4, 5)
